@@ -1,0 +1,67 @@
+"""ctypes binding of libnmhip.so -- the C-ABI drop-in boundary (include/nmhip.h).
+
+The product path fails loudly when the HIP extension is missing: there is no
+CPU fallback anywhere in this package.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnmhip.so")
+
+_lib = None
+
+P = c_void_p
+I = c_int
+L = c_int64
+F = c_float
+
+# name -> (restype, argtypes); must list every symbol include/nmhip.h declares.
+SIGNATURES = {
+    "nm_last_error": (c_char_p, []),
+    "nm_version": (I, []),
+    "nm_gemm_f32": (I, [P, I, I, L, L, L, P, L, P, L, P, L, P, I, I, L, L, L, L, I]),
+    "nm_embedding_gather": (I, [P, P, L, L, P, L, P, L, I, F]),
+    "nm_gru_gates_fwd": (I, [P, P, L, L, L, P, P, P, P, P, I, I, L, L]),
+    "nm_gru_blend_fwd": (I, [P, P, L, L, L, P, P, P, P, P, P, L, L, L, P, I, I, L, L]),
+    "nm_layer_norm_fwd": (I, [P, P, L, P, P, P, L, P, P, L, L, F]),
+    "nm_copy_cols": (I, [P, P, L, P, L, L, L]),
+    "nm_attn_workspace_bytes": (L, [L, L, L]),
+    "nm_attn_fwd": (I, [P, P, P, P, P, P, P, L, L, L, L, L, P, L, P, P, L]),
+    "nm_row_stats": (I, [P, P, L, L, L, P, P, P]),
+    "nm_greedy_update": (I, [P, P, P, P, P, L, I, P]),
+    "nm_xent": (I, [P, P, L, L, L, P, P, P, P, I]),
+    "nm_beam_workspace_bytes": (L, [L, L, L]),
+    "nm_beam_topk_step": (I, [P, P, L, L, L, L, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, L]),
+    "nm_gather_rows_f32": (I, [P, P, L, P, P, L, L, L]),
+    "nm_beam_reorder_tokens": (I, [P, P, P, P, P, L, L]),
+}
+
+
+class NMHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libnmhip.so; raise (never fall back) if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NMHipError(
+            f"{LIB_PATH} is missing: build it with `python -m neuralmonkey_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().nm_last_error()
+        raise NMHipError(f"{what} failed ({code}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,59 @@
+"""Build libnmhip.so (gfx950) in-tree with hipcc.
+
+``python -m neuralmonkey_amd.build`` or ``__graft_entry__.build()``.  The
+shared object is git-ignored but travels to the GPU box with the snapshot.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libnmhip.so")
+ARCH = "gfx950"
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    lib_m = os.path.getmtime(LIB)
+    deps = sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    return any(os.path.getmtime(d) > lib_m for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    for src in sources():
+        obj = src[:-4] + ".o"
+        hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+        if (not force and os.path.exists(obj)
+                and all(os.path.getmtime(obj) > os.path.getmtime(d) for d in [src] + hdrs)):
+            objs.append(obj)
+            continue
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj,
+               "-Wno-unused-result"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((subprocess.Popen(cmd), src))
+        objs.append(obj)
+    for p, src in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {src}")
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,256 @@
+// Fused Bahdanau attention step (score + softmax + mask-renorm + context).
+// Reference: Attention.attention / get_energies, attention/feed_forward.py:120-166:
+//   e[r,s]  = sum_a v[a] * tanh(hf[b,s,a] + y[r,a]) + bias
+//   w       = softmax(e) * mask ; w /= (sum(w) + 1e-8)          (:139-144)
+//   ctx[r]  = sum_s w[r,s] * states[b,s,:]                      (:151-154)
+// with b = r / rows_per_key: the reference cannot tile the keys to a beam
+// (SURVEY 3.3); indexing keys by row/k gives the batch-1 broadcast result for
+// any batch.
+//
+// HBM-bound: one step streams hf [Bk,S,A] and states [Bk,S,C] once
+// (53.5 MB at B=128,S=50,A=C=1024).  Layout: row-major, innermost a/c, so a
+// wave reads one 4 KB row with 16 B per lane, fully coalesced.
+//
+// Split-S (flash-decoding style) so the grid has Bk*nchunk >> 256 workgroups:
+//   attn_partial : block (chunk, b): energies of its SCH rows (one wave per
+//                  row, shuffle reduction over a), chunk-local max / sums, then
+//                  the partial context of the same rows (each wave owns a
+//                  256-column slice, no cross-wave reduction).  All QPK queries
+//                  of one key batch share a single read of hf / states.
+//   attn_combine : per query row, merge the nchunk partials, write ctx and
+//                  the normalised weights.
+// The softmax-then-mask-renorm of the reference is carried exactly:
+//   w_s = exp(e_s-M) m_s / (sum_j exp(e_j-M) m_j + 1e-8 * sum_j exp(e_j-M)).
+#include "nm_common.h"
+
+#define ATT_MAX_SCH 16
+
+struct AttnArgs {
+    const float* y;       // [R,A]
+    const float* hf;      // [Bk,S,A]
+    const float* states;  // [Bk,S,C]
+    const float* mask;    // [Bk,S] or null
+    const float* v;       // [A]
+    const float* bias;    // [1] device scalar or null
+    float* energies;      // [R,S]   raw energies (workspace)
+    float* pctx;          // [R,nchunk,C]
+    float* pstat;         // [R,nchunk,4]  (m, l_all, l_masked, -)
+    int R, S, A, C, nchunk, sch;
+};
+
+template <int QPK, int NCG>
+__global__ __launch_bounds__(256) void attn_partial(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* ys = smem;                         // [QPK][A]
+    float* vs = ys + QPK * p.A;               // [A]
+    float* es = vs + p.A;                     // [QPK][ATT_MAX_SCH]  energies -> p
+    float* ms = es + QPK * ATT_MAX_SCH;       // [ATT_MAX_SCH] mask
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = blockIdx.x, b = blockIdx.y;
+    const int s0 = chunk * p.sch;
+    const int ns = min(p.sch, p.S - s0);
+    const int r0 = b * QPK;
+
+    for (int i = tid * 4; i < QPK * p.A; i += 1024)
+        *reinterpret_cast<float4*>(ys + i) =
+            *reinterpret_cast<const float4*>(p.y + (long)r0 * p.A + i);
+    for (int i = tid * 4; i < p.A; i += 1024)
+        *reinterpret_cast<float4*>(vs + i) = *reinterpret_cast<const float4*>(p.v + i);
+    if (tid < ATT_MAX_SCH)
+        ms[tid] = (tid < ns) ? (p.mask ? p.mask[(long)b * p.S + s0 + tid] : 1.0f) : 0.0f;
+    __syncthreads();
+
+    const float bias = p.bias ? p.bias[0] : 0.0f;
+
+    // ---- phase 1: energies, one wave per key row ---------------------------
+    for (int sl = wave; sl < ns; sl += 4) {
+        const float* hrow = p.hf + ((long)b * p.S + s0 + sl) * p.A;
+        float part[QPK];
+#pragma unroll
+        for (int q = 0; q < QPK; ++q) part[q] = 0.0f;
+        for (int a = lane * 4; a < p.A; a += 256) {
+            const float4 h4 = *reinterpret_cast<const float4*>(hrow + a);
+            const float4 v4 = *reinterpret_cast<const float4*>(vs + a);
+#pragma unroll
+            for (int q = 0; q < QPK; ++q) {
+                const float4 y4 = *reinterpret_cast<const float4*>(ys + q * p.A + a);
+                part[q] += v4.x * nm_tanh(h4.x + y4.x) + v4.y * nm_tanh(h4.y + y4.y) +
+                           v4.z * nm_tanh(h4.z + y4.z) + v4.w * nm_tanh(h4.w + y4.w);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < QPK; ++q) {
+            const float e = nm_wave_sum(part[q]) + bias;
+            if (lane == 0) {
+                es[q * ATT_MAX_SCH + sl] = e;
+                p.energies[(long)(r0 + q) * p.S + s0 + sl] = e;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: chunk-local softmax statistics ---------------------------
+    if (tid < QPK) {
+        const int q = tid;
+        float m = -INFINITY;
+        for (int s = 0; s < ns; ++s) m = fmaxf(m, es[q * ATT_MAX_SCH + s]);
+        float la = 0.0f, lm = 0.0f;
+        for (int s = 0; s < ns; ++s) {
+            const float e = __expf(es[q * ATT_MAX_SCH + s] - m);
+            la += e;
+            const float em = e * ms[s];
+            lm += em;
+            es[q * ATT_MAX_SCH + s] = em;     // masked, un-normalised weight
+        }
+        float* st = p.pstat + ((long)(r0 + q) * p.nchunk + chunk) * 4;
+        st[0] = m; st[1] = la; st[2] = lm; st[3] = 0.0f;
+    }
+    __syncthreads();
+
+    // ---- phase 3: partial context, wave owns 256-column slices -------------
+    float4 acc[QPK][NCG];
+#pragma unroll
+    for (int q = 0; q < QPK; ++q)
+#pragma unroll
+        for (int g = 0; g < NCG; ++g) acc[q][g] = make_float4(0, 0, 0, 0);
+    const float* sbase = p.states + ((long)b * p.S + s0) * p.C;
+#pragma unroll 4
+    for (int sl = 0; sl < ns; ++sl) {
+#pragma unroll
+        for (int g = 0; g < NCG; ++g) {
+            const int col = g * 1024 + wave * 256 + lane * 4;
+            if (col < p.C) {
+                const float4 x = *reinterpret_cast<const float4*>(sbase + (long)sl * p.C + col);
+#pragma unroll
+                for (int q = 0; q < QPK; ++q) {
+                    const float w = es[q * ATT_MAX_SCH + sl];
+                    acc[q][g].x += w * x.x; acc[q][g].y += w * x.y;
+                    acc[q][g].z += w * x.z; acc[q][g].w += w * x.w;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < QPK; ++q)
+#pragma unroll
+        for (int g = 0; g < NCG; ++g) {
+            const int col = g * 1024 + wave * 256 + lane * 4;
+            if (col < p.C)
+                *reinterpret_cast<float4*>(p.pctx + ((long)(r0 + q) * p.nchunk + chunk) * p.C + col) =
+                    acc[q][g];
+        }
+}
+
+__global__ __launch_bounds__(256) void attn_combine(const float* __restrict__ pctx,
+                                                    const float* __restrict__ pstat,
+                                                    const float* __restrict__ energies,
+                                                    const float* __restrict__ mask,
+                                                    float* __restrict__ ctx, long ldctx,
+                                                    float* __restrict__ weights, int S, int C,
+                                                    int nchunk, int rows_per_key) {
+    __shared__ float sc[64];
+    __shared__ float sden, smax;
+    const int r = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {
+        float M = -INFINITY;
+        for (int i = 0; i < nchunk; ++i) M = fmaxf(M, pstat[((long)r * nchunk + i) * 4]);
+        float la = 0.0f, lm = 0.0f;
+        for (int i = 0; i < nchunk; ++i) {
+            const float* st = pstat + ((long)r * nchunk + i) * 4;
+            const float f = __expf(st[0] - M);
+            sc[i] = f;
+            la += f * st[1];
+            lm += f * st[2];
+        }
+        sden = lm + 1e-8f * la;
+        smax = M;
+    }
+    __syncthreads();
+    const float inv = 1.0f / sden;
+    for (int c = tid * 4; c < C; c += 1024) {
+        float4 a = make_float4(0, 0, 0, 0);
+        for (int i = 0; i < nchunk; ++i) {
+            const float4 x = *reinterpret_cast<const float4*>(pctx + ((long)r * nchunk + i) * C + c);
+            const float f = sc[i];
+            a.x += f * x.x; a.y += f * x.y; a.z += f * x.z; a.w += f * x.w;
+        }
+        a.x *= inv; a.y *= inv; a.z *= inv; a.w *= inv;
+        *reinterpret_cast<float4*>(ctx + (long)r * ldctx + c) = a;
+    }
+    if (weights) {
+        const int b = r / rows_per_key;
+        for (int s = tid; s < S; s += 256) {
+            const float mk = mask ? mask[(long)b * S + s] : 1.0f;
+            weights[(long)r * S + s] = __expf(energies[(long)r * S + s] - smax) * mk * inv;
+        }
+    }
+}
+
+static void attn_chunking(int64_t S, int* sch, int* nchunk) {
+    const int64_t n0 = (S + 11) / 12;                 // rows per chunk <= 12
+    *sch = (int)((S + n0 - 1) / n0);
+    *nchunk = (int)((S + *sch - 1) / *sch);
+}
+
+extern "C" int64_t nm_attn_workspace_bytes(int64_t R, int64_t S, int64_t C) {
+    if (R <= 0 || S <= 0 || C <= 0) return 0;
+    int sch, nchunk;
+    attn_chunking(S, &sch, &nchunk);
+    const int64_t e = ((R * S + 3) / 4) * 4;
+    return (int64_t)sizeof(float) * (e + R * nchunk * C + R * nchunk * 4);
+}
+
+extern "C" int nm_attn_fwd(void* stream, const float* y, const float* hf, const float* states,
+                           const float* mask, const float* v, const float* bias, int64_t R,
+                           int64_t rows_per_key, int64_t S, int64_t A, int64_t C, float* ctx,
+                           int64_t ldctx, float* weights, void* workspace, int64_t workspace_bytes) {
+    NM_REQUIRE(y && hf && states && v && ctx && workspace, "nm_attn_fwd: null pointer");
+    NM_REQUIRE(R > 0 && S > 0 && A > 0 && C > 0 && rows_per_key >= 1 && R % rows_per_key == 0,
+               "nm_attn_fwd: bad shape R=%ld k=%ld S=%ld", (long)R, (long)rows_per_key, (long)S);
+    NM_REQUIRE(A % 4 == 0 && C % 4 == 0 && ldctx % 4 == 0, "nm_attn_fwd: A, C, ldctx must be multiples of 4");
+    NM_REQUIRE(C <= 2048, "nm_attn_fwd: C > 2048 unsupported");
+    NM_REQUIRE(rows_per_key <= 8, "nm_attn_fwd: rows_per_key > 8 unsupported");
+    NM_REQUIRE(nm_aligned16(y) && nm_aligned16(hf) && nm_aligned16(states) && nm_aligned16(v) &&
+                   nm_aligned16(ctx) && nm_aligned16(workspace),
+               "nm_attn_fwd: pointers must be 16-byte aligned");
+    NM_REQUIRE(workspace_bytes >= nm_attn_workspace_bytes(R, S, C), "nm_attn_fwd: workspace too small");
+    int sch, nchunk;
+    attn_chunking(S, &sch, &nchunk);
+    NM_REQUIRE(sch <= ATT_MAX_SCH && nchunk <= 64, "nm_attn_fwd: S=%ld too long (max 768)", (long)S);
+    const int qpk = (int)rows_per_key;
+    const int Bk = (int)(R / rows_per_key);
+    float* ws = reinterpret_cast<float*>(workspace);
+    AttnArgs p;
+    p.y = y; p.hf = hf; p.states = states; p.mask = mask; p.v = v; p.bias = bias;
+    p.energies = ws;
+    p.pctx = ws + ((R * S + 3) / 4) * 4;
+    p.pstat = p.pctx + R * nchunk * C;
+    p.R = (int)R; p.S = (int)S; p.A = (int)A; p.C = (int)C; p.nchunk = nchunk; p.sch = sch;
+    const size_t shm = sizeof(float) * ((size_t)qpk * A + A + (size_t)qpk * ATT_MAX_SCH + ATT_MAX_SCH);
+    NM_REQUIRE(shm <= 160 * 1024, "nm_attn_fwd: A too large for LDS staging");
+    hipStream_t st = nm_stream(stream);
+    dim3 grid(nchunk, Bk), block(256);
+    const int ncg = C > 1024 ? 2 : 1;
+#define NM_AT(Q_)                                                                         \
+    do {                                                                                  \
+        if (ncg == 1) hipLaunchKernelGGL((attn_partial<Q_, 1>), grid, block, shm, st, p); \
+        else hipLaunchKernelGGL((attn_partial<Q_, 2>), grid, block, shm, st, p);          \
+    } while (0)
+    switch (qpk) {
+        case 1: NM_AT(1); break;
+        case 2: NM_AT(2); break;
+        case 3: NM_AT(3); break;
+        case 4: NM_AT(4); break;
+        case 5: NM_AT(5); break;
+        case 6: NM_AT(6); break;
+        case 7: NM_AT(7); break;
+        default: NM_AT(8); break;
+    }
+#undef NM_AT
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) NM_FAIL(NM_ERR_HIP, "nm_attn_fwd: partial launch failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(attn_combine, dim3((unsigned)R), dim3(256), 0, st, p.pctx, p.pstat, p.energies,
+                       mask, ctx, (long)ldctx, weights, (int)S, (int)C, nchunk, qpk);
+    NM_LAUNCH_CHECK("nm_attn_fwd");
+}

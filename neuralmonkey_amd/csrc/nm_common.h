@@ -1,0 +1,59 @@
+// Shared helpers for libnmhip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define NM_OK 0
+#define NM_ERR_ARG -1
+#define NM_ERR_HIP -2
+#define NM_ERR_WORKSPACE -3
+
+// thread-local last-error text, exposed through nm_last_error()
+extern thread_local char nm_err_buf[512];
+
+#define NM_FAIL(code, ...)                                   \
+    do {                                                     \
+        snprintf(nm_err_buf, sizeof(nm_err_buf), __VA_ARGS__); \
+        return (code);                                       \
+    } while (0)
+
+#define NM_REQUIRE(cond, ...)                                \
+    do {                                                     \
+        if (!(cond)) NM_FAIL(NM_ERR_ARG, __VA_ARGS__);       \
+    } while (0)
+
+#define NM_LAUNCH_CHECK(name)                                              \
+    do {                                                                   \
+        hipError_t e_ = hipGetLastError();                                 \
+        if (e_ != hipSuccess)                                              \
+            NM_FAIL(NM_ERR_HIP, "%s: launch failed: %s", name, hipGetErrorString(e_)); \
+        return NM_OK;                                                      \
+    } while (0)
+
+static inline hipStream_t nm_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline bool nm_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+static inline int nm_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- device helpers -------------------------------------------------------
+__device__ __forceinline__ float nm_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float nm_wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+// tanh with ~1e-7 absolute error: 1 - 2/(1+exp(2|x|)), sign restored.
+__device__ __forceinline__ float nm_tanh(float x) {
+    float ax = fabsf(x);
+    float e = __expf(2.0f * ax);
+    float t = 1.0f - 2.0f / (e + 1.0f);
+    return copysignf(t, x);
+}
+__device__ __forceinline__ float nm_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }

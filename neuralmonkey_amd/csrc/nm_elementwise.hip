@@ -1,0 +1,243 @@
+// Bandwidth-bound row kernels of the attention-decoder path (forward):
+// embedding gather, GRU gate/blend epilogues, layer norm, small utilities.
+// Reference call sites:
+//   model/sequence.py:170-194            embedding lookup * mask
+//   decoders/autoregressive.py:269-272   decoder embedding lookup
+//   nn/ortho_gru_cell.py:44-53           TF GRUCell gates / candidate / blend
+//   encoders/recurrent.py:86-102         dynamic_rnn length masking + reverse_sequence
+//   tf_utils.py:189-219                  layer_norm
+#include "nm_common.h"
+
+thread_local char nm_err_buf[512] = {0};
+extern "C" const char* nm_last_error(void) { return nm_err_buf; }
+extern "C" int nm_version(void) { return 1; }
+
+// ---------------------------------------------------------------------------
+// embedding gather: out[i,:] = table[ids[i],:] * scale * (mask_pad ? ids[i]!=0 : 1)
+// ---------------------------------------------------------------------------
+__global__ void embedding_gather_kernel(const float* __restrict__ table, long V, int E,
+                                        const int* __restrict__ ids, long n,
+                                        float* __restrict__ out, long ldo, int mask_pad, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    int id = ids[row];
+    float s = scale;
+    if (mask_pad && id == 0) s = 0.0f;
+    if (id < 0 || id >= V) { id = 0; s = 0.0f; }
+    const float* src = table + (long)id * E;
+    float* dst = out + row * ldo;
+    if ((E & 3) == 0 && (ldo & 3) == 0) {
+        for (int c = lane * 4; c < E; c += 256) {
+            float4 v = *reinterpret_cast<const float4*>(src + c);
+            v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+            *reinterpret_cast<float4*>(dst + c) = v;
+        }
+    } else {
+        for (int c = lane; c < E; c += 64) dst[c] = src[c] * s;
+    }
+}
+
+extern "C" int nm_embedding_gather(void* stream, const float* table, int64_t V, int64_t E,
+                                   const int32_t* ids, int64_t n, float* out, int64_t ldo,
+                                   int mask_pad, float scale) {
+    NM_REQUIRE(table && ids && out, "nm_embedding_gather: null pointer");
+    NM_REQUIRE(V > 0 && E > 0 && n >= 0 && ldo >= E, "nm_embedding_gather: bad shape");
+    if (n == 0) return NM_OK;
+    NM_REQUIRE(nm_aligned16(table) && nm_aligned16(out), "nm_embedding_gather: unaligned");
+    hipLaunchKernelGGL(embedding_gather_kernel, dim3(nm_cdiv(n, 4)), dim3(256), 0, nm_stream(stream),
+                       table, (long)V, (int)E, ids, (long)n, out, (long)ldo, mask_pad, scale);
+    NM_LAUNCH_CHECK("nm_embedding_gather");
+}
+
+// ---------------------------------------------------------------------------
+// GRU step epilogues.  The cell is split so both GEMMs run on MFMA:
+//   xp  = x . [Wg_x | Wc_x] + [bg | bc]       (hoisted over all time steps)
+//   hg  = h . Wg_h                  -> gates:  r,u = sigmoid(xp[:, :2H] + hg), rh = r*h
+//   hc  = (r*h) . Wc_h              -> blend:  c = tanh(xp[:, 2H:] + hc), h' = u*h + (1-u)*c
+// xp is addressed as  xp + d*x_dir_off + r*x_row_stride + pos*x_time_stride  where
+// pos = t, or for the backward direction of a length-masked encoder L[r]-1-t
+// (tf.reverse_sequence semantics).  Rows with t >= L[r] are dead: state copied
+// through, outputs left untouched (pre-zeroed by the caller).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool gru_pos(const int* lengths, int r, int d, int t, int& pos) {
+    pos = t;
+    if (!lengths) return true;
+    const int len = lengths[r];
+    if (t >= len) return false;
+    if (d == 1) pos = len - 1 - t;
+    return true;
+}
+
+__global__ void gru_gates_fwd_kernel(const float* __restrict__ xp, long x_dir_off, long x_row_stride,
+                                     long x_time_stride, const float* __restrict__ hg,
+                                     const float* __restrict__ h, float* __restrict__ ru,
+                                     float* __restrict__ rh, const int* __restrict__ lengths, int t,
+                                     long R, int H) {
+    const int d = blockIdx.z;
+    const long r = blockIdx.y;
+    const int j = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (j >= H) return;
+    int pos;
+    const bool live = gru_pos(lengths, (int)r, d, t, pos);
+    const long ro = ((long)d * R + r);
+    float4 rr = make_float4(0, 0, 0, 0), uu = rr, rhv = rr;
+    if (live) {
+        const float* x = xp + d * x_dir_off + r * x_row_stride + (long)pos * x_time_stride;
+        const float4 xr = *reinterpret_cast<const float4*>(x + j);
+        const float4 xu = *reinterpret_cast<const float4*>(x + H + j);
+        const float4 gr = *reinterpret_cast<const float4*>(hg + ro * 2 * H + j);
+        const float4 gu = *reinterpret_cast<const float4*>(hg + ro * 2 * H + H + j);
+        const float4 hv = *reinterpret_cast<const float4*>(h + ro * H + j);
+        rr = make_float4(nm_sigmoid(xr.x + gr.x), nm_sigmoid(xr.y + gr.y), nm_sigmoid(xr.z + gr.z),
+                         nm_sigmoid(xr.w + gr.w));
+        uu = make_float4(nm_sigmoid(xu.x + gu.x), nm_sigmoid(xu.y + gu.y), nm_sigmoid(xu.z + gu.z),
+                         nm_sigmoid(xu.w + gu.w));
+        rhv = make_float4(rr.x * hv.x, rr.y * hv.y, rr.z * hv.z, rr.w * hv.w);
+    }
+    *reinterpret_cast<float4*>(ru + ro * 2 * H + j) = rr;
+    *reinterpret_cast<float4*>(ru + ro * 2 * H + H + j) = uu;
+    *reinterpret_cast<float4*>(rh + ro * H + j) = rhv;
+}
+
+extern "C" int nm_gru_gates_fwd(void* stream, const float* xp, int64_t x_dir_off, int64_t x_row_stride,
+                                int64_t x_time_stride, const float* hg, const float* h, float* ru,
+                                float* rh, const int32_t* lengths, int t, int ndir, int64_t R,
+                                int64_t H) {
+    NM_REQUIRE(xp && hg && h && ru && rh, "nm_gru_gates_fwd: null pointer");
+    NM_REQUIRE(H > 0 && H % 4 == 0 && R > 0 && ndir >= 1 && ndir <= 2, "nm_gru_gates_fwd: bad shape");
+    NM_REQUIRE(x_dir_off % 4 == 0 && x_row_stride % 4 == 0 && x_time_stride % 4 == 0 &&
+                   nm_aligned16(xp) && nm_aligned16(hg) && nm_aligned16(h) && nm_aligned16(ru) &&
+                   nm_aligned16(rh),
+               "nm_gru_gates_fwd: unaligned");
+    const int tpb = 128;
+    dim3 grid(nm_cdiv(H, 4 * tpb), (unsigned)R, ndir);
+    hipLaunchKernelGGL(gru_gates_fwd_kernel, grid, dim3(tpb), 0, nm_stream(stream), xp, (long)x_dir_off,
+                       (long)x_row_stride, (long)x_time_stride, hg, h, ru, rh, lengths, t, (long)R, (int)H);
+    NM_LAUNCH_CHECK("nm_gru_gates_fwd");
+}
+
+__global__ void gru_blend_fwd_kernel(const float* __restrict__ xp, long x_dir_off, long x_row_stride,
+                                     long x_time_stride, const float* __restrict__ hc,
+                                     const float* __restrict__ ru, const float* h_in,
+                                     float* h_out, float* __restrict__ c_save, float* __restrict__ out,
+                                     long out_dir_off, long out_row_stride, long out_time_stride,
+                                     const int* __restrict__ lengths, int t, long R, int H) {
+    const int d = blockIdx.z;
+    const long r = blockIdx.y;
+    const int j = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (j >= H) return;
+    int pos;
+    const bool live = gru_pos(lengths, (int)r, d, t, pos);
+    const long ro = ((long)d * R + r);
+    const float4 hv = *reinterpret_cast<const float4*>(h_in + ro * H + j);
+    if (!live) {
+        if (h_out != h_in) *reinterpret_cast<float4*>(h_out + ro * H + j) = hv;
+        if (c_save) *reinterpret_cast<float4*>(c_save + ro * H + j) = make_float4(0, 0, 0, 0);
+        return;
+    }
+    const float* x = xp + d * x_dir_off + r * x_row_stride + (long)pos * x_time_stride + 2 * H;
+    const float4 xc = *reinterpret_cast<const float4*>(x + j);
+    const float4 cc = *reinterpret_cast<const float4*>(hc + ro * H + j);
+    const float4 uu = *reinterpret_cast<const float4*>(ru + ro * 2 * H + H + j);
+    float4 c = make_float4(nm_tanh(xc.x + cc.x), nm_tanh(xc.y + cc.y), nm_tanh(xc.z + cc.z),
+                           nm_tanh(xc.w + cc.w));
+    float4 hn = make_float4(uu.x * hv.x + (1.0f - uu.x) * c.x, uu.y * hv.y + (1.0f - uu.y) * c.y,
+                            uu.z * hv.z + (1.0f - uu.z) * c.z, uu.w * hv.w + (1.0f - uu.w) * c.w);
+    *reinterpret_cast<float4*>(h_out + ro * H + j) = hn;
+    if (c_save) *reinterpret_cast<float4*>(c_save + ro * H + j) = c;
+    if (out) {
+        float* o = out + d * out_dir_off + r * out_row_stride + (long)pos * out_time_stride;
+        *reinterpret_cast<float4*>(o + j) = hn;
+    }
+}
+
+extern "C" int nm_gru_blend_fwd(void* stream, const float* xp, int64_t x_dir_off, int64_t x_row_stride,
+                                int64_t x_time_stride, const float* hc, const float* ru,
+                                const float* h_in, float* h_out, float* c_save, float* out,
+                                int64_t out_dir_off, int64_t out_row_stride, int64_t out_time_stride,
+                                const int32_t* lengths, int t, int ndir, int64_t R, int64_t H) {
+    NM_REQUIRE(xp && hc && ru && h_in && h_out, "nm_gru_blend_fwd: null pointer");
+    NM_REQUIRE(H > 0 && H % 4 == 0 && R > 0 && ndir >= 1 && ndir <= 2, "nm_gru_blend_fwd: bad shape");
+    NM_REQUIRE(x_dir_off % 4 == 0 && x_row_stride % 4 == 0 && x_time_stride % 4 == 0 &&
+                   out_dir_off % 4 == 0 && out_row_stride % 4 == 0 && out_time_stride % 4 == 0,
+               "nm_gru_blend_fwd: strides must be multiples of 4");
+    const int tpb = 128;
+    dim3 grid(nm_cdiv(H, 4 * tpb), (unsigned)R, ndir);
+    hipLaunchKernelGGL(gru_blend_fwd_kernel, grid, dim3(tpb), 0, nm_stream(stream), xp, (long)x_dir_off,
+                       (long)x_row_stride, (long)x_time_stride, hc, ru, h_in, h_out, c_save, out,
+                       (long)out_dir_off, (long)out_row_stride, (long)out_time_stride, lengths, t,
+                       (long)R, (int)H);
+    NM_LAUNCH_CHECK("nm_gru_blend_fwd");
+}
+
+// ---------------------------------------------------------------------------
+// layer norm forward: y = (x-mean)*rsqrt(var+eps)*gamma+beta, biased variance.
+// One 256-thread block per row; saves mean / rstd for the backward pass.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+    v = nm_wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void layer_norm_fwd_kernel(const float* __restrict__ x, long ldx,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             float* __restrict__ y, long ldy,
+                                                             float* __restrict__ mean_out,
+                                                             float* __restrict__ rstd_out, int D,
+                                                             float eps) {
+    __shared__ float sh[4];
+    const long row = blockIdx.x;
+    const float* xr = x + row * ldx;
+    float s = 0.0f;
+    for (int c = threadIdx.x; c < D; c += 256) s += xr[c];
+    const float mean = block_sum_256(s, sh) / (float)D;
+    float q = 0.0f;
+    for (int c = threadIdx.x; c < D; c += 256) {
+        const float dlt = xr[c] - mean;
+        q += dlt * dlt;
+    }
+    const float var = block_sum_256(q, sh) / (float)D;
+    const float rstd = rsqrtf(var + eps);
+    float* yr = y + row * ldy;
+    for (int c = threadIdx.x; c < D; c += 256) yr[c] = (xr[c] - mean) * rstd * gamma[c] + beta[c];
+    if (threadIdx.x == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+}
+
+extern "C" int nm_layer_norm_fwd(void* stream, const float* x, int64_t ldx, const float* gamma,
+                                 const float* beta, float* y, int64_t ldy, float* mean_out,
+                                 float* rstd_out, int64_t rows, int64_t D, float eps) {
+    NM_REQUIRE(x && gamma && beta && y, "nm_layer_norm_fwd: null pointer");
+    NM_REQUIRE(rows >= 0 && D > 0, "nm_layer_norm_fwd: bad shape");
+    if (rows == 0) return NM_OK;
+    hipLaunchKernelGGL(layer_norm_fwd_kernel, dim3((unsigned)rows), dim3(256), 0, nm_stream(stream), x,
+                       (long)ldx, gamma, beta, y, (long)ldy, mean_out, rstd_out, (int)D, eps);
+    NM_LAUNCH_CHECK("nm_layer_norm_fwd");
+}
+
+// ---------------------------------------------------------------------------
+// concat helper: dst[r, off:off+w] = src[r, :w]   (builds [h | emb | ctx] rows)
+// ---------------------------------------------------------------------------
+__global__ void copy_cols_kernel(const float* __restrict__ src, long lds_, float* __restrict__ dst,
+                                 long ldd, long rows, int w) {
+    const long r = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < w) dst[r * ldd + c] = src[r * lds_ + c];
+}
+
+extern "C" int nm_copy_cols(void* stream, const float* src, int64_t ld_src, float* dst, int64_t ld_dst,
+                            int64_t rows, int64_t width) {
+    NM_REQUIRE(src && dst && rows >= 0 && width >= 0, "nm_copy_cols: bad args");
+    if (rows == 0 || width == 0) return NM_OK;
+    hipLaunchKernelGGL(copy_cols_kernel, dim3(nm_cdiv(width, 256), (unsigned)rows), dim3(256), 0,
+                       nm_stream(stream), src, (long)ld_src, dst, (long)ld_dst, (long)rows, (int)width);
+    NM_LAUNCH_CHECK("nm_copy_cols");
+}

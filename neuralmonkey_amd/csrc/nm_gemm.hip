@@ -1,0 +1,369 @@
+// fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact f32,
+// k-ordered fma chain, 157 TF peak).  Replaces every tf.matmul /
+// tf.layers.dense / 1x1 tf.nn.conv2d call site on the attention-decoder path:
+//   attention/feed_forward.py:111-118,130-132   (key / query projections)
+//   decoders/output_projection.py:115-130       (tanh output projection)
+//   decoders/autoregressive.py:450-459          (state_to_logits)
+//   decoders/encoder_projection.py:47-73        (initial state)
+//   nn/ortho_gru_cell.py:44-53                  (GRUCell kernels)
+// and their autodiff transposes (NT / TN forms).
+//
+// Two kernels:
+//   gemm_tiled  : 64*TM x 64*TN block tile, BK=16, 4 waves (2x2), operands
+//                 staged through LDS k-major so every ds_read_b32 is
+//                 conflict-free; register prefetch of the next k-tile.
+//   gemm_skinny : M <= a few hundred (one decoder step).  One 32x32 output tile
+//                 per block, the block's KS waves split K, fragments go
+//                 global->VGPR directly (no LDS for operands), deterministic
+//                 LDS reduction over the K slices.  Latency- not
+//                 throughput-bound, so the grid is (M/32)*(N/32) blocks.
+#include "nm_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    int M, N, K;
+    long lda, ldb, ldc;
+    long sA, sB, sC;
+    int act;         // 0 none, 1 tanh, 2 relu
+    int accumulate;  // C += ...
+};
+
+__device__ __forceinline__ float apply_act(float x, int act) {
+    if (act == 1) return nm_tanh(x);
+    if (act == 2) return fmaxf(x, 0.0f);
+    return x;
+}
+
+// C/D layout of v_mfma_f32_32x32x2_f32: col = lane&31,
+// row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+__device__ __forceinline__ void store_tile32(const GemmArgs& g, float* __restrict__ C,
+                                             const f32x16& acc, int m0, int n0, int lane) {
+    const int col = n0 + (lane & 31);
+    if (col >= g.N) return;
+    const float bv = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < g.M) {
+            float* p = C + (long)row * g.ldc + col;
+            float v = acc[r] + bv;
+            if (g.accumulate) v += *p;
+            *p = apply_act(v, g.act);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// tiled kernel
+// ---------------------------------------------------------------------------
+template <int TM, int TN, bool TA, bool TB, bool VEC>
+__global__ __launch_bounds__(256) void gemm_tiled(GemmArgs g, int tiles_m) {
+    constexpr int BM = 64 * TM, BN = 64 * TN, BK = 16;
+    constexpr int LDAS = BM + 4, LDBS = BN + 4;
+    __shared__ __attribute__((aligned(16))) float As[2][BK][LDAS];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDBS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bm = blockIdx.x % tiles_m, bn = blockIdx.x / tiles_m;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const float* __restrict__ A = g.A + (long)blockIdx.z * g.sA;
+    const float* __restrict__ B = g.B + (long)blockIdx.z * g.sB;
+    float* __restrict__ C = g.C + (long)blockIdx.z * g.sC;
+
+    float4 ra[TM], rb[TN];
+
+    auto load_a = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < TM; ++it) {
+            const int idx = tid + it * 256;
+            int m, k;
+            if (TA) { k = idx / (BM / 4); m = (idx % (BM / 4)) * 4; }   // m contiguous
+            else    { m = idx / 4;        k = (idx % 4) * 4; }          // k contiguous
+            const int gm = m0 + m, gk = k0 + k;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (TA) {
+                const float* p = A + (long)gk * g.lda + gm;
+                if (gk < g.K) {
+                    if (VEC) { if (gm < g.M) v = *reinterpret_cast<const float4*>(p); }
+                    else {
+                        if (gm + 0 < g.M) v.x = p[0];
+                        if (gm + 1 < g.M) v.y = p[1];
+                        if (gm + 2 < g.M) v.z = p[2];
+                        if (gm + 3 < g.M) v.w = p[3];
+                    }
+                }
+            } else {
+                const float* p = A + (long)gm * g.lda + gk;
+                if (gm < g.M) {
+                    if (VEC) { if (gk < g.K) v = *reinterpret_cast<const float4*>(p); }
+                    else {
+                        if (gk + 0 < g.K) v.x = p[0];
+                        if (gk + 1 < g.K) v.y = p[1];
+                        if (gk + 2 < g.K) v.z = p[2];
+                        if (gk + 3 < g.K) v.w = p[3];
+                    }
+                }
+            }
+            ra[it] = v;
+        }
+    };
+    auto load_b = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < TN; ++it) {
+            const int idx = tid + it * 256;
+            int n, k;
+            if (!TB) { k = idx / (BN / 4); n = (idx % (BN / 4)) * 4; }  // n contiguous
+            else     { n = idx / 4;        k = (idx % 4) * 4; }         // k contiguous
+            const int gn = n0 + n, gk = k0 + k;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!TB) {
+                const float* p = B + (long)gk * g.ldb + gn;
+                if (gk < g.K) {
+                    if (VEC) { if (gn < g.N) v = *reinterpret_cast<const float4*>(p); }
+                    else {
+                        if (gn + 0 < g.N) v.x = p[0];
+                        if (gn + 1 < g.N) v.y = p[1];
+                        if (gn + 2 < g.N) v.z = p[2];
+                        if (gn + 3 < g.N) v.w = p[3];
+                    }
+                }
+            } else {
+                const float* p = B + (long)gn * g.ldb + gk;
+                if (gn < g.N) {
+                    if (VEC) { if (gk < g.K) v = *reinterpret_cast<const float4*>(p); }
+                    else {
+                        if (gk + 0 < g.K) v.x = p[0];
+                        if (gk + 1 < g.K) v.y = p[1];
+                        if (gk + 2 < g.K) v.z = p[2];
+                        if (gk + 3 < g.K) v.w = p[3];
+                    }
+                }
+            }
+            rb[it] = v;
+        }
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < TM; ++it) {
+            const int idx = tid + it * 256;
+            if (TA) {
+                const int k = idx / (BM / 4), m = (idx % (BM / 4)) * 4;
+                *reinterpret_cast<float4*>(&As[buf][k][m]) = ra[it];
+            } else {
+                const int m = idx / 4, k = (idx % 4) * 4;
+                As[buf][k + 0][m] = ra[it].x;
+                As[buf][k + 1][m] = ra[it].y;
+                As[buf][k + 2][m] = ra[it].z;
+                As[buf][k + 3][m] = ra[it].w;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < TN; ++it) {
+            const int idx = tid + it * 256;
+            if (!TB) {
+                const int k = idx / (BN / 4), n = (idx % (BN / 4)) * 4;
+                *reinterpret_cast<float4*>(&Bs[buf][k][n]) = rb[it];
+            } else {
+                const int n = idx / 4, k = (idx % 4) * 4;
+                Bs[buf][k + 0][n] = rb[it].x;
+                Bs[buf][k + 1][n] = rb[it].y;
+                Bs[buf][k + 2][n] = rb[it].z;
+                Bs[buf][k + 3][n] = rb[it].w;
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int wm = (wave >> 1) * 32 * TM, wn = (wave & 1) * 32 * TN;
+    const int nkt = (g.K + BK - 1) / BK;
+
+    load_a(0);
+    load_b(0);
+    store_lds(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) { load_a((kt + 1) * BK); load_b((kt + 1) * BK); }
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const int kr = kk + (lane >> 5);
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[cur][kr][wm + i * 32 + (lane & 31)];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[cur][kr][wn + j * 32 + (lane & 31)];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nkt) store_lds(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            store_tile32(g, C, acc[i][j], m0 + wm + i * 32, n0 + wn + j * 32, lane);
+}
+
+// ---------------------------------------------------------------------------
+// skinny kernel: A is [M,K] k-contiguous (transA = 0), lda % 4 == 0, K % 8 == 0
+// ---------------------------------------------------------------------------
+template <int KS, bool TB>
+__global__ __launch_bounds__(KS * 64) void gemm_skinny(GemmArgs g, int tiles_m) {
+    __shared__ float red[KS][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bm = blockIdx.x % tiles_m, bn = blockIdx.x / tiles_m;
+    const int m0 = bm * 32, n0 = bn * 32;
+    const float* __restrict__ A = g.A + (long)blockIdx.z * g.sA;
+    const float* __restrict__ B = g.B + (long)blockIdx.z * g.sB;
+    float* __restrict__ C = g.C + (long)blockIdx.z * g.sC;
+
+    const int r = lane & 31, half = lane >> 5;
+    const int mm = min(m0 + r, g.M - 1), nn = min(n0 + r, g.N - 1);
+    const int kper = ((g.K / 8 + KS - 1) / KS) * 8;
+    const int kbeg = wave * kper, kend = min(g.K, kbeg + kper);
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+
+    const float* ap = A + (long)mm * g.lda + 4 * half;
+    const float* bp = TB ? (B + (long)nn * g.ldb + 4 * half) : (B + (long)(4 * half) * g.ldb + nn);
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        float4 av[4], bv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k = k0 + 8 * c;
+            av[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            bv[c] = av[c];
+            if (k < kend) {
+                av[c] = *reinterpret_cast<const float4*>(ap + k);
+                if (TB) {
+                    bv[c] = *reinterpret_cast<const float4*>(bp + k);
+                } else {
+                    const float* q = bp + (long)k * g.ldb;
+                    bv[c].x = q[0];
+                    bv[c].y = q[g.ldb];
+                    bv[c].z = q[2 * g.ldb];
+                    bv[c].w = q[3 * g.ldb];
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].x, bv[c].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].y, bv[c].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].z, bv[c].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].w, bv[c].w, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[wave][i][lane] = acc[i];
+    __syncthreads();
+    for (int o = tid; o < 16 * 64; o += KS * 64) {
+        const int reg = o >> 6, ln = o & 63;
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < KS; ++w) s += red[w][reg][ln];
+        const int col = n0 + (ln & 31);
+        const int row = m0 + (reg & 3) + 8 * (reg >> 2) + 4 * (ln >> 5);
+        if (row < g.M && col < g.N) {
+            float* p = C + (long)row * g.ldc + col;
+            float v = s + (g.bias ? g.bias[col] : 0.0f);
+            if (g.accumulate) v += *p;
+            *p = apply_act(v, g.act);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host dispatch
+// ---------------------------------------------------------------------------
+template <int TM, int TN>
+static void launch_tiled(const GemmArgs& g, int batch, bool ta, bool tb, bool vec, hipStream_t st) {
+    const int tiles_m = nm_cdiv(g.M, 64 * TM), tiles_n = nm_cdiv(g.N, 64 * TN);
+    dim3 grid(tiles_m * tiles_n, 1, batch), block(256);
+#define NM_GT(TA_, TB_, V_) \
+    hipLaunchKernelGGL((gemm_tiled<TM, TN, TA_, TB_, V_>), grid, block, 0, st, g, tiles_m)
+    if (vec) {
+        if (!ta && !tb) NM_GT(false, false, true);
+        else if (!ta && tb) NM_GT(false, true, true);
+        else if (ta && !tb) NM_GT(true, false, true);
+        else NM_GT(true, true, true);
+    } else {
+        if (!ta && !tb) NM_GT(false, false, false);
+        else if (!ta && tb) NM_GT(false, true, false);
+        else if (ta && !tb) NM_GT(true, false, false);
+        else NM_GT(true, true, false);
+    }
+#undef NM_GT
+}
+
+extern "C" int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int64_t N, int64_t K,
+                           const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
+                           int64_t ldc, const float* bias, int act, int accumulate, int64_t batch,
+                           int64_t strideA, int64_t strideB, int64_t strideC, int algo) {
+    NM_REQUIRE(A && B && C, "nm_gemm_f32: null operand");
+    NM_REQUIRE(M >= 0 && N >= 0 && K >= 0 && batch >= 1, "nm_gemm_f32: bad shape %ld %ld %ld x%ld",
+               (long)M, (long)N, (long)K, (long)batch);
+    NM_REQUIRE(act >= 0 && act <= 2, "nm_gemm_f32: bad act %d", act);
+    NM_REQUIRE(M < (1 << 30) && N < (1 << 30) && K < (1 << 30), "nm_gemm_f32: dim too large");
+    if (M == 0 || N == 0) return NM_OK;
+    NM_REQUIRE(K > 0, "nm_gemm_f32: K == 0");
+    GemmArgs g{A, B, C, bias, (int)M, (int)N, (int)K, (long)lda, (long)ldb, (long)ldc,
+               (long)strideA, (long)strideB, (long)strideC, act, accumulate};
+    hipStream_t st = nm_stream(stream);
+    const bool ta = transA != 0, tb = transB != 0;
+
+    // vector path: 16-byte aligned rows and contiguous extents divisible by 4
+    const bool a_vec = nm_aligned16(A) && lda % 4 == 0 && strideA % 4 == 0 && ((ta ? M : K) % 4 == 0);
+    const bool b_vec = nm_aligned16(B) && ldb % 4 == 0 && strideB % 4 == 0 && ((tb ? K : N) % 4 == 0);
+    const bool vec = a_vec && b_vec;
+
+    // algo: 0 auto, 1 tiled 128x128, 2 tiled 64x64, 3 skinny
+    bool skinny_ok = !ta && a_vec && K % 8 == 0 && (!tb || b_vec);
+    int pick = algo;
+    if (pick == 0) {
+        const long blocks128 = (long)nm_cdiv(M, 128) * nm_cdiv(N, 128) * batch;
+        if (skinny_ok && M <= 256 && (long)N * K <= (4L << 20)) pick = 3;
+        else if (blocks128 >= 512) pick = 1;
+        else pick = 2;
+    }
+    if (pick == 3) {
+        NM_REQUIRE(skinny_ok, "nm_gemm_f32: skinny path needs transA=0, aligned A, K%%8==0");
+        const int tiles_m = nm_cdiv(M, 32), tiles_n = nm_cdiv(N, 32);
+        dim3 grid(tiles_m * tiles_n, 1, (unsigned)batch);
+        const int ks = (K >= 512) ? 8 : (K >= 128 ? 4 : 1);
+#define NM_GS(KS_)                                                                          \
+    do {                                                                                    \
+        if (tb) hipLaunchKernelGGL((gemm_skinny<KS_, true>), grid, dim3(KS_ * 64), 0, st, g, tiles_m);  \
+        else hipLaunchKernelGGL((gemm_skinny<KS_, false>), grid, dim3(KS_ * 64), 0, st, g, tiles_m);    \
+    } while (0)
+        if (ks == 8) NM_GS(8);
+        else if (ks == 4) NM_GS(4);
+        else NM_GS(1);
+#undef NM_GS
+    } else if (pick == 1) {
+        launch_tiled<2, 2>(g, (int)batch, ta, tb, vec, st);
+    } else {
+        launch_tiled<1, 1>(g, (int)batch, ta, tb, vec, st);
+    }
+    NM_LAUNCH_CHECK("nm_gemm_f32");
+}

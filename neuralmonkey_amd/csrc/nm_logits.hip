@@ -1,0 +1,414 @@
+// Row kernels over the vocabulary axis: max / argmax / log-sum-exp, masked
+// cross entropy (+ its gradient), and the beam-search top-k step.
+// Reference call sites:
+//   decoders/autoregressive.py:470          tf.argmax(logits, axis=1)  (first max wins)
+//   decoders/autoregressive.py:289-316      log_softmax / sequence_loss * mask
+//   decoders/beam_search_decoder.py:440-501 masking, +logprob_sum, length penalty,
+//                                           tf.nn.top_k over [B, k*V], div/mod, gathers
+#include "nm_common.h"
+
+#define NM_NEG_INF_F (-1e9f)   // the reference's INF (beam_search_decoder.py:42)
+
+// ---------------------------------------------------------------------------
+// row statistics: max, first argmax, lse = log(sum(exp(x - max)))
+// two passes over the row (second pass is L2-resident), matching
+// tf.nn.log_softmax = x - max - log(sum(exp(x - max))).
+// ---------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void block_argmax(float& v, int& i, float* shv, int* shi) {
+    // reduce (value desc, index asc) over the block
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(v, off, 64);
+        const int oi = __shfl_xor(i, off, 64);
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { shv[w] = v; shi[w] = i; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float bv = shv[0];
+        int bi = shi[0];
+        for (int k = 1; k < NT / 64; ++k)
+            if (shv[k] > bv || (shv[k] == bv && shi[k] < bi)) { bv = shv[k]; bi = shi[k]; }
+        shv[0] = bv;
+        shi[0] = bi;
+    }
+    __syncthreads();
+    v = shv[0];
+    i = shi[0];
+    __syncthreads();
+}
+
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = nm_wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    float s = 0.0f;
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < NT / 64; ++k) s += sh[k];
+        sh[0] = s;
+    }
+    __syncthreads();
+    s = sh[0];
+    __syncthreads();
+    return s;
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void row_stats_kernel(const float* __restrict__ x, long ldx, int V,
+                                                       float* __restrict__ max_out,
+                                                       float* __restrict__ lse_out,
+                                                       int* __restrict__ argmax_out) {
+    __shared__ float shv[NT / 64];
+    __shared__ int shi[NT / 64];
+    const long row = blockIdx.x;
+    const float* xr = x + row * ldx;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = threadIdx.x; c < V; c += NT) {
+        const float v = xr[c];
+        if (v > bv) { bv = v; bi = c; }     // strided ascending: first max kept
+    }
+    block_argmax<NT>(bv, bi, shv, shi);
+    float s = 0.0f;
+    if (lse_out) {
+        for (int c = threadIdx.x; c < V; c += NT) s += expf(xr[c] - bv);
+        s = block_sum<NT>(s, shv);
+    }
+    if (threadIdx.x == 0) {
+        if (max_out) max_out[row] = bv;
+        if (lse_out) lse_out[row] = logf(s);
+        if (argmax_out) argmax_out[row] = bi;
+    }
+}
+
+extern "C" int nm_row_stats(void* stream, const float* x, int64_t ldx, int64_t rows, int64_t V,
+                            float* max_out, float* lse_out, int32_t* argmax_out) {
+    NM_REQUIRE(x && rows >= 0 && V > 0 && ldx >= V, "nm_row_stats: bad args");
+    if (rows == 0) return NM_OK;
+    hipLaunchKernelGGL((row_stats_kernel<1024>), dim3((unsigned)rows), dim3(1024), 0, nm_stream(stream),
+                       x, (long)ldx, (int)V, max_out, lse_out, argmax_out);
+    NM_LAUNCH_CHECK("nm_row_stats");
+}
+
+// ---------------------------------------------------------------------------
+// greedy symbol update (autoregressive.py:461-480):
+//   sym = argmax * !finished ; finished |= (sym == </s>) ; mask = !finished
+// ---------------------------------------------------------------------------
+__global__ void greedy_update_kernel(const int* __restrict__ argmax, int* __restrict__ finished,
+                                     int* __restrict__ sym_out, int* __restrict__ mask_out, int n,
+                                     int end_id, int* __restrict__ all_finished) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int f = finished[i];
+    const int s = f ? 0 : argmax[i];
+    f = f | (s == end_id);
+    finished[i] = f;
+    sym_out[i] = s;
+    if (mask_out) mask_out[i] = !f;
+    if (all_finished && !f) atomicAnd(all_finished, 0);
+}
+
+extern "C" int nm_greedy_update(void* stream, const int32_t* argmax, int32_t* finished, int32_t* sym_out,
+                                int32_t* mask_out, int64_t n, int end_id, int32_t* all_finished) {
+    NM_REQUIRE(argmax && finished && sym_out && n >= 0, "nm_greedy_update: bad args");
+    if (n == 0) return NM_OK;
+    hipLaunchKernelGGL(greedy_update_kernel, dim3(nm_cdiv(n, 256)), dim3(256), 0, nm_stream(stream),
+                       argmax, finished, sym_out, mask_out, (int)n, end_id, all_finished);
+    NM_LAUNCH_CHECK("nm_greedy_update");
+}
+
+// ---------------------------------------------------------------------------
+// masked cross entropy over [rows, V] logits (+ optional in-place gradient):
+//   loss[r] = -(x[t] - max - lse) * w[r]
+//   dx      = (softmax(x) - onehot(t)) * w[r] * grad_scale        (if write_grad)
+// ---------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(NT) void xent_kernel(float* __restrict__ x, long ldx, int V,
+                                                  const int* __restrict__ targets,
+                                                  const float* __restrict__ weights,
+                                                  float* __restrict__ loss_rows,
+                                                  const float* __restrict__ grad_scale,
+                                                  int write_grad) {
+    __shared__ float shv[NT / 64];
+    __shared__ int shi[NT / 64];
+    const long row = blockIdx.x;
+    float* xr = x + row * ldx;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = threadIdx.x; c < V; c += NT) {
+        const float v = xr[c];
+        if (v > bv) { bv = v; bi = c; }
+    }
+    block_argmax<NT>(bv, bi, shv, shi);
+    float s = 0.0f;
+    for (int c = threadIdx.x; c < V; c += NT) s += expf(xr[c] - bv);
+    s = block_sum<NT>(s, shv);
+    const float lse = logf(s);
+    const int t = targets[row];
+    const float w = weights ? weights[row] : 1.0f;
+    if (threadIdx.x == 0 && loss_rows) {
+        const float lp = (t >= 0 && t < V) ? (xr[t] - bv - lse) : 0.0f;
+        loss_rows[row] = -lp * w;
+    }
+    if (write_grad) {
+        __syncthreads();   // loss read of xr[t] done before overwrite
+        const float gs = w * (grad_scale ? grad_scale[0] : 1.0f);
+        const float inv = 1.0f / s;
+        for (int c = threadIdx.x; c < V; c += NT) {
+            float p = expf(xr[c] - bv) * inv;
+            if (c == t) p -= 1.0f;
+            xr[c] = p * gs;
+        }
+    }
+}
+
+extern "C" int nm_xent(void* stream, float* logits, int64_t ldx, int64_t rows, int64_t V,
+                       const int32_t* targets, const float* weights, float* loss_rows,
+                       const float* grad_scale, int write_grad) {
+    NM_REQUIRE(logits && targets && rows >= 0 && V > 0 && ldx >= V, "nm_xent: bad args");
+    if (rows == 0) return NM_OK;
+    hipLaunchKernelGGL((xent_kernel<1024>), dim3((unsigned)rows), dim3(1024), 0, nm_stream(stream),
+                       logits, (long)ldx, (int)V, targets, weights, loss_rows, grad_scale, write_grad);
+    NM_LAUNCH_CHECK("nm_xent");
+}
+
+// ---------------------------------------------------------------------------
+// beam search step (decoders/beam_search_decoder.py:440-501).
+// Inputs per hypothesis row r = b*k + j: logits [R,V] of the previous parent
+// step with their (max, lse) row statistics; logprob_sum, lengths, finished.
+//   lp        = finished ? (v==PAD ? 0 : -1e9) : (x - max - lse)
+//   hyp       = logprob_sum + lp                       (un-normalised, carried)
+//   score     = hyp / penalty[len + 1 - finished]      (penalty table from host,
+//               ((5+len)/6)^alpha evaluated in fp32 exactly as the oracle does)
+//   top-k over the k*V candidates of sentence b, ties -> lower flat index.
+// Stage 1: each block scans a slice of the k*V candidates of one sentence and
+// keeps its best k; stage 2 merges the slices and emits word / beam ids and the
+// gathered search state.
+// ---------------------------------------------------------------------------
+#define BEAM_MAX_K 8
+
+struct Cand { float score; int idx; };
+
+__device__ __forceinline__ bool cand_better(float sa, int ia, float sb, int ib) {
+    return sa > sb || (sa == sb && ia < ib);
+}
+
+// insert into a descending sorted list of length K (registers)
+template <int K>
+__device__ __forceinline__ void topk_insert(float (&s)[K], int (&ix)[K], float v, int i) {
+    if (!cand_better(v, i, s[K - 1], ix[K - 1])) return;
+    s[K - 1] = v; ix[K - 1] = i;
+#pragma unroll
+    for (int p = K - 1; p > 0; --p) {
+        if (cand_better(s[p], ix[p], s[p - 1], ix[p - 1])) {
+            const float ts = s[p]; s[p] = s[p - 1]; s[p - 1] = ts;
+            const int ti = ix[p]; ix[p] = ix[p - 1]; ix[p - 1] = ti;
+        }
+    }
+}
+
+__device__ __forceinline__ float beam_score(const float* __restrict__ logits, long ldx, int V, int k,
+                                            int b, int flat, const float* rmax, const float* rlse,
+                                            const float* logprob_sum, const int* lengths,
+                                            const int* finished, const float* penalty, float* hyp_out) {
+    const int j = flat / V, v = flat - j * V;
+    const int r = b * k + j;
+    const int fin = finished[r];
+    float lp;
+    if (fin) lp = (v == 0) ? 0.0f : NM_NEG_INF_F;
+    else lp = (logits[(long)r * ldx + v] - rmax[r]) - rlse[r];
+    const float hyp = logprob_sum[r] + lp;
+    const int len = lengths[r] + 1 - (fin ? 1 : 0);
+    if (hyp_out) *hyp_out = hyp;
+    return hyp / penalty[len];
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void beam_topk_partial(const float* __restrict__ logits, long ldx,
+                                                         int V, int k, const float* __restrict__ rmax,
+                                                         const float* __restrict__ rlse,
+                                                         const float* __restrict__ logprob_sum,
+                                                         const int* __restrict__ lengths,
+                                                         const int* __restrict__ finished,
+                                                         const float* __restrict__ penalty,
+                                                         float* __restrict__ part_score,
+                                                         int* __restrict__ part_idx, int nslice) {
+    __shared__ float shs[256 * K];
+    __shared__ int shi[256 * K];
+    const int b = blockIdx.y, slice = blockIdx.x, tid = threadIdx.x;
+    const int total = k * V;
+    const int per = (total + nslice - 1) / nslice;
+    const int beg = slice * per, end = min(total, beg + per);
+    float s[K];
+    int ix[K];
+#pragma unroll
+    for (int p = 0; p < K; ++p) { s[p] = -INFINITY; ix[p] = 0x7fffffff; }
+    for (int f = beg + tid; f < end; f += 256) {
+        const float sc = beam_score(logits, ldx, V, k, b, f, rmax, rlse, logprob_sum, lengths,
+                                    finished, penalty, nullptr);
+        topk_insert<K>(s, ix, sc, f);
+    }
+#pragma unroll
+    for (int p = 0; p < K; ++p) { shs[tid * K + p] = s[p]; shi[tid * K + p] = ix[p]; }
+    __syncthreads();
+    // tree merge of sorted lists
+    for (int stride = 128; stride > 0; stride >>= 1) {
+        if (tid < stride) {
+            float ms[K];
+            int mi[K];
+            int pa = 0, pb = 0;
+            const float* sa = shs + tid * K;
+            const int* ia = shi + tid * K;
+            const float* sb = shs + (tid + stride) * K;
+            const int* ib = shi + (tid + stride) * K;
+#pragma unroll
+            for (int p = 0; p < K; ++p) {
+                const bool takea = cand_better(sa[pa], ia[pa], sb[pb], ib[pb]);
+                ms[p] = takea ? sa[pa] : sb[pb];
+                mi[p] = takea ? ia[pa] : ib[pb];
+                pa += takea ? 1 : 0;
+                pb += takea ? 0 : 1;
+            }
+#pragma unroll
+            for (int p = 0; p < K; ++p) { s[p] = ms[p]; ix[p] = mi[p]; }
+        }
+        __syncthreads();
+        if (tid < stride) {
+#pragma unroll
+            for (int p = 0; p < K; ++p) { shs[tid * K + p] = s[p]; shi[tid * K + p] = ix[p]; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int p = 0; p < K; ++p) {
+            part_score[((long)b * nslice + slice) * K + p] = shs[p];
+            part_idx[((long)b * nslice + slice) * K + p] = shi[p];
+        }
+    }
+}
+
+template <int K>
+__global__ void beam_topk_final(const float* __restrict__ logits, long ldx, int V, int k,
+                                const float* __restrict__ rmax, const float* __restrict__ rlse,
+                                const float* __restrict__ logprob_sum, const int* __restrict__ lengths,
+                                const int* __restrict__ finished, const float* __restrict__ penalty,
+                                const float* __restrict__ part_score, const int* __restrict__ part_idx,
+                                int nslice, int B, int end_id, float* __restrict__ out_score,
+                                int* __restrict__ out_word, int* __restrict__ out_beam,
+                                float* __restrict__ out_logprob_sum, int* __restrict__ out_lengths,
+                                int* __restrict__ out_finished, int* __restrict__ out_src_row) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float s[K];
+    int ix[K];
+#pragma unroll
+    for (int p = 0; p < K; ++p) { s[p] = -INFINITY; ix[p] = 0x7fffffff; }
+    for (int sl = 0; sl < nslice; ++sl)
+        for (int p = 0; p < K; ++p)
+            topk_insert<K>(s, ix, part_score[((long)b * nslice + sl) * K + p],
+                           part_idx[((long)b * nslice + sl) * K + p]);
+    for (int p = 0; p < k; ++p) {
+        const int flat = ix[p];
+        const int j = flat / V, v = flat - j * V;
+        const int r = b * k + j;
+        float hyp;
+        beam_score(logits, ldx, V, k, b, flat, rmax, rlse, logprob_sum, lengths, finished, penalty, &hyp);
+        const int fin = finished[r];
+        const int o = b * k + p;
+        out_score[o] = s[p];
+        out_word[o] = v;
+        out_beam[o] = j;
+        out_logprob_sum[o] = hyp;
+        out_lengths[o] = lengths[r] + 1 - (fin ? 1 : 0);
+        out_finished[o] = fin | (v == end_id);
+        out_src_row[o] = r;
+    }
+}
+
+extern "C" int64_t nm_beam_workspace_bytes(int64_t B, int64_t k, int64_t V) {
+    (void)k; (void)V;
+    return B * 64 * BEAM_MAX_K * 8 + 256;
+}
+
+extern "C" int nm_beam_topk_step(void* stream, const float* logits, int64_t ldx, int64_t B, int64_t k,
+                                 int64_t V, const float* rmax, const float* rlse,
+                                 const float* logprob_sum, const int32_t* lengths,
+                                 const int32_t* finished, const float* penalty, int end_id,
+                                 float* out_score, int32_t* out_word, int32_t* out_beam,
+                                 float* out_logprob_sum, int32_t* out_lengths, int32_t* out_finished,
+                                 int32_t* out_src_row, void* workspace, int64_t workspace_bytes) {
+    NM_REQUIRE(logits && rmax && rlse && logprob_sum && lengths && finished && penalty && out_score &&
+                   out_word && out_beam && out_logprob_sum && out_lengths && out_finished &&
+                   out_src_row && workspace,
+               "nm_beam_topk_step: null pointer");
+    NM_REQUIRE(B > 0 && k >= 1 && k <= BEAM_MAX_K && V > 0 && k * V < (1L << 31),
+               "nm_beam_topk_step: bad shape B=%ld k=%ld V=%ld", (long)B, (long)k, (long)V);
+    NM_REQUIRE(k * V >= k, "nm_beam_topk_step: fewer candidates than beam");
+    NM_REQUIRE(workspace_bytes >= nm_beam_workspace_bytes(B, k, V), "nm_beam_topk_step: workspace too small");
+    // slices so that B*nslice fills the chip; each slice >= 4096 candidates
+    int nslice = (int)((k * V + 16383) / 16384);
+    if (nslice < 1) nslice = 1;
+    if (nslice > 64) nslice = 64;
+    float* ps = reinterpret_cast<float*>(workspace);
+    int* pi = reinterpret_cast<int*>(ps + B * 64 * BEAM_MAX_K);
+    hipStream_t st = nm_stream(stream);
+    dim3 grid(nslice, (unsigned)B);
+#define NM_BK(K_)                                                                                   \
+    do {                                                                                            \
+        hipLaunchKernelGGL((beam_topk_partial<K_>), grid, dim3(256), 0, st, logits, (long)ldx, (int)V, \
+                           (int)k, rmax, rlse, logprob_sum, lengths, finished, penalty, ps, pi, nslice); \
+        hipLaunchKernelGGL((beam_topk_final<K_>), dim3(nm_cdiv(B, 64)), dim3(64), 0, st, logits,     \
+                           (long)ldx, (int)V, (int)k, rmax, rlse, logprob_sum, lengths, finished,    \
+                           penalty, ps, pi, nslice, (int)B, end_id, out_score, out_word, out_beam,   \
+                           out_logprob_sum, out_lengths, out_finished, out_src_row);                 \
+    } while (0)
+    if (k <= 4) NM_BK(4);
+    else NM_BK(8);
+#undef NM_BK
+    NM_LAUNCH_CHECK("nm_beam_topk_step");
+}
+
+// ---------------------------------------------------------------------------
+// row gather: dst[r,:] = src[idx[r],:]   (beam reorder of decoder state,
+// beam_search_decoder.py:503-532 / tf_utils.py:106-131) and the int32 variant
+// for token histories [steps, R].
+// ---------------------------------------------------------------------------
+__global__ void gather_rows_f32_kernel(const float* __restrict__ src, long lds_, const int* __restrict__ idx,
+                                       float* __restrict__ dst, long ldd, long rows, int w) {
+    const long r = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < w) dst[r * ldd + c] = src[(long)idx[r] * lds_ + c];
+}
+
+extern "C" int nm_gather_rows_f32(void* stream, const float* src, int64_t ld_src, const int32_t* idx,
+                                  float* dst, int64_t ld_dst, int64_t rows, int64_t width) {
+    NM_REQUIRE(src && idx && dst && rows >= 0 && width >= 0 && src != dst, "nm_gather_rows_f32: bad args");
+    if (rows == 0 || width == 0) return NM_OK;
+    hipLaunchKernelGGL(gather_rows_f32_kernel, dim3(nm_cdiv(width, 256), (unsigned)rows), dim3(256), 0,
+                       nm_stream(stream), src, (long)ld_src, idx, dst, (long)ld_dst, (long)rows, (int)width);
+    NM_LAUNCH_CHECK("nm_gather_rows_f32");
+}
+
+// token history reorder: dst[t, r] = src[t, idx[r]] for t < steps; dst[steps, r] = word[r]
+__global__ void beam_tokens_kernel(const int* __restrict__ src, const int* __restrict__ idx,
+                                   const int* __restrict__ word, int* __restrict__ dst, int steps, int R) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const int sr = idx[r];
+    for (int t = 0; t < steps; ++t) dst[(long)t * R + r] = src[(long)t * R + sr];
+    dst[(long)steps * R + r] = word[r];
+}
+
+extern "C" int nm_beam_reorder_tokens(void* stream, const int32_t* src, const int32_t* src_row,
+                                      const int32_t* word, int32_t* dst, int64_t steps, int64_t R) {
+    NM_REQUIRE(src && src_row && word && dst && steps >= 0 && R > 0 && src != dst,
+               "nm_beam_reorder_tokens: bad args");
+    hipLaunchKernelGGL(beam_tokens_kernel, dim3(nm_cdiv(R, 256)), dim3(256), 0, nm_stream(stream), src,
+                       src_row, word, dst, (int)steps, (int)R);
+    NM_LAUNCH_CHECK("nm_beam_reorder_tokens");
+}

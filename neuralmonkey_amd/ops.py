@@ -1,0 +1,197 @@
+"""Thin Python wrappers over the C-ABI: torch tensors in, HIP kernels out.
+
+torch is used only as the device allocator and stream owner; every arithmetic
+op on the hot path is a libnmhip kernel launched on torch's current stream.
+"""
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+ACT = {None: 0, "none": 0, "tanh": 1, "relu": 2}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _f32(t):
+    assert t.dtype == torch.float32 and t.is_cuda, (t.dtype, t.device)
+    return t
+
+
+def _i32(t):
+    assert t.dtype == torch.int32 and t.is_cuda, (t.dtype, t.device)
+    return t
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, bias=None, act=None,
+         trans_a=False, trans_b=False, accumulate=False, algo=0):
+    """out[M,N] = act(op(a) @ op(b) + bias (+ out)).  2-D (or batched 3-D with
+    equal leading dim) row-major views with unit inner stride."""
+    lib = _lib.load()
+    _f32(a), _f32(b)
+    batched = a.dim() == 3
+    if batched:
+        assert b.dim() == 3 and a.shape[0] == b.shape[0]
+        nb = a.shape[0]
+        a2, b2 = a[0], b[0]
+        s_a, s_b = a.stride(0), b.stride(0)
+    else:
+        nb, a2, b2, s_a, s_b = 1, a, b, 0, 0
+    assert a2.stride(1) == 1 and b2.stride(1) == 1, "inner stride must be 1"
+    m, k = (a2.shape[1], a2.shape[0]) if trans_a else (a2.shape[0], a2.shape[1])
+    kb, n = (b2.shape[1], b2.shape[0]) if trans_b else (b2.shape[0], b2.shape[1])
+    assert k == kb, f"inner dims differ: {k} vs {kb}"
+    if out is None:
+        assert not accumulate
+        out = torch.empty((nb, m, n) if batched else (m, n), dtype=torch.float32, device=a.device)
+    o2 = out[0] if batched else out
+    assert tuple(o2.shape) == (m, n) and o2.stride(1) == 1
+    s_c = out.stride(0) if batched else 0
+    _lib.check(lib.nm_gemm_f32(_stream(), int(trans_a), int(trans_b), m, n, k,
+                               a.data_ptr(), a2.stride(0), b.data_ptr(), b2.stride(0),
+                               out.data_ptr(), o2.stride(0), _p(bias), ACT[act], int(accumulate),
+                               nb, s_a, s_b, s_c, algo), "nm_gemm_f32")
+    return out
+
+
+def embedding_gather(table, ids, out=None, mask_pad=False, scale=1.0):
+    lib = _lib.load()
+    _f32(table), _i32(ids)
+    n = ids.numel()
+    e = table.shape[1]
+    if out is None:
+        out = torch.empty(tuple(ids.shape) + (e,), dtype=torch.float32, device=table.device)
+    ldo = out.stride(-2) if out.dim() >= 2 else e
+    _lib.check(lib.nm_embedding_gather(_stream(), table.data_ptr(), table.shape[0], e,
+                                       ids.data_ptr(), n, out.data_ptr(), ldo, int(mask_pad),
+                                       float(scale)), "nm_embedding_gather")
+    return out
+
+
+def gru_gates_fwd(xp, x_dir_off, x_row_stride, x_time_stride, hg, h, ru, rh, lengths, t, ndir, rows, hsz):
+    lib = _lib.load()
+    _lib.check(lib.nm_gru_gates_fwd(_stream(), xp.data_ptr(), x_dir_off, x_row_stride, x_time_stride,
+                                    hg.data_ptr(), h.data_ptr(), ru.data_ptr(), rh.data_ptr(),
+                                    _p(lengths), t, ndir, rows, hsz), "nm_gru_gates_fwd")
+
+
+def gru_blend_fwd(xp, x_dir_off, x_row_stride, x_time_stride, hc, ru, h_in, h_out, c_save, out,
+                  out_dir_off, out_row_stride, out_time_stride, lengths, t, ndir, rows, hsz):
+    lib = _lib.load()
+    _lib.check(lib.nm_gru_blend_fwd(_stream(), xp.data_ptr(), x_dir_off, x_row_stride, x_time_stride,
+                                    hc.data_ptr(), ru.data_ptr(), h_in.data_ptr(), h_out.data_ptr(),
+                                    _p(c_save), _p(out), out_dir_off, out_row_stride, out_time_stride,
+                                    _p(lengths), t, ndir, rows, hsz), "nm_gru_blend_fwd")
+
+
+def layer_norm_fwd(x, gamma, beta, out=None, mean=None, rstd=None, eps=1e-6):
+    lib = _lib.load()
+    d = x.shape[-1]
+    rows = x.numel() // d
+    assert x.is_contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(lib.nm_layer_norm_fwd(_stream(), x.data_ptr(), d, gamma.data_ptr(), beta.data_ptr(),
+                                     out.data_ptr(), d, _p(mean), _p(rstd), rows, d, float(eps)),
+               "nm_layer_norm_fwd")
+    return out
+
+
+def copy_cols(src, dst):
+    """dst[:, :w] = src (2-D views, inner stride 1)."""
+    lib = _lib.load()
+    assert src.dim() == 2 and dst.dim() == 2 and src.stride(1) == 1 and dst.stride(1) == 1
+    _lib.check(lib.nm_copy_cols(_stream(), src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0),
+                                src.shape[0], src.shape[1]), "nm_copy_cols")
+
+
+def attn_workspace(rows, s, c, device):
+    lib = _lib.load()
+    nbytes = lib.nm_attn_workspace_bytes(rows, s, c)
+    return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+
+
+def attn_fwd(y, hf, states, mask, v, bias, rows_per_key, ctx, weights, workspace):
+    """Fused Bahdanau step.  y [R,A]; hf [Bk,S,A]; states [Bk,S,C]; mask [Bk,S]."""
+    lib = _lib.load()
+    r, a = y.shape
+    _, s, c = states.shape
+    assert hf.is_contiguous() and states.is_contiguous() and y.is_contiguous()
+    assert ctx.stride(1) == 1
+    _lib.check(lib.nm_attn_fwd(_stream(), y.data_ptr(), hf.data_ptr(), states.data_ptr(), _p(mask),
+                               v.data_ptr(), _p(bias), r, rows_per_key, s, a, c, ctx.data_ptr(),
+                               ctx.stride(0), _p(weights), workspace.data_ptr(),
+                               workspace.numel() * 4), "nm_attn_fwd")
+
+
+def row_stats(x, rmax=None, lse=None, argmax=None):
+    lib = _lib.load()
+    assert x.dim() == 2 and x.stride(1) == 1
+    _lib.check(lib.nm_row_stats(_stream(), x.data_ptr(), x.stride(0), x.shape[0], x.shape[1],
+                                _p(rmax), _p(lse), _p(argmax)), "nm_row_stats")
+
+
+def greedy_update(argmax, finished, sym_out, mask_out, end_id, all_finished=None):
+    lib = _lib.load()
+    _lib.check(lib.nm_greedy_update(_stream(), argmax.data_ptr(), finished.data_ptr(),
+                                    sym_out.data_ptr(), _p(mask_out), argmax.numel(), end_id,
+                                    _p(all_finished)), "nm_greedy_update")
+
+
+def xent(logits, targets, weights, loss_rows, grad_scale=None, write_grad=False):
+    lib = _lib.load()
+    assert logits.dim() == 2 and logits.stride(1) == 1
+    _lib.check(lib.nm_xent(_stream(), logits.data_ptr(), logits.stride(0), logits.shape[0],
+                           logits.shape[1], targets.data_ptr(), _p(weights), _p(loss_rows),
+                           _p(grad_scale), int(write_grad)), "nm_xent")
+
+
+def beam_workspace(b, k, v, device):
+    lib = _lib.load()
+    return torch.empty((lib.nm_beam_workspace_bytes(b, k, v) + 3) // 4, dtype=torch.float32, device=device)
+
+
+def beam_topk_step(logits, b, k, rmax, rlse, logprob_sum, lengths, finished, penalty, end_id,
+                   out_score, out_word, out_beam, out_logprob_sum, out_lengths, out_finished,
+                   out_src_row, workspace):
+    lib = _lib.load()
+    assert logits.dim() == 2 and logits.stride(1) == 1 and logits.shape[0] == b * k
+    _lib.check(lib.nm_beam_topk_step(_stream(), logits.data_ptr(), logits.stride(0), b, k,
+                                     logits.shape[1], rmax.data_ptr(), rlse.data_ptr(),
+                                     logprob_sum.data_ptr(), lengths.data_ptr(), finished.data_ptr(),
+                                     penalty.data_ptr(), end_id, out_score.data_ptr(),
+                                     out_word.data_ptr(), out_beam.data_ptr(),
+                                     out_logprob_sum.data_ptr(), out_lengths.data_ptr(),
+                                     out_finished.data_ptr(), out_src_row.data_ptr(),
+                                     workspace.data_ptr(), workspace.numel() * 4), "nm_beam_topk_step")
+
+
+def gather_rows(src, idx, dst):
+    lib = _lib.load()
+    assert src.dim() == 2 and dst.dim() == 2 and src.stride(1) == 1 and dst.stride(1) == 1
+    _lib.check(lib.nm_gather_rows_f32(_stream(), src.data_ptr(), src.stride(0), idx.data_ptr(),
+                                      dst.data_ptr(), dst.stride(0), dst.shape[0], dst.shape[1]),
+               "nm_gather_rows_f32")
+
+
+def beam_reorder_tokens(src, src_row, word, dst, steps, rows):
+    lib = _lib.load()
+    _lib.check(lib.nm_beam_reorder_tokens(_stream(), src.data_ptr(), src_row.data_ptr(),
+                                          word.data_ptr(), dst.data_ptr(), steps, rows),
+               "nm_beam_reorder_tokens")
+
+
+def length_penalty_table(max_len: int, alpha: float, device) -> torch.Tensor:
+    """((5+len)/6)**alpha for len in [0, max_len], evaluated in fp32 on the host
+    the way the reference's tf.pow sees it (beam_search_decoder.py:561-573)."""
+    lens = np.arange(max_len + 1, dtype=np.float32)
+    tab = ((np.float32(5.0) + lens) / np.float32(6.0)) ** np.float32(alpha)
+    return torch.from_numpy(tab.astype(np.float32)).to(device)

@@ -1,0 +1,377 @@
+"""GPU parity of every libnmhip kernel against the CPU oracle (oracle/) on the
+same seeded inputs.  fp32 tolerance: 1e-4 relative (BASELINE.json north_star);
+integer / index outputs bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nm_oracle as O
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def rel_err(got, ref):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-6))
+
+
+def T(x, dev, dtype=torch.float32):
+    return torch.tensor(np.asarray(x), dtype=dtype, device=dev)
+
+
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("m,n,k,ta,tb,algo", [
+    (128, 1024, 512, False, False, 0),      # decoder-step shape -> skinny
+    (128, 512, 1024, False, True, 0),       # skinny NT
+    (128, 1024, 512, False, False, 2),      # same through tiled 64
+    (128, 1024, 512, False, False, 1),      # same through tiled 128
+    (640, 512, 2048, False, False, 0),      # output projection shape
+    (300, 260, 130, False, False, 0),       # ragged, non-vector path
+    (300, 260, 130, True, True, 0),
+    (259, 131, 77, True, False, 0),
+    (96, 200, 64, False, True, 3),          # skinny forced, ragged M/N
+    (1024, 2048, 256, True, False, 1),      # TN weight-gradient form
+    (512, 384, 640, False, True, 1),
+    (37, 1000, 8, False, False, 0),
+])
+def test_gemm(dev, m, n, k, ta, tb, algo):
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(m * 7 + n * 3 + k)
+    a = rng.standard_normal((k, m) if ta else (m, k)).astype(np.float32)
+    b = rng.standard_normal((n, k) if tb else (k, n)).astype(np.float32)
+    bias = rng.standard_normal(n).astype(np.float32)
+    ref = (a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64)
+    out = ops.gemm(T(a, dev), T(b, dev), trans_a=ta, trans_b=tb, algo=algo)
+    assert rel_err(out.cpu().numpy(), ref) < 2e-6 * np.sqrt(k) + 1e-6
+    out2 = ops.gemm(T(a, dev), T(b, dev), bias=T(bias, dev), act="tanh", trans_a=ta, trans_b=tb, algo=algo)
+    assert rel_err(out2.cpu().numpy(), np.tanh(ref + bias)) < 1e-5
+    c0 = rng.standard_normal((m, n)).astype(np.float32)
+    out3 = T(c0, dev)
+    ops.gemm(T(a, dev), T(b, dev), out=out3, trans_a=ta, trans_b=tb, accumulate=True, algo=algo)
+    assert rel_err(out3.cpu().numpy(), ref + c0) < 2e-6 * np.sqrt(k) + 1e-6
+
+
+def test_gemm_transpose_detecting(dev):
+    """A = I with an asymmetric B catches a swapped C layout."""
+    from neuralmonkey_amd import ops
+    n = 96
+    a = np.eye(n, dtype=np.float32)
+    b = (np.arange(n * n, dtype=np.float32).reshape(n, n) % 97) * 0.25
+    for algo in (1, 2, 3):
+        out = ops.gemm(T(a, dev), T(b, dev), algo=algo)
+        assert np.array_equal(out.cpu().numpy(), b)
+
+
+def test_gemm_batched_strided(dev):
+    """Per-sentence attention-backward forms: batch over b of [T,C]x[C,S]."""
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(5)
+    t, b, c, s = 50, 6, 1024, 50
+    dctx = rng.standard_normal((t, b, c)).astype(np.float32)
+    states = rng.standard_normal((b, s, c)).astype(np.float32)
+    w = rng.standard_normal((t, b, s)).astype(np.float32)
+    d_dctx, d_states, d_w = T(dctx, dev), T(states, dev), T(w, dev)
+    dw = torch.empty((t, b, s), dtype=torch.float32, device=dev)
+    ops.gemm(d_dctx.permute(1, 0, 2), d_states, out=dw.permute(1, 0, 2), trans_b=True)
+    ref = np.einsum("tbc,bsc->tbs", dctx.astype(np.float64), states.astype(np.float64))
+    assert rel_err(dw.cpu().numpy(), ref) < 1e-5
+    dst = torch.empty((b, s, c), dtype=torch.float32, device=dev)
+    ops.gemm(d_w.permute(1, 0, 2), d_dctx.permute(1, 0, 2), out=dst, trans_a=True)
+    ref2 = np.einsum("tbs,tbc->bsc", w.astype(np.float64), dctx.astype(np.float64))
+    assert rel_err(dst.cpu().numpy(), ref2) < 1e-5
+
+
+# --------------------------------------------------------------------------- #
+def test_embedding_gather(dev):
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(0)
+    emb = rng.standard_normal((100, 512)).astype(np.float32)
+    ids = rng.integers(0, 100, size=(7, 9)).astype(np.int32)
+    ids[2, 4:] = 0
+    ref, _ = O.embedded_sequence(emb, ids)
+    got = ops.embedding_gather(T(emb, dev), T(ids, dev, torch.int32), mask_pad=True)
+    assert np.array_equal(got.cpu().numpy(), ref)
+    got2 = ops.embedding_gather(T(emb, dev), T(ids, dev, torch.int32))
+    assert np.array_equal(got2.cpu().numpy(), emb[ids])
+    emb2 = rng.standard_normal((50, 10)).astype(np.float32)     # E % 4 != 0
+    got3 = ops.embedding_gather(T(emb2, dev), T(ids % 50, dev, torch.int32))
+    assert np.array_equal(got3.cpu().numpy(), emb2[ids % 50])
+
+
+def test_layer_norm(dev):
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(1)
+    for d in (1024, 14, 513):
+        x = rng.standard_normal((33, d)).astype(np.float32) * 3 + 1
+        x[5] = 0.0                                   # padded encoder row -> beta
+        g = rng.standard_normal(d).astype(np.float32)
+        b = rng.standard_normal(d).astype(np.float32)
+        got = ops.layer_norm_fwd(T(x, dev), T(g, dev), T(b, dev))
+        ref = O.layer_norm(x.astype(np.float64), g.astype(np.float64), b.astype(np.float64))
+        assert rel_err(got.cpu().numpy(), ref) < 1e-5
+
+
+# --------------------------------------------------------------------------- #
+def _gru_params(rng, d_in, h, std=0.3):
+    return {"gates_kernel": (rng.standard_normal((d_in + h, 2 * h)) * std).astype(np.float32),
+            "gates_bias": np.ones(2 * h, np.float32),
+            "cand_kernel": (rng.standard_normal((d_in + h, h)) * std).astype(np.float32),
+            "cand_bias": (rng.standard_normal(h) * 0.1).astype(np.float32)}
+
+
+def test_gru_decoder_step(dev):
+    """Split GRU (x-part hoisted) == TF GRUCell on concatenated [x,h]."""
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(2)
+    b, e, h = 128, 512, 512
+    p = _gru_params(rng, e, h, 0.05)
+    x = rng.standard_normal((b, e)).astype(np.float32)
+    h0 = rng.standard_normal((b, h)).astype(np.float32)
+    ref = O.gru_cell(x.astype(np.float64), h0.astype(np.float64), {k: v.astype(np.float64) for k, v in p.items()})
+    wx = np.concatenate([p["gates_kernel"][:e], p["cand_kernel"][:e]], 1)
+    bx = np.concatenate([p["gates_bias"], p["cand_bias"]])
+    xp = ops.gemm(T(x, dev), T(wx, dev), bias=T(bx, dev))
+    hd = T(h0, dev)
+    hg = ops.gemm(hd, T(p["gates_kernel"][e:], dev))
+    ru = torch.empty((b, 2 * h), device=dev)
+    rh = torch.empty((b, h), device=dev)
+    ops.gru_gates_fwd(xp, 0, 3 * h, 0, hg, hd, ru, rh, None, 0, 1, b, h)
+    hc = ops.gemm(rh, T(p["cand_kernel"][e:], dev))
+    hn = torch.empty((b, h), device=dev)
+    ops.gru_blend_fwd(xp, 0, 3 * h, 0, hc, ru, hd, hn, None, None, 0, 0, 0, None, 0, 1, b, h)
+    assert rel_err(hn.cpu().numpy(), ref) < RTOL
+
+
+def test_gru_bidirectional_encoder(dev):
+    """Length-masked biGRU sequence == bidirectional_dynamic_rnn restatement."""
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(3)
+    b, s, e, h = 9, 11, 16, 12
+    pf, pb = _gru_params(rng, e, h), _gru_params(rng, e, h)
+    x = rng.standard_normal((b, s, e)).astype(np.float32)
+    lengths = np.array([11, 1, 5, 11, 7, 2, 10, 3, 6], dtype=np.int32)
+    for i, ln in enumerate(lengths):
+        x[i, ln:] = 0
+    ref_states, ref_final = O.bidirectional_rnn(O.gru_cell, x, lengths, pf, pb)
+    wx = np.concatenate([pf["gates_kernel"][:e], pf["cand_kernel"][:e],
+                         pb["gates_kernel"][:e], pb["cand_kernel"][:e]], 1)       # [E, 6H]
+    bx = np.concatenate([pf["gates_bias"], pf["cand_bias"], pb["gates_bias"], pb["cand_bias"]])
+    xp = ops.gemm(T(x.reshape(b * s, e), dev), T(wx, dev), bias=T(bx, dev))      # [B*S, 6H]
+    wgh = T(np.stack([pf["gates_kernel"][e:], pb["gates_kernel"][e:]]), dev)      # [2,H,2H]
+    wch = T(np.stack([pf["cand_kernel"][e:], pb["cand_kernel"][e:]]), dev)        # [2,H,H]
+    hcur = torch.zeros((2, b, h), device=dev)
+    out = torch.zeros((b, s, 2 * h), device=dev)
+    hg = torch.empty((2, b, 2 * h), device=dev)
+    ru = torch.empty((2, b, 2 * h), device=dev)
+    rh = torch.empty((2, b, h), device=dev)
+    hc = torch.empty((2, b, h), device=dev)
+    ld = T(lengths, dev, torch.int32)
+    for t in range(s):
+        ops.gemm(hcur, wgh, out=hg)
+        ops.gru_gates_fwd(xp, 3 * h, s * 6 * h, 6 * h, hg, hcur, ru, rh, ld, t, 2, b, h)
+        ops.gemm(rh, wch, out=hc)
+        ops.gru_blend_fwd(xp, 3 * h, s * 6 * h, 6 * h, hc, ru, hcur, hcur, None, out,
+                          h, s * 2 * h, 2 * h, ld, t, 2, b, h)
+    assert rel_err(out.cpu().numpy(), ref_states) < RTOL
+    fin = torch.cat([hcur[0], hcur[1]], 1).cpu().numpy()
+    assert rel_err(fin, ref_final) < RTOL
+    assert np.all(out.cpu().numpy()[1, 1:] == 0)          # beyond length stays zero
+
+
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("bk,qpk,s,a,c,ragged", [
+    (16, 1, 50, 1024, 1024, False),
+    (16, 1, 50, 1024, 1024, True),
+    (4, 5, 50, 1024, 1024, True),
+    (1, 5, 50, 1024, 1024, True),        # reference-compatible batch-1 beam
+    (3, 3, 7, 64, 32, True),             # single chunk, tiny dims
+    (5, 1, 64, 128, 2048, False),        # captioning shape: S=64, C=2048, state_size 128
+    (2, 8, 13, 512, 1024, True),
+    (2, 2, 100, 256, 512, True),
+])
+def test_attention_fwd(dev, bk, qpk, s, a, c, ragged):
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(bk * 100 + qpk * 10 + s)
+    r = bk * qpk
+    q = rng.standard_normal((r, 48)).astype(np.float32)
+    states = rng.standard_normal((bk, s, c)).astype(np.float32)
+    wk = (rng.standard_normal((c, a)) * 0.05).astype(np.float32)
+    ap = {"query_w": (rng.standard_normal((48, a)) * 0.2).astype(np.float32),
+          "query_b": (rng.standard_normal(a) * 0.1).astype(np.float32),
+          "v": rng.standard_normal(a).astype(np.float32) * 0.3,
+          "bias": np.float32(0.37)}
+    mask = np.ones((bk, s), np.float32)
+    if ragged:
+        for i in range(bk):
+            mask[i, rng.integers(1, s + 1):] = 0
+    hf = O.attention_keys(states, wk)
+    f64 = lambda x: np.asarray(x, dtype=np.float64)
+    ref_ctx, ref_w = O.attention_step(f64(q), np.repeat(f64(hf), qpk, 0), np.repeat(f64(states), qpk, 0),
+                                      np.repeat(f64(mask), qpk, 0), {k: f64(v) for k, v in ap.items()})
+    y = ops.gemm(T(q, dev), T(ap["query_w"], dev), bias=T(ap["query_b"], dev))
+    ctx = torch.empty((r, c), device=dev)
+    w = torch.empty((r, s), device=dev)
+    ws = ops.attn_workspace(r, s, c, dev)
+    ops.attn_fwd(y, T(hf, dev), T(states, dev), T(mask, dev), T(ap["v"], dev),
+                 T(np.array([ap["bias"]]), dev), qpk, ctx, w, ws)
+    assert rel_err(w.cpu().numpy(), ref_w) < RTOL
+    assert rel_err(ctx.cpu().numpy(), ref_ctx) < RTOL
+    assert np.all(w.cpu().numpy()[np.repeat(mask, qpk, 0) == 0] == 0)
+
+
+def test_attention_all_masked_row(dev):
+    """A fully masked sentence gives zero weights (0/(0+1e-8)), not NaN."""
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(9)
+    bk, s, a, c = 2, 20, 64, 64
+    y = T(rng.standard_normal((bk, a)), dev)
+    hf = T(rng.standard_normal((bk, s, a)), dev)
+    st = T(rng.standard_normal((bk, s, c)), dev)
+    mask = np.ones((bk, s), np.float32)
+    mask[1] = 0
+    ctx = torch.empty((bk, c), device=dev)
+    w = torch.empty((bk, s), device=dev)
+    ops.attn_fwd(y, hf, st, T(mask, dev), T(rng.standard_normal(a), dev), None, 1, ctx, w,
+                 ops.attn_workspace(bk, s, c, dev))
+    assert np.all(w.cpu().numpy()[1] == 0) and np.all(ctx.cpu().numpy()[1] == 0)
+    assert abs(w.cpu().numpy()[0].sum() - 1) < 1e-5
+
+
+# --------------------------------------------------------------------------- #
+def test_row_stats_and_argmax_ties(dev):
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(4)
+    r, v = 37, 32000
+    x = (rng.standard_normal((r, v)) * 3).astype(np.float32)
+    x[3, 100] = x[3, 31999] = 50.0       # tie: first index wins (tf.argmax)
+    x[4, :] = 1.0                        # all equal -> index 0
+    xd = T(x, dev)
+    mx = torch.empty(r, device=dev)
+    lse = torch.empty(r, device=dev)
+    am = torch.empty(r, dtype=torch.int32, device=dev)
+    ops.row_stats(xd, mx, lse, am)
+    assert np.array_equal(am.cpu().numpy(), x.argmax(1).astype(np.int32))
+    assert np.array_equal(mx.cpu().numpy(), x.max(1))
+    ref_lse = np.log(np.exp(x.astype(np.float64) - x.max(1, keepdims=True)).sum(1))
+    assert rel_err(lse.cpu().numpy(), ref_lse) < 1e-6
+
+
+def test_xent_fwd_and_grad(dev):
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(6)
+    r, v = 64, 5000
+    x = (rng.standard_normal((r, v)) * 2).astype(np.float32)
+    tgt = rng.integers(0, v, size=r).astype(np.int32)
+    w = (rng.random(r) > 0.3).astype(np.float32)
+    ref = O.sequence_xent(x.astype(np.float64)[None], tgt[None].astype(np.int64), w[None].astype(np.float64))[0]
+    xd = T(x, dev)
+    loss = torch.empty(r, device=dev)
+    ops.xent(xd, T(tgt, dev, torch.int32), T(w, dev), loss)
+    assert rel_err(loss.cpu().numpy(), ref) < 1e-5
+    assert np.array_equal(xd.cpu().numpy(), x)                     # untouched without grad
+    scale = np.float32(1.0 / w.sum())
+    ops.xent(xd, T(tgt, dev, torch.int32), T(w, dev), loss, T(np.array([scale]), dev), True)
+    sm = O.softmax(x.astype(np.float64))
+    sm[np.arange(r), tgt] -= 1
+    ref_g = sm * w[:, None] * scale
+    assert rel_err(xd.cpu().numpy(), ref_g) < 1e-5
+
+
+# --------------------------------------------------------------------------- #
+def _beam_step_ref(logits, k, logprob_sum, lengths, finished, alpha):
+    """One beam_search_decoder body top-k (oracle arithmetic, fp32)."""
+    r, v = logits.shape
+    b = r // k
+    lp = O.log_softmax(logits).reshape(b, k, v)
+    fin_row = np.full(v, -O.INF, np.float32)
+    fin_row[0] = 0
+    fm = finished.astype(np.float32)[:, :, None]
+    lp = (1 - fm) * lp + fm * fin_row
+    hyp = logprob_sum[:, :, None] + lp
+    hl = lengths + 1 - finished.astype(np.int32)
+    sc = (hyp / O.length_penalty(hl, alpha, np.float32)[:, :, None]).reshape(b, k * v).astype(np.float32)
+    ts, ti = O.top_k(sc, k + 1)
+    return sc, hyp.reshape(b, k * v), hl, ts, ti
+
+
+@pytest.mark.parametrize("b,k,v", [(128, 5, 32000), (3, 3, 70), (1, 2, 17), (7, 8, 1000)])
+def test_beam_topk_step(dev, b, k, v):
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(b + k + v)
+    logits = (rng.standard_normal((b * k, v)) * 4).astype(np.float32)
+    lps = (-rng.random((b, k)) * 20).astype(np.float32)
+    lens = rng.integers(0, 30, size=(b, k)).astype(np.int32)
+    fin = rng.random((b, k)) < 0.3
+    fin[0] = True                                       # a fully finished sentence
+    if b > 1:
+        lps[1, 1:] = -O.INF                             # first-step state
+    sc, hyp, hl, ts, ti = _beam_step_ref(logits, k, lps, lens, fin, 0.6)
+    ld = T(logits, dev)
+    mx, lse = torch.empty(b * k, device=dev), torch.empty(b * k, device=dev)
+    ops.row_stats(ld, mx, lse, None)
+    pen = ops.length_penalty_table(64, 0.6, dev)
+    i32 = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
+    o_sc, o_lps = torch.empty((b, k), device=dev), torch.empty((b, k), device=dev)
+    o_w, o_b, o_len, o_fin, o_src = i32(b, k), i32(b, k), i32(b, k), i32(b, k), i32(b, k)
+    ops.beam_topk_step(ld, b, k, mx, lse, T(lps, dev), T(lens, dev, torch.int32),
+                       T(fin.astype(np.int32), dev, torch.int32), pen, O.END, o_sc, o_w, o_b, o_lps,
+                       o_len, o_fin, o_src, ops.beam_workspace(b, k, v, dev))
+    got_idx = (o_b.cpu().numpy().astype(np.int64) * v + o_w.cpu().numpy())
+    ref_idx = ti[:, :k]
+    # exact unless the oracle itself reports a near-tie between neighbours
+    gaps = np.abs(np.diff(ts, axis=1)) / np.maximum(np.abs(ts[:, :-1]), 1e-30)
+    for bi in range(b):
+        if np.array_equal(got_idx[bi], ref_idx[bi]):
+            continue
+        assert gaps[bi].min() < 1e-5, f"beam index mismatch without a near-tie, sentence {bi}"
+    same = np.all(got_idx == ref_idx, axis=1)
+    assert same.mean() > 0.98
+    bi = np.arange(b)[:, None]
+    assert rel_err(o_sc.cpu().numpy()[same], ts[:, :k][same]) < 1e-5
+    assert rel_err(o_lps.cpu().numpy()[same], hyp[bi, ref_idx][same]) < 1e-5
+    beam_ref = ref_idx // v
+    assert np.array_equal(o_len.cpu().numpy()[same], hl[bi, beam_ref][same])
+    fin_ref = fin[bi, beam_ref] | ((ref_idx % v) == O.END)
+    assert np.array_equal(o_fin.cpu().numpy()[same].astype(bool), fin_ref[same])
+    assert np.array_equal(o_src.cpu().numpy()[same], (bi * k + beam_ref)[same])
+
+
+def test_beam_exact_ties_take_lower_index(dev):
+    """Equal scores: tf.nn.top_k returns the lower flat index first."""
+    from neuralmonkey_amd import ops
+    b, k, v = 2, 3, 50
+    logits = np.zeros((b * k, v), np.float32)          # uniform -> all candidates tie per beam
+    lps = np.zeros((b, k), np.float32)
+    lens = np.zeros((b, k), np.int32)
+    fin = np.zeros((b, k), np.int32)
+    ld = T(logits, dev)
+    mx, lse = torch.empty(b * k, device=dev), torch.empty(b * k, device=dev)
+    ops.row_stats(ld, mx, lse, None)
+    i32 = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
+    o_sc, o_lps = torch.empty((b, k), device=dev), torch.empty((b, k), device=dev)
+    o_w, o_b, o_len, o_fin, o_src = i32(b, k), i32(b, k), i32(b, k), i32(b, k), i32(b, k)
+    ops.beam_topk_step(ld, b, k, mx, lse, T(lps, dev), T(lens, dev, torch.int32), T(fin, dev, torch.int32),
+                       ops.length_penalty_table(8, 1.0, dev), O.END, o_sc, o_w, o_b, o_lps, o_len,
+                       o_fin, o_src, ops.beam_workspace(b, k, v, dev))
+    assert np.array_equal(o_b.cpu().numpy(), np.zeros((b, k), np.int32))
+    assert np.array_equal(o_w.cpu().numpy(), np.tile(np.arange(k, dtype=np.int32), (b, 1)))
+
+
+def test_gather_and_token_reorder(dev):
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(8)
+    src = rng.standard_normal((15, 512)).astype(np.float32)
+    idx = rng.integers(0, 15, size=15).astype(np.int32)
+    dst = torch.empty((15, 512), device=dev)
+    ops.gather_rows(T(src, dev), T(idx, dev, torch.int32), dst)
+    assert np.array_equal(dst.cpu().numpy(), src[idx])
+    steps = 4
+    tok = rng.integers(0, 99, size=(6, 15)).astype(np.int32)
+    word = rng.integers(0, 99, size=15).astype(np.int32)
+    out = torch.zeros((6, 15), dtype=torch.int32, device=dev)
+    ops.beam_reorder_tokens(T(tok, dev, torch.int32), T(idx, dev, torch.int32), T(word, dev, torch.int32),
+                            out, steps, 15)
+    ref = np.concatenate([tok[:steps][:, idx], word[None]], 0)
+    assert np.array_equal(out.cpu().numpy()[:steps + 1], ref)
