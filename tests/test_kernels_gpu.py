@@ -45,8 +45,10 @@ def test_gemm(dev, m, n, k, ta, tb, algo):
     ref = (a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64)
     out = ops.gemm(T(a, dev), T(b, dev), trans_a=ta, trans_b=tb, algo=algo)
     assert rel_err(out.cpu().numpy(), ref) < 2e-6 * np.sqrt(k) + 1e-6
-    out2 = ops.gemm(T(a, dev), T(b, dev), bias=T(bias, dev), act="tanh", trans_a=ta, trans_b=tb, algo=algo)
-    assert rel_err(out2.cpu().numpy(), np.tanh(ref + bias)) < 1e-5
+    a_s = (a / np.sqrt(k)).astype(np.float32)          # O(1) pre-activations for the tanh epilogue
+    ref_s = (a_s.T if ta else a_s).astype(np.float64) @ (b.T if tb else b).astype(np.float64)
+    out2 = ops.gemm(T(a_s, dev), T(b, dev), bias=T(bias, dev), act="tanh", trans_a=ta, trans_b=tb, algo=algo)
+    assert rel_err(out2.cpu().numpy(), np.tanh(ref_s + bias)) < 1e-5
     c0 = rng.standard_normal((m, n)).astype(np.float32)
     out3 = T(c0, dev)
     ops.gemm(T(a, dev), T(b, dev), out=out3, trans_a=ta, trans_b=tb, accumulate=True, algo=algo)
