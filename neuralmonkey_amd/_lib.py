@@ -23,17 +23,19 @@ SIGNATURES = {
     "nm_version": (I, []),
     "nm_gemm_f32": (I, [P, I, I, L, L, L, P, L, P, L, P, L, P, I, I, L, L, L, L, I]),
     "nm_embedding_gather": (I, [P, P, L, L, P, L, P, L, I, F]),
-    "nm_gru_gates_fwd": (I, [P, P, L, L, L, P, P, P, P, P, I, I, L, L]),
-    "nm_gru_blend_fwd": (I, [P, P, L, L, L, P, P, P, P, P, P, L, L, L, P, I, I, L, L]),
+    "nm_gru_gates_fwd": (I, [P, P, L, L, L, P, P, P, P, P, I, I, I, L, L]),
+    "nm_gru_blend_fwd": (I, [P, P, L, L, L, P, P, P, P, P, P, L, L, L, P, I, I, I, L, L]),
     "nm_layer_norm_fwd": (I, [P, P, L, P, P, P, L, P, P, L, L, F]),
     "nm_copy_cols": (I, [P, P, L, P, L, L, L]),
+    "nm_reduce_sum": (I, [P, P, L, P]),
+    "nm_log_softmax": (I, [P, P, L, P, P, P, L, L, L]),
     "nm_attn_workspace_bytes": (L, [L, L, L]),
     "nm_attn_fwd": (I, [P, P, P, P, P, P, P, L, L, L, L, L, P, L, P, P, L]),
     "nm_row_stats": (I, [P, P, L, L, L, P, P, P]),
     "nm_greedy_update": (I, [P, P, P, P, P, L, I, P]),
     "nm_xent": (I, [P, P, L, L, L, P, P, P, P, I]),
     "nm_beam_workspace_bytes": (L, [L, L, L]),
-    "nm_beam_topk_step": (I, [P, P, L, L, L, L, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, L]),
+    "nm_beam_topk_step": (I, [P, P, L, L, L, L, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, L, P]),
     "nm_gather_rows_f32": (I, [P, P, L, P, P, L, L, L]),
     "nm_beam_reorder_tokens": (I, [P, P, P, P, P, L, L]),
 }

@@ -1,0 +1,112 @@
+"""Bahdanau feed-forward attention (mirror of neuralmonkey/attention/feed_forward.py).
+
+hidden_features = states . Wk          once per batch  (feed_forward.py:105-118)  -> MFMA GEMM
+attention()     = q . Wq + b, then the fused HIP step kernel nm_attn_fwd
+                  (energies, softmax, mask-renorm, context; feed_forward.py:120-166).
+Keys are indexed by ``row // rows_per_key`` so a beam of k hypotheses per
+sentence shares one copy of the keys."""
+from typing import Optional, Tuple
+
+import torch
+
+from .. import ops
+from ..model.model_part import InitializerSpecs, ModelPart
+from ..model.stateful import SpatialStateful, TemporalStateful
+from ..nn.dropout import dropout
+from ..runtime import tensor
+from ..variables import zeros_initializer
+from .base_attention import (Attendable, AttentionLoopState, BaseAttention, get_attention_mask,
+                             get_attention_states)
+
+
+class Attention(BaseAttention):
+    # pylint: disable=too-many-arguments
+    def __init__(self, name: str, encoder: Attendable, dropout_keep_prob: float = 1.0,
+                 state_size: int = None, reuse: ModelPart = None, save_checkpoint: str = None,
+                 load_checkpoint: str = None, initializers: InitializerSpecs = None) -> None:
+        BaseAttention.__init__(self, name, reuse, save_checkpoint, load_checkpoint, initializers)
+        self.encoder = encoder
+        self.dropout_keep_prob = dropout_keep_prob
+        self._state_size = state_size
+        self.rows_per_key = 1         # set by a beam-search decoder for the duration of its run
+
+    @property
+    def context_vector_size(self) -> int:
+        return self.encoder.dimension
+
+    @property
+    def state_size(self) -> int:
+        return self._state_size if self._state_size is not None else self.context_vector_size
+
+    def bind_query_size(self, size: int) -> None:
+        """The reference learns the query size when the decoder first calls
+        ``attention`` (feed_forward.py:130); sizes must be static here."""
+        if self.query_state_size is not None and self.query_state_size != size:
+            raise ValueError("Attention '{}' is queried with two different state sizes ({} vs {})"
+                             .format(self.name, self.query_state_size, size))
+        self.query_state_size = size
+
+    def declare_variables(self, store) -> None:
+        if self.query_state_size is None:
+            raise RuntimeError("Attention '{}' is not attached to a decoder".format(self.name))
+        self.declare(store, "Attention/attn_query_projection", (self.query_state_size, self.state_size))
+        self.declare(store, "attn_key_projection", (self.context_vector_size, self.state_size))
+        self.declare(store, "attn_similarity_v", (self.state_size,))
+        self.declare(store, "attn_projection_bias", (self.state_size,), zeros_initializer())
+        self.declare(store, "attn_bias", (1,), zeros_initializer())      # scalar, kept as [1] on device
+
+    @tensor
+    def attention_states(self, ctx) -> torch.Tensor:
+        return dropout(ctx, get_attention_states(self.encoder, ctx), self.dropout_keep_prob,
+                       ctx.fed(self.train_mode))
+
+    @tensor
+    def attention_mask(self, ctx) -> Optional[torch.Tensor]:
+        return get_attention_mask(self.encoder, ctx)
+
+    @tensor
+    def hidden_features(self, ctx) -> torch.Tensor:
+        """[B,S,A] = states . Wk, no bias (the reference's 1x1 conv)."""
+        states = self.attention_states(ctx)
+        bsz, slen, c = states.shape
+        hf = ctx.buffer((id(self), "hf"), (bsz, slen, self.state_size))
+        ops.gemm(states.reshape(bsz * slen, c), self.var(ctx, "attn_key_projection"),
+                 out=hf.view(bsz * slen, self.state_size))
+        return hf
+
+    def project_query(self, ctx, query: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+        return ops.gemm(query, self.var(ctx, "Attention/attn_query_projection"), out=out,
+                        bias=self.var(ctx, "attn_projection_bias"))
+
+    def attention_into(self, ctx, query: torch.Tensor, y: torch.Tensor, ctx_out: torch.Tensor,
+                       w_out: Optional[torch.Tensor]) -> None:
+        """y = q.Wq + b (kept by the caller for the backward pass), then the fused step kernel."""
+        rows = query.shape[0]
+        states = self.attention_states(ctx)
+        hf = self.hidden_features(ctx)
+        self.project_query(ctx, query, y)
+        ws = ctx.buffer((id(self), "ws", rows), ((ops._lib.load().nm_attn_workspace_bytes(
+            rows, states.shape[1], states.shape[2]) + 3) // 4,))
+        ops.attn_fwd(y, hf, states, self.attention_mask(ctx), self.var(ctx, "attn_similarity_v"),
+                     self.var(ctx, "attn_bias"), self.rows_per_key, ctx_out, w_out, ws)
+
+    def attention(self, ctx, query: torch.Tensor, decoder_prev_state, decoder_input,
+                  loop_state: AttentionLoopState) -> Tuple[torch.Tensor, AttentionLoopState]:
+        rows = query.shape[0]
+        step = loop_state.step
+        y = ctx.buffer((id(self), "y", rows), (rows, self.state_size))
+        self.attention_into(ctx, query, y, loop_state.contexts[step], loop_state.weights[step])
+        return loop_state.contexts[step], AttentionLoopState(loop_state.contexts, loop_state.weights,
+                                                             step + 1)
+
+    def initial_loop_state(self, ctx, rows: int, max_steps: int) -> AttentionLoopState:
+        states = self.attention_states(ctx)
+        self.hidden_features(ctx)        # pre-compute outside the loop (feed_forward.py:168-186)
+        return AttentionLoopState(
+            contexts=ctx.buffer((id(self), "contexts", rows, max_steps),
+                                (max_steps, rows, self.context_vector_size)),
+            weights=ctx.buffer((id(self), "weights", rows, max_steps), (max_steps, rows, states.shape[1])),
+            step=0)
+
+    def finalize_loop(self, key: str, last_loop_state: AttentionLoopState) -> None:
+        self.histories[key] = last_loop_state.weights[:last_loop_state.step]

@@ -60,12 +60,12 @@ extern "C" int nm_embedding_gather(void* stream, const float* table, int64_t V, 
 // (tf.reverse_sequence semantics).  Rows with t >= L[r] are dead: state copied
 // through, outputs left untouched (pre-zeroed by the caller).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ bool gru_pos(const int* lengths, int r, int d, int t, int& pos) {
+__device__ __forceinline__ bool gru_pos(const int* lengths, int r, int d, int t, int rev_mask, int& pos) {
     pos = t;
     if (!lengths) return true;
     const int len = lengths[r];
     if (t >= len) return false;
-    if (d == 1) pos = len - 1 - t;
+    if ((rev_mask >> d) & 1) pos = len - 1 - t;      // tf.reverse_sequence indexing
     return true;
 }
 
@@ -73,13 +73,13 @@ __global__ void gru_gates_fwd_kernel(const float* __restrict__ xp, long x_dir_of
                                      long x_time_stride, const float* __restrict__ hg,
                                      const float* __restrict__ h, float* __restrict__ ru,
                                      float* __restrict__ rh, const int* __restrict__ lengths, int t,
-                                     long R, int H) {
+                                     int rev_mask, long R, int H) {
     const int d = blockIdx.z;
     const long r = blockIdx.y;
     const int j = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (j >= H) return;
     int pos;
-    const bool live = gru_pos(lengths, (int)r, d, t, pos);
+    const bool live = gru_pos(lengths, (int)r, d, t, rev_mask, pos);
     const long ro = ((long)d * R + r);
     float4 rr = make_float4(0, 0, 0, 0), uu = rr, rhv = rr;
     if (live) {
@@ -102,8 +102,8 @@ __global__ void gru_gates_fwd_kernel(const float* __restrict__ xp, long x_dir_of
 
 extern "C" int nm_gru_gates_fwd(void* stream, const float* xp, int64_t x_dir_off, int64_t x_row_stride,
                                 int64_t x_time_stride, const float* hg, const float* h, float* ru,
-                                float* rh, const int32_t* lengths, int t, int ndir, int64_t R,
-                                int64_t H) {
+                                float* rh, const int32_t* lengths, int t, int rev_mask, int ndir,
+                                int64_t R, int64_t H) {
     NM_REQUIRE(xp && hg && h && ru && rh, "nm_gru_gates_fwd: null pointer");
     NM_REQUIRE(H > 0 && H % 4 == 0 && R > 0 && ndir >= 1 && ndir <= 2, "nm_gru_gates_fwd: bad shape");
     NM_REQUIRE(x_dir_off % 4 == 0 && x_row_stride % 4 == 0 && x_time_stride % 4 == 0 &&
@@ -113,7 +113,8 @@ extern "C" int nm_gru_gates_fwd(void* stream, const float* xp, int64_t x_dir_off
     const int tpb = 128;
     dim3 grid(nm_cdiv(H, 4 * tpb), (unsigned)R, ndir);
     hipLaunchKernelGGL(gru_gates_fwd_kernel, grid, dim3(tpb), 0, nm_stream(stream), xp, (long)x_dir_off,
-                       (long)x_row_stride, (long)x_time_stride, hg, h, ru, rh, lengths, t, (long)R, (int)H);
+                       (long)x_row_stride, (long)x_time_stride, hg, h, ru, rh, lengths, t, rev_mask, (long)R,
+                       (int)H);
     NM_LAUNCH_CHECK("nm_gru_gates_fwd");
 }
 
@@ -122,13 +123,14 @@ __global__ void gru_blend_fwd_kernel(const float* __restrict__ xp, long x_dir_of
                                      const float* __restrict__ ru, const float* h_in,
                                      float* h_out, float* __restrict__ c_save, float* __restrict__ out,
                                      long out_dir_off, long out_row_stride, long out_time_stride,
-                                     const int* __restrict__ lengths, int t, long R, int H) {
+                                     const int* __restrict__ lengths, int t, int rev_mask, long R,
+                                     int H) {
     const int d = blockIdx.z;
     const long r = blockIdx.y;
     const int j = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (j >= H) return;
     int pos;
-    const bool live = gru_pos(lengths, (int)r, d, t, pos);
+    const bool live = gru_pos(lengths, (int)r, d, t, rev_mask, pos);
     const long ro = ((long)d * R + r);
     const float4 hv = *reinterpret_cast<const float4*>(h_in + ro * H + j);
     if (!live) {
@@ -156,7 +158,8 @@ extern "C" int nm_gru_blend_fwd(void* stream, const float* xp, int64_t x_dir_off
                                 int64_t x_time_stride, const float* hc, const float* ru,
                                 const float* h_in, float* h_out, float* c_save, float* out,
                                 int64_t out_dir_off, int64_t out_row_stride, int64_t out_time_stride,
-                                const int32_t* lengths, int t, int ndir, int64_t R, int64_t H) {
+                                const int32_t* lengths, int t, int rev_mask, int ndir, int64_t R,
+                                int64_t H) {
     NM_REQUIRE(xp && hc && ru && h_in && h_out, "nm_gru_blend_fwd: null pointer");
     NM_REQUIRE(H > 0 && H % 4 == 0 && R > 0 && ndir >= 1 && ndir <= 2, "nm_gru_blend_fwd: bad shape");
     NM_REQUIRE(x_dir_off % 4 == 0 && x_row_stride % 4 == 0 && x_time_stride % 4 == 0 &&
@@ -167,7 +170,7 @@ extern "C" int nm_gru_blend_fwd(void* stream, const float* xp, int64_t x_dir_off
     hipLaunchKernelGGL(gru_blend_fwd_kernel, grid, dim3(tpb), 0, nm_stream(stream), xp, (long)x_dir_off,
                        (long)x_row_stride, (long)x_time_stride, hc, ru, h_in, h_out, c_save, out,
                        (long)out_dir_off, (long)out_row_stride, (long)out_time_stride, lengths, t,
-                       (long)R, (int)H);
+                       rev_mask, (long)R, (int)H);
     NM_LAUNCH_CHECK("nm_gru_blend_fwd");
 }
 
@@ -240,4 +243,49 @@ extern "C" int nm_copy_cols(void* stream, const float* src, int64_t ld_src, floa
     hipLaunchKernelGGL(copy_cols_kernel, dim3(nm_cdiv(width, 256), (unsigned)rows), dim3(256), 0,
                        nm_stream(stream), src, (long)ld_src, dst, (long)ld_dst, (long)rows, (int)width);
     NM_LAUNCH_CHECK("nm_copy_cols");
+}
+
+// ---------------------------------------------------------------------------
+// deterministic sum of n floats -> out[0] (single block, fixed reduction tree)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void reduce_sum_kernel(const float* __restrict__ x, long n,
+                                                          float* __restrict__ out) {
+    __shared__ float sh[16];
+    float s = 0.0f;
+    for (long i = threadIdx.x; i < n; i += 1024) s += x[i];
+    s = nm_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+        for (int k = 0; k < 16; ++k) t += sh[k];
+        out[0] = t;
+    }
+}
+
+extern "C" int nm_reduce_sum(void* stream, const float* x, int64_t n, float* out) {
+    NM_REQUIRE(x && out && n >= 0, "nm_reduce_sum: bad args");
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(1024), 0, nm_stream(stream), x, (long)n, out);
+    NM_LAUNCH_CHECK("nm_reduce_sum");
+}
+
+// ---------------------------------------------------------------------------
+// log-softmax from row statistics: out = (x - max) - lse   (runtime_logprobs,
+// decoders/autoregressive.py:373-375; only the ensemble path materialises it)
+// ---------------------------------------------------------------------------
+__global__ void log_softmax_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ rmax,
+                                   const float* __restrict__ rlse, float* __restrict__ out, long ldo,
+                                   int V) {
+    const long r = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < V) out[r * ldo + c] = (x[r * ldx + c] - rmax[r]) - rlse[r];
+}
+
+extern "C" int nm_log_softmax(void* stream, const float* x, int64_t ldx, const float* rmax,
+                              const float* rlse, float* out, int64_t ldo, int64_t rows, int64_t V) {
+    NM_REQUIRE(x && rmax && rlse && out && rows >= 0 && V > 0, "nm_log_softmax: bad args");
+    if (rows == 0) return NM_OK;
+    hipLaunchKernelGGL(log_softmax_kernel, dim3(nm_cdiv(V, 256), (unsigned)rows), dim3(256), 0,
+                       nm_stream(stream), x, (long)ldx, rmax, rlse, out, (long)ldo, (int)V);
+    NM_LAUNCH_CHECK("nm_log_softmax");
 }

@@ -301,7 +301,8 @@ __global__ void beam_topk_final(const float* __restrict__ logits, long ldx, int 
                                 int nslice, int B, int end_id, float* __restrict__ out_score,
                                 int* __restrict__ out_word, int* __restrict__ out_beam,
                                 float* __restrict__ out_logprob_sum, int* __restrict__ out_lengths,
-                                int* __restrict__ out_finished, int* __restrict__ out_src_row) {
+                                int* __restrict__ out_finished, int* __restrict__ out_src_row,
+                                int* __restrict__ all_finished) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     float s[K];
@@ -325,8 +326,10 @@ __global__ void beam_topk_final(const float* __restrict__ logits, long ldx, int 
         out_beam[o] = j;
         out_logprob_sum[o] = hyp;
         out_lengths[o] = lengths[r] + 1 - (fin ? 1 : 0);
-        out_finished[o] = fin | (v == end_id);
+        const int nf = fin | (v == end_id);
+        out_finished[o] = nf;
         out_src_row[o] = r;
+        if (all_finished && !nf) atomicAnd(all_finished, 0);
     }
 }
 
@@ -341,7 +344,8 @@ extern "C" int nm_beam_topk_step(void* stream, const float* logits, int64_t ldx,
                                  const int32_t* finished, const float* penalty, int end_id,
                                  float* out_score, int32_t* out_word, int32_t* out_beam,
                                  float* out_logprob_sum, int32_t* out_lengths, int32_t* out_finished,
-                                 int32_t* out_src_row, void* workspace, int64_t workspace_bytes) {
+                                 int32_t* out_src_row, void* workspace, int64_t workspace_bytes,
+                                 int32_t* all_finished) {
     NM_REQUIRE(logits && rmax && rlse && logprob_sum && lengths && finished && penalty && out_score &&
                    out_word && out_beam && out_logprob_sum && out_lengths && out_finished &&
                    out_src_row && workspace,
@@ -365,7 +369,7 @@ extern "C" int nm_beam_topk_step(void* stream, const float* logits, int64_t ldx,
         hipLaunchKernelGGL((beam_topk_final<K_>), dim3(nm_cdiv(B, 64)), dim3(64), 0, st, logits,     \
                            (long)ldx, (int)V, (int)k, rmax, rlse, logprob_sum, lengths, finished,    \
                            penalty, ps, pi, nslice, (int)B, end_id, out_score, out_word, out_beam,   \
-                           out_logprob_sum, out_lengths, out_finished, out_src_row);                 \
+                           out_logprob_sum, out_lengths, out_finished, out_src_row, all_finished);   \
     } while (0)
     if (k <= 4) NM_BK(4);
     else NM_BK(8);

@@ -1,0 +1,148 @@
+"""Minimal dataset layer (subset of neuralmonkey/dataset.py needed by the
+attention-decoder path): named series of token lists, plain-text loading,
+fixed-size and length-bucketed batching.  Host-side only."""
+import glob
+from typing import Any, Callable, Dict, Iterator, List, Optional, Tuple, Union
+
+
+class BatchingScheme:
+    """dataset.py:55-97."""
+
+    def __init__(self, batch_size: int = None, drop_remainder: bool = False,
+                 bucket_boundaries: List[int] = None, bucket_batch_sizes: List[int] = None,
+                 ignore_series: List[str] = None) -> None:
+        self.batch_size = batch_size
+        self.drop_remainder = drop_remainder
+        self.bucket_boundaries = bucket_boundaries
+        self.bucket_batch_sizes = bucket_batch_sizes
+        self.ignore_series = ignore_series or []
+        if (self.batch_size is None) == (self.bucket_boundaries is None):
+            raise ValueError("You must specify either batch_size or bucket_boundaries, not both")
+        if self.bucket_boundaries is not None:
+            if self.bucket_batch_sizes is None:
+                raise ValueError("You must specify bucket_batch_sizes")
+            if len(self.bucket_batch_sizes) != len(self.bucket_boundaries) + 1:
+                raise ValueError("There should be N+1 batch sizes for N bucket boundaries")
+
+
+def plain_text_reader(files: List[str], encoding: str = "utf-8") -> Iterator[List[str]]:
+    for path in files:
+        with open(path, encoding=encoding) as handle:
+            for line in handle:
+                yield line.strip().split()
+
+
+class Dataset:
+    """Named series of equal length; ``batches()`` yields sub-``Dataset``s."""
+
+    def __init__(self, name: str, series: Dict[str, List[Any]], batching: BatchingScheme = None,
+                 outputs: Dict[str, Tuple[str, Any]] = None, shuffled: bool = False) -> None:
+        self.name = name
+        self._series = {k: list(v) for k, v in series.items()}
+        lengths = {len(v) for v in self._series.values()}
+        if len(lengths) > 1:
+            raise ValueError("Series of dataset '{}' differ in length: {}".format(name, lengths))
+        self._length = lengths.pop() if lengths else 0
+        self.batching = batching
+        self.outputs = outputs or {}
+        self.shuffled = shuffled
+
+    def __len__(self) -> int:
+        return self._length
+
+    def __contains__(self, name: str) -> bool:
+        return name in self._series
+
+    @property
+    def series(self) -> List[str]:
+        return list(self._series)
+
+    def get_series(self, name: str) -> Iterator:
+        if name not in self._series:
+            raise KeyError("Series '{}' is not in the dataset".format(name))
+        return iter(self._series[name])
+
+    def maybe_get_series(self, name: str) -> Optional[Iterator]:
+        return iter(self._series[name]) if name in self._series else None
+
+    def subset(self, start: int, length: int) -> "Dataset":
+        return Dataset("{}.{}.{}".format(self.name, start, length),
+                       {k: v[start:start + length] for k, v in self._series.items()},
+                       self.batching, self.outputs)
+
+    def _rows(self, idx: List[int]) -> "Dataset":
+        return Dataset(self.name, {k: [v[i] for i in idx] for k, v in self._series.items()},
+                       self.batching, self.outputs)
+
+    def batches(self, batching: BatchingScheme = None) -> Iterator["Dataset"]:
+        scheme = batching or self.batching
+        if scheme is None:
+            raise ValueError("No batching scheme for dataset '{}'".format(self.name))
+        if scheme.batch_size is not None:
+            for start in range(0, self._length, scheme.batch_size):
+                idx = list(range(start, min(self._length, start + scheme.batch_size)))
+                if len(idx) < scheme.batch_size and scheme.drop_remainder:
+                    break
+                yield self._rows(idx)
+            return
+        bounds = scheme.bucket_boundaries
+        sizes = scheme.bucket_batch_sizes
+        buckets: List[List[int]] = [[] for _ in sizes]
+        keys = [k for k in self._series if k not in scheme.ignore_series]
+        for i in range(self._length):
+            longest = 0
+            for k in keys:
+                item = self._series[k][i]
+                if isinstance(item, (list, tuple)):
+                    longest = max(longest, len(item))
+            b = 0
+            while b < len(bounds) and longest > bounds[b]:
+                b += 1
+            buckets[b].append(i)
+            if len(buckets[b]) == sizes[b]:
+                yield self._rows(buckets[b])
+                buckets[b] = []
+        if not scheme.drop_remainder:
+            for bucket in buckets:
+                if bucket:
+                    yield self._rows(bucket)
+
+
+def _expand(patterns: Union[str, List[str]]) -> List[str]:
+    if isinstance(patterns, str):
+        patterns = [patterns]
+    paths: List[str] = []
+    for pat in patterns:
+        matched = sorted(glob.glob(pat))
+        if not matched:
+            raise FileNotFoundError("Pattern did not match any files: {}".format(pat))
+        paths.extend(matched)
+    return paths
+
+
+def load(name: str, series: List[str], data: List[Any], batching: BatchingScheme = None,
+         outputs: List[Tuple] = None, buffer_size: int = None, shuffled: bool = False) -> Dataset:
+    """dataset.py:207-333 for source series given as files (optionally
+    ``(files, reader)`` tuples); preprocessor series are out of scope."""
+    if len(series) != len(data):
+        raise ValueError("The 'series' and 'data' lists should have the same number of elements: "
+                         "{} vs {}.".format(len(series), len(data)))
+    if len(series) != len(set(series)):
+        raise ValueError("There are duplicate series.")
+    loaded: Dict[str, List[Any]] = {}
+    for sid, spec in zip(series, data):
+        if isinstance(spec, tuple) and callable(spec[-1]) and not isinstance(spec[0], tuple):
+            files, reader = spec[0], spec[1]
+            loaded[sid] = list(reader(_expand(files)))
+        elif isinstance(spec, (str, list)):
+            loaded[sid] = list(plain_text_reader(_expand(spec)))
+        else:
+            raise NotImplementedError("series '{}': preprocessor series are not supported".format(sid))
+    out_specs = {}
+    for spec in outputs or []:
+        out_specs[spec[0]] = (spec[1], spec[2] if len(spec) > 2 else None)
+    return Dataset(name, loaded, batching, out_specs, shuffled)
+
+
+def from_ids(name: str, series: Dict[str, List[List[str]]], batching: BatchingScheme = None) -> Dataset:
+    return Dataset(name, series, batching)

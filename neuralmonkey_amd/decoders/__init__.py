@@ -1,0 +1,2 @@
+from .decoder import Decoder                             # noqa: F401
+from .beam_search_decoder import BeamSearchDecoder       # noqa: F401

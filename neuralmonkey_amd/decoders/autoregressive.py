@@ -1,0 +1,203 @@
+"""Autoregressive decoder base (mirror of neuralmonkey/decoders/autoregressive.py).
+
+What the reference expresses as tf.while_loop over ``LoopState`` namedtuples
+(autoregressive.py:425-562) runs here as an eager loop over pre-allocated
+time-major history buffers; the fetchable surface (``train_loss``,
+``runtime_loss``, ``runtime_logprobs``, ``decoded`` ...) is kept.
+"""
+from typing import Any, Dict, NamedTuple, Optional
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..model.model_part import FeedDict, InitializerSpecs, ModelPart
+from ..model.sequence import EmbeddedSequence, cached_index
+from ..nn.dropout import dropout
+from ..runtime import Placeholder, tensor
+from ..variables import random_uniform_initializer, zeros_initializer
+from ..vocabulary import (END_TOKEN_INDEX, PAD_TOKEN_INDEX, START_TOKEN_INDEX, UNK_TOKEN_INDEX,
+                          Vocabulary, sentence_mask)
+
+
+class LoopState(NamedTuple):
+    """autoregressive.py:28-45."""
+    histories: Any
+    constants: Any
+    feedables: Any
+
+
+class DecoderHistories(NamedTuple):
+    """autoregressive.py:48-79; time-major, rows < ``steps`` valid."""
+    logits: Optional[torch.Tensor]        # [T,R,V] only when a runner asks for it
+    output_states: torch.Tensor           # [T,R,E]
+    output_symbols: torch.Tensor          # [T,R] int32
+    output_mask: torch.Tensor             # [T,R] int32 (1 = not finished after the step)
+    other: Any
+
+
+class DecoderConstants(NamedTuple):
+    train_inputs: Optional[torch.Tensor]
+
+
+class DecoderFeedables(NamedTuple):
+    """autoregressive.py:92-118."""
+    step: int
+    finished: torch.Tensor                # [R] int32
+    embedded_input: torch.Tensor          # [R,E]
+    other: Any
+
+
+# pylint: disable=too-many-instance-attributes
+class AutoregressiveDecoder(ModelPart):
+    # pylint: disable=too-many-arguments
+    def __init__(self, name: str, vocabulary: Vocabulary, data_id: str, max_output_len: int,
+                 dropout_keep_prob: float = 1.0, embedding_size: int = None,
+                 embeddings_source: EmbeddedSequence = None, tie_embeddings: bool = False,
+                 label_smoothing: float = None, supress_unk: bool = False, reuse: ModelPart = None,
+                 save_checkpoint: str = None, load_checkpoint: str = None,
+                 initializers: InitializerSpecs = None) -> None:
+        ModelPart.__init__(self, name, reuse, save_checkpoint, load_checkpoint, initializers)
+        self.vocabulary = vocabulary
+        self.data_id = data_id
+        self.max_output_len = max_output_len
+        self.dropout_keep_prob = dropout_keep_prob
+        self._embedding_size = embedding_size
+        self.embeddings_source = embeddings_source
+        self.label_smoothing = label_smoothing
+        self.tie_embeddings = tie_embeddings
+        self.supress_unk = supress_unk
+        self.encoder_states = lambda: []
+        self.encoder_masks = lambda: []
+        if self.max_output_len <= 0:
+            raise ValueError("Maximum sequence length must be a positive integer.")
+        if self._embedding_size is not None and self._embedding_size <= 0:
+            raise ValueError("Embedding size must be a positive integer.")
+        if self.dropout_keep_prob < 0.0 or self.dropout_keep_prob > 1.0:
+            raise ValueError("Dropout keep probability must be a real number in the interval [0,1].")
+        if label_smoothing:
+            raise NotImplementedError("label_smoothing is not implemented in the HIP engine "
+                                      "(SURVEY section 9: kept out of the first milestone)")
+        self.train_tokens = Placeholder("{}/{}".format(name, data_id))
+
+    # -- static sizes ------------------------------------------------------------
+    @property
+    def embedding_size(self) -> int:
+        if self.embeddings_source is None:
+            if self._embedding_size is None:
+                raise ValueError("You must specify either embedding size or the embedded sequence "
+                                 "from which to reuse the embeddings (e.g. set 'embedding_size' or "
+                                 "'embeddings_source' parameter)")
+            return self._embedding_size
+        return self.embeddings_source.embedding_sizes[0]
+
+    @property
+    def output_dimension(self) -> int:
+        raise NotImplementedError("Abstract property")
+
+    @property
+    def input_types(self) -> Dict[str, type]:
+        return {self.data_id: str}
+
+    # -- variables -----------------------------------------------------------------
+    def declare_variables(self, store) -> None:
+        if self.embeddings_source is None:
+            self.declare(store, "word_embeddings", (len(self.vocabulary), self.embedding_size))
+        if self.tie_embeddings:
+            if self.embedding_size != self.output_dimension:
+                raise ValueError("`embedding_size must be equal to the output_projection size when "
+                                 "using the `tie_embeddings` option")
+        else:
+            self.declare(store, "state_to_word_W", (self.output_dimension, len(self.vocabulary)),
+                         random_uniform_initializer(-0.5, 0.5))
+            self.declare(store, "state_to_word_b", (len(self.vocabulary),), zeros_initializer())
+
+    def embedding_matrix(self, ctx) -> torch.Tensor:
+        if self.embeddings_source is not None:
+            return self.embeddings_source.embedding_matrix(ctx)
+        return self.var(ctx, "word_embeddings")
+
+    @property
+    def embedding_matrix_name(self) -> str:
+        if self.embeddings_source is not None:
+            return self.embeddings_source.embedding_matrix_name
+        return self.var_name("word_embeddings")
+
+    def decoding_bias(self, ctx) -> Optional[torch.Tensor]:
+        """state_to_word_b, with -1e9 on <unk> when ``supress_unk`` (autoregressive.py:450-459)."""
+        if self.tie_embeddings:
+            b = ctx.buffer((id(self), "zero_b"), (len(self.vocabulary),), zero=True)
+        else:
+            b = self.var(ctx, "state_to_word_b")
+        if not self.supress_unk:
+            return b
+        key = (id(self), "unk_b")
+        if key not in ctx.memo:
+            beff = ctx.buffer(key, (len(self.vocabulary),))
+            beff.copy_(b)
+            beff[UNK_TOKEN_INDEX] -= 1e9
+            ctx.memo[key] = beff
+        return ctx.memo[key]
+
+    def state_to_logits(self, ctx, state: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        """logits = state . W + b as one MFMA GEMM."""
+        bias = self.decoding_bias(ctx)
+        if self.tie_embeddings:
+            return ops.gemm(state, self.embedding_matrix(ctx), out=out, bias=bias, trans_b=True)
+        return ops.gemm(state, self.var(ctx, "state_to_word_W"), out=out, bias=bias)
+
+    def embed_input_symbols(self, ctx, symbols: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+        emb = ops.embedding_gather(self.embedding_matrix(ctx), symbols, out=out)
+        return dropout(ctx, emb, self.dropout_keep_prob, ctx.fed(self.train_mode))
+
+    # -- fed data ---------------------------------------------------------------------
+    def has_targets(self, ctx) -> bool:
+        return ctx.is_fed(self.train_tokens)
+
+    @tensor
+    def train_inputs(self, ctx) -> torch.Tensor:
+        """Target ids, time-major [T,B] (autoregressive.py:216-219)."""
+        return ctx.session.to_device(ctx.fed(self.train_tokens), torch.int32, "tgt_tb",
+                                     lambda ids: np.ascontiguousarray(ids.T))
+
+    @tensor
+    def train_mask(self, ctx) -> torch.Tensor:
+        return ctx.session.to_device(ctx.fed(self.train_tokens), torch.float32, "tgt_mask_tb",
+                                     lambda ids: np.ascontiguousarray(sentence_mask(ids).T))
+
+    def train_token_count(self, ctx) -> float:
+        return float(sentence_mask(ctx.fed(self.train_tokens)).sum())
+
+    def feed_dict(self, dataset, train: bool = False) -> FeedDict:
+        fd = ModelPart.feed_dict(self, dataset, train)
+        sentences = dataset.maybe_get_series(self.data_id)
+        if sentences is None and train:
+            raise ValueError("When training, you must feed reference sentences")
+        if sentences is not None:
+            fd[self.train_tokens] = cached_index(dataset, self.data_id, self.vocabulary,
+                                                 self.max_output_len, False, True)
+        return fd
+
+    # -- fetchable surface (the reference's @tensor names) --------------------------------
+    @tensor
+    def train_loop_result(self, ctx):
+        return self.decoding_loop(ctx, train_mode=True)
+
+    @tensor
+    def runtime_loop_result(self, ctx):
+        return self.decoding_loop(ctx, train_mode=False)
+
+    @tensor
+    def train_loss(self, ctx):
+        raise NotImplementedError("Abstract")
+
+    @tensor
+    def runtime_loss(self, ctx):
+        raise NotImplementedError("Abstract")
+
+    @property
+    def cost(self):
+        return self.train_loss
+
+    def decoding_loop(self, ctx, train_mode: bool, sample: bool = False, temperature: float = 1.0):
+        raise NotImplementedError("Abstract method")

@@ -1,0 +1,182 @@
+"""In-graph-equivalent beam search (mirror of
+neuralmonkey/decoders/beam_search_decoder.py).
+
+Per step (body, beam_search_decoder.py:394-556):
+  masked log-probs -> + logprob_sum -> / length penalty -> top-k over [B, k*V]
+  -> div/mod -> gather search state -> reorder parent state & token history
+  -> embed the chosen words -> parent decoder step -> new log-probs.
+Everything up to the gathers is the fused HIP kernel pair behind
+``nm_beam_topk_step`` reading the parent's raw logits plus their (max, lse)
+row statistics, so the [B,k,V] log-softmax tensor is never materialised.
+
+The reference cannot tile Bahdanau keys to the beam and therefore runs RNN
+beam search at batch 1 only.  Here hypothesis row r reads the
+keys of sentence r // k, which is the same arithmetic for batch 1 and lifts
+the restriction for any batch.
+"""
+from typing import Any, List, NamedTuple, Optional
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..model.model_part import ModelPart
+from ..runtime import Placeholder, tensor
+from ..vocabulary import END_TOKEN_INDEX, PAD_TOKEN_INDEX, START_TOKEN_INDEX, Vocabulary
+from .autoregressive import AutoregressiveDecoder, DecoderFeedables, LoopState
+from .decoder import CHECK_EVERY
+
+INF = 1e9
+
+
+class SearchState(NamedTuple):
+    """beam_search_decoder.py:45-70."""
+    logprob_sum: torch.Tensor        # [B,k]
+    prev_logprobs: Optional[torch.Tensor]   # [B,k,V]; materialised only for ensembles
+    lengths: torch.Tensor            # [B,k] int32
+    finished: torch.Tensor           # [B,k] int32 (0/1)
+
+
+class SearchResults(NamedTuple):
+    """beam_search_decoder.py:73-89."""
+    scores: torch.Tensor             # [B,k]
+    token_ids: torch.Tensor          # [steps+1,B,k]
+
+
+class BeamSearchLoopState(NamedTuple):
+    search_state: SearchState
+    search_results: SearchResults
+    decoder_loop_state: Any
+
+
+class BeamSearchOutput(NamedTuple):
+    """beam_search_decoder.py:112-126."""
+    last_search_step_output: SearchResults
+    last_dec_loop_state: Any
+    last_search_state: SearchState
+    attention_loop_states: List[Any]
+
+
+class BeamSearchDecoder(ModelPart):
+    def __init__(self, name: str, parent_decoder: AutoregressiveDecoder, beam_size: int, max_steps: int,
+                 length_normalization: float) -> None:
+        ModelPart.__init__(self, name)
+        self.parent_decoder = parent_decoder
+        self.beam_size = beam_size
+        self.length_normalization = length_normalization
+        self.max_steps_int = max_steps
+        self.max_steps = Placeholder("{}/max_steps".format(name), default=max_steps)
+        if beam_size < 1 or beam_size > 8:
+            raise ValueError("beam_size must be between 1 and 8 for the HIP top-k kernel, was {}"
+                             .format(beam_size))
+        if not hasattr(parent_decoder, "full_step"):
+            raise NotImplementedError("BeamSearchDecoder: the HIP engine supports the RNN Decoder "
+                                      "as parent for now")
+
+    @property
+    def vocabulary(self) -> Vocabulary:
+        return self.parent_decoder.vocabulary
+
+    def _length_penalty_table(self, ctx, max_len: int) -> torch.Tensor:
+        key = (id(self), "penalty", max_len)
+        if key not in ctx.session.__dict__.setdefault("_const", {}):
+            ctx.session._const[key] = ops.length_penalty_table(max_len, self.length_normalization,
+                                                               ctx.device)
+        return ctx.session._const[key]
+
+    def expand_index(self, ctx, bsz: int) -> torch.Tensor:
+        """expand_to_beam (beam_search_decoder.py:575-596) as a row index: r -> r // k."""
+        key = (id(self), "expand", bsz)
+        if key not in ctx.session.__dict__.setdefault("_const", {}):
+            idx = (np.arange(bsz * self.beam_size) // self.beam_size).astype(np.int32)
+            ctx.session._const[key] = torch.from_numpy(idx).to(ctx.device)
+        return ctx.session._const[key]
+
+    @tensor
+    def outputs(self, ctx) -> BeamSearchOutput:
+        dec = self.parent_decoder
+        for att in dec.attentions:
+            att.rows_per_key = self.beam_size
+        try:
+            return self._search(ctx)
+        finally:
+            for att in dec.attentions:
+                att.rows_per_key = 1
+
+    def _search(self, ctx) -> BeamSearchOutput:
+        dec = self.parent_decoder
+        k = self.beam_size
+        bsz = int(ctx.fed(dec.batch_size))
+        rows = bsz * k
+        e, h, v = dec.embedding_size, dec.rnn_size, len(self.vocabulary)
+        max_steps = int(ctx.fed(self.max_steps))
+        key = (id(self), "bs", bsz)
+        f32 = lambda name, shape, **kw: ctx.buffer(key + (name,), shape, torch.float32, **kw)
+        i32 = lambda name, shape, **kw: ctx.buffer(key + (name,), shape, torch.int32, **kw)
+
+        cell = dec._cell(ctx)
+        bufs = dec._step_bufs(ctx, rows)
+        hbuf = f32("h", (2, rows, h))                     # ping-pong decoder state
+        hsel = f32("hsel", (rows, h))                     # state gathered to the chosen beams
+        emb = f32("emb", (rows, e))
+        out_state = f32("out", (rows, dec.output_dimension))
+        logits = f32("logits", (rows, v))
+        rmax, rlse = f32("rmax", (rows,)), f32("rlse", (rows,))
+        argmax = i32("argmax", (rows,))
+        tok = i32("tok", (2, max_steps + 1, rows))        # ping-pong token history [steps+1, B*k]
+        lps = f32("lps", (2, bsz, k))
+        lens = i32("lens", (2, bsz, k))
+        fin = i32("fin", (2, bsz, k))
+        scores = f32("scores", (bsz, k), zero=True)
+        word, beam, src = i32("word", (bsz, k)), i32("beam", (bsz, k)), i32("src", (bsz, k))
+        allfin = i32("allfin", (max(max_steps, 1),))
+        allfin.fill_(1)
+        ws = ctx.buffer(key + ("ws",), ((ops._lib.load().nm_beam_workspace_bytes(bsz, k, v) + 3) // 4,))
+        penalty = self._length_penalty_table(ctx, max_steps + 2)
+        att_states = [a.initial_loop_state(ctx, rows, max_steps + 1) for a in dec.attentions]
+
+        # ---- get_initial_loop_state (:218-328): tile, run the parent body once
+        ops.gather_rows(dec.initial_state(ctx), self.expand_index(ctx, bsz), hsel)
+        go = i32("go", (rows,))
+        go.fill_(START_TOKEN_INDEX)
+        dec.embed_input_symbols(ctx, go, out=emb)
+        att_states = dec.full_step(ctx, cell, emb, hsel, hbuf[0], att_states, out_state, logits, bufs)
+        ops.row_stats(logits, rmax, rlse, argmax)
+        tok[0, 0].copy_(argmax)                           # parent's greedy symbol, dropped by the runner
+        lps[0].fill_(-INF)
+        lps[0, :, 0] = 0.0
+        lens[0].zero_()
+        fin[0].zero_()
+        cur = 0
+        steps = 0                                         # executed beam bodies
+        # ---- loop (:330-355 criterion, :394-556 body)
+        while steps < max_steps:
+            nxt = cur ^ 1
+            ops.beam_topk_step(logits, bsz, k, rmax, rlse, lps[cur], lens[cur], fin[cur], penalty,
+                               END_TOKEN_INDEX, scores, word, beam, lps[nxt], lens[nxt], fin[nxt], src, ws,
+                               allfin[steps:steps + 1])
+            srcf, wordf = src.view(rows), word.view(rows)
+            ops.gather_rows(hbuf[cur], srcf, hsel)                               # :503-532
+            ops.beam_reorder_tokens(tok[cur], srcf, wordf, tok[nxt], steps + 1, rows)   # :546-551
+            dec.embed_input_symbols(ctx, wordf, out=emb)                         # :507-510
+            att_states = dec.full_step(ctx, cell, emb, hsel, hbuf[nxt], att_states, out_state, logits,
+                                       bufs)                                     # :534-535
+            ops.row_stats(logits, rmax, rlse, None)                              # :537-543
+            cur = nxt
+            steps += 1
+            if steps % CHECK_EVERY == 0 or steps == max_steps:
+                done = np.nonzero(allfin[:steps].cpu().numpy())[0]
+                if done.size:
+                    true_steps = int(done[0]) + 1
+                    # bodies past ``true_steps`` leave the (all finished) search state unchanged
+                    # and only append <pad> rows, which are cropped here
+                    steps_run, steps = steps, true_steps
+                    break
+        token_ids = tok[cur, :steps + 1].view(steps + 1, bsz, k)
+        prev_logprobs = None
+        search_state = SearchState(lps[cur], prev_logprobs, lens[cur], fin[cur])
+        results = SearchResults(scores, token_ids)
+        feedables = DecoderFeedables(step=steps + 1, finished=fin[cur].view(rows), embedded_input=emb,
+                                     other=None)
+        dec_ls = LoopState(histories=None, constants=None, feedables=feedables)
+        return BeamSearchOutput(results, dec_ls, search_state, [])

@@ -1,0 +1,400 @@
+"""RNN attention decoder (mirror of neuralmonkey/decoders/decoder.py).
+
+One step (Decoder.next_state, decoder.py:279-358):
+    cell_output = GRU(rnn_input = embedded_input, prev_rnn_output)
+    ctx         = attention(query = cell_output)
+    output      = output_projection([cell_output, embedded_input, ctx])
+and logits = output . W + b (autoregressive.py:450-459).
+
+Training (teacher forcing): nothing but the GRU state feeds back, so the
+embedding gather, the input half of the GRU, the output projection, the
+logits GEMM and the cross entropy are hoisted out of the time loop and run
+over all T*B rows as large MFMA GEMMs; the loop keeps two skinny recurrent
+GEMMs + fused epilogues + the fused attention kernel per step.
+Greedy / beam decoding feed the argmax back, so every step runs the full chain.
+"""
+from typing import Any, List, NamedTuple, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..attention.base_attention import AttentionLoopState, BaseAttention
+from ..model.model_part import InitializerSpecs, ModelPart
+from ..model.sequence import EmbeddedSequence
+from ..model.stateful import Stateful
+from ..nn.dropout import dropout
+from ..runtime import tensor
+from ..variables import constant_initializer, orthogonal_initializer, zeros_initializer
+from ..vocabulary import END_TOKEN_INDEX, START_TOKEN_INDEX, Vocabulary, sentence_mask
+from .autoregressive import (AutoregressiveDecoder, DecoderConstants, DecoderFeedables,
+                             DecoderHistories, LoopState)
+from .encoder_projection import (EncoderProjection, concat_encoder_projection, empty_initial_state,
+                                 linear_encoder_projection)
+from .output_projection import OutputProjection, OutputProjectionSpec, nonlinear_output
+
+RNN_CELL_TYPES = ("NematusGRU", "GRU", "LSTM")
+CHECK_EVERY = 8       # greedy / beam: host looks at the finished flags every N steps
+
+
+class RNNFeedables(NamedTuple):
+    """decoder.py:34-50."""
+    prev_rnn_state: torch.Tensor
+    prev_rnn_output: torch.Tensor
+    prev_contexts: List[torch.Tensor]
+
+
+class RNNHistories(NamedTuple):
+    """decoder.py:53-66."""
+    rnn_outputs: torch.Tensor            # [T,R,H]
+    attention_histories: List[Any]
+
+
+class TrainResult(NamedTuple):
+    loss_sum: torch.Tensor               # device scalar: sum of masked token xents
+    token_count: float
+    steps: int
+    saved: dict                          # activations for the backward pass
+
+
+class RuntimeResult(NamedTuple):
+    symbols: torch.Tensor                # [T,B] int32
+    mask: torch.Tensor                   # [T,B] int32
+    steps: int
+    xent_sum: Optional[torch.Tensor]     # device scalar over t < min(T_run, T_target)
+    logits: Optional[torch.Tensor]       # [T,B,V] when requested
+    output_states: torch.Tensor          # [T,B,E]
+    rnn_outputs: torch.Tensor            # [T,B,H]
+    attention_weights: List[torch.Tensor]
+
+
+# pylint: disable=too-many-instance-attributes
+class Decoder(AutoregressiveDecoder):
+    # pylint: disable=too-many-arguments,too-many-locals
+    def __init__(self, encoders: List[Stateful], vocabulary: Vocabulary, data_id: str, name: str,
+                 max_output_len: int, dropout_keep_prob: float = 1.0, embedding_size: int = None,
+                 embeddings_source: EmbeddedSequence = None, tie_embeddings: bool = False,
+                 label_smoothing: float = None, rnn_size: int = None,
+                 output_projection: OutputProjectionSpec = None,
+                 encoder_projection: EncoderProjection = None,
+                 attentions: List[BaseAttention] = None, attention_on_input: bool = False,
+                 rnn_cell: str = "GRU", conditional_gru: bool = False, supress_unk: bool = False,
+                 reuse: ModelPart = None, save_checkpoint: str = None, load_checkpoint: str = None,
+                 initializers: InitializerSpecs = None) -> None:
+        AutoregressiveDecoder.__init__(
+            self, name=name, vocabulary=vocabulary, data_id=data_id, max_output_len=max_output_len,
+            dropout_keep_prob=dropout_keep_prob, embedding_size=embedding_size,
+            embeddings_source=embeddings_source, tie_embeddings=tie_embeddings,
+            label_smoothing=label_smoothing, supress_unk=supress_unk, reuse=reuse,
+            save_checkpoint=save_checkpoint, load_checkpoint=load_checkpoint, initializers=initializers)
+        self.encoders = encoders
+        self._output_projection_spec = output_projection
+        self._conditional_gru = conditional_gru
+        self._attention_on_input = attention_on_input
+        self._rnn_cell_str = rnn_cell
+        self._rnn_size = rnn_size
+        self._encoder_projection = encoder_projection
+        self.attentions: List[BaseAttention] = attentions if attentions is not None else []
+        if not rnn_size and not encoder_projection and not encoders:
+            raise ValueError("No RNN size, no encoders and no encoder_projection specified")
+        if self._rnn_cell_str not in RNN_CELL_TYPES:
+            raise ValueError("RNN cell must be a either 'GRU', 'LSTM', or 'NematusGRU'. Not {}"
+                             .format(self._rnn_cell_str))
+        if self._rnn_cell_str != "GRU" or conditional_gru or attention_on_input:
+            raise NotImplementedError(
+                "Decoder '{}': the HIP engine currently implements rnn_cell='GRU' without "
+                "conditional_gru / attention_on_input".format(name))
+        for att in self.attentions:
+            att.bind_query_size(self.rnn_size)
+        if self.embedding_size != self.output_dimension:
+            raise ValueError("The dimension ({}) of the output projection must be same as the "
+                             "dimension of the input embedding ({})"
+                             .format(self.output_dimension, self.embedding_size))
+
+    # -- configuration-derived pieces (decoder.py:176-224) --------------------------------
+    @property
+    def encoder_projection(self) -> EncoderProjection:
+        if not hasattr(self, "_enc_proj_cached"):
+            if self._encoder_projection is not None:
+                proj = self._encoder_projection
+            elif not self.encoders:
+                proj = empty_initial_state
+            elif self._rnn_size is None:
+                proj = concat_encoder_projection
+            else:
+                proj = linear_encoder_projection(self.dropout_keep_prob)
+            self._enc_proj_cached = proj
+        return self._enc_proj_cached
+
+    @property
+    def rnn_size(self) -> int:
+        if self._rnn_size is not None:
+            return self._rnn_size
+        if self._encoder_projection is None:
+            assert self.encoders
+            return sum(e.output_size for e in self.encoders)
+        raise ValueError("Cannot infer RNN size.")
+
+    @property
+    def output_projection_spec(self) -> Tuple[OutputProjection, int]:
+        if not hasattr(self, "_out_proj_cached"):
+            spec = self._output_projection_spec
+            if spec is None:
+                spec = (nonlinear_output(self.rnn_size)[0], self.rnn_size)
+            elif not isinstance(spec, tuple):
+                spec = (spec, self.rnn_size)
+            self._out_proj_cached = spec
+        return self._out_proj_cached
+
+    @property
+    def output_projection(self) -> OutputProjection:
+        return self.output_projection_spec[0]
+
+    @property
+    def output_dimension(self) -> int:
+        return self.output_projection_spec[1]
+
+    def declare_variables(self, store) -> None:
+        AutoregressiveDecoder.declare_variables(self, store)
+        e, h = self.embedding_size, self.rnn_size
+        self.encoder_projection.declare_variables(self, store, self.rnn_size, self.encoders)
+        pre = "attention_decoder/OrthoGRUCell"
+        self.declare(store, pre + "/gates/kernel", (e + h, 2 * h), orthogonal_initializer())
+        self.declare(store, pre + "/gates/bias", (2 * h,), constant_initializer(1.0))
+        self.declare(store, pre + "/candidate/kernel", (e + h, h), orthogonal_initializer())
+        self.declare(store, pre + "/candidate/bias", (h,), zeros_initializer())
+        self.output_projection.declare_variables(
+            self, store, h, e, [a.context_vector_size for a in self.attentions])
+
+    def _cell(self, ctx):
+        pre = "attention_decoder/OrthoGRUCell"
+        e = self.embedding_size
+        wg, wc = self.var(ctx, pre + "/gates/kernel"), self.var(ctx, pre + "/candidate/kernel")
+        return {"wg_x": wg[:e], "wg_h": wg[e:], "bg": self.var(ctx, pre + "/gates/bias"),
+                "wc_x": wc[:e], "wc_h": wc[e:], "bc": self.var(ctx, pre + "/candidate/bias")}
+
+    # -- pieces of one step -------------------------------------------------------------
+    @tensor
+    def initial_state(self, ctx) -> torch.Tensor:
+        """decoder.py:226-252 (the double dropout is the identity at keep_prob 1)."""
+        bsz = int(ctx.fed(self.batch_size))
+        out = ctx.buffer((id(self), "s0"), (bsz, self.rnn_size))
+        train = bool(ctx.fed(self.train_mode))
+        state = self.encoder_projection.apply(ctx, self, self.rnn_size, self.encoders, out, train)
+        return dropout(ctx, state, self.dropout_keep_prob, train)
+
+    def _input_projection(self, ctx, cell, emb, xp):
+        """xp[:, :2H] = emb.Wg_x + bg ; xp[:, 2H:] = emb.Wc_x + bc  (input half of the GRU)."""
+        h = self.rnn_size
+        ops.gemm(emb, cell["wg_x"], out=xp[:, :2 * h], bias=cell["bg"])
+        ops.gemm(emb, cell["wc_x"], out=xp[:, 2 * h:], bias=cell["bc"])
+
+    def _recurrent(self, ctx, cell, xp, t_index, x_time_stride, h_prev, h_out, ru, c_save, bufs):
+        """State half of the GRU + fused epilogues: h_out = GRU(x_t, h_prev)."""
+        h = self.rnn_size
+        rows = h_prev.shape[0]
+        ops.gemm(h_prev, cell["wg_h"], out=bufs["hg"])
+        ops.gru_gates_fwd(xp, 0, 3 * h, x_time_stride, bufs["hg"], h_prev, ru, bufs["rh"], None,
+                          t_index, 1, rows, h)
+        ops.gemm(bufs["rh"], cell["wc_h"], out=bufs["hc"])
+        ops.gru_blend_fwd(xp, 0, 3 * h, x_time_stride, bufs["hc"], ru, h_prev, h_out, c_save, None,
+                          0, 0, 0, None, t_index, 1, rows, h)
+
+    def _step_bufs(self, ctx, rows):
+        h = self.rnn_size
+        key = (id(self), "step", rows)
+        return {"hg": ctx.buffer(key + ("hg",), (rows, 2 * h)), "hc": ctx.buffer(key + ("hc",), (rows, h)),
+                "rh": ctx.buffer(key + ("rh",), (rows, h)), "ru": ctx.buffer(key + ("ru",), (rows, 2 * h)),
+                "xp": ctx.buffer(key + ("xp",), (rows, 3 * h))}
+
+    def full_step(self, ctx, cell, emb_in, h_prev, h_out, att_states, out_state, logits, bufs):
+        """One inference step on R rows: GRU -> attention(s) -> projection -> logits.
+        Returns the new attention loop states."""
+        self._input_projection(ctx, cell, emb_in, bufs["xp"])
+        self._recurrent(ctx, cell, bufs["xp"], 0, 0, h_prev, h_out, bufs["ru"], None, bufs)
+        contexts, new_states = [], []
+        for att, st in zip(self.attentions, att_states):
+            c, ns = att.attention(ctx, h_out, h_prev, emb_in, st)
+            contexts.append(c)
+            new_states.append(ns)
+        self.output_projection.apply(ctx, self, h_out, emb_in, contexts, out_state)
+        self.state_to_logits(ctx, out_state, logits)
+        return new_states
+
+    # -- training path ---------------------------------------------------------------------
+    def _dec_input_ids(self, ctx) -> torch.Tensor:
+        """Step inputs: <s> then the shifted targets (autoregressive.py:377-382,467-480)."""
+        def shift(ids):
+            tb = np.ascontiguousarray(ids.T)
+            out = np.empty_like(tb)
+            out[0] = START_TOKEN_INDEX
+            out[1:] = tb[:-1]
+            return out
+        return ctx.session.to_device(ctx.fed(self.train_tokens), torch.int32, "dec_in_tb", shift)
+
+    def decoding_loop(self, ctx, train_mode: bool, sample: bool = False, temperature: float = 1.0):
+        if sample or temperature != 1.0:
+            raise NotImplementedError("sampling / temperature are not implemented in the HIP engine")
+        return self._train_loop(ctx) if train_mode else self._runtime_loop(ctx, keep_logits=False)
+
+    def _train_loop(self, ctx, want_grad: bool = False, grad_scale: Optional[torch.Tensor] = None) -> TrainResult:
+        key = (id(self), "train")
+        tgt = self.train_inputs(ctx)                        # [T,B]
+        tmask = self.train_mask(ctx)
+        steps, bsz = tgt.shape
+        e, h, v = self.embedding_size, self.rnn_size, len(self.vocabulary)
+        cell = self._cell(ctx)
+        rows = steps * bsz
+
+        emb_all = ctx.buffer(key + ("emb",), (steps, bsz, e))
+        self.embed_input_symbols(ctx, self._dec_input_ids(ctx).reshape(-1), out=emb_all.view(rows, e))
+        xp = ctx.buffer(key + ("xp",), (rows, 3 * h))
+        self._input_projection(ctx, cell, emb_all.view(rows, e), xp)
+
+        s0 = self.initial_state(ctx)
+        s_all = ctx.buffer(key + ("s_all",), (steps, bsz, h))
+        ru_all = ctx.buffer(key + ("ru_all",), (steps, bsz, 2 * h))
+        c_all = ctx.buffer(key + ("c_all",), (steps, bsz, h))
+        bufs = self._step_bufs(ctx, bsz)
+        att_states = [a.initial_loop_state(ctx, bsz, steps) for a in self.attentions]
+        y_all = [ctx.buffer(key + ("y", i), (steps, bsz, a.state_size)) for i, a in enumerate(self.attentions)]
+        for t in range(steps):
+            h_prev = s0 if t == 0 else s_all[t - 1]
+            self._recurrent(ctx, cell, xp, t, bsz * 3 * h, h_prev, s_all[t], ru_all[t], c_all[t], bufs)
+            for i, att in enumerate(self.attentions):
+                att.attention_into(ctx, s_all[t], y_all[i][t], att_states[i].contexts[t],
+                                   att_states[i].weights[t])
+        att_states = [AttentionLoopState(st.contexts, st.weights, steps) for st in att_states]
+
+        out_all = ctx.buffer(key + ("out",), (rows, self.output_dimension))
+        self.output_projection.apply(ctx, self, s_all.view(rows, h), emb_all.view(rows, e),
+                                     [st.contexts.view(rows, -1) for st in att_states], out_all)
+        logits = ctx.buffer(key + ("logits",), (rows, v))
+        self.state_to_logits(ctx, out_all, logits)
+        loss_rows = ctx.buffer(key + ("loss_rows",), (rows,))
+        ops.xent(logits, tgt.reshape(-1), tmask.reshape(-1), loss_rows, grad_scale, want_grad)
+        loss_sum = ctx.buffer(key + ("loss_sum",), (1,))
+        ops.reduce_sum(loss_rows, loss_sum)
+        for att, st in zip(self.attentions, att_states):
+            att.finalize_loop("{}_train".format(self.name), st)
+        saved = {"emb_all": emb_all, "xp": xp, "s0": s0, "s_all": s_all, "ru_all": ru_all,
+                 "c_all": c_all, "y_all": y_all, "att_states": att_states, "out_all": out_all,
+                 "dlogits": logits if want_grad else None, "cell": cell, "steps": steps, "bsz": bsz}
+        return TrainResult(loss_sum, self.train_token_count(ctx), steps, saved)
+
+    @tensor
+    def train_loss(self, ctx) -> torch.Tensor:
+        """sum(xent)/sum(mask) (autoregressive.py:312-316)."""
+        res = self.train_loop_result(ctx)
+        return res.loss_sum[0] / res.token_count
+
+    # -- greedy runtime path -------------------------------------------------------------------
+    def _runtime_loop(self, ctx, keep_logits: bool) -> RuntimeResult:
+        key = (id(self), "run", keep_logits)
+        bsz = int(ctx.fed(self.batch_size))
+        e, h, v = self.embedding_size, self.rnn_size, len(self.vocabulary)
+        tmax = self.max_output_len
+        cell = self._cell(ctx)
+        dev = ctx.device
+        has_tgt = self.has_targets(ctx)
+        if has_tgt:
+            tgt, tmask = self.train_inputs(ctx), self.train_mask(ctx)
+            t_target = tgt.shape[0]
+
+        s0 = self.initial_state(ctx)
+        s_all = ctx.buffer(key + ("s_all",), (tmax, bsz, h))
+        out_all = ctx.buffer(key + ("out_all",), (tmax, bsz, self.output_dimension))
+        symbols = ctx.buffer(key + ("sym",), (tmax, bsz), torch.int32, zero=True)
+        omask = ctx.buffer(key + ("mask",), (tmax, bsz), torch.int32, zero=True)
+        finished = ctx.buffer(key + ("fin",), (bsz,), torch.int32, zero=True)
+        allfin = ctx.buffer(key + ("allfin",), (tmax,), torch.int32)
+        allfin.fill_(1)
+        argmax = ctx.buffer(key + ("argmax",), (bsz,), torch.int32)
+        logits_all = ctx.buffer(key + ("logits_all",), (tmax, bsz, v)) if keep_logits else None
+        logits_one = ctx.buffer(key + ("logits",), (bsz, v))
+        xent_rows = ctx.buffer(key + ("xent_rows",), (tmax, bsz), zero=True) if has_tgt else None
+        emb = ctx.buffer(key + ("emb",), (2, bsz, e))
+        bufs = self._step_bufs(ctx, bsz)
+        att_states = [a.initial_loop_state(ctx, bsz, tmax) for a in self.attentions]
+
+        go = ctx.buffer(key + ("go",), (bsz,), torch.int32)
+        go.fill_(START_TOKEN_INDEX)
+        self.embed_input_symbols(ctx, go, out=emb[0])
+        steps = 0
+        while steps < tmax:
+            t = steps
+            logits = logits_all[t] if keep_logits else logits_one
+            att_states = self.full_step(ctx, cell, emb[t & 1], s0 if t == 0 else s_all[t - 1], s_all[t],
+                                        att_states, out_all[t], logits, bufs)
+            ops.row_stats(logits, None, None, argmax)
+            if has_tgt and t < t_target:
+                ops.xent(logits, tgt[t], tmask[t], xent_rows[t])
+            ops.greedy_update(argmax, finished, symbols[t], omask[t], END_TOKEN_INDEX, allfin[t:t + 1])
+            self.embed_input_symbols(ctx, symbols[t], out=emb[(t + 1) & 1])
+            steps += 1
+            if steps % CHECK_EVERY == 0 or steps == tmax:
+                flags = allfin[:steps].cpu().numpy()
+                done = np.nonzero(flags)[0]
+                if done.size:                      # loop ends after the first all-finished step
+                    steps = int(done[0]) + 1
+                    break
+        xent_sum = None
+        if has_tgt:
+            xent_sum = ctx.buffer(key + ("xent_sum",), (1,))
+            ops.reduce_sum(xent_rows[:min(steps, t_target)].reshape(-1), xent_sum)
+        att_states = [AttentionLoopState(st.contexts, st.weights, steps) for st in att_states]
+        for att, st in zip(self.attentions, att_states):
+            att.finalize_loop("{}_run".format(self.name), st)
+        return RuntimeResult(symbols[:steps], omask[:steps], steps, xent_sum,
+                             logits_all[:steps] if keep_logits else None, out_all[:steps], s_all[:steps],
+                             [st.weights[:steps] for st in att_states])
+
+    @tensor
+    def runtime_loss(self, ctx):
+        """sum(runtime xent over the cropped time) / sum(runtime_mask) (autoregressive.py:351-371)."""
+        res = self.runtime_loop_result(ctx)
+        if res.xent_sum is None:
+            return 0.0
+        return res.xent_sum[0] / res.mask.sum().to(torch.float32)
+
+    @tensor
+    def decoded_symbols(self, ctx) -> torch.Tensor:
+        """[T,B] argmax symbols of the runtime loop (what GreedyRunner's host
+        argmax over ``runtime_logprobs`` yields for a single session)."""
+        return self.runtime_loop_result(ctx).symbols
+
+    @tensor
+    def runtime_mask(self, ctx) -> torch.Tensor:
+        return self.runtime_loop_result(ctx).mask
+
+    @tensor
+    def runtime_logits(self, ctx) -> torch.Tensor:
+        key = (id(self), "runtime_full")
+        if key not in ctx.memo:
+            ctx.memo[key] = self._runtime_loop(ctx, keep_logits=True)
+        return ctx.memo[key].logits
+
+    @tensor
+    def runtime_logprobs(self, ctx) -> torch.Tensor:
+        """[T,B,V] log-softmax of the runtime logits (ensembling path of GreedyRunner)."""
+        logits = self.runtime_logits(ctx)
+        t, b, v = logits.shape
+        mx = ctx.buffer((id(self), "lp_max"), (t * b,))
+        lse = ctx.buffer((id(self), "lp_lse"), (t * b,))
+        ops.row_stats(logits.view(t * b, v), mx, lse, None)
+        out = ctx.buffer((id(self), "logprobs"), (t, b, v))
+        ops.log_softmax_from_stats(logits.view(t * b, v), mx, lse, out.view(t * b, v))
+        return out
+
+    @tensor
+    def runtime_output_states(self, ctx) -> torch.Tensor:
+        return self.runtime_loop_result(ctx).output_states
+
+    @tensor
+    def train_logits(self, ctx) -> torch.Tensor:
+        res = self.train_loop_result(ctx)
+        if res.saved["dlogits"] is not None:
+            raise RuntimeError("train_logits were overwritten by their gradient in this run")
+        steps, bsz = res.saved["steps"], res.saved["bsz"]
+        return ctx.buffer((id(self), "train", "logits"), (steps * bsz, len(self.vocabulary))) \
+            .view(steps, bsz, -1)

@@ -1,0 +1,95 @@
+"""Initial-state projections (mirror of neuralmonkey/decoders/encoder_projection.py)."""
+from typing import List
+
+import torch
+
+from .. import ops
+from ..model.stateful import Stateful
+from ..nn.dropout import dropout
+from ..variables import zeros_initializer
+
+
+class EncoderProjection:
+    def output_size(self, rnn_size, encoders) -> int:
+        raise NotImplementedError
+
+    def declare_variables(self, decoder, store, rnn_size, encoders) -> None:
+        pass
+
+    def apply(self, ctx, decoder, rnn_size, encoders, out, train_mode):
+        raise NotImplementedError
+
+
+class _Empty(EncoderProjection):
+    """empty_initial_state (encoder_projection.py:37-44): zeros, tiled to the batch."""
+
+    def output_size(self, rnn_size, encoders):
+        if rnn_size is None:
+            raise ValueError("You must supply rnn_size for this type of encoder projection")
+        return rnn_size
+
+    def apply(self, ctx, decoder, rnn_size, encoders, out, train_mode):
+        out.zero_()
+        return out
+
+
+class _Concat(EncoderProjection):
+    """concat_encoder_projection (encoder_projection.py:76-96)."""
+
+    def output_size(self, rnn_size, encoders):
+        if not encoders:
+            raise ValueError("There must be at least one encoder for this type of encoder projection")
+        total = sum(e.output_size for e in encoders)
+        if rnn_size is not None and rnn_size != total:
+            raise ValueError("RNN size supplied for concat projection ({}) does not match the size of "
+                             "the concatenated vectors ({}).".format(rnn_size, total))
+        return total
+
+    def apply(self, ctx, decoder, rnn_size, encoders, out, train_mode):
+        col = 0
+        for enc in encoders:
+            val = enc.output(ctx)
+            ops.copy_cols(val, out[:, col:col + val.shape[1]])
+            col += val.shape[1]
+        return out
+
+
+class _Linear(EncoderProjection):
+    """linear_encoder_projection (encoder_projection.py:47-73):
+    dropout(dense(concat(encoder outputs), rnn_size, name="encoders_projection"))."""
+
+    def __init__(self, dropout_keep_prob: float):
+        self.dropout_keep_prob = dropout_keep_prob
+
+    def output_size(self, rnn_size, encoders):
+        if rnn_size is None:
+            raise ValueError("You must supply rnn_size for this type of encoder projection")
+        return rnn_size
+
+    def declare_variables(self, decoder, store, rnn_size, encoders):
+        total = sum(e.output_size for e in encoders)
+        decoder.declare(store, "initial_state/encoders_projection/kernel", (total, rnn_size))
+        decoder.declare(store, "initial_state/encoders_projection/bias", (rnn_size,), zeros_initializer())
+
+    def apply(self, ctx, decoder, rnn_size, encoders, out, train_mode):
+        w = decoder.var(ctx, "initial_state/encoders_projection/kernel")
+        b = decoder.var(ctx, "initial_state/encoders_projection/bias")
+        row = 0
+        for i, enc in enumerate(encoders):
+            val = enc.output(ctx)
+            last = i == len(encoders) - 1
+            ops.gemm(val, w[row:row + val.shape[1]], out=out, accumulate=i > 0, bias=b if last else None)
+            row += val.shape[1]
+        return dropout(ctx, out, self.dropout_keep_prob, train_mode)
+
+
+empty_initial_state = _Empty()
+concat_encoder_projection = _Concat()
+
+
+def linear_encoder_projection(dropout_keep_prob: float) -> EncoderProjection:
+    return _Linear(dropout_keep_prob)
+
+
+def nematus_projection(dropout_keep_prob: float = 1.0) -> EncoderProjection:
+    raise NotImplementedError("nematus_projection is not implemented in the HIP engine yet")

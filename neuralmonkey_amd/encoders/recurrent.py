@@ -1,0 +1,245 @@
+"""Recurrent sentence encoder (mirror of neuralmonkey/encoders/recurrent.py).
+
+RecurrentEncoder.rnn (recurrent.py:179-217) = dropout(input) -> [LN] -> rnn_layer
+-> dropout -> (residual) -> final layer_norm on states and final state.
+rnn_layer (recurrent.py:71-110) = tf.nn.(bidirectional_)dynamic_rnn with
+sequence_length masking and reverse_sequence for the backward direction.
+
+MI355X mapping: the input half of both GRU kernels is hoisted out of the time
+loop into MFMA GEMMs over all B*S positions; the loop runs the two recurrent
+GEMMs (both directions batched in one launch) with fused gate / blend
+epilogue kernels that implement the length masking and the reversed indexing
+of the backward direction in-kernel, so there is no reverse_sequence copy.
+"""
+from typing import Callable, List, NamedTuple, Tuple, Union
+
+import torch
+
+from .. import ops
+from ..model.model_part import InitializerSpecs, ModelPart
+from ..model.sequence import EmbeddedSequence
+from ..model.stateful import TemporalStateful, TemporalStatefulWithOutput
+from ..nn.dropout import dropout
+from ..runtime import tensor
+from ..variables import ones_initializer, orthogonal_initializer, zeros_initializer, constant_initializer
+from ..vocabulary import Vocabulary
+
+RNN_CELL_TYPES = ("NematusGRU", "GRU", "LSTM")
+RNN_DIRECTIONS = ["forward", "backward", "bidirectional"]
+
+RNNSpecTuple = Union[Tuple[int], Tuple[int, str], Tuple[int, str, str]]
+
+
+class RNNSpec(NamedTuple):
+    size: int
+    direction: str
+    cell_type: str
+
+
+def _make_rnn_spec(size: int, direction: str = "bidirectional", cell_type: str = "GRU") -> RNNSpec:
+    """recurrent.py:42-63."""
+    if size <= 0:
+        raise ValueError("RNN size must be a positive integer. {} given.".format(size))
+    if direction not in RNN_DIRECTIONS:
+        raise ValueError("RNN direction must be one of {}. {} given.".format(str(RNN_DIRECTIONS), direction))
+    if cell_type not in RNN_CELL_TYPES:
+        raise ValueError("RNN cell type must be one of {}. {} given.".format(str(RNN_CELL_TYPES), cell_type))
+    return RNNSpec(size, direction, cell_type)
+
+
+class EncoderActivations(NamedTuple):
+    states: torch.Tensor        # [B,S,C] (after the final layer norm)
+    final: torch.Tensor         # [B,C]
+    saved: dict                 # activations kept for the backward pass
+
+
+class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
+    # pylint: disable=too-many-arguments
+    def __init__(self, name: str, input_sequence: TemporalStateful, rnn_layers: List[RNNSpecTuple],
+                 add_residual: bool = False, add_layer_norm: bool = False,
+                 include_final_layer_norm: bool = True, dropout_keep_prob: float = 1.0,
+                 reuse: ModelPart = None, save_checkpoint: str = None, load_checkpoint: str = None,
+                 initializers: InitializerSpecs = None) -> None:
+        ModelPart.__init__(self, name, reuse, save_checkpoint, load_checkpoint, initializers)
+        self.input_sequence = input_sequence
+        self.dropout_keep_prob = dropout_keep_prob
+        self.rnn_specs = [_make_rnn_spec(*r) for r in rnn_layers]
+        self.add_residual = add_residual
+        self.add_layer_norm = add_layer_norm
+        self.include_final_layer_norm = include_final_layer_norm
+        if self.dropout_keep_prob <= 0.0 or self.dropout_keep_prob > 1.0:
+            raise ValueError("Dropout keep prob must be inside (0,1].")
+        layer_sizes = [2 * l.size if l.direction == "bidirectional" else l.size for l in self.rnn_specs]
+        if add_residual and len(set(layer_sizes)) > 1:
+            raise ValueError("When using residual connectiong, all layers must have the same size, "
+                             "but are {}.".format(layer_sizes))
+        self._layer_sizes = layer_sizes
+        # MI355X engine scope this round: one GRU layer (the translation.ini shape).
+        if len(self.rnn_specs) != 1 or self.rnn_specs[0].cell_type != "GRU":
+            raise NotImplementedError(
+                "RecurrentEncoder '{}': the HIP engine currently implements a single GRU layer "
+                "(forward / backward / bidirectional); got {}".format(name, self.rnn_specs))
+        if add_layer_norm or add_residual:
+            raise NotImplementedError("add_layer_norm / add_residual are not implemented in the HIP engine yet")
+
+    # -- static sizes ------------------------------------------------------------
+    @property
+    def dimension(self) -> int:
+        return self._layer_sizes[-1]
+
+    @property
+    def output_size(self) -> int:
+        return self._layer_sizes[-1]
+
+    def _dirs(self, spec: RNNSpec) -> List[str]:
+        if spec.direction == "bidirectional":
+            return ["bidirectional_rnn/fw", "bidirectional_rnn/bw"]
+        return ["rnn"]
+
+    def declare_variables(self, store) -> None:
+        d_in = self.input_sequence.dimension
+        for i, spec in enumerate(self.rnn_specs):
+            h = spec.size
+            for d in self._dirs(spec):
+                pre = "rnn_{}_{}/{}/OrthoGRUCell".format(i, spec.direction, d)
+                self.declare(store, pre + "/gates/kernel", (d_in + h, 2 * h), orthogonal_initializer())
+                self.declare(store, pre + "/gates/bias", (2 * h,), constant_initializer(1.0))
+                self.declare(store, pre + "/candidate/kernel", (d_in + h, h), orthogonal_initializer())
+                self.declare(store, pre + "/candidate/bias", (h,), zeros_initializer())
+            d_in = self._layer_sizes[i]
+        if self.include_final_layer_norm:
+            self.declare(store, "LayerNorm/gamma", (self._layer_sizes[-1],), ones_initializer())
+            self.declare(store, "LayerNorm/beta", (self._layer_sizes[-1],), zeros_initializer())
+
+    # -- weight views for the kernels -----------------------------------------------
+    def _cell_views(self, ctx, layer: int):
+        spec = self.rnn_specs[layer]
+        store = ctx.store
+        views = []
+        for d in self._dirs(spec):
+            pre = "rnn_{}_{}/{}/OrthoGRUCell".format(layer, spec.direction, d)
+            views.append({k: self.var(ctx, pre + k) for k in
+                          ("/gates/kernel", "/gates/bias", "/candidate/kernel", "/candidate/bias")})
+            views[-1]["off_g"] = store.offset(self.var_name(pre + "/gates/kernel"))
+            views[-1]["off_c"] = store.offset(self.var_name(pre + "/candidate/kernel"))
+        return views
+
+    @tensor
+    def rnn_input(self, ctx) -> torch.Tensor:
+        return dropout(ctx, self.input_sequence.temporal_states(ctx), self.dropout_keep_prob,
+                       ctx.fed(self.train_mode))
+
+    @tensor
+    def rnn(self, ctx) -> EncoderActivations:
+        """One (bi)directional GRU layer + final layer norm."""
+        x = self.rnn_input(ctx)                                     # [B,S,E]
+        lengths = self.input_sequence.lengths(ctx)                  # int32 [B]
+        spec = self.rnn_specs[0]
+        bsz, slen, e = x.shape
+        h = spec.size
+        cells = self._cell_views(ctx, 0)
+        ndir = len(cells)
+        c_out = ndir * h
+        key = id(self)
+        theta = ctx.store.theta
+
+        # ---- hoisted input projection: xp[b,s, d*3H : (d+1)*3H] = x.[Wg_x | Wc_x] + [bg | bc]
+        xp = ctx.buffer((key, "xp"), (bsz * slen, ndir * 3 * h))
+        x2 = x.view(bsz * slen, e)
+        for d, cv in enumerate(cells):
+            ops.gemm(x2, cv["/gates/kernel"][:e], out=xp[:, d * 3 * h:d * 3 * h + 2 * h],
+                     bias=cv["/gates/bias"])
+            ops.gemm(x2, cv["/candidate/kernel"][:e], out=xp[:, d * 3 * h + 2 * h:(d + 1) * 3 * h],
+                     bias=cv["/candidate/bias"])
+
+        # ---- recurrent weights of both directions as one strided batch
+        def dir_batch(off_key, ncols):
+            base = cells[0][off_key] + e * ncols
+            stride = (cells[1][off_key] - cells[0][off_key]) if ndir == 2 else 0
+            return theta.as_strided((ndir, h, ncols), (stride, ncols, 1), base)
+        wgh = dir_batch("off_g", 2 * h)
+        wch = dir_batch("off_c", h)
+
+        train = bool(ctx.fed(self.train_mode))
+        states_raw = ctx.buffer((key, "states_raw"), (bsz, slen, c_out), zero=True)
+        hcur = ctx.buffer((key, "hcur"), (ndir, bsz, h), zero=True)
+        hg = ctx.buffer((key, "hg"), (ndir, bsz, 2 * h))
+        hc = ctx.buffer((key, "hc"), (ndir, bsz, h))
+        rh = ctx.buffer((key, "rh"), (ndir, bsz, h))
+        if train:       # keep per-step gates / candidates for the backward pass
+            ru_all = ctx.buffer((key, "ru_all"), (slen, ndir, bsz, 2 * h))
+            c_all = ctx.buffer((key, "c_all"), (slen, ndir, bsz, h))
+        else:
+            ru_all = ctx.buffer((key, "ru_one"), (1, ndir, bsz, 2 * h))
+            c_all = None
+        reverse_only = spec.direction == "backward"
+        len_arg = lengths
+        xrs, xts = slen * ndir * 3 * h, ndir * 3 * h
+        ors, ots = slen * c_out, c_out
+        for t in range(slen):
+            ru = ru_all[t] if train else ru_all[0]
+            ops.gemm(hcur, wgh, out=hg)
+            ops.gru_gates_fwd(xp, 3 * h, xrs, xts, hg, hcur, ru, rh, len_arg, t, ndir, bsz, h,
+                              reverse_dir0=reverse_only)
+            ops.gemm(rh, wch, out=hc)
+            ops.gru_blend_fwd(xp, 3 * h, xrs, xts, hc, ru, hcur, hcur, c_all[t] if train else None,
+                              states_raw, h, ors, ots, len_arg, t, ndir, bsz, h,
+                              reverse_dir0=reverse_only)
+        final_raw = ctx.buffer((key, "final_raw"), (bsz, c_out))
+        for d in range(ndir):
+            ops.copy_cols(hcur[d], final_raw[:, d * h:(d + 1) * h])
+
+        saved = {"x": x, "xp": xp, "ru_all": ru_all, "c_all": c_all, "states_raw": states_raw,
+                 "final_raw": final_raw, "lengths": lengths, "wgh": wgh, "wch": wch, "cells": cells,
+                 "ndir": ndir, "h": h, "reverse_only": reverse_only}
+        if not self.include_final_layer_norm:
+            return EncoderActivations(states_raw, final_raw, saved)
+        gamma, beta = self.var(ctx, "LayerNorm/gamma"), self.var(ctx, "LayerNorm/beta")
+        states = ctx.buffer((key, "states"), (bsz, slen, c_out))
+        final = ctx.buffer((key, "final"), (bsz, c_out))
+        st_mean = ctx.buffer((key, "st_mean"), (bsz * slen,))
+        st_rstd = ctx.buffer((key, "st_rstd"), (bsz * slen,))
+        fi_mean = ctx.buffer((key, "fi_mean"), (bsz,))
+        fi_rstd = ctx.buffer((key, "fi_rstd"), (bsz,))
+        ops.layer_norm_fwd(states_raw, gamma, beta, out=states, mean=st_mean, rstd=st_rstd)
+        ops.layer_norm_fwd(final_raw, gamma, beta, out=final, mean=fi_mean, rstd=fi_rstd)
+        saved.update(st_mean=st_mean, st_rstd=st_rstd, fi_mean=fi_mean, fi_rstd=fi_rstd)
+        return EncoderActivations(states, final, saved)
+
+    @tensor
+    def temporal_states(self, ctx) -> torch.Tensor:
+        return self.rnn(ctx).states
+
+    @tensor
+    def temporal_mask(self, ctx) -> torch.Tensor:
+        return self.input_sequence.temporal_mask(ctx)
+
+    @tensor
+    def output(self, ctx) -> torch.Tensor:
+        return self.rnn(ctx).final
+
+
+class SentenceEncoder(RecurrentEncoder):
+    # pylint: disable=too-many-arguments,too-many-locals
+    def __init__(self, name: str, vocabulary: Vocabulary, data_id: str, embedding_size: int,
+                 rnn_size: int, rnn_cell: str = "GRU", rnn_direction: str = "bidirectional",
+                 add_residual: bool = False, add_layer_norm: bool = False, max_input_len: int = None,
+                 dropout_keep_prob: float = 1.0, reuse: ModelPart = None, save_checkpoint: str = None,
+                 load_checkpoint: str = None, initializers: InitializerSpecs = None,
+                 embedding_initializer: Callable = None) -> None:
+        """recurrent.py:236-314: an EmbeddedSequence named ``<name>_input`` feeding one RNN layer."""
+        s_ckp = "input_{}".format(save_checkpoint) if save_checkpoint else None
+        l_ckp = "input_{}".format(load_checkpoint) if load_checkpoint else None
+        input_initializers = []
+        if embedding_initializer is not None:
+            input_initializers.append(("embedding_matrix_0", embedding_initializer))
+        self.data_id = data_id
+        input_sequence = EmbeddedSequence(
+            name="{}_input".format(name), vocabulary=vocabulary, data_id=data_id,
+            embedding_size=embedding_size, max_length=max_input_len, save_checkpoint=s_ckp,
+            load_checkpoint=l_ckp, initializers=input_initializers)
+        RecurrentEncoder.__init__(
+            self, name=name, input_sequence=input_sequence,
+            rnn_layers=[(rnn_size, rnn_direction, rnn_cell)], add_residual=add_residual,
+            add_layer_norm=add_layer_norm, dropout_keep_prob=dropout_keep_prob, reuse=reuse,
+            save_checkpoint=save_checkpoint, load_checkpoint=load_checkpoint, initializers=initializers)

@@ -76,20 +76,29 @@ def embedding_gather(table, ids, out=None, mask_pad=False, scale=1.0):
     return out
 
 
-def gru_gates_fwd(xp, x_dir_off, x_row_stride, x_time_stride, hg, h, ru, rh, lengths, t, ndir, rows, hsz):
+def _rev_mask(ndir, reverse_dir0):
+    """bit d set -> direction d walks its sequence backwards (reverse_sequence)."""
+    return 1 if reverse_dir0 else (2 if ndir == 2 else 0)
+
+
+def gru_gates_fwd(xp, x_dir_off, x_row_stride, x_time_stride, hg, h, ru, rh, lengths, t, ndir, rows, hsz,
+                  reverse_dir0=False):
     lib = _lib.load()
     _lib.check(lib.nm_gru_gates_fwd(_stream(), xp.data_ptr(), x_dir_off, x_row_stride, x_time_stride,
                                     hg.data_ptr(), h.data_ptr(), ru.data_ptr(), rh.data_ptr(),
-                                    _p(lengths), t, ndir, rows, hsz), "nm_gru_gates_fwd")
+                                    _p(lengths), t, _rev_mask(ndir, reverse_dir0), ndir, rows, hsz),
+               "nm_gru_gates_fwd")
 
 
 def gru_blend_fwd(xp, x_dir_off, x_row_stride, x_time_stride, hc, ru, h_in, h_out, c_save, out,
-                  out_dir_off, out_row_stride, out_time_stride, lengths, t, ndir, rows, hsz):
+                  out_dir_off, out_row_stride, out_time_stride, lengths, t, ndir, rows, hsz,
+                  reverse_dir0=False):
     lib = _lib.load()
     _lib.check(lib.nm_gru_blend_fwd(_stream(), xp.data_ptr(), x_dir_off, x_row_stride, x_time_stride,
                                     hc.data_ptr(), ru.data_ptr(), h_in.data_ptr(), h_out.data_ptr(),
                                     _p(c_save), _p(out), out_dir_off, out_row_stride, out_time_stride,
-                                    _p(lengths), t, ndir, rows, hsz), "nm_gru_blend_fwd")
+                                    _p(lengths), t, _rev_mask(ndir, reverse_dir0), ndir, rows, hsz),
+               "nm_gru_blend_fwd")
 
 
 def layer_norm_fwd(x, gamma, beta, out=None, mean=None, rstd=None, eps=1e-6):
@@ -111,6 +120,21 @@ def copy_cols(src, dst):
     assert src.dim() == 2 and dst.dim() == 2 and src.stride(1) == 1 and dst.stride(1) == 1
     _lib.check(lib.nm_copy_cols(_stream(), src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0),
                                 src.shape[0], src.shape[1]), "nm_copy_cols")
+
+
+def reduce_sum(x, out):
+    lib = _lib.load()
+    assert x.is_contiguous()
+    _lib.check(lib.nm_reduce_sum(_stream(), x.data_ptr(), x.numel(), out.data_ptr()), "nm_reduce_sum")
+    return out
+
+
+def log_softmax_from_stats(x, rmax, rlse, out):
+    lib = _lib.load()
+    assert x.dim() == 2 and out.dim() == 2 and x.stride(1) == 1 and out.stride(1) == 1
+    _lib.check(lib.nm_log_softmax(_stream(), x.data_ptr(), x.stride(0), rmax.data_ptr(), rlse.data_ptr(),
+                                  out.data_ptr(), out.stride(0), x.shape[0], x.shape[1]), "nm_log_softmax")
+    return out
 
 
 def attn_workspace(rows, s, c, device):
@@ -161,7 +185,7 @@ def beam_workspace(b, k, v, device):
 
 def beam_topk_step(logits, b, k, rmax, rlse, logprob_sum, lengths, finished, penalty, end_id,
                    out_score, out_word, out_beam, out_logprob_sum, out_lengths, out_finished,
-                   out_src_row, workspace):
+                   out_src_row, workspace, all_finished=None):
     lib = _lib.load()
     assert logits.dim() == 2 and logits.stride(1) == 1 and logits.shape[0] == b * k
     _lib.check(lib.nm_beam_topk_step(_stream(), logits.data_ptr(), logits.stride(0), b, k,
@@ -171,7 +195,8 @@ def beam_topk_step(logits, b, k, rmax, rlse, logprob_sum, lengths, finished, pen
                                      out_word.data_ptr(), out_beam.data_ptr(),
                                      out_logprob_sum.data_ptr(), out_lengths.data_ptr(),
                                      out_finished.data_ptr(), out_src_row.data_ptr(),
-                                     workspace.data_ptr(), workspace.numel() * 4), "nm_beam_topk_step")
+                                     workspace.data_ptr(), workspace.numel() * 4, _p(all_finished)),
+               "nm_beam_topk_step")
 
 
 def gather_rows(src, idx, dst):

@@ -1,0 +1,2 @@
+from .runner import GreedyRunner                                                # noqa: F401
+from .beamsearch_runner import BeamSearchRunner, beam_search_runner_range       # noqa: F401

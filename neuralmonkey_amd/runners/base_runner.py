@@ -1,0 +1,110 @@
+"""Graph-executor protocol (mirror of neuralmonkey/runners/base_runner.py).
+
+``GraphExecutor.get_executable`` -> ``Executable.next_to_execute()`` returns
+``(fetches, [feed_dict per session])``; the manager evaluates the fetches and
+hands one result dict per session to ``collect_results`` until ``result`` is
+set.  Fetches are ``runtime.Fetch`` handles instead of tf.Tensors."""
+from typing import Any, Dict, Generic, List, NamedTuple, Optional, Set, Tuple, TypeVar, Union
+
+import numpy as np
+
+from ..model.model_part import Feedable, GenericModelPart, Parameterized
+
+FeedDict = Dict[Any, Any]
+NextExecute = Tuple[Union[Dict, List], List[FeedDict]]
+MP = TypeVar("MP", bound=GenericModelPart)
+OutputSeries = Union[List, np.ndarray]
+
+
+class ExecutionResult(NamedTuple):
+    """base_runner.py:21-39."""
+    outputs: Dict[str, OutputSeries]
+    losses: Dict[str, float]
+    size: int
+    summaries: List[Any]
+
+
+class GraphExecutor(GenericModelPart):
+    class Executable:
+        def __init__(self, executor: "GraphExecutor", compute_losses: bool, summaries: bool,
+                     num_sessions: int) -> None:
+            self._executor = executor
+            self.compute_losses = compute_losses
+            self.summaries = summaries
+            self.num_sessions = num_sessions
+            self._result: Optional[ExecutionResult] = None
+
+        def set_result(self, outputs: Dict[str, OutputSeries], losses: Dict[str, float], size: int,
+                       summaries: List[Any]) -> None:
+            self._result = ExecutionResult(outputs, losses, size, summaries)
+
+        @property
+        def result(self) -> Optional[ExecutionResult]:
+            return self._result
+
+        @property
+        def executor(self):
+            return self._executor
+
+        def next_to_execute(self) -> NextExecute:
+            return self.executor.fetches, []
+
+        def collect_results(self, results: List[Dict]) -> None:
+            raise NotImplementedError
+
+    def __init__(self, dependencies: Set[GenericModelPart]) -> None:
+        self._dependencies = dependencies
+        self._feedables, self._parameterizeds = self.get_dependencies()
+
+    def get_executable(self, compute_losses: bool, summaries: bool, num_sessions: int):
+        return self.Executable(self, compute_losses, summaries, num_sessions)
+
+    @property
+    def fetches(self) -> Dict[str, Any]:
+        raise NotImplementedError()
+
+    @property
+    def dependencies(self) -> List[str]:
+        return ["_dependencies"]
+
+    @property
+    def feedables(self) -> Set[Feedable]:
+        return self._feedables
+
+    @property
+    def parameterizeds(self) -> Set[Parameterized]:
+        return self._parameterizeds
+
+
+class BaseRunner(GraphExecutor, Generic[MP]):
+    class Executable(GraphExecutor.Executable):
+        def next_to_execute(self) -> NextExecute:
+            fetches = dict(self.executor.fetches)
+            if not self.compute_losses:
+                for loss in self.executor.loss_names:
+                    fetches[loss] = 0.0
+            return fetches, []
+
+        def set_runner_result(self, outputs: OutputSeries, losses: List[float], size: int = None,
+                              summaries: List[Any] = None) -> None:
+            if summaries is None:
+                summaries = []
+            if size is None:
+                size = len(outputs)
+            loss_names = ["{}/{}".format(self.executor.output_series, loss)
+                          for loss in self.executor.loss_names]
+            self.set_result({self.executor.output_series: outputs}, dict(zip(loss_names, losses)), size,
+                            summaries)
+
+    def __init__(self, output_series: str, decoder: MP) -> None:
+        GraphExecutor.__init__(self, {decoder})
+        self.output_series = output_series
+        self.decoder = decoder
+
+    @property
+    def decoder_data_id(self) -> Optional[str]:
+        return getattr(self.decoder, "data_id", None)
+
+    @property
+    def loss_names(self) -> List[str]:
+        raise NotImplementedError()

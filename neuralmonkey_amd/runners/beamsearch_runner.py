@@ -1,0 +1,80 @@
+"""BeamSearchRunner (mirror of neuralmonkey/runners/beamsearch_runner.py).
+
+Single session: the whole search runs on the device in one ``Session.run``.
+Multi-session ensembling (beamsearch_runner.py:38-82: one Session.run per
+step per model, log-mean of the step distributions on the host) is a "next"
+row and refuses loudly."""
+from typing import Any, Callable, Dict, List
+
+import numpy as np
+
+from ..decoders.beam_search_decoder import BeamSearchDecoder
+from ..vocabulary import END_TOKEN_INDEX
+from .base_runner import BaseRunner, NextExecute
+
+
+class BeamSearchRunner(BaseRunner):
+    class Executable(BaseRunner.Executable):
+        def __init__(self, executor: "BeamSearchRunner", compute_losses: bool, summaries: bool,
+                     num_sessions: int) -> None:
+            super().__init__(executor, compute_losses, summaries, num_sessions)
+            self.rank = executor.rank
+            self.decoder = executor.decoder
+            self.postprocess = executor.postprocess
+            if num_sessions > 1:
+                raise NotImplementedError(
+                    "beam-search ensembling over several sessions is not implemented in the HIP "
+                    "engine yet (SURVEY 8f.4)")
+
+        def next_to_execute(self) -> NextExecute:
+            return {"bs_outputs": self.decoder.outputs}, [{}]
+
+        def collect_results(self, results: List[Dict]) -> None:
+            self.prepare_results(results[0]["bs_outputs"].last_search_step_output)
+
+        def prepare_results(self, output) -> None:
+            """beamsearch_runner.py:84-106: hypothesis ``rank``, first token
+            dropped, cut at </s>; loss = mean(score) * batch."""
+            bs_scores = [s[self.rank - 1] for s in output.scores]
+            tok_ids = np.transpose(output.token_ids, [1, 2, 0])
+            decoded_tokens = []
+            for toks in tok_ids:
+                sent = []
+                for tok_id in toks[self.rank - 1][1:]:
+                    if tok_id == END_TOKEN_INDEX:
+                        break
+                    sent.append(self.decoder.vocabulary.index_to_word[int(tok_id)])
+                decoded_tokens.append(sent)
+            if self.postprocess is not None:
+                decoded_tokens = self.postprocess(decoded_tokens)
+            self.set_runner_result(outputs=decoded_tokens,
+                                   losses=[float(np.mean(bs_scores) * len(bs_scores))])
+
+    def __init__(self, output_series: str, decoder: BeamSearchDecoder, rank: int = 1,
+                 postprocess: Callable[[List[str]], List[str]] = None) -> None:
+        super().__init__(output_series, decoder)
+        if rank < 1 or rank > decoder.beam_size:
+            raise ValueError("Rank of output hypothesis must be between 1 and the beam size ({}), "
+                             "was {}.".format(decoder.beam_size, rank))
+        self.rank = rank
+        self.postprocess = postprocess
+
+    @property
+    def fetches(self) -> Dict[str, Any]:
+        return {"bs_outputs": self.decoder.outputs}
+
+    @property
+    def loss_names(self) -> List[str]:
+        return ["beam_search_score"]
+
+
+def beam_search_runner_range(output_series: str, decoder: BeamSearchDecoder, max_rank: int = None,
+                             postprocess: Callable[[List[str]], List[str]] = None) -> List[BeamSearchRunner]:
+    """beamsearch_runner.py:154-190."""
+    if max_rank is None:
+        max_rank = decoder.beam_size
+    if max_rank > decoder.beam_size:
+        raise ValueError("The maximum rank ({}) cannot be bigger than beam size {}."
+                         .format(max_rank, decoder.beam_size))
+    return [BeamSearchRunner("{}.rank{:03d}".format(output_series, r), decoder, r, postprocess)
+            for r in range(1, max_rank + 1)]

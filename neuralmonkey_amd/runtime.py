@@ -1,0 +1,166 @@
+"""Eager replacement of the TF-1 graph/session machinery.
+
+The reference builds a lazy TF graph through ``@tensor`` properties
+(decorators.py:9-27) and evaluates fetches with ``Session.run``
+(tf_manager.py:158-185).  Here a ``@tensor`` property returns a ``Fetch``
+handle; ``Session.run(fetches, feed_dict)`` evaluates the handles eagerly,
+memoised per run, launching libnmhip kernels on the device.  The call shape
+(fetch dictionaries in, numpy structures out) is unchanged.
+"""
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+
+_REGISTRY: List[Any] = []          # every Parameterized part, in creation order
+
+
+def register_part(part) -> None:
+    _REGISTRY.append(part)
+
+
+def registered_parts() -> List[Any]:
+    return list(_REGISTRY)
+
+
+def reset_registry() -> None:
+    """Forget all model parts (== tf.reset_default_graph())."""
+    _REGISTRY.clear()
+
+
+class Placeholder:
+    """Stands for tf.placeholder: a key of the feed dictionary."""
+    __slots__ = ("name", "default")
+
+    def __init__(self, name: str, default: Any = None):
+        self.name = name
+        self.default = default
+
+    def __repr__(self):
+        return f"<Placeholder {self.name}>"
+
+
+class Fetch:
+    """Handle of a value computable inside a run (stands for a tf.Tensor)."""
+    __slots__ = ("owner", "fn")
+
+    def __init__(self, owner, fn):
+        self.owner, self.fn = owner, fn
+
+    @property
+    def key(self):
+        return (id(self.owner), self.fn.__name__)
+
+    def __call__(self, ctx: "RunContext"):
+        memo = ctx.memo
+        k = self.key
+        if k not in memo:
+            memo[k] = self.fn(self.owner, ctx)
+        return memo[k]
+
+    def __repr__(self):
+        return f"<Fetch {getattr(self.owner, 'name', self.owner)}.{self.fn.__name__}>"
+
+
+def tensor(fn):
+    """``@tensor def x(self, ctx)`` -> property returning a Fetch handle."""
+    return property(lambda self: Fetch(self, fn), doc=fn.__doc__)
+
+
+class RunContext:
+    def __init__(self, session: "Session", feed: Dict[Placeholder, Any]):
+        self.session = session
+        self.feed = feed
+        self.memo: Dict[Any, Any] = {}
+
+    @property
+    def store(self):
+        return self.session.store
+
+    @property
+    def device(self):
+        return self.session.device
+
+    def fed(self, placeholder: Placeholder):
+        if placeholder in self.feed:
+            return self.feed[placeholder]
+        if placeholder.default is not None:
+            return placeholder.default
+        raise KeyError(f"placeholder {placeholder.name} was not fed")
+
+    def is_fed(self, placeholder: Placeholder) -> bool:
+        return placeholder in self.feed
+
+    def buffer(self, key, shape, dtype=torch.float32, zero=False):
+        """Persistent scratch buffer owned by the session (no per-step malloc)."""
+        return self.session.buffer(key, shape, dtype, zero)
+
+
+def _to_host(val):
+    if isinstance(val, torch.Tensor):
+        return val.detach().cpu().numpy()
+    if isinstance(val, tuple) and hasattr(val, "_fields"):
+        return type(val)(*[_to_host(v) for v in val])
+    if isinstance(val, (list, tuple)):
+        return type(val)(_to_host(v) for v in val)
+    if isinstance(val, dict):
+        return {k: _to_host(v) for k, v in val.items()}
+    return val
+
+
+class Session:
+    """One set of variables on one device (stands for a tf.Session)."""
+
+    def __init__(self, device, seed: Optional[int] = None):
+        from .variables import VariableStore
+        self.device = torch.device(device)
+        self.store = VariableStore(self.device, seed)
+        self._buffers: Dict[Any, torch.Tensor] = {}
+        self._h2d: Dict[Any, Any] = {}
+        self.global_step = 0
+
+    def to_device(self, array, dtype, tag=None, derive=None):
+        """Host array (or ``derive(array)``) -> device tensor.  Arrays that are
+        fed again (same object, e.g. a benchmark batch kept by the caller) stay
+        resident in HBM and are not re-derived."""
+        if isinstance(array, torch.Tensor):
+            return array.to(self.device, dtype)
+        key = (id(array), tag, dtype)
+        hit = self._h2d.get(key)
+        if hit is not None and hit[0] is array:
+            return hit[1]
+        src = derive(array) if derive is not None else array
+        ten = torch.as_tensor(np.ascontiguousarray(src)).to(self.device, dtype)
+        if len(self._h2d) > 64:
+            self._h2d.clear()
+        self._h2d[key] = (array, ten)
+        return ten
+
+    def buffer(self, key, shape, dtype=torch.float32, zero=False):
+        shape = tuple(int(s) for s in shape)
+        buf = self._buffers.get(key)
+        if buf is None or tuple(buf.shape) != shape or buf.dtype != dtype:
+            buf = torch.empty(shape, dtype=dtype, device=self.device)
+            self._buffers[key] = buf
+            if not zero:
+                return buf
+        if zero:
+            buf.zero_()
+        return buf
+
+    def _eval(self, fetch, ctx):
+        if isinstance(fetch, Fetch):
+            return fetch(ctx)
+        if isinstance(fetch, dict):
+            return {k: self._eval(v, ctx) for k, v in fetch.items()}
+        if isinstance(fetch, tuple) and hasattr(fetch, "_fields"):
+            return type(fetch)(*[self._eval(v, ctx) for v in fetch])
+        if isinstance(fetch, (list, tuple)):
+            return type(fetch)(self._eval(v, ctx) for v in fetch)
+        return fetch                      # constants / None pass through
+
+    def run(self, fetches, feed_dict: Optional[Dict[Placeholder, Any]] = None):
+        ctx = RunContext(self, dict(feed_dict or {}))
+        with torch.no_grad():
+            out = self._eval(fetches, ctx)
+        return _to_host(out)

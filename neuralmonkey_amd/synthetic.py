@@ -1,0 +1,90 @@
+"""Synthetic translation.ini-shape model and data.
+
+Used by bench.py, ``__graft_entry__.smoke()`` and the parity tests: the model is
+assembled from the same plugin classes an INI file names
+(examples/translation.ini:90-134 topology: SentenceEncoder -> Attention ->
+Decoder -> CrossEntropyTrainer / GreedyRunner / BeamSearchRunner)."""
+from typing import List, NamedTuple, Optional
+
+import numpy as np
+
+from .attention import Attention
+from .dataset import BatchingScheme, Dataset
+from .decoders import BeamSearchDecoder, Decoder
+from .encoders import SentenceEncoder
+from .runners import BeamSearchRunner, GreedyRunner
+from .runtime import reset_registry
+from .tf_manager import TensorFlowManager
+from .vocabulary import END_TOKEN_INDEX, PAD_TOKEN_INDEX, Vocabulary
+
+
+class TranslationModel(NamedTuple):
+    encoder: SentenceEncoder
+    attention: Attention
+    decoder: Decoder
+    beam_decoder: Optional[BeamSearchDecoder]
+    greedy_runner: GreedyRunner
+    beam_runner: Optional[BeamSearchRunner]
+    trainer: object
+    tf_manager: TensorFlowManager
+    src_vocab: Vocabulary
+    tgt_vocab: Vocabulary
+
+
+def synthetic_vocabulary(size: int) -> Vocabulary:
+    return Vocabulary(["w{}".format(i) for i in range(size - 4)])
+
+
+def build_translation_model(vocab_src=32000, vocab_tgt=32000, emb=512, rnn=512, dec_rnn=None,
+                            dec_emb=None, att_size=None, max_len=50, beam_size=5, max_steps=50,
+                            length_normalization=0.6, l2_weight=1e-8, clip_norm=1.0,
+                            with_trainer=True, supress_unk=False, device=None, seed=1234,
+                            num_sessions=1) -> TranslationModel:
+    reset_registry()
+    src_vocab, tgt_vocab = synthetic_vocabulary(vocab_src), synthetic_vocabulary(vocab_tgt)
+    encoder = SentenceEncoder(name="encoder", vocabulary=src_vocab, data_id="source",
+                              embedding_size=emb, rnn_size=rnn, max_input_len=max_len)
+    attention = Attention(name="attention", encoder=encoder, state_size=att_size)
+    decoder = Decoder(encoders=[encoder], vocabulary=tgt_vocab, data_id="target", name="decoder",
+                      max_output_len=max_len, embedding_size=dec_emb or emb, rnn_size=dec_rnn or rnn,
+                      attentions=[attention], supress_unk=supress_unk)
+    beam_decoder = beam_runner = None
+    if beam_size:
+        beam_decoder = BeamSearchDecoder(name="beam_decoder", parent_decoder=decoder, beam_size=beam_size,
+                                         max_steps=max_steps, length_normalization=length_normalization)
+        beam_runner = BeamSearchRunner(output_series="target_beam", decoder=beam_decoder, rank=1)
+    greedy_runner = GreedyRunner(output_series="target", decoder=decoder)
+    trainer = None
+    if with_trainer:
+        from .trainers import CrossEntropyTrainer
+        trainer = CrossEntropyTrainer(decoders=[decoder], l2_weight=l2_weight, clip_norm=clip_norm)
+    tf_manager = TensorFlowManager(num_sessions=num_sessions, num_threads=4, device=device, seed=seed)
+    tf_manager.initialize_sessions()
+    return TranslationModel(encoder, attention, decoder, beam_decoder, greedy_runner, beam_runner,
+                            trainer, tf_manager, src_vocab, tgt_vocab)
+
+
+def synthetic_ids(seed=1234, batch=128, src_len=50, tgt_len=50, vocab=32000, ragged=False):
+    """ids uniform in [4,V); </s> closes every target (added by the decoder's
+    feed_dict, so target sentences here hold len-1 tokens)."""
+    rng = np.random.default_rng(seed)
+    src = rng.integers(4, vocab, size=(batch, src_len)).astype(np.int32)
+    tgt = rng.integers(4, vocab, size=(batch, tgt_len)).astype(np.int32)
+    if ragged:
+        sl = rng.integers(max(1, src_len // 2), src_len + 1, size=batch)
+        tl = rng.integers(max(1, tgt_len // 2), tgt_len + 1, size=batch)
+    else:
+        sl = np.full(batch, src_len)
+        tl = np.full(batch, tgt_len)
+    src_sents = [src[b, :sl[b]] for b in range(batch)]
+    tgt_sents = [tgt[b, :tl[b] - 1] for b in range(batch)]
+    return src_sents, tgt_sents
+
+
+def synthetic_dataset(seed=1234, batch=128, src_len=50, tgt_len=50, vocab=32000, ragged=False,
+                      with_target=True) -> Dataset:
+    src, tgt = synthetic_ids(seed, batch, src_len, tgt_len, vocab, ragged)
+    series = {"source": src}
+    if with_target:
+        series["target"] = tgt
+    return Dataset("synthetic", series, BatchingScheme(batch_size=batch))

@@ -1,0 +1,173 @@
+"""Variable store: every model variable is a view into one flat fp32 buffer.
+
+The reference keeps variables in the TF graph under ``<part-name>/...`` names
+(model/parameterized.py:68-72, SURVEY section 9 "Variable naming"); we keep the
+same names but lay all of them out in a single contiguous device buffer so that
+the optimizer step, the L1/L2 terms and the data-parallel all-reduce each touch
+one allocation (sized for 288 GB HBM: no per-tensor launches or collectives).
+"""
+from collections import OrderedDict
+from typing import Callable, Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+Initializer = Callable[[np.random.Generator, Tuple[int, ...]], np.ndarray]
+
+
+# ---- initializers (tf.* look-alikes used by model parts and INI files) ------
+def random_normal_initializer(mean=0.0, stddev=1.0, seed=None, dtype=None) -> Initializer:
+    return lambda rng, shape: (rng.standard_normal(shape) * stddev + mean).astype(np.float32)
+
+
+def random_uniform_initializer(minval=0.0, maxval=None, seed=None, dtype=None) -> Initializer:
+    hi = 1.0 if maxval is None else maxval
+    return lambda rng, shape: rng.uniform(minval, hi, size=shape).astype(np.float32)
+
+
+def zeros_initializer() -> Initializer:
+    return lambda rng, shape: np.zeros(shape, np.float32)
+
+
+def ones_initializer() -> Initializer:
+    return lambda rng, shape: np.ones(shape, np.float32)
+
+
+def constant_initializer(value) -> Initializer:
+    return lambda rng, shape: np.full(shape, value, np.float32)
+
+
+def orthogonal_initializer(gain=1.0) -> Initializer:
+    """tf.orthogonal_initializer: QR of a normal matrix flattened to 2-D."""
+    def init(rng, shape):
+        rows = int(np.prod(shape[:-1]))
+        cols = int(shape[-1])
+        a = rng.standard_normal((max(rows, cols), min(rows, cols)))
+        q, r = np.linalg.qr(a)
+        q = q * np.sign(np.diag(r))
+        if rows < cols:
+            q = q.T
+        return (gain * q.reshape(shape)).astype(np.float32)
+    return init
+
+
+def glorot_uniform_initializer() -> Initializer:
+    def init(rng, shape):
+        fan_in, fan_out = (shape[0], shape[-1]) if len(shape) > 1 else (shape[0], shape[0])
+        lim = np.sqrt(6.0 / (fan_in + fan_out))
+        return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+    return init
+
+
+class VarSpec:
+    __slots__ = ("name", "shape", "init", "trainable", "offset", "size")
+
+    def __init__(self, name, shape, init, trainable):
+        self.name, self.shape, self.init, self.trainable = name, tuple(int(s) for s in shape), init, trainable
+        self.size = int(np.prod(self.shape)) if self.shape else 1
+        self.offset = -1
+
+
+class VariableStore:
+    """Named variables as views into flat ``theta`` / ``grad`` / Adam buffers."""
+
+    ALIGN = 4          # floats: every variable starts 16-byte aligned
+
+    def __init__(self, device, seed: Optional[int] = None):
+        self.device = torch.device(device)
+        self.seed = seed
+        self.specs: "OrderedDict[str, VarSpec]" = OrderedDict()
+        self.theta: Optional[torch.Tensor] = None
+        self.grad: Optional[torch.Tensor] = None
+        self.adam_m: Optional[torch.Tensor] = None
+        self.adam_v: Optional[torch.Tensor] = None
+        self.total = 0
+        self._views: Dict[str, torch.Tensor] = {}
+        self._gviews: Dict[str, torch.Tensor] = {}
+
+    # -- declaration ---------------------------------------------------------
+    def declare(self, name: str, shape, init: Initializer, trainable: bool = True) -> None:
+        if self.theta is not None:
+            raise RuntimeError(f"store already finalized; cannot declare {name}")
+        spec = VarSpec(name, shape, init, trainable)
+        old = self.specs.get(name)
+        if old is not None:
+            if old.shape != spec.shape:
+                raise ValueError(f"variable {name} re-declared with shape {spec.shape} != {old.shape}")
+            return
+        self.specs[name] = spec
+
+    def finalize(self) -> None:
+        off = 0
+        for spec in self.specs.values():
+            spec.offset = off
+            off += (spec.size + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.total = off
+        host = np.zeros(off, np.float32)
+        rng = np.random.default_rng(self.seed)
+        for spec in self.specs.values():
+            val = np.asarray(spec.init(rng, spec.shape), dtype=np.float32)
+            host[spec.offset:spec.offset + spec.size] = val.reshape(-1)
+        self.theta = torch.from_numpy(host).to(self.device)
+        self._views = {n: self._view(self.theta, s) for n, s in self.specs.items()}
+
+    def _view(self, flat, spec):
+        return flat[spec.offset:spec.offset + spec.size].view(spec.shape)
+
+    # -- access --------------------------------------------------------------
+    def __contains__(self, name):
+        return name in self.specs
+
+    def __getitem__(self, name) -> torch.Tensor:
+        return self._views[name]
+
+    def names(self):
+        return list(self.specs)
+
+    def trainable_names(self):
+        return [n for n, s in self.specs.items() if s.trainable]
+
+    def offset(self, name) -> int:
+        return self.specs[name].offset
+
+    def ensure_grad(self) -> torch.Tensor:
+        if self.grad is None:
+            self.grad = torch.zeros(self.total, dtype=torch.float32, device=self.device)
+            self._gviews = {n: self._view(self.grad, s) for n, s in self.specs.items()}
+        return self.grad
+
+    def g(self, name) -> torch.Tensor:
+        self.ensure_grad()
+        return self._gviews[name]
+
+    def ensure_adam(self):
+        if self.adam_m is None:
+            self.adam_m = torch.zeros(self.total, dtype=torch.float32, device=self.device)
+            self.adam_v = torch.zeros(self.total, dtype=torch.float32, device=self.device)
+        return self.adam_m, self.adam_v
+
+    # -- (de)serialisation: npz keyed by the TF-style variable names ---------
+    def state_dict(self) -> Dict[str, np.ndarray]:
+        return {n: self[n].detach().cpu().numpy().copy() for n in self.specs}
+
+    def load_state_dict(self, values: Dict[str, np.ndarray], strict: bool = True) -> None:
+        for n, spec in self.specs.items():
+            if n not in values:
+                if strict:
+                    raise KeyError(f"checkpoint lacks variable {n}")
+                continue
+            arr = np.asarray(values[n], dtype=np.float32)
+            if tuple(arr.shape) != spec.shape:
+                if arr.size != spec.size or max(arr.ndim, len(spec.shape)) > 1:
+                    raise ValueError(f"{n}: checkpoint shape {arr.shape} != {spec.shape}")
+                arr = arr.reshape(spec.shape)          # scalar () <-> (1,)
+            self[n].copy_(torch.from_numpy(arr).to(self.device))
+
+    def save(self, path: str) -> None:
+        np.savez(path, **{k.replace("/", "|"): v for k, v in self.state_dict().items()})
+
+    def load(self, path: str, strict: bool = True) -> None:
+        if not path.endswith(".npz"):
+            path = path + ".npz"
+        with np.load(path) as data:
+            self.load_state_dict({k.replace("|", "/"): data[k] for k in data.files}, strict)

@@ -1,0 +1,123 @@
+"""End-to-end parity of the plugin surface (SentenceEncoder -> Attention ->
+Decoder -> GreedyRunner / BeamSearchRunner through TensorFlowManager.execute)
+against the CPU oracle on the same weights and the same seeded batch."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(dev, vocab, emb, rnn, batch, slen, tlen, ragged, beam=3, max_steps=None, seed=7, **kw):
+    from neuralmonkey_amd import synthetic
+    model = synthetic.build_translation_model(
+        vocab_src=vocab, vocab_tgt=vocab, emb=emb, rnn=rnn, max_len=max(slen, tlen), beam_size=beam,
+        max_steps=max_steps or tlen, with_trainer=False, device=str(dev), **kw)
+    params = O.init_params(seed=seed, vocab_src=vocab, vocab_tgt=vocab, emb=emb, rnn=rnn, std=kw.pop("std", 0.08))
+    model.tf_manager.sessions[0].store.load_state_dict(params)
+    ds = synthetic.synthetic_dataset(seed=seed + 1, batch=batch, src_len=slen, tgt_len=tlen, vocab=vocab,
+                                     ragged=ragged)
+    src = O.pad_ids([list(s) for s in ds.get_series("source")], max(slen, tlen))
+    tgt = O.pad_ids([list(s) for s in ds.get_series("target")], max(slen, tlen), add_end_symbol=True)
+    return model, params, ds, src, np.ascontiguousarray(tgt.T)
+
+
+def _ids_to_words(vocab, sents):
+    return [[vocab.index_to_word[i] for i in s] for s in sents]
+
+
+@pytest.mark.parametrize("vocab,emb,rnn,batch,slen,tlen,ragged", [
+    (64, 12, 12, 5, 7, 6, True),
+    (500, 32, 32, 16, 20, 12, True),
+    (2000, 64, 64, 32, 30, 25, False),
+])
+def test_encoder_and_greedy_match_oracle(dev, vocab, emb, rnn, batch, slen, tlen, ragged):
+    model, params, ds, src, tgt = _setup(dev, vocab, emb, rnn, batch, slen, tlen, ragged)
+    enc = O.sentence_encoder(params, src)
+    spec = O.DecoderSpec(max_output_len=max(slen, tlen))
+    ref = O.decoding_loop(params, spec, enc, None, False)
+    ref_train = O.decoding_loop(params, spec, enc, tgt, True)
+
+    sess = model.tf_manager.sessions[0]
+    fd = {}
+    for f in model.greedy_runner.feedables:
+        fd.update(f.feed_dict(ds, train=False))
+    got = sess.run({"states": model.encoder.temporal_states, "final": model.encoder.output,
+                    "sym": model.decoder.decoded_symbols, "logits": model.decoder.runtime_logits,
+                    "train_loss": model.decoder.train_loss, "runtime_loss": model.decoder.runtime_loss,
+                    "w": model.attention.hidden_features}, fd)
+    rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-6))
+    assert rel(got["states"], enc.temporal_states) < 1e-4
+    assert rel(got["final"], enc.output) < 1e-4
+    assert np.array_equal(got["sym"], ref.symbols.astype(np.int32)), "greedy symbols differ"
+    assert rel(got["logits"], ref.logits) < 1e-4
+    assert abs(float(got["train_loss"]) - float(O.train_loss(ref_train, tgt))) < 1e-4 * abs(float(O.train_loss(ref_train, tgt)))
+    assert abs(float(got["runtime_loss"]) - float(O.runtime_loss(ref, tgt))) < 1e-4 * abs(float(O.runtime_loss(ref, tgt)))
+
+    res = model.tf_manager.execute(ds, model.greedy_runner.feedables, [model.greedy_runner])[0]
+    want = _ids_to_words(model.tgt_vocab, O.greedy_tokens(ref))
+    assert res.outputs["target"] == want
+    assert set(res.losses) == {"target/train_xent", "target/runtime_xent"}
+    assert res.size == batch
+
+
+@pytest.mark.parametrize("vocab,emb,rnn,batch,slen,tlen,beam,alpha", [
+    (64, 12, 12, 4, 7, 6, 3, 0.6),
+    (500, 32, 32, 1, 20, 12, 5, 1.0),     # the reference's own (batch-1) regime
+    (500, 32, 32, 9, 20, 12, 5, 0.6),
+    (2000, 64, 64, 16, 30, 20, 4, 0.0),
+])
+def test_beam_search_matches_oracle(dev, vocab, emb, rnn, batch, slen, tlen, beam, alpha):
+    model, params, ds, src, tgt = _setup(dev, vocab, emb, rnn, batch, slen, tlen, True, beam=beam,
+                                         max_steps=tlen, length_normalization=alpha)
+    enc = O.sentence_encoder(params, src)
+    spec = O.DecoderSpec(max_output_len=max(slen, tlen))
+    ref = O.beam_search(params, spec, enc, beam, tlen, alpha)
+    sess = model.tf_manager.sessions[0]
+    fd = {}
+    for f in model.beam_runner.feedables:
+        fd.update(f.feed_dict(ds, train=False))
+    out = sess.run({"bs": model.beam_decoder.outputs}, fd)["bs"]
+    tok = out.last_search_step_output.token_ids
+    if ref.min_gap > 1e-5:
+        assert tok.shape == ref.token_ids.shape
+        assert np.array_equal(tok, ref.token_ids.astype(np.int32)), "beam token ids differ"
+        assert np.array_equal(out.last_search_state.lengths, ref.lengths)
+        assert np.array_equal(out.last_search_state.finished.astype(bool), ref.finished)
+        rel = np.abs(out.last_search_step_output.scores - ref.scores).max() / np.abs(ref.scores).max()
+        assert rel < 1e-4
+    else:       # the oracle itself saw a near-tie: report instead of hiding it
+        same = np.mean(tok[:min(len(tok), len(ref.token_ids))] ==
+                       ref.token_ids[:min(len(tok), len(ref.token_ids))])
+        assert same > 0.9, "near-tie reported by the oracle (gap {:.2e}) but outputs diverge widely".format(ref.min_gap)
+    res = model.tf_manager.execute(ds, model.beam_runner.feedables, [model.beam_runner])[0]
+    want, want_loss = O.beam_tokens(ref, 1)
+    if ref.min_gap > 1e-5:
+        assert res.outputs["target_beam"] == _ids_to_words(model.tgt_vocab, want)
+        assert abs(res.losses["target_beam/beam_search_score"] - want_loss) < 1e-3 * abs(want_loss)
+
+
+def test_beam_early_stop_and_greedy_early_stop(dev):
+    """A model that emits </s> immediately: loops stop after the first step and
+    histories are cropped exactly like the reference's while-loop."""
+    model, params, ds, src, tgt = _setup(dev, 64, 12, 12, 4, 7, 6, True, beam=3)
+    params = dict(params)
+    b = params["decoder/state_to_word_b"].copy()
+    b[O.END] = 50.0
+    params["decoder/state_to_word_b"] = b
+    model.tf_manager.sessions[0].store.load_state_dict(params)
+    enc = O.sentence_encoder(params, src)
+    spec = O.DecoderSpec(max_output_len=7)
+    ref = O.decoding_loop(params, spec, enc, None, False)
+    refb = O.beam_search(params, spec, enc, 3, 6, 0.6)
+    sess = model.tf_manager.sessions[0]
+    fd = {}
+    for f in model.beam_runner.feedables | model.greedy_runner.feedables:
+        fd.update(f.feed_dict(ds, train=False))
+    got = sess.run({"sym": model.decoder.decoded_symbols, "bs": model.beam_decoder.outputs}, fd)
+    assert got["sym"].shape == ref.symbols.shape == (1, 4)
+    assert np.array_equal(got["sym"], ref.symbols)
+    assert got["bs"].last_search_step_output.token_ids.shape == refb.token_ids.shape
+    assert np.array_equal(got["bs"].last_search_step_output.token_ids, refb.token_ids)
