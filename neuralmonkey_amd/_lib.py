@@ -7,6 +7,10 @@ import ctypes
 import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
+# torch must be imported first: it ships its own libamdhip64.so, and libnmhip has to
+# bind to that same HIP runtime instance (streams and device pointers come from torch).
+import torch  # noqa: F401  pylint: disable=unused-import
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnmhip.so")
 
@@ -30,12 +34,27 @@ SIGNATURES = {
     "nm_reduce_sum": (I, [P, P, L, P]),
     "nm_log_softmax": (I, [P, P, L, P, P, P, L, L, L]),
     "nm_attn_workspace_bytes": (L, [L, L, L]),
-    "nm_attn_fwd": (I, [P, P, P, P, P, P, P, L, L, L, L, L, P, L, P, P, L]),
+    "nm_attn_fwd": (I, [P, P, P, P, P, P, P, L, L, L, L, L, P, L, P, P, L, P]),
+    "nm_gru_rh_seq": (I, [P, P, P, P, P, I, L, L, I, L]),
+    "nm_prof_enable": (I, [I]),
+    "nm_prof_attn_partial": (I, [P, P]),
     "nm_row_stats": (I, [P, P, L, L, L, P, P, P]),
     "nm_greedy_update": (I, [P, P, P, P, P, L, I, P]),
     "nm_xent": (I, [P, P, L, L, L, P, P, P, P, I]),
     "nm_beam_workspace_bytes": (L, [L, L, L]),
     "nm_beam_topk_step": (I, [P, P, L, L, L, L, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, L, P]),
+    "nm_tanh_bwd": (I, [P, P, P, L]),
+    "nm_colsum_workspace_bytes": (L, [L]),
+    "nm_colsum": (I, [P, P, L, L, L, P, I, P, L]),
+    "nm_embedding_scatter_add": (I, [P, P, L, L, P, L, P, L, I]),
+    "nm_layer_norm_bwd": (I, [P, P, P, P, P, P, P, P, L, L]),
+    "nm_gru_step_bwd": (I, [P, I, P, P, L, L, L, P, P, P, P, L, L, L, P, L, L, L, P, P, P, P, I, I, I, L, L]),
+    "nm_gru_seq_shift": (I, [P, P, P, P, I, L, L, I, L]),
+    "nm_attn_softmax_bwd": (I, [P, P, P, P, P, L, L, L]),
+    "nm_attn_energy_bwd": (I, [P, P, P, P, P, P, P, P, L, L, L, L]),
+    "nm_optim_workspace_bytes": (L, [L, L]),
+    "nm_optim_regularize_norms": (I, [P, P, P, P, P, P, P, P, P, L, L, F, F, P, P, L]),
+    "nm_optim_clip_adam": (I, [P, P, P, P, P, P, P, P, P, P, P, L, L, F, F, F, F, F, P, L]),
     "nm_gather_rows_f32": (I, [P, P, L, P, P, L, L, L]),
     "nm_beam_reorder_tokens": (I, [P, P, P, P, P, L, L]),
 }

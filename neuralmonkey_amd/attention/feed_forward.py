@@ -79,7 +79,7 @@ class Attention(BaseAttention):
                         bias=self.var(ctx, "attn_projection_bias"))
 
     def attention_into(self, ctx, query: torch.Tensor, y: torch.Tensor, ctx_out: torch.Tensor,
-                       w_out: Optional[torch.Tensor]) -> None:
+                       w_out: Optional[torch.Tensor], energies_out: Optional[torch.Tensor] = None) -> None:
         """y = q.Wq + b (kept by the caller for the backward pass), then the fused step kernel."""
         rows = query.shape[0]
         states = self.attention_states(ctx)
@@ -88,7 +88,47 @@ class Attention(BaseAttention):
         ws = ctx.buffer((id(self), "ws", rows), ((ops._lib.load().nm_attn_workspace_bytes(
             rows, states.shape[1], states.shape[2]) + 3) // 4,))
         ops.attn_fwd(y, hf, states, self.attention_mask(ctx), self.var(ctx, "attn_similarity_v"),
-                     self.var(ctx, "attn_bias"), self.rows_per_key, ctx_out, w_out, ws)
+                     self.var(ctx, "attn_bias"), self.rows_per_key, ctx_out, w_out, ws, energies_out)
+
+    def backward(self, ctx, dctx_all: torch.Tensor, queries: torch.Tensor, y_all: torch.Tensor,
+                 w_all: torch.Tensor, e_all: torch.Tensor, dquery_accum: torch.Tensor) -> torch.Tensor:
+        """Gradient of T attention steps at once (nothing here feeds the recurrence).
+
+        dctx_all [T,B,C], queries [T,B,Q], y_all [T,B,A], w_all / e_all [T,B,S].
+        Adds dL/dquery into ``dquery_accum`` [T*B,Q], accumulates this part's
+        variable gradients and returns dL/d(attention_states) [B,S,C]."""
+        store = ctx.store
+        states, hf, mask = self.attention_states(ctx), self.hidden_features(ctx), self.attention_mask(ctx)
+        bsz, slen, c = states.shape
+        steps = dctx_all.shape[0]
+        a = self.state_size
+        rows = steps * bsz
+        key = (id(self), "bwd")
+        dw = ctx.buffer(key + ("dw",), (steps, bsz, slen))
+        dstates = ctx.buffer(key + ("dstates",), (bsz, slen, c))
+        dctx_b = dctx_all.permute(1, 0, 2)                                   # [B,T,C] strided view
+        ops.gemm(dctx_b, states, out=dw.permute(1, 0, 2), trans_b=True)      # dw[t,b,:] = dctx[t,b,:].states[b]^T
+        ops.gemm(w_all.permute(1, 0, 2), dctx_b, out=dstates, trans_a=True)  # dstates[b] = w[:,b,:]^T.dctx[:,b,:]
+        de = ctx.buffer(key + ("de",), (steps, bsz, slen))
+        ops.attn_softmax_bwd(dw, e_all, mask, de, bsz)
+        ops.reduce_sum(de.view(-1), ctx.buffer(key + ("dbias",), (1,)))
+        store.g(self.var_name("attn_bias")).add_(ctx.buffer(key + ("dbias",), (1,)))
+        dhf = ctx.buffer(key + ("dhf",), (bsz, slen, a))
+        dvp = ctx.buffer(key + ("dvp",), (bsz * slen, a))
+        dy = ctx.buffer(key + ("dy",), (steps, bsz, a))
+        ops.attn_energy_bwd(de, hf, y_all, self.var(ctx, "attn_similarity_v"), dhf, dvp, dy)
+        ops.colsum(dvp, store.g(self.var_name("attn_similarity_v")), accumulate=True)
+        dy2 = dy.view(rows, a)
+        ops.colsum(dy2, store.g(self.var_name("attn_projection_bias")), accumulate=True)
+        wq = self.var(ctx, "Attention/attn_query_projection")
+        ops.gemm(queries.reshape(rows, -1), dy2, out=store.g(self.var_name("Attention/attn_query_projection")),
+                 trans_a=True, accumulate=True)
+        ops.gemm(dy2, wq, out=dquery_accum, trans_b=True, accumulate=True)
+        wk = self.var(ctx, "attn_key_projection")
+        ops.gemm(states.reshape(bsz * slen, c), dhf.view(bsz * slen, a),
+                 out=store.g(self.var_name("attn_key_projection")), trans_a=True, accumulate=True)
+        ops.gemm(dhf.view(bsz * slen, a), wk, out=dstates.view(bsz * slen, c), trans_b=True, accumulate=True)
+        return dstates
 
     def attention(self, ctx, query: torch.Tensor, decoder_prev_state, decoder_input,
                   loop_state: AttentionLoopState) -> Tuple[torch.Tensor, AttentionLoopState]:

@@ -23,7 +23,48 @@
 //   w_s = exp(e_s-M) m_s / (sum_j exp(e_j-M) m_j + 1e-8 * sum_j exp(e_j-M)).
 #include "nm_common.h"
 
+#include <utility>
+#include <vector>
+
 #define ATT_MAX_SCH 16
+
+// ---- optional live timing of attn_partial with HIP events on the launch stream
+// (bench.py's `roofline.achieved`); off by default, zero cost when off.
+static bool g_prof_on = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
+static size_t g_prof_used = 0;
+
+extern "C" int nm_prof_enable(int on) {
+    g_prof_on = on != 0;
+    if (g_prof_on) g_prof_used = 0;
+    return NM_OK;
+}
+
+// Sum / count of the recorded attn_partial launches; resets the recorder.
+extern "C" int nm_prof_attn_partial(double* total_ms, int64_t* count) {
+    NM_REQUIRE(total_ms && count, "nm_prof_attn_partial: null pointer");
+    double tot = 0.0;
+    for (size_t i = 0; i < g_prof_used; ++i) {
+        float ms = 0.0f;
+        if (hipEventSynchronize(g_prof_pool[i].second) != hipSuccess ||
+            hipEventElapsedTime(&ms, g_prof_pool[i].first, g_prof_pool[i].second) != hipSuccess)
+            NM_FAIL(NM_ERR_HIP, "nm_prof_attn_partial: event query failed");
+        tot += ms;
+    }
+    *total_ms = tot;
+    *count = (int64_t)g_prof_used;
+    g_prof_used = 0;
+    return NM_OK;
+}
+
+static std::pair<hipEvent_t, hipEvent_t>* prof_next_pair() {
+    if (g_prof_used == g_prof_pool.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return nullptr;
+        g_prof_pool.emplace_back(a, b);
+    }
+    return &g_prof_pool[g_prof_used++];
+}
 
 struct AttnArgs {
     const float* y;       // [R,A]
@@ -204,7 +245,8 @@ extern "C" int64_t nm_attn_workspace_bytes(int64_t R, int64_t S, int64_t C) {
 extern "C" int nm_attn_fwd(void* stream, const float* y, const float* hf, const float* states,
                            const float* mask, const float* v, const float* bias, int64_t R,
                            int64_t rows_per_key, int64_t S, int64_t A, int64_t C, float* ctx,
-                           int64_t ldctx, float* weights, void* workspace, int64_t workspace_bytes) {
+                           int64_t ldctx, float* weights, void* workspace, int64_t workspace_bytes,
+                           float* energies_out) {
     NM_REQUIRE(y && hf && states && v && ctx && workspace, "nm_attn_fwd: null pointer");
     NM_REQUIRE(R > 0 && S > 0 && A > 0 && C > 0 && rows_per_key >= 1 && R % rows_per_key == 0,
                "nm_attn_fwd: bad shape R=%ld k=%ld S=%ld", (long)R, (long)rows_per_key, (long)S);
@@ -223,7 +265,7 @@ extern "C" int nm_attn_fwd(void* stream, const float* y, const float* hf, const 
     float* ws = reinterpret_cast<float*>(workspace);
     AttnArgs p;
     p.y = y; p.hf = hf; p.states = states; p.mask = mask; p.v = v; p.bias = bias;
-    p.energies = ws;
+    p.energies = energies_out ? energies_out : ws;   // kept by the caller for the backward pass
     p.pctx = ws + ((R * S + 3) / 4) * 4;
     p.pstat = p.pctx + R * nchunk * C;
     p.R = (int)R; p.S = (int)S; p.A = (int)A; p.C = (int)C; p.nchunk = nchunk; p.sch = sch;
@@ -237,6 +279,8 @@ extern "C" int nm_attn_fwd(void* stream, const float* y, const float* hf, const 
         if (ncg == 1) hipLaunchKernelGGL((attn_partial<Q_, 1>), grid, block, shm, st, p); \
         else hipLaunchKernelGGL((attn_partial<Q_, 2>), grid, block, shm, st, p);          \
     } while (0)
+    std::pair<hipEvent_t, hipEvent_t>* prof = g_prof_on ? prof_next_pair() : nullptr;
+    if (prof) hipEventRecord(prof->first, st);
     switch (qpk) {
         case 1: NM_AT(1); break;
         case 2: NM_AT(2); break;
@@ -248,6 +292,7 @@ extern "C" int nm_attn_fwd(void* stream, const float* y, const float* hf, const 
         default: NM_AT(8); break;
     }
 #undef NM_AT
+    if (prof) hipEventRecord(prof->second, st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) NM_FAIL(NM_ERR_HIP, "nm_attn_fwd: partial launch failed: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(attn_combine, dim3((unsigned)R), dim3(256), 0, st, p.pctx, p.pstat, p.energies,

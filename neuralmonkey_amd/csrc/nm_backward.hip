@@ -1,0 +1,486 @@
+// Hand-written backward kernels of the attention-decoder path.  The reference
+// obtains these from tf.gradients (trainers/generic_trainer.py:136-142) over
+// the forward ops cited in nm_elementwise.hip / nm_attention.hip.
+//
+// Only the GRU state feeds back through time, so everything else (attention,
+// projections, logits) is differentiated batched over all T steps; the
+// sequential part is two skinny NT GEMMs + the two epilogues below per step.
+#include "nm_common.h"
+
+// ---------------------------------------------------------------------------
+// dpre = dy * (1 - y^2)  in place (tanh epilogue of the output projection)
+// ---------------------------------------------------------------------------
+__global__ void tanh_bwd_kernel(float* __restrict__ dy, const float* __restrict__ y, long n) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        float4 d = *reinterpret_cast<float4*>(dy + i);
+        const float4 v = *reinterpret_cast<const float4*>(y + i);
+        d.x *= 1.0f - v.x * v.x; d.y *= 1.0f - v.y * v.y;
+        d.z *= 1.0f - v.z * v.z; d.w *= 1.0f - v.w * v.w;
+        *reinterpret_cast<float4*>(dy + i) = d;
+    } else {
+        for (long k = i; k < n; ++k) dy[k] *= 1.0f - y[k] * y[k];
+    }
+}
+
+extern "C" int nm_tanh_bwd(void* stream, float* dy, const float* y, int64_t n) {
+    NM_REQUIRE(dy && y && n >= 0 && nm_aligned16(dy) && nm_aligned16(y), "nm_tanh_bwd: bad args");
+    if (n == 0) return NM_OK;
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(nm_cdiv(n, 1024)), dim3(256), 0, nm_stream(stream), dy, y,
+                       (long)n);
+    NM_LAUNCH_CHECK("nm_tanh_bwd");
+}
+
+// ---------------------------------------------------------------------------
+// column sums (bias gradients): out[c] (+)= sum_r x[r,c].  Deterministic two
+// stage: RSPLIT row slices -> partial[RSPLIT][cols] -> fixed-order sum.
+// ---------------------------------------------------------------------------
+#define COLSUM_RSPLIT 32
+__global__ void colsum_partial_kernel(const float* __restrict__ x, long ldx, long rows, int cols,
+                                      float* __restrict__ part) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    const int sl = blockIdx.y;
+    const long per = (rows + COLSUM_RSPLIT - 1) / COLSUM_RSPLIT;
+    const long r0 = sl * per, r1 = min(rows, r0 + per);
+    float s = 0.0f;
+    for (long r = r0; r < r1; ++r) s += x[r * ldx + c];
+    part[(long)sl * cols + c] = s;
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int cols, float* __restrict__ out,
+                                    int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.0f;
+    for (int k = 0; k < COLSUM_RSPLIT; ++k) s += part[(long)k * cols + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+extern "C" int64_t nm_colsum_workspace_bytes(int64_t cols) { return cols * COLSUM_RSPLIT * 4; }
+
+extern "C" int nm_colsum(void* stream, const float* x, int64_t ldx, int64_t rows, int64_t cols, float* out,
+                         int accumulate, void* workspace, int64_t workspace_bytes) {
+    NM_REQUIRE(x && out && workspace && rows >= 0 && cols > 0, "nm_colsum: bad args");
+    NM_REQUIRE(workspace_bytes >= nm_colsum_workspace_bytes(cols), "nm_colsum: workspace too small");
+    hipStream_t st = nm_stream(stream);
+    float* part = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nm_cdiv(cols, 256), COLSUM_RSPLIT), dim3(256), 0, st, x,
+                       (long)ldx, (long)rows, (int)cols, part);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(nm_cdiv(cols, 256)), dim3(256), 0, st, part, (int)cols, out,
+                       accumulate);
+    NM_LAUNCH_CHECK("nm_colsum");
+}
+
+// ---------------------------------------------------------------------------
+// embedding gradient: dtable[ids[i],:] += d[i,:]   (tf.gather gradient;
+// skip_pad drops rows with id 0 = the mask multiply of model/sequence.py:191)
+// ---------------------------------------------------------------------------
+__global__ void embedding_scatter_kernel(float* __restrict__ dtable, long V, int E,
+                                         const int* __restrict__ ids, long n, const float* __restrict__ d,
+                                         long ldd, int skip_pad) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int id = ids[row];
+    if (id < 0 || id >= V || (skip_pad && id == 0)) return;
+    float* dst = dtable + (long)id * E;
+    const float* src = d + row * ldd;
+    for (int c = lane; c < E; c += 64) atomicAdd(dst + c, src[c]);
+}
+
+extern "C" int nm_embedding_scatter_add(void* stream, float* dtable, int64_t V, int64_t E,
+                                        const int32_t* ids, int64_t n, const float* d, int64_t ldd,
+                                        int skip_pad) {
+    NM_REQUIRE(dtable && ids && d && V > 0 && E > 0 && n >= 0, "nm_embedding_scatter_add: bad args");
+    if (n == 0) return NM_OK;
+    hipLaunchKernelGGL(embedding_scatter_kernel, dim3(nm_cdiv(n, 4)), dim3(256), 0, nm_stream(stream),
+                       dtable, (long)V, (int)E, ids, (long)n, d, (long)ldd, skip_pad);
+    NM_LAUNCH_CHECK("nm_embedding_scatter_add");
+}
+
+// ---------------------------------------------------------------------------
+// layer norm backward (tf_utils.py:189-219):
+//   xhat = (x-mean)*rstd ; g = dy*gamma
+//   dx   = rstd * (g - mean(g) - xhat*mean(g*xhat))
+//   dyx  = dy*xhat   (column-summed by the caller into dgamma; dbeta = colsum(dy))
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layer_norm_bwd_kernel(const float* __restrict__ dy,
+                                                             const float* __restrict__ x,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd,
+                                                             const float* __restrict__ gamma,
+                                                             float* __restrict__ dx,
+                                                             float* __restrict__ dyx, int D) {
+    __shared__ float sh[4];
+    const long row = blockIdx.x;
+    const float mu = mean[row], rs = rstd[row];
+    const float* xr = x + row * D;
+    const float* dr = dy + row * D;
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int c = threadIdx.x; c < D; c += 256) {
+        const float xh = (xr[c] - mu) * rs;
+        const float g = dr[c] * gamma[c];
+        s1 += g;
+        s2 += g * xh;
+    }
+    auto bsum = [&](float v) {
+        v = nm_wave_sum(v);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+        __syncthreads();
+        return sh[0] + sh[1] + sh[2] + sh[3];
+    };
+    const float m1 = bsum(s1) / (float)D;
+    const float m2 = bsum(s2) / (float)D;
+    for (int c = threadIdx.x; c < D; c += 256) {
+        const float xh = (xr[c] - mu) * rs;
+        const float g = dr[c] * gamma[c];
+        dx[row * D + c] = rs * (g - m1 - xh * m2);
+        dyx[row * D + c] = dr[c] * xh;
+    }
+}
+
+extern "C" int nm_layer_norm_bwd(void* stream, const float* dy, const float* x, const float* mean,
+                                 const float* rstd, const float* gamma, float* dx, float* dyx,
+                                 int64_t rows, int64_t D) {
+    NM_REQUIRE(dy && x && mean && rstd && gamma && dx && dyx && rows >= 0 && D > 0,
+               "nm_layer_norm_bwd: bad args");
+    if (rows == 0) return NM_OK;
+    hipLaunchKernelGGL(layer_norm_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, nm_stream(stream), dy, x,
+                       mean, rstd, gamma, dx, dyx, (int)D);
+    NM_LAUNCH_CHECK("nm_layer_norm_bwd");
+}
+
+// ---------------------------------------------------------------------------
+// GRU step backward epilogues (see nm_elementwise.hip for the forward split).
+//   h' = u*h + (1-u)*c ; c = tanh(xc + (r*h).Wc_h) ; [r,u] = sigmoid(xg + h.Wg_h)
+// Step t, given dh = dL/dh' (carried) + dout (gradient arriving at this
+// step's output):
+//   blend_bwd : dc_pre, du_pre, dh <- dh*u          (then drh = dc_pre . Wc_h^T by GEMM)
+//   gates_bwd : dr_pre, dh += drh*r                  (then dh += [dr_pre,du_pre] . Wg_h^T by GEMM)
+// The pre-activation gradients are written both to dense [ndir,R,*] GEMM
+// operands and, at the step's sequence position, into dxp (same layout as xp)
+// from which the weight / input gradients are formed after the loop.
+// h_prev(t) is h0 (or zero) at t == 0, else the sequence output one step back
+// along the direction of travel.
+// ---------------------------------------------------------------------------
+struct GruBwdArgs {
+    float* dh;                 // [ndir,R,H] in/out
+    const float* dout;         // sequence-addressed, may be null
+    long do_dir, do_row, do_time;
+    const float* ru;           // [ndir,R,2H] gates of step t
+    const float* c;            // [ndir,R,H]  candidate of step t
+    const float* h0;           // [ndir,R,H] or null (zeros)
+    const float* hseq;         // sequence outputs (h of every step)
+    long hs_dir, hs_row, hs_time;
+    float* dxp;                // sequence-addressed [.., 3H]
+    long dx_dir, dx_row, dx_time;
+    float* dgpre;              // [ndir,R,2H]
+    float* dcpre;              // [ndir,R,H]
+    const float* drh;          // [ndir,R,H]   (gates_bwd only)
+    const int* lengths;
+    int t, rev_mask;
+    long R;
+    int H;
+};
+
+__device__ __forceinline__ bool gru_bwd_pos(const GruBwdArgs& a, int r, int d, int& pos, int& ppos,
+                                            bool& first) {
+    pos = a.t;
+    const bool rev = (a.rev_mask >> d) & 1;
+    if (a.lengths) {
+        const int len = a.lengths[r];
+        if (a.t >= len) return false;
+        if (rev) pos = len - 1 - a.t;
+    }
+    ppos = rev ? pos + 1 : pos - 1;
+    first = (a.t == 0);
+    return true;
+}
+
+__device__ __forceinline__ float4 gru_hprev(const GruBwdArgs& a, long ro, int d, long r, int ppos,
+                                            bool first, int j) {
+    if (first) {
+        if (a.h0) return *reinterpret_cast<const float4*>(a.h0 + ro * a.H + j);
+        return make_float4(0, 0, 0, 0);
+    }
+    return *reinterpret_cast<const float4*>(a.hseq + d * a.hs_dir + r * a.hs_row + (long)ppos * a.hs_time + j);
+}
+
+__global__ void gru_blend_bwd_kernel(GruBwdArgs a) {
+    const int d = blockIdx.z;
+    const long r = blockIdx.y;
+    const int j = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (j >= a.H) return;
+    const long ro = (long)d * a.R + r;
+    int pos, ppos;
+    bool first;
+    const bool live = gru_bwd_pos(a, (int)r, d, pos, ppos, first);
+    const float4 z = make_float4(0, 0, 0, 0);
+    if (!live) {                       // state was copied through: dh unchanged, no parameter gradient
+        *reinterpret_cast<float4*>(a.dcpre + ro * a.H + j) = z;
+        *reinterpret_cast<float4*>(a.dgpre + ro * 2 * a.H + a.H + j) = z;
+        return;
+    }
+    float4 dh = *reinterpret_cast<float4*>(a.dh + ro * a.H + j);
+    if (a.dout) {
+        const float4 o = *reinterpret_cast<const float4*>(a.dout + d * a.do_dir + r * a.do_row +
+                                                          (long)pos * a.do_time + j);
+        dh.x += o.x; dh.y += o.y; dh.z += o.z; dh.w += o.w;
+    }
+    const float4 u = *reinterpret_cast<const float4*>(a.ru + ro * 2 * a.H + a.H + j);
+    const float4 c = *reinterpret_cast<const float4*>(a.c + ro * a.H + j);
+    const float4 hp = gru_hprev(a, ro, d, r, ppos, first, j);
+    float4 dcp, dup, dhd;
+#define NM_BL(f)                                           \
+    {                                                      \
+        const float dc = dh.f * (1.0f - u.f);              \
+        const float du = dh.f * (hp.f - c.f);              \
+        dcp.f = dc * (1.0f - c.f * c.f);                   \
+        dup.f = du * u.f * (1.0f - u.f);                   \
+        dhd.f = dh.f * u.f;                                \
+    }
+    NM_BL(x) NM_BL(y) NM_BL(z) NM_BL(w)
+#undef NM_BL
+    *reinterpret_cast<float4*>(a.dh + ro * a.H + j) = dhd;
+    *reinterpret_cast<float4*>(a.dcpre + ro * a.H + j) = dcp;
+    *reinterpret_cast<float4*>(a.dgpre + ro * 2 * a.H + a.H + j) = dup;
+    float* dx = a.dxp + d * a.dx_dir + r * a.dx_row + (long)pos * a.dx_time;
+    *reinterpret_cast<float4*>(dx + a.H + j) = dup;
+    *reinterpret_cast<float4*>(dx + 2 * a.H + j) = dcp;
+}
+
+__global__ void gru_gates_bwd_kernel(GruBwdArgs a) {
+    const int d = blockIdx.z;
+    const long r = blockIdx.y;
+    const int j = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (j >= a.H) return;
+    const long ro = (long)d * a.R + r;
+    int pos, ppos;
+    bool first;
+    const bool live = gru_bwd_pos(a, (int)r, d, pos, ppos, first);
+    if (!live) {
+        *reinterpret_cast<float4*>(a.dgpre + ro * 2 * a.H + j) = make_float4(0, 0, 0, 0);
+        return;
+    }
+    const float4 rr = *reinterpret_cast<const float4*>(a.ru + ro * 2 * a.H + j);
+    const float4 hp = gru_hprev(a, ro, d, r, ppos, first, j);
+    const float4 drh = *reinterpret_cast<const float4*>(a.drh + ro * a.H + j);
+    float4 dh = *reinterpret_cast<float4*>(a.dh + ro * a.H + j);
+    float4 drp;
+#define NM_GT(f)                                           \
+    {                                                      \
+        const float dr = drh.f * hp.f;                     \
+        drp.f = dr * rr.f * (1.0f - rr.f);                 \
+        dh.f += drh.f * rr.f;                              \
+    }
+    NM_GT(x) NM_GT(y) NM_GT(z) NM_GT(w)
+#undef NM_GT
+    *reinterpret_cast<float4*>(a.dh + ro * a.H + j) = dh;
+    *reinterpret_cast<float4*>(a.dgpre + ro * 2 * a.H + j) = drp;
+    float* dx = a.dxp + d * a.dx_dir + r * a.dx_row + (long)pos * a.dx_time;
+    *reinterpret_cast<float4*>(dx + j) = drp;
+}
+
+extern "C" int nm_gru_step_bwd(void* stream, int phase, float* dh, const float* dout, int64_t do_dir,
+                               int64_t do_row, int64_t do_time, const float* ru, const float* c,
+                               const float* h0, const float* hseq, int64_t hs_dir, int64_t hs_row,
+                               int64_t hs_time, float* dxp, int64_t dx_dir, int64_t dx_row,
+                               int64_t dx_time, float* dgpre, float* dcpre, const float* drh,
+                               const int32_t* lengths, int t, int rev_mask, int ndir, int64_t R,
+                               int64_t H) {
+    NM_REQUIRE(dh && ru && hseq && dxp && dgpre, "nm_gru_step_bwd: null pointer");
+    NM_REQUIRE(phase == 0 || phase == 1, "nm_gru_step_bwd: phase must be 0 (blend) or 1 (gates)");
+    NM_REQUIRE((phase == 0 && c && dcpre) || (phase == 1 && drh), "nm_gru_step_bwd: missing operand");
+    NM_REQUIRE(H > 0 && H % 4 == 0 && R > 0 && ndir >= 1 && ndir <= 2, "nm_gru_step_bwd: bad shape");
+    NM_REQUIRE(do_dir % 4 == 0 && do_row % 4 == 0 && do_time % 4 == 0 && hs_dir % 4 == 0 &&
+                   hs_row % 4 == 0 && hs_time % 4 == 0 && dx_dir % 4 == 0 && dx_row % 4 == 0 &&
+                   dx_time % 4 == 0,
+               "nm_gru_step_bwd: strides must be multiples of 4");
+    GruBwdArgs a;
+    a.dh = dh; a.dout = dout; a.do_dir = do_dir; a.do_row = do_row; a.do_time = do_time;
+    a.ru = ru; a.c = c; a.h0 = h0; a.hseq = hseq; a.hs_dir = hs_dir; a.hs_row = hs_row; a.hs_time = hs_time;
+    a.dxp = dxp; a.dx_dir = dx_dir; a.dx_row = dx_row; a.dx_time = dx_time;
+    a.dgpre = dgpre; a.dcpre = dcpre; a.drh = drh; a.lengths = lengths; a.t = t; a.rev_mask = rev_mask;
+    a.R = R; a.H = (int)H;
+    const int tpb = 128;
+    dim3 grid(nm_cdiv(H, 4 * tpb), (unsigned)R, ndir);
+    if (phase == 0) hipLaunchKernelGGL(gru_blend_bwd_kernel, grid, dim3(tpb), 0, nm_stream(stream), a);
+    else hipLaunchKernelGGL(gru_gates_bwd_kernel, grid, dim3(tpb), 0, nm_stream(stream), a);
+    NM_LAUNCH_CHECK("nm_gru_step_bwd");
+}
+
+// h_prev of every sequence position as a dense [B,S,ndir,H] tensor (operand of
+// the recurrent-kernel weight gradient h_prev^T . dpre): position p of
+// direction d holds the output at p-1 (forward) / p+1 (reversed), zero at the
+// start of travel and at dead positions.
+__global__ void gru_seq_shift_kernel(const float* __restrict__ seq, float* __restrict__ out,
+                                     const int* __restrict__ lengths, int rev_mask, int S, int ndir, int H) {
+    const int b = blockIdx.z, p = blockIdx.y;
+    const int col = (blockIdx.x * blockDim.x + threadIdx.x) * 4;   // over ndir*H
+    if (col >= ndir * H) return;
+    const int d = col / H;
+    const int len = lengths ? lengths[b] : S;
+    const bool rev = (rev_mask >> d) & 1;
+    const int pp = rev ? p + 1 : p - 1;
+    float4 v = make_float4(0, 0, 0, 0);
+    if (p < len && pp >= 0 && pp < len)
+        v = *reinterpret_cast<const float4*>(seq + ((long)b * S + pp) * ndir * H + col);
+    *reinterpret_cast<float4*>(out + ((long)b * S + p) * ndir * H + col) = v;
+}
+
+extern "C" int nm_gru_seq_shift(void* stream, const float* seq, float* out, const int32_t* lengths,
+                                int rev_mask, int64_t B, int64_t S, int ndir, int64_t H) {
+    NM_REQUIRE(seq && out && B > 0 && S > 0 && H % 4 == 0, "nm_gru_seq_shift: bad args");
+    hipLaunchKernelGGL(gru_seq_shift_kernel, dim3(nm_cdiv(ndir * H, 1024), (unsigned)S, (unsigned)B),
+                       dim3(256), 0, nm_stream(stream), seq, out, lengths, rev_mask, (int)S, ndir, (int)H);
+    NM_LAUNCH_CHECK("nm_gru_seq_shift");
+}
+
+// ---------------------------------------------------------------------------
+// attention backward, batched over all T decoder steps (rows = (t,b)).
+// (1) softmax + mask-renorm backward (attention/feed_forward.py:139-144):
+//     p = softmax(e); N = sum(p*m) + 1e-8; w = p*m/N
+//     dp = m/N * (dw - sum(dw*w)) ; de = p * (dp - sum(dp*p))
+// One wave per row.
+// ---------------------------------------------------------------------------
+__global__ void attn_softmax_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ e,
+                                        const float* __restrict__ mask, float* __restrict__ de,
+                                        long rows, int B, int S) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int b = (int)(row % B);
+    const float* er = e + row * S;
+    const float* dwr = dw + row * S;
+    const float* mr = mask ? mask + (long)b * S : nullptr;
+    float mx = -INFINITY;
+    for (int s = lane; s < S; s += 64) mx = fmaxf(mx, er[s]);
+    mx = nm_wave_max(mx);
+    float se = 0.0f, sm = 0.0f;
+    for (int s = lane; s < S; s += 64) {
+        const float x = __expf(er[s] - mx);
+        se += x;
+        sm += x * (mr ? mr[s] : 1.0f);
+    }
+    se = nm_wave_sum(se);
+    sm = nm_wave_sum(sm);
+    const float inv_se = 1.0f / se;
+    const float N = sm * inv_se + 1e-8f;
+    const float invN = 1.0f / N;
+    float sdw = 0.0f;
+    for (int s = lane; s < S; s += 64) {
+        const float p = __expf(er[s] - mx) * inv_se;
+        const float w = p * (mr ? mr[s] : 1.0f) * invN;
+        sdw += dwr[s] * w;
+    }
+    sdw = nm_wave_sum(sdw);
+    float sdp = 0.0f;
+    for (int s = lane; s < S; s += 64) {
+        const float p = __expf(er[s] - mx) * inv_se;
+        const float dp = (mr ? mr[s] : 1.0f) * invN * (dwr[s] - sdw);
+        sdp += dp * p;
+    }
+    sdp = nm_wave_sum(sdp);
+    for (int s = lane; s < S; s += 64) {
+        const float p = __expf(er[s] - mx) * inv_se;
+        const float dp = (mr ? mr[s] : 1.0f) * invN * (dwr[s] - sdw);
+        de[row * S + s] = p * (dp - sdp);
+    }
+}
+
+extern "C" int nm_attn_softmax_bwd(void* stream, const float* dw, const float* e, const float* mask,
+                                   float* de, int64_t rows, int64_t B, int64_t S) {
+    NM_REQUIRE(dw && e && de && rows >= 0 && B > 0 && S > 0, "nm_attn_softmax_bwd: bad args");
+    if (rows == 0) return NM_OK;
+    hipLaunchKernelGGL(attn_softmax_bwd_kernel, dim3(nm_cdiv(rows, 4)), dim3(256), 0, nm_stream(stream), dw,
+                       e, mask, de, (long)rows, (int)B, (int)S);
+    NM_LAUNCH_CHECK("nm_attn_softmax_bwd");
+}
+
+// (2) energies backward (feed_forward.py:120-123), tanh recomputed:
+//     z = tanh(hf[b,s,a] + y[t,b,a]) ; g = de[t,b,s] * (1 - z^2)
+//     dhf[b,s,a] = v[a] * sum_t g        dvp[(b,s),a] = sum_t de * z
+//     dy[t,b,a]  = v[a] * sum_s g
+// Two register-only kernels (tanh evaluated twice, ~0.1 ms at the benchmark
+// shape) instead of one kernel with T*A accumulators in LDS.
+__global__ void attn_dhf_kernel(const float* __restrict__ de, const float* __restrict__ hf,
+                                const float* __restrict__ y, const float* __restrict__ v,
+                                float* __restrict__ dhf, float* __restrict__ dvp, int T, int B, int S,
+                                int A) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = blockIdx.y, b = blockIdx.z;
+    if (a >= A) return;
+    const float h = hf[((long)b * S + s) * A + a];
+    float acc = 0.0f, accv = 0.0f;
+    for (int t = 0; t < T; ++t) {
+        const float d = de[((long)t * B + b) * S + s];
+        const float z = nm_tanh(h + y[((long)t * B + b) * A + a]);
+        acc += d * (1.0f - z * z);
+        accv += d * z;
+    }
+    dhf[((long)b * S + s) * A + a] = v[a] * acc;
+    dvp[((long)b * S + s) * A + a] = accv;
+}
+
+__global__ void attn_dy_kernel(const float* __restrict__ de, const float* __restrict__ hf,
+                               const float* __restrict__ y, const float* __restrict__ v,
+                               float* __restrict__ dy, int T, int B, int S, int A) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.y, b = blockIdx.z;
+    if (a >= A) return;
+    const float yy = y[((long)t * B + b) * A + a];
+    const float* der = de + ((long)t * B + b) * S;
+    float acc = 0.0f;
+    for (int s = 0; s < S; ++s) {
+        const float z = nm_tanh(hf[((long)b * S + s) * A + a] + yy);
+        acc += der[s] * (1.0f - z * z);
+    }
+    dy[((long)t * B + b) * A + a] = v[a] * acc;
+}
+
+extern "C" int nm_attn_energy_bwd(void* stream, const float* de, const float* hf, const float* y,
+                                  const float* v, float* dhf, float* dv_partial, float* dy, int64_t T,
+                                  int64_t B, int64_t S, int64_t A) {
+    NM_REQUIRE(de && hf && y && v && dhf && dv_partial && dy, "nm_attn_energy_bwd: null pointer");
+    NM_REQUIRE(T > 0 && B > 0 && S > 0 && A > 0 && S < 65536 && B < 65536 && T < 65536,
+               "nm_attn_energy_bwd: bad shape");
+    hipStream_t st = nm_stream(stream);
+    hipLaunchKernelGGL(attn_dhf_kernel, dim3(nm_cdiv(A, 256), (unsigned)S, (unsigned)B), dim3(256), 0, st, de,
+                       hf, y, v, dhf, dv_partial, (int)T, (int)B, (int)S, (int)A);
+    hipLaunchKernelGGL(attn_dy_kernel, dim3(nm_cdiv(A, 256), (unsigned)T, (unsigned)B), dim3(256), 0, st, de,
+                       hf, y, v, dy, (int)T, (int)B, (int)S, (int)A);
+    NM_LAUNCH_CHECK("nm_attn_energy_bwd");
+}
+
+// r*h_prev of every sequence position, position-major [B,S,ndir,H] (operand of
+// the candidate-kernel weight gradient (r*h_prev)^T . dc_pre).  ru_all is
+// step-major [S,ndir,B,2H]; the step that visited position p is p (forward) or
+// L-1-p (reversed).
+__global__ void gru_rh_seq_kernel(const float* __restrict__ ru_all, const float* __restrict__ hprev,
+                                  float* __restrict__ out, const int* __restrict__ lengths, int rev_mask,
+                                  int B, int S, int ndir, int H) {
+    const int b = blockIdx.z, p = blockIdx.y;
+    const int col = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (col >= ndir * H) return;
+    const int d = col / H, j = col - d * H;
+    const int len = lengths ? lengths[b] : S;
+    float4 v = make_float4(0, 0, 0, 0);
+    if (p < len) {
+        const int t = ((rev_mask >> d) & 1) ? len - 1 - p : p;
+        const float4 r = *reinterpret_cast<const float4*>(ru_all + (((long)t * ndir + d) * B + b) * 2 * H + j);
+        const float4 h = *reinterpret_cast<const float4*>(hprev + ((long)b * S + p) * ndir * H + col);
+        v = make_float4(r.x * h.x, r.y * h.y, r.z * h.z, r.w * h.w);
+    }
+    *reinterpret_cast<float4*>(out + ((long)b * S + p) * ndir * H + col) = v;
+}
+
+extern "C" int nm_gru_rh_seq(void* stream, const float* ru_all, const float* hprev, float* out,
+                             const int32_t* lengths, int rev_mask, int64_t B, int64_t S, int ndir,
+                             int64_t H) {
+    NM_REQUIRE(ru_all && hprev && out && B > 0 && S > 0 && H % 4 == 0, "nm_gru_rh_seq: bad args");
+    hipLaunchKernelGGL(gru_rh_seq_kernel, dim3(nm_cdiv(ndir * H, 1024), (unsigned)S, (unsigned)B), dim3(256),
+                       0, nm_stream(stream), ru_all, hprev, out, lengths, rev_mask, (int)B, (int)S, ndir,
+                       (int)H);
+    NM_LAUNCH_CHECK("nm_gru_rh_seq");
+}

@@ -1,0 +1,154 @@
+// Trainer arithmetic over the flat parameter / gradient buffers
+// (trainers/generic_trainer.py:84-195):
+//   L1 = sum |v|, L2 = sum v^2 over non-bias variables            (:84-105)
+//   grad += l1_weight*sign(v) + 2*l2_weight*v                     (d/dv of :118-134)
+//   per-tensor tf.clip_by_norm: g * c / max(||g||, c)              (:179-186)
+//   Adam (tf.train.AdamOptimizer, :55-57): lr_t = lr*sqrt(1-b2^t)/(1-b1^t)
+// All variables live in one flat buffer (variables.py); a host-built chunk
+// table maps fixed-size chunks to variables ("segments") so that three launches
+// cover every tensor and all reductions have a fixed order (deterministic).
+#include "nm_common.h"
+
+struct OptChunks {
+    const long* chunk_start;   // [nchunk] flat offset
+    const int* chunk_len;      // [nchunk]
+    const int* chunk_seg;      // [nchunk]
+    const int* seg_first;      // [nseg] first chunk
+    const int* seg_count;      // [nseg] chunks
+    const int* seg_flags;      // [nseg] bit0 regularizable, bit1 trainable
+    int nchunk, nseg;
+};
+
+// pass 1: regulariser terms + squared gradient norm partials per chunk
+__global__ __launch_bounds__(256) void opt_reg_sumsq_kernel(OptChunks t, const float* __restrict__ theta,
+                                                            float* __restrict__ grad, float l1w, float l2w,
+                                                            float* __restrict__ partial) {
+    __shared__ float sh[3][4];
+    const int c = blockIdx.x;
+    const long base = t.chunk_start[c];
+    const int len = t.chunk_len[c];
+    const int flags = t.seg_flags[t.chunk_seg[c]];
+    const bool reg = flags & 1;
+    float gs = 0.0f, a1 = 0.0f, a2 = 0.0f;
+    for (int i = threadIdx.x; i < len; i += 256) {
+        const float th = theta[base + i];
+        float g = grad[base + i];
+        if (reg) {
+            a1 += fabsf(th);
+            a2 += th * th;
+            const float sg = (th > 0.0f) ? 1.0f : ((th < 0.0f) ? -1.0f : 0.0f);
+            g += l1w * sg + 2.0f * l2w * th;
+            grad[base + i] = g;
+        }
+        gs += g * g;
+    }
+    gs = nm_wave_sum(gs); a1 = nm_wave_sum(a1); a2 = nm_wave_sum(a2);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[0][w] = gs; sh[1][w] = a1; sh[2][w] = a2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[c * 3 + 0] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+        partial[c * 3 + 1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+        partial[c * 3 + 2] = sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3];
+    }
+}
+
+// pass 2: per-segment gradient norms; global L1 / L2 (fixed order)
+__global__ void opt_seg_reduce_kernel(OptChunks t, const float* __restrict__ partial,
+                                      float* __restrict__ seg_norm2, float* __restrict__ l1l2) {
+    // one thread per segment (fixed chunk order), then thread 0 adds the segments in order
+    extern __shared__ float seg_l[];          // [2][nseg]
+    for (int s = threadIdx.x; s < t.nseg; s += blockDim.x) {
+        float gs = 0.0f, a1 = 0.0f, a2 = 0.0f;
+        for (int c = t.seg_first[s]; c < t.seg_first[s] + t.seg_count[s]; ++c) {
+            gs += partial[c * 3 + 0];
+            a1 += partial[c * 3 + 1];
+            a2 += partial[c * 3 + 2];
+        }
+        seg_norm2[s] = gs;
+        seg_l[s] = a1;
+        seg_l[t.nseg + s] = a2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float l1 = 0.0f, l2 = 0.0f;
+        for (int s = 0; s < t.nseg; ++s) { l1 += seg_l[s]; l2 += seg_l[t.nseg + s]; }
+        l1l2[0] = l1;
+        l1l2[1] = l2;
+    }
+}
+
+// pass 3: clip per tensor + Adam
+__global__ __launch_bounds__(256) void opt_adam_kernel(OptChunks t, float* __restrict__ theta,
+                                                       const float* __restrict__ grad,
+                                                       float* __restrict__ m, float* __restrict__ v,
+                                                       const float* __restrict__ seg_norm2, float clip,
+                                                       float lr_t, float b1, float b2, float eps) {
+    const int c = blockIdx.x;
+    const int seg = t.chunk_seg[c];
+    if (!(t.seg_flags[seg] & 2)) return;
+    const long base = t.chunk_start[c];
+    const int len = t.chunk_len[c];
+    float scale = 1.0f;
+    if (clip > 0.0f) scale = clip / fmaxf(sqrtf(seg_norm2[seg]), clip);
+    for (int i = threadIdx.x; i < len; i += 256) {
+        const float g = grad[base + i] * scale;
+        const float mm = b1 * m[base + i] + (1.0f - b1) * g;
+        const float vv = b2 * v[base + i] + (1.0f - b2) * g * g;
+        m[base + i] = mm;
+        v[base + i] = vv;
+        theta[base + i] -= lr_t * mm / (sqrtf(vv) + eps);
+    }
+}
+
+static OptChunks make_chunks(const int64_t* chunk_start, const int32_t* chunk_len, const int32_t* chunk_seg,
+                             const int32_t* seg_first, const int32_t* seg_count, const int32_t* seg_flags,
+                             int64_t nchunk, int64_t nseg) {
+    OptChunks t;
+    t.chunk_start = reinterpret_cast<const long*>(chunk_start);
+    t.chunk_len = chunk_len; t.chunk_seg = chunk_seg; t.seg_first = seg_first; t.seg_count = seg_count;
+    t.seg_flags = seg_flags; t.nchunk = (int)nchunk; t.nseg = (int)nseg;
+    return t;
+}
+
+// workspace: partial[nchunk*3] + seg_norm2[nseg]  (floats)
+extern "C" int64_t nm_optim_workspace_bytes(int64_t nchunk, int64_t nseg) { return (nchunk * 3 + nseg) * 4; }
+
+extern "C" int nm_optim_regularize_norms(void* stream, const float* theta, float* grad,
+                                         const int64_t* chunk_start, const int32_t* chunk_len,
+                                         const int32_t* chunk_seg, const int32_t* seg_first,
+                                         const int32_t* seg_count, const int32_t* seg_flags, int64_t nchunk,
+                                         int64_t nseg, float l1_weight, float l2_weight, float* l1l2_out,
+                                         void* workspace, int64_t workspace_bytes) {
+    NM_REQUIRE(theta && grad && chunk_start && chunk_len && chunk_seg && seg_first && seg_count &&
+                   seg_flags && l1l2_out && workspace,
+               "nm_optim_regularize_norms: null pointer");
+    NM_REQUIRE(nchunk > 0 && nseg > 0 && workspace_bytes >= nm_optim_workspace_bytes(nchunk, nseg),
+               "nm_optim_regularize_norms: bad sizes");
+    OptChunks t = make_chunks(chunk_start, chunk_len, chunk_seg, seg_first, seg_count, seg_flags, nchunk, nseg);
+    float* partial = reinterpret_cast<float*>(workspace);
+    float* seg_norm2 = partial + nchunk * 3;
+    hipStream_t st = nm_stream(stream);
+    hipLaunchKernelGGL(opt_reg_sumsq_kernel, dim3((unsigned)nchunk), dim3(256), 0, st, t, theta, grad,
+                       l1_weight, l2_weight, partial);
+    NM_REQUIRE(nseg <= 8192, "nm_optim_regularize_norms: too many variables");
+    hipLaunchKernelGGL(opt_seg_reduce_kernel, dim3(1), dim3(256), (size_t)nseg * 2 * sizeof(float), st, t,
+                       partial, seg_norm2, l1l2_out);
+    NM_LAUNCH_CHECK("nm_optim_regularize_norms");
+}
+
+extern "C" int nm_optim_clip_adam(void* stream, float* theta, const float* grad, float* m, float* v,
+                                  const int64_t* chunk_start, const int32_t* chunk_len,
+                                  const int32_t* chunk_seg, const int32_t* seg_first, const int32_t* seg_count,
+                                  const int32_t* seg_flags, int64_t nchunk, int64_t nseg, float clip_norm,
+                                  float lr_t, float beta1, float beta2, float epsilon, void* workspace,
+                                  int64_t workspace_bytes) {
+    NM_REQUIRE(theta && grad && m && v && workspace, "nm_optim_clip_adam: null pointer");
+    NM_REQUIRE(nchunk > 0 && nseg > 0 && workspace_bytes >= nm_optim_workspace_bytes(nchunk, nseg),
+               "nm_optim_clip_adam: bad sizes");
+    OptChunks t = make_chunks(chunk_start, chunk_len, chunk_seg, seg_first, seg_count, seg_flags, nchunk, nseg);
+    const float* seg_norm2 = reinterpret_cast<const float*>(workspace) + nchunk * 3;
+    hipLaunchKernelGGL(opt_adam_kernel, dim3((unsigned)nchunk), dim3(256), 0, nm_stream(stream), t, theta,
+                       grad, m, v, seg_norm2, clip_norm, lr_t, beta1, beta2, epsilon);
+    NM_LAUNCH_CHECK("nm_optim_clip_adam");
+}

@@ -189,14 +189,15 @@ class Decoder(AutoregressiveDecoder):
         ops.gemm(emb, cell["wg_x"], out=xp[:, :2 * h], bias=cell["bg"])
         ops.gemm(emb, cell["wc_x"], out=xp[:, 2 * h:], bias=cell["bc"])
 
-    def _recurrent(self, ctx, cell, xp, t_index, x_time_stride, h_prev, h_out, ru, c_save, bufs):
+    def _recurrent(self, ctx, cell, xp, t_index, x_time_stride, h_prev, h_out, ru, c_save, bufs, rh=None):
         """State half of the GRU + fused epilogues: h_out = GRU(x_t, h_prev)."""
         h = self.rnn_size
         rows = h_prev.shape[0]
+        rh = bufs["rh"] if rh is None else rh
         ops.gemm(h_prev, cell["wg_h"], out=bufs["hg"])
-        ops.gru_gates_fwd(xp, 0, 3 * h, x_time_stride, bufs["hg"], h_prev, ru, bufs["rh"], None,
+        ops.gru_gates_fwd(xp, 0, 3 * h, x_time_stride, bufs["hg"], h_prev, ru, rh, None,
                           t_index, 1, rows, h)
-        ops.gemm(bufs["rh"], cell["wc_h"], out=bufs["hc"])
+        ops.gemm(rh, cell["wc_h"], out=bufs["hc"])
         ops.gru_blend_fwd(xp, 0, 3 * h, x_time_stride, bufs["hc"], ru, h_prev, h_out, c_save, None,
                           0, 0, 0, None, t_index, 1, rows, h)
 
@@ -252,18 +253,22 @@ class Decoder(AutoregressiveDecoder):
         self._input_projection(ctx, cell, emb_all.view(rows, e), xp)
 
         s0 = self.initial_state(ctx)
-        s_all = ctx.buffer(key + ("s_all",), (steps, bsz, h))
+        s_ext = ctx.buffer(key + ("s_ext",), (steps + 1, bsz, h))      # [s0 ; s_1 .. s_T]
+        s_ext[0].copy_(s0)
+        s_all = s_ext[1:]
         ru_all = ctx.buffer(key + ("ru_all",), (steps, bsz, 2 * h))
         c_all = ctx.buffer(key + ("c_all",), (steps, bsz, h))
+        rh_all = ctx.buffer(key + ("rh_all",), (steps, bsz, h))
         bufs = self._step_bufs(ctx, bsz)
         att_states = [a.initial_loop_state(ctx, bsz, steps) for a in self.attentions]
         y_all = [ctx.buffer(key + ("y", i), (steps, bsz, a.state_size)) for i, a in enumerate(self.attentions)]
+        e_all = [ctx.buffer(key + ("e", i), (steps, bsz, st.weights.shape[2])) for i, st in enumerate(att_states)]
         for t in range(steps):
-            h_prev = s0 if t == 0 else s_all[t - 1]
-            self._recurrent(ctx, cell, xp, t, bsz * 3 * h, h_prev, s_all[t], ru_all[t], c_all[t], bufs)
+            self._recurrent(ctx, cell, xp, t, bsz * 3 * h, s_ext[t], s_all[t], ru_all[t], c_all[t], bufs,
+                            rh=rh_all[t])
             for i, att in enumerate(self.attentions):
                 att.attention_into(ctx, s_all[t], y_all[i][t], att_states[i].contexts[t],
-                                   att_states[i].weights[t])
+                                   att_states[i].weights[t], e_all[i][t])
         att_states = [AttentionLoopState(st.contexts, st.weights, steps) for st in att_states]
 
         out_all = ctx.buffer(key + ("out",), (rows, self.output_dimension))
@@ -277,10 +282,107 @@ class Decoder(AutoregressiveDecoder):
         ops.reduce_sum(loss_rows, loss_sum)
         for att, st in zip(self.attentions, att_states):
             att.finalize_loop("{}_train".format(self.name), st)
-        saved = {"emb_all": emb_all, "xp": xp, "s0": s0, "s_all": s_all, "ru_all": ru_all,
-                 "c_all": c_all, "y_all": y_all, "att_states": att_states, "out_all": out_all,
+        saved = {"emb_all": emb_all, "xp": xp, "s0": s0, "s_all": s_all, "s_ext": s_ext, "ru_all": ru_all,
+                 "c_all": c_all, "rh_all": rh_all, "y_all": y_all, "e_all": e_all,
+                 "att_states": att_states, "out_all": out_all,
                  "dlogits": logits if want_grad else None, "cell": cell, "steps": steps, "bsz": bsz}
         return TrainResult(loss_sum, self.train_token_count(ctx), steps, saved)
+
+    def backward(self, ctx, res: TrainResult) -> None:
+        """Back-propagate the teacher-forced loss (dlogits already in place) into
+        ``ctx.store.grad`` and on into the attentions and encoders."""
+        store = ctx.store
+        sv = res.saved
+        steps, bsz = sv["steps"], sv["bsz"]
+        rows = steps * bsz
+        e, h, v = self.embedding_size, self.rnn_size, len(self.vocabulary)
+        key = (id(self), "bwd")
+        cell = sv["cell"]
+        dlogits, out_all = sv["dlogits"], sv["out_all"]
+        emb2 = sv["emb_all"].view(rows, e)
+        s2 = sv["s_all"].reshape(rows, h)
+        odim = self.output_dimension
+
+        # ---- logits = out . W + b  (autoregressive.py:450-459)
+        d_out = ctx.buffer(key + ("d_out",), (rows, odim))
+        if self.tie_embeddings:
+            emat = self.embedding_matrix(ctx)
+            ops.gemm(dlogits, out_all, out=store.g(self.embedding_matrix_name), trans_a=True, accumulate=True)
+            ops.gemm(dlogits, emat, out=d_out)
+        else:
+            ops.gemm(out_all, dlogits, out=store.g(self.var_name("state_to_word_W")), trans_a=True)
+            ops.colsum(dlogits, store.g(self.var_name("state_to_word_b")))
+            ops.gemm(dlogits, self.var(ctx, "state_to_word_W"), out=d_out, trans_b=True)
+
+        # ---- output projection: out = act([s | emb | ctx...] . Wo + bo)
+        proj = self.output_projection
+        if proj.activation == "tanh":
+            ops.tanh_bwd(d_out, out_all)
+        elif proj.activation != "identity":
+            raise NotImplementedError("backward of activation {}".format(proj.activation))
+        wo = proj.kernel(ctx, self)
+        g_wo = store.g(self.var_name("attention_decoder/{}/kernel".format(proj.scope)))
+        ops.colsum(d_out, store.g(self.var_name("attention_decoder/{}/bias".format(proj.scope))))
+        ctx_all = [st.contexts.view(rows, -1) for st in sv["att_states"]]
+        d_s = ctx.buffer(key + ("d_s",), (rows, h))
+        d_emb = ctx.buffer(key + ("d_emb",), (rows, e))
+        d_ctx = [ctx.buffer(key + ("d_ctx", i), (rows, c.shape[1])) for i, c in enumerate(ctx_all)]
+        row = 0
+        for x, dx, sz in zip([s2, emb2] + ctx_all, [d_s, d_emb] + d_ctx, proj.sizes):
+            ops.gemm(x, d_out, out=g_wo[row:row + sz], trans_a=True)
+            ops.gemm(d_out, wo[row:row + sz], out=dx, trans_b=True)
+            row += sz
+
+        # ---- attentions (batched over time); adds the query path into d_s
+        d_att_states = []
+        for i, att in enumerate(self.attentions):
+            st = sv["att_states"][i]
+            d_att_states.append(att.backward(ctx, d_ctx[i].view(steps, bsz, -1), sv["s_all"], sv["y_all"][i],
+                                             st.weights, sv["e_all"][i], d_s))
+
+        # ---- BPTT through the GRU (the only recurrence)
+        dh = ctx.buffer(key + ("dh",), (1, bsz, h), zero=True)
+        dxp = ctx.buffer(key + ("dxp",), (rows, 3 * h))
+        dgpre = ctx.buffer(key + ("dgpre",), (1, bsz, 2 * h))
+        dcpre = ctx.buffer(key + ("dcpre",), (1, bsz, h))
+        drh = ctx.buffer(key + ("drh",), (1, bsz, h))
+        s_all = sv["s_all"]
+        seq_strides = (0, h, bsz * h)
+        dxp_strides = (0, 3 * h, bsz * 3 * h)
+        for t in range(steps - 1, -1, -1):
+            ops.gru_step_bwd(0, dh, d_s, seq_strides, sv["ru_all"][t], sv["c_all"][t], sv["s0"], s_all,
+                             seq_strides, dxp, dxp_strides, dgpre, dcpre, None, None, t, 1, bsz, h)
+            ops.gemm(dcpre[0], cell["wc_h"], out=drh[0], trans_b=True)
+            ops.gru_step_bwd(1, dh, None, None, sv["ru_all"][t], None, sv["s0"], s_all, seq_strides, dxp,
+                             dxp_strides, dgpre, None, drh, None, t, 1, bsz, h)
+            ops.gemm(dgpre[0], cell["wg_h"], out=dh[0], trans_b=True, accumulate=True)
+        ds0 = dh[0]
+
+        # ---- GRU weight gradients, batched over all steps
+        pre = "attention_decoder/OrthoGRUCell"
+        g_wg, g_wc = store.g(self.var_name(pre + "/gates/kernel")), store.g(self.var_name(pre + "/candidate/kernel"))
+        dg_all, dc_all = dxp[:, :2 * h], dxp[:, 2 * h:]
+        s_prev = sv["s_ext"][:steps].reshape(rows, h)
+        ops.gemm(emb2, dg_all, out=g_wg[:e], trans_a=True)
+        ops.gemm(s_prev, dg_all, out=g_wg[e:], trans_a=True)
+        ops.gemm(emb2, dc_all, out=g_wc[:e], trans_a=True)
+        ops.gemm(sv["rh_all"].view(rows, h), dc_all, out=g_wc[e:], trans_a=True)
+        ops.colsum(dg_all, store.g(self.var_name(pre + "/gates/bias")))
+        ops.colsum(dc_all, store.g(self.var_name(pre + "/candidate/bias")))
+        ops.gemm(dg_all, cell["wg_x"], out=d_emb, trans_b=True, accumulate=True)
+        ops.gemm(dc_all, cell["wc_x"], out=d_emb, trans_b=True, accumulate=True)
+        ops.embedding_scatter_add(store.g(self.embedding_matrix_name), self._dec_input_ids(ctx).reshape(-1),
+                                  d_emb)
+
+        # ---- initial state projection and the encoders
+        d_enc_out = self.encoder_projection.backward(ctx, self, self.rnn_size, self.encoders, ds0)
+        enc_grads = {}
+        for att, dst in zip(self.attentions, d_att_states):
+            enc_grads.setdefault(att.encoder, [None, None])[0] = dst
+        for enc, dfin in zip(self.encoders, d_enc_out):
+            enc_grads.setdefault(enc, [None, None])[1] = dfin
+        for enc, (dst, dfin) in enc_grads.items():
+            enc.backward(ctx, dst, dfin)
 
     @tensor
     def train_loss(self, ctx) -> torch.Tensor:

@@ -19,6 +19,10 @@ class EncoderProjection:
     def apply(self, ctx, decoder, rnn_size, encoders, out, train_mode):
         raise NotImplementedError
 
+    def backward(self, ctx, decoder, rnn_size, encoders, d_state):
+        """Accumulate variable gradients; return dL/d(encoder.output) per encoder."""
+        return [None for _ in encoders]
+
 
 class _Empty(EncoderProjection):
     """empty_initial_state (encoder_projection.py:37-44): zeros, tiled to the batch."""
@@ -53,6 +57,14 @@ class _Concat(EncoderProjection):
             col += val.shape[1]
         return out
 
+    def backward(self, ctx, decoder, rnn_size, encoders, d_state):
+        grads, col = [], 0
+        for enc in encoders:
+            sz = enc.output_size
+            grads.append(d_state[:, col:col + sz].contiguous())
+            col += sz
+        return grads
+
 
 class _Linear(EncoderProjection):
     """linear_encoder_projection (encoder_projection.py:47-73):
@@ -81,6 +93,22 @@ class _Linear(EncoderProjection):
             ops.gemm(val, w[row:row + val.shape[1]], out=out, accumulate=i > 0, bias=b if last else None)
             row += val.shape[1]
         return dropout(ctx, out, self.dropout_keep_prob, train_mode)
+
+    def backward(self, ctx, decoder, rnn_size, encoders, d_state):
+        store = ctx.store
+        w = decoder.var(ctx, "initial_state/encoders_projection/kernel")
+        g_w = store.g(decoder.var_name("initial_state/encoders_projection/kernel"))
+        ops.colsum(d_state, store.g(decoder.var_name("initial_state/encoders_projection/bias")))
+        grads, row = [], 0
+        for i, enc in enumerate(encoders):
+            val = enc.output(ctx)
+            sz = val.shape[1]
+            ops.gemm(val, d_state, out=g_w[row:row + sz], trans_a=True)
+            d_val = ctx.buffer((id(self), "d_enc", i), tuple(val.shape))
+            ops.gemm(d_state, w[row:row + sz], out=d_val, trans_b=True)
+            grads.append(d_val)
+            row += sz
+        return grads
 
 
 empty_initial_state = _Empty()

@@ -11,7 +11,7 @@ GEMMs (both directions batched in one launch) with fused gate / blend
 epilogue kernels that implement the length masking and the reversed indexing
 of the backward direction in-kernel, so there is no reverse_sequence copy.
 """
-from typing import Callable, List, NamedTuple, Tuple, Union
+from typing import Callable, List, NamedTuple, Optional, Tuple, Union
 
 import torch
 
@@ -205,6 +205,87 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
         ops.layer_norm_fwd(final_raw, gamma, beta, out=final, mean=fi_mean, rstd=fi_rstd)
         saved.update(st_mean=st_mean, st_rstd=st_rstd, fi_mean=fi_mean, fi_rstd=fi_rstd)
         return EncoderActivations(states, final, saved)
+
+    def backward(self, ctx, d_states: Optional[torch.Tensor], d_final: Optional[torch.Tensor]) -> None:
+        """dL/d(temporal_states) [B,S,C] and dL/d(output) [B,C] -> variable
+        gradients of this encoder and of its input sequence."""
+        store = ctx.store
+        act = self.rnn(ctx)
+        sv = act.saved
+        x, xp, lengths = sv["x"], sv["xp"], sv["lengths"]
+        bsz, slen, e = x.shape
+        ndir, h, rev0 = sv["ndir"], sv["h"], sv["reverse_only"]
+        c_out = ndir * h
+        key = (id(self), "bwd")
+        states_raw, final_raw = sv["states_raw"], sv["final_raw"]
+
+        # ---- final layer norm (shared gamma/beta for states and final state)
+        if self.include_final_layer_norm:
+            gamma = self.var(ctx, "LayerNorm/gamma")
+            g_gamma, g_beta = store.g(self.var_name("LayerNorm/gamma")), store.g(self.var_name("LayerNorm/beta"))
+            d_states_raw = d_final_raw = None
+            if d_states is not None:
+                d_states_raw = ctx.buffer(key + ("d_states_raw",), (bsz, slen, c_out))
+                tmp = ctx.buffer(key + ("ln_tmp",), (bsz * slen, c_out))
+                ops.layer_norm_bwd(d_states, states_raw, sv["st_mean"], sv["st_rstd"], gamma, d_states_raw, tmp)
+                ops.colsum(tmp, g_gamma, accumulate=True)
+                ops.colsum(d_states.view(bsz * slen, c_out), g_beta, accumulate=True)
+            if d_final is not None:
+                d_final_raw = ctx.buffer(key + ("d_final_raw",), (bsz, c_out))
+                tmp2 = ctx.buffer(key + ("ln_tmp2",), (bsz, c_out))
+                ops.layer_norm_bwd(d_final, final_raw, sv["fi_mean"], sv["fi_rstd"], gamma, d_final_raw, tmp2)
+                ops.colsum(tmp2, g_gamma, accumulate=True)
+                ops.colsum(d_final, g_beta, accumulate=True)
+        else:
+            d_states_raw, d_final_raw = d_states, d_final
+
+        # ---- BPTT over the (bi)directional GRU
+        dh = ctx.buffer(key + ("dh",), (ndir, bsz, h), zero=True)
+        if d_final_raw is not None:
+            for d in range(ndir):
+                ops.copy_cols(d_final_raw[:, d * h:(d + 1) * h], dh[d])
+        dxp = ctx.buffer(key + ("dxp",), (bsz * slen, ndir * 3 * h), zero=True)
+        dgpre = ctx.buffer(key + ("dgpre",), (ndir, bsz, 2 * h))
+        dcpre = ctx.buffer(key + ("dcpre",), (ndir, bsz, h))
+        drh = ctx.buffer(key + ("drh",), (ndir, bsz, h))
+        seq_strides = (h, slen * c_out, c_out)
+        dxp_strides = (3 * h, slen * ndir * 3 * h, ndir * 3 * h)
+        wgh, wch = sv["wgh"], sv["wch"]
+        for t in range(slen - 1, -1, -1):
+            ops.gru_step_bwd(0, dh, d_states_raw, seq_strides if d_states_raw is not None else None,
+                             sv["ru_all"][t], sv["c_all"][t], None, states_raw, seq_strides, dxp, dxp_strides,
+                             dgpre, dcpre, None, lengths, t, ndir, bsz, h, reverse_dir0=rev0)
+            ops.gemm(dcpre, wch, out=drh, trans_b=True)
+            ops.gru_step_bwd(1, dh, None, None, sv["ru_all"][t], None, None, states_raw, seq_strides, dxp,
+                             dxp_strides, dgpre, None, drh, lengths, t, ndir, bsz, h, reverse_dir0=rev0)
+            ops.gemm(dgpre, wgh, out=dh, trans_b=True, accumulate=True)
+
+        # ---- weight gradients, batched over all positions
+        hprev = ctx.buffer(key + ("hprev",), (bsz, slen, ndir, h))
+        rh_seq = ctx.buffer(key + ("rh_seq",), (bsz, slen, ndir, h))
+        ops.gru_seq_shift(states_raw, hprev, lengths, ndir, h, reverse_dir0=rev0)
+        ops.gru_rh_seq(sv["ru_all"], hprev, rh_seq, lengths, ndir, h, reverse_dir0=rev0)
+        x2 = x.view(bsz * slen, e)
+        hp2, rh2 = hprev.view(bsz * slen, c_out), rh_seq.view(bsz * slen, c_out)
+        dx = ctx.buffer(key + ("dx",), (bsz * slen, e))
+        spec = self.rnn_specs[0]
+        first = True
+        for d, (dname, cv) in enumerate(zip(self._dirs(spec), sv["cells"])):
+            pre = "rnn_0_{}/{}/OrthoGRUCell".format(spec.direction, dname)
+            g_wg = store.g(self.var_name(pre + "/gates/kernel"))
+            g_wc = store.g(self.var_name(pre + "/candidate/kernel"))
+            dg = dxp[:, d * 3 * h:d * 3 * h + 2 * h]
+            dc = dxp[:, d * 3 * h + 2 * h:(d + 1) * 3 * h]
+            ops.gemm(x2, dg, out=g_wg[:e], trans_a=True)
+            ops.gemm(hp2[:, d * h:(d + 1) * h], dg, out=g_wg[e:], trans_a=True)
+            ops.gemm(x2, dc, out=g_wc[:e], trans_a=True)
+            ops.gemm(rh2[:, d * h:(d + 1) * h], dc, out=g_wc[e:], trans_a=True)
+            ops.colsum(dg, store.g(self.var_name(pre + "/gates/bias")))
+            ops.colsum(dc, store.g(self.var_name(pre + "/candidate/bias")))
+            ops.gemm(dg, cv["/gates/kernel"][:e], out=dx, trans_b=True, accumulate=not first)
+            ops.gemm(dc, cv["/candidate/kernel"][:e], out=dx, trans_b=True, accumulate=True)
+            first = False
+        self.input_sequence.backward(ctx, dx.view(bsz, slen, e))
 
     @tensor
     def temporal_states(self, ctx) -> torch.Tensor:

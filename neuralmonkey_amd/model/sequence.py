@@ -114,6 +114,25 @@ class EmbeddedFactorSequence(Sequence):
             out.mul_(self.temporal_mask(ctx).unsqueeze(-1))       # plumbing for the multi-factor case
         return out
 
+    def backward(self, ctx, d_states: torch.Tensor) -> None:
+        """dL/d(temporal_states) [B,S,sum(E)] -> embedding matrix gradients
+        (rows of padded positions carry no gradient: the mask multiply)."""
+        if not self.trainable:
+            return
+        ids = self.input_factor_indices(ctx)
+        names = self.embedding_matrix_names()
+        bsz, slen, total = d_states.shape
+        d2 = d_states.view(bsz * slen, total)
+        first_ids = ids[0].reshape(-1)
+        col = 0
+        for idx, name, esz in zip(ids, names, self.embedding_sizes):
+            if self.scale_embeddings_by_depth:
+                raise NotImplementedError("backward of scale_embeddings_by_depth")
+            if len(ids) > 1 and idx is not ids[0]:
+                raise NotImplementedError("backward of multi-factor sequences")
+            ops.embedding_scatter_add(ctx.store.g(name), idx.reshape(-1), d2[:, col:col + esz], skip_pad=True)
+            col += esz
+
     def feed_dict(self, dataset, train: bool = False) -> FeedDict:
         fd = ModelPart.feed_dict(self, dataset, train)
         for plc, name, vocab in zip(self.input_factors, self.data_ids, self.vocabularies):

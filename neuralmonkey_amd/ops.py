@@ -143,7 +143,15 @@ def attn_workspace(rows, s, c, device):
     return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
 
 
-def attn_fwd(y, hf, states, mask, v, bias, rows_per_key, ctx, weights, workspace):
+def gru_rh_seq(ru_all, hprev, out, lengths, ndir, hsz, reverse_dir0=False):
+    lib = _lib.load()
+    b, s = hprev.shape[0], hprev.shape[1]
+    _lib.check(lib.nm_gru_rh_seq(_stream(), ru_all.data_ptr(), hprev.data_ptr(), out.data_ptr(),
+                                 _p(lengths), _rev_mask(ndir, reverse_dir0), b, s, ndir, hsz),
+               "nm_gru_rh_seq")
+
+
+def attn_fwd(y, hf, states, mask, v, bias, rows_per_key, ctx, weights, workspace, energies_out=None):
     """Fused Bahdanau step.  y [R,A]; hf [Bk,S,A]; states [Bk,S,C]; mask [Bk,S]."""
     lib = _lib.load()
     r, a = y.shape
@@ -153,7 +161,7 @@ def attn_fwd(y, hf, states, mask, v, bias, rows_per_key, ctx, weights, workspace
     _lib.check(lib.nm_attn_fwd(_stream(), y.data_ptr(), hf.data_ptr(), states.data_ptr(), _p(mask),
                                v.data_ptr(), _p(bias), r, rows_per_key, s, a, c, ctx.data_ptr(),
                                ctx.stride(0), _p(weights), workspace.data_ptr(),
-                               workspace.numel() * 4), "nm_attn_fwd")
+                               workspace.numel() * 4, _p(energies_out)), "nm_attn_fwd")
 
 
 def row_stats(x, rmax=None, lse=None, argmax=None):
@@ -220,3 +228,138 @@ def length_penalty_table(max_len: int, alpha: float, device) -> torch.Tensor:
     lens = np.arange(max_len + 1, dtype=np.float32)
     tab = ((np.float32(5.0) + lens) / np.float32(6.0)) ** np.float32(alpha)
     return torch.from_numpy(tab.astype(np.float32)).to(device)
+
+
+# ---- backward / trainer kernels ------------------------------------------------
+def tanh_bwd(dy, y):
+    lib = _lib.load()
+    assert dy.is_contiguous() and y.is_contiguous() and dy.numel() == y.numel()
+    _lib.check(lib.nm_tanh_bwd(_stream(), dy.data_ptr(), y.data_ptr(), dy.numel()), "nm_tanh_bwd")
+    return dy
+
+
+_COLSUM_WS = {}
+
+
+def colsum(x, out, accumulate=False):
+    """out[c] (+)= sum_r x[r,c] (bias gradients); deterministic."""
+    lib = _lib.load()
+    assert x.dim() == 2 and x.stride(1) == 1
+    cols = x.shape[1]
+    key = (x.device, cols)
+    ws = _COLSUM_WS.get(key)
+    if ws is None:
+        ws = torch.empty(lib.nm_colsum_workspace_bytes(cols) // 4, dtype=torch.float32, device=x.device)
+        _COLSUM_WS[key] = ws
+    _lib.check(lib.nm_colsum(_stream(), x.data_ptr(), x.stride(0), x.shape[0], cols, out.data_ptr(),
+                             int(accumulate), ws.data_ptr(), ws.numel() * 4), "nm_colsum")
+    return out
+
+
+def embedding_scatter_add(dtable, ids, d, skip_pad=False):
+    lib = _lib.load()
+    assert d.dim() == 2 and d.stride(1) == 1 and dtable.is_contiguous()
+    _lib.check(lib.nm_embedding_scatter_add(_stream(), dtable.data_ptr(), dtable.shape[0], dtable.shape[1],
+                                            ids.data_ptr(), ids.numel(), d.data_ptr(), d.stride(0),
+                                            int(skip_pad)), "nm_embedding_scatter_add")
+
+
+def layer_norm_bwd(dy, x, mean, rstd, gamma, dx, dyx):
+    lib = _lib.load()
+    d = x.shape[-1]
+    rows = x.numel() // d
+    assert dy.is_contiguous() and x.is_contiguous() and dx.is_contiguous() and dyx.is_contiguous()
+    _lib.check(lib.nm_layer_norm_bwd(_stream(), dy.data_ptr(), x.data_ptr(), mean.data_ptr(),
+                                     rstd.data_ptr(), gamma.data_ptr(), dx.data_ptr(), dyx.data_ptr(),
+                                     rows, d), "nm_layer_norm_bwd")
+
+
+def gru_step_bwd(phase, dh, dout, dout_strides, ru, c, h0, hseq, hseq_strides, dxp, dxp_strides, dgpre,
+                 dcpre, drh, lengths, t, ndir, rows, hsz, reverse_dir0=False):
+    """phase 0 = blend backward, phase 1 = gates backward (nm_backward.hip)."""
+    lib = _lib.load()
+    do = dout_strides or (0, 0, 0)
+    _lib.check(lib.nm_gru_step_bwd(_stream(), phase, dh.data_ptr(), _p(dout), do[0], do[1], do[2],
+                                   ru.data_ptr(), _p(c), _p(h0), hseq.data_ptr(), hseq_strides[0],
+                                   hseq_strides[1], hseq_strides[2], dxp.data_ptr(), dxp_strides[0],
+                                   dxp_strides[1], dxp_strides[2], dgpre.data_ptr(), _p(dcpre), _p(drh),
+                                   _p(lengths), t, _rev_mask(ndir, reverse_dir0), ndir, rows, hsz),
+               "nm_gru_step_bwd")
+
+
+def gru_seq_shift(seq, out, lengths, ndir, hsz, reverse_dir0=False):
+    lib = _lib.load()
+    b, s = seq.shape[0], seq.shape[1]
+    _lib.check(lib.nm_gru_seq_shift(_stream(), seq.data_ptr(), out.data_ptr(), _p(lengths),
+                                    _rev_mask(ndir, reverse_dir0), b, s, ndir, hsz), "nm_gru_seq_shift")
+
+
+def attn_softmax_bwd(dw, e, mask, de, bsz):
+    lib = _lib.load()
+    s = dw.shape[-1]
+    rows = dw.numel() // s
+    _lib.check(lib.nm_attn_softmax_bwd(_stream(), dw.data_ptr(), e.data_ptr(), _p(mask), de.data_ptr(),
+                                       rows, bsz, s), "nm_attn_softmax_bwd")
+
+
+def attn_energy_bwd(de, hf, y, v, dhf, dv_partial, dy):
+    lib = _lib.load()
+    t, b, s = de.shape
+    a = hf.shape[-1]
+    _lib.check(lib.nm_attn_energy_bwd(_stream(), de.data_ptr(), hf.data_ptr(), y.data_ptr(), v.data_ptr(),
+                                      dhf.data_ptr(), dv_partial.data_ptr(), dy.data_ptr(), t, b, s, a),
+               "nm_attn_energy_bwd")
+
+
+class OptimizerTables:
+    """Chunk / segment tables of a VariableStore for the flat optimizer kernels."""
+    CHUNK = 65536
+
+    def __init__(self, store, regularizable, trainable):
+        lib = _lib.load()
+        starts, lens, segs, first, count, flags = [], [], [], [], [], []
+        self.names = list(store.specs)
+        for si, (name, spec) in enumerate(store.specs.items()):
+            first.append(len(starts))
+            off = 0
+            while off < spec.size:
+                n = min(self.CHUNK, spec.size - off)
+                starts.append(spec.offset + off)
+                lens.append(n)
+                segs.append(si)
+                off += n
+            count.append(len(starts) - first[-1])
+            flags.append((1 if name in regularizable else 0) | (2 if name in trainable else 0))
+        dev = store.device
+        self.chunk_start = torch.tensor(starts, dtype=torch.int64, device=dev)
+        self.chunk_len = torch.tensor(lens, dtype=torch.int32, device=dev)
+        self.chunk_seg = torch.tensor(segs, dtype=torch.int32, device=dev)
+        self.seg_first = torch.tensor(first, dtype=torch.int32, device=dev)
+        self.seg_count = torch.tensor(count, dtype=torch.int32, device=dev)
+        self.seg_flags = torch.tensor(flags, dtype=torch.int32, device=dev)
+        self.nchunk, self.nseg = len(starts), len(first)
+        self.workspace = torch.empty(lib.nm_optim_workspace_bytes(self.nchunk, self.nseg) // 4,
+                                     dtype=torch.float32, device=dev)
+        self.l1l2 = torch.zeros(2, dtype=torch.float32, device=dev)
+
+    def _tabs(self):
+        return (self.chunk_start.data_ptr(), self.chunk_len.data_ptr(), self.chunk_seg.data_ptr(),
+                self.seg_first.data_ptr(), self.seg_count.data_ptr(), self.seg_flags.data_ptr(),
+                self.nchunk, self.nseg)
+
+    def regularize_and_norms(self, theta, grad, l1_weight, l2_weight):
+        """grad += d(l1*L1 + l2*L2); per-variable ||grad||^2; returns device [L1, L2]."""
+        lib = _lib.load()
+        _lib.check(lib.nm_optim_regularize_norms(_stream(), theta.data_ptr(), grad.data_ptr(), *self._tabs(),
+                                                 float(l1_weight), float(l2_weight), self.l1l2.data_ptr(),
+                                                 self.workspace.data_ptr(), self.workspace.numel() * 4),
+                   "nm_optim_regularize_norms")
+        return self.l1l2
+
+    def clip_adam(self, theta, grad, m, v, clip_norm, lr_t, beta1, beta2, epsilon):
+        lib = _lib.load()
+        _lib.check(lib.nm_optim_clip_adam(_stream(), theta.data_ptr(), grad.data_ptr(), m.data_ptr(),
+                                          v.data_ptr(), *self._tabs(), float(clip_norm or 0.0), float(lr_t),
+                                          float(beta1), float(beta2), float(epsilon),
+                                          self.workspace.data_ptr(), self.workspace.numel() * 4),
+                   "nm_optim_clip_adam")

@@ -1,0 +1,3 @@
+from .cross_entropy_trainer import CrossEntropyTrainer      # noqa: F401
+from .generic_trainer import GenericTrainer                 # noqa: F401
+from .objective import CostObjective                        # noqa: F401

@@ -1,0 +1,146 @@
+"""GenericTrainer (mirror of neuralmonkey/trainers/generic_trainer.py).
+
+train_op = forward (teacher forcing) -> hand-written backward into the flat
+gradient buffer -> [data parallel: all-reduce over RCCL] -> regulariser terms +
+per-tensor clip_by_norm + Adam as three fused launches over the flat buffers.
+Fetch names and the ``ExecutionResult`` loss keys ("<decoder> - cost", "L1",
+"L2") follow generic_trainer.py:39-51,245-250.
+"""
+import re
+from typing import Any, Dict, List, Optional, Sequence
+
+import torch
+
+from .. import ops
+from ..model.model_part import Feedable
+from ..optimizers import AdamOptimizer, Optimizer
+from ..runners.base_runner import GraphExecutor, NextExecute
+from ..runtime import tensor
+from .objective import Objective
+
+BIAS_REGEX = re.compile(r"[Bb]ias")
+
+
+# pylint: disable=too-few-public-methods,too-many-arguments
+class GenericTrainer(GraphExecutor, Feedable):
+    class Executable(GraphExecutor.Executable):
+        def __init__(self, executor: "GenericTrainer", compute_losses: bool, summaries: bool,
+                     num_sessions: int) -> None:
+            assert compute_losses
+            if num_sessions != 1:
+                raise ValueError("Trainer only supports execution in a single session")
+            super().__init__(executor, compute_losses, summaries, num_sessions)
+
+        def next_to_execute(self) -> NextExecute:
+            return self.executor.fetches, []
+
+        def collect_results(self, results: List[Dict]) -> None:
+            assert len(results) == 1
+            result = results[0]
+            objective_names = [obj.name for obj in self.executor.objectives] + ["L1", "L2"]
+            losses = dict(zip(objective_names, [float(x) for x in result["losses"]]))
+            self.set_result({}, losses, int(result["batch_size"]), [])
+
+    @staticmethod
+    def default_optimizer() -> Optimizer:
+        return AdamOptimizer(learning_rate=1e-4)
+
+    def __init__(self, objectives: Sequence[Objective], l1_weight: float = 0.0, l2_weight: float = 0.0,
+                 clip_norm: float = None, optimizer: Optimizer = None, var_scopes: List[str] = None,
+                 var_collection: str = None) -> None:
+        GraphExecutor.__init__(self, {obj.decoder for obj in objectives})
+        Feedable.__init__(self)
+        self.objectives = objectives
+        self.l1_weight = l1_weight
+        self.l2_weight = l2_weight
+        self.clip_norm = clip_norm
+        self.var_scopes = var_scopes
+        self.var_collection = var_collection
+        self.optimizer = optimizer if optimizer is not None else self.default_optimizer()
+        if not isinstance(self.optimizer, AdamOptimizer):
+            raise NotImplementedError("the HIP trainer implements Adam / LazyAdam; got {}"
+                                      .format(type(self.optimizer).__name__))
+        if clip_norm is not None and clip_norm <= 0.0:
+            raise ValueError("clip_norm must be positive")
+        for obj in objectives:
+            if obj.gradients is not None:
+                raise NotImplementedError("objectives with explicit gradients are not supported")
+        self._tables = {}
+
+    # -- variable bookkeeping -------------------------------------------------------------
+    def var_list(self, store) -> List[str]:
+        names = store.trainable_names()
+        if self.var_scopes is None:
+            return names
+        return [n for n in names if any(n.startswith(scope) for scope in self.var_scopes)]
+
+    @staticmethod
+    def regularizable(store) -> List[str]:
+        """generic_trainer.py:87-91: trainables whose name lacks [Bb]ias."""
+        return [n for n in store.trainable_names() if not BIAS_REGEX.findall(n)
+                and not n.startswith(("vgg", "Inception", "resnet"))]
+
+    def _optim_tables(self, store) -> ops.OptimizerTables:
+        key = id(store)
+        if key not in self._tables:
+            self._tables[key] = ops.OptimizerTables(store, set(self.regularizable(store)),
+                                                    set(self.var_list(store)))
+        return self._tables[key]
+
+    # -- the training step --------------------------------------------------------------------
+    @tensor
+    def train_op(self, ctx) -> int:
+        from .. import distributed as dist
+        sess, store = ctx.session, ctx.store
+        grad = store.ensure_grad()
+        grad.zero_()
+        dp = dist.current()
+        results = []
+        for obj in self.objectives:
+            dec = obj.decoder
+            weight = 1.0 if obj.weight is None else float(obj.weight)
+            # loss = sum(xent) / sum(mask): with data parallelism the denominator is the
+            # GLOBAL token count and gradients are summed over ranks
+            count = dec.train_token_count(ctx)
+            global_count = dp.all_reduce_scalar(count) if dp is not None else count
+            scale = ctx.buffer((id(self), "gscale"), (1,))
+            scale.fill_(weight / global_count)
+            res = dec._train_loop(ctx, want_grad=True, grad_scale=scale)     # pylint: disable=protected-access
+            ctx.memo[dec.train_loop_result.key] = res
+            dec.backward(ctx, res)
+            results.append(res)
+        if dp is not None:
+            dp.all_reduce_gradients(store)
+        tables = self._optim_tables(store)
+        l1l2 = tables.regularize_and_norms(store.theta, grad, self.l1_weight, self.l2_weight)
+        ctx.memo[(id(self), "l1l2")] = l1l2.clone()
+        sess.global_step += 1
+        m, v = store.ensure_adam()
+        opt = self.optimizer
+        tables.clip_adam(store.theta, grad, m, v, self.clip_norm, opt.lr_t(sess.global_step), opt.beta1,
+                         opt.beta2, opt.epsilon)
+        return sess.global_step
+
+    @tensor
+    def regularization_losses(self, ctx):
+        key = (id(self), "l1l2")
+        if key not in ctx.memo:        # losses requested without a training step
+            store = ctx.store
+            tables = self._optim_tables(store)
+            scratch = ctx.buffer((id(self), "zero_grad"), (store.total,), zero=True)
+            ctx.memo[key] = tables.regularize_and_norms(store.theta, scratch, 0.0, 0.0).clone()
+        return ctx.memo[key]
+
+    @tensor
+    def objective_values(self, ctx) -> List[Any]:
+        losses = [o.loss(ctx) for o in self.objectives]
+        l1l2 = self.regularization_losses(ctx)
+        return losses + [l1l2[0], l1l2[1]]
+
+    @property
+    def fetches(self) -> Dict[str, Any]:
+        return {"train_op": self.train_op, "losses": self.objective_values, "batch_size": self._batch_size_fetch}
+
+    @tensor
+    def _batch_size_fetch(self, ctx) -> int:
+        return int(ctx.fed(self.batch_size))

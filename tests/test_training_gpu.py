@@ -1,0 +1,103 @@
+"""Training-step parity: hand-written HIP backward + fused clip/Adam against
+torch-CPU autograd of the oracle's forward (oracle/torch_ref.py) on the same
+weights and batch.  Tolerances: gradients 1e-3 of the tensor's max magnitude
+(fp32 accumulation over T steps), loss 1e-4 relative."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nm_oracle as O
+from oracle import torch_ref as TR
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(dev, vocab, emb, rnn, batch, slen, tlen, ragged, seed=11, l1=0.0, l2=1e-8, clip=1.0):
+    from neuralmonkey_amd import synthetic
+    model = synthetic.build_translation_model(vocab_src=vocab, vocab_tgt=vocab, emb=emb, rnn=rnn,
+                                              max_len=max(slen, tlen), beam_size=0, device=str(dev),
+                                              l2_weight=l2, clip_norm=clip)
+    model.trainer.l1_weight = l1
+    params = O.init_params(seed=seed, vocab_src=vocab, vocab_tgt=vocab, emb=emb, rnn=rnn, std=0.1)
+    model.tf_manager.sessions[0].store.load_state_dict(params)
+    ds = synthetic.synthetic_dataset(seed=seed + 1, batch=batch, src_len=slen, tgt_len=tlen, vocab=vocab,
+                                     ragged=ragged)
+    src = O.pad_ids([list(s) for s in ds.get_series("source")], max(slen, tlen))
+    tgt = O.pad_ids([list(s) for s in ds.get_series("target")], max(slen, tlen), add_end_symbol=True)
+    return model, params, ds, src, np.ascontiguousarray(tgt.T)
+
+
+@pytest.mark.parametrize("vocab,emb,rnn,batch,slen,tlen,ragged,l1,l2,clip", [
+    (64, 12, 12, 5, 7, 6, True, 0.0, 1e-8, 1.0),
+    (300, 32, 32, 12, 15, 11, True, 1e-4, 1e-3, 0.05),
+    (1000, 64, 64, 16, 20, 16, False, 0.0, 0.0, None),
+])
+def test_gradients_and_adam_step_match_autograd(dev, vocab, emb, rnn, batch, slen, tlen, ragged, l1, l2, clip):
+    model, params, ds, src, tgt = _build(dev, vocab, emb, rnn, batch, slen, tlen, ragged, l1=l1, l2=l2, clip=clip)
+    sess = model.tf_manager.sessions[0]
+    store = sess.store
+
+    tp = TR.to_torch(params)
+    ref_loss, ref_l1, ref_l2, ref_g = TR.train_step_grads(tp, src, tgt, l1_weight=l1, l2_weight=l2)
+
+    res = model.tf_manager.execute(ds, model.trainer.feedables, [model.trainer], train=True)[0]
+    assert set(res.losses) == {"decoder - cost", "L1", "L2"}
+    assert res.size == batch
+    assert abs(res.losses["decoder - cost"] - float(ref_loss)) < 1e-4 * abs(float(ref_loss))
+    assert abs(res.losses["L1"] - float(ref_l1)) < 1e-4 * float(ref_l1)
+    assert abs(res.losses["L2"] - float(ref_l2)) < 1e-4 * float(ref_l2)
+
+    worst = {}
+    for name in store.names():
+        got = store.g(name).cpu().numpy().reshape(-1)
+        want = ref_g[name].numpy().reshape(-1)
+        scale = max(np.abs(want).max(), 1e-6)   # floor: d/d(attn_bias) is identically 0 (softmax shift invariance)
+        worst[name] = float(np.abs(got - want).max() / scale)
+    bad = {k: v for k, v in worst.items() if v > 1e-3}
+    assert not bad, "gradient mismatch: {}".format(bad)
+
+    # Adam moments after step 1 pin the clipped gradient: m = (1-b1)*g_clip, v = (1-b2)*g_clip^2
+    m, v = store.ensure_adam()
+    for name in store.names():
+        g = ref_g[name]
+        if clip:
+            g = g * (clip / max(float(g.norm()), clip))
+        spec = store.specs[name]
+        got_m = m[spec.offset:spec.offset + spec.size].cpu().numpy()
+        want_m = (0.1 * g).numpy().reshape(-1)
+        assert np.abs(got_m - want_m).max() <= 1e-3 * max(np.abs(want_m).max(), 1e-7), name
+    # parameters moved by at most lr (|update| <= lr_t * ... ~ lr at step 1) and in the right direction
+    for name in ("decoder/state_to_word_W", "attention/attn_similarity_v"):
+        before = params[name].reshape(-1)
+        after = store[name].cpu().numpy().reshape(-1)
+        g = ref_g[name].numpy().reshape(-1)
+        big = np.abs(g) > 1e-3 * np.abs(g).max()
+        assert np.all(np.sign(before - after)[big] == np.sign(g)[big])
+        assert np.abs(before - after).max() <= 1.01e-4
+
+
+def test_three_steps_track_the_reference_optimizer(dev):
+    """Loss trajectory of 3 optimizer steps == torch autograd + clip + Adam."""
+    model, params, ds, src, tgt = _build(dev, 200, 32, 32, 8, 10, 9, True, l2=1e-8, clip=1.0)
+    tp = TR.to_torch(params)
+    m = {k: torch.zeros_like(v) for k, v in tp.items()}
+    v = {k: torch.zeros_like(v_) for k, v_ in tp.items()}
+    ref_losses, got_losses = [], []
+    for step in range(1, 4):
+        loss, _, _, grads = TR.train_step_grads(tp, src, tgt, l1_weight=0.0, l2_weight=1e-8)
+        ref_losses.append(float(loss))
+        TR.clip_and_adam(tp, grads, m, v, step, 1.0)
+        res = model.tf_manager.execute(ds, model.trainer.feedables, [model.trainer], train=True)[0]
+        got_losses.append(res.losses["decoder - cost"])
+    assert np.allclose(got_losses, ref_losses, rtol=2e-4), (got_losses, ref_losses)
+    assert got_losses[2] < got_losses[0]
+
+
+def test_training_then_greedy_share_one_run(dev):
+    """Trainer and runner executed in one ``execute`` call (logging_period path,
+    learning_utils.py:110-125): one forward result is shared, both results come back."""
+    model, params, ds, src, tgt = _build(dev, 64, 12, 12, 5, 7, 6, True)
+    out = model.tf_manager.execute(ds, model.trainer.feedables | model.greedy_runner.feedables,
+                                   [model.trainer, model.greedy_runner], train=True)
+    assert out[0].losses["decoder - cost"] > 0
+    assert len(out[1].outputs["target"]) == 5
