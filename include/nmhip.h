@@ -1,0 +1,150 @@
+/* libnmhip -- C ABI of the MI355X (gfx950) attention-decoder hot path.
+ *
+ * The reference (ufal/neuralmonkey) has no FFI: its arithmetic is issued as
+ * TensorFlow-1.12 ops from Python.  This header is the boundary a maintainer
+ * binds instead (ctypes stub in INTEGRATION.md); each entry point cites the
+ * reference call site (file:line under /root/reference) whose TF op(s) it
+ * replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; nm_last_error() gives
+ *     the thread-local message;
+ *   - all tensor pointers are DEVICE pointers owned by the caller (row-major
+ *     fp32 / int32); the library never allocates or frees caller memory;
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it;
+ *   - sizes and strides are int64_t element counts; "ld*" = leading dimension.
+ */
+#ifndef NMHIP_H
+#define NMHIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* nm_last_error(void);
+int nm_version(void);
+
+/* ---- dense projections: tf.matmul / tf.layers.dense / 1x1 tf.nn.conv2d -------------
+ * attention/feed_forward.py:111-118 (keys), :130-132 (query);
+ * decoders/output_projection.py:115-130; decoders/autoregressive.py:450-459 (logits);
+ * decoders/encoder_projection.py:47-73; nn/ortho_gru_cell.py:44-53 (GRUCell kernels);
+ * and their tf.gradients transposes.
+ * C[M,N] = act(op(A).op(B) + bias (+ C)); transA: A stored [K,M]; transB: B stored [N,K];
+ * act 0 none / 1 tanh / 2 relu; batch > 1 strides the three operands;
+ * algo 0 auto / 1 tiled-128 / 2 tiled-64 / 3 skinny. fp32 MFMA (exact f32). */
+int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int64_t N, int64_t K,
+                const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                const float* bias, int act, int accumulate, int64_t batch, int64_t strideA,
+                int64_t strideB, int64_t strideC, int algo);
+
+/* ---- embedding lookup: model/sequence.py:170-194, decoders/autoregressive.py:269-272 --
+ * out[i,:] = table[ids[i],:] * scale * (mask_pad ? ids[i] != 0 : 1) */
+int nm_embedding_gather(void* stream, const float* table, int64_t V, int64_t E, const int32_t* ids,
+                        int64_t n, float* out, int64_t ldo, int mask_pad, float scale);
+/* gradient of the lookup (tf.gather grad); skip_pad drops id 0 rows (the mask multiply) */
+int nm_embedding_scatter_add(void* stream, float* dtable, int64_t V, int64_t E, const int32_t* ids,
+                             int64_t n, const float* d, int64_t ldd, int skip_pad);
+
+/* ---- GRU cell epilogues: TF GRUCell via OrthoGRUCell, nn/ortho_gru_cell.py:44-53;
+ * length masking / reverse_sequence of (bidirectional_)dynamic_rnn, encoders/recurrent.py:86-102.
+ * xp = x.[Wg_x|Wc_x]+[bg|bc] addressed xp + d*x_dir_off + r*x_row_stride + pos*x_time_stride;
+ * rev_mask bit d: direction d walks its sequence backwards; rows with t >= lengths[r] are dead. */
+int nm_gru_gates_fwd(void* stream, const float* xp, int64_t x_dir_off, int64_t x_row_stride,
+                     int64_t x_time_stride, const float* hg, const float* h, float* ru, float* rh,
+                     const int32_t* lengths, int t, int rev_mask, int ndir, int64_t R, int64_t H);
+int nm_gru_blend_fwd(void* stream, const float* xp, int64_t x_dir_off, int64_t x_row_stride,
+                     int64_t x_time_stride, const float* hc, const float* ru, const float* h_in,
+                     float* h_out, float* c_save, float* out, int64_t out_dir_off,
+                     int64_t out_row_stride, int64_t out_time_stride, const int32_t* lengths, int t,
+                     int rev_mask, int ndir, int64_t R, int64_t H);
+/* one BPTT step of the cell: phase 0 = blend backward, phase 1 = gates backward */
+int nm_gru_step_bwd(void* stream, int phase, float* dh, const float* dout, int64_t do_dir,
+                    int64_t do_row, int64_t do_time, const float* ru, const float* c, const float* h0,
+                    const float* hseq, int64_t hs_dir, int64_t hs_row, int64_t hs_time, float* dxp,
+                    int64_t dx_dir, int64_t dx_row, int64_t dx_time, float* dgpre, float* dcpre,
+                    const float* drh, const int32_t* lengths, int t, int rev_mask, int ndir, int64_t R,
+                    int64_t H);
+int nm_gru_seq_shift(void* stream, const float* seq, float* out, const int32_t* lengths, int rev_mask,
+                     int64_t B, int64_t S, int ndir, int64_t H);
+int nm_gru_rh_seq(void* stream, const float* ru_all, const float* hprev, float* out,
+                  const int32_t* lengths, int rev_mask, int64_t B, int64_t S, int ndir, int64_t H);
+
+/* ---- layer norm: tf_utils.py:189-219 (eps inside rsqrt, biased variance) ------------------ */
+int nm_layer_norm_fwd(void* stream, const float* x, int64_t ldx, const float* gamma, const float* beta,
+                      float* y, int64_t ldy, float* mean_out, float* rstd_out, int64_t rows, int64_t D,
+                      float eps);
+int nm_layer_norm_bwd(void* stream, const float* dy, const float* x, const float* mean,
+                      const float* rstd, const float* gamma, float* dx, float* dyx, int64_t rows,
+                      int64_t D);
+
+/* ---- Bahdanau attention step: Attention.attention, attention/feed_forward.py:120-166 ------
+ * energies + softmax + mask renormalisation (+1e-8) + context, fused; keys of row r are
+ * those of sentence r / rows_per_key (beam search without tiling the keys). */
+int64_t nm_attn_workspace_bytes(int64_t R, int64_t S, int64_t C);
+int nm_attn_fwd(void* stream, const float* y, const float* hf, const float* states, const float* mask,
+                const float* v, const float* bias, int64_t R, int64_t rows_per_key, int64_t S,
+                int64_t A, int64_t C, float* ctx, int64_t ldctx, float* weights, void* workspace,
+                int64_t workspace_bytes, float* energies_out);
+/* backward of T steps at once: softmax/renorm part, then the tanh energies part */
+int nm_attn_softmax_bwd(void* stream, const float* dw, const float* e, const float* mask, float* de,
+                        int64_t rows, int64_t B, int64_t S);
+int nm_attn_energy_bwd(void* stream, const float* de, const float* hf, const float* y, const float* v,
+                       float* dhf, float* dv_partial, float* dy, int64_t T, int64_t B, int64_t S,
+                       int64_t A);
+/* live HIP-event timing of the attn_partial kernel (bench.py roofline) */
+int nm_prof_enable(int on);
+int nm_prof_attn_partial(double* total_ms, int64_t* count);
+
+/* ---- vocabulary-axis rows: tf.argmax / tf.nn.log_softmax / sequence_loss ----------------------
+ * decoders/autoregressive.py:470 (argmax, first max wins), :289-316,351-375 (xent, log-probs) */
+int nm_row_stats(void* stream, const float* x, int64_t ldx, int64_t rows, int64_t V, float* max_out,
+                 float* lse_out, int32_t* argmax_out);
+int nm_log_softmax(void* stream, const float* x, int64_t ldx, const float* rmax, const float* rlse,
+                   float* out, int64_t ldo, int64_t rows, int64_t V);
+int nm_greedy_update(void* stream, const int32_t* argmax, int32_t* finished, int32_t* sym_out,
+                     int32_t* mask_out, int64_t n, int end_id, int32_t* all_finished);
+int nm_xent(void* stream, float* logits, int64_t ldx, int64_t rows, int64_t V, const int32_t* targets,
+            const float* weights, float* loss_rows, const float* grad_scale, int write_grad);
+
+/* ---- beam search step: decoders/beam_search_decoder.py:440-501 (mask, + logprob_sum, length
+ * penalty, tf.nn.top_k over [B,k*V] with lower-index-first ties, div/mod, gathers) and the
+ * state / history reordering :503-551 (tf_utils.py:106-131 gather_flat) */
+int64_t nm_beam_workspace_bytes(int64_t B, int64_t k, int64_t V);
+int nm_beam_topk_step(void* stream, const float* logits, int64_t ldx, int64_t B, int64_t k, int64_t V,
+                      const float* rmax, const float* rlse, const float* logprob_sum,
+                      const int32_t* lengths, const int32_t* finished, const float* penalty, int end_id,
+                      float* out_score, int32_t* out_word, int32_t* out_beam, float* out_logprob_sum,
+                      int32_t* out_lengths, int32_t* out_finished, int32_t* out_src_row, void* workspace,
+                      int64_t workspace_bytes, int32_t* all_finished);
+int nm_gather_rows_f32(void* stream, const float* src, int64_t ld_src, const int32_t* idx, float* dst,
+                       int64_t ld_dst, int64_t rows, int64_t width);
+int nm_beam_reorder_tokens(void* stream, const int32_t* src, const int32_t* src_row, const int32_t* word,
+                           int32_t* dst, int64_t steps, int64_t R);
+
+/* ---- small utilities -------------------------------------------------------------------------- */
+int nm_copy_cols(void* stream, const float* src, int64_t ld_src, float* dst, int64_t ld_dst,
+                 int64_t rows, int64_t width);
+int nm_reduce_sum(void* stream, const float* x, int64_t n, float* out);
+int nm_tanh_bwd(void* stream, float* dy, const float* y, int64_t n);
+int64_t nm_colsum_workspace_bytes(int64_t cols);
+int nm_colsum(void* stream, const float* x, int64_t ldx, int64_t rows, int64_t cols, float* out,
+              int accumulate, void* workspace, int64_t workspace_bytes);
+
+/* ---- trainer arithmetic over the flat parameter buffer: trainers/generic_trainer.py:84-195
+ * (L1/L2 over non-bias variables, per-tensor tf.clip_by_norm, tf.train.AdamOptimizer) ----------- */
+int64_t nm_optim_workspace_bytes(int64_t nchunk, int64_t nseg);
+int nm_optim_regularize_norms(void* stream, const float* theta, float* grad, const int64_t* chunk_start,
+                              const int32_t* chunk_len, const int32_t* chunk_seg, const int32_t* seg_first,
+                              const int32_t* seg_count, const int32_t* seg_flags, int64_t nchunk,
+                              int64_t nseg, float l1_weight, float l2_weight, float* l1l2_out,
+                              void* workspace, int64_t workspace_bytes);
+int nm_optim_clip_adam(void* stream, float* theta, const float* grad, float* m, float* v,
+                       const int64_t* chunk_start, const int32_t* chunk_len, const int32_t* chunk_seg,
+                       const int32_t* seg_first, const int32_t* seg_count, const int32_t* seg_flags,
+                       int64_t nchunk, int64_t nseg, float clip_norm, float lr_t, float beta1,
+                       float beta2, float epsilon, void* workspace, int64_t workspace_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NMHIP_H */

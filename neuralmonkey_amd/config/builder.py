@@ -1,0 +1,107 @@
+"""Object builder for parsed configs (semantics of neuralmonkey/config/builder.py).
+
+``class=`` names resolve like the reference (builder.py:25-58): first as an
+importable module path, then ``tf.*`` against the TensorFlow look-alike
+namespace ``neuralmonkey_amd.tf_shim``, then relative to this package (the
+reference prefixes ``neuralmonkey.``; that prefix is accepted too).  A missing
+``name`` argument defaults to the section name when the callable declares
+``name: str`` (builder.py:170-185)."""
+import collections
+import collections.abc
+import importlib
+from argparse import Namespace
+from inspect import Parameter, isclass, isfunction, signature
+from typing import Any, Dict, Set, Tuple
+
+from .exceptions import ConfigBuildException, ConfigInvalidValueException
+from .parsing import ClassSymbol, ObjectRef
+
+PACKAGE = __name__.rsplit(".", 2)[0]          # "neuralmonkey_amd"
+
+
+def resolve_symbol(dotted: str) -> Any:
+    parts = dotted.split(".")
+    attr, module_path = parts[-1], ".".join(parts[:-1])
+    candidates = [module_path]
+    if parts[0] == "tf":
+        candidates = [PACKAGE + ".tf_shim"]
+    else:
+        if parts[0] == "neuralmonkey":
+            candidates.append(".".join([PACKAGE] + parts[1:-1]))
+        candidates.append(".".join([PACKAGE] + parts[:-1]))
+    last_exc = None
+    for cand in candidates:
+        try:
+            module = importlib.import_module(cand)
+        except ImportError as exc:
+            last_exc = exc
+            continue
+        if parts[0] == "tf":
+            obj = module
+            for piece in parts[1:]:
+                obj = getattr(obj, piece)
+            return obj
+        try:
+            return getattr(module, attr)
+        except AttributeError as exc:
+            raise Exception("Interpretation '{}' as type name, class '{}' does not exist. "
+                            "Did you mean file './{}'? \n{}".format(dotted, attr, dotted, exc))
+    raise Exception("Cannot import module {} ({})".format(module_path, last_exc))
+
+
+def build_object(value: Any, all_dicts: Dict[str, Any], existing: Dict[str, Any], depth: int) -> Any:
+    if depth > 20:
+        raise AssertionError("Config recursion should not be deeper that 20.")
+    if isinstance(value, tuple):
+        return tuple(build_object(v, all_dicts, existing, depth + 1) for v in value)
+    if isinstance(value, collections.abc.Iterable) and not isinstance(value, (str, bytes, dict)):
+        return [build_object(v, all_dicts, existing, depth + 1) for v in value]
+    if isinstance(value, ObjectRef):
+        if value.name not in existing:
+            existing[value.name] = instantiate_class(value.name, all_dicts, existing, depth)
+        value.bind(existing[value.name])
+        return value.target
+    if isinstance(value, ClassSymbol):
+        return resolve_symbol(value.clazz)
+    return value
+
+
+def instantiate_class(name: str, all_dicts: Dict[str, Any], existing: Dict[str, Any], depth: int) -> Any:
+    if name not in all_dicts:
+        raise ConfigInvalidValueException(name, "Undefined object")
+    section = all_dicts[name]
+    if "class" not in section:
+        raise ConfigInvalidValueException(name, "Undefined object type")
+    clazz = resolve_symbol(section["class"].clazz)
+    if not isclass(clazz) and not isfunction(clazz):
+        raise ConfigInvalidValueException(name, "Cannot instantiate object with '{}'".format(clazz))
+    arguments = {key: build_object(val, all_dicts, existing, depth + 1)
+                 for key, val in section.items() if key != "class"}
+    sig = signature(clazz)
+    if "name" in sig.parameters and "name" not in arguments:
+        if sig.parameters["name"].annotation in (str, "str"):
+            arguments["name"] = name
+    try:
+        bound = sig.bind(**arguments)
+    except TypeError as exc:
+        raise ConfigBuildException(clazz, exc)
+    return clazz(*bound.args, **bound.kwargs)
+
+
+def build_config(config_dicts: Dict[str, Any], ignore_names: Set[str],
+                 warn_unused: bool = False) -> Tuple[Dict[str, Any], Dict[str, Any]]:
+    """builder.py:207-249: build every key of [main] (sorted, tf_manager last)."""
+    if "main" not in config_dicts:
+        raise Exception("Configuration does not contain the main block.")
+    existing: Dict[str, Any] = collections.OrderedDict()
+    main = config_dicts["main"]
+    existing["main"] = Namespace(**main)
+    configuration: Dict[str, Any] = collections.OrderedDict()
+    for key in sorted(main, key=lambda k: "zzz" if k == "tf_manager" else k):
+        if key in ignore_names:
+            continue
+        try:
+            configuration[key] = build_object(main[key], config_dicts, existing, 0)
+        except Exception as exc:
+            raise ConfigBuildException(key, exc) from None
+    return configuration, existing

@@ -1,0 +1,98 @@
+"""Data-parallel path on CPU with gloo, world_size 2 (the driver runs the real
+RCCL job): bucketed all-reduce of the flat gradient buffer, global token-count
+normalisation, batch sharding.  The per-rank gradients come from the oracle's
+autograd so the identity checked is the one the GPU trainer relies on:
+
+    sum_r  d/dtheta [ sum_local_r(xent) / sum_global(mask) ]  ==  full-batch gradient.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    torch.set_num_threads(1)
+    from neuralmonkey_amd import distributed, synthetic
+    from neuralmonkey_amd.variables import VariableStore, random_normal_initializer
+    from oracle import nm_oracle as O
+    from oracle import torch_ref as TR
+
+    dp = distributed.init_from_env(backend="gloo")
+    assert dp.rank == rank and dp.world_size == world
+
+    vocab, dim, batch = 50, 8, 6
+    params = O.init_params(seed=5, vocab_src=vocab, vocab_tgt=vocab, emb=dim, rnn=dim, std=0.2)
+    ds = synthetic.synthetic_dataset(seed=6, batch=batch, src_len=7, tgt_len=6, vocab=vocab, ragged=True)
+    shard = dp.shard(ds)
+    assert len(shard) == batch // world
+
+    def arrays(d):
+        src = O.pad_ids([list(s) for s in d.get_series("source")], 7)
+        tgt = O.pad_ids([list(s) for s in d.get_series("target")], 7, add_end_symbol=True)
+        return src, np.ascontiguousarray(tgt.T)
+
+    src, tgt = arrays(shard)
+    local_count = float((tgt != 0).sum())
+    global_count = dp.all_reduce_scalar(local_count)
+
+    # rank-local gradient of sum_local(xent)/sum_global(mask), no regulariser (added once, after the reduce)
+    tp = TR.to_torch(params)
+    loss = TR.train_forward(tp, src, tgt) * (local_count / global_count)
+    loss.backward()
+
+    store = VariableStore("cpu", seed=0)
+    for name, val in params.items():
+        store.declare(name, val.shape if val.shape else (1,), random_normal_initializer())
+    store.finalize()
+    store.ensure_grad()
+    for name in params:
+        store.g(name).copy_(tp[name].grad.reshape(store.g(name).shape))
+    dp.bucket_elems = 1000                      # force several buckets
+    dp.all_reduce_gradients(store)
+
+    if rank == 0:
+        fsrc, ftgt = arrays(ds)
+        ftp = TR.to_torch(params)
+        TR.train_forward(ftp, fsrc, ftgt).backward()
+        worst = 0.0
+        for name in params:
+            want = ftp[name].grad.reshape(-1).numpy()
+            got = store.g(name).reshape(-1).numpy()
+            worst = max(worst, float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-5)))
+        np.save(os.path.join(out_dir, "result.npy"), np.array([worst, global_count, float((ftgt != 0).sum())]))
+    # parameter broadcast makes replicas identical
+    store.theta.add_(float(rank))
+    dp.broadcast_parameters(store, src=0)
+    assert float(store.theta.sum()) == pytest.approx(float(store.theta.sum()))
+    distributed.shutdown()
+
+
+def test_sharded_gradients_equal_full_batch(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    worst, global_count, full_count = np.load(tmp_path / "result.npy")
+    assert global_count == full_count
+    assert worst < 5e-4, worst          # fp32 re-association between shard and full-batch sums
+
+
+def test_single_process_is_a_no_op(monkeypatch):
+    from neuralmonkey_amd import distributed
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    assert distributed.init_from_env() is None and distributed.current() is None
