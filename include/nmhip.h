@@ -31,11 +31,13 @@ int nm_version(void);
  * and their tf.gradients transposes.
  * C[M,N] = act(op(A).op(B) + bias (+ C)); transA: A stored [K,M]; transB: B stored [N,K];
  * act 0 none / 1 tanh / 2 relu; batch > 1 strides the three operands;
- * algo 0 auto / 1 tiled-128 / 2 tiled-64 / 3 skinny. fp32 MFMA (exact f32). */
+ * algo 0 auto / 1 tiled-128 / 2 tiled-64 / 3 skinny. fp32 MFMA (exact f32).
+ * workspace (optional, device): split-K slabs for deep-K / few-tile shapes (weight gradients);
+ * slabs are summed in a fixed order, results stay deterministic. */
 int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int64_t N, int64_t K,
                 const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
                 const float* bias, int act, int accumulate, int64_t batch, int64_t strideA,
-                int64_t strideB, int64_t strideC, int algo);
+                int64_t strideB, int64_t strideC, int algo, void* workspace, int64_t workspace_bytes);
 
 /* ---- embedding lookup: model/sequence.py:170-194, decoders/autoregressive.py:269-272 --
  * out[i,:] = table[ids[i],:] * scale * (mask_pad ? ids[i] != 0 : 1) */

@@ -23,6 +23,7 @@
 //   w_s = exp(e_s-M) m_s / (sum_j exp(e_j-M) m_j + 1e-8 * sum_j exp(e_j-M)).
 #include "nm_common.h"
 
+#include <stdlib.h>
 #include <utility>
 #include <vector>
 
@@ -86,6 +87,7 @@ __global__ __launch_bounds__(256) void attn_partial(AttnArgs p) {
     float* vs = ys + QPK * p.A;               // [A]
     float* es = vs + p.A;                     // [QPK][ATT_MAX_SCH]  energies -> p
     float* ms = es + QPK * ATT_MAX_SCH;       // [ATT_MAX_SCH] mask
+    float* pe = ms + ATT_MAX_SCH;             // [4][QPK][ATT_MAX_SCH] per-wave energy partials
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int chunk = blockIdx.x, b = blockIdx.y;
@@ -104,30 +106,50 @@ __global__ __launch_bounds__(256) void attn_partial(AttnArgs p) {
 
     const float bias = p.bias ? p.bias[0] : 0.0f;
 
-    // ---- phase 1: energies, one wave per key row ---------------------------
-    for (int sl = wave; sl < ns; sl += 4) {
-        const float* hrow = p.hf + ((long)b * p.S + s0 + sl) * p.A;
-        float part[QPK];
+    // ---- phase 1: energies.  Every wave owns 256-column slices of ALL rows of the
+    // chunk (same access pattern as phase 3): 4 rows x 16 B per lane in flight, perfectly
+    // balanced across waves; per-row partial sums meet in LDS.
+    {
+        const float* hbase = p.hf + ((long)b * p.S + s0) * p.A;
+        for (int s4 = 0; s4 < ns; s4 += 4) {
+            float acc[QPK][4];
 #pragma unroll
-        for (int q = 0; q < QPK; ++q) part[q] = 0.0f;
-        for (int a = lane * 4; a < p.A; a += 256) {
-            const float4 h4 = *reinterpret_cast<const float4*>(hrow + a);
-            const float4 v4 = *reinterpret_cast<const float4*>(vs + a);
+            for (int q = 0; q < QPK; ++q)
 #pragma unroll
-            for (int q = 0; q < QPK; ++q) {
-                const float4 y4 = *reinterpret_cast<const float4*>(ys + q * p.A + a);
-                part[q] += v4.x * nm_tanh(h4.x + y4.x) + v4.y * nm_tanh(h4.y + y4.y) +
-                           v4.z * nm_tanh(h4.z + y4.z) + v4.w * nm_tanh(h4.w + y4.w);
+                for (int i = 0; i < 4; ++i) acc[q][i] = 0.0f;
+            for (int a = wave * 256 + lane * 4; a < p.A; a += 1024) {
+                float4 h4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int sl = min(s4 + i, ns - 1);          // clamped duplicates are dropped below
+                    h4[i] = *reinterpret_cast<const float4*>(hbase + (long)sl * p.A + a);
+                }
+                const float4 v4 = *reinterpret_cast<const float4*>(vs + a);
+#pragma unroll
+                for (int q = 0; q < QPK; ++q) {
+                    const float4 y4 = *reinterpret_cast<const float4*>(ys + q * p.A + a);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[q][i] += v4.x * nm_tanh(h4[i].x + y4.x) + v4.y * nm_tanh(h4[i].y + y4.y) +
+                                     v4.z * nm_tanh(h4[i].z + y4.z) + v4.w * nm_tanh(h4[i].w + y4.w);
+                }
             }
-        }
 #pragma unroll
-        for (int q = 0; q < QPK; ++q) {
-            const float e = nm_wave_sum(part[q]) + bias;
-            if (lane == 0) {
-                es[q * ATT_MAX_SCH + sl] = e;
-                p.energies[(long)(r0 + q) * p.S + s0 + sl] = e;
-            }
+            for (int q = 0; q < QPK; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float r = nm_wave_sum(acc[q][i]);
+                    if (lane == 0 && s4 + i < ns) pe[(wave * QPK + q) * ATT_MAX_SCH + s4 + i] = r;
+                }
         }
+    }
+    __syncthreads();
+    if (tid < QPK * ns) {
+        const int q = tid / ns, sl = tid - q * ns;
+        const float e = ((pe[(0 * QPK + q) * ATT_MAX_SCH + sl] + pe[(1 * QPK + q) * ATT_MAX_SCH + sl]) +
+                         (pe[(2 * QPK + q) * ATT_MAX_SCH + sl] + pe[(3 * QPK + q) * ATT_MAX_SCH + sl])) + bias;
+        es[q * ATT_MAX_SCH + sl] = e;
+        p.energies[(long)(r0 + q) * p.S + s0 + sl] = e;
     }
     __syncthreads();
 
@@ -228,8 +250,19 @@ __global__ __launch_bounds__(256) void attn_combine(const float* __restrict__ pc
     }
 }
 
+static int attn_max_rows() {
+    static int rows = 0;
+    if (rows == 0) {
+        const char* env = getenv("NM_ATTN_MAXROWS");     // tuning knob, 1..16
+        rows = env ? atoi(env) : 12;
+        if (rows < 1 || rows > ATT_MAX_SCH) rows = 12;
+    }
+    return rows;
+}
+
 static void attn_chunking(int64_t S, int* sch, int* nchunk) {
-    const int64_t n0 = (S + 11) / 12;                 // rows per chunk <= 12
+    const int64_t mr = attn_max_rows();
+    const int64_t n0 = (S + mr - 1) / mr;             // rows per chunk <= NM_ATTN_MAXROWS (12)
     *sch = (int)((S + n0 - 1) / n0);
     *nchunk = (int)((S + *sch - 1) / *sch);
 }
@@ -269,7 +302,8 @@ extern "C" int nm_attn_fwd(void* stream, const float* y, const float* hf, const 
     p.pctx = ws + ((R * S + 3) / 4) * 4;
     p.pstat = p.pctx + R * nchunk * C;
     p.R = (int)R; p.S = (int)S; p.A = (int)A; p.C = (int)C; p.nchunk = nchunk; p.sch = sch;
-    const size_t shm = sizeof(float) * ((size_t)qpk * A + A + (size_t)qpk * ATT_MAX_SCH + ATT_MAX_SCH);
+    const size_t shm = sizeof(float) * ((size_t)qpk * A + A + (size_t)qpk * ATT_MAX_SCH + ATT_MAX_SCH +
+                                        (size_t)4 * qpk * ATT_MAX_SCH);
     NM_REQUIRE(shm <= 160 * 1024, "nm_attn_fwd: A too large for LDS staging");
     hipStream_t st = nm_stream(stream);
     dim3 grid(nchunk, Bk), block(256);

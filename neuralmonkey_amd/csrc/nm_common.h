@@ -53,7 +53,7 @@ __device__ __forceinline__ float nm_wave_max(float v) {
 __device__ __forceinline__ float nm_tanh(float x) {
     float ax = fabsf(x);
     float e = __expf(2.0f * ax);
-    float t = 1.0f - 2.0f / (e + 1.0f);
+    float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);   // v_rcp_f32: 1 ulp
     return copysignf(t, x);
 }
-__device__ __forceinline__ float nm_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float nm_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }

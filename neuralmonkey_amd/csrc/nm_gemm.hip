@@ -31,6 +31,8 @@ struct GemmArgs {
     long sA, sB, sC;
     int act;         // 0 none, 1 tanh, 2 relu
     int accumulate;  // C += ...
+    float* ws;       // split-K slabs [splitk][M][N] (raw partial sums) or null
+    int splitk;      // K slices handled by blockIdx.y; 1 = write C directly
 };
 
 __device__ __forceinline__ float apply_act(float x, int act) {
@@ -187,14 +189,18 @@ __global__ __launch_bounds__(256) void gemm_tiled(GemmArgs g, int tiles_m) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int wm = (wave >> 1) * 32 * TM, wn = (wave & 1) * 32 * TN;
-    const int nkt = (g.K + BK - 1) / BK;
+    // split-K: slice blockIdx.y owns k-tiles [kt0, nkt)
+    const int nkt_all = (g.K + BK - 1) / BK;
+    const int per_slice = (nkt_all + g.splitk - 1) / g.splitk;
+    const int kt0 = blockIdx.y * per_slice;
+    const int nkt = min(nkt_all, kt0 + per_slice);
 
-    load_a(0);
-    load_b(0);
+    load_a(kt0 * BK);
+    load_b(kt0 * BK);
     store_lds(0);
     __syncthreads();
     int cur = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
+    for (int kt = kt0; kt < nkt; ++kt) {
         if (kt + 1 < nkt) { load_a((kt + 1) * BK); load_b((kt + 1) * BK); }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
@@ -215,11 +221,36 @@ __global__ __launch_bounds__(256) void gemm_tiled(GemmArgs g, int tiles_m) {
         cur ^= 1;
     }
 
+    if (g.splitk > 1) {          // raw partial sums into this slice's slab; epilogue in splitk_reduce
+        GemmArgs gs = g;
+        gs.ldc = g.N; gs.bias = nullptr; gs.act = 0; gs.accumulate = 0;
+        float* slab = g.ws + (long)blockIdx.y * g.M * g.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                store_tile32(gs, slab, acc[i][j], m0 + wm + i * 32, n0 + wn + j * 32, lane);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
             store_tile32(g, C, acc[i][j], m0 + wm + i * 32, n0 + wn + j * 32, lane);
+}
+
+// fixed-order sum of the split-K slabs + the GEMM epilogue (deterministic)
+__global__ void splitk_reduce(GemmArgs g) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)g.M * g.N;
+    if (idx >= total) return;
+    const int row = (int)(idx / g.N), col = (int)(idx - (long)row * g.N);
+    float s = 0.0f;
+    for (int k = 0; k < g.splitk; ++k) s += g.ws[(long)k * total + idx];
+    float* p = g.C + (long)row * g.ldc + col;
+    float v = s + (g.bias ? g.bias[col] : 0.0f);
+    if (g.accumulate) v += *p;
+    *p = apply_act(v, g.act);
 }
 
 // ---------------------------------------------------------------------------
@@ -246,10 +277,12 @@ __global__ __launch_bounds__(KS * 64) void gemm_skinny(GemmArgs g, int tiles_m) 
 
     const float* ap = A + (long)mm * g.lda + 4 * half;
     const float* bp = TB ? (B + (long)nn * g.ldb + 4 * half) : (B + (long)(4 * half) * g.ldb + nn);
-    for (int k0 = kbeg; k0 < kend; k0 += 32) {
-        float4 av[4], bv[4];
+    // all loads of a 64-deep K chunk are issued before the first MFMA: one memory
+    // latency per chunk (the decoder-step shapes have exactly one chunk per wave)
+    for (int k0 = kbeg; k0 < kend; k0 += 64) {
+        float4 av[8], bv[8];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < 8; ++c) {
             const int k = k0 + 8 * c;
             av[c] = make_float4(0.f, 0.f, 0.f, 0.f);
             bv[c] = av[c];
@@ -267,7 +300,8 @@ __global__ __launch_bounds__(KS * 64) void gemm_skinny(GemmArgs g, int tiles_m) 
             }
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < 8; ++c) {
+            if (k0 + 8 * c >= kend) break;
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].x, bv[c].x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].y, bv[c].y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].z, bv[c].z, acc, 0, 0, 0);
@@ -299,7 +333,7 @@ __global__ __launch_bounds__(KS * 64) void gemm_skinny(GemmArgs g, int tiles_m) 
 template <int TM, int TN>
 static void launch_tiled(const GemmArgs& g, int batch, bool ta, bool tb, bool vec, hipStream_t st) {
     const int tiles_m = nm_cdiv(g.M, 64 * TM), tiles_n = nm_cdiv(g.N, 64 * TN);
-    dim3 grid(tiles_m * tiles_n, 1, batch), block(256);
+    dim3 grid(tiles_m * tiles_n, g.splitk, batch), block(256);
 #define NM_GT(TA_, TB_, V_) \
     hipLaunchKernelGGL((gemm_tiled<TM, TN, TA_, TB_, V_>), grid, block, 0, st, g, tiles_m)
     if (vec) {
@@ -319,7 +353,8 @@ static void launch_tiled(const GemmArgs& g, int batch, bool ta, bool tb, bool ve
 extern "C" int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int64_t N, int64_t K,
                            const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
                            int64_t ldc, const float* bias, int act, int accumulate, int64_t batch,
-                           int64_t strideA, int64_t strideB, int64_t strideC, int algo) {
+                           int64_t strideA, int64_t strideB, int64_t strideC, int algo,
+                           void* workspace, int64_t workspace_bytes) {
     NM_REQUIRE(A && B && C, "nm_gemm_f32: null operand");
     NM_REQUIRE(M >= 0 && N >= 0 && K >= 0 && batch >= 1, "nm_gemm_f32: bad shape %ld %ld %ld x%ld",
                (long)M, (long)N, (long)K, (long)batch);
@@ -328,7 +363,7 @@ extern "C" int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int6
     if (M == 0 || N == 0) return NM_OK;
     NM_REQUIRE(K > 0, "nm_gemm_f32: K == 0");
     GemmArgs g{A, B, C, bias, (int)M, (int)N, (int)K, (long)lda, (long)ldb, (long)ldc,
-               (long)strideA, (long)strideB, (long)strideC, act, accumulate};
+               (long)strideA, (long)strideB, (long)strideC, act, accumulate, nullptr, 1};
     hipStream_t st = nm_stream(stream);
     const bool ta = transA != 0, tb = transB != 0;
 
@@ -350,20 +385,42 @@ extern "C" int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int6
         NM_REQUIRE(skinny_ok, "nm_gemm_f32: skinny path needs transA=0, aligned A, K%%8==0");
         const int tiles_m = nm_cdiv(M, 32), tiles_n = nm_cdiv(N, 32);
         dim3 grid(tiles_m * tiles_n, 1, (unsigned)batch);
-        const int ks = (K >= 512) ? 8 : (K >= 128 ? 4 : 1);
+        const int ks = (K >= 512) ? 16 : (K >= 256 ? 8 : (K >= 128 ? 4 : 1));
 #define NM_GS(KS_)                                                                          \
     do {                                                                                    \
         if (tb) hipLaunchKernelGGL((gemm_skinny<KS_, true>), grid, dim3(KS_ * 64), 0, st, g, tiles_m);  \
         else hipLaunchKernelGGL((gemm_skinny<KS_, false>), grid, dim3(KS_ * 64), 0, st, g, tiles_m);    \
     } while (0)
-        if (ks == 8) NM_GS(8);
+        if (ks == 16) NM_GS(16);
+        else if (ks == 8) NM_GS(8);
         else if (ks == 4) NM_GS(4);
         else NM_GS(1);
 #undef NM_GS
-    } else if (pick == 1) {
-        launch_tiled<2, 2>(g, (int)batch, ta, tb, vec, st);
     } else {
-        launch_tiled<1, 1>(g, (int)batch, ta, tb, vec, st);
+        // deep-K problems with few output tiles (weight gradients, dlogits.W^T): split K over
+        // blockIdx.y into slabs and reduce them in a fixed order, so the chip is filled.
+        if (workspace && batch == 1 && K >= 1024) {
+            const bool big = (algo == 1) || (algo == 0 && M >= 128 && N >= 128);
+            const long tiles = big ? (long)nm_cdiv(M, 128) * nm_cdiv(N, 128)
+                                   : (long)nm_cdiv(M, 64) * nm_cdiv(N, 64);
+            if (tiles < 384) {
+                long sk = (768 + tiles - 1) / tiles;
+                if (sk > 16) sk = 16;
+                if (sk > K / 256) sk = K / 256;
+                while (sk > 1 && sk * M * N * (long)sizeof(float) > workspace_bytes) --sk;
+                if (sk >= 2) {
+                    g.splitk = (int)sk;
+                    g.ws = reinterpret_cast<float*>(workspace);
+                    if (algo == 0) pick = big ? 1 : 2;
+                }
+            }
+        }
+        if (pick == 1) launch_tiled<2, 2>(g, (int)batch, ta, tb, vec, st);
+        else launch_tiled<1, 1>(g, (int)batch, ta, tb, vec, st);
+        if (g.splitk > 1) {
+            const long total = (long)M * N;
+            hipLaunchKernelGGL(splitk_reduce, dim3(nm_cdiv(total, 256)), dim3(256), 0, st, g);
+        }
     }
     NM_LAUNCH_CHECK("nm_gemm_f32");
 }

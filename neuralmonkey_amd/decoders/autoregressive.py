@@ -157,13 +157,14 @@ class AutoregressiveDecoder(ModelPart):
     @tensor
     def train_inputs(self, ctx) -> torch.Tensor:
         """Target ids, time-major [T,B] (autoregressive.py:216-219)."""
-        return ctx.session.to_device(ctx.fed(self.train_tokens), torch.int32, "tgt_tb",
-                                     lambda ids: np.ascontiguousarray(ids.T))
+        return ctx.session.staged((id(self), "tgt_tb"), ctx.session.to_device(
+            ctx.fed(self.train_tokens), torch.int32, "tgt_tb", lambda ids: np.ascontiguousarray(ids.T)))
 
     @tensor
     def train_mask(self, ctx) -> torch.Tensor:
-        return ctx.session.to_device(ctx.fed(self.train_tokens), torch.float32, "tgt_mask_tb",
-                                     lambda ids: np.ascontiguousarray(sentence_mask(ids).T))
+        return ctx.session.staged((id(self), "tgt_mask_tb"), ctx.session.to_device(
+            ctx.fed(self.train_tokens), torch.float32, "tgt_mask_tb",
+            lambda ids: np.ascontiguousarray(sentence_mask(ids).T)))
 
     def train_token_count(self, ctx) -> float:
         return float(sentence_mask(ctx.fed(self.train_tokens)).sum())

@@ -263,12 +263,19 @@ class Decoder(AutoregressiveDecoder):
         att_states = [a.initial_loop_state(ctx, bsz, steps) for a in self.attentions]
         y_all = [ctx.buffer(key + ("y", i), (steps, bsz, a.state_size)) for i, a in enumerate(self.attentions)]
         e_all = [ctx.buffer(key + ("e", i), (steps, bsz, st.weights.shape[2])) for i, st in enumerate(att_states)]
-        for t in range(steps):
-            self._recurrent(ctx, cell, xp, t, bsz * 3 * h, s_ext[t], s_all[t], ru_all[t], c_all[t], bufs,
-                            rh=rh_all[t])
-            for i, att in enumerate(self.attentions):
-                att.attention_into(ctx, s_all[t], y_all[i][t], att_states[i].contexts[t],
-                                   att_states[i].weights[t], e_all[i][t])
+        for att in self.attentions:          # touch lazily built tensors outside the captured region
+            att.hidden_features(ctx)
+            att.attention_mask(ctx)
+
+        def time_loop():
+            for t in range(steps):
+                self._recurrent(ctx, cell, xp, t, bsz * 3 * h, s_ext[t], s_all[t], ru_all[t], c_all[t], bufs,
+                                rh=rh_all[t])
+                for i, att in enumerate(self.attentions):
+                    att.attention_into(ctx, s_all[t], y_all[i][t], att_states[i].contexts[t],
+                                       att_states[i].weights[t], e_all[i][t])
+        ctx.session.graphed((id(self), "train_loop", bsz, steps) + tuple(
+            tuple(st.weights.shape) for st in att_states), time_loop)
         att_states = [AttentionLoopState(st.contexts, st.weights, steps) for st in att_states]
 
         out_all = ctx.buffer(key + ("out",), (rows, self.output_dimension))
@@ -349,13 +356,16 @@ class Decoder(AutoregressiveDecoder):
         s_all = sv["s_all"]
         seq_strides = (0, h, bsz * h)
         dxp_strides = (0, 3 * h, bsz * 3 * h)
-        for t in range(steps - 1, -1, -1):
-            ops.gru_step_bwd(0, dh, d_s, seq_strides, sv["ru_all"][t], sv["c_all"][t], sv["s0"], s_all,
-                             seq_strides, dxp, dxp_strides, dgpre, dcpre, None, None, t, 1, bsz, h)
-            ops.gemm(dcpre[0], cell["wc_h"], out=drh[0], trans_b=True)
-            ops.gru_step_bwd(1, dh, None, None, sv["ru_all"][t], None, sv["s0"], s_all, seq_strides, dxp,
-                             dxp_strides, dgpre, None, drh, None, t, 1, bsz, h)
-            ops.gemm(dgpre[0], cell["wg_h"], out=dh[0], trans_b=True, accumulate=True)
+        def bptt_loop():
+            dh.zero_()
+            for t in range(steps - 1, -1, -1):
+                ops.gru_step_bwd(0, dh, d_s, seq_strides, sv["ru_all"][t], sv["c_all"][t], sv["s0"], s_all,
+                                 seq_strides, dxp, dxp_strides, dgpre, dcpre, None, None, t, 1, bsz, h)
+                ops.gemm(dcpre[0], cell["wc_h"], out=drh[0], trans_b=True)
+                ops.gru_step_bwd(1, dh, None, None, sv["ru_all"][t], None, sv["s0"], s_all, seq_strides, dxp,
+                                 dxp_strides, dgpre, None, drh, None, t, 1, bsz, h)
+                ops.gemm(dgpre[0], cell["wg_h"], out=dh[0], trans_b=True, accumulate=True)
+        ctx.session.graphed((id(self), "bptt_loop", bsz, steps), bptt_loop)
         ds0 = dh[0]
 
         # ---- GRU weight gradients, batched over all steps

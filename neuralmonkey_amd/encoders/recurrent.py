@@ -176,15 +176,19 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
         len_arg = lengths
         xrs, xts = slen * ndir * 3 * h, ndir * 3 * h
         ors, ots = slen * c_out, c_out
-        for t in range(slen):
-            ru = ru_all[t] if train else ru_all[0]
-            ops.gemm(hcur, wgh, out=hg)
-            ops.gru_gates_fwd(xp, 3 * h, xrs, xts, hg, hcur, ru, rh, len_arg, t, ndir, bsz, h,
-                              reverse_dir0=reverse_only)
-            ops.gemm(rh, wch, out=hc)
-            ops.gru_blend_fwd(xp, 3 * h, xrs, xts, hc, ru, hcur, hcur, c_all[t] if train else None,
-                              states_raw, h, ors, ots, len_arg, t, ndir, bsz, h,
-                              reverse_dir0=reverse_only)
+        def time_loop():
+            states_raw.zero_()
+            hcur.zero_()
+            for t in range(slen):
+                ru = ru_all[t] if train else ru_all[0]
+                ops.gemm(hcur, wgh, out=hg)
+                ops.gru_gates_fwd(xp, 3 * h, xrs, xts, hg, hcur, ru, rh, len_arg, t, ndir, bsz, h,
+                                  reverse_dir0=reverse_only)
+                ops.gemm(rh, wch, out=hc)
+                ops.gru_blend_fwd(xp, 3 * h, xrs, xts, hc, ru, hcur, hcur, c_all[t] if train else None,
+                                  states_raw, h, ors, ots, len_arg, t, ndir, bsz, h,
+                                  reverse_dir0=reverse_only)
+        ctx.session.graphed((key, "fwd_loop", bsz, slen, train), time_loop)
         final_raw = ctx.buffer((key, "final_raw"), (bsz, c_out))
         for d in range(ndir):
             ops.copy_cols(hcur[d], final_raw[:, d * h:(d + 1) * h])
@@ -251,14 +255,17 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
         seq_strides = (h, slen * c_out, c_out)
         dxp_strides = (3 * h, slen * ndir * 3 * h, ndir * 3 * h)
         wgh, wch = sv["wgh"], sv["wch"]
-        for t in range(slen - 1, -1, -1):
-            ops.gru_step_bwd(0, dh, d_states_raw, seq_strides if d_states_raw is not None else None,
-                             sv["ru_all"][t], sv["c_all"][t], None, states_raw, seq_strides, dxp, dxp_strides,
-                             dgpre, dcpre, None, lengths, t, ndir, bsz, h, reverse_dir0=rev0)
-            ops.gemm(dcpre, wch, out=drh, trans_b=True)
-            ops.gru_step_bwd(1, dh, None, None, sv["ru_all"][t], None, None, states_raw, seq_strides, dxp,
-                             dxp_strides, dgpre, None, drh, lengths, t, ndir, bsz, h, reverse_dir0=rev0)
-            ops.gemm(dgpre, wgh, out=dh, trans_b=True, accumulate=True)
+        def bptt_loop():
+            for t in range(slen - 1, -1, -1):
+                ops.gru_step_bwd(0, dh, d_states_raw, seq_strides if d_states_raw is not None else None,
+                                 sv["ru_all"][t], sv["c_all"][t], None, states_raw, seq_strides, dxp,
+                                 dxp_strides, dgpre, dcpre, None, lengths, t, ndir, bsz, h, reverse_dir0=rev0)
+                ops.gemm(dcpre, wch, out=drh, trans_b=True)
+                ops.gru_step_bwd(1, dh, None, None, sv["ru_all"][t], None, None, states_raw, seq_strides,
+                                 dxp, dxp_strides, dgpre, None, drh, lengths, t, ndir, bsz, h,
+                                 reverse_dir0=rev0)
+                ops.gemm(dgpre, wgh, out=dh, trans_b=True, accumulate=True)
+        ctx.session.graphed((id(self), "bwd_loop", bsz, slen, d_states_raw is not None), bptt_loop)
 
         # ---- weight gradients, batched over all positions
         hprev = ctx.buffer(key + ("hprev",), (bsz, slen, ndir, h))

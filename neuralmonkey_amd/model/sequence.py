@@ -80,16 +80,19 @@ class EmbeddedFactorSequence(Sequence):
 
     @tensor
     def input_factor_indices(self, ctx) -> List[torch.Tensor]:
-        return [ctx.session.to_device(ctx.fed(p), torch.int32) for p in self.input_factors]
+        return [ctx.session.staged((id(self), "ids", i), ctx.session.to_device(ctx.fed(p), torch.int32))
+                for i, p in enumerate(self.input_factors)]
 
     @tensor
     def temporal_mask(self, ctx) -> torch.Tensor:
-        return ctx.session.to_device(ctx.fed(self.input_factors[0]), torch.float32, "mask", sentence_mask)
+        return ctx.session.staged((id(self), "mask"), ctx.session.to_device(
+            ctx.fed(self.input_factors[0]), torch.float32, "mask", sentence_mask))
 
     @tensor
     def lengths(self, ctx) -> torch.Tensor:
-        return ctx.session.to_device(ctx.fed(self.input_factors[0]), torch.int32, "len",
-                                     lambda ids: sentence_mask(ids).sum(1).astype(np.int32))
+        return ctx.session.staged((id(self), "len"), ctx.session.to_device(
+            ctx.fed(self.input_factors[0]), torch.int32, "len",
+            lambda ids: sentence_mask(ids).sum(1).astype(np.int32)))
 
     @tensor
     def temporal_states(self, ctx) -> torch.Tensor:

@@ -55,11 +55,26 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, b
     o2 = out[0] if batched else out
     assert tuple(o2.shape) == (m, n) and o2.stride(1) == 1
     s_c = out.stride(0) if batched else 0
+    ws = _gemm_workspace(a.device) if (nb == 1 and k >= 1024) else None
     _lib.check(lib.nm_gemm_f32(_stream(), int(trans_a), int(trans_b), m, n, k,
                                a.data_ptr(), a2.stride(0), b.data_ptr(), b2.stride(0),
                                out.data_ptr(), o2.stride(0), _p(bias), ACT[act], int(accumulate),
-                               nb, s_a, s_b, s_c, algo), "nm_gemm_f32")
+                               nb, s_a, s_b, s_c, algo, _p(ws), ws.numel() * 4 if ws is not None else 0),
+               "nm_gemm_f32")
     return out
+
+
+_GEMM_WS = {}
+GEMM_WORKSPACE_BYTES = 128 << 20
+
+
+def _gemm_workspace(device):
+    """Persistent split-K slab buffer (one per device; all GEMMs run on one stream)."""
+    ws = _GEMM_WS.get(device)
+    if ws is None:
+        ws = torch.empty(GEMM_WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
+        _GEMM_WS[device] = ws
+    return ws
 
 
 def embedding_gather(table, ids, out=None, mask_pad=False, scale=1.0):

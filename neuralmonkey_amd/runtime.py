@@ -7,6 +7,7 @@ handle; ``Session.run(fetches, feed_dict)`` evaluates the handles eagerly,
 memoised per run, launching libnmhip kernels on the device.  The call shape
 (fetch dictionaries in, numpy structures out) is unchanged.
 """
+import os
 from typing import Any, Dict, List, Optional
 
 import numpy as np
@@ -117,6 +118,8 @@ class Session:
         self.store = VariableStore(self.device, seed)
         self._buffers: Dict[Any, torch.Tensor] = {}
         self._h2d: Dict[Any, Any] = {}
+        self._graphs: Dict[Any, Any] = {}
+        self.use_graphs = os.environ.get("NM_GRAPHS", "1") != "0"
         self.global_step = 0
 
     def to_device(self, array, dtype, tag=None, derive=None):
@@ -137,16 +140,45 @@ class Session:
         return ten
 
     def buffer(self, key, shape, dtype=torch.float32, zero=False):
+        """Persistent scratch tensor.  Keyed by (key, shape, dtype) and never
+        re-allocated, so device pointers baked into captured HIP graphs stay valid."""
         shape = tuple(int(s) for s in shape)
-        buf = self._buffers.get(key)
-        if buf is None or tuple(buf.shape) != shape or buf.dtype != dtype:
+        full = (key, shape, dtype)
+        buf = self._buffers.get(full)
+        if buf is None:
             buf = torch.empty(shape, dtype=dtype, device=self.device)
-            self._buffers[key] = buf
-            if not zero:
-                return buf
+            self._buffers[full] = buf
         if zero:
             buf.zero_()
         return buf
+
+    def staged(self, key, src: torch.Tensor) -> torch.Tensor:
+        """Copy a per-batch device tensor into a persistent buffer (same pointer
+        every run), so time loops that read it can be replayed as HIP graphs."""
+        buf = self.buffer(("staged", key), tuple(src.shape), src.dtype)
+        buf.copy_(src)
+        return buf
+
+    def graphed(self, key, fn) -> None:
+        """Run ``fn`` (kernel launches on persistent buffers only, no host
+        synchronisation).  First call runs eagerly (allocations), second call
+        captures a HIP graph, later calls replay it: the launch-bound time loops
+        stop paying Python / launch overhead per kernel."""
+        if not self.use_graphs or self.device.type != "cuda":
+            fn()
+            return
+        state = self._graphs.get(key)
+        if state is None:
+            fn()
+            self._graphs[key] = 1
+        elif state == 1:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                fn()
+            self._graphs[key] = graph
+            graph.replay()
+        else:
+            state.replay()
 
     def _eval(self, fetch, ctx):
         if isinstance(fetch, Fetch):

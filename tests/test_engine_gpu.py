@@ -121,3 +121,68 @@ def test_beam_early_stop_and_greedy_early_stop(dev):
     assert np.array_equal(got["sym"], ref.symbols)
     assert got["bs"].last_search_step_output.token_ids.shape == refb.token_ids.shape
     assert np.array_equal(got["bs"].last_search_step_output.token_ids, refb.token_ids)
+
+
+@pytest.mark.parametrize("case", ["tiny", "mid"])
+def test_committed_golden_vectors(dev, case):
+    """HIP engine vs the committed fixtures (tests/golden/*.npz, generated by
+    tests/golden/make_golden.py from the oracle) -- no oracle call at run time."""
+    import os
+    from neuralmonkey_amd import synthetic
+    from neuralmonkey_amd.dataset import BatchingScheme, Dataset
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", case + ".npz"))
+    vocab, dim, batch, slen, tlen, ragged, beam, seed = [int(x) for x in gold["meta"]]
+    alpha = float(gold["alpha"])
+    model = synthetic.build_translation_model(vocab_src=vocab, vocab_tgt=vocab, emb=dim, rnn=dim,
+                                              max_len=max(slen, tlen), beam_size=beam, max_steps=tlen,
+                                              length_normalization=alpha, device=str(dev))
+    params = O.init_params(seed=seed, vocab_src=vocab, vocab_tgt=vocab, emb=dim, rnn=dim, std=0.1)
+    store = model.tf_manager.sessions[0].store
+    store.load_state_dict(params)
+    src, tgt = gold["src"], gold["tgt"].T
+    ds = Dataset("gold", {"source": [row[row != 0] for row in src],
+                          "target": [row[(row != 0) & (row != O.END)] for row in tgt]},
+                 BatchingScheme(batch_size=batch))
+    fd = {}
+    for f in model.greedy_runner.feedables | model.beam_runner.feedables:
+        fd.update(f.feed_dict(ds, train=False))
+    sess = model.tf_manager.sessions[0]
+    got = sess.run({"states": model.encoder.temporal_states, "final": model.encoder.output,
+                    "sym": model.decoder.decoded_symbols, "logits": model.decoder.runtime_logits,
+                    "train_loss": model.decoder.train_loss, "runtime_loss": model.decoder.runtime_loss,
+                    "bs": model.beam_decoder.outputs}, fd)
+    rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-6))
+    assert rel(got["states"], gold["enc_states"]) < 1e-4 and rel(got["final"], gold["enc_final"]) < 1e-4
+    assert np.array_equal(got["sym"], gold["greedy_symbols"])
+    assert rel(got["logits"], gold["greedy_logits"]) < 1e-4
+    assert abs(float(got["train_loss"]) - float(gold["train_loss"])) < 1e-4 * float(gold["train_loss"])
+    assert abs(float(got["runtime_loss"]) - float(gold["runtime_loss"])) < 1e-4 * float(gold["runtime_loss"])
+    if float(gold["beam_min_gap"]) > 1e-5:
+        assert np.array_equal(got["bs"].last_search_step_output.token_ids, gold["beam_token_ids"])
+        assert rel(got["bs"].last_search_step_output.scores, gold["beam_scores"]) < 1e-4
+    res = model.tf_manager.execute(ds, model.trainer.feedables, [model.trainer], train=True)[0]
+    assert abs(res.losses["decoder - cost"] - float(gold["torch_loss"])) < 1e-4 * float(gold["torch_loss"])
+    assert abs(res.losses["L2"] - float(gold["l2"])) < 1e-4 * float(gold["l2"])
+    for name, key in (("decoder/state_to_word_W", "grad_logit_w"), ("attention/attn_similarity_v", "grad_attn_v"),
+                      ("encoder_input/embedding_matrix_0", "grad_enc_emb")):
+        assert rel(store.g(name).cpu().numpy(), gold[key]) < 1e-3, name
+
+
+def test_ini_experiment_trains_and_decodes(dev, tmp_path):
+    """An INI config (the reference's plugin surface) builds, trains for a few
+    steps with falling loss and decodes with both runners on the GPU."""
+    from tests.test_host import write_ini
+    from neuralmonkey_amd.config.configuration import load_experiment
+    model = load_experiment(write_ini(tmp_path), changes=['tf_manager.device="{}"'.format(dev)])
+    tfm = model.tf_manager
+    batch = next(model.train_dataset.batches())
+    feedables = set.union(*[r.feedables for r in model.runners + model.trainers])
+    losses = []
+    for _ in range(30):
+        out = tfm.execute(batch, feedables, model.trainers, train=True)
+        losses.append(out[0].losses["decoder - cost"])
+    assert losses[-1] < losses[0] - 0.02
+    results = tfm.execute(batch, feedables, model.runners)
+    assert [len(r.outputs[s]) for r, s in zip(results, ("target", "target_beam.rank001", "target_beam.rank002"))] \
+        == [4, 4, 4]
+    assert all("<unk>" not in sent for sent in results[0].outputs["target"])       # supress_unk

@@ -35,6 +35,11 @@ def T(x, dev, dtype=torch.float32):
     (1024, 2048, 256, True, False, 1),      # TN weight-gradient form
     (512, 384, 640, False, True, 1),
     (37, 1000, 8, False, False, 0),
+    (512, 1024, 6400, True, False, 0),      # weight-gradient form, deep K -> split-K slabs
+    (640, 512, 8192, False, True, 0),       # dlogits . W^T form -> split-K
+    (96, 136, 4096, True, True, 2),         # split-K on the 64 tile, ragged
+    (128, 512, 1024, False, True, 3),       # skinny NT with a 64-deep slice per wave
+    (128, 1536, 256, False, False, 3),      # skinny KS=8
 ])
 def test_gemm(dev, m, n, k, ta, tb, algo):
     from neuralmonkey_amd import ops

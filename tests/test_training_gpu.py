@@ -51,6 +51,10 @@ def test_gradients_and_adam_step_match_autograd(dev, vocab, emb, rnn, batch, sle
     for name in store.names():
         got = store.g(name).cpu().numpy().reshape(-1)
         want = ref_g[name].numpy().reshape(-1)
+        if name.endswith("attn_bias"):
+            # d/d(attn_bias) is identically 0 (softmax shift invariance): both sides hold rounding noise
+            assert abs(got[0]) < 1e-5 and abs(want[0]) < 1e-5
+            continue
         scale = max(np.abs(want).max(), 1e-6)   # floor: d/d(attn_bias) is identically 0 (softmax shift invariance)
         worst[name] = float(np.abs(got - want).max() / scale)
     bad = {k: v for k, v in worst.items() if v > 1e-3}
@@ -59,6 +63,8 @@ def test_gradients_and_adam_step_match_autograd(dev, vocab, emb, rnn, batch, sle
     # Adam moments after step 1 pin the clipped gradient: m = (1-b1)*g_clip, v = (1-b2)*g_clip^2
     m, v = store.ensure_adam()
     for name in store.names():
+        if name.endswith("attn_bias"):
+            continue
         g = ref_g[name]
         if clip:
             g = g * (clip / max(float(g.norm()), clip))

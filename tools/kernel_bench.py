@@ -58,7 +58,11 @@ def main():
               ("keys", 6400, 1024, 1024, False, False, 0),
               ("keys 128tile", 6400, 1024, 1024, False, False, 1),
               ("outproj", 6400, 512, 2048, False, False, 0),
-              ("enc xproj", 6400, 3072, 512, False, False, 0)]
+              ("enc xproj", 6400, 3072, 512, False, False, 0),
+              ("wgrad embT.dxp", 512, 1024, 6400, True, False, 0),
+              ("wgrad sT.dy", 512, 1024, 6400, True, False, 0),
+              ("wgrad statesT.dhf", 1024, 1024, 6400, True, False, 0),
+              ("dx = dxp.WT", 6400, 512, 1024, False, True, 0)]
     for name, m, n, k, ta, tb, algo in shapes:
         a = rn(k, m) if ta else rn(m, k)
         b = rn(n, k) if tb else rn(k, n)
