@@ -66,6 +66,24 @@ int nm_gru_step_bwd(void* stream, int phase, float* dh, const float* dout, int64
                     int64_t dx_dir, int64_t dx_row, int64_t dx_time, float* dgpre, float* dcpre,
                     const float* drh, const int32_t* lengths, int t, int rev_mask, int ndir, int64_t R,
                     int64_t H);
+/* One recurrent GEMM of a GRU step with its epilogue fused into the GEMM kernel, so a step is
+ * two launches (gates, candidate) instead of four.  mode 1: C = h.Wg_h -> r,u,r*h;  2: C =
+ * (r*h).Wc_h -> c, h';  3: C = dc_pre.Wc_h^T -> dr_pre, dh += ..;  4: dh += dg_pre.Wg_h^T, then the
+ * blend backward of step `t` on the completed dh.  M = R, N = 2H (mode 1) or H, batch = ndir. */
+typedef struct nm_gru_epilogue {
+    int32_t mode, t, rev_mask, ndir;
+    int64_t R, H;
+    const int32_t* lengths;
+    const float* xp; int64_t x_dir, x_row, x_time;
+    const float* h_in; float* h_out; float* ru; float* rh; float* c_save;
+    float* out; int64_t o_dir, o_row, o_time;
+    float* dh; const float* dout; int64_t do_dir, do_row, do_time;
+    const float* c; const float* h0; const float* hseq; int64_t hs_dir, hs_row, hs_time;
+    float* dxp; int64_t dx_dir, dx_row, dx_time;
+    float* dgpre; float* dcpre;
+} nm_gru_epilogue;
+int nm_gru_gemm(void* stream, const nm_gru_epilogue* epi, int transB, int64_t K, const float* A,
+                int64_t lda, int64_t strideA, const float* B, int64_t ldb, int64_t strideB);
 int nm_gru_seq_shift(void* stream, const float* seq, float* out, const int32_t* lengths, int rev_mask,
                      int64_t B, int64_t S, int ndir, int64_t H);
 int nm_gru_rh_seq(void* stream, const float* ru_all, const float* hprev, float* out,

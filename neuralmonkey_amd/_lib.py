@@ -36,6 +36,7 @@ SIGNATURES = {
     "nm_attn_workspace_bytes": (L, [L, L, L]),
     "nm_attn_fwd": (I, [P, P, P, P, P, P, P, L, L, L, L, L, P, L, P, P, L, P]),
     "nm_gru_rh_seq": (I, [P, P, P, P, P, I, L, L, I, L]),
+    "nm_gru_gemm": (I, [P, P, I, L, P, L, L, P, L, L]),
     "nm_prof_enable": (I, [I]),
     "nm_prof_attn_partial": (I, [P, P]),
     "nm_row_stats": (I, [P, P, L, L, L, P, P, P]),
@@ -62,6 +63,19 @@ SIGNATURES = {
 
 class NMHipError(RuntimeError):
     pass
+
+
+class GruEpilogue(ctypes.Structure):
+    """``nm_gru_epilogue`` of include/nmhip.h."""
+    _fields_ = [("mode", ctypes.c_int32), ("t", ctypes.c_int32), ("rev_mask", ctypes.c_int32),
+                ("ndir", ctypes.c_int32), ("R", L), ("H", L), ("lengths", P),
+                ("xp", P), ("x_dir", L), ("x_row", L), ("x_time", L),
+                ("h_in", P), ("h_out", P), ("ru", P), ("rh", P), ("c_save", P),
+                ("out", P), ("o_dir", L), ("o_row", L), ("o_time", L),
+                ("dh", P), ("dout", P), ("do_dir", L), ("do_row", L), ("do_time", L),
+                ("c", P), ("h0", P), ("hseq", P), ("hs_dir", L), ("hs_row", L), ("hs_time", L),
+                ("dxp", P), ("dx_dir", L), ("dx_row", L), ("dx_time", L),
+                ("dgpre", P), ("dcpre", P)]
 
 
 def load():

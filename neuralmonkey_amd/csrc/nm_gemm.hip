@@ -256,8 +256,107 @@ __global__ void splitk_reduce(GemmArgs g) {
 // ---------------------------------------------------------------------------
 // skinny kernel: A is [M,K] k-contiguous (transA = 0), lda % 4 == 0, K % 8 == 0
 // ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// GRU epilogues fused into the skinny GEMM: every recurrent step of the encoder
+// / decoder is then TWO launches (gates GEMM, candidate GEMM) instead of four.
+// Same arithmetic as the stand-alone kernels in nm_elementwise.hip /
+// nm_backward.hip (TF GRUCell, nn/ortho_gru_cell.py:44-53; dynamic_rnn length
+// masking and reverse_sequence, encoders/recurrent.py:86-102).
+//   mode 1  gates fwd  : s = (h.Wg_h)[row,col];  r|u = sigmoid(xp + s); rh = r*h
+//   mode 2  blend fwd  : s = (rh.Wc_h)[row,col]; c = tanh(xp + s); h' = u*h + (1-u)*c
+//   mode 3  gates bwd  : s = (dc_pre.Wc_h^T)[row,col] = d(r*h); dr_pre; dh += s*r
+//   mode 4  blend bwd  : s = dh (complete for step t_b) -> dc_pre, du_pre, dh*u of step t_b
+// ---------------------------------------------------------------------------
+struct GruEpi {
+    int mode;
+    const int* lengths;
+    int t, rev_mask, H;
+    long R;
+    // forward
+    const float* xp; long x_dir, x_row, x_time;
+    const float* h_in; float* h_out; float* ru; float* rh; float* c_save;
+    float* out; long o_dir, o_row, o_time;
+    // backward
+    float* dh; const float* dout; long do_dir, do_row, do_time;
+    const float* c; const float* h0; const float* hseq; long hs_dir, hs_row, hs_time;
+    float* dxp; long dx_dir, dx_row, dx_time;
+    float* dgpre; float* dcpre;
+};
+
+__device__ __forceinline__ bool gru_epi_pos(const GruEpi& e, int r, int d, int t, int& pos, int& ppos) {
+    pos = t;
+    const bool rev = (e.rev_mask >> d) & 1;
+    if (e.lengths) {
+        const int len = e.lengths[r];
+        if (t >= len) return false;
+        if (rev) pos = len - 1 - t;
+    }
+    ppos = rev ? pos + 1 : pos - 1;
+    return true;
+}
+
+__device__ __forceinline__ float gru_epi_hprev(const GruEpi& e, long ro, int d, int r, int t, int ppos,
+                                               int col) {
+    if (t == 0) return e.h0 ? e.h0[ro * e.H + col] : 0.0f;
+    return e.hseq[d * e.hs_dir + (long)r * e.hs_row + (long)ppos * e.hs_time + col];
+}
+
+__device__ __forceinline__ void gru_epilogue(const GruEpi& e, int d, int row, int col, float s) {
+    const int H = e.H;
+    const long ro = (long)d * e.R + row;
+    int pos, ppos;
+    const bool live = gru_epi_pos(e, row, d, e.t, pos, ppos);
+    if (e.mode == 1) {                                   // N = 2H: col < H -> r, else u
+        float gate = 0.0f;
+        if (live) gate = nm_sigmoid(e.xp[d * e.x_dir + (long)row * e.x_row + (long)pos * e.x_time + col] + s);
+        e.ru[ro * 2 * H + col] = gate;
+        if (col < H) e.rh[ro * H + col] = live ? gate * e.h_in[ro * H + col] : 0.0f;
+    } else if (e.mode == 2) {                            // N = H
+        const float hp = e.h_in[ro * H + col];
+        if (!live) {
+            if (e.h_out != e.h_in) e.h_out[ro * H + col] = hp;
+            if (e.c_save) e.c_save[ro * H + col] = 0.0f;
+            return;
+        }
+        const float c = nm_tanh(e.xp[d * e.x_dir + (long)row * e.x_row + (long)pos * e.x_time + 2 * H + col] + s);
+        const float u = e.ru[ro * 2 * H + H + col];
+        const float hn = u * hp + (1.0f - u) * c;
+        e.h_out[ro * H + col] = hn;
+        if (e.c_save) e.c_save[ro * H + col] = c;
+        if (e.out) e.out[d * e.o_dir + (long)row * e.o_row + (long)pos * e.o_time + col] = hn;
+    } else if (e.mode == 3) {                            // N = H, s = d(r*h)
+        if (!live) { e.dgpre[ro * 2 * H + col] = 0.0f; return; }
+        const float rr = e.ru[ro * 2 * H + col];
+        const float hp = gru_epi_hprev(e, ro, d, row, e.t, ppos, col);
+        const float drp = s * hp * rr * (1.0f - rr);
+        e.dh[ro * H + col] += s * rr;
+        e.dgpre[ro * 2 * H + col] = drp;
+        e.dxp[d * e.dx_dir + (long)row * e.dx_row + (long)pos * e.dx_time + col] = drp;
+    } else {                                             // mode 4, N = H, s = complete dh of step e.t
+        if (!live) {
+            e.dh[ro * H + col] = s;
+            e.dcpre[ro * H + col] = 0.0f;
+            e.dgpre[ro * 2 * H + H + col] = 0.0f;
+            return;
+        }
+        float dhv = s;
+        if (e.dout) dhv += e.dout[d * e.do_dir + (long)row * e.do_row + (long)pos * e.do_time + col];
+        const float u = e.ru[ro * 2 * H + H + col];
+        const float c = e.c[ro * H + col];
+        const float hp = gru_epi_hprev(e, ro, d, row, e.t, ppos, col);
+        const float dcp = dhv * (1.0f - u) * (1.0f - c * c);
+        const float dup = dhv * (hp - c) * u * (1.0f - u);
+        e.dh[ro * H + col] = dhv * u;
+        e.dcpre[ro * H + col] = dcp;
+        e.dgpre[ro * 2 * H + H + col] = dup;
+        float* dx = e.dxp + d * e.dx_dir + (long)row * e.dx_row + (long)pos * e.dx_time;
+        dx[H + col] = dup;
+        dx[2 * H + col] = dcp;
+    }
+}
+
 template <int KS, bool TB>
-__global__ __launch_bounds__(KS * 64) void gemm_skinny(GemmArgs g, int tiles_m) {
+__global__ __launch_bounds__(KS * 64) void gemm_skinny(GemmArgs g, int tiles_m, GruEpi epi) {
     __shared__ float red[KS][16][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bm = blockIdx.x % tiles_m, bn = blockIdx.x / tiles_m;
@@ -319,6 +418,11 @@ __global__ __launch_bounds__(KS * 64) void gemm_skinny(GemmArgs g, int tiles_m) 
         const int col = n0 + (ln & 31);
         const int row = m0 + (reg & 3) + 8 * (reg >> 2) + 4 * (ln >> 5);
         if (row < g.M && col < g.N) {
+            if (epi.mode) {
+                if (g.accumulate) s += C[(long)row * g.ldc + col];     // mode 4: dh_part + dG.Wg_h^T
+                gru_epilogue(epi, blockIdx.z, row, col, s);
+                continue;
+            }
             float* p = C + (long)row * g.ldc + col;
             float v = s + (g.bias ? g.bias[col] : 0.0f);
             if (g.accumulate) v += *p;
@@ -330,6 +434,23 @@ __global__ __launch_bounds__(KS * 64) void gemm_skinny(GemmArgs g, int tiles_m) 
 // ---------------------------------------------------------------------------
 // host dispatch
 // ---------------------------------------------------------------------------
+static void launch_skinny(const GemmArgs& g, int batch, bool tb, const GruEpi& epi, hipStream_t st) {
+    const int tiles_m = nm_cdiv(g.M, 32), tiles_n = nm_cdiv(g.N, 32);
+    dim3 grid(tiles_m * tiles_n, 1, (unsigned)batch);
+    const int K = g.K;
+    const int ks = (K >= 512) ? 16 : (K >= 256 ? 8 : (K >= 128 ? 4 : 1));
+#define NM_GS(KS_)                                                                                   \
+    do {                                                                                             \
+        if (tb) hipLaunchKernelGGL((gemm_skinny<KS_, true>), grid, dim3(KS_ * 64), 0, st, g, tiles_m, epi);  \
+        else hipLaunchKernelGGL((gemm_skinny<KS_, false>), grid, dim3(KS_ * 64), 0, st, g, tiles_m, epi);    \
+    } while (0)
+    if (ks == 16) NM_GS(16);
+    else if (ks == 8) NM_GS(8);
+    else if (ks == 4) NM_GS(4);
+    else NM_GS(1);
+#undef NM_GS
+}
+
 template <int TM, int TN>
 static void launch_tiled(const GemmArgs& g, int batch, bool ta, bool tb, bool vec, hipStream_t st) {
     const int tiles_m = nm_cdiv(g.M, 64 * TM), tiles_n = nm_cdiv(g.N, 64 * TN);
@@ -383,19 +504,7 @@ extern "C" int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int6
     }
     if (pick == 3) {
         NM_REQUIRE(skinny_ok, "nm_gemm_f32: skinny path needs transA=0, aligned A, K%%8==0");
-        const int tiles_m = nm_cdiv(M, 32), tiles_n = nm_cdiv(N, 32);
-        dim3 grid(tiles_m * tiles_n, 1, (unsigned)batch);
-        const int ks = (K >= 512) ? 16 : (K >= 256 ? 8 : (K >= 128 ? 4 : 1));
-#define NM_GS(KS_)                                                                          \
-    do {                                                                                    \
-        if (tb) hipLaunchKernelGGL((gemm_skinny<KS_, true>), grid, dim3(KS_ * 64), 0, st, g, tiles_m);  \
-        else hipLaunchKernelGGL((gemm_skinny<KS_, false>), grid, dim3(KS_ * 64), 0, st, g, tiles_m);    \
-    } while (0)
-        if (ks == 16) NM_GS(16);
-        else if (ks == 8) NM_GS(8);
-        else if (ks == 4) NM_GS(4);
-        else NM_GS(1);
-#undef NM_GS
+        launch_skinny(g, (int)batch, tb, GruEpi{}, st);
     } else {
         // deep-K problems with few output tiles (weight gradients, dlogits.W^T): split K over
         // blockIdx.y into slabs and reduce them in a fixed order, so the chip is filled.
@@ -423,4 +532,50 @@ extern "C" int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int6
         }
     }
     NM_LAUNCH_CHECK("nm_gemm_f32");
+}
+
+// ---------------------------------------------------------------------------
+// one recurrent GEMM of a GRU step with its epilogue fused (see GruEpi above)
+// ---------------------------------------------------------------------------
+struct nm_gru_epilogue {          // mirrors include/nmhip.h
+    int32_t mode, t, rev_mask, ndir;
+    int64_t R, H;
+    const int32_t* lengths;
+    const float* xp; int64_t x_dir, x_row, x_time;
+    const float* h_in; float* h_out; float* ru; float* rh; float* c_save;
+    float* out; int64_t o_dir, o_row, o_time;
+    float* dh; const float* dout; int64_t do_dir, do_row, do_time;
+    const float* c; const float* h0; const float* hseq; int64_t hs_dir, hs_row, hs_time;
+    float* dxp; int64_t dx_dir, dx_row, dx_time;
+    float* dgpre; float* dcpre;
+};
+
+extern "C" int nm_gru_gemm(void* stream, const nm_gru_epilogue* e, int transB, int64_t K, const float* A,
+                           int64_t lda, int64_t strideA, const float* B, int64_t ldb, int64_t strideB) {
+    NM_REQUIRE(e && A && B, "nm_gru_gemm: null pointer");
+    NM_REQUIRE(e->mode >= 1 && e->mode <= 4, "nm_gru_gemm: mode must be 1..4");
+    NM_REQUIRE(e->R > 0 && e->H > 0 && e->H % 4 == 0 && e->ndir >= 1 && e->ndir <= 2 && K > 0 && K % 8 == 0,
+               "nm_gru_gemm: bad shape R=%ld H=%ld K=%ld", (long)e->R, (long)e->H, (long)K);
+    NM_REQUIRE(nm_aligned16(A) && lda % 4 == 0 && strideA % 4 == 0 &&
+                   (!transB || (nm_aligned16(B) && ldb % 4 == 0 && strideB % 4 == 0)),
+               "nm_gru_gemm: operands must be 16-byte aligned with strides %% 4 == 0");
+    const bool fwd = e->mode <= 2;
+    if (fwd) NM_REQUIRE(e->xp && e->h_in && e->ru && (e->mode == 1 ? (e->rh != nullptr) : (e->h_out != nullptr)),
+                        "nm_gru_gemm: missing forward operand");
+    else NM_REQUIRE(e->dh && e->ru && e->hseq && e->dxp && e->dgpre && (e->mode == 3 || (e->c && e->dcpre)),
+                    "nm_gru_gemm: missing backward operand");
+    const int64_t N = (e->mode == 1) ? 2 * e->H : e->H;
+    GemmArgs g{A, B, e->dh, nullptr, (int)e->R, (int)N, (int)K, (long)lda, (long)ldb, (long)e->H,
+               (long)strideA, (long)strideB, (long)(e->R * e->H), 0, e->mode == 4 ? 1 : 0, nullptr, 1};
+    GruEpi d;
+    d.mode = e->mode; d.lengths = e->lengths; d.t = e->t; d.rev_mask = e->rev_mask; d.H = (int)e->H; d.R = e->R;
+    d.xp = e->xp; d.x_dir = e->x_dir; d.x_row = e->x_row; d.x_time = e->x_time;
+    d.h_in = e->h_in; d.h_out = e->h_out; d.ru = e->ru; d.rh = e->rh; d.c_save = e->c_save;
+    d.out = e->out; d.o_dir = e->o_dir; d.o_row = e->o_row; d.o_time = e->o_time;
+    d.dh = e->dh; d.dout = e->dout; d.do_dir = e->do_dir; d.do_row = e->do_row; d.do_time = e->do_time;
+    d.c = e->c; d.h0 = e->h0; d.hseq = e->hseq; d.hs_dir = e->hs_dir; d.hs_row = e->hs_row; d.hs_time = e->hs_time;
+    d.dxp = e->dxp; d.dx_dir = e->dx_dir; d.dx_row = e->dx_row; d.dx_time = e->dx_time;
+    d.dgpre = e->dgpre; d.dcpre = e->dcpre;
+    launch_skinny(g, e->ndir, transB != 0, d, nm_stream(stream));
+    NM_LAUNCH_CHECK("nm_gru_gemm");
 }

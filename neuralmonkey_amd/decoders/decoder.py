@@ -23,6 +23,7 @@ from ..attention.base_attention import AttentionLoopState, BaseAttention
 from ..model.model_part import InitializerSpecs, ModelPart
 from ..model.sequence import EmbeddedSequence
 from ..model.stateful import Stateful
+from ..nn import gru
 from ..nn.dropout import dropout
 from ..runtime import tensor
 from ..variables import constant_initializer, orthogonal_initializer, zeros_initializer
@@ -194,12 +195,8 @@ class Decoder(AutoregressiveDecoder):
         h = self.rnn_size
         rows = h_prev.shape[0]
         rh = bufs["rh"] if rh is None else rh
-        ops.gemm(h_prev, cell["wg_h"], out=bufs["hg"])
-        ops.gru_gates_fwd(xp, 0, 3 * h, x_time_stride, bufs["hg"], h_prev, ru, rh, None,
-                          t_index, 1, rows, h)
-        ops.gemm(rh, cell["wc_h"], out=bufs["hc"])
-        ops.gru_blend_fwd(xp, 0, 3 * h, x_time_stride, bufs["hc"], ru, h_prev, h_out, c_save, None,
-                          0, 0, 0, None, t_index, 1, rows, h)
+        gru.step_fwd(xp, (0, 3 * h, x_time_stride), h_prev, h_out, cell["wg_h"], cell["wc_h"], ru, rh, c_save,
+                     None, (0, 0, 0), None, t_index, 1, rows, h, False, bufs["hg"], bufs["hc"])
 
     def _step_bufs(self, ctx, rows):
         h = self.rnn_size
@@ -350,7 +347,7 @@ class Decoder(AutoregressiveDecoder):
         # ---- BPTT through the GRU (the only recurrence)
         dh = ctx.buffer(key + ("dh",), (1, bsz, h), zero=True)
         dxp = ctx.buffer(key + ("dxp",), (rows, 3 * h))
-        dgpre = ctx.buffer(key + ("dgpre",), (1, bsz, 2 * h))
+        dgpre = ctx.buffer(key + ("dgpre",), (2, 1, bsz, 2 * h))
         dcpre = ctx.buffer(key + ("dcpre",), (1, bsz, h))
         drh = ctx.buffer(key + ("drh",), (1, bsz, h))
         s_all = sv["s_all"]
@@ -358,13 +355,9 @@ class Decoder(AutoregressiveDecoder):
         dxp_strides = (0, 3 * h, bsz * 3 * h)
         def bptt_loop():
             dh.zero_()
-            for t in range(steps - 1, -1, -1):
-                ops.gru_step_bwd(0, dh, d_s, seq_strides, sv["ru_all"][t], sv["c_all"][t], sv["s0"], s_all,
-                                 seq_strides, dxp, dxp_strides, dgpre, dcpre, None, None, t, 1, bsz, h)
-                ops.gemm(dcpre[0], cell["wc_h"], out=drh[0], trans_b=True)
-                ops.gru_step_bwd(1, dh, None, None, sv["ru_all"][t], None, sv["s0"], s_all, seq_strides, dxp,
-                                 dxp_strides, dgpre, None, drh, None, t, 1, bsz, h)
-                ops.gemm(dgpre[0], cell["wg_h"], out=dh[0], trans_b=True, accumulate=True)
+            gru.bptt(steps, dh, d_s, seq_strides, sv["ru_all"], sv["c_all"], sv["s0"], s_all, seq_strides, dxp,
+                     dxp_strides, cell["wg_h"].unsqueeze(0), cell["wc_h"].unsqueeze(0), None, 1, bsz, h, False,
+                     dgpre, dcpre, drh)
         ctx.session.graphed((id(self), "bptt_loop", bsz, steps), bptt_loop)
         ds0 = dh[0]
 

@@ -19,6 +19,7 @@ from .. import ops
 from ..model.model_part import InitializerSpecs, ModelPart
 from ..model.sequence import EmbeddedSequence
 from ..model.stateful import TemporalStateful, TemporalStatefulWithOutput
+from ..nn import gru
 from ..nn.dropout import dropout
 from ..runtime import tensor
 from ..variables import ones_initializer, orthogonal_initializer, zeros_initializer, constant_initializer
@@ -181,13 +182,8 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
             hcur.zero_()
             for t in range(slen):
                 ru = ru_all[t] if train else ru_all[0]
-                ops.gemm(hcur, wgh, out=hg)
-                ops.gru_gates_fwd(xp, 3 * h, xrs, xts, hg, hcur, ru, rh, len_arg, t, ndir, bsz, h,
-                                  reverse_dir0=reverse_only)
-                ops.gemm(rh, wch, out=hc)
-                ops.gru_blend_fwd(xp, 3 * h, xrs, xts, hc, ru, hcur, hcur, c_all[t] if train else None,
-                                  states_raw, h, ors, ots, len_arg, t, ndir, bsz, h,
-                                  reverse_dir0=reverse_only)
+                gru.step_fwd(xp, (3 * h, xrs, xts), hcur, hcur, wgh, wch, ru, rh, c_all[t] if train else None,
+                             states_raw, (h, ors, ots), len_arg, t, ndir, bsz, h, reverse_only, hg, hc)
         ctx.session.graphed((key, "fwd_loop", bsz, slen, train), time_loop)
         final_raw = ctx.buffer((key, "final_raw"), (bsz, c_out))
         for d in range(ndir):
@@ -249,22 +245,16 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
             for d in range(ndir):
                 ops.copy_cols(d_final_raw[:, d * h:(d + 1) * h], dh[d])
         dxp = ctx.buffer(key + ("dxp",), (bsz * slen, ndir * 3 * h), zero=True)
-        dgpre = ctx.buffer(key + ("dgpre",), (ndir, bsz, 2 * h))
+        dgpre = ctx.buffer(key + ("dgpre",), (2, ndir, bsz, 2 * h))
         dcpre = ctx.buffer(key + ("dcpre",), (ndir, bsz, h))
         drh = ctx.buffer(key + ("drh",), (ndir, bsz, h))
         seq_strides = (h, slen * c_out, c_out)
         dxp_strides = (3 * h, slen * ndir * 3 * h, ndir * 3 * h)
         wgh, wch = sv["wgh"], sv["wch"]
         def bptt_loop():
-            for t in range(slen - 1, -1, -1):
-                ops.gru_step_bwd(0, dh, d_states_raw, seq_strides if d_states_raw is not None else None,
-                                 sv["ru_all"][t], sv["c_all"][t], None, states_raw, seq_strides, dxp,
-                                 dxp_strides, dgpre, dcpre, None, lengths, t, ndir, bsz, h, reverse_dir0=rev0)
-                ops.gemm(dcpre, wch, out=drh, trans_b=True)
-                ops.gru_step_bwd(1, dh, None, None, sv["ru_all"][t], None, None, states_raw, seq_strides,
-                                 dxp, dxp_strides, dgpre, None, drh, lengths, t, ndir, bsz, h,
-                                 reverse_dir0=rev0)
-                ops.gemm(dgpre, wgh, out=dh, trans_b=True, accumulate=True)
+            gru.bptt(slen, dh, d_states_raw, seq_strides if d_states_raw is not None else None, sv["ru_all"],
+                     sv["c_all"], None, states_raw, seq_strides, dxp, dxp_strides, wgh, wch, lengths, ndir, bsz,
+                     h, rev0, dgpre, dcpre, drh)
         ctx.session.graphed((id(self), "bwd_loop", bsz, slen, d_states_raw is not None), bptt_loop)
 
         # ---- weight gradients, batched over all positions

@@ -3,6 +3,7 @@
 torch is used only as the device allocator and stream owner; every arithmetic
 op on the hot path is a libnmhip kernel launched on torch's current stream.
 """
+import ctypes
 from typing import Optional
 
 import numpy as np
@@ -324,6 +325,37 @@ def attn_energy_bwd(de, hf, y, v, dhf, dv_partial, dy):
     _lib.check(lib.nm_attn_energy_bwd(_stream(), de.data_ptr(), hf.data_ptr(), y.data_ptr(), v.data_ptr(),
                                       dhf.data_ptr(), dv_partial.data_ptr(), dy.data_ptr(), t, b, s, a),
                "nm_attn_energy_bwd")
+
+
+def gru_gemm(mode, a, b, trans_b, t, ndir, rows, hsz, lengths=None, reverse_dir0=False, xp=None,
+             x_strides=(0, 0, 0), h_in=None, h_out=None, ru=None, rh=None, c_save=None, out=None,
+             out_strides=(0, 0, 0), dh=None, dout=None, dout_strides=(0, 0, 0), c=None, h0=None, hseq=None,
+             hseq_strides=(0, 0, 0), dxp=None, dxp_strides=(0, 0, 0), dgpre=None, dcpre=None):
+    """Recurrent GEMM of one GRU step with the fused epilogue ``mode`` (nm_gru_gemm).
+    a: [ndir,R,K] (or [R,K]); b: [ndir,K,N] / [ndir,N,K] when trans_b (or 2-D for ndir == 1)."""
+    lib = _lib.load()
+    e = _lib.GruEpilogue()
+    e.mode, e.t, e.rev_mask, e.ndir, e.R, e.H = mode, t, _rev_mask(ndir, reverse_dir0), ndir, rows, hsz
+    e.lengths = _p(lengths)
+    e.xp = _p(xp)
+    e.x_dir, e.x_row, e.x_time = x_strides
+    e.h_in, e.h_out, e.ru, e.rh, e.c_save, e.out = _p(h_in), _p(h_out), _p(ru), _p(rh), _p(c_save), _p(out)
+    e.o_dir, e.o_row, e.o_time = out_strides
+    e.dh, e.dout = _p(dh), _p(dout)
+    e.do_dir, e.do_row, e.do_time = dout_strides
+    e.c, e.h0, e.hseq = _p(c), _p(h0), _p(hseq)
+    e.hs_dir, e.hs_row, e.hs_time = hseq_strides
+    e.dxp = _p(dxp)
+    e.dx_dir, e.dx_row, e.dx_time = dxp_strides
+    e.dgpre, e.dcpre = _p(dgpre), _p(dcpre)
+    a2 = a[0] if a.dim() == 3 else a
+    b2 = b[0] if b.dim() == 3 else b
+    assert a2.stride(1) == 1 and b2.stride(1) == 1
+    k = a2.shape[1]
+    s_a = a.stride(0) if a.dim() == 3 else 0
+    s_b = b.stride(0) if b.dim() == 3 else 0
+    _lib.check(lib.nm_gru_gemm(_stream(), ctypes.byref(e), int(trans_b), k, a.data_ptr(), a2.stride(0), s_a,
+                               b.data_ptr(), b2.stride(0), s_b), "nm_gru_gemm")
 
 
 class OptimizerTables:
