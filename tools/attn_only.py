@@ -1,0 +1,33 @@
+"""Runs only the fused attention step at the benchmark shape (for PMC passes:
+rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE -- python tools/attn_only.py)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from neuralmonkey_amd import ops  # noqa: E402
+
+B, S, A, C = 128, 50, 1024, 1024
+qpk = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(0)
+r = B * qpk
+y = torch.randn(r, A, device=dev, generator=g)
+hf = torch.randn(B, S, A, device=dev, generator=g)
+st = torch.randn(B, S, C, device=dev, generator=g)
+mask = torch.ones(B, S, device=dev)
+v = torch.randn(A, device=dev, generator=g)
+bias = torch.zeros(1, device=dev)
+ctx = torch.empty(r, C, device=dev)
+w = torch.empty(r, S, device=dev)
+ws = ops.attn_workspace(r, S, C, dev)
+# a 512 MB sweep between launches evicts hf/states from the 256 MB Infinity Cache so the
+# counters see HBM traffic, as inside a training step where 800 MB of logits pass in between
+flush = torch.empty(128 << 20, device=dev)
+for i in range(iters):
+    flush.fill_(float(i))
+    ops.attn_fwd(y, hf, st, mask, v, bias, qpk, ctx, w, ws)
+torch.cuda.synchronize()
+print("done", float(ctx.sum()))
