@@ -205,6 +205,82 @@ __global__ __launch_bounds__(256) void attn_partial(AttnArgs p) {
         }
 }
 
+// ---------------------------------------------------------------------------
+// Fast path: one query per key batch (greedy decoding and every training
+// step), A <= 1024, C <= 1024.  Every HBM load of the block -- its rows of hf
+// AND of states, 2 x 12 x 16 B per lane -- is issued before any arithmetic, so
+// the block pays one memory latency instead of one per row group per phase;
+// y / v slices live in registers (no LDS staging), one __syncthreads, and the
+// chunk softmax is evaluated redundantly per thread instead of serially.
+// ---------------------------------------------------------------------------
+#define ATT_FAST_ROWS 12
+template <int ROWS>
+__global__ __launch_bounds__(256) void attn_partial_fast(AttnArgs p) {
+    __shared__ float pe[4][ATT_MAX_SCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = blockIdx.x, b = blockIdx.y;
+    const int s0 = chunk * p.sch;
+    const int ns = min(p.sch, p.S - s0);
+    const int col = wave * 256 + lane * 4;
+    const bool a_ok = col < p.A, c_ok = col < p.C;
+    // out-of-range lanes / rows read a valid address and are weighted by zero below:
+    // no branch sits between the loads, so all 2*ROWS of them are in flight together
+    const float* hbase = p.hf + ((long)b * p.S + s0) * p.A + (a_ok ? col : 0);
+    const float* sbase = p.states + ((long)b * p.S + s0) * p.C + (c_ok ? col : 0);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    float4 hfr[ROWS], str[ROWS];
+#pragma unroll
+    for (int s = 0; s < ROWS; ++s)
+        hfr[s] = *reinterpret_cast<const float4*>(hbase + (long)min(s, ns - 1) * p.A);
+#pragma unroll
+    for (int s = 0; s < ROWS; ++s)
+        str[s] = *reinterpret_cast<const float4*>(sbase + (long)min(s, ns - 1) * p.C);
+    const float4 y4 = *reinterpret_cast<const float4*>(p.y + (long)b * p.A + (a_ok ? col : 0));
+    float4 v4 = *reinterpret_cast<const float4*>(p.v + (a_ok ? col : 0));
+    if (!a_ok) v4 = zero4;
+    const float bias = p.bias ? p.bias[0] : 0.0f;
+
+#pragma unroll
+    for (int s = 0; s < ROWS; ++s) {
+        float part = v4.x * nm_tanh(hfr[s].x + y4.x) + v4.y * nm_tanh(hfr[s].y + y4.y) +
+                     v4.z * nm_tanh(hfr[s].z + y4.z) + v4.w * nm_tanh(hfr[s].w + y4.w);
+        part = nm_wave_sum(part);
+        if (lane == 0) pe[wave][s] = part;
+    }
+    __syncthreads();
+
+    float e[ROWS];
+    float m = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < ROWS; ++s) {
+        e[s] = ((pe[0][s] + pe[1][s]) + (pe[2][s] + pe[3][s])) + bias;
+        if (s < ns) m = fmaxf(m, e[s]);
+    }
+    float la = 0.0f, lm = 0.0f;
+    float4 acc = zero4;
+#pragma unroll
+    for (int s = 0; s < ROWS; ++s) {
+        const bool ok = s < ns;
+        const float ex = ok ? __expf(e[s] - m) : 0.0f;
+        const float mk = (ok && p.mask) ? p.mask[(long)b * p.S + s0 + s] : 1.0f;
+        const float em = ex * mk;
+        la += ex;
+        lm += em;
+        acc.x += em * str[s].x; acc.y += em * str[s].y;
+        acc.z += em * str[s].z; acc.w += em * str[s].w;
+    }
+    if (tid < ns)
+        p.energies[(long)b * p.S + s0 + tid] =
+            ((pe[0][tid] + pe[1][tid]) + (pe[2][tid] + pe[3][tid])) + bias;
+    if (tid == 0) {
+        float* st = p.pstat + ((long)b * p.nchunk + chunk) * 4;
+        st[0] = m; st[1] = la; st[2] = lm; st[3] = 0.0f;
+    }
+    if (c_ok)
+        *reinterpret_cast<float4*>(p.pctx + ((long)b * p.nchunk + chunk) * p.C + col) = acc;
+}
+
 __global__ __launch_bounds__(256) void attn_combine(const float* __restrict__ pctx,
                                                     const float* __restrict__ pstat,
                                                     const float* __restrict__ energies,
@@ -315,6 +391,12 @@ extern "C" int nm_attn_fwd(void* stream, const float* y, const float* hf, const 
     } while (0)
     std::pair<hipEvent_t, hipEvent_t>* prof = g_prof_on ? prof_next_pair() : nullptr;
     if (prof) hipEventRecord(prof->first, st);
+    static const bool no_fast = getenv("NM_ATTN_NOFAST") != nullptr;       // A/B switch for tuning
+    if (qpk == 1 && A <= 1024 && C <= 1024 && sch <= ATT_FAST_ROWS && !no_fast) {
+        if (sch <= 8) hipLaunchKernelGGL(attn_partial_fast<8>, grid, block, 0, st, p);
+        else if (sch <= 10) hipLaunchKernelGGL(attn_partial_fast<10>, grid, block, 0, st, p);
+        else hipLaunchKernelGGL(attn_partial_fast<12>, grid, block, 0, st, p);
+    } else
     switch (qpk) {
         case 1: NM_AT(1); break;
         case 2: NM_AT(2); break;

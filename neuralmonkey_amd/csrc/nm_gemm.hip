@@ -19,6 +19,8 @@
 //                 throughput-bound, so the grid is (M/32)*(N/32) blocks.
 #include "nm_common.h"
 
+#include <stdlib.h>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct GemmArgs {
@@ -432,12 +434,110 @@ __global__ __launch_bounds__(KS * 64) void gemm_skinny(GemmArgs g, int tiles_m, 
 }
 
 // ---------------------------------------------------------------------------
+// skinny kernel on 16x16 tiles (v_mfma_f32_16x16x4_f32): same structure, 4x the
+// workgroups.  A decoder-step GEMM is 134 MFLOP; with 32x32 tiles it runs on
+// 64-128 of the 256 CUs and is bound by their MFMA issue rate, with 16x16 tiles
+// every CU gets work.  Fragment: lane l holds A[l&15][4*(l>>4)+j], j = 0..3 from
+// one 16-byte load; C/D: col = lane&15, row = 4*(lane>>4) + reg.
+// ---------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int KS, bool TB>
+__global__ __launch_bounds__(KS * 64) void gemm_skinny16(GemmArgs g, int tiles_m, GruEpi epi) {
+    __shared__ float red[KS][4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bm = blockIdx.x % tiles_m, bn = blockIdx.x / tiles_m;
+    const int m0 = bm * 16, n0 = bn * 16;
+    const float* __restrict__ A = g.A + (long)blockIdx.z * g.sA;
+    const float* __restrict__ B = g.B + (long)blockIdx.z * g.sB;
+    float* __restrict__ C = g.C + (long)blockIdx.z * g.sC;
+
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int mm = min(m0 + i16, g.M - 1), nn = min(n0 + i16, g.N - 1);
+    const int kper = ((g.K / 16 + KS - 1) / KS) * 16;
+    const int kbeg = wave * kper, kend = min(g.K, kbeg + kper);
+
+    f32x4 acc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = 0.0f;
+
+    const float* ap = A + (long)mm * g.lda + 4 * kq;
+    const float* bp = TB ? (B + (long)nn * g.ldb + 4 * kq) : (B + (long)(4 * kq) * g.ldb + nn);
+    for (int k0 = kbeg; k0 < kend; k0 += 64) {
+        float4 av[4], bv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k = k0 + 16 * c;
+            av[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            bv[c] = av[c];
+            if (k + 4 * kq < kend) {
+                av[c] = *reinterpret_cast<const float4*>(ap + k);
+                if (TB) {
+                    bv[c] = *reinterpret_cast<const float4*>(bp + k);
+                } else {
+                    const float* q = bp + (long)k * g.ldb;
+                    bv[c].x = q[0];
+                    bv[c].y = q[g.ldb];
+                    bv[c].z = q[2 * g.ldb];
+                    bv[c].w = q[3 * g.ldb];
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (k0 + 16 * c >= kend) break;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c].x, bv[c].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c].y, bv[c].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c].z, bv[c].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c].w, bv[c].w, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[wave][i][lane] = acc[i];
+    __syncthreads();
+    for (int o = tid; o < 4 * 64; o += KS * 64) {
+        const int reg = o >> 6, ln = o & 63;
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < KS; ++w) s += red[w][reg][ln];
+        const int col = n0 + (ln & 15);
+        const int row = m0 + 4 * (ln >> 4) + reg;
+        if (row < g.M && col < g.N) {
+            if (epi.mode) {
+                if (g.accumulate) s += C[(long)row * g.ldc + col];
+                gru_epilogue(epi, blockIdx.z, row, col, s);
+                continue;
+            }
+            float* p = C + (long)row * g.ldc + col;
+            float v = s + (g.bias ? g.bias[col] : 0.0f);
+            if (g.accumulate) v += *p;
+            *p = apply_act(v, g.act);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // host dispatch
 // ---------------------------------------------------------------------------
 static void launch_skinny(const GemmArgs& g, int batch, bool tb, const GruEpi& epi, hipStream_t st) {
+    const int K = g.K;
+    static const bool no16 = getenv("NM_GEMM_NO16") != nullptr;              // A/B switch for tuning
+    if (!no16 && K >= 256 && (long)nm_cdiv(g.M, 32) * nm_cdiv(g.N, 32) * batch < 256) {
+        const int tiles_m = nm_cdiv(g.M, 16), tiles_n = nm_cdiv(g.N, 16);
+        dim3 grid(tiles_m * tiles_n, 1, (unsigned)batch);
+        const int ks = (K >= 512) ? 16 : 8;
+#define NM_GS16(KS_)                                                                                       \
+    do {                                                                                                   \
+        if (tb) hipLaunchKernelGGL((gemm_skinny16<KS_, true>), grid, dim3(KS_ * 64), 0, st, g, tiles_m, epi);  \
+        else hipLaunchKernelGGL((gemm_skinny16<KS_, false>), grid, dim3(KS_ * 64), 0, st, g, tiles_m, epi);    \
+    } while (0)
+        if (ks == 16) NM_GS16(16);
+        else NM_GS16(8);
+#undef NM_GS16
+        return;
+    }
     const int tiles_m = nm_cdiv(g.M, 32), tiles_n = nm_cdiv(g.N, 32);
     dim3 grid(tiles_m * tiles_n, 1, (unsigned)batch);
-    const int K = g.K;
     const int ks = (K >= 512) ? 16 : (K >= 256 ? 8 : (K >= 128 ? 4 : 1));
 #define NM_GS(KS_)                                                                                   \
     do {                                                                                             \

@@ -63,12 +63,14 @@ def test_gemm(dev, m, n, k, ta, tb, algo):
 def test_gemm_transpose_detecting(dev):
     """A = I with an asymmetric B catches a swapped C layout."""
     from neuralmonkey_amd import ops
-    n = 96
-    a = np.eye(n, dtype=np.float32)
-    b = (np.arange(n * n, dtype=np.float32).reshape(n, n) % 97) * 0.25
-    for algo in (1, 2, 3):
-        out = ops.gemm(T(a, dev), T(b, dev), algo=algo)
-        assert np.array_equal(out.cpu().numpy(), b)
+    for n in (96, 256):                  # 256: the skinny path switches to its 16x16-tile kernel
+        a = np.eye(n, dtype=np.float32)
+        b = (np.arange(n * n, dtype=np.float32).reshape(n, n) % 97) * 0.25
+        for algo in (1, 2, 3):
+            out = ops.gemm(T(a, dev), T(b, dev), algo=algo)
+            assert np.array_equal(out.cpu().numpy(), b)
+            out = ops.gemm(T(a, dev), T(np.ascontiguousarray(b.T), dev), trans_b=True, algo=algo)
+            assert np.array_equal(out.cpu().numpy(), b)
 
 
 def test_gemm_batched_strided(dev):
