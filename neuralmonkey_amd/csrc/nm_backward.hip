@@ -35,28 +35,35 @@ extern "C" int nm_tanh_bwd(void* stream, float* dy, const float* y, int64_t n) {
 // column sums (bias gradients): out[c] (+)= sum_r x[r,c].  Deterministic two
 // stage: RSPLIT row slices -> partial[RSPLIT][cols] -> fixed-order sum.
 // ---------------------------------------------------------------------------
-#define COLSUM_RSPLIT 32
-__global__ void colsum_partial_kernel(const float* __restrict__ x, long ldx, long rows, int cols,
-                                      float* __restrict__ part) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
+// A block is 64 columns x 4 row lanes over one slice of <= 32 rows (8 rows per thread, all
+// loads independent), so even a [6400, 512] operand launches 1600 workgroups.
+#define COLSUM_MAX_SPLIT 256
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, long ldx,
+                                                             long rows, int cols, int nsplit,
+                                                             float* __restrict__ part) {
+    __shared__ float sh[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
     const int sl = blockIdx.y;
-    const long per = (rows + COLSUM_RSPLIT - 1) / COLSUM_RSPLIT;
+    const long per = (rows + nsplit - 1) / nsplit;
     const long r0 = sl * per, r1 = min(rows, r0 + per);
     float s = 0.0f;
-    for (long r = r0; r < r1; ++r) s += x[r * ldx + c];
-    part[(long)sl * cols + c] = s;
+    if (c < cols)
+        for (long r = r0 + ry; r < r1; r += 4) s += x[r * ldx + c];
+    sh[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && c < cols) part[(long)sl * cols + c] = (sh[0][cx] + sh[1][cx]) + (sh[2][cx] + sh[3][cx]);
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, int cols, float* __restrict__ out,
-                                    int accumulate) {
+__global__ void colsum_final_kernel(const float* __restrict__ part, int cols, int nsplit,
+                                    float* __restrict__ out, int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= cols) return;
     float s = 0.0f;
-    for (int k = 0; k < COLSUM_RSPLIT; ++k) s += part[(long)k * cols + c];
+    for (int k = 0; k < nsplit; ++k) s += part[(long)k * cols + c];
     out[c] = accumulate ? out[c] + s : s;
 }
 
-extern "C" int64_t nm_colsum_workspace_bytes(int64_t cols) { return cols * COLSUM_RSPLIT * 4; }
+extern "C" int64_t nm_colsum_workspace_bytes(int64_t cols) { return cols * COLSUM_MAX_SPLIT * 4; }
 
 extern "C" int nm_colsum(void* stream, const float* x, int64_t ldx, int64_t rows, int64_t cols, float* out,
                          int accumulate, void* workspace, int64_t workspace_bytes) {
@@ -64,10 +71,13 @@ extern "C" int nm_colsum(void* stream, const float* x, int64_t ldx, int64_t rows
     NM_REQUIRE(workspace_bytes >= nm_colsum_workspace_bytes(cols), "nm_colsum: workspace too small");
     hipStream_t st = nm_stream(stream);
     float* part = reinterpret_cast<float*>(workspace);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nm_cdiv(cols, 256), COLSUM_RSPLIT), dim3(256), 0, st, x,
-                       (long)ldx, (long)rows, (int)cols, part);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(nm_cdiv(cols, 256)), dim3(256), 0, st, part, (int)cols, out,
-                       accumulate);
+    int nsplit = (int)((rows + 31) / 32);
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > COLSUM_MAX_SPLIT) nsplit = COLSUM_MAX_SPLIT;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nm_cdiv(cols, 64), nsplit), dim3(256), 0, st, x,
+                       (long)ldx, (long)rows, (int)cols, nsplit, part);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(nm_cdiv(cols, 256)), dim3(256), 0, st, part, (int)cols,
+                       nsplit, out, accumulate);
     NM_LAUNCH_CHECK("nm_colsum");
 }
 

@@ -263,9 +263,37 @@ __global__ __launch_bounds__(1024) void reduce_sum_kernel(const float* __restric
     }
 }
 
+// two-stage variant for long vectors: 64 fixed slices -> library-owned partials -> final sum
+__device__ float g_reduce_partials[64];
+__global__ __launch_bounds__(1024) void reduce_sum_slices_kernel(const float* __restrict__ x, long n) {
+    __shared__ float sh[16];
+    const long per = (n + 63) / 64;
+    const long beg = blockIdx.x * per, end = min(n, beg + per);
+    float s = 0.0f;
+    for (long i = beg + threadIdx.x; i < end; i += 1024) s += x[i];
+    s = nm_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+        for (int k = 0; k < 16; ++k) t += sh[k];
+        g_reduce_partials[blockIdx.x] = t;
+    }
+}
+__global__ void reduce_sum_final_kernel(float* __restrict__ out) {
+    float t = 0.0f;
+    for (int k = 0; k < 64; ++k) t += g_reduce_partials[k];
+    out[0] = t;
+}
+
 extern "C" int nm_reduce_sum(void* stream, const float* x, int64_t n, float* out) {
     NM_REQUIRE(x && out && n >= 0, "nm_reduce_sum: bad args");
-    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(1024), 0, nm_stream(stream), x, (long)n, out);
+    if (n > 65536) {
+        hipLaunchKernelGGL(reduce_sum_slices_kernel, dim3(64), dim3(1024), 0, nm_stream(stream), x, (long)n);
+        hipLaunchKernelGGL(reduce_sum_final_kernel, dim3(1), dim3(1), 0, nm_stream(stream), out);
+    } else {
+        hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(1024), 0, nm_stream(stream), x, (long)n, out);
+    }
     NM_LAUNCH_CHECK("nm_reduce_sum");
 }
 

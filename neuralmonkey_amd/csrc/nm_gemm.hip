@@ -65,9 +65,10 @@ __device__ __forceinline__ void store_tile32(const GemmArgs& g, float* __restric
 // ---------------------------------------------------------------------------
 // tiled kernel
 // ---------------------------------------------------------------------------
-template <int TM, int TN, bool TA, bool TB, bool VEC>
+template <int TM, int TN, bool TA, bool TB, bool VEC, int BK>
 __global__ __launch_bounds__(256) void gemm_tiled(GemmArgs g, int tiles_m) {
-    constexpr int BM = 64 * TM, BN = 64 * TN, BK = 16;
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int LA = TM * BK / 16, LB = TN * BK / 16, KQ = BK / 4;   // float4 loads per thread; float4s per k-row
     constexpr int LDAS = BM + 4, LDBS = BN + 4;
     __shared__ __attribute__((aligned(16))) float As[2][BK][LDAS];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDBS];
@@ -79,15 +80,15 @@ __global__ __launch_bounds__(256) void gemm_tiled(GemmArgs g, int tiles_m) {
     const float* __restrict__ B = g.B + (long)blockIdx.z * g.sB;
     float* __restrict__ C = g.C + (long)blockIdx.z * g.sC;
 
-    float4 ra[TM], rb[TN];
+    float4 ra[LA], rb[LB];
 
     auto load_a = [&](int k0) {
 #pragma unroll
-        for (int it = 0; it < TM; ++it) {
+        for (int it = 0; it < LA; ++it) {
             const int idx = tid + it * 256;
             int m, k;
             if (TA) { k = idx / (BM / 4); m = (idx % (BM / 4)) * 4; }   // m contiguous
-            else    { m = idx / 4;        k = (idx % 4) * 4; }          // k contiguous
+            else    { m = idx / KQ;       k = (idx % KQ) * 4; }         // k contiguous
             const int gm = m0 + m, gk = k0 + k;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (TA) {
@@ -118,11 +119,11 @@ __global__ __launch_bounds__(256) void gemm_tiled(GemmArgs g, int tiles_m) {
     };
     auto load_b = [&](int k0) {
 #pragma unroll
-        for (int it = 0; it < TN; ++it) {
+        for (int it = 0; it < LB; ++it) {
             const int idx = tid + it * 256;
             int n, k;
             if (!TB) { k = idx / (BN / 4); n = (idx % (BN / 4)) * 4; }  // n contiguous
-            else     { n = idx / 4;        k = (idx % 4) * 4; }         // k contiguous
+            else     { n = idx / KQ;       k = (idx % KQ) * 4; }        // k contiguous
             const int gn = n0 + n, gk = k0 + k;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (!TB) {
@@ -153,13 +154,13 @@ __global__ __launch_bounds__(256) void gemm_tiled(GemmArgs g, int tiles_m) {
     };
     auto store_lds = [&](int buf) {
 #pragma unroll
-        for (int it = 0; it < TM; ++it) {
+        for (int it = 0; it < LA; ++it) {
             const int idx = tid + it * 256;
             if (TA) {
                 const int k = idx / (BM / 4), m = (idx % (BM / 4)) * 4;
                 *reinterpret_cast<float4*>(&As[buf][k][m]) = ra[it];
             } else {
-                const int m = idx / 4, k = (idx % 4) * 4;
+                const int m = idx / KQ, k = (idx % KQ) * 4;
                 As[buf][k + 0][m] = ra[it].x;
                 As[buf][k + 1][m] = ra[it].y;
                 As[buf][k + 2][m] = ra[it].z;
@@ -167,13 +168,13 @@ __global__ __launch_bounds__(256) void gemm_tiled(GemmArgs g, int tiles_m) {
             }
         }
 #pragma unroll
-        for (int it = 0; it < TN; ++it) {
+        for (int it = 0; it < LB; ++it) {
             const int idx = tid + it * 256;
             if (!TB) {
                 const int k = idx / (BN / 4), n = (idx % (BN / 4)) * 4;
                 *reinterpret_cast<float4*>(&Bs[buf][k][n]) = rb[it];
             } else {
-                const int n = idx / 4, k = (idx % 4) * 4;
+                const int n = idx / KQ, k = (idx % KQ) * 4;
                 Bs[buf][k + 0][n] = rb[it].x;
                 Bs[buf][k + 1][n] = rb[it].y;
                 Bs[buf][k + 2][n] = rb[it].z;
@@ -551,12 +552,12 @@ static void launch_skinny(const GemmArgs& g, int batch, bool tb, const GruEpi& e
 #undef NM_GS
 }
 
-template <int TM, int TN>
+template <int TM, int TN, int BK>
 static void launch_tiled(const GemmArgs& g, int batch, bool ta, bool tb, bool vec, hipStream_t st) {
     const int tiles_m = nm_cdiv(g.M, 64 * TM), tiles_n = nm_cdiv(g.N, 64 * TN);
     dim3 grid(tiles_m * tiles_n, g.splitk, batch), block(256);
 #define NM_GT(TA_, TB_, V_) \
-    hipLaunchKernelGGL((gemm_tiled<TM, TN, TA_, TB_, V_>), grid, block, 0, st, g, tiles_m)
+    hipLaunchKernelGGL((gemm_tiled<TM, TN, TA_, TB_, V_, BK>), grid, block, 0, st, g, tiles_m)
     if (vec) {
         if (!ta && !tb) NM_GT(false, false, true);
         else if (!ta && tb) NM_GT(false, true, true);
@@ -624,8 +625,14 @@ extern "C" int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int6
                 }
             }
         }
-        if (pick == 1) launch_tiled<2, 2>(g, (int)batch, ta, tb, vec, st);
-        else launch_tiled<1, 1>(g, (int)batch, ta, tb, vec, st);
+        static const int bk_env = getenv("NM_GEMM_BK") ? atoi(getenv("NM_GEMM_BK")) : 16;   // tuning knob
+        if (pick == 1) {
+            if (bk_env == 32) launch_tiled<2, 2, 32>(g, (int)batch, ta, tb, vec, st);
+            else launch_tiled<2, 2, 16>(g, (int)batch, ta, tb, vec, st);
+        } else {
+            if (bk_env == 32) launch_tiled<1, 1, 32>(g, (int)batch, ta, tb, vec, st);
+            else launch_tiled<1, 1, 16>(g, (int)batch, ta, tb, vec, st);
+        }
         if (g.splitk > 1) {
             const long total = (long)M * N;
             hipLaunchKernelGGL(splitk_reduce, dim3(nm_cdiv(total, 256)), dim3(256), 0, st, g);

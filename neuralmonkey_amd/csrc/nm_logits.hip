@@ -133,20 +133,38 @@ __global__ __launch_bounds__(NT) void xent_kernel(float* __restrict__ x, long ld
                                                   float* __restrict__ loss_rows,
                                                   const float* __restrict__ grad_scale,
                                                   int write_grad) {
-    __shared__ float shv[NT / 64];
-    __shared__ int shi[NT / 64];
+    __shared__ float shm[NT / 64], shs[NT / 64];
     const long row = blockIdx.x;
     float* xr = x + row * ldx;
-    float bv = -INFINITY;
-    int bi = 0x7fffffff;
+    // one pass over the row: running (max, sum exp(x - max)) per thread, merged pairwise
+    float bv = -INFINITY, s = 0.0f;
     for (int c = threadIdx.x; c < V; c += NT) {
         const float v = xr[c];
-        if (v > bv) { bv = v; bi = c; }
+        if (v > bv) { s = s * expf(bv - v) + 1.0f; bv = v; }
+        else s += expf(v - bv);
     }
-    block_argmax<NT>(bv, bi, shv, shi);
-    float s = 0.0f;
-    for (int c = threadIdx.x; c < V; c += NT) s += expf(xr[c] - bv);
-    s = block_sum<NT>(s, shv);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float om = __shfl_xor(bv, off, 64), os = __shfl_xor(s, off, 64);
+        const float mm = fmaxf(bv, om);
+        s = (bv == -INFINITY ? 0.0f : s * expf(bv - mm)) + (om == -INFINITY ? 0.0f : os * expf(om - mm));
+        bv = mm;
+    }
+    if ((threadIdx.x & 63) == 0) { shm[threadIdx.x >> 6] = bv; shs[threadIdx.x >> 6] = s; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float mm = shm[0], ss = shs[0];
+        for (int k = 1; k < NT / 64; ++k) {
+            const float om = shm[k], os = shs[k], nm = fmaxf(mm, om);
+            ss = (mm == -INFINITY ? 0.0f : ss * expf(mm - nm)) + (om == -INFINITY ? 0.0f : os * expf(om - nm));
+            mm = nm;
+        }
+        shm[0] = mm;
+        shs[0] = ss;
+    }
+    __syncthreads();
+    bv = shm[0];
+    s = shs[0];
     const float lse = logf(s);
     const int t = targets[row];
     const float w = weights ? weights[row] : 1.0f;
