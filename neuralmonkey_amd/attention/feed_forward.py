@@ -117,17 +117,19 @@ class Attention(BaseAttention):
         dvp = ctx.buffer(key + ("dvp",), (bsz * slen, a))
         dy = ctx.buffer(key + ("dy",), (steps, bsz, a))
         ops.attn_energy_bwd(de, hf, y_all, self.var(ctx, "attn_similarity_v"), dhf, dvp, dy)
-        ops.colsum(dvp, store.g(self.var_name("attn_similarity_v")), accumulate=True)
         dy2 = dy.view(rows, a)
-        ops.colsum(dy2, store.g(self.var_name("attn_projection_bias")), accumulate=True)
         wq = self.var(ctx, "Attention/attn_query_projection")
-        ops.gemm(queries.reshape(rows, -1), dy2, out=store.g(self.var_name("Attention/attn_query_projection")),
-                 trans_a=True, accumulate=True)
         ops.gemm(dy2, wq, out=dquery_accum, trans_b=True, accumulate=True)
         wk = self.var(ctx, "attn_key_projection")
-        ops.gemm(states.reshape(bsz * slen, c), dhf.view(bsz * slen, a),
-                 out=store.g(self.var_name("attn_key_projection")), trans_a=True, accumulate=True)
         ops.gemm(dhf.view(bsz * slen, a), wk, out=dstates.view(bsz * slen, c), trans_b=True, accumulate=True)
+        with ctx.session.side():          # leaf gradients of this part's variables
+            ops.colsum(dvp, store.g(self.var_name("attn_similarity_v")), accumulate=True)
+            ops.colsum(dy2, store.g(self.var_name("attn_projection_bias")), accumulate=True)
+            ops.gemm(queries.reshape(rows, -1), dy2,
+                     out=store.g(self.var_name("Attention/attn_query_projection")), trans_a=True,
+                     accumulate=True)
+            ops.gemm(states.reshape(bsz * slen, c), dhf.view(bsz * slen, a),
+                     out=store.g(self.var_name("attn_key_projection")), trans_a=True, accumulate=True)
         return dstates
 
     def attention(self, ctx, query: torch.Tensor, decoder_prev_state, decoder_input,

@@ -205,19 +205,31 @@ __global__ __launch_bounds__(256) void gemm_tiled(GemmArgs g, int tiles_m) {
     int cur = 0;
     for (int kt = kt0; kt < nkt; ++kt) {
         if (kt + 1 < nkt) { load_a((kt + 1) * BK); load_b((kt + 1) * BK); }
+        // fragments of the next k-pair are read from LDS before the MFMAs of the current pair
+        // are issued, so the LDS latency sits under 4 x 64 cycles of matrix work
+        float a[2][TM], b[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = As[cur][lane >> 5][wm + i * 32 + (lane & 31)];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[0][j] = Bs[cur][lane >> 5][wn + j * 32 + (lane & 31)];
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            const int kr = kk + (lane >> 5);
-            float a[TM], b[TN];
+            const int p = (kk >> 1) & 1;
+            if (kk + 2 < BK) {
+                const int kr = kk + 2 + (lane >> 5);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[cur][kr][wm + i * 32 + (lane & 31)];
+                for (int i = 0; i < TM; ++i) a[p ^ 1][i] = As[cur][kr][wm + i * 32 + (lane & 31)];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[cur][kr][wn + j * 32 + (lane & 31)];
+                for (int j = 0; j < TN; ++j) b[p ^ 1][j] = Bs[cur][kr][wn + j * 32 + (lane & 31)];
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p][i], b[p][j], acc[i][j], 0, 0, 0);
+            // pin the order: the two LDS reads of the next pair first, then this pair's MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
         }
         if (kt + 1 < nkt) store_lds(cur ^ 1);
         __syncthreads();

@@ -307,15 +307,16 @@ class Decoder(AutoregressiveDecoder):
         s2 = sv["s_all"].reshape(rows, h)
         odim = self.output_dimension
 
+        # Leaf work (weight gradients, bias column sums: nothing downstream reads them) is
+        # enqueued on the session's side stream so it overlaps the latency-bound BPTT loops.
+        side = ctx.session.side
+
         # ---- logits = out . W + b  (autoregressive.py:450-459)
         d_out = ctx.buffer(key + ("d_out",), (rows, odim))
         if self.tie_embeddings:
             emat = self.embedding_matrix(ctx)
-            ops.gemm(dlogits, out_all, out=store.g(self.embedding_matrix_name), trans_a=True, accumulate=True)
             ops.gemm(dlogits, emat, out=d_out)
         else:
-            ops.gemm(out_all, dlogits, out=store.g(self.var_name("state_to_word_W")), trans_a=True)
-            ops.colsum(dlogits, store.g(self.var_name("state_to_word_b")))
             ops.gemm(dlogits, self.var(ctx, "state_to_word_W"), out=d_out, trans_b=True)
 
         # ---- output projection: out = act([s | emb | ctx...] . Wo + bo)
@@ -326,16 +327,26 @@ class Decoder(AutoregressiveDecoder):
             raise NotImplementedError("backward of activation {}".format(proj.activation))
         wo = proj.kernel(ctx, self)
         g_wo = store.g(self.var_name("attention_decoder/{}/kernel".format(proj.scope)))
-        ops.colsum(d_out, store.g(self.var_name("attention_decoder/{}/bias".format(proj.scope))))
         ctx_all = [st.contexts.view(rows, -1) for st in sv["att_states"]]
         d_s = ctx.buffer(key + ("d_s",), (rows, h))
         d_emb = ctx.buffer(key + ("d_emb",), (rows, e))
         d_ctx = [ctx.buffer(key + ("d_ctx", i), (rows, c.shape[1])) for i, c in enumerate(ctx_all)]
         row = 0
         for x, dx, sz in zip([s2, emb2] + ctx_all, [d_s, d_emb] + d_ctx, proj.sizes):
-            ops.gemm(x, d_out, out=g_wo[row:row + sz], trans_a=True)
             ops.gemm(d_out, wo[row:row + sz], out=dx, trans_b=True)
             row += sz
+        with side():
+            row = 0
+            for x, sz in zip([s2, emb2] + ctx_all, proj.sizes):
+                ops.gemm(x, d_out, out=g_wo[row:row + sz], trans_a=True)
+                row += sz
+            ops.colsum(d_out, store.g(self.var_name("attention_decoder/{}/bias".format(proj.scope))))
+            if self.tie_embeddings:
+                ops.gemm(dlogits, out_all, out=store.g(self.embedding_matrix_name), trans_a=True,
+                         accumulate=True)
+            else:
+                ops.gemm(out_all, dlogits, out=store.g(self.var_name("state_to_word_W")), trans_a=True)
+                ops.colsum(dlogits, store.g(self.var_name("state_to_word_b")))
 
         # ---- attentions (batched over time); adds the query path into d_s
         d_att_states = []
@@ -361,21 +372,22 @@ class Decoder(AutoregressiveDecoder):
         ctx.session.graphed((id(self), "bptt_loop", bsz, steps), bptt_loop)
         ds0 = dh[0]
 
-        # ---- GRU weight gradients, batched over all steps
+        # ---- GRU weight gradients, batched over all steps (side stream: overlaps the encoder BPTT)
         pre = "attention_decoder/OrthoGRUCell"
         g_wg, g_wc = store.g(self.var_name(pre + "/gates/kernel")), store.g(self.var_name(pre + "/candidate/kernel"))
         dg_all, dc_all = dxp[:, :2 * h], dxp[:, 2 * h:]
         s_prev = sv["s_ext"][:steps].reshape(rows, h)
-        ops.gemm(emb2, dg_all, out=g_wg[:e], trans_a=True)
-        ops.gemm(s_prev, dg_all, out=g_wg[e:], trans_a=True)
-        ops.gemm(emb2, dc_all, out=g_wc[:e], trans_a=True)
-        ops.gemm(sv["rh_all"].view(rows, h), dc_all, out=g_wc[e:], trans_a=True)
-        ops.colsum(dg_all, store.g(self.var_name(pre + "/gates/bias")))
-        ops.colsum(dc_all, store.g(self.var_name(pre + "/candidate/bias")))
-        ops.gemm(dg_all, cell["wg_x"], out=d_emb, trans_b=True, accumulate=True)
-        ops.gemm(dc_all, cell["wc_x"], out=d_emb, trans_b=True, accumulate=True)
-        ops.embedding_scatter_add(store.g(self.embedding_matrix_name), self._dec_input_ids(ctx).reshape(-1),
-                                  d_emb)
+        with side():
+            ops.gemm(emb2, dg_all, out=g_wg[:e], trans_a=True)
+            ops.gemm(s_prev, dg_all, out=g_wg[e:], trans_a=True)
+            ops.gemm(emb2, dc_all, out=g_wc[:e], trans_a=True)
+            ops.gemm(sv["rh_all"].view(rows, h), dc_all, out=g_wc[e:], trans_a=True)
+            ops.colsum(dg_all, store.g(self.var_name(pre + "/gates/bias")))
+            ops.colsum(dc_all, store.g(self.var_name(pre + "/candidate/bias")))
+            ops.gemm(dg_all, cell["wg_x"], out=d_emb, trans_b=True, accumulate=True)
+            ops.gemm(dc_all, cell["wc_x"], out=d_emb, trans_b=True, accumulate=True)
+            ops.embedding_scatter_add(store.g(self.embedding_matrix_name), self._dec_input_ids(ctx).reshape(-1),
+                                      d_emb)
 
         # ---- initial state projection and the encoders
         d_enc_out = self.encoder_projection.backward(ctx, self, self.rnn_size, self.encoders, ds0)

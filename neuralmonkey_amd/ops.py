@@ -70,11 +70,13 @@ GEMM_WORKSPACE_BYTES = 128 << 20
 
 
 def _gemm_workspace(device):
-    """Persistent split-K slab buffer (one per device; all GEMMs run on one stream)."""
-    ws = _GEMM_WS.get(device)
+    """Persistent split-K slab buffer, one per (device, stream): kernels of one
+    stream are ordered, kernels of different streams must not share slabs."""
+    key = (device, _stream())
+    ws = _GEMM_WS.get(key)
     if ws is None:
         ws = torch.empty(GEMM_WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
-        _GEMM_WS[device] = ws
+        _GEMM_WS[key] = ws
     return ws
 
 
@@ -262,7 +264,7 @@ def colsum(x, out, accumulate=False):
     lib = _lib.load()
     assert x.dim() == 2 and x.stride(1) == 1
     cols = x.shape[1]
-    key = (x.device, cols)
+    key = (x.device, cols, _stream())
     ws = _COLSUM_WS.get(key)
     if ws is None:
         ws = torch.empty(lib.nm_colsum_workspace_bytes(cols) // 4, dtype=torch.float32, device=x.device)

@@ -8,6 +8,7 @@ memoised per run, launching libnmhip kernels on the device.  The call shape
 (fetch dictionaries in, numpy structures out) is unchanged.
 """
 import os
+from contextlib import contextmanager
 from typing import Any, Dict, List, Optional
 
 import numpy as np
@@ -120,6 +121,9 @@ class Session:
         self._h2d: Dict[Any, Any] = {}
         self._graphs: Dict[Any, Any] = {}
         self.use_graphs = os.environ.get("NM_GRAPHS", "1") != "0"
+        self.use_side_stream = os.environ.get("NM_SIDE_STREAM", "1") != "0"
+        self._side_stream = None
+        self._side_dirty = False
         self.global_step = 0
 
     def to_device(self, array, dtype, tag=None, derive=None):
@@ -158,6 +162,33 @@ class Session:
         buf = self.buffer(("staged", key), tuple(src.shape), src.dtype)
         buf.copy_(src)
         return buf
+
+    @contextmanager
+    def side(self):
+        """Run the enclosed launches on the session's second HIP stream, ordered
+        after everything already enqueued on the main stream.  Used for "leaf"
+        work of the backward pass (weight-gradient GEMMs, bias column sums) so that
+        it fills the CUs the latency-bound BPTT loops leave idle.  ``join_side``
+        orders the main stream after it."""
+        if not self.use_side_stream or self.device.type != "cuda":
+            yield
+            return
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self._side_stream.wait_event(ev)
+        with torch.cuda.stream(self._side_stream):
+            yield
+        self._side_dirty = True
+
+    def join_side(self) -> None:
+        if self._side_dirty:
+            ev = torch.cuda.Event()
+            ev.record(self._side_stream)
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            self._side_dirty = False
 
     def graphed(self, key, fn) -> None:
         """Run ``fn`` (kernel launches on persistent buffers only, no host

@@ -109,6 +109,7 @@ class GenericTrainer(GraphExecutor, Feedable):
             ctx.memo[dec.train_loop_result.key] = res
             dec.backward(ctx, res)
             results.append(res)
+        sess.join_side()
         if dp is not None:
             dp.all_reduce_gradients(store)
         tables = self._optim_tables(store)
