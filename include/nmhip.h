@@ -105,6 +105,14 @@ int nm_attn_fwd(void* stream, const float* y, const float* hf, const float* stat
                 const float* v, const float* bias, int64_t R, int64_t rows_per_key, int64_t S,
                 int64_t A, int64_t C, float* ctx, int64_t ldctx, float* weights, void* workspace,
                 int64_t workspace_bytes, float* energies_out);
+/* nq queries per key batch in one launch; query q of key batch b is row b*q_stride_b + q*q_stride_q
+ * of y / ctx / weights: [Bk,nq]-major (beam hypotheses) or [nq,Bk]-major (all T teacher-forced
+ * steps of training at once -- the keys are then read from HBM once for the whole target sentence). */
+int nm_attn_fwd_multi(void* stream, const float* y, const float* hf, const float* states,
+                      const float* mask, const float* v, const float* bias, int64_t Bk, int64_t nq,
+                      int64_t q_stride_b, int64_t q_stride_q, int64_t S, int64_t A, int64_t C, float* ctx,
+                      int64_t ldctx, float* weights, void* workspace, int64_t workspace_bytes,
+                      float* energies_out);
 /* backward of T steps at once: softmax/renorm part, then the tanh energies part */
 int nm_attn_softmax_bwd(void* stream, const float* dw, const float* e, const float* mask, float* de,
                         int64_t rows, int64_t B, int64_t S);

@@ -35,6 +35,7 @@ SIGNATURES = {
     "nm_log_softmax": (I, [P, P, L, P, P, P, L, L, L]),
     "nm_attn_workspace_bytes": (L, [L, L, L]),
     "nm_attn_fwd": (I, [P, P, P, P, P, P, P, L, L, L, L, L, P, L, P, P, L, P]),
+    "nm_attn_fwd_multi": (I, [P, P, P, P, P, P, P, L, L, L, L, L, L, L, P, L, P, P, L, P]),
     "nm_gru_rh_seq": (I, [P, P, P, P, P, I, L, L, I, L]),
     "nm_gru_gemm": (I, [P, P, I, L, P, L, L, P, L, L]),
     "nm_prof_enable": (I, [I]),

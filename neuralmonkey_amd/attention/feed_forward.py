@@ -90,6 +90,21 @@ class Attention(BaseAttention):
         ops.attn_fwd(y, hf, states, self.attention_mask(ctx), self.var(ctx, "attn_similarity_v"),
                      self.var(ctx, "attn_bias"), self.rows_per_key, ctx_out, w_out, ws, energies_out)
 
+    def attention_all_steps(self, ctx, queries: torch.Tensor, y_all: torch.Tensor, ctx_all: torch.Tensor,
+                            w_all: torch.Tensor, e_all: torch.Tensor) -> None:
+        """Teacher-forced training: the attention of step t only needs the decoder
+        state s_t (nothing of it feeds the recurrence), so all T steps run as one
+        projection GEMM + one fused attention launch in which every sentence's
+        keys are read from HBM once for all T queries.  queries [T,B,Q]."""
+        steps, bsz, qdim = queries.shape
+        states = self.attention_states(ctx)
+        hf = self.hidden_features(ctx)
+        self.project_query(ctx, queries.reshape(steps * bsz, qdim), y_all.view(steps * bsz, -1))
+        ws = ctx.buffer((id(self), "ws_all", steps, bsz), ((ops._lib.load().nm_attn_workspace_bytes(
+            steps * bsz, states.shape[1], states.shape[2]) + 3) // 4,))
+        ops.attn_fwd_time_major(y_all, hf, states, self.attention_mask(ctx), self.var(ctx, "attn_similarity_v"),
+                                self.var(ctx, "attn_bias"), ctx_all, w_all, ws, e_all)
+
     def backward(self, ctx, dctx_all: torch.Tensor, queries: torch.Tensor, y_all: torch.Tensor,
                  w_all: torch.Tensor, e_all: torch.Tensor, dquery_accum: torch.Tensor) -> torch.Tensor:
         """Gradient of T attention steps at once (nothing here feeds the recurrence).

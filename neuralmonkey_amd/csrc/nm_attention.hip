@@ -78,7 +78,14 @@ struct AttnArgs {
     float* pctx;          // [R,nchunk,C]
     float* pstat;         // [R,nchunk,4]  (m, l_all, l_masked, -)
     int R, S, A, C, nchunk, sch;
+    // query q (0 <= q < nq) of key batch b is row b*qsb + q*qsq of y / ctx / weights:
+    // beam layout (qsb = nq, qsq = 1) or time-major layout (qsb = 1, qsq = Bk)
+    int qsb, qsq, nq;
 };
+
+__device__ __forceinline__ long attn_qrow(const AttnArgs& p, int b, int qi) {
+    return (long)b * p.qsb + (long)min(qi, p.nq - 1) * p.qsq;
+}
 
 template <int QPK, int NCG>
 __global__ __launch_bounds__(256) void attn_partial(AttnArgs p) {
@@ -93,11 +100,13 @@ __global__ __launch_bounds__(256) void attn_partial(AttnArgs p) {
     const int chunk = blockIdx.x, b = blockIdx.y;
     const int s0 = chunk * p.sch;
     const int ns = min(p.sch, p.S - s0);
-    const int r0 = b * QPK;
+    const int q0 = blockIdx.z * QPK;            // first query of this block's group
 
-    for (int i = tid * 4; i < QPK * p.A; i += 1024)
-        *reinterpret_cast<float4*>(ys + i) =
-            *reinterpret_cast<const float4*>(p.y + (long)r0 * p.A + i);
+#pragma unroll
+    for (int q = 0; q < QPK; ++q)
+        for (int i = tid * 4; i < p.A; i += 1024)
+            *reinterpret_cast<float4*>(ys + q * p.A + i) =
+                *reinterpret_cast<const float4*>(p.y + attn_qrow(p, b, q0 + q) * p.A + i);
     for (int i = tid * 4; i < p.A; i += 1024)
         *reinterpret_cast<float4*>(vs + i) = *reinterpret_cast<const float4*>(p.v + i);
     if (tid < ATT_MAX_SCH)
@@ -149,7 +158,7 @@ __global__ __launch_bounds__(256) void attn_partial(AttnArgs p) {
         const float e = ((pe[(0 * QPK + q) * ATT_MAX_SCH + sl] + pe[(1 * QPK + q) * ATT_MAX_SCH + sl]) +
                          (pe[(2 * QPK + q) * ATT_MAX_SCH + sl] + pe[(3 * QPK + q) * ATT_MAX_SCH + sl])) + bias;
         es[q * ATT_MAX_SCH + sl] = e;
-        p.energies[(long)(r0 + q) * p.S + s0 + sl] = e;
+        if (q0 + q < p.nq) p.energies[attn_qrow(p, b, q0 + q) * p.S + s0 + sl] = e;
     }
     __syncthreads();
 
@@ -166,8 +175,10 @@ __global__ __launch_bounds__(256) void attn_partial(AttnArgs p) {
             lm += em;
             es[q * ATT_MAX_SCH + s] = em;     // masked, un-normalised weight
         }
-        float* st = p.pstat + ((long)(r0 + q) * p.nchunk + chunk) * 4;
-        st[0] = m; st[1] = la; st[2] = lm; st[3] = 0.0f;
+        if (q0 + q < p.nq) {
+            float* st = p.pstat + (attn_qrow(p, b, q0 + q) * p.nchunk + chunk) * 4;
+            st[0] = m; st[1] = la; st[2] = lm; st[3] = 0.0f;
+        }
     }
     __syncthreads();
 
@@ -199,8 +210,8 @@ __global__ __launch_bounds__(256) void attn_partial(AttnArgs p) {
 #pragma unroll
         for (int g = 0; g < NCG; ++g) {
             const int col = g * 1024 + wave * 256 + lane * 4;
-            if (col < p.C)
-                *reinterpret_cast<float4*>(p.pctx + ((long)(r0 + q) * p.nchunk + chunk) * p.C + col) =
+            if (col < p.C && q0 + q < p.nq)
+                *reinterpret_cast<float4*>(p.pctx + (attn_qrow(p, b, q0 + q) * p.nchunk + chunk) * p.C + col) =
                     acc[q][g];
         }
 }
@@ -287,7 +298,7 @@ __global__ __launch_bounds__(256) void attn_combine(const float* __restrict__ pc
                                                     const float* __restrict__ mask,
                                                     float* __restrict__ ctx, long ldctx,
                                                     float* __restrict__ weights, int S, int C,
-                                                    int nchunk, int rows_per_key) {
+                                                    int nchunk, int mask_div, int mask_mod) {
     __shared__ float sc[64];
     __shared__ float sden, smax;
     const int r = blockIdx.x, tid = threadIdx.x;
@@ -318,7 +329,7 @@ __global__ __launch_bounds__(256) void attn_combine(const float* __restrict__ pc
         *reinterpret_cast<float4*>(ctx + (long)r * ldctx + c) = a;
     }
     if (weights) {
-        const int b = r / rows_per_key;
+        const int b = (r / mask_div) % mask_mod;      // key batch of row r in either query layout
         for (int s = tid; s < S; s += 256) {
             const float mk = mask ? mask[(long)b * S + s] : 1.0f;
             weights[(long)r * S + s] = __expf(energies[(long)r * S + s] - smax) * mk * inv;
@@ -351,17 +362,20 @@ extern "C" int64_t nm_attn_workspace_bytes(int64_t R, int64_t S, int64_t C) {
     return (int64_t)sizeof(float) * (e + R * nchunk * C + R * nchunk * 4);
 }
 
-extern "C" int nm_attn_fwd(void* stream, const float* y, const float* hf, const float* states,
-                           const float* mask, const float* v, const float* bias, int64_t R,
-                           int64_t rows_per_key, int64_t S, int64_t A, int64_t C, float* ctx,
-                           int64_t ldctx, float* weights, void* workspace, int64_t workspace_bytes,
-                           float* energies_out) {
+extern "C" int nm_attn_fwd_multi(void* stream, const float* y, const float* hf, const float* states,
+                                 const float* mask, const float* v, const float* bias, int64_t Bk,
+                                 int64_t nq, int64_t q_stride_b, int64_t q_stride_q, int64_t S, int64_t A,
+                                 int64_t C, float* ctx, int64_t ldctx, float* weights, void* workspace,
+                                 int64_t workspace_bytes, float* energies_out) {
     NM_REQUIRE(y && hf && states && v && ctx && workspace, "nm_attn_fwd: null pointer");
-    NM_REQUIRE(R > 0 && S > 0 && A > 0 && C > 0 && rows_per_key >= 1 && R % rows_per_key == 0,
-               "nm_attn_fwd: bad shape R=%ld k=%ld S=%ld", (long)R, (long)rows_per_key, (long)S);
+    NM_REQUIRE(Bk > 0 && nq > 0 && S > 0 && A > 0 && C > 0, "nm_attn_fwd: bad shape Bk=%ld nq=%ld S=%ld",
+               (long)Bk, (long)nq, (long)S);
+    const bool beam_layout = (q_stride_b == nq && q_stride_q == 1);
+    const bool time_layout = (q_stride_b == 1 && q_stride_q == Bk);
+    NM_REQUIRE(beam_layout || time_layout, "nm_attn_fwd: query rows must be [Bk,nq] or [nq,Bk] major");
+    const int64_t R = Bk * nq;
     NM_REQUIRE(A % 4 == 0 && C % 4 == 0 && ldctx % 4 == 0, "nm_attn_fwd: A, C, ldctx must be multiples of 4");
     NM_REQUIRE(C <= 2048, "nm_attn_fwd: C > 2048 unsupported");
-    NM_REQUIRE(rows_per_key <= 8, "nm_attn_fwd: rows_per_key > 8 unsupported");
     NM_REQUIRE(nm_aligned16(y) && nm_aligned16(hf) && nm_aligned16(states) && nm_aligned16(v) &&
                    nm_aligned16(ctx) && nm_aligned16(workspace),
                "nm_attn_fwd: pointers must be 16-byte aligned");
@@ -369,8 +383,9 @@ extern "C" int nm_attn_fwd(void* stream, const float* y, const float* hf, const 
     int sch, nchunk;
     attn_chunking(S, &sch, &nchunk);
     NM_REQUIRE(sch <= ATT_MAX_SCH && nchunk <= 64, "nm_attn_fwd: S=%ld too long (max 768)", (long)S);
-    const int qpk = (int)rows_per_key;
-    const int Bk = (int)(R / rows_per_key);
+    const int qpk = (int)(nq < 8 ? nq : 8);
+    const int groups = (int)((nq + qpk - 1) / qpk);
+    NM_REQUIRE(groups <= 65535 && Bk <= 65535, "nm_attn_fwd: grid too large");
     float* ws = reinterpret_cast<float*>(workspace);
     AttnArgs p;
     p.y = y; p.hf = hf; p.states = states; p.mask = mask; p.v = v; p.bias = bias;
@@ -378,11 +393,12 @@ extern "C" int nm_attn_fwd(void* stream, const float* y, const float* hf, const 
     p.pctx = ws + ((R * S + 3) / 4) * 4;
     p.pstat = p.pctx + R * nchunk * C;
     p.R = (int)R; p.S = (int)S; p.A = (int)A; p.C = (int)C; p.nchunk = nchunk; p.sch = sch;
+    p.qsb = (int)q_stride_b; p.qsq = (int)q_stride_q; p.nq = (int)nq;
     const size_t shm = sizeof(float) * ((size_t)qpk * A + A + (size_t)qpk * ATT_MAX_SCH + ATT_MAX_SCH +
                                         (size_t)4 * qpk * ATT_MAX_SCH);
     NM_REQUIRE(shm <= 160 * 1024, "nm_attn_fwd: A too large for LDS staging");
     hipStream_t st = nm_stream(stream);
-    dim3 grid(nchunk, Bk), block(256);
+    dim3 grid(nchunk, (unsigned)Bk, groups), block(256);
     const int ncg = C > 1024 ? 2 : 1;
 #define NM_AT(Q_)                                                                         \
     do {                                                                                  \
@@ -392,7 +408,7 @@ extern "C" int nm_attn_fwd(void* stream, const float* y, const float* hf, const 
     std::pair<hipEvent_t, hipEvent_t>* prof = g_prof_on ? prof_next_pair() : nullptr;
     if (prof) hipEventRecord(prof->first, st);
     static const bool no_fast = getenv("NM_ATTN_NOFAST") != nullptr;       // A/B switch for tuning
-    if (qpk == 1 && A <= 1024 && C <= 1024 && sch <= ATT_FAST_ROWS && !no_fast) {
+    if (nq == 1 && A <= 1024 && C <= 1024 && sch <= ATT_FAST_ROWS && !no_fast) {
         if (sch <= 8) hipLaunchKernelGGL(attn_partial_fast<8>, grid, block, 0, st, p);
         else if (sch <= 10) hipLaunchKernelGGL(attn_partial_fast<10>, grid, block, 0, st, p);
         else hipLaunchKernelGGL(attn_partial_fast<12>, grid, block, 0, st, p);
@@ -412,6 +428,19 @@ extern "C" int nm_attn_fwd(void* stream, const float* y, const float* hf, const 
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) NM_FAIL(NM_ERR_HIP, "nm_attn_fwd: partial launch failed: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(attn_combine, dim3((unsigned)R), dim3(256), 0, st, p.pctx, p.pstat, p.energies,
-                       mask, ctx, (long)ldctx, weights, (int)S, (int)C, nchunk, qpk);
+                       mask, ctx, (long)ldctx, weights, (int)S, (int)C, nchunk,
+                       beam_layout ? (int)nq : 1, (int)Bk);
     NM_LAUNCH_CHECK("nm_attn_fwd");
+}
+
+extern "C" int nm_attn_fwd(void* stream, const float* y, const float* hf, const float* states,
+                           const float* mask, const float* v, const float* bias, int64_t R,
+                           int64_t rows_per_key, int64_t S, int64_t A, int64_t C, float* ctx,
+                           int64_t ldctx, float* weights, void* workspace, int64_t workspace_bytes,
+                           float* energies_out) {
+    NM_REQUIRE(R > 0 && rows_per_key >= 1 && rows_per_key <= 8 && R % rows_per_key == 0,
+               "nm_attn_fwd: bad shape R=%ld k=%ld", (long)R, (long)rows_per_key);
+    return nm_attn_fwd_multi(stream, y, hf, states, mask, v, bias, R / rows_per_key, rows_per_key,
+                             rows_per_key, 1, S, A, C, ctx, ldctx, weights, workspace, workspace_bytes,
+                             energies_out);
 }

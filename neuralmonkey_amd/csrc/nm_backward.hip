@@ -71,9 +71,12 @@ extern "C" int nm_colsum(void* stream, const float* x, int64_t ldx, int64_t rows
     NM_REQUIRE(workspace_bytes >= nm_colsum_workspace_bytes(cols), "nm_colsum: workspace too small");
     hipStream_t st = nm_stream(stream);
     float* part = reinterpret_cast<float*>(workspace);
-    int nsplit = (int)((rows + 31) / 32);
+    // enough row slices to fill the chip (cols/64 * nsplit >= ~1024 workgroups), few enough that
+    // the fixed-order final pass (nsplit sequential adds per column) stays short
+    int nsplit = (int)((1024 * 64 + cols - 1) / cols);
+    if (nsplit > (int)((rows + 31) / 32)) nsplit = (int)((rows + 31) / 32);
+    if (nsplit > 48) nsplit = 48;
     if (nsplit < 1) nsplit = 1;
-    if (nsplit > COLSUM_MAX_SPLIT) nsplit = COLSUM_MAX_SPLIT;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nm_cdiv(cols, 64), nsplit), dim3(256), 0, st, x,
                        (long)ldx, (long)rows, (int)cols, nsplit, part);
     hipLaunchKernelGGL(colsum_final_kernel, dim3(nm_cdiv(cols, 256)), dim3(256), 0, st, part, (int)cols,

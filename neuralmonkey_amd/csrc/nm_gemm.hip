@@ -65,10 +65,13 @@ __device__ __forceinline__ void store_tile32(const GemmArgs& g, float* __restric
 // ---------------------------------------------------------------------------
 // tiled kernel
 // ---------------------------------------------------------------------------
-template <int TM, int TN, bool TA, bool TB, bool VEC, int BK>
-__global__ __launch_bounds__(256) void gemm_tiled(GemmArgs g, int tiles_m) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr int LA = TM * BK / 16, LB = TN * BK / 16, KQ = BK / 4;   // float4 loads per thread; float4s per k-row
+// WM x WN waves, each owning TM x TN MFMA tiles of 32x32: block tile (WM*32*TM) x (WN*32*TN).
+template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool VEC, int BK>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_tiled(GemmArgs g, int tiles_m) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int BM = WM * 32 * TM, BN = WN * 32 * TN;
+    constexpr int LA = BM * BK / 4 / NT, LB = BN * BK / 4 / NT, KQ = BK / 4;   // float4 loads per thread; float4s per k-row
+    static_assert(LA >= 1 && LB >= 1 && LA * NT * 4 == BM * BK && LB * NT * 4 == BN * BK, "tile / thread mismatch");
     constexpr int LDAS = BM + 4, LDBS = BN + 4;
     __shared__ __attribute__((aligned(16))) float As[2][BK][LDAS];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDBS];
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(256) void gemm_tiled(GemmArgs g, int tiles_m) {
     auto load_a = [&](int k0) {
 #pragma unroll
         for (int it = 0; it < LA; ++it) {
-            const int idx = tid + it * 256;
+            const int idx = tid + it * NT;
             int m, k;
             if (TA) { k = idx / (BM / 4); m = (idx % (BM / 4)) * 4; }   // m contiguous
             else    { m = idx / KQ;       k = (idx % KQ) * 4; }         // k contiguous
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256) void gemm_tiled(GemmArgs g, int tiles_m) {
     auto load_b = [&](int k0) {
 #pragma unroll
         for (int it = 0; it < LB; ++it) {
-            const int idx = tid + it * 256;
+            const int idx = tid + it * NT;
             int n, k;
             if (!TB) { k = idx / (BN / 4); n = (idx % (BN / 4)) * 4; }  // n contiguous
             else     { n = idx / KQ;       k = (idx % KQ) * 4; }        // k contiguous
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(256) void gemm_tiled(GemmArgs g, int tiles_m) {
     auto store_lds = [&](int buf) {
 #pragma unroll
         for (int it = 0; it < LA; ++it) {
-            const int idx = tid + it * 256;
+            const int idx = tid + it * NT;
             if (TA) {
                 const int k = idx / (BM / 4), m = (idx % (BM / 4)) * 4;
                 *reinterpret_cast<float4*>(&As[buf][k][m]) = ra[it];
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256) void gemm_tiled(GemmArgs g, int tiles_m) {
         }
 #pragma unroll
         for (int it = 0; it < LB; ++it) {
-            const int idx = tid + it * 256;
+            const int idx = tid + it * NT;
             if (!TB) {
                 const int k = idx / (BN / 4), n = (idx % (BN / 4)) * 4;
                 *reinterpret_cast<float4*>(&Bs[buf][k][n]) = rb[it];
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256) void gemm_tiled(GemmArgs g, int tiles_m) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int wm = (wave >> 1) * 32 * TM, wn = (wave & 1) * 32 * TN;
+    const int wm = (wave / WN) * 32 * TM, wn = (wave % WN) * 32 * TN;
     // split-K: slice blockIdx.y owns k-tiles [kt0, nkt)
     const int nkt_all = (g.K + BK - 1) / BK;
     const int per_slice = (nkt_all + g.splitk - 1) / g.splitk;
@@ -564,12 +567,12 @@ static void launch_skinny(const GemmArgs& g, int batch, bool tb, const GruEpi& e
 #undef NM_GS
 }
 
-template <int TM, int TN, int BK>
+template <int WM, int WN, int TM, int TN, int BK>
 static void launch_tiled(const GemmArgs& g, int batch, bool ta, bool tb, bool vec, hipStream_t st) {
-    const int tiles_m = nm_cdiv(g.M, 64 * TM), tiles_n = nm_cdiv(g.N, 64 * TN);
-    dim3 grid(tiles_m * tiles_n, g.splitk, batch), block(256);
+    const int tiles_m = nm_cdiv(g.M, WM * 32 * TM), tiles_n = nm_cdiv(g.N, WN * 32 * TN);
+    dim3 grid(tiles_m * tiles_n, g.splitk, batch), block(WM * WN * 64);
 #define NM_GT(TA_, TB_, V_) \
-    hipLaunchKernelGGL((gemm_tiled<TM, TN, TA_, TB_, V_, BK>), grid, block, 0, st, g, tiles_m)
+    hipLaunchKernelGGL((gemm_tiled<WM, WN, TM, TN, TA_, TB_, V_, BK>), grid, block, 0, st, g, tiles_m)
     if (vec) {
         if (!ta && !tb) NM_GT(false, false, true);
         else if (!ta && tb) NM_GT(false, true, true);
@@ -637,13 +640,16 @@ extern "C" int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int6
                 }
             }
         }
-        static const int bk_env = getenv("NM_GEMM_BK") ? atoi(getenv("NM_GEMM_BK")) : 16;   // tuning knob
+        static const int cfg_env = getenv("NM_GEMM_CFG") ? atoi(getenv("NM_GEMM_CFG")) : 1;   // tuning knob (1 measured best)
         if (pick == 1) {
-            if (bk_env == 32) launch_tiled<2, 2, 32>(g, (int)batch, ta, tb, vec, st);
-            else launch_tiled<2, 2, 16>(g, (int)batch, ta, tb, vec, st);
+            if (cfg_env == 1) launch_tiled<4, 2, 1, 2, 16>(g, (int)batch, ta, tb, vec, st);        // 128x128, 8 waves
+            else if (cfg_env == 3) launch_tiled<4, 4, 1, 1, 32>(g, (int)batch, ta, tb, vec, st);   // 128x128, 16 waves
+            else if (cfg_env == 4) launch_tiled<4, 2, 1, 2, 32>(g, (int)batch, ta, tb, vec, st);   // 128x128, 8 waves, BK 32
+            else if (cfg_env == 5) launch_tiled<2, 4, 2, 1, 16>(g, (int)batch, ta, tb, vec, st);   // 128x128, 8 waves 64x32
+            else if (cfg_env == 2) launch_tiled<4, 2, 2, 2, 16>(g, (int)batch, ta, tb, vec, st);   // 256x128, 8 waves
+            else launch_tiled<2, 2, 2, 2, 16>(g, (int)batch, ta, tb, vec, st);                     // 128x128, 4 waves
         } else {
-            if (bk_env == 32) launch_tiled<1, 1, 32>(g, (int)batch, ta, tb, vec, st);
-            else launch_tiled<1, 1, 16>(g, (int)batch, ta, tb, vec, st);
+            launch_tiled<2, 2, 1, 1, 16>(g, (int)batch, ta, tb, vec, st);                          // 64x64
         }
         if (g.splitk > 1) {
             const long total = (long)M * N;

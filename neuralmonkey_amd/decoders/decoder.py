@@ -268,11 +268,10 @@ class Decoder(AutoregressiveDecoder):
             for t in range(steps):
                 self._recurrent(ctx, cell, xp, t, bsz * 3 * h, s_ext[t], s_all[t], ru_all[t], c_all[t], bufs,
                                 rh=rh_all[t])
-                for i, att in enumerate(self.attentions):
-                    att.attention_into(ctx, s_all[t], y_all[i][t], att_states[i].contexts[t],
-                                       att_states[i].weights[t], e_all[i][t])
-        ctx.session.graphed((id(self), "train_loop", bsz, steps) + tuple(
-            tuple(st.weights.shape) for st in att_states), time_loop)
+        ctx.session.graphed((id(self), "train_loop", bsz, steps), time_loop)
+        # attention of all T steps at once (the contexts do not feed the recurrence)
+        for i, att in enumerate(self.attentions):
+            att.attention_all_steps(ctx, s_all, y_all[i], att_states[i].contexts, att_states[i].weights, e_all[i])
         att_states = [AttentionLoopState(st.contexts, st.weights, steps) for st in att_states]
 
         out_all = ctx.buffer(key + ("out",), (rows, self.output_dimension))

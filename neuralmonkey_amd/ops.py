@@ -182,6 +182,19 @@ def attn_fwd(y, hf, states, mask, v, bias, rows_per_key, ctx, weights, workspace
                                workspace.numel() * 4, _p(energies_out)), "nm_attn_fwd")
 
 
+def attn_fwd_time_major(y_all, hf, states, mask, v, bias, ctx_all, w_all, workspace, energies_out=None):
+    """All T teacher-forced attention steps in one launch.  y_all [T,B,A] (time-major query
+    projections), ctx_all [T,B,C], w_all / energies_out [T,B,S]; keys are read once per sentence."""
+    lib = _lib.load()
+    t, b, a = y_all.shape
+    _, s, c = states.shape
+    assert y_all.is_contiguous() and ctx_all.is_contiguous() and hf.is_contiguous() and states.is_contiguous()
+    _lib.check(lib.nm_attn_fwd_multi(_stream(), y_all.data_ptr(), hf.data_ptr(), states.data_ptr(), _p(mask),
+                                     v.data_ptr(), _p(bias), b, t, 1, b, s, a, c, ctx_all.data_ptr(), c,
+                                     _p(w_all), workspace.data_ptr(), workspace.numel() * 4,
+                                     _p(energies_out)), "nm_attn_fwd_multi")
+
+
 def row_stats(x, rmax=None, lse=None, argmax=None):
     lib = _lib.load()
     assert x.dim() == 2 and x.stride(1) == 1
