@@ -118,7 +118,7 @@ int nm_attn_softmax_bwd(void* stream, const float* dw, const float* e, const flo
                         int64_t rows, int64_t B, int64_t S);
 int nm_attn_energy_bwd(void* stream, const float* de, const float* hf, const float* y, const float* v,
                        float* dhf, float* dv_partial, float* dy, int64_t T, int64_t B, int64_t S,
-                       int64_t A);
+                       int64_t A, int accumulate /* dhf, dv_partial += (per-step backward) */);
 /* live HIP-event timing of the attn_partial kernel (bench.py roofline) */
 int nm_prof_enable(int on);
 int nm_prof_attn_partial(double* total_ms, int64_t* count);
@@ -157,6 +157,42 @@ int nm_tanh_bwd(void* stream, float* dy, const float* y, int64_t n);
 int64_t nm_colsum_workspace_bytes(int64_t cols);
 int nm_colsum(void* stream, const float* x, int64_t ldx, int64_t rows, int64_t cols, float* out,
               int accumulate, void* workspace, int64_t workspace_bytes);
+
+/* ---- strided element-wise primitives of the general (taped) path -----------------------------
+ * Cells other than the fused TF GRU (NematusGRUCell nn/ortho_gru_cell.py:57-105, LSTMCell
+ * decoders/decoder.py:309-325), conditional GRU (decoders/decoder.py:303-307), attention on input
+ * (:264-277), output-projection variants (decoders/output_projection.py:35-188) and the
+ * Transformer blocks are compositions of MFMA GEMMs and these one-pass kernels.
+ * op codes: 0 copy, 1 a+b, 2 a-b, 3 a*b, 4 alpha*a, 5 sigmoid(a+alpha), 6 tanh(a), 7 relu(a),
+ *           8 b*a*(1-a), 9 b*(1-a^2), 10 b*(a>0)   (8-10: a = forward output, b = upstream grad) */
+int nm_ew(void* stream, int op, const float* a, int64_t lda, const float* b, int64_t ldb, float* out,
+          int64_t ldo, int64_t rows, int64_t cols, float alpha, int accumulate);
+/* h' = u*h + (1-u)*c  and its gradient (du, dh, dc accumulate; any may be NULL) */
+int nm_blend_fwd(void* stream, const float* u, int64_t ldu, const float* h, int64_t ldh, const float* c,
+                 int64_t ldc, float* out, int64_t ldo, int64_t rows, int64_t cols);
+int nm_blend_bwd(void* stream, const float* dy, int64_t lddy, const float* u, int64_t ldu, const float* h,
+                 int64_t ldh, const float* c, int64_t ldc, float* du, int64_t lddu, float* dh,
+                 int64_t lddh, float* dc, int64_t lddc, int64_t rows, int64_t cols);
+/* nn/utils.py:6-22 (tf.nn.dropout): keep iff floor(keep_prob + u_i) == 1, scale 1/keep_prob;
+ * u_i = hash(salt, i) (counter based: the backward pass and the CPU oracle regenerate the mask) */
+int nm_dropout(void* stream, const float* x, int64_t ldx, float* out, int64_t ldo, int64_t rows,
+               int64_t cols, float keep_prob, uint32_t salt, int accumulate);
+/* tf.nn.dynamic_rnn(sequence_length) step t (encoders/recurrent.py:86-110): rows with
+ * t >= lengths[r] carry h_prev through and emit zeros */
+int nm_rnn_select_fwd(void* stream, const float* h_new, int64_t ld_new, const float* h_prev,
+                      int64_t ld_prev, const int32_t* lengths, int t, float* h_out, int64_t ld_h,
+                      float* y_out, int64_t ld_y, int64_t rows, int64_t cols);
+int nm_rnn_select_bwd(void* stream, const float* dh, int64_t ld_dh, const float* dy, int64_t ld_dy,
+                      const int32_t* lengths, int t, float* d_new, int64_t ld_dnew, float* d_prev,
+                      int64_t ld_dprev, int64_t rows, int64_t cols);
+/* tf.reverse_sequence(x [B,S,D], lengths, seq_axis=1); self-inverse */
+int nm_reverse_sequence(void* stream, const float* x, float* out, const int32_t* lengths, int64_t B,
+                        int64_t S, int64_t D, int accumulate);
+/* nn/projection.py:7-35 maxout: out[r,g] = max_p x[r, p*groups + g] */
+int nm_maxout_fwd(void* stream, const float* x, int64_t ldx, float* out, int64_t ldo, int32_t* argmax,
+                  int64_t rows, int64_t groups, int64_t pool);
+int nm_maxout_bwd(void* stream, const float* dy, int64_t lddy, const int32_t* argmax, float* dx,
+                  int64_t lddx, int64_t rows, int64_t groups, int64_t pool);
 
 /* ---- trainer arithmetic over the flat parameter buffer: trainers/generic_trainer.py:84-195
  * (L1/L2 over non-bias variables, per-tensor tf.clip_by_norm, tf.train.AdamOptimizer) ----------- */

@@ -53,7 +53,16 @@ SIGNATURES = {
     "nm_gru_step_bwd": (I, [P, I, P, P, L, L, L, P, P, P, P, L, L, L, P, L, L, L, P, P, P, P, I, I, I, L, L]),
     "nm_gru_seq_shift": (I, [P, P, P, P, I, L, L, I, L]),
     "nm_attn_softmax_bwd": (I, [P, P, P, P, P, L, L, L]),
-    "nm_attn_energy_bwd": (I, [P, P, P, P, P, P, P, P, L, L, L, L]),
+    "nm_attn_energy_bwd": (I, [P, P, P, P, P, P, P, P, L, L, L, L, I]),
+    "nm_ew": (I, [P, I, P, L, P, L, P, L, L, L, F, I]),
+    "nm_blend_fwd": (I, [P, P, L, P, L, P, L, P, L, L, L]),
+    "nm_blend_bwd": (I, [P, P, L, P, L, P, L, P, L, P, L, P, L, P, L, L, L]),
+    "nm_dropout": (I, [P, P, L, P, L, L, L, F, ctypes.c_uint32, I]),
+    "nm_rnn_select_fwd": (I, [P, P, L, P, L, P, I, P, L, P, L, L, L]),
+    "nm_rnn_select_bwd": (I, [P, P, L, P, L, P, I, P, L, P, L, L, L]),
+    "nm_reverse_sequence": (I, [P, P, P, P, L, L, L, I]),
+    "nm_maxout_fwd": (I, [P, P, L, P, L, P, L, L, L]),
+    "nm_maxout_bwd": (I, [P, P, L, P, P, L, L, L, L]),
     "nm_optim_workspace_bytes": (L, [L, L]),
     "nm_optim_regularize_norms": (I, [P, P, P, P, P, P, P, P, P, L, L, F, F, P, P, L]),
     "nm_optim_clip_adam": (I, [P, P, P, P, P, P, P, P, P, P, P, L, L, F, F, F, F, F, P, L]),

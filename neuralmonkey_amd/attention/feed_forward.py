@@ -147,6 +147,10 @@ class Attention(BaseAttention):
                      out=store.g(self.var_name("attn_key_projection")), trans_a=True, accumulate=True)
         return dstates
 
+    def tape_session(self, tape, train_mode: bool) -> "AttentionTapeSession":
+        """The general (taped) path: keys and per-step attention as differentiable tape ops."""
+        return AttentionTapeSession(self, tape, train_mode)
+
     def attention(self, ctx, query: torch.Tensor, decoder_prev_state, decoder_input,
                   loop_state: AttentionLoopState) -> Tuple[torch.Tensor, AttentionLoopState]:
         rows = query.shape[0]
@@ -156,9 +160,10 @@ class Attention(BaseAttention):
         return loop_state.contexts[step], AttentionLoopState(loop_state.contexts, loop_state.weights,
                                                              step + 1)
 
-    def initial_loop_state(self, ctx, rows: int, max_steps: int) -> AttentionLoopState:
-        states = self.attention_states(ctx)
-        self.hidden_features(ctx)        # pre-compute outside the loop (feed_forward.py:168-186)
+    def initial_loop_state(self, ctx, rows: int, max_steps: int, precompute: bool = True) -> AttentionLoopState:
+        states = get_attention_states(self.encoder, ctx)
+        if precompute:
+            self.hidden_features(ctx)    # pre-compute outside the loop (feed_forward.py:168-186)
         return AttentionLoopState(
             contexts=ctx.buffer((id(self), "contexts", rows, max_steps),
                                 (max_steps, rows, self.context_vector_size)),
@@ -167,3 +172,81 @@ class Attention(BaseAttention):
 
     def finalize_loop(self, key: str, last_loop_state: AttentionLoopState) -> None:
         self.histories[key] = last_loop_state.weights[:last_loop_state.step]
+
+
+class AttentionTapeSession:
+    """One decoding run of an ``Attention`` on an autodiff tape (general path: conditional GRU,
+    attention on input, dropout, NematusGRU / LSTM decoders -- anything where the context feeds
+    the recurrence, so the attention gradient has to be taken step by step).
+
+    Setup (once per run): attention_states = dropout(states) (feed_forward.py:47-51) and the
+    keys states.Wk (:105-118) as tape ops, so their gradients -- dL/d(encoder states) and the
+    key-projection gradient -- fall out of ``Tape.backward``.  ``step`` is the fused kernel
+    ``nm_attn_fwd``; its gradient closure runs the same kernels as ``Attention.backward`` with T=1
+    and accumulates into the keys' gradient."""
+
+    def __init__(self, att: Attention, tape, train_mode: bool):
+        from .. import autodiff as F
+        ctx = tape.ctx
+        self.att, self.tape = att, tape
+        raw = get_attention_states(att.encoder, ctx)
+        self.bsz, self.slen, self.csz = raw.shape
+        self.asz = att.state_size
+        self.states_in = tape.leaf(raw.reshape(self.bsz * self.slen, self.csz), needs_grad=True)
+        self.states = F.dropout(tape, self.states_in, att.dropout_keep_prob, train_mode,
+                                ctx.salt(att.name, "attention_states"))
+        self.hf = F.linear(tape, self.states, tape.param(att, "attn_key_projection"))
+        self.mask = att.attention_mask(ctx)
+        self.wq = tape.param(att, "Attention/attn_query_projection")
+        self.bq = tape.param(att, "attn_projection_bias")
+        self.v = tape.param(att, "attn_similarity_v")
+        self.bias = tape.param(att, "attn_bias")
+        self._dvp = None
+
+        def finish():           # recorded first => runs after every step's gradient closure
+            if self._dvp is not None:
+                ops.colsum(self._dvp, self.v.grad, accumulate=True)
+        tape.record(finish)
+
+    @property
+    def d_states(self) -> Optional[torch.Tensor]:
+        """dL/d(encoder states) [B,S,C] after ``Tape.backward``."""
+        g = self.states_in.grad
+        return None if g is None else g.view(self.bsz, self.slen, self.csz)
+
+    def step(self, query, w_out: Optional[torch.Tensor] = None):
+        """query Var [R,Q] -> context Var [R,C]; ``w_out`` [R,S] receives the weights."""
+        from .. import autodiff as F
+        tape, att = self.tape, self.att
+        ctx = tape.ctx
+        b, s, c, a = self.bsz, self.slen, self.csz, self.asz
+        rows = query.shape[0]
+        y = F.linear(tape, query, self.wq, self.bq)
+        out = tape.new((rows, c))
+        w = w_out if w_out is not None else tape.buf((rows, s))
+        e = tape.buf((rows, s)) if tape.recording else None
+        ws = ctx.buffer((id(att), "ws", rows), ((ops._lib.load().nm_attn_workspace_bytes(rows, s, c) + 3) // 4,))
+        hf3, st3 = self.hf.data.view(b, s, a), self.states.data.view(b, s, c)
+        ops.attn_fwd(y.data, hf3, st3, self.mask, self.v.data, self.bias.data, att.rows_per_key, out.data, w, ws, e)
+
+        def bwd():
+            dctx = out.grad
+            if dctx is None:
+                return
+            assert rows == b, "the attention gradient is defined for one query per sentence"
+            dw = tape.buf((b, 1, s))
+            ops.gemm(dctx.view(b, 1, c), st3, out=dw, trans_b=True)
+            if self.states.needs_grad:
+                ops.gemm(w.view(b, 1, s), dctx.view(b, 1, c), out=tape.grad(self.states).view(b, s, c),
+                         trans_a=True, accumulate=True)
+            de = tape.buf((1, b, s))
+            ops.attn_softmax_bwd(dw.view(1, b, s), e.view(1, b, s), self.mask, de, b)
+            dbias = tape.buf((1,))
+            ops.reduce_sum(de.view(-1), dbias)
+            ops.ew("copy", dbias, None, self.bias.grad, accumulate=True)
+            if self._dvp is None:
+                self._dvp = tape.buf((b * s, a), zero=True)
+            ops.attn_energy_bwd(de, hf3, y.data.view(1, b, a), self.v.data, tape.grad(self.hf).view(b, s, a),
+                                self._dvp, tape.grad(y).view(1, b, a), accumulate=True)
+        tape.record(bwd)
+        return out

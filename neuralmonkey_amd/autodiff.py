@@ -1,0 +1,365 @@
+"""Reverse-mode tape over libnmhip kernels: the general model path.
+
+The reference gets its gradients from ``tf.gradients`` over the TF graph
+(trainers/generic_trainer.py:160-170).  The headline configuration (TF GRU
+cells, Bahdanau attention that does not feed the recurrence, no dropout) has a
+hand-scheduled forward/backward in ``decoders/decoder.py`` and
+``encoders/recurrent.py``.  Every other configuration the reference accepts --
+NematusGRU / LSTM cells, conditional GRU, attention on input, dropout, the
+output-projection variants, the Transformer -- runs through this tape: a model
+part expresses one step with the functions below, each of which launches its
+forward kernel(s) and, when the tape is recording, appends a closure that
+launches the matching gradient kernels.  ``Tape.backward`` replays the closures
+in reverse.  Gradients always *accumulate* into zero-initialised buffers, so
+fan-out needs no special casing and column / row views alias their parent.
+
+Buffers come from the session's persistent scratch pool keyed by
+(tape key, slot, creation index): the same model on the same shapes re-uses
+the same device memory every run.  During inference the tape does not record
+and ``rewind(slot)`` re-uses one step's buffers for every step (two slots, so
+that the state of step t-1 survives while step t is computed).
+"""
+from typing import Callable, List, Optional, Sequence
+
+import torch
+
+from . import ops
+
+
+class Var:
+    """A tensor on the tape plus (lazily) its gradient."""
+    __slots__ = ("data", "grad", "needs_grad")
+
+    def __init__(self, data: torch.Tensor, grad: Optional[torch.Tensor] = None, needs_grad: bool = True):
+        self.data = data
+        self.grad = grad
+        self.needs_grad = needs_grad
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+
+class Tape:
+    def __init__(self, ctx, key, recording: bool = True):
+        self.ctx = ctx
+        self.key = key
+        self.recording = recording
+        self._ops: List[Callable[[], None]] = []
+        self._n = 0
+        self._slot = 0
+
+    # -- buffers ------------------------------------------------------------------------------
+    def rewind(self, slot: int = 0) -> None:
+        assert not self.recording, "a recording tape must keep every intermediate"
+        self._n = 0
+        self._slot = slot
+
+    def buf(self, shape, dtype=torch.float32, zero: bool = False) -> torch.Tensor:
+        key = ("tape", self.key, self._slot, self._n)
+        self._n += 1
+        return self.ctx.buffer(key, shape, dtype, zero)
+
+    def new(self, shape) -> Var:
+        return Var(self.buf(shape), None, self.recording)
+
+    def leaf(self, data: torch.Tensor, needs_grad: bool = False) -> Var:
+        """Wrap an existing tensor (an encoder output, an embedded input)."""
+        return Var(data, None, needs_grad and self.recording)
+
+    def param(self, part, name: str) -> Var:
+        """A trainable variable of ``part``; its gradient is its slice of the flat gradient buffer."""
+        ctx = self.ctx
+        grad = ctx.store.g(part.var_name(name)) if self.recording else None
+        return Var(part.var(ctx, name), grad, self.recording)
+
+    def named_param(self, full_name: str) -> Var:
+        """A variable addressed by its full store name (e.g. a shared embedding matrix)."""
+        store = self.ctx.store
+        return Var(store[full_name], store.g(full_name) if self.recording else None, self.recording)
+
+    def grad(self, v: Var) -> Optional[torch.Tensor]:
+        if not v.needs_grad:
+            return None
+        if v.grad is None:
+            v.grad = self.buf(tuple(v.data.shape), zero=True)
+        return v.grad
+
+    def view(self, v: Var, fn: Callable[[torch.Tensor], torch.Tensor]) -> Var:
+        """A strided view (column / row block) of ``v``; gradient flows by aliasing."""
+        g = self.grad(v) if (self.recording and v.needs_grad) else None
+        return Var(fn(v.data), None if g is None else fn(g), g is not None)
+
+    def cols(self, v: Var, lo: int, hi: int) -> Var:
+        return self.view(v, lambda t: t[:, lo:hi])
+
+    def rows(self, v: Var, lo: int, hi: int) -> Var:
+        return self.view(v, lambda t: t[lo:hi])
+
+    # -- recording ----------------------------------------------------------------------------
+    def record(self, fn: Callable[[], None]) -> None:
+        if self.recording:
+            self._ops.append(fn)
+
+    def backward(self) -> None:
+        for fn in reversed(self._ops):
+            fn()
+        self._ops = []
+
+
+# ------------------------------------------------------------------------------------------------
+# functions (forward kernel now, gradient closure on the tape)
+# ------------------------------------------------------------------------------------------------
+def linear(tape: Tape, x: Var, w: Var, b: Optional[Var] = None, out: Optional[Var] = None,
+           accumulate: bool = False, trans_b: bool = False) -> Var:
+    """out (+)= x . op(w) + b   -- tf.layers.dense / tf.matmul on MFMA."""
+    n = w.shape[0] if trans_b else w.shape[1]
+    if out is None:
+        assert not accumulate
+        out = tape.new((x.shape[0], n))
+    ops.gemm(x.data, w.data, out=out.data, bias=None if b is None else b.data, accumulate=accumulate,
+             trans_b=trans_b)
+
+    def bwd():
+        dy = out.grad
+        if dy is None:
+            return
+        if x.needs_grad:
+            ops.gemm(dy, w.data, out=tape.grad(x), trans_b=not trans_b, accumulate=True)
+        if w.needs_grad:
+            if trans_b:
+                ops.gemm(dy, x.data, out=w.grad, trans_a=True, accumulate=True)
+            else:
+                ops.gemm(x.data, dy, out=w.grad, trans_a=True, accumulate=True)
+        if b is not None and b.needs_grad:
+            ops.colsum(dy, b.grad, accumulate=True)
+    tape.record(bwd)
+    return out
+
+
+def _unary(tape: Tape, op: str, bwd_op: Optional[str], x: Var, alpha: float = 0.0,
+           out: Optional[Var] = None) -> Var:
+    if out is None:
+        out = tape.new(tuple(x.shape))
+    ops.ew(op, x.data, None, out.data, alpha=alpha)
+
+    def bwd():
+        if out.grad is None or not x.needs_grad:
+            return
+        if bwd_op is None:           # copy / scale
+            ops.ew("scale" if op == "scale" else "copy", out.grad, None, tape.grad(x), alpha=alpha,
+                   accumulate=True)
+        else:
+            ops.ew(bwd_op, out.data, out.grad, tape.grad(x), accumulate=True)
+    tape.record(bwd)
+    return out
+
+
+def sigmoid(tape: Tape, x: Var, shift: float = 0.0) -> Var:
+    """sigmoid(x + shift) (shift = the LSTM forget bias)."""
+    return _unary(tape, "sigmoid", "sigmoid_bwd", x, alpha=shift)
+
+
+def tanh(tape: Tape, x: Var) -> Var:
+    return _unary(tape, "tanh", "tanh_bwd", x)
+
+
+def relu(tape: Tape, x: Var) -> Var:
+    return _unary(tape, "relu", "relu_bwd", x)
+
+
+def scale(tape: Tape, x: Var, alpha: float) -> Var:
+    return _unary(tape, "scale", None, x, alpha=alpha)
+
+
+def copy(tape: Tape, x: Var, out: Optional[Var] = None) -> Var:
+    return _unary(tape, "copy", None, x, out=out)
+
+
+ACTIVATIONS = {"tanh": tanh, "relu": relu, "sigmoid": sigmoid, "identity": lambda tape, x: x}
+
+
+def add(tape: Tape, a: Var, b: Var) -> Var:
+    out = tape.new(tuple(a.shape))
+    ops.ew("add", a.data, b.data, out.data)
+
+    def bwd():
+        if out.grad is None:
+            return
+        for v in (a, b):
+            if v.needs_grad:
+                ops.ew("copy", out.grad, None, tape.grad(v), accumulate=True)
+    tape.record(bwd)
+    return out
+
+
+def add_(tape: Tape, acc: Var, x: Var) -> Var:
+    """acc += x in place (a sum needs none of its inputs in the backward pass)."""
+    ops.ew("copy", x.data, None, acc.data, accumulate=True)
+
+    def bwd():
+        if acc.grad is not None and x.needs_grad:
+            ops.ew("copy", acc.grad, None, tape.grad(x), accumulate=True)
+    tape.record(bwd)
+    return acc
+
+
+def mul(tape: Tape, a: Var, b: Var) -> Var:
+    out = tape.new(tuple(a.shape))
+    ops.ew("mul", a.data, b.data, out.data)
+
+    def bwd():
+        if out.grad is None:
+            return
+        if a.needs_grad:
+            ops.ew("mul", out.grad, b.data, tape.grad(a), accumulate=True)
+        if b.needs_grad:
+            ops.ew("mul", out.grad, a.data, tape.grad(b), accumulate=True)
+    tape.record(bwd)
+    return out
+
+
+def blend(tape: Tape, u: Var, h: Var, c: Var) -> Var:
+    """u*h + (1-u)*c."""
+    out = tape.new(tuple(h.shape))
+    ops.blend_fwd(u.data, h.data, c.data, out.data)
+
+    def bwd():
+        if out.grad is None:
+            return
+        ops.blend_bwd(out.grad, u.data, h.data, c.data, tape.grad(u), tape.grad(h), tape.grad(c))
+    tape.record(bwd)
+    return out
+
+
+def dropout(tape: Tape, x: Var, keep_prob: float, train_mode: bool, salt: int) -> Var:
+    """nn/utils.py:6-22.  Identity at keep_prob 1 or outside training."""
+    if keep_prob <= 0.0 or keep_prob > 1.0:
+        raise ValueError("keep_prob must be a scalar tensor or a float in the range (0, 1], got {}"
+                         .format(keep_prob))
+    if keep_prob == 1.0 or not train_mode:
+        return x
+    out = tape.new(tuple(x.shape))
+    ops.dropout(x.data, out.data, keep_prob, salt)
+
+    def bwd():
+        if out.grad is not None and x.needs_grad:
+            ops.dropout(out.grad, tape.grad(x), keep_prob, salt, accumulate=True)
+    tape.record(bwd)
+    return out
+
+
+def concat(tape: Tape, parts: Sequence[Var]) -> Var:
+    """tf.concat(parts, 1)."""
+    if len(parts) == 1:
+        return parts[0]
+    rows = parts[0].shape[0]
+    widths = [p.shape[1] for p in parts]
+    out = tape.new((rows, sum(widths)))
+    col = 0
+    for p, w in zip(parts, widths):
+        ops.ew("copy", p.data, None, out.data[:, col:col + w])
+        col += w
+
+    def bwd():
+        if out.grad is None:
+            return
+        c = 0
+        for p, w in zip(parts, widths):
+            if p.needs_grad:
+                ops.ew("copy", out.grad[:, c:c + w], None, tape.grad(p), accumulate=True)
+            c += w
+    tape.record(bwd)
+    return out
+
+
+def embedding(tape: Tape, table: Var, ids: torch.Tensor, out: Optional[Var] = None, mask_pad: bool = False,
+              scale_by: float = 1.0) -> Var:
+    """tf.nn.embedding_lookup (model/sequence.py:170-194, autoregressive.py:258-272)."""
+    if out is None:
+        out = tape.new((ids.numel(), table.shape[1]))
+    ops.embedding_gather(table.data, ids, out=out.data, mask_pad=mask_pad, scale=scale_by)
+
+    def bwd():
+        if out.grad is None or not table.needs_grad:
+            return
+        d = out.grad
+        if scale_by != 1.0:
+            d = ops.ew("scale", out.grad, None, tape.buf(tuple(out.grad.shape)), alpha=scale_by)
+        ops.embedding_scatter_add(table.grad, ids, d, skip_pad=mask_pad)
+    tape.record(bwd)
+    return out
+
+
+def layer_norm(tape: Tape, x: Var, gamma: Var, beta: Var, eps: float = 1e-6) -> Var:
+    """tf_utils.py:189-219."""
+    rows = x.data.numel() // x.shape[-1]
+    out = tape.new(tuple(x.shape))
+    mean, rstd = tape.buf((rows,)), tape.buf((rows,))
+    ops.layer_norm_fwd(x.data, gamma.data, beta.data, out=out.data, mean=mean, rstd=rstd, eps=eps)
+
+    def bwd():
+        if out.grad is None:
+            return
+        d = x.shape[-1]
+        dx, dyx = tape.buf(tuple(x.shape)), tape.buf(tuple(x.shape))
+        ops.layer_norm_bwd(out.grad, x.data, mean, rstd, gamma.data, dx, dyx)
+        if x.needs_grad:
+            ops.ew("copy", dx, None, tape.grad(x), accumulate=True)
+        if gamma.needs_grad:
+            ops.colsum(dyx.view(rows, d), gamma.grad, accumulate=True)
+            ops.colsum(out.grad.view(rows, d), beta.grad, accumulate=True)
+    tape.record(bwd)
+    return out
+
+
+def rnn_select(tape: Tape, h_new: Var, h_prev: Var, lengths: Optional[torch.Tensor], t: int,
+               y_out: Optional[Var]) -> Var:
+    """dynamic_rnn length masking of step t: returns the carried state, writes the emitted row."""
+    h_out = tape.new(tuple(h_new.shape))
+    ops.rnn_select_fwd(h_new.data, h_prev.data, lengths, t, h_out.data, None if y_out is None else y_out.data)
+
+    def bwd():
+        dh = h_out.grad
+        dy = None if y_out is None else y_out.grad
+        if dh is None and dy is None:
+            return
+        ops.rnn_select_bwd(dh, dy, lengths, t, tape.grad(h_new), tape.grad(h_prev) if dh is not None else None)
+    tape.record(bwd)
+    return h_out
+
+
+def reverse_sequence(tape: Tape, x: Var, lengths: torch.Tensor) -> Var:
+    out = tape.new(tuple(x.shape))
+    ops.reverse_sequence(x.data, out.data, lengths)
+
+    def bwd():
+        if out.grad is not None and x.needs_grad:
+            ops.reverse_sequence(out.grad, tape.grad(x), lengths, accumulate=True)
+    tape.record(bwd)
+    return out
+
+
+def maxout(tape: Tape, x: Var, pool: int = 2) -> Var:
+    rows, cols = x.shape
+    out = tape.new((rows, cols // pool))
+    arg = tape.buf((rows, cols // pool), torch.int32)
+    ops.maxout_fwd(x.data, out.data, arg, pool)
+
+    def bwd():
+        if out.grad is not None and x.needs_grad:
+            ops.maxout_bwd(out.grad, arg, tape.grad(x), pool)
+    tape.record(bwd)
+    return out
+
+
+def xent(tape: Tape, logits: Var, targets: torch.Tensor, weights: torch.Tensor,
+         grad_scale: Optional[torch.Tensor]) -> torch.Tensor:
+    """Masked sparse softmax cross entropy per row (autoregressive.py:289-316).  When recording,
+    the kernel overwrites the logits with their gradient (scaled by ``grad_scale``), which then
+    *is* the gradient buffer of ``logits``."""
+    loss_rows = tape.buf((logits.shape[0],))
+    ops.xent(logits.data, targets, weights, loss_rows, grad_scale, tape.recording)
+    if tape.recording:
+        logits.grad = logits.data
+    return loss_rows

@@ -362,6 +362,70 @@ extern "C" int64_t nm_attn_workspace_bytes(int64_t R, int64_t S, int64_t C) {
     return (int64_t)sizeof(float) * (e + R * nchunk * C + R * nchunk * 4);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Any-shape fallback: A, C or the context row stride not a multiple of 4 (e.g. the reference's
+// tests/small.ini: rnn_size 7 -> C = 14), S beyond the chunked kernels' limit, or C > 2048.  One
+// workgroup per query row, scalar loads, the whole row of energies in LDS.  Same arithmetic
+// (feed_forward.py:120-166: softmax over all S, then mask, then renormalise with +1e-8).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_generic(AttnArgs p, float* __restrict__ ctx, long ldctx,
+                                                    float* __restrict__ weights, float* __restrict__ energies,
+                                                    int Bk) {
+    extern __shared__ float gsm[];          // [S] energies -> weights, then [4] reduction slots
+    float* es = gsm;
+    float* red = gsm + p.S;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = blockIdx.x % p.nq, b = blockIdx.x / p.nq;
+    const long row = (long)b * p.qsb + (long)q * p.qsq;
+    const float* yr = p.y + row * p.A;
+    const float* hfb = p.hf + (long)b * p.S * p.A;
+    const float bias = p.bias ? p.bias[0] : 0.0f;
+    for (int s = wave; s < p.S; s += 4) {
+        const float* h = hfb + (long)s * p.A;
+        float acc = 0.0f;
+        for (int a = lane; a < p.A; a += 64) acc += p.v[a] * nm_tanh(h[a] + yr[a]);
+        acc = nm_wave_sum(acc);
+        if (lane == 0) es[s] = acc + bias;
+    }
+    __syncthreads();
+    if (energies)
+        for (int s = tid; s < p.S; s += 256) energies[row * p.S + s] = es[s];
+    float mx = -INFINITY;
+    for (int s = tid; s < p.S; s += 256) mx = fmaxf(mx, es[s]);
+    mx = nm_wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float se = 0.0f, sm = 0.0f;
+    for (int s = tid; s < p.S; s += 256) {
+        const float e = __expf(es[s] - mx);
+        se += e;
+        sm += e * (p.mask ? p.mask[(long)b * p.S + s] : 1.0f);
+    }
+    se = nm_wave_sum(se);
+    sm = nm_wave_sum(sm);
+    if (lane == 0) { red[wave] = se; red[4 + wave] = sm; }
+    __syncthreads();
+    se = red[0] + red[1] + red[2] + red[3];
+    sm = red[4] + red[5] + red[6] + red[7];
+    const float inv_se = 1.0f / se;
+    const float inv_n = 1.0f / (sm * inv_se + 1e-8f);
+    __syncthreads();
+    for (int s = tid; s < p.S; s += 256) {
+        const float w = __expf(es[s] - mx) * inv_se * (p.mask ? p.mask[(long)b * p.S + s] : 1.0f) * inv_n;
+        es[s] = w;
+        if (weights) weights[row * p.S + s] = w;
+    }
+    __syncthreads();
+    const float* stb = p.states + (long)b * p.S * p.C;
+    for (int c = tid; c < p.C; c += 256) {
+        float acc = 0.0f;
+        for (int s = 0; s < p.S; ++s) acc += es[s] * stb[(long)s * p.C + c];
+        ctx[row * ldctx + c] = acc;
+    }
+}
+
 extern "C" int nm_attn_fwd_multi(void* stream, const float* y, const float* hf, const float* states,
                                  const float* mask, const float* v, const float* bias, int64_t Bk,
                                  int64_t nq, int64_t q_stride_b, int64_t q_stride_q, int64_t S, int64_t A,
@@ -374,15 +438,24 @@ extern "C" int nm_attn_fwd_multi(void* stream, const float* y, const float* hf, 
     const bool time_layout = (q_stride_b == 1 && q_stride_q == Bk);
     NM_REQUIRE(beam_layout || time_layout, "nm_attn_fwd: query rows must be [Bk,nq] or [nq,Bk] major");
     const int64_t R = Bk * nq;
-    NM_REQUIRE(A % 4 == 0 && C % 4 == 0 && ldctx % 4 == 0, "nm_attn_fwd: A, C, ldctx must be multiples of 4");
-    NM_REQUIRE(C <= 2048, "nm_attn_fwd: C > 2048 unsupported");
-    NM_REQUIRE(nm_aligned16(y) && nm_aligned16(hf) && nm_aligned16(states) && nm_aligned16(v) &&
-                   nm_aligned16(ctx) && nm_aligned16(workspace),
-               "nm_attn_fwd: pointers must be 16-byte aligned");
-    NM_REQUIRE(workspace_bytes >= nm_attn_workspace_bytes(R, S, C), "nm_attn_fwd: workspace too small");
     int sch, nchunk;
     attn_chunking(S, &sch, &nchunk);
-    NM_REQUIRE(sch <= ATT_MAX_SCH && nchunk <= 64, "nm_attn_fwd: S=%ld too long (max 768)", (long)S);
+    const bool vector_ok = A % 4 == 0 && C % 4 == 0 && ldctx % 4 == 0 && C <= 2048 && sch <= ATT_MAX_SCH &&
+                           nchunk <= 64 && nm_aligned16(y) && nm_aligned16(hf) && nm_aligned16(states) &&
+                           nm_aligned16(v) && nm_aligned16(ctx) && nm_aligned16(workspace);
+    if (!vector_ok) {
+        NM_REQUIRE(S <= 16000, "nm_attn_fwd: S=%ld too long for the any-shape kernel", (long)S);
+        NM_REQUIRE(R < (1LL << 31), "nm_attn_fwd: too many query rows");
+        AttnArgs g;
+        g.y = y; g.hf = hf; g.states = states; g.mask = mask; g.v = v; g.bias = bias;
+        g.energies = nullptr; g.pctx = nullptr; g.pstat = nullptr;
+        g.R = (int)R; g.S = (int)S; g.A = (int)A; g.C = (int)C; g.nchunk = 1; g.sch = (int)S;
+        g.qsb = (int)q_stride_b; g.qsq = (int)q_stride_q; g.nq = (int)nq;
+        hipLaunchKernelGGL(attn_generic, dim3((unsigned)R), dim3(256), sizeof(float) * (S + 8), nm_stream(stream),
+                           g, ctx, (long)ldctx, weights, energies_out, (int)Bk);
+        NM_LAUNCH_CHECK("nm_attn_fwd");
+    }
+    NM_REQUIRE(workspace_bytes >= nm_attn_workspace_bytes(R, S, C), "nm_attn_fwd: workspace too small");
     const int qpk = (int)(nq < 8 ? nq : 8);
     const int groups = (int)((nq + qpk - 1) / qpk);
     NM_REQUIRE(groups <= 65535 && Bk <= 65535, "nm_attn_fwd: grid too large");

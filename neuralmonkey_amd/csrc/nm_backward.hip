@@ -420,7 +420,7 @@ extern "C" int nm_attn_softmax_bwd(void* stream, const float* dw, const float* e
 __global__ void attn_dhf_kernel(const float* __restrict__ de, const float* __restrict__ hf,
                                 const float* __restrict__ y, const float* __restrict__ v,
                                 float* __restrict__ dhf, float* __restrict__ dvp, int T, int B, int S,
-                                int A) {
+                                int A, int accumulate) {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     const int s = blockIdx.y, b = blockIdx.z;
     if (a >= A) return;
@@ -432,8 +432,14 @@ __global__ void attn_dhf_kernel(const float* __restrict__ de, const float* __res
         acc += d * (1.0f - z * z);
         accv += d * z;
     }
-    dhf[((long)b * S + s) * A + a] = v[a] * acc;
-    dvp[((long)b * S + s) * A + a] = accv;
+    const long o = ((long)b * S + s) * A + a;
+    if (accumulate) {
+        dhf[o] += v[a] * acc;
+        dvp[o] += accv;
+    } else {
+        dhf[o] = v[a] * acc;
+        dvp[o] = accv;
+    }
 }
 
 __global__ void attn_dy_kernel(const float* __restrict__ de, const float* __restrict__ hf,
@@ -454,13 +460,13 @@ __global__ void attn_dy_kernel(const float* __restrict__ de, const float* __rest
 
 extern "C" int nm_attn_energy_bwd(void* stream, const float* de, const float* hf, const float* y,
                                   const float* v, float* dhf, float* dv_partial, float* dy, int64_t T,
-                                  int64_t B, int64_t S, int64_t A) {
+                                  int64_t B, int64_t S, int64_t A, int accumulate) {
     NM_REQUIRE(de && hf && y && v && dhf && dv_partial && dy, "nm_attn_energy_bwd: null pointer");
     NM_REQUIRE(T > 0 && B > 0 && S > 0 && A > 0 && S < 65536 && B < 65536 && T < 65536,
                "nm_attn_energy_bwd: bad shape");
     hipStream_t st = nm_stream(stream);
     hipLaunchKernelGGL(attn_dhf_kernel, dim3(nm_cdiv(A, 256), (unsigned)S, (unsigned)B), dim3(256), 0, st, de,
-                       hf, y, v, dhf, dv_partial, (int)T, (int)B, (int)S, (int)A);
+                       hf, y, v, dhf, dv_partial, (int)T, (int)B, (int)S, (int)A, accumulate);
     hipLaunchKernelGGL(attn_dy_kernel, dim3(nm_cdiv(A, 256), (unsigned)T, (unsigned)B), dim3(256), 0, st, de,
                        hf, y, v, dy, (int)T, (int)B, (int)S, (int)A);
     NM_LAUNCH_CHECK("nm_attn_energy_bwd");

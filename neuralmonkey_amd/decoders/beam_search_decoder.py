@@ -25,6 +25,7 @@ from ..runtime import Placeholder, tensor
 from ..vocabulary import END_TOKEN_INDEX, PAD_TOKEN_INDEX, START_TOKEN_INDEX, Vocabulary
 from .autoregressive import AutoregressiveDecoder, DecoderFeedables, LoopState
 from .decoder import CHECK_EVERY
+from .decoder_general import make_stepper
 
 INF = 1e9
 
@@ -114,10 +115,8 @@ class BeamSearchDecoder(ModelPart):
         f32 = lambda name, shape, **kw: ctx.buffer(key + (name,), shape, torch.float32, **kw)
         i32 = lambda name, shape, **kw: ctx.buffer(key + (name,), shape, torch.int32, **kw)
 
-        cell = dec._cell(ctx)
-        bufs = dec._step_bufs(ctx, rows)
-        hbuf = f32("h", (2, rows, h))                     # ping-pong decoder state
-        hsel = f32("hsel", (rows, h))                     # state gathered to the chosen beams
+        stepper = make_stepper(dec, ctx, rows, "beam")    # decoder state, ping-pong + beam gather
+        hsel = f32("hsel", (rows, h))
         emb = f32("emb", (rows, e))
         out_state = f32("out", (rows, dec.output_dimension))
         logits = f32("logits", (rows, v))
@@ -140,7 +139,8 @@ class BeamSearchDecoder(ModelPart):
         go = i32("go", (rows,))
         go.fill_(START_TOKEN_INDEX)
         dec.embed_input_symbols(ctx, go, out=emb)
-        att_states = dec.full_step(ctx, cell, emb, hsel, hbuf[0], att_states, out_state, logits, bufs)
+        stepper.start(hsel)
+        att_states = stepper.step(emb, att_states, out_state, logits)
         ops.row_stats(logits, rmax, rlse, argmax)
         tok[0, 0].copy_(argmax)                           # parent's greedy symbol, dropped by the runner
         lps[0].fill_(-INF)
@@ -156,11 +156,10 @@ class BeamSearchDecoder(ModelPart):
                                END_TOKEN_INDEX, scores, word, beam, lps[nxt], lens[nxt], fin[nxt], src, ws,
                                allfin[steps:steps + 1])
             srcf, wordf = src.view(rows), word.view(rows)
-            ops.gather_rows(hbuf[cur], srcf, hsel)                               # :503-532
+            stepper.reorder(srcf)                                                # :503-532
             ops.beam_reorder_tokens(tok[cur], srcf, wordf, tok[nxt], steps + 1, rows)   # :546-551
             dec.embed_input_symbols(ctx, wordf, out=emb)                         # :507-510
-            att_states = dec.full_step(ctx, cell, emb, hsel, hbuf[nxt], att_states, out_state, logits,
-                                       bufs)                                     # :534-535
+            att_states = stepper.step(emb, att_states, out_state, logits)        # :534-535
             ops.row_stats(logits, rmax, rlse, None)                              # :537-543
             cur = nxt
             steps += 1

@@ -30,6 +30,7 @@ from ..variables import constant_initializer, orthogonal_initializer, zeros_init
 from ..vocabulary import END_TOKEN_INDEX, START_TOKEN_INDEX, Vocabulary, sentence_mask
 from .autoregressive import (AutoregressiveDecoder, DecoderConstants, DecoderFeedables,
                              DecoderHistories, LoopState)
+from .decoder_general import GeneralDecoderMixin, make_stepper
 from .encoder_projection import (EncoderProjection, concat_encoder_projection, empty_initial_state,
                                  linear_encoder_projection)
 from .output_projection import OutputProjection, OutputProjectionSpec, nonlinear_output
@@ -70,7 +71,7 @@ class RuntimeResult(NamedTuple):
 
 
 # pylint: disable=too-many-instance-attributes
-class Decoder(AutoregressiveDecoder):
+class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
     # pylint: disable=too-many-arguments,too-many-locals
     def __init__(self, encoders: List[Stateful], vocabulary: Vocabulary, data_id: str, name: str,
                  max_output_len: int, dropout_keep_prob: float = 1.0, embedding_size: int = None,
@@ -101,12 +102,9 @@ class Decoder(AutoregressiveDecoder):
         if self._rnn_cell_str not in RNN_CELL_TYPES:
             raise ValueError("RNN cell must be a either 'GRU', 'LSTM', or 'NematusGRU'. Not {}"
                              .format(self._rnn_cell_str))
-        if self._rnn_cell_str != "GRU" or conditional_gru or attention_on_input:
-            raise NotImplementedError(
-                "Decoder '{}': the HIP engine currently implements rnn_cell='GRU' without "
-                "conditional_gru / attention_on_input".format(name))
         for att in self.attentions:
             att.bind_query_size(self.rnn_size)
+        self._build_cells()
         if self.embedding_size != self.output_dimension:
             raise ValueError("The dimension ({}) of the output projection must be same as the "
                              "dimension of the input embedding ({})"
@@ -159,11 +157,7 @@ class Decoder(AutoregressiveDecoder):
         AutoregressiveDecoder.declare_variables(self, store)
         e, h = self.embedding_size, self.rnn_size
         self.encoder_projection.declare_variables(self, store, self.rnn_size, self.encoders)
-        pre = "attention_decoder/OrthoGRUCell"
-        self.declare(store, pre + "/gates/kernel", (e + h, 2 * h), orthogonal_initializer())
-        self.declare(store, pre + "/gates/bias", (2 * h,), constant_initializer(1.0))
-        self.declare(store, pre + "/candidate/kernel", (e + h, h), orthogonal_initializer())
-        self.declare(store, pre + "/candidate/bias", (h,), zeros_initializer())
+        self._declare_general_variables(store)      # the cell(s): same names on both paths
         self.output_projection.declare_variables(
             self, store, h, e, [a.context_vector_size for a in self.attentions])
 
@@ -236,6 +230,8 @@ class Decoder(AutoregressiveDecoder):
         return self._train_loop(ctx) if train_mode else self._runtime_loop(ctx, keep_logits=False)
 
     def _train_loop(self, ctx, want_grad: bool = False, grad_scale: Optional[torch.Tensor] = None) -> TrainResult:
+        if self.uses_general_path(bool(ctx.fed(self.train_mode))):
+            return self._general_train_loop(ctx, want_grad, grad_scale)
         key = (id(self), "train")
         tgt = self.train_inputs(ctx)                        # [T,B]
         tmask = self.train_mask(ctx)
@@ -296,6 +292,8 @@ class Decoder(AutoregressiveDecoder):
         ``ctx.store.grad`` and on into the attentions and encoders."""
         store = ctx.store
         sv = res.saved
+        if "tape" in sv:
+            return self._general_backward(ctx, res)
         steps, bsz = sv["steps"], sv["bsz"]
         rows = steps * bsz
         e, h, v = self.embedding_size, self.rnn_size, len(self.vocabulary)
@@ -410,8 +408,6 @@ class Decoder(AutoregressiveDecoder):
         bsz = int(ctx.fed(self.batch_size))
         e, h, v = self.embedding_size, self.rnn_size, len(self.vocabulary)
         tmax = self.max_output_len
-        cell = self._cell(ctx)
-        dev = ctx.device
         has_tgt = self.has_targets(ctx)
         if has_tgt:
             tgt, tmask = self.train_inputs(ctx), self.train_mask(ctx)
@@ -430,7 +426,8 @@ class Decoder(AutoregressiveDecoder):
         logits_one = ctx.buffer(key + ("logits",), (bsz, v))
         xent_rows = ctx.buffer(key + ("xent_rows",), (tmax, bsz), zero=True) if has_tgt else None
         emb = ctx.buffer(key + ("emb",), (2, bsz, e))
-        bufs = self._step_bufs(ctx, bsz)
+        stepper = make_stepper(self, ctx, bsz, "greedy")
+        stepper.start(s0)
         att_states = [a.initial_loop_state(ctx, bsz, tmax) for a in self.attentions]
 
         go = ctx.buffer(key + ("go",), (bsz,), torch.int32)
@@ -440,8 +437,7 @@ class Decoder(AutoregressiveDecoder):
         while steps < tmax:
             t = steps
             logits = logits_all[t] if keep_logits else logits_one
-            att_states = self.full_step(ctx, cell, emb[t & 1], s0 if t == 0 else s_all[t - 1], s_all[t],
-                                        att_states, out_all[t], logits, bufs)
+            att_states = stepper.step(emb[t & 1], att_states, out_all[t], logits, h_out=s_all[t])
             ops.row_stats(logits, None, None, argmax)
             if has_tgt and t < t_target:
                 ops.xent(logits, tgt[t], tmask[t], xent_rows[t])
@@ -512,5 +508,7 @@ class Decoder(AutoregressiveDecoder):
         if res.saved["dlogits"] is not None:
             raise RuntimeError("train_logits were overwritten by their gradient in this run")
         steps, bsz = res.saved["steps"], res.saved["bsz"]
+        if "tape" in res.saved:
+            return res.saved["logits"].view(steps, bsz, -1)
         return ctx.buffer((id(self), "train", "logits"), (steps * bsz, len(self.vocabulary))) \
             .view(steps, bsz, -1)

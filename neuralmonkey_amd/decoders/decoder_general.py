@@ -1,0 +1,241 @@
+"""General (taped) path of the RNN decoder: every ``Decoder`` configuration outside the
+hand-scheduled plain-GRU fast path of ``decoder.py``.
+
+    rnn_cell = "NematusGRU" | "LSTM"                 decoders/decoder.py:253-254, 309-325
+    conditional_gru (second cell on the contexts)    decoders/decoder.py:256-261, 303-307
+    attention_on_input                               decoders/decoder.py:264-277
+    dropout_keep_prob < 1 in training                decoders/decoder.py:235-240, 331-334,
+                                                     autoregressive.py:269-272
+    nematus / maxout / mlp output projections        decoders/output_projection.py:76-188
+
+One step is written once (``general_step``) against ``autodiff`` and used by training (tape
+recording, gradients by ``Tape.backward``) and by greedy / beam decoding (non-recording tape whose
+step buffers are recycled).  The context vectors feed the recurrence in most of these
+configurations, so nothing is hoisted out of the time loop except the embedding gather and the
+vocabulary projection + cross entropy.
+"""
+from typing import List, Optional
+
+import torch
+
+from .. import autodiff as F
+from .. import ops
+from ..nn.cells import GRUCell, LSTMCell, NematusGRUCell, make_cell
+from ..variables import zeros_initializer
+
+
+class GeneralDecoderMixin:
+    """Mixed into ``Decoder``; relies on its configuration attributes."""
+
+    # -- configuration -------------------------------------------------------------------------
+    def _build_cells(self) -> None:
+        e, h = self.embedding_size, self.rnn_size
+        self._cell_obj = make_cell(self._rnn_cell_str, self, "attention_decoder", e, h)
+        self._cond_cell = None
+        if self._conditional_gru and self._rnn_cell_str in ("GRU", "NematusGRU"):
+            ctx_total = sum(a.context_vector_size for a in self.attentions)
+            if ctx_total == 0:
+                raise ValueError("conditional_gru needs at least one attention")
+            if self._rnn_cell_str == "NematusGRU":      # decoders/decoder.py:256-261
+                self._cond_cell = NematusGRUCell(self, "attention_decoder", ctx_total, h, use_state_bias=True,
+                                                 use_input_bias=False, cell_scope="cond_gru_2_cell")
+            else:
+                self._cond_cell = GRUCell(self, "attention_decoder", ctx_total, h, cell_scope="cond_gru_2_cell")
+
+    def _declare_general_variables(self, store) -> None:
+        self._cell_obj.declare_variables(store)
+        if self._cond_cell is not None:
+            self._cond_cell.declare_variables(store)
+        if self._attention_on_input:
+            e = self.embedding_size
+            width = e + sum(a.context_vector_size for a in self.attentions)
+            self.declare(store, "attention_decoder/input_projection/kernel", (width, e))
+            self.declare(store, "attention_decoder/input_projection/bias", (e,), zeros_initializer())
+
+    def uses_general_path(self, train_mode: bool) -> bool:
+        from .output_projection import NonlinearOutput
+        if self._rnn_cell_str != "GRU" or self._cond_cell is not None or self._attention_on_input:
+            return True
+        proj = self.output_projection
+        if not isinstance(proj, NonlinearOutput) or proj.activation not in ("tanh", "identity"):
+            return True
+        if train_mode:
+            keeps = [self.dropout_keep_prob, proj.dropout_keep_prob, self.encoder_projection.dropout_keep_prob]
+            keeps += [getattr(a, "dropout_keep_prob", 1.0) for a in self.attentions]
+            if any(k != 1.0 for k in keeps):
+                return True
+        return False
+
+    def state_sizes(self) -> List[int]:
+        """Widths of the tensors carried between steps: RNNFeedables (decoders/decoder.py:34-50)."""
+        return [self.rnn_size, self.rnn_size] + [a.context_vector_size for a in self.attentions]
+
+    # -- one step --------------------------------------------------------------------------------
+    def general_step(self, tape: F.Tape, emb_in: F.Var, state: List[F.Var], sessions, w_outs, train: bool,
+                     t: int):
+        """Decoder.next_state (decoders/decoder.py:279-358).  ``state`` = [prev_rnn_state,
+        prev_rnn_output, *prev_contexts]; returns (output, new_state)."""
+        ctx = tape.ctx
+        keep = self.dropout_keep_prob
+        prev_state, prev_out, prev_ctxs = state[0], state[1], state[2:]
+        if self._attention_on_input:                                   # :264-277
+            w = tape.param(self, "attention_decoder/input_projection/kernel")
+            b = tape.param(self, "attention_decoder/input_projection/bias")
+            x, row = None, 0
+            for part in [emb_in] + list(prev_ctxs):
+                sz = part.shape[1]
+                x = F.linear(tape, part, tape.rows(w, row, row + sz), b if x is None else None, out=x,
+                             accumulate=x is not None)
+                row += sz
+            rnn_input = F.dropout(tape, x, keep, train, ctx.salt(self.name, "input_projection", t))
+        else:
+            rnn_input = emb_in
+        if isinstance(self._cell_obj, LSTMCell):                       # :309-325
+            cell_output, (next_state, _) = self._cell_obj.step(tape, rnn_input, (prev_state, prev_out))
+            contexts = [s.step(cell_output, w) for s, w in zip(sessions, w_outs)]
+        else:                                                          # :288-307
+            cell_output, (next_state,) = self._cell_obj.step(tape, rnn_input, (prev_out,))
+            contexts = [s.step(cell_output, w) for s, w in zip(sessions, w_outs)]
+            if self._cond_cell is not None:
+                cell_output, (next_state,) = self._cond_cell.step(tape, F.concat(tape, contexts), (next_state,))
+        contexts = [F.dropout(tape, c, keep, train, ctx.salt(self.name, "context", i, t))
+                    for i, c in enumerate(contexts)]                   # :331-332
+        cell_output = F.dropout(tape, cell_output, keep, train, ctx.salt(self.name, "cell_output", t))
+        output = self.output_projection.apply_var(tape, self, cell_output, emb_in, contexts, train,
+                                                  ctx.salt(self.name, "output_projection", t))
+        return output, [next_state, cell_output] + contexts
+
+    def _logit_params(self, tape: F.Tape):
+        """(W Var, trans_b, bias Var) of state_to_logits (autoregressive.py:450-459)."""
+        ctx = tape.ctx
+        bias_data = self.decoding_bias(ctx)
+        if self.tie_embeddings:
+            return tape.named_param(self.embedding_matrix_name), True, tape.leaf(bias_data)
+        b = tape.param(self, "state_to_word_b")
+        return tape.param(self, "state_to_word_W"), False, F.Var(bias_data, b.grad, b.needs_grad)
+
+    # -- training --------------------------------------------------------------------------------
+    def _general_train_loop(self, ctx, want_grad: bool, grad_scale: Optional[torch.Tensor]):
+        from .decoder import TrainResult
+        train = bool(ctx.fed(self.train_mode))
+        tape = F.Tape(ctx, (id(self), "gtrain"), recording=want_grad)
+        tgt, tmask = self.train_inputs(ctx), self.train_mask(ctx)
+        steps, bsz = tgt.shape
+        rows = steps * bsz
+        keep = self.dropout_keep_prob
+
+        table = tape.named_param(self.embedding_matrix_name)
+        emb_all = F.embedding(tape, table, self._dec_input_ids(ctx).reshape(-1))
+        emb_all = F.dropout(tape, emb_all, keep, train, ctx.salt(self.name, "embedded_input"))
+
+        enc_outs = [tape.leaf(enc.output(ctx), needs_grad=True) for enc in self.encoders]
+        s0 = self.encoder_projection.apply_var(tape, self, self.rnn_size, enc_outs, bsz, train)
+        s0 = F.dropout(tape, s0, keep, train, ctx.salt(self.name, "initial_state"))      # :235-240
+        sessions = [a.tape_session(tape, train) for a in self.attentions]
+        att_states = [a.initial_loop_state(ctx, bsz, steps, precompute=False) for a in self.attentions]
+        state = [s0, s0] + [tape.leaf(tape.buf((bsz, a.context_vector_size), zero=True))
+                            for a in self.attentions]
+        out_all = tape.new((rows, self.output_dimension))
+        for t in range(steps):
+            emb_t = tape.rows(emb_all, t * bsz, (t + 1) * bsz)
+            out_t, state = self.general_step(tape, emb_t, state, sessions, [st.weights[t] for st in att_states],
+                                             train, t)
+            F.copy(tape, out_t, out=tape.rows(out_all, t * bsz, (t + 1) * bsz))
+        w, trans_b, bias = self._logit_params(tape)
+        logits = F.linear(tape, out_all, w, bias, trans_b=trans_b)
+        loss_rows = F.xent(tape, logits, tgt.reshape(-1), tmask.reshape(-1), grad_scale)
+        loss_sum = ctx.buffer((id(self), "gtrain", "loss_sum"), (1,))
+        ops.reduce_sum(loss_rows, loss_sum)
+        from ..attention.base_attention import AttentionLoopState
+        for att, st in zip(self.attentions, att_states):
+            att.finalize_loop("{}_train".format(self.name), AttentionLoopState(st.contexts, st.weights, steps))
+        saved = {"tape": tape, "enc_outs": enc_outs, "sessions": sessions, "steps": steps, "bsz": bsz,
+                 "dlogits": logits.data if want_grad else None, "logits": logits.data}
+        return TrainResult(loss_sum, self.train_token_count(ctx), steps, saved)
+
+    def _general_backward(self, ctx, res) -> None:
+        sv = res.saved
+        sv["tape"].backward()
+        enc_grads = {}
+        for att, sess in zip(self.attentions, sv["sessions"]):
+            enc_grads.setdefault(att.encoder, [None, None])[0] = sess.d_states
+        for enc, var in zip(self.encoders, sv["enc_outs"]):
+            enc_grads.setdefault(enc, [None, None])[1] = var.grad
+        for enc, (dst, dfin) in enc_grads.items():
+            if hasattr(enc, "backward"):
+                enc.backward(ctx, dst, dfin)
+
+
+class FastStepper:
+    """Inference steps of the plain TF-GRU decoder: fused GRU GEMM epilogues + fused attention."""
+
+    def __init__(self, dec, ctx, rows: int, tag: str):
+        self.dec, self.ctx = dec, ctx
+        self.cell = dec._cell(ctx)                        # pylint: disable=protected-access
+        self.bufs = dec._step_bufs(ctx, rows)             # pylint: disable=protected-access
+        h = dec.rnn_size
+        self.hbuf = ctx.buffer((id(dec), tag, "h", rows), (2, rows, h))
+        self.sel = ctx.buffer((id(dec), tag, "hsel", rows), (rows, h))
+        self.cur = 0
+        self.src = None
+
+    def start(self, s0: torch.Tensor) -> None:
+        self.src = s0
+
+    def step(self, emb, att_states, out_state, logits, h_out: Optional[torch.Tensor] = None):
+        nxt = self.cur ^ 1
+        dst = h_out if h_out is not None else self.hbuf[nxt]
+        att_states = self.dec.full_step(self.ctx, self.cell, emb, self.src, dst, att_states, out_state, logits,
+                                        self.bufs)
+        self.cur, self.src = nxt, dst
+        return att_states
+
+    def reorder(self, src_rows: torch.Tensor) -> None:
+        ops.gather_rows(self.src, src_rows, self.sel)
+        self.src = self.sel
+
+
+class GeneralStepper:
+    """Inference steps of any other decoder configuration (non-recording tape)."""
+
+    def __init__(self, dec, ctx, rows: int, tag: str):
+        self.dec, self.ctx, self.rows = dec, ctx, rows
+        self.tape = F.Tape(ctx, (id(dec), tag, rows), recording=False)
+        self.sessions = [a.tape_session(self.tape, False) for a in dec.attentions]
+        self.sel = [ctx.buffer((id(dec), tag, "sel", rows, i), (rows, sz))
+                    for i, sz in enumerate(dec.state_sizes())]
+        self.zero_ctx = [ctx.buffer((id(dec), tag, "ctx0", rows, i), (rows, a.context_vector_size), zero=True)
+                         for i, a in enumerate(dec.attentions)]
+        self.base = self.tape._n                          # pylint: disable=protected-access
+        self.t = 0
+        self.state = None
+
+    def start(self, s0: torch.Tensor) -> None:
+        tape = self.tape
+        self.state = [tape.leaf(s0), tape.leaf(s0)] + [tape.leaf(z) for z in self.zero_ctx]
+        self.t = 0
+
+    def step(self, emb, att_states, out_state, logits, h_out: Optional[torch.Tensor] = None):
+        from ..attention.base_attention import AttentionLoopState
+        tape, dec = self.tape, self.dec
+        tape._n, tape._slot = self.base, self.t & 1       # recycle this parity's step buffers
+        w_outs = [st.weights[st.step] for st in att_states]
+        out, self.state = dec.general_step(tape, tape.leaf(emb), self.state, self.sessions, w_outs, False,
+                                           self.t)
+        out_state.copy_(out.data)
+        dec.state_to_logits(self.ctx, out_state, logits)
+        if h_out is not None:
+            h_out.copy_(self.state[1].data)
+        self.t += 1
+        return [AttentionLoopState(st.contexts, st.weights, st.step + 1) for st in att_states]
+
+    def reorder(self, src_rows: torch.Tensor) -> None:
+        for var, sel in zip(self.state, self.sel):
+            ops.gather_rows(var.data, src_rows, sel)
+        self.state = [self.tape.leaf(sel) for sel in self.sel]
+
+
+def make_stepper(dec, ctx, rows: int, tag: str):
+    if dec.uses_general_path(False):
+        return GeneralStepper(dec, ctx, rows, tag)
+    return FastStepper(dec, ctx, rows, tag)

@@ -1,8 +1,12 @@
-"""Initial-state projections (mirror of neuralmonkey/decoders/encoder_projection.py)."""
+"""Initial-state projections (mirror of neuralmonkey/decoders/encoder_projection.py).
+
+``apply`` / ``backward`` serve the hand-scheduled fast path of the decoder,
+``apply_var`` is the same arithmetic on an autodiff tape (general path)."""
 from typing import List
 
 import torch
 
+from .. import autodiff as F
 from .. import ops
 from ..model.stateful import Stateful
 from ..nn.dropout import dropout
@@ -10,6 +14,8 @@ from ..variables import zeros_initializer
 
 
 class EncoderProjection:
+    dropout_keep_prob = 1.0
+
     def output_size(self, rnn_size, encoders) -> int:
         raise NotImplementedError
 
@@ -23,6 +29,10 @@ class EncoderProjection:
         """Accumulate variable gradients; return dL/d(encoder.output) per encoder."""
         return [None for _ in encoders]
 
+    def apply_var(self, tape, decoder, rnn_size, enc_outputs, bsz: int, train_mode: bool):
+        """enc_outputs: one Var [B,D] per encoder -> initial state Var [B,rnn_size]."""
+        raise NotImplementedError
+
 
 class _Empty(EncoderProjection):
     """empty_initial_state (encoder_projection.py:37-44): zeros, tiled to the batch."""
@@ -35,6 +45,9 @@ class _Empty(EncoderProjection):
     def apply(self, ctx, decoder, rnn_size, encoders, out, train_mode):
         out.zero_()
         return out
+
+    def apply_var(self, tape, decoder, rnn_size, enc_outputs, bsz, train_mode):
+        return tape.leaf(tape.buf((bsz, rnn_size), zero=True))
 
 
 class _Concat(EncoderProjection):
@@ -64,6 +77,11 @@ class _Concat(EncoderProjection):
             grads.append(d_state[:, col:col + sz].contiguous())
             col += sz
         return grads
+
+    def apply_var(self, tape, decoder, rnn_size, enc_outputs, bsz, train_mode):
+        if len(enc_outputs) == 1:          # a copy, so that later in-place use cannot alias the encoder
+            return F.copy(tape, enc_outputs[0])
+        return F.concat(tape, enc_outputs)
 
 
 class _Linear(EncoderProjection):
@@ -109,6 +127,18 @@ class _Linear(EncoderProjection):
             grads.append(d_val)
             row += sz
         return grads
+
+    def apply_var(self, tape, decoder, rnn_size, enc_outputs, bsz, train_mode):
+        w = tape.param(decoder, "initial_state/encoders_projection/kernel")
+        b = tape.param(decoder, "initial_state/encoders_projection/bias")
+        out, row = None, 0
+        for val in enc_outputs:
+            sz = val.shape[1]
+            out = F.linear(tape, val, tape.rows(w, row, row + sz), b if out is None else None, out=out,
+                           accumulate=out is not None)
+            row += sz
+        return F.dropout(tape, out, self.dropout_keep_prob, train_mode,
+                         tape.ctx.salt(decoder.name, "encoders_projection"))
 
 
 empty_initial_state = _Empty()

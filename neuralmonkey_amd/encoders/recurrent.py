@@ -15,11 +15,13 @@ from typing import Callable, List, NamedTuple, Optional, Tuple, Union
 
 import torch
 
+from .. import autodiff as F
 from .. import ops
 from ..model.model_part import InitializerSpecs, ModelPart
 from ..model.sequence import EmbeddedSequence
 from ..model.stateful import TemporalStateful, TemporalStatefulWithOutput
 from ..nn import gru
+from ..nn.cells import make_cell
 from ..nn.dropout import dropout
 from ..runtime import tensor
 from ..variables import ones_initializer, orthogonal_initializer, zeros_initializer, constant_initializer
@@ -75,13 +77,22 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
             raise ValueError("When using residual connectiong, all layers must have the same size, "
                              "but are {}.".format(layer_sizes))
         self._layer_sizes = layer_sizes
-        # MI355X engine scope this round: one GRU layer (the translation.ini shape).
+        # one cell object per (layer, direction): variables + the taped step of the general path
+        self._cells = []
+        d_in = input_sequence.dimension
+        for i, spec in enumerate(self.rnn_specs):
+            self._cells.append([make_cell(spec.cell_type, self, "rnn_{}_{}/{}".format(i, spec.direction, d),
+                                          d_in, spec.size) for d in self._dirs(spec)])
+            d_in = layer_sizes[i]
+
+    def uses_general_path(self, train_mode: bool) -> bool:
+        """The hand-scheduled path covers one TF-GRU layer without layer norm / residual and
+        without dropout; everything else runs on the autodiff tape."""
         if len(self.rnn_specs) != 1 or self.rnn_specs[0].cell_type != "GRU":
-            raise NotImplementedError(
-                "RecurrentEncoder '{}': the HIP engine currently implements a single GRU layer "
-                "(forward / backward / bidirectional); got {}".format(name, self.rnn_specs))
-        if add_layer_norm or add_residual:
-            raise NotImplementedError("add_layer_norm / add_residual are not implemented in the HIP engine yet")
+            return True
+        if self.add_layer_norm or self.add_residual:
+            return True
+        return train_mode and self.dropout_keep_prob != 1.0
 
     # -- static sizes ------------------------------------------------------------
     @property
@@ -100,13 +111,12 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
     def declare_variables(self, store) -> None:
         d_in = self.input_sequence.dimension
         for i, spec in enumerate(self.rnn_specs):
-            h = spec.size
-            for d in self._dirs(spec):
-                pre = "rnn_{}_{}/{}/OrthoGRUCell".format(i, spec.direction, d)
-                self.declare(store, pre + "/gates/kernel", (d_in + h, 2 * h), orthogonal_initializer())
-                self.declare(store, pre + "/gates/bias", (2 * h,), constant_initializer(1.0))
-                self.declare(store, pre + "/candidate/kernel", (d_in + h, h), orthogonal_initializer())
-                self.declare(store, pre + "/candidate/bias", (h,), zeros_initializer())
+            for cell in self._cells[i]:
+                cell.declare_variables(store)          # GRU: <scope>/OrthoGRUCell/{gates,candidate}/...
+            if self.add_layer_norm:
+                pre = "rnn_{}_{}/LayerNorm".format(i, spec.direction)
+                self.declare(store, pre + "/gamma", (d_in,), ones_initializer())
+                self.declare(store, pre + "/beta", (d_in,), zeros_initializer())
             d_in = self._layer_sizes[i]
         if self.include_final_layer_norm:
             self.declare(store, "LayerNorm/gamma", (self._layer_sizes[-1],), ones_initializer())
@@ -133,6 +143,8 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
     @tensor
     def rnn(self, ctx) -> EncoderActivations:
         """One (bi)directional GRU layer + final layer norm."""
+        if self.uses_general_path(bool(ctx.fed(self.train_mode))):
+            return self._general_rnn(ctx)
         x = self.rnn_input(ctx)                                     # [B,S,E]
         lengths = self.input_sequence.lengths(ctx)                  # int32 [B]
         spec = self.rnn_specs[0]
@@ -212,6 +224,8 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
         store = ctx.store
         act = self.rnn(ctx)
         sv = act.saved
+        if "tape" in sv:
+            return self._general_backward(ctx, sv, d_states, d_final)
         x, xp, lengths = sv["x"], sv["xp"], sv["lengths"]
         bsz, slen, e = x.shape
         ndir, h, rev0 = sv["ndir"], sv["h"], sv["reverse_only"]
@@ -283,6 +297,84 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
             ops.gemm(dc, cv["/candidate/kernel"][:e], out=dx, trans_b=True, accumulate=True)
             first = False
         self.input_sequence.backward(ctx, dx.view(bsz, slen, e))
+
+    # -- general (taped) path: any cell, stacked layers, layer norm, residual, dropout ------------
+    def _general_layer(self, tape, x, bsz: int, slen: int, lengths, layer: int, train: bool):
+        """rnn_layer (recurrent.py:71-110) on the tape.  x: Var [B*S, D] -> (outputs Var
+        [B*S, ndir*H], final Var [B, ndir*H])."""
+        spec = self.rnn_specs[layer]
+        cells = self._cells[layer]
+        ndir, h = len(cells), spec.size
+        width = ndir * h
+        out = tape.new((bsz * slen, width))
+        final = tape.new((bsz, width))
+        for d, cell in enumerate(cells):
+            reverse = spec.direction == "backward" or (spec.direction == "bidirectional" and d == 1)
+            d_in = x.shape[1]
+            if reverse:
+                src = F.reverse_sequence(tape, tape.view(x, lambda t: t.view(bsz, slen, d_in)), lengths)
+                src = tape.view(src, lambda t: t.view(bsz * slen, d_in))
+                dst = tape.new((bsz * slen, h))
+                lo = 0
+            else:
+                src, dst, lo = x, out, d * h
+            state = tuple(tape.leaf(tape.buf((bsz, h), zero=True)) for _ in range(cell.state_count))
+            for t in range(slen):
+                x_t = tape.view(src, lambda v, t=t: v.view(bsz, slen, -1)[:, t])
+                y_t = tape.view(dst, lambda v, t=t: v.view(bsz, slen, -1)[:, t, lo:lo + h])
+                _, new_state = cell.step(tape, x_t, state)
+                # dynamic_rnn: beyond the sentence length the state is carried and the output is 0
+                carried = [F.rnn_select(tape, n, p, lengths, t, None) for n, p in zip(new_state[:-1], state[:-1])]
+                carried.append(F.rnn_select(tape, new_state[-1], state[-1], lengths, t, y_t))
+                state = tuple(carried)
+            if reverse:
+                back = F.reverse_sequence(tape, tape.view(dst, lambda t: t.view(bsz, slen, h)), lengths)
+                F.copy(tape, tape.view(back, lambda t: t.view(bsz * slen, h)), out=tape.cols(out, d * h, (d + 1) * h))
+            F.copy(tape, state[-1], out=tape.cols(final, d * h, (d + 1) * h))      # LSTM: .h
+        return out, final
+
+    def _general_rnn(self, ctx) -> EncoderActivations:
+        """RecurrentEncoder.rnn (recurrent.py:179-217) on the autodiff tape."""
+        train = bool(ctx.fed(self.train_mode))
+        keep = self.dropout_keep_prob
+        tape = F.Tape(ctx, (id(self), "genc"), recording=train)
+        x_raw = self.input_sequence.temporal_states(ctx)
+        lengths = self.input_sequence.lengths(ctx)
+        bsz, slen, e = x_raw.shape
+        x_in = tape.leaf(x_raw.reshape(bsz * slen, e), needs_grad=True)
+        layer_input = F.dropout(tape, x_in, keep, train, ctx.salt(self.name, "rnn_input"))
+        layer_final = tape.view(layer_input, lambda t: t.view(bsz, slen, -1)[:, slen - 1])
+        for i, spec in enumerate(self.rnn_specs):
+            if self.add_layer_norm:
+                pre = "rnn_{}_{}/LayerNorm".format(i, spec.direction)
+                layer_input = F.layer_norm(tape, layer_input, tape.param(self, pre + "/gamma"),
+                                           tape.param(self, pre + "/beta"))
+            out, fin = self._general_layer(tape, layer_input, bsz, slen, lengths, i, train)
+            out = F.dropout(tape, out, keep, train, ctx.salt(self.name, "layer_output", i))
+            fin = F.dropout(tape, fin, keep, train, ctx.salt(self.name, "layer_final", i))
+            if self.add_residual and layer_input.shape[1] == out.shape[1]:
+                layer_input = F.add(tape, layer_input, out)
+                layer_final = F.add(tape, layer_final, fin)
+            else:
+                layer_input, layer_final = out, fin
+        if self.include_final_layer_norm:
+            gamma, beta = tape.param(self, "LayerNorm/gamma"), tape.param(self, "LayerNorm/beta")
+            layer_input = F.layer_norm(tape, layer_input, gamma, beta)
+            layer_final = F.layer_norm(tape, layer_final, gamma, beta)
+        saved = {"tape": tape, "x_in": x_in, "states": layer_input, "final": layer_final,
+                 "shape": (bsz, slen, e)}
+        return EncoderActivations(layer_input.data.view(bsz, slen, -1), layer_final.data, saved)
+
+    def _general_backward(self, ctx, sv, d_states, d_final) -> None:
+        tape = sv["tape"]
+        bsz, slen, e = sv["shape"]
+        if d_states is not None:
+            sv["states"].grad = d_states.reshape(bsz * slen, -1)
+        if d_final is not None:
+            sv["final"].grad = d_final
+        tape.backward()
+        if sv["x_in"].grad is not None:
+            self.input_sequence.backward(ctx, sv["x_in"].grad.view(bsz, slen, e))
 
     @tensor
     def temporal_states(self, ctx) -> torch.Tensor:

@@ -1,0 +1,146 @@
+"""RNN cells of the general (taped) path.
+
+    GRU         tf.contrib.rnn.GRUCell via OrthoGRUCell      nn/ortho_gru_cell.py:44-53
+    NematusGRU  NematusGRUCell                               nn/ortho_gru_cell.py:57-105
+    LSTM        tf.contrib.rnn.LSTMCell (forget_bias 1.0)    encoders/recurrent.py:21, decoders/decoder.py:29
+
+Each cell declares the variables TF would create under ``<scope>/`` (names as
+in scripts/import_nematus.py:88-130) and evaluates one step as MFMA GEMMs plus
+the element-wise kernels of ``autodiff``.  The plain-GRU fast path
+(``nn/gru.py``: fused GEMM epilogues, HIP-graph loops) uses the same variables.
+"""
+from typing import List, Tuple
+
+from .. import autodiff as F
+from ..variables import constant_initializer, orthogonal_initializer, zeros_initializer
+
+RNN_CELL_TYPES = ("NematusGRU", "GRU", "LSTM")
+
+
+class Cell:
+    """One recurrent cell bound to ``part`` (the ModelPart owning the variables)."""
+    state_count = 1                  # tensors carried between steps
+
+    def __init__(self, part, scope: str, input_size: int, num_units: int):
+        self.part, self.scope, self.input_size, self.num_units = part, scope, input_size, num_units
+
+    def _n(self, suffix: str) -> str:
+        return "{}/{}".format(self.scope, suffix)
+
+    def declare_variables(self, store) -> None:
+        raise NotImplementedError
+
+    def step(self, tape: F.Tape, x: F.Var, state: Tuple[F.Var, ...]) -> Tuple[F.Var, Tuple[F.Var, ...]]:
+        """(output, new_state)."""
+        raise NotImplementedError
+
+
+class GRUCell(Cell):
+    """r,u = sigmoid([x,h].Wg + bg) ; c = tanh([x, r*h].Wc + bc) ; h' = u*h + (1-u)*c."""
+
+    def __init__(self, part, scope, input_size, num_units, cell_scope: str = "OrthoGRUCell"):
+        Cell.__init__(self, part, "{}/{}".format(scope, cell_scope) if scope else cell_scope, input_size,
+                      num_units)
+
+    def declare_variables(self, store) -> None:
+        d, h = self.input_size, self.num_units
+        self.part.declare(store, self._n("gates/kernel"), (d + h, 2 * h), orthogonal_initializer())
+        self.part.declare(store, self._n("gates/bias"), (2 * h,), constant_initializer(1.0))
+        self.part.declare(store, self._n("candidate/kernel"), (d + h, h), orthogonal_initializer())
+        self.part.declare(store, self._n("candidate/bias"), (h,), zeros_initializer())
+
+    def step(self, tape, x, state):
+        (h_prev,) = state
+        d, h = self.input_size, self.num_units
+        wg, bg = tape.param(self.part, self._n("gates/kernel")), tape.param(self.part, self._n("gates/bias"))
+        wc, bc = tape.param(self.part, self._n("candidate/kernel")), tape.param(self.part,
+                                                                                 self._n("candidate/bias"))
+        g_pre = F.linear(tape, x, tape.rows(wg, 0, d), bg)
+        F.linear(tape, h_prev, tape.rows(wg, d, d + h), out=g_pre, accumulate=True)
+        g = F.sigmoid(tape, g_pre)
+        r, u = tape.cols(g, 0, h), tape.cols(g, h, 2 * h)
+        rh = F.mul(tape, r, h_prev)
+        c_pre = F.linear(tape, x, tape.rows(wc, 0, d), bc)
+        F.linear(tape, rh, tape.rows(wc, d, d + h), out=c_pre, accumulate=True)
+        c = F.tanh(tape, c_pre)
+        h_new = F.blend(tape, u, h_prev, c)
+        return h_new, (h_new,)
+
+
+class NematusGRUCell(Cell):
+    """Reset gate applied after the state projection: c = tanh(x.Wc + r*(h.Uc + bcs) + bci)."""
+
+    def __init__(self, part, scope, input_size, num_units, use_state_bias: bool = False,
+                 use_input_bias: bool = True, cell_scope: str = "nematus_gru_cell"):
+        Cell.__init__(self, part, "{}/{}".format(scope, cell_scope) if scope else cell_scope, input_size,
+                      num_units)
+        self.use_state_bias, self.use_input_bias = use_state_bias, use_input_bias
+
+    def declare_variables(self, store) -> None:
+        d, h = self.input_size, self.num_units
+        for block, width in (("gates", 2 * h), ("candidate", h)):
+            self.part.declare(store, self._n(block + "/input_proj/kernel"), (d, width))
+            self.part.declare(store, self._n(block + "/state_proj/kernel"), (h, width), orthogonal_initializer())
+            if self.use_input_bias:
+                self.part.declare(store, self._n(block + "/input_proj/bias"), (width,), zeros_initializer())
+            if self.use_state_bias:
+                self.part.declare(store, self._n(block + "/state_proj/bias"), (width,), zeros_initializer())
+
+    def _proj(self, tape, block, which, inp, use_bias, out=None, accumulate=False):
+        w = tape.param(self.part, self._n("{}/{}_proj/kernel".format(block, which)))
+        b = tape.param(self.part, self._n("{}/{}_proj/bias".format(block, which))) if use_bias else None
+        return F.linear(tape, inp, w, b, out=out, accumulate=accumulate)
+
+    def step(self, tape, x, state):
+        (h_prev,) = state
+        h = self.num_units
+        g_pre = self._proj(tape, "gates", "state", h_prev, self.use_state_bias)
+        self._proj(tape, "gates", "input", x, self.use_input_bias, out=g_pre, accumulate=True)
+        g = F.sigmoid(tape, g_pre)
+        r, u = tape.cols(g, 0, h), tape.cols(g, h, 2 * h)
+        sc = self._proj(tape, "candidate", "state", h_prev, self.use_state_bias)
+        c_pre = F.mul(tape, sc, r)
+        self._proj(tape, "candidate", "input", x, self.use_input_bias, out=c_pre, accumulate=True)
+        c = F.tanh(tape, c_pre)
+        h_new = F.blend(tape, u, h_prev, c)
+        return h_new, (h_new,)
+
+
+class LSTMCell(Cell):
+    """z = [x,h].W + b ; i,j,f,o = split(z) ; c' = sigmoid(f+1)*c + sigmoid(i)*tanh(j) ;
+    h' = sigmoid(o)*tanh(c').  State = (c, h)."""
+    state_count = 2
+
+    def __init__(self, part, scope, input_size, num_units, cell_scope: str = "lstm_cell"):
+        Cell.__init__(self, part, "{}/{}".format(scope, cell_scope) if scope else cell_scope, input_size,
+                      num_units)
+
+    def declare_variables(self, store) -> None:
+        d, h = self.input_size, self.num_units
+        self.part.declare(store, self._n("kernel"), (d + h, 4 * h))
+        self.part.declare(store, self._n("bias"), (4 * h,), zeros_initializer())
+
+    def step(self, tape, x, state):
+        c_prev, h_prev = state
+        d, h = self.input_size, self.num_units
+        w, b = tape.param(self.part, self._n("kernel")), tape.param(self.part, self._n("bias"))
+        z = F.linear(tape, x, tape.rows(w, 0, d), b)
+        F.linear(tape, h_prev, tape.rows(w, d, d + h), out=z, accumulate=True)
+        i = F.sigmoid(tape, tape.cols(z, 0, h))
+        j = F.tanh(tape, tape.cols(z, h, 2 * h))
+        f = F.sigmoid(tape, tape.cols(z, 2 * h, 3 * h), shift=1.0)
+        o = F.sigmoid(tape, tape.cols(z, 3 * h, 4 * h))
+        c_new = F.mul(tape, f, c_prev)
+        F.add_(tape, c_new, F.mul(tape, i, j))
+        h_new = F.mul(tape, o, F.tanh(tape, c_new))
+        return h_new, (c_new, h_new)
+
+
+def make_cell(kind: str, part, scope: str, input_size: int, num_units: int, **kw) -> Cell:
+    if kind == "GRU":
+        return GRUCell(part, scope, input_size, num_units, **kw)
+    if kind == "NematusGRU":
+        return NematusGRUCell(part, scope, input_size, num_units, **kw)
+    if kind == "LSTM":
+        return LSTMCell(part, scope, input_size, num_units, **kw)
+    raise ValueError("RNN cell must be a either 'GRU', 'LSTM', or 'NematusGRU'. Not {}".format(kind))

@@ -333,13 +333,116 @@ def attn_softmax_bwd(dw, e, mask, de, bsz):
                                        rows, bsz, s), "nm_attn_softmax_bwd")
 
 
-def attn_energy_bwd(de, hf, y, v, dhf, dv_partial, dy):
+def attn_energy_bwd(de, hf, y, v, dhf, dv_partial, dy, accumulate=False):
     lib = _lib.load()
     t, b, s = de.shape
     a = hf.shape[-1]
     _lib.check(lib.nm_attn_energy_bwd(_stream(), de.data_ptr(), hf.data_ptr(), y.data_ptr(), v.data_ptr(),
-                                      dhf.data_ptr(), dv_partial.data_ptr(), dy.data_ptr(), t, b, s, a),
-               "nm_attn_energy_bwd")
+                                      dhf.data_ptr(), dv_partial.data_ptr(), dy.data_ptr(), t, b, s, a,
+                                      int(accumulate)), "nm_attn_energy_bwd")
+
+
+# ---- strided element-wise primitives (general / taped path) -------------------------------------
+EW = {"copy": 0, "add": 1, "sub": 2, "mul": 3, "scale": 4, "sigmoid": 5, "tanh": 6, "relu": 7,
+      "sigmoid_bwd": 8, "tanh_bwd": 9, "relu_bwd": 10}
+
+
+def _rc(t):
+    """(rows, cols, ld) of a 1-D / 2-D / contiguous n-D float tensor with unit inner stride."""
+    _f32(t)
+    if t.dim() == 2:
+        assert t.stride(1) == 1 or t.shape[1] == 1
+        return t.shape[0], t.shape[1], t.stride(0)
+    assert t.is_contiguous(), "n-D operands of element-wise kernels must be contiguous"
+    return 1, t.numel(), t.numel()
+
+
+def ew(op, a, b, out, alpha=0.0, accumulate=False):
+    """out (+)= op(a, b) element-wise; 2-D operands may be column slices (row stride = ld)."""
+    lib = _lib.load()
+    rows, cols, lda = _rc(a)
+    ro, co, ldo = _rc(out)
+    assert (rows, cols) == (ro, co), (a.shape, out.shape)
+    ldb = 0
+    if b is not None:
+        rb, cb, ldb = _rc(b)
+        assert (rb, cb) == (rows, cols), (a.shape, b.shape)
+    _lib.check(lib.nm_ew(_stream(), EW[op], a.data_ptr(), lda, _p(b), ldb, out.data_ptr(), ldo, rows, cols,
+                         float(alpha), int(accumulate)), "nm_ew")
+    return out
+
+
+def blend_fwd(u, h, c, out):
+    lib = _lib.load()
+    rows, cols, ldu = _rc(u)
+    _lib.check(lib.nm_blend_fwd(_stream(), u.data_ptr(), ldu, h.data_ptr(), _rc(h)[2], c.data_ptr(), _rc(c)[2],
+                                out.data_ptr(), _rc(out)[2], rows, cols), "nm_blend_fwd")
+    return out
+
+
+def blend_bwd(dy, u, h, c, du, dh, dc):
+    lib = _lib.load()
+    rows, cols, ldu = _rc(u)
+    ld = lambda t: 0 if t is None else _rc(t)[2]
+    _lib.check(lib.nm_blend_bwd(_stream(), dy.data_ptr(), _rc(dy)[2], u.data_ptr(), ldu, h.data_ptr(), ld(h),
+                                c.data_ptr(), ld(c), _p(du), ld(du), _p(dh), ld(dh), _p(dc), ld(dc), rows, cols),
+               "nm_blend_bwd")
+
+
+def dropout_salt(*parts) -> int:
+    """32-bit salt of a dropout call site: crc32 of the "/"-joined parts (restated by the CPU checker in tests)."""
+    import zlib
+    return zlib.crc32("/".join(str(p) for p in parts).encode()) & 0xFFFFFFFF
+
+
+def dropout(x, out, keep_prob, salt, accumulate=False):
+    lib = _lib.load()
+    rows, cols, ldx = _rc(x)
+    _lib.check(lib.nm_dropout(_stream(), x.data_ptr(), ldx, out.data_ptr(), _rc(out)[2], rows, cols,
+                              float(keep_prob), int(salt) & 0xFFFFFFFF, int(accumulate)), "nm_dropout")
+    return out
+
+
+def rnn_select_fwd(h_new, h_prev, lengths, t, h_out, y_out):
+    lib = _lib.load()
+    rows, cols, ldn = _rc(h_new)
+    _lib.check(lib.nm_rnn_select_fwd(_stream(), h_new.data_ptr(), ldn, h_prev.data_ptr(), _rc(h_prev)[2],
+                                     _p(lengths), t, h_out.data_ptr(), _rc(h_out)[2], _p(y_out),
+                                     0 if y_out is None else _rc(y_out)[2], rows, cols), "nm_rnn_select_fwd")
+
+
+def rnn_select_bwd(dh, dy, lengths, t, d_new, d_prev):
+    lib = _lib.load()
+    rows, cols, ldn = _rc(d_new)
+    ld = lambda x: 0 if x is None else _rc(x)[2]
+    _lib.check(lib.nm_rnn_select_bwd(_stream(), _p(dh), ld(dh), _p(dy), ld(dy), _p(lengths), t, d_new.data_ptr(),
+                                     ldn, _p(d_prev), ld(d_prev), rows, cols), "nm_rnn_select_bwd")
+
+
+def reverse_sequence(x, out, lengths, accumulate=False):
+    lib = _lib.load()
+    b, s, d = x.shape
+    assert x.is_contiguous() and out.is_contiguous() and out.shape == x.shape
+    _lib.check(lib.nm_reverse_sequence(_stream(), x.data_ptr(), out.data_ptr(), _i32(lengths).data_ptr(), b, s, d,
+                                       int(accumulate)), "nm_reverse_sequence")
+    return out
+
+
+def maxout_fwd(x, out, argmax, pool=2):
+    lib = _lib.load()
+    rows, cols, ldx = _rc(x)
+    groups = cols // pool
+    assert groups * pool == cols and out.shape[1] == groups
+    _lib.check(lib.nm_maxout_fwd(_stream(), x.data_ptr(), ldx, out.data_ptr(), _rc(out)[2], _p(argmax), rows,
+                                 groups, pool), "nm_maxout_fwd")
+    return out
+
+
+def maxout_bwd(dy, argmax, dx, pool=2):
+    lib = _lib.load()
+    rows, groups, lddy = _rc(dy)
+    _lib.check(lib.nm_maxout_bwd(_stream(), dy.data_ptr(), lddy, argmax.data_ptr(), dx.data_ptr(), _rc(dx)[2],
+                                 rows, groups, pool), "nm_maxout_bwd")
 
 
 def gru_gemm(mode, a, b, trans_b, t, ndir, rows, hsz, lengths=None, reverse_dir0=False, xp=None,

@@ -97,6 +97,13 @@ class RunContext:
         """Persistent scratch buffer owned by the session (no per-step malloc)."""
         return self.session.buffer(key, shape, dtype, zero)
 
+    def salt(self, *site) -> int:
+        """32-bit salt of a dropout call site in this run: crc32 of the site path, advanced by
+        the global step so that every training step draws fresh masks (nm_dropout)."""
+        import zlib
+        base = zlib.crc32("/".join(str(s) for s in site).encode()) & 0xFFFFFFFF
+        return (base + self.session.global_step * 0x9E3779B9) & 0xFFFFFFFF
+
 
 def _to_host(val):
     if isinstance(val, torch.Tensor):

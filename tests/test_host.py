@@ -163,10 +163,18 @@ def test_unsupported_features_refuse_loudly():
     from neuralmonkey_amd.runtime import reset_registry
     reset_registry()
     vocab = V.Vocabulary(["a"])
+    from neuralmonkey_amd.decoders.encoder_projection import nematus_projection
     with pytest.raises(NotImplementedError):
         Decoder(encoders=[], vocabulary=vocab, data_id="t", name="d", max_output_len=5, embedding_size=4,
-                rnn_size=4, rnn_cell="LSTM")
+                rnn_size=4, label_smoothing=0.1)
     with pytest.raises(NotImplementedError):
+        nematus_projection()
+    # cells / conditional GRU / attention on input are served by the general (taped) path
+    for i, kw in enumerate((dict(rnn_cell="LSTM"), dict(rnn_cell="NematusGRU"), dict(attention_on_input=True))):
+        dec = Decoder(encoders=[], vocabulary=vocab, data_id="t", name="dg{}".format(i), max_output_len=5,
+                      embedding_size=4, rnn_size=4, **kw)
+        assert dec.uses_general_path(False)
+    with pytest.raises(ValueError):          # a conditional GRU conditions on attention contexts
         Decoder(encoders=[], vocabulary=vocab, data_id="t", name="d2", max_output_len=5, embedding_size=4,
                 rnn_size=4, conditional_gru=True)
 

@@ -199,6 +199,8 @@ def test_gru_bidirectional_encoder(dev):
     (5, 1, 64, 128, 2048, False),        # captioning shape: S=64, C=2048, state_size 128
     (2, 8, 13, 512, 1024, True),
     (2, 2, 100, 256, 512, True),
+    (3, 2, 9, 10, 14, True),             # tests/small.ini-like: C = 2*7, no dim a multiple of 4
+    (2, 1, 300, 6, 7, True),             # any-shape kernel, long S
 ])
 def test_attention_fwd(dev, bk, qpk, s, a, c, ragged):
     from neuralmonkey_amd import ops
@@ -228,6 +230,54 @@ def test_attention_fwd(dev, bk, qpk, s, a, c, ragged):
     assert rel_err(w.cpu().numpy(), ref_w) < RTOL
     assert rel_err(ctx.cpu().numpy(), ref_ctx) < RTOL
     assert np.all(w.cpu().numpy()[np.repeat(mask, qpk, 0) == 0] == 0)
+
+
+@pytest.mark.parametrize("t,b,s,a,c", [
+    (50, 16, 50, 1024, 1024),            # teacher-forced training shape (fewer sentences)
+    (7, 3, 13, 64, 32),                  # one query group, single chunk
+    (11, 5, 100, 256, 512),              # query groups of 8 + a ragged tail of 3
+    (1, 4, 20, 128, 128),
+])
+def test_attention_time_major_all_steps(dev, t, b, s, a, c):
+    """nm_attn_fwd_multi, time-major layout: all T teacher-forced queries of a sentence in
+    one launch must equal T independent attention steps (attention/feed_forward.py:66-104)."""
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(t * 1000 + b * 10 + s)
+    q = rng.standard_normal((t, b, 48)).astype(np.float32)
+    states = rng.standard_normal((b, s, c)).astype(np.float32)
+    wk = (rng.standard_normal((c, a)) * 0.05).astype(np.float32)
+    ap = {"query_w": (rng.standard_normal((48, a)) * 0.2).astype(np.float32),
+          "query_b": (rng.standard_normal(a) * 0.1).astype(np.float32),
+          "v": rng.standard_normal(a).astype(np.float32) * 0.3,
+          "bias": np.float32(-0.21)}
+    mask = np.ones((b, s), np.float32)
+    for i in range(b):
+        mask[i, rng.integers(1, s + 1):] = 0
+    hf = O.attention_keys(states, wk)
+    f64 = lambda x: np.asarray(x, dtype=np.float64)
+    ap64 = {k: f64(v) for k, v in ap.items()}
+    ref = [O.attention_step(f64(q[i]), f64(hf), f64(states), f64(mask), ap64) for i in range(t)]
+    ref_ctx = np.stack([r[0] for r in ref])
+    ref_w = np.stack([r[1] for r in ref])
+    y_all = ops.gemm(T(q.reshape(t * b, 48), dev), T(ap["query_w"], dev),
+                     bias=T(ap["query_b"], dev)).view(t, b, a)
+    ctx = torch.empty((t, b, c), device=dev)
+    w = torch.empty((t, b, s), device=dev)
+    e = torch.empty((t, b, s), device=dev)
+    ops.attn_fwd_time_major(y_all, T(hf, dev), T(states, dev), T(mask, dev), T(ap["v"], dev),
+                            T(np.array([ap["bias"]]), dev), ctx, w, ops.attn_workspace(t * b, s, c, dev), e)
+    assert rel_err(w.cpu().numpy(), ref_w) < RTOL
+    assert rel_err(ctx.cpu().numpy(), ref_ctx) < RTOL
+    assert np.all(w.cpu().numpy()[:, mask == 0] == 0)
+    # the same numbers as T single-step launches of the decoding kernel
+    ctx1 = torch.empty((b, c), device=dev)
+    w1 = torch.empty((b, s), device=dev)
+    ws1 = ops.attn_workspace(b, s, c, dev)
+    for i in (0, t - 1):
+        ops.attn_fwd(y_all[i], T(hf, dev), T(states, dev), T(mask, dev), T(ap["v"], dev),
+                     T(np.array([ap["bias"]]), dev), 1, ctx1, w1, ws1)
+        assert rel_err(w1.cpu().numpy(), w[i].cpu().numpy()) < 1e-5
+        assert rel_err(ctx1.cpu().numpy(), ctx[i].cpu().numpy()) < 1e-5
 
 
 def test_attention_all_masked_row(dev):
