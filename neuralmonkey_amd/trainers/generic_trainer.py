@@ -88,14 +88,13 @@ class GenericTrainer(GraphExecutor, Feedable):
         return self._tables[key]
 
     # -- the training step --------------------------------------------------------------------
-    @tensor
-    def train_op(self, ctx) -> int:
+    def _objective_gradients(self, ctx) -> None:
+        """Forward + backward of every objective into the (zeroed) flat gradient buffer."""
         from .. import distributed as dist
         sess, store = ctx.session, ctx.store
         grad = store.ensure_grad()
         grad.zero_()
         dp = dist.current()
-        results = []
         for obj in self.objectives:
             dec = obj.decoder
             weight = 1.0 if obj.weight is None else float(obj.weight)
@@ -108,8 +107,14 @@ class GenericTrainer(GraphExecutor, Feedable):
             res = dec._train_loop(ctx, want_grad=True, grad_scale=scale)     # pylint: disable=protected-access
             ctx.memo[dec.train_loop_result.key] = res
             dec.backward(ctx, res)
-            results.append(res)
         sess.join_side()
+
+    def _apply_gradients(self, ctx) -> int:
+        """[all-reduce] -> L1/L2 terms -> per-tensor clip_by_norm -> Adam -> global_step += 1."""
+        from .. import distributed as dist
+        sess, store = ctx.session, ctx.store
+        grad = store.ensure_grad()
+        dp = dist.current()
         if dp is not None:
             dp.all_reduce_gradients(store)
         tables = self._optim_tables(store)
@@ -121,6 +126,11 @@ class GenericTrainer(GraphExecutor, Feedable):
         tables.clip_adam(store.theta, grad, m, v, self.clip_norm, opt.lr_t(sess.global_step), opt.beta1,
                          opt.beta2, opt.epsilon)
         return sess.global_step
+
+    @tensor
+    def train_op(self, ctx) -> int:
+        self._objective_gradients(ctx)
+        return self._apply_gradients(ctx)
 
     @tensor
     def regularization_losses(self, ctx):

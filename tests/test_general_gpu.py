@@ -227,3 +227,109 @@ def test_elementwise_primitives(dev):
     want[0] = seq[0].cpu().flip(0)
     want[1, :2] = seq[1, :2].cpu().flip(0)
     assert torch.equal(rev.cpu(), want)
+
+
+SMALL_INI = """
+; model sections of the reference's tests/small.ini (NematusGRU encoder/decoder, conditional GRU,
+; dropout 0.5); data, evaluation and logging sections belong to the control plane
+[vars]
+drop_keep_p=0.5
+[main]
+name="small.ini shape"
+batch_size=4
+epochs=1
+train_dataset=<train_data>
+trainer=<trainer>
+runners=[<runner>]
+[batching]
+class=dataset.BatchingScheme
+batch_size=4
+[train_data]
+class=dataset.load
+series=["source", "target"]
+data=["{src}", "{tgt}"]
+batching=<batching>
+[encoder_vocabulary]
+class=vocabulary.from_wordlist
+path="{vocab}"
+[decoder_vocabulary]
+class=vocabulary.from_wordlist
+path="{vocab}"
+[my_encoder]
+class=encoders.SentenceEncoder
+rnn_size=7
+max_input_len=5
+embedding_size=11
+dropout_keep_prob=$drop_keep_p
+data_id="source"
+vocabulary=<encoder_vocabulary>
+rnn_cell="NematusGRU"
+embedding_initializer=<embedding_initializer>
+[embedding_initializer]
+class=tf.random_uniform_initializer
+minval=-0.5
+maxval=0.5
+[my_attention]
+class=attention.Attention
+encoder=<my_encoder>
+initializers=[("Attention/attn_query_projection", <query_projection_initializer>)]
+[query_projection_initializer]
+class=tf.random_normal_initializer
+stddev=0.001
+[my_decoder]
+class=decoders.Decoder
+conditional_gru=True
+encoders=[<my_encoder>]
+attentions=[<my_attention>]
+rnn_size=9
+embedding_size=9
+dropout_keep_prob=$drop_keep_p
+data_id="target"
+max_output_len=5
+vocabulary=<decoder_vocabulary>
+attention_on_input=False
+rnn_cell="NematusGRU"
+[optimizer]
+class=tf.train.AdamOptimizer
+learning_rate=0.01
+[trainer]
+class=trainers.CrossEntropyTrainer
+decoders=[<my_decoder>]
+l2_weight=1.0e-8
+clip_norm=1.0
+optimizer=<optimizer>
+[runner]
+class=runners.GreedyRunner
+decoder=<my_decoder>
+output_series="target"
+"""
+
+
+def test_small_ini_shape_experiment(dev, tmp_path):
+    """BASELINE configs[0]: the model of tests/small.ini builds from INI text through the plugin
+    surface, trains with dropout (falling loss) and decodes."""
+    from neuralmonkey_amd.config.configuration import load_experiment
+    (tmp_path / "src.txt").write_text("a b c\nb c\nc a a b\na\n")
+    (tmp_path / "tgt.txt").write_text("x y\ny\nx x y\ny y\n")
+    (tmp_path / "vocab.tsv").write_text("Word\tCount\n<pad>\t1\n<s>\t1\n</s>\t1\n<unk>\t1\n"
+                                        "a\t9\nb\t8\nc\t7\nx\t6\ny\t5\n")
+    path = tmp_path / "small.ini"
+    path.write_text(SMALL_INI.format(src=tmp_path / "src.txt", tgt=tmp_path / "tgt.txt",
+                                     vocab=tmp_path / "vocab.tsv"))
+    model = load_experiment(str(path), device=str(dev), seed=4321)
+    dec = model.trainers[0].objectives[0].decoder
+    assert dec.uses_general_path(True) and dec.uses_general_path(False)
+    store = model.tf_manager.sessions[0].store
+    for name in ("my_encoder/rnn_0_bidirectional/bidirectional_rnn/fw/nematus_gru_cell/gates/state_proj/kernel",
+                 "my_decoder/attention_decoder/nematus_gru_cell/candidate/input_proj/bias",
+                 "my_decoder/attention_decoder/cond_gru_2_cell/gates/state_proj/bias",
+                 "my_decoder/attention_decoder/cond_gru_2_cell/candidate/input_proj/kernel"):
+        assert name in store, name
+    assert "my_decoder/attention_decoder/cond_gru_2_cell/gates/input_proj/bias" not in store
+    batch = next(model.train_dataset.batches())
+    feedables = set.union(*[r.feedables for r in model.runners + model.trainers])
+    losses = [model.tf_manager.execute(batch, feedables, model.trainers, train=True)[0].losses["my_decoder - cost"]
+              for _ in range(60)]
+    assert np.mean(losses[-10:]) < np.mean(losses[:10]) - 0.05, (losses[:3], losses[-3:])
+    out = model.tf_manager.execute(batch, feedables, model.runners)[0]
+    assert len(out.outputs["target"]) == 4

@@ -107,3 +107,33 @@ def test_training_then_greedy_share_one_run(dev):
                                    [model.trainer, model.greedy_runner], train=True)
     assert out[0].losses["decoder - cost"] > 0
     assert len(out[1].outputs["target"]) == 5
+
+
+def test_delayed_update_trainer_accumulates_and_averages(dev):
+    """DelayedUpdateTrainer (trainers/delayed_update_trainer.py:142-204): no update before the
+    N-th batch; the N-th applies the mean gradient.  Feeding one batch N times must therefore
+    land on exactly the parameters of one ordinary step on that batch."""
+    from neuralmonkey_amd.trainers import DelayedUpdateTrainer
+    from neuralmonkey_amd.trainers.objective import CostObjective
+    model, params, ds, src, tgt = _build(dev, 64, 12, 12, 5, 7, 6, True, l2=1e-3, clip=0.5)
+    tfm = model.tf_manager
+    store = tfm.sessions[0].store
+    tfm.execute(ds, model.trainer.feedables, [model.trainer], train=True)
+    want = {n: store[n].cpu().numpy().copy() for n in store.names()}
+
+    store.load_state_dict(params)
+    m, v = store.ensure_adam()
+    m.zero_(), v.zero_()
+    tfm.sessions[0].global_step = 0
+    delayed = DelayedUpdateTrainer(batches_per_update=3, objectives=[CostObjective(model.decoder)],
+                                   l2_weight=1e-3, clip_norm=0.5)
+    for i in range(3):
+        res = tfm.execute(ds, delayed.feedables, [delayed], train=True)[0]
+        assert set(res.losses) == {"decoder - cost", "L1", "L2"}
+        if i < 2:       # accumulating: parameters and global step untouched
+            assert tfm.sessions[0].global_step == 0
+            assert all(np.array_equal(store[n].cpu().numpy().reshape(-1),
+                                      np.asarray(params[n], np.float32).reshape(-1)) for n in store.names())
+    assert tfm.sessions[0].global_step == 1
+    for n in store.names():
+        assert np.abs(store[n].cpu().numpy() - want[n]).max() <= 2e-7 + 1e-5 * np.abs(want[n]).max(), n
