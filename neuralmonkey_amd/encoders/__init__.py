@@ -1,1 +1,2 @@
 from .recurrent import RecurrentEncoder, SentenceEncoder   # noqa: F401
+from .numpy_stateful_filler import SpatialFiller          # noqa: F401

@@ -1,0 +1,128 @@
+"""Pre-computed feature maps as encoders (mirror of neuralmonkey/encoders/numpy_stateful_filler.py).
+
+``SpatialFiller`` (:155-245) feeds [B,H,W,D] convolutional maps (the captioning configuration:
+8x8x2048 ResNet maps, BASELINE configs[3]) to the same Bahdanau attention kernels as a sentence
+encoder; the optional 1x1 convolutions are MFMA GEMMs over the B*H*W positions.  ``output`` is
+the mean over positions (:209-212), computed as a batched [1,S]x[S,D] GEMM.
+"""
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+from .. import autodiff as F
+from .. import ops
+from ..model.model_part import FeedDict, InitializerSpecs, ModelPart
+from ..model.stateful import SpatialStatefulWithOutput, Stateful
+from ..runtime import Placeholder, tensor
+from ..variables import glorot_uniform_initializer, zeros_initializer
+
+
+class SpatialFiller(ModelPart, SpatialStatefulWithOutput):
+    # pylint: disable=too-many-arguments
+    def __init__(self, name: str, input_shape: List[int], data_id: str, projection_dim: int = None,
+                 ff_hidden_dim: int = None, reuse: ModelPart = None, save_checkpoint: str = None,
+                 load_checkpoint: str = None, initializers: InitializerSpecs = None) -> None:
+        ModelPart.__init__(self, name, reuse, save_checkpoint, load_checkpoint, initializers)
+        self.data_id = data_id
+        self.input_shape = list(input_shape)
+        self.projection_dim = projection_dim
+        self.ff_hidden_dim = ff_hidden_dim
+        if self.ff_hidden_dim is not None and self.projection_dim is None:
+            raise ValueError("projection_dim must be provided when using ff_hidden_dim")
+        if len(self.input_shape) != 3:
+            raise ValueError("The input shape should have 3 dimensions.")
+        self.spatial_input = Placeholder("{}/spatial_input".format(name))
+
+    @property
+    def input_types(self) -> Dict[str, type]:
+        return {self.data_id: np.float32}
+
+    @property
+    def input_shapes(self) -> Dict[str, List]:
+        return {self.data_id: [None] + self.input_shape}
+
+    @property
+    def dimension(self) -> int:
+        return self.projection_dim if self.projection_dim else self.input_shape[2]
+
+    @property
+    def output_size(self) -> int:
+        return self.dimension
+
+    def _layers(self):
+        """[(variable scope, in, out, relu)] of the 1x1 convolutions (tf.layers.conv2d default names)."""
+        layers, d = [], self.input_shape[2]
+        if self.ff_hidden_dim:
+            layers.append(("conv2d", d, self.ff_hidden_dim, True))
+            d = self.ff_hidden_dim
+        if self.projection_dim:
+            layers.append(("conv2d_1" if layers else "conv2d", d, self.projection_dim, False))
+        return layers
+
+    def declare_variables(self, store) -> None:
+        for scope, d_in, d_out, _ in self._layers():
+            # tf.layers.conv2d kernel [1,1,in,out] stored as the [in,out] matrix it is
+            self.declare(store, scope + "/kernel", (d_in, d_out), glorot_uniform_initializer())
+            self.declare(store, scope + "/bias", (d_out,), zeros_initializer())
+
+    def feed_dict(self, dataset, train: bool = False) -> FeedDict:
+        fd = ModelPart.feed_dict(self, dataset, train)
+        fd[self.spatial_input] = np.stack([np.asarray(x, np.float32) for x in dataset.get_series(self.data_id)])
+        return fd
+
+    @tensor
+    def _activations(self, ctx):
+        maps = ctx.fed(self.spatial_input)
+        if tuple(maps.shape[1:]) != tuple(self.input_shape):
+            raise ValueError("SpatialFiller '{}': fed maps of shape {}, expected {}"
+                             .format(self.name, tuple(maps.shape[1:]), tuple(self.input_shape)))
+        x = ctx.session.to_device(maps, torch.float32, "spatial_input")
+        bsz, h, w, d = x.shape
+        s = h * w
+        train = bool(ctx.fed(self.train_mode))
+        tape = F.Tape(ctx, (id(self), "filler"), recording=train and bool(self._layers()))
+        cur = tape.leaf(x.reshape(bsz * s, d))
+        for scope, _, _, use_relu in self._layers():
+            cur = F.linear(tape, cur, tape.param(self, scope + "/kernel"), tape.param(self, scope + "/bias"))
+            if use_relu:
+                cur = F.relu(tape, cur)
+        dim = cur.shape[1]
+        states = cur.data.view(bsz, h, w, dim)
+        # average_image: mean over the S positions as ones[1,S]/S . states[b]
+        avg_w = ctx.buffer((id(self), "avg_w", s), (1, s))
+        avg_w.fill_(1.0 / s)
+        out = ctx.buffer((id(self), "output", bsz), (bsz, 1, dim))
+        ops.gemm(avg_w.expand(bsz, 1, s), cur.data.view(bsz, s, dim), out=out)
+        return {"tape": tape, "states_var": cur, "states": states, "output": out.view(bsz, dim), "avg_w": avg_w,
+                "shape": (bsz, s, dim)}
+
+    @tensor
+    def spatial_states(self, ctx) -> torch.Tensor:
+        return self._activations(ctx)["states"]
+
+    @tensor
+    def spatial_mask(self, ctx) -> torch.Tensor:
+        st = self._activations(ctx)["states"]
+        mask = ctx.buffer((id(self), "mask", tuple(st.shape[:3])), tuple(st.shape[:3]))
+        mask.fill_(1.0)
+        return mask
+
+    @tensor
+    def output(self, ctx) -> torch.Tensor:
+        return self._activations(ctx)["output"]
+
+    def backward(self, ctx, d_states, d_final) -> None:
+        """dL/d(spatial_states) [B,S,D] (from the attention) and dL/d(output) [B,D]."""
+        act = self._activations(ctx)
+        tape, var = act["tape"], act["states_var"]
+        if not tape.recording:
+            return                                   # raw maps: nothing trainable upstream
+        bsz, s, dim = act["shape"]
+        g = tape.grad(var).view(bsz, s, dim)
+        if d_states is not None:
+            ops.ew("copy", d_states.reshape(bsz * s, dim), None, g.view(bsz * s, dim), accumulate=True)
+        if d_final is not None:                      # d mean: every position receives d_final / S
+            ops.gemm(act["avg_w"].expand(bsz, 1, s), d_final.reshape(bsz, 1, dim), out=g, trans_a=True,
+                     accumulate=True)
+        tape.backward()

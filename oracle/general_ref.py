@@ -64,6 +64,7 @@ class Config(NamedTuple):
     tie_embeddings: bool = False
     supress_unk: bool = False
     rnn_size: int = 4
+    spatial: Optional[Tuple] = None                         # (ff_hidden_dim, projection_dim): SpatialFiller encoder
 
 
 def _act(name):
@@ -152,8 +153,30 @@ class GeneralModel:
         return torch.stack(outs, 1), state[-1]
 
     # -- encoder (encoders/recurrent.py:71-110, 179-217) ---------------------------------------
+    def encode_spatial(self, maps: np.ndarray):
+        """SpatialFiller (encoders/numpy_stateful_filler.py:155-245): optional 1x1 convolutions,
+        states flattened to [B, H*W, D] with an all-ones mask (attention/base_attention.py:79-122),
+        output = mean over positions."""
+        cfg, p = self.cfg, self.p
+        x = torch.as_tensor(np.asarray(maps), dtype=self.dtype)
+        bsz, h, w, _ = x.shape
+        x = x.reshape(bsz, h * w, -1)
+        ff_dim, proj_dim = cfg.spatial
+        scopes = []
+        if ff_dim:
+            scopes.append(("conv2d", True))
+        if proj_dim:
+            scopes.append(("conv2d_1" if scopes else "conv2d", False))
+        for scope, use_relu in scopes:
+            x = x @ p["{}/{}/kernel".format(cfg.enc_name, scope)] + p["{}/{}/bias".format(cfg.enc_name, scope)]
+            if use_relu:
+                x = torch.relu(x)
+        return x, torch.ones(bsz, h * w, dtype=self.dtype), x.mean(1)
+
     def encode(self, src_ids: np.ndarray, train: bool):
         cfg, p = self.cfg, self.p
+        if cfg.spatial is not None:
+            return self.encode_spatial(src_ids)
         name = cfg.enc_name
         ids = torch.as_tensor(src_ids.astype(np.int64))
         mask = (ids != PAD).to(self.dtype)
