@@ -194,6 +194,34 @@ int nm_maxout_fwd(void* stream, const float* x, int64_t ldx, float* out, int64_t
 int nm_maxout_bwd(void* stream, const float* dy, int64_t lddy, const int32_t* argmax, float* dx,
                   int64_t lddx, int64_t rows, int64_t groups, int64_t pool);
 
+/* ---- Transformer blocks: attention/scaled_dot_product.py:98-226, encoders/transformer.py,
+ * decoders/transformer.py ------------------------------------------------------------------------
+ * Multi-head scaled dot-product attention over [B, T, H*dh] tensors (heads = column blocks):
+ * energies = (q/sqrt(dh)).k^T, optional future mask (where(tril, e, -1e9)), optional key mask
+ * (e*m + (1-m)*-1e9), softmax, dropout on the weights (counter-based mask over the flattened
+ * [Bq,H,Tq,Tk] tensor), context = w.v.  *_bs are batch strides in floats; query row r reads key
+ * batch r / rows_per_key (a beam shares its encoder keys; Tq = 1 against a key/value cache is a
+ * decoding step).  `weights` [Bq,H,Tq,Tk] receives the softmax output (needed by the backward). */
+int nm_sdp_attn_fwd(void* stream, const float* q, int64_t q_bs, const float* k, int64_t k_bs,
+                    const float* v, int64_t v_bs, const float* key_mask, int64_t mask_bs, int64_t Bq,
+                    int64_t rows_per_key, int64_t Tq, int64_t Tk, int64_t H, int64_t dh, int causal,
+                    float keep_prob, uint32_t salt, float* ctx, int64_t ctx_bs, float* weights);
+int nm_sdp_attn_bwd(void* stream, const float* q, int64_t q_bs, const float* k, int64_t k_bs,
+                    const float* v, int64_t v_bs, const float* key_mask, int64_t mask_bs,
+                    const float* weights, const float* dctx, int64_t dctx_bs, int64_t B, int64_t Tq,
+                    int64_t Tk, int64_t H, int64_t dh, int causal, float keep_prob, uint32_t salt,
+                    float* dq, int64_t dq_bs, float* dk, int64_t dk_bs, float* dv, int64_t dv_bs,
+                    float* de_workspace /* [B,H,Tq,Tk] */, int accumulate);
+/* out[b,t,:] = x[b,t,:] + signal[t0+t,:]  (position_signal, encoders/transformer.py:23-45) */
+int nm_add_position(void* stream, const float* x, const float* signal, float* out, int64_t B, int64_t T,
+                    int64_t D, int64_t t0);
+/* out[r*ld_out] = finished[r] ? 0 : 1: the key-mask column of a new decoding position
+ * (decoders/transformer.py:493-497) */
+int nm_unfinished_mask(void* stream, const int32_t* finished, float* out, int64_t ld_out, int64_t n);
+/* TransformerEncoder.output = sum over time (encoders/transformer.py:170-172) and its gradient */
+int nm_time_sum(void* stream, const float* x, float* out, int64_t B, int64_t T, int64_t D);
+int nm_time_bcast_add(void* stream, const float* dy, float* dx, int64_t B, int64_t T, int64_t D);
+
 /* ---- trainer arithmetic over the flat parameter buffer: trainers/generic_trainer.py:84-195
  * (L1/L2 over non-bias variables, per-tensor tf.clip_by_norm, tf.train.AdamOptimizer) ----------- */
 int64_t nm_optim_workspace_bytes(int64_t nchunk, int64_t nseg);

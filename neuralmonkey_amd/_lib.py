@@ -63,6 +63,13 @@ SIGNATURES = {
     "nm_reverse_sequence": (I, [P, P, P, P, L, L, L, I]),
     "nm_maxout_fwd": (I, [P, P, L, P, L, P, L, L, L]),
     "nm_maxout_bwd": (I, [P, P, L, P, P, L, L, L, L]),
+    "nm_sdp_attn_fwd": (I, [P, P, L, P, L, P, L, P, L, L, L, L, L, L, L, I, F, ctypes.c_uint32, P, L, P]),
+    "nm_sdp_attn_bwd": (I, [P, P, L, P, L, P, L, P, L, P, P, L, L, L, L, L, L, I, F, ctypes.c_uint32,
+                            P, L, P, L, P, L, P, I]),
+    "nm_add_position": (I, [P, P, P, P, L, L, L, L]),
+    "nm_unfinished_mask": (I, [P, P, P, L, L]),
+    "nm_time_sum": (I, [P, P, P, L, L, L]),
+    "nm_time_bcast_add": (I, [P, P, P, L, L, L]),
     "nm_optim_workspace_bytes": (L, [L, L]),
     "nm_optim_regularize_norms": (I, [P, P, P, P, P, P, P, P, P, L, L, F, F, P, P, L]),
     "nm_optim_clip_adam": (I, [P, P, P, P, P, P, P, P, P, P, P, L, L, F, F, F, F, F, P, L]),

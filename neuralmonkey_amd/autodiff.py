@@ -353,6 +353,58 @@ def maxout(tape: Tape, x: Var, pool: int = 2) -> Var:
     return out
 
 
+def sdp_attention(tape: Tape, q: Var, k: Var, v: Var, key_mask: Optional[torch.Tensor], heads: int, bq: int,
+                  tq: int, bk: int, tk: int, causal: bool = False, keep_prob: float = 1.0, salt: int = 0,
+                  k_data: Optional[torch.Tensor] = None, v_data: Optional[torch.Tensor] = None) -> Var:
+    """Multi-head scaled dot-product attention (attention/scaled_dot_product.py:98-226) on
+    [B*T, D] rows.  ``k_data`` / ``v_data`` override the key / value storage (a [R,Tmax,D] cache
+    view during decoding); gradients are defined for bq == bk."""
+    d = q.shape[1]
+    out = tape.new((bq * tq, d))
+    w = tape.buf((bq, heads, tq, tk)) if tape.recording else None
+    k3 = k_data if k_data is not None else k.data.view(bk, tk, d)
+    v3 = v_data if v_data is not None else v.data.view(bk, tk, d)
+    ops.sdp_attn_fwd(q.data.view(bq, tq, d), k3, v3, key_mask, heads, out.data.view(bq, tq, d), w, causal,
+                     bq // bk, keep_prob, salt)
+
+    def bwd():
+        if out.grad is None:
+            return
+        assert bq == bk and k_data is None and v_data is None
+        de = tape.buf((bq, heads, tq, tk))
+        ops.sdp_attn_bwd(q.data.view(bq, tq, d), k3, v3, key_mask, w, out.grad.view(bq, tq, d), heads,
+                         tape.grad(q).view(bq, tq, d), tape.grad(k).view(bk, tk, d), tape.grad(v).view(bk, tk, d),
+                         de, causal, keep_prob, salt, accumulate=True)
+    tape.record(bwd)
+    return out
+
+
+def add_position(tape: Tape, x: Var, signal: torch.Tensor, bsz: int, steps: int, t0: int = 0) -> Var:
+    """x [B*T, D] + position_signal[t0:t0+T] (encoders/transformer.py:23-45, 187-189)."""
+    d = x.shape[1]
+    out = tape.new((bsz * steps, d))
+    ops.add_position(x.data.view(bsz, steps, d), signal, out.data.view(bsz, steps, d), t0)
+
+    def bwd():
+        if out.grad is not None and x.needs_grad:
+            ops.ew("copy", out.grad, None, tape.grad(x), accumulate=True)
+    tape.record(bwd)
+    return out
+
+
+def time_sum(tape: Tape, x: Var, bsz: int, steps: int) -> Var:
+    """[B*T, D] -> [B, D] sum over time (encoders/transformer.py:170-172)."""
+    d = x.shape[1]
+    out = tape.new((bsz, d))
+    ops.time_sum(x.data.view(bsz, steps, d), out.data)
+
+    def bwd():
+        if out.grad is not None and x.needs_grad:
+            ops.time_bcast_add(out.grad, tape.grad(x).view(bsz, steps, d))
+    tape.record(bwd)
+    return out
+
+
 def xent(tape: Tape, logits: Var, targets: torch.Tensor, weights: torch.Tensor,
          grad_scale: Optional[torch.Tensor]) -> torch.Tensor:
     """Masked sparse softmax cross entropy per row (autoregressive.py:289-316).  When recording,

@@ -25,7 +25,6 @@ from ..runtime import Placeholder, tensor
 from ..vocabulary import END_TOKEN_INDEX, PAD_TOKEN_INDEX, START_TOKEN_INDEX, Vocabulary
 from .autoregressive import AutoregressiveDecoder, DecoderFeedables, LoopState
 from .decoder import CHECK_EVERY
-from .decoder_general import make_stepper
 
 INF = 1e9
 
@@ -70,9 +69,9 @@ class BeamSearchDecoder(ModelPart):
         if beam_size < 1 or beam_size > 8:
             raise ValueError("beam_size must be between 1 and 8 for the HIP top-k kernel, was {}"
                              .format(beam_size))
-        if not hasattr(parent_decoder, "full_step"):
-            raise NotImplementedError("BeamSearchDecoder: the HIP engine supports the RNN Decoder "
-                                      "as parent for now")
+        if not hasattr(parent_decoder, "make_stepper"):
+            raise NotImplementedError("BeamSearchDecoder: parent decoder '{}' has no stepwise inference "
+                                      "interface (make_stepper)".format(type(parent_decoder).__name__))
 
     @property
     def vocabulary(self) -> Vocabulary:
@@ -109,14 +108,13 @@ class BeamSearchDecoder(ModelPart):
         k = self.beam_size
         bsz = int(ctx.fed(dec.batch_size))
         rows = bsz * k
-        e, h, v = dec.embedding_size, dec.rnn_size, len(self.vocabulary)
+        e, v = dec.embedding_size or dec.output_dimension, len(self.vocabulary)
         max_steps = int(ctx.fed(self.max_steps))
         key = (id(self), "bs", bsz)
         f32 = lambda name, shape, **kw: ctx.buffer(key + (name,), shape, torch.float32, **kw)
         i32 = lambda name, shape, **kw: ctx.buffer(key + (name,), shape, torch.int32, **kw)
 
-        stepper = make_stepper(dec, ctx, rows, "beam")    # decoder state, ping-pong + beam gather
-        hsel = f32("hsel", (rows, h))
+        stepper = dec.make_stepper(ctx, rows, "beam", k, max_positions=max_steps + 1)
         emb = f32("emb", (rows, e))
         out_state = f32("out", (rows, dec.output_dimension))
         logits = f32("logits", (rows, v))
@@ -135,18 +133,22 @@ class BeamSearchDecoder(ModelPart):
         att_states = [a.initial_loop_state(ctx, rows, max_steps + 1) for a in dec.attentions]
 
         # ---- get_initial_loop_state (:218-328): tile, run the parent body once
-        ops.gather_rows(dec.initial_state(ctx), self.expand_index(ctx, bsz), hsel)
+        if hasattr(dec, "initial_state"):                 # RNN decoder: tile the initial state (:575-596)
+            hsel = f32("hsel", (rows, dec.rnn_size))
+            ops.gather_rows(dec.initial_state(ctx), self.expand_index(ctx, bsz), hsel)
+            stepper.start(hsel)
+        else:
+            stepper.start()
+        fin[0].zero_()
         go = i32("go", (rows,))
         go.fill_(START_TOKEN_INDEX)
         dec.embed_input_symbols(ctx, go, out=emb)
-        stepper.start(hsel)
-        att_states = stepper.step(emb, att_states, out_state, logits)
+        att_states = stepper.step(emb, att_states, out_state, logits, finished=fin[0].view(rows))
         ops.row_stats(logits, rmax, rlse, argmax)
         tok[0, 0].copy_(argmax)                           # parent's greedy symbol, dropped by the runner
         lps[0].fill_(-INF)
         lps[0, :, 0] = 0.0
         lens[0].zero_()
-        fin[0].zero_()
         cur = 0
         steps = 0                                         # executed beam bodies
         # ---- loop (:330-355 criterion, :394-556 body)
@@ -159,7 +161,8 @@ class BeamSearchDecoder(ModelPart):
             stepper.reorder(srcf)                                                # :503-532
             ops.beam_reorder_tokens(tok[cur], srcf, wordf, tok[nxt], steps + 1, rows)   # :546-551
             dec.embed_input_symbols(ctx, wordf, out=emb)                         # :507-510
-            att_states = stepper.step(emb, att_states, out_state, logits)        # :534-535
+            att_states = stepper.step(emb, att_states, out_state, logits,
+                                      finished=fin[nxt].view(rows))              # :534-535
             ops.row_stats(logits, rmax, rlse, None)                              # :537-543
             cur = nxt
             steps += 1

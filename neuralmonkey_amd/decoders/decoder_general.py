@@ -66,6 +66,10 @@ class GeneralDecoderMixin:
                 return True
         return False
 
+    def make_stepper(self, ctx, rows: int, tag: str, rows_per_key: int = 1, max_positions: int = 0):
+        """Stepwise inference driver (greedy loop, beam search)."""
+        return make_stepper(self, ctx, rows, tag)
+
     def state_sizes(self) -> List[int]:
         """Widths of the tensors carried between steps: RNNFeedables (decoders/decoder.py:34-50)."""
         return [self.rnn_size, self.rnn_size] + [a.context_vector_size for a in self.attentions]
@@ -182,7 +186,7 @@ class FastStepper:
     def start(self, s0: torch.Tensor) -> None:
         self.src = s0
 
-    def step(self, emb, att_states, out_state, logits, h_out: Optional[torch.Tensor] = None):
+    def step(self, emb, att_states, out_state, logits, h_out: Optional[torch.Tensor] = None, finished=None):
         nxt = self.cur ^ 1
         dst = h_out if h_out is not None else self.hbuf[nxt]
         att_states = self.dec.full_step(self.ctx, self.cell, emb, self.src, dst, att_states, out_state, logits,
@@ -215,7 +219,7 @@ class GeneralStepper:
         self.state = [tape.leaf(s0), tape.leaf(s0)] + [tape.leaf(z) for z in self.zero_ctx]
         self.t = 0
 
-    def step(self, emb, att_states, out_state, logits, h_out: Optional[torch.Tensor] = None):
+    def step(self, emb, att_states, out_state, logits, h_out: Optional[torch.Tensor] = None, finished=None):
         from ..attention.base_attention import AttentionLoopState
         tape, dec = self.tape, self.dec
         tape._n, tape._slot = self.base, self.t & 1       # recycle this parity's step buffers

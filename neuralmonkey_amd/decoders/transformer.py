@@ -1,0 +1,414 @@
+"""Transformer decoder (mirror of neuralmonkey/decoders/transformer.py).
+
+Per layer (transformer.py:360-390): pre-LN masked self-attention + residual (:270-295), pre-LN
+encoder-decoder attention per encoder, ``serial`` combination (:297-332,
+attention/transformer_cross_layer.py:12-103), pre-LN ReLU feed-forward + residual (:334-358); a final
+layer norm; logits = states . W + b with W tied to the embedding matrix by default
+(autoregressive.py:226-251).  As in the reference at this commit, the decoder inputs carry no
+position signal (``embed_input_symbol`` -- singular -- is dead code, :240-256).
+
+Training is one pass over the shifted targets (:393-453) on the autodiff tape.
+
+Decoding: the reference re-runs all layers over the whole prefix at every step (:487-516).  The
+masked self-attention makes the states of earlier positions independent of later ones, so the
+same numbers come out of a key/value cache: a step projects only the new position, appends its
+keys / values to per-layer [R, Tmax, D] caches and attends with one query per row
+(``nm_sdp_attn_fwd`` with Tq = 1).  The key mask column of a new position is ``not finished`` of its
+row (:493-497); encoder keys / values are projected once per sentence and shared by the rows of a
+beam (row r reads sentence r // k).
+"""
+from typing import Any, List, NamedTuple, Optional, Union
+
+import numpy as np
+import torch
+
+from .. import autodiff as F
+from .. import ops
+from ..attention.base_attention import Attendable, get_attention_mask, get_attention_states
+from ..model.model_part import InitializerSpecs, ModelPart
+from ..model.sequence import EmbeddedSequence
+from ..nn import transformer_blocks as TB
+from ..runtime import tensor
+from ..variables import glorot_uniform_initializer, ones_initializer, zeros_initializer
+from ..vocabulary import END_TOKEN_INDEX, START_TOKEN_INDEX, Vocabulary
+from .autoregressive import AutoregressiveDecoder
+from .decoder import CHECK_EVERY, RuntimeResult, TrainResult
+
+STRATEGIES = ["serial", "parallel", "flat", "hierarchical"]
+
+
+# pylint: disable=too-many-instance-attributes
+class TransformerDecoder(AutoregressiveDecoder):
+    # pylint: disable=too-many-arguments,too-many-locals
+    def __init__(self, name: str, encoders: List[Attendable], vocabulary: Vocabulary, data_id: str,
+                 ff_hidden_size: int, n_heads_self: int, n_heads_enc: Union[List[int], int], depth: int,
+                 max_output_len: int, attention_combination_strategy: str = "serial", n_heads_hier: int = None,
+                 dropout_keep_prob: float = 1.0, embedding_size: int = None,
+                 embeddings_source: EmbeddedSequence = None, tie_embeddings: bool = True,
+                 label_smoothing: float = None, self_attention_dropout_keep_prob: float = 1.0,
+                 attention_dropout_keep_prob: Union[float, List[float]] = 1.0,
+                 use_att_transform_bias: bool = False, supress_unk: bool = False, reuse: ModelPart = None,
+                 save_checkpoint: str = None, load_checkpoint: str = None,
+                 initializers: InitializerSpecs = None) -> None:
+        self.encoders = encoders
+        if embedding_size is None and embeddings_source is None:
+            embedding_size = self._model_dimension(encoders, None)
+        AutoregressiveDecoder.__init__(
+            self, name=name, vocabulary=vocabulary, data_id=data_id, max_output_len=max_output_len,
+            dropout_keep_prob=dropout_keep_prob, embedding_size=embedding_size,
+            embeddings_source=embeddings_source, tie_embeddings=tie_embeddings, label_smoothing=label_smoothing,
+            supress_unk=supress_unk, reuse=reuse, save_checkpoint=save_checkpoint,
+            load_checkpoint=load_checkpoint, initializers=initializers)
+        self.ff_hidden_size = ff_hidden_size
+        self.n_heads_self = n_heads_self
+        if isinstance(n_heads_enc, int):
+            self.n_heads_enc = [n_heads_enc] if attention_combination_strategy == "flat" \
+                else [n_heads_enc for _ in self.encoders]
+        else:
+            self.n_heads_enc = list(n_heads_enc)
+        self.depth = depth
+        if isinstance(attention_dropout_keep_prob, float):
+            self.attention_dropout_keep_prob = [attention_dropout_keep_prob for _ in encoders]
+        else:
+            self.attention_dropout_keep_prob = list(attention_dropout_keep_prob)
+        self.self_att_dropout_keep_prob = self_attention_dropout_keep_prob
+        self.use_att_transform_bias = use_att_transform_bias
+        self.attention_combination_strategy = attention_combination_strategy
+        self.n_heads_hier = n_heads_hier
+        self.attentions: List[Any] = []          # no Bahdanau-style loop states (runners look at this)
+        if self.attention_combination_strategy not in STRATEGIES:
+            raise ValueError("Unknown attention combination strategy '{}'. Allowed: {}."
+                             .format(self.attention_combination_strategy, ", ".join(STRATEGIES)))
+        if self.attention_combination_strategy == "hierarchical" and self.n_heads_hier is None:
+            raise ValueError("You must provide n_heads_hier when using the hierarchical attention "
+                             "combination strategy.")
+        if self.attention_combination_strategy == "flat" and len(self.n_heads_enc) != 1:
+            raise ValueError("For the flat attention combination strategy, only a single value is permitted "
+                             "in n_heads_enc.")
+        if self.attention_combination_strategy != "serial":
+            raise NotImplementedError("attention_combination_strategy '{}' is not implemented in the HIP engine "
+                                      "(serial is)".format(self.attention_combination_strategy))
+        if self.depth <= 0:
+            raise ValueError("Depth must be a positive integer.")
+        _ = self.dimension                        # dimension checks of the reference (:195-222)
+        self.set_default_initializer(glorot_uniform_initializer())
+
+    @staticmethod
+    def _model_dimension(encoders, embedding_size) -> int:
+        dims = [e.dimension for e in encoders]
+        if dims:
+            for i, dim in enumerate(dims):
+                if dim != dims[0]:
+                    raise ValueError("Dimension of the {}-th encoder ({}) differs from the dimension of the "
+                                     "first one ({}).".format(i, dim, dims[0]))
+            if embedding_size is not None and embedding_size != dims[0]:
+                raise ValueError("Model dimension and input embedding size do not match")
+            return dims[0]
+        if embedding_size is None:
+            raise ValueError("'embedding_size' must be specified when no encoders are provided")
+        return embedding_size
+
+    @property
+    def dimension(self) -> int:
+        return self._model_dimension(self.encoders, self.embedding_size)
+
+    @property
+    def output_dimension(self) -> int:
+        return self.dimension
+
+    # -- variables --------------------------------------------------------------------------------
+    def declare_variables(self, store) -> None:
+        AutoregressiveDecoder.declare_variables(self, store)
+        d = self.dimension
+        for i in range(self.depth):
+            pre = "layer_{}".format(i)
+            TB.declare_layer_norm(self, store, pre + "/self_attention", d)
+            TB.declare_attention(self, store, pre + "/self_attention", d, self.n_heads_self,
+                                 self.use_att_transform_bias)
+            for j, heads in enumerate(self.n_heads_enc):
+                scope = "{}/encdec_attention/enc_{}".format(pre, j)
+                TB.declare_layer_norm(self, store, scope, d)
+                TB.declare_attention(self, store, scope, d, heads, False)       # serial(): no transform bias
+            TB.declare_feedforward(self, store, pre + "/feedforward", d, self.ff_hidden_size)
+        self.declare(store, "LayerNorm/gamma", (d,), ones_initializer())
+        self.declare(store, "LayerNorm/beta", (d,), zeros_initializer())
+
+    # -- the layer stack over whole sequences (training) ------------------------------------------------
+    def _layers(self, tape: F.Tape, x: F.Var, mask: torch.Tensor, bsz: int, steps: int, enc, train: bool) -> F.Var:
+        """layer(depth, inputs, mask) (:360-390).  x [B*T, D]; enc = [(states Var [B*S,D], mask, S)]."""
+        ctx = tape.ctx
+        keep = self.dropout_keep_prob
+        for i in range(self.depth):
+            pre = "layer_{}".format(i)
+            site = (self.name, pre)
+            normed = TB.layer_norm(tape, self, pre + "/self_attention", x)
+            att = TB.multihead_attention(tape, self, pre + "/self_attention", normed, normed, mask,
+                                         self.n_heads_self, bsz, steps, bsz, steps, True,
+                                         self.self_att_dropout_keep_prob, train,
+                                         ctx.salt(*site, "self_attention_weights"), self.use_att_transform_bias)
+            att = F.dropout(tape, att, keep, train, ctx.salt(*site, "self_attention"))
+            x = F.add(tape, att, x)
+            for j, ((evar, emask, elen), heads, att_keep) in enumerate(zip(enc, self.n_heads_enc,
+                                                                          self.attention_dropout_keep_prob)):
+                scope = "{}/encdec_attention/enc_{}".format(pre, j)
+                normed = TB.layer_norm(tape, self, scope, x)
+                att = TB.multihead_attention(tape, self, scope, normed, evar, emask, heads, bsz, steps, bsz, elen,
+                                             False, att_keep, train, ctx.salt(*site, "encdec_weights", j), False)
+                att = F.dropout(tape, att, keep, train, ctx.salt(*site, "encdec", j))
+                x = F.add(tape, att, x)
+            x = TB.feedforward_sublayer(tape, self, pre + "/feedforward", x, keep, train, site)
+        return F.layer_norm(tape, x, tape.param(self, "LayerNorm/gamma"), tape.param(self, "LayerNorm/beta"))
+
+    def _logit_params(self, tape: F.Tape):
+        ctx = tape.ctx
+        bias_data = self.decoding_bias(ctx)
+        if self.tie_embeddings:
+            return tape.named_param(self.embedding_matrix_name), True, tape.leaf(bias_data)
+        b = tape.param(self, "state_to_word_b")
+        return tape.param(self, "state_to_word_W"), False, F.Var(bias_data, b.grad, b.needs_grad)
+
+    def _train_input_symbols(self, ctx) -> torch.Tensor:
+        """[B,T]: <s> then the targets without their last step (:258-268)."""
+        def shift(ids):                       # fed ids are [B,T]
+            out = np.empty_like(ids)
+            out[:, 0] = START_TOKEN_INDEX
+            out[:, 1:] = ids[:, :-1]
+            return out
+        return ctx.session.to_device(ctx.fed(self.train_tokens), torch.int32, "tdec_in_bt", shift)
+
+    def decoding_loop(self, ctx, train_mode: bool, sample: bool = False, temperature: float = 1.0):
+        if sample or temperature != 1.0:
+            raise NotImplementedError("sampling / temperature are not implemented in the HIP engine")
+        return self._train_loop(ctx) if train_mode else self._runtime_loop(ctx, keep_logits=False)
+
+    def _train_loop(self, ctx, want_grad: bool = False, grad_scale: Optional[torch.Tensor] = None) -> TrainResult:
+        train = bool(ctx.fed(self.train_mode))
+        tape = F.Tape(ctx, (id(self), "ttrain"), recording=want_grad)
+        ids = self._train_input_symbols(ctx)                       # [B,T]
+        bsz, steps = ids.shape
+        tgt_bt = ctx.session.to_device(ctx.fed(self.train_tokens), torch.int32, "tdec_tgt_bt")
+        mask_bt = ctx.session.to_device(ctx.fed(self.train_tokens), torch.float32, "tdec_mask_bt",
+                                        lambda a: (a != 0).astype(np.float32))
+        table = tape.named_param(self.embedding_matrix_name)
+        emb = F.embedding(tape, table, ids.reshape(-1))            # base embed_input_symbols: lookup + dropout
+        emb = F.dropout(tape, emb, self.dropout_keep_prob, train, ctx.salt(self.name, "embedded_input"))
+        enc = []
+        for e in self.encoders:
+            st = get_attention_states(e, ctx)
+            enc.append((tape.leaf(st.reshape(st.shape[0] * st.shape[1], st.shape[2]), needs_grad=True),
+                        get_attention_mask(e, ctx), st.shape[1]))
+        states = self._layers(tape, emb, mask_bt, bsz, steps, enc, train)
+        w, trans_b, bias = self._logit_params(tape)
+        logits = F.linear(tape, states, w, bias, trans_b=trans_b)   # [B*T, V], batch-major rows
+        loss_rows = F.xent(tape, logits, tgt_bt.reshape(-1), mask_bt.reshape(-1), grad_scale)
+        loss_sum = ctx.buffer((id(self), "ttrain", "loss_sum"), (1,))
+        ops.reduce_sum(loss_rows, loss_sum)
+        saved = {"tape": tape, "enc": enc, "steps": steps, "bsz": bsz, "logits": logits.data,
+                 "dlogits": logits.data if want_grad else None, "states": states}
+        return TrainResult(loss_sum, self.train_token_count(ctx), steps, saved)
+
+    def backward(self, ctx, res: TrainResult) -> None:
+        sv = res.saved
+        sv["tape"].backward()
+        bsz = sv["bsz"]
+        for e, (var, _, slen) in zip(self.encoders, sv["enc"]):
+            if var.grad is not None and hasattr(e, "backward"):
+                e.backward(ctx, var.grad.view(bsz, slen, -1), None)
+
+    @tensor
+    def train_loss(self, ctx) -> torch.Tensor:
+        res = self.train_loop_result(ctx)
+        return res.loss_sum[0] / res.token_count
+
+    @tensor
+    def train_logits(self, ctx) -> torch.Tensor:
+        """[T,B,V] (time-major like every decoder history)."""
+        res = self.train_loop_result(ctx)
+        if res.saved["dlogits"] is not None:
+            raise RuntimeError("train_logits were overwritten by their gradient in this run")
+        return res.saved["logits"].view(res.saved["bsz"], res.saved["steps"], -1).transpose(0, 1)
+
+    # -- decoding with a key/value cache ------------------------------------------------------------
+    def make_stepper(self, ctx, rows: int, tag: str, rows_per_key: int = 1,
+                     max_positions: int = 0) -> "TransformerStepper":
+        return TransformerStepper(self, ctx, rows, tag, rows_per_key, max_positions)
+
+    def _runtime_loop(self, ctx, keep_logits: bool) -> RuntimeResult:
+        key = (id(self), "trun", keep_logits)
+        bsz = int(ctx.fed(self.batch_size))
+        d, v = self.dimension, len(self.vocabulary)
+        tmax = self.max_output_len
+        has_tgt = self.has_targets(ctx)
+        if has_tgt:
+            tgt, tmask = self.train_inputs(ctx), self.train_mask(ctx)
+            t_target = tgt.shape[0]
+        out_all = ctx.buffer(key + ("out_all",), (tmax, bsz, d))
+        symbols = ctx.buffer(key + ("sym",), (tmax, bsz), torch.int32, zero=True)
+        omask = ctx.buffer(key + ("mask",), (tmax, bsz), torch.int32, zero=True)
+        finished = ctx.buffer(key + ("fin",), (bsz,), torch.int32, zero=True)
+        allfin = ctx.buffer(key + ("allfin",), (tmax,), torch.int32)
+        allfin.fill_(1)
+        argmax = ctx.buffer(key + ("argmax",), (bsz,), torch.int32)
+        logits_all = ctx.buffer(key + ("logits_all",), (tmax, bsz, v)) if keep_logits else None
+        logits_one = ctx.buffer(key + ("logits",), (bsz, v))
+        xent_rows = ctx.buffer(key + ("xent_rows",), (tmax, bsz), zero=True) if has_tgt else None
+        emb = ctx.buffer(key + ("emb",), (2, bsz, d))
+        stepper = self.make_stepper(ctx, bsz, "greedy")
+        stepper.start()
+        go = ctx.buffer(key + ("go",), (bsz,), torch.int32)
+        go.fill_(START_TOKEN_INDEX)
+        self.embed_input_symbols(ctx, go, out=emb[0])
+        steps = 0
+        while steps < tmax:
+            t = steps
+            logits = logits_all[t] if keep_logits else logits_one
+            stepper.step(emb[t & 1], [], out_all[t], logits, finished=finished)
+            ops.row_stats(logits, None, None, argmax)
+            if has_tgt and t < t_target:
+                ops.xent(logits, tgt[t], tmask[t], xent_rows[t])
+            ops.greedy_update(argmax, finished, symbols[t], omask[t], END_TOKEN_INDEX, allfin[t:t + 1])
+            self.embed_input_symbols(ctx, symbols[t], out=emb[(t + 1) & 1])
+            steps += 1
+            if steps % CHECK_EVERY == 0 or steps == tmax:
+                done = np.nonzero(allfin[:steps].cpu().numpy())[0]
+                if done.size:
+                    steps = int(done[0]) + 1
+                    break
+        xent_sum = None
+        if has_tgt:
+            xent_sum = ctx.buffer(key + ("xent_sum",), (1,))
+            ops.reduce_sum(xent_rows[:min(steps, t_target)].reshape(-1), xent_sum)
+        return RuntimeResult(symbols[:steps], omask[:steps], steps, xent_sum,
+                             logits_all[:steps] if keep_logits else None, out_all[:steps], None, [])
+
+    @tensor
+    def runtime_loss(self, ctx):
+        res = self.runtime_loop_result(ctx)
+        if res.xent_sum is None:
+            return 0.0
+        return res.xent_sum[0] / res.mask.sum().to(torch.float32)
+
+    @tensor
+    def decoded_symbols(self, ctx) -> torch.Tensor:
+        return self.runtime_loop_result(ctx).symbols
+
+    @tensor
+    def runtime_mask(self, ctx) -> torch.Tensor:
+        return self.runtime_loop_result(ctx).mask
+
+    @tensor
+    def runtime_logits(self, ctx) -> torch.Tensor:
+        key = (id(self), "runtime_full")
+        if key not in ctx.memo:
+            ctx.memo[key] = self._runtime_loop(ctx, keep_logits=True)
+        return ctx.memo[key].logits
+
+    @tensor
+    def runtime_logprobs(self, ctx) -> torch.Tensor:
+        logits = self.runtime_logits(ctx)
+        t, b, v = logits.shape
+        mx = ctx.buffer((id(self), "lp_max"), (t * b,))
+        lse = ctx.buffer((id(self), "lp_lse"), (t * b,))
+        ops.row_stats(logits.view(t * b, v), mx, lse, None)
+        out = ctx.buffer((id(self), "logprobs"), (t, b, v))
+        ops.log_softmax_from_stats(logits.view(t * b, v), mx, lse, out.view(t * b, v))
+        return out
+
+    @tensor
+    def runtime_output_states(self, ctx) -> torch.Tensor:
+        return self.runtime_loop_result(ctx).output_states
+
+
+class TransformerStepper:
+    """Cached decoding steps for R rows (greedy: R = B; beam: R = B*k, ``rows_per_key`` = k)."""
+
+    def __init__(self, dec: TransformerDecoder, ctx, rows: int, tag: str, rows_per_key: int = 1,
+                 max_positions: int = 0):
+        self.dec, self.ctx, self.rows, self.rpk = dec, ctx, rows, rows_per_key
+        d = dec.dimension
+        self.tmax = max(dec.max_output_len, max_positions) + 1
+        key = (id(dec), tag, rows, self.tmax)
+        self.tape = F.Tape(ctx, key + ("tape",), recording=False)
+        buf = lambda name, shape: ctx.buffer(key + (name,), shape)
+        # per layer: keys / values of the positions decoded so far, two copies for the beam reorder
+        self.kcache = [buf(("k", l), (2, rows, self.tmax, d)) for l in range(dec.depth)]
+        self.vcache = [buf(("v", l), (2, rows, self.tmax, d)) for l in range(dec.depth)]
+        self.mask = buf("mask", (2, rows, self.tmax))
+        self.cur = 0
+        self.t = 0
+        self.enc_kv = None
+
+    def start(self) -> None:
+        """Project the encoder states to keys / values of every layer once per batch."""
+        dec, tape = self.dec, self.tape
+        tape._n, tape._slot = 0, 2                # pylint: disable=protected-access
+        self.enc_kv = []
+        for j, (e, heads) in enumerate(zip(dec.encoders, dec.n_heads_enc)):
+            st = get_attention_states(e, self.ctx)
+            bk, slen, d = st.shape
+            var = tape.leaf(st.reshape(bk * slen, d))
+            per_layer = []
+            for l in range(dec.depth):
+                scope = "layer_{}/encdec_attention/enc_{}".format(l, j)
+                k = TB.project(tape, dec, scope, "keys_proj", var, heads, False)
+                v = TB.project(tape, dec, scope, "vals_proj", var, heads, False)
+                per_layer.append((k.data.view(bk, slen, d), v.data.view(bk, slen, d)))
+            self.enc_kv.append((per_layer, get_attention_mask(e, self.ctx), bk, slen))
+        self.base = tape._n                       # pylint: disable=protected-access
+        self.cur, self.t = 0, 0
+
+    def step(self, emb, att_states, out_state, logits, h_out=None, finished=None):
+        dec, tape, rows, t = self.dec, self.tape, self.rows, self.t
+        assert t < self.tmax, "decoding ran past the key/value cache"
+        d = dec.dimension
+        tape._n, tape._slot = self.base, 0        # pylint: disable=protected-access
+        cur = self.cur
+        mask = self.mask[cur]
+        ops.unfinished_mask(finished, mask[:, t])                               # :493-497
+        x = tape.leaf(emb)
+        for l in range(dec.depth):
+            pre = "layer_{}".format(l)
+            scope = pre + "/self_attention"
+            normed = TB.layer_norm(tape, dec, scope, x)
+            q = TB.project(tape, dec, scope, "query_proj", normed, dec.n_heads_self, dec.use_att_transform_bias)
+            kc, vc = self.kcache[l][cur], self.vcache[l][cur]
+            if dec.n_heads_self > 1:
+                bias = lambda p: tape.param(dec, "{}/{}/bias".format(scope, p)) if dec.use_att_transform_bias else None
+                F.linear(tape, normed, tape.param(dec, scope + "/keys_proj/kernel"), bias("keys_proj"),
+                         out=tape.leaf(kc[:, t]))
+                F.linear(tape, normed, tape.param(dec, scope + "/vals_proj/kernel"), bias("vals_proj"),
+                         out=tape.leaf(vc[:, t]))
+            else:
+                ops.ew("copy", normed.data, None, kc[:, t])
+                ops.ew("copy", normed.data, None, vc[:, t])
+            att = F.sdp_attention(tape, q, None, None, mask[:, :t + 1], dec.n_heads_self, rows, 1, rows, t + 1,
+                                  False, 1.0, 0, k_data=kc[:, :t + 1], v_data=vc[:, :t + 1])
+            att = TB.project(tape, dec, scope, "output_proj", att, dec.n_heads_self, dec.use_att_transform_bias)
+            x = F.add(tape, att, x)
+            for j, (heads, (per_layer, emask, bk, slen)) in enumerate(zip(dec.n_heads_enc, self.enc_kv)):
+                scope = "{}/encdec_attention/enc_{}".format(pre, j)
+                normed = TB.layer_norm(tape, dec, scope, x)
+                q = TB.project(tape, dec, scope, "query_proj", normed, heads, False)
+                ek, ev = per_layer[l]
+                att = F.sdp_attention(tape, q, None, None, emask, heads, rows, 1, bk, slen, False, 1.0, 0,
+                                      k_data=ek, v_data=ev)
+                att = TB.project(tape, dec, scope, "output_proj", att, heads, False)
+                x = F.add(tape, att, x)
+            x = TB.feedforward_sublayer(tape, dec, pre + "/feedforward", x, 1.0, False, (dec.name, pre))
+        ops.layer_norm_fwd(x.data, dec.var(self.ctx, "LayerNorm/gamma"), dec.var(self.ctx, "LayerNorm/beta"),
+                           out=out_state)
+        dec.state_to_logits(self.ctx, out_state, logits)
+        self.t += 1
+        return att_states
+
+    def reorder(self, src_rows: torch.Tensor) -> None:
+        """Beam step: row r continues hypothesis ``src_rows[r]`` -- gather the cached prefix."""
+        cur, nxt, t = self.cur, self.cur ^ 1, self.t
+        d = self.dec.dimension
+        width = t * d
+        for l in range(self.dec.depth):
+            for cache in (self.kcache[l], self.vcache[l]):
+                ops.gather_rows(cache[cur].view(self.rows, self.tmax * d)[:, :width], src_rows,
+                                cache[nxt].view(self.rows, self.tmax * d)[:, :width])
+        ops.gather_rows(self.mask[cur][:, :t], src_rows, self.mask[nxt][:, :t])
+        self.cur = nxt

@@ -438,6 +438,82 @@ def maxout_fwd(x, out, argmax, pool=2):
     return out
 
 
+def _bs(t):
+    """Batch stride (floats) of a [B, T, D] tensor whose rows are contiguous."""
+    assert t.dim() == 3 and t.stride(2) == 1 and t.stride(1) == t.shape[2], (t.shape, t.stride())
+    return t.stride(0)
+
+
+def sdp_attn_fwd(q, k, v, key_mask, heads, ctx, weights=None, causal=False, rows_per_key=1, keep_prob=1.0,
+                 salt=0):
+    """Multi-head scaled dot-product attention.  q/ctx [Bq,Tq,D], k/v [Bk,Tk,D] (Bq = Bk*rows_per_key;
+    batch strides may exceed T*D: a key/value cache), key_mask [Bk,Tk] or None, weights [Bq,H,Tq,Tk]."""
+    lib = _lib.load()
+    bq, tq, d = q.shape
+    bk, tk, _ = k.shape
+    assert d % heads == 0 and bq == bk * rows_per_key and v.shape[1] == tk
+    mask_bs = 0
+    if key_mask is not None:
+        assert key_mask.dim() == 2 and key_mask.stride(1) == 1 and key_mask.shape[1] >= tk
+        mask_bs = key_mask.stride(0)
+    if weights is not None:
+        assert weights.is_contiguous() and weights.numel() == bq * heads * tq * tk
+    _lib.check(lib.nm_sdp_attn_fwd(_stream(), q.data_ptr(), _bs(q), k.data_ptr(), _bs(k), v.data_ptr(), _bs(v),
+                                   _p(key_mask), mask_bs, bq, rows_per_key, tq, tk, heads, d // heads, int(causal),
+                                   float(keep_prob), int(salt) & 0xFFFFFFFF, ctx.data_ptr(), _bs(ctx),
+                                   _p(weights)), "nm_sdp_attn_fwd")
+    return ctx
+
+
+def sdp_attn_bwd(q, k, v, key_mask, weights, dctx, heads, dq, dk, dv, de_ws, causal=False, keep_prob=1.0, salt=0,
+                 accumulate=False):
+    lib = _lib.load()
+    b, tq, d = q.shape
+    tk = k.shape[1]
+    mask_bs = 0 if key_mask is None else key_mask.stride(0)
+    assert de_ws.numel() >= b * heads * tq * tk
+    _lib.check(lib.nm_sdp_attn_bwd(_stream(), q.data_ptr(), _bs(q), k.data_ptr(), _bs(k), v.data_ptr(), _bs(v),
+                                   _p(key_mask), mask_bs, weights.data_ptr(), dctx.data_ptr(), _bs(dctx), b, tq, tk,
+                                   heads, d // heads, int(causal), float(keep_prob), int(salt) & 0xFFFFFFFF,
+                                   dq.data_ptr(), _bs(dq), dk.data_ptr(), _bs(dk), dv.data_ptr(), _bs(dv),
+                                   de_ws.data_ptr(), int(accumulate)), "nm_sdp_attn_bwd")
+
+
+def add_position(x, signal, out, t0=0):
+    """out[b,t,:] = x[b,t,:] + signal[t0+t,:]; x [B,T,D] contiguous, signal [Tmax,D]."""
+    lib = _lib.load()
+    b, t, d = x.shape
+    assert x.is_contiguous() and out.is_contiguous() and signal.is_contiguous()
+    assert signal.shape[1] == d and signal.shape[0] >= t0 + t
+    _lib.check(lib.nm_add_position(_stream(), x.data_ptr(), signal.data_ptr(), out.data_ptr(), b, t, d, t0),
+               "nm_add_position")
+    return out
+
+
+def unfinished_mask(finished, out_col):
+    """out_col[r] = 0.0 where finished[r] else 1.0; ``out_col`` may be a strided column view."""
+    lib = _lib.load()
+    n = finished.numel()
+    assert out_col.dim() == 1 and out_col.numel() == n
+    _lib.check(lib.nm_unfinished_mask(_stream(), _i32(finished).data_ptr(), out_col.data_ptr(),
+                                      out_col.stride(0) if n > 1 else 1, n), "nm_unfinished_mask")
+
+
+def time_sum(x, out):
+    lib = _lib.load()
+    b, t, d = x.shape
+    assert x.is_contiguous() and out.is_contiguous()
+    _lib.check(lib.nm_time_sum(_stream(), x.data_ptr(), out.data_ptr(), b, t, d), "nm_time_sum")
+    return out
+
+
+def time_bcast_add(dy, dx):
+    lib = _lib.load()
+    b, t, d = dx.shape
+    assert dy.is_contiguous() and dx.is_contiguous()
+    _lib.check(lib.nm_time_bcast_add(_stream(), dy.data_ptr(), dx.data_ptr(), b, t, d), "nm_time_bcast_add")
+
+
 def maxout_bwd(dy, argmax, dx, pool=2):
     lib = _lib.load()
     rows, groups, lddy = _rc(dy)

@@ -20,7 +20,9 @@ class AdamOptimizer(Optimizer):
         self.beta1, self.beta2, self.epsilon = beta1, beta2, epsilon
 
     def learning_rate(self, step: int) -> float:
-        return float(self._lr(step)) if callable(self._lr) else float(self._lr)
+        """Learning rate of update number ``step`` (1-based).  A schedule is evaluated at the
+        global step before the update, as the TF graph does (functions.py)."""
+        return float(self._lr(step - 1)) if callable(self._lr) else float(self._lr)
 
     def lr_t(self, step: int) -> float:
         """``step`` counts from 1 (the value of global_step after this update)."""

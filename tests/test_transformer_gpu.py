@@ -1,0 +1,211 @@
+"""Transformer path parity (BASELINE configs[4], tests/transformer.ini shape and larger):
+scaled dot-product attention kernels, TransformerEncoder / TransformerDecoder training step
+(gradients of every variable against autograd), greedy and beam decoding through the key/value
+cache against the oracle's literal re-run-the-prefix decoding.
+
+Checker: oracle/transformer_ref.py.  Tolerances: loss 1e-4 relative; gradients 1e-3 of each
+tensor's max magnitude; greedy / beam indices exact (beam unless the oracle reports a near-tie);
+logits 1e-4 relative."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import general_ref as G
+from oracle import nm_oracle as O
+from oracle import transformer_ref as TRF
+
+pytestmark = pytest.mark.gpu
+
+VOCAB = 40
+
+
+# ------------------------------------------------------------------------------------------- kernels
+@pytest.mark.parametrize("b,tq,tk,heads,dh,causal,masked,keep,rpk", [
+    (3, 7, 7, 3, 2, True, True, 1.0, 1),          # transformer.ini: d=6, 3 heads
+    (4, 9, 13, 2, 8, False, True, 1.0, 1),        # cross attention, Tq != Tk
+    (5, 12, 12, 8, 64, True, True, 0.8, 1),       # base-model head shape with attention dropout
+    (2, 50, 50, 8, 64, False, True, 1.0, 1),
+    (6, 1, 11, 4, 16, False, True, 1.0, 3),       # decoding step of a beam (3 rows per sentence)
+    (2, 70, 130, 1, 32, False, False, 1.0, 1),    # more keys than one wave pass, no mask
+])
+def test_sdp_attention_fwd_bwd(dev, b, tq, tk, heads, dh, causal, masked, keep, rpk):
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(b * 100 + tq)
+    d = heads * dh
+    bk = b // rpk
+    q = torch.tensor(rng.standard_normal((b, tq, d)).astype(np.float32), requires_grad=True)
+    k = torch.tensor(rng.standard_normal((bk, tk, d)).astype(np.float32), requires_grad=True)
+    v = torch.tensor(rng.standard_normal((bk, tk, d)).astype(np.float32), requires_grad=True)
+    mask = np.ones((bk, tk), np.float32)
+    if masked:
+        for i in range(bk):
+            mask[i, rng.integers(1, tk + 1):] = 0
+    mt = torch.tensor(mask)
+    salt = 4242
+
+    def ref():
+        split = lambda x, n: x.view(x.shape[0], x.shape[1], heads, dh).permute(0, 2, 1, 3)
+        qq = split(q / math.sqrt(dh), b)
+        kk = split(k, bk).repeat_interleave(rpk, 0)
+        vv = split(v, bk).repeat_interleave(rpk, 0)
+        e = qq @ kk.transpose(-1, -2)
+        if causal:
+            i = torch.arange(tq)[:, None]
+            j = torch.arange(tk)[None, :]
+            e = torch.where(j <= i + tk - tq, e, torch.full_like(e, -1e9))
+        m4 = mt.repeat_interleave(rpk, 0)[:, None, None, :]
+        e = e * m4 + (1 - m4) * -1e9
+        w = torch.softmax(e, -1)
+        wd = w
+        if keep < 1.0:
+            wd = w * torch.from_numpy(G.dropout_mask(w.numel(), keep, salt)).view(w.shape)
+        return (wd @ vv).permute(0, 2, 1, 3).reshape(b, tq, d), w
+    want_ctx, want_w = ref()
+    qd, kd, vd = (x.detach().to(dev) for x in (q, k, v))
+    ctx = torch.empty((b, tq, d), device=dev)
+    w = torch.empty((b, heads, tq, tk), device=dev)
+    ops.sdp_attn_fwd(qd, kd, vd, mt.to(dev), heads, ctx, w, causal, rpk, keep, salt)
+    assert np.abs(w.cpu().numpy() - want_w.detach().numpy()).max() < 2e-6
+    scale = float(want_ctx.abs().max())
+    assert float((ctx.cpu() - want_ctx.detach()).abs().max()) < 1e-5 * max(scale, 1.0)
+    if rpk != 1:
+        return
+    g = torch.tensor(rng.standard_normal((b, tq, d)).astype(np.float32))
+    want_ctx.backward(g)
+    dq, dk, dv = (torch.zeros_like(x) for x in (qd, kd, vd))
+    de = torch.empty((b, heads, tq, tk), device=dev)
+    ops.sdp_attn_bwd(qd, kd, vd, mt.to(dev), w, g.to(dev), heads, dq, dk, dv, de, causal, keep, salt, accumulate=True)
+    for got, want in ((dq, q.grad), (dk, k.grad), (dv, v.grad)):
+        assert float((got.cpu() - want).abs().max()) < 2e-5 * max(float(want.abs().max()), 1.0)
+
+
+def test_position_signal_matches_the_reference_formula(dev):
+    from neuralmonkey_amd.nn.transformer_blocks import position_signal
+    for dim, length in ((6, 7), (16, 50), (7, 5), (512, 64)):
+        got = position_signal(dim, length)
+        want = TRF.position_signal(dim, length).numpy()
+        assert got.shape == (length, dim)
+        assert np.abs(got - want).max() < 1e-5
+
+
+# ------------------------------------------------------------------------------------------- models
+def _build(dev, cfg: TRF.TConfig, d, ff, max_len=8, beam=3, seed=7, init_std=0.4):
+    from neuralmonkey_amd.decoders import BeamSearchDecoder, TransformerDecoder
+    from neuralmonkey_amd.encoders import TransformerEncoder
+    from neuralmonkey_amd.model.sequence import EmbeddedSequence
+    from neuralmonkey_amd.runtime import reset_registry
+    from neuralmonkey_amd.synthetic import synthetic_vocabulary
+    from neuralmonkey_amd.tf_manager import TensorFlowManager
+    from neuralmonkey_amd.trainers import CrossEntropyTrainer
+    reset_registry()
+    vocab = synthetic_vocabulary(VOCAB)
+    seq = EmbeddedSequence(name=cfg.enc_name + "_input", vocabulary=vocab, data_id="source", embedding_size=d,
+                           max_length=max_len)
+    enc = TransformerEncoder(name=cfg.enc_name, input_sequence=seq, ff_hidden_size=ff, depth=cfg.depth,
+                             n_heads=cfg.n_heads, dropout_keep_prob=cfg.enc_dropout,
+                             attention_dropout_keep_prob=cfg.enc_att_dropout,
+                             use_att_transform_bias=cfg.use_att_transform_bias,
+                             use_positional_encoding=cfg.use_positional_encoding)
+    dec = TransformerDecoder(name=cfg.dec_name, encoders=[enc], vocabulary=vocab, data_id="target",
+                             ff_hidden_size=ff, n_heads_self=cfg.n_heads_self, n_heads_enc=cfg.n_heads_enc,
+                             depth=cfg.depth, max_output_len=max_len, dropout_keep_prob=cfg.dec_dropout,
+                             embedding_size=d, tie_embeddings=cfg.tie_embeddings,
+                             self_attention_dropout_keep_prob=cfg.self_att_dropout,
+                             attention_dropout_keep_prob=cfg.encdec_att_dropout,
+                             use_att_transform_bias=cfg.use_att_transform_bias, supress_unk=cfg.supress_unk)
+    bdec = BeamSearchDecoder(name="beam_decoder", parent_decoder=dec, beam_size=beam, max_steps=max_len,
+                             length_normalization=0.6)
+    trainer = CrossEntropyTrainer(decoders=[dec], l2_weight=0.0, clip_norm=None)
+    tfm = TensorFlowManager(num_sessions=1, num_threads=1, device=str(dev), seed=seed)
+    tfm.initialize_sessions()
+    store = tfm.sessions[0].store
+    rng = np.random.default_rng(seed)
+    vals = store.state_dict()
+    for name, v in vals.items():
+        if v.ndim >= 2:
+            vals[name] = (rng.standard_normal(v.shape) * init_std / max(1.0, (v.shape[0] / 16.0) ** 0.5)
+                          ).astype(np.float32)
+        else:
+            vals[name] = (v + rng.standard_normal(v.shape) * 0.1).astype(np.float32)
+    store.load_state_dict(vals)
+    return dict(enc=enc, dec=dec, bdec=bdec, trainer=trainer, tfm=tfm, store=store, params=store.state_dict())
+
+
+def _data(batch, slen, tlen, max_len, seed=3, with_target=True):
+    from neuralmonkey_amd import synthetic
+    ds = synthetic.synthetic_dataset(seed=seed, batch=batch, src_len=slen, tgt_len=tlen, vocab=VOCAB, ragged=True,
+                                     with_target=with_target)
+    src = O.pad_ids([list(s) for s in ds.get_series("source")], max_len)
+    tgt = O.pad_ids([list(s) for s in ds.get_series("target")], max_len, add_end_symbol=True) if with_target else None
+    return ds, src, tgt
+
+
+CASES = {
+    # tests/transformer.ini: d=6, 3 self-attention heads, 2 enc-dec heads, ff 10, depth 2, dropout 0.9 / 0.5
+    "transformer_ini": (TRF.TConfig(depth=2, n_heads=3, n_heads_self=3, n_heads_enc=2, enc_dropout=0.9,
+                                    dec_dropout=0.5), 6, 10),
+    "single_head_bias_untied": (TRF.TConfig(depth=1, n_heads=1, n_heads_self=1, n_heads_enc=1,
+                                            use_att_transform_bias=True, tie_embeddings=False, supress_unk=True),
+                                16, 24),
+    "attention_dropouts": (TRF.TConfig(depth=2, n_heads=4, n_heads_self=2, n_heads_enc=4, enc_att_dropout=0.8,
+                                       self_att_dropout=0.7, encdec_att_dropout=0.9,
+                                       use_att_transform_bias=True, use_positional_encoding=False), 16, 32),
+    "wide": (TRF.TConfig(depth=3, n_heads=8, n_heads_self=8, n_heads_enc=8), 64, 128),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_transformer_train_step_gradients(dev, case):
+    cfg, d, ff = CASES[case]
+    m = _build(dev, cfg, d, ff)
+    ds, src, tgt = _data(5, 7, 6, 8)
+    ref = TRF.TransformerModel(m["params"], cfg, requires_grad=True)
+    ref_loss, ref_g = ref.train_grads(src, tgt, train=True)
+    res = m["tfm"].execute(ds, m["trainer"].feedables, [m["trainer"]], train=True)[0]
+    assert abs(res.losses[cfg.dec_name + " - cost"] - ref_loss) < 1e-4 * abs(ref_loss)
+    store = m["store"]
+    bad = {}
+    # floor of the per-tensor scale: d/d(keys_proj/bias) is identically zero (a constant added to every
+    # key shifts all energies of a query alike and softmax is shift invariant), both sides hold noise
+    gmax = max(float(np.abs(g).max()) for g in ref_g.values() if g is not None)
+    for name in store.names():
+        got = store.g(name).cpu().numpy().reshape(-1)
+        want = ref_g[name]
+        want = np.zeros_like(got) if want is None else want.reshape(-1)
+        err = float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-3 * gmax))
+        if err > 1e-3:
+            bad[name] = err
+    assert not bad, "gradient mismatch: {}".format(bad)
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_transformer_greedy_and_beam(dev, case):
+    cfg, d, ff = CASES[case]
+    m = _build(dev, cfg, d, ff)
+    ds, src, _ = _data(4, 7, 6, 8, with_target=False)
+    ref = TRF.TransformerModel(m["params"], cfg)
+    enc_states, _, enc_out = ref.encode(src, False)
+    ref_sym, ref_mask, ref_logits = ref.greedy(src, 8)
+    dec, sess = m["dec"], m["tfm"].sessions[0]
+    fd = {}
+    for part in (m["enc"].input_sequence, m["enc"], dec):
+        fd.update(part.feed_dict(ds, train=False))
+    out = sess.run({"sym": dec.decoded_symbols, "mask": dec.runtime_mask, "logits": dec.runtime_logits,
+                    "enc": m["enc"].temporal_states, "enc_out": m["enc"].output}, fd)
+    assert np.abs(out["enc"] - enc_states.numpy()).max() <= 1e-4 * np.abs(enc_states.numpy()).max()
+    assert np.abs(out["enc_out"] - enc_out.numpy()).max() <= 1e-4 * np.abs(enc_out.numpy()).max()
+    assert out["sym"].shape == ref_sym.shape
+    assert np.array_equal(out["sym"], ref_sym)
+    assert np.array_equal(out["mask"].astype(bool), ref_mask)
+    keep = np.abs(ref_logits) < 1e8
+    assert np.abs(out["logits"] - ref_logits)[keep].max() <= 1e-4 * np.abs(ref_logits[keep]).max()
+
+    tok, scores, gap = ref.beam(src, 3, 8, 0.6)
+    got = sess.run(m["bdec"].outputs, fd)
+    got_tok = np.asarray(got.last_search_step_output.token_ids)
+    assert got_tok.shape == tok.shape
+    if gap > 1e-5:
+        assert np.array_equal(got_tok[1:], tok[1:])
+    assert np.abs(np.asarray(got.last_search_step_output.scores) - scores).max() <= 1e-4 * np.abs(scores).max()
