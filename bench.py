@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--len", type=int, default=50, dest="length")
     ap.add_argument("--hidden", type=int, default=512)
     ap.add_argument("--vocab", type=int, default=32000)
-    ap.add_argument("--beam-batches", type=int, default=2, help="beam-5 decode batches to time (0 = skip)")
+    ap.add_argument("--beam-batches", type=int, default=4, help="beam-5 decode batches to time (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     return ap.parse_args()
@@ -126,7 +126,8 @@ def main():
         logit_b[2] = -1e9
         dsb = synthetic.synthetic_dataset(seed=99 + rank, batch=args.batch, src_len=args.length,
                                           tgt_len=args.length, vocab=args.vocab, with_target=False)
-        out = tfm.execute(dsb, runner.feedables, [runner], compute_losses=False)[0]     # warm-up
+        for _ in range(2):                  # warm-up: eager pass (allocations) + HIP-graph capture pass
+            out = tfm.execute(dsb, runner.feedables, [runner], compute_losses=False)[0]
         barrier()
         tb = time.perf_counter()
         emitted = 0
@@ -165,14 +166,23 @@ def main():
     dsg = synthetic.synthetic_dataset(seed=77 + rank, batch=args.batch, src_len=args.length,
                                       tgt_len=args.length, vocab=args.vocab, with_target=False)
     grunner = model.greedy_runner
-    tfm.execute(dsg, grunner.feedables, [grunner], compute_losses=False)          # warm-up
+    for _ in range(2):                      # warm-up: eager pass + HIP-graph capture pass
+        tfm.execute(dsg, grunner.feedables, [grunner], compute_losses=False)
     barrier()
-    lib.nm_prof_enable(1)
     tg = time.perf_counter()
+    for _ in range(4):
+        tfm.execute(dsg, grunner.feedables, [grunner], compute_losses=False)
+    barrier()
+    greedy_ms = (time.perf_counter() - tg) * 1e3 / 4
+    # the same decode once more with graph replay off, HIP events around every attn_partial launch
+    sess0 = tfm.sessions[0]
+    graphs_were = sess0.use_graphs
+    sess0.use_graphs = False
+    lib.nm_prof_enable(1)
     tfm.execute(dsg, grunner.feedables, [grunner], compute_losses=False)
     barrier()
-    greedy_ms = (time.perf_counter() - tg) * 1e3
     lib.nm_prof_enable(0)
+    sess0.use_graphs = graphs_were
     logit_b[2] = saved_end_bias
     tot_ms, cnt = ctypes.c_double(0.0), ctypes.c_int64(0)
     lib.nm_prof_attn_partial(ctypes.byref(tot_ms), ctypes.byref(cnt))

@@ -39,6 +39,7 @@ static inline bool nm_aligned16(const void* p) { return (reinterpret_cast<uintpt
 static inline int nm_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- device helpers -------------------------------------------------------
+__device__ __forceinline__ bool nm_aligned16_dev(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 __device__ __forceinline__ float nm_wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

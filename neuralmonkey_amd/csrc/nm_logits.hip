@@ -245,6 +245,44 @@ __device__ __forceinline__ float beam_score(const float* __restrict__ logits, lo
     return hyp / penalty[len];
 }
 
+// top K of the union of two descending lists held in registers: C[p] = better(A[p], B[K-1-p]) is a
+// bitonic sequence holding the K best, log2(K) compare-exchange stages sort it.  All indices are
+// compile-time constants, so the lists stay in VGPRs.
+template <int K>
+__device__ __forceinline__ void topk_merge_regs(float (&s)[K], int (&ix)[K], const float (&os)[K], const int (&oi)[K]) {
+#pragma unroll
+    for (int p = 0; p < K; ++p) {
+        if (cand_better(os[K - 1 - p], oi[K - 1 - p], s[p], ix[p])) { s[p] = os[K - 1 - p]; ix[p] = oi[K - 1 - p]; }
+    }
+#pragma unroll
+    for (int stride = K / 2; stride >= 1; stride /= 2) {
+#pragma unroll
+        for (int p = 0; p < K; ++p) {
+            if ((p & stride) == 0 && cand_better(s[p + stride], ix[p + stride], s[p], ix[p])) {
+                const float ts = s[p]; s[p] = s[p + stride]; s[p + stride] = ts;
+                const int ti = ix[p]; ix[p] = ix[p + stride]; ix[p + stride] = ti;
+            }
+        }
+    }
+}
+
+// butterfly over the 64 lanes: afterwards every lane holds the wave's K best
+template <int K>
+__device__ __forceinline__ void topk_wave_merge(float (&s)[K], int (&ix)[K]) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        float os[K];
+        int oi[K];
+#pragma unroll
+        for (int p = 0; p < K; ++p) { os[p] = __shfl_xor(s[p], off, 64); oi[p] = __shfl_xor(ix[p], off, 64); }
+        topk_merge_regs<K>(s, ix, os, oi);
+    }
+}
+
+// Stage 1: workgroup (slice, r) scans a slice of ONE hypothesis row, so the row constants (finished,
+// max, lse, logprob_sum, penalty) live in registers and the logits stream in as float4.  The score of
+// every candidate is computed exactly as the reference does (subtract, subtract, add, divide): the
+// selection is over the same fp32 values the oracle ranks.
 template <int K>
 __global__ __launch_bounds__(256) void beam_topk_partial(const float* __restrict__ logits, long ldx,
                                                          int V, int k, const float* __restrict__ rmax,
@@ -254,64 +292,70 @@ __global__ __launch_bounds__(256) void beam_topk_partial(const float* __restrict
                                                          const int* __restrict__ finished,
                                                          const float* __restrict__ penalty,
                                                          float* __restrict__ part_score,
-                                                         int* __restrict__ part_idx, int nslice) {
-    __shared__ float shs[256 * K];
-    __shared__ int shi[256 * K];
-    const int b = blockIdx.y, slice = blockIdx.x, tid = threadIdx.x;
-    const int total = k * V;
-    const int per = (total + nslice - 1) / nslice;
-    const int beg = slice * per, end = min(total, beg + per);
+                                                         int* __restrict__ part_idx, int ns, int per) {
+    __shared__ float shs[4 * K];
+    __shared__ int shi[4 * K];
+    const int r = blockIdx.y, slice = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = r % k;
+    const int fin = finished[r];
+    const float mx = rmax[r], lse = rlse[r], lps = logprob_sum[r];
+    const float pen = penalty[lengths[r] + 1 - (fin ? 1 : 0)];
+    const int beg = slice * per, end = min(V, beg + per);
+    const float* row = logits + (long)r * ldx;
+    const int base = j * V;
     float s[K];
     int ix[K];
 #pragma unroll
     for (int p = 0; p < K; ++p) { s[p] = -INFINITY; ix[p] = 0x7fffffff; }
-    for (int f = beg + tid; f < end; f += 256) {
-        const float sc = beam_score(logits, ldx, V, k, b, f, rmax, rlse, logprob_sum, lengths,
-                                    finished, penalty, nullptr);
-        topk_insert<K>(s, ix, sc, f);
+    if (fin) {
+        // finished hypothesis: lp = 0 for <pad>, -1e9 otherwise (:444-456); equal scores -> lowest ids win
+        const int v = beg + tid;
+        if (tid < K && v < end) {
+            const float lp = (v == 0) ? 0.0f : NM_NEG_INF_F;
+            topk_insert<K>(s, ix, (lps + lp) / pen, base + v);
+        }
+    } else if ((ldx & 3) == 0 && nm_aligned16_dev(row)) {
+        const int end4 = beg + ((end - beg) & ~3);
+        for (int v = beg + tid * 4; v < end4; v += 1024) {
+            const float4 x = *reinterpret_cast<const float4*>(row + v);
+            topk_insert<K>(s, ix, (lps + ((x.x - mx) - lse)) / pen, base + v);
+            topk_insert<K>(s, ix, (lps + ((x.y - mx) - lse)) / pen, base + v + 1);
+            topk_insert<K>(s, ix, (lps + ((x.z - mx) - lse)) / pen, base + v + 2);
+            topk_insert<K>(s, ix, (lps + ((x.w - mx) - lse)) / pen, base + v + 3);
+        }
+        for (int v = end4 + tid; v < end; v += 256)
+            topk_insert<K>(s, ix, (lps + ((row[v] - mx) - lse)) / pen, base + v);
+    } else {
+        for (int v = beg + tid; v < end; v += 256)
+            topk_insert<K>(s, ix, (lps + ((row[v] - mx) - lse)) / pen, base + v);
     }
+    topk_wave_merge<K>(s, ix);
+    if (lane == 0) {
 #pragma unroll
-    for (int p = 0; p < K; ++p) { shs[tid * K + p] = s[p]; shi[tid * K + p] = ix[p]; }
+        for (int p = 0; p < K; ++p) { shs[wave * K + p] = s[p]; shi[wave * K + p] = ix[p]; }
+    }
     __syncthreads();
-    // tree merge of sorted lists
-    for (int stride = 128; stride > 0; stride >>= 1) {
-        if (tid < stride) {
-            float ms[K];
-            int mi[K];
-            int pa = 0, pb = 0;
-            const float* sa = shs + tid * K;
-            const int* ia = shi + tid * K;
-            const float* sb = shs + (tid + stride) * K;
-            const int* ib = shi + (tid + stride) * K;
-#pragma unroll
-            for (int p = 0; p < K; ++p) {
-                const bool takea = cand_better(sa[pa], ia[pa], sb[pb], ib[pb]);
-                ms[p] = takea ? sa[pa] : sb[pb];
-                mi[p] = takea ? ia[pa] : ib[pb];
-                pa += takea ? 1 : 0;
-                pb += takea ? 0 : 1;
-            }
-#pragma unroll
-            for (int p = 0; p < K; ++p) { s[p] = ms[p]; ix[p] = mi[p]; }
-        }
-        __syncthreads();
-        if (tid < stride) {
-#pragma unroll
-            for (int p = 0; p < K; ++p) { shs[tid * K + p] = s[p]; shi[tid * K + p] = ix[p]; }
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
+    if (wave == 0) {
 #pragma unroll
         for (int p = 0; p < K; ++p) {
-            part_score[((long)b * nslice + slice) * K + p] = shs[p];
-            part_idx[((long)b * nslice + slice) * K + p] = shi[p];
+            s[p] = lane < 4 ? shs[lane * K + p] : -INFINITY;
+            ix[p] = lane < 4 ? shi[lane * K + p] : 0x7fffffff;
+        }
+        topk_wave_merge<K>(s, ix);
+        if (lane == 0) {
+#pragma unroll
+            for (int p = 0; p < K; ++p) {
+                part_score[((long)r * ns + slice) * K + p] = s[p];
+                part_idx[((long)r * ns + slice) * K + p] = ix[p];
+            }
         }
     }
 }
 
+// Stage 2: one wave per sentence merges its k*ns slice lists (lanes take lists round-robin, butterfly
+// merge), then lanes 0..k-1 emit word / beam ids and the gathered search state.
 template <int K>
-__global__ void beam_topk_final(const float* __restrict__ logits, long ldx, int V, int k,
+__global__ __launch_bounds__(64) void beam_topk_final(const float* __restrict__ logits, long ldx, int V, int k,
                                 const float* __restrict__ rmax, const float* __restrict__ rlse,
                                 const float* __restrict__ logprob_sum, const int* __restrict__ lengths,
                                 const int* __restrict__ finished, const float* __restrict__ penalty,
@@ -321,25 +365,39 @@ __global__ void beam_topk_final(const float* __restrict__ logits, long ldx, int 
                                 float* __restrict__ out_logprob_sum, int* __restrict__ out_lengths,
                                 int* __restrict__ out_finished, int* __restrict__ out_src_row,
                                 int* __restrict__ all_finished) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+    __shared__ float fs[K];
+    __shared__ int fi[K];
+    const int b = blockIdx.x, lane = threadIdx.x;
     float s[K];
     int ix[K];
 #pragma unroll
     for (int p = 0; p < K; ++p) { s[p] = -INFINITY; ix[p] = 0x7fffffff; }
-    for (int sl = 0; sl < nslice; ++sl)
-        for (int p = 0; p < K; ++p)
-            topk_insert<K>(s, ix, part_score[((long)b * nslice + sl) * K + p],
-                           part_idx[((long)b * nslice + sl) * K + p]);
-    for (int p = 0; p < k; ++p) {
-        const int flat = ix[p];
+    for (int sl = lane; sl < nslice; sl += 64) {
+        float os[K];
+        int oi[K];
+#pragma unroll
+        for (int p = 0; p < K; ++p) {
+            os[p] = part_score[((long)b * nslice + sl) * K + p];
+            oi[p] = part_idx[((long)b * nslice + sl) * K + p];
+        }
+        topk_merge_regs<K>(s, ix, os, oi);
+    }
+    topk_wave_merge<K>(s, ix);
+    if (lane == 0) {
+#pragma unroll
+        for (int p = 0; p < K; ++p) { fs[p] = s[p]; fi[p] = ix[p]; }
+    }
+    __syncthreads();
+    if (lane < k) {
+        const int p = lane;
+        const int flat = fi[p];
         const int j = flat / V, v = flat - j * V;
         const int r = b * k + j;
         float hyp;
         beam_score(logits, ldx, V, k, b, flat, rmax, rlse, logprob_sum, lengths, finished, penalty, &hyp);
         const int fin = finished[r];
         const int o = b * k + p;
-        out_score[o] = s[p];
+        out_score[o] = fs[p];
         out_word[o] = v;
         out_beam[o] = j;
         out_logprob_sum[o] = hyp;
@@ -372,19 +430,22 @@ extern "C" int nm_beam_topk_step(void* stream, const float* logits, int64_t ldx,
                "nm_beam_topk_step: bad shape B=%ld k=%ld V=%ld", (long)B, (long)k, (long)V);
     NM_REQUIRE(k * V >= k, "nm_beam_topk_step: fewer candidates than beam");
     NM_REQUIRE(workspace_bytes >= nm_beam_workspace_bytes(B, k, V), "nm_beam_topk_step: workspace too small");
-    // slices so that B*nslice fills the chip; each slice >= 4096 candidates
-    int nslice = (int)((k * V + 16383) / 16384);
-    if (nslice < 1) nslice = 1;
-    if (nslice > 64) nslice = 64;
+    // ns slices per hypothesis row (>= 4096 candidates each, k*ns <= 64 lists per sentence)
+    int ns = (int)((V + 4095) / 4096);
+    if (ns < 1) ns = 1;
+    if (ns > 64 / k) ns = (int)(64 / k);
+    const int per = (int)((((V + ns - 1) / ns) + 3) & ~3L);          // multiple of 4: float4 loads stay aligned
+    const int nslice = (int)(k * ns);                                 // lists per sentence, contiguous
+    NM_REQUIRE(B * k <= 65535, "nm_beam_topk_step: too many hypothesis rows");
     float* ps = reinterpret_cast<float*>(workspace);
     int* pi = reinterpret_cast<int*>(ps + B * 64 * BEAM_MAX_K);
     hipStream_t st = nm_stream(stream);
-    dim3 grid(nslice, (unsigned)B);
+    dim3 grid(ns, (unsigned)(B * k));
 #define NM_BK(K_)                                                                                   \
     do {                                                                                            \
         hipLaunchKernelGGL((beam_topk_partial<K_>), grid, dim3(256), 0, st, logits, (long)ldx, (int)V, \
-                           (int)k, rmax, rlse, logprob_sum, lengths, finished, penalty, ps, pi, nslice); \
-        hipLaunchKernelGGL((beam_topk_final<K_>), dim3(nm_cdiv(B, 64)), dim3(64), 0, st, logits,     \
+                           (int)k, rmax, rlse, logprob_sum, lengths, finished, penalty, ps, pi, ns, per); \
+        hipLaunchKernelGGL((beam_topk_final<K_>), dim3((unsigned)B), dim3(64), 0, st, logits,         \
                            (long)ldx, (int)V, (int)k, rmax, rlse, logprob_sum, lengths, finished,    \
                            penalty, ps, pi, nslice, (int)B, end_id, out_score, out_word, out_beam,   \
                            out_logprob_sum, out_lengths, out_finished, out_src_row, all_finished);   \

@@ -115,7 +115,9 @@ class BeamSearchDecoder(ModelPart):
         i32 = lambda name, shape, **kw: ctx.buffer(key + (name,), shape, torch.int32, **kw)
 
         stepper = dec.make_stepper(ctx, rows, "beam", k, max_positions=max_steps + 1)
-        emb = f32("emb", (rows, e))
+        emb = getattr(stepper, "emb_view", None)          # embed straight into the stepper's input slot
+        if emb is None:
+            emb = f32("emb", (rows, e))
         out_state = f32("out", (rows, dec.output_dimension))
         logits = f32("logits", (rows, v))
         rmax, rlse = f32("rmax", (rows,)), f32("rlse", (rows,))
@@ -143,37 +145,63 @@ class BeamSearchDecoder(ModelPart):
         go = i32("go", (rows,))
         go.fill_(START_TOKEN_INDEX)
         dec.embed_input_symbols(ctx, go, out=emb)
-        att_states = stepper.step(emb, att_states, out_state, logits, finished=fin[0].view(rows))
+        fast = getattr(stepper, "graph_safe", False)      # steps keep no Python-side state: HIP-graph capturable
+        att0 = att_states
+        from ..attention.base_attention import AttentionLoopState
+        att_at = lambda i: [AttentionLoopState(a.contexts, a.weights, i) for a in att0]
+        if fast:
+            stepper.step(emb, att_at(0), out_state, logits, h_prev=hsel, h_out=stepper.hbuf[0])
+        else:
+            att_states = stepper.step(emb, att_states, out_state, logits, finished=fin[0].view(rows))
         ops.row_stats(logits, rmax, rlse, argmax)
         tok[0, 0].copy_(argmax)                           # parent's greedy symbol, dropped by the runner
         lps[0].fill_(-INF)
         lps[0, :, 0] = 0.0
         lens[0].zero_()
-        cur = 0
-        steps = 0                                         # executed beam bodies
-        # ---- loop (:330-355 criterion, :394-556 body)
-        while steps < max_steps:
-            nxt = cur ^ 1
+        srcf, wordf = src.view(rows), word.view(rows)
+        loop = {"att": att_states}
+
+        def body(s):
+            """Beam body number s (:394-556); every buffer it touches is a function of s alone."""
+            cur, nxt = s & 1, (s & 1) ^ 1
             ops.beam_topk_step(logits, bsz, k, rmax, rlse, lps[cur], lens[cur], fin[cur], penalty,
                                END_TOKEN_INDEX, scores, word, beam, lps[nxt], lens[nxt], fin[nxt], src, ws,
-                               allfin[steps:steps + 1])
-            srcf, wordf = src.view(rows), word.view(rows)
-            stepper.reorder(srcf)                                                # :503-532
-            ops.beam_reorder_tokens(tok[cur], srcf, wordf, tok[nxt], steps + 1, rows)   # :546-551
+                               allfin[s:s + 1])
+            if fast:
+                ops.gather_rows(stepper.hbuf[cur], srcf, stepper.sel)            # :503-532
+            else:
+                stepper.reorder(srcf)
+            ops.beam_reorder_tokens(tok[cur], srcf, wordf, tok[nxt], s + 1, rows)    # :546-551
             dec.embed_input_symbols(ctx, wordf, out=emb)                         # :507-510
-            att_states = stepper.step(emb, att_states, out_state, logits,
-                                      finished=fin[nxt].view(rows))              # :534-535
+            if fast:
+                stepper.step(emb, att_at(s + 1), out_state, logits, h_prev=stepper.sel,
+                             h_out=stepper.hbuf[nxt])                            # :534-535
+            else:
+                loop["att"] = stepper.step(emb, loop["att"], out_state, logits, finished=fin[nxt].view(rows))
             ops.row_stats(logits, rmax, rlse, None)                              # :537-543
-            cur = nxt
-            steps += 1
-            if steps % CHECK_EVERY == 0 or steps == max_steps:
-                done = np.nonzero(allfin[:steps].cpu().numpy())[0]
-                if done.size:
-                    true_steps = int(done[0]) + 1
-                    # bodies past ``true_steps`` leave the (all finished) search state unchanged
-                    # and only append <pad> rows, which are cropped here
-                    steps_run, steps = steps, true_steps
-                    break
+
+        shape_key = tuple(tuple(a.weights.shape) for a in att0)
+        steps = executed = 0
+        # ---- loop (:330-355 criterion, :394-556 body); the host checks the finished flags between chunks
+        while steps < max_steps:
+            s0, n = steps, min(CHECK_EVERY, max_steps - steps)
+
+            def chunk(s0=s0, n=n):
+                for s in range(s0, s0 + n):
+                    body(s)
+            if fast:
+                ctx.session.graphed(key + ("chunk", s0, n, k, v, shape_key), chunk)
+            else:
+                chunk()
+            steps += n
+            executed = steps
+            done = np.nonzero(allfin[:steps].cpu().numpy())[0]
+            if done.size:
+                # bodies past the first all-finished one leave the search state unchanged and only
+                # append <pad> rows, which are cropped here
+                steps = int(done[0]) + 1
+                break
+        cur = executed & 1                                # buffers the last executed body wrote
         token_ids = tok[cur, :steps + 1].view(steps + 1, bsz, k)
         prev_logprobs = None
         search_state = SearchState(lps[cur], prev_logprobs, lens[cur], fin[cur])

@@ -425,31 +425,53 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
         logits_all = ctx.buffer(key + ("logits_all",), (tmax, bsz, v)) if keep_logits else None
         logits_one = ctx.buffer(key + ("logits",), (bsz, v))
         xent_rows = ctx.buffer(key + ("xent_rows",), (tmax, bsz), zero=True) if has_tgt else None
-        emb = ctx.buffer(key + ("emb",), (2, bsz, e))
         stepper = make_stepper(self, ctx, bsz, "greedy")
         stepper.start(s0)
+        emb = stepper.emb_view                      # the step input is embedded straight into the stepper
         att_states = [a.initial_loop_state(ctx, bsz, tmax) for a in self.attentions]
 
         go = ctx.buffer(key + ("go",), (bsz,), torch.int32)
         go.fill_(START_TOKEN_INDEX)
-        self.embed_input_symbols(ctx, go, out=emb[0])
-        steps = 0
-        while steps < tmax:
-            t = steps
+        self.embed_input_symbols(ctx, go, out=emb)
+        att0 = att_states
+        graph_ok = getattr(stepper, "graph_safe", False)
+        for att in self.attentions:          # evaluate lazily built tensors (H2D copies) outside the captured region
+            att.hidden_features(ctx)
+            att.attention_mask(ctx)
+        self.decoding_bias(ctx)
+        t_xent = min(t_target, tmax) if has_tgt else 0
+
+        def body(t):
+            """Step t touches persistent buffers only and depends on nothing but t (graph capturable)."""
             logits = logits_all[t] if keep_logits else logits_one
-            att_states = stepper.step(emb[t & 1], att_states, out_all[t], logits, h_out=s_all[t])
+            st_t = [AttentionLoopState(st.contexts, st.weights, t) for st in att0]
+            if graph_ok:
+                stepper.step(emb, st_t, out_all[t], logits, h_out=s_all[t], h_prev=s0 if t == 0 else s_all[t - 1])
+            else:
+                stepper.step(emb, st_t, out_all[t], logits, h_out=s_all[t])
             ops.row_stats(logits, None, None, argmax)
-            if has_tgt and t < t_target:
+            if t < t_xent:
                 ops.xent(logits, tgt[t], tmask[t], xent_rows[t])
             ops.greedy_update(argmax, finished, symbols[t], omask[t], END_TOKEN_INDEX, allfin[t:t + 1])
-            self.embed_input_symbols(ctx, symbols[t], out=emb[(t + 1) & 1])
-            steps += 1
-            if steps % CHECK_EVERY == 0 or steps == tmax:
-                flags = allfin[:steps].cpu().numpy()
-                done = np.nonzero(flags)[0]
-                if done.size:                      # loop ends after the first all-finished step
-                    steps = int(done[0]) + 1
-                    break
+            self.embed_input_symbols(ctx, symbols[t], out=emb)
+
+        shape_key = tuple(tuple(st.weights.shape) for st in att0)
+        steps = 0
+        while steps < tmax:
+            t0, n = steps, min(CHECK_EVERY, tmax - steps)
+
+            def chunk(t0=t0, n=n):
+                for t in range(t0, t0 + n):
+                    body(t)
+            if graph_ok:      # the host only looks at the finished flags between chunks of steps
+                ctx.session.graphed(key + ("chunk", t0, n, bsz, t_xent, shape_key), chunk)
+            else:
+                chunk()
+            steps += n
+            done = np.nonzero(allfin[:steps].cpu().numpy())[0]
+            if done.size:                          # loop ends after the first all-finished step
+                steps = int(done[0]) + 1
+                break
         xent_sum = None
         if has_tgt:
             xent_sum = ctx.buffer(key + ("xent_sum",), (1,))

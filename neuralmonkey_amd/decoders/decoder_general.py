@@ -171,28 +171,74 @@ class GeneralDecoderMixin:
 
 
 class FastStepper:
-    """Inference steps of the plain TF-GRU decoder: fused GRU GEMM epilogues + fused attention."""
+    """Inference steps of the plain TF-GRU decoder, 6 GEMM launches per step:
+
+        xp     = emb . [Wg_x | Wc_x] + [bg | bc]      one GEMM over a fused copy of the input halves
+        h      = GRU(xp, h_prev)                      two skinny MFMA GEMMs with gate / blend epilogues
+        ctx    = attention(h)                         query GEMM + fused Bahdanau kernel
+        out    = tanh([h | emb | ctx] . Wo + bo)      one GEMM: the three producers write side by side
+        logits = out . W + b
+
+    ``emb_view`` is where the caller embeds the step's input symbols.  A step touches persistent
+    buffers only and keeps no Python-side state when ``h_prev`` / ``h_out`` are passed explicitly, so
+    runs of steps can be captured into HIP graphs (``graph_safe``)."""
+    graph_safe = True
 
     def __init__(self, dec, ctx, rows: int, tag: str):
-        self.dec, self.ctx = dec, ctx
+        self.dec, self.ctx, self.rows = dec, ctx, rows
         self.cell = dec._cell(ctx)                        # pylint: disable=protected-access
         self.bufs = dec._step_bufs(ctx, rows)             # pylint: disable=protected-access
-        h = dec.rnn_size
-        self.hbuf = ctx.buffer((id(dec), tag, "h", rows), (2, rows, h))
-        self.sel = ctx.buffer((id(dec), tag, "hsel", rows), (rows, h))
+        e, h = dec.embedding_size, dec.rnn_size
+        csz = [a.context_vector_size for a in dec.attentions]
+        key = (id(dec), tag, rows)
+        self.hbuf = ctx.buffer(key + ("h",), (2, rows, h))
+        self.sel = ctx.buffer(key + ("hsel",), (rows, h))
+        self.cat = ctx.buffer(key + ("cat",), (rows, h + e + sum(csz)))      # [h | emb | ctx...]
+        self.emb_view = self.cat[:, h:h + e]
+        self.ctx_views, col = [], h + e
+        for c in csz:
+            self.ctx_views.append(self.cat[:, col:col + c])
+            col += c
+        self.y = [ctx.buffer(key + ("y", i), (rows, a.state_size)) for i, a in enumerate(dec.attentions)]
+        # fused input halves of the two GRU kernels (weights are constant during a decoding run)
+        cell = self.cell
+        self.w_in = ctx.buffer(key + ("w_in",), (e, 3 * h))
+        self.b_in = ctx.buffer(key + ("b_in",), (3 * h,))
+        ops.copy_cols(cell["wg_x"], self.w_in[:, :2 * h])
+        ops.copy_cols(cell["wc_x"], self.w_in[:, 2 * h:])
+        self.b_in[:2 * h].copy_(cell["bg"])
+        self.b_in[2 * h:].copy_(cell["bc"])
         self.cur = 0
         self.src = None
 
     def start(self, s0: torch.Tensor) -> None:
         self.src = s0
 
-    def step(self, emb, att_states, out_state, logits, h_out: Optional[torch.Tensor] = None, finished=None):
+    def step(self, emb, att_states, out_state, logits, h_out: Optional[torch.Tensor] = None, finished=None,
+             h_prev: Optional[torch.Tensor] = None):
+        from ..attention.base_attention import AttentionLoopState
+        from ..nn import gru
+        dec, ctx, rows = self.dec, self.ctx, self.rows
+        h = dec.rnn_size
         nxt = self.cur ^ 1
         dst = h_out if h_out is not None else self.hbuf[nxt]
-        att_states = self.dec.full_step(self.ctx, self.cell, emb, self.src, dst, att_states, out_state, logits,
-                                        self.bufs)
+        if h_prev is not None:
+            self.src = h_prev
+        if emb.data_ptr() != self.emb_view.data_ptr():           # caller used its own buffer
+            ops.copy_cols(emb, self.emb_view)
+        bufs = self.bufs
+        xp = ops.gemm(self.emb_view, self.w_in, out=bufs["xp"], bias=self.b_in)
+        ld = self.cat.stride(0)
+        gru.step_fwd(xp, (0, 3 * h, 0), self.src, dst, self.cell["wg_h"], self.cell["wc_h"], bufs["ru"], bufs["rh"],
+                     None, self.cat, (0, ld, 0), None, 0, 1, rows, h, False, bufs["hg"], bufs["hc"])
+        new_states = []
+        for att, st, y, cview in zip(dec.attentions, att_states, self.y, self.ctx_views):
+            att.attention_into(ctx, dst, y, cview, st.weights[st.step])
+            new_states.append(AttentionLoopState(st.contexts, st.weights, st.step + 1))
+        dec.output_projection.apply_concat(ctx, dec, self.cat, out_state)
+        dec.state_to_logits(ctx, out_state, logits)
         self.cur, self.src = nxt, dst
-        return att_states
+        return new_states
 
     def reorder(self, src_rows: torch.Tensor) -> None:
         ops.gather_rows(self.src, src_rows, self.sel)
@@ -201,6 +247,7 @@ class FastStepper:
 
 class GeneralStepper:
     """Inference steps of any other decoder configuration (non-recording tape)."""
+    graph_safe = False          # the carried state is a chain of Python-side Vars
 
     def __init__(self, dec, ctx, rows: int, tag: str):
         self.dec, self.ctx, self.rows = dec, ctx, rows
@@ -210,6 +257,7 @@ class GeneralStepper:
                     for i, sz in enumerate(dec.state_sizes())]
         self.zero_ctx = [ctx.buffer((id(dec), tag, "ctx0", rows, i), (rows, a.context_vector_size), zero=True)
                          for i, a in enumerate(dec.attentions)]
+        self.emb_view = ctx.buffer((id(dec), tag, "emb", rows), (rows, dec.embedding_size))
         self.base = self.tape._n                          # pylint: disable=protected-access
         self.t = 0
         self.state = None
@@ -219,7 +267,8 @@ class GeneralStepper:
         self.state = [tape.leaf(s0), tape.leaf(s0)] + [tape.leaf(z) for z in self.zero_ctx]
         self.t = 0
 
-    def step(self, emb, att_states, out_state, logits, h_out: Optional[torch.Tensor] = None, finished=None):
+    def step(self, emb, att_states, out_state, logits, h_out: Optional[torch.Tensor] = None, finished=None,
+             h_prev=None):
         from ..attention.base_attention import AttentionLoopState
         tape, dec = self.tape, self.dec
         tape._n, tape._slot = self.base, self.t & 1       # recycle this parity's step buffers

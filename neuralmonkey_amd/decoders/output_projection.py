@@ -93,6 +93,12 @@ class NonlinearOutput(OutputProjection):
             row += sz
         return out
 
+    def apply_concat(self, ctx, decoder, concat, out):
+        """The same projection when the producers already wrote [state | prev_output | ctx...]
+        side by side into ``concat`` [R, sum(sizes)]: one GEMM with the activation in its epilogue."""
+        return ops.gemm(concat, self.kernel(ctx, decoder), out=out, bias=self.bias(ctx, decoder),
+                        act=self.activation if self.activation != "identity" else None)
+
     def apply_var(self, tape, decoder, state, prev_output, ctx_vars, train_mode, salt):
         pre = _dense_blocks(tape, decoder, self.scope, [state, prev_output] + list(ctx_vars), self.sizes)
         return self._dropout(tape, F.ACTIVATIONS[self.activation](tape, pre), train_mode, salt)

@@ -186,3 +186,34 @@ def test_ini_experiment_trains_and_decodes(dev, tmp_path):
     assert [len(r.outputs[s]) for r, s in zip(results, ("target", "target_beam.rank001", "target_beam.rank002"))] \
         == [4, 4, 4]
     assert all("<unk>" not in sent for sent in results[0].outputs["target"])       # supress_unk
+
+
+def test_decode_graph_replay_matches_eager_on_fresh_batches(dev):
+    """Greedy and beam decoding capture their step chunks into HIP graphs (eager -> capture ->
+    replay).  Five different batches of the same shape: every pass, replayed ones included, must
+    reproduce the oracle on its own batch (no stale pointers baked into the graphs)."""
+    from neuralmonkey_amd import synthetic
+    vocab, emb, rnn, batch, slen = 120, 16, 16, 6, 9
+    model = synthetic.build_translation_model(vocab_src=vocab, vocab_tgt=vocab, emb=emb, rnn=rnn, max_len=12,
+                                              beam_size=3, max_steps=12, device=str(dev), with_trainer=False)
+    params = O.init_params(seed=21, vocab_src=vocab, vocab_tgt=vocab, emb=emb, rnn=rnn, std=0.3)
+    sess = model.tf_manager.sessions[0]
+    sess.store.load_state_dict(params)
+    assert sess.use_graphs
+    spec = O.DecoderSpec(max_output_len=12)
+    for i in range(5):
+        ds = synthetic.synthetic_dataset(seed=100 + i, batch=batch, src_len=slen, tgt_len=slen, vocab=vocab,
+                                         ragged=True, with_target=False)
+        src = O.pad_ids([list(s) for s in ds.get_series("source")], 12)
+        enc = O.sentence_encoder(params, src)
+        want = O.greedy_tokens(O.decoding_loop(params, spec, enc, None, False))
+        res = model.tf_manager.execute(ds, model.greedy_runner.feedables | model.beam_runner.feedables,
+                                       [model.greedy_runner, model.beam_runner], compute_losses=False)
+        w2i = model.tgt_vocab._word_to_index
+        got = [[w2i[w] for w in sent] for sent in res[0].outputs["target"]]
+        assert got == want, "greedy mismatch on pass {}".format(i)
+        bres = O.beam_search(params, spec, enc, 3, 12, 0.6)
+        want_beam, _ = O.beam_tokens(bres, 1)
+        got_beam = [[w2i[w] for w in sent] for sent in res[1].outputs["target_beam"]]
+        if bres.min_gap > 1e-5:
+            assert got_beam == want_beam, "beam mismatch on pass {}".format(i)
