@@ -144,6 +144,15 @@ int nm_beam_topk_step(void* stream, const float* logits, int64_t ldx, int64_t B,
                       float* out_score, int32_t* out_word, int32_t* out_beam, float* out_logprob_sum,
                       int32_t* out_lengths, int32_t* out_finished, int32_t* out_src_row, void* workspace,
                       int64_t workspace_bytes, int32_t* all_finished);
+/* the same step on the raw logits of the previous parent step: max / lse / candidates of every row come
+ * from ONE register-resident scan of the row (no separate nm_row_stats pass); rmax_out / rlse_out
+ * [B*k] receive the row statistics */
+int nm_beam_topk_step_fused(void* stream, const float* logits, int64_t ldx, int64_t B, int64_t k, int64_t V,
+                            const float* logprob_sum, const int32_t* lengths, const int32_t* finished,
+                            const float* penalty, int end_id, float* out_score, int32_t* out_word,
+                            int32_t* out_beam, float* out_logprob_sum, int32_t* out_lengths,
+                            int32_t* out_finished, int32_t* out_src_row, void* workspace,
+                            int64_t workspace_bytes, int32_t* all_finished, float* rmax_out, float* rlse_out);
 int nm_gather_rows_f32(void* stream, const float* src, int64_t ld_src, const int32_t* idx, float* dst,
                        int64_t ld_dst, int64_t rows, int64_t width);
 int nm_beam_reorder_tokens(void* stream, const int32_t* src, const int32_t* src_row, const int32_t* word,

@@ -45,6 +45,7 @@ SIGNATURES = {
     "nm_xent": (I, [P, P, L, L, L, P, P, P, P, I]),
     "nm_beam_workspace_bytes": (L, [L, L, L]),
     "nm_beam_topk_step": (I, [P, P, L, L, L, L, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, L, P]),
+    "nm_beam_topk_step_fused": (I, [P, P, L, L, L, L, P, P, P, P, I, P, P, P, P, P, P, P, P, L, P, P, P]),
     "nm_tanh_bwd": (I, [P, P, P, L]),
     "nm_colsum_workspace_bytes": (L, [L]),
     "nm_colsum": (I, [P, P, L, L, L, P, I, P, L]),

@@ -6,6 +6,7 @@
 //   decoders/beam_search_decoder.py:440-501 masking, +logprob_sum, length penalty,
 //                                           tf.nn.top_k over [B, k*V], div/mod, gathers
 #include "nm_common.h"
+#include <stdlib.h>
 
 #define NM_NEG_INF_F (-1e9f)   // the reference's INF (beam_search_decoder.py:42)
 
@@ -83,15 +84,6 @@ __global__ __launch_bounds__(NT) void row_stats_kernel(const float* __restrict__
         if (lse_out) lse_out[row] = logf(s);
         if (argmax_out) argmax_out[row] = bi;
     }
-}
-
-extern "C" int nm_row_stats(void* stream, const float* x, int64_t ldx, int64_t rows, int64_t V,
-                            float* max_out, float* lse_out, int32_t* argmax_out) {
-    NM_REQUIRE(x && rows >= 0 && V > 0 && ldx >= V, "nm_row_stats: bad args");
-    if (rows == 0) return NM_OK;
-    hipLaunchKernelGGL((row_stats_kernel<1024>), dim3((unsigned)rows), dim3(1024), 0, nm_stream(stream),
-                       x, (long)ldx, (int)V, max_out, lse_out, argmax_out);
-    NM_LAUNCH_CHECK("nm_row_stats");
 }
 
 // ---------------------------------------------------------------------------
@@ -409,6 +401,136 @@ __global__ __launch_bounds__(64) void beam_topk_final(const float* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Register-resident row scan: one 1024-thread workgroup per row loads the whole row ONCE (up to NV
+// float4 per thread, all loads issued before the first use), and from registers derives max /
+// first argmax / lse and -- for the beam -- the row's K best candidates with the exact scores.
+// One HBM pass instead of the three of row_stats (2) + top-k (1): at B*k = 640 rows of 32000 logits
+// that is 82 MB read once.
+// ---------------------------------------------------------------------------------------------
+template <int K, int NV, bool TOPK>
+__global__ __launch_bounds__(1024) void row_scan_kernel(const float* __restrict__ x, long ldx, int V,
+                                                        float* __restrict__ max_out, float* __restrict__ lse_out,
+                                                        int* __restrict__ argmax_out, int k,
+                                                        const float* __restrict__ logprob_sum,
+                                                        const int* __restrict__ lengths,
+                                                        const int* __restrict__ finished,
+                                                        const float* __restrict__ penalty,
+                                                        float* __restrict__ part_score, int* __restrict__ part_idx) {
+    __shared__ float shv[16];
+    __shared__ int shi[16];
+    __shared__ float shs[16 * K];
+    __shared__ int shx[16 * K];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int base = TOPK ? (r % k) * V : 0;
+    if (TOPK && finished[r]) {
+        // finished hypothesis: lp = 0 for <pad>, -1e9 otherwise (:444-456): the K lowest ids win, no scan
+        if (tid < K) {
+            const float pen = penalty[lengths[r]];
+            const float lp = (tid == 0) ? 0.0f : NM_NEG_INF_F;
+            part_score[(long)r * K + tid] = tid < V ? (logprob_sum[r] + lp) / pen : -INFINITY;
+            part_idx[(long)r * K + tid] = tid < V ? base + tid : 0x7fffffff;
+        }
+        return;
+    }
+    const float4* x4 = reinterpret_cast<const float4*>(x + (long)r * ldx);
+    const int V4 = V >> 2;
+    float4 xv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int q = tid + i * 1024;
+        xv[i] = q < V4 ? x4[q] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    }
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {          // ascending element order within the thread: first max kept
+        const int e = (tid + i * 1024) * 4;
+        if (xv[i].x > bv) { bv = xv[i].x; bi = e; }
+        if (xv[i].y > bv) { bv = xv[i].y; bi = e + 1; }
+        if (xv[i].z > bv) { bv = xv[i].z; bi = e + 2; }
+        if (xv[i].w > bv) { bv = xv[i].w; bi = e + 3; }
+    }
+    block_argmax<1024>(bv, bi, shv, shi);
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        sum += expf(xv[i].x - bv) + expf(xv[i].y - bv) + expf(xv[i].z - bv) + expf(xv[i].w - bv);
+    sum = block_sum<1024>(sum, shv);
+    const float lse = logf(sum);
+    if (tid == 0) {
+        if (max_out) max_out[r] = bv;
+        if (lse_out) lse_out[r] = lse;
+        if (argmax_out) argmax_out[r] = bi;
+    }
+    if (!TOPK) return;
+    const float lps = logprob_sum[r];
+    const float pen = penalty[lengths[r] + 1];
+    float s[K];
+    int ix[K];
+#pragma unroll
+    for (int p = 0; p < K; ++p) { s[p] = -INFINITY; ix[p] = 0x7fffffff; }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int q = tid + i * 1024;
+        if (q < V4) {
+            const int e = base + q * 4;
+            topk_insert<K>(s, ix, (lps + ((xv[i].x - bv) - lse)) / pen, e);
+            topk_insert<K>(s, ix, (lps + ((xv[i].y - bv) - lse)) / pen, e + 1);
+            topk_insert<K>(s, ix, (lps + ((xv[i].z - bv) - lse)) / pen, e + 2);
+            topk_insert<K>(s, ix, (lps + ((xv[i].w - bv) - lse)) / pen, e + 3);
+        }
+    }
+    topk_wave_merge<K>(s, ix);
+    if (lane == 0) {
+#pragma unroll
+        for (int p = 0; p < K; ++p) { shs[wave * K + p] = s[p]; shx[wave * K + p] = ix[p]; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int p = 0; p < K; ++p) {
+            s[p] = lane < 16 ? shs[lane * K + p] : -INFINITY;
+            ix[p] = lane < 16 ? shx[lane * K + p] : 0x7fffffff;
+        }
+        topk_wave_merge<K>(s, ix);
+        if (lane == 0) {
+#pragma unroll
+            for (int p = 0; p < K; ++p) { part_score[(long)r * K + p] = s[p]; part_idx[(long)r * K + p] = ix[p]; }
+        }
+    }
+}
+
+// rows whose length fits the register file of one workgroup and whose float4 view is aligned
+static inline int row_scan_nv(const float* x, int64_t ldx, int64_t V) {
+    if ((V & 3) || (ldx & 3) || !nm_aligned16(x)) return 0;
+    const int64_t v4 = V >> 2;
+    if (v4 <= 8 * 1024) return 8;
+    if (v4 <= 16 * 1024) return 16;
+    if (v4 <= 32 * 1024) return 32;
+    return 0;
+}
+
+extern "C" int nm_row_stats(void* stream, const float* x, int64_t ldx, int64_t rows, int64_t V,
+                            float* max_out, float* lse_out, int32_t* argmax_out) {
+    NM_REQUIRE(x && rows >= 0 && V > 0 && ldx >= V, "nm_row_stats: bad args");
+    if (rows == 0) return NM_OK;
+    const int nv = row_scan_nv(x, ldx, V);
+#define NM_RS(NV_)                                                                                         \
+    hipLaunchKernelGGL((row_scan_kernel<4, NV_, false>), dim3((unsigned)rows), dim3(1024), 0, nm_stream(stream), x, \
+                       (long)ldx, (int)V, max_out, lse_out, argmax_out, 1, (const float*)nullptr,             \
+                       (const int*)nullptr, (const int*)nullptr, (const float*)nullptr, (float*)nullptr,      \
+                       (int*)nullptr)
+    if (nv == 8) NM_RS(8);
+    else if (nv == 16) NM_RS(16);
+    else if (nv == 32) NM_RS(32);
+    else
+        hipLaunchKernelGGL((row_stats_kernel<1024>), dim3((unsigned)rows), dim3(1024), 0, nm_stream(stream),
+                           x, (long)ldx, (int)V, max_out, lse_out, argmax_out);
+#undef NM_RS
+    NM_LAUNCH_CHECK("nm_row_stats");
+}
+
 extern "C" int64_t nm_beam_workspace_bytes(int64_t B, int64_t k, int64_t V) {
     (void)k; (void)V;
     return B * 64 * BEAM_MAX_K * 8 + 256;
@@ -431,7 +553,8 @@ extern "C" int nm_beam_topk_step(void* stream, const float* logits, int64_t ldx,
     NM_REQUIRE(k * V >= k, "nm_beam_topk_step: fewer candidates than beam");
     NM_REQUIRE(workspace_bytes >= nm_beam_workspace_bytes(B, k, V), "nm_beam_topk_step: workspace too small");
     // ns slices per hypothesis row (>= 4096 candidates each, k*ns <= 64 lists per sentence)
-    int ns = (int)((V + 4095) / 4096);
+    static const int ns_env = getenv("NM_BEAM_NS") ? atoi(getenv("NM_BEAM_NS")) : 0;     // tuning override
+    int ns = ns_env > 0 ? ns_env : (int)((V + 4095) / 4096);
     if (ns < 1) ns = 1;
     if (ns > 64 / k) ns = (int)(64 / k);
     const int per = (int)((((V + ns - 1) / ns) + 3) & ~3L);          // multiple of 4: float4 loads stay aligned
@@ -454,6 +577,54 @@ extern "C" int nm_beam_topk_step(void* stream, const float* logits, int64_t ldx,
     else NM_BK(8);
 #undef NM_BK
     NM_LAUNCH_CHECK("nm_beam_topk_step");
+}
+
+// The same beam step reading the raw logits of the previous parent step directly: max / lse and the
+// per-row candidates come from one register-resident scan of each row (row_scan_kernel), the second
+// stage merges the k row lists of a sentence.  rmax_out / rlse_out / argmax_out are optional.
+extern "C" int nm_beam_topk_step_fused(void* stream, const float* logits, int64_t ldx, int64_t B, int64_t k,
+                                       int64_t V, const float* logprob_sum, const int32_t* lengths,
+                                       const int32_t* finished, const float* penalty, int end_id,
+                                       float* out_score, int32_t* out_word, int32_t* out_beam,
+                                       float* out_logprob_sum, int32_t* out_lengths, int32_t* out_finished,
+                                       int32_t* out_src_row, void* workspace, int64_t workspace_bytes,
+                                       int32_t* all_finished, float* rmax_out, float* rlse_out) {
+    NM_REQUIRE(logits && logprob_sum && lengths && finished && penalty && out_score && out_word && out_beam &&
+                   out_logprob_sum && out_lengths && out_finished && out_src_row && workspace && rmax_out && rlse_out,
+               "nm_beam_topk_step_fused: null pointer");
+    NM_REQUIRE(B > 0 && k >= 1 && k <= BEAM_MAX_K && V > 0 && k * V < (1L << 31),
+               "nm_beam_topk_step_fused: bad shape B=%ld k=%ld V=%ld", (long)B, (long)k, (long)V);
+    NM_REQUIRE(workspace_bytes >= nm_beam_workspace_bytes(B, k, V), "nm_beam_topk_step_fused: workspace too small");
+    const int nv = row_scan_nv(logits, ldx, V);
+    hipStream_t st = nm_stream(stream);
+    if (nv == 0) {      // unaligned or very long rows: statistics pass + sliced top-k pass
+        hipLaunchKernelGGL((row_stats_kernel<1024>), dim3((unsigned)(B * k)), dim3(1024), 0, st, logits, (long)ldx,
+                           (int)V, rmax_out, rlse_out, (int*)nullptr);
+        return nm_beam_topk_step(stream, logits, ldx, B, k, V, rmax_out, rlse_out, logprob_sum, lengths, finished,
+                                 penalty, end_id, out_score, out_word, out_beam, out_logprob_sum, out_lengths,
+                                 out_finished, out_src_row, workspace, workspace_bytes, all_finished);
+    }
+    float* ps = reinterpret_cast<float*>(workspace);
+    int* pi = reinterpret_cast<int*>(ps + B * 64 * BEAM_MAX_K);
+    const unsigned rows = (unsigned)(B * k);
+#define NM_SCAN(K_, NV_)                                                                                       \
+    hipLaunchKernelGGL((row_scan_kernel<K_, NV_, true>), dim3(rows), dim3(1024), 0, st, logits, (long)ldx, (int)V, \
+                       rmax_out, rlse_out, (int*)nullptr, (int)k, logprob_sum, lengths, finished, penalty, ps, pi)
+#define NM_FUSED(K_)                                                                                           \
+    do {                                                                                                       \
+        if (nv == 8) NM_SCAN(K_, 8);                                                                           \
+        else if (nv == 16) NM_SCAN(K_, 16);                                                                    \
+        else NM_SCAN(K_, 32);                                                                                  \
+        hipLaunchKernelGGL((beam_topk_final<K_>), dim3((unsigned)B), dim3(64), 0, st, logits, (long)ldx, (int)V, \
+                           (int)k, rmax_out, rlse_out, logprob_sum, lengths, finished, penalty, ps, pi, (int)k,  \
+                           (int)B, end_id, out_score, out_word, out_beam, out_logprob_sum, out_lengths,         \
+                           out_finished, out_src_row, all_finished);                                           \
+    } while (0)
+    if (k <= 4) NM_FUSED(4);
+    else NM_FUSED(8);
+#undef NM_FUSED
+#undef NM_SCAN
+    NM_LAUNCH_CHECK("nm_beam_topk_step_fused");
 }
 
 // ---------------------------------------------------------------------------

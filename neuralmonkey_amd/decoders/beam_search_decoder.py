@@ -164,9 +164,9 @@ class BeamSearchDecoder(ModelPart):
         def body(s):
             """Beam body number s (:394-556); every buffer it touches is a function of s alone."""
             cur, nxt = s & 1, (s & 1) ^ 1
-            ops.beam_topk_step(logits, bsz, k, rmax, rlse, lps[cur], lens[cur], fin[cur], penalty,
-                               END_TOKEN_INDEX, scores, word, beam, lps[nxt], lens[nxt], fin[nxt], src, ws,
-                               allfin[s:s + 1])
+            ops.beam_topk_step_fused(logits, bsz, k, lps[cur], lens[cur], fin[cur], penalty, END_TOKEN_INDEX,
+                                     scores, word, beam, lps[nxt], lens[nxt], fin[nxt], src, ws, rmax, rlse,
+                                     allfin[s:s + 1])     # log-softmax statistics (:537-543) fused in
             if fast:
                 ops.gather_rows(stepper.hbuf[cur], srcf, stepper.sel)            # :503-532
             else:
@@ -178,7 +178,6 @@ class BeamSearchDecoder(ModelPart):
                              h_out=stepper.hbuf[nxt])                            # :534-535
             else:
                 loop["att"] = stepper.step(emb, loop["att"], out_state, logits, finished=fin[nxt].view(rows))
-            ops.row_stats(logits, rmax, rlse, None)                              # :537-543
 
         shape_key = tuple(tuple(a.weights.shape) for a in att0)
         steps = executed = 0

@@ -238,6 +238,20 @@ def beam_topk_step(logits, b, k, rmax, rlse, logprob_sum, lengths, finished, pen
                "nm_beam_topk_step")
 
 
+def beam_topk_step_fused(logits, b, k, logprob_sum, lengths, finished, penalty, end_id, out_score, out_word,
+                         out_beam, out_logprob_sum, out_lengths, out_finished, out_src_row, workspace, rmax, rlse,
+                         all_finished=None):
+    """One beam body straight from the raw parent logits (row statistics fused into the scan)."""
+    lib = _lib.load()
+    assert logits.dim() == 2 and logits.stride(1) == 1 and logits.shape[0] == b * k
+    _lib.check(lib.nm_beam_topk_step_fused(
+        _stream(), logits.data_ptr(), logits.stride(0), b, k, logits.shape[1], logprob_sum.data_ptr(),
+        lengths.data_ptr(), finished.data_ptr(), penalty.data_ptr(), end_id, out_score.data_ptr(),
+        out_word.data_ptr(), out_beam.data_ptr(), out_logprob_sum.data_ptr(), out_lengths.data_ptr(),
+        out_finished.data_ptr(), out_src_row.data_ptr(), workspace.data_ptr(), workspace.numel() * 4,
+        _p(all_finished), rmax.data_ptr(), rlse.data_ptr()), "nm_beam_topk_step_fused")
+
+
 def gather_rows(src, idx, dst):
     lib = _lib.load()
     assert src.dim() == 2 and dst.dim() == 2 and src.stride(1) == 1 and dst.stride(1) == 1
