@@ -131,8 +131,11 @@ int nm_log_softmax(void* stream, const float* x, int64_t ldx, const float* rmax,
                    float* out, int64_t ldo, int64_t rows, int64_t V);
 int nm_greedy_update(void* stream, const int32_t* argmax, int32_t* finished, int32_t* sym_out,
                      int32_t* mask_out, int64_t n, int end_id, int32_t* all_finished);
+/* label_smoothing eps (decoders/autoregressive.py:292-299, tf.losses.softmax_cross_entropy): the
+ * target distribution is (1-eps)*onehot + eps/V */
 int nm_xent(void* stream, float* logits, int64_t ldx, int64_t rows, int64_t V, const int32_t* targets,
-            const float* weights, float* loss_rows, const float* grad_scale, int write_grad);
+            const float* weights, float* loss_rows, const float* grad_scale, int write_grad,
+            float label_smoothing);
 
 /* ---- beam search step: decoders/beam_search_decoder.py:440-501 (mask, + logprob_sum, length
  * penalty, tf.nn.top_k over [B,k*V] with lower-index-first ties, div/mod, gathers) and the

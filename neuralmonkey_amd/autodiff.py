@@ -405,13 +405,13 @@ def time_sum(tape: Tape, x: Var, bsz: int, steps: int) -> Var:
     return out
 
 
-def xent(tape: Tape, logits: Var, targets: torch.Tensor, weights: torch.Tensor,
-         grad_scale: Optional[torch.Tensor]) -> torch.Tensor:
+def xent(tape: Tape, logits: Var, targets: torch.Tensor, weights: Optional[torch.Tensor],
+         grad_scale: Optional[torch.Tensor], label_smoothing: float = 0.0) -> torch.Tensor:
     """Masked sparse softmax cross entropy per row (autoregressive.py:289-316).  When recording,
     the kernel overwrites the logits with their gradient (scaled by ``grad_scale``), which then
     *is* the gradient buffer of ``logits``."""
     loss_rows = tape.buf((logits.shape[0],))
-    ops.xent(logits.data, targets, weights, loss_rows, grad_scale, tape.recording)
+    ops.xent(logits.data, targets, weights, loss_rows, grad_scale, tape.recording, label_smoothing)
     if tape.recording:
         logits.grad = logits.data
     return loss_rows

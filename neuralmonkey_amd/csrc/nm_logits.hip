@@ -124,14 +124,16 @@ __global__ __launch_bounds__(NT) void xent_kernel(float* __restrict__ x, long ld
                                                   const float* __restrict__ weights,
                                                   float* __restrict__ loss_rows,
                                                   const float* __restrict__ grad_scale,
-                                                  int write_grad) {
-    __shared__ float shm[NT / 64], shs[NT / 64];
+                                                  int write_grad, float smoothing) {
+    __shared__ float shm[NT / 64], shs[NT / 64], shx[NT / 64];
     const long row = blockIdx.x;
     float* xr = x + row * ldx;
-    // one pass over the row: running (max, sum exp(x - max)) per thread, merged pairwise
-    float bv = -INFINITY, s = 0.0f;
+    // one pass over the row: running (max, sum exp(x - max)) per thread, merged pairwise;
+    // label smoothing also needs the plain sum of the logits
+    float bv = -INFINITY, s = 0.0f, sx = 0.0f;
     for (int c = threadIdx.x; c < V; c += NT) {
         const float v = xr[c];
+        sx += v;
         if (v > bv) { s = s * expf(bv - v) + 1.0f; bv = v; }
         else s += expf(v - bv);
     }
@@ -141,36 +143,43 @@ __global__ __launch_bounds__(NT) void xent_kernel(float* __restrict__ x, long ld
         const float mm = fmaxf(bv, om);
         s = (bv == -INFINITY ? 0.0f : s * expf(bv - mm)) + (om == -INFINITY ? 0.0f : os * expf(om - mm));
         bv = mm;
+        sx += __shfl_xor(sx, off, 64);
     }
-    if ((threadIdx.x & 63) == 0) { shm[threadIdx.x >> 6] = bv; shs[threadIdx.x >> 6] = s; }
+    if ((threadIdx.x & 63) == 0) { shm[threadIdx.x >> 6] = bv; shs[threadIdx.x >> 6] = s; shx[threadIdx.x >> 6] = sx; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        float mm = shm[0], ss = shs[0];
+        float mm = shm[0], ss = shs[0], xx = shx[0];
         for (int k = 1; k < NT / 64; ++k) {
             const float om = shm[k], os = shs[k], nm = fmaxf(mm, om);
             ss = (mm == -INFINITY ? 0.0f : ss * expf(mm - nm)) + (om == -INFINITY ? 0.0f : os * expf(om - nm));
             mm = nm;
+            xx += shx[k];
         }
         shm[0] = mm;
         shs[0] = ss;
+        shx[0] = xx;
     }
     __syncthreads();
     bv = shm[0];
     s = shs[0];
+    sx = shx[0];
     const float lse = logf(s);
     const int t = targets[row];
     const float w = weights ? weights[row] : 1.0f;
     if (threadIdx.x == 0 && loss_rows) {
-        const float lp = (t >= 0 && t < V) ? (xr[t] - bv - lse) : 0.0f;
-        loss_rows[row] = -lp * w;
+        // -sum_v q_v log p_v with q = (1-eps)*onehot + eps/V  (tf.losses.softmax_cross_entropy label_smoothing)
+        const float nll = (t >= 0 && t < V) ? -(xr[t] - bv - lse) : 0.0f;
+        const float uniform = (bv + lse) - sx / (float)V;
+        loss_rows[row] = ((1.0f - smoothing) * nll + smoothing * uniform) * w;
     }
     if (write_grad) {
         __syncthreads();   // loss read of xr[t] done before overwrite
         const float gs = w * (grad_scale ? grad_scale[0] : 1.0f);
         const float inv = 1.0f / s;
+        const float qu = smoothing / (float)V;
         for (int c = threadIdx.x; c < V; c += NT) {
-            float p = expf(xr[c] - bv) * inv;
-            if (c == t) p -= 1.0f;
+            float p = expf(xr[c] - bv) * inv - qu;
+            if (c == t) p -= 1.0f - smoothing;
             xr[c] = p * gs;
         }
     }
@@ -178,11 +187,14 @@ __global__ __launch_bounds__(NT) void xent_kernel(float* __restrict__ x, long ld
 
 extern "C" int nm_xent(void* stream, float* logits, int64_t ldx, int64_t rows, int64_t V,
                        const int32_t* targets, const float* weights, float* loss_rows,
-                       const float* grad_scale, int write_grad) {
+                       const float* grad_scale, int write_grad, float label_smoothing) {
     NM_REQUIRE(logits && targets && rows >= 0 && V > 0 && ldx >= V, "nm_xent: bad args");
+    NM_REQUIRE(label_smoothing >= 0.0f && label_smoothing < 1.0f, "nm_xent: label_smoothing %g outside [0,1)",
+               label_smoothing);
     if (rows == 0) return NM_OK;
     hipLaunchKernelGGL((xent_kernel<1024>), dim3((unsigned)rows), dim3(1024), 0, nm_stream(stream),
-                       logits, (long)ldx, (int)V, targets, weights, loss_rows, grad_scale, write_grad);
+                       logits, (long)ldx, (int)V, targets, weights, loss_rows, grad_scale, write_grad,
+                       label_smoothing);
     NM_LAUNCH_CHECK("nm_xent");
 }
 

@@ -75,9 +75,8 @@ class AutoregressiveDecoder(ModelPart):
             raise ValueError("Embedding size must be a positive integer.")
         if self.dropout_keep_prob < 0.0 or self.dropout_keep_prob > 1.0:
             raise ValueError("Dropout keep probability must be a real number in the interval [0,1].")
-        if label_smoothing:
-            raise NotImplementedError("label_smoothing is not implemented in the HIP engine "
-                                      "(SURVEY section 9: kept out of the first milestone)")
+        if label_smoothing is not None and not 0.0 <= label_smoothing < 1.0:
+            raise ValueError("label_smoothing must be in [0, 1), was {}".format(label_smoothing))
         self.train_tokens = Placeholder("{}/{}".format(name, data_id))
 
     # -- static sizes ------------------------------------------------------------
@@ -167,7 +166,18 @@ class AutoregressiveDecoder(ModelPart):
             lambda ids: np.ascontiguousarray(sentence_mask(ids).T)))
 
     def train_token_count(self, ctx) -> float:
+        """Denominator of the training loss.  Plain: sum(train_mask) (autoregressive.py:312-316).
+        With label smoothing the reference's loss function returns ONE scalar, the mean smoothed
+        cross entropy over all B*T positions (tf.losses.softmax_cross_entropy reduces), which
+        sequence_loss broadcasts against the mask (:292-310): sum(xents)/sum(mask) is then that mean
+        itself -- over every position, padded ones included."""
+        if self.label_smoothing:
+            return float(np.asarray(ctx.fed(self.train_tokens)).size)
         return float(sentence_mask(ctx.fed(self.train_tokens)).sum())
+
+    def xent_weights(self, mask):
+        """Per-position weights of the training cross entropy (see ``train_token_count``)."""
+        return None if self.label_smoothing else mask
 
     def feed_dict(self, dataset, train: bool = False) -> FeedDict:
         fd = ModelPart.feed_dict(self, dataset, train)

@@ -276,7 +276,8 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
         logits = ctx.buffer(key + ("logits",), (rows, v))
         self.state_to_logits(ctx, out_all, logits)
         loss_rows = ctx.buffer(key + ("loss_rows",), (rows,))
-        ops.xent(logits, tgt.reshape(-1), tmask.reshape(-1), loss_rows, grad_scale, want_grad)
+        ops.xent(logits, tgt.reshape(-1), self.xent_weights(tmask.reshape(-1)), loss_rows, grad_scale, want_grad,
+                 self.label_smoothing or 0.0)
         loss_sum = ctx.buffer(key + ("loss_sum",), (1,))
         ops.reduce_sum(loss_rows, loss_sum)
         for att, st in zip(self.attentions, att_states):

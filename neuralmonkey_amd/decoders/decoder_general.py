@@ -147,7 +147,8 @@ class GeneralDecoderMixin:
             F.copy(tape, out_t, out=tape.rows(out_all, t * bsz, (t + 1) * bsz))
         w, trans_b, bias = self._logit_params(tape)
         logits = F.linear(tape, out_all, w, bias, trans_b=trans_b)
-        loss_rows = F.xent(tape, logits, tgt.reshape(-1), tmask.reshape(-1), grad_scale)
+        loss_rows = F.xent(tape, logits, tgt.reshape(-1), self.xent_weights(tmask.reshape(-1)), grad_scale,
+                           self.label_smoothing or 0.0)
         loss_sum = ctx.buffer((id(self), "gtrain", "loss_sum"), (1,))
         ops.reduce_sum(loss_rows, loss_sum)
         from ..attention.base_attention import AttentionLoopState

@@ -200,7 +200,8 @@ class TransformerDecoder(AutoregressiveDecoder):
         states = self._layers(tape, emb, mask_bt, bsz, steps, enc, train)
         w, trans_b, bias = self._logit_params(tape)
         logits = F.linear(tape, states, w, bias, trans_b=trans_b)   # [B*T, V], batch-major rows
-        loss_rows = F.xent(tape, logits, tgt_bt.reshape(-1), mask_bt.reshape(-1), grad_scale)
+        loss_rows = F.xent(tape, logits, tgt_bt.reshape(-1), self.xent_weights(mask_bt.reshape(-1)), grad_scale,
+                           self.label_smoothing or 0.0)
         loss_sum = ctx.buffer((id(self), "ttrain", "loss_sum"), (1,))
         ops.reduce_sum(loss_rows, loss_sum)
         saved = {"tape": tape, "enc": enc, "steps": steps, "bsz": bsz, "logits": logits.data,

@@ -129,11 +129,13 @@ class EmbeddedFactorSequence(Sequence):
         first_ids = ids[0].reshape(-1)
         col = 0
         for idx, name, esz in zip(ids, names, self.embedding_sizes):
-            if self.scale_embeddings_by_depth:
-                raise NotImplementedError("backward of scale_embeddings_by_depth")
             if len(ids) > 1 and idx is not ids[0]:
                 raise NotImplementedError("backward of multi-factor sequences")
-            ops.embedding_scatter_add(ctx.store.g(name), idx.reshape(-1), d2[:, col:col + esz], skip_pad=True)
+            d_part = d2[:, col:col + esz]
+            if self.scale_embeddings_by_depth:          # forward multiplied the rows by sqrt(E) (sequence.py:185-187)
+                scaled = ctx.buffer((id(self), "d_scaled", col), (bsz * slen, esz))
+                d_part = ops.ew("scale", d_part, None, scaled, alpha=float(esz) ** 0.5)
+            ops.embedding_scatter_add(ctx.store.g(name), idx.reshape(-1), d_part, skip_pad=True)
             col += esz
 
     def feed_dict(self, dataset, train: bool = False) -> FeedDict:

@@ -209,12 +209,12 @@ def greedy_update(argmax, finished, sym_out, mask_out, end_id, all_finished=None
                                     _p(all_finished)), "nm_greedy_update")
 
 
-def xent(logits, targets, weights, loss_rows, grad_scale=None, write_grad=False):
+def xent(logits, targets, weights, loss_rows, grad_scale=None, write_grad=False, label_smoothing=0.0):
     lib = _lib.load()
     assert logits.dim() == 2 and logits.stride(1) == 1
     _lib.check(lib.nm_xent(_stream(), logits.data_ptr(), logits.stride(0), logits.shape[0],
                            logits.shape[1], targets.data_ptr(), _p(weights), _p(loss_rows),
-                           _p(grad_scale), int(write_grad)), "nm_xent")
+                           _p(grad_scale), int(write_grad), float(label_smoothing)), "nm_xent")
 
 
 def beam_workspace(b, k, v, device):

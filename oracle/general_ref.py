@@ -65,6 +65,7 @@ class Config(NamedTuple):
     supress_unk: bool = False
     rnn_size: int = 4
     spatial: Optional[Tuple] = None                         # (ff_hidden_dim, projection_dim): SpatialFiller encoder
+    label_smoothing: float = 0.0
 
 
 def _act(name):
@@ -336,6 +337,16 @@ class GeneralModel:
         tgt = torch.as_tensor(tgt_tb.reshape(-1).astype(np.int64))
         tmask = (tgt != PAD).to(self.dtype)
         lp = torch.log_softmax(logits, -1)
+        if cfg.label_smoothing:
+            # autoregressive.py:292-310: tf.losses.softmax_cross_entropy(onehot, logits, label_smoothing)
+            # reduces to ONE scalar (mean over all B*T positions, weights 1.0); sequence_loss broadcasts it
+            # against the mask, so sum(xents)/sum(mask) is that mean itself
+            eps, vsz = cfg.label_smoothing, logits.shape[-1]
+            q = torch.full_like(lp, eps / vsz)
+            q[torch.arange(tgt.numel()), tgt] += 1.0 - eps
+            mean_all = -(q * lp).sum(-1).mean()
+            xents = mean_all * tmask
+            return xents.sum() / tmask.sum(), logits.view(steps, bsz, -1), torch.stack(weights)
         xent = -lp[torch.arange(tgt.numel()), tgt] * tmask
         return xent.sum() / tmask.sum(), logits.view(steps, bsz, -1), torch.stack(weights)
 

@@ -56,7 +56,7 @@ def _build(dev, cfg: G.Config, emb_src, emb_tgt, max_len=8, beam=3, seed=5, init
                   output_projection=proj, encoder_projection=enc_proj, attentions=[att],
                   attention_on_input=cfg.attention_on_input, rnn_cell=cfg.dec_cell,
                   conditional_gru=cfg.conditional_gru, supress_unk=cfg.supress_unk,
-                  tie_embeddings=cfg.tie_embeddings)
+                  tie_embeddings=cfg.tie_embeddings, label_smoothing=cfg.label_smoothing or None)
     bdec = BeamSearchDecoder(name="beam_decoder", parent_decoder=dec, beam_size=beam, max_steps=max_len,
                              length_normalization=0.6)
     greedy = GreedyRunner(output_series="target", decoder=dec)
@@ -110,6 +110,10 @@ CASES = {
     # plain GRU model: dropout sends training to the tape, inference stays on the fused fast path
     "gru_dropout_only": (G.Config(rnn_layers=((4, "bidirectional", "GRU"),), enc_dropout=0.6, dec_dropout=0.6,
                                   rnn_size=8), 8, 8),
+    # label smoothing (autoregressive.py:292-299) on the hand-scheduled fast path and on the tape
+    "smoothing_fast": (G.Config(rnn_layers=((4, "bidirectional", "GRU"),), rnn_size=8, label_smoothing=0.1), 8, 8),
+    "smoothing_taped": (G.Config(rnn_layers=((4, "bidirectional", "NematusGRU"),), dec_cell="NematusGRU",
+                                 rnn_size=8, label_smoothing=0.2), 8, 8),
     "concat_tied": (G.Config(rnn_layers=((4, "bidirectional", "GRU"),), include_final_layer_norm=False,
                              encoder_projection="concat", rnn_size=8, tie_embeddings=True, attention_on_input=True,
                              output_projection=("nonlinear", "relu", 1.0)), 8, 8),

@@ -164,11 +164,14 @@ def test_unsupported_features_refuse_loudly():
     reset_registry()
     vocab = V.Vocabulary(["a"])
     from neuralmonkey_amd.decoders.encoder_projection import nematus_projection
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):
         Decoder(encoders=[], vocabulary=vocab, data_id="t", name="d", max_output_len=5, embedding_size=4,
-                rnn_size=4, label_smoothing=0.1)
+                rnn_size=4, label_smoothing=1.5)
     with pytest.raises(NotImplementedError):
         nematus_projection()
+    with pytest.raises(NotImplementedError):
+        Decoder(encoders=[], vocabulary=vocab, data_id="t", name="ds", max_output_len=5, embedding_size=4,
+                rnn_size=4).decoding_loop(None, False, sample=True)
     # cells / conditional GRU / attention on input are served by the general (taped) path
     for i, kw in enumerate((dict(rnn_cell="LSTM"), dict(rnn_cell="NematusGRU"), dict(attention_on_input=True))):
         dec = Decoder(encoders=[], vocabulary=vocab, data_id="t", name="dg{}".format(i), max_output_len=5,
