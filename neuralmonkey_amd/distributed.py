@@ -28,14 +28,25 @@ class DataParallel:
         self.rank = dist.get_rank()
         self.world_size = dist.get_world_size()
         self.bucket_elems = max(1, bucket_bytes // 4)
+        # Host scalars (the global target-token count of a step) travel over a gloo side group:
+        # reading an RCCL result back would synchronise the device every step and stop the host
+        # from enqueueing ahead of the GPU.
+        self._host_group = None
+        if self.world_size > 1 and dist.get_backend() == "nccl":
+            try:
+                self._host_group = dist.new_group(backend="gloo")
+            except Exception:           # pylint: disable=broad-except
+                self._host_group = None  # fall back to a device all-reduce + readback
 
     def all_reduce_scalar(self, value: float) -> float:
         """Sum of a host scalar over ranks (global target-token count)."""
         if self.world_size == 1:
             return value
-        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" \
-            else torch.device("cpu")
-        t = torch.tensor([value], dtype=torch.float64, device=dev)
+        if dist.get_backend() != "nccl" or self._host_group is not None:
+            t = torch.tensor([value], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self._host_group)
+            return float(t.item())
+        t = torch.tensor([value], dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return float(t.item())
 
