@@ -84,6 +84,15 @@ typedef struct nm_gru_epilogue {
 } nm_gru_epilogue;
 int nm_gru_gemm(void* stream, const nm_gru_epilogue* epi, int transB, int64_t K, const float* A,
                 int64_t lda, int64_t strideA, const float* B, int64_t ldb, int64_t strideB);
+/* The whole forward time loop of a GRU layer (both directions) in ONE persistent launch: per step two
+ * phases of the same tiles + epilogues (modes 1, 2) separated by grid barriers, so a step costs two
+ * barriers instead of two kernel launches.  `e` holds the step-0 pointers; step t uses h_in/h_out +
+ * t*h_step, ru + t*ru_step, rh + t*rh_step, c_save + t*c_step.  workspace: >= 256 B of device
+ * memory (barrier counter + error flag, cleared by the call). */
+int nm_gru_seq_fwd(void* stream, const nm_gru_epilogue* e, int32_t steps, int64_t h_step, int64_t ru_step,
+                   int64_t rh_step, int64_t c_step, const float* wgh, int64_t ld_g, int64_t stride_g,
+                   const float* wch, int64_t ld_c, int64_t stride_c, void* workspace,
+                   int64_t workspace_bytes);
 int nm_gru_seq_shift(void* stream, const float* seq, float* out, const int32_t* lengths, int rev_mask,
                      int64_t B, int64_t S, int ndir, int64_t H);
 int nm_gru_rh_seq(void* stream, const float* ru_all, const float* hprev, float* out,

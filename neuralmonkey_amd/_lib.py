@@ -38,6 +38,7 @@ SIGNATURES = {
     "nm_attn_fwd_multi": (I, [P, P, P, P, P, P, P, L, L, L, L, L, L, L, P, L, P, P, L, P]),
     "nm_gru_rh_seq": (I, [P, P, P, P, P, I, L, L, I, L]),
     "nm_gru_gemm": (I, [P, P, I, L, P, L, L, P, L, L]),
+    "nm_gru_seq_fwd": (I, [P, P, ctypes.c_int32, L, L, L, L, P, L, L, P, L, L, P, L]),
     "nm_prof_enable": (I, [I]),
     "nm_prof_attn_partial": (I, [P, P]),
     "nm_row_stats": (I, [P, P, L, L, L, P, P, P]),

@@ -35,6 +35,7 @@ struct GemmArgs {
     int accumulate;  // C += ...
     float* ws;       // split-K slabs [splitk][M][N] (raw partial sums) or null
     int splitk;      // K slices handled by blockIdx.y; 1 = write C directly
+    int swizzle;     // XCD-aware tile order (gemm_tiled)
 };
 
 __device__ __forceinline__ float apply_act(float x, int act) {
@@ -77,7 +78,30 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tiled(GemmArgs g, int tiles
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDBS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bm = blockIdx.x % tiles_m, bn = blockIdx.x / tiles_m;
+    // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MB
+    // L2): give XCD x the contiguous range [x*n/8, (x+1)*n/8) of a grouped tile order in which
+    // consecutive ids sweep GROUP_M row tiles before moving to the next column tile, so the ~32
+    // workgroups resident on one XCD form a compact GROUP_M x 4 block of tiles that shares its A
+    // and B panels in that XCD's L2.
+    int bm, bn;
+    {
+        const int npid = (int)gridDim.x;
+        int pid = (int)blockIdx.x;
+        if (g.swizzle) {
+            const int per = npid / 8, rem = npid % 8, x = pid % 8, i = pid / 8;
+            pid = x * per + (x < rem ? x : rem) + i;                 // contiguous range per XCD
+            constexpr int GROUP_M = 8;
+            const int tiles_n = npid / tiles_m;
+            const int width = GROUP_M * tiles_n;
+            const int group = pid / width, first = group * GROUP_M;
+            const int gsz = (tiles_m - first) < GROUP_M ? (tiles_m - first) : GROUP_M;
+            bm = first + (pid % width) % gsz;
+            bn = (pid % width) / gsz;
+        } else {
+            bm = pid % tiles_m;
+            bn = pid / tiles_m;
+        }
+    }
     const int m0 = bm * BM, n0 = bn * BN;
     const float* __restrict__ A = g.A + (long)blockIdx.z * g.sA;
     const float* __restrict__ B = g.B + (long)blockIdx.z * g.sB;
@@ -458,15 +482,17 @@ __global__ __launch_bounds__(KS * 64) void gemm_skinny(GemmArgs g, int tiles_m, 
 // ---------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// one 16x16 output tile (tile id ``tile`` of batch entry ``z``): K split over the KS waves of the
+// workgroup, partial sums meet in LDS, then bias/activation or a fused GRU epilogue
 template <int KS, bool TB>
-__global__ __launch_bounds__(KS * 64) void gemm_skinny16(GemmArgs g, int tiles_m, GruEpi epi) {
-    __shared__ float red[KS][4][64];
+__device__ __forceinline__ void skinny16_tile(const GemmArgs& g, int tiles_m, const GruEpi& epi, int tile, int z,
+                                              float (*red)[4][64]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bm = blockIdx.x % tiles_m, bn = blockIdx.x / tiles_m;
+    const int bm = tile % tiles_m, bn = tile / tiles_m;
     const int m0 = bm * 16, n0 = bn * 16;
-    const float* __restrict__ A = g.A + (long)blockIdx.z * g.sA;
-    const float* __restrict__ B = g.B + (long)blockIdx.z * g.sB;
-    float* __restrict__ C = g.C + (long)blockIdx.z * g.sC;
+    const float* __restrict__ A = g.A + (long)z * g.sA;
+    const float* __restrict__ B = g.B + (long)z * g.sB;
+    float* __restrict__ C = g.C + (long)z * g.sC;
 
     const int i16 = lane & 15, kq = lane >> 4;
     const int mm = min(m0 + i16, g.M - 1), nn = min(n0 + i16, g.N - 1);
@@ -521,7 +547,7 @@ __global__ __launch_bounds__(KS * 64) void gemm_skinny16(GemmArgs g, int tiles_m
         if (row < g.M && col < g.N) {
             if (epi.mode) {
                 if (g.accumulate) s += C[(long)row * g.ldc + col];
-                gru_epilogue(epi, blockIdx.z, row, col, s);
+                gru_epilogue(epi, z, row, col, s);
                 continue;
             }
             float* p = C + (long)row * g.ldc + col;
@@ -529,6 +555,91 @@ __global__ __launch_bounds__(KS * 64) void gemm_skinny16(GemmArgs g, int tiles_m
             if (g.accumulate) v += *p;
             *p = apply_act(v, g.act);
         }
+    }
+}
+
+
+template <int KS, bool TB>
+__global__ __launch_bounds__(KS * 64) void gemm_skinny16(GemmArgs g, int tiles_m, GruEpi epi) {
+    __shared__ float red[KS][4][64];
+    skinny16_tile<KS, TB>(g, tiles_m, epi, (int)blockIdx.x, (int)blockIdx.z, red);
+}
+
+// ---------------------------------------------------------------------------
+// Persistent forward time loop of a GRU layer: ONE launch runs all `steps` recurrent steps.  Every
+// step is two phases of 16x16 tiles (gates GEMM + epilogue, candidate GEMM + blend epilogue -- the
+// same tile code and epilogues as the per-step launches) separated by grid barriers; the workgroups
+// stay resident, so a step costs two barriers instead of two kernel launches with their ramp-up.
+// Barrier = monotonically increasing agent-scope counter: all stores of the phase are released
+// (L2 write-back) before the arrive, the wait is followed by an acquire (L2 invalidate), because the
+// per-XCD L2s are not coherent with each other for plain stores.  The spin is bounded: a workgroup
+// that waits too long raises the error flag and leaves instead of hanging the GPU.
+// ---------------------------------------------------------------------------
+struct GruSeq {
+    GruEpi e;                    // pointers of step 0
+    int steps, ndir;
+    long h_step, ru_step, rh_step, c_step;     // added per step to h_in/h_out, ru, rh, c_save
+    const float* wg; long ldg, sg;             // state half of the gates kernel   [ndir][H][2H]
+    const float* wc; long ldc, sc;             // state half of the candidate kernel [ndir][H][H]
+    unsigned* bar;               // [0] arrive counter, [1] error flag (zeroed before the launch)
+};
+
+__device__ __forceinline__ void nm_grid_barrier(unsigned* bar, unsigned target) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        long spins = 0;
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1L << 22)) {          // seconds, not microseconds: something is wrong
+                __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
+template <int KS>
+__global__ __launch_bounds__(KS * 64) void gru_seq_fwd_kernel(GruSeq q) {
+    __shared__ float red[KS][4][64];
+    const int P = (int)gridDim.x;
+    const int H = q.e.H;
+    const int R = (int)q.e.R;
+    const int tiles_m = (R + 15) / 16;
+    const int tiles_a = tiles_m * ((2 * H + 15) / 16), tiles_b = tiles_m * ((H + 15) / 16);
+    unsigned epoch = 0;
+    for (int t = 0; t < q.steps; ++t) {
+        GruEpi e = q.e;
+        e.t = t;
+        e.h_in += (long)t * q.h_step;
+        e.h_out += (long)t * q.h_step;
+        e.ru += (long)t * q.ru_step;
+        e.rh += (long)t * q.rh_step;
+        if (e.c_save) e.c_save += (long)t * q.c_step;
+        GemmArgs g{e.h_in, q.wg, nullptr, nullptr, R, 2 * H, H, (long)H, q.ldg, 0, (long)R * H, q.sg, 0,
+                   0, 0, nullptr, 1, 0};
+        e.mode = 1;                               // r|u = sigmoid(xp + h.Wg_h), rh = r*h
+        for (int w = (int)blockIdx.x; w < tiles_a * q.ndir; w += P) {
+            skinny16_tile<KS, false>(g, tiles_m, e, w % tiles_a, w / tiles_a, red);
+            __syncthreads();
+        }
+        nm_grid_barrier(q.bar, ++epoch * (unsigned)P);
+        g.A = e.rh;
+        g.B = q.wc;
+        g.N = H;
+        g.ldb = q.ldc;
+        g.sB = q.sc;
+        e.mode = 2;                               // c = tanh(xp + (r*h).Wc_h), h' = u*h + (1-u)*c
+        for (int w = (int)blockIdx.x; w < tiles_b * q.ndir; w += P) {
+            skinny16_tile<KS, false>(g, tiles_m, e, w % tiles_b, w / tiles_b, red);
+            __syncthreads();
+        }
+        nm_grid_barrier(q.bar, ++epoch * (unsigned)P);
     }
 }
 
@@ -600,7 +711,9 @@ extern "C" int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int6
     if (M == 0 || N == 0) return NM_OK;
     NM_REQUIRE(K > 0, "nm_gemm_f32: K == 0");
     GemmArgs g{A, B, C, bias, (int)M, (int)N, (int)K, (long)lda, (long)ldb, (long)ldc,
-               (long)strideA, (long)strideB, (long)strideC, act, accumulate, nullptr, 1};
+               (long)strideA, (long)strideB, (long)strideC, act, accumulate, nullptr, 1, 0};
+    static const int swz_env = getenv("NM_GEMM_SWZ") ? atoi(getenv("NM_GEMM_SWZ")) : 1;   // A/B switch
+    g.swizzle = swz_env;
     hipStream_t st = nm_stream(stream);
     const bool ta = transA != 0, tb = transB != 0;
 
@@ -691,7 +804,7 @@ extern "C" int nm_gru_gemm(void* stream, const nm_gru_epilogue* e, int transB, i
                     "nm_gru_gemm: missing backward operand");
     const int64_t N = (e->mode == 1) ? 2 * e->H : e->H;
     GemmArgs g{A, B, e->dh, nullptr, (int)e->R, (int)N, (int)K, (long)lda, (long)ldb, (long)e->H,
-               (long)strideA, (long)strideB, (long)(e->R * e->H), 0, e->mode == 4 ? 1 : 0, nullptr, 1};
+               (long)strideA, (long)strideB, (long)(e->R * e->H), 0, e->mode == 4 ? 1 : 0, nullptr, 1, 0};
     GruEpi d;
     d.mode = e->mode; d.lengths = e->lengths; d.t = e->t; d.rev_mask = e->rev_mask; d.H = (int)e->H; d.R = e->R;
     d.xp = e->xp; d.x_dir = e->x_dir; d.x_row = e->x_row; d.x_time = e->x_time;
@@ -703,4 +816,49 @@ extern "C" int nm_gru_gemm(void* stream, const nm_gru_epilogue* e, int transB, i
     d.dgpre = e->dgpre; d.dcpre = e->dcpre;
     launch_skinny(g, e->ndir, transB != 0, d, nm_stream(stream));
     NM_LAUNCH_CHECK("nm_gru_gemm");
+}
+
+// ---------------------------------------------------------------------------
+// the whole forward time loop of a GRU layer in one persistent launch (see gru_seq_fwd_kernel)
+// ---------------------------------------------------------------------------
+extern "C" int nm_gru_seq_fwd(void* stream, const nm_gru_epilogue* e, int32_t steps, int64_t h_step,
+                              int64_t ru_step, int64_t rh_step, int64_t c_step, const float* wgh, int64_t ld_g,
+                              int64_t stride_g, const float* wch, int64_t ld_c, int64_t stride_c,
+                              void* workspace, int64_t workspace_bytes) {
+    NM_REQUIRE(e && wgh && wch && workspace && workspace_bytes >= 256, "nm_gru_seq_fwd: null pointer / workspace");
+    NM_REQUIRE(steps >= 0 && e->R > 0 && e->H > 0 && e->H % 16 == 0 && e->ndir >= 1 && e->ndir <= 2,
+               "nm_gru_seq_fwd: bad shape R=%ld H=%ld", (long)e->R, (long)e->H);
+    NM_REQUIRE(e->xp && e->h_in && e->h_out && e->ru && e->rh, "nm_gru_seq_fwd: missing operand");
+    NM_REQUIRE(nm_aligned16(e->h_in) && nm_aligned16(e->rh) && nm_aligned16(wgh) && nm_aligned16(wch) &&
+                   h_step % 4 == 0 && rh_step % 4 == 0,
+               "nm_gru_seq_fwd: operands must be 16-byte aligned");
+    if (steps == 0) return NM_OK;
+    GruSeq q;
+    GruEpi& d = q.e;
+    d.mode = 1; d.lengths = e->lengths; d.t = 0; d.rev_mask = e->rev_mask; d.H = (int)e->H; d.R = e->R;
+    d.xp = e->xp; d.x_dir = e->x_dir; d.x_row = e->x_row; d.x_time = e->x_time;
+    d.h_in = e->h_in; d.h_out = e->h_out; d.ru = e->ru; d.rh = e->rh; d.c_save = e->c_save;
+    d.out = e->out; d.o_dir = e->o_dir; d.o_row = e->o_row; d.o_time = e->o_time;
+    d.dh = nullptr; d.dout = nullptr; d.do_dir = d.do_row = d.do_time = 0;
+    d.c = nullptr; d.h0 = nullptr; d.hseq = nullptr; d.hs_dir = d.hs_row = d.hs_time = 0;
+    d.dxp = nullptr; d.dx_dir = d.dx_row = d.dx_time = 0; d.dgpre = nullptr; d.dcpre = nullptr;
+    q.steps = steps; q.ndir = e->ndir;
+    q.h_step = h_step; q.ru_step = ru_step; q.rh_step = rh_step; q.c_step = c_step;
+    q.wg = wgh; q.ldg = ld_g; q.sg = stride_g; q.wc = wch; q.ldc = ld_c; q.sc = stride_c;
+    q.bar = reinterpret_cast<unsigned*>(workspace);
+    hipStream_t st = nm_stream(stream);
+    if (hipMemsetAsync(workspace, 0, 256, st) != hipSuccess) NM_FAIL(NM_ERR_HIP, "nm_gru_seq_fwd: memset failed");
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (ncu <= 0) ncu = 64;
+    }
+    // one 1024-thread workgroup per CU at most: all of them are resident at once (the grid barrier
+    // needs that), and no more than there are tiles in the larger phase
+    const long tiles = (long)((e->R + 15) / 16) * ((2 * e->H + 15) / 16) * e->ndir;
+    const int P = (int)(tiles < ncu ? tiles : ncu);
+    hipLaunchKernelGGL((gru_seq_fwd_kernel<16>), dim3(P), dim3(1024), 0, st, q);
+    NM_LAUNCH_CHECK("nm_gru_seq_fwd");
 }

@@ -264,7 +264,13 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
             for t in range(steps):
                 self._recurrent(ctx, cell, xp, t, bsz * 3 * h, s_ext[t], s_all[t], ru_all[t], c_all[t], bufs,
                                 rh=rh_all[t])
-        ctx.session.graphed((id(self), "train_loop", bsz, steps), time_loop)
+        if ctx.session.use_persistent and gru.fused_ok(bsz, h) and h % 16 == 0:
+            # the whole recurrence as one persistent launch: two grid barriers per step, no launches
+            ops.gru_seq_fwd(steps, 1, bsz, h, xp, (0, 3 * h, bsz * 3 * h), s_ext[0], s_ext[1], bsz * h,
+                            ru_all[0], bsz * 2 * h, rh_all[0], bsz * h, c_all[0], bsz * h, cell["wg_h"],
+                            cell["wc_h"], ctx.buffer((id(self), "seq_ws"), (64,)))
+        else:
+            ctx.session.graphed((id(self), "train_loop", bsz, steps), time_loop)
         # attention of all T steps at once (the contexts do not feed the recurrence)
         for i, att in enumerate(self.attentions):
             att.attention_all_steps(ctx, s_all, y_all[i], att_states[i].contexts, att_states[i].weights, e_all[i])

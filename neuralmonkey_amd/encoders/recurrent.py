@@ -196,7 +196,16 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
                 ru = ru_all[t] if train else ru_all[0]
                 gru.step_fwd(xp, (3 * h, xrs, xts), hcur, hcur, wgh, wch, ru, rh, c_all[t] if train else None,
                              states_raw, (h, ors, ots), len_arg, t, ndir, bsz, h, reverse_only, hg, hc)
-        ctx.session.graphed((key, "fwd_loop", bsz, slen, train), time_loop)
+        if ctx.session.use_persistent and gru.fused_ok(bsz, h) and h % 16 == 0:
+            # both directions, all positions: one persistent launch (two grid barriers per step)
+            states_raw.zero_()
+            hcur.zero_()
+            ops.gru_seq_fwd(slen, ndir, bsz, h, xp, (3 * h, xrs, xts), hcur, hcur, 0, ru_all[0],
+                            ndir * bsz * 2 * h if train else 0, rh, 0, c_all[0] if train else None,
+                            ndir * bsz * h, wgh, wch, ctx.buffer((key, "seq_ws"), (64,)), lengths=len_arg,
+                            reverse_dir0=reverse_only, out=states_raw, out_strides=(h, ors, ots))
+        else:
+            ctx.session.graphed((key, "fwd_loop", bsz, slen, train), time_loop)
         final_raw = ctx.buffer((key, "final_raw"), (bsz, c_out))
         for d in range(ndir):
             ops.copy_cols(hcur[d], final_raw[:, d * h:(d + 1) * h])

@@ -566,6 +566,29 @@ def gru_gemm(mode, a, b, trans_b, t, ndir, rows, hsz, lengths=None, reverse_dir0
                                b.data_ptr(), b2.stride(0), s_b), "nm_gru_gemm")
 
 
+def gru_seq_fwd(steps, ndir, rows, hsz, xp, x_strides, h_in0, h_out0, h_step, ru0, ru_step, rh0, rh_step, c0,
+                c_step, wgh, wch, workspace, lengths=None, reverse_dir0=False, out=None, out_strides=(0, 0, 0)):
+    """All ``steps`` forward GRU steps in one persistent launch (nm_gru_seq_fwd).  Tensors of step t:
+    h_in0 + t*h_step etc. (element strides); wgh [ndir,H,2H], wch [ndir,H,H] (2-D accepted for ndir 1)."""
+    lib = _lib.load()
+    e = _lib.GruEpilogue()
+    e.mode, e.t, e.rev_mask, e.ndir, e.R, e.H = 1, 0, _rev_mask(ndir, reverse_dir0), ndir, rows, hsz
+    e.lengths = _p(lengths)
+    e.xp = xp.data_ptr()
+    e.x_dir, e.x_row, e.x_time = x_strides
+    e.h_in, e.h_out, e.ru, e.rh, e.c_save, e.out = (h_in0.data_ptr(), h_out0.data_ptr(), ru0.data_ptr(),
+                                                   rh0.data_ptr(), _p(c0), _p(out))
+    e.o_dir, e.o_row, e.o_time = out_strides
+    g2 = wgh[0] if wgh.dim() == 3 else wgh
+    c2 = wch[0] if wch.dim() == 3 else wch
+    assert g2.stride(1) == 1 and c2.stride(1) == 1
+    _lib.check(lib.nm_gru_seq_fwd(_stream(), ctypes.byref(e), steps, h_step, ru_step, rh_step, c_step,
+                                  wgh.data_ptr(), g2.stride(0), wgh.stride(0) if wgh.dim() == 3 else 0,
+                                  wch.data_ptr(), c2.stride(0), wch.stride(0) if wch.dim() == 3 else 0,
+                                  workspace.data_ptr(), workspace.numel() * workspace.element_size()),
+               "nm_gru_seq_fwd")
+
+
 class OptimizerTables:
     """Chunk / segment tables of a VariableStore for the flat optimizer kernels."""
     CHUNK = 65536

@@ -129,6 +129,11 @@ class Session:
         self._graphs: Dict[Any, Any] = {}
         self.use_graphs = os.environ.get("NM_GRAPHS", "1") != "0"
         self.use_side_stream = os.environ.get("NM_SIDE_STREAM", "1") != "0"
+        # Persistent GRU time loops (nm_gru_seq_fwd: one launch, two grid barriers per step).  Measured
+        # on MI355X at the benchmark shape: 17.4 ms/step against 15.0 ms/step for the HIP-graph replay of
+        # two launches per step -- an agent-scope release/acquire pair (L2 write-back + invalidate on
+        # every XCD) costs more than a launch boundary inside a graph.  Off by default.
+        self.use_persistent = os.environ.get("NM_PERSISTENT", "0") != "0"
         self._side_stream = None
         self._side_dirty = False
         self.global_step = 0

@@ -137,3 +137,20 @@ def test_delayed_update_trainer_accumulates_and_averages(dev):
     assert tfm.sessions[0].global_step == 1
     for n in store.names():
         assert np.abs(store[n].cpu().numpy() - want[n]).max() <= 2e-7 + 1e-5 * np.abs(want[n]).max(), n
+
+
+def test_persistent_time_loops_match_graph_replay(dev):
+    """nm_gru_seq_fwd (whole forward recurrence in one persistent launch with grid barriers) is an
+    alternative schedule of the same tiles and epilogues: identical losses and gradients."""
+    results = []
+    for persistent in (False, True):
+        model, params, ds, src, tgt = _build(dev, 200, 32, 32, 8, 10, 9, True, l2=0.0, clip=None)
+        sess = model.tf_manager.sessions[0]
+        sess.use_persistent = persistent
+        res = model.tf_manager.execute(ds, model.trainer.feedables, [model.trainer], train=True)[0]
+        grads = {n: sess.store.g(n).cpu().numpy().copy() for n in sess.store.names()}
+        results.append((res.losses["decoder - cost"], grads))
+    (l0, g0), (l1, g1) = results
+    assert abs(l0 - l1) <= 1e-6 * abs(l0)
+    for n in g0:
+        assert np.abs(g0[n] - g1[n]).max() <= 1e-5 * max(np.abs(g0[n]).max(), 1e-8), n
