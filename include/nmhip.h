@@ -185,7 +185,9 @@ int nm_colsum(void* stream, const float* x, int64_t ldx, int64_t rows, int64_t c
  * (:264-277), output-projection variants (decoders/output_projection.py:35-188) and the
  * Transformer blocks are compositions of MFMA GEMMs and these one-pass kernels.
  * op codes: 0 copy, 1 a+b, 2 a-b, 3 a*b, 4 alpha*a, 5 sigmoid(a+alpha), 6 tanh(a), 7 relu(a),
- *           8 b*a*(1-a), 9 b*(1-a^2), 10 b*(a>0)   (8-10: a = forward output, b = upstream grad) */
+ *           8 b*a*(1-a), 9 b*(1-a^2), 10 b*(a>0)   (8-10: a = forward output, b = upstream grad),
+ *           11 log(exp(a)+exp(b)) (ensemble mean in log space, runners/beamsearch_runner.py:50-55),
+ *           12 a+alpha */
 int nm_ew(void* stream, int op, const float* a, int64_t lda, const float* b, int64_t ldb, float* out,
           int64_t ldo, int64_t rows, int64_t cols, float alpha, int accumulate);
 /* h' = u*h + (1-u)*c  and its gradient (du, dh, dc accumulate; any may be NULL) */

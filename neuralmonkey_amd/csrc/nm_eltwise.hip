@@ -26,7 +26,9 @@ enum {
     NM_EW_SIGMOID_BWD = 8,  // b * a * (1 - a)        a = forward output, b = upstream gradient
     NM_EW_TANH_BWD = 9,     // b * (1 - a^2)
     NM_EW_RELU_BWD = 10,    // b * (a > 0)
-    NM_EW_OPS = 11
+    NM_EW_LOGADDEXP = 11,   // log(exp(a) + exp(b))   (ensemble mean of probabilities in log space)
+    NM_EW_ADD_SCALAR = 12,  // a + alpha
+    NM_EW_OPS = 13
 };
 
 template <int OP>
@@ -42,6 +44,11 @@ __device__ __forceinline__ float ew_apply(float a, float b, float alpha) {
     if (OP == NM_EW_SIGMOID_BWD) return b * a * (1.0f - a);
     if (OP == NM_EW_TANH_BWD) return b * (1.0f - a * a);
     if (OP == NM_EW_RELU_BWD) return a > 0.0f ? b : 0.0f;
+    if (OP == NM_EW_LOGADDEXP) {
+        const float hi = fmaxf(a, b), lo = fminf(a, b);
+        return hi == -INFINITY ? -INFINITY : hi + log1pf(expf(lo - hi));
+    }
+    if (OP == NM_EW_ADD_SCALAR) return a + alpha;
     return 0.0f;
 }
 
@@ -102,7 +109,8 @@ extern "C" int nm_ew(void* stream, int op, const float* a, int64_t lda, const fl
                      int64_t ldo, int64_t rows, int64_t cols, float alpha, int accumulate) {
     NM_REQUIRE(op >= 0 && op < NM_EW_OPS, "nm_ew: unknown op %d", op);
     NM_REQUIRE(a && out && rows >= 0 && cols >= 0 && cols < (1LL << 31), "nm_ew: bad args");
-    const bool binary = op == NM_EW_ADD || op == NM_EW_SUB || op == NM_EW_MUL || op >= NM_EW_SIGMOID_BWD;
+    const bool binary = op == NM_EW_ADD || op == NM_EW_SUB || op == NM_EW_MUL ||
+                        (op >= NM_EW_SIGMOID_BWD && op <= NM_EW_LOGADDEXP);
     NM_REQUIRE(!binary || b, "nm_ew: op %d needs a second operand", op);
     if (rows == 0 || cols == 0) return NM_OK;
     hipStream_t st = nm_stream(stream);
@@ -120,6 +128,8 @@ extern "C" int nm_ew(void* stream, int op, const float* a, int64_t lda, const fl
         NM_EW_CASE(NM_EW_SIGMOID_BWD, true)
         NM_EW_CASE(NM_EW_TANH_BWD, true)
         NM_EW_CASE(NM_EW_RELU_BWD, true)
+        NM_EW_CASE(NM_EW_LOGADDEXP, true)
+        NM_EW_CASE(NM_EW_ADD_SCALAR, false)
         default: break;
     }
 #undef NM_EW_CASE

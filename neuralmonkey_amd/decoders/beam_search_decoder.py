@@ -103,6 +103,115 @@ class BeamSearchDecoder(ModelPart):
             for att in dec.attentions:
                 att.rows_per_key = 1
 
+    def ensemble_outputs(self, ctxs: List[Any]) -> BeamSearchOutput:
+        """Beam search over an ensemble: one run context (= one set of variables) per model, all on
+        this device.  Every step each model advances its own decoder state on the SAME hypotheses;
+        the step distributions are averaged in log space,
+        ``logsumexp_m(log_softmax(logits_m)) - log M`` (runners/beamsearch_runner.py:47-55), and the
+        shared beam body (:394-556) selects on that average.  The reference drives this from the host
+        with one Session.run per step and model; here the whole search stays on the device."""
+        dec = self.parent_decoder
+        for att in dec.attentions:
+            att.rows_per_key = self.beam_size
+        try:
+            return self._search_ensemble(ctxs)
+        finally:
+            for att in dec.attentions:
+                att.rows_per_key = 1
+
+    def _search_ensemble(self, ctxs: List[Any]) -> BeamSearchOutput:
+        import math
+        from ..attention.base_attention import AttentionLoopState
+        dec, k, nmod = self.parent_decoder, self.beam_size, len(ctxs)
+        ctx0 = ctxs[0]
+        bsz = int(ctx0.fed(dec.batch_size))
+        rows = bsz * k
+        e, v = dec.embedding_size or dec.output_dimension, len(self.vocabulary)
+        max_steps = int(ctx0.fed(self.max_steps))
+        key = (id(self), "bs_ens", bsz, nmod)
+        f32 = lambda name, shape, **kw: ctx0.buffer(key + (name,), shape, torch.float32, **kw)
+        i32 = lambda name, shape, **kw: ctx0.buffer(key + (name,), shape, torch.int32, **kw)
+        tok = i32("tok", (2, max_steps + 1, rows))
+        lps, lens, fin = f32("lps", (2, bsz, k)), i32("lens", (2, bsz, k)), i32("fin", (2, bsz, k))
+        scores = f32("scores", (bsz, k), zero=True)
+        word, beam, src = i32("word", (bsz, k)), i32("beam", (bsz, k)), i32("src", (bsz, k))
+        allfin = i32("allfin", (max(max_steps, 1),))
+        allfin.fill_(1)
+        ws = ctx0.buffer(key + ("ws",), ((ops._lib.load().nm_beam_workspace_bytes(bsz, k, v) + 3) // 4,))
+        penalty = self._length_penalty_table(ctx0, max_steps + 2)
+        zero_stat = f32("zero_stat", (rows,), zero=True)      # the averaged log-probs need no max / lse shift
+        ens = f32("ens_logprobs", (rows, v))
+        lp_m = f32("lp_m", (rows, v))
+        rmax, rlse, argmax = f32("rmax", (rows,)), f32("rlse", (rows,)), i32("argmax", (rows,))
+        go = i32("go", (rows,))
+        go.fill_(START_TOKEN_INDEX)
+        models = []
+        for m, ctx in enumerate(ctxs):
+            stepper = dec.make_stepper(ctx, rows, "beam_ens", k, max_positions=max_steps + 1)
+            emb = getattr(stepper, "emb_view", None)
+            if emb is None:
+                emb = ctx.buffer(key + ("emb", m), (rows, e))
+            models.append({"ctx": ctx, "stepper": stepper, "emb": emb,
+                           "out": ctx.buffer(key + ("out", m), (rows, dec.output_dimension)),
+                           "logits": ctx.buffer(key + ("logits", m), (rows, v)),
+                           "att": [a.initial_loop_state(ctx, rows, max_steps + 1) for a in dec.attentions]})
+
+        def average(first_symbols: bool) -> None:
+            """ens = log mean_m softmax(logits_m)."""
+            for m, mod in enumerate(models):
+                ops.row_stats(mod["logits"], rmax, rlse, argmax if (first_symbols and m == 0) else None)
+                ops.log_softmax_from_stats(mod["logits"], rmax, rlse, ens if m == 0 else lp_m)
+                if m > 0:
+                    ops.ew("logaddexp", ens, lp_m, ens)
+            if nmod > 1:
+                ops.ew("add_scalar", ens, None, ens, alpha=-math.log(nmod))
+
+        # ---- initial parent step of every model on the tiled rows (:218-328)
+        fin[0].zero_()
+        for mod in models:
+            ctx, stepper = mod["ctx"], mod["stepper"]
+            if hasattr(dec, "initial_state"):
+                hsel = ctx.buffer(key + ("hsel",), (rows, dec.rnn_size))
+                ops.gather_rows(dec.initial_state(ctx), self.expand_index(ctx, bsz), hsel)
+                stepper.start(hsel)
+            else:
+                stepper.start()
+            dec.embed_input_symbols(ctx, go, out=mod["emb"])
+            mod["att"] = stepper.step(mod["emb"], mod["att"], mod["out"], mod["logits"], finished=fin[0].view(rows))
+        average(first_symbols=True)
+        tok[0, 0].copy_(argmax)
+        lps[0].fill_(-INF)
+        lps[0, :, 0] = 0.0
+        lens[0].zero_()
+        srcf, wordf = src.view(rows), word.view(rows)
+        steps = executed = 0
+        while steps < max_steps:
+            cur, nxt = steps & 1, (steps & 1) ^ 1
+            ops.beam_topk_step(ens, bsz, k, zero_stat, zero_stat, lps[cur], lens[cur], fin[cur], penalty,
+                               END_TOKEN_INDEX, scores, word, beam, lps[nxt], lens[nxt], fin[nxt], src, ws,
+                               allfin[steps:steps + 1])
+            ops.beam_reorder_tokens(tok[cur], srcf, wordf, tok[nxt], steps + 1, rows)
+            for mod in models:
+                mod["stepper"].reorder(srcf)
+                dec.embed_input_symbols(mod["ctx"], wordf, out=mod["emb"])
+                mod["att"] = mod["stepper"].step(mod["emb"], mod["att"], mod["out"], mod["logits"],
+                                                 finished=fin[nxt].view(rows))
+            average(first_symbols=False)
+            steps += 1
+            executed = steps
+            if steps % CHECK_EVERY == 0 or steps == max_steps:
+                done = np.nonzero(allfin[:steps].cpu().numpy())[0]
+                if done.size:
+                    steps = int(done[0]) + 1
+                    break
+        cur = executed & 1
+        token_ids = tok[cur, :steps + 1].view(steps + 1, bsz, k)
+        search_state = SearchState(lps[cur], None, lens[cur], fin[cur])
+        feedables = DecoderFeedables(step=steps + 1, finished=fin[cur].view(rows), embedded_input=models[0]["emb"],
+                                     other=None)
+        return BeamSearchOutput(SearchResults(scores, token_ids),
+                                LoopState(histories=None, constants=None, feedables=feedables), search_state, [])
+
     def _search(self, ctx) -> BeamSearchOutput:
         dec = self.parent_decoder
         k = self.beam_size

@@ -358,7 +358,7 @@ def attn_energy_bwd(de, hf, y, v, dhf, dv_partial, dy, accumulate=False):
 
 # ---- strided element-wise primitives (general / taped path) -------------------------------------
 EW = {"copy": 0, "add": 1, "sub": 2, "mul": 3, "scale": 4, "sigmoid": 5, "tanh": 6, "relu": 7,
-      "sigmoid_bwd": 8, "tanh_bwd": 9, "relu_bwd": 10}
+      "sigmoid_bwd": 8, "tanh_bwd": 9, "relu_bwd": 10, "logaddexp": 11, "add_scalar": 12}
 
 
 def _rc(t):

@@ -1,9 +1,10 @@
 """BeamSearchRunner (mirror of neuralmonkey/runners/beamsearch_runner.py).
 
 Single session: the whole search runs on the device in one ``Session.run``.
-Multi-session ensembling (beamsearch_runner.py:38-82: one Session.run per
-step per model, log-mean of the step distributions on the host) is a "next"
-row and refuses loudly."""
+Several sessions = an ensemble (beamsearch_runner.py:38-82: the reference does
+one Session.run per step per model and averages the step distributions in log
+space on the host): here ``BeamSearchDecoder.ensemble_outputs`` runs the whole
+ensemble search on the device, one decoder state per model, one shared beam."""
 from typing import Any, Callable, Dict, List
 
 import numpy as np
@@ -21,13 +22,16 @@ class BeamSearchRunner(BaseRunner):
             self.rank = executor.rank
             self.decoder = executor.decoder
             self.postprocess = executor.postprocess
-            if num_sessions > 1:
-                raise NotImplementedError(
-                    "beam-search ensembling over several sessions is not implemented in the HIP "
-                    "engine yet (SURVEY 8f.4)")
+            self.ensemble = num_sessions > 1     # TensorFlowManager then calls run_ensemble once
 
         def next_to_execute(self) -> NextExecute:
+            if self.ensemble:
+                return {}, []
             return {"bs_outputs": self.decoder.outputs}, [{}]
+
+        def run_ensemble(self, ctxs) -> Dict[str, Any]:
+            """All sessions' run contexts at once (same device): the ensemble search."""
+            return {"bs_outputs": self.decoder.ensemble_outputs(ctxs)}
 
         def collect_results(self, results: List[Dict]) -> None:
             self.prepare_results(results[0]["bs_outputs"].last_search_step_output)

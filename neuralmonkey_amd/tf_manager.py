@@ -16,7 +16,7 @@ import torch
 
 from .model.model_part import Feedable
 from .runners.base_runner import ExecutionResult, GraphExecutor
-from .runtime import Session, registered_parts
+from .runtime import Session, registered_parts, RunContext, _to_host
 
 
 def default_device() -> torch.device:
@@ -100,9 +100,19 @@ class TensorFlowManager:
                     fdict.update(add_fd)
         for fdict in feed_dicts:
             fdict.update(feed_dict)
+        # executables that combine the models of all sessions on the device (beam-search ensembles)
+        ensemble_results = {}
+        for executable in pending:
+            if getattr(executable, "ensemble", False):
+                ctxs = [RunContext(sess, dict(fd)) for sess, fd in zip(self.sessions, feed_dicts)]
+                with torch.no_grad():
+                    ensemble_results[executable] = _to_host(executable.run_ensemble(ctxs))
         session_results = [sess.run(all_fetches, feed_dict=fd) for sess, fd in zip(self.sessions, feed_dicts)]
         for executable in pending:
-            executable.collect_results([res[executable] for res in session_results])
+            if executable in ensemble_results:
+                executable.collect_results([ensemble_results[executable] for _ in self.sessions])
+            else:
+                executable.collect_results([res[executable] for res in session_results])
 
     def execute(self, batch, feedables: Set[Feedable], runners: Sequence[GraphExecutor],
                 train: bool = False, compute_losses: bool = True,
