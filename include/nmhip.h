@@ -23,6 +23,9 @@ extern "C" {
 
 const char* nm_last_error(void);
 int nm_version(void);
+/* host utility: CRC-32C (Castagnoli) of a HOST buffer, chained through `crc` (start with 0) -- the
+ * checksum of TensorFlow tensor-bundle checkpoints (tf_manager.py:274-288 -> tf.train.Saver) */
+uint32_t nm_crc32c(uint32_t crc, const void* data, int64_t n);
 
 /* ---- dense projections: tf.matmul / tf.layers.dense / 1x1 tf.nn.conv2d -------------
  * attention/feed_forward.py:111-118 (keys), :130-132 (query);

@@ -25,6 +25,7 @@ F = c_float
 SIGNATURES = {
     "nm_last_error": (c_char_p, []),
     "nm_version": (I, []),
+    "nm_crc32c": (ctypes.c_uint32, [ctypes.c_uint32, P, L]),
     "nm_gemm_f32": (I, [P, I, I, L, L, L, P, L, P, L, P, L, P, I, I, L, L, L, L, I, P, L]),
     "nm_embedding_gather": (I, [P, P, L, L, P, L, P, L, I, F]),
     "nm_gru_gates_fwd": (I, [P, P, L, L, L, P, P, P, P, P, I, I, I, L, L]),

@@ -163,10 +163,22 @@ class VariableStore:
                 arr = arr.reshape(spec.shape)          # scalar () <-> (1,)
             self[n].copy_(torch.from_numpy(arr).to(self.device))
 
-    def save(self, path: str) -> None:
+    def save(self, path: str, fmt: str = "npz") -> None:
+        """``fmt`` "npz" (one file) or "tf" (TensorFlow tensor bundle ``path``.index / .data-00000-of-00001,
+        what the reference's tf.train.Saver writes: tf_manager.py:274-277)."""
+        if fmt == "tf":
+            from . import tf_bundle
+            tf_bundle.export_store(self, path)
+            return
         np.savez(path, **{k.replace("/", "|"): v for k, v in self.state_dict().items()})
 
     def load(self, path: str, strict: bool = True) -> None:
+        """A TensorFlow checkpoint prefix (``path``.index exists) or an .npz file."""
+        import os
+        if os.path.exists(path + ".index"):
+            from . import tf_bundle
+            tf_bundle.import_store(self, path, strict)
+            return
         if not path.endswith(".npz"):
             path = path + ".npz"
         with np.load(path) as data:

@@ -1,0 +1,133 @@
+"""TensorFlow tensor-bundle checkpoints (neuralmonkey_amd/tf_bundle.py): known answers of the
+published building blocks (CRC-32C, leveldb CRC masking, varints, protobuf encodings, SSTable footer)
+and write -> read round trips.  Host-only: runs in the CPU suite."""
+import struct
+
+import numpy as np
+import pytest
+
+from neuralmonkey_amd import tf_bundle as TB
+
+
+def test_crc32c_known_answers():
+    # RFC 3720 / leveldb crc32c_test.cc vectors
+    assert TB.crc32c(b"123456789") == 0xE3069283
+    assert TB.crc32c(bytes(32)) == 0x8A9136AA
+    assert TB.crc32c(b"\xff" * 32) == 0x62A8AB43
+    assert TB.crc32c(bytes(range(32))) == 0x46DD794E
+    assert TB.crc32c(bytes(range(31, -1, -1))) == 0x113FDB5C
+    # chaining and ndarray input
+    assert TB.crc32c(b"6789", TB.crc32c(b"12345")) == 0xE3069283
+    arr = np.arange(1000, dtype=np.float32)
+    assert TB.crc32c(arr) == TB.crc32c(arr.tobytes())
+    # leveldb mask: unmask(mask(x)) == x, and masking changes the value
+    crc = TB.crc32c(b"foo")
+    assert TB.unmask_crc(TB.mask_crc(crc)) == crc and TB.mask_crc(crc) != crc
+    assert TB.mask_crc(TB.mask_crc(crc)) != crc
+
+
+def test_varint_and_protobuf_encodings():
+    for value, enc in ((0, b"\x00"), (1, b"\x01"), (127, b"\x7f"), (128, b"\x80\x01"), (300, b"\xac\x02"),
+                       (2 ** 32, b"\x80\x80\x80\x80\x10")):
+        assert TB.put_varint(value) == enc
+        assert TB.get_varint(enc + b"\xff", 0) == (value, len(enc))
+    # BundleHeaderProto {num_shards: 1, version {producer: 1}}
+    assert TB.HEADER == b"\x08\x01\x1a\x02\x08\x01"
+    # BundleEntryProto {dtype: DT_FLOAT, shape {dim {size: 3} dim {size: 4}}, offset: 48, size: 48, crc32c}
+    enc = TB.encode_entry(1, (3, 4), 48, 48, 0xDEADBEEF)
+    assert enc == b"\x08\x01" + b"\x12\x08" + b"\x12\x02\x08\x03" + b"\x12\x02\x08\x04" + b"\x20\x30" + b"\x28\x30" \
+        + b"\x35" + struct.pack("<I", 0xDEADBEEF)
+    dec = TB.decode_entry(enc)
+    assert (dec["dtype"], dec["shape"], dec["offset"], dec["size"], dec["crc32c"]) == (1, [3, 4], 48, 48, 0xDEADBEEF)
+    scalar = TB.decode_entry(TB.encode_entry(9, (), 0, 8, 1))
+    assert scalar["shape"] == [] and scalar["offset"] == 0 and scalar["dtype"] == 9
+
+
+def test_sstable_round_trip_and_layout():
+    rng = np.random.default_rng(0)
+    items = [(b"", b"header")]
+    for i in range(700):        # several 4 KB blocks, long shared prefixes
+        items.append(("decoder/attention_decoder/layer_{:04d}/kernel".format(i).encode(),
+                      bytes(rng.integers(0, 256, size=int(rng.integers(1, 60)), dtype=np.uint8))))
+    table = TB.write_table(items)
+    assert struct.unpack("<Q", table[-8:])[0] == 0xDB4775248B80FB57 and len(table[-48:]) == 48
+    assert TB.read_table(table) == sorted(items)
+    # a flipped payload byte is caught by the block checksum
+    bad = bytearray(table)
+    bad[100] ^= 0x40
+    with pytest.raises(ValueError):
+        TB.read_table(bytes(bad))
+    with pytest.raises(ValueError):
+        TB.read_table(table[:-1] + b"\x00")
+
+
+def test_bundle_round_trip(tmp_path):
+    rng = np.random.default_rng(1)
+    tensors = {"encoder/rnn/kernel": rng.standard_normal((37, 12)).astype(np.float32),
+               "attention/attn_key_projection": rng.standard_normal((1, 1, 8, 6)).astype(np.float32),
+               "attention/attn_bias": np.float32(0.25),
+               "global_step": np.int64(1234),
+               "lengths": np.arange(7, dtype=np.int32)}
+    prefix = str(tmp_path / "variables.data")
+    TB.write_bundle(prefix, tensors)
+    got = TB.read_bundle(prefix)
+    assert sorted(got) == sorted(tensors)
+    for name, arr in tensors.items():
+        assert got[name].dtype == np.asarray(arr).dtype and got[name].shape == np.asarray(arr).shape
+        assert np.array_equal(got[name], arr)
+    # corrupt one tensor byte: the per-tensor CRC-32C catches it
+    data_file = prefix + ".data-00000-of-00001"
+    raw = bytearray(open(data_file, "rb").read())
+    raw[5] ^= 1
+    open(data_file, "wb").write(bytes(raw))
+    with pytest.raises(ValueError):
+        TB.read_bundle(prefix)
+
+
+def test_store_export_import(tmp_path):
+    import torch
+    from neuralmonkey_amd.variables import VariableStore, random_normal_initializer, zeros_initializer
+    store = VariableStore("cpu", seed=3)
+    store.declare("attention/attn_key_projection", (8, 6), random_normal_initializer(stddev=0.5))
+    store.declare("attention/attn_bias", (1,), random_normal_initializer(stddev=0.5))
+    store.declare("encoder/conv2d/kernel", (5, 4), random_normal_initializer(stddev=0.5))
+    store.declare("decoder/state_to_word_b", (9,), zeros_initializer())
+    store.finalize()
+    m, v = store.ensure_adam()
+    m.copy_(torch.arange(store.total, dtype=torch.float32))
+    v.copy_(torch.arange(store.total, dtype=torch.float32) * 2)
+    prefix = str(tmp_path / "variables.data")
+    TB.export_store(store, prefix, global_step=17, with_adam=True)
+    raw = TB.read_bundle(prefix)
+    # TensorFlow's shapes on disk: conv filters [1,1,in,out], scalar attention bias
+    assert raw["attention/attn_key_projection"].shape == (1, 1, 8, 6)
+    assert raw["encoder/conv2d/kernel"].shape == (1, 1, 5, 4)
+    assert raw["attention/attn_bias"].shape == ()
+    assert int(raw["global_step"]) == 17 and "decoder/state_to_word_b/Adam_1" in raw
+    other = VariableStore("cpu", seed=99)
+    for name, spec in store.specs.items():
+        other.declare(name, spec.shape, zeros_initializer())
+    other.finalize()
+    info = TB.import_store(other, prefix)
+    assert info == {"missing": [], "unused": [], "global_step": 17}
+    for name in store.names():
+        assert torch.equal(other[name], store[name])
+    for spec in store.specs.values():          # (alignment padding between variables is not stored)
+        sl = slice(spec.offset, spec.offset + spec.size)
+        assert torch.equal(other.adam_m[sl], store.adam_m[sl]) and torch.equal(other.adam_v[sl], store.adam_v[sl])
+    # VariableStore.load picks the bundle up by its prefix; save(fmt="tf") writes one
+    third = VariableStore("cpu", seed=5)
+    for name, spec in store.specs.items():
+        third.declare(name, spec.shape, zeros_initializer())
+    third.finalize()
+    third.load(prefix)
+    assert all(torch.equal(third[n], store[n]) for n in store.names())
+    third.save(str(tmp_path / "again"), fmt="tf")
+    assert set(TB.read_bundle(str(tmp_path / "again"))) == set(store.names())
+    # a variable the checkpoint lacks
+    third2 = VariableStore("cpu", seed=5)
+    third2.declare("new/variable", (3,), zeros_initializer())
+    third2.finalize()
+    with pytest.raises(KeyError):
+        TB.import_store(third2, prefix)
+    assert TB.import_store(third2, prefix, strict=False)["missing"] == ["new/variable"]
