@@ -37,6 +37,9 @@ class TensorFlowManager:
         self.saver_max_to_keep = save_n_best
         self.minimize_metric = minimize_metric
         self.num_sessions = num_sessions
+        # "npz" (one file per checkpoint) or "tf": TensorFlow tensor bundles, the format the reference's
+        # tf.train.Saver writes (tf_manager.py:274-277); restore() recognises either by the files present
+        self.checkpoint_format = os.environ.get("NM_CHECKPOINT_FORMAT", "npz")
         self.num_threads = num_threads
         self.device = torch.device(device) if device is not None else default_device()
         self.seed = seed
@@ -147,7 +150,7 @@ class TensorFlowManager:
         if self.saver is None:
             raise RuntimeError("Saver uninitialized")
         if isinstance(variable_files, str) and len(self.sessions) == 1:
-            self.sessions[0].store.save(variable_files)
+            self.sessions[0].store.save(variable_files, fmt=self.checkpoint_format)
             return
         if isinstance(variable_files, str):
             variable_files = ["{}.{}".format(variable_files, i) for i in range(len(self.sessions))]
@@ -155,7 +158,7 @@ class TensorFlowManager:
             raise Exception("Provided {} files for saving {} sessions.".format(
                 len(variable_files), len(self.sessions)))
         for sess, file_name in zip(self.sessions, variable_files):
-            sess.store.save(file_name)
+            sess.store.save(file_name, fmt=self.checkpoint_format)
 
     def restore(self, variable_files: Union[str, List[str]]) -> None:
         if self.saver is None:
