@@ -209,3 +209,132 @@ def test_transformer_greedy_and_beam(dev, case):
     if gap > 1e-5:
         assert np.array_equal(got_tok[1:], tok[1:])
     assert np.abs(np.asarray(got.last_search_step_output.scores) - scores).max() <= 1e-4 * np.abs(scores).max()
+
+
+TRANSFORMER_INI = """
+; model / trainer / runner sections of the reference's tests/transformer.ini and tests/beamsearch.ini
+[main]
+name="transformer.ini shape"
+tf_manager=<tf_manager>
+batch_size=4
+epochs=1
+train_dataset=<train_data>
+trainer=<trainer>
+runners=[<runner>, <beam_runners>]
+[tf_manager]
+class=tf_manager.TensorFlowManager
+num_threads=4
+num_sessions={sessions}
+[batching]
+class=dataset.BatchingScheme
+batch_size=4
+[train_data]
+class=dataset.load
+series=["source", "target"]
+data=["{src}", "{tgt}"]
+batching=<batching>
+[encoder_vocabulary]
+class=vocabulary.from_wordlist
+path="{vocab}"
+[inpseq]
+class=model.sequence.EmbeddedSequence
+name="input"
+embedding_size=6
+max_length=7
+data_id="source"
+vocabulary=<encoder_vocabulary>
+[encoder]
+class=encoders.transformer.TransformerEncoder
+name="transformer_encoder"
+input_sequence=<inpseq>
+ff_hidden_size=10
+depth=2
+n_heads=3
+dropout_keep_prob=0.9
+[decoder]
+class=decoders.transformer.TransformerDecoder
+name="decoder"
+encoders=[<encoder>]
+dropout_keep_prob=0.5
+data_id="target"
+max_output_len=5
+vocabulary=<encoder_vocabulary>
+embedding_size=6
+ff_hidden_size=10
+depth=2
+n_heads_self=3
+n_heads_enc=2
+[trainer]
+class=trainers.delayed_update_trainer.DelayedUpdateTrainer
+batches_per_update=2
+l2_weight=1.0e-8
+clip_norm=1.0
+objectives=[<obj>]
+optimizer=<lazyadam_g>
+[obj]
+class=trainers.cross_entropy_trainer.CostObjective
+decoder=<decoder>
+[decayed_lr]
+class=functions.noam_decay
+learning_rate=0.2
+model_dimension=6
+warmup_steps=20
+[lazyadam_g]
+class=tf.contrib.opt.LazyAdamOptimizer
+beta1=0.9
+beta2=0.98
+epsilon=1.0e-9
+learning_rate=<decayed_lr>
+[runner]
+class=runners.GreedyRunner
+decoder=<decoder>
+output_series="target"
+[beam_decoder]
+class=decoders.beam_search_decoder.BeamSearchDecoder
+parent_decoder=<decoder>
+beam_size=3
+max_steps=5
+length_normalization=0.6
+[beam_runners]
+class=runners.beam_search_runner_range
+output_series="target_beam"
+decoder=<beam_decoder>
+max_rank=2
+"""
+
+
+def _write_transformer_ini(tmp_path, sessions):
+    (tmp_path / "src.txt").write_text("a b c\nb c\nc a a b\na\n")
+    (tmp_path / "tgt.txt").write_text("b a\nc\nb b a\nc c\n")
+    (tmp_path / "vocab.tsv").write_text("Word\tCount\n<pad>\t1\n<s>\t1\n</s>\t1\n<unk>\t1\na\t9\nb\t8\nc\t7\n")
+    path = tmp_path / "transformer_{}.ini".format(sessions)
+    path.write_text(TRANSFORMER_INI.format(src=tmp_path / "src.txt", tgt=tmp_path / "tgt.txt",
+                                           vocab=tmp_path / "vocab.tsv", sessions=sessions))
+    return str(path)
+
+
+def test_transformer_ini_experiment_and_ensemble_invariant(dev, tmp_path):
+    """The model of tests/transformer.ini (+ the beam runners of tests/beamsearch.ini) builds from INI
+    text, trains with DelayedUpdateTrainer / noam_decay / LazyAdam (falling loss), decodes greedily and
+    with beam search; a 2-session ensemble of the trained model with itself decodes the same sentences
+    (tests/beamsearch_ensembles.ini, tests/tests_run.sh:41-50)."""
+    from neuralmonkey_amd.config.configuration import load_experiment
+    model = load_experiment(_write_transformer_ini(tmp_path, 1), device=str(dev), seed=1234)
+    tfm = model.tf_manager
+    batch = next(model.train_dataset.batches())
+    feedables = set.union(*[r.feedables for r in model.runners + model.trainers])
+    losses = [tfm.execute(batch, feedables, model.trainers, train=True)[0].losses["decoder - cost"]
+              for _ in range(80)]
+    assert tfm.sessions[0].global_step == 40                      # one update per two batches
+    assert np.mean(losses[-10:]) < np.mean(losses[:10]) - 0.05, (losses[:3], losses[-3:])
+    single = tfm.execute(batch, feedables, model.runners, compute_losses=False)
+    assert [len(r.outputs[s]) for r, s in zip(single, ("target", "target_beam.rank001", "target_beam.rank002"))] \
+        == [4, 4, 4]
+    trained = tfm.sessions[0].store.state_dict()
+    ens = load_experiment(_write_transformer_ini(tmp_path, 2), device=str(dev), seed=99)
+    for sess in ens.tf_manager.sessions:
+        sess.store.load_state_dict(trained)
+    feedables2 = set.union(*[r.feedables for r in ens.runners])
+    both = ens.tf_manager.execute(next(ens.train_dataset.batches()), feedables2, ens.runners, compute_losses=False)
+    for one, two, series in zip(single, both, ("target", "target_beam.rank001", "target_beam.rank002")):
+        assert one.outputs[series] == two.outputs[series], series
