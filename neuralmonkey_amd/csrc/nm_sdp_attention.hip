@@ -176,16 +176,22 @@ struct SdpBwdArgs {
     int accumulate;            // dq/dk/dv += instead of =
 };
 
+// WLDS: the [Tq,Tk] energy-gradient and dropped-weight matrices of the head stay in LDS between the
+// two phases (phase 2 walks them by columns); otherwise they go through global memory.
+template <bool WLDS>
 __global__ __launch_bounds__(256) void sdp_bwd_kernel(SdpBwdArgs a) {
     extern __shared__ float sm[];
     const SdpArgs& p = a.f;
     const int ldt = p.dh + 1;
+    const int ldw = p.Tk + 1;
     float* ks = sm;                                 // [Tk][dh+1]
     float* vs = ks + (long)p.Tk * ldt;              // [Tk][dh+1]
     float* qs = vs + (long)p.Tk * ldt;              // [Tq][dh+1] scaled queries
     float* gs = qs + (long)p.Tq * ldt;              // [Tq][dh+1] dctx
     float* ms = gs + (long)p.Tq * ldt;              // [Tk]
     float* rw = ms + p.Tk;                          // [4 waves][Tk] row scratch
+    float* des = rw + 4 * p.Tk;                     // [Tq][Tk+1] energy gradients        (WLDS)
+    float* wds = des + (WLDS ? (long)p.Tq * ldw : 0);   // [Tq][Tk+1] dropout(weights)    (WLDS)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.x % p.H, b = blockIdx.x / p.H;
@@ -220,9 +226,11 @@ __global__ __launch_bounds__(256) void sdp_bwd_kernel(SdpBwdArgs a) {
             const float* gr = gs + i * ldt;
             const float* vr = vs + j * ldt;
             for (int c = 0; c < p.dh; ++c) acc += gr[c] * vr[c];
-            const float dw = acc * sdp_keep(p, b, h, i, j);       // through the weight dropout
+            const float keep = sdp_keep(p, b, h, i, j);
+            const float dw = acc * keep;                           // through the weight dropout
             row[j] = dw;
             dot += dw * wg[j];
+            if (WLDS) wds[i * ldw + j] = wg[j] * keep;
         }
         dot = nm_wave_sum(dot);
         for (int j = lane; active && j < p.Tk; j += 64) {
@@ -230,7 +238,8 @@ __global__ __launch_bounds__(256) void sdp_bwd_kernel(SdpBwdArgs a) {
             if (p.causal && j > i + p.Tk - p.Tq) de = 0.0f;        // tf.where passes no gradient
             de *= ms[j];                                           // e*m + const
             row[j] = de;
-            a.de[wbase + j] = de;
+            if (WLDS) des[i * ldw + j] = de;
+            else a.de[wbase + j] = de;
         }
         __syncthreads();
         float* dqg = a.dq + (long)b * a.dq_bs + (long)i * d + (long)h * p.dh;
@@ -250,10 +259,17 @@ __global__ __launch_bounds__(256) void sdp_bwd_kernel(SdpBwdArgs a) {
         float* dvg = a.dv + (long)b * a.dv_bs + (long)j * d + (long)h * p.dh;
         for (int c = lane; c < p.dh; c += 64) {
             float acck = 0.0f, accv = 0.0f;
-            for (int i = 0; i < p.Tq; ++i) {
-                const long wi = (((long)b * p.H + h) * p.Tq + i) * p.Tk + j;
-                acck += a.de[wi] * qs[i * ldt + c];
-                accv += p.weights[wi] * sdp_keep(p, b, h, i, j) * gs[i * ldt + c];
+            if (WLDS) {
+                for (int i = 0; i < p.Tq; ++i) {
+                    acck += des[i * ldw + j] * qs[i * ldt + c];
+                    accv += wds[i * ldw + j] * gs[i * ldt + c];
+                }
+            } else {
+                for (int i = 0; i < p.Tq; ++i) {
+                    const long wi = (((long)b * p.H + h) * p.Tq + i) * p.Tk + j;
+                    acck += a.de[wi] * qs[i * ldt + c];
+                    accv += p.weights[wi] * sdp_keep(p, b, h, i, j) * gs[i * ldt + c];
+                }
             }
             dkg[c] = a.accumulate ? dkg[c] + acck : acck;
             dvg[c] = a.accumulate ? dvg[c] + accv : accv;
@@ -271,9 +287,12 @@ extern "C" int nm_sdp_attn_bwd(void* stream, const float* q, int64_t q_bs, const
     NM_REQUIRE(B > 0 && Tq > 0 && Tk > 0 && H > 0 && dh > 0, "nm_sdp_attn_bwd: bad shape");
     NM_REQUIRE(keep_prob > 0.0f && keep_prob <= 1.0f, "nm_sdp_attn_bwd: keep_prob %g outside (0,1]", keep_prob);
     NM_REQUIRE(B * H < (1LL << 31), "nm_sdp_attn_bwd: grid too large");
-    const size_t lds = sizeof(float) * (2 * (Tk + Tq) * (dh + 1) + Tk + 4 * Tk);
+    size_t lds = sizeof(float) * (2 * (Tk + Tq) * (dh + 1) + Tk + 4 * Tk);
     NM_REQUIRE(lds <= 160 * 1024, "nm_sdp_attn_bwd: Tq=%ld Tk=%ld dh=%ld tiles do not fit LDS", (long)Tq, (long)Tk,
                (long)dh);
+    const size_t lds_w = lds + sizeof(float) * 2 * Tq * (Tk + 1);
+    const bool wlds = lds_w <= 160 * 1024;          // base shape (T=50, dh=64): 72 KB
+    if (wlds) lds = lds_w;
     SdpBwdArgs a;
     SdpArgs& p = a.f;
     p.q = q; p.q_bs = q_bs; p.k = k; p.k_bs = k_bs; p.v = v; p.v_bs = v_bs;
@@ -286,10 +305,14 @@ extern "C" int nm_sdp_attn_bwd(void* stream, const float* q, int64_t q_bs, const
     a.dv = dv; a.dv_bs = dv_bs; a.de = de_workspace; a.accumulate = accumulate;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)sdp_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)sdp_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024);
+        (void)hipFuncSetAttribute((const void*)sdp_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(sdp_bwd_kernel, dim3((unsigned)(B * H)), dim3(256), lds, nm_stream(stream), a);
+    if (wlds) hipLaunchKernelGGL(sdp_bwd_kernel<true>, dim3((unsigned)(B * H)), dim3(256), lds, nm_stream(stream), a);
+    else hipLaunchKernelGGL(sdp_bwd_kernel<false>, dim3((unsigned)(B * H)), dim3(256), lds, nm_stream(stream), a);
     NM_LAUNCH_CHECK("nm_sdp_attn_bwd");
 }
 

@@ -7,7 +7,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from neuralmonkey_amd import synthetic  # noqa: E402
 from neuralmonkey_amd.decoders import BeamSearchDecoder, TransformerDecoder  # noqa: E402
 from neuralmonkey_amd.encoders import TransformerEncoder  # noqa: E402
