@@ -59,6 +59,8 @@ class GeneralDecoderMixin:
         proj = self.output_projection
         if not isinstance(proj, NonlinearOutput) or proj.activation not in ("tanh", "identity"):
             return True
+        if train_mode and not getattr(self.encoder_projection, "fast_path", True):
+            return True                  # the projection has no hand-scheduled backward (nematus_projection)
         if train_mode:
             keeps = [self.dropout_keep_prob, proj.dropout_keep_prob, self.encoder_projection.dropout_keep_prob]
             keeps += [getattr(a, "dropout_keep_prob", 1.0) for a in self.attentions]
@@ -166,6 +168,16 @@ class GeneralDecoderMixin:
             enc_grads.setdefault(att.encoder, [None, None])[0] = sess.d_states
         for enc, var in zip(self.encoders, sv["enc_outs"]):
             enc_grads.setdefault(enc, [None, None])[1] = var.grad
+        proj_states = getattr(self.encoder_projection, "states_var", None)
+        if proj_states is not None and proj_states.grad is not None:     # nematus_projection reads the states
+            enc = self.encoders[0]
+            slot = enc_grads.setdefault(enc, [None, None])
+            g = proj_states.grad.view(sv["bsz"], -1, proj_states.shape[1])
+            if slot[0] is None:
+                slot[0] = g
+            else:
+                ops.ew("copy", g.reshape(-1, g.shape[-1]), None, slot[0].reshape(-1, g.shape[-1]), accumulate=True)
+            self.encoder_projection.states_var = None
         for enc, (dst, dfin) in enc_grads.items():
             if hasattr(enc, "backward"):
                 enc.backward(ctx, dst, dfin)

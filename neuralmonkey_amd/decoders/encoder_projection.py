@@ -149,5 +149,73 @@ def linear_encoder_projection(dropout_keep_prob: float) -> EncoderProjection:
     return _Linear(dropout_keep_prob)
 
 
+class _Nematus(EncoderProjection):
+    """nematus_projection (encoder_projection.py:99-145): tanh(dense(dropout(mean over the valid
+    positions of the encoder states))).  The masked mean is a batched [1,S] x [S,D] GEMM with the
+    host-built weights mask/length; training runs on the tape (no hand-scheduled backward)."""
+    fast_path = False
+
+    def __init__(self, dropout_keep_prob: float):
+        self.dropout_keep_prob = dropout_keep_prob
+
+    def output_size(self, rnn_size, encoders):
+        if rnn_size is None:
+            raise ValueError("You must supply rnn_size for this type of encoder projection")
+        return rnn_size
+
+    @staticmethod
+    def _encoder(encoders):
+        if len(encoders) != 1:
+            raise ValueError("Exactly one encoder required for this type of projection. {} given."
+                             .format(len(encoders)))
+        return encoders[0]
+
+    def declare_variables(self, decoder, store, rnn_size, encoders):
+        from ..variables import orthogonal_initializer
+        dim = self._encoder(encoders).dimension
+        decoder.declare(store, "initial_state/encoders_projection/kernel", (dim, rnn_size),
+                        orthogonal_initializer() if dim == rnn_size else None)
+        decoder.declare(store, "initial_state/encoders_projection/bias", (rnn_size,), zeros_initializer())
+
+    @staticmethod
+    def _mean_weights(ctx, encoder):
+        """[B,1,S] = mask / length (host arithmetic on the fed mask, then resident on the device)."""
+        mask = encoder.temporal_mask(ctx)
+        lens = mask.sum(1, keepdim=True)                 # plumbing: B scalars
+        return (mask / lens).unsqueeze(1).contiguous()
+
+    def apply(self, ctx, decoder, rnn_size, encoders, out, train_mode):
+        enc = self._encoder(encoders)
+        states = enc.temporal_states(ctx)
+        bsz, slen, dim = states.shape
+        means = ctx.buffer((id(self), "means", bsz), (bsz, 1, dim))
+        ops.gemm(self._mean_weights(ctx, enc), states, out=means)
+        means2 = dropout(ctx, means.view(bsz, dim), self.dropout_keep_prob, train_mode)
+        return ops.gemm(means2, decoder.var(ctx, "initial_state/encoders_projection/kernel"), out=out,
+                        bias=decoder.var(ctx, "initial_state/encoders_projection/bias"), act="tanh")
+
+    def apply_var(self, tape, decoder, rnn_size, enc_outputs, bsz, train_mode):
+        ctx = tape.ctx
+        enc = self._encoder(decoder.encoders)
+        states = enc.temporal_states(ctx)
+        _, slen, dim = states.shape
+        weights = self._mean_weights(ctx, enc)
+        st_var = tape.leaf(states.reshape(bsz * slen, dim), needs_grad=True)
+        self.states_var = st_var                          # the decoder adds its gradient to d(encoder states)
+        means = tape.new((bsz, dim))
+        ops.gemm(weights, states, out=means.data.view(bsz, 1, dim))
+
+        def bwd():
+            if means.grad is not None:
+                ops.gemm(weights, means.grad.view(bsz, 1, dim), out=tape.grad(st_var).view(bsz, slen, dim),
+                         trans_a=True, accumulate=True)
+        tape.record(bwd)
+        dropped = F.dropout(tape, means, self.dropout_keep_prob, train_mode,
+                            ctx.salt(decoder.name, "encoders_projection"))      # (bwd closes over ``means``)
+        pre = F.linear(tape, dropped, tape.param(decoder, "initial_state/encoders_projection/kernel"),
+                       tape.param(decoder, "initial_state/encoders_projection/bias"))
+        return F.tanh(tape, pre)
+
+
 def nematus_projection(dropout_keep_prob: float = 1.0) -> EncoderProjection:
-    raise NotImplementedError("nematus_projection is not implemented in the HIP engine yet")
+    return _Nematus(dropout_keep_prob)

@@ -301,11 +301,16 @@ class GeneralModel:
             lg = lg + unk
         return lg
 
-    def initial_state(self, final, train):
+    def initial_state(self, final, train, states=None, mask=None):
         cfg, p = self.cfg, self.p
         d = cfg.dec_name
         bsz = final.shape[0]
-        if cfg.encoder_projection == "linear":                         # encoder_projection.py:47-73
+        if cfg.encoder_projection == "nematus":                        # encoder_projection.py:99-145
+            means = (states * mask.unsqueeze(-1)).sum(1) / mask.sum(1, keepdim=True)
+            means = self.dropout(means, cfg.dec_dropout, train, d, "encoders_projection")
+            s0 = torch.tanh(means @ p[d + "/initial_state/encoders_projection/kernel"]
+                            + p[d + "/initial_state/encoders_projection/bias"])
+        elif cfg.encoder_projection == "linear":                         # encoder_projection.py:47-73
             s0 = final @ p[d + "/initial_state/encoders_projection/kernel"] \
                 + p[d + "/initial_state/encoders_projection/bias"]
             s0 = self.dropout(s0, cfg.dec_dropout, train, d, "encoders_projection")
@@ -325,7 +330,7 @@ class GeneralModel:
         emb_all = p[cfg.dec_name + "/word_embeddings"][torch.as_tensor(dec_in.reshape(-1).astype(np.int64))]
         emb_all = self.dropout(emb_all, cfg.dec_dropout, train, cfg.dec_name, "embedded_input")
         emb_all = emb_all.view(steps, bsz, -1)
-        s0 = self.initial_state(final, train)
+        s0 = self.initial_state(final, train, states, mask)
         csz = st.shape[-1]
         state = [s0, s0, torch.zeros(bsz, csz, dtype=self.dtype)]
         outs, weights = [], []
@@ -360,7 +365,7 @@ class GeneralModel:
     def _decode_setup(self, src_ids, rep: int = 1):
         states, mask, final = self.encode(src_ids, False)
         st, hf = self.attention_setup(states, False)
-        s0 = self.initial_state(final, False)
+        s0 = self.initial_state(final, False, states, mask)
         if rep > 1:
             st, hf, mask, s0 = (x.repeat_interleave(rep, 0) for x in (st, hf, mask, s0))
         rows = s0.shape[0]

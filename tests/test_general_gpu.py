@@ -48,8 +48,8 @@ def _build(dev, cfg: G.Config, emb_src, emb_tgt, max_len=8, beam=3, seed=5, init
     else:
         proj = OP.mlp_output(list(cfg.output_projection[1]), act(cfg.output_projection[2]), cfg.output_projection[3])
     # concat is what the reference infers from rnn_size=None without a projection (decoder.py:176-191)
-    enc_proj = {"linear": None, "concat": None,
-                "empty": EP.empty_initial_state}[cfg.encoder_projection]
+    enc_proj = {"linear": None, "concat": None, "empty": EP.empty_initial_state,
+                "nematus": EP.nematus_projection(cfg.dec_dropout)}[cfg.encoder_projection]
     dec = Decoder(encoders=[enc], vocabulary=vocab, data_id="target", name=cfg.dec_name, max_output_len=max_len,
                   dropout_keep_prob=cfg.dec_dropout, embedding_size=emb_tgt,
                   rnn_size=None if cfg.encoder_projection == "concat" else cfg.rnn_size,
@@ -114,6 +114,10 @@ CASES = {
     "smoothing_fast": (G.Config(rnn_layers=((4, "bidirectional", "GRU"),), rnn_size=8, label_smoothing=0.1), 8, 8),
     "smoothing_taped": (G.Config(rnn_layers=((4, "bidirectional", "NematusGRU"),), dec_cell="NematusGRU",
                                  rnn_size=8, label_smoothing=0.2), 8, 8),
+    # tests/nematus.ini shape: NematusGRU everywhere, conditional GRU, nematus initial state and output
+    "nematus_ini": (G.Config(rnn_layers=((6, "bidirectional", "NematusGRU"),), enc_dropout=0.9, dec_cell="NematusGRU",
+                             conditional_gru=True, dec_dropout=0.8, rnn_size=8, encoder_projection="nematus",
+                             output_projection=("nematus", "tanh", 0.8)), 10, 8),
     "concat_tied": (G.Config(rnn_layers=((4, "bidirectional", "GRU"),), include_final_layer_norm=False,
                              encoder_projection="concat", rnn_size=8, tie_embeddings=True, attention_on_input=True,
                              output_projection=("nonlinear", "relu", 1.0)), 8, 8),

@@ -167,8 +167,8 @@ def test_unsupported_features_refuse_loudly():
     with pytest.raises(ValueError):
         Decoder(encoders=[], vocabulary=vocab, data_id="t", name="d", max_output_len=5, embedding_size=4,
                 rnn_size=4, label_smoothing=1.5)
-    with pytest.raises(NotImplementedError):
-        nematus_projection()
+    with pytest.raises(ValueError):          # nematus_projection: exactly one encoder
+        nematus_projection().declare_variables(None, None, 4, [])
     with pytest.raises(NotImplementedError):
         Decoder(encoders=[], vocabulary=vocab, data_id="t", name="ds", max_output_len=5, embedding_size=4,
                 rnn_size=4).decoding_loop(None, False, sample=True)
