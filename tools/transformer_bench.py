@@ -1,13 +1,13 @@
 """Transformer-base shape (BASELINE configs[4]: 6+6 layers, d=512, 8 heads, ff 2048, tied embeddings,
 B=128, len 50, V=32000): training step time, greedy and beam-5 decode time on one GPU.
 Not a bench.py line (configs[4] is a parity case); numbers go into DESIGN.md."""
+import os
 import sys
 import time
 
-import numpy as np
 import torch
 
-sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from neuralmonkey_amd import synthetic  # noqa: E402
 from neuralmonkey_amd.decoders import BeamSearchDecoder, TransformerDecoder  # noqa: E402
 from neuralmonkey_amd.encoders import TransformerEncoder  # noqa: E402
