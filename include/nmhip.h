@@ -202,7 +202,9 @@ int nm_blend_bwd(void* stream, const float* dy, int64_t lddy, const float* u, in
 /* nn/utils.py:6-22 (tf.nn.dropout): keep iff floor(keep_prob + u_i) == 1, scale 1/keep_prob;
  * u_i = hash(salt, i) (counter based: the backward pass and the CPU oracle regenerate the mask) */
 int nm_dropout(void* stream, const float* x, int64_t ldx, float* out, int64_t ldo, int64_t rows,
-               int64_t cols, float keep_prob, uint32_t salt, int accumulate);
+               int64_t cols, float keep_prob, uint32_t salt, const uint32_t* step /* optional device
+               scalar (the global step): salt += step * 0x9E3779B9, so a HIP-graph replay of a training
+               step draws fresh masks */, int accumulate);
 /* tf.nn.dynamic_rnn(sequence_length) step t (encoders/recurrent.py:86-110): rows with
  * t >= lengths[r] carry h_prev through and emit zeros */
 int nm_rnn_select_fwd(void* stream, const float* h_new, int64_t ld_new, const float* h_prev,
@@ -231,12 +233,13 @@ int nm_maxout_bwd(void* stream, const float* dy, int64_t lddy, const int32_t* ar
 int nm_sdp_attn_fwd(void* stream, const float* q, int64_t q_bs, const float* k, int64_t k_bs,
                     const float* v, int64_t v_bs, const float* key_mask, int64_t mask_bs, int64_t Bq,
                     int64_t rows_per_key, int64_t Tq, int64_t Tk, int64_t H, int64_t dh, int causal,
-                    float keep_prob, uint32_t salt, float* ctx, int64_t ctx_bs, float* weights);
+                    float keep_prob, uint32_t salt, const uint32_t* step /* as nm_dropout */, float* ctx,
+                    int64_t ctx_bs, float* weights);
 int nm_sdp_attn_bwd(void* stream, const float* q, int64_t q_bs, const float* k, int64_t k_bs,
                     const float* v, int64_t v_bs, const float* key_mask, int64_t mask_bs,
                     const float* weights, const float* dctx, int64_t dctx_bs, int64_t B, int64_t Tq,
                     int64_t Tk, int64_t H, int64_t dh, int causal, float keep_prob, uint32_t salt,
-                    float* dq, int64_t dq_bs, float* dk, int64_t dk_bs, float* dv, int64_t dv_bs,
+                    const uint32_t* step, float* dq, int64_t dq_bs, float* dk, int64_t dk_bs, float* dv, int64_t dv_bs,
                     float* de_workspace /* [B,H,Tq,Tk] */, int accumulate);
 /* out[b,t,:] = x[b,t,:] + signal[t0+t,:]  (position_signal, encoders/transformer.py:23-45) */
 int nm_add_position(void* stream, const float* x, const float* signal, float* out, int64_t B, int64_t T,

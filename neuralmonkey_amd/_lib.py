@@ -60,14 +60,14 @@ SIGNATURES = {
     "nm_ew": (I, [P, I, P, L, P, L, P, L, L, L, F, I]),
     "nm_blend_fwd": (I, [P, P, L, P, L, P, L, P, L, L, L]),
     "nm_blend_bwd": (I, [P, P, L, P, L, P, L, P, L, P, L, P, L, P, L, L, L]),
-    "nm_dropout": (I, [P, P, L, P, L, L, L, F, ctypes.c_uint32, I]),
+    "nm_dropout": (I, [P, P, L, P, L, L, L, F, ctypes.c_uint32, P, I]),
     "nm_rnn_select_fwd": (I, [P, P, L, P, L, P, I, P, L, P, L, L, L]),
     "nm_rnn_select_bwd": (I, [P, P, L, P, L, P, I, P, L, P, L, L, L]),
     "nm_reverse_sequence": (I, [P, P, P, P, L, L, L, I]),
     "nm_maxout_fwd": (I, [P, P, L, P, L, P, L, L, L]),
     "nm_maxout_bwd": (I, [P, P, L, P, P, L, L, L, L]),
-    "nm_sdp_attn_fwd": (I, [P, P, L, P, L, P, L, P, L, L, L, L, L, L, L, I, F, ctypes.c_uint32, P, L, P]),
-    "nm_sdp_attn_bwd": (I, [P, P, L, P, L, P, L, P, L, P, P, L, L, L, L, L, L, I, F, ctypes.c_uint32,
+    "nm_sdp_attn_fwd": (I, [P, P, L, P, L, P, L, P, L, L, L, L, L, L, L, I, F, ctypes.c_uint32, P, P, L, P]),
+    "nm_sdp_attn_bwd": (I, [P, P, L, P, L, P, L, P, L, P, P, L, L, L, L, L, L, I, F, ctypes.c_uint32, P,
                             P, L, P, L, P, L, P, I]),
     "nm_add_position": (I, [P, P, P, P, L, L, L, L]),
     "nm_unfinished_mask": (I, [P, P, P, L, L]),

@@ -240,11 +240,12 @@ def dropout(tape: Tape, x: Var, keep_prob: float, train_mode: bool, salt: int) -
     if keep_prob == 1.0 or not train_mode:
         return x
     out = tape.new(tuple(x.shape))
-    ops.dropout(x.data, out.data, keep_prob, salt)
+    step = tape.ctx.session.step_tensor()          # device-side global step: fresh masks on graph replays
+    ops.dropout(x.data, out.data, keep_prob, salt, step=step)
 
     def bwd():
         if out.grad is not None and x.needs_grad:
-            ops.dropout(out.grad, tape.grad(x), keep_prob, salt, accumulate=True)
+            ops.dropout(out.grad, tape.grad(x), keep_prob, salt, accumulate=True, step=step)
     tape.record(bwd)
     return out
 
@@ -364,8 +365,9 @@ def sdp_attention(tape: Tape, q: Var, k: Var, v: Var, key_mask: Optional[torch.T
     w = tape.buf((bq, heads, tq, tk)) if tape.recording else None
     k3 = k_data if k_data is not None else k.data.view(bk, tk, d)
     v3 = v_data if v_data is not None else v.data.view(bk, tk, d)
+    step = tape.ctx.session.step_tensor() if keep_prob < 1.0 else None
     ops.sdp_attn_fwd(q.data.view(bq, tq, d), k3, v3, key_mask, heads, out.data.view(bq, tq, d), w, causal,
-                     bq // bk, keep_prob, salt)
+                     bq // bk, keep_prob, salt, step)
 
     def bwd():
         if out.grad is None:
@@ -374,7 +376,7 @@ def sdp_attention(tape: Tape, q: Var, k: Var, v: Var, key_mask: Optional[torch.T
         de = tape.buf((bq, heads, tq, tk))
         ops.sdp_attn_bwd(q.data.view(bq, tq, d), k3, v3, key_mask, w, out.grad.view(bq, tq, d), heads,
                          tape.grad(q).view(bq, tq, d), tape.grad(k).view(bk, tk, d), tape.grad(v).view(bk, tk, d),
-                         de, causal, keep_prob, salt, accumulate=True)
+                         de, causal, keep_prob, salt, accumulate=True, step=step)
     tape.record(bwd)
     return out
 

@@ -204,9 +204,14 @@ __host__ __device__ __forceinline__ uint32_t nm_mix32(uint32_t x) {
     return x;
 }
 
+// ``step`` (optional device scalar: the optimizer's global step) advances the salt on the device,
+// salt_eff = salt + step * 0x9E3779B9, so that a training step captured once into a HIP graph draws
+// fresh masks at every replay.
 __global__ void dropout_kernel(const float* __restrict__ x, long ldx, float* __restrict__ out, long ldo,
-                               long rows, int cols, float keep_prob, float inv_keep, uint32_t salt, int acc) {
+                               long rows, int cols, float keep_prob, float inv_keep, uint32_t salt,
+                               const uint32_t* __restrict__ step, int acc) {
     const long total = rows * cols;
+    if (step) salt += step[0] * 0x9E3779B9u;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long r = i / cols;
         const int c = (int)(i - r * cols);
@@ -220,13 +225,13 @@ __global__ void dropout_kernel(const float* __restrict__ x, long ldx, float* __r
 }
 
 extern "C" int nm_dropout(void* stream, const float* x, int64_t ldx, float* out, int64_t ldo, int64_t rows,
-                          int64_t cols, float keep_prob, uint32_t salt, int accumulate) {
+                          int64_t cols, float keep_prob, uint32_t salt, const uint32_t* step, int accumulate) {
     NM_REQUIRE(x && out && rows >= 0 && cols >= 0, "nm_dropout: bad args");
     NM_REQUIRE(keep_prob > 0.0f && keep_prob <= 1.0f, "nm_dropout: keep_prob %g outside (0,1]", keep_prob);
     NM_REQUIRE(rows * cols < (1LL << 32), "nm_dropout: more than 2^32 elements in one mask");
     if (rows * cols == 0) return NM_OK;
     hipLaunchKernelGGL(dropout_kernel, dim3(ew_blocks(rows * cols)), dim3(256), 0, nm_stream(stream), x, ldx, out,
-                       ldo, rows, (int)cols, keep_prob, 1.0f / keep_prob, salt, accumulate);
+                       ldo, rows, (int)cols, keep_prob, 1.0f / keep_prob, salt, step, accumulate);
     NM_LAUNCH_CHECK("nm_dropout");
 }
 

@@ -29,6 +29,7 @@ struct SdpArgs {
     int Bq, rpk, Tq, Tk, H, dh, causal;
     float scale, keep_prob, inv_keep;
     uint32_t salt;
+    const uint32_t* step;             // optional device scalar: salt += step * 0x9E3779B9 (graph replays)
 };
 
 __device__ __forceinline__ uint32_t sdp_mix32(uint32_t x) {
@@ -45,7 +46,8 @@ __device__ __forceinline__ uint32_t sdp_mix32(uint32_t x) {
 __device__ __forceinline__ float sdp_keep(const SdpArgs& p, int b, int h, int i, int j) {
     if (p.keep_prob >= 1.0f) return 1.0f;
     const uint32_t idx = (uint32_t)((((long)b * p.H + h) * p.Tq + i) * p.Tk + j);
-    const uint32_t bits = sdp_mix32(idx * 0x9E3779B1u + p.salt);
+    const uint32_t salt = p.salt + (p.step ? p.step[0] * 0x9E3779B9u : 0u);
+    const uint32_t bits = sdp_mix32(idx * 0x9E3779B1u + salt);
     const float uni = (float)(bits >> 8) * (1.0f / 16777216.0f);
     return (p.keep_prob + uni >= 1.0f) ? p.inv_keep : 0.0f;
 }
@@ -136,7 +138,8 @@ static size_t sdp_fwd_lds(long Tk, long dh) { return sizeof(float) * (2 * Tk * (
 extern "C" int nm_sdp_attn_fwd(void* stream, const float* q, int64_t q_bs, const float* k, int64_t k_bs,
                                const float* v, int64_t v_bs, const float* key_mask, int64_t mask_bs, int64_t Bq,
                                int64_t rows_per_key, int64_t Tq, int64_t Tk, int64_t H, int64_t dh, int causal,
-                               float keep_prob, uint32_t salt, float* ctx, int64_t ctx_bs, float* weights) {
+                               float keep_prob, uint32_t salt, const uint32_t* step, float* ctx, int64_t ctx_bs,
+                               float* weights) {
     NM_REQUIRE(q && k && v && ctx, "nm_sdp_attn_fwd: null pointer");
     NM_REQUIRE(Bq > 0 && rows_per_key >= 1 && Bq % rows_per_key == 0 && Tq > 0 && Tk > 0 && H > 0 && dh > 0,
                "nm_sdp_attn_fwd: bad shape Bq=%ld Tq=%ld Tk=%ld H=%ld dh=%ld", (long)Bq, (long)Tq, (long)Tk, (long)H,
@@ -153,7 +156,7 @@ extern "C" int nm_sdp_attn_fwd(void* stream, const float* q, int64_t q_bs, const
     p.Bq = (int)Bq; p.rpk = (int)rows_per_key; p.Tq = (int)Tq; p.Tk = (int)Tk; p.H = (int)H; p.dh = (int)dh;
     p.causal = causal;
     p.scale = 1.0f / sqrtf((float)dh);
-    p.keep_prob = keep_prob; p.inv_keep = 1.0f / keep_prob; p.salt = salt;
+    p.keep_prob = keep_prob; p.inv_keep = 1.0f / keep_prob; p.salt = salt; p.step = step;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)sdp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -281,7 +284,7 @@ extern "C" int nm_sdp_attn_bwd(void* stream, const float* q, int64_t q_bs, const
                                const float* v, int64_t v_bs, const float* key_mask, int64_t mask_bs,
                                const float* weights, const float* dctx, int64_t dctx_bs, int64_t B, int64_t Tq,
                                int64_t Tk, int64_t H, int64_t dh, int causal, float keep_prob, uint32_t salt,
-                               float* dq, int64_t dq_bs, float* dk, int64_t dk_bs, float* dv, int64_t dv_bs,
+                               const uint32_t* step, float* dq, int64_t dq_bs, float* dk, int64_t dk_bs, float* dv, int64_t dv_bs,
                                float* de_workspace, int accumulate) {
     NM_REQUIRE(q && k && v && weights && dctx && dq && dk && dv && de_workspace, "nm_sdp_attn_bwd: null pointer");
     NM_REQUIRE(B > 0 && Tq > 0 && Tk > 0 && H > 0 && dh > 0, "nm_sdp_attn_bwd: bad shape");
@@ -300,7 +303,7 @@ extern "C" int nm_sdp_attn_bwd(void* stream, const float* q, int64_t q_bs, const
     p.weights = const_cast<float*>(weights);
     p.Bq = (int)B; p.rpk = 1; p.Tq = (int)Tq; p.Tk = (int)Tk; p.H = (int)H; p.dh = (int)dh; p.causal = causal;
     p.scale = 1.0f / sqrtf((float)dh);
-    p.keep_prob = keep_prob; p.inv_keep = 1.0f / keep_prob; p.salt = salt;
+    p.keep_prob = keep_prob; p.inv_keep = 1.0f / keep_prob; p.salt = salt; p.step = step;
     a.dctx = dctx; a.dctx_bs = dctx_bs; a.dq = dq; a.dq_bs = dq_bs; a.dk = dk; a.dk_bs = dk_bs;
     a.dv = dv; a.dv_bs = dv_bs; a.de = de_workspace; a.accumulate = accumulate;
     static bool attr_set = false;

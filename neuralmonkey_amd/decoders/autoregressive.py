@@ -165,6 +165,12 @@ class AutoregressiveDecoder(ModelPart):
             ctx.fed(self.train_tokens), torch.float32, "tgt_mask_tb",
             lambda ids: np.ascontiguousarray(sentence_mask(ids).T)))
 
+    def stage_inputs(self, ctx) -> None:
+        """Evaluate every fetch that copies fed data to the device (see Feedable.stage_inputs)."""
+        if self.has_targets(ctx):
+            self.train_inputs(ctx)
+            self.train_mask(ctx)
+
     def train_token_count(self, ctx) -> float:
         """Denominator of the training loss.  Plain: sum(train_mask) (autoregressive.py:312-316).
         With label smoothing the reference's loss function returns ONE scalar, the mean smoothed

@@ -222,7 +222,16 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
             out[0] = START_TOKEN_INDEX
             out[1:] = tb[:-1]
             return out
-        return ctx.session.to_device(ctx.fed(self.train_tokens), torch.int32, "dec_in_tb", shift)
+        key = (id(self), "dec_in_tb")
+        if key not in ctx.memo:        # one H2D copy per run, into a persistent (graph-safe) buffer
+            ctx.memo[key] = ctx.session.staged(key, ctx.session.to_device(ctx.fed(self.train_tokens), torch.int32,
+                                                                         "dec_in_tb", shift))
+        return ctx.memo[key]
+
+    def stage_inputs(self, ctx) -> None:
+        AutoregressiveDecoder.stage_inputs(self, ctx)
+        if self.has_targets(ctx):
+            self._dec_input_ids(ctx)
 
     def decoding_loop(self, ctx, train_mode: bool, sample: bool = False, temperature: float = 1.0):
         if sample or temperature != 1.0:

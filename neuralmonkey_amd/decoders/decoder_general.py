@@ -68,6 +68,13 @@ class GeneralDecoderMixin:
                 return True
         return False
 
+    def graph_safe_training(self, train_mode: bool) -> bool:
+        """May forward + backward of a training step be captured as one HIP graph?  Yes on the tape
+        (kernel launches on persistent buffers, no host round trips); the hand-scheduled fast path
+        keeps its own loop graphs and its side-stream overlap instead."""
+        return self.uses_general_path(train_mode) and all(
+            getattr(e, "graph_safe_training", lambda t: False)(train_mode) for e in self.encoders)
+
     def make_stepper(self, ctx, rows: int, tag: str, rows_per_key: int = 1, max_positions: int = 0):
         """Stepwise inference driver (greedy loop, beam search)."""
         return make_stepper(self, ctx, rows, tag)

@@ -174,7 +174,26 @@ class TransformerDecoder(AutoregressiveDecoder):
             out[:, 0] = START_TOKEN_INDEX
             out[:, 1:] = ids[:, :-1]
             return out
-        return ctx.session.to_device(ctx.fed(self.train_tokens), torch.int32, "tdec_in_bt", shift)
+        return self._staged(ctx, "tdec_in_bt", torch.int32, shift)
+
+    def graph_safe_training(self, train_mode: bool) -> bool:
+        return all(getattr(e, "graph_safe_training", lambda t: False)(train_mode) for e in self.encoders)
+
+    def _staged(self, ctx, tag: str, dtype, derive=None) -> torch.Tensor:
+        """Batch-major [B,T] view of the fed target ids in a persistent device buffer (one H2D copy per
+        run; the buffer address is stable, so a captured training step can read it)."""
+        key = (id(self), tag)
+        if key not in ctx.memo:
+            ctx.memo[key] = ctx.session.staged(key, ctx.session.to_device(ctx.fed(self.train_tokens), dtype, tag,
+                                                                         derive))
+        return ctx.memo[key]
+
+    def stage_inputs(self, ctx) -> None:
+        AutoregressiveDecoder.stage_inputs(self, ctx)
+        if self.has_targets(ctx):
+            self._train_input_symbols(ctx)
+            self._staged(ctx, "tdec_tgt_bt", torch.int32)
+            self._staged(ctx, "tdec_mask_bt", torch.float32, lambda a: (a != 0).astype(np.float32))
 
     def decoding_loop(self, ctx, train_mode: bool, sample: bool = False, temperature: float = 1.0):
         if sample or temperature != 1.0:
@@ -186,9 +205,8 @@ class TransformerDecoder(AutoregressiveDecoder):
         tape = F.Tape(ctx, (id(self), "ttrain"), recording=want_grad)
         ids = self._train_input_symbols(ctx)                       # [B,T]
         bsz, steps = ids.shape
-        tgt_bt = ctx.session.to_device(ctx.fed(self.train_tokens), torch.int32, "tdec_tgt_bt")
-        mask_bt = ctx.session.to_device(ctx.fed(self.train_tokens), torch.float32, "tdec_mask_bt",
-                                        lambda a: (a != 0).astype(np.float32))
+        tgt_bt = self._staged(ctx, "tdec_tgt_bt", torch.int32)
+        mask_bt = self._staged(ctx, "tdec_mask_bt", torch.float32, lambda a: (a != 0).astype(np.float32))
         table = tape.named_param(self.embedding_matrix_name)
         emb = F.embedding(tape, table, ids.reshape(-1))            # base embed_input_symbols: lookup + dropout
         emb = F.dropout(tape, emb, self.dropout_keep_prob, train, ctx.salt(self.name, "embedded_input"))

@@ -72,12 +72,23 @@ class SpatialFiller(ModelPart, SpatialStatefulWithOutput):
         return fd
 
     @tensor
-    def _activations(self, ctx):
+    def _maps(self, ctx) -> torch.Tensor:
+        """The fed maps in a persistent device buffer."""
         maps = ctx.fed(self.spatial_input)
         if tuple(maps.shape[1:]) != tuple(self.input_shape):
             raise ValueError("SpatialFiller '{}': fed maps of shape {}, expected {}"
                              .format(self.name, tuple(maps.shape[1:]), tuple(self.input_shape)))
-        x = ctx.session.to_device(maps, torch.float32, "spatial_input")
+        return ctx.session.staged((id(self), "maps"), ctx.session.to_device(maps, torch.float32, "spatial_input"))
+
+    def stage_inputs(self, ctx) -> None:
+        self._maps(ctx)
+
+    def graph_safe_training(self, train_mode: bool) -> bool:
+        return True
+
+    @tensor
+    def _activations(self, ctx):
+        x = self._maps(ctx)
         bsz, h, w, d = x.shape
         s = h * w
         train = bool(ctx.fed(self.train_mode))

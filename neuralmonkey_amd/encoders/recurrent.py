@@ -94,6 +94,10 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
             return True
         return train_mode and self.dropout_keep_prob != 1.0
 
+    def graph_safe_training(self, train_mode: bool) -> bool:
+        """The taped path is pure kernel launches on persistent buffers (see Decoder.graph_safe_training)."""
+        return self.uses_general_path(train_mode)
+
     # -- static sizes ------------------------------------------------------------
     @property
     def dimension(self) -> int:

@@ -85,6 +85,17 @@ class TransformerEncoder(ModelPart, TemporalStatefulWithOutput):
     def output_size(self) -> int:
         return self.model_dimension
 
+    def stage_inputs(self, ctx) -> None:
+        """The position-signal table is built on the host: make sure it covers this batch before a
+        training step is (re)played as a graph."""
+        if self.use_positional_encoding:
+            mask = self.input_sequence.temporal_mask(ctx)
+            TB.signal_table(ctx, self.model_dimension, mask.shape[1])
+
+    def graph_safe_training(self, train_mode: bool) -> bool:
+        return self.input_for_cross_attention is None or getattr(
+            self.input_for_cross_attention, "graph_safe_training", lambda t: False)(train_mode)
+
     def declare_variables(self, store) -> None:
         d = self.model_dimension
         for i in range(self.depth):

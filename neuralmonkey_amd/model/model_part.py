@@ -21,6 +21,11 @@ class Feedable:
     def feed_dict(self, dataset, train: bool = True) -> FeedDict:
         return {self.train_mode: train, self.batch_size: len(dataset)}
 
+    def stage_inputs(self, ctx) -> None:
+        """Evaluate the fetches that copy this part's fed data into persistent device buffers.  The
+        trainer calls it on every feedable before a (possibly HIP-graph replayed) training step: the
+        host-to-device copies cannot be part of a captured graph and must happen on every step."""
+
     @property
     def input_types(self) -> Dict[str, Any]:
         return {}

@@ -78,6 +78,11 @@ class EmbeddedFactorSequence(Sequence):
             return self.embeddings_source.embedding_matrix_names()
         return [self.var_name("embedding_matrix_{}".format(i)) for i in range(len(self.data_ids))]
 
+    def stage_inputs(self, ctx) -> None:
+        self.input_factor_indices(ctx)
+        self.temporal_mask(ctx)
+        self.lengths(ctx)
+
     @tensor
     def input_factor_indices(self, ctx) -> List[torch.Tensor]:
         return [ctx.session.staged((id(self), "ids", i), ctx.session.to_device(ctx.fed(p), torch.int32))

@@ -409,11 +409,12 @@ def dropout_salt(*parts) -> int:
     return zlib.crc32("/".join(str(p) for p in parts).encode()) & 0xFFFFFFFF
 
 
-def dropout(x, out, keep_prob, salt, accumulate=False):
+def dropout(x, out, keep_prob, salt, accumulate=False, step=None):
+    """``step``: optional int32 device scalar (global step) that advances the salt on the device."""
     lib = _lib.load()
     rows, cols, ldx = _rc(x)
     _lib.check(lib.nm_dropout(_stream(), x.data_ptr(), ldx, out.data_ptr(), _rc(out)[2], rows, cols,
-                              float(keep_prob), int(salt) & 0xFFFFFFFF, int(accumulate)), "nm_dropout")
+                              float(keep_prob), int(salt) & 0xFFFFFFFF, _p(step), int(accumulate)), "nm_dropout")
     return out
 
 
@@ -459,7 +460,7 @@ def _bs(t):
 
 
 def sdp_attn_fwd(q, k, v, key_mask, heads, ctx, weights=None, causal=False, rows_per_key=1, keep_prob=1.0,
-                 salt=0):
+                 salt=0, step=None):
     """Multi-head scaled dot-product attention.  q/ctx [Bq,Tq,D], k/v [Bk,Tk,D] (Bq = Bk*rows_per_key;
     batch strides may exceed T*D: a key/value cache), key_mask [Bk,Tk] or None, weights [Bq,H,Tq,Tk]."""
     lib = _lib.load()
@@ -474,13 +475,13 @@ def sdp_attn_fwd(q, k, v, key_mask, heads, ctx, weights=None, causal=False, rows
         assert weights.is_contiguous() and weights.numel() == bq * heads * tq * tk
     _lib.check(lib.nm_sdp_attn_fwd(_stream(), q.data_ptr(), _bs(q), k.data_ptr(), _bs(k), v.data_ptr(), _bs(v),
                                    _p(key_mask), mask_bs, bq, rows_per_key, tq, tk, heads, d // heads, int(causal),
-                                   float(keep_prob), int(salt) & 0xFFFFFFFF, ctx.data_ptr(), _bs(ctx),
+                                   float(keep_prob), int(salt) & 0xFFFFFFFF, _p(step), ctx.data_ptr(), _bs(ctx),
                                    _p(weights)), "nm_sdp_attn_fwd")
     return ctx
 
 
 def sdp_attn_bwd(q, k, v, key_mask, weights, dctx, heads, dq, dk, dv, de_ws, causal=False, keep_prob=1.0, salt=0,
-                 accumulate=False):
+                 accumulate=False, step=None):
     lib = _lib.load()
     b, tq, d = q.shape
     tk = k.shape[1]
@@ -489,7 +490,7 @@ def sdp_attn_bwd(q, k, v, key_mask, weights, dctx, heads, dq, dk, dv, de_ws, cau
     _lib.check(lib.nm_sdp_attn_bwd(_stream(), q.data_ptr(), _bs(q), k.data_ptr(), _bs(k), v.data_ptr(), _bs(v),
                                    _p(key_mask), mask_bs, weights.data_ptr(), dctx.data_ptr(), _bs(dctx), b, tq, tk,
                                    heads, d // heads, int(causal), float(keep_prob), int(salt) & 0xFFFFFFFF,
-                                   dq.data_ptr(), _bs(dq), dk.data_ptr(), _bs(dk), dv.data_ptr(), _bs(dv),
+                                   _p(step), dq.data_ptr(), _bs(dq), dk.data_ptr(), _bs(dk), dv.data_ptr(), _bs(dv),
                                    de_ws.data_ptr(), int(accumulate)), "nm_sdp_attn_bwd")
 
 

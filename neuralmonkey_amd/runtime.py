@@ -98,11 +98,11 @@ class RunContext:
         return self.session.buffer(key, shape, dtype, zero)
 
     def salt(self, *site) -> int:
-        """32-bit salt of a dropout call site in this run: crc32 of the site path, advanced by
-        the global step so that every training step draws fresh masks (nm_dropout)."""
+        """32-bit salt of a dropout call site: crc32 of the site path.  The kernels add
+        global_step * 0x9E3779B9 on the device (``Session.step_tensor``), so every training step draws
+        fresh masks -- also when the step is a replayed HIP graph."""
         import zlib
-        base = zlib.crc32("/".join(str(s) for s in site).encode()) & 0xFFFFFFFF
-        return (base + self.session.global_step * 0x9E3779B9) & 0xFFFFFFFF
+        return zlib.crc32("/".join(str(s) for s in site).encode()) & 0xFFFFFFFF
 
 
 def _to_host(val):
@@ -129,6 +129,8 @@ class Session:
         self._graphs: Dict[Any, Any] = {}
         self.use_graphs = os.environ.get("NM_GRAPHS", "1") != "0"
         self.use_side_stream = os.environ.get("NM_SIDE_STREAM", "1") != "0"
+        # whole training steps of taped (general-path) models as one HIP graph per batch shape
+        self.use_step_graphs = os.environ.get("NM_STEP_GRAPHS", "1") != "0"
         # Persistent GRU time loops (nm_gru_seq_fwd: one launch, two grid barriers per step).  Measured
         # on MI355X at the benchmark shape: 17.4 ms/step against 15.0 ms/step for the HIP-graph replay of
         # two launches per step -- an agent-scope release/acquire pair (L2 write-back + invalidate on
@@ -182,7 +184,7 @@ class Session:
         work of the backward pass (weight-gradient GEMMs, bias column sums) so that
         it fills the CUs the latency-bound BPTT loops leave idle.  ``join_side``
         orders the main stream after it."""
-        if not self.use_side_stream or self.device.type != "cuda":
+        if not self.use_side_stream or self.device.type != "cuda" or torch.cuda.is_current_stream_capturing():
             yield
             return
         if self._side_stream is None:
@@ -207,8 +209,8 @@ class Session:
         synchronisation).  First call runs eagerly (allocations), second call
         captures a HIP graph, later calls replay it: the launch-bound time loops
         stop paying Python / launch overhead per kernel."""
-        if not self.use_graphs or self.device.type != "cuda":
-            fn()
+        if not self.use_graphs or self.device.type != "cuda" or torch.cuda.is_current_stream_capturing():
+            fn()                      # (inside an enclosing capture the launches simply join that graph)
             return
         state = self._graphs.get(key)
         if state is None:
@@ -222,6 +224,44 @@ class Session:
             graph.replay()
         else:
             state.replay()
+
+    MAX_STEP_GRAPHS = 8
+
+    def graphed_call(self, key, fn):
+        """Like ``graphed`` for a whole training step of the taped path: ``fn`` returns a value made of
+        persistent buffers (a TrainResult); it is kept with the graph and handed back on replay, when
+        the Python body does not run.  At most ``MAX_STEP_GRAPHS`` shapes are kept (least recently
+        used first out): length-bucketed training sees many shapes, each capture pins its buffers."""
+        if not self.use_graphs or self.device.type != "cuda" or torch.cuda.is_current_stream_capturing():
+            return fn()
+        store = self.__dict__.setdefault("_step_graphs", {})
+        state = store.pop(key, None)
+        if state is None:
+            result = fn()
+            state = (1, None, result)
+        elif state[0] == 1:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                result = fn()
+            graph.replay()
+            state = (2, graph, result)
+        else:
+            state[1].replay()
+        store[key] = state               # re-inserted last = most recently used
+        while len(store) > self.MAX_STEP_GRAPHS:
+            store.pop(next(iter(store)))
+        return state[2]
+
+    def step_tensor(self) -> torch.Tensor:
+        """Device copy of ``global_step`` (int32 [1]): dropout kernels read it to advance their salts,
+        so a captured training step draws fresh masks on every replay."""
+        if getattr(self, "_step_dev", None) is None:
+            self._step_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._step_dev_value = 0
+        if self._step_dev_value != self.global_step:
+            self._step_dev.fill_(self.global_step)
+            self._step_dev_value = self.global_step
+        return self._step_dev
 
     def _eval(self, fetch, ctx):
         if isinstance(fetch, Fetch):

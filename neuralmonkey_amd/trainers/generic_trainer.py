@@ -7,9 +7,9 @@ Fetch names and the ``ExecutionResult`` loss keys ("<decoder> - cost", "L1",
 "L2") follow generic_trainer.py:39-51,245-250.
 """
 import re
-from typing import Any, Dict, List, Optional, Sequence
+from typing import Any, Dict, List, Sequence
 
-import torch
+import numpy as np
 
 from .. import ops
 from ..model.model_part import Feedable
@@ -95,18 +95,34 @@ class GenericTrainer(GraphExecutor, Feedable):
         grad = store.ensure_grad()
         grad.zero_()
         dp = dist.current()
-        for obj in self.objectives:
+        sess.step_tensor()                   # device copy of global_step (dropout salts), outside any capture
+        for part in self.feedables:          # host -> device copies of the fed batch, into persistent buffers
+            part.stage_inputs(ctx)
+        train = bool(ctx.fed(self.train_mode)) if ctx.is_fed(self.train_mode) else True
+        for i, obj in enumerate(self.objectives):
             dec = obj.decoder
             weight = 1.0 if obj.weight is None else float(obj.weight)
             # loss = sum(xent) / sum(mask): with data parallelism the denominator is the
             # GLOBAL token count and gradients are summed over ranks
             count = dec.train_token_count(ctx)
             global_count = dp.all_reduce_scalar(count) if dp is not None else count
-            scale = ctx.buffer((id(self), "gscale"), (1,))
+            scale = ctx.buffer((id(self), "gscale", i), (1,))
             scale.fill_(weight / global_count)
-            res = dec._train_loop(ctx, want_grad=True, grad_scale=scale)     # pylint: disable=protected-access
+
+            def forward_backward(dec=dec, scale=scale):
+                res = dec._train_loop(ctx, want_grad=True, grad_scale=scale)     # pylint: disable=protected-access
+                dec.backward(ctx, res)
+                return res
+            if sess.use_step_graphs and getattr(dec, "graph_safe_training", lambda t: False)(train):
+                # Taped (general-path) models launch hundreds of small kernels per step from Python:
+                # the whole forward + backward becomes one HIP graph per batch shape.
+                shapes = tuple(sorted((ph.name, tuple(np.shape(val))) for ph, val in ctx.feed.items()
+                                      if hasattr(val, "shape")))
+                res = sess.graphed_call((id(self), id(dec), train, shapes), forward_backward)
+                res = res._replace(token_count=count)
+            else:
+                res = forward_backward()
             ctx.memo[dec.train_loop_result.key] = res
-            dec.backward(ctx, res)
         sess.join_side()
 
     def _apply_gradients(self, ctx) -> int:
