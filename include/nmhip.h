@@ -131,6 +131,11 @@ int nm_attn_softmax_bwd(void* stream, const float* dw, const float* e, const flo
 int nm_attn_energy_bwd(void* stream, const float* de, const float* hf, const float* y, const float* v,
                        float* dhf, float* dv_partial, float* dy, int64_t T, int64_t B, int64_t S,
                        int64_t A, int accumulate /* dhf, dv_partial += (per-step backward) */);
+/* the distribution alone, from energies assembled by the caller (several encoders + a sentinel):
+ * attention/combination.py:301-307 (FlatMultiAttention._renorm_softmax), :421 (hierarchical softmax,
+ * mask == NULL).  Mask row of query row r: (r / rows_per_key) % B. */
+int nm_attn_softmax_fwd(void* stream, const float* e, const float* mask, float* w, int64_t rows, int64_t B,
+                        int64_t S, int64_t rows_per_key);
 /* live HIP-event timing of the attn_partial kernel (bench.py roofline) */
 int nm_prof_enable(int on);
 int nm_prof_attn_partial(double* total_ms, int64_t* count);

@@ -1,1 +1,2 @@
 from .feed_forward import Attention   # noqa: F401
+from .combination import FlatMultiAttention, HierarchicalMultiAttention   # noqa: F401

@@ -214,8 +214,14 @@ class AttentionTapeSession:
         g = self.states_in.grad
         return None if g is None else g.view(self.bsz, self.slen, self.csz)
 
-    def step(self, query, w_out: Optional[torch.Tensor] = None):
-        """query Var [R,Q] -> context Var [R,C]; ``w_out`` [R,S] receives the weights."""
+    def encoder_grads(self):
+        """[(encoder, dL/d states [B,S,C])] after ``Tape.backward``."""
+        g = self.d_states
+        return [] if g is None else [(self.att.encoder, g)]
+
+    def step(self, query, w_out: Optional[torch.Tensor] = None, prev_state=None, rnn_input=None):
+        """query Var [R,Q] -> context Var [R,C]; ``w_out`` [R,S] receives the weights.  (The previous
+        decoder state and the RNN input of the reference's signature only matter to sentinels.)"""
         from .. import autodiff as F
         tape, att = self.tape, self.att
         ctx = tape.ctx

@@ -128,11 +128,11 @@ def linear(tape: Tape, x: Var, w: Var, b: Optional[Var] = None, out: Optional[Va
             ops.gemm(dy, w.data, out=tape.grad(x), trans_b=not trans_b, accumulate=True)
         if w.needs_grad:
             if trans_b:
-                ops.gemm(dy, x.data, out=w.grad, trans_a=True, accumulate=True)
+                ops.gemm(dy, x.data, out=tape.grad(w), trans_a=True, accumulate=True)
             else:
-                ops.gemm(x.data, dy, out=w.grad, trans_a=True, accumulate=True)
+                ops.gemm(x.data, dy, out=tape.grad(w), trans_a=True, accumulate=True)
         if b is not None and b.needs_grad:
-            ops.colsum(dy, b.grad, accumulate=True)
+            ops.colsum(dy, tape.grad(b), accumulate=True)
     tape.record(bwd)
     return out
 
@@ -377,6 +377,97 @@ def sdp_attention(tape: Tape, q: Var, k: Var, v: Var, key_mask: Optional[torch.T
         ops.sdp_attn_bwd(q.data.view(bq, tq, d), k3, v3, key_mask, w, out.grad.view(bq, tq, d), heads,
                          tape.grad(q).view(bq, tq, d), tape.grad(k).view(bk, tk, d), tape.grad(v).view(bk, tk, d),
                          de, causal, keep_prob, salt, accumulate=True, step=step)
+    tape.record(bwd)
+    return out
+
+
+def rowscale(tape: Tape, x: Var, s: Var, out: Optional[Var] = None, accumulate: bool = False) -> Var:
+    """out (+)= x[r,:] * s[r,0]: one attention weight per row times that row's vector."""
+    if out is None:
+        assert not accumulate
+        out = tape.new(tuple(x.shape))
+    ops.ew("rowscale", x.data, s.data, out.data, accumulate=accumulate)
+
+    def bwd():
+        if out.grad is None:
+            return
+        if x.needs_grad:
+            ops.ew("rowscale", out.grad, s.data, tape.grad(x), accumulate=True)
+        if s.needs_grad:                      # ds[r] = <dout[r,:], x[r,:]> as a [R,A].[A,1] product of the products
+            prod = ops.ew("mul", out.grad, x.data, tape.buf(tuple(x.shape)))
+            ones = tape.buf((x.shape[1], 1))
+            ones.fill_(1.0)
+            ops.gemm(prod, ones, out=tape.grad(s), accumulate=True)
+    tape.record(bwd)
+    return out
+
+
+def attn_energies(tape: Tape, y: Var, hf: Var, v: Var, bsz: int, slen: int, rows_per_key: int = 1) -> Var:
+    """e[r,s] = sum_a v[a] * tanh(y[r,a] + hf[r // k, s, a])  -- the Bahdanau energies alone, for
+    attentions that assemble their distribution from several sources (combination.py:262-266).
+    Forward: the fused step kernel with its context output discarded; backward: nm_attn_energy_bwd."""
+    ctx = tape.ctx
+    rows, a = y.shape
+    out = tape.new((rows, slen))
+    hf3 = hf.data.view(bsz, slen, a)
+    ws = ctx.buffer(("attn_energies_ws", rows, slen, a), ((ops._lib.load().nm_attn_workspace_bytes(rows, slen, a)
+                                                            + 3) // 4,))
+    scratch_ctx = ctx.buffer(("attn_energies_ctx", rows, a), (rows, a))
+    ops.attn_fwd(y.data, hf3, hf3, None, v.data, None, rows_per_key, scratch_ctx, None, ws, out.data)
+
+    def bwd():
+        if out.grad is None:
+            return
+        assert rows == bsz, "the attention gradient is defined for one query per sentence"
+        dhf, dvp, dy = tape.buf((bsz * slen, a)), tape.buf((bsz * slen, a)), tape.buf((rows, a))
+        ops.attn_energy_bwd(out.grad.view(1, bsz, slen), hf3, y.data.view(1, bsz, a), v.data, dhf.view(bsz, slen, a),
+                            dvp, dy.view(1, bsz, a))
+        if hf.needs_grad:
+            ops.ew("copy", dhf, None, tape.grad(hf), accumulate=True)
+        if y.needs_grad:
+            ops.ew("copy", dy, None, tape.grad(y), accumulate=True)
+        if v.needs_grad:
+            ops.colsum(dvp, v.grad.view(-1), accumulate=True)
+    tape.record(bwd)
+    return out
+
+
+def attn_softmax(tape: Tape, e: Var, mask: Optional[torch.Tensor], bsz: int, rows_per_key: int = 1,
+                 w_out: Optional[torch.Tensor] = None) -> Var:
+    """softmax over all positions, mask, renormalise with +1e-8 (feed_forward.py:139-144,
+    combination.py:301-307); plain softmax when ``mask`` is None."""
+    w = Var(w_out, None, tape.recording) if w_out is not None else tape.new(tuple(e.shape))
+    ops.attn_softmax_fwd(e.data, mask, w.data, bsz, rows_per_key)
+
+    def bwd():
+        if w.grad is None or not e.needs_grad:
+            return
+        assert e.shape[0] == bsz
+        de = tape.buf(tuple(e.shape))
+        ops.attn_softmax_bwd(w.grad, e.data, mask, de, bsz)
+        ops.ew("copy", de, None, tape.grad(e), accumulate=True)
+    tape.record(bwd)
+    return w
+
+
+def weighted_sum(tape: Tape, w: Var, vals: Var, bsz: int, slen: int, rows_per_key: int = 1) -> Var:
+    """ctx[r,:] = sum_s w[r,s] * vals[r // k, s, :] over the first ``slen`` columns of ``w``."""
+    rows, width = w.shape
+    a = vals.shape[1]
+    k = rows_per_key
+    out = tape.new((rows, a))
+    w3 = w.data.view(bsz, k, width)[:, :, :slen]
+    v3 = vals.data.view(bsz, slen, a)
+    ops.gemm(w3, v3, out=out.data.view(bsz, k, a))
+
+    def bwd():
+        if out.grad is None:
+            return
+        d3 = out.grad.view(bsz, k, a)
+        if w.needs_grad:
+            ops.gemm(d3, v3, out=tape.grad(w).view(bsz, k, width)[:, :, :slen], trans_b=True, accumulate=True)
+        if vals.needs_grad:
+            ops.gemm(w3, d3, out=tape.grad(vals).view(bsz, slen, a), trans_a=True, accumulate=True)
     tape.record(bwd)
     return out
 

@@ -411,6 +411,44 @@ extern "C" int nm_attn_softmax_bwd(void* stream, const float* dw, const float* e
     NM_LAUNCH_CHECK("nm_attn_softmax_bwd");
 }
 
+// The same distribution computed forward from ready-made energies: softmax over all S, mask,
+// renormalise with +1e-8 (feed_forward.py:139-144, combination.py:301-307).  Used where the energies
+// are assembled from several sources (FlatMultiAttention: encoders + sentinel), one wave per row;
+// the mask row of query row r is (r / rows_per_key) % B.
+__global__ void attn_softmax_fwd_kernel(const float* __restrict__ e, const float* __restrict__ mask,
+                                        float* __restrict__ w, long rows, int B, int S, int rpk) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int b = (int)((row / rpk) % B);
+    const float* er = e + row * S;
+    const float* mr = mask ? mask + (long)b * S : nullptr;
+    float mx = -INFINITY;
+    for (int s = lane; s < S; s += 64) mx = fmaxf(mx, er[s]);
+    mx = nm_wave_max(mx);
+    float se = 0.0f, sm = 0.0f;
+    for (int s = lane; s < S; s += 64) {
+        const float x = __expf(er[s] - mx);
+        se += x;
+        sm += x * (mr ? mr[s] : 1.0f);
+    }
+    se = nm_wave_sum(se);
+    sm = nm_wave_sum(sm);
+    const float inv_se = 1.0f / se;
+    const float invN = 1.0f / (sm * inv_se + 1e-8f);
+    for (int s = lane; s < S; s += 64)
+        w[row * S + s] = __expf(er[s] - mx) * inv_se * (mr ? mr[s] : 1.0f) * invN;
+}
+
+extern "C" int nm_attn_softmax_fwd(void* stream, const float* e, const float* mask, float* w, int64_t rows,
+                                   int64_t B, int64_t S, int64_t rows_per_key) {
+    NM_REQUIRE(e && w && rows >= 0 && B > 0 && S > 0 && rows_per_key >= 1, "nm_attn_softmax_fwd: bad args");
+    if (rows == 0) return NM_OK;
+    hipLaunchKernelGGL(attn_softmax_fwd_kernel, dim3(nm_cdiv(rows, 4)), dim3(256), 0, nm_stream(stream), e, mask,
+                       w, (long)rows, (int)B, (int)S, (int)rows_per_key);
+    NM_LAUNCH_CHECK("nm_attn_softmax_fwd");
+}
+
 // (2) energies backward (feed_forward.py:120-123), tanh recomputed:
 //     z = tanh(hf[b,s,a] + y[t,b,a]) ; g = de[t,b,s] * (1 - z^2)
 //     dhf[b,s,a] = v[a] * sum_t g        dvp[(b,s),a] = sum_t de * z

@@ -28,7 +28,8 @@ enum {
     NM_EW_RELU_BWD = 10,    // b * (a > 0)
     NM_EW_LOGADDEXP = 11,   // log(exp(a) + exp(b))   (ensemble mean of probabilities in log space)
     NM_EW_ADD_SCALAR = 12,  // a + alpha
-    NM_EW_OPS = 13
+    NM_EW_ROWSCALE = 13,    // a[r,c] * b[r,0]        (a per-row scalar: attention weight of a single vector)
+    NM_EW_OPS = 14
 };
 
 template <int OP>
@@ -49,6 +50,7 @@ __device__ __forceinline__ float ew_apply(float a, float b, float alpha) {
         return hi == -INFINITY ? -INFINITY : hi + log1pf(expf(lo - hi));
     }
     if (OP == NM_EW_ADD_SCALAR) return a + alpha;
+    if (OP == NM_EW_ROWSCALE) return a * b;
     return 0.0f;
 }
 
@@ -60,7 +62,7 @@ __global__ void ew_kernel(const float* __restrict__ a, long lda, const float* __
         const long r = i / cols;
         const int c = (int)(i - r * cols);
         const float av = a[r * lda + c];
-        const float bv = BIN ? b[r * ldb + c] : 0.0f;
+        const float bv = BIN ? b[r * ldb + (OP == NM_EW_ROWSCALE ? 0 : c)] : 0.0f;
         float v = ew_apply<OP>(av, bv, alpha);
         if (acc) v += out[r * ldo + c];
         out[r * ldo + c] = v;
@@ -92,7 +94,8 @@ template <int OP, bool BIN>
 static void ew_launch(hipStream_t st, const float* a, long lda, const float* b, long ldb, float* out, long ldo,
                       long rows, long cols, float alpha, int acc) {
     const long total = rows * cols;
-    const bool contiguous = (rows == 1) || (lda == cols && ldo == cols && (!BIN || ldb == cols));
+    const bool contiguous = OP != NM_EW_ROWSCALE &&
+                            ((rows == 1) || (lda == cols && ldo == cols && (!BIN || ldb == cols)));
     if (contiguous && total % 4 == 0 && nm_aligned16(a) && nm_aligned16(out) && (!BIN || nm_aligned16(b))) {
         const long n4 = total / 4;
         const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
@@ -109,7 +112,7 @@ extern "C" int nm_ew(void* stream, int op, const float* a, int64_t lda, const fl
                      int64_t ldo, int64_t rows, int64_t cols, float alpha, int accumulate) {
     NM_REQUIRE(op >= 0 && op < NM_EW_OPS, "nm_ew: unknown op %d", op);
     NM_REQUIRE(a && out && rows >= 0 && cols >= 0 && cols < (1LL << 31), "nm_ew: bad args");
-    const bool binary = op == NM_EW_ADD || op == NM_EW_SUB || op == NM_EW_MUL ||
+    const bool binary = op == NM_EW_ADD || op == NM_EW_SUB || op == NM_EW_MUL || op == NM_EW_ROWSCALE ||
                         (op >= NM_EW_SIGMOID_BWD && op <= NM_EW_LOGADDEXP);
     NM_REQUIRE(!binary || b, "nm_ew: op %d needs a second operand", op);
     if (rows == 0 || cols == 0) return NM_OK;
@@ -130,6 +133,7 @@ extern "C" int nm_ew(void* stream, int op, const float* a, int64_t lda, const fl
         NM_EW_CASE(NM_EW_RELU_BWD, true)
         NM_EW_CASE(NM_EW_LOGADDEXP, true)
         NM_EW_CASE(NM_EW_ADD_SCALAR, false)
+        NM_EW_CASE(NM_EW_ROWSCALE, true)
         default: break;
     }
 #undef NM_EW_CASE

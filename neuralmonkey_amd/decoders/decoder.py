@@ -104,6 +104,8 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
                              .format(self._rnn_cell_str))
         for att in self.attentions:
             att.bind_query_size(self.rnn_size)
+            if hasattr(att, "bind_decoder"):
+                att.bind_decoder(self)
         self._build_cells()
         if self.embedding_size != self.output_dimension:
             raise ValueError("The dimension ({}) of the output projection must be same as the "
@@ -451,7 +453,7 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
         self.embed_input_symbols(ctx, go, out=emb)
         att0 = att_states
         graph_ok = getattr(stepper, "graph_safe", False)
-        for att in self.attentions:          # evaluate lazily built tensors (H2D copies) outside the captured region
+        for att in self.attentions if graph_ok else []:   # lazily built tensors (H2D copies): outside the capture
             att.hidden_features(ctx)
             att.attention_mask(ctx)
         self.decoding_bias(ctx)

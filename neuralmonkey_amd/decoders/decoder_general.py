@@ -51,11 +51,16 @@ class GeneralDecoderMixin:
             width = e + sum(a.context_vector_size for a in self.attentions)
             self.declare(store, "attention_decoder/input_projection/kernel", (width, e))
             self.declare(store, "attention_decoder/input_projection/bias", (e,), zeros_initializer())
+        for att in self.attentions:                  # variables the attention creates in the decoder's step scope
+            if hasattr(att, "declare_decoder_variables"):
+                att.declare_decoder_variables(self, store)
 
     def uses_general_path(self, train_mode: bool) -> bool:
         from .output_projection import NonlinearOutput
         if self._rnn_cell_str != "GRU" or self._cond_cell is not None or self._attention_on_input:
             return True
+        if any(getattr(a, "tape_only", False) for a in self.attentions):
+            return True                  # combination / dot-product attentions exist on the tape only
         proj = self.output_projection
         if not isinstance(proj, NonlinearOutput) or proj.activation not in ("tanh", "identity"):
             return True
@@ -105,10 +110,12 @@ class GeneralDecoderMixin:
             rnn_input = emb_in
         if isinstance(self._cell_obj, LSTMCell):                       # :309-325
             cell_output, (next_state, _) = self._cell_obj.step(tape, rnn_input, (prev_state, prev_out))
-            contexts = [s.step(cell_output, w) for s, w in zip(sessions, w_outs)]
+            contexts = [s.step(cell_output, w, prev_state=prev_out, rnn_input=rnn_input)
+                        for s, w in zip(sessions, w_outs)]
         else:                                                          # :288-307
             cell_output, (next_state,) = self._cell_obj.step(tape, rnn_input, (prev_out,))
-            contexts = [s.step(cell_output, w) for s, w in zip(sessions, w_outs)]
+            contexts = [s.step(cell_output, w, prev_state=prev_out, rnn_input=rnn_input)
+                        for s, w in zip(sessions, w_outs)]
             if self._cond_cell is not None:
                 cell_output, (next_state,) = self._cond_cell.step(tape, F.concat(tape, contexts), (next_state,))
         contexts = [F.dropout(tape, c, keep, train, ctx.salt(self.name, "context", i, t))
@@ -171,19 +178,21 @@ class GeneralDecoderMixin:
         sv = res.saved
         sv["tape"].backward()
         enc_grads = {}
-        for att, sess in zip(self.attentions, sv["sessions"]):
-            enc_grads.setdefault(att.encoder, [None, None])[0] = sess.d_states
+
+        def add_states_grad(enc, g):
+            slot = enc_grads.setdefault(enc, [None, None])
+            if slot[0] is None:
+                slot[0] = g
+            else:                        # several attentions over one encoder
+                ops.ew("copy", g.reshape(-1, g.shape[-1]), None, slot[0].reshape(-1, g.shape[-1]), accumulate=True)
+        for sess in sv["sessions"]:
+            for enc, g in sess.encoder_grads():
+                add_states_grad(enc, g)
         for enc, var in zip(self.encoders, sv["enc_outs"]):
             enc_grads.setdefault(enc, [None, None])[1] = var.grad
         proj_states = getattr(self.encoder_projection, "states_var", None)
         if proj_states is not None and proj_states.grad is not None:     # nematus_projection reads the states
-            enc = self.encoders[0]
-            slot = enc_grads.setdefault(enc, [None, None])
-            g = proj_states.grad.view(sv["bsz"], -1, proj_states.shape[1])
-            if slot[0] is None:
-                slot[0] = g
-            else:
-                ops.ew("copy", g.reshape(-1, g.shape[-1]), None, slot[0].reshape(-1, g.shape[-1]), accumulate=True)
+            add_states_grad(self.encoders[0], proj_states.grad.view(sv["bsz"], -1, proj_states.shape[1]))
             self.encoder_projection.states_var = None
         for enc, (dst, dfin) in enc_grads.items():
             if hasattr(enc, "backward"):

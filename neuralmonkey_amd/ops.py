@@ -347,6 +347,17 @@ def attn_softmax_bwd(dw, e, mask, de, bsz):
                                        rows, bsz, s), "nm_attn_softmax_bwd")
 
 
+def attn_softmax_fwd(e, mask, w, bsz, rows_per_key=1):
+    """w = renorm(softmax(e) * mask) of contiguous [R,S] energies assembled by the caller."""
+    lib = _lib.load()
+    assert e.is_contiguous() and w.is_contiguous() and e.shape == w.shape
+    s = e.shape[-1]
+    rows = e.numel() // s
+    _lib.check(lib.nm_attn_softmax_fwd(_stream(), e.data_ptr(), _p(mask), w.data_ptr(), rows, bsz, s,
+                                       rows_per_key), "nm_attn_softmax_fwd")
+    return w
+
+
 def attn_energy_bwd(de, hf, y, v, dhf, dv_partial, dy, accumulate=False):
     lib = _lib.load()
     t, b, s = de.shape
@@ -358,7 +369,7 @@ def attn_energy_bwd(de, hf, y, v, dhf, dv_partial, dy, accumulate=False):
 
 # ---- strided element-wise primitives (general / taped path) -------------------------------------
 EW = {"copy": 0, "add": 1, "sub": 2, "mul": 3, "scale": 4, "sigmoid": 5, "tanh": 6, "relu": 7,
-      "sigmoid_bwd": 8, "tanh_bwd": 9, "relu_bwd": 10, "logaddexp": 11, "add_scalar": 12}
+      "sigmoid_bwd": 8, "tanh_bwd": 9, "relu_bwd": 10, "logaddexp": 11, "add_scalar": 12, "rowscale": 13}
 
 
 def _rc(t):
@@ -380,7 +391,7 @@ def ew(op, a, b, out, alpha=0.0, accumulate=False):
     ldb = 0
     if b is not None:
         rb, cb, ldb = _rc(b)
-        assert (rb, cb) == (rows, cols), (a.shape, b.shape)
+        assert (rb, cb) == ((rows, 1) if op == "rowscale" else (rows, cols)), (a.shape, b.shape)
     _lib.check(lib.nm_ew(_stream(), EW[op], a.data_ptr(), lda, _p(b), ldb, out.data_ptr(), ldo, rows, cols,
                          float(alpha), int(accumulate)), "nm_ew")
     return out

@@ -285,9 +285,15 @@ def read_bundle(prefix: str, verify: bool = True) -> Dict[str, np.ndarray]:
 # -- VariableStore bridge ------------------------------------------------------------------------------
 def tf_shape(name: str, shape: Tuple[int, ...]) -> Tuple[int, ...]:
     """The shape TensorFlow gives the variable ``name`` (see the module docstring)."""
-    if name.endswith("attn_bias") and tuple(shape) == (1,):
-        return ()
     parts = name.split("/")
+    leaf = parts[-1]
+    # scalars: Attention's attn_bias, FlatMultiAttention's attn_bias_<i>, the vector_bias of _vector_logit
+    scalar = leaf == "attn_bias" or leaf == "vector_bias" or \
+        (leaf.startswith("attn_bias_") and leaf[len("attn_bias_"):].isdigit())
+    if scalar and tuple(shape) == (1,):
+        return ()
+    if leaf == "attn_v" and len(shape) == 1:          # combination.py:66-70: [1, 1, attention_state_size]
+        return (1, 1) + tuple(shape)
     conv_kernel = len(parts) >= 2 and parts[-1] == "kernel" and parts[-2].startswith("conv2d")
     if len(shape) == 2 and (name.endswith("attn_key_projection") or conv_kernel):
         return (1, 1) + tuple(shape)

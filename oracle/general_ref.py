@@ -154,7 +154,7 @@ class GeneralModel:
         return torch.stack(outs, 1), state[-1]
 
     # -- encoder (encoders/recurrent.py:71-110, 179-217) ---------------------------------------
-    def encode_spatial(self, maps: np.ndarray):
+    def encode_spatial(self, maps: np.ndarray, name: Optional[str] = None, spatial: Optional[Tuple] = None):
         """SpatialFiller (encoders/numpy_stateful_filler.py:155-245): optional 1x1 convolutions,
         states flattened to [B, H*W, D] with an all-ones mask (attention/base_attention.py:79-122),
         output = mean over positions."""
@@ -162,14 +162,15 @@ class GeneralModel:
         x = torch.as_tensor(np.asarray(maps), dtype=self.dtype)
         bsz, h, w, _ = x.shape
         x = x.reshape(bsz, h * w, -1)
-        ff_dim, proj_dim = cfg.spatial
+        ff_dim, proj_dim = spatial if spatial is not None else cfg.spatial
+        name = name or cfg.enc_name
         scopes = []
         if ff_dim:
             scopes.append(("conv2d", True))
         if proj_dim:
             scopes.append(("conv2d_1" if scopes else "conv2d", False))
         for scope, use_relu in scopes:
-            x = x @ p["{}/{}/kernel".format(cfg.enc_name, scope)] + p["{}/{}/bias".format(cfg.enc_name, scope)]
+            x = x @ p["{}/{}/kernel".format(name, scope)] + p["{}/{}/bias".format(name, scope)]
             if use_relu:
                 x = torch.relu(x)
         return x, torch.ones(bsz, h * w, dtype=self.dtype), x.mean(1)
@@ -266,6 +267,7 @@ class GeneralModel:
         d = cfg.dec_name
         scope = d + "/attention_decoder"
         prev_state, prev_out, prev_ctxs = state[0], state[1], list(state[2:])
+        self._step_t = t
         if cfg.attention_on_input:                                     # :264-277
             x = torch.cat([emb_in] + prev_ctxs, 1) @ p[scope + "/input_projection/kernel"] \
                 + p[scope + "/input_projection/bias"]
@@ -273,6 +275,8 @@ class GeneralModel:
         else:
             rnn_input = emb_in
         self._size = cfg.rnn_size
+        # a.attention(cell_output, prev_rnn_output, rnn_input, loop_state) (decoder.py:291-297): sentinels read these
+        self._step_extra = (prev_out, rnn_input)
         if cfg.dec_cell == "LSTM":                                     # :309-325
             cell_output, (next_state, _) = self.cell("LSTM", scope, rnn_input, (prev_state, prev_out))
             ctx, w = self.attention(cell_output, st, hf, mask)
@@ -331,8 +335,7 @@ class GeneralModel:
         emb_all = self.dropout(emb_all, cfg.dec_dropout, train, cfg.dec_name, "embedded_input")
         emb_all = emb_all.view(steps, bsz, -1)
         s0 = self.initial_state(final, train, states, mask)
-        csz = st.shape[-1]
-        state = [s0, s0, torch.zeros(bsz, csz, dtype=self.dtype)]
+        state = [s0, s0, torch.zeros(bsz, self.context_size(st), dtype=self.dtype)]
         outs, weights = [], []
         for t in range(steps):
             out, state, w = self.decoder_step(emb_all[t], state, st, hf, mask, train, t)
@@ -367,10 +370,19 @@ class GeneralModel:
         st, hf = self.attention_setup(states, False)
         s0 = self.initial_state(final, False, states, mask)
         if rep > 1:
-            st, hf, mask, s0 = (x.repeat_interleave(rep, 0) for x in (st, hf, mask, s0))
+            st, hf, mask = self.repeat_sources(st, hf, mask, rep)
+            s0 = s0.repeat_interleave(rep, 0)
         rows = s0.shape[0]
-        state = [s0, s0, torch.zeros(rows, st.shape[-1], dtype=self.dtype)]
+        state = [s0, s0, torch.zeros(rows, self.context_size(st), dtype=self.dtype)]
         return st, hf, mask, state
+
+    # hooks for models whose attention reads several sources (oracle/multisource_ref.py)
+    def context_size(self, st) -> int:
+        return st.shape[-1]
+
+    def repeat_sources(self, st, hf, mask, rep: int):
+        """expand_to_beam (beam_search_decoder.py:575-596): row order b*k + j."""
+        return tuple(x.repeat_interleave(rep, 0) for x in (st, hf, mask))
 
     def greedy(self, src_ids, max_len: int):
         with torch.no_grad():
@@ -397,8 +409,8 @@ class GeneralModel:
     def beam(self, src_ids, k: int, max_steps: int, alpha: float):
         with torch.no_grad():
             p, d, dt = self.p, self.cfg.dec_name, self.dtype
-            bsz = src_ids.shape[0]
             st, hf, mask, state = self._decode_setup(src_ids, k)
+            bsz = state[0].shape[0] // k
             rows = bsz * k
             table = p[d + "/word_embeddings"]
             out, state, _ = self.decoder_step(table[torch.full((rows,), START)], state, st, hf, mask, False, 0)

@@ -1,0 +1,174 @@
+"""Multi-source attention combinations (attention/combination.py; the model family of the
+reference's tests/flat-multiattention.ini and tests/hier-multiattention.ini): a sentence encoder
+and a SpatialFiller over image maps, attended by FlatMultiAttention / HierarchicalMultiAttention
+with and without shared projections and sentinels.
+
+Checker: oracle/multisource_ref.py (torch-CPU restatement + autograd) on the engine's own weights.
+Tolerances: loss 1e-4 relative; gradients 1e-3 of each tensor's max magnitude; greedy / beam
+indices exact (unless the oracle reports a near-tie); logits 1e-4 relative.  Unlike the reference,
+whose sentinel variants tile encoder projections batch-major (combination.py:289-299) and are only
+right for batch size 1 under beam search, the engine indexes keys by row // k: beam search is
+checked at batch 4."""
+import numpy as np
+import pytest
+
+from oracle import general_ref as G
+from oracle import multisource_ref as M
+from oracle import nm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+VOCAB = 40
+SHAPE = (3, 4, 12)
+MAXLEN = 8
+
+
+def _build(dev, cfg: G.Config, mcfg: M.MultiConfig, seed=11, beam=3):
+    from neuralmonkey_amd.attention import Attention
+    from neuralmonkey_amd.attention.combination import FlatMultiAttention, HierarchicalMultiAttention
+    from neuralmonkey_amd.dataset import BatchingScheme, Dataset
+    from neuralmonkey_amd.decoders import BeamSearchDecoder, Decoder
+    from neuralmonkey_amd.encoders import RecurrentEncoder, SpatialFiller
+    from neuralmonkey_amd.model.sequence import EmbeddedSequence
+    from neuralmonkey_amd.runtime import reset_registry
+    from neuralmonkey_amd.synthetic import synthetic_vocabulary
+    from neuralmonkey_amd.tf_manager import TensorFlowManager
+    from neuralmonkey_amd.trainers import CrossEntropyTrainer
+    reset_registry()
+    vocab = synthetic_vocabulary(VOCAB)
+    seq = EmbeddedSequence(name=cfg.enc_name + "_input", vocabulary=vocab, data_id="source", embedding_size=6,
+                           max_length=MAXLEN)
+    enc = RecurrentEncoder(name=cfg.enc_name, input_sequence=seq, rnn_layers=[tuple(l) for l in cfg.rnn_layers],
+                           dropout_keep_prob=cfg.enc_dropout)
+    ff, proj = mcfg.image_spatial
+    img = SpatialFiller(name=mcfg.image_name, input_shape=list(SHAPE), data_id="images", projection_dim=proj,
+                        ff_hidden_dim=ff)
+    if mcfg.kind == "flat":
+        att = FlatMultiAttention(name=mcfg.att_name, encoders=[enc, img], attention_state_size=mcfg.state_size,
+                                 share_attn_projections=mcfg.share, use_sentinels=mcfg.sentinel)
+    else:
+        children = [Attention(name=mcfg.child_names[0], encoder=enc), Attention(name=mcfg.child_names[1], encoder=img,
+                                                                               state_size=7)]
+        att = HierarchicalMultiAttention(name=mcfg.att_name, attentions=children,
+                                         attention_state_size=mcfg.state_size, use_sentinels=mcfg.sentinel,
+                                         share_attn_projections=mcfg.share)
+    dec = Decoder(encoders=[enc, img], vocabulary=vocab, data_id="target", name=cfg.dec_name, max_output_len=MAXLEN,
+                  dropout_keep_prob=cfg.dec_dropout, embedding_size=cfg.rnn_size, rnn_size=cfg.rnn_size, attentions=[att],
+                  rnn_cell=cfg.dec_cell, conditional_gru=cfg.conditional_gru,
+                  attention_on_input=cfg.attention_on_input)
+    bdec = BeamSearchDecoder(name="beam_decoder", parent_decoder=dec, beam_size=beam, max_steps=MAXLEN,
+                             length_normalization=0.6)
+    trainer = CrossEntropyTrainer(decoders=[dec], l2_weight=0.0, clip_norm=None)
+    tfm = TensorFlowManager(num_sessions=1, num_threads=1, device=str(dev), seed=seed)
+    tfm.initialize_sessions()
+    store = tfm.sessions[0].store
+    rng = np.random.default_rng(seed)
+    vals = store.state_dict()
+    for name, v in vals.items():
+        if v.ndim >= 2 or name.endswith("attn_similarity_v") or name.endswith("attn_v"):
+            vals[name] = (rng.standard_normal(v.shape) * 0.35).astype(np.float32)
+        elif "bias" in name or name.endswith("_b") or name.endswith("beta"):
+            vals[name] = (v + rng.standard_normal(v.shape) * 0.1).astype(np.float32)
+    store.load_state_dict(vals)
+    return dict(enc=enc, img=img, att=att, dec=dec, bdec=bdec, trainer=trainer, tfm=tfm, store=store,
+                params=store.state_dict(), vocab=vocab)
+
+
+def _data(m, bsz, seed=3, with_target=True):
+    from neuralmonkey_amd.dataset import BatchingScheme, Dataset
+    rng = np.random.default_rng(seed)
+    words = lambda n: ["w{}".format(int(i)) for i in rng.integers(0, VOCAB - 4, size=int(n))]
+    src_sents = [words(n) for n in rng.integers(2, 7, size=bsz)]
+    tgt_sents = [words(n) for n in rng.integers(2, 6, size=bsz)]
+    maps = np.maximum(rng.standard_normal((bsz,) + SHAPE), 0).astype(np.float32)
+    series = {"source": src_sents, "images": list(maps)}
+    if with_target:
+        series["target"] = tgt_sents
+    ds = Dataset("multisource", series, BatchingScheme(batch_size=bsz))
+    w2i = m["vocab"]._word_to_index
+    src = O.pad_ids([[w2i[w] for w in s] for s in src_sents], MAXLEN)
+    tgt = np.ascontiguousarray(O.pad_ids([[w2i[w] for w in s] for s in tgt_sents], MAXLEN, add_end_symbol=True).T)
+    return ds, (src, maps), tgt
+
+
+BASE = G.Config(rnn_layers=((4, "bidirectional", "GRU"),), rnn_size=6)
+CASES = {
+    # the four wrappers of tests/flat-multiattention.ini
+    "flat_noshare_nosentinel": (BASE, M.MultiConfig("flat", "wrapper_fnn", 5, False, False)),
+    "flat_share_nosentinel": (BASE, M.MultiConfig("flat", "wrapper_fsn", 5, True, False)),
+    "flat_share_sentinel": (BASE._replace(enc_dropout=0.5, dec_dropout=0.5),
+                            M.MultiConfig("flat", "wrapper_fss", 5, True, True)),
+    "flat_noshare_sentinel": (BASE._replace(dec_cell="NematusGRU", conditional_gru=True),
+                              M.MultiConfig("flat", "wrapper_fns", 5, False, True, image_spatial=(None, 8))),
+    # tests/hier-multiattention.ini
+    "hier_noshare_nosentinel": (BASE, M.MultiConfig("hier", "wrapper_hnn", 5, False, False)),
+    "hier_share_sentinel": (BASE._replace(dec_dropout=0.7), M.MultiConfig("hier", "wrapper_hss", 6, True, True)),
+    "hier_noshare_sentinel_lstm": (BASE._replace(dec_cell="LSTM", attention_on_input=True),
+                                   M.MultiConfig("hier", "wrapper_hns", 5, False, True)),
+}
+
+# gradients that are identically zero by softmax shift invariance (both sides hold rounding noise)
+ZERO_GRAD_SUFFIXES = ("attn_bias",)
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_multisource_train_step_gradients(dev, case):
+    cfg, mcfg = CASES[case]
+    m = _build(dev, cfg, mcfg)
+    ds, src, tgt = _data(m, 5)
+    ref = M.MultiSourceModel(m["params"], cfg, mcfg, requires_grad=True)
+    ref_loss, ref_g = ref.train_grads(src, tgt, train=True)
+    res = m["tfm"].execute(ds, m["trainer"].feedables, [m["trainer"]], train=True)[0]
+    assert abs(res.losses[cfg.dec_name + " - cost"] - ref_loss) < 1e-4 * abs(ref_loss)
+    store = m["store"]
+    gmax = max(float(np.abs(g).max()) for g in ref_g.values() if g is not None)
+    bad = {}
+    for name in store.names():
+        got = store.g(name).cpu().numpy().reshape(-1)
+        want = ref_g[name]
+        want = np.zeros_like(got) if want is None else want.reshape(-1)
+        floor = 1e-3 * gmax if name.endswith(ZERO_GRAD_SUFFIXES) else 1e-6
+        err = float(np.abs(got - want).max() / max(np.abs(want).max(), floor))
+        if err > 1e-3:
+            bad[name] = err
+    assert not bad, "gradient mismatch: {}".format(bad)
+    # the weights history the decoder keeps for this attention (finalize_loop)
+    hist = m["att"].histories[cfg.dec_name + "_train"]
+    _, _, ref_w = ref.train_loss(src, tgt, train=True)
+    assert np.abs(hist.cpu().numpy() - ref_w.detach().numpy()).max() < 1e-5
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_multisource_greedy_and_beam(dev, case):
+    cfg, mcfg = CASES[case]
+    m = _build(dev, cfg, mcfg)
+    ds, src, _ = _data(m, 4, seed=5, with_target=False)
+    ref = M.MultiSourceModel(m["params"], cfg, mcfg)
+    ref_sym, ref_mask, ref_logits = ref.greedy(src, MAXLEN)
+    dec, sess = m["dec"], m["tfm"].sessions[0]
+    fd = {}
+    for part in (m["enc"].input_sequence, m["enc"], m["img"], m["att"], dec):
+        fd.update(part.feed_dict(ds, train=False))
+    out = sess.run({"sym": dec.decoded_symbols, "mask": dec.runtime_mask, "logits": dec.runtime_logits}, fd)
+    assert np.array_equal(out["sym"], ref_sym)
+    assert np.array_equal(out["mask"].astype(bool), ref_mask)
+    assert np.abs(out["logits"] - ref_logits).max() <= 1e-4 * np.abs(ref_logits).max()
+    tok, scores, gap = ref.beam(src, 3, MAXLEN, 0.6)
+    got = sess.run(m["bdec"].outputs, fd)
+    if gap > 1e-5:
+        assert np.array_equal(np.asarray(got.last_search_step_output.token_ids)[1:], tok[1:])
+    assert np.abs(np.asarray(got.last_search_step_output.scores) - scores).max() <= 1e-4 * np.abs(scores).max()
+
+
+def test_multisource_variable_names_follow_the_reference_scopes(dev):
+    """Step variables live in the decoder's scope, projections in the attention's (combination.py:199-232,254)."""
+    cfg, mcfg = CASES["flat_noshare_sentinel"]
+    m = _build(dev, cfg, mcfg)
+    names = set(m["store"].names())
+    a, d = mcfg.att_name, cfg.dec_name
+    for n in (a + "/attn_v", a + "/logits_projections/proj_matrix_0", a + "/context_projections/proj_bias_1",
+              a + "/attn_bias_1", d + "/attention_decoder/attention_" + a + "/dense/kernel",
+              d + "/attention_decoder/attention_" + a + "/sentinel/dense/kernel",
+              d + "/attention_decoder/attention_" + a + "/sentinel_logit/vector_bias",
+              d + "/attention_decoder/attention_" + a + "/sentinel_logit/vector_ctx_proj/kernel"):
+        assert n in names, n
