@@ -412,7 +412,7 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
         for enc, dfin in zip(self.encoders, d_enc_out):
             enc_grads.setdefault(enc, [None, None])[1] = dfin
         for enc, (dst, dfin) in enc_grads.items():
-            enc.backward(ctx, dst, dfin)
+            ctx.defer_backward(enc, dst, dfin)
 
     @tensor
     def train_loss(self, ctx) -> torch.Tensor:

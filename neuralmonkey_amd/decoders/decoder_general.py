@@ -61,6 +61,8 @@ class GeneralDecoderMixin:
             return True
         if any(getattr(a, "tape_only", False) for a in self.attentions):
             return True                  # combination / dot-product attentions exist on the tape only
+        if self.rnn_size % 4 != 0 or self.embedding_size % 4 != 0:
+            return True                  # the fused gate kernels move float4s
         proj = self.output_projection
         if not isinstance(proj, NonlinearOutput) or proj.activation not in ("tanh", "identity"):
             return True
@@ -195,8 +197,7 @@ class GeneralDecoderMixin:
             add_states_grad(self.encoders[0], proj_states.grad.view(sv["bsz"], -1, proj_states.shape[1]))
             self.encoder_projection.states_var = None
         for enc, (dst, dfin) in enc_grads.items():
-            if hasattr(enc, "backward"):
-                enc.backward(ctx, dst, dfin)
+            ctx.defer_backward(enc, dst, dfin)
 
 
 class FastStepper:

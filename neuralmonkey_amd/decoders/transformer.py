@@ -231,8 +231,8 @@ class TransformerDecoder(AutoregressiveDecoder):
         sv["tape"].backward()
         bsz = sv["bsz"]
         for e, (var, _, slen) in zip(self.encoders, sv["enc"]):
-            if var.grad is not None and hasattr(e, "backward"):
-                e.backward(ctx, var.grad.view(bsz, slen, -1), None)
+            if var.grad is not None:
+                ctx.defer_backward(e, var.grad.view(bsz, slen, -1), None)
 
     @tensor
     def train_loss(self, ctx) -> torch.Tensor:

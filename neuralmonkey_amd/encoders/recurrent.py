@@ -92,6 +92,8 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
             return True
         if self.add_layer_norm or self.add_residual:
             return True
+        if self.rnn_specs[0].size % 4 != 0 or self.input_sequence.dimension % 4 != 0:
+            return True                  # the fused gate kernels move float4s (tests/bahdanau.ini: GRU 7)
         return train_mode and self.dropout_keep_prob != 1.0
 
     def graph_safe_training(self, train_mode: bool) -> bool:

@@ -182,6 +182,6 @@ class TransformerEncoder(ModelPart, TemporalStatefulWithOutput):
         if act["x_in"].grad is not None and hasattr(self.input_sequence, "backward"):
             self.input_sequence.backward(ctx, act["x_in"].grad.view(bsz, slen, d))
         cross = act["cross"]
-        if cross is not None and cross[0].grad is not None and hasattr(self.input_for_cross_attention, "backward"):
+        if cross is not None and cross[0].grad is not None:
             cs = cross[0].grad
-            self.input_for_cross_attention.backward(ctx, cs.view(bsz, cross[2], -1), None)
+            ctx.defer_backward(self.input_for_cross_attention, cs.view(bsz, cross[2], -1), None)

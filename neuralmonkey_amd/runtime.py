@@ -97,6 +97,44 @@ class RunContext:
         """Persistent scratch buffer owned by the session (no per-step malloc)."""
         return self.session.buffer(key, shape, dtype, zero)
 
+    # -- encoder gradients shared by several decoders ---------------------------------------------------
+    def defer_backward(self, encoder, d_states, d_final) -> None:
+        """A decoder hands the gradient of an encoder's states / final output over here instead of
+        calling ``encoder.backward`` itself: an encoder read by several decoders (multi-task trainers,
+        tests/flat-multiattention.ini trains four decoders over two encoders) must run its backward pass
+        ONCE, on the sum of what its readers sent (what tf.gradients does with a fan-out node)."""
+        if not self.memo.get("backward_deferred", False):
+            if hasattr(encoder, "backward"):
+                encoder.backward(self, d_states, d_final)
+            return
+        from . import ops
+        pending = self.memo.setdefault("pending_backward", {})
+        slot = pending.setdefault(encoder, [None, None, False, False])      # grads, "is my own accumulator"
+        for i, g in enumerate((d_states, d_final)):
+            if g is None:
+                continue
+            if slot[i] is None:
+                slot[i] = g
+                continue
+            if not slot[2 + i]:                       # second reader: start a private accumulator
+                acc = self.buffer((id(encoder), "deferred_grad", i, tuple(g.shape)), tuple(g.shape))
+                ops.ew("copy", slot[i].reshape(-1, g.shape[-1]), None, acc.view(-1, g.shape[-1]))
+                slot[i], slot[2 + i] = acc, True
+            ops.ew("copy", g.reshape(-1, g.shape[-1]), None, slot[i].view(-1, g.shape[-1]), accumulate=True)
+
+    def flush_backward(self) -> None:
+        """Run the deferred encoder backward passes, readers before the encoders they read."""
+        pending = self.memo.get("pending_backward", {})
+        while pending:
+            order = list(pending)
+            # an encoder that another pending encoder cross-attends to waits for that one's gradient
+            ready = [e for e in order if not any(getattr(o, "input_for_cross_attention", None) is e
+                                                 for o in order if o is not e)]
+            enc = (ready or order)[0]
+            d_states, d_final = pending.pop(enc)[:2]
+            if hasattr(enc, "backward"):
+                enc.backward(self, d_states, d_final)
+
     def salt(self, *site) -> int:
         """32-bit salt of a dropout call site: crc32 of the site path.  The kernels add
         global_step * 0x9E3779B9 on the device (``Session.step_tensor``), so every training step draws

@@ -99,8 +99,11 @@ class GenericTrainer(GraphExecutor, Feedable):
         for part in self.feedables:          # host -> device copies of the fed batch, into persistent buffers
             part.stage_inputs(ctx)
         train = bool(ctx.fed(self.train_mode)) if ctx.is_fed(self.train_mode) else True
+        decoders, scales, counts = [], [], []
         for i, obj in enumerate(self.objectives):
             dec = obj.decoder
+            if dec in decoders:
+                raise NotImplementedError("two objectives over the decoder '{}' in one trainer".format(dec.name))
             weight = 1.0 if obj.weight is None else float(obj.weight)
             # loss = sum(xent) / sum(mask): with data parallelism the denominator is the
             # GLOBAL token count and gradients are summed over ranks
@@ -108,20 +111,32 @@ class GenericTrainer(GraphExecutor, Feedable):
             global_count = dp.all_reduce_scalar(count) if dp is not None else count
             scale = ctx.buffer((id(self), "gscale", i), (1,))
             scale.fill_(weight / global_count)
+            decoders.append(dec)
+            scales.append(scale)
+            counts.append(count)
 
-            def forward_backward(dec=dec, scale=scale):
+        def forward_backward():
+            """Every objective's forward + backward; encoders shared by several decoders run their
+            backward pass once, on the summed gradient (RunContext.defer_backward)."""
+            ctx.memo["backward_deferred"] = True
+            results = []
+            for dec, scale in zip(decoders, scales):
                 res = dec._train_loop(ctx, want_grad=True, grad_scale=scale)     # pylint: disable=protected-access
                 dec.backward(ctx, res)
-                return res
-            if sess.use_step_graphs and getattr(dec, "graph_safe_training", lambda t: False)(train):
-                # Taped (general-path) models launch hundreds of small kernels per step from Python:
-                # the whole forward + backward becomes one HIP graph per batch shape.
-                shapes = tuple(sorted((ph.name, tuple(np.shape(val))) for ph, val in ctx.feed.items()
-                                      if hasattr(val, "shape")))
-                res = sess.graphed_call((id(self), id(dec), train, shapes), forward_backward)
-                res = res._replace(token_count=count)
-            else:
-                res = forward_backward()
+                results.append(res)
+            ctx.flush_backward()
+            ctx.memo["backward_deferred"] = False
+            return results
+        if sess.use_step_graphs and all(getattr(d, "graph_safe_training", lambda t: False)(train) for d in decoders):
+            # Taped (general-path) models launch hundreds of small kernels per step from Python:
+            # the whole forward + backward becomes one HIP graph per batch shape.
+            shapes = tuple(sorted((ph.name, tuple(np.shape(val))) for ph, val in ctx.feed.items()
+                                  if hasattr(val, "shape")))
+            results = sess.graphed_call((id(self), train, shapes), forward_backward)
+            results = [res._replace(token_count=count) for res, count in zip(results, counts)]
+        else:
+            results = forward_backward()
+        for dec, res in zip(decoders, results):
             ctx.memo[dec.train_loop_result.key] = res
         sess.join_side()
 

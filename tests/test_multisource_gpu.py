@@ -172,3 +172,74 @@ def test_multisource_variable_names_follow_the_reference_scopes(dev):
               d + "/attention_decoder/attention_" + a + "/sentinel_logit/vector_bias",
               d + "/attention_decoder/attention_" + a + "/sentinel_logit/vector_ctx_proj/kernel"):
         assert n in names, n
+
+
+def test_encoders_shared_by_several_decoders_receive_the_summed_gradient(dev):
+    """tests/flat-multiattention.ini trains four decoders over the same two encoders with one
+    CrossEntropyTrainer: the gradient of the summed objectives is the sum of the objectives'
+    gradients, and every shared encoder runs its backward pass once (RunContext.defer_backward).
+    Checked through linearity: grads([A, B]) == grads([A]) + grads([B]), the training step replayed
+    from a captured graph included."""
+    import torch
+    from neuralmonkey_amd.attention import Attention
+    from neuralmonkey_amd.attention.combination import FlatMultiAttention, HierarchicalMultiAttention
+    from neuralmonkey_amd.decoders import Decoder
+    from neuralmonkey_amd.encoders import RecurrentEncoder, SpatialFiller
+    from neuralmonkey_amd.model.sequence import EmbeddedSequence
+    from neuralmonkey_amd.runtime import RunContext, reset_registry
+    from neuralmonkey_amd.synthetic import synthetic_vocabulary
+    from neuralmonkey_amd.tf_manager import TensorFlowManager
+    from neuralmonkey_amd.trainers import CrossEntropyTrainer
+    reset_registry()
+    vocab = synthetic_vocabulary(VOCAB)
+    seq = EmbeddedSequence(name="enc_input", vocabulary=vocab, data_id="source", embedding_size=6, max_length=MAXLEN)
+    enc = RecurrentEncoder(name="enc", input_sequence=seq, rnn_layers=[(4, "bidirectional", "NematusGRU")])
+    img = SpatialFiller(name="img", input_shape=list(SHAPE), data_id="images", projection_dim=8)
+    flat = FlatMultiAttention(name="flat", encoders=[enc, img], attention_state_size=5, use_sentinels=True)
+    hier = HierarchicalMultiAttention(name="hier", attentions=[Attention(name="a_txt", encoder=enc),
+                                                              Attention(name="a_img", encoder=img)],
+                                      attention_state_size=5, use_sentinels=False, share_attn_projections=True)
+    plain = Attention(name="plain", encoder=enc)
+    mk = lambda name, att, cond, size: Decoder(encoders=[enc, img], vocabulary=vocab, data_id="target", name=name,
+                                               max_output_len=MAXLEN, embedding_size=size, rnn_size=size,
+                                               attentions=[att], conditional_gru=cond)
+    decs = [mk("dec_flat", flat, False, 6), mk("dec_hier", hier, True, 6), mk("dec_plain", plain, False, 8)]
+    assert not decs[2].uses_general_path(True) and decs[0].uses_general_path(True)
+    trainers = [CrossEntropyTrainer(decoders=[d], l2_weight=0.0, clip_norm=None) for d in decs]
+    joint = CrossEntropyTrainer(decoders=decs, l2_weight=0.0, clip_norm=None)        # taped + fast path: eager
+    joint_taped = CrossEntropyTrainer(decoders=decs[:2], l2_weight=0.0, clip_norm=None)   # one graph per step
+    tfm = TensorFlowManager(num_sessions=1, num_threads=1, device=str(dev), seed=3)
+    tfm.initialize_sessions()
+    sess = tfm.sessions[0]
+    store = sess.store
+    rng = np.random.default_rng(0)
+    vals = store.state_dict()
+    for name, v in vals.items():
+        if v.ndim >= 2 or name.endswith("_v"):
+            vals[name] = (rng.standard_normal(v.shape) * 0.35).astype(np.float32)
+    store.load_state_dict(vals)
+    m = {"vocab": vocab}
+    ds, _, _ = _data(m, 5)
+
+    def grads(trainer):
+        fd = {}
+        for part in trainer.feedables:
+            fd.update(part.feed_dict(ds, train=True))
+        fd.update(trainer.feed_dict(ds, train=True))
+        with torch.no_grad():
+            trainer._objective_gradients(RunContext(sess, fd))        # pylint: disable=protected-access
+        torch.cuda.synchronize()
+        return store.ensure_grad().clone()
+
+    parts = [grads(t) for t in trainers]
+    want = parts[0] + parts[1] + parts[2]
+    scale = float(want.abs().max())
+    err = float((grads(joint) - want).abs().max())
+    assert err <= 2e-5 * scale, (err, scale)
+    for attempt in ("eager", "capture", "replay"):
+        err = float((grads(joint_taped) - (parts[0] + parts[1])).abs().max())
+        assert err <= 2e-5 * scale, (attempt, err, scale)
+    assert any(st[0] == 2 for st in sess.__dict__.get("_step_graphs", {}).values())
+    # the shared encoder did receive something from every decoder
+    g_enc = store.g("enc/rnn_0_bidirectional/bidirectional_rnn/fw/nematus_gru_cell/gates/state_proj/kernel")
+    assert float(g_enc.abs().max()) > 0
