@@ -1,2 +1,3 @@
 from .feed_forward import Attention   # noqa: F401
 from .combination import FlatMultiAttention, HierarchicalMultiAttention   # noqa: F401
+from .scaled_dot_product import MultiHeadAttention, ScaledDotProdAttention   # noqa: F401

@@ -356,13 +356,15 @@ def maxout(tape: Tape, x: Var, pool: int = 2) -> Var:
 
 def sdp_attention(tape: Tape, q: Var, k: Var, v: Var, key_mask: Optional[torch.Tensor], heads: int, bq: int,
                   tq: int, bk: int, tk: int, causal: bool = False, keep_prob: float = 1.0, salt: int = 0,
-                  k_data: Optional[torch.Tensor] = None, v_data: Optional[torch.Tensor] = None) -> Var:
+                  k_data: Optional[torch.Tensor] = None, v_data: Optional[torch.Tensor] = None,
+                  w_out: Optional[torch.Tensor] = None) -> Var:
     """Multi-head scaled dot-product attention (attention/scaled_dot_product.py:98-226) on
     [B*T, D] rows.  ``k_data`` / ``v_data`` override the key / value storage (a [R,Tmax,D] cache
-    view during decoding); gradients are defined for bq == bk."""
+    view during decoding); gradients are defined for bq == bk.  ``w_out`` [bq, heads, tq, tk] receives
+    the (post-dropout) weights, e.g. a decoder's attention history."""
     d = q.shape[1]
     out = tape.new((bq * tq, d))
-    w = tape.buf((bq, heads, tq, tk)) if tape.recording else None
+    w = w_out if w_out is not None else (tape.buf((bq, heads, tq, tk)) if tape.recording else None)
     k3 = k_data if k_data is not None else k.data.view(bk, tk, d)
     v3 = v_data if v_data is not None else v.data.view(bk, tk, d)
     step = tape.ctx.session.step_tensor() if keep_prob < 1.0 else None

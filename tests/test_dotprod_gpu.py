@@ -1,0 +1,148 @@
+"""Scaled dot-product / multi-head attention on the RNN decoder path (attention/scaled_dot_product.py
+classes; the reference's tests/factored.ini and tests/post-edit.ini use them with ``Decoder``).
+
+Checker: oracle/dotprod_ref.py on the engine's own weights.  Tolerances as in test_general_gpu.py:
+loss 1e-4 relative, gradients 1e-3 of each tensor's max magnitude, decoded indices exact, logits
+1e-4 relative."""
+import numpy as np
+import pytest
+
+from oracle import dotprod_ref as D
+from oracle import general_ref as G
+from oracle import nm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+VOCAB = 40
+MAXLEN = 8
+
+
+def _build(dev, cfg: G.Config, heads: int, att_keep: float, seed=13, beam=3):
+    from neuralmonkey_amd.attention.scaled_dot_product import MultiHeadAttention, ScaledDotProdAttention
+    from neuralmonkey_amd.decoders import BeamSearchDecoder, Decoder
+    from neuralmonkey_amd.encoders import RecurrentEncoder
+    from neuralmonkey_amd.model.sequence import EmbeddedSequence
+    from neuralmonkey_amd.runtime import reset_registry
+    from neuralmonkey_amd.synthetic import synthetic_vocabulary
+    from neuralmonkey_amd.tf_manager import TensorFlowManager
+    from neuralmonkey_amd.trainers import CrossEntropyTrainer
+    reset_registry()
+    vocab = synthetic_vocabulary(VOCAB)
+    seq = EmbeddedSequence(name=cfg.enc_name + "_input", vocabulary=vocab, data_id="source", embedding_size=6,
+                           max_length=MAXLEN)
+    enc = RecurrentEncoder(name=cfg.enc_name, input_sequence=seq, rnn_layers=[tuple(l) for l in cfg.rnn_layers],
+                           dropout_keep_prob=cfg.enc_dropout)
+    if heads == 1:
+        att = ScaledDotProdAttention(name=cfg.att_name, keys_encoder=enc, dropout_keep_prob=att_keep)
+    else:
+        att = MultiHeadAttention(name=cfg.att_name, n_heads=heads, keys_encoder=enc, values_encoder=enc,
+                                 dropout_keep_prob=att_keep)
+    dec = Decoder(encoders=[enc], vocabulary=vocab, data_id="target", name=cfg.dec_name, max_output_len=MAXLEN,
+                  dropout_keep_prob=cfg.dec_dropout, embedding_size=cfg.rnn_size, rnn_size=cfg.rnn_size,
+                  attentions=[att], rnn_cell=cfg.dec_cell, conditional_gru=cfg.conditional_gru)
+    bdec = BeamSearchDecoder(name="beam_decoder", parent_decoder=dec, beam_size=beam, max_steps=MAXLEN,
+                             length_normalization=0.6)
+    trainer = CrossEntropyTrainer(decoders=[dec], l2_weight=0.0, clip_norm=None)
+    tfm = TensorFlowManager(num_sessions=1, num_threads=1, device=str(dev), seed=seed)
+    tfm.initialize_sessions()
+    store = tfm.sessions[0].store
+    rng = np.random.default_rng(seed)
+    vals = store.state_dict()
+    for name, v in vals.items():
+        if v.ndim >= 2:
+            vals[name] = (rng.standard_normal(v.shape) * 0.35).astype(np.float32)
+        elif "bias" in name or name.endswith("_b") or name.endswith("beta"):
+            vals[name] = (v + rng.standard_normal(v.shape) * 0.1).astype(np.float32)
+    store.load_state_dict(vals)
+    return dict(enc=enc, att=att, dec=dec, bdec=bdec, trainer=trainer, tfm=tfm, store=store,
+                params=store.state_dict())
+
+
+def _data(batch, seed=3, with_target=True):
+    from neuralmonkey_amd import synthetic
+    ds = synthetic.synthetic_dataset(seed=seed, batch=batch, src_len=7, tgt_len=6, vocab=VOCAB, ragged=True,
+                                     with_target=with_target)
+    src = O.pad_ids([list(s) for s in ds.get_series("source")], MAXLEN)
+    tgt = None
+    if with_target:
+        tgt = np.ascontiguousarray(O.pad_ids([list(s) for s in ds.get_series("target")], MAXLEN,
+                                             add_end_symbol=True).T)
+    return ds, src, tgt
+
+
+BASE = G.Config(rnn_layers=((4, "bidirectional", "GRU"),), rnn_size=8)
+CASES = {
+    # tests/factored.ini / post-edit.ini: ScaledDotProdAttention = one head, no projections
+    "single_head": (BASE, 1, 1.0),
+    "single_head_dropout_condgru": (BASE._replace(dec_cell="NematusGRU", conditional_gru=True, dec_dropout=0.8), 1, 0.7),
+    # post-edit.ini: attention.scaled_dot_product.MultiHeadAttention (n_heads=3 there; the state size must divide)
+    "two_heads": (BASE, 2, 1.0),
+    "four_heads_dropout_lstm": (BASE._replace(dec_cell="LSTM", enc_dropout=0.9), 4, 0.8),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_dotprod_train_step_gradients(dev, case):
+    cfg, heads, keep = CASES[case]
+    m = _build(dev, cfg, heads, keep)
+    ds, src, tgt = _data(5)
+    ref = D.DotProdModel(m["params"], cfg, heads, keep, requires_grad=True)
+    ref_loss, ref_g = ref.train_grads(src, tgt, train=True)
+    res = m["tfm"].execute(ds, m["trainer"].feedables, [m["trainer"]], train=True)[0]
+    assert abs(res.losses[cfg.dec_name + " - cost"] - ref_loss) < 1e-4 * abs(ref_loss)
+    store = m["store"]
+    bad = {}
+    for name in store.names():
+        got = store.g(name).cpu().numpy().reshape(-1)
+        want = ref_g[name]
+        want = np.zeros_like(got) if want is None else want.reshape(-1)
+        err = float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-6))
+        if err > 1e-3:
+            bad[name] = err
+    assert not bad, "gradient mismatch: {}".format(bad)
+    if keep == 1.0:          # per-head histories (scaled_dot_product.py:362-366)
+        _, _, ref_w = ref.train_loss(src, tgt, train=True)
+        steps, bsz = tgt.shape
+        want = ref_w.detach().numpy().reshape(steps, bsz, heads, -1)
+        for h in range(heads):
+            got = m["att"].histories["{}_train_head{}".format(cfg.dec_name, h)].cpu().numpy()
+            assert np.abs(got - want[:, :, h]).max() < 1e-5
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_dotprod_greedy_and_beam(dev, case):
+    cfg, heads, keep = CASES[case]
+    m = _build(dev, cfg, heads, keep)
+    ds, src, _ = _data(4, seed=5, with_target=False)
+    ref = D.DotProdModel(m["params"], cfg, heads, keep)
+    ref_sym, ref_mask, ref_logits = ref.greedy(src, MAXLEN)
+    dec, sess = m["dec"], m["tfm"].sessions[0]
+    fd = {}
+    for part in (m["enc"].input_sequence, m["enc"], m["att"], dec):
+        fd.update(part.feed_dict(ds, train=False))
+    out = sess.run({"sym": dec.decoded_symbols, "mask": dec.runtime_mask, "logits": dec.runtime_logits}, fd)
+    assert np.array_equal(out["sym"], ref_sym)
+    assert np.array_equal(out["mask"].astype(bool), ref_mask)
+    assert np.abs(out["logits"] - ref_logits).max() <= 1e-4 * np.abs(ref_logits).max()
+    tok, scores, gap = ref.beam(src, 3, MAXLEN, 0.6)
+    got = sess.run(m["bdec"].outputs, fd)
+    if gap > 1e-5:
+        assert np.array_equal(np.asarray(got.last_search_step_output.token_ids)[1:], tok[1:])
+    assert np.abs(np.asarray(got.last_search_step_output.scores) - scores).max() <= 1e-4 * np.abs(scores).max()
+
+
+def test_dotprod_shape_checks():
+    """The shape errors of attention() (scaled_dot_product.py:151-168) surface when the decoder binds."""
+    from neuralmonkey_amd.attention.scaled_dot_product import MultiHeadAttention, ScaledDotProdAttention
+
+    class Enc:
+        dimension = 8
+    with pytest.raises(ValueError):
+        MultiHeadAttention(name="a", n_heads=0, keys_encoder=Enc())
+    with pytest.raises(ValueError):
+        ScaledDotProdAttention(name="b", keys_encoder=Enc(), dropout_keep_prob=0.0)
+    att = MultiHeadAttention(name="c", n_heads=3, keys_encoder=Enc())
+    with pytest.raises(ValueError):
+        att.bind_query_size(8)          # 8 % 3
+    with pytest.raises(ValueError):
+        ScaledDotProdAttention(name="d", keys_encoder=Enc()).bind_query_size(6)     # queries vs keys
