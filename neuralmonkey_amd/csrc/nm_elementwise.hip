@@ -17,7 +17,8 @@ extern "C" int nm_version(void) { return 1; }
 // ---------------------------------------------------------------------------
 __global__ void embedding_gather_kernel(const float* __restrict__ table, long V, int E,
                                         const int* __restrict__ ids, long n,
-                                        float* __restrict__ out, long ldo, int mask_pad, float scale) {
+                                        float* __restrict__ out, long ldo, int mask_pad, float scale,
+                                        int vec) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= n) return;
@@ -27,7 +28,7 @@ __global__ void embedding_gather_kernel(const float* __restrict__ table, long V,
     if (id < 0 || id >= V) { id = 0; s = 0.0f; }
     const float* src = table + (long)id * E;
     float* dst = out + row * ldo;
-    if ((E & 3) == 0 && (ldo & 3) == 0) {
+    if (vec) {
         for (int c = lane * 4; c < E; c += 256) {
             float4 v = *reinterpret_cast<const float4*>(src + c);
             v.x *= s; v.y *= s; v.z *= s; v.w *= s;
@@ -44,9 +45,11 @@ extern "C" int nm_embedding_gather(void* stream, const float* table, int64_t V, 
     NM_REQUIRE(table && ids && out, "nm_embedding_gather: null pointer");
     NM_REQUIRE(V > 0 && E > 0 && n >= 0 && ldo >= E, "nm_embedding_gather: bad shape");
     if (n == 0) return NM_OK;
-    NM_REQUIRE(nm_aligned16(table) && nm_aligned16(out), "nm_embedding_gather: unaligned");
+    // float4 rows when everything is 16-byte aligned; factored inputs (embedding sizes 5 + 3 side by side,
+    // tests/factored.ini) take the scalar path
+    const int vec = (E % 4 == 0 && ldo % 4 == 0 && nm_aligned16(table) && nm_aligned16(out)) ? 1 : 0;
     hipLaunchKernelGGL(embedding_gather_kernel, dim3(nm_cdiv(n, 4)), dim3(256), 0, nm_stream(stream),
-                       table, (long)V, (int)E, ids, (long)n, out, (long)ldo, mask_pad, scale);
+                       table, (long)V, (int)E, ids, (long)n, out, (long)ldo, mask_pad, scale, vec);
     NM_LAUNCH_CHECK("nm_embedding_gather");
 }
 

@@ -428,3 +428,27 @@ class SentenceEncoder(RecurrentEncoder):
             rnn_layers=[(rnn_size, rnn_direction, rnn_cell)], add_residual=add_residual,
             add_layer_norm=add_layer_norm, dropout_keep_prob=dropout_keep_prob, reuse=reuse,
             save_checkpoint=save_checkpoint, load_checkpoint=load_checkpoint, initializers=initializers)
+
+
+class FactoredEncoder(RecurrentEncoder):
+    # pylint: disable=too-many-arguments,too-many-locals
+    def __init__(self, name: str, vocabularies: List[Vocabulary], data_ids: List[str], embedding_sizes: List[int],
+                 rnn_size: int, rnn_cell: str = "GRU", rnn_direction: str = "bidirectional",
+                 add_residual: bool = False, add_layer_norm: bool = False, max_input_len: int = None,
+                 dropout_keep_prob: float = 1.0, reuse: ModelPart = None, save_checkpoint: str = None,
+                 load_checkpoint: str = None, initializers: InitializerSpecs = None,
+                 input_initializers: InitializerSpecs = None) -> None:
+        """recurrent.py:317-391: an EmbeddedFactorSequence named ``<name>_input`` (one embedding matrix per
+        factor, concatenated along the feature axis) feeding one RNN layer (tests/factored.ini)."""
+        from ..model.sequence import EmbeddedFactorSequence
+        s_ckp = "input_{}".format(save_checkpoint) if save_checkpoint else None
+        l_ckp = "input_{}".format(load_checkpoint) if load_checkpoint else None
+        input_sequence = EmbeddedFactorSequence(
+            name="{}_input".format(name), vocabularies=vocabularies, data_ids=data_ids,
+            embedding_sizes=embedding_sizes, max_length=max_input_len, save_checkpoint=s_ckp,
+            load_checkpoint=l_ckp, initializers=input_initializers)
+        RecurrentEncoder.__init__(
+            self, name=name, input_sequence=input_sequence,
+            rnn_layers=[(rnn_size, rnn_direction, rnn_cell)], add_residual=add_residual,
+            add_layer_norm=add_layer_norm, dropout_keep_prob=dropout_keep_prob, reuse=reuse,
+            save_checkpoint=save_checkpoint, load_checkpoint=load_checkpoint, initializers=initializers)

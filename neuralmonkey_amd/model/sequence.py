@@ -119,7 +119,8 @@ class EmbeddedFactorSequence(Sequence):
                 ops.embedding_gather(mat, idx.reshape(-1), out=view, mask_pad=False, scale=scale)
             col += esz
         if len(ids) > 1:
-            out.mul_(self.temporal_mask(ctx).unsqueeze(-1))       # plumbing for the multi-factor case
+            flat = out.view(bsz * slen, total)
+            ops.ew("rowscale", flat, self.temporal_mask(ctx).reshape(-1, 1), flat)
         return out
 
     def backward(self, ctx, d_states: torch.Tensor) -> None:
@@ -131,16 +132,18 @@ class EmbeddedFactorSequence(Sequence):
         names = self.embedding_matrix_names()
         bsz, slen, total = d_states.shape
         d2 = d_states.view(bsz * slen, total)
-        first_ids = ids[0].reshape(-1)
         col = 0
-        for idx, name, esz in zip(ids, names, self.embedding_sizes):
-            if len(ids) > 1 and idx is not ids[0]:
-                raise NotImplementedError("backward of multi-factor sequences")
+        for f, (idx, name, esz) in enumerate(zip(ids, names, self.embedding_sizes)):
             d_part = d2[:, col:col + esz]
             if self.scale_embeddings_by_depth:          # forward multiplied the rows by sqrt(E) (sequence.py:185-187)
                 scaled = ctx.buffer((id(self), "d_scaled", col), (bsz * slen, esz))
                 d_part = ops.ew("scale", d_part, None, scaled, alpha=float(esz) ** 0.5)
-            ops.embedding_scatter_add(ctx.store.g(name), idx.reshape(-1), d_part, skip_pad=True)
+            if f == 0:                                  # own pad positions == the mask
+                ops.embedding_scatter_add(ctx.store.g(name), idx.reshape(-1), d_part, skip_pad=True)
+            else:                                       # every factor is masked by the FIRST factor's padding
+                masked = ctx.buffer((id(self), "d_masked", col), (bsz * slen, esz))
+                ops.ew("rowscale", d_part, self.temporal_mask(ctx).reshape(-1, 1), masked)
+                ops.embedding_scatter_add(ctx.store.g(name), idx.reshape(-1), masked, skip_pad=False)
             col += esz
 
     def feed_dict(self, dataset, train: bool = False) -> FeedDict:

@@ -180,10 +180,14 @@ class GeneralModel:
         if cfg.spatial is not None:
             return self.encode_spatial(src_ids)
         name = cfg.enc_name
-        ids = torch.as_tensor(src_ids.astype(np.int64))
-        mask = (ids != PAD).to(self.dtype)
+        # model/sequence.py:170-199: one embedding matrix per factor, concatenated along the feature axis; the
+        # mask comes from the first factor.  ``src_ids`` is [B,S] or, for a factored input, [F,B,S].
+        factors = src_ids if src_ids.ndim == 3 else src_ids[None]
+        ids = torch.as_tensor(factors.astype(np.int64))
+        mask = (ids[0] != PAD).to(self.dtype)
         lengths = mask.sum(1).to(torch.int64).numpy()
-        x = p[name + "_input/embedding_matrix_0"][ids] * mask.unsqueeze(-1)       # model/sequence.py:170-194
+        x = torch.cat([p["{}_input/embedding_matrix_{}".format(name, f)][ids[f]] for f in range(ids.shape[0])], -1)
+        x = x * mask.unsqueeze(-1)
         layer_input = self.dropout(x, cfg.enc_dropout, train, name, "rnn_input")
         layer_final = layer_input[:, -1]
         for i, (size, direction, kind) in enumerate(cfg.rnn_layers):
