@@ -93,7 +93,9 @@ class Dataset:
             longest = 0
             for k in keys:
                 item = self._series[k][i]
-                if isinstance(item, (list, tuple)):
+                # dataset.py:525: max(len(row[key])) over the series -- token lists, pre-indexed id arrays
+                # (input_pipeline.preindex) and feature arrays alike
+                if hasattr(item, "__len__") and not isinstance(item, (str, bytes)):
                     longest = max(longest, len(item))
             b = 0
             while b < len(bounds) and longest > bounds[b]:

@@ -172,18 +172,34 @@ def index_series(sentences, vocab: Vocabulary, max_length: Optional[int], add_st
     """pad_batch + strings_to_indices on the host.  Sentences may already be
     int id sequences (pre-indexed data), which skips the dictionary lookup."""
     from ..vocabulary import END_TOKEN_INDEX, PAD_TOKEN_INDEX, START_TOKEN_INDEX
-    if sentences and len(sentences[0]) and not isinstance(sentences[0][0], str):
+    indexed = False
+    for sent in sentences:                        # id arrays, or the first non-empty sentence holds no strings
+        if isinstance(sent, np.ndarray) or len(sent):
+            indexed = isinstance(sent, np.ndarray) or not isinstance(sent[0], str)
+            break
+    if indexed:
         longest = max(len(s) for s in sentences) + (1 if add_end_symbol else 0)
         if max_length is not None:
             longest = min(max_length, longest)
-        width = longest + (1 if add_start_symbol else 0)
-        out = np.full((len(sentences), width), PAD_TOKEN_INDEX, dtype=np.int32)
-        for i, sent in enumerate(sentences):
-            row = list(sent) + ([END_TOKEN_INDEX] if add_end_symbol else [])
-            row = row[:longest]
-            if add_start_symbol:
-                row = [START_TOKEN_INDEX] + row
-            out[i, :len(row)] = row
+        off = 1 if add_start_symbol else 0
+        n = len(sentences)
+        out = np.full((n, longest + off), PAD_TOKEN_INDEX, dtype=np.int32)
+        # one scatter for the whole batch: (row, column) of every kept token of the concatenated sentences
+        lens = np.fromiter((len(s) for s in sentences), dtype=np.int64, count=n)
+        kept = np.minimum(lens, longest)
+        if (kept < lens).any():
+            sentences = [s[:k] for s, k in zip(sentences, kept)]
+        total = int(kept.sum())
+        if total:
+            flat = np.concatenate([np.asarray(s, dtype=np.int32) for s in sentences if len(s)])
+            starts = np.cumsum(kept) - kept
+            rows = np.repeat(np.arange(n), kept)
+            out[rows, np.arange(total) - np.repeat(starts, kept) + off] = flat
+        if add_end_symbol:                        # </s> right after the sentence unless max_length cut it away
+            fits = np.nonzero(lens < longest)[0]
+            out[fits, lens[fits] + off] = END_TOKEN_INDEX
+        if add_start_symbol:
+            out[:, 0] = START_TOKEN_INDEX
         return out
     return vocab.strings_to_indices(pad_batch(sentences, max_length, add_start_symbol, add_end_symbol))
 

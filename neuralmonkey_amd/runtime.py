@@ -8,6 +8,7 @@ memoised per run, launching libnmhip kernels on the device.  The call shape
 (fetch dictionaries in, numpy structures out) is unchanged.
 """
 import os
+import threading
 from contextlib import contextmanager
 from typing import Any, Dict, List, Optional
 
@@ -176,6 +177,8 @@ class Session:
         self.use_persistent = os.environ.get("NM_PERSISTENT", "0") != "0"
         self._side_stream = None
         self._side_dirty = False
+        self._copy_stream = None
+        self._tls = threading.local()
         self.global_step = 0
 
     def to_device(self, array, dtype, tag=None, derive=None):
@@ -187,13 +190,45 @@ class Session:
         key = (id(array), tag, dtype)
         hit = self._h2d.get(key)
         if hit is not None and hit[0] is array:
+            if len(hit) > 2 and hit[2] is not None and not self.prefetching:
+                # uploaded ahead of time on the copy stream (input_pipeline.Prefetcher): order this stream
+                # after the copy, once, and tell the allocator the tensor is in use here
+                torch.cuda.current_stream(self.device).wait_event(hit[2])
+                hit[1].record_stream(torch.cuda.current_stream(self.device))
+                self._h2d[key] = (hit[0], hit[1], None)
             return hit[1]
         src = derive(array) if derive is not None else array
-        ten = torch.as_tensor(np.ascontiguousarray(src)).to(self.device, dtype)
-        if len(self._h2d) > 64:
-            self._h2d.clear()
-        self._h2d[key] = (array, ten)
+        host = torch.as_tensor(np.ascontiguousarray(src))
+        event = None
+        if self.prefetching and self.device.type == "cuda":
+            # pinned staging buffer + asynchronous copy on the session's copy stream: the DMA engine moves the
+            # next batch while the compute stream runs the current step
+            if self._copy_stream is None:
+                self._copy_stream = torch.cuda.Stream(device=self.device)
+            with torch.cuda.stream(self._copy_stream):
+                ten = host.to(dtype).pin_memory().to(self.device, non_blocking=True)
+                event = torch.cuda.Event()
+                event.record(self._copy_stream)
+        else:
+            ten = host.to(self.device, dtype)
+        if len(self._h2d) > 256:
+            for old in list(self._h2d)[:128]:          # oldest half (dicts keep insertion order)
+                self._h2d.pop(old, None)
+        self._h2d[key] = (array, ten, event)
         return ten
+
+    @property
+    def prefetching(self) -> bool:
+        """True on a thread that is uploading a FUTURE batch (input_pipeline.Prefetcher)."""
+        return getattr(self._tls, "prefetching", False)
+
+    @contextmanager
+    def prefetch_scope(self):
+        self._tls.prefetching = True
+        try:
+            yield
+        finally:
+            self._tls.prefetching = False
 
     def buffer(self, key, shape, dtype=torch.float32, zero=False):
         """Persistent scratch tensor.  Keyed by (key, shape, dtype) and never
@@ -211,6 +246,8 @@ class Session:
     def staged(self, key, src: torch.Tensor) -> torch.Tensor:
         """Copy a per-batch device tensor into a persistent buffer (same pointer
         every run), so time loops that read it can be replayed as HIP graphs."""
+        if self.prefetching:          # a future batch: the persistent buffer still belongs to the running step
+            return src
         buf = self.buffer(("staged", key), tuple(src.shape), src.dtype)
         buf.copy_(src)
         return buf

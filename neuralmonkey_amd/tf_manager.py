@@ -177,10 +177,21 @@ class TensorFlowManager:
 
 
 def _feed_dicts(dataset, coders: Set[Feedable], train: bool = False) -> Dict:
-    res: Dict = {}
-    for coder in coders:
-        res.update(coder.feed_dict(dataset, train=train))
-    return res
+    """Merged feed dict of ``coders`` for one batch, remembered on the batch object: a batch that was
+    prepared ahead of time (input_pipeline.Prefetcher) or is executed again hands back the SAME host
+    arrays, which ``Session.to_device`` recognises as already resident on the device."""
+    cache = getattr(dataset, "__dict__", {}).setdefault("_feed_cache", {}) if hasattr(dataset, "__dict__") else {}
+    ordered = sorted(coders, key=id)
+    key = (train, tuple(id(c) for c in ordered))
+    hit = cache.get(key)
+    if hit is None or len(hit[0]) != len(ordered) or any(a is not b for a, b in zip(hit[0], ordered)):
+        res: Dict = {}
+        for coder in coders:
+            res.update(coder.feed_dict(dataset, train=train))
+        if len(cache) >= 8:
+            cache.clear()
+        hit = cache[key] = (ordered, res)       # the parts are kept alive with the entry: ids cannot be recycled
+    return dict(hit[1])
 
 
 def get_default_tf_manager() -> TensorFlowManager:
