@@ -88,7 +88,9 @@ def main():
     world = dp.world_size if dp else 1
     if world != args.gpus:
         raise SystemExit("--gpus {} but WORLD_SIZE={}".format(args.gpus, world))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    # one rank per GPU; ranks beyond the visible devices wrap around (only meaningful with
+    # NM_DIST_BACKEND=gloo, the single-GPU smoke test of the multi-rank code path)
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = "cuda:{}".format(local)
     lib = _lib.load()

@@ -325,6 +325,9 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
         # Leaf work (weight gradients, bias column sums: nothing downstream reads them) is
         # enqueued on the session's side stream so it overlaps the latency-bound BPTT loops.
         side = ctx.session.side
+        from .. import distributed
+        dp = distributed.current()
+        dp_overlap = dp is not None and bool(ctx.memo.get("dp_overlap", False))
 
         # ---- logits = out . W + b  (autoregressive.py:450-459)
         d_out = ctx.buffer(key + ("d_out",), (rows, odim))
@@ -362,6 +365,8 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
             else:
                 ops.gemm(out_all, dlogits, out=store.g(self.var_name("state_to_word_W")), trans_a=True)
                 ops.colsum(dlogits, store.g(self.var_name("state_to_word_b")))
+                if dp_overlap:        # the largest gradient slice is final: its all-reduce runs under the BPTT
+                    dp.all_reduce_early(store, [self.var_name("state_to_word_W"), self.var_name("state_to_word_b")])
 
         # ---- attentions (batched over time); adds the query path into d_s
         d_att_states = []
@@ -403,6 +408,8 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
             ops.gemm(dc_all, cell["wc_x"], out=d_emb, trans_b=True, accumulate=True)
             ops.embedding_scatter_add(store.g(self.embedding_matrix_name), self._dec_input_ids(ctx).reshape(-1),
                                       d_emb)
+            if dp_overlap and not self.tie_embeddings and self.embeddings_source is None:
+                dp.all_reduce_early(store, [self.embedding_matrix_name])     # runs under the encoder's backward
 
         # ---- initial state projection and the encoders
         d_enc_out = self.encoder_projection.backward(ctx, self, self.rnn_size, self.encoders, ds0)

@@ -28,6 +28,9 @@ class DataParallel:
         self.rank = dist.get_rank()
         self.world_size = dist.get_world_size()
         self.bucket_elems = max(1, bucket_bytes // 4)
+        self.overlap = os.environ.get("NM_DP_OVERLAP", "1") != "0"
+        self._handles: list = []          # collectives in flight this step
+        self._early: list = []            # [lo, hi) spans of the flat gradient already being reduced
         # Host scalars (the global target-token count of a step) travel over a gloo side group:
         # reading an RCCL result back would synchronise the device every step and stop the host
         # from enqueueing ahead of the GPU.
@@ -50,17 +53,59 @@ class DataParallel:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return float(t.item())
 
+    def begin_step(self) -> None:
+        """Forget the bookkeeping of a step that did not reach ``all_reduce_gradients`` (an exception)."""
+        for hnd in self._handles:
+            hnd.wait()
+        self._handles, self._early = [], []
+
+    def _reduce_span(self, grad, lo: int, hi: int) -> None:
+        for start in range(lo, hi, self.bucket_elems):
+            chunk = grad[start:min(hi, start + self.bucket_elems)]
+            self._handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
+
+    def all_reduce_early(self, store, names) -> None:
+        """Start summing the gradient slices of ``names`` NOW, while the rest of the backward pass still
+        runs: the vocabulary projection (65 MB at V=32k) is final after the first GEMMs of the backward
+        pass, the decoder embeddings after the decoder's BPTT -- together more than half of the 228 MB
+        exchanged per step.  The collective is ordered after the *current* stream (call it
+        on the stream that produced the slices); ``all_reduce_gradients`` later skips these spans and
+        waits for them.  A caller must only name variables that receive no further contributions."""
+        if self.world_size == 1 or not self.overlap:
+            return
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return
+        grad = store.ensure_grad()
+        spans = sorted((store.offset(n), store.offset(n) + store[n].numel()) for n in names)
+        merged = []
+        for lo, hi in spans:
+            if merged and lo <= merged[-1][1]:
+                merged[-1][1] = max(merged[-1][1], hi)
+            else:
+                merged.append([lo, hi])
+        for lo, hi in merged:
+            if any(lo < dhi and dlo < hi for dlo, dhi in self._early):
+                raise RuntimeError("gradient span [{}, {}) was already reduced this step".format(lo, hi))
+            self._early.append((lo, hi))
+            self._reduce_span(grad, lo, hi)
+
     def all_reduce_gradients(self, store) -> None:
-        """In-place sum of the flat gradient buffer over ranks, in large buckets."""
+        """In-place sum of the flat gradient buffer over ranks, in large buckets (minus the spans
+        ``all_reduce_early`` already started); returns with every collective of the step ordered
+        before the current stream."""
         if self.world_size == 1:
             return
         grad = store.ensure_grad()
-        handles = []
-        for start in range(0, grad.numel(), self.bucket_elems):
-            chunk = grad[start:start + self.bucket_elems]
-            handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
-        for hnd in handles:
+        pos = 0
+        for lo, hi in sorted(self._early):
+            if lo > pos:
+                self._reduce_span(grad, pos, lo)
+            pos = max(pos, hi)
+        if pos < grad.numel():
+            self._reduce_span(grad, pos, grad.numel())
+        for hnd in self._handles:
             hnd.wait()
+        self._handles, self._early = [], []
 
     def broadcast_parameters(self, store, src: int = 0) -> None:
         """Make every replica start from rank ``src``'s variables."""
@@ -83,7 +128,7 @@ def init_from_env(backend: Optional[str] = None) -> Optional[DataParallel]:
         return None
     if not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("NM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

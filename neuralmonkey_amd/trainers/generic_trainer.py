@@ -95,6 +95,8 @@ class GenericTrainer(GraphExecutor, Feedable):
         grad = store.ensure_grad()
         grad.zero_()
         dp = dist.current()
+        if dp is not None:
+            dp.begin_step()
         sess.step_tensor()                   # device copy of global_step (dropout salts), outside any capture
         for part in self.feedables:          # host -> device copies of the fed batch, into persistent buffers
             part.stage_inputs(ctx)
@@ -160,6 +162,9 @@ class GenericTrainer(GraphExecutor, Feedable):
 
     @tensor
     def train_op(self, ctx) -> int:
+        # one optimizer step per batch: gradient slices that are final early in the backward pass may start
+        # their all-reduce right away (distributed.DataParallel.all_reduce_early)
+        ctx.memo["dp_overlap"] = True
         self._objective_gradients(ctx)
         return self._apply_gradients(ctx)
 

@@ -65,7 +65,20 @@ def _worker(rank, world, port, out_dir):
     for name in params:
         store.g(name).copy_(tp[name].grad.reshape(store.g(name).shape))
     dp.bucket_elems = 1000                      # force several buckets
+    # two slices start their reduction early (what Decoder.backward does for the vocabulary projection and the
+    # decoder embeddings while the rest of the backward pass runs); the final call covers the remaining spans
+    names = sorted(params)
+    early = [names[len(names) // 2], names[0]]
+    dp.begin_step()
+    dp.all_reduce_early(store, [early[0]])
+    dp.all_reduce_early(store, [early[1]])
+    try:
+        dp.all_reduce_early(store, [early[0]])
+        raise AssertionError("a span was reduced twice")
+    except RuntimeError:
+        pass
     dp.all_reduce_gradients(store)
+    assert not dp._early and not dp._handles
 
     if rank == 0:
         fsrc, ftgt = arrays(ds)
