@@ -216,5 +216,25 @@ class AutoregressiveDecoder(ModelPart):
     def cost(self):
         return self.train_loss
 
+    @tensor
+    def train_xents(self, ctx) -> torch.Tensor:
+        """[B,T] masked cross entropy of the teacher-forced pass (autoregressive.py:289-310; XentRunner)."""
+        res = self.train_loop_result(ctx)
+        rows, steps, bsz = res.saved["loss_rows"], res.saved["steps"], res.saved["bsz"]
+        xents = rows.view(steps, bsz).t() if res.saved["loss_layout"] == "tb" else rows.view(bsz, steps)
+        if self.label_smoothing:         # one scalar, the mean over all positions, broadcast against the mask (:292-310)
+            xents = (rows.sum() / rows.numel()) * self.train_mask(ctx).t()
+        return xents
+
+    @tensor
+    def decoded(self, ctx) -> torch.Tensor:
+        """[T,B] argmax(runtime_logits[:, :, 1:]) + 1: greedy symbols with <pad> excluded
+        (autoregressive.py:341-349; PlainRunner)."""
+        logits = self.runtime_logits(ctx)
+        steps, bsz, vsz = logits.shape
+        out = ctx.buffer((id(self), "decoded", steps, bsz), (steps * bsz,), torch.int32)
+        ops.row_stats(logits.view(steps * bsz, vsz)[:, 1:], None, None, out)
+        return (out + 1).view(steps, bsz)
+
     def decoding_loop(self, ctx, train_mode: bool, sample: bool = False, temperature: float = 1.0):
         raise NotImplementedError("Abstract method")

@@ -302,7 +302,8 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
         saved = {"emb_all": emb_all, "xp": xp, "s0": s0, "s_all": s_all, "s_ext": s_ext, "ru_all": ru_all,
                  "c_all": c_all, "rh_all": rh_all, "y_all": y_all, "e_all": e_all,
                  "att_states": att_states, "out_all": out_all,
-                 "dlogits": logits if want_grad else None, "cell": cell, "steps": steps, "bsz": bsz}
+                 "dlogits": logits if want_grad else None, "cell": cell, "steps": steps, "bsz": bsz,
+                 "loss_rows": loss_rows, "loss_layout": "tb"}
         return TrainResult(loss_sum, self.train_token_count(ctx), steps, saved)
 
     def backward(self, ctx, res: TrainResult) -> None:

@@ -173,7 +173,8 @@ class GeneralDecoderMixin:
         for att, st in zip(self.attentions, att_states):
             att.finalize_loop("{}_train".format(self.name), AttentionLoopState(st.contexts, st.weights, steps))
         saved = {"tape": tape, "enc_outs": enc_outs, "sessions": sessions, "steps": steps, "bsz": bsz,
-                 "dlogits": logits.data if want_grad else None, "logits": logits.data}
+                 "dlogits": logits.data if want_grad else None, "logits": logits.data,
+                 "loss_rows": loss_rows, "loss_layout": "tb"}
         return TrainResult(loss_sum, self.train_token_count(ctx), steps, saved)
 
     def _general_backward(self, ctx, res) -> None:

@@ -223,7 +223,8 @@ class TransformerDecoder(AutoregressiveDecoder):
         loss_sum = ctx.buffer((id(self), "ttrain", "loss_sum"), (1,))
         ops.reduce_sum(loss_rows, loss_sum)
         saved = {"tape": tape, "enc": enc, "steps": steps, "bsz": bsz, "logits": logits.data,
-                 "dlogits": logits.data if want_grad else None, "states": states}
+                 "dlogits": logits.data if want_grad else None, "states": states,
+                 "loss_rows": loss_rows, "loss_layout": "bt"}
         return TrainResult(loss_sum, self.train_token_count(ctx), steps, saved)
 
     def backward(self, ctx, res: TrainResult) -> None:

@@ -1,2 +1,4 @@
 from .runner import GreedyRunner                                                # noqa: F401
 from .beamsearch_runner import BeamSearchRunner, beam_search_runner_range       # noqa: F401
+from .plain_runner import PlainRunner                                           # noqa: F401
+from .xent_runner import XentRunner                                             # noqa: F401
