@@ -11,7 +11,6 @@ import torch
 
 from .. import ops
 from ..model.model_part import InitializerSpecs, ModelPart
-from ..model.stateful import SpatialStateful, TemporalStateful
 from ..nn.dropout import dropout
 from ..runtime import tensor
 from ..variables import zeros_initializer

@@ -10,7 +10,7 @@ import collections
 import collections.abc
 import importlib
 from argparse import Namespace
-from inspect import Parameter, isclass, isfunction, signature
+from inspect import isclass, isfunction, signature
 from typing import Any, Dict, Set, Tuple
 
 from .exceptions import ConfigBuildException, ConfigInvalidValueException

@@ -26,7 +26,6 @@ from ..model.stateful import Stateful
 from ..nn import gru
 from ..nn.dropout import dropout
 from ..runtime import tensor
-from ..variables import constant_initializer, orthogonal_initializer, zeros_initializer
 from ..vocabulary import END_TOKEN_INDEX, START_TOKEN_INDEX, Vocabulary, sentence_mask
 from .autoregressive import (AutoregressiveDecoder, DecoderConstants, DecoderFeedables,
                              DecoderHistories, LoopState)

@@ -2,13 +2,8 @@
 
 ``apply`` / ``backward`` serve the hand-scheduled fast path of the decoder,
 ``apply_var`` is the same arithmetic on an autodiff tape (general path)."""
-from typing import List
-
-import torch
-
 from .. import autodiff as F
 from .. import ops
-from ..model.stateful import Stateful
 from ..nn.dropout import dropout
 from ..variables import zeros_initializer
 

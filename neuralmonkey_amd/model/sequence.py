@@ -2,7 +2,7 @@
 
 ``EmbeddedSequence``: ids [B,S] -> embedding gather * mask (sequence.py:170-194)
 as one HIP kernel (nm_embedding_gather)."""
-from typing import Callable, Dict, List, Optional
+from typing import Dict, List, Optional
 
 import numpy as np
 import torch

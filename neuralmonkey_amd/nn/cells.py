@@ -9,7 +9,7 @@ in scripts/import_nematus.py:88-130) and evaluates one step as MFMA GEMMs plus
 the element-wise kernels of ``autodiff``.  The plain-GRU fast path
 (``nn/gru.py``: fused GEMM epilogues, HIP-graph loops) uses the same variables.
 """
-from typing import List, Tuple
+from typing import Tuple
 
 from .. import autodiff as F
 from ..variables import constant_initializer, orthogonal_initializer, zeros_initializer

@@ -9,7 +9,6 @@ from typing import Any, Callable, Dict, List
 
 import numpy as np
 
-from ..runtime import Fetch
 from .base_runner import BaseRunner, NextExecute
 
 Postprocessor = Callable[[List[List[str]]], List[List[str]]]

@@ -4,7 +4,7 @@ Used by bench.py, ``__graft_entry__.smoke()`` and the parity tests: the model is
 assembled from the same plugin classes an INI file names
 (examples/translation.ini:90-134 topology: SentenceEncoder -> Attention ->
 Decoder -> CrossEntropyTrainer / GreedyRunner / BeamSearchRunner)."""
-from typing import List, NamedTuple, Optional
+from typing import NamedTuple, Optional
 
 import numpy as np
 
@@ -15,7 +15,7 @@ from .encoders import SentenceEncoder
 from .runners import BeamSearchRunner, GreedyRunner
 from .runtime import reset_registry
 from .tf_manager import TensorFlowManager
-from .vocabulary import END_TOKEN_INDEX, PAD_TOKEN_INDEX, Vocabulary
+from .vocabulary import Vocabulary
 
 
 class TranslationModel(NamedTuple):

@@ -9,7 +9,7 @@ accepted for config compatibility and ignored (one process per GPU, HIP
 streams instead of TF thread pools).
 """
 import os
-from typing import Any, Dict, List, Optional, Sequence, Set, Union
+from typing import Dict, List, Optional, Sequence, Set, Union
 
 import numpy as np
 import torch
