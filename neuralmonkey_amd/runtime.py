@@ -17,6 +17,12 @@ import torch
 
 _REGISTRY: List[Any] = []          # every Parameterized part, in creation order
 
+# HIP-graph captures are thread-local: other threads of the process keep making runtime calls while this
+# thread captures -- the RCCL watchdog polls the events of in-flight collectives, the input-pipeline
+# worker uploads the next batch on its copy stream -- and under the default ("global") mode any such
+# call would invalidate the capture.
+CAPTURE_MODE = "thread_local"
+
 
 def register_part(part) -> None:
     _REGISTRY.append(part)
@@ -293,7 +299,7 @@ class Session:
             self._graphs[key] = 1
         elif state == 1:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode=CAPTURE_MODE):
                 fn()
             self._graphs[key] = graph
             graph.replay()
@@ -316,7 +322,7 @@ class Session:
             state = (1, None, result)
         elif state[0] == 1:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode=CAPTURE_MODE):
                 result = fn()
             graph.replay()
             state = (2, graph, result)
