@@ -420,6 +420,7 @@ __global__ __launch_bounds__(64) void beam_topk_final(const float* __restrict__ 
 // One HBM pass instead of the three of row_stats (2) + top-k (1): at B*k = 640 rows of 32000 logits
 // that is 82 MB read once.
 // ---------------------------------------------------------------------------------------------
+#define ROW_SCAN_CAND 256
 template <int K, int NV, bool TOPK>
 __global__ __launch_bounds__(1024) void row_scan_kernel(const float* __restrict__ x, long ldx, int V,
                                                         float* __restrict__ max_out, float* __restrict__ lse_out,
@@ -433,6 +434,9 @@ __global__ __launch_bounds__(1024) void row_scan_kernel(const float* __restrict_
     __shared__ int shi[16];
     __shared__ float shs[16 * K];
     __shared__ int shx[16 * K];
+    __shared__ float cand_s[ROW_SCAN_CAND];
+    __shared__ int cand_i[ROW_SCAN_CAND];
+    __shared__ int cand_n;
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int base = TOPK ? (r % k) * V : 0;
     if (TOPK && finished[r]) {
@@ -482,6 +486,68 @@ __global__ __launch_bounds__(1024) void row_scan_kernel(const float* __restrict_
     int ix[K];
 #pragma unroll
     for (int p = 0; p < K; ++p) { s[p] = -INFINITY; ix[p] = 0x7fffffff; }
+
+    // ---- candidate filter.  The score (lps + ((x - max) - lse)) / pen is monotone in x, so the row's K
+    // best candidates are among its largest logits.  tau = the K-th largest of the 16 wave maxima: at
+    // least K elements are >= tau, hence every element of the exact top K scores at least score(tau).
+    // Elements below tau - margin score STRICTLY less (margin = 2^-18 of the magnitudes entering the
+    // score, far above the few ulps within which distinct logits can round to equal scores) and
+    // cannot be in the top K whatever the index tie-break says.  Typically 5-10 of the 32000 logits
+    // survive; they are scored exactly and ranked by the same (score, flat index) order as before.  A
+    // row whose survivors do not fit the list (many equal logits, or |logprob_sum| so large that all
+    // scores collapse: the -1e9 of the not-yet-live beams of the first step) takes the full
+    // insertion path below.
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) tmax = fmaxf(tmax, fmaxf(fmaxf(xv[i].x, xv[i].y), fmaxf(xv[i].z, xv[i].w)));
+    tmax = nm_wave_max(tmax);
+    __syncthreads();                       // shv was used by the block reductions above
+    if (lane == 0) shv[wave] = tmax;
+    if (tid == 0) cand_n = 0;
+    __syncthreads();
+    float tau = -INFINITY;
+    {
+        float wm = lane < 16 ? shv[lane] : -INFINITY;      // every wave derives tau itself (no second barrier)
+#pragma unroll
+        for (int p = 0; p < K; ++p) {
+            tau = nm_wave_max(wm);
+            const unsigned long long hit = __ballot(wm == tau);
+            if (lane == __ffsll((long long)hit) - 1) wm = -INFINITY;     // drop ONE instance of the maximum
+        }
+    }
+    const float margin = (fabsf(lse) + fabsf(lps) + (bv - tau) + 1.0f) * (1.0f / 262144.0f);
+    const float cut = tau - margin;
+    if (cut > -INFINITY) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int q = tid + i * 1024;
+            const float xe[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (xe[c] >= cut) {                                       // (padding lanes hold -inf)
+                    const int slot = atomicAdd(&cand_n, 1);
+                    if (slot < ROW_SCAN_CAND) {
+                        cand_s[slot] = (lps + ((xe[c] - bv) - lse)) / pen;
+                        cand_i[slot] = base + q * 4 + c;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int ncand = cand_n;
+    if (cut > -INFINITY && ncand <= ROW_SCAN_CAND) {
+        if (wave == 0) {
+            for (int c = lane; c < ncand; c += 64) topk_insert<K>(s, ix, cand_s[c], cand_i[c]);
+            topk_wave_merge<K>(s, ix);
+            if (lane == 0) {
+#pragma unroll
+                for (int p = 0; p < K; ++p) { part_score[(long)r * K + p] = s[p]; part_idx[(long)r * K + p] = ix[p]; }
+            }
+        }
+        return;
+    }
+    // ---- full path: every element through the per-thread insertion lists and the merge tree
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int q = tid + i * 1024;
