@@ -185,6 +185,77 @@ __global__ __launch_bounds__(NT) void xent_kernel(float* __restrict__ x, long ld
     }
 }
 
+// Register-resident variant: the row is read from HBM ONCE (NV float4 per thread, all loads in flight
+// together), max / sum exp / sum x are reduced from registers and the gradient is written straight
+// from them -- 1 read + 1 write of the [rows, V] logits instead of 2 reads + 1 write.
+template <int NV>
+__global__ __launch_bounds__(1024) void xent_regs_kernel(float* __restrict__ x, long ldx, int V,
+                                                         const int* __restrict__ targets,
+                                                         const float* __restrict__ weights,
+                                                         float* __restrict__ loss_rows,
+                                                         const float* __restrict__ grad_scale,
+                                                         int write_grad, float smoothing) {
+    __shared__ float sh[16];
+    const long row = blockIdx.x;
+    const int tid = threadIdx.x;
+    float4* x4 = reinterpret_cast<float4*>(x + row * ldx);
+    const int V4 = V >> 2;
+    float4 xv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int q = tid + i * 1024;
+        xv[i] = q < V4 ? x4[q] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    }
+    float bv = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) bv = fmaxf(bv, fmaxf(fmaxf(xv[i].x, xv[i].y), fmaxf(xv[i].z, xv[i].w)));
+    bv = nm_wave_max(bv);
+    if ((tid & 63) == 0) sh[tid >> 6] = bv;
+    __syncthreads();
+    bv = sh[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) bv = fmaxf(bv, sh[w]);
+    __syncthreads();
+    float s = 0.0f, sx = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (tid + i * 1024 < V4) {
+            s += expf(xv[i].x - bv) + expf(xv[i].y - bv) + expf(xv[i].z - bv) + expf(xv[i].w - bv);
+            sx += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
+        }
+    }
+    s = block_sum<1024>(s, sh);
+    __syncthreads();
+    if (smoothing != 0.0f) { sx = block_sum<1024>(sx, sh); __syncthreads(); }
+    const float lse = logf(s);
+    const int t = targets[row];
+    const float w = weights ? weights[row] : 1.0f;
+    if (tid == 0 && loss_rows) {
+        const float nll = (t >= 0 && t < V) ? -(x[row * ldx + t] - bv - lse) : 0.0f;    // not yet overwritten: see barrier
+        const float uniform = (bv + lse) - sx / (float)V;
+        loss_rows[row] = ((1.0f - smoothing) * nll + smoothing * uniform) * w;
+    }
+    if (!write_grad) return;
+    __syncthreads();                       // the loss read of x[t] precedes every store of this row
+    const float gs = w * (grad_scale ? grad_scale[0] : 1.0f);
+    const float inv = 1.0f / s;
+    const float qu = smoothing / (float)V;
+    const float hot = 1.0f - smoothing;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int q = tid + i * 1024;
+        if (q < V4) {
+            const int e = q * 4;
+            float4 g;
+            g.x = (expf(xv[i].x - bv) * inv - qu - (e == t ? hot : 0.0f)) * gs;
+            g.y = (expf(xv[i].y - bv) * inv - qu - (e + 1 == t ? hot : 0.0f)) * gs;
+            g.z = (expf(xv[i].z - bv) * inv - qu - (e + 2 == t ? hot : 0.0f)) * gs;
+            g.w = (expf(xv[i].w - bv) * inv - qu - (e + 3 == t ? hot : 0.0f)) * gs;
+            x4[q] = g;
+        }
+    }
+}
+
 extern "C" int nm_xent(void* stream, float* logits, int64_t ldx, int64_t rows, int64_t V,
                        const int32_t* targets, const float* weights, float* loss_rows,
                        const float* grad_scale, int write_grad, float label_smoothing) {
@@ -192,9 +263,18 @@ extern "C" int nm_xent(void* stream, float* logits, int64_t ldx, int64_t rows, i
     NM_REQUIRE(label_smoothing >= 0.0f && label_smoothing < 1.0f, "nm_xent: label_smoothing %g outside [0,1)",
                label_smoothing);
     if (rows == 0) return NM_OK;
-    hipLaunchKernelGGL((xent_kernel<1024>), dim3((unsigned)rows), dim3(1024), 0, nm_stream(stream),
-                       logits, (long)ldx, (int)V, targets, weights, loss_rows, grad_scale, write_grad,
-                       label_smoothing);
+    hipStream_t st = nm_stream(stream);
+    const bool vec = (V % 4 == 0) && (ldx % 4 == 0) && nm_aligned16(logits);
+    const int64_t v4 = V / 4;
+#define NM_XR(NV_)                                                                                               \
+    hipLaunchKernelGGL((xent_regs_kernel<NV_>), dim3((unsigned)rows), dim3(1024), 0, st, logits, (long)ldx, (int)V, \
+                       targets, weights, loss_rows, grad_scale, write_grad, label_smoothing)
+    if (vec && v4 <= 8 * 1024) NM_XR(8);
+    else if (vec && v4 <= 16 * 1024) NM_XR(16);
+    else
+        hipLaunchKernelGGL((xent_kernel<1024>), dim3((unsigned)rows), dim3(1024), 0, st, logits, (long)ldx, (int)V,
+                           targets, weights, loss_rows, grad_scale, write_grad, label_smoothing);
+#undef NM_XR
     NM_LAUNCH_CHECK("nm_xent");
 }
 

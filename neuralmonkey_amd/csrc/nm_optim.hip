@@ -30,17 +30,32 @@ __global__ __launch_bounds__(256) void opt_reg_sumsq_kernel(OptChunks t, const f
     const int flags = t.seg_flags[t.chunk_seg[c]];
     const bool reg = flags & 1;
     float gs = 0.0f, a1 = 0.0f, a2 = 0.0f;
-    for (int i = threadIdx.x; i < len; i += 256) {
-        const float th = theta[base + i];
-        float g = grad[base + i];
+    auto one = [&](float th, float g) -> float {
         if (reg) {
             a1 += fabsf(th);
             a2 += th * th;
             const float sg = (th > 0.0f) ? 1.0f : ((th < 0.0f) ? -1.0f : 0.0f);
             g += l1w * sg + 2.0f * l2w * th;
-            grad[base + i] = g;
         }
         gs += g * g;
+        return g;
+    };
+    int done = 0;
+    if ((base & 3) == 0) {                 // 16-byte rows: the pass is a pure stream over theta and grad
+        const int len4 = len >> 2;
+        const float4* th4 = reinterpret_cast<const float4*>(theta + base);
+        float4* g4 = reinterpret_cast<float4*>(grad + base);
+        for (int i = threadIdx.x; i < len4; i += 256) {
+            const float4 th = th4[i];
+            float4 g = g4[i];
+            g.x = one(th.x, g.x); g.y = one(th.y, g.y); g.z = one(th.z, g.z); g.w = one(th.w, g.w);
+            if (reg) g4[i] = g;
+        }
+        done = len4 << 2;
+    }
+    for (int i = done + threadIdx.x; i < len; i += 256) {
+        const float g = one(theta[base + i], grad[base + i]);
+        if (reg) grad[base + i] = g;
     }
     gs = nm_wave_sum(gs); a1 = nm_wave_sum(a1); a2 = nm_wave_sum(a2);
     const int w = threadIdx.x >> 6;
