@@ -38,6 +38,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=128, help="sentences per GPU (weak scaling)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --batch sentences per GPU (default, what the driver runs); strong: --batch "
+                         "sentences per optimizer step in total, sharded over the GPUs (BASELINE.json's "
+                         "'shards minibatches': 16 per GPU at N=8)")
     ap.add_argument("--len", type=int, default=50, dest="length")
     ap.add_argument("--hidden", type=int, default=512)
     ap.add_argument("--vocab", type=int, default=32000)
@@ -94,6 +98,10 @@ def main():
     torch.cuda.set_device(local)
     dev = "cuda:{}".format(local)
     lib = _lib.load()
+    if args.scaling == "strong":
+        if args.batch % world:
+            raise SystemExit("--scaling strong: --batch {} is not divisible by {} GPUs".format(args.batch, world))
+        args.batch //= world                  # from here on: sentences per GPU
 
     h = args.hidden
     model = synthetic.build_translation_model(vocab_src=args.vocab, vocab_tgt=args.vocab, emb=h, rnn=h,
@@ -207,7 +215,7 @@ def main():
             "metric": "target tokens/sec/node (train), 512-hid GRU+attn",
             "value": tokens_global * args.steps / elapsed, "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "translation.ini-shape: biGRU-{h} enc + Bahdanau attn + GRU-{h} dec, "
                                    "B={b}/GPU, src_len=tgt_len={l}, V={v}, CrossEntropyTrainer(l2=1e-8, "

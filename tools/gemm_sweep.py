@@ -5,7 +5,10 @@ import os
 import subprocess
 import sys
 
-SHAPES = [("logits fwd NN", 6400, 32000, 512, False, False),
+SHAPES = [("beam logits NN", 640, 32000, 512, False, False),
+          ("greedy logit NN", 128, 32000, 512, False, False),
+          ("beam outproj NN", 640, 512, 2048, False, False),
+          ("logits fwd NN", 6400, 32000, 512, False, False),
           ("dlogits.WT NT", 6400, 512, 32000, False, True),
           ("OT.dlogits TN", 512, 32000, 6400, True, False),
           ("keys NN", 6400, 1024, 1024, False, False),
