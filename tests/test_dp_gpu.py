@@ -1,0 +1,99 @@
+"""Data-parallel trainer on the device, two ranks on ONE GPU over gloo (NM_DIST_BACKEND=gloo; the
+driver runs the real RCCL job on 8 GPUs): every rank runs the HIP training path on its shard of the
+batch -- global token-count normalisation, early all-reduce of the vocabulary-projection and
+decoder-embedding gradient slices from inside the backward pass, bucketed reduction of the rest,
+clip + Adam on identical data -- and must end up where one process training on the whole batch
+ends up (sum_r d/dtheta[sum_local_r(xent) / sum_global(mask)] == full-batch gradient)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+VOCAB, DIM, BATCH, LEN = 120, 16, 8, 9
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _model():
+    from neuralmonkey_amd import synthetic
+    return synthetic.build_translation_model(vocab_src=VOCAB, vocab_tgt=VOCAB, emb=DIM, rnn=DIM, max_len=LEN,
+                                             beam_size=0, l2_weight=1e-4, clip_norm=1.0, device="cuda:0", seed=21)
+
+
+def _batch():
+    from neuralmonkey_amd import synthetic
+    return synthetic.synthetic_dataset(seed=5, batch=BATCH, src_len=LEN, tgt_len=LEN - 1, vocab=VOCAB, ragged=True)
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", NM_DIST_BACKEND="gloo")
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from neuralmonkey_amd import distributed
+    torch.cuda.set_device(0)
+    dp = distributed.init_from_env()
+    assert dp is not None and dp.world_size == world and dp.overlap
+    model = _model()
+    store = model.tf_manager.sessions[0].store
+    if rank == 1:
+        store.theta.add_(0.5)                       # replicas start from rank 0's variables
+    dp.broadcast_parameters(store)
+    shard = dp.shard(_batch())
+    assert len(shard) == BATCH // world
+    seen_early = []
+    real_early = dp.all_reduce_early
+
+    def spy(st, names):
+        seen_early.append(list(names))
+        return real_early(st, names)
+    dp.all_reduce_early = spy
+    losses, grad1 = [], None
+    for step in range(3):
+        res = model.tf_manager.execute(shard, model.trainer.feedables, [model.trainer], train=True)[0]
+        losses.append(res.losses["decoder - cost"])
+        if step == 0:
+            grad1 = store.ensure_grad().cpu().numpy().copy()      # summed over ranks + L2 term, before clipping
+    torch.cuda.synchronize()
+    assert len(seen_early) == 6 and "decoder/state_to_word_W" in seen_early[0]      # two early spans per step
+    np.savez(os.path.join(out_dir, "rank{}.npz".format(rank)), theta=store.theta.cpu().numpy(),
+             losses=np.asarray(losses), grad1=grad1)
+    distributed.shutdown()
+
+
+def test_two_ranks_equal_one_process_on_the_full_batch(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert np.array_equal(r0["theta"], r1["theta"]), "replicas diverged"
+    # the reference point: one process, whole batch, same seed
+    model = _model()
+    store = model.tf_manager.sessions[0].store
+    start = store.theta.cpu().numpy().copy()
+    full = _batch()
+    model.tf_manager.execute(full, model.trainer.feedables, [model.trainer], train=True)
+    want_g = store.ensure_grad().cpu().numpy().copy()
+    scale = np.abs(want_g).max()
+    assert scale > 0
+    err = np.abs(r0["grad1"] - want_g).max()
+    assert err <= 2e-4 * scale, (err, scale)          # fp32 re-association between shard sums and the full batch
+    for _ in range(2):
+        model.tf_manager.execute(full, model.trainer.feedables, [model.trainer], train=True)
+    want = store.theta.cpu().numpy()
+    # Adam normalises every element's step to ~lr, so elements whose gradient is rounding noise may step the
+    # other way: the variables agree to within a few steps' worth, the gradients above are the sharp check
+    assert np.abs(want - start).max() > 1e-4
+    assert np.abs(r0["theta"] - want).max() <= 6.5e-4
+    assert np.median(np.abs(r0["theta"] - want)) <= 1e-6
+    assert r0["losses"].shape == (3,) and np.all(np.isfinite(r0["losses"])) and r0["losses"][2] < r0["losses"][0]
