@@ -7,8 +7,11 @@ handle; ``Session.run(fetches, feed_dict)`` evaluates the handles eagerly,
 memoised per run, launching libnmhip kernels on the device.  The call shape
 (fetch dictionaries in, numpy structures out) is unchanged.
 """
+import atexit
+import gc
 import os
 import threading
+import weakref
 from contextlib import contextmanager
 from typing import Any, Dict, List, Optional
 
@@ -162,6 +165,45 @@ def _to_host(val):
     return val
 
 
+_LIVE_SESSIONS: "weakref.WeakSet" = weakref.WeakSet()
+
+
+@contextmanager
+def _capture(graph):
+    """Stream capture with Python's cyclic garbage collector held off.  A collection that happens to run
+    inside a capture may finalise objects of models built earlier -- captured graphs with their private
+    memory pools, events -- and releasing those calls hipFree / hipGraphExecDestroy, which is illegal on a
+    capturing thread and aborts the process from inside a destructor (seen once in ~10 runs of the test
+    suite, always under "Garbage-collecting").  Reference-counted frees of tensors are fine: the caching
+    allocator defers them."""
+    was_enabled = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, capture_error_mode=CAPTURE_MODE):
+            yield
+    finally:
+        if was_enabled:
+            gc.enable()
+
+
+def _release_device_objects() -> None:
+    """Interpreter exit: drain the device and drop captured graphs / streams / events while the HIP
+    runtime is still up, in a fixed order (module teardown order is arbitrary otherwise)."""
+    try:
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            torch.cuda.synchronize()
+    except Exception:        # pylint: disable=broad-except
+        return
+    for sess in list(_LIVE_SESSIONS):
+        sess.__dict__.get("_step_graphs", {}).clear()
+        sess._graphs.clear()                      # pylint: disable=protected-access
+        sess._h2d.clear()                         # pylint: disable=protected-access
+
+
+atexit.register(_release_device_objects)
+
+
 class Session:
     """One set of variables on one device (stands for a tf.Session)."""
 
@@ -169,6 +211,7 @@ class Session:
         from .variables import VariableStore
         self.device = torch.device(device)
         self.store = VariableStore(self.device, seed)
+        _LIVE_SESSIONS.add(self)
         self._buffers: Dict[Any, torch.Tensor] = {}
         self._h2d: Dict[Any, Any] = {}
         self._graphs: Dict[Any, Any] = {}
@@ -299,7 +342,7 @@ class Session:
             self._graphs[key] = 1
         elif state == 1:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, capture_error_mode=CAPTURE_MODE):
+            with _capture(graph):
                 fn()
             self._graphs[key] = graph
             graph.replay()
@@ -322,7 +365,7 @@ class Session:
             state = (1, None, result)
         elif state[0] == 1:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, capture_error_mode=CAPTURE_MODE):
+            with _capture(graph):
                 result = fn()
             graph.replay()
             state = (2, graph, result)
@@ -330,6 +373,7 @@ class Session:
             state[1].replay()
         store[key] = state               # re-inserted last = most recently used
         while len(store) > self.MAX_STEP_GRAPHS:
+            torch.cuda.synchronize(self.device)       # never destroy a graph that may still be executing
             store.pop(next(iter(store)))
         return state[2]
 
