@@ -292,6 +292,103 @@ __global__ __launch_bounds__(256) void attn_partial_fast(AttnArgs p) {
         *reinterpret_cast<float4*>(p.pctx + ((long)b * p.nchunk + chunk) * p.C + col) = acc;
 }
 
+// ---------------------------------------------------------------------------
+// The same idea for a handful of queries per key batch (beam search: the k hypotheses of a
+// sentence share its keys): every HBM load of the block is in flight before the first tanh, the
+// query slices live in registers, the NQ x ROWS chunk-local softmax is evaluated by NQ threads and
+// handed to the context phase through LDS.  Queries beyond nq are clamped duplicates whose results
+// are not stored (nq = 3 runs the NQ = 4 instance).
+// ---------------------------------------------------------------------------
+template <int ROWS, int NQ>
+__global__ __launch_bounds__(256) void attn_partial_fastq(AttnArgs p) {
+    __shared__ float pe[4][NQ][ATT_MAX_SCH];
+    __shared__ float wq[NQ][ATT_MAX_SCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = blockIdx.x, b = blockIdx.y;
+    const int s0 = chunk * p.sch;
+    const int ns = min(p.sch, p.S - s0);
+    const int col = wave * 256 + lane * 4;
+    const bool a_ok = col < p.A, c_ok = col < p.C;
+    const float* hbase = p.hf + ((long)b * p.S + s0) * p.A + (a_ok ? col : 0);
+    const float* sbase = p.states + ((long)b * p.S + s0) * p.C + (c_ok ? col : 0);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    float4 hfr[ROWS], str[ROWS], y4[NQ];
+#pragma unroll
+    for (int s = 0; s < ROWS; ++s)
+        hfr[s] = *reinterpret_cast<const float4*>(hbase + (long)min(s, ns - 1) * p.A);
+#pragma unroll
+    for (int s = 0; s < ROWS; ++s)
+        str[s] = *reinterpret_cast<const float4*>(sbase + (long)min(s, ns - 1) * p.C);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+        y4[q] = *reinterpret_cast<const float4*>(p.y + attn_qrow(p, b, q) * p.A + (a_ok ? col : 0));
+    float4 v4 = *reinterpret_cast<const float4*>(p.v + (a_ok ? col : 0));
+    if (!a_ok) v4 = zero4;
+    const float bias = p.bias ? p.bias[0] : 0.0f;
+
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+        for (int s = 0; s < ROWS; ++s) {
+            float part = v4.x * nm_tanh(hfr[s].x + y4[q].x) + v4.y * nm_tanh(hfr[s].y + y4[q].y) +
+                         v4.z * nm_tanh(hfr[s].z + y4[q].z) + v4.w * nm_tanh(hfr[s].w + y4[q].w);
+            part = nm_wave_sum(part);
+            if (lane == 0) pe[wave][q][s] = part;
+        }
+    }
+    __syncthreads();
+    if (tid < NQ) {                                   // chunk-local softmax statistics of query tid
+        const int q = tid;
+        const bool live = q < p.nq;
+        const long qr = attn_qrow(p, b, q);
+        float e[ROWS];
+        float m = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < ROWS; ++s) {
+            e[s] = ((pe[0][q][s] + pe[1][q][s]) + (pe[2][q][s] + pe[3][q][s])) + bias;
+            if (s < ns) {
+                m = fmaxf(m, e[s]);
+                if (live) p.energies[qr * p.S + s0 + s] = e[s];
+            }
+        }
+        float la = 0.0f, lm = 0.0f;
+#pragma unroll
+        for (int s = 0; s < ROWS; ++s) {
+            const bool ok = s < ns;
+            const float ex = ok ? __expf(e[s] - m) : 0.0f;
+            const float mk = (ok && p.mask) ? p.mask[(long)b * p.S + s0 + s] : 1.0f;
+            const float em = ex * mk;
+            la += ex;
+            lm += em;
+            wq[q][s] = em;
+        }
+        if (live) {
+            float* st = p.pstat + (qr * p.nchunk + chunk) * 4;
+            st[0] = m; st[1] = la; st[2] = lm; st[3] = 0.0f;
+        }
+    }
+    __syncthreads();
+    float4 acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = zero4;
+#pragma unroll
+    for (int s = 0; s < ROWS; ++s) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const float w = wq[q][s];                  // zero beyond ns
+            acc[q].x += w * str[s].x; acc[q].y += w * str[s].y;
+            acc[q].z += w * str[s].z; acc[q].w += w * str[s].w;
+        }
+    }
+    if (c_ok) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            if (q < p.nq)
+                *reinterpret_cast<float4*>(p.pctx + (attn_qrow(p, b, q) * p.nchunk + chunk) * p.C + col) = acc[q];
+    }
+}
+
 __global__ __launch_bounds__(256) void attn_combine(const float* __restrict__ pctx,
                                                     const float* __restrict__ pstat,
                                                     const float* __restrict__ energies,
@@ -485,6 +582,18 @@ extern "C" int nm_attn_fwd_multi(void* stream, const float* y, const float* hf, 
         if (sch <= 8) hipLaunchKernelGGL(attn_partial_fast<8>, grid, block, 0, st, p);
         else if (sch <= 10) hipLaunchKernelGGL(attn_partial_fast<10>, grid, block, 0, st, p);
         else hipLaunchKernelGGL(attn_partial_fast<12>, grid, block, 0, st, p);
+    } else if (nq <= 8 && groups == 1 && A <= 1024 && C <= 1024 && sch <= ATT_FAST_ROWS && !no_fast) {
+        // a few queries per key batch (beam search): all loads in flight first, queries in registers
+#define NM_AQ(R_)                                                                                  \
+        do {                                                                                       \
+            if (nq <= 2) hipLaunchKernelGGL((attn_partial_fastq<R_, 2>), grid, block, 0, st, p);      \
+            else if (nq <= 4) hipLaunchKernelGGL((attn_partial_fastq<R_, 4>), grid, block, 0, st, p); \
+            else if (nq == 5) hipLaunchKernelGGL((attn_partial_fastq<R_, 5>), grid, block, 0, st, p); \
+            else hipLaunchKernelGGL((attn_partial_fastq<R_, 8>), grid, block, 0, st, p);              \
+        } while (0)
+        if (sch <= 10) NM_AQ(10);
+        else NM_AQ(12);
+#undef NM_AQ
     } else
     switch (qpk) {
         case 1: NM_AT(1); break;

@@ -199,6 +199,11 @@ def test_gru_bidirectional_encoder(dev):
     (5, 1, 64, 128, 2048, False),        # captioning shape: S=64, C=2048, state_size 128
     (2, 8, 13, 512, 1024, True),
     (2, 2, 100, 256, 512, True),
+    (2, 3, 50, 256, 256, True),          # beam widths that run a wider register instance (3 -> 4, 6 / 7 -> 8)
+    (3, 4, 24, 512, 256, True),
+    (2, 6, 30, 128, 512, False),
+    (2, 7, 50, 1024, 1024, True),
+    (2, 8, 50, 640, 1024, True),
     (3, 2, 9, 10, 14, True),             # tests/small.ini-like: C = 2*7, no dim a multiple of 4
     (2, 1, 300, 6, 7, True),             # any-shape kernel, long S
 ])
