@@ -131,6 +131,42 @@ def from_dataset(datasets, series_ids: List[str], max_size: int, save_to_file: s
     return vocab
 
 
+def from_t2t_vocabulary(path: str, encoding: str = "utf-8") -> Vocabulary:
+    """vocabulary.py:102-134: a tensor2tensor subword vocabulary, one (optionally quoted) token per
+    line; its own ``<pad>`` / ``<EOS>`` entries are dropped (ours come first anyway)."""
+    words: List[str] = []
+    with open(path, encoding=encoding) as handle:
+        for raw in handle:
+            token = raw.strip()
+            if len(token) >= 2 and token[0] == token[-1] and token[0] in "'\"":
+                token = token[1:-1]
+            if token not in ("<pad>", "<EOS>"):
+                words.append(token)
+    return Vocabulary(words)
+
+
+def from_nematus_json(path: str, max_size: int = None, pad_to_max_size: bool = False) -> Vocabulary:
+    """vocabulary.py:137-173: a Nematus word -> index dictionary.  Words come in index order, the two
+    lowest indices (Nematus' own <eos> / unk slots) are skipped, ``max_size`` counts real words, and
+    ``pad_to_max_size`` fills up with ``<pad_i>`` dummies so that an imported embedding matrix keeps
+    its row count (the import path of ``scripts/import_nematus.py``)."""
+    import json
+    with open(path, "r", encoding="utf-8") as handle:
+        index_of = json.load(handle)
+    words: List[str] = []
+    for word in sorted(index_of, key=lambda w: index_of[w]):
+        if index_of[word] < 2:
+            continue
+        words.append(word)
+        if max_size is not None and len(words) == max_size:
+            break
+    if max_size is None:
+        max_size = len(words) - 2          # the reference's own off-by-two, kept: no padding is added below
+    if pad_to_max_size:
+        words.extend("<pad_{}>".format(i) for i in range(max_size - len(words) + 2))
+    return Vocabulary(words)
+
+
 def pad_batch(sentences: List[List[str]], max_length: int = None, add_start_symbol: bool = False,
               add_end_symbol: bool = False) -> List[List[str]]:
     """vocabulary.py:331-354 (</s> may be truncated away by max_length)."""
