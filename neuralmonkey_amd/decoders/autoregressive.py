@@ -222,7 +222,7 @@ class AutoregressiveDecoder(ModelPart):
         res = self.train_loop_result(ctx)
         rows, steps, bsz = res.saved["loss_rows"], res.saved["steps"], res.saved["bsz"]
         xents = rows.view(steps, bsz).t() if res.saved["loss_layout"] == "tb" else rows.view(bsz, steps)
-        if self.label_smoothing:         # one scalar, the mean over all positions, broadcast against the mask (:292-310)
+        if self.label_smoothing:         # one scalar (mean over all positions) against the mask (:292-310)
             xents = (rows.sum() / rows.numel()) * self.train_mask(ctx).t()
         return xents
 

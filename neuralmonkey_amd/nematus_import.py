@@ -66,8 +66,8 @@ def variable_map(encoder: str = "encoder", decoder: str = "decoder", attention: 
             "candidate/input_proj/bias": "bx"}
     for direction, prefix in (("fw", "encoder_"), ("bw", "encoder_r_")):
         for local, suffix in cell.items():
-            table["{}/rnn_0_bidirectional/bidirectional_rnn/{}/nematus_gru_cell/{}".format(encoder, direction, local)] = \
-                (prefix + suffix, None)
+            scope = "{}/rnn_0_bidirectional/bidirectional_rnn/{}/nematus_gru_cell".format(encoder, direction)
+            table["{}/{}".format(scope, local)] = (prefix + suffix, None)
     for local, suffix in cell.items():
         table["{}/attention_decoder/nematus_gru_cell/{}".format(decoder, local)] = ("decoder_" + suffix, None)
     cond = {"gates/state_proj/kernel": "decoder_U_nl", "gates/input_proj/kernel": "decoder_Wc",
