@@ -24,9 +24,12 @@ class AdamOptimizer(Optimizer):
         global step before the update, as the TF graph does (functions.py)."""
         return float(self._lr(step - 1)) if callable(self._lr) else float(self._lr)
 
-    def lr_t(self, step: int) -> float:
-        """``step`` counts from 1 (the value of global_step after this update)."""
-        return self.learning_rate(step) * math.sqrt(1.0 - self.beta2 ** step) / (1.0 - self.beta1 ** step)
+    def lr_t(self, step: int, applied: int = None) -> float:
+        """``step`` counts from 1 (the value of global_step after this update) and drives the learning
+        rate schedule; ``applied`` is the number of updates this optimizer has applied including this
+        one (TF keeps beta1_power / beta2_power per optimizer) -- equal to ``step`` with one trainer."""
+        t = step if applied is None else applied
+        return self.learning_rate(step) * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
 
 
 class LazyAdamOptimizer(AdamOptimizer):

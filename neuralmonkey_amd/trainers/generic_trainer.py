@@ -10,6 +10,7 @@ import re
 from typing import Any, Dict, List, Sequence
 
 import numpy as np
+import torch
 
 from .. import ops
 from ..model.model_part import Feedable
@@ -88,9 +89,17 @@ class GenericTrainer(GraphExecutor, Feedable):
         return self._tables[key]
 
     # -- the training step --------------------------------------------------------------------
-    def _objective_gradients(self, ctx) -> None:
-        """Forward + backward of every objective into the (zeroed) flat gradient buffer."""
+    def _objective_gradients(self, outer) -> None:
+        """Forward + backward of every objective into the (zeroed) flat gradient buffer.
+
+        The pass runs in a run context of its own: an experiment may list several trainers that update
+        on the same batch (tests/bahdanau.ini), and each must see activations computed from the CURRENT
+        variables and own the backward tapes of the encoders it reads -- TensorFlow gives every trainer
+        its own gradient subgraph.  The decoders' train results are handed back to the caller's context."""
         from .. import distributed as dist
+        from ..runtime import RunContext
+        ctx = RunContext(outer.session, outer.feed)
+        ctx.memo["dp_overlap"] = bool(outer.memo.get("dp_overlap", False))
         sess, store = ctx.session, ctx.store
         grad = store.ensure_grad()
         grad.zero_()
@@ -139,7 +148,7 @@ class GenericTrainer(GraphExecutor, Feedable):
         else:
             results = forward_backward()
         for dec, res in zip(decoders, results):
-            ctx.memo[dec.train_loop_result.key] = res
+            outer.memo[dec.train_loop_result.key] = res
         sess.join_side()
 
     def _apply_gradients(self, ctx) -> int:
@@ -153,12 +162,33 @@ class GenericTrainer(GraphExecutor, Feedable):
         tables = self._optim_tables(store)
         l1l2 = tables.regularize_and_norms(store.theta, grad, self.l1_weight, self.l2_weight)
         ctx.memo[(id(self), "l1l2")] = l1l2.clone()
+        state = self._adam_state(sess, store)
         sess.global_step += 1
-        m, v = store.ensure_adam()
+        state["applied"] += 1
         opt = self.optimizer
-        tables.clip_adam(store.theta, grad, m, v, self.clip_norm, opt.lr_t(sess.global_step), opt.beta1,
-                         opt.beta2, opt.epsilon)
+        tables.clip_adam(store.theta, grad, state["m"], state["v"], self.clip_norm,
+                         opt.lr_t(sess.global_step, state["applied"]), opt.beta1, opt.beta2, opt.epsilon)
         return sess.global_step
+
+    def _adam_state(self, sess, store):
+        """Adam slots and the number of updates THIS optimizer has applied.  TensorFlow keeps one set of
+        slots and one pair of beta powers per optimizer, while ``global_step`` is shared: an experiment
+        with two trainers (tests/bahdanau.ini: ``trainer=[<mt_trainer>, <greedy_trainer>]``) advances the
+        global step twice per batch but each optimizer's bias correction once.  The first trainer to
+        update a store uses the store's own slots (the ones checkpoints carry) and continues from its
+        global step; any further trainer gets private slots starting at zero."""
+        key = id(store)
+        state = self.__dict__.setdefault("_adam", {}).get(key)
+        if state is None:
+            owners = sess.__dict__.setdefault("_adam_owner", {})
+            if owners.setdefault(key, self) is self:
+                m, v = store.ensure_adam()
+                applied = sess.global_step
+            else:
+                m, v = torch.zeros_like(store.theta), torch.zeros_like(store.theta)
+                applied = 0
+            state = self._adam[key] = {"m": m, "v": v, "applied": applied}
+        return state
 
     @tensor
     def train_op(self, ctx) -> int:
