@@ -255,6 +255,7 @@ class BeamSearchDecoder(ModelPart):
         go.fill_(START_TOKEN_INDEX)
         dec.embed_input_symbols(ctx, go, out=emb)
         fast = getattr(stepper, "graph_safe", False)      # steps keep no Python-side state: HIP-graph capturable
+        indexed = getattr(stepper, "indexed", False)      # steps are a function of an explicit position: also capturable
         att0 = att_states
         from ..attention.base_attention import AttentionLoopState
         att_at = lambda i: [AttentionLoopState(a.contexts, a.weights, i) for a in att0]
@@ -279,6 +280,8 @@ class BeamSearchDecoder(ModelPart):
             if fast:
                 ops.gather_rows(stepper.hbuf[cur], srcf, stepper.sel)            # :503-532
             else:
+                if indexed:                      # s bodies and the initial step so far: position s + 1, cache copy s & 1
+                    stepper.set_position(s + 1, cur)
                 stepper.reorder(srcf)
             ops.beam_reorder_tokens(tok[cur], srcf, wordf, tok[nxt], s + 1, rows)    # :546-551
             dec.embed_input_symbols(ctx, wordf, out=emb)                         # :507-510
@@ -297,8 +300,8 @@ class BeamSearchDecoder(ModelPart):
             def chunk(s0=s0, n=n):
                 for s in range(s0, s0 + n):
                     body(s)
-            if fast:
-                ctx.session.graphed(key + ("chunk", s0, n, k, v, shape_key), chunk)
+            if fast or indexed:
+                ctx.session.graphed(key + ("chunk", s0, n, k, v, shape_key, getattr(stepper, "shape_key", ())), chunk)
             else:
                 chunk()
             steps += n

@@ -278,22 +278,34 @@ class TransformerDecoder(AutoregressiveDecoder):
         go = ctx.buffer(key + ("go",), (bsz,), torch.int32)
         go.fill_(START_TOKEN_INDEX)
         self.embed_input_symbols(ctx, go, out=emb[0])
-        steps = 0
-        while steps < tmax:
-            t = steps
+        self.decoding_bias(ctx)              # lazily built tensors: outside the captured chunks
+        t_xent = min(t_target, tmax) if has_tgt else 0
+
+        def body(t):
+            """Step t touches persistent buffers only and depends on nothing but t (graph capturable)."""
             logits = logits_all[t] if keep_logits else logits_one
+            stepper.set_position(t, 0)
             stepper.step(emb[t & 1], [], out_all[t], logits, finished=finished)
             ops.row_stats(logits, None, None, argmax)
-            if has_tgt and t < t_target:
+            if t < t_xent:
                 ops.xent(logits, tgt[t], tmask[t], xent_rows[t])
             ops.greedy_update(argmax, finished, symbols[t], omask[t], END_TOKEN_INDEX, allfin[t:t + 1])
             self.embed_input_symbols(ctx, symbols[t], out=emb[(t + 1) & 1])
-            steps += 1
-            if steps % CHECK_EVERY == 0 or steps == tmax:
-                done = np.nonzero(allfin[:steps].cpu().numpy())[0]
-                if done.size:
-                    steps = int(done[0]) + 1
-                    break
+
+        steps = 0
+        while steps < tmax:
+            t0, n = steps, min(CHECK_EVERY, tmax - steps)
+
+            def chunk(t0=t0, n=n):
+                for t in range(t0, t0 + n):
+                    body(t)
+            # the host only looks at the finished flags between chunks of steps (one HIP graph per chunk)
+            ctx.session.graphed(key + ("chunk", t0, n, bsz, t_xent, stepper.shape_key), chunk)
+            steps += n
+            done = np.nonzero(allfin[:steps].cpu().numpy())[0]
+            if done.size:                          # loop ends after the first all-finished step
+                steps = int(done[0]) + 1
+                break
         xent_sum = None
         if has_tgt:
             xent_sum = ctx.buffer(key + ("xent_sum",), (1,))
@@ -376,6 +388,18 @@ class TransformerStepper:
             self.enc_kv.append((per_layer, get_attention_mask(e, self.ctx), bk, slen))
         self.base = tape._n                       # pylint: disable=protected-access
         self.cur, self.t = 0, 0
+
+    indexed = True       # set_position(t, cur) makes a step a function of its index: HIP-graph capturable
+
+    @property
+    def shape_key(self):
+        """What a captured step depends on besides its index: the encoder batches it attends to."""
+        return tuple((bk, slen) for _, _, bk, slen in self.enc_kv)
+
+    def set_position(self, t: int, cur: int) -> None:
+        """Decode position ``t`` next, reading cache copy ``cur`` (graph replays skip the Python-side
+        bookkeeping of ``step`` / ``reorder``, so captured callers state the position explicitly)."""
+        self.t, self.cur = t, cur
 
     def step(self, emb, att_states, out_state, logits, h_out=None, finished=None):
         dec, tape, rows, t = self.dec, self.tape, self.rows, self.t
