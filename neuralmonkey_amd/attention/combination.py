@@ -265,6 +265,10 @@ class FlatSession(_MultiSession):
         self.pos_bias = F.linear(tape, biases, tape.leaf(seg))
         self._ones = {}
 
+    @property
+    def shape_key(self):
+        return (self.bsz, tuple(self.lens), self.width)
+
     def encoder_grads(self):
         out = []
         for enc, st, slen in zip(self.encoders, self.states_in, self.lens):
@@ -364,6 +368,10 @@ class HierarchicalSession(_MultiSession):
         _MultiSession.__init__(self, att, tape)
         self.children = [c.tape_session(tape, train_mode) for c in att.attentions]
         self.t = 0
+
+    @property
+    def shape_key(self):
+        return tuple(child.shape_key for child in self.children)
 
     def encoder_grads(self):
         out = []

@@ -213,6 +213,10 @@ class AttentionTapeSession:
         g = self.states_in.grad
         return None if g is None else g.view(self.bsz, self.slen, self.csz)
 
+    @property
+    def shape_key(self):
+        return (self.bsz, self.slen, self.csz, self.asz)
+
     def encoder_grads(self):
         """[(encoder, dL/d states [B,S,C])] after ``Tape.backward``."""
         g = self.d_states

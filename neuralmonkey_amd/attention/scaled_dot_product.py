@@ -161,6 +161,10 @@ class DotProductSession:
     def _w(self, proj: str) -> F.Var:
         return self.tape.param(self.dec, "attention_decoder/{}/kernel".format(proj))
 
+    @property
+    def shape_key(self):
+        return (self.bsz, self.slen, self.att.n_heads)
+
     def encoder_grads(self):
         att, out = self.att, []
         if self.keys_in.grad is not None:

@@ -288,6 +288,8 @@ class BeamSearchDecoder(ModelPart):
             if fast:
                 stepper.step(emb, att_at(s + 1), out_state, logits, h_prev=stepper.sel,
                              h_out=stepper.hbuf[nxt])                            # :534-535
+            elif indexed:
+                stepper.step(emb, att_at(s + 1), out_state, logits, finished=fin[nxt].view(rows))
             else:
                 loop["att"] = stepper.step(emb, loop["att"], out_state, logits, finished=fin[nxt].view(rows))
 

@@ -460,6 +460,7 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
         self.embed_input_symbols(ctx, go, out=emb)
         att0 = att_states
         graph_ok = getattr(stepper, "graph_safe", False)
+        indexed = getattr(stepper, "indexed", False)      # general path: steps addressed by their index
         for att in self.attentions if graph_ok else []:   # lazily built tensors (H2D copies): outside the capture
             att.hidden_features(ctx)
             att.attention_mask(ctx)
@@ -473,6 +474,8 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
             if graph_ok:
                 stepper.step(emb, st_t, out_all[t], logits, h_out=s_all[t], h_prev=s0 if t == 0 else s_all[t - 1])
             else:
+                if indexed:
+                    stepper.set_position(t, 0)
                 stepper.step(emb, st_t, out_all[t], logits, h_out=s_all[t])
             ops.row_stats(logits, None, None, argmax)
             if t < t_xent:
@@ -488,8 +491,9 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
             def chunk(t0=t0, n=n):
                 for t in range(t0, t0 + n):
                     body(t)
-            if graph_ok:      # the host only looks at the finished flags between chunks of steps
-                ctx.session.graphed(key + ("chunk", t0, n, bsz, t_xent, shape_key), chunk)
+            if graph_ok or indexed:      # the host only looks at the finished flags between chunks of steps
+                ctx.session.graphed(key + ("chunk", t0, n, bsz, t_xent, shape_key,
+                                           getattr(stepper, "shape_key", ())), chunk)
             else:
                 chunk()
             steps += n

@@ -278,7 +278,7 @@ class FastStepper:
 
 class GeneralStepper:
     """Inference steps of any other decoder configuration (non-recording tape)."""
-    graph_safe = False          # the carried state is a chain of Python-side Vars
+    graph_safe = False          # the carried state is a chain of Python-side Vars (see ``indexed`` below)
 
     def __init__(self, dec, ctx, rows: int, tag: str):
         self.dec, self.ctx, self.rows = dec, ctx, rows
@@ -292,10 +292,31 @@ class GeneralStepper:
         self.base = self.tape._n                          # pylint: disable=protected-access
         self.t = 0
         self.state = None
+        self._initial = None
+        # The state a step of parity p produces lives in the same persistent buffers on every batch: the
+        # handles are kept with the session so that a chunk of steps launched from Python can follow a chunk
+        # that was replayed from a captured graph (whose Python body did not run).
+        self._produced = ctx.session.__dict__.setdefault("_stepper_state", {}).setdefault(
+            (id(dec), tag, rows), {})
+
+    indexed = True       # set_position(t, cur) makes a step a function of its index: HIP-graph capturable
+
+    @property
+    def shape_key(self):
+        """What a captured step depends on besides its index: the shapes its attentions read."""
+        return tuple(getattr(s, "shape_key", ()) for s in self.sessions)
+
+    def set_position(self, t: int, cur: int = 0) -> None:
+        """Run step ``t`` next, from the state step ``t - 1`` left in its parity's buffers."""
+        self.t = t
+        for sess in self.sessions:
+            if hasattr(sess, "t"):
+                sess.t = t
+        self.state = self._initial if t == 0 else self._produced[(t - 1) & 1]
 
     def start(self, s0: torch.Tensor) -> None:
         tape = self.tape
-        self.state = [tape.leaf(s0), tape.leaf(s0)] + [tape.leaf(z) for z in self.zero_ctx]
+        self.state = self._initial = [tape.leaf(s0), tape.leaf(s0)] + [tape.leaf(z) for z in self.zero_ctx]
         self.t = 0
 
     def step(self, emb, att_states, out_state, logits, h_out: Optional[torch.Tensor] = None, finished=None,
@@ -306,6 +327,7 @@ class GeneralStepper:
         w_outs = [st.weights[st.step] for st in att_states]
         out, self.state = dec.general_step(tape, tape.leaf(emb), self.state, self.sessions, w_outs, False,
                                            self.t)
+        self._produced[self.t & 1] = self.state
         out_state.copy_(out.data)
         dec.state_to_logits(self.ctx, out_state, logits)
         if h_out is not None:
