@@ -47,6 +47,8 @@ class TransformerEncoder(ModelPart, TemporalStatefulWithOutput):
             raise ValueError("Depth must be a positive integer.")
         if self.ff_hidden_size <= 0:
             raise ValueError("Feed forward hidden size must be a positive integer.")
+        if self.n_heads <= 0:                              # the reference fails on this when it splits the heads
+            raise ValueError("Number of heads must be a positive integer.")
         if self.dropout_keep_prob <= 0.0 or self.dropout_keep_prob > 1.0:
             raise ValueError("Dropout keep prob must be inside (0,1].")
         if self.attention_dropout_keep_prob <= 0.0 or self.attention_dropout_keep_prob > 1.0:

@@ -3,6 +3,7 @@ feedable}.py): dependency collection by attribute name, per-part variable
 scopes, feed dictionaries with ``train_mode`` / ``batch_size``."""
 from typing import Any, Callable, Dict, Iterable, List, Optional, Set, Tuple
 
+from ..checking import check_constructor_chain
 from ..runtime import Placeholder, register_part
 from ..variables import Initializer, random_normal_initializer
 
@@ -50,6 +51,7 @@ class Parameterized:
 
     def __init__(self, name: str, reuse: "Parameterized" = None, save_checkpoint: str = None,
                  load_checkpoint: str = None, initializers: InitializerSpecs = None) -> None:
+        check_constructor_chain(self)                       # the reference's check_argument_types() calls
         self._name = name
         self._save_checkpoint = save_checkpoint
         self._load_checkpoint = load_checkpoint

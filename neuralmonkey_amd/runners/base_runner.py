@@ -8,6 +8,7 @@ from typing import Any, Dict, Generic, List, NamedTuple, Optional, Set, Tuple, T
 
 import numpy as np
 
+from ..checking import check_constructor_chain
 from ..model.model_part import Feedable, GenericModelPart, Parameterized
 
 FeedDict = Dict[Any, Any]
@@ -53,6 +54,7 @@ class GraphExecutor(GenericModelPart):
             raise NotImplementedError
 
     def __init__(self, dependencies: Set[GenericModelPart]) -> None:
+        check_constructor_chain(self)                       # runners / trainers: check_argument_types()
         self._dependencies = dependencies
         self._feedables, self._parameterizeds = self.get_dependencies()
 

@@ -186,7 +186,9 @@ def test_dotprod_shape_checks():
     """The shape errors of attention() (scaled_dot_product.py:151-168) surface when the decoder binds."""
     from neuralmonkey_amd.attention.scaled_dot_product import MultiHeadAttention, ScaledDotProdAttention
 
-    class Enc:
+    from neuralmonkey_amd.model.stateful import TemporalStateful
+
+    class Enc(TemporalStateful):
         dimension = 8
     with pytest.raises(ValueError):
         MultiHeadAttention(name="a", n_heads=0, keys_encoder=Enc())
