@@ -124,22 +124,50 @@ def _expand(patterns: Union[str, List[str]]) -> List[str]:
 
 def load(name: str, series: List[str], data: List[Any], batching: BatchingScheme = None,
          outputs: List[Tuple] = None, buffer_size: int = None, shuffled: bool = False) -> Dataset:
-    """dataset.py:207-333 for source series given as files (optionally
-    ``(files, reader)`` tuples); preprocessor series are out of scope."""
+    """dataset.py:207-333.  A series is given by one of
+
+    * a path / glob / list of them, or ``(files, reader)`` -- read from files (whitespace tokens by default);
+    * ``(preprocessor, source_series)`` -- the preprocessor applied to every item of a series read from
+      files (series-level preprocessors do not stack, as in the reference);
+    * a callable -- a dataset-level preprocessor, called once with ``{series: () -> iterator}`` of all
+      the series above and returning the items of the new series.
+
+    The series are materialised here (``buffer_size`` is accepted and ignored: the lazy refill of the
+    reference bounds host memory, the batches are the same)."""
     if len(series) != len(data):
         raise ValueError("The 'series' and 'data' lists should have the same number of elements: "
                          "{} vs {}.".format(len(series), len(data)))
     if len(series) != len(set(series)):
         raise ValueError("There are duplicate series.")
+    if outputs is not None and len({spec[0] for spec in outputs}) != len(outputs):
+        raise ValueError("Multiple outputs for a single series")
     loaded: Dict[str, List[Any]] = {}
+    series_level: Dict[str, Tuple[Callable, str]] = {}
+    dataset_level: Dict[str, Callable] = {}
     for sid, spec in zip(series, data):
-        if isinstance(spec, tuple) and callable(spec[-1]) and not isinstance(spec[0], tuple):
-            files, reader = spec[0], spec[1]
-            loaded[sid] = list(reader(_expand(files)))
-        elif isinstance(spec, (str, list)):
+        if isinstance(spec, (str, list)):
             loaded[sid] = list(plain_text_reader(_expand(spec)))
+        elif isinstance(spec, tuple) and len(spec) == 2 and isinstance(spec[0], (str, list)) and callable(spec[1]):
+            loaded[sid] = list(spec[1](_expand(spec[0])))
+        elif isinstance(spec, tuple) and len(spec) == 2 and callable(spec[0]) and isinstance(spec[1], str):
+            series_level[sid] = spec
+        elif callable(spec):
+            dataset_level[sid] = spec
         else:
-            raise NotImplementedError("series '{}': preprocessor series are not supported".format(sid))
+            raise TypeError("series '{}': {!r} is neither files, (files, reader), (preprocessor, series) "
+                            "nor a dataset-level preprocessor".format(sid, spec))
+    from_files = set(loaded)
+    for sid, (preprocessor, source) in series_level.items():
+        if source not in from_files:
+            raise ValueError("Source series for series-level preprocessor nonexistent: Preprocessed series "
+                             "'{}', source series '{}'".format(sid, source))
+        loaded[sid] = [preprocessor(item) for item in loaded[source]]
+    if dataset_level:
+        def _factory(items):
+            return lambda: iter(items)
+        iterators = {sid: _factory(items) for sid, items in loaded.items()}
+        for sid, func in dataset_level.items():
+            loaded[sid] = list(func(iterators))
     out_specs = {}
     for spec in outputs or []:
         out_specs[spec[0]] = (spec[1], spec[2] if len(spec) > 2 else None)

@@ -109,22 +109,49 @@ class Parameterized:
 
     # -- per-part checkpoints (parameterized.py:101-125) -------------------------
     def save(self, session) -> None:
-        if self._save_checkpoint:
-            import numpy as np
-            vals = {n.replace("/", "|"): session.store[n].detach().cpu().numpy()
-                    for n in self.variable_names(session.store)}
-            np.savez(self._save_checkpoint, **vals)
+        """The variables of this part's scope as a TensorFlow tensor bundle (what the reference's
+        per-part ``tf.train.Saver(var_list=...)`` writes: ``<path>.index`` + ``<path>.data-00000-of-00001``),
+        or one .npz file when the path says so."""
+        if not self._save_checkpoint:
+            return
+        import numpy as np
+        vals = {n: session.store[n].detach().cpu().numpy() for n in self.variable_names(session.store)}
+        if self._save_checkpoint.endswith(".npz"):
+            np.savez(self._save_checkpoint, **{n.replace("/", "|"): v for n, v in vals.items()})
+            return
+        from .. import tf_bundle
+        tf_bundle.write_bundle(self._save_checkpoint, {
+            n: np.asarray(v, np.float32).reshape(tf_bundle.tf_shape(n, v.shape)) for n, v in vals.items()})
 
     def load(self, session) -> None:
-        if self._load_checkpoint:
-            import numpy as np
-            path = self._load_checkpoint
-            if not path.endswith(".npz"):
+        """Restore this part's variables from ``load_checkpoint`` -- a bundle the reference (or ``save``)
+        wrote, e.g. a pre-trained encoder; every variable of the scope must be there, as with
+        ``Saver.restore``."""
+        if not self._load_checkpoint:
+            return
+        import os
+        import numpy as np
+        path = self._load_checkpoint
+        mine = self.variable_names(session.store)
+        if os.path.exists(path + ".index"):
+            from .. import tf_bundle
+            bundle = tf_bundle.read_bundle(path)
+            vals = {}
+            for n in mine:
+                if n not in bundle:
+                    raise KeyError("checkpoint '{}' lacks variable '{}' of model part '{}'".format(path, n, self.name))
+                shape = session.store.specs[n].shape
+                if [d for d in bundle[n].shape if d != 1] != [d for d in shape if d != 1]:
+                    raise ValueError("shape of '{}' in checkpoint '{}' is {}, the model part declares {}"
+                                     .format(n, path, bundle[n].shape, shape))
+                vals[n] = np.asarray(bundle[n], np.float32).reshape(shape)
+        else:
+            if not path.endswith(".npz") and not os.path.exists(path):
                 path += ".npz"
             with np.load(path) as data:
                 vals = {k.replace("|", "/"): data[k] for k in data.files}
-            mine = set(self.variable_names(session.store))
-            session.store.load_state_dict({k: v for k, v in vals.items() if k in mine}, strict=False)
+            vals = {k: v for k, v in vals.items() if k in set(mine)}
+        session.store.load_state_dict(vals, strict=False)
 
 
 def _is_rng_init(init) -> bool:

@@ -1,6 +1,9 @@
 """Known answers taken from the reference's own unit tests (test data, not code): the INI value grammar
 (neuralmonkey/tests/test_config.py:8-43), piecewise_function (test_functions.py:12-22) and the vocabulary
-(test_vocabulary.py:14-66) -- the few numbers on this path that the reference itself pins."""
+(test_vocabulary.py:14-66), bucketed batching (test_dataset.py:169-258), the constructor tables
+(test_encoders_init.py, test_decoder.py), variable sharing and per-part checkpoints (test_model_part.py)
+-- the few answers on this path that the reference itself pins."""
+import numpy as np
 import pytest
 
 from neuralmonkey_amd.config import parsing
@@ -191,3 +194,187 @@ def test_argument_type_matching():
     for args in ((3.5,), (3, "a"), (3, None, "fast")):
         with pytest.raises(TypeError):
             build(*args)
+
+
+# ---- neuralmonkey/tests/test_model_part.py: variable sharing by ``reuse``, per-part checkpoints ---------
+class _HostSession:
+    """Parameterized.save / load only touch ``session.store``; a host-memory store has no kernels to run."""
+
+    def __init__(self, parts, seed):
+        from neuralmonkey_amd.variables import VariableStore
+        self.store = VariableStore("cpu", seed=seed)
+        for part in parts:
+            part.declare_variables(self.store)
+        self.store.finalize()
+
+
+def test_reuse_shares_the_embedding_matrix():
+    from neuralmonkey_amd.model.sequence import EmbeddedSequence
+    from neuralmonkey_amd.vocabulary import Vocabulary
+    vocabulary = Vocabulary(["a", "b"])
+    seq1 = EmbeddedSequence(name="seq1", vocabulary=vocabulary, data_id="id", embedding_size=10)
+    seq2 = EmbeddedSequence(name="seq2", vocabulary=vocabulary, embedding_size=10, data_id="id")
+    seq3 = EmbeddedSequence(name="seq3", vocabulary=vocabulary, data_id="id", embedding_size=10, reuse=seq1)
+    sess = _HostSession([seq1, seq2, seq3], seed=3)
+    mats = [part.var(sess, part.variable_names(sess.store)[0].split("/", 1)[1]) for part in (seq1, seq2, seq3)]
+    assert not np.array_equal(mats[0].numpy(), mats[1].numpy())
+    assert mats[0].data_ptr() == mats[2].data_ptr()                  # one variable, not two equal ones
+    assert seq3.variable_names(sess.store) == seq1.variable_names(sess.store)
+    with pytest.raises(ValueError):                                  # parameterized.py:48-52
+        EmbeddedSequence(name="seq4", vocabulary=vocabulary, data_id="id", embedding_size=10, reuse=seq1,
+                         initializers=[("word_embeddings", lambda shape: np.zeros(shape))])
+
+
+def test_part_checkpoint_save_and_load(tmp_path):
+    from neuralmonkey_amd import tf_bundle
+    from neuralmonkey_amd.encoders.recurrent import SentenceEncoder
+    from neuralmonkey_amd.vocabulary import Vocabulary
+    prefix = str(tmp_path / "enc.ckpt")
+    encoder = SentenceEncoder(name="enc", vocabulary=Vocabulary(["a", "b"]), data_id="data_id", embedding_size=10,
+                              rnn_size=20, max_input_len=30, save_checkpoint=prefix, load_checkpoint=prefix)
+    parts = [encoder.input_sequence, encoder]
+    sess_1, sess_2 = _HostSession(parts, seed=1), _HostSession(parts, seed=2)
+    names = encoder.variable_names(sess_1.store)
+    assert names and any(not np.array_equal(sess_1.store[n].numpy(), sess_2.store[n].numpy()) for n in names)
+    encoder.save(sess_1)
+    bundle = tf_bundle.read_bundle(prefix)                           # a TensorFlow tensor bundle of the scope "enc"
+    assert sorted(bundle) == sorted(names) and all(n.startswith("enc/") for n in names)
+    before = {n: sess_2.store[n].numpy().copy() for n in sess_2.store.names() if n not in names}
+    encoder.load(sess_2)
+    for n in names:
+        assert np.array_equal(sess_1.store[n].numpy(), sess_2.store[n].numpy()), n
+    for n, value in before.items():                                  # the embeddings live in their own scope
+        assert np.array_equal(value, sess_2.store[n].numpy()), n
+    # a checkpoint that lacks one of the scope's variables is refused, as Saver.restore refuses it
+    partial = dict(bundle)
+    partial.pop(names[0])
+    tf_bundle.write_bundle(prefix, partial)
+    with pytest.raises(KeyError):
+        encoder.load(sess_2)
+
+
+# ---- neuralmonkey/tests/test_readers.py: vectors as text, the T2T tokenizer -----------------------------
+INT_ROWS = "\n1   2 3\n4 5   6\n7 8 9 10\n\n"
+FLOAT_ROWS = "\n1 2       3.5\n      4 -5.0e10     6\n7 8 9.2e-12 10.1123213213214123141234123112312312\n"
+SQUARE_INT_ROWS = "\n1 2 3\n4 5 6\n7 8 9\n"
+
+
+def _rows(text, dtype):
+    return [np.array(row.split(), dtype=dtype) for row in text.strip().split("\n")]
+
+
+def _same(got, want):
+    return len(got) == len(want) and all(a.dtype == b.dtype and np.array_equal(a, b) for a, b in zip(got, want))
+
+
+def test_string_vector_reader_known_answers(tmp_path):
+    from neuralmonkey_amd.readers.string_vector_reader import get_string_vector_reader
+    paths = {}
+    for name, text in (("ints", INT_ROWS), ("floats", FLOAT_ROWS), ("square", SQUARE_INT_ROWS)):
+        paths[name] = str(tmp_path / name)
+        with open(paths[name], "w") as handle:
+            handle.write(text)
+    assert _same(list(get_string_vector_reader(np.float32)([paths["floats"]])), _rows(FLOAT_ROWS, np.float32))
+    assert _same(list(get_string_vector_reader(np.int32)([paths["ints"], paths["square"]])),
+                 _rows(INT_ROWS, np.int32) + _rows(SQUARE_INT_ROWS, np.int32))
+    for cols in (2, 3):
+        for name, dtype in (("ints", np.int32), ("floats", np.float32)):
+            with pytest.raises(ValueError, match="Wrong number of columns"):
+                list(get_string_vector_reader(dtype, columns=cols)([paths[name]]))
+    with pytest.raises(ValueError, match=r"Wrong number of columns \(4\) on line 4"):   # blank lines are counted
+        list(get_string_vector_reader(np.int32, columns=3)([paths["ints"]]))
+    with pytest.raises(ValueError, match="Wrong number of columns"):
+        list(get_string_vector_reader(np.int32, columns=2)([paths["square"]]))
+    assert _same(list(get_string_vector_reader(np.int32, columns=3)([paths["square"]])), _rows(SQUARE_INT_ROWS, np.int32))
+
+
+def test_text_readers_known_answers(tmp_path):
+    import gzip
+    from neuralmonkey_amd.readers.plain_text_reader import (T2TReader, UtfPlainTextReader, csv_reader, t2t_tokenize,
+                                                            tsv_reader)
+    path = str(tmp_path / "text")
+    with open(path, "w", encoding="utf-8") as handle:
+        handle.write("Ich bin  der čermák -=- - !!! alfonso ")
+    assert list(T2TReader([path])) == [["Ich", "bin", "  ", "der", "čermák", " -=- - !!! ", "alfonso"]]
+    assert list(UtfPlainTextReader([path])) == [["Ich", "bin", "der", "čermák", "-=-", "-", "!!!", "alfonso"]]
+    assert t2t_tokenize("") == [""] and t2t_tokenize("a b") == ["a", "b"] and t2t_tokenize(", a") == [", ", "a"]
+    zipped = str(tmp_path / "text.gz")
+    with gzip.open(zipped, "wt", encoding="utf-8") as handle:
+        handle.write("a b\n\nčermák\n")
+    assert list(UtfPlainTextReader([zipped, path]))[:3] == [["a", "b"], [], ["čermák"]]
+    table = str(tmp_path / "table")
+    with open(table, "w", encoding="utf-8") as handle:
+        handle.write('one two\t"x, y" z\nthree\n')
+    with pytest.warns(UserWarning, match="missing column number 2"):
+        assert list(tsv_reader(2)([table])) == [['"x,', 'y"', "z"], []]
+    assert list(tsv_reader(1)([table])) == [["one", "two"], ["three"]]
+    with open(table, "w", encoding="utf-8") as handle:
+        handle.write('one two, "x, y" z\n')
+    assert list(csv_reader(2)([table])) == [["x,", "y", "z"]]
+
+
+# ---- neuralmonkey/tests/test_wordpiece.py -----------------------------------------------------------------
+def _wordpiece_vocabulary():
+    from neuralmonkey_amd.vocabulary import Vocabulary
+    corpus = ["the colorless ideas slept furiously", "pooh slept all night", "working class hero is something to be",
+              "I am the working class walrus", "walrus for president"]
+    words = {word + "_" for sentence in corpus for word in sentence.split()}
+    chars = {piece for char in set("".join(corpus)) for piece in (char, char + "_")}
+    return Vocabulary(list(chars | set("\\_u0987654321;") | words) + ["\\269;", "225"])
+
+
+WORDPIECES = [
+    ("I am the walrus", "I_ am_ the_ walrus_"),
+    ("Ich bin der walrus", "I c h_ b i n_ d e r_ walrus_"),
+    ("Ich bin der čermák", "I c h_ b i n_ d e r_ \\269; e r m \\ 225 ; k_"),
+]
+
+
+@pytest.mark.parametrize("raw,pieces", WORDPIECES)
+def test_wordpiece_known_answers(raw, pieces):
+    from neuralmonkey_amd.processors.wordpiece import WordpiecePostprocessor, WordpiecePreprocessor
+    preprocessor = WordpiecePreprocessor(_wordpiece_vocabulary())
+    assert preprocessor(raw.split()) == pieces.split()
+    assert WordpiecePostprocessor([pieces.split()]) == [raw.split()]
+
+
+def test_wordpiece_refusals():
+    from neuralmonkey_amd.processors.wordpiece import WordpiecePreprocessor, unescape_token
+    from neuralmonkey_amd.vocabulary import Vocabulary
+    with pytest.raises(TypeError):
+        WordpiecePreprocessor(["not", "a", "vocabulary"])
+    with pytest.raises(AssertionError, match="No token substring"):
+        WordpiecePreprocessor(Vocabulary(["a", "a_"]))(["ab"])        # "b" is written as its code point, which has no pieces
+    assert unescape_token("a\\ub\\\\c\\99999999999;_") == "a_b\\c〓"
+
+
+# ---- neuralmonkey/dataset.py:207-333: the three kinds of series -----------------------------------------
+def test_dataset_load_series_kinds(tmp_path):
+    from neuralmonkey_amd import dataset
+    from neuralmonkey_amd.processors.helpers import pipeline, preprocess_char_based
+    from neuralmonkey_amd.readers.plain_text_reader import T2TReader
+    path = str(tmp_path / "src")
+    with open(path, "w") as handle:
+        handle.write("ab c\nd, e\n")
+
+    def lengths(iterators):
+        return ([str(len(a)), str(len(b))] for a, b in zip(iterators["source"](), iterators["chars"]()))
+
+    data = dataset.load("d", ["source", "t2t", "chars", "lens"],
+                        [path, (path, T2TReader), (pipeline([preprocess_char_based]), "source"), lengths],
+                        dataset.BatchingScheme(batch_size=2))
+    assert list(data.get_series("source")) == [["ab", "c"], ["d,", "e"]]
+    assert list(data.get_series("t2t")) == [["ab", "c"], ["d", ", ", "e"]]
+    assert list(data.get_series("chars")) == [list("ab c"), list("d, e")]
+    assert list(data.get_series("lens")) == [["2", "4"], ["2", "4"]]
+    with pytest.raises(ValueError, match="series-level preprocessor"):   # preprocessors do not stack
+        dataset.load("d", ["source", "chars", "chars2"], [path, (preprocess_char_based, "source"),
+                                                          (preprocess_char_based, "chars")],
+                     dataset.BatchingScheme(batch_size=2))
+    with pytest.raises(ValueError, match="Multiple outputs"):
+        dataset.load("d", ["source"], [path], dataset.BatchingScheme(batch_size=2),
+                     outputs=[("target", "a.txt"), ("target", "b.txt")])
+    with pytest.raises(ValueError, match="duplicate"):
+        dataset.load("d", ["source", "source"], [path, path], dataset.BatchingScheme(batch_size=2))
+    with pytest.raises(TypeError):
+        dataset.load("d", ["source"], [3], dataset.BatchingScheme(batch_size=2))
