@@ -487,6 +487,24 @@ def add_position(tape: Tape, x: Var, signal: torch.Tensor, bsz: int, steps: int,
     return out
 
 
+def add_row(tape: Tape, x: Var, row: Var) -> Var:
+    """x [N, D] + row [1, D] on every row (the target-modality embedding of encoders/transformer.py:202-203);
+    the broadcast add is the position-signal kernel with one time step per row."""
+    n, d = x.shape
+    out = tape.new((n, d))
+    ops.add_position(x.data.view(n, 1, d), row.data.reshape(1, d), out.data.view(n, 1, d), 0)
+
+    def bwd():
+        if out.grad is None:
+            return
+        if x.needs_grad:
+            ops.ew("copy", out.grad, None, tape.grad(x), accumulate=True)
+        if row.needs_grad:
+            ops.colsum(out.grad, tape.grad(row).view(d), accumulate=True)
+    tape.record(bwd)
+    return out
+
+
 def time_sum(tape: Tape, x: Var, bsz: int, steps: int) -> Var:
     """[B*T, D] -> [B, D] sum over time (encoders/transformer.py:170-172)."""
     d = x.shape[1]

@@ -59,8 +59,6 @@ class TransformerEncoder(ModelPart, TemporalStatefulWithOutput):
         if (input_for_cross_attention is None) != (n_cross_att_heads is None):
             raise ValueError("Either both input_for_cross_attention and n_cross_att_heads must be provided "
                              "or none of them.")
-        if self.target_space_id is not None:
-            raise NotImplementedError("target_space_id (modality embedding) is not implemented in the HIP engine")
         # variance_scaling_initializer(mode="fan_avg", distribution="uniform") (transformer.py:152-153)
         self.set_default_initializer(glorot_uniform_initializer())
 
@@ -109,6 +107,8 @@ class TransformerEncoder(ModelPart, TemporalStatefulWithOutput):
                 TB.declare_attention(self, store, pre + "/cross_attention", d, self.n_cross_att_heads,
                                      self.use_att_transform_bias)
             TB.declare_feedforward(self, store, pre + "/feedforward", d, self.ff_hidden_size)
+        if self.target_space_id is not None:                                   # :175-188, all 32 modalities
+            self.declare(store, "target_modality_embedding_matrix", (32, d))
         self.declare(store, "LayerNorm/gamma", (d,), ones_initializer())      # after the last layer (:309-310)
         self.declare(store, "LayerNorm/beta", (d,), zeros_initializer())
 
@@ -123,7 +123,10 @@ class TransformerEncoder(ModelPart, TemporalStatefulWithOutput):
         tape = F.Tape(ctx, (id(self), "tenc"), recording=train)
         x_in = tape.leaf(x_raw.reshape(bsz * slen, d), needs_grad=True)
         x = x_in
-        if self.use_positional_encoding:                                      # :187-189
+        if self.target_space_id is not None:                                  # :202-203
+            table = tape.param(self, "target_modality_embedding_matrix")
+            x = F.add_row(tape, x, tape.rows(table, self.target_space_id, self.target_space_id + 1))
+        if self.use_positional_encoding:                                      # :205-209
             x = F.add_position(tape, x, TB.signal_table(ctx, d, slen), bsz, slen)
         x = F.dropout(tape, x, keep, train, ctx.salt(self.name, "encoder_inputs"))
         cross = None

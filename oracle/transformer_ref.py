@@ -32,6 +32,7 @@ class TConfig(NamedTuple):
     use_positional_encoding: bool = True
     tie_embeddings: bool = True
     supress_unk: bool = False
+    target_space_id: Optional[int] = None
 
 
 def position_signal(dimension: int, length: int) -> torch.Tensor:
@@ -112,6 +113,8 @@ class TransformerModel:
         ids = torch.as_tensor(src_ids.astype(np.int64))
         mask = (ids != PAD).to(self.dtype)
         x = p[name + "_input/embedding_matrix_0"][ids] * mask.unsqueeze(-1)
+        if cfg.target_space_id is not None:        # encoders/transformer.py:175-203: one row of a [32, D] table
+            x = x + p[name + "/target_modality_embedding_matrix"][cfg.target_space_id].reshape(1, 1, -1)
         if cfg.use_positional_encoding:
             x = x + position_signal(x.shape[-1], x.shape[1]).to(self.dtype)
         x = self.dropout(x, cfg.enc_dropout, train, name, "encoder_inputs")

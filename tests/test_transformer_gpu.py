@@ -107,7 +107,8 @@ def _build(dev, cfg: TRF.TConfig, d, ff, max_len=8, beam=3, seed=7, init_std=0.4
                              n_heads=cfg.n_heads, dropout_keep_prob=cfg.enc_dropout,
                              attention_dropout_keep_prob=cfg.enc_att_dropout,
                              use_att_transform_bias=cfg.use_att_transform_bias,
-                             use_positional_encoding=cfg.use_positional_encoding)
+                             use_positional_encoding=cfg.use_positional_encoding,
+                             target_space_id=cfg.target_space_id)
     dec = TransformerDecoder(name=cfg.dec_name, encoders=[enc], vocabulary=vocab, data_id="target",
                              ff_hidden_size=ff, n_heads_self=cfg.n_heads_self, n_heads_enc=cfg.n_heads_enc,
                              depth=cfg.depth, max_output_len=max_len, dropout_keep_prob=cfg.dec_dropout,
@@ -153,6 +154,8 @@ CASES = {
                                        self_att_dropout=0.7, encdec_att_dropout=0.9,
                                        use_att_transform_bias=True, use_positional_encoding=False), 16, 32),
     "wide": (TRF.TConfig(depth=3, n_heads=8, n_heads_self=8, n_heads_enc=8), 64, 128),
+    # a target-space modality embedding (row 5 of the 32) added to the encoder input, as in the T2T imports
+    "target_space": (TRF.TConfig(depth=1, n_heads=2, n_heads_self=2, n_heads_enc=2, target_space_id=5), 8, 16),
 }
 
 
