@@ -14,6 +14,7 @@ bool is NOT accepted for an int or float (the INI grammar has separate literals 
 import collections.abc
 import gc
 import inspect
+import numbers
 import sys
 import typing
 from typing import Any, Optional
@@ -76,10 +77,10 @@ def matches(value: Any, hint: Any) -> bool:
         return not args or all(matches(k, args[0]) and matches(v, args[1]) for k, v in value.items())
     if origin is not None:                                                # some other generic: check the container only
         return isinstance(value, origin) if inspect.isclass(origin) else True
-    if hint is float:
-        return isinstance(value, (int, float)) and not isinstance(value, bool)
+    if hint is float:                                                     # numpy scalars count as numbers
+        return isinstance(value, numbers.Real) and not isinstance(value, bool)
     if hint is int:
-        return isinstance(value, int) and not isinstance(value, bool)
+        return isinstance(value, numbers.Integral) and not isinstance(value, bool)
     if hint is complex:
         return isinstance(value, (int, float, complex)) and not isinstance(value, bool)
     if inspect.isclass(hint):
