@@ -85,9 +85,9 @@ class TransformerDecoder(AutoregressiveDecoder):
         if self.attention_combination_strategy == "flat" and len(self.n_heads_enc) != 1:
             raise ValueError("For the flat attention combination strategy, only a single value is permitted "
                              "in n_heads_enc.")
-        if self.attention_combination_strategy != "serial":
+        if self.attention_combination_strategy not in ("serial", "parallel"):
             raise NotImplementedError("attention_combination_strategy '{}' is not implemented in the HIP engine "
-                                      "(serial is)".format(self.attention_combination_strategy))
+                                      "(serial and parallel are)".format(self.attention_combination_strategy))
         if self.depth <= 0:
             raise ValueError("Depth must be a positive integer.")
         _ = self.dimension                        # dimension checks of the reference (:195-222)
@@ -125,10 +125,14 @@ class TransformerDecoder(AutoregressiveDecoder):
             TB.declare_layer_norm(self, store, pre + "/self_attention", d)
             TB.declare_attention(self, store, pre + "/self_attention", d, self.n_heads_self,
                                  self.use_att_transform_bias)
+            parallel = self.attention_combination_strategy == "parallel"
+            if parallel:          # one normalisation of the queries for all encoders (transformer_cross_layer.py:139)
+                TB.declare_layer_norm(self, store, pre + "/encdec_attention", d)
             for j, heads in enumerate(self.n_heads_enc):
                 scope = "{}/encdec_attention/enc_{}".format(pre, j)
-                TB.declare_layer_norm(self, store, scope, d)
-                TB.declare_attention(self, store, scope, d, heads, False)       # serial(): no transform bias
+                if not parallel:
+                    TB.declare_layer_norm(self, store, scope, d)
+                TB.declare_attention(self, store, scope, d, heads, False)       # single(): no transform bias
             TB.declare_feedforward(self, store, pre + "/feedforward", d, self.ff_hidden_size)
         self.declare(store, "LayerNorm/gamma", (d,), ones_initializer())
         self.declare(store, "LayerNorm/beta", (d,), zeros_initializer())
@@ -148,10 +152,15 @@ class TransformerDecoder(AutoregressiveDecoder):
                                          ctx.salt(*site, "self_attention_weights"), self.use_att_transform_bias)
             att = F.dropout(tape, att, keep, train, ctx.salt(*site, "self_attention"))
             x = F.add(tape, att, x)
+            # serial (:68-103): norm + attend + dropout + residual per encoder, each on the previous result;
+            # parallel (:106-152): every encoder is queried with the same normalised input, the contexts
+            # and the input are summed
+            parallel = self.attention_combination_strategy == "parallel"
+            queries = TB.layer_norm(tape, self, pre + "/encdec_attention", x) if parallel else None
             for j, ((evar, emask, elen), heads, att_keep) in enumerate(zip(enc, self.n_heads_enc,
                                                                           self.attention_dropout_keep_prob)):
                 scope = "{}/encdec_attention/enc_{}".format(pre, j)
-                normed = TB.layer_norm(tape, self, scope, x)
+                normed = queries if parallel else TB.layer_norm(tape, self, scope, x)
                 att = TB.multihead_attention(tape, self, scope, normed, evar, emask, heads, bsz, steps, bsz, elen,
                                              False, att_keep, train, ctx.salt(*site, "encdec_weights", j), False)
                 att = F.dropout(tape, att, keep, train, ctx.salt(*site, "encdec", j))
@@ -429,9 +438,11 @@ class TransformerStepper:
                                   False, 1.0, 0, k_data=kc[:, :t + 1], v_data=vc[:, :t + 1])
             att = TB.project(tape, dec, scope, "output_proj", att, dec.n_heads_self, dec.use_att_transform_bias)
             x = F.add(tape, att, x)
+            parallel = dec.attention_combination_strategy == "parallel"
+            queries = TB.layer_norm(tape, dec, pre + "/encdec_attention", x) if parallel else None
             for j, (heads, (per_layer, emask, bk, slen)) in enumerate(zip(dec.n_heads_enc, self.enc_kv)):
                 scope = "{}/encdec_attention/enc_{}".format(pre, j)
-                normed = TB.layer_norm(tape, dec, scope, x)
+                normed = queries if parallel else TB.layer_norm(tape, dec, scope, x)
                 q = TB.project(tape, dec, scope, "query_proj", normed, heads, False)
                 ek, ev = per_layer[l]
                 att = F.sdp_attention(tape, q, None, None, emask, heads, rows, 1, bk, slen, False, 1.0, 0,

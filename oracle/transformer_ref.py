@@ -33,6 +33,8 @@ class TConfig(NamedTuple):
     tie_embeddings: bool = True
     supress_unk: bool = False
     target_space_id: Optional[int] = None
+    extra_encoders: Tuple[str, ...] = ()      # names of further encoders (same hyper-parameters) the decoder attends to
+    strategy: str = "serial"                  # attention_combination_strategy: "serial" | "parallel"
 
 
 def position_signal(dimension: int, length: int) -> torch.Tensor:
@@ -108,8 +110,18 @@ class TransformerModel:
         return out + x
 
     # -- encoder -------------------------------------------------------------------------------------
-    def encode(self, src_ids: np.ndarray, train: bool):
-        cfg, p, name = self.cfg, self.p, self.cfg.enc_name
+    def encode_all(self, src_ids, train: bool):
+        """States and masks of every encoder the decoder attends to: ``src_ids`` is one id matrix, or a list
+        with one matrix per encoder (cfg.enc_name, then cfg.extra_encoders)."""
+        if isinstance(src_ids, np.ndarray):
+            src_ids = [src_ids]
+        names = (self.cfg.enc_name,) + tuple(self.cfg.extra_encoders)
+        assert len(src_ids) == len(names)
+        encoded = [self.encode(ids, train, name) for ids, name in zip(src_ids, names)]
+        return [e[0] for e in encoded], [e[1] for e in encoded]
+
+    def encode(self, src_ids: np.ndarray, train: bool, name: Optional[str] = None):
+        cfg, p, name = self.cfg, self.p, name or self.cfg.enc_name
         ids = torch.as_tensor(src_ids.astype(np.int64))
         mask = (ids != PAD).to(self.dtype)
         x = p[name + "_input/embedding_matrix_0"][ids] * mask.unsqueeze(-1)
@@ -141,11 +153,17 @@ class TransformerModel:
                                  cfg.self_att_dropout, train, cfg.use_att_transform_bias,
                                  site + ("self_attention_weights",))
             x = self.dropout(att, cfg.dec_dropout, train, *site, "self_attention") + x
-            scope = pre + "/encdec_attention/enc_0"
-            normed = self.layer_norm(x, scope + "/")
-            att = self.attention(scope, normed, enc_states, enc_mask, cfg.n_heads_enc, False, cfg.encdec_att_dropout,
-                                 train, False, site + ("encdec_weights", 0))
-            x = self.dropout(att, cfg.dec_dropout, train, *site, "encdec", 0) + x
+            # attention/transformer_cross_layer.py: serial (:68-103) re-normalises the running result for every
+            # encoder; parallel (:106-152) queries all encoders with one normalised input and sums
+            if not isinstance(enc_states, (list, tuple)):
+                enc_states, enc_mask = [enc_states], [enc_mask]
+            queries = self.layer_norm(x, pre + "/encdec_attention/") if cfg.strategy == "parallel" else None
+            for j, (states, smask) in enumerate(zip(enc_states, enc_mask)):
+                scope = pre + "/encdec_attention/enc_{}".format(j)
+                normed = queries if queries is not None else self.layer_norm(x, scope + "/")
+                att = self.attention(scope, normed, states, smask, cfg.n_heads_enc, False, cfg.encdec_att_dropout,
+                                     train, False, site + ("encdec_weights", j))
+                x = self.dropout(att, cfg.dec_dropout, train, *site, "encdec", j) + x
             x = self.feedforward(pre + "/feedforward", x, cfg.dec_dropout, train, site)
         return self.layer_norm(x, name + "/")
 
@@ -164,7 +182,7 @@ class TransformerModel:
     def train_loss(self, src_ids, tgt_bt, train=True):
         """train_loop_result (:393-453): one pass over <s> + targets[:-1]; loss autoregressive.py:289-316."""
         cfg, p = self.cfg, self.p
-        enc_states, enc_mask, _ = self.encode(src_ids, train)
+        enc_states, enc_mask = self.encode_all(src_ids, train)
         bsz, steps = tgt_bt.shape
         dec_in = np.concatenate([np.full((bsz, 1), START, tgt_bt.dtype), tgt_bt[:, :-1]], 1)
         emb = p[cfg.dec_name + "/word_embeddings"][torch.as_tensor(dec_in.astype(np.int64))]
@@ -190,8 +208,8 @@ class TransformerModel:
     def greedy(self, src_ids, max_len: int):
         with torch.no_grad():
             table = self.p[self.cfg.dec_name + "/word_embeddings"]
-            enc_states, enc_mask, _ = self.encode(src_ids, False)
-            rows = enc_states.shape[0]
+            enc_states, enc_mask = self.encode_all(src_ids, False)
+            rows = enc_states[0].shape[0]
             emb = table[torch.full((rows,), START)]
             finished = torch.zeros(rows, dtype=torch.bool)
             seq = torch.zeros(rows, 0, table.shape[1], dtype=self.dtype)
@@ -216,9 +234,10 @@ class TransformerModel:
         with torch.no_grad():
             dt = self.dtype
             table = self.p[self.cfg.dec_name + "/word_embeddings"]
-            enc_states, enc_mask, _ = self.encode(src_ids, False)
-            bsz = enc_states.shape[0]
-            enc_states, enc_mask = enc_states.repeat_interleave(k, 0), enc_mask.repeat_interleave(k, 0)
+            enc_states, enc_mask = self.encode_all(src_ids, False)
+            bsz = enc_states[0].shape[0]
+            enc_states = [e.repeat_interleave(k, 0) for e in enc_states]
+            enc_mask = [m.repeat_interleave(k, 0) for m in enc_mask]
             rows = bsz * k
             seq = table[torch.full((rows,), START)].unsqueeze(1)
             seq_mask = torch.ones(rows, 1, dtype=dt)
