@@ -85,9 +85,9 @@ class TransformerDecoder(AutoregressiveDecoder):
         if self.attention_combination_strategy == "flat" and len(self.n_heads_enc) != 1:
             raise ValueError("For the flat attention combination strategy, only a single value is permitted "
                              "in n_heads_enc.")
-        if self.attention_combination_strategy not in ("serial", "parallel"):
-            raise NotImplementedError("attention_combination_strategy '{}' is not implemented in the HIP engine "
-                                      "(serial and parallel are)".format(self.attention_combination_strategy))
+        if self.attention_combination_strategy == "flat" and len(set(self.attention_dropout_keep_prob)) != 1:
+            raise ValueError("For the flat attention combination strategy, the attention dropout must be the "
+                             "same for all encoders.")
         if self.depth <= 0:
             raise ValueError("Depth must be a positive integer.")
         _ = self.dimension                        # dimension checks of the reference (:195-222)
@@ -125,14 +125,21 @@ class TransformerDecoder(AutoregressiveDecoder):
             TB.declare_layer_norm(self, store, pre + "/self_attention", d)
             TB.declare_attention(self, store, pre + "/self_attention", d, self.n_heads_self,
                                  self.use_att_transform_bias)
-            parallel = self.attention_combination_strategy == "parallel"
-            if parallel:          # one normalisation of the queries for all encoders (transformer_cross_layer.py:139)
+            strategy = self.attention_combination_strategy
+            if strategy == "flat":  # single() over the concatenated encoders, right in the sublayer's scope (:236-268)
+                TB.declare_layer_norm(self, store, pre + "/encdec_attention", d)
+                TB.declare_attention(self, store, pre + "/encdec_attention", d, self.n_heads_enc[0], False)
+                TB.declare_feedforward(self, store, pre + "/feedforward", d, self.ff_hidden_size)
+                continue
+            if strategy != "serial":   # one normalisation of the queries for all encoders (:139, :182)
                 TB.declare_layer_norm(self, store, pre + "/encdec_attention", d)
             for j, heads in enumerate(self.n_heads_enc):
                 scope = "{}/encdec_attention/enc_{}".format(pre, j)
-                if not parallel:
+                if strategy == "serial":
                     TB.declare_layer_norm(self, store, scope, d)
                 TB.declare_attention(self, store, scope, d, heads, False)       # single(): no transform bias
+            if strategy == "hierarchical":
+                TB.declare_attention(self, store, pre + "/encdec_attention/enc_hier", d, self.n_heads_hier, False)
             TB.declare_feedforward(self, store, pre + "/feedforward", d, self.ff_hidden_size)
         self.declare(store, "LayerNorm/gamma", (d,), ones_initializer())
         self.declare(store, "LayerNorm/beta", (d,), zeros_initializer())
@@ -152,21 +159,50 @@ class TransformerDecoder(AutoregressiveDecoder):
                                          ctx.salt(*site, "self_attention_weights"), self.use_att_transform_bias)
             att = F.dropout(tape, att, keep, train, ctx.salt(*site, "self_attention"))
             x = F.add(tape, att, x)
-            # serial (:68-103): norm + attend + dropout + residual per encoder, each on the previous result;
-            # parallel (:106-152): every encoder is queried with the same normalised input, the contexts
-            # and the input are summed
-            parallel = self.attention_combination_strategy == "parallel"
-            queries = TB.layer_norm(tape, self, pre + "/encdec_attention", x) if parallel else None
-            for j, ((evar, emask, elen), heads, att_keep) in enumerate(zip(enc, self.n_heads_enc,
-                                                                          self.attention_dropout_keep_prob)):
-                scope = "{}/encdec_attention/enc_{}".format(pre, j)
-                normed = queries if parallel else TB.layer_norm(tape, self, scope, x)
-                att = TB.multihead_attention(tape, self, scope, normed, evar, emask, heads, bsz, steps, bsz, elen,
-                                             False, att_keep, train, ctx.salt(*site, "encdec_weights", j), False)
-                att = F.dropout(tape, att, keep, train, ctx.salt(*site, "encdec", j))
-                x = F.add(tape, att, x)
+            x = self._encoder_attention(tape, x, enc, bsz, steps, train, pre, site)
             x = TB.feedforward_sublayer(tape, self, pre + "/feedforward", x, keep, train, site)
         return F.layer_norm(tape, x, tape.param(self, "LayerNorm/gamma"), tape.param(self, "LayerNorm/beta"))
+
+    def _encoder_attention(self, tape: F.Tape, x: F.Var, enc, bsz: int, steps: int, train: bool, pre: str,
+                           site) -> F.Var:
+        """encoder_attention_sublayer (:297-340) over whole sequences, the four strategies of
+        attention/transformer_cross_layer.py: ``serial`` (:68-103) norm + attend + dropout + residual per encoder,
+        each on the previous result; ``parallel`` (:106-152) one normalised input queries every encoder, contexts
+        and input are summed; ``hierarchical`` (:155-232) a second attention (``enc_hier``) of the same queries over
+        the per-encoder contexts; ``flat`` (:236-268) one attention over the encoders concatenated in time."""
+        ctx, keep, strategy = tape.ctx, self.dropout_keep_prob, self.attention_combination_strategy
+        rows, d = bsz * steps, self.dimension
+        top = pre + "/encdec_attention"
+        if strategy == "flat":
+            evar, emask, elen = concat_in_time(tape, enc, bsz, d, (id(self), "flat_mask", bsz))
+            normed = TB.layer_norm(tape, self, top, x)
+            att = TB.multihead_attention(tape, self, top, normed, evar, emask, self.n_heads_enc[0], bsz, steps, bsz,
+                                         elen, False, self.attention_dropout_keep_prob[0], train,
+                                         ctx.salt(*site, "encdec_weights", 0), False)
+            return F.add(tape, F.dropout(tape, att, keep, train, ctx.salt(*site, "encdec", 0)), x)
+        queries = None if strategy == "serial" else TB.layer_norm(tape, self, top, x)
+        contexts = []
+        for j, ((evar, emask, elen), heads, att_keep) in enumerate(zip(enc, self.n_heads_enc,
+                                                                      self.attention_dropout_keep_prob)):
+            scope = "{}/enc_{}".format(top, j)
+            normed = queries if queries is not None else TB.layer_norm(tape, self, scope, x)
+            att = TB.multihead_attention(tape, self, scope, normed, evar, emask, heads, bsz, steps, bsz, elen,
+                                         False, att_keep, train, ctx.salt(*site, "encdec_weights", j), False)
+            att = F.dropout(tape, att, keep, train, ctx.salt(*site, "encdec", j))
+            if strategy == "hierarchical":
+                contexts.append(att)
+            else:
+                x = F.add(tape, att, x)
+        if strategy != "hierarchical":
+            return x
+        n = len(contexts)
+        stacked = tape.view(F.concat(tape, contexts), lambda t: t.view(rows * n, d))    # [B*T, n, D]
+        ones = ctx.buffer((id(self), "hier_mask", rows, n), (rows, n))
+        ones.fill_(1.0)
+        # the weights of the second attention are dropped with dropout_keep_prob (:221-226)
+        att = TB.multihead_attention(tape, self, top + "/enc_hier", queries, stacked, ones, self.n_heads_hier, rows, 1,
+                                     rows, n, False, keep, train, ctx.salt(*site, "encdec_hier_weights"), False)
+        return F.add(tape, F.dropout(tape, att, keep, train, ctx.salt(*site, "encdec_hier")), x)
 
     def _logit_params(self, tape: F.Tape):
         ctx = tape.ctx
@@ -360,6 +396,21 @@ class TransformerDecoder(AutoregressiveDecoder):
         return self.runtime_loop_result(ctx).output_states
 
 
+def concat_in_time(tape: F.Tape, enc, bsz: int, d: int, mask_key):
+    """tf.concat(states, 1), tf.concat(masks, 1) of batch-major encoder states: (Var [B*S,D], mask [B,S], S)."""
+    if len(enc) == 1:
+        return enc[0]
+    total = sum(elen for _, _, elen in enc)
+    parts = [tape.view(evar, lambda t, n=elen: t.view(bsz, n * d)) for evar, _, elen in enc]
+    states = tape.view(F.concat(tape, parts), lambda t: t.view(bsz * total, d))
+    mask = tape.ctx.buffer(mask_key + (total,), (bsz, total))
+    col = 0
+    for _, emask, elen in enc:
+        ops.ew("copy", emask, None, mask[:, col:col + elen])
+        col += elen
+    return states, mask, total
+
+
 class TransformerStepper:
     """Cached decoding steps for R rows (greedy: R = B; beam: R = B*k, ``rows_per_key`` = k)."""
 
@@ -375,6 +426,8 @@ class TransformerStepper:
         self.kcache = [buf(("k", l), (2, rows, self.tmax, d)) for l in range(dec.depth)]
         self.vcache = [buf(("v", l), (2, rows, self.tmax, d)) for l in range(dec.depth)]
         self.mask = buf("mask", (2, rows, self.tmax))
+        self.hier_ones = buf("hier_ones", (rows, len(dec.encoders)))
+        self.hier_ones.fill_(1.0)
         self.cur = 0
         self.t = 0
         self.enc_kv = None
@@ -384,17 +437,23 @@ class TransformerStepper:
         dec, tape = self.dec, self.tape
         tape._n, tape._slot = 0, 2                # pylint: disable=protected-access
         self.enc_kv = []
-        for j, (e, heads) in enumerate(zip(dec.encoders, dec.n_heads_enc)):
+        flat = dec.attention_combination_strategy == "flat"
+        sources = []
+        for e in dec.encoders:
             st = get_attention_states(e, self.ctx)
             bk, slen, d = st.shape
-            var = tape.leaf(st.reshape(bk * slen, d))
+            sources.append((tape.leaf(st.reshape(bk * slen, d)), get_attention_mask(e, self.ctx), slen))
+        if flat:
+            sources = [concat_in_time(tape, sources, bk, d, (id(dec), "flat_mask_step", bk))]
+        for j, ((var, emask, slen), heads) in enumerate(zip(sources, dec.n_heads_enc)):
             per_layer = []
             for l in range(dec.depth):
-                scope = "layer_{}/encdec_attention/enc_{}".format(l, j)
+                scope = "layer_{}/encdec_attention".format(l) if flat else \
+                    "layer_{}/encdec_attention/enc_{}".format(l, j)
                 k = TB.project(tape, dec, scope, "keys_proj", var, heads, False)
                 v = TB.project(tape, dec, scope, "vals_proj", var, heads, False)
                 per_layer.append((k.data.view(bk, slen, d), v.data.view(bk, slen, d)))
-            self.enc_kv.append((per_layer, get_attention_mask(e, self.ctx), bk, slen))
+            self.enc_kv.append((per_layer, emask, bk, slen))
         self.base = tape._n                       # pylint: disable=protected-access
         self.cur, self.t = 0, 0
 
@@ -438,16 +497,27 @@ class TransformerStepper:
                                   False, 1.0, 0, k_data=kc[:, :t + 1], v_data=vc[:, :t + 1])
             att = TB.project(tape, dec, scope, "output_proj", att, dec.n_heads_self, dec.use_att_transform_bias)
             x = F.add(tape, att, x)
-            parallel = dec.attention_combination_strategy == "parallel"
-            queries = TB.layer_norm(tape, dec, pre + "/encdec_attention", x) if parallel else None
+            strategy = dec.attention_combination_strategy
+            top = pre + "/encdec_attention"
+            queries = None if strategy == "serial" else TB.layer_norm(tape, dec, top, x)
+            contexts = []
             for j, (heads, (per_layer, emask, bk, slen)) in enumerate(zip(dec.n_heads_enc, self.enc_kv)):
-                scope = "{}/encdec_attention/enc_{}".format(pre, j)
-                normed = queries if parallel else TB.layer_norm(tape, dec, scope, x)
+                scope = top if strategy == "flat" else "{}/enc_{}".format(top, j)
+                normed = queries if queries is not None else TB.layer_norm(tape, dec, scope, x)
                 q = TB.project(tape, dec, scope, "query_proj", normed, heads, False)
                 ek, ev = per_layer[l]
                 att = F.sdp_attention(tape, q, None, None, emask, heads, rows, 1, bk, slen, False, 1.0, 0,
                                       k_data=ek, v_data=ev)
                 att = TB.project(tape, dec, scope, "output_proj", att, heads, False)
+                if strategy == "hierarchical":
+                    contexts.append(att)
+                else:
+                    x = F.add(tape, att, x)
+            if strategy == "hierarchical":
+                n = len(contexts)
+                stacked = tape.view(F.concat(tape, contexts), lambda t, n=n: t.view(rows * n, d))
+                att = TB.multihead_attention(tape, dec, top + "/enc_hier", queries, stacked, self.hier_ones,
+                                             dec.n_heads_hier, rows, 1, rows, n, False, 1.0, False, 0, False)
                 x = F.add(tape, att, x)
             x = TB.feedforward_sublayer(tape, dec, pre + "/feedforward", x, 1.0, False, (dec.name, pre))
         ops.layer_norm_fwd(x.data, dec.var(self.ctx, "LayerNorm/gamma"), dec.var(self.ctx, "LayerNorm/beta"),

@@ -34,7 +34,8 @@ class TConfig(NamedTuple):
     supress_unk: bool = False
     target_space_id: Optional[int] = None
     extra_encoders: Tuple[str, ...] = ()      # names of further encoders (same hyper-parameters) the decoder attends to
-    strategy: str = "serial"                  # attention_combination_strategy: "serial" | "parallel"
+    strategy: str = "serial"                  # attention_combination_strategy: serial | parallel | flat | hierarchical
+    n_heads_hier: int = 1
 
 
 def position_signal(dimension: int, length: int) -> torch.Tensor:
@@ -157,13 +158,29 @@ class TransformerModel:
             # encoder; parallel (:106-152) queries all encoders with one normalised input and sums
             if not isinstance(enc_states, (list, tuple)):
                 enc_states, enc_mask = [enc_states], [enc_mask]
-            queries = self.layer_norm(x, pre + "/encdec_attention/") if cfg.strategy == "parallel" else None
+            top = pre + "/encdec_attention"
+            if cfg.strategy == "flat":              # :236-268: one attention over the encoders concatenated in time
+                enc_states, enc_mask = [torch.cat(list(enc_states), 1)], [torch.cat(list(enc_mask), 1)]
+            queries = self.layer_norm(x, top + "/") if cfg.strategy != "serial" else None
+            contexts = []
             for j, (states, smask) in enumerate(zip(enc_states, enc_mask)):
-                scope = pre + "/encdec_attention/enc_{}".format(j)
+                scope = top if cfg.strategy == "flat" else top + "/enc_{}".format(j)
                 normed = queries if queries is not None else self.layer_norm(x, scope + "/")
                 att = self.attention(scope, normed, states, smask, cfg.n_heads_enc, False, cfg.encdec_att_dropout,
                                      train, False, site + ("encdec_weights", j))
-                x = self.dropout(att, cfg.dec_dropout, train, *site, "encdec", j) + x
+                att = self.dropout(att, cfg.dec_dropout, train, *site, "encdec", j)
+                if cfg.strategy == "hierarchical":
+                    contexts.append(att)
+                else:
+                    x = att + x
+            if cfg.strategy == "hierarchical":      # :155-232: the same queries attend to the stacked contexts
+                bsz, steps, dim = x.shape
+                stacked = torch.stack(contexts, 2).reshape(bsz * steps, len(contexts), dim)
+                ones = torch.ones(bsz * steps, len(contexts), dtype=self.dtype)
+                att = self.attention(top + "/enc_hier", queries.reshape(bsz * steps, 1, dim), stacked, ones,
+                                     cfg.n_heads_hier, False, cfg.dec_dropout, train, False,
+                                     site + ("encdec_hier_weights",))
+                x = self.dropout(att.reshape(bsz, steps, dim), cfg.dec_dropout, train, *site, "encdec_hier") + x
             x = self.feedforward(pre + "/feedforward", x, cfg.dec_dropout, train, site)
         return self.layer_norm(x, name + "/")
 

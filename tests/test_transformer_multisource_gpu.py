@@ -1,5 +1,5 @@
-"""Transformer decoder over two encoders: the ``serial`` and ``parallel`` attention combination strategies
-(neuralmonkey/attention/transformer_cross_layer.py:68-152) against oracle/transformer_ref.py -- loss and every
+"""Transformer decoder over two encoders: the ``serial``, ``parallel``, ``flat`` and ``hierarchical`` attention
+combination strategies (neuralmonkey/attention/transformer_cross_layer.py:68-268) against oracle/transformer_ref.py -- loss and every
 gradient of one training step, greedy decoding through the key/value cache, beam search."""
 import numpy as np
 import pytest
@@ -10,11 +10,12 @@ from oracle import transformer_ref as TRF
 pytestmark = pytest.mark.gpu
 VOCAB = 23
 D, FF, MAX_LEN = 16, 24, 8
+STRATEGIES = ["serial", "parallel", "flat", "hierarchical"]
 
 
 def _cfg(strategy):
     return TRF.TConfig(depth=2, n_heads=2, n_heads_self=4, n_heads_enc=2, extra_encoders=("encoder2",),
-                       strategy=strategy, enc_dropout=0.9, dec_dropout=0.8, encdec_att_dropout=0.9)
+                       strategy=strategy, n_heads_hier=4, enc_dropout=0.9, dec_dropout=0.8, encdec_att_dropout=0.9)
 
 
 def _build(dev, cfg, seed=11):
@@ -37,7 +38,8 @@ def _build(dev, cfg, seed=11):
                              ff_hidden_size=FF, n_heads_self=cfg.n_heads_self, n_heads_enc=cfg.n_heads_enc,
                              depth=cfg.depth, max_output_len=MAX_LEN, dropout_keep_prob=cfg.dec_dropout,
                              embedding_size=D, attention_dropout_keep_prob=cfg.encdec_att_dropout,
-                             attention_combination_strategy=cfg.strategy)
+                             attention_combination_strategy=cfg.strategy,
+                             n_heads_hier=cfg.n_heads_hier if cfg.strategy == "hierarchical" else None)
     bdec = BeamSearchDecoder(name="beam_decoder", parent_decoder=dec, beam_size=3, max_steps=MAX_LEN,
                              length_normalization=0.6)
     trainer = CrossEntropyTrainer(decoders=[dec], l2_weight=0.0, clip_norm=None)
@@ -69,7 +71,7 @@ def _data(batch, with_target=True):
     return Dataset("two_sources", series), ids, tgt
 
 
-@pytest.mark.parametrize("strategy", ["serial", "parallel"])
+@pytest.mark.parametrize("strategy", STRATEGIES)
 def test_two_encoder_train_step_gradients(dev, strategy):
     cfg = _cfg(strategy)
     m = _build(dev, cfg)
@@ -81,7 +83,7 @@ def test_two_encoder_train_step_gradients(dev, strategy):
     store = m["store"]
     names = store.names()
     layer_norms = [n for n in names if "/encdec_attention/" in n and n.endswith("LayerNorm/gamma")]
-    assert len(layer_norms) == (cfg.depth if strategy == "parallel" else 2 * cfg.depth), layer_norms
+    assert len(layer_norms) == (2 * cfg.depth if strategy == "serial" else cfg.depth), layer_norms
     gmax = max(float(np.abs(g).max()) for g in ref_g.values() if g is not None)
     bad = {}
     for name in names:
@@ -97,7 +99,7 @@ def test_two_encoder_train_step_gradients(dev, strategy):
         assert float(store.g(enc.name + "/layer_0/feedforward/hidden_state/kernel").abs().max()) > 0.0
 
 
-@pytest.mark.parametrize("strategy", ["serial", "parallel"])
+@pytest.mark.parametrize("strategy", STRATEGIES)
 def test_two_encoder_greedy_and_beam(dev, strategy):
     cfg = _cfg(strategy)
     m = _build(dev, cfg)
