@@ -17,6 +17,7 @@ from typing import Callable, List, Tuple, Union
 
 from .. import autodiff as F
 from .. import ops
+from ..checking import check_argument_types
 from ..variables import zeros_initializer
 
 
@@ -199,9 +200,29 @@ def mlp_output(layer_sizes: List[int], activation: Callable = None,
     return MlpOutput(layer_sizes, act, dropout_keep_prob), layer_sizes[-1]
 
 
+class LegacyOutput(OutputProjection):
+    """_legacy_linear / _legacy_relu (output_projection.py:33-72): ``[relu](dense(concat[state, *ctx]))`` in the
+    scope ``AttnOutputProjection``; the previous output is not an input and there is no dropout."""
+
+    def __init__(self, output_size: int, activation: str):
+        self.output_size, self.activation = output_size, activation
+
+    def declare_variables(self, decoder, store, state_size, emb_size, ctx_sizes):
+        self.sizes = [state_size] + list(ctx_sizes)
+        decoder.declare(store, "attention_decoder/AttnOutputProjection/kernel", (sum(self.sizes), self.output_size))
+        decoder.declare(store, "attention_decoder/AttnOutputProjection/bias", (self.output_size,),
+                        zeros_initializer())
+
+    def apply_var(self, tape, decoder, state, prev_output, ctx_vars, train_mode, salt):
+        pre = _dense_blocks(tape, decoder, "AttnOutputProjection", [state] + list(ctx_vars), self.sizes)
+        return F.ACTIVATIONS[self.activation](tape, pre)
+
+
 def _legacy_linear(output_size: int) -> Tuple[OutputProjection, int]:
-    raise NotImplementedError("_legacy_linear output projection is not implemented in the HIP engine")
+    check_argument_types()
+    return LegacyOutput(output_size, "identity"), output_size
 
 
 def _legacy_relu(output_size: int) -> Tuple[OutputProjection, int]:
-    raise NotImplementedError("_legacy_relu output projection is not implemented in the HIP engine")
+    check_argument_types()
+    return LegacyOutput(output_size, "relu"), output_size

@@ -247,6 +247,10 @@ class GeneralModel:
                  + emb_in @ p[pre + "prev_out/kernel"] + p[pre + "prev_out/bias"]
                  + torch.cat(contexts, 1) @ p[pre + "context/kernel"] + p[pre + "context/bias"])
             return self.dropout(_act(act)(s), keep, train, *site)
+        if kind == "legacy":                                           # :33-72: no previous output, no dropout
+            state_with_ctx = torch.cat([cell_output] + contexts, 1)
+            return _act(cfg.output_projection[1])(state_with_ctx @ p[pre + "AttnOutputProjection/kernel"]
+                                                  + p[pre + "AttnOutputProjection/bias"])
         if kind == "maxout":                                           # :133-160, nn/projection.py:7-35
             _, size, keep = cfg.output_projection
             z = cat @ p[pre + "MaxoutProjection/MaxoutProjection/kernel"] \

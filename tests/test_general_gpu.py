@@ -45,6 +45,9 @@ def _build(dev, cfg: G.Config, emb_src, emb_tgt, max_len=8, beam=3, seed=5, init
         proj = OP.nematus_output(emb_tgt, act(cfg.output_projection[1]), cfg.output_projection[2])
     elif kind == "maxout":
         proj = OP.maxout_output(cfg.output_projection[1], cfg.output_projection[2])
+    elif kind == "legacy":
+        legacy = {"relu": OP._legacy_relu, "identity": OP._legacy_linear}     # pylint: disable=protected-access
+        proj = legacy[cfg.output_projection[1]](emb_tgt)
     else:
         proj = OP.mlp_output(list(cfg.output_projection[1]), act(cfg.output_projection[2]), cfg.output_projection[3])
     # concat is what the reference infers from rnn_size=None without a projection (decoder.py:176-191)
@@ -107,6 +110,11 @@ CASES = {
     "gru_dropout_mlp": (G.Config(rnn_layers=((4, "bidirectional", "GRU"),), enc_dropout=0.8, att_dropout=0.9,
                                  dec_dropout=0.7, rnn_size=8, supress_unk=True,
                                  output_projection=("mlp", (12, 8), "relu", 0.8)), 8, 8),
+    # the output projections of old experiments: dense(concat[state, context]) without the previous output
+    "legacy_relu": (G.Config(rnn_layers=((4, "bidirectional", "GRU"),), rnn_size=8, dec_dropout=0.8,
+                             output_projection=("legacy", "relu")), 8, 8),
+    "legacy_linear_lstm": (G.Config(rnn_layers=((4, "bidirectional", "LSTM"),), dec_cell="LSTM", rnn_size=8,
+                                    output_projection=("legacy", "identity")), 8, 8),
     # plain GRU model: dropout sends training to the tape, inference stays on the fused fast path
     "gru_dropout_only": (G.Config(rnn_layers=((4, "bidirectional", "GRU"),), enc_dropout=0.6, dec_dropout=0.6,
                                   rnn_size=8), 8, 8),
