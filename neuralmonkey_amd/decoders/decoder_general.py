@@ -188,11 +188,17 @@ class GeneralDecoderMixin:
                 slot[0] = g
             else:                        # several attentions over one encoder
                 ops.ew("copy", g.reshape(-1, g.shape[-1]), None, slot[0].reshape(-1, g.shape[-1]), accumulate=True)
+        def add_output_grad(enc, g):
+            slot = enc_grads.setdefault(enc, [None, None])
+            if slot[1] is None or g is None:
+                slot[1] = g if slot[1] is None else slot[1]
+            else:                        # initial state and a StatefulContext over one encoder
+                ops.ew("copy", g, None, slot[1], accumulate=True)
         for sess in sv["sessions"]:
-            for enc, g in sess.encoder_grads():
-                add_states_grad(enc, g)
+            for enc, g, *kind in sess.encoder_grads():
+                (add_output_grad if kind == ["output"] else add_states_grad)(enc, g)
         for enc, var in zip(self.encoders, sv["enc_outs"]):
-            enc_grads.setdefault(enc, [None, None])[1] = var.grad
+            add_output_grad(enc, var.grad)
         proj_states = getattr(self.encoder_projection, "states_var", None)
         if proj_states is not None and proj_states.grad is not None:     # nematus_projection reads the states
             add_states_grad(self.encoders[0], proj_states.grad.view(sv["bsz"], -1, proj_states.shape[1]))

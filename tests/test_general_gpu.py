@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 VOCAB = 40
 
 
-def _build(dev, cfg: G.Config, emb_src, emb_tgt, max_len=8, beam=3, seed=5, init_std=0.35):
+def _build(dev, cfg: G.Config, emb_src, emb_tgt, max_len=8, beam=3, seed=5, init_std=0.35, make_attention=None):
     from neuralmonkey_amd.attention import Attention
     from neuralmonkey_amd.decoders import BeamSearchDecoder, Decoder
     from neuralmonkey_amd.decoders import encoder_projection as EP
@@ -36,7 +36,8 @@ def _build(dev, cfg: G.Config, emb_src, emb_tgt, max_len=8, beam=3, seed=5, init
                            add_residual=cfg.add_residual, add_layer_norm=cfg.add_layer_norm,
                            include_final_layer_norm=cfg.include_final_layer_norm,
                            dropout_keep_prob=cfg.enc_dropout)
-    att = Attention(name=cfg.att_name, encoder=enc, dropout_keep_prob=cfg.att_dropout)
+    att = make_attention(enc) if make_attention else Attention(name=cfg.att_name, encoder=enc,
+                                                                 dropout_keep_prob=cfg.att_dropout)
     kind = cfg.output_projection[0]
     act = lambda name: type("Act", (), {"nm_name": name})()
     if kind == "nonlinear":
