@@ -288,6 +288,7 @@ def test_string_vector_reader_known_answers(tmp_path):
     assert _same(list(get_string_vector_reader(np.int32, columns=3)([paths["square"]])), _rows(SQUARE_INT_ROWS, np.int32))
 
 
+@pytest.mark.filterwarnings("ignore:A mismatch in number of columns")
 def test_text_readers_known_answers(tmp_path):
     import gzip
     from neuralmonkey_amd.readers.plain_text_reader import (T2TReader, UtfPlainTextReader, csv_reader, t2t_tokenize,
