@@ -1,6 +1,12 @@
-"""MultitaskTrainer (mirror of neuralmonkey/trainers/multitask_trainer.py:12-48): a task-switching
-schedule -- every ``get_executable`` hands out the next trainer of the list, round robin
-(tests/bahdanau.ini)."""
+"""``MultitaskTrainer``: task switching by round robin (interface of
+neuralmonkey/trainers/multitask_trainer.py:12-48; used by tests/bahdanau.ini).
+
+The object is a trainer only by name: it owns no step of its own.  Each call of ``get_executable``
+returns the executable of the next wrapped trainer, so batch i is trained by trainer ``i mod n``.
+Every wrapped trainer keeps its own Adam slots and update count (see ``GenericTrainer._adam_state``),
+as TensorFlow's per-optimizer slot variables do in the reference.
+"""
+from itertools import chain
 from typing import Any, Dict, List
 
 from ..runners.base_runner import GraphExecutor
@@ -9,26 +15,24 @@ from .generic_trainer import GenericTrainer
 
 class MultitaskTrainer(GraphExecutor):
     def __init__(self, trainers: List[GenericTrainer]) -> None:
-        if not trainers:
+        if len(trainers) == 0:
             raise ValueError("MultitaskTrainer needs at least one trainer")
-        GraphExecutor.__init__(self, set(trainers))
+        super().__init__(set(trainers))
         self.trainers = trainers
-        self.trainer_idx = 0
-
-    def var_list(self, store) -> List[str]:
-        names: List[str] = []
-        for trainer in self.trainers:
-            names.extend(n for n in trainer.var_list(store) if n not in names)
-        return names
+        self.trainer_idx = 0                       # whose turn it is (the reference's attribute name)
 
     def get_executable(self, compute_losses: bool = True, summaries: bool = True, num_sessions: int = 1):
-        focused = self.trainers[self.trainer_idx]
-        self.trainer_idx = (self.trainer_idx + 1) % len(self.trainers)
-        return focused.get_executable(compute_losses, summaries, num_sessions)
+        turn, self.trainer_idx = self.trainer_idx, (self.trainer_idx + 1) % len(self.trainers)
+        return self.trainers[turn].get_executable(compute_losses, summaries, num_sessions)
 
     @property
     def fetches(self) -> Dict[str, Any]:
-        fetches: Dict[str, Any] = {}
+        """Union of the wrapped trainers' fetches (later trainers win on equal keys)."""
+        return dict(chain.from_iterable(trainer.fetches.items() for trainer in self.trainers))
+
+    def var_list(self, store) -> List[str]:
+        """Every variable some wrapped trainer updates, once, in first-seen order."""
+        seen: Dict[str, None] = {}
         for trainer in self.trainers:
-            fetches.update(trainer.fetches)
-        return fetches
+            seen.update(dict.fromkeys(trainer.var_list(store)))
+        return list(seen)
