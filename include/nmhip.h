@@ -136,9 +136,10 @@ int nm_attn_energy_bwd(void* stream, const float* de, const float* hf, const flo
  * mask == NULL).  Mask row of query row r: (r / rows_per_key) % B. */
 int nm_attn_softmax_fwd(void* stream, const float* e, const float* mask, float* w, int64_t rows, int64_t B,
                         int64_t S, int64_t rows_per_key);
-/* live HIP-event timing of the attn_partial kernel (bench.py roofline) */
+/* live HIP-event timing of one attention step = everything nm_attn_fwd launches (split-S partial kernel +
+ * combine), events recorded on the launch stream (bench.py roofline) */
 int nm_prof_enable(int on);
-int nm_prof_attn_partial(double* total_ms, int64_t* count);
+int nm_prof_attn_step(double* total_ms, int64_t* count);
 
 /* ---- vocabulary-axis rows: tf.argmax / tf.nn.log_softmax / sequence_loss ----------------------
  * decoders/autoregressive.py:470 (argmax, first max wins), :289-316,351-375 (xent, log-probs) */

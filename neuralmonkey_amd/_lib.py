@@ -41,7 +41,7 @@ SIGNATURES = {
     "nm_gru_gemm": (I, [P, P, I, L, P, L, L, P, L, L]),
     "nm_gru_seq_fwd": (I, [P, P, ctypes.c_int32, L, L, L, L, P, L, L, P, L, L, P, L]),
     "nm_prof_enable": (I, [I]),
-    "nm_prof_attn_partial": (I, [P, P]),
+    "nm_prof_attn_step": (I, [P, P]),
     "nm_row_stats": (I, [P, P, L, L, L, P, P, P]),
     "nm_greedy_update": (I, [P, P, P, P, P, L, I, P]),
     "nm_xent": (I, [P, P, L, L, L, P, P, P, P, I, F]),

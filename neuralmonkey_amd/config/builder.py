@@ -18,6 +18,34 @@ from .parsing import ClassSymbol, ObjectRef
 
 PACKAGE = __name__.rsplit(".", 2)[0]          # "neuralmonkey_amd"
 
+# [main] keys whose object graphs belong to the reference's host control plane (out of
+# scope: evaluators, series post-processing).  An INI written for the reference names classes there that
+# this package does not ship; such a class -- and only under these keys -- builds into an
+# ``OutOfScope`` placeholder so that the file loads unmodified (experiment.py:60-120 lists the keys).
+SOFT_MAIN_KEYS = frozenset(["evaluation", "postprocess"])
+
+
+class OutOfScope:
+    """Placeholder for an object of the reference's control plane (evaluator, postprocessor) that an
+    unmodified INI file names.  Remembers what was asked for; calling it is an error."""
+
+    def __init__(self, symbol: str, arguments: Dict[str, Any] = None) -> None:
+        self.symbol = symbol
+        self.arguments = dict(arguments or {})
+        self.name = self.arguments.get("name", symbol.rsplit(".", 1)[-1])
+
+    def __call__(self, *args, **kwargs):
+        raise NotImplementedError("{} belongs to the reference's host control plane and is not part of "
+                                  "the MI355X engine".format(self.symbol))
+
+    def __repr__(self):
+        return "OutOfScope({})".format(self.symbol)
+
+
+class _Soft:
+    """Build context of one [main] key: ``on`` while unresolvable classes may become placeholders."""
+    on = False
+
 
 def resolve_symbol(dotted: str) -> Any:
     parts = dotted.split(".")
@@ -62,6 +90,11 @@ def build_object(value: Any, all_dicts: Dict[str, Any], existing: Dict[str, Any]
         value.bind(existing[value.name])
         return value.target
     if isinstance(value, ClassSymbol):
+        if _Soft.on:
+            try:
+                return resolve_symbol(value.clazz)
+            except Exception:      # pylint: disable=broad-except
+                return OutOfScope(value.clazz)
         return resolve_symbol(value.clazz)
     return value
 
@@ -72,7 +105,13 @@ def instantiate_class(name: str, all_dicts: Dict[str, Any], existing: Dict[str, 
     section = all_dicts[name]
     if "class" not in section:
         raise ConfigInvalidValueException(name, "Undefined object type")
-    clazz = resolve_symbol(section["class"].clazz)
+    try:
+        clazz = resolve_symbol(section["class"].clazz)
+    except Exception:              # pylint: disable=broad-except
+        if not _Soft.on:
+            raise
+        return OutOfScope(section["class"].clazz,
+                          {k: v for k, v in section.items() if k != "class" and isinstance(v, (str, int, float))})
     if not isclass(clazz) and not isfunction(clazz):
         raise ConfigInvalidValueException(name, "Cannot instantiate object with '{}'".format(clazz))
     arguments = {key: build_object(val, all_dicts, existing, depth + 1)
@@ -100,8 +139,11 @@ def build_config(config_dicts: Dict[str, Any], ignore_names: Set[str],
     for key in sorted(main, key=lambda k: "zzz" if k == "tf_manager" else k):
         if key in ignore_names:
             continue
+        _Soft.on = key in SOFT_MAIN_KEYS
         try:
             configuration[key] = build_object(main[key], config_dicts, existing, 0)
         except Exception as exc:
             raise ConfigBuildException(key, exc) from None
+        finally:
+            _Soft.on = False
     return configuration, existing

@@ -29,8 +29,9 @@
 
 #define ATT_MAX_SCH 16
 
-// ---- optional live timing of attn_partial with HIP events on the launch stream
-// (bench.py's `roofline.achieved`); off by default, zero cost when off.
+// ---- optional live timing of the attention step (attn_partial* + attn_combine, i.e. everything
+// nm_attn_fwd launches) with HIP events on the launch stream (bench.py's `roofline.achieved`);
+// off by default, zero cost when off.
 static bool g_prof_on = false;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
 static size_t g_prof_used = 0;
@@ -41,15 +42,15 @@ extern "C" int nm_prof_enable(int on) {
     return NM_OK;
 }
 
-// Sum / count of the recorded attn_partial launches; resets the recorder.
-extern "C" int nm_prof_attn_partial(double* total_ms, int64_t* count) {
-    NM_REQUIRE(total_ms && count, "nm_prof_attn_partial: null pointer");
+// Sum / count of the recorded attention steps; resets the recorder.
+extern "C" int nm_prof_attn_step(double* total_ms, int64_t* count) {
+    NM_REQUIRE(total_ms && count, "nm_prof_attn_step: null pointer");
     double tot = 0.0;
     for (size_t i = 0; i < g_prof_used; ++i) {
         float ms = 0.0f;
         if (hipEventSynchronize(g_prof_pool[i].second) != hipSuccess ||
             hipEventElapsedTime(&ms, g_prof_pool[i].first, g_prof_pool[i].second) != hipSuccess)
-            NM_FAIL(NM_ERR_HIP, "nm_prof_attn_partial: event query failed");
+            NM_FAIL(NM_ERR_HIP, "nm_prof_attn_step: event query failed");
         tot += ms;
     }
     *total_ms = tot;
@@ -606,12 +607,12 @@ extern "C" int nm_attn_fwd_multi(void* stream, const float* y, const float* hf, 
         default: NM_AT(8); break;
     }
 #undef NM_AT
-    if (prof) hipEventRecord(prof->second, st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) NM_FAIL(NM_ERR_HIP, "nm_attn_fwd: partial launch failed: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(attn_combine, dim3((unsigned)R), dim3(256), 0, st, p.pctx, p.pstat, p.energies,
                        mask, ctx, (long)ldctx, weights, (int)S, (int)C, nchunk,
                        beam_layout ? (int)nq : 1, (int)Bk);
+    if (prof) hipEventRecord(prof->second, st);
     NM_LAUNCH_CHECK("nm_attn_fwd");
 }
 

@@ -88,3 +88,33 @@ def synthetic_dataset(seed=1234, batch=128, src_len=50, tgt_len=50, vocab=32000,
     if with_target:
         series["target"] = tgt
     return Dataset("synthetic", series, BatchingScheme(batch_size=batch))
+
+
+def load_baseline_weights(store, seed: int = 1234, std: float = 0.05) -> None:
+    """Random-init weights of BASELINE.md section 3 for the benchmark model: dense / embedding matrices and
+    the attention vector ~ N(0, std); the recurrent H x H blocks of the GRU kernels orthogonal
+    (tf.orthogonal_initializer, nn/ortho_gru_cell.py:20-41) with N(0, std) input rows; GRU gate bias 1,
+    every other bias 0; LayerNorm gamma 1, beta 0.  (The model parts' own default initialisers are
+    N(0, 0.001)-class and make attention and beam search degenerate.)"""
+    from .variables import orthogonal_initializer
+    rng = np.random.default_rng(seed)
+    ortho = orthogonal_initializer()
+    values = {}
+    for name in store.names():
+        shape = tuple(store[name].shape)
+        leaf = name.rsplit("/", 1)[-1]
+        if "OrthoGRUCell" in name and leaf == "kernel":
+            rows, cols = shape
+            hsz = cols // 2 if "/gates/" in name else cols
+            top = (rng.standard_normal((rows - hsz, cols)) * std).astype(np.float32)
+            rec = np.concatenate([ortho(rng, (hsz, hsz)) for _ in range(cols // hsz)], 1)
+            values[name] = np.concatenate([top, rec], 0)
+        elif "OrthoGRUCell" in name and "/gates/" in name and leaf == "bias":
+            values[name] = np.ones(shape, np.float32)
+        elif leaf == "gamma":
+            values[name] = np.ones(shape, np.float32)
+        elif len(shape) >= 2 or leaf == "attn_similarity_v":
+            values[name] = (rng.standard_normal(shape) * std).astype(np.float32)
+        else:
+            values[name] = np.zeros(shape, np.float32)
+    store.load_state_dict(values)

@@ -399,6 +399,8 @@ class BeamResult(NamedTuple):
     min_gap: float           # smallest (k-th)-( k+1-th) score gap seen (tie report)
     beam_ids: np.ndarray     # [steps,B,k] parent beam of each selection
     word_ids: np.ndarray     # [steps,B,k]
+    gaps: Optional[np.ndarray] = None   # [steps,B] smallest NON-ZERO relative gap between adjacent scores of
+                                        # the top k+1 (exact ties are ordered by index and are not near-ties)
 
 
 def length_penalty(lengths, alpha, dt):
@@ -440,7 +442,7 @@ def beam_search(params, spec: DecoderSpec, enc: EncoderOutput, beam_size: int,
     scores = np.zeros((bsz, k), dtype=dt)
     dec_step = 1
     min_gap = np.inf
-    beam_hist, word_hist = [], []
+    beam_hist, word_hist, gap_hist = [], [], []
 
     finished_row = np.full(vsz, -INF, dtype=dt)
     finished_row[PAD] = 0.0
@@ -455,6 +457,9 @@ def beam_search(params, spec: DecoderSpec, enc: EncoderOutput, beam_size: int,
         sc = hyp / length_penalty(hyp_len, length_normalization, dt)[:, :, None]  # :467-468
         flat = sc.reshape(bsz, k * vsz).astype(dt)
         top_sc, top_idx = top_k(flat, min(k + 1, flat.shape[1]))
+        adj = top_sc[:, :-1] - top_sc[:, 1:]
+        adj_rel = np.where(adj > 0, adj / np.maximum(np.abs(top_sc[:, :-1]), 1e-30), np.inf)
+        gap_hist.append(np.where(finished.all(axis=1), np.inf, adj_rel.min(axis=1)))
         if top_sc.shape[1] > k:
             live = ~finished.all(axis=1)
             if live.any():
@@ -482,7 +487,8 @@ def beam_search(params, spec: DecoderSpec, enc: EncoderOutput, beam_size: int,
     z = np.zeros((0, bsz, k), dtype=np.int64)
     return BeamResult(scores, token_ids, logprob_sum, lengths, finished, min_gap,
                       np.stack(beam_hist) if beam_hist else z,
-                      np.stack(word_hist) if word_hist else z)
+                      np.stack(word_hist) if word_hist else z,
+                      np.stack(gap_hist) if gap_hist else np.zeros((0, bsz)))
 
 
 def beam_tokens(res: BeamResult, rank: int = 1) -> Tuple[List[List[int]], float]:

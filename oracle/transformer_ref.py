@@ -270,6 +270,7 @@ class TransformerModel:
             fin_row[PAD] = 0.0
             bidx = torch.arange(bsz).view(-1, 1)
             step, min_gap = 1, float("inf")
+            self.beam_gaps = []        # per step [B]: smallest non-zero relative gap among the top k+1 scores
             while (step - 1) < max_steps and not bool(finished.all()):
                 fm = finished.to(dt).unsqueeze(-1)
                 lp = (1.0 - fm) * prev_lp + fm * fin_row
@@ -280,6 +281,9 @@ class TransformerModel:
                 order = torch.argsort(-flat, dim=1, stable=True)[:, :k + 1]
                 top = torch.gather(flat, 1, order)
                 live = ~finished.all(1)
+                adj = top[:, :-1] - top[:, 1:]
+                adj = torch.where(adj > 0, adj / top[:, :-1].abs().clamp_min(1e-30), torch.full_like(adj, float("inf")))
+                self.beam_gaps.append(torch.where(live, adj.min(1).values, torch.full_like(adj[:, 0], float("inf"))).numpy())
                 if order.shape[1] > k and bool(live.any()):
                     gap = (top[live, k - 1] - top[live, k]) / top[live, k - 1].abs().clamp_min(1e-30)
                     min_gap = min(min_gap, float(gap.min()))

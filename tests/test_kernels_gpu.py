@@ -189,6 +189,118 @@ def test_gru_bidirectional_encoder(dev):
     assert np.all(out.cpu().numpy()[1, 1:] == 0)          # beyond length stays zero
 
 
+def _split_gru_ref(xp, wgh, wch, lengths, h0=None):
+    """torch restatement of the biGRU on pre-projected inputs (the arithmetic of O.gru_cell /
+    O.bidirectional_rnn with the input half hoisted): xp [B,S,ndir,3H] = x.[Wg_x|Wc_x]+[bg|bc];
+    direction 1 walks each sentence backwards over its own length (reverse_sequence).  Returns
+    (states [B,S,ndir*H], final [ndir,B,H])."""
+    b, s, ndir, h3 = xp.shape
+    h = h3 // 3
+    outs = [[None] * s for _ in range(ndir)]
+    finals = []
+    ar = torch.arange(b)
+    for d in range(ndir):
+        hcur = xp.new_zeros(b, h) if h0 is None else h0[d]
+        per_pos = [[] for _ in range(s)]
+        for t in range(s):
+            live = t < lengths
+            pos = torch.where(live, (lengths - 1 - t) if d == 1 else torch.full_like(lengths, t),
+                              torch.zeros_like(lengths))
+            x_t = xp[ar, pos, d]
+            g = torch.sigmoid(x_t[:, :2 * h] + hcur @ wgh[d])
+            r, u = g[:, :h], g[:, h:]
+            c = torch.tanh(x_t[:, 2 * h:] + (r * hcur) @ wch[d])
+            hn = u * hcur + (1 - u) * c
+            hcur = torch.where(live[:, None], hn, hcur)
+            per_pos[t] = (pos, live, hn)
+        rows = []
+        for i in range(b):
+            row = [xp.new_zeros(h) for _ in range(s)]
+            for t in range(s):
+                pos, live, hn = per_pos[t]
+                if bool(live[i]):
+                    row[int(pos[i])] = hn[i]
+            rows.append(torch.stack(row))
+        outs[d] = torch.stack(rows)                   # [B,S,H]
+        finals.append(hcur)
+    return torch.cat(outs, 2), torch.stack(finals)
+
+
+@pytest.mark.parametrize("b,s,e,h", [(128, 6, 512, 512), (16, 5, 64, 64), (128, 4, 256, 1024)])
+def test_gru_gemm_fused_epilogues_fwd_bwd(dev, b, s, e, h):
+    """nm_gru_gemm modes 1-4 (recurrent GEMM + fused gate / blend epilogues, forward and BPTT) at the
+    headline shape R=128, H=512, both directions, ragged lengths: forward against O.bidirectional_rnn
+    (nn/ortho_gru_cell.py:44-53, encoders/recurrent.py:86-102), backward against autograd of the
+    restated forward."""
+    from neuralmonkey_amd import ops
+    from neuralmonkey_amd.nn import gru
+    rng = np.random.default_rng(b + s + h)
+    ndir = 2
+    pf, pb = _gru_params(rng, e, h, 0.05), _gru_params(rng, e, h, 0.05)
+    x = rng.standard_normal((b, s, e)).astype(np.float32)
+    lengths = rng.integers(1, s + 1, size=b).astype(np.int32)
+    lengths[0] = s
+    for i, ln in enumerate(lengths):
+        x[i, ln:] = 0
+    ref_states, ref_final = O.bidirectional_rnn(O.gru_cell, x, lengths, pf, pb)
+    wx = np.concatenate([pf["gates_kernel"][:e], pf["cand_kernel"][:e],
+                         pb["gates_kernel"][:e], pb["cand_kernel"][:e]], 1)       # [E, 6H]
+    bx = np.concatenate([pf["gates_bias"], pf["cand_bias"], pb["gates_bias"], pb["cand_bias"]])
+    xp = ops.gemm(T(x.reshape(b * s, e), dev), T(wx, dev), bias=T(bx, dev))      # [B*S, ndir*3H]
+    wgh_np = np.stack([pf["gates_kernel"][e:], pb["gates_kernel"][e:]])
+    wch_np = np.stack([pf["cand_kernel"][e:], pb["cand_kernel"][e:]])
+    wgh, wch = T(wgh_np, dev), T(wch_np, dev)
+    assert gru.fused_ok(b, h)
+    c_out = ndir * h
+    hcur = torch.zeros((ndir, b, h), device=dev)
+    states = torch.zeros((b, s, c_out), device=dev)
+    ru_all = torch.empty((s, ndir, b, 2 * h), device=dev)
+    c_all = torch.empty((s, ndir, b, h), device=dev)
+    rh = torch.empty((ndir, b, h), device=dev)
+    ld = T(lengths, dev, torch.int32)
+    xrs, xts, ors, ots = s * ndir * 3 * h, ndir * 3 * h, s * c_out, c_out
+    for t in range(s):
+        gru.step_fwd(xp, (3 * h, xrs, xts), hcur, hcur, wgh, wch, ru_all[t], rh, c_all[t], states,
+                     (h, ors, ots), ld, t, ndir, b, h, False, None, None)
+    assert rel_err(states.cpu().numpy(), ref_states) < RTOL
+    assert rel_err(torch.cat([hcur[0], hcur[1]], 1).cpu().numpy(), ref_final) < RTOL
+
+    # ---- backward: random upstream gradients on the states and on the final states
+    d_states = rng.standard_normal((b, s, c_out)).astype(np.float32)
+    for i, ln in enumerate(lengths):
+        d_states[i, ln:] = 0                              # dead positions emit zeros: no gradient path
+    d_final = rng.standard_normal((ndir, b, h)).astype(np.float32)
+    xp_ref = torch.tensor(xp.cpu().numpy().astype(np.float64).reshape(b, s, ndir, 3 * h), requires_grad=True)
+    wg_ref = torch.tensor(wgh_np.astype(np.float64), requires_grad=True)
+    wc_ref = torch.tensor(wch_np.astype(np.float64), requires_grad=True)
+    st, fin = _split_gru_ref(xp_ref, wg_ref, wc_ref, torch.tensor(lengths.astype(np.int64)))
+    assert rel_err(st.detach().numpy(), ref_states) < 1e-5        # the restatement IS the oracle's forward
+    ((st * torch.tensor(d_states.astype(np.float64))).sum()
+     + (fin * torch.tensor(d_final.astype(np.float64))).sum()).backward()
+    dh = T(d_final, dev)
+    dxp = torch.zeros((b * s, ndir * 3 * h), device=dev)
+    dgpre = torch.empty((2, ndir, b, 2 * h), device=dev)
+    dcpre = torch.empty((ndir, b, h), device=dev)
+    drh = torch.empty((ndir, b, h), device=dev)
+    seq_strides = (h, s * c_out, c_out)
+    gru.bptt(s, dh, T(d_states, dev), seq_strides, ru_all, c_all, None, states, seq_strides, dxp,
+             (3 * h, xrs, xts), wgh, wch, ld, ndir, b, h, False, dgpre, dcpre, drh)
+    want = xp_ref.grad.numpy().reshape(b * s, ndir * 3 * h)
+    assert rel_err(dxp.cpu().numpy(), want) < 1e-4
+    # weight gradients assembled from the kernel's pre-activation gradients == autograd's
+    hprev = torch.empty((b, s, ndir, h), device=dev)
+    rh_seq = torch.empty((b, s, ndir, h), device=dev)
+    ops.gru_seq_shift(states, hprev, ld, ndir, h)
+    ops.gru_rh_seq(ru_all, hprev, rh_seq, ld, ndir, h)
+    for d in range(ndir):
+        dg = dxp[:, d * 3 * h:d * 3 * h + 2 * h]
+        dc = dxp[:, d * 3 * h + 2 * h:(d + 1) * 3 * h]
+        g_wg = ops.gemm(hprev.view(b * s, c_out)[:, d * h:(d + 1) * h], dg, trans_a=True)
+        g_wc = ops.gemm(rh_seq.view(b * s, c_out)[:, d * h:(d + 1) * h], dc, trans_a=True)
+        assert rel_err(g_wg.cpu().numpy(), wg_ref.grad[d].numpy()) < 2e-4
+        assert rel_err(g_wc.cpu().numpy(), wc_ref.grad[d].numpy()) < 2e-4
+
+
 # --------------------------------------------------------------------------- #
 @pytest.mark.parametrize("bk,qpk,s,a,c,ragged", [
     (16, 1, 50, 1024, 1024, False),

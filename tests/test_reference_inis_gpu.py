@@ -1,0 +1,90 @@
+"""GPU half of test_reference_inis.py: each of the reference's acceptance configs, loaded byte for byte
+from tests/golden/reference_tests.tar.gz with the working directory at the bundle root (its own
+tests/data), initialises its variables on the MI355X, runs optimizer steps through
+``TensorFlowManager.execute`` exactly as the reference's training loop does (learning_utils.py:193-235)
+and decodes a validation batch with every runner the file lists.
+
+The last test is the reference's ensemble invariant on its own files (tests/tests_run.sh:41-50): the
+model of tests/beamsearch.ini, trained for a few steps and saved, scores the validation data exactly as
+tests/beamsearch_ensembles.ini does with that checkpoint loaded into all four of its sessions.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from .test_reference_inis import INIS, load_verbatim, ref_root  # noqa: F401  pylint: disable=unused-import
+
+pytestmark = pytest.mark.gpu
+
+
+def _feedables(model):
+    return set.union(*[r.feedables for r in model.runners + model.trainers])
+
+
+@pytest.mark.parametrize("name", INIS)
+def test_reference_ini_trains_and_decodes(dev, ref_root, name):      # noqa: F811
+    model = load_verbatim(ref_root, name, device=str(dev), seed=1234)
+    tfm = model.tf_manager
+    feedables = _feedables(model)
+    scheme = getattr(model.train_dataset, "batching", None)
+    batches = []
+    for batch in model.train_dataset.batches() if scheme is not None and scheme.batch_size else \
+            model.train_dataset.batches(_scheme(model.batch_size)):
+        batches.append(batch)
+        if len(batches) == 3:
+            break
+    assert len(batches) == 3
+    step0 = tfm.sessions[0].global_step
+    losses = []
+    for batch in batches:
+        res = tfm.execute(batch, feedables, model.trainers, train=True)
+        assert len(res) == len(model.trainers)
+        for r in res:
+            assert r.losses and all(np.isfinite(v) for v in r.losses.values()), r.losses
+        losses.append(sum(res[0].losses.values()))
+    assert tfm.sessions[0].global_step > step0 or name == "transformer"     # DelayedUpdateTrainer: every 2nd batch
+    val = next(model.val_dataset.batches() if getattr(model.val_dataset, "batching", None) is not None
+               and model.val_dataset.batching.batch_size else model.val_dataset.batches(_scheme(model.batch_size)))
+    out = tfm.execute(val, feedables, model.runners, compute_losses=True)
+    assert len(out) == len(model.runners)
+    for runner, result in zip(model.runners, out):
+        series = runner.output_series
+        rows = result.outputs[series] if isinstance(result.outputs, dict) else result.outputs
+        assert len(rows) == len(val), (series, len(rows), len(val))
+    # every evaluated series of the file is produced by one of its runners (the evaluators themselves are
+    # host control plane: placeholders)
+    produced = {r.output_series for r in model.runners}
+    assert {item[0] for item in model.evaluation} <= produced
+
+
+def _scheme(batch_size):
+    from neuralmonkey_amd.dataset import BatchingScheme
+    return BatchingScheme(batch_size=batch_size)
+
+
+def test_reference_ensemble_invariant_on_its_own_configs(dev, ref_root, tmp_path):     # noqa: F811
+    single = load_verbatim(ref_root, "beamsearch", device=str(dev), seed=1234)
+    tfm = single.tf_manager
+    feedables = _feedables(single)
+    n = 0
+    for batch in single.train_dataset.batches(_scheme(single.batch_size)):
+        tfm.execute(batch, feedables, single.trainers, train=True)
+        n += 1
+        if n == 12:
+            break
+    ckpt = str(tmp_path / "variables.data.0")
+    tfm.save(ckpt)
+    val = single.val_dataset.subset(0, 10)                  # tests/test_data_ensembles_*.ini: batch_size=10
+    run_feed = set.union(*[r.feedables for r in single.runners])
+    one = tfm.execute(val, run_feed, single.runners, compute_losses=True)
+    ens = load_verbatim(ref_root, "beamsearch_ensembles", device=str(dev), seed=99)
+    assert len(ens.tf_manager.sessions) == 4
+    ens.tf_manager.restore([ckpt] * 4)                      # test_data_ensembles_duplicate.ini: variables=[x]*4
+    ens_feed = set.union(*[r.feedables for r in ens.runners])
+    four = ens.tf_manager.execute(ens.val_dataset.subset(0, 10), ens_feed, ens.runners, compute_losses=True)
+    for a, b in zip(one, four):
+        assert a.outputs == b.outputs
+        ka = [k for k in a.losses if k.endswith("beam_search_score")]
+        for k in ka:          # tests_run.sh compares the first 8 characters of the two printed scores
+            assert abs(a.losses[k] - b.losses[k]) <= 1e-5 * max(1.0, abs(a.losses[k])), (k, a.losses[k], b.losses[k])

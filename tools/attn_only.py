@@ -1,5 +1,6 @@
-"""Runs only the fused attention step at the benchmark shape (for PMC passes:
-rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE -- python tools/attn_only.py)."""
+"""Runs only the fused attention step at the benchmark shape (for PMC / kernel-trace passes:
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python tools/attn_only.py [queries_per_key] [iters] [cold|warm]).
+"cold" (default): a 1 GiB fill between launches evicts hf / states from the 256 MB Infinity Cache."""
 import os
 import sys
 
@@ -11,6 +12,7 @@ from neuralmonkey_amd import ops  # noqa: E402
 B, S, A, C = 128, 50, 1024, 1024
 qpk = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+cold = (sys.argv[3] if len(sys.argv) > 3 else "cold") == "cold"
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(0)
 r = B * qpk
@@ -23,11 +25,12 @@ bias = torch.zeros(1, device=dev)
 ctx = torch.empty(r, C, device=dev)
 w = torch.empty(r, S, device=dev)
 ws = ops.attn_workspace(r, S, C, dev)
-# a 512 MB sweep between launches evicts hf/states from the 256 MB Infinity Cache so the
+# a 1 GiB sweep between launches evicts hf/states from the 256 MB Infinity Cache so the
 # counters see HBM traffic, as inside a training step where 800 MB of logits pass in between
-flush = torch.empty(128 << 20, device=dev)
+flush = torch.empty(256 << 20, device=dev)
 for i in range(iters):
-    flush.fill_(float(i))
+    if cold:
+        flush.fill_(float(i))
     ops.attn_fwd(y, hf, st, mask, v, bias, qpk, ctx, w, ws)
 torch.cuda.synchronize()
 print("done", float(ctx.sum()))
