@@ -271,7 +271,7 @@ def main():
 
     # cold: the same launch at the same shape with a 1 GB sweep in between (evicts the 256 MB Infinity
     # Cache), as inside a training step where 800 MB of logits pass between two uses of the keys
-    cold_us = cold_n = None
+    cold_us = cold_n = dirty_us = None
     if rank == 0:
         a = c = 2 * h
         gen = torch.Generator(device=dev).manual_seed(0)
@@ -284,19 +284,29 @@ def main():
         ctx = torch.empty(args.batch, c, device=dev)
         wts = torch.empty(args.batch, args.length, device=dev)
         ws = ops.attn_workspace(args.batch, args.length, c, dev)
-        flush = torch.empty(256 << 20, device=dev)                      # 1 GiB of fp32
-        for i in range(3):
-            flush.fill_(float(i))
-            ops.attn_fwd(y, hf, st, mask, vv, bias, 1, ctx, wts, ws)
-        torch.cuda.synchronize()
-        lib.nm_prof_enable(1)
-        for i in range(20):
-            flush.fill_(float(i))
-            ops.attn_fwd(y, hf, st, mask, vv, bias, 1, ctx, wts, ws)
-        torch.cuda.synchronize()
-        lib.nm_prof_enable(0)
-        lib.nm_prof_attn_step(ctypes.byref(tot_ms), ctypes.byref(cnt))
-        cold_us, cold_n = (tot_ms.value * 1e3 / cnt.value) if cnt.value else None, cnt.value
+        flush = torch.zeros(256 << 20, device=dev)                      # 1 GiB of fp32
+        sink = torch.zeros(1, device=dev)
+
+        def cold_pass(n, dirty):
+            """n launches, each preceded by a sweep over 1 GiB: read-only (the caches are left holding CLEAN
+            lines of the sweep) or written (DIRTY lines: the launch then also pays for their write-back)."""
+            for i in range(n):
+                if dirty:
+                    flush.fill_(float(i))
+                else:
+                    sink.add_(flush.sum())
+                ops.attn_fwd(y, hf, st, mask, vv, bias, 1, ctx, wts, ws)
+            torch.cuda.synchronize()
+
+        def measure(dirty):
+            cold_pass(3, dirty)
+            lib.nm_prof_enable(1)
+            cold_pass(20, dirty)
+            lib.nm_prof_enable(0)
+            lib.nm_prof_attn_step(ctypes.byref(tot_ms), ctypes.byref(cnt))
+            return ((tot_ms.value * 1e3 / cnt.value) if cnt.value else None), cnt.value
+        cold_us, cold_n = measure(False)
+        dirty_us, _ = measure(True)
         del flush
 
     if rank == 0:
@@ -335,8 +345,11 @@ def main():
                          "frac": (cold / HBM_PEAK_GBPS) if cold else None, "traffic": traffic,
                          "traffic_kernels": pmc_kernels,
                          "achieved_cold": cold, "cold_launch_us": cold_us, "cold_launches": cold_n,
-                         "cold_how": "1 GiB fill between launches (Infinity Cache evicted), HIP events around "
-                                     "partial+combine",
+                         "cold_how": "1 GiB read sweep between launches (L2 + 256 MB Infinity Cache evicted, clean "
+                                     "lines), HIP events around partial+combine",
+                         "cold_dirty_launch_us": dirty_us,
+                         "cold_dirty_how": "the same with a 1 GiB WRITE sweep: the caches hold dirty lines whose "
+                                           "write-back competes with the kernel's reads",
                          "achieved_warm": warm, "frac_warm": (warm / HBM_PEAK_GBPS) if warm else None,
                          "warm_launch_us": warm_us, "warm_launches": warm_n,
                          "warm_how": "inside a greedy decode of one B={} batch, {} steps, launched eagerly".format(

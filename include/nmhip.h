@@ -174,6 +174,33 @@ int nm_beam_topk_step_fused(void* stream, const float* logits, int64_t ldx, int6
                             int32_t* out_beam, float* out_logprob_sum, int32_t* out_lengths,
                             int32_t* out_finished, int32_t* out_src_row, void* workspace,
                             int64_t workspace_bytes, int32_t* all_finished, float* rmax_out, float* rlse_out);
+/* ---- the vocabulary projection with its row statistics in the GEMM epilogue ----------------------------
+ * decoders/autoregressive.py:450-459 (logits = state.W + b) fused with what the decoding loops do to the
+ * logits next: tf.argmax (:470) and tf.nn.log_softmax (beam_search_decoder.py:537-543).  Every 128-column
+ * tile of a row leaves {max, sum exp(x - max), first argmax (int bits), -} in stats[row][tile]; the logits
+ * themselves are written only when C != NULL (greedy decoding never reads them back: nm_greedy_finish works
+ * on the statistics; a beam step reads back only the tiles that can hold a top-k candidate).
+ * transB: B stored [N,K] (tied embeddings).  A, B 16-byte aligned, K, N, lda, ldb multiples of 4. */
+int64_t nm_logits_stats_tile(void);                       /* columns per statistics tile (128) */
+int64_t nm_logits_stats_bytes(int64_t M, int64_t N);
+int nm_logits_stats_gemm(void* stream, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                         const float* B, int64_t ldb, const float* bias, float* C /* or NULL */, int64_t ldc,
+                         float* stats, int64_t stats_bytes);
+/* greedy step tail on the statistics (decoders/autoregressive.py:461-480 + the embedding lookup of the next
+ * input, :269-272): sym = finished ? 0 : argmax; finished |= sym == </s>; mask = !finished;
+ * emb_out[r,:] = table[sym[r],:] (skipped when emb_out == NULL).  argmax / max / lse outputs optional. */
+int nm_greedy_finish(void* stream, const float* stats, int64_t ntiles, int64_t R, int32_t* finished,
+                     int32_t* sym_out, int32_t* mask_out, int end_id, int32_t* all_finished, const float* table,
+                     int64_t V, int64_t E, float* emb_out, int64_t ld_emb, int32_t* argmax_out, float* max_out,
+                     float* lse_out);
+/* nm_beam_topk_step_fused on logits whose tile statistics are known: max / lse from the merged tiles, the
+ * exact top-k from the few tiles whose maximum can reach it (same scores, same tie order) */
+int nm_beam_topk_step_tiles(void* stream, const float* logits, int64_t ldx, const float* stats, int64_t ntiles,
+                            int64_t B, int64_t k, int64_t V, const float* logprob_sum, const int32_t* lengths,
+                            const int32_t* finished, const float* penalty, int end_id, float* out_score,
+                            int32_t* out_word, int32_t* out_beam, float* out_logprob_sum, int32_t* out_lengths,
+                            int32_t* out_finished, int32_t* out_src_row, void* workspace, int64_t workspace_bytes,
+                            int32_t* all_finished, float* rmax_out, float* rlse_out);
 int nm_gather_rows_f32(void* stream, const float* src, int64_t ld_src, const int32_t* idx, float* dst,
                        int64_t ld_dst, int64_t rows, int64_t width);
 int nm_beam_reorder_tokens(void* stream, const int32_t* src, const int32_t* src_row, const int32_t* word,

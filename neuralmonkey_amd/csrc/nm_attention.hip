@@ -390,6 +390,11 @@ __global__ __launch_bounds__(256) void attn_partial_fastq(AttnArgs p) {
     }
 }
 
+// Merge of the split-S partials of one query row.  Latency-bound (2.6 MB in, 0.5 MB out over 128 rows), so
+// nothing waits on anything it does not need: every thread issues its loads of the partial contexts first,
+// derives the chunk scales from the (broadcast) statistics by itself -- no LDS, no barrier -- and the
+// first S threads write the normalised weights.
+#define ATT_COMBINE_MAXCH 8
 __global__ __launch_bounds__(256) void attn_combine(const float* __restrict__ pctx,
                                                     const float* __restrict__ pstat,
                                                     const float* __restrict__ energies,
@@ -397,19 +402,65 @@ __global__ __launch_bounds__(256) void attn_combine(const float* __restrict__ pc
                                                     float* __restrict__ ctx, long ldctx,
                                                     float* __restrict__ weights, int S, int C,
                                                     int nchunk, int mask_div, int mask_mod) {
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const float* pc = pctx + (long)r * nchunk * C;
+    const float4* st = reinterpret_cast<const float4*>(pstat) + (long)r * nchunk;
+    if (nchunk <= ATT_COMBINE_MAXCH && C <= 1024) {
+        const int c = tid * 4;
+        const bool c_ok = c < C;
+        float4 x[ATT_COMBINE_MAXCH];
+#pragma unroll
+        for (int i = 0; i < ATT_COMBINE_MAXCH; ++i)
+            x[i] = (c_ok && i < nchunk) ? *reinterpret_cast<const float4*>(pc + (long)i * C + c)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int b = (r / mask_div) % mask_mod;      // key batch of row r in either query layout
+        float e_s = 0.0f, mk = 1.0f;
+        const bool w_ok = weights && tid < S;
+        if (w_ok) {
+            e_s = energies[(long)r * S + tid];
+            if (mask) mk = mask[(long)b * S + tid];
+        }
+        float4 sv[ATT_COMBINE_MAXCH];
+        float M = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < ATT_COMBINE_MAXCH; ++i) {
+            sv[i] = i < nchunk ? st[i] : make_float4(-INFINITY, 0.f, 0.f, 0.f);
+            M = fmaxf(M, sv[i].x);
+        }
+        float la = 0.0f, lm = 0.0f;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < ATT_COMBINE_MAXCH; ++i) {
+            const float f = i < nchunk ? __expf(sv[i].x - M) : 0.0f;
+            la += f * sv[i].y;
+            lm += f * sv[i].z;
+            a.x += f * x[i].x; a.y += f * x[i].y; a.z += f * x[i].z; a.w += f * x[i].w;
+        }
+        const float inv = 1.0f / (lm + 1e-8f * la);
+        if (c_ok) {
+            a.x *= inv; a.y *= inv; a.z *= inv; a.w *= inv;
+            *reinterpret_cast<float4*>(ctx + (long)r * ldctx + c) = a;
+        }
+        if (w_ok) weights[(long)r * S + tid] = __expf(e_s - M) * mk * inv;
+        if (weights)
+            for (int s = tid + 256; s < S; s += 256) {
+                const float m2 = mask ? mask[(long)b * S + s] : 1.0f;
+                weights[(long)r * S + s] = __expf(energies[(long)r * S + s] - M) * m2 * inv;
+            }
+        return;
+    }
     __shared__ float sc[64];
     __shared__ float sden, smax;
-    const int r = blockIdx.x, tid = threadIdx.x;
     if (tid == 0) {
         float M = -INFINITY;
         for (int i = 0; i < nchunk; ++i) M = fmaxf(M, pstat[((long)r * nchunk + i) * 4]);
         float la = 0.0f, lm = 0.0f;
         for (int i = 0; i < nchunk; ++i) {
-            const float* st = pstat + ((long)r * nchunk + i) * 4;
-            const float f = __expf(st[0] - M);
+            const float* s4 = pstat + ((long)r * nchunk + i) * 4;
+            const float f = __expf(s4[0] - M);
             sc[i] = f;
-            la += f * st[1];
-            lm += f * st[2];
+            la += f * s4[1];
+            lm += f * s4[2];
         }
         sden = lm + 1e-8f * la;
         smax = M;

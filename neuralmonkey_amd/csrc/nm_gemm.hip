@@ -36,6 +36,8 @@ struct GemmArgs {
     float* ws;       // split-K slabs [splitk][M][N] (raw partial sums) or null
     int splitk;      // K slices handled by blockIdx.y; 1 = write C directly
     int swizzle;     // XCD-aware tile order (gemm_tiled)
+    float* stats;    // [M][tiles_n][4] per-tile row statistics (max, sum exp(x-max), argmax bits, -) or null
+    int store_c;     // 0: the statistics are the only output (greedy decoding never reads the logits)
 };
 
 __device__ __forceinline__ float apply_act(float x, int act) {
@@ -67,7 +69,7 @@ __device__ __forceinline__ void store_tile32(const GemmArgs& g, float* __restric
 // tiled kernel
 // ---------------------------------------------------------------------------
 // WM x WN waves, each owning TM x TN MFMA tiles of 32x32: block tile (WM*32*TM) x (WN*32*TN).
-template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool VEC, int BK>
+template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool VEC, int BK, bool STATS = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_tiled(GemmArgs g, int tiles_m) {
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * 32 * TM, BN = WN * 32 * TN;
@@ -272,6 +274,93 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tiled(GemmArgs g, int tiles
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 store_tile32(gs, slab, acc[i][j], m0 + wm + i * 32, n0 + wn + j * 32, lane);
+        return;
+    }
+    if constexpr (STATS) {
+        // ---- vocabulary-axis statistics of this tile's rows, straight from the accumulators
+        // (tf.argmax / tf.nn.log_softmax over the logits, decoders/autoregressive.py:470,
+        // beam_search_decoder.py:537-543): per row the tile's max, its first argmax and
+        // sum exp(x - max); nm_greedy_finish / the beam tile scan merge the tiles of a row.
+        // The logits themselves are stored only when somebody reads them (g.store_c).
+        __shared__ float sx_max[WN][BM];
+        __shared__ int sx_arg[WN][BM];
+        __shared__ float sx_sum[WN][BM];
+        const int wcol = wave % WN;
+        int colj[TN];
+        bool okj[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            colj[j] = n0 + wn + j * 32 + (lane & 31);
+            okj[j] = colj[j] < g.N;
+            const float bv = (okj[j] && g.bias) ? g.bias[colj[j]] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += bv;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float best = -INFINITY;
+                int bi = 0x7fffffff;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)          // ascending columns, strict >: the first maximum is kept
+                    if (okj[j] && acc[i][j][r] > best) { best = acc[i][j][r]; bi = colj[j]; }
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) {
+                    const float ov = __shfl_xor(best, off, 64);
+                    const int oi = __shfl_xor(bi, off, 64);
+                    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+                }
+                if ((lane & 31) == 0) {
+                    const int rl = wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    sx_max[wcol][rl] = best;
+                    sx_arg[wcol][rl] = bi;
+                }
+            }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float m = sx_max[0][rl];
+#pragma unroll
+                for (int w = 1; w < WN; ++w) m = fmaxf(m, sx_max[w][rl]);
+                float sum = 0.0f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    if (okj[j]) sum += expf(acc[i][j][r] - m);
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+                if ((lane & 31) == 0) sx_sum[wcol][rl] = sum;
+            }
+        __syncthreads();
+        const int tiles_n = (int)gridDim.x / tiles_m;
+        for (int rl = tid; rl < BM; rl += NT) {
+            const int row = m0 + rl;
+            if (row >= g.M) continue;
+            float m = sx_max[0][rl], sum = sx_sum[0][rl];
+            int a = sx_arg[0][rl];
+#pragma unroll
+            for (int w = 1; w < WN; ++w) {
+                const float om = sx_max[w][rl];
+                if (om > m || (om == m && sx_arg[w][rl] < a)) { m = om; a = sx_arg[w][rl]; }
+                sum += sx_sum[w][rl];
+            }
+            float4 rec;
+            rec.x = m; rec.y = sum; rec.z = __int_as_float(a); rec.w = 0.0f;
+            *reinterpret_cast<float4*>(g.stats + ((long)row * tiles_n + bn) * 4) = rec;
+        }
+        if (!g.store_c) return;
+        GemmArgs gs = g;
+        gs.bias = nullptr;                    // already added above
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                store_tile32(gs, C, acc[i][j], m0 + wm + i * 32, n0 + wn + j * 32, lane);
         return;
     }
 #pragma unroll
@@ -622,7 +711,7 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_fwd_kernel(GruSeq q) {
         e.rh += (long)t * q.rh_step;
         if (e.c_save) e.c_save += (long)t * q.c_step;
         GemmArgs g{e.h_in, q.wg, nullptr, nullptr, R, 2 * H, H, (long)H, q.ldg, 0, (long)R * H, q.sg, 0,
-                   0, 0, nullptr, 1, 0};
+                   0, 0, nullptr, 1, 0, nullptr, 1};
         e.mode = 1;                               // r|u = sigmoid(xp + h.Wg_h), rh = r*h
         for (int w = (int)blockIdx.x; w < tiles_a * q.ndir; w += P) {
             skinny16_tile<KS, false>(g, tiles_m, e, w % tiles_a, w / tiles_a, red);
@@ -711,7 +800,7 @@ extern "C" int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int6
     if (M == 0 || N == 0) return NM_OK;
     NM_REQUIRE(K > 0, "nm_gemm_f32: K == 0");
     GemmArgs g{A, B, C, bias, (int)M, (int)N, (int)K, (long)lda, (long)ldb, (long)ldc,
-               (long)strideA, (long)strideB, (long)strideC, act, accumulate, nullptr, 1, 0};
+               (long)strideA, (long)strideB, (long)strideC, act, accumulate, nullptr, 1, 0, nullptr, 1};
     static const int swz_env = getenv("NM_GEMM_SWZ") ? atoi(getenv("NM_GEMM_SWZ")) : 1;   // A/B switch
     g.swizzle = swz_env;
     hipStream_t st = nm_stream(stream);
@@ -804,7 +893,7 @@ extern "C" int nm_gru_gemm(void* stream, const nm_gru_epilogue* e, int transB, i
                     "nm_gru_gemm: missing backward operand");
     const int64_t N = (e->mode == 1) ? 2 * e->H : e->H;
     GemmArgs g{A, B, e->dh, nullptr, (int)e->R, (int)N, (int)K, (long)lda, (long)ldb, (long)e->H,
-               (long)strideA, (long)strideB, (long)(e->R * e->H), 0, e->mode == 4 ? 1 : 0, nullptr, 1, 0};
+               (long)strideA, (long)strideB, (long)(e->R * e->H), 0, e->mode == 4 ? 1 : 0, nullptr, 1, 0, nullptr, 1};
     GruEpi d;
     d.mode = e->mode; d.lengths = e->lengths; d.t = e->t; d.rev_mask = e->rev_mask; d.H = (int)e->H; d.R = e->R;
     d.xp = e->xp; d.x_dir = e->x_dir; d.x_row = e->x_row; d.x_time = e->x_time;
@@ -861,4 +950,39 @@ extern "C" int nm_gru_seq_fwd(void* stream, const nm_gru_epilogue* e, int32_t st
     const int P = (int)(tiles < ncu ? tiles : ncu);
     hipLaunchKernelGGL((gru_seq_fwd_kernel<16>), dim3(P), dim3(1024), 0, st, q);
     NM_LAUNCH_CHECK("nm_gru_seq_fwd");
+}
+
+// ---------------------------------------------------------------------------
+// vocabulary projection with the row statistics in the GEMM epilogue
+// ---------------------------------------------------------------------------
+#define NM_STATS_TILE 128
+extern "C" int64_t nm_logits_stats_tile(void) { return NM_STATS_TILE; }
+
+extern "C" int64_t nm_logits_stats_bytes(int64_t M, int64_t N) {
+    if (M <= 0 || N <= 0) return 0;
+    return M * ((N + NM_STATS_TILE - 1) / NM_STATS_TILE) * 4 * (int64_t)sizeof(float);
+}
+
+extern "C" int nm_logits_stats_gemm(void* stream, int transB, int64_t M, int64_t N, int64_t K, const float* A,
+                                    int64_t lda, const float* B, int64_t ldb, const float* bias, float* C,
+                                    int64_t ldc, float* stats, int64_t stats_bytes) {
+    NM_REQUIRE(A && B && stats, "nm_logits_stats_gemm: null operand");
+    NM_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1 << 30) && N < (1 << 30) && K < (1 << 30),
+               "nm_logits_stats_gemm: bad shape %ld %ld %ld", (long)M, (long)N, (long)K);
+    NM_REQUIRE(stats_bytes >= nm_logits_stats_bytes(M, N) && nm_aligned16(stats),
+               "nm_logits_stats_gemm: statistics buffer too small / unaligned");
+    NM_REQUIRE(!C || ldc >= N, "nm_logits_stats_gemm: ldc < N");
+    const bool tb = transB != 0;
+    const bool vec = nm_aligned16(A) && lda % 4 == 0 && K % 4 == 0 && nm_aligned16(B) && ldb % 4 == 0 &&
+                     ((tb ? K : N) % 4 == 0);
+    NM_REQUIRE(vec, "nm_logits_stats_gemm: operands must be 16-byte aligned with K, N and the leading dimensions "
+                    "multiples of 4");
+    GemmArgs g{A, B, C, bias, (int)M, (int)N, (int)K, (long)lda, (long)ldb, (long)(C ? ldc : 0), 0, 0, 0, 0, 0,
+               nullptr, 1, 1, stats, C ? 1 : 0};
+    const int tiles_m = nm_cdiv(M, 128), tiles_n = nm_cdiv(N, NM_STATS_TILE);
+    dim3 grid(tiles_m * tiles_n, 1, 1), block(512);
+    hipStream_t st = nm_stream(stream);
+    if (tb) hipLaunchKernelGGL((gemm_tiled<4, 2, 1, 2, false, true, true, 16, true>), grid, block, 0, st, g, tiles_m);
+    else hipLaunchKernelGGL((gemm_tiled<4, 2, 1, 2, false, false, true, 16, true>), grid, block, 0, st, g, tiles_m);
+    NM_LAUNCH_CHECK("nm_logits_stats_gemm");
 }

@@ -785,6 +785,271 @@ extern "C" int nm_beam_topk_step_fused(void* stream, const float* logits, int64_
     NM_LAUNCH_CHECK("nm_beam_topk_step_fused");
 }
 
+// ---------------------------------------------------------------------------------------------
+// Consumers of the per-tile row statistics that nm_logits_stats_gemm leaves behind
+// (stats[row][tile] = {max, sum exp(x - max), argmax bits, -}, tiles of NM_STATS_TILE columns).
+// ---------------------------------------------------------------------------------------------
+#define NM_STATS_TILE 128
+
+// merge the tiles of one row: global max, first argmax, lse = log(sum exp(x - max)); every thread of the
+// block returns the same values.  `sh` needs 3 * (NT/64) words.
+template <int NT>
+__device__ __forceinline__ void merge_row_tiles(const float4* __restrict__ st, int ntiles, float& M, int& A, float& lse,
+                                                float* shf, int* shi) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int t = threadIdx.x; t < ntiles; t += NT) {
+        const float4 r = st[t];
+        const int a = __float_as_int(r.z);
+        if (r.x > bv || (r.x == bv && a < bi)) { bv = r.x; bi = a; }
+    }
+    block_argmax<NT>(bv, bi, shf, shi);
+    float s = 0.0f;
+    for (int t = threadIdx.x; t < ntiles; t += NT) {
+        const float4 r = st[t];
+        s += r.y * expf(r.x - bv);
+    }
+    s = block_sum<NT>(s, shf);
+    M = bv; A = bi; lse = logf(s);
+}
+
+// greedy step tail (decoders/autoregressive.py:461-480) on the tile statistics: argmax over the
+// vocabulary, symbol zeroing / finished update (nm_greedy_update) and the embedding lookup of the new
+// symbol (autoregressive.py:269-272), one workgroup per sentence.
+__global__ __launch_bounds__(256) void greedy_finish_kernel(const float4* __restrict__ stats, int ntiles,
+                                                            int* __restrict__ finished, int* __restrict__ sym_out,
+                                                            int* __restrict__ mask_out, int end_id,
+                                                            int* __restrict__ all_finished,
+                                                            const float* __restrict__ table, int V, int E,
+                                                            float* __restrict__ emb_out, long ld_emb,
+                                                            int* __restrict__ argmax_out, float* __restrict__ max_out,
+                                                            float* __restrict__ lse_out) {
+    __shared__ float shf[4];
+    __shared__ int shi[4];
+    __shared__ int sym_s;
+    const int r = blockIdx.x;
+    float M, lse;
+    int A;
+    merge_row_tiles<256>(stats + (long)r * ntiles, ntiles, M, A, lse, shf, shi);
+    if (threadIdx.x == 0) {
+        int f = finished[r];
+        const int s = f ? 0 : A;
+        f = f | (s == end_id);
+        finished[r] = f;
+        sym_out[r] = s;
+        if (mask_out) mask_out[r] = !f;
+        if (all_finished && !f) atomicAnd(all_finished, 0);
+        if (argmax_out) argmax_out[r] = A;
+        if (max_out) max_out[r] = M;
+        if (lse_out) lse_out[r] = lse;
+        sym_s = s;
+    }
+    __syncthreads();
+    if (!emb_out) return;
+    int s = sym_s;
+    s = s < 0 ? 0 : (s >= V ? V - 1 : s);
+    const float* src = table + (long)s * E;
+    float* dst = emb_out + (long)r * ld_emb;
+    if ((E & 3) == 0 && (ld_emb & 3) == 0 && nm_aligned16_dev(src) && nm_aligned16_dev(dst)) {
+        for (int c = threadIdx.x * 4; c < E; c += 1024)
+            *reinterpret_cast<float4*>(dst + c) = *reinterpret_cast<const float4*>(src + c);
+    } else {
+        for (int c = threadIdx.x; c < E; c += 256) dst[c] = src[c];
+    }
+}
+
+extern "C" int nm_greedy_finish(void* stream, const float* stats, int64_t ntiles, int64_t R, int32_t* finished,
+                                int32_t* sym_out, int32_t* mask_out, int end_id, int32_t* all_finished,
+                                const float* table, int64_t V, int64_t E, float* emb_out, int64_t ld_emb,
+                                int32_t* argmax_out, float* max_out, float* lse_out) {
+    NM_REQUIRE(stats && finished && sym_out && R >= 0 && ntiles > 0, "nm_greedy_finish: bad args");
+    NM_REQUIRE(nm_aligned16(stats), "nm_greedy_finish: statistics must be 16-byte aligned");
+    NM_REQUIRE(!emb_out || (table && V > 0 && E > 0 && ld_emb >= E), "nm_greedy_finish: bad embedding arguments");
+    if (R == 0) return NM_OK;
+    hipLaunchKernelGGL(greedy_finish_kernel, dim3((unsigned)R), dim3(256), 0, nm_stream(stream),
+                       reinterpret_cast<const float4*>(stats), (int)ntiles, finished, sym_out, mask_out, end_id,
+                       all_finished, table, (int)V, (int)E, emb_out, (long)ld_emb, argmax_out, max_out, lse_out);
+    NM_LAUNCH_CHECK("nm_greedy_finish");
+}
+
+// Beam step, first stage, on the tile statistics: max / lse of the row come from the merged tiles; the
+// candidate filter of row_scan_kernel works on TILE maxima (tau = the K-th largest tile maximum: at least K
+// elements of the row are >= tau, so the exact top K all score at least score(tau); elements below
+// tau - margin score strictly less), so only the handful of tiles whose maximum reaches tau - margin are
+// read back from the logits: ~K x 512 B per row instead of the whole 128 KB row.  Exact scores and the
+// (score, flat index) order are those of row_scan_kernel / beam_topk_partial; a row whose survivors do not
+// fit the list takes the full insertion path over the whole row.
+#define TILE_SCAN_TILES 64
+template <int K>
+__global__ __launch_bounds__(256) void beam_tile_scan_kernel(const float* __restrict__ x, long ldx, int V,
+                                                             const float4* __restrict__ stats, int ntiles,
+                                                             float* __restrict__ max_out, float* __restrict__ lse_out,
+                                                             int k, const float* __restrict__ logprob_sum,
+                                                             const int* __restrict__ lengths,
+                                                             const int* __restrict__ finished,
+                                                             const float* __restrict__ penalty,
+                                                             float* __restrict__ part_score, int* __restrict__ part_idx) {
+    __shared__ float shf[4];
+    __shared__ int shi[4];
+    __shared__ float shs[4 * K];
+    __shared__ int shx[4 * K];
+    __shared__ float cand_s[ROW_SCAN_CAND];
+    __shared__ int cand_i[ROW_SCAN_CAND];
+    __shared__ int cand_n, tile_n;
+    __shared__ int tile_list[TILE_SCAN_TILES];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int base = (r % k) * V;
+    if (finished[r]) {
+        // finished hypothesis: lp = 0 for <pad>, -1e9 otherwise (:444-456): the K lowest ids win, no scan
+        if (tid < K) {
+            const float pen = penalty[lengths[r]];
+            const float lp = (tid == 0) ? 0.0f : NM_NEG_INF_F;
+            part_score[(long)r * K + tid] = tid < V ? (logprob_sum[r] + lp) / pen : -INFINITY;
+            part_idx[(long)r * K + tid] = tid < V ? base + tid : 0x7fffffff;
+        }
+        return;
+    }
+    const float4* st = stats + (long)r * ntiles;
+    float bv, lse;
+    int bi;
+    merge_row_tiles<256>(st, ntiles, bv, bi, lse, shf, shi);
+    if (tid == 0) {
+        if (max_out) max_out[r] = bv;
+        if (lse_out) lse_out[r] = lse;
+        cand_n = 0;
+        tile_n = 0;
+    }
+    const float lps = logprob_sum[r];
+    const float pen = penalty[lengths[r] + 1];
+    // tau = K-th largest tile maximum (K knock-out rounds over the block; ntiles is a few hundred)
+    float tau = -INFINITY;
+    {
+        float mine[4];                                      // this thread's tile maxima (ntiles <= 1024)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mine[q] = (tid + q * 256 < ntiles) ? st[tid + q * 256].x : -INFINITY;
+        for (int p = 0; p < K; ++p) {
+            float v = fmaxf(fmaxf(mine[0], mine[1]), fmaxf(mine[2], mine[3]));
+            int who = tid;
+            block_argmax<256>(v, who, shf, shi);            // (value desc, thread id asc): a unique owner
+            tau = v;
+            if (who == tid) {                               // drop ONE instance of the maximum
+                bool done = false;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (!done && mine[q] == v) { mine[q] = -INFINITY; done = true; }
+            }
+        }
+    }
+    const float margin = (fabsf(lse) + fabsf(lps) + (bv - tau) + 1.0f) * (1.0f / 262144.0f);
+    const float cut = tau - margin;
+    __syncthreads();
+    bool overflow = !(cut > -INFINITY) || ntiles > 1024;
+    if (!overflow) {
+        for (int t = tid; t < ntiles; t += 256) {
+            if (st[t].x >= cut) {
+                const int slot = atomicAdd(&tile_n, 1);
+                if (slot < TILE_SCAN_TILES) tile_list[slot] = t;
+            }
+        }
+        __syncthreads();
+        const int nt = tile_n;
+        if (nt > TILE_SCAN_TILES) overflow = true;
+        else {
+            const float* row = x + (long)r * ldx;
+            for (int i = tid; i < nt * NM_STATS_TILE; i += 256) {
+                const int col = tile_list[i / NM_STATS_TILE] * NM_STATS_TILE + (i % NM_STATS_TILE);
+                if (col < V) {
+                    const float xe = row[col];
+                    if (xe >= cut) {
+                        const int slot = atomicAdd(&cand_n, 1);
+                        if (slot < ROW_SCAN_CAND) {
+                            cand_s[slot] = (lps + ((xe - bv) - lse)) / pen;
+                            cand_i[slot] = base + col;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (cand_n > ROW_SCAN_CAND) overflow = true;
+        }
+    }
+    float s[K];
+    int ix[K];
+#pragma unroll
+    for (int p = 0; p < K; ++p) { s[p] = -INFINITY; ix[p] = 0x7fffffff; }
+    if (!overflow) {
+        if (wave == 0) {
+            const int ncand = cand_n;
+            for (int c = lane; c < ncand; c += 64) topk_insert<K>(s, ix, cand_s[c], cand_i[c]);
+            topk_wave_merge<K>(s, ix);
+            if (lane == 0) {
+#pragma unroll
+                for (int p = 0; p < K; ++p) { part_score[(long)r * K + p] = s[p]; part_idx[(long)r * K + p] = ix[p]; }
+            }
+        }
+        return;
+    }
+    // ---- full path: every element of the row through the per-thread insertion lists and the merge tree
+    {
+        const float* row = x + (long)r * ldx;
+        for (int v = tid; v < V; v += 256) topk_insert<K>(s, ix, (lps + ((row[v] - bv) - lse)) / pen, base + v);
+    }
+    topk_wave_merge<K>(s, ix);
+    if (lane == 0) {
+#pragma unroll
+        for (int p = 0; p < K; ++p) { shs[wave * K + p] = s[p]; shx[wave * K + p] = ix[p]; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int p = 0; p < K; ++p) {
+            s[p] = lane < 4 ? shs[lane * K + p] : -INFINITY;
+            ix[p] = lane < 4 ? shx[lane * K + p] : 0x7fffffff;
+        }
+        topk_wave_merge<K>(s, ix);
+        if (lane == 0) {
+#pragma unroll
+            for (int p = 0; p < K; ++p) { part_score[(long)r * K + p] = s[p]; part_idx[(long)r * K + p] = ix[p]; }
+        }
+    }
+}
+
+// nm_beam_topk_step_fused on logits whose per-tile statistics are known (nm_logits_stats_gemm)
+extern "C" int nm_beam_topk_step_tiles(void* stream, const float* logits, int64_t ldx, const float* stats,
+                                       int64_t ntiles, int64_t B, int64_t k, int64_t V, const float* logprob_sum,
+                                       const int32_t* lengths, const int32_t* finished, const float* penalty,
+                                       int end_id, float* out_score, int32_t* out_word, int32_t* out_beam,
+                                       float* out_logprob_sum, int32_t* out_lengths, int32_t* out_finished,
+                                       int32_t* out_src_row, void* workspace, int64_t workspace_bytes,
+                                       int32_t* all_finished, float* rmax_out, float* rlse_out) {
+    NM_REQUIRE(logits && stats && logprob_sum && lengths && finished && penalty && out_score && out_word && out_beam &&
+                   out_logprob_sum && out_lengths && out_finished && out_src_row && workspace && rmax_out && rlse_out,
+               "nm_beam_topk_step_tiles: null pointer");
+    NM_REQUIRE(B > 0 && k >= 1 && k <= BEAM_MAX_K && V > 0 && k * V < (1L << 31) && ldx >= V,
+               "nm_beam_topk_step_tiles: bad shape B=%ld k=%ld V=%ld", (long)B, (long)k, (long)V);
+    NM_REQUIRE(ntiles == (V + NM_STATS_TILE - 1) / NM_STATS_TILE && nm_aligned16(stats),
+               "nm_beam_topk_step_tiles: statistics do not match V=%ld", (long)V);
+    NM_REQUIRE(workspace_bytes >= nm_beam_workspace_bytes(B, k, V), "nm_beam_topk_step_tiles: workspace too small");
+    float* ps = reinterpret_cast<float*>(workspace);
+    int* pi = reinterpret_cast<int*>(ps + B * 64 * BEAM_MAX_K);
+    const unsigned rows = (unsigned)(B * k);
+    hipStream_t st = nm_stream(stream);
+    const float4* st4 = reinterpret_cast<const float4*>(stats);
+#define NM_TILES(K_)                                                                                              \
+    do {                                                                                                          \
+        hipLaunchKernelGGL((beam_tile_scan_kernel<K_>), dim3(rows), dim3(256), 0, st, logits, (long)ldx, (int)V, st4, \
+                           (int)ntiles, rmax_out, rlse_out, (int)k, logprob_sum, lengths, finished, penalty, ps, pi);  \
+        hipLaunchKernelGGL((beam_topk_final<K_>), dim3((unsigned)B), dim3(64), 0, st, logits, (long)ldx, (int)V,   \
+                           (int)k, rmax_out, rlse_out, logprob_sum, lengths, finished, penalty, ps, pi, (int)k,    \
+                           (int)B, end_id, out_score, out_word, out_beam, out_logprob_sum, out_lengths,           \
+                           out_finished, out_src_row, all_finished);                                             \
+    } while (0)
+    if (k <= 4) NM_TILES(4);
+    else NM_TILES(8);
+#undef NM_TILES
+    NM_LAUNCH_CHECK("nm_beam_topk_step_tiles");
+}
+
 // ---------------------------------------------------------------------------
 // row gather: dst[r,:] = src[idx[r],:]   (beam reorder of decoder state,
 // beam_search_decoder.py:503-532 / tf_utils.py:106-131) and the int32 variant

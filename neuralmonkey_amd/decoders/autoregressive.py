@@ -145,6 +145,23 @@ class AutoregressiveDecoder(ModelPart):
             return ops.gemm(state, self.embedding_matrix(ctx), out=out, bias=bias, trans_b=True)
         return ops.gemm(state, self.var(ctx, "state_to_word_W"), out=out, bias=bias)
 
+    def logits_stats_ok(self, ctx, state: torch.Tensor) -> bool:
+        """May the vocabulary projection run with its row statistics in the GEMM epilogue
+        (``ops.logits_stats_gemm``: float4 operand loads, 16-byte aligned rows)?"""
+        w = self.embedding_matrix(ctx) if self.tie_embeddings else self.var(ctx, "state_to_word_W")
+        return (w.shape[0] % 4 == 0 and w.shape[1] % 4 == 0 and w.stride(0) % 4 == 0 and w.data_ptr() % 16 == 0
+                and state.stride(0) % 4 == 0 and state.shape[1] % 4 == 0 and state.data_ptr() % 16 == 0)
+
+    def state_to_logits_stats(self, ctx, state: torch.Tensor, stats: torch.Tensor,
+                              out: Optional[torch.Tensor] = None) -> None:
+        """``state_to_logits`` + per-tile {max, sum exp, argmax} of every row in ``stats``; the logits are
+        written only when ``out`` is given (autoregressive.py:450-459 + :470 / beam_search_decoder.py:537-543)."""
+        bias = self.decoding_bias(ctx)
+        if self.tie_embeddings:
+            ops.logits_stats_gemm(state, self.embedding_matrix(ctx), bias, stats, out=out, trans_b=True)
+        else:
+            ops.logits_stats_gemm(state, self.var(ctx, "state_to_word_W"), bias, stats, out=out)
+
     def embed_input_symbols(self, ctx, symbols: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
         emb = ops.embedding_gather(self.embedding_matrix(ctx), symbols, out=out)
         return dropout(ctx, emb, self.dropout_keep_prob, ctx.fed(self.train_mode))

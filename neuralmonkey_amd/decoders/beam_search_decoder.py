@@ -259,8 +259,12 @@ class BeamSearchDecoder(ModelPart):
         att0 = att_states
         from ..attention.base_attention import AttentionLoopState
         att_at = lambda i: [AttentionLoopState(a.contexts, a.weights, i) for a in att0]
+        # fast path: the vocabulary projection leaves per-tile row statistics behind (nm_logits_stats_gemm) and
+        # the beam body reads back only the tiles that can hold a top-k candidate (nm_beam_topk_step_tiles)
+        use_stats = fast and dec.logits_stats_ok(ctx, out_state)
+        stats = f32("stats", (ops.logits_stats_numel(rows, v),)) if use_stats else None
         if fast:
-            stepper.step(emb, att_at(0), out_state, logits, h_prev=hsel, h_out=stepper.hbuf[0])
+            stepper.step(emb, att_at(0), out_state, logits, h_prev=hsel, h_out=stepper.hbuf[0], stats=stats)
         else:
             att_states = stepper.step(emb, att_states, out_state, logits, finished=fin[0].view(rows))
         ops.row_stats(logits, rmax, rlse, argmax)
@@ -274,9 +278,14 @@ class BeamSearchDecoder(ModelPart):
         def body(s):
             """Beam body number s (:394-556); every buffer it touches is a function of s alone."""
             cur, nxt = s & 1, (s & 1) ^ 1
-            ops.beam_topk_step_fused(logits, bsz, k, lps[cur], lens[cur], fin[cur], penalty, END_TOKEN_INDEX,
-                                     scores, word, beam, lps[nxt], lens[nxt], fin[nxt], src, ws, rmax, rlse,
-                                     allfin[s:s + 1])     # log-softmax statistics (:537-543) fused in
+            if use_stats:
+                ops.beam_topk_step_tiles(logits, stats, bsz, k, lps[cur], lens[cur], fin[cur], penalty,
+                                         END_TOKEN_INDEX, scores, word, beam, lps[nxt], lens[nxt], fin[nxt], src, ws,
+                                         rmax, rlse, allfin[s:s + 1])
+            else:
+                ops.beam_topk_step_fused(logits, bsz, k, lps[cur], lens[cur], fin[cur], penalty, END_TOKEN_INDEX,
+                                         scores, word, beam, lps[nxt], lens[nxt], fin[nxt], src, ws, rmax, rlse,
+                                         allfin[s:s + 1])     # log-softmax statistics (:537-543) fused in
             if fast:
                 ops.gather_rows(stepper.hbuf[cur], srcf, stepper.sel)            # :503-532
             else:
@@ -287,7 +296,7 @@ class BeamSearchDecoder(ModelPart):
             dec.embed_input_symbols(ctx, wordf, out=emb)                         # :507-510
             if fast:
                 stepper.step(emb, att_at(s + 1), out_state, logits, h_prev=stepper.sel,
-                             h_out=stepper.hbuf[nxt])                            # :534-535
+                             h_out=stepper.hbuf[nxt], stats=stats)               # :534-535
             elif indexed:
                 stepper.step(emb, att_at(s + 1), out_state, logits, finished=fin[nxt].view(rows))
             else:

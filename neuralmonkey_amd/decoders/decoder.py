@@ -467,10 +467,26 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
         self.decoding_bias(ctx)
         t_xent = min(t_target, tmax) if has_tgt else 0
 
+        # fast path: max / argmax of every vocabulary tile come out of the logits GEMM's epilogue and
+        # nm_greedy_finish turns them into the step's symbols, flags and the next input embedding -- the
+        # [B,V] logits are neither re-read nor (unless a runner or the runtime loss wants them) written
+        use_stats = graph_ok and self.logits_stats_ok(ctx, out_all[0])
+        stats = ctx.buffer(key + ("stats",), (ops.logits_stats_numel(bsz, v),)) if use_stats else None
+        table = self.embedding_matrix(ctx)
+
         def body(t):
             """Step t touches persistent buffers only and depends on nothing but t (graph capturable)."""
             logits = logits_all[t] if keep_logits else logits_one
             st_t = [AttentionLoopState(st.contexts, st.weights, t) for st in att0]
+            if use_stats:
+                want_logits = keep_logits or t < t_xent
+                stepper.step(emb, st_t, out_all[t], logits if want_logits else None, h_out=s_all[t],
+                             h_prev=s0 if t == 0 else s_all[t - 1], stats=stats)
+                if t < t_xent:
+                    ops.xent(logits, tgt[t], tmask[t], xent_rows[t])
+                ops.greedy_finish(stats, v, finished, symbols[t], omask[t], END_TOKEN_INDEX, allfin[t:t + 1],
+                                  table=table, emb_out=emb)
+                return
             if graph_ok:
                 stepper.step(emb, st_t, out_all[t], logits, h_out=s_all[t], h_prev=s0 if t == 0 else s_all[t - 1])
             else:

