@@ -223,7 +223,7 @@ def test_transformer_base_width_matches_the_oracle(dev):
     Gradients at this width carry visible fp32 noise on BOTH sides (ReLU units whose pre-activation is within
     rounding of zero flip their derivative; four LayerNorm-ed residual blocks amplify it): the fp32 oracle
     itself is 0.1-3 % away from the same oracle run in float64.  The yardstick is therefore the float64
-    oracle, and the engine must be within 4x the fp32 oracle's own distance from it (L2 and max norm per
+    oracle, and the engine must be within 4x (L2 norm) / 8x (max norm) the fp32 oracle's own distance from it (per
     tensor, floors 2e-3 / 1e-3)."""
     cfg = TRF.TConfig(depth=2, n_heads=8, n_heads_self=8, n_heads_enc=8)
     vsz, max_len, bsz = 4000, 24, 32
@@ -254,7 +254,7 @@ def test_transformer_base_width_matches_the_oracle(dev):
         scale2, scalem = max(np.linalg.norm(want), 1e-3 * gmax), max(np.abs(want).max(), 1e-3 * gmax)
         err2, noise2 = np.linalg.norm(got - want) / scale2, np.linalg.norm(w32 - want) / scale2
         errm, noisem = np.abs(got - want).max() / scalem, np.abs(w32 - want).max() / scalem
-        if err2 > max(2e-3, 4 * noise2) or errm > max(1e-3, 4 * noisem):
+        if err2 > max(2e-3, 4 * noise2) or errm > max(1e-3, 8 * noisem):
             bad[name] = (float(err2), float(noise2), float(errm), float(noisem))
     assert not bad, "gradient mismatch (l2 err, l2 fp32-oracle noise, max err, max noise): {}".format(bad)
 
