@@ -141,6 +141,44 @@ int nm_attn_softmax_fwd(void* stream, const float* e, const float* mask, float* 
 int nm_prof_enable(int on);
 int nm_prof_attn_step(double* total_ms, int64_t* count);
 
+/* The attention step WITHOUT its combine launch: energies [R,S] (workspace offset 0) and the split-S partials
+ * stay in the workspace for a consumer that merges them while it loads them (nm_step_group, a_kind 1).
+ * nm_attn_partials_layout: float offsets of the partial contexts [R,nchunk,C] and statistics [R,nchunk,4] =
+ * {max, sum exp, sum exp*mask, -} inside that workspace; <0 when the shape takes the any-shape kernel. */
+int nm_attn_partials_layout(int64_t R, int64_t S, int64_t A, int64_t C, int64_t* nchunk, int64_t* pctx_off,
+                            int64_t* pstat_off);
+int nm_attn_fwd_partials(void* stream, const float* y, const float* hf, const float* states, const float* mask,
+                         const float* v, const float* bias, int64_t R, int64_t rows_per_key, int64_t S, int64_t A,
+                         int64_t C, void* workspace, int64_t workspace_bytes);
+
+/* ---- one inference step of the RNN attention decoder as groups of skinny GEMMs: Decoder.next_state,
+ * decoders/decoder.py:279-358 (GRUCell nn/ortho_gru_cell.py:44-53, query projection
+ * attention/feed_forward.py:130-132, output projection decoders/output_projection.py:115-130).
+ * Every problem of a group is C[M,N] = epilogue(A[M,K] . Bt[N,K]^T) with M common to the group; problems of
+ * one group do not depend on each other and share a launch.  Weights are passed transposed ([N,K]).
+ *   a_kind   0: A as stored.  1: A[r,:] = sum_i f_i pctx[r,i,:] / den -- the merge of the split-S attention
+ *               partials (softmax -> mask -> renormalise +1e-8, feed_forward.py:139-154) done in the operand
+ *               loader (K = C); with `weights` != NULL the normalised distribution [M,S] is written too
+ *               (mask row of query row r: (r / mask_div) % mask_mod).
+ *   epilogue 0: C = act(s + bias + add), act 0 none / 1 tanh.
+ *            1: GRU gates, N = 2H: ru = sigmoid(s + bias), rh = r * h.
+ *            2: GRU candidate + blend, N = H: c = tanh(xc + s), h' = u*h + (1-u)*c -> h_out (and h_out2). */
+typedef struct nm_step_problem {
+    const float* A; int64_t lda;
+    const float* Bt; int64_t ldb;
+    int64_t N, K;
+    int32_t a_kind, epilogue, act, nchunk;
+    const float* bias; const float* add; int64_t ldadd;
+    float* C; int64_t ldc;
+    const float* pctx; const float* pstat;
+    const float* energies; const float* mask; float* weights; int64_t S, mask_div, mask_mod;
+    const float* h; int64_t ldh;
+    float* ru; float* rh;
+    const float* xc; int64_t ldxc;
+    float* h_out; int64_t ldho; float* h_out2; int64_t ldho2;
+} nm_step_problem;
+int nm_step_group(void* stream, int64_t M, const nm_step_problem* problems, int32_t nproblems);
+
 /* ---- vocabulary-axis rows: tf.argmax / tf.nn.log_softmax / sequence_loss ----------------------
  * decoders/autoregressive.py:470 (argmax, first max wins), :289-316,351-375 (xent, log-probs) */
 int nm_row_stats(void* stream, const float* x, int64_t ldx, int64_t rows, int64_t V, float* max_out,
@@ -181,7 +219,7 @@ int nm_beam_topk_step_fused(void* stream, const float* logits, int64_t ldx, int6
  * themselves are written only when C != NULL (greedy decoding never reads them back: nm_greedy_finish works
  * on the statistics; a beam step reads back only the tiles that can hold a top-k candidate).
  * transB: B stored [N,K] (tied embeddings).  A, B 16-byte aligned, K, N, lda, ldb multiples of 4. */
-int64_t nm_logits_stats_tile(void);                       /* columns per statistics tile (128) */
+int64_t nm_logits_stats_tile(int64_t M);     /* columns per statistics tile: 64 for M <= 256 rows, else 128 */
 int64_t nm_logits_stats_bytes(int64_t M, int64_t N);
 int nm_logits_stats_gemm(void* stream, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                          const float* B, int64_t ldb, const float* bias, float* C /* or NULL */, int64_t ldc,
@@ -195,7 +233,7 @@ int nm_greedy_finish(void* stream, const float* stats, int64_t ntiles, int64_t R
                      float* lse_out);
 /* nm_beam_topk_step_fused on logits whose tile statistics are known: max / lse from the merged tiles, the
  * exact top-k from the few tiles whose maximum can reach it (same scores, same tie order) */
-int nm_beam_topk_step_tiles(void* stream, const float* logits, int64_t ldx, const float* stats, int64_t ntiles,
+int nm_beam_topk_step_tiles(void* stream, const float* logits, int64_t ldx, const float* stats, int64_t tile_w,
                             int64_t B, int64_t k, int64_t V, const float* logprob_sum, const int32_t* lengths,
                             const int32_t* finished, const float* penalty, int end_id, float* out_score,
                             int32_t* out_word, int32_t* out_beam, float* out_logprob_sum, int32_t* out_lengths,

@@ -79,10 +79,13 @@ SIGNATURES = {
     "nm_optim_clip_adam": (I, [P, P, P, P, P, P, P, P, P, P, P, L, L, F, F, F, F, F, P, L]),
     "nm_gather_rows_f32": (I, [P, P, L, P, P, L, L, L]),
     "nm_beam_reorder_tokens": (I, [P, P, P, P, P, L, L]),
-    "nm_logits_stats_tile": (L, []),
+    "nm_logits_stats_tile": (L, [L]),
     "nm_logits_stats_bytes": (L, [L, L]),
     "nm_logits_stats_gemm": (I, [P, I, L, L, L, P, L, P, L, P, P, L, P, L]),
     "nm_greedy_finish": (I, [P, P, L, L, P, P, P, I, P, P, L, L, P, L, P, P, P]),
+    "nm_attn_partials_layout": (I, [L, L, L, L, P, P, P]),
+    "nm_attn_fwd_partials": (I, [P, P, P, P, P, P, P, L, L, L, L, L, P, L]),
+    "nm_step_group": (I, [P, L, P, ctypes.c_int32]),
     "nm_beam_topk_step_tiles": (I, [P, P, L, P, L, L, L, L, P, P, P, P, I, P, P, P, P, P, P, P, P, L, P, P, P]),
 }
 
@@ -102,6 +105,18 @@ class GruEpilogue(ctypes.Structure):
                 ("c", P), ("h0", P), ("hseq", P), ("hs_dir", L), ("hs_row", L), ("hs_time", L),
                 ("dxp", P), ("dx_dir", L), ("dx_row", L), ("dx_time", L),
                 ("dgpre", P), ("dcpre", P)]
+
+
+class StepProblem(ctypes.Structure):
+    """``nm_step_problem`` of include/nmhip.h."""
+    _fields_ = [("A", P), ("lda", L), ("Bt", P), ("ldb", L), ("N", L), ("K", L),
+                ("a_kind", ctypes.c_int32), ("epilogue", ctypes.c_int32), ("act", ctypes.c_int32),
+                ("nchunk", ctypes.c_int32),
+                ("bias", P), ("add", P), ("ldadd", L), ("C", P), ("ldc", L),
+                ("pctx", P), ("pstat", P), ("energies", P), ("mask", P), ("weights", P),
+                ("S", L), ("mask_div", L), ("mask_mod", L),
+                ("h", P), ("ldh", L), ("ru", P), ("rh", P), ("xc", P), ("ldxc", L),
+                ("h_out", P), ("ldho", L), ("h_out2", P), ("ldho2", L)]
 
 
 def load():

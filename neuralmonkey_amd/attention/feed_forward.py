@@ -89,6 +89,29 @@ class Attention(BaseAttention):
         ops.attn_fwd(y, hf, states, self.attention_mask(ctx), self.var(ctx, "attn_similarity_v"),
                      self.var(ctx, "attn_bias"), self.rows_per_key, ctx_out, w_out, ws, energies_out)
 
+    def partials_plan(self, ctx, rows: int):
+        """Can a step of ``rows`` queries leave its split-S partials for a fused consumer (``nm_step_group``)?
+        Returns None or a dict with the workspace and the views a consumer needs."""
+        if self.dropout_keep_prob != 1.0 and bool(ctx.fed(self.train_mode)):
+            return None
+        states = self.attention_states(ctx)
+        bk, slen, c = states.shape
+        a = self.state_size
+        lay = ops.attn_partials_layout(rows, slen, a, c)
+        if lay is None or lay[0] > 8 or c % 16 or a % 4 or rows % self.rows_per_key or rows // self.rows_per_key != bk:
+            return None
+        nchunk, pctx_off, pstat_off = lay
+        ws = ctx.buffer((id(self), "ws", rows), ((ops._lib.load().nm_attn_workspace_bytes(rows, slen, c) + 3) // 4,))
+        return {"ws": ws, "nchunk": nchunk, "energies": ws[:rows * slen].view(rows, slen),
+                "pctx": ws[pctx_off:pctx_off + rows * nchunk * c], "pstat": ws[pstat_off:pstat_off + rows * nchunk * 4],
+                "S": slen, "C": c, "Bk": bk}
+
+    def attention_partials(self, ctx, y: torch.Tensor, plan) -> None:
+        """Energies and split-S partials of one step for projected queries ``y`` [R,A] (no combine launch)."""
+        ops.attn_fwd_partials(y, self.hidden_features(ctx), self.attention_states(ctx), self.attention_mask(ctx),
+                              self.var(ctx, "attn_similarity_v"), self.var(ctx, "attn_bias"), self.rows_per_key,
+                              plan["ws"])
+
     def attention_all_steps(self, ctx, queries: torch.Tensor, y_all: torch.Tensor, ctx_all: torch.Tensor,
                             w_all: torch.Tensor, e_all: torch.Tensor) -> None:
         """Teacher-forced training: the attention of step t only needs the decoder

@@ -575,12 +575,19 @@ __global__ __launch_bounds__(256) void attn_generic(AttnArgs p, float* __restric
     }
 }
 
-extern "C" int nm_attn_fwd_multi(void* stream, const float* y, const float* hf, const float* states,
-                                 const float* mask, const float* v, const float* bias, int64_t Bk,
-                                 int64_t nq, int64_t q_stride_b, int64_t q_stride_q, int64_t S, int64_t A,
-                                 int64_t C, float* ctx, int64_t ldctx, float* weights, void* workspace,
-                                 int64_t workspace_bytes, float* energies_out) {
-    NM_REQUIRE(y && hf && states && v && ctx && workspace, "nm_attn_fwd: null pointer");
+static bool attn_vector_shape(int64_t S, int64_t A, int64_t C, int* sch, int* nchunk) {
+    attn_chunking(S, sch, nchunk);
+    return A % 4 == 0 && C % 4 == 0 && C <= 2048 && *sch <= ATT_MAX_SCH && *nchunk <= 64;
+}
+
+// do_combine == 0: only the split-S partial kernel is launched; the caller merges the partials (pctx / pstat
+// in the workspace, nm_attn_partials_layout) inside its own consumer -- nm_step_group's a_kind 1 operand loader
+static int attn_fwd_impl(void* stream, const float* y, const float* hf, const float* states,
+                         const float* mask, const float* v, const float* bias, int64_t Bk,
+                         int64_t nq, int64_t q_stride_b, int64_t q_stride_q, int64_t S, int64_t A,
+                         int64_t C, float* ctx, int64_t ldctx, float* weights, void* workspace,
+                         int64_t workspace_bytes, float* energies_out, int do_combine) {
+    NM_REQUIRE(y && hf && states && v && (ctx || !do_combine) && workspace, "nm_attn_fwd: null pointer");
     NM_REQUIRE(Bk > 0 && nq > 0 && S > 0 && A > 0 && C > 0, "nm_attn_fwd: bad shape Bk=%ld nq=%ld S=%ld",
                (long)Bk, (long)nq, (long)S);
     const bool beam_layout = (q_stride_b == nq && q_stride_q == 1);
@@ -592,6 +599,7 @@ extern "C" int nm_attn_fwd_multi(void* stream, const float* y, const float* hf, 
     const bool vector_ok = A % 4 == 0 && C % 4 == 0 && ldctx % 4 == 0 && C <= 2048 && sch <= ATT_MAX_SCH &&
                            nchunk <= 64 && nm_aligned16(y) && nm_aligned16(hf) && nm_aligned16(states) &&
                            nm_aligned16(v) && nm_aligned16(ctx) && nm_aligned16(workspace);
+    NM_REQUIRE(vector_ok || do_combine, "nm_attn_fwd_partials: shape / alignment outside the split-S kernels");
     if (!vector_ok) {
         NM_REQUIRE(S <= 16000, "nm_attn_fwd: S=%ld too long for the any-shape kernel", (long)S);
         NM_REQUIRE(R < (1LL << 31), "nm_attn_fwd: too many query rows");
@@ -660,11 +668,47 @@ extern "C" int nm_attn_fwd_multi(void* stream, const float* y, const float* hf, 
 #undef NM_AT
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) NM_FAIL(NM_ERR_HIP, "nm_attn_fwd: partial launch failed: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(attn_combine, dim3((unsigned)R), dim3(256), 0, st, p.pctx, p.pstat, p.energies,
-                       mask, ctx, (long)ldctx, weights, (int)S, (int)C, nchunk,
-                       beam_layout ? (int)nq : 1, (int)Bk);
+    if (do_combine)
+        hipLaunchKernelGGL(attn_combine, dim3((unsigned)R), dim3(256), 0, st, p.pctx, p.pstat, p.energies,
+                           mask, ctx, (long)ldctx, weights, (int)S, (int)C, nchunk,
+                           beam_layout ? (int)nq : 1, (int)Bk);
     if (prof) hipEventRecord(prof->second, st);
     NM_LAUNCH_CHECK("nm_attn_fwd");
+}
+
+extern "C" int nm_attn_fwd_multi(void* stream, const float* y, const float* hf, const float* states,
+                                 const float* mask, const float* v, const float* bias, int64_t Bk,
+                                 int64_t nq, int64_t q_stride_b, int64_t q_stride_q, int64_t S, int64_t A,
+                                 int64_t C, float* ctx, int64_t ldctx, float* weights, void* workspace,
+                                 int64_t workspace_bytes, float* energies_out) {
+    return attn_fwd_impl(stream, y, hf, states, mask, v, bias, Bk, nq, q_stride_b, q_stride_q, S, A, C, ctx, ldctx,
+                         weights, workspace, workspace_bytes, energies_out, 1);
+}
+
+// Where the split-S partials of R query rows live inside the attention workspace (float offsets): energies
+// [R,S] at 0, partial contexts [R,nchunk,C] at *pctx_off, statistics [R,nchunk,4] = {max, sum exp, sum exp*mask,
+// -} at *pstat_off.  Returns <0 when the shape is served by the any-shape kernel (no partials exist).
+extern "C" int nm_attn_partials_layout(int64_t R, int64_t S, int64_t A, int64_t C, int64_t* nchunk,
+                                       int64_t* pctx_off, int64_t* pstat_off) {
+    NM_REQUIRE(R > 0 && S > 0 && A > 0 && C > 0 && nchunk && pctx_off && pstat_off, "nm_attn_partials_layout: bad args");
+    int sch, nch;
+    if (!attn_vector_shape(S, A, C, &sch, &nch)) NM_FAIL(NM_ERR_ARG, "nm_attn_partials_layout: any-shape kernel");
+    *nchunk = nch;
+    *pctx_off = ((R * S + 3) / 4) * 4;
+    *pstat_off = *pctx_off + R * nch * C;
+    return NM_OK;
+}
+
+// The attention step WITHOUT its combine launch: energies (workspace offset 0) and the split-S partials are
+// left in the workspace for a consumer that merges them on the fly (nm_step_group).  rows_per_key as nm_attn_fwd.
+extern "C" int nm_attn_fwd_partials(void* stream, const float* y, const float* hf, const float* states,
+                                    const float* mask, const float* v, const float* bias, int64_t R,
+                                    int64_t rows_per_key, int64_t S, int64_t A, int64_t C, void* workspace,
+                                    int64_t workspace_bytes) {
+    NM_REQUIRE(R > 0 && rows_per_key >= 1 && rows_per_key <= 8 && R % rows_per_key == 0,
+               "nm_attn_fwd_partials: bad shape R=%ld k=%ld", (long)R, (long)rows_per_key);
+    return attn_fwd_impl(stream, y, hf, states, mask, v, bias, R / rows_per_key, rows_per_key, rows_per_key, 1, S, A,
+                         C, nullptr, 4, nullptr, workspace, workspace_bytes, nullptr, 0);
 }
 
 extern "C" int nm_attn_fwd(void* stream, const float* y, const float* hf, const float* states,

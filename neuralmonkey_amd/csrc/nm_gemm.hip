@@ -955,12 +955,15 @@ extern "C" int nm_gru_seq_fwd(void* stream, const nm_gru_epilogue* e, int32_t st
 // ---------------------------------------------------------------------------
 // vocabulary projection with the row statistics in the GEMM epilogue
 // ---------------------------------------------------------------------------
-#define NM_STATS_TILE 128
-extern "C" int64_t nm_logits_stats_tile(void) { return NM_STATS_TILE; }
+// Columns per statistics tile = the N extent of the GEMM's block tile: 128 in general; 64 when M <= 256 (one
+// decoding step of <= 256 rows has a single row of block tiles: 128x64 tiles put TWO independent 8-wave
+// workgroups on every CU instead of one, whose barrier-separated load / MFMA phases then overlap).
+extern "C" int64_t nm_logits_stats_tile(int64_t M) { return M <= 256 ? 64 : 128; }
 
 extern "C" int64_t nm_logits_stats_bytes(int64_t M, int64_t N) {
     if (M <= 0 || N <= 0) return 0;
-    return M * ((N + NM_STATS_TILE - 1) / NM_STATS_TILE) * 4 * (int64_t)sizeof(float);
+    const int64_t tile = nm_logits_stats_tile(M);
+    return M * ((N + tile - 1) / tile) * 4 * (int64_t)sizeof(float);
 }
 
 extern "C" int nm_logits_stats_gemm(void* stream, int transB, int64_t M, int64_t N, int64_t K, const float* A,
@@ -979,10 +982,16 @@ extern "C" int nm_logits_stats_gemm(void* stream, int transB, int64_t M, int64_t
                     "multiples of 4");
     GemmArgs g{A, B, C, bias, (int)M, (int)N, (int)K, (long)lda, (long)ldb, (long)(C ? ldc : 0), 0, 0, 0, 0, 0,
                nullptr, 1, 1, stats, C ? 1 : 0};
-    const int tiles_m = nm_cdiv(M, 128), tiles_n = nm_cdiv(N, NM_STATS_TILE);
+    const int tile = (int)nm_logits_stats_tile(M);
+    const int tiles_m = nm_cdiv(M, 128), tiles_n = nm_cdiv(N, tile);
     dim3 grid(tiles_m * tiles_n, 1, 1), block(512);
     hipStream_t st = nm_stream(stream);
-    if (tb) hipLaunchKernelGGL((gemm_tiled<4, 2, 1, 2, false, true, true, 16, true>), grid, block, 0, st, g, tiles_m);
-    else hipLaunchKernelGGL((gemm_tiled<4, 2, 1, 2, false, false, true, 16, true>), grid, block, 0, st, g, tiles_m);
+    if (tile == 64) {
+        if (tb) hipLaunchKernelGGL((gemm_tiled<4, 2, 1, 1, false, true, true, 32, true>), grid, block, 0, st, g, tiles_m);
+        else hipLaunchKernelGGL((gemm_tiled<4, 2, 1, 1, false, false, true, 32, true>), grid, block, 0, st, g, tiles_m);
+    } else {
+        if (tb) hipLaunchKernelGGL((gemm_tiled<4, 2, 1, 2, false, true, true, 16, true>), grid, block, 0, st, g, tiles_m);
+        else hipLaunchKernelGGL((gemm_tiled<4, 2, 1, 2, false, false, true, 16, true>), grid, block, 0, st, g, tiles_m);
+    }
     NM_LAUNCH_CHECK("nm_logits_stats_gemm");
 }

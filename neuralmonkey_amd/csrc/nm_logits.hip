@@ -787,9 +787,8 @@ extern "C" int nm_beam_topk_step_fused(void* stream, const float* logits, int64_
 
 // ---------------------------------------------------------------------------------------------
 // Consumers of the per-tile row statistics that nm_logits_stats_gemm leaves behind
-// (stats[row][tile] = {max, sum exp(x - max), argmax bits, -}, tiles of NM_STATS_TILE columns).
+// (stats[row][tile] = {max, sum exp(x - max), argmax bits, -}, tiles of `tile_w` columns: nm_logits_stats_tile(rows)).
 // ---------------------------------------------------------------------------------------------
-#define NM_STATS_TILE 128
 
 // merge the tiles of one row: global max, first argmax, lse = log(sum exp(x - max)); every thread of the
 // block returns the same values.  `sh` needs 3 * (NT/64) words.
@@ -882,7 +881,7 @@ extern "C" int nm_greedy_finish(void* stream, const float* stats, int64_t ntiles
 #define TILE_SCAN_TILES 64
 template <int K>
 __global__ __launch_bounds__(256) void beam_tile_scan_kernel(const float* __restrict__ x, long ldx, int V,
-                                                             const float4* __restrict__ stats, int ntiles,
+                                                             const float4* __restrict__ stats, int ntiles, int tile_w,
                                                              float* __restrict__ max_out, float* __restrict__ lse_out,
                                                              int k, const float* __restrict__ logprob_sum,
                                                              const int* __restrict__ lengths,
@@ -956,8 +955,8 @@ __global__ __launch_bounds__(256) void beam_tile_scan_kernel(const float* __rest
         if (nt > TILE_SCAN_TILES) overflow = true;
         else {
             const float* row = x + (long)r * ldx;
-            for (int i = tid; i < nt * NM_STATS_TILE; i += 256) {
-                const int col = tile_list[i / NM_STATS_TILE] * NM_STATS_TILE + (i % NM_STATS_TILE);
+            for (int i = tid; i < nt * tile_w; i += 256) {
+                const int col = tile_list[i / tile_w] * tile_w + (i % tile_w);
                 if (col < V) {
                     const float xe = row[col];
                     if (xe >= cut) {
@@ -1016,7 +1015,7 @@ __global__ __launch_bounds__(256) void beam_tile_scan_kernel(const float* __rest
 
 // nm_beam_topk_step_fused on logits whose per-tile statistics are known (nm_logits_stats_gemm)
 extern "C" int nm_beam_topk_step_tiles(void* stream, const float* logits, int64_t ldx, const float* stats,
-                                       int64_t ntiles, int64_t B, int64_t k, int64_t V, const float* logprob_sum,
+                                       int64_t tile_w, int64_t B, int64_t k, int64_t V, const float* logprob_sum,
                                        const int32_t* lengths, const int32_t* finished, const float* penalty,
                                        int end_id, float* out_score, int32_t* out_word, int32_t* out_beam,
                                        float* out_logprob_sum, int32_t* out_lengths, int32_t* out_finished,
@@ -1027,8 +1026,9 @@ extern "C" int nm_beam_topk_step_tiles(void* stream, const float* logits, int64_
                "nm_beam_topk_step_tiles: null pointer");
     NM_REQUIRE(B > 0 && k >= 1 && k <= BEAM_MAX_K && V > 0 && k * V < (1L << 31) && ldx >= V,
                "nm_beam_topk_step_tiles: bad shape B=%ld k=%ld V=%ld", (long)B, (long)k, (long)V);
-    NM_REQUIRE(ntiles == (V + NM_STATS_TILE - 1) / NM_STATS_TILE && nm_aligned16(stats),
-               "nm_beam_topk_step_tiles: statistics do not match V=%ld", (long)V);
+    NM_REQUIRE((tile_w == 64 || tile_w == 128) && nm_aligned16(stats),
+               "nm_beam_topk_step_tiles: tile width %ld (nm_logits_stats_tile gives 64 or 128)", (long)tile_w);
+    const int64_t ntiles = (V + tile_w - 1) / tile_w;
     NM_REQUIRE(workspace_bytes >= nm_beam_workspace_bytes(B, k, V), "nm_beam_topk_step_tiles: workspace too small");
     float* ps = reinterpret_cast<float*>(workspace);
     int* pi = reinterpret_cast<int*>(ps + B * 64 * BEAM_MAX_K);
@@ -1038,7 +1038,8 @@ extern "C" int nm_beam_topk_step_tiles(void* stream, const float* logits, int64_
 #define NM_TILES(K_)                                                                                              \
     do {                                                                                                          \
         hipLaunchKernelGGL((beam_tile_scan_kernel<K_>), dim3(rows), dim3(256), 0, st, logits, (long)ldx, (int)V, st4, \
-                           (int)ntiles, rmax_out, rlse_out, (int)k, logprob_sum, lengths, finished, penalty, ps, pi);  \
+                           (int)ntiles, (int)tile_w, rmax_out, rlse_out, (int)k, logprob_sum, lengths, finished, penalty, \
+                           ps, pi);                                                                               \
         hipLaunchKernelGGL((beam_topk_final<K_>), dim3((unsigned)B), dim3(64), 0, st, logits, (long)ldx, (int)V,   \
                            (int)k, rmax_out, rlse_out, logprob_sum, lengths, finished, penalty, ps, pi, (int)k,    \
                            (int)B, end_id, out_score, out_word, out_beam, out_logprob_sum, out_lengths,           \

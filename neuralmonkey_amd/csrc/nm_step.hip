@@ -1,0 +1,263 @@
+// Decoder-step GEMM groups: the dense products of ONE inference step of the RNN attention decoder
+// (Decoder.next_state, decoders/decoder.py:279-358) launched as a few groups of skinny GEMMs whose
+// epilogues / operand loaders absorb everything that is not a matrix product:
+//
+//   group 1  [emb | h] . Wg + bg -> r, u, r*h        (GRUCell gates, nn/ortho_gru_cell.py:44-49: ONE product
+//            emb . Wc_x + bc     -> xc                over the concatenated [inputs, state], as TF does)
+//   group 2  (r*h) . Wc_h + xc   -> c, h'            (candidate + blend, :50-53)
+//   group 3  h' . Wq + bq        -> y                 (attention query projection, feed_forward.py:130-132)
+//            [emb | h'] . Wo_eh  -> P                 (the part of the output projection that does not wait
+//                                                      for the context, output_projection.py:115-130)
+//   (nm_attn_fwd_partials: split-S attention partial kernel, no combine launch)
+//   group 4  ctx . Wo_c + P + bo -> tanh -> out       with ctx assembled WHILE the A operand is loaded:
+//            ctx[r,:] = sum_i f_i pctx[r,i,:] / den   (the merge of the split-S partials, attn_combine's
+//            arithmetic); the same workgroups write the step's attention weights.
+//
+// Every product is M x N x K with M = rows of the step (128 sentences, 640 beam hypotheses): too small to
+// fill the chip with 128x128 tiles and latency-bound, so -- like gemm_skinny16 -- a workgroup owns one
+// 16x16 output tile, its 16 waves split K (v_mfma_f32_16x16x4_f32, exact f32), partial sums meet in LDS.
+// Weights are passed TRANSPOSED ([N,K], k contiguous; the stepper transposes them once per decoding run), so
+// both fragments of a wave are single 16-byte loads and all loads of a wave are in flight before its first
+// MFMA.  Several products that do not depend on each other share one launch (a "group").
+#include "nm_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define NM_STEP_MAX_PROB 3
+#define NM_STEP_MAX_CHUNK 8
+
+struct StepProb {           // mirrors nm_step_problem (include/nmhip.h)
+    const float* A; long lda;
+    const float* Bt; long ldb;
+    long N, K;
+    int a_kind, epilogue, act, nchunk;
+    const float* bias; const float* add; long ldadd;
+    float* C; long ldc;
+    const float* pctx; const float* pstat;
+    const float* energies; const float* mask; float* weights; long S, mask_div, mask_mod;
+    const float* h; long ldh;
+    float* ru; float* rh;
+    const float* xc; long ldxc;
+    float* h_out; long ldho; float* h_out2; long ldho2;
+};
+
+struct StepGroup {
+    StepProb p[NM_STEP_MAX_PROB];
+    int begin[NM_STEP_MAX_PROB + 1];      // first workgroup of every problem
+    int nprob, M, tiles_m;
+};
+
+// scale of partial i of query row `row`: f_i / den with f_i = exp(m_i - M), den = sum f_i lm_i + 1e-8 sum f_i la_i
+// (attention/feed_forward.py:139-144 carried through the split-S statistics, as attn_combine does)
+__device__ __forceinline__ void step_row_scales(const StepProb& p, int row, float (&sc)[NM_STEP_MAX_CHUNK],
+                                                float& M, float& inv) {
+    const float4* st = reinterpret_cast<const float4*>(p.pstat) + (long)row * p.nchunk;
+    float4 sv[NM_STEP_MAX_CHUNK];
+    M = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NM_STEP_MAX_CHUNK; ++i) {
+        sv[i] = i < p.nchunk ? st[i] : make_float4(-INFINITY, 0.f, 0.f, 0.f);
+        M = fmaxf(M, sv[i].x);
+    }
+    float la = 0.0f, lm = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NM_STEP_MAX_CHUNK; ++i) {
+        sc[i] = i < p.nchunk ? __expf(sv[i].x - M) : 0.0f;
+        la += sc[i] * sv[i].y;
+        lm += sc[i] * sv[i].z;
+    }
+    inv = 1.0f / (lm + 1e-8f * la);
+}
+
+template <int KS>
+__global__ __launch_bounds__(KS * 64) void step_group_kernel(StepGroup g) {
+    __shared__ float red[KS][4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < NM_STEP_MAX_PROB; ++i)
+        if (i < g.nprob && (int)blockIdx.x >= g.begin[i]) pi = i;
+    const StepProb& p = g.p[pi];
+    const int tile = (int)blockIdx.x - g.begin[pi];
+    const int bm = tile % g.tiles_m, bn = tile / g.tiles_m;
+    const int m0 = bm * 16, n0 = bn * 16;
+    const int N = (int)p.N, K = (int)p.K;
+
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int mm = min(m0 + i16, g.M - 1), nn = min(n0 + i16, N - 1);
+    const int kper = ((K / 16 + KS - 1) / KS) * 16;
+    const int kbeg = wave * kper, kend = min(K, kbeg + kper);
+
+    f32x4 acc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = 0.0f;
+    const float* bp = p.Bt + (long)nn * p.ldb + 4 * kq;
+
+    if (p.a_kind == 0) {
+        const float* ap = p.A + (long)mm * p.lda + 4 * kq;
+        for (int k0 = kbeg; k0 < kend; k0 += 64) {
+            float4 av[4], bv[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int k = k0 + 16 * c;
+                av[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                bv[c] = av[c];
+                if (k + 4 * kq < kend) {
+                    av[c] = *reinterpret_cast<const float4*>(ap + k);
+                    bv[c] = *reinterpret_cast<const float4*>(bp + k);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (k0 + 16 * c >= kend) break;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c].x, bv[c].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c].y, bv[c].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c].z, bv[c].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c].w, bv[c].w, acc, 0, 0, 0);
+            }
+        }
+    } else {
+        // A[row, k] = sum_i scale_i * pctx[row, i, k]: the merge of the split-S attention partials happens in
+        // the operand loader, the context vector itself is never written
+        float sc[NM_STEP_MAX_CHUNK], M, inv;
+        step_row_scales(p, mm, sc, M, inv);
+#pragma unroll
+        for (int i = 0; i < NM_STEP_MAX_CHUNK; ++i) sc[i] *= inv;
+        const float* ap = p.pctx + (long)mm * p.nchunk * K + 4 * kq;
+        for (int k0 = kbeg; k0 < kend; k0 += 32) {
+            float4 pv[2][NM_STEP_MAX_CHUNK], bv[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int k = k0 + 16 * c;
+                const bool ok = k + 4 * kq < kend;
+                bv[c] = ok ? *reinterpret_cast<const float4*>(bp + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < NM_STEP_MAX_CHUNK; ++i)
+                    pv[c][i] = (ok && i < p.nchunk) ? *reinterpret_cast<const float4*>(ap + (long)i * K + k)
+                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (k0 + 16 * c >= kend) break;
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < NM_STEP_MAX_CHUNK; ++i) {
+                    a.x += sc[i] * pv[c][i].x; a.y += sc[i] * pv[c][i].y;
+                    a.z += sc[i] * pv[c][i].z; a.w += sc[i] * pv[c][i].w;
+                }
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bv[c].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bv[c].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bv[c].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bv[c].w, acc, 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[wave][i][lane] = acc[i];
+    __syncthreads();
+    if (tid < 256) {
+        const int reg = tid >> 6, ln = tid & 63;
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < KS; ++w) s += red[w][reg][ln];
+        const int col = n0 + (ln & 15);
+        const int row = m0 + 4 * (ln >> 4) + reg;
+        if (row < g.M && col < N) {
+            if (p.epilogue == 0) {
+                float v = s + (p.bias ? p.bias[col] : 0.0f);
+                if (p.add) v += p.add[(long)row * p.ldadd + col];
+                if (p.act == 1) v = nm_tanh(v);
+                p.C[(long)row * p.ldc + col] = v;
+            } else if (p.epilogue == 1) {              // N = 2H: r | u = sigmoid(. + bg); rh = r * h
+                const int H = N >> 1;
+                const float gate = nm_sigmoid(s + p.bias[col]);
+                p.ru[(long)row * N + col] = gate;
+                if (col < H) p.rh[(long)row * H + col] = gate * p.h[(long)row * p.ldh + col];
+            } else {                                   // N = H: c = tanh(xc + .); h' = u*h + (1-u)*c
+                const float c = nm_tanh(p.xc[(long)row * p.ldxc + col] + s);
+                const float u = p.ru[(long)row * 2 * N + N + col];
+                const float hp = p.h[(long)row * p.ldh + col];
+                const float hn = u * hp + (1.0f - u) * c;
+                p.h_out[(long)row * p.ldho + col] = hn;
+                if (p.h_out2) p.h_out2[(long)row * p.ldho2 + col] = hn;
+            }
+        }
+    }
+    // the step's attention distribution (feed_forward.py:139-144), written by the first column tile of
+    // every row block of the problem that consumes the partials
+    if (p.a_kind == 1 && p.weights && bn == 0) {
+        const int S = (int)p.S;
+        for (int idx = tid; idx < 16 * S; idx += KS * 64) {
+            const int row = m0 + idx / S, sidx = idx % S;
+            if (row >= g.M) break;
+            float sc[NM_STEP_MAX_CHUNK], M, inv;
+            step_row_scales(p, row, sc, M, inv);
+            const long b = (row / p.mask_div) % p.mask_mod;
+            const float mk = p.mask ? p.mask[b * S + sidx] : 1.0f;
+            p.weights[(long)row * S + sidx] = __expf(p.energies[(long)row * S + sidx] - M) * mk * inv;
+        }
+    }
+}
+
+struct nm_step_problem {          // mirrors include/nmhip.h
+    const float* A; int64_t lda;
+    const float* Bt; int64_t ldb;
+    int64_t N, K;
+    int32_t a_kind, epilogue, act, nchunk;
+    const float* bias; const float* add; int64_t ldadd;
+    float* C; int64_t ldc;
+    const float* pctx; const float* pstat;
+    const float* energies; const float* mask; float* weights; int64_t S, mask_div, mask_mod;
+    const float* h; int64_t ldh;
+    float* ru; float* rh;
+    const float* xc; int64_t ldxc;
+    float* h_out; int64_t ldho; float* h_out2; int64_t ldho2;
+};
+
+extern "C" int nm_step_group(void* stream, int64_t M, const nm_step_problem* probs, int32_t nprob) {
+    NM_REQUIRE(probs && nprob >= 1 && nprob <= NM_STEP_MAX_PROB, "nm_step_group: 1..%d problems", NM_STEP_MAX_PROB);
+    NM_REQUIRE(M > 0 && M < (1 << 24), "nm_step_group: bad M %ld", (long)M);
+    StepGroup g;
+    g.nprob = nprob;
+    g.M = (int)M;
+    g.tiles_m = nm_cdiv(M, 16);
+    int next = 0;
+    for (int i = 0; i < nprob; ++i) {
+        const nm_step_problem& q = probs[i];
+        StepProb& p = g.p[i];
+        NM_REQUIRE(q.Bt && q.N > 0 && q.K > 0 && q.K % 16 == 0 && q.N < (1 << 24) && q.K < (1 << 24),
+                   "nm_step_group[%d]: bad shape N=%ld K=%ld (K must be a multiple of 16)", i, (long)q.N, (long)q.K);
+        NM_REQUIRE(nm_aligned16(q.Bt) && q.ldb % 4 == 0 && q.ldb >= q.K, "nm_step_group[%d]: weights must be [N,K], "
+                   "16-byte aligned rows", i);
+        NM_REQUIRE(q.a_kind == 0 || q.a_kind == 1, "nm_step_group[%d]: bad a_kind", i);
+        if (q.a_kind == 0)
+            NM_REQUIRE(q.A && nm_aligned16(q.A) && q.lda % 4 == 0 && q.lda >= q.K, "nm_step_group[%d]: A must be "
+                       "[M,K] with 16-byte aligned rows", i);
+        else
+            NM_REQUIRE(q.pctx && q.pstat && nm_aligned16(q.pctx) && nm_aligned16(q.pstat) && q.nchunk >= 1 &&
+                       q.nchunk <= NM_STEP_MAX_CHUNK && (!q.weights || (q.energies && q.S > 0 && q.mask_div >= 1 &&
+                                                                         q.mask_mod >= 1)),
+                       "nm_step_group[%d]: bad attention partials (1..%d chunks)", i, NM_STEP_MAX_CHUNK);
+        NM_REQUIRE(q.epilogue >= 0 && q.epilogue <= 2, "nm_step_group[%d]: bad epilogue", i);
+        if (q.epilogue == 0) NM_REQUIRE(q.C && q.ldc >= q.N && (!q.add || q.ldadd >= q.N) && (q.act == 0 || q.act == 1),
+                                        "nm_step_group[%d]: bad plain epilogue", i);
+        if (q.epilogue == 1) NM_REQUIRE(q.bias && q.ru && q.rh && q.h && q.N % 2 == 0 && q.ldh >= q.N / 2,
+                                        "nm_step_group[%d]: bad gates epilogue", i);
+        if (q.epilogue == 2) NM_REQUIRE(q.xc && q.ru && q.h && q.h_out && q.ldxc >= q.N && q.ldh >= q.N &&
+                                        q.ldho >= q.N && (!q.h_out2 || q.ldho2 >= q.N),
+                                        "nm_step_group[%d]: bad candidate epilogue", i);
+        p.A = q.A; p.lda = q.lda; p.Bt = q.Bt; p.ldb = q.ldb; p.N = q.N; p.K = q.K;
+        p.a_kind = q.a_kind; p.epilogue = q.epilogue; p.act = q.act; p.nchunk = q.nchunk;
+        p.bias = q.bias; p.add = q.add; p.ldadd = q.ldadd; p.C = q.C; p.ldc = q.ldc;
+        p.pctx = q.pctx; p.pstat = q.pstat; p.energies = q.energies; p.mask = q.mask; p.weights = q.weights;
+        p.S = q.S; p.mask_div = q.mask_div; p.mask_mod = q.mask_mod;
+        p.h = q.h; p.ldh = q.ldh; p.ru = q.ru; p.rh = q.rh; p.xc = q.xc; p.ldxc = q.ldxc;
+        p.h_out = q.h_out; p.ldho = q.ldho; p.h_out2 = q.h_out2; p.ldho2 = q.ldho2;
+        g.begin[i] = next;
+        next += g.tiles_m * nm_cdiv(q.N, 16);
+    }
+    for (int i = nprob; i <= NM_STEP_MAX_PROB; ++i) g.begin[i] = next;
+    for (int i = nprob; i < NM_STEP_MAX_PROB; ++i) g.p[i] = g.p[0];
+    hipLaunchKernelGGL((step_group_kernel<16>), dim3((unsigned)next), dim3(1024), 0, nm_stream(stream), g);
+    NM_LAUNCH_CHECK("nm_step_group");
+}

@@ -474,6 +474,9 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
         stats = ctx.buffer(key + ("stats",), (ops.logits_stats_numel(bsz, v),)) if use_stats else None
         table = self.embedding_matrix(ctx)
 
+        resident = getattr(stepper, "state_resident", False)     # the stepper keeps h_t in its own input row
+        h_prev_of = lambda t: s0 if t == 0 else (None if resident else s_all[t - 1])
+
         def body(t):
             """Step t touches persistent buffers only and depends on nothing but t (graph capturable)."""
             logits = logits_all[t] if keep_logits else logits_one
@@ -481,14 +484,14 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
             if use_stats:
                 want_logits = keep_logits or t < t_xent
                 stepper.step(emb, st_t, out_all[t], logits if want_logits else None, h_out=s_all[t],
-                             h_prev=s0 if t == 0 else s_all[t - 1], stats=stats)
+                             h_prev=h_prev_of(t), stats=stats)
                 if t < t_xent:
                     ops.xent(logits, tgt[t], tmask[t], xent_rows[t])
                 ops.greedy_finish(stats, v, finished, symbols[t], omask[t], END_TOKEN_INDEX, allfin[t:t + 1],
                                   table=table, emb_out=emb)
                 return
             if graph_ok:
-                stepper.step(emb, st_t, out_all[t], logits, h_out=s_all[t], h_prev=s0 if t == 0 else s_all[t - 1])
+                stepper.step(emb, st_t, out_all[t], logits, h_out=s_all[t], h_prev=h_prev_of(t))
             else:
                 if indexed:
                     stepper.set_position(t, 0)

@@ -279,9 +279,9 @@ def greedy_finish(stats, vocab, finished, sym_out, mask_out, end_id, all_finishe
                   argmax_out=None, max_out=None, lse_out=None):
     """Greedy step tail from the tile statistics: argmax, symbol / finished update, next input embedding."""
     lib = _lib.load()
-    tile = lib.nm_logits_stats_tile()
-    ntiles = (vocab + tile - 1) // tile
     rows = sym_out.numel()
+    tile = lib.nm_logits_stats_tile(rows)
+    ntiles = (vocab + tile - 1) // tile
     if emb_out is not None:
         assert emb_out.dim() == 2 and emb_out.stride(1) == 1 and emb_out.shape[0] == rows
     _lib.check(lib.nm_greedy_finish(_stream(), stats.data_ptr(), ntiles, rows, finished.data_ptr(),
@@ -298,14 +298,60 @@ def beam_topk_step_tiles(logits, stats, b, k, logprob_sum, lengths, finished, pe
     """One beam body from logits whose tile statistics ``logits_stats_gemm`` left in ``stats``."""
     lib = _lib.load()
     assert logits.dim() == 2 and logits.stride(1) == 1 and logits.shape[0] == b * k
-    tile = lib.nm_logits_stats_tile()
+    tile = lib.nm_logits_stats_tile(b * k)
     v = logits.shape[1]
     _lib.check(lib.nm_beam_topk_step_tiles(
-        _stream(), logits.data_ptr(), logits.stride(0), stats.data_ptr(), (v + tile - 1) // tile, b, k, v,
+        _stream(), logits.data_ptr(), logits.stride(0), stats.data_ptr(), tile, b, k, v,
         logprob_sum.data_ptr(), lengths.data_ptr(), finished.data_ptr(), penalty.data_ptr(), end_id,
         out_score.data_ptr(), out_word.data_ptr(), out_beam.data_ptr(), out_logprob_sum.data_ptr(),
         out_lengths.data_ptr(), out_finished.data_ptr(), out_src_row.data_ptr(), workspace.data_ptr(),
         workspace.numel() * 4, _p(all_finished), rmax.data_ptr(), rlse.data_ptr()), "nm_beam_topk_step_tiles")
+
+
+def attn_partials_layout(rows, s, a, c):
+    """(nchunk, pctx offset, pstat offset) in floats inside the attention workspace, or None when the shape is
+    served by the any-shape kernel (no split-S partials)."""
+    lib = _lib.load()
+    n, po, so = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    if lib.nm_attn_partials_layout(rows, s, a, c, ctypes.byref(n), ctypes.byref(po), ctypes.byref(so)) != 0:
+        return None
+    return int(n.value), int(po.value), int(so.value)
+
+
+def attn_fwd_partials(y, hf, states, mask, v, bias, rows_per_key, workspace):
+    """The attention step without its combine launch: energies + split-S partials stay in ``workspace``."""
+    lib = _lib.load()
+    r, a = y.shape
+    _, s, c = states.shape
+    assert hf.is_contiguous() and states.is_contiguous() and y.is_contiguous()
+    _lib.check(lib.nm_attn_fwd_partials(_stream(), y.data_ptr(), hf.data_ptr(), states.data_ptr(), _p(mask),
+                                        v.data_ptr(), _p(bias), r, rows_per_key, s, a, c, workspace.data_ptr(),
+                                        workspace.numel() * 4), "nm_attn_fwd_partials")
+
+
+class StepGroup:
+    """A launch of ``nm_step_group``: problem descriptors are built once (all pointers are persistent buffers)
+    and re-launched every step; ``patch`` changes the per-step pointers (history rows)."""
+
+    def __init__(self, rows, problems):
+        lib = _lib.load()
+        self.rows = rows
+        self.keep = []                       # tensors the descriptors point into
+        self.arr = (_lib.StepProblem * len(problems))()
+        for slot, spec in zip(self.arr, problems):
+            for name, val in spec.items():
+                if isinstance(val, torch.Tensor):
+                    self.keep.append(val)
+                    val = val.data_ptr()
+                setattr(slot, name, val)
+        self._fn = lib.nm_step_group
+
+    def patch(self, index, **fields):
+        for name, val in fields.items():
+            setattr(self.arr[index], name, val.data_ptr() if isinstance(val, torch.Tensor) else (val or 0))
+
+    def launch(self):
+        _lib.check(self._fn(_stream(), self.rows, self.arr, len(self.arr)), "nm_step_group")
 
 
 def gather_rows(src, idx, dst):

@@ -18,7 +18,12 @@ from .test_beam_fused_gpu import _state
 
 pytestmark = pytest.mark.gpu
 END = 2
-TILE = 128
+
+
+def tile_of(rows):
+    """Columns per statistics tile: the N extent of the GEMM's block tile (64 for <= 256 rows, else 128)."""
+    from neuralmonkey_amd import _lib
+    return int(_lib.load().nm_logits_stats_tile(rows))
 
 
 def T(a, dev, dt=torch.float32):
@@ -27,7 +32,8 @@ def T(a, dev, dt=torch.float32):
 
 def merged(stats, rows, v):
     """NumPy merge of the kernel's tile records -> (max, argmax, lse)."""
-    nt = (v + TILE - 1) // TILE
+    tile = tile_of(rows)
+    nt = (v + tile - 1) // tile
     st = stats.cpu().numpy().reshape(rows, nt, 4)
     mx = st[:, :, 0]
     sm = st[:, :, 1].astype(np.float64)

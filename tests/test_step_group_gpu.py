@@ -1,0 +1,184 @@
+"""nm_step_group (csrc/nm_step.hip): the GEMM groups of one inference step of the RNN attention decoder
+(Decoder.next_state, decoders/decoder.py:279-358) against the CPU oracle.
+
+  * plain problems: C = act(A . Bt^T + bias + add), several independent problems in one launch;
+  * GRU gates / candidate epilogues == O.gru_cell (nn/ortho_gru_cell.py:44-53) at R = 128, H = 512 and at
+    ragged sizes;
+  * the attention partials merged in the operand loader: ctx . W computed from nm_attn_fwd_partials'
+    workspace == O.attention_step's context . W, and the weights written by the same launch == the oracle's
+    distribution (feed_forward.py:139-154), one and five queries per key batch;
+  * FusedStepper == FastStepper: the same greedy / beam decode through both step drivers.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nm_oracle as O
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def T(a, dev, dt=torch.float32):
+    return torch.tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
+
+
+def rel(got, ref):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-6))
+
+
+@pytest.mark.parametrize("m", [128, 37, 640])
+def test_plain_problems_share_a_launch(dev, m):
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(m)
+    shapes = [(1024, 512, True, 1), (512, 1024, False, 0), (40, 64, True, 0)]          # (N, K, add?, act)
+    probs, want, outs = [], [], []
+    for n, k, has_add, act in shapes:
+        a = rng.standard_normal((m, k + 8)).astype(np.float32)                          # lda > K
+        w = (rng.standard_normal((k, n)) * 0.05).astype(np.float32)
+        bias = rng.standard_normal(n).astype(np.float32)
+        add = rng.standard_normal((m, n)).astype(np.float32) if has_add else None
+        ref = a[:, :k].astype(np.float64) @ w.astype(np.float64) + bias + (add if has_add else 0.0)
+        want.append(np.tanh(ref) if act else ref)
+        ad, wt, bd = T(a, dev), T(w.T, dev), T(bias, dev)
+        out = torch.full((m, n + 4), float("nan"), device=dev)
+        spec = dict(A=ad, lda=k + 8, Bt=wt, ldb=k, N=n, K=k, epilogue=0, act=act, bias=bd, C=out, ldc=n + 4)
+        if has_add:
+            spec.update(add=T(add, dev), ldadd=n)
+        probs.append(spec)
+        outs.append(out)
+    ops.StepGroup(m, probs).launch()
+    for out, ref, (n, _, _, _) in zip(outs, want, shapes):
+        got = out.cpu().numpy()
+        assert rel(got[:, :n], ref) < RTOL
+        assert np.isnan(got[:, n:]).all()                                                # nothing beyond N is touched
+
+
+@pytest.mark.parametrize("rows,e,h", [(128, 512, 512), (23, 48, 80), (640, 512, 512)])
+def test_gru_groups_match_the_cell(dev, rows, e, h):
+    """group 1 ([emb | h] . Wg -> r, u, r*h ; emb . Wc_x -> xc) + group 2 (candidate, blend in place)."""
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(rows + h)
+    p = {"gates_kernel": (rng.standard_normal((e + h, 2 * h)) * 0.05).astype(np.float32),
+         "gates_bias": np.ones(2 * h, np.float32),
+         "cand_kernel": (rng.standard_normal((e + h, h)) * 0.05).astype(np.float32),
+         "cand_bias": (rng.standard_normal(h) * 0.1).astype(np.float32)}
+    x = rng.standard_normal((rows, e)).astype(np.float32)
+    h0 = rng.standard_normal((rows, h)).astype(np.float32)
+    ref = O.gru_cell(x.astype(np.float64), h0.astype(np.float64), {k: v.astype(np.float64) for k, v in p.items()})
+    cat = T(np.concatenate([x, h0], 1), dev)
+    sel = cat[:, e:]
+    ru, rh, xc = (torch.empty((rows, w), device=dev) for w in (2 * h, h, h))
+    hist = torch.empty((rows, h), device=dev)
+    wg_t, wcx_t, wch_t = T(p["gates_kernel"].T, dev), T(p["cand_kernel"][:e].T, dev), T(p["cand_kernel"][e:].T, dev)
+    ld = e + h
+    ops.StepGroup(rows, [
+        dict(A=cat, lda=ld, Bt=wg_t, ldb=ld, N=2 * h, K=ld, epilogue=1, bias=T(p["gates_bias"], dev), h=sel, ldh=ld,
+             ru=ru, rh=rh),
+        dict(A=cat, lda=ld, Bt=wcx_t, ldb=e, N=h, K=e, epilogue=0, bias=T(p["cand_bias"], dev), C=xc, ldc=h)]).launch()
+    ops.StepGroup(rows, [
+        dict(A=rh, lda=h, Bt=wch_t, ldb=h, N=h, K=h, epilogue=2, xc=xc, ldxc=h, ru=ru, h=sel, ldh=ld, h_out=sel,
+             ldho=ld, h_out2=hist, ldho2=h)]).launch()
+    assert rel(hist.cpu().numpy(), ref) < RTOL
+    assert torch.equal(cat[:, e:], hist)                              # the new state replaced the old one in place
+    assert np.array_equal(cat[:, :e].cpu().numpy(), x)                # the input half is untouched
+
+
+@pytest.mark.parametrize("bk,qpk,s,a,c,o", [(128, 1, 50, 1024, 1024, 512), (16, 5, 50, 1024, 1024, 512),
+                                            (9, 1, 23, 64, 48, 20), (3, 3, 7, 32, 2048, 36)])
+def test_partials_merged_in_the_operand_loader(dev, bk, qpk, s, a, c, o):
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(bk * 7 + qpk)
+    r = bk * qpk
+    q = rng.standard_normal((r, 40)).astype(np.float32)
+    ap = {"query_w": (rng.standard_normal((40, a)) * 0.2).astype(np.float32),
+          "query_b": (rng.standard_normal(a) * 0.1).astype(np.float32),
+          "v": (rng.standard_normal(a) * 0.3).astype(np.float32), "bias": np.float32(0.1)}
+    hf = rng.standard_normal((bk, s, a)).astype(np.float32)
+    states = rng.standard_normal((bk, s, c)).astype(np.float32)
+    mask = np.ones((bk, s), np.float32)
+    for i in range(bk):
+        mask[i, rng.integers(1, s + 1):] = 0
+    rep = lambda x: np.repeat(x, qpk, axis=0)
+    ctx_ref, w_ref = O.attention_step(q.astype(np.float64), rep(hf).astype(np.float64), rep(states).astype(np.float64),
+                                      rep(mask).astype(np.float64), {k: np.asarray(v, np.float64) for k, v in ap.items()})
+    wo = (rng.standard_normal((c, o)) * 0.05).astype(np.float32)
+    pre = rng.standard_normal((r, o)).astype(np.float32)
+    want = np.tanh(ctx_ref @ wo.astype(np.float64) + pre)
+    lay = ops.attn_partials_layout(r, s, a, c)
+    assert lay is not None
+    nchunk, pctx_off, pstat_off = lay
+    ws = ops.attn_workspace(r, s, c, dev)
+    y = T(q @ ap["query_w"] + ap["query_b"], dev)
+    ops.attn_fwd_partials(y, T(hf, dev), T(states, dev), T(mask, dev), T(ap["v"], dev), T([ap["bias"]], dev), qpk, ws)
+    out = torch.empty((r, o), device=dev)
+    weights = torch.empty((r, s), device=dev)
+    pre_d = T(pre, dev)
+    ops.StepGroup(r, [dict(a_kind=1, Bt=T(wo.T, dev), ldb=c, N=o, K=c, epilogue=0, act=1, add=pre_d, ldadd=o, C=out,
+                           ldc=o, pctx=ws[pctx_off:], pstat=ws[pstat_off:], nchunk=nchunk, energies=ws,
+                           mask=T(mask, dev), weights=weights, S=s, mask_div=qpk, mask_mod=bk)]).launch()
+    assert rel(out.cpu().numpy(), want) < RTOL
+    assert np.abs(weights.cpu().numpy() - w_ref).max() < 2e-6
+    # and identical (to rounding) to the two-launch path: attention + combine, then a plain GEMM
+    ctx2 = torch.empty((r, c), device=dev)
+    w2 = torch.empty((r, s), device=dev)
+    ops.attn_fwd(y, T(hf, dev), T(states, dev), T(mask, dev), T(ap["v"], dev), T([ap["bias"]], dev), qpk, ctx2, w2, ws)
+    assert rel(ctx2.cpu().numpy(), ctx_ref) < RTOL
+    assert torch.allclose(w2, weights, atol=1e-7, rtol=0)
+
+
+def _decode_both_ways(dev, beam):
+    """The same model and batch through FusedStepper and (NM_NO_FUSED_STEP=1) FastStepper."""
+    from neuralmonkey_amd import synthetic
+    from neuralmonkey_amd.decoders import decoder as decoder_mod
+    outs = []
+    for no_fused in ("", "1"):
+        if no_fused:
+            os.environ["NM_NO_FUSED_STEP"] = "1"
+        else:
+            os.environ.pop("NM_NO_FUSED_STEP", None)
+        try:
+            model = synthetic.build_translation_model(vocab_src=2000, vocab_tgt=2000, emb=64, rnn=64, max_len=20,
+                                                      beam_size=beam, max_steps=12, with_trainer=False,
+                                                      device=str(dev))
+            store = model.tf_manager.sessions[0].store
+            store.load_state_dict(O.init_params(seed=5, vocab_src=2000, vocab_tgt=2000, emb=64, rnn=64, std=0.1))
+            ds = synthetic.synthetic_dataset(seed=6, batch=24, src_len=20, tgt_len=15, vocab=2000, ragged=True)
+            sess = model.tf_manager.sessions[0]
+            fd = {}
+            for f in model.greedy_runner.feedables | model.beam_runner.feedables:
+                fd.update(f.feed_dict(ds, train=False))
+            got = sess.run({"sym": model.decoder.decoded_symbols, "logits": model.decoder.runtime_logits,
+                            "bs": model.beam_decoder.outputs, "w": model.decoder.runtime_loop_result}, fd)
+            kinds = set()
+            real = decoder_mod.make_stepper
+
+            def spy(*args, **kw):
+                st = real(*args, **kw)
+                kinds.add(type(st).__name__)
+                return st
+            decoder_mod.make_stepper = spy
+            try:
+                sess.run({"sym": model.decoder.decoded_symbols}, fd)
+            finally:
+                decoder_mod.make_stepper = real
+            outs.append((got, kinds))
+        finally:
+            os.environ.pop("NM_NO_FUSED_STEP", None)
+    return outs
+
+
+def test_fused_stepper_equals_the_six_gemm_stepper(dev):
+    (fused, kf), (plain, kp) = _decode_both_ways(dev, beam=4)
+    assert kf == {"FusedStepper"} and kp == {"FastStepper"}
+    assert np.array_equal(fused["sym"], plain["sym"])
+    assert rel(fused["logits"], plain["logits"]) < 2e-5
+    wf, wp = np.asarray(fused["w"].attention_weights[0]), np.asarray(plain["w"].attention_weights[0])
+    assert wf.shape == wp.shape and np.abs(wf - wp).max() < 1e-6
+    tf_, tp = (np.asarray(x["bs"].last_search_step_output.token_ids) for x in (fused, plain))
+    assert tf_.shape == tp.shape and (tf_ == tp).mean() > 0.98          # near-ties may flip between roundings
+    sf, sp = (np.asarray(x["bs"].last_search_step_output.scores) for x in (fused, plain))
+    assert np.abs(sf - sp).max() < 1e-4 * np.abs(sp).max()
