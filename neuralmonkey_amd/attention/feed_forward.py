@@ -85,7 +85,7 @@ class Attention(BaseAttention):
         hf = self.hidden_features(ctx)
         self.project_query(ctx, query, y)
         ws = ctx.buffer((id(self), "ws", rows), ((ops._lib.load().nm_attn_workspace_bytes(
-            rows, states.shape[1], states.shape[2]) + 3) // 4,))
+            rows, states.shape[1], states.shape[2]) + 3) // 4,), zero_init=True)
         ops.attn_fwd(y, hf, states, self.attention_mask(ctx), self.var(ctx, "attn_similarity_v"),
                      self.var(ctx, "attn_bias"), self.rows_per_key, ctx_out, w_out, ws, energies_out)
 
@@ -101,7 +101,7 @@ class Attention(BaseAttention):
         if lay is None or lay[0] > 8 or c % 16 or a % 4 or rows % self.rows_per_key or rows // self.rows_per_key != bk:
             return None
         nchunk, pctx_off, pstat_off = lay
-        ws = ctx.buffer((id(self), "ws", rows), ((ops._lib.load().nm_attn_workspace_bytes(rows, slen, c) + 3) // 4,))
+        ws = ctx.buffer((id(self), "ws", rows), ((ops._lib.load().nm_attn_workspace_bytes(rows, slen, c) + 3) // 4,), zero_init=True)
         return {"ws": ws, "nchunk": nchunk, "energies": ws[:rows * slen].view(rows, slen),
                 "pctx": ws[pctx_off:pctx_off + rows * nchunk * c], "pstat": ws[pstat_off:pstat_off + rows * nchunk * 4],
                 "S": slen, "C": c, "Bk": bk}
@@ -123,7 +123,7 @@ class Attention(BaseAttention):
         hf = self.hidden_features(ctx)
         self.project_query(ctx, queries.reshape(steps * bsz, qdim), y_all.view(steps * bsz, -1))
         ws = ctx.buffer((id(self), "ws_all", steps, bsz), ((ops._lib.load().nm_attn_workspace_bytes(
-            steps * bsz, states.shape[1], states.shape[2]) + 3) // 4,))
+            steps * bsz, states.shape[1], states.shape[2]) + 3) // 4,), zero_init=True)
         ops.attn_fwd_time_major(y_all, hf, states, self.attention_mask(ctx), self.var(ctx, "attn_similarity_v"),
                                 self.var(ctx, "attn_bias"), ctx_all, w_all, ws, e_all)
 
@@ -257,7 +257,7 @@ class AttentionTapeSession:
         out = tape.new((rows, c))
         w = w_out if w_out is not None else tape.buf((rows, s))
         e = tape.buf((rows, s)) if tape.recording else None
-        ws = ctx.buffer((id(att), "ws", rows), ((ops._lib.load().nm_attn_workspace_bytes(rows, s, c) + 3) // 4,))
+        ws = ctx.buffer((id(att), "ws", rows), ((ops._lib.load().nm_attn_workspace_bytes(rows, s, c) + 3) // 4,), zero_init=True)
         hf3, st3 = self.hf.data.view(b, s, a), self.states.data.view(b, s, c)
         ops.attn_fwd(y.data, hf3, st3, self.mask, self.v.data, self.bias.data, att.rows_per_key, out.data, w, ws, e)
 

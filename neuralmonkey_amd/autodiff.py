@@ -413,7 +413,7 @@ def attn_energies(tape: Tape, y: Var, hf: Var, v: Var, bsz: int, slen: int, rows
     out = tape.new((rows, slen))
     hf3 = hf.data.view(bsz, slen, a)
     ws = ctx.buffer(("attn_energies_ws", rows, slen, a), ((ops._lib.load().nm_attn_workspace_bytes(rows, slen, a)
-                                                            + 3) // 4,))
+                                                            + 3) // 4,), zero_init=True)
     scratch_ctx = ctx.buffer(("attn_energies_ctx", rows, a), (rows, a))
     ops.attn_fwd(y.data, hf3, hf3, None, v.data, None, rows_per_key, scratch_ctx, None, ws, out.data)
 

@@ -82,10 +82,107 @@ struct AttnArgs {
     // query q (0 <= q < nq) of key batch b is row b*qsb + q*qsq of y / ctx / weights:
     // beam layout (qsb = nq, qsq = 1) or time-major layout (qsb = 1, qsq = Bk)
     int qsb, qsq, nq;
+    // in-kernel merge of the split-S partials (fast kernels): the chunk workgroup that arrives LAST for its key
+    // batch merges all partials and writes ctx / weights -- no combine launch
+    unsigned* tickets;    // [Bk] arrival counters, zero between launches (the merging workgroup restores the zero)
+    float* ctx; long ldctx;
+    float* weights;       // [R,S] or null
+    int merge, Bk;
 };
 
 __device__ __forceinline__ long attn_qrow(const AttnArgs& p, int b, int qi) {
     return (long)b * p.qsb + (long)min(qi, p.nq - 1) * p.qsq;
+}
+
+
+// ---- in-kernel hand-off of the partials to the merging workgroup (MI355X: per-XCD L2s are not coherent, a CU's
+// L1 is never refreshed by other CUs' stores).  Producer side of the guide's recipe R1: the payload is stored
+// WRITE-THROUGH (agent-scope relaxed stores lower to `global_store ... sc1`), every storing wave drains its
+// stores (s_waitcnt vmcnt(0)), the workgroup meets, ONE lane takes a ticket with an agent-scope atomic.  The
+// workgroup that draws the last ticket is the consumer: one agent-scope acquire (invalidates its L1), a
+// barrier, then plain loads.
+__device__ __forceinline__ void st_wt2(float* p, float a, float b) {
+    const unsigned long long x = ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_wt4(float* p, float4 v) { st_wt2(p, v.x, v.y); st_wt2(p + 2, v.z, v.w); }
+__device__ __forceinline__ void st_wt1(float* p, float a) {
+    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// true for every thread of the workgroup that arrived last for key batch b
+__device__ __forceinline__ bool attn_arrive_last(const AttnArgs& p, int b, int* s_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its write-through stores
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(p.tickets + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (t == (unsigned)(p.nchunk - 1));
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(p.tickets + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        }
+        *s_flag = last;
+    }
+    __syncthreads();
+    return *s_flag != 0;
+}
+
+// merge of the nchunk partials of query row qr (key batch b) by the 256 threads of the last-arriving workgroup:
+// attn_combine's arithmetic (feed_forward.py:139-154 carried through the chunk statistics)
+#define ATT_MERGE_MAXCH 8
+__device__ __forceinline__ void attn_merge_row(const AttnArgs& p, long qr, int b) {
+    const int tid = threadIdx.x;
+    const float* pc = p.pctx + qr * p.nchunk * p.C;
+    const float4* st = reinterpret_cast<const float4*>(p.pstat) + qr * p.nchunk;
+    float4 x[ATT_MERGE_MAXCH];
+    {
+        const int c = tid * 4;
+#pragma unroll
+        for (int i = 0; i < ATT_MERGE_MAXCH; ++i)
+            x[i] = (c < p.C && i < p.nchunk) ? *reinterpret_cast<const float4*>(pc + (long)i * p.C + c)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float e_s = 0.0f, mk = 1.0f;
+    const bool w_ok = p.weights && tid < p.S;
+    if (w_ok) {
+        e_s = p.energies[qr * p.S + tid];
+        if (p.mask) mk = p.mask[(long)b * p.S + tid];
+    }
+    float4 sv[ATT_MERGE_MAXCH];
+    float M = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < ATT_MERGE_MAXCH; ++i) {
+        sv[i] = i < p.nchunk ? st[i] : make_float4(-INFINITY, 0.f, 0.f, 0.f);
+        M = fmaxf(M, sv[i].x);
+    }
+    float la = 0.0f, lm = 0.0f, f[ATT_MERGE_MAXCH];
+#pragma unroll
+    for (int i = 0; i < ATT_MERGE_MAXCH; ++i) {
+        f[i] = i < p.nchunk ? __expf(sv[i].x - M) : 0.0f;
+        la += f[i] * sv[i].y;
+        lm += f[i] * sv[i].z;
+    }
+    const float inv = 1.0f / (lm + 1e-8f * la);
+    for (int c = tid * 4; c < p.C; c += 1024) {
+        if (c >= 1024) {                               // second 1024-column group (C up to 2048): one more round trip
+#pragma unroll
+            for (int i = 0; i < ATT_MERGE_MAXCH; ++i)
+                x[i] = i < p.nchunk ? *reinterpret_cast<const float4*>(pc + (long)i * p.C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < ATT_MERGE_MAXCH; ++i) {
+            a.x += f[i] * x[i].x; a.y += f[i] * x[i].y; a.z += f[i] * x[i].z; a.w += f[i] * x[i].w;
+        }
+        a.x *= inv; a.y *= inv; a.z *= inv; a.w *= inv;
+        *reinterpret_cast<float4*>(p.ctx + qr * p.ldctx + c) = a;
+    }
+    if (w_ok) p.weights[qr * p.S + tid] = __expf(e_s - M) * mk * inv;
+    if (p.weights)
+        for (int s2 = tid + 256; s2 < p.S; s2 += 256) {
+            const float m2 = p.mask ? p.mask[(long)b * p.S + s2] : 1.0f;
+            p.weights[qr * p.S + s2] = __expf(p.energies[qr * p.S + s2] - M) * m2 * inv;
+        }
 }
 
 template <int QPK, int NCG>
@@ -282,15 +379,22 @@ __global__ __launch_bounds__(256) void attn_partial_fast(AttnArgs p) {
         acc.x += em * str[s].x; acc.y += em * str[s].y;
         acc.z += em * str[s].z; acc.w += em * str[s].w;
     }
-    if (tid < ns)
-        p.energies[(long)b * p.S + s0 + tid] =
-            ((pe[0][tid] + pe[1][tid]) + (pe[2][tid] + pe[3][tid])) + bias;
-    if (tid == 0) {
-        float* st = p.pstat + ((long)b * p.nchunk + chunk) * 4;
-        st[0] = m; st[1] = la; st[2] = lm; st[3] = 0.0f;
+    const float e_own = tid < ns ? ((pe[0][tid] + pe[1][tid]) + (pe[2][tid] + pe[3][tid])) + bias : 0.0f;
+    float* st = p.pstat + ((long)b * p.nchunk + chunk) * 4;
+    float* pc = p.pctx + ((long)b * p.nchunk + chunk) * p.C + col;
+    if (!p.merge) {
+        if (tid < ns) p.energies[(long)b * p.S + s0 + tid] = e_own;
+        if (tid == 0) { st[0] = m; st[1] = la; st[2] = lm; st[3] = 0.0f; }
+        if (c_ok) *reinterpret_cast<float4*>(pc) = acc;
+        return;
     }
-    if (c_ok)
-        *reinterpret_cast<float4*>(p.pctx + ((long)b * p.nchunk + chunk) * p.C + col) = acc;
+    // write-through hand-off to the workgroup that merges this sentence's partials (the last one to arrive)
+    if (tid < ns) st_wt1(p.energies + (long)b * p.S + s0 + tid, e_own);
+    if (tid == 0) st_wt4(st, make_float4(m, la, lm, 0.0f));
+    if (c_ok) st_wt4(pc, acc);
+    __shared__ int s_last;
+    if (!attn_arrive_last(p, b, &s_last)) return;
+    attn_merge_row(p, b, b);
 }
 
 // ---------------------------------------------------------------------------
@@ -350,7 +454,10 @@ __global__ __launch_bounds__(256) void attn_partial_fastq(AttnArgs p) {
             e[s] = ((pe[0][q][s] + pe[1][q][s]) + (pe[2][q][s] + pe[3][q][s])) + bias;
             if (s < ns) {
                 m = fmaxf(m, e[s]);
-                if (live) p.energies[qr * p.S + s0 + s] = e[s];
+                if (live) {
+                    if (p.merge) st_wt1(p.energies + qr * p.S + s0 + s, e[s]);
+                    else p.energies[qr * p.S + s0 + s] = e[s];
+                }
             }
         }
         float la = 0.0f, lm = 0.0f;
@@ -366,7 +473,8 @@ __global__ __launch_bounds__(256) void attn_partial_fastq(AttnArgs p) {
         }
         if (live) {
             float* st = p.pstat + (qr * p.nchunk + chunk) * 4;
-            st[0] = m; st[1] = la; st[2] = lm; st[3] = 0.0f;
+            if (p.merge) st_wt4(st, make_float4(m, la, lm, 0.0f));
+            else { st[0] = m; st[1] = la; st[2] = lm; st[3] = 0.0f; }
         }
     }
     __syncthreads();
@@ -385,9 +493,16 @@ __global__ __launch_bounds__(256) void attn_partial_fastq(AttnArgs p) {
     if (c_ok) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
-            if (q < p.nq)
-                *reinterpret_cast<float4*>(p.pctx + (attn_qrow(p, b, q) * p.nchunk + chunk) * p.C + col) = acc[q];
+            if (q < p.nq) {
+                float* pc = p.pctx + (attn_qrow(p, b, q) * p.nchunk + chunk) * p.C + col;
+                if (p.merge) st_wt4(pc, acc[q]);
+                else *reinterpret_cast<float4*>(pc) = acc[q];
+            }
     }
+    if (!p.merge) return;
+    __shared__ int s_last;
+    if (!attn_arrive_last(p, b, &s_last)) return;
+    for (int q = 0; q < p.nq; ++q) attn_merge_row(p, attn_qrow(p, b, q), b);
 }
 
 // Merge of the split-S partials of one query row.  Latency-bound (2.6 MB in, 0.5 MB out over 128 rows), so
@@ -508,7 +623,9 @@ extern "C" int64_t nm_attn_workspace_bytes(int64_t R, int64_t S, int64_t C) {
     int sch, nchunk;
     attn_chunking(S, &sch, &nchunk);
     const int64_t e = ((R * S + 3) / 4) * 4;
-    return (int64_t)sizeof(float) * (e + R * nchunk * C + R * nchunk * 4);
+    // energies | partial contexts | partial statistics | one arrival counter per key batch (<= R of them).  The
+    // counters must be ZERO when a step is launched; the kernels leave them zero, so a workspace is zeroed once.
+    return (int64_t)sizeof(float) * (e + R * nchunk * C + R * nchunk * 4 + ((R + 3) / 4) * 4);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -624,6 +741,10 @@ static int attn_fwd_impl(void* stream, const float* y, const float* hf, const fl
     p.pstat = p.pctx + R * nchunk * C;
     p.R = (int)R; p.S = (int)S; p.A = (int)A; p.C = (int)C; p.nchunk = nchunk; p.sch = sch;
     p.qsb = (int)q_stride_b; p.qsq = (int)q_stride_q; p.nq = (int)nq;
+    p.tickets = reinterpret_cast<unsigned*>(p.pstat + R * nchunk * 4);
+    p.ctx = ctx; p.ldctx = (long)ldctx; p.weights = weights; p.merge = 0; p.Bk = (int)Bk;
+    static const bool no_merge = getenv("NM_ATTN_NOMERGE") != nullptr;      // A/B switch: separate combine launch
+    const bool may_merge = do_combine && !no_merge && nchunk <= ATT_MERGE_MAXCH;
     const size_t shm = sizeof(float) * ((size_t)qpk * A + A + (size_t)qpk * ATT_MAX_SCH + ATT_MAX_SCH +
                                         (size_t)4 * qpk * ATT_MAX_SCH);
     NM_REQUIRE(shm <= 160 * 1024, "nm_attn_fwd: A too large for LDS staging");
@@ -639,11 +760,14 @@ static int attn_fwd_impl(void* stream, const float* y, const float* hf, const fl
     if (prof) hipEventRecord(prof->first, st);
     static const bool no_fast = getenv("NM_ATTN_NOFAST") != nullptr;       // A/B switch for tuning
     if (nq == 1 && A <= 1024 && C <= 1024 && sch <= ATT_FAST_ROWS && !no_fast) {
+        p.merge = may_merge;
         if (sch <= 8) hipLaunchKernelGGL(attn_partial_fast<8>, grid, block, 0, st, p);
         else if (sch <= 10) hipLaunchKernelGGL(attn_partial_fast<10>, grid, block, 0, st, p);
         else hipLaunchKernelGGL(attn_partial_fast<12>, grid, block, 0, st, p);
     } else if (nq <= 8 && groups == 1 && A <= 1024 && C <= 1024 && sch <= ATT_FAST_ROWS && !no_fast) {
-        // a few queries per key batch (beam search): all loads in flight first, queries in registers
+        // a few queries per key batch (beam search): all loads in flight first, queries in registers.  (No
+        // in-kernel merge here: one workgroup merging the k rows of a sentence one after the other was measured
+        // 10 us slower than the separate combine launch it saves, 40.6 vs 30.5 + 5.3 us at k = 5.)
 #define NM_AQ(R_)                                                                                  \
         do {                                                                                       \
             if (nq <= 2) hipLaunchKernelGGL((attn_partial_fastq<R_, 2>), grid, block, 0, st, p);      \
@@ -668,7 +792,7 @@ static int attn_fwd_impl(void* stream, const float* y, const float* hf, const fl
 #undef NM_AT
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) NM_FAIL(NM_ERR_HIP, "nm_attn_fwd: partial launch failed: %s", hipGetErrorString(e));
-    if (do_combine)
+    if (do_combine && !p.merge)
         hipLaunchKernelGGL(attn_combine, dim3((unsigned)R), dim3(256), 0, st, p.pctx, p.pstat, p.energies,
                            mask, ctx, (long)ldctx, weights, (int)S, (int)C, nchunk,
                            beam_layout ? (int)nq : 1, (int)Bk);

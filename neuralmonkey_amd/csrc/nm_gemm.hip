@@ -69,15 +69,22 @@ __device__ __forceinline__ void store_tile32(const GemmArgs& g, float* __restric
 // tiled kernel
 // ---------------------------------------------------------------------------
 // WM x WN waves, each owning TM x TN MFMA tiles of 32x32: block tile (WM*32*TM) x (WN*32*TN).
-template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool VEC, int BK, bool STATS = false>
+template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool VEC, int BK, bool STATS = false, int PF = 1>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_tiled(GemmArgs g, int tiles_m) {
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * 32 * TM, BN = WN * 32 * TN;
     constexpr int LA = BM * BK / 4 / NT, LB = BN * BK / 4 / NT, KQ = BK / 4;   // float4 loads per thread; float4s per k-row
     static_assert(LA >= 1 && LB >= 1 && LA * NT * 4 == BM * BK && LB * NT * 4 == BN * BK, "tile / thread mismatch");
     constexpr int LDAS = BM + 4, LDBS = BN + 4;
-    __shared__ __attribute__((aligned(16))) float As[2][BK][LDAS];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDBS];
+    // one LDS allocation: the double-buffered operand tiles; the statistics epilogue (STATS) re-uses it for
+    // half an output tile at a time
+    constexpr int A_FLOATS = 2 * BK * LDAS, B_FLOATS = 2 * BK * LDBS;
+    constexpr int ST_FLOATS = STATS ? (BM / 2) * (BN + 1) + 3 * NT : 0;
+    constexpr int SM_FLOATS = A_FLOATS + B_FLOATS > ST_FLOATS ? A_FLOATS + B_FLOATS : ST_FLOATS;
+    static_assert((A_FLOATS * 4) % 16 == 0, "B tile must stay 16-byte aligned");
+    __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
+    float (*As)[BK][LDAS] = reinterpret_cast<float (*)[BK][LDAS]>(smem);
+    float (*Bs)[BK][LDBS] = reinterpret_cast<float (*)[BK][LDBS]>(smem + A_FLOATS);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MB
@@ -109,9 +116,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tiled(GemmArgs g, int tiles
     const float* __restrict__ B = g.B + (long)blockIdx.z * g.sB;
     float* __restrict__ C = g.C + (long)blockIdx.z * g.sC;
 
-    float4 ra[LA], rb[LB];
+    float4 ra0[LA], rb0[LB], ra1[PF == 2 ? LA : 1], rb1[PF == 2 ? LB : 1];
 
-    auto load_a = [&](int k0) {
+    auto load_a = [&](int k0, float4* ra) {
 #pragma unroll
         for (int it = 0; it < LA; ++it) {
             const int idx = tid + it * NT;
@@ -146,7 +153,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tiled(GemmArgs g, int tiles
             ra[it] = v;
         }
     };
-    auto load_b = [&](int k0) {
+    auto load_b = [&](int k0, float4* rb) {
 #pragma unroll
         for (int it = 0; it < LB; ++it) {
             const int idx = tid + it * NT;
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tiled(GemmArgs g, int tiles
             rb[it] = v;
         }
     };
-    auto store_lds = [&](int buf) {
+    auto store_lds = [&](int buf, const float4* ra, const float4* rb) {
 #pragma unroll
         for (int it = 0; it < LA; ++it) {
             const int idx = tid + it * NT;
@@ -227,15 +234,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tiled(GemmArgs g, int tiles
     const int kt0 = blockIdx.y * per_slice;
     const int nkt = min(nkt_all, kt0 + per_slice);
 
-    load_a(kt0 * BK);
-    load_b(kt0 * BK);
-    store_lds(0);
-    __syncthreads();
-    int cur = 0;
-    for (int kt = kt0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) { load_a((kt + 1) * BK); load_b((kt + 1) * BK); }
-        // fragments of the next k-pair are read from LDS before the MFMAs of the current pair
-        // are issued, so the LDS latency sits under 4 x 64 cycles of matrix work
+    // one k-tile of MFMA work on LDS buffer `cur`: fragments of the next k-pair are read from LDS before
+    // the MFMAs of the current pair are issued, so the LDS latency sits under 4 x 64 cycles of matrix work
+    auto mma_tile = [&](int cur) {
         float a[2][TM], b[2][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) a[0][i] = As[cur][lane >> 5][wm + i * 32 + (lane & 31)];
@@ -256,13 +257,43 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tiled(GemmArgs g, int tiles
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p][i], b[p][j], acc[i][j], 0, 0, 0);
-            // pin the order: the two LDS reads of the next pair first, then this pair's MFMAs
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            // pin the order: the LDS reads of the next pair first, then this pair's MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
         }
-        if (kt + 1 < nkt) store_lds(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+    };
+
+    load_a(kt0 * BK, ra0);
+    load_b(kt0 * BK, rb0);
+    store_lds(0, ra0, rb0);
+    __syncthreads();
+    if constexpr (PF == 2) {
+        // global loads run TWO k-tiles ahead of the MFMAs (two register sets, alternating): a workgroup that is
+        // alone on its CU (one decoding step: a single row of block tiles, every weight tile a first touch)
+        // has nothing else to hide the memory latency behind
+        if (kt0 + 1 < nkt) { load_a((kt0 + 1) * BK, ra1); load_b((kt0 + 1) * BK, rb1); }
+        int kt = kt0;
+        while (kt < nkt) {
+            if (kt + 2 < nkt) { load_a((kt + 2) * BK, ra0); load_b((kt + 2) * BK, rb0); }
+            mma_tile(0);
+            if (kt + 1 < nkt) store_lds(1, ra1, rb1);
+            __syncthreads();
+            if (++kt >= nkt) break;
+            if (kt + 2 < nkt) { load_a((kt + 2) * BK, ra1); load_b((kt + 2) * BK, rb1); }
+            mma_tile(1);
+            if (kt + 1 < nkt) store_lds(0, ra0, rb0);
+            __syncthreads();
+            ++kt;
+        }
+    } else {
+        int cur = 0;
+        for (int kt = kt0; kt < nkt; ++kt) {
+            if (kt + 1 < nkt) { load_a((kt + 1) * BK, ra0); load_b((kt + 1) * BK, rb0); }
+            mma_tile(cur);
+            if (kt + 1 < nkt) store_lds(cur ^ 1, ra0, rb0);
+            __syncthreads();
+            cur ^= 1;
+        }
     }
 
     if (g.splitk > 1) {          // raw partial sums into this slice's slab; epilogue in splitk_reduce
@@ -282,76 +313,81 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tiled(GemmArgs g, int tiles
         // beam_search_decoder.py:537-543): per row the tile's max, its first argmax and
         // sum exp(x - max); nm_greedy_finish / the beam tile scan merge the tiles of a row.
         // The logits themselves are stored only when somebody reads them (g.store_c).
-        __shared__ float sx_max[WN][BM];
-        __shared__ int sx_arg[WN][BM];
-        __shared__ float sx_sum[WN][BM];
-        const int wcol = wave % WN;
-        int colj[TN];
+        if (g.act == 9) return;         // NM_STATS_ABLATE=1: timing ablation, the epilogue is skipped entirely
+        // The tile goes through LDS, half of its rows at a time (the operand buffers are free by now): every
+        // row is then scanned by NT / (BM/2) threads that read contiguous column segments -- two short
+        // conflict-free LDS loops (max / first argmax, then sum exp) instead of ~250 cross-lane shuffles per
+        // thread on the accumulator layout (measured: 14 of the 58 us of one decoding step's projection).
+        constexpr int HR = BM / 2, TS = BN + 1;          // rows per half; odd row stride: column scans hit 32 banks
+        constexpr int TPR = NT / HR, CW = BN / TPR;      // threads per row, columns per thread
+        static_assert(NT % HR == 0 && BN % TPR == 0 && TPR <= 16, "statistics epilogue thread layout");
+        float* T = smem;
+        float* pmax = smem + HR * TS;
+        int* parg = reinterpret_cast<int*>(pmax + NT);
+        float* psum = pmax + 2 * NT;
         bool okj[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            colj[j] = n0 + wn + j * 32 + (lane & 31);
-            okj[j] = colj[j] < g.N;
-            const float bv = (okj[j] && g.bias) ? g.bias[colj[j]] : 0.0f;
+            const int col = n0 + wn + j * 32 + (lane & 31);
+            okj[j] = col < g.N;
+            const float bv = (okj[j] && g.bias) ? g.bias[col] : 0.0f;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] += bv;
         }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float best = -INFINITY;
-                int bi = 0x7fffffff;
-#pragma unroll
-                for (int j = 0; j < TN; ++j)          // ascending columns, strict >: the first maximum is kept
-                    if (okj[j] && acc[i][j][r] > best) { best = acc[i][j][r]; bi = colj[j]; }
-#pragma unroll
-                for (int off = 16; off > 0; off >>= 1) {
-                    const float ov = __shfl_xor(best, off, 64);
-                    const int oi = __shfl_xor(bi, off, 64);
-                    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-                }
-                if ((lane & 31) == 0) {
-                    const int rl = wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    sx_max[wcol][rl] = best;
-                    sx_arg[wcol][rl] = bi;
-                }
-            }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rl = wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                float m = sx_max[0][rl];
-#pragma unroll
-                for (int w = 1; w < WN; ++w) m = fmaxf(m, sx_max[w][rl]);
-                float sum = 0.0f;
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    if (okj[j]) sum += expf(acc[i][j][r] - m);
-#pragma unroll
-                for (int off = 16; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-                if ((lane & 31) == 0) sx_sum[wcol][rl] = sum;
-            }
-        __syncthreads();
         const int tiles_n = (int)gridDim.x / tiles_m;
-        for (int rl = tid; rl < BM; rl += NT) {
-            const int row = m0 + rl;
-            if (row >= g.M) continue;
-            float m = sx_max[0][rl], sum = sx_sum[0][rl];
-            int a = sx_arg[0][rl];
+        const int rr = tid % HR, q = tid / HR;
+        for (int h = 0; h < 2; ++h) {
+            __syncthreads();                              // previous users of the buffer are done
 #pragma unroll
-            for (int w = 1; w < WN; ++w) {
-                const float om = sx_max[w][rl];
-                if (om > m || (om == m && sx_arg[w][rl] < a)) { m = om; a = sx_arg[w][rl]; }
-                sum += sx_sum[w][rl];
+            for (int i = 0; i < TM; ++i) {
+                const int rbase = wm + i * 32 - h * HR;   // this 32-row MFMA tile inside the half (wave-uniform)
+                if (rbase >= 0 && rbase < HR) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            T[(rbase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * TS + wn + j * 32 + (lane & 31)] =
+                                okj[j] ? acc[i][j][r] : -INFINITY;
+                }
             }
-            float4 rec;
-            rec.x = m; rec.y = sum; rec.z = __int_as_float(a); rec.w = 0.0f;
-            *reinterpret_cast<float4*>(g.stats + ((long)row * tiles_n + bn) * 4) = rec;
+            __syncthreads();
+            const float* trow = T + rr * TS + q * CW;
+            float best = -INFINITY;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {                // ascending columns, strict >: the first maximum is kept
+                const float v = trow[c];
+                if (v > best) { best = v; bi = n0 + q * CW + c; }
+            }
+            pmax[q * HR + rr] = best;
+            parg[q * HR + rr] = bi;
+            __syncthreads();
+            float m = pmax[rr];
+#pragma unroll
+            for (int w = 1; w < TPR; ++w) m = fmaxf(m, pmax[w * HR + rr]);
+            float sum = 0.0f;
+#pragma unroll
+            for (int c = 0; c < CW; ++c) sum += expf(trow[c] - m);          // padding columns hold -inf: exp -> 0
+            psum[q * HR + rr] = sum;
+            __syncthreads();
+            const int row = m0 + h * HR + tid;
+            if (tid < HR && row < g.M) {
+                float tot = psum[tid];
+                int a = parg[tid];
+#pragma unroll
+                for (int w = 1; w < TPR; ++w) {           // ascending column segments, strict >: first maximum
+                    tot += psum[w * HR + tid];
+                }
+                float bm = pmax[tid];
+#pragma unroll
+                for (int w = 1; w < TPR; ++w)
+                    if (pmax[w * HR + tid] > bm) { bm = pmax[w * HR + tid]; a = parg[w * HR + tid]; }
+                float4 rec;
+                rec.x = bm; rec.y = tot; rec.z = __int_as_float(a); rec.w = 0.0f;
+                *reinterpret_cast<float4*>(g.stats + ((long)row * tiles_n + bn) * 4) = rec;
+            }
         }
         if (!g.store_c) return;
         GemmArgs gs = g;
@@ -363,6 +399,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tiled(GemmArgs g, int tiles
                 store_tile32(gs, C, acc[i][j], m0 + wm + i * 32, n0 + wn + j * 32, lane);
         return;
     }
+    if (!g.store_c) return;             // NM_GEMM_NOSTORE timing ablation
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -486,6 +523,99 @@ __device__ __forceinline__ void gru_epilogue(const GruEpi& e, int d, int row, in
     }
 }
 
+// The same epilogues split in two: the operands of one output element are REQUESTED before the K loop of the
+// skinny kernels (gru_epi_load) and consumed after the cross-wave reduction (gru_epi_apply), so their memory
+// latency hides under the main loop instead of adding a second round trip behind it -- a recurrent step is pure
+// latency, two dependent launches of a few microseconds each.
+struct GruPre {
+    float a, b, c, d;
+    int pos, ppos;
+    bool live;
+};
+
+__device__ __forceinline__ GruPre gru_epi_load(const GruEpi& e, int d, int row, int col, const float* __restrict__ C,
+                                               long ldc, bool accumulate) {
+    GruPre q;
+    q.a = q.b = q.c = q.d = 0.0f;
+    const int H = e.H;
+    const long ro = (long)d * e.R + row;
+    q.live = gru_epi_pos(e, row, d, e.t, q.pos, q.ppos);
+    if (e.mode == 1) {
+        if (q.live) q.a = e.xp[d * e.x_dir + (long)row * e.x_row + (long)q.pos * e.x_time + col];
+        if (col < H && q.live) q.b = e.h_in[ro * H + col];
+    } else if (e.mode == 2) {
+        q.b = e.h_in[ro * H + col];
+        if (q.live) {
+            q.a = e.xp[d * e.x_dir + (long)row * e.x_row + (long)q.pos * e.x_time + 2 * H + col];
+            q.c = e.ru[ro * 2 * H + H + col];
+        }
+    } else if (e.mode == 3) {
+        if (q.live) {
+            q.a = e.ru[ro * 2 * H + col];
+            q.b = gru_epi_hprev(e, ro, d, row, e.t, q.ppos, col);
+            q.c = e.dh[ro * H + col];
+        }
+    } else {
+        if (accumulate) q.d = C[(long)row * ldc + col];
+        if (q.live) {
+            if (e.dout) q.a = e.dout[d * e.do_dir + (long)row * e.do_row + (long)q.pos * e.do_time + col];
+            q.b = e.ru[ro * 2 * H + H + col];
+            q.c = e.c[ro * H + col];
+        }
+    }
+    return q;
+}
+
+// hprev of mode 4 is fetched late on purpose: a fifth early load would push the kernel over 64 VGPRs
+__device__ __forceinline__ void gru_epi_apply(const GruEpi& e, const GruPre& q, int d, int row, int col, float s) {
+    const int H = e.H;
+    const long ro = (long)d * e.R + row;
+    if (e.mode == 1) {
+        const float gate = q.live ? nm_sigmoid(q.a + s) : 0.0f;
+        e.ru[ro * 2 * H + col] = gate;
+        if (col < H) e.rh[ro * H + col] = q.live ? gate * q.b : 0.0f;
+    } else if (e.mode == 2) {
+        const float hp = q.b;
+        if (!q.live) {
+            if (e.h_out != e.h_in) e.h_out[ro * H + col] = hp;
+            if (e.c_save) e.c_save[ro * H + col] = 0.0f;
+            return;
+        }
+        const float c = nm_tanh(q.a + s);
+        const float u = q.c;
+        const float hn = u * hp + (1.0f - u) * c;
+        e.h_out[ro * H + col] = hn;
+        if (e.c_save) e.c_save[ro * H + col] = c;
+        if (e.out) e.out[d * e.o_dir + (long)row * e.o_row + (long)q.pos * e.o_time + col] = hn;
+    } else if (e.mode == 3) {
+        if (!q.live) { e.dgpre[ro * 2 * H + col] = 0.0f; return; }
+        const float rr = q.a, hp = q.b;
+        const float drp = s * hp * rr * (1.0f - rr);
+        e.dh[ro * H + col] = q.c + s * rr;
+        e.dgpre[ro * 2 * H + col] = drp;
+        e.dxp[d * e.dx_dir + (long)row * e.dx_row + (long)q.pos * e.dx_time + col] = drp;
+    } else {
+        s += q.d;
+        if (!q.live) {
+            e.dh[ro * H + col] = s;
+            e.dcpre[ro * H + col] = 0.0f;
+            e.dgpre[ro * 2 * H + H + col] = 0.0f;
+            return;
+        }
+        const float dhv = s + q.a;
+        const float u = q.b, c = q.c;
+        const float hp = gru_epi_hprev(e, ro, d, row, e.t, q.ppos, col);
+        const float dcp = dhv * (1.0f - u) * (1.0f - c * c);
+        const float dup = dhv * (hp - c) * u * (1.0f - u);
+        e.dh[ro * H + col] = dhv * u;
+        e.dcpre[ro * H + col] = dcp;
+        e.dgpre[ro * 2 * H + H + col] = dup;
+        float* dx = e.dxp + d * e.dx_dir + (long)row * e.dx_row + (long)q.pos * e.dx_time;
+        dx[H + col] = dup;
+        dx[2 * H + col] = dcp;
+    }
+}
+
 template <int KS, bool TB>
 __global__ __launch_bounds__(KS * 64) void gemm_skinny(GemmArgs g, int tiles_m, GruEpi epi) {
     __shared__ float red[KS][16][64];
@@ -592,6 +722,19 @@ __device__ __forceinline__ void skinny16_tile(const GemmArgs& g, int tiles_m, co
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = 0.0f;
 
+    // this thread's output element (threads 0..255 of the workgroup) and its epilogue operands, requested early
+    const int e_col = n0 + (tid & 15), e_row = m0 + 4 * ((tid & 63) >> 4) + (tid >> 6);
+    const bool e_ok = tid < 256 && e_row < g.M && e_col < g.N;
+    GruPre pre;
+    float e_bias = 0.0f, e_old = 0.0f;
+    if (e_ok) {
+        if (epi.mode) pre = gru_epi_load(epi, z, e_row, e_col, C, g.ldc, g.accumulate != 0);
+        else {
+            if (g.bias) e_bias = g.bias[e_col];
+            if (g.accumulate) e_old = C[(long)e_row * g.ldc + e_col];
+        }
+    }
+
     const float* ap = A + (long)mm * g.lda + 4 * kq;
     const float* bp = TB ? (B + (long)nn * g.ldb + 4 * kq) : (B + (long)(4 * kq) * g.ldb + nn);
     for (int k0 = kbeg; k0 < kend; k0 += 64) {
@@ -626,24 +769,14 @@ __device__ __forceinline__ void skinny16_tile(const GemmArgs& g, int tiles_m, co
 #pragma unroll
     for (int i = 0; i < 4; ++i) red[wave][i][lane] = acc[i];
     __syncthreads();
-    for (int o = tid; o < 4 * 64; o += KS * 64) {
-        const int reg = o >> 6, ln = o & 63;
+    static_assert(KS >= 4, "the epilogue maps one output element to each of the first 256 threads");
+    if (e_ok) {
+        const int reg = tid >> 6, ln = tid & 63;
         float s = 0.0f;
 #pragma unroll
         for (int w = 0; w < KS; ++w) s += red[w][reg][ln];
-        const int col = n0 + (ln & 15);
-        const int row = m0 + 4 * (ln >> 4) + reg;
-        if (row < g.M && col < g.N) {
-            if (epi.mode) {
-                if (g.accumulate) s += C[(long)row * g.ldc + col];
-                gru_epilogue(epi, z, row, col, s);
-                continue;
-            }
-            float* p = C + (long)row * g.ldc + col;
-            float v = s + (g.bias ? g.bias[col] : 0.0f);
-            if (g.accumulate) v += *p;
-            *p = apply_act(v, g.act);
-        }
+        if (epi.mode) gru_epi_apply(epi, pre, z, e_row, e_col, s);
+        else C[(long)e_row * g.ldc + e_col] = apply_act(s + e_bias + e_old, g.act);
     }
 }
 
@@ -767,12 +900,12 @@ static void launch_skinny(const GemmArgs& g, int batch, bool tb, const GruEpi& e
 #undef NM_GS
 }
 
-template <int WM, int WN, int TM, int TN, int BK>
+template <int WM, int WN, int TM, int TN, int BK, int PF = 1>
 static void launch_tiled(const GemmArgs& g, int batch, bool ta, bool tb, bool vec, hipStream_t st) {
     const int tiles_m = nm_cdiv(g.M, WM * 32 * TM), tiles_n = nm_cdiv(g.N, WN * 32 * TN);
     dim3 grid(tiles_m * tiles_n, g.splitk, batch), block(WM * WN * 64);
 #define NM_GT(TA_, TB_, V_) \
-    hipLaunchKernelGGL((gemm_tiled<WM, WN, TM, TN, TA_, TB_, V_, BK>), grid, block, 0, st, g, tiles_m)
+    hipLaunchKernelGGL((gemm_tiled<WM, WN, TM, TN, TA_, TB_, V_, BK, false, PF>), grid, block, 0, st, g, tiles_m)
     if (vec) {
         if (!ta && !tb) NM_GT(false, false, true);
         else if (!ta && tb) NM_GT(false, true, true);
@@ -803,6 +936,8 @@ extern "C" int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int6
                (long)strideA, (long)strideB, (long)strideC, act, accumulate, nullptr, 1, 0, nullptr, 1};
     static const int swz_env = getenv("NM_GEMM_SWZ") ? atoi(getenv("NM_GEMM_SWZ")) : 1;   // A/B switch
     g.swizzle = swz_env;
+    static const bool nostore = getenv("NM_GEMM_NOSTORE") != nullptr;    // timing ablation only: results are NOT written
+    if (nostore) g.store_c = 0;
     hipStream_t st = nm_stream(stream);
     const bool ta = transA != 0, tb = transB != 0;
 
@@ -849,6 +984,10 @@ extern "C" int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int6
             else if (cfg_env == 4) launch_tiled<4, 2, 1, 2, 32>(g, (int)batch, ta, tb, vec, st);   // 128x128, 8 waves, BK 32
             else if (cfg_env == 5) launch_tiled<2, 4, 2, 1, 16>(g, (int)batch, ta, tb, vec, st);   // 128x128, 8 waves 64x32
             else if (cfg_env == 2) launch_tiled<4, 2, 2, 2, 16>(g, (int)batch, ta, tb, vec, st);   // 256x128, 8 waves
+            else if (cfg_env == 6) launch_tiled<4, 2, 1, 2, 16, 2>(g, (int)batch, ta, tb, vec, st); // cfg 1, loads 2 k-tiles ahead
+            else if (cfg_env == 7) launch_tiled<4, 2, 2, 2, 16, 2>(g, (int)batch, ta, tb, vec, st); // cfg 2, loads 2 k-tiles ahead
+            else if (cfg_env == 8) launch_tiled<2, 2, 2, 2, 16, 2>(g, (int)batch, ta, tb, vec, st); // 128x128, 4 waves, 2 ahead
+            else if (cfg_env == 9) launch_tiled<4, 2, 1, 2, 32, 2>(g, (int)batch, ta, tb, vec, st); // cfg 4, 2 ahead
             else launch_tiled<2, 2, 2, 2, 16>(g, (int)batch, ta, tb, vec, st);                     // 128x128, 4 waves
         } else {
             launch_tiled<2, 2, 1, 1, 16>(g, (int)batch, ta, tb, vec, st);                          // 64x64
@@ -955,10 +1094,14 @@ extern "C" int nm_gru_seq_fwd(void* stream, const nm_gru_epilogue* e, int32_t st
 // ---------------------------------------------------------------------------
 // vocabulary projection with the row statistics in the GEMM epilogue
 // ---------------------------------------------------------------------------
-// Columns per statistics tile = the N extent of the GEMM's block tile: 128 in general; 64 when M <= 256 (one
-// decoding step of <= 256 rows has a single row of block tiles: 128x64 tiles put TWO independent 8-wave
-// workgroups on every CU instead of one, whose barrier-separated load / MFMA phases then overlap).
-extern "C" int64_t nm_logits_stats_tile(int64_t M) { return M <= 256 ? 64 : 128; }
+// Columns per statistics tile = the N extent of the GEMM's block tile: 128 (NM_STATS_CFG bit 0 clear: 64 when
+// M <= 256 -- two independent 8-wave workgroups per CU for a single row of block tiles; measured slower).
+static int stats_cfg() {       // tuning switch, bit 0: 128-wide tiles also for M <= 256, bit 1: loads two k-tiles ahead.
+    // measured (gpurun_out r2d sweep, M=128 / 640, us): cfg 0 56.8 / 217, 1 53.7 / 216, 2 53.8 / 209, 3 51.6 / 209
+    static const int c = getenv("NM_STATS_CFG") ? atoi(getenv("NM_STATS_CFG")) : 3;
+    return c;
+}
+extern "C" int64_t nm_logits_stats_tile(int64_t M) { return (M <= 256 && !(stats_cfg() & 1)) ? 64 : 128; }
 
 extern "C" int64_t nm_logits_stats_bytes(int64_t M, int64_t N) {
     if (M <= 0 || N <= 0) return 0;
@@ -982,16 +1125,22 @@ extern "C" int nm_logits_stats_gemm(void* stream, int transB, int64_t M, int64_t
                     "multiples of 4");
     GemmArgs g{A, B, C, bias, (int)M, (int)N, (int)K, (long)lda, (long)ldb, (long)(C ? ldc : 0), 0, 0, 0, 0, 0,
                nullptr, 1, 1, stats, C ? 1 : 0};
+    static const bool ablate = getenv("NM_STATS_ABLATE") != nullptr;
+    if (ablate) g.act = 9;
     const int tile = (int)nm_logits_stats_tile(M);
     const int tiles_m = nm_cdiv(M, 128), tiles_n = nm_cdiv(N, tile);
     dim3 grid(tiles_m * tiles_n, 1, 1), block(512);
     hipStream_t st = nm_stream(stream);
+    const bool pf2 = (stats_cfg() & 2) != 0;
+#define NM_ST(TN_, BK_, TB_, PF_) \
+    hipLaunchKernelGGL((gemm_tiled<4, 2, 1, TN_, false, TB_, true, BK_, true, PF_>), grid, block, 0, st, g, tiles_m)
     if (tile == 64) {
-        if (tb) hipLaunchKernelGGL((gemm_tiled<4, 2, 1, 1, false, true, true, 32, true>), grid, block, 0, st, g, tiles_m);
-        else hipLaunchKernelGGL((gemm_tiled<4, 2, 1, 1, false, false, true, 32, true>), grid, block, 0, st, g, tiles_m);
+        if (tb) { if (pf2) NM_ST(1, 32, true, 2); else NM_ST(1, 32, true, 1); }
+        else { if (pf2) NM_ST(1, 32, false, 2); else NM_ST(1, 32, false, 1); }
     } else {
-        if (tb) hipLaunchKernelGGL((gemm_tiled<4, 2, 1, 2, false, true, true, 16, true>), grid, block, 0, st, g, tiles_m);
-        else hipLaunchKernelGGL((gemm_tiled<4, 2, 1, 2, false, false, true, 16, true>), grid, block, 0, st, g, tiles_m);
+        if (tb) { if (pf2) NM_ST(2, 16, true, 2); else NM_ST(2, 16, true, 1); }
+        else { if (pf2) NM_ST(2, 16, false, 2); else NM_ST(2, 16, false, 1); }
     }
+#undef NM_ST
     NM_LAUNCH_CHECK("nm_logits_stats_gemm");
 }

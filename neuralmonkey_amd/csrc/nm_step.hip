@@ -21,10 +21,13 @@
 // MFMA.  Several products that do not depend on each other share one launch (a "group").
 #include "nm_common.h"
 
+#include <type_traits>
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define NM_STEP_MAX_PROB 3
 #define NM_STEP_MAX_CHUNK 8
+#define NM_Z4 make_float4(0.f, 0.f, 0.f, 0.f)
 
 struct StepProb {           // mirrors nm_step_problem (include/nmhip.h)
     const float* A; long lda;
@@ -45,6 +48,7 @@ struct StepGroup {
     StepProb p[NM_STEP_MAX_PROB];
     int begin[NM_STEP_MAX_PROB + 1];      // first workgroup of every problem
     int nprob, M, tiles_m;
+    int wblocks;                          // leading workgroups that write the attention weights (a_kind 1)
 };
 
 // scale of partial i of query row `row`: f_i / den with f_i = exp(m_i - M), den = sum f_i lm_i + 1e-8 sum f_i la_i
@@ -69,132 +73,173 @@ __device__ __forceinline__ void step_row_scales(const StepProb& p, int row, floa
     inv = 1.0f / (lm + 1e-8f * la);
 }
 
-template <int KS>
-__global__ __launch_bounds__(KS * 64) void step_group_kernel(StepGroup g) {
-    __shared__ float red[KS][4][64];
+// KS waves split K; TM 16-row MFMA tiles per workgroup (they share the weight fragments); AKIND: operand loader
+// of the group (all problems of a launch share it).  These launches are pure latency: every workgroup of a
+// group should be resident at once and every wave should pay ONE memory round trip, so the plain loader is held
+// to 64 VGPRs (8 waves per SIMD, two 1024-thread workgroups per CU) and the host picks the tile height so that
+// a group has at most 512 workgroups.
+template <int KS, int TM, int AKIND>
+__global__ __launch_bounds__(KS * 64, AKIND == 0 ? 8 : 4) void step_group_kernel(StepGroup g) {
+    __shared__ float red[KS][TM * 4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bid = (int)blockIdx.x;
+    if constexpr (AKIND == 1) {
+        // the step's attention distribution (feed_forward.py:139-144): the FIRST workgroups of the grid, 16 query
+        // rows each -- short, dispatched first, out of the way of the GEMM tiles
+        const StepProb& q = g.p[0];
+        if (bid < g.wblocks) {
+            const int S = (int)q.S;
+            for (int idx = tid; idx < 16 * S; idx += KS * 64) {
+                const int row = bid * 16 + idx / S, sidx = idx % S;
+                if (row >= g.M) break;
+                float sc[NM_STEP_MAX_CHUNK], M, inv;
+                step_row_scales(q, row, sc, M, inv);
+                const long b = (row / q.mask_div) % q.mask_mod;
+                const float mk = q.mask ? q.mask[b * S + sidx] : 1.0f;
+                q.weights[(long)row * S + sidx] = __expf(q.energies[(long)row * S + sidx] - M) * mk * inv;
+            }
+            return;
+        }
+        bid -= g.wblocks;
+    }
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < NM_STEP_MAX_PROB; ++i)
-        if (i < g.nprob && (int)blockIdx.x >= g.begin[i]) pi = i;
+        if (i < g.nprob && bid >= g.begin[i]) pi = i;
     const StepProb& p = g.p[pi];
-    const int tile = (int)blockIdx.x - g.begin[pi];
+    const int tile = bid - g.begin[pi];
     const int bm = tile % g.tiles_m, bn = tile / g.tiles_m;
-    const int m0 = bm * 16, n0 = bn * 16;
+    const int m0 = bm * 16 * TM, n0 = bn * 16;
     const int N = (int)p.N, K = (int)p.K;
 
     const int i16 = lane & 15, kq = lane >> 4;
-    const int mm = min(m0 + i16, g.M - 1), nn = min(n0 + i16, N - 1);
+    const int nn = min(n0 + i16, N - 1);
     const int kper = ((K / 16 + KS - 1) / KS) * 16;
     const int kbeg = wave * kper, kend = min(K, kbeg + kper);
 
-    f32x4 acc;
+    // epilogue operands of this thread's output element are requested before the operand fragments, so their
+    // latency hides under the main loop instead of following the LDS reduction
+    const int e_t = tid >> 8;                                           // row tile of this thread's output element
+    const int e_col = n0 + (tid & 15), e_row = m0 + e_t * 16 + 4 * ((tid & 63) >> 4) + ((tid >> 6) & 3);
+    const bool e_ok = tid < 256 * TM && e_row < g.M && e_col < N;
+    float e_bias = 0.0f, e_x = 0.0f, e_h = 0.0f, e_u = 0.0f;
+    if (e_ok) {
+        if (p.epilogue == 0) {
+            if (p.bias) e_bias = p.bias[e_col];
+            if (p.add) e_x = p.add[(long)e_row * p.ldadd + e_col];
+        } else if (p.epilogue == 1) {
+            e_bias = p.bias[e_col];
+            if (e_col < (N >> 1)) e_h = p.h[(long)e_row * p.ldh + e_col];
+        } else {
+            e_x = p.xc[(long)e_row * p.ldxc + e_col];
+            e_u = p.ru[(long)e_row * 2 * N + N + e_col];
+            e_h = p.h[(long)e_row * p.ldh + e_col];
+        }
+    }
+
+    f32x4 acc[TM];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = 0.0f;
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][i] = 0.0f;
     const float* bp = p.Bt + (long)nn * p.ldb + 4 * kq;
 
-    if (p.a_kind == 0) {
-        const float* ap = p.A + (long)mm * p.lda + 4 * kq;
-        for (int k0 = kbeg; k0 < kend; k0 += 64) {
-            float4 av[4], bv[4];
+    if constexpr (AKIND == 0) {
+        static_assert(TM <= 2, "one or two row tiles per workgroup");
+        const float* ap0 = p.A + (long)min(m0 + i16, g.M - 1) * p.lda + 4 * kq;
+        const float* ap1 = p.A + (long)min(m0 + (TM - 1) * 16 + i16, g.M - 1) * p.lda + 4 * kq;
+        constexpr int CPI = TM == 1 ? 4 : 2;          // 16-deep chunks in flight per trip: what 64 VGPRs hold
+        for (int k0 = kbeg; k0 < kend; k0 += 16 * CPI) {
+            float4 av[TM][CPI], bv[CPI];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < CPI; ++c) {
                 const int k = k0 + 16 * c;
-                av[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-                bv[c] = av[c];
-                if (k + 4 * kq < kend) {
-                    av[c] = *reinterpret_cast<const float4*>(ap + k);
-                    bv[c] = *reinterpret_cast<const float4*>(bp + k);
-                }
+                const bool ok = k + 4 * kq < kend;
+                bv[c] = ok ? *reinterpret_cast<const float4*>(bp + k) : NM_Z4;
+#pragma unroll
+                for (int t = 0; t < TM; ++t)
+                    av[t][c] = ok ? *reinterpret_cast<const float4*>((t == 0 ? ap0 : ap1) + k) : NM_Z4;
             }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < CPI; ++c) {
                 if (k0 + 16 * c >= kend) break;
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c].x, bv[c].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c].y, bv[c].y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c].z, bv[c].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c].w, bv[c].w, acc, 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < TM; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][c].x, bv[c].x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][c].y, bv[c].y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][c].z, bv[c].z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][c].w, bv[c].w, acc[t], 0, 0, 0);
+                }
             }
         }
     } else {
         // A[row, k] = sum_i scale_i * pctx[row, i, k]: the merge of the split-S attention partials happens in
-        // the operand loader, the context vector itself is never written
+        // the operand loader, the context vector itself is never written.  TM == 1; up to 5 partials per row (the
+        // usual S <= 60) or up to 8, two 16-deep chunks of the wave's K slice in flight per trip.
+        static_assert(AKIND == 0 || TM == 1, "the partial-merging loader owns one row tile");
+        const int mm = min(m0 + i16, g.M - 1);
         float sc[NM_STEP_MAX_CHUNK], M, inv;
         step_row_scales(p, mm, sc, M, inv);
 #pragma unroll
         for (int i = 0; i < NM_STEP_MAX_CHUNK; ++i) sc[i] *= inv;
-        const float* ap = p.pctx + (long)mm * p.nchunk * K + 4 * kq;
-        for (int k0 = kbeg; k0 < kend; k0 += 32) {
-            float4 pv[2][NM_STEP_MAX_CHUNK], bv[2];
+        const float* pp = p.pctx + (long)mm * p.nchunk * K + 4 * kq;
+        auto run = [&](auto cpi_tag, auto np_tag) {
+            constexpr int CPI = decltype(cpi_tag)::value, NP = decltype(np_tag)::value;
+            for (int k0 = kbeg; k0 < kend; k0 += 16 * CPI) {
+                float4 pv[CPI][NP], bv[CPI];
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int k = k0 + 16 * c;
-                const bool ok = k + 4 * kq < kend;
-                bv[c] = ok ? *reinterpret_cast<const float4*>(bp + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int c = 0; c < CPI; ++c) {
+                    const int k = k0 + 16 * c;
+                    const bool ok = k + 4 * kq < kend;
+                    bv[c] = ok ? *reinterpret_cast<const float4*>(bp + k) : NM_Z4;
 #pragma unroll
-                for (int i = 0; i < NM_STEP_MAX_CHUNK; ++i)
-                    pv[c][i] = (ok && i < p.nchunk) ? *reinterpret_cast<const float4*>(ap + (long)i * K + k)
-                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                if (k0 + 16 * c >= kend) break;
-                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int i = 0; i < NM_STEP_MAX_CHUNK; ++i) {
-                    a.x += sc[i] * pv[c][i].x; a.y += sc[i] * pv[c][i].y;
-                    a.z += sc[i] * pv[c][i].z; a.w += sc[i] * pv[c][i].w;
+                    for (int i = 0; i < NP; ++i)
+                        pv[c][i] = (ok && i < p.nchunk) ? *reinterpret_cast<const float4*>(pp + (long)i * K + k) : NM_Z4;
                 }
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bv[c].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bv[c].y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bv[c].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bv[c].w, acc, 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < CPI; ++c) {
+                    if (k0 + 16 * c >= kend) break;
+                    float4 a = NM_Z4;
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) {
+                        a.x += sc[i] * pv[c][i].x; a.y += sc[i] * pv[c][i].y;
+                        a.z += sc[i] * pv[c][i].z; a.w += sc[i] * pv[c][i].w;
+                    }
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bv[c].x, acc[0], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bv[c].y, acc[0], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bv[c].z, acc[0], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bv[c].w, acc[0], 0, 0, 0);
+                }
             }
-        }
+        };
+        if (p.nchunk <= 5) run(std::integral_constant<int, 2>{}, std::integral_constant<int, 5>{});
+        else run(std::integral_constant<int, 2>{}, std::integral_constant<int, NM_STEP_MAX_CHUNK>{});
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) red[wave][i][lane] = acc[i];
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[wave][t * 4 + i][lane] = acc[t][i];
     __syncthreads();
-    if (tid < 256) {
-        const int reg = tid >> 6, ln = tid & 63;
+    if (e_ok) {
+        const int reg = e_t * 4 + ((tid >> 6) & 3), ln = tid & 63;
         float s = 0.0f;
 #pragma unroll
         for (int w = 0; w < KS; ++w) s += red[w][reg][ln];
-        const int col = n0 + (ln & 15);
-        const int row = m0 + 4 * (ln >> 4) + reg;
-        if (row < g.M && col < N) {
-            if (p.epilogue == 0) {
-                float v = s + (p.bias ? p.bias[col] : 0.0f);
-                if (p.add) v += p.add[(long)row * p.ldadd + col];
-                if (p.act == 1) v = nm_tanh(v);
-                p.C[(long)row * p.ldc + col] = v;
-            } else if (p.epilogue == 1) {              // N = 2H: r | u = sigmoid(. + bg); rh = r * h
-                const int H = N >> 1;
-                const float gate = nm_sigmoid(s + p.bias[col]);
-                p.ru[(long)row * N + col] = gate;
-                if (col < H) p.rh[(long)row * H + col] = gate * p.h[(long)row * p.ldh + col];
-            } else {                                   // N = H: c = tanh(xc + .); h' = u*h + (1-u)*c
-                const float c = nm_tanh(p.xc[(long)row * p.ldxc + col] + s);
-                const float u = p.ru[(long)row * 2 * N + N + col];
-                const float hp = p.h[(long)row * p.ldh + col];
-                const float hn = u * hp + (1.0f - u) * c;
-                p.h_out[(long)row * p.ldho + col] = hn;
-                if (p.h_out2) p.h_out2[(long)row * p.ldho2 + col] = hn;
-            }
-        }
-    }
-    // the step's attention distribution (feed_forward.py:139-144), written by the first column tile of
-    // every row block of the problem that consumes the partials
-    if (p.a_kind == 1 && p.weights && bn == 0) {
-        const int S = (int)p.S;
-        for (int idx = tid; idx < 16 * S; idx += KS * 64) {
-            const int row = m0 + idx / S, sidx = idx % S;
-            if (row >= g.M) break;
-            float sc[NM_STEP_MAX_CHUNK], M, inv;
-            step_row_scales(p, row, sc, M, inv);
-            const long b = (row / p.mask_div) % p.mask_mod;
-            const float mk = p.mask ? p.mask[b * S + sidx] : 1.0f;
-            p.weights[(long)row * S + sidx] = __expf(p.energies[(long)row * S + sidx] - M) * mk * inv;
+        const int col = e_col, row = e_row;
+        if (p.epilogue == 0) {
+            float v = s + e_bias + e_x;
+            if (p.act == 1) v = nm_tanh(v);
+            p.C[(long)row * p.ldc + col] = v;
+        } else if (p.epilogue == 1) {              // N = 2H: r | u = sigmoid(. + bg); rh = r * h
+            const int H = N >> 1;
+            const float gate = nm_sigmoid(s + e_bias);
+            p.ru[(long)row * N + col] = gate;
+            if (col < H) p.rh[(long)row * H + col] = gate * e_h;
+        } else {                                   // N = H: c = tanh(xc + .); h' = u*h + (1-u)*c
+            const float c = nm_tanh(e_x + s);
+            const float hn = e_u * e_h + (1.0f - e_u) * c;
+            p.h_out[(long)row * p.ldho + col] = hn;
+            if (p.h_out2) p.h_out2[(long)row * p.ldho2 + col] = hn;
         }
     }
 }
@@ -220,7 +265,12 @@ extern "C" int nm_step_group(void* stream, int64_t M, const nm_step_problem* pro
     StepGroup g;
     g.nprob = nprob;
     g.M = (int)M;
-    g.tiles_m = nm_cdiv(M, 16);
+    // tile height: 16 rows per workgroup while the whole group stays within 512 workgroups (two per CU), else 32
+    long tiles16 = 0;
+    for (int i = 0; i < nprob; ++i) tiles16 += (long)nm_cdiv(M, 16) * nm_cdiv(probs[i].N, 16);
+    const int tm = (probs[0].a_kind == 0 && tiles16 > 512) ? 2 : 1;
+    g.tiles_m = nm_cdiv(M, 16 * tm);
+    g.wblocks = (probs[0].a_kind == 1 && probs[0].weights) ? nm_cdiv(M, 16) : 0;
     int next = 0;
     for (int i = 0; i < nprob; ++i) {
         const nm_step_problem& q = probs[i];
@@ -258,6 +308,12 @@ extern "C" int nm_step_group(void* stream, int64_t M, const nm_step_problem* pro
     }
     for (int i = nprob; i <= NM_STEP_MAX_PROB; ++i) g.begin[i] = next;
     for (int i = nprob; i < NM_STEP_MAX_PROB; ++i) g.p[i] = g.p[0];
-    hipLaunchKernelGGL((step_group_kernel<16>), dim3((unsigned)next), dim3(1024), 0, nm_stream(stream), g);
+    for (int i = 1; i < nprob; ++i)
+        NM_REQUIRE(probs[i].a_kind == probs[0].a_kind, "nm_step_group: the problems of a group share one operand loader");
+    hipStream_t st = nm_stream(stream);
+    const unsigned grid = (unsigned)(next + g.wblocks);
+    if (probs[0].a_kind == 1) hipLaunchKernelGGL((step_group_kernel<16, 1, 1>), dim3(grid), dim3(1024), 0, st, g);
+    else if (tm == 2) hipLaunchKernelGGL((step_group_kernel<16, 2, 0>), dim3(grid), dim3(1024), 0, st, g);
+    else hipLaunchKernelGGL((step_group_kernel<16, 1, 0>), dim3(grid), dim3(1024), 0, st, g);
     NM_LAUNCH_CHECK("nm_step_group");
 }

@@ -200,7 +200,7 @@ class BeamSearchDecoder(ModelPart):
             steps += 1
             executed = steps
             if steps % CHECK_EVERY == 0 or steps == max_steps:
-                done = np.nonzero(allfin[:steps].cpu().numpy())[0]
+                done = np.nonzero(ctx0.session.read_small(allfin[:steps]))[0]
                 if done.size:
                     steps = int(done[0]) + 1
                     break
@@ -317,7 +317,7 @@ class BeamSearchDecoder(ModelPart):
                 chunk()
             steps += n
             executed = steps
-            done = np.nonzero(allfin[:steps].cpu().numpy())[0]
+            done = np.nonzero(ctx.session.read_small(allfin[:steps]))[0]
             if done.size:
                 # bodies past the first all-finished one leave the search state unchanged and only
                 # append <pad> rows, which are cropped here

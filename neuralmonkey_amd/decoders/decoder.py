@@ -185,13 +185,16 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
         ops.gemm(emb, cell["wg_x"], out=xp[:, :2 * h], bias=cell["bg"])
         ops.gemm(emb, cell["wc_x"], out=xp[:, 2 * h:], bias=cell["bc"])
 
-    def _recurrent(self, ctx, cell, xp, t_index, x_time_stride, h_prev, h_out, ru, c_save, bufs, rh=None):
-        """State half of the GRU + fused epilogues: h_out = GRU(x_t, h_prev)."""
+    def _recurrent(self, ctx, cell, xp, t_index, x_time_stride, h_prev, h_out, ru, c_save, bufs, rh=None, wt=None):
+        """State half of the GRU + fused epilogues: h_out = GRU(x_t, h_prev).  ``wt``: transposed recurrent
+        kernels of this time loop (gru.transposed_weights)."""
         h = self.rnn_size
         rows = h_prev.shape[0]
         rh = bufs["rh"] if rh is None else rh
-        gru.step_fwd(xp, (0, 3 * h, x_time_stride), h_prev, h_out, cell["wg_h"], cell["wc_h"], ru, rh, c_save,
-                     None, (0, 0, 0), None, t_index, 1, rows, h, False, bufs["hg"], bufs["hc"])
+        wg, wc = wt if wt is not None else (cell["wg_h"], cell["wc_h"])
+        gru.step_fwd(xp, (0, 3 * h, x_time_stride), h_prev, h_out, wg, wc, ru, rh, c_save,
+                     None, (0, 0, 0), None, t_index, 1, rows, h, False, bufs["hg"], bufs["hc"],
+                     transposed=wt is not None)
 
     def _step_bufs(self, ctx, rows):
         h = self.rnn_size
@@ -270,10 +273,13 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
             att.hidden_features(ctx)
             att.attention_mask(ctx)
 
+        wt = gru.transposed_weights(ctx, (id(self), "train"), cell["wg_h"], cell["wc_h"]) \
+            if gru.fused_ok(bsz, h) else None
+
         def time_loop():
             for t in range(steps):
                 self._recurrent(ctx, cell, xp, t, bsz * 3 * h, s_ext[t], s_all[t], ru_all[t], c_all[t], bufs,
-                                rh=rh_all[t])
+                                rh=rh_all[t], wt=wt)
         if ctx.session.use_persistent and gru.fused_ok(bsz, h) and h % 16 == 0:
             # the whole recurrence as one persistent launch: two grid barriers per step, no launches
             ops.gru_seq_fwd(steps, 1, bsz, h, xp, (0, 3 * h, bsz * 3 * h), s_ext[0], s_ext[1], bsz * h,
@@ -325,6 +331,7 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
         # Leaf work (weight gradients, bias column sums: nothing downstream reads them) is
         # enqueued on the session's side stream so it overlaps the latency-bound BPTT loops.
         side = ctx.session.side
+        acc = self.shares_variables          # another part trains the same variables (reuse=): add, never overwrite
         from .. import distributed
         dp = distributed.current()
         dp_overlap = dp is not None and bool(ctx.memo.get("dp_overlap", False))
@@ -356,15 +363,15 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
         with side():
             row = 0
             for x, sz in zip([s2, emb2] + ctx_all, proj.sizes):
-                ops.gemm(x, d_out, out=g_wo[row:row + sz], trans_a=True)
+                ops.gemm(x, d_out, out=g_wo[row:row + sz], trans_a=True, accumulate=acc)
                 row += sz
-            ops.colsum(d_out, store.g(self.var_name("attention_decoder/{}/bias".format(proj.scope))))
+            ops.colsum(d_out, store.g(self.var_name("attention_decoder/{}/bias".format(proj.scope))), accumulate=acc)
             if self.tie_embeddings:
                 ops.gemm(dlogits, out_all, out=store.g(self.embedding_matrix_name), trans_a=True,
                          accumulate=True)
             else:
-                ops.gemm(out_all, dlogits, out=store.g(self.var_name("state_to_word_W")), trans_a=True)
-                ops.colsum(dlogits, store.g(self.var_name("state_to_word_b")))
+                ops.gemm(out_all, dlogits, out=store.g(self.var_name("state_to_word_W")), trans_a=True, accumulate=acc)
+                ops.colsum(dlogits, store.g(self.var_name("state_to_word_b")), accumulate=acc)
                 if dp_overlap:        # the largest gradient slice is final: its all-reduce runs under the BPTT
                     dp.all_reduce_early(store, [self.var_name("state_to_word_W"), self.var_name("state_to_word_b")])
 
@@ -398,12 +405,12 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
         dg_all, dc_all = dxp[:, :2 * h], dxp[:, 2 * h:]
         s_prev = sv["s_ext"][:steps].reshape(rows, h)
         with side():
-            ops.gemm(emb2, dg_all, out=g_wg[:e], trans_a=True)
-            ops.gemm(s_prev, dg_all, out=g_wg[e:], trans_a=True)
-            ops.gemm(emb2, dc_all, out=g_wc[:e], trans_a=True)
-            ops.gemm(sv["rh_all"].view(rows, h), dc_all, out=g_wc[e:], trans_a=True)
-            ops.colsum(dg_all, store.g(self.var_name(pre + "/gates/bias")))
-            ops.colsum(dc_all, store.g(self.var_name(pre + "/candidate/bias")))
+            ops.gemm(emb2, dg_all, out=g_wg[:e], trans_a=True, accumulate=acc)
+            ops.gemm(s_prev, dg_all, out=g_wg[e:], trans_a=True, accumulate=acc)
+            ops.gemm(emb2, dc_all, out=g_wc[:e], trans_a=True, accumulate=acc)
+            ops.gemm(sv["rh_all"].view(rows, h), dc_all, out=g_wc[e:], trans_a=True, accumulate=acc)
+            ops.colsum(dg_all, store.g(self.var_name(pre + "/gates/bias")), accumulate=acc)
+            ops.colsum(dc_all, store.g(self.var_name(pre + "/candidate/bias")), accumulate=acc)
             ops.gemm(dg_all, cell["wg_x"], out=d_emb, trans_b=True, accumulate=True)
             ops.gemm(dc_all, cell["wc_x"], out=d_emb, trans_b=True, accumulate=True)
             ops.embedding_scatter_add(store.g(self.embedding_matrix_name), self._dec_input_ids(ctx).reshape(-1),
@@ -516,7 +523,7 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
             else:
                 chunk()
             steps += n
-            done = np.nonzero(allfin[:steps].cpu().numpy())[0]
+            done = np.nonzero(ctx.session.read_small(allfin[:steps]))[0]
             if done.size:                          # loop ends after the first all-finished step
                 steps = int(done[0]) + 1
                 break

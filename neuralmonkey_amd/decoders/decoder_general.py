@@ -357,12 +357,12 @@ class FusedStepper:
     and the split-S attention kernel (``nm_step_group``, csrc/nm_step.hip) -- Decoder.next_state,
     decoders/decoder.py:279-358:
 
-        group 1   [emb | h] . Wg + bg -> r, u, r*h           emb . Wc_x + bc -> xc
+        group 1   [emb | h] . Wg + bg -> r, u, r*h     emb . Wc_x + bc -> xc     emb . Wo[emb rows] -> Pe
         group 2   (r*h) . Wc_h + xc -> c ; h' = u*h + (1-u)*c     (in place in ``cat`` and into ``h_out``)
-        group 3   y = h' . Wq + bq                            P = [emb | h'] . Wo[emb,h rows] + bo
-        attention partial kernel (energies + split-S partial contexts; no combine launch)
-        group 4   out = act(ctx . Wo[ctx rows] + P), ctx merged from the partials while the operand is loaded;
-                  the attention weights of the step are written by the same launch
+        group 3   y = h' . Wq + bq                      P = h' . Wo[h rows] + Pe + bo
+        attention (one launch: energies, softmax, mask renormalisation, context; the split-S partials are merged
+                  by the last-arriving chunk workgroup of every sentence)
+        group 4   out = act(ctx . Wo[ctx rows] + P)
         logits    (+ per-tile row statistics when the caller passes ``stats``)
 
     ``cat`` = [emb | h] is the persistent input row of the step: the caller embeds the next input symbols
@@ -378,8 +378,8 @@ class FusedStepper:
         if len(dec.attentions) != 1 or type(dec.attentions[0]) is not Attention:      # pylint: disable=unidiomatic-typecheck
             return None
         e, h = dec.embedding_size, dec.rnn_size
-        if e % 16 or h % 16 or dec.output_dimension % 4:
-            return None
+        if e % 16 or h % 16 or dec.output_dimension % 4 or rows > 256:
+            return None          # (16-row tiles re-read every weight rows/16 times: beyond 256 rows the tiled GEMMs win)
         return dec.attentions[0].partials_plan(ctx, rows)
 
     def __init__(self, dec, ctx, rows: int, tag: str, plan):
@@ -393,7 +393,7 @@ class FusedStepper:
         self.emb_view, self.sel = self.cat[:, :e], self.cat[:, e:]
         self.hbuf = buf("h", (2, rows, h))
         self.ru, self.rh, self.xc = buf("ru", (rows, 2 * h)), buf("rh", (rows, h)), buf("xc", (rows, h))
-        self.y, self.pre = buf("y", (rows, a)), buf("pre", (rows, o))
+        self.y, self.pre, self.pre_e = buf("y", (rows, a)), buf("pre", (rows, o)), buf("pre_e", (rows, o))
         # transposed weights of this run
         pre = "attention_decoder/OrthoGRUCell"
         wg, wc = dec.var(ctx, pre + "/gates/kernel"), dec.var(ctx, pre + "/candidate/kernel")
@@ -403,35 +403,32 @@ class FusedStepper:
         self.wg_t = tr("wgT", wg)                                     # [2H, E+H]
         self.wcx_t, self.wch_t = tr("wcxT", wc[:e]), tr("wchT", wc[e:])
         self.wq_t = tr("wqT", att.var(ctx, "Attention/attn_query_projection"))
-        wo_eh = buf("wo_eh", (e + h, o))
-        wo_eh[:e].copy_(wo[h:h + e])
-        wo_eh[e:].copy_(wo[:h])
-        self.wo_eh_t, self.wo_c_t = tr("wo_ehT", wo_eh), tr("wo_cT", wo[h + e:])
+        self.wo_h_t, self.wo_e_t, self.wo_c_t = tr("wo_hT", wo[:h]), tr("wo_eT", wo[h:h + e]), tr("wo_cT", wo[h + e:])
         bg, bc = dec.var(ctx, pre + "/gates/bias"), dec.var(ctx, pre + "/candidate/bias")
         ld = e + h
         rpk, bk = att.rows_per_key, plan["Bk"]
         self.g1 = ops.StepGroup(rows, [
             dict(A=self.cat, lda=ld, Bt=self.wg_t, ldb=ld, N=2 * h, K=ld, epilogue=1, bias=bg, h=self.sel, ldh=ld,
                  ru=self.ru, rh=self.rh),
-            dict(A=self.cat, lda=ld, Bt=self.wcx_t, ldb=e, N=h, K=e, epilogue=0, bias=bc, C=self.xc, ldc=h)])
+            dict(A=self.cat, lda=ld, Bt=self.wcx_t, ldb=e, N=h, K=e, epilogue=0, bias=bc, C=self.xc, ldc=h),
+            dict(A=self.cat, lda=ld, Bt=self.wo_e_t, ldb=e, N=o, K=e, epilogue=0, C=self.pre_e, ldc=o)])
         self.g2 = ops.StepGroup(rows, [
             dict(A=self.rh, lda=h, Bt=self.wch_t, ldb=h, N=h, K=h, epilogue=2, xc=self.xc, ldxc=h, ru=self.ru,
                  h=self.sel, ldh=ld, h_out=self.sel, ldho=ld, h_out2=self.hbuf[0], ldho2=h)])
         self.g3 = ops.StepGroup(rows, [
             dict(A=self.sel, lda=ld, Bt=self.wq_t, ldb=h, N=a, K=h, epilogue=0, bias=att.var(ctx, "attn_projection_bias"),
                  C=self.y, ldc=a),
-            dict(A=self.cat, lda=ld, Bt=self.wo_eh_t, ldb=ld, N=o, K=ld, epilogue=0, bias=proj.bias(ctx, dec),
-                 C=self.pre, ldc=o)])
-        mask = att.attention_mask(ctx)
+            dict(A=self.sel, lda=ld, Bt=self.wo_h_t, ldb=h, N=o, K=h, epilogue=0, bias=proj.bias(ctx, dec),
+                 add=self.pre_e, ldadd=o, C=self.pre, ldc=o)])
+        self.ctxbuf = buf("ctx", (rows, c))
         self.g4 = ops.StepGroup(rows, [
-            dict(a_kind=1, Bt=self.wo_c_t, ldb=c, N=o, K=c, epilogue=0, act=1 if proj.activation == "tanh" else 0,
-                 add=self.pre, ldadd=o, C=self.pre, ldc=o, pctx=plan["pctx"], pstat=plan["pstat"],
-                 nchunk=plan["nchunk"], energies=plan["energies"], mask=mask if mask is not None else 0,
-                 weights=plan["energies"], S=plan["S"], mask_div=rpk, mask_mod=bk)])
+            dict(A=self.ctxbuf, lda=c, Bt=self.wo_c_t, ldb=c, N=o, K=c, epilogue=0,
+                 act=1 if proj.activation == "tanh" else 0, add=self.pre, ldadd=o, C=self.pre, ldc=o)])
         att.hidden_features(ctx)
+        self._pending, self._cur = None, 0
 
     def start(self, s0: torch.Tensor) -> None:
-        self.s0 = s0
+        self._pending, self._cur = s0, 0
 
     def step(self, emb, att_states, out_state, logits, h_out: Optional[torch.Tensor] = None, finished=None,
              h_prev: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None):
@@ -439,15 +436,26 @@ class FusedStepper:
         dec, ctx = self.dec, self.ctx
         if emb.data_ptr() != self.emb_view.data_ptr():
             ops.copy_cols(emb, self.emb_view)
+        if h_prev is None and self._pending is not None:          # stateful use (ensembles): start() then step()s
+            h_prev = self._pending
+        self._pending = None
         if h_prev is not None and h_prev.data_ptr() != self.sel.data_ptr():
             ops.copy_cols(h_prev, self.sel)                       # first step of a loop: the initial state
+        if h_out is None:                                         # stateful use: keep a copy for reorder()
+            self._cur ^= 1
+            h_out = self.hbuf[self._cur]
         st = att_states[0]
         self.g1.launch()
         self.g2.patch(0, h_out2=h_out, ldho2=h_out.stride(0) if h_out is not None else 0)
         self.g2.launch()
         self.g3.launch()
-        self.att.attention_partials(ctx, self.y, self.plan)
-        self.g4.patch(0, C=out_state, ldc=out_state.stride(0), weights=st.weights[st.step])
+        att = self.att
+        # energies, softmax, mask renormalisation and context in ONE launch: the chunk workgroup that arrives last
+        # for a sentence merges the split-S partials (nm_attn_fwd, csrc/nm_attention.hip)
+        ops.attn_fwd(self.y, att.hidden_features(ctx), att.attention_states(ctx), att.attention_mask(ctx),
+                     att.var(ctx, "attn_similarity_v"), att.var(ctx, "attn_bias"), att.rows_per_key, self.ctxbuf,
+                     st.weights[st.step], self.plan["ws"])
+        self.g4.patch(0, C=out_state, ldc=out_state.stride(0))
         self.g4.launch()
         if stats is not None:
             dec.state_to_logits_stats(ctx, out_state, stats, out=logits)
@@ -456,7 +464,7 @@ class FusedStepper:
         return [AttentionLoopState(st.contexts, st.weights, st.step + 1)]
 
     def reorder(self, src_rows: torch.Tensor) -> None:
-        raise RuntimeError("FusedStepper: the beam search gathers the surviving states into ``sel`` itself")
+        ops.gather_rows(self.hbuf[self._cur], src_rows, self.sel)
 
 
 def make_stepper(dec, ctx, rows: int, tag: str):

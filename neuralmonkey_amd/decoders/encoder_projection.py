@@ -111,12 +111,13 @@ class _Linear(EncoderProjection):
         store = ctx.store
         w = decoder.var(ctx, "initial_state/encoders_projection/kernel")
         g_w = store.g(decoder.var_name("initial_state/encoders_projection/kernel"))
-        ops.colsum(d_state, store.g(decoder.var_name("initial_state/encoders_projection/bias")))
+        acc = decoder.shares_variables         # decoders sharing the scope (reuse=) add their gradients up
+        ops.colsum(d_state, store.g(decoder.var_name("initial_state/encoders_projection/bias")), accumulate=acc)
         grads, row = [], 0
         for i, enc in enumerate(encoders):
             val = enc.output(ctx)
             sz = val.shape[1]
-            ops.gemm(val, d_state, out=g_w[row:row + sz], trans_a=True)
+            ops.gemm(val, d_state, out=g_w[row:row + sz], trans_a=True, accumulate=acc)
             d_val = ctx.buffer((id(self), "d_enc", i), tuple(val.shape))
             ops.gemm(d_state, w[row:row + sz], out=d_val, trans_b=True)
             grads.append(d_val)

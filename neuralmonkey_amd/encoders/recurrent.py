@@ -195,13 +195,17 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
         len_arg = lengths
         xrs, xts = slen * ndir * 3 * h, ndir * 3 * h
         ors, ots = slen * c_out, c_out
+        fused = gru.fused_ok(bsz, h)
+        wg_f, wc_f = gru.transposed_weights(ctx, key, wgh, wch) if fused else (wgh, wch)
+
         def time_loop():
             states_raw.zero_()
             hcur.zero_()
             for t in range(slen):
                 ru = ru_all[t] if train else ru_all[0]
-                gru.step_fwd(xp, (3 * h, xrs, xts), hcur, hcur, wgh, wch, ru, rh, c_all[t] if train else None,
-                             states_raw, (h, ors, ots), len_arg, t, ndir, bsz, h, reverse_only, hg, hc)
+                gru.step_fwd(xp, (3 * h, xrs, xts), hcur, hcur, wg_f, wc_f, ru, rh, c_all[t] if train else None,
+                             states_raw, (h, ors, ots), len_arg, t, ndir, bsz, h, reverse_only, hg, hc,
+                             transposed=fused)
         if ctx.session.use_persistent and gru.fused_ok(bsz, h) and h % 16 == 0:
             # both directions, all positions: one persistent launch (two grid barriers per step)
             states_raw.zero_()
@@ -302,12 +306,13 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
             g_wc = store.g(self.var_name(pre + "/candidate/kernel"))
             dg = dxp[:, d * 3 * h:d * 3 * h + 2 * h]
             dc = dxp[:, d * 3 * h + 2 * h:(d + 1) * 3 * h]
-            ops.gemm(x2, dg, out=g_wg[:e], trans_a=True)
-            ops.gemm(hp2[:, d * h:(d + 1) * h], dg, out=g_wg[e:], trans_a=True)
-            ops.gemm(x2, dc, out=g_wc[:e], trans_a=True)
-            ops.gemm(rh2[:, d * h:(d + 1) * h], dc, out=g_wc[e:], trans_a=True)
-            ops.colsum(dg, store.g(self.var_name(pre + "/gates/bias")))
-            ops.colsum(dc, store.g(self.var_name(pre + "/candidate/bias")))
+            acc = self.shares_variables          # encoders sharing this scope (reuse=) add their gradients up
+            ops.gemm(x2, dg, out=g_wg[:e], trans_a=True, accumulate=acc)
+            ops.gemm(hp2[:, d * h:(d + 1) * h], dg, out=g_wg[e:], trans_a=True, accumulate=acc)
+            ops.gemm(x2, dc, out=g_wc[:e], trans_a=True, accumulate=acc)
+            ops.gemm(rh2[:, d * h:(d + 1) * h], dc, out=g_wc[e:], trans_a=True, accumulate=acc)
+            ops.colsum(dg, store.g(self.var_name(pre + "/gates/bias")), accumulate=acc)
+            ops.colsum(dc, store.g(self.var_name(pre + "/candidate/bias")), accumulate=acc)
             ops.gemm(dg, cv["/gates/kernel"][:e], out=dx, trans_b=True, accumulate=not first)
             ops.gemm(dc, cv["/candidate/kernel"][:e], out=dx, trans_b=True, accumulate=True)
             first = False

@@ -78,6 +78,15 @@ class Parameterized:
     def scope(self) -> str:
         return self._scope
 
+    @property
+    def shares_variables(self) -> bool:
+        """Do several model parts live in this part's variable scope (``reuse=``)?  Their gradient passes
+        then ADD into the same gradient tensors (tf.gradients sums the contributions of every use of a
+        variable); a part alone in its scope may overwrite (the buffer is zeroed at the start of the step,
+        but an overwrite saves a read of the weight-sized gradient)."""
+        from ..runtime import registered_parts
+        return sum(1 for p in registered_parts() if getattr(p, "_scope", None) == self._scope) > 1
+
     def __str__(self) -> str:
         return self.name
 

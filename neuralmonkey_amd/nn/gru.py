@@ -12,16 +12,31 @@ def fused_ok(rows: int, hsz: int) -> bool:
     return hsz % 8 == 0 and rows <= 1024
 
 
+def transposed_weights(ctx, key, wgh, wch):
+    """[ndir,H,2H] / [ndir,H,H] recurrent kernels -> persistent transposed copies [ndir,2H,H] / [ndir,H,H]
+    ([N,K]: both MFMA fragments of a wave of the skinny kernel are then single 16-byte loads and the kernel
+    stays within 64 VGPRs, i.e. every workgroup of a step is resident at once).  Refreshed by the caller once
+    per time loop -- the weights change with every optimizer step."""
+    g3 = wgh if wgh.dim() == 3 else wgh.unsqueeze(0)
+    c3 = wch if wch.dim() == 3 else wch.unsqueeze(0)
+    wg_t = ctx.buffer((key, "wgh_t"), (g3.shape[0], g3.shape[2], g3.shape[1]))
+    wc_t = ctx.buffer((key, "wch_t"), (c3.shape[0], c3.shape[2], c3.shape[1]))
+    wg_t.copy_(g3.transpose(1, 2))
+    wc_t.copy_(c3.transpose(1, 2))
+    return (wg_t, wc_t) if wgh.dim() == 3 else (wg_t[0], wc_t[0])
+
+
 def step_fwd(xp, x_strides, h_in, h_out, wgh, wch, ru, rh, c_save, out, out_strides, lengths, t, ndir, rows,
-             hsz, rev0, hg, hc):
+             hsz, rev0, hg, hc, transposed=False):
     """h_out = GRU(x_t, h_in) for ``ndir`` directions; tensors are [ndir,R,*]
-    (2-D accepted when ndir == 1)."""
+    (2-D accepted when ndir == 1).  ``transposed``: wgh / wch are the [N,K] copies of ``transposed_weights``."""
     if fused_ok(rows, hsz):
-        ops.gru_gemm(1, h_in, wgh, False, t, ndir, rows, hsz, lengths, rev0, xp=xp, x_strides=x_strides,
+        ops.gru_gemm(1, h_in, wgh, transposed, t, ndir, rows, hsz, lengths, rev0, xp=xp, x_strides=x_strides,
                      h_in=h_in, ru=ru, rh=rh)
-        ops.gru_gemm(2, rh, wch, False, t, ndir, rows, hsz, lengths, rev0, xp=xp, x_strides=x_strides,
+        ops.gru_gemm(2, rh, wch, transposed, t, ndir, rows, hsz, lengths, rev0, xp=xp, x_strides=x_strides,
                      h_in=h_in, h_out=h_out, ru=ru, c_save=c_save, out=out, out_strides=out_strides)
         return
+    assert not transposed
     ops.gemm(h_in, wgh, out=hg)
     ops.gru_gates_fwd(xp, x_strides[0], x_strides[1], x_strides[2], hg, h_in, ru, rh, lengths, t, ndir, rows,
                       hsz, reverse_dir0=rev0)

@@ -158,7 +158,8 @@ def log_softmax_from_stats(x, rmax, rlse, out):
 def attn_workspace(rows, s, c, device):
     lib = _lib.load()
     nbytes = lib.nm_attn_workspace_bytes(rows, s, c)
-    return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+    # zeroed ONCE: the tail holds the arrival counters of the in-kernel merge, which the kernels leave at zero
+    return torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=device)
 
 
 def gru_rh_seq(ru_all, hprev, out, lengths, ndir, hsz, reverse_dir0=False):

@@ -103,9 +103,10 @@ class RunContext:
     def is_fed(self, placeholder: Placeholder) -> bool:
         return placeholder in self.feed
 
-    def buffer(self, key, shape, dtype=torch.float32, zero=False):
-        """Persistent scratch buffer owned by the session (no per-step malloc)."""
-        return self.session.buffer(key, shape, dtype, zero)
+    def buffer(self, key, shape, dtype=torch.float32, zero=False, zero_init=False):
+        """Persistent scratch buffer owned by the session (no per-step malloc).  ``zero``: cleared on every
+        request; ``zero_init``: cleared when it is created only (state the kernels themselves keep at zero)."""
+        return self.session.buffer(key, shape, dtype, zero, zero_init)
 
     # -- encoder gradients shared by several decoders ---------------------------------------------------
     def defer_backward(self, encoder, d_states, d_final) -> None:
@@ -279,18 +280,36 @@ class Session:
         finally:
             self._tls.prefetching = False
 
-    def buffer(self, key, shape, dtype=torch.float32, zero=False):
+    def buffer(self, key, shape, dtype=torch.float32, zero=False, zero_init=False):
         """Persistent scratch tensor.  Keyed by (key, shape, dtype) and never
         re-allocated, so device pointers baked into captured HIP graphs stay valid."""
         shape = tuple(int(s) for s in shape)
         full = (key, shape, dtype)
         buf = self._buffers.get(full)
         if buf is None:
-            buf = torch.empty(shape, dtype=dtype, device=self.device)
+            make = torch.zeros if zero_init else torch.empty
+            buf = make(shape, dtype=dtype, device=self.device)
             self._buffers[full] = buf
         if zero:
             buf.zero_()
         return buf
+
+    def read_small(self, dev_tensor: torch.Tensor):
+        """A few device words (loop flags) -> host NumPy array, through a persistent PINNED buffer: one
+        asynchronous copy + one event wait instead of a pageable ``.cpu()`` (staging allocation, blocking copy).
+        The decoding loops do this between chunks of steps while the GPU idles, so its latency is step time."""
+        if self.device.type != "cuda":
+            return dev_tensor.cpu().numpy()
+        key = (dev_tensor.numel(), dev_tensor.dtype)
+        slot = self.__dict__.setdefault("_pinned_small", {}).get(key)
+        if slot is None:
+            slot = (torch.empty(dev_tensor.numel(), dtype=dev_tensor.dtype).pin_memory(), torch.cuda.Event())
+            self._pinned_small[key] = slot
+        host, event = slot
+        host.copy_(dev_tensor.reshape(-1), non_blocking=True)
+        event.record()
+        event.synchronize()
+        return host.numpy().reshape(tuple(dev_tensor.shape))
 
     def staged(self, key, src: torch.Tensor) -> torch.Tensor:
         """Copy a per-batch device tensor into a persistent buffer (same pointer

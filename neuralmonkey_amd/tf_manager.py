@@ -150,7 +150,8 @@ class TensorFlowManager:
         if self.saver is None:
             raise RuntimeError("Saver uninitialized")
         if isinstance(variable_files, str) and len(self.sessions) == 1:
-            self.sessions[0].store.save(variable_files, fmt=self.checkpoint_format)
+            self.sessions[0].store.save(variable_files, fmt=self.checkpoint_format,
+                                        global_step=self.sessions[0].global_step)
             return
         if isinstance(variable_files, str):
             variable_files = ["{}.{}".format(variable_files, i) for i in range(len(self.sessions))]
@@ -158,7 +159,7 @@ class TensorFlowManager:
             raise Exception("Provided {} files for saving {} sessions.".format(
                 len(variable_files), len(self.sessions)))
         for sess, file_name in zip(self.sessions, variable_files):
-            sess.store.save(file_name, fmt=self.checkpoint_format)
+            sess.store.save(file_name, fmt=self.checkpoint_format, global_step=sess.global_step)
 
     def restore(self, variable_files: Union[str, List[str]]) -> None:
         if self.saver is None:
@@ -169,7 +170,17 @@ class TensorFlowManager:
             raise Exception("Provided {} files for restoring {} sessions.".format(
                 len(variable_files), len(self.sessions)))
         for sess, file_name in zip(self.sessions, variable_files):
-            sess.store.load(file_name)
+            info = sess.store.load(file_name) or {}
+            step = info.get("global_step")
+            if step is not None:
+                # the Saver restores ALL global variables (tf_manager.py:257-261): global_step and the optimizer's
+                # slots / beta powers continue where the checkpoint left them (learning-rate schedules, Adam's
+                # bias correction, dropout salts)
+                sess.global_step = step
+                owner = sess.__dict__.get("_adam_owner", {}).get(id(sess.store))
+                state = getattr(owner, "_adam", {}).get(id(sess.store)) if owner is not None else None
+                if state is not None:
+                    state["applied"] = step
 
     def restore_best_vars(self) -> None:
         assert self.best_score_index is not None

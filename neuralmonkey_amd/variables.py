@@ -163,23 +163,45 @@ class VariableStore:
                 arr = arr.reshape(spec.shape)          # scalar () <-> (1,)
             self[n].copy_(torch.from_numpy(arr).to(self.device))
 
-    def save(self, path: str, fmt: str = "npz") -> None:
+    def save(self, path: str, fmt: str = "npz", global_step: Optional[int] = None) -> None:
         """``fmt`` "npz" (one file) or "tf" (TensorFlow tensor bundle ``path``.index / .data-00000-of-00001,
-        what the reference's tf.train.Saver writes: tf_manager.py:274-277)."""
+        what the reference's tf.train.Saver writes: tf_manager.py:274-277).  Like the Saver over all global
+        variables, a checkpoint carries the optimizer state too: the Adam slots (``<var>/Adam``,
+        ``<var>/Adam_1``) once an optimizer has created them, and ``global_step`` when given."""
         if fmt == "tf":
             from . import tf_bundle
-            tf_bundle.export_store(self, path)
+            tf_bundle.export_store(self, path, global_step=global_step, with_adam=self.adam_m is not None)
             return
-        np.savez(path, **{k.replace("/", "|"): v for k, v in self.state_dict().items()})
+        arrays = {k.replace("/", "|"): v for k, v in self.state_dict().items()}
+        if self.adam_m is not None:
+            m, v = self.adam_m.cpu().numpy(), self.adam_v.cpu().numpy()
+            for name, spec in self.specs.items():
+                arrays[(name + "/Adam").replace("/", "|")] = m[spec.offset:spec.offset + spec.size].reshape(spec.shape)
+                arrays[(name + "/Adam_1").replace("/", "|")] = v[spec.offset:spec.offset + spec.size].reshape(spec.shape)
+        if global_step is not None:
+            arrays["global_step"] = np.int64(global_step)
+        np.savez(path, **arrays)
 
-    def load(self, path: str, strict: bool = True) -> None:
-        """A TensorFlow checkpoint prefix (``path``.index exists) or an .npz file."""
+    def load(self, path: str, strict: bool = True) -> Dict[str, object]:
+        """A TensorFlow checkpoint prefix (``path``.index exists) or an .npz file.  Variables, and -- when the
+        file has them -- the Adam slots; returns {"global_step": int or None}."""
         import os
         if os.path.exists(path + ".index"):
             from . import tf_bundle
-            tf_bundle.import_store(self, path, strict)
-            return
+            return tf_bundle.import_store(self, path, strict)
         if not path.endswith(".npz"):
             path = path + ".npz"
         with np.load(path) as data:
-            self.load_state_dict({k.replace("|", "/"): data[k] for k in data.files}, strict)
+            values = {k.replace("|", "/"): data[k] for k in data.files}
+        self.load_state_dict(values, strict)
+        names = [n for n in self.specs if n in values]
+        if names and all(n + "/Adam" in values and n + "/Adam_1" in values for n in names):
+            m, v = self.ensure_adam()
+            for n in names:
+                spec = self.specs[n]
+                m[spec.offset:spec.offset + spec.size] = torch.from_numpy(
+                    np.asarray(values[n + "/Adam"], np.float32).reshape(-1)).to(m.device)
+                v[spec.offset:spec.offset + spec.size] = torch.from_numpy(
+                    np.asarray(values[n + "/Adam_1"], np.float32).reshape(-1)).to(v.device)
+        step = values.get("global_step")
+        return {"global_step": None if step is None else int(step)}

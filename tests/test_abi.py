@@ -39,7 +39,8 @@ def test_error_reporting_without_gpu(lib):
     # argument validation happens before any launch: a null operand is an error, not a crash
     rc = lib.nm_gemm_f32(None, 0, 0, 4, 4, 4, None, 4, None, 4, None, 4, None, 0, 0, 1, 0, 0, 0, 0, None, 0)
     assert rc < 0 and b"null" in lib.nm_last_error()
-    assert lib.nm_attn_workspace_bytes(128, 50, 1024) == 4 * (6400 + 128 * 5 * 1024 + 128 * 5 * 4)
+    # energies + split-S partial contexts + partial statistics + one arrival counter per key batch
+    assert lib.nm_attn_workspace_bytes(128, 50, 1024) == 4 * (6400 + 128 * 5 * 1024 + 128 * 5 * 4 + 128)
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -226,6 +226,51 @@ def _split_gru_ref(xp, wgh, wch, lengths, h0=None):
     return torch.cat(outs, 2), torch.stack(finals)
 
 
+@pytest.mark.parametrize("bk,qpk", [(128, 1), (32, 5), (7, 3)])
+def test_attention_in_kernel_merge_survives_buffer_reuse(dev, bk, qpk):
+    """The split-S partials are handed to the last-arriving chunk workgroup INSIDE the launch (write-through
+    stores, one arrival counter per sentence, one agent-scope acquire): the same device buffers -- keys, queries,
+    workspace, outputs -- are refilled with new values and the step is re-run back to back, with other kernels
+    dirtying the caches in between; a consumer that read a stale partial (its own L1, another XCD's L2) would
+    reproduce the previous round's context.  Every round is checked against the float64 oracle
+    (attention/feed_forward.py:120-166) and the arrival counters must be back at zero."""
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(bk + qpk)
+    s, a, c = 50, 1024, 1024
+    r = bk * qpk
+    yd, hfd, std = (torch.empty(shape, device=dev) for shape in ((r, a), (bk, s, a), (bk, s, c)))
+    maskd = torch.empty((bk, s), device=dev)
+    vd, biasd = torch.empty(a, device=dev), torch.empty(1, device=dev)
+    ctx, w = torch.empty((r, c), device=dev), torch.empty((r, s), device=dev)
+    ws = ops.attn_workspace(r, s, c, dev)
+    nbytes = ops._lib.load().nm_attn_workspace_bytes(r, s, c)
+    junk = torch.empty(64 << 20, device=dev)
+    f64 = lambda x: np.asarray(x, dtype=np.float64)
+    for rnd in range(5):
+        y = (rng.standard_normal((r, a)) * 0.5).astype(np.float32)
+        hf = rng.standard_normal((bk, s, a)).astype(np.float32)
+        states = rng.standard_normal((bk, s, c)).astype(np.float32) * (rnd + 1)
+        mask = np.ones((bk, s), np.float32)
+        for i in range(bk):
+            mask[i, rng.integers(1, s + 1):] = 0
+        v = (rng.standard_normal(a) * 0.3).astype(np.float32)
+        for dst, src in ((yd, y), (hfd, hf), (std, states), (maskd, mask), (vd, v), (biasd, np.float32([0.1 * rnd]))):
+            dst.copy_(torch.from_numpy(np.ascontiguousarray(src)))
+        for rep in range(3):                                  # back to back on the same buffers
+            junk.fill_(float(rep))                            # 256 MB of dirty lines between the launches
+            ops.attn_fwd(yd, hfd, std, maskd, vd, biasd, qpk, ctx, w, ws)
+        e = (f64(v) * np.tanh(np.repeat(f64(hf), qpk, 0) + f64(y)[:, None, :])).sum(-1) + 0.1 * rnd
+        sm = np.exp(e - e.max(1, keepdims=True))
+        sm /= sm.sum(1, keepdims=True)
+        wm = sm * np.repeat(f64(mask), qpk, 0)
+        ref_w = wm / (wm.sum(1, keepdims=True) + 1e-8)
+        ref_ctx = np.einsum("rs,rsc->rc", ref_w, np.repeat(f64(states), qpk, 0))
+        assert rel_err(w.cpu().numpy(), ref_w) < RTOL, rnd
+        assert rel_err(ctx.cpu().numpy(), ref_ctx) < RTOL, rnd
+        tail = ws.view(torch.int32)[nbytes // 4 - ((r + 3) // 4) * 4:]
+        assert int(tail.abs().sum().item()) == 0, "arrival counters not restored"
+
+
 @pytest.mark.parametrize("b,s,e,h", [(128, 6, 512, 512), (16, 5, 64, 64), (128, 4, 256, 1024)])
 def test_gru_gemm_fused_epilogues_fwd_bwd(dev, b, s, e, h):
     """nm_gru_gemm modes 1-4 (recurrent GEMM + fused gate / blend epilogues, forward and BPTT) at the

@@ -123,7 +123,8 @@ def test_store_export_import(tmp_path):
     third.load(prefix)
     assert all(torch.equal(third[n], store[n]) for n in store.names())
     third.save(str(tmp_path / "again"), fmt="tf")
-    assert set(TB.read_bundle(str(tmp_path / "again"))) == set(store.names())
+    again = TB.read_bundle(str(tmp_path / "again"))         # the restored Adam slots travel on (Saver: all globals)
+    assert set(store.names()) <= set(again) and "decoder/state_to_word_b/Adam" in again and "global_step" not in again
     # a variable the checkpoint lacks
     third2 = VariableStore("cpu", seed=5)
     third2.declare("new/variable", (3,), zeros_initializer())
@@ -131,3 +132,81 @@ def test_store_export_import(tmp_path):
     with pytest.raises(KeyError):
         TB.import_store(third2, prefix)
     assert TB.import_store(third2, prefix, strict=False)["missing"] == ["new/variable"]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# cross-check against an INDEPENDENT implementation of the format (tests/golden/make_tf_bundle_fixture.py:
+# written from the TensorFlow 1.12 on-disk format, no code shared with neuralmonkey_amd/tf_bundle.py)
+# ---------------------------------------------------------------------------------------------------------
+def _indep():
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_tf_bundle_fixture.py")
+    spec = importlib.util.spec_from_file_location("make_tf_bundle_fixture", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod, os.path.join(os.path.dirname(path), "tf_bundle")
+
+
+@pytest.mark.parametrize("which", ["big_blocks", "small_blocks"])
+def test_reader_reads_the_independently_written_bundle(which):
+    """The committed fixtures (one data block with TF's 256 KB block size; many 512-byte blocks with
+    shortened separator keys in the index block) decode to exactly the tensors their generator wrote."""
+    import os
+    from neuralmonkey_amd import tf_bundle
+    mod, root = _indep()
+    want = mod.fixture_tensors()
+    got = tf_bundle.read_bundle(os.path.join(root, which))
+    assert set(got) == set(want)
+    for name, arr in want.items():
+        assert got[name].dtype == np.asarray(arr).dtype and got[name].shape == np.asarray(arr).shape, name
+        assert np.array_equal(got[name], arr), name
+    assert got["attention/attn_bias"].shape == () and got["attention/attn_key_projection"].shape == (1, 1, 8, 8)
+    assert int(got["global_step"]) == 7
+
+
+def test_the_committed_fixture_is_what_the_generator_writes(tmp_path):
+    import os
+    mod, root = _indep()
+    for which, block in (("big_blocks", 262144), ("small_blocks", 512)):
+        mod.write_fixture(str(tmp_path / which), block)
+        for ext in (".index", ".data-00000-of-00001"):
+            with open(os.path.join(root, which + ext), "rb") as a, open(str(tmp_path / which) + ext, "rb") as b:
+                assert a.read() == b.read(), which + ext
+
+
+def test_independent_reader_reads_the_product_writer(tmp_path):
+    """... and the other way round: what tf_bundle.write_bundle writes (several blocks forced) is parsed by
+    the independent reader, checksums, separator keys and protobuf field numbers included."""
+    from neuralmonkey_amd import tf_bundle
+    mod, _ = _indep()
+    tensors = mod.fixture_tensors()
+    prefix = str(tmp_path / "ours")
+    tf_bundle.write_bundle(prefix, tensors)
+    got = mod.parse_bundle(prefix)
+    assert set(got) == set(tensors)
+    for name, arr in tensors.items():
+        assert np.array_equal(got[name], arr) and got[name].shape == np.asarray(arr).shape, name
+    items = [(b"k%04d" % i, bytes([i % 251]) * (i % 37)) for i in range(400)]
+    assert mod.parse_table(tf_bundle.write_table(items, block_bytes=300)) == sorted(items)
+    assert tf_bundle.read_table(mod.build_table(items, 300)) == sorted(items)
+
+
+def test_store_import_of_the_independent_bundle():
+    """A checkpoint written the TensorFlow way restores a model of the same shapes: variables (TF conv-filter /
+    scalar shapes folded), Adam slots and global_step."""
+    import os
+    from neuralmonkey_amd import synthetic, tf_bundle
+    mod, root = _indep()
+    model = synthetic.build_translation_model(vocab_src=11, vocab_tgt=11, emb=4, rnn=4, max_len=5, beam_size=0,
+                                              with_trainer=False, device="cpu")
+    store = model.tf_manager.sessions[0].store
+    info = tf_bundle.import_store(store, os.path.join(root, "small_blocks"))
+    want = mod.fixture_tensors()
+    assert not info["missing"] and not info["unused"] and info["global_step"] == 7
+    for name in store.names():
+        assert np.array_equal(store[name].numpy().reshape(-1), want[name].reshape(-1)), name
+    m, v = store.ensure_adam()
+    for name, spec in store.specs.items():
+        assert np.array_equal(m[spec.offset:spec.offset + spec.size].numpy(), want[name + "/Adam"].reshape(-1))
+        assert np.array_equal(v[spec.offset:spec.offset + spec.size].numpy(), want[name + "/Adam_1"].reshape(-1))

@@ -1,5 +1,10 @@
 """Sweep the tiled-GEMM configurations (NM_GEMM_CFG) over the large GEMM shapes of one training step.
-Each configuration runs in its own process (the knob is read once per process)."""
+Each configuration runs in its own process (the knob is read once per process).
+
+    python tools/gemm_sweep.py 1 6 2 7 1+NOSTORE      a column per NM_GEMM_CFG value; +NOSTORE = the timing
+                                                       ablation that skips the C stores
+A second table times the vocabulary projection with the statistics epilogue (nm_logits_stats_gemm) at one
+greedy step (M=128) and one beam step (M=640) for NM_STATS_CFG = 0..3."""
 import json
 import os
 import subprocess
@@ -42,6 +47,25 @@ def child():
         torch.cuda.synchronize()
         t = e0.elapsed_time(e1) * 1e-3 / 10
         res[name] = round(2.0 * m * n * k / t / 1e12, 1)
+    for m in (128, 640):                      # vocabulary projection with the statistics epilogue
+        n, k = 32000, 512
+        a, bias = rn(m, k), rn(n)
+        stats = ops.logits_stats_buffer(m, n, dev)
+        out = torch.empty(m, n, device=dev)
+        for tb in (False, True):              # W as stored [K,N] / transposed [N,K] (a tile is then contiguous)
+            w = rn(n, k) if tb else rn(k, n)
+            for with_c in (False, True):
+                for _ in range(3):
+                    ops.logits_stats_gemm(a, w, bias, stats, out=out if with_c else None, trans_b=tb)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    ops.logits_stats_gemm(a, w, bias, stats, out=out if with_c else None, trans_b=tb)
+                e1.record()
+                torch.cuda.synchronize()
+                res["stats M={} {}{}".format(m, "WT " if tb else "W  ", "C" if with_c else "noC")] = \
+                    round(e0.elapsed_time(e1) * 1e3 / 20, 1)   # us
     print(json.dumps(res))
 
 
@@ -52,12 +76,22 @@ if __name__ == "__main__":
         cfgs = sys.argv[1:] or ["1", "2", "4", "5", "6"]
         rows = {}
         for cfg in cfgs:
-            env = dict(os.environ, NM_GEMM_CFG=cfg)
+            num = cfg.split("+")[0]
+            env = dict(os.environ, NM_GEMM_CFG=num, NM_STATS_CFG=num if int(num) <= 3 else "0")
+            if "+NOSTORE" in cfg:
+                env["NM_GEMM_NOSTORE"] = "1"
             out = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, capture_output=True,
                                  text=True)
             line = [l for l in out.stdout.splitlines() if l.startswith("{")]
             rows[cfg] = json.loads(line[-1]) if line else {"error": out.stderr[-300:]}
         names = [s[0] for s in SHAPES]
-        print("{:16s}".format("TFLOP/s  cfg:") + "".join("{:>8s}".format(c) for c in cfgs))
+        print("{:16s}".format("TFLOP/s  cfg:") + "".join("{:>11s}".format(c) for c in cfgs))
         for n in names:
-            print("{:16s}".format(n) + "".join("{:>8}".format(rows[c].get(n, "-")) for c in cfgs))
+            print("{:16s}".format(n) + "".join("{:>11}".format(rows[c].get(n, "-")) for c in cfgs))
+        print("us per launch, nm_logits_stats_gemm (NM_STATS_CFG = cfg when cfg <= 3: 0 default, 1 128-wide tiles, "
+              "+2 loads two k-tiles ahead)")
+        for n in sorted(k for k in rows[cfgs[0]] if k.startswith("stats")):
+            print("{:16s}".format(n) + "".join("{:>11}".format(rows[c].get(n, "-")) for c in cfgs))
+        for c in cfgs:
+            if "error" in rows[c]:
+                print(c, rows[c]["error"])
