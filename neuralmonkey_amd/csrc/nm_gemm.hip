@@ -963,18 +963,36 @@ extern "C" int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int6
         // blockIdx.y into slabs and reduce them in a fixed order, so the chip is filled.
         if (workspace && batch == 1 && K >= 1024) {
             const bool big = (algo == 1) || (algo == 0 && M >= 128 && N >= 128);
-            const long tiles = big ? (long)nm_cdiv(M, 128) * nm_cdiv(N, 128)
-                                   : (long)nm_cdiv(M, 64) * nm_cdiv(N, 64);
-            if (tiles < 384) {
-                long sk = (768 + tiles - 1) / tiles;
-                if (sk > 16) sk = 16;
-                if (sk > K / 256) sk = K / 256;
-                while (sk > 1 && sk * M * N * (long)sizeof(float) > workspace_bytes) --sk;
-                if (sk >= 2) {
-                    g.splitk = (int)sk;
-                    g.ws = reinterpret_cast<float*>(workspace);
-                    if (algo == 0) pick = big ? 1 : 2;
-                }
+            const int tile = big ? 128 : 64;
+            const long tiles = (long)nm_cdiv(M, tile) * nm_cdiv(N, tile);
+            // Split factor from a makespan model instead of "fill 768 slots": the chip finishes a GEMM in
+            // ceil(workgroups / 256 CUs) rounds of (k-tiles per workgroup) each, so 200 output tiles split 4
+            // ways (800 workgroups) take 4 x K/4 -- as long as no split at all on 200 CUs -- while 5 ways
+            // (1000 workgroups) take 4 x K/5.  Costs in microseconds: one 128x128x16 k-tile of a workgroup at
+            // the per-CU share of the sustained fp32 MFMA rate (~0.95 us; 64x64: a quarter), few workgroups per
+            // CU run below that rate (nothing to hide latencies behind), and the slab reduction streams
+            // (sk + 1) M N floats at ~3 TB/s plus a launch.
+            static const int sk_env = getenv("NM_GEMM_SK") ? atoi(getenv("NM_GEMM_SK")) : 0;     // tuning override
+            const long nkt = (K + 15) / 16;
+            const double kt_us = big ? 0.95 : 0.30;
+            long best_sk = 1;
+            double best = 1e30;
+            for (long sk = 1; sk <= 16; ++sk) {
+                if (sk > 1 && (K / sk < 128 || sk * M * N * (long)sizeof(float) > workspace_bytes)) break;
+                const long blocks = tiles * sk;
+                const long rounds = (blocks + 255) / 256;
+                const double per_cu = (double)blocks / 256.0;
+                const double thin = per_cu <= 1.0 ? 1.35 : (per_cu <= 2.0 ? 1.15 : 1.0);
+                double cost = (double)rounds * (double)((nkt + sk - 1) / sk) * kt_us * thin;
+                if (sk > 1) cost += (double)(sk + 1) * M * N * 4.0 / 3.0e6 + 3.0;
+                if (cost < best) { best = cost; best_sk = sk; }
+            }
+            if (sk_env > 0 && sk_env <= 16 && K / sk_env >= 128 &&
+                (long)sk_env * M * N * (long)sizeof(float) <= workspace_bytes) best_sk = sk_env;
+            if (best_sk >= 2) {
+                g.splitk = (int)best_sk;
+                g.ws = reinterpret_cast<float*>(workspace);
+                if (algo == 0) pick = big ? 1 : 2;
             }
         }
         static const int cfg_env = getenv("NM_GEMM_CFG") ? atoi(getenv("NM_GEMM_CFG")) : 1;   // tuning knob (1 measured best)

@@ -113,10 +113,17 @@ class DataParallel:
             dist.broadcast(store.theta, src=src)
 
     def shard(self, dataset):
-        """This rank's contiguous B/N rows of a batch (SURVEY 8e partitioning)."""
+        """This rank's contiguous share of a batch (SURVEY 8e partitioning): the rows are dealt as evenly as
+        possible (sizes differ by at most one), so no rank is left without work while another holds two rows
+        more.  A batch with fewer rows than ranks cannot be sharded: every rank sees the same batch and raises
+        the same error -- nobody is left waiting in a collective."""
         n = len(dataset)
-        per = (n + self.world_size - 1) // self.world_size
-        return dataset.subset(self.rank * per, max(0, min(per, n - self.rank * per)))
+        if n < self.world_size:
+            raise ValueError("a batch of {} sentences cannot be sharded over {} ranks: drop or pad the last batch "
+                             "(dataset.BatchingScheme(drop_remainder=True))".format(n, self.world_size))
+        base, rem = divmod(n, self.world_size)
+        start = self.rank * base + min(self.rank, rem)
+        return dataset.subset(start, base + (1 if self.rank < rem else 0))
 
 
 def init_from_env(backend: Optional[str] = None) -> Optional[DataParallel]:

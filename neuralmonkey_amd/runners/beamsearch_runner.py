@@ -40,15 +40,13 @@ class BeamSearchRunner(BaseRunner):
             """beamsearch_runner.py:84-106: hypothesis ``rank``, first token
             dropped, cut at </s>; loss = mean(score) * batch."""
             bs_scores = [s[self.rank - 1] for s in output.scores]
-            tok_ids = np.transpose(output.token_ids, [1, 2, 0])
-            decoded_tokens = []
-            for toks in tok_ids:
-                sent = []
-                for tok_id in toks[self.rank - 1][1:]:
-                    if tok_id == END_TOKEN_INDEX:
-                        break
-                    sent.append(self.decoder.vocabulary.index_to_word[int(tok_id)])
-                decoded_tokens.append(sent)
+            # hypothesis `rank` of every sentence, time-major without the parent's first symbol; the word lookup
+            # and the cut at </s> are vectorised in Vocabulary.vectors_to_sentences
+            tok_tb = np.asarray(output.token_ids)[1:, :, self.rank - 1]
+            if tok_tb.shape[0] == 0:
+                decoded_tokens = [[] for _ in range(tok_tb.shape[1])]
+            else:
+                decoded_tokens = self.decoder.vocabulary.vectors_to_sentences(tok_tb)
             if self.postprocess is not None:
                 decoded_tokens = self.postprocess(decoded_tokens)
             self.set_runner_result(outputs=decoded_tokens,

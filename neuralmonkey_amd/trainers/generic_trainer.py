@@ -121,7 +121,7 @@ class GenericTrainer(GraphExecutor, Feedable):
             count = dec.train_token_count(ctx)
             global_count = dp.all_reduce_scalar(count) if dp is not None else count
             scale = ctx.buffer((id(self), "gscale", i), (1,))
-            scale.fill_(weight / global_count)
+            scale.fill_(weight / global_count if global_count else 0.0)     # a batch without target tokens: no gradient
             decoders.append(dec)
             scales.append(scale)
             counts.append(count)

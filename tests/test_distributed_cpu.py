@@ -109,3 +109,22 @@ def test_single_process_is_a_no_op(monkeypatch):
     from neuralmonkey_amd import distributed
     monkeypatch.setenv("WORLD_SIZE", "1")
     assert distributed.init_from_env() is None and distributed.current() is None
+
+
+def test_shard_sizes_are_even_and_tiny_batches_are_refused():
+    """3 ranks, 8 rows -> 3/3/2 contiguous rows covering the batch; fewer rows than ranks raise on every rank
+    alike (an empty shard would leave its rank out of the step while the others wait in all_reduce)."""
+    from neuralmonkey_amd.dataset import BatchingScheme, Dataset
+    from neuralmonkey_amd.distributed import DataParallel
+    ds = Dataset("d", {"source": [[str(i)] for i in range(8)]}, BatchingScheme(batch_size=8))
+    seen = []
+    for rank in range(3):
+        dp = DataParallel.__new__(DataParallel)
+        dp.rank, dp.world_size = rank, 3
+        part = dp.shard(ds)
+        seen.append([s[0] for s in part.get_series("source")])
+    assert [len(p) for p in seen] == [3, 3, 2]
+    assert sum(seen, []) == [str(i) for i in range(8)]
+    dp.world_size = 9
+    with pytest.raises(ValueError, match="cannot be sharded"):
+        dp.shard(ds)

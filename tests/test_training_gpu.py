@@ -186,9 +186,19 @@ def test_checkpoint_carries_optimizer_state_and_global_step(dev, tmp_path, fmt, 
     sess_b = b.tf_manager.sessions[0]
     assert sess_b.global_step == 3
     assert float(sess_b.store.adam_v.abs().max()) > 0.0
-    losses_b = [step(b, ds).losses["decoder - cost"] for ds in batches[3:]]
+    b_start = sess_b.store.state_dict()
+    losses_b = [step(b, batches[3]).losses["decoder - cost"]]
+    after_one = sess_b.store.state_dict()
+    losses_b.append(step(b, batches[4]).losses["decoder - cost"])
     assert sess_b.global_step == 5
-    assert losses_a == losses_b
+    assert np.allclose(losses_a, losses_b, rtol=1e-6, atol=0)
     final_b = sess_b.store.state_dict()
-    for name, want in final_a.items():
-        assert np.array_equal(final_b[name], want), name
+    for name, want in final_a.items():      # (the embedding-gradient scatter adds with atomics: last-bit differences)
+        assert np.abs(final_b[name] - want).max() <= 1e-6, name
+    # and a restore that dropped the optimizer state would NOT reproduce the run: Adam's first-step update is
+    # lr * sign(g), three orders of magnitude above this tolerance
+    c = fresh()
+    c.tf_manager.sessions[0].store.load_state_dict(b_start)
+    step(c, batches[3])
+    worst = max(float(np.abs(c.tf_manager.sessions[0].store.state_dict()[n] - after_one[n]).max()) for n in after_one)
+    assert worst > 1e-5

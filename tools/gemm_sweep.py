@@ -80,6 +80,9 @@ if __name__ == "__main__":
             env = dict(os.environ, NM_GEMM_CFG=num, NM_STATS_CFG=num if int(num) <= 3 else "0")
             if "+NOSTORE" in cfg:
                 env["NM_GEMM_NOSTORE"] = "1"
+            for part in cfg.split("+")[1:]:
+                if part.startswith("SK"):
+                    env["NM_GEMM_SK"] = part[2:]
             out = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, capture_output=True,
                                  text=True)
             line = [l for l in out.stdout.splitlines() if l.startswith("{")]
