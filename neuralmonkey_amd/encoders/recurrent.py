@@ -195,8 +195,11 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
         len_arg = lengths
         xrs, xts = slen * ndir * 3 * h, ndir * 3 * h
         ors, ots = slen * c_out, c_out
-        fused = gru.fused_ok(bsz, h)
-        wg_f, wc_f = gru.transposed_weights(ctx, key, wgh, wch) if fused else (wgh, wch)
+        # (transposed [N,K] copies of the recurrent kernels were measured SLOWER here, 17.4 vs 16.7 us per step:
+        # a lane's 16-byte fragment then comes from its own 2 KB row, while the [K,N] layout serves 16 lanes from
+        # one 64-byte segment -- tools/gru_loop_bench.py)
+        fused = False
+        wg_f, wc_f = wgh, wch
 
         def time_loop():
             states_raw.zero_()
