@@ -23,8 +23,11 @@ def main():
     ap.add_argument("--vocab", type=int, default=32000)
     args = ap.parse_args()
     from neuralmonkey_amd import synthetic
+    if os.environ.get("NM_MAIN_PRIO"):        # experiment: the step's own stream above the side (leaf-GEMM) stream
+        torch.cuda.set_stream(torch.cuda.Stream(priority=-1))
     model = synthetic.build_translation_model(vocab_src=args.vocab, vocab_tgt=args.vocab, emb=args.hidden,
                                               rnn=args.hidden, max_len=args.length, beam_size=0, device="cuda:0")
+    synthetic.load_baseline_weights(model.tf_manager.sessions[0].store)
     ds = synthetic.synthetic_dataset(seed=1234, batch=args.batch, src_len=args.length, tgt_len=args.length,
                                      vocab=args.vocab)
     tfm, trainer = model.tf_manager, model.trainer
