@@ -248,6 +248,11 @@ int nm_gather_rows_f32(void* stream, const float* src, int64_t ld_src, const int
                        int64_t ld_dst, int64_t rows, int64_t width);
 int nm_beam_reorder_tokens(void* stream, const int32_t* src, const int32_t* src_row, const int32_t* word,
                            int32_t* dst, int64_t steps, int64_t R);
+/* the same histories from back-pointers, once per search instead of once per step: src_row / word [steps,R] are
+ * the out_src_row / out_word of every beam body, first [R] the parent's initial symbols;
+ * out[t+1,r] = word[t, ancestor_t(r)], out[0,r] = first[ancestor_0(r)]  (beam_search_decoder.py:546-551) */
+int nm_beam_backtrace(void* stream, const int32_t* src_row, const int32_t* word, const int32_t* first,
+                      int32_t* out, int64_t steps, int64_t R);
 
 /* ---- small utilities -------------------------------------------------------------------------- */
 int nm_copy_cols(void* stream, const float* src, int64_t ld_src, float* dst, int64_t ld_dst,

@@ -79,6 +79,7 @@ SIGNATURES = {
     "nm_optim_clip_adam": (I, [P, P, P, P, P, P, P, P, P, P, P, L, L, F, F, F, F, F, P, L]),
     "nm_gather_rows_f32": (I, [P, P, L, P, P, L, L, L]),
     "nm_beam_reorder_tokens": (I, [P, P, P, P, P, L, L]),
+    "nm_beam_backtrace": (I, [P, P, P, P, P, L, L]),
     "nm_logits_stats_tile": (L, [L]),
     "nm_logits_stats_bytes": (L, [L, L]),
     "nm_logits_stats_gemm": (I, [P, I, L, L, L, P, L, P, L, P, P, L, P, L]),

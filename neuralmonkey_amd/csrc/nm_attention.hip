@@ -99,8 +99,8 @@ __device__ __forceinline__ long attn_qrow(const AttnArgs& p, int b, int qi) {
 // L1 is never refreshed by other CUs' stores).  Producer side of the guide's recipe R1: the payload is stored
 // WRITE-THROUGH (agent-scope relaxed stores lower to `global_store ... sc1`), every storing wave drains its
 // stores (s_waitcnt vmcnt(0)), the workgroup meets, ONE lane takes a ticket with an agent-scope atomic.  The
-// workgroup that draws the last ticket is the consumer: one agent-scope acquire (invalidates its L1), a
-// barrier, then plain loads.
+// workgroup that draws the last ticket is the consumer: it reads the partials with L1-bypassing (sc1) loads
+// (measured the same as the recipe's agent-scope acquire + plain loads: 17.8 us cold either way).
 __device__ __forceinline__ void st_wt2(float* p, float a, float b) {
     const unsigned long long x = ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a);
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -108,6 +108,21 @@ __device__ __forceinline__ void st_wt2(float* p, float a, float b) {
 __device__ __forceinline__ void st_wt4(float* p, float4 v) { st_wt2(p, v.x, v.y); st_wt2(p + 2, v.z, v.w); }
 __device__ __forceinline__ void st_wt1(float* p, float a) {
     __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// consumer side: agent-scope relaxed loads (`global_load ... sc1`) bypass this CU's L1, which may still hold the
+// previous step's lines of the same buffers; they are valid without an acquire fence because the producers
+// stored sc1 (write-through) and drained before taking their tickets
+__device__ __forceinline__ float4 ld_wt4(const float* p) {
+    const unsigned long long lo = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long hi = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p) + 1,
+                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)),
+                       __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32)));
+}
+__device__ __forceinline__ float ld_wt1(const float* p) {
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT));
 }
 
 // true for every thread of the workgroup that arrived last for key batch b
@@ -117,10 +132,8 @@ __device__ __forceinline__ bool attn_arrive_last(const AttnArgs& p, int b, int* 
     if (threadIdx.x == 0) {
         const unsigned t = __hip_atomic_fetch_add(p.tickets + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = (t == (unsigned)(p.nchunk - 1));
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(p.tickets + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-        }
+        if (last)      // ready for the next launch; (no acquire fence: the merge reads with sc1 loads, see ld_wt4)
+            __hip_atomic_store(p.tickets + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *s_flag = last;
     }
     __syncthreads();
@@ -139,20 +152,19 @@ __device__ __forceinline__ void attn_merge_row(const AttnArgs& p, long qr, int b
         const int c = tid * 4;
 #pragma unroll
         for (int i = 0; i < ATT_MERGE_MAXCH; ++i)
-            x[i] = (c < p.C && i < p.nchunk) ? *reinterpret_cast<const float4*>(pc + (long)i * p.C + c)
-                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            x[i] = (c < p.C && i < p.nchunk) ? ld_wt4(pc + (long)i * p.C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     float e_s = 0.0f, mk = 1.0f;
     const bool w_ok = p.weights && tid < p.S;
     if (w_ok) {
-        e_s = p.energies[qr * p.S + tid];
+        e_s = ld_wt1(p.energies + qr * p.S + tid);
         if (p.mask) mk = p.mask[(long)b * p.S + tid];
     }
     float4 sv[ATT_MERGE_MAXCH];
     float M = -INFINITY;
 #pragma unroll
     for (int i = 0; i < ATT_MERGE_MAXCH; ++i) {
-        sv[i] = i < p.nchunk ? st[i] : make_float4(-INFINITY, 0.f, 0.f, 0.f);
+        sv[i] = i < p.nchunk ? ld_wt4(reinterpret_cast<const float*>(st + i)) : make_float4(-INFINITY, 0.f, 0.f, 0.f);
         M = fmaxf(M, sv[i].x);
     }
     float la = 0.0f, lm = 0.0f, f[ATT_MERGE_MAXCH];
@@ -167,7 +179,7 @@ __device__ __forceinline__ void attn_merge_row(const AttnArgs& p, long qr, int b
         if (c >= 1024) {                               // second 1024-column group (C up to 2048): one more round trip
 #pragma unroll
             for (int i = 0; i < ATT_MERGE_MAXCH; ++i)
-                x[i] = i < p.nchunk ? *reinterpret_cast<const float4*>(pc + (long)i * p.C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                x[i] = i < p.nchunk ? ld_wt4(pc + (long)i * p.C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -181,7 +193,7 @@ __device__ __forceinline__ void attn_merge_row(const AttnArgs& p, long qr, int b
     if (p.weights)
         for (int s2 = tid + 256; s2 < p.S; s2 += 256) {
             const float m2 = p.mask ? p.mask[(long)b * p.S + s2] : 1.0f;
-            p.weights[qr * p.S + s2] = __expf(p.energies[qr * p.S + s2] - M) * m2 * inv;
+            p.weights[qr * p.S + s2] = __expf(ld_wt1(p.energies + qr * p.S + s2) - M) * m2 * inv;
         }
 }
 

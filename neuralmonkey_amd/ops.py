@@ -370,6 +370,16 @@ def beam_reorder_tokens(src, src_row, word, dst, steps, rows):
                "nm_beam_reorder_tokens")
 
 
+def beam_backtrace(src_hist, word_hist, first, out, steps):
+    """Token histories [steps+1, R] from the per-step (source row, word) records of a beam search."""
+    lib = _lib.load()
+    rows = first.numel()
+    assert src_hist.is_contiguous() and word_hist.is_contiguous() and out.is_contiguous()
+    assert src_hist.shape[1] == rows and word_hist.shape[1] == rows and out.shape[1] == rows and out.shape[0] > steps
+    _lib.check(lib.nm_beam_backtrace(_stream(), src_hist.data_ptr(), word_hist.data_ptr(), first.data_ptr(),
+                                     out.data_ptr(), steps, rows), "nm_beam_backtrace")
+
+
 def length_penalty_table(max_len: int, alpha: float, device) -> torch.Tensor:
     """((5+len)/6)**alpha for len in [0, max_len], evaluated in fp32 on the host
     the way the reference's tf.pow sees it (beam_search_decoder.py:561-573)."""

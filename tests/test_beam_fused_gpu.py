@@ -103,3 +103,39 @@ def test_fused_huge_and_tiny_magnitudes(dev):
     lps, lens, fin = _state(rng, b, k)
     lps[1] = np.float32(-3e4)
     _run_both(dev, logits, k, lps, lens, fin)
+
+
+def test_backtrace_equals_the_per_step_history_gather(dev):
+    """nm_beam_backtrace (one walk over the back-pointers at the end) == nm_beam_reorder_tokens applied at every
+    step (the reference's per-step gather of the whole token history, beam_search_decoder.py:546-551)."""
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(11)
+    bsz, k, steps = 7, 5, 13
+    rows = bsz * k
+    parent = np.stack([(np.arange(bsz)[:, None] * k + rng.integers(0, k, size=(bsz, k))).reshape(-1)
+                       for _ in range(steps)]).astype(np.int32)                 # a parent inside the same sentence
+    word = rng.integers(0, 1000, size=(steps, rows)).astype(np.int32)
+    first = rng.integers(0, 1000, size=rows).astype(np.int32)
+    dt = lambda a: torch.tensor(a, dtype=torch.int32, device=dev)
+    tok = torch.zeros((2, steps + 1, rows), dtype=torch.int32, device=dev)
+    tok[0, 0].copy_(dt(first))
+    for s in range(steps):
+        ops.beam_reorder_tokens(tok[s & 1], dt(parent[s]), dt(word[s]), tok[(s & 1) ^ 1], s + 1, rows)
+    want = tok[steps & 1].cpu().numpy()
+    out = torch.full((steps + 1, rows), -1, dtype=torch.int32, device=dev)
+    ops.beam_backtrace(dt(parent), dt(word), dt(first), out, steps)
+    assert np.array_equal(out.cpu().numpy(), want)
+    # NumPy restatement of the walk
+    def walk(n):
+        ref = np.zeros((n + 1, rows), np.int32)
+        for r in range(rows):
+            cur = r
+            for t in range(n - 1, -1, -1):
+                ref[t + 1, r] = word[t, cur]
+                cur = parent[t, cur]
+            ref[0, r] = first[cur]
+        return ref
+    assert np.array_equal(want, walk(steps))
+    short = torch.full((steps + 1, rows), -1, dtype=torch.int32, device=dev)
+    ops.beam_backtrace(dt(parent), dt(word), dt(first), short, 4)                # a search that stopped after 4 bodies
+    assert np.array_equal(short[:5].cpu().numpy(), walk(4)) and int(short[5:].max()) == -1

@@ -1,10 +1,9 @@
 set -x
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-T=r2k
-python tools/train_profile.py --steps 20 > gpurun_out/${T}_base.log 2>&1
-NM_MAIN_PRIO=1 python tools/train_profile.py --steps 20 > gpurun_out/${T}_prio.log 2>&1
-NM_SIDE_STREAM=0 python tools/train_profile.py --steps 20 > gpurun_out/${T}_noside.log 2>&1
-python tools/train_profile.py --steps 20 --batch 16 > gpurun_out/${T}_b16.log 2>&1
-NM_SIDE_STREAM=0 python tools/train_profile.py --steps 20 --batch 16 > gpurun_out/${T}_b16_noside.log 2>&1
-grep -h train gpurun_out/${T}_*.log
+T=r2m
+python -m pytest tests/test_beam_fused_gpu.py tests/test_engine_gpu.py tests/test_fullsize_parity_gpu.py tests/test_ensemble_gpu.py tests/test_transformer_gpu.py -q -m gpu --timeout=900 > gpurun_out/${T}_tests.log 2>&1
+echo "tests rc=$?" >> gpurun_out/${T}_tests.log
+python tools/gemm_sweep.py 1 1+NT > gpurun_out/${T}_gemm_sweep.log 2>&1
+python tools/decode_profile.py --mode beam --batches 8 > gpurun_out/${T}_beam.log 2>&1
+tail -3 gpurun_out/${T}_tests.log; cat gpurun_out/${T}_gemm_sweep.log | head -16; grep -v amdgpu gpurun_out/${T}_beam.log
