@@ -307,7 +307,25 @@ def main():
             return ((tot_ms.value * 1e3 / cnt.value) if cnt.value else None), cnt.value
         cold_us, cold_n = measure(False)
         dirty_us, _ = measure(True)
-        del flush
+        # yardstick: the same number of bytes read cold by a plain streaming kernel (nm_prof_stream_read), same
+        # sweep in between, same event pool -- what ONE launch of this size can reach on this part
+        nbytes = attention_step_bytes(args.batch, args.length, a, c) // 16 * 16
+        probe = torch.randn(nbytes // 4, device=dev, generator=gen)
+        psink = torch.zeros(2048, device=dev)
+
+        def stream_pass(n):
+            for _ in range(n):
+                sink.add_(flush.sum())
+                _lib.check(lib.nm_prof_stream_read(ops._stream(), probe.data_ptr(), nbytes, psink.data_ptr()),
+                           "nm_prof_stream_read")
+            torch.cuda.synchronize()
+        stream_pass(3)
+        lib.nm_prof_enable(1)
+        stream_pass(20)
+        lib.nm_prof_enable(0)
+        lib.nm_prof_attn_step(ctypes.byref(tot_ms), ctypes.byref(cnt))
+        stream_us = (tot_ms.value * 1e3 / cnt.value) if cnt.value else None
+        del flush, probe
 
     if rank == 0:
         a = c = 2 * h
@@ -354,6 +372,12 @@ def main():
                          "cold_dirty_launch_us": dirty_us,
                          "cold_dirty_how": "the same with a 1 GiB WRITE sweep: the caches hold dirty lines whose "
                                            "write-back competes with the kernel's reads",
+                         "stream_read_cold_us": stream_us,
+                         "stream_read_how": "yardstick: the same {} bytes read cold by a plain float4 streaming kernel "
+                                            "(nm_prof_stream_read), same sweep, same events; cold_launch_us / this = "
+                                            "how far the step kernel is from what one launch of this size can "
+                                            "reach".format(step_bytes // 16 * 16),
+                         "frac_of_stream_read": (stream_us / cold_us) if (stream_us and cold_us) else None,
                          "achieved_warm": warm, "frac_warm": (warm / HBM_PEAK_GBPS) if warm else None,
                          "warm_launch_us": warm_us, "warm_launches": warm_n,
                          "warm_how": "inside a greedy decode of one B={} batch, {} steps, launched eagerly".format(

@@ -145,6 +145,9 @@ int nm_attn_softmax_fwd(void* stream, const float* e, const float* mask, float* 
  * combine), events recorded on the launch stream (bench.py roofline) */
 int nm_prof_enable(int on);
 int nm_prof_attn_step(double* total_ms, int64_t* count);
+/* yardstick for that timing: a plain streaming read (float4 loads, one partial sum per workgroup into
+ * sink[0..2047]) of `bytes` bytes, timed by the same event pool when profiling is enabled */
+int nm_prof_stream_read(void* stream, const void* src, int64_t bytes, float* sink);
 
 /* The attention step WITHOUT its combine launch: energies [R,S] (workspace offset 0) and the split-S partials
  * stay in the workspace for a consumer that merges them while it loads them (nm_step_group, a_kind 1).
@@ -183,6 +186,48 @@ typedef struct nm_step_problem {
     float* h_out; int64_t ldho; float* h_out2; int64_t ldho2;
 } nm_step_problem;
 int nm_step_group(void* stream, int64_t M, const nm_step_problem* problems, int32_t nproblems);
+
+/* ---- the WHOLE inference step of the headline decoder behind one call (SURVEY 8(b)4 nm_decoder_step_fused):
+ * Decoder.next_state, decoders/decoder.py:279-358 (plain GRUCell nn/ortho_gru_cell.py:44-53, ONE Bahdanau
+ * attention attention/feed_forward.py:120-166, nonlinear output projection decoders/output_projection.py:115-130)
+ * followed by the vocabulary projection of get_body, decoders/autoregressive.py:450-459.
+ * Seven launches on `stream`: nm_step_group x3, nm_attn_fwd, nm_step_group, nm_logits_stats_gemm (plain
+ * nm_gemm_f32 when stats == NULL); a caller that replays the step captures this call in a HIP graph.
+ *   cat        [rows, emb+rnn] = [embedded input symbol | state]: the persistent input row.  The state half is
+ *              REPLACED by h'; the caller embeds the next symbols into the left half (nm_greedy_finish emb_out,
+ *              ld_emb = emb+rnn) and -- beam search -- gathers the surviving states into the right half.
+ *   h_copy     optional second copy of h' (ld_h_copy), the state history of a beam search
+ *   out_state  [rows, out] the projected output the logits are computed from
+ *   attn_weights [rows, src_len] the distribution of this step, or NULL
+ *   logits / stats   as nm_logits_stats_gemm (logits may be NULL with stats: greedy decoding)
+ *   ru rh xc y pre_e pre ctx   dense scratch [rows, 2*rnn | rnn | rnn | attn_state | out | out | ctx_width]
+ *   attn_workspace   nm_attn_workspace_bytes(rows, src_len, ctx_width), zeroed once after allocation
+ *   *_t        parameters TRANSPOSED to [N,K]: wg_t [2*rnn, emb+rnn] (gates kernel), wcx_t [rnn, emb] / wch_t
+ *              [rnn, rnn] (candidate kernel rows of the input / of the state), wq_t [attn_state, rnn] (query
+ *              projection), wo_h_t / wo_e_t / wo_c_t [out, rnn | emb | ctx_width] (output projection kernel rows
+ *              [state | embedded input | context]); biases bg [2*rnn], bc [rnn], bq [attn_state] or NULL, bo [out]
+ *   keys [Bk,src_len,attn_state], values [Bk,src_len,ctx_width], mask [Bk,src_len], v [attn_state], attn_bias [1]
+ *              with Bk = rows / rows_per_key
+ *   w_vocab    [out, vocab] (vocab_trans_b: [vocab, out], tied embeddings), ld_w_vocab; b_vocab [vocab] or NULL
+ *   out_act    0 none / 1 tanh.  emb, rnn, ctx_width multiples of 16; all pointers 16-byte aligned. */
+typedef struct nm_decoder_step {
+    int64_t rows, emb, rnn, attn_state, ctx_width, out, vocab, src_len, rows_per_key;
+    float* cat;
+    float* h_copy; int64_t ld_h_copy;
+    float* out_state; int64_t ld_out_state;
+    float* attn_weights;
+    float* logits; int64_t ld_logits;
+    float* stats; int64_t stats_bytes;
+    float* ru; float* rh; float* xc; float* y; float* pre_e; float* pre; float* ctx;
+    void* attn_workspace; int64_t attn_workspace_bytes;
+    const float* wg_t; const float* bg; const float* wcx_t; const float* wch_t; const float* bc;
+    const float* wq_t; const float* bq; const float* keys; const float* values; const float* mask;
+    const float* v; const float* attn_bias;
+    const float* wo_h_t; const float* wo_e_t; const float* wo_c_t; const float* bo;
+    const float* w_vocab; int64_t ld_w_vocab; const float* b_vocab;
+    int32_t out_act, vocab_trans_b;
+} nm_decoder_step;
+int nm_decoder_step_fused(void* stream, const nm_decoder_step* step);
 
 /* ---- vocabulary-axis rows: tf.argmax / tf.nn.log_softmax / sequence_loss ----------------------
  * decoders/autoregressive.py:470 (argmax, first max wins), :289-316,351-375 (xent, log-probs) */
@@ -271,7 +316,7 @@ int nm_colsum(void* stream, const float* x, int64_t ldx, int64_t rows, int64_t c
  * op codes: 0 copy, 1 a+b, 2 a-b, 3 a*b, 4 alpha*a, 5 sigmoid(a+alpha), 6 tanh(a), 7 relu(a),
  *           8 b*a*(1-a), 9 b*(1-a^2), 10 b*(a>0)   (8-10: a = forward output, b = upstream grad),
  *           11 log(exp(a)+exp(b)) (ensemble mean in log space, runners/beamsearch_runner.py:50-55),
- *           12 a+alpha */
+ *           12 a+alpha, 13 a[r,c]*b[r,0] (per-row scalar), 14 a/b (attention/coverage.py:57) */
 int nm_ew(void* stream, int op, const float* a, int64_t lda, const float* b, int64_t ldb, float* out,
           int64_t ldo, int64_t rows, int64_t cols, float alpha, int accumulate);
 /* h' = u*h + (1-u)*c  and its gradient (du, dh, dc accumulate; any may be NULL) */

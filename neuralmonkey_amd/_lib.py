@@ -87,6 +87,8 @@ SIGNATURES = {
     "nm_attn_partials_layout": (I, [L, L, L, L, P, P, P]),
     "nm_attn_fwd_partials": (I, [P, P, P, P, P, P, P, L, L, L, L, L, P, L]),
     "nm_step_group": (I, [P, L, P, ctypes.c_int32]),
+    "nm_decoder_step_fused": (I, [P, P]),
+    "nm_prof_stream_read": (I, [P, P, L, P]),
     "nm_beam_topk_step_tiles": (I, [P, P, L, P, L, L, L, L, P, P, P, P, I, P, P, P, P, P, P, P, P, L, P, P, P]),
 }
 
@@ -118,6 +120,19 @@ class StepProblem(ctypes.Structure):
                 ("S", L), ("mask_div", L), ("mask_mod", L),
                 ("h", P), ("ldh", L), ("ru", P), ("rh", P), ("xc", P), ("ldxc", L),
                 ("h_out", P), ("ldho", L), ("h_out2", P), ("ldho2", L)]
+
+
+class DecoderStep(ctypes.Structure):
+    """``nm_decoder_step`` of include/nmhip.h."""
+    _fields_ = ([(n, L) for n in ("rows", "emb", "rnn", "attn_state", "ctx_width", "out", "vocab", "src_len",
+                                  "rows_per_key")] +
+                [("cat", P), ("h_copy", P), ("ld_h_copy", L), ("out_state", P), ("ld_out_state", L),
+                 ("attn_weights", P), ("logits", P), ("ld_logits", L), ("stats", P), ("stats_bytes", L)] +
+                [(n, P) for n in ("ru", "rh", "xc", "y", "pre_e", "pre", "ctx")] +
+                [("attn_workspace", P), ("attn_workspace_bytes", L)] +
+                [(n, P) for n in ("wg_t", "bg", "wcx_t", "wch_t", "bc", "wq_t", "bq", "keys", "values", "mask", "v",
+                                  "attn_bias", "wo_h_t", "wo_e_t", "wo_c_t", "bo", "w_vocab")] +
+                [("ld_w_vocab", L), ("b_vocab", P), ("out_act", ctypes.c_int32), ("vocab_trans_b", ctypes.c_int32)])
 
 
 def load():

@@ -219,6 +219,29 @@ def mul(tape: Tape, a: Var, b: Var) -> Var:
     return out
 
 
+def div(tape: Tape, a: Var, b: Var) -> Var:
+    """a / b element-wise."""
+    out = tape.new(tuple(a.shape))
+    ops.ew("div", a.data, b.data, out.data)
+
+    def bwd():
+        if out.grad is None:
+            return
+        if a.needs_grad:
+            ops.ew("div", out.grad, b.data, tape.grad(a), accumulate=True)
+        if b.needs_grad:                                   # d(a/b)/db = -(a/b)/b
+            tmp = tape.buf(tuple(a.shape))
+            ops.ew("mul", out.grad, out.data, tmp)
+            ops.ew("div", tmp, b.data, tmp)
+            ops.ew("scale", tmp, None, tape.grad(b), alpha=-1.0, accumulate=True)
+    tape.record(bwd)
+    return out
+
+
+def add_scalar(tape: Tape, x: Var, alpha: float) -> Var:
+    return _unary(tape, "add_scalar", None, x, alpha=alpha)
+
+
 def blend(tape: Tape, u: Var, h: Var, c: Var) -> Var:
     """u*h + (1-u)*c."""
     out = tape.new(tuple(h.shape))

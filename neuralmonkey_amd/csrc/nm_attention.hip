@@ -68,6 +68,37 @@ static std::pair<hipEvent_t, hipEvent_t>* prof_next_pair() {
     return &g_prof_pool[g_prof_used++];
 }
 
+// Yardstick for the timing above: the same number of bytes read by the simplest possible kernel (16-byte loads,
+// four in flight per lane, 2048 workgroups), timed through the same event pool.
+__global__ __launch_bounds__(256) void stream_read_kernel(const float4* __restrict__ src, long n4, float* __restrict__ sink) {
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    float acc = 0.f;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        acc += (a.x + a.y + a.z + a.w) + (b.x + b.y + b.z + b.w) + (c.x + c.y + c.z + c.w) + (d.x + d.y + d.z + d.w);
+    }
+    for (; i < n4; i += stride) {
+        const float4 a = src[i];
+        acc += a.x + a.y + a.z + a.w;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) sink[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+extern "C" int nm_prof_stream_read(void* stream, const void* src, int64_t bytes, float* sink) {
+    NM_REQUIRE(src && sink && bytes >= 16 && nm_aligned16(src), "nm_prof_stream_read: bad arguments");
+    hipStream_t st = nm_stream(stream);
+    std::pair<hipEvent_t, hipEvent_t>* prof = g_prof_on ? prof_next_pair() : nullptr;
+    if (prof) (void)hipEventRecord(prof->first, st);
+    hipLaunchKernelGGL(stream_read_kernel, dim3(2048), dim3(256), 0, st, (const float4*)src, (long)(bytes / 16), sink);
+    if (prof) (void)hipEventRecord(prof->second, st);
+    NM_LAUNCH_CHECK("nm_prof_stream_read");
+}
+
 struct AttnArgs {
     const float* y;       // [R,A]
     const float* hf;      // [Bk,S,A]
@@ -334,7 +365,7 @@ __global__ __launch_bounds__(256) void attn_partial(AttnArgs p) {
 // y / v slices live in registers (no LDS staging), one __syncthreads, and the
 // chunk softmax is evaluated redundantly per thread instead of serially.
 // ---------------------------------------------------------------------------
-#define ATT_FAST_ROWS 12
+#define ATT_FAST_ROWS 14
 template <int ROWS>
 __global__ __launch_bounds__(256) void attn_partial_fast(AttnArgs p) {
     __shared__ float pe[4][ATT_MAX_SCH];
@@ -769,13 +800,14 @@ static int attn_fwd_impl(void* stream, const float* y, const float* hf, const fl
         else hipLaunchKernelGGL((attn_partial<Q_, 2>), grid, block, shm, st, p);          \
     } while (0)
     std::pair<hipEvent_t, hipEvent_t>* prof = g_prof_on ? prof_next_pair() : nullptr;
-    if (prof) hipEventRecord(prof->first, st);
+    if (prof) (void)hipEventRecord(prof->first, st);
     static const bool no_fast = getenv("NM_ATTN_NOFAST") != nullptr;       // A/B switch for tuning
     if (nq == 1 && A <= 1024 && C <= 1024 && sch <= ATT_FAST_ROWS && !no_fast) {
         p.merge = may_merge;
         if (sch <= 8) hipLaunchKernelGGL(attn_partial_fast<8>, grid, block, 0, st, p);
         else if (sch <= 10) hipLaunchKernelGGL(attn_partial_fast<10>, grid, block, 0, st, p);
-        else hipLaunchKernelGGL(attn_partial_fast<12>, grid, block, 0, st, p);
+        else if (sch <= 12) hipLaunchKernelGGL(attn_partial_fast<12>, grid, block, 0, st, p);
+        else hipLaunchKernelGGL(attn_partial_fast<14>, grid, block, 0, st, p);
     } else if (nq <= 8 && groups == 1 && A <= 1024 && C <= 1024 && sch <= ATT_FAST_ROWS && !no_fast) {
         // a few queries per key batch (beam search): all loads in flight first, queries in registers.  (No
         // in-kernel merge here: one workgroup merging the k rows of a sentence one after the other was measured
@@ -788,7 +820,8 @@ static int attn_fwd_impl(void* stream, const float* y, const float* hf, const fl
             else hipLaunchKernelGGL((attn_partial_fastq<R_, 8>), grid, block, 0, st, p);              \
         } while (0)
         if (sch <= 10) NM_AQ(10);
-        else NM_AQ(12);
+        else if (sch <= 12) NM_AQ(12);
+        else NM_AQ(14);
 #undef NM_AQ
     } else
     switch (qpk) {
@@ -808,7 +841,7 @@ static int attn_fwd_impl(void* stream, const float* y, const float* hf, const fl
         hipLaunchKernelGGL(attn_combine, dim3((unsigned)R), dim3(256), 0, st, p.pctx, p.pstat, p.energies,
                            mask, ctx, (long)ldctx, weights, (int)S, (int)C, nchunk,
                            beam_layout ? (int)nq : 1, (int)Bk);
-    if (prof) hipEventRecord(prof->second, st);
+    if (prof) (void)hipEventRecord(prof->second, st);
     NM_LAUNCH_CHECK("nm_attn_fwd");
 }
 

@@ -29,7 +29,8 @@ enum {
     NM_EW_LOGADDEXP = 11,   // log(exp(a) + exp(b))   (ensemble mean of probabilities in log space)
     NM_EW_ADD_SCALAR = 12,  // a + alpha
     NM_EW_ROWSCALE = 13,    // a[r,c] * b[r,0]        (a per-row scalar: attention weight of a single vector)
-    NM_EW_OPS = 14
+    NM_EW_DIV = 14,         // a / b                  (coverage / fertility, attention/coverage.py:57)
+    NM_EW_OPS = 15
 };
 
 template <int OP>
@@ -51,6 +52,7 @@ __device__ __forceinline__ float ew_apply(float a, float b, float alpha) {
     }
     if (OP == NM_EW_ADD_SCALAR) return a + alpha;
     if (OP == NM_EW_ROWSCALE) return a * b;
+    if (OP == NM_EW_DIV) return a / b;
     return 0.0f;
 }
 
@@ -112,7 +114,7 @@ extern "C" int nm_ew(void* stream, int op, const float* a, int64_t lda, const fl
                      int64_t ldo, int64_t rows, int64_t cols, float alpha, int accumulate) {
     NM_REQUIRE(op >= 0 && op < NM_EW_OPS, "nm_ew: unknown op %d", op);
     NM_REQUIRE(a && out && rows >= 0 && cols >= 0 && cols < (1LL << 31), "nm_ew: bad args");
-    const bool binary = op == NM_EW_ADD || op == NM_EW_SUB || op == NM_EW_MUL || op == NM_EW_ROWSCALE ||
+    const bool binary = op == NM_EW_ADD || op == NM_EW_SUB || op == NM_EW_MUL || op == NM_EW_ROWSCALE || op == NM_EW_DIV ||
                         (op >= NM_EW_SIGMOID_BWD && op <= NM_EW_LOGADDEXP);
     NM_REQUIRE(!binary || b, "nm_ew: op %d needs a second operand", op);
     if (rows == 0 || cols == 0) return NM_OK;
@@ -134,6 +136,7 @@ extern "C" int nm_ew(void* stream, int op, const float* a, int64_t lda, const fl
         NM_EW_CASE(NM_EW_LOGADDEXP, true)
         NM_EW_CASE(NM_EW_ADD_SCALAR, false)
         NM_EW_CASE(NM_EW_ROWSCALE, true)
+        NM_EW_CASE(NM_EW_DIV, true)
         default: break;
     }
 #undef NM_EW_CASE

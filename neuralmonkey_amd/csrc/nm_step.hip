@@ -317,3 +317,94 @@ extern "C" int nm_step_group(void* stream, int64_t M, const nm_step_problem* pro
     else hipLaunchKernelGGL((step_group_kernel<16, 1, 0>), dim3(grid), dim3(1024), 0, st, g);
     NM_LAUNCH_CHECK("nm_step_group");
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// The whole step behind ONE call: Decoder.next_state (decoders/decoder.py:279-358, plain GRUCell, one Bahdanau
+// attention, nonlinear output projection) followed by the vocabulary projection of get_body
+// (decoders/autoregressive.py:450-459).  Host sequencing only -- the seven launches are the ones documented at
+// the top of this file; a caller that replays the step (HIP graph) captures this call.
+extern "C" int nm_attn_fwd(void* stream, const float* y, const float* hf, const float* states, const float* mask,
+                           const float* v, const float* bias, int64_t R, int64_t rows_per_key, int64_t S, int64_t A,
+                           int64_t C, float* ctx, int64_t ldctx, float* weights, void* workspace,
+                           int64_t workspace_bytes, float* energies_out);
+extern "C" int nm_logits_stats_gemm(void* stream, int transB, int64_t M, int64_t N, int64_t K, const float* A,
+                                    int64_t lda, const float* B, int64_t ldb, const float* bias, float* C, int64_t ldc,
+                                    float* stats, int64_t stats_bytes);
+extern "C" int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A,
+                           int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int act,
+                           int accumulate, int64_t batch, int64_t strideA, int64_t strideB, int64_t strideC, int algo,
+                           void* workspace, int64_t workspace_bytes);
+
+struct nm_decoder_step {          // mirrors include/nmhip.h
+    int64_t rows, emb, rnn, attn_state, ctx_width, out, vocab, src_len, rows_per_key;
+    float* cat;
+    float* h_copy; int64_t ld_h_copy;
+    float* out_state; int64_t ld_out_state;
+    float* attn_weights;
+    float* logits; int64_t ld_logits;
+    float* stats; int64_t stats_bytes;
+    float* ru; float* rh; float* xc; float* y; float* pre_e; float* pre; float* ctx;
+    void* attn_workspace; int64_t attn_workspace_bytes;
+    const float* wg_t; const float* bg; const float* wcx_t; const float* wch_t; const float* bc;
+    const float* wq_t; const float* bq; const float* keys; const float* values; const float* mask;
+    const float* v; const float* attn_bias;
+    const float* wo_h_t; const float* wo_e_t; const float* wo_c_t; const float* bo;
+    const float* w_vocab; int64_t ld_w_vocab; const float* b_vocab;
+    int32_t out_act, vocab_trans_b;
+};
+
+extern "C" int nm_decoder_step_fused(void* stream, const nm_decoder_step* d) {
+    NM_REQUIRE(d, "nm_decoder_step_fused: null descriptor");
+    const int64_t M = d->rows, E = d->emb, H = d->rnn, A = d->attn_state, C = d->ctx_width, O = d->out;
+    NM_REQUIRE(M > 0 && E > 0 && H > 0 && A > 0 && C > 0 && O > 0 && d->vocab > 0 && d->src_len > 0 &&
+               d->rows_per_key >= 1 && M % d->rows_per_key == 0, "nm_decoder_step_fused: bad sizes");
+    NM_REQUIRE(E % 16 == 0 && H % 16 == 0 && C % 16 == 0, "nm_decoder_step_fused: emb, rnn and context widths must be "
+               "multiples of 16 (the K of the step GEMMs)");
+    NM_REQUIRE(d->cat && d->out_state && d->ru && d->rh && d->xc && d->y && d->pre_e && d->pre && d->ctx &&
+               d->attn_workspace, "nm_decoder_step_fused: null step buffer");
+    NM_REQUIRE(d->wg_t && d->bg && d->wcx_t && d->wch_t && d->bc && d->wq_t && d->keys && d->values && d->v &&
+               d->wo_h_t && d->wo_e_t && d->wo_c_t && d->w_vocab, "nm_decoder_step_fused: null parameter");
+    NM_REQUIRE(d->logits || d->stats, "nm_decoder_step_fused: neither logits nor tile statistics requested");
+    const int64_t ld = E + H;
+    float* h = d->cat + E;                       // the state half of the input row
+    nm_step_problem p[3];
+    int rc;
+    // group 1: gates over [emb | h]; the two products that only need the embedded input
+    memset(p, 0, sizeof(p));
+    p[0].A = d->cat; p[0].lda = ld; p[0].Bt = d->wg_t; p[0].ldb = ld; p[0].N = 2 * H; p[0].K = ld; p[0].epilogue = 1;
+    p[0].bias = d->bg; p[0].h = h; p[0].ldh = ld; p[0].ru = d->ru; p[0].rh = d->rh;
+    p[1].A = d->cat; p[1].lda = ld; p[1].Bt = d->wcx_t; p[1].ldb = E; p[1].N = H; p[1].K = E; p[1].bias = d->bc;
+    p[1].C = d->xc; p[1].ldc = H;
+    p[2].A = d->cat; p[2].lda = ld; p[2].Bt = d->wo_e_t; p[2].ldb = E; p[2].N = O; p[2].K = E;
+    p[2].C = d->pre_e; p[2].ldc = O;
+    if ((rc = nm_step_group(stream, M, p, 3)) != 0) return rc;
+    // group 2: candidate + blend, h' in place (and into the caller's history row)
+    memset(p, 0, sizeof(p));
+    p[0].A = d->rh; p[0].lda = H; p[0].Bt = d->wch_t; p[0].ldb = H; p[0].N = H; p[0].K = H; p[0].epilogue = 2;
+    p[0].xc = d->xc; p[0].ldxc = H; p[0].ru = d->ru; p[0].h = h; p[0].ldh = ld; p[0].h_out = h; p[0].ldho = ld;
+    p[0].h_out2 = d->h_copy; p[0].ldho2 = d->h_copy ? d->ld_h_copy : 0;
+    if ((rc = nm_step_group(stream, M, p, 1)) != 0) return rc;
+    // group 3: attention query; the state part of the output projection
+    memset(p, 0, sizeof(p));
+    p[0].A = h; p[0].lda = ld; p[0].Bt = d->wq_t; p[0].ldb = H; p[0].N = A; p[0].K = H; p[0].bias = d->bq;
+    p[0].C = d->y; p[0].ldc = A;
+    p[1].A = h; p[1].lda = ld; p[1].Bt = d->wo_h_t; p[1].ldb = H; p[1].N = O; p[1].K = H; p[1].bias = d->bo;
+    p[1].add = d->pre_e; p[1].ldadd = O; p[1].C = d->pre; p[1].ldc = O;
+    if ((rc = nm_step_group(stream, M, p, 2)) != 0) return rc;
+    // attention: one launch
+    if ((rc = nm_attn_fwd(stream, d->y, d->keys, d->values, d->mask, d->v, d->attn_bias, M, d->rows_per_key,
+                          d->src_len, A, C, d->ctx, C, d->attn_weights, d->attn_workspace, d->attn_workspace_bytes,
+                          nullptr)) != 0) return rc;
+    // group 4: the context part of the output projection + activation
+    memset(p, 0, sizeof(p));
+    p[0].A = d->ctx; p[0].lda = C; p[0].Bt = d->wo_c_t; p[0].ldb = C; p[0].N = O; p[0].K = C; p[0].act = d->out_act;
+    p[0].add = d->pre; p[0].ldadd = O; p[0].C = d->out_state; p[0].ldc = d->ld_out_state;
+    if ((rc = nm_step_group(stream, M, p, 1)) != 0) return rc;
+    // vocabulary projection
+    if (d->stats)
+        return nm_logits_stats_gemm(stream, d->vocab_trans_b, M, d->vocab, O, d->out_state, d->ld_out_state, d->w_vocab,
+                                    d->ld_w_vocab, d->b_vocab, d->logits, d->logits ? d->ld_logits : 0, d->stats,
+                                    d->stats_bytes);
+    return nm_gemm_f32(stream, 0, d->vocab_trans_b, M, d->vocab, O, d->out_state, d->ld_out_state, d->w_vocab,
+                       d->ld_w_vocab, d->logits, d->ld_logits, d->b_vocab, 0, 0, 1, 0, 0, 0, 0, nullptr, 0);
+}

@@ -14,6 +14,7 @@ step buffers are recycled).  The context vectors feed the recurrence in most of 
 configurations, so nothing is hoisted out of the time loop except the embedding gather and the
 vocabulary projection + cross entropy.
 """
+import os
 from typing import List, Optional
 
 import torch
@@ -350,6 +351,9 @@ class GeneralStepper:
         for var, sel in zip(self.state, self.sel):
             ops.gather_rows(var.data, src_rows, sel)
         self.state = [self.tape.leaf(sel) for sel in self.sel]
+        for sess in self.sessions:                        # per-hypothesis attention state (coverage)
+            if hasattr(sess, "reorder"):
+                sess.reorder(src_rows)
 
 
 class FusedStepper:
@@ -426,6 +430,22 @@ class FusedStepper:
                  act=1 if proj.activation == "tanh" else 0, add=self.pre, ldadd=o, C=self.pre, ldc=o)])
         att.hidden_features(ctx)
         self._pending, self._cur = None, 0
+        # the same step behind the single C entry (nm_decoder_step_fused): descriptor built once, per-step
+        # pointers patched in step()
+        tied = dec.tie_embeddings
+        wv = dec.embedding_matrix(ctx) if tied else dec.var(ctx, "state_to_word_W")
+        self.whole = ops.DecoderStepCall(dict(
+            rows=rows, emb=e, rnn=h, attn_state=a, ctx_width=c, out=o, vocab=wv.shape[0] if tied else wv.shape[1],
+            src_len=att.attention_states(ctx).shape[1], rows_per_key=rpk, cat=self.cat,
+            ru=self.ru, rh=self.rh, xc=self.xc, y=self.y, pre_e=self.pre_e, pre=self.pre, ctx=self.ctxbuf,
+            attn_workspace=plan["ws"], attn_workspace_bytes=plan["ws"].numel() * 4,
+            wg_t=self.wg_t, bg=bg, wcx_t=self.wcx_t, wch_t=self.wch_t, bc=bc, wq_t=self.wq_t,
+            bq=att.var(ctx, "attn_projection_bias"), keys=att.hidden_features(ctx), values=att.attention_states(ctx),
+            mask=att.attention_mask(ctx), v=att.var(ctx, "attn_similarity_v"), attn_bias=att.var(ctx, "attn_bias"),
+            wo_h_t=self.wo_h_t, wo_e_t=self.wo_e_t, wo_c_t=self.wo_c_t, bo=proj.bias(ctx, dec),
+            out_act=1 if proj.activation == "tanh" else 0, w_vocab=wv, ld_w_vocab=wv.stride(0),
+            b_vocab=dec.decoding_bias(ctx), vocab_trans_b=int(tied)))
+        self.single_call = not os.environ.get("NM_STEP_GROUPS")
 
     def start(self, s0: torch.Tensor) -> None:
         self._pending, self._cur = s0, 0
@@ -445,6 +465,12 @@ class FusedStepper:
             self._cur ^= 1
             h_out = self.hbuf[self._cur]
         st = att_states[0]
+        if self.single_call:
+            self.whole.launch(h_copy=h_out, ld_h_copy=h_out.stride(0), out_state=out_state,
+                              ld_out_state=out_state.stride(0), attn_weights=st.weights[st.step], logits=logits,
+                              ld_logits=logits.stride(0) if logits is not None else 0, stats=stats,
+                              stats_bytes=stats.numel() * 4 if stats is not None else 0)
+            return [AttentionLoopState(st.contexts, st.weights, st.step + 1)]
         self.g1.launch()
         self.g2.patch(0, h_out2=h_out, ldho2=h_out.stride(0) if h_out is not None else 0)
         self.g2.launch()

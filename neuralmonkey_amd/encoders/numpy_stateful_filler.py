@@ -92,7 +92,7 @@ class SpatialFiller(ModelPart, SpatialStatefulWithOutput):
         bsz, h, w, d = x.shape
         s = h * w
         train = bool(ctx.fed(self.train_mode))
-        tape = F.Tape(ctx, (id(self), "filler"), recording=train and bool(self._layers()))
+        tape = F.Tape(ctx, (id(self), "filler"), recording=ctx.wants_backward(train) and bool(self._layers()))
         cur = tape.leaf(x.reshape(bsz * s, d))
         for scope, _, _, use_relu in self._layers():
             cur = F.linear(tape, cur, tape.param(self, scope + "/kernel"), tape.param(self, scope + "/bias"))

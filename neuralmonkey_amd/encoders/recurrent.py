@@ -179,7 +179,7 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
         wgh = dir_batch("off_g", 2 * h)
         wch = dir_batch("off_c", h)
 
-        train = bool(ctx.fed(self.train_mode))
+        train = ctx.wants_backward(bool(ctx.fed(self.train_mode)))
         states_raw = ctx.buffer((key, "states_raw"), (bsz, slen, c_out), zero=True)
         hcur = ctx.buffer((key, "hcur"), (ndir, bsz, h), zero=True)
         hg = ctx.buffer((key, "hg"), (ndir, bsz, 2 * h))
@@ -360,7 +360,7 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
         """RecurrentEncoder.rnn (recurrent.py:179-217) on the autodiff tape."""
         train = bool(ctx.fed(self.train_mode))
         keep = self.dropout_keep_prob
-        tape = F.Tape(ctx, (id(self), "genc"), recording=train)
+        tape = F.Tape(ctx, (id(self), "genc"), recording=ctx.wants_backward(train))
         x_raw = self.input_sequence.temporal_states(ctx)
         lengths = self.input_sequence.lengths(ctx)
         bsz, slen, e = x_raw.shape

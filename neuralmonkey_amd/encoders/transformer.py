@@ -120,7 +120,7 @@ class TransformerEncoder(ModelPart, TemporalStatefulWithOutput):
         x_raw = self.input_sequence.temporal_states(ctx)                     # [B,S,D]
         mask = self.input_sequence.temporal_mask(ctx)                        # [B,S] float
         bsz, slen, d = x_raw.shape
-        tape = F.Tape(ctx, (id(self), "tenc"), recording=train)
+        tape = F.Tape(ctx, (id(self), "tenc"), recording=ctx.wants_backward(train))
         x_in = tape.leaf(x_raw.reshape(bsz * slen, d), needs_grad=True)
         x = x_in
         if self.target_space_id is not None:                                  # :202-203

@@ -355,6 +355,29 @@ class StepGroup:
         _lib.check(self._fn(_stream(), self.rows, self.arr, len(self.arr)), "nm_step_group")
 
 
+class DecoderStepCall:
+    """``nm_decoder_step_fused``: the descriptor of a whole decoder step, built once from persistent buffers;
+    ``launch`` patches the per-step pointers (history rows, outputs) and makes the one call."""
+
+    def __init__(self, fields):
+        lib = _lib.load()
+        self.keep = {}
+        self.desc = _lib.DecoderStep()
+        self._set(fields)
+        self._fn = lib.nm_decoder_step_fused
+
+    def _set(self, fields):
+        for name, val in fields.items():
+            if isinstance(val, torch.Tensor):
+                self.keep[name] = val
+                val = val.data_ptr()
+            setattr(self.desc, name, val or 0)
+
+    def launch(self, **fields):
+        self._set(fields)
+        _lib.check(self._fn(_stream(), ctypes.byref(self.desc)), "nm_decoder_step_fused")
+
+
 def gather_rows(src, idx, dst):
     lib = _lib.load()
     assert src.dim() == 2 and dst.dim() == 2 and src.stride(1) == 1 and dst.stride(1) == 1
@@ -482,7 +505,7 @@ def attn_energy_bwd(de, hf, y, v, dhf, dv_partial, dy, accumulate=False):
 
 # ---- strided element-wise primitives (general / taped path) -------------------------------------
 EW = {"copy": 0, "add": 1, "sub": 2, "mul": 3, "scale": 4, "sigmoid": 5, "tanh": 6, "relu": 7,
-      "sigmoid_bwd": 8, "tanh_bwd": 9, "relu_bwd": 10, "logaddexp": 11, "add_scalar": 12, "rowscale": 13}
+      "sigmoid_bwd": 8, "tanh_bwd": 9, "relu_bwd": 10, "logaddexp": 11, "add_scalar": 12, "rowscale": 13, "div": 14}
 
 
 def _rc(t):

@@ -103,6 +103,12 @@ class RunContext:
     def is_fed(self, placeholder: Placeholder) -> bool:
         return placeholder in self.feed
 
+    def wants_backward(self, train_mode: bool) -> bool:
+        """Must a forward pass keep what its backward pass reads?  Yes in training mode, and whenever a trainer
+        runs this context -- the reference's train_op differentiates whatever ``train_mode`` is fed (the
+        placeholder only switches dropout, model/model_part.py)."""
+        return bool(train_mode) or bool(self.memo.get("want_backward", False))
+
     def buffer(self, key, shape, dtype=torch.float32, zero=False, zero_init=False):
         """Persistent scratch buffer owned by the session (no per-step malloc).  ``zero``: cleared on every
         request; ``zero_init``: cleared when it is created only (state the kernels themselves keep at zero)."""

@@ -100,6 +100,7 @@ class GenericTrainer(GraphExecutor, Feedable):
         from ..runtime import RunContext
         ctx = RunContext(outer.session, outer.feed)
         ctx.memo["dp_overlap"] = bool(outer.memo.get("dp_overlap", False))
+        ctx.memo["want_backward"] = True     # encoders keep their per-step state even when train_mode is fed False
         sess, store = ctx.session, ctx.store
         grad = store.ensure_grad()
         grad.zero_()

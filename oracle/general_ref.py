@@ -388,6 +388,9 @@ class GeneralModel:
     def context_size(self, st) -> int:
         return st.shape[-1]
 
+    def reorder_attention(self, src) -> None:
+        """Hook for attentions that carry per-hypothesis state through a beam search (oracle/coverage_ref.py)."""
+
     def repeat_sources(self, st, hf, mask, rep: int):
         """expand_to_beam (beam_search_decoder.py:575-596): row order b*k + j."""
         return tuple(x.repeat_interleave(rep, 0) for x in (st, hf, mask))
@@ -458,6 +461,7 @@ class GeneralModel:
                 finished = finished[bidx, beam] | (word == END)
                 src = (bidx * k + beam).reshape(-1)
                 state = [s[src] for s in state]
+                self.reorder_attention(src)
                 out, state, _ = self.decoder_step(table[word.reshape(-1)], state, st, hf, mask, False, step)
                 prev_lp = torch.log_softmax(self.logits(out), -1).view(bsz, k, vsz)
                 token_ids = torch.cat([token_ids[:, bidx, beam], word.unsqueeze(0)], 0)

@@ -354,6 +354,9 @@ def test_gru_gemm_fused_epilogues_fwd_bwd(dev, b, s, e, h):
     (1, 5, 50, 1024, 1024, True),        # reference-compatible batch-1 beam
     (3, 3, 7, 64, 32, True),             # single chunk, tiny dims
     (5, 1, 64, 128, 2048, False),        # captioning shape: S=64, C=2048, state_size 128
+    (4, 1, 120, 256, 256, True),         # long sources: 10 chunks -> too many for the in-kernel merge, combine launch
+    (2, 5, 200, 128, 128, True),         # 17 chunks, five queries per sentence
+    (6, 1, 96, 512, 1024, True),         # 8 chunks: the most the in-kernel merge takes
     (2, 8, 13, 512, 1024, True),
     (2, 2, 100, 256, 512, True),
     (2, 3, 50, 256, 256, True),          # beam widths that run a wider register instance (3 -> 4, 6 / 7 -> 8)

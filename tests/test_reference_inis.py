@@ -79,3 +79,19 @@ def test_reference_ini_builds_from_the_reference_tree(name):
         pytest.skip("no reference tree on this machine")
     model = load_verbatim(REF, name, initialize=False, device="cpu")
     assert model.trainers and model.runners
+
+
+def test_coverage_attention_is_a_drop_in_section(ref_root):
+    """tests/bahdanau.ini with its [attention] section switched to attention.CoverageAttention
+    (attention/coverage.py:19-36: same arguments plus max_fertility) builds like the original."""
+    from neuralmonkey_amd.attention import CoverageAttention
+    src = os.path.join(ref_root, "tests", "bahdanau.ini")
+    with open(src) as fh:
+        text = fh.read()
+    assert "class=attention.Attention" in text
+    with open(os.path.join(ref_root, "tests", "bahdanau_coverage.ini"), "w") as fh:
+        fh.write(text.replace("class=attention.Attention", "class=attention.CoverageAttention\nmax_fertility=4"))
+    model = load_verbatim(ref_root, "bahdanau_coverage", initialize=False, device="cpu")
+    atts = model.runners[0].decoder.attentions
+    assert atts and isinstance(atts[0], CoverageAttention) and atts[0].max_fertility == 4
+    assert atts[0].name == "attention_sentence_encoder"

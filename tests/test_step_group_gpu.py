@@ -182,3 +182,69 @@ def test_fused_stepper_equals_the_six_gemm_stepper(dev):
     assert tf_.shape == tp.shape and (tf_ == tp).mean() > 0.98          # near-ties may flip between roundings
     sf, sp = (np.asarray(x["bs"].last_search_step_output.scores) for x in (fused, plain))
     assert np.abs(sf - sp).max() < 1e-4 * np.abs(sp).max()
+
+
+@pytest.mark.parametrize("bk,qpk,s,e,h,a,c,o,v,with_stats", [
+    (128, 1, 50, 512, 512, 1024, 1024, 512, 32000, True),       # the headline greedy step
+    (16, 5, 50, 512, 512, 1024, 1024, 512, 32000, True),        # beam rows share the keys of their sentence
+    (7, 1, 13, 32, 48, 64, 96, 40, 516, False),                 # ragged, plain logits GEMM
+    (3, 2, 9, 16, 16, 32, 32, 16, 260, True)])
+def test_decoder_step_fused_is_the_oracle_step(dev, bk, qpk, s, e, h, a, c, o, v, with_stats):
+    """nm_decoder_step_fused through the C-ABI == O.decoder_step + O.state_to_logits (decoders/decoder.py:279-358,
+    autoregressive.py:450-459) in float64: new state (in place and copy), attention distribution, projected
+    output, logits, and -- with statistics -- the arg max of every row."""
+    from neuralmonkey_amd import _lib, ops
+    lib = _lib.load()
+    rng = np.random.default_rng(bk * 131 + s)
+    rows = bk * qpk
+    f = lambda *shape, sc=0.05: (rng.standard_normal(shape) * sc).astype(np.float32)
+    cellp = {"gates_kernel": f(e + h, 2 * h), "gates_bias": np.ones(2 * h, np.float32),
+             "cand_kernel": f(e + h, h), "cand_bias": f(h, sc=0.1)}
+    attp = {"query_w": f(h, a), "query_b": f(a, sc=0.1), "v": f(a), "bias": f(1)[0]}
+    out_w, out_b = f(h + e + c, o), f(o, sc=0.1)
+    logit_w, logit_b = f(o, v), f(v, sc=0.5)
+    emb, h0 = f(rows, e, sc=1.0), f(rows, h, sc=1.0)
+    keys, vals = f(bk, s, a, sc=1.0), f(bk, s, c, sc=1.0)
+    mask = (np.arange(s)[None, :] < rng.integers(1, s + 1, bk)[:, None]).astype(np.float32)
+    d64 = lambda x: {k: np.asarray(w, np.float64) for k, w in x.items()}
+    dp = {"cell": d64(cellp), "att": d64(attp), "out_w": out_w.astype(np.float64), "out_b": out_b.astype(np.float64),
+          "logit_w": logit_w.astype(np.float64), "logit_b": logit_b.astype(np.float64)}
+    rep = lambda x: np.repeat(x, qpk, axis=0).astype(np.float64)
+    r_out, r_h, _, r_w = O.decoder_step(dp, O.DecoderSpec(), emb.astype(np.float64), h0.astype(np.float64),
+                                        rep(keys), rep(vals), rep(mask))
+    r_logits = O.state_to_logits(dp, O.DecoderSpec(), r_out)
+
+    cat = T(np.concatenate([emb, h0], 1), dev)
+    z = lambda *shape: torch.full(shape, float("nan"), device=dev)
+    h_copy, out_state, w_out, logits = z(rows, h), z(rows, o), z(rows, s), z(rows, v)
+    stats = torch.empty(lib.nm_logits_stats_bytes(rows, v) // 4, device=dev) if with_stats else None
+    ws = ops.attn_workspace(rows, s, c, dev)
+    call = ops.DecoderStepCall(dict(
+        rows=rows, emb=e, rnn=h, attn_state=a, ctx_width=c, out=o, vocab=v, src_len=s, rows_per_key=qpk, cat=cat,
+        ru=z(rows, 2 * h), rh=z(rows, h), xc=z(rows, h), y=z(rows, a), pre_e=z(rows, o), pre=z(rows, o), ctx=z(rows, c),
+        attn_workspace=ws, attn_workspace_bytes=ws.numel() * 4,
+        wg_t=T(cellp["gates_kernel"].T, dev), bg=T(cellp["gates_bias"], dev), wcx_t=T(cellp["cand_kernel"][:e].T, dev),
+        wch_t=T(cellp["cand_kernel"][e:].T, dev), bc=T(cellp["cand_bias"], dev), wq_t=T(attp["query_w"].T, dev),
+        bq=T(attp["query_b"], dev), keys=T(keys, dev), values=T(vals, dev), mask=T(mask, dev), v=T(attp["v"], dev),
+        attn_bias=T(np.asarray([attp["bias"]]), dev), wo_h_t=T(out_w[:h].T, dev), wo_e_t=T(out_w[h:h + e].T, dev),
+        wo_c_t=T(out_w[h + e:].T, dev), bo=T(out_b, dev), out_act=1, w_vocab=T(logit_w, dev), ld_w_vocab=v,
+        b_vocab=T(logit_b, dev), vocab_trans_b=0))
+    for _ in range(2):                                   # twice: the arrival counters of the workspace are left at zero
+        cat[:, e:] = T(h0, dev)
+        call.launch(h_copy=h_copy, ld_h_copy=h, out_state=out_state, ld_out_state=o, attn_weights=w_out, logits=logits,
+                    ld_logits=v, stats=stats, stats_bytes=stats.numel() * 4 if with_stats else 0)
+        torch.cuda.synchronize()
+        assert rel(h_copy.cpu().numpy(), r_h) < RTOL
+        assert torch.equal(cat[:, e:], h_copy) and np.array_equal(cat[:, :e].cpu().numpy(), emb)
+        assert np.abs(w_out.cpu().numpy() - r_w).max() < 1e-5
+        assert rel(out_state.cpu().numpy(), r_out) < RTOL
+        assert rel(logits.cpu().numpy(), r_logits) < RTOL
+    if with_stats:
+        sym, fin = torch.zeros(rows, dtype=torch.int32, device=dev), torch.zeros(rows, dtype=torch.int32, device=dev)
+        arg = torch.zeros(rows, dtype=torch.int32, device=dev)
+        ops.greedy_finish(stats, v, fin, sym, None, 2, argmax_out=arg)
+        got = logits.cpu().numpy()
+        assert np.array_equal(arg.cpu().numpy(), got.argmax(1))          # first maximum of the fp32 logits it wrote
+    # a descriptor without any output for the projection is refused, not ignored
+    with pytest.raises(_lib.NMHipError):
+        call.launch(logits=None, stats=None, stats_bytes=0)

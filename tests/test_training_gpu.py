@@ -202,3 +202,20 @@ def test_checkpoint_carries_optimizer_state_and_global_step(dev, tmp_path, fmt, 
     step(c, batches[3])
     worst = max(float(np.abs(c.tf_manager.sessions[0].store.state_dict()[n] - after_one[n]).max()) for n in after_one)
     assert worst > 1e-5
+
+
+def test_train_op_differentiates_with_train_mode_fed_false(dev):
+    """The reference's train_op differentiates whatever ``train_mode`` is fed (the placeholder only switches
+    dropout, model/model_part.py): a trainer run with train=False yields the gradients of a train=True run of
+    the same dropout-free model, not a crash on forward state that was never kept."""
+    model, _, ds, _, _ = _build(dev, 64, 12, 12, 5, 7, 6, True)
+    store = model.tf_manager.sessions[0].store
+    theta0 = store.theta.clone()
+    res_t = model.tf_manager.execute(ds, model.trainer.feedables, [model.trainer], train=True)[0]
+    g_t = store.ensure_grad().clone()
+    store.theta.copy_(theta0)
+    res_f = model.tf_manager.execute(ds, model.trainer.feedables, [model.trainer], train=False)[0]
+    g_f = store.ensure_grad().clone()
+    assert res_f.losses["decoder - cost"] == pytest.approx(res_t.losses["decoder - cost"], rel=1e-6)
+    assert float((g_t - g_f).abs().max()) <= 1e-6 * float(g_t.abs().max())
+    assert float(g_t.abs().max()) > 0

@@ -30,11 +30,35 @@ ws = ops.attn_workspace(r, S, C, dev)
 # counters see HBM traffic
 flush = torch.zeros(256 << 20, device=dev)
 sink = torch.zeros(1, device=dev)
-for i in range(iters):
-    if mode == "dirty":
-        flush.fill_(float(i))
-    elif mode == "cold":
-        sink.add_(flush.sum())
-    ops.attn_fwd(y, hf, st, mask, v, bias, qpk, ctx, w, ws)
-torch.cuda.synchronize()
-print("done", float(ctx.sum()))
+import ctypes  # noqa: E402
+
+from neuralmonkey_amd import _lib  # noqa: E402
+
+lib = _lib.load()
+
+
+def run(n):
+    for i in range(n):
+        if mode == "dirty":
+            flush.fill_(float(i))
+        elif mode == "cold":
+            sink.add_(flush.sum())
+        ops.attn_fwd(y, hf, st, mask, v, bias, qpk, ctx, w, ws)
+    torch.cuda.synchronize()
+
+
+run(3)
+lib.nm_prof_enable(1)
+run(iters)
+lib.nm_prof_enable(0)
+tot, cnt = ctypes.c_double(0.0), ctypes.c_int64(0)
+lib.nm_prof_attn_step(ctypes.byref(tot), ctypes.byref(cnt))
+# reference of the same step in float64 (feed_forward.py:120-166)
+yd, hfd, std = y.double(), hf.double(), st.double()
+e = (v.double() * torch.tanh(hfd.repeat_interleave(qpk, 0) + yd[:, None, :])).sum(-1)
+wr = torch.softmax(e, -1) * mask.double().repeat_interleave(qpk, 0)
+wr = wr / (wr.sum(1, keepdim=True) + 1e-8)
+cr = (wr[:, :, None] * std.repeat_interleave(qpk, 0)).sum(1)
+err = float((ctx.double() - cr).abs().max() / cr.abs().max())
+print("NM_ATTN_MAXROWS={} mode={} qpk={}: {:.2f} us/launch (HIP events, {} launches)  rel err {:.1e}".format(
+    os.environ.get("NM_ATTN_MAXROWS", "-"), mode, qpk, tot.value * 1e3 / max(cnt.value, 1), cnt.value, err))
