@@ -357,12 +357,13 @@ def main():
             "ms_per_step_fresh": fresh_ms, "ms_per_step_strings": strings_ms,
             "beam5_decode_tok_s": beam_tok_s, "beam5_ms_per_batch": beam_ms_per_batch,
             "greedy_decode_tok_s": tokens_local / (greedy_ms * 1e-3), "greedy_ms_per_batch": greedy_ms,
-            "roofline": {"kernel": "nm_attn_fwd = attn_partial_fast, ONE launch (fused Bahdanau score + softmax + "
-                                   "mask-renorm + context of one decoding step; the split-S partials are merged by "
-                                   "the last-arriving chunk workgroup of every sentence, no combine launch)",
+            "roofline": {"kernel": "nm_attn_fwd = attn_whole_fast<13>, ONE launch (fused Bahdanau score + softmax + "
+                                   "mask-renorm + context of one decoding step; one 1024-thread workgroup per sentence: "
+                                   "no split-S partials, no merge; smaller batches / longer sources take the split-S "
+                                   "kernel with its in-kernel merge)",
                          "timing": "HIP events on the launch stream around every nm_attn_fwd call: includes the "
                                    "dispatch latency of the launch (~3 us); rocprofv3 kernel durations of the same "
-                                   "modes are in profiles/r02_attn_step_trace_{warm,cold,dirty}_v2.json",
+                                   "modes are in profiles/r02_attn_step_trace_{cold,warm,dirty}_v3.json",
                          "bound": "hbm", "achieved": cold, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (cold / HBM_PEAK_GBPS) if cold else None, "traffic": traffic,
                          "traffic_kernels": pmc_kernels,

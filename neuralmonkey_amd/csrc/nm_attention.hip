@@ -441,6 +441,89 @@ __global__ __launch_bounds__(256) void attn_partial_fast(AttnArgs p) {
 }
 
 // ---------------------------------------------------------------------------
+// One query per sentence, short sources (S <= 4 * ATT_WHOLE_ROWS): ONE 1024-thread workgroup per sentence does
+// the whole step -- no split-S partials, no cross-workgroup hand-off, no merge.  16 waves = 4 row groups x 4
+// column waves: every lane requests its 16-byte slice of the keys AND values of its group's rows up front (all
+// of the sentence's 300 KB in flight at once), the energies of the 4 column waves meet in LDS, wave 0 evaluates
+// softmax -> mask -> renormalise (+1e-8) with one source position per lane, the 4 row groups' partial contexts
+// meet in LDS.  Half the CUs stay idle at 128 sentences, but the launch no longer ends with write-through
+// stores + a ticket + a second pass over the partials by the last-arriving workgroup.
+// ---------------------------------------------------------------------------
+#define ATT_WHOLE_ROWS 13
+template <int ROWS>
+__global__ __launch_bounds__(1024) void attn_whole_fast(AttnArgs p) {
+    __shared__ float pe[4][4 * ROWS];          // [column wave][row group * ROWS + row]
+    __shared__ float wsh[4 * ROWS];            // normalised weights, same indexing
+    __shared__ float4 red[3][256];             // partial contexts of row groups 1..3
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = wave >> 2, cw = wave & 3;
+    const int b = blockIdx.x;
+    const int rpg = (p.S + 3) >> 2;            // rows per row group
+    const int s0 = grp * rpg;
+    const int ns = max(0, min(rpg, p.S - s0));
+    const int col = cw * 256 + lane * 4;
+    const bool a_ok = col < p.A, c_ok = col < p.C;
+    const float* hbase = p.hf + (long)b * p.S * p.A + (a_ok ? col : 0);
+    const float* sbase = p.states + (long)b * p.S * p.C + (c_ok ? col : 0);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    float4 hfr[ROWS], str[ROWS];
+#pragma unroll
+    for (int s = 0; s < ROWS; ++s)            // clamped rows are weighted by zero below
+        hfr[s] = *reinterpret_cast<const float4*>(hbase + (long)min(s0 + min(s, max(ns - 1, 0)), p.S - 1) * p.A);
+#pragma unroll
+    for (int s = 0; s < ROWS; ++s)
+        str[s] = *reinterpret_cast<const float4*>(sbase + (long)min(s0 + min(s, max(ns - 1, 0)), p.S - 1) * p.C);
+    const float4 y4 = *reinterpret_cast<const float4*>(p.y + (long)b * p.A + (a_ok ? col : 0));
+    float4 v4 = *reinterpret_cast<const float4*>(p.v + (a_ok ? col : 0));
+    if (!a_ok) v4 = zero4;
+    const float bias = p.bias ? p.bias[0] : 0.0f;
+
+#pragma unroll
+    for (int s = 0; s < ROWS; ++s) {
+        float part = v4.x * nm_tanh(hfr[s].x + y4.x) + v4.y * nm_tanh(hfr[s].y + y4.y) +
+                     v4.z * nm_tanh(hfr[s].z + y4.z) + v4.w * nm_tanh(hfr[s].w + y4.w);
+        part = nm_wave_sum(part);
+        if (lane == 0) pe[cw][grp * ROWS + s] = part;
+    }
+    __syncthreads();
+
+    if (wave == 0) {                           // one source position per lane (S <= 52)
+        const bool ok = lane < p.S;
+        const int g = ok ? lane / rpg : 0, idx = g * ROWS + (ok ? lane - g * rpg : 0);
+        const float e = ok ? ((pe[0][idx] + pe[1][idx]) + (pe[2][idx] + pe[3][idx])) + bias : -INFINITY;
+        const float m = nm_wave_max(e);
+        const float ex = ok ? __expf(e - m) : 0.0f;
+        const float mk = (ok && p.mask) ? p.mask[(long)b * p.S + lane] : 1.0f;
+        const float em = ex * mk;
+        const float la = nm_wave_sum(ex), lm = nm_wave_sum(em);
+        const float w = em * (1.0f / (lm + 1e-8f * la));
+        if (ok) {
+            wsh[idx] = w;
+            p.energies[(long)b * p.S + lane] = e;
+            if (p.weights) p.weights[(long)b * p.S + lane] = w;
+        }
+    }
+    __syncthreads();
+
+    float4 acc = zero4;
+#pragma unroll
+    for (int s = 0; s < ROWS; ++s) {
+        const float w = s < ns ? wsh[grp * ROWS + s] : 0.0f;
+        acc.x += w * str[s].x; acc.y += w * str[s].y;
+        acc.z += w * str[s].z; acc.w += w * str[s].w;
+    }
+    if (grp > 0) red[grp - 1][cw * 64 + lane] = acc;
+    __syncthreads();
+    if (grp == 0 && c_ok) {
+        const float4 r0 = red[0][cw * 64 + lane], r1 = red[1][cw * 64 + lane], r2 = red[2][cw * 64 + lane];
+        acc.x += (r0.x + r1.x) + r2.x; acc.y += (r0.y + r1.y) + r2.y;
+        acc.z += (r0.z + r1.z) + r2.z; acc.w += (r0.w + r1.w) + r2.w;
+        *reinterpret_cast<float4*>(p.ctx + (long)b * p.ldctx + col) = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // The same idea for a handful of queries per key batch (beam search: the k hypotheses of a
 // sentence share its keys): every HBM load of the block is in flight before the first tanh, the
 // query slices live in registers, the NQ x ROWS chunk-local softmax is evaluated by NQ threads and
@@ -802,6 +885,18 @@ static int attn_fwd_impl(void* stream, const float* y, const float* hf, const fl
     std::pair<hipEvent_t, hipEvent_t>* prof = g_prof_on ? prof_next_pair() : nullptr;
     if (prof) (void)hipEventRecord(prof->first, st);
     static const bool no_fast = getenv("NM_ATTN_NOFAST") != nullptr;       // A/B switch for tuning
+    // Whole-sentence workgroups where they were measured faster than split-S + in-kernel merge (HIP events, cold /
+    // warm, profiles/r02_attn_whole_vs_split.txt): 128 sentences x 50 positions 20.4 / 16.6 us against 21.4 / 18.7;
+    // slower at 64 sentences (13.7 vs 13.2 warm), at 16 (12.8 vs 11.5) and at 30 positions (13.9 vs 13.4), where
+    // too few CUs get a workgroup or a workgroup too little to stream.
+    static const char* whole_env = getenv("NM_ATTN_WHOLE");               // A/B switch: 0 off, 1 whenever possible
+    const bool whole = do_combine && nq == 1 && A <= 1024 && C <= 1024 && S <= 4 * ATT_WHOLE_ROWS && !no_fast &&
+                       (whole_env ? atoi(whole_env) != 0 : (Bk >= 96 && S >= 40));
+    if (whole) {
+        hipLaunchKernelGGL(attn_whole_fast<ATT_WHOLE_ROWS>, dim3((unsigned)Bk), dim3(1024), 0, st, p);
+        if (prof) (void)hipEventRecord(prof->second, st);
+        NM_LAUNCH_CHECK("nm_attn_fwd");
+    }
     if (nq == 1 && A <= 1024 && C <= 1024 && sch <= ATT_FAST_ROWS && !no_fast) {
         p.merge = may_merge;
         if (sch <= 8) hipLaunchKernelGGL(attn_partial_fast<8>, grid, block, 0, st, p);

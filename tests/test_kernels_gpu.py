@@ -350,6 +350,9 @@ def test_gru_gemm_fused_epilogues_fwd_bwd(dev, b, s, e, h):
 @pytest.mark.parametrize("bk,qpk,s,a,c,ragged", [
     (16, 1, 50, 1024, 1024, False),
     (16, 1, 50, 1024, 1024, True),
+    (128, 1, 50, 1024, 1024, True),      # headline step: whole-sentence workgroups (>= 96 sentences, 40..52 positions)
+    (100, 1, 41, 200, 72, True),         # the same kernel with partial column waves and a short last row group
+    (96, 1, 52, 1024, 512, False),
     (4, 5, 50, 1024, 1024, True),
     (1, 5, 50, 1024, 1024, True),        # reference-compatible batch-1 beam
     (3, 3, 7, 64, 32, True),             # single chunk, tiny dims
@@ -395,6 +398,22 @@ def test_attention_fwd(dev, bk, qpk, s, a, c, ragged):
     assert rel_err(w.cpu().numpy(), ref_w) < RTOL
     assert rel_err(ctx.cpu().numpy(), ref_ctx) < RTOL
     assert np.all(w.cpu().numpy()[np.repeat(mask, qpk, 0) == 0] == 0)
+
+
+@pytest.mark.parametrize("whole", ["0", "1"])
+def test_attention_fwd_under_either_dispatch(whole):
+    """The one-query step has two kernels (split-S + in-kernel merge / one workgroup per sentence) chosen by shape;
+    NM_ATTN_WHOLE forces either wherever it applies: every shape above passes under both (a fresh process each,
+    the switch is read once)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, NM_ATTN_WHOLE=whole)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-m", "pytest", "tests/test_kernels_gpu.py", "-q", "-x", "-k",
+                          "test_attention_fwd and not dispatch or all_masked_row or merge_survives"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
 
 
 @pytest.mark.parametrize("t,b,s,a,c", [

@@ -127,7 +127,7 @@ def test_partials_merged_in_the_operand_loader(dev, bk, qpk, s, a, c, o):
     w2 = torch.empty((r, s), device=dev)
     ops.attn_fwd(y, T(hf, dev), T(states, dev), T(mask, dev), T(ap["v"], dev), T([ap["bias"]], dev), qpk, ctx2, w2, ws)
     assert rel(ctx2.cpu().numpy(), ctx_ref) < RTOL
-    assert torch.allclose(w2, weights, atol=1e-7, rtol=0)
+    assert torch.allclose(w2, weights, atol=1e-6, rtol=0)     # (whole-sentence kernel: sums in another order)
 
 
 def _decode_both_ways(dev, beam):

@@ -10,7 +10,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from neuralmonkey_amd import ops  # noqa: E402
 
-B, S, A, C = 128, 50, 1024, 1024
+B, S, A, C = int(os.environ.get("NM_B", "128")), int(os.environ.get("NM_S", "50")), 1024, 1024
 qpk = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 mode = sys.argv[3] if len(sys.argv) > 3 else "cold"      # cold (read sweep) | dirty (write sweep) | warm
@@ -60,5 +60,5 @@ wr = torch.softmax(e, -1) * mask.double().repeat_interleave(qpk, 0)
 wr = wr / (wr.sum(1, keepdim=True) + 1e-8)
 cr = (wr[:, :, None] * std.repeat_interleave(qpk, 0)).sum(1)
 err = float((ctx.double() - cr).abs().max() / cr.abs().max())
-print("NM_ATTN_MAXROWS={} mode={} qpk={}: {:.2f} us/launch (HIP events, {} launches)  rel err {:.1e}".format(
-    os.environ.get("NM_ATTN_MAXROWS", "-"), mode, qpk, tot.value * 1e3 / max(cnt.value, 1), cnt.value, err))
+print("NM_ATTN_MAXROWS={} whole={} B={} S={} mode={} qpk={}: {:.2f} us/launch (HIP events, {} launches)  rel err {:.1e}".format(
+    os.environ.get("NM_ATTN_MAXROWS", "-"), os.environ.get("NM_ATTN_WHOLE", "-"), B, S, mode, qpk, tot.value * 1e3 / max(cnt.value, 1), cnt.value, err))
