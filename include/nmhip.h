@@ -112,7 +112,7 @@ int nm_layer_norm_bwd(void* stream, const float* dy, const float* x, const float
 /* ---- Bahdanau attention step: Attention.attention, attention/feed_forward.py:120-166 ------
  * energies + softmax + mask renormalisation (+1e-8) + context, fused; keys of row r are
  * those of sentence r / rows_per_key (beam search without tiling the keys).
- * Split-S: every sentence is scored by several chunk workgroups; at the decoding shapes (<= 8 queries per
+ * Split-S: every sentence is scored by several chunk workgroups; at the decoding shapes (one query per sentence, or <= 8 queries per
  * sentence, A, C <= 1024) the workgroup that arrives LAST merges the partials itself (write-through hand-off +
  * one arrival counter per sentence), otherwise a combine kernel follows.  The workspace therefore ends with
  * arrival counters that must be ZERO at launch: zero a workspace once after allocating it -- the kernels leave

@@ -969,7 +969,7 @@ extern "C" int nm_attn_fwd_partials(void* stream, const float* y, const float* h
                                     const float* mask, const float* v, const float* bias, int64_t R,
                                     int64_t rows_per_key, int64_t S, int64_t A, int64_t C, void* workspace,
                                     int64_t workspace_bytes) {
-    NM_REQUIRE(R > 0 && rows_per_key >= 1 && rows_per_key <= 8 && R % rows_per_key == 0,
+    NM_REQUIRE(R > 0 && rows_per_key >= 1 && rows_per_key <= 64 && R % rows_per_key == 0,
                "nm_attn_fwd_partials: bad shape R=%ld k=%ld", (long)R, (long)rows_per_key);
     return attn_fwd_impl(stream, y, hf, states, mask, v, bias, R / rows_per_key, rows_per_key, rows_per_key, 1, S, A,
                          C, nullptr, 4, nullptr, workspace, workspace_bytes, nullptr, 0);
@@ -980,7 +980,7 @@ extern "C" int nm_attn_fwd(void* stream, const float* y, const float* hf, const 
                            int64_t rows_per_key, int64_t S, int64_t A, int64_t C, float* ctx,
                            int64_t ldctx, float* weights, void* workspace, int64_t workspace_bytes,
                            float* energies_out) {
-    NM_REQUIRE(R > 0 && rows_per_key >= 1 && rows_per_key <= 8 && R % rows_per_key == 0,
+    NM_REQUIRE(R > 0 && rows_per_key >= 1 && rows_per_key <= 64 && R % rows_per_key == 0,
                "nm_attn_fwd: bad shape R=%ld k=%ld", (long)R, (long)rows_per_key);
     return nm_attn_fwd_multi(stream, y, hf, states, mask, v, bias, R / rows_per_key, rows_per_key,
                              rows_per_key, 1, S, A, C, ctx, ldctx, weights, workspace, workspace_bytes,

@@ -291,7 +291,7 @@ extern "C" int nm_xent(void* stream, float* logits, int64_t ldx, int64_t rows, i
 // keeps its best k; stage 2 merges the slices and emits word / beam ids and the
 // gathered search state.
 // ---------------------------------------------------------------------------
-#define BEAM_MAX_K 8
+#define BEAM_MAX_K 16
 
 struct Cand { float score; int idx; };
 
@@ -732,7 +732,8 @@ extern "C" int nm_beam_topk_step(void* stream, const float* logits, int64_t ldx,
                            out_logprob_sum, out_lengths, out_finished, out_src_row, all_finished);   \
     } while (0)
     if (k <= 4) NM_BK(4);
-    else NM_BK(8);
+    else if (k <= 8) NM_BK(8);
+    else NM_BK(16);
 #undef NM_BK
     NM_LAUNCH_CHECK("nm_beam_topk_step");
 }
@@ -779,7 +780,8 @@ extern "C" int nm_beam_topk_step_fused(void* stream, const float* logits, int64_
                            out_finished, out_src_row, all_finished);                                           \
     } while (0)
     if (k <= 4) NM_FUSED(4);
-    else NM_FUSED(8);
+    else if (k <= 8) NM_FUSED(8);
+    else NM_FUSED(16);
 #undef NM_FUSED
 #undef NM_SCAN
     NM_LAUNCH_CHECK("nm_beam_topk_step_fused");
@@ -1046,7 +1048,8 @@ extern "C" int nm_beam_topk_step_tiles(void* stream, const float* logits, int64_
                            out_finished, out_src_row, all_finished);                                             \
     } while (0)
     if (k <= 4) NM_TILES(4);
-    else NM_TILES(8);
+    else if (k <= 8) NM_TILES(8);
+    else NM_TILES(16);
 #undef NM_TILES
     NM_LAUNCH_CHECK("nm_beam_topk_step_tiles");
 }

@@ -66,8 +66,8 @@ class BeamSearchDecoder(ModelPart):
         self.length_normalization = length_normalization
         self.max_steps_int = max_steps
         self.max_steps = Placeholder("{}/max_steps".format(name), default=max_steps)
-        if beam_size < 1 or beam_size > 8:
-            raise ValueError("beam_size must be between 1 and 8 for the HIP top-k kernel, was {}"
+        if beam_size < 1 or beam_size > 16:
+            raise ValueError("beam_size must be between 1 and 16 for the HIP top-k kernels, was {}"
                              .format(beam_size))
         if not hasattr(parent_decoder, "make_stepper"):
             raise NotImplementedError("BeamSearchDecoder: parent decoder '{}' has no stepwise inference "

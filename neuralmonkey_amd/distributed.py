@@ -130,7 +130,9 @@ def init_from_env(backend: Optional[str] = None) -> Optional[DataParallel]:
     """Initialise from torchrun's RANK / WORLD_SIZE / MASTER_* variables."""
     global _CURRENT
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1 and not dist.is_initialized():
+    # a world of one trains without a process group -- unless NM_DIST_FORCE is set: the single-GPU smoke test of
+    # the RCCL code path (process-group set-up, bucketed / early all-reduce on its streams) with nobody to talk to
+    if world <= 1 and not dist.is_initialized() and not os.environ.get("NM_DIST_FORCE"):
         _CURRENT = None
         return None
     if not dist.is_initialized():

@@ -97,3 +97,43 @@ def test_two_ranks_equal_one_process_on_the_full_batch(tmp_path):
     assert np.abs(r0["theta"] - want).max() <= 6.5e-4
     assert np.median(np.abs(r0["theta"] - want)) <= 1e-6
     assert r0["losses"].shape == (3,) and np.all(np.isfinite(r0["losses"])) and r0["losses"][2] < r0["losses"][0]
+
+
+def _rccl_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      NM_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.pop("NM_DIST_BACKEND", None)             # default on a GPU box: nccl = RCCL
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    from neuralmonkey_amd import distributed
+    dp = distributed.init_from_env()
+    assert dp is not None and dp.world_size == 1 and dist.get_backend() == "nccl"
+    model = _model()
+    store = model.tf_manager.sessions[0].store
+    dp.broadcast_parameters(store)
+    batch = dp.shard(_batch())
+    assert len(batch) == BATCH
+    losses = []
+    for _ in range(3):
+        res = model.tf_manager.execute(batch, model.trainer.feedables, [model.trainer], train=True)[0]
+        losses.append(res.losses["decoder - cost"])
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, "rccl.npz"), theta=store.theta.cpu().numpy(), losses=np.asarray(losses))
+    distributed.shutdown()
+
+
+def test_rccl_process_group_of_one_trains_like_no_process_group(tmp_path):
+    """The RCCL path itself (backend nccl: process group, broadcast, early + bucketed all-reduce on their streams,
+    global token count) with a world of one, where every collective is the identity: three optimizer steps end
+    bit for bit where the same model ends without a process group."""
+    mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    got = np.load(tmp_path / "rccl.npz")
+    model = _model()
+    store = model.tf_manager.sessions[0].store
+    full = _batch()
+    want_losses = [model.tf_manager.execute(full, model.trainer.feedables, [model.trainer], train=True)[0]
+                   .losses["decoder - cost"] for _ in range(3)]
+    assert np.allclose(got["losses"], want_losses, rtol=1e-5, atol=0)
+    diff = np.abs(got["theta"] - store.theta.cpu().numpy())       # (embedding-gradient atomics: see the test above)
+    assert diff.max() <= 6.5e-4 and np.median(diff) <= 1e-6

@@ -68,6 +68,8 @@ def test_encoder_and_greedy_match_oracle(dev, vocab, emb, rnn, batch, slen, tlen
     (500, 32, 32, 1, 20, 12, 5, 1.0),     # the reference's own (batch-1) regime
     (500, 32, 32, 9, 20, 12, 5, 0.6),
     (2000, 64, 64, 16, 30, 20, 4, 0.0),
+    (500, 32, 32, 6, 20, 12, 12, 0.6),    # beams wider than 8: the 16-wide top-k instances, two attention query groups
+    (300, 16, 16, 3, 9, 8, 16, 1.0),
 ])
 def test_beam_search_matches_oracle(dev, vocab, emb, rnn, batch, slen, tlen, beam, alpha):
     model, params, ds, src, tgt = _setup(dev, vocab, emb, rnn, batch, slen, tlen, True, beam=beam,

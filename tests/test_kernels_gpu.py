@@ -60,6 +60,51 @@ def test_gemm(dev, m, n, k, ta, tb, algo):
     assert rel_err(out3.cpu().numpy(), ref + c0) < 2e-6 * np.sqrt(k) + 1e-6
 
 
+def test_gemm_random_shapes(dev):
+    """Seeded sweep over shapes nobody picked by hand: every layout, odd and aligned sizes, row strides larger than
+    the row, bias / activation / accumulate, every kernel family (auto dispatch and forced), with and without the
+    split-K workspace -- against float64."""
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(20260925)
+    sizes = [1, 2, 3, 4, 5, 7, 8, 12, 15, 16, 17, 31, 32, 33, 48, 63, 64, 65, 100, 127, 128, 129, 200, 256, 260, 384, 511,
+             512, 640, 1000, 1024, 1300, 2048]
+    for case in range(60):
+        m, n = (int(rng.choice(sizes)) for _ in range(2))
+        k = int(rng.choice(sizes + [4096, 6400]))
+        ta, tb = bool(rng.integers(2)), bool(rng.integers(2))
+        algo = int(rng.choice([0, 0, 0, 1, 2, 3]))
+        pad_a, pad_b, pad_c = (int(rng.choice([0, 0, 4, 3])) for _ in range(3))
+        if algo == 3 and (ta or k % 8 or (k + pad_a) % 4 or (tb and (k + pad_b) % 4) or (not tb and (n + pad_b) % 4)):
+            algo = 0            # the skinny kernels are only ever forced where they apply (they refuse loudly otherwise)
+        scale = 1.0 / np.sqrt(k)
+        a_full = (rng.standard_normal(((k, m + pad_a) if ta else (m, k + pad_a))) * scale).astype(np.float32)
+        b_full = rng.standard_normal(((n, k + pad_b) if tb else (k, n + pad_b))).astype(np.float32)
+        a_np = a_full[:, :m] if ta else a_full[:, :k]
+        b_np = b_full[:, :k] if tb else b_full[:, :n]
+        a_d = T(a_full, dev)[:, :a_np.shape[1]]
+        b_d = T(b_full, dev)[:, :b_np.shape[1]]
+        bias = rng.standard_normal(n).astype(np.float32) if rng.integers(2) else None
+        act = [None, "tanh", "relu"][int(rng.integers(3))]
+        acc = bool(rng.integers(2)) and act is None
+        ref = (a_np.T if ta else a_np).astype(np.float64) @ (b_np.T if tb else b_np).astype(np.float64)
+        if bias is not None:
+            ref = ref + bias
+        c0 = rng.standard_normal((m, n + pad_c)).astype(np.float32)
+        out_full = T(c0 if acc else np.full_like(c0, np.nan), dev)
+        out = out_full[:, :n]
+        if acc:
+            ref = ref + c0[:, :n]
+        ref = {"tanh": np.tanh, "relu": lambda x: np.maximum(x, 0), None: lambda x: x}[act](ref)
+        ops.gemm(a_d, b_d, out=out, bias=None if bias is None else T(bias, dev), act=act, trans_a=ta, trans_b=tb,
+                 accumulate=acc, algo=algo)
+        got = out_full.cpu().numpy()
+        what = "case {}: m={} n={} k={} ta={} tb={} algo={} pads=({},{},{}) bias={} act={} acc={}".format(
+            case, m, n, k, ta, tb, algo, pad_a, pad_b, pad_c, bias is not None, act, acc)
+        assert rel_err(got[:, :n], ref) < 3e-5, what
+        if pad_c and not acc:
+            assert np.isnan(got[:, n:]).all(), what               # nothing beyond the N columns is written
+
+
 def test_gemm_transpose_detecting(dev):
     """A = I with an asymmetric B catches a swapped C layout."""
     from neuralmonkey_amd import ops
@@ -367,6 +412,8 @@ def test_gru_gemm_fused_epilogues_fwd_bwd(dev, b, s, e, h):
     (2, 6, 30, 128, 512, False),
     (2, 7, 50, 1024, 1024, True),
     (2, 8, 50, 640, 1024, True),
+    (3, 12, 50, 1024, 1024, True),       # beams wider than one query group: two groups of 8 + 4
+    (2, 16, 23, 256, 512, True),
     (3, 2, 9, 10, 14, True),             # tests/small.ini-like: C = 2*7, no dim a multiple of 4
     (2, 1, 300, 6, 7, True),             # any-shape kernel, long S
 ])
@@ -398,6 +445,42 @@ def test_attention_fwd(dev, bk, qpk, s, a, c, ragged):
     assert rel_err(w.cpu().numpy(), ref_w) < RTOL
     assert rel_err(ctx.cpu().numpy(), ref_ctx) < RTOL
     assert np.all(w.cpu().numpy()[np.repeat(mask, qpk, 0) == 0] == 0)
+
+
+def test_attention_fwd_random_shapes(dev):
+    """Seeded sweep of the attention step over sizes nobody picked by hand (every kernel: whole-sentence, split-S with
+    in-kernel merge, split-S + combine, several queries per sentence, any-shape) against float64."""
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(424242)
+    for case in range(40):
+        qpk = int(rng.choice([1, 1, 1, 2, 3, 5, 8, 11]))
+        bk = int(rng.choice([1, 2, 3, 7, 33, 97, 130])) if qpk == 1 else int(rng.choice([1, 2, 5, 9]))
+        s = int(rng.choice([1, 2, 5, 9, 13, 26, 39, 40, 47, 52, 53, 64, 97, 130]))
+        a = int(rng.choice([4, 6, 32, 100, 256, 512, 1024]))
+        c = int(rng.choice([4, 7, 48, 256, 516, 1024, 2048]))
+        r = bk * qpk
+        y = rng.standard_normal((r, a)).astype(np.float32)
+        hf = rng.standard_normal((bk, s, a)).astype(np.float32)
+        states = rng.standard_normal((bk, s, c)).astype(np.float32)
+        v = (rng.standard_normal(a) * 0.3).astype(np.float32)
+        mask = (np.arange(s)[None, :] < rng.integers(1, s + 1, bk)[:, None]).astype(np.float32)
+        e = (v.astype(np.float64) * np.tanh(np.repeat(hf, qpk, 0).astype(np.float64) + y[:, None, :])).sum(-1) + 0.25
+        p = np.exp(e - e.max(1, keepdims=True))
+        w_all = p / p.sum(1, keepdims=True) * np.repeat(mask, qpk, 0)
+        ref_w = w_all / (w_all.sum(1, keepdims=True) + 1e-8)
+        ref_ctx = (ref_w[:, :, None] * np.repeat(states, qpk, 0).astype(np.float64)).sum(1)
+        ctx = torch.full((r, c + 4), float("nan"), device=dev)
+        w = torch.empty((r, s), device=dev)
+        en = torch.empty((r, s), device=dev)
+        ws = ops.attn_workspace(r, s, c, dev)
+        for _ in range(2):                      # twice: arrival counters left at zero
+            ops.attn_fwd(T(y, dev), T(hf, dev), T(states, dev), T(mask, dev), T(v, dev), T(np.array([0.25]), dev), qpk,
+                         ctx[:, :c], w, ws, en)
+        what = "case {}: bk={} qpk={} s={} a={} c={}".format(case, bk, qpk, s, a, c)
+        assert rel_err(en.cpu().numpy(), e) < RTOL, what
+        assert np.abs(w.cpu().numpy() - ref_w).max() < 2e-6, what
+        assert rel_err(ctx[:, :c].cpu().numpy(), ref_ctx) < RTOL, what
+        assert torch.isnan(ctx[:, c:]).all(), what
 
 
 @pytest.mark.parametrize("whole", ["0", "1"])
@@ -539,7 +622,8 @@ def _beam_step_ref(logits, k, logprob_sum, lengths, finished, alpha):
     return sc, hyp.reshape(b, k * v), hl, ts, ti
 
 
-@pytest.mark.parametrize("b,k,v", [(128, 5, 32000), (3, 3, 70), (1, 2, 17), (7, 8, 1000)])
+@pytest.mark.parametrize("b,k,v", [(128, 5, 32000), (3, 3, 70), (1, 2, 17), (7, 8, 1000), (16, 12, 32000), (5, 16, 516),
+                                   (2, 10, 37)])
 def test_beam_topk_step(dev, b, k, v):
     from neuralmonkey_amd import ops
     rng = np.random.default_rng(b + k + v)
