@@ -325,6 +325,19 @@ def main():
         lib.nm_prof_enable(0)
         lib.nm_prof_attn_step(ctypes.byref(tot_ms), ctypes.byref(cnt))
         stream_us = (tot_ms.value * 1e3 / cnt.value) if cnt.value else None
+        # what the event pair itself costs: the same protocol around a 4-thread-block's worth of work (16 bytes)
+        def empty_pass(n):
+            for _ in range(n):
+                sink.add_(flush.sum())
+                _lib.check(lib.nm_prof_stream_read(ops._stream(), probe.data_ptr(), 16, psink.data_ptr()),
+                           "nm_prof_stream_read")
+            torch.cuda.synchronize()
+        empty_pass(3)
+        lib.nm_prof_enable(1)
+        empty_pass(20)
+        lib.nm_prof_enable(0)
+        lib.nm_prof_attn_step(ctypes.byref(tot_ms), ctypes.byref(cnt))
+        overhead_us = (tot_ms.value * 1e3 / cnt.value) if cnt.value else None
         del flush, probe
 
     if rank == 0:
@@ -338,6 +351,13 @@ def main():
             with open(pmc) as fh:
                 rec = json.load(fh)
             traffic, pmc_kernels = rec.get("hbm_bytes_per_launch"), rec.get("kernels")
+        # rocprofv3 kernel durations of the same launches (committed summaries of separate profiled runs)
+        rocprof_us = {}
+        for mode in ("cold", "warm", "dirty"):
+            path = os.path.join(ROOT, "profiles", "r02_attn_step_trace_{}_v3.json".format(mode))
+            if os.path.exists(path):
+                with open(path) as fh:
+                    rocprof_us[mode] = json.load(fh).get("sum_avg_us")
         dstep_bytes = decoder_step_bytes(args.batch, args.length, h, args.vocab)
         dstep_us = greedy_ms * 1e3 / args.length
         line = {
@@ -367,6 +387,9 @@ def main():
                          "bound": "hbm", "achieved": cold, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (cold / HBM_PEAK_GBPS) if cold else None, "traffic": traffic,
                          "traffic_kernels": pmc_kernels,
+                         "rocprof_kernel_us": rocprof_us or None,
+                         "frac_rocprof_cold": (step_bytes / (rocprof_us["cold"] * 1e-6) / 1e9 / HBM_PEAK_GBPS)
+                         if rocprof_us.get("cold") else None,
                          "achieved_cold": cold, "cold_launch_us": cold_us, "cold_launches": cold_n,
                          "cold_how": "1 GiB read sweep between launches (L2 + 256 MB Infinity Cache evicted, clean "
                                      "lines), HIP events around the launch",
@@ -379,6 +402,9 @@ def main():
                                             "how far the step kernel is from what one launch of this size can "
                                             "reach".format(step_bytes // 16 * 16),
                          "frac_of_stream_read": (stream_us / cold_us) if (stream_us and cold_us) else None,
+                         "event_pair_overhead_us": overhead_us,
+                         "event_pair_overhead_how": "the same event pair around a launch that reads 16 bytes: what of "
+                                                    "cold_launch_us is dispatch + event latency rather than kernel",
                          "achieved_warm": warm, "frac_warm": (warm / HBM_PEAK_GBPS) if warm else None,
                          "warm_launch_us": warm_us, "warm_launches": warm_n,
                          "warm_how": "inside a greedy decode of one B={} batch, {} steps, launched eagerly".format(

@@ -94,7 +94,9 @@ extern "C" int nm_prof_stream_read(void* stream, const void* src, int64_t bytes,
     hipStream_t st = nm_stream(stream);
     std::pair<hipEvent_t, hipEvent_t>* prof = g_prof_on ? prof_next_pair() : nullptr;
     if (prof) (void)hipEventRecord(prof->first, st);
-    hipLaunchKernelGGL(stream_read_kernel, dim3(2048), dim3(256), 0, st, (const float4*)src, (long)(bytes / 16), sink);
+    const long n4 = (long)(bytes / 16);
+    const unsigned blocks = (unsigned)(n4 >= 2048L * 256 ? 2048 : (n4 + 255) / 256);
+    hipLaunchKernelGGL(stream_read_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)src, n4, sink);
     if (prof) (void)hipEventRecord(prof->second, st);
     NM_LAUNCH_CHECK("nm_prof_stream_read");
 }
@@ -447,7 +449,11 @@ __global__ __launch_bounds__(256) void attn_partial_fast(AttnArgs p) {
 // of the sentence's 300 KB in flight at once), the energies of the 4 column waves meet in LDS, wave 0 evaluates
 // softmax -> mask -> renormalise (+1e-8) with one source position per lane, the 4 row groups' partial contexts
 // meet in LDS.  Half the CUs stay idle at 128 sentences, but the launch no longer ends with write-through
-// stores + a ticket + a second pass over the partials by the last-arriving workgroup.
+// stores + a ticket + a second pass over the partials by the last-arriving workgroup.  (Measured and not kept:
+// two workgroups per sentence split by COLUMNS that exchange their partial energies as 8-byte {value, tag}
+// granules -- all 256 CUs busy, nothing merged afterwards, yet 21.9 / 17.3 us cold / warm against 20.6 / 16.6
+// here: the exchange waits in the consumer CU's memory queue behind its own streaming loads,
+// profiles/r02_attn_pair_vs_whole.txt.)
 // ---------------------------------------------------------------------------
 #define ATT_WHOLE_ROWS 13
 template <int ROWS>

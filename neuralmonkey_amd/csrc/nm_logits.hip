@@ -756,7 +756,8 @@ extern "C" int nm_beam_topk_step_fused(void* stream, const float* logits, int64_
     NM_REQUIRE(workspace_bytes >= nm_beam_workspace_bytes(B, k, V), "nm_beam_topk_step_fused: workspace too small");
     const int nv = row_scan_nv(logits, ldx, V);
     hipStream_t st = nm_stream(stream);
-    if (nv == 0) {      // unaligned or very long rows: statistics pass + sliced top-k pass
+    if (nv == 0 || k > 8) {   // unaligned or very long rows, or a beam wider than the register-resident scan's lists
+                              // (its 16-wide instances spill): statistics pass + sliced top-k pass
         hipLaunchKernelGGL((row_stats_kernel<1024>), dim3((unsigned)(B * k)), dim3(1024), 0, st, logits, (long)ldx,
                            (int)V, rmax_out, rlse_out, (int*)nullptr);
         return nm_beam_topk_step(stream, logits, ldx, B, k, V, rmax_out, rlse_out, logprob_sum, lengths, finished,
@@ -780,8 +781,7 @@ extern "C" int nm_beam_topk_step_fused(void* stream, const float* logits, int64_
                            out_finished, out_src_row, all_finished);                                           \
     } while (0)
     if (k <= 4) NM_FUSED(4);
-    else if (k <= 8) NM_FUSED(8);
-    else NM_FUSED(16);
+    else NM_FUSED(8);
 #undef NM_FUSED
 #undef NM_SCAN
     NM_LAUNCH_CHECK("nm_beam_topk_step_fused");
