@@ -284,6 +284,7 @@ def main():
         ctx = torch.empty(args.batch, c, device=dev)
         wts = torch.empty(args.batch, args.length, device=dev)
         ws = ops.attn_workspace(args.batch, args.length, c, dev)
+        nbytes_of = attention_step_bytes(args.batch, args.length, a, c) // 16 * 16
         flush = torch.zeros(256 << 20, device=dev)                      # 1 GiB of fp32
         sink = torch.zeros(1, device=dev)
 
@@ -307,6 +308,42 @@ def main():
             return ((tot_ms.value * 1e3 / cnt.value) if cnt.value else None), cnt.value
         cold_us, cold_n = measure(False)
         dirty_us, _ = measure(True)
+        # cold without a sweep in between: NSETS distinct key / value sets (428 MB > the 256 MB Infinity Cache)
+        # visited round-robin, launches back to back, ONE event pair around the whole sequence -- every launch reads
+        # lines that 7 x 53 MB of other sets have pushed out since its last visit, and the event pair's own cost
+        # (event_pair_overhead_us below) is spread over all of them instead of added to each
+        NSETS, ROUNDS = 8, 4
+        sets = [(hf, st)] + [(torch.randn_like(hf), torch.randn_like(st)) for _ in range(NSETS - 1)]
+
+        def rotate_pass(rounds):
+            for i in range(rounds * NSETS):
+                khf, kst = sets[i % NSETS]
+                ops.attn_fwd(y, khf, kst, mask, vv, bias, 1, ctx, wts, ws)
+        rotate_pass(1)
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        rotate_pass(ROUNDS)
+        ev1.record()
+        torch.cuda.synchronize()
+        rot_us = ev0.elapsed_time(ev1) * 1e3 / (ROUNDS * NSETS)
+        rot_n = ROUNDS * NSETS
+        # the same sequence for the streaming yardstick
+        probes = [torch.randn(nbytes_of // 4, device=dev, generator=gen) for _ in range(NSETS)]
+        psink0 = torch.zeros(2048, device=dev)
+
+        def rotate_stream(rounds):
+            for i in range(rounds * NSETS):
+                _lib.check(lib.nm_prof_stream_read(ops._stream(), probes[i % NSETS].data_ptr(), nbytes_of,
+                                                   psink0.data_ptr()), "nm_prof_stream_read")
+        rotate_stream(1)
+        torch.cuda.synchronize()
+        ev0.record()
+        rotate_stream(ROUNDS)
+        ev1.record()
+        torch.cuda.synchronize()
+        rot_stream_us = ev0.elapsed_time(ev1) * 1e3 / (ROUNDS * NSETS)
+        del sets, probes
         # yardstick: the same number of bytes read cold by a plain streaming kernel (nm_prof_stream_read), same
         # sweep in between, same event pool -- what ONE launch of this size can reach on this part
         nbytes = attention_step_bytes(args.batch, args.length, a, c) // 16 * 16
@@ -344,7 +381,7 @@ def main():
         a = c = 2 * h
         step_bytes = attention_step_bytes(args.batch, args.length, a, c)
         gbps = lambda us: (step_bytes / (us * 1e-6) / 1e9) if us else None
-        warm, cold = gbps(warm_us), gbps(cold_us)
+        warm, cold, rot = gbps(warm_us), gbps(cold_us), gbps(rot_us)
         traffic = pmc_kernels = None
         pmc = os.path.join(ROOT, "profiles", "attn_step_pmc.json")
         if os.path.exists(pmc):
@@ -381,18 +418,29 @@ def main():
                                    "mask-renorm + context of one decoding step; one 1024-thread workgroup per sentence: "
                                    "no split-S partials, no merge; smaller batches / longer sources take the split-S "
                                    "kernel with its in-kernel merge)",
-                         "timing": "HIP events on the launch stream around every nm_attn_fwd call: includes the "
-                                   "dispatch latency of the launch (~3 us); rocprofv3 kernel durations of the same "
-                                   "modes are in profiles/r02_attn_step_trace_{cold,warm,dirty}_v3.json",
-                         "bound": "hbm", "achieved": cold, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": (cold / HBM_PEAK_GBPS) if cold else None, "traffic": traffic,
+                         "timing": "HIP events on the launch stream (the library's recorder around single calls, one "
+                                   "torch.cuda.Event pair -- torch's current stream IS the launch stream -- around the "
+                                   "back-to-back sequence); rocprofv3 kernel durations of the same kernel: "
+                                   "profiles/r02_attn_step_trace_{cold,warm,dirty}_v3.json, repeated in "
+                                   "rocprof_kernel_us",
+                         "bound": "hbm", "achieved": rot, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": (rot / HBM_PEAK_GBPS) if rot else None, "traffic": traffic,
+                         "achieved_how": "cold, back to back: {} launches over {} distinct key / value sets (428 MB, "
+                                         "round-robin: a set's lines are evicted from L2 and the 256 MB Infinity Cache "
+                                         "before its next visit), ONE HIP-event pair on the launch stream around the "
+                                         "sequence; {:.2f} us per launch".format(rot_n, NSETS, rot_us),
+                         "cold_rotating_launch_us": rot_us,
+                         "stream_read_rotating_us": rot_stream_us,
+                         "frac_of_stream_read_rotating": (rot_stream_us / rot_us) if rot_us else None,
                          "traffic_kernels": pmc_kernels,
                          "rocprof_kernel_us": rocprof_us or None,
                          "frac_rocprof_cold": (step_bytes / (rocprof_us["cold"] * 1e-6) / 1e9 / HBM_PEAK_GBPS)
                          if rocprof_us.get("cold") else None,
-                         "achieved_cold": cold, "cold_launch_us": cold_us, "cold_launches": cold_n,
-                         "cold_how": "1 GiB read sweep between launches (L2 + 256 MB Infinity Cache evicted, clean "
-                                     "lines), HIP events around the launch",
+                         "achieved_cold": cold, "frac_cold_single": (cold / HBM_PEAK_GBPS) if cold else None,
+                         "cold_launch_us": cold_us, "cold_launches": cold_n,
+                         "cold_how": "ONE launch between two events, a 1 GiB read sweep before it (L2 + 256 MB Infinity "
+                                     "Cache evicted, clean lines): includes what the event pair itself costs "
+                                     "(event_pair_overhead_us)",
                          "cold_dirty_launch_us": dirty_us,
                          "cold_dirty_how": "the same with a 1 GiB WRITE sweep: the caches hold dirty lines whose "
                                            "write-back competes with the kernel's reads",

@@ -66,6 +66,16 @@ def test_reference_ini_trains_and_decodes(dev, ref_root, name):      # noqa: F81
     assert {item[0] for item in model.evaluation} <= produced
 
 
+def test_coverage_attention_variant_of_bahdanau_ini_trains_and_decodes(dev, ref_root):     # noqa: F811
+    """tests/bahdanau.ini with its attention section switched to attention.CoverageAttention (coverage.py:19-36 takes
+    the same arguments + max_fertility): the same three optimizer steps and decoding runs."""
+    with open(os.path.join(ref_root, "tests", "bahdanau.ini")) as fh:
+        text = fh.read()
+    with open(os.path.join(ref_root, "tests", "bahdanau_coverage.ini"), "w") as fh:
+        fh.write(text.replace("class=attention.Attention", "class=attention.CoverageAttention\nmax_fertility=4"))
+    test_reference_ini_trains_and_decodes(dev, ref_root, "bahdanau_coverage")
+
+
 def _scheme(batch_size):
     from neuralmonkey_amd.dataset import BatchingScheme
     return BatchingScheme(batch_size=batch_size)
