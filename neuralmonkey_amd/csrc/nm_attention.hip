@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void attn_partial(AttnArgs p) {
             for (int q = 0; q < QPK; ++q)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float r = nm_wave_sum(acc[q][i]);
+                    const float r = nm_wave_sum_dpp(acc[q][i]);
                     if (lane == 0 && s4 + i < ns) pe[(wave * QPK + q) * ATT_MAX_SCH + s4 + i] = r;
                 }
         }
@@ -383,6 +383,11 @@ __global__ __launch_bounds__(256) void attn_partial_fast(AttnArgs p) {
     const float* sbase = p.states + ((long)b * p.S + s0) * p.C + (c_ok ? col : 0);
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
+    // y / v before the rows: vmcnt counts in issue order, a tanh of row s then only waits for rows 0..s
+    const float4 y4 = *reinterpret_cast<const float4*>(p.y + (long)b * p.A + (a_ok ? col : 0));
+    float4 v4 = *reinterpret_cast<const float4*>(p.v + (a_ok ? col : 0));
+    if (!a_ok) v4 = zero4;
+    const float bias = p.bias ? p.bias[0] : 0.0f;
     float4 hfr[ROWS], str[ROWS];
 #pragma unroll
     for (int s = 0; s < ROWS; ++s)
@@ -390,16 +395,12 @@ __global__ __launch_bounds__(256) void attn_partial_fast(AttnArgs p) {
 #pragma unroll
     for (int s = 0; s < ROWS; ++s)
         str[s] = *reinterpret_cast<const float4*>(sbase + (long)min(s, ns - 1) * p.C);
-    const float4 y4 = *reinterpret_cast<const float4*>(p.y + (long)b * p.A + (a_ok ? col : 0));
-    float4 v4 = *reinterpret_cast<const float4*>(p.v + (a_ok ? col : 0));
-    if (!a_ok) v4 = zero4;
-    const float bias = p.bias ? p.bias[0] : 0.0f;
 
 #pragma unroll
     for (int s = 0; s < ROWS; ++s) {
         float part = v4.x * nm_tanh(hfr[s].x + y4.x) + v4.y * nm_tanh(hfr[s].y + y4.y) +
                      v4.z * nm_tanh(hfr[s].z + y4.z) + v4.w * nm_tanh(hfr[s].w + y4.w);
-        part = nm_wave_sum(part);
+        part = nm_wave_sum_dpp(part);
         if (lane == 0) pe[wave][s] = part;
     }
     __syncthreads();
@@ -473,6 +474,13 @@ __global__ __launch_bounds__(1024) void attn_whole_fast(AttnArgs p) {
     const float* sbase = p.states + (long)b * p.S * p.C + (c_ok ? col : 0);
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
+    // the query slice and v FIRST: vmcnt counts loads in issue order, so a tanh of key row s may start as soon as
+    // rows 0..s have landed only if nothing it needs was requested after the rows (with y / v requested last the
+    // compiler had to wait for all 26 row loads -- s_waitcnt vmcnt(0) -- before the first tanh)
+    const float4 y4 = *reinterpret_cast<const float4*>(p.y + (long)b * p.A + (a_ok ? col : 0));
+    float4 v4 = *reinterpret_cast<const float4*>(p.v + (a_ok ? col : 0));
+    if (!a_ok) v4 = zero4;
+    const float bias = p.bias ? p.bias[0] : 0.0f;
     float4 hfr[ROWS], str[ROWS];
 #pragma unroll
     for (int s = 0; s < ROWS; ++s)            // clamped rows are weighted by zero below
@@ -480,16 +488,12 @@ __global__ __launch_bounds__(1024) void attn_whole_fast(AttnArgs p) {
 #pragma unroll
     for (int s = 0; s < ROWS; ++s)
         str[s] = *reinterpret_cast<const float4*>(sbase + (long)min(s0 + min(s, max(ns - 1, 0)), p.S - 1) * p.C);
-    const float4 y4 = *reinterpret_cast<const float4*>(p.y + (long)b * p.A + (a_ok ? col : 0));
-    float4 v4 = *reinterpret_cast<const float4*>(p.v + (a_ok ? col : 0));
-    if (!a_ok) v4 = zero4;
-    const float bias = p.bias ? p.bias[0] : 0.0f;
 
 #pragma unroll
     for (int s = 0; s < ROWS; ++s) {
         float part = v4.x * nm_tanh(hfr[s].x + y4.x) + v4.y * nm_tanh(hfr[s].y + y4.y) +
                      v4.z * nm_tanh(hfr[s].z + y4.z) + v4.w * nm_tanh(hfr[s].w + y4.w);
-        part = nm_wave_sum(part);
+        part = nm_wave_sum_dpp(part);
         if (lane == 0) pe[cw][grp * ROWS + s] = part;
     }
     __syncthreads();
@@ -498,11 +502,11 @@ __global__ __launch_bounds__(1024) void attn_whole_fast(AttnArgs p) {
         const bool ok = lane < p.S;
         const int g = ok ? lane / rpg : 0, idx = g * ROWS + (ok ? lane - g * rpg : 0);
         const float e = ok ? ((pe[0][idx] + pe[1][idx]) + (pe[2][idx] + pe[3][idx])) + bias : -INFINITY;
-        const float m = nm_wave_max(e);
+        const float m = nm_wave_max_dpp(e);
         const float ex = ok ? __expf(e - m) : 0.0f;
         const float mk = (ok && p.mask) ? p.mask[(long)b * p.S + lane] : 1.0f;
         const float em = ex * mk;
-        const float la = nm_wave_sum(ex), lm = nm_wave_sum(em);
+        const float la = nm_wave_sum_dpp(ex), lm = nm_wave_sum_dpp(em);
         const float w = em * (1.0f / (lm + 1e-8f * la));
         if (ok) {
             wsh[idx] = w;
@@ -550,27 +554,29 @@ __global__ __launch_bounds__(256) void attn_partial_fastq(AttnArgs p) {
     const float* sbase = p.states + ((long)b * p.S + s0) * p.C + (c_ok ? col : 0);
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
+    // queries and v before the rows (vmcnt counts in issue order), and rows outermost below: every query's tanh of
+    // row s runs as soon as rows 0..s have landed
     float4 hfr[ROWS], str[ROWS], y4[NQ];
-#pragma unroll
-    for (int s = 0; s < ROWS; ++s)
-        hfr[s] = *reinterpret_cast<const float4*>(hbase + (long)min(s, ns - 1) * p.A);
-#pragma unroll
-    for (int s = 0; s < ROWS; ++s)
-        str[s] = *reinterpret_cast<const float4*>(sbase + (long)min(s, ns - 1) * p.C);
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
         y4[q] = *reinterpret_cast<const float4*>(p.y + attn_qrow(p, b, q) * p.A + (a_ok ? col : 0));
     float4 v4 = *reinterpret_cast<const float4*>(p.v + (a_ok ? col : 0));
     if (!a_ok) v4 = zero4;
     const float bias = p.bias ? p.bias[0] : 0.0f;
+#pragma unroll
+    for (int s = 0; s < ROWS; ++s)
+        hfr[s] = *reinterpret_cast<const float4*>(hbase + (long)min(s, ns - 1) * p.A);
+#pragma unroll
+    for (int s = 0; s < ROWS; ++s)
+        str[s] = *reinterpret_cast<const float4*>(sbase + (long)min(s, ns - 1) * p.C);
 
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
+    for (int s = 0; s < ROWS; ++s) {
 #pragma unroll
-        for (int s = 0; s < ROWS; ++s) {
+        for (int q = 0; q < NQ; ++q) {
             float part = v4.x * nm_tanh(hfr[s].x + y4[q].x) + v4.y * nm_tanh(hfr[s].y + y4[q].y) +
                          v4.z * nm_tanh(hfr[s].z + y4[q].z) + v4.w * nm_tanh(hfr[s].w + y4[q].w);
-            part = nm_wave_sum(part);
+            part = nm_wave_sum_dpp(part);
             if (lane == 0) pe[wave][q][s] = part;
         }
     }

@@ -518,8 +518,18 @@ extern "C" int nm_attn_energy_bwd(void* stream, const float* de, const float* hf
     hipStream_t st = nm_stream(stream);
     const dim3 grid(nm_cdiv(A, 128), (unsigned)B);
     // positions per register chunk: the smallest chunk that covers S in ceil(S/16) passes (S=50 -> 4 x 13)
-    const int passes = (int)nm_cdiv(S, 16);
-    const int sch = S <= 8 ? 8 : (int)nm_cdiv(S, passes);
+    // ... and up to 32 positions per pass while two waves per SIMD still fit their registers (<= 176 VGPRs, no
+    // scratch; 40 and more spill): S = 50 runs 2 x 25 instead of 4 x 13 -- every query row y[t] is loaded twice
+    // instead of four times, dy[t] is read-modified-written once instead of three times, and 25 independent tanh
+    // per query hide the next query's load
+    static const bool wide_off = getenv("NM_AEB_WIDE") && atoi(getenv("NM_AEB_WIDE")) == 0;
+    int sch;
+    if (S <= 8) sch = 8;
+    else if (wide_off || S <= 16) sch = (int)nm_cdiv(S, nm_cdiv(S, 16));
+    else {
+        const int want = (int)nm_cdiv(S, nm_cdiv(S, 32));
+        sch = want <= 20 ? 20 : want <= 24 ? 24 : want <= 26 ? 26 : want <= 28 ? 28 : 32;
+    }
 #define NM_AEB(SCH_)                                                                                       \
     case SCH_:                                                                                             \
         hipLaunchKernelGGL(attn_energy_bwd_kernel<SCH_>, grid, dim3(128), 0, st, de, hf, y, v, dhf,        \
@@ -527,6 +537,7 @@ extern "C" int nm_attn_energy_bwd(void* stream, const float* de, const float* hf
         break;
     switch (sch) {
         NM_AEB(8) NM_AEB(9) NM_AEB(10) NM_AEB(11) NM_AEB(12) NM_AEB(13) NM_AEB(14) NM_AEB(15)
+        NM_AEB(20) NM_AEB(24) NM_AEB(26) NM_AEB(28) NM_AEB(32)
         default:
             hipLaunchKernelGGL(attn_energy_bwd_kernel<16>, grid, dim3(128), 0, st, de, hf, y, v, dhf, dv_partial,
                                dy, (int)T, (int)B, (int)S, (int)A, accumulate);

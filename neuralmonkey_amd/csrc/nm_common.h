@@ -50,6 +50,32 @@ __device__ __forceinline__ float nm_wave_max(float v) {
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
     return v;
 }
+// Wave reductions on the DPP crossbar instead of ds_bpermute (what __shfl_xor lowers to: an LDS-pipe round trip per
+// step, six dependent ones per reduction).  quad_perm x2 -> row_half_mirror -> row_mirror leave every lane with the
+// sum of its row of 16; row_bcast:15 / row_bcast:31 carry the rows' sums up to lane 63; v_readlane hands the total
+// to every lane.  ONLY for call sites where all 64 lanes are active (EXEC full).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float nm_dpp(float old, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float nm_wave_sum_dpp(float v) {
+    v += nm_dpp<0xB1, 0xf>(0.0f, v);            // quad_perm [1,0,3,2]
+    v += nm_dpp<0x4E, 0xf>(0.0f, v);            // quad_perm [2,3,0,1]
+    v += nm_dpp<0x141, 0xf>(0.0f, v);           // row_half_mirror
+    v += nm_dpp<0x140, 0xf>(0.0f, v);           // row_mirror
+    v += nm_dpp<0x142, 0xa>(0.0f, v);           // row_bcast:15 -> rows 1, 3
+    v += nm_dpp<0x143, 0xc>(0.0f, v);           // row_bcast:31 -> rows 2, 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float nm_wave_max_dpp(float v) {
+    v = fmaxf(v, nm_dpp<0xB1, 0xf>(-INFINITY, v));
+    v = fmaxf(v, nm_dpp<0x4E, 0xf>(-INFINITY, v));
+    v = fmaxf(v, nm_dpp<0x141, 0xf>(-INFINITY, v));
+    v = fmaxf(v, nm_dpp<0x140, 0xf>(-INFINITY, v));
+    v = fmaxf(v, nm_dpp<0x142, 0xa>(-INFINITY, v));
+    v = fmaxf(v, nm_dpp<0x143, 0xc>(-INFINITY, v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 // tanh with ~1e-7 absolute error: 1 - 2/(1+exp(2|x|)), sign restored.
 __device__ __forceinline__ float nm_tanh(float x) {
     float ax = fabsf(x);
