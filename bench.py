@@ -391,7 +391,7 @@ def main():
         # rocprofv3 kernel durations of the same launches (committed summaries of separate profiled runs)
         rocprof_us = {}
         for mode in ("cold", "warm", "dirty"):
-            path = os.path.join(ROOT, "profiles", "r02_attn_step_trace_{}_v3.json".format(mode))
+            path = os.path.join(ROOT, "profiles", "r02_attn_step_trace_{}_v4.json".format(mode))
             if os.path.exists(path):
                 with open(path) as fh:
                     rocprof_us[mode] = json.load(fh).get("sum_avg_us")
@@ -421,7 +421,7 @@ def main():
                          "timing": "HIP events on the launch stream (the library's recorder around single calls, one "
                                    "torch.cuda.Event pair -- torch's current stream IS the launch stream -- around the "
                                    "back-to-back sequence); rocprofv3 kernel durations of the same kernel: "
-                                   "profiles/r02_attn_step_trace_{cold,warm,dirty}_v3.json, repeated in "
+                                   "profiles/r02_attn_step_trace_{cold,warm,dirty}_v4.json, repeated in "
                                    "rocprof_kernel_us",
                          "bound": "hbm", "achieved": rot, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (rot / HBM_PEAK_GBPS) if rot else None, "traffic": traffic,
