@@ -477,9 +477,11 @@ __global__ __launch_bounds__(128) void attn_energy_bwd_kernel(
             g_acc[i] = 0.0f;
             z_acc[i] = 0.0f;
         }
+        float yy_next = y[(long)b * A + a];                   // query slice of t = 0; the next one is requested a step ahead
         for (int t = 0; t < T; ++t) {
             const long row = (long)t * B + b;
-            const float yy = y[row * A + a];
+            const float yy = yy_next;
+            if (t + 1 < T) yy_next = y[(row + B) * A + a];
             const float* der = de + row * S + s0;
             float dsum = 0.0f;
 #pragma unroll

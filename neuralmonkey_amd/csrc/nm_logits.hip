@@ -101,7 +101,8 @@ __global__ void greedy_update_kernel(const int* __restrict__ argmax, int* __rest
     finished[i] = f;
     sym_out[i] = s;
     if (mask_out) mask_out[i] = !f;
-    if (all_finished && !f) atomicAnd(all_finished, 0);
+    if (all_finished && !f) *all_finished = 0;       // (a plain store: every writer writes the same 0 --
+                                                       //  640 atomics on one word were ~8 us of a beam step)
 }
 
 extern "C" int nm_greedy_update(void* stream, const int32_t* argmax, int32_t* finished, int32_t* sym_out,
@@ -451,7 +452,28 @@ __global__ __launch_bounds__(64) void beam_topk_final(const float* __restrict__ 
                                 int* __restrict__ all_finished) {
     __shared__ float fs[K];
     __shared__ int fi[K];
+    __shared__ float cs[256];
+    __shared__ int ci[256];
     const int b = blockIdx.x, lane = threadIdx.x;
+    const int ncand = nslice * K;
+    if (ncand <= 256) {
+        // few lists (the tile-scan path leaves k of them): no merge tree -- every candidate counts how many of the
+        // others beat it ((score desc, flat index asc) is a strict order over distinct indices) and drops itself
+        // into that slot.  A few hundred broadcast LDS reads instead of six dependent butterfly rounds.
+        for (int c = lane; c < ncand; c += 64) {
+            cs[c] = part_score[(long)b * ncand + c];
+            ci[c] = part_idx[(long)b * ncand + c];
+        }
+        __syncthreads();
+        for (int c = lane; c < ncand; c += 64) {
+            const float sc = cs[c];
+            const int ic = ci[c];
+            int rank = 0;
+            for (int j = 0; j < ncand; ++j) rank += cand_better(cs[j], ci[j], sc, ic) ? 1 : 0;
+            if (rank < K && ic != 0x7fffffff) { fs[rank] = sc; fi[rank] = ic; }
+        }
+        __syncthreads();
+    } else {
     float s[K];
     int ix[K];
 #pragma unroll
@@ -472,6 +494,7 @@ __global__ __launch_bounds__(64) void beam_topk_final(const float* __restrict__ 
         for (int p = 0; p < K; ++p) { fs[p] = s[p]; fi[p] = ix[p]; }
     }
     __syncthreads();
+    }
     if (lane < k) {
         const int p = lane;
         const int flat = fi[p];
@@ -489,7 +512,7 @@ __global__ __launch_bounds__(64) void beam_topk_final(const float* __restrict__ 
         const int nf = fin | (v == end_id);
         out_finished[o] = nf;
         out_src_row[o] = r;
-        if (all_finished && !nf) atomicAnd(all_finished, 0);
+        if (all_finished && !nf) *all_finished = 0;     // plain store, see nm_greedy_update
     }
 }
 
@@ -839,7 +862,8 @@ __global__ __launch_bounds__(256) void greedy_finish_kernel(const float4* __rest
         finished[r] = f;
         sym_out[r] = s;
         if (mask_out) mask_out[r] = !f;
-        if (all_finished && !f) atomicAnd(all_finished, 0);
+        if (all_finished && !f) *all_finished = 0;       // (a plain store: every writer writes the same 0 --
+                                                       //  640 atomics on one word were ~8 us of a beam step)
         if (argmax_out) argmax_out[r] = A;
         if (max_out) max_out[r] = M;
         if (lse_out) lse_out[r] = lse;
@@ -979,14 +1003,18 @@ __global__ __launch_bounds__(256) void beam_tile_scan_kernel(const float* __rest
 #pragma unroll
     for (int p = 0; p < K; ++p) { s[p] = -INFINITY; ix[p] = 0x7fffffff; }
     if (!overflow) {
-        if (wave == 0) {
-            const int ncand = cand_n;
-            for (int c = lane; c < ncand; c += 64) topk_insert<K>(s, ix, cand_s[c], cand_i[c]);
-            topk_wave_merge<K>(s, ix);
-            if (lane == 0) {
-#pragma unroll
-                for (int p = 0; p < K; ++p) { part_score[(long)r * K + p] = s[p]; part_idx[(long)r * K + p] = ix[p]; }
-            }
+        // the survivors (<= 256, one per thread) rank themselves: the slot of a candidate is the number of
+        // candidates that beat it; slots beyond the survivors are padded by the threads that hold none
+        const int ncand = cand_n;
+        if (tid < ncand) {
+            const float sc = cand_s[tid];
+            const int ic = cand_i[tid];
+            int rank = 0;
+            for (int j = 0; j < ncand; ++j) rank += cand_better(cand_s[j], cand_i[j], sc, ic) ? 1 : 0;
+            if (rank < K) { part_score[(long)r * K + rank] = sc; part_idx[(long)r * K + rank] = ic; }
+        } else if (tid < K) {
+            part_score[(long)r * K + tid] = -INFINITY;
+            part_idx[(long)r * K + tid] = 0x7fffffff;
         }
         return;
     }
