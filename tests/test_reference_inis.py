@@ -95,3 +95,12 @@ def test_coverage_attention_is_a_drop_in_section(ref_root):
     atts = model.runners[0].decoder.attentions
     assert atts and isinstance(atts[0], CoverageAttention) and atts[0].max_fertility == 4
     assert atts[0].name == "attention_sentence_encoder"
+    # the variables the reference's graph would hold for this part (coverage.py:38-46; no attn_bias: the override of
+    # get_energies never touches bias_term), with TensorFlow's shapes
+    model = load_verbatim(ref_root, "bahdanau_coverage", device="cpu")
+    store = model.tf_manager.sessions[0].store
+    mine = {n.split("/", 1)[1]: tuple(store[n].shape) for n in store.names() if n.startswith("attention_sentence_encoder/")}
+    width = atts[0].context_vector_size
+    assert mine == {"Attention/attn_query_projection": (8, width), "attn_key_projection": (width, width),
+                    "attn_similarity_v": (width,), "attn_projection_bias": (width,),
+                    "coverage_matrix": (1, 1, 1, width), "fertility_matrix": (1, 1, width)}
