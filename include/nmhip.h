@@ -112,11 +112,12 @@ int nm_layer_norm_bwd(void* stream, const float* dy, const float* x, const float
 /* ---- Bahdanau attention step: Attention.attention, attention/feed_forward.py:120-166 ------
  * energies + softmax + mask renormalisation (+1e-8) + context, fused; keys of row r are
  * those of sentence r / rows_per_key (beam search without tiling the keys).
- * Split-S: every sentence is scored by several chunk workgroups; at the decoding shapes (one query per sentence, or <= 8 queries per
- * sentence, A, C <= 1024) the workgroup that arrives LAST merges the partials itself (write-through hand-off +
- * one arrival counter per sentence), otherwise a combine kernel follows.  The workspace therefore ends with
- * arrival counters that must be ZERO at launch: zero a workspace once after allocating it -- the kernels leave
- * the counters at zero. */
+ * Dispatch by shape.  One query per sentence, >= 96 sentences, 40..52 positions (the headline decoding step): one
+ * 1024-thread workgroup per sentence does the whole step, nothing is merged afterwards.  Otherwise split-S: every
+ * sentence is scored by several chunk workgroups; with one query per sentence and <= 8 chunks the workgroup that
+ * arrives LAST merges the partials itself (write-through hand-off + one arrival counter per sentence), else a combine
+ * kernel follows (several queries per sentence: beam search).  The workspace therefore ends with arrival counters
+ * that must be ZERO at launch: zero a workspace once after allocating it -- the kernels leave the counters at zero. */
 int64_t nm_attn_workspace_bytes(int64_t R, int64_t S, int64_t C);
 int nm_attn_fwd(void* stream, const float* y, const float* hf, const float* states, const float* mask,
                 const float* v, const float* bias, int64_t R, int64_t rows_per_key, int64_t S,
