@@ -58,3 +58,58 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in re.sub(r"#.*", "", src).replace('"""', ""), os.path.join(dirpath, f)
+
+
+def _header_struct(name):
+    """[(C type, field)] of ``typedef struct <name> { ... } <name>;`` in include/nmhip.h, in declaration order."""
+    text = open(os.path.join(ROOT, "include", "nmhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), text, flags=re.S).group(1)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        ctype, names = re.match(r"((?:const\s+)?\w+\s*\*?)\s*(.*)", decl, flags=re.S).groups()
+        for item in names.split(","):
+            item = item.strip()
+            fields.append((ctype.strip() + ("*" if item.startswith("*") else ""), item.lstrip("* ")))
+    return fields
+
+
+@pytest.mark.parametrize("cname,pyname", [("nm_step_problem", "StepProblem"), ("nm_decoder_step", "DecoderStep")])
+def test_descriptor_structs_match_the_header(cname, pyname):
+    """The ctypes mirrors of the by-pointer descriptors have the header's fields, order and widths (a drift here is a
+    silent ABI break: every field after it would be read from the wrong offset)."""
+    from neuralmonkey_amd import _lib
+    want = _header_struct(cname)
+    got = getattr(_lib, pyname)._fields_
+    assert [n for _, n in want] == [n for n, _ in got]
+    for (ctype, field), (_, pytype) in zip(want, got):
+        if "*" in ctype:
+            assert pytype is ctypes.c_void_p, field
+        elif ctype.endswith("int64_t"):
+            assert ctypes.sizeof(pytype) == 8, field
+        elif ctype.endswith("int32_t"):
+            assert ctypes.sizeof(pytype) == 4, field
+        else:
+            raise AssertionError("unexpected field type {} {}".format(ctype, field))
+
+
+@pytest.mark.parametrize("cname", ["nm_step_problem", "nm_decoder_step"])
+def test_kernel_side_structs_match_the_header(cname):
+    """csrc/nm_step.hip re-declares the descriptors it receives by pointer: field for field the header's."""
+    text = open(os.path.join(ROOT, "neuralmonkey_amd", "csrc", "nm_step.hip")).read()
+    text = re.sub(r"//[^\n]*", "", text)
+    body = re.search(r"struct %s \{(.*?)\};" % cname, text, flags=re.S).group(1)
+    mine = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        ctype, names = re.match(r"((?:const\s+)?\w+\s*\*?)\s*(.*)", decl, flags=re.S).groups()
+        for item in names.split(","):
+            item = item.strip()
+            mine.append((ctype.strip() + ("*" if item.startswith("*") else ""), item.lstrip("* ")))
+    norm = lambda fields: [(t.replace(" ", ""), n) for t, n in fields]
+    assert norm(mine) == norm(_header_struct(cname))
