@@ -77,7 +77,8 @@ def _header_struct(name):
     return fields
 
 
-@pytest.mark.parametrize("cname,pyname", [("nm_step_problem", "StepProblem"), ("nm_decoder_step", "DecoderStep")])
+@pytest.mark.parametrize("cname,pyname", [("nm_step_problem", "StepProblem"), ("nm_decoder_step", "DecoderStep"),
+                                          ("nm_gru_epilogue", "GruEpilogue")])
 def test_descriptor_structs_match_the_header(cname, pyname):
     """The ctypes mirrors of the by-pointer descriptors have the header's fields, order and widths (a drift here is a
     silent ABI break: every field after it would be read from the wrong offset)."""
