@@ -102,6 +102,10 @@ class Attention(BaseAttention):
             return None
         nchunk, pctx_off, pstat_off = lay
         ws = ctx.buffer((id(self), "ws", rows), ((ops._lib.load().nm_attn_workspace_bytes(rows, slen, c) + 3) // 4,), zero_init=True)
+        # the arrival counters of the in-kernel merge (workspace tail) must be zero when a step is launched; the
+        # merging workgroup restores the zero, but an aborted launch or a failed capture would leave them counting
+        # and every later merge silently skipped -- one small memset per decoding run makes that self-healing
+        ws[-(((rows + 3) // 4) * 4):].zero_()
         return {"ws": ws, "nchunk": nchunk, "energies": ws[:rows * slen].view(rows, slen),
                 "pctx": ws[pctx_off:pctx_off + rows * nchunk * c], "pstat": ws[pstat_off:pstat_off + rows * nchunk * 4],
                 "S": slen, "C": c, "Bk": bk}

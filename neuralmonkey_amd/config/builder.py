@@ -47,6 +47,32 @@ class _Soft:
     on = False
 
 
+# namespaces of the reference's host control plane: only names in here may turn into placeholders
+SOFT_NAMESPACES = frozenset(["evaluators", "processors"])
+
+
+class SymbolNotShipped(Exception):
+    """The dotted name points at a module or attribute this package does not have (as opposed to a shipped
+    module that failed while being imported)."""
+
+
+def resolve_soft(dotted: str) -> Any:
+    """``resolve_symbol`` under a SOFT_MAIN_KEYS key: a class of the reference's evaluators / processors that
+    is not shipped becomes an ``OutOfScope`` placeholder (with a warning naming it); everything else -- other
+    namespaces, import errors inside a shipped module -- raises as usual."""
+    parts = dotted.split(".")
+    namespace = parts[1] if parts[0] == "neuralmonkey" and len(parts) > 1 else parts[0]
+    try:
+        return resolve_symbol(dotted)
+    except SymbolNotShipped as exc:
+        if namespace not in SOFT_NAMESPACES:
+            raise
+        import warnings
+        warnings.warn("{} is not part of this engine (host control plane of the reference): placeholder built "
+                      "({})".format(dotted, exc), stacklevel=2)
+        return None
+
+
 def resolve_symbol(dotted: str) -> Any:
     parts = dotted.split(".")
     attr, module_path = parts[-1], ".".join(parts[:-1])
@@ -61,7 +87,9 @@ def resolve_symbol(dotted: str) -> Any:
     for cand in candidates:
         try:
             module = importlib.import_module(cand)
-        except ImportError as exc:
+        except ModuleNotFoundError as exc:
+            if exc.name is None or not (cand == exc.name or cand.startswith(exc.name + ".")):
+                raise                          # the module exists, something IT imports is missing
             last_exc = exc
             continue
         if parts[0] == "tf":
@@ -72,9 +100,9 @@ def resolve_symbol(dotted: str) -> Any:
         try:
             return getattr(module, attr)
         except AttributeError as exc:
-            raise Exception("Interpretation '{}' as type name, class '{}' does not exist. "
-                            "Did you mean file './{}'? \n{}".format(dotted, attr, dotted, exc))
-    raise Exception("Cannot import module {} ({})".format(module_path, last_exc))
+            raise SymbolNotShipped("Interpretation '{}' as type name, class '{}' does not exist. "
+                                   "Did you mean file './{}'? \n{}".format(dotted, attr, dotted, exc))
+    raise SymbolNotShipped("Cannot import module {} ({})".format(module_path, last_exc))
 
 
 def build_object(value: Any, all_dicts: Dict[str, Any], existing: Dict[str, Any], depth: int) -> Any:
@@ -91,10 +119,8 @@ def build_object(value: Any, all_dicts: Dict[str, Any], existing: Dict[str, Any]
         return value.target
     if isinstance(value, ClassSymbol):
         if _Soft.on:
-            try:
-                return resolve_symbol(value.clazz)
-            except Exception:      # pylint: disable=broad-except
-                return OutOfScope(value.clazz)
+            obj = resolve_soft(value.clazz)
+            return OutOfScope(value.clazz) if obj is None else obj
         return resolve_symbol(value.clazz)
     return value
 
@@ -105,13 +131,13 @@ def instantiate_class(name: str, all_dicts: Dict[str, Any], existing: Dict[str, 
     section = all_dicts[name]
     if "class" not in section:
         raise ConfigInvalidValueException(name, "Undefined object type")
-    try:
+    if _Soft.on:
+        clazz = resolve_soft(section["class"].clazz)
+        if clazz is None:
+            return OutOfScope(section["class"].clazz,
+                              {k: v for k, v in section.items() if k != "class" and isinstance(v, (str, int, float))})
+    else:
         clazz = resolve_symbol(section["class"].clazz)
-    except Exception:              # pylint: disable=broad-except
-        if not _Soft.on:
-            raise
-        return OutOfScope(section["class"].clazz,
-                          {k: v for k, v in section.items() if k != "class" and isinstance(v, (str, int, float))})
     if not isclass(clazz) and not isfunction(clazz):
         raise ConfigInvalidValueException(name, "Cannot instantiate object with '{}'".format(clazz))
     arguments = {key: build_object(val, all_dicts, existing, depth + 1)

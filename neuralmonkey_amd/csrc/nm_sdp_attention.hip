@@ -17,46 +17,7 @@
 // The backward kernel keeps Q, K, V and dctx tiles in LDS: phase 1 (wave per query) produces the
 // energy gradients and dQ, phase 2 (wave per key) reduces dK and dV over the queries -- no atomics,
 // deterministic.
-#include "nm_common.h"
-
-struct SdpArgs {
-    const float* q; long q_bs;        // [Bq, Tq, H*dh], batch stride in floats
-    const float* k; long k_bs;        // [Bk, Tk, H*dh]
-    const float* v; long v_bs;
-    const float* mask; long mask_bs;  // [Bk, Tk] float 0/1 or null
-    float* ctx; long ctx_bs;          // [Bq, Tq, H*dh]
-    float* weights;                   // [Bq, H, Tq, Tk] softmax output (before dropout) or null
-    int Bq, rpk, Tq, Tk, H, dh, causal;
-    float scale, keep_prob, inv_keep;
-    uint32_t salt;
-    const uint32_t* step;             // optional device scalar: salt += step * 0x9E3779B9 (graph replays)
-};
-
-__device__ __forceinline__ uint32_t sdp_mix32(uint32_t x) {
-    x ^= x >> 16;
-    x *= 0x21f0aaadu;
-    x ^= x >> 15;
-    x *= 0x735a2d97u;
-    x ^= x >> 15;
-    return x;
-}
-
-// dropout factor of weight element (b,h,i,j): same counter-based mask as nm_dropout over the
-// flattened [Bq,H,Tq,Tk] tensor
-__device__ __forceinline__ float sdp_keep(const SdpArgs& p, int b, int h, int i, int j) {
-    if (p.keep_prob >= 1.0f) return 1.0f;
-    const uint32_t idx = (uint32_t)((((long)b * p.H + h) * p.Tq + i) * p.Tk + j);
-    const uint32_t salt = p.salt + (p.step ? p.step[0] * 0x9E3779B9u : 0u);
-    const uint32_t bits = sdp_mix32(idx * 0x9E3779B1u + salt);
-    const float uni = (float)(bits >> 8) * (1.0f / 16777216.0f);
-    return (p.keep_prob + uni >= 1.0f) ? p.inv_keep : 0.0f;
-}
-
-__device__ __forceinline__ float sdp_masked_energy(const SdpArgs& p, float e, int i, int j, float m) {
-    if (p.causal && j > i + p.Tk - p.Tq) e = -1e9f;
-    if (p.mask) e = e * m + (1.0f - m) * -1e9f;
-    return e;
-}
+#include "nm_sdp.h"
 
 __global__ __launch_bounds__(256) void sdp_fwd_kernel(SdpArgs p) {
     extern __shared__ float sm[];
@@ -157,6 +118,9 @@ extern "C" int nm_sdp_attn_fwd(void* stream, const float* q, int64_t q_bs, const
     p.causal = causal;
     p.scale = 1.0f / sqrtf((float)dh);
     p.keep_prob = keep_prob; p.inv_keep = 1.0f / keep_prob; p.salt = salt; p.step = step;
+    if (nm_sdp_mfma_fwd(p, nm_stream(stream))) {      // training / encoding shapes: matrix cores (nm_sdp_mfma.hip)
+        NM_LAUNCH_CHECK("nm_sdp_attn_fwd (mfma)");
+    }
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)sdp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -169,16 +133,6 @@ extern "C" int nm_sdp_attn_fwd(void* stream, const float* q, int64_t q_bs, const
 // ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
-struct SdpBwdArgs {
-    SdpArgs f;                 // forward arguments (q, k, v, mask, weights = saved softmax output)
-    const float* dctx; long dctx_bs;
-    float* dq; long dq_bs;     // written
-    float* dk; long dk_bs;     // written (or accumulated when f.rpk > 1 is not supported: rpk must be 1)
-    float* dv; long dv_bs;
-    float* de;                 // workspace [Bq, H, Tq, Tk]: energy gradients
-    int accumulate;            // dq/dk/dv += instead of =
-};
-
 // WLDS: the [Tq,Tk] energy-gradient and dropped-weight matrices of the head stay in LDS between the
 // two phases (phase 2 walks them by columns); otherwise they go through global memory.
 template <bool WLDS>
@@ -306,6 +260,9 @@ extern "C" int nm_sdp_attn_bwd(void* stream, const float* q, int64_t q_bs, const
     p.keep_prob = keep_prob; p.inv_keep = 1.0f / keep_prob; p.salt = salt; p.step = step;
     a.dctx = dctx; a.dctx_bs = dctx_bs; a.dq = dq; a.dq_bs = dq_bs; a.dk = dk; a.dk_bs = dk_bs;
     a.dv = dv; a.dv_bs = dv_bs; a.de = de_workspace; a.accumulate = accumulate;
+    if (nm_sdp_mfma_bwd(a, nm_stream(stream))) {
+        NM_LAUNCH_CHECK("nm_sdp_attn_bwd (mfma)");
+    }
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)sdp_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -476,12 +476,18 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
         # fast path: max / argmax of every vocabulary tile come out of the logits GEMM's epilogue and
         # nm_greedy_finish turns them into the step's symbols, flags and the next input embedding -- the
         # [B,V] logits are neither re-read nor (unless a runner or the runtime loss wants them) written
-        use_stats = graph_ok and self.logits_stats_ok(ctx, out_all[0])
+        # (not when the loop runs in train mode with input dropout: nm_greedy_finish gathers the next input
+        # embedding straight from the table, embed_input_symbols applies the dropout of autoregressive.py:199-214)
+        drops = bool(ctx.fed(self.train_mode)) and self.dropout_keep_prob < 1.0
+        use_stats = graph_ok and not drops and self.logits_stats_ok(ctx, out_all[0])
         stats = ctx.buffer(key + ("stats",), (ops.logits_stats_numel(bsz, v),)) if use_stats else None
         table = self.embedding_matrix(ctx)
 
         resident = getattr(stepper, "state_resident", False)     # the stepper keeps h_t in its own input row
-        h_prev_of = lambda t: s0 if t == 0 else (None if resident else s_all[t - 1])
+        # (a resident stepper gets its OWN state row back for t > 0: step() then neither copies nor looks at the
+        # initial state start() left pending -- a chunk captured later than chunk 0, whose Python body no longer
+        # runs once it is a graph, must not bake a reset to s0 into its graph)
+        h_prev_of = lambda t: s0 if t == 0 else (stepper.sel if resident else s_all[t - 1])
 
         def body(t):
             """Step t touches persistent buffers only and depends on nothing but t (graph capturable)."""

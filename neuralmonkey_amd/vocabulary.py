@@ -65,6 +65,8 @@ class Vocabulary:
         # vectorised: one fancy-index lookup for the whole [T,B] block, every sentence cut before its first </s>
         # (the reference appends token by token in Python: 1.5 ms per 128 x 50 batch, a fifth of a decoded batch here)
         arr = np.stack([np.asarray(v) for v in vectors]) if isinstance(vectors, list) else np.asarray(vectors)
+        if arr.shape[0] == 0:                       # a loop that ran zero steps: empty sentences, as the token loop gave
+            return [[] for _ in range(batch_size)]
         arr = arr.reshape(arr.shape[0], batch_size).astype(np.int64, copy=False)
         table = self.__dict__.get("_i2w_array")
         if table is None or len(table) != len(self.index_to_word):

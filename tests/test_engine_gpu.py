@@ -219,3 +219,49 @@ def test_decode_graph_replay_matches_eager_on_fresh_batches(dev):
         got_beam = [[w2i[w] for w in sent] for sent in res[1].outputs["target_beam"]]
         if bres.min_gap > 1e-5:
             assert got_beam == want_beam, "beam mismatch on pass {}".format(i)
+
+
+def test_greedy_chunks_captured_at_different_times_keep_the_state(dev):
+    """the greedy loop runs in chunks of 8 steps, each captured as a HIP graph the second time
+    it is reached.  Batches of one shape whose outputs end inside the first chunk (eager, capture, replay) are
+    followed by outputs that run on: the later chunks are then launched from Python while chunk 0 is a replayed
+    graph whose body no longer runs -- the stepper must not fall back to the initial state it was started
+    with.  Every pass is compared with the oracle, fused step on and off."""
+    import os
+    from neuralmonkey_amd import synthetic
+    vocab, emb, rnn, batch, slen, tmax = 120, 16, 16, 6, 9, 24
+    params = O.init_params(seed=33, vocab_src=vocab, vocab_tgt=vocab, emb=emb, rnn=rnn, std=0.3)
+    spec = O.DecoderSpec(max_output_len=tmax)
+    w2i = None
+    for fused in (True, False):
+        old = os.environ.pop("NM_NO_FUSED_STEP", None)
+        if not fused:
+            os.environ["NM_NO_FUSED_STEP"] = "1"
+        try:
+            model = synthetic.build_translation_model(vocab_src=vocab, vocab_tgt=vocab, emb=emb, rnn=rnn,
+                                                      max_len=tmax, beam_size=3, max_steps=tmax, device=str(dev),
+                                                      with_trainer=False)
+            sess = model.tf_manager.sessions[0]
+            assert sess.use_graphs
+            w2i = model.tgt_vocab._word_to_index
+            lengths = []
+            for i, end_bias in enumerate((50.0, 50.0, 50.0, -1e9, -1e9, 50.0, -1e9)):
+                p = dict(params)
+                b = p["decoder/state_to_word_b"].copy()
+                b[O.END] = end_bias
+                p["decoder/state_to_word_b"] = b
+                sess.store.load_state_dict(p)
+                ds = synthetic.synthetic_dataset(seed=300 + i, batch=batch, src_len=slen, tgt_len=slen, vocab=vocab,
+                                                 ragged=True, with_target=False)
+                src = O.pad_ids([list(s) for s in ds.get_series("source")], tmax)
+                want = O.greedy_tokens(O.decoding_loop(p, spec, O.sentence_encoder(p, src), None, False))
+                res = model.tf_manager.execute(ds, model.greedy_runner.feedables, [model.greedy_runner],
+                                               compute_losses=False)[0]
+                got = [[w2i[w] for w in sent] for sent in res.outputs["target"]]
+                assert got == want, "greedy mismatch on pass {} (fused step {})".format(i, fused)
+                lengths.append(max(len(s) for s in want))
+            assert min(lengths) <= 1 and max(lengths) == tmax
+        finally:
+            os.environ.pop("NM_NO_FUSED_STEP", None)
+            if old is not None:
+                os.environ["NM_NO_FUSED_STEP"] = old

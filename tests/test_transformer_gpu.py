@@ -29,6 +29,15 @@ VOCAB = 40
     (2, 50, 50, 8, 64, False, True, 1.0, 1),
     (6, 1, 11, 4, 16, False, True, 1.0, 3),       # decoding step of a beam (3 rows per sentence)
     (2, 70, 130, 1, 32, False, False, 1.0, 1),    # more keys than one wave pass, no mask
+    # matrix-core kernels (nm_sdp_mfma.hip): head width 16..128, up to 128 positions
+    (128, 50, 50, 8, 64, False, True, 1.0, 1),    # BASELINE configs[4]: encoder self-attention at full size
+    (3, 50, 50, 8, 64, True, True, 0.9, 1),       # decoder self-attention with attention dropout
+    (2, 70, 100, 4, 32, False, True, 1.0, 1),     # two query blocks of 64, 8 key tiles
+    (2, 100, 128, 2, 16, True, False, 0.8, 1),    # narrow heads, the largest tile count
+    (4, 20, 30, 2, 128, False, True, 1.0, 1),     # wide heads
+    (6, 9, 40, 4, 64, False, True, 1.0, 3),       # several query rows per key batch (forward only)
+    (2, 33, 17, 8, 64, True, True, 1.0, 1),       # odd key count (unpaired weight stores), more queries than keys
+    (3, 64, 64, 2, 64, True, True, 0.7, 1),       # exactly full tiles
 ])
 def test_sdp_attention_fwd_bwd(dev, b, tq, tk, heads, dh, causal, masked, keep, rpk):
     from neuralmonkey_amd import ops
