@@ -24,7 +24,9 @@ Prints ONE JSON line (rank 0) with
                      (keys come from HBM); ``achieved`` / ``frac`` are the COLD figures;
   ``roofline_step``  the whole greedy decoder step against its ~165 MB of algorithmic traffic;
   ``cpu_baseline``   torch-CPU / NumPy restatement of the reference's step (NOT TF 1.12 -- TF cannot
-                     be installed here) on a bounded sample, median of 5 after 2 warm-ups.
+                     be installed here) on the headline batch (B=128), median of 3 after 1 warm-up;
+  ``configs``        BASELINE configs[3] (captioning) and configs[4] (Transformer-base) at their own shapes:
+                     training step, greedy and beam-5 decoding, each with its own roofline.
 """
 import argparse
 import ctypes
@@ -40,6 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TF = 157.3      # fp32 matrix peak (v_mfma_f32_32x32x2_f32), same guide
 NUM_BATCHES = 8               # distinct batches rotated through the timed loop
 
 
@@ -58,9 +61,12 @@ def parse():
     ap.add_argument("--vocab", type=int, default=32000)
     ap.add_argument("--beam-batches", type=int, default=4, help="beam-5 decode batches to time (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=16, help="sentences of the CPU baseline's sample")
-    ap.add_argument("--cpu-steps", type=int, default=5, help="timed CPU training steps (after 2 warm-ups)")
+    ap.add_argument("--cpu-batch", type=int, default=128, help="sentences of the CPU baseline's training sample")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU training steps (after 1 warm-up)")
+    ap.add_argument("--cpu-beam-batch", type=int, default=16, help="sentences of the CPU baseline's beam-5 sample")
     ap.add_argument("--no-feed-legs", action="store_true", help="skip the fresh / strings feeding legs")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the legs of BASELINE configs[3] (captioning) and configs[4] (Transformer)")
     return ap.parse_args()
 
 
@@ -82,8 +88,9 @@ def decoder_step_bytes(b, s, h, v):
 def cpu_baseline(args):
     """The reference's step restated for the host CPU at the reference's op granularity (per-step cell /
     attention / projection / logits): training = oracle/torch_ref.py (torch-CPU fp32, autograd), beam-5 =
-    oracle/nm_oracle.py (NumPy).  Bounded sample of the same workload: the same model, lengths and
-    vocabulary on ``--cpu-batch`` sentences; median of ``--cpu-steps`` timed steps after 2 warm-ups."""
+    oracle/nm_oracle.py (NumPy).  Bounded sample of the SAME workload as the GPU leg: the headline batch
+    (``--cpu-batch`` = 128 sentences, all lengths 50, V and H as timed on the GPU), median of ``--cpu-steps``
+    optimizer steps after one warm-up; beam-5 on ``--cpu-beam-batch`` sentences x 50 steps, one pass."""
     from oracle import nm_oracle as O
     from oracle import torch_ref as TR
     h, bsz = args.hidden, args.cpu_batch
@@ -94,15 +101,15 @@ def cpu_baseline(args):
     m = {k: torch.zeros_like(v) for k, v in tp.items()}
     v = {k: torch.zeros_like(x) for k, x in tp.items()}
     times = []
-    for step in range(1, 2 + args.cpu_steps + 1):
+    for step in range(1, 1 + args.cpu_steps + 1):
         t0 = time.perf_counter()
         _, _, _, grads = TR.train_step_grads(tp, src, tgt_tb, l1_weight=0.0, l2_weight=1e-8)
         TR.clip_and_adam(tp, grads, m, v, step, 1.0)
         times.append(time.perf_counter() - t0)
-    sec = float(np.median(times[2:]))
+    sec = float(np.median(times[1:]))
     tokens = bsz * args.length
-    # beam-5 over the full 50 steps (</s> unreachable, as in the GPU leg) on a quarter of the sample
-    bb = max(1, bsz // 4)
+    # beam-5 over the full 50 steps (</s> unreachable, as in the GPU leg)
+    bb = max(1, min(bsz, args.cpu_beam_batch))
     pb = dict(params)
     bias = pb["decoder/state_to_word_b"].copy()
     bias[O.END] = -1e9
@@ -112,11 +119,132 @@ def cpu_baseline(args):
     O.beam_search(pb, O.DecoderSpec(max_output_len=args.length), enc, 5, args.length, 0.6)
     beam_sec = time.perf_counter() - t0
     return {"value": tokens / sec, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "training: {} sentences (B={} of the headline workload, len={} V={} H={}), median of {} "
-                      "optimizer steps after 2 warm-ups, torch-CPU fp32 restatement of the reference step, not "
-                      "TF 1.12; beam-5: {} sentences x {} steps, NumPy restatement, one pass".format(
-                          bsz, bsz, args.length, args.vocab, h, args.cpu_steps, bb, args.length),
+            "sample": "training: the headline batch, B={} sentences x len {} (ragged=False as on the GPU), V={} H={}, "
+                      "median of {} optimizer steps after 1 warm-up, torch-CPU fp32 restatement of the reference "
+                      "step, not TF 1.12; beam-5: {} sentences x {} steps, NumPy restatement, one pass".format(
+                          bsz, args.length, args.vocab, h, args.cpu_steps, bb, args.length),
             "sec_per_step": sec, "beam5_tok_s": bb * args.length / beam_sec, "beam5_sec": beam_sec}
+
+
+def _timed_gpu(fn, warm, reps):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def transformer_leg(args, dev):
+    """BASELINE configs[4]: Transformer-base (6 + 6 layers, d=512, 8 heads, ff 2048, tied embeddings), B=128,
+    len 50, V=32000, beam 5 -- training step, greedy and beam-5 decoding through the key/value cache."""
+    from neuralmonkey_amd import synthetic
+    batch, length, vocab = args.batch, args.length, args.vocab
+    m = synthetic.build_transformer_model(vocab=vocab, max_len=length, max_steps=length, device=dev, seed=1234)
+    tfm = m.tf_manager
+    store = tfm.sessions[0].store
+    synthetic.load_baseline_weights(store, seed=1234, std=0.05)
+    pool = [synthetic.synthetic_dataset(seed=4000 + i, batch=batch, src_len=length, tgt_len=length, vocab=vocab)
+            for i in range(4)]
+    it = iter(range(1 << 30))
+    res = {}
+
+    def train():
+        res["out"] = tfm.execute(pool[next(it) % 4], m.trainer.feedables, [m.trainer], train=True)[0]
+    t_train = _timed_gpu(train, 3, 8)
+    tokens = batch * length
+    flops = synthetic.transformer_train_flops(batch, length, vocab)
+    # decode the full length: with tied embeddings (W = E^T, no bias) </s> cannot be pushed down by a bias, so the
+    # final layer norm gets a large offset along one direction and the </s> embedding points the other way
+    u = torch.zeros(store["decoder/LayerNorm/beta"].shape[0], device=dev)
+    u[0] = 1.0
+    store["decoder/LayerNorm/beta"].copy_(10.0 * u)
+    store["decoder/word_embeddings"][2].copy_(-100.0 * u)
+    dsd = [synthetic.synthetic_dataset(seed=5000 + i, batch=batch, src_len=length, tgt_len=length, vocab=vocab,
+                                       with_target=False) for i in range(2)]
+    out = {}
+    for name, runner in (("greedy", m.greedy_runner), ("beam5", m.beam_runner)):
+        t = _timed_gpu(lambda: tfm.execute(dsd[next(it) % 2], runner.feedables, [runner], compute_losses=False), 2, 3)
+        r = tfm.execute(dsd[0], runner.feedables, [runner], compute_losses=False)[0]
+        steps = max(len(sent) for sent in r.outputs[runner.output_series])
+        out[name] = (t, steps)
+    tf = flops / t_train / 1e12
+    return {"workload": "tests/transformer.ini-shape at the Transformer-base size: 6+6 layers, d=512, 8 heads, ff 2048, "
+                        "tied embeddings, B={}, len={}, V={}, CrossEntropyTrainer(l2=1e-8, clip_norm=1.0) + Adam, "
+                        "weights N(0,0.05), 4 HBM-resident batches in rotation".format(batch, length, vocab),
+            "parameters": int(store.total), "train_ms_per_step": t_train * 1e3, "train_tok_s": tokens / t_train,
+            "loss": res["out"].losses["decoder - cost"],
+            "greedy_ms_per_batch": out["greedy"][0] * 1e3, "greedy_steps": out["greedy"][1],
+            "greedy_tok_s": batch * out["greedy"][1] / out["greedy"][0],
+            "beam5_ms_per_batch": out["beam5"][0] * 1e3, "beam5_steps": out["beam5"][1],
+            "beam5_tok_s": batch * out["beam5"][1] / out["beam5"][0],
+            "roofline": {"bound": "mfma", "what": "whole training step: 2 x multiply-adds of every dense product, "
+                                                  "forward + backward (synthetic.transformer_train_flops)",
+                         "flops_per_step": flops, "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": tf / MFMA_F32_PEAK_TF}}
+
+
+def captioning_leg(args, dev, lib):
+    """BASELINE configs[3]: pre-extracted 8x8x2048 maps -> SpatialFiller -> Bahdanau attention over the 64 positions
+    (state 512) -> GRU-512 decoder, B=128, target len 50, V=32000, beam 5."""
+    from neuralmonkey_amd import synthetic
+    batch, length, vocab, shape, asz = args.batch, args.length, args.vocab, (8, 8, 2048), 512
+    m = synthetic.build_captioning_model(vocab=vocab, shape=shape, att_size=asz, max_len=length, max_steps=length,
+                                         device=dev, seed=1234)
+    tfm = m.tf_manager
+    store = tfm.sessions[0].store
+    synthetic.load_baseline_weights(store, seed=1234, std=0.05)
+    pool = [synthetic.synthetic_captioning_dataset(seed=6000 + i, batch=batch, shape=shape, tgt_len=length, vocab=vocab)
+            for i in range(2)]
+    it = iter(range(1 << 30))
+    res = {}
+
+    def train():
+        res["out"] = tfm.execute(pool[next(it) % 2], m.trainer.feedables, [m.trainer], train=True)[0]
+    t_train = _timed_gpu(train, 3, 8)
+    store["decoder/state_to_word_b"][2] = -1e9                   # </s> unreachable: all 50 steps run
+    dsd = [synthetic.synthetic_captioning_dataset(seed=7000 + i, batch=batch, shape=shape, tgt_len=length, vocab=vocab,
+                                                  with_target=False) for i in range(2)]
+    out = {}
+    for name, runner in (("greedy", m.greedy_runner), ("beam5", m.beam_runner)):
+        t = _timed_gpu(lambda: tfm.execute(dsd[next(it) % 2], runner.feedables, [runner], compute_losses=False), 2, 3)
+        r = tfm.execute(dsd[0], runner.feedables, [runner], compute_losses=False)[0]
+        steps = max(len(sent) for sent in r.outputs[runner.output_series])
+        out[name] = (t, steps)
+    # the attention step kernel at this shape (one query per image, 64 positions x 2048 channels), warm, inside an
+    # eagerly launched greedy decode with HIP events around every nm_attn_fwd call
+    sess0 = tfm.sessions[0]
+    graphs_were = sess0.use_graphs
+    sess0.use_graphs = False
+    lib.nm_prof_enable(1)
+    tfm.execute(dsd[0], m.greedy_runner.feedables, [m.greedy_runner], compute_losses=False)
+    torch.cuda.synchronize()
+    lib.nm_prof_enable(0)
+    sess0.use_graphs = graphs_were
+    tot_ms, cnt = ctypes.c_double(0.0), ctypes.c_int64(0)
+    lib.nm_prof_attn_step(ctypes.byref(tot_ms), ctypes.byref(cnt))
+    s, c = shape[0] * shape[1], shape[2]
+    nbytes = attention_step_bytes(batch, s, asz, c)
+    att_us = (tot_ms.value * 1e3 / cnt.value) if cnt.value else None
+    gbps = (nbytes / (att_us * 1e-6) / 1e9) if att_us else None
+    tokens = batch * length
+    return {"workload": "tests/captioning.ini-shape: 8x8x2048 maps (N(0,1) clipped at 0) -> SpatialFiller -> Attention("
+                        "state {}) -> GRU-512 decoder, B={}, target len={}, V={}, CrossEntropyTrainer + Adam".format(
+                            asz, batch, length, vocab),
+            "train_ms_per_step": t_train * 1e3, "train_tok_s": tokens / t_train,
+            "loss": res["out"].losses["decoder - cost"],
+            "greedy_ms_per_batch": out["greedy"][0] * 1e3, "greedy_steps": out["greedy"][1],
+            "greedy_tok_s": batch * out["greedy"][1] / out["greedy"][0],
+            "beam5_ms_per_batch": out["beam5"][0] * 1e3, "beam5_steps": out["beam5"][1],
+            "beam5_tok_s": batch * out["beam5"][1] / out["beam5"][0],
+            "roofline": {"bound": "hbm", "kernel": "nm_attn_fwd at S=64, A={}, C=2048 (one decoding step, warm: the maps "
+                                                   "stay in the Infinity Cache between steps), HIP events on the launch "
+                                                   "stream around single calls (event-pair cost included)".format(asz),
+                         "algorithmic_bytes_per_launch": nbytes, "launch_us": att_us, "launches": cnt.value,
+                         "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": (gbps / HBM_PEAK_GBPS) if gbps else None}}
 
 
 def main():
@@ -425,6 +553,9 @@ def main():
                                    "rocprof_kernel_us",
                          "bound": "hbm", "achieved": rot, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (rot / HBM_PEAK_GBPS) if rot else None, "traffic": traffic,
+                         "traffic_how": "HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                        "passes (gfx950 wide-read correction applied), read from the committed "
+                                        "profiles/attn_step_pmc.json -- NOT counted during this run",
                          "achieved_how": "cold, back to back: {} launches over {} distinct key / value sets (428 MB, "
                                          "round-robin: a set's lines are evicted from L2 and the 256 MB Infinity Cache "
                                          "before its next visit), ONE HIP-event pair on the launch stream around the "
@@ -464,6 +595,16 @@ def main():
                               "achieved": dstep_bytes / (dstep_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS,
                               "unit": "GB/s", "frac": dstep_bytes / (dstep_us * 1e-6) / 1e9 / HBM_PEAK_GBPS},
         }
+        if world == 1 and not args.no_configs:
+            # free the headline model's buffers first: the legs build their own sessions
+            legs = {}
+            for name, fn in (("transformer", lambda: transformer_leg(args, dev)),
+                             ("captioning", lambda: captioning_leg(args, dev, lib))):
+                try:
+                    legs[name] = fn()
+                except Exception as exc:                  # pragma: no cover  (never hide the headline number)
+                    legs[name] = {"error": repr(exc)}
+            line["configs"] = legs
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(args)

@@ -118,3 +118,108 @@ def load_baseline_weights(store, seed: int = 1234, std: float = 0.05) -> None:
         else:
             values[name] = np.zeros(shape, np.float32)
     store.load_state_dict(values)
+
+
+class TransformerModel(NamedTuple):
+    input_sequence: object
+    encoder: object
+    decoder: object
+    beam_decoder: Optional[BeamSearchDecoder]
+    greedy_runner: GreedyRunner
+    beam_runner: Optional[BeamSearchRunner]
+    trainer: object
+    tf_manager: TensorFlowManager
+    vocab: Vocabulary
+
+
+def build_transformer_model(vocab=32000, dim=512, ff=2048, depth=6, heads=8, max_len=50, beam_size=5, max_steps=50,
+                            length_normalization=0.6, l2_weight=1e-8, clip_norm=1.0, with_trainer=True, device=None,
+                            seed=1234) -> TransformerModel:
+    """BASELINE configs[4] (tests/transformer.ini topology at the Transformer-base size): EmbeddedSequence ->
+    TransformerEncoder -> TransformerDecoder with tied embeddings, shared source / target vocabulary."""
+    from .decoders import TransformerDecoder
+    from .encoders import TransformerEncoder
+    from .model.sequence import EmbeddedSequence
+    reset_registry()
+    voc = synthetic_vocabulary(vocab)
+    seq = EmbeddedSequence(name="encoder_input", vocabulary=voc, data_id="source", embedding_size=dim,
+                           max_length=max_len, scale_embeddings_by_depth=True)
+    enc = TransformerEncoder(name="encoder", input_sequence=seq, ff_hidden_size=ff, depth=depth, n_heads=heads)
+    dec = TransformerDecoder(name="decoder", encoders=[enc], vocabulary=voc, data_id="target", ff_hidden_size=ff,
+                             n_heads_self=heads, n_heads_enc=heads, depth=depth, max_output_len=max_len,
+                             embedding_size=dim)
+    bdec = brun = None
+    if beam_size:
+        bdec = BeamSearchDecoder(name="beam_decoder", parent_decoder=dec, beam_size=beam_size, max_steps=max_steps,
+                                 length_normalization=length_normalization)
+        brun = BeamSearchRunner(output_series="target_beam", decoder=bdec, rank=1)
+    grun = GreedyRunner(output_series="target", decoder=dec)
+    trainer = None
+    if with_trainer:
+        from .trainers import CrossEntropyTrainer
+        trainer = CrossEntropyTrainer(decoders=[dec], l2_weight=l2_weight, clip_norm=clip_norm)
+    tfm = TensorFlowManager(num_sessions=1, num_threads=4, device=device, seed=seed)
+    tfm.initialize_sessions()
+    return TransformerModel(seq, enc, dec, bdec, grun, brun, trainer, tfm, voc)
+
+
+def transformer_train_flops(batch, length, vocab=32000, dim=512, ff=2048, depth=6) -> float:
+    """Multiply-add flops (x2) of one training step of the model above, forward + backward = 3 x forward: per layer
+    the four attention projections (8 N d^2), the attention core (4 N T d), the feed-forward block (4 N d ff); the
+    decoder has two attention blocks per layer; the tied vocabulary projection 2 N d V."""
+    n = float(batch * length)
+    att = 8 * n * dim * dim + 4 * n * length * dim
+    ffn = 4 * n * dim * ff
+    fwd = depth * (att + ffn) + depth * (2 * att + ffn) + 2 * n * dim * vocab
+    return 3.0 * fwd
+
+
+class CaptioningModel(NamedTuple):
+    encoder: object
+    attention: Attention
+    decoder: Decoder
+    beam_decoder: Optional[BeamSearchDecoder]
+    greedy_runner: GreedyRunner
+    beam_runner: Optional[BeamSearchRunner]
+    trainer: object
+    tf_manager: TensorFlowManager
+    vocab: Vocabulary
+
+
+def build_captioning_model(vocab=32000, shape=(8, 8, 2048), att_size=512, emb=512, rnn=512, max_len=50, beam_size=5,
+                           max_steps=50, length_normalization=0.6, l2_weight=1e-8, clip_norm=1.0, with_trainer=True,
+                           device=None, seed=1234) -> CaptioningModel:
+    """BASELINE configs[3] (tests/captioning.ini topology): pre-extracted convolutional maps -> SpatialFiller ->
+    Bahdanau attention over the 64 positions -> attention GRU decoder."""
+    from .encoders import SpatialFiller
+    reset_registry()
+    voc = synthetic_vocabulary(vocab)
+    enc = SpatialFiller(name="image_encoder", input_shape=list(shape), data_id="images")
+    att = Attention(name="attention", encoder=enc, state_size=att_size)
+    dec = Decoder(encoders=[enc], vocabulary=voc, data_id="target", name="decoder", max_output_len=max_len,
+                  embedding_size=emb, rnn_size=rnn, attentions=[att])
+    bdec = brun = None
+    if beam_size:
+        bdec = BeamSearchDecoder(name="beam_decoder", parent_decoder=dec, beam_size=beam_size, max_steps=max_steps,
+                                 length_normalization=length_normalization)
+        brun = BeamSearchRunner(output_series="target_beam", decoder=bdec, rank=1)
+    grun = GreedyRunner(output_series="target", decoder=dec)
+    trainer = None
+    if with_trainer:
+        from .trainers import CrossEntropyTrainer
+        trainer = CrossEntropyTrainer(decoders=[dec], l2_weight=l2_weight, clip_norm=clip_norm)
+    tfm = TensorFlowManager(num_sessions=1, num_threads=4, device=device, seed=seed)
+    tfm.initialize_sessions()
+    return CaptioningModel(enc, att, dec, bdec, grun, brun, trainer, tfm, voc)
+
+
+def synthetic_captioning_dataset(seed=1234, batch=128, shape=(8, 8, 2048), tgt_len=50, vocab=32000,
+                                 with_target=True) -> Dataset:
+    """Maps N(0,1) clipped at zero; targets as in ``synthetic_ids``."""
+    rng = np.random.default_rng(seed)
+    maps = np.maximum(rng.standard_normal((batch,) + tuple(shape), dtype=np.float32), 0.0)
+    series = {"images": list(maps)}
+    if with_target:
+        tgt = rng.integers(4, vocab, size=(batch, tgt_len - 1)).astype(np.int32)
+        series["target"] = list(tgt)
+    return Dataset("synthetic_captions", series, BatchingScheme(batch_size=batch))

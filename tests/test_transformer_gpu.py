@@ -100,7 +100,8 @@ def test_position_signal_matches_the_reference_formula(dev):
 
 
 # ------------------------------------------------------------------------------------------- models
-def _build(dev, cfg: TRF.TConfig, d, ff, max_len=8, beam=3, seed=7, init_std=0.4, vocab_size=VOCAB):
+def _build(dev, cfg: TRF.TConfig, d, ff, max_len=8, beam=3, seed=7, init_std=0.4, vocab_size=VOCAB,
+           beam_steps=None):
     from neuralmonkey_amd.decoders import BeamSearchDecoder, TransformerDecoder
     from neuralmonkey_amd.encoders import TransformerEncoder
     from neuralmonkey_amd.model.sequence import EmbeddedSequence
@@ -125,7 +126,7 @@ def _build(dev, cfg: TRF.TConfig, d, ff, max_len=8, beam=3, seed=7, init_std=0.4
                              self_attention_dropout_keep_prob=cfg.self_att_dropout,
                              attention_dropout_keep_prob=cfg.encdec_att_dropout,
                              use_att_transform_bias=cfg.use_att_transform_bias, supress_unk=cfg.supress_unk)
-    bdec = BeamSearchDecoder(name="beam_decoder", parent_decoder=dec, beam_size=beam, max_steps=max_len,
+    bdec = BeamSearchDecoder(name="beam_decoder", parent_decoder=dec, beam_size=beam, max_steps=beam_steps or max_len,
                              length_normalization=0.6)
     trainer = CrossEntropyTrainer(decoders=[dec], l2_weight=0.0, clip_norm=None)
     tfm = TensorFlowManager(num_sessions=1, num_threads=1, device=str(dev), seed=seed)
