@@ -23,6 +23,22 @@ extern "C" {
 
 const char* nm_last_error(void);
 int nm_version(void);
+
+/* ---- library contexts (nm_create / nm_destroy; the reference's counterpart is the tf.Session a
+ * TensorFlowManager owns, tf_manager.py:78-79) -----------------------------------------------------------------
+ * A context owns everything the library keeps between calls: the NM_* A/B and tuning switches (read from the
+ * environment once, in nm_create), the HIP-event pool of the live attention-step timer, the device it was made
+ * for.  nm_ctx_bind makes a context current for the CALLING THREAD; entry points called from that thread use
+ * it.  A thread that never bound one uses the process default context (created on first use, never destroyed).
+ * Handles are opaque; device = -1 takes the current HIP device. */
+typedef void nm_ctx;
+int nm_create(int device, nm_ctx** out_ctx);
+int nm_destroy(nm_ctx* ctx);
+int nm_ctx_bind(nm_ctx* ctx /* NULL: back to the default context */);
+nm_ctx* nm_ctx_current(void);
+int nm_ctx_device(nm_ctx* ctx /* NULL: the calling thread's */);
+/* value of a switch as the context read it at creation: NM_ATTN_WHOLE -> "attn_whole" (-1 = unset) ... */
+int nm_ctx_switch(nm_ctx* ctx, const char* name, int* value);
 /* host utility: CRC-32C (Castagnoli) of a HOST buffer, chained through `crc` (start with 0) -- the
  * checksum of TensorFlow tensor-bundle checkpoints (tf_manager.py:274-288 -> tf.train.Saver) */
 uint32_t nm_crc32c(uint32_t crc, const void* data, int64_t n);
@@ -143,9 +159,10 @@ int nm_attn_energy_bwd(void* stream, const float* de, const float* hf, const flo
 int nm_attn_softmax_fwd(void* stream, const float* e, const float* mask, float* w, int64_t rows, int64_t B,
                         int64_t S, int64_t rows_per_key);
 /* live HIP-event timing of one attention step = everything nm_attn_fwd launches (split-S partial kernel +
- * combine), events recorded on the launch stream (bench.py roofline) */
-int nm_prof_enable(int on);
-int nm_prof_attn_step(double* total_ms, int64_t* count);
+ * combine), events recorded on the launch stream (bench.py roofline); the recorder belongs to the context: launches
+ * made by threads bound to other contexts are not seen */
+int nm_prof_enable(nm_ctx* ctx /* NULL: the calling thread's context */, int on);
+int nm_prof_attn_step(nm_ctx* ctx, double* total_ms, int64_t* count);
 /* yardstick for that timing: a plain streaming read (float4 loads, one partial sum per workgroup into
  * sink[0..2047]) of `bytes` bytes, timed by the same event pool when profiling is enabled */
 int nm_prof_stream_read(void* stream, const void* src, int64_t bytes, float* sink);

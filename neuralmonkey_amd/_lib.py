@@ -40,8 +40,14 @@ SIGNATURES = {
     "nm_gru_rh_seq": (I, [P, P, P, P, P, I, L, L, I, L]),
     "nm_gru_gemm": (I, [P, P, I, L, P, L, L, P, L, L]),
     "nm_gru_seq_fwd": (I, [P, P, ctypes.c_int32, L, L, L, L, P, L, L, P, L, L, P, L]),
-    "nm_prof_enable": (I, [I]),
-    "nm_prof_attn_step": (I, [P, P]),
+    "nm_create": (I, [I, P]),
+    "nm_destroy": (I, [P]),
+    "nm_ctx_bind": (I, [P]),
+    "nm_ctx_current": (P, []),
+    "nm_ctx_device": (I, [P]),
+    "nm_ctx_switch": (I, [P, c_char_p, P]),
+    "nm_prof_enable": (I, [P, I]),
+    "nm_prof_attn_step": (I, [P, P, P]),
     "nm_row_stats": (I, [P, P, L, L, L, P, P, P]),
     "nm_greedy_update": (I, [P, P, P, P, P, L, I, P]),
     "nm_xent": (I, [P, P, L, L, L, P, P, P, P, I, F]),

@@ -29,45 +29,6 @@
 
 #define ATT_MAX_SCH 16
 
-// ---- optional live timing of the attention step (attn_partial* + attn_combine, i.e. everything
-// nm_attn_fwd launches) with HIP events on the launch stream (bench.py's `roofline.achieved`);
-// off by default, zero cost when off.
-static bool g_prof_on = false;
-static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
-static size_t g_prof_used = 0;
-
-extern "C" int nm_prof_enable(int on) {
-    g_prof_on = on != 0;
-    if (g_prof_on) g_prof_used = 0;
-    return NM_OK;
-}
-
-// Sum / count of the recorded attention steps; resets the recorder.
-extern "C" int nm_prof_attn_step(double* total_ms, int64_t* count) {
-    NM_REQUIRE(total_ms && count, "nm_prof_attn_step: null pointer");
-    double tot = 0.0;
-    for (size_t i = 0; i < g_prof_used; ++i) {
-        float ms = 0.0f;
-        if (hipEventSynchronize(g_prof_pool[i].second) != hipSuccess ||
-            hipEventElapsedTime(&ms, g_prof_pool[i].first, g_prof_pool[i].second) != hipSuccess)
-            NM_FAIL(NM_ERR_HIP, "nm_prof_attn_step: event query failed");
-        tot += ms;
-    }
-    *total_ms = tot;
-    *count = (int64_t)g_prof_used;
-    g_prof_used = 0;
-    return NM_OK;
-}
-
-static std::pair<hipEvent_t, hipEvent_t>* prof_next_pair() {
-    if (g_prof_used == g_prof_pool.size()) {
-        hipEvent_t a, b;
-        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return nullptr;
-        g_prof_pool.emplace_back(a, b);
-    }
-    return &g_prof_pool[g_prof_used++];
-}
-
 // Yardstick for the timing above: the same number of bytes read by the simplest possible kernel (16-byte loads,
 // four in flight per lane, 2048 workgroups), timed through the same event pool.
 __global__ __launch_bounds__(256) void stream_read_kernel(const float4* __restrict__ src, long n4, float* __restrict__ sink) {
@@ -92,7 +53,8 @@ __global__ __launch_bounds__(256) void stream_read_kernel(const float4* __restri
 extern "C" int nm_prof_stream_read(void* stream, const void* src, int64_t bytes, float* sink) {
     NM_REQUIRE(src && sink && bytes >= 16 && nm_aligned16(src), "nm_prof_stream_read: bad arguments");
     hipStream_t st = nm_stream(stream);
-    std::pair<hipEvent_t, hipEvent_t>* prof = g_prof_on ? prof_next_pair() : nullptr;
+    NmCtx* const nmc = nm_cur();
+    std::pair<hipEvent_t, hipEvent_t>* prof = nmc->prof_on ? nm_prof_next_pair(nmc) : nullptr;
     if (prof) (void)hipEventRecord(prof->first, st);
     const long n4 = (long)(bytes / 16);
     const unsigned blocks = (unsigned)(n4 >= 2048L * 256 ? 2048 : (n4 + 255) / 256);
@@ -739,15 +701,7 @@ __global__ __launch_bounds__(256) void attn_combine(const float* __restrict__ pc
     }
 }
 
-static int attn_max_rows() {
-    static int rows = 0;
-    if (rows == 0) {
-        const char* env = getenv("NM_ATTN_MAXROWS");     // tuning knob, 1..16
-        rows = env ? atoi(env) : 12;
-        if (rows < 1 || rows > ATT_MAX_SCH) rows = 12;
-    }
-    return rows;
-}
+static int attn_max_rows() { return nm_cur()->sw.attn_maxrows; }      // NM_ATTN_MAXROWS, read when the context was made
 
 static void attn_chunking(int64_t S, int* sch, int* nchunk) {
     const int64_t mr = attn_max_rows();
@@ -881,7 +835,7 @@ static int attn_fwd_impl(void* stream, const float* y, const float* hf, const fl
     p.qsb = (int)q_stride_b; p.qsq = (int)q_stride_q; p.nq = (int)nq;
     p.tickets = reinterpret_cast<unsigned*>(p.pstat + R * nchunk * 4);
     p.ctx = ctx; p.ldctx = (long)ldctx; p.weights = weights; p.merge = 0; p.Bk = (int)Bk;
-    static const bool no_merge = getenv("NM_ATTN_NOMERGE") != nullptr;      // A/B switch: separate combine launch
+    const bool no_merge = nm_cur()->sw.attn_nomerge;                        // A/B switch: separate combine launch
     const bool may_merge = do_combine && !no_merge && nchunk <= ATT_MERGE_MAXCH;
     const size_t shm = sizeof(float) * ((size_t)qpk * A + A + (size_t)qpk * ATT_MAX_SCH + ATT_MAX_SCH +
                                         (size_t)4 * qpk * ATT_MAX_SCH);
@@ -894,16 +848,17 @@ static int attn_fwd_impl(void* stream, const float* y, const float* hf, const fl
         if (ncg == 1) hipLaunchKernelGGL((attn_partial<Q_, 1>), grid, block, shm, st, p); \
         else hipLaunchKernelGGL((attn_partial<Q_, 2>), grid, block, shm, st, p);          \
     } while (0)
-    std::pair<hipEvent_t, hipEvent_t>* prof = g_prof_on ? prof_next_pair() : nullptr;
+    NmCtx* const nmc = nm_cur();
+    std::pair<hipEvent_t, hipEvent_t>* prof = nmc->prof_on ? nm_prof_next_pair(nmc) : nullptr;
     if (prof) (void)hipEventRecord(prof->first, st);
-    static const bool no_fast = getenv("NM_ATTN_NOFAST") != nullptr;       // A/B switch for tuning
+    const bool no_fast = nmc->sw.attn_nofast;                              // A/B switch for tuning
     // Whole-sentence workgroups where they were measured faster than split-S + in-kernel merge (HIP events, cold /
     // warm, profiles/r02_attn_whole_vs_split.txt): 128 sentences x 50 positions 20.4 / 16.6 us against 21.4 / 18.7;
     // slower at 64 sentences (13.7 vs 13.2 warm), at 16 (12.8 vs 11.5) and at 30 positions (13.9 vs 13.4), where
     // too few CUs get a workgroup or a workgroup too little to stream.
-    static const char* whole_env = getenv("NM_ATTN_WHOLE");               // A/B switch: 0 off, 1 whenever possible
+    const int whole_sw = nmc->sw.attn_whole;                              // A/B switch: 0 off, 1 whenever possible, -1 unset
     const bool whole = do_combine && nq == 1 && A <= 1024 && C <= 1024 && S <= 4 * ATT_WHOLE_ROWS && !no_fast &&
-                       (whole_env ? atoi(whole_env) != 0 : (Bk >= 96 && S >= 40));
+                       (whole_sw >= 0 ? whole_sw != 0 : (Bk >= 96 && S >= 40));
     if (whole) {
         hipLaunchKernelGGL(attn_whole_fast<ATT_WHOLE_ROWS>, dim3((unsigned)Bk), dim3(1024), 0, st, p);
         if (prof) (void)hipEventRecord(prof->second, st);

@@ -524,7 +524,7 @@ extern "C" int nm_attn_energy_bwd(void* stream, const float* de, const float* hf
     // scratch; 40 and more spill): S = 50 runs 2 x 25 instead of 4 x 13 -- every query row y[t] is loaded twice
     // instead of four times, dy[t] is read-modified-written once instead of three times, and 25 independent tanh
     // per query hide the next query's load
-    static const bool wide_off = getenv("NM_AEB_WIDE") && atoi(getenv("NM_AEB_WIDE")) == 0;
+    const bool wide_off = nm_cur()->sw.aeb_wide_off;                    // NM_AEB_WIDE=0
     int sch;
     if (S <= 8) sch = 8;
     else if (wide_off || S <= 16) sch = (int)nm_cdiv(S, nm_cdiv(S, 16));

@@ -34,6 +34,47 @@ extern thread_local char nm_err_buf[512];
 
 static inline hipStream_t nm_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// ---- library context (nm_create / nm_destroy / nm_ctx_bind, nm_host.hip) -----------------------------------
+// Everything the library keeps between calls lives in a context: the A/B and tuning switches (read from the
+// environment ONCE, when the context is created -- never into function-local statics), the HIP-event pool of the
+// live attention-step timer and the device the context was made for.  Entry points take the context that is
+// bound to the calling thread (nm_ctx_bind); a thread that never bound one uses the process default context,
+// created on first use.
+#include <utility>
+#include <vector>
+
+struct NmSwitches {
+    int attn_maxrows;      // NM_ATTN_MAXROWS   rows per split-S chunk, 1..16 (12)
+    bool attn_nomerge;     // NM_ATTN_NOMERGE   separate combine launch instead of the in-kernel merge
+    bool attn_nofast;      // NM_ATTN_NOFAST    vectorised attention kernels off
+    int attn_whole;        // NM_ATTN_WHOLE     -1 dispatch by measured crossover, 0 never, 1 whenever possible
+    bool aeb_wide_off;     // NM_AEB_WIDE=0     attention energies backward in passes of <= 16 positions
+    bool gemm_no16;        // NM_GEMM_NO16      16x16 skinny tiles off
+    int gemm_swz;          // NM_GEMM_SWZ       XCD-aware tile order (1)
+    bool gemm_nostore;     // NM_GEMM_NOSTORE   timing ablation: results are NOT written
+    int gemm_sk;           // NM_GEMM_SK        split-K override (0 = makespan model)
+    int gemm_cfg;          // NM_GEMM_CFG       tile configuration of the large GEMMs (1)
+    int stats_cfg;         // NM_STATS_CFG      statistics-GEMM tile / prefetch bits (3)
+    bool stats_ablate;     // NM_STATS_ABLATE   timing ablation: statistics epilogue skipped
+    int beam_ns;           // NM_BEAM_NS        slices per hypothesis row override (0 = by vocabulary size)
+    bool sdp_mfma;         // NM_SDP_MFMA=0     matrix-core attention kernels off
+    int medium_m;          // NM_STEP_MEDIUM    medium-M (beam search) step groups: 1 on, 0 off
+};
+
+struct NmCtx {
+    uint32_t magic;
+    int device;
+    NmSwitches sw;
+    bool prof_on;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
+    size_t prof_used;
+};
+
+// the context of the calling thread (never null)
+NmCtx* nm_cur();
+// next free event pair of the context's timer (null if events cannot be created)
+std::pair<hipEvent_t, hipEvent_t>* nm_prof_next_pair(NmCtx* c);
+
 static inline bool nm_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 static inline int nm_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

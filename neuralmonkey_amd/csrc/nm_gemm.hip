@@ -870,7 +870,7 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_fwd_kernel(GruSeq q) {
 // ---------------------------------------------------------------------------
 static void launch_skinny(const GemmArgs& g, int batch, bool tb, const GruEpi& epi, hipStream_t st) {
     const int K = g.K;
-    static const bool no16 = getenv("NM_GEMM_NO16") != nullptr;              // A/B switch for tuning
+    const bool no16 = nm_cur()->sw.gemm_no16;                                // A/B switch for tuning
     if (!no16 && K >= 256 && (long)nm_cdiv(g.M, 32) * nm_cdiv(g.N, 32) * batch < 256) {
         const int tiles_m = nm_cdiv(g.M, 16), tiles_n = nm_cdiv(g.N, 16);
         dim3 grid(tiles_m * tiles_n, 1, (unsigned)batch);
@@ -934,9 +934,10 @@ extern "C" int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int6
     NM_REQUIRE(K > 0, "nm_gemm_f32: K == 0");
     GemmArgs g{A, B, C, bias, (int)M, (int)N, (int)K, (long)lda, (long)ldb, (long)ldc,
                (long)strideA, (long)strideB, (long)strideC, act, accumulate, nullptr, 1, 0, nullptr, 1};
-    static const int swz_env = getenv("NM_GEMM_SWZ") ? atoi(getenv("NM_GEMM_SWZ")) : 1;   // A/B switch
+    const NmSwitches& sw = nm_cur()->sw;
+    const int swz_env = sw.gemm_swz;                                     // A/B switch
     g.swizzle = swz_env;
-    static const bool nostore = getenv("NM_GEMM_NOSTORE") != nullptr;    // timing ablation only: results are NOT written
+    const bool nostore = sw.gemm_nostore;                                // timing ablation only: results are NOT written
     if (nostore) g.store_c = 0;
     hipStream_t st = nm_stream(stream);
     const bool ta = transA != 0, tb = transB != 0;
@@ -972,7 +973,7 @@ extern "C" int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int6
             // the per-CU share of the sustained fp32 MFMA rate (~0.95 us; 64x64: a quarter), few workgroups per
             // CU run below that rate (nothing to hide latencies behind), and the slab reduction streams
             // (sk + 1) M N floats at ~3 TB/s plus a launch.
-            static const int sk_env = getenv("NM_GEMM_SK") ? atoi(getenv("NM_GEMM_SK")) : 0;     // tuning override
+            const int sk_env = sw.gemm_sk;                                                       // tuning override
             const long nkt = (K + 15) / 16;
             const double kt_us = big ? 0.95 : 0.30;
             long best_sk = 1;
@@ -995,7 +996,7 @@ extern "C" int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int6
                 if (algo == 0) pick = big ? 1 : 2;
             }
         }
-        static const int cfg_env = getenv("NM_GEMM_CFG") ? atoi(getenv("NM_GEMM_CFG")) : 1;   // tuning knob (1 measured best)
+        const int cfg_env = sw.gemm_cfg;                                                      // tuning knob (1 measured best)
         if (pick == 1) {
             if (cfg_env == 1) launch_tiled<4, 2, 1, 2, 16>(g, (int)batch, ta, tb, vec, st);        // 128x128, 8 waves
             else if (cfg_env == 3) launch_tiled<4, 4, 1, 1, 32>(g, (int)batch, ta, tb, vec, st);   // 128x128, 16 waves
@@ -1116,8 +1117,7 @@ extern "C" int nm_gru_seq_fwd(void* stream, const nm_gru_epilogue* e, int32_t st
 // M <= 256 -- two independent 8-wave workgroups per CU for a single row of block tiles; measured slower).
 static int stats_cfg() {       // tuning switch, bit 0: 128-wide tiles also for M <= 256, bit 1: loads two k-tiles ahead.
     // measured (gpurun_out r2d sweep, M=128 / 640, us): cfg 0 56.8 / 217, 1 53.7 / 216, 2 53.8 / 209, 3 51.6 / 209
-    static const int c = getenv("NM_STATS_CFG") ? atoi(getenv("NM_STATS_CFG")) : 3;
-    return c;
+    return nm_cur()->sw.stats_cfg;
 }
 extern "C" int64_t nm_logits_stats_tile(int64_t M) { return (M <= 256 && !(stats_cfg() & 1)) ? 64 : 128; }
 
@@ -1143,7 +1143,7 @@ extern "C" int nm_logits_stats_gemm(void* stream, int transB, int64_t M, int64_t
                     "multiples of 4");
     GemmArgs g{A, B, C, bias, (int)M, (int)N, (int)K, (long)lda, (long)ldb, (long)(C ? ldc : 0), 0, 0, 0, 0, 0,
                nullptr, 1, 1, stats, C ? 1 : 0};
-    static const bool ablate = getenv("NM_STATS_ABLATE") != nullptr;
+    const bool ablate = nm_cur()->sw.stats_ablate;
     if (ablate) g.act = 9;
     const int tile = (int)nm_logits_stats_tile(M);
     const int tiles_m = nm_cdiv(M, 128), tiles_n = nm_cdiv(N, tile);

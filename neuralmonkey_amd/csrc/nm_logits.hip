@@ -734,7 +734,7 @@ extern "C" int nm_beam_topk_step(void* stream, const float* logits, int64_t ldx,
     NM_REQUIRE(k * V >= k, "nm_beam_topk_step: fewer candidates than beam");
     NM_REQUIRE(workspace_bytes >= nm_beam_workspace_bytes(B, k, V), "nm_beam_topk_step: workspace too small");
     // ns slices per hypothesis row (>= 4096 candidates each, k*ns <= 64 lists per sentence)
-    static const int ns_env = getenv("NM_BEAM_NS") ? atoi(getenv("NM_BEAM_NS")) : 0;     // tuning override
+    const int ns_env = nm_cur()->sw.beam_ns;                                            // tuning override
     int ns = ns_env > 0 ? ns_env : (int)((V + 4095) / 4096);
     if (ns < 1) ns = 1;
     if (ns > 64 / k) ns = (int)(64 / k);

@@ -176,14 +176,7 @@ static void sdp_fwd_mfma_launch(const SdpArgs& p, hipStream_t stream) {
                        dim3(256), lds, stream, p);
 }
 
-static bool sdp_mfma_enabled() {
-    static int on = -1;
-    if (on < 0) {
-        const char* e = getenv("NM_SDP_MFMA");
-        on = (e && e[0] == '0') ? 0 : 1;
-    }
-    return on == 1;
-}
+static bool sdp_mfma_enabled() { return nm_cur()->sw.sdp_mfma; }       // NM_SDP_MFMA=0: wave-per-query kernels only
 
 static bool sdp_vec_ok(const void* ptr, long bs, long d) { return nm_aligned16(ptr) && (bs & 3) == 0 && (d & 3) == 0; }
 

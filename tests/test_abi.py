@@ -114,3 +114,45 @@ def test_kernel_side_structs_match_the_header(cname):
             mine.append((ctype.strip() + ("*" if item.startswith("*") else ""), item.lstrip("* ")))
     norm = lambda fields: [(t.replace(" ", ""), n) for t, n in fields]
     assert norm(mine) == norm(_header_struct(cname))
+
+
+def test_contexts_own_their_switches_and_timers(lib, monkeypatch):
+    """nm_create reads the NM_* switches ONCE; a later change of the environment is seen by the next context
+    only.  Timer state is per context; the default context cannot be destroyed; a destroyed handle is refused."""
+    def switch(ctx, name):
+        out = ctypes.c_int(12345)
+        assert lib.nm_ctx_switch(ctx, name.encode(), ctypes.byref(out)) == 0, lib.nm_last_error()
+        return out.value
+
+    monkeypatch.delenv("NM_ATTN_WHOLE", raising=False)
+    monkeypatch.delenv("NM_GEMM_SK", raising=False)
+    a = ctypes.c_void_p()
+    assert lib.nm_create(-1, ctypes.byref(a)) == 0 and a.value
+    monkeypatch.setenv("NM_ATTN_WHOLE", "0")
+    monkeypatch.setenv("NM_GEMM_SK", "4")
+    b = ctypes.c_void_p()
+    assert lib.nm_create(0, ctypes.byref(b)) == 0 and b.value and b.value != a.value
+    assert switch(a, "attn_whole") == -1 and switch(a, "gemm_sk") == 0          # read before the change
+    assert switch(b, "attn_whole") == 0 and switch(b, "gemm_sk") == 4
+    assert lib.nm_ctx_device(b) == 0
+    out = ctypes.c_int()
+    assert lib.nm_ctx_switch(a, b"no_such_switch", ctypes.byref(out)) < 0
+
+    default = lib.nm_ctx_current()
+    assert default and default not in (a.value, b.value)
+    assert lib.nm_ctx_bind(b) == 0 and lib.nm_ctx_current() == b.value
+    assert switch(None, "gemm_sk") == 4                                        # NULL = the bound context
+    assert lib.nm_ctx_bind(None) == 0 and lib.nm_ctx_current() == default
+
+    # timers: enabling one context's recorder leaves the other's alone (no GPU: nothing is recorded, counts are 0)
+    tot, cnt = ctypes.c_double(-1.0), ctypes.c_int64(-1)
+    assert lib.nm_prof_enable(a, 1) == 0
+    assert lib.nm_prof_attn_step(b, ctypes.byref(tot), ctypes.byref(cnt)) == 0 and cnt.value == 0
+    assert lib.nm_prof_attn_step(a, ctypes.byref(tot), ctypes.byref(cnt)) == 0 and cnt.value == 0
+    assert lib.nm_prof_enable(a, 0) == 0
+
+    assert lib.nm_destroy(ctypes.c_void_p(default)) < 0 and b"default" in lib.nm_last_error()
+    assert lib.nm_ctx_bind(a) == 0
+    assert lib.nm_destroy(a) == 0                      # unbinds itself
+    assert lib.nm_ctx_current() == default
+    assert lib.nm_destroy(b) == 0

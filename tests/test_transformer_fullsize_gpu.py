@@ -52,38 +52,55 @@ def _feed(m):
 
 
 def test_greedy_and_beam_through_the_cache_match_the_prefix_recompute(world):
+    """Yardstick: the oracle in float64.  Twelve LayerNorm-ed residual blocks amplify fp32 rounding, so next to the
+    engine's distance from the float64 logits the test measures the float32 ORACLE's own distance from them (two
+    fp32 implementations of the same arithmetic cannot be closer to each other than each is to the exact result) and
+    prints both; the engine has to stay within 1e-4 relative or 3x that noise, whichever is larger."""
     m, cfg = world, world["cfg"]
     m["store"].load_state_dict(m["params"])
     sess = m["tfm"].sessions[0]
     plain = TRF.TransformerModel(m["params"], cfg)
-    enc_states, _, _ = plain.encode(m["src"], False)
+    exact = TRF.TransformerModel(m["params"], cfg, dtype=torch.float64)
+    enc_states, _, _ = exact.encode(m["src"], False)
+    enc32, _, _ = plain.encode(m["src"], False)
     fd = _feed(m)
     out = sess.run({"sym": m["dec"].decoded_symbols, "logits": m["dec"].runtime_logits,
                     "enc": m["enc"].temporal_states}, fd)
-    assert np.abs(out["enc"] - enc_states.numpy()).max() <= 1e-4 * np.abs(enc_states.numpy()).max()
-    ref_sym, _, ref_logits = plain.greedy(m["src"], DECODE_STEPS)
+    es = np.abs(enc_states.numpy()).max()
+    enc_err, enc_noise = np.abs(out["enc"] - enc_states.numpy()).max() / es, np.abs(enc32.numpy() - enc_states.numpy()).max() / es
+    print("encoder states vs float64: engine {:.3g}, fp32 oracle {:.3g} (relative to the max)".format(enc_err, enc_noise))
+    assert enc_err <= max(1e-4, 3 * enc_noise)
+    ref_sym, _, ref_logits = exact.greedy(m["src"], DECODE_STEPS)
+    _, _, logits32 = plain.greedy(m["src"], DECODE_STEPS)
     steps = min(len(ref_sym), len(out["sym"]))
     assert steps == DECODE_STEPS
     top2 = np.partition(ref_logits[:steps], VOCAB - 2, axis=-1)[..., -2:]
     safe = np.minimum.accumulate((top2[..., 1] - top2[..., 0]) > NEAR_TIE * np.abs(top2[..., 1]), axis=0)
     assert safe.mean() > 0.9, "too many near-ties in the oracle: {}".format(safe.mean())
     assert np.array_equal(out["sym"][:steps][safe], ref_sym[:steps][safe]), "greedy symbols differ"
-    diff = np.abs(out["logits"][:steps] - ref_logits[:steps]).max(-1)
     scale = np.abs(ref_logits[:steps]).max()
-    print("greedy logits: max |diff| / max |logit| = {:.3g} over decided (sentence, step) pairs".format(
-        float(diff[safe].max() / scale)))
-    assert diff[safe].max() <= 1e-4 * scale
+    err = np.abs(out["logits"][:steps] - ref_logits[:steps]).max(-1)[safe] / scale
+    noise = np.abs(logits32[:steps] - ref_logits[:steps]).max(-1)[safe] / scale
+    print("greedy logits vs float64 over {} decided (sentence, step) pairs, relative to max |logit| = {:.3g}:\n"
+          "  engine      max {:.3g}  median {:.3g}\n  fp32 oracle max {:.3g}  median {:.3g}".format(
+              int(safe.sum()), scale, err.max(), np.median(err), noise.max(), np.median(noise)))
+    assert err.max() <= max(1e-4, 3 * noise.max())
 
-    tok, scores, _ = plain.beam(m["src"], 5, DECODE_STEPS, 0.6)
+    tok, scores, _ = exact.beam(m["src"], 5, DECODE_STEPS, 0.6)
+    gaps = np.stack(exact.beam_gaps)
+    _, scores32, _ = plain.beam(m["src"], 5, DECODE_STEPS, 0.6)
     got = sess.run(m["bdec"].outputs, fd)
     got_tok = np.asarray(got.last_search_step_output.token_ids)
     assert got_tok.shape == tok.shape == (DECODE_STEPS + 1, B, 5)
-    clean = (np.stack(plain.beam_gaps) > NEAR_TIE).all(axis=0)
+    clean = (gaps > NEAR_TIE).all(axis=0)
     print("beam-5: {:.0%} of the sentences are decided by more than {} at every step".format(clean.mean(), NEAR_TIE))
     assert clean.mean() >= 0.7, "too many near-ties in the oracle ({} clean)".format(clean.mean())
     assert np.array_equal(got_tok[1:][:, clean], tok[1:][:, clean]), "beam token ids differ"
     got_scores = np.asarray(got.last_search_step_output.scores)
-    assert np.abs(got_scores[clean] - scores[clean]).max() <= 1e-4 * np.abs(scores[clean]).max()
+    sscale = np.abs(scores[clean]).max()
+    serr, snoise = np.abs(got_scores[clean] - scores[clean]).max() / sscale, np.abs(scores32[clean] - scores[clean]).max() / sscale
+    print("beam scores vs float64: engine {:.3g}, fp32 oracle {:.3g}".format(serr, snoise))
+    assert serr <= max(1e-4, 3 * snoise)
 
 
 def test_training_step_loss_and_every_gradient(world):

@@ -48,11 +48,11 @@ def run(n):
 
 
 run(3)
-lib.nm_prof_enable(1)
+lib.nm_prof_enable(None, 1)
 run(iters)
-lib.nm_prof_enable(0)
+lib.nm_prof_enable(None, 0)
 tot, cnt = ctypes.c_double(0.0), ctypes.c_int64(0)
-lib.nm_prof_attn_step(ctypes.byref(tot), ctypes.byref(cnt))
+lib.nm_prof_attn_step(None, ctypes.byref(tot), ctypes.byref(cnt))
 # reference of the same step in float64 (feed_forward.py:120-166)
 yd, hfd, std = y.double(), hf.double(), st.double()
 e = (v.double() * torch.tanh(hfd.repeat_interleave(qpk, 0) + yd[:, None, :])).sum(-1)
