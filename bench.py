@@ -346,11 +346,44 @@ def main():
         uploader.upload(b)
     for i in range(max(args.warmup, 2)):
         step(pool[i % NUM_BATCHES])
+    if dp:
+        dp.timing = True
+        dp.exchange_report()
     elapsed, res = timed(pool[i % NUM_BATCHES] for i in range(args.steps))
+    dp_report = None
     if dp:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+        dp_report = dp.exchange_report()
+        dp_report["how"] = ("allreduce_exposed_ms: HIP events on rank 0's compute stream around the point where the "
+                            "optimizer has to wait for the gradient collectives (mean over the timed steps) = the part "
+                            "of the exchange that the backward pass did not hide; bytes: flat gradient buffer per "
+                            "step and rank, early_bytes: the spans whose all-reduce starts inside the backward pass")
+
+    # ---- the other scaling mode in the same run (N > 1): BASELINE.json's wording is the STRONG split (one
+    # minibatch of --batch sentences sharded over the GPUs); `value` above is the weak one unless --scaling strong
+    other = None
+    if dp and world > 1 and args.scaling == "weak" and args.batch % world == 0:
+        sb = args.batch // world
+        spool = [synthetic.synthetic_dataset(seed=4321 + 1000 * i + rank, batch=sb, src_len=args.length,
+                                             tgt_len=args.length, vocab=args.vocab, ragged=False)
+                 for i in range(NUM_BATCHES)]
+        for b in spool:
+            uploader.upload(b)
+        for i in range(3):
+            step(spool[i % NUM_BATCHES])
+        t_strong, _ = timed(spool[i % NUM_BATCHES] for i in range(args.steps))
+        t = torch.tensor([t_strong], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        t_strong = float(t.item())
+        rep = dp.exchange_report()
+        other = {"scaling": "strong", "sentences_per_gpu": sb, "global_batch": args.batch,
+                 "ms_per_step": t_strong / args.steps * 1e3,
+                 "value": sb * args.length * world * args.steps / t_strong, "unit": "tokens/s",
+                 "allreduce_exposed_ms": rep["allreduce_exposed_ms"]}
+    if dp:
+        dp.timing = False
 
     # ---- the same step fed from the host inside the timed loop (rank 0 reports; not `value`)
     fresh_ms = strings_ms = None
@@ -539,6 +572,7 @@ def main():
                        "global_batch": args.batch * world, "seq_len": args.length,
                        "parallelism": "dp{}".format(world)},
             "loss": res.losses["decoder - cost"],
+            "dp": dp_report, "other_scaling": other,
             "ms_per_step_fresh": fresh_ms, "ms_per_step_strings": strings_ms,
             "beam5_decode_tok_s": beam_tok_s, "beam5_ms_per_batch": beam_ms_per_batch,
             "greedy_decode_tok_s": tokens_local / (greedy_ms * 1e-3), "greedy_ms_per_batch": greedy_ms,

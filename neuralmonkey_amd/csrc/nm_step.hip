@@ -244,6 +244,126 @@ __global__ __launch_bounds__(KS * 64, AKIND == 0 ? 8 : 4) void step_group_kernel
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Medium M (beam search: batch x beam = 640 hypotheses per step).  At a few hundred rows the 16-row tiles above
+// re-read every weight M/16 times and a group needs thousands of 1024-thread workgroups (measured 52 us per
+// group at 640 rows), while the LDS-tiled GEMMs put ONE 4-wave workgroup on a CU with nothing to hide its
+// global -> LDS -> MFMA chain behind (64x64 tiles: 23.5 us for a 1 GFLOP product = 3.4x its MFMA time).  Here a
+// workgroup owns one 32x32 output tile (v_mfma_f32_32x32x2_f32, exact f32), its KS waves split K, both fragments
+// of a wave arrive as coalesced 128-byte lines through a wave-private LDS tile (no workgroup barrier in the loop),
+// the next trip's lines are requested before the current trip's MFMAs, partial sums meet in LDS.  A group of the
+// 640-row step is 640..1280 workgroups of 4 waves, four of them resident per CU (37 KB LDS each); weights are read
+// M/32 times from L2.  Same problems, epilogues and results as step_group_kernel (a_kind 0).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int KS>
+__global__ __launch_bounds__(KS * 64, 4) void step_group_medium_kernel(StepGroup g) {
+    constexpr int LDT = 36;                                 // tile row stride in floats: 16-byte aligned rows, and the
+                                                            // 16 lanes of a ds_read_b128 group cover all 64 banks
+    __shared__ __attribute__((aligned(16))) float lds[KS * 2 * 32 * LDT];
+    static_assert(KS * 2 * 32 * LDT >= KS * 16 * 64, "the K reduction re-uses the operand tiles");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bid = (int)blockIdx.x;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < NM_STEP_MAX_PROB; ++i)
+        if (i < g.nprob && bid >= g.begin[i]) pi = i;
+    const StepProb& p = g.p[pi];
+    const int tile = bid - g.begin[pi];
+    const int bm = tile % g.tiles_m, bn = tile / g.tiles_m;         // consecutive workgroups share a weight tile
+    const int m0 = bm * 32, n0 = bn * 32;
+    const int N = (int)p.N, K = (int)p.K;
+    // A trip = 32 consecutive k of the wave's K slice = one 128-byte line of each of the 32 + 32 operand rows.  The
+    // lines are fetched COALESCED (8 lanes x 16 bytes per row, 8 rows per instruction) and turned into MFMA fragments
+    // through a wave-private LDS tile: letting every lane fetch its own row (lane = row, as the 16-row kernels above
+    // do) costs one address-unit pass per LANE -- measured 45 us for group 1 of the 640-row step against 13 us of
+    // MFMA time, with either 16 or 64 contiguous bytes per lane and trip.
+    const int kper = ((K / 32 + KS - 1) / KS) * 32;
+    const int kbeg = wave * kper, kend = min(K, kbeg + kper);
+    const int lr = lane >> 3, lq = lane & 7;
+    long aoff[4], boff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        aoff[i] = (long)min(m0 + lr + 8 * i, g.M - 1) * p.lda + 4 * lq;
+        boff[i] = (long)min(n0 + lr + 8 * i, N - 1) * p.ldb + 4 * lq;
+    }
+    float* as = lds + wave * (2 * 32 * LDT);
+    float* bs = as + 32 * LDT;
+    const int m = lane & 31, half = lane >> 5;
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    float4 ra[4], rb[4];
+    auto fetch = [&](int k0) {
+        const bool ok = k0 + 4 * lq < kend;         // K is a multiple of 16: a slice may end in the middle of a trip
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = ok ? *reinterpret_cast<const float4*>(p.A + aoff[i] + k0) : NM_Z4;
+            rb[i] = ok ? *reinterpret_cast<const float4*>(p.Bt + boff[i] + k0) : NM_Z4;
+        }
+    };
+    if (kbeg < kend) fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float4*>(as + (lr + 8 * i) * LDT + 4 * lq) = ra[i];
+            *reinterpret_cast<float4*>(bs + (lr + 8 * i) * LDT + 4 * lq) = rb[i];
+        }
+        __builtin_amdgcn_wave_barrier();             // (LDS operations of one wave complete in order)
+        if (k0 + 32 < kend) fetch(k0 + 32);          // the next trip's lines travel under this trip's MFMAs
+        float4 av[4], bv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {                // lane (m, half): k = k0 + 16 half + 4 c + j
+            av[c] = *reinterpret_cast<const float4*>(as + m * LDT + 16 * half + 4 * c);
+            bv[c] = *reinterpret_cast<const float4*>(bs + m * LDT + 16 * half + 4 * c);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {                // MFMA (c, j): k-slot `half` <-> the same k on both operands
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].x, bv[c].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].y, bv[c].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].z, bv[c].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c].w, bv[c].w, acc, 0, 0, 0);
+        }
+    }
+    __syncthreads();                                 // every wave is done with its tiles: they become the reduction buffer
+    float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(lds);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[wave][i][lane] = acc[i];
+    __syncthreads();
+    // C/D layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5); thread (wq, lane)
+    // finishes registers 4 wq .. 4 wq + 3 of that lane
+    const int wq = tid >> 6;
+    const int col = n0 + (lane & 31);
+    if (wq >= 4 || col >= N) return;                 // (KS > 4: the extra waves only contributed partial sums)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int reg = 4 * wq + q;
+        const int row = m0 + q + 8 * wq + 4 * (lane >> 5);
+        if (row >= g.M) continue;
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < KS; ++w) s += red[w][reg][lane];
+        if (p.epilogue == 0) {
+            float v = s + (p.bias ? p.bias[col] : 0.0f) + (p.add ? p.add[(long)row * p.ldadd + col] : 0.0f);
+            if (p.act == 1) v = nm_tanh(v);
+            p.C[(long)row * p.ldc + col] = v;
+        } else if (p.epilogue == 1) {              // N = 2H: r | u = sigmoid(. + bg); rh = r * h
+            const int H = N >> 1;
+            const float gate = nm_sigmoid(s + p.bias[col]);
+            p.ru[(long)row * N + col] = gate;
+            if (col < H) p.rh[(long)row * H + col] = gate * p.h[(long)row * p.ldh + col];
+        } else {                                   // N = H: c = tanh(xc + .); h' = u*h + (1-u)*c
+            const float c = nm_tanh(p.xc[(long)row * p.ldxc + col] + s);
+            const float u = p.ru[(long)row * 2 * N + N + col];
+            const float hn = u * p.h[(long)row * p.ldh + col] + (1.0f - u) * c;
+            p.h_out[(long)row * p.ldho + col] = hn;
+            if (p.h_out2) p.h_out2[(long)row * p.ldho2 + col] = hn;
+        }
+    }
+}
+
 struct nm_step_problem {          // mirrors include/nmhip.h
     const float* A; int64_t lda;
     const float* Bt; int64_t ldb;
@@ -268,7 +388,11 @@ extern "C" int nm_step_group(void* stream, int64_t M, const nm_step_problem* pro
     // tile height: 16 rows per workgroup while the whole group stays within 512 workgroups (two per CU), else 32
     long tiles16 = 0;
     for (int i = 0; i < nprob; ++i) tiles16 += (long)nm_cdiv(M, 16) * nm_cdiv(probs[i].N, 16);
-    const int tm = (probs[0].a_kind == 0 && tiles16 > 512) ? 2 : 1;
+    // medium M (beam search): 32x32 tiles, 4 waves split K (step_group_medium_kernel); NM_STEP_MEDIUM=0 keeps the
+    // 16-row tiles
+    const bool medium = probs[0].a_kind == 0 && M > 256 && nm_cur()->sw.medium_m != 0;
+    const int tm = medium ? 2 : ((probs[0].a_kind == 0 && tiles16 > 512) ? 2 : 1);
+    const int tile_n = medium ? 32 : 16;
     g.tiles_m = nm_cdiv(M, 16 * tm);
     g.wblocks = (probs[0].a_kind == 1 && probs[0].weights) ? nm_cdiv(M, 16) : 0;
     int next = 0;
@@ -304,7 +428,7 @@ extern "C" int nm_step_group(void* stream, int64_t M, const nm_step_problem* pro
         p.h = q.h; p.ldh = q.ldh; p.ru = q.ru; p.rh = q.rh; p.xc = q.xc; p.ldxc = q.ldxc;
         p.h_out = q.h_out; p.ldho = q.ldho; p.h_out2 = q.h_out2; p.ldho2 = q.ldho2;
         g.begin[i] = next;
-        next += g.tiles_m * nm_cdiv(q.N, 16);
+        next += g.tiles_m * nm_cdiv(q.N, tile_n);
     }
     for (int i = nprob; i <= NM_STEP_MAX_PROB; ++i) g.begin[i] = next;
     for (int i = nprob; i < NM_STEP_MAX_PROB; ++i) g.p[i] = g.p[0];
@@ -312,7 +436,8 @@ extern "C" int nm_step_group(void* stream, int64_t M, const nm_step_problem* pro
         NM_REQUIRE(probs[i].a_kind == probs[0].a_kind, "nm_step_group: the problems of a group share one operand loader");
     hipStream_t st = nm_stream(stream);
     const unsigned grid = (unsigned)(next + g.wblocks);
-    if (probs[0].a_kind == 1) hipLaunchKernelGGL((step_group_kernel<16, 1, 1>), dim3(grid), dim3(1024), 0, st, g);
+    if (medium) hipLaunchKernelGGL((step_group_medium_kernel<4>), dim3(grid), dim3(256), 0, st, g);
+    else if (probs[0].a_kind == 1) hipLaunchKernelGGL((step_group_kernel<16, 1, 1>), dim3(grid), dim3(1024), 0, st, g);
     else if (tm == 2) hipLaunchKernelGGL((step_group_kernel<16, 2, 0>), dim3(grid), dim3(1024), 0, st, g);
     else hipLaunchKernelGGL((step_group_kernel<16, 1, 0>), dim3(grid), dim3(1024), 0, st, g);
     NM_LAUNCH_CHECK("nm_step_group");

@@ -103,6 +103,17 @@ class BeamSearchDecoder(ModelPart):
             for att in dec.attentions:
                 att.rows_per_key = 1
 
+    @tensor
+    def selection_history(self, ctx):
+        """(parent beam [steps,B,k], word [steps,B,k]) of every executed beam body (:481-483): the raw
+        selections the token histories are traced back from -- what a parity check needs to tell a flipped
+        near-tie from a wrong selection."""
+        self.outputs(ctx)
+        src, word, steps, bsz = ctx.memo[(id(self), "_raw_selections")]
+        k = self.beam_size
+        beam = src[:steps].view(steps, bsz, k) - (torch.arange(bsz, device=src.device, dtype=src.dtype) * k).view(1, bsz, 1)
+        return beam, word[:steps].view(steps, bsz, k)
+
     def ensemble_outputs(self, ctxs: List[Any]) -> BeamSearchOutput:
         """Beam search over an ensemble: one run context (= one set of variables) per model, all on
         this device.  Every step each model advances its own decoder state on the SAME hypotheses;
@@ -329,6 +340,7 @@ class BeamSearchDecoder(ModelPart):
         cur = executed & 1                                # buffers the last executed body wrote
         # token histories (:546-551) from the back-pointers, once: out[t+1, r] = word_t[ancestor_t(r)]
         ops.beam_backtrace(src_hist, word_hist, first_sym, tok, executed)
+        ctx.memo[(id(self), "_raw_selections")] = (src_hist, word_hist, steps, bsz)
         token_ids = tok[:steps + 1].view(steps + 1, bsz, k)
         prev_logprobs = None
         search_state = SearchState(lps[cur], prev_logprobs, lens[cur], fin[cur])

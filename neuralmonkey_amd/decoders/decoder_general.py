@@ -382,8 +382,11 @@ class FusedStepper:
         if len(dec.attentions) != 1 or type(dec.attentions[0]) is not Attention:      # pylint: disable=unidiomatic-typecheck
             return None
         e, h = dec.embedding_size, dec.rnn_size
-        if e % 16 or h % 16 or dec.output_dimension % 4 or rows > 256:
-            return None          # (16-row tiles re-read every weight rows/16 times: beyond 256 rows the tiled GEMMs win)
+        # up to 256 rows the groups run on 16-row tiles, above (beam search: batch x beam hypotheses) on 32x32 tiles
+        # (step_group_medium_kernel, csrc/nm_step.hip); NM_STEP_MEDIUM=0 sends those to the six-GEMM stepper
+        limit = 4096 if os.environ.get("NM_STEP_MEDIUM", "1") != "0" else 256
+        if e % 16 or h % 16 or dec.output_dimension % 4 or rows > limit:
+            return None
         return dec.attentions[0].partials_plan(ctx, rows)
 
     def __init__(self, dec, ctx, rows: int, tag: str, plan):

@@ -29,8 +29,19 @@ class DataParallel:
         self.world_size = dist.get_world_size()
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.overlap = os.environ.get("NM_DP_OVERLAP", "1") != "0"
+        # NM_DP_SPARSE_EMB=1: an embedding matrix whose gradient touches only the rows of this rank's tokens travels
+        # as (row ids, rows) instead of as a dense [V, E] slice of the flat buffer (exchange_sparse_rows)
+        self.sparse_embeddings = os.environ.get("NM_DP_SPARSE_EMB", "0") == "1"
+        self._sparse_bufs: dict = {}
+        self.sparse_bytes_per_step = 0
         self._handles: list = []          # collectives in flight this step
         self._early: list = []            # [lo, hi) spans of the flat gradient already being reduced
+        # optional accounting of the exchange (bench.py --gpus N): event pairs on the compute stream around the
+        # point where it has to wait for the collectives = the part of the all-reduce that is NOT hidden
+        self.timing = False
+        self._timed: list = []
+        self.bytes_per_step = 0
+        self.early_bytes_per_step = 0
         # Host scalars (the global target-token count of a step) travel over a gloo side group:
         # reading an RCCL result back would synchronise the device every step and stop the host
         # from enqueueing ahead of the GPU.
@@ -58,6 +69,7 @@ class DataParallel:
         for hnd in self._handles:
             hnd.wait()
         self._handles, self._early = [], []
+        self.sparse_bytes_per_step = 0
 
     def _reduce_span(self, grad, lo: int, hi: int) -> None:
         for start in range(lo, hi, self.bucket_elems):
@@ -89,6 +101,83 @@ class DataParallel:
             self._early.append((lo, hi))
             self._reduce_span(grad, lo, hi)
 
+    def _host_all_gather_int(self, value: int):
+        """``value`` of every rank, in rank order (host side: the gloo group next to RCCL, or the gloo world)."""
+        if dist.get_backend() != "nccl" or self._host_group is not None:
+            mine = torch.tensor([int(value)], dtype=torch.int64)
+            out = [torch.zeros(1, dtype=torch.int64) for _ in range(self.world_size)]
+            dist.all_gather(out, mine, group=self._host_group)
+            return [int(t.item()) for t in out]
+        dev = torch.device("cuda", torch.cuda.current_device())
+        mine = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+        out = torch.zeros(self.world_size, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(out, mine)
+        return [int(x) for x in out.cpu().tolist()]
+
+    def exchange_sparse_rows(self, store, name: str, host_ids, gather_rows, scatter_add, negate) -> bool:
+        """Sum the gradient of the embedding matrix ``name`` over ranks by exchanging only the rows that are not
+        zero: every rank contributes the rows of ITS tokens (``host_ids``: the ids the rank embedded this step,
+        pad id 0 excluded), B*S rows of E floats instead of V rows -- 13 MB instead of 65 MB per rank at the
+        benchmark shape.  Protocol: (1) the local dense gradient is complete (the caller's
+        scatter-add ran); (2) unique sorted ids -> the dense rows at those ids are gathered into a [cap, E] block,
+        cap = the largest count of any rank; (3) all-gather of the id and row blocks; (4) the local rows are
+        cancelled (x + (-x) = +0 exactly) and every rank's block is added in RANK ORDER, one launch per rank, no id
+        twice within a launch -- so every element sees the same additions in the same order on every rank and
+        the replicas stay bit-identical, which atomics over raw token rows would not guarantee; (5) the span is
+        marked reduced: ``all_reduce_gradients`` skips it.  ``gather_rows(src, idx, dst)``,
+        ``scatter_add(table, ids, rows)`` and ``negate(src, dst)`` are the device primitives (libnmhip kernels in the
+        product path).  Returns False when the exchange did not happen (world of one, switch off, graph capture):
+        the dense all-reduce then covers the span as usual."""
+        import numpy as np
+        if self.world_size == 1 or not self.sparse_embeddings:
+            return False
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return False
+        table = store.g(name)                                        # [V, E] view of the flat gradient
+        vsz, esz = table.shape
+        lo = store.offset(name)
+        hi = lo + table.numel()
+        if any(lo < dhi and dlo < hi for dlo, dhi in self._early):
+            raise RuntimeError("gradient span [{}, {}) was already reduced this step".format(lo, hi))
+        ids = np.unique(np.asarray(host_ids).reshape(-1))
+        ids = ids[ids != 0].astype(np.int32)
+        counts = self._host_all_gather_int(len(ids))
+        cap = max(256, -(-max(counts) // 256) * 256)
+        dev = table.device
+        bufs = self._sparse_bufs.get(name)
+        if bufs is None or bufs["cap"] < cap:
+            bufs = {"cap": cap,
+                    "ids": torch.zeros(cap, dtype=torch.int32, device=dev),
+                    "rows": torch.zeros(cap * esz, dtype=torch.float32, device=dev),
+                    "neg": torch.zeros(cap * esz, dtype=torch.float32, device=dev),
+                    "all_ids": torch.zeros(self.world_size * cap, dtype=torch.int32, device=dev),
+                    "all_rows": torch.zeros(self.world_size * cap * esz, dtype=torch.float32, device=dev)}
+            self._sparse_bufs[name] = bufs
+        n = len(ids)
+        padded = np.zeros(cap, np.int32)
+        padded[:n] = ids
+        my_ids = bufs["ids"][:cap]
+        my_ids.copy_(torch.from_numpy(padded))
+        rows = bufs["rows"][:cap * esz].view(cap, esz)
+        neg = bufs["neg"][:cap * esz].view(cap, esz)
+        if n:
+            gather_rows(table, my_ids[:n], rows[:n])
+        all_ids = bufs["all_ids"][:self.world_size * cap]
+        all_rows = bufs["all_rows"][:self.world_size * cap * esz]
+        dist.all_gather_into_tensor(all_ids, my_ids)
+        dist.all_gather_into_tensor(all_rows, rows.view(-1))
+        if n:
+            negate(rows[:n], neg[:n])
+            scatter_add(table, my_ids[:n], neg[:n])                  # exactly zero again
+        all_ids = all_ids.view(self.world_size, cap)
+        all_rows = all_rows.view(self.world_size, cap, esz)
+        for r, cnt in enumerate(counts):
+            if cnt:
+                scatter_add(table, all_ids[r, :cnt], all_rows[r, :cnt])
+        self._early.append((lo, hi))
+        self.sparse_bytes_per_step += 4 * cap * (esz + 1)
+        return True
+
     def all_reduce_gradients(self, store) -> None:
         """In-place sum of the flat gradient buffer over ranks, in large buckets (minus the spans
         ``all_reduce_early`` already started); returns with every collective of the step ordered
@@ -103,9 +192,32 @@ class DataParallel:
             pos = max(pos, hi)
         if pos < grad.numel():
             self._reduce_span(grad, pos, grad.numel())
+        timed = self.timing and grad.is_cuda
+        if timed:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         for hnd in self._handles:
             hnd.wait()
+        if timed:
+            ev1.record()
+            self._timed.append((ev0, ev1))
+        self.bytes_per_step = 4 * grad.numel()
+        self.early_bytes_per_step = 4 * sum(hi - lo for lo, hi in self._early)
+        self.sparse_bytes_last, self.sparse_bytes_per_step = self.sparse_bytes_per_step, 0
         self._handles, self._early = [], []
+
+    def exchange_report(self) -> dict:
+        """Mean exposed wait per step since the last call (``timing`` on), bytes exchanged per step and how many of
+        them were started early, from inside the backward pass."""
+        waits = []
+        for first, second in self._timed:
+            second.synchronize()
+            waits.append(first.elapsed_time(second))
+        self._timed = []
+        return {"allreduce_exposed_ms": (sum(waits) / len(waits)) if waits else None, "steps": len(waits),
+                "bytes": self.bytes_per_step, "early_bytes": self.early_bytes_per_step,
+                "sparse_rows_bytes": getattr(self, "sparse_bytes_last", 0),
+                "buckets_mb": self.bucket_elems * 4 / 2 ** 20}
 
     def broadcast_parameters(self, store, src: int = 0) -> None:
         """Make every replica start from rank ``src``'s variables."""

@@ -140,11 +140,31 @@ class EmbeddedFactorSequence(Sequence):
                 d_part = ops.ew("scale", d_part, None, scaled, alpha=float(esz) ** 0.5)
             if f == 0:                                  # own pad positions == the mask
                 ops.embedding_scatter_add(ctx.store.g(name), idx.reshape(-1), d_part, skip_pad=True)
+                self._exchange_sparse(ctx, name)
             else:                                       # every factor is masked by the FIRST factor's padding
                 masked = ctx.buffer((id(self), "d_masked", col), (bsz * slen, esz))
                 ops.ew("rowscale", d_part, self.temporal_mask(ctx).reshape(-1, 1), masked)
                 ops.embedding_scatter_add(ctx.store.g(name), idx.reshape(-1), masked, skip_pad=False)
             col += esz
+
+    def _exchange_sparse(self, ctx, name: str) -> None:
+        """Data parallelism, NM_DP_SPARSE_EMB=1: this matrix's gradient is final here and has at most B*S non-zero
+        rows -- exchange (ids, rows) instead of the dense slice (distributed.DataParallel.exchange_sparse_rows).
+        Only for a single-factor sequence whose matrix nobody else reads (no ``embeddings_source`` / ``reuse``
+        sharing: further contributions would arrive after the exchange), and only when the trainer applies one
+        update per batch (the ``dp_overlap`` marker GenericTrainer.train_op sets)."""
+        from .. import distributed
+        from ..runtime import registered_parts
+        dp = distributed.current()
+        if dp is None or not dp.sparse_embeddings or not ctx.memo.get("dp_overlap", False):
+            return
+        if len(self.data_ids) != 1 or self.embeddings_source is not None or self.shares_variables:
+            return
+        if any(getattr(part, "embeddings_source", None) is self for part in registered_parts()):
+            return
+        negate = lambda src, dst: ops.ew("scale", src, None, dst, alpha=-1.0)
+        scatter = lambda table, ids, rows: ops.embedding_scatter_add(table, ids, rows, skip_pad=False)
+        dp.exchange_sparse_rows(ctx.store, name, ctx.fed(self.input_factors[0]), ops.gather_rows, scatter, negate)
 
     def feed_dict(self, dataset, train: bool = False) -> FeedDict:
         fd = ModelPart.feed_dict(self, dataset, train)

@@ -401,6 +401,8 @@ class BeamResult(NamedTuple):
     word_ids: np.ndarray     # [steps,B,k]
     gaps: Optional[np.ndarray] = None   # [steps,B] smallest NON-ZERO relative gap between adjacent scores of
                                         # the top k+1 (exact ties are ordered by index and are not near-ties)
+    tie_sets: Optional[dict] = None     # sentence -> (step, flat candidate ids, scores) of the best k + 16 candidates
+                                        # at the sentence's FIRST near-tie step (beam_search(tie_margin=...))
 
 
 def length_penalty(lengths, alpha, dt):
@@ -410,7 +412,7 @@ def length_penalty(lengths, alpha, dt):
 
 
 def beam_search(params, spec: DecoderSpec, enc: EncoderOutput, beam_size: int,
-                max_steps: int, length_normalization: float) -> BeamResult:
+                max_steps: int, length_normalization: float, tie_margin: Optional[float] = None) -> BeamResult:
     """BeamSearchDecoder over the RNN Decoder.
 
     The reference tiles the parent loop state to B*k rows (expand_to_beam
@@ -443,6 +445,7 @@ def beam_search(params, spec: DecoderSpec, enc: EncoderOutput, beam_size: int,
     dec_step = 1
     min_gap = np.inf
     beam_hist, word_hist, gap_hist = [], [], []
+    tie_sets = {}
 
     finished_row = np.full(vsz, -INF, dtype=dt)
     finished_row[PAD] = 0.0
@@ -460,6 +463,11 @@ def beam_search(params, spec: DecoderSpec, enc: EncoderOutput, beam_size: int,
         adj = top_sc[:, :-1] - top_sc[:, 1:]
         adj_rel = np.where(adj > 0, adj / np.maximum(np.abs(top_sc[:, :-1]), 1e-30), np.inf)
         gap_hist.append(np.where(finished.all(axis=1), np.inf, adj_rel.min(axis=1)))
+        if tie_margin is not None:               # candidates around a sentence's first near-tie, for the checker
+            for b in np.nonzero(gap_hist[-1] <= tie_margin)[0]:
+                if int(b) not in tie_sets:
+                    ws_sc, ws_idx = top_k(flat[b:b + 1], min(k + 16, flat.shape[1]))
+                    tie_sets[int(b)] = (dec_step - 1, ws_idx[0].copy(), ws_sc[0].copy())
         if top_sc.shape[1] > k:
             live = ~finished.all(axis=1)
             if live.any():
@@ -488,7 +496,7 @@ def beam_search(params, spec: DecoderSpec, enc: EncoderOutput, beam_size: int,
     return BeamResult(scores, token_ids, logprob_sum, lengths, finished, min_gap,
                       np.stack(beam_hist) if beam_hist else z,
                       np.stack(word_hist) if word_hist else z,
-                      np.stack(gap_hist) if gap_hist else np.zeros((0, bsz)))
+                      np.stack(gap_hist) if gap_hist else np.zeros((0, bsz)), tie_sets)
 
 
 def beam_tokens(res: BeamResult, rank: int = 1) -> Tuple[List[List[int]], float]:

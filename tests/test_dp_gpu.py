@@ -25,10 +25,10 @@ def _free_port():
     return port
 
 
-def _model():
+def _model(device="cuda:0"):
     from neuralmonkey_amd import synthetic
     return synthetic.build_translation_model(vocab_src=VOCAB, vocab_tgt=VOCAB, emb=DIM, rnn=DIM, max_len=LEN,
-                                             beam_size=0, l2_weight=1e-4, clip_norm=1.0, device="cuda:0", seed=21)
+                                             beam_size=0, l2_weight=1e-4, clip_norm=1.0, device=device, seed=21)
 
 
 def _batch():
@@ -36,16 +36,19 @@ def _batch():
     return synthetic.synthetic_dataset(seed=5, batch=BATCH, src_len=LEN, tgt_len=LEN - 1, vocab=VOCAB, ragged=True)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, backend="gloo"):
+    """backend gloo: all ranks share GPU 0; backend nccl (= RCCL): rank r owns GPU r."""
+    local = rank if backend == "nccl" else 0
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK="0", NM_DIST_BACKEND="gloo")
+                      LOCAL_RANK=str(local), NM_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
     from neuralmonkey_amd import distributed
-    torch.cuda.set_device(0)
+    torch.cuda.set_device(local)
     dp = distributed.init_from_env()
-    assert dp is not None and dp.world_size == world and dp.overlap
-    model = _model()
+    assert dp is not None and dp.world_size == world and dp.overlap and dist.get_backend() == backend
+    model = _model("cuda:{}".format(local))
     store = model.tf_manager.sessions[0].store
     if rank == 1:
         store.theta.add_(0.5)                       # replicas start from rank 0's variables
@@ -72,11 +75,13 @@ def _worker(rank, world, port, out_dir):
     distributed.shutdown()
 
 
-def test_two_ranks_equal_one_process_on_the_full_batch(tmp_path):
+def _ranks_against_one_process(tmp_path, world, backend):
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
-    assert np.array_equal(r0["theta"], r1["theta"]), "replicas diverged"
+    mp.spawn(_worker, args=(world, port, str(tmp_path), backend), nprocs=world, join=True)
+    ranks = [np.load(tmp_path / "rank{}.npz".format(r)) for r in range(world)]
+    r0 = ranks[0]
+    for other in ranks[1:]:
+        assert np.array_equal(r0["theta"], other["theta"]), "replicas diverged"
     # the reference point: one process, whole batch, same seed
     model = _model()
     store = model.tf_manager.sessions[0].store
@@ -97,6 +102,22 @@ def test_two_ranks_equal_one_process_on_the_full_batch(tmp_path):
     assert np.abs(r0["theta"] - want).max() <= 6.5e-4
     assert np.median(np.abs(r0["theta"] - want)) <= 1e-6
     assert r0["losses"].shape == (3,) and np.all(np.isfinite(r0["losses"])) and r0["losses"][2] < r0["losses"][0]
+
+
+def test_two_ranks_equal_one_process_on_the_full_batch(tmp_path):
+    _ranks_against_one_process(tmp_path, 2, "gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: one RCCL rank per GPU")
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_ranks_over_rccl_equal_one_process_on_the_full_batch(tmp_path, world):
+    """The same identity with the collectives on RCCL over xGMI, one rank per GPU: replicas bit-identical after
+    three optimizer steps, the summed gradient of step 1 equal to the full-batch gradient of one process, both
+    early spans issued from inside the backward pass.  Runs wherever >= `world` GPUs are visible (skipped on the
+    single-GPU boxes the round's tests run on)."""
+    if torch.cuda.device_count() < world or BATCH % world:
+        pytest.skip("{} GPUs visible".format(torch.cuda.device_count()))
+    _ranks_against_one_process(tmp_path, world, "nccl")
 
 
 def _rccl_worker(rank, world, port, out_dir):

@@ -7,17 +7,21 @@ the fused GRU epilogues, the 6-GEMM FastStepper step, attn_partial_fast<10> / at
 split-K gemm_tiled, the register-resident cross entropy and beam scan), so every one of them is
 compared with the CPU oracle here, end to end:
 
-  * one training step: loss (1e-4), every gradient (1e-3 of the tensor's max) against autograd of
-    oracle/torch_ref.py, and the variables after clip_by_norm + Adam against TR.clip_and_adam;
+  * one training step: loss (1e-4 against float64), every gradient against float64 autograd of
+    oracle/torch_ref.py within max(2e-5, 3 x the float32 restatement's own distance) of the tensor's
+    maximum (measured: engine <= 3.9e-6, fp32 oracle <= 1.3e-6), and the variables after clip_by_norm +
+    Adam against TR.clip_and_adam;
   * greedy decoding: encoder states, the logits of the first 10 steps within 1e-4 relative, symbols
     exact (decoders/decoder.py:279-358, autoregressive.py:442-519);
-  * beam search, k = 5, alpha = 0.6, 10 steps: (beam, word) selections and token histories exact,
-    scores within 1e-4 (beam_search_decoder.py:394-556).
+  * beam search, k = 5, alpha = 0.6, 10 steps on BASELINE.md's weights and all 50 steps with a sharper
+    vocabulary projection: the raw (beam, word) selections of every beam body
+    (BeamSearchDecoder.selection_history) exact up to a sentence's first near-tie step, inside the
+    oracle's tie set AT that step, token histories / lengths / finished flags / scores (1e-4) of every
+    sentence without a near-tie (beam_search_decoder.py:394-556).
 
 Near-tie rule (SURVEY 8c protocol 3): the oracle reports, per sentence and step, the relative gap
-between adjacent candidates; a sentence is compared exactly up to the first step whose gap is below
-1e-5 (two fp32 implementations may order such candidates differently); the test demands that at least
-90 % of all (sentence, step) decisions are above the threshold and compares every one of those.
+between adjacent candidates of its top k+1 and keeps the candidates around a sentence's first gap below
+1e-5 (two fp32 implementations may order such candidates differently).
 The oracle needs ~1 minute of host CPU for all three parts.
 """
 import numpy as np
@@ -87,27 +91,29 @@ def test_greedy_logits_and_symbols_match_the_oracle(world):
     assert float(err[safe].max()) <= 1e-4 * scale, float(err[safe].max() / scale)
 
 
-@pytest.mark.parametrize("logit_std,min_clean", [(None, 0.3), (0.2, 0.9)])
-def test_beam_search_selections_match_the_oracle(world, logit_std, min_clean):
-    """With BASELINE.md's N(0, 0.05) vocabulary projection the softmax over 32000 words is nearly flat and
-    ~60 % of the sentences see two candidates within the near-tie margin somewhere in 10 steps (the oracle
-    reports them); the second variant sharpens the projection to N(0, 0.2) so that >= 90 % of the sentences
-    are decided by more than the margin at every step.  Every sentence without a near-tie must match
-    exactly in both."""
-    model, enc = world["model"], world["enc"]
-    params = dict(world["params"])
-    if logit_std is not None:
-        w = params["decoder/state_to_word_W"]
-        params["decoder/state_to_word_W"] = (np.random.default_rng(5).standard_normal(w.shape) * logit_std
-                                             ).astype(np.float32)
-    model.tf_manager.sessions[0].store.load_state_dict(params)
-    ref = O.beam_search(params, O.DecoderSpec(max_output_len=LEN), enc, 5, DECODE_STEPS, 0.6)
-    sess = model.tf_manager.sessions[0]
-    out = sess.run({"bs": model.beam_decoder.outputs}, _feed(model, world["ds"]))["bs"]
-    tok = np.asarray(out.last_search_step_output.token_ids)            # [steps+1,B,k]
-    assert tok.shape == ref.token_ids.shape == (DECODE_STEPS + 1, B, 5)
-    clean = (ref.gaps > NEAR_TIE).all(axis=0)                           # sentences without a near-tie at any step
-    assert clean.mean() >= min_clean, "too many near-ties in the oracle: {} clean".format(clean.mean())
+def _check_beam(ref, sel_beam, sel_word, tok, out, k):
+    """Per sentence: exact agreement with the oracle up to the sentence's first near-tie step; AT that step every
+    selection of the engine has to come out of the oracle's tie set (a candidate the oracle ranks within the
+    near-tie margin of its k-th best); afterwards the two searches may legitimately follow different hypotheses and
+    nothing is compared.  Sentences without a near-tie are compared in full, final state included."""
+    steps, bsz = ref.gaps.shape
+    first_tie = np.where((ref.gaps <= NEAR_TIE).any(axis=0), (ref.gaps <= NEAR_TIE).argmax(axis=0), steps)
+    clean = first_tie == steps
+    exact_steps = flipped = 0
+    for b in range(bsz):
+        t = int(first_tie[b])
+        assert np.array_equal(sel_beam[:t, b], ref.beam_ids[:t, b]) and \
+            np.array_equal(sel_word[:t, b], ref.word_ids[:t, b]), "sentence {}: selections differ before step {}".format(b, t)
+        exact_steps += t
+        if t == steps:
+            continue
+        tstep, cand, sc = ref.tie_sets[b]
+        assert tstep == t
+        floor = sc[k - 1] - 2 * NEAR_TIE * abs(sc[k - 1])
+        allowed = set(int(c) for c, s_ in zip(cand, sc) if s_ >= floor)
+        picks = [int(x) for x in (sel_beam[t, b].astype(np.int64) * VOCAB + sel_word[t, b])]
+        assert set(picks) <= allowed, "sentence {} step {}: pick outside the oracle's tie set".format(b, t)
+        flipped += picks != [int(c) for c in cand[:k]]
     assert np.array_equal(tok[:, clean], ref.token_ids.astype(np.int32)[:, clean]), "beam token ids differ"
     assert np.array_equal(np.asarray(out.last_search_state.lengths)[clean], ref.lengths[clean])
     assert np.array_equal(np.asarray(out.last_search_state.finished).astype(bool)[clean], ref.finished[clean])
@@ -115,40 +121,87 @@ def test_beam_search_selections_match_the_oracle(world, logit_std, min_clean):
     assert np.abs(sc[clean] - ref.scores[clean]).max() <= 1e-4 * np.abs(ref.scores[clean]).max()
     lps = np.asarray(out.last_search_state.logprob_sum)
     assert np.abs(lps[clean] - ref.logprob_sum[clean]).max() <= 1e-4 * np.abs(ref.logprob_sum[clean]).max()
-    # the near-tied sentences differ at most by the order / choice of the tied candidates
-    assert (tok[:, ~clean] == ref.token_ids[:, ~clean]).mean() > 0.7 if (~clean).any() else True
+    return clean.mean(), exact_steps / float(steps * bsz), flipped
+
+
+@pytest.mark.parametrize("logit_std,min_clean,steps", [(None, 0.3, DECODE_STEPS), (0.2, 0.2, LEN)])
+def test_beam_search_selections_match_the_oracle(world, logit_std, min_clean, steps):
+    """With BASELINE.md's N(0, 0.05) vocabulary projection the softmax over 32000 words is nearly flat and ~60 % of
+    the sentences see two candidates within the near-tie margin somewhere in 10 steps (the oracle reports them);
+    the second variant sharpens the projection to N(0, 0.2) and runs all 50 steps (30 % of the sentences then get
+    through all 50 steps without a near-tie, 65 % of all (sentence, step) selections are compared exactly,
+    profiles/r03_fullsize_parity.txt).  Every (sentence, step)
+    selection before a sentence's first near-tie must be the oracle's, the selection AT the near-tie must come out
+    of the oracle's tie set, sentences without any near-tie must match to the end (``_check_beam``)."""
+    model, enc = world["model"], world["enc"]
+    params = dict(world["params"])
+    if logit_std is not None:
+        w = params["decoder/state_to_word_W"]
+        params["decoder/state_to_word_W"] = (np.random.default_rng(5).standard_normal(w.shape) * logit_std
+                                             ).astype(np.float32)
+    model.tf_manager.sessions[0].store.load_state_dict(params)
+    ref = O.beam_search(params, O.DecoderSpec(max_output_len=LEN), enc, 5, steps, 0.6, tie_margin=NEAR_TIE)
+    sess = model.tf_manager.sessions[0]
+    fd = _feed(model, world["ds"])
+    fd[model.beam_decoder.max_steps] = steps
+    got = sess.run({"bs": model.beam_decoder.outputs, "sel": model.beam_decoder.selection_history}, fd)
+    out = got["bs"]
+    sel_beam, sel_word = (np.asarray(x.cpu() if hasattr(x, "cpu") else x) for x in got["sel"])
+    tok = np.asarray(out.last_search_step_output.token_ids)            # [steps+1,B,k]
+    assert tok.shape == ref.token_ids.shape == (steps + 1, B, 5)
+    assert sel_beam.shape == ref.beam_ids.shape == (steps, B, 5)
+    clean, exact, flipped = _check_beam(ref, sel_beam, sel_word, tok, out, 5)
+    print("beam-5, {} steps, projection std {}: {:.0%} of the sentences without a near-tie, {:.1%} of all (sentence, "
+          "step) selections compared exactly, {} near-tie steps where the engine ordered the tie set differently"
+          .format(steps, logit_std or 0.05, clean, exact, flipped))
+    assert clean >= min_clean, "too many near-ties in the oracle: {} clean".format(clean)
 
 
 def test_training_step_gradients_and_adam_match_the_oracle(world):
+    """Yardstick: autograd of the restated step in float64; next to the engine's distance from it the test prints
+    the float32 restatement's own distance (what a second fp32 implementation of the same arithmetic shows) and
+    bounds the engine per tensor by max(floor, 3 x that noise) in the max norm."""
     _load(world)
     model = world["model"]
     tp = TR.to_torch(world["params"])
-    ref_loss, _, _, ref_g = TR.train_step_grads(tp, world["src"], world["tgt"], l1_weight=0.0, l2_weight=1e-8)
+    ref_loss, _, _, g32 = TR.train_step_grads(tp, world["src"], world["tgt"], l1_weight=0.0, l2_weight=1e-8)
+    tp64 = TR.to_torch(world["params"], dtype=torch.float64)
+    loss64, _, _, g64 = TR.train_step_grads(tp64, world["src"], world["tgt"], l1_weight=0.0, l2_weight=1e-8)
     res = model.tf_manager.execute(world["ds"], model.trainer.feedables, [model.trainer], train=True)[0]
-    assert abs(res.losses["decoder - cost"] - float(ref_loss)) < 1e-4 * float(ref_loss)
+    assert abs(res.losses["decoder - cost"] - float(loss64)) < 1e-4 * float(loss64)
     store = model.tf_manager.sessions[0].store
     bad = {}
+    print("{:<72} {:>10} {:>10}".format("gradient, max |diff| / max |g| against float64", "engine", "fp32 oracle"))
     for name in store.names():
-        got = store.g(name).cpu().numpy()
-        want = ref_g[name].numpy()
+        got = store.g(name).cpu().numpy().astype(np.float64)
+        want = g64[name].numpy()
+        w32 = g32[name].numpy().astype(np.float64)
         if name.endswith("attn_bias"):        # softmax is shift invariant: both sides hold rounding noise
-            assert abs(float(got.reshape(-1)[0])) < 1e-5 and abs(float(want.reshape(-1)[0])) < 1e-5
+            assert abs(float(got.reshape(-1)[0])) < 1e-5 and abs(float(w32.reshape(-1)[0])) < 1e-5
             continue
-        err = float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-12))
-        if err > 1e-3:
-            bad[name] = err
-    assert not bad, "gradient mismatch: {}".format(bad)
-    # the variables after per-tensor clip_by_norm(1.0) + Adam(1e-4), step 1 (generic_trainer.py:179-195)
+        scale = max(np.abs(want).max(), 1e-12)
+        err, noise = float(np.abs(got - want).max() / scale), float(np.abs(w32 - want).max() / scale)
+        print("{:<72} {:>10.2e} {:>10.2e}".format(name[-72:], err, noise))
+        if err > max(2e-5, 3 * noise):
+            bad[name] = (err, noise)
+    assert not bad, "gradient mismatch (engine error, fp32-oracle noise): {}".format(bad)
+    # the variables after per-tensor clip_by_norm(1.0) + Adam(1e-4), step 1 (generic_trainer.py:179-195).  Adam's
+    # first step is delta = -lr g / (|g| + eps') with eps' = eps / sqrt(1 - beta2): for |g| >> eps' every element
+    # moves by lr, so a relative gradient error d changes delta by lr d eps' / |g| -- negligible -- and the check
+    # is sharp only where |g| ~ eps'; where the (clipped) gradient exceeds 100 eps' the step must agree to 1 %.
     m = {k: torch.zeros_like(v) for k, v in tp.items()}
     v = {k: torch.zeros_like(x) for k, x in tp.items()}
     before = {k: x.detach().clone() for k, x in tp.items()}
-    TR.clip_and_adam(tp, ref_g, m, v, 1, 1.0)
+    TR.clip_and_adam(tp, g32, m, v, 1, 1.0)
     after = store.state_dict()
+    eps_eff = 1e-8 / np.sqrt(1.0 - 0.999)
     for name in ("decoder/state_to_word_W", "attention/attn_similarity_v",
                  "decoder/attention_decoder/OrthoGRUCell/gates/kernel", "encoder_input/embedding_matrix_0",
                  "encoder/rnn_0_bidirectional/bidirectional_rnn/bw/OrthoGRUCell/candidate/kernel"):
         want_delta = (tp[name].detach() - before[name]).numpy()
         got_delta = after[name] - before[name].numpy()
-        # Adam's first step is lr * g / (|g| + eps): compare where the gradient is not rounding noise
-        big = np.abs(ref_g[name].numpy()) > 1e-3 * np.abs(ref_g[name].numpy()).max()
-        assert np.abs(got_delta - want_delta)[big].max() <= 2e-2 * np.abs(want_delta).max(), name
+        g = g32[name].numpy()
+        clipped = g * min(1.0, 1.0 / max(float(np.linalg.norm(g)), 1e-30))
+        big = np.abs(clipped) > 100 * eps_eff
+        assert big.any(), name
+        assert np.abs(got_delta - want_delta)[big].max() <= 1e-2 * np.abs(want_delta).max(), name

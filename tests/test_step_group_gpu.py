@@ -30,7 +30,7 @@ def rel(got, ref):
     return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-6))
 
 
-@pytest.mark.parametrize("m", [128, 37, 640])
+@pytest.mark.parametrize("m", [128, 37, 640, 300])     # > 256 rows: 32x32 tiles (step_group_medium_kernel)
 def test_plain_problems_share_a_launch(dev, m):
     from neuralmonkey_amd import ops
     rng = np.random.default_rng(m)
@@ -130,7 +130,7 @@ def test_partials_merged_in_the_operand_loader(dev, bk, qpk, s, a, c, o):
     assert torch.allclose(w2, weights, atol=1e-6, rtol=0)     # (whole-sentence kernel: sums in another order)
 
 
-def _decode_both_ways(dev, beam):
+def _decode_both_ways(dev, beam, batch=24):
     """The same model and batch through FusedStepper and (NM_NO_FUSED_STEP=1) FastStepper."""
     from neuralmonkey_amd import synthetic
     from neuralmonkey_amd.decoders import decoder as decoder_mod
@@ -146,7 +146,7 @@ def _decode_both_ways(dev, beam):
                                                       device=str(dev))
             store = model.tf_manager.sessions[0].store
             store.load_state_dict(O.init_params(seed=5, vocab_src=2000, vocab_tgt=2000, emb=64, rnn=64, std=0.1))
-            ds = synthetic.synthetic_dataset(seed=6, batch=24, src_len=20, tgt_len=15, vocab=2000, ragged=True)
+            ds = synthetic.synthetic_dataset(seed=6, batch=batch, src_len=20, tgt_len=15, vocab=2000, ragged=True)
             sess = model.tf_manager.sessions[0]
             fd = {}
             for f in model.greedy_runner.feedables | model.beam_runner.feedables:
@@ -184,8 +184,20 @@ def test_fused_stepper_equals_the_six_gemm_stepper(dev):
     assert np.abs(sf - sp).max() < 1e-4 * np.abs(sp).max()
 
 
+def test_fused_stepper_serves_a_beam_of_hundreds_of_rows(dev):
+    """72 sentences x beam 4 = 288 hypotheses: the beam body's step runs the fused groups on 32x32 tiles
+    (step_group_medium_kernel) and must select what the six-GEMM stepper selects."""
+    (fused, _), (plain, _) = _decode_both_ways(dev, beam=4, batch=72)
+    tf_, tp = (np.asarray(x["bs"].last_search_step_output.token_ids) for x in (fused, plain))
+    assert tf_.shape == tp.shape and (tf_ == tp).mean() > 0.98          # near-ties may flip between roundings
+    sf, sp = (np.asarray(x["bs"].last_search_step_output.scores) for x in (fused, plain))
+    assert np.abs(sf - sp).max() < 1e-4 * np.abs(sp).max()
+    assert np.array_equal(fused["sym"], plain["sym"])
+
+
 @pytest.mark.parametrize("bk,qpk,s,e,h,a,c,o,v,with_stats", [
     (128, 1, 50, 512, 512, 1024, 1024, 512, 32000, True),       # the headline greedy step
+    (128, 5, 50, 512, 512, 1024, 1024, 512, 32000, True),       # the headline beam step: 640 rows, medium-M groups
     (16, 5, 50, 512, 512, 1024, 1024, 512, 32000, True),        # beam rows share the keys of their sentence
     (7, 1, 13, 32, 48, 64, 96, 40, 516, False),                 # ragged, plain logits GEMM
     (3, 2, 9, 16, 16, 32, 32, 16, 260, True)])

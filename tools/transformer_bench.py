@@ -49,6 +49,8 @@ def main():
 
     t_train = timed(lambda: tfm.execute(ds, trainer.feedables, [trainer], train=True), 2, 5)
     print("train: {:.2f} ms/step  {:.0f} tok/s".format(t_train * 1e3, tokens / t_train))
+    if "--train-only" in sys.argv:
+        return
     dsd = synthetic.synthetic_dataset(seed=2, batch=batch, src_len=length, tgt_len=length, vocab=vocab_size,
                                       with_target=False)
     # decode the full length: with tied embeddings (W = E^T, b = 0) there is no bias to push </s> down, so
