@@ -322,6 +322,9 @@ int nm_copy_cols(void* stream, const float* src, int64_t ld_src, float* dst, int
                  int64_t rows, int64_t width);
 int nm_reduce_sum(void* stream, const float* x, int64_t n, float* out);
 int nm_tanh_bwd(void* stream, float* dy, const float* y, int64_t n);
+/* out[c] (+)= sum_r x[r,c] (bias / LayerNorm gradients: tf.gradients of a broadcast add), ONE launch, sums in a
+ * fixed order.  The workspace (device) must be ZERO when first used and belongs to one stream at a time: its tail
+ * holds arrival counters that the kernel itself puts back to zero. */
 int64_t nm_colsum_workspace_bytes(int64_t cols);
 int nm_colsum(void* stream, const float* x, int64_t ldx, int64_t rows, int64_t cols, float* out,
               int accumulate, void* workspace, int64_t workspace_bytes);

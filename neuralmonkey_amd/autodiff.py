@@ -85,6 +85,18 @@ class Tape:
             v.grad = self.buf(tuple(v.data.shape), zero=True)
         return v.grad
 
+    def grad_slot(self, v: Var):
+        """(gradient buffer of ``v``, accumulate?) for a backward kernel that can either overwrite or add: the first
+        contribution to a fresh buffer OVERWRITES it (accumulate False), which saves the zero-fill ``grad`` would
+        have issued -- 195 fills of 13 MB per step of the Transformer-base model, 1.3 of 33 ms.  Buffers that were
+        handed out before (``grad``, views, parameter slices of the flat gradient) accumulate as always."""
+        if not v.needs_grad:
+            return None, False
+        if v.grad is None:
+            v.grad = self.buf(tuple(v.data.shape), zero=False)
+            return v.grad, False
+        return v.grad, True
+
     def view(self, v: Var, fn: Callable[[torch.Tensor], torch.Tensor]) -> Var:
         """A strided view (column / row block) of ``v``; gradient flows by aliasing."""
         g = self.grad(v) if (self.recording and v.needs_grad) else None
@@ -125,7 +137,8 @@ def linear(tape: Tape, x: Var, w: Var, b: Optional[Var] = None, out: Optional[Va
         if dy is None:
             return
         if x.needs_grad:
-            ops.gemm(dy, w.data, out=tape.grad(x), trans_b=not trans_b, accumulate=True)
+            gx, acc = tape.grad_slot(x)
+            ops.gemm(dy, w.data, out=gx, trans_b=not trans_b, accumulate=acc)
         if w.needs_grad:
             if trans_b:
                 ops.gemm(dy, x.data, out=tape.grad(w), trans_a=True, accumulate=True)
@@ -146,11 +159,11 @@ def _unary(tape: Tape, op: str, bwd_op: Optional[str], x: Var, alpha: float = 0.
     def bwd():
         if out.grad is None or not x.needs_grad:
             return
+        gx, acc = tape.grad_slot(x)
         if bwd_op is None:           # copy / scale
-            ops.ew("scale" if op == "scale" else "copy", out.grad, None, tape.grad(x), alpha=alpha,
-                   accumulate=True)
+            ops.ew("scale" if op == "scale" else "copy", out.grad, None, gx, alpha=alpha, accumulate=acc)
         else:
-            ops.ew(bwd_op, out.data, out.grad, tape.grad(x), accumulate=True)
+            ops.ew(bwd_op, out.data, out.grad, gx, accumulate=acc)
     tape.record(bwd)
     return out
 
@@ -188,7 +201,8 @@ def add(tape: Tape, a: Var, b: Var) -> Var:
             return
         for v in (a, b):
             if v.needs_grad:
-                ops.ew("copy", out.grad, None, tape.grad(v), accumulate=True)
+                gv, acc = tape.grad_slot(v)
+                ops.ew("copy", out.grad, None, gv, accumulate=acc)
     tape.record(bwd)
     return out
 
@@ -268,7 +282,8 @@ def dropout(tape: Tape, x: Var, keep_prob: float, train_mode: bool, salt: int) -
 
     def bwd():
         if out.grad is not None and x.needs_grad:
-            ops.dropout(out.grad, tape.grad(x), keep_prob, salt, accumulate=True, step=step)
+            gx, acc = tape.grad_slot(x)
+            ops.dropout(out.grad, gx, keep_prob, salt, accumulate=acc, step=step)
     tape.record(bwd)
     return out
 
@@ -326,10 +341,13 @@ def layer_norm(tape: Tape, x: Var, gamma: Var, beta: Var, eps: float = 1e-6) -> 
         if out.grad is None:
             return
         d = x.shape[-1]
-        dx, dyx = tape.buf(tuple(x.shape)), tape.buf(tuple(x.shape))
+        gx, acc = tape.grad_slot(x)
+        dyx = tape.buf(tuple(x.shape))
+        # a fresh gradient buffer takes dx directly (no scratch + copy); otherwise dx is added to what is there
+        dx = gx if (gx is not None and not acc and gx.is_contiguous()) else tape.buf(tuple(x.shape))
         ops.layer_norm_bwd(out.grad, x.data, mean, rstd, gamma.data, dx, dyx)
-        if x.needs_grad:
-            ops.ew("copy", dx, None, tape.grad(x), accumulate=True)
+        if gx is not None and dx is not gx:
+            ops.ew("copy", dx, None, gx, accumulate=True)
         if gamma.needs_grad:
             ops.colsum(dyx.view(rows, d), gamma.grad, accumulate=True)
             ops.colsum(out.grad.view(rows, d), beta.grad, accumulate=True)
@@ -399,9 +417,15 @@ def sdp_attention(tape: Tape, q: Var, k: Var, v: Var, key_mask: Optional[torch.T
             return
         assert bq == bk and k_data is None and v_data is None
         de = tape.buf((bq, heads, tq, tk))
+        (gq, aq), (gk, ak), (gv, av) = tape.grad_slot(q), tape.grad_slot(k), tape.grad_slot(v)
+        if not (aq == ak == av):         # one accumulate flag for the three outputs: zero whichever buffer is fresh
+            for g, a in ((gq, aq), (gk, ak), (gv, av)):
+                if not a:
+                    g.zero_()
+            aq = True
         ops.sdp_attn_bwd(q.data.view(bq, tq, d), k3, v3, key_mask, w, out.grad.view(bq, tq, d), heads,
-                         tape.grad(q).view(bq, tq, d), tape.grad(k).view(bk, tk, d), tape.grad(v).view(bk, tk, d),
-                         de, causal, keep_prob, salt, accumulate=True, step=step)
+                         gq.view(bq, tq, d), gk.view(bk, tk, d), gv.view(bk, tk, d),
+                         de, causal, keep_prob, salt, accumulate=aq, step=step)
     tape.record(bwd)
     return out
 

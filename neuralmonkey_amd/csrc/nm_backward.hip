@@ -38,10 +38,27 @@ extern "C" int nm_tanh_bwd(void* stream, float* dy, const float* y, int64_t n) {
 // A block is 64 columns x 4 row lanes over one slice of <= 32 rows (8 rows per thread, all
 // loads independent), so even a [6400, 512] operand launches 1600 workgroups.
 #define COLSUM_MAX_SPLIT 256
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, long ldx,
-                                                             long rows, int cols, int nsplit,
-                                                             float* __restrict__ part) {
+// One launch: every (column tile, row slice) workgroup leaves its partial sums in the workspace; the workgroup that
+// arrives LAST for a column tile adds the slices in a fixed order and writes the result -- deterministic, and half
+// the launches of the two-kernel version (a Transformer-base training step has 88 bias / LayerNorm gradients:
+// 2 x 88 launches of ~12 us were 2.1 of its 33 ms).  Hand-off as in nm_attention.hip (CDNA4: a CU's L1 is never
+// refreshed by other CUs' stores): partials stored write-through, every storing wave drains, one lane takes a ticket
+// with an agent-scope atomic, the last workgroup reads the partials with L1-bypassing loads and puts the ticket back
+// to zero for the next launch.
+__device__ __forceinline__ void colsum_st_wt(float* p, float a) {
+    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float colsum_ld_wt(const float* p) {
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT));
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long ldx, long rows, int cols,
+                                                     int nsplit, float* __restrict__ part,
+                                                     unsigned* __restrict__ tickets, float* __restrict__ out,
+                                                     int accumulate) {
     __shared__ float sh[4][64];
+    __shared__ int s_last;
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
     const int sl = blockIdx.y;
@@ -52,18 +69,39 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
         for (long r = r0 + ry; r < r1; r += 4) s += x[r * ldx + c];
     sh[ry][cx] = s;
     __syncthreads();
-    if (ry == 0 && c < cols) part[(long)sl * cols + c] = (sh[0][cx] + sh[1][cx]) + (sh[2][cx] + sh[3][cx]);
-}
-__global__ void colsum_final_kernel(const float* __restrict__ part, int cols, int nsplit,
-                                    float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
-    float s = 0.0f;
-    for (int k = 0; k < nsplit; ++k) s += part[(long)k * cols + c];
-    out[c] = accumulate ? out[c] + s : s;
+    const float mine = (sh[0][cx] + sh[1][cx]) + (sh[2][cx] + sh[3][cx]);
+    if (nsplit == 1) {
+        if (ry == 0 && c < cols) out[c] = accumulate ? out[c] + mine : mine;
+        return;
+    }
+    if (ry == 0 && c < cols) colsum_st_wt(part + (long)sl * cols + c, mine);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(tickets + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (t == (unsigned)(nsplit - 1));
+        if (last) __hip_atomic_store(tickets + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    float f = 0.0f;
+    if (c < cols)
+        for (int k = ry; k < nsplit; k += 4) f += colsum_ld_wt(part + (long)k * cols + c);
+    __syncthreads();
+    sh[ry][cx] = f;
+    __syncthreads();
+    if (ry == 0 && c < cols) {
+        const float tot = (sh[0][cx] + sh[1][cx]) + (sh[2][cx] + sh[3][cx]);
+        out[c] = accumulate ? out[c] + tot : tot;
+    }
 }
 
-extern "C" int64_t nm_colsum_workspace_bytes(int64_t cols) { return cols * COLSUM_MAX_SPLIT * 4; }
+// partial sums [COLSUM_MAX_SPLIT][cols] + one arrival counter per 64 columns.  The counters must be ZERO when a
+// launch starts (the kernel leaves them zero): allocate the workspace zero-initialised.
+extern "C" int64_t nm_colsum_workspace_bytes(int64_t cols) {
+    return (cols * COLSUM_MAX_SPLIT + ((cols + 63) / 64 + 3) / 4 * 4) * 4;
+}
 
 extern "C" int nm_colsum(void* stream, const float* x, int64_t ldx, int64_t rows, int64_t cols, float* out,
                          int accumulate, void* workspace, int64_t workspace_bytes) {
@@ -71,16 +109,15 @@ extern "C" int nm_colsum(void* stream, const float* x, int64_t ldx, int64_t rows
     NM_REQUIRE(workspace_bytes >= nm_colsum_workspace_bytes(cols), "nm_colsum: workspace too small");
     hipStream_t st = nm_stream(stream);
     float* part = reinterpret_cast<float*>(workspace);
+    unsigned* tickets = reinterpret_cast<unsigned*>(part + cols * COLSUM_MAX_SPLIT);
     // enough row slices to fill the chip (cols/64 * nsplit >= ~1024 workgroups), few enough that
-    // the fixed-order final pass (nsplit sequential adds per column) stays short
+    // the fixed-order final pass (nsplit / 4 sequential adds per thread) stays short
     int nsplit = (int)((1024 * 64 + cols - 1) / cols);
     if (nsplit > (int)((rows + 31) / 32)) nsplit = (int)((rows + 31) / 32);
     if (nsplit > 48) nsplit = 48;
     if (nsplit < 1) nsplit = 1;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nm_cdiv(cols, 64), nsplit), dim3(256), 0, st, x,
-                       (long)ldx, (long)rows, (int)cols, nsplit, part);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(nm_cdiv(cols, 256)), dim3(256), 0, st, part, (int)cols,
-                       nsplit, out, accumulate);
+    hipLaunchKernelGGL(colsum_kernel, dim3(nm_cdiv(cols, 64), nsplit), dim3(256), 0, st, x, (long)ldx, (long)rows,
+                       (int)cols, nsplit, part, tickets, out, accumulate);
     NM_LAUNCH_CHECK("nm_colsum");
 }
 

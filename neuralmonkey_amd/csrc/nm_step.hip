@@ -257,9 +257,13 @@ __global__ __launch_bounds__(KS * 64, AKIND == 0 ? 8 : 4) void step_group_kernel
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int KS>
-__global__ __launch_bounds__(KS * 64, 4) void step_group_medium_kernel(StepGroup g) {
-    constexpr int LDT = 36;                                 // tile row stride in floats: 16-byte aligned rows, and the
-                                                            // 16 lanes of a ds_read_b128 group cover all 64 banks
+__global__ __launch_bounds__(KS * 64, KS == 4 ? 5 : 2) void step_group_medium_kernel(StepGroup g) {
+    // Tile rows are exactly one 128-byte line (no padding: 8 KB per wave, 32 KB per 4-wave workgroup = FIVE
+    // workgroups per CU, which is what lets the 1280 workgroups of group 1 at 640 rows run as one balanced round).
+    // Bank conflicts are avoided by storing 16-byte chunk q of row r at chunk position q ^ ((r >> 1) & 7): the 16
+    // lanes of a ds_read_b128 group hold 16 different values of r & 15, i.e. 16 different (row parity, chunk
+    // position) pairs = all 64 banks; the 8 lanes of a ds_write_b128 group write the 8 chunks of one row.
+    constexpr int LDT = 32;
     __shared__ __attribute__((aligned(16))) float lds[KS * 2 * 32 * LDT];
     static_assert(KS * 2 * 32 * LDT >= KS * 16 * 64, "the K reduction re-uses the operand tiles");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -307,16 +311,19 @@ __global__ __launch_bounds__(KS * 64, 4) void step_group_medium_kernel(StepGroup
     for (int k0 = kbeg; k0 < kend; k0 += 32) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<float4*>(as + (lr + 8 * i) * LDT + 4 * lq) = ra[i];
-            *reinterpret_cast<float4*>(bs + (lr + 8 * i) * LDT + 4 * lq) = rb[i];
+            const int r = lr + 8 * i;
+            const int pos = 4 * (lq ^ ((r >> 1) & 7));
+            *reinterpret_cast<float4*>(as + r * LDT + pos) = ra[i];
+            *reinterpret_cast<float4*>(bs + r * LDT + pos) = rb[i];
         }
         __builtin_amdgcn_wave_barrier();             // (LDS operations of one wave complete in order)
         if (k0 + 32 < kend) fetch(k0 + 32);          // the next trip's lines travel under this trip's MFMAs
         float4 av[4], bv[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {                // lane (m, half): k = k0 + 16 half + 4 c + j
-            av[c] = *reinterpret_cast<const float4*>(as + m * LDT + 16 * half + 4 * c);
-            bv[c] = *reinterpret_cast<const float4*>(bs + m * LDT + 16 * half + 4 * c);
+            const int pos = 4 * ((4 * half + c) ^ ((m >> 1) & 7));
+            av[c] = *reinterpret_cast<const float4*>(as + m * LDT + pos);
+            bv[c] = *reinterpret_cast<const float4*>(bs + m * LDT + pos);
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -436,7 +443,10 @@ extern "C" int nm_step_group(void* stream, int64_t M, const nm_step_problem* pro
         NM_REQUIRE(probs[i].a_kind == probs[0].a_kind, "nm_step_group: the problems of a group share one operand loader");
     hipStream_t st = nm_stream(stream);
     const unsigned grid = (unsigned)(next + g.wblocks);
-    if (medium) hipLaunchKernelGGL((step_group_medium_kernel<4>), dim3(grid), dim3(256), 0, st, g);
+    // few tiles (a single 512-wide product at 640 rows: 320 tiles on 256 CUs): 8 waves split K, so that the one or
+    // two workgroups a CU gets are half as long
+    if (medium && grid <= 640) hipLaunchKernelGGL((step_group_medium_kernel<8>), dim3(grid), dim3(512), 0, st, g);
+    else if (medium) hipLaunchKernelGGL((step_group_medium_kernel<4>), dim3(grid), dim3(256), 0, st, g);
     else if (probs[0].a_kind == 1) hipLaunchKernelGGL((step_group_kernel<16, 1, 1>), dim3(grid), dim3(1024), 0, st, g);
     else if (tm == 2) hipLaunchKernelGGL((step_group_kernel<16, 2, 0>), dim3(grid), dim3(1024), 0, st, g);
     else hipLaunchKernelGGL((step_group_kernel<16, 1, 0>), dim3(grid), dim3(1024), 0, st, g);

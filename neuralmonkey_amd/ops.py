@@ -430,7 +430,8 @@ def colsum(x, out, accumulate=False):
     key = (x.device, cols, _stream())
     ws = _COLSUM_WS.get(key)
     if ws is None:
-        ws = torch.empty(lib.nm_colsum_workspace_bytes(cols) // 4, dtype=torch.float32, device=x.device)
+        # zeroed ONCE: the tail holds the arrival counters of the in-kernel final pass, which the kernel leaves at zero
+        ws = torch.zeros(lib.nm_colsum_workspace_bytes(cols) // 4, dtype=torch.float32, device=x.device)
         _COLSUM_WS[key] = ws
     _lib.check(lib.nm_colsum(_stream(), x.data_ptr(), x.stride(0), x.shape[0], cols, out.data_ptr(),
                              int(accumulate), ws.data_ptr(), ws.numel() * 4), "nm_colsum")

@@ -80,6 +80,40 @@ def _worker(rank, world, port, out_dir):
     dp.all_reduce_gradients(store)
     assert not dp._early and not dp._handles
 
+    # ---- the same step with the encoder embeddings exchanged as (ids, rows) (NM_DP_SPARSE_EMB=1): the device
+    # primitives are stand-ins here (the product path passes libnmhip kernels, tests/test_dp_gpu.py runs those);
+    # what is under test is the protocol -- counts, padding, rank order, span bookkeeping
+    dense = {name: store.g(name).clone() for name in params}
+    for name in params:
+        store.g(name).copy_(tp[name].grad.reshape(store.g(name).shape))
+    emb_name = "encoder_input/embedding_matrix_0"
+    calls = []
+
+    def gather_rows(src_t, idx, dst):
+        dst.copy_(src_t[idx.long()])
+
+    def scatter_add(table, ids, rows):
+        assert len(set(ids.tolist())) == len(ids), "an id twice within one launch"
+        calls.append(len(ids))
+        table.index_add_(0, ids.long(), rows)
+
+    dp.sparse_embeddings = True
+    dp.begin_step()
+    assert dp.exchange_sparse_rows(store, emb_name, src, gather_rows, scatter_add,
+                                   lambda a, b: b.copy_(-a))
+    assert len(calls) == 1 + world                       # cancel the local rows, then one launch per rank
+    try:
+        dp.all_reduce_early(store, [emb_name])
+        raise AssertionError("a span was reduced twice")
+    except RuntimeError:
+        pass
+    dp.all_reduce_gradients(store)
+    dp.sparse_embeddings = False
+    for name in params:
+        a, b = store.g(name), dense[name]
+        assert float((a - b).abs().max()) <= 1e-6 * max(float(b.abs().max()), 1e-6), name
+    np.save(os.path.join(out_dir, "emb_rank{}.npy".format(rank)), store.g(emb_name).numpy())
+
     if rank == 0:
         fsrc, ftgt = arrays(ds)
         ftp = TR.to_torch(params)
@@ -103,6 +137,8 @@ def test_sharded_gradients_equal_full_batch(tmp_path):
     worst, global_count, full_count = np.load(tmp_path / "result.npy")
     assert global_count == full_count
     assert worst < 5e-4, worst          # fp32 re-association between shard and full-batch sums
+    # sparse exchange: every rank added the same blocks in the same order -> bit-identical replicas
+    assert np.array_equal(np.load(tmp_path / "emb_rank0.npy"), np.load(tmp_path / "emb_rank1.npy"))
 
 
 def test_single_process_is_a_no_op(monkeypatch):

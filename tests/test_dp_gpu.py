@@ -36,11 +36,12 @@ def _batch():
     return synthetic.synthetic_dataset(seed=5, batch=BATCH, src_len=LEN, tgt_len=LEN - 1, vocab=VOCAB, ragged=True)
 
 
-def _worker(rank, world, port, out_dir, backend="gloo"):
+def _worker(rank, world, port, out_dir, backend="gloo", sparse=False):
     """backend gloo: all ranks share GPU 0; backend nccl (= RCCL): rank r owns GPU r."""
     local = rank if backend == "nccl" else 0
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(local), NM_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      LOCAL_RANK=str(local), NM_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      NM_DP_SPARSE_EMB="1" if sparse else "0")
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch.distributed as dist
@@ -48,6 +49,15 @@ def _worker(rank, world, port, out_dir, backend="gloo"):
     torch.cuda.set_device(local)
     dp = distributed.init_from_env()
     assert dp is not None and dp.world_size == world and dp.overlap and dist.get_backend() == backend
+    assert dp.sparse_embeddings == sparse
+    seen_sparse = []
+    real_sparse = dp.exchange_sparse_rows
+
+    def spy_sparse(st, name, *args):
+        done = real_sparse(st, name, *args)
+        seen_sparse.append((name, done))
+        return done
+    dp.exchange_sparse_rows = spy_sparse
     model = _model("cuda:{}".format(local))
     store = model.tf_manager.sessions[0].store
     if rank == 1:
@@ -70,14 +80,15 @@ def _worker(rank, world, port, out_dir, backend="gloo"):
             grad1 = store.ensure_grad().cpu().numpy().copy()      # summed over ranks + L2 term, before clipping
     torch.cuda.synchronize()
     assert len(seen_early) == 6 and "decoder/state_to_word_W" in seen_early[0]      # two early spans per step
+    assert seen_sparse == ([("encoder_input/embedding_matrix_0", True)] * 3 if sparse else [])
     np.savez(os.path.join(out_dir, "rank{}.npz".format(rank)), theta=store.theta.cpu().numpy(),
              losses=np.asarray(losses), grad1=grad1)
     distributed.shutdown()
 
 
-def _ranks_against_one_process(tmp_path, world, backend):
+def _ranks_against_one_process(tmp_path, world, backend, sparse=False):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path), backend), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), backend, sparse), nprocs=world, join=True)
     ranks = [np.load(tmp_path / "rank{}.npz".format(r)) for r in range(world)]
     r0 = ranks[0]
     for other in ranks[1:]:
@@ -108,6 +119,13 @@ def test_two_ranks_equal_one_process_on_the_full_batch(tmp_path):
     _ranks_against_one_process(tmp_path, 2, "gloo")
 
 
+def test_two_ranks_with_the_encoder_embeddings_exchanged_as_rows(tmp_path):
+    """NM_DP_SPARSE_EMB=1: the encoder's embedding gradient travels as (unique ids, rows) -- gathered, cancelled
+    and re-added by libnmhip kernels in rank order -- instead of through the dense all-reduce; same identities:
+    replicas bit-identical, summed gradient == one process on the full batch."""
+    _ranks_against_one_process(tmp_path, 2, "gloo", sparse=True)
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: one RCCL rank per GPU")
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_ranks_over_rccl_equal_one_process_on_the_full_batch(tmp_path, world):
@@ -117,7 +135,7 @@ def test_ranks_over_rccl_equal_one_process_on_the_full_batch(tmp_path, world):
     single-GPU boxes the round's tests run on)."""
     if torch.cuda.device_count() < world or BATCH % world:
         pytest.skip("{} GPUs visible".format(torch.cuda.device_count()))
-    _ranks_against_one_process(tmp_path, world, "nccl")
+    _ranks_against_one_process(tmp_path, world, "nccl", sparse=(world == 4))
 
 
 def _rccl_worker(rank, world, port, out_dir):

@@ -1,20 +1,16 @@
 set -x
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-T=r03e
+T=r03g
 R=$PWD
-timeout 900 python -m pytest tests/test_step_group_gpu.py tests/test_beam_fused_gpu.py -x -q -m gpu > gpurun_out/${T}_tests.txt 2>&1
+cd /tmp
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/${T}_pmc1 -- python $R/tools/decode_profile.py --mode beam --batches 2 > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/${T}_pmc2 -- python $R/tools/decode_profile.py --mode beam --batches 2 > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${T}_pmc3 -- python $R/tools/decode_profile.py --mode beam --batches 2 > /dev/null 2>&1
+cd $R
+python tools/pmc_kernel.py gpurun_out/${T}_pmc1 gpurun_out/${T}_pmc2 gpurun_out/${T}_pmc3 --match step_group_medium > gpurun_out/${T}_medium_pmc.txt 2>&1
+cat gpurun_out/${T}_medium_pmc.txt
+rm -rf gpurun_out/${T}_pmc1 gpurun_out/${T}_pmc2 gpurun_out/${T}_pmc3
+timeout 900 python -m pytest tests/test_transformer_gpu.py tests/test_general_gpu.py tests/test_training_gpu.py tests/test_kernels_gpu.py tests/test_step_graphs_gpu.py -x -q -m gpu > gpurun_out/${T}_tests.txt 2>&1
 echo "tests rc=$?"; tail -5 gpurun_out/${T}_tests.txt | cut -c1-400
-python tools/decode_profile.py --mode beam --batches 6 2>&1 | tail -1
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${T}_bprof -- python $R/tools/decode_profile.py --mode beam --batches 4 > /dev/null 2>&1
-cd $R
-find gpurun_out/${T}_bprof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${T}_decode_beam_kernels.csv
-rm -rf gpurun_out/${T}_bprof
-head -8 gpurun_out/${T}_decode_beam_kernels.csv | cut -c1-180
-timeout 1500 python -m pytest tests/test_fullsize_parity_gpu.py -q -s -m gpu > gpurun_out/${T}_fullsize.txt 2>&1
-echo "fullsize rc=$?"; grep -v "^decoder/\|^encoder\|^attention/" gpurun_out/${T}_fullsize.txt | tail -30 | cut -c1-300
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${T}_tprof -- python $R/tools/transformer_bench.py --train-only > /dev/null 2>&1
-cd $R
-find gpurun_out/${T}_tprof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${T}_transformer_train_kernel_stats.csv
-rm -rf gpurun_out/${T}_tprof
-head -30 gpurun_out/${T}_transformer_train_kernel_stats.csv | cut -c1-200
+python tools/transformer_bench.py --train-only 2>&1 | tail -2
