@@ -207,16 +207,28 @@ __global__ __launch_bounds__(256) void attn_partial(AttnArgs p) {
     const int ns = min(p.sch, p.S - s0);
     const int q0 = blockIdx.z * QPK;            // first query of this block's group
 
+    // the queries are staged as exp(2 y): every key element is read by QPK queries, so exp(2 hf) is evaluated once
+    // per element and a tanh costs one v_rcp_f32 (nm_tanh_prod); queries or keys beyond the exact range of that
+    // form (|.| > NM_EXP2X_MAX) send their slice through nm_tanh on the original values
+    __shared__ int y_wide;
+    if (tid == 0) y_wide = 0;
+    __syncthreads();
+    bool wide = false;
 #pragma unroll
     for (int q = 0; q < QPK; ++q)
-        for (int i = tid * 4; i < p.A; i += 1024)
+        for (int i = tid * 4; i < p.A; i += 1024) {
+            const float4 y4 = *reinterpret_cast<const float4*>(p.y + attn_qrow(p, b, q0 + q) * p.A + i);
+            wide |= fmaxf(fmaxf(fabsf(y4.x), fabsf(y4.y)), fmaxf(fabsf(y4.z), fabsf(y4.w))) > NM_EXP2X_MAX;
             *reinterpret_cast<float4*>(ys + q * p.A + i) =
-                *reinterpret_cast<const float4*>(p.y + attn_qrow(p, b, q0 + q) * p.A + i);
+                make_float4(nm_exp2x(y4.x), nm_exp2x(y4.y), nm_exp2x(y4.z), nm_exp2x(y4.w));
+        }
+    if (wide) y_wide = 1;
     for (int i = tid * 4; i < p.A; i += 1024)
         *reinterpret_cast<float4*>(vs + i) = *reinterpret_cast<const float4*>(p.v + i);
     if (tid < ATT_MAX_SCH)
         ms[tid] = (tid < ns) ? (p.mask ? p.mask[(long)b * p.S + s0 + tid] : 1.0f) : 0.0f;
     __syncthreads();
+    const bool y_exact = y_wide != 0;
 
     const float bias = p.bias ? p.bias[0] : 0.0f;
 
@@ -239,13 +251,32 @@ __global__ __launch_bounds__(256) void attn_partial(AttnArgs p) {
                     h4[i] = *reinterpret_cast<const float4*>(hbase + (long)sl * p.A + a);
                 }
                 const float4 v4 = *reinterpret_cast<const float4*>(vs + a);
+                float hmax = 0.0f;
 #pragma unroll
-                for (int q = 0; q < QPK; ++q) {
-                    const float4 y4 = *reinterpret_cast<const float4*>(ys + q * p.A + a);
+                for (int i = 0; i < 4; ++i)
+                    hmax = fmaxf(fmaxf(hmax, fmaxf(fabsf(h4[i].x), fabsf(h4[i].y))), fmaxf(fabsf(h4[i].z), fabsf(h4[i].w)));
+                if (y_exact || hmax > NM_EXP2X_MAX) {            // outside the product form's exact range (rare)
+#pragma unroll
+                    for (int q = 0; q < QPK; ++q) {
+                        const float4 y4 = *reinterpret_cast<const float4*>(p.y + attn_qrow(p, b, q0 + q) * p.A + a);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            acc[q][i] += v4.x * nm_tanh(h4[i].x + y4.x) + v4.y * nm_tanh(h4[i].y + y4.y) +
+                                         v4.z * nm_tanh(h4[i].z + y4.z) + v4.w * nm_tanh(h4[i].w + y4.w);
+                    }
+                } else {
+                    float4 eh[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        acc[q][i] += v4.x * nm_tanh(h4[i].x + y4.x) + v4.y * nm_tanh(h4[i].y + y4.y) +
-                                     v4.z * nm_tanh(h4[i].z + y4.z) + v4.w * nm_tanh(h4[i].w + y4.w);
+                        eh[i] = make_float4(nm_exp2x(h4[i].x), nm_exp2x(h4[i].y), nm_exp2x(h4[i].z), nm_exp2x(h4[i].w));
+#pragma unroll
+                    for (int q = 0; q < QPK; ++q) {
+                        const float4 ey = *reinterpret_cast<const float4*>(ys + q * p.A + a);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            acc[q][i] += v4.x * nm_tanh_prod(eh[i].x, ey.x) + v4.y * nm_tanh_prod(eh[i].y, ey.y) +
+                                         v4.z * nm_tanh_prod(eh[i].z, ey.z) + v4.w * nm_tanh_prod(eh[i].w, ey.w);
+                    }
                 }
             }
 #pragma unroll
@@ -532,14 +563,36 @@ __global__ __launch_bounds__(256) void attn_partial_fastq(AttnArgs p) {
     for (int s = 0; s < ROWS; ++s)
         str[s] = *reinterpret_cast<const float4*>(sbase + (long)min(s, ns - 1) * p.C);
 
+    // NQ queries read every key element: exp(2 hf) once per element, exp(2 y) once per query column, one v_rcp_f32
+    // per tanh (nm_tanh_prod); a wave whose queries or keys leave that form's exact range takes nm_tanh instead
+    float ymax = 0.0f;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+        ymax = fmaxf(fmaxf(ymax, fmaxf(fabsf(y4[q].x), fabsf(y4[q].y))), fmaxf(fabsf(y4[q].z), fabsf(y4[q].w)));
+    float4 ey[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+        ey[q] = make_float4(nm_exp2x(y4[q].x), nm_exp2x(y4[q].y), nm_exp2x(y4[q].z), nm_exp2x(y4[q].w));
 #pragma unroll
     for (int s = 0; s < ROWS; ++s) {
+        const float hmax = fmaxf(fmaxf(fabsf(hfr[s].x), fabsf(hfr[s].y)), fmaxf(fabsf(hfr[s].z), fabsf(hfr[s].w)));
+        if (__any(fmaxf(hmax, ymax) > NM_EXP2X_MAX)) {           // wave-uniform: the DPP sums below need all lanes
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            float part = v4.x * nm_tanh(hfr[s].x + y4[q].x) + v4.y * nm_tanh(hfr[s].y + y4[q].y) +
-                         v4.z * nm_tanh(hfr[s].z + y4[q].z) + v4.w * nm_tanh(hfr[s].w + y4[q].w);
-            part = nm_wave_sum_dpp(part);
-            if (lane == 0) pe[wave][q][s] = part;
+            for (int q = 0; q < NQ; ++q) {
+                float part = v4.x * nm_tanh(hfr[s].x + y4[q].x) + v4.y * nm_tanh(hfr[s].y + y4[q].y) +
+                             v4.z * nm_tanh(hfr[s].z + y4[q].z) + v4.w * nm_tanh(hfr[s].w + y4[q].w);
+                part = nm_wave_sum_dpp(part);
+                if (lane == 0) pe[wave][q][s] = part;
+            }
+        } else {
+            const float4 eh = make_float4(nm_exp2x(hfr[s].x), nm_exp2x(hfr[s].y), nm_exp2x(hfr[s].z), nm_exp2x(hfr[s].w));
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                float part = v4.x * nm_tanh_prod(eh.x, ey[q].x) + v4.y * nm_tanh_prod(eh.y, ey[q].y) +
+                             v4.z * nm_tanh_prod(eh.z, ey[q].z) + v4.w * nm_tanh_prod(eh.w, ey[q].w);
+                part = nm_wave_sum_dpp(part);
+                if (lane == 0) pe[wave][q][s] = part;
+            }
         }
     }
     __syncthreads();

@@ -507,10 +507,16 @@ __global__ __launch_bounds__(128) void attn_energy_bwd_kernel(
     if (a >= A) return;
     const float va = v[a];
     for (int s0 = 0; s0 < S; s0 += SCH) {
-        float h[SCH], g_acc[SCH], z_acc[SCH];
+        // every key element h[i] meets all T queries: exp(2 h) once per element, exp(2 y) once per query, one
+        // v_rcp_f32 per tanh (nm_tanh_prod); beyond that form's exact range (|.| > NM_EXP2X_MAX) the thread takes
+        // nm_tanh on the sums for the affected queries
+        float h[SCH], eh[SCH], g_acc[SCH], z_acc[SCH];
+        float hmax = 0.0f;
 #pragma unroll
         for (int i = 0; i < SCH; ++i) {
             h[i] = (s0 + i < S) ? hf[((long)b * S + s0 + i) * A + a] : 0.0f;
+            eh[i] = nm_exp2x(h[i]);
+            hmax = fmaxf(hmax, fabsf(h[i]));
             g_acc[i] = 0.0f;
             z_acc[i] = 0.0f;
         }
@@ -521,14 +527,29 @@ __global__ __launch_bounds__(128) void attn_energy_bwd_kernel(
             if (t + 1 < T) yy_next = y[(row + B) * A + a];
             const float* der = de + row * S + s0;
             float dsum = 0.0f;
+            // (two loops, not a select per element: hipcc if-converts `exact ? nm_tanh : nm_tanh_prod` and then
+            // evaluates BOTH -- three transcendentals per element, measured 0.49 ms against 0.39 before the change)
+            if (fmaxf(hmax, fabsf(yy)) > NM_EXP2X_MAX) {
 #pragma unroll
-            for (int i = 0; i < SCH; ++i) {
-                const float d = (s0 + i < S) ? der[i] : 0.0f;
-                const float z = nm_tanh(h[i] + yy);
-                const float g = d * (1.0f - z * z);
-                g_acc[i] += g;
-                z_acc[i] += d * z;
-                dsum += g;
+                for (int i = 0; i < SCH; ++i) {
+                    const float d = (s0 + i < S) ? der[i] : 0.0f;
+                    const float z = nm_tanh(h[i] + yy);
+                    const float g = d * (1.0f - z * z);
+                    g_acc[i] += g;
+                    z_acc[i] += d * z;
+                    dsum += g;
+                }
+            } else {
+                const float ey = nm_exp2x(yy);
+#pragma unroll
+                for (int i = 0; i < SCH; ++i) {
+                    const float d = (s0 + i < S) ? der[i] : 0.0f;
+                    const float z = nm_tanh_prod(eh[i], ey);
+                    const float g = d * (1.0f - z * z);
+                    g_acc[i] += g;
+                    z_acc[i] += d * z;
+                    dsum += g;
+                }
             }
             float* dyp = dy + row * A + a;
             *dyp = (s0 == 0) ? va * dsum : *dyp + va * dsum;

@@ -125,3 +125,14 @@ __device__ __forceinline__ float nm_tanh(float x) {
     return copysignf(t, x);
 }
 __device__ __forceinline__ float nm_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+// tanh(a + b) = 1 - 2 / (1 + exp(2a) exp(2b)): when one of the two exponentials is shared by many elements (a key row
+// that several queries read, a query that many key rows read) an element costs ONE quarter-rate transcendental
+// (v_rcp_f32) instead of nm_tanh's two (v_exp_f32 + v_rcp_f32).  ~1e-7 absolute error, like nm_tanh.  A product that
+// overflows gives +1, one that underflows gives -1; nm_exp2x clamps its argument to NM_EXP2X_MAX so that neither
+// factor is ever inf or 0 (no inf * 0), which is exact as long as |a|, |b| <= NM_EXP2X_MAX: callers check that
+// (max |.| of what they exponentiate) and take nm_tanh(a + b) otherwise.
+#define NM_EXP2X_MAX 43.0f
+__device__ __forceinline__ float nm_exp2x(float x) { return __expf(2.0f * fminf(fmaxf(x, -NM_EXP2X_MAX), NM_EXP2X_MAX)); }
+__device__ __forceinline__ float nm_tanh_prod(float ea, float eb) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(fmaf(ea, eb, 1.0f));
+}

@@ -36,3 +36,27 @@ def test_attn_energy_bwd_matches_torch(dev, t, b, s, a, accumulate):
     for got, want in ((dhf, want_dhf), (dvp.view(b, s, a), want_dvp), (dy, want_dy)):
         scale = float(want.abs().max())
         assert float((got - want).abs().max()) <= 2e-5 * max(scale, 1.0)
+
+
+@pytest.mark.parametrize("t,b,s,a", [(4, 2, 50, 260), (3, 2, 9, 130)])
+def test_attn_energy_bwd_beyond_the_product_form_range(dev, t, b, s, a):
+    """Keys / queries of magnitude up to ~60 that nearly cancel: exp(2 x) overflows fp32 beyond |x| = 44, so the
+    product form tanh(h + y) = 1 - 2 / (1 + exp(2h) exp(2y)) is only used up to NM_EXP2X_MAX = 43 and the kernel
+    must take tanh(h + y) itself for the affected elements -- same tolerance as everywhere else."""
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(s * 7 + a)
+    mk = lambda *shape: torch.tensor(rng.standard_normal(shape).astype(np.float32), device=dev)
+    de, v = mk(t, b, s), mk(a)
+    hf = mk(b, s, a)
+    hf[:, ::3, ::5] += 55.0                                     # some key elements far outside
+    hf[:, 1::4, 1::7] -= 60.0
+    y = mk(t, b, a)
+    y[:, :, ::5] -= 54.0                                        # ... cancelled by the matching query columns
+    y[1:, :, 1::7] += 59.0
+    dhf, dvp, dy = torch.zeros(b, s, a, device=dev), torch.zeros(b * s, a, device=dev), torch.zeros(t, b, a, device=dev)
+    ops.attn_energy_bwd(de, hf, y, v, dhf, dvp, dy, accumulate=False)
+    want_dhf, want_dvp, want_dy = _reference(de, hf, y, v)
+    for got, want in ((dhf, want_dhf), (dvp.view(b, s, a), want_dvp), (dy, want_dy)):
+        assert torch.isfinite(got).all()
+        scale = float(want.abs().max())
+        assert float((got - want).abs().max()) <= 2e-5 * max(scale, 1.0)

@@ -547,6 +547,57 @@ def test_attention_time_major_all_steps(dev, t, b, s, a, c):
         assert rel_err(ctx1.cpu().numpy(), ctx[i].cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("bk,qpk,t", [(4, 5, 0), (3, 1, 6)])
+def test_attention_beyond_the_product_form_range(dev, bk, qpk, t):
+    """The multi-query kernels evaluate tanh(hf + y) as 1 - 2 / (1 + exp(2 hf) exp(2 y)) -- exact only while
+    exp(2 x) stays inside fp32 (|x| <= 43).  Keys and queries of magnitude ~55 that nearly cancel must come out
+    like everything else (beam queries per sentence: qpk = 5; all steps of a sentence: t = 6)."""
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(bk * 17 + qpk)
+    s, a, c = 50, 1024, 1024
+    states = rng.standard_normal((bk, s, c)).astype(np.float32)
+    hf = rng.standard_normal((bk, s, a)).astype(np.float32)
+    hf[:, ::3, ::5] += 55.0
+    hf[:, 1::4, 1::7] -= 60.0
+    mask = np.ones((bk, s), np.float32)
+    mask[0, 40:] = 0
+    v = (rng.standard_normal(a) * 0.3).astype(np.float32)
+    nq = t or qpk
+    y = rng.standard_normal((bk * nq if not t else t * bk, a)).astype(np.float32)
+    y[:, ::5] -= 54.0
+    y[1::2, 1::7] += 59.0
+    f64 = lambda x: np.asarray(x, dtype=np.float64)
+
+    def ref(yrows, b):
+        e = np.tanh(f64(hf[b])[None] + f64(yrows)[:, None, :]) @ f64(v) + 0.37        # [nq, S]
+        ex = np.exp(e - e.max(1, keepdims=True))
+        sm = ex / ex.sum(1, keepdims=True)
+        w = sm * f64(mask[b])
+        w = w / (w.sum(1, keepdims=True) + 1e-8)
+        return w @ f64(states[b]), w
+    bias = T(np.array([0.37], np.float32), dev)
+    if t:
+        ctx = torch.empty((t, bk, c), device=dev)
+        w = torch.empty((t, bk, s), device=dev)
+        e = torch.empty((t, bk, s), device=dev)
+        ops.attn_fwd_time_major(T(y, dev).view(t, bk, a), T(hf, dev), T(states, dev), T(mask, dev), T(v, dev), bias,
+                                ctx, w, ops.attn_workspace(t * bk, s, c, dev), e)
+        got_ctx, got_w = ctx.cpu().numpy(), w.cpu().numpy()
+        for b in range(bk):
+            rc, rw = ref(y.reshape(t, bk, a)[:, b], b)
+            assert rel_err(got_w[:, b], rw) < RTOL and rel_err(got_ctx[:, b], rc) < RTOL
+    else:
+        ctx = torch.empty((bk * qpk, c), device=dev)
+        w = torch.empty((bk * qpk, s), device=dev)
+        ops.attn_fwd(T(y, dev), T(hf, dev), T(states, dev), T(mask, dev), T(v, dev), bias, qpk, ctx, w,
+                     ops.attn_workspace(bk * qpk, s, c, dev))
+        got_ctx, got_w = ctx.cpu().numpy(), w.cpu().numpy()
+        assert np.isfinite(got_ctx).all()
+        for b in range(bk):
+            rc, rw = ref(y[b * qpk:(b + 1) * qpk], b)
+            assert rel_err(got_w[b * qpk:(b + 1) * qpk], rw) < RTOL and rel_err(got_ctx[b * qpk:(b + 1) * qpk], rc) < RTOL
+
+
 def test_attention_all_masked_row(dev):
     """A fully masked sentence gives zero weights (0/(0+1e-8)), not NaN."""
     from neuralmonkey_amd import ops
