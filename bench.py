@@ -318,13 +318,17 @@ def main():
         dsb = [synthetic.synthetic_dataset(seed=99 + 10 * i + rank, batch=args.batch, src_len=args.length,
                                            tgt_len=args.length, vocab=args.vocab, with_target=False)
                for i in range(min(4, args.beam_batches))]
-        for i in range(2):                  # warm-up: eager pass (allocations) + HIP-graph capture pass
-            out = tfm.execute(dsb[i % len(dsb)], runner.feedables, [runner], compute_losses=False)[0]
+        for i in range(5):                  # warm-up: eager pass (allocations) + HIP-graph capture pass, in BOTH
+            #                                     buffer slots consecutive batches alternate between (look-ahead)
+            out = tfm.execute(dsb[i % len(dsb)], runner.feedables, [runner], compute_losses=False,
+                              lookahead=dsb[(i + 1) % len(dsb)])[0]
         barrier()
         tb = time.perf_counter()
         emitted = 0
         for i in range(args.beam_batches):
-            out = tfm.execute(dsb[i % len(dsb)], runner.feedables, [runner], compute_losses=False)[0]
+            # a stream of batches: the next batch's encoder runs on a second stream under this batch's search
+            nxt = dsb[(i + 1) % len(dsb)] if i + 1 < args.beam_batches else None
+            out = tfm.execute(dsb[i % len(dsb)], runner.feedables, [runner], compute_losses=False, lookahead=nxt)[0]
             emitted += sum(min(len(s) + 1, args.length) for s in out.outputs[runner.output_series])
         barrier()
         tb = time.perf_counter() - tb
@@ -408,14 +412,16 @@ def main():
     dsg = [synthetic.synthetic_dataset(seed=77 + 10 * i + rank, batch=args.batch, src_len=args.length,
                                        tgt_len=args.length, vocab=args.vocab, with_target=False) for i in range(4)]
     grunner = model.greedy_runner
-    for i in range(2):                      # warm-up: eager pass + HIP-graph capture pass
-        tfm.execute(dsg[i], grunner.feedables, [grunner], compute_losses=False)
+    for i in range(5):                      # warm-up: eager pass + HIP-graph capture pass in both buffer slots
+        tfm.execute(dsg[i % 4], grunner.feedables, [grunner], compute_losses=False, lookahead=dsg[(i + 1) % 4])
     barrier()
     tg = time.perf_counter()
-    for i in range(4):
-        tfm.execute(dsg[i], grunner.feedables, [grunner], compute_losses=False)
+    GREEDY_BATCHES = 8
+    for i in range(GREEDY_BATCHES):
+        nxt = dsg[(i + 1) % 4] if i + 1 < GREEDY_BATCHES else None
+        tfm.execute(dsg[i % 4], grunner.feedables, [grunner], compute_losses=False, lookahead=nxt)
     barrier()
-    greedy_ms = (time.perf_counter() - tg) * 1e3 / 4
+    greedy_ms = (time.perf_counter() - tg) * 1e3 / GREEDY_BATCHES
     # the same decode once more with graph replay off, HIP events around every attention step
     sess0 = tfm.sessions[0]
     graphs_were = sess0.use_graphs

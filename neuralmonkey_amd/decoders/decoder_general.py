@@ -309,7 +309,7 @@ class GeneralStepper:
         # handles are kept with the session so that a chunk of steps launched from Python can follow a chunk
         # that was replayed from a captured graph (whose Python body did not run).
         self._produced = ctx.session.__dict__.setdefault("_stepper_state", {}).setdefault(
-            (id(dec), tag, rows), {})
+            (id(dec), tag, rows, ctx.session.slot), {})
 
     indexed = True       # set_position(t, cur) makes a step a function of its index: HIP-graph capturable
 

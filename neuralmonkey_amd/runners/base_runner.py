@@ -11,6 +11,29 @@ import numpy as np
 from ..checking import check_constructor_chain
 from ..model.model_part import Feedable, GenericModelPart, Parameterized
 
+
+def encoder_side_fetches(decoder) -> List[Any]:
+    """What a decoding run needs that does not depend on the decoding loop itself: the states / masks / outputs
+    of the decoder's encoders, the keys of its attentions, its initial state.  ``TensorFlowManager.execute(...,
+    lookahead=next_batch)`` evaluates these for the NEXT batch on a second stream while the current batch decodes."""
+    from ..runtime import Fetch
+    found: List[Any] = []
+
+    def take(owner, names):
+        for name in names:
+            try:
+                handle = getattr(owner, name, None)
+            except Exception:                # pylint: disable=broad-except   (a property that needs a run context)
+                handle = None
+            if isinstance(handle, Fetch):
+                found.append(handle)
+    for enc in getattr(decoder, "encoders", None) or []:
+        take(enc, ("temporal_states", "temporal_mask", "spatial_states", "spatial_mask", "output"))
+    for att in getattr(decoder, "attentions", None) or []:
+        take(att, ("attention_states", "attention_mask", "hidden_features"))
+    take(decoder, ("initial_state",))
+    return found
+
 FeedDict = Dict[Any, Any]
 NextExecute = Tuple[Union[Dict, List], List[FeedDict]]
 MP = TypeVar("MP", bound=GenericModelPart)

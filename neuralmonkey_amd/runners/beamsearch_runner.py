@@ -61,6 +61,10 @@ class BeamSearchRunner(BaseRunner):
         self.rank = rank
         self.postprocess = postprocess
 
+    def ahead_fetches(self) -> List[Any]:
+        from .base_runner import encoder_side_fetches
+        return encoder_side_fetches(self.decoder.parent_decoder)
+
     @property
     def fetches(self) -> Dict[str, Any]:
         return {"bs_outputs": self.decoder.outputs}

@@ -55,6 +55,10 @@ class GreedyRunner(BaseRunner):
         self.postprocess = postprocess
         self.vocabulary = self.decoder.vocabulary
 
+    def ahead_fetches(self) -> List[Any]:
+        from .base_runner import encoder_side_fetches
+        return encoder_side_fetches(self.decoder)
+
     @property
     def fetches(self) -> Dict[str, Any]:
         return {"decoded_symbols": self.decoder.decoded_symbols,

@@ -236,6 +236,13 @@ class Session:
         self._copy_stream = None
         self._tls = threading.local()
         self.global_step = 0
+        # Look-ahead (``run(..., ahead=...)``): the encoder side of the NEXT batch is evaluated on a second stream
+        # while this batch decodes.  Every persistent buffer and captured graph belongs to a SLOT; consecutive
+        # batches alternate between slot 0 and slot 1, so the batch that is being encoded ahead never touches what
+        # the running batch reads.
+        self.slot = 0
+        self._ahead: list = []                # [(feed signature, slot, memo, event, feed)]
+        self._ahead_stream = None
 
     def to_device(self, array, dtype, tag=None, derive=None):
         """Host array (or ``derive(array)``) -> device tensor.  Arrays that are
@@ -290,7 +297,7 @@ class Session:
         """Persistent scratch tensor.  Keyed by (key, shape, dtype) and never
         re-allocated, so device pointers baked into captured HIP graphs stay valid."""
         shape = tuple(int(s) for s in shape)
-        full = (key, shape, dtype)
+        full = (key, shape, dtype) if not self.slot else (("slot", self.slot), key, shape, dtype)
         buf = self._buffers.get(full)
         if buf is None:
             make = torch.zeros if zero_init else torch.empty
@@ -361,6 +368,8 @@ class Session:
         if not self.use_graphs or self.device.type != "cuda" or torch.cuda.is_current_stream_capturing():
             fn()                      # (inside an enclosing capture the launches simply join that graph)
             return
+        if self.slot:
+            key = (("slot", self.slot), key)
         state = self._graphs.get(key)
         if state is None:
             fn()
@@ -384,6 +393,8 @@ class Session:
         if not self.use_graphs or self.device.type != "cuda" or torch.cuda.is_current_stream_capturing():
             return fn()
         store = self.__dict__.setdefault("_step_graphs", {})
+        if self.slot:
+            key = (("slot", self.slot), key)
         state = store.pop(key, None)
         if state is None:
             result = fn()
@@ -424,8 +435,66 @@ class Session:
             return type(fetch)(self._eval(v, ctx) for v in fetch)
         return fetch                      # constants / None pass through
 
-    def run(self, fetches, feed_dict: Optional[Dict[Placeholder, Any]] = None):
-        ctx = RunContext(self, dict(feed_dict or {}))
+    # -- look-ahead ---------------------------------------------------------------------------------------
+    @staticmethod
+    def _feed_signature(feed) -> frozenset:
+        """Which batch a feed dictionary belongs to: the identities of the host arrays it feeds (a batch hands
+        out the SAME id arrays every time it is fed, model/sequence.py:cached_index)."""
+        return frozenset((ph.name, id(val)) for ph, val in feed.items() if isinstance(val, np.ndarray))
+
+    def _claim_ahead(self, feed) -> Optional[Dict[Any, Any]]:
+        """If this feed was evaluated ahead: switch to its buffer slot, order the current stream after the
+        look-ahead stream's work and hand back what was computed.  Stale entries (batches that never came) go."""
+        if not self._ahead:
+            return None
+        now = self._feed_signature(feed)
+        hit = None
+        for entry in self._ahead:
+            if entry[0] and entry[0] <= now:
+                hit = entry
+        self._ahead = []
+        if hit is None:
+            return None
+        _, slot, memo, event, _ = hit
+        self.slot = slot
+        torch.cuda.current_stream(self.device).wait_event(event)
+        return memo
+
+    def _run_ahead(self, fetches, feed) -> None:
+        """Evaluate ``fetches`` (the encoder side of a FUTURE batch) on the look-ahead stream, into the buffer slot
+        the running batch does not use.  Nothing of the running batch is touched: the other slot's buffers were last
+        read by the batch before it, whose results the host has already collected."""
+        if self.device.type != "cuda" or torch.cuda.is_current_stream_capturing():
+            return
+        if self._ahead_stream is None:
+            self._ahead_stream = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        start = torch.cuda.Event()
+        start.record(main)                                   # after whatever is already queued (nothing, normally)
+        mine = self.slot
+        self.slot = mine ^ 1
+        try:
+            self._ahead_stream.wait_event(start)
+            with torch.cuda.stream(self._ahead_stream), torch.no_grad():
+                ctx = RunContext(self, dict(feed))
+                self._eval(fetches, ctx)
+                done = torch.cuda.Event()
+                done.record(self._ahead_stream)
+            self._ahead.append((self._feed_signature(feed), self.slot, ctx.memo, done, feed))
+        finally:
+            self.slot = mine
+
+    def run(self, fetches, feed_dict: Optional[Dict[Placeholder, Any]] = None, ahead=None):
+        """``ahead`` = (fetches, feed_dict) of the NEXT batch: tensors that do not depend on this run (its encoder
+        states, attention keys, initial decoder state) are evaluated on a second stream while this run decodes;
+        the run that later feeds that batch finds them computed."""
+        feed = dict(feed_dict or {})
+        claimed = self._claim_ahead(feed)
+        if ahead is not None:
+            self._run_ahead(*ahead)
+        ctx = RunContext(self, feed)
+        if claimed:
+            ctx.memo.update(claimed)
         with torch.no_grad():
             out = self._eval(fetches, ctx)
         return _to_host(out)

@@ -91,7 +91,7 @@ class TensorFlowManager:
                 self.best_score_index = worst_index
 
     # -- execution (tf_manager.py:158-225) -----------------------------------------------
-    def _run_executables(self, feed_dict: Dict, executables: List[GraphExecutor.Executable]) -> None:
+    def _run_executables(self, feed_dict: Dict, executables: List[GraphExecutor.Executable], ahead=None) -> None:
         all_fetches = {}
         feed_dicts: List[Dict] = [{} for _ in self.sessions]
         pending = [ex for ex in executables if ex.result is None]
@@ -110,7 +110,8 @@ class TensorFlowManager:
                 ctxs = [RunContext(sess, dict(fd)) for sess, fd in zip(self.sessions, feed_dicts)]
                 with torch.no_grad():
                     ensemble_results[executable] = _to_host(executable.run_ensemble(ctxs))
-        session_results = [sess.run(all_fetches, feed_dict=fd) for sess, fd in zip(self.sessions, feed_dicts)]
+        session_results = [sess.run(all_fetches, feed_dict=fd, ahead=ahead if len(self.sessions) == 1 else None)
+                           for sess, fd in zip(self.sessions, feed_dicts)]
         for executable in pending:
             if executable in ensemble_results:
                 executable.collect_results([ensemble_results[executable] for _ in self.sessions])
@@ -119,12 +120,22 @@ class TensorFlowManager:
 
     def execute(self, batch, feedables: Set[Feedable], runners: Sequence[GraphExecutor],
                 train: bool = False, compute_losses: bool = True,
-                summaries: bool = True) -> List[ExecutionResult]:
+                summaries: bool = True, lookahead=None) -> List[ExecutionResult]:
+        """tf_manager.py:188-225.  ``lookahead`` (not in the reference) names the batch that will be executed
+        NEXT with the same runners: its encoder side (what ``GraphExecutor.ahead_fetches`` lists: encoder states,
+        attention keys, initial decoder states) is evaluated on a second stream while this batch decodes -- both
+        are latency-bound and leave most CUs idle (runtime.Session.run).  Inference with one session only."""
         default_feed_dict = _feed_dicts(batch, feedables, train=train)
         executables = [runner.get_executable(compute_losses=compute_losses, summaries=summaries,
                                              num_sessions=len(self.sessions)) for runner in runners]
+        ahead = None
+        if lookahead is not None and not train and len(self.sessions) == 1:
+            fetches = [f for runner in runners for f in getattr(runner, "ahead_fetches", lambda: [])()]
+            if fetches:
+                ahead = (fetches, _feed_dicts(lookahead, feedables, train=False))
         while not all(ex.result is not None for ex in executables):
-            self._run_executables(default_feed_dict, executables)
+            self._run_executables(default_feed_dict, executables, ahead)
+            ahead = None
         return [ex.result for ex in executables]
 
     # -- variables ---------------------------------------------------------------------------

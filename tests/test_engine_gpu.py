@@ -265,3 +265,44 @@ def test_greedy_chunks_captured_at_different_times_keep_the_state(dev):
             os.environ.pop("NM_NO_FUSED_STEP", None)
             if old is not None:
                 os.environ["NM_NO_FUSED_STEP"] = old
+
+
+def test_lookahead_encodes_the_next_batch_on_a_second_stream(dev):
+    """``TensorFlowManager.execute(..., lookahead=next_batch)``: the next batch's encoder states, attention keys and
+    initial decoder state are evaluated on a second stream, in the other buffer slot, while the current batch
+    decodes.  Seven batches (the slots alternate; eager, capture and replay passes in both), one announced batch
+    that never comes, one batch of another shape in between: every greedy and beam result is the oracle's."""
+    from neuralmonkey_amd import synthetic
+    vocab, emb, rnn, slen = 120, 16, 16, 9
+    model = synthetic.build_translation_model(vocab_src=vocab, vocab_tgt=vocab, emb=emb, rnn=rnn, max_len=12,
+                                              beam_size=3, max_steps=12, device=str(dev), with_trainer=False)
+    params = O.init_params(seed=21, vocab_src=vocab, vocab_tgt=vocab, emb=emb, rnn=rnn, std=0.3)
+    sess = model.tf_manager.sessions[0]
+    sess.store.load_state_dict(params)
+    spec = O.DecoderSpec(max_output_len=12)
+    w2i = model.tgt_vocab._word_to_index
+    sizes = [6, 6, 6, 4, 6, 6, 6]
+    batches = [synthetic.synthetic_dataset(seed=500 + i, batch=b, src_len=slen, tgt_len=slen, vocab=vocab, ragged=True,
+                                           with_target=False) for i, b in enumerate(sizes)]
+    never = synthetic.synthetic_dataset(seed=999, batch=6, src_len=slen, tgt_len=slen, vocab=vocab, ragged=True,
+                                        with_target=False)
+    runners = [model.greedy_runner, model.beam_runner]
+    feedables = model.greedy_runner.feedables | model.beam_runner.feedables
+    slots = []
+    for i, ds in enumerate(batches):
+        nxt = batches[i + 1] if i + 1 < len(batches) else None
+        if i == 4:
+            nxt = never                                   # announced, never executed: dropped at the next run
+        res = model.tf_manager.execute(ds, feedables, runners, compute_losses=False, lookahead=nxt)
+        slots.append(sess.slot)
+        src = O.pad_ids([list(s) for s in ds.get_series("source")], 12)
+        enc = O.sentence_encoder(params, src)
+        want = O.greedy_tokens(O.decoding_loop(params, spec, enc, None, False))
+        got = [[w2i[w] for w in sent] for sent in res[0].outputs["target"]]
+        assert got == want, "greedy mismatch on pass {}".format(i)
+        bres = O.beam_search(params, spec, enc, 3, 12, 0.6)
+        if bres.min_gap > 1e-5:
+            want_beam, _ = O.beam_tokens(bres, 1)
+            assert [[w2i[w] for w in sent] for sent in res[1].outputs["target_beam"]] == want_beam, i
+    assert slots[:5] == [0, 1, 0, 1, 0] and slots[5] == 0 and slots[6] == 1      # batch 5 was not announced
+    assert not sess._ahead

@@ -28,12 +28,15 @@ def main():
                                         with_target=False) for i in range(2)]
     tfm = model.tf_manager
     runner = model.beam_runner if args.mode == "beam" else model.greedy_runner
-    for i in range(2):
-        tfm.execute(sets[i], runner.feedables, [runner], compute_losses=False)
+    for i in range(5):           # eager + capture passes in both buffer slots (look-ahead alternates them)
+        tfm.execute(sets[i % 2], runner.feedables, [runner], compute_losses=False,
+                    lookahead=None if os.environ.get("NM_NO_LOOKAHEAD") else sets[(i + 1) % 2])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    ahead = not os.environ.get("NM_NO_LOOKAHEAD")
     for i in range(args.batches):
-        tfm.execute(sets[i % 2], runner.feedables, [runner], compute_losses=False)
+        nxt = sets[(i + 1) % 2] if (ahead and i + 1 < args.batches) else None
+        tfm.execute(sets[i % 2], runner.feedables, [runner], compute_losses=False, lookahead=nxt)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.batches
     print("{}: {:.2f} ms/batch  {:.1f} us/step  {:.0f} tok/s".format(args.mode, dt * 1e3, dt * 1e6 / 50,
