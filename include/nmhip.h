@@ -244,6 +244,10 @@ typedef struct nm_decoder_step {
     const float* wo_h_t; const float* wo_e_t; const float* wo_c_t; const float* bo;
     const float* w_vocab; int64_t ld_w_vocab; const float* b_vocab;
     int32_t out_act, vocab_trans_b;
+    /* leading dimensions in floats, 0 = dense (emb + rnn for cat and wg_t, the K of the product for the other
+     * transposed weights, ctx_width for ctx).  Power-of-two row strides (4 KB at the benchmark shape) put every
+     * row of an operand tile on the same L2 channel; a caller that pads its rows by 128 bytes spreads them. */
+    int64_t ld_cat, ld_ctx, ld_wg, ld_wcx, ld_wch, ld_wq, ld_wo_h, ld_wo_e, ld_wo_c;
 } nm_decoder_step;
 int nm_decoder_step_fused(void* stream, const nm_decoder_step* step);
 

@@ -138,7 +138,9 @@ class DecoderStep(ctypes.Structure):
                 [("attn_workspace", P), ("attn_workspace_bytes", L)] +
                 [(n, P) for n in ("wg_t", "bg", "wcx_t", "wch_t", "bc", "wq_t", "bq", "keys", "values", "mask", "v",
                                   "attn_bias", "wo_h_t", "wo_e_t", "wo_c_t", "bo", "w_vocab")] +
-                [("ld_w_vocab", L), ("b_vocab", P), ("out_act", ctypes.c_int32), ("vocab_trans_b", ctypes.c_int32)])
+                [("ld_w_vocab", L), ("b_vocab", P), ("out_act", ctypes.c_int32), ("vocab_trans_b", ctypes.c_int32)] +
+                [(n, L) for n in ("ld_cat", "ld_ctx", "ld_wg", "ld_wcx", "ld_wch", "ld_wq", "ld_wo_h", "ld_wo_e",
+                                  "ld_wo_c")])
 
 
 def load():

@@ -252,8 +252,15 @@ __global__ __launch_bounds__(KS * 64, AKIND == 0 ? 8 : 4) void step_group_kernel
 // workgroup owns one 32x32 output tile (v_mfma_f32_32x32x2_f32, exact f32), its KS waves split K, both fragments
 // of a wave arrive as coalesced 128-byte lines through a wave-private LDS tile (no workgroup barrier in the loop),
 // the next trip's lines are requested before the current trip's MFMAs, partial sums meet in LDS.  A group of the
-// 640-row step is 640..1280 workgroups of 4 waves, four of them resident per CU (37 KB LDS each); weights are read
-// M/32 times from L2.  Same problems, epilogues and results as step_group_kernel (a_kind 0).
+// 640-row step is 640..1280 workgroups of 4 waves (32 KB LDS each); weights are read M/32 times from L2.  Same
+// problems, epilogues and results as step_group_kernel (a_kind 0).
+// Measured and not kept: (1) the same loop as an explicit three-stage software pipeline (next-but-one trip's lines in
+// flight, next trip's fragments read from LDS under the current trip's 16 MFMAs; 193 VGPRs, two workgroups per CU):
+// group 1 at 640 rows 39.1 us against 39.4, the 8-wave groups 18.7 against 14.1 us; (2) operand rows padded by 128
+// bytes against L2-channel aliasing of the 4 KB row stride: no difference.  Every variant of this kernel -- lane-per-
+// row loads, coalesced lines, 4 or 5 workgroups per CU, pipelined or not -- lands at ~50 TFLOP/s, a third of the
+// matrix peak; the PMC passes (profiles/r03_step_group_medium_pmc.txt) show the matrix pipes 31 % busy and ~10 waves
+// per CU resident on average.  What bounds it is an open question.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int KS>
@@ -397,7 +404,9 @@ extern "C" int nm_step_group(void* stream, int64_t M, const nm_step_problem* pro
     for (int i = 0; i < nprob; ++i) tiles16 += (long)nm_cdiv(M, 16) * nm_cdiv(probs[i].N, 16);
     // medium M (beam search): 32x32 tiles, 4 waves split K (step_group_medium_kernel); NM_STEP_MEDIUM=0 keeps the
     // 16-row tiles
-    const bool medium = probs[0].a_kind == 0 && M > 256 && nm_cur()->sw.medium_m != 0;
+    bool medium = probs[0].a_kind == 0 && M > 256 && nm_cur()->sw.medium_m != 0;
+    for (int i = 0; i < nprob && medium; ++i)          // 32-bit element offsets inside the medium kernel
+        medium = M * probs[i].lda < (1LL << 31) && probs[i].N * probs[i].ldb < (1LL << 31);
     const int tm = medium ? 2 : ((probs[0].a_kind == 0 && tiles16 > 512) ? 2 : 1);
     const int tile_n = medium ? 32 : 16;
     g.tiles_m = nm_cdiv(M, 16 * tm);
@@ -486,6 +495,7 @@ struct nm_decoder_step {          // mirrors include/nmhip.h
     const float* wo_h_t; const float* wo_e_t; const float* wo_c_t; const float* bo;
     const float* w_vocab; int64_t ld_w_vocab; const float* b_vocab;
     int32_t out_act, vocab_trans_b;
+    int64_t ld_cat, ld_ctx, ld_wg, ld_wcx, ld_wch, ld_wq, ld_wo_h, ld_wo_e, ld_wo_c;
 };
 
 extern "C" int nm_decoder_step_fused(void* stream, const nm_decoder_step* d) {
@@ -500,39 +510,46 @@ extern "C" int nm_decoder_step_fused(void* stream, const nm_decoder_step* d) {
     NM_REQUIRE(d->wg_t && d->bg && d->wcx_t && d->wch_t && d->bc && d->wq_t && d->keys && d->values && d->v &&
                d->wo_h_t && d->wo_e_t && d->wo_c_t && d->w_vocab, "nm_decoder_step_fused: null parameter");
     NM_REQUIRE(d->logits || d->stats, "nm_decoder_step_fused: neither logits nor tile statistics requested");
-    const int64_t ld = E + H;
+    const int64_t ld = d->ld_cat ? d->ld_cat : E + H;
+    const int64_t ld_ctx = d->ld_ctx ? d->ld_ctx : C;
+    const int64_t ld_wg = d->ld_wg ? d->ld_wg : E + H, ld_wcx = d->ld_wcx ? d->ld_wcx : E,
+                  ld_wch = d->ld_wch ? d->ld_wch : H, ld_wq = d->ld_wq ? d->ld_wq : H,
+                  ld_wo_h = d->ld_wo_h ? d->ld_wo_h : H, ld_wo_e = d->ld_wo_e ? d->ld_wo_e : E,
+                  ld_wo_c = d->ld_wo_c ? d->ld_wo_c : C;
+    NM_REQUIRE(ld >= E + H && ld_ctx >= C && ld % 4 == 0 && ld_ctx % 4 == 0, "nm_decoder_step_fused: bad leading "
+               "dimensions of the input row / context buffer");
     float* h = d->cat + E;                       // the state half of the input row
     nm_step_problem p[3];
     int rc;
     // group 1: gates over [emb | h]; the two products that only need the embedded input
     memset(p, 0, sizeof(p));
-    p[0].A = d->cat; p[0].lda = ld; p[0].Bt = d->wg_t; p[0].ldb = ld; p[0].N = 2 * H; p[0].K = ld; p[0].epilogue = 1;
+    p[0].A = d->cat; p[0].lda = ld; p[0].Bt = d->wg_t; p[0].ldb = ld_wg; p[0].N = 2 * H; p[0].K = E + H; p[0].epilogue = 1;
     p[0].bias = d->bg; p[0].h = h; p[0].ldh = ld; p[0].ru = d->ru; p[0].rh = d->rh;
-    p[1].A = d->cat; p[1].lda = ld; p[1].Bt = d->wcx_t; p[1].ldb = E; p[1].N = H; p[1].K = E; p[1].bias = d->bc;
+    p[1].A = d->cat; p[1].lda = ld; p[1].Bt = d->wcx_t; p[1].ldb = ld_wcx; p[1].N = H; p[1].K = E; p[1].bias = d->bc;
     p[1].C = d->xc; p[1].ldc = H;
-    p[2].A = d->cat; p[2].lda = ld; p[2].Bt = d->wo_e_t; p[2].ldb = E; p[2].N = O; p[2].K = E;
+    p[2].A = d->cat; p[2].lda = ld; p[2].Bt = d->wo_e_t; p[2].ldb = ld_wo_e; p[2].N = O; p[2].K = E;
     p[2].C = d->pre_e; p[2].ldc = O;
     if ((rc = nm_step_group(stream, M, p, 3)) != 0) return rc;
     // group 2: candidate + blend, h' in place (and into the caller's history row)
     memset(p, 0, sizeof(p));
-    p[0].A = d->rh; p[0].lda = H; p[0].Bt = d->wch_t; p[0].ldb = H; p[0].N = H; p[0].K = H; p[0].epilogue = 2;
+    p[0].A = d->rh; p[0].lda = H; p[0].Bt = d->wch_t; p[0].ldb = ld_wch; p[0].N = H; p[0].K = H; p[0].epilogue = 2;
     p[0].xc = d->xc; p[0].ldxc = H; p[0].ru = d->ru; p[0].h = h; p[0].ldh = ld; p[0].h_out = h; p[0].ldho = ld;
     p[0].h_out2 = d->h_copy; p[0].ldho2 = d->h_copy ? d->ld_h_copy : 0;
     if ((rc = nm_step_group(stream, M, p, 1)) != 0) return rc;
     // group 3: attention query; the state part of the output projection
     memset(p, 0, sizeof(p));
-    p[0].A = h; p[0].lda = ld; p[0].Bt = d->wq_t; p[0].ldb = H; p[0].N = A; p[0].K = H; p[0].bias = d->bq;
+    p[0].A = h; p[0].lda = ld; p[0].Bt = d->wq_t; p[0].ldb = ld_wq; p[0].N = A; p[0].K = H; p[0].bias = d->bq;
     p[0].C = d->y; p[0].ldc = A;
-    p[1].A = h; p[1].lda = ld; p[1].Bt = d->wo_h_t; p[1].ldb = H; p[1].N = O; p[1].K = H; p[1].bias = d->bo;
+    p[1].A = h; p[1].lda = ld; p[1].Bt = d->wo_h_t; p[1].ldb = ld_wo_h; p[1].N = O; p[1].K = H; p[1].bias = d->bo;
     p[1].add = d->pre_e; p[1].ldadd = O; p[1].C = d->pre; p[1].ldc = O;
     if ((rc = nm_step_group(stream, M, p, 2)) != 0) return rc;
     // attention: one launch
     if ((rc = nm_attn_fwd(stream, d->y, d->keys, d->values, d->mask, d->v, d->attn_bias, M, d->rows_per_key,
-                          d->src_len, A, C, d->ctx, C, d->attn_weights, d->attn_workspace, d->attn_workspace_bytes,
+                          d->src_len, A, C, d->ctx, ld_ctx, d->attn_weights, d->attn_workspace, d->attn_workspace_bytes,
                           nullptr)) != 0) return rc;
     // group 4: the context part of the output projection + activation
     memset(p, 0, sizeof(p));
-    p[0].A = d->ctx; p[0].lda = C; p[0].Bt = d->wo_c_t; p[0].ldb = C; p[0].N = O; p[0].K = C; p[0].act = d->out_act;
+    p[0].A = d->ctx; p[0].lda = ld_ctx; p[0].Bt = d->wo_c_t; p[0].ldb = ld_wo_c; p[0].N = O; p[0].K = C; p[0].act = d->out_act;
     p[0].add = d->pre; p[0].ldadd = O; p[0].C = d->out_state; p[0].ldc = d->ld_out_state;
     if ((rc = nm_step_group(stream, M, p, 1)) != 0) return rc;
     // vocabulary projection

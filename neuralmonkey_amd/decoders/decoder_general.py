@@ -396,7 +396,13 @@ class FusedStepper:
         a, c = att.state_size, att.context_vector_size
         key = (id(dec), tag, rows, "fused")
         buf = lambda name, shape: ctx.buffer(key + (name,), shape)
-        self.cat = buf("cat", (rows, e + h))
+        # Operand rows are padded by 128 bytes: with power-of-two row strides (E + H = 1024 floats = 4 KB) every row
+        # of a 16- or 32-row operand tile starts on the SAME L2 channel, and all workgroups of a group walk K in
+        # step.  Measured at 640 and 128 rows with 32 floats of padding: no difference (group 1: 39.4 us either way,
+        # profiles/r03_decode_beam_kernels_v2.csv), so the default stays dense; NM_STEP_PAD=32 pads.
+        pad = int(os.environ.get("NM_STEP_PAD", "0"))
+        padded = lambda name, r, c: buf(name, (r, c + pad))[:, :c]
+        self.cat = padded("cat", rows, e + h)
         self.emb_view, self.sel = self.cat[:, :e], self.cat[:, e:]
         self.hbuf = buf("h", (2, rows, h))
         self.ru, self.rh, self.xc = buf("ru", (rows, 2 * h)), buf("rh", (rows, h)), buf("xc", (rows, h))
@@ -406,30 +412,32 @@ class FusedStepper:
         wg, wc = dec.var(ctx, pre + "/gates/kernel"), dec.var(ctx, pre + "/candidate/kernel")
         proj = dec.output_projection
         wo = proj.kernel(ctx, dec)                                    # rows [h | emb | ctx]
-        tr = lambda name, w: buf(name, (w.shape[1], w.shape[0])).copy_(w.t())
+        tr = lambda name, w: padded(name, w.shape[1], w.shape[0]).copy_(w.t())
         self.wg_t = tr("wgT", wg)                                     # [2H, E+H]
         self.wcx_t, self.wch_t = tr("wcxT", wc[:e]), tr("wchT", wc[e:])
         self.wq_t = tr("wqT", att.var(ctx, "Attention/attn_query_projection"))
         self.wo_h_t, self.wo_e_t, self.wo_c_t = tr("wo_hT", wo[:h]), tr("wo_eT", wo[h:h + e]), tr("wo_cT", wo[h + e:])
         bg, bc = dec.var(ctx, pre + "/gates/bias"), dec.var(ctx, pre + "/candidate/bias")
-        ld = e + h
+        ld = self.cat.stride(0)
+        lds = lambda w: w.stride(0)
         rpk, bk = att.rows_per_key, plan["Bk"]
         self.g1 = ops.StepGroup(rows, [
-            dict(A=self.cat, lda=ld, Bt=self.wg_t, ldb=ld, N=2 * h, K=ld, epilogue=1, bias=bg, h=self.sel, ldh=ld,
-                 ru=self.ru, rh=self.rh),
-            dict(A=self.cat, lda=ld, Bt=self.wcx_t, ldb=e, N=h, K=e, epilogue=0, bias=bc, C=self.xc, ldc=h),
-            dict(A=self.cat, lda=ld, Bt=self.wo_e_t, ldb=e, N=o, K=e, epilogue=0, C=self.pre_e, ldc=o)])
+            dict(A=self.cat, lda=ld, Bt=self.wg_t, ldb=lds(self.wg_t), N=2 * h, K=e + h, epilogue=1, bias=bg, h=self.sel,
+                 ldh=ld, ru=self.ru, rh=self.rh),
+            dict(A=self.cat, lda=ld, Bt=self.wcx_t, ldb=lds(self.wcx_t), N=h, K=e, epilogue=0, bias=bc, C=self.xc, ldc=h),
+            dict(A=self.cat, lda=ld, Bt=self.wo_e_t, ldb=lds(self.wo_e_t), N=o, K=e, epilogue=0, C=self.pre_e, ldc=o)])
         self.g2 = ops.StepGroup(rows, [
-            dict(A=self.rh, lda=h, Bt=self.wch_t, ldb=h, N=h, K=h, epilogue=2, xc=self.xc, ldxc=h, ru=self.ru,
+            dict(A=self.rh, lda=h, Bt=self.wch_t, ldb=lds(self.wch_t), N=h, K=h, epilogue=2, xc=self.xc, ldxc=h, ru=self.ru,
                  h=self.sel, ldh=ld, h_out=self.sel, ldho=ld, h_out2=self.hbuf[0], ldho2=h)])
         self.g3 = ops.StepGroup(rows, [
-            dict(A=self.sel, lda=ld, Bt=self.wq_t, ldb=h, N=a, K=h, epilogue=0, bias=att.var(ctx, "attn_projection_bias"),
-                 C=self.y, ldc=a),
-            dict(A=self.sel, lda=ld, Bt=self.wo_h_t, ldb=h, N=o, K=h, epilogue=0, bias=proj.bias(ctx, dec),
+            dict(A=self.sel, lda=ld, Bt=self.wq_t, ldb=lds(self.wq_t), N=a, K=h, epilogue=0,
+                 bias=att.var(ctx, "attn_projection_bias"), C=self.y, ldc=a),
+            dict(A=self.sel, lda=ld, Bt=self.wo_h_t, ldb=lds(self.wo_h_t), N=o, K=h, epilogue=0, bias=proj.bias(ctx, dec),
                  add=self.pre_e, ldadd=o, C=self.pre, ldc=o)])
-        self.ctxbuf = buf("ctx", (rows, c))
+        self.ctxbuf = padded("ctx", rows, c)
+        ldc_ = self.ctxbuf.stride(0)
         self.g4 = ops.StepGroup(rows, [
-            dict(A=self.ctxbuf, lda=c, Bt=self.wo_c_t, ldb=c, N=o, K=c, epilogue=0,
+            dict(A=self.ctxbuf, lda=ldc_, Bt=self.wo_c_t, ldb=lds(self.wo_c_t), N=o, K=c, epilogue=0,
                  act=1 if proj.activation == "tanh" else 0, add=self.pre, ldadd=o, C=self.pre, ldc=o)])
         att.hidden_features(ctx)
         self._pending, self._cur = None, 0
@@ -447,7 +455,9 @@ class FusedStepper:
             mask=att.attention_mask(ctx), v=att.var(ctx, "attn_similarity_v"), attn_bias=att.var(ctx, "attn_bias"),
             wo_h_t=self.wo_h_t, wo_e_t=self.wo_e_t, wo_c_t=self.wo_c_t, bo=proj.bias(ctx, dec),
             out_act=1 if proj.activation == "tanh" else 0, w_vocab=wv, ld_w_vocab=wv.stride(0),
-            b_vocab=dec.decoding_bias(ctx), vocab_trans_b=int(tied)))
+            b_vocab=dec.decoding_bias(ctx), vocab_trans_b=int(tied),
+            ld_cat=ld, ld_ctx=ldc_, ld_wg=lds(self.wg_t), ld_wcx=lds(self.wcx_t), ld_wch=lds(self.wch_t),
+            ld_wq=lds(self.wq_t), ld_wo_h=lds(self.wo_h_t), ld_wo_e=lds(self.wo_e_t), ld_wo_c=lds(self.wo_c_t)))
         self.single_call = not os.environ.get("NM_STEP_GROUPS")
 
     def start(self, s0: torch.Tensor) -> None:
