@@ -202,6 +202,10 @@ typedef struct nm_step_problem {
     float* ru; float* rh;
     const float* xc; int64_t ldxc;
     float* h_out; int64_t ldho; float* h_out2; int64_t ldho2;
+    /* optional row indirection of the epilogue operands: `add` (epilogues 0 and 1: added to the sum before the
+     * activation / the sigmoid) is read at row add_ids[row], `xc` (epilogue 2) at row xc_ids[row] -- rows of a
+     * table indexed by the step's input symbols (nm_decoder_step.in_table) */
+    const int32_t* add_ids; const int32_t* xc_ids;
 } nm_step_problem;
 int nm_step_group(void* stream, int64_t M, const nm_step_problem* problems, int32_t nproblems);
 
@@ -248,6 +252,12 @@ typedef struct nm_decoder_step {
      * transposed weights, ctx_width for ctx).  Power-of-two row strides (4 KB at the benchmark shape) put every
      * row of an operand tile on the same L2 channel; a caller that pads its rows by 128 bytes spreads them. */
     int64_t ld_cat, ld_ctx, ld_wg, ld_wcx, ld_wch, ld_wq, ld_wo_h, ld_wo_e, ld_wo_c;
+    /* Input tables (optional).  Everything the step computes from the EMBEDDED INPUT SYMBOL alone is a function of
+     * the symbol: in_table [V, 2*rnn + rnn + out] = [E.Wg_x | E.Wc_x + bc | E.Wo_e] (E = the embedding matrix; one
+     * GEMM per set of weights).  With in_table and in_ids (the rows' input symbols) the embedding half of group 1
+     * becomes a gather in the epilogues: gates = sigmoid(h.Wg_h + in_table[id, :2*rnn] + bg), xc = in_table[id,
+     * 2*rnn:3*rnn], the output projection adds in_table[id, 3*rnn:]; the left half of `cat` is then not read. */
+    const float* in_table; int64_t ld_table; const int32_t* in_ids;
 } nm_decoder_step;
 int nm_decoder_step_fused(void* stream, const nm_decoder_step* step);
 

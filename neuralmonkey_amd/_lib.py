@@ -125,7 +125,7 @@ class StepProblem(ctypes.Structure):
                 ("pctx", P), ("pstat", P), ("energies", P), ("mask", P), ("weights", P),
                 ("S", L), ("mask_div", L), ("mask_mod", L),
                 ("h", P), ("ldh", L), ("ru", P), ("rh", P), ("xc", P), ("ldxc", L),
-                ("h_out", P), ("ldho", L), ("h_out2", P), ("ldho2", L)]
+                ("h_out", P), ("ldho", L), ("h_out2", P), ("ldho2", L), ("add_ids", P), ("xc_ids", P)]
 
 
 class DecoderStep(ctypes.Structure):
@@ -140,7 +140,8 @@ class DecoderStep(ctypes.Structure):
                                   "attn_bias", "wo_h_t", "wo_e_t", "wo_c_t", "bo", "w_vocab")] +
                 [("ld_w_vocab", L), ("b_vocab", P), ("out_act", ctypes.c_int32), ("vocab_trans_b", ctypes.c_int32)] +
                 [(n, L) for n in ("ld_cat", "ld_ctx", "ld_wg", "ld_wcx", "ld_wch", "ld_wq", "ld_wo_h", "ld_wo_e",
-                                  "ld_wo_c")])
+                                  "ld_wo_c")] +
+                [("in_table", P), ("ld_table", L), ("in_ids", P)])
 
 
 def load():

@@ -42,6 +42,7 @@ struct StepProb {           // mirrors nm_step_problem (include/nmhip.h)
     float* ru; float* rh;
     const float* xc; long ldxc;
     float* h_out; long ldho; float* h_out2; long ldho2;
+    const int* add_ids; const int* xc_ids;
 };
 
 struct StepGroup {
@@ -126,12 +127,13 @@ __global__ __launch_bounds__(KS * 64, AKIND == 0 ? 8 : 4) void step_group_kernel
     if (e_ok) {
         if (p.epilogue == 0) {
             if (p.bias) e_bias = p.bias[e_col];
-            if (p.add) e_x = p.add[(long)e_row * p.ldadd + e_col];
+            if (p.add) e_x = p.add[(long)(p.add_ids ? p.add_ids[e_row] : e_row) * p.ldadd + e_col];
         } else if (p.epilogue == 1) {
             e_bias = p.bias[e_col];
+            if (p.add) e_x = p.add[(long)(p.add_ids ? p.add_ids[e_row] : e_row) * p.ldadd + e_col];
             if (e_col < (N >> 1)) e_h = p.h[(long)e_row * p.ldh + e_col];
         } else {
-            e_x = p.xc[(long)e_row * p.ldxc + e_col];
+            e_x = p.xc[(long)(p.xc_ids ? p.xc_ids[e_row] : e_row) * p.ldxc + e_col];
             e_u = p.ru[(long)e_row * 2 * N + N + e_col];
             e_h = p.h[(long)e_row * p.ldh + e_col];
         }
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(KS * 64, AKIND == 0 ? 8 : 4) void step_group_kernel
             p.C[(long)row * p.ldc + col] = v;
         } else if (p.epilogue == 1) {              // N = 2H: r | u = sigmoid(. + bg); rh = r * h
             const int H = N >> 1;
-            const float gate = nm_sigmoid(s + e_bias);
+            const float gate = nm_sigmoid(s + e_bias + e_x);
             p.ru[(long)row * N + col] = gate;
             if (col < H) p.rh[(long)row * H + col] = gate * e_h;
         } else {                                   // N = H: c = tanh(xc + .); h' = u*h + (1-u)*c
@@ -368,17 +370,18 @@ void step_group_medium_kernel(StepGroup g) {
         float s = 0.0f;
 #pragma unroll
         for (int w = 0; w < KS; ++w) s += red[sub * KS + w][reg][lane];
+        const float addv = p.add ? p.add[(long)(p.add_ids ? p.add_ids[row] : row) * p.ldadd + col] : 0.0f;
         if (p.epilogue == 0) {
-            float v = s + (p.bias ? p.bias[col] : 0.0f) + (p.add ? p.add[(long)row * p.ldadd + col] : 0.0f);
+            float v = s + (p.bias ? p.bias[col] : 0.0f) + addv;
             if (p.act == 1) v = nm_tanh(v);
             p.C[(long)row * p.ldc + col] = v;
         } else if (p.epilogue == 1) {              // N = 2H: r | u = sigmoid(. + bg); rh = r * h
             const int H = N >> 1;
-            const float gate = nm_sigmoid(s + p.bias[col]);
+            const float gate = nm_sigmoid(s + p.bias[col] + addv);
             p.ru[(long)row * N + col] = gate;
             if (col < H) p.rh[(long)row * H + col] = gate * p.h[(long)row * p.ldh + col];
         } else {                                   // N = H: c = tanh(xc + .); h' = u*h + (1-u)*c
-            const float c = nm_tanh(p.xc[(long)row * p.ldxc + col] + s);
+            const float c = nm_tanh(p.xc[(long)(p.xc_ids ? p.xc_ids[row] : row) * p.ldxc + col] + s);
             const float u = p.ru[(long)row * 2 * N + N + col];
             const float hn = u * p.h[(long)row * p.ldh + col] + (1.0f - u) * c;
             p.h_out[(long)row * p.ldho + col] = hn;
@@ -400,6 +403,7 @@ struct nm_step_problem {          // mirrors include/nmhip.h
     float* ru; float* rh;
     const float* xc; int64_t ldxc;
     float* h_out; int64_t ldho; float* h_out2; int64_t ldho2;
+    const int32_t* add_ids; const int32_t* xc_ids;
 };
 
 extern "C" int nm_step_group(void* stream, int64_t M, const nm_step_problem* probs, int32_t nprob) {
@@ -452,8 +456,10 @@ extern "C" int nm_step_group(void* stream, int64_t M, const nm_step_problem* pro
         NM_REQUIRE(q.epilogue >= 0 && q.epilogue <= 2, "nm_step_group[%d]: bad epilogue", i);
         if (q.epilogue == 0) NM_REQUIRE(q.C && q.ldc >= q.N && (!q.add || q.ldadd >= q.N) && (q.act == 0 || q.act == 1),
                                         "nm_step_group[%d]: bad plain epilogue", i);
-        if (q.epilogue == 1) NM_REQUIRE(q.bias && q.ru && q.rh && q.h && q.N % 2 == 0 && q.ldh >= q.N / 2,
-                                        "nm_step_group[%d]: bad gates epilogue", i);
+        if (q.epilogue == 1) NM_REQUIRE(q.bias && q.ru && q.rh && q.h && q.N % 2 == 0 && q.ldh >= q.N / 2 &&
+                                            (!q.add || q.ldadd >= q.N), "nm_step_group[%d]: bad gates epilogue", i);
+        NM_REQUIRE((!q.add_ids || q.add) && (!q.xc_ids || q.epilogue == 2), "nm_step_group[%d]: row ids without the "
+                   "operand they index", i);
         if (q.epilogue == 2) NM_REQUIRE(q.xc && q.ru && q.h && q.h_out && q.ldxc >= q.N && q.ldh >= q.N &&
                                         q.ldho >= q.N && (!q.h_out2 || q.ldho2 >= q.N),
                                         "nm_step_group[%d]: bad candidate epilogue", i);
@@ -464,6 +470,7 @@ extern "C" int nm_step_group(void* stream, int64_t M, const nm_step_problem* pro
         p.S = q.S; p.mask_div = q.mask_div; p.mask_mod = q.mask_mod;
         p.h = q.h; p.ldh = q.ldh; p.ru = q.ru; p.rh = q.rh; p.xc = q.xc; p.ldxc = q.ldxc;
         p.h_out = q.h_out; p.ldho = q.ldho; p.h_out2 = q.h_out2; p.ldho2 = q.ldho2;
+        p.add_ids = q.add_ids; p.xc_ids = q.xc_ids;
         g.begin[i] = next;
         next += g.tiles_m * nm_cdiv(q.N, tile_n);
     }
@@ -520,6 +527,7 @@ struct nm_decoder_step {          // mirrors include/nmhip.h
     const float* w_vocab; int64_t ld_w_vocab; const float* b_vocab;
     int32_t out_act, vocab_trans_b;
     int64_t ld_cat, ld_ctx, ld_wg, ld_wcx, ld_wch, ld_wq, ld_wo_h, ld_wo_e, ld_wo_c;
+    const float* in_table; int64_t ld_table; const int32_t* in_ids;
 };
 
 extern "C" int nm_decoder_step_fused(void* stream, const nm_decoder_step* d) {
@@ -545,6 +553,18 @@ extern "C" int nm_decoder_step_fused(void* stream, const nm_decoder_step* d) {
     float* h = d->cat + E;                       // the state half of the input row
     nm_step_problem p[3];
     int rc;
+    const bool tables = d->in_table != nullptr;
+    NM_REQUIRE(!tables || (d->in_ids && d->ld_table >= 3 * H + O), "nm_decoder_step_fused: input tables need the rows' "
+               "symbols and [V, 2*rnn + rnn + out] columns");
+    if (tables) {
+        // group 1 with input tables: only the state half of the gates product is left -- h . Wg_h (the state rows of
+        // the gates kernel = columns emb.. of wg_t) + in_table[id, :2H] + bg
+        memset(p, 0, sizeof(p));
+        p[0].A = h; p[0].lda = ld; p[0].Bt = d->wg_t + E; p[0].ldb = ld_wg; p[0].N = 2 * H; p[0].K = H; p[0].epilogue = 1;
+        p[0].bias = d->bg; p[0].h = h; p[0].ldh = ld; p[0].ru = d->ru; p[0].rh = d->rh;
+        p[0].add = d->in_table; p[0].ldadd = d->ld_table; p[0].add_ids = d->in_ids;
+        if ((rc = nm_step_group(stream, M, p, 1)) != 0) return rc;
+    } else {
     // group 1: gates over [emb | h]; the two products that only need the embedded input
     memset(p, 0, sizeof(p));
     p[0].A = d->cat; p[0].lda = ld; p[0].Bt = d->wg_t; p[0].ldb = ld_wg; p[0].N = 2 * H; p[0].K = E + H; p[0].epilogue = 1;
@@ -554,10 +574,12 @@ extern "C" int nm_decoder_step_fused(void* stream, const nm_decoder_step* d) {
     p[2].A = d->cat; p[2].lda = ld; p[2].Bt = d->wo_e_t; p[2].ldb = ld_wo_e; p[2].N = O; p[2].K = E;
     p[2].C = d->pre_e; p[2].ldc = O;
     if ((rc = nm_step_group(stream, M, p, 3)) != 0) return rc;
+    }
     // group 2: candidate + blend, h' in place (and into the caller's history row)
     memset(p, 0, sizeof(p));
     p[0].A = d->rh; p[0].lda = H; p[0].Bt = d->wch_t; p[0].ldb = ld_wch; p[0].N = H; p[0].K = H; p[0].epilogue = 2;
     p[0].xc = d->xc; p[0].ldxc = H; p[0].ru = d->ru; p[0].h = h; p[0].ldh = ld; p[0].h_out = h; p[0].ldho = ld;
+    if (tables) { p[0].xc = d->in_table + 2 * H; p[0].ldxc = d->ld_table; p[0].xc_ids = d->in_ids; }
     p[0].h_out2 = d->h_copy; p[0].ldho2 = d->h_copy ? d->ld_h_copy : 0;
     if ((rc = nm_step_group(stream, M, p, 1)) != 0) return rc;
     // group 3: attention query; the state part of the output projection
@@ -566,6 +588,7 @@ extern "C" int nm_decoder_step_fused(void* stream, const nm_decoder_step* d) {
     p[0].C = d->y; p[0].ldc = A;
     p[1].A = h; p[1].lda = ld; p[1].Bt = d->wo_h_t; p[1].ldb = ld_wo_h; p[1].N = O; p[1].K = H; p[1].bias = d->bo;
     p[1].add = d->pre_e; p[1].ldadd = O; p[1].C = d->pre; p[1].ldc = O;
+    if (tables) { p[1].add = d->in_table + 3 * H; p[1].ldadd = d->ld_table; p[1].add_ids = d->in_ids; }
     if ((rc = nm_step_group(stream, M, p, 2)) != 0) return rc;
     // attention: one launch
     if ((rc = nm_attn_fwd(stream, d->y, d->keys, d->values, d->mask, d->v, d->attn_bias, M, d->rows_per_key,

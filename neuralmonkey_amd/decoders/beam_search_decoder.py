@@ -276,8 +276,10 @@ class BeamSearchDecoder(ModelPart):
         # the beam body reads back only the tiles that can hold a top-k candidate (nm_beam_topk_step_tiles)
         use_stats = fast and dec.logits_stats_ok(ctx, out_state)
         stats = f32("stats", (ops.logits_stats_numel(rows, v),)) if use_stats else None
+        tabled = fast and getattr(stepper, "table", None) is not None       # input tables: steps take symbols
         if fast:
-            stepper.step(emb, att_at(0), out_state, logits, h_prev=hsel, h_out=stepper.hbuf[0], stats=stats)
+            stepper.step(emb, att_at(0), out_state, logits, h_prev=hsel, h_out=stepper.hbuf[0], stats=stats,
+                         **({"ids": go} if tabled else {}))
         else:
             att_states = stepper.step(emb, att_states, out_state, logits, finished=fin[0].view(rows))
         ops.row_stats(logits, rmax, rlse, argmax)
@@ -307,10 +309,11 @@ class BeamSearchDecoder(ModelPart):
                 if indexed:                      # s bodies and the initial step so far: position s + 1, cache copy s & 1
                     stepper.set_position(s + 1, cur)
                 stepper.reorder(srcf)
-            dec.embed_input_symbols(ctx, wordf, out=emb)                         # :507-510 (:546-551: see below)
+            if not tabled:
+                dec.embed_input_symbols(ctx, wordf, out=emb)                     # :507-510 (:546-551: see below)
             if fast:
                 stepper.step(emb, att_at(s + 1), out_state, logits, h_prev=stepper.sel,
-                             h_out=stepper.hbuf[nxt], stats=stats)               # :534-535
+                             h_out=stepper.hbuf[nxt], stats=stats, **({"ids": wordf} if tabled else {}))   # :534-535
             elif indexed:
                 stepper.step(emb, att_at(s + 1), out_state, logits, finished=fin[nxt].view(rows))
             else:

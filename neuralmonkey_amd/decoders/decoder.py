@@ -489,6 +489,11 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
         # runs once it is a graph, must not bake a reset to s0 into its graph)
         h_prev_of = lambda t: s0 if t == 0 else (stepper.sel if resident else s_all[t - 1])
 
+        # input tables (FusedStepper.table): the step reads what it needs of its input symbol from a table indexed by
+        # the symbol itself -- nobody has to embed the symbols of the previous step
+        tabled = getattr(stepper, "table", None) is not None
+        ids_kw = (lambda t: {"ids": go if t == 0 else symbols[t - 1]}) if tabled else (lambda t: {})
+
         def body(t):
             """Step t touches persistent buffers only and depends on nothing but t (graph capturable)."""
             logits = logits_all[t] if keep_logits else logits_one
@@ -496,14 +501,14 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
             if use_stats:
                 want_logits = keep_logits or t < t_xent
                 stepper.step(emb, st_t, out_all[t], logits if want_logits else None, h_out=s_all[t],
-                             h_prev=h_prev_of(t), stats=stats)
+                             h_prev=h_prev_of(t), stats=stats, **ids_kw(t))
                 if t < t_xent:
                     ops.xent(logits, tgt[t], tmask[t], xent_rows[t])
                 ops.greedy_finish(stats, v, finished, symbols[t], omask[t], END_TOKEN_INDEX, allfin[t:t + 1],
-                                  table=table, emb_out=emb)
+                                  table=None if tabled else table, emb_out=None if tabled else emb)
                 return
             if graph_ok:
-                stepper.step(emb, st_t, out_all[t], logits, h_out=s_all[t], h_prev=h_prev_of(t))
+                stepper.step(emb, st_t, out_all[t], logits, h_out=s_all[t], h_prev=h_prev_of(t), **ids_kw(t))
             else:
                 if indexed:
                     stepper.set_position(t, 0)
@@ -512,7 +517,8 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
             if t < t_xent:
                 ops.xent(logits, tgt[t], tmask[t], xent_rows[t])
             ops.greedy_update(argmax, finished, symbols[t], omask[t], END_TOKEN_INDEX, allfin[t:t + 1])
-            self.embed_input_symbols(ctx, symbols[t], out=emb)
+            if not (tabled and graph_ok):
+                self.embed_input_symbols(ctx, symbols[t], out=emb)
 
         shape_key = tuple(tuple(st.weights.shape) for st in att0)
         steps = 0

@@ -356,6 +356,46 @@ class GeneralStepper:
                 sess.reorder(src_rows)
 
 
+def input_table(dec, ctx) -> Optional[torch.Tensor]:
+    """[V, 2H + H + O] = [E.Wg_x | E.Wc_x + bc | E.Wo_e]: everything an inference step of the plain-GRU decoder
+    computes from the embedded input symbol alone (the input rows of the GRU kernels, nn/ortho_gru_cell.py:44-53,
+    and the embedding rows of the output projection, decoders/output_projection.py:115-130) is a function of the
+    symbol, so it is tabulated once per set of weights -- one [V, E] x [E, 2048] GEMM, 0.5 ms and 262 MB at the
+    benchmark shape -- and the step's group 1 shrinks to the state half of the gates product
+    (``nm_decoder_step.in_table``).  The table is tied to the CONTENTS of the variables it is made of: their sums
+    are re-read at the start of every decoding run (five small reductions + one 20-byte read-back) and the table is
+    rebuilt when one of them moved (an optimizer step, a checkpoint, a test poking a row).  NM_STEP_TABLES=0: off."""
+    if os.environ.get("NM_STEP_TABLES", "1") == "0" or ctx.device.type != "cuda":
+        return None
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    e, h, o = dec.embedding_size, dec.rnn_size, dec.output_dimension
+    pre = "attention_decoder/OrthoGRUCell"
+    emb = dec.embedding_matrix(ctx)
+    wg, wc = dec.var(ctx, pre + "/gates/kernel"), dec.var(ctx, pre + "/candidate/kernel")
+    bc = dec.var(ctx, pre + "/candidate/bias")
+    wo = dec.output_projection.kernel(ctx, dec)                  # rows [h | emb | ctx]
+    parts = [emb, wg[:e], wc[:e], bc, wo[h:h + e]]
+    if not all(p.is_contiguous() for p in parts):
+        return None
+    cache = ctx.session.__dict__.setdefault("_input_tables", {})
+    entry = cache.get(id(dec))
+    sums = entry[2] if entry is not None else torch.zeros(8, device=ctx.device)
+    for i, part in enumerate(parts):
+        ops.reduce_sum(part.reshape(-1), sums[i:i + 1])
+    print_ = tuple(float(x) for x in ctx.session.read_small(sums[:len(parts)])) + tuple(p.data_ptr() for p in parts)
+    if entry is not None and entry[0] == print_:
+        return entry[1]
+    vsz = emb.shape[0]
+    table = entry[1] if entry is not None and tuple(entry[1].shape) == (vsz, 3 * h + o) else \
+        torch.empty((vsz, 3 * h + o), dtype=torch.float32, device=ctx.device)
+    ops.gemm(emb, wg[:e], out=table[:, :2 * h])
+    ops.gemm(emb, wc[:e], out=table[:, 2 * h:3 * h], bias=bc)
+    ops.gemm(emb, wo[h:h + e], out=table[:, 3 * h:])
+    cache[id(dec)] = (print_, table, sums)
+    return table
+
+
 class FusedStepper:
     """One inference step of the plain-GRU decoder with ONE Bahdanau attention in four GEMM-group launches
     and the split-S attention kernel (``nm_step_group``, csrc/nm_step.hip) -- Decoder.next_state,
@@ -459,15 +499,27 @@ class FusedStepper:
             ld_cat=ld, ld_ctx=ldc_, ld_wg=lds(self.wg_t), ld_wcx=lds(self.wcx_t), ld_wch=lds(self.wch_t),
             ld_wq=lds(self.wq_t), ld_wo_h=lds(self.wo_h_t), ld_wo_e=lds(self.wo_e_t), ld_wo_c=lds(self.wo_c_t)))
         self.single_call = not os.environ.get("NM_STEP_GROUPS")
+        # the same step with the embedding half of group 1 read from the input tables (``step(..., ids=)``)
+        self.table = input_table(dec, ctx) if self.single_call else None
+        self.whole_tab = None
+        if self.table is not None:
+            fields = {name: getattr(self.whole.desc, name) for name, _ in self.whole.desc._fields_}
+            self.whole_tab = ops.DecoderStepCall(fields)
+            self.whole_tab.keep = dict(self.whole.keep)
+            self.whole_tab.launch_fields = dict(in_table=self.table, ld_table=self.table.stride(0))
 
     def start(self, s0: torch.Tensor) -> None:
         self._pending, self._cur = s0, 0
 
     def step(self, emb, att_states, out_state, logits, h_out: Optional[torch.Tensor] = None, finished=None,
-             h_prev: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None):
+             h_prev: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None,
+             ids: Optional[torch.Tensor] = None):
+        """``ids`` (int32 [rows], the step's input symbols): with input tables the embedded input is not read at
+        all -- the caller need not embed."""
         from ..attention.base_attention import AttentionLoopState
         dec, ctx = self.dec, self.ctx
-        if emb.data_ptr() != self.emb_view.data_ptr():
+        tabled = ids is not None and self.whole_tab is not None
+        if not tabled and emb.data_ptr() != self.emb_view.data_ptr():
             ops.copy_cols(emb, self.emb_view)
         if h_prev is None and self._pending is not None:          # stateful use (ensembles): start() then step()s
             h_prev = self._pending
@@ -479,10 +531,12 @@ class FusedStepper:
             h_out = self.hbuf[self._cur]
         st = att_states[0]
         if self.single_call:
-            self.whole.launch(h_copy=h_out, ld_h_copy=h_out.stride(0), out_state=out_state,
-                              ld_out_state=out_state.stride(0), attn_weights=st.weights[st.step], logits=logits,
-                              ld_logits=logits.stride(0) if logits is not None else 0, stats=stats,
-                              stats_bytes=stats.numel() * 4 if stats is not None else 0)
+            call = self.whole_tab if tabled else self.whole
+            extra = dict(call.launch_fields, in_ids=ids) if tabled else {}
+            call.launch(h_copy=h_out, ld_h_copy=h_out.stride(0), out_state=out_state,
+                        ld_out_state=out_state.stride(0), attn_weights=st.weights[st.step], logits=logits,
+                        ld_logits=logits.stride(0) if logits is not None else 0, stats=stats,
+                        stats_bytes=stats.numel() * 4 if stats is not None else 0, **extra)
             return [AttentionLoopState(st.contexts, st.weights, st.step + 1)]
         self.g1.launch()
         self.g2.patch(0, h_out2=h_out, ldho2=h_out.stride(0) if h_out is not None else 0)

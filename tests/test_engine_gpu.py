@@ -306,3 +306,51 @@ def test_lookahead_encodes_the_next_batch_on_a_second_stream(dev):
             assert [[w2i[w] for w in sent] for sent in res[1].outputs["target_beam"]] == want_beam, i
     assert slots[:5] == [0, 1, 0, 1, 0] and slots[5] == 0 and slots[6] == 1      # batch 5 was not announced
     assert not sess._ahead
+
+
+def test_input_tables_follow_the_variables(dev):
+    """The decoder step reads E.Wg_x / E.Wc_x / E.Wo_e from a table indexed by the input symbol
+    (decoder_general.input_table).  The table must follow the CONTENTS of the variables: decode, change the
+    embedding of one frequent word in place (no official mutation path involved), decode again -- both results are
+    the oracle's on the respective weights, with tables on and off."""
+    import os
+    from neuralmonkey_amd import synthetic
+    vocab, emb, rnn, batch, slen = 120, 16, 16, 6, 9
+    params = O.init_params(seed=41, vocab_src=vocab, vocab_tgt=vocab, emb=emb, rnn=rnn, std=0.3)
+    spec = O.DecoderSpec(max_output_len=12)
+    ds = synthetic.synthetic_dataset(seed=77, batch=batch, src_len=slen, tgt_len=slen, vocab=vocab, ragged=True,
+                                     with_target=False)
+    src = O.pad_ids([list(s) for s in ds.get_series("source")], 12)
+    for tables in ("1", "0"):
+        os.environ["NM_STEP_TABLES"] = tables
+        try:
+            model = synthetic.build_translation_model(vocab_src=vocab, vocab_tgt=vocab, emb=emb, rnn=rnn, max_len=12,
+                                                      beam_size=3, max_steps=12, device=str(dev), with_trainer=False)
+            sess = model.tf_manager.sessions[0]
+            sess.store.load_state_dict(params)
+            w2i = model.tgt_vocab._word_to_index
+            p = dict(params)
+            for round_ in range(3):
+                if round_ == 1:                     # poke the embeddings of the decoder in place
+                    name = model.decoder.embedding_matrix_name
+                    first = O.greedy_tokens(O.decoding_loop(p, spec, O.sentence_encoder(p, src), None, False))
+                    word = max(set(sum(first, [])), key=sum(first, []).count) if sum(first, []) else 5
+                    sess.store[name][word].mul_(-2.0)
+                    p = dict(p)
+                    e2 = p[name].copy()
+                    e2[word] *= -2.0
+                    p[name] = e2
+                enc = O.sentence_encoder(p, src)
+                want = O.greedy_tokens(O.decoding_loop(p, spec, enc, None, False))
+                res = model.tf_manager.execute(ds, model.greedy_runner.feedables | model.beam_runner.feedables,
+                                               [model.greedy_runner, model.beam_runner], compute_losses=False)
+                got = [[w2i[w] for w in sent] for sent in res[0].outputs["target"]]
+                assert got == want, "greedy mismatch in round {} (tables {})".format(round_, tables)
+                bres = O.beam_search(p, spec, enc, 3, 12, 0.6)
+                if bres.min_gap > 1e-5:
+                    want_beam, _ = O.beam_tokens(bres, 1)
+                    assert [[w2i[w] for w in sent] for sent in res[1].outputs["target_beam"]] == want_beam
+            if tables == "1":
+                assert sess.__dict__.get("_input_tables"), "the fused stepper did not build its input table"
+        finally:
+            os.environ.pop("NM_STEP_TABLES", None)

@@ -251,6 +251,31 @@ def test_decoder_step_fused_is_the_oracle_step(dev, bk, qpk, s, e, h, a, c, o, v
         assert np.abs(w_out.cpu().numpy() - r_w).max() < 1e-5
         assert rel(out_state.cpu().numpy(), r_out) < RTOL
         assert rel(logits.cpu().numpy(), r_logits) < RTOL
+    # ---- the same step with INPUT TABLES: the rows' input symbols index a table [V', 2H + H + O] = [E.Wg_x | E.Wc_x
+    # + bc | E.Wo_e]; the embedded half of the input row is not read (poisoned here)
+    vt = 37
+    ids = rng.integers(0, vt, rows).astype(np.int32)
+    etab = f(vt, e, sc=1.0)
+    etab[ids] = emb                                       # rows with the same id share an embedding: last one wins ...
+    emb_t = etab[ids]                                     # ... so re-read what each row really gets
+    table = np.concatenate([etab.astype(np.float64) @ cellp["gates_kernel"][:e],
+                            etab.astype(np.float64) @ cellp["cand_kernel"][:e] + cellp["cand_bias"],
+                            etab.astype(np.float64) @ out_w[h:h + e]], 1).astype(np.float32)
+    t_out, t_h, _, t_w = O.decoder_step(dp, O.DecoderSpec(), emb_t.astype(np.float64), h0.astype(np.float64),
+                                        rep(keys), rep(vals), rep(mask))
+    t_logits = O.state_to_logits(dp, O.DecoderSpec(), t_out)
+    cat[:, :e] = float("nan")
+    cat[:, e:] = T(h0, dev)
+    table_d, ids_d = T(table, dev), T(ids, dev, torch.int32)
+    call.launch(h_copy=h_copy, ld_h_copy=h, out_state=out_state, ld_out_state=o, attn_weights=w_out, logits=logits,
+                ld_logits=v, stats=stats, stats_bytes=stats.numel() * 4 if with_stats else 0,
+                in_table=table_d, ld_table=table.shape[1], in_ids=ids_d)
+    torch.cuda.synchronize()
+    assert rel(h_copy.cpu().numpy(), t_h) < RTOL and torch.equal(cat[:, e:], h_copy)
+    assert np.abs(w_out.cpu().numpy() - t_w).max() < 1e-5
+    assert rel(out_state.cpu().numpy(), t_out) < RTOL
+    assert rel(logits.cpu().numpy(), t_logits) < RTOL
+    call._set(dict(in_table=None, ld_table=0, in_ids=None))          # pylint: disable=protected-access
     if with_stats:
         sym, fin = torch.zeros(rows, dtype=torch.int32, device=dev), torch.zeros(rows, dtype=torch.int32, device=dev)
         arg = torch.zeros(rows, dtype=torch.int32, device=dev)
