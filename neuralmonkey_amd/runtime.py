@@ -450,15 +450,22 @@ class Session:
         now = self._feed_signature(feed)
         hit = None
         for entry in self._ahead:
-            if entry[0] and entry[0] <= now:
+            # (the variables must be the ones the look-ahead saw: torch-side writes bump the version counter of the
+            # flat parameter tensor, the optimizer kernels -- raw pointers -- announce themselves, variables_changed)
+            if entry[0] and entry[0] <= now and entry[5] == self.store.theta._version:
                 hit = entry
         self._ahead = []
         if hit is None:
             return None
-        _, slot, memo, event, _ = hit
+        _, slot, memo, event, _, _ = hit
         self.slot = slot
         torch.cuda.current_stream(self.device).wait_event(event)
         return memo
+
+    def variables_changed(self) -> None:
+        """Called by whoever rewrites the variables behind torch's back (optimizer kernels): anything evaluated
+        ahead of time from the old values is dropped."""
+        self._ahead = []
 
     def _run_ahead(self, fetches, feed) -> None:
         """Evaluate ``fetches`` (the encoder side of a FUTURE batch) on the look-ahead stream, into the buffer slot
@@ -480,7 +487,8 @@ class Session:
                 self._eval(fetches, ctx)
                 done = torch.cuda.Event()
                 done.record(self._ahead_stream)
-            self._ahead.append((self._feed_signature(feed), self.slot, ctx.memo, done, feed))
+            self._ahead.append((self._feed_signature(feed), self.slot, ctx.memo, done, feed,
+                                self.store.theta._version))
         finally:
             self.slot = mine
 

@@ -169,6 +169,7 @@ class GenericTrainer(GraphExecutor, Feedable):
         opt = self.optimizer
         tables.clip_adam(store.theta, grad, state["m"], state["v"], self.clip_norm,
                          opt.lr_t(sess.global_step, state["applied"]), opt.beta1, opt.beta2, opt.epsilon)
+        sess.variables_changed()
         return sess.global_step
 
     def _adam_state(self, sess, store):

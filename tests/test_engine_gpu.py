@@ -306,6 +306,17 @@ def test_lookahead_encodes_the_next_batch_on_a_second_stream(dev):
             assert [[w2i[w] for w in sent] for sent in res[1].outputs["target_beam"]] == want_beam, i
     assert slots[:5] == [0, 1, 0, 1, 0] and slots[5] == 0 and slots[6] == 1      # batch 5 was not announced
     assert not sess._ahead
+    # variables rewritten between the announcement and the run: what was encoded ahead is stale and must be dropped
+    model.tf_manager.execute(batches[0], feedables, runners, compute_losses=False, lookahead=batches[1])
+    assert sess._ahead
+    name = model.encoder.input_sequence.embedding_matrix_name
+    sess.store[name].mul_(-1.0)
+    p2 = dict(params)
+    p2[name] = -params[name]
+    res = model.tf_manager.execute(batches[1], feedables, runners, compute_losses=False)
+    src = O.pad_ids([list(s) for s in batches[1].get_series("source")], 12)
+    want = O.greedy_tokens(O.decoding_loop(p2, spec, O.sentence_encoder(p2, src), None, False))
+    assert [[w2i[w] for w in sent] for sent in res[0].outputs["target"]] == want
 
 
 def test_input_tables_follow_the_variables(dev):
