@@ -23,6 +23,10 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// nm_step.hip: the medium-M route (returns false when the shape is not taken)
+bool nm_medium_gemm(hipStream_t st, int transB, long M, long N, long K, const float* A, long lda, const float* B,
+                    long ldb, float* C, long ldc, const float* bias, int act, int accumulate);
+
 struct GemmArgs {
     const float* A;
     const float* B;
@@ -941,6 +945,12 @@ extern "C" int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int6
     if (nostore) g.store_c = 0;
     hipStream_t st = nm_stream(stream);
     const bool ta = transA != 0, tb = transB != 0;
+    // a few hundred rows and too few 64x64 tiles for the chip (Transformer / general-path beam steps: 640 rows): the
+    // 32x32 K-split tiles of the decoder-step groups (nm_step.hip)
+    if (algo == 0 && !ta && batch == 1 && !nostore &&
+        nm_medium_gemm(st, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate)) {
+        NM_LAUNCH_CHECK("nm_gemm_f32 (medium)");
+    }
 
     // vector path: 16-byte aligned rows and contiguous extents divisible by 4
     const bool a_vec = nm_aligned16(A) && lda % 4 == 0 && strideA % 4 == 0 && ((ta ? M : K) % 4 == 0);

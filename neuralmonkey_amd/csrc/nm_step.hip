@@ -270,8 +270,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // TR x TC sub-tiles of 32x32 per workgroup (each with its own KS waves): the same arithmetic in fewer, fatter
 // workgroups.
-template <int KS, int TR, int TC>
-__global__ __launch_bounds__(KS * TR * TC * 64, (KS * TR * TC == 4) ? 5 : (KS * TR * TC == 8 ? 2 : 1))
+// BT: the second operand is stored [N, K] (transposed weights of the decoder step); !BT: [K, N] as nm_gemm_f32 takes it
+// (its tile is then fetched 8 k-rows x 128 bytes per instruction and read from LDS one float per MFMA).
+template <int KS, int TR, int TC, bool BT = true>
+__global__ __launch_bounds__(KS * TR * TC * 64, (KS * TR * TC == 4) ? (BT ? 5 : 4) : (KS * TR * TC == 8 ? 2 : 1))
 void step_group_medium_kernel(StepGroup g) {
     constexpr int NW = KS * TR * TC;
     // Tile rows are exactly one 128-byte line (no padding: 8 KB per wave, 32 KB per 4-wave workgroup = FIVE
@@ -307,7 +309,8 @@ void step_group_medium_kernel(StepGroup g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         aoff[i] = (long)min(m0 + lr + 8 * i, g.M - 1) * p.lda + 4 * lq;
-        boff[i] = (long)min(n0 + lr + 8 * i, N - 1) * p.ldb + 4 * lq;
+        boff[i] = BT ? (long)min(n0 + lr + 8 * i, N - 1) * p.ldb + 4 * lq
+                     : (long)(lr + 8 * i) * p.ldb + min(n0 + 4 * lq, N - 4);     // row = k, 16-byte chunk of 4 columns
     }
     float* as = lds + wave * (2 * 32 * LDT);
     float* bs = as + 32 * LDT;
@@ -322,7 +325,8 @@ void step_group_medium_kernel(StepGroup g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             ra[i] = ok ? *reinterpret_cast<const float4*>(p.A + aoff[i] + k0) : NM_Z4;
-            rb[i] = ok ? *reinterpret_cast<const float4*>(p.Bt + boff[i] + k0) : NM_Z4;
+            if (BT) rb[i] = ok ? *reinterpret_cast<const float4*>(p.Bt + boff[i] + k0) : NM_Z4;
+            else rb[i] = (k0 + lr + 8 * i < kend) ? *reinterpret_cast<const float4*>(p.Bt + boff[i] + (long)k0 * p.ldb) : NM_Z4;
         }
     };
     if (kbeg < kend) fetch(kbeg);
@@ -332,7 +336,7 @@ void step_group_medium_kernel(StepGroup g) {
             const int r = lr + 8 * i;
             const int pos = 4 * (lq ^ ((r >> 1) & 7));
             *reinterpret_cast<float4*>(as + r * LDT + pos) = ra[i];
-            *reinterpret_cast<float4*>(bs + r * LDT + pos) = rb[i];
+            *reinterpret_cast<float4*>(bs + r * LDT + (BT ? pos : 4 * lq)) = rb[i];       // !BT: row = k, plain
         }
         __builtin_amdgcn_wave_barrier();             // (LDS operations of one wave complete in order)
         if (k0 + 32 < kend) fetch(k0 + 32);          // the next trip's lines travel under this trip's MFMAs
@@ -341,7 +345,11 @@ void step_group_medium_kernel(StepGroup g) {
         for (int c = 0; c < 4; ++c) {                // lane (m, half): k = k0 + 16 half + 4 c + j
             const int pos = 4 * ((4 * half + c) ^ ((m >> 1) & 7));
             av[c] = *reinterpret_cast<const float4*>(as + m * LDT + pos);
-            bv[c] = *reinterpret_cast<const float4*>(bs + m * LDT + pos);
+            if (BT) bv[c] = *reinterpret_cast<const float4*>(bs + m * LDT + pos);
+            else {                                   // column m of k-rows 16 half + 4 c .. + 3: 32 lanes = 32 banks
+                const float* col = bs + (16 * half + 4 * c) * LDT + m;
+                bv[c] = make_float4(col[0], col[LDT], col[2 * LDT], col[3 * LDT]);
+            }
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -374,6 +382,7 @@ void step_group_medium_kernel(StepGroup g) {
         if (p.epilogue == 0) {
             float v = s + (p.bias ? p.bias[col] : 0.0f) + addv;
             if (p.act == 1) v = nm_tanh(v);
+            else if (p.act == 2) v = fmaxf(v, 0.0f);
             p.C[(long)row * p.ldc + col] = v;
         } else if (p.epilogue == 1) {              // N = 2H: r | u = sigmoid(. + bg); rh = r * h
             const int H = N >> 1;
@@ -491,6 +500,39 @@ extern "C" int nm_step_group(void* stream, int64_t M, const nm_step_problem* pro
     else if (tm == 2) hipLaunchKernelGGL((step_group_kernel<16, 2, 0>), dim3(grid), dim3(1024), 0, st, g);
     else hipLaunchKernelGGL((step_group_kernel<16, 1, 0>), dim3(grid), dim3(1024), 0, st, g);
     NM_LAUNCH_CHECK("nm_step_group");
+}
+
+// nm_gemm_f32's medium-M route: C[M,N] = act(A[M,K] . B + bias (+ C)) for a few hundred rows, where 128x128 / 64x64
+// tiles leave most CUs without a workgroup (a 640 x 512 x 512 product of a Transformer beam step: 80 tiles of 64x64,
+// 26.8 us = 12.5 TFLOP/s) -- the 32x32 K-split tiles of the decoder-step groups fill the chip (~11 us).  Returns false
+// when the shape is not taken.
+bool nm_medium_gemm(hipStream_t st, int transB, long M, long N, long K, const float* A, long lda, const float* B,
+                    long ldb, float* C, long ldc, const float* bias, int act, int accumulate) {
+    if (M <= 256 || M > 2048 || nm_cur()->sw.medium_m == 0) return false;
+    if (K % 16 || N % 32 || lda % 4 || ldb % 4 || !nm_aligned16(A) || !nm_aligned16(B)) return false;
+    if (act < 0 || act > 2 || M * lda >= (1L << 31) || (transB ? N : K) * ldb >= (1L << 31)) return false;
+    const long t64 = (long)nm_cdiv(M, 64) * nm_cdiv(N, 64);
+    if (t64 >= 256) return false;                                    // the tiled kernels fill the chip themselves
+    StepGroup g;
+    memset(&g, 0, sizeof(g));
+    g.nprob = 1; g.M = (int)M; g.wblocks = 0;
+    StepProb& p = g.p[0];
+    p.A = A; p.lda = lda; p.Bt = B; p.ldb = ldb; p.N = N; p.K = K; p.epilogue = 0; p.act = act;
+    p.bias = bias; p.add = accumulate ? C : nullptr; p.ldadd = ldc; p.C = C; p.ldc = ldc;
+    for (int i = 1; i < NM_STEP_MAX_PROB; ++i) g.p[i] = g.p[0];
+    g.tiles_m = nm_cdiv(M, 32);
+    const long tiles = (long)g.tiles_m * nm_cdiv(N, 32);
+    g.begin[0] = 0;
+    for (int i = 1; i <= NM_STEP_MAX_PROB; ++i) g.begin[i] = (int)tiles;
+    const unsigned grid = (unsigned)tiles;
+    if (transB) {
+        if (tiles <= 640) hipLaunchKernelGGL((step_group_medium_kernel<8, 1, 1, true>), dim3(grid), dim3(512), 0, st, g);
+        else hipLaunchKernelGGL((step_group_medium_kernel<4, 1, 1, true>), dim3(grid), dim3(256), 0, st, g);
+    } else {
+        if (tiles <= 640) hipLaunchKernelGGL((step_group_medium_kernel<8, 1, 1, false>), dim3(grid), dim3(512), 0, st, g);
+        else hipLaunchKernelGGL((step_group_medium_kernel<4, 1, 1, false>), dim3(grid), dim3(256), 0, st, g);
+    }
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------------------

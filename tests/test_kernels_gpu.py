@@ -40,6 +40,12 @@ def T(x, dev, dtype=torch.float32):
     (96, 136, 4096, True, True, 2),         # split-K on the 64 tile, ragged
     (128, 512, 1024, False, True, 3),       # skinny NT with a 64-deep slice per wave
     (128, 1536, 256, False, False, 3),      # skinny KS=8
+    # a few hundred rows, too few 64x64 tiles for the chip: 32x32 K-split tiles (nm_medium_gemm, nm_step.hip)
+    (640, 512, 512, False, False, 0),       # a Transformer beam-step projection, weights [K,N]
+    (640, 2048, 512, False, False, 0),      # its feed-forward expansion (relu checked below)
+    (640, 512, 2048, False, False, 0),
+    (300, 96, 48, False, True, 0),          # ragged rows, a K slice that ends in the middle of a trip, weights [N,K]
+    (1000, 64, 80, False, False, 0),
 ])
 def test_gemm(dev, m, n, k, ta, tb, algo):
     from neuralmonkey_amd import ops
@@ -58,6 +64,8 @@ def test_gemm(dev, m, n, k, ta, tb, algo):
     out3 = T(c0, dev)
     ops.gemm(T(a, dev), T(b, dev), out=out3, trans_a=ta, trans_b=tb, accumulate=True, algo=algo)
     assert rel_err(out3.cpu().numpy(), ref + c0) < 2e-6 * np.sqrt(k) + 1e-6
+    out4 = ops.gemm(T(a_s, dev), T(b, dev), bias=T(bias, dev), act="relu", trans_a=ta, trans_b=tb, algo=algo)
+    assert rel_err(out4.cpu().numpy(), np.maximum(ref_s + bias, 0.0)) < 1e-5
 
 
 def test_gemm_random_shapes(dev):
