@@ -302,7 +302,7 @@ void step_group_medium_kernel(StepGroup g) {
     // through a wave-private LDS tile: letting every lane fetch its own row (lane = row, as the 16-row kernels above
     // do) costs one address-unit pass per LANE -- measured 45 us for group 1 of the 640-row step against 13 us of
     // MFMA time, with either 16 or 64 contiguous bytes per lane and trip.
-    const int kper = ((K / 32 + KS - 1) / KS) * 32;
+    const int kper = (((K + 31) / 32 + KS - 1) / KS) * 32;        // (K may end on a half trip: K % 32 == 16)
     const int kbeg = ks * kper, kend = min(K, kbeg + kper);
     const int lr = lane >> 3, lq = lane & 7;
     long aoff[4], boff[4];

@@ -334,6 +334,7 @@ class BeamSearchDecoder(ModelPart):
                 chunk()
             steps += n
             executed = steps
+            ctx.session.kick_ahead()               # the next batch's encoder is launched while this chunk runs
             done = np.nonzero(ctx.session.read_small(allfin[:steps]))[0]
             if done.size:
                 # bodies past the first all-finished one leave the search state unchanged and only

@@ -534,6 +534,7 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
             else:
                 chunk()
             steps += n
+            ctx.session.kick_ahead()               # the next batch's encoder is launched while this chunk runs
             done = np.nonzero(ctx.session.read_small(allfin[:steps]))[0]
             if done.size:                          # loop ends after the first all-finished step
                 steps = int(done[0]) + 1

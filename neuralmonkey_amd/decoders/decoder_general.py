@@ -362,9 +362,11 @@ def input_table(dec, ctx) -> Optional[torch.Tensor]:
     and the embedding rows of the output projection, decoders/output_projection.py:115-130) is a function of the
     symbol, so it is tabulated once per set of weights -- one [V, E] x [E, 2048] GEMM, 0.5 ms and 262 MB at the
     benchmark shape -- and the step's group 1 shrinks to the state half of the gates product
-    (``nm_decoder_step.in_table``).  The table is tied to the CONTENTS of the variables it is made of: their sums
-    are re-read at the start of every decoding run (five small reductions + one 20-byte read-back) and the table is
-    rebuilt when one of them moved (an optimizer step, a checkpoint, a test poking a row).  NM_STEP_TABLES=0: off."""
+    (``nm_decoder_step.in_table``).  The table is tied to the session's variable signature
+    (``Session.variables_signature``: torch's version counter of the flat parameter tensor + the counter that
+    kernels writing through raw pointers bump) and rebuilt when that moved -- an optimizer step, a checkpoint, a
+    test poking a row.  (Round 3 first compared the SUMS of the five tensors at the start of every decoding run:
+    five reductions + a blocking 20-byte read-back, 0.15 ms of every batch.)  NM_STEP_TABLES=0: off."""
     if os.environ.get("NM_STEP_TABLES", "1") == "0" or ctx.device.type != "cuda":
         return None
     if torch.cuda.is_current_stream_capturing():
@@ -380,10 +382,7 @@ def input_table(dec, ctx) -> Optional[torch.Tensor]:
         return None
     cache = ctx.session.__dict__.setdefault("_input_tables", {})
     entry = cache.get(id(dec))
-    sums = entry[2] if entry is not None else torch.zeros(8, device=ctx.device)
-    for i, part in enumerate(parts):
-        ops.reduce_sum(part.reshape(-1), sums[i:i + 1])
-    print_ = tuple(float(x) for x in ctx.session.read_small(sums[:len(parts)])) + tuple(p.data_ptr() for p in parts)
+    print_ = ctx.session.variables_signature() + tuple(p.data_ptr() for p in parts)
     if entry is not None and entry[0] == print_:
         return entry[1]
     vsz = emb.shape[0]
@@ -392,7 +391,7 @@ def input_table(dec, ctx) -> Optional[torch.Tensor]:
     ops.gemm(emb, wg[:e], out=table[:, :2 * h])
     ops.gemm(emb, wc[:e], out=table[:, 2 * h:3 * h], bias=bc)
     ops.gemm(emb, wo[h:h + e], out=table[:, 3 * h:])
-    cache[id(dec)] = (print_, table, sums)
+    cache[id(dec)] = (print_, table)
     return table
 
 
@@ -567,5 +566,25 @@ def make_stepper(dec, ctx, rows: int, tag: str):
     if not os.environ.get("NM_NO_FUSED_STEP"):
         plan = FusedStepper.supported(dec, ctx, rows)
         if plan is not None:
-            return FusedStepper(dec, ctx, rows, tag, plan)
+            # A stepper is a pile of descriptors over persistent buffers plus seven transposed weight matrices:
+            # building one costs 0.6 ms of host time in front of every batch's first step.  It is kept per buffer
+            # slot and re-used while nothing it points at moved: same variables (signature), same per-batch
+            # tensors (keys, values, mask, workspace: persistent buffers keyed by shape -- compared by address).
+            att = dec.attentions[0]
+            ptr = lambda t: 0 if t is None else t.data_ptr()
+            ident = (ctx.session.variables_signature(), plan["ws"].data_ptr(), plan["S"], plan["C"], plan["Bk"],
+                     att.hidden_features(ctx).data_ptr(), att.attention_states(ctx).data_ptr(),
+                     ptr(att.attention_mask(ctx)), ptr(dec.decoding_bias(ctx)), ptr(dec.embedding_matrix(ctx)),
+                     os.environ.get("NM_STEP_GROUPS"), os.environ.get("NM_STEP_TABLES"), os.environ.get("NM_STEP_PAD"))
+            cache = ctx.session.__dict__.setdefault("_fused_steppers", {})
+            ckey = (id(dec), tag, rows, ctx.session.slot)
+            hit = cache.get(ckey)
+            if hit is not None and hit[0] == ident:
+                stepper = hit[1]
+                stepper.ctx, stepper.plan = ctx, plan
+                stepper._pending, stepper._cur = None, 0          # pylint: disable=protected-access
+                return stepper
+            stepper = FusedStepper(dec, ctx, rows, tag, plan)
+            cache[ckey] = (ident, stepper)
+            return stepper
     return FastStepper(dec, ctx, rows, tag)

@@ -347,6 +347,7 @@ class TransformerDecoder(AutoregressiveDecoder):
             # the host only looks at the finished flags between chunks of steps (one HIP graph per chunk)
             ctx.session.graphed(key + ("chunk", t0, n, bsz, t_xent, stepper.shape_key), chunk)
             steps += n
+            ctx.session.kick_ahead()
             done = np.nonzero(ctx.session.read_small(allfin[:steps]))[0]
             if done.size:                          # loop ends after the first all-finished step
                 steps = int(done[0]) + 1

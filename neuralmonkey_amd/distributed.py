@@ -223,6 +223,7 @@ class DataParallel:
         """Make every replica start from rank ``src``'s variables."""
         if self.world_size > 1:
             dist.broadcast(store.theta, src=src)
+            store.epoch += 1              # (a collective wrote the variables: Session.variables_signature)
 
     def shard(self, dataset):
         """This rank's contiguous share of a batch (SURVEY 8e partitioning): the rows are dealt as evenly as

@@ -40,6 +40,36 @@ MP = TypeVar("MP", bound=GenericModelPart)
 OutputSeries = Union[List, np.ndarray]
 
 
+class LazyLosses(dict):
+    """``ExecutionResult.losses`` of a training step whose scalars are still being copied to the host
+    (runtime.HostPending): a dict that fills itself in on first access."""
+
+    def __init__(self, names, pending) -> None:
+        super().__init__()
+        self._names, self._pending = list(names), pending
+
+    def _fill(self) -> None:
+        pending, self._pending = self._pending, None
+        if pending is not None:
+            dict.update(self, zip(self._names, [float(x) for x in pending.get()]))
+
+    def _filled(name):      # pylint: disable=no-self-argument
+        def method(self, *args, **kwargs):
+            self._fill()
+            return getattr(dict, name)(self, *args, **kwargs)     # pylint: disable=protected-access
+        method.__name__ = name
+        return method
+
+    for _name in ("__getitem__", "__iter__", "__len__", "__contains__", "__repr__", "__eq__", "__ne__", "keys",
+                  "values", "items", "get", "copy", "__reversed__", "__or__", "__ror__"):
+        locals()[_name] = _filled(_name)
+    del _name, _filled
+
+    def __reduce__(self):
+        self._fill()
+        return (dict, (dict(self),))
+
+
 class ExecutionResult(NamedTuple):
     """base_runner.py:21-39."""
     outputs: Dict[str, OutputSeries]

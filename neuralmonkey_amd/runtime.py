@@ -172,6 +172,36 @@ def _to_host(val):
     return val
 
 
+class HostPending:
+    """A few device words on their way to the host: an asynchronous copy into pinned memory plus an event.
+    ``get()`` waits for the event.  A training step hands its loss scalars back like this, so the host thread is
+    free to enqueue the next step while the GPU still runs this one (a blocking read-back at the end of every
+    step left the GPU idle for ~0.3 ms at the start of the next: `profiles/r03_train_step_timeline.txt`)."""
+
+    def __init__(self, session=None, key=None, host=None, event=None, shape=(), value=None):
+        self._session, self._key, self._host, self._event, self._shape, self._value = (
+            session, key, host, event, tuple(shape), value)
+
+    def get(self) -> np.ndarray:
+        if self._value is None:
+            self._event.synchronize()
+            self._value = self._host.numpy().copy().reshape(self._shape)
+            self._release()
+        return self._value
+
+    def _release(self):
+        host, self._host = self._host, None
+        if host is not None and self._session is not None:
+            # re-use is ordered by the stream: the next copy into this buffer is enqueued behind this one
+            self._session._pinned_pool.setdefault(self._key, []).append(host)     # pylint: disable=protected-access
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:        # pylint: disable=broad-except
+            pass
+
+
 _LIVE_SESSIONS: "weakref.WeakSet" = weakref.WeakSet()
 
 
@@ -240,6 +270,8 @@ class Session:
         # while this batch decodes.  Every persistent buffer and captured graph belongs to a SLOT; consecutive
         # batches alternate between slot 0 and slot 1, so the batch that is being encoded ahead never touches what
         # the running batch reads.
+        self._pending_ahead = None
+        self._pinned_pool: Dict[Any, list] = {}      # pinned host buffers of to_host_async, by (numel, dtype)
         self.slot = 0
         self._ahead: list = []                # [(feed signature, slot, memo, event, feed)]
         self._ahead_stream = None
@@ -323,6 +355,19 @@ class Session:
         event.record()
         event.synchronize()
         return host.numpy().reshape(tuple(dev_tensor.shape))
+
+    def to_host_async(self, dev_tensor: torch.Tensor) -> HostPending:
+        """Start copying a small device tensor to pinned host memory; the caller reads it with ``get()`` when (if)
+        it wants the values."""
+        if self.device.type != "cuda" or torch.cuda.is_current_stream_capturing():
+            return HostPending(value=dev_tensor.detach().cpu().numpy())
+        key = (dev_tensor.numel(), dev_tensor.dtype)
+        pool = self._pinned_pool.setdefault(key, [])
+        host = pool.pop() if pool else torch.empty(dev_tensor.numel(), dtype=dev_tensor.dtype).pin_memory()
+        host.copy_(dev_tensor.detach().reshape(-1), non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        return HostPending(self, key, host, event, tuple(dev_tensor.shape))
 
     def staged(self, key, src: torch.Tensor) -> torch.Tensor:
         """Copy a per-batch device tensor into a persistent buffer (same pointer
@@ -452,7 +497,7 @@ class Session:
         for entry in self._ahead:
             # (the variables must be the ones the look-ahead saw: torch-side writes bump the version counter of the
             # flat parameter tensor, the optimizer kernels -- raw pointers -- announce themselves, variables_changed)
-            if entry[0] and entry[0] <= now and entry[5] == self.store.theta._version:
+            if entry[0] and entry[0] <= now and entry[5] == self.variables_signature():
                 hit = entry
         self._ahead = []
         if hit is None:
@@ -463,9 +508,26 @@ class Session:
         return memo
 
     def variables_changed(self) -> None:
-        """Called by whoever rewrites the variables behind torch's back (optimizer kernels): anything evaluated
-        ahead of time from the old values is dropped."""
+        """Called by whoever rewrites the variables behind torch's back (optimizer kernels, collectives): anything
+        evaluated ahead of time or tabulated from the old values is dropped."""
         self._ahead = []
+        self.store.epoch += 1
+
+    def variables_signature(self):
+        """Changes whenever the variables may have: torch-side writes (``store[name].copy_``, a restored
+        checkpoint, a test poking a row) bump the version counter the views of the flat parameter tensor share,
+        kernels that write through raw pointers announce themselves with ``variables_changed``.  Things derived
+        from the variables alone (transposed step weights, input tables) are cached under it."""
+        theta = self.store.theta
+        return (theta.data_ptr(), theta._version, self.store.epoch)     # pylint: disable=protected-access
+
+    def kick_ahead(self) -> None:
+        """Start the look-ahead evaluation ``run`` was asked for.  The decoding loops call this right after they
+        have enqueued their first chunk of steps: the host then launches the next batch's encoder while the GPU is
+        busy instead of in front of the first step."""
+        pending, self._pending_ahead = self._pending_ahead, None
+        if pending is not None:
+            self._run_ahead(*pending)
 
     def _run_ahead(self, fetches, feed) -> None:
         """Evaluate ``fetches`` (the encoder side of a FUTURE batch) on the look-ahead stream, into the buffer slot
@@ -488,7 +550,7 @@ class Session:
                 done = torch.cuda.Event()
                 done.record(self._ahead_stream)
             self._ahead.append((self._feed_signature(feed), self.slot, ctx.memo, done, feed,
-                                self.store.theta._version))
+                                self.variables_signature()))
         finally:
             self.slot = mine
 
@@ -498,11 +560,11 @@ class Session:
         the run that later feeds that batch finds them computed."""
         feed = dict(feed_dict or {})
         claimed = self._claim_ahead(feed)
-        if ahead is not None:
-            self._run_ahead(*ahead)
+        self._pending_ahead = ahead       # started by the first decoding loop (kick_ahead) or right after the fetches
         ctx = RunContext(self, feed)
         if claimed:
             ctx.memo.update(claimed)
         with torch.no_grad():
             out = self._eval(fetches, ctx)
+        self.kick_ahead()
         return _to_host(out)

@@ -6,6 +6,7 @@ per-tensor clip_by_norm + Adam as three fused launches over the flat buffers.
 Fetch names and the ``ExecutionResult`` loss keys ("<decoder> - cost", "L1",
 "L2") follow generic_trainer.py:39-51,245-250.
 """
+import os
 import re
 from typing import Any, Dict, List, Sequence
 
@@ -15,11 +16,12 @@ import torch
 from .. import ops
 from ..model.model_part import Feedable
 from ..optimizers import AdamOptimizer, Optimizer
-from ..runners.base_runner import GraphExecutor, NextExecute
-from ..runtime import tensor
+from ..runners.base_runner import GraphExecutor, LazyLosses, NextExecute
+from ..runtime import HostPending, tensor
 from .objective import Objective
 
 BIAS_REGEX = re.compile(r"[Bb]ias")
+DEFER_LOSSES = os.environ.get("NM_DEFER_LOSSES", "1") != "0"
 
 
 # pylint: disable=too-few-public-methods,too-many-arguments
@@ -39,7 +41,11 @@ class GenericTrainer(GraphExecutor, Feedable):
             assert len(results) == 1
             result = results[0]
             objective_names = [obj.name for obj in self.executor.objectives] + ["L1", "L2"]
-            losses = dict(zip(objective_names, [float(x) for x in result["losses"]]))
+            values = result["losses"]
+            if isinstance(values, HostPending):       # still on their way to the host: read on first access
+                losses = LazyLosses(objective_names, values)
+            else:
+                losses = dict(zip(objective_names, [float(x) for x in values]))
             self.set_result({}, losses, int(result["batch_size"]), [])
 
     @staticmethod
@@ -214,7 +220,13 @@ class GenericTrainer(GraphExecutor, Feedable):
     def objective_values(self, ctx) -> List[Any]:
         losses = [o.loss(ctx) for o in self.objectives]
         l1l2 = self.regularization_losses(ctx)
-        return losses + [l1l2[0], l1l2[1]]
+        values = losses + [l1l2[0], l1l2[1]]
+        # The scalars travel to the host asynchronously (Session.to_host_async) and ExecutionResult.losses reads
+        # them on first access: the training loop only looks at them when it logs, and a blocking read-back per
+        # step keeps the host from enqueuing the next step while this one runs.  NM_DEFER_LOSSES=0: read at once.
+        if DEFER_LOSSES and all(isinstance(v, torch.Tensor) and v.is_cuda for v in values):
+            return ctx.session.to_host_async(torch.stack([v.detach().reshape(()) for v in values]))
+        return values
 
     @property
     def fetches(self) -> Dict[str, Any]:

@@ -82,6 +82,7 @@ class VariableStore:
         self.adam_m: Optional[torch.Tensor] = None
         self.adam_v: Optional[torch.Tensor] = None
         self.total = 0
+        self.epoch = 0          # bumped by whoever writes the variables through raw pointers (Session.variables_changed)
         self._views: Dict[str, torch.Tensor] = {}
         self._gviews: Dict[str, torch.Tensor] = {}
 

@@ -46,6 +46,8 @@ def T(x, dev, dtype=torch.float32):
     (640, 512, 2048, False, False, 0),
     (300, 96, 48, False, True, 0),          # ragged rows, a K slice that ends in the middle of a trip, weights [N,K]
     (1000, 64, 80, False, False, 0),
+    (512, 32, 16, False, True, 0),          # K shorter than one trip (a 16-channel projection's input gradient)
+    (512, 32, 272, False, False, 0),        # 8 full trips + half a trip: the half belongs to the LAST K slice
 ])
 def test_gemm(dev, m, n, k, ta, tb, algo):
     from neuralmonkey_amd import ops
