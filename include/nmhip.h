@@ -396,6 +396,14 @@ int nm_sdp_attn_fwd(void* stream, const float* q, int64_t q_bs, const float* k, 
                     int64_t rows_per_key, int64_t Tq, int64_t Tk, int64_t H, int64_t dh, int causal,
                     float keep_prob, uint32_t salt, const uint32_t* step /* as nm_dropout */, float* ctx,
                     int64_t ctx_bs, float* weights);
+/* One decoding step (Tq = 1) against a key/value cache addressed through an ancestor table: position j of query
+ * row b is read from cache row ancestors[b * anc_ld + j].  Beam search (beam_search_decoder.py:218-330 gathers the
+ * decoder's loop state, i.e. every layer's cached keys and values, at every step) re-points rows at their
+ * ancestors instead of copying the caches. */
+int nm_sdp_attn_step(void* stream, const float* q, int64_t q_bs, const float* k, int64_t k_bs, const float* v,
+                     int64_t v_bs, const float* key_mask, int64_t mask_bs, int64_t Bq, int64_t Tk, int64_t H,
+                     int64_t dh, const int32_t* ancestors, int64_t anc_ld, float* ctx, int64_t ctx_bs,
+                     float* weights);
 int nm_sdp_attn_bwd(void* stream, const float* q, int64_t q_bs, const float* k, int64_t k_bs,
                     const float* v, int64_t v_bs, const float* key_mask, int64_t mask_bs,
                     const float* weights, const float* dctx, int64_t dctx_bs, int64_t B, int64_t Tq,

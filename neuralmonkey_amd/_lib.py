@@ -74,6 +74,7 @@ SIGNATURES = {
     "nm_maxout_fwd": (I, [P, P, L, P, L, P, L, L, L]),
     "nm_maxout_bwd": (I, [P, P, L, P, P, L, L, L, L]),
     "nm_sdp_attn_fwd": (I, [P, P, L, P, L, P, L, P, L, L, L, L, L, L, L, I, F, ctypes.c_uint32, P, P, L, P]),
+    "nm_sdp_attn_step": (I, [P, P, L, P, L, P, L, P, L, L, L, L, L, P, L, P, L, P]),
     "nm_sdp_attn_bwd": (I, [P, P, L, P, L, P, L, P, L, P, P, L, L, L, L, L, L, I, F, ctypes.c_uint32, P,
                             P, L, P, L, P, L, P, I]),
     "nm_add_position": (I, [P, P, P, P, L, L, L, L]),

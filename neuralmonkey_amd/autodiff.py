@@ -398,7 +398,7 @@ def maxout(tape: Tape, x: Var, pool: int = 2) -> Var:
 def sdp_attention(tape: Tape, q: Var, k: Var, v: Var, key_mask: Optional[torch.Tensor], heads: int, bq: int,
                   tq: int, bk: int, tk: int, causal: bool = False, keep_prob: float = 1.0, salt: int = 0,
                   k_data: Optional[torch.Tensor] = None, v_data: Optional[torch.Tensor] = None,
-                  w_out: Optional[torch.Tensor] = None) -> Var:
+                  w_out: Optional[torch.Tensor] = None, ancestors: Optional[torch.Tensor] = None) -> Var:
     """Multi-head scaled dot-product attention (attention/scaled_dot_product.py:98-226) on
     [B*T, D] rows.  ``k_data`` / ``v_data`` override the key / value storage (a [R,Tmax,D] cache
     view during decoding); gradients are defined for bq == bk.  ``w_out`` [bq, heads, tq, tk] receives
@@ -409,6 +409,10 @@ def sdp_attention(tape: Tape, q: Var, k: Var, v: Var, key_mask: Optional[torch.T
     k3 = k_data if k_data is not None else k.data.view(bk, tk, d)
     v3 = v_data if v_data is not None else v.data.view(bk, tk, d)
     step = tape.ctx.session.step_tensor() if keep_prob < 1.0 else None
+    if ancestors is not None:            # a decoding step whose cache rows are addressed through an ancestor table
+        assert tq == 1 and bq == bk and keep_prob >= 1.0 and not tape.recording
+        ops.sdp_attn_step(q.data.view(bq, 1, d), k3, v3, key_mask, heads, ancestors, out.data.view(bq, 1, d), w)
+        return out
     ops.sdp_attn_fwd(q.data.view(bq, tq, d), k3, v3, key_mask, heads, out.data.view(bq, tq, d), w, causal,
                      bq // bk, keep_prob, salt, step)
 

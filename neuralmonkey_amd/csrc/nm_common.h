@@ -59,6 +59,7 @@ struct NmSwitches {
     int beam_ns;           // NM_BEAM_NS        slices per hypothesis row override (0 = by vocabulary size)
     bool sdp_mfma;         // NM_SDP_MFMA=0     matrix-core attention kernels off
     int medium_m;          // NM_STEP_MEDIUM    medium-M (beam search) step groups: 1 on, 0 off
+    bool sdp_decode;       // NM_SDP_DECODE=0   wave-per-(row, head) kernel of cached decoding steps off
 };
 
 struct NmCtx {

@@ -34,6 +34,7 @@ static void switches_from_env(NmSwitches* sw) {
     sw->beam_ns = env_int("NM_BEAM_NS", 0);
     sw->sdp_mfma = !(getenv("NM_SDP_MFMA") && env_int("NM_SDP_MFMA", 1) == 0);
     sw->medium_m = env_int("NM_STEP_MEDIUM", 1);
+    sw->sdp_decode = !(getenv("NM_SDP_DECODE") && env_int("NM_SDP_DECODE", 1) == 0);
 }
 
 static NmCtx* ctx_new(int device) {
@@ -135,7 +136,8 @@ extern "C" int nm_ctx_switch(void* ctx, const char* name, int* value) {
         {"attn_whole", s.attn_whole}, {"aeb_wide_off", s.aeb_wide_off}, {"gemm_no16", s.gemm_no16},
         {"gemm_swz", s.gemm_swz}, {"gemm_nostore", s.gemm_nostore}, {"gemm_sk", s.gemm_sk},
         {"gemm_cfg", s.gemm_cfg}, {"stats_cfg", s.stats_cfg}, {"stats_ablate", s.stats_ablate},
-        {"beam_ns", s.beam_ns}, {"sdp_mfma", s.sdp_mfma}, {"medium_m", s.medium_m}};
+        {"beam_ns", s.beam_ns}, {"sdp_mfma", s.sdp_mfma}, {"medium_m", s.medium_m},
+        {"sdp_decode", s.sdp_decode}};
     for (auto& t : tab)
         if (strcmp(t.n, name) == 0) {
             *value = t.v;

@@ -94,6 +94,108 @@ __global__ __launch_bounds__(256) void sdp_fwd_kernel(SdpArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// One query per row (a cached decoding step, Tq == 1): staging the head's K / V tiles in LDS for a single query
+// leaves three of the four waves idle and walks the tiles with 4-byte loads (46.7 us per call at 640 rows x 8 heads
+// against the ~20 us the bytes take).  Here a wave owns one (row, head): LPK = dh / 4 lanes x 16 bytes cover the
+// head's channels of one key row, so every load instruction of the wave fetches 64 / LPK whole key rows, coalesced;
+// energies are reduced inside the lane group, softmax is accumulated online per lane group (running max, sum and
+// weighted value sum) with the key AND value loads of a pass in flight together, and the lane groups merge at the
+// end.  `anc` (optional, [Bq][anc_ld] int32): the cache row that holds position j of row b's history -- beam search
+// then re-points its hypotheses at their ancestors' keys and values instead of copying the cached prefixes of every
+// layer at every step (decoders/transformer.py: TransformerStepper.reorder).
+// ---------------------------------------------------------------------------------------------
+template <int LPK>
+__global__ __launch_bounds__(1024) void sdp_decode_kernel(SdpArgs p, const int* __restrict__ anc, long anc_ld) {
+    constexpr int KPP = 64 / LPK;                   // keys per pass of the wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int sub = lane % LPK, grp = lane / LPK;
+    const int b = blockIdx.x, kb = b / p.rpk;
+    const int d = p.H * p.dh;
+    const int* arow = anc ? anc + (long)b * anc_ld : nullptr;
+    for (int h = wave; h < p.H; h += nwaves) {
+        const long col = (long)h * p.dh + 4 * sub;
+        float4 q4 = *reinterpret_cast<const float4*>(p.q + (long)b * p.q_bs + col);
+        q4.x *= p.scale; q4.y *= p.scale; q4.z *= p.scale; q4.w *= p.scale;
+        float* wg = p.weights ? p.weights + ((long)b * p.H + h) * p.Tk : nullptr;
+        float m = -INFINITY, ssum = 0.0f;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        constexpr int UN = 4;
+        for (int j0 = grp; j0 < p.Tk; j0 += KPP * UN) {
+            float4 k4[UN], v4[UN];
+            float mk[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int j = min(j0 + u * KPP, p.Tk - 1);               // clamped duplicates are dropped below
+                const long row = arow ? (long)arow[j] : (long)kb;
+                k4[u] = *reinterpret_cast<const float4*>(p.k + row * p.k_bs + (long)j * d + col);
+                v4[u] = *reinterpret_cast<const float4*>(p.v + row * p.v_bs + (long)j * d + col);
+                mk[u] = p.mask ? p.mask[(long)kb * p.mask_bs + j] : 1.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int j = j0 + u * KPP;
+                float e = (q4.x * k4[u].x + q4.y * k4[u].y) + (q4.z * k4[u].z + q4.w * k4[u].w);
+#pragma unroll
+                for (int off = 1; off < LPK; off <<= 1) e += __shfl_xor(e, off, 64);
+                if (j < p.Tk) {                                             // (uniform inside a lane group)
+                    e = sdp_masked_energy(p, e, 0, j, mk[u]);
+                    if (wg && sub == 0) wg[j] = e;                          // normalised below, by the same lane
+                    const float mn = fmaxf(m, e);
+                    const float sc = __expf(m - mn), ex = __expf(e - mn);   // exp(-inf) = 0 on the first key
+                    const float w = ex * sdp_keep(p, b, h, 0, j);
+                    ssum = ssum * sc + ex;
+                    acc.x = acc.x * sc + w * v4[u].x; acc.y = acc.y * sc + w * v4[u].y;
+                    acc.z = acc.z * sc + w * v4[u].z; acc.w = acc.w * sc + w * v4[u].w;
+                    m = mn;
+                }
+            }
+        }
+        // merge the lane groups (a group that saw no key carries m = -inf, sum 0)
+#pragma unroll
+        for (int off = LPK; off < 64; off <<= 1) {
+            const float mo = __shfl_xor(m, off, 64), so = __shfl_xor(ssum, off, 64);
+            float4 ao;
+            ao.x = __shfl_xor(acc.x, off, 64); ao.y = __shfl_xor(acc.y, off, 64);
+            ao.z = __shfl_xor(acc.z, off, 64); ao.w = __shfl_xor(acc.w, off, 64);
+            const float mn = fmaxf(m, mo);
+            const float s1 = (m == -INFINITY) ? 0.0f : __expf(m - mn), s2 = (mo == -INFINITY) ? 0.0f : __expf(mo - mn);
+            ssum = ssum * s1 + so * s2;
+            acc.x = acc.x * s1 + ao.x * s2; acc.y = acc.y * s1 + ao.y * s2;
+            acc.z = acc.z * s1 + ao.z * s2; acc.w = acc.w * s1 + ao.w * s2;
+            m = mn;
+        }
+        const float inv = 1.0f / ssum;
+        if (grp == 0) {
+            acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+            *reinterpret_cast<float4*>(p.ctx + (long)b * p.ctx_bs + col) = acc;
+        }
+        if (wg && sub == 0)
+            for (int j = grp; j < p.Tk; j += KPP) wg[j] = __expf(wg[j] - m) * inv;
+    }
+}
+
+// Tq == 1 dispatch.  Returns false when the shape is not taken (odd head widths, unaligned operands).
+static bool sdp_decode_launch(const SdpArgs& p, const int* anc, long anc_ld, hipStream_t st) {
+    if (p.Tq != 1 || p.dh % 4 || 64 % (p.dh / 4) || p.dh > 256) return false;
+    const int d = p.H * p.dh;
+    if (d % 4 || p.q_bs % 4 || p.k_bs % 4 || p.v_bs % 4 || p.ctx_bs % 4 || !nm_aligned16(p.q) || !nm_aligned16(p.k) ||
+        !nm_aligned16(p.v) || !nm_aligned16(p.ctx))
+        return false;
+    const int waves = p.H < 16 ? p.H : 16;
+    dim3 grid((unsigned)p.Bq), block(64 * waves);
+    switch (p.dh / 4) {
+        case 1: hipLaunchKernelGGL(sdp_decode_kernel<1>, grid, block, 0, st, p, anc, anc_ld); break;
+        case 2: hipLaunchKernelGGL(sdp_decode_kernel<2>, grid, block, 0, st, p, anc, anc_ld); break;
+        case 4: hipLaunchKernelGGL(sdp_decode_kernel<4>, grid, block, 0, st, p, anc, anc_ld); break;
+        case 8: hipLaunchKernelGGL(sdp_decode_kernel<8>, grid, block, 0, st, p, anc, anc_ld); break;
+        case 16: hipLaunchKernelGGL(sdp_decode_kernel<16>, grid, block, 0, st, p, anc, anc_ld); break;
+        case 32: hipLaunchKernelGGL(sdp_decode_kernel<32>, grid, block, 0, st, p, anc, anc_ld); break;
+        default: hipLaunchKernelGGL(sdp_decode_kernel<64>, grid, block, 0, st, p, anc, anc_ld); break;
+    }
+    return true;
+}
+
 static size_t sdp_fwd_lds(long Tk, long dh) { return sizeof(float) * (2 * Tk * (dh + 1) + Tk + 4 * dh + 4 * Tk); }
 
 extern "C" int nm_sdp_attn_fwd(void* stream, const float* q, int64_t q_bs, const float* k, int64_t k_bs,
@@ -121,6 +223,9 @@ extern "C" int nm_sdp_attn_fwd(void* stream, const float* q, int64_t q_bs, const
     if (nm_sdp_mfma_fwd(p, nm_stream(stream))) {      // training / encoding shapes: matrix cores (nm_sdp_mfma.hip)
         NM_LAUNCH_CHECK("nm_sdp_attn_fwd (mfma)");
     }
+    if (nm_cur()->sw.sdp_decode && sdp_decode_launch(p, nullptr, 0, nm_stream(stream))) {     // one query per row
+        NM_LAUNCH_CHECK("nm_sdp_attn_fwd (decode)");
+    }
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)sdp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -128,6 +233,29 @@ extern "C" int nm_sdp_attn_fwd(void* stream, const float* q, int64_t q_bs, const
     }
     hipLaunchKernelGGL(sdp_fwd_kernel, dim3((unsigned)(Bq * H)), dim3(256), lds, nm_stream(stream), p);
     NM_LAUNCH_CHECK("nm_sdp_attn_fwd");
+}
+
+// One decoding step against a key/value cache whose rows are addressed through an ancestor table:
+// position j of query row b lives in cache row ancestors[b * anc_ld + j] (decoders/transformer.py:493-516 with the
+// beam search's gather of the cached prefixes, beam_search_decoder.py:218-330, folded into the addressing).
+extern "C" int nm_sdp_attn_step(void* stream, const float* q, int64_t q_bs, const float* k, int64_t k_bs,
+                                const float* v, int64_t v_bs, const float* key_mask, int64_t mask_bs, int64_t Bq,
+                                int64_t Tk, int64_t H, int64_t dh, const int32_t* ancestors, int64_t anc_ld,
+                                float* ctx, int64_t ctx_bs, float* weights) {
+    NM_REQUIRE(q && k && v && ctx && ancestors, "nm_sdp_attn_step: null pointer");
+    NM_REQUIRE(Bq > 0 && Tk > 0 && H > 0 && dh > 0 && anc_ld >= Tk && Bq < (1LL << 31),
+               "nm_sdp_attn_step: bad shape Bq=%ld Tk=%ld H=%ld dh=%ld anc_ld=%ld", (long)Bq, (long)Tk, (long)H,
+               (long)dh, (long)anc_ld);
+    SdpArgs p;
+    p.q = q; p.q_bs = q_bs; p.k = k; p.k_bs = k_bs; p.v = v; p.v_bs = v_bs;
+    p.mask = key_mask; p.mask_bs = mask_bs; p.ctx = ctx; p.ctx_bs = ctx_bs; p.weights = weights;
+    p.Bq = (int)Bq; p.rpk = 1; p.Tq = 1; p.Tk = (int)Tk; p.H = (int)H; p.dh = (int)dh; p.causal = 0;
+    p.scale = 1.0f / sqrtf((float)dh);
+    p.keep_prob = 1.0f; p.inv_keep = 1.0f; p.salt = 0; p.step = nullptr;
+    NM_REQUIRE(sdp_decode_launch(p, ancestors, anc_ld, nm_stream(stream)),
+               "nm_sdp_attn_step: dh=%ld must be 4, 8, 16, 32, 64, 128 or 256 and the operands 16-byte aligned",
+               (long)dh);
+    NM_LAUNCH_CHECK("nm_sdp_attn_step");
 }
 
 // ---------------------------------------------------------------------------------------------

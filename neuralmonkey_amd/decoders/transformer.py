@@ -17,6 +17,7 @@ keys / values to per-layer [R, Tmax, D] caches and attends with one query per ro
 row (:493-497); encoder keys / values are projected once per sentence and shared by the rows of a
 beam (row r reads sentence r // k).
 """
+import os
 from typing import Any, List, NamedTuple, Optional, Union
 
 import numpy as np
@@ -423,9 +424,20 @@ class TransformerStepper:
         key = (id(dec), tag, rows, self.tmax)
         self.tape = F.Tape(ctx, key + ("tape",), recording=False)
         buf = lambda name, shape: ctx.buffer(key + (name,), shape)
-        # per layer: keys / values of the positions decoded so far, two copies for the beam reorder
-        self.kcache = [buf(("k", l), (2, rows, self.tmax, d)) for l in range(dec.depth)]
-        self.vcache = [buf(("v", l), (2, rows, self.tmax, d)) for l in range(dec.depth)]
+        # Per layer: keys / values of the positions decoded so far.  Beam search does not move them: row r's history
+        # is addressed through an ancestor table (``anc[r, j]`` = the cache row that holds position j of the
+        # hypothesis row r continues; position t is always written to row r itself), and a beam step re-points the
+        # rows -- one gather of a [rows, t] int32 table -- where it used to copy the cached prefixes of every
+        # layer (12 gathers of up to 65 MB per step at the Transformer-base shape, 13 % of a beam step).
+        # NM_KV_ANCESTORS=0: two cache copies and the gathers.
+        # (the table is read by the wave-per-(row, head) kernel, which wants head widths of 4 .. 256 floats in powers
+        # of two; anything else -- tests/transformer.ini has heads of 2 -- keeps the gathers)
+        self.use_anc = (tag.startswith("beam") and os.environ.get("NM_KV_ANCESTORS", "1") != "0" and
+                        d % dec.n_heads_self == 0 and d // dec.n_heads_self in (4, 8, 16, 32, 64, 128, 256))
+        copies = 1 if (self.use_anc or not tag.startswith("beam")) else 2
+        self.kcache = [buf(("k", l), (copies, rows, self.tmax, d)) for l in range(dec.depth)]
+        self.vcache = [buf(("v", l), (copies, rows, self.tmax, d)) for l in range(dec.depth)]
+        self.anc = ctx.buffer(key + ("anc",), (2, rows, self.tmax), torch.int32) if self.use_anc else None
         self.mask = buf("mask", (2, rows, self.tmax))
         self.hier_ones = buf("hier_ones", (rows, len(dec.encoders)))
         self.hier_ones.fill_(1.0)
@@ -457,6 +469,9 @@ class TransformerStepper:
             self.enc_kv.append((per_layer, emask, bk, slen))
         self.base = tape._n                       # pylint: disable=protected-access
         self.cur, self.t = 0, 0
+        if self.anc is not None:                  # every row starts as its own ancestor at every position
+            iota = torch.arange(self.rows, dtype=torch.int32, device=self.anc.device).view(1, self.rows, 1)
+            self.anc.copy_(iota.expand(2, self.rows, self.tmax))
 
     indexed = True       # set_position(t, cur) makes a step a function of its index: HIP-graph capturable
 
@@ -484,7 +499,7 @@ class TransformerStepper:
             scope = pre + "/self_attention"
             normed = TB.layer_norm(tape, dec, scope, x)
             q = TB.project(tape, dec, scope, "query_proj", normed, dec.n_heads_self, dec.use_att_transform_bias)
-            kc, vc = self.kcache[l][cur], self.vcache[l][cur]
+            kc, vc = self.kcache[l][cur if len(self.kcache[l]) > 1 else 0], self.vcache[l][cur if len(self.vcache[l]) > 1 else 0]
             if dec.n_heads_self > 1:
                 bias = lambda p: tape.param(dec, "{}/{}/bias".format(scope, p)) if dec.use_att_transform_bias else None
                 F.linear(tape, normed, tape.param(dec, scope + "/keys_proj/kernel"), bias("keys_proj"),
@@ -495,7 +510,8 @@ class TransformerStepper:
                 ops.ew("copy", normed.data, None, kc[:, t])
                 ops.ew("copy", normed.data, None, vc[:, t])
             att = F.sdp_attention(tape, q, None, None, mask[:, :t + 1], dec.n_heads_self, rows, 1, rows, t + 1,
-                                  False, 1.0, 0, k_data=kc[:, :t + 1], v_data=vc[:, :t + 1])
+                                  False, 1.0, 0, k_data=kc[:, :t + 1], v_data=vc[:, :t + 1],
+                                  ancestors=self.anc[cur] if self.anc is not None else None)
             att = TB.project(tape, dec, scope, "output_proj", att, dec.n_heads_self, dec.use_att_transform_bias)
             x = F.add(tape, att, x)
             strategy = dec.attention_combination_strategy
@@ -532,9 +548,12 @@ class TransformerStepper:
         cur, nxt, t = self.cur, self.cur ^ 1, self.t
         d = self.dec.dimension
         width = t * d
-        for l in range(self.dec.depth):
-            for cache in (self.kcache[l], self.vcache[l]):
-                ops.gather_rows(cache[cur].view(self.rows, self.tmax * d)[:, :width], src_rows,
-                                cache[nxt].view(self.rows, self.tmax * d)[:, :width])
+        if self.anc is not None:                  # (int32 rows moved as their bit patterns)
+            ops.gather_rows(self.anc[cur].view(torch.float32)[:, :t], src_rows, self.anc[nxt].view(torch.float32)[:, :t])
+        else:
+            for l in range(self.dec.depth):
+                for cache in (self.kcache[l], self.vcache[l]):
+                    ops.gather_rows(cache[cur].view(self.rows, self.tmax * d)[:, :width], src_rows,
+                                    cache[nxt].view(self.rows, self.tmax * d)[:, :width])
         ops.gather_rows(self.mask[cur][:, :t], src_rows, self.mask[nxt][:, :t])
         self.cur = nxt

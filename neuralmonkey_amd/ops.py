@@ -628,6 +628,24 @@ def sdp_attn_fwd(q, k, v, key_mask, heads, ctx, weights=None, causal=False, rows
     return ctx
 
 
+def sdp_attn_step(q, k, v, key_mask, heads, ancestors, ctx, weights=None):
+    """One cached decoding step: q/ctx [R,1,D]; k/v [R,Tk,D] views of the caches; position j of row r is read from
+    cache row ``ancestors[r, j]`` (int32 [R, >=Tk])."""
+    lib = _lib.load()
+    rows, tq, d = q.shape
+    tk = k.shape[1]
+    assert tq == 1 and d % heads == 0 and ancestors.dtype == torch.int32 and ancestors.stride(1) == 1
+    assert ancestors.shape[0] == rows and ancestors.shape[1] >= tk
+    mask_bs = 0
+    if key_mask is not None:
+        assert key_mask.dim() == 2 and key_mask.stride(1) == 1 and key_mask.shape[1] >= tk
+        mask_bs = key_mask.stride(0)
+    _lib.check(lib.nm_sdp_attn_step(_stream(), q.data_ptr(), _bs(q), k.data_ptr(), _bs(k), v.data_ptr(), _bs(v),
+                                    _p(key_mask), mask_bs, rows, tk, heads, d // heads, ancestors.data_ptr(),
+                                    ancestors.stride(0), ctx.data_ptr(), _bs(ctx), _p(weights)), "nm_sdp_attn_step")
+    return ctx
+
+
 def sdp_attn_bwd(q, k, v, key_mask, weights, dctx, heads, dq, dk, dv, de_ws, causal=False, keep_prob=1.0, salt=0,
                  accumulate=False, step=None):
     lib = _lib.load()

@@ -38,6 +38,13 @@ VOCAB = 40
     (6, 9, 40, 4, 64, False, True, 1.0, 3),       # several query rows per key batch (forward only)
     (2, 33, 17, 8, 64, True, True, 1.0, 1),       # odd key count (unpaired weight stores), more queries than keys
     (3, 64, 64, 2, 64, True, True, 0.7, 1),       # exactly full tiles
+    # one query per row (sdp_decode_kernel: a wave per (row, head), online softmax over lane groups)
+    (10, 1, 50, 8, 64, False, True, 1.0, 5),      # BASELINE configs[4] beam step: cross attention, 5 rows per sentence
+    (7, 1, 37, 8, 64, True, True, 1.0, 1),        # self attention against a cache (the future mask is a no-op)
+    (4, 1, 1, 2, 32, False, True, 1.0, 1),        # a single key: three of the four lane groups see nothing
+    (3, 1, 130, 1, 128, False, False, 1.0, 1),    # more keys than an unrolled pass, two keys per load
+    (2, 1, 9, 20, 256, False, True, 1.0, 1),      # a key row per wave pass; more heads than waves
+    (5, 1, 23, 3, 4, False, True, 0.8, 1),        # one lane per key, dropout on the weights
 ])
 def test_sdp_attention_fwd_bwd(dev, b, tq, tk, heads, dh, causal, masked, keep, rpk):
     from neuralmonkey_amd import ops
@@ -88,6 +95,28 @@ def test_sdp_attention_fwd_bwd(dev, b, tq, tk, heads, dh, causal, masked, keep, 
     ops.sdp_attn_bwd(qd, kd, vd, mt.to(dev), w, g.to(dev), heads, dq, dk, dv, de, causal, keep, salt, accumulate=True)
     for got, want in ((dq, q.grad), (dk, k.grad), (dv, v.grad)):
         assert float((got.cpu() - want).abs().max()) < 2e-5 * max(float(want.abs().max()), 1.0)
+
+
+@pytest.mark.parametrize("rows,tk,tmax,heads,dh", [(10, 7, 12, 8, 64), (640, 50, 51, 8, 64), (6, 1, 4, 2, 16)])
+def test_sdp_step_through_an_ancestor_table(dev, rows, tk, tmax, heads, dh):
+    """nm_sdp_attn_step reads position j of row r from cache row ancestors[r, j]: the same numbers as gathering the
+    caches first (what TransformerStepper.reorder did at every beam step) and attending to the copy."""
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(rows + tk)
+    d = heads * dh
+    q = torch.tensor(rng.standard_normal((rows, 1, d)).astype(np.float32), device=dev)
+    kc = torch.tensor(rng.standard_normal((rows, tmax, d)).astype(np.float32), device=dev)
+    vc = torch.tensor(rng.standard_normal((rows, tmax, d)).astype(np.float32), device=dev)
+    anc = torch.tensor(rng.integers(0, rows, (rows, tmax)).astype(np.int32), device=dev)
+    mask = torch.tensor((rng.random((rows, tmax)) < 0.8).astype(np.float32), device=dev)
+    mask[:, 0] = 1.0
+    pos = torch.arange(tmax, device=dev)[None, :].expand(rows, tmax)
+    kg, vg = kc[anc.long(), pos], vc[anc.long(), pos]            # [rows, tmax, d] gathered copies (indexing: plumbing)
+    want, want_w = torch.empty((rows, 1, d), device=dev), torch.empty((rows, heads, 1, tk), device=dev)
+    ops.sdp_attn_fwd(q, kg[:, :tk], vg[:, :tk], mask, heads, want, want_w)
+    got, got_w = torch.empty_like(want), torch.empty_like(want_w)
+    ops.sdp_attn_step(q, kc[:, :tk], vc[:, :tk], mask, heads, anc, got, got_w)
+    assert torch.equal(got, want) and torch.equal(got_w, want_w)
 
 
 def test_position_signal_matches_the_reference_formula(dev):

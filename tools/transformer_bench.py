@@ -47,9 +47,11 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps
 
-    t_train = timed(lambda: tfm.execute(ds, trainer.feedables, [trainer], train=True), 2, 5)
-    print("train: {:.2f} ms/step  {:.0f} tok/s".format(t_train * 1e3, tokens / t_train))
-    if "--train-only" in sys.argv:
+    only = [a[2:-5] for a in sys.argv if a.startswith("--") and a.endswith("-only")]       # --train-only, --beam-5-only ...
+    if not only or "train" in only:
+        t_train = timed(lambda: tfm.execute(ds, trainer.feedables, [trainer], train=True), 2, 5)
+        print("train: {:.2f} ms/step  {:.0f} tok/s".format(t_train * 1e3, tokens / t_train))
+    if only == ["train"]:
         return
     dsd = synthetic.synthetic_dataset(seed=2, batch=batch, src_len=length, tgt_len=length, vocab=vocab_size,
                                       with_target=False)
@@ -60,6 +62,8 @@ def main():
     store["decoder/LayerNorm/beta"].copy_(10.0 * u)
     store["decoder/word_embeddings"][2].copy_(-100.0 * u)
     for name, runner, series in (("greedy", greedy, "target"), ("beam-5", beam, "target_beam")):
+        if only and name not in only:
+            continue
         t = timed(lambda: tfm.execute(dsd, runner.feedables, [runner], compute_losses=False), 2, 3)
         out = tfm.execute(dsd, runner.feedables, [runner], compute_losses=False)[0]
         steps = max(len(sent) for sent in out.outputs[series])
