@@ -1,6 +1,8 @@
 set -x
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-T=r03ag
-timeout 900 python -m pytest tests/test_transformer_gpu.py tests/test_transformer_fullsize_gpu.py tests/test_dotprod_gpu.py tests/test_reference_inis_gpu.py tests/test_multisource_gpu.py -q -m gpu > gpurun_out/${T}_tests.txt 2>&1
-echo "tests rc=$?"; tail -5 gpurun_out/${T}_tests.txt | cut -c1-400
+T=r03ai
+python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
+echo "bench rc=$?"
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/${T}_smoke.txt 2>&1
+tail -1 gpurun_out/${T}_smoke.txt
