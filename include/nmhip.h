@@ -274,6 +274,12 @@ int nm_greedy_update(void* stream, const int32_t* argmax, int32_t* finished, int
 int nm_xent(void* stream, float* logits, int64_t ldx, int64_t rows, int64_t V, const int32_t* targets,
             const float* weights, float* loss_rows, const float* grad_scale, int write_grad,
             float label_smoothing);
+/* The same with the column sums of the gradient -- the bias gradient of the vocabulary projection
+ * (decoders/autoregressive.py:450-459 under tf.gradients) -- accumulated on the way: partial[g, :] receives the sums
+ * over logits rows g, g + partial_rows, ...; nm_colsum over `partial` finishes the reduction.  V % 4 == 0, V <= 32768. */
+int nm_xent_colsum(void* stream, float* logits, int64_t ldx, int64_t rows, int64_t V, const int32_t* targets,
+                   const float* weights, float* loss_rows, const float* grad_scale, float label_smoothing,
+                   float* partial, int64_t partial_rows);
 
 /* ---- beam search step: decoders/beam_search_decoder.py:440-501 (mask, + logprob_sum, length
  * penalty, tf.nn.top_k over [B,k*V] with lower-index-first ties, div/mod, gathers) and the

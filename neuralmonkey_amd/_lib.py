@@ -51,6 +51,7 @@ SIGNATURES = {
     "nm_row_stats": (I, [P, P, L, L, L, P, P, P]),
     "nm_greedy_update": (I, [P, P, P, P, P, L, I, P]),
     "nm_xent": (I, [P, P, L, L, L, P, P, P, P, I, F]),
+    "nm_xent_colsum": (I, [P, P, L, L, L, P, P, P, P, F, P, L]),
     "nm_beam_workspace_bytes": (L, [L, L, L]),
     "nm_beam_topk_step": (I, [P, P, L, L, L, L, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, L, P]),
     "nm_beam_topk_step_fused": (I, [P, P, L, L, L, L, P, P, P, P, I, P, P, P, P, P, P, P, P, L, P, P, P]),

@@ -257,6 +257,154 @@ __global__ __launch_bounds__(1024) void xent_regs_kernel(float* __restrict__ x, 
     }
 }
 
+// The same cross entropy + in-place gradient with the COLUMN SUMS of the gradient (the bias gradient of the
+// vocabulary projection, decoders/autoregressive.py:450-459 under tf.gradients) as a by-product: a workgroup walks
+// rows blockIdx.x, blockIdx.x + G, ... with the same thread -> column mapping for every row and adds what it stores
+// to a [V] accumulator in LDS (each thread only ever touches its own entries); the G partial vectors are summed by
+// nm_colsum afterwards.  The separate column-sum pass this replaces re-read the 819 MB gradient (0.27 ms at the
+// benchmark shape) on the side stream, right under the first launches of the BPTT loop, which waited for it.
+// Per-row arithmetic is xent_regs_kernel's.
+#define XC_NT 1024
+typedef float xc_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 xc_load_nt(const float4* p) {
+    const xc_f4 v = __builtin_nontemporal_load(reinterpret_cast<const xc_f4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+template <int NV>
+__global__ __launch_bounds__(XC_NT) void xent_cols_kernel(float* __restrict__ x, long ldx, int V, int rows,
+                                                          const int* __restrict__ targets,
+                                                          const float* __restrict__ weights,
+                                                          float* __restrict__ loss_rows,
+                                                          const float* __restrict__ grad_scale, float smoothing,
+                                                          float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float4 cs4[];      // [V / 4]
+    __shared__ float sh[XC_NT / 64];
+    const int tid = threadIdx.x;
+    const int V4 = V >> 2;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (tid + i * XC_NT < V4) cs4[tid + i * XC_NT] = zero4;
+    const float4 ninf4 = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    const float gsc = grad_scale ? grad_scale[0] : 1.0f;
+    const float qu = smoothing / (float)V;
+    const float hot = 1.0f - smoothing;
+    const long G = gridDim.x;
+
+    // (non-temporal builtin: a plain conditional float4 load is split into four guarded dword loads)
+    auto load_row = [&](float4 (&r)[NV], long row) {
+        const float4* r4 = reinterpret_cast<const float4*>(x + row * ldx);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            r[i] = ninf4;
+            if (tid + i * XC_NT < V4) r[i] = xc_load_nt(&r4[tid + i * XC_NT]);
+        }
+    };
+    // one row from registers: statistics, loss, gradient stored in place and added to the column accumulator.
+    // `xt` = the target's logit, read by the caller before the row is overwritten
+    auto process = [&](float4 (&xv)[NV], long row, int t, float xt) {
+        float4* x4 = reinterpret_cast<float4*>(x + row * ldx);
+        float bv = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) bv = fmaxf(bv, fmaxf(fmaxf(xv[i].x, xv[i].y), fmaxf(xv[i].z, xv[i].w)));
+        bv = nm_wave_max(bv);
+        if ((tid & 63) == 0) sh[tid >> 6] = bv;
+        __syncthreads();
+        bv = sh[0];
+#pragma unroll
+        for (int w = 1; w < XC_NT / 64; ++w) bv = fmaxf(bv, sh[w]);
+        __syncthreads();
+        float s = 0.0f, sx = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (tid + i * XC_NT < V4) {
+                sx += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
+                xv[i].x = expf(xv[i].x - bv); xv[i].y = expf(xv[i].y - bv);      // kept for the gradient
+                xv[i].z = expf(xv[i].z - bv); xv[i].w = expf(xv[i].w - bv);
+                s += xv[i].x + xv[i].y + xv[i].z + xv[i].w;
+            }
+        }
+        s = block_sum<XC_NT>(s, sh);
+        __syncthreads();
+        if (smoothing != 0.0f) { sx = block_sum<XC_NT>(sx, sh); __syncthreads(); }
+        const float lse = logf(s);
+        const float w = weights ? weights[row] : 1.0f;
+        if (tid == 0 && loss_rows) {
+            const float nll = (t >= 0 && t < V) ? -(xt - bv - lse) : 0.0f;
+            const float uniform = (bv + lse) - sx / (float)V;
+            loss_rows[row] = ((1.0f - smoothing) * nll + smoothing * uniform) * w;
+        }
+        const float gs = w * gsc;
+        const float inv = 1.0f / s;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int q = tid + i * XC_NT;
+            if (q < V4) {
+                const int e = q * 4;
+                float4 g;
+                g.x = (xv[i].x * inv - qu - (e == t ? hot : 0.0f)) * gs;
+                g.y = (xv[i].y * inv - qu - (e + 1 == t ? hot : 0.0f)) * gs;
+                g.z = (xv[i].z * inv - qu - (e + 2 == t ? hot : 0.0f)) * gs;
+                g.w = (xv[i].w * inv - qu - (e + 3 == t ? hot : 0.0f)) * gs;
+                x4[q] = g;
+                float4 c = cs4[q];
+                c.x += g.x; c.y += g.y; c.z += g.z; c.w += g.w;
+                cs4[q] = c;
+            }
+        }
+    };
+    auto target_logit = [&](long row, int t) {
+        return (tid == 0 && t >= 0 && t < V) ? x[row * ldx + t] : 0.0f;
+    };
+
+    // (Prefetching the next row into a second register set was tried three ways -- copied sets, ping-pong sets, 512
+    // threads x 16 float4: hipcc either waits for the prefetch right behind its issue (vmcnt counts in order across
+    // the loop's back edge) or spills 28-101 registers; the plain loop runs at 3.9 TB/s.)
+    float4 xv[NV];
+    for (long row = blockIdx.x; row < rows; row += G) {
+        const int t = targets[row];
+        const float xt = target_logit(row, t);
+        load_row(xv, row);
+        process(xv, row, t, xt);
+    }
+    float4* out = reinterpret_cast<float4*>(partial + (long)blockIdx.x * V);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (tid + i * XC_NT < V4) out[tid + i * XC_NT] = cs4[tid + i * XC_NT];
+}
+
+// partial [partial_rows, V]: row g receives the column sums of logits rows g, g + partial_rows, ...
+extern "C" int nm_xent_colsum(void* stream, float* logits, int64_t ldx, int64_t rows, int64_t V,
+                              const int32_t* targets, const float* weights, float* loss_rows,
+                              const float* grad_scale, float label_smoothing, float* partial, int64_t partial_rows) {
+    NM_REQUIRE(logits && targets && partial && rows > 0 && V > 0 && ldx >= V, "nm_xent_colsum: bad args");
+    NM_REQUIRE(label_smoothing >= 0.0f && label_smoothing < 1.0f, "nm_xent_colsum: label_smoothing %g outside [0,1)",
+               label_smoothing);
+    NM_REQUIRE(partial_rows >= 1 && partial_rows <= rows && partial_rows < (1 << 30), "nm_xent_colsum: partial_rows %ld",
+               (long)partial_rows);
+    NM_REQUIRE(V % 4 == 0 && ldx % 4 == 0 && nm_aligned16(logits) && nm_aligned16(partial) && V / 4 <= 8 * XC_NT &&
+                   V * 4 <= 144 * 1024,
+               "nm_xent_colsum: V=%ld must be a multiple of 4, at most 32768, rows 16-byte aligned", (long)V);
+    const int nv = (int)((V / 4 + XC_NT - 1) / XC_NT);
+#define NM_XC(NV_)                                                                                                    \
+    do {                                                                                                              \
+        static bool attr_set = false;                                                                                 \
+        if (!attr_set) {                                                                                              \
+            (void)hipFuncSetAttribute((const void*)xent_cols_kernel<NV_>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                      144 * 1024);                                                                    \
+            attr_set = true;                                                                                          \
+        }                                                                                                             \
+        hipLaunchKernelGGL((xent_cols_kernel<NV_>), dim3((unsigned)partial_rows), dim3(XC_NT), (size_t)V * 4,           \
+                           nm_stream(stream), logits, (long)ldx, (int)V, (int)rows, targets, weights, loss_rows,      \
+                           grad_scale, label_smoothing, partial);                                                     \
+    } while (0)
+    if (nv <= 2) NM_XC(2);
+    else if (nv <= 4) NM_XC(4);
+    else NM_XC(8);
+#undef NM_XC
+    NM_LAUNCH_CHECK("nm_xent_colsum");
+}
+
 extern "C" int nm_xent(void* stream, float* logits, int64_t ldx, int64_t rows, int64_t V,
                        const int32_t* targets, const float* weights, float* loss_rows,
                        const float* grad_scale, int write_grad, float label_smoothing) {

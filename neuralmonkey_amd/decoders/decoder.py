@@ -297,8 +297,15 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
         logits = ctx.buffer(key + ("logits",), (rows, v))
         self.state_to_logits(ctx, out_all, logits)
         loss_rows = ctx.buffer(key + ("loss_rows",), (rows,))
-        ops.xent(logits, tgt.reshape(-1), self.xent_weights(tmask.reshape(-1)), loss_rows, grad_scale, want_grad,
-                 self.label_smoothing or 0.0)
+        db_partial = None
+        if want_grad and not self.tie_embeddings and ops.xent_colsum_ok(logits):
+            # the bias gradient of the vocabulary projection falls out of the pass that writes dlogits
+            db_partial = ctx.buffer(key + ("db_partial",), (min(rows, ops.XENT_COLSUM_ROWS), v))
+            ops.xent_colsum(logits, tgt.reshape(-1), self.xent_weights(tmask.reshape(-1)), loss_rows, grad_scale,
+                            self.label_smoothing or 0.0, db_partial)
+        else:
+            ops.xent(logits, tgt.reshape(-1), self.xent_weights(tmask.reshape(-1)), loss_rows, grad_scale, want_grad,
+                     self.label_smoothing or 0.0)
         loss_sum = ctx.buffer(key + ("loss_sum",), (1,))
         ops.reduce_sum(loss_rows, loss_sum)
         for att, st in zip(self.attentions, att_states):
@@ -306,7 +313,8 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
         saved = {"emb_all": emb_all, "xp": xp, "s0": s0, "s_all": s_all, "s_ext": s_ext, "ru_all": ru_all,
                  "c_all": c_all, "rh_all": rh_all, "y_all": y_all, "e_all": e_all,
                  "att_states": att_states, "out_all": out_all,
-                 "dlogits": logits if want_grad else None, "cell": cell, "steps": steps, "bsz": bsz,
+                 "dlogits": logits if want_grad else None, "db_partial": db_partial, "cell": cell, "steps": steps,
+                 "bsz": bsz,
                  "loss_rows": loss_rows, "loss_layout": "tb"}
         return TrainResult(loss_sum, self.train_token_count(ctx), steps, saved)
 
@@ -370,7 +378,8 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
                          accumulate=True)
             else:
                 ops.gemm(out_all, dlogits, out=store.g(self.var_name("state_to_word_W")), trans_a=True, accumulate=acc)
-                ops.colsum(dlogits, store.g(self.var_name("state_to_word_b")), accumulate=acc)
+                ops.colsum(sv["db_partial"] if sv.get("db_partial") is not None else dlogits,
+                           store.g(self.var_name("state_to_word_b")), accumulate=acc)
                 if dp_overlap:        # the largest gradient slice is final: its all-reduce runs under the BPTT
                     dp.all_reduce_early(store, [self.var_name("state_to_word_W"), self.var_name("state_to_word_b")])
 

@@ -4,6 +4,7 @@ torch is used only as the device allocator and stream owner; every arithmetic
 op on the hot path is a libnmhip kernel launched on torch's current stream.
 """
 import ctypes
+import os
 from typing import Optional
 
 import numpy as np
@@ -216,6 +217,26 @@ def xent(logits, targets, weights, loss_rows, grad_scale=None, write_grad=False,
     _lib.check(lib.nm_xent(_stream(), logits.data_ptr(), logits.stride(0), logits.shape[0],
                            logits.shape[1], targets.data_ptr(), _p(weights), _p(loss_rows),
                            _p(grad_scale), int(write_grad), float(label_smoothing)), "nm_xent")
+
+
+XENT_COLSUM_ROWS = 256        # one 1024-thread workgroup per CU
+
+
+def xent_colsum_ok(logits) -> bool:
+    v = logits.shape[1]
+    return (logits.is_cuda and v % 4 == 0 and v <= 32768 and logits.stride(0) % 4 == 0 and
+            logits.data_ptr() % 16 == 0 and os.environ.get("NM_XENT_COLSUM", "1") != "0")
+
+
+def xent_colsum(logits, targets, weights, loss_rows, grad_scale, label_smoothing, partial):
+    """Cross entropy + in-place gradient as ``xent(..., write_grad=True)``; ``partial`` [G, V] receives per-workgroup
+    column sums of the gradient (G <= rows): ``colsum(partial, bias_grad)`` is the projection's bias gradient."""
+    lib = _lib.load()
+    assert logits.dim() == 2 and logits.stride(1) == 1 and partial.is_contiguous()
+    assert partial.shape[1] == logits.shape[1] and 1 <= partial.shape[0] <= logits.shape[0]
+    _lib.check(lib.nm_xent_colsum(_stream(), logits.data_ptr(), logits.stride(0), logits.shape[0], logits.shape[1],
+                                  targets.data_ptr(), _p(weights), _p(loss_rows), _p(grad_scale),
+                                  float(label_smoothing), partial.data_ptr(), partial.shape[0]), "nm_xent_colsum")
 
 
 def beam_workspace(b, k, v, device):

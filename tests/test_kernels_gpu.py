@@ -666,6 +666,31 @@ def test_xent_fwd_and_grad(dev):
     assert rel_err(xd.cpu().numpy(), ref_g) < 1e-5
 
 
+@pytest.mark.parametrize("r,v,g,smoothing", [(64, 5000, 7, 0.0), (300, 32000, 256, 0.0), (33, 1024, 33, 0.1),
+                                             (5, 36, 1, 0.0)])
+def test_xent_with_column_sums(dev, r, v, g, smoothing):
+    """nm_xent_colsum: loss and in-place gradient bit-identical to nm_xent, partial column sums add up to the
+    column sums of that gradient (float64 yardstick)."""
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(r + v)
+    x = (rng.standard_normal((r, v)) * 2).astype(np.float32)
+    tgt = rng.integers(0, v, size=r).astype(np.int32)
+    w = (rng.random(r) > 0.3).astype(np.float32)
+    scale = T(np.array([1.0 / max(w.sum(), 1.0)], np.float32), dev)
+    want, got = T(x, dev), T(x, dev)
+    loss_want, loss_got = torch.empty(r, device=dev), torch.empty(r, device=dev)
+    ops.xent(want, T(tgt, dev, torch.int32), T(w, dev), loss_want, scale, True, smoothing)
+    assert ops.xent_colsum_ok(got)
+    partial = torch.full((g, v), float("nan"), device=dev)
+    ops.xent_colsum(got, T(tgt, dev, torch.int32), T(w, dev), loss_got, scale, smoothing, partial)
+    assert torch.equal(got, want) and torch.equal(loss_got, loss_want)
+    ref = want.cpu().numpy().astype(np.float64).sum(0)
+    bias = torch.zeros(v, device=dev)
+    ops.colsum(partial, bias)
+    assert np.abs(bias.cpu().numpy() - ref).max() < 1e-6 * max(np.abs(ref).max(), 1e-3) + 1e-9
+    assert np.abs(partial.cpu().numpy().astype(np.float64).sum(0) - ref).max() < 1e-6 * max(np.abs(ref).max(), 1e-3) + 1e-9
+
+
 # --------------------------------------------------------------------------- #
 def _beam_step_ref(logits, k, logprob_sum, lengths, finished, alpha):
     """One beam_search_decoder body top-k (oracle arithmetic, fp32)."""
