@@ -118,6 +118,11 @@ int nm_gru_rh_seq(void* stream, const float* ru_all, const float* hprev, float* 
                   const int32_t* lengths, int rev_mask, int64_t B, int64_t S, int ndir, int64_t H);
 
 /* ---- layer norm: tf_utils.py:189-219 (eps inside rsqrt, biased variance) ------------------ */
+/* sum_out = a + x ; y = layer_norm(sum_out): the residual connection that ends a Transformer sub-layer and the
+ * pre-norm that starts the next (decoders/transformer.py:270-358, tf_utils.py:189-219) in one pass. */
+int nm_add_layer_norm_fwd(void* stream, const float* a, int64_t lda, const float* x, int64_t ldx,
+                          const float* gamma, const float* beta, float* sum_out, int64_t lds, float* y, int64_t ldy,
+                          int64_t rows, int64_t D, float eps);
 int nm_layer_norm_fwd(void* stream, const float* x, int64_t ldx, const float* gamma, const float* beta,
                       float* y, int64_t ldy, float* mean_out, float* rstd_out, int64_t rows, int64_t D,
                       float eps);

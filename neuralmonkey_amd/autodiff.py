@@ -123,14 +123,16 @@ class Tape:
 # functions (forward kernel now, gradient closure on the tape)
 # ------------------------------------------------------------------------------------------------
 def linear(tape: Tape, x: Var, w: Var, b: Optional[Var] = None, out: Optional[Var] = None,
-           accumulate: bool = False, trans_b: bool = False) -> Var:
-    """out (+)= x . op(w) + b   -- tf.layers.dense / tf.matmul on MFMA."""
+           accumulate: bool = False, trans_b: bool = False, act: Optional[str] = None) -> Var:
+    """out (+)= x . op(w) + b   -- tf.layers.dense / tf.matmul on MFMA.  ``act`` (inference tapes only): the
+    activation in the product's epilogue instead of a launch of its own."""
     n = w.shape[0] if trans_b else w.shape[1]
     if out is None:
         assert not accumulate
         out = tape.new((x.shape[0], n))
+    assert act is None or not tape.recording, "fused activations have no backward closure"
     ops.gemm(x.data, w.data, out=out.data, bias=None if b is None else b.data, accumulate=accumulate,
-             trans_b=trans_b)
+             trans_b=trans_b, act=act)
 
     def bwd():
         dy = out.grad
@@ -353,6 +355,17 @@ def layer_norm(tape: Tape, x: Var, gamma: Var, beta: Var, eps: float = 1e-6) -> 
             ops.colsum(out.grad.view(rows, d), beta.grad, accumulate=True)
     tape.record(bwd)
     return out
+
+
+def add_layer_norm(tape: Tape, a: Var, x: Var, gamma: Var, beta: Var, eps: float = 1e-6):
+    """(a + x, layer_norm(a + x)): a residual connection and the next sub-layer's pre-norm.  One launch on an
+    inference tape (nm_add_layer_norm_fwd); ``add`` + ``layer_norm`` when the tape records."""
+    if tape.recording or not (a.data.is_contiguous() and x.data.is_contiguous()):
+        total = add(tape, a, x)
+        return total, layer_norm(tape, total, gamma, beta, eps)
+    total, normed = tape.new(tuple(x.shape)), tape.new(tuple(x.shape))
+    ops.add_layer_norm_fwd(a.data, x.data, gamma.data, beta.data, total.data, normed.data, eps)
+    return total, normed
 
 
 def rnn_select(tape: Tape, h_new: Var, h_prev: Var, lengths: Optional[torch.Tensor], t: int,

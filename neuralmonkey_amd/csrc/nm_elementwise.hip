@@ -218,6 +218,52 @@ __global__ __launch_bounds__(256) void layer_norm_fwd_kernel(const float* __rest
     }
 }
 
+// s = a + x ; y = layer_norm(s): a residual connection and the pre-norm of the next sub-layer in one pass
+// (decoders/transformer.py:270-358: every sub-layer ends in `+ x` and the next one starts with layer_norm).  The
+// arithmetic is ew "add" followed by layer_norm_fwd_kernel's, element for element.
+__global__ __launch_bounds__(256) void add_layer_norm_fwd_kernel(const float* __restrict__ a, long lda,
+                                                                 const float* __restrict__ x, long ldx,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta,
+                                                                 float* __restrict__ sum_out, long lds,
+                                                                 float* __restrict__ y, long ldy, int D, float eps) {
+    __shared__ float sh[4];
+    extern __shared__ float srow[];               // [D] the summed row
+    const long row = blockIdx.x;
+    const float* ar = a + row * lda;
+    const float* xr = x + row * ldx;
+    float* sr = sum_out + row * lds;
+    float s = 0.0f;
+    for (int c = threadIdx.x; c < D; c += 256) {
+        const float v = ar[c] + xr[c];
+        srow[c] = v;
+        sr[c] = v;
+        s += v;
+    }
+    const float mean = block_sum_256(s, sh) / (float)D;
+    float q = 0.0f;
+    for (int c = threadIdx.x; c < D; c += 256) {
+        const float dlt = srow[c] - mean;
+        q += dlt * dlt;
+    }
+    const float var = block_sum_256(q, sh) / (float)D;
+    const float rstd = rsqrtf(var + eps);
+    float* yr = y + row * ldy;
+    for (int c = threadIdx.x; c < D; c += 256) yr[c] = (srow[c] - mean) * rstd * gamma[c] + beta[c];
+}
+
+extern "C" int nm_add_layer_norm_fwd(void* stream, const float* a, int64_t lda, const float* x, int64_t ldx,
+                                     const float* gamma, const float* beta, float* sum_out, int64_t lds, float* y,
+                                     int64_t ldy, int64_t rows, int64_t D, float eps) {
+    NM_REQUIRE(a && x && gamma && beta && sum_out && y, "nm_add_layer_norm_fwd: null pointer");
+    NM_REQUIRE(rows >= 0 && D > 0 && D <= 16384, "nm_add_layer_norm_fwd: bad shape rows=%ld D=%ld", (long)rows, (long)D);
+    if (rows == 0) return NM_OK;
+    hipLaunchKernelGGL(add_layer_norm_fwd_kernel, dim3((unsigned)rows), dim3(256), (size_t)D * sizeof(float),
+                       nm_stream(stream), a, (long)lda, x, (long)ldx, gamma, beta, sum_out, (long)lds, y, (long)ldy,
+                       (int)D, eps);
+    NM_LAUNCH_CHECK("nm_add_layer_norm_fwd");
+}
+
 extern "C" int nm_layer_norm_fwd(void* stream, const float* x, int64_t ldx, const float* gamma,
                                  const float* beta, float* y, int64_t ldy, float* mean_out,
                                  float* rstd_out, int64_t rows, int64_t D, float eps) {

@@ -494,6 +494,12 @@ class TransformerStepper:
         mask = self.mask[cur]
         ops.unfinished_mask(finished, mask[:, t])                               # :493-497
         x = tape.leaf(emb)
+        if len(self.enc_kv) == 1 and dec.attention_combination_strategy != "hierarchical" and \
+                os.environ.get("NM_STEP_FUSE_LN", "1") != "0":
+            self._step_fused(x, t, cur, mask, out_state)
+            dec.state_to_logits(self.ctx, out_state, logits)
+            self.t += 1
+            return att_states
         for l in range(dec.depth):
             pre = "layer_{}".format(l)
             scope = pre + "/self_attention"
@@ -542,6 +548,55 @@ class TransformerStepper:
         dec.state_to_logits(self.ctx, out_state, logits)
         self.t += 1
         return att_states
+
+    def _step_fused(self, x, t: int, cur: int, mask, out_state) -> None:
+        """The layers of one step for ONE encoder (decoders/transformer.py:270-358), with every residual connection
+        and the layer norm that follows it in one launch (``F.add_layer_norm``) and the feed-forward ReLU in its
+        product's epilogue: 24 launches of ~5 us fewer per step than the sub-layer-by-sub-layer formulation in
+        ``step``, element for element the same arithmetic."""
+        dec, tape, rows = self.dec, self.tape, self.rows
+        ln = lambda scope: (tape.param(dec, scope + "/LayerNorm/gamma"), tape.param(dec, scope + "/LayerNorm/beta"))
+        strategy = dec.attention_combination_strategy
+        per_layer, emask, bk, slen = self.enc_kv[0]
+        heads_enc = dec.n_heads_enc[0]
+        normed = TB.layer_norm(tape, dec, "layer_0/self_attention", x)
+        for l in range(dec.depth):
+            pre = "layer_{}".format(l)
+            scope = pre + "/self_attention"
+            q = TB.project(tape, dec, scope, "query_proj", normed, dec.n_heads_self, dec.use_att_transform_bias)
+            kc, vc = self.kcache[l][cur if len(self.kcache[l]) > 1 else 0], self.vcache[l][cur if len(self.vcache[l]) > 1 else 0]
+            if dec.n_heads_self > 1:
+                bias = lambda p: tape.param(dec, "{}/{}/bias".format(scope, p)) if dec.use_att_transform_bias else None
+                F.linear(tape, normed, tape.param(dec, scope + "/keys_proj/kernel"), bias("keys_proj"),
+                         out=tape.leaf(kc[:, t]))
+                F.linear(tape, normed, tape.param(dec, scope + "/vals_proj/kernel"), bias("vals_proj"),
+                         out=tape.leaf(vc[:, t]))
+            else:
+                ops.ew("copy", normed.data, None, kc[:, t])
+                ops.ew("copy", normed.data, None, vc[:, t])
+            att = F.sdp_attention(tape, q, None, None, mask[:, :t + 1], dec.n_heads_self, rows, 1, rows, t + 1,
+                                  False, 1.0, 0, k_data=kc[:, :t + 1], v_data=vc[:, :t + 1],
+                                  ancestors=self.anc[cur] if self.anc is not None else None)
+            att = TB.project(tape, dec, scope, "output_proj", att, dec.n_heads_self, dec.use_att_transform_bias)
+            top = pre + "/encdec_attention"
+            scope = top if strategy == "flat" else top + "/enc_0"
+            x, normed = F.add_layer_norm(tape, att, x, *ln(scope if strategy == "serial" else top))
+            q = TB.project(tape, dec, scope, "query_proj", normed, heads_enc, False)
+            ek, ev = per_layer[l]
+            att = F.sdp_attention(tape, q, None, None, emask, heads_enc, rows, 1, bk, slen, False, 1.0, 0,
+                                  k_data=ek, v_data=ev)
+            att = TB.project(tape, dec, scope, "output_proj", att, heads_enc, False)
+            scope = pre + "/feedforward"
+            x, normed = F.add_layer_norm(tape, att, x, *ln(scope))
+            hidden = F.linear(tape, normed, tape.param(dec, scope + "/hidden_state/kernel"),
+                              tape.param(dec, scope + "/hidden_state/bias"), act="relu")
+            out = F.linear(tape, hidden, tape.param(dec, scope + "/output/kernel"), tape.param(dec, scope + "/output/bias"))
+            if l + 1 < dec.depth:
+                x, normed = F.add_layer_norm(tape, out, x, *ln("layer_{}/self_attention".format(l + 1)))
+            else:
+                total = tape.new(tuple(x.shape))
+                ops.add_layer_norm_fwd(out.data, x.data, dec.var(self.ctx, "LayerNorm/gamma"),
+                                       dec.var(self.ctx, "LayerNorm/beta"), total.data, out_state)
 
     def reorder(self, src_rows: torch.Tensor) -> None:
         """Beam step: row r continues hypothesis ``src_rows[r]`` -- gather the cached prefix."""

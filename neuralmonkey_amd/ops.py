@@ -33,6 +33,19 @@ def _i32(t):
     return t
 
 
+def add_layer_norm_fwd(a, x, gamma, beta, sum_out, out, eps=1e-6):
+    """sum_out = a + x ; out = layer_norm(sum_out) over the last dimension (contiguous [rows, D] operands)."""
+    lib = _lib.load()
+    d = x.shape[-1]
+    rows = x.numel() // d
+    assert a.is_contiguous() and x.is_contiguous() and sum_out.is_contiguous() and out.is_contiguous()
+    assert a.numel() == x.numel() == sum_out.numel() == out.numel()
+    _lib.check(lib.nm_add_layer_norm_fwd(_stream(), a.data_ptr(), d, x.data_ptr(), d, gamma.data_ptr(),
+                                         beta.data_ptr(), sum_out.data_ptr(), d, out.data_ptr(), d, rows, d, float(eps)),
+               "nm_add_layer_norm_fwd")
+    return sum_out, out
+
+
 def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, bias=None, act=None,
          trans_a=False, trans_b=False, accumulate=False, algo=0):
     """out[M,N] = act(op(a) @ op(b) + bias (+ out)).  2-D (or batched 3-D with

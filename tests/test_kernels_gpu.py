@@ -177,6 +177,20 @@ def test_layer_norm(dev):
         assert rel_err(got.cpu().numpy(), ref) < 1e-5
 
 
+def test_add_layer_norm_is_add_then_layer_norm(dev):
+    """nm_add_layer_norm_fwd: the residual sum and its layer norm, bit for bit what the two separate launches give."""
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(11)
+    for rows, d in ((640, 512), (7, 14), (33, 1030)):
+        a = T(rng.standard_normal((rows, d)).astype(np.float32) * 2, dev)
+        x = T(rng.standard_normal((rows, d)).astype(np.float32) * 3 + 1, dev)
+        g, b = T(rng.standard_normal(d).astype(np.float32), dev), T(rng.standard_normal(d).astype(np.float32), dev)
+        want_sum = ops.ew("add", a, x, torch.empty_like(x))
+        want = ops.layer_norm_fwd(want_sum, g, b)
+        got_sum, got = ops.add_layer_norm_fwd(a, x, g, b, torch.empty_like(x), torch.empty_like(x))
+        assert torch.equal(got_sum, want_sum) and torch.equal(got, want)
+
+
 # --------------------------------------------------------------------------- #
 def _gru_params(rng, d_in, h, std=0.3):
     return {"gates_kernel": (rng.standard_normal((d_in + h, 2 * h)) * std).astype(np.float32),

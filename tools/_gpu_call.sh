@@ -1,9 +1,8 @@
 set -x
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-T=r03al
-timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "xent" > gpurun_out/${T}_tests.txt 2>&1
-echo "tests rc=$?"; tail -3 gpurun_out/${T}_tests.txt | cut -c1-400
-python tools/train_profile.py --steps 20 > gpurun_out/${T}_train.txt 2>&1
-NM_XENT_COLSUM=0 python tools/train_profile.py --steps 20 >> gpurun_out/${T}_train.txt 2>&1
-grep "train:" gpurun_out/${T}_train.txt
+T=r03am
+timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_transformer_gpu.py tests/test_transformer_fullsize_gpu.py tests/test_reference_inis_gpu.py -x -q -m gpu -k "layer_norm or transformer or Transformer or greedy or beam or ini" > gpurun_out/${T}_tests.txt 2>&1
+echo "tests rc=$?"; tail -4 gpurun_out/${T}_tests.txt | cut -c1-400
+python tools/transformer_bench.py --greedy-only --beam-5-only > gpurun_out/${T}_tb.txt 2>&1
+tail -2 gpurun_out/${T}_tb.txt
