@@ -1,8 +1,10 @@
 set -x
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-T=r03am
-timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_transformer_gpu.py tests/test_transformer_fullsize_gpu.py tests/test_reference_inis_gpu.py -x -q -m gpu -k "layer_norm or transformer or Transformer or greedy or beam or ini" > gpurun_out/${T}_tests.txt 2>&1
-echo "tests rc=$?"; tail -4 gpurun_out/${T}_tests.txt | cut -c1-400
-python tools/transformer_bench.py --greedy-only --beam-5-only > gpurun_out/${T}_tb.txt 2>&1
-tail -2 gpurun_out/${T}_tb.txt
+T=r03final
+timeout 1500 python -m pytest tests -q -m gpu > gpurun_out/${T}_tests.txt 2>&1
+echo "tests rc=$?"; tail -3 gpurun_out/${T}_tests.txt | cut -c1-300
+python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
+echo "bench rc=$?"
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/${T}_smoke.txt 2>&1
+tail -1 gpurun_out/${T}_smoke.txt
