@@ -45,8 +45,11 @@ class LazyLosses(dict):
     (runtime.HostPending): a dict that fills itself in on first access."""
 
     def __init__(self, names, pending) -> None:
-        super().__init__()
+        # The keys are there from the start (values NaN until read): C-level consumers of dict subclasses -- json's
+        # encoder -- look at the raw size first and take the mapping protocol, i.e. the methods below, only for a
+        # non-empty dict; anything that reads the raw storage directly sees NaN rather than nothing.
         self._names, self._pending = list(names), pending
+        super().__init__((name, float("nan")) for name in self._names)
 
     def _fill(self) -> None:
         pending, self._pending = self._pending, None

@@ -300,3 +300,50 @@ def test_ini_builds_the_plugin_surface(tmp_path):
     # section override from the command line (-s section.key=value)
     model2 = load_experiment(write_ini(tmp_path), changes=["beam_decoder.beam_size=2", "beam_runners.max_rank=1"])
     assert len(model2.runners) == 2
+
+
+def test_lazy_losses_fill_in_on_first_access():
+    """ExecutionResult.losses of a training step: a dict whose values are still on their way to the host."""
+    import json
+    import pickle
+
+    from neuralmonkey_amd.runners.base_runner import LazyLosses
+    from neuralmonkey_amd.runtime import HostPending
+
+    class Counting(HostPending):
+        reads = 0
+
+        def get(self):
+            Counting.reads += 1
+            return super().get()
+
+    make = lambda: LazyLosses(["decoder - cost", "L1", "L2"], Counting(value=np.array([1.5, 0.0, 2.5], np.float32)))
+    losses = make()
+    assert Counting.reads == 0                                  # nothing is read until somebody looks
+    assert losses["L2"] == 2.5 and Counting.reads == 1
+    assert list(losses) == ["decoder - cost", "L1", "L2"] and len(losses) == 3 and Counting.reads == 1
+    for view in (lambda d: sum(d.values()), lambda d: dict(d)["L1"], lambda d: json.loads(json.dumps(d))["L2"],
+                 lambda d: pickle.loads(pickle.dumps(d))["decoder - cost"], lambda d: d.get("L1", 7.0),
+                 lambda d: "{}".format(d), lambda d: d == {"decoder - cost": 1.5, "L1": 0.0, "L2": 2.5},
+                 lambda d: "L1" in d, lambda d: bool(d)):
+        assert view(make()) is not None
+    assert isinstance(make(), dict) and all(isinstance(v, float) for v in make().values())
+
+
+def test_variables_signature_follows_writes():
+    """What input tables and transposed step weights are cached under: torch-side writes to any variable view and
+    the explicit hook of raw-pointer writers both change it; reads do not."""
+    from neuralmonkey_amd.runtime import Session
+    from neuralmonkey_amd.variables import zeros_initializer
+    sess = Session("cpu", seed=1)
+    sess.store.declare("a/w", (4, 3), zeros_initializer())
+    sess.store.declare("a/b", (3,), zeros_initializer())
+    sess.store.finalize()
+    sig0 = sess.variables_signature()
+    float(sess.store["a/w"].sum())
+    assert sess.variables_signature() == sig0
+    sess.store["a/b"][1] = 2.0                                  # a test poking a row, a restored checkpoint
+    sig1 = sess.variables_signature()
+    assert sig1 != sig0
+    sess.variables_changed()                                    # optimizer kernels, collectives
+    assert sess.variables_signature() not in (sig0, sig1)
