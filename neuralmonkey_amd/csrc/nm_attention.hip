@@ -447,7 +447,10 @@ __global__ __launch_bounds__(256) void attn_partial_fast(AttnArgs p) {
 // two workgroups per sentence split by COLUMNS that exchange their partial energies as 8-byte {value, tag}
 // granules -- all 256 CUs busy, nothing merged afterwards, yet 21.9 / 17.3 us cold / warm against 20.6 / 16.6
 // here: the exchange waits in the consumer CU's memory queue behind its own streaming loads,
-// profiles/r02_attn_pair_vs_whole.txt.)
+// profiles/r02_attn_pair_vs_whole.txt.  Round 3, the same question split by POSITIONS: two 1024-thread workgroups
+// per sentence with half of the rows each, write-through partials, the half that arrives second merges -- 17.7 /
+// 14.9 us cold / warm against 17.2 / 13.7 for this kernel in the same run, greedy batch 5.92 vs 5.84 ms: the
+// hand-off costs more than the second set of CUs brings.)
 // ---------------------------------------------------------------------------
 #define ATT_WHOLE_ROWS 13
 template <int ROWS>
