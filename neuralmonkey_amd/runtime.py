@@ -160,16 +160,52 @@ class RunContext:
         return zlib.crc32("/".join(str(s) for s in site).encode()) & 0xFFFFFFFF
 
 
-def _to_host(val):
+_PINNED_FETCH: Dict[Any, list] = {}       # pinned staging buffers of _to_host, by (capacity in elements, dtype)
+
+
+def _map_tensors(val, fn):
     if isinstance(val, torch.Tensor):
-        return val.detach().cpu().numpy()
+        return fn(val)
     if isinstance(val, tuple) and hasattr(val, "_fields"):
-        return type(val)(*[_to_host(v) for v in val])
+        return type(val)(*[_map_tensors(v, fn) for v in val])
     if isinstance(val, (list, tuple)):
-        return type(val)(_to_host(v) for v in val)
+        return type(val)(_map_tensors(v, fn) for v in val)
     if isinstance(val, dict):
-        return {k: _to_host(v) for k, v in val.items()}
+        return {k: _map_tensors(v, fn) for k, v in val.items()}
     return val
+
+
+def _to_host(val):
+    """Fetched tensors -> NumPy arrays.  All device tensors of a fetch structure (a beam search returns seven) are
+    copied into pinned staging buffers asynchronously and the stream is waited for ONCE, instead of one blocking
+    pageable copy per tensor (~35 us each)."""
+    devs = []
+    _map_tensors(val, lambda t: devs.append(t) if t.is_cuda else None)
+    if not devs:
+        return _map_tensors(val, lambda t: t.detach().cpu().numpy())
+    staged = {}
+    for t in devs:
+        if id(t) in staged or t.numel() == 0:
+            continue
+        cap = 1 << max(8, (t.numel() - 1).bit_length())          # few distinct buffers for the varying decode lengths
+        pool = _PINNED_FETCH.setdefault((cap, t.dtype), [])
+        host = pool.pop() if pool else torch.empty(cap, dtype=t.dtype).pin_memory()
+        flat = host[:t.numel()]
+        flat.copy_(t.detach().reshape(-1), non_blocking=True)
+        staged[id(t)] = (host, flat, (cap, t.dtype))
+    for device in {t.device for t in devs}:
+        torch.cuda.current_stream(device).synchronize()
+
+    def fetch(t):
+        if not t.is_cuda:
+            return t.detach().cpu().numpy()
+        if t.numel() == 0:
+            return np.empty(tuple(t.shape), dtype=torch.empty(0, dtype=t.dtype).numpy().dtype)
+        return staged[id(t)][1].numpy().reshape(tuple(t.shape)).copy()
+    out = _map_tensors(val, fetch)
+    for host, _, key in staged.values():
+        _PINNED_FETCH[key].append(host)
+    return out
 
 
 class HostPending:
