@@ -40,6 +40,17 @@ MP = TypeVar("MP", bound=GenericModelPart)
 OutputSeries = Union[List, np.ndarray]
 
 
+def _after_fill(name):
+    """A dict method that first makes sure the values have arrived."""
+    plain = getattr(dict, name)
+
+    def method(self, *args, **kwargs):
+        self._fill()          # pylint: disable=protected-access
+        return plain(self, *args, **kwargs)
+    method.__name__ = name
+    return method
+
+
 class LazyLosses(dict):
     """``ExecutionResult.losses`` of a training step whose scalars are still being copied to the host
     (runtime.HostPending): a dict that fills itself in on first access."""
@@ -56,17 +67,22 @@ class LazyLosses(dict):
         if pending is not None:
             dict.update(self, zip(self._names, [float(x) for x in pending.get()]))
 
-    def _filled(name):      # pylint: disable=no-self-argument
-        def method(self, *args, **kwargs):
-            self._fill()
-            return getattr(dict, name)(self, *args, **kwargs)     # pylint: disable=protected-access
-        method.__name__ = name
-        return method
-
-    for _name in ("__getitem__", "__iter__", "__len__", "__contains__", "__repr__", "__eq__", "__ne__", "keys",
-                  "values", "items", "get", "copy", "__reversed__", "__or__", "__ror__"):
-        locals()[_name] = _filled(_name)
-    del _name, _filled
+    __getitem__ = _after_fill("__getitem__")
+    __iter__ = _after_fill("__iter__")
+    __len__ = _after_fill("__len__")
+    __contains__ = _after_fill("__contains__")
+    __repr__ = _after_fill("__repr__")
+    __eq__ = _after_fill("__eq__")
+    __ne__ = _after_fill("__ne__")
+    __reversed__ = _after_fill("__reversed__")
+    __or__ = _after_fill("__or__")
+    __ror__ = _after_fill("__ror__")
+    keys = _after_fill("keys")
+    values = _after_fill("values")
+    items = _after_fill("items")
+    get = _after_fill("get")
+    copy = _after_fill("copy")
+    __hash__ = None
 
     def __reduce__(self):
         self._fill()
