@@ -170,7 +170,8 @@ class GeneralModel:
         if proj_dim:
             scopes.append(("conv2d_1" if scopes else "conv2d", False))
         for scope, use_relu in scopes:
-            x = x @ p["{}/{}/kernel".format(name, scope)] + p["{}/{}/bias".format(name, scope)]
+            kernel = p["{}/{}/kernel".format(name, scope)]         # tf.layers.conv2d: [1, 1, in, out]
+            x = x @ kernel.reshape(kernel.shape[-2], kernel.shape[-1]) + p["{}/{}/bias".format(name, scope)]
             if use_relu:
                 x = torch.relu(x)
         return x, torch.ones(bsz, h * w, dtype=self.dtype), x.mean(1)

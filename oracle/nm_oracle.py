@@ -411,30 +411,18 @@ def length_penalty(lengths, alpha, dt):
             ** np.asarray(alpha, dt)).astype(dt)
 
 
-def beam_search(params, spec: DecoderSpec, enc: EncoderOutput, beam_size: int,
-                max_steps: int, length_normalization: float, tie_margin: Optional[float] = None) -> BeamResult:
-    """BeamSearchDecoder over the RNN Decoder.
+def beam_search_core(first_logits, step_fn, bsz: int, beam_size: int, max_steps: int, length_normalization: float,
+                     tie_margin: Optional[float] = None) -> BeamResult:
+    """BeamSearchDecoder around ANY parent decoder (beam_search_decoder.py:218-556).
 
-    The reference tiles the parent loop state to B*k rows (expand_to_beam
-    :575-596, row order b*k+j) but not the Bahdanau tensors, so it only runs
-    at batch 1 through broadcasting (SURVEY 3.3).  Tiling the keys is the same
-    arithmetic as that broadcast; we tile them here so any batch works and
-    batch 1 is bit-identical to the broadcast.
+    ``first_logits`` [B*k, V]: the parent step that ``get_initial_loop_state`` runs on the tiled rows (:255-300).
+    ``step_fn(src_rows [B*k], words [B*k]) -> logits [B*k, V]``: reorder the parent's per-row state by ``src_rows``
+    (gather_flat, :503-532), feed ``words`` and run one parent body (:534-535).
     """
-    dp = _dec_params(params, spec)
-    dt = enc.output.dtype
-    bsz, k = enc.output.shape[0], beam_size
-    vsz = dp["logit_w"].shape[1]
-    rows = bsz * k
-    rep = lambda a: np.repeat(a, k, axis=0)
-    states, mask = rep(enc.temporal_states), rep(enc.temporal_mask)
-    hf = attention_keys(states, dp["key_w"])
-
-    # --- get_initial_loop_state (:218-328): one parent step on tiled rows
-    prev = rep(decoder_initial_state(enc.output, dp))
-    emb_in = dp["emb"][np.full(rows, START)]
-    out, prev, _, _ = decoder_step(dp, spec, emb_in, prev, hf, states, mask)
-    logits = state_to_logits(dp, spec, out)
+    k = beam_size
+    dt = first_logits.dtype
+    vsz = first_logits.shape[1]
+    logits = first_logits
     first_sym = logits.argmax(1)                     # parent greedy symbol, stored as token_ids[0]
     logprob_sum = np.tile(np.array([0.0] + [-INF] * (k - 1), dtype=dt), (bsz, 1))
     prev_logprobs = log_softmax(logits).reshape(bsz, k, vsz)
@@ -481,10 +469,7 @@ def beam_search(params, spec: DecoderSpec, enc: EncoderOutput, beam_size: int,
         logprob_sum = hyp.reshape(bsz, k * vsz)[bidx, top_idx]                # :493-496 (unnormalised)
         finished = finished[bidx, beam] | (word == END)                       # :499-501
         flat_src = (bidx * k + beam).reshape(-1)
-        prev = prev[flat_src]                                                 # :503-532 gather_flat
-        emb_in = dp["emb"][word.reshape(-1)]                                  # :507-510
-        out, prev, _, _ = decoder_step(dp, spec, emb_in, prev, hf, states, mask)  # :534-535
-        logits = state_to_logits(dp, spec, out)
+        logits = step_fn(flat_src, word.reshape(-1))                          # :503-535
         prev_logprobs = log_softmax(logits).reshape(bsz, k, vsz)              # :537-543
         token_ids = np.concatenate(
             [token_ids[:, bidx, beam], word[None]], axis=0)                   # :546-551
@@ -497,6 +482,38 @@ def beam_search(params, spec: DecoderSpec, enc: EncoderOutput, beam_size: int,
                       np.stack(beam_hist) if beam_hist else z,
                       np.stack(word_hist) if word_hist else z,
                       np.stack(gap_hist) if gap_hist else np.zeros((0, bsz)), tie_sets)
+
+
+def beam_search(params, spec: DecoderSpec, enc: EncoderOutput, beam_size: int,
+                max_steps: int, length_normalization: float, tie_margin: Optional[float] = None) -> BeamResult:
+    """BeamSearchDecoder over the RNN Decoder.
+
+    The reference tiles the parent loop state to B*k rows (expand_to_beam
+    :575-596, row order b*k+j) but not the Bahdanau tensors, so it only runs
+    at batch 1 through broadcasting (SURVEY 3.3).  Tiling the keys is the same
+    arithmetic as that broadcast; we tile them here so any batch works and
+    batch 1 is bit-identical to the broadcast.
+    """
+    dp = _dec_params(params, spec)
+    bsz, k = enc.output.shape[0], beam_size
+    rows = bsz * k
+    rep = lambda a: np.repeat(a, k, axis=0)
+    states, mask = rep(enc.temporal_states), rep(enc.temporal_mask)
+    hf = attention_keys(states, dp["key_w"])
+
+    # --- get_initial_loop_state (:218-328): one parent step on tiled rows
+    carried = {"prev": rep(decoder_initial_state(enc.output, dp))}
+    emb_in = dp["emb"][np.full(rows, START)]
+    out, carried["prev"], _, _ = decoder_step(dp, spec, emb_in, carried["prev"], hf, states, mask)
+
+    def step_fn(flat_src, words):
+        prev = carried["prev"][flat_src]                                      # :503-532 gather_flat
+        emb = dp["emb"][words]                                                # :507-510
+        o, carried["prev"], _, _ = decoder_step(dp, spec, emb, prev, hf, states, mask)   # :534-535
+        return state_to_logits(dp, spec, o)
+
+    return beam_search_core(state_to_logits(dp, spec, out), step_fn, bsz, k, max_steps, length_normalization,
+                            tie_margin)
 
 
 def beam_tokens(res: BeamResult, rank: int = 1) -> Tuple[List[List[int]], float]:

@@ -36,6 +36,8 @@ class TConfig(NamedTuple):
     extra_encoders: Tuple[str, ...] = ()      # names of further encoders (same hyper-parameters) the decoder attends to
     strategy: str = "serial"                  # attention_combination_strategy: serial | parallel | flat | hierarchical
     n_heads_hier: int = 1
+    shared_embeddings: bool = False           # decoder(embeddings_source=<the encoder's input sequence>): one matrix
+    scale_embeddings: bool = False            # EmbeddedSequence(scale_embeddings_by_depth=True), model/sequence.py:185-187
 
 
 def position_signal(dimension: int, length: int) -> torch.Tensor:
@@ -49,6 +51,18 @@ def position_signal(dimension: int, length: int) -> torch.Tensor:
     if dimension % 2:
         signal = torch.nn.functional.pad(signal, (0, 1))
     return signal
+
+
+def mask_future(e: torch.Tensor, mask_value: float = -1e9) -> torch.Tensor:
+    """scaled_dot_product.py:72-93: keep the lower triangle (key <= query), the rest becomes ``mask_value``."""
+    tril = torch.tril(torch.ones_like(e))
+    return torch.where(tril == 1, e, torch.full_like(e, mask_value))
+
+
+def mask_energies(e: torch.Tensor, keys_mask: torch.Tensor, mask_value: float = -1e9) -> torch.Tensor:
+    """scaled_dot_product.py:45-69: ``e * m + (1 - m) * mask_value`` with the key mask broadcast over heads and queries."""
+    m4 = keys_mask[:, None, None, :]
+    return e * m4 + (1.0 - m4) * mask_value
 
 
 class TransformerModel:
@@ -69,7 +83,8 @@ class TransformerModel:
         var = ((x - mean) ** 2).mean(-1, keepdim=True)
         return (x - mean) * torch.rsqrt(var + 1e-6) * g + b
 
-    def attention(self, scope, queries, keys, keys_mask, heads, masked, att_keep, train, use_bias, site):
+    def attention(self, scope, queries, keys, keys_mask, heads, masked, att_keep, train, use_bias, site,
+                  return_weights=False):
         """scaled_dot_product.py:98-226 with values == keys."""
         p = self.p
         dim = queries.shape[-1]
@@ -88,18 +103,24 @@ class TransformerModel:
             return x.view(b, t, heads, dh).permute(0, 2, 1, 3)
         q, k, v = split(q), split(k), split(v)
         e = q @ k.transpose(-1, -2)                                             # [B,H,Tq,Tk]
-        if masked:                                                              # mask_future :72-93
-            tril = torch.tril(torch.ones_like(e))
-            e = torch.where(tril == 1, e, torch.full_like(e, -1e9))
-        if keys_mask is not None:                                               # mask_energies :45-69
-            m4 = keys_mask[:, None, None, :]
-            e = e * m4 + (1.0 - m4) * -1e9
+        if masked:                                                              # mask_future BEFORE the key mask
+            e = mask_future(e)
+        if keys_mask is not None:
+            e = mask_energies(e, keys_mask)
         w = torch.softmax(e, -1)
         w = self.dropout(w, att_keep, train, *site)
         ctx = (w @ v).permute(0, 2, 1, 3).reshape(queries.shape[0], queries.shape[1], dim)
         if heads > 1:
             ctx = dense(ctx, "output_proj")
-        return ctx
+        return (ctx, w) if return_weights else ctx
+
+    def target_embeddings(self):
+        """autoregressive.py:253-267: the decoder's own ``word_embeddings`` or, with ``embeddings_source``, the
+        source sequence's matrix (decoder inputs are NOT scaled by sqrt(E): the loop embeds through the base
+        ``embed_input_symbols``, :269-272)."""
+        if self.cfg.shared_embeddings:
+            return self.p[self.cfg.enc_name + "_input/embedding_matrix_0"]
+        return self.p[self.cfg.dec_name + "/word_embeddings"]
 
     def feedforward(self, scope, x, keep, train, site):
         p = self.p
@@ -125,7 +146,10 @@ class TransformerModel:
         cfg, p, name = self.cfg, self.p, name or self.cfg.enc_name
         ids = torch.as_tensor(src_ids.astype(np.int64))
         mask = (ids != PAD).to(self.dtype)
-        x = p[name + "_input/embedding_matrix_0"][ids] * mask.unsqueeze(-1)
+        x = p[name + "_input/embedding_matrix_0"][ids]
+        if cfg.scale_embeddings:                   # model/sequence.py:185-187: scaled before the mask is applied
+            x = x * (x.shape[-1] ** 0.5)
+        x = x * mask.unsqueeze(-1)
         if cfg.target_space_id is not None:        # encoders/transformer.py:175-203: one row of a [32, D] table
             x = x + p[name + "/target_modality_embedding_matrix"][cfg.target_space_id].reshape(1, 1, -1)
         if cfg.use_positional_encoding:
@@ -187,7 +211,7 @@ class TransformerModel:
     def logits(self, states):
         cfg, p = self.cfg, self.p
         if cfg.tie_embeddings:
-            lg = states @ p[cfg.dec_name + "/word_embeddings"].t()
+            lg = states @ self.target_embeddings().t()
         else:
             lg = states @ p[cfg.dec_name + "/state_to_word_W"] + p[cfg.dec_name + "/state_to_word_b"]
         if cfg.supress_unk:
@@ -202,7 +226,7 @@ class TransformerModel:
         enc_states, enc_mask = self.encode_all(src_ids, train)
         bsz, steps = tgt_bt.shape
         dec_in = np.concatenate([np.full((bsz, 1), START, tgt_bt.dtype), tgt_bt[:, :-1]], 1)
-        emb = p[cfg.dec_name + "/word_embeddings"][torch.as_tensor(dec_in.astype(np.int64))]
+        emb = self.target_embeddings()[torch.as_tensor(dec_in.astype(np.int64))]
         emb = self.dropout(emb, cfg.dec_dropout, train, cfg.dec_name, "embedded_input")
         tgt = torch.as_tensor(tgt_bt.astype(np.int64))
         tmask = (tgt != PAD).to(self.dtype)
@@ -224,7 +248,7 @@ class TransformerModel:
 
     def greedy(self, src_ids, max_len: int):
         with torch.no_grad():
-            table = self.p[self.cfg.dec_name + "/word_embeddings"]
+            table = self.target_embeddings()
             enc_states, enc_mask = self.encode_all(src_ids, False)
             rows = enc_states[0].shape[0]
             emb = table[torch.full((rows,), START)]
@@ -250,7 +274,7 @@ class TransformerModel:
         """decoders/beam_search_decoder.py:218-556 around the Transformer parent."""
         with torch.no_grad():
             dt = self.dtype
-            table = self.p[self.cfg.dec_name + "/word_embeddings"]
+            table = self.target_embeddings()
             enc_states, enc_mask = self.encode_all(src_ids, False)
             bsz = enc_states[0].shape[0]
             enc_states = [e.repeat_interleave(k, 0) for e in enc_states]

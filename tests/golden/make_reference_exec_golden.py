@@ -1,0 +1,622 @@
+"""Generate ``tests/golden/ref_exec/*.npz``: numbers produced by the REFERENCE'S OWN Python.
+
+Runs only in the build container (needs ``/root/reference``; nothing at test time does).  It installs the NumPy-eager
+TensorFlow stand-in (``tests/ref_exec/tf_eager.py``) as ``sys.modules["tensorflow"]``, imports the model parts from
+``/root/reference/neuralmonkey`` UNMODIFIED and runs them -- constructors, ``feed_dict``, the lazy ``@tensor``
+properties, the ``tf.while_loop`` bodies of ``AutoregressiveDecoder`` / ``BeamSearchDecoder``, ``BeamSearchRunner``'s
+executable -- on seeded inputs.  What TensorFlow itself would compute inside its ops (GRUCell, LSTMCell, dynamic_rnn,
+dense, softmax, top_k, sequence_loss) is the stand-in's restatement; every line between those ops is the reference's.
+
+A fixture holds: ``cfg`` (JSON: how the model was built), ``p/<variable name>`` (every variable the reference created,
+under the name TensorFlow's scoping rules give it, in creation order in ``var_order``), ``in/*`` (token strings and
+what ``Vocabulary.strings_to_indices`` made of them), ``out/*`` (what the reference computed).
+
+    python tests/golden/make_reference_exec_golden.py            # all cases
+    python tests/golden/make_reference_exec_golden.py rnn_gru    # one case
+
+``tests/test_reference_exec.py`` asserts that ``oracle/`` reproduces every fixture; ``tests/test_reference_exec_gpu.py``
+runs the engine on the same strings and variables.
+"""
+import collections
+import collections.abc
+import json
+import os
+import sys
+import zlib
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+OUT = os.path.join(HERE, "ref_exec")
+REFERENCE = "/root/reference"
+
+sys.dont_write_bytecode = True                      # /root/reference is read-only
+collections.Sized = collections.abc.Sized           # the reference targets Python <= 3.7 (vocabulary.py:175)
+sys.path.insert(0, REPO)
+from tests.ref_exec import tf_eager                 # noqa: E402
+
+tf = tf_eager.install()
+sys.path.insert(0, REFERENCE)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# variables: values are a function of the variable's NAME (the oracle / the engine receive the same arrays by name)
+# ----------------------------------------------------------------------------------------------------------------
+SCALE = {"default": 0.35}
+
+
+def variable_factory(name, shape, np_dtype, initializer):
+    if np.dtype(np_dtype).kind != "f":
+        return np.zeros(shape, np_dtype)
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    scale = SCALE["default"]
+    if name.endswith("gamma"):                           # layer-norm gains around one
+        return (1.0 + rng.normal(0, 0.2, shape)).astype(np_dtype)
+    if "word_embeddings" in name or "embedding_matrix" in name:
+        scale = 0.6
+    if name.endswith("state_to_word_W"):
+        scale = 0.9
+    return rng.normal(0, scale, shape).astype(np_dtype)
+
+
+tf_eager.VARIABLE_FACTORY = variable_factory
+
+
+def fresh_graph():
+    tf_eager.reset_default_graph()
+
+
+def joined(sentence):
+    """A decoded sentence as one string.  NB ``BeamSearchRunner.prepare_results`` (beamsearch_runner.py:88-99) assigns
+    ``decoded_tokens[i] = decoded`` INSIDE its token loop, after the ``break`` on ``</s>``: a hypothesis whose first
+    token is ``</s>`` keeps its raw id array instead of becoming ``[]``; such entries come out as digits here."""
+    return " ".join(str(t) for t in sentence)
+
+
+def to_numpy(struct):
+    return tf_eager.nest.map_structure(
+        lambda t: t.numpy() if isinstance(t, tf_eager.Tensor) else t, struct)
+
+
+def variables():
+    order = [n for n, _ in tf_eager.CREATION_LOG]
+    return order, {n: tf_eager._STORE.vars[n].numpy().copy() for n in order}
+
+
+def save(case, cfg, arrays):
+    os.makedirs(OUT, exist_ok=True)
+    order, params = variables()
+    blob = {"cfg": np.asarray(json.dumps(cfg, sort_keys=True)), "var_order": np.asarray(order)}
+    for n, v in params.items():
+        blob["p/" + n] = v
+    for k, v in arrays.items():
+        v = np.asarray(v)
+        if v.dtype == object:
+            v = v.astype(str)
+        blob[k] = v
+    path = os.path.join(OUT, case + ".npz")
+    np.savez_compressed(path, **blob)
+    print("{:28s} {:4d} variables {:4d} arrays {:8d} bytes".format(
+        case, len(order), len(arrays), os.path.getsize(path)))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# data
+# ----------------------------------------------------------------------------------------------------------------
+def make_vocab(n):
+    from neuralmonkey.vocabulary import Vocabulary
+    return Vocabulary(["w{}".format(i) for i in range(n)])
+
+
+def sentences(rng, count, vocab_words, min_len, max_len, oov_every=0):
+    out = []
+    for i in range(count):
+        n = int(rng.integers(min_len, max_len + 1))
+        sent = ["w{}".format(int(rng.integers(0, vocab_words))) for _ in range(n)]
+        if oov_every and n and i % oov_every == 0:
+            sent[int(rng.integers(0, n))] = "never-seen"
+        out.append(sent)
+    return out
+
+
+def dataset(series):
+    from neuralmonkey.dataset import Dataset
+    return Dataset("fixture", {k: (lambda v=v: iter(v)) for k, v in series.items()}, batching=None)
+
+
+def feed(parts, ds, train, inputs):
+    for p in parts:
+        p.register_input(inputs)
+    fd = {}
+    for p in parts:
+        fd.update(p.feed_dict(ds, train=train))
+    return fd
+
+
+def string_inputs(*names):
+    return {n: tf.placeholder(tf.string, [None, None], n) for n in names}
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# RNN encoder-decoder family
+# ----------------------------------------------------------------------------------------------------------------
+RNN_DEFAULT = dict(
+    src_vocab=17, tgt_vocab=13, emb=6, enc_layers=[[5, "bidirectional", "GRU"]], sentence_encoder=True,
+    add_layer_norm=False, add_residual=False, enc_keep=1.0, att_keep=1.0, att_state=None,
+    dec_cell="GRU", rnn_size=6, conditional_gru=False, attention_on_input=False, dec_keep=1.0,
+    output_projection=["nonlinear", "tanh"], encoder_projection="linear", tie_embeddings=False, supress_unk=False,
+    max_output_len=7, max_input_len=None, beam=[3, 6, 0.6], seed=1, batch=5, spatial=None)
+
+
+def build_rnn(cfg):
+    from neuralmonkey.encoders.recurrent import SentenceEncoder, RecurrentEncoder
+    from neuralmonkey.model.sequence import EmbeddedSequence
+    from neuralmonkey.attention.feed_forward import Attention
+    from neuralmonkey.decoders.decoder import Decoder
+    from neuralmonkey.decoders import output_projection as OP
+    from neuralmonkey.decoders import encoder_projection as EP
+    sv, tv = make_vocab(cfg["src_vocab"]), make_vocab(cfg["tgt_vocab"])
+    parts = []
+    if cfg["spatial"] is not None:
+        from neuralmonkey.encoders.numpy_stateful_filler import SpatialFiller
+        h, w, c, ff_dim, proj_dim = cfg["spatial"]
+        enc = SpatialFiller(name="encoder", input_shape=[h, w, c], data_id="maps",
+                            projection_dim=proj_dim, ff_hidden_dim=ff_dim)
+        parts.append(enc)
+    elif cfg["sentence_encoder"]:
+        size, direction, cell = cfg["enc_layers"][0]
+        enc = SentenceEncoder(name="encoder", vocabulary=sv, data_id="source", embedding_size=cfg["emb"],
+                              rnn_size=size, rnn_cell=cell, rnn_direction=direction,
+                              add_residual=cfg["add_residual"], add_layer_norm=cfg["add_layer_norm"],
+                              max_input_len=cfg["max_input_len"], dropout_keep_prob=cfg["enc_keep"])
+        parts += [enc, enc.input_sequence]
+    else:
+        seq = EmbeddedSequence(name="encoder_input", vocabulary=sv, data_id="source", embedding_size=cfg["emb"],
+                               max_length=cfg["max_input_len"])
+        enc = RecurrentEncoder(name="encoder", input_sequence=seq,
+                               rnn_layers=[tuple(layer) for layer in cfg["enc_layers"]],
+                               add_residual=cfg["add_residual"], add_layer_norm=cfg["add_layer_norm"],
+                               dropout_keep_prob=cfg["enc_keep"])
+        parts += [enc, seq]
+    att = Attention(name="attention", encoder=enc, dropout_keep_prob=cfg["att_keep"], state_size=cfg["att_state"])
+    kind = cfg["output_projection"][0]
+    act = {"tanh": tf.tanh, "relu": tf.nn.relu}
+    if kind == "nonlinear":
+        op = OP.nonlinear_output(cfg["rnn_size"], act[cfg["output_projection"][1]], cfg["dec_keep"])
+    elif kind == "nematus":
+        op = OP.nematus_output(cfg["rnn_size"], act[cfg["output_projection"][1]], cfg["dec_keep"])
+    elif kind == "maxout":
+        op = OP.maxout_output(cfg["rnn_size"], cfg["dec_keep"])
+    elif kind == "mlp":
+        op = OP.mlp_output(list(cfg["output_projection"][1]), act[cfg["output_projection"][2]], cfg["dec_keep"])
+    elif kind == "default":
+        op = None
+    else:
+        raise ValueError(kind)
+    ep = {"linear": None, "nematus": EP.nematus_projection(cfg["dec_keep"]),
+          "concat": None, "empty": EP.empty_initial_state}[cfg["encoder_projection"]]
+    dec = Decoder(encoders=[enc], vocabulary=tv, data_id="target", name="decoder",
+                  max_output_len=cfg["max_output_len"], dropout_keep_prob=cfg["dec_keep"],
+                  embedding_size=cfg["rnn_size"], rnn_size=None if cfg["encoder_projection"] == "concat" else cfg["rnn_size"],
+                  output_projection=op, encoder_projection=ep, attentions=[att],
+                  attention_on_input=cfg["attention_on_input"], rnn_cell=cfg["dec_cell"],
+                  conditional_gru=cfg["conditional_gru"], tie_embeddings=cfg["tie_embeddings"],
+                  supress_unk=cfg["supress_unk"])
+    parts += [att, dec]
+    return enc, att, dec, parts
+
+
+def rnn_series(cfg):
+    rng = np.random.default_rng(cfg["seed"])
+    bsz = cfg["batch"]
+    tgt = sentences(rng, bsz, cfg["tgt_vocab"], 1, cfg["max_output_len"] + 2, oov_every=3)
+    if cfg["spatial"] is not None:
+        h, w, c = cfg["spatial"][:3]
+        maps = np.maximum(rng.normal(0, 1, (bsz, h, w, c)), 0).astype(np.float32)
+        return {"maps": list(maps), "target": tgt}
+    src = sentences(rng, bsz, cfg["src_vocab"], 2, 7, oov_every=2)
+    src[-1] = src[-1][:1]                                        # a one-word sentence
+    if bsz > 2:
+        src[1] = (src[1] * 7)[:7]                                 # the longest one
+    return {"source": src, "target": tgt}
+
+
+def run_rnn(case, **overrides):
+    cfg = dict(RNN_DEFAULT, **overrides)
+    series = rnn_series(cfg)
+    out = {}
+    src_key = "maps" if cfg["spatial"] is not None else "source"
+
+    # -- teacher-forced pass and greedy decoding on the whole batch ------------------------------------------------
+    fresh_graph()
+    enc, att, dec, parts = build_rnn(cfg)
+    inputs = string_inputs("source", "target")
+    if cfg["spatial"] is not None:
+        inputs["maps"] = tf.placeholder(tf.float32, [None] + list(cfg["spatial"][:3]), "maps")
+    ds = dataset(series)
+    fd = feed(parts, ds, False, inputs)
+    with tf_eager.feeding(fd):
+        if cfg["spatial"] is None:
+            out["in/src_tokens"] = enc.input_sequence.input_factors[0].numpy()
+            out["in/src_ids"] = enc.input_sequence.inputs.numpy()
+            out["out/enc_input"] = enc.input_sequence.temporal_states.numpy()
+            out["out/enc_states"] = enc.temporal_states.numpy()
+            out["out/enc_mask"] = enc.temporal_mask.numpy()
+        else:
+            out["in/maps"] = np.stack(series["maps"])
+            out["out/enc_states"] = enc.spatial_states.numpy()
+            out["out/att_states"] = att.attention_states.numpy()
+        out["out/enc_output"] = enc.output.numpy()
+        out["in/tgt_tokens"] = dec.train_tokens.numpy()
+        out["in/tgt_ids"] = dec.train_inputs.numpy()                     # time-major [T,B]
+        out["out/train_mask"] = dec.train_mask.numpy()
+        out["out/hidden_features"] = att.hidden_features.numpy()
+        out["out/initial_state"] = dec.initial_state.numpy()
+        out["out/train_logits"] = dec.train_logits.numpy()
+        out["out/train_output_states"] = dec.train_output_states.numpy()
+        out["out/train_xents"] = dec.train_xents.numpy()
+        out["out/train_loss"] = dec.train_loss.numpy()
+        tr = dec.train_loop_result
+        out["out/train_rnn_outputs"] = tr.histories.other.rnn_outputs.numpy()
+        out["out/train_att_weights"] = att.histories["decoder_train"].numpy()
+        out["out/train_contexts"] = tr.histories.other.attention_histories[0].contexts.numpy()
+        rr = dec.runtime_loop_result
+        out["out/runtime_logits"] = dec.runtime_logits.numpy()
+        out["out/runtime_symbols"] = rr.histories.output_symbols.numpy()
+        out["out/runtime_mask"] = dec.runtime_mask.numpy()
+        out["out/runtime_steps"] = rr.feedables.step.numpy()
+        out["out/runtime_finished"] = rr.feedables.finished.numpy()
+        out["out/runtime_att_weights"] = att.histories["decoder_run"].numpy()
+        out["out/runtime_xents"] = dec.runtime_xents.numpy()
+        out["out/runtime_loss"] = dec.runtime_loss.numpy()
+        out["out/runtime_logprobs"] = dec.runtime_logprobs.numpy()
+        out["out/decoded"] = dec.decoded.numpy()
+        # GreedyRunner's post-processing (runners/runner.py:35-63 -> vocabulary.py:257-288)
+        amax = np.argmax(out["out/runtime_logprobs"], axis=2)
+        sents = dec.vocabulary.vectors_to_sentences(amax)
+        out["out/greedy_sentences"] = np.asarray([" ".join(s) for s in sents])
+    order_full, _ = variables()
+
+    # -- beam search, one sentence at a time (the reference does not tile Bahdanau keys: batch 1 only) ---------------
+    k, max_steps, alpha = cfg["beam"]
+    from neuralmonkey.decoders.beam_search_decoder import BeamSearchDecoder
+    from neuralmonkey.runners.beamsearch_runner import BeamSearchRunner
+    for i in range(cfg["batch"]):
+        fresh_graph()
+        enc, att, dec, parts = build_rnn(cfg)
+        bs = BeamSearchDecoder(name="beam", parent_decoder=dec, beam_size=k, max_steps=max_steps,
+                               length_normalization=alpha)
+        runner = BeamSearchRunner(output_series="hyp", decoder=bs, rank=1)
+        one = {name: [vals[i]] for name, vals in series.items()}
+        fd = feed(parts + [bs], dataset(one), False, inputs)
+        with tf_eager.feeding(fd):
+            ex = runner.get_executable(compute_losses=False, summaries=False, num_sessions=1)
+            fetches, _ = ex.next_to_execute()
+            res = to_numpy(fetches)
+            ex.collect_results([res])
+            bo = res["bs_outputs"]
+            pre = "out/beam{}_".format(i)
+            out[pre + "scores"] = bo.last_search_step_output.scores
+            out[pre + "token_ids"] = bo.last_search_step_output.token_ids
+            out[pre + "logprob_sum"] = bo.last_search_state.logprob_sum
+            out[pre + "lengths"] = bo.last_search_state.lengths
+            out[pre + "finished"] = bo.last_search_state.finished
+            out[pre + "prev_logprobs"] = bo.last_search_state.prev_logprobs
+            out[pre + "dec_step"] = bo.last_dec_loop_state.feedables.step
+            out[pre + "sentence"] = np.asarray(joined(ex.result.outputs["hyp"][0]))
+            out[pre + "loss"] = np.asarray(ex.result.losses["hyp/beam_search_score"])
+        order_beam, _ = variables()
+        missing = [n for n in order_beam if n not in order_full]
+        assert not missing, missing
+    # leave the store holding the full-batch graph's variables for save()
+    fresh_graph()
+    enc, att, dec, parts = build_rnn(cfg)
+    with tf_eager.feeding(feed(parts, ds, False, inputs)):
+        dec.train_loss.numpy()
+        dec.runtime_logits.numpy()
+    save(case, cfg, out)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Transformer (rows a19-a21)
+# ----------------------------------------------------------------------------------------------------------------
+TR_DEFAULT = dict(src_vocab=19, tgt_vocab=19, dim=8, ff=12, depth=2, heads=2, heads_self=2, heads_enc=2,
+                  max_output_len=7, tie_embeddings=True, use_att_transform_bias=False, target_space_id=None,
+                  shared_embeddings=False, scale_embeddings=False,
+                  beam=[3, 6, 0.6], seed=3, batch=4)
+
+
+def build_transformer(cfg):
+    from neuralmonkey.model.sequence import EmbeddedSequence
+    from neuralmonkey.encoders.transformer import TransformerEncoder
+    from neuralmonkey.decoders.transformer import TransformerDecoder
+    sv = make_vocab(cfg["src_vocab"])
+    tv = sv if cfg["shared_embeddings"] else make_vocab(cfg["tgt_vocab"])
+    seq = EmbeddedSequence(name="encoder_input", vocabulary=sv, data_id="source", embedding_size=cfg["dim"],
+                           scale_embeddings_by_depth=cfg["scale_embeddings"])
+    enc = TransformerEncoder(name="encoder", input_sequence=seq, ff_hidden_size=cfg["ff"], depth=cfg["depth"],
+                             n_heads=cfg["heads"], target_space_id=cfg["target_space_id"],
+                             use_att_transform_bias=cfg["use_att_transform_bias"])
+    dec = TransformerDecoder(name="decoder", encoders=[enc], vocabulary=tv, data_id="target",
+                             ff_hidden_size=cfg["ff"], n_heads_self=cfg["heads_self"], n_heads_enc=cfg["heads_enc"],
+                             depth=cfg["depth"], max_output_len=cfg["max_output_len"],
+                             embedding_size=None if cfg["shared_embeddings"] else cfg["dim"],
+                             embeddings_source=seq if cfg["shared_embeddings"] else None,
+                             tie_embeddings=cfg["tie_embeddings"],
+                             use_att_transform_bias=cfg["use_att_transform_bias"])
+    return seq, enc, dec, [seq, enc, dec]
+
+
+def run_transformer(case, **overrides):
+    cfg = dict(TR_DEFAULT, **overrides)
+    rng = np.random.default_rng(cfg["seed"])
+    bsz = cfg["batch"]
+    src = sentences(rng, bsz, cfg["src_vocab"], 1, 6, oov_every=2)
+    tgt = sentences(rng, bsz, cfg["tgt_vocab"], 1, cfg["max_output_len"] + 1, oov_every=3)
+    src[-1] = src[-1][:1]
+    series = {"source": src, "target": tgt}
+    out = {}
+    fresh_graph()
+    seq, enc, dec, parts = build_transformer(cfg)
+    inputs = string_inputs("source", "target")
+    ds = dataset(series)
+    with tf_eager.feeding(feed(parts, ds, False, inputs)):
+        out["in/src_tokens"] = seq.input_factors[0].numpy()
+        out["in/src_ids"] = seq.inputs.numpy()
+        out["in/tgt_tokens"] = dec.train_tokens.numpy()
+        out["in/tgt_ids"] = dec.train_inputs.numpy()
+        out["out/encoder_inputs"] = enc.encoder_inputs.numpy()
+        out["out/enc_states"] = enc.temporal_states.numpy()
+        out["out/enc_mask"] = enc.temporal_mask.numpy()
+        out["out/enc_output"] = enc.output.numpy()
+        with enc.use_scope():       # ``layer`` is a plain method: its callers are inside the part's scope
+            for lvl in range(cfg["depth"] + 1):
+                out["out/enc_layer{}".format(lvl)] = enc.layer(lvl).temporal_states.numpy()
+        out["out/train_input_symbols"] = dec.train_input_symbols.numpy()
+        out["out/train_logits"] = dec.train_logits.numpy()
+        out["out/train_output_states"] = dec.train_output_states.numpy()
+        out["out/train_xents"] = dec.train_xents.numpy()
+        out["out/train_loss"] = dec.train_loss.numpy()
+        rr = dec.runtime_loop_result
+        out["out/runtime_logits"] = dec.runtime_logits.numpy()
+        out["out/runtime_symbols"] = rr.histories.output_symbols.numpy()
+        out["out/runtime_mask"] = dec.runtime_mask.numpy()
+        out["out/runtime_loss"] = dec.runtime_loss.numpy()
+        out["out/decoded"] = dec.decoded.numpy()
+    # beam search on the whole batch (encoder states are tiled to the beam: beam_search_decoder.py:166-178)
+    from neuralmonkey.decoders.beam_search_decoder import BeamSearchDecoder
+    from neuralmonkey.runners.beamsearch_runner import BeamSearchRunner
+    k, max_steps, alpha = cfg["beam"]
+    fresh_graph()
+    seq, enc, dec, parts = build_transformer(cfg)
+    bs = BeamSearchDecoder(name="beam", parent_decoder=dec, beam_size=k, max_steps=max_steps,
+                           length_normalization=alpha)
+    runner = BeamSearchRunner(output_series="hyp", decoder=bs, rank=1)
+    with tf_eager.feeding(feed(parts + [bs], ds, False, inputs)):
+        ex = runner.get_executable(compute_losses=False, summaries=False, num_sessions=1)
+        fetches, _ = ex.next_to_execute()
+        res = to_numpy(fetches)
+        ex.collect_results([res])
+        bo = res["bs_outputs"]
+        out["out/beam_scores"] = bo.last_search_step_output.scores
+        out["out/beam_token_ids"] = bo.last_search_step_output.token_ids
+        out["out/beam_logprob_sum"] = bo.last_search_state.logprob_sum
+        out["out/beam_lengths"] = bo.last_search_state.lengths
+        out["out/beam_finished"] = bo.last_search_state.finished
+        out["out/beam_sentences"] = np.asarray([joined(s) for s in ex.result.outputs["hyp"]])
+        out["out/beam_loss"] = np.asarray(ex.result.losses["hyp/beam_search_score"])
+    save(case, cfg, out)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# function-level cases with hand-made edge inputs
+# ----------------------------------------------------------------------------------------------------------------
+def run_functions(case):
+    """Reference functions called directly: layer_norm, position_signal, the scaled-dot-product helpers, the
+    Bahdanau step with an all-padding row, pad_batch, _length_penalty, the beam body on hand-made distributions with
+    exact ties and finished hypotheses."""
+    from neuralmonkey import tf_utils
+    from neuralmonkey.encoders.transformer import position_signal
+    from neuralmonkey.attention import scaled_dot_product as sdp
+    from neuralmonkey.vocabulary import pad_batch
+    rng = np.random.default_rng(11)
+    out = {}
+    fresh_graph()
+    # tf_utils.layer_norm (:189-219)
+    x = rng.normal(0, 2, (3, 4, 10)).astype(np.float32)
+    x[0, 0] = 3.0                                              # a constant row: variance 0, eps decides
+    with tf.variable_scope("ln_case", reuse=tf.AUTO_REUSE):
+        out["in/ln_x"] = x
+        out["out/ln_y"] = tf_utils.layer_norm(tf.constant(x)).numpy()
+    # position_signal (encoders/transformer.py:23-45), even and odd dimension
+    out["out/pos_8_5"] = position_signal(8, tf.constant(5)).numpy()
+    out["out/pos_7_4"] = position_signal(7, tf.constant(4)).numpy()
+    # split_for_heads / mask_energies / mask_future (scaled_dot_product.py:24-93)
+    q = rng.normal(0, 1, (2, 3, 8)).astype(np.float32)
+    out["in/heads_x"] = q
+    out["out/heads_y"] = sdp.split_for_heads(tf.constant(q), 4, 2).numpy()
+    e = rng.normal(0, 1, (2, 2, 3, 3)).astype(np.float32)
+    m = np.asarray([[1, 1, 0], [0, 0, 0]], np.float32)          # second row: every key masked
+    out["in/energies"], out["in/key_mask"] = e, m
+    out["out/mask_energies"] = sdp.mask_energies(tf.constant(e), tf.constant(m)).numpy()
+    out["out/mask_future"] = sdp.mask_future(tf.constant(e)).numpy()
+    out["out/mask_future_then_keys"] = sdp.mask_energies(sdp.mask_future(tf.constant(e)), tf.constant(m)).numpy()
+    # attention() without and with head projections, masked, all keys of a row masked (:98-226)
+    keys = rng.normal(0, 1, (2, 3, 8)).astype(np.float32)
+    out["in/sdp_q"], out["in/sdp_k"] = q, keys
+    with tf.variable_scope("sdp1", reuse=tf.AUTO_REUSE):
+        ctx, w = sdp.attention(tf.constant(q), tf.constant(keys), tf.constant(keys), tf.constant(m), 1,
+                               lambda t: t, masked=True)
+        out["out/sdp1_ctx"], out["out/sdp1_w"] = ctx.numpy(), w.numpy()
+    with tf.variable_scope("sdp4", reuse=tf.AUTO_REUSE):
+        ctx, w = sdp.attention(tf.constant(q), tf.constant(keys), tf.constant(keys), tf.constant(m), 4,
+                               lambda t: t, masked=False, use_bias=True)
+        out["out/sdp4_ctx"], out["out/sdp4_w"] = ctx.numpy(), w.numpy()
+    # pad_batch (vocabulary.py:331-354)
+    sents = [["a", "b", "c"], [], ["d"] * 6]
+    for tag, kw in (("plain", {}), ("max4", {"max_length": 4}), ("end", {"add_end_symbol": True}),
+                    ("end_max4", {"max_length": 4, "add_end_symbol": True}),
+                    ("start_end_max4", {"max_length": 4, "add_start_symbol": True, "add_end_symbol": True})):
+        out["out/pad_" + tag] = np.asarray(pad_batch(sents, **kw))
+    save(case, {"kind": "functions"}, out)
+
+
+def run_beam_body(case):
+    """``BeamSearchDecoder`` (beam_search_decoder.py:218-596) over a hand-made parent decoder whose step
+    distributions are read from a table indexed by (step, previous symbol): exact score ties (TopK must take the
+    lower flat index), hypotheses that finish at different steps, a sentence whose whole beam finishes early, the
+    max_steps stop.  Only the beam logic is exercised, so every number is exact in float32."""
+    from neuralmonkey.decoders.autoregressive import AutoregressiveDecoder
+    from neuralmonkey.decoders.beam_search_decoder import BeamSearchDecoder
+    from neuralmonkey.runners.beamsearch_runner import BeamSearchRunner
+    vsz, k, max_steps, alpha = 7, 3, 5, 0.6
+    bsz = 3
+    rng = np.random.default_rng(5)
+    # logits[sentence, step, prev_symbol, :]: small multiples of 1/4 so that sums and ties are exact
+    table = (rng.integers(-8, 9, (bsz, max_steps + 2, vsz, vsz)) / 4.0).astype(np.float32)
+    table[0, 0, 1] = [-3, -3, -3, 1.0, 1.0, 1.0, 0.5]           # sentence 0, step 0 from <s>: three-way exact tie
+    table[0, 1, 3] = table[0, 1, 4]                              # identical continuations -> tied scores next step
+    table[0, 1, 5, 2] = 6.0                                      # a hypothesis that ends at once
+    table[1, 1:, :, 2] += 9.0                                    # sentence 1: the whole beam ends early
+    table[2, :, :, 2] = -9.0                                     # sentence 2: never ends, runs into max_steps
+
+    class TableDecoder(AutoregressiveDecoder):
+        """Parent decoder whose logits are table[sentence, step, previous symbol]; the sentence index of a row
+        travels in ``feedables.other`` (tiled by expand_to_beam, reordered by gather_flat like any state)."""
+
+        def __init__(self):
+            AutoregressiveDecoder.__init__(self, name="table", vocabulary=make_vocab(vsz - 4), data_id="target",
+                                           max_output_len=max_steps + 1, embedding_size=vsz)
+
+        @property
+        def output_dimension(self):
+            return vsz
+
+        # identity "embedding" and identity output projection
+        @property
+        def embedding_matrix(self):
+            return tf.constant(np.eye(vsz, dtype=np.float32))
+
+        @property
+        def decoding_w(self):
+            return tf.constant(np.eye(vsz, dtype=np.float32))
+
+        @property
+        def decoding_b(self):
+            return tf.zeros([vsz])
+
+        def get_initial_histories(self):
+            h = AutoregressiveDecoder.get_initial_histories(self)
+            return h._replace(other=tf.zeros([]))
+
+        def get_initial_feedables(self):
+            f = AutoregressiveDecoder.get_initial_feedables(self)
+            return f._replace(other=tf.reshape(tf.range(self.batch_size), [-1, 1]))
+
+        def next_state(self, loop_state):
+            step = loop_state.feedables.step
+            sent = loop_state.feedables.other[:, 0]
+            prev = tf.to_int32(tf.argmax(loop_state.feedables.embedded_input, axis=1))
+            idx = tf.stack([sent, tf.fill(tf.shape(sent), step), prev], axis=1)
+            logits = tf.gather_nd(tf.constant(table), idx)
+            return logits, loop_state.feedables.other, loop_state.histories.other
+
+    out = {"in/table": table}
+    fresh_graph()
+    dec = TableDecoder()
+    bs = BeamSearchDecoder(name="beam", parent_decoder=dec, beam_size=k, max_steps=max_steps,
+                           length_normalization=alpha)
+    runner = BeamSearchRunner(output_series="hyp", decoder=bs, rank=2)
+    series = {"target": [["w0"]] * bsz}
+    inputs = string_inputs("target")
+    with tf_eager.feeding(feed([dec, bs], dataset(series), False, inputs)):
+        out["out/length_penalty"] = bs._length_penalty(tf.constant(np.arange(0, 12, dtype=np.int32))).numpy()
+        ex = runner.get_executable(compute_losses=False, summaries=False, num_sessions=1)
+        fetches, _ = ex.next_to_execute()
+        res = to_numpy(fetches)
+        ex.collect_results([res])
+        bo = res["bs_outputs"]
+        out["out/scores"] = bo.last_search_step_output.scores
+        out["out/token_ids"] = bo.last_search_step_output.token_ids
+        out["out/logprob_sum"] = bo.last_search_state.logprob_sum
+        out["out/lengths"] = bo.last_search_state.lengths
+        out["out/finished"] = bo.last_search_state.finished
+        out["out/dec_step"] = bo.last_dec_loop_state.feedables.step
+        out["out/rank2_sentences"] = np.asarray([joined(s) for s in ex.result.outputs["hyp"]])
+        out["out/rank2_loss"] = np.asarray(ex.result.losses["hyp/beam_search_score"])
+    save(case, {"kind": "beam_body", "vocab": vsz, "beam": [k, max_steps, alpha], "batch": bsz}, out)
+
+
+def run_defects(case):
+    """Configurations the reference cannot execute at this commit: the exception IS the reference behaviour."""
+    import traceback
+    found = {}
+    # Decoder(attention_on_input=True): decoder.py:270-273 reads ``feedables.prev_contexts`` where the field lives in
+    # ``feedables.other`` (RNNFeedables) -- AttributeError as soon as the loop body is traced
+    cfg = dict(RNN_DEFAULT, attention_on_input=True)
+    fresh_graph()
+    enc, att, dec, parts = build_rnn(cfg)
+    inputs = string_inputs("source", "target")
+    try:
+        with tf_eager.feeding(feed(parts, dataset(rnn_series(cfg)), False, inputs)):
+            dec.train_logits.numpy()
+        found["attention_on_input"] = ""
+    except AttributeError as exc:
+        tb = traceback.extract_tb(exc.__traceback__)[-1]
+        found["attention_on_input"] = "{}:{} {}".format(os.path.relpath(tb.filename, REFERENCE), tb.lineno, exc)
+    # CoverageAttention: coverage.py:52 calls ``.size()`` on a tf.Tensor
+    from neuralmonkey.attention.coverage import CoverageAttention
+    fresh_graph()
+    cfg = dict(RNN_DEFAULT)
+    enc, att, dec, parts = build_rnn(cfg)
+    cov = CoverageAttention(name="coverage", encoder=enc)
+    try:
+        with tf_eager.feeding(feed(parts + [cov], dataset(rnn_series(cfg)), False, inputs)):
+            cov.attention(tf.zeros([cfg["batch"], cfg["rnn_size"]]), None, None, cov.initial_loop_state())
+        found["coverage"] = ""
+    except Exception as exc:        # noqa: BLE001 -- whatever it raises is what we record
+        tb = traceback.extract_tb(exc.__traceback__)
+        here = [t for t in tb if t.filename.startswith(REFERENCE)][-1]
+        found["coverage"] = "{}:{} {}: {}".format(os.path.relpath(here.filename, REFERENCE), here.lineno,
+                                                  type(exc).__name__, exc)
+    fresh_graph()
+    print(json.dumps(found, indent=1))
+    save(case, found, {})
+
+
+CASES = collections.OrderedDict([
+    ("functions", lambda: run_functions("functions")),
+    ("beam_body", lambda: run_beam_body("beam_body")),
+    ("rnn_gru", lambda: run_rnn("rnn_gru")),
+    ("rnn_gru_supress_unk", lambda: run_rnn("rnn_gru_supress_unk", supress_unk=True, seed=2, max_input_len=5,
+                                            att_state=7)),
+    ("rnn_nematus_cgru", lambda: run_rnn(
+        "rnn_nematus_cgru", enc_layers=[[5, "bidirectional", "NematusGRU"]], dec_cell="NematusGRU",
+        conditional_gru=True, output_projection=["nematus", "tanh"], encoder_projection="nematus",
+        enc_keep=0.5, att_keep=0.5, dec_keep=0.5, seed=4)),
+    ("defects", lambda: run_defects("defects")),
+    ("rnn_lstm", lambda: run_rnn("rnn_lstm", enc_layers=[[5, "bidirectional", "LSTM"]], dec_cell="LSTM", seed=6,
+                                 output_projection=["maxout"])),
+    ("rnn_stacked", lambda: run_rnn(
+        "rnn_stacked", sentence_encoder=False, enc_layers=[[3, "bidirectional", "GRU"], [6, "forward", "GRU"],
+                                                           [6, "backward", "LSTM"]],
+        add_layer_norm=True, add_residual=True, output_projection=["mlp", [7, 6], "relu"],
+        encoder_projection="concat", seed=7)),
+    ("rnn_tied", lambda: run_rnn("rnn_tied", tie_embeddings=True, output_projection=["default"],
+                                 encoder_projection="empty", seed=8)),
+    ("captioning", lambda: run_rnn("captioning", spatial=[3, 3, 10, None, None], seed=9)),
+    ("captioning_projected", lambda: run_rnn("captioning_projected", spatial=[2, 3, 10, 9, 8], seed=10)),
+    ("transformer", lambda: run_transformer("transformer")),
+    ("transformer_bias_untied", lambda: run_transformer(
+        "transformer_bias_untied", tie_embeddings=False, use_att_transform_bias=True, heads=4, heads_self=1,
+        heads_enc=2, depth=3, target_space_id=5, seed=12)),
+    ("transformer_shared", lambda: run_transformer("transformer_shared", shared_embeddings=True,
+                                                   scale_embeddings=True, seed=13)),
+])
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(CASES)
+    for name in names:
+        CASES[name]()

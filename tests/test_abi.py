@@ -57,7 +57,10 @@ def test_product_package_never_imports_the_oracle():
         for f in files:
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
-                assert "oracle" not in re.sub(r"#.*", "", src).replace('"""', ""), os.path.join(dirpath, f)
+                code = re.sub(r"#.*", "", src).replace('"""', "")
+                assert "oracle" not in code, os.path.join(dirpath, f)
+                # the NumPy-eager TensorFlow stand-in that executes the reference's files is test infrastructure too
+                assert "tf_eager" not in code and "ref_exec" not in code, os.path.join(dirpath, f)
 
 
 def _header_struct(name):

@@ -1,0 +1,336 @@
+"""The oracle against numbers produced by the REFERENCE'S OWN code.
+
+``tests/golden/ref_exec/*.npz`` were written by ``tests/golden/make_reference_exec_golden.py``, which imports the
+model parts from ``/root/reference`` unmodified and runs them on a NumPy-eager stand-in for the TensorFlow calls they
+make (``tests/ref_exec/tf_eager.py``).  Here every ``oracle/`` restatement has to reproduce those numbers: integer /
+index outputs exactly, float32 within 2e-6 of the tensor's largest magnitude (torch-CPU / NumPy differ from the
+stand-in's NumPy in matmul blocking and libm ulps only).  This is what pins the oracle for the reference-authored
+arithmetic; TF-internal ops (GRUCell, LSTMCell, dynamic_rnn, dense, sequence_loss, top_k order) are restated from
+SURVEY.md section 9 on both sides.
+
+No GPU, no ``/root/reference`` needed at test time.
+"""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import general_ref as G
+from oracle import nm_oracle as O
+from oracle import transformer_ref as T
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIX = os.path.join(HERE, "golden", "ref_exec")
+TOL = 2e-6
+
+
+def load(case):
+    z = np.load(os.path.join(FIX, case + ".npz"))
+    cfg = json.loads(str(z["cfg"]))
+    params = {k[2:]: z[k] for k in z.files if k.startswith("p/")}
+    return z, cfg, params
+
+
+def close(got, want, what, tol=TOL):
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape, "{}: shape {} vs reference {}".format(what, got.shape, want.shape)
+    if want.size == 0:
+        return
+    scale = max(float(np.abs(want).max()), 1.0)
+    err = float(np.abs(got.astype(np.float64) - want.astype(np.float64)).max())
+    assert err <= tol * scale, "{}: max |diff| {:.3e} (scale {:.3g})".format(what, err, scale)
+
+
+def same(got, want, what):
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape, "{}: shape {} vs reference {}".format(what, got.shape, want.shape)
+    assert np.array_equal(got, want), "{}:\n{}\nreference:\n{}".format(what, got, want)
+
+
+def words(vocab_words):
+    return ["<pad>", "<s>", "</s>", "<unk>"] + ["w{}".format(i) for i in range(vocab_words)]
+
+
+def sentence(ids, vocab):
+    return " ".join(vocab[i] for i in ids)
+
+
+def test_every_generated_case_is_checked_here():
+    have = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(FIX, "*.npz")))
+    checked = sorted(["functions", "beam_body", "defects"] + RNN_CASES + TRANSFORMER_CASES)
+    assert have == checked
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# functions called directly
+# --------------------------------------------------------------------------------------------------------------------
+def test_layer_norm_position_signal_and_attention_helpers():
+    z, _, p = load("functions")
+    x = z["in/ln_x"]
+    close(O.layer_norm(x, p["ln_case/LayerNorm/gamma"], p["ln_case/LayerNorm/beta"]), z["out/ln_y"],
+          "tf_utils.layer_norm")
+    close(T.position_signal(8, 5).numpy()[None], z["out/pos_8_5"], "position_signal(8, 5)")
+    close(T.position_signal(7, 4).numpy()[None], z["out/pos_7_4"], "position_signal(7, 4)")
+
+    # split_for_heads (scaled_dot_product.py:24-42): [B,T,D] -> [B,H,T,D/H]
+    hx = z["in/heads_x"]
+    same(hx.reshape(2, 3, 4, 2).transpose(0, 2, 1, 3), z["out/heads_y"], "split_for_heads")
+
+    # mask_energies / mask_future (:45-93) as the oracle's attention applies them
+    e, m = torch.tensor(z["in/energies"]), torch.tensor(z["in/key_mask"])
+    close(T.mask_energies(e, m), z["out/mask_energies"], "mask_energies")
+    close(T.mask_future(e), z["out/mask_future"], "mask_future")
+    close(T.mask_energies(T.mask_future(e), m), z["out/mask_future_then_keys"], "mask_future -> mask_energies")
+
+    # attention(): one head without projections (masked), four heads with biased projections
+    q, k = torch.tensor(z["in/sdp_q"]), torch.tensor(z["in/sdp_k"])
+    model = T.TransformerModel(p, T.TConfig())
+    ctx, w = model.attention("sdp1", q, k, m, 1, True, 1.0, False, False, ("t",), return_weights=True)
+    close(ctx, z["out/sdp1_ctx"], "attention(1 head) context")
+    close(w, z["out/sdp1_w"], "attention(1 head) weights")
+    ctx, w = model.attention("sdp4", q, k, m, 4, False, 1.0, False, True, ("t",), return_weights=True)
+    close(ctx, z["out/sdp4_ctx"], "attention(4 heads) context")
+    close(w, z["out/sdp4_w"], "attention(4 heads) weights")
+
+
+def test_pad_batch_of_the_product_equals_the_reference():
+    """vocabulary.py:331-354 -- host logic of the product (no kernel involved)."""
+    from neuralmonkey_amd.vocabulary import pad_batch
+    z, _, _ = load("functions")
+    sents = [["a", "b", "c"], [], ["d"] * 6]
+    for tag, kw in (("plain", {}), ("max4", {"max_length": 4}), ("end", {"add_end_symbol": True}),
+                    ("end_max4", {"max_length": 4, "add_end_symbol": True}),
+                    ("start_end_max4", {"max_length": 4, "add_start_symbol": True, "add_end_symbol": True})):
+        same(np.asarray(pad_batch(sents, **kw)), z["out/pad_" + tag], "pad_batch " + tag)
+
+
+def test_beam_body_with_exact_ties_and_early_finishes():
+    """BeamSearchDecoder + BeamSearchRunner over a table-driven parent decoder: every number is exact."""
+    z, cfg, _ = load("beam_body")
+    table = z["in/table"]
+    k, max_steps, alpha = cfg["beam"]
+    bsz, vsz = cfg["batch"], cfg["vocab"]
+    rows = bsz * k
+    state = {"step": 1}
+    sent = np.repeat(np.arange(bsz), k)
+
+    def step_fn(flat_src, word_ids):
+        lg = table[sent, state["step"], word_ids]
+        state["step"] += 1
+        return lg
+
+    first = table[sent, 0, O.START]
+    res = O.beam_search_core(first, step_fn, bsz, k, max_steps, alpha)
+    same(res.token_ids, z["out/token_ids"], "token_ids")
+    same(res.lengths, z["out/lengths"], "lengths")
+    same(res.finished, z["out/finished"], "finished")
+    close(res.scores, z["out/scores"], "scores", 1e-7)
+    close(res.logprob_sum, z["out/logprob_sum"], "logprob_sum", 1e-7)
+    assert state["step"] == int(z["out/dec_step"])
+    close(O.length_penalty(np.arange(12), alpha, np.float32), z["out/length_penalty"], "_length_penalty", 1e-7)
+    sents, loss = O.beam_tokens(res, rank=2)
+    vocab = words(vsz - 4)
+    got = [sentence(s, vocab) for s in sents]
+    want = [str(s) for s in z["out/rank2_sentences"]]
+    for g, w, toks in zip(got, want, np.transpose(res.token_ids, (1, 2, 0))):
+        if toks[1][1] == O.END:         # beamsearch_runner.py:88-99 leaves the raw ids when </s> comes first
+            assert w == " ".join(str(t) for t in toks[1][1:]) and g == ""
+        else:
+            assert g == w
+    close(loss, z["out/rank2_loss"], "runner loss", 1e-6)
+    # the fixture really contains what it was built for
+    assert res.finished.all(axis=1).any() and not res.finished.all()
+
+
+def test_reference_defects_are_recorded():
+    """Configurations the reference itself cannot build at this commit (no behaviour to pin)."""
+    z, cfg, _ = load("defects")
+    assert "prev_contexts" in cfg["attention_on_input"]          # decoder.py:273: feedables.prev_contexts
+    assert cfg["coverage"]                                       # coverage.py:52: .size() on a tf.Tensor
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# RNN encoder-decoder family
+# --------------------------------------------------------------------------------------------------------------------
+RNN_CASES = ["rnn_gru", "rnn_gru_supress_unk", "rnn_nematus_cgru", "rnn_lstm", "rnn_stacked", "rnn_tied",
+             "captioning", "captioning_projected"]
+
+
+def general_config(cfg):
+    op = cfg["output_projection"]
+    kind = op[0]
+    if kind in ("nonlinear", "nematus"):
+        proj = (kind, op[1], cfg["dec_keep"])
+    elif kind == "default":
+        proj = ("nonlinear", "tanh", 1.0)
+    elif kind == "maxout":
+        proj = ("maxout", cfg["rnn_size"], cfg["dec_keep"])
+    else:
+        proj = ("mlp", tuple(op[1]), op[2], cfg["dec_keep"])
+    spatial = None
+    if cfg["spatial"] is not None:
+        spatial = (cfg["spatial"][3], cfg["spatial"][4])
+    return G.Config(rnn_layers=tuple(tuple(layer) for layer in cfg["enc_layers"]),
+                    add_layer_norm=cfg["add_layer_norm"], add_residual=cfg["add_residual"],
+                    enc_dropout=cfg["enc_keep"], att_dropout=cfg["att_keep"], dec_cell=cfg["dec_cell"],
+                    conditional_gru=cfg["conditional_gru"], attention_on_input=cfg["attention_on_input"],
+                    dec_dropout=cfg["dec_keep"], output_projection=proj,
+                    encoder_projection=cfg["encoder_projection"], tie_embeddings=cfg["tie_embeddings"],
+                    supress_unk=cfg["supress_unk"], rnn_size=cfg["rnn_size"], spatial=spatial)
+
+
+def source_of(z, cfg, rows=slice(None)):
+    if cfg["spatial"] is not None:
+        return z["in/maps"][rows]
+    return z["in/src_ids"][rows]
+
+
+@pytest.mark.parametrize("case", RNN_CASES)
+def test_rnn_family_equals_the_reference(case):
+    z, cfg, params = load(case)
+    gcfg = general_config(cfg)
+    model = G.GeneralModel(params, gcfg)
+    src, tgt = source_of(z, cfg), z["in/tgt_ids"]
+
+    # a1: what the reference's Vocabulary made of the strings
+    if cfg["spatial"] is None:
+        vocab = words(cfg["src_vocab"])
+        index = {w: i for i, w in enumerate(vocab)}
+        same(np.vectorize(lambda w: index.get(str(w), O.UNK))(z["in/src_tokens"]), z["in/src_ids"], "source ids")
+    tvocab = words(cfg["tgt_vocab"])
+    tindex = {w: i for i, w in enumerate(tvocab)}
+    same(np.vectorize(lambda w: tindex.get(str(w), O.UNK))(z["in/tgt_tokens"]).T, tgt, "target ids (time-major)")
+    same(O.sentence_mask(tgt), z["out/train_mask"], "train_mask")
+
+    # a2-a6: encoder, attention keys
+    with torch.no_grad():
+        states, mask, final = model.encode(src, False)
+        st, hf = model.attention_setup(states, False)
+        if cfg["spatial"] is None:
+            close(states, z["out/enc_states"], "encoder temporal_states")
+            same(mask.numpy(), z["out/enc_mask"], "encoder temporal_mask")
+        else:
+            close(states, z["out/att_states"], "attention states of the maps")
+        close(final, z["out/enc_output"], "encoder output")
+        close(hf, z["out/hidden_features"][:, :, 0, :], "attention hidden_features")
+        close(model.initial_state(final, False, states, mask), z["out/initial_state"], "decoder initial_state")
+
+        # a9-a13: teacher-forced pass
+        loss, logits, weights = model.train_loss(src, tgt, train=False)
+        close(logits, z["out/train_logits"], "train_logits")
+        close(weights, z["out/train_att_weights"], "attention weights (train)")
+        close(loss, z["out/train_loss"], "train_loss")
+        lp = torch.log_softmax(logits, -1).numpy()
+        t_, b_ = tgt.shape
+        xent = -lp[np.arange(t_)[:, None], np.arange(b_)[None, :], tgt] * z["out/train_mask"]
+        close(xent.T, z["out/train_xents"], "train_xents [B,T]")
+
+    # a11-a12, a18: greedy decoding
+    syms, masks, run_logits = model.greedy(src, cfg["max_output_len"])
+    same(syms, z["out/runtime_symbols"], "runtime symbols")
+    same(masks, z["out/runtime_mask"], "runtime mask")
+    close(run_logits, z["out/runtime_logits"], "runtime_logits")
+    assert len(syms) == int(z["out/runtime_steps"])
+    same(run_logits[:, :, 1:].argmax(-1) + 1, z["out/decoded"], "decoded (argmax without pad)")
+    mt = min(len(tgt), len(run_logits))                          # autoregressive.py:351-371
+    rlp = torch.log_softmax(torch.tensor(run_logits[:mt]), -1).numpy()
+    rx = -rlp[np.arange(mt)[:, None], np.arange(b_)[None, :], tgt[:mt]] * z["out/train_mask"][:mt]
+    close(rx.T, z["out/runtime_xents"], "runtime_xents")
+    close(rx.sum() / masks.astype(np.float32).sum(), z["out/runtime_loss"], "runtime_loss")
+    amax = torch.log_softmax(torch.tensor(run_logits), -1).numpy().argmax(-1)
+    res = O.DecodeResult(run_logits, None, amax, None, None, None, None)
+    got = [sentence(s, tvocab) for s in O.greedy_tokens(res)]
+    assert got == [str(s) for s in z["out/greedy_sentences"]]
+
+    # a14-a17: beam search, sentence by sentence as the reference runs it (batch 1)
+    k, max_steps, alpha = cfg["beam"]
+    for i in range(cfg["batch"]):
+        one = source_of(z, cfg, slice(i, i + 1))
+        if cfg["spatial"] is None:
+            one = one[:, :max(int(z["out/enc_mask"][i].sum()), 1)]   # feed_dict pads to the longest of the BATCH
+        tok, scores, _ = model.beam(one, k, max_steps, alpha)
+        pre = "out/beam{}_".format(i)
+        same(tok, z[pre + "token_ids"], "beam token_ids of sentence {}".format(i))
+        close(scores, z[pre + "scores"], "beam scores of sentence {}".format(i))
+        hyp = []
+        for t in tok[1:, 0, 0]:
+            if t == O.END:
+                break
+            hyp.append(int(t))
+        if tok.shape[0] > 1 and tok[1, 0, 0] == O.END:
+            assert str(z[pre + "sentence"]) == " ".join(str(t) for t in tok[1:, 0, 0])
+        else:
+            assert sentence(hyp, tvocab) == str(z[pre + "sentence"])
+        close(float(np.mean(scores[:, 0])) * scores.shape[0], z[pre + "loss"], "runner loss")
+
+
+def test_headline_model_through_the_numpy_oracle_as_well():
+    """oracle/nm_oracle.py (the restatement bench.py's CPU baseline and the kernel tests use) on the same fixture."""
+    z, cfg, params = load("rnn_gru")
+    src, tgt = z["in/src_ids"], z["in/tgt_ids"]
+    enc = O.sentence_encoder(params, src)
+    close(enc.rnn_input, z["out/enc_input"], "embedded input")
+    close(enc.temporal_states, z["out/enc_states"], "encoder states")
+    close(enc.output, z["out/enc_output"], "encoder output")
+    spec = O.DecoderSpec(max_output_len=cfg["max_output_len"])
+    res = O.decoding_loop(params, spec, enc, tgt, True)
+    close(res.logits, z["out/train_logits"], "train logits")
+    close(res.output_states, z["out/train_output_states"], "train output states")
+    close(res.rnn_outputs, z["out/train_rnn_outputs"], "train rnn outputs")
+    close(res.contexts, z["out/train_contexts"], "train contexts")
+    close(res.weights, z["out/train_att_weights"], "attention weights")
+    close(O.train_loss(res, tgt), z["out/train_loss"], "train loss")
+    run = O.decoding_loop(params, spec, enc, None, False)
+    same(run.symbols, z["out/runtime_symbols"], "greedy symbols")
+    same(run.mask, z["out/runtime_mask"], "runtime mask")
+    close(run.weights, z["out/runtime_att_weights"], "attention weights (run)")
+    close(O.runtime_loss(run, tgt), z["out/runtime_loss"], "runtime loss")
+    k, max_steps, alpha = cfg["beam"]
+    for i in range(cfg["batch"]):
+        n = int(z["out/enc_mask"][i].sum())
+        b = O.beam_search(params, spec, O.sentence_encoder(params, src[i:i + 1, :n]), k, max_steps, alpha)
+        pre = "out/beam{}_".format(i)
+        same(b.token_ids, z[pre + "token_ids"], "token_ids")
+        same(b.lengths, z[pre + "lengths"], "lengths")
+        same(b.finished, z[pre + "finished"], "finished")
+        close(b.scores, z[pre + "scores"], "scores")
+        close(b.logprob_sum, z[pre + "logprob_sum"], "logprob_sum")
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Transformer
+# --------------------------------------------------------------------------------------------------------------------
+TRANSFORMER_CASES = ["transformer", "transformer_bias_untied", "transformer_shared"]
+
+
+def transformer_config(cfg):
+    return T.TConfig(depth=cfg["depth"], n_heads=cfg["heads"], n_heads_self=cfg["heads_self"],
+                     n_heads_enc=cfg["heads_enc"], use_att_transform_bias=cfg["use_att_transform_bias"],
+                     tie_embeddings=cfg["tie_embeddings"], target_space_id=cfg["target_space_id"],
+                     shared_embeddings=cfg["shared_embeddings"], scale_embeddings=cfg["scale_embeddings"])
+
+
+@pytest.mark.parametrize("case", TRANSFORMER_CASES)
+def test_transformer_equals_the_reference(case):
+    z, cfg, params = load(case)
+    model = T.TransformerModel(params, transformer_config(cfg))
+    src, tgt = z["in/src_ids"], z["in/tgt_ids"]                 # tgt time-major [T,B]
+    with torch.no_grad():
+        states, mask, output = model.encode(src, False)
+        close(states, z["out/enc_states"], "encoder states")
+        same(mask.numpy(), z["out/enc_mask"], "encoder mask")
+        close(output, z["out/enc_output"], "encoder output (sum over time)")
+        loss, logits = model.train_loss(src, tgt.T, train=False)
+        close(logits.transpose(0, 1), z["out/train_logits"], "train_logits [T,B,V]", 4e-6)
+        close(loss, z["out/train_loss"], "train_loss")
+    syms, masks, run_logits = model.greedy(src, cfg["max_output_len"])
+    same(syms, z["out/runtime_symbols"], "greedy symbols")
+    same(masks, z["out/runtime_mask"], "runtime mask")
+    close(run_logits, z["out/runtime_logits"], "runtime logits", 4e-6)
+    k, max_steps, alpha = cfg["beam"]
+    tok, scores, _ = model.beam(src, k, max_steps, alpha)
+    same(tok, z["out/beam_token_ids"], "beam token_ids")
+    close(scores, z["out/beam_scores"], "beam scores", 4e-6)
