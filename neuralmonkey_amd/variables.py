@@ -159,9 +159,11 @@ class VariableStore:
                 continue
             arr = np.asarray(values[n], dtype=np.float32)
             if tuple(arr.shape) != spec.shape:
-                if arr.size != spec.size or max(arr.ndim, len(spec.shape)) > 1:
+                # size-one axes may differ: scalar () <-> (1,), TF's [1,1,in,out] 1x1 conv filters <-> [in,out]
+                squeeze = lambda shape: tuple(d for d in shape if d != 1)
+                if arr.size != spec.size or squeeze(arr.shape) != squeeze(spec.shape):
                     raise ValueError(f"{n}: checkpoint shape {arr.shape} != {spec.shape}")
-                arr = arr.reshape(spec.shape)          # scalar () <-> (1,)
+                arr = arr.reshape(spec.shape)
             self[n].copy_(torch.from_numpy(arr).to(self.device))
 
     def save(self, path: str, fmt: str = "npz", global_step: Optional[int] = None) -> None:

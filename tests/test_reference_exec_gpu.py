@@ -1,0 +1,328 @@
+"""The ENGINE against numbers produced by the reference's own code (``tests/golden/ref_exec``, see
+``tests/test_reference_exec.py`` for how they were made): the same token strings go through the product's vocabulary,
+the same variables are loaded under the reference's TensorFlow names, and the HIP path has to reproduce the reference's
+encoder states, logits, losses, greedy symbols and beam searches.
+
+Tolerance (north_star): floats 1e-4 relative to the tensor's largest magnitude, indices exact.  Sentences whose
+beam search the fixture itself decides by less than 1e-5 are not in the fixtures (the generator's seeds avoid them;
+``min_gap`` is re-checked here through the oracle)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import general_ref as G
+from oracle import transformer_ref as T
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIX = os.path.join(HERE, "golden", "ref_exec")
+TOL = 1e-4
+PAD, END = "<pad>", "</s>"
+
+
+def load(case):
+    z = np.load(os.path.join(FIX, case + ".npz"))
+    cfg = json.loads(str(z["cfg"]))
+    params = {k[2:]: z[k] for k in z.files if k.startswith("p/")}
+    return z, cfg, params
+
+
+def close(got, want, what, tol=TOL):
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape, "{}: shape {} vs reference {}".format(what, got.shape, want.shape)
+    keep = np.abs(want) < 1e8                     # the -1e9 of supress_unk aside
+    scale = max(float(np.abs(want[keep]).max()), 1e-6)
+    err = float(np.abs(got.astype(np.float64) - want.astype(np.float64))[keep].max())
+    assert err <= tol * scale, "{}: max |diff| {:.3e} (scale {:.3g})".format(what, err, scale)
+
+
+def unpad(tokens, strip_end=False):
+    out = []
+    for row in tokens:
+        sent = [str(t) for t in row if str(t) != PAD]
+        if strip_end and sent and sent[-1] == END:
+            sent = sent[:-1]
+        out.append(sent)
+    return out
+
+
+def vocabulary(n_words):
+    from neuralmonkey_amd.vocabulary import Vocabulary
+    return Vocabulary(["w{}".format(i) for i in range(n_words)])
+
+
+def load_variables(store, params):
+    """Every variable the ENGINE declares must exist in the reference under the same name (the checkpoint
+    contract); variables only the reference creates are listed by the caller's assertion."""
+    missing = [n for n in store.names() if n not in params]
+    assert not missing, "engine variables the reference does not have: {}".format(missing)
+    store.load_state_dict(params)
+    return sorted(set(params) - set(store.names()))
+
+
+RNN_CASES = ["rnn_gru", "rnn_gru_supress_unk", "rnn_nematus_cgru", "rnn_lstm", "rnn_stacked", "rnn_tied",
+             "captioning", "captioning_projected"]
+
+
+def build_rnn(dev, cfg):
+    from neuralmonkey_amd.attention import Attention
+    from neuralmonkey_amd.decoders import BeamSearchDecoder, Decoder
+    from neuralmonkey_amd.decoders import encoder_projection as EP
+    from neuralmonkey_amd.decoders import output_projection as OP
+    from neuralmonkey_amd.encoders import RecurrentEncoder, SentenceEncoder
+    from neuralmonkey_amd.encoders.numpy_stateful_filler import SpatialFiller
+    from neuralmonkey_amd.model.sequence import EmbeddedSequence
+    from neuralmonkey_amd.runners import BeamSearchRunner, GreedyRunner
+    from neuralmonkey_amd.runtime import reset_registry
+    from neuralmonkey_amd.tf_manager import TensorFlowManager
+    from neuralmonkey_amd.trainers import CrossEntropyTrainer
+    reset_registry()
+    sv, tv = vocabulary(cfg["src_vocab"]), vocabulary(cfg["tgt_vocab"])
+    feedables = []
+    if cfg["spatial"] is not None:
+        h, w, c, ff_dim, proj_dim = cfg["spatial"]
+        enc = SpatialFiller(name="encoder", input_shape=[h, w, c], data_id="maps", projection_dim=proj_dim,
+                            ff_hidden_dim=ff_dim)
+        feedables.append(enc)
+    elif cfg["sentence_encoder"]:
+        size, direction, cell = cfg["enc_layers"][0]
+        enc = SentenceEncoder(name="encoder", vocabulary=sv, data_id="source", embedding_size=cfg["emb"],
+                              rnn_size=size, rnn_cell=cell, rnn_direction=direction,
+                              add_residual=cfg["add_residual"], add_layer_norm=cfg["add_layer_norm"],
+                              max_input_len=cfg["max_input_len"], dropout_keep_prob=cfg["enc_keep"])
+        feedables += [enc.input_sequence, enc]
+    else:
+        seq = EmbeddedSequence(name="encoder_input", vocabulary=sv, data_id="source", embedding_size=cfg["emb"],
+                               max_length=cfg["max_input_len"])
+        enc = RecurrentEncoder(name="encoder", input_sequence=seq,
+                               rnn_layers=[tuple(layer) for layer in cfg["enc_layers"]],
+                               add_residual=cfg["add_residual"], add_layer_norm=cfg["add_layer_norm"],
+                               dropout_keep_prob=cfg["enc_keep"])
+        feedables += [seq, enc]
+    att = Attention(name="attention", encoder=enc, dropout_keep_prob=cfg["att_keep"], state_size=cfg["att_state"])
+    act = lambda name: type("Act", (), {"nm_name": name})()
+    op = cfg["output_projection"]
+    if op[0] == "nonlinear":
+        proj = OP.nonlinear_output(cfg["rnn_size"], act(op[1]), cfg["dec_keep"])
+    elif op[0] == "nematus":
+        proj = OP.nematus_output(cfg["rnn_size"], act(op[1]), cfg["dec_keep"])
+    elif op[0] == "maxout":
+        proj = OP.maxout_output(cfg["rnn_size"], cfg["dec_keep"])
+    elif op[0] == "mlp":
+        proj = OP.mlp_output(list(op[1]), act(op[2]), cfg["dec_keep"])
+    else:
+        proj = None
+    ep = {"linear": None, "nematus": EP.nematus_projection(cfg["dec_keep"]), "concat": None,
+          "empty": EP.empty_initial_state}[cfg["encoder_projection"]]
+    dec = Decoder(encoders=[enc], vocabulary=tv, data_id="target", name="decoder",
+                  max_output_len=cfg["max_output_len"], dropout_keep_prob=cfg["dec_keep"],
+                  embedding_size=cfg["rnn_size"],
+                  rnn_size=None if cfg["encoder_projection"] == "concat" else cfg["rnn_size"],
+                  output_projection=proj, encoder_projection=ep, attentions=[att],
+                  attention_on_input=cfg["attention_on_input"], rnn_cell=cfg["dec_cell"],
+                  conditional_gru=cfg["conditional_gru"], tie_embeddings=cfg["tie_embeddings"],
+                  supress_unk=cfg["supress_unk"])
+    k, max_steps, alpha = cfg["beam"]
+    bdec = BeamSearchDecoder(name="beam", parent_decoder=dec, beam_size=k, max_steps=max_steps,
+                             length_normalization=alpha)
+    greedy = GreedyRunner(output_series="target", decoder=dec)
+    brun = BeamSearchRunner(output_series="hyp", decoder=bdec, rank=1)
+    trainer = CrossEntropyTrainer(decoders=[dec], l2_weight=0.0, clip_norm=None)
+    tfm = TensorFlowManager(num_sessions=1, num_threads=1, device=str(dev), seed=1)
+    tfm.initialize_sessions()
+    feedables += [att, dec]
+    return dict(enc=enc, att=att, dec=dec, bdec=bdec, greedy=greedy, brun=brun, trainer=trainer, tfm=tfm,
+                feedables=feedables, store=tfm.sessions[0].store)
+
+
+def dataset_of(z, cfg, rows=None):
+    from neuralmonkey_amd.dataset import BatchingScheme, Dataset
+    series = {"target": unpad(z["in/tgt_tokens"], strip_end=True)}
+    # the fixture's target strings were cut at max_output_len by the reference's feed_dict; feeding the cut sentence
+    # again gives the same padded batch except where </s> itself was cut away -- keep those rows as they are
+    for i, row in enumerate(z["in/tgt_tokens"]):
+        toks = [str(t) for t in row if str(t) != PAD]
+        if toks and toks[-1] != END:
+            series["target"][i] = toks + ["w0"]          # longer than max_output_len: cut again, </s> never fits
+    if cfg["spatial"] is not None:
+        series["maps"] = list(z["in/maps"])
+    else:
+        series["source"] = unpad(z["in/src_tokens"])
+    if rows is not None:
+        series = {k: [v[i] for i in rows] for k, v in series.items()}
+    n = len(series["target"])
+    return Dataset("fixture", series, BatchingScheme(batch_size=n))
+
+
+@pytest.mark.parametrize("case", RNN_CASES)
+def test_rnn_family_engine_equals_the_reference(dev, case):
+    z, cfg, params = load(case)
+    m = build_rnn(dev, cfg)
+    only_reference = load_variables(m["store"], params)
+    # what only the reference creates: GRUCell.build's unused gates/candidate variables under NematusGRUCell
+    # (nn/ortho_gru_cell.py:57-105 overrides call() but inherits build())
+    for name in only_reference:
+        assert "nematus_gru_cell" in name or "cond_gru_2_cell" in name, name
+    ds = dataset_of(z, cfg)
+    sess = m["tfm"].sessions[0]
+    dec, enc, att = m["dec"], m["enc"], m["att"]
+    fd = {}
+    for part in m["feedables"]:
+        fd.update(part.feed_dict(ds, train=False))
+    fetches = {"enc_output": enc.output, "train_logits": dec.train_logits, "train_loss": dec.train_loss,
+               "sym": dec.decoded_symbols, "mask": dec.runtime_mask, "logits": dec.runtime_logits,
+               "runtime_loss": dec.runtime_loss}
+    if cfg["spatial"] is None:
+        fetches["enc_states"] = enc.temporal_states
+    out = sess.run(fetches, fd)
+    if cfg["spatial"] is None:
+        close(out["enc_states"], z["out/enc_states"], "encoder temporal_states")
+    close(out["enc_output"], z["out/enc_output"], "encoder output")
+    close(out["train_logits"], z["out/train_logits"], "train_logits")
+    close(out["train_loss"], z["out/train_loss"], "train_loss")
+    assert np.array_equal(out["sym"], z["out/runtime_symbols"]), "greedy symbols"
+    assert np.array_equal(np.asarray(out["mask"]).astype(bool), z["out/runtime_mask"]), "runtime mask"
+    close(out["logits"], z["out/runtime_logits"], "runtime_logits")
+    close(out["runtime_loss"], z["out/runtime_loss"], "runtime_loss")
+
+    # the runner's sentences
+    res = m["tfm"].execute(ds, set(m["feedables"]), [m["greedy"]], train=False, compute_losses=False)[0]
+    assert [" ".join(s) for s in res.outputs["target"]] == [str(s) for s in z["out/greedy_sentences"]]
+
+    # beam search, one sentence per run as the reference executes it
+    for i in range(cfg["batch"]):
+        one = dataset_of(z, cfg, rows=[i])
+        fd1 = {}
+        for part in m["feedables"] + [m["bdec"]]:
+            fd1.update(part.feed_dict(one, train=False))
+        got = sess.run(m["bdec"].outputs, fd1)
+        pre = "out/beam{}_".format(i)
+        tok = np.asarray(got.last_search_step_output.token_ids)
+        assert np.array_equal(tok[1:], z[pre + "token_ids"][1:]), "beam token_ids of sentence {}".format(i)
+        close(np.asarray(got.last_search_step_output.scores), z[pre + "scores"], "beam scores {}".format(i))
+        close(np.asarray(got.last_search_state.logprob_sum), z[pre + "logprob_sum"], "logprob_sum {}".format(i))
+        assert np.array_equal(np.asarray(got.last_search_state.lengths), z[pre + "lengths"])
+        assert np.array_equal(np.asarray(got.last_search_state.finished).astype(bool), z[pre + "finished"])
+        res = m["tfm"].execute(one, set(m["feedables"] + [m["bdec"]]), [m["brun"]], train=False)[0]
+        want = str(z[pre + "sentence"])
+        first_is_end = z[pre + "token_ids"].shape[0] > 1 and z[pre + "token_ids"][1, 0, 0] == 2
+        if not first_is_end:            # beamsearch_runner.py:88-99 leaves raw ids there; the engine returns []
+            assert " ".join(res.outputs["hyp"][0]) == want
+        close(res.losses["hyp/beam_search_score"], z[pre + "loss"], "runner loss {}".format(i))
+
+
+def test_batched_beam_search_equals_the_per_sentence_searches_of_the_reference(dev):
+    """The engine tiles the Bahdanau keys to the beam (the reference cannot: batch 1 only); the whole batch in one
+    search has to give every sentence the result of its own batch-1 search."""
+    z, cfg, params = load("rnn_gru")
+    m = build_rnn(dev, cfg)
+    load_variables(m["store"], params)
+    ds = dataset_of(z, cfg)
+    fd = {}
+    for part in m["feedables"] + [m["bdec"]]:
+        fd.update(part.feed_dict(ds, train=False))
+    got = m["tfm"].sessions[0].run(m["bdec"].outputs, fd)
+    tok = np.asarray(got.last_search_step_output.token_ids)
+    sc = np.asarray(got.last_search_step_output.scores)
+    for i in range(cfg["batch"]):
+        want = z["out/beam{}_token_ids".format(i)]
+        n = want.shape[0]
+        fin = z["out/beam{}_finished".format(i)][0]
+        # a sentence whose beam finished early stops in the reference; inside a batch it keeps emitting <pad>
+        assert np.array_equal(tok[1:n, i], want[1:, 0])
+        assert np.all(tok[n:, i][:, fin] == 0)
+        if fin.all() or n == tok.shape[0]:
+            close(sc[i], z["out/beam{}_scores".format(i)][0], "scores of sentence {}".format(i))
+
+
+TRANSFORMER_CASES = ["transformer", "transformer_bias_untied", "transformer_shared"]
+
+
+def build_transformer(dev, cfg):
+    from neuralmonkey_amd.decoders import BeamSearchDecoder
+    from neuralmonkey_amd.decoders.transformer import TransformerDecoder
+    from neuralmonkey_amd.encoders.transformer import TransformerEncoder
+    from neuralmonkey_amd.model.sequence import EmbeddedSequence
+    from neuralmonkey_amd.runners import BeamSearchRunner
+    from neuralmonkey_amd.runtime import reset_registry
+    from neuralmonkey_amd.tf_manager import TensorFlowManager
+    reset_registry()
+    sv = vocabulary(cfg["src_vocab"])
+    tv = sv if cfg["shared_embeddings"] else vocabulary(cfg["tgt_vocab"])
+    seq = EmbeddedSequence(name="encoder_input", vocabulary=sv, data_id="source", embedding_size=cfg["dim"],
+                           scale_embeddings_by_depth=cfg["scale_embeddings"])
+    enc = TransformerEncoder(name="encoder", input_sequence=seq, ff_hidden_size=cfg["ff"], depth=cfg["depth"],
+                             n_heads=cfg["heads"], target_space_id=cfg["target_space_id"],
+                             use_att_transform_bias=cfg["use_att_transform_bias"])
+    dec = TransformerDecoder(name="decoder", encoders=[enc], vocabulary=tv, data_id="target",
+                             ff_hidden_size=cfg["ff"], n_heads_self=cfg["heads_self"], n_heads_enc=cfg["heads_enc"],
+                             depth=cfg["depth"], max_output_len=cfg["max_output_len"],
+                             embedding_size=None if cfg["shared_embeddings"] else cfg["dim"],
+                             embeddings_source=seq if cfg["shared_embeddings"] else None,
+                             tie_embeddings=cfg["tie_embeddings"],
+                             use_att_transform_bias=cfg["use_att_transform_bias"])
+    k, max_steps, alpha = cfg["beam"]
+    bdec = BeamSearchDecoder(name="beam", parent_decoder=dec, beam_size=k, max_steps=max_steps,
+                             length_normalization=alpha)
+    brun = BeamSearchRunner(output_series="hyp", decoder=bdec, rank=1)
+    tfm = TensorFlowManager(num_sessions=1, num_threads=1, device=str(dev), seed=1)
+    tfm.initialize_sessions()
+    return dict(seq=seq, enc=enc, dec=dec, bdec=bdec, brun=brun, tfm=tfm, feedables=[seq, enc, dec],
+                store=tfm.sessions[0].store)
+
+
+@pytest.mark.parametrize("case", TRANSFORMER_CASES)
+def test_transformer_engine_equals_the_reference(dev, case):
+    z, cfg, params = load(case)
+    cfg = dict(cfg, spatial=None)
+    m = build_transformer(dev, cfg)
+    assert load_variables(m["store"], params) == []
+    ds = dataset_of(z, cfg)
+    sess = m["tfm"].sessions[0]
+    enc, dec = m["enc"], m["dec"]
+    fd = {}
+    for part in m["feedables"] + [m["bdec"]]:
+        fd.update(part.feed_dict(ds, train=False))
+    out = sess.run({"enc_states": enc.temporal_states, "enc_output": enc.output, "train_logits": dec.train_logits,
+                    "train_loss": dec.train_loss, "sym": dec.decoded_symbols, "mask": dec.runtime_mask,
+                    "logits": dec.runtime_logits}, fd)
+    close(out["enc_states"], z["out/enc_states"], "encoder states")
+    close(out["enc_output"], z["out/enc_output"], "encoder output")
+    close(out["train_logits"], z["out/train_logits"], "train_logits")
+    close(out["train_loss"], z["out/train_loss"], "train_loss")
+    assert np.array_equal(out["sym"], z["out/runtime_symbols"])
+    assert np.array_equal(np.asarray(out["mask"]).astype(bool), z["out/runtime_mask"])
+    close(out["logits"], z["out/runtime_logits"], "runtime logits")
+    got = sess.run(m["bdec"].outputs, fd)
+    assert np.array_equal(np.asarray(got.last_search_step_output.token_ids)[1:], z["out/beam_token_ids"][1:])
+    close(np.asarray(got.last_search_step_output.scores), z["out/beam_scores"], "beam scores")
+    res = m["tfm"].execute(ds, set(m["feedables"] + [m["bdec"]]), [m["brun"]], train=False)[0]
+    for got_s, want, toks in zip(res.outputs["hyp"], z["out/beam_sentences"],
+                                 np.transpose(z["out/beam_token_ids"], (1, 2, 0))):
+        if toks[0][1] != 2:
+            assert " ".join(got_s) == str(want)
+    close(res.losses["hyp/beam_search_score"], z["out/beam_loss"], "runner loss")
+
+
+def test_fixture_beam_searches_are_decided_by_more_than_rounding():
+    """Oracle-side guard (CPU arithmetic, runs with the GPU tests because it qualifies THEIR exactness claim)."""
+    for case in RNN_CASES:
+        z, cfg, params = load(case)
+        from tests.test_reference_exec import general_config, source_of
+        model = G.GeneralModel(params, general_config(cfg))
+        k, max_steps, alpha = cfg["beam"]
+        for i in range(cfg["batch"]):
+            one = source_of(z, cfg, slice(i, i + 1))
+            if cfg["spatial"] is None:
+                one = one[:, :max(int(z["out/enc_mask"][i].sum()), 1)]
+            _, _, gap = model.beam(one, k, max_steps, alpha)
+            assert gap > 1e-5, "{} sentence {}: near-tie {:.2e}: regenerate with another seed".format(case, i, gap)
+    for case in TRANSFORMER_CASES:
+        z, cfg, params = load(case)
+        from tests.test_reference_exec import transformer_config
+        k, max_steps, alpha = cfg["beam"]
+        _, _, gap = T.TransformerModel(params, transformer_config(cfg)).beam(z["in/src_ids"], k, max_steps, alpha)
+        assert gap > 1e-5, "{}: near-tie {:.2e}".format(case, gap)
