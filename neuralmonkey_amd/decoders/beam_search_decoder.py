@@ -24,7 +24,7 @@ from ..model.model_part import ModelPart
 from ..runtime import Placeholder, tensor
 from ..vocabulary import END_TOKEN_INDEX, PAD_TOKEN_INDEX, START_TOKEN_INDEX, Vocabulary
 from .autoregressive import AutoregressiveDecoder, DecoderFeedables, LoopState
-from .decoder import CHECK_EVERY
+from .decoder import CHECK_EVERY, CHECK_EVERY_BEAM
 
 INF = 1e9
 
@@ -320,27 +320,21 @@ class BeamSearchDecoder(ModelPart):
                 loop["att"] = stepper.step(emb, loop["att"], out_state, logits, finished=fin[nxt].view(rows))
 
         shape_key = tuple(tuple(a.weights.shape) for a in att0)
-        steps = executed = 0
-        # ---- loop (:330-355 criterion, :394-556 body); the host checks the finished flags between chunks
-        while steps < max_steps:
-            s0, n = steps, min(CHECK_EVERY, max_steps - steps)
+        # ---- loop (:330-355 criterion, :394-556 body): the criterion is evaluated on the device, the host reads the
+        # flags one chunk behind what it has enqueued; bodies past the first all-finished one leave the search state
+        # unchanged and only append <pad> rows, which are cropped below
+        graphed = fast or indexed
+        chunk_key = key + ("chunk", k, v, shape_key, getattr(stepper, "shape_key", ()))
 
-            def chunk(s0=s0, n=n):
+        def launch(s0, n):
+            def chunk():
                 for s in range(s0, s0 + n):
                     body(s)
-            if fast or indexed:
-                ctx.session.graphed(key + ("chunk", s0, n, k, v, shape_key, getattr(stepper, "shape_key", ())), chunk)
+            if graphed:
+                ctx.session.graphed(chunk_key + (s0, n), chunk)
             else:
                 chunk()
-            steps += n
-            executed = steps
-            ctx.session.kick_ahead()               # the next batch's encoder is launched while this chunk runs
-            done = np.nonzero(ctx.session.read_small(allfin[:steps]))[0]
-            if done.size:
-                # bodies past the first all-finished one leave the search state unchanged and only
-                # append <pad> rows, which are cropped here
-                steps = int(done[0]) + 1
-                break
+        steps, executed = ctx.session.decode_chunks(max_steps, CHECK_EVERY_BEAM, launch, allfin, run_ahead=graphed)
         cur = executed & 1                                # buffers the last executed body wrote
         # token histories (:546-551) from the back-pointers, once: out[t+1, r] = word_t[ancestor_t(r)]
         ops.beam_backtrace(src_hist, word_hist, first_sym, tok, executed)

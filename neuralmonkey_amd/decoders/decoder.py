@@ -15,6 +15,8 @@ Greedy / beam decoding feed the argmax back, so every step runs the full chain.
 """
 from typing import Any, List, NamedTuple, Optional, Tuple
 
+import os
+
 import numpy as np
 import torch
 
@@ -35,7 +37,12 @@ from .encoder_projection import (EncoderProjection, concat_encoder_projection, e
 from .output_projection import OutputProjection, OutputProjectionSpec, nonlinear_output
 
 RNN_CELL_TYPES = ("NematusGRU", "GRU", "LSTM")
-CHECK_EVERY = 8       # greedy / beam: host looks at the finished flags every N steps
+# Steps per enqueued chunk (= per HIP graph) of a decoding loop.  The host reads the finished flags one chunk behind
+# what it has enqueued (Session.decode_chunks), so a chunk only has to outlast one host round trip (~0.1 ms); a batch
+# that finishes early wastes at most one chunk, hence fewer steps per chunk where a step is long.
+CHECK_EVERY = int(os.environ.get("NM_CHECK_EVERY", "8"))            # greedy RNN step ~0.1 ms
+CHECK_EVERY_BEAM = int(os.environ.get("NM_CHECK_EVERY_BEAM", "4"))  # beam-5 step ~0.35 ms (Transformer: 1.4 ms)
+CHECK_EVERY_TRANSFORMER = int(os.environ.get("NM_CHECK_EVERY_TRANSFORMER", "4"))   # cached greedy step ~0.65 ms
 
 
 class RNNFeedables(NamedTuple):
@@ -530,24 +537,20 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
                 self.embed_input_symbols(ctx, symbols[t], out=emb)
 
         shape_key = tuple(tuple(st.weights.shape) for st in att0)
-        steps = 0
-        while steps < tmax:
-            t0, n = steps, min(CHECK_EVERY, tmax - steps)
+        graphed = graph_ok or indexed
+        chunk_key = key + ("chunk", bsz, t_xent, shape_key, getattr(stepper, "shape_key", ()))
 
-            def chunk(t0=t0, n=n):
+        def launch(t0, n):
+            def chunk():
                 for t in range(t0, t0 + n):
                     body(t)
-            if graph_ok or indexed:      # the host only looks at the finished flags between chunks of steps
-                ctx.session.graphed(key + ("chunk", t0, n, bsz, t_xent, shape_key,
-                                           getattr(stepper, "shape_key", ())), chunk)
+            if graphed:                  # one HIP graph per chunk of steps
+                ctx.session.graphed(chunk_key + (t0, n), chunk)
             else:
                 chunk()
-            steps += n
-            ctx.session.kick_ahead()               # the next batch's encoder is launched while this chunk runs
-            done = np.nonzero(ctx.session.read_small(allfin[:steps]))[0]
-            if done.size:                          # loop ends after the first all-finished step
-                steps = int(done[0]) + 1
-                break
+        # the loop criterion (autoregressive.py:425-437) is evaluated on the device; the host reads the flags one
+        # chunk behind what it has enqueued
+        steps, _ = ctx.session.decode_chunks(tmax, CHECK_EVERY, launch, allfin, run_ahead=graphed)
         xent_sum = None
         if has_tgt:
             xent_sum = ctx.buffer(key + ("xent_sum",), (1,))

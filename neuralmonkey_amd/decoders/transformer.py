@@ -33,7 +33,7 @@ from ..runtime import tensor
 from ..variables import glorot_uniform_initializer, ones_initializer, zeros_initializer
 from ..vocabulary import END_TOKEN_INDEX, START_TOKEN_INDEX, Vocabulary
 from .autoregressive import AutoregressiveDecoder
-from .decoder import CHECK_EVERY, RuntimeResult, TrainResult
+from .decoder import CHECK_EVERY_TRANSFORMER, RuntimeResult, TrainResult
 
 STRATEGIES = ["serial", "parallel", "flat", "hierarchical"]
 
@@ -338,21 +338,13 @@ class TransformerDecoder(AutoregressiveDecoder):
             ops.greedy_update(argmax, finished, symbols[t], omask[t], END_TOKEN_INDEX, allfin[t:t + 1])
             self.embed_input_symbols(ctx, symbols[t], out=emb[(t + 1) & 1])
 
-        steps = 0
-        while steps < tmax:
-            t0, n = steps, min(CHECK_EVERY, tmax - steps)
-
-            def chunk(t0=t0, n=n):
+        def launch(t0, n):
+            def chunk():
                 for t in range(t0, t0 + n):
                     body(t)
-            # the host only looks at the finished flags between chunks of steps (one HIP graph per chunk)
+            # one HIP graph per chunk of steps; the host reads the finished flags one chunk behind
             ctx.session.graphed(key + ("chunk", t0, n, bsz, t_xent, stepper.shape_key), chunk)
-            steps += n
-            ctx.session.kick_ahead()
-            done = np.nonzero(ctx.session.read_small(allfin[:steps]))[0]
-            if done.size:                          # loop ends after the first all-finished step
-                steps = int(done[0]) + 1
-                break
+        steps, _ = ctx.session.decode_chunks(tmax, CHECK_EVERY_TRANSFORMER, launch, allfin)
         xent_sum = None
         if has_tgt:
             xent_sum = ctx.buffer(key + ("xent_sum",), (1,))

@@ -392,6 +392,38 @@ class Session:
         event.synchronize()
         return host.numpy().reshape(tuple(dev_tensor.shape))
 
+    def decode_chunks(self, total: int, every: int, launch, allfin: torch.Tensor, run_ahead: bool = True):
+        """The host side of ``tf.while_loop`` around a decoding body (decoders/autoregressive.py:425-437,554;
+        beam_search_decoder.py:330-355,371): ``launch(t0, n)`` enqueues steps t0 .. t0+n-1, every step leaves
+        ``allfin[t]`` != 0 when all rows were finished after it.  The loop's criterion lives on the device; what the
+        host needs is only WHEN TO STOP ENQUEUEING, so with ``run_ahead`` it reads the flags of chunk i while chunk
+        i+1 already runs (a copy enqueued behind chunk i, waited for after chunk i+1 is enqueued): the GPU never
+        waits for a flag read-back (7 of them were ~1.1 ms of a 5.8 ms greedy batch,
+        profiles/r03_decode_batch_boundary.txt).  Steps past the first all-finished one leave the loop state
+        unchanged and append <pad> rows, which the callers crop, so a batch that finishes early costs at most one
+        chunk of wasted steps.  Returns (steps of the reference's loop, steps enqueued)."""
+        steps, pending = 0, None
+        if os.environ.get("NM_DECODE_RUN_AHEAD", "1") == "0":      # A/B switch: read every chunk's own flags
+            run_ahead = False
+        while steps < total:
+            n = min(every, total - steps)
+            launch(steps, n)
+            steps += n
+            self.kick_ahead()                       # the next batch's encoder is launched while this chunk runs
+            probe = self.to_host_async(allfin[:steps])
+            if not run_ahead:
+                pending, probe = probe, None
+            if pending is not None:
+                done = np.nonzero(pending.get())[0]
+                if done.size:                       # the loop ends after the first all-finished step
+                    return int(done[0]) + 1, steps
+            pending = probe
+        if pending is not None:
+            done = np.nonzero(pending.get())[0]
+            if done.size:
+                return int(done[0]) + 1, steps
+        return steps, steps
+
     def to_host_async(self, dev_tensor: torch.Tensor) -> HostPending:
         """Start copying a small device tensor to pinned host memory; the caller reads it with ``get()`` when (if)
         it wants the values."""

@@ -12,10 +12,11 @@ pytestmark = pytest.mark.gpu
 
 def _setup(dev, vocab, emb, rnn, batch, slen, tlen, ragged, beam=3, max_steps=None, seed=7, **kw):
     from neuralmonkey_amd import synthetic
+    std = kw.pop("std", 0.08)
     model = synthetic.build_translation_model(
         vocab_src=vocab, vocab_tgt=vocab, emb=emb, rnn=rnn, max_len=max(slen, tlen), beam_size=beam,
         max_steps=max_steps or tlen, with_trainer=False, device=str(dev), **kw)
-    params = O.init_params(seed=seed, vocab_src=vocab, vocab_tgt=vocab, emb=emb, rnn=rnn, std=kw.pop("std", 0.08))
+    params = O.init_params(seed=seed, vocab_src=vocab, vocab_tgt=vocab, emb=emb, rnn=rnn, std=std)
     model.tf_manager.sessions[0].store.load_state_dict(params)
     ds = synthetic.synthetic_dataset(seed=seed + 1, batch=batch, src_len=slen, tgt_len=tlen, vocab=vocab,
                                      ragged=ragged)
@@ -365,3 +366,49 @@ def test_input_tables_follow_the_variables(dev):
                 assert sess.__dict__.get("_input_tables"), "the fused stepper did not build its input table"
         finally:
             os.environ.pop("NM_STEP_TABLES", None)
+
+
+@pytest.mark.parametrize("seed,end_bias,expect", [(7, 3.0, "early"), (8, 1.5, "mid"), (26, 2.0, "mid"),
+                                                  (7, -50.0, "full")])
+def test_loops_that_finish_early_mid_and_never_equal_the_chunk_by_chunk_path(dev, monkeypatch, seed, end_bias,
+                                                                             expect):
+    """The decoding loops enqueue one chunk of steps AHEAD of the finished-flag read-back (Session.decode_chunks);
+    whatever the step at which a batch finishes, symbols / masks / beam histories equal the path that reads every
+    chunk's flags before enqueueing the next one, and the oracle's while-loop (autoregressive.py:425-437,
+    beam_search_decoder.py:330-355)."""
+    tmax = 50
+    model, params, ds, src, tgt = _setup(dev, 96, 16, 16, 6, 9, tmax, True, beam=3, max_steps=tmax, std=0.25,
+                                         seed=seed)
+    params = dict(params)
+    b = params["decoder/state_to_word_b"].copy()
+    b[O.END] = end_bias
+    params["decoder/state_to_word_b"] = b
+    sess = model.tf_manager.sessions[0]
+    sess.store.load_state_dict(params)
+    enc = O.sentence_encoder(params, src)
+    spec = O.DecoderSpec(max_output_len=tmax)
+    ref = O.decoding_loop(params, spec, enc, None, False)
+    refb = O.beam_search(params, spec, enc, 3, tmax, 0.6)
+    steps = ref.symbols.shape[0]
+    assert {"early": steps <= 6, "mid": 8 < steps < 40, "full": steps == tmax}[expect], steps     # 4 / 10 / 15 / 50
+    fd = {}
+    for f in model.beam_runner.feedables | model.greedy_runner.feedables:
+        fd.update(f.feed_dict(ds, train=False))
+    fetch = {"sym": model.decoder.decoded_symbols, "mask": model.decoder.runtime_mask,
+             "bs": model.beam_decoder.outputs}
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NM_DECODE_RUN_AHEAD", mode)
+        for _ in range(2):                      # second run: every chunk replays its captured graph
+            got = sess.run(fetch, fd)
+        outs[mode] = (np.asarray(got["sym"]).copy(), np.asarray(got["mask"]).copy(),
+                      np.asarray(got["bs"].last_search_step_output.token_ids).copy(),
+                      np.asarray(got["bs"].last_search_step_output.scores).copy())
+    for a, b_ in zip(outs["1"], outs["0"]):
+        assert a.shape == b_.shape and np.array_equal(a, b_)
+    sym, mask, tok, _ = outs["1"]
+    assert sym.shape == ref.symbols.shape and np.array_equal(sym, ref.symbols)
+    assert np.array_equal(mask.astype(bool), ref.mask)
+    assert tok.shape == refb.token_ids.shape
+    if refb.min_gap > 1e-5:
+        assert np.array_equal(tok[1:], refb.token_ids[1:])

@@ -1,5 +1,13 @@
-"""Where the host time between two greedy batches goes: timestamps around the chunk launches and flag reads
-(monkeypatched ``Session.graphed`` / ``Session.read_small``), relative to the start of ``execute``."""
+"""Where the time of a decoding batch goes, host side and GPU side, without a profiler attached (rocprofv3 slows
+HIP-graph launches by milliseconds): ``Session.decode_chunks`` (the loop of step chunks) is wrapped with a HIP event
+on either side and host time stamps; flag read-backs (``HostPending.get``) are timed on the host.
+
+    python tools/batch_boundary_probe.py greedy|beam [batches=8]
+
+Per batch: wall time of ``execute``; host time from entry to the loop, inside the loop, from the loop to the return;
+GPU time of the loop itself (event to event) and GPU time between the end of the previous batch's loop and the start
+of this one (what of the encoder / set-up / result hand-over is NOT hidden under decoding); host time spent waiting
+for flag read-backs."""
 import os
 import sys
 import time
@@ -9,11 +17,10 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from neuralmonkey_amd import runtime, synthetic  # noqa: E402
 
-LOG = []
-
 
 def main():
     mode = sys.argv[1] if len(sys.argv) > 1 else "greedy"
+    batches = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     model = synthetic.build_translation_model(vocab_src=32000, vocab_tgt=32000, emb=512, rnn=512, max_len=50,
                                               beam_size=5, max_steps=50, length_normalization=0.6, device="cuda:0")
     store = model.tf_manager.sessions[0].store
@@ -23,49 +30,52 @@ def main():
                                         with_target=False) for i in range(2)]
     tfm = model.tf_manager
     runner = model.beam_runner if mode == "beam" else model.greedy_runner
+    ahead = not os.environ.get("NM_NO_LOOKAHEAD")
     run = lambda i: tfm.execute(sets[i % 2], runner.feedables, [runner], compute_losses=False,
-                                lookahead=sets[(i + 1) % 2])
+                                lookahead=sets[(i + 1) % 2] if ahead else None)
     for i in range(5):
         run(i)
     torch.cuda.synchronize()
-    g0, r0 = runtime.Session.graphed, runtime.Session.read_small
 
-    def graphed(self, key, fn):
-        LOG.append(("launch", time.perf_counter()))
-        return g0(self, key, fn)
+    log = []
+    cur = {}
+    d0, g0 = runtime.Session.decode_chunks, runtime.HostPending.get
 
-    def read_small(self, t):
-        LOG.append(("read>", time.perf_counter()))
-        out = r0(self, t)
-        LOG.append(("read<", time.perf_counter()))
+    def decode_chunks(self, *a, **k):
+        cur["loop_in"] = time.perf_counter()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = d0(self, *a, **k)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        cur["loop_out"] = time.perf_counter()
+        cur["ev"] = (e0, e1)
         return out
-    runtime.Session.graphed, runtime.Session.read_small = graphed, read_small
-    marks = []
-    for i in range(6):
-        LOG.append(("exec>", time.perf_counter()))
+
+    def get(self):
+        t = time.perf_counter()
+        out = g0(self)
+        cur["wait"] = cur.get("wait", 0.0) + time.perf_counter() - t
+        cur["reads"] = cur.get("reads", 0) + 1
+        return out
+    runtime.Session.decode_chunks, runtime.HostPending.get = decode_chunks, get
+    for i in range(batches):
+        cur = {"t0": time.perf_counter()}
         run(i)
-        LOG.append(("exec<", time.perf_counter()))
+        cur["t1"] = time.perf_counter()
+        log.append(cur)
     torch.cuda.synchronize()
-    # per batch: exec> -> first launch, last read< -> exec<, read waits
-    batches, cur = [], None
-    for name, t in LOG:
-        if name == "exec>":
-            cur = {"t0": t, "ev": []}
-        elif name == "exec<":
-            cur["t1"] = t
-            batches.append(cur)
-        else:
-            cur["ev"].append((name, t))
-    for b in batches[1:]:
-        ev = b["ev"]
-        first_launch = next(t for n, t in ev if n == "launch")
-        last_read = [t for n, t in ev if n == "read<"][-1]
-        waits = sum(t2 - t1 for (n1, t1), (n2, t2) in zip(ev, ev[1:]) if n1 == "read>" and n2 == "read<")
-        gaps = [t2 - t1 for (n1, t1), (n2, t2) in zip(ev, ev[1:]) if n1 == "read<" and n2 == "launch"]
-        print("{}: batch {:.2f} ms | entry -> first launch {:.0f} us | {} flag reads waiting {:.2f} ms | read -> next launch "
-              "{:.0f} us each | last read -> return {:.0f} us".format(
-                  mode, (b["t1"] - b["t0"]) * 1e3, (first_launch - b["t0"]) * 1e6, len(gaps) + 1, waits * 1e3,
-                  1e6 * sum(gaps) / max(len(gaps), 1), (b["t1"] - last_read) * 1e6))
+    prev_end = None
+    for b in log:
+        e0, e1 = b["ev"]
+        loop_gpu = e0.elapsed_time(e1)
+        between = prev_end.elapsed_time(e0) if prev_end is not None else float("nan")
+        prev_end = e1
+        print("{}: batch {:.2f} ms | host: entry->loop {:.0f} us, in loop {:.2f} ms ({} flag reads waiting {:.2f} ms), "
+              "loop->return {:.0f} us | GPU: loop {:.2f} ms, previous loop end -> this loop start {:.2f} ms".format(
+                  mode, (b["t1"] - b["t0"]) * 1e3, (b["loop_in"] - b["t0"]) * 1e6,
+                  (b["loop_out"] - b["loop_in"]) * 1e3, b.get("reads", 0), b.get("wait", 0.0) * 1e3,
+                  (b["t1"] - b["loop_out"]) * 1e6, loop_gpu, between))
 
 
 if __name__ == "__main__":
