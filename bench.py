@@ -17,14 +17,18 @@ strings, the reference's feeding model) is reported next to it.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line (rank 0) with
-  ``roofline``       the fused Bahdanau attention step (everything nm_attn_fwd launches: split-S
-                     partial kernel + combine), HBM-bound, timed live with HIP events on its stream:
-                     ``achieved_warm`` inside a greedy decode (keys sit in the 256 MB Infinity
-                     Cache between steps), ``achieved_cold`` with a 1 GB sweep between launches
-                     (keys come from HBM); ``achieved`` / ``frac`` are the COLD figures;
+  ``roofline``       the fused Bahdanau attention step (nm_attn_fwd = ONE launch of attn_whole_fast<13>:
+                     score + softmax + mask-renorm + context of a decoding step), HBM-bound, timed live
+                     with HIP events on its stream: ``achieved`` / ``frac`` = 32 back-to-back launches
+                     over 8 key / value sets that evict each other (cold, one event pair around the
+                     sequence); ``achieved_warm`` inside a greedy decode (keys sit in the 256 MB Infinity
+                     Cache between steps), ``achieved_cold_single`` one launch behind a 1 GB sweep;
+                     ``traffic`` and ``rocprof_kernel_us`` from the newest committed rocprofv3 passes of
+                     the same kernel (tools/attn_evidence.sh -> profiles/rNN_attn_step_*.json);
   ``roofline_step``  the whole greedy decoder step against its ~165 MB of algorithmic traffic;
   ``cpu_baseline``   torch-CPU / NumPy restatement of the reference's step (NOT TF 1.12 -- TF cannot
-                     be installed here) on the headline batch (B=128), median of 3 after 1 warm-up;
+                     be installed here) on the headline batch (B=128): SURVEY 8(d)'s protocol (8 threads,
+                     median of 5 after 2 warm-ups) on a bounded sample, next to it all host threads;
   ``configs``        BASELINE configs[3] (captioning) and configs[4] (Transformer-base) at their own shapes:
                      training step, greedy and beam-5 decoding, each with its own roofline.
 """
@@ -46,6 +50,13 @@ MFMA_F32_PEAK_TF = 157.3      # fp32 matrix peak (v_mfma_f32_32x32x2_f32), same 
 NUM_BATCHES = 8               # distinct batches rotated through the timed loop
 
 
+def newest_profile(pattern):
+    """Newest round's committed evidence file matching ``profiles/<pattern>`` (rNN_ prefixes sort by round)."""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return hits[-1] if hits else None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,7 +73,9 @@ def parse():
     ap.add_argument("--beam-batches", type=int, default=4, help="beam-5 decode batches to time (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=128, help="sentences of the CPU baseline's training sample")
-    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU training steps (after 1 warm-up)")
+    ap.add_argument("--cpu-steps", type=int, default=2, help="timed full-batch CPU training steps on all threads "
+                                                             "(after 1 warm-up)")
+    ap.add_argument("--cpu-sample", type=int, default=16, help="sentences of the 8-thread CPU baseline's sample")
     ap.add_argument("--cpu-beam-batch", type=int, default=16, help="sentences of the CPU baseline's beam-5 sample")
     ap.add_argument("--no-feed-legs", action="store_true", help="skip the fresh / strings feeding legs")
     ap.add_argument("--no-configs", action="store_true",
@@ -88,28 +101,42 @@ def decoder_step_bytes(b, s, h, v):
 def cpu_baseline(args):
     """The reference's step restated for the host CPU at the reference's op granularity (per-step cell /
     attention / projection / logits): training = oracle/torch_ref.py (torch-CPU fp32, autograd), beam-5 =
-    oracle/nm_oracle.py (NumPy).  Bounded sample of the SAME workload as the GPU leg: the headline batch
-    (``--cpu-batch`` = 128 sentences, all lengths 50, V and H as timed on the GPU), median of ``--cpu-steps``
-    optimizer steps after one warm-up; beam-5 on ``--cpu-beam-batch`` sentences x 50 steps, one pass."""
+    oracle/nm_oracle.py (NumPy).  NOT TensorFlow 1.12 (cannot be installed here).
+
+    Primary figure = SURVEY 8(d)'s protocol: ``torch.set_num_threads(8)``, median of 5 optimizer steps after 2
+    warm-ups, on a BOUNDED SAMPLE of the headline workload -- ``--cpu-sample`` (16) of the batch's 128 sentences, all
+    lengths 50, V and H as timed on the GPU (the full batch takes ~15 s per step on the host: seven of them would
+    not fit the few minutes a default run may take).  Next to it (``all_threads``): the full headline batch on every
+    host thread, median of ``--cpu-steps`` after 1 warm-up -- faster per token, but it wanders with whatever else
+    the host is doing.  Beam-5: ``--cpu-beam-batch`` sentences x 50 steps, NumPy, one pass."""
     from oracle import nm_oracle as O
     from oracle import torch_ref as TR
-    h, bsz = args.hidden, args.cpu_batch
+    h = args.hidden
     params = O.init_params(seed=1234, vocab_src=args.vocab, vocab_tgt=args.vocab, emb=h, rnn=h)
-    src, tgt_tb = O.synthetic_batch(seed=1234, batch=bsz, src_len=args.length, tgt_len=args.length,
+    src, tgt_tb = O.synthetic_batch(seed=1234, batch=args.cpu_batch, src_len=args.length, tgt_len=args.length,
                                     vocab=args.vocab, ragged=False)
-    tp = TR.to_torch(params)
-    m = {k: torch.zeros_like(v) for k, v in tp.items()}
-    v = {k: torch.zeros_like(x) for k, x in tp.items()}
-    times = []
-    for step in range(1, 1 + args.cpu_steps + 1):
-        t0 = time.perf_counter()
-        _, _, _, grads = TR.train_step_grads(tp, src, tgt_tb, l1_weight=0.0, l2_weight=1e-8)
-        TR.clip_and_adam(tp, grads, m, v, step, 1.0)
-        times.append(time.perf_counter() - t0)
-    sec = float(np.median(times[1:]))
-    tokens = bsz * args.length
+
+    def steps(bsz, warm, timed):
+        tp = TR.to_torch(params)
+        m = {k: torch.zeros_like(v) for k, v in tp.items()}
+        v = {k: torch.zeros_like(x) for k, x in tp.items()}
+        times = []
+        for step in range(1, warm + timed + 1):
+            t0 = time.perf_counter()
+            _, _, _, grads = TR.train_step_grads(tp, src[:bsz], tgt_tb[:, :bsz], l1_weight=0.0, l2_weight=1e-8)
+            TR.clip_and_adam(tp, grads, m, v, step, 1.0)
+            times.append(time.perf_counter() - t0)
+        return float(np.median(times[warm:]))
+    all_threads = torch.get_num_threads()
+    sample = max(1, min(args.cpu_batch, args.cpu_sample))
+    torch.set_num_threads(8)
+    try:
+        sec8 = steps(sample, 2, 5)
+    finally:
+        torch.set_num_threads(all_threads)
+    sec_all = steps(args.cpu_batch, 1, args.cpu_steps)
     # beam-5 over the full 50 steps (</s> unreachable, as in the GPU leg)
-    bb = max(1, min(bsz, args.cpu_beam_batch))
+    bb = max(1, min(args.cpu_batch, args.cpu_beam_batch))
     pb = dict(params)
     bias = pb["decoder/state_to_word_b"].copy()
     bias[O.END] = -1e9
@@ -118,12 +145,16 @@ def cpu_baseline(args):
     t0 = time.perf_counter()
     O.beam_search(pb, O.DecoderSpec(max_output_len=args.length), enc, 5, args.length, 0.6)
     beam_sec = time.perf_counter() - t0
-    return {"value": tokens / sec, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "training: the headline batch, B={} sentences x len {} (ragged=False as on the GPU), V={} H={}, "
-                      "median of {} optimizer steps after 1 warm-up, torch-CPU fp32 restatement of the reference "
-                      "step, not TF 1.12; beam-5: {} sentences x {} steps, NumPy restatement, one pass".format(
-                          bsz, args.length, args.vocab, h, args.cpu_steps, bb, args.length),
-            "sec_per_step": sec, "beam5_tok_s": bb * args.length / beam_sec, "beam5_sec": beam_sec}
+    return {"value": sample * args.length / sec8, "unit": "tokens/s", "cores": 8, "kind": "port",
+            "sample": "training: {} of the headline batch's 128 sentences x len {} (ragged=False as on the GPU), V={} "
+                      "H={}, torch.set_num_threads(8), median of 5 optimizer steps after 2 warm-ups (SURVEY 8d), "
+                      "torch-CPU fp32 restatement of the reference step, not TF 1.12; beam-5: {} sentences x {} steps, "
+                      "NumPy restatement, one pass".format(sample, args.length, args.vocab, h, bb, args.length),
+            "sec_per_step": sec8,
+            "all_threads": {"value": args.cpu_batch * args.length / sec_all, "unit": "tokens/s", "cores": all_threads,
+                            "sample": "the full headline batch, B={}, median of {} steps after 1 warm-up".format(
+                                args.cpu_batch, args.cpu_steps), "sec_per_step": sec_all},
+            "beam5_tok_s": bb * args.length / beam_sec, "beam5_sec": beam_sec}
 
 
 def _timed_gpu(fn, warm, reps):
@@ -228,7 +259,45 @@ def captioning_leg(args, dev, lib):
     s, c = shape[0] * shape[1], shape[2]
     nbytes = attention_step_bytes(batch, s, asz, c)
     att_us = (tot_ms.value * 1e3 / cnt.value) if cnt.value else None
-    gbps = (nbytes / (att_us * 1e-6) / 1e9) if att_us else None
+    warm_gbps = (nbytes / (att_us * 1e-6) / 1e9) if att_us else None
+    # COLD: launches back to back over NSETS distinct key / value sets (4 x 84 MB > the 256 MB Infinity Cache: a set
+    # is evicted before its next visit), one event pair around the sequence -- the protocol of the headline figure
+    from neuralmonkey_amd import ops
+    gen = torch.Generator(device=dev).manual_seed(7)
+    NSETS, ROUNDS = 4, 6
+    sets = [(torch.randn(batch, s, asz, device=dev, generator=gen), torch.randn(batch, s, c, device=dev, generator=gen))
+            for _ in range(NSETS)]
+    y = torch.randn(batch, asz, device=dev, generator=gen)
+    vv = torch.randn(asz, device=dev, generator=gen)
+    mask, bias = torch.ones(batch, s, device=dev), torch.zeros(1, device=dev)
+    ctx_o, wts = torch.empty(batch, c, device=dev), torch.empty(batch, s, device=dev)
+    ws = ops.attn_workspace(batch, s, c, dev)
+
+    def rotate(rounds):
+        for i in range(rounds * NSETS):
+            ops.attn_fwd(y, sets[i % NSETS][0], sets[i % NSETS][1], mask, vv, bias, 1, ctx_o, wts, ws)
+    rotate(1)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    rotate(ROUNDS)
+    ev1.record()
+    torch.cuda.synchronize()
+    cold_us = ev0.elapsed_time(ev1) * 1e3 / (ROUNDS * NSETS)
+    cold_gbps = nbytes / (cold_us * 1e-6) / 1e9
+    del sets
+    traffic, rocprof_us, files = None, {}, []
+    pmc = newest_profile("r[0-9][0-9]_attn_cap_pmc_cold.json")
+    if pmc:
+        with open(pmc) as fh:
+            traffic = json.load(fh).get("hbm_bytes_per_launch")
+        files.append(os.path.relpath(pmc, ROOT))
+    for mode in ("cold", "warm", "dirty"):
+        path = newest_profile("r[0-9][0-9]_attn_cap_trace_{}.json".format(mode))
+        if path:
+            with open(path) as fh:
+                rocprof_us[mode] = json.load(fh).get("sum_avg_us")
+            files.append(os.path.relpath(path, ROOT))
     tokens = batch * length
     return {"workload": "tests/captioning.ini-shape: 8x8x2048 maps (N(0,1) clipped at 0) -> SpatialFiller -> Attention("
                         "state {}) -> GRU-512 decoder, B={}, target len={}, V={}, CrossEntropyTrainer + Adam".format(
@@ -239,12 +308,16 @@ def captioning_leg(args, dev, lib):
             "greedy_tok_s": batch * out["greedy"][1] / out["greedy"][0],
             "beam5_ms_per_batch": out["beam5"][0] * 1e3, "beam5_steps": out["beam5"][1],
             "beam5_tok_s": batch * out["beam5"][1] / out["beam5"][0],
-            "roofline": {"bound": "hbm", "kernel": "nm_attn_fwd at S=64, A={}, C=2048 (one decoding step, warm: the maps "
-                                                   "stay in the Infinity Cache between steps), HIP events on the launch "
-                                                   "stream around single calls (event-pair cost included)".format(asz),
-                         "algorithmic_bytes_per_launch": nbytes, "launch_us": att_us, "launches": cnt.value,
-                         "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": (gbps / HBM_PEAK_GBPS) if gbps else None}}
+            "roofline": {"bound": "hbm", "kernel": "nm_attn_fwd at S=64, A={}, C=2048 (one decoding step)".format(asz),
+                         "timing": "COLD: {} back-to-back launches over {} key / value sets that evict each other "
+                                   "(one HIP event pair on the launch stream around the sequence); achieved_warm: "
+                                   "inside a greedy decode (the maps stay in the Infinity Cache between steps), event "
+                                   "pairs around single calls (event-pair cost included)".format(ROUNDS * NSETS, NSETS),
+                         "algorithmic_bytes_per_launch": nbytes, "launch_us": cold_us, "launches": ROUNDS * NSETS,
+                         "achieved": cold_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": cold_gbps / HBM_PEAK_GBPS,
+                         "achieved_warm": warm_gbps, "launch_us_warm": att_us,
+                         "traffic": traffic, "rocprof_kernel_us": rocprof_us or None,
+                         "evidence": files or None}}
 
 
 def main():
@@ -307,7 +380,7 @@ def main():
         return time.perf_counter() - t0, out
 
     # ---- beam-5 decode throughput (emitted rank-1 tokens up to and incl. </s>)
-    beam_tok_s = beam_ms_per_batch = None
+    beam_tok_s = beam_ms_per_batch = beam_b1_ms = None
     logit_b = store["decoder/state_to_word_b"]
     if args.beam_batches > 0:
         runner = model.beam_runner
@@ -340,6 +413,20 @@ def main():
             tb, emitted = float(tmax[0].item()), float(t[1].item())
         beam_tok_s = emitted / tb
         beam_ms_per_batch = tb / args.beam_batches * 1e3
+        # the reference-compatible regime: the reference cannot tile Bahdanau keys to a beam
+        # and runs its RNN beam search one sentence at a time -- the same search at batch 1 here (5 hypothesis rows)
+        if rank == 0:
+            ones = [synthetic.synthetic_dataset(seed=777 + i, batch=1, src_len=args.length, tgt_len=args.length,
+                                                vocab=args.vocab, with_target=False) for i in range(4)]
+            for i in range(6):
+                tfm.execute(ones[i % 4], runner.feedables, [runner], compute_losses=False)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n1 = 16
+            for i in range(n1):
+                tfm.execute(ones[i % 4], runner.feedables, [runner], compute_losses=False)
+            torch.cuda.synchronize()
+            beam_b1_ms = (time.perf_counter() - t1) / n1 * 1e3
         logit_b[2] = saved_end_bias
 
     # ---- training: the headline number.  All NUM_BATCHES batches are uploaded first (feed dicts built,
@@ -550,18 +637,21 @@ def main():
         gbps = lambda us: (step_bytes / (us * 1e-6) / 1e9) if us else None
         warm, cold, rot = gbps(warm_us), gbps(cold_us), gbps(rot_us)
         traffic = pmc_kernels = None
-        pmc = os.path.join(ROOT, "profiles", "attn_step_pmc.json")
+        pmc = newest_profile("r[0-9][0-9]_attn_step_pmc_cold.json") or os.path.join(ROOT, "profiles", "attn_step_pmc.json")
         if os.path.exists(pmc):
             with open(pmc) as fh:
                 rec = json.load(fh)
             traffic, pmc_kernels = rec.get("hbm_bytes_per_launch"), rec.get("kernels")
-        # rocprofv3 kernel durations of the same launches (committed summaries of separate profiled runs)
-        rocprof_us = {}
+        # rocprofv3 kernel durations of the same launches (committed summaries of separate profiled runs:
+        # tools/attn_evidence.sh, the newest round's files)
+        rocprof_us, rocprof_files = {}, []
         for mode in ("cold", "warm", "dirty"):
-            path = os.path.join(ROOT, "profiles", "r02_attn_step_trace_{}_v4.json".format(mode))
+            path = newest_profile("r[0-9][0-9]_attn_step_trace_{}.json".format(mode)) or \
+                os.path.join(ROOT, "profiles", "r02_attn_step_trace_{}_v4.json".format(mode))
             if os.path.exists(path):
                 with open(path) as fh:
                     rocprof_us[mode] = json.load(fh).get("sum_avg_us")
+                rocprof_files.append(os.path.relpath(path, ROOT))
         dstep_bytes = decoder_step_bytes(args.batch, args.length, h, args.vocab)
         dstep_us = greedy_ms * 1e3 / args.length
         line = {
@@ -581,6 +671,8 @@ def main():
             "dp": dp_report, "other_scaling": other,
             "ms_per_step_fresh": fresh_ms, "ms_per_step_strings": strings_ms,
             "beam5_decode_tok_s": beam_tok_s, "beam5_ms_per_batch": beam_ms_per_batch,
+            "beam5_batch1_ms_per_sentence": beam_b1_ms,
+            "beam5_batch1_tok_s": (args.length / (beam_b1_ms * 1e-3)) if beam_b1_ms else None,
             "greedy_decode_tok_s": tokens_local / (greedy_ms * 1e-3), "greedy_ms_per_batch": greedy_ms,
             "roofline": {"kernel": "nm_attn_fwd = attn_whole_fast<13>, ONE launch (fused Bahdanau score + softmax + "
                                    "mask-renorm + context of one decoding step; one 1024-thread workgroup per sentence: "
@@ -588,14 +680,13 @@ def main():
                                    "kernel with its in-kernel merge)",
                          "timing": "HIP events on the launch stream (the library's recorder around single calls, one "
                                    "torch.cuda.Event pair -- torch's current stream IS the launch stream -- around the "
-                                   "back-to-back sequence); rocprofv3 kernel durations of the same kernel: "
-                                   "profiles/r02_attn_step_trace_{cold,warm,dirty}_v4.json, repeated in "
-                                   "rocprof_kernel_us",
+                                   "back-to-back sequence); rocprofv3 kernel durations of the same kernel: {}, "
+                                   "repeated in rocprof_kernel_us".format(", ".join(rocprof_files)),
                          "bound": "hbm", "achieved": rot, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (rot / HBM_PEAK_GBPS) if rot else None, "traffic": traffic,
                          "traffic_how": "HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                         "passes (gfx950 wide-read correction applied), read from the committed "
-                                        "profiles/attn_step_pmc.json -- NOT counted during this run",
+                                        "{} -- NOT counted during this run".format(os.path.relpath(pmc, ROOT)),
                          "achieved_how": "cold, back to back: {} launches over {} distinct key / value sets (428 MB, "
                                          "round-robin: a set's lines are evicted from L2 and the 256 MB Infinity Cache "
                                          "before its next visit), ONE HIP-event pair on the launch stream around the "

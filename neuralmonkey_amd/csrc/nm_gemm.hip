@@ -73,7 +73,18 @@ __device__ __forceinline__ void store_tile32(const GemmArgs& g, float* __restric
 // tiled kernel
 // ---------------------------------------------------------------------------
 // WM x WN waves, each owning TM x TN MFMA tiles of 32x32: block tile (WM*32*TM) x (WN*32*TN).
-template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool VEC, int BK, bool STATS = false, int PF = 1>
+// NCH > 1: interleaved accumulation chains.  v_mfma_f32_32x32x2_f32 adds the products of a k-chain to its accumulator
+// one after the other, so a K-long dot product is a K-long chain of fp32 roundings (rms error ~ u K / sqrt(2) of the
+// term size; a blocked CPU sgemm keeps 16+ partial sums per dot product).  With NCH accumulator sets, k-tile t goes to
+// set t mod NCH and the sets are added once at the end: NCH independent chains of K / NCH products, error down by
+// sqrt(NCH), no vector instruction inside the loop (a periodic "acc2 += acc; acc = 0" flush was tried first: hipcc
+// then moves the accumulators out of the AGPRs and the 64x64 kernel goes from 30 to 84 VGPRs, occupancy 8 -> 4,
+// Transformer-base step 31.1 -> 32.9 ms).  profiles/r04_transformer_noise_ablation.txt: with the dense products
+// exact the median error of the Transformer-base logits is the 1.4e-5 of a torch-CPU fp32 implementation instead of
+// 2.3e-5 -- the accumulation order of the products is what made the engine "2x noisier".  Costs (NCH - 1) * TM * TN *
+// 16 accumulator registers: used for the 64x64 tiles only.
+template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool VEC, int BK, bool STATS = false, int PF = 1,
+          int NCH = 1>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_tiled(GemmArgs g, int tiles_m) {
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * 32 * TM, BN = WN * 32 * TN;
@@ -223,13 +234,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tiled(GemmArgs g, int tiles
         }
     };
 
-    f32x16 acc[TM][TN];
+    static_assert(NCH == 1 || NCH == 2 || NCH == 4, "accumulation chains: 1, 2 or 4");
+    static_assert(NCH == 1 || PF == 1, "chains are implemented for the one-tile-ahead loop");
+    f32x16 accs[NCH][TM][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int c = 0; c < NCH; ++c)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accs[c][i][j][r] = 0.0f;
+    f32x16 (&acc)[TM][TN] = accs[0];
 
     const int wm = (wave / WN) * 32 * TM, wn = (wave % WN) * 32 * TN;
     // split-K: slice blockIdx.y owns k-tiles [kt0, nkt)
@@ -240,7 +256,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tiled(GemmArgs g, int tiles
 
     // one k-tile of MFMA work on LDS buffer `cur`: fragments of the next k-pair are read from LDS before
     // the MFMAs of the current pair are issued, so the LDS latency sits under 4 x 64 cycles of matrix work
-    auto mma_tile = [&](int cur) {
+    auto mma_tile = [&](int cur, f32x16 (&acc)[TM][TN]) {
         float a[2][TM], b[2][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) a[0][i] = As[cur][lane >> 5][wm + i * 32 + (lane & 31)];
@@ -279,25 +295,51 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tiled(GemmArgs g, int tiles
         int kt = kt0;
         while (kt < nkt) {
             if (kt + 2 < nkt) { load_a((kt + 2) * BK, ra0); load_b((kt + 2) * BK, rb0); }
-            mma_tile(0);
+            mma_tile(0, accs[0]);
             if (kt + 1 < nkt) store_lds(1, ra1, rb1);
             __syncthreads();
             if (++kt >= nkt) break;
             if (kt + 2 < nkt) { load_a((kt + 2) * BK, ra1); load_b((kt + 2) * BK, rb1); }
-            mma_tile(1);
+            mma_tile(1, accs[0]);
             if (kt + 1 < nkt) store_lds(0, ra0, rb0);
             __syncthreads();
             ++kt;
         }
-    } else {
+    } else if constexpr (NCH == 1) {
         int cur = 0;
         for (int kt = kt0; kt < nkt; ++kt) {
             if (kt + 1 < nkt) { load_a((kt + 1) * BK, ra0); load_b((kt + 1) * BK, rb0); }
-            mma_tile(cur);
+            mma_tile(cur, accs[0]);
             if (kt + 1 < nkt) store_lds(cur ^ 1, ra0, rb0);
             __syncthreads();
             cur ^= 1;
         }
+    } else {
+        // the loop unrolled NCH times: k-tile kt0 + t accumulates into set t mod NCH (LDS buffer t mod 2)
+        int kt = kt0;
+        while (kt < nkt) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                if (kt + 1 < nkt) { load_a((kt + 1) * BK, ra0); load_b((kt + 1) * BK, rb0); }
+                mma_tile(c & 1, accs[c]);
+                if (kt + 1 < nkt) store_lds((c & 1) ^ 1, ra0, rb0);
+                __syncthreads();
+                if (++kt >= nkt) break;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (NCH == 4) {       // (0 + 1) + (2 + 3): a fixed order
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        accs[0][i][j][r] = (accs[0][i][j][r] + accs[1][i][j][r]) + (accs[2][i][j][r] + accs[3][i][j][r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accs[0][i][j][r] += accs[1][i][j][r];
+                }
+            }
     }
 
     if (g.splitk > 1) {          // raw partial sums into this slice's slab; epilogue in splitk_reduce
@@ -904,12 +946,12 @@ static void launch_skinny(const GemmArgs& g, int batch, bool tb, const GruEpi& e
 #undef NM_GS
 }
 
-template <int WM, int WN, int TM, int TN, int BK, int PF = 1>
+template <int WM, int WN, int TM, int TN, int BK, int PF = 1, int NCH = 1>
 static void launch_tiled(const GemmArgs& g, int batch, bool ta, bool tb, bool vec, hipStream_t st) {
     const int tiles_m = nm_cdiv(g.M, WM * 32 * TM), tiles_n = nm_cdiv(g.N, WN * 32 * TN);
     dim3 grid(tiles_m * tiles_n, g.splitk, batch), block(WM * WN * 64);
 #define NM_GT(TA_, TB_, V_) \
-    hipLaunchKernelGGL((gemm_tiled<WM, WN, TM, TN, TA_, TB_, V_, BK, false, PF>), grid, block, 0, st, g, tiles_m)
+    hipLaunchKernelGGL((gemm_tiled<WM, WN, TM, TN, TA_, TB_, V_, BK, false, PF, NCH>), grid, block, 0, st, g, tiles_m)
     if (vec) {
         if (!ta && !tb) NM_GT(false, false, true);
         else if (!ta && tb) NM_GT(false, true, true);
@@ -1018,6 +1060,10 @@ extern "C" int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int6
             else if (cfg_env == 8) launch_tiled<2, 2, 2, 2, 16, 2>(g, (int)batch, ta, tb, vec, st); // 128x128, 4 waves, 2 ahead
             else if (cfg_env == 9) launch_tiled<4, 2, 1, 2, 32, 2>(g, (int)batch, ta, tb, vec, st); // cfg 4, 2 ahead
             else launch_tiled<2, 2, 2, 2, 16>(g, (int)batch, ta, tb, vec, st);                     // 128x128, 4 waves
+        } else if (sw.gemm_chains == 4) {
+            launch_tiled<2, 2, 1, 1, 16, 1, 4>(g, (int)batch, ta, tb, vec, st);                    // 64x64, 4 chains
+        } else if (sw.gemm_chains == 2) {
+            launch_tiled<2, 2, 1, 1, 16, 1, 2>(g, (int)batch, ta, tb, vec, st);                    // 64x64, 2 chains
         } else {
             launch_tiled<2, 2, 1, 1, 16>(g, (int)batch, ta, tb, vec, st);                          // 64x64
         }

@@ -29,6 +29,7 @@ static void switches_from_env(NmSwitches* sw) {
     sw->gemm_nostore = getenv("NM_GEMM_NOSTORE") != nullptr;
     sw->gemm_sk = env_int("NM_GEMM_SK", 0);
     sw->gemm_cfg = env_int("NM_GEMM_CFG", 1);
+    sw->gemm_chains = env_int("NM_GEMM_CHAINS", 2);
     sw->stats_cfg = env_int("NM_STATS_CFG", 3);
     sw->stats_ablate = getenv("NM_STATS_ABLATE") != nullptr;
     sw->beam_ns = env_int("NM_BEAM_NS", 0);
@@ -135,7 +136,7 @@ extern "C" int nm_ctx_switch(void* ctx, const char* name, int* value) {
         {"attn_maxrows", s.attn_maxrows}, {"attn_nomerge", s.attn_nomerge}, {"attn_nofast", s.attn_nofast},
         {"attn_whole", s.attn_whole}, {"aeb_wide_off", s.aeb_wide_off}, {"gemm_no16", s.gemm_no16},
         {"gemm_swz", s.gemm_swz}, {"gemm_nostore", s.gemm_nostore}, {"gemm_sk", s.gemm_sk},
-        {"gemm_cfg", s.gemm_cfg}, {"stats_cfg", s.stats_cfg}, {"stats_ablate", s.stats_ablate},
+        {"gemm_cfg", s.gemm_cfg}, {"gemm_chains", s.gemm_chains}, {"stats_cfg", s.stats_cfg}, {"stats_ablate", s.stats_ablate},
         {"beam_ns", s.beam_ns}, {"sdp_mfma", s.sdp_mfma}, {"medium_m", s.medium_m},
         {"sdp_decode", s.sdp_decode}};
     for (auto& t : tab)

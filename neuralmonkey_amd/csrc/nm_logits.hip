@@ -388,11 +388,12 @@ extern "C" int nm_xent_colsum(void* stream, float* logits, int64_t ldx, int64_t 
     const int nv = (int)((V / 4 + XC_NT - 1) / XC_NT);
 #define NM_XC(NV_)                                                                                                    \
     do {                                                                                                              \
-        static bool attr_set = false;                                                                                 \
-        if (!attr_set) {                                                                                              \
+        static unsigned attr_devs = 0; /* per device */                                                               \
+        const unsigned attr_bit = 1u << (nm_cur()->device & 31);                                                      \
+        if (!(attr_devs & attr_bit)) {                                                                                \
             (void)hipFuncSetAttribute((const void*)xent_cols_kernel<NV_>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                       144 * 1024);                                                                    \
-            attr_set = true;                                                                                          \
+            attr_devs |= attr_bit;                                                                                    \
         }                                                                                                             \
         hipLaunchKernelGGL((xent_cols_kernel<NV_>), dim3((unsigned)partial_rows), dim3(XC_NT), (size_t)V * 4,           \
                            nm_stream(stream), logits, (long)ldx, (int)V, (int)rows, targets, weights, loss_rows,      \

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void sdp_fwd_kernel(SdpArgs p) {
         // each lane only revisits the entries it wrote itself until the barrier
         float se = 0.0f;
         for (int j = lane; active && j < p.Tk; j += 64) {
-            const float ex = __expf(ww[j] - mx);
+            const float ex = expf(ww[j] - mx);
             ww[j] = ex;
             se += ex;
         }
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(1024) void sdp_decode_kernel(SdpArgs p, const int* 
                     e = sdp_masked_energy(p, e, 0, j, mk[u]);
                     if (wg && sub == 0) wg[j] = e;                          // normalised below, by the same lane
                     const float mn = fmaxf(m, e);
-                    const float sc = __expf(m - mn), ex = __expf(e - mn);   // exp(-inf) = 0 on the first key
+                    const float sc = expf(m - mn), ex = expf(e - mn);       // exp(-inf) = 0 on the first key
                     const float w = ex * sdp_keep(p, b, h, 0, j);
                     ssum = ssum * sc + ex;
                     acc.x = acc.x * sc + w * v4[u].x; acc.y = acc.y * sc + w * v4[u].y;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(1024) void sdp_decode_kernel(SdpArgs p, const int* 
             ao.x = __shfl_xor(acc.x, off, 64); ao.y = __shfl_xor(acc.y, off, 64);
             ao.z = __shfl_xor(acc.z, off, 64); ao.w = __shfl_xor(acc.w, off, 64);
             const float mn = fmaxf(m, mo);
-            const float s1 = (m == -INFINITY) ? 0.0f : __expf(m - mn), s2 = (mo == -INFINITY) ? 0.0f : __expf(mo - mn);
+            const float s1 = (m == -INFINITY) ? 0.0f : expf(m - mn), s2 = (mo == -INFINITY) ? 0.0f : expf(mo - mn);
             ssum = ssum * s1 + so * s2;
             acc.x = acc.x * s1 + ao.x * s2; acc.y = acc.y * s1 + ao.y * s2;
             acc.z = acc.z * s1 + ao.z * s2; acc.w = acc.w * s1 + ao.w * s2;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(1024) void sdp_decode_kernel(SdpArgs p, const int* 
             *reinterpret_cast<float4*>(p.ctx + (long)b * p.ctx_bs + col) = acc;
         }
         if (wg && sub == 0)
-            for (int j = grp; j < p.Tk; j += KPP) wg[j] = __expf(wg[j] - m) * inv;
+            for (int j = grp; j < p.Tk; j += KPP) wg[j] = expf(wg[j] - m) * inv;
     }
 }
 
@@ -226,10 +226,11 @@ extern "C" int nm_sdp_attn_fwd(void* stream, const float* q, int64_t q_bs, const
     if (nm_cur()->sw.sdp_decode && sdp_decode_launch(p, nullptr, 0, nm_stream(stream))) {     // one query per row
         NM_LAUNCH_CHECK("nm_sdp_attn_fwd (decode)");
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned attr_devs = 0;                     // the attribute is per device: one bit per device id
+    const unsigned attr_bit = 1u << (nm_cur()->device & 31);
+    if (!(attr_devs & attr_bit)) {
         (void)hipFuncSetAttribute((const void*)sdp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_devs |= attr_bit;
     }
     hipLaunchKernelGGL(sdp_fwd_kernel, dim3((unsigned)(Bq * H)), dim3(256), lds, nm_stream(stream), p);
     NM_LAUNCH_CHECK("nm_sdp_attn_fwd");
@@ -391,13 +392,14 @@ extern "C" int nm_sdp_attn_bwd(void* stream, const float* q, int64_t q_bs, const
     if (nm_sdp_mfma_bwd(a, nm_stream(stream))) {
         NM_LAUNCH_CHECK("nm_sdp_attn_bwd (mfma)");
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned attr_devs = 0;                     // per device, as above
+    const unsigned attr_bit = 1u << (nm_cur()->device & 31);
+    if (!(attr_devs & attr_bit)) {
         (void)hipFuncSetAttribute((const void*)sdp_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    160 * 1024);
         (void)hipFuncSetAttribute((const void*)sdp_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    160 * 1024);
-        attr_set = true;
+        attr_devs |= attr_bit;
     }
     if (wlds) hipLaunchKernelGGL(sdp_bwd_kernel<true>, dim3((unsigned)(B * H)), dim3(256), lds, nm_stream(stream), a);
     else hipLaunchKernelGGL(sdp_bwd_kernel<false>, dim3((unsigned)(B * H)), dim3(256), lds, nm_stream(stream), a);

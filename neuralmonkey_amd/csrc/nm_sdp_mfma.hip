@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void sdp_fwd_mfma_kernel(SdpArgs p) {
     for (int t = 0; t < NKT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float ex = __expf(acc[t][r] - mx);
+            const float ex = expf(acc[t][r] - mx);          // exact: softmax weights to 1 ulp
             acc[t][r] = ex;
             se += ex;
         }
@@ -165,12 +165,14 @@ static size_t sdp_fwd_mfma_lds() { return sizeof(float) * 16 * NKT * ((16 * NDT 
 
 template <int NKT, int NDT>
 static void sdp_fwd_mfma_launch(const SdpArgs& p, hipStream_t stream) {
-    static bool attr_set = false;
+    // the attribute is per DEVICE (library contexts exist per device: nm_create): one bit per device id
+    static unsigned attr_devs = 0;
+    const unsigned attr_bit = 1u << (nm_cur()->device & 31);
     const size_t lds = sdp_fwd_mfma_lds<NKT, NDT>();
-    if (!attr_set) {
+    if (!(attr_devs & attr_bit)) {
         (void)hipFuncSetAttribute((const void*)sdp_fwd_mfma_kernel<NKT, NDT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds);
-        attr_set = true;
+        attr_devs |= attr_bit;
     }
     hipLaunchKernelGGL((sdp_fwd_mfma_kernel<NKT, NDT>), dim3((unsigned)(p.Bq * p.H), (unsigned)((p.Tq + 63) / 64)),
                        dim3(256), lds, stream, p);
@@ -432,13 +434,14 @@ static size_t sdp_bwd_mfma_lds() {
 
 template <int NT, int NDT>
 static bool sdp_bwd_mfma_launch(const SdpBwdArgs& a, hipStream_t stream) {
-    static bool attr_set = false;
+    static unsigned attr_devs = 0;                     // per device, as in sdp_fwd_mfma_launch
+    const unsigned attr_bit = 1u << (nm_cur()->device & 31);
     const size_t lds = sdp_bwd_mfma_lds<NT, NDT>();
     if (lds > 160 * 1024) return false;
-    if (!attr_set) {
+    if (!(attr_devs & attr_bit)) {
         (void)hipFuncSetAttribute((const void*)sdp_bwd_mfma_kernel<NT, NDT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds);
-        attr_set = true;
+        attr_devs |= attr_bit;
     }
     hipLaunchKernelGGL((sdp_bwd_mfma_kernel<NT, NDT>), dim3((unsigned)(a.f.Bq * a.f.H)), dim3(256), lds, stream, a);
     return true;

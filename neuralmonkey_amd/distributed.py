@@ -64,6 +64,24 @@ class DataParallel:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return float(t.item())
 
+    def scale_by_global_count(self, count: float, weight: float, scale: torch.Tensor) -> None:
+        """``scale[0] = weight / sum over ranks of count`` (0 when nobody has a target token): the factor every rank
+        back-propagates with, sum_local(xent) / sum_global(mask) (decoders/autoregressive.py:313-316).
+
+        With RCCL the sum never visits the host: the local count goes into a device scalar, the all-reduce is
+        enqueued behind the current stream and the division runs on the device, so the host thread goes straight on
+        to enqueueing the forward pass -- the first reader of ``scale`` is the cross-entropy backward, a whole
+        forward pass later.  (The host-side gloo exchange this replaces blocked every rank at the top of every
+        step until the slowest rank had arrived.)  Other backends (gloo on CPU / in tests) keep the host sum."""
+        forced = os.environ.get("NM_DIST_FORCE") == "1"           # world-of-one runs exercise the collective path
+        if (self.world_size == 1 and not forced) or dist.get_backend() != "nccl" or scale.device.type != "cuda":
+            total = self.all_reduce_scalar(count)
+            scale.fill_(weight / total if total else 0.0)
+            return
+        t = torch.full((1,), float(count), dtype=torch.float64, device=scale.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)                  # the stream waits for it, the host does not
+        scale.copy_(torch.where(t > 0, float(weight) / t.clamp_min(1.0), torch.zeros_like(t)).to(scale.dtype))
+
     def begin_step(self) -> None:
         """Forget the bookkeeping of a step that did not reach ``all_reduce_gradients`` (an exception)."""
         for hnd in self._handles:

@@ -81,12 +81,18 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, b
 
 _GEMM_WS = {}
 GEMM_WORKSPACE_BYTES = 128 << 20
+# Scratch that kernels re-use from call to call (split-K slabs, column-sum partials + tickets) is keyed by the stream
+# the launch goes to -- but every torch.cuda.graph capture uses torch's ONE capture stream, so two captured graphs
+# would share a workspace and may later replay on different streams at the same time (a look-ahead encoder graph
+# next to the running batch's decoding graphs).  Whoever captures work for a second stream sets a tag
+# (runtime.Session._run_ahead): tagged launches get workspaces of their own.
+WORKSPACE_TAG = None
 
 
 def _gemm_workspace(device):
-    """Persistent split-K slab buffer, one per (device, stream): kernels of one
+    """Persistent split-K slab buffer, one per (device, stream, tag): kernels of one
     stream are ordered, kernels of different streams must not share slabs."""
-    key = (device, _stream())
+    key = (device, _stream(), WORKSPACE_TAG)
     ws = _GEMM_WS.get(key)
     if ws is None:
         ws = torch.empty(GEMM_WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
@@ -461,7 +467,7 @@ def colsum(x, out, accumulate=False):
     lib = _lib.load()
     assert x.dim() == 2 and x.stride(1) == 1
     cols = x.shape[1]
-    key = (x.device, cols, _stream())
+    key = (x.device, cols, _stream(), WORKSPACE_TAG)
     ws = _COLSUM_WS.get(key)
     if ws is None:
         # zeroed ONCE: the tail holds the arrival counters of the in-kernel final pass, which the kernel leaves at zero

@@ -561,15 +561,19 @@ class Session:
         if not self._ahead:
             return None
         now = self._feed_signature(feed)
-        hit = None
-        for entry in self._ahead:
-            # (the variables must be the ones the look-ahead saw: torch-side writes bump the version counter of the
-            # flat parameter tensor, the optimizer kernels -- raw pointers -- announce themselves, variables_changed)
-            if entry[0] and entry[0] <= now and entry[5] == self.variables_signature():
-                hit = entry
-        self._ahead = []
+        # (the variables must be the ones the look-ahead saw: torch-side writes bump the version counter of the
+        # flat parameter tensor, the optimizer kernels -- raw pointers -- announce themselves, variables_changed)
+        current = self.variables_signature()
+        live = [entry for entry in self._ahead if entry[5] == current]
+        hit = next((entry for entry in reversed(live) if entry[0] and entry[0] <= now), None)
         if hit is None:
+            # not this batch's: a second run() for the batch that is being decoded (tf_manager.execute loops until
+            # every executable has its result) must not throw away what was just evaluated for the NEXT batch.  An
+            # entry whose batch never comes is dropped after two misses.
+            self._ahead_misses = getattr(self, "_ahead_misses", 0) + 1
+            self._ahead = live[-1:] if self._ahead_misses < 2 else []
             return None
+        self._ahead, self._ahead_misses = [], 0
         _, slot, memo, event, _, _ = hit
         self.slot = slot
         torch.cuda.current_stream(self.device).wait_event(event)
@@ -595,7 +599,15 @@ class Session:
         busy instead of in front of the first step."""
         pending, self._pending_ahead = self._pending_ahead, None
         if pending is not None:
-            self._run_ahead(*pending)
+            try:
+                self._run_ahead(*pending)
+            except Exception as exc:        # pylint: disable=broad-except
+                # the look-ahead is an optimisation of the NEXT batch; the batch that is being decoded must not
+                # fail because of it (the next batch then simply computes its encoder itself -- and reports the
+                # error there, if it is one of the model's)
+                import warnings
+                warnings.warn("look-ahead evaluation dropped: {!r}".format(exc))
+                self._ahead = []
 
     def _run_ahead(self, fetches, feed) -> None:
         """Evaluate ``fetches`` (the encoder side of a FUTURE batch) on the look-ahead stream, into the buffer slot
@@ -610,6 +622,8 @@ class Session:
         start.record(main)                                   # after whatever is already queued (nothing, normally)
         mine = self.slot
         self.slot = mine ^ 1
+        from . import ops
+        tag, ops.WORKSPACE_TAG = ops.WORKSPACE_TAG, ("ahead", self.slot)     # scratch of its own (ops.WORKSPACE_TAG)
         try:
             self._ahead_stream.wait_event(start)
             with torch.cuda.stream(self._ahead_stream), torch.no_grad():
@@ -617,10 +631,11 @@ class Session:
                 self._eval(fetches, ctx)
                 done = torch.cuda.Event()
                 done.record(self._ahead_stream)
-            self._ahead.append((self._feed_signature(feed), self.slot, ctx.memo, done, feed,
-                                self.variables_signature()))
+            self._ahead = [(self._feed_signature(feed), self.slot, ctx.memo, done, feed,
+                            self.variables_signature())]          # one batch ahead, never a backlog
         finally:
             self.slot = mine
+            ops.WORKSPACE_TAG = tag
 
     def run(self, fetches, feed_dict: Optional[Dict[Placeholder, Any]] = None, ahead=None):
         """``ahead`` = (fetches, feed_dict) of the NEXT batch: tensors that do not depend on this run (its encoder
@@ -628,6 +643,11 @@ class Session:
         the run that later feeds that batch finds them computed."""
         feed = dict(feed_dict or {})
         claimed = self._claim_ahead(feed)
+        if claimed is None:
+            if self._ahead:                # a batch evaluated ahead is waiting in its slot: stay out of it
+                self.slot = self._ahead[-1][1] ^ 1
+            elif ahead is None:            # no look-ahead in play (training steps, plain runs): the default buffers --
+                self.slot = 0              # the slot is not sticky, or every shape would be allocated and captured twice
         self._pending_ahead = ahead       # started by the first decoding loop (kick_ahead) or right after the fetches
         ctx = RunContext(self, feed)
         if claimed:

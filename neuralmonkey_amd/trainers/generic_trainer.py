@@ -126,9 +126,11 @@ class GenericTrainer(GraphExecutor, Feedable):
             # loss = sum(xent) / sum(mask): with data parallelism the denominator is the
             # GLOBAL token count and gradients are summed over ranks
             count = dec.train_token_count(ctx)
-            global_count = dp.all_reduce_scalar(count) if dp is not None else count
             scale = ctx.buffer((id(self), "gscale", i), (1,))
-            scale.fill_(weight / global_count if global_count else 0.0)     # a batch without target tokens: no gradient
+            if dp is not None:
+                dp.scale_by_global_count(count, weight, scale)               # on the device: no host exchange
+            else:
+                scale.fill_(weight / count if count else 0.0)               # a batch without target tokens: no gradient
             decoders.append(dec)
             scales.append(scale)
             counts.append(count)

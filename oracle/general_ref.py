@@ -417,6 +417,29 @@ class GeneralModel:
                 t += 1
             return np.stack(syms), np.stack(masks), np.stack(logit_hist)
 
+    def beam_follow(self, src_ids, k: int, max_steps: int, alpha: float, follow=None, tie_margin=None):
+        """The beam search through ``nm_oracle.beam_search_core`` (one restatement of the beam body for every parent
+        decoder), optionally FOLLOWING another implementation's selections -- see ``beam_search_core``."""
+        from . import nm_oracle as O
+        with torch.no_grad():
+            p, d = self.p, self.cfg.dec_name
+            st, hf, mask, state = self._decode_setup(src_ids, k)
+            rows = state[0].shape[0]
+            table = p[d + "/word_embeddings"]
+            out, state, _ = self.decoder_step(table[torch.full((rows,), START)], state, st, hf, mask, False, 0)
+            box = {"state": state, "t": 1}
+
+            def step_fn(src_rows, words):
+                src = torch.as_tensor(np.asarray(src_rows, dtype=np.int64))
+                prev = [s[src] for s in box["state"]]
+                self.reorder_attention(src)
+                o, box["state"], _ = self.decoder_step(table[torch.as_tensor(np.asarray(words, dtype=np.int64))], prev,
+                                                       st, hf, mask, False, box["t"])
+                box["t"] += 1
+                return self.logits(o).numpy()
+            return O.beam_search_core(self.logits(out).numpy(), step_fn, rows // k, k, max_steps, alpha,
+                                      tie_margin=tie_margin, follow=follow)
+
     # -- beam search (decoders/beam_search_decoder.py:218-556) --------------------------------------
     def beam(self, src_ids, k: int, max_steps: int, alpha: float):
         with torch.no_grad():

@@ -60,6 +60,18 @@ def layer_norm(x, gamma, beta, eps=1e-6):
 def top_k(x, k):
     """tf.nn.top_k on the last axis: values descending, equal values -> lower
     index first (decoders/beam_search_decoder.py:475)."""
+    n = x.shape[-1]
+    if n > 4096 and k * 8 < n:
+        # a wide row (beam scores over k*V candidates): everything that ties with or beats the k-th largest value
+        # is kept by a threshold, then ordered like the plain path -- identical result, no full sort of the row
+        kth = np.partition(x, n - k, axis=-1)[..., n - k:n - k + 1]
+        keep = x >= kth
+        width = int(keep.sum(-1).max())
+        cols = np.argsort(~keep, axis=-1, kind="stable")[..., :width]          # kept columns first, ascending index
+        vals = np.where(np.take_along_axis(keep, cols, -1), np.take_along_axis(x, cols, -1), -np.inf)
+        order = np.argsort(-vals, axis=-1, kind="stable")[..., :k]
+        idx = np.take_along_axis(cols, order, -1)
+        return np.take_along_axis(x, idx, axis=-1), idx.astype(np.int32)
     # stable argsort of -x keeps the lower index first among equal values
     idx = np.argsort(-x, axis=-1, kind="stable")[..., :k]
     return np.take_along_axis(x, idx, axis=-1), idx.astype(np.int32)
@@ -403,6 +415,8 @@ class BeamResult(NamedTuple):
                                         # the top k+1 (exact ties are ordered by index and are not near-ties)
     tie_sets: Optional[dict] = None     # sentence -> (step, flat candidate ids, scores) of the best k + 16 candidates
                                         # at the sentence's FIRST near-tie step (beam_search(tie_margin=...))
+    follow: Optional[dict] = None       # beam_search(follow=...): per step what the oracle would have picked and what
+                                        # it thinks of the picks it was made to follow (see beam_search_core)
 
 
 def length_penalty(lengths, alpha, dt):
@@ -412,12 +426,21 @@ def length_penalty(lengths, alpha, dt):
 
 
 def beam_search_core(first_logits, step_fn, bsz: int, beam_size: int, max_steps: int, length_normalization: float,
-                     tie_margin: Optional[float] = None) -> BeamResult:
+                     tie_margin: Optional[float] = None, follow=None) -> BeamResult:
     """BeamSearchDecoder around ANY parent decoder (beam_search_decoder.py:218-556).
 
     ``first_logits`` [B*k, V]: the parent step that ``get_initial_loop_state`` runs on the tiled rows (:255-300).
     ``step_fn(src_rows [B*k], words [B*k]) -> logits [B*k, V]``: reorder the parent's per-row state by ``src_rows``
     (gather_flat, :503-532), feed ``words`` and run one parent body (:534-535).
+
+    ``follow = (beam_ids [steps,B,k], word_ids [steps,B,k])`` -- the selections of ANOTHER implementation of the
+    search: at every step the oracle scores the candidates from its own state, records its own top k AND its scores
+    of the selections it was given, then advances along the GIVEN selections.  A checker can thus account for every
+    selection of a whole search even where two fp32 implementations legitimately order near-tied candidates
+    differently (the searches would otherwise diverge at the first near-tie and nothing later could be compared).
+    ``BeamResult.follow``: ``own_idx`` / ``own_scores`` [steps,B,k+1] (the oracle's best k+1 flat candidates),
+    ``given_scores`` [steps,B,k] (its scores of the given picks), ``best_other`` [steps,B] (its best candidate NOT
+    among the given picks).
     """
     k = beam_size
     dt = first_logits.dtype
@@ -434,6 +457,7 @@ def beam_search_core(first_logits, step_fn, bsz: int, beam_size: int, max_steps:
     min_gap = np.inf
     beam_hist, word_hist, gap_hist = [], [], []
     tie_sets = {}
+    rep = {"own_idx": [], "own_scores": [], "given_scores": [], "best_other": []} if follow is not None else None
 
     finished_row = np.full(vsz, -INF, dtype=dt)
     finished_row[PAD] = 0.0
@@ -462,6 +486,19 @@ def beam_search_core(first_logits, step_fn, bsz: int, beam_size: int, max_steps:
                 gap = (top_sc[live, k - 1] - top_sc[live, k])
                 rel = gap / np.maximum(np.abs(top_sc[live, k - 1]), 1e-30)
                 min_gap = min(min_gap, float(rel.min()))
+        if follow is not None:
+            step_i = dec_step - 1
+            if step_i >= len(follow[0]):
+                break
+            given = (follow[0][step_i].astype(np.int64) * vsz + follow[1][step_i].astype(np.int64))   # [B,k]
+            own_sc, own_idx = top_k(flat, min(2 * k + 1, flat.shape[1]))
+            rep["own_idx"].append(own_idx[:, :k + 1].copy())
+            rep["own_scores"].append(own_sc[:, :k + 1].copy())
+            rep["given_scores"].append(flat[bidx, given])
+            other = np.where((own_idx[:, :, None] == given[:, None, :]).any(-1), -np.inf, own_sc)
+            rep["best_other"].append(other.max(axis=1))
+            top_idx = given.astype(np.int32)
+            top_sc = flat[bidx, given]
         top_sc, top_idx = top_sc[:, :k], top_idx[:, :k]
         word = (top_idx % vsz).astype(np.int64)                               # :481-483
         beam = top_idx // vsz
@@ -481,11 +518,13 @@ def beam_search_core(first_logits, step_fn, bsz: int, beam_size: int, max_steps:
     return BeamResult(scores, token_ids, logprob_sum, lengths, finished, min_gap,
                       np.stack(beam_hist) if beam_hist else z,
                       np.stack(word_hist) if word_hist else z,
-                      np.stack(gap_hist) if gap_hist else np.zeros((0, bsz)), tie_sets)
+                      np.stack(gap_hist) if gap_hist else np.zeros((0, bsz)), tie_sets,
+                      None if rep is None else {n: np.stack(v) for n, v in rep.items()})
 
 
 def beam_search(params, spec: DecoderSpec, enc: EncoderOutput, beam_size: int,
-                max_steps: int, length_normalization: float, tie_margin: Optional[float] = None) -> BeamResult:
+                max_steps: int, length_normalization: float, tie_margin: Optional[float] = None,
+                follow=None) -> BeamResult:
     """BeamSearchDecoder over the RNN Decoder.
 
     The reference tiles the parent loop state to B*k rows (expand_to_beam
@@ -513,7 +552,7 @@ def beam_search(params, spec: DecoderSpec, enc: EncoderOutput, beam_size: int,
         return state_to_logits(dp, spec, o)
 
     return beam_search_core(state_to_logits(dp, spec, out), step_fn, bsz, k, max_steps, length_normalization,
-                            tie_margin)
+                            tie_margin, follow)
 
 
 def beam_tokens(res: BeamResult, rank: int = 1) -> Tuple[List[List[int]], float]:

@@ -13,15 +13,16 @@ compared with the CPU oracle here, end to end:
     Adam against TR.clip_and_adam;
   * greedy decoding: encoder states, the logits of the first 10 steps within 1e-4 relative, symbols
     exact (decoders/decoder.py:279-358, autoregressive.py:442-519);
-  * beam search, k = 5, alpha = 0.6, 10 steps on BASELINE.md's weights and all 50 steps with a sharper
-    vocabulary projection: the raw (beam, word) selections of every beam body
-    (BeamSearchDecoder.selection_history) exact up to a sentence's first near-tie step, inside the
-    oracle's tie set AT that step, token histories / lengths / finished flags / scores (1e-4) of every
-    sentence without a near-tie (beam_search_decoder.py:394-556).
+  * beam search, k = 5, alpha = 0.6, ALL 50 steps on BASELINE.md's weights and with a sharper vocabulary
+    projection: the raw (beam, word) selections of every beam body (BeamSearchDecoder.selection_history)
+    are handed to the oracle, which follows them (O.beam_search(follow=...)) and accounts for every one
+    of the 50 x 128 x 5 selections: the oracle's own pick, or a legitimate ordering of candidates it
+    scores within the near-tie margin; final token histories / lengths / finished flags exact, scores
+    1e-4, for ALL sentences (beam_search_decoder.py:394-556).
 
-Near-tie rule (SURVEY 8c protocol 3): the oracle reports, per sentence and step, the relative gap
-between adjacent candidates of its top k+1 and keeps the candidates around a sentence's first gap below
-1e-5 (two fp32 implementations may order such candidates differently).
+Near-tie rule (SURVEY 8c protocol 3): two fp32 implementations may order candidates whose scores differ
+by less than 1e-5 relative differently; such a step is accepted when the engine's top 5 is a valid top 5
+of the oracle's scores up to twice that margin, and the oracle continues from the engine's picks.
 The oracle needs ~1 minute of host CPU for all three parts.
 """
 import numpy as np
@@ -30,6 +31,7 @@ import torch
 
 from oracle import nm_oracle as O
 from oracle import torch_ref as TR
+from tests.beam_accounting import account_for_every_selection
 
 pytestmark = pytest.mark.gpu
 
@@ -91,48 +93,13 @@ def test_greedy_logits_and_symbols_match_the_oracle(world):
     assert float(err[safe].max()) <= 1e-4 * scale, float(err[safe].max() / scale)
 
 
-def _check_beam(ref, sel_beam, sel_word, tok, out, k):
-    """Per sentence: exact agreement with the oracle up to the sentence's first near-tie step; AT that step every
-    selection of the engine has to come out of the oracle's tie set (a candidate the oracle ranks within the
-    near-tie margin of its k-th best); afterwards the two searches may legitimately follow different hypotheses and
-    nothing is compared.  Sentences without a near-tie are compared in full, final state included."""
-    steps, bsz = ref.gaps.shape
-    first_tie = np.where((ref.gaps <= NEAR_TIE).any(axis=0), (ref.gaps <= NEAR_TIE).argmax(axis=0), steps)
-    clean = first_tie == steps
-    exact_steps = flipped = 0
-    for b in range(bsz):
-        t = int(first_tie[b])
-        assert np.array_equal(sel_beam[:t, b], ref.beam_ids[:t, b]) and \
-            np.array_equal(sel_word[:t, b], ref.word_ids[:t, b]), "sentence {}: selections differ before step {}".format(b, t)
-        exact_steps += t
-        if t == steps:
-            continue
-        tstep, cand, sc = ref.tie_sets[b]
-        assert tstep == t
-        floor = sc[k - 1] - 2 * NEAR_TIE * abs(sc[k - 1])
-        allowed = set(int(c) for c, s_ in zip(cand, sc) if s_ >= floor)
-        picks = [int(x) for x in (sel_beam[t, b].astype(np.int64) * VOCAB + sel_word[t, b])]
-        assert set(picks) <= allowed, "sentence {} step {}: pick outside the oracle's tie set".format(b, t)
-        flipped += picks != [int(c) for c in cand[:k]]
-    assert np.array_equal(tok[:, clean], ref.token_ids.astype(np.int32)[:, clean]), "beam token ids differ"
-    assert np.array_equal(np.asarray(out.last_search_state.lengths)[clean], ref.lengths[clean])
-    assert np.array_equal(np.asarray(out.last_search_state.finished).astype(bool)[clean], ref.finished[clean])
-    sc = np.asarray(out.last_search_step_output.scores)
-    assert np.abs(sc[clean] - ref.scores[clean]).max() <= 1e-4 * np.abs(ref.scores[clean]).max()
-    lps = np.asarray(out.last_search_state.logprob_sum)
-    assert np.abs(lps[clean] - ref.logprob_sum[clean]).max() <= 1e-4 * np.abs(ref.logprob_sum[clean]).max()
-    return clean.mean(), exact_steps / float(steps * bsz), flipped
-
-
-@pytest.mark.parametrize("logit_std,min_clean,steps", [(None, 0.3, DECODE_STEPS), (0.2, 0.2, LEN)])
-def test_beam_search_selections_match_the_oracle(world, logit_std, min_clean, steps):
-    """With BASELINE.md's N(0, 0.05) vocabulary projection the softmax over 32000 words is nearly flat and ~60 % of
-    the sentences see two candidates within the near-tie margin somewhere in 10 steps (the oracle reports them);
-    the second variant sharpens the projection to N(0, 0.2) and runs all 50 steps (30 % of the sentences then get
-    through all 50 steps without a near-tie, 65 % of all (sentence, step) selections are compared exactly,
-    profiles/r03_fullsize_parity.txt).  Every (sentence, step)
-    selection before a sentence's first near-tie must be the oracle's, the selection AT the near-tie must come out
-    of the oracle's tie set, sentences without any near-tie must match to the end (``_check_beam``)."""
+@pytest.mark.parametrize("logit_std", [None, 0.2])
+def test_beam_search_every_selection_of_all_50_steps_is_accounted_for(world, logit_std):
+    """All 50 steps x 128 sentences x 5 hypotheses of the search, on BASELINE.md's N(0, 0.05) vocabulary projection
+    (whose softmax over 32000 words is nearly flat: most sentences meet candidates within the near-tie margin of
+    1e-5 somewhere) and on a sharper N(0, 0.2) projection.  The oracle follows the engine's selections
+    (``tests/beam_accounting.py``), so a near-tie does not end the comparison of a sentence: 100 % of the
+    selections are either the oracle's own or a legitimate ordering of a near-tie."""
     model, enc = world["model"], world["enc"]
     params = dict(world["params"])
     if logit_std is not None:
@@ -140,7 +107,7 @@ def test_beam_search_selections_match_the_oracle(world, logit_std, min_clean, st
         params["decoder/state_to_word_W"] = (np.random.default_rng(5).standard_normal(w.shape) * logit_std
                                              ).astype(np.float32)
     model.tf_manager.sessions[0].store.load_state_dict(params)
-    ref = O.beam_search(params, O.DecoderSpec(max_output_len=LEN), enc, 5, steps, 0.6, tie_margin=NEAR_TIE)
+    steps = LEN
     sess = model.tf_manager.sessions[0]
     fd = _feed(model, world["ds"])
     fd[model.beam_decoder.max_steps] = steps
@@ -148,13 +115,13 @@ def test_beam_search_selections_match_the_oracle(world, logit_std, min_clean, st
     out = got["bs"]
     sel_beam, sel_word = (np.asarray(x.cpu() if hasattr(x, "cpu") else x) for x in got["sel"])
     tok = np.asarray(out.last_search_step_output.token_ids)            # [steps+1,B,k]
-    assert tok.shape == ref.token_ids.shape == (steps + 1, B, 5)
-    assert sel_beam.shape == ref.beam_ids.shape == (steps, B, 5)
-    clean, exact, flipped = _check_beam(ref, sel_beam, sel_word, tok, out, 5)
-    print("beam-5, {} steps, projection std {}: {:.0%} of the sentences without a near-tie, {:.1%} of all (sentence, "
-          "step) selections compared exactly, {} near-tie steps where the engine ordered the tie set differently"
-          .format(steps, logit_std or 0.05, clean, exact, flipped))
-    assert clean >= min_clean, "too many near-ties in the oracle: {} clean".format(clean)
+    assert tok.shape == (steps + 1, B, 5) and sel_beam.shape == (steps, B, 5)
+    ref = O.beam_search(params, O.DecoderSpec(max_output_len=LEN), enc, 5, steps, 0.6, follow=(sel_beam, sel_word))
+    assert ref.token_ids.shape == tok.shape
+    exact, reordered, never = account_for_every_selection(ref, sel_beam, sel_word, tok, out, 5, VOCAB, NEAR_TIE)
+    print("beam-5, {} steps, projection std {}: all {} selections accounted for -- {:.2%} of the (step, sentence) "
+          "top-5 lists exactly the oracle's, {} lists a legitimate ordering of a near-tie; {:.0%} of the sentences "
+          "never met a near-tie".format(steps, logit_std or 0.05, steps * B * 5, exact, int(reordered), never))
 
 
 def test_training_step_gradients_and_adam_match_the_oracle(world):

@@ -10,7 +10,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from neuralmonkey_amd import ops  # noqa: E402
 
-B, S, A, C = int(os.environ.get("NM_B", "128")), int(os.environ.get("NM_S", "50")), 1024, 1024
+B, S = int(os.environ.get("NM_B", "128")), int(os.environ.get("NM_S", "50"))
+A, C = int(os.environ.get("NM_A", "1024")), int(os.environ.get("NM_C", "1024"))     # captioning: NM_S=64 NM_A=512 NM_C=2048
 qpk = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 mode = sys.argv[3] if len(sys.argv) > 3 else "cold"      # cold (read sweep) | dirty (write sweep) | warm
