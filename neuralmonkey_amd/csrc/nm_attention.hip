@@ -361,7 +361,9 @@ __global__ __launch_bounds__(256) void attn_partial(AttnArgs p) {
 // chunk softmax is evaluated redundantly per thread instead of serially.
 // ---------------------------------------------------------------------------
 #define ATT_FAST_ROWS 14
-template <int ROWS>
+// NCG = value column groups of 1024 per lane: 1 for C <= 1024, 2 for C <= 2048 (config 4: 8x8x2048 maps attended with
+// state 512 -- each lane then streams its 16-byte key slice and TWO 16-byte value slices of every row of the chunk)
+template <int ROWS, int NCG = 1>
 __global__ __launch_bounds__(256) void attn_partial_fast(AttnArgs p) {
     __shared__ float pe[4][ATT_MAX_SCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -369,11 +371,14 @@ __global__ __launch_bounds__(256) void attn_partial_fast(AttnArgs p) {
     const int s0 = chunk * p.sch;
     const int ns = min(p.sch, p.S - s0);
     const int col = wave * 256 + lane * 4;
-    const bool a_ok = col < p.A, c_ok = col < p.C;
+    const bool a_ok = col < p.A;
+    bool c_ok[NCG];
+#pragma unroll
+    for (int g = 0; g < NCG; ++g) c_ok[g] = col + g * 1024 < p.C;
     // out-of-range lanes / rows read a valid address and are weighted by zero below:
-    // no branch sits between the loads, so all 2*ROWS of them are in flight together
+    // no branch sits between the loads, so all (1 + NCG) * ROWS of them are in flight together
     const float* hbase = p.hf + ((long)b * p.S + s0) * p.A + (a_ok ? col : 0);
-    const float* sbase = p.states + ((long)b * p.S + s0) * p.C + (c_ok ? col : 0);
+    const float* sbase = p.states + ((long)b * p.S + s0) * p.C;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     // y / v before the rows: vmcnt counts in issue order, a tanh of row s then only waits for rows 0..s
@@ -381,13 +386,16 @@ __global__ __launch_bounds__(256) void attn_partial_fast(AttnArgs p) {
     float4 v4 = *reinterpret_cast<const float4*>(p.v + (a_ok ? col : 0));
     if (!a_ok) v4 = zero4;
     const float bias = p.bias ? p.bias[0] : 0.0f;
-    float4 hfr[ROWS], str[ROWS];
+    float4 hfr[ROWS], str[NCG][ROWS];
 #pragma unroll
     for (int s = 0; s < ROWS; ++s)
         hfr[s] = *reinterpret_cast<const float4*>(hbase + (long)min(s, ns - 1) * p.A);
 #pragma unroll
-    for (int s = 0; s < ROWS; ++s)
-        str[s] = *reinterpret_cast<const float4*>(sbase + (long)min(s, ns - 1) * p.C);
+    for (int g = 0; g < NCG; ++g)
+#pragma unroll
+        for (int s = 0; s < ROWS; ++s)
+            str[g][s] = *reinterpret_cast<const float4*>(sbase + (long)min(s, ns - 1) * p.C +
+                                                         (c_ok[g] ? col + g * 1024 : 0));
 
 #pragma unroll
     for (int s = 0; s < ROWS; ++s) {
@@ -406,7 +414,9 @@ __global__ __launch_bounds__(256) void attn_partial_fast(AttnArgs p) {
         if (s < ns) m = fmaxf(m, e[s]);
     }
     float la = 0.0f, lm = 0.0f;
-    float4 acc = zero4;
+    float4 acc[NCG];
+#pragma unroll
+    for (int g = 0; g < NCG; ++g) acc[g] = zero4;
 #pragma unroll
     for (int s = 0; s < ROWS; ++s) {
         const bool ok = s < ns;
@@ -415,8 +425,11 @@ __global__ __launch_bounds__(256) void attn_partial_fast(AttnArgs p) {
         const float em = ex * mk;
         la += ex;
         lm += em;
-        acc.x += em * str[s].x; acc.y += em * str[s].y;
-        acc.z += em * str[s].z; acc.w += em * str[s].w;
+#pragma unroll
+        for (int g = 0; g < NCG; ++g) {
+            acc[g].x += em * str[g][s].x; acc[g].y += em * str[g][s].y;
+            acc[g].z += em * str[g][s].z; acc[g].w += em * str[g][s].w;
+        }
     }
     const float e_own = tid < ns ? ((pe[0][tid] + pe[1][tid]) + (pe[2][tid] + pe[3][tid])) + bias : 0.0f;
     float* st = p.pstat + ((long)b * p.nchunk + chunk) * 4;
@@ -424,13 +437,17 @@ __global__ __launch_bounds__(256) void attn_partial_fast(AttnArgs p) {
     if (!p.merge) {
         if (tid < ns) p.energies[(long)b * p.S + s0 + tid] = e_own;
         if (tid == 0) { st[0] = m; st[1] = la; st[2] = lm; st[3] = 0.0f; }
-        if (c_ok) *reinterpret_cast<float4*>(pc) = acc;
+#pragma unroll
+        for (int g = 0; g < NCG; ++g)
+            if (c_ok[g]) *reinterpret_cast<float4*>(pc + g * 1024) = acc[g];
         return;
     }
     // write-through hand-off to the workgroup that merges this sentence's partials (the last one to arrive)
     if (tid < ns) st_wt1(p.energies + (long)b * p.S + s0 + tid, e_own);
     if (tid == 0) st_wt4(st, make_float4(m, la, lm, 0.0f));
-    if (c_ok) st_wt4(pc, acc);
+#pragma unroll
+    for (int g = 0; g < NCG; ++g)
+        if (c_ok[g]) st_wt4(pc + g * 1024, acc[g]);
     __shared__ int s_last;
     if (!attn_arrive_last(p, b, &s_last)) return;
     attn_merge_row(p, b, b);
@@ -926,6 +943,12 @@ static int attn_fwd_impl(void* stream, const float* y, const float* hf, const fl
         else if (sch <= 10) hipLaunchKernelGGL(attn_partial_fast<10>, grid, block, 0, st, p);
         else if (sch <= 12) hipLaunchKernelGGL(attn_partial_fast<12>, grid, block, 0, st, p);
         else hipLaunchKernelGGL(attn_partial_fast<14>, grid, block, 0, st, p);
+    } else if (nq == 1 && A <= 1024 && C <= 2048 && sch <= 12 && !no_fast) {
+        // wide values (config 4: C = 2048): the same kernel with two value slices per lane, merged in the launch
+        p.merge = may_merge;
+        if (sch <= 8) hipLaunchKernelGGL((attn_partial_fast<8, 2>), grid, block, 0, st, p);
+        else if (sch <= 10) hipLaunchKernelGGL((attn_partial_fast<10, 2>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((attn_partial_fast<12, 2>), grid, block, 0, st, p);
     } else if (nq <= 8 && groups == 1 && A <= 1024 && C <= 1024 && sch <= ATT_FAST_ROWS && !no_fast) {
         // a few queries per key batch (beam search): all loads in flight first, queries in registers.  (No
         // in-kernel merge here: one workgroup merging the k rows of a sentence one after the other was measured

@@ -54,7 +54,7 @@ struct NmSwitches {
     bool gemm_nostore;     // NM_GEMM_NOSTORE   timing ablation: results are NOT written
     int gemm_sk;           // NM_GEMM_SK        split-K override (0 = makespan model)
     int gemm_cfg;          // NM_GEMM_CFG       tile configuration of the large GEMMs (1)
-    int gemm_chains;       // NM_GEMM_CHAINS    interleaved accumulation chains of the 64x64 tiles: 1, 2 or 4 (2)
+    int gemm_chains;       // NM_GEMM_CHAINS    interleaved accumulation chains of the 64x64 tiles: 1, 2 or 4 (1)
     int stats_cfg;         // NM_STATS_CFG      statistics-GEMM tile / prefetch bits (3)
     bool stats_ablate;     // NM_STATS_ABLATE   timing ablation: statistics epilogue skipped
     int beam_ns;           // NM_BEAM_NS        slices per hypothesis row override (0 = by vocabulary size)

@@ -29,7 +29,7 @@ static void switches_from_env(NmSwitches* sw) {
     sw->gemm_nostore = getenv("NM_GEMM_NOSTORE") != nullptr;
     sw->gemm_sk = env_int("NM_GEMM_SK", 0);
     sw->gemm_cfg = env_int("NM_GEMM_CFG", 1);
-    sw->gemm_chains = env_int("NM_GEMM_CHAINS", 2);
+    sw->gemm_chains = env_int("NM_GEMM_CHAINS", 1);
     sw->stats_cfg = env_int("NM_STATS_CFG", 3);
     sw->stats_ablate = getenv("NM_STATS_ABLATE") != nullptr;
     sw->beam_ns = env_int("NM_BEAM_NS", 0);

@@ -70,3 +70,42 @@ def beam_ensemble(models: List[GeneralModel], src_ids, k: int, max_steps: int, a
             scores = top
             step += 1
         return token_ids.numpy(), scores.numpy(), min_gap
+
+
+def beam_ensemble_transformer(models, src_ids, k: int, max_steps: int, alpha: float, follow=None):
+    """The same protocol over ``transformer_ref.TransformerModel`` replicas (the only parent decoder the reference's
+    runner can ensemble at this commit: over an RNN ``Decoder`` its feed dictionary is keyed by a structure that
+    holds lists and raises TypeError, tests/golden/ref_exec/defects.npz).  Every model re-runs its stack over the
+    whole prefix of every hypothesis (decoders/transformer.py:487-516); the step distributions are averaged in log
+    space (float64 logsumexp as scipy's, beamsearch_runner.py:50-55) and one beam body (``beam_search_core``) selects
+    on the average -- the averaged log-probabilities are themselves normalised, so handing them to the core as
+    "logits" leaves them unchanged up to one rounding."""
+    from . import nm_oracle as O
+    with torch.no_grad():
+        dt = models[0].dtype
+        bsz = src_ids.shape[0]
+        rows = bsz * k
+        enc = []
+        for m in models:
+            states, masks = m.encode_all(src_ids, False)
+            enc.append(([e.repeat_interleave(k, 0) for e in states], [x.repeat_interleave(k, 0) for x in masks]))
+        tables = [m.target_embeddings() for m in models]
+        seqs = [t[torch.full((rows,), START)].unsqueeze(1) for t in tables]
+        box = {"seqs": seqs, "mask": torch.ones(rows, 1, dtype=dt)}
+
+        def mean_lp():
+            lps = [torch.log_softmax(m.logits(m._next_output(s, box["mask"], es, em)), -1)      # pylint: disable=protected-access
+                   for m, s, (es, em) in zip(models, box["seqs"], enc)]
+            return (torch.logsumexp(torch.stack(lps).double(), 0) - math.log(len(lps))).to(dt).numpy()
+
+        finished = {"f": np.zeros(rows, dtype=bool)}
+
+        def step_fn(src_rows, words):
+            src = torch.as_tensor(np.asarray(src_rows, dtype=np.int64))
+            w = torch.as_tensor(np.asarray(words, dtype=np.int64))
+            finished["f"] = finished["f"][np.asarray(src_rows)] | (np.asarray(words) == END)
+            box["seqs"] = [torch.cat([s[src], t[w].unsqueeze(1)], 1) for s, t in zip(box["seqs"], tables)]
+            live = torch.as_tensor((~finished["f"]).astype(np.float64)).to(dt).reshape(-1, 1)
+            box["mask"] = torch.cat([box["mask"][src], live], 1)
+            return mean_lp()
+        return O.beam_search_core(mean_lp(), step_fn, bsz, k, max_steps, alpha, follow=follow)

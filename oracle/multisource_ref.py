@@ -83,7 +83,7 @@ class MultiSourceModel(GeneralModel):
             proj_ctx = proj_logit
         else:
             proj_ctx = vector @ p[pre + "/vector_ctx_proj/kernel"] + p[pre + "/vector_ctx_proj/bias"]
-        v = p[self.m.att_name + "/attn_v"]
+        v = p[self.m.att_name + "/attn_v"].reshape(-1)      # the reference declares it [1, 1, A] (combination.py:65-69)
         logit = (v * torch.tanh(projected_state + proj_logit)).sum(-1, keepdim=True) + p[pre + "/vector_bias"]
         return proj_ctx, logit
 
@@ -98,7 +98,7 @@ class MultiSourceModel(GeneralModel):
         m, p = self.m, self.p
         prev_state, rnn_input = self._step_extra
         projected = query @ p[self._step_name("dense/kernel")] + p[self._step_name("dense/bias")]     # [R,A]
-        v = p[m.att_name + "/attn_v"]
+        v = p[m.att_name + "/attn_v"].reshape(-1)           # [1, 1, A] in the reference (combination.py:65-69)
         if m.kind == "flat":                                              # :245-296
             logits = []
             for i, k in enumerate(st["keys"]):

@@ -304,7 +304,7 @@ def run_rnn(case, **overrides):
             out[pre + "finished"] = bo.last_search_state.finished
             out[pre + "prev_logprobs"] = bo.last_search_state.prev_logprobs
             out[pre + "dec_step"] = bo.last_dec_loop_state.feedables.step
-            out[pre + "sentence"] = np.asarray(joined(ex.result.outputs["hyp"][0]))
+            out[pre + "sentence"] = np.asarray([joined(sent) for sent in ex.result.outputs["hyp"]])
             out[pre + "loss"] = np.asarray(ex.result.losses["hyp/beam_search_score"])
         order_beam, _ = variables()
         missing = [n for n in order_beam if n not in order_full]
@@ -548,6 +548,217 @@ def run_beam_body(case):
     save(case, {"kind": "beam_body", "vocab": vsz, "beam": [k, max_steps, alpha], "batch": bsz}, out)
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# attention variants on the RNN decoder (row f3): combinations over two encoders, dot-product attention
+# ----------------------------------------------------------------------------------------------------------------
+MS_DEFAULT = dict(kind="flat", state_size=5, share=False, sentinel=False, image=[2, 3, 7, None, None],
+                  src_vocab=17, tgt_vocab=13, emb=6, enc_size=4, rnn_size=6, dec_cell="GRU", conditional_gru=False,
+                  max_output_len=6, seed=21, batch=4, heads=None, factored=False, label_smoothing=None)
+
+
+def build_multisource(cfg):
+    from neuralmonkey.encoders.recurrent import SentenceEncoder, FactoredEncoder
+    from neuralmonkey.encoders.numpy_stateful_filler import SpatialFiller
+    from neuralmonkey.attention.feed_forward import Attention
+    from neuralmonkey.attention.combination import FlatMultiAttention, HierarchicalMultiAttention
+    from neuralmonkey.attention.scaled_dot_product import MultiHeadAttention
+    from neuralmonkey.decoders.decoder import Decoder
+    sv, tv = make_vocab(cfg["src_vocab"]), make_vocab(cfg["tgt_vocab"])
+    if cfg["factored"]:
+        enc = FactoredEncoder(name="encoder", vocabularies=[sv, make_vocab(5)], data_ids=["source", "tags"],
+                              embedding_sizes=[cfg["emb"], 3], rnn_size=cfg["enc_size"])
+    else:
+        enc = SentenceEncoder(name="encoder", vocabulary=sv, data_id="source", embedding_size=cfg["emb"],
+                              rnn_size=cfg["enc_size"])
+    parts = [enc, enc.input_sequence]
+    encoders = [enc]
+    if cfg["kind"] in ("flat", "hier"):
+        h, w, c, ff_dim, proj_dim = cfg["image"]
+        img = SpatialFiller(name="imagenet", input_shape=[h, w, c], data_id="maps", projection_dim=proj_dim,
+                            ff_hidden_dim=ff_dim)
+        parts.append(img)
+        encoders.append(img)
+    if cfg["kind"] == "flat":
+        att = FlatMultiAttention(name="wrapper", encoders=encoders, attention_state_size=cfg["state_size"],
+                                 share_attn_projections=cfg["share"], use_sentinels=cfg["sentinel"])
+        parts.append(att)
+    elif cfg["kind"] == "hier":
+        children = [Attention(name="att_text", encoder=enc), Attention(name="att_image", encoder=img, state_size=7)]
+        att = HierarchicalMultiAttention(name="wrapper", attentions=children, attention_state_size=cfg["state_size"],
+                                         use_sentinels=cfg["sentinel"], share_attn_projections=cfg["share"])
+        parts += children + [att]
+    elif cfg["kind"] == "dotprod":
+        att = MultiHeadAttention(name="attention", n_heads=cfg["heads"], keys_encoder=enc)
+        parts.append(att)
+    else:
+        att = Attention(name="attention", encoder=enc)
+        parts.append(att)
+    dec = Decoder(encoders=encoders, vocabulary=tv, data_id="target", name="decoder",
+                  max_output_len=cfg["max_output_len"], embedding_size=cfg["rnn_size"], rnn_size=cfg["rnn_size"],
+                  attentions=[att], rnn_cell=cfg["dec_cell"], conditional_gru=cfg["conditional_gru"],
+                  label_smoothing=cfg["label_smoothing"])
+    parts.append(dec)
+    return enc, att, dec, parts
+
+
+def run_multisource(case, **overrides):
+    cfg = dict(MS_DEFAULT, **overrides)
+    rng = np.random.default_rng(cfg["seed"])
+    bsz = cfg["batch"]
+    src = sentences(rng, bsz, cfg["src_vocab"], 2, 6, oov_every=2)
+    src[-1] = src[-1][:1]
+    series = {"source": src, "target": sentences(rng, bsz, cfg["tgt_vocab"], 1, cfg["max_output_len"] + 1, oov_every=3)}
+    inputs = string_inputs("source", "target", "tags")
+    if cfg["factored"]:
+        series["tags"] = [["w{}".format(int(rng.integers(0, 5))) for _ in s] for s in src]
+    if cfg["kind"] in ("flat", "hier"):
+        h, w, c = cfg["image"][:3]
+        series["maps"] = list(np.maximum(rng.normal(0, 1, (bsz, h, w, c)), 0).astype(np.float32))
+        inputs["maps"] = tf.placeholder(tf.float32, [None, h, w, c], "maps")
+    out = {}
+    fresh_graph()
+    enc, att, dec, parts = build_multisource(cfg)
+    with tf_eager.feeding(feed(parts, dataset(series), False, inputs)):
+        out["in/src_ids"] = enc.input_sequence.input_factor_indices[0].numpy()
+        if cfg["factored"]:
+            out["in/tag_ids"] = enc.input_sequence.input_factor_indices[1].numpy()
+        if "maps" in series:
+            out["in/maps"] = np.stack(series["maps"])
+        out["in/tgt_ids"] = dec.train_inputs.numpy()
+        out["out/enc_states"] = enc.temporal_states.numpy()
+        out["out/enc_output"] = enc.output.numpy()
+        out["out/train_logits"] = dec.train_logits.numpy()
+        out["out/train_xents"] = dec.train_xents.numpy()
+        out["out/train_loss"] = dec.train_loss.numpy()
+        rr = dec.runtime_loop_result
+        out["out/runtime_logits"] = dec.runtime_logits.numpy()
+        out["out/runtime_symbols"] = rr.histories.output_symbols.numpy()
+        out["out/runtime_mask"] = dec.runtime_mask.numpy()
+    save(case, cfg, out)
+
+
+def run_ensemble(case, family="transformer"):
+    """BeamSearchRunner over several sessions (runners/beamsearch_runner.py:38-82): every session advances its own
+    model by ONE beam body per call, the step distributions are averaged in log space on the host (scipy logsumexp)
+    and fed back -- driven here exactly as tf_manager.execute drives it (next_to_execute -> run -> collect_results
+    until the executable has a result), on three sets of variables of the ``transformer`` fixture's model.  (Over an
+    RNN ``Decoder`` the reference cannot run this protocol at this commit: ``fd = {self.decoder.decoder_state: ...}``
+    (beamsearch_runner.py:70-75) uses a LoopState that holds LISTS (RNNFeedables.prev_contexts,
+    RNNHistories.attention_histories) as a dictionary key -> ``TypeError: unhashable type: 'list'``; recorded by the
+    ``defects`` case.)"""
+    from neuralmonkey.decoders.beam_search_decoder import BeamSearchDecoder
+    from neuralmonkey.runners.beamsearch_runner import BeamSearchRunner
+    if family == "transformer":
+        cfg = dict(TR_DEFAULT, seed=31, batch=3, beam=[3, 5, 0.6])
+        rng = np.random.default_rng(cfg["seed"])
+        series = {"source": sentences(rng, cfg["batch"], cfg["src_vocab"], 2, 6, oov_every=2),
+                  "target": sentences(rng, cfg["batch"], cfg["tgt_vocab"], 1, 4)}
+
+        def builder(c):
+            seq, enc, dec, parts = build_transformer(c)
+            return enc, None, dec, parts
+    else:
+        cfg = dict(RNN_DEFAULT, seed=31, batch=3, beam=[3, 5, 0.6])
+        series = rnn_series(cfg)
+        builder = build_rnn
+    k, max_steps, alpha = cfg["beam"]
+    n_models = 3
+    out = {}
+    inputs = string_inputs("source", "target")
+    stores = []
+    base_factory = tf_eager.VARIABLE_FACTORY
+    for m in range(n_models):                       # the variables of "session" m: another seed per model
+        tf_eager.VARIABLE_FACTORY = lambda name, shape, dt, init, m=m: base_factory("model{}/".format(m) + name,
+                                                                                    shape, dt, init)
+        fresh_graph()
+        enc, att, dec, parts = builder(cfg)
+        with tf_eager.feeding(feed(parts, dataset(series), False, inputs)):
+            dec.runtime_logits.numpy()
+        order, params = variables()
+        stores.append(params)
+        for n in order:
+            out["p{}/{}".format(m, n)] = params[n]
+    groups = [list(range(cfg["batch"]))] if family == "transformer" else [[i] for i in range(cfg["batch"])]
+    for i, rows in enumerate(groups):
+        one = {name: [vals[r] for r in rows] for name, vals in series.items()}
+        # one graph per session, as TensorFlowManager holds one tf.Session (= one set of variable values) each
+        sessions = []
+        for m in range(n_models):
+            factory = lambda name, shape, dt, init, m=m: stores[m][name]
+            with tf_eager.session_store(None, factory) as store:      # variables are created lazily, at first use
+                enc, att, dec, parts = builder(cfg)
+                bs = BeamSearchDecoder(name="beam", parent_decoder=dec, beam_size=k, max_steps=max_steps,
+                                       length_normalization=alpha)
+                fd = feed(parts + [bs], dataset(one), False, inputs)
+            sessions.append((bs, fd, store, factory))
+        runner = BeamSearchRunner(output_series="hyp", decoder=sessions[0][0], rank=1)
+        ex = runner.get_executable(compute_losses=False, summaries=False, num_sessions=n_models)
+        first = sessions[0][0]
+        calls = 0
+        while ex.result is None:
+            # (graph construction in TF; in the eager stand-in the first access of ``outputs`` COMPUTES: it has to
+            # happen under the feeds of the first call -- max_steps 0: the initial loop state, no beam body)
+            zero = dict(sessions[0][1])
+            zero[first.max_steps] = 0
+            with tf_eager.session_store(sessions[0][2], sessions[0][3]), tf_eager.feeding(zero):
+                _, extra_feeds = ex.next_to_execute()
+            results = []
+            for (bs, fd, store, factory), extra in zip(sessions, extra_feeds):
+                # the runner's feeds name tensors of ITS decoder (session 0's graph); every session's graph has the
+                # same structure, fed by position
+                mapped = {}
+                for key, val in extra.items():
+                    if key is first.max_steps:
+                        mapped[bs.max_steps] = val
+                    else:
+                        with tf_eager.session_store(store, factory), tf_eager.feeding(fd):
+                            mine = {id(first.search_state): lambda: bs.search_state,
+                                    id(first.search_results): lambda: bs.search_results,
+                                    id(first.decoder_state): lambda: bs.decoder_state}[id(key)]()
+                        mapped[mine] = val
+                base = dict(fd)
+                base[bs.max_steps] = mapped.pop(bs.max_steps)
+                with tf_eager.session_store(store, factory), tf_eager.feeding(base):
+                    with tf_eager.feeding(mapped):
+                        if calls == 0:
+                            res = bs.outputs                # builds the initial loop state (one parent step) + loop
+                        else:
+                            # session.run again: the same loop from the FED state; the encoder states the parent
+                            # attends to are tiled to the beam as ``outputs`` tiles them (beam_search_decoder.py:166-178)
+                            par = bs.parent_decoder
+                            es, em = par.encoder_states, par.encoder_masks
+                            par.encoder_states = lambda es=es: [bs.expand_to_beam(x) for x in es()]
+                            par.encoder_masks = lambda em=em: [bs.expand_to_beam(x) for x in em()]
+                            try:
+                                with bs.use_scope():
+                                    res = bs.decoding_loop()
+                            finally:
+                                par.encoder_states, par.encoder_masks = es, em
+                        results.append(to_numpy({"bs_outputs": res}))
+            ex.collect_results(results)
+            calls += 1
+        pre = "out/ens{}_".format(i)
+        out[pre + "calls"] = np.asarray(calls)
+        out[pre + "sentence"] = np.asarray([joined(sent) for sent in ex.result.outputs["hyp"]])
+        out[pre + "loss"] = np.asarray(ex.result.losses["hyp/beam_search_score"])
+        last = results[0]["bs_outputs"]
+        out[pre + "token_ids"] = last.last_search_step_output.token_ids
+        out[pre + "scores"] = last.last_search_step_output.scores
+    tf_eager.VARIABLE_FACTORY = base_factory
+    fresh_graph()
+    out["in/src_ids_note"] = np.asarray("sources / targets are those of rnn_series(cfg) with cfg in the 'cfg' entry")
+    with tf_eager.feeding({}):
+        pass
+    # source ids for the oracle
+    fresh_graph()
+    enc, att, dec, parts = builder(cfg)
+    with tf_eager.feeding(feed(parts, dataset(series), False, inputs)):
+        out["in/src_ids"] = enc.input_sequence.inputs.numpy()
+        out["out/enc_mask"] = enc.temporal_mask.numpy()
+    fresh_graph()
+    save(case, dict(cfg, n_models=n_models, family=family), out)
+
+
 def run_defects(case):
     """Configurations the reference cannot execute at this commit: the exception IS the reference behaviour."""
     import traceback
@@ -580,6 +791,16 @@ def run_defects(case):
         here = [t for t in tb if t.filename.startswith(REFERENCE)][-1]
         found["coverage"] = "{}:{} {}: {}".format(os.path.relpath(here.filename, REFERENCE), here.lineno,
                                                   type(exc).__name__, exc)
+    # BeamSearchRunner over several sessions of an RNN decoder: an unhashable feed key (see run_ensemble)
+    try:
+        run_ensemble("_rnn_ensemble_probe", family="rnn")
+        found["rnn_ensemble"] = ""
+    except TypeError as exc:
+        tb = [t for t in traceback.extract_tb(exc.__traceback__) if t.filename.startswith(REFERENCE)][-1]
+        found["rnn_ensemble"] = "{}:{} {}: {}".format(os.path.relpath(tb.filename, REFERENCE), tb.lineno,
+                                                      type(exc).__name__, exc)
+    finally:
+        tf_eager.VARIABLE_FACTORY = variable_factory
     fresh_graph()
     print(json.dumps(found, indent=1))
     save(case, found, {})
@@ -607,6 +828,20 @@ CASES = collections.OrderedDict([
                                  encoder_projection="empty", seed=8)),
     ("captioning", lambda: run_rnn("captioning", spatial=[3, 3, 10, None, None], seed=9)),
     ("captioning_projected", lambda: run_rnn("captioning_projected", spatial=[2, 3, 10, 9, 8], seed=10)),
+    ("ms_flat", lambda: run_multisource("ms_flat")),
+    ("ms_flat_share_sentinel", lambda: run_multisource("ms_flat_share_sentinel", share=True, sentinel=True, seed=22,
+                                                       dec_cell="NematusGRU", conditional_gru=True)),
+    ("ms_flat_projected_sentinel", lambda: run_multisource("ms_flat_projected_sentinel", sentinel=True, seed=23,
+                                                           image=[2, 3, 7, None, 8])),
+    ("ms_hier", lambda: run_multisource("ms_hier", kind="hier", seed=24)),
+    ("ms_hier_share_sentinel", lambda: run_multisource("ms_hier_share_sentinel", kind="hier", share=True,
+                                                       sentinel=True, state_size=6, seed=25)),
+    ("dotprod_heads2", lambda: run_multisource("dotprod_heads2", kind="dotprod", heads=2, enc_size=3, seed=26)),
+    ("dotprod_heads1", lambda: run_multisource("dotprod_heads1", kind="dotprod", heads=1, enc_size=3, seed=27,
+                                               dec_cell="LSTM")),
+    ("factored_smoothing", lambda: run_multisource("factored_smoothing", kind="plain", factored=True,
+                                                   label_smoothing=0.1, seed=28)),
+    ("ensemble", lambda: run_ensemble("ensemble")),
     ("transformer", lambda: run_transformer("transformer")),
     ("transformer_bias_untied", lambda: run_transformer(
         "transformer_bias_untied", tie_embeddings=False, use_att_transform_bias=True, heads=4, heads_self=1,

@@ -195,10 +195,15 @@ _FEEDS = [{}]       # stack of active feed dictionaries: id(placeholder) -> nump
 def feeding(feed_dict):
     """Make ``feed_dict`` ({placeholder: value}) the active feeds (what Session.run(feed_dict=...) does)."""
     frame = dict(_FEEDS[-1])
-    for k, v in feed_dict.items():
-        if not isinstance(k, Tensor):
-            raise TypeError("feed key is not a tensor: {!r}".format(k))
-        frame[id(k)] = k._coerce_feed(v)
+    for key, val in feed_dict.items():
+        # a key may be a nested structure of tensors fed with the same structure of values (TF flattens both)
+        keys, vals = (nest.flatten(key), nest.flatten(val)) if nest.is_sequence(key) else ([key], [val])
+        if len(keys) != len(vals):
+            raise ValueError("feed structure mismatch for {!r}".format(key))
+        for k, v in zip(keys, vals):
+            if not isinstance(k, Tensor):
+                raise TypeError("feed key is not a tensor: {!r}".format(k))
+            frame[id(k)] = k._coerce_feed(v)
     _FEEDS.append(frame)
     try:
         yield
@@ -288,10 +293,15 @@ class Tensor:
 
     # -- value -----------------------------------------------------------------------------------------------------
     def numpy(self):
+        feeds = _FEEDS[-1]
+        if feeds and id(self) in feeds:          # Session.run(feed_dict=...) may override ANY tensor, not only placeholders
+            return feeds[id(self)]
         return self._value
 
     def _coerce_feed(self, v):
-        return np.asarray(v)
+        mine = self._value
+        v = np.asarray(v)
+        return v.astype(mine.dtype) if mine is not None and mine.dtype.kind != "O" else v
 
     # -- static information ------------------------------------------------------------------------------------------
     @property
@@ -584,6 +594,21 @@ def reset_default_graph():
     _LAYER_UIDS.clear()
 
 
+@contextlib.contextmanager
+def session_store(store=None, factory=None):
+    """Run the enclosed code against another variable store (and variable factory): one per tf.Session that holds
+    its own values of the same variable names (ensembles: runners/beamsearch_runner.py, tf_manager.py:158-185)."""
+    global _STORE, VARIABLE_FACTORY
+    saved = (_STORE, VARIABLE_FACTORY)
+    _STORE = store if store is not None else _Store()
+    if factory is not None:
+        VARIABLE_FACTORY = factory
+    try:
+        yield _STORE
+    finally:
+        _STORE, VARIABLE_FACTORY = saved
+
+
 def get_variable_scope():
     return _STORE.scope
 
@@ -838,6 +863,13 @@ def stop_gradient(x, name=None):
 
 def Print(x, data, message=None, **_):      # noqa: N802
     return _t(x)
+
+
+def assert_equal(x, y, data=None, summarize=None, message=None, name=None):
+    a, b = _binary_operands(x, y)
+    if not np.array_equal(a, b):
+        raise AssertionError("tf.assert_equal failed: {} {!r} vs {!r}".format(message or "", a, b))
+    return no_op()
 
 
 def no_op(name=None):

@@ -18,7 +18,10 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import dotprod_ref as D
+from oracle import ensemble_ref as E
 from oracle import general_ref as G
+from oracle import multisource_ref as M
 from oracle import nm_oracle as O
 from oracle import transformer_ref as T
 
@@ -60,7 +63,7 @@ def sentence(ids, vocab):
 
 def test_every_generated_case_is_checked_here():
     have = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(FIX, "*.npz")))
-    checked = sorted(["functions", "beam_body", "defects"] + RNN_CASES + TRANSFORMER_CASES)
+    checked = sorted(["functions", "beam_body", "defects", "ensemble"] + RNN_CASES + TRANSFORMER_CASES + VARIANT_CASES)
     assert have == checked
 
 
@@ -150,6 +153,7 @@ def test_reference_defects_are_recorded():
     z, cfg, _ = load("defects")
     assert "prev_contexts" in cfg["attention_on_input"]          # decoder.py:273: feedables.prev_contexts
     assert cfg["coverage"]                                       # coverage.py:52: .size() on a tf.Tensor
+    assert "unhashable" in cfg["rnn_ensemble"]                   # beamsearch_runner.py:70-75 over an RNN Decoder
 
 
 # --------------------------------------------------------------------------------------------------------------------
@@ -334,3 +338,76 @@ def test_transformer_equals_the_reference(case):
     tok, scores, _ = model.beam(src, k, max_steps, alpha)
     same(tok, z["out/beam_token_ids"], "beam token_ids")
     close(scores, z["out/beam_scores"], "beam scores", 4e-6)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# attention variants on the RNN decoder: combinations over two encoders, dot-product attention, factored input
+# --------------------------------------------------------------------------------------------------------------------
+VARIANT_CASES = ["ms_flat", "ms_flat_share_sentinel", "ms_flat_projected_sentinel", "ms_hier", "ms_hier_share_sentinel",
+                 "dotprod_heads2", "dotprod_heads1", "factored_smoothing"]
+
+
+def variant_model(cfg, params):
+    layers = ((cfg["enc_size"], "bidirectional", "GRU"),)
+    gcfg = G.Config(rnn_layers=layers, dec_cell=cfg["dec_cell"], conditional_gru=cfg["conditional_gru"],
+                    rnn_size=cfg["rnn_size"], label_smoothing=cfg["label_smoothing"] or 0.0)
+    if cfg["kind"] in ("flat", "hier"):
+        mcfg = M.MultiConfig(kind=cfg["kind"], att_name="wrapper", state_size=cfg["state_size"], share=cfg["share"],
+                             sentinel=cfg["sentinel"], image_name="imagenet",
+                             image_spatial=(cfg["image"][3], cfg["image"][4]))
+        return M.MultiSourceModel(params, gcfg, mcfg)
+    if cfg["kind"] == "dotprod":
+        return D.DotProdModel(params, gcfg, cfg["heads"])
+    return G.GeneralModel(params, gcfg)
+
+
+@pytest.mark.parametrize("case", VARIANT_CASES)
+def test_attention_variants_equal_the_reference(case):
+    z, cfg, params = load(case)
+    model = variant_model(cfg, params)
+    ids = z["in/src_ids"]
+    if cfg["factored"]:
+        ids = np.stack([ids, z["in/tag_ids"]])
+    src = (ids, z["in/maps"]) if cfg["kind"] in ("flat", "hier") else ids
+    tgt = z["in/tgt_ids"]
+    with torch.no_grad():
+        loss, logits, _ = model.train_loss(src, tgt, train=False)
+    close(logits, z["out/train_logits"], "train_logits")
+    close(loss, z["out/train_loss"], "train_loss")
+    syms, masks, run_logits = model.greedy(src, cfg["max_output_len"])
+    same(syms, z["out/runtime_symbols"], "runtime symbols")
+    same(masks, z["out/runtime_mask"], "runtime mask")
+    close(run_logits, z["out/runtime_logits"], "runtime_logits")
+
+
+def test_beam_search_ensemble_equals_the_reference_runner():
+    """runners/beamsearch_runner.py:38-82 driven call by call over three sets of variables of the Transformer model
+    (over an RNN decoder the reference's runner raises TypeError at this commit: ``defects``)."""
+    z, cfg, _ = load("ensemble")
+    n = cfg["n_models"]
+    tcfg = transformer_config(cfg)
+    models = [T.TransformerModel({k[len("p%d/" % m):]: z[k] for k in z.files if k.startswith("p%d/" % m)}, tcfg)
+              for m in range(n)]
+    k, max_steps, alpha = cfg["beam"]
+    res = E.beam_ensemble_transformer(models, z["in/src_ids"], k, max_steps, alpha)
+    assert res.min_gap > 1e-5
+    same(res.token_ids[1:], z["out/ens0_token_ids"][1:], "ensemble token_ids")
+    close(res.scores, z["out/ens0_scores"], "ensemble scores", 4e-6)
+    sents, loss = O.beam_tokens(res, 1)
+    vocab = words(cfg["tgt_vocab"])
+    for got, want, toks in zip(sents, z["out/ens0_sentence"], np.transpose(res.token_ids, (1, 2, 0))):
+        if toks[0][1] != O.END:
+            assert sentence(got, vocab) == str(want)
+    close(loss, z["out/ens0_loss"], "runner loss", 4e-6)
+    # one call with max_steps 0 (the initial loop state) + one call per beam body
+    assert int(z["out/ens0_calls"]) == res.token_ids.shape[0]
+
+
+def test_single_model_ensemble_is_the_plain_search():
+    """The ensemble invariant of the reference's tests/tests_run.sh:41-50, on the oracle."""
+    z, cfg, params = load("transformer")
+    model = T.TransformerModel(params, transformer_config(cfg))
+    k, max_steps, alpha = cfg["beam"]
+    res = E.beam_ensemble_transformer([model], z["in/src_ids"], k, max_steps, alpha)
+    same(res.token_ids[1:], z["out/beam_token_ids"][1:], "token_ids")
+    close(res.scores, z["out/beam_scores"], "scores", 4e-6)
