@@ -371,6 +371,19 @@ int nm_blend_fwd(void* stream, const float* u, int64_t ldu, const float* h, int6
 int nm_blend_bwd(void* stream, const float* dy, int64_t lddy, const float* u, int64_t ldu, const float* h,
                  int64_t ldh, const float* c, int64_t ldc, float* du, int64_t lddu, float* dh,
                  int64_t lddh, float* dc, int64_t lddc, int64_t rows, int64_t cols);
+/* The point-wise part of one LSTMCell step (SURVEY 8(b)4 nm_lstm_cell_{fwd,bwd}; tf.nn.rnn_cell.LSTMCell as the
+ * reference uses it: decoders/decoder.py:29,309-325, encoders/recurrent.py:21).  z [rows, 4H] = [x, h].W + b from the
+ * caller's products, gate order i, j, f, o:  c' = sigmoid(f + forget_bias) c + sigmoid(i) tanh(j),
+ * h' = sigmoid(o) tanh(c').  gates (optional) receives the ACTIVATED gates [rows, 4H] for the backward.
+ * bwd: dh / dc_new may be NULL (no gradient from that side); dz is written (accumulate_dz 0) or added to;
+ * dc_prev (optional) likewise. */
+int nm_lstm_cell_fwd(void* stream, const float* z, int64_t ldz, const float* c_prev, int64_t ldc, float* c_new,
+                     int64_t ldcn, float* h_new, int64_t ldh, float* gates, int64_t ldg, int64_t rows, int64_t H,
+                     float forget_bias);
+int nm_lstm_cell_bwd(void* stream, const float* dh, int64_t lddh, const float* dc_new, int64_t lddc,
+                     const float* gates, int64_t ldg, const float* c_prev, int64_t ldc, const float* c_new,
+                     int64_t ldcn, float* dz, int64_t lddz, float* dc_prev, int64_t lddcp, int64_t rows, int64_t H,
+                     int accumulate_dz, int accumulate_dc_prev);
 /* nn/utils.py:6-22 (tf.nn.dropout): keep iff floor(keep_prob + u_i) == 1, scale 1/keep_prob;
  * u_i = hash(salt, i) (counter based: the backward pass and the CPU oracle regenerate the mask) */
 int nm_dropout(void* stream, const float* x, int64_t ldx, float* out, int64_t ldo, int64_t rows,

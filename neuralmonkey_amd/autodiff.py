@@ -28,12 +28,13 @@ from . import ops
 
 class Var:
     """A tensor on the tape plus (lazily) its gradient."""
-    __slots__ = ("data", "grad", "needs_grad")
+    __slots__ = ("data", "grad", "needs_grad", "fresh")
 
     def __init__(self, data: torch.Tensor, grad: Optional[torch.Tensor] = None, needs_grad: bool = True):
         self.data = data
         self.grad = grad
         self.needs_grad = needs_grad
+        self.fresh = False          # ``grad`` was handed out unwritten: the first contribution overwrites it
 
     @property
     def shape(self):
@@ -83,6 +84,9 @@ class Tape:
             return None
         if v.grad is None:
             v.grad = self.buf(tuple(v.data.shape), zero=True)
+        elif v.fresh:
+            v.grad.zero_()
+            v.fresh = False
         return v.grad
 
     def grad_slot(self, v: Var):
@@ -94,6 +98,9 @@ class Tape:
             return None, False
         if v.grad is None:
             v.grad = self.buf(tuple(v.data.shape), zero=False)
+            return v.grad, False
+        if v.fresh:                 # a pre-assigned slice of a shared buffer (linear_multi) that nobody wrote yet
+            v.fresh = False
             return v.grad, False
         return v.grad, True
 
@@ -150,6 +157,66 @@ def linear(tape: Tape, x: Var, w: Var, b: Optional[Var] = None, out: Optional[Va
             ops.colsum(dy, tape.grad(b), accumulate=True)
     tape.record(bwd)
     return out
+
+
+def lstm_cell(tape: Tape, z: Var, c_prev: Var, forget_bias: float = 1.0):
+    """(h', c') of one LSTMCell step from its pre-activations z = [x, h].W + b [R, 4H] (gate order i, j, f, o) in
+    ONE launch forward and one backward (nm_lstm_cell_fwd / _bwd) -- was four activation and four element-wise
+    launches each way (decoders/decoder.py:309-325, encoders/recurrent.py:21 around tf's LSTMCell)."""
+    rows, h = c_prev.shape
+    c_new, h_new = tape.new((rows, h)), tape.new((rows, h))
+    gates = tape.buf((rows, 4 * h)) if tape.recording else None
+    ops.lstm_cell_fwd(z.data, c_prev.data, c_new.data, h_new.data, gates, forget_bias)
+
+    def bwd():
+        if h_new.grad is None and c_new.grad is None:
+            return
+        dz, acc_z = tape.grad_slot(z)
+        dcp, acc_c = tape.grad_slot(c_prev)
+        if dz is None:
+            return
+        ops.lstm_cell_bwd(h_new.grad, c_new.grad, gates, c_prev.data, c_new.data, dz, dcp, acc_z, acc_c)
+    tape.record(bwd)
+    return h_new, c_new
+
+
+def linear_multi(tape: Tape, x: Var, ws: List[Var]) -> List[Var]:
+    """``[x . w for w in ws]`` -- the query / key / value projections of one attention block read the same rows
+    (attention/scaled_dot_product.py:170-176) -- as ONE batched product when the kernels lie back to back in the flat
+    parameter buffer: grid z = len(ws) fills the chip with 128x128 tiles (600 workgroups for three 6400 x 512 x 512
+    products) where each product alone runs on 64x64 tiles at 65-73 TF.  The outputs (and their gradients) are the
+    slices of one [n, rows, N] buffer.  Backward: the weight gradients stay separate products (they split K over
+    workgroups, which the batched launch cannot), the input gradient is the sum over the projections as before.
+    Falls back to separate products when the kernels are not adjacent."""
+    n = len(ws)
+    w0 = ws[0].data
+    adjacent = n > 1 and all(
+        w.data.shape == w0.shape and w.data.is_contiguous()
+        and w.data.data_ptr() == w0.data_ptr() + i * w0.numel() * w0.element_size() for i, w in enumerate(ws))
+    if not adjacent:
+        return [linear(tape, x, w) for w in ws]
+    rows, k = x.shape
+    nout = w0.shape[1]
+    w3 = torch.as_strided(w0, (n, k, nout), (k * nout, nout, 1))
+    out3 = tape.buf((n, rows, nout))
+    ops.gemm(x.data.unsqueeze(0).expand(n, rows, k), w3, out=out3)
+    outs = [Var(out3[i], None, tape.recording) for i in range(n)]
+    if tape.recording:
+        g3 = tape.buf((n, rows, nout))
+        for i, o in enumerate(outs):
+            o.grad, o.fresh = g3[i], True
+
+    def bwd():
+        for o, w in zip(outs, ws):
+            if o.fresh:                      # nobody consumed this projection
+                continue
+            if x.needs_grad:
+                gx, acc = tape.grad_slot(x)
+                ops.gemm(o.grad, w.data, out=gx, trans_b=True, accumulate=acc)
+            if w.needs_grad:
+                ops.gemm(x.data, o.grad, out=tape.grad(w), trans_a=True, accumulate=True)
+    tape.record(bwd)
+    return outs
 
 
 def _unary(tape: Tape, op: str, bwd_op: Optional[str], x: Var, alpha: float = 0.0,

@@ -214,6 +214,89 @@ __host__ __device__ __forceinline__ uint32_t nm_mix32(uint32_t x) {
 // ``step`` (optional device scalar: the optimizer's global step) advances the salt on the device,
 // salt_eff = salt + step * 0x9E3779B9, so that a training step captured once into a HIP graph draws
 // fresh masks at every replay.
+// ---------------------------------------------------------------------------
+// LSTMCell point-wise part (tf.nn.rnn_cell.LSTMCell without peepholes / projection: decoders/decoder.py:29,309-325,
+// encoders/recurrent.py:21): z = [x, h].W + b comes from the caller's products, gate order i, j, f, o;
+//   c' = sigmoid(f + forget_bias) c + sigmoid(i) tanh(j) ;  h' = sigmoid(o) tanh(c')
+// One launch instead of four activations + four element-wise products; the activated gates are kept for the backward.
+// ---------------------------------------------------------------------------
+__global__ void lstm_cell_fwd_kernel(const float* __restrict__ z, long ldz, const float* __restrict__ c_prev, long ldc,
+                                     float* __restrict__ c_new, long ldcn, float* __restrict__ h_new, long ldh,
+                                     float* __restrict__ gates, long ldg, long rows, int H, float forget_bias) {
+    const long total = rows * H;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx / H;
+        const int k = (int)(idx - r * H);
+        const float* zr = z + r * ldz;
+        const float gi = nm_sigmoid(zr[k]);
+        const float gj = nm_tanh(zr[H + k]);
+        const float gf = nm_sigmoid(zr[2 * H + k] + forget_bias);
+        const float go = nm_sigmoid(zr[3 * H + k]);
+        const float c = gf * c_prev[r * ldc + k] + gi * gj;
+        c_new[r * ldcn + k] = c;
+        h_new[r * ldh + k] = go * nm_tanh(c);
+        if (gates) {
+            float* gr = gates + r * ldg;
+            gr[k] = gi; gr[H + k] = gj; gr[2 * H + k] = gf; gr[3 * H + k] = go;
+        }
+    }
+}
+
+// dz = [di i (1-i), dj (1-j^2), df f (1-f), do o (1-o)] with tc = tanh(c'), do = dh tc, dc = dc' + dh o (1 - tc^2),
+// di = dc j, dj = dc i, df = dc c, dc_prev (+)= dc f
+__global__ void lstm_cell_bwd_kernel(const float* __restrict__ dh, long lddh, const float* __restrict__ dc_new, long lddc,
+                                     const float* __restrict__ gates, long ldg, const float* __restrict__ c_prev,
+                                     long ldc, const float* __restrict__ c_new, long ldcn, float* __restrict__ dz,
+                                     long lddz, float* __restrict__ dc_prev, long lddcp, long rows, int H, int acc_dz,
+                                     int acc_dcp) {
+    const long total = rows * H;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx / H;
+        const int k = (int)(idx - r * H);
+        const float* gr = gates + r * ldg;
+        const float gi = gr[k], gj = gr[H + k], gf = gr[2 * H + k], go = gr[3 * H + k];
+        const float tc = nm_tanh(c_new[r * ldcn + k]);
+        const float g_h = dh ? dh[r * lddh + k] : 0.0f;
+        const float dc = (dc_new ? dc_new[r * lddc + k] : 0.0f) + g_h * go * (1.0f - tc * tc);
+        float* dr = dz + r * lddz;
+        const float d_i = dc * gj * gi * (1.0f - gi), d_j = dc * gi * (1.0f - gj * gj);
+        const float d_f = dc * c_prev[r * ldc + k] * gf * (1.0f - gf), d_o = g_h * tc * go * (1.0f - go);
+        if (acc_dz) { dr[k] += d_i; dr[H + k] += d_j; dr[2 * H + k] += d_f; dr[3 * H + k] += d_o; }
+        else { dr[k] = d_i; dr[H + k] = d_j; dr[2 * H + k] = d_f; dr[3 * H + k] = d_o; }
+        if (dc_prev) {
+            if (acc_dcp) dc_prev[r * lddcp + k] += dc * gf;
+            else dc_prev[r * lddcp + k] = dc * gf;
+        }
+    }
+}
+
+extern "C" int nm_lstm_cell_fwd(void* stream, const float* z, int64_t ldz, const float* c_prev, int64_t ldc,
+                                float* c_new, int64_t ldcn, float* h_new, int64_t ldh, float* gates, int64_t ldg,
+                                int64_t rows, int64_t H, float forget_bias) {
+    NM_REQUIRE(z && c_prev && c_new && h_new, "nm_lstm_cell_fwd: null pointer");
+    NM_REQUIRE(rows >= 0 && H > 0 && ldz >= 4 * H && ldc >= H && ldcn >= H && ldh >= H && (!gates || ldg >= 4 * H),
+               "nm_lstm_cell_fwd: bad shape rows=%ld H=%ld", (long)rows, (long)H);
+    if (rows == 0) return NM_OK;
+    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(ew_blocks(rows * H)), dim3(256), 0, nm_stream(stream), z, (long)ldz,
+                       c_prev, (long)ldc, c_new, (long)ldcn, h_new, (long)ldh, gates, (long)ldg, (long)rows, (int)H,
+                       forget_bias);
+    NM_LAUNCH_CHECK("nm_lstm_cell_fwd");
+}
+
+extern "C" int nm_lstm_cell_bwd(void* stream, const float* dh, int64_t lddh, const float* dc_new, int64_t lddc,
+                                const float* gates, int64_t ldg, const float* c_prev, int64_t ldc, const float* c_new,
+                                int64_t ldcn, float* dz, int64_t lddz, float* dc_prev, int64_t lddcp, int64_t rows,
+                                int64_t H, int accumulate_dz, int accumulate_dc_prev) {
+    NM_REQUIRE(gates && c_prev && c_new && dz, "nm_lstm_cell_bwd: null pointer");
+    NM_REQUIRE(rows >= 0 && H > 0 && ldg >= 4 * H && lddz >= 4 * H && ldc >= H && ldcn >= H,
+               "nm_lstm_cell_bwd: bad shape rows=%ld H=%ld", (long)rows, (long)H);
+    if (rows == 0) return NM_OK;
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(ew_blocks(rows * H)), dim3(256), 0, nm_stream(stream), dh, (long)lddh,
+                       dc_new, (long)lddc, gates, (long)ldg, c_prev, (long)ldc, c_new, (long)ldcn, dz, (long)lddz,
+                       dc_prev, (long)lddcp, (long)rows, (int)H, accumulate_dz, accumulate_dc_prev);
+    NM_LAUNCH_CHECK("nm_lstm_cell_bwd");
+}
+
 __global__ void dropout_kernel(const float* __restrict__ x, long ldx, float* __restrict__ out, long ldo,
                                long rows, int cols, float keep_prob, float inv_keep, uint32_t salt,
                                const uint32_t* __restrict__ step, int acc) {

@@ -126,13 +126,7 @@ class LSTMCell(Cell):
         w, b = tape.param(self.part, self._n("kernel")), tape.param(self.part, self._n("bias"))
         z = F.linear(tape, x, tape.rows(w, 0, d), b)
         F.linear(tape, h_prev, tape.rows(w, d, d + h), out=z, accumulate=True)
-        i = F.sigmoid(tape, tape.cols(z, 0, h))
-        j = F.tanh(tape, tape.cols(z, h, 2 * h))
-        f = F.sigmoid(tape, tape.cols(z, 2 * h, 3 * h), shift=1.0)
-        o = F.sigmoid(tape, tape.cols(z, 3 * h, 4 * h))
-        c_new = F.mul(tape, f, c_prev)
-        F.add_(tape, c_new, F.mul(tape, i, j))
-        h_new = F.mul(tape, o, F.tanh(tape, c_new))
+        h_new, c_new = F.lstm_cell(tape, z, c_prev, forget_bias=1.0)      # gates + blend: one launch each way
         return h_new, (c_new, h_new)
 
 

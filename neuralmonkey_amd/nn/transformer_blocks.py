@@ -79,9 +79,18 @@ def multihead_attention(tape: F.Tape, part, scope: str, queries: F.Var, keys: F.
                         heads: int, bq: int, tq: int, bk: int, tk: int, causal: bool, keep_prob: float,
                         train: bool, salt: int, use_bias: bool) -> F.Var:
     """attention() of scaled_dot_product.py:98-226 with keys == values."""
-    q = project(tape, part, scope, "query_proj", queries, heads, use_bias)
-    k = project(tape, part, scope, "keys_proj", keys, heads, use_bias)
-    v = project(tape, part, scope, "vals_proj", keys, heads, use_bias)
+    if heads > 1 and not use_bias and queries.shape[0] >= 1024:
+        # training / encoding shapes: projections that read the same rows go out as one batched product
+        kern = lambda proj: tape.param(part, "{}/{}/kernel".format(scope, proj))
+        if queries is keys:
+            q, k, v = F.linear_multi(tape, queries, [kern("query_proj"), kern("keys_proj"), kern("vals_proj")])
+        else:
+            q = project(tape, part, scope, "query_proj", queries, heads, use_bias)
+            k, v = F.linear_multi(tape, keys, [kern("keys_proj"), kern("vals_proj")])
+    else:
+        q = project(tape, part, scope, "query_proj", queries, heads, use_bias)
+        k = project(tape, part, scope, "keys_proj", keys, heads, use_bias)
+        v = project(tape, part, scope, "vals_proj", keys, heads, use_bias)
     ctx = F.sdp_attention(tape, q, k, v, key_mask, heads, bq, tq, bk, tk, causal,
                           keep_prob if train else 1.0, salt)
     return project(tape, part, scope, "output_proj", ctx, heads, use_bias)

@@ -582,6 +582,27 @@ def blend_fwd(u, h, c, out):
     return out
 
 
+def lstm_cell_fwd(z, c_prev, c_new, h_new, gates=None, forget_bias=1.0):
+    """One LSTMCell step after its products: z [R,4H] (i, j, f, o) -> c', h' (+ the activated gates)."""
+    lib = _lib.load()
+    rows, h = c_prev.shape
+    assert z.shape == (rows, 4 * h) and z.stride(1) == 1
+    _lib.check(lib.nm_lstm_cell_fwd(_stream(), z.data_ptr(), z.stride(0), c_prev.data_ptr(), _rc(c_prev)[2],
+                                    c_new.data_ptr(), _rc(c_new)[2], h_new.data_ptr(), _rc(h_new)[2], _p(gates),
+                                    0 if gates is None else gates.stride(0), rows, h, float(forget_bias)),
+               "nm_lstm_cell_fwd")
+
+
+def lstm_cell_bwd(dh, dc_new, gates, c_prev, c_new, dz, dc_prev, accumulate_dz=False, accumulate_dc_prev=False):
+    lib = _lib.load()
+    rows, h = c_prev.shape
+    ld = lambda t: 0 if t is None else _rc(t)[2]
+    _lib.check(lib.nm_lstm_cell_bwd(_stream(), _p(dh), ld(dh), _p(dc_new), ld(dc_new), gates.data_ptr(),
+                                    gates.stride(0), c_prev.data_ptr(), ld(c_prev), c_new.data_ptr(), ld(c_new),
+                                    dz.data_ptr(), dz.stride(0), _p(dc_prev), ld(dc_prev), rows, h,
+                                    int(accumulate_dz), int(accumulate_dc_prev)), "nm_lstm_cell_bwd")
+
+
 def blend_bwd(dy, u, h, c, du, dh, dc):
     lib = _lib.load()
     rows, cols, ldu = _rc(u)
