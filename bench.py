@@ -320,6 +320,46 @@ def captioning_leg(args, dev, lib):
                          "evidence": files or None}}
 
 
+def bf16x3_costing_leg(args, dev, lib):
+    """VERDICT r3 item 10 -- COSTED, NOT SHIPPED: the vocabulary projection's product shape (states . E^T, the tied /
+    "NT" form: M = B*len, N = V, K = hidden) through a three-term split-bf16 emulation on the bf16 matrix cores
+    (csrc/nm_gemm_bf16x3.hip) next to the exact-fp32 kernel every number above uses.  Its own dtype, its own entry;
+    nothing in the headline or in the other configs runs it."""
+    from neuralmonkey_amd import _lib, ops
+    m, n, k = args.batch * args.length, args.vocab, args.hidden
+    gen = torch.Generator(device=dev).manual_seed(3)
+    a = torch.randn(m, k, device=dev, generator=gen)
+    b = torch.randn(n, k, device=dev, generator=gen) * 0.05
+    c32, c3 = torch.empty(m, n, device=dev), torch.empty(m, n, device=dev)
+
+    def timed(fn, reps=10):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3
+    t32 = timed(lambda: ops.gemm(a, b, out=c32, trans_b=True))
+    call = lambda: _lib.check(lib.nm_gemm_bf16x3_nt(ops._stream(), m, n, k, a.data_ptr(), a.stride(0), b.data_ptr(),
+                                                    b.stride(0), c3.data_ptr(), c3.stride(0), 3, 2), "nm_gemm_bf16x3_nt")
+    t3 = timed(call)
+    exact = a[:256].double() @ b.double().t()
+    scale = float(exact.abs().max())
+    flops = 2.0 * m * n * k
+    return {"workload": "ONE product of the vocabulary-projection shape, C[{},{}] = A[{},{}] . B[{},{}]^T; costing only "
+                        "(VERDICT r3 item 10): not used by any other number in this line".format(m, n, m, k, n, k),
+            "dtype": "bf16x3 (fp32 operands split into bf16 hi + lo, three bf16 MFMA products, fp32 accumulate)",
+            "us": t3, "tflops_equivalent": flops / t3 / 1e6,
+            "max_error_vs_float64_rel_to_max": float((c3[:256].double() - exact).abs().max()) / scale,
+            "exact_f32": {"dtype": "f32", "us": t32, "tflops": flops / t32 / 1e6,
+                          "max_error_vs_float64_rel_to_max": float((c32[:256].double() - exact).abs().max()) / scale},
+            "speedup_over_exact_f32": t32 / t3}
+
+
 def main():
     args = parse()
     from neuralmonkey_amd import _lib, distributed, ops, synthetic
@@ -730,7 +770,8 @@ def main():
             # free the headline model's buffers first: the legs build their own sessions
             legs = {}
             for name, fn in (("transformer", lambda: transformer_leg(args, dev)),
-                             ("captioning", lambda: captioning_leg(args, dev, lib))):
+                             ("captioning", lambda: captioning_leg(args, dev, lib)),
+                             ("logits_gemm_bf16x3", lambda: bf16x3_costing_leg(args, dev, lib))):
                 try:
                     legs[name] = fn()
                 except Exception as exc:                  # pragma: no cover  (never hide the headline number)

@@ -214,6 +214,13 @@ typedef struct nm_step_problem {
 } nm_step_problem;
 int nm_step_group(void* stream, int64_t M, const nm_step_problem* problems, int32_t nproblems);
 
+/* ---- COSTING ONLY (not called by the product path): C[M,N] = A[M,K] . B[N,K]^T with the fp32 operands emulated by
+ * three bf16 matrix-core products (split-bf16: hi.hi + hi.lo + lo.hi, fp32 accumulate; terms = 1: plain bf16).  The
+ * shapes of tf.matmul(state, decoding_w) with tied embeddings (decoders/autoregressive.py:226-251,450-459) and of
+ * its input gradient.  K % 4 == 0, rows 16-byte aligned.  See csrc/nm_gemm_bf16x3.hip, tools/gemm_bf16x3_cost.py. */
+int nm_gemm_bf16x3_nt(void* stream, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+                      int64_t ldb, float* C, int64_t ldc, int terms, int variant /* tile / k-depth choice, 0..3 */);
+
 /* ---- the WHOLE inference step of the headline decoder behind one call (SURVEY 8(b)4 nm_decoder_step_fused):
  * Decoder.next_state, decoders/decoder.py:279-358 (plain GRUCell nn/ortho_gru_cell.py:44-53, ONE Bahdanau
  * attention attention/feed_forward.py:120-166, nonlinear output projection decoders/output_projection.py:115-130)

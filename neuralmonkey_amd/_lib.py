@@ -69,6 +69,7 @@ SIGNATURES = {
     "nm_ew": (I, [P, I, P, L, P, L, P, L, L, L, F, I]),
     "nm_blend_fwd": (I, [P, P, L, P, L, P, L, P, L, L, L]),
     "nm_blend_bwd": (I, [P, P, L, P, L, P, L, P, L, P, L, P, L, P, L, L, L]),
+    "nm_gemm_bf16x3_nt": (I, [P, L, L, L, P, L, P, L, P, L, I, I]),
     "nm_lstm_cell_fwd": (I, [P, P, L, P, L, P, L, P, L, P, L, L, L, F]),
     "nm_lstm_cell_bwd": (I, [P, P, L, P, L, P, L, P, L, P, L, P, L, P, L, L, L, I, I]),
     "nm_dropout": (I, [P, P, L, P, L, L, L, F, ctypes.c_uint32, P, I]),
