@@ -28,7 +28,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
-OUT = os.path.join(HERE, "ref_exec")
+OUT = os.environ.get("NM_REF_EXEC_OUT") or os.path.join(HERE, "ref_exec")
 REFERENCE = "/root/reference"
 
 sys.dont_write_bytecode = True                      # /root/reference is read-only
@@ -276,6 +276,17 @@ def run_rnn(case, **overrides):
         amax = np.argmax(out["out/runtime_logprobs"], axis=2)
         sents = dec.vocabulary.vectors_to_sentences(amax)
         out["out/greedy_sentences"] = np.asarray([" ".join(s) for s in sents])
+        # the trainer's objective (trainers/generic_trainer.py:84-135, cross_entropy_trainer.py:21-53): which variables
+        # the L1 / L2 terms cover (name regex), the terms, the weighted sum.  (Gradients / Adam are TensorFlow's.)
+        if case == "rnn_gru":
+            from neuralmonkey.trainers.cross_entropy_trainer import CrossEntropyTrainer
+            trainer = CrossEntropyTrainer(decoders=[dec], l1_weight=0.3, l2_weight=0.02, clip_norm=1.0)
+            l1, l2 = trainer.regularization_losses
+            out["out/trainer_l1"], out["out/trainer_l2"] = l1.numpy(), l2.numpy()
+            out["out/trainer_loss_sum"] = trainer.differentiable_loss_sum.numpy()
+            out["out/trainer_objective_values"] = np.stack([np.asarray(v.numpy(), np.float32)
+                                                            for v in trainer.objective_values])
+            out["out/trainer_loss_names"] = np.asarray([o.name for o in trainer.objectives] + ["L1", "L2"])
     order_full, _ = variables()
 
     # -- beam search, one sentence at a time (the reference does not tile Bahdanau keys: batch 1 only) ---------------
@@ -304,7 +315,7 @@ def run_rnn(case, **overrides):
             out[pre + "finished"] = bo.last_search_state.finished
             out[pre + "prev_logprobs"] = bo.last_search_state.prev_logprobs
             out[pre + "dec_step"] = bo.last_dec_loop_state.feedables.step
-            out[pre + "sentence"] = np.asarray([joined(sent) for sent in ex.result.outputs["hyp"]])
+            out[pre + "sentence"] = np.asarray(joined(ex.result.outputs["hyp"][0]))
             out[pre + "loss"] = np.asarray(ex.result.losses["hyp/beam_search_score"])
         order_beam, _ = variables()
         missing = [n for n in order_beam if n not in order_full]

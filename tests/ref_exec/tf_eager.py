@@ -395,6 +395,9 @@ class Tensor:
     def __neg__(self):
         return Tensor(-self.numpy())
 
+    def __abs__(self):
+        return Tensor(np.abs(self.numpy()))
+
     def __lt__(self, o):
         return less(self, o)
 

@@ -271,6 +271,24 @@ def test_rnn_family_equals_the_reference(case):
         close(float(np.mean(scores[:, 0])) * scores.shape[0], z[pre + "loss"], "runner loss")
 
 
+def test_trainer_objective_covers_the_variables_the_reference_regularizes():
+    """trainers/generic_trainer.py:84-135: L1 / L2 over the trainable variables whose NAME does not match [Bb]ias
+    (embeddings, layer-norm beta and the vocabulary projection's ``state_to_word_b`` included), the weighted sum
+    with the decoder's cost; loss names of trainers/generic_trainer.py:48-51, trainers/objective.py:85."""
+    z, cfg, params = load("rnn_gru")
+    names = O.regularizable(sorted(params))
+    assert "decoder/state_to_word_b" in names and "encoder/LayerNorm/beta" in names
+    assert not any("bias" in n.lower() for n in names)
+    l1, l2 = O.l1_l2(params)
+    close(l1, z["out/trainer_l1"], "L1 term", 1e-5)
+    close(l2, z["out/trainer_l2"], "L2 term", 1e-5)
+    cost = float(z["out/train_loss"])
+    close(cost + 0.3 * float(l1) + 0.02 * float(l2), z["out/trainer_loss_sum"], "differentiable_loss_sum", 1e-5)
+    assert [str(n) for n in z["out/trainer_loss_names"]] == ["decoder - cost", "L1", "L2"]
+    close(np.asarray([cost, float(l1), float(l2)], np.float32), z["out/trainer_objective_values"], "objective values",
+          1e-5)
+
+
 def test_headline_model_through_the_numpy_oracle_as_well():
     """oracle/nm_oracle.py (the restatement bench.py's CPU baseline and the kernel tests use) on the same fixture."""
     z, cfg, params = load("rnn_gru")
