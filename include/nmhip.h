@@ -39,6 +39,11 @@ nm_ctx* nm_ctx_current(void);
 int nm_ctx_device(nm_ctx* ctx /* NULL: the calling thread's */);
 /* value of a switch as the context read it at creation: NM_ATTN_WHOLE -> "attn_whole" (-1 = unset) ... */
 int nm_ctx_switch(nm_ctx* ctx, const char* name, int* value);
+/* background mode: the launches that follow run beside a latency-bound loop of another stream (the reference
+ * evaluates one batch at a time, tf_manager.py:226-262; here the encoder of batch n+1 runs under the decoding loop of
+ * batch n).  Automatic GEMMs and recurrent step kernels cap their residency per CU (algo 4 of nm_gemm_f32) and
+ * leave the wave priority to the foreground loop. */
+int nm_ctx_set_background(nm_ctx* ctx /* NULL: the calling thread's */, int on);
 /* host utility: CRC-32C (Castagnoli) of a HOST buffer, chained through `crc` (start with 0) -- the
  * checksum of TensorFlow tensor-bundle checkpoints (tf_manager.py:274-288 -> tf.train.Saver) */
 uint32_t nm_crc32c(uint32_t crc, const void* data, int64_t n);
@@ -50,7 +55,9 @@ uint32_t nm_crc32c(uint32_t crc, const void* data, int64_t n);
  * and their tf.gradients transposes.
  * C[M,N] = act(op(A).op(B) + bias (+ C)); transA: A stored [K,M]; transB: B stored [N,K];
  * act 0 none / 1 tanh / 2 relu; batch > 1 strides the three operands;
- * algo 0 auto / 1 tiled-128 / 2 tiled-64 / 3 skinny. fp32 MFMA (exact f32).
+ * algo 0 auto / 1 tiled-128 / 2 tiled-64 / 3 skinny / 4 background: 128x128 tiles, at most NM_GEMM_BG_WGS (1)
+ * workgroups resident per CU, for a long leaf GEMM that runs beside another stream's latency-bound launches.
+ * fp32 MFMA (exact f32).
  * workspace (optional, device): split-K slabs for deep-K / few-tile shapes (weight gradients);
  * slabs are summed in a fixed order, results stay deterministic. */
 int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int64_t N, int64_t K,

@@ -47,6 +47,7 @@ SIGNATURES = {
     "nm_ctx_current": (P, []),
     "nm_ctx_device": (I, [P]),
     "nm_ctx_switch": (I, [P, c_char_p, P]),
+    "nm_ctx_set_background": (I, [P, I]),
     "nm_prof_enable": (I, [P, I]),
     "nm_prof_attn_step": (I, [P, P, P]),
     "nm_row_stats": (I, [P, P, L, L, L, P, P, P]),

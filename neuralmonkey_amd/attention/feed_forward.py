@@ -163,14 +163,15 @@ class Attention(BaseAttention):
         ops.gemm(dy2, wq, out=dquery_accum, trans_b=True, accumulate=True)
         wk = self.var(ctx, "attn_key_projection")
         ops.gemm(dhf.view(bsz * slen, a), wk, out=dstates.view(bsz * slen, c), trans_b=True, accumulate=True)
+        bg = ctx.session.leaf_algo()
         with ctx.session.side():          # leaf gradients of this part's variables
             ops.colsum(dvp, store.g(self.var_name("attn_similarity_v")), accumulate=True)
             ops.colsum(dy2, store.g(self.var_name("attn_projection_bias")), accumulate=True)
             ops.gemm(queries.reshape(rows, -1), dy2,
                      out=store.g(self.var_name("Attention/attn_query_projection")), trans_a=True,
-                     accumulate=True)
+                     accumulate=True, algo=bg)
             ops.gemm(states.reshape(bsz * slen, c), dhf.view(bsz * slen, a),
-                     out=store.g(self.var_name("attn_key_projection")), trans_a=True, accumulate=True)
+                     out=store.g(self.var_name("attn_key_projection")), trans_a=True, accumulate=True, algo=bg)
         return dstates
 
     def tape_session(self, tape, train_mode: bool) -> "AttentionTapeSession":

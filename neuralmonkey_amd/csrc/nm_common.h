@@ -55,6 +55,9 @@ struct NmSwitches {
     int gemm_sk;           // NM_GEMM_SK        split-K override (0 = makespan model)
     int gemm_cfg;          // NM_GEMM_CFG       tile configuration of the large GEMMs (1)
     int gemm_chains;       // NM_GEMM_CHAINS    interleaved accumulation chains of the 64x64 tiles: 1, 2 or 4 (1)
+    int gemm_bg_wgs;       // NM_GEMM_BG_WGS    workgroups per CU of a background GEMM (algo 4): 1..3, 0 = uncapped (1)
+    int background;        // (nm_ctx_set_background, not an environment switch) launches run beside a foreground loop
+    int step_prio;         // NM_STEP_PRIO      skinny (time-loop) GEMM kernels raise their wave priority (1)
     int stats_cfg;         // NM_STATS_CFG      statistics-GEMM tile / prefetch bits (3)
     bool stats_ablate;     // NM_STATS_ABLATE   timing ablation: statistics epilogue skipped
     int beam_ns;           // NM_BEAM_NS        slices per hypothesis row override (0 = by vocabulary size)

@@ -42,6 +42,8 @@ struct GemmArgs {
     int swizzle;     // XCD-aware tile order (gemm_tiled)
     float* stats;    // [M][tiles_n][4] per-tile row statistics (max, sum exp(x-max), argmax bits, -) or null
     int store_c;     // 0: the statistics are the only output (greedy decoding never reads the logits)
+    int prio;        // skinny kernels: raise the wave priority (s_setprio) -- launches of a time loop that share the
+                     // chip with a background GEMM of another stream get the issue slots first
 };
 
 __device__ __forceinline__ float apply_act(float x, int act) {
@@ -664,6 +666,7 @@ __device__ __forceinline__ void gru_epi_apply(const GruEpi& e, const GruPre& q, 
 
 template <int KS, bool TB>
 __global__ __launch_bounds__(KS * 64) void gemm_skinny(GemmArgs g, int tiles_m, GruEpi epi) {
+    if (g.prio) __builtin_amdgcn_s_setprio(3);
     __shared__ float red[KS][16][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bm = blockIdx.x % tiles_m, bn = blockIdx.x / tiles_m;
@@ -829,6 +832,7 @@ __device__ __forceinline__ void skinny16_tile(const GemmArgs& g, int tiles_m, co
 
 template <int KS, bool TB>
 __global__ __launch_bounds__(KS * 64) void gemm_skinny16(GemmArgs g, int tiles_m, GruEpi epi) {
+    if (g.prio) __builtin_amdgcn_s_setprio(3);
     __shared__ float red[KS][4][64];
     skinny16_tile<KS, TB>(g, tiles_m, epi, (int)blockIdx.x, (int)blockIdx.z, red);
 }
@@ -914,44 +918,93 @@ __global__ __launch_bounds__(KS * 64) void gru_seq_fwd_kernel(GruSeq q) {
 // ---------------------------------------------------------------------------
 // host dispatch
 // ---------------------------------------------------------------------------
-static void launch_skinny(const GemmArgs& g, int batch, bool tb, const GruEpi& epi, hipStream_t st) {
+// dynamic LDS that brings a workgroup of ``static_lds`` bytes up to ``want_lds`` (0: no padding)
+static constexpr int NM_GEMM_BG_MAX_PAD = 96 * 1024;        // + a kernel's own LDS (<= 64 KB) stays under a CU's 160 KB
+static inline int bg_pad(int want_lds, int static_lds) {
+    if (want_lds <= static_lds) return 0;
+    const int pad = ((want_lds - static_lds + 255) / 256) * 256;
+    return pad > NM_GEMM_BG_MAX_PAD ? NM_GEMM_BG_MAX_PAD : pad;
+}
+
+// Launch with ``pad`` bytes of dynamic LDS the kernel never touches (residency cap, see nm_gemm_f32 algo 4).  More
+// than 64 KB per workgroup needs the attribute once per kernel and device (``devs``: one bit per device).
+template <typename Kern, typename... Args>
+static void launch_padded(Kern kern, unsigned& devs, int pad, dim3 grid, dim3 block, hipStream_t st, Args... args) {
+    if (pad > 0) {
+        const unsigned bit = 1u << (nm_cur()->device & 31);
+        if (!(devs & bit)) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    NM_GEMM_BG_MAX_PAD) != hipSuccess) {
+                (void)hipGetLastError();
+                if (pad > 30 * 1024) pad = 30 * 1024;      // fits without the attribute: a weaker cap
+            } else {
+                devs |= bit;
+            }
+        }
+    }
+    hipLaunchKernelGGL(kern, grid, block, (size_t)pad, st, args...);
+}
+
+// LDS bytes a workgroup of a background launch should occupy (0: no cap configured)
+static inline int bg_lds_target() {
+    const int cap = nm_cur()->sw.gemm_bg_wgs;
+    return (cap >= 1 && cap <= 3) ? 160 * 1024 / (cap + 1) + 512 : 0;
+}
+
+static void launch_skinny(const GemmArgs& g_in, int batch, bool tb, const GruEpi& epi, hipStream_t st) {
+    GemmArgs g = g_in;
+    // A context in background mode (nm_ctx_set_background: the encoder of the NEXT batch, evaluated beside the
+    // decoding loop of the running one) launches its time-loop kernels residency-capped and at the default wave
+    // priority; everything else raises its priority, so the foreground loop gets the issue slots.
+    const bool background = nm_cur()->sw.background != 0;
+    g.prio = background ? 0 : nm_cur()->sw.step_prio;
+    const int want = background ? bg_lds_target() : 0;
     const int K = g.K;
     const bool no16 = nm_cur()->sw.gemm_no16;                                // A/B switch for tuning
     if (!no16 && K >= 256 && (long)nm_cdiv(g.M, 32) * nm_cdiv(g.N, 32) * batch < 256) {
         const int tiles_m = nm_cdiv(g.M, 16), tiles_n = nm_cdiv(g.N, 16);
         dim3 grid(tiles_m * tiles_n, 1, (unsigned)batch);
         const int ks = (K >= 512) ? 16 : 8;
-#define NM_GS16(KS_)                                                                                       \
-    do {                                                                                                   \
-        if (tb) hipLaunchKernelGGL((gemm_skinny16<KS_, true>), grid, dim3(KS_ * 64), 0, st, g, tiles_m, epi);  \
-        else hipLaunchKernelGGL((gemm_skinny16<KS_, false>), grid, dim3(KS_ * 64), 0, st, g, tiles_m, epi);    \
+        static unsigned devs16[4] = {0, 0, 0, 0};
+#define NM_GS16(KS_, I_)                                                                                               \
+    do {                                                                                                               \
+        const int pad = bg_pad(want, KS_ * 1024);                                                                      \
+        if (tb) launch_padded(gemm_skinny16<KS_, true>, devs16[I_], pad, grid, dim3(KS_ * 64), st, g, tiles_m, epi);   \
+        else launch_padded(gemm_skinny16<KS_, false>, devs16[I_ + 1], pad, grid, dim3(KS_ * 64), st, g, tiles_m, epi); \
     } while (0)
-        if (ks == 16) NM_GS16(16);
-        else NM_GS16(8);
+        if (ks == 16) NM_GS16(16, 0);
+        else NM_GS16(8, 2);
 #undef NM_GS16
         return;
     }
     const int tiles_m = nm_cdiv(g.M, 32), tiles_n = nm_cdiv(g.N, 32);
     dim3 grid(tiles_m * tiles_n, 1, (unsigned)batch);
     const int ks = (K >= 512) ? 16 : (K >= 256 ? 8 : (K >= 128 ? 4 : 1));
-#define NM_GS(KS_)                                                                                   \
-    do {                                                                                             \
-        if (tb) hipLaunchKernelGGL((gemm_skinny<KS_, true>), grid, dim3(KS_ * 64), 0, st, g, tiles_m, epi);  \
-        else hipLaunchKernelGGL((gemm_skinny<KS_, false>), grid, dim3(KS_ * 64), 0, st, g, tiles_m, epi);    \
+    static unsigned devs32[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define NM_GS(KS_, I_)                                                                                               \
+    do {                                                                                                             \
+        const int pad = bg_pad(want, KS_ * 4096);                                                                    \
+        if (tb) launch_padded(gemm_skinny<KS_, true>, devs32[I_], pad, grid, dim3(KS_ * 64), st, g, tiles_m, epi);   \
+        else launch_padded(gemm_skinny<KS_, false>, devs32[I_ + 1], pad, grid, dim3(KS_ * 64), st, g, tiles_m, epi); \
     } while (0)
-    if (ks == 16) NM_GS(16);
-    else if (ks == 8) NM_GS(8);
-    else if (ks == 4) NM_GS(4);
-    else NM_GS(1);
+    if (ks == 16) NM_GS(16, 0);
+    else if (ks == 8) NM_GS(8, 2);
+    else if (ks == 4) NM_GS(4, 4);
+    else NM_GS(1, 6);
 #undef NM_GS
 }
 
+// ``pad_lds`` > 0: that many bytes of dynamic LDS the kernel never touches.  LDS is what the dispatcher runs out of
+// first then, so the number of workgroups of THIS launch resident on a CU is capped (nm_gemm_f32, algo 4) and the
+// registers / wave slots it would otherwise fill stay free for the launches of other streams.
 template <int WM, int WN, int TM, int TN, int BK, int PF = 1, int NCH = 1>
-static void launch_tiled(const GemmArgs& g, int batch, bool ta, bool tb, bool vec, hipStream_t st) {
+static void launch_tiled(const GemmArgs& g, int batch, bool ta, bool tb, bool vec, hipStream_t st, int pad_lds = 0) {
     const int tiles_m = nm_cdiv(g.M, WM * 32 * TM), tiles_n = nm_cdiv(g.N, WN * 32 * TN);
     dim3 grid(tiles_m * tiles_n, g.splitk, batch), block(WM * WN * 64);
-#define NM_GT(TA_, TB_, V_) \
-    hipLaunchKernelGGL((gemm_tiled<WM, WN, TM, TN, TA_, TB_, V_, BK, false, PF, NCH>), grid, block, 0, st, g, tiles_m)
+    static unsigned attr_devs[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // per kernel instance (ta, tb, vec), one bit per device
+#define NM_GT(TA_, TB_, V_)                                                                              \
+    launch_padded(gemm_tiled<WM, WN, TM, TN, TA_, TB_, V_, BK, false, PF, NCH>,                         \
+                  attr_devs[(TA_ ? 4 : 0) + (TB_ ? 2 : 0) + (V_ ? 1 : 0)], pad_lds, grid, block, st, g, tiles_m)
     if (vec) {
         if (!ta && !tb) NM_GT(false, false, true);
         else if (!ta && tb) NM_GT(false, true, true);
@@ -989,7 +1042,7 @@ extern "C" int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int6
     const bool ta = transA != 0, tb = transB != 0;
     // a few hundred rows and too few 64x64 tiles for the chip (Transformer / general-path beam steps: 640 rows): the
     // 32x32 K-split tiles of the decoder-step groups (nm_step.hip)
-    if (algo == 0 && !ta && batch == 1 && !nostore &&
+    if (algo == 0 && !sw.background && !ta && batch == 1 && !nostore &&
         nm_medium_gemm(st, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate)) {
         NM_LAUNCH_CHECK("nm_gemm_f32 (medium)");
     }
@@ -999,7 +1052,19 @@ extern "C" int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int6
     const bool b_vec = nm_aligned16(B) && ldb % 4 == 0 && strideB % 4 == 0 && ((tb ? K : N) % 4 == 0);
     const bool vec = a_vec && b_vec;
 
-    // algo: 0 auto, 1 tiled 128x128, 2 tiled 64x64, 3 skinny
+    // algo: 0 auto, 1 tiled 128x128, 2 tiled 64x64, 3 skinny, 4 background
+    // Background: a leaf GEMM meant to run BESIDE latency-bound launches of another stream (the vocabulary
+    // projection's weight gradient next to the BPTT loops).  Left alone, the 1000 workgroups of that GEMM all become
+    // resident at once -- 3 per CU, 480 of a SIMD's 512 vector registers -- and every launch of the other stream
+    // waits ~1.4 ms for the first of them to retire (profiles/r04_train_step_timeline_v2.txt).  A background GEMM
+    // is the automatic choice of kernel with at most NM_GEMM_BG_WGS (1) workgroups resident per CU: unused dynamic
+    // LDS caps the residency, registers and wave slots stay free for a 16-wave recurrent workgroup.
+    // A context in background mode (nm_ctx_set_background) launches every automatic GEMM that way.
+    int bg_lds = 0;                                                    // LDS bytes one workgroup should occupy
+    if (algo == 4 || (algo == 0 && sw.background)) {
+        algo = 0;
+        bg_lds = bg_lds_target();
+    }
     bool skinny_ok = !ta && a_vec && K % 8 == 0 && (!tb || b_vec);
     int pick = algo;
     if (pick == 0) {
@@ -1050,7 +1115,7 @@ extern "C" int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int6
         }
         const int cfg_env = sw.gemm_cfg;                                                      // tuning knob (1 measured best)
         if (pick == 1) {
-            if (cfg_env == 1) launch_tiled<4, 2, 1, 2, 16>(g, (int)batch, ta, tb, vec, st);        // 128x128, 8 waves
+            if (cfg_env == 1) launch_tiled<4, 2, 1, 2, 16>(g, (int)batch, ta, tb, vec, st, bg_pad(bg_lds, 33792)); // 128x128, 8 waves
             else if (cfg_env == 3) launch_tiled<4, 4, 1, 1, 32>(g, (int)batch, ta, tb, vec, st);   // 128x128, 16 waves
             else if (cfg_env == 4) launch_tiled<4, 2, 1, 2, 32>(g, (int)batch, ta, tb, vec, st);   // 128x128, 8 waves, BK 32
             else if (cfg_env == 5) launch_tiled<2, 4, 2, 1, 16>(g, (int)batch, ta, tb, vec, st);   // 128x128, 8 waves 64x32
@@ -1065,7 +1130,7 @@ extern "C" int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int6
         } else if (sw.gemm_chains == 2) {
             launch_tiled<2, 2, 1, 1, 16, 1, 2>(g, (int)batch, ta, tb, vec, st);                    // 64x64, 2 chains
         } else {
-            launch_tiled<2, 2, 1, 1, 16>(g, (int)batch, ta, tb, vec, st);                          // 64x64
+            launch_tiled<2, 2, 1, 1, 16>(g, (int)batch, ta, tb, vec, st, bg_pad(bg_lds, 17408));   // 64x64
         }
         if (g.splitk > 1) {
             const long total = (long)M * N;

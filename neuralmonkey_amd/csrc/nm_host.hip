@@ -30,6 +30,9 @@ static void switches_from_env(NmSwitches* sw) {
     sw->gemm_sk = env_int("NM_GEMM_SK", 0);
     sw->gemm_cfg = env_int("NM_GEMM_CFG", 1);
     sw->gemm_chains = env_int("NM_GEMM_CHAINS", 1);
+    sw->gemm_bg_wgs = env_int("NM_GEMM_BG_WGS", 1);
+    sw->background = 0;
+    sw->step_prio = env_int("NM_STEP_PRIO", 1);
     sw->stats_cfg = env_int("NM_STATS_CFG", 3);
     sw->stats_ablate = getenv("NM_STATS_ABLATE") != nullptr;
     sw->beam_ns = env_int("NM_BEAM_NS", 0);
@@ -121,6 +124,17 @@ extern "C" int nm_ctx_bind(void* ctx) {
 
 extern "C" void* nm_ctx_current(void) { return nm_cur(); }
 
+// Background mode of a context: the launches that follow are meant to run BESIDE a latency-bound loop of another
+// stream (the encoder of the next batch under the decoding loop of the running one).  GEMMs chosen automatically
+// and the recurrent time-loop kernels then cap their residency at NM_GEMM_BG_WGS workgroups per CU (nm_gemm_f32,
+// algo 4) and do not raise their wave priority.  Captured launches keep the mode they were captured in.
+extern "C" int nm_ctx_set_background(void* ctx, int on) {
+    NmCtx* c = ctx_of(ctx);
+    NM_REQUIRE(c, "nm_ctx_set_background: not a context");
+    c->sw.background = on ? 1 : 0;
+    return NM_OK;
+}
+
 extern "C" int nm_ctx_device(void* ctx) {
     NmCtx* c = ctx_of(ctx);
     return c ? c->device : -1;
@@ -136,7 +150,8 @@ extern "C" int nm_ctx_switch(void* ctx, const char* name, int* value) {
         {"attn_maxrows", s.attn_maxrows}, {"attn_nomerge", s.attn_nomerge}, {"attn_nofast", s.attn_nofast},
         {"attn_whole", s.attn_whole}, {"aeb_wide_off", s.aeb_wide_off}, {"gemm_no16", s.gemm_no16},
         {"gemm_swz", s.gemm_swz}, {"gemm_nostore", s.gemm_nostore}, {"gemm_sk", s.gemm_sk},
-        {"gemm_cfg", s.gemm_cfg}, {"gemm_chains", s.gemm_chains}, {"stats_cfg", s.stats_cfg}, {"stats_ablate", s.stats_ablate},
+        {"gemm_cfg", s.gemm_cfg}, {"gemm_chains", s.gemm_chains}, {"gemm_bg_wgs", s.gemm_bg_wgs}, {"step_prio", s.step_prio},
+        {"stats_cfg", s.stats_cfg}, {"stats_ablate", s.stats_ablate},
         {"beam_ns", s.beam_ns}, {"sdp_mfma", s.sdp_mfma}, {"medium_m", s.medium_m},
         {"sdp_decode", s.sdp_decode}};
     for (auto& t : tab)

@@ -40,6 +40,7 @@ RNN_CELL_TYPES = ("NematusGRU", "GRU", "LSTM")
 # Steps per enqueued chunk (= per HIP graph) of a decoding loop.  The host reads the finished flags one chunk behind
 # what it has enqueued (Session.decode_chunks), so a chunk only has to outlast one host round trip (~0.1 ms); a batch
 # that finishes early wastes at most one chunk, hence fewer steps per chunk where a step is long.
+FORWARD_OVERLAP = int(os.environ.get("NM_FWD_OVERLAP", "1"))     # 0 off, 1 on, 2 on with residency-capped GEMMs
 CHECK_EVERY = int(os.environ.get("NM_CHECK_EVERY", "8"))            # greedy RNN step ~0.1 ms
 CHECK_EVERY_BEAM = int(os.environ.get("NM_CHECK_EVERY_BEAM", "4"))  # beam-5 step ~0.35 ms (Transformer: 1.4 ms)
 CHECK_EVERY_TRANSFORMER = int(os.environ.get("NM_CHECK_EVERY_TRANSFORMER", "4"))   # cached greedy step ~0.65 ms
@@ -186,11 +187,11 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
         state = self.encoder_projection.apply(ctx, self, self.rnn_size, self.encoders, out, train)
         return dropout(ctx, state, self.dropout_keep_prob, train)
 
-    def _input_projection(self, ctx, cell, emb, xp):
+    def _input_projection(self, ctx, cell, emb, xp, algo=0):
         """xp[:, :2H] = emb.Wg_x + bg ; xp[:, 2H:] = emb.Wc_x + bc  (input half of the GRU)."""
         h = self.rnn_size
-        ops.gemm(emb, cell["wg_x"], out=xp[:, :2 * h], bias=cell["bg"])
-        ops.gemm(emb, cell["wc_x"], out=xp[:, 2 * h:], bias=cell["bc"])
+        ops.gemm(emb, cell["wg_x"], out=xp[:, :2 * h], bias=cell["bg"], algo=algo)
+        ops.gemm(emb, cell["wc_x"], out=xp[:, 2 * h:], bias=cell["bc"], algo=algo)
 
     def _recurrent(self, ctx, cell, xp, t_index, x_time_stride, h_prev, h_out, ru, c_save, bufs, rh=None, wt=None):
         """State half of the GRU + fused epilogues: h_out = GRU(x_t, h_prev).  ``wt``: transposed recurrent
@@ -260,12 +261,32 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
         cell = self._cell(ctx)
         rows = steps * bsz
 
+        # The input half of the GRU (embedding rows, emb.W_x for all steps) needs nothing of the encoders: on a side
+        # lane it runs beside the encoders' time loops, which ``initial_state`` evaluates and which leave the chip
+        # idle.  Likewise the attention keys (states.W_k), beside this decoder's own time loop.
+        overlap = FORWARD_OVERLAP and ctx.session.side_active()
         emb_all = ctx.buffer(key + ("emb",), (steps, bsz, e))
-        self.embed_input_symbols(ctx, self._dec_input_ids(ctx).reshape(-1), out=emb_all.view(rows, e))
         xp = ctx.buffer(key + ("xp",), (rows, 3 * h))
-        self._input_projection(ctx, cell, emb_all.view(rows, e), xp)
+        dec_ids = self._dec_input_ids(ctx)
+        def input_half():
+            self.embed_input_symbols(ctx, dec_ids.reshape(-1), out=emb_all.view(rows, e))
+            self._input_projection(ctx, cell, emb_all.view(rows, e), xp,
+                                   algo=ops.GEMM_BACKGROUND if overlap and FORWARD_OVERLAP == 2 else 0)
+        if overlap:
+            ctx.session.defer_side(input_half)       # started by the first encoder time loop ...
+        else:
+            input_half()
 
         s0 = self.initial_state(ctx)
+        if overlap:
+            ctx.session.start_deferred_side()        # ... or here, when the encoders were evaluated already
+            ctx.session.join_side(0)
+            for att in self.attentions:
+                att.attention_states(ctx)
+                att.attention_mask(ctx)
+            with ctx.session.side(0):
+                for att in self.attentions:
+                    att.hidden_features(ctx)
         s_ext = ctx.buffer(key + ("s_ext",), (steps + 1, bsz, h))      # [s0 ; s_1 .. s_T]
         s_ext[0].copy_(s0)
         s_all = s_ext[1:]
@@ -293,6 +314,8 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
                             cell["wc_h"], ctx.buffer((id(self), "seq_ws"), (64,)))
         else:
             ctx.session.graphed((id(self), "train_loop", bsz, steps), time_loop)
+        if overlap:
+            ctx.session.join_side(0)
         # attention of all T steps at once (the contexts do not feed the recurrence)
         for i, att in enumerate(self.attentions):
             att.attention_all_steps(ctx, s_all, y_all[i], att_states[i].contexts, att_states[i].weights, e_all[i])
@@ -345,6 +368,7 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
         # Leaf work (weight gradients, bias column sums: nothing downstream reads them) is
         # enqueued on the session's side stream so it overlaps the latency-bound BPTT loops.
         side = ctx.session.side
+        bg = ctx.session.leaf_algo()        # leaf GEMMs run beside the main stream's time loops: residency-capped
         acc = self.shares_variables          # another part trains the same variables (reuse=): add, never overwrite
         from .. import distributed
         dp = distributed.current()
@@ -377,18 +401,29 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
         with side():
             row = 0
             for x, sz in zip([s2, emb2] + ctx_all, proj.sizes):
-                ops.gemm(x, d_out, out=g_wo[row:row + sz], trans_a=True, accumulate=acc)
+                ops.gemm(x, d_out, out=g_wo[row:row + sz], trans_a=True, accumulate=acc, algo=bg)
                 row += sz
             ops.colsum(d_out, store.g(self.var_name("attention_decoder/{}/bias".format(proj.scope))), accumulate=acc)
+
+        def vocabulary_projection_gradient():
             if self.tie_embeddings:
                 ops.gemm(dlogits, out_all, out=store.g(self.embedding_matrix_name), trans_a=True,
-                         accumulate=True)
+                         accumulate=True, algo=bg)
             else:
-                ops.gemm(out_all, dlogits, out=store.g(self.var_name("state_to_word_W")), trans_a=True, accumulate=acc)
+                ops.gemm(out_all, dlogits, out=store.g(self.var_name("state_to_word_W")), trans_a=True, accumulate=acc,
+                         algo=bg)
                 ops.colsum(sv["db_partial"] if sv.get("db_partial") is not None else dlogits,
                            store.g(self.var_name("state_to_word_b")), accumulate=acc)
                 if dp_overlap:        # the largest gradient slice is final: its all-reduce runs under the BPTT
                     dp.all_reduce_early(store, [self.var_name("state_to_word_W"), self.var_name("state_to_word_b")])
+        # The step's one long leaf GEMM ([rows, out]^T . [rows, V], ~2 ms).  Started HERE it runs beside the
+        # attentions' backward, which is throughput work itself: the two trade places (a 67 us GEMM of the main
+        # stream took 1.1 ms next to it, profiles/r04_train_step_timeline.txt).  Started after them it runs beside
+        # the BPTT loops only, whose launches are latency-bound and leave the chip idle.
+        early_dw = os.environ.get("NM_DW_EARLY", "0") != "0"
+        if early_dw:
+            with side(1):
+                vocabulary_projection_gradient()
 
         # ---- attentions (batched over time); adds the query path into d_s
         d_att_states = []
@@ -396,6 +431,9 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
             st = sv["att_states"][i]
             d_att_states.append(att.backward(ctx, d_ctx[i].view(steps, bsz, -1), sv["s_all"], sv["y_all"][i],
                                              st.weights, sv["e_all"][i], d_s))
+        if not early_dw:
+            with side(1):
+                vocabulary_projection_gradient()
 
         # ---- BPTT through the GRU (the only recurrence)
         dh = ctx.buffer(key + ("dh",), (1, bsz, h), zero=True)
@@ -420,14 +458,14 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
         dg_all, dc_all = dxp[:, :2 * h], dxp[:, 2 * h:]
         s_prev = sv["s_ext"][:steps].reshape(rows, h)
         with side():
-            ops.gemm(emb2, dg_all, out=g_wg[:e], trans_a=True, accumulate=acc)
-            ops.gemm(s_prev, dg_all, out=g_wg[e:], trans_a=True, accumulate=acc)
-            ops.gemm(emb2, dc_all, out=g_wc[:e], trans_a=True, accumulate=acc)
-            ops.gemm(sv["rh_all"].view(rows, h), dc_all, out=g_wc[e:], trans_a=True, accumulate=acc)
+            ops.gemm(emb2, dg_all, out=g_wg[:e], trans_a=True, accumulate=acc, algo=bg)
+            ops.gemm(s_prev, dg_all, out=g_wg[e:], trans_a=True, accumulate=acc, algo=bg)
+            ops.gemm(emb2, dc_all, out=g_wc[:e], trans_a=True, accumulate=acc, algo=bg)
+            ops.gemm(sv["rh_all"].view(rows, h), dc_all, out=g_wc[e:], trans_a=True, accumulate=acc, algo=bg)
             ops.colsum(dg_all, store.g(self.var_name(pre + "/gates/bias")), accumulate=acc)
             ops.colsum(dc_all, store.g(self.var_name(pre + "/candidate/bias")), accumulate=acc)
-            ops.gemm(dg_all, cell["wg_x"], out=d_emb, trans_b=True, accumulate=True)
-            ops.gemm(dc_all, cell["wc_x"], out=d_emb, trans_b=True, accumulate=True)
+            ops.gemm(dg_all, cell["wg_x"], out=d_emb, trans_b=True, accumulate=True, algo=bg)
+            ops.gemm(dc_all, cell["wc_x"], out=d_emb, trans_b=True, accumulate=True, algo=bg)
             ops.embedding_scatter_add(store.g(self.embedding_matrix_name), self._dec_input_ids(ctx).reshape(-1),
                                       d_emb)
             if dp_overlap and not self.tie_embeddings and self.embeddings_source is None:

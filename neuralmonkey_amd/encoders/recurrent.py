@@ -218,6 +218,7 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
                             ndir * bsz * h, wgh, wch, ctx.buffer((key, "seq_ws"), (64,)), lengths=len_arg,
                             reverse_dir0=reverse_only, out=states_raw, out_strides=(h, ors, ots))
         else:
+            ctx.session.start_deferred_side()      # work that waits for a time loop to hide under (Session.defer_side)
             ctx.session.graphed((key, "fwd_loop", bsz, slen, train), time_loop)
         final_raw = ctx.buffer((key, "final_raw"), (bsz, c_out))
         for d in range(ndir):

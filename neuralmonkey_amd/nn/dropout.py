@@ -1,6 +1,10 @@
-"""nn/utils.py:6-22.  Dropout cannot reproduce TF's Philox stream, so parity
-holds for keep_prob == 1 or train=False; with keep_prob < 1 in train mode the
-HIP engine refuses loudly instead of silently training a different model."""
+"""nn/utils.py:6-22 on the hand-scheduled (untaped) fast paths: identity at keep_prob 1 or outside training.
+
+Training-mode dropout itself IS implemented -- ``autodiff.dropout`` (counter-based masks of ``nm_dropout``, the same
+mask re-derived in the backward pass; TF's Philox stream is not reproducible, so the masks differ from the
+reference's while the distribution is the same).  Parts configured with dropout_keep_prob < 1 are routed to the taped
+general path, which calls that one; this function is what the fast paths call, and they refuse loudly instead of
+silently training a different model if such a configuration ever reaches them."""
 
 
 def dropout(ctx, variable, keep_prob: float, train_mode: bool):
@@ -10,5 +14,5 @@ def dropout(ctx, variable, keep_prob: float, train_mode: bool):
     if keep_prob == 1.0 or not train_mode:
         return variable
     raise NotImplementedError(
-        "dropout_keep_prob < 1 in training mode is not implemented in the HIP engine yet "
-        "(set dropout_keep_prob=1.0)")
+        "dropout_keep_prob < 1 in training mode reached a hand-scheduled fast path; such models train on the "
+        "taped general path (autodiff.dropout)")

@@ -46,6 +46,9 @@ def add_layer_norm_fwd(a, x, gamma, beta, sum_out, out, eps=1e-6):
     return sum_out, out
 
 
+GEMM_BACKGROUND = 4     # nm_gemm_f32 algo: residency-capped 128x128 tiles for a long leaf GEMM on a side stream
+
+
 def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, bias=None, act=None,
          trans_a=False, trans_b=False, accumulate=False, algo=0):
     """out[M,N] = act(op(a) @ op(b) + bias (+ out)).  2-D (or batched 3-D with

@@ -303,8 +303,12 @@ class Session:
         # two launches per step -- an agent-scope release/acquire pair (L2 write-back + invalidate on
         # every XCD) costs more than a launch boundary inside a graph.  Off by default.
         self.use_persistent = os.environ.get("NM_PERSISTENT", "0") != "0"
-        self._side_stream = None
-        self._side_dirty = False
+        self.background_leaves = os.environ.get("NM_LEAF_BACKGROUND", "1") != "0"
+        self.ahead_in_background = os.environ.get("NM_AHEAD_BACKGROUND", "1") != "0"
+        self._background = False         # inside _run_ahead: launches (and captures) are in the library's background mode
+        self._deferred_side = []
+        self._side_streams = {}          # lane -> HIP stream
+        self._side_dirty = set()
         self._copy_stream = None
         self._tls = threading.local()
         self.global_step = 0
@@ -468,31 +472,61 @@ class Session:
         return buf
 
     @contextmanager
-    def side(self):
-        """Run the enclosed launches on the session's second HIP stream, ordered
-        after everything already enqueued on the main stream.  Used for "leaf"
-        work of the backward pass (weight-gradient GEMMs, bias column sums) so that
-        it fills the CUs the latency-bound BPTT loops leave idle.  ``join_side``
-        orders the main stream after it."""
+    def side(self, lane: int = 0):
+        """Run the enclosed launches on one of the session's secondary HIP streams
+        (``lane``), ordered after everything already enqueued on the main stream.
+        Used for "leaf" work of the backward pass (weight-gradient GEMMs, bias
+        column sums) so that it fills the CUs the latency-bound BPTT loops leave
+        idle.  Lane 1 is for the one long leaf GEMM of a step (the vocabulary
+        projection's weight gradient): on its own lane the short leaf launches of
+        lane 0 do not queue behind it.  ``join_side`` orders the main stream after
+        every lane."""
         if not self.use_side_stream or self.device.type != "cuda" or torch.cuda.is_current_stream_capturing():
             yield
             return
-        if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(device=self.device)
+        stream = self._side_streams.get(lane)
+        if stream is None:
+            stream = self._side_streams[lane] = torch.cuda.Stream(device=self.device)
         main = torch.cuda.current_stream(self.device)
         ev = torch.cuda.Event()
         ev.record(main)
-        self._side_stream.wait_event(ev)
-        with torch.cuda.stream(self._side_stream):
+        stream.wait_event(ev)
+        with torch.cuda.stream(stream):
             yield
-        self._side_dirty = True
+        self._side_dirty.add(lane)
 
-    def join_side(self) -> None:
-        if self._side_dirty:
+    def defer_side(self, fn) -> None:
+        """``fn`` (launches that depend on nothing still to come) is to run on side lane 0 beside the NEXT time loop
+        the main stream launches -- ``start_deferred_side`` is called by the loops' owners right before they launch,
+        and by whoever deferred the work once the loop it hoped for can no longer come."""
+        self._deferred_side.append(fn)
+
+    def start_deferred_side(self) -> None:
+        if self._deferred_side:
+            todo, self._deferred_side = self._deferred_side, []
+            with self.side(0):
+                for fn in todo:
+                    fn()
+
+    def side_active(self) -> bool:
+        """Would ``side()`` move launches to another stream right now?"""
+        return bool(self.use_side_stream and self.device.type == "cuda"
+                    and not torch.cuda.is_current_stream_capturing())
+
+    def leaf_algo(self) -> int:
+        """``algo`` of a leaf GEMM enqueued under ``side()``: the residency-capped background kernels when the
+        launches really go to another stream (they then run beside the main stream's time loops)."""
+        from . import ops
+        return ops.GEMM_BACKGROUND if self.side_active() and self.background_leaves else 0
+
+    def join_side(self, lane: Optional[int] = None) -> None:
+        """Order the main stream after one lane (or, by default, after every lane) of ``side()`` work."""
+        lanes = sorted(self._side_dirty) if lane is None else [lane] if lane in self._side_dirty else []
+        for ln in lanes:
             ev = torch.cuda.Event()
-            ev.record(self._side_stream)
+            ev.record(self._side_streams[ln])
             torch.cuda.current_stream(self.device).wait_event(ev)
-            self._side_dirty = False
+            self._side_dirty.discard(ln)
 
     def graphed(self, key, fn) -> None:
         """Run ``fn`` (kernel launches on persistent buffers only, no host
@@ -504,6 +538,8 @@ class Session:
             return
         if self.slot:
             key = (("slot", self.slot), key)
+        if self._background:             # a capture keeps the mode it was made in
+            key = ("background", key)
         state = self._graphs.get(key)
         if state is None:
             fn()
@@ -637,14 +673,21 @@ class Session:
         if self.device.type != "cuda" or torch.cuda.is_current_stream_capturing():
             return
         if self._ahead_stream is None:
-            self._ahead_stream = torch.cuda.Stream(device=self.device)
+            self._ahead_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("NM_AHEAD_PRIO", "0")))
         main = torch.cuda.current_stream(self.device)
         start = torch.cuda.Event()
         start.record(main)                                   # after whatever is already queued (nothing, normally)
         mine = self.slot
         self.slot = mine ^ 1
-        from . import ops
+        from . import _lib, ops
         tag, ops.WORKSPACE_TAG = ops.WORKSPACE_TAG, ("ahead", self.slot)     # scratch of its own (ops.WORKSPACE_TAG)
+        # The look-ahead work runs under the decoding loop of the running batch.  Left alone, every launch of its
+        # encoder time loops (1024 workgroups of 16 waves) fills the chip for a few microseconds and the decoding
+        # steps queue behind them: the two loops add up instead of overlapping (4.45 -> 5.4 ms per greedy batch).
+        # In background mode they take half a CU each and leave the issue priority to the decoding steps.
+        self._background = self.ahead_in_background
+        if self._background:
+            _lib.check(_lib.load().nm_ctx_set_background(None, 1), "nm_ctx_set_background")
         try:
             self._ahead_stream.wait_event(start)
             with torch.cuda.stream(self._ahead_stream), torch.no_grad():
@@ -655,6 +698,9 @@ class Session:
             self._ahead = [(self._feed_signature(feed), self.slot, ctx.memo, done, feed,
                             self.variables_signature())]          # one batch ahead, never a backlog
         finally:
+            if self._background:
+                _lib.check(_lib.load().nm_ctx_set_background(None, 0), "nm_ctx_set_background")
+            self._background = False
             self.slot = mine
             ops.WORKSPACE_TAG = tag
 
@@ -669,6 +715,7 @@ class Session:
                 self.slot = self._ahead[-1][1] ^ 1
             elif ahead is None:            # no look-ahead in play (training steps, plain runs): the default buffers --
                 self.slot = 0              # the slot is not sticky, or every shape would be allocated and captured twice
+        self._deferred_side = []          # (left over only if a previous run raised)
         self._pending_ahead = ahead       # started by the first decoding loop (kick_ahead) or right after the fetches
         ctx = RunContext(self, feed)
         if claimed:

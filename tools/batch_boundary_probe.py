@@ -21,6 +21,8 @@ from neuralmonkey_amd import runtime, synthetic  # noqa: E402
 def main():
     mode = sys.argv[1] if len(sys.argv) > 1 else "greedy"
     batches = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    if os.environ.get("NM_MAIN_PRIO"):        # experiment: the decoding stream above the look-ahead stream
+        torch.cuda.set_stream(torch.cuda.Stream(priority=-1))
     model = synthetic.build_translation_model(vocab_src=32000, vocab_tgt=32000, emb=512, rnn=512, max_len=50,
                                               beam_size=5, max_steps=50, length_normalization=0.6, device="cuda:0")
     store = model.tf_manager.sessions[0].store
