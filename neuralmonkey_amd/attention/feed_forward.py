@@ -5,6 +5,7 @@ attention()     = q . Wq + b, then the fused HIP step kernel nm_attn_fwd
                   (energies, softmax, mask-renorm, context; feed_forward.py:120-166).
 Keys are indexed by ``row // rows_per_key`` so a beam of k hypotheses per
 sentence shares one copy of the keys."""
+import contextlib
 from typing import Optional, Tuple
 
 import torch
@@ -163,8 +164,9 @@ class Attention(BaseAttention):
         ops.gemm(dy2, wq, out=dquery_accum, trans_b=True, accumulate=True)
         wk = self.var(ctx, "attn_key_projection")
         ops.gemm(dhf.view(bsz * slen, a), wk, out=dstates.view(bsz * slen, c), trans_b=True, accumulate=True)
-        bg = ctx.session.leaf_algo()
-        with ctx.session.side():          # leaf gradients of this part's variables
+        loops = getattr(self.encoder, "has_time_loop", False)      # see Decoder.backward: side streams pay beside loops
+        bg = ctx.session.leaf_algo() if loops else 0
+        with (ctx.session.side() if loops else contextlib.nullcontext()):   # leaf gradients of this part's variables
             ops.colsum(dvp, store.g(self.var_name("attn_similarity_v")), accumulate=True)
             ops.colsum(dy2, store.g(self.var_name("attn_projection_bias")), accumulate=True)
             ops.gemm(queries.reshape(rows, -1), dy2,

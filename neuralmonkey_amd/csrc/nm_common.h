@@ -56,6 +56,7 @@ struct NmSwitches {
     int gemm_cfg;          // NM_GEMM_CFG       tile configuration of the large GEMMs (1)
     int gemm_chains;       // NM_GEMM_CHAINS    interleaved accumulation chains of the 64x64 tiles: 1, 2 or 4 (1)
     int gemm_bg_wgs;       // NM_GEMM_BG_WGS    workgroups per CU of a background GEMM (algo 4): 1..3, 0 = uncapped (1)
+    int gemm_bg_cfg;       // NM_GEMM_BG_CFG    tile of a background GEMM: 1 = 128x128, 2 = 256x128 (1)
     int background;        // (nm_ctx_set_background, not an environment switch) launches run beside a foreground loop
     int step_prio;         // NM_STEP_PRIO      skinny (time-loop) GEMM kernels raise their wave priority (1)
     int stats_cfg;         // NM_STATS_CFG      statistics-GEMM tile / prefetch bits (3)

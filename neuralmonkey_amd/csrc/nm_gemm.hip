@@ -96,7 +96,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tiled(GemmArgs g, int tiles
     // one LDS allocation: the double-buffered operand tiles; the statistics epilogue (STATS) re-uses it for
     // half an output tile at a time
     constexpr int A_FLOATS = 2 * BK * LDAS, B_FLOATS = 2 * BK * LDBS;
-    constexpr int ST_FLOATS = STATS ? (BM / 2) * (BN + 1) + 3 * NT : 0;
+    constexpr int ST_ROWS = BM > 256 ? 128 : BM / 2;           // rows of one pass of the statistics epilogue
+    constexpr int ST_FLOATS = STATS ? ST_ROWS * (BN + 1) + 3 * NT : 0;
     constexpr int SM_FLOATS = A_FLOATS + B_FLOATS > ST_FLOATS ? A_FLOATS + B_FLOATS : ST_FLOATS;
     static_assert((A_FLOATS * 4) % 16 == 0, "B tile must stay 16-byte aligned");
     __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
@@ -362,11 +363,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tiled(GemmArgs g, int tiles
         // sum exp(x - max); nm_greedy_finish / the beam tile scan merge the tiles of a row.
         // The logits themselves are stored only when somebody reads them (g.store_c).
         if (g.act == 9) return;         // NM_STATS_ABLATE=1: timing ablation, the epilogue is skipped entirely
-        // The tile goes through LDS, half of its rows at a time (the operand buffers are free by now): every
-        // row is then scanned by NT / (BM/2) threads that read contiguous column segments -- two short
+        // The tile goes through LDS, HR of its rows at a time (half of a 128-row tile, a fifth of the 640-row tile of a
+        // beam step; the operand buffers are free by now): every
+        // row is then scanned by NT / HR threads that read contiguous column segments -- two short
         // conflict-free LDS loops (max / first argmax, then sum exp) instead of ~250 cross-lane shuffles per
         // thread on the accumulator layout (measured: 14 of the 58 us of one decoding step's projection).
-        constexpr int HR = BM / 2, TS = BN + 1;          // rows per half; odd row stride: column scans hit 32 banks
+        constexpr int HR = ST_ROWS, TS = BN + 1;         // rows per pass; odd row stride: column scans hit 32 banks
+        constexpr int NP = BM / HR;
+        static_assert(NP * HR == BM, "statistics epilogue: whole passes");
         constexpr int TPR = NT / HR, CW = BN / TPR;      // threads per row, columns per thread
         static_assert(NT % HR == 0 && BN % TPR == 0 && TPR <= 16, "statistics epilogue thread layout");
         float* T = smem;
@@ -386,7 +390,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tiled(GemmArgs g, int tiles
         }
         const int tiles_n = (int)gridDim.x / tiles_m;
         const int rr = tid % HR, q = tid / HR;
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NP; ++h) {
             __syncthreads();                              // previous users of the buffer are done
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -1115,7 +1119,8 @@ extern "C" int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int6
         }
         const int cfg_env = sw.gemm_cfg;                                                      // tuning knob (1 measured best)
         if (pick == 1) {
-            if (cfg_env == 1) launch_tiled<4, 2, 1, 2, 16>(g, (int)batch, ta, tb, vec, st, bg_pad(bg_lds, 33792)); // 128x128, 8 waves
+            if (bg_lds > 0 && sw.gemm_bg_cfg == 2) launch_tiled<4, 2, 2, 2, 16>(g, (int)batch, ta, tb, vec, st, bg_pad(bg_lds, 50176)); // background, 256x128
+            else if (cfg_env == 1) launch_tiled<4, 2, 1, 2, 16>(g, (int)batch, ta, tb, vec, st, bg_pad(bg_lds, 33792)); // 128x128, 8 waves
             else if (cfg_env == 3) launch_tiled<4, 4, 1, 1, 32>(g, (int)batch, ta, tb, vec, st);   // 128x128, 16 waves
             else if (cfg_env == 4) launch_tiled<4, 2, 1, 2, 32>(g, (int)batch, ta, tb, vec, st);   // 128x128, 8 waves, BK 32
             else if (cfg_env == 5) launch_tiled<2, 4, 2, 1, 16>(g, (int)batch, ta, tb, vec, st);   // 128x128, 8 waves 64x32
@@ -1267,10 +1272,15 @@ extern "C" int nm_logits_stats_gemm(void* stream, int transB, int64_t M, int64_t
     const bool ablate = nm_cur()->sw.stats_ablate;
     if (ablate) g.act = 9;
     const int tile = (int)nm_logits_stats_tile(M);
-    const int tiles_m = nm_cdiv(M, 128), tiles_n = nm_cdiv(N, tile);
-    dim3 grid(tiles_m * tiles_n, 1, 1), block(512);
     hipStream_t st = nm_stream(stream);
     const bool pf2 = (stats_cfg() & 2) != 0;
+    // One beam step (B x beam = 640 rows) is 5 x 250 = 1250 workgroups of 128x128 for 512 slots: 2.44 rounds, the
+    // third one 44 % full.  Measured and rejected: one 640x128 tile per workgroup (gemm_tiled<4, 2, 5, 2, ...>: 8 waves
+    // of 160x64, one round of 250 workgroups, the weights read once instead of five times) -- 160 accumulator
+    // registers per lane leave hipcc 100+ spilled registers at 2 waves per SIMD: 314 us against 228 us
+    // (tools/stats_tall_probe.py, round 4); with loads two k-tiles ahead 837 us.
+    const int tiles_m = nm_cdiv(M, 128), tiles_n = nm_cdiv(N, tile);
+    dim3 grid(tiles_m * tiles_n, 1, 1), block(512);
 #define NM_ST(TN_, BK_, TB_, PF_) \
     hipLaunchKernelGGL((gemm_tiled<4, 2, 1, TN_, false, TB_, true, BK_, true, PF_>), grid, block, 0, st, g, tiles_m)
     if (tile == 64) {

@@ -31,6 +31,7 @@ static void switches_from_env(NmSwitches* sw) {
     sw->gemm_cfg = env_int("NM_GEMM_CFG", 1);
     sw->gemm_chains = env_int("NM_GEMM_CHAINS", 1);
     sw->gemm_bg_wgs = env_int("NM_GEMM_BG_WGS", 1);
+    sw->gemm_bg_cfg = env_int("NM_GEMM_BG_CFG", 1);
     sw->background = 0;
     sw->step_prio = env_int("NM_STEP_PRIO", 1);
     sw->stats_cfg = env_int("NM_STATS_CFG", 3);

@@ -15,6 +15,7 @@ Greedy / beam decoding feed the argmax back, so every step runs the full chain.
 """
 from typing import Any, List, NamedTuple, Optional, Tuple
 
+import contextlib
 import os
 
 import numpy as np
@@ -187,6 +188,12 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
         state = self.encoder_projection.apply(ctx, self, self.rnn_size, self.encoders, out, train)
         return dropout(ctx, state, self.dropout_keep_prob, train)
 
+    def _time_loops_beside(self) -> bool:
+        """Is there an encoder whose forward / backward pass is a time loop (work of this decoder that depends on
+        nothing of it can then run beside that loop on a side stream)?"""
+        encs = list(self.encoders) + [att.encoder for att in self.attentions]
+        return any(getattr(enc, "has_time_loop", False) for enc in encs)
+
     def _input_projection(self, ctx, cell, emb, xp, algo=0):
         """xp[:, :2H] = emb.Wg_x + bg ; xp[:, 2H:] = emb.Wc_x + bc  (input half of the GRU)."""
         h = self.rnn_size
@@ -264,7 +271,7 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
         # The input half of the GRU (embedding rows, emb.W_x for all steps) needs nothing of the encoders: on a side
         # lane it runs beside the encoders' time loops, which ``initial_state`` evaluates and which leave the chip
         # idle.  Likewise the attention keys (states.W_k), beside this decoder's own time loop.
-        overlap = FORWARD_OVERLAP and ctx.session.side_active()
+        overlap = FORWARD_OVERLAP and ctx.session.side_active() and self._time_loops_beside()
         emb_all = ctx.buffer(key + ("emb",), (steps, bsz, e))
         xp = ctx.buffer(key + ("xp",), (rows, 3 * h))
         dec_ids = self._dec_input_ids(ctx)
@@ -367,8 +374,14 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
 
         # Leaf work (weight gradients, bias column sums: nothing downstream reads them) is
         # enqueued on the session's side stream so it overlaps the latency-bound BPTT loops.
-        side = ctx.session.side
-        bg = ctx.session.leaf_algo()        # leaf GEMMs run beside the main stream's time loops: residency-capped
+        # Leaf GEMMs go to side streams and run residency-capped (ops.GEMM_BACKGROUND: the loops' launches find room on
+        # every CU) beside the main stream's BPTT loops -- when there are two loops to hide them under, this decoder's
+        # and a recurrent encoder's.  With this decoder's alone (captioning: the encoder is a spatial filler, the
+        # attention's backward over 64 x 2048 maps is bandwidth work itself) the second stream only adds contention:
+        # 10.6 ms per step with it, 10.1 in stream order (tools/captioning_train_probe.py, NM_SIDE_STREAM=0).
+        loops = self._time_loops_beside()
+        side = ctx.session.side if loops else (lambda lane=0: contextlib.nullcontext())
+        bg = ctx.session.leaf_algo() if loops else 0
         acc = self.shares_variables          # another part trains the same variables (reuse=): add, never overwrite
         from .. import distributed
         dp = distributed.current()

@@ -57,6 +57,8 @@ class EncoderActivations(NamedTuple):
 
 
 class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
+    has_time_loop = True      # its backward pass is a latency-bound BPTT loop: leaf GEMMs of other parts hide under it
+
     # pylint: disable=too-many-arguments
     def __init__(self, name: str, input_sequence: TemporalStateful, rnn_layers: List[RNNSpecTuple],
                  add_residual: bool = False, add_layer_norm: bool = False,

@@ -304,7 +304,10 @@ class Session:
         # every XCD) costs more than a launch boundary inside a graph.  Off by default.
         self.use_persistent = os.environ.get("NM_PERSISTENT", "0") != "0"
         self.background_leaves = os.environ.get("NM_LEAF_BACKGROUND", "1") != "0"
-        self.ahead_in_background = os.environ.get("NM_AHEAD_BACKGROUND", "1") != "0"
+        # Measured and left off: greedy batches are unchanged (5.72 vs 5.74 ms), beam batches go from 17.8 to 23 ms --
+        # the beam step's kernels need up to 128 KB of LDS, a CU that holds a capped (82 KB) workgroup cannot take
+        # them, and a capped launch keeps every CU occupied four times longer (profiles/r04_lookahead_background.txt)
+        self.ahead_in_background = os.environ.get("NM_AHEAD_BACKGROUND", "0") != "0"
         self._background = False         # inside _run_ahead: launches (and captures) are in the library's background mode
         self._deferred_side = []
         self._side_streams = {}          # lane -> HIP stream

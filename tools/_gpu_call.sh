@@ -1,7 +1,6 @@
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-python -c "import torch; print(torch.cuda.Stream.priority_range())"
-echo "== main high prio"; NM_MAIN_PRIO=1 python tools/batch_boundary_probe.py greedy 6 2>&1 | tail -1
-echo "== main high prio, ahead not background"; NM_AHEAD_BACKGROUND=0 NM_MAIN_PRIO=1 python tools/batch_boundary_probe.py greedy 6 2>&1 | tail -1
-echo "== main high prio beam"; NM_MAIN_PRIO=1 python tools/batch_boundary_probe.py beam 6 2>&1 | tail -1
-echo "== default"; python tools/batch_boundary_probe.py greedy 6 2>&1 | tail -1
+python tools/captioning_train_probe.py 2>&1 | tail -1
+python -m pytest tests -q -m gpu 2>&1 | tail -5 > gpurun_out/r04_tests_full_v2.txt
+cat gpurun_out/r04_tests_full_v2.txt
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
