@@ -347,3 +347,24 @@ def test_variables_signature_follows_writes():
     assert sig1 != sig0
     sess.variables_changed()                                    # optimizer kernels, collectives
     assert sess.variables_signature() not in (sig0, sig1)
+
+
+def test_side_lanes_degrade_to_stream_order_without_a_gpu():
+    """`Session.side` / `defer_side` / `join_side` are a schedule, not a semantics: where there is no second stream
+    (CPU sessions, inside a graph capture) the enclosed work simply runs in place, deferred work runs when its time
+    loop -- or whoever deferred it -- starts it, and nothing is left pending."""
+    from neuralmonkey_amd.runtime import Session
+    sess = Session("cpu", seed=1)
+    assert not sess.side_active() and sess.leaf_algo() == 0
+    order = []
+    with sess.side(1):
+        order.append("leaf")
+    sess.defer_side(lambda: order.append("deferred a"))
+    sess.defer_side(lambda: order.append("deferred b"))
+    order.append("main")
+    sess.start_deferred_side()
+    sess.start_deferred_side()            # nothing left: a no-op
+    sess.join_side(0)
+    sess.join_side()
+    assert order == ["leaf", "main", "deferred a", "deferred b"]
+    assert not sess._deferred_side and not sess._side_dirty
