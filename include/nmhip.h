@@ -472,6 +472,19 @@ int nm_optim_clip_adam(void* stream, float* theta, const float* grad, float* m, 
                        int64_t nchunk, int64_t nseg, float clip_norm, float lr_t, float beta1,
                        float beta2, float epsilon, void* workspace, int64_t workspace_bytes);
 
+/* ---- data-parallel gradient exchange (the reference is single-device, tf_manager.py:62-100): the
+ * in-place sum over ranks of slices of the flat gradient buffer on RCCL, ordered against HIP streams only.  RCCL is
+ * resolved at run time (the copy already in the process, else librccl.so.1): no link-time dependency.
+ *   unique_id  rank 0 fills 128 bytes, the caller distributes them;  init  one communicator (+ its own stream) per
+ *   process on the current device;  bucket  buf[0:count] <- sum over ranks, after everything enqueued on `stream` so
+ *   far, running beside what `stream` enqueues next;  wait  `stream` waits on the device for all buckets so far. */
+typedef void nm_comm;
+int nm_allreduce_unique_id(void* out, int64_t bytes /* >= 128 */);
+int nm_allreduce_init(int rank, int world, const void* unique_id, nm_comm** out_comm);
+int nm_allreduce_bucket(nm_comm* comm, void* stream, float* buf, int64_t count);
+int nm_allreduce_wait(nm_comm* comm, void* stream);
+int nm_allreduce_destroy(nm_comm* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,11 @@ SIGNATURES = {
     "nm_ctx_device": (I, [P]),
     "nm_ctx_switch": (I, [P, c_char_p, P]),
     "nm_ctx_set_background": (I, [P, I]),
+    "nm_allreduce_unique_id": (I, [P, L]),
+    "nm_allreduce_init": (I, [I, I, P, P]),
+    "nm_allreduce_bucket": (I, [P, P, P, L]),
+    "nm_allreduce_wait": (I, [P, P]),
+    "nm_allreduce_destroy": (I, [P]),
     "nm_prof_enable": (I, [P, I]),
     "nm_prof_attn_step": (I, [P, P, P]),
     "nm_row_stats": (I, [P, P, L, L, L, P, P, P]),

@@ -29,6 +29,9 @@ class DataParallel:
         self.world_size = dist.get_world_size()
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.overlap = os.environ.get("NM_DP_OVERLAP", "1") != "0"
+        # NM_DIST_FORCE=1: a world of one issues its collectives all the same (every one of them is the identity):
+        # the single-GPU check of the exchange code -- ordering against the streams, early spans, buckets
+        self.forced = os.environ.get("NM_DIST_FORCE") == "1"
         # NM_DP_SPARSE_EMB=1: an embedding matrix whose gradient touches only the rows of this rank's tokens travels
         # as (row ids, rows) instead of as a dense [V, E] slice of the flat buffer (exchange_sparse_rows)
         self.sparse_embeddings = os.environ.get("NM_DP_SPARSE_EMB", "0") == "1"
@@ -45,12 +48,42 @@ class DataParallel:
         # Host scalars (the global target-token count of a step) travel over a gloo side group:
         # reading an RCCL result back would synchronise the device every step and stop the host
         # from enqueueing ahead of the GPU.
+        # NM_DIST_ALLREDUCE=nmhip: the gradient buckets go through the library's own RCCL communicator
+        # (nm_allreduce_*, csrc/nm_comm.hip) instead of torch.distributed's; torch's process group stays for what is
+        # not on the step's critical path (parameter broadcast, the unique id, host scalars).  Opt-in: the default
+        # path is the one the multi-rank tests have run on.
+        self._comm = None
+        if os.environ.get("NM_DIST_ALLREDUCE", "torch") == "nmhip":
+            self._init_library_communicator()
         self._host_group = None
         if self.world_size > 1 and dist.get_backend() == "nccl":
             try:
                 self._host_group = dist.new_group(backend="gloo")
             except Exception:           # pylint: disable=broad-except
                 self._host_group = None  # fall back to a device all-reduce + readback
+
+    def _init_library_communicator(self) -> None:
+        import ctypes
+        from . import _lib
+        if dist.get_backend() != "nccl" or not torch.cuda.is_available():
+            raise RuntimeError("NM_DIST_ALLREDUCE=nmhip needs the nccl (RCCL) backend on GPUs")
+        lib = _lib.load()
+        uid = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            _lib.check(lib.nm_allreduce_unique_id(uid, 128), "nm_allreduce_unique_id")
+        box = [uid.raw]
+        if self.world_size > 1:
+            dist.broadcast_object_list(box, src=0)            # any side channel does: here torch's own group
+        handle = ctypes.c_void_p()
+        _lib.check(lib.nm_allreduce_init(self.rank, self.world_size, ctypes.create_string_buffer(box[0], 128),
+                                         ctypes.byref(handle)), "nm_allreduce_init")
+        self._comm = handle
+
+    def close(self) -> None:
+        if self._comm is not None:
+            from . import _lib
+            _lib.check(_lib.load().nm_allreduce_destroy(self._comm), "nm_allreduce_destroy")
+            self._comm = None
 
     def all_reduce_scalar(self, value: float) -> float:
         """Sum of a host scalar over ranks (global target-token count)."""
@@ -73,8 +106,7 @@ class DataParallel:
         to enqueueing the forward pass -- the first reader of ``scale`` is the cross-entropy backward, a whole
         forward pass later.  (The host-side gloo exchange this replaces blocked every rank at the top of every
         step until the slowest rank had arrived.)  Other backends (gloo on CPU / in tests) keep the host sum."""
-        forced = os.environ.get("NM_DIST_FORCE") == "1"           # world-of-one runs exercise the collective path
-        if (self.world_size == 1 and not forced) or dist.get_backend() != "nccl" or scale.device.type != "cuda":
+        if (self.world_size == 1 and not self.forced) or dist.get_backend() != "nccl" or scale.device.type != "cuda":
             total = self.all_reduce_scalar(count)
             scale.fill_(weight / total if total else 0.0)
             return
@@ -82,17 +114,33 @@ class DataParallel:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)                  # the stream waits for it, the host does not
         scale.copy_(torch.where(t > 0, float(weight) / t.clamp_min(1.0), torch.zeros_like(t)).to(scale.dtype))
 
-    def begin_step(self) -> None:
-        """Forget the bookkeeping of a step that did not reach ``all_reduce_gradients`` (an exception)."""
+    def _wait_handles(self) -> None:
+        """The current stream waits for every collective of the step enqueued so far."""
+        if self._comm is not None:
+            if self._handles:
+                from . import _lib
+                _lib.check(_lib.load().nm_allreduce_wait(self._comm, torch.cuda.current_stream().cuda_stream),
+                           "nm_allreduce_wait")
+            return
         for hnd in self._handles:
             hnd.wait()
+
+    def begin_step(self) -> None:
+        """Forget the bookkeeping of a step that did not reach ``all_reduce_gradients`` (an exception)."""
+        self._wait_handles()
         self._handles, self._early = [], []
         self.sparse_bytes_per_step = 0
 
     def _reduce_span(self, grad, lo: int, hi: int) -> None:
         for start in range(lo, hi, self.bucket_elems):
             chunk = grad[start:min(hi, start + self.bucket_elems)]
-            self._handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
+            if self._comm is not None:
+                from . import _lib
+                _lib.check(_lib.load().nm_allreduce_bucket(self._comm, torch.cuda.current_stream().cuda_stream,
+                                                           chunk.data_ptr(), chunk.numel()), "nm_allreduce_bucket")
+                self._handles.append(None)
+            else:
+                self._handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
 
     def all_reduce_early(self, store, names) -> None:
         """Start summing the gradient slices of ``names`` NOW, while the rest of the backward pass still
@@ -101,7 +149,7 @@ class DataParallel:
         exchanged per step.  The collective is ordered after the *current* stream (call it
         on the stream that produced the slices); ``all_reduce_gradients`` later skips these spans and
         waits for them.  A caller must only name variables that receive no further contributions."""
-        if self.world_size == 1 or not self.overlap:
+        if (self.world_size == 1 and not self.forced) or not self.overlap:
             return
         if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
             return
@@ -200,7 +248,7 @@ class DataParallel:
         """In-place sum of the flat gradient buffer over ranks, in large buckets (minus the spans
         ``all_reduce_early`` already started); returns with every collective of the step ordered
         before the current stream."""
-        if self.world_size == 1:
+        if self.world_size == 1 and not self.forced:
             return
         grad = store.ensure_grad()
         pos = 0
@@ -214,8 +262,7 @@ class DataParallel:
         if timed:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        for hnd in self._handles:
-            hnd.wait()
+        self._wait_handles()
         if timed:
             ev1.record()
             self._timed.append((ev0, ev1))
@@ -283,6 +330,8 @@ def current() -> Optional[DataParallel]:
 
 def shutdown() -> None:
     global _CURRENT
+    if _CURRENT is not None:
+        _CURRENT.close()
     _CURRENT = None
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -159,3 +159,21 @@ def test_contexts_own_their_switches_and_timers(lib, monkeypatch):
     assert lib.nm_destroy(a) == 0                      # unbinds itself
     assert lib.nm_ctx_current() == default
     assert lib.nm_destroy(b) == 0
+
+
+def test_gradient_exchange_entry_points_refuse_without_a_device_or_a_communicator():
+    """nm_allreduce_* (RCCL resolved at run time, csrc/nm_comm.hip): no compute here -- the argument checks, and that
+    a box without a GPU gets an error code and a message instead of a crash or a load failure of the library."""
+    import ctypes
+    from neuralmonkey_amd import _lib
+    lib = _lib.load()
+    assert lib.nm_allreduce_unique_id(None, 128) != 0 and b"128 bytes" in lib.nm_last_error()
+    uid = ctypes.create_string_buffer(128)
+    comm = ctypes.c_void_p()
+    assert lib.nm_allreduce_init(3, 2, uid, ctypes.byref(comm)) != 0 and b"rank 3 of 2" in lib.nm_last_error()
+    assert lib.nm_allreduce_bucket(None, None, None, 0) != 0 and b"not a communicator" in lib.nm_last_error()
+    assert lib.nm_allreduce_wait(None, None) != 0 and lib.nm_allreduce_destroy(None) != 0
+    import torch
+    if not torch.cuda.is_available():
+        assert lib.nm_allreduce_init(0, 1, uid, ctypes.byref(comm)) != 0
+        assert b"nm_allreduce_init" in lib.nm_last_error()

@@ -138,16 +138,20 @@ def test_ranks_over_rccl_equal_one_process_on_the_full_batch(tmp_path, world):
     _ranks_against_one_process(tmp_path, world, "nccl", sparse=(world == 4))
 
 
-def _rccl_worker(rank, world, port, out_dir):
+def _rccl_worker(rank, world, port, out_dir, allreduce="torch"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
-                      NM_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      NM_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", NM_DIST_ALLREDUCE=allreduce)
     os.environ.pop("NM_DIST_BACKEND", None)             # default on a GPU box: nccl = RCCL
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch.distributed as dist
     from neuralmonkey_amd import distributed
     dp = distributed.init_from_env()
-    assert dp is not None and dp.world_size == 1 and dist.get_backend() == "nccl"
+    assert dp is not None and dp.world_size == 1 and dist.get_backend() == "nccl" and dp.forced
+    assert (dp._comm is not None) == (allreduce == "nmhip")
+    reduced = []
+    real_span = dp._reduce_span
+    dp._reduce_span = lambda grad, lo, hi: (reduced.append((lo, hi)), real_span(grad, lo, hi))[1]
     model = _model()
     store = model.tf_manager.sessions[0].store
     dp.broadcast_parameters(store)
@@ -158,15 +162,20 @@ def _rccl_worker(rank, world, port, out_dir):
         res = model.tf_manager.execute(batch, model.trainer.feedables, [model.trainer], train=True)[0]
         losses.append(res.losses["decoder - cost"])
     torch.cuda.synchronize()
+    # every step: two early spans from inside the backward pass + the rest of the flat buffer, all of it covered
+    assert len(reduced) >= 3 * 3
+    assert sum(hi - lo for lo, hi in reduced) == 3 * store.ensure_grad().numel()
     np.savez(os.path.join(out_dir, "rccl.npz"), theta=store.theta.cpu().numpy(), losses=np.asarray(losses))
     distributed.shutdown()
 
 
-def test_rccl_process_group_of_one_trains_like_no_process_group(tmp_path):
+@pytest.mark.parametrize("allreduce", ["torch", "nmhip"])
+def test_rccl_process_group_of_one_trains_like_no_process_group(tmp_path, allreduce):
     """The RCCL path itself (backend nccl: process group, broadcast, early + bucketed all-reduce on their streams,
     global token count) with a world of one, where every collective is the identity: three optimizer steps end
-    bit for bit where the same model ends without a process group."""
-    mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    bit for bit where the same model ends without a process group.  ``nmhip``: the gradient buckets go through the
+    library's own communicator (nm_allreduce_*, NM_DIST_ALLREDUCE=nmhip) instead of torch.distributed's."""
+    mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path), allreduce), nprocs=1, join=True)
     got = np.load(tmp_path / "rccl.npz")
     model = _model()
     store = model.tf_manager.sessions[0].store
@@ -176,3 +185,30 @@ def test_rccl_process_group_of_one_trains_like_no_process_group(tmp_path):
     assert np.allclose(got["losses"], want_losses, rtol=1e-5, atol=0)
     diff = np.abs(got["theta"] - store.theta.cpu().numpy())       # (embedding-gradient atomics: see the test above)
     assert diff.max() <= 6.5e-4 and np.median(diff) <= 1e-6
+
+
+def test_library_communicator_of_one_rank(dev):
+    """nm_allreduce_* straight through the C ABI: id, communicator of one rank, two buckets enqueued behind the
+    kernels that fill them, a device-side wait, destroy.  A sum over one rank is the identity; what is checked is the
+    ordering against the caller's stream (the buckets are written right before and read right after)."""
+    import ctypes
+    from neuralmonkey_amd import _lib
+    lib = _lib.load()
+    uid = ctypes.create_string_buffer(128)
+    _lib.check(lib.nm_allreduce_unique_id(uid, 128), "nm_allreduce_unique_id")
+    assert any(uid.raw)
+    comm = ctypes.c_void_p()
+    _lib.check(lib.nm_allreduce_init(0, 1, uid, ctypes.byref(comm)), "nm_allreduce_init")
+    stream = torch.cuda.current_stream().cuda_stream
+    buf = torch.empty(3_000_000, device=dev)
+    for rnd in range(3):
+        buf.copy_(torch.arange(buf.numel(), device=dev, dtype=torch.float32) * (rnd + 1))
+        _lib.check(lib.nm_allreduce_bucket(comm, stream, buf.data_ptr(), 1_000_000), "nm_allreduce_bucket")
+        _lib.check(lib.nm_allreduce_bucket(comm, stream, buf.data_ptr() + 4_000_000, 2_000_000), "nm_allreduce_bucket")
+        _lib.check(lib.nm_allreduce_wait(comm, stream), "nm_allreduce_wait")
+        total = float(buf.double().sum())
+        n = buf.numel()
+        assert total == (rnd + 1) * n * (n - 1) / 2
+    assert lib.nm_allreduce_bucket(comm, stream, None, 10) != 0           # refused, with a message
+    assert b"empty bucket" in lib.nm_last_error()
+    _lib.check(lib.nm_allreduce_destroy(comm), "nm_allreduce_destroy")
