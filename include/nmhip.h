@@ -284,6 +284,10 @@ int nm_decoder_step_fused(void* stream, const nm_decoder_step* step);
  * decoders/autoregressive.py:470 (argmax, first max wins), :289-316,351-375 (xent, log-probs) */
 int nm_row_stats(void* stream, const float* x, int64_t ldx, int64_t rows, int64_t V, float* max_out,
                  float* lse_out, int32_t* argmax_out);
+/* one draw per row from softmax(x): tf.multinomial(logits, 1) of the sampling decoder body
+ * (decoders/autoregressive.py:470-473), as argmax(x + Gumbel noise) with counter-based noise of (salt, row, column) */
+int nm_gumbel_argmax(void* stream, const float* x, int64_t ldx, int64_t rows, int64_t V, uint32_t salt,
+                     int32_t* out);
 int nm_log_softmax(void* stream, const float* x, int64_t ldx, const float* rmax, const float* rlse,
                    float* out, int64_t ldo, int64_t rows, int64_t V);
 int nm_greedy_update(void* stream, const int32_t* argmax, int32_t* finished, int32_t* sym_out,

@@ -56,6 +56,7 @@ SIGNATURES = {
     "nm_prof_enable": (I, [P, I]),
     "nm_prof_attn_step": (I, [P, P, P]),
     "nm_row_stats": (I, [P, P, L, L, L, P, P, P]),
+    "nm_gumbel_argmax": (I, [P, P, L, L, L, ctypes.c_uint32, P]),
     "nm_greedy_update": (I, [P, P, P, P, P, L, I, P]),
     "nm_xent": (I, [P, P, L, L, L, P, P, P, P, I, F]),
     "nm_xent_colsum": (I, [P, P, L, L, L, P, P, P, P, F, P, L]),

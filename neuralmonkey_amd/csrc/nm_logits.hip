@@ -861,6 +861,62 @@ extern "C" int nm_row_stats(void* stream, const float* x, int64_t ldx, int64_t r
     NM_LAUNCH_CHECK("nm_row_stats");
 }
 
+// ---------------------------------------------------------------------------
+// Sampling step (decoders/autoregressive.py:470-473: tf.multinomial(logits, 1) when ``sample``): one draw per row
+// from softmax(x), as argmax_c (x[r,c] + g[r,c]) with Gumbel noise g = -log(-log(u)).  TF's Philox stream cannot be
+// replayed by anyone; u is a counter-based hash of (salt, row, column) as for dropout (nm_eltwise.hip), so that the
+// CPU checker restates the draw (oracle/nm_oracle.py:gumbel_noise):
+//   key = mix32(salt + row * 0x85EBCA6B),  bits = mix32(column * 0x9E3779B1 + key),  u = ((bits >> 8) + 0.5) / 2^24.
+// The caller folds the step (and whatever else distinguishes two draws) into ``salt``.  Ties: the first maximum.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t sample_mix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x21f0aaadu;
+    x ^= x >> 15;
+    x *= 0x735a2d97u;
+    x ^= x >> 15;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void gumbel_argmax_kernel(const float* __restrict__ x, long ldx, int V, uint32_t salt,
+                                                            int* __restrict__ out) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const int r = blockIdx.x;
+    const float* row = x + (long)r * ldx;
+    const uint32_t key = sample_mix32(salt + (uint32_t)r * 0x85EBCA6Bu);
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = threadIdx.x; c < V; c += 256) {
+        const uint32_t bits = sample_mix32((uint32_t)c * 0x9E3779B1u + key);
+        const float u = ((float)(bits >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float v = row[c] - logf(-logf(u));
+        if (v > best) { best = v; bi = c; }           // ascending columns per thread: its first maximum
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(best, off);
+        const int oi = __shfl_xor(bi, off);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+        out[r] = bi;
+    }
+}
+
+extern "C" int nm_gumbel_argmax(void* stream, const float* x, int64_t ldx, int64_t rows, int64_t V, uint32_t salt,
+                                int32_t* out) {
+    NM_REQUIRE(x && out && rows >= 0 && V > 0 && ldx >= V && V < (1 << 30), "nm_gumbel_argmax: bad args");
+    if (rows == 0) return NM_OK;
+    hipLaunchKernelGGL(gumbel_argmax_kernel, dim3((unsigned)rows), dim3(256), 0, nm_stream(stream), x, (long)ldx,
+                       (int)V, salt, out);
+    NM_LAUNCH_CHECK("nm_gumbel_argmax");
+}
+
 extern "C" int64_t nm_beam_workspace_bytes(int64_t B, int64_t k, int64_t V) {
     (void)k; (void)V;
     return B * 64 * BEAM_MAX_K * 8 + 256;

@@ -5,7 +5,7 @@ What the reference expresses as tf.while_loop over ``LoopState`` namedtuples
 time-major history buffers; the fetchable surface (``train_loss``,
 ``runtime_loss``, ``runtime_logprobs``, ``decoded`` ...) is kept.
 """
-from typing import Any, Dict, NamedTuple, Optional
+from typing import List, Any, Dict, NamedTuple, Optional
 
 import numpy as np
 import torch
@@ -255,3 +255,27 @@ class AutoregressiveDecoder(ModelPart):
 
     def decoding_loop(self, ctx, train_mode: bool, sample: bool = False, temperature: float = 1.0):
         raise NotImplementedError("Abstract method")
+
+    def sampling_salts(self, ctx, steps: int) -> List[int]:
+        """Salts of the ``steps`` draws of ONE sampling loop (autoregressive.py:470-473: tf.multinomial per step).
+        TF seeds tf.multinomial from the graph / op seeds; here a draw is a counter-based hash of (salt, row,
+        column) (``nm_gumbel_argmax``) and the salt folds in the session's seed, the decoder's name, how many
+        sampling loops the session has run before this one and the step -- reproducible for a seeded session,
+        different from loop to loop.  Kept in ``ctx.memo[(id(self), "sampling_salts")]`` for whoever checks."""
+        sess = ctx.session
+        draw = sess.__dict__.get("_sampling_loops", 0)
+        sess.__dict__["_sampling_loops"] = draw + 1
+        base = ctx.salt(self.name, "sample", getattr(sess, "seed", None))
+        salts = [(base + draw * 0x9E3779B9 + t * 0x632BE5AB) & 0xFFFFFFFF for t in range(steps)]
+        ctx.memo[(id(self), "sampling_salts")] = salts
+        return salts
+
+    @staticmethod
+    def check_sampling_args(train_mode: bool, sample: bool, temperature: float) -> None:
+        if temperature <= 0.0:
+            raise ValueError("temperature must be positive, got {}".format(temperature))
+        if train_mode and (sample or temperature != 1.0):
+            # (autoregressive.py:466-473 lets `sample` override teacher forcing; the only caller in the reference,
+            # trainers/rl_trainer.py:122-125 -- out of scope, SURVEY 8 -- passes train_mode=False)
+            raise NotImplementedError("sampling / temperature in a teacher-forced loop are not implemented "
+                                      "(the reference's only caller samples with train_mode=False)")

@@ -253,9 +253,15 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
             self._dec_input_ids(ctx)
 
     def decoding_loop(self, ctx, train_mode: bool, sample: bool = False, temperature: float = 1.0):
+        """autoregressive.py:527-562.  ``sample`` / ``temperature`` (get_body, :440-493): the step's logits are
+        divided by the temperature and the next symbol is drawn from their softmax instead of taken as the argmax;
+        the loop then keeps its logits (the histories the reference's caller reads)."""
+        self.check_sampling_args(train_mode, sample, temperature)
+        if train_mode:
+            return self._train_loop(ctx)
         if sample or temperature != 1.0:
-            raise NotImplementedError("sampling / temperature are not implemented in the HIP engine")
-        return self._train_loop(ctx) if train_mode else self._runtime_loop(ctx, keep_logits=False)
+            return self._runtime_loop(ctx, keep_logits=True, sample=sample, temperature=float(temperature))
+        return self._runtime_loop(ctx, keep_logits=False)
 
     def _train_loop(self, ctx, want_grad: bool = False, grad_scale: Optional[torch.Tensor] = None) -> TrainResult:
         if self.uses_general_path(bool(ctx.fed(self.train_mode))):
@@ -501,8 +507,11 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
         return res.loss_sum[0] / res.token_count
 
     # -- greedy runtime path -------------------------------------------------------------------
-    def _runtime_loop(self, ctx, keep_logits: bool) -> RuntimeResult:
+    def _runtime_loop(self, ctx, keep_logits: bool, sample: bool = False, temperature: float = 1.0) -> RuntimeResult:
         key = (id(self), "run", keep_logits)
+        plain = not sample and temperature == 1.0          # the greedy loop of the runners
+        if not plain:
+            key = key + ("sample" if sample else "argmax", temperature)
         bsz = int(ctx.fed(self.batch_size))
         e, h, v = self.embedding_size, self.rnn_size, len(self.vocabulary)
         tmax = self.max_output_len
@@ -546,7 +555,8 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
         # (not when the loop runs in train mode with input dropout: nm_greedy_finish gathers the next input
         # embedding straight from the table, embed_input_symbols applies the dropout of autoregressive.py:199-214)
         drops = bool(ctx.fed(self.train_mode)) and self.dropout_keep_prob < 1.0
-        use_stats = graph_ok and not drops and self.logits_stats_ok(ctx, out_all[0])
+        use_stats = plain and graph_ok and not drops and self.logits_stats_ok(ctx, out_all[0])
+        salts = self.sampling_salts(ctx, tmax) if sample else None
         stats = ctx.buffer(key + ("stats",), (ops.logits_stats_numel(bsz, v),)) if use_stats else None
         table = self.embedding_matrix(ctx)
 
@@ -580,7 +590,12 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
                 if indexed:
                     stepper.set_position(t, 0)
                 stepper.step(emb, st_t, out_all[t], logits, h_out=s_all[t])
-            ops.row_stats(logits, None, None, argmax)
+            if temperature != 1.0:                       # logits /= temperature (autoregressive.py:493)
+                ops.ew("scale", logits, None, logits, alpha=1.0 / temperature)
+            if sample:                                   # tf.multinomial(logits, 1) (:470-473)
+                ops.gumbel_argmax(logits, salts[t], argmax)
+            else:
+                ops.row_stats(logits, None, None, argmax)
             if t < t_xent:
                 ops.xent(logits, tgt[t], tmask[t], xent_rows[t])
             ops.greedy_update(argmax, finished, symbols[t], omask[t], END_TOKEN_INDEX, allfin[t:t + 1])
@@ -588,7 +603,7 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
                 self.embed_input_symbols(ctx, symbols[t], out=emb)
 
         shape_key = tuple(tuple(st.weights.shape) for st in att0)
-        graphed = graph_ok or indexed
+        graphed = (graph_ok or indexed) and not sample      # (a draw's salt is a launch argument: eager launches)
         chunk_key = key + ("chunk", bsz, t_xent, shape_key, getattr(stepper, "shape_key", ()))
 
         def launch(t0, n):

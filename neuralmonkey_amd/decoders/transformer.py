@@ -242,9 +242,13 @@ class TransformerDecoder(AutoregressiveDecoder):
             self._staged(ctx, "tdec_mask_bt", torch.float32, lambda a: (a != 0).astype(np.float32))
 
     def decoding_loop(self, ctx, train_mode: bool, sample: bool = False, temperature: float = 1.0):
+        """autoregressive.py:527-562; ``sample`` / ``temperature`` as in ``Decoder.decoding_loop``."""
+        self.check_sampling_args(train_mode, sample, temperature)
+        if train_mode:
+            return self._train_loop(ctx)
         if sample or temperature != 1.0:
-            raise NotImplementedError("sampling / temperature are not implemented in the HIP engine")
-        return self._train_loop(ctx) if train_mode else self._runtime_loop(ctx, keep_logits=False)
+            return self._runtime_loop(ctx, keep_logits=True, sample=sample, temperature=float(temperature))
+        return self._runtime_loop(ctx, keep_logits=False)
 
     def _train_loop(self, ctx, want_grad: bool = False, grad_scale: Optional[torch.Tensor] = None) -> TrainResult:
         train = bool(ctx.fed(self.train_mode))
@@ -299,8 +303,10 @@ class TransformerDecoder(AutoregressiveDecoder):
                      max_positions: int = 0) -> "TransformerStepper":
         return TransformerStepper(self, ctx, rows, tag, rows_per_key, max_positions)
 
-    def _runtime_loop(self, ctx, keep_logits: bool) -> RuntimeResult:
+    def _runtime_loop(self, ctx, keep_logits: bool, sample: bool = False, temperature: float = 1.0) -> RuntimeResult:
         key = (id(self), "trun", keep_logits)
+        if sample or temperature != 1.0:
+            key = key + ("sample" if sample else "argmax", temperature)
         bsz = int(ctx.fed(self.batch_size))
         d, v = self.dimension, len(self.vocabulary)
         tmax = self.max_output_len
@@ -326,13 +332,19 @@ class TransformerDecoder(AutoregressiveDecoder):
         self.embed_input_symbols(ctx, go, out=emb[0])
         self.decoding_bias(ctx)              # lazily built tensors: outside the captured chunks
         t_xent = min(t_target, tmax) if has_tgt else 0
+        salts = self.sampling_salts(ctx, tmax) if sample else None
 
         def body(t):
             """Step t touches persistent buffers only and depends on nothing but t (graph capturable)."""
             logits = logits_all[t] if keep_logits else logits_one
             stepper.set_position(t, 0)
             stepper.step(emb[t & 1], [], out_all[t], logits, finished=finished)
-            ops.row_stats(logits, None, None, argmax)
+            if temperature != 1.0:                       # logits /= temperature (autoregressive.py:493)
+                ops.ew("scale", logits, None, logits, alpha=1.0 / temperature)
+            if sample:                                   # tf.multinomial(logits, 1) (:470-473)
+                ops.gumbel_argmax(logits, salts[t], argmax)
+            else:
+                ops.row_stats(logits, None, None, argmax)
             if t < t_xent:
                 ops.xent(logits, tgt[t], tmask[t], xent_rows[t])
             ops.greedy_update(argmax, finished, symbols[t], omask[t], END_TOKEN_INDEX, allfin[t:t + 1])
@@ -343,8 +355,11 @@ class TransformerDecoder(AutoregressiveDecoder):
                 for t in range(t0, t0 + n):
                     body(t)
             # one HIP graph per chunk of steps; the host reads the finished flags one chunk behind
-            ctx.session.graphed(key + ("chunk", t0, n, bsz, t_xent, stepper.shape_key), chunk)
-        steps, _ = ctx.session.decode_chunks(tmax, CHECK_EVERY_TRANSFORMER, launch, allfin)
+            if sample:                                   # (a draw's salt is a launch argument: eager launches)
+                chunk()
+            else:
+                ctx.session.graphed(key + ("chunk", t0, n, bsz, t_xent, stepper.shape_key), chunk)
+        steps, _ = ctx.session.decode_chunks(tmax, CHECK_EVERY_TRANSFORMER, launch, allfin, run_ahead=not sample)
         xent_sum = None
         if has_tgt:
             xent_sum = ctx.buffer(key + ("xent_sum",), (1,))

@@ -226,6 +226,14 @@ def row_stats(x, rmax=None, lse=None, argmax=None):
                                 _p(rmax), _p(lse), _p(argmax)), "nm_row_stats")
 
 
+def gumbel_argmax(x, salt: int, out):
+    """One categorical draw per row from softmax(x) (tf.multinomial): argmax of x + Gumbel noise of (salt, row, col)."""
+    lib = _lib.load()
+    assert x.dim() == 2 and x.stride(1) == 1 and out.dtype == torch.int32
+    _lib.check(lib.nm_gumbel_argmax(_stream(), x.data_ptr(), x.stride(0), x.shape[0], x.shape[1],
+                                    int(salt) & 0xFFFFFFFF, out.data_ptr()), "nm_gumbel_argmax")
+
+
 def greedy_update(argmax, finished, sym_out, mask_out, end_id, all_finished=None):
     lib = _lib.load()
     _lib.check(lib.nm_greedy_update(_stream(), argmax.data_ptr(), finished.data_ptr(),

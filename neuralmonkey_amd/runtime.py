@@ -289,6 +289,7 @@ class Session:
     def __init__(self, device, seed: Optional[int] = None):
         from .variables import VariableStore
         self.device = torch.device(device)
+        self.seed = seed                 # also folded into the salts of sampling loops (decoders/autoregressive.py)
         self.store = VariableStore(self.device, seed)
         _LIVE_SESSIONS.add(self)
         self._buffers: Dict[Any, torch.Tensor] = {}

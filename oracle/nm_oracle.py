@@ -332,10 +332,31 @@ class DecodeResult(NamedTuple):
     weights: np.ndarray         # [T,R,S]
 
 
+def gumbel_noise(rows: int, vocab: int, salt: int) -> np.ndarray:
+    """The noise of one sampling step of the engine (csrc/nm_logits.hip:gumbel_argmax_kernel), restated: TF's
+    tf.multinomial (autoregressive.py:470-473) draws from a Philox stream nobody can replay, the engine draws
+    argmax(logits + g) with g = -log(-log(u)) and u a counter-based hash of (salt, row, column).  float32 [rows, vocab]."""
+    def mix(x):
+        x = x.astype(np.uint32)
+        x ^= x >> np.uint32(16)
+        x *= np.uint32(0x21F0AAAD)
+        x ^= x >> np.uint32(15)
+        x *= np.uint32(0x735A2D97)
+        x ^= x >> np.uint32(15)
+        return x
+    with np.errstate(over="ignore"):
+        key = mix(np.uint32(salt & 0xFFFFFFFF) + np.arange(rows, dtype=np.uint32) * np.uint32(0x85EBCA6B))
+        bits = mix(np.arange(vocab, dtype=np.uint32)[None, :] * np.uint32(0x9E3779B1) + key[:, None])
+    u = ((bits >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+    return (-np.log(-np.log(u))).astype(np.float32)
+
+
 def decoding_loop(params, spec: DecoderSpec, enc: EncoderOutput,
-                  train_inputs: Optional[np.ndarray], train_mode: bool) -> DecodeResult:
+                  train_inputs: Optional[np.ndarray], train_mode: bool, temperature: float = 1.0) -> DecodeResult:
     """AutoregressiveDecoder.decoding_loop (autoregressive.py:425-562) around
-    Decoder.next_state.  ``train_inputs`` is time-major [T,B] (:216-219)."""
+    Decoder.next_state.  ``train_inputs`` is time-major [T,B] (:216-219).  ``temperature``: logits /= temperature
+    (:493).  (A sampled loop is checked by teacher-forcing the engine's draws through this function and restating
+    each draw with ``gumbel_noise``: tests/test_sampling_gpu.py.)"""
     dp = _dec_params(params, spec)
     bsz = enc.output.shape[0]
     hf = attention_keys(enc.temporal_states, dp["key_w"])
@@ -348,6 +369,8 @@ def decoding_loop(params, spec: DecoderSpec, enc: EncoderOutput,
         out, state, ctx, w = decoder_step(dp, spec, emb_in, state, hf,
                                           enc.temporal_states, enc.temporal_mask)
         logits = state_to_logits(dp, spec, out)
+        if temperature != 1.0:
+            logits = (logits / np.asarray(temperature, logits.dtype)).astype(logits.dtype)     # :493
         if train_mode:
             nxt = train_inputs[step].astype(np.int64)                 # :467-468
         else:

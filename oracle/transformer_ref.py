@@ -246,7 +246,10 @@ class TransformerModel:
     def _next_output(self, seq, seq_mask, enc_states, enc_mask):
         return self.decoder_layers(seq, seq_mask, enc_states, enc_mask, False)[:, -1]
 
-    def greedy(self, src_ids, max_len: int):
+    def greedy(self, src_ids, max_len: int, pick=None, temperature: float = 1.0):
+        """``pick(t, logits) -> symbols`` replaces the argmax (autoregressive.py:466-473: tf.multinomial when the body
+        samples -- the checker hands the engine's draws back in and restates each of them, tests/test_sampling_gpu.py);
+        ``temperature``: logits /= temperature (:493)."""
         with torch.no_grad():
             table = self.target_embeddings()
             enc_states, enc_mask = self.encode_all(src_ids, False)
@@ -261,7 +264,10 @@ class TransformerModel:
                 seq = torch.cat([seq, emb.unsqueeze(1)], 1)
                 seq_mask = torch.cat([seq_mask, (~finished).to(self.dtype).unsqueeze(1)], 1)
                 lg = self.logits(self._next_output(seq, seq_mask, enc_states, enc_mask))
-                nxt = lg.argmax(1) * (~finished)
+                if temperature != 1.0:
+                    lg = lg / temperature
+                nxt = (torch.as_tensor(np.asarray(pick(t, lg.numpy())).astype(np.int64)) if pick else lg.argmax(1))
+                nxt = nxt * (~finished)
                 finished = finished | (nxt == END)
                 emb = table[nxt]
                 syms.append(nxt.numpy())

@@ -169,9 +169,12 @@ def test_unsupported_features_refuse_loudly():
                 rnn_size=4, label_smoothing=1.5)
     with pytest.raises(ValueError):          # nematus_projection: exactly one encoder
         nematus_projection().declare_variables(None, None, 4, [])
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError):     # sampling inside a teacher-forced loop (no caller in the reference)
         Decoder(encoders=[], vocabulary=vocab, data_id="t", name="ds", max_output_len=5, embedding_size=4,
-                rnn_size=4).decoding_loop(None, False, sample=True)
+                rnn_size=4).decoding_loop(None, True, sample=True)
+    with pytest.raises(ValueError):
+        Decoder(encoders=[], vocabulary=vocab, data_id="t", name="dt", max_output_len=5, embedding_size=4,
+                rnn_size=4).decoding_loop(None, False, temperature=-1.0)
     # cells / conditional GRU / attention on input are served by the general (taped) path
     for i, kw in enumerate((dict(rnn_cell="LSTM"), dict(rnn_cell="NematusGRU"), dict(attention_on_input=True))):
         dec = Decoder(encoders=[], vocabulary=vocab, data_id="t", name="dg{}".format(i), max_output_len=5,
