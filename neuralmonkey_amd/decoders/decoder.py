@@ -42,6 +42,7 @@ RNN_CELL_TYPES = ("NematusGRU", "GRU", "LSTM")
 # what it has enqueued (Session.decode_chunks), so a chunk only has to outlast one host round trip (~0.1 ms); a batch
 # that finishes early wastes at most one chunk, hence fewer steps per chunk where a step is long.
 FORWARD_OVERLAP = int(os.environ.get("NM_FWD_OVERLAP", "1"))     # 0 off, 1 on, 2 on with residency-capped GEMMs
+DW_EARLY = os.environ.get("NM_DW_EARLY", "0") != "0"             # A/B: the long leaf GEMM before the attentions' backward
 CHECK_EVERY = int(os.environ.get("NM_CHECK_EVERY", "8"))            # greedy RNN step ~0.1 ms
 CHECK_EVERY_BEAM = int(os.environ.get("NM_CHECK_EVERY_BEAM", "4"))  # beam-5 step ~0.35 ms (Transformer: 1.4 ms)
 CHECK_EVERY_TRANSFORMER = int(os.environ.get("NM_CHECK_EVERY_TRANSFORMER", "4"))   # cached greedy step ~0.65 ms
@@ -439,7 +440,7 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
         # attentions' backward, which is throughput work itself: the two trade places (a 67 us GEMM of the main
         # stream took 1.1 ms next to it, profiles/r04_train_step_timeline.txt).  Started after them it runs beside
         # the BPTT loops only, whose launches are latency-bound and leave the chip idle.
-        early_dw = os.environ.get("NM_DW_EARLY", "0") != "0"
+        early_dw = DW_EARLY
         if early_dw:
             with side(1):
                 vocabulary_projection_gradient()
