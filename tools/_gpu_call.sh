@@ -1,2 +1,4 @@
+mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 500 python -m pytest tests/test_sampling_gpu.py -x -q -m gpu 2>&1 | tail -25
+python -m pytest tests -q -m gpu > gpurun_out/r04_tests_full_v4.log 2>&1
+grep -E "passed|failed|error" gpurun_out/r04_tests_full_v4.log | tail -3
