@@ -335,6 +335,7 @@ def run_rnn(case, **overrides):
 TR_DEFAULT = dict(src_vocab=19, tgt_vocab=19, dim=8, ff=12, depth=2, heads=2, heads_self=2, heads_enc=2,
                   max_output_len=7, tie_embeddings=True, use_att_transform_bias=False, target_space_id=None,
                   shared_embeddings=False, scale_embeddings=False,
+                  second_encoder=False, strategy="serial", heads_hier=None,
                   beam=[3, 6, 0.6], seed=3, batch=4)
 
 
@@ -349,14 +350,22 @@ def build_transformer(cfg):
     enc = TransformerEncoder(name="encoder", input_sequence=seq, ff_hidden_size=cfg["ff"], depth=cfg["depth"],
                              n_heads=cfg["heads"], target_space_id=cfg["target_space_id"],
                              use_att_transform_bias=cfg["use_att_transform_bias"])
-    dec = TransformerDecoder(name="decoder", encoders=[enc], vocabulary=tv, data_id="target",
+    encoders, parts = [enc], [seq, enc]
+    if cfg["second_encoder"]:      # attention/transformer_cross_layer.py:68-268: the four combination strategies
+        seq2 = EmbeddedSequence(name="encoder2_input", vocabulary=sv, data_id="source2", embedding_size=cfg["dim"])
+        enc2 = TransformerEncoder(name="encoder2", input_sequence=seq2, ff_hidden_size=cfg["ff"], depth=cfg["depth"],
+                                  n_heads=cfg["heads"])
+        encoders.append(enc2)
+        parts += [seq2, enc2]
+    dec = TransformerDecoder(name="decoder", encoders=encoders, vocabulary=tv, data_id="target",
                              ff_hidden_size=cfg["ff"], n_heads_self=cfg["heads_self"], n_heads_enc=cfg["heads_enc"],
                              depth=cfg["depth"], max_output_len=cfg["max_output_len"],
                              embedding_size=None if cfg["shared_embeddings"] else cfg["dim"],
                              embeddings_source=seq if cfg["shared_embeddings"] else None,
                              tie_embeddings=cfg["tie_embeddings"],
-                             use_att_transform_bias=cfg["use_att_transform_bias"])
-    return seq, enc, dec, [seq, enc, dec]
+                             use_att_transform_bias=cfg["use_att_transform_bias"],
+                             attention_combination_strategy=cfg["strategy"], n_heads_hier=cfg["heads_hier"])
+    return seq, enc, dec, parts + [dec]
 
 
 def run_transformer(case, **overrides):
@@ -367,14 +376,20 @@ def run_transformer(case, **overrides):
     tgt = sentences(rng, bsz, cfg["tgt_vocab"], 1, cfg["max_output_len"] + 1, oov_every=3)
     src[-1] = src[-1][:1]
     series = {"source": src, "target": tgt}
+    if cfg["second_encoder"]:
+        series["source2"] = sentences(rng, bsz, cfg["src_vocab"], 1, 5, oov_every=4)
     out = {}
     fresh_graph()
     seq, enc, dec, parts = build_transformer(cfg)
-    inputs = string_inputs("source", "target")
+    inputs = string_inputs("source", "target", "source2")
     ds = dataset(series)
     with tf_eager.feeding(feed(parts, ds, False, inputs)):
         out["in/src_tokens"] = seq.input_factors[0].numpy()
         out["in/src_ids"] = seq.inputs.numpy()
+        if cfg["second_encoder"]:
+            out["in/src2_tokens"] = parts[2].input_factors[0].numpy()
+            out["in/src2_ids"] = parts[2].inputs.numpy()
+            out["out/enc2_states"] = parts[3].temporal_states.numpy()
         out["in/tgt_tokens"] = dec.train_tokens.numpy()
         out["in/tgt_ids"] = dec.train_inputs.numpy()
         out["out/encoder_inputs"] = enc.encoder_inputs.numpy()
@@ -859,6 +874,13 @@ CASES = collections.OrderedDict([
         heads_enc=2, depth=3, target_space_id=5, seed=12)),
     ("transformer_shared", lambda: run_transformer("transformer_shared", shared_embeddings=True,
                                                    scale_embeddings=True, seed=13)),
+    ("transformer_ms_serial", lambda: run_transformer("transformer_ms_serial", second_encoder=True, seed=31)),
+    ("transformer_ms_parallel", lambda: run_transformer("transformer_ms_parallel", second_encoder=True,
+                                                        strategy="parallel", seed=32)),
+    ("transformer_ms_flat", lambda: run_transformer("transformer_ms_flat", second_encoder=True, strategy="flat",
+                                                    seed=33)),
+    ("transformer_ms_hier", lambda: run_transformer("transformer_ms_hier", second_encoder=True,
+                                                    strategy="hierarchical", heads_hier=4, seed=34)),
 ])
 
 

@@ -325,14 +325,19 @@ def test_headline_model_through_the_numpy_oracle_as_well():
 # --------------------------------------------------------------------------------------------------------------------
 # Transformer
 # --------------------------------------------------------------------------------------------------------------------
-TRANSFORMER_CASES = ["transformer", "transformer_bias_untied", "transformer_shared"]
+TRANSFORMER_CASES = ["transformer", "transformer_bias_untied", "transformer_shared",
+                     # two encoders: attention/transformer_cross_layer.py:68-268, the four combination strategies
+                     "transformer_ms_serial", "transformer_ms_parallel", "transformer_ms_flat", "transformer_ms_hier"]
 
 
 def transformer_config(cfg):
+    two = cfg.get("second_encoder", False)
     return T.TConfig(depth=cfg["depth"], n_heads=cfg["heads"], n_heads_self=cfg["heads_self"],
                      n_heads_enc=cfg["heads_enc"], use_att_transform_bias=cfg["use_att_transform_bias"],
                      tie_embeddings=cfg["tie_embeddings"], target_space_id=cfg["target_space_id"],
-                     shared_embeddings=cfg["shared_embeddings"], scale_embeddings=cfg["scale_embeddings"])
+                     shared_embeddings=cfg["shared_embeddings"], scale_embeddings=cfg["scale_embeddings"],
+                     extra_encoders=("encoder2",) if two else (), strategy=cfg.get("strategy", "serial"),
+                     n_heads_hier=cfg.get("heads_hier") or 1)
 
 
 @pytest.mark.parametrize("case", TRANSFORMER_CASES)
@@ -345,6 +350,9 @@ def test_transformer_equals_the_reference(case):
         close(states, z["out/enc_states"], "encoder states")
         same(mask.numpy(), z["out/enc_mask"], "encoder mask")
         close(output, z["out/enc_output"], "encoder output (sum over time)")
+        if cfg.get("second_encoder", False):
+            close(model.encode(z["in/src2_ids"], False, "encoder2")[0], z["out/enc2_states"], "second encoder")
+            src = [src, z["in/src2_ids"]]
         loss, logits = model.train_loss(src, tgt.T, train=False)
         close(logits.transpose(0, 1), z["out/train_logits"], "train_logits [T,B,V]", 4e-6)
         close(loss, z["out/train_loss"], "train_loss")

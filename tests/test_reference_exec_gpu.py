@@ -151,6 +151,8 @@ def dataset_of(z, cfg, rows=None):
         series["maps"] = list(z["in/maps"])
     else:
         series["source"] = unpad(z["in/src_tokens"])
+    if "in/src2_tokens" in z:
+        series["source2"] = unpad(z["in/src2_tokens"])
     if rows is not None:
         series = {k: [v[i] for i in rows] for k, v in series.items()}
     n = len(series["target"])
@@ -238,7 +240,8 @@ def test_batched_beam_search_equals_the_per_sentence_searches_of_the_reference(d
             close(sc[i], z["out/beam{}_scores".format(i)][0], "scores of sentence {}".format(i))
 
 
-TRANSFORMER_CASES = ["transformer", "transformer_bias_untied", "transformer_shared"]
+TRANSFORMER_CASES = ["transformer", "transformer_bias_untied", "transformer_shared",
+                     "transformer_ms_serial", "transformer_ms_parallel", "transformer_ms_flat", "transformer_ms_hier"]
 
 
 def build_transformer(dev, cfg):
@@ -257,20 +260,29 @@ def build_transformer(dev, cfg):
     enc = TransformerEncoder(name="encoder", input_sequence=seq, ff_hidden_size=cfg["ff"], depth=cfg["depth"],
                              n_heads=cfg["heads"], target_space_id=cfg["target_space_id"],
                              use_att_transform_bias=cfg["use_att_transform_bias"])
-    dec = TransformerDecoder(name="decoder", encoders=[enc], vocabulary=tv, data_id="target",
+    encoders, feedables = [enc], [seq, enc]
+    if cfg.get("second_encoder", False):
+        seq2 = EmbeddedSequence(name="encoder2_input", vocabulary=sv, data_id="source2", embedding_size=cfg["dim"])
+        enc2 = TransformerEncoder(name="encoder2", input_sequence=seq2, ff_hidden_size=cfg["ff"], depth=cfg["depth"],
+                                  n_heads=cfg["heads"])
+        encoders.append(enc2)
+        feedables += [seq2, enc2]
+    dec = TransformerDecoder(name="decoder", encoders=encoders, vocabulary=tv, data_id="target",
                              ff_hidden_size=cfg["ff"], n_heads_self=cfg["heads_self"], n_heads_enc=cfg["heads_enc"],
                              depth=cfg["depth"], max_output_len=cfg["max_output_len"],
                              embedding_size=None if cfg["shared_embeddings"] else cfg["dim"],
                              embeddings_source=seq if cfg["shared_embeddings"] else None,
                              tie_embeddings=cfg["tie_embeddings"],
-                             use_att_transform_bias=cfg["use_att_transform_bias"])
+                             use_att_transform_bias=cfg["use_att_transform_bias"],
+                             attention_combination_strategy=cfg.get("strategy", "serial"),
+                             n_heads_hier=cfg.get("heads_hier"))
     k, max_steps, alpha = cfg["beam"]
     bdec = BeamSearchDecoder(name="beam", parent_decoder=dec, beam_size=k, max_steps=max_steps,
                              length_normalization=alpha)
     brun = BeamSearchRunner(output_series="hyp", decoder=bdec, rank=1)
     tfm = TensorFlowManager(num_sessions=1, num_threads=1, device=str(dev), seed=1)
     tfm.initialize_sessions()
-    return dict(seq=seq, enc=enc, dec=dec, bdec=bdec, brun=brun, tfm=tfm, feedables=[seq, enc, dec],
+    return dict(seq=seq, enc=enc, dec=dec, bdec=bdec, brun=brun, tfm=tfm, feedables=feedables + [dec],
                 store=tfm.sessions[0].store)
 
 
@@ -324,7 +336,8 @@ def test_fixture_beam_searches_are_decided_by_more_than_rounding():
         z, cfg, params = load(case)
         from tests.test_reference_exec import transformer_config
         k, max_steps, alpha = cfg["beam"]
-        _, _, gap = T.TransformerModel(params, transformer_config(cfg)).beam(z["in/src_ids"], k, max_steps, alpha)
+        src = [z["in/src_ids"], z["in/src2_ids"]] if cfg.get("second_encoder", False) else z["in/src_ids"]
+        _, _, gap = T.TransformerModel(params, transformer_config(cfg)).beam(src, k, max_steps, alpha)
         assert gap > 1e-5, "{}: near-tie {:.2e}".format(case, gap)
 
 

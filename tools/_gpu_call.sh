@@ -1,4 +1,2 @@
-mkdir -p gpurun_out
 export TMPDIR=/tmp
-python -m pytest tests -q -m gpu > gpurun_out/r04_tests_full_v4.log 2>&1
-grep -E "passed|failed|error" gpurun_out/r04_tests_full_v4.log | tail -3
+timeout 200 python -m pytest tests/test_reference_exec_gpu.py -q -m gpu -k "transformer or decided" 2>&1 | grep -E "passed|failed|Error|assert" | tail -12
