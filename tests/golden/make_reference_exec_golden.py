@@ -616,6 +616,10 @@ def build_multisource(cfg):
     elif cfg["kind"] == "dotprod":
         att = MultiHeadAttention(name="attention", n_heads=cfg["heads"], keys_encoder=enc)
         parts.append(att)
+    elif cfg["kind"] == "stateful":
+        from neuralmonkey.attention.stateful_context import StatefulContext
+        att = StatefulContext(name="attention", encoder=enc)
+        parts.append(att)
     else:
         att = Attention(name="attention", encoder=enc)
         parts.append(att)
@@ -867,6 +871,8 @@ CASES = collections.OrderedDict([
                                                dec_cell="LSTM")),
     ("factored_smoothing", lambda: run_multisource("factored_smoothing", kind="plain", factored=True,
                                                    label_smoothing=0.1, seed=28)),
+    ("stateful_context", lambda: run_multisource("stateful_context", kind="stateful", seed=30,
+                                                 conditional_gru=True)),
     ("ensemble", lambda: run_ensemble("ensemble")),
     ("transformer", lambda: run_transformer("transformer")),
     ("transformer_bias_untied", lambda: run_transformer(

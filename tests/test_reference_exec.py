@@ -370,7 +370,7 @@ def test_transformer_equals_the_reference(case):
 # attention variants on the RNN decoder: combinations over two encoders, dot-product attention, factored input
 # --------------------------------------------------------------------------------------------------------------------
 VARIANT_CASES = ["ms_flat", "ms_flat_share_sentinel", "ms_flat_projected_sentinel", "ms_hier", "ms_hier_share_sentinel",
-                 "dotprod_heads2", "dotprod_heads1", "factored_smoothing"]
+                 "dotprod_heads2", "dotprod_heads1", "factored_smoothing", "stateful_context"]
 
 
 def variant_model(cfg, params):
@@ -384,6 +384,9 @@ def variant_model(cfg, params):
         return M.MultiSourceModel(params, gcfg, mcfg)
     if cfg["kind"] == "dotprod":
         return D.DotProdModel(params, gcfg, cfg["heads"])
+    if cfg["kind"] == "stateful":
+        from oracle.stateful_ref import StaticContextModel
+        return StaticContextModel(params, gcfg)
     return G.GeneralModel(params, gcfg)
 
 

@@ -345,7 +345,7 @@ def test_fixture_beam_searches_are_decided_by_more_than_rounding():
 # attention variants on the RNN decoder (row f3) and the ensemble runner (row f4)
 # --------------------------------------------------------------------------------------------------------------------
 VARIANT_CASES = ["ms_flat", "ms_flat_share_sentinel", "ms_flat_projected_sentinel", "ms_hier", "ms_hier_share_sentinel",
-                 "dotprod_heads2", "dotprod_heads1", "factored_smoothing"]
+                 "dotprod_heads2", "dotprod_heads1", "factored_smoothing", "stateful_context"]
 
 
 def build_variant(dev, cfg):
@@ -383,6 +383,10 @@ def build_variant(dev, cfg):
         feedables += children + [att]
     elif cfg["kind"] == "dotprod":
         att = MultiHeadAttention(name="attention", n_heads=cfg["heads"], keys_encoder=enc)
+        feedables.append(att)
+    elif cfg["kind"] == "stateful":
+        from neuralmonkey_amd.attention.stateful_context import StatefulContext
+        att = StatefulContext(name="attention", encoder=enc)
         feedables.append(att)
     else:
         att = Attention(name="attention", encoder=enc)

@@ -7,30 +7,10 @@ import pytest
 import torch
 
 from oracle import general_ref as G
+from oracle.stateful_ref import StaticContextModel
 from tests import test_general_gpu as T
 
 pytestmark = pytest.mark.gpu
-
-
-class StaticContextModel(G.GeneralModel):
-    """The oracle's decoder with ``attention()`` == the encoder output (weights: ones of width 1)."""
-
-    def encode(self, src_ids, train):
-        states, mask, final = super().encode(src_ids, train)
-        self._final = final
-        return states, mask, final
-
-    def attention_setup(self, states, train):
-        return self._final, self._final
-
-    def context_size(self, st) -> int:
-        return st.shape[-1]
-
-    def repeat_sources(self, st, hf, mask, rep: int):
-        return st.repeat_interleave(rep, 0), hf.repeat_interleave(rep, 0), mask.repeat_interleave(rep, 0)
-
-    def attention(self, query, st, hf, mask):
-        return st, torch.ones(st.shape[0], 1, dtype=self.dtype)
 
 
 CASES = {
