@@ -488,7 +488,7 @@ def run_functions(case):
     save(case, {"kind": "functions"}, out)
 
 
-def run_beam_body(case):
+def run_beam_body(case, vsz=7, k=3, max_steps=5, alpha=0.6, seed=5, rank=2):
     """``BeamSearchDecoder`` (beam_search_decoder.py:218-596) over a hand-made parent decoder whose step
     distributions are read from a table indexed by (step, previous symbol): exact score ties (TopK must take the
     lower flat index), hypotheses that finish at different steps, a sentence whose whole beam finishes early, the
@@ -496,12 +496,13 @@ def run_beam_body(case):
     from neuralmonkey.decoders.autoregressive import AutoregressiveDecoder
     from neuralmonkey.decoders.beam_search_decoder import BeamSearchDecoder
     from neuralmonkey.runners.beamsearch_runner import BeamSearchRunner
-    vsz, k, max_steps, alpha = 7, 3, 5, 0.6
     bsz = 3
-    rng = np.random.default_rng(5)
+    rng = np.random.default_rng(seed)
     # logits[sentence, step, prev_symbol, :]: small multiples of 1/4 so that sums and ties are exact
     table = (rng.integers(-8, 9, (bsz, max_steps + 2, vsz, vsz)) / 4.0).astype(np.float32)
-    table[0, 0, 1] = [-3, -3, -3, 1.0, 1.0, 1.0, 0.5]           # sentence 0, step 0 from <s>: three-way exact tie
+    first = np.full(vsz, -3.0, np.float32)
+    first[3:6], first[6] = 1.0, 0.5
+    table[0, 0, 1] = first                                       # sentence 0, step 0 from <s>: three-way exact tie
     table[0, 1, 3] = table[0, 1, 4]                              # identical continuations -> tied scores next step
     table[0, 1, 5, 2] = 6.0                                      # a hypothesis that ends at once
     table[1, 1:, :, 2] += 9.0                                    # sentence 1: the whole beam ends early
@@ -553,7 +554,7 @@ def run_beam_body(case):
     dec = TableDecoder()
     bs = BeamSearchDecoder(name="beam", parent_decoder=dec, beam_size=k, max_steps=max_steps,
                            length_normalization=alpha)
-    runner = BeamSearchRunner(output_series="hyp", decoder=bs, rank=2)
+    runner = BeamSearchRunner(output_series="hyp", decoder=bs, rank=rank)
     series = {"target": [["w0"]] * bsz}
     inputs = string_inputs("target")
     with tf_eager.feeding(feed([dec, bs], dataset(series), False, inputs)):
@@ -571,7 +572,7 @@ def run_beam_body(case):
         out["out/dec_step"] = bo.last_dec_loop_state.feedables.step
         out["out/rank2_sentences"] = np.asarray([joined(s) for s in ex.result.outputs["hyp"]])
         out["out/rank2_loss"] = np.asarray(ex.result.losses["hyp/beam_search_score"])
-    save(case, {"kind": "beam_body", "vocab": vsz, "beam": [k, max_steps, alpha], "batch": bsz}, out)
+    save(case, {"kind": "beam_body", "vocab": vsz, "beam": [k, max_steps, alpha], "batch": bsz, "rank": rank}, out)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -839,6 +840,12 @@ def run_defects(case):
 CASES = collections.OrderedDict([
     ("functions", lambda: run_functions("functions")),
     ("beam_body", lambda: run_beam_body("beam_body")),
+    # no length normalisation (alpha 0: scores are the plain log-probability sums) with a beam as wide as the live
+    # vocabulary allows; alpha 1 with a longer search
+    ("beam_body_k5_alpha0", lambda: run_beam_body("beam_body_k5_alpha0", vsz=9, k=5, max_steps=6, alpha=0.0, seed=6,
+                                                  rank=3)),
+    ("beam_body_k4_alpha1", lambda: run_beam_body("beam_body_k4_alpha1", vsz=8, k=4, max_steps=8, alpha=1.0, seed=7,
+                                                  rank=1)),
     ("rnn_gru", lambda: run_rnn("rnn_gru")),
     ("rnn_gru_supress_unk", lambda: run_rnn("rnn_gru_supress_unk", supress_unk=True, seed=2, max_input_len=5,
                                             att_state=7)),

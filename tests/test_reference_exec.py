@@ -63,7 +63,8 @@ def sentence(ids, vocab):
 
 def test_every_generated_case_is_checked_here():
     have = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(FIX, "*.npz")))
-    checked = sorted(["functions", "beam_body", "defects", "ensemble"] + RNN_CASES + TRANSFORMER_CASES + VARIANT_CASES)
+    checked = sorted(["functions", "defects", "ensemble"] + BEAM_BODY_CASES + RNN_CASES + TRANSFORMER_CASES
+                     + VARIANT_CASES)
     assert have == checked
 
 
@@ -110,9 +111,14 @@ def test_pad_batch_of_the_product_equals_the_reference():
         same(np.asarray(pad_batch(sents, **kw)), z["out/pad_" + tag], "pad_batch " + tag)
 
 
-def test_beam_body_with_exact_ties_and_early_finishes():
+BEAM_BODY_CASES = ["beam_body", "beam_body_k5_alpha0", "beam_body_k4_alpha1"]     # (k, alpha) = (3, .6), (5, 0), (4, 1)
+
+
+@pytest.mark.parametrize("case", BEAM_BODY_CASES)
+def test_beam_body_with_exact_ties_and_early_finishes(case):
     """BeamSearchDecoder + BeamSearchRunner over a table-driven parent decoder: every number is exact."""
-    z, cfg, _ = load("beam_body")
+    z, cfg, _ = load(case)
+    rank = cfg.get("rank", 2)
     table = z["in/table"]
     k, max_steps, alpha = cfg["beam"]
     bsz, vsz = cfg["batch"], cfg["vocab"]
@@ -134,13 +140,13 @@ def test_beam_body_with_exact_ties_and_early_finishes():
     close(res.logprob_sum, z["out/logprob_sum"], "logprob_sum", 1e-7)
     assert state["step"] == int(z["out/dec_step"])
     close(O.length_penalty(np.arange(12), alpha, np.float32), z["out/length_penalty"], "_length_penalty", 1e-7)
-    sents, loss = O.beam_tokens(res, rank=2)
+    sents, loss = O.beam_tokens(res, rank=rank)
     vocab = words(vsz - 4)
     got = [sentence(s, vocab) for s in sents]
-    want = [str(s) for s in z["out/rank2_sentences"]]
+    want = [str(s) for s in z["out/rank2_sentences"]]              # (the key keeps its first name: the runner's rank)
     for g, w, toks in zip(got, want, np.transpose(res.token_ids, (1, 2, 0))):
-        if toks[1][1] == O.END:         # beamsearch_runner.py:88-99 leaves the raw ids when </s> comes first
-            assert w == " ".join(str(t) for t in toks[1][1:]) and g == ""
+        if toks[rank - 1][1] == O.END:  # beamsearch_runner.py:88-99 leaves the raw ids when </s> comes first
+            assert w == " ".join(str(t) for t in toks[rank - 1][1:]) and g == ""
         else:
             assert g == w
     close(loss, z["out/rank2_loss"], "runner loss", 1e-6)

@@ -11,8 +11,10 @@ import os
 
 import numpy as np
 import pytest
+import torch
 
 from oracle import general_ref as G
+from oracle import nm_oracle as O
 from oracle import transformer_ref as T
 
 pytestmark = pytest.mark.gpu
@@ -445,3 +447,66 @@ def test_attention_variants_engine_equals_the_reference(dev, case):
     assert np.array_equal(out["sym"], z["out/runtime_symbols"]), "greedy symbols"
     assert np.array_equal(np.asarray(out["mask"]).astype(bool), z["out/runtime_mask"]), "runtime mask"
     close(out["logits"], z["out/runtime_logits"], "runtime_logits")
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# the beam body's kernels on the reference's table-driven searches (exact float32 ties, early finishes, max_steps)
+# --------------------------------------------------------------------------------------------------------------------
+BEAM_BODY_CASES = ["beam_body", "beam_body_k5_alpha0", "beam_body_k4_alpha1"]
+
+
+@pytest.mark.parametrize("case", BEAM_BODY_CASES)
+@pytest.mark.parametrize("fused", [False, True])
+def test_beam_kernels_reproduce_the_reference_search_over_a_table(dev, case, fused):
+    """``nm_beam_topk_step`` / ``nm_beam_topk_step_fused`` driven step by step over the logits table of the
+    ``beam_body`` fixtures (what the REFERENCE'S BeamSearchDecoder produced for them, beam_search_decoder.py:394-556):
+    selections under exact score ties (TopK takes the lower flat index), finished hypotheses continuing with <pad> at
+    score 0, the length penalty (alpha 0.6 / 0 / 1), unnormalised log-probability sums, lengths, flags and the final
+    scores.  The tables hold small multiples of 1/4 and tied candidates come from IDENTICAL logit rows, so ties are
+    exact in any implementation: symbols, lengths and flags are compared with ==, sums and scores to 2e-6 (the
+    log-softmax is evaluated by different exp / log routines)."""
+    from neuralmonkey_amd import ops
+    z, cfg, _ = load(case)
+    table = z["in/table"]
+    k, max_steps, alpha = cfg["beam"]
+    bsz, vsz = cfg["batch"], cfg["vocab"]
+    rows = bsz * k
+    sent = np.repeat(np.arange(bsz), k)
+    f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev)
+    i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.int32)).to(dev)
+    new_i = lambda: torch.empty((bsz, k), dtype=torch.int32, device=dev)
+    new_f = lambda: torch.empty((bsz, k), dtype=torch.float32, device=dev)
+    lps = f32(np.tile(np.array([0.0] + [-O.INF] * (k - 1), np.float32), (bsz, 1)))
+    lens, fin = i32(np.zeros((bsz, k))), i32(np.zeros((bsz, k)))
+    pen = ops.length_penalty_table(64, alpha, dev)
+    ws = ops.beam_workspace(bsz, k, vsz, dev)
+    mx, lse = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+    logits = table[sent, 0, 1]                                      # the initial parent step, from <s>
+    tokens = logits.argmax(1).reshape(1, bsz, k).astype(np.int64)   # token_ids[0]: the parent's greedy symbol
+    scores = None
+    step = 1
+    while step - 1 < max_steps and not bool(fin.bool().all()):
+        ld = f32(logits)
+        o_sc, o_lps = new_f(), new_f()
+        o_w, o_b, o_len, o_fin, o_src = new_i(), new_i(), new_i(), new_i(), new_i()
+        if fused:
+            ops.beam_topk_step_fused(ld, bsz, k, lps, lens, fin, pen, 2, o_sc, o_w, o_b, o_lps, o_len, o_fin, o_src,
+                                     ws, mx, lse)
+        else:
+            ops.row_stats(ld, mx, lse, None)
+            ops.beam_topk_step(ld, bsz, k, mx, lse, lps, lens, fin, pen, 2, o_sc, o_w, o_b, o_lps, o_len, o_fin,
+                               o_src, ws)
+        word, beam = o_w.cpu().numpy().astype(np.int64), o_b.cpu().numpy().astype(np.int64)
+        bidx = np.arange(bsz)[:, None]
+        tokens = np.concatenate([tokens[:, bidx, beam], word[None]], 0)
+        assert np.array_equal(o_src.cpu().numpy(), bidx * k + beam)
+        lps, lens, fin, scores = o_lps, o_len, o_fin, o_sc
+        logits = table[sent, step, word.reshape(-1)]
+        step += 1
+    assert step == int(z["out/dec_step"])
+    assert np.array_equal(tokens, z["out/token_ids"])
+    assert np.array_equal(lens.cpu().numpy(), z["out/lengths"])
+    assert np.array_equal(fin.cpu().numpy().astype(bool), z["out/finished"])
+    close(lps.cpu().numpy(), z["out/logprob_sum"], "logprob_sum", 2e-6)
+    close(scores.cpu().numpy(), z["out/scores"], "scores", 2e-6)
+    close(pen.cpu().numpy()[:12], z["out/length_penalty"], "length penalty table", 1e-7)
