@@ -436,6 +436,88 @@ def run_transformer(case, **overrides):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# gradients of the reference's loss, by central differences of the reference's own forward pass (row a22)
+# ----------------------------------------------------------------------------------------------------------------
+def run_fd_gradients(case, family, per_variable=4, h=5e-3, **overrides):
+    """``tf.gradients`` is TensorFlow's (trainers/generic_trainer.py:136-195) and the stand-in has no autodiff -- but
+    it can evaluate the reference's ``train_loss`` (decoders/autoregressive.py:289-316) at perturbed variables.  For
+    ``per_variable`` coordinates of every trainable variable: (loss(theta + h e_i) - loss(theta - h e_i)) / 2h, the
+    graph rebuilt for each evaluation.  float32 forward passes: about 1e-4 of absolute noise on each derivative,
+    enough to tell a wrong gradient (a missing term, a transposed product, a wrong mask) from a right one."""
+    if family == "rnn":
+        cfg = dict(RNN_DEFAULT, **overrides)
+        series = rnn_series(cfg)
+        inputs = string_inputs("source", "target")
+
+        def build():
+            enc, att, dec, parts = build_rnn(cfg)
+            return dec, parts
+    else:
+        cfg = dict(TR_DEFAULT, **overrides)
+        rng = np.random.default_rng(cfg["seed"])
+        src = sentences(rng, cfg["batch"], cfg["src_vocab"], 1, 6, oov_every=2)
+        tgt = sentences(rng, cfg["batch"], cfg["tgt_vocab"], 1, cfg["max_output_len"] + 1, oov_every=3)
+        series = {"source": src, "target": tgt}
+        inputs = string_inputs("source", "target", "source2")
+
+        def build():
+            seq, enc, dec, parts = build_transformer(cfg)
+            return dec, parts
+    ds = dataset(series)
+    bump = {}
+
+    def factory(name, shape, np_dtype, initializer):
+        value = variable_factory(name, shape, np_dtype, initializer)
+        if name in bump:
+            idx, delta = bump[name]
+            value = value.copy()
+            value.reshape(-1)[idx] += np.asarray(delta, value.dtype)
+        return value
+
+    def loss():
+        fresh_graph()
+        dec, parts = build()
+        with tf_eager.feeding(feed(parts, ds, False, inputs)):
+            return float(dec.train_loss.numpy()), dec, parts
+    tf_eager.VARIABLE_FACTORY = factory
+    try:
+        base, dec, parts = loss()
+        out = {"out/train_loss": np.asarray(base, np.float32)}
+        with tf_eager.feeding(feed(parts, ds, False, inputs)):
+            out["in/tgt_ids"] = dec.train_inputs.numpy()
+            if family == "rnn":
+                out["in/src_ids"] = parts[1].inputs.numpy()
+            else:
+                out["in/src_ids"] = parts[0].inputs.numpy()
+        order, params = variables()
+        rng = np.random.default_rng(zlib.crc32(case.encode()))
+        names, index, value = [], [], []
+        for name in order:
+            v = params[name]
+            if v.dtype.kind != "f" or v.size == 0:
+                continue
+            picks = rng.choice(v.size, size=min(per_variable, v.size), replace=False)
+            for i in picks:
+                bump.clear()
+                bump[name] = (int(i), +h)
+                up = loss()[0]
+                bump[name] = (int(i), -h)
+                down = loss()[0]
+                names.append(name)
+                index.append(int(i))
+                value.append((up - down) / (2.0 * h))
+        bump.clear()
+        loss()                                   # leave the unperturbed variables in the store for save()
+        out["fd/names"] = np.asarray(names)
+        out["fd/index"] = np.asarray(index, np.int64)
+        out["fd/value"] = np.asarray(value, np.float64)
+        out["fd/h"] = np.asarray(h)
+    finally:
+        tf_eager.VARIABLE_FACTORY = variable_factory
+    save(case, dict(cfg, family=family), out)
+
+
+# ----------------------------------------------------------------------------------------------------------------
 # function-level cases with hand-made edge inputs
 # ----------------------------------------------------------------------------------------------------------------
 def run_functions(case):
@@ -880,6 +962,11 @@ CASES = collections.OrderedDict([
                                                    label_smoothing=0.1, seed=28)),
     ("stateful_context", lambda: run_multisource("stateful_context", kind="stateful", seed=30,
                                                  conditional_gru=True)),
+    ("fd_gradients_rnn_gru", lambda: run_fd_gradients("fd_gradients_rnn_gru", "rnn")),
+    ("fd_gradients_rnn_nematus_lstm", lambda: run_fd_gradients(
+        "fd_gradients_rnn_nematus_lstm", "rnn", enc_layers=[[5, "bidirectional", "NematusGRU"]], dec_cell="LSTM",
+        output_projection=["nematus", "tanh"], encoder_projection="nematus", seed=16)),
+    ("fd_gradients_transformer", lambda: run_fd_gradients("fd_gradients_transformer", "transformer")),
     ("ensemble", lambda: run_ensemble("ensemble")),
     ("transformer", lambda: run_transformer("transformer")),
     ("transformer_bias_untied", lambda: run_transformer(

@@ -64,7 +64,7 @@ def sentence(ids, vocab):
 def test_every_generated_case_is_checked_here():
     have = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(FIX, "*.npz")))
     checked = sorted(["functions", "defects", "ensemble"] + BEAM_BODY_CASES + RNN_CASES + TRANSFORMER_CASES
-                     + VARIANT_CASES)
+                     + VARIANT_CASES + FD_CASES)
     assert have == checked
 
 
@@ -446,3 +446,55 @@ def test_single_model_ensemble_is_the_plain_search():
     res = E.beam_ensemble_transformer([model], z["in/src_ids"], k, max_steps, alpha)
     same(res.token_ids[1:], z["out/beam_token_ids"][1:], "token_ids")
     close(res.scores, z["out/beam_scores"], "scores", 4e-6)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# gradients (row a22): central differences of the REFERENCE'S loss against the oracle's autograd
+# --------------------------------------------------------------------------------------------------------------------
+FD_CASES = ["fd_gradients_rnn_gru", "fd_gradients_rnn_nematus_lstm", "fd_gradients_transformer"]
+
+
+@pytest.mark.parametrize("case", FD_CASES)
+def test_oracle_gradients_equal_the_finite_differences_of_the_reference_loss(case):
+    """``tf.gradients`` is TensorFlow's and the stand-in has none; what the reference's own code can give is its
+    loss at perturbed variables.  The fixture holds (loss(theta + h e_i) - loss(theta - h e_i)) / 2h for a few
+    coordinates of EVERY trainable variable, each from two executions of the reference's train_loss.  Two links:
+      (1) the ORACLE'S loss gives the same central difference at the same h (float64 oracle against the reference's
+          float32: what is left is the float32 rounding of the reference's two losses, ~1e-4) -- the oracle's loss
+          IS the reference's loss around theta, not only at theta;
+      (2) the oracle's autograd gradient -- the one the engine's backward kernels are tested against -- is the
+          derivative of that loss (float64 central difference at h = 1e-6).
+    A central difference at the fixture's h = 5e-3 is NOT the derivative to better than O(h^2) curvature and O(h)
+    at ReLU kinks (up to 4e-3 here), which is why (1) compares like with like."""
+    z, cfg, params = load(case)
+    h = float(z["fd/h"])
+    if cfg["family"] == "rnn":
+        make = lambda p, **kw: G.GeneralModel(p, general_config(cfg), **kw)
+        args = (z["in/src_ids"], z["in/tgt_ids"])
+    else:
+        make = lambda p, **kw: T.TransformerModel(p, transformer_config(cfg), **kw)
+        args = (z["in/src_ids"], z["in/tgt_ids"].T)
+    loss, grads = make(params, requires_grad=True).train_grads(*args, train=False)
+    close(loss, z["out/train_loss"], "train_loss")
+    names, index, value = [str(n) for n in z["fd/names"]], z["fd/index"], z["fd/value"]
+    assert len(set(names)) == sum(1 for v in params.values() if v.dtype.kind == "f" and v.size)    # every variable
+
+    def central(name, i, step):
+        p = {k: np.asarray(v, np.float64).copy() if v.dtype.kind == "f" else v for k, v in params.items()}
+        with torch.no_grad():
+            p[name].reshape(-1)[i] += step
+            up = float(make(p, dtype=torch.float64).train_loss(*args, train=False)[0])
+            p[name].reshape(-1)[i] -= 2 * step
+            down = float(make(p, dtype=torch.float64).train_loss(*args, train=False)[0])
+        return (up - down) / (2 * step)
+    sizeable = 0
+    for name, i, fd in zip(names, index, value):
+        same_h = central(name, int(i), h)
+        assert abs(same_h - fd) <= 3e-4, "{}[{}]: oracle {:.6f} vs reference {:.6f} at h={}".format(name, i, same_h, fd, h)
+        g = grads[name]
+        got = 0.0 if g is None else float(g.reshape(-1)[i])
+        exact = central(name, int(i), 1e-6)
+        assert abs(got - exact) <= 2e-5 + 1e-4 * abs(exact), "{}[{}]: autograd {:.7f} vs d/dtheta {:.7f}".format(
+            name, i, got, exact)
+        sizeable += abs(fd) > 1e-3
+    assert sizeable > len(value) // 3, "too few coordinates with a gradient to speak of"

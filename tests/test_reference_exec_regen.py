@@ -11,7 +11,8 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REFERENCE = "/root/reference"
-CASES = ["functions", "beam_body", "rnn_gru", "ms_hier_share_sentinel", "transformer", "transformer_ms_hier", "defects"]
+CASES = ["functions", "beam_body", "rnn_gru", "ms_hier_share_sentinel", "transformer", "transformer_ms_hier",
+         "fd_gradients_rnn_gru", "defects"]
 
 
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "neuralmonkey")), reason="no reference tree here")
