@@ -448,9 +448,27 @@ def run_fd_gradients(case, family, per_variable=4, h=5e-3, **overrides):
         cfg = dict(RNN_DEFAULT, **overrides)
         series = rnn_series(cfg)
         inputs = string_inputs("source", "target")
+        if cfg["spatial"] is not None:
+            inputs["maps"] = tf.placeholder(tf.float32, [None] + list(cfg["spatial"][:3]), "maps")
 
         def build():
             enc, att, dec, parts = build_rnn(cfg)
+            return dec, parts
+    elif family == "ms":
+        cfg = dict(MS_DEFAULT, **overrides)
+        rng = np.random.default_rng(cfg["seed"])
+        bsz = cfg["batch"]
+        src = sentences(rng, bsz, cfg["src_vocab"], 2, 6, oov_every=2)
+        series = {"source": src,
+                  "target": sentences(rng, bsz, cfg["tgt_vocab"], 1, cfg["max_output_len"] + 1, oov_every=3)}
+        inputs = string_inputs("source", "target", "tags")
+        if cfg["kind"] in ("flat", "hier"):
+            hh, ww, cc = cfg["image"][:3]
+            series["maps"] = list(np.maximum(rng.normal(0, 1, (bsz, hh, ww, cc)), 0).astype(np.float32))
+            inputs["maps"] = tf.placeholder(tf.float32, [None, hh, ww, cc], "maps")
+
+        def build():
+            enc, att, dec, parts = build_multisource(cfg)
             return dec, parts
     else:
         cfg = dict(TR_DEFAULT, **overrides)
@@ -458,6 +476,8 @@ def run_fd_gradients(case, family, per_variable=4, h=5e-3, **overrides):
         src = sentences(rng, cfg["batch"], cfg["src_vocab"], 1, 6, oov_every=2)
         tgt = sentences(rng, cfg["batch"], cfg["tgt_vocab"], 1, cfg["max_output_len"] + 1, oov_every=3)
         series = {"source": src, "target": tgt}
+        if cfg["second_encoder"]:
+            series["source2"] = sentences(rng, cfg["batch"], cfg["src_vocab"], 1, 5, oov_every=4)
         inputs = string_inputs("source", "target", "source2")
 
         def build():
@@ -485,10 +505,18 @@ def run_fd_gradients(case, family, per_variable=4, h=5e-3, **overrides):
         out = {"out/train_loss": np.asarray(base, np.float32)}
         with tf_eager.feeding(feed(parts, ds, False, inputs)):
             out["in/tgt_ids"] = dec.train_inputs.numpy()
-            if family == "rnn":
+            if family == "rnn" and cfg["spatial"] is not None:
+                out["in/maps"] = np.stack(series["maps"])
+            elif family == "rnn":
                 out["in/src_ids"] = parts[1].inputs.numpy()
+            elif family == "ms":
+                out["in/src_ids"] = parts[1].input_factor_indices[0].numpy()
+                if "maps" in series:
+                    out["in/maps"] = np.stack(series["maps"])
             else:
                 out["in/src_ids"] = parts[0].inputs.numpy()
+                if cfg["second_encoder"]:
+                    out["in/src2_ids"] = parts[2].inputs.numpy()
         order, params = variables()
         rng = np.random.default_rng(zlib.crc32(case.encode()))
         names, index, value = [], [], []
@@ -967,6 +995,17 @@ CASES = collections.OrderedDict([
         "fd_gradients_rnn_nematus_lstm", "rnn", enc_layers=[[5, "bidirectional", "NematusGRU"]], dec_cell="LSTM",
         output_projection=["nematus", "tanh"], encoder_projection="nematus", seed=16)),
     ("fd_gradients_transformer", lambda: run_fd_gradients("fd_gradients_transformer", "transformer")),
+    ("fd_gradients_ms_hier", lambda: run_fd_gradients("fd_gradients_ms_hier", "ms", kind="hier", share=True,
+                                                      sentinel=True, state_size=6, seed=36, per_variable=3)),
+    ("fd_gradients_ms_flat", lambda: run_fd_gradients("fd_gradients_ms_flat", "ms", kind="flat", sentinel=True,
+                                                      image=[2, 3, 7, None, 8], seed=37, per_variable=3)),
+    ("fd_gradients_dotprod", lambda: run_fd_gradients("fd_gradients_dotprod", "ms", kind="dotprod", heads=2,
+                                                      enc_size=3, seed=38, per_variable=3)),
+    ("fd_gradients_captioning", lambda: run_fd_gradients("fd_gradients_captioning", "rnn", spatial=[2, 3, 10, 9, 8],
+                                                         seed=17)),
+    ("fd_gradients_transformer_ms_hier", lambda: run_fd_gradients(
+        "fd_gradients_transformer_ms_hier", "transformer", second_encoder=True, strategy="hierarchical",
+        heads_hier=4, seed=35, per_variable=2)),
     ("ensemble", lambda: run_ensemble("ensemble")),
     ("transformer", lambda: run_transformer("transformer")),
     ("transformer_bias_untied", lambda: run_transformer(

@@ -379,7 +379,7 @@ VARIANT_CASES = ["ms_flat", "ms_flat_share_sentinel", "ms_flat_projected_sentine
                  "dotprod_heads2", "dotprod_heads1", "factored_smoothing", "stateful_context"]
 
 
-def variant_model(cfg, params):
+def variant_model(cfg, params, **kw):
     layers = ((cfg["enc_size"], "bidirectional", "GRU"),)
     gcfg = G.Config(rnn_layers=layers, dec_cell=cfg["dec_cell"], conditional_gru=cfg["conditional_gru"],
                     rnn_size=cfg["rnn_size"], label_smoothing=cfg["label_smoothing"] or 0.0)
@@ -387,13 +387,13 @@ def variant_model(cfg, params):
         mcfg = M.MultiConfig(kind=cfg["kind"], att_name="wrapper", state_size=cfg["state_size"], share=cfg["share"],
                              sentinel=cfg["sentinel"], image_name="imagenet",
                              image_spatial=(cfg["image"][3], cfg["image"][4]))
-        return M.MultiSourceModel(params, gcfg, mcfg)
+        return M.MultiSourceModel(params, gcfg, mcfg, **kw)
     if cfg["kind"] == "dotprod":
-        return D.DotProdModel(params, gcfg, cfg["heads"])
+        return D.DotProdModel(params, gcfg, cfg["heads"], **kw)
     if cfg["kind"] == "stateful":
         from oracle.stateful_ref import StaticContextModel
-        return StaticContextModel(params, gcfg)
-    return G.GeneralModel(params, gcfg)
+        return StaticContextModel(params, gcfg, **kw)
+    return G.GeneralModel(params, gcfg, **kw)
 
 
 @pytest.mark.parametrize("case", VARIANT_CASES)
@@ -451,7 +451,9 @@ def test_single_model_ensemble_is_the_plain_search():
 # --------------------------------------------------------------------------------------------------------------------
 # gradients (row a22): central differences of the REFERENCE'S loss against the oracle's autograd
 # --------------------------------------------------------------------------------------------------------------------
-FD_CASES = ["fd_gradients_rnn_gru", "fd_gradients_rnn_nematus_lstm", "fd_gradients_transformer"]
+FD_CASES = ["fd_gradients_rnn_gru", "fd_gradients_rnn_nematus_lstm", "fd_gradients_transformer",
+            "fd_gradients_captioning", "fd_gradients_transformer_ms_hier", "fd_gradients_ms_hier",
+            "fd_gradients_ms_flat", "fd_gradients_dotprod"]
 
 
 @pytest.mark.parametrize("case", FD_CASES)
@@ -470,10 +472,15 @@ def test_oracle_gradients_equal_the_finite_differences_of_the_reference_loss(cas
     h = float(z["fd/h"])
     if cfg["family"] == "rnn":
         make = lambda p, **kw: G.GeneralModel(p, general_config(cfg), **kw)
-        args = (z["in/src_ids"], z["in/tgt_ids"])
+        args = (source_of(z, cfg), z["in/tgt_ids"])
+    elif cfg["family"] == "ms":
+        make = lambda p, **kw: variant_model(cfg, p, **kw)
+        src = (z["in/src_ids"], z["in/maps"]) if cfg["kind"] in ("flat", "hier") else z["in/src_ids"]
+        args = (src, z["in/tgt_ids"])
     else:
         make = lambda p, **kw: T.TransformerModel(p, transformer_config(cfg), **kw)
-        args = (z["in/src_ids"], z["in/tgt_ids"].T)
+        src = [z["in/src_ids"], z["in/src2_ids"]] if cfg.get("second_encoder", False) else z["in/src_ids"]
+        args = (src, z["in/tgt_ids"].T)
     loss, grads = make(params, requires_grad=True).train_grads(*args, train=False)
     close(loss, z["out/train_loss"], "train_loss")
     names, index, value = [str(n) for n in z["fd/names"]], z["fd/index"], z["fd/value"]
