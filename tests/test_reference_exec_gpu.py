@@ -510,3 +510,42 @@ def test_beam_kernels_reproduce_the_reference_search_over_a_table(dev, case, fus
     close(lps.cpu().numpy(), z["out/logprob_sum"], "logprob_sum", 2e-6)
     close(scores.cpu().numpy(), z["out/scores"], "scores", 2e-6)
     close(pen.cpu().numpy()[:12], z["out/length_penalty"], "length penalty table", 1e-7)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# gradients (row a22): the engine's backward pass against central differences of the REFERENCE'S loss
+# --------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["fd_gradients_rnn_gru", "fd_gradients_rnn_nematus_lstm", "fd_gradients_captioning"])
+def test_engine_gradients_against_the_reference_finite_differences(dev, case):
+    """The direct link (tests/test_reference_exec.py has the tight one, through the oracle): one training step of the
+    engine on the fixture's batch; its loss is the reference's (1e-4) and its gradient agrees with the reference's
+    (loss(theta + h e_i) - loss(theta - h e_i)) / 2h at every recorded coordinate of every variable, to what such a
+    difference is worth at h = 5e-3 (curvature and ReLU / maxout kinks: a few 1e-3 absolute)."""
+    from neuralmonkey_amd.dataset import BatchingScheme, Dataset
+    z, cfg, params = load(case)
+    m = build_rnn(dev, cfg)
+    only_reference = load_variables(m["store"], params)
+    for name in only_reference:
+        assert "nematus_gru_cell" in name or "cond_gru_2_cell" in name, name
+    tgt = ids_to_words(z["in/tgt_ids"].T, cfg["tgt_vocab"], strip_end=True)
+    for i, row in enumerate(z["in/tgt_ids"].T):
+        if 2 not in row:                                  # cut at max_output_len: one more word, cut again
+            tgt[i] = tgt[i] + ["w0"]
+    series = {"target": tgt}
+    if cfg["spatial"] is not None:
+        series["maps"] = list(z["in/maps"])
+    else:
+        series["source"] = [[w if w != "<unk>" else "never-seen" for w in s]
+                            for s in ids_to_words(z["in/src_ids"], cfg["src_vocab"])]
+    ds = Dataset("fixture", series, BatchingScheme(batch_size=len(tgt)))
+    res = m["tfm"].execute(ds, m["trainer"].feedables, [m["trainer"]], train=True)[0]
+    close(res.losses["decoder - cost"], z["out/train_loss"], "train_loss", 1e-4)
+    store = m["store"]
+    for name, i, fd in zip([str(n) for n in z["fd/names"]], z["fd/index"], z["fd/value"]):
+        if name not in store.names():
+            assert abs(fd) < 1e-6, name                    # a variable only the reference creates: no gradient
+            continue
+        g = store.g(name).reshape(-1)
+        got = float(g[int(i)])
+        assert abs(got - fd) <= 6e-3 + 2e-2 * abs(fd), "{}[{}]: engine {:.6f} vs finite difference {:.6f}".format(
+            name, i, got, fd)
