@@ -39,10 +39,13 @@ class GreedyRunner(BaseRunner):
             if self.num_sessions == 1:
                 argmaxes = list(results[0]["decoded_symbols"])
             else:
-                steps = min(res["decoded_logprobs"].shape[0] for res in results)
-                summed = [-np.inf for _ in range(steps)]
+                # runners/runner.py:37-49, to the letter: one entry per step of SESSION 0'S loop; every session's
+                # loop stops on its own, so a session that stopped earlier contributes to its own steps only, and one
+                # that ran longer makes the list access fail with the reference's IndexError (pinned by
+                # tests/golden/ref_exec/greedy_runner_ensemble.npz)
+                summed = [-np.inf for _ in range(results[0]["decoded_logprobs"].shape[0])]
                 for sess_result in results:
-                    for i, logprob in enumerate(sess_result["decoded_logprobs"][:steps]):
+                    for i, logprob in enumerate(sess_result["decoded_logprobs"]):
                         summed[i] = np.logaddexp(summed[i], logprob)
                 argmaxes = [np.argmax(l, axis=1) for l in summed]
             decoded_tokens = self.executor.vocabulary.vectors_to_sentences(argmaxes)

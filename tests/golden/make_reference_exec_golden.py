@@ -900,6 +900,42 @@ def run_ensemble(case, family="transformer"):
     save(case, dict(cfg, n_models=n_models, family=family), out)
 
 
+def run_greedy_runner_ensemble(case):
+    """``GreedyRunner.Executable.collect_results`` (runners/runner.py:35-63) over several sessions: the [T,B,V]
+    log-probabilities of the sessions are combined step by step with ``np.logaddexp`` into a list as long as
+    SESSION 0'S loop -- a session that stopped earlier contributes to its own steps only, one that ran longer makes
+    the list assignment fail.  Plain NumPy in the reference: called here on hand-made session results."""
+    from neuralmonkey.runners.runner import GreedyRunner
+    cfg = dict(RNN_DEFAULT)
+    fresh_graph()
+    enc, att, dec, parts = build_rnn(cfg)
+    runner = GreedyRunner(output_series="target", decoder=dec)
+    rng = np.random.default_rng(41)
+    bsz, vsz = 4, cfg["tgt_vocab"] + 4
+
+    def session(steps, xents):
+        lg = rng.normal(0, 2.0, (steps, bsz, vsz)).astype(np.float32)
+        lp = lg - np.log(np.exp(lg - lg.max(-1, keepdims=True)).sum(-1, keepdims=True)) - lg.max(-1, keepdims=True)
+        return {"decoded_logprobs": lp.astype(np.float32), "train_xent": np.float32(xents[0]),
+                "runtime_xent": np.float32(xents[1])}
+    out = {}
+    for tag, lengths in (("equal", (5, 5, 5)), ("shorter", (5, 3, 4)), ("longer", (3, 5, 3))):
+        results = [session(n, (1.25 + i, 2.5 + i)) for i, n in enumerate(lengths)]
+        for i, res in enumerate(results):
+            out["in/{}_logprobs{}".format(tag, i)] = res["decoded_logprobs"]
+            out["in/{}_xents{}".format(tag, i)] = np.asarray([res["train_xent"], res["runtime_xent"]])
+        ex = runner.get_executable(compute_losses=True, summaries=False, num_sessions=len(results))
+        try:
+            ex.collect_results(results)
+            out["out/{}_sentences".format(tag)] = np.asarray([joined(s) for s in ex.result.outputs["target"]])
+            out["out/{}_losses".format(tag)] = np.asarray([ex.result.losses["target/train_xent"],
+                                                           ex.result.losses["target/runtime_xent"]], np.float32)
+            out["out/{}_error".format(tag)] = np.asarray("")
+        except Exception as exc:        # noqa: BLE001 -- whatever it raises is the reference's behaviour
+            out["out/{}_error".format(tag)] = np.asarray("{}: {}".format(type(exc).__name__, exc))
+    save(case, {"kind": "greedy_runner_ensemble", "tgt_vocab": cfg["tgt_vocab"], "batch": bsz}, out)
+
+
 def run_defects(case):
     """Configurations the reference cannot execute at this commit: the exception IS the reference behaviour."""
     import traceback
@@ -1006,6 +1042,7 @@ CASES = collections.OrderedDict([
     ("fd_gradients_transformer_ms_hier", lambda: run_fd_gradients(
         "fd_gradients_transformer_ms_hier", "transformer", second_encoder=True, strategy="hierarchical",
         heads_hier=4, seed=35, per_variable=2)),
+    ("greedy_runner_ensemble", lambda: run_greedy_runner_ensemble("greedy_runner_ensemble")),
     ("ensemble", lambda: run_ensemble("ensemble")),
     ("transformer", lambda: run_transformer("transformer")),
     ("transformer_bias_untied", lambda: run_transformer(

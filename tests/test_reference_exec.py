@@ -63,7 +63,7 @@ def sentence(ids, vocab):
 
 def test_every_generated_case_is_checked_here():
     have = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(FIX, "*.npz")))
-    checked = sorted(["functions", "defects", "ensemble"] + BEAM_BODY_CASES + RNN_CASES + TRANSFORMER_CASES
+    checked = sorted(["functions", "defects", "ensemble", "greedy_runner_ensemble"] + BEAM_BODY_CASES + RNN_CASES + TRANSFORMER_CASES
                      + VARIANT_CASES + FD_CASES)
     assert have == checked
 
@@ -505,3 +505,38 @@ def test_oracle_gradients_equal_the_finite_differences_of_the_reference_loss(cas
             name, i, got, exact)
         sizeable += abs(fd) > 1e-3
     assert sizeable > len(value) // 3, "too few coordinates with a gradient to speak of"
+
+
+def test_greedy_runner_over_several_sessions_equals_the_reference_runner():
+    """The PRODUCT'S ``GreedyRunner.Executable.collect_results`` (host logic, no GPU) on the session results the
+    reference's was given (runners/runner.py:35-63): np.logaddexp over the sessions step by step along session 0's
+    loop; shorter sessions contribute to their own steps, a longer one raises the reference's IndexError."""
+    from neuralmonkey_amd.runners import GreedyRunner
+    from neuralmonkey_amd.vocabulary import Vocabulary
+    z, cfg, _ = load("greedy_runner_ensemble")
+
+    from neuralmonkey_amd.decoders import Decoder
+    from neuralmonkey_amd.runtime import reset_registry
+    reset_registry()
+    dec = Decoder(encoders=[], vocabulary=Vocabulary(words(cfg["tgt_vocab"])[4:]), data_id="target", name="decoder",
+                  max_output_len=5, embedding_size=4, rnn_size=4)       # collect_results only needs its vocabulary
+    runner = GreedyRunner(output_series="target", decoder=dec)
+    for tag in ("equal", "shorter", "longer"):
+        results = []
+        i = 0
+        while "in/{}_logprobs{}".format(tag, i) in z.files:
+            xe = z["in/{}_xents{}".format(tag, i)]
+            results.append({"decoded_logprobs": z["in/{}_logprobs{}".format(tag, i)], "train_xent": xe[0],
+                            "runtime_xent": xe[1]})
+            i += 1
+        ex = runner.get_executable(compute_losses=True, summaries=False, num_sessions=len(results))
+        want_error = str(z["out/{}_error".format(tag)])
+        if want_error:
+            with pytest.raises(IndexError) as info:
+                ex.collect_results(results)
+            assert want_error == "IndexError: {}".format(info.value)
+            continue
+        ex.collect_results(results)
+        assert [" ".join(s) for s in ex.result.outputs["target"]] == [str(s) for s in z["out/{}_sentences".format(tag)]]
+        close(np.asarray([ex.result.losses["target/train_xent"], ex.result.losses["target/runtime_xent"]], np.float32),
+              z["out/{}_losses".format(tag)], "summed losses")
