@@ -88,7 +88,10 @@ class Dataset:
         bounds = scheme.bucket_boundaries
         sizes = scheme.bucket_batch_sizes
         buckets: List[List[int]] = [[] for _ in sizes]
-        keys = [k for k in self._series if k not in scheme.ignore_series]
+        # (``scheme.ignore_series`` is accepted and, as in the reference at this commit, not consulted: dataset.py:521
+        # "TODO: use only specific series to determine the bucket number" -- the longest of ALL series decides;
+        # tests/golden/ref_exec/dataset_batching.npz, scheme "buckets_ignore")
+        keys = list(self._series)
         for i in range(self._length):
             longest = 0
             for k in keys:
@@ -97,9 +100,14 @@ class Dataset:
                 # (input_pipeline.preindex) and feature arrays alike
                 if hasattr(item, "__len__") and not isinstance(item, (str, bytes)):
                     longest = max(longest, len(item))
-            b = 0
-            while b < len(bounds) and longest > bounds[b]:
-                b += 1
+            # dataset.py:524-535: the TIGHTEST boundary that fits (the boundaries need not be sorted); none fits: the
+            # last bucket (the reference's ``buckets[-1]``)
+            b = -1
+            for cand, limit in enumerate(bounds):
+                if longest <= limit and (b == -1 or limit < bounds[b]):
+                    b = cand
+            if b == -1:
+                b = len(buckets) - 1
             buckets[b].append(i)
             if len(buckets[b]) == sizes[b]:
                 yield self._rows(buckets[b])

@@ -936,6 +936,40 @@ def run_greedy_runner_ensemble(case):
     save(case, {"kind": "greedy_runner_ensemble", "tgt_vocab": cfg["tgt_vocab"], "batch": bsz}, out)
 
 
+def run_dataset_batching(case):
+    """``Dataset.batches`` (dataset.py:467-579): fixed-size batches and length buckets (a row goes to the TIGHTEST
+    bucket that fits the longest of its series, to the last one when none does), with and without the remainder.
+    No TensorFlow involved: the reference's own host code on seeded sentences."""
+    from neuralmonkey.dataset import BatchingScheme, Dataset
+    rng = np.random.default_rng(43)
+    rows = 41
+    src = [["s{}".format(i)] + ["x"] * int(rng.integers(0, 11)) for i in range(rows)]
+    tgt = [["t{}".format(i)] + ["y"] * int(rng.integers(0, 9)) for i in range(rows)]
+    schemes = {
+        "fixed": dict(batch_size=7),
+        "fixed_drop": dict(batch_size=7, drop_remainder=True),
+        "buckets": dict(bucket_boundaries=[3, 6, 9], bucket_batch_sizes=[4, 3, 2, 5]),
+        "buckets_drop": dict(bucket_boundaries=[3, 6, 9], bucket_batch_sizes=[4, 3, 2, 5], drop_remainder=True),
+        "buckets_unsorted": dict(bucket_boundaries=[6, 3, 9], bucket_batch_sizes=[3, 4, 2, 5]),
+        # ``ignore_series`` is stored and never read at this commit (dataset.py:521 "TODO: use only specific series"):
+        # the longest of ALL series decides
+        "buckets_ignore": dict(bucket_boundaries=[3, 6, 9], bucket_batch_sizes=[4, 3, 2, 5], ignore_series=["target"]),
+    }
+    out = {"in/source_lengths": np.asarray([len(s) for s in src]), "in/target_lengths": np.asarray([len(t) for t in tgt])}
+    for tag, kw in schemes.items():
+        ds = Dataset("data", {"source": lambda: iter(src), "target": lambda: iter(tgt)}, BatchingScheme(**kw))
+        batches = []
+        for b in ds.batches():
+            ids = [int(row[0][1:]) for row in b.get_series("source")]
+            assert ids == [int(row[0][1:]) for row in b.get_series("target")]
+            batches.append(ids)
+        out["out/{}_batch_of_row".format(tag)] = np.asarray(
+            [next((j for j, ids in enumerate(batches) if i in ids), -1) for i in range(rows)])
+        out["out/{}_order".format(tag)] = np.asarray([i for ids in batches for i in ids])
+        out["out/{}_sizes".format(tag)] = np.asarray([len(ids) for ids in batches])
+    save(case, {"kind": "dataset_batching", "rows": rows, "schemes": schemes}, out)
+
+
 def run_defects(case):
     """Configurations the reference cannot execute at this commit: the exception IS the reference behaviour."""
     import traceback
@@ -1042,6 +1076,7 @@ CASES = collections.OrderedDict([
     ("fd_gradients_transformer_ms_hier", lambda: run_fd_gradients(
         "fd_gradients_transformer_ms_hier", "transformer", second_encoder=True, strategy="hierarchical",
         heads_hier=4, seed=35, per_variable=2)),
+    ("dataset_batching", lambda: run_dataset_batching("dataset_batching")),
     ("greedy_runner_ensemble", lambda: run_greedy_runner_ensemble("greedy_runner_ensemble")),
     ("ensemble", lambda: run_ensemble("ensemble")),
     ("transformer", lambda: run_transformer("transformer")),

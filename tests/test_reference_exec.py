@@ -63,7 +63,7 @@ def sentence(ids, vocab):
 
 def test_every_generated_case_is_checked_here():
     have = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(FIX, "*.npz")))
-    checked = sorted(["functions", "defects", "ensemble", "greedy_runner_ensemble"] + BEAM_BODY_CASES + RNN_CASES + TRANSFORMER_CASES
+    checked = sorted(["functions", "defects", "ensemble", "greedy_runner_ensemble", "dataset_batching"] + BEAM_BODY_CASES + RNN_CASES + TRANSFORMER_CASES
                      + VARIANT_CASES + FD_CASES)
     assert have == checked
 
@@ -540,3 +540,18 @@ def test_greedy_runner_over_several_sessions_equals_the_reference_runner():
         assert [" ".join(s) for s in ex.result.outputs["target"]] == [str(s) for s in z["out/{}_sentences".format(tag)]]
         close(np.asarray([ex.result.losses["target/train_xent"], ex.result.losses["target/runtime_xent"]], np.float32),
               z["out/{}_losses".format(tag)], "summed losses")
+
+
+def test_dataset_batches_equal_the_reference_batches():
+    """The PRODUCT'S ``Dataset.batches`` (host code) against the reference's (dataset.py:467-579) on the same seeded
+    sentences: fixed-size batches, length buckets (tightest fitting boundary, also when the boundaries are not
+    sorted; the last bucket when none fits), with and without the remainder -- same batches, same order."""
+    from neuralmonkey_amd.dataset import BatchingScheme, Dataset
+    z, cfg, _ = load("dataset_batching")
+    src = [["s{}".format(i)] + ["x"] * (int(n) - 1) for i, n in enumerate(z["in/source_lengths"])]
+    tgt = [["t{}".format(i)] + ["y"] * (int(n) - 1) for i, n in enumerate(z["in/target_lengths"])]
+    for tag, kw in cfg["schemes"].items():
+        ds = Dataset("data", {"source": src, "target": tgt}, BatchingScheme(**kw))
+        batches = [[int(row[0][1:]) for row in b.get_series("source")] for b in ds.batches()]
+        same(np.asarray([len(ids) for ids in batches]), z["out/{}_sizes".format(tag)], tag + ": batch sizes")
+        same(np.asarray([i for ids in batches for i in ids]), z["out/{}_order".format(tag)], tag + ": row order")
