@@ -970,6 +970,53 @@ def run_dataset_batching(case):
     save(case, {"kind": "dataset_batching", "rows": rows, "schemes": schemes}, out)
 
 
+VOCAB_FILES = {
+    # wordlist with header and frequencies (vocabulary.py:32-99), the format save_wordlist writes
+    "wordlist_header": "word\tcount\nthe\t120\ncat\t7\nsat\t3\n\u010de\u0161tina\t1\n",
+    # bare wordlist: no header, no second column
+    "wordlist_plain": "alpha\nbeta\ngamma\n",
+    # tensor2tensor vocabulary (vocabulary.py:102-134): quoted tokens, <pad> and <EOS> first
+    "t2t": "'<pad>'\n'<EOS>'\n'hello_'\n'wor'\n'ld_'\n'\\u;_'\n",
+    # Nematus JSON (vocabulary.py:137-187): word -> index, eos / UNK at 0 / 1
+    "nematus": '{"eos": 0, "UNK": 1, "der": 2, "die": 3, "das": 4, "und": 5, "ist": 6}',
+}
+
+
+def run_vocabulary_formats(case):
+    """The vocabulary loaders and ``vectors_to_sentences`` of the reference (vocabulary.py, no TensorFlow involved) on
+    small files whose text is kept in the fixture: the product's loaders are run on the same text by the CPU test."""
+    import tempfile
+    from neuralmonkey import vocabulary as V
+    out = {}
+    loaded = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        paths = {}
+        for name, text in VOCAB_FILES.items():
+            paths[name] = os.path.join(tmp, name)
+            with open(paths[name], "w", encoding="utf-8") as handle:
+                handle.write(text)
+        loaded["wordlist_header"] = V.from_wordlist(paths["wordlist_header"])
+        loaded["wordlist_plain"] = V.from_wordlist(paths["wordlist_plain"], contains_header=False,
+                                                   contains_frequencies=False)
+        loaded["t2t"] = V.from_t2t_vocabulary(paths["t2t"])
+        loaded["nematus"] = V.from_nematus_json(paths["nematus"])
+        loaded["nematus_max5"] = V.from_nematus_json(paths["nematus"], max_size=5)
+        loaded["nematus_pad9"] = V.from_nematus_json(paths["nematus"], max_size=9, pad_to_max_size=True)
+    for name, vocab in loaded.items():
+        out["out/{}_words".format(name)] = np.asarray(list(vocab.index_to_word))
+    # vectors_to_sentences (:257-288): time-major ids, every sentence cut at its first </s>, <pad> kept as a word
+    vocab = loaded["wordlist_header"]
+    rng = np.random.default_rng(47)
+    ids = rng.integers(0, len(vocab), (6, 5))
+    ids[2, 1] = 2                # </s> in the middle
+    ids[0, 3] = 2                # </s> first: an empty sentence
+    ids[:, 4] = [4, 0, 5, 0, 2, 6]
+    out["in/time_major_ids"] = ids
+    out["out/sentences_array"] = np.asarray([" ".join(s) for s in vocab.vectors_to_sentences(ids)])
+    out["out/sentences_list"] = np.asarray([" ".join(s) for s in vocab.vectors_to_sentences([row for row in ids])])
+    save(case, {"kind": "vocabulary_formats", "files": VOCAB_FILES}, out)
+
+
 def run_defects(case):
     """Configurations the reference cannot execute at this commit: the exception IS the reference behaviour."""
     import traceback
@@ -1076,6 +1123,7 @@ CASES = collections.OrderedDict([
     ("fd_gradients_transformer_ms_hier", lambda: run_fd_gradients(
         "fd_gradients_transformer_ms_hier", "transformer", second_encoder=True, strategy="hierarchical",
         heads_hier=4, seed=35, per_variable=2)),
+    ("vocabulary_formats", lambda: run_vocabulary_formats("vocabulary_formats")),
     ("dataset_batching", lambda: run_dataset_batching("dataset_batching")),
     ("greedy_runner_ensemble", lambda: run_greedy_runner_ensemble("greedy_runner_ensemble")),
     ("ensemble", lambda: run_ensemble("ensemble")),

@@ -63,7 +63,8 @@ def sentence(ids, vocab):
 
 def test_every_generated_case_is_checked_here():
     have = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(FIX, "*.npz")))
-    checked = sorted(["functions", "defects", "ensemble", "greedy_runner_ensemble", "dataset_batching"] + BEAM_BODY_CASES + RNN_CASES + TRANSFORMER_CASES
+    checked = sorted(["functions", "defects", "ensemble", "greedy_runner_ensemble", "dataset_batching",
+                      "vocabulary_formats"] + BEAM_BODY_CASES + RNN_CASES + TRANSFORMER_CASES
                      + VARIANT_CASES + FD_CASES)
     assert have == checked
 
@@ -555,3 +556,30 @@ def test_dataset_batches_equal_the_reference_batches():
         batches = [[int(row[0][1:]) for row in b.get_series("source")] for b in ds.batches()]
         same(np.asarray([len(ids) for ids in batches]), z["out/{}_sizes".format(tag)], tag + ": batch sizes")
         same(np.asarray([i for ids in batches for i in ids]), z["out/{}_order".format(tag)], tag + ": row order")
+
+
+def test_vocabulary_loaders_equal_the_reference_loaders(tmp_path):
+    """The PRODUCT'S vocabulary loaders and ``vectors_to_sentences`` against the reference's (vocabulary.py:32-187,
+    257-288, no TensorFlow involved) on the files whose text the fixture carries."""
+    from neuralmonkey_amd import vocabulary as V
+    z, cfg, _ = load("vocabulary_formats")
+    paths = {}
+    for name, text in cfg["files"].items():
+        paths[name] = str(tmp_path / name)
+        with open(paths[name], "w", encoding="utf-8") as handle:
+            handle.write(text)
+    loaded = {
+        "wordlist_header": V.from_wordlist(paths["wordlist_header"]),
+        "wordlist_plain": V.from_wordlist(paths["wordlist_plain"], contains_header=False, contains_frequencies=False),
+        "t2t": V.from_t2t_vocabulary(paths["t2t"]),
+        "nematus": V.from_nematus_json(paths["nematus"]),
+        "nematus_max5": V.from_nematus_json(paths["nematus"], max_size=5),
+        "nematus_pad9": V.from_nematus_json(paths["nematus"], max_size=9, pad_to_max_size=True),
+    }
+    for name, vocab in loaded.items():
+        assert list(vocab.index_to_word) == [str(w) for w in z["out/{}_words".format(name)]], name
+    vocab = loaded["wordlist_header"]
+    ids = z["in/time_major_ids"]
+    assert [" ".join(s) for s in vocab.vectors_to_sentences(ids)] == [str(s) for s in z["out/sentences_array"]]
+    assert [" ".join(s) for s in vocab.vectors_to_sentences([row for row in ids])] == \
+        [str(s) for s in z["out/sentences_list"]]
