@@ -1017,6 +1017,58 @@ def run_vocabulary_formats(case):
     save(case, {"kind": "vocabulary_formats", "files": VOCAB_FILES}, out)
 
 
+TEXT_FILES = {
+    "plain.txt": "the  cat sat\n\n  leading and trailing  \nÜnïcödé wörds ok\n",
+    "t2t.txt": "Hello, world! It's 3.5 (approx.)\nDon't  stop\u2014now\n",
+    "table.tsv": "a b\tfirst col\t1\nc d e\tsecond \"quoted\" col\t2\n",
+    "table.csv": "a b,\"x, y\",1\nc,\"he said \"\"hi\"\"\",2\n",
+    "vectors.txt": "1 2.5 -3\n0.125 4e2 5\n",
+}
+
+
+def run_host_text_pipeline(case):
+    """Readers and string processors of the reference, none of which touches TensorFlow: plain_text_reader.py:23-134
+    (whitespace tokens, the tensor2tensor tokenizer, column readers), string_vector_reader.py:6-40,
+    processors/helpers.py:5-52, processors/wordpiece.py:22-130 -- on files whose text the fixture carries."""
+    import tempfile
+    from neuralmonkey.readers import plain_text_reader as R
+    from neuralmonkey.readers.string_vector_reader import get_string_vector_reader
+    from neuralmonkey.processors import helpers as H
+    from neuralmonkey.processors import wordpiece as W
+    from neuralmonkey.vocabulary import Vocabulary
+    out = {}
+    join = lambda rows: np.asarray(["\x1f".join(r) for r in rows])          # unit separator: tokens may hold spaces
+    with tempfile.TemporaryDirectory() as tmp:
+        paths = {}
+        for name, text in TEXT_FILES.items():
+            paths[name] = os.path.join(tmp, name)
+            with open(paths[name], "w", encoding="utf-8") as handle:
+                handle.write(text)
+        out["out/string_reader"] = np.asarray(list(R.string_reader()([paths["plain.txt"]])))
+        out["out/tokenized"] = join(R.tokenized_text_reader()([paths["plain.txt"], paths["t2t.txt"]]))
+        out["out/t2t_tokenized"] = join(R.t2t_tokenized_text_reader()([paths["t2t.txt"]]))
+        out["out/tsv_col1"] = join(R.tsv_reader(1)([paths["table.tsv"]]))
+        out["out/tsv_col2"] = join(R.tsv_reader(2)([paths["table.tsv"]]))
+        out["out/csv_col2"] = join(R.csv_reader(2)([paths["table.csv"]]))
+        out["out/vectors"] = np.stack(list(get_string_vector_reader()([paths["vectors.txt"]])))
+    sents = [["the", "cat"], ["Ünï", "x"], [], ["a"]]
+    out["out/char_based"] = join([H.preprocess_char_based(s) for s in sents])
+    out["out/char_based_back"] = join(H.postprocess_char_based([H.preprocess_char_based(s) for s in sents]))
+    out["out/untruecase"] = join(list(H.untruecase([["hello", "World"], ["x"], []])))
+    out["out/pipeline"] = join([H.pipeline([H.preprocess_char_based, lambda s: s[::-1]])(["ab", "c"])])
+    # wordpieces over a vocabulary of pieces (the tensor2tensor scheme: underscore ends a word, escapes)
+    pieces = ["the_", "c", "a", "t", "t_", "at_", "s", "sa", "_", "\\", "u", "9", "5", ";", "x", "1", "2", "3", "4",
+              "6", "7", "8", "0"]
+    vocab = Vocabulary(pieces)
+    enc = [W.wordpiece_encode(s, vocab) for s in (["the", "cat"], ["sat", "cat"], ["ta_t"], ["\u00e9x"])]
+    out["in/wordpiece_vocab"] = np.asarray(pieces)
+    out["out/wordpiece_encoded"] = join(enc)
+    out["out/wordpiece_decoded"] = join([W.wordpiece_decode(e) for e in enc])
+    out["out/escape"] = np.asarray([W.escape_token(t, set("abc_\\;0123456789u")) for t in ("abc", "a_b", "a\\b", "\u00e9")])
+    out["out/unescape"] = np.asarray([W.unescape_token(t) for t in ("abc_", "a\\ub_", "a\\\\b_", "\\233;_", "\\x;_")])
+    save(case, {"kind": "host_text_pipeline", "files": TEXT_FILES}, out)
+
+
 def run_defects(case):
     """Configurations the reference cannot execute at this commit: the exception IS the reference behaviour."""
     import traceback
@@ -1124,6 +1176,7 @@ CASES = collections.OrderedDict([
         "fd_gradients_transformer_ms_hier", "transformer", second_encoder=True, strategy="hierarchical",
         heads_hier=4, seed=35, per_variable=2)),
     ("vocabulary_formats", lambda: run_vocabulary_formats("vocabulary_formats")),
+    ("host_text_pipeline", lambda: run_host_text_pipeline("host_text_pipeline")),
     ("dataset_batching", lambda: run_dataset_batching("dataset_batching")),
     ("greedy_runner_ensemble", lambda: run_greedy_runner_ensemble("greedy_runner_ensemble")),
     ("ensemble", lambda: run_ensemble("ensemble")),

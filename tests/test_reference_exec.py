@@ -64,7 +64,7 @@ def sentence(ids, vocab):
 def test_every_generated_case_is_checked_here():
     have = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(FIX, "*.npz")))
     checked = sorted(["functions", "defects", "ensemble", "greedy_runner_ensemble", "dataset_batching",
-                      "vocabulary_formats"] + BEAM_BODY_CASES + RNN_CASES + TRANSFORMER_CASES
+                      "vocabulary_formats", "host_text_pipeline"] + BEAM_BODY_CASES + RNN_CASES + TRANSFORMER_CASES
                      + VARIANT_CASES + FD_CASES)
     assert have == checked
 
@@ -583,3 +583,41 @@ def test_vocabulary_loaders_equal_the_reference_loaders(tmp_path):
     assert [" ".join(s) for s in vocab.vectors_to_sentences(ids)] == [str(s) for s in z["out/sentences_array"]]
     assert [" ".join(s) for s in vocab.vectors_to_sentences([row for row in ids])] == \
         [str(s) for s in z["out/sentences_list"]]
+
+
+def test_readers_and_string_processors_equal_the_reference(tmp_path):
+    """The PRODUCT'S readers (plain / tensor2tensor-tokenized / column / string-vector) and string processors
+    (character-level helpers, untruecase, pipeline, wordpieces) against the reference's own functions
+    (readers/plain_text_reader.py:23-134, readers/string_vector_reader.py:6-40, processors/helpers.py:5-52,
+    processors/wordpiece.py:22-130 -- no TensorFlow involved) on the text the fixture carries."""
+    from neuralmonkey_amd.processors import helpers as H
+    from neuralmonkey_amd.processors import wordpiece as W
+    from neuralmonkey_amd.readers import plain_text_reader as R
+    from neuralmonkey_amd.readers.string_vector_reader import get_string_vector_reader
+    from neuralmonkey_amd.vocabulary import Vocabulary
+    z, cfg, _ = load("host_text_pipeline")
+    paths = {}
+    for name, text in cfg["files"].items():
+        paths[name] = str(tmp_path / name)
+        with open(paths[name], "w", encoding="utf-8") as handle:
+            handle.write(text)
+    join = lambda rows: ["\x1f".join(r) for r in rows]
+    want = lambda key: [str(x) for x in z["out/" + key]]
+    assert list(R.string_reader()([paths["plain.txt"]])) == want("string_reader")
+    assert join(R.tokenized_text_reader()([paths["plain.txt"], paths["t2t.txt"]])) == want("tokenized")
+    assert join(R.t2t_tokenized_text_reader()([paths["t2t.txt"]])) == want("t2t_tokenized")
+    assert join(R.tsv_reader(1)([paths["table.tsv"]])) == want("tsv_col1")
+    assert join(R.tsv_reader(2)([paths["table.tsv"]])) == want("tsv_col2")
+    assert join(R.csv_reader(2)([paths["table.csv"]])) == want("csv_col2")
+    same(np.stack(list(get_string_vector_reader()([paths["vectors.txt"]]))), z["out/vectors"], "string vectors")
+    sents = [["the", "cat"], ["Ünï", "x"], [], ["a"]]
+    assert join([H.preprocess_char_based(s) for s in sents]) == want("char_based")
+    assert join(H.postprocess_char_based([H.preprocess_char_based(s) for s in sents])) == want("char_based_back")
+    assert join(list(H.untruecase([["hello", "World"], ["x"], []]))) == want("untruecase")
+    assert join([H.pipeline([H.preprocess_char_based, lambda s: s[::-1]])(["ab", "c"])]) == want("pipeline")
+    vocab = Vocabulary([str(p) for p in z["in/wordpiece_vocab"]])
+    enc = [W.wordpiece_encode(s, vocab) for s in (["the", "cat"], ["sat", "cat"], ["ta_t"], ["\u00e9x"])]
+    assert join(enc) == want("wordpiece_encoded")
+    assert join([W.wordpiece_decode(e) for e in enc]) == want("wordpiece_decoded")
+    assert [W.escape_token(t, set("abc_\\;0123456789u")) for t in ("abc", "a_b", "a\\b", "\u00e9")] == want("escape")
+    assert [W.unescape_token(t) for t in ("abc_", "a\\ub_", "a\\\\b_", "\\233;_", "\\x;_")] == want("unescape")
