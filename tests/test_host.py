@@ -371,3 +371,31 @@ def test_side_lanes_degrade_to_stream_order_without_a_gpu():
     sess.join_side()
     assert order == ["leaf", "main", "deferred a", "deferred b"]
     assert not sess._deferred_side and not sess._side_dirty
+
+
+@pytest.mark.parametrize("finish_at", [1, 3, 8, 11, 16, None])
+@pytest.mark.parametrize("run_ahead", [False, True])
+def test_decode_chunks_stops_where_the_reference_loop_stops(finish_at, run_ahead):
+    """``Session.decode_chunks`` is the host side of tf.while_loop around a decoding body
+    (decoders/autoregressive.py:425-437): the criterion lives in the flags the steps leave behind; the host only
+    decides when to stop enqueueing.  Whatever the chunking and whether or not it reads the flags one chunk behind,
+    the number of steps of the reference's loop it reports is the index of the first all-finished step + 1 (or the
+    maximum), and it never enqueues more than one chunk past that."""
+    import torch
+    from neuralmonkey_amd.runtime import Session
+    sess = Session("cpu", seed=1)
+    total, every = 16, 4
+    allfin = torch.zeros(total, dtype=torch.int32)
+    launched = []
+
+    def launch(t0, n):
+        launched.append((t0, n))
+        for t in range(t0, t0 + n):                       # step t leaves allfin[t] != 0 once every row has finished
+            allfin[t] = 1 if finish_at is not None and t + 1 >= finish_at else 0
+    steps, enqueued = sess.decode_chunks(total, every, launch, allfin, run_ahead=run_ahead)
+    want = total if finish_at is None else finish_at
+    assert steps == want
+    assert enqueued == sum(n for _, n in launched) and enqueued >= steps
+    chunks_needed = -(-want // every)
+    assert len(launched) <= min(total // every, chunks_needed + (1 if run_ahead else 0))
+    assert [t0 for t0, _ in launched] == list(range(0, enqueued, every))
