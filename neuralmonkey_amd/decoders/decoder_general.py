@@ -15,6 +15,7 @@ configurations, so nothing is hoisted out of the time loop except the embedding 
 vocabulary projection + cross entropy.
 """
 import os
+import weakref
 from typing import List, Optional
 
 import torch
@@ -380,8 +381,10 @@ def input_table(dec, ctx) -> Optional[torch.Tensor]:
     parts = [emb, wg[:e], wc[:e], bc, wo[h:h + e]]
     if not all(p.is_contiguous() for p in parts):
         return None
-    cache = ctx.session.__dict__.setdefault("_input_tables", {})
-    entry = cache.get(id(dec))
+    # keyed by the decoder OBJECT (weakly): an entry dies with its model part, and a new part that happens to get
+    # the address of a collected one can never hit its table
+    cache = ctx.session.__dict__.setdefault("_input_tables", weakref.WeakKeyDictionary())
+    entry = cache.get(dec)
     print_ = ctx.session.variables_signature() + tuple(p.data_ptr() for p in parts)
     if entry is not None and entry[0] == print_:
         return entry[1]
@@ -391,7 +394,7 @@ def input_table(dec, ctx) -> Optional[torch.Tensor]:
     ops.gemm(emb, wg[:e], out=table[:, :2 * h])
     ops.gemm(emb, wc[:e], out=table[:, 2 * h:3 * h], bias=bc)
     ops.gemm(emb, wo[h:h + e], out=table[:, 3 * h:])
-    cache[id(dec)] = (print_, table)
+    cache[dec] = (print_, table)
     return table
 
 
@@ -576,8 +579,8 @@ def make_stepper(dec, ctx, rows: int, tag: str):
                      att.hidden_features(ctx).data_ptr(), att.attention_states(ctx).data_ptr(),
                      ptr(att.attention_mask(ctx)), ptr(dec.decoding_bias(ctx)), ptr(dec.embedding_matrix(ctx)),
                      os.environ.get("NM_STEP_GROUPS"), os.environ.get("NM_STEP_TABLES"), os.environ.get("NM_STEP_PAD"))
-            cache = ctx.session.__dict__.setdefault("_fused_steppers", {})
-            ckey = (id(dec), tag, rows, ctx.session.slot)
+            cache = ctx.session.__dict__.setdefault("_fused_steppers", weakref.WeakKeyDictionary()).setdefault(dec, {})
+            ckey = (tag, rows, ctx.session.slot)
             hit = cache.get(ckey)
             if hit is not None and hit[0] == ident:
                 stepper = hit[1]

@@ -727,4 +727,9 @@ class Session:
         with torch.no_grad():
             out = self._eval(fetches, ctx)
         self.kick_ahead()
+        # cached steppers (decoders/decoder_general.py) are re-used by the next batch with ITS context: between
+        # runs they must not keep this run's memo -- every tensor evaluated for this batch -- alive
+        for per_decoder in self.__dict__.get("_fused_steppers", {}).values():
+            for _, stepper in per_decoder.values():
+                stepper.ctx = None
         return _to_host(out)

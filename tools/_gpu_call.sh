@@ -1,3 +1,2 @@
 export TMPDIR=/tmp
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-timeout 150 python -m pytest tests/test_kernels_gpu.py tests/test_sampling_gpu.py tests/test_background_gpu.py -x -q -m gpu 2>&1 | grep -E "passed|failed" | tail -2
+timeout 100 python -m pytest tests/test_engine_gpu.py tests/test_general_decode_graphs_gpu.py tests/test_runners_gpu.py -x -q -m gpu 2>&1 | grep -E "passed|failed|Error" | tail -3
