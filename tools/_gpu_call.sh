@@ -1,2 +1,5 @@
 export TMPDIR=/tmp
-timeout 100 python -m pytest tests/test_engine_gpu.py tests/test_general_decode_graphs_gpu.py tests/test_runners_gpu.py -x -q -m gpu 2>&1 | grep -E "passed|failed|Error" | tail -3
+python bench.py --steps 10 --no-configs --no-cpu-baseline --no-feed-legs 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print({k:round(d[k],2) for k in ['ms_per_step','beam5_ms_per_batch','greedy_ms_per_batch','beam5_batch1_ms_per_sentence']})"
