@@ -1069,6 +1069,35 @@ def run_host_text_pipeline(case):
     save(case, {"kind": "host_text_pipeline", "files": TEXT_FILES}, out)
 
 
+def run_schedules(case):
+    """functions.py:9-80 (the schedules INI files name for learning rates and sampling probabilities), evaluated by the
+    reference against the graph's global step."""
+    from neuralmonkey import functions as F
+    fresh_graph()
+    gs = tf.train.get_or_create_global_step()
+    steps = [0, 1, 2, 5, 99, 100, 101, 3999, 4000, 4001, 5000, 10000, 100000]
+    rows = {"noam_512_4000": [], "noam_64_10": [], "inverse_sigmoid_300": [], "inverse_sigmoid_2_scaled": [],
+            "piecewise": []}
+    for step in steps:
+        gs.assign(step)
+        x = tf.to_float(gs)
+        rows["noam_512_4000"].append(F.noam_decay(0.2, 512, 4000).numpy())
+        rows["noam_64_10"].append(F.noam_decay(1.0, 64, 10).numpy())
+        rows["inverse_sigmoid_300"].append(F.inverse_sigmoid_decay(x, 300.0).numpy())
+        rows["inverse_sigmoid_2_scaled"].append(F.inverse_sigmoid_decay(x / 1000.0, 2.0, 0.1, 0.9).numpy())
+        rows["piecewise"].append(F.piecewise_function(x, [1.0, 0.5, 0.1], [100, 5000]).numpy())
+    out = {"in/steps": np.asarray(steps, np.int64)}
+    for name, vals in rows.items():
+        out["out/" + name] = np.asarray(vals, np.float32)
+    try:
+        F.piecewise_function(tf.to_float(gs), [1.0, 0.5], [1, 2])
+        out["out/piecewise_error"] = np.asarray("")
+    except ValueError as exc:
+        out["out/piecewise_error"] = np.asarray(str(exc))
+    fresh_graph()
+    save(case, {"kind": "schedules"}, out)
+
+
 def run_defects(case):
     """Configurations the reference cannot execute at this commit: the exception IS the reference behaviour."""
     import traceback
@@ -1177,6 +1206,7 @@ CASES = collections.OrderedDict([
         heads_hier=4, seed=35, per_variable=2)),
     ("vocabulary_formats", lambda: run_vocabulary_formats("vocabulary_formats")),
     ("host_text_pipeline", lambda: run_host_text_pipeline("host_text_pipeline")),
+    ("schedules", lambda: run_schedules("schedules")),
     ("dataset_batching", lambda: run_dataset_batching("dataset_batching")),
     ("greedy_runner_ensemble", lambda: run_greedy_runner_ensemble("greedy_runner_ensemble")),
     ("ensemble", lambda: run_ensemble("ensemble")),

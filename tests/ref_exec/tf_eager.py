@@ -1291,6 +1291,29 @@ def cond(pred, true_fn=None, false_fn=None, name=None, strict=False):
     return true_fn() if _pred(pred) else false_fn()
 
 
+def case(pred_fn_pairs, default=None, exclusive=False, strict=False, name="case"):      # noqa: A002
+    """tf.case: the function of the FIRST predicate that holds (a list keeps its order), else ``default``."""
+    pairs = list(pred_fn_pairs.items()) if isinstance(pred_fn_pairs, dict) else list(pred_fn_pairs)
+    hits = [fn for pred, fn in pairs if _pred(pred)]
+    if exclusive and len(hits) > 1:
+        raise ValueError("tf.case(exclusive=True): more than one predicate holds")
+    if hits:
+        return hits[0]()
+    if default is None:
+        raise ValueError("tf.case: no predicate holds and there is no default")
+    return default()
+
+
+def _global_step():
+    """tf.train.get_or_create_global_step: the graph's ``global_step`` variable (a collection entry in TF, outside
+    every variable scope), made on first use and handed back ever after."""
+    existing = _STORE.vars.get("global_step")
+    if existing is None:
+        existing = Variable(np.zeros([], np.int64), "global_step", trainable=False)
+        _STORE.vars["global_step"] = existing
+    return existing
+
+
 def while_loop(cond, body, loop_vars, shape_invariants=None, parallel_iterations=10, back_prop=True,      # noqa: A002
                swap_memory=False, name=None, maximum_iterations=None, return_same_structure=False):
     """Python loop: ``cond`` is evaluated BEFORE each iteration on the loop variables the previous iteration
@@ -1941,8 +1964,7 @@ def build_modules():
                       histogram=lambda *a, **k: None, merge=lambda *a, **k: None,
                       FileWriter=lambda *a, **k: None)
     train = _module("tensorflow.train", Saver=_Saver, Optimizer=_Optimizer, AdamOptimizer=_Optimizer,
-                    get_or_create_global_step=lambda: get_variable("global_step", [], dtype=int64,
-                                                                   initializer=zeros_initializer(), trainable=False))
+                    get_or_create_global_step=_global_step)
 
     contrib = _module("tensorflow.contrib")
     contrib.rnn = _module("tensorflow.contrib.rnn", RNNCell=RNNCell, GRUCell=GRUCell, LSTMCell=LSTMCell,

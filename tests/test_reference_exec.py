@@ -64,7 +64,7 @@ def sentence(ids, vocab):
 def test_every_generated_case_is_checked_here():
     have = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(FIX, "*.npz")))
     checked = sorted(["functions", "defects", "ensemble", "greedy_runner_ensemble", "dataset_batching",
-                      "vocabulary_formats", "host_text_pipeline"] + BEAM_BODY_CASES + RNN_CASES + TRANSFORMER_CASES
+                      "vocabulary_formats", "host_text_pipeline", "schedules"] + BEAM_BODY_CASES + RNN_CASES + TRANSFORMER_CASES
                      + VARIANT_CASES + FD_CASES)
     assert have == checked
 
@@ -621,3 +621,26 @@ def test_readers_and_string_processors_equal_the_reference(tmp_path):
     assert join([W.wordpiece_decode(e) for e in enc]) == want("wordpiece_decoded")
     assert [W.escape_token(t, set("abc_\\;0123456789u")) for t in ("abc", "a_b", "a\\b", "\u00e9")] == want("escape")
     assert [W.unescape_token(t) for t in ("abc_", "a\\ub_", "a\\\\b_", "\\233;_", "\\x;_")] == want("unescape")
+
+
+def test_schedules_equal_the_reference_functions():
+    """functions.py:9-80 -- noam_decay, inverse_sigmoid_decay, piecewise_function -- evaluated by the reference against
+    its global step; the PRODUCT'S schedules are callables of the step (what the optimizer reads when it applies an
+    update) and must give the same float32 values, the same ValueError text for mismatched change points."""
+    from neuralmonkey_amd import functions as F
+    z, _, _ = load("schedules")
+    steps = [int(v) for v in z["in/steps"]]
+    ident = lambda step: float(step)
+    got = {
+        "noam_512_4000": [F.noam_decay(0.2, 512, 4000)(t) for t in steps],
+        "noam_64_10": [F.noam_decay(1.0, 64, 10)(t) for t in steps],
+        "inverse_sigmoid_300": [F.inverse_sigmoid_decay(ident, 300.0)(t) for t in steps],
+        "inverse_sigmoid_2_scaled": [F.inverse_sigmoid_decay(lambda t: t / 1000.0, 2.0, 0.1, 0.9)(t) for t in steps],
+        "piecewise": [F.piecewise_function(ident, [1.0, 0.5, 0.1], [100, 5000])(t) for t in steps],
+    }
+    for name, vals in got.items():
+        want = z["out/" + name].astype(np.float64)
+        assert np.allclose(np.asarray(vals, np.float64), want, rtol=2e-6, atol=1e-12), name
+    with pytest.raises(ValueError) as info:
+        F.piecewise_function(ident, [1.0, 0.5], [1, 2])
+    assert str(info.value) == str(z["out/piecewise_error"])
