@@ -90,7 +90,7 @@ class Dataset:
         buckets: List[List[int]] = [[] for _ in sizes]
         # (``scheme.ignore_series`` is accepted and, as in the reference at this commit, not consulted: dataset.py:521
         # "TODO: use only specific series to determine the bucket number" -- the longest of ALL series decides;
-        # tests/golden/ref_exec/dataset_batching.npz, scheme "buckets_ignore")
+        # the reference-executed fixture "dataset_batching" under tests/golden, scheme "buckets_ignore")
         keys = list(self._series)
         for i in range(self._length):
             longest = 0

@@ -42,7 +42,7 @@ class GreedyRunner(BaseRunner):
                 # runners/runner.py:37-49, to the letter: one entry per step of SESSION 0'S loop; every session's
                 # loop stops on its own, so a session that stopped earlier contributes to its own steps only, and one
                 # that ran longer makes the list access fail with the reference's IndexError (pinned by
-                # tests/golden/ref_exec/greedy_runner_ensemble.npz)
+                # the reference-executed fixture "greedy_runner_ensemble" under tests/golden)
                 summed = [-np.inf for _ in range(results[0]["decoded_logprobs"].shape[0])]
                 for sess_result in results:
                     for i, logprob in enumerate(sess_result["decoded_logprobs"]):

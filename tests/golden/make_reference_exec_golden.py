@@ -1098,6 +1098,62 @@ def run_schedules(case):
     save(case, {"kind": "schedules"}, out)
 
 
+def canonical_ini_value(value):
+    """A parsed INI value as JSON-able structure: class symbols and object references by what they name."""
+    kind = type(value).__name__
+    if kind == "ClassSymbol":
+        return {"class": value.clazz}
+    if kind == "ObjectRef":
+        return {"object": value.expression}
+    if isinstance(value, (list, tuple)):
+        return {"list" if isinstance(value, list) else "tuple": [canonical_ini_value(v) for v in value]}
+    if isinstance(value, (bool, int, float, str)) or value is None:
+        return {type(value).__name__: value}
+    raise TypeError("unexpected parsed value {!r}".format(value))
+
+
+def run_ini_grammar(case):
+    """``config/parsing.py:parse_file`` (the INI value grammar: numbers, strings with $variables, lists, tuples, class
+    symbols, <object.attribute> references, the [vars] section) on every configuration file of the reference's own
+    test suite -- no TensorFlow involved.  The files' text is kept in the fixture; $TIME is pinned."""
+    import glob
+    import time as time_module
+    from neuralmonkey.config import parsing
+    real = time_module.strftime
+    time_module.strftime = lambda fmt, *a: "TIME"
+    os.environ["NM_EXPERIMENT_NAME"] = "exp-7"          # a [vars]-less variable some files take from the environment
+    out, files = {}, {}
+    try:
+        for path in sorted(glob.glob(os.path.join(REFERENCE, "tests", "*.ini"))):
+            name = os.path.basename(path)
+            with open(path, encoding="utf-8") as handle:
+                text = handle.read()
+            files[name] = text
+            raw, parsed = parsing.parse_file(text.splitlines(True))
+            out["out/" + name] = np.asarray(json.dumps(
+                {sec: {k: canonical_ini_value(v) for k, v in body.items()} for sec, body in parsed.items()},
+                sort_keys=True))
+            out["raw/" + name] = np.asarray(json.dumps(raw, sort_keys=True))
+        # the value grammar probe by probe (each in a file of its own): what it parses to, or the error it gives
+        probes = ['1', '-4', '2.5e-3', '1e3', '-.5', '.5', '1.', '"s t"', '"pre-$x-{x}"', '"{nowhere_defined}"', '$x',
+                  '[1, 2]', '[]', '()', '(3,)', '(1, 2)', '[ [1,2] , (3, 4) ]', '["s, t"]', '[1, 2', 'tf.nn.relu',
+                  'a.b', 'a', '<obj>', '<obj.attr.b>', 'None', 'True', 'False', 'true', '1 2', '"unterminated',
+                  '[1,,2]', '[1, 2,]', '0x10', '1_000', '-', '"a" "b"', "'single'"]
+        files["_probes"] = json.dumps(probes)
+        results = []
+        for probe in probes:
+            text = "[vars]\nx=3\n[main]\nv={}\n".format(probe)
+            try:
+                _, parsed = parsing.parse_file(text.splitlines(True))
+                results.append({"value": canonical_ini_value(parsed["main"]["v"])})
+            except Exception as exc:        # noqa: BLE001
+                results.append({"error": "{}: {}".format(type(exc).__name__, exc)})
+        out["out/_probes"] = np.asarray(json.dumps(results, sort_keys=True))
+    finally:
+        time_module.strftime = real
+    save(case, {"kind": "ini_grammar", "files": files}, out)
+
+
 def run_defects(case):
     """Configurations the reference cannot execute at this commit: the exception IS the reference behaviour."""
     import traceback
@@ -1207,6 +1263,7 @@ CASES = collections.OrderedDict([
     ("vocabulary_formats", lambda: run_vocabulary_formats("vocabulary_formats")),
     ("host_text_pipeline", lambda: run_host_text_pipeline("host_text_pipeline")),
     ("schedules", lambda: run_schedules("schedules")),
+    ("ini_grammar", lambda: run_ini_grammar("ini_grammar")),
     ("dataset_batching", lambda: run_dataset_batching("dataset_batching")),
     ("greedy_runner_ensemble", lambda: run_greedy_runner_ensemble("greedy_runner_ensemble")),
     ("ensemble", lambda: run_ensemble("ensemble")),
