@@ -1154,6 +1154,90 @@ def run_ini_grammar(case):
     save(case, {"kind": "ini_grammar", "files": files}, out)
 
 
+BUILDER_INI = """[vars]
+n=3
+[main]
+pair=(<frac>, <frac.numerator>)
+items=[<frac>, <other>, $n, "s"]
+tf_manager=<first>
+zeta=<other>
+alpha=<third.tag>
+[frac]
+class=fractions.Fraction
+numerator=3
+denominator=4
+[other]
+class=argparse.Namespace
+a=<frac>
+b=[1, <frac.denominator>]
+[first]
+class=argparse.Namespace
+tag="first"
+[third]
+class=argparse.Namespace
+tag=fractions.Fraction
+[unused]
+class=argparse.Namespace
+"""
+
+BUILDER_ERRORS = {
+    "undefined_object": "[main]\na=<nope>\n",
+    "no_class": "[main]\na=<sec>\n[sec]\nx=1\n",
+    "not_callable": "[main]\na=<sec>\n[sec]\nclass=math.pi\n",
+    "bad_kwargs": "[main]\na=<sec>\n[sec]\nclass=fractions.Fraction\nnumerator=1\nno_such_argument=2\n",
+    "cycle": "[main]\na=<x>\n[x]\nclass=argparse.Namespace\ny=<y>\n[y]\nclass=argparse.Namespace\nx=<x>\n",
+    "constructor_raises": "[main]\na=<sec>\n[sec]\nclass=fractions.Fraction\nnumerator=1\ndenominator=0\n",
+    "no_main": "[other]\nclass=argparse.Namespace\n",
+}
+
+
+def describe_built(value):
+    """A built configuration value in words: type name + content, recursively (objects by their repr)."""
+    if isinstance(value, (list, tuple)):
+        return {type(value).__name__: [describe_built(v) for v in value]}
+    if isinstance(value, type):
+        return {"class": "{}.{}".format(value.__module__, value.__qualname__)}
+    if type(value).__name__ == "Namespace":
+        return {"Namespace": {k: describe_built(v) for k, v in sorted(vars(value).items())}}
+    return {type(value).__name__: repr(value)}
+
+
+def run_config_builder(case):
+    """``config/builder.py:build_config`` (object references resolved recursively and once, attribute chains,
+    class symbols, ``tf_manager`` built last, the errors of bad configurations) on a configuration that names only
+    standard-library callables, so that the product's builder can be run on the same text."""
+    import collections.abc
+    collections.Iterable = collections.abc.Iterable          # (builder.py:114 uses the pre-3.10 alias)
+    from neuralmonkey.config import parsing
+    from neuralmonkey.config.builder import build_config
+    out = {}
+    _, parsed = parsing.parse_file(BUILDER_INI.splitlines(True))
+    configuration, existing = build_config(parsed, ignore_names=set(), warn_unused=True)
+    out["out/configuration"] = np.asarray(json.dumps({k: describe_built(v) for k, v in configuration.items()}))
+    out["out/configuration_order"] = np.asarray(list(configuration))
+    out["out/construction_order"] = np.asarray(list(existing))
+    out["out/shared_identity"] = np.asarray([configuration["pair"][0] is configuration["items"][0],
+                                             configuration["items"][1] is configuration["zeta"],
+                                             configuration["items"][1].a is configuration["pair"][0]])
+    _, parsed = parsing.parse_file(BUILDER_INI.splitlines(True))
+    ignored, _ = build_config(parsed, ignore_names={"zeta", "items"}, warn_unused=False)
+    out["out/ignored_order"] = np.asarray(list(ignored))
+    errors = {}
+    for tag, text in BUILDER_ERRORS.items():
+        _, parsed = parsing.parse_file(text.splitlines(True))
+        try:
+            build_config(parsed, ignore_names=set())
+            errors[tag] = ""
+        except BaseException as exc:        # noqa: BLE001
+            inner = getattr(exc, "original_exception", None)
+            errors[tag] = {"type": type(exc).__name__, "object_name": str(getattr(exc, "object_name", "")),
+                           "inner_type": type(inner).__name__ if inner is not None else "",
+                           # (a nested ConfigBuildException prints a traceback with this machine's paths: cut)
+                           "inner_text": (str(inner) if inner is not None else str(exc)).split("\nTraceback")[0]}
+    out["out/errors"] = np.asarray(json.dumps(errors, sort_keys=True))
+    save(case, {"kind": "config_builder", "ini": BUILDER_INI, "errors": BUILDER_ERRORS}, out)
+
+
 def run_defects(case):
     """Configurations the reference cannot execute at this commit: the exception IS the reference behaviour."""
     import traceback
@@ -1264,6 +1348,7 @@ CASES = collections.OrderedDict([
     ("host_text_pipeline", lambda: run_host_text_pipeline("host_text_pipeline")),
     ("schedules", lambda: run_schedules("schedules")),
     ("ini_grammar", lambda: run_ini_grammar("ini_grammar")),
+    ("config_builder", lambda: run_config_builder("config_builder")),
     ("dataset_batching", lambda: run_dataset_batching("dataset_batching")),
     ("greedy_runner_ensemble", lambda: run_greedy_runner_ensemble("greedy_runner_ensemble")),
     ("ensemble", lambda: run_ensemble("ensemble")),

@@ -64,7 +64,8 @@ def sentence(ids, vocab):
 def test_every_generated_case_is_checked_here():
     have = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(FIX, "*.npz")))
     checked = sorted(["functions", "defects", "ensemble", "greedy_runner_ensemble", "dataset_batching",
-                      "vocabulary_formats", "host_text_pipeline", "schedules", "ini_grammar"] + BEAM_BODY_CASES + RNN_CASES + TRANSFORMER_CASES
+                      "vocabulary_formats", "host_text_pipeline", "schedules", "ini_grammar", "config_builder"]
+                     + BEAM_BODY_CASES + RNN_CASES + TRANSFORMER_CASES
                      + VARIANT_CASES + FD_CASES)
     assert have == checked
 
@@ -700,3 +701,46 @@ def test_ini_grammar_equals_the_reference_parser(monkeypatch):
             assert "error" in expected and got == {"value": LENIENT_PROBES[probe]}, probe
             continue
         assert got == expected, "probe {!r}: {} vs reference {}".format(probe, got, expected)
+
+
+def _describe_built(value):
+    if isinstance(value, (list, tuple)):
+        return {type(value).__name__: [_describe_built(v) for v in value]}
+    if isinstance(value, type):
+        return {"class": "{}.{}".format(value.__module__, value.__qualname__)}
+    if type(value).__name__ == "Namespace":
+        return {"Namespace": {k: _describe_built(v) for k, v in sorted(vars(value).items())}}
+    return {type(value).__name__: repr(value)}
+
+
+def test_config_builder_equals_the_reference_builder():
+    """The PRODUCT'S ``build_config`` against ``config/builder.py:build_config`` of the reference on a configuration
+    of standard-library callables: what is built, in which order the main keys come out (``tf_manager`` last) and the
+    sections are constructed, that a section referenced twice is ONE object, ``ignore_names``, and the exception
+    (type, key it is reported under, inner type and text) of seven broken configurations."""
+    from neuralmonkey_amd.config import parsing
+    from neuralmonkey_amd.config.builder import build_config
+    z, cfg, _ = load("config_builder")
+    _, parsed = parsing.parse_file(cfg["ini"].splitlines(True))
+    configuration, existing = build_config(parsed, ignore_names=set(), warn_unused=True)
+    assert {k: _describe_built(v) for k, v in configuration.items()} == json.loads(str(z["out/configuration"]))
+    assert list(configuration) == [str(k) for k in z["out/configuration_order"]]
+    assert list(existing) == [str(k) for k in z["out/construction_order"]]
+    shared = [configuration["pair"][0] is configuration["items"][0], configuration["items"][1] is configuration["zeta"],
+              configuration["items"][1].a is configuration["pair"][0]]
+    assert shared == [bool(v) for v in z["out/shared_identity"]]
+    _, parsed = parsing.parse_file(cfg["ini"].splitlines(True))
+    ignored, _ = build_config(parsed, ignore_names={"zeta", "items"}, warn_unused=False)
+    assert list(ignored) == [str(k) for k in z["out/ignored_order"]]
+    want = json.loads(str(z["out/errors"]))
+    for tag, text in cfg["errors"].items():
+        _, parsed = parsing.parse_file(text.splitlines(True))
+        try:
+            build_config(parsed, ignore_names=set())
+            got = ""
+        except BaseException as exc:        # noqa: BLE001
+            inner = getattr(exc, "original_exception", None)
+            got = {"type": type(exc).__name__, "object_name": str(getattr(exc, "object_name", "")),
+                   "inner_type": type(inner).__name__ if inner is not None else "",
+                   "inner_text": (str(inner) if inner is not None else str(exc)).split("\nTraceback")[0]}
+        assert got == want[tag], "{}: {} vs reference {}".format(tag, got, want[tag])
