@@ -39,9 +39,10 @@ class Dataset:
                  outputs: Dict[str, Tuple[str, Any]] = None, shuffled: bool = False) -> None:
         self.name = name
         self._series = {k: list(v) for k, v in series.items()}
-        lengths = {len(v) for v in self._series.values()}
-        if len(lengths) > 1:
-            raise ValueError("Series of dataset '{}' differ in length: {}".format(name, lengths))
+        length_dict = {k: len(v) for k, v in self._series.items()}
+        lengths = set(length_dict.values())
+        if len(lengths) > 1:                  # dataset.py:398-405, the reference's text
+            raise ValueError("Lengths of data series do not match: {}".format(str(length_dict)))
         self._length = lengths.pop() if lengths else 0
         self.batching = batching
         self.outputs = outputs or {}
@@ -142,6 +143,15 @@ def load(name: str, series: List[str], data: List[Any], batching: BatchingScheme
 
     The series are materialised here (``buffer_size`` is accepted and ignored: the lazy refill of the
     reference bounds host memory, the batches are the same)."""
+    def from_file(spec) -> bool:         # a ReaderDef of the reference: files, or (files, reader)
+        if isinstance(spec, (str, list)):
+            return True
+        return isinstance(spec, tuple) and len(spec) == 2 and isinstance(spec[0], (str, list)) and callable(spec[1])
+    # the checks of dataset.py:246-266, in the reference's order and with its texts
+    if not series:
+        raise ValueError("No dataset series specified.")
+    if not any(from_file(spec) for spec in data):
+        raise ValueError("At least one data series should be from a file")
     if len(series) != len(data):
         raise ValueError("The 'series' and 'data' lists should have the same number of elements: "
                          "{} vs {}.".format(len(series), len(data)))
@@ -167,8 +177,9 @@ def load(name: str, series: List[str], data: List[Any], batching: BatchingScheme
     from_files = set(loaded)
     for sid, (preprocessor, source) in series_level.items():
         if source not in from_files:
-            raise ValueError("Source series for series-level preprocessor nonexistent: Preprocessed series "
-                             "'{}', source series '{}'".format(sid, source))
+            # (dataset.py:309-312 never fills the two placeholders in: the text below IS the reference's)
+            raise ValueError("Source series for series-level preprocessor nonexistent: "
+                             "Preprocessed series '{}', source series '{}'")
         loaded[sid] = [preprocessor(item) for item in loaded[source]]
     if dataset_level:
         def _factory(items):

@@ -940,6 +940,7 @@ def run_dataset_batching(case):
     """``Dataset.batches`` (dataset.py:467-579): fixed-size batches and length buckets (a row goes to the TIGHTEST
     bucket that fits the longest of its series, to the last one when none does), with and without the remainder.
     No TensorFlow involved: the reference's own host code on seeded sentences."""
+    fresh_graph()                 # (no variables of an earlier case in this fixture)
     from neuralmonkey.dataset import BatchingScheme, Dataset
     rng = np.random.default_rng(43)
     rows = 41
@@ -985,6 +986,7 @@ VOCAB_FILES = {
 def run_vocabulary_formats(case):
     """The vocabulary loaders and ``vectors_to_sentences`` of the reference (vocabulary.py, no TensorFlow involved) on
     small files whose text is kept in the fixture: the product's loaders are run on the same text by the CPU test."""
+    fresh_graph()                 # (no variables of an earlier case in this fixture)
     import tempfile
     from neuralmonkey import vocabulary as V
     out = {}
@@ -1030,6 +1032,7 @@ def run_host_text_pipeline(case):
     """Readers and string processors of the reference, none of which touches TensorFlow: plain_text_reader.py:23-134
     (whitespace tokens, the tensor2tensor tokenizer, column readers), string_vector_reader.py:6-40,
     processors/helpers.py:5-52, processors/wordpiece.py:22-130 -- on files whose text the fixture carries."""
+    fresh_graph()                 # (no variables of an earlier case in this fixture)
     import tempfile
     from neuralmonkey.readers import plain_text_reader as R
     from neuralmonkey.readers.string_vector_reader import get_string_vector_reader
@@ -1116,6 +1119,7 @@ def run_ini_grammar(case):
     """``config/parsing.py:parse_file`` (the INI value grammar: numbers, strings with $variables, lists, tuples, class
     symbols, <object.attribute> references, the [vars] section) on every configuration file of the reference's own
     test suite -- no TensorFlow involved.  The files' text is kept in the fixture; $TIME is pinned."""
+    fresh_graph()                 # (no variables of an earlier case in this fixture)
     import glob
     import time as time_module
     from neuralmonkey.config import parsing
@@ -1206,6 +1210,7 @@ def run_config_builder(case):
     """``config/builder.py:build_config`` (object references resolved recursively and once, attribute chains,
     class symbols, ``tf_manager`` built last, the errors of bad configurations) on a configuration that names only
     standard-library callables, so that the product's builder can be run on the same text."""
+    fresh_graph()                 # (no variables of an earlier case in this fixture)
     import collections.abc
     collections.Iterable = collections.abc.Iterable          # (builder.py:114 uses the pre-3.10 alias)
     from neuralmonkey.config import parsing
@@ -1236,6 +1241,66 @@ def run_config_builder(case):
                            "inner_text": (str(inner) if inner is not None else str(exc)).split("\nTraceback")[0]}
     out["out/errors"] = np.asarray(json.dumps(errors, sort_keys=True))
     save(case, {"kind": "config_builder", "ini": BUILDER_INI, "errors": BUILDER_ERRORS}, out)
+
+
+LOAD_FILES = {
+    "train.a.src": "the cat\nsat on\n",
+    "train.b.src": "a mat\n",
+    "train.tgt": "le chat\nassis sur\nun tapis\n",
+    "short.tgt": "le chat\n",
+}
+
+
+def lengths_of(iterators):
+    """A dataset-level preprocessor: called with {series: () -> iterator} of the series read so far."""
+    return (len(s) + len(t) for s, t in zip(iterators["source"](), iterators["target"]()))
+
+
+def run_dataset_loading(case):
+    """``dataset.load`` (dataset.py:207-333): series read from files (a glob over two files, a (files, reader) pair),
+    a series-level preprocessor, a dataset-level preprocessor -- and the errors of bad specifications."""
+    fresh_graph()                 # (no variables of an earlier case in this fixture)
+    import tempfile
+    from neuralmonkey.dataset import BatchingScheme, load
+    from neuralmonkey.processors.helpers import preprocess_char_based
+    from neuralmonkey.readers.plain_text_reader import tokenized_text_reader
+    out = {}
+    scheme = BatchingScheme(batch_size=2)
+    join = lambda rows: np.asarray(["\x1f".join(str(t) for t in r) if isinstance(r, (list, tuple)) else str(r)
+                                    for r in rows])
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, text in LOAD_FILES.items():
+            with open(os.path.join(tmp, name), "w", encoding="utf-8") as handle:
+                handle.write(text)
+        at = lambda name: os.path.join(tmp, name)
+        ds = load("data", ["source", "target", "chars", "lens"],
+                  [at("train.*.src"), (at("train.tgt"), tokenized_text_reader()),
+                   (preprocess_char_based, "source"), lengths_of], scheme)
+        for sid in ("source", "target", "chars", "lens"):
+            out["out/" + sid] = join(list(ds.get_series(sid)))
+        out["out/length"] = np.asarray(len(ds))
+        out["out/batches"] = np.asarray([len(list(b.get_series("source"))) for b in ds.batches()])
+        probes = {
+            "count_mismatch": lambda: load("d", ["source", "target"], [at("train.tgt")], scheme),
+            "duplicates": lambda: load("d", ["source", "source"], [at("train.tgt"), at("train.tgt")], scheme),
+            "missing_file": lambda: load("d", ["source"], [at("nowhere.txt")], scheme),
+            "no_file_series": lambda: load("d", ["chars"], [(preprocess_char_based, "source")], scheme),
+            "no_series": lambda: load("d", [], [], scheme),
+            "unknown_source": lambda: load("d", ["source", "chars"], [at("train.tgt"), (preprocess_char_based, "nope")],
+                                           scheme),
+            "unequal_lengths": lambda: load("d", ["source", "target"], [at("train.tgt"), at("short.tgt")], scheme),
+            "multiple_outputs": lambda: load("d", ["source"], [at("train.tgt")], scheme,
+                                             outputs=[("source", "a.txt"), ("source", "b.txt")]),
+        }
+        errors = {}
+        for tag, probe in probes.items():
+            try:
+                probe()
+                errors[tag] = ""
+            except Exception as exc:        # noqa: BLE001
+                errors[tag] = "{}: {}".format(type(exc).__name__, str(exc).replace(tmp, "<dir>"))
+    out["out/errors"] = np.asarray(json.dumps(errors, sort_keys=True))
+    save(case, {"kind": "dataset_loading", "files": LOAD_FILES}, out)
 
 
 def run_defects(case):
@@ -1349,6 +1414,7 @@ CASES = collections.OrderedDict([
     ("schedules", lambda: run_schedules("schedules")),
     ("ini_grammar", lambda: run_ini_grammar("ini_grammar")),
     ("config_builder", lambda: run_config_builder("config_builder")),
+    ("dataset_loading", lambda: run_dataset_loading("dataset_loading")),
     ("dataset_batching", lambda: run_dataset_batching("dataset_batching")),
     ("greedy_runner_ensemble", lambda: run_greedy_runner_ensemble("greedy_runner_ensemble")),
     ("ensemble", lambda: run_ensemble("ensemble")),

@@ -2000,16 +2000,59 @@ def build_modules():
     return mods
 
 
+def _check_type(argname, value, expected_type, memo=None):
+    """``typeguard.check_type`` for the annotations the reference hands to it through ``util/match_type.py`` (the
+    dataset series specifications of dataset.py:24-52): classes, Any, Union, List / Tuple / Dict / Iterable /
+    Callable with or without parameters.  Raises TypeError on a mismatch, like typeguard 2."""
+    import collections.abc as abc
+    import typing
+
+    def matches(val, tp):
+        if tp is typing.Any or tp is None and val is None:
+            return True
+        if tp is None:
+            return val is None
+        origin = typing.get_origin(tp)
+        args = typing.get_args(tp)
+        if origin is typing.Union:
+            return any(matches(val, a) for a in args)
+        if origin in (list, abc.Sequence, abc.Iterable, abc.MutableSequence):
+            want = list if origin is list else abc.Iterable
+            if not isinstance(val, want) or (origin is not list and isinstance(val, str)):
+                return isinstance(val, want) and origin is abc.Iterable
+            return not args or all(matches(v, args[0]) for v in val)
+        if origin is tuple:
+            if not isinstance(val, tuple):
+                return False
+            if not args:
+                return True
+            if len(args) == 2 and args[1] is Ellipsis:
+                return all(matches(v, args[0]) for v in val)
+            return len(val) == len(args) and all(matches(v, a) for v, a in zip(val, args))
+        if origin is dict:
+            return isinstance(val, dict) and (not args or all(matches(k, args[0]) and matches(v, args[1])
+                                                              for k, v in val.items()))
+        if origin is abc.Callable:
+            return callable(val)
+        if origin is not None:
+            return isinstance(val, origin)
+        if isinstance(tp, type):
+            return isinstance(val, tp) and not (tp is int and isinstance(val, bool))
+        return True                      # TypeVars, forward references: not checked
+    if not matches(value, expected_type):
+        raise TypeError("type of {} must be {}; got {} instead".format(argname, expected_type, type(value).__name__))
+
+
 def install():
-    """Put the stand-in (plus no-op ``typeguard`` / ``termcolor``) into ``sys.modules``.  Refuses to shadow a real
-    TensorFlow."""
+    """Put the stand-in (plus a minimal ``typeguard`` and a no-op ``termcolor``) into ``sys.modules``.  Refuses to
+    shadow a real TensorFlow."""
     if "tensorflow" in sys.modules and not getattr(sys.modules["tensorflow"], "__version__", "").endswith("standin"):
         raise RuntimeError("a real tensorflow is already imported")
     mods = build_modules()
     sys.modules.update(mods)
     if "typeguard" not in sys.modules:
         sys.modules["typeguard"] = _module("typeguard", check_argument_types=lambda *a, **k: True,
-                                           check_type=lambda *a, **k: None)
+                                           check_type=_check_type)
     if "termcolor" not in sys.modules:
         sys.modules["termcolor"] = _module("termcolor", colored=lambda text, *a, **k: text)
     return mods["tensorflow"]

@@ -64,7 +64,8 @@ def sentence(ids, vocab):
 def test_every_generated_case_is_checked_here():
     have = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(FIX, "*.npz")))
     checked = sorted(["functions", "defects", "ensemble", "greedy_runner_ensemble", "dataset_batching",
-                      "vocabulary_formats", "host_text_pipeline", "schedules", "ini_grammar", "config_builder"]
+                      "vocabulary_formats", "host_text_pipeline", "schedules", "ini_grammar", "config_builder",
+                      "dataset_loading"]
                      + BEAM_BODY_CASES + RNN_CASES + TRANSFORMER_CASES
                      + VARIANT_CASES + FD_CASES)
     assert have == checked
@@ -744,3 +745,50 @@ def test_config_builder_equals_the_reference_builder():
                    "inner_type": type(inner).__name__ if inner is not None else "",
                    "inner_text": (str(inner) if inner is not None else str(exc)).split("\nTraceback")[0]}
         assert got == want[tag], "{}: {} vs reference {}".format(tag, got, want[tag])
+
+
+def _lengths_of(iterators):
+    return (len(s) + len(t) for s, t in zip(iterators["source"](), iterators["target"]()))
+
+
+def test_dataset_load_equals_the_reference_load(tmp_path):
+    """The PRODUCT'S ``dataset.load`` against the reference's (dataset.py:207-333) on the same files: a glob over two
+    files, a (files, reader) pair, a series-level and a dataset-level preprocessor; and type + text of the error of
+    eight bad specifications (the reference's own unformatted message for an unknown source series included)."""
+    from neuralmonkey_amd.dataset import BatchingScheme, load as load_dataset
+    from neuralmonkey_amd.processors.helpers import preprocess_char_based
+    from neuralmonkey_amd.readers.plain_text_reader import tokenized_text_reader
+    z, cfg, _ = load("dataset_loading")
+    for name, text in cfg["files"].items():
+        with open(str(tmp_path / name), "w", encoding="utf-8") as handle:
+            handle.write(text)
+    at = lambda name: str(tmp_path / name)
+    scheme = BatchingScheme(batch_size=2)
+    join = lambda rows: ["\x1f".join(str(t) for t in r) if isinstance(r, (list, tuple)) else str(r) for r in rows]
+    ds = load_dataset("data", ["source", "target", "chars", "lens"],
+                      [at("train.*.src"), (at("train.tgt"), tokenized_text_reader()),
+                       (preprocess_char_based, "source"), _lengths_of], scheme)
+    for sid in ("source", "target", "chars", "lens"):
+        assert join(list(ds.get_series(sid))) == [str(x) for x in z["out/" + sid]], sid
+    assert len(ds) == int(z["out/length"])
+    assert [len(list(b.get_series("source"))) for b in ds.batches()] == [int(n) for n in z["out/batches"]]
+    probes = {
+        "count_mismatch": lambda: load_dataset("d", ["source", "target"], [at("train.tgt")], scheme),
+        "duplicates": lambda: load_dataset("d", ["source", "source"], [at("train.tgt"), at("train.tgt")], scheme),
+        "missing_file": lambda: load_dataset("d", ["source"], [at("nowhere.txt")], scheme),
+        "no_file_series": lambda: load_dataset("d", ["chars"], [(preprocess_char_based, "source")], scheme),
+        "no_series": lambda: load_dataset("d", [], [], scheme),
+        "unknown_source": lambda: load_dataset("d", ["source", "chars"],
+                                               [at("train.tgt"), (preprocess_char_based, "nope")], scheme),
+        "unequal_lengths": lambda: load_dataset("d", ["source", "target"], [at("train.tgt"), at("short.tgt")], scheme),
+        "multiple_outputs": lambda: load_dataset("d", ["source"], [at("train.tgt")], scheme,
+                                                 outputs=[("source", "a.txt"), ("source", "b.txt")]),
+    }
+    want = json.loads(str(z["out/errors"]))
+    for tag, probe in probes.items():
+        try:
+            probe()
+            got = ""
+        except Exception as exc:        # noqa: BLE001
+            got = "{}: {}".format(type(exc).__name__, str(exc).replace(str(tmp_path), "<dir>"))
+        assert got == want[tag], "{}: {!r} vs reference {!r}".format(tag, got, want[tag])
