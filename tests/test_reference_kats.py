@@ -377,5 +377,7 @@ def test_dataset_load_series_kinds(tmp_path):
                      outputs=[("target", "a.txt"), ("target", "b.txt")])
     with pytest.raises(ValueError, match="duplicate"):
         dataset.load("d", ["source", "source"], [path, path], dataset.BatchingScheme(batch_size=2))
-    with pytest.raises(TypeError):
+    with pytest.raises(ValueError, match="from a file"):        # dataset.py:249-250: nothing here is a file series
         dataset.load("d", ["source"], [3], dataset.BatchingScheme(batch_size=2))
+    with pytest.raises(TypeError):                              # (the reference: a bare assert, dataset.py:300)
+        dataset.load("d", ["source", "x"], [path, 3], dataset.BatchingScheme(batch_size=2))
