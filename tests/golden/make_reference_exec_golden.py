@@ -1004,6 +1004,19 @@ def run_vocabulary_formats(case):
         loaded["nematus"] = V.from_nematus_json(paths["nematus"])
         loaded["nematus_max5"] = V.from_nematus_json(paths["nematus"], max_size=5)
         loaded["nematus_pad9"] = V.from_nematus_json(paths["nematus"], max_size=9, pad_to_max_size=True)
+        # save_wordlist (:290-320): what it writes, that it refuses to overwrite, and that its output loads back
+        saved = os.path.join(tmp, "saved.tsv")
+        loaded["wordlist_header"].save_wordlist(saved)
+        with open(saved, encoding="utf-8") as handle:
+            out["out/saved_wordlist"] = np.asarray(handle.read())
+        try:
+            loaded["wordlist_header"].save_wordlist(saved)
+            out["out/save_again_error"] = np.asarray("")
+        except Exception as exc:        # noqa: BLE001
+            out["out/save_again_error"] = np.asarray("{}: {}".format(type(exc).__name__, str(exc).replace(tmp, "<dir>")))
+        loaded["wordlist_header"].save_wordlist(saved, overwrite=True)
+        out["out/saved_reloaded_words"] = np.asarray(list(V.from_wordlist(
+            saved, contains_header=True, contains_frequencies=False).index_to_word))
     for name, vocab in loaded.items():
         out["out/{}_words".format(name)] = np.asarray(list(vocab.index_to_word))
     # vectors_to_sentences (:257-288): time-major ids, every sentence cut at its first </s>, <pad> kept as a word

@@ -580,6 +580,17 @@ def test_vocabulary_loaders_equal_the_reference_loaders(tmp_path):
     }
     for name, vocab in loaded.items():
         assert list(vocab.index_to_word) == [str(w) for w in z["out/{}_words".format(name)]], name
+    # save_wordlist (vocabulary.py:290-320): the file it writes, the refusal to overwrite, loading it back
+    saved = str(tmp_path / "saved.tsv")
+    loaded["wordlist_header"].save_wordlist(saved)
+    with open(saved, encoding="utf-8") as handle:
+        assert handle.read() == str(z["out/saved_wordlist"])
+    with pytest.raises(FileExistsError) as info:
+        loaded["wordlist_header"].save_wordlist(saved)
+    assert "FileExistsError: {}".format(str(info.value).replace(str(tmp_path), "<dir>")) == str(z["out/save_again_error"])
+    loaded["wordlist_header"].save_wordlist(saved, overwrite=True)
+    again = V.from_wordlist(saved, contains_header=True, contains_frequencies=False)
+    assert list(again.index_to_word) == [str(w) for w in z["out/saved_reloaded_words"]]
     vocab = loaded["wordlist_header"]
     ids = z["in/time_major_ids"]
     assert [" ".join(s) for s in vocab.vectors_to_sentences(ids)] == [str(s) for s in z["out/sentences_array"]]
