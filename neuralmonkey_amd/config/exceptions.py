@@ -1,46 +1,51 @@
-"""Exceptions of config parsing and loading (mirror of neuralmonkey/config/exceptions.py: same classes, same
-attributes, same texts -- the text of a ParseError is pinned by the reference-executed fixture "ini_grammar" under tests/golden)."""
+"""What configuration parsing and loading raise.  The three public classes carry the attributes and print the texts
+a caller of the reference sees (neuralmonkey/config/exceptions.py); the texts are pinned by the reference-executed
+fixtures "ini_grammar" and "config_builder" under tests/golden."""
 import traceback
-from typing import Any
 
 
-class ParseError(Exception):
-    """A syntax error in an INI file (config/exceptions.py:7-23)."""
+class _ConfigError(Exception):
+    """Named fields, kept as attributes, and one line of text made from them on demand."""
+    fields = ()
 
-    def __init__(self, message: str, line: int = None) -> None:
-        super().__init__()
-        self.message = message
+    def __init__(self, *values) -> None:
+        Exception.__init__(self)
+        values = values + (None,) * (len(self.fields) - len(values))
+        for field, value in zip(self.fields, values):
+            setattr(self, field, value)
+
+    def describe(self) -> str:
+        raise NotImplementedError
+
+    def __str__(self) -> str:
+        return self.describe()
+
+
+class ParseError(_ConfigError):
+    """A line of an INI file that the value grammar does not accept; ``line`` is filled in by the file parser."""
+    fields = ("message", "line")
+
+    def set_line(self, line) -> None:
         self.line = line
 
-    def set_line(self, line: int) -> None:
-        self.line = line
-
-    def __str__(self) -> str:
-        if self.line is not None:
-            return "INI error on line {}: {}".format(self.line, self.message)
-        return "INI parsing error: {}".format(self.message)
+    def describe(self) -> str:
+        where = "parsing error" if self.line is None else "error on line {}".format(self.line)
+        return "INI {}: {}".format(where, self.message)
 
 
-class ConfigInvalidValueException(Exception):
-    """config/exceptions.py:26-42."""
+class ConfigInvalidValueException(_ConfigError):
+    """A section that cannot be turned into an object (undefined, without a class, not callable)."""
+    fields = ("value", "message")
 
-    def __init__(self, value: Any, message: str) -> None:
-        super().__init__()
-        self.value = value
-        self.message = message
-
-    def __str__(self) -> str:
-        return "Error in configuration of {}: {}".format(self.value, self.message)
+    def describe(self) -> str:
+        return "Error in configuration of {0.value}: {0.message}".format(self)
 
 
-class ConfigBuildException(Exception):
-    """An object of the configuration failed to build (config/exceptions.py:45-66)."""
+class ConfigBuildException(_ConfigError):
+    """Whatever went wrong while the object named ``object_name`` was being built, kept in ``original_exception``."""
+    fields = ("object_name", "original_exception")
 
-    def __init__(self, object_name: str, original_exception: Exception) -> None:
-        super().__init__()
-        self.object_name = object_name
-        self.original_exception = original_exception
-
-    def __str__(self) -> str:
-        trc = "".join(traceback.format_list(traceback.extract_tb(self.original_exception.__traceback__)))
-        return "Error while loading '{}': {}\nTraceback: {}".format(self.object_name, self.original_exception, trc)
+    def describe(self) -> str:
+        frames = traceback.extract_tb(self.original_exception.__traceback__)
+        return "Error while loading '{}': {}\nTraceback: {}".format(
+            self.object_name, self.original_exception, "".join(traceback.format_list(frames)))

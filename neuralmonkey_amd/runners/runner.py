@@ -14,6 +14,22 @@ from .base_runner import BaseRunner, NextExecute
 Postprocessor = Callable[[List[List[str]]], List[List[str]]]
 
 
+def ensemble_logprobs(per_session: List[np.ndarray]) -> np.ndarray:
+    """[T,B,V] log-probabilities of several sessions -> log of their summed probabilities, step by step along the
+    loop of the FIRST session (runners/runner.py:37-49; pinned by the reference-executed fixture
+    "greedy_runner_ensemble" under tests/golden).  Every session's loop stops on its own: one that stopped earlier
+    contributes to its own steps only; one that ran LONGER than the first makes the reference index past the end of
+    its per-step list -- the same IndexError is raised here, before anything is combined."""
+    steps = per_session[0].shape[0]
+    if any(logprobs.shape[0] > steps for logprobs in per_session):
+        raise IndexError("list index out of range")
+    combined = np.full(per_session[0].shape, -np.inf, dtype=per_session[0].dtype)
+    for logprobs in per_session:
+        upto = logprobs.shape[0]
+        combined[:upto] = np.logaddexp(combined[:upto], logprobs)
+    return combined
+
+
 class GreedyRunner(BaseRunner):
     class Executable(BaseRunner.Executable):
         def next_to_execute(self) -> NextExecute:
@@ -31,27 +47,15 @@ class GreedyRunner(BaseRunner):
             return fetches, []
 
         def collect_results(self, results: List[Dict]) -> None:
-            train_loss = 0.0
-            runtime_loss = 0.0
-            for sess_result in results:
-                train_loss += float(sess_result["train_xent"])
-                runtime_loss += float(sess_result["runtime_xent"])
+            losses = [sum(float(session[key]) for session in results) for key in ("train_xent", "runtime_xent")]
             if self.num_sessions == 1:
-                argmaxes = list(results[0]["decoded_symbols"])
+                steps = list(results[0]["decoded_symbols"])
             else:
-                # runners/runner.py:37-49, to the letter: one entry per step of SESSION 0'S loop; every session's
-                # loop stops on its own, so a session that stopped earlier contributes to its own steps only, and one
-                # that ran longer makes the list access fail with the reference's IndexError (pinned by
-                # the reference-executed fixture "greedy_runner_ensemble" under tests/golden)
-                summed = [-np.inf for _ in range(results[0]["decoded_logprobs"].shape[0])]
-                for sess_result in results:
-                    for i, logprob in enumerate(sess_result["decoded_logprobs"]):
-                        summed[i] = np.logaddexp(summed[i], logprob)
-                argmaxes = [np.argmax(l, axis=1) for l in summed]
-            decoded_tokens = self.executor.vocabulary.vectors_to_sentences(argmaxes)
+                steps = list(np.argmax(ensemble_logprobs([s["decoded_logprobs"] for s in results]), axis=2))
+            sentences = self.executor.vocabulary.vectors_to_sentences(steps)
             if self.executor.postprocess is not None:
-                decoded_tokens = self.executor.postprocess(decoded_tokens)
-            self.set_runner_result(outputs=decoded_tokens, losses=[train_loss, runtime_loss], summaries=None)
+                sentences = self.executor.postprocess(sentences)
+            self.set_runner_result(outputs=sentences, losses=losses, summaries=None)
 
     def __init__(self, output_series: str, decoder, postprocess: Postprocessor = None) -> None:
         super().__init__(output_series, decoder)

@@ -1,25 +1,26 @@
-"""XentRunner (mirror of neuralmonkey/runners/xent_runner.py:16-40): per-sentence, per-position
-cross entropies of the teacher-forced pass ([B,T], zero on padding), averaged over sessions."""
+"""XentRunner: the cross entropy of every target position of the teacher-forced pass ([B,T], zero on padding) as a
+runner output -- what neuralmonkey/runners/xent_runner.py:16-40 fetches from ``decoder.train_xents``.  With several
+sessions the tables are averaged element by element; the reported loss is the mean of that table."""
 from typing import Any, Dict, List
 
 import numpy as np
 
 from .base_runner import BaseRunner
 
+XENT_FETCH = "xents"
+
 
 class XentRunner(BaseRunner):
+    loss_names = ["xent"]
+
     class Executable(BaseRunner.Executable):
         def collect_results(self, results: List[Dict]) -> None:
-            xents = np.mean([np.asarray(res["xents"]) for res in results], axis=0)
-            self.set_runner_result(outputs=xents.tolist(), losses=[float(np.mean(xents))])
+            table = np.stack([np.asarray(session[XENT_FETCH]) for session in results]).mean(axis=0)
+            self.set_runner_result(outputs=table.tolist(), losses=[float(table.mean())])
 
     def __init__(self, output_series: str, decoder) -> None:
-        super().__init__(output_series, decoder)
+        BaseRunner.__init__(self, output_series, decoder)
 
     @property
     def fetches(self) -> Dict[str, Any]:
-        return {"xents": self.decoder.train_xents}
-
-    @property
-    def loss_names(self) -> List[str]:
-        return ["xent"]
+        return {XENT_FETCH: self.decoder.train_xents}

@@ -1,4 +1,5 @@
-"""Training objectives (mirror of neuralmonkey/trainers/objective.py)."""
+"""What a trainer optimises: named losses of model parts, each with an optional weight (the interface of
+neuralmonkey/trainers/objective.py; ``CostObjective`` is its :62-102 -- the ``cost`` of a decoder)."""
 from typing import Optional
 
 from ..model.model_part import GenericModelPart
@@ -7,44 +8,29 @@ ObjectiveWeight = Optional[float]
 
 
 class Objective:
+    """Base: a name for logs, the part whose loss it is.  ``gradients`` (hand-made gradients, used by the reference's
+    reinforcement-learning trainers only) and ``weight`` default to None = "differentiate the loss" / "weight 1"."""
+    gradients = None
+    weight: ObjectiveWeight = None
+
     def __init__(self, name: str, decoder) -> None:
-        self._name = name
-        self._decoder = decoder
+        self._name, self._decoder = name, decoder
 
-    @property
-    def decoder(self):
-        return self._decoder
-
-    @property
-    def name(self) -> str:
-        return self._name
+    name = property(lambda self: self._name)
+    decoder = property(lambda self: self._decoder)
 
     @property
     def loss(self):
         raise NotImplementedError()
 
-    @property
-    def gradients(self):
-        return None
-
-    @property
-    def weight(self) -> ObjectiveWeight:
-        return None
-
 
 class CostObjective(Objective):
-    """objective.py:62-102: the decoder's ``cost`` with an optional weight."""
-
     def __init__(self, decoder: GenericModelPart, weight: ObjectiveWeight = None) -> None:
         if "cost" not in dir(decoder):
             raise TypeError("The decoder does not have the 'cost' attribute")
-        super().__init__("{} - cost".format(str(decoder)), decoder)
-        self._weight = weight
+        Objective.__init__(self, "{} - cost".format(decoder), decoder)
+        self.weight = weight
 
     @property
     def loss(self):
-        return getattr(self.decoder, "cost")
-
-    @property
-    def weight(self) -> ObjectiveWeight:
-        return self._weight
+        return self.decoder.cost
