@@ -1316,6 +1316,59 @@ def run_dataset_loading(case):
     save(case, {"kind": "dataset_loading", "files": LOAD_FILES}, out)
 
 
+def run_ini(case, ini_name, wanted, decoder_key="decoder", encoder_key="encoder", attention_key="attention",
+            runner_key="runner", dataset_key="train_data"):
+    """One of the reference's own acceptance configurations (tests/<ini_name>.ini), built by the reference's parser
+    and builder from the file as it is: vocabularies and the training data from tests/data, the model parts and the
+    runner from their sections (the trainers, the TensorFlow manager and the evaluators are TensorFlow's / the host
+    control plane and stay unbuilt).  The first batch the file's batching scheme yields is fed with train_mode False
+    (the file's dropout is then the identity) and the model's numbers are recorded under the variables' own names."""
+    import collections.abc
+    collections.Iterable = collections.abc.Iterable
+    from neuralmonkey.config import parsing
+    from neuralmonkey.config.builder import ObjectRef, build_config
+    cwd = os.getcwd()
+    os.chdir(REFERENCE)                          # the file's data paths are relative to the repository root
+    try:
+        fresh_graph()
+        with open(os.path.join("tests", ini_name + ".ini"), encoding="utf-8") as handle:
+            _, parsed = parsing.parse_file(handle.read().splitlines(True))
+        parsed["main"] = collections.OrderedDict((key, ObjectRef(section)) for key, section in wanted.items())
+        built, _ = build_config(parsed, ignore_names=set())
+        enc, att, dec = built[encoder_key], built[attention_key], built[decoder_key]
+        runner, data = built[runner_key], built[dataset_key]
+        batch = next(iter(data.batches()))
+        parts = [enc, enc.input_sequence, att, dec]
+        inputs = string_inputs("source", "target")
+        out = {}
+        with tf_eager.feeding(feed(parts, batch, False, inputs)):
+            out["in/src_tokens"] = enc.input_sequence.input_factors[0].numpy()
+            out["in/src_ids"] = enc.input_sequence.inputs.numpy()
+            out["in/tgt_tokens"] = dec.train_tokens.numpy()
+            out["in/tgt_ids"] = dec.train_inputs.numpy()
+            out["out/enc_states"] = enc.temporal_states.numpy()
+            out["out/enc_mask"] = enc.temporal_mask.numpy()
+            out["out/enc_output"] = enc.output.numpy()
+            out["out/train_logits"] = dec.train_logits.numpy()
+            out["out/train_xents"] = dec.train_xents.numpy()
+            out["out/train_loss"] = dec.train_loss.numpy()
+            out["out/runtime_logits"] = dec.runtime_logits.numpy()
+            out["out/runtime_symbols"] = dec.runtime_loop_result.histories.output_symbols.numpy()
+            out["out/runtime_mask"] = dec.runtime_mask.numpy()
+            out["out/runtime_loss"] = dec.runtime_loss.numpy()
+            ex = runner.get_executable(compute_losses=True, summaries=False, num_sessions=1)
+            fetches, _ = ex.next_to_execute()
+            ex.collect_results([to_numpy(fetches)])
+            out["out/runner_sentences"] = np.asarray([joined(sent) for sent in ex.result.outputs[runner.output_series]])
+            out["out/runner_losses"] = np.asarray([ex.result.losses["{}/{}".format(runner.output_series, name)]
+                                                   for name in runner.loss_names], np.float32)
+        out["in/src_vocabulary"] = np.asarray(list(enc.input_sequence.vocabularies[0].index_to_word))
+        out["in/tgt_vocabulary"] = np.asarray(list(dec.vocabulary.index_to_word))
+    finally:
+        os.chdir(cwd)
+    save(case, {"kind": "ini", "ini": ini_name, "batch": int(out["in/src_ids"].shape[0])}, out)
+
+
 def run_defects(case):
     """Configurations the reference cannot execute at this commit: the exception IS the reference behaviour."""
     import traceback
@@ -1424,6 +1477,9 @@ CASES = collections.OrderedDict([
         heads_hier=4, seed=35, per_variable=2)),
     ("vocabulary_formats", lambda: run_vocabulary_formats("vocabulary_formats")),
     ("host_text_pipeline", lambda: run_host_text_pipeline("host_text_pipeline")),
+    ("ini_bahdanau", lambda: run_ini("ini_bahdanau", "bahdanau", collections.OrderedDict(
+        [("encoder", "encoder"), ("attention", "attention"), ("decoder", "decoder"), ("runner", "runner"),
+         ("train_data", "train_data")]))),
     ("schedules", lambda: run_schedules("schedules")),
     ("ini_grammar", lambda: run_ini_grammar("ini_grammar")),
     ("config_builder", lambda: run_config_builder("config_builder")),

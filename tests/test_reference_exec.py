@@ -65,7 +65,7 @@ def test_every_generated_case_is_checked_here():
     have = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(FIX, "*.npz")))
     checked = sorted(["functions", "defects", "ensemble", "greedy_runner_ensemble", "dataset_batching",
                       "vocabulary_formats", "host_text_pipeline", "schedules", "ini_grammar", "config_builder",
-                      "dataset_loading"]
+                      "dataset_loading", "ini_bahdanau"]
                      + BEAM_BODY_CASES + RNN_CASES + TRANSFORMER_CASES
                      + VARIANT_CASES + FD_CASES)
     assert have == checked
@@ -803,3 +803,46 @@ def test_dataset_load_equals_the_reference_load(tmp_path):
         except Exception as exc:        # noqa: BLE001
             got = "{}: {}".format(type(exc).__name__, str(exc).replace(str(tmp_path), "<dir>"))
         assert got == want[tag], "{}: {!r} vs reference {!r}".format(tag, got, want[tag])
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# one of the reference's own acceptance configurations, built by the reference's parser and builder from the file
+# --------------------------------------------------------------------------------------------------------------------
+def bahdanau_ini_config():
+    """tests/bahdanau.ini in the oracle's terms: SentenceEncoder "sentence_encoder" (GRU 7, bidirectional, embeddings
+    11, max_input_len 10), Attention "attention_sentence_encoder", Decoder "bahdanau_decoder" (GRU 8, embeddings 9,
+    maxout_output(9), supress_unk, max_output_len 10; dropout 0.5 is the identity with train_mode False)."""
+    return G.Config(enc_name="sentence_encoder", dec_name="bahdanau_decoder", att_name="attention_sentence_encoder",
+                    rnn_layers=((7, "bidirectional", "GRU"),), rnn_size=8, output_projection=("maxout", 9, 1.0),
+                    supress_unk=True)
+
+
+def test_the_reference_built_bahdanau_ini_equals_the_oracle():
+    """tests/bahdanau.ini parsed and built by the REFERENCE (its vocabularies, data files, bucketed batching, model
+    parts and GreedyRunner), first batch, train_mode False: encoder, teacher-forced pass, greedy loop and the runner's
+    sentences against the oracle on the variables the reference created under its own names."""
+    z, cfg, params = load("ini_bahdanau")
+    model = G.GeneralModel(params, bahdanau_ini_config())
+    src, tgt = z["in/src_ids"], z["in/tgt_ids"]
+    assert src.shape[1] <= 10 and tgt.shape[0] <= 10                 # max_input_len / max_output_len of the file
+    svoc = {str(w): i for i, w in enumerate(z["in/src_vocabulary"])}
+    same(np.vectorize(lambda w: svoc.get(str(w), O.UNK))(z["in/src_tokens"]), src, "source ids from the word list")
+    with torch.no_grad():
+        states, mask, final = model.encode(src, False)
+        close(states, z["out/enc_states"], "encoder states")
+        same(mask.numpy(), z["out/enc_mask"], "encoder mask")
+        close(final, z["out/enc_output"], "encoder output")
+        loss, logits, _ = model.train_loss(src, tgt, train=False)
+    keep = np.abs(z["out/train_logits"]) < 1e8                        # the -1e9 of supress_unk aside
+    close(logits.numpy()[keep], z["out/train_logits"][keep], "train_logits")
+    assert float(loss) > 1e8 and abs(float(loss) - float(z["out/train_loss"])) <= 1e-6 * float(z["out/train_loss"])
+    syms, masks, run_logits = model.greedy(src, 10)
+    same(syms, z["out/runtime_symbols"], "greedy symbols")
+    same(masks, z["out/runtime_mask"], "runtime mask")
+    keep = np.abs(z["out/runtime_logits"]) < 1e8
+    close(run_logits[keep], z["out/runtime_logits"][keep], "runtime logits")
+    tvoc = [str(w) for w in z["in/tgt_vocabulary"]]
+    amax = torch.log_softmax(torch.tensor(run_logits), -1).numpy().argmax(-1)
+    got = [" ".join(tvoc[i] for i in sent) for sent in O.greedy_tokens(O.DecodeResult(run_logits, None, amax, None, None,
+                                                                                      None, None))]
+    assert got == [str(s) for s in z["out/runner_sentences"]]

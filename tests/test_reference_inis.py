@@ -104,3 +104,24 @@ def test_coverage_attention_is_a_drop_in_section(ref_root):
     assert mine == {"Attention/attn_query_projection": (8, width), "attn_key_projection": (width, width),
                     "attn_similarity_v": (width,), "attn_projection_bias": (width,),
                     "coverage_matrix": (1, 1, 1, width), "fertility_matrix": (1, 1, width)}
+
+
+def test_first_batch_of_bahdanau_ini_is_the_batch_the_reference_built(ref_root):
+    """The PRODUCT, loading tests/bahdanau.ini from the bundle, reads the same files through the same bucketed
+    batching scheme: its first training batch is, sentence for sentence, the batch the REFERENCE'S own parser,
+    builder and ``Dataset.batches`` produced for the fixture ``tests/golden/ref_exec/ini_bahdanau.npz``."""
+    import numpy as np
+    fixture = np.load(os.path.join(HERE, "golden", "ref_exec", "ini_bahdanau.npz"))
+    model = load_verbatim(ref_root, "bahdanau", initialize=False, device="cpu")
+    batch = next(iter(model.train_dataset.batches()))
+    want_src = [[str(t) for t in row if str(t) != "<pad>"] for row in fixture["in/src_tokens"]]
+    got_src = [list(s)[:10] for s in batch.get_series("source")]             # max_input_len=10 of the encoder section
+    assert got_src == want_src
+    want_tgt = [[str(t) for t in row if str(t) not in ("<pad>", "</s>")] for row in fixture["in/tgt_tokens"]]
+    got_tgt = [list(s)[:len(w)] for s, w in zip(batch.get_series("target"), want_tgt)]
+    assert got_tgt == want_tgt
+    # and the vocabularies the INI's word lists give
+    runner = model.runners[0]
+    assert list(runner.decoder.vocabulary.index_to_word) == [str(w) for w in fixture["in/tgt_vocabulary"]]
+    enc = runner.decoder.encoders[0]
+    assert list(enc.input_sequence.vocabularies[0].index_to_word) == [str(w) for w in fixture["in/src_vocabulary"]]

@@ -106,3 +106,46 @@ def test_reference_ensemble_invariant_on_its_own_configs(dev, ref_root, tmp_path
         ka = [k for k in a.losses if k.endswith("beam_search_score")]
         for k in ka:          # tests_run.sh compares the first 8 characters of the two printed scores
             assert abs(a.losses[k] - b.losses[k]) <= 1e-5 * max(1.0, abs(a.losses[k])), (k, a.losses[k], b.losses[k])
+
+
+def test_bahdanau_ini_on_the_engine_equals_the_reference_built_model(dev, ref_root):      # noqa: F811
+    """tests/bahdanau.ini end to end on both sides: the REFERENCE'S parser, builder, data pipeline and model parts
+    produced ``tests/golden/ref_exec/ini_bahdanau.npz`` (first training batch, train_mode False); the product loads
+    the same file from the bundle, takes the reference's variables under their own names, and must give the encoder
+    states, teacher-forced logits, greedy symbols and the GreedyRunner's sentences of the reference."""
+    fixture = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_exec",
+                                   "ini_bahdanau.npz"))
+    params = {k[2:]: fixture[k] for k in fixture.files if k.startswith("p/")}
+    model = load_verbatim(ref_root, "bahdanau", device=str(dev), seed=1234)
+    tfm = model.tf_manager
+    store = tfm.sessions[0].store
+    assert sorted(store.names()) == sorted(params), set(store.names()) ^ set(params)
+    store.load_state_dict(params)
+    batch = next(iter(model.train_dataset.batches()))
+    runner = model.runners[0]
+    dec = runner.decoder
+    enc = dec.encoders[0]
+    fd = {}
+    for part in runner.feedables:
+        fd.update(part.feed_dict(batch, train=False))
+    out = tfm.sessions[0].run({"enc": enc.temporal_states, "final": enc.output, "train_logits": dec.train_logits,
+                               "sym": dec.decoded_symbols, "mask": dec.runtime_mask,
+                               "logits": dec.runtime_logits}, fd)
+
+    def close(got, want, what, tol=1e-4):
+        got, want = np.asarray(got), np.asarray(want)
+        assert got.shape == want.shape, (what, got.shape, want.shape)
+        keep = np.abs(want) < 1e8                      # the -1e9 of supress_unk aside
+        err = np.abs(got - want)[keep].max()
+        assert err <= tol * max(np.abs(want[keep]).max(), 1e-6), "{}: {:.3e}".format(what, err)
+    close(out["enc"], fixture["out/enc_states"], "encoder states")
+    close(out["final"], fixture["out/enc_output"], "encoder output")
+    close(out["train_logits"], fixture["out/train_logits"], "train logits")
+    assert np.array_equal(np.asarray(out["sym"]), fixture["out/runtime_symbols"])
+    assert np.array_equal(np.asarray(out["mask"]).astype(bool), fixture["out/runtime_mask"])
+    close(out["logits"], fixture["out/runtime_logits"], "runtime logits")
+    res = tfm.execute(batch, runner.feedables, [runner], compute_losses=True)[0]
+    assert [" ".join(s) for s in res.outputs[runner.output_series]] == [str(s) for s in fixture["out/runner_sentences"]]
+    want_losses = fixture["out/runner_losses"]
+    got_losses = [res.losses["{}/{}".format(runner.output_series, n)] for n in runner.loss_names]
+    assert np.allclose(got_losses, want_losses, rtol=1e-5)
