@@ -1369,6 +1369,87 @@ def run_ini(case, ini_name, wanted, decoder_key="decoder", encoder_key="encoder"
     save(case, {"kind": "ini", "ini": ini_name, "batch": int(out["in/src_ids"].shape[0])}, out)
 
 
+def run_ini_beamsearch(case, rows=6):
+    """tests/beamsearch.ini (TransformerEncoder / TransformerDecoder of dimension 6 + BeamSearchDecoder, beam 3,
+    length normalisation 0.6, 10 steps) built by the reference's parser and builder from the file as it is.  Its
+    datasets rely on ``main.batch_size`` through the running Experiment (host control plane), so the batch here is
+    the first ``rows`` sentence pairs of the file's training data, read by the reference's reader."""
+    import collections.abc
+    collections.Iterable = collections.abc.Iterable
+    from neuralmonkey.config import parsing
+    from neuralmonkey.config.builder import ObjectRef, build_config
+    from neuralmonkey.readers.plain_text_reader import UtfPlainTextReader
+    from neuralmonkey.runners.beamsearch_runner import BeamSearchRunner
+    cwd = os.getcwd()
+    os.chdir(REFERENCE)
+    try:
+        fresh_graph()
+        with open(os.path.join("tests", "beamsearch.ini"), encoding="utf-8") as handle:
+            _, parsed = parsing.parse_file(handle.read().splitlines(True))
+        files = parsed["train_data"]["data"][:2]
+        parsed["main"] = collections.OrderedDict((key, ObjectRef(key)) for key in ("inpseq", "encoder", "decoder",
+                                                                                   "bs_decoder"))
+        built, _ = build_config(parsed, ignore_names=set())
+        seq, enc, dec, bs = built["inpseq"], built["encoder"], built["decoder"], built["bs_decoder"]
+        series = {"source": list(UtfPlainTextReader([files[0]]))[:rows], "target": list(UtfPlainTextReader([files[1]]))[:rows]}
+        ds = dataset(series)
+        inputs = string_inputs("source", "target")
+        out = {}
+        with tf_eager.feeding(feed([seq, enc, dec], ds, False, inputs)):
+            out["in/src_tokens"] = seq.input_factors[0].numpy()
+            out["in/src_ids"] = seq.inputs.numpy()
+            out["in/tgt_tokens"] = dec.train_tokens.numpy()
+            out["in/tgt_ids"] = dec.train_inputs.numpy()
+            out["out/enc_states"] = enc.temporal_states.numpy()
+            out["out/enc_mask"] = enc.temporal_mask.numpy()
+            out["out/train_logits"] = dec.train_logits.numpy()
+            out["out/train_loss"] = dec.train_loss.numpy()
+            out["out/runtime_logits"] = dec.runtime_logits.numpy()
+            out["out/runtime_symbols"] = dec.runtime_loop_result.histories.output_symbols.numpy()
+            out["out/runtime_mask"] = dec.runtime_mask.numpy()
+        order_full, _ = variables()
+        # the beam search of the file's [bs_decoder], through a rank-1 and a rank-2 runner as its [bs_runners] makes
+        for rank in (1, 2):
+            fresh_graph()
+            with open(os.path.join("tests", "beamsearch.ini"), encoding="utf-8") as handle:
+                _, parsed = parsing.parse_file(handle.read().splitlines(True))
+            parsed["main"] = collections.OrderedDict((key, ObjectRef(key)) for key in ("inpseq", "encoder", "decoder",
+                                                                                       "bs_decoder"))
+            built, _ = build_config(parsed, ignore_names=set())
+            seq, enc, dec, bs = built["inpseq"], built["encoder"], built["decoder"], built["bs_decoder"]
+            runner = BeamSearchRunner(output_series="target_beam", decoder=bs, rank=rank)
+            with tf_eager.feeding(feed([seq, enc, dec, bs], ds, False, inputs)):
+                ex = runner.get_executable(compute_losses=False, summaries=False, num_sessions=1)
+                fetches, _ = ex.next_to_execute()
+                res = to_numpy(fetches)
+                ex.collect_results([res])
+                bo = res["bs_outputs"]
+                if rank == 1:
+                    out["out/beam_scores"] = bo.last_search_step_output.scores
+                    out["out/beam_token_ids"] = bo.last_search_step_output.token_ids
+                out["out/rank{}_sentences".format(rank)] = np.asarray([joined(t) for t in ex.result.outputs["target_beam"]])
+                out["out/rank{}_loss".format(rank)] = np.asarray(ex.result.losses["target_beam/beam_search_score"])
+        out["in/src_vocabulary"] = np.asarray(list(seq.vocabularies[0].index_to_word))
+        out["in/tgt_vocabulary"] = np.asarray(list(dec.vocabulary.index_to_word))
+        out["cfg/beam"] = np.asarray([bs.beam_size, bs.max_steps_int, 0], np.int64)
+    finally:
+        os.chdir(cwd)
+    # leave the store holding the full model's variables for save()
+    os.chdir(REFERENCE)
+    try:
+        fresh_graph()
+        with open(os.path.join("tests", "beamsearch.ini"), encoding="utf-8") as handle:
+            _, parsed = parsing.parse_file(handle.read().splitlines(True))
+        parsed["main"] = collections.OrderedDict((key, ObjectRef(key)) for key in ("inpseq", "encoder", "decoder"))
+        built, _ = build_config(parsed, ignore_names=set())
+        with tf_eager.feeding(feed([built["inpseq"], built["encoder"], built["decoder"]], ds, False, inputs)):
+            built["decoder"].train_loss.numpy()
+            built["decoder"].runtime_logits.numpy()
+    finally:
+        os.chdir(cwd)
+    save(case, {"kind": "ini", "ini": "beamsearch", "batch": rows}, out)
+
+
 def run_defects(case):
     """Configurations the reference cannot execute at this commit: the exception IS the reference behaviour."""
     import traceback
@@ -1480,6 +1561,7 @@ CASES = collections.OrderedDict([
     ("ini_bahdanau", lambda: run_ini("ini_bahdanau", "bahdanau", collections.OrderedDict(
         [("encoder", "encoder"), ("attention", "attention"), ("decoder", "decoder"), ("runner", "runner"),
          ("train_data", "train_data")]))),
+    ("ini_beamsearch", lambda: run_ini_beamsearch("ini_beamsearch")),
     ("schedules", lambda: run_schedules("schedules")),
     ("ini_grammar", lambda: run_ini_grammar("ini_grammar")),
     ("config_builder", lambda: run_config_builder("config_builder")),

@@ -65,7 +65,7 @@ def test_every_generated_case_is_checked_here():
     have = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(FIX, "*.npz")))
     checked = sorted(["functions", "defects", "ensemble", "greedy_runner_ensemble", "dataset_batching",
                       "vocabulary_formats", "host_text_pipeline", "schedules", "ini_grammar", "config_builder",
-                      "dataset_loading", "ini_bahdanau"]
+                      "dataset_loading", "ini_bahdanau", "ini_beamsearch"]
                      + BEAM_BODY_CASES + RNN_CASES + TRANSFORMER_CASES
                      + VARIANT_CASES + FD_CASES)
     assert have == checked
@@ -846,3 +846,47 @@ def test_the_reference_built_bahdanau_ini_equals_the_oracle():
     got = [" ".join(tvoc[i] for i in sent) for sent in O.greedy_tokens(O.DecodeResult(run_logits, None, amax, None, None,
                                                                                       None, None))]
     assert got == [str(s) for s in z["out/runner_sentences"]]
+
+
+def test_the_reference_built_beamsearch_ini_equals_the_oracle():
+    """tests/beamsearch.ini (Transformer of dimension 6, 3 / 3 / 2 heads, feed-forward 10, depth 2; beam 3, length
+    normalisation 0.6, 10 steps) parsed and built by the REFERENCE: encoder, teacher-forced pass, greedy loop, the
+    batched beam search and what its rank-1 / rank-2 runners make of it, against the oracle."""
+    z, cfg, params = load("ini_beamsearch")
+    params = dict(params)
+    params["transformer_encoder_input/embedding_matrix_0"] = params["input/embedding_matrix_0"]   # [inpseq] name="input"
+    tcfg = T.TConfig(enc_name="transformer_encoder", dec_name="decoder", depth=2, n_heads=3, n_heads_self=3,
+                     n_heads_enc=2)
+    model = T.TransformerModel(params, tcfg)
+    src, tgt = z["in/src_ids"], z["in/tgt_ids"]
+    assert src.shape[1] <= 7 and tgt.shape[0] <= 3                     # max_length / max_output_len of the file
+    with torch.no_grad():
+        states, mask, _ = model.encode(src, False)
+        close(states, z["out/enc_states"], "encoder states")
+        same(mask.numpy(), z["out/enc_mask"], "encoder mask")
+        loss, logits = model.train_loss(src, tgt.T, train=False)
+        close(logits.transpose(0, 1), z["out/train_logits"], "train logits", 4e-6)
+        close(loss, z["out/train_loss"], "train loss")
+    syms, masks, run_logits = model.greedy(src, 3)
+    same(syms, z["out/runtime_symbols"], "greedy symbols")
+    same(masks, z["out/runtime_mask"], "runtime mask")
+    close(run_logits, z["out/runtime_logits"], "runtime logits", 4e-6)
+    k, max_steps = int(z["cfg/beam"][0]), int(z["cfg/beam"][1])
+    tok, scores, gap = model.beam(src, k, max_steps, 0.6)
+    assert gap > 1e-5
+    same(tok, z["out/beam_token_ids"], "beam token ids")
+    close(scores, z["out/beam_scores"], "beam scores", 4e-6)
+    tvoc = [str(w) for w in z["in/tgt_vocabulary"]]
+    for rank in (1, 2):
+        want = [str(x) for x in z["out/rank{}_sentences".format(rank)]]
+        for i, sent in enumerate(want):
+            ids = []
+            for t in tok[1:, i, rank - 1]:
+                if t == O.END:
+                    break
+                ids.append(int(t))
+            if tok.shape[0] > 1 and tok[1, i, rank - 1] == O.END:
+                continue                                   # beamsearch_runner.py:88-99 leaves raw ids: not a sentence
+            assert " ".join(tvoc[t] for t in ids) == sent
+        close(float(np.mean(scores[:, rank - 1])) * scores.shape[0], z["out/rank{}_loss".format(rank)], "runner loss",
+              4e-6)

@@ -149,3 +149,58 @@ def test_bahdanau_ini_on_the_engine_equals_the_reference_built_model(dev, ref_ro
     want_losses = fixture["out/runner_losses"]
     got_losses = [res.losses["{}/{}".format(runner.output_series, n)] for n in runner.loss_names]
     assert np.allclose(got_losses, want_losses, rtol=1e-5)
+
+
+def test_beamsearch_ini_on_the_engine_equals_the_reference_built_model(dev, ref_root):      # noqa: F811
+    """tests/beamsearch.ini (Transformer + BeamSearchDecoder + beam_search_runner_range) end to end on both sides: the
+    fixture ``ini_beamsearch`` is what the REFERENCE'S parser, builder and model parts gave for the first six sentence
+    pairs of the file's training data; the product loads the same file from the bundle, takes the reference's
+    variables under their own names and must give its encoder states, logits, greedy symbols, beam search and the
+    sentences / scores of its rank-1 and rank-2 runners."""
+    from neuralmonkey_amd.dataset import BatchingScheme, Dataset
+    fixture = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_exec",
+                                   "ini_beamsearch.npz"))
+    params = {k[2:]: fixture[k] for k in fixture.files if k.startswith("p/")}
+    model = load_verbatim(ref_root, "beamsearch", device=str(dev), seed=1234)
+    tfm = model.tf_manager
+    store = tfm.sessions[0].store
+    assert sorted(store.names()) == sorted(params), set(store.names()) ^ set(params)
+    store.load_state_dict(params)
+    unpad = lambda rows, drop: [[str(t) for t in row if str(t) not in drop] for row in rows]
+    batch = Dataset("fixture", {"source": unpad(fixture["in/src_tokens"], ("<pad>",)),
+                                "target": unpad(fixture["in/tgt_tokens"], ("<pad>", "</s>"))},
+                    BatchingScheme(batch_size=int(fixture["in/src_ids"].shape[0])))
+    runners = model.runners
+    assert [r.rank for r in runners] == [1, 2]
+    bdec = runners[0].decoder
+    dec = bdec.parent_decoder
+    enc = dec.encoders[0]
+    feedables = set.union(*[r.feedables for r in runners])
+    fd = {}
+    for part in feedables:
+        fd.update(part.feed_dict(batch, train=False))
+    out = tfm.sessions[0].run({"enc": enc.temporal_states, "train_logits": dec.train_logits, "sym": dec.decoded_symbols,
+                               "logits": dec.runtime_logits, "bs": bdec.outputs}, fd)
+
+    def close(got, want, what, tol=1e-4):
+        got, want = np.asarray(got), np.asarray(want)
+        assert got.shape == want.shape, (what, got.shape, want.shape)
+        err = np.abs(got - want).max()
+        assert err <= tol * max(np.abs(want).max(), 1e-6), "{}: {:.3e}".format(what, err)
+    close(out["enc"], fixture["out/enc_states"], "encoder states")
+    close(out["train_logits"], fixture["out/train_logits"], "train logits")
+    assert np.array_equal(np.asarray(out["sym"]), fixture["out/runtime_symbols"])
+    close(out["logits"], fixture["out/runtime_logits"], "runtime logits")
+    tok = np.asarray(out["bs"].last_search_step_output.token_ids)
+    assert np.array_equal(tok[1:], fixture["out/beam_token_ids"][1:])
+    close(np.asarray(out["bs"].last_search_step_output.scores), fixture["out/beam_scores"], "beam scores")
+    res = tfm.execute(batch, feedables, runners, compute_losses=False)
+    for rank, r in zip((1, 2), res):
+        want = [str(s) for s in fixture["out/rank{}_sentences".format(rank)]]
+        got = [" ".join(s) for s in r.outputs[runners[rank - 1].output_series]]
+        for g, w, first in zip(got, want, fixture["out/beam_token_ids"][1, :, rank - 1]):
+            if first != 2:                        # (a hypothesis that starts with </s>: raw ids in the reference)
+                assert g == w
+        loss_name = "{}/beam_search_score".format(runners[rank - 1].output_series)
+        assert abs(r.losses[loss_name] - float(fixture["out/rank{}_loss".format(rank)])) <= \
+            1e-4 * abs(float(fixture["out/rank{}_loss".format(rank)]))
