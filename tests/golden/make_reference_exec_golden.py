@@ -1450,6 +1450,56 @@ def run_ini_beamsearch(case, rows=6):
     save(case, {"kind": "ini", "ini": "beamsearch", "batch": rows}, out)
 
 
+def run_ini_factored(case, rows=6):
+    """tests/factored.ini (FactoredEncoder over word forms and tags, ScaledDotProdAttention with one head, GRU decoder
+    of size 32) built by the reference's parser and builder from the file as it is; like tests/beamsearch.ini its
+    datasets lean on ``main.batch_size``, so the batch is the first ``rows`` lines of the file's training data."""
+    import collections.abc
+    collections.Iterable = collections.abc.Iterable
+    from neuralmonkey.config import parsing
+    from neuralmonkey.config.builder import ObjectRef, build_config
+    from neuralmonkey.readers.plain_text_reader import UtfPlainTextReader
+    cwd = os.getcwd()
+    os.chdir(REFERENCE)
+    try:
+        fresh_graph()
+        with open(os.path.join("tests", "factored.ini"), encoding="utf-8") as handle:
+            _, parsed = parsing.parse_file(handle.read().splitlines(True))
+        names, files = parsed["train_data"]["series"], parsed["train_data"]["data"]
+        parsed["main"] = collections.OrderedDict((key, ObjectRef(key)) for key in ("encoder", "attention", "decoder",
+                                                                                   "runner"))
+        built, _ = build_config(parsed, ignore_names=set())
+        enc, att, dec, runner = built["encoder"], built["attention"], built["decoder"], built["runner"]
+        series = {name: list(UtfPlainTextReader([path]))[:rows] for name, path in zip(names, files)}
+        ds = dataset(series)
+        inputs = string_inputs("source", "tags", "target")
+        out = {}
+        with tf_eager.feeding(feed([enc, enc.input_sequence, att, dec], ds, False, inputs)):
+            out["in/src_tokens"] = enc.input_sequence.input_factors[0].numpy()
+            out["in/tag_tokens"] = enc.input_sequence.input_factors[1].numpy()
+            out["in/src_ids"] = enc.input_sequence.input_factor_indices[0].numpy()
+            out["in/tag_ids"] = enc.input_sequence.input_factor_indices[1].numpy()
+            out["in/tgt_tokens"] = dec.train_tokens.numpy()
+            out["in/tgt_ids"] = dec.train_inputs.numpy()
+            out["out/enc_states"] = enc.temporal_states.numpy()
+            out["out/enc_output"] = enc.output.numpy()
+            out["out/train_logits"] = dec.train_logits.numpy()
+            out["out/train_loss"] = dec.train_loss.numpy()
+            out["out/runtime_logits"] = dec.runtime_logits.numpy()
+            out["out/runtime_symbols"] = dec.runtime_loop_result.histories.output_symbols.numpy()
+            out["out/runtime_mask"] = dec.runtime_mask.numpy()
+            ex = runner.get_executable(compute_losses=True, summaries=False, num_sessions=1)
+            fetches, _ = ex.next_to_execute()
+            ex.collect_results([to_numpy(fetches)])
+            out["out/runner_sentences"] = np.asarray([joined(sent) for sent in ex.result.outputs["target"]])
+            out["out/runner_losses"] = np.asarray([ex.result.losses["target/train_xent"],
+                                                   ex.result.losses["target/runtime_xent"]], np.float32)
+        out["in/tgt_vocabulary"] = np.asarray(list(dec.vocabulary.index_to_word))
+    finally:
+        os.chdir(cwd)
+    save(case, {"kind": "ini", "ini": "factored", "batch": rows}, out)
+
+
 def run_defects(case):
     """Configurations the reference cannot execute at this commit: the exception IS the reference behaviour."""
     import traceback
@@ -1562,6 +1612,7 @@ CASES = collections.OrderedDict([
         [("encoder", "encoder"), ("attention", "attention"), ("decoder", "decoder"), ("runner", "runner"),
          ("train_data", "train_data")]))),
     ("ini_beamsearch", lambda: run_ini_beamsearch("ini_beamsearch")),
+    ("ini_factored", lambda: run_ini_factored("ini_factored")),
     ("schedules", lambda: run_schedules("schedules")),
     ("ini_grammar", lambda: run_ini_grammar("ini_grammar")),
     ("config_builder", lambda: run_config_builder("config_builder")),

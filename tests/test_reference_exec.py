@@ -65,7 +65,7 @@ def test_every_generated_case_is_checked_here():
     have = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(FIX, "*.npz")))
     checked = sorted(["functions", "defects", "ensemble", "greedy_runner_ensemble", "dataset_batching",
                       "vocabulary_formats", "host_text_pipeline", "schedules", "ini_grammar", "config_builder",
-                      "dataset_loading", "ini_bahdanau", "ini_beamsearch"]
+                      "dataset_loading", "ini_bahdanau", "ini_beamsearch", "ini_factored"]
                      + BEAM_BODY_CASES + RNN_CASES + TRANSFORMER_CASES
                      + VARIANT_CASES + FD_CASES)
     assert have == checked
@@ -890,3 +890,34 @@ def test_the_reference_built_beamsearch_ini_equals_the_oracle():
             assert " ".join(tvoc[t] for t in ids) == sent
         close(float(np.mean(scores[:, rank - 1])) * scores.shape[0], z["out/rank{}_loss".format(rank)], "runner loss",
               4e-6)
+
+
+def test_the_reference_built_factored_ini_equals_the_oracle():
+    """tests/factored.ini (FactoredEncoder over forms + tags with embeddings 20 + 10 and GRU 16, max_input_len 10;
+    ScaledDotProdAttention; Decoder GRU 32, max_output_len 10) parsed and built by the REFERENCE on the first six
+    lines of its training data: encoder, teacher-forced pass, greedy loop and the GreedyRunner's sentences and losses
+    against the oracle."""
+    z, cfg, params = load("ini_factored")
+    gcfg = G.Config(enc_name="factored_encoder", dec_name="decoder", att_name="attention_sentence_encoder",
+                    rnn_layers=((16, "bidirectional", "GRU"),), rnn_size=32)
+    model = D.DotProdModel(params, gcfg, 1)
+    ids = np.stack([z["in/src_ids"], z["in/tag_ids"]])
+    tgt = z["in/tgt_ids"]
+    assert ids.shape[2] <= 10 and tgt.shape[0] <= 10
+    with torch.no_grad():
+        states, _, final = model.encode(ids, False)
+        close(states, z["out/enc_states"], "encoder states")
+        close(final, z["out/enc_output"], "encoder output")
+        loss, logits, _ = model.train_loss(ids, tgt, train=False)
+    close(logits, z["out/train_logits"], "train logits", 4e-6)
+    close(loss, z["out/train_loss"], "train loss")
+    syms, masks, run_logits = model.greedy(ids, 10)
+    same(syms, z["out/runtime_symbols"], "greedy symbols")
+    same(masks, z["out/runtime_mask"], "runtime mask")
+    close(run_logits, z["out/runtime_logits"], "runtime logits", 4e-6)
+    tvoc = [str(w) for w in z["in/tgt_vocabulary"]]
+    amax = torch.log_softmax(torch.tensor(run_logits), -1).numpy().argmax(-1)
+    got = [" ".join(tvoc[i] for i in sent) for sent in O.greedy_tokens(O.DecodeResult(run_logits, None, amax, None, None,
+                                                                                      None, None))]
+    assert got == [str(s) for s in z["out/runner_sentences"]]
+    close(float(loss), z["out/runner_losses"][0], "runner train_xent")
