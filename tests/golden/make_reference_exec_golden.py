@@ -1329,6 +1329,7 @@ def run_ini(case, ini_name, wanted, decoder_key="decoder", encoder_key="encoder"
     from neuralmonkey.config.builder import ObjectRef, build_config
     cwd = os.getcwd()
     os.chdir(REFERENCE)                          # the file's data paths are relative to the repository root
+    os.environ.setdefault("NM_EXPERIMENT_NAME", "small")       # tests/tests_run.sh:33 (tests/small.ini reads it)
     try:
         fresh_graph()
         with open(os.path.join("tests", ini_name + ".ini"), encoding="utf-8") as handle:
@@ -1613,6 +1614,9 @@ CASES = collections.OrderedDict([
          ("train_data", "train_data")]))),
     ("ini_beamsearch", lambda: run_ini_beamsearch("ini_beamsearch")),
     ("ini_factored", lambda: run_ini_factored("ini_factored")),
+    ("ini_small", lambda: run_ini("ini_small", "small", collections.OrderedDict(
+        [("encoder", "my_encoder"), ("attention", "my_attention"), ("decoder", "my_decoder"), ("runner", "runner"),
+         ("data", "val_data")]), dataset_key="data")),
     ("schedules", lambda: run_schedules("schedules")),
     ("ini_grammar", lambda: run_ini_grammar("ini_grammar")),
     ("config_builder", lambda: run_config_builder("config_builder")),

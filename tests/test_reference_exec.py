@@ -65,7 +65,7 @@ def test_every_generated_case_is_checked_here():
     have = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(FIX, "*.npz")))
     checked = sorted(["functions", "defects", "ensemble", "greedy_runner_ensemble", "dataset_batching",
                       "vocabulary_formats", "host_text_pipeline", "schedules", "ini_grammar", "config_builder",
-                      "dataset_loading", "ini_bahdanau", "ini_beamsearch", "ini_factored"]
+                      "dataset_loading", "ini_bahdanau", "ini_beamsearch", "ini_factored", "ini_small"]
                      + BEAM_BODY_CASES + RNN_CASES + TRANSFORMER_CASES
                      + VARIANT_CASES + FD_CASES)
     assert have == checked
@@ -921,3 +921,32 @@ def test_the_reference_built_factored_ini_equals_the_oracle():
                                                                                       None, None))]
     assert got == [str(s) for s in z["out/runner_sentences"]]
     close(float(loss), z["out/runner_losses"][0], "runner train_xent")
+
+
+def test_the_reference_built_small_ini_equals_the_oracle():
+    """tests/small.ini built by the REFERENCE: the model parts take their NAMES from their sections (``my_encoder``,
+    ``my_attention``, ``my_decoder``: builder.py:159-176), NematusGRU encoder (7, max_input_len 5) and conditional
+    NematusGRU decoder (9, max_output_len 1); first batch of its bucketed validation data, train_mode False."""
+    z, cfg, params = load("ini_small")
+    gcfg = G.Config(enc_name="my_encoder", dec_name="my_decoder", att_name="my_attention",
+                    rnn_layers=((7, "bidirectional", "NematusGRU"),), dec_cell="NematusGRU", conditional_gru=True,
+                    rnn_size=9)
+    model = G.GeneralModel(params, gcfg)
+    src, tgt = z["in/src_ids"], z["in/tgt_ids"]
+    assert src.shape[1] <= 5 and tgt.shape[0] == 1
+    with torch.no_grad():
+        states, mask, final = model.encode(src, False)
+        close(states, z["out/enc_states"], "encoder states")
+        same(mask.numpy(), z["out/enc_mask"], "encoder mask")
+        close(final, z["out/enc_output"], "encoder output")
+        loss, logits, _ = model.train_loss(src, tgt, train=False)
+    close(logits, z["out/train_logits"], "train logits")
+    close(loss, z["out/train_loss"], "train loss")
+    syms, masks, run_logits = model.greedy(src, 1)
+    same(syms, z["out/runtime_symbols"], "greedy symbols")
+    close(run_logits, z["out/runtime_logits"], "runtime logits")
+    tvoc = [str(w) for w in z["in/tgt_vocabulary"]]
+    amax = torch.log_softmax(torch.tensor(run_logits), -1).numpy().argmax(-1)
+    got = [" ".join(tvoc[i] for i in sent) for sent in O.greedy_tokens(O.DecodeResult(run_logits, None, amax, None, None,
+                                                                                      None, None))]
+    assert got == [str(s) for s in z["out/runner_sentences"]]
