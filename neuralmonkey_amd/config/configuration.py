@@ -31,7 +31,12 @@ class Configuration:
         self.args = Namespace(**{**self.defaults, **{k: v for k, v in main.items()}})
 
     def build_model(self, warn_unused: bool = False) -> Namespace:
-        built, objects = build_config(self.config_dict, self.ignored, warn_unused)
+        from .. import dataset
+        dataset._MAIN_BATCH_SIZE.append(getattr(self.args, "batch_size", None))       # dataset.load's default scheme
+        try:
+            built, objects = build_config(self.config_dict, self.ignored, warn_unused)
+        finally:
+            dataset._MAIN_BATCH_SIZE.pop()
         self.objects = objects
         self.model = Namespace(**{**self.defaults, **built})
         return self.model

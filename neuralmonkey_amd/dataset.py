@@ -131,6 +131,11 @@ def _expand(patterns: Union[str, List[str]]) -> List[str]:
     return paths
 
 
+# [main] batch_size of the configuration that is being built right now (innermost last): what the reference reads
+# through ``Experiment.get_current().config.args.batch_size`` (dataset.py:237-246).  Pushed by config.Configuration.
+_MAIN_BATCH_SIZE: List[Any] = []
+
+
 def load(name: str, series: List[str], data: List[Any], batching: BatchingScheme = None,
          outputs: List[Tuple] = None, buffer_size: int = None, shuffled: bool = False) -> Dataset:
     """dataset.py:207-333.  A series is given by one of
@@ -147,6 +152,12 @@ def load(name: str, series: List[str], data: List[Any], batching: BatchingScheme
         if isinstance(spec, (str, list)):
             return True
         return isinstance(spec, tuple) and len(spec) == 2 and isinstance(spec[0], (str, list)) and callable(spec[1])
+    # a dataset section without ``batching`` batches by [main] batch_size (dataset.py:237-246); outside a
+    # configuration the scheme stays open and ``batches`` asks for one
+    if batching is None and _MAIN_BATCH_SIZE:
+        if _MAIN_BATCH_SIZE[-1] is None:
+            raise ValueError("Argument main.batch_size is not specified, cannot use default batching scheme.")
+        batching = BatchingScheme(batch_size=_MAIN_BATCH_SIZE[-1])
     # the checks of dataset.py:246-266, in the reference's order and with its texts
     if not series:
         raise ValueError("No dataset series specified.")

@@ -105,6 +105,14 @@ class Parameterized:
             init = _wrap_foreign_init(init)
         store.declare(full, shape, init, trainable)
 
+    def declare_checkpoint_only(self, store, local: str, shape, initializer: Optional[Initializer] = None) -> None:
+        """A variable of this part's scope that only checkpoints know (VariableStore.declare_checkpoint_only)."""
+        full = self.var_name(local)
+        init = self._initializer_overrides.get(full, initializer or self._default_initializer)
+        if callable(init) and not _is_rng_init(init):
+            init = _wrap_foreign_init(init)
+        store.declare_checkpoint_only(full, shape, init)
+
     def declare_variables(self, store) -> None:
         """Declare every variable of this part in ``store`` (overridden)."""
 

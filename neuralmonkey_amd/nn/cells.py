@@ -85,6 +85,14 @@ class NematusGRUCell(Cell):
                 self.part.declare(store, self._n(block + "/input_proj/bias"), (width,), zeros_initializer())
             if self.use_state_bias:
                 self.part.declare(store, self._n(block + "/state_proj/bias"), (width,), zeros_initializer())
+        # NematusGRUCell overrides GRUCell.call and inherits GRUCell.build (nn/ortho_gru_cell.py:57-72): TensorFlow
+        # creates the plain cell's four variables in the cell's scope as well, no computation reads them, and every
+        # checkpoint of the reference holds them (kernels from the scope's initializer: no kernel_initializer is
+        # passed; gates bias 1, candidate bias 0)
+        self.part.declare_checkpoint_only(store, self._n("gates/kernel"), (d + h, 2 * h))
+        self.part.declare_checkpoint_only(store, self._n("gates/bias"), (2 * h,), constant_initializer(1.0))
+        self.part.declare_checkpoint_only(store, self._n("candidate/kernel"), (d + h, h))
+        self.part.declare_checkpoint_only(store, self._n("candidate/bias"), (h,), zeros_initializer())
 
     def _proj(self, tape, block, which, inp, use_bias, out=None, accumulate=False):
         w = tape.param(self.part, self._n("{}/{}_proj/kernel".format(block, which)))

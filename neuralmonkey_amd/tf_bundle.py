@@ -19,9 +19,10 @@ Validation status: CRC-32C and the varint / protobuf / SSTable encoders are chec
 published known answers and by write -> read round trips (tests/test_host.py); no TensorFlow-written
 file exists in the reference repository to read, so interoperability with TF itself is untested.
 
-Shape conventions that differ from the flat store: ``attn_key_projection`` and SpatialFiller
-``conv2d*/kernel`` are [1,1,in,out] conv filters in TF ([in,out] here), ``attn_bias`` is a scalar
-([1] here).  Import accepts any TF shape with the same element order (extra unit dimensions);
+Shape conventions that differ from the flat store: SpatialFiller's ``conv2d*/kernel`` are [1,1,in,out]
+conv filters in TF ([in,out] here), ``attn_bias`` / ``attn_bias_<i>`` / ``vector_bias`` are scalars ([1] here),
+``attn_v`` is [1,1,n] ([n] here) -- pinned to the variables the reference itself creates for its acceptance
+configurations (tests/test_reference_inis.py).  Import accepts any TF shape with the same element order (extra unit dimensions);
 export writes the TF shapes.  Adam slots (``<var>/Adam``, ``<var>/Adam_1``), ``beta1_power``,
 ``beta2_power`` and ``global_step`` are carried when present / requested.
 """
@@ -294,8 +295,10 @@ def tf_shape(name: str, shape: Tuple[int, ...]) -> Tuple[int, ...]:
         return ()
     if leaf == "attn_v" and len(shape) == 1:          # combination.py:66-70: [1, 1, attention_state_size]
         return (1, 1) + tuple(shape)
+    # tf.layers.conv2d filters of SpatialFiller's 1x1 projections.  (Attention's attn_key_projection is created
+    # [in, out] and expanded inside the graph: attention/feed_forward.py:77-82,108-113.)
     conv_kernel = len(parts) >= 2 and parts[-1] == "kernel" and parts[-2].startswith("conv2d")
-    if len(shape) == 2 and (name.endswith("attn_key_projection") or conv_kernel):
+    if len(shape) == 2 and conv_kernel:
         return (1, 1) + tuple(shape)
     return tuple(shape)
 
@@ -305,6 +308,14 @@ def export_store(store, prefix: str, global_step: Optional[int] = None, with_ada
     tensors = {}
     for name, arr in store.state_dict().items():
         tensors[name] = np.asarray(arr, np.float32).reshape(tf_shape(name, arr.shape))
+    # variables of the reference's graph that nothing reads (VariableStore.declare_checkpoint_only): a Saver over all
+    # global variables expects their keys -- and, being trainable, their Adam slots
+    extras = store.checkpoint_only_values()
+    tensors.update(extras)
+    if with_adam and store.adam_m is not None:
+        for name, arr in extras.items():
+            tensors[name + "/Adam"] = np.zeros_like(arr)
+            tensors[name + "/Adam_1"] = np.zeros_like(arr)
     if with_adam and store.adam_m is not None:
         m, v = store.adam_m.cpu().numpy(), store.adam_v.cpu().numpy()
         for name, spec in store.specs.items():
@@ -344,7 +355,9 @@ def import_store(store, prefix: str, strict: bool = True) -> Dict[str, object]:
                 np.asarray(bundle[name + "/Adam"], np.float32).reshape(-1)).to(m.device)
             v[spec.offset:spec.offset + spec.size] = torch.from_numpy(
                 np.asarray(bundle[name + "/Adam_1"], np.float32).reshape(-1)).to(v.device)
-    known = set(values) | {n + s for n in values for s in ("/Adam", "/Adam_1")}
+    extras = store.take_checkpoint_only(bundle)
+    known = set(values) | set(extras)
+    known |= {n + s for n in known for s in ("/Adam", "/Adam_1")}
     step = bundle.get("global_step")
     return {"missing": missing, "unused": sorted(set(bundle) - known - {"global_step", "beta1_power", "beta2_power"}),
             "global_step": None if step is None else int(step)}

@@ -7,7 +7,7 @@ the optimizer step, the L1/L2 terms and the data-parallel all-reduce each touch
 one allocation (sized for 288 GB HBM: no per-tensor launches or collectives).
 """
 from collections import OrderedDict
-from typing import Callable, Dict, Optional, Tuple
+from typing import List, Callable, Dict, Optional, Tuple
 
 import numpy as np
 import torch
@@ -85,6 +85,9 @@ class VariableStore:
         self.epoch = 0          # bumped by whoever writes the variables through raw pointers (Session.variables_changed)
         self._views: Dict[str, torch.Tensor] = {}
         self._gviews: Dict[str, torch.Tensor] = {}
+        # variables the reference's graph creates and no computation reads (declare_checkpoint_only)
+        self.checkpoint_only: "OrderedDict[str, VarSpec]" = OrderedDict()
+        self._checkpoint_values: Dict[str, np.ndarray] = {}
 
     # -- declaration ---------------------------------------------------------
     def declare(self, name: str, shape, init: Initializer, trainable: bool = True) -> None:
@@ -97,6 +100,36 @@ class VariableStore:
                 raise ValueError(f"variable {name} re-declared with shape {spec.shape} != {old.shape}")
             return
         self.specs[name] = spec
+
+    def declare_checkpoint_only(self, name: str, shape, init: Initializer) -> None:
+        """A variable that exists in the reference's checkpoints and that nothing ever reads (TensorFlow's
+        ``GRUCell.build`` creates ``gates/kernel`` ... under ``NematusGRUCell``, which overrides ``call`` only:
+        nn/ortho_gru_cell.py:57-105).  It takes no room in the flat buffers and no part in a step; checkpoints carry
+        it -- written so that a Saver of the reference finds every key it restores, read back when a file has it."""
+        if name in self.specs:
+            raise ValueError(f"{name} is a variable of the model already")
+        self.checkpoint_only.setdefault(name, VarSpec(name, shape, init, True))
+
+    def checkpoint_only_values(self) -> Dict[str, np.ndarray]:
+        """name -> array of the checkpoint-only variables: what a checkpoint brought, else their initial values (drawn
+        from a generator of their own, so that they leave the model's initialisation stream alone)."""
+        rng = np.random.default_rng([0 if self.seed is None else int(self.seed), 0xC0FFEE])
+        for name, spec in self.checkpoint_only.items():
+            fresh = np.asarray(spec.init(rng, spec.shape), dtype=np.float32).reshape(spec.shape)
+            self._checkpoint_values.setdefault(name, fresh)
+        return {name: self._checkpoint_values[name] for name in self.checkpoint_only}
+
+    def take_checkpoint_only(self, values) -> List[str]:
+        """Keep the checkpoint-only variables found in ``values`` (name -> array); returns their names."""
+        taken = []
+        for name, spec in self.checkpoint_only.items():
+            if name in values:
+                arr = np.asarray(values[name], dtype=np.float32)
+                if arr.size != spec.size:
+                    raise ValueError(f"{name}: checkpoint shape {arr.shape} != {spec.shape}")
+                self._checkpoint_values[name] = arr.reshape(spec.shape).copy()
+                taken.append(name)
+        return taken
 
     def finalize(self) -> None:
         off = 0
@@ -176,6 +209,7 @@ class VariableStore:
             tf_bundle.export_store(self, path, global_step=global_step, with_adam=self.adam_m is not None)
             return
         arrays = {k.replace("/", "|"): v for k, v in self.state_dict().items()}
+        arrays.update({k.replace("/", "|"): v for k, v in self.checkpoint_only_values().items()})
         if self.adam_m is not None:
             m, v = self.adam_m.cpu().numpy(), self.adam_v.cpu().numpy()
             for name, spec in self.specs.items():
@@ -197,6 +231,7 @@ class VariableStore:
         with np.load(path) as data:
             values = {k.replace("|", "/"): data[k] for k in data.files}
         self.load_state_dict(values, strict)
+        self.take_checkpoint_only(values)
         names = [n for n in self.specs if n in values]
         if names and all(n + "/Adam" in values and n + "/Adam_1" in values for n in names):
             m, v = self.ensure_adam()

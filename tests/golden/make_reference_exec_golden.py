@@ -1041,6 +1041,51 @@ TEXT_FILES = {
 }
 
 
+def edit_pairs():
+    """Seeded sentence pairs over a five-word alphabet (many equally cheap alignments), with the empty sentence, equal
+    sentences, disjoint ones, and the two special tokens occurring as ordinary words."""
+    rng = np.random.default_rng(77)
+    words = ["a", "b", "c", "d", "e"]
+    pairs = [([], []), ([], ["a", "b"]), (["a", "b"], []), (["a"], ["a"]), (["a", "b", "c"], ["a", "b", "c"]),
+             (["a", "b"], ["c", "d"]), (["a", "a", "a"], ["a"]), (["a"], ["a", "a", "a"]),
+             (["<keep>", "a"], ["a", "<delete>"]), (["a", "b", "a", "b"], ["b", "a", "b", "a"])]
+    for _ in range(150):
+        pairs.append(([words[i] for i in rng.integers(0, 5, rng.integers(0, 9))],
+                      [words[i] for i in rng.integers(0, 5, rng.integers(0, 9))]))
+    return pairs
+
+
+def run_editops(case):
+    """processors/editops.py (the post-editing scripts of tests/post-edit.ini; no TensorFlow): ``convert_to_edits``
+    on seeded pairs, ``reconstruct`` on those scripts, on scripts cut short (the decoder's length limit) and on
+    scripts that keep / delete beyond the end of the sentence; ``Preprocess`` / ``Postprocess`` as the dataset and
+    [main] call them, and the errors of ``Postprocess``."""
+    fresh_graph()                 # (no variables of an earlier case in this fixture)
+    from neuralmonkey.processors import editops as E
+    pairs = edit_pairs()
+    join = lambda rows: np.asarray(["\x1f".join(r) for r in rows])
+    scripts = [E.convert_to_edits(list(a), list(b)) for a, b in pairs]
+    out = {"in/source": join([a for a, _ in pairs]), "in/target": join([b for _, b in pairs]),
+           "out/scripts": join(scripts),
+           "out/rebuilt": join([E.reconstruct(list(a), list(sc)) for (a, _), sc in zip(pairs, scripts)]),
+           "out/rebuilt_cut": join([E.reconstruct(list(a), list(sc[:len(sc) // 2])) for (a, _), sc in zip(pairs, scripts)]),
+           "out/rebuilt_long": join([E.reconstruct(list(a), list(sc) + ["<keep>", "z", "<delete>", "<keep>"])
+                                     for (a, _), sc in zip(pairs, scripts)])}
+    series = {"mt": lambda: iter([list(a) for a, _ in pairs]), "pe": lambda: iter([list(b) for _, b in pairs])}
+    out["out/preprocess"] = join(list(E.Preprocess("mt", "pe")(series)))
+    post = E.Postprocess("mt", "edits")
+    out["out/postprocess"] = join(post({"mt": [list(a) for a, _ in pairs]}, {"edits": scripts}))
+    errors = []
+    for dataset, generated in (({}, {"edits": []}), ({"mt": []}, {})):
+        try:
+            post(dataset, generated)
+            errors.append("")
+        except Exception as exc:        # noqa: BLE001
+            errors.append("{}: {}".format(type(exc).__name__, exc))
+    out["out/errors"] = np.asarray(errors)
+    save(case, {"kind": "editops"}, out)
+
+
 def run_host_text_pipeline(case):
     """Readers and string processors of the reference, none of which touches TensorFlow: plain_text_reader.py:23-134
     (whitespace tokens, the tensor2tensor tokenizer, column readers), string_vector_reader.py:6-40,
@@ -1316,6 +1361,18 @@ def run_dataset_loading(case):
     save(case, {"kind": "dataset_loading", "files": LOAD_FILES}, out)
 
 
+def experiment_stand_in(batch_size):
+    """What ``Experiment.get_current()`` answers while a configuration is being built: the reference's own
+    ``_DummyExperiment`` (the initializer registry of model parts created outside a run, experiment.py:494-523) plus
+    the one number of [main] that a dataset section without ``batching`` reads (dataset.py:237-246).  The Experiment
+    proper -- output directories, logging, the training loop -- is host control plane."""
+    from argparse import Namespace
+    from neuralmonkey.experiment import _DummyExperiment
+    stand_in = _DummyExperiment()
+    stand_in.config = Namespace(args=Namespace(batch_size=batch_size))
+    return stand_in
+
+
 def run_ini(case, ini_name, wanted, decoder_key="decoder", encoder_key="encoder", attention_key="attention",
             runner_key="runner", dataset_key="train_data"):
     """One of the reference's own acceptance configurations (tests/<ini_name>.ini), built by the reference's parser
@@ -1334,8 +1391,15 @@ def run_ini(case, ini_name, wanted, decoder_key="decoder", encoder_key="encoder"
         fresh_graph()
         with open(os.path.join("tests", ini_name + ".ini"), encoding="utf-8") as handle:
             _, parsed = parsing.parse_file(handle.read().splitlines(True))
+        # a dataset section without ``batching`` takes main.batch_size from the experiment being built
+        # (dataset.py:237-246); the Experiment itself is host control plane, so only that one number stands in
+        from neuralmonkey.experiment import Experiment
+        Experiment._current_experiment = experiment_stand_in(parsed["main"].get("batch_size"))
         parsed["main"] = collections.OrderedDict((key, ObjectRef(section)) for key, section in wanted.items())
-        built, _ = build_config(parsed, ignore_names=set())
+        try:
+            built, _ = build_config(parsed, ignore_names=set())
+        finally:
+            Experiment._current_experiment = None
         enc, att, dec = built[encoder_key], built[attention_key], built[decoder_key]
         runner, data = built[runner_key], built[dataset_key]
         batch = next(iter(data.batches()))
@@ -1368,6 +1432,68 @@ def run_ini(case, ini_name, wanted, decoder_key="decoder", encoder_key="encoder"
     finally:
         os.chdir(cwd)
     save(case, {"kind": "ini", "ini": ini_name, "batch": int(out["in/src_ids"].shape[0])}, out)
+
+
+INI_VARIABLE_FILES = ["small", "bahdanau", "factored", "post-edit", "beamsearch", "transformer", "flat-multiattention",
+                      "nematus"]
+
+
+def run_ini_variables(case):
+    """The variable-name contract of a checkpoint (parameterized.py:68-125, tf_manager.py:274-277): for
+    each of the reference's acceptance configurations, the runners of [main] and the training data are built by the
+    reference's parser and builder from the file as it is, every runner's fetches and every decoder's training loss
+    are evaluated once on the first batch -- which is when the reference's lazily built model creates its variables
+    -- and the names and shapes of all variables are recorded (the optimizer's slots belong to TensorFlow's trainers
+    and are not built).  A file the reference itself refuses to build is recorded with its error."""
+    import collections.abc
+    collections.Iterable = collections.abc.Iterable
+    from neuralmonkey.config import parsing
+    from neuralmonkey.config.builder import build_config
+    from neuralmonkey.experiment import Experiment
+    cwd = os.getcwd()
+    os.chdir(REFERENCE)
+    os.environ.setdefault("NM_EXPERIMENT_NAME", "small")
+    out = {}
+    try:
+        for ini in INI_VARIABLE_FILES:
+            fresh_graph()
+            with open(os.path.join("tests", ini + ".ini"), encoding="utf-8") as handle:
+                _, parsed = parsing.parse_file(handle.read().splitlines(True))
+            main = parsed["main"]
+            Experiment._current_experiment = experiment_stand_in(main.get("batch_size"))
+            parsed["main"] = collections.OrderedDict([("runners", main["runners"]),
+                                                      ("train_dataset", main["train_dataset"])])
+            try:
+                built, _ = build_config(parsed, ignore_names=set())
+            except Exception as exc:        # noqa: BLE001
+                inner = getattr(exc, "original_exception", exc)
+                out["out/" + ini] = np.asarray(json.dumps({"error": {
+                    "type": type(inner).__name__, "text": str(inner), "section": str(getattr(exc, "object_name", ""))}}))
+                continue
+            finally:
+                Experiment._current_experiment = None
+            runners = built["runners"]
+            batch = next(iter(built["train_dataset"].batches()))
+            feedables = sorted(set.union(*[set(r.feedables) for r in runners]), key=lambda f: str(getattr(f, "name", "")))
+            inputs = {}
+            for part in feedables:
+                for series, dtype in part.input_types.items():
+                    if series not in inputs:
+                        inputs[series] = tf.placeholder(dtype, part.input_shapes[series], series)
+            with tf_eager.feeding(feed(feedables, batch, False, inputs)):
+                for runner in runners:
+                    ex = runner.get_executable(compute_losses=True, summaries=False, num_sessions=1)
+                    ex.next_to_execute()
+                    decoder = getattr(runner, "decoder", None)
+                    for part in (decoder, getattr(decoder, "parent_decoder", None)):
+                        if part is not None and hasattr(type(part), "train_loss"):
+                            part.train_loss      # noqa: B018  (the trainer's fetch: creates what only training reads)
+            order, params = variables()
+            out["out/" + ini] = np.asarray(json.dumps({"variables": [[n, list(params[n].shape)] for n in order]}))
+    finally:
+        os.chdir(cwd)
+    fresh_graph()
+    save(case, {"kind": "ini_variables", "files": INI_VARIABLE_FILES}, out)
 
 
 def run_ini_beamsearch(case, rows=6):
@@ -1609,6 +1735,7 @@ CASES = collections.OrderedDict([
         heads_hier=4, seed=35, per_variable=2)),
     ("vocabulary_formats", lambda: run_vocabulary_formats("vocabulary_formats")),
     ("host_text_pipeline", lambda: run_host_text_pipeline("host_text_pipeline")),
+    ("editops", lambda: run_editops("editops")),
     ("ini_bahdanau", lambda: run_ini("ini_bahdanau", "bahdanau", collections.OrderedDict(
         [("encoder", "encoder"), ("attention", "attention"), ("decoder", "decoder"), ("runner", "runner"),
          ("train_data", "train_data")]))),
@@ -1617,6 +1744,7 @@ CASES = collections.OrderedDict([
     ("ini_small", lambda: run_ini("ini_small", "small", collections.OrderedDict(
         [("encoder", "my_encoder"), ("attention", "my_attention"), ("decoder", "my_decoder"), ("runner", "runner"),
          ("data", "val_data")]), dataset_key="data")),
+    ("ini_variables", lambda: run_ini_variables("ini_variables")),
     ("schedules", lambda: run_schedules("schedules")),
     ("ini_grammar", lambda: run_ini_grammar("ini_grammar")),
     ("config_builder", lambda: run_config_builder("config_builder")),

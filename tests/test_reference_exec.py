@@ -65,7 +65,9 @@ def test_every_generated_case_is_checked_here():
     have = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(FIX, "*.npz")))
     checked = sorted(["functions", "defects", "ensemble", "greedy_runner_ensemble", "dataset_batching",
                       "vocabulary_formats", "host_text_pipeline", "schedules", "ini_grammar", "config_builder",
-                      "dataset_loading", "ini_bahdanau", "ini_beamsearch", "ini_factored", "ini_small"]
+                      "dataset_loading", "ini_bahdanau", "ini_beamsearch", "ini_factored", "ini_small",
+                      "editops",              # below
+                      "ini_variables"]        # tests/test_reference_inis.py
                      + BEAM_BODY_CASES + RNN_CASES + TRANSFORMER_CASES
                      + VARIANT_CASES + FD_CASES)
     assert have == checked
@@ -950,3 +952,38 @@ def test_the_reference_built_small_ini_equals_the_oracle():
     got = [" ".join(tvoc[i] for i in sent) for sent in O.greedy_tokens(O.DecodeResult(run_logits, None, amax, None, None,
                                                                                       None, None))]
     assert got == [str(s) for s in z["out/runner_sentences"]]
+
+
+def test_post_editing_scripts_equal_the_reference_scripts():
+    """processors/editops.py of the reference (tests/post-edit.ini's dataset-level preprocessor and [main]
+    postprocessor; no TensorFlow in it) on 160 sentence pairs, most of them with several equally cheap alignments:
+    the PRODUCT'S ``processors.editops`` -- a cost table read back from its end instead of a script per table cell --
+    gives the same scripts, applies them the same way (also scripts cut short or running past the sentence), and
+    refuses missing series with the same words."""
+    from neuralmonkey_amd.processors import editops as E
+    z = np.load(os.path.join(FIX, "editops.npz"))
+    rows = lambda key: [r.split("\x1f") if r else [] for r in z[key].tolist()]
+    src, tgt, scripts = rows("in/source"), rows("in/target"), rows("out/scripts")
+    assert len(src) == 160 and any(s == [] for s in src) and any(t == [] for t in tgt)
+    assert [E.convert_to_edits(a, b) for a, b in zip(src, tgt)] == scripts
+    assert sum("<keep>" in s and "<delete>" in s and len(set(s) - {"<keep>", "<delete>"}) > 0 for s in scripts) > 50
+    rebuilt = [E.reconstruct(a, s) for a, s in zip(src, scripts)]
+    assert rebuilt == rows("out/rebuilt")
+    # a script applied to its sentence gives the target back -- unless the target holds one of the two operation
+    # names as a WORD (inserted, it is read as the operation: the reference's behaviour, pair 8 of the fixture)
+    plain = [i for i, t in enumerate(tgt) if not {"<keep>", "<delete>"} & set(t)]
+    assert len(plain) == len(tgt) - 1 and all(rebuilt[i] == tgt[i] for i in plain)
+    assert [E.reconstruct(a, s[:len(s) // 2]) for a, s in zip(src, scripts)] == rows("out/rebuilt_cut")
+    assert [E.reconstruct(a, s + ["<keep>", "z", "<delete>", "<keep>"])
+            for a, s in zip(src, scripts)] == rows("out/rebuilt_long")
+    series = {"mt": lambda: iter(src), "pe": lambda: iter(tgt)}
+    lazy = E.Preprocess("mt", "pe")(series)
+    assert iter(lazy) is lazy and list(lazy) == rows("out/preprocess") == scripts
+    post = E.Postprocess("mt", "edits")
+    assert post({"mt": src}, {"edits": scripts}) == rows("out/postprocess")
+    errors = []
+    for dataset, generated in (({}, {"edits": []}), ({"mt": []}, {})):
+        with pytest.raises(ValueError) as info:
+            post(dataset, generated)
+        errors.append("ValueError: {}".format(info.value))
+    assert errors == z["out/errors"].tolist()

@@ -92,15 +92,20 @@ def test_store_export_import(tmp_path):
     store.declare("attention/attn_bias", (1,), random_normal_initializer(stddev=0.5))
     store.declare("encoder/conv2d/kernel", (5, 4), random_normal_initializer(stddev=0.5))
     store.declare("decoder/state_to_word_b", (9,), zeros_initializer())
+    # a variable of the reference's graph that nothing reads (GRUCell.build's kernel under NematusGRUCell)
+    store.declare_checkpoint_only("encoder/nematus_gru_cell/gates/kernel", (3, 4), random_normal_initializer(stddev=0.5))
     store.finalize()
+    assert "encoder/nematus_gru_cell/gates/kernel" not in store.names() and store.total == 48 + 4 + 20 + 12
     m, v = store.ensure_adam()
     m.copy_(torch.arange(store.total, dtype=torch.float32))
     v.copy_(torch.arange(store.total, dtype=torch.float32) * 2)
     prefix = str(tmp_path / "variables.data")
     TB.export_store(store, prefix, global_step=17, with_adam=True)
     raw = TB.read_bundle(prefix)
-    # TensorFlow's shapes on disk: conv filters [1,1,in,out], scalar attention bias
-    assert raw["attention/attn_key_projection"].shape == (1, 1, 8, 6)
+    # TensorFlow's shapes on disk: tf.layers.conv2d filters [1,1,in,out], scalar attention bias; the attention's key
+    # projection is a matrix (expanded in the graph: attention/feed_forward.py:77-82) -- the shapes the reference
+    # itself creates, tests/test_reference_inis.py
+    assert raw["attention/attn_key_projection"].shape == (8, 6)
     assert raw["encoder/conv2d/kernel"].shape == (1, 1, 5, 4)
     assert raw["attention/attn_bias"].shape == ()
     assert int(raw["global_step"]) == 17 and "decoder/state_to_word_b/Adam_1" in raw
@@ -108,8 +113,19 @@ def test_store_export_import(tmp_path):
     for name, spec in store.specs.items():
         other.declare(name, spec.shape, zeros_initializer())
     other.finalize()
+    # the unread variable travels with its (zero) Adam slots; a store that does not know it reports it unused
+    extra = raw["encoder/nematus_gru_cell/gates/kernel"]
+    assert extra.shape == (3, 4) and np.abs(extra).max() > 0 and not raw["encoder/nematus_gru_cell/gates/kernel/Adam"].any()
     info = TB.import_store(other, prefix)
-    assert info == {"missing": [], "unused": [], "global_step": 17}
+    assert info == {"missing": [], "global_step": 17, "unused": [
+        "encoder/nematus_gru_cell/gates/kernel" + s for s in ("", "/Adam", "/Adam_1")]}
+    knows = VariableStore("cpu", seed=1)
+    for name, spec in store.specs.items():
+        knows.declare(name, spec.shape, zeros_initializer())
+    knows.declare_checkpoint_only("encoder/nematus_gru_cell/gates/kernel", (3, 4), zeros_initializer())
+    knows.finalize()
+    assert TB.import_store(knows, prefix)["unused"] == []
+    assert np.array_equal(knows.checkpoint_only_values()["encoder/nematus_gru_cell/gates/kernel"], extra)   # carried on
     for name in store.names():
         assert torch.equal(other[name], store[name])
     for spec in store.specs.values():          # (alignment padding between variables is not stored)
