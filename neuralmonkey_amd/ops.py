@@ -832,11 +832,16 @@ class OptimizerTables:
     """Chunk / segment tables of a VariableStore for the flat optimizer kernels."""
     CHUNK = 65536
 
-    def __init__(self, store, regularizable, trainable):
+    def __init__(self, store, regularizable, trainable, only=None):
+        """``only``: restrict the tables to these variables (the trainer's early / late halves of a step); the three
+        kernels then touch nothing else of the flat buffers."""
         lib = _lib.load()
         starts, lens, segs, first, count, flags = [], [], [], [], [], []
-        self.names = list(store.specs)
-        for si, (name, spec) in enumerate(store.specs.items()):
+        chosen = [(name, spec) for name, spec in store.specs.items() if only is None or name in only]
+        if not chosen:
+            raise ValueError("optimizer tables over no variable")
+        self.names = [name for name, _ in chosen]
+        for si, (name, spec) in enumerate(chosen):
             first.append(len(starts))
             off = 0
             while off < spec.size:

@@ -476,9 +476,10 @@ class Session:
         return buf
 
     @contextmanager
-    def side(self, lane: int = 0):
+    def side(self, lane: int = 0, after=()):
         """Run the enclosed launches on one of the session's secondary HIP streams
-        (``lane``), ordered after everything already enqueued on the main stream.
+        (``lane``), ordered after everything already enqueued on the main stream
+        -- and after what the lanes ``after`` hold so far.
         Used for "leaf" work of the backward pass (weight-gradient GEMMs, bias
         column sums) so that it fills the CUs the latency-bound BPTT loops leave
         idle.  Lane 1 is for the one long leaf GEMM of a step (the vocabulary
@@ -495,6 +496,11 @@ class Session:
         ev = torch.cuda.Event()
         ev.record(main)
         stream.wait_event(ev)
+        for other in after:
+            if other != lane and other in self._side_dirty:
+                done = torch.cuda.Event()
+                done.record(self._side_streams[other])
+                stream.wait_event(done)
         with torch.cuda.stream(stream):
             yield
         self._side_dirty.add(lane)

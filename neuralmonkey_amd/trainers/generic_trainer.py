@@ -22,6 +22,12 @@ from .objective import Objective
 
 BIAS_REGEX = re.compile(r"[Bb]ias")
 DEFER_LOSSES = os.environ.get("NM_DEFER_LOSSES", "1") != "0"
+# NM_OPT_EARLY=1: the optimizer step of the DECODER-side variables (their gradients are final once the decoders'
+# backward is enqueued, and nothing reads them again in the step) runs on a side stream beside the encoders' backward
+# instead of at the end of the step -- bandwidth work under latency-bound time loops.  Off by default: built after
+# the round's GPU time was spent, to be measured (GenericTrainer._early_optimizer).
+OPT_EARLY = os.environ.get("NM_OPT_EARLY", "0") == "1"
+OPT_EARLY_LANE = 2
 
 
 # pylint: disable=too-few-public-methods,too-many-arguments
@@ -87,12 +93,54 @@ class GenericTrainer(GraphExecutor, Feedable):
         return [n for n in store.trainable_names() if not BIAS_REGEX.findall(n)
                 and not n.startswith(("vgg", "Inception", "resnet"))]
 
-    def _optim_tables(self, store) -> ops.OptimizerTables:
-        key = id(store)
+    def _optim_tables(self, store, half: str = "all", names=None) -> ops.OptimizerTables:
+        """``half`` "all": every variable of the store; "early" / "late": ``names`` and the rest (OPT_EARLY)."""
+        key = (id(store), half) if half != "all" else id(store)
         if key not in self._tables:
+            only = None
+            if half == "early":
+                only = set(names)
+            elif half == "late":
+                only = set(store.names()) - set(names)
             self._tables[key] = ops.OptimizerTables(store, set(self.regularizable(store)),
-                                                    set(self.var_list(store)))
+                                                    set(self.var_list(store)), only=only)
         return self._tables[key]
+
+    def early_variables(self, store, decoders) -> List[str]:
+        """Variables that only the decoders' own backward passes write and read: those in the scope of a decoder or of
+        one of its attentions, when no other model part lives in that scope (``reuse=``).  Everything an encoder's
+        deferred backward still touches -- its own variables, embeddings a decoder borrows through
+        ``embeddings_source`` -- lives in another scope and stays for the end of the step."""
+        from ..runtime import registered_parts
+        scopes = []
+        for dec in decoders:
+            for part in [dec] + list(getattr(dec, "attentions", [])):
+                scope = getattr(part, "_scope", None)
+                if scope and sum(1 for p in registered_parts() if getattr(p, "_scope", None) == scope) == 1:
+                    scopes.append(scope + "/")
+        return [n for n in store.names() if n.startswith(tuple(scopes))] if scopes else []
+
+    def _step_rate(self, sess, state) -> float:
+        """lr_t of the update that the running step will apply (global step and bias correction one ahead)."""
+        return self.optimizer.lr_t(sess.global_step + 1, state["applied"] + 1)
+
+    def _early_optimizer(self, ctx, outer, decoders) -> None:
+        """L1/L2 terms, per-tensor clipping and Adam for ``early_variables``, enqueued on a side lane that waits for
+        the main stream (every read of these variables is enqueued by now) and for the leaf lanes (their weight
+        gradients).  ``_apply_gradients`` then covers the remaining variables only."""
+        sess, store = ctx.session, ctx.store
+        names = self.early_variables(store, decoders)
+        if not names or len(names) == len(store.names()):
+            return
+        early = self._optim_tables(store, "early", names)
+        self._optim_tables(store, "late", names)
+        state = self._adam_state(sess, store)
+        opt = self.optimizer
+        with sess.side(OPT_EARLY_LANE, after=(0, 1)):
+            l1l2 = early.regularize_and_norms(store.theta, store.ensure_grad(), self.l1_weight, self.l2_weight)
+            early.clip_adam(store.theta, store.ensure_grad(), state["m"], state["v"], self.clip_norm,
+                            self._step_rate(sess, state), opt.beta1, opt.beta2, opt.epsilon)
+        outer.memo[(id(self), "early")] = (names, l1l2)
 
     # -- the training step --------------------------------------------------------------------
     def _objective_gradients(self, outer) -> None:
@@ -135,7 +183,7 @@ class GenericTrainer(GraphExecutor, Feedable):
             scales.append(scale)
             counts.append(count)
 
-        def forward_backward():
+        def forward_backward(early=None):
             """Every objective's forward + backward; encoders shared by several decoders run their
             backward pass once, on the summed gradient (RunContext.defer_backward)."""
             ctx.memo["backward_deferred"] = True
@@ -144,6 +192,8 @@ class GenericTrainer(GraphExecutor, Feedable):
                 res = dec._train_loop(ctx, want_grad=True, grad_scale=scale)     # pylint: disable=protected-access
                 dec.backward(ctx, res)
                 results.append(res)
+            if early is not None:
+                early()                      # the decoders' share of the optimizer step, beside the encoders' backward
             ctx.flush_backward()
             ctx.memo["backward_deferred"] = False
             return results
@@ -155,7 +205,11 @@ class GenericTrainer(GraphExecutor, Feedable):
             results = sess.graphed_call((id(self), train, shapes), forward_backward)
             results = [res._replace(token_count=count) for res, count in zip(results, counts)]
         else:
-            results = forward_backward()
+            # (never inside a captured step graph: the learning rate of the step would be baked into it)
+            early = None
+            if OPT_EARLY and dp is None and outer.memo.get("one_update_per_batch") and len(decoders) > 0:
+                early = lambda: self._early_optimizer(ctx, outer, decoders)
+            results = forward_backward(early)
         for dec, res in zip(decoders, results):
             outer.memo[dec.train_loop_result.key] = res
         sess.join_side()
@@ -168,9 +222,15 @@ class GenericTrainer(GraphExecutor, Feedable):
         dp = dist.current()
         if dp is not None:
             dp.all_reduce_gradients(store)
-        tables = self._optim_tables(store)
-        l1l2 = tables.regularize_and_norms(store.theta, grad, self.l1_weight, self.l2_weight)
-        ctx.memo[(id(self), "l1l2")] = l1l2.clone()
+        early = ctx.memo.pop((id(self), "early"), None)
+        if early is None:
+            tables = self._optim_tables(store)
+            l1l2 = tables.regularize_and_norms(store.theta, grad, self.l1_weight, self.l2_weight)
+            ctx.memo[(id(self), "l1l2")] = l1l2.clone()
+        else:           # the decoders' variables were updated beside the encoders' backward (_early_optimizer)
+            tables = self._optim_tables(store, "late", early[0])
+            l1l2 = tables.regularize_and_norms(store.theta, grad, self.l1_weight, self.l2_weight)
+            ctx.memo[(id(self), "l1l2")] = l1l2 + early[1]        # (the main stream has joined the side lanes)
         state = self._adam_state(sess, store)
         sess.global_step += 1
         state["applied"] += 1
@@ -205,6 +265,7 @@ class GenericTrainer(GraphExecutor, Feedable):
         # one optimizer step per batch: gradient slices that are final early in the backward pass may start
         # their all-reduce right away (distributed.DataParallel.all_reduce_early)
         ctx.memo["dp_overlap"] = True
+        ctx.memo["one_update_per_batch"] = True       # (DelayedUpdateTrainer accumulates: no early optimizer there)
         self._objective_gradients(ctx)
         return self._apply_gradients(ctx)
 

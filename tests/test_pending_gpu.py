@@ -1,0 +1,117 @@
+"""GPU tests written AFTER round 4's GPU budget was spent: they have never run on a device.  The driver's round-end
+suite is `pytest -x`, so they are skipped unless NM_RUN_PENDING=1 -- the first GPU call of the next round runs them
+(tools/r05_first_call.sh), fixes what they find, and moves them into the files they belong to
+(test_reference_inis_gpu.py, test_background_gpu.py) without the gate.
+
+What they cover:
+  * tests/small.ini on the engine against the model the REFERENCE built from that file (fixture ``ini_small``;
+    neuralmonkey/config/builder.py:159-176 names, NematusGRU cells, conditional GRU decoder);
+  * the early half of the optimizer step (NM_OPT_EARLY, trainers/generic_trainer.py: the decoders' variables are
+    updated on a side lane beside the encoders' backward; trainers/generic_trainer.py:136-195 of the reference is the
+    arithmetic, which must not change): three steps with it equal three steps without it;
+  * a checkpoint written by the engine for a NematusGRU model holds exactly the reference's variables.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from .test_reference_inis import load_verbatim, ref_root, reference_variables  # noqa: F401  pylint: disable=unused-import
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("NM_RUN_PENDING") != "1",
+                                 reason="never run on a GPU yet: NM_RUN_PENDING=1 (tools/r05_first_call.sh)")]
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_small_ini_on_the_engine_equals_the_reference_built_model(dev, ref_root):      # noqa: F811
+    fixture = np.load(os.path.join(HERE, "golden", "ref_exec", "ini_small.npz"))
+    params = {k[2:]: fixture[k] for k in fixture.files if k.startswith("p/")}
+    model = load_verbatim(ref_root, "small", device=str(dev), seed=1234)
+    tfm = model.tf_manager
+    store = tfm.sessions[0].store
+    # the engine's variables + GRUCell.build's unread ones == the reference's graph
+    assert sorted(list(store.names()) + list(store.checkpoint_only)) == sorted(params)
+    store.load_state_dict(params)
+    # the fixture's batch: the first batch of the file's validation data under its bucketed scheme
+    val = model.val_dataset[0] if isinstance(model.val_dataset, list) else model.val_dataset
+    batch = next(iter(val.batches()))
+    runner = model.runners[0]
+    dec = runner.decoder
+    enc = dec.encoders[0]
+    fd = {}
+    for part in runner.feedables:
+        fd.update(part.feed_dict(batch, train=False))
+    out = tfm.sessions[0].run({"enc": enc.temporal_states, "final": enc.output, "train_logits": dec.train_logits,
+                               "sym": dec.decoded_symbols, "mask": dec.runtime_mask,
+                               "logits": dec.runtime_logits}, fd)
+
+    def close(got, want, what, tol=1e-4):
+        got, want = np.asarray(got), np.asarray(want)
+        assert got.shape == want.shape, (what, got.shape, want.shape)
+        err = np.abs(got - want).max()
+        assert err <= tol * max(np.abs(want).max(), 1e-6), "{}: {:.3e}".format(what, err)
+    close(out["enc"], fixture["out/enc_states"], "encoder states")
+    close(out["final"], fixture["out/enc_output"], "encoder output")
+    close(out["train_logits"], fixture["out/train_logits"], "train logits")
+    assert np.array_equal(np.asarray(out["sym"]), fixture["out/runtime_symbols"])
+    assert np.array_equal(np.asarray(out["mask"]).astype(bool), fixture["out/runtime_mask"])
+    close(out["logits"], fixture["out/runtime_logits"], "runtime logits")
+    res = tfm.execute(batch, runner.feedables, [runner], compute_losses=True)[0]
+    assert [" ".join(s) for s in res.outputs[runner.output_series]] == [str(s) for s in fixture["out/runner_sentences"]]
+    got_losses = [res.losses["{}/{}".format(runner.output_series, n)] for n in runner.loss_names]
+    assert np.allclose(got_losses, fixture["out/runner_losses"], rtol=1e-5)
+
+
+def test_small_ini_checkpoint_holds_the_references_variables(dev, ref_root, tmp_path):      # noqa: F811
+    """``variables.data`` as the engine writes it for tests/small.ini: the names and shapes the reference's Saver
+    would look for (fixture ``ini_variables``), GRUCell.build's unread variables included; read back, it restores
+    every variable bit for bit."""
+    import torch
+    from neuralmonkey_amd import tf_bundle
+    model = load_verbatim(ref_root, "small", device=str(dev), seed=7)
+    store = model.tf_manager.sessions[0].store
+    prefix = str(tmp_path / "variables.data")
+    model.tf_manager.checkpoint_format = "tf"
+    model.tf_manager.save(prefix)
+    written = tf_bundle.read_bundle(prefix)
+    theirs = {n: tuple(s) for n, s in reference_variables("small")["variables"]}
+    mine = {n: tuple(a.shape) for n, a in written.items() if n != "global_step" and not n.endswith(("/Adam", "/Adam_1"))
+            and n not in ("beta1_power", "beta2_power")}
+    assert mine == theirs
+    before = {n: store[n].clone() for n in store.names()}
+    store.theta.zero_()
+    model.tf_manager.restore(prefix)
+    assert all(torch.equal(store[n], before[n]) for n in store.names())
+
+
+def _three_steps(dev, monkeypatch, early):
+    import torch
+    from neuralmonkey_amd import synthetic
+    from neuralmonkey_amd.trainers import generic_trainer
+    from oracle import nm_oracle as O
+    monkeypatch.setattr(generic_trainer, "OPT_EARLY", early)
+    model = synthetic.build_translation_model(vocab_src=2000, vocab_tgt=2000, emb=64, rnn=64, max_len=24,
+                                              beam_size=0, device=str(dev), l2_weight=1e-6, clip_norm=1.0)
+    sess = model.tf_manager.sessions[0]
+    sess.store.load_state_dict(O.init_params(seed=3, vocab_src=2000, vocab_tgt=2000, emb=64, rnn=64, std=0.1))
+    ds = synthetic.synthetic_dataset(seed=4, batch=32, src_len=24, tgt_len=20, vocab=2000, ragged=True)
+    losses = []
+    for _ in range(3):
+        res = model.tf_manager.execute(ds, model.trainer.feedables, [model.trainer], train=True)[0]
+        losses.append([float(res.losses[k]) for k in ("decoder - cost", "L1", "L2")])
+    torch.cuda.synchronize()
+    halves = [key for key in model.trainer._tables if isinstance(key, tuple)]
+    return losses, {n: sess.store[n].cpu().numpy().copy() for n in sess.store.names()}, halves, sess.global_step
+
+
+def test_early_optimizer_half_changes_no_parameter(dev, monkeypatch):
+    """Clipping, the regulariser's gradient and Adam are per tensor: splitting the variables into two launches
+    changes no update.  Only the reported L1 / L2 sums are added in another order."""
+    l_early, p_early, halves, step_early = _three_steps(dev, monkeypatch, True)
+    l_plain, p_plain, none, step_plain = _three_steps(dev, monkeypatch, False)
+    assert len(halves) == 2 and not none and step_early == step_plain == 3
+    assert np.allclose(l_early, l_plain, rtol=1e-6, atol=0.0), (l_early, l_plain)
+    for name, want in p_plain.items():
+        assert np.array_equal(p_early[name], want), name
