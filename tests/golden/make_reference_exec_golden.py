@@ -1627,6 +1627,76 @@ def run_ini_factored(case, rows=6):
     save(case, {"kind": "ini", "ini": "factored", "batch": rows}, out)
 
 
+def run_ini_postedit(case):
+    """tests/post-edit.ini (tests/tests_run.sh:12) built by the reference's parser and builder from the file as it is:
+    a GRU ``SentenceEncoder`` over the source, an LSTM ``RecurrentEncoder`` over the machine translation, an RNN
+    decoder of the edit scripts (``processors.editops.Preprocess`` makes that series while the data are loaded) that
+    borrows the translation's embeddings and attends with a three-head ``MultiHeadAttention`` (keys: source encoder,
+    values: translation encoder) and a ``ScaledDotProdAttention`` over the source.  First batch of the training data
+    (two sentences, [main] batch_size), train_mode False."""
+    import collections.abc
+    collections.Iterable = collections.abc.Iterable
+    from neuralmonkey.config import parsing
+    from neuralmonkey.config.builder import ObjectRef, build_config
+    from neuralmonkey.experiment import Experiment
+    cwd = os.getcwd()
+    os.chdir(REFERENCE)
+    try:
+        fresh_graph()
+        with open(os.path.join("tests", "post-edit.ini"), encoding="utf-8") as handle:
+            _, parsed = parsing.parse_file(handle.read().splitlines(True))
+        Experiment._current_experiment = experiment_stand_in(parsed["main"].get("batch_size"))
+        parsed["main"] = collections.OrderedDict((key, ObjectRef(key)) for key in (
+            "src_encoder", "trans_encoder", "trans_embedded_input", "src_attention", "trans_attention", "decoder",
+            "runner", "train_dataset", "postprocess"))
+        try:
+            built, _ = build_config(parsed, ignore_names=set())
+        finally:
+            Experiment._current_experiment = None
+        src, trans, seq = built["src_encoder"], built["trans_encoder"], built["trans_embedded_input"]
+        dec, runner = built["decoder"], built["runner"]
+        batch = next(iter(built["train_dataset"].batches()))
+        parts = [src, src.input_sequence, trans, seq, built["src_attention"], built["trans_attention"], dec]
+        inputs = string_inputs("source", "translated", "edits")
+        out = {}
+        with tf_eager.feeding(feed(parts, batch, False, inputs)):
+            out["in/src_tokens"] = src.input_sequence.input_factors[0].numpy()
+            out["in/src_ids"] = src.input_sequence.inputs.numpy()
+            out["in/mt_tokens"] = seq.input_factors[0].numpy()
+            out["in/mt_ids"] = seq.inputs.numpy()
+            out["in/tgt_tokens"] = dec.train_tokens.numpy()
+            out["in/tgt_ids"] = dec.train_inputs.numpy()
+            out["out/src_states"] = src.temporal_states.numpy()
+            out["out/src_mask"] = src.temporal_mask.numpy()
+            out["out/src_output"] = src.output.numpy()
+            out["out/mt_states"] = trans.temporal_states.numpy()
+            out["out/mt_mask"] = trans.temporal_mask.numpy()
+            out["out/mt_output"] = trans.output.numpy()
+            out["out/train_logits"] = dec.train_logits.numpy()
+            out["out/train_xents"] = dec.train_xents.numpy()
+            out["out/train_loss"] = dec.train_loss.numpy()
+            out["out/runtime_logits"] = dec.runtime_logits.numpy()
+            out["out/runtime_symbols"] = dec.runtime_loop_result.histories.output_symbols.numpy()
+            out["out/runtime_mask"] = dec.runtime_mask.numpy()
+            ex = runner.get_executable(compute_losses=True, summaries=False, num_sessions=1)
+            fetches, _ = ex.next_to_execute()
+            ex.collect_results([to_numpy(fetches)])
+            scripts = ex.result.outputs[runner.output_series]
+            out["out/runner_sentences"] = np.asarray([joined(sent) for sent in scripts])
+            out["out/runner_losses"] = np.asarray([ex.result.losses["{}/{}".format(runner.output_series, name)]
+                                                   for name in runner.loss_names], np.float32)
+        # [main] postprocess=[("target", <postprocess>)]: the generated scripts applied to the batch's translations
+        translated = list(batch.get_series("translated"))
+        rebuilt = built["postprocess"]({"translated": translated}, {"edits": scripts})
+        out["out/postprocessed"] = np.asarray([joined(sent) for sent in rebuilt])
+        out["in/translated"] = np.asarray([joined(sent) for sent in translated])
+        out["in/src_vocabulary"] = np.asarray(list(src.input_sequence.vocabularies[0].index_to_word))
+        out["in/tgt_vocabulary"] = np.asarray(list(dec.vocabulary.index_to_word))
+    finally:
+        os.chdir(cwd)
+    save(case, {"kind": "ini", "ini": "post-edit", "batch": int(out["in/src_ids"].shape[0])}, out)
+
+
 def run_defects(case):
     """Configurations the reference cannot execute at this commit: the exception IS the reference behaviour."""
     import traceback
@@ -1745,6 +1815,7 @@ CASES = collections.OrderedDict([
         [("encoder", "my_encoder"), ("attention", "my_attention"), ("decoder", "my_decoder"), ("runner", "runner"),
          ("data", "val_data")]), dataset_key="data")),
     ("ini_variables", lambda: run_ini_variables("ini_variables")),
+    ("ini_postedit", lambda: run_ini_postedit("ini_postedit")),
     ("schedules", lambda: run_schedules("schedules")),
     ("ini_grammar", lambda: run_ini_grammar("ini_grammar")),
     ("config_builder", lambda: run_config_builder("config_builder")),

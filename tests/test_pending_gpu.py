@@ -4,8 +4,9 @@ suite is `pytest -x`, so they are skipped unless NM_RUN_PENDING=1 -- the first G
 (test_reference_inis_gpu.py, test_background_gpu.py) without the gate.
 
 What they cover:
-  * tests/small.ini on the engine against the model the REFERENCE built from that file (fixture ``ini_small``;
-    neuralmonkey/config/builder.py:159-176 names, NematusGRU cells, conditional GRU decoder);
+  * tests/small.ini and tests/post-edit.ini on the engine against the models the REFERENCE built from those files
+    (fixtures ``ini_small``, ``ini_postedit``; neuralmonkey/config/builder.py:159-176 names, NematusGRU cells,
+    conditional GRU decoder; two encoders under dot-product attentions, attention/scaled_dot_product.py:247-400);
   * the early half of the optimizer step (NM_OPT_EARLY, trainers/generic_trainer.py: the decoders' variables are
     updated on a side lane beside the encoders' backward; trainers/generic_trainer.py:136-195 of the reference is the
     arithmetic, which must not change): three steps with it equal three steps without it;
@@ -62,6 +63,51 @@ def test_small_ini_on_the_engine_equals_the_reference_built_model(dev, ref_root)
     assert [" ".join(s) for s in res.outputs[runner.output_series]] == [str(s) for s in fixture["out/runner_sentences"]]
     got_losses = [res.losses["{}/{}".format(runner.output_series, n)] for n in runner.loss_names]
     assert np.allclose(got_losses, fixture["out/runner_losses"], rtol=1e-5)
+
+
+def test_post_edit_ini_on_the_engine_equals_the_reference_built_model(dev, ref_root):      # noqa: F811
+    """tests/post-edit.ini end to end on both sides (fixture ``ini_postedit``): two encoders, a multi-head attention
+    with keys and values from different encoders plus a one-head attention, borrowed embeddings, the edit-script
+    series made while the data load."""
+    fixture = np.load(os.path.join(HERE, "golden", "ref_exec", "ini_postedit.npz"))
+    params = {k[2:]: fixture[k] for k in fixture.files if k.startswith("p/")}
+    model = load_verbatim(ref_root, "post-edit", device=str(dev), seed=1234)
+    tfm = model.tf_manager
+    store = tfm.sessions[0].store
+    assert sorted(store.names()) == sorted(params), set(store.names()) ^ set(params)
+    store.load_state_dict(params)
+    batch = next(iter(model.train_dataset.batches()))
+    runner = model.runners[0]
+    dec = runner.decoder
+    trans, src = dec.encoders
+    fd = {}
+    for part in runner.feedables:
+        fd.update(part.feed_dict(batch, train=False))
+    out = tfm.sessions[0].run({"src": src.temporal_states, "mt": trans.temporal_states, "src_out": src.output,
+                               "mt_out": trans.output, "train_logits": dec.train_logits, "sym": dec.decoded_symbols,
+                               "mask": dec.runtime_mask, "logits": dec.runtime_logits}, fd)
+
+    def close(got, want, what, tol=1e-4):
+        got, want = np.asarray(got), np.asarray(want)
+        assert got.shape == want.shape, (what, got.shape, want.shape)
+        err = np.abs(got - want).max()
+        assert err <= tol * max(np.abs(want).max(), 1e-6), "{}: {:.3e}".format(what, err)
+    close(out["src"], fixture["out/src_states"], "source encoder states")
+    close(out["mt"], fixture["out/mt_states"], "translation encoder states")
+    close(out["src_out"], fixture["out/src_output"], "source encoder output")
+    close(out["mt_out"], fixture["out/mt_output"], "translation encoder output")
+    close(out["train_logits"], fixture["out/train_logits"], "train logits")
+    assert np.array_equal(np.asarray(out["sym"]), fixture["out/runtime_symbols"])
+    assert np.array_equal(np.asarray(out["mask"]).astype(bool), fixture["out/runtime_mask"])
+    close(out["logits"], fixture["out/runtime_logits"], "runtime logits")
+    res = tfm.execute(batch, runner.feedables, [runner], compute_losses=True)[0]
+    scripts = res.outputs[runner.output_series]
+    assert [" ".join(s) for s in scripts] == [str(s) for s in fixture["out/runner_sentences"]]
+    got_losses = [res.losses["{}/{}".format(runner.output_series, n)] for n in runner.loss_names]
+    assert np.allclose(got_losses, fixture["out/runner_losses"], rtol=1e-5)
+    (_, post), = model.postprocess
+    rebuilt = post({"translated": list(batch.get_series("translated"))}, {"edits": scripts})
+    assert [" ".join(r) for r in rebuilt] == fixture["out/postprocessed"].tolist()
 
 
 def test_small_ini_checkpoint_holds_the_references_variables(dev, ref_root, tmp_path):      # noqa: F811

@@ -198,6 +198,13 @@ def test_post_edit_ini_builds_and_its_scripts_are_the_references(ref_root):
     (series, post), = model.postprocess
     assert series == "target" and isinstance(post, Postprocess)
     assert post({"translated": mt}, {"edits": edits}) == pe
+    # ... and it is the batch the REFERENCE'S pipeline made of the file (fixture ini_postedit: the model's inputs
+    # after its length limit of 5)
+    import numpy as np
+    z = np.load(os.path.join(HERE, "golden", "ref_exec", "ini_postedit.npz"))
+    assert [" ".join(sentence) for sentence in mt] == z["in/translated"].tolist()
+    assert [sentence[:5] for sentence in first.get_series("source")] == z["in/src_tokens"].tolist()
+    assert [script[:5] for script in edits] == [[t for t in row if t != "<pad>"] for row in z["in/tgt_tokens"].tolist()]
 
 
 def test_a_dataset_without_batching_needs_main_batch_size(ref_root, tmp_path):
