@@ -1697,6 +1697,91 @@ def run_ini_postedit(case):
     save(case, {"kind": "ini", "ini": "post-edit", "batch": int(out["in/src_ids"].shape[0])}, out)
 
 
+FLAT_DECODERS = [("flat_noshare_nosentinel", "wrapper_fnn"), ("flat_share_nosentinel", "wrapper_fsn"),
+                 ("flat_share_sentinel", "wrapper_fss"), ("flat_noshare_sentinel", "wrapper_fns")]
+
+
+def run_ini_flat(case):
+    """tests/flat-multiattention.ini (tests/tests_run.sh:28) built by the reference's parser and builder from the file
+    as it is: a ``SpatialFiller`` over pre-extracted 8x8x2048 feature maps (read through ``numpy_reader.from_file_list``)
+    and a ``SentenceEncoder``, four RNN decoders over both, each with its own ``FlatMultiAttention`` (projections
+    shared or not, sentinel or not), a ``GreedyRunner`` per decoder, and the RNN beam search (beam 2, length
+    normalisation 1.0, 3 steps, ``BeamSearchRunner(rank=2)``) over the shared-projections-with-sentinel decoder.  First
+    batch of the training data ([main] batch_size 1: the reference's beam search over an RNN decoder is confined to
+    it), train_mode False."""
+    import collections.abc
+    collections.Iterable = collections.abc.Iterable
+    from neuralmonkey.config import parsing
+    from neuralmonkey.config.builder import build_config
+    from neuralmonkey.experiment import Experiment
+    cwd = os.getcwd()
+    os.chdir(REFERENCE)
+    try:
+        fresh_graph()
+        with open(os.path.join("tests", "flat-multiattention.ini"), encoding="utf-8") as handle:
+            _, parsed = parsing.parse_file(handle.read().splitlines(True))
+        main = parsed["main"]
+        Experiment._current_experiment = experiment_stand_in(main.get("batch_size"))
+        parsed["main"] = collections.OrderedDict([("runners", main["runners"]), ("train_dataset", main["train_dataset"])])
+        try:
+            built, _ = build_config(parsed, ignore_names=set())
+        finally:
+            Experiment._current_experiment = None
+        runners = built["runners"]
+        batch = next(iter(built["train_dataset"].batches()))
+        feedables = sorted(set.union(*[set(r.feedables) for r in runners]), key=lambda f: str(getattr(f, "name", "")))
+        inputs = {}
+        for part in feedables:
+            for series, dtype in part.input_types.items():
+                if series not in inputs:
+                    inputs[series] = tf.placeholder(dtype, part.input_shapes[series], series)
+        out = {}
+        with tf_eager.feeding(feed(feedables, batch, False, inputs)):
+            first = runners[0].decoder
+            enc, img = first.encoders
+            out["in/src_tokens"] = enc.input_sequence.input_factors[0].numpy()
+            out["in/src_ids"] = enc.input_sequence.inputs.numpy()
+            out["in/maps"] = img.spatial_states.numpy()
+            out["in/tgt_tokens"] = first.train_tokens.numpy()
+            out["in/tgt_ids"] = first.train_inputs.numpy()
+            out["out/enc_states"] = enc.temporal_states.numpy()
+            out["out/enc_output"] = enc.output.numpy()
+            for runner, (tag, _) in zip(runners[:4], FLAT_DECODERS):
+                dec = runner.decoder
+                assert dec.name == "decoder_" + tag, dec.name
+                out["out/{}/train_logits".format(tag)] = dec.train_logits.numpy()
+                out["out/{}/train_loss".format(tag)] = dec.train_loss.numpy()
+                out["out/{}/runtime_logits".format(tag)] = dec.runtime_logits.numpy()
+                out["out/{}/runtime_symbols".format(tag)] = dec.runtime_loop_result.histories.output_symbols.numpy()
+                out["out/{}/runtime_mask".format(tag)] = dec.runtime_mask.numpy()
+                ex = runner.get_executable(compute_losses=True, summaries=False, num_sessions=1)
+                fetches, _ = ex.next_to_execute()
+                ex.collect_results([to_numpy(fetches)])
+                out["out/{}/runner_sentences".format(tag)] = np.asarray(
+                    [joined(sent) for sent in ex.result.outputs[runner.output_series]])
+                out["out/{}/runner_losses".format(tag)] = np.asarray(
+                    [ex.result.losses["{}/{}".format(runner.output_series, name)] for name in runner.loss_names],
+                    np.float32)
+            beam_runner = runners[4]
+            bs = beam_runner.decoder
+            ex = beam_runner.get_executable(compute_losses=True, summaries=False, num_sessions=1)
+            fetches, _ = ex.next_to_execute()
+            res = to_numpy(fetches)
+            ex.collect_results([res])
+            bo = res["bs_outputs"]
+            out["out/beam_scores"] = bo.last_search_step_output.scores
+            out["out/beam_token_ids"] = bo.last_search_step_output.token_ids
+            out["out/beam_runner_sentences"] = np.asarray([joined(sent) for sent in
+                                                           ex.result.outputs[beam_runner.output_series]])
+            out["out/beam_runner_loss"] = np.asarray(
+                ex.result.losses["{}/beam_search_score".format(beam_runner.output_series)], np.float32)
+        out["in/tgt_vocabulary"] = np.asarray(list(first.vocabulary.index_to_word))
+        out["cfg/beam"] = np.asarray([bs.beam_size, bs.max_steps_int, beam_runner.rank], np.int64)
+    finally:
+        os.chdir(cwd)
+    save(case, {"kind": "ini", "ini": "flat-multiattention", "batch": int(out["in/src_ids"].shape[0])}, out)
+
+
 def run_defects(case):
     """Configurations the reference cannot execute at this commit: the exception IS the reference behaviour."""
     import traceback
@@ -1816,6 +1901,7 @@ CASES = collections.OrderedDict([
          ("data", "val_data")]), dataset_key="data")),
     ("ini_variables", lambda: run_ini_variables("ini_variables")),
     ("ini_postedit", lambda: run_ini_postedit("ini_postedit")),
+    ("ini_flat", lambda: run_ini_flat("ini_flat")),
     ("schedules", lambda: run_schedules("schedules")),
     ("ini_grammar", lambda: run_ini_grammar("ini_grammar")),
     ("config_builder", lambda: run_config_builder("config_builder")),

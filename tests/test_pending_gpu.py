@@ -4,8 +4,8 @@ suite is `pytest -x`, so they are skipped unless NM_RUN_PENDING=1 -- the first G
 (test_reference_inis_gpu.py, test_background_gpu.py) without the gate.
 
 What they cover:
-  * tests/small.ini and tests/post-edit.ini on the engine against the models the REFERENCE built from those files
-    (fixtures ``ini_small``, ``ini_postedit``; neuralmonkey/config/builder.py:159-176 names, NematusGRU cells,
+  * tests/small.ini, tests/post-edit.ini and tests/flat-multiattention.ini on the engine against the models the
+    REFERENCE built from those files (fixtures ``ini_small``, ``ini_postedit``, ``ini_flat``; neuralmonkey/config/builder.py:159-176 names, NematusGRU cells,
     conditional GRU decoder; two encoders under dot-product attentions, attention/scaled_dot_product.py:247-400);
   * the early half of the optimizer step (NM_OPT_EARLY, trainers/generic_trainer.py: the decoders' variables are
     updated on a side lane beside the encoders' backward; trainers/generic_trainer.py:136-195 of the reference is the
@@ -108,6 +108,52 @@ def test_post_edit_ini_on_the_engine_equals_the_reference_built_model(dev, ref_r
     (_, post), = model.postprocess
     rebuilt = post({"translated": list(batch.get_series("translated"))}, {"edits": scripts})
     assert [" ".join(r) for r in rebuilt] == fixture["out/postprocessed"].tolist()
+
+
+def test_flat_multiattention_ini_on_the_engine_equals_the_reference_built_model(dev, ref_root):      # noqa: F811
+    """tests/flat-multiattention.ini end to end on both sides (fixture ``ini_flat``): the four decoders' teacher-forced
+    logits, greedy loops and runner outputs, and the RNN beam search with its rank-2 runner."""
+    fixture = np.load(os.path.join(HERE, "golden", "ref_exec", "ini_flat.npz"))
+    params = {k[2:]: fixture[k] for k in fixture.files if k.startswith("p/")}
+    model = load_verbatim(ref_root, "flat-multiattention", device=str(dev), seed=1234)
+    tfm = model.tf_manager
+    store = tfm.sessions[0].store
+    assert sorted(store.names()) == sorted(params), set(store.names()) ^ set(params)
+    store.load_state_dict(params)
+    batch = next(iter(model.train_dataset.batches()))
+    assert len(batch) == 1
+    feedables = set.union(*[r.feedables for r in model.runners])
+    fd = {}
+    for part in feedables:
+        fd.update(part.feed_dict(batch, train=False))
+
+    def close(got, want, what, tol=1e-4):
+        got, want = np.asarray(got), np.asarray(want)
+        assert got.shape == want.shape, (what, got.shape, want.shape)
+        err = np.abs(got - want).max()
+        assert err <= tol * max(np.abs(want).max(), 1e-6), "{}: {:.3e}".format(what, err)
+    for runner in model.runners[:4]:
+        dec = runner.decoder
+        tag = dec.name[len("decoder_"):]
+        out = tfm.sessions[0].run({"train_logits": dec.train_logits, "sym": dec.decoded_symbols,
+                                   "mask": dec.runtime_mask, "logits": dec.runtime_logits}, fd)
+        pre = "out/{}/".format(tag)
+        close(out["train_logits"], fixture[pre + "train_logits"], tag + " train logits")
+        assert np.array_equal(np.asarray(out["sym"]), fixture[pre + "runtime_symbols"]), tag
+        assert np.array_equal(np.asarray(out["mask"]).astype(bool), fixture[pre + "runtime_mask"]), tag
+        close(out["logits"], fixture[pre + "runtime_logits"], tag + " runtime logits")
+    results = tfm.execute(batch, feedables, model.runners, compute_losses=True)
+    for runner, res in zip(model.runners[:4], results):
+        tag = runner.decoder.name[len("decoder_"):]
+        assert [" ".join(s) for s in res.outputs[runner.output_series]] == \
+            [str(s) for s in fixture["out/{}/runner_sentences".format(tag)]]
+        got = [res.losses["{}/{}".format(runner.output_series, n)] for n in runner.loss_names]
+        assert np.allclose(got, fixture["out/{}/runner_losses".format(tag)], rtol=1e-5)
+    beam_runner, beam = model.runners[4], results[4]
+    assert [" ".join(s) for s in beam.outputs[beam_runner.output_series]] == \
+        [str(s) for s in fixture["out/beam_runner_sentences"]]
+    assert abs(beam.losses[beam_runner.output_series + "/beam_search_score"] - float(fixture["out/beam_runner_loss"])) \
+        <= 1e-5 * abs(float(fixture["out/beam_runner_loss"]))
 
 
 def test_small_ini_checkpoint_holds_the_references_variables(dev, ref_root, tmp_path):      # noqa: F811

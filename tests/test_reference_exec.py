@@ -66,7 +66,7 @@ def test_every_generated_case_is_checked_here():
     checked = sorted(["functions", "defects", "ensemble", "greedy_runner_ensemble", "dataset_batching",
                       "vocabulary_formats", "host_text_pipeline", "schedules", "ini_grammar", "config_builder",
                       "dataset_loading", "ini_bahdanau", "ini_beamsearch", "ini_factored", "ini_small",
-                      "editops", "ini_postedit",        # below
+                      "editops", "ini_postedit", "ini_flat",        # below
                       "ini_variables"]        # tests/test_reference_inis.py
                      + BEAM_BODY_CASES + RNN_CASES + TRANSFORMER_CASES
                      + VARIANT_CASES + FD_CASES)
@@ -1035,3 +1035,57 @@ def test_the_reference_built_post_edit_ini_equals_the_oracle():
     rebuilt = Postprocess("translated", "edits")({"translated": [t.split(" ") for t in z["in/translated"].tolist()]},
                                                  {"edits": [s.split(" ") for s in got]})
     assert [" ".join(r) for r in rebuilt] == z["out/postprocessed"].tolist()
+
+
+FLAT_INI_DECODERS = [("flat_noshare_nosentinel", "wrapper_fnn", False, False), ("flat_share_nosentinel", "wrapper_fsn", True, False),
+                     ("flat_share_sentinel", "wrapper_fss", True, True), ("flat_noshare_sentinel", "wrapper_fns", False, True)]
+
+
+@pytest.mark.parametrize("tag,wrapper,share,sentinel", FLAT_INI_DECODERS)
+def test_the_reference_built_flat_multiattention_ini_equals_the_oracle(tag, wrapper, share, sentinel):
+    """tests/flat-multiattention.ini built by the REFERENCE (SpatialFiller over an 8x8x2048 map read through
+    ``from_file_list``, SentenceEncoder GRU 4 with max_input_len 3, four decoders GRU 3 each under its own
+    FlatMultiAttention of state size 5): each decoder's teacher-forced pass, greedy loop and GreedyRunner output --
+    and, for the decoder with shared projections and a sentinel, the RNN beam search (beam 2, alpha 1.0, 3 steps)
+    with what ``BeamSearchRunner(rank=2)`` makes of it -- against the oracle."""
+    z, cfg, params = load("ini_flat")
+    gcfg = G.Config(enc_name="sentence_encoder", dec_name="decoder_" + tag, rnn_layers=((4, "bidirectional", "GRU"),),
+                    rnn_size=3)
+    mcfg = M.MultiConfig(kind="flat", att_name=wrapper, state_size=5, share=share, sentinel=sentinel,
+                         image_name="imagenet", image_spatial=(None, None))
+    model = M.MultiSourceModel(params, gcfg, mcfg)
+    src, tgt = (z["in/src_ids"], z["in/maps"]), z["in/tgt_ids"]
+    assert src[0].shape == (1, 3) and src[1].shape == (1, 8, 8, 2048) and tgt.shape[0] <= 3
+    pre = "out/{}/".format(tag)
+    with torch.no_grad():
+        (s_txt, _), _, final = model.encode(src, False)
+        close(s_txt, z["out/enc_states"], "encoder states")
+        close(final[:, :8], z["out/enc_output"], "encoder output")
+        loss, logits, _ = model.train_loss(src, tgt, train=False)
+    # (1e-5: the projections of the feature map are 2048-term float32 sums, added in another order by NumPy and torch)
+    close(logits, z[pre + "train_logits"], "train logits", 1e-5)
+    close(loss, z[pre + "train_loss"], "train loss")
+    syms, masks, run_logits = model.greedy(src, 3)
+    same(syms, z[pre + "runtime_symbols"], "greedy symbols")
+    same(masks, z[pre + "runtime_mask"], "runtime mask")
+    close(run_logits, z[pre + "runtime_logits"], "runtime logits", 1e-5)
+    tvoc = [str(w) for w in z["in/tgt_vocabulary"]]
+    amax = torch.log_softmax(torch.tensor(run_logits), -1).numpy().argmax(-1)
+    got = [" ".join(tvoc[i] for i in sent) for sent in O.greedy_tokens(O.DecodeResult(run_logits, None, amax, None, None,
+                                                                                      None, None))]
+    assert got == [str(s) for s in z[pre + "runner_sentences"]]
+    close(float(loss), z[pre + "runner_losses"][0], "runner train_xent")
+    if tag != "flat_share_sentinel":
+        return
+    k, max_steps, rank = (int(v) for v in z["cfg/beam"])
+    tok, scores, gap = model.beam(src, k, max_steps, 1.0)
+    assert gap > 1e-5
+    same(tok, z["out/beam_token_ids"], "beam token ids")
+    close(scores, z["out/beam_scores"], "beam scores", 4e-6)
+    ids = []
+    for t in tok[1:, 0, rank - 1]:
+        if t == O.END:
+            break
+        ids.append(int(t))
+    assert " ".join(tvoc[t] for t in ids) == str(z["out/beam_runner_sentences"][0])
+    close(float(scores[0, rank - 1]), z["out/beam_runner_loss"], "beam runner loss", 4e-6)
