@@ -1782,6 +1782,74 @@ def run_ini_flat(case):
     save(case, {"kind": "ini", "ini": "flat-multiattention", "batch": int(out["in/src_ids"].shape[0])}, out)
 
 
+TRAINER_INIS = collections.OrderedDict([("small", ["trainer"]), ("bahdanau", ["trainer1", "trainer2", "greedy_trainer"]),
+                                        ("post-edit", ["trainer"])])
+
+
+def run_ini_trainer_objectives(case):
+    """trainers/generic_trainer.py:84-134 (what a training step minimises) for the trainers of three acceptance
+    configurations, built by the reference's parser and builder from the files as they are: which variables the
+    regulariser covers (trainable, no ``[Bb]ias`` in the name, :87-91), the L1 and L2 sums over them,
+    ``objective_values`` (losses, L1, L2) and ``differentiable_loss_sum`` (objective weights, ``l1_weight``,
+    ``l2_weight``) on the first training batch with train_mode False, and the trainer's ``var_list``.  The optimizer
+    and ``tf.gradients`` are TensorFlow's and are not run."""
+    import collections.abc
+    collections.Iterable = collections.abc.Iterable
+    import re
+    from neuralmonkey.config import parsing
+    from neuralmonkey.config.builder import ObjectRef, build_config
+    from neuralmonkey.experiment import Experiment
+    bias = re.compile(r"[Bb]ias")
+    cwd = os.getcwd()
+    os.chdir(REFERENCE)
+    os.environ.setdefault("NM_EXPERIMENT_NAME", "small")
+    out = {}
+    try:
+        for ini, sections in TRAINER_INIS.items():
+            fresh_graph()
+            with open(os.path.join("tests", ini + ".ini"), encoding="utf-8") as handle:
+                _, parsed = parsing.parse_file(handle.read().splitlines(True))
+            main = parsed["main"]
+            Experiment._current_experiment = experiment_stand_in(main.get("batch_size"))
+            parsed["main"] = collections.OrderedDict([(sec, ObjectRef(sec)) for sec in sections]
+                                                     + [("train_dataset", main["train_dataset"])])
+            try:
+                built, _ = build_config(parsed, ignore_names=set())
+            finally:
+                Experiment._current_experiment = None
+            trainers = [built[sec] for sec in sections]
+            batch = next(iter(built["train_dataset"].batches()))
+            feedables = sorted(set.union(*[set(t.feedables) | {t} for t in trainers]),
+                               key=lambda f: str(getattr(f, "name", type(f).__name__)))
+            inputs = {}
+            for part in feedables:
+                for series, dtype in part.input_types.items():
+                    if series not in inputs:
+                        inputs[series] = tf.placeholder(dtype, part.input_shapes[series], series)
+            record = collections.OrderedDict()
+            with tf_eager.feeding(feed(feedables, batch, False, inputs)):
+                for sec, trainer in zip(sections, trainers):
+                    values = [float(v.numpy()) for v in trainer.objective_values]
+                    record[sec] = {"objective_values": values,
+                                   "differentiable_loss_sum": float(trainer.differentiable_loss_sum.numpy()),
+                                   "l1_weight": trainer.l1_weight, "l2_weight": trainer.l2_weight,
+                                   "clip_norm": trainer.clip_norm,
+                                   "objective_names": [obj.name for obj in trainer.objectives],
+                                   "objective_weights": [obj.weight for obj in trainer.objectives],
+                                   "var_list": [v.name for v in trainer.var_list]}
+            order, params = variables()
+            trainable = [v.name for v in tf.trainable_variables()]
+            record["_regularizable"] = [n for n in trainable if not bias.findall(n)]
+            record["_trainable"] = trainable
+            out["out/" + ini] = np.asarray(json.dumps(record))
+            for name in order:
+                out["vars/{}/{}".format(ini, name)] = params[name]
+    finally:
+        os.chdir(cwd)
+    fresh_graph()
+    save(case, {"kind": "ini_trainer_objectives", "files": list(TRAINER_INIS)}, out)
+
+
 def run_defects(case):
     """Configurations the reference cannot execute at this commit: the exception IS the reference behaviour."""
     import traceback
@@ -1902,6 +1970,7 @@ CASES = collections.OrderedDict([
     ("ini_variables", lambda: run_ini_variables("ini_variables")),
     ("ini_postedit", lambda: run_ini_postedit("ini_postedit")),
     ("ini_flat", lambda: run_ini_flat("ini_flat")),
+    ("ini_trainer_objectives", lambda: run_ini_trainer_objectives("ini_trainer_objectives")),
     ("schedules", lambda: run_schedules("schedules")),
     ("ini_grammar", lambda: run_ini_grammar("ini_grammar")),
     ("config_builder", lambda: run_config_builder("config_builder")),

@@ -156,6 +156,30 @@ def test_flat_multiattention_ini_on_the_engine_equals_the_reference_built_model(
         <= 1e-5 * abs(float(fixture["out/beam_runner_loss"]))
 
 
+@pytest.mark.parametrize("name,section", [("bahdanau", "greedy_trainer"), ("bahdanau", "trainer1"),
+                                          ("post-edit", "trainer")])
+def test_trainer_losses_on_the_engine_equal_the_reference_trainers(dev, ref_root, name, section):      # noqa: F811
+    """``objective_values`` of the reference's trainers on their first training batch (fixture
+    ``ini_trainer_objectives``: decoder cost, L1, L2 over the reference's choice of variables, train_mode False)
+    against the losses the engine's trainer reports for the same variables and batch."""
+    import json
+    from .test_reference_inis import _product_trainers
+    z = np.load(os.path.join(HERE, "golden", "ref_exec", "ini_trainer_objectives.npz"))
+    want = json.loads(str(z["out/" + name]))[section]
+    model = load_verbatim(ref_root, name, device=str(dev), seed=3)
+    tfm = model.tf_manager
+    store = tfm.sessions[0].store
+    store.load_state_dict({n: z["vars/{}/{}".format(name, n)] for n in store.names()})
+    trainer = _product_trainers(model, name)[section]
+    batch = next(iter(model.train_dataset.batches()))
+    res = tfm.execute(batch, trainer.feedables, [trainer], train=False)[0]
+    loss, l1, l2 = want["objective_values"]
+    keys = list(res.losses)
+    assert keys[-2:] == ["L1", "L2"] and keys[0] == want["objective_names"][0]
+    assert abs(res.losses[keys[0]] - loss) <= 1e-4 * abs(loss)
+    assert abs(res.losses["L1"] - l1) <= 1e-5 * l1 and abs(res.losses["L2"] - l2) <= 1e-5 * l2
+
+
 def test_small_ini_checkpoint_holds_the_references_variables(dev, ref_root, tmp_path):      # noqa: F811
     """``variables.data`` as the engine writes it for tests/small.ini: the names and shapes the reference's Saver
     would look for (fixture ``ini_variables``), GRUCell.build's unread variables included; read back, it restores

@@ -67,7 +67,7 @@ def test_every_generated_case_is_checked_here():
                       "vocabulary_formats", "host_text_pipeline", "schedules", "ini_grammar", "config_builder",
                       "dataset_loading", "ini_bahdanau", "ini_beamsearch", "ini_factored", "ini_small",
                       "editops", "ini_postedit", "ini_flat",        # below
-                      "ini_variables"]        # tests/test_reference_inis.py
+                      "ini_variables", "ini_trainer_objectives"]        # tests/test_reference_inis.py
                      + BEAM_BODY_CASES + RNN_CASES + TRANSFORMER_CASES
                      + VARIANT_CASES + FD_CASES)
     assert have == checked
