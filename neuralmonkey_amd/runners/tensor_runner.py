@@ -20,8 +20,9 @@ class TensorRunner(BaseRunner):
                 per_session = [self._examples(res) for res in results]
                 batched = list(zip(*per_session))
             else:
-                index = self.executor.select_session or 0
-                batched = self._examples(results[index if len(results) > 1 else 0])
+                # tensor_runner.py:33-34: with ``select_session`` set the reference hands out the FIRST session's
+                # tensors, whatever the number says (pinned by the reference-executed fixture ``tensor_runner``)
+                batched = self._examples(results[0])
             self.set_runner_result(outputs=batched, losses=[])
 
         def _examples(self, sess_results: Dict) -> List:

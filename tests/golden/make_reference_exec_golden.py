@@ -936,6 +936,67 @@ def run_greedy_runner_ensemble(case):
     save(case, {"kind": "greedy_runner_ensemble", "tgt_vocab": cfg["tgt_vocab"], "batch": bsz}, out)
 
 
+def canonical_rows(rows):
+    """TensorRunner outputs as JSON-able structures: arrays -> nested lists, dicts keep their key order."""
+    def one(v):
+        if isinstance(v, dict):
+            return {"dict": [[k, one(x)] for k, x in v.items()]}
+        if isinstance(v, (list, tuple)):
+            return {type(v).__name__: [one(x) for x in v]}
+        return {"array": np.asarray(v).tolist()}
+    return one(rows)
+
+
+def run_tensor_runner(case):
+    """``TensorRunner.Executable.collect_results`` (runners/tensor_runner.py:24-55, plain NumPy in the reference) on
+    hand-made session results: the batch axis of every fetched tensor moved to the front and cut into one entry per
+    example, as dictionaries or -- ``single_tensor`` -- bare arrays; several sessions zipped example by example, or,
+    with ``select_session`` set, SESSION 0'S RESULTS whatever the number says (:27-34).  The runner's constructor
+    checks (:105-118) with their texts; ``RepresentationRunner`` is a single-tensor TensorRunner."""
+    from neuralmonkey.runners.tensor_runner import RepresentationRunner, TensorRunner
+    cfg = dict(RNN_DEFAULT)
+    fresh_graph()
+    enc, att, dec, parts = build_rnn(cfg)
+    rng = np.random.default_rng(47)
+    sessions = [{"a": rng.normal(size=(3, 2, 4)).astype(np.float32), "b": rng.normal(size=(5, 3)).astype(np.float32)}
+                for _ in range(3)]
+    out = {}
+    for i, res in enumerate(sessions):
+        out["in/a{}".format(i)], out["in/b{}".format(i)] = res["a"], res["b"]
+    settings = collections.OrderedDict([
+        ("one_session", dict(n=1, select=None, single=False)), ("three_sessions", dict(n=3, select=None, single=False)),
+        ("three_sessions_select_2", dict(n=3, select=2, single=False)),
+        ("single_tensor", dict(n=1, select=None, single=True)),
+        ("single_tensor_three_sessions", dict(n=3, select=None, single=True))])
+    record = {}
+    for tag, st in settings.items():
+        names = ["a"] if st["single"] else ["a", "b"]
+        runner = TensorRunner(output_series="dbg", modelparts=[enc] * len(names),
+                              tensors=["temporal_states"] * len(names), batch_dims=[0] * len(names),
+                              tensors_by_name=[], batch_dims_by_name=[], select_session=st["select"],
+                              single_tensor=st["single"])
+        runner.batch_ids = {"a": 0, "b": 1}                 # (what ``fetches`` would have filled in: a's batch axis 0, b's 1)
+        ex = runner.get_executable(compute_losses=False, summaries=False, num_sessions=st["n"])
+        ex.collect_results([{k: res[k] for k in names} for res in sessions[:st["n"]]])
+        record[tag] = {"outputs": canonical_rows(ex.result.outputs["dbg"]), "losses": dict(ex.result.losses)}
+    errors = {}
+    for tag, kw in (("no_parts", dict(modelparts=[], tensors=[], batch_dims=[])),
+                    ("lengths", dict(modelparts=[enc], tensors=["output", "temporal_states"], batch_dims=[0, 0])),
+                    ("single_of_two", dict(modelparts=[enc, enc], tensors=["output", "temporal_states"],
+                                           batch_dims=[0, 0], single_tensor=True))):
+        try:
+            TensorRunner(output_series="dbg", tensors_by_name=[], batch_dims_by_name=[], **kw)
+            errors[tag] = ""
+        except Exception as exc:        # noqa: BLE001
+            errors[tag] = "{}: {}".format(type(exc).__name__, exc)
+    rep = RepresentationRunner(output_series="encoded", encoder=enc)
+    record["representation"] = {"single_tensor": rep.single_tensor, "batch_dims": rep.batch_dims,
+                                "tensors": rep._tensors, "loss_names": rep.loss_names}
+    out["out/record"] = np.asarray(json.dumps(record))
+    out["out/errors"] = np.asarray(json.dumps(errors))
+    save(case, {"kind": "tensor_runner"}, out)
+
+
 def run_dataset_batching(case):
     """``Dataset.batches`` (dataset.py:467-579): fixed-size batches and length buckets (a row goes to the TIGHTEST
     bucket that fits the longest of its series, to the last one when none does), with and without the remainder.
@@ -1977,6 +2038,7 @@ CASES = collections.OrderedDict([
     ("dataset_loading", lambda: run_dataset_loading("dataset_loading")),
     ("dataset_batching", lambda: run_dataset_batching("dataset_batching")),
     ("greedy_runner_ensemble", lambda: run_greedy_runner_ensemble("greedy_runner_ensemble")),
+    ("tensor_runner", lambda: run_tensor_runner("tensor_runner")),
     ("ensemble", lambda: run_ensemble("ensemble")),
     ("transformer", lambda: run_transformer("transformer")),
     ("transformer_bias_untied", lambda: run_transformer(
