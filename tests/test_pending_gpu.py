@@ -10,7 +10,9 @@ What they cover:
   * the early half of the optimizer step (NM_OPT_EARLY, trainers/generic_trainer.py: the decoders' variables are
     updated on a side lane beside the encoders' backward; trainers/generic_trainer.py:136-195 of the reference is the
     arithmetic, which must not change): three steps with it equal three steps without it;
-  * a checkpoint written by the engine for a NematusGRU model holds exactly the reference's variables.
+  * the launches in front of the encoder's BPTT loop inside that loop's graph (NM_ENC_BWD_GRAPH): nothing changes;
+  * a checkpoint written by the engine for a NematusGRU model holds exactly the reference's variables;
+  * the trainers' reported losses against the reference trainers' ``objective_values``.
 """
 import os
 
@@ -202,19 +204,21 @@ def test_small_ini_checkpoint_holds_the_references_variables(dev, ref_root, tmp_
     assert all(torch.equal(store[n], before[n]) for n in store.names())
 
 
-def _three_steps(dev, monkeypatch, early):
+def _three_steps(dev, monkeypatch, early, prologue_in_graph=False, steps=3):
     import torch
     from neuralmonkey_amd import synthetic
+    from neuralmonkey_amd.encoders import recurrent
     from neuralmonkey_amd.trainers import generic_trainer
     from oracle import nm_oracle as O
     monkeypatch.setattr(generic_trainer, "OPT_EARLY", early)
+    monkeypatch.setattr(recurrent, "BWD_PROLOGUE_IN_GRAPH", prologue_in_graph)
     model = synthetic.build_translation_model(vocab_src=2000, vocab_tgt=2000, emb=64, rnn=64, max_len=24,
                                               beam_size=0, device=str(dev), l2_weight=1e-6, clip_norm=1.0)
     sess = model.tf_manager.sessions[0]
     sess.store.load_state_dict(O.init_params(seed=3, vocab_src=2000, vocab_tgt=2000, emb=64, rnn=64, std=0.1))
     ds = synthetic.synthetic_dataset(seed=4, batch=32, src_len=24, tgt_len=20, vocab=2000, ragged=True)
     losses = []
-    for _ in range(3):
+    for _ in range(steps):
         res = model.tf_manager.execute(ds, model.trainer.feedables, [model.trainer], train=True)[0]
         losses.append([float(res.losses[k]) for k in ("decoder - cost", "L1", "L2")])
     torch.cuda.synchronize()
@@ -231,3 +235,13 @@ def test_early_optimizer_half_changes_no_parameter(dev, monkeypatch):
     assert np.allclose(l_early, l_plain, rtol=1e-6, atol=0.0), (l_early, l_plain)
     for name, want in p_plain.items():
         assert np.array_equal(p_early[name], want), name
+
+
+def test_encoder_backward_prologue_inside_the_loop_graph_changes_nothing(dev, monkeypatch):
+    """NM_ENC_BWD_GRAPH (encoders/recurrent.py): the same launches in the same order, ten of them moved into the BPTT
+    loop's HIP graph -- eager pass, capture and three replays against the plain path, bit for bit."""
+    l_graph, p_graph, _, _ = _three_steps(dev, monkeypatch, False, prologue_in_graph=True, steps=5)
+    l_plain, p_plain, _, _ = _three_steps(dev, monkeypatch, False, prologue_in_graph=False, steps=5)
+    assert l_graph == l_plain
+    for name, want in p_plain.items():
+        assert np.array_equal(p_graph[name], want), name
