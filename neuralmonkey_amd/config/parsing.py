@@ -122,6 +122,11 @@ def parse_value(text: str, variables: VarsDict) -> Any:
     raise ParseError("Cannot parse value: '{}'.".format(text))
 
 
+# the names under which the reference's own unit tests reach the value grammar (neuralmonkey/tests/test_config.py)
+_parse_value = parse_value
+_split_on_commas = _split_top_level
+
+
 def _read_ini(lines: Iterable[str]) -> "OrderedDict[str, OrderedDict]":
     """Sections -> key -> (line number, raw text).  configparser joins
     continuation lines; the line number of a key is that of its first line."""

@@ -63,7 +63,7 @@ def preindex(dataset: Dataset, feedables: Iterable) -> Dataset:
             items = [np.fromiter((w2i.get(tok, UNK_TOKEN_INDEX) for tok in sent), dtype=np.int32, count=len(sent))
                      for sent in items]
         series[name] = items
-    return Dataset(dataset.name, series, dataset.batching, dataset.outputs, dataset.shuffled)
+    return Dataset(dataset.name, series, dataset.batching, dataset.outputs, None, dataset.shuffled)
 
 
 class Prefetcher:

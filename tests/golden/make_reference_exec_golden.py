@@ -997,6 +997,70 @@ def run_tensor_runner(case):
     save(case, {"kind": "tensor_runner"}, out)
 
 
+LAZY_SHUFFLE_SETTINGS = collections.OrderedDict([
+    ("eager_shuffled", dict(scheme=dict(batch_size=4), buffer=None, shuffled=True)),
+    ("eager_shuffled_buckets", dict(scheme=dict(bucket_boundaries=[3, 6], bucket_batch_sizes=[3, 2, 4]), buffer=None,
+                                    shuffled=True)),
+    ("lazy", dict(scheme=dict(batch_size=4), buffer=[6, 10], shuffled=False)),
+    ("lazy_buckets_drop", dict(scheme=dict(bucket_boundaries=[3, 6], bucket_batch_sizes=[3, 2, 4], drop_remainder=True),
+                               buffer=[6, 10], shuffled=False)),
+    ("lazy_shuffled", dict(scheme=dict(batch_size=4), buffer=[6, 10], shuffled=True)),
+    ("lazy_shuffled_buckets", dict(scheme=dict(bucket_boundaries=[3, 6], bucket_batch_sizes=[3, 2, 4]), buffer=[5, 9],
+                                   shuffled=True)),
+    ("lazy_small_low_mark", dict(scheme=dict(batch_size=4), buffer=[2, 7], shuffled=True)),
+])
+
+
+def run_dataset_lazy_shuffle(case):
+    """``Dataset`` (dataset.py:335-640; no TensorFlow) as a LAZY and as a SHUFFLED dataset: rows drawn into a buffer
+    of ``buffer_size`` that is topped up when fewer than ``buffer_min_size`` are left, ``random.shuffle`` of all rows
+    (eager) or of the buffer at every top-up (lazy), two passes after one ``random.seed(11)`` each; ``len()`` of a
+    lazy dataset, ``subset`` (rows 5..16, passed once), and how often the series' factories are opened."""
+    fresh_graph()                 # (no variables of an earlier case in this fixture)
+    import random
+    from neuralmonkey.dataset import BatchingScheme, Dataset
+    rng = np.random.default_rng(53)
+    rows = 23
+    src = [["s{}".format(i)] + ["x"] * int(rng.integers(0, 8)) for i in range(rows)]
+    tgt = [["t{}".format(i)] + ["y"] * int(rng.integers(0, 7)) for i in range(rows)]
+    out = {"in/source_lengths": np.asarray([len(s) for s in src]), "in/target_lengths": np.asarray([len(t) for t in tgt])}
+    record = {}
+    for tag, st in LAZY_SHUFFLE_SETTINGS.items():
+        opened = {"source": 0, "target": 0}
+
+        def factory(key, items):
+            def open_series():
+                opened[key] += 1
+                return iter(items)
+            return open_series
+        ds = Dataset("data", {"source": factory("source", src), "target": factory("target", tgt)},
+                     BatchingScheme(**st["scheme"]), None, None if st["buffer"] is None else tuple(st["buffer"]),
+                     st["shuffled"])
+        after_init = dict(opened)
+        random.seed(11)
+        passes, names = [], []
+        for _ in range(2):
+            batches = []
+            for b in ds.batches():
+                ids = [int(row[0][1:]) for row in b.get_series("source")]
+                assert ids == [int(row[0][1:]) for row in b.get_series("target")]
+                batches.append(ids)
+                names.append(b.name)
+            passes.append(batches)
+        try:
+            length = len(ds)
+        except NotImplementedError as exc:
+            length = "NotImplementedError: {}".format(exc)
+        random.seed(11)
+        sub = ds.subset(5, 11)
+        record[tag] = {"passes": passes, "names": names[:3], "len": length, "opened_at_init": after_init,
+                       "opened_after_two_passes": dict(opened), "series": ds.series, "lazy": ds.lazy,
+                       "subset_name": sub.name, "subset_lazy": sub.lazy,
+                       "subset_batches": [[int(row[0][1:]) for row in b.get_series("source")] for b in sub.batches()]}
+    out["out/record"] = np.asarray(json.dumps(record))
+    save(case, {"kind": "dataset_lazy_shuffle", "rows": rows, "settings": LAZY_SHUFFLE_SETTINGS}, out)
+
+
 def run_dataset_batching(case):
     """``Dataset.batches`` (dataset.py:467-579): fixed-size batches and length buckets (a row goes to the TIGHTEST
     bucket that fits the longest of its series, to the last one when none does), with and without the remainder.
@@ -2037,6 +2101,7 @@ CASES = collections.OrderedDict([
     ("config_builder", lambda: run_config_builder("config_builder")),
     ("dataset_loading", lambda: run_dataset_loading("dataset_loading")),
     ("dataset_batching", lambda: run_dataset_batching("dataset_batching")),
+    ("dataset_lazy_shuffle", lambda: run_dataset_lazy_shuffle("dataset_lazy_shuffle")),
     ("greedy_runner_ensemble", lambda: run_greedy_runner_ensemble("greedy_runner_ensemble")),
     ("tensor_runner", lambda: run_tensor_runner("tensor_runner")),
     ("ensemble", lambda: run_ensemble("ensemble")),

@@ -66,7 +66,15 @@ def test_reference_ini_builds_unmodified(ref_root, name):
     from neuralmonkey_amd.config.builder import OutOfScope
     model = load_verbatim(ref_root, name, initialize=False, device="cpu")
     assert model.trainers and model.runners
-    assert len(model.train_dataset) > 0 and model.val_dataset is not None
+    # (tests/small.ini and tests/beamsearch*.ini give their training data a ``buffer_size``: lazy datasets, whose
+    # length the reference refuses to tell -- dataset.py:407-419 -- and so does the product)
+    if name in ("small", "beamsearch", "beamsearch_ensembles"):
+        assert model.train_dataset.lazy
+        with pytest.raises(NotImplementedError, match="Querying the len of a lazy dataset."):
+            len(model.train_dataset)
+    else:
+        assert len(model.train_dataset) > 0
+    assert len(next(iter(model.train_dataset.batches()))) > 0 and model.val_dataset is not None
     # the evaluation list survives with its series names; the evaluators are placeholders
     assert model.evaluation and all(isinstance(item[-1], OutOfScope) for item in model.evaluation)
     assert model.batch_size > 0 and model.epochs > 0 and isinstance(model.output, str)
