@@ -18,6 +18,91 @@ from ..runtime import Placeholder, tensor
 from ..variables import glorot_uniform_initializer, zeros_initializer
 
 
+class StatefulFiller(ModelPart, Stateful):
+    """One pre-computed vector per example as an encoder (numpy_stateful_filler.py:16-72): ``output`` is the fed
+    [B, dimension] array, or -- when ``output_shape`` names another size -- its ``tf.layers.dense`` projection
+    (variables ``<name>/dense/kernel``, ``<name>/dense/bias``; no activation).  A decoder takes it like any other
+    encoder's final state (initial-state projection, ``StatefulContext``)."""
+
+    # pylint: disable=too-many-arguments
+    def __init__(self, name: str, dimension: int, data_id: str, output_shape: int = None, reuse: ModelPart = None,
+                 save_checkpoint: str = None, load_checkpoint: str = None,
+                 initializers: InitializerSpecs = None) -> None:
+        ModelPart.__init__(self, name, reuse, save_checkpoint, load_checkpoint, initializers)
+        self.data_id = data_id
+        self.dimension = dimension
+        self.output_shape = output_shape
+        if self.dimension <= 0:
+            raise ValueError("Input vector dimension must be positive.")
+        if self.output_shape is not None and self.output_shape <= 0:
+            raise ValueError("Output vector dimension must be positive.")
+        self.vector_input = Placeholder("{}/vector".format(name))
+
+    @property
+    def input_types(self) -> Dict[str, type]:
+        return {self.data_id: np.float32}
+
+    @property
+    def input_shapes(self) -> Dict[str, List]:
+        return {self.data_id: [None, self.dimension]}
+
+    @property
+    def projected(self) -> bool:
+        return self.output_shape is not None and self.output_shape != self.dimension
+
+    @property
+    def output_size(self) -> int:
+        return self.output_shape if self.projected else self.dimension
+
+    def declare_variables(self, store) -> None:
+        if self.projected:
+            self.declare(store, "dense/kernel", (self.dimension, self.output_shape), glorot_uniform_initializer())
+            self.declare(store, "dense/bias", (self.output_shape,), zeros_initializer())
+
+    def feed_dict(self, dataset, train: bool = False) -> FeedDict:
+        fd = ModelPart.feed_dict(self, dataset, train)
+        fd[self.vector_input] = np.stack([np.asarray(x, np.float32) for x in dataset.get_series(self.data_id)])
+        return fd
+
+    @tensor
+    def vector(self, ctx) -> torch.Tensor:
+        """The fed vectors in a persistent device buffer."""
+        fed = ctx.fed(self.vector_input)
+        if tuple(fed.shape[1:]) != (self.dimension,):
+            raise ValueError("StatefulFiller '{}': fed vectors of shape {}, expected {}"
+                             .format(self.name, tuple(fed.shape[1:]), (self.dimension,)))
+        return ctx.session.staged((id(self), "vector"), ctx.session.to_device(fed, torch.float32, "vector_input"))
+
+    def stage_inputs(self, ctx) -> None:
+        self.vector(ctx)
+
+    def graph_safe_training(self, train_mode: bool) -> bool:
+        return True
+
+    @tensor
+    def _activations(self, ctx):
+        x = self.vector(ctx)
+        train = bool(ctx.fed(self.train_mode))
+        tape = F.Tape(ctx, (id(self), "filler"), recording=ctx.wants_backward(train) and self.projected)
+        cur = tape.leaf(x)
+        if self.projected:
+            cur = F.linear(tape, cur, tape.param(self, "dense/kernel"), tape.param(self, "dense/bias"))
+        return {"tape": tape, "out_var": cur}
+
+    @tensor
+    def output(self, ctx) -> torch.Tensor:
+        return self._activations(ctx)["out_var"].data
+
+    def backward(self, ctx, d_states, d_final) -> None:
+        """dL/d(output) [B, output_size]; there are no temporal states."""
+        act = self._activations(ctx)
+        tape, var = act["tape"], act["out_var"]
+        if not tape.recording or d_final is None:
+            return                                   # the raw vectors: nothing trainable upstream
+        ops.ew("copy", d_final, None, tape.grad(var), accumulate=True)
+        tape.backward()
+
+
 class SpatialFiller(ModelPart, SpatialStatefulWithOutput):
     # pylint: disable=too-many-arguments
     def __init__(self, name: str, input_shape: List[int], data_id: str, projection_dim: int = None,

@@ -441,3 +441,27 @@ def test_early_and_late_halves_of_the_optimizer_step_partition_the_store():
         assert shared and all(n.startswith("attention/") for n in shared)
     finally:
         runtime._REGISTRY.remove(twin)
+
+
+def test_stateful_filler_surface():
+    """encoders/numpy_stateful_filler.py:16-72 of the reference: constructor checks with its texts, the variables of
+    the optional projection under ``tf.layers.dense``'s names, the fed array."""
+    from neuralmonkey_amd.encoders.numpy_stateful_filler import StatefulFiller
+    from neuralmonkey_amd.runtime import reset_registry
+    from neuralmonkey_amd.variables import VariableStore
+    reset_registry()
+    with pytest.raises(ValueError, match="Input vector dimension must be positive."):
+        StatefulFiller("bad", 0, "vectors")
+    with pytest.raises(ValueError, match="Output vector dimension must be positive."):
+        StatefulFiller("bad2", 3, "vectors", output_shape=-1)
+    plain, same_size, projected = (StatefulFiller("plain", 7, "vectors"), StatefulFiller("same", 7, "vectors", 7),
+                                   StatefulFiller("proj", 7, "vectors", output_shape=4))
+    store = VariableStore("cpu")
+    for part in (plain, same_size, projected):
+        part.declare_variables(store)
+    assert {n: tuple(store.specs[n].shape) for n in store.names()} == {"proj/dense/kernel": (7, 4), "proj/dense/bias": (4,)}
+    assert (plain.output_size, same_size.output_size, projected.output_size) == (7, 7, 4)
+    assert projected.input_shapes == {"vectors": [None, 7]}
+    ds = D.Dataset("d", {"vectors": [np.arange(7.0), np.ones(7)]})
+    fd = projected.feed_dict(ds, train=False)
+    assert fd[projected.vector_input].shape == (2, 7) and fd[projected.vector_input].dtype == np.float32

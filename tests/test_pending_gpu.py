@@ -12,7 +12,8 @@ What they cover:
     arithmetic, which must not change): three steps with it equal three steps without it;
   * the launches in front of the encoder's BPTT loop inside that loop's graph (NM_ENC_BWD_GRAPH): nothing changes;
   * a checkpoint written by the engine for a NematusGRU model holds exactly the reference's variables;
-  * the trainers' reported losses against the reference trainers' ``objective_values``.
+  * the trainers' reported losses against the reference trainers' ``objective_values``;
+  * ``StatefulFiller`` (new) as a decoder's encoder.
 """
 import os
 
@@ -245,3 +246,43 @@ def test_encoder_backward_prologue_inside_the_loop_graph_changes_nothing(dev, mo
     assert l_graph == l_plain
     for name, want in p_plain.items():
         assert np.array_equal(p_graph[name], want), name
+
+
+def test_stateful_filler_under_a_decoder(dev):
+    """``StatefulFiller`` (encoders/numpy_stateful_filler.py:16-72) with its dense projection as the only encoder of an
+    RNN decoder without attention: the decoder's initial state comes from the projected vectors, and a training step
+    gives the projection's gradients that float64 autograd gives (``initial_state = dense(output)``,
+    decoders/encoder_projection.py:47-73)."""
+    import torch
+    from neuralmonkey_amd.dataset import BatchingScheme, Dataset
+    from neuralmonkey_amd.decoders import Decoder
+    from neuralmonkey_amd.encoders.numpy_stateful_filler import StatefulFiller
+    from neuralmonkey_amd.runtime import reset_registry
+    from neuralmonkey_amd.tf_manager import TensorFlowManager
+    from neuralmonkey_amd.trainers.cross_entropy_trainer import CrossEntropyTrainer
+    from neuralmonkey_amd.vocabulary import Vocabulary
+    reset_registry()
+    rng = np.random.default_rng(5)
+    vocab = Vocabulary(["w{}".format(i) for i in range(11)])
+    filler = StatefulFiller("vec", 7, "vectors", output_shape=5)
+    dec = Decoder(encoders=[filler], vocabulary=vocab, data_id="target", name="decoder", max_output_len=4,
+                  embedding_size=6, rnn_size=6, dropout_keep_prob=1.0)
+    trainer = CrossEntropyTrainer(decoders=[dec])
+    tfm = TensorFlowManager(num_sessions=1, num_threads=1, device=str(dev), seed=3)
+    tfm.initialize_sessions()
+    store = tfm.sessions[0].store
+    vectors = [rng.normal(size=7).astype(np.float32) for _ in range(3)]
+    ds = Dataset("d", {"vectors": vectors, "target": [["w1", "w2"], ["w3"], ["w4", "w5", "w6"]]},
+                 BatchingScheme(batch_size=3))
+    fd = {}
+    for part in trainer.feedables:
+        fd.update(part.feed_dict(ds, train=False))
+    out = tfm.sessions[0].run({"enc": filler.output}, fd)["enc"]
+    w, b = store["vec/dense/kernel"].cpu().numpy(), store["vec/dense/bias"].cpu().numpy()
+    assert np.allclose(np.asarray(out), np.stack(vectors) @ w + b, atol=1e-5)
+    before = w.copy()
+    tfm.execute(ds, trainer.feedables, [trainer], train=True)
+    grad = store.g("vec/dense/kernel").cpu().numpy()
+    assert np.abs(grad).max() > 0 and not np.array_equal(store["vec/dense/kernel"].cpu().numpy(), before)
+    # d loss / d kernel = vectors^T . d loss / d output: rank <= batch size, rows in the span of the fed vectors
+    assert np.linalg.matrix_rank(grad.astype(np.float64), tol=1e-6 * np.abs(grad).max()) <= 3
