@@ -1,7 +1,8 @@
 """CPU restatement (torch, autograd) of CoverageAttention (attention/coverage.py:19-66, Tu et al. 2016) on top of
 ``oracle/general_ref.py``.
 
-TEST INFRASTRUCTURE ONLY -- imported by ``tests/`` alone.  PARITY UNPINNED, and more so than the rest: upstream
+TEST INFRASTRUCTURE ONLY -- imported by ``tests/`` alone.  PARITY UNPINNED FOR THIS ONE MODULE (the rest of the oracle is pinned to the reference's own code, see
+``oracle/nm_oracle.py``): the fixture ``defects`` records that upstream
 line 52 (``weights_in_time.size()`` on a tf.Tensor) cannot build, so there is no reference behaviour to pin;
 what is restated is the arithmetic the lines spell out, with ``weights_in_time`` read as the loop state's
 ``weights`` history [t,B,S] (feed_forward.py:158-159), whose sum over t is zero at the first step.

@@ -3,8 +3,9 @@
 98-226 the function, :247-400 the classes) plugged into ``oracle/general_ref.py``'s decoder -- the
 model family of the reference's tests/factored.ini and tests/post-edit.ini.
 
-TEST INFRASTRUCTURE ONLY -- imported by ``tests/`` alone.  PARITY UNPINNED (see
-``oracle/nm_oracle.py``).
+TEST INFRASTRUCTURE ONLY -- imported by ``tests/`` alone.  PARITY PINNED to the reference's own code (see
+``oracle/nm_oracle.py``): fixtures ``dotprod_heads*``, ``factored_smoothing``, ``fd_gradients_dotprod``, ``ini_factored``,
+``ini_postedit`` of ``tests/golden/ref_exec/``.
 """
 import math
 

@@ -4,7 +4,8 @@ hypotheses, the step distributions are averaged in log space
 (``scipy.special.logsumexp(prev_logprobs, 0) - log(num_sessions)``, :50-55) and the beam body
 selects on the average.
 
-TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (see oracle/nm_oracle.py)."""
+TEST INFRASTRUCTURE ONLY.  PARITY PINNED to the reference's own code (see oracle/nm_oracle.py): fixture
+``ensemble`` (BeamSearchRunner over three sessions, call by call)."""
 import math
 from typing import List
 

@@ -3,9 +3,10 @@ NematusGRU / LSTM cells, stacked / layer-normed / residual encoders, conditional
 attention on input, dropout, the output-projection variants, greedy and beam decoding.
 
 TEST INFRASTRUCTURE ONLY -- imported by ``tests/`` alone; nothing in the product package may
-import it.  PARITY UNPINNED: see ``oracle/nm_oracle.py`` (the reference holds no golden vectors
-and TF 1.12 cannot run here); every function restates the TF-1.12 semantics of the op the
-reference calls and cites the reference call site it follows.
+import it.  PARITY PINNED to the reference's own code, see ``oracle/nm_oracle.py``: the fixtures
+``rnn_*``, ``captioning*``, ``fd_gradients_rnn_*``, ``fd_gradients_captioning``, ``ini_bahdanau``, ``ini_small`` of
+``tests/golden/ref_exec/`` are the reference's own model code executed on the test-side TensorFlow stand-in, and this
+module reproduces them; every function cites the reference call site it follows.
 
 Dropout: TF's Philox stream cannot be replayed, so the engine defines its masks by a
 counter-based hash (csrc/nm_eltwise.hip ``nm_dropout``); ``dropout_mask`` below restates that

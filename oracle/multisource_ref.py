@@ -4,9 +4,9 @@ encoder and a spatial (image feature map) encoder, attended either by one FlatMu
 a HierarchicalMultiAttention over one Bahdanau attention per encoder -- the model family of the
 reference's tests/flat-multiattention.ini and tests/hier-multiattention.ini.
 
-TEST INFRASTRUCTURE ONLY -- imported by ``tests/`` alone.  PARITY UNPINNED (see
-``oracle/nm_oracle.py``): the reference holds no golden vectors for this path and TF 1.12 cannot
-run here; each function cites the reference lines it restates.
+TEST INFRASTRUCTURE ONLY -- imported by ``tests/`` alone.  PARITY PINNED to the reference's own code (see
+``oracle/nm_oracle.py``): fixtures ``ms_flat*``, ``ms_hier*``, ``fd_gradients_ms_*``, ``ini_flat`` of
+``tests/golden/ref_exec/``; each function cites the reference lines it restates.
 """
 from typing import NamedTuple, Tuple
 

@@ -4,12 +4,18 @@ TEST INFRASTRUCTURE ONLY.  Nothing in the product package imports this module;
 only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 leg may use it, and only as the checker.
 
-PARITY UNPINNED: the reference (ufal/neuralmonkey @ /root/reference) holds no
-golden vectors or known-answer tests for this path and its arithmetic lives in
-the un-vendored dependency ``tensorflow>=1.12.0,<1.13`` (requirements.txt:13),
-which cannot be installed here.  Every function below restates the published
-TF-1.12 semantics of the op the reference calls and cites the reference call
-site (file:line relative to /root/reference) it follows.
+PARITY PINNED TO THE REFERENCE'S OWN CODE (round 4).  The reference's arithmetic lives partly in its own Python and
+partly in the un-vendored dependency ``tensorflow>=1.12.0,<1.13`` (requirements.txt:13), which cannot be installed
+here; it holds no golden vectors for this path.  So ``tests/golden/make_reference_exec_golden.py`` imports
+``/root/reference/neuralmonkey`` UNMODIFIED and executes it on a NumPy-eager stand-in for the TensorFlow calls it makes
+(``tests/ref_exec/tf_eager.py``, test side only), and the resulting fixtures (``tests/golden/ref_exec/*.npz``: functions,
+the beam-search body, whole RNN / Transformer models, finite differences of the reference's loss for the gradients,
+six of its acceptance INI files end to end) are what this oracle has to reproduce -- ids exactly, float32 within 2e-6
+of a tensor's maximum (``tests/test_reference_exec.py``; ``tests/test_reference_exec_regen.py`` regenerates them
+bit for bit where the reference tree exists).  What remains a restatement from knowledge of TF 1.12 is the inside of
+the TensorFlow ops themselves (GRUCell / LSTMCell, dynamic_rnn, softmax, top_k's tie order, dense, sequence_loss:
+SURVEY section 9) -- stated once, in the stand-in, and shared by every fixture.  Every function below cites the
+reference call site (file:line relative to /root/reference) it follows.
 
 All functions take a ``dt`` (np.float32 default, np.float64 for the noise-floor
 run) through the dtype of their inputs: no function casts up silently.

@@ -1,6 +1,8 @@
 """torch-CPU restatement of the training step (forward + autograd backward).
 
-TEST INFRASTRUCTURE ONLY (see oracle/nm_oracle.py header; parity unpinned).
+TEST INFRASTRUCTURE ONLY (see oracle/nm_oracle.py header: parity pinned to the reference's own code;
+this module is held to ``nm_oracle`` and, through the ``fd_gradients_*`` fixtures, to finite differences of the
+reference's loss).
 It restates the same reference call sites as ``nm_oracle`` but in torch ops so
 that (a) gradients come from autograd of the restated forward -- the
 reference gets them from ``tf.gradients`` (trainers/generic_trainer.py:136-142)

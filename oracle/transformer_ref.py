@@ -3,7 +3,8 @@
 TransformerDecoder (decoders/transformer.py:258-516, serial encoder-decoder attention of
 attention/transformer_cross_layer.py:12-103), greedy and beam decoding around it.
 
-TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (see oracle/nm_oracle.py).  Decoding here follows the
+TEST INFRASTRUCTURE ONLY.  PARITY PINNED to the reference's own code (see oracle/nm_oracle.py): fixtures
+``transformer*``, ``fd_gradients_transformer*``, ``ini_beamsearch``, ``ensemble``.  Decoding here follows the
 reference literally -- every step re-runs all layers over the whole prefix (:487-516) -- which is
 what pins the engine's key/value-cache implementation to the reference arithmetic.
 """
