@@ -1,8 +1,8 @@
 """Generate the committed golden vectors from the CPU oracle.
 
-The reference holds no golden vectors for this path and cannot run here
-(TensorFlow 1.12 absent), so these pin the ORACLE (parity unpinned, see
-oracle/nm_oracle.py).  Re-run only when the oracle is deliberately changed:
+The reference holds no golden vectors for this path, so these freeze the ORACLE'S outputs against silent
+drift.  (Since round 4 the oracle itself is pinned to the reference's own code: see oracle/nm_oracle.py and
+tests/golden/make_reference_exec_golden.py.)  Re-run only when the oracle is deliberately changed:
 
     python tests/golden/make_golden.py
 """

@@ -1,7 +1,8 @@
 """Golden vectors of the configurable-model oracles (oracle/general_ref.py, multisource_ref.py,
 dotprod_ref.py, transformer_ref.py): loss, gradient norms, greedy symbols and beam hypotheses of one
 seeded model per family.  Like tiny.npz / mid.npz these pin the ORACLE against accidental change
-(parity with the reference itself is unpinned: no TF 1.12 here, no vectors in the reference).  The
+(frozen oracle outputs; parity with the reference itself is pinned separately, by the reference-executed fixtures of
+tests/golden/make_reference_exec_golden.py).  The
 parameters come from the engine's own variable store built on the CPU device (host-side plumbing
 only; no kernel runs), so the generator also exercises the plugin surface.
 
