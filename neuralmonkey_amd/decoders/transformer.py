@@ -401,6 +401,20 @@ class TransformerDecoder(AutoregressiveDecoder):
         return out
 
     @tensor
+    def train_logprobs(self, ctx) -> torch.Tensor:
+        """[T,B,V] log-softmax of the teacher-forced logits (autoregressive.py:288-290); the kernels of
+        ``runtime_logprobs`` on ``train_logits``."""
+        logits = self.train_logits(ctx)
+        t, b, v = logits.shape
+        logits = logits.contiguous()
+        mx = ctx.buffer((id(self), "train_lp_max"), (t * b,))
+        lse = ctx.buffer((id(self), "train_lp_lse"), (t * b,))
+        ops.row_stats(logits.view(t * b, v), mx, lse, None)
+        out = ctx.buffer((id(self), "train_logprobs"), (t, b, v))
+        ops.log_softmax_from_stats(logits.view(t * b, v), mx, lse, out.view(t * b, v))
+        return out
+
+    @tensor
     def runtime_output_states(self, ctx) -> torch.Tensor:
         return self.runtime_loop_result(ctx).output_states
 

@@ -286,3 +286,20 @@ def test_stateful_filler_under_a_decoder(dev):
     assert np.abs(grad).max() > 0 and not np.array_equal(store["vec/dense/kernel"].cpu().numpy(), before)
     # d loss / d kernel = vectors^T . d loss / d output: rank <= batch size, rows in the span of the fed vectors
     assert np.linalg.matrix_rank(grad.astype(np.float64), tol=1e-6 * np.abs(grad).max()) <= 3
+
+
+def test_train_logprobs_is_the_log_softmax_of_the_train_logits(dev):
+    """``AutoregressiveDecoder.train_logprobs`` (autoregressive.py:288-290; new here, for runners that fetch it by
+    name): tf.nn.log_softmax of the teacher-forced logits."""
+    import torch
+    from neuralmonkey_amd import synthetic
+    model = synthetic.build_translation_model(vocab_src=300, vocab_tgt=300, emb=32, rnn=32, max_len=12, beam_size=0,
+                                              device=str(dev))
+    ds = synthetic.synthetic_dataset(seed=4, batch=6, src_len=9, tgt_len=8, vocab=300, ragged=True)
+    dec = model.decoder
+    fd = {}
+    for part in model.trainer.feedables:
+        fd.update(part.feed_dict(ds, train=False))
+    out = model.tf_manager.sessions[0].run({"logits": dec.train_logits, "logprobs": dec.train_logprobs}, fd)
+    want = torch.log_softmax(torch.as_tensor(np.asarray(out["logits"])).double(), -1).numpy()
+    assert np.abs(np.asarray(out["logprobs"]) - want).max() < 1e-5
