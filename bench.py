@@ -760,6 +760,14 @@ def main():
                          "warm_how": "inside a greedy decode of one B={} batch, {} steps, launched eagerly".format(
                              args.batch, args.length),
                          "algorithmic_bytes_per_launch": step_bytes},
+            "roofline_train": (lambda fl, sec: {
+                "what": "the timed region of `value`: one whole training step (forward, backward, clip, Adam) against "
+                        "the fp32 matrix-core peak; flops = 2 x multiply-adds of every dense product, forward + "
+                        "backward (synthetic.translation_train_flops: the Bahdanau energies / contexts on the vector "
+                        "units are not counted)",
+                "bound": "mfma", "flops_per_step": fl, "achieved": fl / sec / 1e12, "peak": MFMA_F32_PEAK_TF,
+                "unit": "TFLOP/s", "frac": fl / sec / 1e12 / MFMA_F32_PEAK_TF})(
+                    synthetic.translation_train_flops(args.batch, args.length, args.vocab, h), elapsed / args.steps),
             "roofline_step": {"what": "one greedy decoder step (GRU + attention + output projection + logits + "
                                       "argmax), HIP-graph replayed", "bound": "hbm",
                               "algorithmic_bytes_per_step": dstep_bytes, "us_per_step": dstep_us,

@@ -475,6 +475,13 @@ int nm_optim_clip_adam(void* stream, float* theta, const float* grad, float* m, 
                        const int32_t* seg_first, const int32_t* seg_count, const int32_t* seg_flags,
                        int64_t nchunk, int64_t nseg, float clip_norm, float lr_t, float beta1,
                        float beta2, float epsilon, void* workspace, int64_t workspace_bytes);
+/* tf.train.AdadeltaOptimizer (tests/bpe.ini:102-108, tests/str.ini:100-106; TF 1.12 ApplyAdadelta) behind the same
+ * per-tensor clip: accum / accum_update are the optimizer's two slots, `lr` the plain learning rate. */
+int nm_optim_clip_adadelta(void* stream, float* theta, const float* grad, float* accum, float* accum_update,
+                           const int64_t* chunk_start, const int32_t* chunk_len, const int32_t* chunk_seg,
+                           const int32_t* seg_first, const int32_t* seg_count, const int32_t* seg_flags,
+                           int64_t nchunk, int64_t nseg, float clip_norm, float lr, float rho, float epsilon,
+                           void* workspace, int64_t workspace_bytes);
 
 /* ---- data-parallel gradient exchange (the reference is single-device, tf_manager.py:62-100): the
  * in-place sum over ranks of slices of the flat gradient buffer on RCCL, ordered against HIP streams only.  RCCL is

@@ -96,6 +96,7 @@ SIGNATURES = {
     "nm_optim_workspace_bytes": (L, [L, L]),
     "nm_optim_regularize_norms": (I, [P, P, P, P, P, P, P, P, P, L, L, F, F, P, P, L]),
     "nm_optim_clip_adam": (I, [P, P, P, P, P, P, P, P, P, P, P, L, L, F, F, F, F, F, P, L]),
+    "nm_optim_clip_adadelta": (I, [P, P, P, P, P, P, P, P, P, P, P, L, L, F, F, F, F, P, L]),
     "nm_gather_rows_f32": (I, [P, P, L, P, P, L, L, L]),
     "nm_beam_reorder_tokens": (I, [P, P, P, P, P, L, L]),
     "nm_beam_backtrace": (I, [P, P, P, P, P, L, L]),

@@ -1,51 +1,47 @@
-"""What configuration parsing and loading raise.  The three public classes carry the attributes and print the texts
-a caller of the reference sees (neuralmonkey/config/exceptions.py); the texts are pinned by the reference-executed
-fixtures "ini_grammar" and "config_builder" under tests/golden."""
+"""What configuration parsing and loading raise: the attributes and the texts a caller of the reference sees
+(neuralmonkey/config/exceptions.py); the texts are pinned by the reference-executed fixtures "ini_grammar" and
+"config_builder" under tests/golden."""
 import traceback
 
 
-class _ConfigError(Exception):
-    """Named fields, kept as attributes, and one line of text made from them on demand."""
-    fields = ()
-
-    def __init__(self, *values) -> None:
-        Exception.__init__(self)
-        values = values + (None,) * (len(self.fields) - len(values))
-        for field, value in zip(self.fields, values):
-            setattr(self, field, value)
-
-    def describe(self) -> str:
-        raise NotImplementedError
-
-    def __str__(self) -> str:
-        return self.describe()
-
-
-class ParseError(_ConfigError):
+class ParseError(Exception):
     """A line of an INI file that the value grammar does not accept; ``line`` is filled in by the file parser."""
-    fields = ("message", "line")
+
+    def __init__(self, message, line=None) -> None:
+        super().__init__()
+        self.message = message
+        self.line = line
 
     def set_line(self, line) -> None:
         self.line = line
 
-    def describe(self) -> str:
+    def __str__(self) -> str:
         where = "parsing error" if self.line is None else "error on line {}".format(self.line)
         return "INI {}: {}".format(where, self.message)
 
 
-class ConfigInvalidValueException(_ConfigError):
+class ConfigInvalidValueException(Exception):
     """A section that cannot be turned into an object (undefined, without a class, not callable)."""
-    fields = ("value", "message")
 
-    def describe(self) -> str:
-        return "Error in configuration of {0.value}: {0.message}".format(self)
+    def __init__(self, value, message) -> None:
+        super().__init__()
+        self.value = value
+        self.message = message
+
+    def __str__(self) -> str:
+        return "Error in configuration of {}: {}".format(self.value, self.message)
 
 
-class ConfigBuildException(_ConfigError):
+class ConfigBuildException(Exception):
     """Whatever went wrong while the object named ``object_name`` was being built, kept in ``original_exception``."""
-    fields = ("object_name", "original_exception")
 
-    def describe(self) -> str:
-        frames = traceback.extract_tb(self.original_exception.__traceback__)
+    def __init__(self, object_name, original_exception=None) -> None:
+        super().__init__()
+        self.object_name = object_name
+        self.original_exception = original_exception
+
+    def __str__(self) -> str:
+        # (a value that is not an exception, or none at all, has no traceback: the text must still print)
+        frames = traceback.extract_tb(getattr(self.original_exception, "__traceback__", None))
         return "Error while loading '{}': {}\nTraceback: {}".format(
             self.object_name, self.original_exception, "".join(traceback.format_list(frames)))

@@ -40,6 +40,7 @@ static inline hipStream_t nm_stream(void* s) { return reinterpret_cast<hipStream
 // live attention-step timer and the device the context was made for.  Entry points take the context that is
 // bound to the calling thread (nm_ctx_bind); a thread that never bound one uses the process default context,
 // created on first use.
+#include <atomic>
 #include <utility>
 #include <vector>
 

@@ -17,6 +17,8 @@
 //                 global->VGPR directly (no LDS for operands), deterministic
 //                 LDS reduction over the K slices.  Latency- not
 //                 throughput-bound, so the grid is (M/32)*(N/32) blocks.
+#include <atomic>
+
 #include "nm_common.h"
 
 #include <stdlib.h>
@@ -932,19 +934,22 @@ static inline int bg_pad(int want_lds, int static_lds) {
 
 // Launch with ``pad`` bytes of dynamic LDS the kernel never touches (residency cap, see nm_gemm_f32 algo 4).  More
 // than 64 KB per workgroup needs the attribute once per kernel and device (``devs``: one bit per device).
+// Per kernel: one bit per device for "attribute set" (low half) and "attribute refused" (high half), so the attribute
+// call happens once per kernel and device whatever its answer; contexts live on several threads, hence atomic.
+typedef std::atomic<unsigned> DevMask;
+
 template <typename Kern, typename... Args>
-static void launch_padded(Kern kern, unsigned& devs, int pad, dim3 grid, dim3 block, hipStream_t st, Args... args) {
+static void launch_padded(Kern kern, DevMask& devs, int pad, dim3 grid, dim3 block, hipStream_t st, Args... args) {
     if (pad > 0) {
-        const unsigned bit = 1u << (nm_cur()->device & 31);
-        if (!(devs & bit)) {
-            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    NM_GEMM_BG_MAX_PAD) != hipSuccess) {
-                (void)hipGetLastError();
-                if (pad > 30 * 1024) pad = 30 * 1024;      // fits without the attribute: a weaker cap
-            } else {
-                devs |= bit;
-            }
+        const unsigned ok_bit = 1u << (nm_cur()->device & 15), bad_bit = ok_bit << 16;
+        unsigned seen = devs.load(std::memory_order_relaxed);
+        if (!(seen & (ok_bit | bad_bit))) {
+            const bool ok = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                NM_GEMM_BG_MAX_PAD) == hipSuccess;
+            if (!ok) (void)hipGetLastError();
+            seen = devs.fetch_or(ok ? ok_bit : bad_bit, std::memory_order_relaxed) | (ok ? ok_bit : bad_bit);
         }
+        if ((seen & bad_bit) && pad > 30 * 1024) pad = 30 * 1024;      // fits without the attribute: a weaker cap
     }
     hipLaunchKernelGGL(kern, grid, block, (size_t)pad, st, args...);
 }
@@ -969,7 +974,7 @@ static void launch_skinny(const GemmArgs& g_in, int batch, bool tb, const GruEpi
         const int tiles_m = nm_cdiv(g.M, 16), tiles_n = nm_cdiv(g.N, 16);
         dim3 grid(tiles_m * tiles_n, 1, (unsigned)batch);
         const int ks = (K >= 512) ? 16 : 8;
-        static unsigned devs16[4] = {0, 0, 0, 0};
+        static DevMask devs16[4];
 #define NM_GS16(KS_, I_)                                                                                               \
     do {                                                                                                               \
         const int pad = bg_pad(want, KS_ * 1024);                                                                      \
@@ -984,7 +989,7 @@ static void launch_skinny(const GemmArgs& g_in, int batch, bool tb, const GruEpi
     const int tiles_m = nm_cdiv(g.M, 32), tiles_n = nm_cdiv(g.N, 32);
     dim3 grid(tiles_m * tiles_n, 1, (unsigned)batch);
     const int ks = (K >= 512) ? 16 : (K >= 256 ? 8 : (K >= 128 ? 4 : 1));
-    static unsigned devs32[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    static DevMask devs32[8];
 #define NM_GS(KS_, I_)                                                                                               \
     do {                                                                                                             \
         const int pad = bg_pad(want, KS_ * 4096);                                                                    \
@@ -1005,7 +1010,7 @@ template <int WM, int WN, int TM, int TN, int BK, int PF = 1, int NCH = 1>
 static void launch_tiled(const GemmArgs& g, int batch, bool ta, bool tb, bool vec, hipStream_t st, int pad_lds = 0) {
     const int tiles_m = nm_cdiv(g.M, WM * 32 * TM), tiles_n = nm_cdiv(g.N, WN * 32 * TN);
     dim3 grid(tiles_m * tiles_n, g.splitk, batch), block(WM * WN * 64);
-    static unsigned attr_devs[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // per kernel instance (ta, tb, vec), one bit per device
+    static DevMask attr_devs[8];                                   // per kernel instance (ta, tb, vec), one bit per device
 #define NM_GT(TA_, TB_, V_)                                                                              \
     launch_padded(gemm_tiled<WM, WN, TM, TN, TA_, TB_, V_, BK, false, PF, NCH>,                         \
                   attr_devs[(TA_ ? 4 : 0) + (TB_ ? 2 : 0) + (V_ ? 1 : 0)], pad_lds, grid, block, st, g, tiles_m)

@@ -388,12 +388,12 @@ extern "C" int nm_xent_colsum(void* stream, float* logits, int64_t ldx, int64_t 
     const int nv = (int)((V / 4 + XC_NT - 1) / XC_NT);
 #define NM_XC(NV_)                                                                                                    \
     do {                                                                                                              \
-        static unsigned attr_devs = 0; /* per device */                                                               \
+        static std::atomic<unsigned> attr_devs{0}; /* per device */                                                               \
         const unsigned attr_bit = 1u << (nm_cur()->device & 31);                                                      \
-        if (!(attr_devs & attr_bit)) {                                                                                \
+        if (!(attr_devs.load(std::memory_order_relaxed) & attr_bit)) {                                                                                \
             (void)hipFuncSetAttribute((const void*)xent_cols_kernel<NV_>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                       144 * 1024);                                                                    \
-            attr_devs |= attr_bit;                                                                                    \
+            attr_devs.fetch_or(attr_bit, std::memory_order_relaxed);                                                                                    \
         }                                                                                                             \
         hipLaunchKernelGGL((xent_cols_kernel<NV_>), dim3((unsigned)partial_rows), dim3(XC_NT), (size_t)V * 4,           \
                            nm_stream(stream), logits, (long)ldx, (int)V, (int)rows, targets, weights, loss_rows,      \
@@ -866,7 +866,8 @@ extern "C" int nm_row_stats(void* stream, const float* x, int64_t ldx, int64_t r
 // from softmax(x), as argmax_c (x[r,c] + g[r,c]) with Gumbel noise g = -log(-log(u)).  TF's Philox stream cannot be
 // replayed by anyone; u is a counter-based hash of (salt, row, column) as for dropout (nm_eltwise.hip), so that the
 // CPU checker restates the draw (oracle/nm_oracle.py:gumbel_noise):
-//   key = mix32(salt + row * 0x85EBCA6B),  bits = mix32(column * 0x9E3779B1 + key),  u = ((bits >> 8) + 0.5) / 2^24.
+//   key = mix32(salt + row * 0x85EBCA6B),  bits = mix32(column * 0x9E3779B1 + key),  u = ((bits >> 9) + 0.5) / 2^23
+// (23 bits + 0.5 is exact in fp32, so u stays strictly inside (0, 1) and the noise finite for every bit pattern).
 // The caller folds the step (and whatever else distinguishes two draws) into ``salt``.  Ties: the first maximum.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t sample_mix32(uint32_t x) {
@@ -886,10 +887,10 @@ __global__ __launch_bounds__(256) void gumbel_argmax_kernel(const float* __restr
     const float* row = x + (long)r * ldx;
     const uint32_t key = sample_mix32(salt + (uint32_t)r * 0x85EBCA6Bu);
     float best = -INFINITY;
-    int bi = 0x7fffffff;
+    int bi = 0;                                       // a row of NaN / -inf logits still yields a valid symbol
     for (int c = threadIdx.x; c < V; c += 256) {
         const uint32_t bits = sample_mix32((uint32_t)c * 0x9E3779B1u + key);
-        const float u = ((float)(bits >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float u = ((float)(bits >> 9) + 0.5f) * (1.0f / 8388608.0f);
         const float v = row[c] - logf(-logf(u));
         if (v > best) { best = v; bi = c; }           // ascending columns per thread: its first maximum
     }

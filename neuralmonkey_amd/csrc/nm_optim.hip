@@ -4,6 +4,7 @@
 //   grad += l1_weight*sign(v) + 2*l2_weight*v                     (d/dv of :118-134)
 //   per-tensor tf.clip_by_norm: g * c / max(||g||, c)              (:179-186)
 //   Adam (tf.train.AdamOptimizer, :55-57): lr_t = lr*sqrt(1-b2^t)/(1-b1^t)
+//   Adadelta (tf.train.AdadeltaOptimizer, tests/bpe.ini:102-108): TF 1.12 ApplyAdadelta
 // All variables live in one flat buffer (variables.py); a host-built chunk
 // table maps fixed-size chunks to variables ("segments") so that three launches
 // cover every tensor and all reductions have a fixed order (deterministic).
@@ -116,6 +117,31 @@ __global__ __launch_bounds__(256) void opt_adam_kernel(OptChunks t, float* __res
     }
 }
 
+// pass 3, Adadelta: accum <- rho*accum + (1-rho)*g^2; update = sqrt(accum_update + eps) * rsqrt(accum + eps) * g;
+// var -= lr*update; accum_update <- rho*accum_update + (1-rho)*update^2   (the order TF's kernel evaluates them in)
+__global__ __launch_bounds__(256) void opt_adadelta_kernel(OptChunks t, float* __restrict__ theta,
+                                                           const float* __restrict__ grad,
+                                                           float* __restrict__ accum, float* __restrict__ accum_update,
+                                                           const float* __restrict__ seg_norm2, float clip,
+                                                           float lr, float rho, float eps) {
+    const int c = blockIdx.x;
+    const int seg = t.chunk_seg[c];
+    if (!(t.seg_flags[seg] & 2)) return;
+    const long base = t.chunk_start[c];
+    const int len = t.chunk_len[c];
+    float scale = 1.0f;
+    if (clip > 0.0f) scale = clip / fmaxf(sqrtf(seg_norm2[seg]), clip);
+    for (int i = threadIdx.x; i < len; i += 256) {
+        const float g = grad[base + i] * scale;
+        const float a = rho * accum[base + i] + (1.0f - rho) * g * g;
+        const float au = accum_update[base + i];
+        const float upd = sqrtf(au + eps) * (1.0f / sqrtf(a + eps)) * g;
+        accum[base + i] = a;
+        theta[base + i] -= lr * upd;
+        accum_update[base + i] = rho * au + (1.0f - rho) * upd * upd;
+    }
+}
+
 static OptChunks make_chunks(const int64_t* chunk_start, const int32_t* chunk_len, const int32_t* chunk_seg,
                              const int32_t* seg_first, const int32_t* seg_count, const int32_t* seg_flags,
                              int64_t nchunk, int64_t nseg) {
@@ -166,4 +192,20 @@ extern "C" int nm_optim_clip_adam(void* stream, float* theta, const float* grad,
     hipLaunchKernelGGL(opt_adam_kernel, dim3((unsigned)nchunk), dim3(256), 0, nm_stream(stream), t, theta,
                        grad, m, v, seg_norm2, clip_norm, lr_t, beta1, beta2, epsilon);
     NM_LAUNCH_CHECK("nm_optim_clip_adam");
+}
+
+extern "C" int nm_optim_clip_adadelta(void* stream, float* theta, const float* grad, float* accum, float* accum_update,
+                                      const int64_t* chunk_start, const int32_t* chunk_len,
+                                      const int32_t* chunk_seg, const int32_t* seg_first, const int32_t* seg_count,
+                                      const int32_t* seg_flags, int64_t nchunk, int64_t nseg, float clip_norm,
+                                      float lr, float rho, float epsilon, void* workspace,
+                                      int64_t workspace_bytes) {
+    NM_REQUIRE(theta && grad && accum && accum_update && workspace, "nm_optim_clip_adadelta: null pointer");
+    NM_REQUIRE(nchunk > 0 && nseg > 0 && workspace_bytes >= nm_optim_workspace_bytes(nchunk, nseg),
+               "nm_optim_clip_adadelta: bad sizes");
+    OptChunks t = make_chunks(chunk_start, chunk_len, chunk_seg, seg_first, seg_count, seg_flags, nchunk, nseg);
+    const float* seg_norm2 = reinterpret_cast<const float*>(workspace) + nchunk * 3;
+    hipLaunchKernelGGL(opt_adadelta_kernel, dim3((unsigned)nchunk), dim3(256), 0, nm_stream(stream), t, theta,
+                       grad, accum, accum_update, seg_norm2, clip_norm, lr, rho, epsilon);
+    NM_LAUNCH_CHECK("nm_optim_clip_adadelta");
 }

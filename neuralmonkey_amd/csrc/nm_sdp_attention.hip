@@ -226,11 +226,11 @@ extern "C" int nm_sdp_attn_fwd(void* stream, const float* q, int64_t q_bs, const
     if (nm_cur()->sw.sdp_decode && sdp_decode_launch(p, nullptr, 0, nm_stream(stream))) {     // one query per row
         NM_LAUNCH_CHECK("nm_sdp_attn_fwd (decode)");
     }
-    static unsigned attr_devs = 0;                     // the attribute is per device: one bit per device id
+    static std::atomic<unsigned> attr_devs{0};                     // the attribute is per device: one bit per device id
     const unsigned attr_bit = 1u << (nm_cur()->device & 31);
-    if (!(attr_devs & attr_bit)) {
+    if (!(attr_devs.load(std::memory_order_relaxed) & attr_bit)) {
         (void)hipFuncSetAttribute((const void*)sdp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_devs |= attr_bit;
+        attr_devs.fetch_or(attr_bit, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL(sdp_fwd_kernel, dim3((unsigned)(Bq * H)), dim3(256), lds, nm_stream(stream), p);
     NM_LAUNCH_CHECK("nm_sdp_attn_fwd");
@@ -392,14 +392,14 @@ extern "C" int nm_sdp_attn_bwd(void* stream, const float* q, int64_t q_bs, const
     if (nm_sdp_mfma_bwd(a, nm_stream(stream))) {
         NM_LAUNCH_CHECK("nm_sdp_attn_bwd (mfma)");
     }
-    static unsigned attr_devs = 0;                     // per device, as above
+    static std::atomic<unsigned> attr_devs{0};                     // per device, as above
     const unsigned attr_bit = 1u << (nm_cur()->device & 31);
-    if (!(attr_devs & attr_bit)) {
+    if (!(attr_devs.load(std::memory_order_relaxed) & attr_bit)) {
         (void)hipFuncSetAttribute((const void*)sdp_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    160 * 1024);
         (void)hipFuncSetAttribute((const void*)sdp_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    160 * 1024);
-        attr_devs |= attr_bit;
+        attr_devs.fetch_or(attr_bit, std::memory_order_relaxed);
     }
     if (wlds) hipLaunchKernelGGL(sdp_bwd_kernel<true>, dim3((unsigned)(B * H)), dim3(256), lds, nm_stream(stream), a);
     else hipLaunchKernelGGL(sdp_bwd_kernel<false>, dim3((unsigned)(B * H)), dim3(256), lds, nm_stream(stream), a);

@@ -166,13 +166,13 @@ static size_t sdp_fwd_mfma_lds() { return sizeof(float) * 16 * NKT * ((16 * NDT 
 template <int NKT, int NDT>
 static void sdp_fwd_mfma_launch(const SdpArgs& p, hipStream_t stream) {
     // the attribute is per DEVICE (library contexts exist per device: nm_create): one bit per device id
-    static unsigned attr_devs = 0;
+    static std::atomic<unsigned> attr_devs{0};
     const unsigned attr_bit = 1u << (nm_cur()->device & 31);
     const size_t lds = sdp_fwd_mfma_lds<NKT, NDT>();
-    if (!(attr_devs & attr_bit)) {
+    if (!(attr_devs.load(std::memory_order_relaxed) & attr_bit)) {
         (void)hipFuncSetAttribute((const void*)sdp_fwd_mfma_kernel<NKT, NDT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds);
-        attr_devs |= attr_bit;
+        attr_devs.fetch_or(attr_bit, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL((sdp_fwd_mfma_kernel<NKT, NDT>), dim3((unsigned)(p.Bq * p.H), (unsigned)((p.Tq + 63) / 64)),
                        dim3(256), lds, stream, p);
@@ -434,14 +434,14 @@ static size_t sdp_bwd_mfma_lds() {
 
 template <int NT, int NDT>
 static bool sdp_bwd_mfma_launch(const SdpBwdArgs& a, hipStream_t stream) {
-    static unsigned attr_devs = 0;                     // per device, as in sdp_fwd_mfma_launch
+    static std::atomic<unsigned> attr_devs{0};                     // per device, as in sdp_fwd_mfma_launch
     const unsigned attr_bit = 1u << (nm_cur()->device & 31);
     const size_t lds = sdp_bwd_mfma_lds<NT, NDT>();
     if (lds > 160 * 1024) return false;
-    if (!(attr_devs & attr_bit)) {
+    if (!(attr_devs.load(std::memory_order_relaxed) & attr_bit)) {
         (void)hipFuncSetAttribute((const void*)sdp_bwd_mfma_kernel<NT, NDT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds);
-        attr_devs |= attr_bit;
+        attr_devs.fetch_or(attr_bit, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL((sdp_bwd_mfma_kernel<NT, NDT>), dim3((unsigned)(a.f.Bq * a.f.H)), dim3(256), lds, stream, a);
     return true;

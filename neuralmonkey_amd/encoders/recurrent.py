@@ -11,7 +11,6 @@ GEMMs (both directions batched in one launch) with fused gate / blend
 epilogue kernels that implement the length masking and the reversed indexing
 of the backward direction in-kernel, so there is no reverse_sequence copy.
 """
-import os
 from typing import Callable, List, NamedTuple, Optional, Tuple, Union
 
 import torch
@@ -29,9 +28,6 @@ from ..variables import ones_initializer, orthogonal_initializer, zeros_initiali
 from ..vocabulary import Vocabulary
 
 RNN_CELL_TYPES = ("NematusGRU", "GRU", "LSTM")
-# NM_ENC_BWD_GRAPH=1: the launches in front of the encoder's BPTT loop inside the loop's HIP graph
-# (RecurrentEncoder._backward_loop_with_prologue).  Off by default: written after round 4's GPU time was spent.
-BWD_PROLOGUE_IN_GRAPH = os.environ.get("NM_ENC_BWD_GRAPH", "0") == "1"
 RNN_DIRECTIONS = ["forward", "backward", "bidirectional"]
 
 RNNSpecTuple = Union[Tuple[int], Tuple[int, str], Tuple[int, str, str]]
@@ -296,61 +292,6 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
         ctx.session.graphed((id(self), "bwd_loop", bsz, slen, d_states_raw is not None), bptt_loop)
         return dxp
 
-    def _backward_loop_with_prologue(self, ctx, sv, d_states, d_final) -> torch.Tensor:
-        """``_backward_loop`` with the ten launches in front of the loop (layer norm's backward, its column sums, the
-        clearing of ``dh`` / ``dxp``) INSIDE the loop's graph: one graph launch instead of ten eager launches between
-        the decoder's BPTT loop and this one (NM_ENC_BWD_GRAPH=1; ``profiles/r04_train_step_timeline_background.txt``
-        shows the main queue 0.55 ms idle there, a launch every 65 us).  The incoming gradients are somebody else's
-        buffers: their addresses are part of the graph's key, so a caller that hands over fresh tensors gets a fresh
-        capture instead of a stale read -- and after a few different addresses (graphs are never freed) the plain path."""
-        pointers = tuple(None if t is None else t.data_ptr()
-                         for t in (d_states, d_final, sv["states_raw"], sv["final_raw"]))
-        seen = ctx.session.__dict__.setdefault("_enc_bwd_graph_inputs", {}).setdefault(id(self), set())
-        seen.add(pointers)
-        if len(seen) > 4:
-            return self._backward_loop(ctx, sv, d_states, d_final)
-        store = ctx.store
-        x, lengths = sv["x"], sv["lengths"]
-        bsz, slen, _ = x.shape
-        ndir, h, rev0 = sv["ndir"], sv["h"], sv["reverse_only"]
-        c_out = ndir * h
-        key = (id(self), "bwd")
-        states_raw, final_raw = sv["states_raw"], sv["final_raw"]
-        norm = self.include_final_layer_norm
-        buf = lambda name, shape: ctx.buffer(key + (name,), shape)
-        d_states_raw = buf("d_states_raw", (bsz, slen, c_out)) if norm and d_states is not None else d_states
-        d_final_raw = buf("d_final_raw", (bsz, c_out)) if norm and d_final is not None else d_final
-        tmp, tmp2 = buf("ln_tmp", (bsz * slen, c_out)), buf("ln_tmp2", (bsz, c_out))
-        dh, dxp = buf("dh", (ndir, bsz, h)), buf("dxp", (bsz * slen, ndir * 3 * h))
-        dgpre, dcpre, drh = buf("dgpre", (2, ndir, bsz, 2 * h)), buf("dcpre", (ndir, bsz, h)), buf("drh", (ndir, bsz, h))
-        seq_strides = (h, slen * c_out, c_out)
-        dxp_strides = (3 * h, slen * ndir * 3 * h, ndir * 3 * h)
-        wgh, wch = sv["wgh"], sv["wch"]
-
-        def prologue_and_loop():
-            if norm:
-                gamma = self.var(ctx, "LayerNorm/gamma")
-                g_gamma = store.g(self.var_name("LayerNorm/gamma"))
-                g_beta = store.g(self.var_name("LayerNorm/beta"))
-                if d_states is not None:
-                    ops.layer_norm_bwd(d_states, states_raw, sv["st_mean"], sv["st_rstd"], gamma, d_states_raw, tmp)
-                    ops.colsum(tmp, g_gamma, accumulate=True)
-                    ops.colsum(d_states.view(bsz * slen, c_out), g_beta, accumulate=True)
-                if d_final is not None:
-                    ops.layer_norm_bwd(d_final, final_raw, sv["fi_mean"], sv["fi_rstd"], gamma, d_final_raw, tmp2)
-                    ops.colsum(tmp2, g_gamma, accumulate=True)
-                    ops.colsum(d_final, g_beta, accumulate=True)
-            dh.zero_()
-            if d_final_raw is not None:
-                for d in range(ndir):
-                    ops.copy_cols(d_final_raw[:, d * h:(d + 1) * h], dh[d])
-            dxp.zero_()
-            gru.bptt(slen, dh, d_states_raw, seq_strides if d_states_raw is not None else None, sv["ru_all"],
-                     sv["c_all"], None, states_raw, seq_strides, dxp, dxp_strides, wgh, wch, lengths, ndir, bsz,
-                     h, rev0, dgpre, dcpre, drh)
-        ctx.session.graphed((id(self), "bwd_loop_all", bsz, slen, norm, pointers), prologue_and_loop)
-        return dxp
-
     def backward(self, ctx, d_states: Optional[torch.Tensor], d_final: Optional[torch.Tensor]) -> None:
         """dL/d(temporal_states) [B,S,C] and dL/d(output) [B,C] -> variable
         gradients of this encoder and of its input sequence."""
@@ -366,10 +307,7 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
         key = (id(self), "bwd")
         states_raw, final_raw = sv["states_raw"], sv["final_raw"]
 
-        if BWD_PROLOGUE_IN_GRAPH:
-            dxp = self._backward_loop_with_prologue(ctx, sv, d_states, d_final)
-        else:
-            dxp = self._backward_loop(ctx, sv, d_states, d_final)
+        dxp = self._backward_loop(ctx, sv, d_states, d_final)
 
         # ---- weight gradients, batched over all positions
         hprev = ctx.buffer(key + ("hprev",), (bsz, slen, ndir, h))

@@ -5,6 +5,7 @@ op on the hot path is a libnmhip kernel launched on torch's current stream.
 """
 import ctypes
 import os
+import threading
 from typing import Optional
 
 import numpy as np
@@ -88,14 +89,27 @@ GEMM_WORKSPACE_BYTES = 128 << 20
 # the launch goes to -- but every torch.cuda.graph capture uses torch's ONE capture stream, so two captured graphs
 # would share a workspace and may later replay on different streams at the same time (a look-ahead encoder graph
 # next to the running batch's decoding graphs).  Whoever captures work for a second stream sets a tag
-# (runtime.Session._run_ahead): tagged launches get workspaces of their own.
-WORKSPACE_TAG = None
+# (runtime.Session._run_ahead): tagged launches get workspaces of their own.  The tag is per THREAD, like the library's
+# context (nm_cur()): another session launching from another thread (the input pipeline's prefetcher, an ensemble's
+# sessions) keeps its own.
+_TLS = threading.local()
+
+
+def workspace_tag():
+    return getattr(_TLS, "workspace_tag", None)
+
+
+def set_workspace_tag(tag):
+    """Sets this thread's tag; returns the previous one (to be restored by the caller)."""
+    old = workspace_tag()
+    _TLS.workspace_tag = tag
+    return old
 
 
 def _gemm_workspace(device):
     """Persistent split-K slab buffer, one per (device, stream, tag): kernels of one
     stream are ordered, kernels of different streams must not share slabs."""
-    key = (device, _stream(), WORKSPACE_TAG)
+    key = (device, _stream(), workspace_tag())
     ws = _GEMM_WS.get(key)
     if ws is None:
         ws = torch.empty(GEMM_WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
@@ -478,7 +492,7 @@ def colsum(x, out, accumulate=False):
     lib = _lib.load()
     assert x.dim() == 2 and x.stride(1) == 1
     cols = x.shape[1]
-    key = (x.device, cols, _stream(), WORKSPACE_TAG)
+    key = (x.device, cols, _stream(), workspace_tag())
     ws = _COLSUM_WS.get(key)
     if ws is None:
         # zeroed ONCE: the tail holds the arrival counters of the in-kernel final pass, which the kernel leaves at zero
@@ -832,14 +846,10 @@ class OptimizerTables:
     """Chunk / segment tables of a VariableStore for the flat optimizer kernels."""
     CHUNK = 65536
 
-    def __init__(self, store, regularizable, trainable, only=None):
-        """``only``: restrict the tables to these variables (the trainer's early / late halves of a step); the three
-        kernels then touch nothing else of the flat buffers."""
+    def __init__(self, store, regularizable, trainable):
         lib = _lib.load()
         starts, lens, segs, first, count, flags = [], [], [], [], [], []
-        chosen = [(name, spec) for name, spec in store.specs.items() if only is None or name in only]
-        if not chosen:
-            raise ValueError("optimizer tables over no variable")
+        chosen = list(store.specs.items())
         self.names = [name for name, _ in chosen]
         for si, (name, spec) in enumerate(chosen):
             first.append(len(starts))
@@ -885,3 +895,11 @@ class OptimizerTables:
                                           float(beta1), float(beta2), float(epsilon),
                                           self.workspace.data_ptr(), self.workspace.numel() * 4),
                    "nm_optim_clip_adam")
+
+    def clip_adadelta(self, theta, grad, accum, accum_update, clip_norm, lr, rho, epsilon):
+        lib = _lib.load()
+        _lib.check(lib.nm_optim_clip_adadelta(_stream(), theta.data_ptr(), grad.data_ptr(), accum.data_ptr(),
+                                              accum_update.data_ptr(), *self._tabs(), float(clip_norm or 0.0),
+                                              float(lr), float(rho), float(epsilon),
+                                              self.workspace.data_ptr(), self.workspace.numel() * 4),
+                   "nm_optim_clip_adadelta")

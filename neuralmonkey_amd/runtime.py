@@ -690,7 +690,7 @@ class Session:
         mine = self.slot
         self.slot = mine ^ 1
         from . import _lib, ops
-        tag, ops.WORKSPACE_TAG = ops.WORKSPACE_TAG, ("ahead", self.slot)     # scratch of its own (ops.WORKSPACE_TAG)
+        tag = ops.set_workspace_tag(("ahead", self.slot))     # scratch of its own (ops.workspace_tag: per thread)
         # The look-ahead work runs under the decoding loop of the running batch.  Left alone, every launch of its
         # encoder time loops (1024 workgroups of 16 waves) fills the chip for a few microseconds and the decoding
         # steps queue behind them: the two loops add up instead of overlapping (4.45 -> 5.4 ms per greedy batch).
@@ -712,7 +712,7 @@ class Session:
                 _lib.check(_lib.load().nm_ctx_set_background(None, 0), "nm_ctx_set_background")
             self._background = False
             self.slot = mine
-            ops.WORKSPACE_TAG = tag
+            ops.set_workspace_tag(tag)
 
     def run(self, fetches, feed_dict: Optional[Dict[Placeholder, Any]] = None, ahead=None):
         """``ahead`` = (fetches, feed_dict) of the NEXT batch: tensors that do not depend on this run (its encoder

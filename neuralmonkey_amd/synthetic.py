@@ -174,6 +174,21 @@ def transformer_train_flops(batch, length, vocab=32000, dim=512, ff=2048, depth=
     return 3.0 * fwd
 
 
+def translation_train_flops(batch, length, vocab=32000, dim=512, att=None) -> float:
+    """Multiply-add flops (x2) of the DENSE products of one training step of ``build_translation_model`` (emb = rnn =
+    ``dim``, attention state size ``att`` = 2 dim by default), forward + backward = 3 x forward (every product has an
+    input gradient and a weight gradient of its own size).  Per source position: both directions' gate and candidate
+    kernels ([emb + rnn] x 3 rnn each) and the attention keys (2 rnn x att); per target position: the decoder cell
+    ([emb + rnn] x 3 rnn), the attention query (rnn x att), the output projection ([rnn + emb + 2 rnn] x rnn) and the
+    logits (rnn x vocab).  The Bahdanau energies / contexts (2 x att and 2 x 2 rnn flops per position pair) are
+    elementwise-and-reduce work on the vector units and are NOT counted."""
+    att = 2 * dim if att is None else att
+    n = float(batch * length)
+    src = 2 * (2 * dim) * (3 * dim) + (2 * dim) * att
+    tgt = (2 * dim) * (3 * dim) + dim * att + (4 * dim) * dim + dim * vocab
+    return 3.0 * 2.0 * n * (src + tgt)
+
+
 class CaptioningModel(NamedTuple):
     encoder: object
     attention: Attention

@@ -312,19 +312,20 @@ def export_store(store, prefix: str, global_step: Optional[int] = None, with_ada
     # global variables expects their keys -- and, being trainable, their Adam slots
     extras = store.checkpoint_only_values()
     tensors.update(extras)
+    s0, s1 = store.slot_suffixes
     if with_adam and store.adam_m is not None:
         for name, arr in extras.items():
-            tensors[name + "/Adam"] = np.zeros_like(arr)
-            tensors[name + "/Adam_1"] = np.zeros_like(arr)
-    if with_adam and store.adam_m is not None:
+            tensors[name + s0] = np.zeros_like(arr)
+            tensors[name + s1] = np.zeros_like(arr)
         m, v = store.adam_m.cpu().numpy(), store.adam_v.cpu().numpy()
         for name, spec in store.specs.items():
             shape = tf_shape(name, spec.shape)
-            tensors[name + "/Adam"] = m[spec.offset:spec.offset + spec.size].reshape(shape)
-            tensors[name + "/Adam_1"] = v[spec.offset:spec.offset + spec.size].reshape(shape)
-        step = global_step or 0
-        tensors["beta1_power"] = np.float32(beta1 ** (step + 1))
-        tensors["beta2_power"] = np.float32(beta2 ** (step + 1))
+            tensors[name + s0] = m[spec.offset:spec.offset + spec.size].reshape(shape)
+            tensors[name + s1] = v[spec.offset:spec.offset + spec.size].reshape(shape)
+        if s0 == "/Adam":                  # Adam's two non-slot variables; Adadelta has none
+            step = global_step or 0
+            tensors["beta1_power"] = np.float32(beta1 ** (step + 1))
+            tensors["beta2_power"] = np.float32(beta2 ** (step + 1))
     if global_step is not None:
         tensors["global_step"] = np.int64(global_step)
     write_bundle(prefix, tensors)
@@ -346,18 +347,20 @@ def import_store(store, prefix: str, strict: bool = True) -> Dict[str, object]:
     if strict and missing:
         raise KeyError("variables missing from the checkpoint: {}".format(missing[:8]))
     store.load_state_dict(values, strict=False)
-    if all(n + "/Adam" in bundle and n + "/Adam_1" in bundle for n in values) and values:
+    from .variables import find_slot_suffixes
+    s0, s1 = store.slot_suffixes = find_slot_suffixes(bundle, values, store.slot_suffixes)
+    if all(n + s0 in bundle and n + s1 in bundle for n in values) and values:
         import torch
         m, v = store.ensure_adam()
         for name in values:
             spec = store.specs[name]
             m[spec.offset:spec.offset + spec.size] = torch.from_numpy(
-                np.asarray(bundle[name + "/Adam"], np.float32).reshape(-1)).to(m.device)
+                np.asarray(bundle[name + s0], np.float32).reshape(-1)).to(m.device)
             v[spec.offset:spec.offset + spec.size] = torch.from_numpy(
-                np.asarray(bundle[name + "/Adam_1"], np.float32).reshape(-1)).to(v.device)
+                np.asarray(bundle[name + s1], np.float32).reshape(-1)).to(v.device)
     extras = store.take_checkpoint_only(bundle)
     known = set(values) | set(extras)
-    known |= {n + s for n in known for s in ("/Adam", "/Adam_1")}
+    known |= {n + s for n in known for s in (s0, s1)}
     step = bundle.get("global_step")
     return {"missing": missing, "unused": sorted(set(bundle) - known - {"global_step", "beta1_power", "beta2_power"}),
             "global_step": None if step is None else int(step)}

@@ -27,7 +27,7 @@ tanh = _activation("tanh")
 identity = _activation("identity")
 nn = SimpleNamespace(relu=_activation("relu"), tanh=tanh)
 
-train = SimpleNamespace(AdamOptimizer=_opt.AdamOptimizer)
+train = SimpleNamespace(AdamOptimizer=_opt.AdamOptimizer, AdadeltaOptimizer=_opt.AdadeltaOptimizer)
 contrib = SimpleNamespace(opt=SimpleNamespace(LazyAdamOptimizer=_opt.LazyAdamOptimizer))
 initializers = SimpleNamespace(random_uniform=random_uniform_initializer,
                                random_normal=random_normal_initializer, zeros=zeros_initializer,

@@ -15,19 +15,13 @@ import torch
 
 from .. import ops
 from ..model.model_part import Feedable
-from ..optimizers import AdamOptimizer, Optimizer
+from ..optimizers import AdadeltaOptimizer, AdamOptimizer, Optimizer
 from ..runners.base_runner import GraphExecutor, LazyLosses, NextExecute
 from ..runtime import HostPending, tensor
 from .objective import Objective
 
 BIAS_REGEX = re.compile(r"[Bb]ias")
 DEFER_LOSSES = os.environ.get("NM_DEFER_LOSSES", "1") != "0"
-# NM_OPT_EARLY=1: the optimizer step of the DECODER-side variables (their gradients are final once the decoders'
-# backward is enqueued, and nothing reads them again in the step) runs on a side stream beside the encoders' backward
-# instead of at the end of the step -- bandwidth work under latency-bound time loops.  Off by default: built after
-# the round's GPU time was spent, to be measured (GenericTrainer._early_optimizer).
-OPT_EARLY = os.environ.get("NM_OPT_EARLY", "0") == "1"
-OPT_EARLY_LANE = 2
 
 
 # pylint: disable=too-few-public-methods,too-many-arguments
@@ -70,8 +64,8 @@ class GenericTrainer(GraphExecutor, Feedable):
         self.var_scopes = var_scopes
         self.var_collection = var_collection
         self.optimizer = optimizer if optimizer is not None else self.default_optimizer()
-        if not isinstance(self.optimizer, AdamOptimizer):
-            raise NotImplementedError("the HIP trainer implements Adam / LazyAdam; got {}"
+        if not isinstance(self.optimizer, (AdamOptimizer, AdadeltaOptimizer)):
+            raise NotImplementedError("the HIP trainer implements Adam / LazyAdam / Adadelta; got {}"
                                       .format(type(self.optimizer).__name__))
         if clip_norm is not None and clip_norm <= 0.0:
             raise ValueError("clip_norm must be positive")
@@ -93,54 +87,11 @@ class GenericTrainer(GraphExecutor, Feedable):
         return [n for n in store.trainable_names() if not BIAS_REGEX.findall(n)
                 and not n.startswith(("vgg", "Inception", "resnet"))]
 
-    def _optim_tables(self, store, half: str = "all", names=None) -> ops.OptimizerTables:
-        """``half`` "all": every variable of the store; "early" / "late": ``names`` and the rest (OPT_EARLY)."""
-        key = (id(store), half) if half != "all" else id(store)
+    def _optim_tables(self, store) -> ops.OptimizerTables:
+        key = id(store)
         if key not in self._tables:
-            only = None
-            if half == "early":
-                only = set(names)
-            elif half == "late":
-                only = set(store.names()) - set(names)
-            self._tables[key] = ops.OptimizerTables(store, set(self.regularizable(store)),
-                                                    set(self.var_list(store)), only=only)
+            self._tables[key] = ops.OptimizerTables(store, set(self.regularizable(store)), set(self.var_list(store)))
         return self._tables[key]
-
-    def early_variables(self, store, decoders) -> List[str]:
-        """Variables that only the decoders' own backward passes write and read: those in the scope of a decoder or of
-        one of its attentions, when no other model part lives in that scope (``reuse=``).  Everything an encoder's
-        deferred backward still touches -- its own variables, embeddings a decoder borrows through
-        ``embeddings_source`` -- lives in another scope and stays for the end of the step."""
-        from ..runtime import registered_parts
-        scopes = []
-        for dec in decoders:
-            for part in [dec] + list(getattr(dec, "attentions", [])):
-                scope = getattr(part, "_scope", None)
-                if scope and sum(1 for p in registered_parts() if getattr(p, "_scope", None) == scope) == 1:
-                    scopes.append(scope + "/")
-        return [n for n in store.names() if n.startswith(tuple(scopes))] if scopes else []
-
-    def _step_rate(self, sess, state) -> float:
-        """lr_t of the update that the running step will apply (global step and bias correction one ahead)."""
-        return self.optimizer.lr_t(sess.global_step + 1, state["applied"] + 1)
-
-    def _early_optimizer(self, ctx, outer, decoders) -> None:
-        """L1/L2 terms, per-tensor clipping and Adam for ``early_variables``, enqueued on a side lane that waits for
-        the main stream (every read of these variables is enqueued by now) and for the leaf lanes (their weight
-        gradients).  ``_apply_gradients`` then covers the remaining variables only."""
-        sess, store = ctx.session, ctx.store
-        names = self.early_variables(store, decoders)
-        if not names or len(names) == len(store.names()):
-            return
-        early = self._optim_tables(store, "early", names)
-        self._optim_tables(store, "late", names)
-        state = self._adam_state(sess, store)
-        opt = self.optimizer
-        with sess.side(OPT_EARLY_LANE, after=(0, 1)):
-            l1l2 = early.regularize_and_norms(store.theta, store.ensure_grad(), self.l1_weight, self.l2_weight)
-            early.clip_adam(store.theta, store.ensure_grad(), state["m"], state["v"], self.clip_norm,
-                            self._step_rate(sess, state), opt.beta1, opt.beta2, opt.epsilon)
-        outer.memo[(id(self), "early")] = (names, l1l2)
 
     # -- the training step --------------------------------------------------------------------
     def _objective_gradients(self, outer) -> None:
@@ -183,7 +134,7 @@ class GenericTrainer(GraphExecutor, Feedable):
             scales.append(scale)
             counts.append(count)
 
-        def forward_backward(early=None):
+        def forward_backward():
             """Every objective's forward + backward; encoders shared by several decoders run their
             backward pass once, on the summed gradient (RunContext.defer_backward)."""
             ctx.memo["backward_deferred"] = True
@@ -192,8 +143,6 @@ class GenericTrainer(GraphExecutor, Feedable):
                 res = dec._train_loop(ctx, want_grad=True, grad_scale=scale)     # pylint: disable=protected-access
                 dec.backward(ctx, res)
                 results.append(res)
-            if early is not None:
-                early()                      # the decoders' share of the optimizer step, beside the encoders' backward
             ctx.flush_backward()
             ctx.memo["backward_deferred"] = False
             return results
@@ -205,43 +154,38 @@ class GenericTrainer(GraphExecutor, Feedable):
             results = sess.graphed_call((id(self), train, shapes), forward_backward)
             results = [res._replace(token_count=count) for res, count in zip(results, counts)]
         else:
-            # (never inside a captured step graph: the learning rate of the step would be baked into it)
-            early = None
-            if OPT_EARLY and dp is None and outer.memo.get("one_update_per_batch") and len(decoders) > 0:
-                early = lambda: self._early_optimizer(ctx, outer, decoders)
-            results = forward_backward(early)
+            results = forward_backward()
         for dec, res in zip(decoders, results):
             outer.memo[dec.train_loop_result.key] = res
         sess.join_side()
 
     def _apply_gradients(self, ctx) -> int:
-        """[all-reduce] -> L1/L2 terms -> per-tensor clip_by_norm -> Adam -> global_step += 1."""
+        """[all-reduce] -> L1/L2 terms -> per-tensor clip_by_norm -> Adam / Adadelta -> global_step += 1."""
         from .. import distributed as dist
         sess, store = ctx.session, ctx.store
         grad = store.ensure_grad()
         dp = dist.current()
         if dp is not None:
             dp.all_reduce_gradients(store)
-        early = ctx.memo.pop((id(self), "early"), None)
-        if early is None:
-            tables = self._optim_tables(store)
-            l1l2 = tables.regularize_and_norms(store.theta, grad, self.l1_weight, self.l2_weight)
-            ctx.memo[(id(self), "l1l2")] = l1l2.clone()
-        else:           # the decoders' variables were updated beside the encoders' backward (_early_optimizer)
-            tables = self._optim_tables(store, "late", early[0])
-            l1l2 = tables.regularize_and_norms(store.theta, grad, self.l1_weight, self.l2_weight)
-            ctx.memo[(id(self), "l1l2")] = l1l2 + early[1]        # (the main stream has joined the side lanes)
+        tables = self._optim_tables(store)
+        l1l2 = tables.regularize_and_norms(store.theta, grad, self.l1_weight, self.l2_weight)
+        ctx.memo[(id(self), "l1l2")] = l1l2.clone()
         state = self._adam_state(sess, store)
         sess.global_step += 1
         state["applied"] += 1
         opt = self.optimizer
-        tables.clip_adam(store.theta, grad, state["m"], state["v"], self.clip_norm,
-                         opt.lr_t(sess.global_step, state["applied"]), opt.beta1, opt.beta2, opt.epsilon)
+        if isinstance(opt, AdadeltaOptimizer):
+            tables.clip_adadelta(store.theta, grad, state["m"], state["v"], self.clip_norm,
+                                 opt.learning_rate(sess.global_step), opt.rho, opt.epsilon)
+        else:
+            tables.clip_adam(store.theta, grad, state["m"], state["v"], self.clip_norm,
+                             opt.lr_t(sess.global_step, state["applied"]), opt.beta1, opt.beta2, opt.epsilon)
         sess.variables_changed()
         return sess.global_step
 
     def _adam_state(self, sess, store):
-        """Adam slots and the number of updates THIS optimizer has applied.  TensorFlow keeps one set of
+        """The optimizer's two slots per variable (Adam: m, v; Adadelta: accum, accum_update) and the number of
+        updates THIS optimizer has applied.  TensorFlow keeps one set of
         slots and one pair of beta powers per optimizer, while ``global_step`` is shared: an experiment
         with two trainers (tests/bahdanau.ini: ``trainer=[<mt_trainer>, <greedy_trainer>]``) advances the
         global step twice per batch but each optimizer's bias correction once.  The first trainer to
@@ -253,6 +197,7 @@ class GenericTrainer(GraphExecutor, Feedable):
             owners = sess.__dict__.setdefault("_adam_owner", {})
             if owners.setdefault(key, self) is self:
                 m, v = store.ensure_adam()
+                store.slot_suffixes = tuple(self.optimizer.slot_suffixes)     # the slots' names in checkpoints
                 applied = sess.global_step
             else:
                 m, v = torch.zeros_like(store.theta), torch.zeros_like(store.theta)
@@ -265,7 +210,6 @@ class GenericTrainer(GraphExecutor, Feedable):
         # one optimizer step per batch: gradient slices that are final early in the backward pass may start
         # their all-reduce right away (distributed.DataParallel.all_reduce_early)
         ctx.memo["dp_overlap"] = True
-        ctx.memo["one_update_per_batch"] = True       # (DelayedUpdateTrainer accumulates: no early optimizer there)
         self._objective_gradients(ctx)
         return self._apply_gradients(ctx)
 

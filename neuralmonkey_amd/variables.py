@@ -68,6 +68,22 @@ class VarSpec:
         self.offset = -1
 
 
+def find_slot_suffixes(keys, names, preferred):
+    """The names under which a checkpoint holds the optimizer's two slots of every variable: ``preferred`` when
+    present, else whatever pair ``<var>/<opt>``, ``<var>/<opt>_1`` all of ``names`` carry (a checkpoint is read
+    before the trainer that owns the slots has taken its first step and named them)."""
+    names = list(names)
+    if not names or all(n + preferred[0] in keys and n + preferred[1] in keys for n in names):
+        return preferred
+    first = names[0] + "/"
+    for key in keys:
+        if key.startswith(first) and "/" not in key[len(first):] and key + "_1" in keys:
+            pair = ("/" + key[len(first):], "/" + key[len(first):] + "_1")
+            if all(n + pair[0] in keys and n + pair[1] in keys for n in names):
+                return pair
+    return preferred
+
+
 class VariableStore:
     """Named variables as views into flat ``theta`` / ``grad`` / Adam buffers."""
 
@@ -79,8 +95,9 @@ class VariableStore:
         self.specs: "OrderedDict[str, VarSpec]" = OrderedDict()
         self.theta: Optional[torch.Tensor] = None
         self.grad: Optional[torch.Tensor] = None
-        self.adam_m: Optional[torch.Tensor] = None
-        self.adam_v: Optional[torch.Tensor] = None
+        self.adam_m: Optional[torch.Tensor] = None      # the optimizer's two slots per variable (Adam: m, v;
+        self.adam_v: Optional[torch.Tensor] = None      # Adadelta: accum, accum_update) ...
+        self.slot_suffixes = ("/Adam", "/Adam_1")       # ... and their names in a checkpoint (Optimizer.slot_suffixes)
         self.total = 0
         self.epoch = 0          # bumped by whoever writes the variables through raw pointers (Session.variables_changed)
         self._views: Dict[str, torch.Tensor] = {}
@@ -213,8 +230,8 @@ class VariableStore:
         if self.adam_m is not None:
             m, v = self.adam_m.cpu().numpy(), self.adam_v.cpu().numpy()
             for name, spec in self.specs.items():
-                arrays[(name + "/Adam").replace("/", "|")] = m[spec.offset:spec.offset + spec.size].reshape(spec.shape)
-                arrays[(name + "/Adam_1").replace("/", "|")] = v[spec.offset:spec.offset + spec.size].reshape(spec.shape)
+                arrays[(name + self.slot_suffixes[0]).replace("/", "|")] = m[spec.offset:spec.offset + spec.size].reshape(spec.shape)
+                arrays[(name + self.slot_suffixes[1]).replace("/", "|")] = v[spec.offset:spec.offset + spec.size].reshape(spec.shape)
         if global_step is not None:
             arrays["global_step"] = np.int64(global_step)
         np.savez(path, **arrays)
@@ -233,13 +250,14 @@ class VariableStore:
         self.load_state_dict(values, strict)
         self.take_checkpoint_only(values)
         names = [n for n in self.specs if n in values]
-        if names and all(n + "/Adam" in values and n + "/Adam_1" in values for n in names):
+        s0, s1 = self.slot_suffixes = find_slot_suffixes(values, names, self.slot_suffixes)
+        if names and all(n + s0 in values and n + s1 in values for n in names):
             m, v = self.ensure_adam()
             for n in names:
                 spec = self.specs[n]
                 m[spec.offset:spec.offset + spec.size] = torch.from_numpy(
-                    np.asarray(values[n + "/Adam"], np.float32).reshape(-1)).to(m.device)
+                    np.asarray(values[n + s0], np.float32).reshape(-1)).to(m.device)
                 v[spec.offset:spec.offset + spec.size] = torch.from_numpy(
-                    np.asarray(values[n + "/Adam_1"], np.float32).reshape(-1)).to(v.device)
+                    np.asarray(values[n + s1], np.float32).reshape(-1)).to(v.device)
         step = values.get("global_step")
         return {"global_step": None if step is None else int(step)}

@@ -353,7 +353,8 @@ def gumbel_noise(rows: int, vocab: int, salt: int) -> np.ndarray:
     with np.errstate(over="ignore"):
         key = mix(np.uint32(salt & 0xFFFFFFFF) + np.arange(rows, dtype=np.uint32) * np.uint32(0x85EBCA6B))
         bits = mix(np.arange(vocab, dtype=np.uint32)[None, :] * np.uint32(0x9E3779B1) + key[:, None])
-    u = ((bits >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+    # 23 bits + 0.5 is exact in float32: u in [2^-24, 1 - 2^-24], the noise is finite for every bit pattern
+    u = ((bits >> np.uint32(9)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 8388608.0)
     return (-np.log(-np.log(u))).astype(np.float32)
 
 

@@ -160,3 +160,24 @@ def clip_and_adam(p, grads, m, v, t, clip_norm: Optional[float], lr=1e-4,
             m[k].mul_(b1).add_(g, alpha=1 - b1)
             v[k].mul_(b2).addcmul_(g, g, value=1 - b2)
             p[k].sub_(lr_t * m[k] / (v[k].sqrt() + eps))
+
+
+def clip_and_adadelta(p, grads, accum, accum_update, clip_norm: Optional[float], lr=1e-3, rho=0.95, eps=1e-8):
+    """Per-tensor clip_by_norm (generic_trainer.py:179-186) then tf.train.AdadeltaOptimizer as the reference's
+    configs set it up (tests/bpe.ini:102-108: learning_rate 1e-4, epsilon 1e-6, rho 0.95).  The update rule is
+    TensorFlow 1.12's ``ApplyAdadelta`` (tensorflow/core/kernels/training_ops.cc, a dependency that is not part of
+    /root/reference -- restated from its published definition, UNPINNED by any reference-executed fixture):
+        accum        = rho * accum + (1 - rho) * g^2
+        update       = sqrt(accum_update + eps) * rsqrt(accum + eps) * g
+        var         -= lr * update
+        accum_update = rho * accum_update + (1 - rho) * update^2
+    Mutates p / accum / accum_update in place."""
+    with torch.no_grad():
+        for k in p:
+            g = grads[k]
+            if clip_norm:
+                g = g * (clip_norm / max(float(g.norm()), clip_norm))
+            accum[k].mul_(rho).addcmul_(g, g, value=1 - rho)
+            update = (accum_update[k] + eps).sqrt() * (accum[k] + eps).rsqrt() * g
+            p[k].sub_(lr * update)
+            accum_update[k].mul_(rho).addcmul_(update, update, value=1 - rho)

@@ -286,6 +286,26 @@ def write_ini(tmp_path):
     return str(path)
 
 
+def test_ini_with_the_adadelta_section_of_bpe_ini(tmp_path):
+    """``[adadelta] class=tf.train.AdadeltaOptimizer`` with the arguments of tests/bpe.ini:102-108 / tests/str.ini
+    builds through the tf.* shim; slots are named after the optimizer (TF: ``<var>/<name>``, ``<var>/<name>_1``)."""
+    from neuralmonkey_amd.config.configuration import load_experiment
+    from neuralmonkey_amd.optimizers import AdadeltaOptimizer
+    path = write_ini(tmp_path)
+    with open(path) as fh:
+        text = fh.read()
+    text = text.replace("class=tf.contrib.opt.LazyAdamOptimizer\nlearning_rate=0.001",
+                        'class=tf.train.AdadeltaOptimizer\nname="adadelta"\nlearning_rate=1e-4\nepsilon=1.0e-6\nrho=0.95')
+    assert "AdadeltaOptimizer" in text
+    with open(path, "w") as fh:
+        fh.write(text)
+    model = load_experiment(path)
+    opt = model.trainer.optimizer
+    assert isinstance(opt, AdadeltaOptimizer)
+    assert (opt.learning_rate(1), opt.epsilon, opt.rho) == (1e-4, 1e-6, 0.95)
+    assert opt.slot_suffixes == ("/adadelta", "/adadelta_1") and AdadeltaOptimizer().slot_suffixes[0] == "/Adadelta"
+
+
 def test_ini_builds_the_plugin_surface(tmp_path):
     from neuralmonkey_amd.config.configuration import load_experiment
     model = load_experiment(write_ini(tmp_path))
@@ -400,47 +420,6 @@ def test_decode_chunks_stops_where_the_reference_loop_stops(finish_at, run_ahead
     assert len(launched) <= min(total // every, chunks_needed + (1 if run_ahead else 0))
     assert [t0 for t0, _ in launched] == list(range(0, enqueued, every))
 
-
-def test_early_and_late_halves_of_the_optimizer_step_partition_the_store():
-    """NM_OPT_EARLY (trainers/generic_trainer.py): the decoders' and their attentions' variables form the early half of
-    an optimizer step, everything an encoder's backward still writes the late half; the two chunk tables cover every
-    float of every variable exactly once and carry the flags of the one-table step."""
-    from neuralmonkey_amd import ops
-    m = small_model()
-    store = m.tf_manager.sessions[0].store
-    early = m.trainer.early_variables(store, [m.decoder])
-    assert early and all(n.startswith(("decoder/", "attention/")) for n in early)
-    assert sorted(early) == sorted(n for n in store.names() if n.startswith(("decoder/", "attention/")))
-    assert "encoder_input/embedding_matrix_0" not in early and "decoder/word_embeddings" in early
-    whole = m.trainer._optim_tables(store)
-    first = m.trainer._optim_tables(store, "early", early)
-    second = m.trainer._optim_tables(store, "late", early)
-    assert first is m.trainer._optim_tables(store, "early", early)           # built once per store
-    assert sorted(first.names + second.names) == sorted(store.names()) and not set(first.names) & set(second.names)
-    covered = np.zeros(store.total, np.int32)
-    for tab in (first, second):
-        assert tab.nseg == len(tab.names) and int(tab.seg_count.sum()) == tab.nchunk
-        for start, length, seg in zip(tab.chunk_start.tolist(), tab.chunk_len.tolist(), tab.chunk_seg.tolist()):
-            spec = store.specs[tab.names[seg]]
-            assert spec.offset <= start and start + length <= spec.offset + spec.size
-            covered[start:start + length] += 1
-        flags = dict(zip(tab.names, tab.seg_flags.tolist()))
-        assert all(flags[n] == dict(zip(whole.names, whole.seg_flags.tolist()))[n] for n in tab.names)
-    wanted = np.zeros(store.total, np.int32)
-    for spec in store.specs.values():
-        wanted[spec.offset:spec.offset + spec.size] = 1                     # (alignment padding belongs to nobody)
-    assert np.array_equal(covered, wanted)
-    with pytest.raises(ValueError):
-        ops.OptimizerTables(store, set(), set(), only={"no/such/variable"})
-    # a scope shared by two parts (reuse=) is nobody's alone: nothing of it is early
-    from neuralmonkey_amd import runtime
-    twin = type("Twin", (), {"_scope": "decoder"})()
-    runtime.register_part(twin)
-    try:
-        shared = m.trainer.early_variables(store, [m.decoder])
-        assert shared and all(n.startswith("attention/") for n in shared)
-    finally:
-        runtime._REGISTRY.remove(twin)
 
 
 def test_stateful_filler_surface():

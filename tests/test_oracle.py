@@ -129,3 +129,18 @@ def test_regularizable_follows_bias_regex():
     names = ["a/kernel", "a/bias", "att/attn_bias", "att/attn_projection_bias", "dec/state_to_word_b",
              "enc/LayerNorm/beta", "enc/gates/Bias"]
     assert O.regularizable(names) == ["a/kernel", "dec/state_to_word_b", "enc/LayerNorm/beta"]
+
+
+def test_gumbel_noise_is_finite_for_every_bit_pattern():
+    """u = ((bits >> 9) + 0.5) / 2^23 stays strictly inside (0, 1) in float32 (csrc/nm_logits.hip:gumbel_argmax_kernel
+    and its restatement): the round-4 form ((bits >> 8) + 0.5) / 2^24 rounded to 1.0 for bits = 0xFFFFFFFF, an
+    infinite noise term that made that column win whatever its logit."""
+    for bits in (0x00000000, 0x000001FF, 0xFFFFFE00, 0xFFFFFFFF):
+        u = (np.float32(bits >> 9) + np.float32(0.5)) * np.float32(1.0 / 8388608.0)
+        assert np.float32(0.0) < u < np.float32(1.0)
+        assert np.isfinite(-np.log(-np.log(u)))
+    old = (np.float32(0xFFFFFFFF >> 8) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+    assert old == np.float32(1.0)
+    noise = O.gumbel_noise(64, 4096, 12345)
+    assert noise.dtype == np.float32 and np.isfinite(noise).all()
+

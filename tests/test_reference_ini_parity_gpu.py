@@ -1,19 +1,13 @@
-"""GPU tests written AFTER round 4's GPU budget was spent: they have never run on a device.  The driver's round-end
-suite is `pytest -x`, so they are skipped unless NM_RUN_PENDING=1 -- the first GPU call of the next round runs them
-(tools/r05_first_call.sh), fixes what they find, and moves them into the files they belong to
-(test_reference_inis_gpu.py, test_background_gpu.py) without the gate.
+"""The reference's acceptance configs on the engine against the models the REFERENCE built from the same files
+(``/root/reference/tests/tests_run.sh:12,28,33``; fixtures under tests/golden/ref_exec made by
+tests/golden/make_reference_exec_golden.py, which imports /root/reference unmodified):
 
-What they cover:
-  * tests/small.ini, tests/post-edit.ini and tests/flat-multiattention.ini on the engine against the models the
-    REFERENCE built from those files (fixtures ``ini_small``, ``ini_postedit``, ``ini_flat``; neuralmonkey/config/builder.py:159-176 names, NematusGRU cells,
-    conditional GRU decoder; two encoders under dot-product attentions, attention/scaled_dot_product.py:247-400);
-  * the early half of the optimizer step (NM_OPT_EARLY, trainers/generic_trainer.py: the decoders' variables are
-    updated on a side lane beside the encoders' backward; trainers/generic_trainer.py:136-195 of the reference is the
-    arithmetic, which must not change): three steps with it equal three steps without it;
-  * the launches in front of the encoder's BPTT loop inside that loop's graph (NM_ENC_BWD_GRAPH): nothing changes;
-  * a checkpoint written by the engine for a NematusGRU model holds exactly the reference's variables;
+  * tests/small.ini (BASELINE configs[0]), tests/post-edit.ini and tests/flat-multiattention.ini: variable names of
+    neuralmonkey/config/builder.py:159-176, NematusGRU cells, the conditional GRU decoder, two encoders under
+    dot-product attentions (attention/scaled_dot_product.py:247-400) -- encoder states, train / runtime logits,
+    decoded symbols, runner sentences and losses (``ini_small``, ``ini_postedit``, ``ini_flat``);
   * the trainers' reported losses against the reference trainers' ``objective_values``;
-  * ``StatefulFiller`` (new) as a decoder's encoder.
+  * a checkpoint written by the engine for a NematusGRU model holds exactly the reference's variables.
 """
 import os
 
@@ -22,9 +16,7 @@ import pytest
 
 from .test_reference_inis import load_verbatim, ref_root, reference_variables  # noqa: F401  pylint: disable=unused-import
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("NM_RUN_PENDING") != "1",
-                                 reason="never run on a GPU yet: NM_RUN_PENDING=1 (tools/r05_first_call.sh)")]
+pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -203,103 +195,3 @@ def test_small_ini_checkpoint_holds_the_references_variables(dev, ref_root, tmp_
     store.theta.zero_()
     model.tf_manager.restore(prefix)
     assert all(torch.equal(store[n], before[n]) for n in store.names())
-
-
-def _three_steps(dev, monkeypatch, early, prologue_in_graph=False, steps=3):
-    import torch
-    from neuralmonkey_amd import synthetic
-    from neuralmonkey_amd.encoders import recurrent
-    from neuralmonkey_amd.trainers import generic_trainer
-    from oracle import nm_oracle as O
-    monkeypatch.setattr(generic_trainer, "OPT_EARLY", early)
-    monkeypatch.setattr(recurrent, "BWD_PROLOGUE_IN_GRAPH", prologue_in_graph)
-    model = synthetic.build_translation_model(vocab_src=2000, vocab_tgt=2000, emb=64, rnn=64, max_len=24,
-                                              beam_size=0, device=str(dev), l2_weight=1e-6, clip_norm=1.0)
-    sess = model.tf_manager.sessions[0]
-    sess.store.load_state_dict(O.init_params(seed=3, vocab_src=2000, vocab_tgt=2000, emb=64, rnn=64, std=0.1))
-    ds = synthetic.synthetic_dataset(seed=4, batch=32, src_len=24, tgt_len=20, vocab=2000, ragged=True)
-    losses = []
-    for _ in range(steps):
-        res = model.tf_manager.execute(ds, model.trainer.feedables, [model.trainer], train=True)[0]
-        losses.append([float(res.losses[k]) for k in ("decoder - cost", "L1", "L2")])
-    torch.cuda.synchronize()
-    halves = [key for key in model.trainer._tables if isinstance(key, tuple)]
-    return losses, {n: sess.store[n].cpu().numpy().copy() for n in sess.store.names()}, halves, sess.global_step
-
-
-def test_early_optimizer_half_changes_no_parameter(dev, monkeypatch):
-    """Clipping, the regulariser's gradient and Adam are per tensor: splitting the variables into two launches
-    changes no update.  Only the reported L1 / L2 sums are added in another order."""
-    l_early, p_early, halves, step_early = _three_steps(dev, monkeypatch, True)
-    l_plain, p_plain, none, step_plain = _three_steps(dev, monkeypatch, False)
-    assert len(halves) == 2 and not none and step_early == step_plain == 3
-    assert np.allclose(l_early, l_plain, rtol=1e-6, atol=0.0), (l_early, l_plain)
-    for name, want in p_plain.items():
-        assert np.array_equal(p_early[name], want), name
-
-
-def test_encoder_backward_prologue_inside_the_loop_graph_changes_nothing(dev, monkeypatch):
-    """NM_ENC_BWD_GRAPH (encoders/recurrent.py): the same launches in the same order, ten of them moved into the BPTT
-    loop's HIP graph -- eager pass, capture and three replays against the plain path, bit for bit."""
-    l_graph, p_graph, _, _ = _three_steps(dev, monkeypatch, False, prologue_in_graph=True, steps=5)
-    l_plain, p_plain, _, _ = _three_steps(dev, monkeypatch, False, prologue_in_graph=False, steps=5)
-    assert l_graph == l_plain
-    for name, want in p_plain.items():
-        assert np.array_equal(p_graph[name], want), name
-
-
-def test_stateful_filler_under_a_decoder(dev):
-    """``StatefulFiller`` (encoders/numpy_stateful_filler.py:16-72) with its dense projection as the only encoder of an
-    RNN decoder without attention: the decoder's initial state comes from the projected vectors, and a training step
-    gives the projection's gradients that float64 autograd gives (``initial_state = dense(output)``,
-    decoders/encoder_projection.py:47-73)."""
-    import torch
-    from neuralmonkey_amd.dataset import BatchingScheme, Dataset
-    from neuralmonkey_amd.decoders import Decoder
-    from neuralmonkey_amd.encoders.numpy_stateful_filler import StatefulFiller
-    from neuralmonkey_amd.runtime import reset_registry
-    from neuralmonkey_amd.tf_manager import TensorFlowManager
-    from neuralmonkey_amd.trainers.cross_entropy_trainer import CrossEntropyTrainer
-    from neuralmonkey_amd.vocabulary import Vocabulary
-    reset_registry()
-    rng = np.random.default_rng(5)
-    vocab = Vocabulary(["w{}".format(i) for i in range(11)])
-    filler = StatefulFiller("vec", 7, "vectors", output_shape=5)
-    dec = Decoder(encoders=[filler], vocabulary=vocab, data_id="target", name="decoder", max_output_len=4,
-                  embedding_size=6, rnn_size=6, dropout_keep_prob=1.0)
-    trainer = CrossEntropyTrainer(decoders=[dec])
-    tfm = TensorFlowManager(num_sessions=1, num_threads=1, device=str(dev), seed=3)
-    tfm.initialize_sessions()
-    store = tfm.sessions[0].store
-    vectors = [rng.normal(size=7).astype(np.float32) for _ in range(3)]
-    ds = Dataset("d", {"vectors": vectors, "target": [["w1", "w2"], ["w3"], ["w4", "w5", "w6"]]},
-                 BatchingScheme(batch_size=3))
-    fd = {}
-    for part in trainer.feedables:
-        fd.update(part.feed_dict(ds, train=False))
-    out = tfm.sessions[0].run({"enc": filler.output}, fd)["enc"]
-    w, b = store["vec/dense/kernel"].cpu().numpy(), store["vec/dense/bias"].cpu().numpy()
-    assert np.allclose(np.asarray(out), np.stack(vectors) @ w + b, atol=1e-5)
-    before = w.copy()
-    tfm.execute(ds, trainer.feedables, [trainer], train=True)
-    grad = store.g("vec/dense/kernel").cpu().numpy()
-    assert np.abs(grad).max() > 0 and not np.array_equal(store["vec/dense/kernel"].cpu().numpy(), before)
-    # d loss / d kernel = vectors^T . d loss / d output: rank <= batch size, rows in the span of the fed vectors
-    assert np.linalg.matrix_rank(grad.astype(np.float64), tol=1e-6 * np.abs(grad).max()) <= 3
-
-
-def test_train_logprobs_is_the_log_softmax_of_the_train_logits(dev):
-    """``AutoregressiveDecoder.train_logprobs`` (autoregressive.py:288-290; new here, for runners that fetch it by
-    name): tf.nn.log_softmax of the teacher-forced logits."""
-    import torch
-    from neuralmonkey_amd import synthetic
-    model = synthetic.build_translation_model(vocab_src=300, vocab_tgt=300, emb=32, rnn=32, max_len=12, beam_size=0,
-                                              device=str(dev))
-    ds = synthetic.synthetic_dataset(seed=4, batch=6, src_len=9, tgt_len=8, vocab=300, ragged=True)
-    dec = model.decoder
-    fd = {}
-    for part in model.trainer.feedables:
-        fd.update(part.feed_dict(ds, train=False))
-    out = model.tf_manager.sessions[0].run({"logits": dec.train_logits, "logprobs": dec.train_logprobs}, fd)
-    want = torch.log_softmax(torch.as_tensor(np.asarray(out["logits"])).double(), -1).numpy()
-    assert np.abs(np.asarray(out["logprobs"]) - want).max() < 1e-5

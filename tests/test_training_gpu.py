@@ -110,33 +110,115 @@ def test_training_then_greedy_share_one_run(dev):
 
 
 def test_delayed_update_trainer_accumulates_and_averages(dev):
-    """DelayedUpdateTrainer (trainers/delayed_update_trainer.py:142-204): no update before the
-    N-th batch; the N-th applies the mean gradient.  Feeding one batch N times must therefore
-    land on exactly the parameters of one ordinary step on that batch."""
+    """DelayedUpdateTrainer (trainers/delayed_update_trainer.py:142-204): no update before the N-th batch; the N-th
+    applies the MEAN of the N accumulated gradients (each ``raw_gradients`` of generic_trainer.py:136-142, i.e. with
+    the regulariser's share) through clip_by_norm and Adam.  Six DISTINCT batches = two updates, against the oracle's
+    autograd -> mean -> clip -> Adam on the same batches.  Adam's first moment after update 1 is 0.1 x the clipped
+    mean gradient, so a sum instead of a mean shows there (x3 on every tensor the clip leaves alone) -- the
+    parameters alone could not tell (Adam's first step is scale invariant)."""
+    from neuralmonkey_amd import synthetic
     from neuralmonkey_amd.trainers import DelayedUpdateTrainer
     from neuralmonkey_amd.trainers.objective import CostObjective
-    model, params, ds, src, tgt = _build(dev, 64, 12, 12, 5, 7, 6, True, l2=1e-3, clip=0.5)
+    vocab, n, l2, clip = 64, 3, 1e-3, 0.02
+    model, params, _, _, _ = _build(dev, vocab, 12, 12, 5, 7, 6, True, l2=l2, clip=clip)
+    tfm = model.tf_manager
+    sess = tfm.sessions[0]
+    store = sess.store
+    delayed = DelayedUpdateTrainer(batches_per_update=n, objectives=[CostObjective(model.decoder)],
+                                   l2_weight=l2, clip_norm=clip)
+    batches = []
+    for i in range(2 * n):
+        ds = synthetic.synthetic_dataset(seed=40 + i, batch=4 + i % 3, src_len=7, tgt_len=6, vocab=vocab, ragged=True)
+        src = O.pad_ids([list(s) for s in ds.get_series("source")], 7)
+        tgt = O.pad_ids([list(s) for s in ds.get_series("target")], 7, add_end_symbol=True)
+        batches.append((ds, src, np.ascontiguousarray(tgt.T)))
+
+    tp = TR.to_torch(params)
+    ref_m = {k: torch.zeros_like(v) for k, v in tp.items()}
+    ref_v = {k: torch.zeros_like(v) for k, v in tp.items()}
+    clipped, solid = 0, {}
+    for update in range(2):
+        before = {name: store[name].cpu().numpy().copy() for name in store.names()}
+        mean = {k: torch.zeros_like(v) for k, v in tp.items()}
+        for i in range(n):
+            ds, src, tgt = batches[update * n + i]
+            loss, _, _, grads = TR.train_step_grads(tp, src, tgt, l1_weight=0.0, l2_weight=l2)
+            for k in mean:
+                mean[k] += grads[k] / n
+            res = tfm.execute(ds, delayed.feedables, [delayed], train=True)[0]
+            assert set(res.losses) == {"decoder - cost", "L1", "L2"}
+            assert abs(res.losses["decoder - cost"] - float(loss)) < 1e-4 * float(loss)
+            if i < n - 1:       # accumulating: parameters and global step untouched
+                assert sess.global_step == update
+                assert all(np.array_equal(store[name].cpu().numpy(), before[name]) for name in store.names())
+        assert sess.global_step == update + 1
+        clipped += sum(1 for g in mean.values() if float(g.norm()) > clip)
+        TR.clip_and_adam(tp, mean, ref_m, ref_v, update + 1, clip)
+        m, _ = store.ensure_adam()
+        for name in store.names():
+            if name.endswith("attn_bias"):
+                continue
+            spec = store.specs[name]
+            got_m = m[spec.offset:spec.offset + spec.size].cpu().numpy()
+            want_m = ref_m[name].numpy().reshape(-1)
+            assert np.abs(got_m - want_m).max() <= 2e-3 * max(np.abs(want_m).max(), 1e-7), (update, name)
+            # parameters: Adam's early updates are ~ lr * g / |g|, so an entry whose gradient is noise-sized may go
+            # either way (bounded by 2 lr per update); entries with a real gradient must land on the oracle's value
+            got, want = store[name].cpu().numpy().reshape(-1), tp[name].detach().numpy().reshape(-1)
+            g = mean[name].numpy().reshape(-1)
+            big = solid[name] = solid.get(name, True) & (np.abs(g) > 2e-2 * np.abs(g).max())
+            assert np.abs(got - want).max() <= 2.1e-4 * (update + 1), (update, name)
+            assert np.abs(got - want)[big].max() <= 2e-6 + 1e-5 * np.abs(want).max(), (update, name)
+    assert 0 < clipped < 2 * len(tp), "the clip must bite on some tensors and spare others for the test to mean anything"
+
+
+def test_adadelta_steps_track_the_oracle(dev, tmp_path):
+    """tf.train.AdadeltaOptimizer with the arguments of tests/bpe.ini:102-108 behind the trainer's clip: four updates
+    against the oracle's restatement of TF 1.12's ApplyAdadelta (oracle/torch_ref.py:clip_and_adadelta).  Both slots
+    and the parameters are compared entry by entry (Adadelta has no sign-like first step: update ~ sqrt(eps / ((1-rho)
+    g^2 + eps)) * g, smooth in g), and a checkpoint carries the slots under the optimizer's name."""
+    from neuralmonkey_amd.optimizers import AdadeltaOptimizer
+    from neuralmonkey_amd.trainers import CrossEntropyTrainer
+    lr, eps, rho, clip, l2 = 0.5, 1e-6, 0.95, 0.05, 1e-3          # (lr 0.5: four steps must move the loss visibly)
+    model, params, ds, src, tgt = _build(dev, 200, 32, 32, 8, 10, 9, True, l2=l2, clip=clip)
+    trainer = CrossEntropyTrainer(decoders=[model.decoder], l2_weight=l2, clip_norm=clip,
+                                  optimizer=AdadeltaOptimizer(learning_rate=lr, epsilon=eps, rho=rho, name="adadelta"))
     tfm = model.tf_manager
     store = tfm.sessions[0].store
-    tfm.execute(ds, model.trainer.feedables, [model.trainer], train=True)
-    want = {n: store[n].cpu().numpy().copy() for n in store.names()}
-
-    store.load_state_dict(params)
-    m, v = store.ensure_adam()
-    m.zero_(), v.zero_()
-    tfm.sessions[0].global_step = 0
-    delayed = DelayedUpdateTrainer(batches_per_update=3, objectives=[CostObjective(model.decoder)],
-                                   l2_weight=1e-3, clip_norm=0.5)
-    for i in range(3):
-        res = tfm.execute(ds, delayed.feedables, [delayed], train=True)[0]
-        assert set(res.losses) == {"decoder - cost", "L1", "L2"}
-        if i < 2:       # accumulating: parameters and global step untouched
-            assert tfm.sessions[0].global_step == 0
-            assert all(np.array_equal(store[n].cpu().numpy().reshape(-1),
-                                      np.asarray(params[n], np.float32).reshape(-1)) for n in store.names())
-    assert tfm.sessions[0].global_step == 1
-    for n in store.names():
-        assert np.abs(store[n].cpu().numpy() - want[n]).max() <= 2e-7 + 1e-5 * np.abs(want[n]).max(), n
+    tp = TR.to_torch(params)
+    acc = {k: torch.zeros_like(v) for k, v in tp.items()}
+    acc_u = {k: torch.zeros_like(v) for k, v in tp.items()}
+    ref_losses, got_losses = [], []
+    for _ in range(4):
+        loss, _, _, grads = TR.train_step_grads(tp, src, tgt, l1_weight=0.0, l2_weight=l2)
+        ref_losses.append(float(loss))
+        TR.clip_and_adadelta(tp, grads, acc, acc_u, clip, lr=lr, rho=rho, eps=eps)
+        res = tfm.execute(ds, trainer.feedables, [trainer], train=True)[0]
+        got_losses.append(res.losses["decoder - cost"])
+    assert np.allclose(got_losses, ref_losses, rtol=2e-4), (got_losses, ref_losses)
+    assert got_losses[3] < got_losses[0] - 1e-3
+    a, au = store.ensure_adam()
+    for name in store.names():
+        if name.endswith("attn_bias"):
+            continue
+        spec = store.specs[name]
+        sl = slice(spec.offset, spec.offset + spec.size)
+        for got, want, what in ((a[sl], acc[name], "accum"), (au[sl], acc_u[name], "accum_update"),
+                                (store[name], tp[name].detach(), "variable")):
+            got, want = got.cpu().numpy().reshape(-1), want.numpy().reshape(-1)
+            assert np.abs(got - want).max() <= 5e-3 * max(np.abs(want).max(), 1e-12), (name, what)
+    tfm.checkpoint_format = "tf"
+    prefix = str(tmp_path / "variables.data")
+    tfm.save(prefix)
+    from neuralmonkey_amd import tf_bundle
+    keys = set(tf_bundle.read_bundle(prefix))
+    assert all(n + "/adadelta" in keys and n + "/adadelta_1" in keys for n in store.names())
+    assert "beta1_power" not in keys and not any(k.endswith("/Adam") for k in keys)
+    kept = a.clone()
+    a.zero_()
+    store.slot_suffixes = ("/Adam", "/Adam_1")                # a fresh process has not named the slots yet
+    tfm.restore(prefix)
+    assert torch.equal(store.ensure_adam()[0], kept) and store.slot_suffixes == ("/adadelta", "/adadelta_1")
 
 
 def test_persistent_time_loops_match_graph_replay(dev):
