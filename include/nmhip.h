@@ -110,15 +110,33 @@ typedef struct nm_gru_epilogue {
 } nm_gru_epilogue;
 int nm_gru_gemm(void* stream, const nm_gru_epilogue* epi, int transB, int64_t K, const float* A,
                 int64_t lda, int64_t strideA, const float* B, int64_t ldb, int64_t strideB);
-/* The whole forward time loop of a GRU layer (both directions) in ONE persistent launch: per step two
- * phases of the same tiles + epilogues (modes 1, 2) separated by grid barriers, so a step costs two
- * barriers instead of two kernel launches.  `e` holds the step-0 pointers; step t uses h_in/h_out +
- * t*h_step, ru + t*ru_step, rh + t*rh_step, c_save + t*c_step.  workspace: >= 256 B of device
- * memory (barrier counter + error flag, cleared by the call). */
+/* The time loops of a GRU layer (both directions) as ONE launch each (csrc/nm_gru_cluster.hip): the chip is cut into
+ * clusters of workgroups = (direction, block of 16 or 32 rows); a workgroup keeps its 16 hidden units' slices of the
+ * recurrent kernels in registers for all steps and hands its stage outputs to the rest of its cluster as tagged 8-byte
+ * granules -- no launch, no barrier and no cache invalidate between steps.  Products, accumulation order and
+ * epilogues are those of nm_gru_gemm (forward: modes 1, 2; backward: modes 4, 3).  `e` holds the step-0 pointers.
+ *   supported        1 when (R, H, ndir) can run this way on the current device (H % 128 == 0, 256 <= H <= 512, the
+ *                    clusters -- ndir * ceil(R / 16), or ndir * ceil(R / 32) at H = 512 -- fit the XCDs with their
+ *                    H/16 workgroups each: ceil(clusters / 8) * H / 16 <= CUs / 8), else the caller steps with
+ *                    nm_gru_gemm;
+ *   workspace_bytes  device memory a call needs (header + granules; zeroed by the call, 16-byte aligned);
+ *   failed           after a synchronisation: 1 when a loop that used `workspace` gave up waiting for a hand-off
+ *                    (0.2 s without progress; its results are garbage), 0 otherwise;
+ *   fwd              step t writes h_out + t*h_step, ru + t*ru_step, rh + t*rh_step (rh may be null), c_save +
+ *                    t*c_step and `out` at the step's position; h_in is read once;
+ *   bwd              dh holds dL/dh after the last step on entry and dL/dh_0 on exit; step t (last first) reads ru +
+ *                    t*ru_step, c + t*c_step, h_prev through hseq / h0 and dout at the step's position, and writes the
+ *                    three pre-activation gradients of that position into dxp (dead positions are left alone). */
+int nm_gru_seq_supported(int64_t R, int64_t H, int32_t ndir);
+int64_t nm_gru_seq_workspace_bytes(int64_t R, int64_t H, int32_t ndir);
+int nm_gru_seq_failed(const void* workspace);
 int nm_gru_seq_fwd(void* stream, const nm_gru_epilogue* e, int32_t steps, int64_t h_step, int64_t ru_step,
                    int64_t rh_step, int64_t c_step, const float* wgh, int64_t ld_g, int64_t stride_g,
                    const float* wch, int64_t ld_c, int64_t stride_c, void* workspace,
                    int64_t workspace_bytes);
+int nm_gru_seq_bwd(void* stream, const nm_gru_epilogue* e, int32_t steps, int64_t ru_step, int64_t c_step,
+                   const float* wgh, int64_t ld_g, int64_t stride_g, const float* wch, int64_t ld_c,
+                   int64_t stride_c, void* workspace, int64_t workspace_bytes);
 int nm_gru_seq_shift(void* stream, const float* seq, float* out, const int32_t* lengths, int rev_mask,
                      int64_t B, int64_t S, int ndir, int64_t H);
 int nm_gru_rh_seq(void* stream, const float* ru_all, const float* hprev, float* out,

@@ -39,7 +39,7 @@ def build(force=False, verbose=True):
             objs.append(obj)
             continue
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj,
-               "-Wno-unused-result"]
+               "-Wno-unused-result"] + os.environ.get("NM_HIPCC_FLAGS", "").split()
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((subprocess.Popen(cmd), src))

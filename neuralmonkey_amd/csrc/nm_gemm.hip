@@ -489,39 +489,7 @@ __global__ void splitk_reduce(GemmArgs g) {
 //   mode 3  gates bwd  : s = (dc_pre.Wc_h^T)[row,col] = d(r*h); dr_pre; dh += s*r
 //   mode 4  blend bwd  : s = dh (complete for step t_b) -> dc_pre, du_pre, dh*u of step t_b
 // ---------------------------------------------------------------------------
-struct GruEpi {
-    int mode;
-    const int* lengths;
-    int t, rev_mask, H;
-    long R;
-    // forward
-    const float* xp; long x_dir, x_row, x_time;
-    const float* h_in; float* h_out; float* ru; float* rh; float* c_save;
-    float* out; long o_dir, o_row, o_time;
-    // backward
-    float* dh; const float* dout; long do_dir, do_row, do_time;
-    const float* c; const float* h0; const float* hseq; long hs_dir, hs_row, hs_time;
-    float* dxp; long dx_dir, dx_row, dx_time;
-    float* dgpre; float* dcpre;
-};
-
-__device__ __forceinline__ bool gru_epi_pos(const GruEpi& e, int r, int d, int t, int& pos, int& ppos) {
-    pos = t;
-    const bool rev = (e.rev_mask >> d) & 1;
-    if (e.lengths) {
-        const int len = e.lengths[r];
-        if (t >= len) return false;
-        if (rev) pos = len - 1 - t;
-    }
-    ppos = rev ? pos + 1 : pos - 1;
-    return true;
-}
-
-__device__ __forceinline__ float gru_epi_hprev(const GruEpi& e, long ro, int d, int r, int t, int ppos,
-                                               int col) {
-    if (t == 0) return e.h0 ? e.h0[ro * e.H + col] : 0.0f;
-    return e.hseq[d * e.hs_dir + (long)r * e.hs_row + (long)ppos * e.hs_time + col];
-}
+#include "nm_gru.h"      // struct GruEpi, gru_epi_pos, gru_epi_hprev (shared with nm_gru_cluster.hip)
 
 __device__ __forceinline__ void gru_epilogue(const GruEpi& e, int d, int row, int col, float s) {
     const int H = e.H;
@@ -844,84 +812,6 @@ __global__ __launch_bounds__(KS * 64) void gemm_skinny16(GemmArgs g, int tiles_m
 }
 
 // ---------------------------------------------------------------------------
-// Persistent forward time loop of a GRU layer: ONE launch runs all `steps` recurrent steps.  Every
-// step is two phases of 16x16 tiles (gates GEMM + epilogue, candidate GEMM + blend epilogue -- the
-// same tile code and epilogues as the per-step launches) separated by grid barriers; the workgroups
-// stay resident, so a step costs two barriers instead of two kernel launches with their ramp-up.
-// Barrier = monotonically increasing agent-scope counter: all stores of the phase are released
-// (L2 write-back) before the arrive, the wait is followed by an acquire (L2 invalidate), because the
-// per-XCD L2s are not coherent with each other for plain stores.  The spin is bounded: a workgroup
-// that waits too long raises the error flag and leaves instead of hanging the GPU.
-// ---------------------------------------------------------------------------
-struct GruSeq {
-    GruEpi e;                    // pointers of step 0
-    int steps, ndir;
-    long h_step, ru_step, rh_step, c_step;     // added per step to h_in/h_out, ru, rh, c_save
-    const float* wg; long ldg, sg;             // state half of the gates kernel   [ndir][H][2H]
-    const float* wc; long ldc, sc;             // state half of the candidate kernel [ndir][H][H]
-    unsigned* bar;               // [0] arrive counter, [1] error flag (zeroed before the launch)
-};
-
-__device__ __forceinline__ void nm_grid_barrier(unsigned* bar, unsigned target) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        long spins = 0;
-        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1L << 22)) {          // seconds, not microseconds: something is wrong
-                __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-}
-
-template <int KS>
-__global__ __launch_bounds__(KS * 64) void gru_seq_fwd_kernel(GruSeq q) {
-    __shared__ float red[KS][4][64];
-    const int P = (int)gridDim.x;
-    const int H = q.e.H;
-    const int R = (int)q.e.R;
-    const int tiles_m = (R + 15) / 16;
-    const int tiles_a = tiles_m * ((2 * H + 15) / 16), tiles_b = tiles_m * ((H + 15) / 16);
-    unsigned epoch = 0;
-    for (int t = 0; t < q.steps; ++t) {
-        GruEpi e = q.e;
-        e.t = t;
-        e.h_in += (long)t * q.h_step;
-        e.h_out += (long)t * q.h_step;
-        e.ru += (long)t * q.ru_step;
-        e.rh += (long)t * q.rh_step;
-        if (e.c_save) e.c_save += (long)t * q.c_step;
-        GemmArgs g{e.h_in, q.wg, nullptr, nullptr, R, 2 * H, H, (long)H, q.ldg, 0, (long)R * H, q.sg, 0,
-                   0, 0, nullptr, 1, 0, nullptr, 1};
-        e.mode = 1;                               // r|u = sigmoid(xp + h.Wg_h), rh = r*h
-        for (int w = (int)blockIdx.x; w < tiles_a * q.ndir; w += P) {
-            skinny16_tile<KS, false>(g, tiles_m, e, w % tiles_a, w / tiles_a, red);
-            __syncthreads();
-        }
-        nm_grid_barrier(q.bar, ++epoch * (unsigned)P);
-        g.A = e.rh;
-        g.B = q.wc;
-        g.N = H;
-        g.ldb = q.ldc;
-        g.sB = q.sc;
-        e.mode = 2;                               // c = tanh(xp + (r*h).Wc_h), h' = u*h + (1-u)*c
-        for (int w = (int)blockIdx.x; w < tiles_b * q.ndir; w += P) {
-            skinny16_tile<KS, false>(g, tiles_m, e, w % tiles_b, w / tiles_b, red);
-            __syncthreads();
-        }
-        nm_grid_barrier(q.bar, ++epoch * (unsigned)P);
-    }
-}
-
-// ---------------------------------------------------------------------------
 // host dispatch
 // ---------------------------------------------------------------------------
 // dynamic LDS that brings a workgroup of ``static_lds`` bytes up to ``want_lds`` (0: no padding)
@@ -1153,18 +1043,6 @@ extern "C" int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int6
 // ---------------------------------------------------------------------------
 // one recurrent GEMM of a GRU step with its epilogue fused (see GruEpi above)
 // ---------------------------------------------------------------------------
-struct nm_gru_epilogue {          // mirrors include/nmhip.h
-    int32_t mode, t, rev_mask, ndir;
-    int64_t R, H;
-    const int32_t* lengths;
-    const float* xp; int64_t x_dir, x_row, x_time;
-    const float* h_in; float* h_out; float* ru; float* rh; float* c_save;
-    float* out; int64_t o_dir, o_row, o_time;
-    float* dh; const float* dout; int64_t do_dir, do_row, do_time;
-    const float* c; const float* h0; const float* hseq; int64_t hs_dir, hs_row, hs_time;
-    float* dxp; int64_t dx_dir, dx_row, dx_time;
-    float* dgpre; float* dcpre;
-};
 
 extern "C" int nm_gru_gemm(void* stream, const nm_gru_epilogue* e, int transB, int64_t K, const float* A,
                            int64_t lda, int64_t strideA, const float* B, int64_t ldb, int64_t strideB) {
@@ -1194,51 +1072,6 @@ extern "C" int nm_gru_gemm(void* stream, const nm_gru_epilogue* e, int transB, i
     d.dgpre = e->dgpre; d.dcpre = e->dcpre;
     launch_skinny(g, e->ndir, transB != 0, d, nm_stream(stream));
     NM_LAUNCH_CHECK("nm_gru_gemm");
-}
-
-// ---------------------------------------------------------------------------
-// the whole forward time loop of a GRU layer in one persistent launch (see gru_seq_fwd_kernel)
-// ---------------------------------------------------------------------------
-extern "C" int nm_gru_seq_fwd(void* stream, const nm_gru_epilogue* e, int32_t steps, int64_t h_step,
-                              int64_t ru_step, int64_t rh_step, int64_t c_step, const float* wgh, int64_t ld_g,
-                              int64_t stride_g, const float* wch, int64_t ld_c, int64_t stride_c,
-                              void* workspace, int64_t workspace_bytes) {
-    NM_REQUIRE(e && wgh && wch && workspace && workspace_bytes >= 256, "nm_gru_seq_fwd: null pointer / workspace");
-    NM_REQUIRE(steps >= 0 && e->R > 0 && e->H > 0 && e->H % 16 == 0 && e->ndir >= 1 && e->ndir <= 2,
-               "nm_gru_seq_fwd: bad shape R=%ld H=%ld", (long)e->R, (long)e->H);
-    NM_REQUIRE(e->xp && e->h_in && e->h_out && e->ru && e->rh, "nm_gru_seq_fwd: missing operand");
-    NM_REQUIRE(nm_aligned16(e->h_in) && nm_aligned16(e->rh) && nm_aligned16(wgh) && nm_aligned16(wch) &&
-                   h_step % 4 == 0 && rh_step % 4 == 0,
-               "nm_gru_seq_fwd: operands must be 16-byte aligned");
-    if (steps == 0) return NM_OK;
-    GruSeq q;
-    GruEpi& d = q.e;
-    d.mode = 1; d.lengths = e->lengths; d.t = 0; d.rev_mask = e->rev_mask; d.H = (int)e->H; d.R = e->R;
-    d.xp = e->xp; d.x_dir = e->x_dir; d.x_row = e->x_row; d.x_time = e->x_time;
-    d.h_in = e->h_in; d.h_out = e->h_out; d.ru = e->ru; d.rh = e->rh; d.c_save = e->c_save;
-    d.out = e->out; d.o_dir = e->o_dir; d.o_row = e->o_row; d.o_time = e->o_time;
-    d.dh = nullptr; d.dout = nullptr; d.do_dir = d.do_row = d.do_time = 0;
-    d.c = nullptr; d.h0 = nullptr; d.hseq = nullptr; d.hs_dir = d.hs_row = d.hs_time = 0;
-    d.dxp = nullptr; d.dx_dir = d.dx_row = d.dx_time = 0; d.dgpre = nullptr; d.dcpre = nullptr;
-    q.steps = steps; q.ndir = e->ndir;
-    q.h_step = h_step; q.ru_step = ru_step; q.rh_step = rh_step; q.c_step = c_step;
-    q.wg = wgh; q.ldg = ld_g; q.sg = stride_g; q.wc = wch; q.ldc = ld_c; q.sc = stride_c;
-    q.bar = reinterpret_cast<unsigned*>(workspace);
-    hipStream_t st = nm_stream(stream);
-    if (hipMemsetAsync(workspace, 0, 256, st) != hipSuccess) NM_FAIL(NM_ERR_HIP, "nm_gru_seq_fwd: memset failed");
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (ncu <= 0) ncu = 64;
-    }
-    // one 1024-thread workgroup per CU at most: all of them are resident at once (the grid barrier
-    // needs that), and no more than there are tiles in the larger phase
-    const long tiles = (long)((e->R + 15) / 16) * ((2 * e->H + 15) / 16) * e->ndir;
-    const int P = (int)(tiles < ncu ? tiles : ncu);
-    hipLaunchKernelGGL((gru_seq_fwd_kernel<16>), dim3(P), dim3(1024), 0, st, q);
-    NM_LAUNCH_CHECK("nm_gru_seq_fwd");
 }
 
 // ---------------------------------------------------------------------------

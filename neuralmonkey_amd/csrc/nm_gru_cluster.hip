@@ -1,0 +1,694 @@
+// The time loops of a GRU layer as ONE launch each: weight-stationary workgroup clusters with point-to-point
+// hand-offs instead of two dependent launches per step (nm_gru_gemm).
+//
+// Arithmetic: TF GRUCell under dynamic_rnn (nn/ortho_gru_cell.py:44-53, encoders/recurrent.py:86-102) and its
+// back-propagation -- the products and epilogues of the per-step launches (nm_gemm.hip: skinny16_tile +
+// gru_epi_apply, modes 1-4): K split over H/64 waves, a 16x16x4 fp32 MFMA chain per wave, partials added wave
+// 0..NW-1.  Eight waves of ~110 registers (not sixteen of ~100) so that a workgroup leaves room on its CU: the loops run
+// BESIDE the weight-gradient GEMMs of other streams (one residency-capped 8-wave workgroup per CU, nm_gemm_f32 algo 4),
+// and a 16-wave workgroup that needs a whole CU's registers waits until those drain -- measured: loops ten times and
+// the GEMMs two times slower than alone (profiles/r05_cluster_loops.md).
+//
+// Decomposition.  A step is a chain of two products with an elementwise stage after each (forward: gates, then
+// candidate + blend; backward: d(r*h), then dh).  Rows are independent, columns are not: the second product needs
+// ALL columns of the first stage's result for a row.  So the chip is cut into clusters = (direction, block of
+// 16*RT rows) and every workgroup of a cluster owns 16 hidden units: its slices of the recurrent kernels (K x 48
+// floats = 96 KB at H = 512) live in REGISTERS for the whole loop (48 per lane), the state of its (row, unit)
+// elements lives in the registers of the threads that blend them.  What crosses workgroups per stage is the
+// stage's output for the cluster's rows: 16*RT x 16 values per workgroup, published as 8-byte {value, tag} granules
+// with ONE store each and read -- by every workgroup of the cluster, each WAVE only the K-slice it multiplies --
+// with agent-scope (sc1: past the reader's L1) loads until the tags carry the stage's epoch: the data is the flag,
+// there is no fence, no barrier and no cache invalidate on the path (cdna_hip_programming.md section 6,
+// Guideline 16, form R2).
+//
+// Placement.  The hand-off is correct under ANY placement when the granules are stored write-through (sc1), and
+// that is the fallback.  A write-through store drops the line from the writer's L2, though, so every hop then pays
+// two round trips to the fabric (~1 us each).  When every workgroup of a cluster runs on ONE XCD, plain stores are
+// enough -- the XCD's L2 is the coherence point of its 32 CUs, only the readers' L1 has to be bypassed -- and a hop
+// is two L2 round trips.  HIP promises nothing about placement, so the kernels do not assume it: every workgroup
+// reads its XCC_ID, takes a ticket on that XCD's counter, waits (once per launch) until all workgroups of the grid
+// have done so, and only if every XCD got the tickets its clusters need do roles follow the tickets (cluster =
+// XCD * clusters-per-XCD + ticket / (H/16)) and stores stay plain; otherwise roles follow blockIdx and stores are
+// write-through.  Workgroups without a role exit at once (the grid is always one workgroup per CU).
+//
+// Tags count stages within the launch, the header and the granule buffers are zeroed by a memset node in front of
+// every launch, spins are bounded by the wall clock: a workgroup that waits 0.2 s raises the error word, everyone
+// stops waiting, and the results are garbage (nm_gru_seq_failed reports it).
+//
+// Why overwriting a granule needs no acknowledgement: a buffer that stage s published is next written by stage
+// s + 2 of the same producer, which runs after the producer consumed stage s + 1 of EVERY cluster member, each of
+// which published that only after all its waves had consumed stage s (their partial sums meet in LDS behind a
+// workgroup barrier before the epilogue publishes).  The one buffer that would be rewritten a single stage later --
+// the update-gate half of the backward loop's second operand -- alternates between two copies.
+#include <stdlib.h>
+
+#include "nm_gru.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+typedef __attribute__((address_space(1))) u64 gu64;
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+#define NM_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+// workspace header (unsigned words): [0] error, [1] workgroups that took a ticket, [8 + x] tickets of XCD x
+#define CLU_HDR_BYTES 256
+
+struct GruClu {
+    GruEpi e;                    // pointers of step 0
+    int steps, ndir, nrb;        // row blocks of 16*RT rows per direction
+    long h_step, ru_step, rh_step, c_step;     // added per step to h_out, ru, rh, c_save (forward) / ru, c (backward)
+    const float* wg; long ldg, sg;             // state half of the gates kernel     [ndir][H][2H]
+    const float* wc; long ldc, sc;             // state half of the candidate kernel [ndir][H][H]
+    unsigned* hdr;
+    u64* xa;                     // granules of the first stage's output  [cluster][16 RT][H]
+    u64* xb;                     // granules of the second stage's output [cluster][16 RT][H] (backward: [2][..][2H])
+    long* dbg;                   // timing probe (NM_CLU_DEBUG builds only)
+};
+
+// ---- roles -------------------------------------------------------------------------------------------------------
+struct CluRole {
+    int cl, jb;                  // cluster, block of 16 hidden units
+    bool active, local;          // local: the whole cluster sits on this XCD, plain stores publish
+};
+
+// workgroups XCD x needs when roles follow the tickets: it hosts clusters x * cpx .. , at most cpx of them
+__device__ __forceinline__ int clu_need(int x, int ncl, int cpx, int nj) { return nj * max(0, min(cpx, ncl - x * cpx)); }
+
+__device__ __forceinline__ bool clu_gave_up(gu32* err, long& t0, unsigned& spins) {
+    __builtin_amdgcn_s_sleep(1);
+    if ((++spins & 63) != 0) return false;
+    // ~ every 50 us: has anybody raised the error word, or have we waited 0.2 s (100 MHz clock)?
+    if (__hip_atomic_load(err, NM_RLX_AGENT) != 0) return true;
+    const long now = (long)wall_clock64();
+    if (t0 == 0) t0 = now;
+    else if (now - t0 > 20000000L) {
+        __hip_atomic_store(err, 1u, NM_RLX_AGENT);
+        return true;
+    }
+    return false;
+}
+
+__device__ __forceinline__ CluRole clu_roles(unsigned* hdr_, int ncl, int nj, int* sh) {
+    gu32* hdr = (gu32*)hdr_;
+    const int cpx = (ncl + 7) / 8;
+    if (threadIdx.x == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 7u;
+        const unsigned ticket = __hip_atomic_fetch_add(hdr + 8 + xcc, 1u, NM_RLX_AGENT);
+        __hip_atomic_fetch_add(hdr + 1, 1u, NM_RLX_AGENT);
+        long t0 = 0;
+        unsigned spins = 0;
+        bool lost = false;
+        while (__hip_atomic_load(hdr + 1, NM_RLX_AGENT) < gridDim.x)
+            if (clu_gave_up(hdr, t0, spins)) { lost = true; break; }
+        bool local = !lost;
+        for (int x = 0; x < 8; ++x) local &= (int)__hip_atomic_load(hdr + 8 + x, NM_RLX_AGENT) >= clu_need(x, ncl, cpx, nj);
+        int cl, jb;
+        bool active;
+        if (local) {
+            const int lc = (int)ticket / nj;
+            cl = (int)xcc * cpx + lc;
+            jb = (int)ticket % nj;
+            active = lc < cpx && cl < ncl;
+        } else {
+            cl = (int)blockIdx.x % ncl;
+            jb = (int)blockIdx.x / ncl;
+            active = (int)blockIdx.x < ncl * nj;
+        }
+        sh[0] = cl; sh[1] = jb; sh[2] = active ? 1 : 0; sh[3] = local ? 1 : 0;
+    }
+    __syncthreads();
+    CluRole r;
+    r.cl = sh[0]; r.jb = sh[1]; r.active = sh[2] != 0; r.local = sh[3] != 0;
+    __syncthreads();
+    return r;
+}
+
+// ---- hand-off primitives ---------------------------------------------------------------------------------------
+// Granule layout of one cluster's stage output (16*RT rows x K values): what ONE consuming wave reads with ONE load
+// instruction is 1 KB of consecutive bytes -- [wave slice w][row tile rt][chunk c][half hh][k-quad kq][row i16]
+// units of 16 bytes = two granules {value, tag} (k = 16 (w NCH + c) + 4 kq + 2 hh + slot).  Lane (i16, kq)
+// of the MFMA fragment is lane 16 kq + i16, the position of its unit in the 1 KB: the sweep needs no shuffles.
+template <int RT, int NCH>
+__device__ __forceinline__ long clu_unit(int w, int c, int hh, int rt, int i16, int kq) {
+    return (((((long)w * RT + rt) * NCH + c) * 2 + hh) * 4 + kq) * 16 + i16;
+}
+
+// value of (row tile rt, row r, k) of the cluster's stage output, tagged
+template <int RT, int NCH>
+__device__ __forceinline__ void clu_publish(u64* X, bool local, int rt, int r, int k, unsigned tag, float v) {
+    const int n = k & 15, kc = k >> 4;
+    u64* g = X + clu_unit<RT, NCH>(kc / NCH, kc % NCH, (n & 3) >> 1, rt, r, n >> 2) * 2 + (n & 1);
+    const u64 x = ((u64)tag << 32) | (u64)__float_as_uint(v);
+    if (local) __hip_atomic_store((gu64*)g, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // stays in this XCD's L2
+    else __hip_atomic_store((gu64*)g, x, NM_RLX_AGENT);                                            // write-through
+}
+
+// 16-byte agent-scope (sc1: past L1, served by L2) loads of 4 or 8 consecutive KB; a load holds two granules, each
+// written by ONE 8-byte store.  Inline assembly: hipcc has no 16-byte atomic load, and it hoists buffer-load builtins
+// out of a spin loop (a "memory" clobber does not stop it) -- loads and their wait are one volatile statement.
+template <int N>
+__device__ __forceinline__ void clu_load_kb(const char* base, u32x4 (&x)[N]) {
+    static_assert(N == 4 || N == 8, "pieces of 4 or 8 KB per wave");
+    if constexpr (N == 4) {
+        asm volatile("global_load_dwordx4 %0, %4, off sc1\n"
+                     "global_load_dwordx4 %1, %4, off offset:1024 sc1\n"
+                     "global_load_dwordx4 %2, %4, off offset:2048 sc1\n"
+                     "global_load_dwordx4 %3, %4, off offset:3072 sc1\n"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]) : "v"(base) : "memory");
+    } else {
+        const char* hi = base + 4096;
+        asm volatile("global_load_dwordx4 %0, %8, off sc1\n"
+                     "global_load_dwordx4 %1, %8, off offset:1024 sc1\n"
+                     "global_load_dwordx4 %2, %8, off offset:2048 sc1\n"
+                     "global_load_dwordx4 %3, %8, off offset:3072 sc1\n"
+                     "global_load_dwordx4 %4, %9, off sc1\n"
+                     "global_load_dwordx4 %5, %9, off offset:1024 sc1\n"
+                     "global_load_dwordx4 %6, %9, off offset:2048 sc1\n"
+                     "global_load_dwordx4 %7, %9, off offset:3072 sc1\n"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7])
+                     : "v"(base), "v"(hi) : "memory");
+    }
+}
+
+// A wave waits for its producers: ONE granule per producer (lanes 0..NCH-1, one 8-byte load each -- a thousand lanes
+// per CU polling would keep the memory pipes busy with polls), the one its LAST epilogue thread writes (row 15 of the
+// last row tile, k 15 of the chunk).
+struct CluWait {
+    long t0;
+    unsigned spins;
+};
+
+template <int RT, int NCH>
+__device__ __forceinline__ void clu_wait(const u64* __restrict__ X, int wave, int lane, unsigned tag, gu32* err, CluWait& w) {
+    w.t0 = 0;
+    w.spins = 0;
+    const gu64* poll = (const gu64*)(X + clu_unit<RT, NCH>(wave, min(lane, NCH - 1), 1, RT - 1, 15, 3) * 2 + 1);
+    for (;;) {
+        bool ok = true;
+        if (lane < NCH) ok = (unsigned)(__hip_atomic_load(poll, NM_RLX_AGENT) >> 32) == tag;
+        if (__all(ok)) return;
+        if (clu_gave_up(err, w.t0, w.spins)) return;
+    }
+}
+
+// ... and gathers its K-slice of one row tile of the cluster's operand in pieces of 8 KB = 4 chunks of 16 k (32
+// registers in flight), each piece read again until its tags are right -- after the wait that is nearly always the
+// first pass.
+template <int RT, int NCH>
+__device__ __forceinline__ void clu_gather(const u64* __restrict__ X, int wave, int lane, int rt, int piece, unsigned tag,
+                                           gu32* err, CluWait& w, float (&a)[4][4]) {
+    static_assert(NCH % 4 == 0, "whole pieces");
+    const char* base = (const char*)X + (clu_unit<RT, NCH>(wave, 4 * piece, 0, rt, 0, 0) + lane) * 16;
+    for (;;) {
+        bool ok = true;
+        u32x4 x[8];
+        clu_load_kb<8>(base, x);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {                             // unit block (chunk q / 2 of the piece, hh = q % 2)
+            a[q / 2][2 * (q & 1)] = __uint_as_float(x[q][0]);
+            a[q / 2][2 * (q & 1) + 1] = __uint_as_float(x[q][2]);
+            ok &= x[q][1] == tag && x[q][3] == tag;
+        }
+        if (__all(ok)) return;
+        if (clu_gave_up(err, w.t0, w.spins)) return;
+    }
+}
+
+// plain (not handed-off) operand rows of one row tile: the forward loop's initial state
+__device__ __forceinline__ void clu_load_plain(const float* __restrict__ A, long ld, int R, int row0, int k_wave,
+                                               int lane, float (&a)[4][4]) {
+    const int i16 = lane & 15, kq = lane >> 4;
+    const float* p = A + (long)min(row0 + i16, R - 1) * ld + k_wave + 4 * kq;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float4 v = *reinterpret_cast<const float4*>(p + 16 * c);
+        a[c][0] = v.x; a[c][1] = v.y; a[c][2] = v.z; a[c][3] = v.w;
+    }
+}
+
+// acc += A-piece . B-piece for one 16x16 output tile: the chain of nm_gemm.hip's skinny16_tile (chunk by chunk, the
+// four k-phases of a chunk in order); ``b`` points at the piece's four chunks of this wave's kernel slice
+__device__ __forceinline__ void clu_mma(f32x4& acc, const float (&a)[4][4], const float (*b)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[c][j], acc, 0, 0, 0);
+}
+
+// partial tile of this wave -> LDS [wave][tile][reg][lane]
+__device__ __forceinline__ void clu_put(float* red, int ntiles, int wave, int tile, int lane, const f32x4& acc) {
+    float* p = red + ((long)(wave * ntiles + tile) * 4) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i * 64] = acc[i];
+}
+
+// sum over the waves, in order (the order of skinny16_tile's epilogue)
+__device__ __forceinline__ float clu_get(const float* red, int ntiles, int nw, int tile, int reg, int ln) {
+    float s = 0.0f;
+    for (int w = 0; w < nw; ++w) s += red[((long)(w * ntiles + tile) * 4 + reg) * 64 + ln];
+    return s;
+}
+
+#ifdef NM_CLU_DEBUG
+#define CLU_STAMP(i) do { if (q.dbg && role.cl == 3 && role.jb == 5 && lane == 0 && (wave == 0 || wave == NW - 1) && t >= 20 && t < 24) \
+        q.dbg[((t - 20) * 2 + (wave ? 1 : 0)) * 8 + (i)] = (long)wall_clock64(); } while (0)
+#else
+#define CLU_STAMP(i) do { } while (0)
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward: per step  r|u = sigmoid(xp + h.Wg_h), rh = r*h  ->  c = tanh(xp + rh.Wc_h), h' = u*h + (1-u)*c
+// ---------------------------------------------------------------------------------------------------------------
+template <int RT>
+__global__ __launch_bounds__(512, 3) void gru_cluster_fwd_kernel(GruClu q) {
+    constexpr int NCH = 4;                               // 64 k-values per wave
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NW = (int)(blockDim.x >> 6);
+    const int H = q.e.H, R = (int)q.e.R;
+    const CluRole role = clu_roles(q.hdr, q.ndir * q.nrb, H / 16, reinterpret_cast<int*>(lds));
+    if (!role.active) return;
+    __builtin_amdgcn_s_setprio(3);
+    const int jb = role.jb;
+    const int d = role.cl / q.nrb, rb = role.cl % q.nrb;
+    const int row0 = rb * 16 * RT;
+    const int n16 = lane & 15, kq = lane >> 4;
+    const int k_wave = wave * 16 * NCH;
+    float* red1 = lds;                                   // [NW][2 RT][4][64]
+    float* red2 = lds + (long)NW * 2 * RT * 256;         // [NW][RT][4][64]
+    gu32* err = (gu32*)q.hdr;
+
+    // this wave's slices of the recurrent kernels, for the whole loop
+    float wr[NCH][4], wu[NCH][4], wk[NCH][4];
+    {
+        const float* Wg = q.wg + (long)d * q.sg + 16 * jb + n16;
+        const float* Wc = q.wc + (long)d * q.sc + 16 * jb + n16;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long k = k_wave + 16 * c + 4 * kq + j;
+                wr[c][j] = Wg[k * q.ldg];
+                wu[c][j] = Wg[k * q.ldg + H];
+                wk[c][j] = Wc[k * q.ldc];
+            }
+    }
+
+    // epilogue threads: ONE element (row, col) each, laid out as skinny16_tile maps a 16x16 tile (threads 0..255 the
+    // first row tile, 256..511 the second: a workgroup has at least 256 RT threads)
+    const bool epi = tid < 256 * RT;
+    const int ert = tid >> 8, reg = (tid >> 6) & 3, ln = tid & 63;
+    const int rloc = 4 * (ln >> 4) + reg, col = 16 * jb + (ln & 15);
+    const int row = row0 + 16 * ert + rloc;
+    const bool mine = epi && row < R;
+    const long ro = (long)d * R + min(row, R - 1);
+    const int len = (mine && q.e.lengths) ? q.e.lengths[row] : 0x7fffffff;
+    float hreg = mine ? q.e.h_in[ro * H + col] : 0.0f;
+    const bool rev = ((q.e.rev_mask >> d) & 1) && q.e.lengths;
+    u64* XA = q.xa + (long)role.cl * 16 * RT * H;        // this cluster's granules of r*h ...
+    u64* XB = q.xb + (long)role.cl * 16 * RT * H;        // ... and of h'
+
+    for (int t = 0; t < q.steps; ++t) {
+        CLU_STAMP(0);
+        // what the epilogues need from plain memory, requested before any waiting
+        const bool live = mine && t < len;
+        const int pos = rev ? len - 1 - t : t;
+        float xr = 0.0f, xu = 0.0f, xc = 0.0f, ureg = 0.0f;
+        if (live) {
+            const float* x = q.e.xp + d * q.e.x_dir + (long)row * q.e.x_row + (long)pos * q.e.x_time + col;
+            xr = x[0];
+            xu = x[H];
+            xc = x[2 * H];
+        }
+        float a[4][4];
+        CluWait cw;
+        const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+        // ---- stage A: gates
+        if (t > 0) clu_wait<RT, NCH>(XB, wave, lane, (unsigned)(2 * t), err, cw);
+        CLU_STAMP(1);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            if (t == 0) clu_load_plain(q.e.h_in + (long)d * R * H, H, R, row0 + 16 * rt, k_wave, lane, a);
+            else clu_gather<RT, NCH>(XB, wave, lane, rt, 0, (unsigned)(2 * t), err, cw, a);
+            f32x4 ar = zero, au = zero;
+            clu_mma(ar, a, wr);
+            clu_mma(au, a, wu);
+            clu_put(red1, 2 * RT, wave, 2 * rt, lane, ar);
+            clu_put(red1, 2 * RT, wave, 2 * rt + 1, lane, au);
+        }
+        CLU_STAMP(2);
+        __syncthreads();
+        CLU_STAMP(3);
+        if (epi) {
+            const float sr = clu_get(red1, 2 * RT, NW, 2 * ert, reg, ln);
+            const float su = clu_get(red1, 2 * RT, NW, 2 * ert + 1, reg, ln);
+            const float r = live ? nm_sigmoid(xr + sr) : 0.0f;
+            const float u = live ? nm_sigmoid(xu + su) : 0.0f;
+            const float rh = live ? r * hreg : 0.0f;
+            ureg = u;
+            clu_publish<RT, NCH>(XA, role.local, ert, rloc, col, (unsigned)(2 * t + 1), rh);    // (rows past R: zeros)
+            if (mine) {
+                float* ru = q.e.ru + (long)t * q.ru_step + ro * 2 * H;
+                ru[col] = r;
+                ru[H + col] = u;
+                if (q.e.rh) q.e.rh[(long)t * q.rh_step + ro * H + col] = rh;
+            }
+        }
+        // ---- stage B: candidate + blend
+        CLU_STAMP(4);
+        clu_wait<RT, NCH>(XA, wave, lane, (unsigned)(2 * t + 1), err, cw);
+        CLU_STAMP(5);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            clu_gather<RT, NCH>(XA, wave, lane, rt, 0, (unsigned)(2 * t + 1), err, cw, a);
+            f32x4 ac = zero;
+            clu_mma(ac, a, wk);
+            clu_put(red2, RT, wave, rt, lane, ac);
+        }
+        __syncthreads();
+        CLU_STAMP(6);
+        if (epi) {
+            const float sc = clu_get(red2, RT, NW, ert, reg, ln);
+            float hn = hreg, c = 0.0f;
+            if (live) {
+                c = nm_tanh(xc + sc);
+                hn = ureg * hreg + (1.0f - ureg) * c;
+            }
+            hreg = hn;
+            if (t + 1 < q.steps) clu_publish<RT, NCH>(XB, role.local, ert, rloc, col, (unsigned)(2 * t + 2), hn);
+            if (mine) {
+                q.e.h_out[(long)t * q.h_step + ro * H + col] = hn;
+                if (q.e.c_save) q.e.c_save[(long)t * q.c_step + ro * H + col] = c;
+                if (live && q.e.out)
+                    q.e.out[d * q.e.o_dir + (long)row * q.e.o_row + (long)pos * q.e.o_time + col] = hn;
+            }
+        }
+        CLU_STAMP(7);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward (nm_gru_gemm modes 4, 3 per step, last step first).  State per element: dh.  Step t:
+//   blend bwd   dhv = dh (+ sB of the step after: d(gates) . Wg_h^T) + dout;  dc_pre = dhv (1-u)(1-c^2),
+//               du_pre = dhv (h_prev - c) u (1-u),  dh = dhv u                      -> publishes dc_pre and du_pre
+//   stage A     sA = dc_pre . Wc_h^T = d(r*h)          (K = H)
+//   gates bwd   dr_pre = sA h_prev r (1-r),  dh += sA r                               -> publishes dr_pre
+//   stage B     sB = [dr_pre | du_pre] . Wg_h^T        (K = 2H: waves 0..NW/2-1 the reset half, the rest the update half)
+// and after step 0: dh_0 = dh + sB.
+// ---------------------------------------------------------------------------------------------------------------
+template <int RT>
+__global__ __launch_bounds__(512, 3) void gru_cluster_bwd_kernel(GruClu q) {
+    constexpr int NCA = 4, NCB = 8;                      // 64 k-values per wave of K = H, 128 of K = 2H
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NW = (int)(blockDim.x >> 6);
+    const int H = q.e.H, R = (int)q.e.R;
+    const CluRole role = clu_roles(q.hdr, q.ndir * q.nrb, H / 16, reinterpret_cast<int*>(lds));
+    if (!role.active) return;
+    __builtin_amdgcn_s_setprio(3);
+    const int jb = role.jb;
+    const int d = role.cl / q.nrb, rb = role.cl % q.nrb;
+    const int row0 = rb * 16 * RT;
+    const int n16 = lane & 15, kq = lane >> 4;
+    float* redA = lds;                                   // [NW][RT][4][64]
+    float* redB = lds + (long)NW * RT * 256;             // [NW][RT][4][64]
+    gu32* err = (gu32*)q.hdr;
+
+    // rows 16 jb + n16 of the recurrent kernels ([K_in][N_out]: their transposes' columns), this wave's K-slices
+    float wc[NCA][4], wg[NCB][4];
+    {
+        const float* Wc = q.wc + (long)d * q.sc + (long)(16 * jb + n16) * q.ldc + wave * 16 * NCA + 4 * kq;
+        const float* Wg = q.wg + (long)d * q.sg + (long)(16 * jb + n16) * q.ldg + wave * 16 * NCB + 4 * kq;
+#pragma unroll
+        for (int c = 0; c < NCA; ++c) {
+            const float4 v = *reinterpret_cast<const float4*>(Wc + 16 * c);
+            wc[c][0] = v.x; wc[c][1] = v.y; wc[c][2] = v.z; wc[c][3] = v.w;
+        }
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+            const float4 v = *reinterpret_cast<const float4*>(Wg + 16 * c);
+            wg[c][0] = v.x; wg[c][1] = v.y; wg[c][2] = v.z; wg[c][3] = v.w;
+        }
+    }
+
+    const bool epi = tid < 256 * RT;
+    const int ert = tid >> 8, reg = (tid >> 6) & 3, ln = tid & 63;
+    const int rloc = 4 * (ln >> 4) + reg, col = 16 * jb + (ln & 15);
+    const int row = row0 + 16 * ert + rloc;
+    const bool mine = epi && row < R;
+    const long ro = (long)d * R + min(row, R - 1);
+    const int len = (mine && q.e.lengths) ? q.e.lengths[row] : 0x7fffffff;
+    float dh = mine ? q.e.dh[ro * H + col] : 0.0f;
+    const bool rev = ((q.e.rev_mask >> d) & 1) && q.e.lengths;
+    u64* XA = q.xa + (long)role.cl * 16 * RT * H;                       // dc_pre
+    u64* XB = q.xb + (long)role.cl * 16 * RT * 2 * H;                   // [dr_pre | du_pre], two copies
+    const long xb_copy = (long)q.ndir * q.nrb * 16 * RT * 2 * H;
+    const unsigned upper = wave >= NW / 2 ? 1u : 0u;                    // this wave multiplies the update half
+    float sB = 0.0f;
+
+    for (int i = 0; i < q.steps; ++i) {
+        const int t = q.steps - 1 - i;
+        const bool live = mine && t < len;
+        const int pos = rev ? len - 1 - t : t;
+        const int ppos = rev ? pos + 1 : pos - 1;
+        float r = 0.0f, u = 0.0f, c = 0.0f, hp = 0.0f, dout = 0.0f;
+        if (live) {
+            const float* ru = q.e.ru + (long)t * q.ru_step + ro * 2 * H;
+            r = ru[col];
+            u = ru[H + col];
+            c = q.e.c[(long)t * q.c_step + ro * H + col];
+            hp = gru_epi_hprev(q.e, ro, d, row, t, ppos, col);
+            if (q.e.dout) dout = q.e.dout[d * q.e.do_dir + (long)row * q.e.do_row + (long)pos * q.e.do_time + col];
+        }
+        u64* XBi = XB + (i & 1) * xb_copy;
+        // ---- blend backward of step t (sB: the product of the step after, reduced at the end of the last pass)
+        if (epi) {
+            const float s = (i == 0) ? dh : sB + dh;
+            float dcp = 0.0f, dup = 0.0f;
+            if (live) {
+                const float dhv = s + dout;
+                dcp = dhv * (1.0f - u) * (1.0f - c * c);
+                dup = dhv * (hp - c) * u * (1.0f - u);
+                dh = dhv * u;
+            } else {
+                dh = s;
+            }
+            clu_publish<RT, NCA>(XA, role.local, ert, rloc, col, (unsigned)(2 * i + 1), dcp);
+            clu_publish<RT, NCB>(XBi, role.local, ert, rloc, H + col, (unsigned)(2 * i + 1), dup);
+            if (live) {
+                float* dx = q.e.dxp + d * q.e.dx_dir + (long)row * q.e.dx_row + (long)pos * q.e.dx_time;
+                dx[H + col] = dup;
+                dx[2 * H + col] = dcp;
+            }
+        }
+        // ---- stage A: d(r*h) = dc_pre . Wc_h^T
+        const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+        {
+            float a[4][4];
+            CluWait cw;
+            clu_wait<RT, NCA>(XA, wave, lane, (unsigned)(2 * i + 1), err, cw);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                clu_gather<RT, NCA>(XA, wave, lane, rt, 0, (unsigned)(2 * i + 1), err, cw, a);
+                f32x4 acc = zero;
+                clu_mma(acc, a, wc);
+                clu_put(redA, RT, wave, rt, lane, acc);
+            }
+        }
+        __syncthreads();
+        if (epi) {
+            const float sA = clu_get(redA, RT, NW, ert, reg, ln);
+            float drp = 0.0f;
+            if (live) {
+                drp = sA * hp * r * (1.0f - r);
+                dh = dh + sA * r;
+                q.e.dxp[d * q.e.dx_dir + (long)row * q.e.dx_row + (long)pos * q.e.dx_time + col] = drp;
+            }
+            clu_publish<RT, NCB>(XBi, role.local, ert, rloc, col, (unsigned)(2 * i + 2), drp);
+        }
+        // ---- stage B: [dr_pre | du_pre] . Wg_h^T (the update half was published a stage earlier)
+        {
+            float a[4][4];
+            CluWait cw;
+            clu_wait<RT, NCB>(XBi, wave, lane, (unsigned)(2 * i + 2) - upper, err, cw);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                f32x4 acc = zero;
+#pragma unroll
+                for (int piece = 0; piece < NCB / 4; ++piece) {
+                    clu_gather<RT, NCB>(XBi, wave, lane, rt, piece, (unsigned)(2 * i + 2) - upper, err, cw, a);
+                    clu_mma(acc, a, wg + 4 * piece);
+                }
+                clu_put(redB, RT, wave, rt, lane, acc);
+            }
+        }
+        __syncthreads();
+        if (epi) sB = clu_get(redB, RT, NW, ert, reg, ln);
+    }
+    if (mine) q.e.dh[ro * H + col] = sB + dh;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+struct CluShape {
+    int RT, NW, nrb, grid;
+    long granules;               // of one stage output of width H, all clusters
+};
+
+// Which (R, H, ndir) the cluster kernels take: H a multiple of 128 between 256 and 512 (H/64 waves of 64 k-values, an
+// even number of them: the two halves of the backward loop's 2H-wide operand fall on whole waves; one epilogue thread
+// per element: 256 RT <= 64 NW), clusters of 16 or 32 rows whose H/16 workgroups all fit ONE XCD's CUs, one workgroup
+// per CU.
+static bool clu_shape(long R, long H, int ndir, CluShape* s) {
+    if (H < 256 || H > 512 || H % 128 != 0 || R < 1 || ndir < 1 || ndir > 2) return false;
+    int ncu = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 8) return false;
+    const int nj = (int)(H / 16), nw = (int)(H / 64);
+    for (int rt = 1; rt <= 2 && 256 * rt <= 64 * nw; ++rt) {
+        const int nrb = (int)((R + 16 * rt - 1) / (16 * rt));
+        const int ncl = ndir * nrb, cpx = (ncl + 7) / 8;
+        if (cpx * nj <= ncu / 8) {
+            s->RT = rt; s->NW = nw; s->nrb = nrb; s->grid = ncu;
+            s->granules = (long)ncl * 16 * rt * H;
+            return true;
+        }
+    }
+    return false;
+}
+
+extern "C" int nm_gru_seq_supported(int64_t R, int64_t H, int32_t ndir) {
+    CluShape s;
+    return clu_shape(R, H, ndir, &s) ? 1 : 0;
+}
+
+// header + granules: forward two stage outputs of width H, backward one of width H and two copies of width 2H
+extern "C" int64_t nm_gru_seq_workspace_bytes(int64_t R, int64_t H, int32_t ndir) {
+    CluShape s;
+    if (!clu_shape(R, H, ndir, &s)) return CLU_HDR_BYTES;
+    return CLU_HDR_BYTES + s.granules * 8 * 5;
+}
+
+template <typename Kern>
+static bool clu_prepare(Kern kern, size_t lds) {
+    static std::atomic<unsigned> devs{0};
+    const unsigned ok_bit = 1u << (nm_cur()->device & 15), bad_bit = ok_bit << 16;
+    unsigned seen = devs.load(std::memory_order_relaxed);
+    if (!(seen & (ok_bit | bad_bit))) {
+        bool ok = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) == hipSuccess;
+        int per_cu = 0;
+        ok = ok && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 512, 64 * 1024) == hipSuccess && per_cu >= 1;
+        if (!ok) (void)hipGetLastError();
+        seen = devs.fetch_or(ok ? ok_bit : bad_bit, std::memory_order_relaxed) | (ok ? ok_bit : bad_bit);
+    }
+    return (seen & ok_bit) && lds <= 64 * 1024;
+}
+
+static void clu_fill(GruClu& q, const nm_gru_epilogue* e) {
+    GruEpi& d = q.e;
+    d.mode = 0; d.lengths = e->lengths; d.t = 0; d.rev_mask = e->rev_mask; d.H = (int)e->H; d.R = e->R;
+    d.xp = e->xp; d.x_dir = e->x_dir; d.x_row = e->x_row; d.x_time = e->x_time;
+    d.h_in = e->h_in; d.h_out = e->h_out; d.ru = e->ru; d.rh = e->rh; d.c_save = e->c_save;
+    d.out = e->out; d.o_dir = e->o_dir; d.o_row = e->o_row; d.o_time = e->o_time;
+    d.dh = e->dh; d.dout = e->dout; d.do_dir = e->do_dir; d.do_row = e->do_row; d.do_time = e->do_time;
+    d.c = e->c; d.h0 = e->h0; d.hseq = e->hseq; d.hs_dir = e->hs_dir; d.hs_row = e->hs_row; d.hs_time = e->hs_time;
+    d.dxp = e->dxp; d.dx_dir = e->dx_dir; d.dx_row = e->dx_row; d.dx_time = e->dx_time;
+    d.dgpre = e->dgpre; d.dcpre = e->dcpre;
+    q.ndir = e->ndir;
+    q.dbg = reinterpret_cast<long*>(getenv("NM_CLU_DEBUG_PTR") ? strtoull(getenv("NM_CLU_DEBUG_PTR"), nullptr, 0) : 0ull);
+}
+
+extern "C" int nm_gru_seq_fwd(void* stream, const nm_gru_epilogue* e, int32_t steps, int64_t h_step,
+                              int64_t ru_step, int64_t rh_step, int64_t c_step, const float* wgh, int64_t ld_g,
+                              int64_t stride_g, const float* wch, int64_t ld_c, int64_t stride_c,
+                              void* workspace, int64_t workspace_bytes) {
+    NM_REQUIRE(e && wgh && wch && workspace, "nm_gru_seq_fwd: null pointer / workspace");
+    NM_REQUIRE(steps >= 0 && e->R > 0 && e->H > 0 && e->ndir >= 1 && e->ndir <= 2,
+               "nm_gru_seq_fwd: bad shape R=%ld H=%ld", (long)e->R, (long)e->H);
+    NM_REQUIRE(e->xp && e->h_in && e->h_out && e->ru, "nm_gru_seq_fwd: missing operand");
+    NM_REQUIRE(nm_aligned16(e->h_in) && nm_aligned16(workspace), "nm_gru_seq_fwd: operands must be 16-byte aligned");
+    CluShape s;
+    NM_REQUIRE(clu_shape(e->R, e->H, e->ndir, &s), "nm_gru_seq_fwd: shape R=%ld H=%ld ndir=%d not supported "
+               "(nm_gru_seq_supported)", (long)e->R, (long)e->H, (int)e->ndir);
+    NM_REQUIRE(workspace_bytes >= nm_gru_seq_workspace_bytes(e->R, e->H, e->ndir), "nm_gru_seq_fwd: workspace too small");
+    if (steps == 0) return NM_OK;
+    GruClu q;
+    clu_fill(q, e);
+    q.steps = steps; q.nrb = s.nrb;
+    q.h_step = h_step; q.ru_step = ru_step; q.rh_step = rh_step; q.c_step = c_step;
+    q.wg = wgh; q.ldg = ld_g; q.sg = stride_g; q.wc = wch; q.ldc = ld_c; q.sc = stride_c;
+    q.hdr = reinterpret_cast<unsigned*>(workspace);
+    q.xa = reinterpret_cast<u64*>(reinterpret_cast<char*>(workspace) + CLU_HDR_BYTES);
+    q.xb = q.xa + s.granules;
+    hipStream_t st = nm_stream(stream);
+    if (hipMemsetAsync(workspace, 0, CLU_HDR_BYTES + (size_t)s.granules * 8 * 2, st) != hipSuccess)
+        NM_FAIL(NM_ERR_HIP, "nm_gru_seq_fwd: memset failed");
+    const size_t lds = (size_t)s.NW * s.RT * 3 * 1024;
+    bool ok;
+    if (s.RT == 1) {
+        ok = clu_prepare(gru_cluster_fwd_kernel<1>, lds);
+        if (ok) hipLaunchKernelGGL((gru_cluster_fwd_kernel<1>), dim3(s.grid), dim3(s.NW * 64), lds, st, q);
+    } else {
+        ok = clu_prepare(gru_cluster_fwd_kernel<2>, lds);
+        if (ok) hipLaunchKernelGGL((gru_cluster_fwd_kernel<2>), dim3(s.grid), dim3(s.NW * 64), lds, st, q);
+    }
+    if (!ok) NM_FAIL(NM_ERR_HIP, "nm_gru_seq_fwd: the kernel cannot be made resident on this device");
+    NM_LAUNCH_CHECK("nm_gru_seq_fwd");
+}
+
+// The whole BPTT loop: e->dh holds dL/dh after the last step on entry and dL/dh_0 on exit; step t reads ru + t*ru_step,
+// c + t*c_step, h_prev through hseq / h0, dout at the step's position, and writes the three pre-activation gradients
+// of the step's position into dxp.
+extern "C" int nm_gru_seq_bwd(void* stream, const nm_gru_epilogue* e, int32_t steps, int64_t ru_step, int64_t c_step,
+                              const float* wgh, int64_t ld_g, int64_t stride_g, const float* wch, int64_t ld_c,
+                              int64_t stride_c, void* workspace, int64_t workspace_bytes) {
+    NM_REQUIRE(e && wgh && wch && workspace, "nm_gru_seq_bwd: null pointer / workspace");
+    NM_REQUIRE(steps >= 0 && e->R > 0 && e->H > 0 && e->ndir >= 1 && e->ndir <= 2,
+               "nm_gru_seq_bwd: bad shape R=%ld H=%ld", (long)e->R, (long)e->H);
+    NM_REQUIRE(e->dh && e->ru && e->c && e->hseq && e->dxp, "nm_gru_seq_bwd: missing operand");
+    NM_REQUIRE(nm_aligned16(wgh) && nm_aligned16(wch) && ld_g % 4 == 0 && ld_c % 4 == 0 && stride_g % 4 == 0 &&
+                   stride_c % 4 == 0 && nm_aligned16(workspace),
+               "nm_gru_seq_bwd: kernels must be 16-byte aligned with leading dimensions %% 4 == 0");
+    CluShape s;
+    NM_REQUIRE(clu_shape(e->R, e->H, e->ndir, &s), "nm_gru_seq_bwd: shape R=%ld H=%ld ndir=%d not supported "
+               "(nm_gru_seq_supported)", (long)e->R, (long)e->H, (int)e->ndir);
+    NM_REQUIRE(workspace_bytes >= nm_gru_seq_workspace_bytes(e->R, e->H, e->ndir), "nm_gru_seq_bwd: workspace too small");
+    if (steps == 0) return NM_OK;
+    GruClu q;
+    clu_fill(q, e);
+    q.steps = steps; q.nrb = s.nrb;
+    q.h_step = 0; q.ru_step = ru_step; q.rh_step = 0; q.c_step = c_step;
+    q.wg = wgh; q.ldg = ld_g; q.sg = stride_g; q.wc = wch; q.ldc = ld_c; q.sc = stride_c;
+    q.hdr = reinterpret_cast<unsigned*>(workspace);
+    q.xa = reinterpret_cast<u64*>(reinterpret_cast<char*>(workspace) + CLU_HDR_BYTES);
+    q.xb = q.xa + s.granules;
+    hipStream_t st = nm_stream(stream);
+    if (hipMemsetAsync(workspace, 0, CLU_HDR_BYTES + (size_t)s.granules * 8 * 5, st) != hipSuccess)
+        NM_FAIL(NM_ERR_HIP, "nm_gru_seq_bwd: memset failed");
+    const size_t lds = (size_t)s.NW * s.RT * 2 * 1024;
+    bool ok;
+    if (s.RT == 1) {
+        ok = clu_prepare(gru_cluster_bwd_kernel<1>, lds);
+        if (ok) hipLaunchKernelGGL((gru_cluster_bwd_kernel<1>), dim3(s.grid), dim3(s.NW * 64), lds, st, q);
+    } else {
+        ok = clu_prepare(gru_cluster_bwd_kernel<2>, lds);
+        if (ok) hipLaunchKernelGGL((gru_cluster_bwd_kernel<2>), dim3(s.grid), dim3(s.NW * 64), lds, st, q);
+    }
+    if (!ok) NM_FAIL(NM_ERR_HIP, "nm_gru_seq_bwd: the kernel cannot be made resident on this device");
+    NM_LAUNCH_CHECK("nm_gru_seq_bwd");
+}
+
+// 1 when a cluster loop that used ``workspace`` gave up waiting (its results are garbage); reads 4 bytes back, so
+// the caller synchronises first
+extern "C" int nm_gru_seq_failed(const void* workspace) {
+    unsigned flag = 0;
+    if (!workspace || hipMemcpy(&flag, workspace, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return flag != 0 ? 1 : 0;
+}

@@ -12,6 +12,28 @@ def fused_ok(rows: int, hsz: int) -> bool:
     return hsz % 8 == 0 and rows <= 1024
 
 
+_CLUSTER_OK = {}
+
+
+def cluster_ok(session, rows: int, hsz: int, ndir: int, wgh, wch) -> bool:
+    """Does this time loop run as one cluster launch (ops.gru_seq_fwd / gru_seq_bwd)?  The shape must be one the
+    kernels take on this device, the recurrent kernels 16-byte aligned row by row (their fragments are 16-byte loads)."""
+    if not session.use_cluster_loops:
+        return False
+    for w in (wgh, wch):
+        if w.data_ptr() % 16 or any(st % 4 for st in w.stride()[:-1]) or w.stride(-1) != 1:
+            return False
+    key = (rows, hsz, ndir)
+    if key not in _CLUSTER_OK:
+        _CLUSTER_OK[key] = ops.gru_seq_supported(rows, hsz, ndir)
+    return _CLUSTER_OK[key]
+
+
+def cluster_workspace(ctx, key, rows: int, hsz: int, ndir: int):
+    """Hand-off buffers of one module's cluster loops (forward and backward run one after the other)."""
+    return ctx.buffer((key, "cluster_ws"), (ops.gru_seq_workspace_floats(rows, hsz, ndir),))
+
+
 def transposed_weights(ctx, key, wgh, wch):
     """[ndir,H,2H] / [ndir,H,H] recurrent kernels -> persistent transposed copies [ndir,2H,H] / [ndir,H,H]
     ([N,K]: both MFMA fragments of a wave of the skinny kernel are then single 16-byte loads and the kernel

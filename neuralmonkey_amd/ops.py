@@ -819,10 +819,30 @@ def gru_gemm(mode, a, b, trans_b, t, ndir, rows, hsz, lengths=None, reverse_dir0
                                b.data_ptr(), b2.stride(0), s_b), "nm_gru_gemm")
 
 
+def gru_seq_supported(rows, hsz, ndir) -> bool:
+    """Can the time loops of this shape run as one cluster launch each (nm_gru_seq_fwd / nm_gru_seq_bwd)?"""
+    return bool(_lib.load().nm_gru_seq_supported(rows, hsz, ndir))
+
+
+def gru_seq_workspace_floats(rows, hsz, ndir) -> int:
+    return _lib.load().nm_gru_seq_workspace_bytes(rows, hsz, ndir) // 4
+
+
+def gru_seq_workspace(rows, hsz, ndir, device) -> torch.Tensor:
+    """Header + granule buffers of one cluster loop (the call zeroes what it needs)."""
+    return torch.empty(gru_seq_workspace_floats(rows, hsz, ndir), dtype=torch.float32, device=device)
+
+
+def gru_seq_failed(workspace) -> bool:
+    """After a synchronisation: did a cluster loop that used ``workspace`` give up waiting for a hand-off?"""
+    return _lib.load().nm_gru_seq_failed(workspace.data_ptr()) != 0
+
+
 def gru_seq_fwd(steps, ndir, rows, hsz, xp, x_strides, h_in0, h_out0, h_step, ru0, ru_step, rh0, rh_step, c0,
                 c_step, wgh, wch, workspace, lengths=None, reverse_dir0=False, out=None, out_strides=(0, 0, 0)):
-    """All ``steps`` forward GRU steps in one persistent launch (nm_gru_seq_fwd).  Tensors of step t:
-    h_in0 + t*h_step etc. (element strides); wgh [ndir,H,2H], wch [ndir,H,H] (2-D accepted for ndir 1)."""
+    """All ``steps`` forward GRU steps in one launch (nm_gru_seq_fwd: workgroup clusters, csrc/nm_gru_cluster.hip).
+    Tensors of step t: h_out0 + t*h_step etc. (element strides); ``rh0`` may be None; wgh [ndir,H,2H], wch [ndir,H,H]
+    (2-D accepted for ndir 1); ``workspace`` from ``gru_seq_workspace``."""
     lib = _lib.load()
     e = _lib.GruEpilogue()
     e.mode, e.t, e.rev_mask, e.ndir, e.R, e.H = 1, 0, _rev_mask(ndir, reverse_dir0), ndir, rows, hsz
@@ -830,7 +850,7 @@ def gru_seq_fwd(steps, ndir, rows, hsz, xp, x_strides, h_in0, h_out0, h_step, ru
     e.xp = xp.data_ptr()
     e.x_dir, e.x_row, e.x_time = x_strides
     e.h_in, e.h_out, e.ru, e.rh, e.c_save, e.out = (h_in0.data_ptr(), h_out0.data_ptr(), ru0.data_ptr(),
-                                                   rh0.data_ptr(), _p(c0), _p(out))
+                                                   _p(rh0), _p(c0), _p(out))
     e.o_dir, e.o_row, e.o_time = out_strides
     g2 = wgh[0] if wgh.dim() == 3 else wgh
     c2 = wch[0] if wch.dim() == 3 else wch
@@ -840,6 +860,31 @@ def gru_seq_fwd(steps, ndir, rows, hsz, xp, x_strides, h_in0, h_out0, h_step, ru
                                   wch.data_ptr(), c2.stride(0), wch.stride(0) if wch.dim() == 3 else 0,
                                   workspace.data_ptr(), workspace.numel() * workspace.element_size()),
                "nm_gru_seq_fwd")
+
+
+def gru_seq_bwd(steps, ndir, rows, hsz, dh, dout, dout_strides, ru0, ru_step, c0, c_step, h0, hseq, hseq_strides,
+                dxp, dxp_strides, wgh, wch, workspace, lengths=None, reverse_dir0=False):
+    """The whole BPTT loop in one launch (nm_gru_seq_bwd): ``dh`` [ndir,R,H] holds dL/dh after the last step on entry
+    and dL/dh_0 on exit; ``ru0`` / ``c0`` are the gates / candidates of step 0 (step t at + t*step elements);
+    pre-activation gradients land in ``dxp``; wgh [ndir,H,2H], wch [ndir,H,H] (2-D accepted for ndir 1)."""
+    lib = _lib.load()
+    e = _lib.GruEpilogue()
+    e.mode, e.t, e.rev_mask, e.ndir, e.R, e.H = 4, 0, _rev_mask(ndir, reverse_dir0), ndir, rows, hsz
+    e.lengths = _p(lengths)
+    e.dh, e.dout = dh.data_ptr(), _p(dout)
+    e.do_dir, e.do_row, e.do_time = dout_strides or (0, 0, 0)
+    e.ru, e.c, e.h0, e.hseq = ru0.data_ptr(), c0.data_ptr(), _p(h0), hseq.data_ptr()
+    e.hs_dir, e.hs_row, e.hs_time = hseq_strides
+    e.dxp = dxp.data_ptr()
+    e.dx_dir, e.dx_row, e.dx_time = dxp_strides
+    g2 = wgh[0] if wgh.dim() == 3 else wgh
+    c2 = wch[0] if wch.dim() == 3 else wch
+    assert g2.stride(1) == 1 and c2.stride(1) == 1
+    _lib.check(lib.nm_gru_seq_bwd(_stream(), ctypes.byref(e), steps, ru_step, c_step,
+                                  wgh.data_ptr(), g2.stride(0), wgh.stride(0) if wgh.dim() == 3 else 0,
+                                  wch.data_ptr(), c2.stride(0), wch.stride(0) if wch.dim() == 3 else 0,
+                                  workspace.data_ptr(), workspace.numel() * workspace.element_size()),
+               "nm_gru_seq_bwd")
 
 
 class OptimizerTables:

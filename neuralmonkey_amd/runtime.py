@@ -299,11 +299,11 @@ class Session:
         self.use_side_stream = os.environ.get("NM_SIDE_STREAM", "1") != "0"
         # whole training steps of taped (general-path) models as one HIP graph per batch shape
         self.use_step_graphs = os.environ.get("NM_STEP_GRAPHS", "1") != "0"
-        # Persistent GRU time loops (nm_gru_seq_fwd: one launch, two grid barriers per step).  Measured
-        # on MI355X at the benchmark shape: 17.4 ms/step against 15.0 ms/step for the HIP-graph replay of
-        # two launches per step -- an agent-scope release/acquire pair (L2 write-back + invalidate on
-        # every XCD) costs more than a launch boundary inside a graph.  Off by default.
-        self.use_persistent = os.environ.get("NM_PERSISTENT", "0") != "0"
+        # GRU time loops as ONE launch each (nm_gru_seq_fwd / nm_gru_seq_bwd: workgroup clusters that keep the recurrent
+        # kernels in registers and hand stage outputs over as tagged granules, csrc/nm_gru_cluster.hip) wherever the
+        # shape allows (ops.gru_seq_supported); NM_CLUSTER_LOOPS=0: two graph-replayed launches per step everywhere.
+        # Per step at 128 rows x 512 units (tools/gru_loop_bench.py): forward 11.1 -> 5.0 us, BPTT 12.1 -> 5.2 us.
+        self.use_cluster_loops = os.environ.get("NM_CLUSTER_LOOPS", "1") != "0"
         self.background_leaves = os.environ.get("NM_LEAF_BACKGROUND", "1") != "0"
         # Measured and left off: greedy batches are unchanged (5.72 vs 5.74 ms), beam batches go from 17.8 to 23 ms --
         # the beam step's kernels need up to 128 KB of LDS, a CU that holds a capped (82 KB) workgroup cannot take

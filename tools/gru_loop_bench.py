@@ -65,6 +65,27 @@ def main():
             dh.zero_()
             gru.bptt(s, dh, d_out, seq, ru_all, c_all, None, out, seq, dxp, (3 * h, xrs, xts), wgh, wch, lengths, ndir,
                      rows, h, False, dgpre, dcpre, drh)
+        ws = ops.gru_seq_workspace(rows, h, ndir, dev) if ops.gru_seq_supported(rows, h, ndir) else None
+
+        def fwd_cluster():
+            hcur.zero_()
+            ops.gru_seq_fwd(s, ndir, rows, h, xp, (3 * h, xrs, xts), hcur, hcur, 0, ru_all[0], ndir * rows * 2 * h,
+                            None, 0, c_all[0], ndir * rows * h, wgh, wch, ws, lengths=lengths, out=out,
+                            out_strides=(h, ors, ots))
+        if ws is not None:
+            t_c = bench(fwd_cluster)
+            torch.cuda.synchronize()
+            print("rows {} ndir {} masked {}: forward as ONE cluster launch {:.2f} us/step ({:.1f} us per loop){}".format(
+                rows, ndir, masked, t_c / s, t_c, "  GAVE UP WAITING" if ops.gru_seq_failed(ws) else ""))
+        def bwd_cluster():
+            dh.zero_()
+            ops.gru_seq_bwd(s, ndir, rows, h, dh, d_out, seq, ru_all[0], ndir * rows * 2 * h, c_all[0], ndir * rows * h,
+                            None, out, seq, dxp, (3 * h, xrs, xts), wgh, wch, ws, lengths=lengths)
+        if ws is not None:
+            t_cb = bench(bwd_cluster)
+            torch.cuda.synchronize()
+            print("rows {} ndir {} masked {}: BPTT as ONE cluster launch {:.2f} us/step ({:.1f} us per loop){}".format(
+                rows, ndir, masked, t_cb / s, t_cb, "  GAVE UP WAITING" if ops.gru_seq_failed(ws) else ""))
         t_f = bench(lambda: fwd(False))
         t_ft = bench(lambda: fwd(True))
         t_b = bench(bwd)
