@@ -121,7 +121,8 @@ int nm_gru_gemm(void* stream, const nm_gru_epilogue* epi, int transB, int64_t K,
  *                    nm_gru_gemm;
  *   workspace_bytes  device memory a call needs (header + granules; zeroed by the call, 16-byte aligned);
  *   failed           after a synchronisation: 1 when a loop that used `workspace` gave up waiting for a hand-off
- *                    (0.2 s without progress; its results are garbage), 0 otherwise;
+ *                    (0.2 s without progress; its results are garbage), 0 otherwise; a launch that gave up also
+ *                    sets the caller's device word `sticky_error` (null: none) to 1 and never clears it;
  *   fwd              step t writes h_out + t*h_step, ru + t*ru_step, rh + t*rh_step (rh may be null), c_save +
  *                    t*c_step and `out` at the step's position; h_in is read once;
  *   bwd              dh holds dL/dh after the last step on entry and dL/dh_0 on exit; step t (last first) reads ru +
@@ -133,10 +134,10 @@ int nm_gru_seq_failed(const void* workspace);
 int nm_gru_seq_fwd(void* stream, const nm_gru_epilogue* e, int32_t steps, int64_t h_step, int64_t ru_step,
                    int64_t rh_step, int64_t c_step, const float* wgh, int64_t ld_g, int64_t stride_g,
                    const float* wch, int64_t ld_c, int64_t stride_c, void* workspace,
-                   int64_t workspace_bytes);
+                   int64_t workspace_bytes, uint32_t* sticky_error);
 int nm_gru_seq_bwd(void* stream, const nm_gru_epilogue* e, int32_t steps, int64_t ru_step, int64_t c_step,
                    const float* wgh, int64_t ld_g, int64_t stride_g, const float* wch, int64_t ld_c,
-                   int64_t stride_c, void* workspace, int64_t workspace_bytes);
+                   int64_t stride_c, void* workspace, int64_t workspace_bytes, uint32_t* sticky_error);
 int nm_gru_seq_shift(void* stream, const float* seq, float* out, const int32_t* lengths, int rev_mask,
                      int64_t B, int64_t S, int ndir, int64_t H);
 int nm_gru_rh_seq(void* stream, const float* ru_all, const float* hprev, float* out,

@@ -40,8 +40,8 @@ SIGNATURES = {
     "nm_attn_fwd_multi": (I, [P, P, P, P, P, P, P, L, L, L, L, L, L, L, P, L, P, P, L, P]),
     "nm_gru_rh_seq": (I, [P, P, P, P, P, I, L, L, I, L]),
     "nm_gru_gemm": (I, [P, P, I, L, P, L, L, P, L, L]),
-    "nm_gru_seq_fwd": (I, [P, P, ctypes.c_int32, L, L, L, L, P, L, L, P, L, L, P, L]),
-    "nm_gru_seq_bwd": (I, [P, P, ctypes.c_int32, L, L, P, L, L, P, L, L, P, L]),
+    "nm_gru_seq_fwd": (I, [P, P, ctypes.c_int32, L, L, L, L, P, L, L, P, L, L, P, L, P]),
+    "nm_gru_seq_bwd": (I, [P, P, ctypes.c_int32, L, L, P, L, L, P, L, L, P, L, P]),
     "nm_gru_seq_supported": (I, [L, L, ctypes.c_int32]),
     "nm_gru_seq_workspace_bytes": (L, [L, L, ctypes.c_int32]),
     "nm_gru_seq_failed": (I, [P]),

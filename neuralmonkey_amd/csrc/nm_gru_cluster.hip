@@ -64,6 +64,7 @@ struct GruClu {
     unsigned* hdr;
     u64* xa;                     // granules of the first stage's output  [cluster][16 RT][H]
     u64* xb;                     // granules of the second stage's output [cluster][16 RT][H] (backward: [2][..][2H])
+    unsigned* sticky;            // the caller's error word: set (never cleared) when this launch gave up; may be null
     long* dbg;                   // timing probe (NM_CLU_DEBUG builds only)
 };
 
@@ -391,6 +392,7 @@ __global__ __launch_bounds__(512, 3) void gru_cluster_fwd_kernel(GruClu q) {
         }
         CLU_STAMP(7);
     }
+    if (tid == 0 && q.sticky && __hip_atomic_load(err, NM_RLX_AGENT) != 0) __hip_atomic_store((gu32*)q.sticky, 1u, NM_RLX_AGENT);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -532,6 +534,7 @@ __global__ __launch_bounds__(512, 3) void gru_cluster_bwd_kernel(GruClu q) {
         if (epi) sB = clu_get(redB, RT, NW, ert, reg, ln);
     }
     if (mine) q.e.dh[ro * H + col] = sB + dh;
+    if (tid == 0 && q.sticky && __hip_atomic_load(err, NM_RLX_AGENT) != 0) __hip_atomic_store((gu32*)q.sticky, 1u, NM_RLX_AGENT);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -608,7 +611,7 @@ static void clu_fill(GruClu& q, const nm_gru_epilogue* e) {
 extern "C" int nm_gru_seq_fwd(void* stream, const nm_gru_epilogue* e, int32_t steps, int64_t h_step,
                               int64_t ru_step, int64_t rh_step, int64_t c_step, const float* wgh, int64_t ld_g,
                               int64_t stride_g, const float* wch, int64_t ld_c, int64_t stride_c,
-                              void* workspace, int64_t workspace_bytes) {
+                              void* workspace, int64_t workspace_bytes, uint32_t* sticky_error) {
     NM_REQUIRE(e && wgh && wch && workspace, "nm_gru_seq_fwd: null pointer / workspace");
     NM_REQUIRE(steps >= 0 && e->R > 0 && e->H > 0 && e->ndir >= 1 && e->ndir <= 2,
                "nm_gru_seq_fwd: bad shape R=%ld H=%ld", (long)e->R, (long)e->H);
@@ -625,6 +628,7 @@ extern "C" int nm_gru_seq_fwd(void* stream, const nm_gru_epilogue* e, int32_t st
     q.h_step = h_step; q.ru_step = ru_step; q.rh_step = rh_step; q.c_step = c_step;
     q.wg = wgh; q.ldg = ld_g; q.sg = stride_g; q.wc = wch; q.ldc = ld_c; q.sc = stride_c;
     q.hdr = reinterpret_cast<unsigned*>(workspace);
+    q.sticky = sticky_error;
     q.xa = reinterpret_cast<u64*>(reinterpret_cast<char*>(workspace) + CLU_HDR_BYTES);
     q.xb = q.xa + s.granules;
     hipStream_t st = nm_stream(stream);
@@ -648,7 +652,7 @@ extern "C" int nm_gru_seq_fwd(void* stream, const nm_gru_epilogue* e, int32_t st
 // of the step's position into dxp.
 extern "C" int nm_gru_seq_bwd(void* stream, const nm_gru_epilogue* e, int32_t steps, int64_t ru_step, int64_t c_step,
                               const float* wgh, int64_t ld_g, int64_t stride_g, const float* wch, int64_t ld_c,
-                              int64_t stride_c, void* workspace, int64_t workspace_bytes) {
+                              int64_t stride_c, void* workspace, int64_t workspace_bytes, uint32_t* sticky_error) {
     NM_REQUIRE(e && wgh && wch && workspace, "nm_gru_seq_bwd: null pointer / workspace");
     NM_REQUIRE(steps >= 0 && e->R > 0 && e->H > 0 && e->ndir >= 1 && e->ndir <= 2,
                "nm_gru_seq_bwd: bad shape R=%ld H=%ld", (long)e->R, (long)e->H);
@@ -667,6 +671,7 @@ extern "C" int nm_gru_seq_bwd(void* stream, const nm_gru_epilogue* e, int32_t st
     q.h_step = 0; q.ru_step = ru_step; q.rh_step = 0; q.c_step = c_step;
     q.wg = wgh; q.ldg = ld_g; q.sg = stride_g; q.wc = wch; q.ldc = ld_c; q.sc = stride_c;
     q.hdr = reinterpret_cast<unsigned*>(workspace);
+    q.sticky = sticky_error;
     q.xa = reinterpret_cast<u64*>(reinterpret_cast<char*>(workspace) + CLU_HDR_BYTES);
     q.xb = q.xa + s.granules;
     hipStream_t st = nm_stream(stream);

@@ -325,7 +325,7 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
             # the whole recurrence as ONE launch (csrc/nm_gru_cluster.hip)
             ops.gru_seq_fwd(steps, 1, bsz, h, xp, (0, 3 * h, bsz * 3 * h), s_ext[0], s_ext[1], bsz * h,
                             ru_all[0], bsz * 2 * h, rh_all[0], bsz * h, c_all[0], bsz * h, cell["wg_h"],
-                            cell["wc_h"], gru.cluster_workspace(ctx, id(self), bsz, h, 1))
+                            cell["wc_h"], gru.cluster_workspace(ctx, id(self), bsz, h, 1), sticky=ctx.session.error_word())
         else:
             ctx.session.graphed((id(self), "train_loop", bsz, steps), time_loop)
         if overlap:
@@ -473,7 +473,7 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
             dh.zero_()
             ops.gru_seq_bwd(steps, 1, bsz, h, dh, d_s, seq_strides, sv["ru_all"][0], bsz * 2 * h, sv["c_all"][0],
                             bsz * h, sv["s0"], s_all, seq_strides, dxp, dxp_strides, cell["wg_h"], cell["wc_h"],
-                            gru.cluster_workspace(ctx, id(self), bsz, h, 1))
+                            gru.cluster_workspace(ctx, id(self), bsz, h, 1), sticky=ctx.session.error_word())
         else:
             ctx.session.graphed((id(self), "bptt_loop", bsz, steps), bptt_loop)
         ds0 = dh[0]

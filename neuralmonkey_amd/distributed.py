@@ -279,10 +279,22 @@ class DataParallel:
             second.synchronize()
             waits.append(first.elapsed_time(second))
         self._timed = []
-        return {"allreduce_exposed_ms": (sum(waits) / len(waits)) if waits else None, "steps": len(waits),
+        return {"ranks_seen": self.ranks_seen(),
+                "allreduce_exposed_ms": (sum(waits) / len(waits)) if waits else None, "steps": len(waits),
                 "bytes": self.bytes_per_step, "early_bytes": self.early_bytes_per_step,
                 "sparse_rows_bytes": getattr(self, "sparse_bytes_last", 0),
                 "buckets_mb": self.bucket_elems * 4 / 2 ** 20}
+
+    def ranks_seen(self) -> int:
+        """How many distinct ranks answer an all-gather over the process group (RCCL on GPUs): the proof, inside a
+        bench line, that N processes really exchanged data (tools/scale.sh asserts it equals --gpus)."""
+        if getattr(self, "_ranks_seen", None) is None:
+            dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+            mine = torch.tensor([self.rank], dtype=torch.int64, device=dev)
+            everyone = [torch.zeros_like(mine) for _ in range(self.world_size)]
+            dist.all_gather(everyone, mine)
+            self._ranks_seen = len({int(t.item()) for t in everyone})
+        return self._ranks_seen
 
     def broadcast_parameters(self, store, src: int = 0) -> None:
         """Make every replica start from rank ``src``'s variables."""

@@ -219,6 +219,7 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
             ops.gru_seq_fwd(slen, ndir, bsz, h, xp, (3 * h, xrs, xts), hcur, hcur, 0, ru_all[0],
                             ndir * bsz * 2 * h if train else 0, None, 0, c_all[0] if train else None,
                             ndir * bsz * h, wgh, wch, gru.cluster_workspace(ctx, key, bsz, h, ndir), lengths=len_arg,
+                            sticky=ctx.session.error_word(),
                             reverse_dir0=reverse_only, out=states_raw, out_strides=(h, ors, ots))
         else:
             ctx.session.start_deferred_side()
@@ -290,7 +291,7 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
             ops.gru_seq_bwd(slen, ndir, bsz, h, dh, d_states_raw, seq_strides if d_states_raw is not None else None,
                             sv["ru_all"][0], ndir * bsz * 2 * h, sv["c_all"][0], ndir * bsz * h, None, states_raw,
                             seq_strides, dxp, dxp_strides, wgh, wch, gru.cluster_workspace(ctx, id(self), bsz, h, ndir),
-                            lengths=lengths, reverse_dir0=rev0)
+                            lengths=lengths, reverse_dir0=rev0, sticky=ctx.session.error_word())
             return dxp
 
         def bptt_loop():

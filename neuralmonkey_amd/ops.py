@@ -839,10 +839,12 @@ def gru_seq_failed(workspace) -> bool:
 
 
 def gru_seq_fwd(steps, ndir, rows, hsz, xp, x_strides, h_in0, h_out0, h_step, ru0, ru_step, rh0, rh_step, c0,
-                c_step, wgh, wch, workspace, lengths=None, reverse_dir0=False, out=None, out_strides=(0, 0, 0)):
+                c_step, wgh, wch, workspace, lengths=None, reverse_dir0=False, out=None, out_strides=(0, 0, 0),
+                sticky=None):
     """All ``steps`` forward GRU steps in one launch (nm_gru_seq_fwd: workgroup clusters, csrc/nm_gru_cluster.hip).
     Tensors of step t: h_out0 + t*h_step etc. (element strides); ``rh0`` may be None; wgh [ndir,H,2H], wch [ndir,H,H]
-    (2-D accepted for ndir 1); ``workspace`` from ``gru_seq_workspace``."""
+    (2-D accepted for ndir 1); ``workspace`` from ``gru_seq_workspace``; ``sticky``: an int32 device word that a launch
+    which gave up waiting sets to 1 (runtime.Session.error_word)."""
     lib = _lib.load()
     e = _lib.GruEpilogue()
     e.mode, e.t, e.rev_mask, e.ndir, e.R, e.H = 1, 0, _rev_mask(ndir, reverse_dir0), ndir, rows, hsz
@@ -858,12 +860,12 @@ def gru_seq_fwd(steps, ndir, rows, hsz, xp, x_strides, h_in0, h_out0, h_step, ru
     _lib.check(lib.nm_gru_seq_fwd(_stream(), ctypes.byref(e), steps, h_step, ru_step, rh_step, c_step,
                                   wgh.data_ptr(), g2.stride(0), wgh.stride(0) if wgh.dim() == 3 else 0,
                                   wch.data_ptr(), c2.stride(0), wch.stride(0) if wch.dim() == 3 else 0,
-                                  workspace.data_ptr(), workspace.numel() * workspace.element_size()),
+                                  workspace.data_ptr(), workspace.numel() * workspace.element_size(), _p(sticky)),
                "nm_gru_seq_fwd")
 
 
 def gru_seq_bwd(steps, ndir, rows, hsz, dh, dout, dout_strides, ru0, ru_step, c0, c_step, h0, hseq, hseq_strides,
-                dxp, dxp_strides, wgh, wch, workspace, lengths=None, reverse_dir0=False):
+                dxp, dxp_strides, wgh, wch, workspace, lengths=None, reverse_dir0=False, sticky=None):
     """The whole BPTT loop in one launch (nm_gru_seq_bwd): ``dh`` [ndir,R,H] holds dL/dh after the last step on entry
     and dL/dh_0 on exit; ``ru0`` / ``c0`` are the gates / candidates of step 0 (step t at + t*step elements);
     pre-activation gradients land in ``dxp``; wgh [ndir,H,2H], wch [ndir,H,H] (2-D accepted for ndir 1)."""
@@ -883,7 +885,7 @@ def gru_seq_bwd(steps, ndir, rows, hsz, dh, dout, dout_strides, ru0, ru_step, c0
     _lib.check(lib.nm_gru_seq_bwd(_stream(), ctypes.byref(e), steps, ru_step, c_step,
                                   wgh.data_ptr(), g2.stride(0), wgh.stride(0) if wgh.dim() == 3 else 0,
                                   wch.data_ptr(), c2.stride(0), wch.stride(0) if wch.dim() == 3 else 0,
-                                  workspace.data_ptr(), workspace.numel() * workspace.element_size()),
+                                  workspace.data_ptr(), workspace.numel() * workspace.element_size(), _p(sticky)),
                "nm_gru_seq_bwd")
 
 

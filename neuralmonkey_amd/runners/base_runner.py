@@ -65,7 +65,13 @@ class LazyLosses(dict):
     def _fill(self) -> None:
         pending, self._pending = self._pending, None
         if pending is not None:
-            dict.update(self, zip(self._names, [float(x) for x in pending.get()]))
+            values = [float(x) for x in pending.get()]
+            dict.update(self, zip(self._names, values))
+            # one value more than there are names: the session's device error word of that step (Session.error_word)
+            if len(values) > len(self._names) and values[len(self._names)] != 0.0:
+                raise RuntimeError("the training step that produced these losses ran a GRU time loop that gave up "
+                                   "waiting for a hand-off between workgroups: its results are garbage "
+                                   "(NM_CLUSTER_LOOPS=0 runs the loops as two launches per step)")
 
     __getitem__ = _after_fill("__getitem__")
     __iter__ = _after_fill("__iter__")

@@ -304,6 +304,8 @@ class Session:
         # shape allows (ops.gru_seq_supported); NM_CLUSTER_LOOPS=0: two graph-replayed launches per step everywhere.
         # Per step at 128 rows x 512 units (tools/gru_loop_bench.py): forward 11.1 -> 5.0 us, BPTT 12.1 -> 5.2 us.
         self.use_cluster_loops = os.environ.get("NM_CLUSTER_LOOPS", "1") != "0"
+        self._error_word = None
+        self._error_pending = None
         self.background_leaves = os.environ.get("NM_LEAF_BACKGROUND", "1") != "0"
         # Measured and left off: greedy batches are unchanged (5.72 vs 5.74 ms), beam batches go from 17.8 to 23 ms --
         # the beam step's kernels need up to 128 KB of LDS, a CU that holds a capped (82 KB) workgroup cannot take
@@ -437,6 +439,31 @@ class Session:
             if done.size:
                 return int(done[0]) + 1, steps
         return steps, steps
+
+    # -- errors that only the device can see ------------------------------------------------------------------
+    def error_word(self) -> torch.Tensor:
+        """One int32 on the device that kernels set (and never clear) when they gave up: today the cluster time loops
+        whose hand-offs timed out (ops.gru_seq_fwd / gru_seq_bwd, ``sticky``).  Their results are garbage, so whoever
+        hands results to the caller looks at the word first: the trainer reads it with the step's losses
+        (GenericTrainer.objective_values), inference polls it one batch late (``poll_device_errors``)."""
+        if self._error_word is None:
+            self._error_word = torch.zeros(1, dtype=torch.int32, device=self.device)
+        return self._error_word
+
+    def raise_device_error(self) -> None:
+        raise RuntimeError("a GRU time loop gave up waiting for a hand-off between workgroups (0.2 s without progress): "
+                           "the results of this and later steps are garbage.  NM_CLUSTER_LOOPS=0 runs the loops as "
+                           "two launches per step")
+
+    def poll_device_errors(self) -> None:
+        """Without stalling the streams: read the copy of the error word that the PREVIOUS call started, start the
+        next one."""
+        if self._error_word is None or self.device.type != "cuda":
+            return
+        pending, self._error_pending = self._error_pending, None
+        if pending is not None and int(pending.get()[0]) != 0:
+            self.raise_device_error()
+        self._error_pending = self.to_host_async(self._error_word)
 
     def to_host_async(self, dev_tensor: torch.Tensor, off_stream: bool = False) -> HostPending:
         """Start copying a small device tensor to pinned host memory; the caller reads it with ``get()`` when (if)

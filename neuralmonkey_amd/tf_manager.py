@@ -136,6 +136,9 @@ class TensorFlowManager:
         while not all(ex.result is not None for ex in executables):
             self._run_executables(default_feed_dict, executables, ahead)
             ahead = None
+        if not train:                # (a training step's error word travels with its losses)
+            for sess in self.sessions:
+                sess.poll_device_errors()
         return [ex.result for ex in executables]
 
     # -- variables ---------------------------------------------------------------------------

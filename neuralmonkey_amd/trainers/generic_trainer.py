@@ -231,8 +231,12 @@ class GenericTrainer(GraphExecutor, Feedable):
         # The scalars travel to the host asynchronously (Session.to_host_async) and ExecutionResult.losses reads
         # them on first access: the training loop only looks at them when it logs, and a blocking read-back per
         # step keeps the host from enqueuing the next step while this one runs.  NM_DEFER_LOSSES=0: read at once.
+        # (behind them travels the session's device error word: a time loop that gave up makes the step garbage)
         if DEFER_LOSSES and all(isinstance(v, torch.Tensor) and v.is_cuda for v in values):
-            return ctx.session.to_host_async(torch.stack([v.detach().reshape(()) for v in values]))
+            return ctx.session.to_host_async(torch.stack([v.detach().reshape(()) for v in values]
+                                                         + [ctx.session.error_word()[0].float()]))
+        if ctx.session.device.type == "cuda" and int(ctx.session.error_word().item()) != 0:
+            ctx.session.raise_device_error()
         return values
 
     @property

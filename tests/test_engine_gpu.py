@@ -469,3 +469,28 @@ def test_train_logprobs_is_the_log_softmax_of_the_train_logits(dev):
     out = model.tf_manager.sessions[0].run({"logits": dec.train_logits, "logprobs": dec.train_logprobs}, fd)
     want = torch.log_softmax(torch.as_tensor(np.asarray(out["logits"])).double(), -1).numpy()
     assert np.abs(np.asarray(out["logprobs"]) - want).max() < 1e-5
+
+
+def test_a_set_device_error_word_reaches_the_caller(dev):
+    """The kernels' only way to say "my results are garbage" is the session's device error word (cluster time loops
+    whose hand-offs timed out: csrc/nm_gru_cluster.hip, ``sticky_error``).  It travels to the host with a training
+    step's losses and, for inference, with one batch of delay -- never by stalling the streams.  (The word is set by
+    hand here: the loops do not fail on a healthy device.)"""
+    from neuralmonkey_amd import synthetic
+    model = synthetic.build_translation_model(vocab_src=300, vocab_tgt=300, emb=32, rnn=32, max_len=12, beam_size=0,
+                                              device=str(dev))
+    ds = synthetic.synthetic_dataset(seed=4, batch=6, src_len=9, tgt_len=8, vocab=300, ragged=True)
+    tfm = model.tf_manager
+    sess = tfm.sessions[0]
+    res = tfm.execute(ds, model.trainer.feedables, [model.trainer], train=True)[0]
+    assert res.losses["decoder - cost"] > 0                       # a clean word: the losses read as ever
+    tfm.execute(ds, model.greedy_runner.feedables, [model.greedy_runner])
+    tfm.execute(ds, model.greedy_runner.feedables, [model.greedy_runner])
+    sess.error_word().fill_(1)
+    res = tfm.execute(ds, model.trainer.feedables, [model.trainer], train=True)[0]
+    with pytest.raises(RuntimeError, match="gave up waiting"):
+        res.losses["decoder - cost"]
+    tfm.execute(ds, model.greedy_runner.feedables, [model.greedy_runner])       # starts the copy of the set word ...
+    with pytest.raises(RuntimeError, match="gave up waiting"):
+        tfm.execute(ds, model.greedy_runner.feedables, [model.greedy_runner])   # ... which the next call reads
+
