@@ -39,6 +39,15 @@ class DataParallel:
         self.sparse_bytes_per_step = 0
         self._handles: list = []          # collectives in flight this step
         self._early: list = []            # [lo, hi) spans of the flat gradient already being reduced
+        # Early spans are ORDERED on the device where their producer stands (an event), but their collectives are
+        # ENQUEUED by the host only at the end of the backward pass (all_reduce_gradients): enqueueing an RCCL
+        # collective behind unfinished work holds the host thread until that work is done -- 1 ms of every step at
+        # the headline shape, the main stream idle meanwhile (profiles/r05_dp_early_issue.txt).  The host runs
+        # milliseconds ahead of the device, so the collectives are still in the queue long before their events
+        # fire.  NM_DP_EARLY_ISSUE=now: the round-4 behaviour.
+        self.defer_issue = os.environ.get("NM_DP_EARLY_ISSUE", "deferred") != "now"
+        self._early_pending: list = []    # (event, lo, hi) not yet enqueued
+        self._issue_stream = None
         # optional accounting of the exchange (bench.py --gpus N): event pairs on the compute stream around the
         # point where it has to wait for the collectives = the part of the all-reduce that is NOT hidden
         self.timing = False
@@ -128,7 +137,7 @@ class DataParallel:
     def begin_step(self) -> None:
         """Forget the bookkeeping of a step that did not reach ``all_reduce_gradients`` (an exception)."""
         self._wait_handles()
-        self._handles, self._early = [], []
+        self._handles, self._early, self._early_pending = [], [], []
         self.sparse_bytes_per_step = 0
 
     def _reduce_span(self, grad, lo: int, hi: int) -> None:
@@ -165,7 +174,24 @@ class DataParallel:
             if any(lo < dhi and dlo < hi for dlo, dhi in self._early):
                 raise RuntimeError("gradient span [{}, {}) was already reduced this step".format(lo, hi))
             self._early.append((lo, hi))
-            self._reduce_span(grad, lo, hi)
+            if self.defer_issue and grad.is_cuda:
+                done = torch.cuda.Event()
+                done.record()                  # on the producer's stream
+                self._early_pending.append((done, lo, hi))
+            else:
+                self._reduce_span(grad, lo, hi)
+
+    def _issue_early(self, grad) -> None:
+        """Enqueue the collectives of the early spans, each ordered after the event its producer left behind."""
+        if not self._early_pending:
+            return
+        if self._issue_stream is None:
+            self._issue_stream = torch.cuda.Stream(device=grad.device)
+        pending, self._early_pending = self._early_pending, []
+        with torch.cuda.stream(self._issue_stream):
+            for done, lo, hi in pending:
+                self._issue_stream.wait_event(done)
+                self._reduce_span(grad, lo, hi)
 
     def _host_all_gather_int(self, value: int):
         """``value`` of every rank, in rank order (host side: the gloo group next to RCCL, or the gloo world)."""
@@ -251,6 +277,7 @@ class DataParallel:
         if self.world_size == 1 and not self.forced:
             return
         grad = store.ensure_grad()
+        self._issue_early(grad)
         pos = 0
         for lo, hi in sorted(self._early):
             if lo > pos:
