@@ -467,7 +467,10 @@ __global__ __launch_bounds__(256) void attn_partial_fast(AttnArgs p) {
 // profiles/r02_attn_pair_vs_whole.txt.  Round 3, the same question split by POSITIONS: two 1024-thread workgroups
 // per sentence with half of the rows each, write-through partials, the half that arrives second merges -- 17.7 /
 // 14.9 us cold / warm against 17.2 / 13.7 for this kernel in the same run, greedy batch 5.92 vs 5.84 ms: the
-// hand-off costs more than the second set of CUs brings.)
+// hand-off costs more than the second set of CUs brings.  Round 5, no hand-off at all: two workgroups per sentence on
+// one XCD that each score the sentence by themselves and blend half of the value columns -- the split that took the
+// captioning step from 30 to 16 us (attn_whole_wide below) -- 13.7 / 11.4 us cold / warm against 13.5 / 10.9 for this
+// kernel (rocprofv3, same run): at this size the step is not bound by what one CU can stream.)
 // ---------------------------------------------------------------------------
 #define ATT_WHOLE_ROWS 13
 template <int ROWS>
@@ -525,6 +528,112 @@ __global__ __launch_bounds__(1024) void attn_whole_fast(AttnArgs p) {
             wsh[idx] = w;
             p.energies[(long)b * p.S + lane] = e;
             if (p.weights) p.weights[(long)b * p.S + lane] = w;
+        }
+    }
+    __syncthreads();
+
+    float4 acc = zero4;
+#pragma unroll
+    for (int s = 0; s < ROWS; ++s) {
+        const float w = s < ns ? wsh[grp * ROWS + s] : 0.0f;
+        acc.x += w * str[s].x; acc.y += w * str[s].y;
+        acc.z += w * str[s].z; acc.w += w * str[s].w;
+    }
+    if (grp > 0) red[grp - 1][cw * 64 + lane] = acc;
+    __syncthreads();
+    if (grp == 0 && c_ok) {
+        const float4 r0 = red[0][cw * 64 + lane], r1 = red[1][cw * 64 + lane], r2 = red[2][cw * 64 + lane];
+        acc.x += (r0.x + r1.x) + r2.x; acc.y += (r0.y + r1.y) + r2.y;
+        acc.z += (r0.z + r1.z) + r2.z; acc.w += (r0.w + r1.w) + r2.w;
+        *reinterpret_cast<float4*>(p.ctx + (long)b * p.ldctx + col) = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Wide values, narrow keys (config 4, captioning: 8x8 maps of 2048 channels under a 512-wide attention, S = 64,
+// encoders/numpy_stateful_filler.py:209-245 -> attention/feed_forward.py:125-166): TWO 1024-thread workgroups per
+// sentence, split by VALUE columns.  Each scores the sentence by itself -- the keys are a fifth of the bytes and the
+// second reader finds them in its XCD's L2 -- so nothing crosses workgroups: no split-S partial contexts, no
+// ticket, no merge (the split-S kernels wrote 6.3 MB of partials and read them back: 99.6 MB of HBM traffic for 85.3 MB
+// of operands, profiles/r04_attn_cap_pmc_cold.json), and all 256 CUs stream (one workgroup per sentence would leave
+// half of them idle, each of the others filling its L1 with 655 KB).  Per thread: 8 key slices (a key row is 128
+// 16-byte slices = 32 lanes of each of the 4 column waves: a wave loads TWO rows at a time) and 16 value slices,
+// all 96 registers of loads in flight before the first tanh; softmax and the cross-group sum as in attn_whole_fast.
+// ---------------------------------------------------------------------------
+#define ATT_WIDE_ROWS 16
+__device__ __forceinline__ void nm_half_sums_dpp(float v, float& lo, float& hi) {      // sums of lanes 0..31 / 32..63
+    v += nm_dpp<0xB1, 0xf>(0.0f, v);            // quad_perm [1,0,3,2]
+    v += nm_dpp<0x4E, 0xf>(0.0f, v);            // quad_perm [2,3,0,1]
+    v += nm_dpp<0x141, 0xf>(0.0f, v);           // row_half_mirror
+    v += nm_dpp<0x140, 0xf>(0.0f, v);           // row_mirror
+    v += nm_dpp<0x142, 0xa>(0.0f, v);           // row_bcast:15 -> rows 1, 3
+    lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+    hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+__global__ __launch_bounds__(1024) void attn_whole_wide(AttnArgs p) {
+    constexpr int ROWS = ATT_WIDE_ROWS;
+    __shared__ float pe[4][4 * ROWS];          // [column wave][row group * ROWS + row]
+    __shared__ float wsh[4 * ROWS];
+    __shared__ float4 red[3][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = wave >> 2, cw = wave & 3;
+    // the two halves of a sentence are blocks i and i + 8: the same XCD under round-robin dispatch, so the second
+    // reader of the keys finds them in that XCD's L2 (speed only: nothing is exchanged)
+    const int b = ((int)blockIdx.x >> 4) * 8 + ((int)blockIdx.x & 7), half = ((int)blockIdx.x >> 3) & 1;
+    if (b >= p.Bk) return;
+    const int rpg = (p.S + 3) >> 2;            // rows per row group (<= 16)
+    const int s0 = grp * rpg;
+    const int ns = max(0, min(rpg, p.S - s0));
+    const int hl = lane & 31, hr = lane >> 5;
+    const int acol = cw * 128 + hl * 4;        // key columns: 512 = 4 column waves x 32 lanes x 4
+    const int col = half * 1024 + cw * 256 + lane * 4;
+    const bool a_ok = acol < p.A, c_ok = col < p.C;
+    const float* hbase = p.hf + (long)b * p.S * p.A + (a_ok ? acol : 0);
+    const float* sbase = p.states + (long)b * p.S * p.C + (c_ok ? col : 0);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const float4 y4 = *reinterpret_cast<const float4*>(p.y + (long)b * p.A + (a_ok ? acol : 0));
+    float4 v4 = *reinterpret_cast<const float4*>(p.v + (a_ok ? acol : 0));
+    if (!a_ok) v4 = zero4;
+    const float bias = p.bias ? p.bias[0] : 0.0f;
+    float4 hfr[ROWS / 2], str[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS / 2; ++i)        // lanes 0..31: row 2i, lanes 32..63: row 2i + 1 (clamped rows weigh zero)
+        hfr[i] = *reinterpret_cast<const float4*>(hbase + (long)min(s0 + min(2 * i + hr, max(ns - 1, 0)), p.S - 1) * p.A);
+#pragma unroll
+    for (int s = 0; s < ROWS; ++s)
+        str[s] = *reinterpret_cast<const float4*>(sbase + (long)min(s0 + min(s, max(ns - 1, 0)), p.S - 1) * p.C);
+
+#pragma unroll
+    for (int i = 0; i < ROWS / 2; ++i) {
+        const float part = v4.x * nm_tanh(hfr[i].x + y4.x) + v4.y * nm_tanh(hfr[i].y + y4.y) +
+                           v4.z * nm_tanh(hfr[i].z + y4.z) + v4.w * nm_tanh(hfr[i].w + y4.w);
+        float lo, hi;
+        nm_half_sums_dpp(part, lo, hi);
+        if (lane == 0) {
+            pe[cw][grp * ROWS + 2 * i] = lo;
+            pe[cw][grp * ROWS + 2 * i + 1] = hi;
+        }
+    }
+    __syncthreads();
+
+    if (wave == 0) {                           // one source position per lane (S <= 64)
+        const bool ok = lane < p.S;
+        const int g = ok ? lane / rpg : 0, idx = g * ROWS + (ok ? lane - g * rpg : 0);
+        const float e = ok ? ((pe[0][idx] + pe[1][idx]) + (pe[2][idx] + pe[3][idx])) + bias : -INFINITY;
+        const float m = nm_wave_max_dpp(e);
+        const float ex = ok ? __expf(e - m) : 0.0f;
+        const float mk = (ok && p.mask) ? p.mask[(long)b * p.S + lane] : 1.0f;
+        const float em = ex * mk;
+        const float la = nm_wave_sum_dpp(ex), lm = nm_wave_sum_dpp(em);
+        const float w = em * (1.0f / (lm + 1e-8f * la));
+        if (ok) {
+            wsh[idx] = w;
+            if (half == 0) {                   // (both halves compute the same numbers; one of them stores them)
+                p.energies[(long)b * p.S + lane] = e;
+                if (p.weights) p.weights[(long)b * p.S + lane] = w;
+            }
         }
     }
     __syncthreads();
@@ -934,6 +1043,14 @@ static int attn_fwd_impl(void* stream, const float* y, const float* hf, const fl
                        (whole_sw >= 0 ? whole_sw != 0 : (Bk >= 96 && S >= 40));
     if (whole) {
         hipLaunchKernelGGL(attn_whole_fast<ATT_WHOLE_ROWS>, dim3((unsigned)Bk), dim3(1024), 0, st, p);
+        if (prof) (void)hipEventRecord(prof->second, st);
+        NM_LAUNCH_CHECK("nm_attn_fwd");
+    }
+    // wide values under narrow keys (captioning): two whole-sentence workgroups per sentence, split by value columns
+    const bool wide = do_combine && nq == 1 && A <= 512 && C > 1024 && C <= 2048 && S <= 4 * ATT_WIDE_ROWS && !no_fast &&
+                      (whole_sw >= 0 ? whole_sw != 0 : Bk >= 64);
+    if (wide) {
+        hipLaunchKernelGGL(attn_whole_wide, dim3((unsigned)(((Bk + 7) / 8) * 16)), dim3(1024), 0, st, p);
         if (prof) (void)hipEventRecord(prof->second, st);
         NM_LAUNCH_CHECK("nm_attn_fwd");
     }

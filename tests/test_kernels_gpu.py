@@ -426,6 +426,8 @@ def test_gru_gemm_fused_epilogues_fwd_bwd(dev, b, s, e, h):
     (1, 5, 50, 1024, 1024, True),        # reference-compatible batch-1 beam
     (3, 3, 7, 64, 32, True),             # single chunk, tiny dims
     (5, 1, 64, 128, 2048, False),        # captioning shape: S=64, C=2048, state_size 128
+    (128, 1, 64, 512, 2048, True),       # config 4 as benchmarked: two whole-sentence workgroups per sentence, split by value columns
+    (70, 1, 61, 300, 1540, True),        # the same kernel: partial key / value column waves, a short last row group
     (4, 1, 120, 256, 256, True),         # long sources: 10 chunks -> too many for the in-kernel merge, combine launch
     (2, 5, 200, 128, 128, True),         # 17 chunks, five queries per sentence
     (6, 1, 96, 512, 1024, True),         # 8 chunks: the most the in-kernel merge takes
