@@ -165,7 +165,7 @@ __device__ __forceinline__ void attn_merge_row(const AttnArgs& p, long qr, int b
     float la = 0.0f, lm = 0.0f, f[ATT_MERGE_MAXCH];
 #pragma unroll
     for (int i = 0; i < ATT_MERGE_MAXCH; ++i) {
-        f[i] = i < p.nchunk ? __expf(sv[i].x - M) : 0.0f;
+        f[i] = i < p.nchunk ? expf(sv[i].x - M) : 0.0f;
         la += f[i] * sv[i].y;
         lm += f[i] * sv[i].z;
     }
@@ -184,11 +184,11 @@ __device__ __forceinline__ void attn_merge_row(const AttnArgs& p, long qr, int b
         a.x *= inv; a.y *= inv; a.z *= inv; a.w *= inv;
         *reinterpret_cast<float4*>(p.ctx + qr * p.ldctx + c) = a;
     }
-    if (w_ok) p.weights[qr * p.S + tid] = __expf(e_s - M) * mk * inv;
+    if (w_ok) p.weights[qr * p.S + tid] = expf(e_s - M) * mk * inv;
     if (p.weights)
         for (int s2 = tid + 256; s2 < p.S; s2 += 256) {
             const float m2 = p.mask ? p.mask[(long)b * p.S + s2] : 1.0f;
-            p.weights[qr * p.S + s2] = __expf(ld_wt1(p.energies + qr * p.S + s2) - M) * m2 * inv;
+            p.weights[qr * p.S + s2] = expf(ld_wt1(p.energies + qr * p.S + s2) - M) * m2 * inv;
         }
 }
 
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void attn_partial(AttnArgs p) {
         for (int s = 0; s < ns; ++s) m = fmaxf(m, es[q * ATT_MAX_SCH + s]);
         float la = 0.0f, lm = 0.0f;
         for (int s = 0; s < ns; ++s) {
-            const float e = __expf(es[q * ATT_MAX_SCH + s] - m);
+            const float e = expf(es[q * ATT_MAX_SCH + s] - m);
             la += e;
             const float em = e * ms[s];
             lm += em;
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void attn_partial_fast(AttnArgs p) {
 #pragma unroll
     for (int s = 0; s < ROWS; ++s) {
         const bool ok = s < ns;
-        const float ex = ok ? __expf(e[s] - m) : 0.0f;
+        const float ex = ok ? expf(e[s] - m) : 0.0f;
         const float mk = (ok && p.mask) ? p.mask[(long)b * p.S + s0 + s] : 1.0f;
         const float em = ex * mk;
         la += ex;
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(1024) void attn_whole_fast(AttnArgs p) {
         const int g = ok ? lane / rpg : 0, idx = g * ROWS + (ok ? lane - g * rpg : 0);
         const float e = ok ? ((pe[0][idx] + pe[1][idx]) + (pe[2][idx] + pe[3][idx])) + bias : -INFINITY;
         const float m = nm_wave_max_dpp(e);
-        const float ex = ok ? __expf(e - m) : 0.0f;
+        const float ex = ok ? expf(e - m) : 0.0f;
         const float mk = (ok && p.mask) ? p.mask[(long)b * p.S + lane] : 1.0f;
         const float em = ex * mk;
         const float la = nm_wave_sum_dpp(ex), lm = nm_wave_sum_dpp(em);
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(1024) void attn_whole_wide(AttnArgs p) {
         const int g = ok ? lane / rpg : 0, idx = g * ROWS + (ok ? lane - g * rpg : 0);
         const float e = ok ? ((pe[0][idx] + pe[1][idx]) + (pe[2][idx] + pe[3][idx])) + bias : -INFINITY;
         const float m = nm_wave_max_dpp(e);
-        const float ex = ok ? __expf(e - m) : 0.0f;
+        const float ex = ok ? expf(e - m) : 0.0f;
         const float mk = (ok && p.mask) ? p.mask[(long)b * p.S + lane] : 1.0f;
         const float em = ex * mk;
         const float la = nm_wave_sum_dpp(ex), lm = nm_wave_sum_dpp(em);
@@ -746,7 +746,7 @@ __global__ __launch_bounds__(256) void attn_partial_fastq(AttnArgs p) {
 #pragma unroll
         for (int s = 0; s < ROWS; ++s) {
             const bool ok = s < ns;
-            const float ex = ok ? __expf(e[s] - m) : 0.0f;
+            const float ex = ok ? expf(e[s] - m) : 0.0f;
             const float mk = (ok && p.mask) ? p.mask[(long)b * p.S + s0 + s] : 1.0f;
             const float em = ex * mk;
             la += ex;
@@ -828,7 +828,7 @@ __global__ __launch_bounds__(256) void attn_combine(const float* __restrict__ pc
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < ATT_COMBINE_MAXCH; ++i) {
-            const float f = i < nchunk ? __expf(sv[i].x - M) : 0.0f;
+            const float f = i < nchunk ? expf(sv[i].x - M) : 0.0f;
             la += f * sv[i].y;
             lm += f * sv[i].z;
             a.x += f * x[i].x; a.y += f * x[i].y; a.z += f * x[i].z; a.w += f * x[i].w;
@@ -838,11 +838,11 @@ __global__ __launch_bounds__(256) void attn_combine(const float* __restrict__ pc
             a.x *= inv; a.y *= inv; a.z *= inv; a.w *= inv;
             *reinterpret_cast<float4*>(ctx + (long)r * ldctx + c) = a;
         }
-        if (w_ok) weights[(long)r * S + tid] = __expf(e_s - M) * mk * inv;
+        if (w_ok) weights[(long)r * S + tid] = expf(e_s - M) * mk * inv;
         if (weights)
             for (int s = tid + 256; s < S; s += 256) {
                 const float m2 = mask ? mask[(long)b * S + s] : 1.0f;
-                weights[(long)r * S + s] = __expf(energies[(long)r * S + s] - M) * m2 * inv;
+                weights[(long)r * S + s] = expf(energies[(long)r * S + s] - M) * m2 * inv;
             }
         return;
     }
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(256) void attn_combine(const float* __restrict__ pc
         float la = 0.0f, lm = 0.0f;
         for (int i = 0; i < nchunk; ++i) {
             const float* s4 = pstat + ((long)r * nchunk + i) * 4;
-            const float f = __expf(s4[0] - M);
+            const float f = expf(s4[0] - M);
             sc[i] = f;
             la += f * s4[1];
             lm += f * s4[2];
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(256) void attn_combine(const float* __restrict__ pc
         const int b = (r / mask_div) % mask_mod;      // key batch of row r in either query layout
         for (int s = tid; s < S; s += 256) {
             const float mk = mask ? mask[(long)b * S + s] : 1.0f;
-            weights[(long)r * S + s] = __expf(energies[(long)r * S + s] - smax) * mk * inv;
+            weights[(long)r * S + s] = expf(energies[(long)r * S + s] - smax) * mk * inv;
         }
     }
 }
@@ -939,7 +939,7 @@ __global__ __launch_bounds__(256) void attn_generic(AttnArgs p, float* __restric
     __syncthreads();
     float se = 0.0f, sm = 0.0f;
     for (int s = tid; s < p.S; s += 256) {
-        const float e = __expf(es[s] - mx);
+        const float e = expf(es[s] - mx);
         se += e;
         sm += e * (p.mask ? p.mask[(long)b * p.S + s] : 1.0f);
     }
@@ -953,7 +953,7 @@ __global__ __launch_bounds__(256) void attn_generic(AttnArgs p, float* __restric
     const float inv_n = 1.0f / (sm * inv_se + 1e-8f);
     __syncthreads();
     for (int s = tid; s < p.S; s += 256) {
-        const float w = __expf(es[s] - mx) * inv_se * (p.mask ? p.mask[(long)b * p.S + s] : 1.0f) * inv_n;
+        const float w = expf(es[s] - mx) * inv_se * (p.mask ? p.mask[(long)b * p.S + s] : 1.0f) * inv_n;
         es[s] = w;
         if (weights) weights[row * p.S + s] = w;
     }

@@ -409,7 +409,7 @@ __global__ void attn_softmax_bwd_kernel(const float* __restrict__ dw, const floa
     mx = nm_wave_max(mx);
     float se = 0.0f, sm = 0.0f;
     for (int s = lane; s < S; s += 64) {
-        const float x = __expf(er[s] - mx);
+        const float x = expf(er[s] - mx);
         se += x;
         sm += x * (mr ? mr[s] : 1.0f);
     }
@@ -420,20 +420,20 @@ __global__ void attn_softmax_bwd_kernel(const float* __restrict__ dw, const floa
     const float invN = 1.0f / N;
     float sdw = 0.0f;
     for (int s = lane; s < S; s += 64) {
-        const float p = __expf(er[s] - mx) * inv_se;
+        const float p = expf(er[s] - mx) * inv_se;
         const float w = p * (mr ? mr[s] : 1.0f) * invN;
         sdw += dwr[s] * w;
     }
     sdw = nm_wave_sum(sdw);
     float sdp = 0.0f;
     for (int s = lane; s < S; s += 64) {
-        const float p = __expf(er[s] - mx) * inv_se;
+        const float p = expf(er[s] - mx) * inv_se;
         const float dp = (mr ? mr[s] : 1.0f) * invN * (dwr[s] - sdw);
         sdp += dp * p;
     }
     sdp = nm_wave_sum(sdp);
     for (int s = lane; s < S; s += 64) {
-        const float p = __expf(er[s] - mx) * inv_se;
+        const float p = expf(er[s] - mx) * inv_se;
         const float dp = (mr ? mr[s] : 1.0f) * invN * (dwr[s] - sdw);
         de[row * S + s] = p * (dp - sdp);
     }
@@ -465,7 +465,7 @@ __global__ void attn_softmax_fwd_kernel(const float* __restrict__ e, const float
     mx = nm_wave_max(mx);
     float se = 0.0f, sm = 0.0f;
     for (int s = lane; s < S; s += 64) {
-        const float x = __expf(er[s] - mx);
+        const float x = expf(er[s] - mx);
         se += x;
         sm += x * (mr ? mr[s] : 1.0f);
     }
@@ -474,7 +474,7 @@ __global__ void attn_softmax_fwd_kernel(const float* __restrict__ e, const float
     const float inv_se = 1.0f / se;
     const float invN = 1.0f / (sm * inv_se + 1e-8f);
     for (int s = lane; s < S; s += 64)
-        w[row * S + s] = __expf(er[s] - mx) * inv_se * (mr ? mr[s] : 1.0f) * invN;
+        w[row * S + s] = expf(er[s] - mx) * inv_se * (mr ? mr[s] : 1.0f) * invN;
 }
 
 extern "C" int nm_attn_softmax_fwd(void* stream, const float* e, const float* mask, float* w, int64_t rows,
