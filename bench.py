@@ -320,6 +320,67 @@ def captioning_leg(args, dev, lib):
                          "evidence": files or None}}
 
 
+def time_loops_leg(args, dev):
+    """The four GRU time loops of the headline training step on their own (rows = --batch, H = --hidden, --len steps):
+    microseconds per recurrent step, HIP-graph replayed, as ONE cluster launch per loop (csrc/nm_gru_cluster.hip --
+    what the timed training step runs) and as two launches per step (the round-4 path, NM_CLUSTER_LOOPS=0)."""
+    from neuralmonkey_amd import ops
+    from neuralmonkey_amd.nn import gru
+    rows, h, s = args.batch, args.hidden, args.length
+    g = torch.Generator(device=dev).manual_seed(0)
+    out = {}
+    for ndir, tag in ((1, "decoder"), (2, "encoder_2dir")):
+        rn = lambda *shape: torch.randn(*shape, device=dev, generator=g) * 0.1
+        xp, wgh, wch = rn(rows * s, ndir * 3 * h), rn(ndir, h, 2 * h), rn(ndir, h, h)
+        hcur, states = torch.zeros(ndir, rows, h, device=dev), torch.zeros(rows, s, ndir * h, device=dev)
+        ru_all, c_all = torch.empty(s, ndir, rows, 2 * h, device=dev), torch.empty(s, ndir, rows, h, device=dev)
+        rh = torch.empty(ndir, rows, h, device=dev)
+        dh, d_out = torch.zeros(ndir, rows, h, device=dev), rn(rows, s, ndir * h)
+        dxp = torch.zeros(rows * s, ndir * 3 * h, device=dev)
+        scratch = (torch.empty(2, ndir, rows, 2 * h, device=dev), torch.empty(ndir, rows, h, device=dev),
+                   torch.empty(ndir, rows, h, device=dev))
+        xst, seq = (3 * h, s * ndir * 3 * h, ndir * 3 * h), (h, s * ndir * h, ndir * h)
+
+        def fwd_steps():
+            hcur.zero_()
+            for t in range(s):
+                gru.step_fwd(xp, xst, hcur, hcur, wgh, wch, ru_all[t], rh, c_all[t], states, seq, None, t, ndir, rows, h,
+                             False, None, None)
+
+        def bwd_steps():
+            dh.zero_()
+            gru.bptt(s, dh, d_out, seq, ru_all, c_all, None, states, seq, dxp, xst, wgh, wch, None, ndir, rows, h, False,
+                     *scratch)
+
+        def replayed(fn, reps=10):
+            fn()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                fn()
+            graph.replay()
+            return _timed_gpu(graph.replay, 1, reps) * 1e6 / s
+        entry = {"two_launches_per_step": {"forward_us_per_step": replayed(fwd_steps), "bptt_us_per_step": replayed(bwd_steps)}}
+        if ops.gru_seq_supported(rows, h, ndir):
+            ws = ops.gru_seq_workspace(rows, h, ndir, dev)
+
+            def fwd_cluster():
+                hcur.zero_()
+                ops.gru_seq_fwd(s, ndir, rows, h, xp, xst, hcur, hcur, 0, ru_all[0], ndir * rows * 2 * h, None, 0,
+                                c_all[0], ndir * rows * h, wgh, wch, ws, out=states, out_strides=seq)
+
+            def bwd_cluster():
+                dh.zero_()
+                ops.gru_seq_bwd(s, ndir, rows, h, dh, d_out, seq, ru_all[0], ndir * rows * 2 * h, c_all[0], ndir * rows * h,
+                                None, states, seq, dxp, xst, wgh, wch, ws)
+            entry["one_cluster_launch_per_loop"] = {"forward_us_per_step": replayed(fwd_cluster),
+                                                    "bptt_us_per_step": replayed(bwd_cluster),
+                                                    "gave_up": bool(ops.gru_seq_failed(ws))}
+        out[tag] = entry
+    return {"what": "GRU time loops alone, us per recurrent step ({} rows, H = {}, {} steps, HIP-graph replayed)".format(
+        rows, h, s), "dtype": "f32", **out}
+
+
 def bf16x3_costing_leg(args, dev, lib):
     """VERDICT r3 item 10 -- COSTED, NOT SHIPPED: the vocabulary projection's product shape (states . E^T, the tied /
     "NT" form: M = B*len, N = V, K = hidden) through a three-term split-bf16 emulation on the bf16 matrix cores
@@ -779,6 +840,7 @@ def main():
             legs = {}
             for name, fn in (("transformer", lambda: transformer_leg(args, dev)),
                              ("captioning", lambda: captioning_leg(args, dev, lib)),
+                             ("gru_time_loops", lambda: time_loops_leg(args, dev)),
                              ("logits_gemm_bf16x3", lambda: bf16x3_costing_leg(args, dev, lib))):
                 try:
                     legs[name] = fn()

@@ -474,6 +474,8 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
             ops.gru_seq_bwd(steps, 1, bsz, h, dh, d_s, seq_strides, sv["ru_all"][0], bsz * 2 * h, sv["c_all"][0],
                             bsz * h, sv["s0"], s_all, seq_strides, dxp, dxp_strides, cell["wg_h"], cell["wc_h"],
                             gru.cluster_workspace(ctx, id(self), bsz, h, 1), sticky=ctx.session.error_word())
+            if dp is not None:
+                dp.after_time_loops()
         else:
             ctx.session.graphed((id(self), "bptt_loop", bsz, steps), bptt_loop)
         ds0 = dh[0]

@@ -48,6 +48,7 @@ class DataParallel:
         self.defer_issue = os.environ.get("NM_DP_EARLY_ISSUE", "deferred") != "now"
         self._early_pending: list = []    # (event, lo, hi) not yet enqueued
         self._issue_stream = None
+        self._loops_done = None           # event behind the step's last cluster time loop (after_time_loops)
         # optional accounting of the exchange (bench.py --gpus N): event pairs on the compute stream around the
         # point where it has to wait for the collectives = the part of the all-reduce that is NOT hidden
         self.timing = False
@@ -138,6 +139,7 @@ class DataParallel:
         """Forget the bookkeeping of a step that did not reach ``all_reduce_gradients`` (an exception)."""
         self._wait_handles()
         self._handles, self._early, self._early_pending = [], [], []
+        self._loops_done = None
         self.sparse_bytes_per_step = 0
 
     def _reduce_span(self, grad, lo: int, hi: int) -> None:
@@ -181,14 +183,27 @@ class DataParallel:
             else:
                 self._reduce_span(grad, lo, hi)
 
+    def after_time_loops(self) -> None:
+        """Called on the stream that just launched a cluster time loop (ops.gru_seq_bwd): early collectives start
+        only once the LAST such loop of the step is done.  A cluster loop needs every CU to take one of its
+        workgroups (320 of a SIMD's 512 registers beside a capped GEMM workgroup's 160); an RCCL workgroup that sits
+        on a CU when the loop is launched would keep the whole loop waiting for the collective to finish.  The
+        leaf GEMMs behind the loops (~2 ms at the headline shape) still hide the early spans' exchange."""
+        if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+            self._loops_done = torch.cuda.Event()
+            self._loops_done.record()
+
     def _issue_early(self, grad) -> None:
-        """Enqueue the collectives of the early spans, each ordered after the event its producer left behind."""
+        """Enqueue the collectives of the early spans, each ordered after the event its producer left behind (and
+        after the step's last cluster time loop)."""
         if not self._early_pending:
             return
         if self._issue_stream is None:
             self._issue_stream = torch.cuda.Stream(device=grad.device)
         pending, self._early_pending = self._early_pending, []
         with torch.cuda.stream(self._issue_stream):
+            if self._loops_done is not None:
+                self._issue_stream.wait_event(self._loops_done)
             for done, lo, hi in pending:
                 self._issue_stream.wait_event(done)
                 self._reduce_span(grad, lo, hi)

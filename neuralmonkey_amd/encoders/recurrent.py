@@ -292,6 +292,9 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
                             sv["ru_all"][0], ndir * bsz * 2 * h, sv["c_all"][0], ndir * bsz * h, None, states_raw,
                             seq_strides, dxp, dxp_strides, wgh, wch, gru.cluster_workspace(ctx, id(self), bsz, h, ndir),
                             lengths=lengths, reverse_dir0=rev0, sticky=ctx.session.error_word())
+            from .. import distributed
+            if distributed.current() is not None:
+                distributed.current().after_time_loops()
             return dxp
 
         def bptt_loop():
