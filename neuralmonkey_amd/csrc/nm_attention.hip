@@ -470,7 +470,10 @@ __global__ __launch_bounds__(256) void attn_partial_fast(AttnArgs p) {
 // hand-off costs more than the second set of CUs brings.  Round 5, no hand-off at all: two workgroups per sentence on
 // one XCD that each score the sentence by themselves and blend half of the value columns -- the split that took the
 // captioning step from 30 to 16 us (attn_whole_wide below) -- 13.7 / 11.4 us cold / warm against 13.5 / 10.9 for this
-// kernel (rocprofv3, same run): at this size the step is not bound by what one CU can stream.)
+// kernel (rocprofv3, same run): at this size the step is not bound by what one CU can stream.  And the beam step's five
+// queries per sentence on such workgroup pairs (no split-S partials, no combine launch): 31.6 us per step against
+// 24.9 + 5.6 for attn_partial_fastq + attn_combine -- every workgroup of a pair evaluates all 5 x 51 200 tanh, and at
+// one quarter-rate v_rcp_f32 each the transcendental pipes, not the loads, set the time.)
 // ---------------------------------------------------------------------------
 #define ATT_WHOLE_ROWS 13
 template <int ROWS>
@@ -546,145 +549,6 @@ __global__ __launch_bounds__(1024) void attn_whole_fast(AttnArgs p) {
         acc.x += (r0.x + r1.x) + r2.x; acc.y += (r0.y + r1.y) + r2.y;
         acc.z += (r0.z + r1.z) + r2.z; acc.w += (r0.w + r1.w) + r2.w;
         *reinterpret_cast<float4*>(p.ctx + (long)b * p.ldctx + col) = acc;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// attn_whole_fast for a handful of queries per sentence (beam search: the k hypotheses of a sentence share its keys
-// and values): whole-sentence workgroups (two per sentence, see below) load the sentence once -- all of it in flight
-// before the first transcendental, as above -- and score, normalise and blend it for every query: no split-S partials of k rows per
-// sentence, no combine launch (attn_partial_fastq + attn_combine: 23.9 + 5.4 us per beam step at k = 5,
-// profiles/r04_decode_beam_kernel_stats.csv).  exp(2 hf) replaces the key slices in their registers, exp(2 y) of
-// the queries lives in LDS: one v_rcp_f32 per (key element, query) (nm_tanh_prod); a wave whose keys or queries
-// leave that form's exact range re-reads them and takes nm_tanh.  Wave q normalises query q, one position per lane.
-// ---------------------------------------------------------------------------
-// (a real call on purpose: inlined into the kernel, the rarely taken exact path costs it ~120 spilled registers)
-__device__ __attribute__((noinline)) float attn_part_exact(float4 h, float4 y, float4 v) {
-    return v.x * nm_tanh(h.x + y.x) + v.y * nm_tanh(h.y + y.y) + v.z * nm_tanh(h.z + y.z) + v.w * nm_tanh(h.w + y.w);
-}
-
-template <int ROWS, int NQ>
-__global__ __launch_bounds__(1024) void attn_whole_fastq(AttnArgs p) {
-    __shared__ float4 eys[NQ][256];            // exp(2 y): [query][16-byte slice of the A columns]
-    __shared__ float pe[4][NQ][4 * ROWS];      // [column wave][query][row group * ROWS + row]
-    __shared__ float wsh[NQ][4 * ROWS];        // normalised weights
-    __shared__ float2 red[4][NQ][256];         // partial contexts of the four row groups
-    __shared__ int y_wide;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int grp = wave >> 2, cw = wave & 3;
-    // two workgroups per sentence, blocks i and i + 8 (one XCD under round-robin dispatch: the second reader of the
-    // keys finds them in L2): both score the sentence, each blends half of the value columns -- 78 instead of 104
-    // registers of loads per thread leave room for the queries, and all 256 CUs stream
-    const int b = ((int)blockIdx.x >> 4) * 8 + ((int)blockIdx.x & 7), half = ((int)blockIdx.x >> 3) & 1;
-    if (b >= p.Bk) return;
-    const int rpg = (p.S + 3) >> 2;
-    const int s0 = grp * rpg;
-    const int ns = max(0, min(rpg, p.S - s0));
-    const int col = cw * 256 + lane * 4;                   // key columns: all of them
-    const int vcol = half * 512 + cw * 128 + lane * 2;     // value columns: this half's 512
-    const bool a_ok = col < p.A, c_ok = vcol < p.C;
-    const float* hbase = p.hf + (long)b * p.S * p.A + (a_ok ? col : 0);
-    const float* sbase = p.states + (long)b * p.S * p.C + (c_ok ? vcol : 0);
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    if (tid == 0) y_wide = 0;
-    float4 v4 = *reinterpret_cast<const float4*>(p.v + (a_ok ? col : 0));
-    if (!a_ok) v4 = zero4;
-    const float bias = p.bias ? p.bias[0] : 0.0f;
-    float4 hfr[ROWS];
-    float2 str[ROWS];
-#pragma unroll
-    for (int s = 0; s < ROWS; ++s)
-        hfr[s] = *reinterpret_cast<const float4*>(hbase + (long)min(s0 + min(s, max(ns - 1, 0)), p.S - 1) * p.A);
-#pragma unroll
-    for (int s = 0; s < ROWS; ++s)
-        str[s] = *reinterpret_cast<const float2*>(sbase + (long)min(s0 + min(s, max(ns - 1, 0)), p.S - 1) * p.C);
-
-    __syncthreads();                           // (y_wide = 0 is visible)
-    for (int q = grp; q < NQ; q += 4) {        // row group g stages queries g, g + 4: 256 threads cover the A columns
-        const float4 yq = *reinterpret_cast<const float4*>(p.y + attn_qrow(p, b, q) * p.A + (a_ok ? col : 0));
-        eys[q][cw * 64 + lane] = make_float4(nm_exp2x(yq.x), nm_exp2x(yq.y), nm_exp2x(yq.z), nm_exp2x(yq.w));
-        if (fmaxf(fmaxf(fabsf(yq.x), fabsf(yq.y)), fmaxf(fabsf(yq.z), fabsf(yq.w))) > NM_EXP2X_MAX) y_wide = 1;
-    }
-    float hmax = 0.0f;
-#pragma unroll
-    for (int s = 0; s < ROWS; ++s)
-        hmax = fmaxf(hmax, fmaxf(fmaxf(fabsf(hfr[s].x), fabsf(hfr[s].y)), fmaxf(fabsf(hfr[s].z), fabsf(hfr[s].w))));
-    __syncthreads();
-    const bool exact = __any(hmax > NM_EXP2X_MAX) || y_wide != 0;      // wave-uniform: the DPP sums need all lanes
-    if (!exact) {
-#pragma unroll
-        for (int s = 0; s < ROWS; ++s)         // exp(2 hf) takes the key slices' registers
-            hfr[s] = make_float4(nm_exp2x(hfr[s].x), nm_exp2x(hfr[s].y), nm_exp2x(hfr[s].z), nm_exp2x(hfr[s].w));
-    }
-#pragma unroll 1
-    for (int q = 0; q < NQ; ++q) {             // (not unrolled: one query's exponentials in registers at a time)
-        if (!exact) {
-            const float4 ey = eys[q][cw * 64 + lane];
-#pragma unroll
-            for (int s = 0; s < ROWS; ++s) {
-                float part = v4.x * nm_tanh_prod(hfr[s].x, ey.x) + v4.y * nm_tanh_prod(hfr[s].y, ey.y) +
-                             v4.z * nm_tanh_prod(hfr[s].z, ey.z) + v4.w * nm_tanh_prod(hfr[s].w, ey.w);
-                part = nm_wave_sum_dpp(part);
-                if (lane == 0) pe[cw][q][grp * ROWS + s] = part;
-            }
-        } else {
-            const float4 y4 = *reinterpret_cast<const float4*>(p.y + attn_qrow(p, b, q) * p.A + (a_ok ? col : 0));
-#pragma unroll
-            for (int s = 0; s < ROWS; ++s) {
-                float part = attn_part_exact(hfr[s], y4, v4);
-                part = nm_wave_sum_dpp(part);
-                if (lane == 0) pe[cw][q][grp * ROWS + s] = part;
-            }
-        }
-    }
-    __syncthreads();
-
-    if (wave < NQ) {                           // wave q: softmax -> mask -> renormalise of query q, a position per lane
-        const int q = wave;
-        const bool ok = lane < p.S;
-        const int g = ok ? lane / rpg : 0, idx = g * ROWS + (ok ? lane - g * rpg : 0);
-        const float e = ok ? ((pe[0][q][idx] + pe[1][q][idx]) + (pe[2][q][idx] + pe[3][q][idx])) + bias : -INFINITY;
-        const float m = nm_wave_max_dpp(e);
-        const float ex = ok ? expf(e - m) : 0.0f;
-        const float mk = (ok && p.mask) ? p.mask[(long)b * p.S + lane] : 1.0f;
-        const float em = ex * mk;
-        const float la = nm_wave_sum_dpp(ex), lm = nm_wave_sum_dpp(em);
-        const float w = em * (1.0f / (lm + 1e-8f * la));
-        if (ok) {
-            wsh[q][idx] = w;
-            if (q < p.nq && half == 0) {       // (both halves compute the same numbers; one of them stores them)
-                const long qr = attn_qrow(p, b, q);
-                p.energies[qr * p.S + lane] = e;
-                if (p.weights) p.weights[qr * p.S + lane] = w;
-            }
-        }
-    }
-    __syncthreads();
-
-    // one query at a time (the loop is NOT unrolled: 13 weights in registers, not 65): every row group leaves its
-    // partial context in LDS, row group 0 adds the four up
-#pragma unroll 1
-    for (int q = 0; q < NQ; ++q) {
-        float2 acc = make_float2(0.f, 0.f);
-#pragma unroll
-        for (int s = 0; s < ROWS; ++s) {
-            const float w = s < ns ? wsh[q][grp * ROWS + s] : 0.0f;
-            acc.x += w * str[s].x; acc.y += w * str[s].y;
-        }
-        red[grp][q][cw * 64 + lane] = acc;
-    }
-    __syncthreads();
-    if (grp == 0 && c_ok) {
-#pragma unroll 1
-        for (int q = 0; q < min(NQ, p.nq); ++q) {
-            const float2 r0 = red[0][q][cw * 64 + lane], r1 = red[1][q][cw * 64 + lane];
-            const float2 r2 = red[2][q][cw * 64 + lane], r3 = red[3][q][cw * 64 + lane];
-            float2 o;
-            o.x = r0.x + ((r1.x + r2.x) + r3.x);
-            o.y = r0.y + ((r1.y + r2.y) + r3.y);
-            *reinterpret_cast<float2*>(p.ctx + attn_qrow(p, b, q) * p.ldctx + vcol) = o;
-        }
     }
 }
 
@@ -1182,16 +1046,6 @@ static int attn_fwd_impl(void* stream, const float* y, const float* hf, const fl
                        (whole_sw >= 0 ? whole_sw != 0 : (Bk >= 96 && S >= 40));
     if (whole) {
         hipLaunchKernelGGL(attn_whole_fast<ATT_WHOLE_ROWS>, dim3((unsigned)Bk), dim3(1024), 0, st, p);
-        if (prof) (void)hipEventRecord(prof->second, st);
-        NM_LAUNCH_CHECK("nm_attn_fwd");
-    }
-    // a few queries per sentence (beam search) at the headline size: one whole-sentence workgroup scores all of them
-    const bool whole_q = do_combine && nq >= 2 && nq <= 5 && groups == 1 && A <= 1024 && C <= 1024 &&
-                         S <= 4 * ATT_WHOLE_ROWS && !no_fast && (whole_sw >= 0 ? whole_sw != 0 : (Bk >= 96 && S >= 40));
-    if (whole_q) {
-        if (nq == 2) hipLaunchKernelGGL((attn_whole_fastq<ATT_WHOLE_ROWS, 2>), dim3((unsigned)(((Bk + 7) / 8) * 16)), dim3(1024), 0, st, p);
-        else if (nq <= 4) hipLaunchKernelGGL((attn_whole_fastq<ATT_WHOLE_ROWS, 4>), dim3((unsigned)(((Bk + 7) / 8) * 16)), dim3(1024), 0, st, p);
-        else hipLaunchKernelGGL((attn_whole_fastq<ATT_WHOLE_ROWS, 5>), dim3((unsigned)(((Bk + 7) / 8) * 16)), dim3(1024), 0, st, p);
         if (prof) (void)hipEventRecord(prof->second, st);
         NM_LAUNCH_CHECK("nm_attn_fwd");
     }

@@ -423,8 +423,8 @@ def test_gru_gemm_fused_epilogues_fwd_bwd(dev, b, s, e, h):
     (100, 1, 41, 200, 72, True),         # the same kernel with partial column waves and a short last row group
     (96, 1, 52, 1024, 512, False),
     (4, 5, 50, 1024, 1024, True),
-    (128, 5, 50, 1024, 1024, True),      # the beam step as benchmarked: whole-sentence workgroups score all 5 queries
-    (100, 3, 47, 600, 520, True),        # the same kernel: 3 queries on the 4-query instance, partial column waves
+    (128, 5, 50, 1024, 1024, True),      # the beam step as benchmarked
+    (100, 3, 47, 600, 520, True),        # 3 queries on the 4-query instance, partial column waves
     (96, 2, 52, 1024, 1024, False),
     (97, 4, 41, 256, 1024, True),
     (1, 5, 50, 1024, 1024, True),        # reference-compatible batch-1 beam
@@ -577,7 +577,7 @@ def test_attention_time_major_all_steps(dev, t, b, s, a, c):
         assert rel_err(ctx1.cpu().numpy(), ctx[i].cpu().numpy()) < 1e-5
 
 
-@pytest.mark.parametrize("bk,qpk,t", [(4, 5, 0), (3, 1, 6), (100, 5, 0)])     # (100 sentences: the whole-sentence kernel)
+@pytest.mark.parametrize("bk,qpk,t", [(4, 5, 0), (3, 1, 6), (100, 5, 0)])
 def test_attention_beyond_the_product_form_range(dev, bk, qpk, t):
     """The multi-query kernels evaluate tanh(hf + y) as 1 - 2 / (1 + exp(2 hf) exp(2 y)) -- exact only while
     exp(2 x) stays inside fp32 (|x| <= 43).  Keys and queries of magnitude ~55 that nearly cancel must come out
