@@ -605,7 +605,10 @@ static void clu_fill(GruClu& q, const nm_gru_epilogue* e) {
     d.dxp = e->dxp; d.dx_dir = e->dx_dir; d.dx_row = e->dx_row; d.dx_time = e->dx_time;
     d.dgpre = e->dgpre; d.dcpre = e->dcpre;
     q.ndir = e->ndir;
-    q.dbg = reinterpret_cast<long*>(getenv("NM_CLU_DEBUG_PTR") ? strtoull(getenv("NM_CLU_DEBUG_PTR"), nullptr, 0) : 0ull);
+    q.dbg = nullptr;
+#ifdef NM_CLU_DEBUG          // timing probe of one workgroup (tools/clu_stamps.py): a device buffer of 64 longs
+    if (getenv("NM_CLU_DEBUG_PTR")) q.dbg = reinterpret_cast<long*>(strtoull(getenv("NM_CLU_DEBUG_PTR"), nullptr, 0));
+#endif
 }
 
 extern "C" int nm_gru_seq_fwd(void* stream, const nm_gru_epilogue* e, int32_t steps, int64_t h_step,

@@ -1,5 +1,10 @@
+"""Where a recurrent step of the cluster forward loop spends its time (in-kernel 100 MHz clock stamps of one workgroup,
+steps 20..23; needs a build with NM_HIPCC_FLAGS=-DNM_CLU_DEBUG):
+
+    NM_HIPCC_FLAGS=-DNM_CLU_DEBUG python -m neuralmonkey_amd.build --force && python tools/clu_stamps.py 128 1
+"""
 import sys, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
 dev = torch.device("cuda:0")
 dbg = torch.zeros(64, dtype=torch.int64, device=dev)

@@ -1,7 +1,8 @@
 #!/bin/bash
-# kernel trace + timeline of one training step; args: tag, extra env assignments
+# rocprofv3 kernel trace + per-queue timeline (tools/trace_timeline.py) of one training step:
+#     bash tools/trace_train.sh <tag> [ENV=VALUE ...]     -> gpurun_out/r05_clu/timeline_<tag>.txt
 tag=$1; shift
-ROOT=$(cd "$(dirname "$0")/../.." && pwd)
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/r05_clu
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
