@@ -64,6 +64,7 @@ struct GruClu {
     unsigned* hdr;
     u64* xa;                     // granules of the first stage's output  [cluster][16 RT][H]
     u64* xb;                     // granules of the second stage's output [cluster][16 RT][H] (backward: [2][..][2H])
+    int force_global;            // NM_CLUSTER_PLACEMENT=blockidx: roles by blockIdx + write-through stores even when the tickets would do
     unsigned* sticky;            // the caller's error word: set (never cleared) when this launch gave up; may be null
     long* dbg;                   // timing probe (NM_CLU_DEBUG builds only)
 };
@@ -91,7 +92,7 @@ __device__ __forceinline__ bool clu_gave_up(gu32* err, long& t0, unsigned& spins
     return false;
 }
 
-__device__ __forceinline__ CluRole clu_roles(unsigned* hdr_, int ncl, int nj, int* sh) {
+__device__ __forceinline__ CluRole clu_roles(unsigned* hdr_, int ncl, int nj, int* sh, int force_global) {
     gu32* hdr = (gu32*)hdr_;
     const int cpx = (ncl + 7) / 8;
     if (threadIdx.x == 0) {
@@ -105,7 +106,7 @@ __device__ __forceinline__ CluRole clu_roles(unsigned* hdr_, int ncl, int nj, in
         bool lost = false;
         while (__hip_atomic_load(hdr + 1, NM_RLX_AGENT) < gridDim.x)
             if (clu_gave_up(hdr, t0, spins)) { lost = true; break; }
-        bool local = !lost;
+        bool local = !lost && !force_global;
         for (int x = 0; x < 8; ++x) local &= (int)__hip_atomic_load(hdr + 8 + x, NM_RLX_AGENT) >= clu_need(x, ncl, cpx, nj);
         int cl, jb;
         bool active;
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(512, 3) void gru_cluster_fwd_kernel(GruClu q) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NW = (int)(blockDim.x >> 6);
     const int H = q.e.H, R = (int)q.e.R;
-    const CluRole role = clu_roles(q.hdr, q.ndir * q.nrb, H / 16, reinterpret_cast<int*>(lds));
+    const CluRole role = clu_roles(q.hdr, q.ndir * q.nrb, H / 16, reinterpret_cast<int*>(lds), q.force_global);
     if (!role.active) return;
     __builtin_amdgcn_s_setprio(3);
     const int jb = role.jb;
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(512, 3) void gru_cluster_bwd_kernel(GruClu q) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NW = (int)(blockDim.x >> 6);
     const int H = q.e.H, R = (int)q.e.R;
-    const CluRole role = clu_roles(q.hdr, q.ndir * q.nrb, H / 16, reinterpret_cast<int*>(lds));
+    const CluRole role = clu_roles(q.hdr, q.ndir * q.nrb, H / 16, reinterpret_cast<int*>(lds), q.force_global);
     if (!role.active) return;
     __builtin_amdgcn_s_setprio(3);
     const int jb = role.jb;
@@ -605,6 +606,10 @@ static void clu_fill(GruClu& q, const nm_gru_epilogue* e) {
     d.dxp = e->dxp; d.dx_dir = e->dx_dir; d.dx_row = e->dx_row; d.dx_time = e->dx_time;
     d.dgpre = e->dgpre; d.dcpre = e->dcpre;
     q.ndir = e->ndir;
+    {   // test hook: the placement-independent path (what runs when an XCD does not get its tickets)
+        const char* place = getenv("NM_CLUSTER_PLACEMENT");
+        q.force_global = (place && strcmp(place, "blockidx") == 0) ? 1 : 0;
+    }
     q.dbg = nullptr;
 #ifdef NM_CLU_DEBUG          // timing probe of one workgroup (tools/clu_stamps.py): a device buffer of 64 longs
     if (getenv("NM_CLU_DEBUG_PTR")) q.dbg = reinterpret_cast<long*>(strtoull(getenv("NM_CLU_DEBUG_PTR"), nullptr, 0));

@@ -49,6 +49,8 @@ def _stepwise(dev, rows, steps, h, ndir, xp, wgh, wch, h0, lengths, rev0):
     (37, 7, 256, 2, True, False),           # rows that do not fill the row tiles, four waves
     (16, 6, 512, 1, False, False),          # one cluster (strong scaling's 16 sentences per GPU)
     (40, 5, 384, 2, True, False),           # six waves
+    (128, 6, 256, 2, True, False),          # 16 clusters: two per XCD
+    (100, 5, 256, 2, True, True),           # 14 clusters: the last XCD hosts none; first direction reversed
 ])
 def test_forward_loop_in_one_launch_equals_the_stepwise_launches(dev, rows, steps, h, ndir, ragged, rev0):
     from neuralmonkey_amd import ops
@@ -88,6 +90,8 @@ def test_forward_loop_in_one_launch_equals_the_stepwise_launches(dev, rows, step
     (37, 7, 256, 2, True, False, True, True),
     (16, 6, 512, 1, False, False, True, False),
     (40, 5, 384, 2, True, False, True, False),
+    (128, 6, 256, 2, True, False, True, True),
+    (100, 5, 256, 2, True, True, True, False),
 ])
 def test_bptt_loop_in_one_launch_equals_the_stepwise_launches(dev, rows, steps, h, ndir, ragged, rev0, with_dout, with_h0):
     from neuralmonkey_amd import ops
@@ -130,6 +134,21 @@ def test_bptt_loop_in_one_launch_equals_the_stepwise_launches(dev, rows, steps, 
         assert not ops.gru_seq_failed(ws)
         for name, a, b in (("dh0", dh, dh_want), ("dxp", dxp, dxp_want)):
             assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max())), (attempt, name)
+
+
+def test_the_placement_independent_path_gives_the_same_loops():
+    """When an XCD does not get the workgroups its clusters need, roles follow blockIdx and the granules are stored
+    write-through (correct under any placement, ~2x slower per hop).  On this hardware the tickets always work out, so
+    the path is forced (NM_CLUSTER_PLACEMENT=blockidx, read per launch) and every case above is run through it in a
+    fresh process."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, NM_CLUSTER_PLACEMENT="blockidx")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gru_cluster_gpu.py", "-q", "-x", "-k",
+                          "one_launch_equals"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
 
 
 def test_unsupported_shapes_are_refused_not_run(dev):
