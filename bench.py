@@ -381,6 +381,70 @@ def time_loops_leg(args, dev):
         rows, h, s), "dtype": "f32", **out}
 
 
+def split_projection_leg(args, dev):
+    """OPT-IN (NM_PROJ_SPLIT=1), its own dtype, NOT the number of record: greedy and beam-5 decoding of the headline
+    model with the steps' vocabulary projection on the bf16 matrix cores -- operands split three ways into bf16 (24
+    mantissa bits), six products, fp32 accumulate (csrc/nm_gemm_bf16x3.hip gemm_split6_stats) -- next to the
+    exact-fp32 projection every number above uses.  A model of its own (fresh decoding graphs), the same weights and
+    batches as the main decoding legs; the accuracy of the product against float64 beside the exact kernel's."""
+    from neuralmonkey_amd import ops, synthetic
+    h = args.hidden
+    ops.PROJ_SPLIT = True
+    try:
+        model = synthetic.build_translation_model(vocab_src=args.vocab, vocab_tgt=args.vocab, emb=h, rnn=h,
+                                                  max_len=args.length, beam_size=5, max_steps=args.length,
+                                                  length_normalization=0.6, with_trainer=False, device=dev, seed=1234)
+        tfm = model.tf_manager
+        store = tfm.sessions[0].store
+        synthetic.load_baseline_weights(store, seed=1234, std=0.05)
+        store["decoder/state_to_word_b"][2] = -1e9                 # </s> unreachable: all steps run
+        dsd = [synthetic.synthetic_dataset(seed=99 + 10 * i, batch=args.batch, src_len=args.length, tgt_len=args.length,
+                                           vocab=args.vocab, with_target=False) for i in range(4)]
+        out = {}
+        for name, runner in (("greedy", model.greedy_runner), ("beam5", model.beam_runner)):
+            for i in range(5):
+                tfm.execute(dsd[i % 4], runner.feedables, [runner], compute_losses=False, lookahead=dsd[(i + 1) % 4])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 6
+            for i in range(n):
+                tfm.execute(dsd[i % 4], runner.feedables, [runner], compute_losses=False,
+                            lookahead=dsd[(i + 1) % 4] if i + 1 < n else None)
+            torch.cuda.synchronize()
+            out[name] = (time.perf_counter() - t0) / n
+        # the product itself at the two decoding shapes: time per launch and error against float64, both kernels
+        w, bias = store["decoder/state_to_word_W"], store["decoder/state_to_word_b"].clone()
+        bias[2] = 0.0                                              # (the -1e9 above would be the error's yardstick)
+        gen = torch.Generator(device=dev).manual_seed(5)
+        product = {}
+        for rows in (args.batch, 5 * args.batch):
+            a = torch.randn(rows, h, device=dev, generator=gen)
+            want = a.double() @ w.double() + bias.double()
+            st, lg = ops.logits_stats_buffer(rows, args.vocab, dev), torch.empty(rows, args.vocab, device=dev)
+            planes = ops.proj_split_prepare(w)
+            t3 = _timed_gpu(lambda: ops.logits_stats_gemm(a, w, bias, st, out=lg), 3, 20) * 1e6
+            e3 = float((lg.double() - want).abs().max() / want.abs().max())
+            ops.proj_split_forget(w)
+            t32 = _timed_gpu(lambda: ops.logits_stats_gemm(a, w, bias, st, out=lg), 3, 20) * 1e6
+            e32 = float((lg.double() - want).abs().max() / want.abs().max())
+            del planes
+            product["rows_{}".format(rows)] = {"split_us": t3, "exact_f32_us": t32, "split_max_error_vs_float64": e3,
+                                               "exact_f32_max_error_vs_float64": e32}
+        tok = args.batch * args.length
+        return {"dtype": "bf16x6 (fp32 operands split into bf16 hi + mid + lo: 24 mantissa bits; six bf16 MFMA products, "
+                         "fp32 accumulate) for the vocabulary projection of the decoding steps; everything else f32",
+                "switch": "NM_PROJ_SPLIT=1 (off by default: the exact-fp32 projection is the number of record)",
+                "greedy_ms_per_batch": out["greedy"] * 1e3, "greedy_tok_s": tok / out["greedy"],
+                "beam5_ms_per_batch": out["beam5"] * 1e3, "beam5_tok_s": tok / out["beam5"],
+                "projection": product,
+                "parity": "tests/test_proj_split_gpu.py: product error <= 2x the exact kernel's against float64, its "
+                          "statistics exact for its own logits, and the decoding parity tests (full-size greedy / "
+                          "beam accounting, the reference-executed fixtures) pass under the switch"}
+    finally:
+        ops.PROJ_SPLIT = False
+        ops.proj_split_forget()
+
+
 def bf16x3_costing_leg(args, dev, lib):
     """VERDICT r3 item 10 -- COSTED, NOT SHIPPED: the vocabulary projection's product shape (states . E^T, the tied /
     "NT" form: M = B*len, N = V, K = hidden) through a three-term split-bf16 emulation on the bf16 matrix cores
@@ -841,6 +905,7 @@ def main():
             for name, fn in (("transformer", lambda: transformer_leg(args, dev)),
                              ("captioning", lambda: captioning_leg(args, dev, lib)),
                              ("gru_time_loops", lambda: time_loops_leg(args, dev)),
+                             ("decode_split_projection", lambda: split_projection_leg(args, dev)),
                              ("logits_gemm_bf16x3", lambda: bf16x3_costing_leg(args, dev, lib))):
                 try:
                     legs[name] = fn()

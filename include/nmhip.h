@@ -247,6 +247,18 @@ int nm_step_group(void* stream, int64_t M, const nm_step_problem* problems, int3
 int nm_gemm_bf16x3_nt(void* stream, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
                       int64_t ldb, float* C, int64_t ldc, int terms, int variant /* tile / k-depth choice, 0..3 */);
 
+/* ---- OPT-IN: the decoding steps' vocabulary projection (tf.matmul(state, decoding_w) + bias,
+ * decoders/autoregressive.py:450-459) on the bf16 matrix cores with fp32-class accuracy (csrc/nm_gemm_bf16x3.hip):
+ * both operands split three ways into bf16 (24 mantissa bits), six products, fp32 accumulate.  The weights are
+ * split once: `prepare` fills `planes` (split_bytes(N, K) bytes, 16-byte aligned; K % 16 == 0; W is [K][N], or
+ * [N][K] with trans_b) and registers W -- from then on nm_logits_stats_gemm called with this B pointer (same N, K,
+ * trans_b; 128-column statistics tiles) takes the split kernel; `forget` (NULL: every matrix) returns it to the
+ * exact-fp32 kernel, which stays the default.  The caller re-prepares when W changes. */
+int64_t nm_proj_split_bytes(int64_t N, int64_t K);
+int nm_proj_split_prepare(void* stream, const float* W, int64_t ldw, int trans_b, int64_t N, int64_t K, void* planes,
+                          int64_t planes_bytes);
+int nm_proj_split_forget(const float* W);
+
 /* ---- the WHOLE inference step of the headline decoder behind one call (SURVEY 8(b)4 nm_decoder_step_fused):
  * Decoder.next_state, decoders/decoder.py:279-358 (plain GRUCell nn/ortho_gru_cell.py:44-53, ONE Bahdanau
  * attention attention/feed_forward.py:120-166, nonlinear output projection decoders/output_projection.py:115-130)

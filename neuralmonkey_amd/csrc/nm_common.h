@@ -143,3 +143,9 @@ __device__ __forceinline__ float nm_exp2x(float x) { return __expf(2.0f * fminf(
 __device__ __forceinline__ float nm_tanh_prod(float ea, float eb) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(fmaf(ea, eb, 1.0f));
 }
+
+// nm_gemm_bf16x3.hip: the vocabulary projection on the bf16 matrix cores for weights registered with
+// nm_proj_split_prepare (opt-in); true when the product was launched
+bool nm_proj_split_try(hipStream_t st, int trans_b, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                       const float* B, const float* bias, float* C, int64_t ldc, float* stats, int stats_tile);
+

@@ -1111,6 +1111,10 @@ extern "C" int nm_logits_stats_gemm(void* stream, int transB, int64_t M, int64_t
     if (ablate) g.act = 9;
     const int tile = (int)nm_logits_stats_tile(M);
     hipStream_t st = nm_stream(stream);
+    // weights with split planes (nm_proj_split_prepare, opt-in): the product runs on the bf16 matrix cores
+    if (!ablate && nm_proj_split_try(st, transB, M, N, K, A, lda, B, bias, C, C ? ldc : 0, stats, tile)) {
+        NM_LAUNCH_CHECK("nm_logits_stats_gemm (split)");
+    }
     const bool pf2 = (stats_cfg() & 2) != 0;
     // One beam step (B x beam = 640 rows) is 5 x 250 = 1250 workgroups of 128x128 for 512 slots: 2.44 rounds, the
     // third one 44 % full.  Measured and rejected: one 640x128 tile per workgroup (gemm_tiled<4, 2, 5, 2, ...>: 8 waves

@@ -17,6 +17,8 @@
 // bench.py `configs.logits_gemm_bf16x3`); the shipped path stays exact fp32.
 #include "nm_common.h"
 
+#include <mutex>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -183,3 +185,265 @@ extern "C" int nm_gemm_bf16x3_nt(void* stream, int64_t M, int64_t N, int64_t K, 
     }
     NM_LAUNCH_CHECK("nm_gemm_bf16x3_nt");
 }
+
+// =====================================================================================================================
+// OPT-IN product path (NM_PROJ_SPLIT=1, its own dtype in the bench line): the vocabulary projection of the DECODING
+// steps -- tf.matmul(state, decoding_w) + bias, decoders/autoregressive.py:450-459, with the row statistics of
+// nm_logits_stats_gemm -- on the bf16 matrix cores with fp32-class accuracy.  Every fp32 operand is split THREE ways,
+// x = hi + mid + lo with hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): 24 mantissa bits, all of fp32's;
+// six products are kept (hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi: everything down to 2^-24 of a term), summed in
+// fp32 from the smallest to the largest.  6 x 32 cycles of v_mfma_f32_32x32x16_bf16 per 16 k against 8 x 64 of
+// v_mfma_f32_32x32x2_f32.  The weights do not change while a model decodes: they are split ONCE
+// (nm_proj_split_prepare) into planes laid out tile by tile -- [column tile of 128][k tile of 16][hi|mid|lo][128][16]
+// bf16 -- so that what a workgroup stages per k step is 12 KB of consecutive bytes; the activations are split while
+// they are staged.  The exact-fp32 kernel stays the default and the number of record.
+// =====================================================================================================================
+__device__ __forceinline__ void split3_2(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+    const unsigned h0 = bf3_hi_bits(x0), h1 = bf3_hi_bits(x1);
+    const float r0 = x0 - __uint_as_float(h0), r1 = x1 - __uint_as_float(h1);
+    const unsigned m0 = bf3_hi_bits(r0), m1 = bf3_hi_bits(r1);
+    const unsigned l0 = bf3_hi_bits(r0 - __uint_as_float(m0)), l1 = bf3_hi_bits(r1 - __uint_as_float(m1));
+    hi = (h0 >> 16) | h1;
+    mid = (m0 >> 16) | m1;
+    lo = (l0 >> 16) | l1;
+}
+
+// planes[((bn * KT + kt) * 3 + plane) * 2048 + n_local * 16 + k_local] of W: [K][N] (trans_b 0) or [N][K] (trans_b 1)
+__global__ __launch_bounds__(256) void split3_planes_kernel(const float* __restrict__ W, long ldw, int trans_b, int N, int K,
+                                                           unsigned short* __restrict__ planes) {
+    const int KT = K / 16;
+    const int bn = blockIdx.x / KT, kt = blockIdx.x % KT;
+    unsigned short* dst = planes + (long)(bn * KT + kt) * 3 * 2048;
+    for (int e = threadIdx.x; e < 2048; e += 256) {
+        const int nl = trans_b ? e / 16 : e % 128, kl = trans_b ? e % 16 : e / 128;      // read along the contiguous axis
+        const int n = bn * 128 + nl, k = kt * 16 + kl;
+        float x = 0.0f;
+        if (n < N) x = trans_b ? W[(long)n * ldw + k] : W[(long)k * ldw + n];
+        const unsigned h = bf3_hi_bits(x);
+        const float r = x - __uint_as_float(h);
+        const unsigned m = bf3_hi_bits(r);
+        const unsigned l = bf3_hi_bits(r - __uint_as_float(m));
+        dst[nl * 16 + kl] = (unsigned short)(h >> 16);
+        dst[2048 + nl * 16 + kl] = (unsigned short)(m >> 16);
+        dst[4096 + nl * 16 + kl] = (unsigned short)(l >> 16);
+    }
+}
+
+struct Split6Args {
+    const float* A; long lda;                // [M][K] fp32
+    const unsigned short* planes;            // split weights, tiled (see above)
+    const float* bias;                       // [N] or null
+    float* C; long ldc;                      // [M][N] or null: the logits are stored only when somebody reads them
+    float* stats;                            // [M][tiles_n][4] = {max, sum exp(x - max), first argmax, -}
+    int M, N, K;
+};
+
+__global__ __launch_bounds__(512) void gemm_split6_stats(Split6Args g, int tiles_m) {
+    constexpr int BM = 128, BN = 128, BK = 16, NT = 512, TN = 2;
+    constexpr int HR = 64, TS = BN + 1;                       // statistics epilogue: rows per pass, odd row stride
+    // operand tiles [buf][plane][row][16] bf16, re-used by the epilogue as [HR][129] floats + 3 x 512 scratch
+    __shared__ __attribute__((aligned(16))) unsigned short lds_raw[2 * 2 * 3 * 128 * 16];      // 48 KB
+    unsigned short (*As)[3][BM][BK] = reinterpret_cast<unsigned short (*)[3][BM][BK]>(lds_raw);
+    unsigned short (*Bs)[3][BN][BK] = reinterpret_cast<unsigned short (*)[3][BN][BK]>(lds_raw + 2 * 3 * 128 * 16);
+    static_assert(HR * TS + 3 * NT <= 2 * 2 * 3 * 128 * 16 / 2, "the epilogue fits the operand buffers");
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bm = (int)blockIdx.x % tiles_m, bn = (int)blockIdx.x / tiles_m;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int KT = g.K / BK;
+    const float* __restrict__ A = g.A;
+    const uint4* __restrict__ Bt = reinterpret_cast<const uint4*>(g.planes + (long)bn * KT * 3 * 2048);   // 384 uint4 per k tile... x2
+
+    // staging: A one float4 per thread (128 rows x 4 quads); B 768 16-byte chunks (3 planes x 128 rows x 2 halves)
+    const int am = tid >> 2, ak = (tid & 3) * 4;
+    float4 ra;
+    uint4 rb0, rb1;
+    auto load = [&](int kt) {
+        const int gm = m0 + am;
+        ra = gm < g.M ? *reinterpret_cast<const float4*>(A + (long)gm * g.lda + kt * BK + ak) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const uint4* src = Bt + (long)kt * 768;
+        rb0 = src[tid];
+        if (tid < 256) rb1 = src[512 + tid];
+    };
+    auto stage = [&](int buf) {
+        uint2 hi, mid, lo;
+        split3_2(ra.x, ra.y, hi.x, mid.x, lo.x);
+        split3_2(ra.z, ra.w, hi.y, mid.y, lo.y);
+        *reinterpret_cast<uint2*>(&As[buf][0][am][ak]) = hi;
+        *reinterpret_cast<uint2*>(&As[buf][1][am][ak]) = mid;
+        *reinterpret_cast<uint2*>(&As[buf][2][am][ak]) = lo;
+        uint4* dst = reinterpret_cast<uint4*>(&Bs[buf][0][0][0]);
+        dst[tid] = rb0;
+        if (tid < 256) dst[512 + tid] = rb1;
+    };
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 64;
+    const int row = lane & 31, kh = (lane >> 5) * 8;
+
+    load(0);
+    stage(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < KT; ++kt) {
+        if (kt + 1 < KT) load(kt + 1);
+        bf16x8 a3[3], b3[TN][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            a3[pl] = *reinterpret_cast<const bf16x8*>(&As[cur][pl][wm + row][kh]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b3[j][pl] = *reinterpret_cast<const bf16x8*>(&Bs[cur][pl][wn + j * 32 + row][kh]);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {       // smallest contributions first
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[2], b3[j][0], acc[j], 0, 0, 0);     // lo . hi
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b3[j][2], acc[j], 0, 0, 0);     // hi . lo
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[1], b3[j][1], acc[j], 0, 0, 0);     // mid . mid
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[1], b3[j][0], acc[j], 0, 0, 0);     // mid . hi
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b3[j][1], acc[j], 0, 0, 0);     // hi . mid
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b3[j][0], acc[j], 0, 0, 0);     // hi . hi
+        }
+        if (kt + 1 < KT) stage(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: bias, per-tile row statistics (the arithmetic and the layout of nm_gemm.hip's STATS epilogue:
+    // first maximum of ascending columns, sum exp(x - max) with expf), logits stored when asked for
+    float* smem = reinterpret_cast<float*>(lds_raw);
+    float* T = smem;
+    float* pmax = smem + HR * TS;
+    int* parg = reinterpret_cast<int*>(pmax + NT);
+    float* psum = pmax + 2 * NT;
+    constexpr int TPR = NT / HR, CW = BN / TPR;               // 8 threads per row, 16 columns each
+    bool okj[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn + j * 32 + (lane & 31);
+        okj[j] = col < g.N;
+        const float bv = (okj[j] && g.bias) ? g.bias[col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] += bv;
+    }
+    const int tiles_n = (int)gridDim.x / tiles_m;
+    const int rr = tid % HR, q = tid / HR;
+    for (int h = 0; h < BM / HR; ++h) {
+        __syncthreads();
+        const int rbase = wm - h * HR;                        // this wave's 32 rows inside the pass (wave-uniform)
+        if (rbase >= 0 && rbase < HR) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    T[(rbase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * TS + wn + j * 32 + (lane & 31)] =
+                        okj[j] ? acc[j][r] : -INFINITY;
+        }
+        __syncthreads();
+        const float* trow = T + rr * TS + q * CW;
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+            const float v = trow[c];
+            if (v > best) { best = v; bi = n0 + q * CW + c; }
+        }
+        pmax[q * HR + rr] = best;
+        parg[q * HR + rr] = bi;
+        __syncthreads();
+        float m = pmax[rr];
+#pragma unroll
+        for (int w = 1; w < TPR; ++w) m = fmaxf(m, pmax[w * HR + rr]);
+        float sum = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CW; ++c) sum += expf(trow[c] - m);
+        psum[q * HR + rr] = sum;
+        __syncthreads();
+        const int orow = m0 + h * HR + tid;
+        if (tid < HR && orow < g.M) {
+            float tot = psum[tid];
+            int a = parg[tid];
+#pragma unroll
+            for (int w = 1; w < TPR; ++w) tot += psum[w * HR + tid];
+            float bmx = pmax[tid];
+#pragma unroll
+            for (int w = 1; w < TPR; ++w)
+                if (pmax[w * HR + tid] > bmx) { bmx = pmax[w * HR + tid]; a = parg[w * HR + tid]; }
+            float4 rec;
+            rec.x = bmx; rec.y = tot; rec.z = __int_as_float(a); rec.w = 0.0f;
+            *reinterpret_cast<float4*>(g.stats + ((long)orow * tiles_n + bn) * 4) = rec;
+        }
+    }
+    if (!g.C) return;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn + j * 32 + (lane & 31);
+        if (col >= g.N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int orow = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (orow < g.M) g.C[(long)orow * g.ldc + col] = acc[j][r];
+        }
+    }
+}
+
+// ---- the registry: which weight matrices of this process have split planes (per device pointer).  A handful of
+// entries (one per decoding model); nm_logits_stats_gemm looks its B operand up.
+namespace {
+struct SplitEntry { const float* w; const unsigned short* planes; long N, K; int trans_b; };
+std::mutex g_split_mu;
+std::vector<SplitEntry> g_split;
+}
+
+extern "C" int64_t nm_proj_split_bytes(int64_t N, int64_t K) {
+    if (N <= 0 || K <= 0 || K % 16) return 0;
+    return ((N + 127) / 128) * (K / 16) * 3 * 2048 * (int64_t)sizeof(unsigned short);
+}
+
+// planes <- the three bf16 planes of W ([K][N], or [N][K] when trans_b), and W is registered: from now on
+// nm_logits_stats_gemm with this B pointer (same N, K, trans_b, 128-column statistics tiles) runs on the bf16 cores.
+extern "C" int nm_proj_split_prepare(void* stream, const float* W, int64_t ldw, int trans_b, int64_t N, int64_t K,
+                                     void* planes, int64_t planes_bytes) {
+    NM_REQUIRE(W && planes && N > 0 && K > 0 && K % 16 == 0, "nm_proj_split_prepare: bad arguments (K %% 16 == 0)");
+    NM_REQUIRE(planes_bytes >= nm_proj_split_bytes(N, K) && nm_aligned16(planes), "nm_proj_split_prepare: planes too small");
+    const int blocks = (int)(((N + 127) / 128) * (K / 16));
+    hipLaunchKernelGGL(split3_planes_kernel, dim3(blocks), dim3(256), 0, nm_stream(stream), W, (long)ldw, trans_b,
+                       (int)N, (int)K, reinterpret_cast<unsigned short*>(planes));
+    {
+        std::lock_guard<std::mutex> lock(g_split_mu);
+        bool found = false;
+        for (auto& e : g_split)
+            if (e.w == W) { e = SplitEntry{W, reinterpret_cast<const unsigned short*>(planes), (long)N, (long)K, trans_b}; found = true; }
+        if (!found) g_split.push_back(SplitEntry{W, reinterpret_cast<const unsigned short*>(planes), (long)N, (long)K, trans_b});
+    }
+    NM_LAUNCH_CHECK("nm_proj_split_prepare");
+}
+
+extern "C" int nm_proj_split_forget(const float* W) {       // W == NULL: forget every matrix
+    std::lock_guard<std::mutex> lock(g_split_mu);
+    if (!W) g_split.clear();
+    else
+        for (size_t i = 0; i < g_split.size(); ++i)
+            if (g_split[i].w == W) { g_split.erase(g_split.begin() + i); break; }
+    return NM_OK;
+}
+
+// called by nm_logits_stats_gemm: true when the product was launched here
+bool nm_proj_split_try(hipStream_t st, int trans_b, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                       const float* B, const float* bias, float* C, int64_t ldc, float* stats, int stats_tile) {
+    const unsigned short* planes = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_split_mu);
+        for (const auto& e : g_split)
+            if (e.w == B && e.N == N && e.K == K && e.trans_b == trans_b) planes = e.planes;
+    }
+    if (!planes || stats_tile != 128 || K % 16 || lda % 4 || !nm_aligned16(A)) return false;
+    Split6Args g{A, (long)lda, planes, bias, C, (long)ldc, stats, (int)M, (int)N, (int)K};
+    const int tm = nm_cdiv(M, 128), tn = nm_cdiv(N, 128);
+    hipLaunchKernelGGL(gemm_split6_stats, dim3(tm * tn), dim3(512), 0, st, g, tm);
+    return true;
+}
+

@@ -157,10 +157,24 @@ class AutoregressiveDecoder(ModelPart):
         """``state_to_logits`` + per-tile {max, sum exp, argmax} of every row in ``stats``; the logits are
         written only when ``out`` is given (autoregressive.py:450-459 + :470 / beam_search_decoder.py:537-543)."""
         bias = self.decoding_bias(ctx)
+        self.ensure_split_projection(ctx)
         if self.tie_embeddings:
             ops.logits_stats_gemm(state, self.embedding_matrix(ctx), bias, stats, out=out, trans_b=True)
         else:
             ops.logits_stats_gemm(state, self.var(ctx, "state_to_word_W"), bias, stats, out=out)
+
+    def ensure_split_projection(self, ctx) -> None:
+        """NM_PROJ_SPLIT=1 (opt-in, inference): the projection's weights as three bf16 planes, re-split whenever the
+        variables change (ops.proj_split_prepare); the statistics GEMM of the decoding steps then runs on the bf16
+        matrix cores.  A no-op without the switch."""
+        if not ops.PROJ_SPLIT or ctx.session.device.type != "cuda" or torch.cuda.is_current_stream_capturing():
+            return
+        sig = ctx.session.variables_signature()
+        state = self.__dict__.setdefault("_split_proj", {})
+        if state.get("sig") != sig:
+            w = self.embedding_matrix(ctx) if self.tie_embeddings else self.var(ctx, "state_to_word_W")
+            state["planes"] = ops.proj_split_prepare(w, trans_b=self.tie_embeddings, planes=state.get("planes"))
+            state["sig"] = sig
 
     def embed_input_symbols(self, ctx, symbols: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
         emb = ops.embedding_gather(self.embedding_matrix(ctx), symbols, out=out)

@@ -482,6 +482,7 @@ class FusedStepper:
             dict(A=self.ctxbuf, lda=ldc_, Bt=self.wo_c_t, ldb=lds(self.wo_c_t), N=o, K=c, epilogue=0,
                  act=1 if proj.activation == "tanh" else 0, add=self.pre, ldadd=o, C=self.pre, ldc=o)])
         att.hidden_features(ctx)
+        dec.ensure_split_projection(ctx)          # (opt-in NM_PROJ_SPLIT=1; a no-op otherwise)
         self._pending, self._cur = None, 0
         # the same step behind the single C entry (nm_decoder_step_fused): descriptor built once, per-step
         # pointers patched in step()

@@ -341,6 +341,32 @@ def logits_stats_gemm(state, w, bias, stats, out=None, trans_b=False):
                                         stats.numel() * 4), "nm_logits_stats_gemm")
 
 
+PROJ_SPLIT = os.environ.get("NM_PROJ_SPLIT", "0") == "1"
+
+
+def proj_split_prepare(w, trans_b=False, planes=None):
+    """OPT-IN (NM_PROJ_SPLIT=1): split the vocabulary projection's weights ``w`` ([K,N]; [N,K] with ``trans_b``) into
+    three bf16 planes and register them: ``logits_stats_gemm`` with this ``w`` then runs six bf16 matrix-core products
+    instead of the exact-fp32 kernel (nm_proj_split_prepare).  Returns the planes (keep them alive while ``w`` is
+    registered; call again when ``w`` changes)."""
+    lib = _lib.load()
+    _f32(w)
+    assert w.dim() == 2 and w.stride(1) == 1
+    n, k = (w.shape[0], w.shape[1]) if trans_b else (w.shape[1], w.shape[0])
+    nbytes = lib.nm_proj_split_bytes(n, k)
+    if nbytes <= 0:
+        return None
+    if planes is None or planes.numel() * 2 < nbytes:
+        planes = torch.empty(nbytes // 2, dtype=torch.int16, device=w.device)
+    _lib.check(lib.nm_proj_split_prepare(_stream(), w.data_ptr(), w.stride(0), int(trans_b), n, k, planes.data_ptr(),
+                                         planes.numel() * 2), "nm_proj_split_prepare")
+    return planes
+
+
+def proj_split_forget(w=None):
+    _lib.check(_lib.load().nm_proj_split_forget(_p(w)), "nm_proj_split_forget")
+
+
 def greedy_finish(stats, vocab, finished, sym_out, mask_out, end_id, all_finished=None, table=None, emb_out=None,
                   argmax_out=None, max_out=None, lse_out=None):
     """Greedy step tail from the tile statistics: argmax, symbol / finished update, next input embedding."""

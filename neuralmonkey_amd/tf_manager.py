@@ -146,6 +146,9 @@ class TensorFlowManager:
         """Create and initialise every variable of every registered model part
         (== global_variables_initializer + Saver over all globals)."""
         parts = registered_parts()
+        from . import ops
+        if ops.PROJ_SPLIT and self.sessions and self.sessions[0].device.type == "cuda":
+            ops.proj_split_forget()          # a new model: no weight matrix of an earlier one stays registered
         for sess in self.sessions:
             for part in parts:
                 part.declare_variables(sess.store)

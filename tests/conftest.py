@@ -19,6 +19,7 @@ SLOW = (
     "test_fullsize_parity_gpu.py::test_beam_search_every_selection_of_all_50_steps_is_accounted_for",
     "test_captioning_fullsize_gpu.py::test_every_beam_selection_of_all_50_steps_is_accounted_for",
     "test_transformer_gpu.py::test_transformer_base_width_matches_the_oracle",
+    "test_proj_split_gpu.py::test_decoding_parity_holds_under_the_split_projection",
 )
 
 
