@@ -509,6 +509,9 @@ extern "C" int nm_step_group(void* stream, int64_t M, const nm_step_problem* pro
 bool nm_medium_gemm(hipStream_t st, int transB, long M, long N, long K, const float* A, long lda, const float* B,
                     long ldb, float* C, long ldc, const float* bias, int act, int accumulate) {
     if (M <= 256 || M > 2048 || nm_cur()->sw.medium_m == 0) return false;
+    // (a 32x32 tile walks ALL of K: made for K ~ 512..2048.  The input gradient of the vocabulary projection at a few
+    // hundred rows -- K = 32000 -- took 401 us here against ~250 us on the split-K tiled kernels)
+    if (K > 4096) return false;
     if (K % 16 || N % 32 || lda % 4 || ldb % 4 || !nm_aligned16(A) || !nm_aligned16(B)) return false;
     if (act < 0 || act > 2 || M * lda >= (1L << 31) || (transB ? N : K) * ldb >= (1L << 31)) return false;
     const long t64 = (long)nm_cdiv(M, 64) * nm_cdiv(N, 64);
