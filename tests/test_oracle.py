@@ -144,3 +144,33 @@ def test_gumbel_noise_is_finite_for_every_bit_pattern():
     noise = O.gumbel_noise(64, 4096, 12345)
     assert noise.dtype == np.float32 and np.isfinite(noise).all()
 
+
+def test_adadelta_restatement_follows_tf_apply_adadelta():
+    """``TR.clip_and_adadelta`` (the checker of the HIP Adadelta kernel) against the four lines of TensorFlow 1.12's
+    ApplyAdadelta written out in NumPy float64, two updates, with the clip biting on one tensor and sparing the other
+    (tests/bpe.ini:102-108: rho 0.95, epsilon 1e-6)."""
+    rng = np.random.default_rng(4)
+    p = {"a": torch.tensor(rng.standard_normal((3, 4)), dtype=torch.float32),
+         "b": torch.tensor(rng.standard_normal(5), dtype=torch.float32)}
+    acc = {k: torch.zeros_like(v) for k, v in p.items()}
+    acc_u = {k: torch.zeros_like(v) for k, v in p.items()}
+    ref = {k: v.double().numpy().copy() for k, v in p.items()}
+    r_acc = {k: np.zeros_like(v) for k, v in ref.items()}
+    r_acc_u = {k: np.zeros_like(v) for k, v in ref.items()}
+    lr, rho, eps, clip = 0.5, 0.95, 1e-6, 1.0
+    for step in range(2):
+        grads = {"a": torch.tensor(rng.standard_normal((3, 4)) * 3.0, dtype=torch.float32),        # norm > clip
+                 "b": torch.tensor(rng.standard_normal(5) * 0.1, dtype=torch.float32)}             # norm < clip
+        assert float(grads["a"].norm()) > clip > float(grads["b"].norm())
+        TR.clip_and_adadelta(p, grads, acc, acc_u, clip, lr=lr, rho=rho, eps=eps)
+        for k in ref:
+            g = grads[k].double().numpy()
+            g = g * (clip / max(np.sqrt((g * g).sum()), clip))
+            r_acc[k] = rho * r_acc[k] + (1 - rho) * g * g
+            update = np.sqrt(r_acc_u[k] + eps) / np.sqrt(r_acc[k] + eps) * g
+            ref[k] = ref[k] - lr * update
+            r_acc_u[k] = rho * r_acc_u[k] + (1 - rho) * update * update
+    for k in ref:
+        assert np.allclose(p[k].numpy(), ref[k], rtol=1e-5, atol=1e-7)
+        assert np.allclose(acc[k].numpy(), r_acc[k], rtol=1e-5) and np.allclose(acc_u[k].numpy(), r_acc_u[k], rtol=1e-5)
+

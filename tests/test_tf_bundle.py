@@ -226,3 +226,50 @@ def test_store_import_of_the_independent_bundle():
     for name, spec in store.specs.items():
         assert np.array_equal(m[spec.offset:spec.offset + spec.size].numpy(), want[name + "/Adam"].reshape(-1))
         assert np.array_equal(v[spec.offset:spec.offset + spec.size].numpy(), want[name + "/Adam_1"].reshape(-1))
+
+
+@pytest.mark.parametrize("fmt", ["tf", "npz"])
+def test_slots_travel_under_the_optimizers_name(tmp_path, fmt):
+    """TensorFlow names an optimizer's slot variables after the optimizer: ``<var>/Adam`` and ``<var>/Adam_1``, or --
+    tests/bpe.ini:102-108, ``name="adadelta"`` -- ``<var>/adadelta`` and ``<var>/adadelta_1`` (no beta powers there).  A
+    store writes its two slots under ``slot_suffixes`` and a reader that has not been told the names (a fresh process
+    restores before its trainer has taken a step) finds the pair every variable carries."""
+    import torch
+    from neuralmonkey_amd.optimizers import AdadeltaOptimizer
+    from neuralmonkey_amd.variables import VariableStore, find_slot_suffixes, random_normal_initializer
+    store = VariableStore("cpu", seed=3)
+    store.declare("decoder/state_to_word_W", (4, 6), random_normal_initializer(stddev=0.5))
+    store.declare("decoder/state_to_word_b", (6,), random_normal_initializer(stddev=0.5))
+    store.finalize()
+    accum, accum_update = store.ensure_adam()
+    accum.copy_(torch.arange(store.total, dtype=torch.float32) + 1)
+    accum_update.copy_(torch.arange(store.total, dtype=torch.float32) * 3 + 2)
+    store.slot_suffixes = tuple(AdadeltaOptimizer(name="adadelta").slot_suffixes)
+    path = str(tmp_path / ("variables.data" if fmt == "tf" else "variables.npz"))
+    store.save(path, fmt=fmt, global_step=5)
+    if fmt == "tf":
+        keys = set(TB.read_bundle(path))
+    else:
+        with np.load(path) as data:
+            keys = {k.replace("|", "/") for k in data.files}
+    assert {"decoder/state_to_word_W/adadelta", "decoder/state_to_word_b/adadelta_1", "global_step"} <= keys
+    assert "beta1_power" not in keys and not any(k.endswith(("/Adam", "/Adam_1")) for k in keys)
+    fresh = VariableStore("cpu", seed=9)
+    for name, spec in store.specs.items():
+        fresh.declare(name, spec.shape, random_normal_initializer(stddev=0.5))
+    fresh.finalize()
+    assert fresh.slot_suffixes == ("/Adam", "/Adam_1")
+    info = fresh.load(path)
+    assert info["global_step"] == 5 and fresh.slot_suffixes == ("/adadelta", "/adadelta_1")
+    assert torch.equal(fresh.theta, store.theta)
+    for spec in store.specs.values():                 # (the flat buffers carry alignment padding no file holds)
+        span = slice(spec.offset, spec.offset + spec.size)
+        assert torch.equal(fresh.adam_m[span], accum[span]) and torch.equal(fresh.adam_v[span], accum_update[span])
+    # the helper on its own: the preferred pair when present, else the pair all variables carry, else the preferred
+    names = ["a/w", "b"]
+    assert find_slot_suffixes({"a/w", "b", "a/w/Adam", "a/w/Adam_1", "b/Adam", "b/Adam_1"}, names,
+                              ("/Adam", "/Adam_1")) == ("/Adam", "/Adam_1")
+    assert find_slot_suffixes({"a/w", "b", "a/w/opt", "a/w/opt_1", "b/opt", "b/opt_1"}, names,
+                              ("/Adam", "/Adam_1")) == ("/opt", "/opt_1")
+    assert find_slot_suffixes({"a/w", "b", "a/w/opt", "a/w/opt_1"}, names, ("/Adam", "/Adam_1")) == ("/Adam", "/Adam_1")
+
