@@ -177,3 +177,33 @@ def test_gradient_exchange_entry_points_refuse_without_a_device_or_a_communicato
     if not torch.cuda.is_available():
         assert lib.nm_allreduce_init(0, 1, uid, ctypes.byref(comm)) != 0
         assert b"nm_allreduce_init" in lib.nm_last_error()
+
+
+def test_register_budgets_of_the_overlapped_kernels(lib):
+    """What the training step's schedule rests on, read from the code objects inside the built library
+    (tools/kernel_resources.py; no GPU): a cluster time loop (neuralmonkey_amd/csrc/nm_gru_cluster.hip, 8 waves per
+    workgroup = 2 per SIMD) has to fit on a CU BESIDE one residency-capped leaf-GEMM workgroup (nm_gemm_f32 algo 4:
+    gemm_tiled<4,2,1,2,..,16,false,1,1>, 8 waves = 2 per SIMD) within a SIMD's 512 vector registers per lane --
+    measured when it did not: loops ten times slower (profiles/r05_cluster_loops.md).  And nothing on a hot path may
+    spill: only the wide-beam variants of the first-step row scan (13 launches per beam batch) carry scratch."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from kernel_resources import kernel_resources
+    finally:
+        sys.path.pop(0)
+    table = kernel_resources()
+    assert len(table) > 300
+    loops = {k: v for k, v in table.items() if "gru_cluster_" in k}
+    assert len(loops) == 4                                   # forward / backward x one / two row tiles
+    capped = {k: v for k, v in table.items() if re.match(r"_Z10gemm_tiledILi4ELi2ELi1ELi2ELb[01]ELb[01]ELb[01]ELi16ELb0ELi1ELi1EE", k)}
+    assert len(capped) == 8
+    for v in list(loops.values()) + list(capped.values()):
+        assert v["max_threads"] == 512 and v["scratch"] == 0
+    widest_loop = max(v["arch_vgprs"] for v in loops.values())
+    widest_gemm = max(v["arch_vgprs"] for v in capped.values())
+    assert widest_loop <= 160 and widest_gemm <= 80
+    assert 2 * widest_loop + 2 * widest_gemm <= 512
+    spilling = sorted(k for k, v in table.items() if v["scratch"])
+    assert all("row_scan_kernel" in k for k in spilling), spilling
+
