@@ -100,7 +100,9 @@ __device__ __forceinline__ CluRole clu_roles(unsigned* hdr_, int ncl, int nj, in
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         xcc &= 7u;
         const unsigned ticket = __hip_atomic_fetch_add(hdr + 8 + xcc, 1u, NM_RLX_AGENT);
-        __hip_atomic_fetch_add(hdr + 1, 1u, NM_RLX_AGENT);
+        // the arrival is counted only after the ticket has been taken: its operand depends on the ticket's RETURNED
+        // value (always < 2^31), so whoever sees all arrivals also sees all tickets without a fence on either side
+        __hip_atomic_fetch_add(hdr + 1, 1u + (ticket >> 31), NM_RLX_AGENT);
         long t0 = 0;
         unsigned spins = 0;
         bool lost = false;
