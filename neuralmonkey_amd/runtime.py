@@ -445,7 +445,8 @@ class Session:
         """One int32 on the device that kernels set (and never clear) when they gave up: today the cluster time loops
         whose hand-offs timed out (ops.gru_seq_fwd / gru_seq_bwd, ``sticky``).  Their results are garbage, so whoever
         hands results to the caller looks at the word first: the trainer reads it with the step's losses
-        (GenericTrainer.objective_values), inference polls it one batch late (``poll_device_errors``)."""
+        (GenericTrainer.objective_values), inference polls it one batch late while batches are announced ahead, at once
+        otherwise (``poll_device_errors``)."""
         if self._error_word is None:
             self._error_word = torch.zeros(1, dtype=torch.int32, device=self.device)
         return self._error_word
@@ -455,14 +456,20 @@ class Session:
                            "the results of this and later steps are garbage.  NM_CLUSTER_LOOPS=0 runs the loops as "
                            "two launches per step")
 
-    def poll_device_errors(self) -> None:
+    def poll_device_errors(self, last: bool = False) -> None:
         """Without stalling the streams: read the copy of the error word that the PREVIOUS call started, start the
-        next one."""
+        next one.  ``last``: nobody announced a next batch (no look-ahead), so no later call may come to read that copy
+        -- the word is read at once; the batch's results are on the host by then and the stream has nothing left to
+        wait for."""
         if self._error_word is None or self.device.type != "cuda":
             return
         pending, self._error_pending = self._error_pending, None
         if pending is not None and int(pending.get()[0]) != 0:
             self.raise_device_error()
+        if last:
+            if int(self._error_word.item()) != 0:
+                self.raise_device_error()
+            return
         self._error_pending = self.to_host_async(self._error_word)
 
     def to_host_async(self, dev_tensor: torch.Tensor, off_stream: bool = False) -> HostPending:

@@ -138,7 +138,7 @@ class TensorFlowManager:
             ahead = None
         if not train:                # (a training step's error word travels with its losses)
             for sess in self.sessions:
-                sess.poll_device_errors()
+                sess.poll_device_errors(last=lookahead is None)
         return [ex.result for ex in executables]
 
     # -- variables ---------------------------------------------------------------------------

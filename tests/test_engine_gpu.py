@@ -474,8 +474,8 @@ def test_train_logprobs_is_the_log_softmax_of_the_train_logits(dev):
 def test_a_set_device_error_word_reaches_the_caller(dev):
     """The kernels' only way to say "my results are garbage" is the session's device error word (cluster time loops
     whose hand-offs timed out: csrc/nm_gru_cluster.hip, ``sticky_error``).  It travels to the host with a training
-    step's losses and, for inference, with one batch of delay -- never by stalling the streams.  (The word is set by
-    hand here: the loops do not fail on a healthy device.)"""
+    step's losses and, for inference, with one batch of delay while batches are announced ahead -- never by stalling
+    the streams.  (The word is set by hand here: the loops do not fail on a healthy device.)"""
     from neuralmonkey_amd import synthetic
     model = synthetic.build_translation_model(vocab_src=300, vocab_tgt=300, emb=32, rnn=32, max_len=12, beam_size=0,
                                               device=str(dev))
@@ -490,7 +490,10 @@ def test_a_set_device_error_word_reaches_the_caller(dev):
     res = tfm.execute(ds, model.trainer.feedables, [model.trainer], train=True)[0]
     with pytest.raises(RuntimeError, match="gave up waiting"):
         res.losses["decoder - cost"]
-    tfm.execute(ds, model.greedy_runner.feedables, [model.greedy_runner])       # starts the copy of the set word ...
+    # inference: while the caller announces the next batch the word is polled one batch late ...
+    tfm.execute(ds, model.greedy_runner.feedables, [model.greedy_runner], lookahead=ds)      # starts the copy ...
     with pytest.raises(RuntimeError, match="gave up waiting"):
-        tfm.execute(ds, model.greedy_runner.feedables, [model.greedy_runner])   # ... which the next call reads
-
+        tfm.execute(ds, model.greedy_runner.feedables, [model.greedy_runner], lookahead=ds)  # ... the next call reads
+    # ... and the batch nobody announced a successor for (the last one of a data set) is checked before it returns
+    with pytest.raises(RuntimeError, match="gave up waiting"):
+        tfm.execute(ds, model.greedy_runner.feedables, [model.greedy_runner])
