@@ -43,6 +43,24 @@ def test_error_reporting_without_gpu(lib):
     assert lib.nm_attn_workspace_bytes(128, 50, 1024) == 4 * (6400 + 128 * 5 * 1024 + 128 * 5 * 4 + 128)
 
 
+def test_round5_entry_points_validate_before_any_launch(lib):
+    """The cluster time loops, the split projection and Adadelta: sizes are plain arithmetic, a shape no device here
+    can take is "not supported" (never an exception), null operands are errors with a text, not crashes."""
+    assert lib.nm_gru_seq_supported(128, 512, 2) == 0             # no device: nothing is supported, callers step
+    assert lib.nm_gru_seq_workspace_bytes(128, 512, 2) == 256     # ... and the workspace is its header alone
+    assert lib.nm_proj_split_bytes(32000, 512) == 3 * 2 * 32000 * 512          # three bf16 planes
+    assert lib.nm_proj_split_forget(None) == 0                    # forgetting everything with nothing registered
+    rc = lib.nm_gru_seq_fwd(None, None, 5, 0, 0, 0, 0, None, 0, 0, None, 0, 0, None, 0, None)
+    assert rc < 0 and b"nm_gru_seq_fwd" in lib.nm_last_error()
+    rc = lib.nm_gru_seq_bwd(None, None, 5, 0, 0, None, 0, 0, None, 0, 0, None, 0, None)
+    assert rc < 0 and b"nm_gru_seq_bwd" in lib.nm_last_error()
+    rc = lib.nm_proj_split_prepare(None, None, 0, 0, 32000, 512, None, 0)
+    assert rc < 0 and b"nm_proj_split_prepare" in lib.nm_last_error()
+    rc = lib.nm_optim_clip_adadelta(None, None, None, None, None, None, None, None, None, None, None, 0, 0,
+                                    1.0, 1.0, 0.95, 1e-6, None, 0)
+    assert rc < 0 and b"null" in lib.nm_last_error()
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from neuralmonkey_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
