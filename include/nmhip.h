@@ -119,7 +119,8 @@ int nm_gru_gemm(void* stream, const nm_gru_epilogue* epi, int transB, int64_t K,
  *                    clusters -- ndir * ceil(R / 16), or ndir * ceil(R / 32) at H = 512 -- fit the XCDs with their
  *                    H/16 workgroups each: ceil(clusters / 8) * H / 16 <= CUs / 8), else the caller steps with
  *                    nm_gru_gemm;
- *   workspace_bytes  device memory a call needs (header + granules; zeroed by the call, 16-byte aligned);
+ *   workspace_bytes  device memory a call needs (header + granules; zeroed by the call, 16-byte aligned); a workspace
+ *                    belongs to ONE loop in flight (the next call on the same stream may reuse it);
  *   failed           after a synchronisation: 1 when a loop that used `workspace` gave up waiting for a hand-off
  *                    (0.2 s without progress; its results are garbage), 0 otherwise; a launch that gave up also
  *                    sets the caller's device word `sticky_error` (null: none) to 1 and never clears it;
