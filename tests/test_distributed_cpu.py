@@ -124,6 +124,12 @@ def _worker(rank, world, port, out_dir):
             got = store.g(name).reshape(-1).numpy()
             worst = max(worst, float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-5)))
         np.save(os.path.join(out_dir, "result.npy"), np.array([worst, global_count, float((ftgt != 0).sum())]))
+    # what a bench line reports about the exchange (bench.py "dp", tools/scale.sh): every rank answered an all-gather,
+    # bytes per step = the flat gradient buffer, the early spans counted apart
+    assert dp.ranks_seen() == world
+    report = dp.exchange_report()
+    assert report["ranks_seen"] == world and report["bytes"] == store.total * 4
+    assert 0 <= report["early_bytes"] <= report["bytes"]
     # parameter broadcast makes replicas identical
     store.theta.add_(float(rank))
     dp.broadcast_parameters(store, src=0)
