@@ -132,6 +132,14 @@ int nm_gru_gemm(void* stream, const nm_gru_epilogue* epi, int transB, int64_t K,
 int nm_gru_seq_supported(int64_t R, int64_t H, int32_t ndir);
 int64_t nm_gru_seq_workspace_bytes(int64_t R, int64_t H, int32_t ndir);
 int nm_gru_seq_failed(const void* workspace);
+/* Test hook: the next `launches` cluster loops of this process raise their error word at once (what a launch does
+ * after 0.2 s without progress when something else holds compute units): the recovery paths of the host side
+ * (runtime.Session.recover_training, TensorFlowManager.execute) are exercised on a healthy device.  Returns the
+ * number of forced launches that were still pending. */
+int nm_gru_seq_force_give_up(int32_t launches);
+/* Test utility: `blocks` workgroups that each hold `lds_bytes` of LDS on a CU for `microseconds` (sleeping): what a
+ * long-running kernel of another stream or process does to a cluster loop launched meanwhile. */
+int nm_gru_seq_test_hog(void* stream, int32_t blocks, int64_t lds_bytes, int64_t microseconds);
 int nm_gru_seq_fwd(void* stream, const nm_gru_epilogue* e, int32_t steps, int64_t h_step, int64_t ru_step,
                    int64_t rh_step, int64_t c_step, const float* wgh, int64_t ld_g, int64_t stride_g,
                    const float* wch, int64_t ld_c, int64_t stride_c, void* workspace,
@@ -514,6 +522,33 @@ int nm_optim_clip_adadelta(void* stream, float* theta, const float* grad, float*
                            const int32_t* seg_first, const int32_t* seg_count, const int32_t* seg_flags,
                            int64_t nchunk, int64_t nseg, float clip_norm, float lr, float rho, float epsilon,
                            void* workspace, int64_t workspace_bytes);
+
+/* The same three passes over a RANGE of chunks, for a rank that owns a slice of the flat buffers (sharded optimizer,
+ * reduce-scatter -> Adam on the rank's slice -> all-gather; the reference applies the identical
+ * update on one device, trainers/generic_trainer.py:179-195).  nm_optim_partials: regulariser terms into `grad` and
+ * the per-chunk partial sums into the workspace for chunks [chunk_begin, chunk_end); the partial vector (the first
+ * 3 * nchunk floats of the workspace, zero where no rank wrote) is summed over ranks -- one non-zero contributor per
+ * entry, so the sum is exact; nm_optim_segments: per-tensor squared norms + global L1 / L2 from the whole partial
+ * vector in a fixed order; nm_optim_apply: per-tensor clip + update of chunks [chunk_begin, chunk_end), kind 0 = Adam
+ * (p0..p3 = lr_t, beta1, beta2, epsilon), kind 1 = Adadelta (lr, rho, epsilon, -).  `skip_word` (may be null): a
+ * device word that turns the launch into a no-op when it is not zero -- the error word of nm_gru_seq_fwd / _bwd: the
+ * update of a step whose time loop gave up is never applied, the caller runs the step again. */
+int nm_optim_partials(void* stream, const float* theta, float* grad, const int64_t* chunk_start,
+                      const int32_t* chunk_len, const int32_t* chunk_seg, const int32_t* seg_first,
+                      const int32_t* seg_count, const int32_t* seg_flags, int64_t nchunk, int64_t nseg,
+                      float l1_weight, float l2_weight, int64_t chunk_begin, int64_t chunk_end, void* workspace,
+                      int64_t workspace_bytes);
+int nm_optim_segments(void* stream, const int64_t* chunk_start, const int32_t* chunk_len, const int32_t* chunk_seg,
+                      const int32_t* seg_first, const int32_t* seg_count, const int32_t* seg_flags, int64_t nchunk,
+                      int64_t nseg, float* l1l2_out, void* workspace, int64_t workspace_bytes);
+int nm_optim_apply(void* stream, int32_t kind, float* theta, const float* grad, float* slot0, float* slot1,
+                   const int64_t* chunk_start, const int32_t* chunk_len, const int32_t* chunk_seg,
+                   const int32_t* seg_first, const int32_t* seg_count, const int32_t* seg_flags, int64_t nchunk,
+                   int64_t nseg, float clip_norm, float p0, float p1, float p2, float p3, int64_t chunk_begin,
+                   int64_t chunk_end, const int32_t* skip_word, void* workspace, int64_t workspace_bytes);
+/* x[0..n) = 0 when *word != 0: the gradient a given-up time loop left behind must not reach an accumulation buffer
+ * (trainers/delayed_update_trainer.py:146-150) or a collective as NaNs */
+int nm_zero_if(void* stream, const int32_t* word, float* x, int64_t n);
 
 /* ---- data-parallel gradient exchange (the reference is single-device, tf_manager.py:62-100): the
  * in-place sum over ranks of slices of the flat gradient buffer on RCCL, ordered against HIP streams only.  RCCL is

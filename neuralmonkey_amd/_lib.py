@@ -48,6 +48,8 @@ SIGNATURES = {
     "nm_gru_seq_supported": (I, [L, L, ctypes.c_int32]),
     "nm_gru_seq_workspace_bytes": (L, [L, L, ctypes.c_int32]),
     "nm_gru_seq_failed": (I, [P]),
+    "nm_gru_seq_force_give_up": (I, [ctypes.c_int32]),
+    "nm_gru_seq_test_hog": (I, [P, ctypes.c_int32, L, L]),
     "nm_create": (I, [I, P]),
     "nm_destroy": (I, [P]),
     "nm_ctx_bind": (I, [P]),
@@ -104,6 +106,10 @@ SIGNATURES = {
     "nm_optim_regularize_norms": (I, [P, P, P, P, P, P, P, P, P, L, L, F, F, P, P, L]),
     "nm_optim_clip_adam": (I, [P, P, P, P, P, P, P, P, P, P, P, L, L, F, F, F, F, F, P, L]),
     "nm_optim_clip_adadelta": (I, [P, P, P, P, P, P, P, P, P, P, P, L, L, F, F, F, F, P, L]),
+    "nm_optim_partials": (I, [P, P, P, P, P, P, P, P, P, L, L, F, F, L, L, P, L]),
+    "nm_optim_segments": (I, [P, P, P, P, P, P, P, L, L, P, P, L]),
+    "nm_optim_apply": (I, [P, I, P, P, P, P, P, P, P, P, P, P, L, L, F, F, F, F, F, L, L, P, P, L]),
+    "nm_zero_if": (I, [P, P, P, L]),
     "nm_gather_rows_f32": (I, [P, P, L, P, P, L, L, L]),
     "nm_beam_reorder_tokens": (I, [P, P, P, P, P, L, L]),
     "nm_beam_backtrace": (I, [P, P, P, P, P, L, L]),

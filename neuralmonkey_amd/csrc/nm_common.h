@@ -149,3 +149,9 @@ __device__ __forceinline__ float nm_tanh_prod(float ea, float eb) {
 bool nm_proj_split_try(hipStream_t st, int trans_b, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                        const float* B, const float* bias, float* C, int64_t ldc, float* stats, int stats_tile);
 
+
+// nm_proj.hip: the decoding steps' vocabulary projection as an activation-stationary stream over the weights (W stored
+// [K, N], K a multiple of 128 up to 512, a few row tiles); true when the product was launched
+bool nm_proj_astat_try(hipStream_t st, int trans_b, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                       const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc, float* stats,
+                       int stats_tile);

@@ -1115,6 +1115,11 @@ extern "C" int nm_logits_stats_gemm(void* stream, int transB, int64_t M, int64_t
     if (!ablate && nm_proj_split_try(st, transB, M, N, K, A, lda, B, bias, C, C ? ldc : 0, stats, tile)) {
         NM_LAUNCH_CHECK("nm_logits_stats_gemm (split)");
     }
+    // W stored [K, N] with K <= 512 (the RNN decoders' output projection): the state rows stay in registers, the
+    // weights stream through LDS by LDS-DMA (nm_proj.hip)
+    if (!ablate && nm_proj_astat_try(st, transB, M, N, K, A, lda, B, ldb, bias, C, C ? ldc : 0, stats, tile)) {
+        NM_LAUNCH_CHECK("nm_logits_stats_gemm (activation-stationary)");
+    }
     const bool pf2 = (stats_cfg() & 2) != 0;
     // One beam step (B x beam = 640 rows) is 5 x 250 = 1250 workgroups of 128x128 for 512 slots: 2.44 rounds, the
     // third one 44 % full.  Measured and rejected: one 640x128 tile per workgroup (gemm_tiled<4, 2, 5, 2, ...>: 8 waves

@@ -66,6 +66,7 @@ struct GruClu {
     u64* xb;                     // granules of the second stage's output [cluster][16 RT][H] (backward: [2][..][2H])
     int force_global;            // NM_CLUSTER_PLACEMENT=blockidx: roles by blockIdx + write-through stores even when the tickets would do
     unsigned* sticky;            // the caller's error word: set (never cleared) when this launch gave up; may be null
+    int force_fail;              // test hook (nm_gru_seq_force_give_up): this launch raises its error word at once
     long* dbg;                   // timing probe (NM_CLU_DEBUG builds only)
 };
 
@@ -100,14 +101,16 @@ __device__ __forceinline__ CluRole clu_roles(unsigned* hdr_, int ncl, int nj, in
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         xcc &= 7u;
         const unsigned ticket = __hip_atomic_fetch_add(hdr + 8 + xcc, 1u, NM_RLX_AGENT);
-        // the arrival is counted only after the ticket has been taken: its operand depends on the ticket's RETURNED
-        // value (always < 2^31), so whoever sees all arrivals also sees all tickets without a fence on either side
-        __hip_atomic_fetch_add(hdr + 1, 1u + (ticket >> 31), NM_RLX_AGENT);
+        // the arrival is counted only after the ticket has been taken: a RELEASE increment, and whoever sees all
+        // arrivals re-reads the counter with ACQUIRE before it looks at the tickets (once per launch: the two fences
+        // cost nothing next to the loop) -- every workgroup then decides local / global from the same ticket counts
+        __hip_atomic_fetch_add(hdr + 1, 1u + (ticket >> 31), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         long t0 = 0;
         unsigned spins = 0;
         bool lost = false;
         while (__hip_atomic_load(hdr + 1, NM_RLX_AGENT) < gridDim.x)
             if (clu_gave_up(hdr, t0, spins)) { lost = true; break; }
+        (void)__hip_atomic_load(hdr + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
         bool local = !lost && !force_global;
         for (int x = 0; x < 8; ++x) local &= (int)__hip_atomic_load(hdr + 8 + x, NM_RLX_AGENT) >= clu_need(x, ncl, cpx, nj);
         int cl, jb;
@@ -276,8 +279,13 @@ __global__ __launch_bounds__(512, 3) void gru_cluster_fwd_kernel(GruClu q) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NW = (int)(blockDim.x >> 6);
     const int H = q.e.H, R = (int)q.e.R;
+    if (q.force_fail && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store((gu32*)q.hdr, 1u, NM_RLX_AGENT);
     const CluRole role = clu_roles(q.hdr, q.ndir * q.nrb, H / 16, reinterpret_cast<int*>(lds), q.force_global);
-    if (!role.active) return;
+    if (!role.active) {
+        // (a workgroup without a role still reports a raised error word: with force_fail it may be the only one to see it early)
+        if (tid == 0 && q.sticky && __hip_atomic_load((gu32*)q.hdr, NM_RLX_AGENT) != 0) __hip_atomic_store((gu32*)q.sticky, 1u, NM_RLX_AGENT);
+        return;
+    }
     __builtin_amdgcn_s_setprio(3);
     const int jb = role.jb;
     const int d = role.cl / q.nrb, rb = role.cl % q.nrb;
@@ -414,8 +422,13 @@ __global__ __launch_bounds__(512, 3) void gru_cluster_bwd_kernel(GruClu q) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NW = (int)(blockDim.x >> 6);
     const int H = q.e.H, R = (int)q.e.R;
+    if (q.force_fail && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store((gu32*)q.hdr, 1u, NM_RLX_AGENT);
     const CluRole role = clu_roles(q.hdr, q.ndir * q.nrb, H / 16, reinterpret_cast<int*>(lds), q.force_global);
-    if (!role.active) return;
+    if (!role.active) {
+        // (a workgroup without a role still reports a raised error word: with force_fail it may be the only one to see it early)
+        if (tid == 0 && q.sticky && __hip_atomic_load((gu32*)q.hdr, NM_RLX_AGENT) != 0) __hip_atomic_store((gu32*)q.sticky, 1u, NM_RLX_AGENT);
+        return;
+    }
     __builtin_amdgcn_s_setprio(3);
     const int jb = role.jb;
     const int d = role.cl / q.nrb, rb = role.cl % q.nrb;
@@ -597,6 +610,38 @@ static bool clu_prepare(Kern kern, size_t lds) {
     return (seen & ok_bit) && lds <= 64 * 1024;
 }
 
+static std::atomic<int> clu_force_fail{0};
+
+// Test hook: the next ``launches`` cluster loops (nm_gru_seq_fwd / nm_gru_seq_bwd, any stream of this process) raise
+// their error word at once -- what a launch does after 0.2 s without progress when something else holds compute
+// units.  Their results are garbage and the caller's sticky word is set: the recovery paths can be tested on a
+// healthy device.  Returns the number of forced launches that were still pending.
+extern "C" int nm_gru_seq_force_give_up(int32_t launches) {
+    return clu_force_fail.exchange(launches < 0 ? 0 : launches, std::memory_order_relaxed);
+}
+
+// Test utility: ``blocks`` workgroups that each pin ``lds_bytes`` of LDS and 256 threads on a CU for ``microseconds``
+// (sleeping, not spinning) -- what a long-running kernel of another stream or process does to a cluster loop: the
+// CUs it sits on cannot take the loop's workgroups, the rest of the loop waits for them and gives up after 0.2 s.
+__global__ __launch_bounds__(256) void clu_hog_kernel(long ticks, int* sink) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    lds[threadIdx.x] = 0.0f;
+    const long t0 = (long)wall_clock64();
+    while ((long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+    if (sink && lds[threadIdx.x] != 0.0f) *sink = 1;
+}
+
+extern "C" int nm_gru_seq_test_hog(void* stream, int32_t blocks, int64_t lds_bytes, int64_t microseconds) {
+    NM_REQUIRE(blocks > 0 && blocks <= 4096 && lds_bytes >= 1024 && lds_bytes <= 160 * 1024 && microseconds >= 0 &&
+                   microseconds <= 5000000, "nm_gru_seq_test_hog: bad arguments");
+    if (hipFuncSetAttribute((const void*)clu_hog_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) !=
+        hipSuccess)
+        NM_FAIL(NM_ERR_HIP, "nm_gru_seq_test_hog: cannot reserve %ld bytes of LDS", (long)lds_bytes);
+    hipLaunchKernelGGL(clu_hog_kernel, dim3((unsigned)blocks), dim3(256), (size_t)lds_bytes, nm_stream(stream),
+                       (long)(microseconds * 100), (int*)nullptr);           // wall_clock64 ticks at 100 MHz
+    NM_LAUNCH_CHECK("nm_gru_seq_test_hog");
+}
+
 static void clu_fill(GruClu& q, const nm_gru_epilogue* e) {
     GruEpi& d = q.e;
     d.mode = 0; d.lengths = e->lengths; d.t = 0; d.rev_mask = e->rev_mask; d.H = (int)e->H; d.R = e->R;
@@ -613,6 +658,12 @@ static void clu_fill(GruClu& q, const nm_gru_epilogue* e) {
         q.force_global = (place && strcmp(place, "blockidx") == 0) ? 1 : 0;
     }
     q.dbg = nullptr;
+    {   // test hook: the next nm_gru_seq_force_give_up(n) launches behave like launches whose hand-offs timed out
+        int left = clu_force_fail.load(std::memory_order_relaxed);
+        q.force_fail = 0;
+        while (left > 0 && !clu_force_fail.compare_exchange_weak(left, left - 1, std::memory_order_relaxed)) { }
+        if (left > 0) q.force_fail = 1;
+    }
 #ifdef NM_CLU_DEBUG          // timing probe of one workgroup (tools/clu_stamps.py): a device buffer of 64 longs
     if (getenv("NM_CLU_DEBUG_PTR")) q.dbg = reinterpret_cast<long*>(strtoull(getenv("NM_CLU_DEBUG_PTR"), nullptr, 0));
 #endif

@@ -23,9 +23,9 @@ struct OptChunks {
 // pass 1: regulariser terms + squared gradient norm partials per chunk
 __global__ __launch_bounds__(256) void opt_reg_sumsq_kernel(OptChunks t, const float* __restrict__ theta,
                                                             float* __restrict__ grad, float l1w, float l2w,
-                                                            float* __restrict__ partial) {
+                                                            float* __restrict__ partial, int c0) {
     __shared__ float sh[3][4];
-    const int c = blockIdx.x;
+    const int c = c0 + (int)blockIdx.x;
     const long base = t.chunk_start[c];
     const int len = t.chunk_len[c];
     const int flags = t.seg_flags[t.chunk_seg[c]];
@@ -99,8 +99,10 @@ __global__ __launch_bounds__(256) void opt_adam_kernel(OptChunks t, float* __res
                                                        const float* __restrict__ grad,
                                                        float* __restrict__ m, float* __restrict__ v,
                                                        const float* __restrict__ seg_norm2, float clip,
-                                                       float lr_t, float b1, float b2, float eps) {
-    const int c = blockIdx.x;
+                                                       float lr_t, float b1, float b2, float eps, int c0,
+                                                       const int* __restrict__ skip) {
+    if (skip && *skip != 0) return;          // the step's gradient is garbage (a time loop gave up): nothing is applied
+    const int c = c0 + (int)blockIdx.x;
     const int seg = t.chunk_seg[c];
     if (!(t.seg_flags[seg] & 2)) return;
     const long base = t.chunk_start[c];
@@ -123,8 +125,10 @@ __global__ __launch_bounds__(256) void opt_adadelta_kernel(OptChunks t, float* _
                                                            const float* __restrict__ grad,
                                                            float* __restrict__ accum, float* __restrict__ accum_update,
                                                            const float* __restrict__ seg_norm2, float clip,
-                                                           float lr, float rho, float eps) {
-    const int c = blockIdx.x;
+                                                           float lr, float rho, float eps, int c0,
+                                                           const int* __restrict__ skip) {
+    if (skip && *skip != 0) return;
+    const int c = c0 + (int)blockIdx.x;
     const int seg = t.chunk_seg[c];
     if (!(t.seg_flags[seg] & 2)) return;
     const long base = t.chunk_start[c];
@@ -155,6 +159,89 @@ static OptChunks make_chunks(const int64_t* chunk_start, const int32_t* chunk_le
 // workspace: partial[nchunk*3] + seg_norm2[nseg]  (floats)
 extern "C" int64_t nm_optim_workspace_bytes(int64_t nchunk, int64_t nseg) { return (nchunk * 3 + nseg) * 4; }
 
+// pass 1 over the chunks [chunk_begin, chunk_end): regulariser terms into the gradient, the chunks' partial sums into
+// the workspace.  A rank that owns a slice of the flat buffers (sharded optimizer, distributed.py) runs its own chunks
+// only; the partial vector (3 floats per chunk, zero where nobody wrote) is then summed over ranks -- every entry has
+// exactly one non-zero contributor, so the sum is exact and nm_optim_segments sees the same numbers on every rank as
+// one process would.
+extern "C" int nm_optim_partials(void* stream, const float* theta, float* grad, const int64_t* chunk_start,
+                                 const int32_t* chunk_len, const int32_t* chunk_seg, const int32_t* seg_first,
+                                 const int32_t* seg_count, const int32_t* seg_flags, int64_t nchunk, int64_t nseg,
+                                 float l1_weight, float l2_weight, int64_t chunk_begin, int64_t chunk_end,
+                                 void* workspace, int64_t workspace_bytes) {
+    NM_REQUIRE(theta && grad && chunk_start && chunk_len && chunk_seg && seg_first && seg_count && seg_flags && workspace,
+               "nm_optim_partials: null pointer");
+    NM_REQUIRE(nchunk > 0 && nseg > 0 && workspace_bytes >= nm_optim_workspace_bytes(nchunk, nseg),
+               "nm_optim_partials: bad sizes");
+    NM_REQUIRE(chunk_begin >= 0 && chunk_begin <= chunk_end && chunk_end <= nchunk,
+               "nm_optim_partials: bad chunk range [%ld, %ld) of %ld", (long)chunk_begin, (long)chunk_end, (long)nchunk);
+    if (chunk_begin == chunk_end) return NM_OK;
+    OptChunks t = make_chunks(chunk_start, chunk_len, chunk_seg, seg_first, seg_count, seg_flags, nchunk, nseg);
+    hipLaunchKernelGGL(opt_reg_sumsq_kernel, dim3((unsigned)(chunk_end - chunk_begin)), dim3(256), 0, nm_stream(stream),
+                       t, theta, grad, l1_weight, l2_weight, reinterpret_cast<float*>(workspace), (int)chunk_begin);
+    NM_LAUNCH_CHECK("nm_optim_partials");
+}
+
+// pass 2: per-variable squared gradient norms and the global L1 / L2 terms from the partial vector, in a fixed order
+extern "C" int nm_optim_segments(void* stream, const int64_t* chunk_start, const int32_t* chunk_len,
+                                 const int32_t* chunk_seg, const int32_t* seg_first, const int32_t* seg_count,
+                                 const int32_t* seg_flags, int64_t nchunk, int64_t nseg, float* l1l2_out,
+                                 void* workspace, int64_t workspace_bytes) {
+    NM_REQUIRE(chunk_start && chunk_len && chunk_seg && seg_first && seg_count && seg_flags && l1l2_out && workspace,
+               "nm_optim_segments: null pointer");
+    NM_REQUIRE(nchunk > 0 && nseg > 0 && nseg <= 8192 && workspace_bytes >= nm_optim_workspace_bytes(nchunk, nseg),
+               "nm_optim_segments: bad sizes");
+    OptChunks t = make_chunks(chunk_start, chunk_len, chunk_seg, seg_first, seg_count, seg_flags, nchunk, nseg);
+    float* partial = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(opt_seg_reduce_kernel, dim3(1), dim3(256), (size_t)nseg * 2 * sizeof(float), nm_stream(stream), t,
+                       partial, partial + nchunk * 3, l1l2_out);
+    NM_LAUNCH_CHECK("nm_optim_segments");
+}
+
+// pass 3 over the chunks [chunk_begin, chunk_end): per-tensor clip + the optimizer's update.  kind 0: Adam
+// (p = lr_t, beta1, beta2, epsilon), kind 1: Adadelta (p = lr, rho, epsilon, -).  ``skip_word`` (may be null): a device
+// word that, when not zero, turns the launch into a no-op -- the session's error word (a GRU time loop gave up: the
+// gradient is garbage and the step will be run again, runtime.Session.recover_training).
+extern "C" int nm_optim_apply(void* stream, int32_t kind, float* theta, const float* grad, float* slot0, float* slot1,
+                              const int64_t* chunk_start, const int32_t* chunk_len, const int32_t* chunk_seg,
+                              const int32_t* seg_first, const int32_t* seg_count, const int32_t* seg_flags,
+                              int64_t nchunk, int64_t nseg, float clip_norm, float p0, float p1, float p2, float p3,
+                              int64_t chunk_begin, int64_t chunk_end, const int32_t* skip_word, void* workspace,
+                              int64_t workspace_bytes) {
+    NM_REQUIRE(theta && grad && slot0 && slot1 && workspace, "nm_optim_apply: null pointer");
+    NM_REQUIRE(kind == 0 || kind == 1, "nm_optim_apply: kind %d (0 Adam, 1 Adadelta)", (int)kind);
+    NM_REQUIRE(nchunk > 0 && nseg > 0 && workspace_bytes >= nm_optim_workspace_bytes(nchunk, nseg),
+               "nm_optim_apply: bad sizes");
+    NM_REQUIRE(chunk_begin >= 0 && chunk_begin <= chunk_end && chunk_end <= nchunk,
+               "nm_optim_apply: bad chunk range [%ld, %ld) of %ld", (long)chunk_begin, (long)chunk_end, (long)nchunk);
+    if (chunk_begin == chunk_end) return NM_OK;
+    OptChunks t = make_chunks(chunk_start, chunk_len, chunk_seg, seg_first, seg_count, seg_flags, nchunk, nseg);
+    const float* seg_norm2 = reinterpret_cast<const float*>(workspace) + nchunk * 3;
+    const unsigned grid = (unsigned)(chunk_end - chunk_begin);
+    if (kind == 0)
+        hipLaunchKernelGGL(opt_adam_kernel, dim3(grid), dim3(256), 0, nm_stream(stream), t, theta, grad, slot0, slot1,
+                           seg_norm2, clip_norm, p0, p1, p2, p3, (int)chunk_begin, skip_word);
+    else
+        hipLaunchKernelGGL(opt_adadelta_kernel, dim3(grid), dim3(256), 0, nm_stream(stream), t, theta, grad, slot0, slot1,
+                           seg_norm2, clip_norm, p0, p1, p2, (int)chunk_begin, skip_word);
+    NM_LAUNCH_CHECK("nm_optim_apply");
+}
+
+// x[0..n) = 0 when *word != 0 (the session's error word): a gradient that a given-up time loop left behind must not
+// reach an accumulation buffer or a collective as NaNs
+__global__ __launch_bounds__(256) void zero_if_kernel(const int* __restrict__ word, float* __restrict__ x, long n) {
+    if (*word == 0) return;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] = 0.0f;
+}
+
+extern "C" int nm_zero_if(void* stream, const int32_t* word, float* x, int64_t n) {
+    NM_REQUIRE(word && x && n >= 0, "nm_zero_if: bad arguments");
+    if (n == 0) return NM_OK;
+    const unsigned grid = (unsigned)(n / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(zero_if_kernel, dim3(grid), dim3(256), 0, nm_stream(stream), word, x, (long)n);
+    NM_LAUNCH_CHECK("nm_zero_if");
+}
+
 extern "C" int nm_optim_regularize_norms(void* stream, const float* theta, float* grad,
                                          const int64_t* chunk_start, const int32_t* chunk_len,
                                          const int32_t* chunk_seg, const int32_t* seg_first,
@@ -166,16 +253,12 @@ extern "C" int nm_optim_regularize_norms(void* stream, const float* theta, float
                "nm_optim_regularize_norms: null pointer");
     NM_REQUIRE(nchunk > 0 && nseg > 0 && workspace_bytes >= nm_optim_workspace_bytes(nchunk, nseg),
                "nm_optim_regularize_norms: bad sizes");
-    OptChunks t = make_chunks(chunk_start, chunk_len, chunk_seg, seg_first, seg_count, seg_flags, nchunk, nseg);
-    float* partial = reinterpret_cast<float*>(workspace);
-    float* seg_norm2 = partial + nchunk * 3;
-    hipStream_t st = nm_stream(stream);
-    hipLaunchKernelGGL(opt_reg_sumsq_kernel, dim3((unsigned)nchunk), dim3(256), 0, st, t, theta, grad,
-                       l1_weight, l2_weight, partial);
     NM_REQUIRE(nseg <= 8192, "nm_optim_regularize_norms: too many variables");
-    hipLaunchKernelGGL(opt_seg_reduce_kernel, dim3(1), dim3(256), (size_t)nseg * 2 * sizeof(float), st, t,
-                       partial, seg_norm2, l1l2_out);
-    NM_LAUNCH_CHECK("nm_optim_regularize_norms");
+    int rc = nm_optim_partials(stream, theta, grad, chunk_start, chunk_len, chunk_seg, seg_first, seg_count, seg_flags,
+                               nchunk, nseg, l1_weight, l2_weight, 0, nchunk, workspace, workspace_bytes);
+    if (rc != NM_OK) return rc;
+    return nm_optim_segments(stream, chunk_start, chunk_len, chunk_seg, seg_first, seg_count, seg_flags, nchunk, nseg,
+                             l1l2_out, workspace, workspace_bytes);
 }
 
 extern "C" int nm_optim_clip_adam(void* stream, float* theta, const float* grad, float* m, float* v,
@@ -187,11 +270,9 @@ extern "C" int nm_optim_clip_adam(void* stream, float* theta, const float* grad,
     NM_REQUIRE(theta && grad && m && v && workspace, "nm_optim_clip_adam: null pointer");
     NM_REQUIRE(nchunk > 0 && nseg > 0 && workspace_bytes >= nm_optim_workspace_bytes(nchunk, nseg),
                "nm_optim_clip_adam: bad sizes");
-    OptChunks t = make_chunks(chunk_start, chunk_len, chunk_seg, seg_first, seg_count, seg_flags, nchunk, nseg);
-    const float* seg_norm2 = reinterpret_cast<const float*>(workspace) + nchunk * 3;
-    hipLaunchKernelGGL(opt_adam_kernel, dim3((unsigned)nchunk), dim3(256), 0, nm_stream(stream), t, theta,
-                       grad, m, v, seg_norm2, clip_norm, lr_t, beta1, beta2, epsilon);
-    NM_LAUNCH_CHECK("nm_optim_clip_adam");
+    return nm_optim_apply(stream, 0, theta, grad, m, v, chunk_start, chunk_len, chunk_seg, seg_first, seg_count,
+                          seg_flags, nchunk, nseg, clip_norm, lr_t, beta1, beta2, epsilon, 0, nchunk, nullptr,
+                          workspace, workspace_bytes);
 }
 
 extern "C" int nm_optim_clip_adadelta(void* stream, float* theta, const float* grad, float* accum, float* accum_update,
@@ -203,9 +284,7 @@ extern "C" int nm_optim_clip_adadelta(void* stream, float* theta, const float* g
     NM_REQUIRE(theta && grad && accum && accum_update && workspace, "nm_optim_clip_adadelta: null pointer");
     NM_REQUIRE(nchunk > 0 && nseg > 0 && workspace_bytes >= nm_optim_workspace_bytes(nchunk, nseg),
                "nm_optim_clip_adadelta: bad sizes");
-    OptChunks t = make_chunks(chunk_start, chunk_len, chunk_seg, seg_first, seg_count, seg_flags, nchunk, nseg);
-    const float* seg_norm2 = reinterpret_cast<const float*>(workspace) + nchunk * 3;
-    hipLaunchKernelGGL(opt_adadelta_kernel, dim3((unsigned)nchunk), dim3(256), 0, nm_stream(stream), t, theta,
-                       grad, accum, accum_update, seg_norm2, clip_norm, lr, rho, epsilon);
-    NM_LAUNCH_CHECK("nm_optim_clip_adadelta");
+    return nm_optim_apply(stream, 1, theta, grad, accum, accum_update, chunk_start, chunk_len, chunk_seg, seg_first,
+                          seg_count, seg_flags, nchunk, nseg, clip_norm, lr, rho, epsilon, 0.0f, 0, nchunk, nullptr,
+                          workspace, workspace_bytes);
 }

@@ -11,6 +11,20 @@ The gradient lives in ONE contiguous buffer (variables.py), so the exchange is
 a handful of large collectives (``bucket_bytes`` each) instead of one per
 tensor; on the fully connected 8-GPU xGMI mesh large messages are what lets
 RCCL drive all seven links per GPU.
+
+Sharded optimizer (default with more than one rank; NM_DP_SHARDED=0:
+the replicated update above).  The flat buffers are cut into buckets that follow the
+variable layout (``ShardPlan``); every bucket is split evenly over the ranks.  Per step:
+reduce-scatter of every bucket's gradient (each rank ends up with the SUM of its slice
+only) -> regulariser terms + squared norms of the rank's own chunks, the per-chunk
+partial sums all-reduced (3 floats per 64 K elements: every entry has ONE non-zero
+contributor, so the sum is exact) -> per-tensor clip + Adam / Adadelta on the rank's
+slices only (1/N of the optimizer's 7 streams over the parameters) -> all-gather of the
+updated parameter slices.  The update every replica ends up with is the reference's
+(trainers/generic_trainer.py:179-195: clip by the norm of the SUMMED gradient of a whole
+tensor, one identical step everywhere); replicas are bit-identical by construction -- each
+element is updated once, by its owner, and copied.  The optimizer slots are valid on
+their owners only (``gather_optimizer_slots`` before a checkpoint).
 """
 import os
 from typing import Optional
@@ -19,6 +33,71 @@ import torch
 import torch.distributed as dist
 
 _CURRENT: Optional["DataParallel"] = None
+
+
+class ShardPlan:
+    """Who owns which elements of a store's flat buffers.
+
+    Buckets follow the VARIABLE LAYOUT, never a step's run-time state, so ownership is stable for the life of the
+    store (the optimizer slots of an element live on its owner): a variable of ``big`` elements or more is a run of
+    buckets of its own (at most ``bucket_elems`` each) -- such a variable can be exchanged on its own, early in the
+    backward pass or as rows -- and smaller variables are packed, in layout order, into shared buckets.  A bucket
+    [lo, hi) is split into ``world`` slices of q = 4 * floor((hi - lo) / (4 * world)) elements (rank r owns
+    [lo + r q, lo + (r + 1) q): what reduce_scatter_tensor / all_gather_into_tensor move in place) and a tail of fewer
+    than 4 * world elements that is all-reduced and updated by every rank alike."""
+
+    def __init__(self, store, world: int, bucket_elems: int, big: int) -> None:
+        self.world, self.total = world, int(store.total)
+        self.buckets = []                  # (lo, hi, q, variable name or None)
+        self.of_variable = {}              # name -> indices of the buckets that hold nothing but this variable
+        specs = sorted(store.specs.items(), key=lambda kv: kv[1].offset)
+        group_lo = None
+
+        def close(lo, hi, name):
+            if hi > lo:
+                self.buckets.append((lo, hi, ((hi - lo) // (4 * world)) * 4, name))
+                if name is not None:
+                    self.of_variable.setdefault(name, []).append(len(self.buckets) - 1)
+
+        pos = 0
+        for name, spec in specs:
+            lo, hi = spec.offset, spec.offset + spec.size
+            if spec.size >= big:
+                if group_lo is not None:
+                    close(group_lo, lo, None)
+                    group_lo = None
+                elif lo > pos:
+                    close(pos, lo, None)           # (padding between variables, if the layout has any)
+                for start in range(lo, hi, bucket_elems):
+                    close(start, min(hi, start + bucket_elems), name)
+            else:
+                if group_lo is None:
+                    group_lo = pos
+                if hi - group_lo >= bucket_elems:
+                    close(group_lo, hi, None)
+                    group_lo = None
+            pos = hi
+        if group_lo is not None:
+            close(group_lo, self.total, None)
+        elif pos < self.total:
+            close(pos, self.total, None)
+        assert sum(hi - lo for lo, hi, _, _ in self.buckets) == self.total and self.buckets[0][0] == 0
+        cuts = set()
+        for lo, hi, q, _ in self.buckets:
+            cuts.update(lo + r * q for r in range(world + 1))
+            cuts.add(hi)
+        self.cuts = sorted(cuts)
+
+    def owned(self, rank: int):
+        """[lo, hi) ranges of the flat buffers that ``rank`` reduces, updates and publishes."""
+        return [(lo + rank * q, lo + (rank + 1) * q) for lo, _, q, _ in self.buckets if q]
+
+    def tails(self):
+        """The buckets' indivisible remainders: all-reduced, updated by every rank."""
+        return [(lo + self.world * q, hi) for lo, hi, q, _ in self.buckets if lo + self.world * q < hi]
+
+    def owned_elements(self, rank: int) -> int:
+        return sum(hi - lo for lo, hi in self.owned(rank)) + sum(hi - lo for lo, hi in self.tails())
 
 
 class DataParallel:
@@ -35,6 +114,15 @@ class DataParallel:
         # NM_DP_SPARSE_EMB=1: an embedding matrix whose gradient touches only the rows of this rank's tokens travels
         # as (row ids, rows) instead of as a dense [V, E] slice of the flat buffer (exchange_sparse_rows)
         self.sparse_embeddings = os.environ.get("NM_DP_SPARSE_EMB", "0") == "1"
+        # NM_DP_SHARDED=0: every rank all-reduces the whole gradient and applies the whole update (the round-1..5 path)
+        self.sharded = os.environ.get("NM_DP_SHARDED", "1") != "0"
+        self.big_variable = int(os.environ.get("NM_DP_BIG_VARIABLE", str(1 << 20)))      # elements
+        self._plans: dict = {}
+        self._reduced_buckets: set = set()     # buckets of this step whose gradient is already reduced / scattered
+        self._bucket_events: dict = {}         # bucket -> event of its producer (early, deferred issue)
+        self.poison_foreign = False            # tests: after a reduction, what this rank does not own reads NaN
+        self.optimizer_ms: list = []
+        self.gather_bytes_per_step = 0
         self._sparse_bufs: dict = {}
         self.sparse_bytes_per_step = 0
         self._handles: list = []          # collectives in flight this step
@@ -139,6 +227,7 @@ class DataParallel:
         """Forget the bookkeeping of a step that did not reach ``all_reduce_gradients`` (an exception)."""
         self._wait_handles()
         self._handles, self._early, self._early_pending = [], [], []
+        self._reduced_buckets, self._bucket_events = set(), {}
         self._loops_done = None
         self.sparse_bytes_per_step = 0
 
@@ -165,6 +254,21 @@ class DataParallel:
         if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
             return
         grad = store.ensure_grad()
+        if self.sharded_active():
+            # whole buckets only: a variable big enough to own its buckets starts its reduce-scatter now (ordered
+            # behind its producer), small ones wait for the end of the backward pass with their bucket mates
+            plan = self.plan(store)
+            for name in names:
+                for idx in plan.of_variable.get(name, ()):
+                    if idx in self._reduced_buckets or idx in self._bucket_events:
+                        raise RuntimeError("bucket {} of {} was already reduced this step".format(idx, name))
+                    if self.defer_issue and grad.is_cuda:
+                        done = torch.cuda.Event()
+                        done.record()
+                        self._bucket_events[idx] = done
+                    else:
+                        self._reduce_bucket(grad, plan, idx)
+            return
         spans = sorted((store.offset(n), store.offset(n) + store[n].numel()) for n in names)
         merged = []
         for lo, hi in spans:
@@ -244,6 +348,13 @@ class DataParallel:
         vsz, esz = table.shape
         lo = store.offset(name)
         hi = lo + table.numel()
+        own_buckets = None
+        if self.sharded_active():
+            own_buckets = self.plan(store).of_variable.get(name)
+            if not own_buckets:                 # shares its buckets with other variables: dense, with them
+                return False
+            if any(i in self._reduced_buckets or i in self._bucket_events for i in own_buckets):
+                raise RuntimeError("gradient of {} was already reduced this step".format(name))
         if any(lo < dhi and dlo < hi for dlo, dhi in self._early):
             raise RuntimeError("gradient span [{}, {}) was already reduced this step".format(lo, hi))
         ids = np.unique(np.asarray(host_ids).reshape(-1))
@@ -281,17 +392,31 @@ class DataParallel:
         for r, cnt in enumerate(counts):
             if cnt:
                 scatter_add(table, all_ids[r, :cnt], all_rows[r, :cnt])
-        self._early.append((lo, hi))
+        if own_buckets is not None:
+            self._reduced_buckets.update(own_buckets)      # summed on EVERY rank: the owners find their slices complete
+        else:
+            self._early.append((lo, hi))
         self.sparse_bytes_per_step += 4 * cap * (esz + 1)
         return True
 
-    def all_reduce_gradients(self, store) -> None:
+    def all_reduce_gradients(self, store, error_word=None) -> None:
         """In-place sum of the flat gradient buffer over ranks, in large buckets (minus the spans
         ``all_reduce_early`` already started); returns with every collective of the step ordered
-        before the current stream."""
+        before the current stream.  Sharded optimizer: every bucket is reduce-SCATTERED instead -- afterwards a rank
+        holds the sum of the slices it owns (and of the buckets' tails), the rest of its gradient buffer is stale.
+        ``error_word``: the session's device error word (int32 [1]): its maximum over ranks travels with the
+        gradients, so that a step one rank must run again is skipped -- and run again -- by all of them."""
         if self.world_size == 1 and not self.forced:
             return
         grad = store.ensure_grad()
+        if self.sharded_active():
+            self._reduce_scatter_gradients(store, grad, error_word)
+            return
+        if error_word is not None and self.world_size > 1:
+            if self._comm is None:
+                self._handles.append(dist.all_reduce(error_word, op=dist.ReduceOp.MAX, async_op=True))
+            else:
+                dist.all_reduce(error_word, op=dist.ReduceOp.MAX)
         self._issue_early(grad)
         pos = 0
         for lo, hi in sorted(self._early):
@@ -313,6 +438,145 @@ class DataParallel:
         self.sparse_bytes_last, self.sparse_bytes_per_step = self.sparse_bytes_per_step, 0
         self._handles, self._early = [], []
 
+    # -- sharded optimizer ------------------------------------------------------------------------------------
+    def sharded_active(self) -> bool:
+        """Reduce-scatter -> update of this rank's slices -> all-gather?  (Needs torch.distributed's collectives: the
+        library's own communicator only knows the all-reduce.)"""
+        return self.sharded and (self.world_size > 1 or self.forced) and self._comm is None
+
+    def plan(self, store) -> ShardPlan:
+        key = id(store)
+        if key not in self._plans:
+            self._plans[key] = ShardPlan(store, self.world_size, self.bucket_elems, self.big_variable)
+        return self._plans[key]
+
+    def optimizer_cuts(self, store):
+        """Flat offsets at which the optimizer's chunk table must be cut (ops.OptimizerTables(cuts=...)).  The same for
+        the sharded and the replicated update: both then add the same partial sums in the same order."""
+        return self.plan(store).cuts
+
+    def _in_place(self) -> bool:
+        return dist.get_backend() == "nccl"
+
+    def _reduce_bucket(self, grad, plan: ShardPlan, idx: int) -> None:
+        lo, hi, q, _ = plan.buckets[idx]
+        n, r = self.world_size, self.rank
+        if q:
+            whole, mine = grad[lo:lo + n * q], grad[lo + r * q:lo + (r + 1) * q]
+            if self._in_place():             # RCCL reduces in place when the output is the rank's slice of the input
+                self._handles.append(dist.reduce_scatter_tensor(mine, whole, op=dist.ReduceOp.SUM, async_op=True))
+            else:
+                tmp = torch.empty_like(mine)
+                dist.reduce_scatter_tensor(tmp, whole, op=dist.ReduceOp.SUM)
+                mine.copy_(tmp)
+        if lo + n * q < hi:
+            self._handles.append(dist.all_reduce(grad[lo + n * q:hi], op=dist.ReduceOp.SUM, async_op=True))
+        self._reduced_buckets.add(idx)
+
+    def _reduce_scatter_gradients(self, store, grad, error_word) -> None:
+        plan = self.plan(store)
+        if self._bucket_events:
+            if self._issue_stream is None and grad.is_cuda:
+                self._issue_stream = torch.cuda.Stream(device=grad.device)
+            pending, self._bucket_events = self._bucket_events, {}
+            with torch.cuda.stream(self._issue_stream):
+                if self._loops_done is not None:
+                    self._issue_stream.wait_event(self._loops_done)
+                for idx, done in sorted(pending.items()):
+                    self._issue_stream.wait_event(done)
+                    self._reduce_bucket(grad, plan, idx)
+        early = len(self._reduced_buckets)
+        early_bytes = 4 * sum(plan.buckets[i][1] - plan.buckets[i][0] for i in self._reduced_buckets)
+        if error_word is not None and self.world_size > 1:
+            self._handles.append(dist.all_reduce(error_word, op=dist.ReduceOp.MAX, async_op=True))
+        for idx in range(len(plan.buckets)):
+            if idx not in self._reduced_buckets:
+                self._reduce_bucket(grad, plan, idx)
+        timed = self.timing and grad.is_cuda
+        if timed:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        self._wait_handles()
+        if timed:
+            ev1.record()
+            self._timed.append((ev0, ev1))
+        if self.poison_foreign:                  # (tests) nothing may read what this rank does not own
+            keep = torch.zeros(grad.numel(), dtype=torch.bool, device=grad.device)
+            for lo, hi in plan.owned(self.rank) + plan.tails():
+                keep[lo:hi] = True
+            grad[~keep] = float("nan")
+        self.bytes_per_step = 4 * grad.numel()
+        self.early_bytes_per_step = early_bytes if early else 0
+        self.sparse_bytes_last, self.sparse_bytes_per_step = self.sparse_bytes_per_step, 0
+        self._handles, self._early, self._reduced_buckets = [], [], set()
+
+    def _gather_buckets(self, flat, plan: ShardPlan) -> int:
+        """In-place all-gather of every bucket's slices of ``flat`` (parameters after the update; optimizer slots before
+        a checkpoint).  Returns the bytes a rank receives."""
+        n, r = self.world_size, self.rank
+        handles, moved = [], 0
+        for lo, _, q, _ in plan.buckets:
+            if not q:
+                continue
+            whole, mine = flat[lo:lo + n * q], flat[lo + r * q:lo + (r + 1) * q]
+            if self._in_place():
+                handles.append(dist.all_gather_into_tensor(whole, mine, async_op=True))
+            else:
+                tmp = torch.empty_like(whole)
+                dist.all_gather_into_tensor(tmp, mine.clone())
+                whole.copy_(tmp)
+            moved += 4 * (n - 1) * q
+        for hnd in handles:
+            hnd.wait()
+        return moved
+
+    def optimizer_step(self, store, tables, kind, slot0, slot1, l1_weight, l2_weight, clip_norm, params, skip=None):
+        """Everything between the backward pass and the next forward pass: gradient exchange, regulariser terms and
+        per-tensor norms, clip + update, and -- sharded -- the all-gather of the updated parameters.  ``tables``: the
+        optimizer's chunk tables (ops.OptimizerTables built with ``optimizer_cuts``: ``partials`` / ``partial_vector`` /
+        ``segments`` / ``apply`` / ``chunk_range``); kind 0 Adam, 1 Adadelta, ``params`` their four scalars; ``skip``:
+        the device word that voids the update (its maximum over ranks is taken here).  Returns the device [L1, L2]."""
+        grad = store.ensure_grad()
+        self.all_reduce_gradients(store, error_word=skip)
+        timed = self.timing and grad.is_cuda
+        if timed:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        if not self.sharded_active():
+            tables.partials(store.theta, grad, l1_weight, l2_weight, (0, tables.nchunk))
+            l1l2 = tables.segments()
+            tables.apply(kind, store.theta, grad, slot0, slot1, clip_norm, params, skip=skip)
+        else:
+            plan = self.plan(store)
+            ranges = [tables.chunk_range(lo, hi) for lo, hi in plan.owned(self.rank)]
+            tails = [tables.chunk_range(lo, hi) for lo, hi in plan.tails()]
+            partial = tables.partial_vector()
+            partial.zero_()
+            for rng in ranges + tails:
+                tables.partials(store.theta, grad, l1_weight, l2_weight, rng)
+            if self.rank != 0:                   # the tails are everybody's: their partial sums count once
+                for b, e in tails:
+                    partial[3 * b:3 * e] = 0.0
+            if self.world_size > 1:
+                dist.all_reduce(partial, op=dist.ReduceOp.SUM)
+            l1l2 = tables.segments()
+            for rng in ranges + tails:
+                tables.apply(kind, store.theta, grad, slot0, slot1, clip_norm, params, skip=skip, chunks=rng)
+            self.gather_bytes_per_step = self._gather_buckets(store.theta, plan)
+            store.epoch += 1                     # (a collective wrote the variables: Session.variables_signature)
+        if timed:
+            ev1.record()
+            self.optimizer_ms.append((ev0, ev1))
+        return l1l2
+
+    def gather_optimizer_slots(self, store, slot0, slot1) -> None:
+        """Sharded optimizer: a rank holds the slots of its own slices only.  Before they are written to a checkpoint
+        (or compared in a test) every rank collects the others'."""
+        if self.sharded_active() and self.world_size > 1:
+            plan = self.plan(store)
+            self._gather_buckets(slot0, plan)
+            self._gather_buckets(slot1, plan)
+
     def exchange_report(self) -> dict:
         """Mean exposed wait per step since the last call (``timing`` on), bytes exchanged per step and how many of
         them were started early, from inside the backward pass."""
@@ -321,11 +585,28 @@ class DataParallel:
             second.synchronize()
             waits.append(first.elapsed_time(second))
         self._timed = []
+        opt = []
+        for first, second in self.optimizer_ms:
+            second.synchronize()
+            opt.append(first.elapsed_time(second))
+        self.optimizer_ms = []
+        sharded = self.sharded_active()
+        plan = next(iter(self._plans.values()), None)
+        # bytes a rank SENDS per step with ring collectives: reduce-scatter and all-gather move (N-1)/N of the buffer
+        # each, an all-reduce both; embedding rows exchanged as rows replace their dense share
+        n = max(1, self.world_size)
+        dense = self.bytes_per_step
         return {"ranks_seen": self.ranks_seen(),
                 "allreduce_exposed_ms": (sum(waits) / len(waits)) if waits else None, "steps": len(waits),
                 "bytes": self.bytes_per_step, "early_bytes": self.early_bytes_per_step,
                 "sparse_rows_bytes": getattr(self, "sparse_bytes_last", 0),
-                "buckets_mb": self.bucket_elems * 4 / 2 ** 20}
+                "buckets_mb": self.bucket_elems * 4 / 2 ** 20,
+                "optimizer": "sharded" if sharded else "replicated",
+                "optimizer_ms": (sum(opt) / len(opt)) if opt else None,
+                "optimizer_elements_per_rank": plan.owned_elements(self.rank) if (sharded and plan) else None,
+                "exchanged_bytes_per_rank": {"gradients": int(dense * (n - 1) / n) * (1 if sharded else 2),
+                                             "parameters": self.gather_bytes_per_step if sharded else 0,
+                                             "rows": getattr(self, "sparse_bytes_last", 0)}}
 
     def ranks_seen(self) -> int:
         """How many distinct ranks answer an all-gather over the process group (RCCL on GPUs): the proof, inside a

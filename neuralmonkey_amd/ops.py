@@ -610,6 +610,12 @@ def _rc(t):
     return 1, t.numel(), t.numel()
 
 
+def zero_if(word, x):
+    """``x[:] = 0`` when the int32 device word is not zero (nm_zero_if): the gradient of a step whose time loop gave up
+    must not reach an accumulation buffer or a collective as NaNs."""
+    _lib.check(_lib.load().nm_zero_if(_stream(), word.data_ptr(), x.data_ptr(), x.numel()), "nm_zero_if")
+
+
 def ew(op, a, b, out, alpha=0.0, accumulate=False):
     """out (+)= op(a, b) element-wise; 2-D operands may be column slices (row stride = ld)."""
     lib = _lib.load()
@@ -859,9 +865,48 @@ def gru_seq_workspace(rows, hsz, ndir, device) -> torch.Tensor:
     return torch.empty(gru_seq_workspace_floats(rows, hsz, ndir), dtype=torch.float32, device=device)
 
 
+def gru_seq_force_give_up(launches: int) -> int:
+    """Test hook (nm_gru_seq_force_give_up): the next ``launches`` cluster loops behave like loops whose hand-offs
+    timed out."""
+    return int(_lib.load().nm_gru_seq_force_give_up(int(launches)))
+
+
+def gru_seq_test_hog(blocks: int, lds_bytes: int, microseconds: int, stream=None) -> None:
+    """Test utility (nm_gru_seq_test_hog): ``blocks`` workgroups that hold ``lds_bytes`` of LDS each for a while."""
+    st = stream.cuda_stream if stream is not None else _stream()
+    _lib.check(_lib.load().nm_gru_seq_test_hog(st, int(blocks), int(lds_bytes), int(microseconds)), "nm_gru_seq_test_hog")
+
+
 def gru_seq_failed(workspace) -> bool:
     """After a synchronisation: did a cluster loop that used ``workspace`` give up waiting for a hand-off?"""
     return _lib.load().nm_gru_seq_failed(workspace.data_ptr()) != 0
+
+
+# One cluster loop at a time per device.  A launch is ``ncu`` workgroups that must ALL be resident before they agree on
+# their roles (csrc/nm_gru_cluster.hip); by registers exactly one such workgroup fits a CU (8 waves x 160 VGPRs = 2 per
+# SIMD x 160 of 512), so two loops launched on two streams interleave over the CUs and neither becomes resident until
+# both time out.  Every launch therefore waits for the previous one's event, whatever its stream, and leaves its own.
+# Inside a stream capture the order is the captured stream's (a graph holds one loop after the other anyway).
+_LAST_CLUSTER_LAUNCH = {}          # device index -> (event, stream it was recorded on)
+
+
+def _cluster_serialize_before():
+    if not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
+        return None
+    stream = torch.cuda.current_stream()
+    last = _LAST_CLUSTER_LAUNCH.get(stream.device.index)
+    if last is not None and last[1] != stream.cuda_stream:
+        stream.wait_event(last[0])
+    return stream
+
+
+def _cluster_serialize_after(stream):
+    if stream is None:
+        return
+    last = _LAST_CLUSTER_LAUNCH.get(stream.device.index)
+    event = last[0] if last is not None else torch.cuda.Event()
+    event.record(stream)
+    _LAST_CLUSTER_LAUNCH[stream.device.index] = (event, stream.cuda_stream)
 
 
 def gru_seq_fwd(steps, ndir, rows, hsz, xp, x_strides, h_in0, h_out0, h_step, ru0, ru_step, rh0, rh_step, c0,
@@ -883,11 +928,13 @@ def gru_seq_fwd(steps, ndir, rows, hsz, xp, x_strides, h_in0, h_out0, h_step, ru
     g2 = wgh[0] if wgh.dim() == 3 else wgh
     c2 = wch[0] if wch.dim() == 3 else wch
     assert g2.stride(1) == 1 and c2.stride(1) == 1
+    serial = _cluster_serialize_before()
     _lib.check(lib.nm_gru_seq_fwd(_stream(), ctypes.byref(e), steps, h_step, ru_step, rh_step, c_step,
                                   wgh.data_ptr(), g2.stride(0), wgh.stride(0) if wgh.dim() == 3 else 0,
                                   wch.data_ptr(), c2.stride(0), wch.stride(0) if wch.dim() == 3 else 0,
                                   workspace.data_ptr(), workspace.numel() * workspace.element_size(), _p(sticky)),
                "nm_gru_seq_fwd")
+    _cluster_serialize_after(serial)
 
 
 def gru_seq_bwd(steps, ndir, rows, hsz, dh, dout, dout_strides, ru0, ru_step, c0, c_step, h0, hseq, hseq_strides,
@@ -908,34 +955,61 @@ def gru_seq_bwd(steps, ndir, rows, hsz, dh, dout, dout_strides, ru0, ru_step, c0
     g2 = wgh[0] if wgh.dim() == 3 else wgh
     c2 = wch[0] if wch.dim() == 3 else wch
     assert g2.stride(1) == 1 and c2.stride(1) == 1
+    serial = _cluster_serialize_before()
     _lib.check(lib.nm_gru_seq_bwd(_stream(), ctypes.byref(e), steps, ru_step, c_step,
                                   wgh.data_ptr(), g2.stride(0), wgh.stride(0) if wgh.dim() == 3 else 0,
                                   wch.data_ptr(), c2.stride(0), wch.stride(0) if wch.dim() == 3 else 0,
                                   workspace.data_ptr(), workspace.numel() * workspace.element_size(), _p(sticky)),
                "nm_gru_seq_bwd")
+    _cluster_serialize_after(serial)
+
+
+def optimizer_chunk_table(store, regularizable, trainable, cuts=(), chunk=65536):
+    """The host side of the flat optimizer kernels' tables: every variable ("segment") is cut into chunks of at most
+    ``chunk`` elements -- and at every flat offset in ``cuts`` (the slice boundaries of a sharded optimizer,
+    distributed.ShardPlan.cuts: a chunk never straddles one, so every rank owns whole chunks).  The table -- and with it
+    the order of every reduction -- depends on the cuts only, not on who owns which slice: one process and N ranks that
+    use the same cuts compute bit-identical norms.  Returns (starts, lens, segs, seg_first, seg_count, seg_flags)."""
+    import bisect
+    cuts = sorted(set(int(c) for c in cuts))
+    starts, lens, segs, first, count, flags = [], [], [], [], [], []
+    for si, (name, spec) in enumerate(store.specs.items()):
+        first.append(len(starts))
+        off = 0
+        while off < spec.size:
+            n = min(chunk, spec.size - off)
+            if cuts:
+                k = bisect.bisect_right(cuts, spec.offset + off)
+                if k < len(cuts) and cuts[k] < spec.offset + off + n:
+                    n = cuts[k] - (spec.offset + off)
+            starts.append(spec.offset + off)
+            lens.append(n)
+            segs.append(si)
+            off += n
+        count.append(len(starts) - first[-1])
+        flags.append((1 if name in regularizable else 0) | (2 if name in trainable else 0))
+    return starts, lens, segs, first, count, flags
+
+
+def chunk_range_of(starts, lens, lo, hi):
+    """The chunks whose elements lie in [lo, hi) of the flat buffer: (begin, end); the range must start and end on
+    chunk boundaries."""
+    import bisect
+    b, e = bisect.bisect_left(starts, lo), bisect.bisect_left(starts, hi)
+    assert b == e or (starts[b] == lo and starts[e - 1] + lens[e - 1] == hi), "a slice does not end on a chunk boundary"
+    return b, e
 
 
 class OptimizerTables:
     """Chunk / segment tables of a VariableStore for the flat optimizer kernels."""
     CHUNK = 65536
 
-    def __init__(self, store, regularizable, trainable):
+    def __init__(self, store, regularizable, trainable, cuts=()):
         lib = _lib.load()
-        starts, lens, segs, first, count, flags = [], [], [], [], [], []
-        chosen = list(store.specs.items())
-        self.names = [name for name, _ in chosen]
-        for si, (name, spec) in enumerate(chosen):
-            first.append(len(starts))
-            off = 0
-            while off < spec.size:
-                n = min(self.CHUNK, spec.size - off)
-                starts.append(spec.offset + off)
-                lens.append(n)
-                segs.append(si)
-                off += n
-            count.append(len(starts) - first[-1])
-            flags.append((1 if name in regularizable else 0) | (2 if name in trainable else 0))
+        self.names = list(store.specs)
+        starts, lens, segs, first, count, flags = optimizer_chunk_table(store, regularizable, trainable, cuts, self.CHUNK)
         dev = store.device
+        self._starts_host, self._lens_host = list(starts), list(lens)
         self.chunk_start = torch.tensor(starts, dtype=torch.int64, device=dev)
         self.chunk_len = torch.tensor(lens, dtype=torch.int32, device=dev)
         self.chunk_seg = torch.tensor(segs, dtype=torch.int32, device=dev)
@@ -961,18 +1035,43 @@ class OptimizerTables:
                    "nm_optim_regularize_norms")
         return self.l1l2
 
-    def clip_adam(self, theta, grad, m, v, clip_norm, lr_t, beta1, beta2, epsilon):
-        lib = _lib.load()
-        _lib.check(lib.nm_optim_clip_adam(_stream(), theta.data_ptr(), grad.data_ptr(), m.data_ptr(),
-                                          v.data_ptr(), *self._tabs(), float(clip_norm or 0.0), float(lr_t),
-                                          float(beta1), float(beta2), float(epsilon),
-                                          self.workspace.data_ptr(), self.workspace.numel() * 4),
-                   "nm_optim_clip_adam")
+    def clip_adam(self, theta, grad, m, v, clip_norm, lr_t, beta1, beta2, epsilon, skip=None, chunks=None):
+        """Per-tensor clip + Adam.  ``skip``: an int32 device word that, when not zero, turns the launch into a no-op
+        (the session's error word: the update of a step whose time loop gave up is never applied); ``chunks``: the
+        (begin, end) range of chunks a rank owns under the sharded optimizer (default: all)."""
+        self.apply(0, theta, grad, m, v, clip_norm, (lr_t, beta1, beta2, epsilon), skip=skip, chunks=chunks)
 
-    def clip_adadelta(self, theta, grad, accum, accum_update, clip_norm, lr, rho, epsilon):
+    def clip_adadelta(self, theta, grad, accum, accum_update, clip_norm, lr, rho, epsilon, skip=None, chunks=None):
+        self.apply(1, theta, grad, accum, accum_update, clip_norm, (lr, rho, epsilon, 0.0), skip=skip, chunks=chunks)
+
+    def apply(self, kind, theta, grad, slot0, slot1, clip_norm, params, skip=None, chunks=None):
+        """nm_optim_apply: kind 0 Adam (lr_t, beta1, beta2, epsilon), 1 Adadelta (lr, rho, epsilon, -)."""
         lib = _lib.load()
-        _lib.check(lib.nm_optim_clip_adadelta(_stream(), theta.data_ptr(), grad.data_ptr(), accum.data_ptr(),
-                                              accum_update.data_ptr(), *self._tabs(), float(clip_norm or 0.0),
-                                              float(lr), float(rho), float(epsilon),
-                                              self.workspace.data_ptr(), self.workspace.numel() * 4),
-                   "nm_optim_clip_adadelta")
+        c0, c1 = chunks if chunks is not None else (0, self.nchunk)
+        p0, p1, p2, p3 = (float(x) for x in params)
+        _lib.check(lib.nm_optim_apply(_stream(), int(kind), theta.data_ptr(), grad.data_ptr(), slot0.data_ptr(),
+                                      slot1.data_ptr(), *self._tabs(), float(clip_norm or 0.0), p0, p1, p2, p3,
+                                      int(c0), int(c1), _p(skip), self.workspace.data_ptr(),
+                                      self.workspace.numel() * 4), "nm_optim_apply")
+
+    def partials(self, theta, grad, l1_weight, l2_weight, chunks):
+        """Pass 1 over the chunks [begin, end): regulariser terms into ``grad``, partial sums into the workspace."""
+        lib = _lib.load()
+        _lib.check(lib.nm_optim_partials(_stream(), theta.data_ptr(), grad.data_ptr(), *self._tabs(),
+                                         float(l1_weight), float(l2_weight), int(chunks[0]), int(chunks[1]),
+                                         self.workspace.data_ptr(), self.workspace.numel() * 4), "nm_optim_partials")
+
+    def partial_vector(self):
+        """The 3 floats per chunk that ``partials`` writes (a view of the workspace)."""
+        return self.workspace[:3 * self.nchunk]
+
+    def segments(self):
+        """Pass 2: per-variable squared norms + [L1, L2] from the whole partial vector, in a fixed order."""
+        lib = _lib.load()
+        _lib.check(lib.nm_optim_segments(_stream(), *self._tabs(), self.l1l2.data_ptr(), self.workspace.data_ptr(),
+                                         self.workspace.numel() * 4), "nm_optim_segments")
+        return self.l1l2
+
+    def chunk_range(self, lo, hi):
+        """The chunks whose elements lie in [lo, hi) of the flat buffer: (begin, end)."""
+        return chunk_range_of(self._starts_host, self._lens_host, lo, hi)

@@ -66,12 +66,19 @@ class LazyLosses(dict):
         pending, self._pending = self._pending, None
         if pending is not None:
             values = [float(x) for x in pending.get()]
-            dict.update(self, zip(self._names, values))
-            # one value more than there are names: the session's device error word of that step (Session.error_word)
+            # one value more than there are names: the session's device error word of that step (Session.error_word).
+            # Set = a GRU time loop of the step gave up and its update was skipped on the device: the session runs the
+            # step (and those enqueued since) again on the per-step path and these losses become that run's
             if len(values) > len(self._names) and values[len(self._names)] != 0.0:
-                raise RuntimeError("the training step that produced these losses ran a GRU time loop that gave up "
-                                   "waiting for a hand-off between workgroups: its results are garbage "
-                                   "(NM_CLUSTER_LOOPS=0 runs the loops as two launches per step)")
+                sess = getattr(pending, "session", None)
+                if sess is None:
+                    raise RuntimeError("the training step that produced these losses ran a GRU time loop that gave up "
+                                       "waiting for a hand-off between workgroups: its results are garbage")
+                sess.recover_training(pending=pending)
+                values = [float(x) for x in pending.get()]
+                if values[len(self._names)] != 0.0:
+                    sess.raise_device_error()
+            dict.update(self, zip(self._names, values))
 
     __getitem__ = _after_fill("__getitem__")
     __iter__ = _after_fill("__iter__")

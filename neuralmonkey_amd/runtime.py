@@ -217,13 +217,25 @@ class HostPending:
     def __init__(self, session=None, key=None, host=None, event=None, shape=(), value=None):
         self._session, self._key, self._host, self._event, self._shape, self._value = (
             session, key, host, event, tuple(shape), value)
+        self._redirect = None
 
     def get(self) -> np.ndarray:
+        if self._redirect is not None:            # the step was run again (Session.recover_training)
+            return self._redirect.get()
         if self._value is None:
             self._event.synchronize()
             self._value = self._host.numpy().copy().reshape(self._shape)
             self._release()
         return self._value
+
+    def redirect(self, other: "HostPending") -> None:
+        """The values this copy carries are void (the step that produced them was run again): ``get`` hands out
+        ``other``'s from now on."""
+        self._redirect = other
+
+    @property
+    def session(self):
+        return self._session
 
     def _release(self):
         host, self._host = self._host, None
@@ -446,31 +458,134 @@ class Session:
         whose hand-offs timed out (ops.gru_seq_fwd / gru_seq_bwd, ``sticky``).  Their results are garbage, so whoever
         hands results to the caller looks at the word first: the trainer reads it with the step's losses
         (GenericTrainer.objective_values), inference polls it one batch late while batches are announced ahead, at once
-        otherwise (``poll_device_errors``)."""
+        otherwise (``poll_device_errors``).  A set word is not the end of the run: ``recover_training`` /
+        ``TensorFlowManager.execute`` run the affected work again on the per-step path."""
         if self._error_word is None:
             self._error_word = torch.zeros(1, dtype=torch.int32, device=self.device)
         return self._error_word
 
     def raise_device_error(self) -> None:
-        raise RuntimeError("a GRU time loop gave up waiting for a hand-off between workgroups (0.2 s without progress): "
-                           "the results of this and later steps are garbage.  NM_CLUSTER_LOOPS=0 runs the loops as "
-                           "two launches per step")
+        raise RuntimeError("a GRU time loop gave up waiting for a hand-off between workgroups (0.2 s without progress) "
+                           "and so did the stepwise fallback: the results of this and later steps are garbage")
+
+    # -- recovery: a cluster loop that gives up costs a slow step, not the run ----------------------------------
+    # A cluster loop needs every one of its workgroups resident at once (csrc/nm_gru_cluster.hip); anything that holds
+    # CUs for long -- another process on the GPU, a communication kernel, a second loop on another stream -- makes its
+    # hand-offs time out.  The launch then raises the session's error word and its results are garbage.  Nothing of
+    # that reaches the variables: the optimizer kernels skip their update while the word is set (nm_optim_apply,
+    # ``skip_word``), and the host runs the affected steps / batches again on the per-step path, which has no
+    # residency requirement, with the cluster loops off for the rest of the session.
+    def cluster_failure(self) -> bool:
+        """Blocking read of the error word (a few microseconds once the stream is idle)."""
+        if self._error_word is None or self.device.type != "cuda":
+            return False
+        return int(self._error_word.item()) != 0
+
+    def demote_cluster_loops(self) -> None:
+        """A time loop gave up: from now on this session steps its loops with two launches per step.  ONE warning;
+        raises when the loops were already off (the error word was raised by the fallback path itself)."""
+        import warnings
+        torch.cuda.synchronize(self.device)
+        if not self.use_cluster_loops:
+            self.raise_device_error()
+        self.use_cluster_loops = False
+        self.cluster_demotions = getattr(self, "cluster_demotions", 0) + 1
+        warnings.warn("a GRU time loop launched as one cluster kernel gave up waiting for a hand-off between "
+                      "workgroups (something else held compute units for 0.2 s): the affected work is run again and "
+                      "this session continues with two launches per recurrent step (what NM_CLUSTER_LOOPS=0 selects)")
+        if self._error_word is not None:
+            self._error_word.zero_()
+        self._error_pending = None
+        # graphs that were captured with a cluster launch inside must not be replayed; anything evaluated ahead of
+        # time may hold a given-up loop's results
+        self._graphs.clear()
+        self.__dict__.get("_step_graphs", {}).clear()
+        self._ahead = []
+        self._pending_ahead = None
+        torch.cuda.synchronize(self.device)
+
+    def begin_guarded_step(self, trainer, feed, lookback: int = 2) -> None:
+        """Called by a trainer before it enqueues anything of a step.  Reads the error flags of the steps that are
+        more than ``lookback`` steps old (their copies to the host finished long ago: the host stays at most that
+        many steps ahead of the device) and runs everything since a failed one again; then opens the record of the
+        new step: its feed and the host-side counters an update advances."""
+        guard = self.__dict__.setdefault("_train_guard", [])
+        if self.device.type != "cuda":
+            return
+        self.__dict__.setdefault("_guarded_trainers", weakref.WeakSet()).add(trainer)
+        if not getattr(self, "_recovering", False):
+            while len(guard) > lookback:
+                rec = guard[0]
+                if rec["pending"] is not None and float(rec["pending"].get().reshape(-1)[-1]) != 0.0:
+                    self.recover_training(0)
+                    break
+                guard.pop(0)
+        guard.append({"trainer": trainer, "feed": dict(feed), "pending": None,
+                      "snap": (self.global_step, [(t, t.snapshot_counters(self)) for t in self._guarded_trainers])})
+
+    def settle_training(self) -> None:
+        """Read every outstanding error flag of the training steps enqueued so far (blocking) and run the steps since a
+        failed one again: afterwards variables, optimizer slots and ``global_step`` are those of clean steps only.
+        Called before variables are saved or exported."""
+        guard = self.__dict__.get("_train_guard") or []
+        if self.device.type != "cuda" or getattr(self, "_recovering", False):
+            return
+        for i, rec in enumerate(list(guard)):
+            if rec["pending"] is not None and float(rec["pending"].get().reshape(-1)[-1]) != 0.0:
+                self.recover_training(i)
+                self.settle_training()              # (the steps that were run again left records of their own)
+                return
+        if guard and any(rec["pending"] is None for rec in guard) and self.cluster_failure():
+            hits = [i for i, rec in enumerate(guard) if rec["pending"] is None]
+            self.recover_training(hits[0])
+            self.settle_training()
+            return
+        del guard[:]
+
+    def attach_guarded_losses(self, trainer, pending) -> None:
+        guard = self.__dict__.get("_train_guard") or []
+        if guard and guard[-1]["trainer"] is trainer and guard[-1]["pending"] is None:
+            guard[-1]["pending"] = pending
+
+    def recover_training(self, index: int = 0, pending=None) -> None:
+        """The step of record ``index`` (or the one whose losses ``pending`` carries) ran a time loop that gave up.
+        Its update and those of the steps enqueued since were skipped on the device (the error word is sticky), so the
+        variables and optimizer slots are those of the moment before that step: switch to the per-step path, put the
+        host counters back, run those steps again from their saved feeds and point the losses their callers hold at
+        the new values."""
+        guard = self.__dict__.setdefault("_train_guard", [])
+        if pending is not None:
+            hits = [i for i, rec in enumerate(guard) if rec["pending"] is pending]
+            if not hits:
+                self.raise_device_error()          # too old to run again: nothing was saved for it
+            index = hits[0]
+        # earlier records may have failed too (the word is sticky, but a step can finish before anybody looks)
+        for i in range(index):
+            rec = guard[i]
+            if rec["pending"] is not None and float(rec["pending"].get().reshape(-1)[-1]) != 0.0:
+                index = i
+                break
+        bad = guard[index:]
+        del guard[index:]
+        self.demote_cluster_loops()
+        step, counters = bad[0]["snap"]
+        self.global_step = step
+        for trainer, snap in counters:
+            trainer.restore_counters(self, snap)
+        self._recovering = True
+        try:
+            for rec in bad:
+                out = self.run({"again": rec["trainer"].fetches}, feed_dict=rec["feed"])["again"]
+                new = out.get("losses") if isinstance(out, dict) else None
+                if rec["pending"] is not None and isinstance(new, HostPending):
+                    rec["pending"].redirect(new)
+        finally:
+            self._recovering = False
 
     def poll_device_errors(self, last: bool = False) -> None:
-        """Without stalling the streams: read the copy of the error word that the PREVIOUS call started, start the
-        next one.  ``last``: nobody announced a next batch (no look-ahead), so no later call may come to read that copy
-        -- the word is read at once; the batch's results are on the host by then and the stream has nothing left to
-        wait for."""
-        if self._error_word is None or self.device.type != "cuda":
-            return
-        pending, self._error_pending = self._error_pending, None
-        if pending is not None and int(pending.get()[0]) != 0:
+        """Kept for callers that drive a session without TensorFlowManager.execute: raise if the error word is set."""
+        if self.cluster_failure():
             self.raise_device_error()
-        if last:
-            if int(self._error_word.item()) != 0:
-                self.raise_device_error()
-            return
-        self._error_pending = self.to_host_async(self._error_word)
 
     def to_host_async(self, dev_tensor: torch.Tensor, off_stream: bool = False) -> HostPending:
         """Start copying a small device tensor to pinned host memory; the caller reads it with ``get()`` when (if)

@@ -133,12 +133,23 @@ class TensorFlowManager:
             fetches = [f for runner in runners for f in getattr(runner, "ahead_fetches", lambda: [])()]
             if fetches:
                 ahead = (fetches, _feed_dicts(lookahead, feedables, train=False))
-        while not all(ex.result is not None for ex in executables):
-            self._run_executables(default_feed_dict, executables, ahead)
-            ahead = None
-        if not train:                # (a training step's error word travels with its losses)
-            for sess in self.sessions:
-                sess.poll_device_errors(last=lookahead is None)
+        while True:
+            while not all(ex.result is not None for ex in executables):
+                self._run_executables(default_feed_dict, executables, ahead)
+                ahead = None
+            if train:                # (a training step's error word travels with its losses: Session.recover_training)
+                break
+            # inference: the results are on the host, the stream is idle -- reading the sessions' error words costs a
+            # few microseconds.  A set word = a GRU time loop launched as one cluster kernel gave up (something else
+            # held compute units): that session continues on the per-step path (one warning) and the batch is run
+            # again; only a failure of the fallback itself raises.
+            failed = [sess for sess in self.sessions if sess.cluster_failure()]
+            if not failed:
+                break
+            for sess in failed:
+                sess.demote_cluster_loops()
+            executables = [runner.get_executable(compute_losses=compute_losses, summaries=summaries,
+                                                 num_sessions=len(self.sessions)) for runner in runners]
         return [ex.result for ex in executables]
 
     # -- variables ---------------------------------------------------------------------------
@@ -166,6 +177,17 @@ class TensorFlowManager:
     def save(self, variable_files: Union[str, List[str]]) -> None:
         if self.saver is None:
             raise RuntimeError("Saver uninitialized")
+        from . import distributed as dist
+        dp = dist.current()
+        for sess in self.sessions:
+            # nothing is written while a training step's error flag is still unread: a step whose time loop gave up
+            # is run again first (its update was skipped on the device, so the variables are clean either way -- but
+            # global_step and the steps enqueued since belong to the checkpoint too)
+            sess.settle_training()
+            if dp is not None and dp.sharded_active() and sess.store.adam_m is not None:
+                # sharded optimizer: every rank holds the slots of its own slices; a checkpoint carries all of them
+                # (a collective: every rank calls save, as every rank runs every training step)
+                dp.gather_optimizer_slots(sess.store, sess.store.adam_m, sess.store.adam_v)
         if isinstance(variable_files, str) and len(self.sessions) == 1:
             self.sessions[0].store.save(variable_files, fmt=self.checkpoint_format,
                                         global_step=self.sessions[0].global_step)

@@ -29,11 +29,25 @@ class DelayedUpdateTrainer(GenericTrainer):
         self.batches_per_update = batches_per_update
         self._counter = 0                      # cumulator_counter (:138-140)
 
+    # the accumulation buffer lives across steps: a step's error flag is read before the NEXT step starts (the host
+    # stays one step ahead at most), so at most one garbage gradient -- zeroed on the device, below -- ever meets it
+    GUARD_LOOKBACK = 1
+
+    def snapshot_counters(self, sess):
+        return (GenericTrainer.snapshot_counters(self, sess), self._counter)
+
+    def restore_counters(self, sess, snap) -> None:
+        GenericTrainer.restore_counters(self, sess, snap[0])
+        self._counter = snap[1]
+
     @tensor
     def train_op(self, ctx) -> int:
         store = ctx.store
+        ctx.session.begin_guarded_step(self, ctx.feed, self.GUARD_LOOKBACK)
         self._objective_gradients(ctx)
         grad = store.ensure_grad()
+        if ctx.session.device.type == "cuda":
+            ops.zero_if(ctx.session.error_word(), grad)       # a given-up time loop's gradient never enters the buffer
         accum = ctx.buffer((id(self), "gradient_buffer"), (store.total,))
         if self._counter == 0:
             accum.copy_(grad)                                  # first batch after a reset (:160-168)

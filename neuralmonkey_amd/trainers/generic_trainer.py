@@ -17,7 +17,7 @@ from .. import ops
 from ..model.model_part import Feedable
 from ..optimizers import AdadeltaOptimizer, AdamOptimizer, Optimizer
 from ..runners.base_runner import GraphExecutor, LazyLosses, NextExecute
-from ..runtime import HostPending, tensor
+from ..runtime import HostPending, RunContext, tensor
 from .objective import Objective
 
 BIAS_REGEX = re.compile(r"[Bb]ias")
@@ -90,7 +90,13 @@ class GenericTrainer(GraphExecutor, Feedable):
     def _optim_tables(self, store) -> ops.OptimizerTables:
         key = id(store)
         if key not in self._tables:
-            self._tables[key] = ops.OptimizerTables(store, set(self.regularizable(store)), set(self.var_list(store)))
+            from .. import distributed as dist
+            dp = dist.current()
+            # data parallel: chunks end where the ranks' slices of the flat buffers end (sharded optimizer); the table
+            # is the same whether the update is sharded or replicated, so both add the same partial sums in one order
+            cuts = dp.optimizer_cuts(store) if dp is not None and (dp.world_size > 1 or dp.forced) else ()
+            self._tables[key] = ops.OptimizerTables(store, set(self.regularizable(store)), set(self.var_list(store)),
+                                                    cuts=cuts)
         return self._tables[key]
 
     # -- the training step --------------------------------------------------------------------
@@ -160,28 +166,46 @@ class GenericTrainer(GraphExecutor, Feedable):
         sess.join_side()
 
     def _apply_gradients(self, ctx) -> int:
-        """[all-reduce] -> L1/L2 terms -> per-tensor clip_by_norm -> Adam / Adadelta -> global_step += 1."""
+        """[gradient exchange] -> L1/L2 terms -> per-tensor clip_by_norm -> Adam / Adadelta -> [parameter all-gather]
+        -> global_step += 1.  With data parallelism the exchange and the update are distributed.DataParallel's
+        (replicated, or sharded over the ranks' slices of the flat buffers)."""
         from .. import distributed as dist
         sess, store = ctx.session, ctx.store
         grad = store.ensure_grad()
         dp = dist.current()
-        if dp is not None:
-            dp.all_reduce_gradients(store)
         tables = self._optim_tables(store)
-        l1l2 = tables.regularize_and_norms(store.theta, grad, self.l1_weight, self.l2_weight)
-        ctx.memo[(id(self), "l1l2")] = l1l2.clone()
         state = self._adam_state(sess, store)
         sess.global_step += 1
         state["applied"] += 1
         opt = self.optimizer
         if isinstance(opt, AdadeltaOptimizer):
-            tables.clip_adadelta(store.theta, grad, state["m"], state["v"], self.clip_norm,
-                                 opt.learning_rate(sess.global_step), opt.rho, opt.epsilon)
+            kind, params = 1, (opt.learning_rate(sess.global_step), opt.rho, opt.epsilon, 0.0)
         else:
-            tables.clip_adam(store.theta, grad, state["m"], state["v"], self.clip_norm,
-                             opt.lr_t(sess.global_step, state["applied"]), opt.beta1, opt.beta2, opt.epsilon)
+            kind, params = 0, (opt.lr_t(sess.global_step, state["applied"]), opt.beta1, opt.beta2, opt.epsilon)
+        # the update is a no-op on the device while the session's error word is set (a time loop of this step gave up:
+        # the gradient is garbage, Session.recover_training runs the step again)
+        skip = sess.error_word() if sess.device.type == "cuda" else None
+        if dp is not None and (dp.world_size > 1 or dp.forced):
+            l1l2 = dp.optimizer_step(store, tables, kind, state["m"], state["v"], self.l1_weight, self.l2_weight,
+                                     self.clip_norm, params, skip=skip)
+        else:
+            l1l2 = tables.regularize_and_norms(store.theta, grad, self.l1_weight, self.l2_weight)
+            tables.apply(kind, store.theta, grad, state["m"], state["v"], self.clip_norm, params, skip=skip)
+        ctx.memo[(id(self), "l1l2")] = l1l2.clone()
         sess.variables_changed()
         return sess.global_step
+
+    # -- what Session.recover_training puts back before it runs steps again -----------------------------------
+    GUARD_LOOKBACK = 2            # steps the host may run ahead of the oldest unchecked error flag
+
+    def snapshot_counters(self, sess):
+        state = self.__dict__.get("_adam", {}).get(id(sess.store))
+        return None if state is None else state["applied"]
+
+    def restore_counters(self, sess, snap) -> None:
+        state = self.__dict__.get("_adam", {}).get(id(sess.store))
+        if state is not None:
+            state["applied"] = snap if snap is not None else sess.global_step
 
     def _adam_state(self, sess, store):
         """The optimizer's two slots per variable (Adam: m, v; Adadelta: accum, accum_update) and the number of
@@ -196,8 +220,19 @@ class GenericTrainer(GraphExecutor, Feedable):
         if state is None:
             owners = sess.__dict__.setdefault("_adam_owner", {})
             if owners.setdefault(key, self) is self:
+                had_slots = store.adam_m is not None
                 m, v = store.ensure_adam()
-                store.slot_suffixes = tuple(self.optimizer.slot_suffixes)     # the slots' names in checkpoints
+                mine = tuple(self.optimizer.slot_suffixes)
+                if had_slots and tuple(store.slot_suffixes) != mine:
+                    # a checkpoint written by ANOTHER optimizer (Adam's signed first moment is not an Adadelta
+                    # accumulator: sqrt(accum + eps) would go NaN).  TensorFlow's Saver refuses such a restore (the
+                    # slot variables it looks for are missing); here the variables stay and the slots start afresh.
+                    import warnings
+                    warnings.warn("optimizer slots {} of the restored checkpoint do not belong to {} (slots {}): they "
+                                  "are reset to zero".format(store.slot_suffixes, type(self.optimizer).__name__, mine))
+                    m.zero_()
+                    v.zero_()
+                store.slot_suffixes = mine                                    # the slots' names in checkpoints
                 applied = sess.global_step
             else:
                 m, v = torch.zeros_like(store.theta), torch.zeros_like(store.theta)
@@ -209,6 +244,7 @@ class GenericTrainer(GraphExecutor, Feedable):
     def train_op(self, ctx) -> int:
         # one optimizer step per batch: gradient slices that are final early in the backward pass may start
         # their all-reduce right away (distributed.DataParallel.all_reduce_early)
+        ctx.session.begin_guarded_step(self, ctx.feed, self.GUARD_LOOKBACK)
         ctx.memo["dp_overlap"] = True
         self._objective_gradients(ctx)
         return self._apply_gradients(ctx)
@@ -233,10 +269,21 @@ class GenericTrainer(GraphExecutor, Feedable):
         # step keeps the host from enqueuing the next step while this one runs.  NM_DEFER_LOSSES=0: read at once.
         # (behind them travels the session's device error word: a time loop that gave up makes the step garbage)
         if DEFER_LOSSES and all(isinstance(v, torch.Tensor) and v.is_cuda for v in values):
-            return ctx.session.to_host_async(torch.stack([v.detach().reshape(()) for v in values]
-                                                         + [ctx.session.error_word()[0].float()]))
-        if ctx.session.device.type == "cuda" and int(ctx.session.error_word().item()) != 0:
-            ctx.session.raise_device_error()
+            pending = ctx.session.to_host_async(torch.stack([v.detach().reshape(()) for v in values]
+                                                            + [ctx.session.error_word()[0].float()]))
+            ctx.session.attach_guarded_losses(self, pending)
+            return pending
+        if ctx.session.cluster_failure():
+            # read at once: run the step again on the per-step path and hand out ITS losses
+            sess = ctx.session
+            guard = sess.__dict__.get("_train_guard") or []
+            if getattr(sess, "_recovering", False) or not guard or guard[-1]["trainer"] is not self:
+                sess.raise_device_error()
+            sess.recover_training(len(guard) - 1)
+            again = RunContext(sess, ctx.feed)
+            losses = [o.loss(again) for o in self.objectives]
+            l1l2 = self.regularization_losses(again)
+            return losses + [l1l2[0], l1l2[1]]
         return values
 
     @property

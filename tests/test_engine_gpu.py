@@ -474,8 +474,10 @@ def test_train_logprobs_is_the_log_softmax_of_the_train_logits(dev):
 def test_a_set_device_error_word_reaches_the_caller(dev):
     """The kernels' only way to say "my results are garbage" is the session's device error word (cluster time loops
     whose hand-offs timed out: csrc/nm_gru_cluster.hip, ``sticky_error``).  It travels to the host with a training
-    step's losses and, for inference, with one batch of delay while batches are announced ahead -- never by stalling
-    the streams.  (The word is set by hand here: the loops do not fail on a healthy device.)"""
+    step's losses and is read after every inference batch.  The first time, the session falls back to the per-step
+    path and runs the work again (tests/test_cluster_recovery_gpu.py); a word raised with the loops already off is
+    the fallback's own failure and reaches the caller as an exception.  (The word is set by hand here.)"""
+    import warnings
     from neuralmonkey_amd import synthetic
     model = synthetic.build_translation_model(vocab_src=300, vocab_tgt=300, emb=32, rnn=32, max_len=12, beam_size=0,
                                               device=str(dev))
@@ -485,15 +487,23 @@ def test_a_set_device_error_word_reaches_the_caller(dev):
     res = tfm.execute(ds, model.trainer.feedables, [model.trainer], train=True)[0]
     assert res.losses["decoder - cost"] > 0                       # a clean word: the losses read as ever
     tfm.execute(ds, model.greedy_runner.feedables, [model.greedy_runner])
-    tfm.execute(ds, model.greedy_runner.feedables, [model.greedy_runner])
+    want = tfm.execute(ds, model.greedy_runner.feedables, [model.greedy_runner])[0].outputs["target"]
+    was_on = sess.use_cluster_loops
     sess.error_word().fill_(1)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        got = tfm.execute(ds, model.greedy_runner.feedables, [model.greedy_runner])[0].outputs["target"]
+    if was_on:
+        assert got == want and not sess.use_cluster_loops
+        assert len([w for w in caught if "gave up waiting" in str(w.message)]) == 1
+        sess.error_word().fill_(1)
+    # the loops are off now: a set word is the fallback's failure
     res = tfm.execute(ds, model.trainer.feedables, [model.trainer], train=True)[0]
     with pytest.raises(RuntimeError, match="gave up waiting"):
         res.losses["decoder - cost"]
-    # inference: while the caller announces the next batch the word is polled one batch late ...
-    tfm.execute(ds, model.greedy_runner.feedables, [model.greedy_runner], lookahead=ds)      # starts the copy ...
+    sess.error_word().fill_(1)
     with pytest.raises(RuntimeError, match="gave up waiting"):
-        tfm.execute(ds, model.greedy_runner.feedables, [model.greedy_runner], lookahead=ds)  # ... the next call reads
-    # ... and the batch nobody announced a successor for (the last one of a data set) is checked before it returns
+        tfm.execute(ds, model.greedy_runner.feedables, [model.greedy_runner], lookahead=ds)
+    sess.error_word().fill_(1)
     with pytest.raises(RuntimeError, match="gave up waiting"):
         tfm.execute(ds, model.greedy_runner.feedables, [model.greedy_runner])
