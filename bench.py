@@ -202,6 +202,23 @@ def transformer_leg(args, dev):
         steps = max(len(sent) for sent in r.outputs[runner.output_series])
         out[name] = (t, steps)
     tf = flops / t_train / 1e12
+    # one cached decoding step against the fp32 matrix peak: how far the launch chain of a step is from its products
+    dec_flops = {name: synthetic.transformer_decode_step_flops(batch * (5 if name == "beam5" else 1), vocab,
+                                                               cached_len=length // 2, src_len=length)
+                 for name in ("greedy", "beam5")}
+    roofline_decode = {}
+    for name in ("greedy", "beam5"):
+        us = out[name][0] / max(1, out[name][1]) * 1e6
+        ach = dec_flops[name] / (us * 1e-6) / 1e12
+        roofline_decode[name] = {"bound": "mfma", "rows": batch * (5 if name == "beam5" else 1), "us_per_step": us,
+                                 "flops_per_step": dec_flops[name], "achieved": ach, "peak": MFMA_F32_PEAK_TF,
+                                 "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF}
+    roofline_decode["what"] = ("one cached decoding step (mean over the steps of a batch): 2 x multiply-adds of the six "
+                               "decoder layers' projections, both attention cores (own prefix at half the length, "
+                               "encoder at full length), the feed-forward blocks and the tied vocabulary projection "
+                               "(synthetic.transformer_decode_step_flops); a step is a chain of ~70 dependent launches "
+                               "of 128- or 640-row products: launch-latency-bound, not matrix-bound "
+                               "(profiles/r06_transformer_{greedy,beam}_kernel_stats.csv)")
     return {"workload": "tests/transformer.ini-shape at the Transformer-base size: 6+6 layers, d=512, 8 heads, ff 2048, "
                         "tied embeddings, B={}, len={}, V={}, CrossEntropyTrainer(l2=1e-8, clip_norm=1.0) + Adam, "
                         "weights N(0,0.05), 4 HBM-resident batches in rotation".format(batch, length, vocab),
@@ -214,7 +231,8 @@ def transformer_leg(args, dev):
             "roofline": {"bound": "mfma", "what": "whole training step: 2 x multiply-adds of every dense product, "
                                                   "forward + backward (synthetic.transformer_train_flops)",
                          "flops_per_step": flops, "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": tf / MFMA_F32_PEAK_TF}}
+                         "frac": tf / MFMA_F32_PEAK_TF},
+            "roofline_decode": roofline_decode}
 
 
 def captioning_leg(args, dev, lib):
@@ -615,7 +633,11 @@ def main():
         dp_report["how"] = ("allreduce_exposed_ms: HIP events on rank 0's compute stream around the point where the "
                             "optimizer has to wait for the gradient collectives (mean over the timed steps) = the part "
                             "of the exchange that the backward pass did not hide; bytes: flat gradient buffer per "
-                            "step and rank, early_bytes: the spans whose all-reduce starts inside the backward pass")
+                            "step and rank, early_bytes: the spans whose collective starts inside the backward pass; "
+                            "optimizer: 'sharded' = reduce-scatter -> clip + Adam on this rank's slices of the flat "
+                            "buffers -> all-gather of the parameters (NM_DP_SHARDED=0: all-reduce + the whole update on "
+                            "every rank); optimizer_ms: HIP events around norms + update (+ all-gather); "
+                            "exchanged_bytes_per_rank: what a rank sends per step with ring collectives")
 
     # ---- the other scaling mode in the same run (N > 1): BASELINE.json's wording is the STRONG split (one
     # minibatch of --batch sentences sharded over the GPUs); `value` above is the weak one unless --scaling strong
@@ -637,7 +659,8 @@ def main():
         other = {"scaling": "strong", "sentences_per_gpu": sb, "global_batch": args.batch,
                  "ms_per_step": t_strong / args.steps * 1e3,
                  "value": sb * args.length * world * args.steps / t_strong, "unit": "tokens/s",
-                 "allreduce_exposed_ms": rep["allreduce_exposed_ms"]}
+                 "allreduce_exposed_ms": rep["allreduce_exposed_ms"], "optimizer": rep.get("optimizer"),
+                 "optimizer_ms": rep.get("optimizer_ms")}
     if dp:
         dp.timing = False
 

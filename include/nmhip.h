@@ -317,8 +317,17 @@ typedef struct nm_decoder_step {
      * becomes a gather in the epilogues: gates = sigmoid(h.Wg_h + in_table[id, :2*rnn] + bg), xc = in_table[id,
      * 2*rnn:3*rnn], the output projection adds in_table[id, 3*rnn:]; the left half of `cat` is then not read. */
     const float* in_table; int64_t ld_table; const int32_t* in_ids;
+    /* Optional, with input tables: a ZERO-initialised workspace of nm_dec_step_cluster_workspace_bytes(rows, rnn)
+     * bytes that belongs to this decoder alone.  When the shape is taken (nm_dec_step_cluster_supported: greedy-sized
+     * steps, rnn 256 / 384 / 512) the gates, the candidate + blend, the attention query and the state part of the
+     * output projection (decoders/decoder.py:279-325) run as ONE launch of workgroup clusters with tagged hand-offs
+     * instead of three dependent launches; `sticky_error` is the error word of nm_gru_seq_fwd: set when the hand-offs
+     * timed out (the step's results are garbage then; the caller runs the batch again without the workspace). */
+    void* cluster_ws; int64_t cluster_ws_bytes; uint32_t* sticky_error;
 } nm_decoder_step;
 int nm_decoder_step_fused(void* stream, const nm_decoder_step* step);
+int nm_dec_step_cluster_supported(int64_t rows, int64_t rnn, int64_t attn_state, int64_t out);
+int64_t nm_dec_step_cluster_workspace_bytes(int64_t rows, int64_t rnn);
 
 /* ---- vocabulary-axis rows: tf.argmax / tf.nn.log_softmax / sequence_loss ----------------------
  * decoders/autoregressive.py:470 (argmax, first max wins), :289-316,351-375 (xent, log-probs) */

@@ -121,6 +121,8 @@ SIGNATURES = {
     "nm_attn_fwd_partials": (I, [P, P, P, P, P, P, P, L, L, L, L, L, P, L]),
     "nm_step_group": (I, [P, L, P, ctypes.c_int32]),
     "nm_decoder_step_fused": (I, [P, P]),
+    "nm_dec_step_cluster_supported": (I, [L, L, L, L]),
+    "nm_dec_step_cluster_workspace_bytes": (L, [L, L]),
     "nm_prof_stream_read": (I, [P, P, L, P]),
     "nm_beam_topk_step_tiles": (I, [P, P, L, P, L, L, L, L, P, P, P, P, I, P, P, P, P, P, P, P, P, L, P, P, P]),
 }
@@ -168,7 +170,8 @@ class DecoderStep(ctypes.Structure):
                 [("ld_w_vocab", L), ("b_vocab", P), ("out_act", ctypes.c_int32), ("vocab_trans_b", ctypes.c_int32)] +
                 [(n, L) for n in ("ld_cat", "ld_ctx", "ld_wg", "ld_wcx", "ld_wch", "ld_wq", "ld_wo_h", "ld_wo_e",
                                   "ld_wo_c")] +
-                [("in_table", P), ("ld_table", L), ("in_ids", P)])
+                [("in_table", P), ("ld_table", L), ("in_ids", P)] +
+                [("cluster_ws", P), ("cluster_ws_bytes", L), ("sticky_error", P)])
 
 
 def load():

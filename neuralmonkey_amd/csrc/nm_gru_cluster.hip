@@ -554,6 +554,194 @@ __global__ __launch_bounds__(512, 3) void gru_cluster_bwd_kernel(GruClu q) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// One DECODING step's recurrent part as one launch (round 6): Decoder.next_state up to the attention query
+// (decoders/decoder.py:279-325, plain GRUCell + input tables, what nm_decoder_step_fused launched as three dependent
+// step groups: 7.2 + 7.2 + 9.4 us of kernels and two graph edges per greedy step):
+//   stage 1   r | u = sigmoid(h . Wg_h + table[id, :2H] + bg),  rh = r * h                       -> publishes rh
+//   stage 2   c = tanh(rh . Wc_h + table[id, 2H:3H]),  h' = u h + (1 - u) c                     -> publishes h'
+//   stage 3   y = h' . Wq + bq  (attention query),  pre = h' . Wo_h + table[id, 3H:] + bo        -> plain stores
+// Same clusters, roles, granules and hand-offs as the time loops above (16 rows per cluster, H / 16 workgroups of 16
+// hidden units each, H / 64 waves that split K); stage 3's A + O output columns are dealt to the cluster's workgroups
+// tile by tile.  The weights are NOT stationary here -- a launch is one step, the vocabulary projection and the argmax
+// sit between two of them -- so every wave fetches its slices ([N, K] transposed weights: 16 bytes per lane) while
+// the roles are agreed.  Nothing is zeroed between launches: the header counts launches (``epoch``), tags are
+// 4 epoch + stage, and the workgroup that finishes last puts the role counters back and advances the epoch.
+// ---------------------------------------------------------------------------------------------------------------
+#define DEC_T3_MAX 4
+struct DecClu {
+    int R, H, A, O, ncl;                       // rows, state, query and output widths; clusters of 16 rows
+    const float* h_in; long ld_h;
+    const float* table; long ld_table; const int* ids;
+    const float* bg; const float* bq; const float* bo;
+    const float* wg_t; long ld_wg;             // [2H][K = H] state half of the gates kernel, transposed
+    const float* wc_t; long ld_wc;             // [H][H]
+    const float* wq_t; long ld_wq;             // [A][H]
+    const float* wo_t; long ld_wo;             // [O][H]
+    float* h_out; long ld_ho; float* h_out2; long ld_ho2;
+    float* y; long ld_y; float* pre; long ld_pre;
+    unsigned* hdr; u64* xa; u64* xb;
+    int force_global; unsigned* sticky; int force_fail;
+};
+
+// header words: [0] error, [1] arrivals, [2] workgroups done, [3] epoch, [8 + x] tickets of XCD x
+__device__ __forceinline__ void dec_load_w(const float* Wt, long ld, int n_first, int nmax, int k_wave, int lane,
+                                           float (&w)[4][4]) {
+    const int n16 = lane & 15, kq = lane >> 4;
+    const float* p = Wt + (long)min(n_first + n16, nmax - 1) * ld + k_wave + 4 * kq;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float4 v = *reinterpret_cast<const float4*>(p + 16 * c);
+        w[c][0] = v.x; w[c][1] = v.y; w[c][2] = v.z; w[c][3] = v.w;
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void dec_step_cluster_kernel(DecClu q) {
+    constexpr int NCH = 4, RT = 1;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NW = (int)(blockDim.x >> 6);
+    const int H = q.H, R = q.R;
+    const int nj = H / 16;
+    const int nt3 = (q.A + q.O) / 16, t3n = (nt3 + nj - 1) / nj;          // stage-3 tiles, per workgroup
+    gu32* err = (gu32*)q.hdr;
+    if (q.force_fail && blockIdx.x == 0 && tid == 0) __hip_atomic_store(err, 1u, NM_RLX_AGENT);
+    // (the launch's epoch travels through a word BEHIND the reduction buffers: no static __shared__ object next to the
+    // dynamic region, and nothing a fast wave writes later can land on it)
+    unsigned* epoch_s = reinterpret_cast<unsigned*>(lds + (long)NW * (3 + t3n) * 256);
+    if (tid == 0) *epoch_s = __hip_atomic_load((gu32*)q.hdr + 3, NM_RLX_AGENT);
+    const CluRole role = clu_roles(q.hdr, q.ncl, nj, reinterpret_cast<int*>(lds), q.force_global);
+    const unsigned epoch = *epoch_s;
+    auto finish = [&]() {
+        // the last workgroup of the launch puts the role counters back and opens the next epoch (every workgroup has
+        // read the counters by then: it counts itself done only behind its own role agreement)
+        if (tid == 0) {
+            if (q.sticky && __hip_atomic_load(err, NM_RLX_AGENT) != 0) __hip_atomic_store((gu32*)q.sticky, 1u, NM_RLX_AGENT);
+            const unsigned d = __hip_atomic_fetch_add((gu32*)q.hdr + 2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (d == gridDim.x - 1) {
+                for (int x = 0; x < 8; ++x) __hip_atomic_store((gu32*)q.hdr + 8 + x, 0u, NM_RLX_AGENT);
+                __hip_atomic_store((gu32*)q.hdr + 1, 0u, NM_RLX_AGENT);
+                __hip_atomic_store((gu32*)q.hdr + 2, 0u, NM_RLX_AGENT);
+                __hip_atomic_store(err, 0u, NM_RLX_AGENT);
+                __hip_atomic_store((gu32*)q.hdr + 3, epoch + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+    if (!role.active) { finish(); return; }
+    __builtin_amdgcn_s_setprio(3);
+    const int jb = role.jb, row0 = role.cl * 16;
+    const int k_wave = wave * 16 * NCH;
+    const unsigned tag1 = 4u * epoch + 1u, tag2 = 4u * epoch + 2u;
+    float* red1 = lds;                                   // [NW][2][4][64]
+    float* red2 = red1 + (long)NW * 2 * 256;             // [NW][1][4][64]
+    float* red3 = red2 + (long)NW * 256;                 // [NW][t3n][4][64]
+
+    // this wave's K-slices of the weights it multiplies (requested now, used stage by stage)
+    float wr[NCH][4], wu[NCH][4], wk[NCH][4], w3[DEC_T3_MAX][NCH][4];
+    dec_load_w(q.wg_t, q.ld_wg, 16 * jb, 2 * H, k_wave, lane, wr);
+    dec_load_w(q.wg_t, q.ld_wg, H + 16 * jb, 2 * H, k_wave, lane, wu);
+    dec_load_w(q.wc_t, q.ld_wc, 16 * jb, H, k_wave, lane, wk);
+#pragma unroll
+    for (int i = 0; i < DEC_T3_MAX; ++i) {
+        const int t3 = jb * t3n + i;                      // tile of [y | pre]
+        if (i < t3n && t3 < nt3) {
+            if (16 * t3 < q.A) dec_load_w(q.wq_t, q.ld_wq, 16 * t3, q.A, k_wave, lane, w3[i]);
+            else dec_load_w(q.wo_t, q.ld_wo, 16 * t3 - q.A, q.O, k_wave, lane, w3[i]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w3[i][c][j] = 0.0f;
+        }
+    }
+
+    // epilogue threads: one element (row, col) of a 16x16 tile each, laid out as skinny16_tile maps it
+    const bool epi = tid < 256;
+    const int reg = (tid >> 6) & 3, ln = tid & 63;
+    const int rloc = 4 * (ln >> 4) + reg, c16 = ln & 15;
+    const int row = row0 + rloc, col = 16 * jb + c16;
+    const bool mine = epi && row < R;
+    const int rr = min(row, R - 1);
+    const float* trow = q.table + (long)(mine ? q.ids[rr] : 0) * q.ld_table;
+    float hreg = 0.0f, xr = 0.0f, xu = 0.0f, xc = 0.0f;
+    if (mine) {
+        hreg = q.h_in[(long)row * q.ld_h + col];
+        xr = trow[col] + q.bg[col];
+        xu = trow[H + col] + q.bg[H + col];
+        xc = trow[2 * H + col];
+    }
+    u64* XA = q.xa + (long)role.cl * 16 * H;             // this cluster's granules of r*h ...
+    u64* XB = q.xb + (long)role.cl * 16 * H;             // ... and of h'
+    float a[4][4];
+    CluWait cw;
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    float ureg = 0.0f;
+    // ---- stage 1: gates
+    {
+        clu_load_plain(q.h_in, q.ld_h, R, row0, k_wave, lane, a);
+        f32x4 ar = zero, au = zero;
+        clu_mma(ar, a, wr);
+        clu_mma(au, a, wu);
+        clu_put(red1, 2, wave, 0, lane, ar);
+        clu_put(red1, 2, wave, 1, lane, au);
+    }
+    __syncthreads();
+    if (epi) {
+        const float sr = clu_get(red1, 2, NW, 0, reg, ln), su = clu_get(red1, 2, NW, 1, reg, ln);
+        const float r = mine ? nm_sigmoid(xr + sr) : 0.0f;
+        ureg = mine ? nm_sigmoid(xu + su) : 0.0f;
+        clu_publish<RT, NCH>(XA, role.local, 0, rloc, col, tag1, mine ? r * hreg : 0.0f);
+    }
+    // ---- stage 2: candidate + blend
+    clu_wait<RT, NCH>(XA, wave, lane, tag1, err, cw);
+    {
+        clu_gather<RT, NCH>(XA, wave, lane, 0, 0, tag1, err, cw, a);
+        f32x4 ac = zero;
+        clu_mma(ac, a, wk);
+        clu_put(red2, 1, wave, 0, lane, ac);
+    }
+    __syncthreads();
+    if (epi) {
+        const float sc = clu_get(red2, 1, NW, 0, reg, ln);
+        float hn = 0.0f;
+        if (mine) {
+            const float c = nm_tanh(xc + sc);
+            hn = ureg * hreg + (1.0f - ureg) * c;
+            q.h_out[(long)row * q.ld_ho + col] = hn;
+            if (q.h_out2) q.h_out2[(long)row * q.ld_ho2 + col] = hn;
+        }
+        clu_publish<RT, NCH>(XB, role.local, 0, rloc, col, tag2, hn);
+    }
+    // ---- stage 3: attention query and the state part of the output projection
+    clu_wait<RT, NCH>(XB, wave, lane, tag2, err, cw);
+    {
+        clu_gather<RT, NCH>(XB, wave, lane, 0, 0, tag2, err, cw, a);
+#pragma unroll
+        for (int i = 0; i < DEC_T3_MAX; ++i) {
+            if (i < t3n) {
+                f32x4 acc = zero;
+                clu_mma(acc, a, w3[i]);
+                clu_put(red3, t3n, wave, i, lane, acc);
+            }
+        }
+    }
+    __syncthreads();
+    if (mine) {
+        for (int i = 0; i < t3n; ++i) {
+            const int t3 = jb * t3n + i;
+            if (t3 >= nt3) break;
+            const float s3 = clu_get(red3, t3n, NW, i, reg, ln);
+            const int c3 = 16 * t3 + c16;
+            if (c3 < q.A) q.y[(long)row * q.ld_y + c3] = s3 + (q.bq ? q.bq[c3] : 0.0f);
+            else {
+                const int co = c3 - q.A;
+                q.pre[(long)row * q.ld_pre + co] = s3 + (q.bo ? q.bo[co] : 0.0f) + trow[3 * H + co];
+            }
+        }
+    }
+    finish();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
 struct CluShape {
@@ -758,3 +946,69 @@ extern "C" int nm_gru_seq_failed(const void* workspace) {
     if (!workspace || hipMemcpy(&flag, workspace, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return flag != 0 ? 1 : 0;
 }
+
+static bool dec_clu_shape(long R, long H, long A, long O, int* ncl_out, int* grid_out) {
+    if (H < 256 || H > 512 || H % 128 != 0 || R < 1 || A % 16 || O % 16 || A < 16 || O < 16) return false;
+    int ncu = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 8) return false;
+    const int nj = (int)(H / 16), ncl = (int)((R + 15) / 16), cpx = (ncl + 7) / 8;
+    if (cpx * nj > ncu / 8) return false;                                   // every cluster on ONE XCD
+    const long nt3 = (A + O) / 16;
+    if ((nt3 + nj - 1) / nj > DEC_T3_MAX) return false;
+    *ncl_out = ncl;
+    *grid_out = ncu;
+    return true;
+}
+
+extern "C" int nm_dec_step_cluster_supported(int64_t R, int64_t H, int64_t A, int64_t O) {
+    int ncl, grid;
+    return dec_clu_shape(R, H, A, O, &ncl, &grid) ? 1 : 0;
+}
+
+// header + the granules of r*h and h' (8 bytes per value).  The workspace must be ZERO when it is first used (tags
+// and counters start there) and is never cleared again.
+extern "C" int64_t nm_dec_step_cluster_workspace_bytes(int64_t R, int64_t H) {
+    const int64_t ncl = (R + 15) / 16;
+    return CLU_HDR_BYTES + ncl * 16 * H * 8 * 2;
+}
+
+// internal: groups 1-3 of nm_decoder_step_fused (input tables) as one launch; false when the shape is not taken
+bool nm_dec_step_cluster_try(hipStream_t st, int64_t R, int64_t H, int64_t A, int64_t O, const float* h_in, int64_t ld_h,
+                             const float* table, int64_t ld_table, const int32_t* ids, const float* bg, const float* bq,
+                             const float* bo, const float* wg_t, int64_t ld_wg, const float* wc_t, int64_t ld_wc,
+                             const float* wq_t, int64_t ld_wq, const float* wo_t, int64_t ld_wo, float* h_out,
+                             int64_t ld_ho, float* h_out2, int64_t ld_ho2, float* y, int64_t ld_y, float* pre,
+                             int64_t ld_pre, void* workspace, int64_t workspace_bytes, uint32_t* sticky) {
+    int ncl = 0, grid = 0;
+    if (!workspace || !dec_clu_shape(R, H, A, O, &ncl, &grid)) return false;
+    if (workspace_bytes < nm_dec_step_cluster_workspace_bytes(R, H)) return false;
+    if (!nm_aligned16(h_in) || ld_h % 4 || !nm_aligned16(wg_t) || ld_wg % 4 || !nm_aligned16(wc_t) || ld_wc % 4 ||
+        !nm_aligned16(wq_t) || ld_wq % 4 || !nm_aligned16(wo_t) || ld_wo % 4 || !nm_aligned16(workspace) || !bg)
+        return false;
+    const int nw = (int)(H / 64), nj = (int)(H / 16);
+    const int t3n = (int)(((A + O) / 16 + nj - 1) / nj);
+    const size_t lds = (size_t)nw * (2 + 1 + t3n) * 1024 + 64;
+    if (!clu_prepare(dec_step_cluster_kernel, lds)) return false;
+    DecClu q;
+    q.R = (int)R; q.H = (int)H; q.A = (int)A; q.O = (int)O; q.ncl = ncl;
+    q.h_in = h_in; q.ld_h = ld_h; q.table = table; q.ld_table = ld_table; q.ids = ids;
+    q.bg = bg; q.bq = bq; q.bo = bo;
+    q.wg_t = wg_t; q.ld_wg = ld_wg; q.wc_t = wc_t; q.ld_wc = ld_wc; q.wq_t = wq_t; q.ld_wq = ld_wq; q.wo_t = wo_t; q.ld_wo = ld_wo;
+    q.h_out = h_out; q.ld_ho = ld_ho; q.h_out2 = h_out2; q.ld_ho2 = ld_ho2; q.y = y; q.ld_y = ld_y; q.pre = pre; q.ld_pre = ld_pre;
+    q.hdr = reinterpret_cast<unsigned*>(workspace);
+    q.xa = reinterpret_cast<u64*>(reinterpret_cast<char*>(workspace) + CLU_HDR_BYTES);
+    q.xb = q.xa + (long)ncl * 16 * H;
+    q.sticky = sticky;
+    {
+        const char* place = getenv("NM_CLUSTER_PLACEMENT");
+        q.force_global = (place && strcmp(place, "blockidx") == 0) ? 1 : 0;
+        int left = clu_force_fail.load(std::memory_order_relaxed);
+        q.force_fail = 0;
+        while (left > 0 && !clu_force_fail.compare_exchange_weak(left, left - 1, std::memory_order_relaxed)) { }
+        if (left > 0) q.force_fail = 1;
+    }
+    hipLaunchKernelGGL(dec_step_cluster_kernel, dim3(grid), dim3(nw * 64), lds, st, q);
+    return hipGetLastError() == hipSuccess;
+}
+

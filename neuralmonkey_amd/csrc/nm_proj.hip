@@ -35,7 +35,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define PJ_NBUF 4
+#define PJ_NBUF 3
 #define PJ_BIAS_MAX 4096                  // columns of one workgroup's range (bias staged in LDS)
 
 struct ProjArgs {
@@ -49,7 +49,7 @@ struct ProjArgs {
     int swz;                              // grid % 8 == 0: workgroups of one XCD take consecutive (row tile, range) units
     long* dbg;                            // NM_PROJ_ASTAT_DBG_PTR: per-chunk clock stamps of two workgroups (tools/proj_astat_probe.py stamps)
     int ablate;                           // timing ablations (NM_PROJ_ASTAT_ABLATE): 1 no weight stream, 2 no matrix work,
-                                          // 8 no per-chunk wait + barrier, 16 no statistics arithmetic
+                                          // 8 no per-chunk wait + barrier, 16 no statistics arithmetic, 32 no sum exp
 };
 
 // one LDS-DMA piece: 64 lanes x 16 bytes -> 1 KB at the wave-uniform LDS byte address ``dst``
@@ -83,14 +83,13 @@ __device__ __forceinline__ void pj_for_each(F& f, std::integer_sequence<int, Cs.
 
 // KC: K / 128; CK: k-rows per chunk (64: a 16 KB image; 128 measured no faster)
 //
-// Schedule.  The matrix pipe of a SIMD is shared by two waves (w and w + 4).  Whatever a wave does that is not an
-// MFMA -- issuing its LDS-DMA pieces, requesting its rows, the statistics of the block that just ended -- only costs
-// matrix time if its SIMD partner does the same thing at the same moment, which is exactly what happens when both
-// run the same code behind the same barrier (measured: 2.15 us per chunk against 1.71 us of matrix time, and 2 us of
-// idle pipe per block for the statistics).  So the two halves of the workgroup do their bookkeeping half a chunk
-// apart: the EARLY waves (0-3) at the top of a chunk, the LATE waves (4-7) in the middle of it, and the epilogue of a
-// block is cut into its four accumulator rows, one per chunk of the next block, read back from an LDS copy of the
-// accumulators (the registers are accumulating the next block by then).
+// What was measured on the way (profiles/r06_proj_astat_*.txt): the two waves that share a SIMD share its matrix pipe
+// AND its vector issue, so everything a wave does besides MFMAs -- LDS-DMA issue (~150 cycles a piece), the
+// statistics arithmetic -- comes out of the pair's matrix time wherever it is placed: doing the epilogue of the two
+// waves half a chunk apart, or row by row during the next block from an LDS copy of the accumulators, moved the
+// time around and added instructions (19.6 -> 20.2 us per 64-column block).  The shader clock under this mix of
+// MFMA + LDS + HBM traffic is 2.12 GHz (2.40 in a bare MFMA loop): the matrix time of a block is 15.4 us, not 13.65.
+// So: the simplest schedule, and as few vector instructions per output as the statistics allow.
 template <int KC, int CK>
 __global__ __launch_bounds__(512, 2) void proj_astat_kernel(ProjArgs g) {
     constexpr int BUF = CK * 64;                 // floats of one chunk image: CK k-rows x 64 columns
@@ -98,8 +97,7 @@ __global__ __launch_bounds__(512, 2) void proj_astat_kernel(ProjArgs g) {
     constexpr int RPW = CK / 8;                  // k-rows of a chunk that one wave fetches
     constexpr int S = CK / 4;                    // MFMA steps per chunk
     constexpr int D = 2;                         // B fragments in flight (S % D == 0: the ring runs on across chunks)
-    static_assert(S % D == 0 && (S / 2) % D == 0, "the fragment ring must close over half a chunk");
-    static_assert(NCB >= 2, "two chunks per block at least");
+    static_assert(S % D == 0, "the fragment ring must close over a chunk");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const long t_start = g.dbg ? (long)wall_clock64() : 0;
     const long c_start = g.dbg ? (long)clock64() : 0;             // shader clock: (c_end - c_start) / wall time = the frequency
@@ -107,8 +105,6 @@ __global__ __launch_bounds__(512, 2) void proj_astat_kernel(ProjArgs g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kq = lane >> 4;
-    const bool late = wave >= 4;
-    float* sav_s = bias_s + PJ_BIAS_MAX + wave * 1024;             // this wave's copy of its accumulators [p][lane][r]
 
     int v = (int)blockIdx.x;
     if (g.swz) v = (v & 7) * ((int)gridDim.x >> 3) + (v >> 3);
@@ -133,20 +129,18 @@ __global__ __launch_bounds__(512, 2) void proj_astat_kernel(ProjArgs g) {
 #pragma unroll
         for (int u = 0; u < RPW / 4; ++u) pj_dma16(src + (long)(4 * u) * g.ldw, dst + (unsigned)(4 * u * 64 * 4));
     };
-    // early waves run two chunks ahead of the matrix work, late waves (who issue half a chunk later) three
     issue(0);
     issue(1);
-    if (late) issue(2);
 
-    // the bias of this range
+    // the bias of this range, pre-multiplied copies are not needed: it is added to the logits as it is
     {
         const int ncol = min(g.N, tile1 * 128) - col_first;
         for (int i = tid; i < ncol; i += 512) bias_s[i] = g.bias ? g.bias[col_first + i] : 0.0f;
     }
     // this wave's 16 rows, for the whole launch: a[4 j + q] = A[row][16 j + 4 kq + q].  They arrive chunk by chunk
-    // while the first block is computed: a CU ingests its rows (256 KB at K = 512) at the rate it fills its L1 --
-    // ~10 us if the matrix work had to wait for all of it.  (Rows past M re-read row M - 1: their outputs are never
-    // stored and rows do not mix.)
+    // while the first block is computed (the k-slice of chunk c + 2 is requested when chunk c starts): a CU ingests
+    // its rows (256 KB at K = 512) at the rate it fills its L1 -- ~10 us if the matrix work had to wait for all of it.
+    // (Rows past M re-read row M - 1: their outputs are never stored and rows do not mix.)
     float a[32 * KC];
     const float* a_src = g.A + (long)min(m0 + 16 * wave + n, g.M - 1) * g.lda + 4 * kq;
     auto load_a = [&](int c) {                                    // the registers chunk c multiplies
@@ -160,78 +154,85 @@ __global__ __launch_bounds__(512, 2) void proj_astat_kernel(ProjArgs g) {
 #pragma unroll
     for (int j = 0; j < 32 * KC; ++j) a[j] = 0.0f;
     load_a(0);
-    load_a(1);
-    if (NCB > 2 && late) load_a(2);                               // (late waves request three chunks ahead, like their pieces)
+    if (NCB > 1) load_a(1);
 
     f32x4 acc[4];
     const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int p = 0; p < 4; ++p) acc[p] = zero;
     // running statistics of the current 128-column tile, per row r of this lane (rows 4 kq + r): the lane's maximum so
-    // far (first occurrence) and sum exp(x - that maximum)
+    // far (first occurrence) and sum 2^((x - that maximum) log2 e)
+    constexpr float L2E = 1.4426950408889634f;
     float rs[4], bv[4];
     int bi[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { rs[r] = 0.0f; bv[r] = -INFINITY; bi[r] = 0x7fffffff; }
 
     const int row_lane0 = m0 + 16 * wave + 4 * kq;                // first of this lane's four rows
-    // one accumulator row of block ``blk``: x[p] = the lane's four consecutive columns
-    auto epilogue_row = [&](int blk, int r, float x0, float x1, float x2, float x3) {
+    auto epilogue = [&](int blk) {
         const int nb = col_first + 64 * blk;
         const int col = nb + 4 * n;
         const bool okc = col < g.N;                                // N % 4 == 0: the whole float4 or nothing
         float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (okc) b4 = *reinterpret_cast<const float4*>(bias_s + (col - col_first));
-        float x[4] = {x0 + b4.x, x1 + b4.y, x2 + b4.z, x3 + b4.w};
-        const int row = row_lane0 + r;
-        if (g.C && okc && row < g.M)
-            *reinterpret_cast<float4*>(g.C + (long)row * g.ldc + col) = make_float4(x[0], x[1], x[2], x[3]);
-        if (g.ablate & 16) return;
-        if (!okc) { x[0] = x[1] = x[2] = x[3] = -INFINITY; }
-        const float before = bv[r];
+        if (!okc) b4.x = b4.y = b4.z = b4.w = -INFINITY;           // columns past N: never a maximum, exp -> 0
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
-            if (x[p] > bv[r]) { bv[r] = x[p]; bi[r] = col + p; }               // ascending columns, strict >
-        if (bv[r] > -INFINITY) {
-            float sum = rs[r] * __expf(before - bv[r]);                        // (before = -inf: rs = 0, exp(-inf) = 0)
-#pragma unroll
-            for (int p = 0; p < 4; ++p) sum += __expf(x[p] - bv[r]);
-            rs[r] = sum;
+        for (int r = 0; r < 4; ++r) {
+            const float x0 = acc[0][r] + b4.x, x1 = acc[1][r] + b4.y, x2 = acc[2][r] + b4.z, x3 = acc[3][r] + b4.w;
+            const int row = row_lane0 + r;
+            if (g.C && okc && row < g.M)
+                *reinterpret_cast<float4*>(g.C + (long)row * g.ldc + col) = make_float4(x0, x1, x2, x3);
+            if (g.ablate & 16) continue;
+            // first maximum of the four (ascending columns), then against the running one (strict >: earlier wins)
+            const float m01 = fmaxf(x0, x1), m23 = fmaxf(x2, x3), m4 = fmaxf(m01, m23);
+            const int i4 = col + (x0 == m4 ? 0 : (x1 == m4 ? 1 : (x2 == m4 ? 2 : 3)));
+            const float before = bv[r];
+            const bool up = m4 > before;
+            bv[r] = up ? m4 : before;
+            bi[r] = up ? i4 : bi[r];
+            if (g.ablate & 32) continue;
+            // sum exp(x - max) in base 2: one fma + one v_exp_f32 per value; (max = -inf only while every column so
+            // far was past N: the products below are NaN then and the sum is re-started by the select)
+            const float ml = bv[r] * L2E;
+            float sum = rs[r] * __builtin_amdgcn_exp2f(fmaf(before, L2E, -ml));
+            sum += __builtin_amdgcn_exp2f(fmaf(x0, L2E, -ml));
+            sum += __builtin_amdgcn_exp2f(fmaf(x1, L2E, -ml));
+            sum += __builtin_amdgcn_exp2f(fmaf(x2, L2E, -ml));
+            sum += __builtin_amdgcn_exp2f(fmaf(x3, L2E, -ml));
+            rs[r] = bv[r] > -INFINITY ? sum : 0.0f;
         }
-        if (blk & 1) {                       // the tile is complete: merge the 16 lanes of the row, write, reset
+        if (blk & 1) {                       // the tile is complete: merge the 16 lanes of each row, write, reset
             const int tile = tile0 + (blk >> 1);
-            float mv = bv[r];
-            int mi = bi[r];
-            pj_argmax_step<0xB1>(mv, mi);
-            pj_argmax_step<0x4E>(mv, mi);
-            pj_argmax_step<0x141>(mv, mi);
-            pj_argmax_step<0x140>(mv, mi);
-            const float mine = bv[r] > -INFINITY ? rs[r] * __expf(bv[r] - mv) : 0.0f;
-            const float tot = pj_row16_sum(mine);
-            if (n == 0 && row < g.M) {
-                float4 rec;
-                rec.x = mv; rec.y = tot; rec.z = __int_as_float(mi); rec.w = 0.0f;
-                *reinterpret_cast<float4*>(g.stats + ((long)row * g.ntile + tile) * 4) = rec;
-            }
-            rs[r] = 0.0f; bv[r] = -INFINITY; bi[r] = 0x7fffffff;
-        }
-    };
-    // everything of a chunk that is not matrix work; ``gi`` = the chunk the matrix pipe is working on
-    auto bookkeeping = [&](int gi, int blk, int c, int ahead) {
-        if (blk == 0 && c + ahead < NCB) load_a(c + ahead);       // (the first block: the rows are still arriving)
-        issue(gi + ahead);
-        if (blk > 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (r % NCB == c)
-                    epilogue_row(blk - 1, r, sav_s[(0 * 64 + lane) * 4 + r], sav_s[(1 * 64 + lane) * 4 + r],
-                                 sav_s[(2 * 64 + lane) * 4 + r], sav_s[(3 * 64 + lane) * 4 + r]);
+            for (int r = 0; r < 4; ++r) {
+                float mv = bv[r];
+                int mi = bi[r];
+                pj_argmax_step<0xB1>(mv, mi);
+                pj_argmax_step<0x4E>(mv, mi);
+                pj_argmax_step<0x141>(mv, mi);
+                pj_argmax_step<0x140>(mv, mi);
+                const float mine = bv[r] > -INFINITY ? rs[r] * __builtin_amdgcn_exp2f((bv[r] - mv) * L2E) : 0.0f;
+                const float tot = pj_row16_sum(mine);
+                const int row = row_lane0 + r;
+                if (n == 0 && row < g.M) {
+                    float4 rec;
+                    rec.x = mv; rec.y = tot; rec.z = __int_as_float(mi); rec.w = 0.0f;
+                    *reinterpret_cast<float4*>(g.stats + ((long)row * g.ntile + tile) * 4) = rec;
+                }
+                rs[r] = 0.0f; bv[r] = -INFINITY; bi[r] = 0x7fffffff;
+            }
         }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[p] = zero;
     };
 
+    // One continuous stream of MFMA steps over the chunks; the B fragment of a step is read from LDS D steps ahead,
+    // across chunk boundaries too: chunk gi + 1 is complete in LDS from the barrier that opens chunk gi (every wave
+    // waited for its pieces before it), so the tail of chunk gi reads the head of chunk gi + 1 and the barrier
+    // between them costs no LDS round trip.
     const float* bl = lds + (4 * kq) * 64 + 4 * n;                 // this lane's corner of a chunk image
     auto frag = [&](const float* bp, int s) { return *reinterpret_cast<const float4*>(bp + (16 * (s >> 2) + (s & 3)) * 64); };
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // the first chunks (this wave's pieces), the bias, the rows
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // chunks 0, 1 (this wave's pieces), the bias, the rows
     __builtin_amdgcn_s_barrier();
     float4 ring[D];
 #pragma unroll
@@ -242,34 +243,23 @@ __global__ __launch_bounds__(512, 2) void proj_astat_kernel(ProjArgs g) {
         // registers a[] must be indexed by constants)
         auto chunk = [&](auto c_tag) {
             constexpr int c = decltype(c_tag)::value;
-            if (gi > 0) {
-                // Behind this barrier every piece of chunk gi + 1 is in LDS (the tail of chunk gi reads its head):
-                // the early waves waited for theirs just now, the late ones in the middle of chunk gi - 1; and
-                // everybody is done reading chunk gi - 1, whose buffer the next pieces overwrite.
-                if (!late && !(g.ablate & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (!(g.ablate & 8)) __builtin_amdgcn_s_barrier();
-            }
-            if (c == 0 && blk > 0) {       // the block that just ended: its accumulators go aside, row by row they
-#pragma unroll                              // become logits + statistics during the next chunks
-                for (int p = 0; p < 4; ++p) {
-                    *reinterpret_cast<f32x4*>(sav_s + (p * 64 + lane) * 4) = acc[p];
-                    acc[p] = zero;
-                }
+            if (gi > 0 && !(g.ablate & 8)) {
+                // every DMA piece this wave issued (chunks <= gi + 1, the youngest a whole chunk of matrix work ago)
+                // and every logits store has landed; behind the barrier that holds for all waves, and everybody is
+                // done reading chunk gi - 1, whose buffer chunk gi + 2 overwrites
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
             }
             if (g.dbg && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 101) && gi < 60)
                 g.dbg[(blockIdx.x ? 64 : 0) + gi] = (long)wall_clock64();
-            if (!late) bookkeeping(gi, blk, c, 2);
+            if (blk == 0 && c + 2 < NCB) load_a(c + 2);          // (the first block: the rows are still arriving)
+            issue(gi + 2);
+            if (c == 0 && blk > 0) epilogue(blk - 1);
             const float* bp = bl + (gi % PJ_NBUF) * BUF;
             const float* bn = bl + ((gi + 1) % PJ_NBUF) * BUF;
             if (g.ablate & 2) { ++gi; return; }
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                if (s == S / 2 && late) {
-                    // the late waves' turn: their pieces of chunk gi + 2 (issued half a chunk + one chunk ago) have to
-                    // be in LDS behind the NEXT barrier
-                    if (!(g.ablate & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    bookkeeping(gi, blk, c, 3);
-                }
                 const int jj = s >> 2, q = s & 3;
                 const float4 b = ring[s % D];
                 ring[s % D] = (s + D < S) ? frag(bp, s + D) : frag(bn, s + D - S);
@@ -285,9 +275,7 @@ __global__ __launch_bounds__(512, 2) void proj_astat_kernel(ProjArgs g) {
         };
         pj_for_each(chunk, std::make_integer_sequence<int, NCB>{});
     }
-    // the last block: nothing left to hide its epilogue behind
-#pragma unroll
-    for (int r = 0; r < 4; ++r) epilogue_row(nblk - 1, r, acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+    epilogue(nblk - 1);
     if (g.dbg && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 101)) {
         g.dbg[(blockIdx.x ? 64 : 0) + 60] = (long)wall_clock64();
         g.dbg[(blockIdx.x ? 64 : 0) + 61] = t_start;
@@ -345,7 +333,7 @@ bool nm_proj_astat_try(hipStream_t st, int trans_b, int64_t M, int64_t N, int64_
     g.dbg = nullptr;
     if (const char* e = getenv("NM_PROJ_ASTAT_DBG_PTR")) g.dbg = reinterpret_cast<long*>(strtoull(e, nullptr, 0));
     const int kc = (int)(K / 128);
-    const size_t lds = (size_t)(PJ_NBUF * 64 * 64 + PJ_BIAS_MAX + 8 * 1024) * sizeof(float);   // chunks, bias, the waves' accumulator copies
+    const size_t lds = (size_t)(PJ_NBUF * 64 * 64 + PJ_BIAS_MAX) * sizeof(float);   // chunk images + the bias of the range
     switch (kc) {
         case 1: return pj_launch(proj_astat_kernel<1, 64>, 0, dev, grid, lds, st, g);
         case 2: return pj_launch(proj_astat_kernel<2, 64>, 1, dev, grid, lds, st, g);

@@ -21,6 +21,8 @@
 // MFMA.  Several products that do not depend on each other share one launch (a "group").
 #include "nm_common.h"
 
+#include <atomic>
+#include <stdlib.h>
 #include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -399,6 +401,149 @@ void step_group_medium_kernel(StepGroup g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Medium M through LDS-DMA (round 6).  step_group_medium_kernel above is bound by how fast a CU fills its L1 (a 32x32
+// tile per K-split wave set re-reads every operand row M / 32 or N / 32 times: 82 MB for group 1 of a 640-row step)
+// and by the registers its loads in flight cost.  Here a 4-wave workgroup owns a 64x64 output tile (41 MB for the same
+// group), both operands arrive as 64-k chunks by global_load_lds_dwordx4 -- no staging registers, no ds_write pass,
+// three chunks in flight ahead of the one being multiplied -- into four 32 KB LDS images.
+// Both operands are stored k-contiguous ([M, K] activations, [N, K] transposed weights), so a DMA piece is 4 rows x 256
+// bytes and the LDS image is [row][64 k]; an MFMA fragment (lane = row, 4 consecutive k = one ds_read_b128) would hit
+// one bank 16 times over, so the 16-byte unit u of row r is FETCHED into position u ^ (r & 15) (LDS-DMA writes lane-
+// linear: the swizzle goes on the source address) and read back from there: 16 rows -> 16 different units.
+// v_mfma_f32_32x32x2_f32: lane (m = l & 31, half = l >> 5); the four MFMAs fed by one 16-byte unit U = 2 i + half use
+// k = 8 i + 4 half + j on BOTH operands.  Same problems, epilogues and results as step_group_kernel (a_kind 0); the
+// products of a row are added in another order than there (chunks of 64 k, two k per MFMA), to rounding the same.
+#define SGD_CK 64                          // k per chunk
+#define SGD_IMG (64 * SGD_CK)              // floats of one operand image: 64 rows x 64 k
+
+__device__ __forceinline__ void sgd_dma16(const float* src, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
+
+__global__ __launch_bounds__(256, 1) void step_group_dma_kernel(StepGroup g) {
+    extern __shared__ __attribute__((aligned(16))) float sgd_lds[];          // [4 buffers][A image | B image]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = (int)blockIdx.x;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < NM_STEP_MAX_PROB; ++i)
+        if (i < g.nprob && bid >= g.begin[i]) pi = i;
+    const StepProb& p = g.p[pi];
+    const int tile = bid - g.begin[pi];
+    const int bm = tile % g.tiles_m, bn = tile / g.tiles_m;         // consecutive workgroups share a weight tile
+    const int m0 = bm * 64, n0 = bn * 64;
+    const int N = (int)p.N, K = (int)p.K;
+    const int nchunk = K / SGD_CK;
+
+    // DMA: 32 pieces of 1 KB per chunk (16 of A, 16 of B), eight per wave: wave w fetches rows 16 w .. 16 w + 15 of
+    // both images, piece u its rows 4 u .. 4 u + 3; lane L -> row 4 u + (L >> 4), position L & 15 <- unit (L & 15) ^ (row & 15)
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)sgd_lds;
+    const int prow = lane >> 4, ppos = lane & 15;
+    const float* asrc[4];
+    const float* bsrc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int r = 16 * wave + 4 * u + prow;                      // row of the image
+        const int unit = ppos ^ (r & 15);
+        asrc[u] = p.A + (long)min(m0 + r, g.M - 1) * p.lda + 4 * unit;
+        bsrc[u] = p.Bt + (long)min(n0 + r, N - 1) * p.ldb + 4 * unit;
+    }
+    auto issue = [&](int c) {
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((c & 3) * 2 * SGD_IMG + 16 * wave * SGD_CK) * 4u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            sgd_dma16(asrc[u] + c * SGD_CK, dst + (unsigned)(4 * u * SGD_CK * 4));
+            sgd_dma16(bsrc[u] + c * SGD_CK, dst + (unsigned)((SGD_IMG + 4 * u * SGD_CK) * 4));
+        }
+    };
+
+    const int wr = wave >> 1, wc = wave & 1;                          // this wave's 32x32 quadrant of the tile
+    const int m = lane & 31, half = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    const int arow = 32 * wr + m, brow = 32 * wc + m;
+    // three chunks in flight ahead of the one being multiplied (four LDS images): a piece is ~2 us on its way, a
+    // chunk is ~1 us of matrix work -- with one chunk ahead every chunk waited for its pieces (26.7 us per group of a
+    // 640-row step against 19 for the register-staged kernel)
+    issue(0);
+    if (nchunk > 1) issue(1);
+    if (nchunk > 2) issue(2);
+    for (int c = 0; c < nchunk; ++c) {
+        // this wave's pieces of chunk c have landed (the younger chunks stay in flight) ...
+        const int younger = min(nchunk - 1 - c, 2);
+        if (younger == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ... behind the barrier everybody else's too, and everybody is done with chunk c - 1, whose image chunk
+        // c + 3 overwrites
+        __builtin_amdgcn_s_barrier();
+        if (c + 3 < nchunk) issue(c + 3);
+        const float* as = sgd_lds + (c & 3) * 2 * SGD_IMG + arow * SGD_CK;
+        const float* bs = sgd_lds + (c & 3) * 2 * SGD_IMG + SGD_IMG + brow * SGD_CK;
+        float4 av[8], bv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int unit = (2 * i + half) ^ (m & 15);
+            av[i] = *reinterpret_cast<const float4*>(as + 4 * unit);
+            bv[i] = *reinterpret_cast<const float4*>(bs + 4 * unit);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[i].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[i].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[i].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[i].w, acc, 0, 0, 0);
+        }
+    }
+    // C/D layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    const int col = n0 + 32 * wc + (lane & 31);
+    if (col >= N) return;
+    const float bias = (p.bias && p.epilogue != 2) ? p.bias[col] : 0.0f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = m0 + 32 * wr + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        if (row >= g.M) continue;
+        const float s = acc[reg];
+        if (p.epilogue == 0) {
+            const float addv = p.add ? p.add[(long)(p.add_ids ? p.add_ids[row] : row) * p.ldadd + col] : 0.0f;
+            float v = s + bias + addv;
+            if (p.act == 1) v = nm_tanh(v);
+            else if (p.act == 2) v = fmaxf(v, 0.0f);
+            p.C[(long)row * p.ldc + col] = v;
+        } else if (p.epilogue == 1) {              // N = 2H: r | u = sigmoid(. + bg); rh = r * h
+            const int H = N >> 1;
+            const float addv = p.add ? p.add[(long)(p.add_ids ? p.add_ids[row] : row) * p.ldadd + col] : 0.0f;
+            const float gate = nm_sigmoid(s + bias + addv);
+            p.ru[(long)row * N + col] = gate;
+            if (col < H) p.rh[(long)row * H + col] = gate * p.h[(long)row * p.ldh + col];
+        } else {                                   // N = H: c = tanh(xc + .); h' = u*h + (1-u)*c
+            const float c = nm_tanh(p.xc[(long)(p.xc_ids ? p.xc_ids[row] : row) * p.ldxc + col] + s);
+            const float u = p.ru[(long)row * 2 * N + N + col];
+            const float hn = u * p.h[(long)row * p.ldh + col] + (1.0f - u) * c;
+            p.h_out[(long)row * p.ldho + col] = hn;
+            if (p.h_out2) p.h_out2[(long)row * p.ldho2 + col] = hn;
+        }
+    }
+}
+
+static bool sgd_prepare() {
+    static std::atomic<unsigned> devs{0};
+    const unsigned ok_bit = 1u << (nm_cur()->device & 15), bad_bit = ok_bit << 16;
+    unsigned seen = devs.load(std::memory_order_relaxed);
+    if (!(seen & (ok_bit | bad_bit))) {
+        const bool ok = hipFuncSetAttribute((const void*)step_group_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            8 * SGD_IMG * 4) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        seen = devs.fetch_or(ok ? ok_bit : bad_bit, std::memory_order_relaxed) | (ok ? ok_bit : bad_bit);
+    }
+    return (seen & ok_bit) != 0;
+}
+
 struct nm_step_problem {          // mirrors include/nmhip.h
     const float* A; int64_t lda;
     const float* Bt; int64_t ldb;
@@ -414,6 +559,21 @@ struct nm_step_problem {          // mirrors include/nmhip.h
     float* h_out; int64_t ldho; float* h_out2; int64_t ldho2;
     const int32_t* add_ids; const int32_t* xc_ids;
 };
+
+// OPT-IN (NM_STEP_DMA=1).  Measured per group of a 640-row step, alone and warm (tools/step_group_probe.py,
+// profiles/r06_step_group_probe.txt): 16.7 / 16.0 / 18.0 / 25.5 us against the register-staged kernels' 15.9 / 10.5 /
+// 19.1 / 16.5, and 26.7 us per group inside a beam step with one chunk in flight (profiles/
+// r06_decode_beam_kernel_stats_v1.csv).  These groups are bound by the ~25 GB/s at which a CU fills its L1, whatever
+// carries the bytes: halving the bytes per tile (64x64 against 32x32) leaves 160-240 workgroups of 256 KB each for 256
+// CUs, and every LDS-DMA piece costs its wave ~150 issue cycles that the register-staged waves spend on MFMAs.
+static bool sgd_switch() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("NM_STEP_DMA");
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v != 0;
+}
 
 extern "C" int nm_step_group(void* stream, int64_t M, const nm_step_problem* probs, int32_t nprob) {
     NM_REQUIRE(probs && nprob >= 1 && nprob <= NM_STEP_MAX_PROB, "nm_step_group: 1..%d problems", NM_STEP_MAX_PROB);
@@ -435,8 +595,15 @@ extern "C" int nm_step_group(void* stream, int64_t M, const nm_step_problem* pro
     // workgroup halves the fill traffic (16 flop / byte): group 1 of the 640-row step 39.4 -> 32.0 us.  Fat
     // workgroups only while >= 256 of them remain (320 at 640 rows: some CUs then run two in a row, which is what
     // is left of the 32 us); 64x32 measured no better than 32x32 (17.9 / 38.3 us against 17.4 / 39.4).
+    // LDS-DMA tiles (step_group_dma_kernel, opt-in: NM_STEP_DMA=1) when every product of the group has whole 64-k chunks
+    bool dma = medium && medium_sw == 1 && sgd_switch();
+    for (int i = 0; i < nprob && dma; ++i)
+        dma = probs[i].K % SGD_CK == 0 && probs[i].K >= SGD_CK && probs[i].a_kind == 0 && probs[i].lda % 4 == 0 &&
+              probs[i].ldb % 4 == 0;
+    if (dma) dma = sgd_prepare();
     int tr = 1, tc = 1;
-    if (medium && medium_sw == 1) {
+    if (dma) { tr = 2; tc = 2; }
+    else if (medium && medium_sw == 1) {
         long t44 = 0;
         for (int i = 0; i < nprob; ++i) t44 += (long)nm_cdiv(M, 64) * nm_cdiv(probs[i].N, 64);
         if (t44 >= 256) { tr = 2; tc = 2; }
@@ -491,7 +658,9 @@ extern "C" int nm_step_group(void* stream, int64_t M, const nm_step_problem* pro
     const unsigned grid = (unsigned)(next + g.wblocks);
     // few tiles (a single 512-wide product at 640 rows: 320 tiles on 256 CUs): 8 waves split K, so that the one or
     // two workgroups a CU gets are half as long
-    if (medium && tr == 2 && tc == 2)
+    if (dma)
+        hipLaunchKernelGGL(step_group_dma_kernel, dim3(grid), dim3(256), 8 * SGD_IMG * 4, st, g);
+    else if (medium && tr == 2 && tc == 2)
         hipLaunchKernelGGL((step_group_medium_kernel<4, 2, 2>), dim3(grid), dim3(1024), 0, st, g);
     else if (medium && grid <= 640)
         hipLaunchKernelGGL((step_group_medium_kernel<8, 1, 1>), dim3(grid), dim3(512), 0, st, g);
@@ -573,7 +742,16 @@ struct nm_decoder_step {          // mirrors include/nmhip.h
     int32_t out_act, vocab_trans_b;
     int64_t ld_cat, ld_ctx, ld_wg, ld_wcx, ld_wch, ld_wq, ld_wo_h, ld_wo_e, ld_wo_c;
     const float* in_table; int64_t ld_table; const int32_t* in_ids;
+    void* cluster_ws; int64_t cluster_ws_bytes; uint32_t* sticky_error;
 };
+
+// nm_gru_cluster.hip: groups 1-3 of a step with input tables as ONE cluster launch; false when the shape is not taken
+bool nm_dec_step_cluster_try(hipStream_t st, int64_t R, int64_t H, int64_t A, int64_t O, const float* h_in, int64_t ld_h,
+                             const float* table, int64_t ld_table, const int32_t* ids, const float* bg, const float* bq,
+                             const float* bo, const float* wg_t, int64_t ld_wg, const float* wc_t, int64_t ld_wc,
+                             const float* wq_t, int64_t ld_wq, const float* wo_t, int64_t ld_wo, float* h_out,
+                             int64_t ld_ho, float* h_out2, int64_t ld_ho2, float* y, int64_t ld_y, float* pre,
+                             int64_t ld_pre, void* workspace, int64_t workspace_bytes, uint32_t* sticky);
 
 extern "C" int nm_decoder_step_fused(void* stream, const nm_decoder_step* d) {
     NM_REQUIRE(d, "nm_decoder_step_fused: null descriptor");
@@ -601,7 +779,15 @@ extern "C" int nm_decoder_step_fused(void* stream, const nm_decoder_step* d) {
     const bool tables = d->in_table != nullptr;
     NM_REQUIRE(!tables || (d->in_ids && d->ld_table >= 3 * H + O), "nm_decoder_step_fused: input tables need the rows' "
                "symbols and [V, 2*rnn + rnn + out] columns");
-    if (tables) {
+    // greedy-sized steps with input tables: gates, candidate + blend, query and the state part of the output projection
+    // in ONE launch of workgroup clusters (dec_step_cluster_kernel) instead of the three dependent groups below
+    const bool clustered = tables && d->cluster_ws &&
+        nm_dec_step_cluster_try(nm_stream(stream), M, H, A, O, h, ld, d->in_table, d->ld_table, d->in_ids, d->bg, d->bq,
+                                d->bo, d->wg_t + E, ld_wg, d->wch_t, ld_wch, d->wq_t, ld_wq, d->wo_h_t, ld_wo_h, h, ld,
+                                d->h_copy, d->h_copy ? d->ld_h_copy : 0, d->y, A, d->pre, O, d->cluster_ws,
+                                d->cluster_ws_bytes, d->sticky_error);
+    if (clustered) {
+    } else if (tables) {
         // group 1 with input tables: only the state half of the gates product is left -- h . Wg_h (the state rows of
         // the gates kernel = columns emb.. of wg_t) + in_table[id, :2H] + bg
         memset(p, 0, sizeof(p));
@@ -620,6 +806,7 @@ extern "C" int nm_decoder_step_fused(void* stream, const nm_decoder_step* d) {
     p[2].C = d->pre_e; p[2].ldc = O;
     if ((rc = nm_step_group(stream, M, p, 3)) != 0) return rc;
     }
+    if (!clustered) {
     // group 2: candidate + blend, h' in place (and into the caller's history row)
     memset(p, 0, sizeof(p));
     p[0].A = d->rh; p[0].lda = H; p[0].Bt = d->wch_t; p[0].ldb = ld_wch; p[0].N = H; p[0].K = H; p[0].epilogue = 2;
@@ -635,6 +822,7 @@ extern "C" int nm_decoder_step_fused(void* stream, const nm_decoder_step* d) {
     p[1].add = d->pre_e; p[1].ldadd = O; p[1].C = d->pre; p[1].ldc = O;
     if (tables) { p[1].add = d->in_table + 3 * H; p[1].ldadd = d->ld_table; p[1].add_ids = d->in_ids; }
     if ((rc = nm_step_group(stream, M, p, 2)) != 0) return rc;
+    }
     // attention: one launch
     if ((rc = nm_attn_fwd(stream, d->y, d->keys, d->values, d->mask, d->v, d->attn_bias, M, d->rows_per_key,
                           d->src_len, A, C, d->ctx, ld_ctx, d->attn_weights, d->attn_workspace, d->attn_workspace_bytes,

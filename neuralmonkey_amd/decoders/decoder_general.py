@@ -510,6 +510,19 @@ class FusedStepper:
             self.whole_tab = ops.DecoderStepCall(fields)
             self.whole_tab.keep = dict(self.whole.keep)
             self.whole_tab.launch_fields = dict(in_table=self.table, ld_table=self.table.stride(0))
+            # greedy-sized steps: the three recurrent step groups as ONE launch of workgroup clusters
+            # (dec_step_cluster_kernel, csrc/nm_gru_cluster.hip).  The workspace -- counters, epoch, tagged granules --
+            # is this stepper's own and starts as zeros.  OPT-IN (NM_STEP_CLUSTER=1): measured SLOWER than the three
+            # launches, 37.1 against 23.8 us per greedy step (profiles/r06_decode_greedy_kernel_stats_v1.csv) -- a launch
+            # is one step, so the weights are not stationary as in the time loops: every workgroup re-fetches its 192 KB
+            # of weight slices per step and gathers 128 KB of granules, the same L1-fill traffic as the three groups,
+            # plus the role agreement; kept as a verified negative result (tests/test_step_cluster_gpu.py).
+            self.cluster_ws = None
+            lib = ops._lib.load()               # pylint: disable=protected-access
+            if (os.environ.get("NM_STEP_CLUSTER", "0") == "1" and ctx.session.use_cluster_loops
+                    and lib.nm_dec_step_cluster_supported(rows, h, a, o)):
+                self.cluster_ws = torch.zeros(lib.nm_dec_step_cluster_workspace_bytes(rows, h) // 4,
+                                              dtype=torch.float32, device=self.cat.device)
 
     def start(self, s0: torch.Tensor) -> None:
         self._pending, self._cur = s0, 0
@@ -536,6 +549,12 @@ class FusedStepper:
         if self.single_call:
             call = self.whole_tab if tabled else self.whole
             extra = dict(call.launch_fields, in_ids=ids) if tabled else {}
+            if tabled:
+                # (a session that fell back to per-step launches -- Session.demote_cluster_loops -- takes the three
+                # step groups again: the chunks' graphs are captured anew after a demotion)
+                ws = self.cluster_ws if (self.cluster_ws is not None and ctx.session.use_cluster_loops) else None
+                extra.update(cluster_ws=ws, cluster_ws_bytes=ws.numel() * 4 if ws is not None else 0,
+                             sticky_error=ctx.session.error_word() if ws is not None else None)
             call.launch(h_copy=h_out, ld_h_copy=h_out.stride(0), out_state=out_state,
                         ld_out_state=out_state.stride(0), attn_weights=st.weights[st.step], logits=logits,
                         ld_logits=logits.stride(0) if logits is not None else 0, stats=stats,

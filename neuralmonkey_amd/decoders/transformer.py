@@ -490,9 +490,67 @@ class TransformerStepper:
             self.enc_kv.append((per_layer, emask, bk, slen))
         self.base = tape._n                       # pylint: disable=protected-access
         self.cur, self.t = 0, 0
+        self._prepare_qkv()
         if self.anc is not None:                  # every row starts as its own ancestor at every position
             iota = torch.arange(self.rows, dtype=torch.int32, device=self.anc.device).view(1, self.rows, 1)
             self.anc.copy_(iota.expand(2, self.rows, self.tmax))
+
+    def _prepare_qkv(self) -> None:
+        """The three self-attention projections of a layer read the same normed rows: ONE launch of nm_step_group
+        with three problems (queries, the new key row, the new value row) instead of three products -- 12 launches
+        of ~6 us fewer per step at depth 6 (decoders/transformer.py:282-300 of the reference: the same three
+        tf.layers.dense calls).  nm_step_group multiplies by [N, K] weights: the kernels are transposed once per
+        batch (they change between batches only when somebody trains in between).  NM_STEP_QKV=0: three products."""
+        dec, ctx = self.dec, self.ctx
+        self.qkv = None
+        d = dec.dimension
+        if (os.environ.get("NM_STEP_QKV", "1") == "0" or dec.n_heads_self <= 1 or d % 16 != 0
+                or self.kcache[0].device.type != "cuda"):
+            return
+        key = (id(dec), "qkvT", self.rows)
+        self.qkv = []
+        for l in range(dec.depth):
+            scope = "layer_{}/self_attention".format(l)
+            wts, biases = [], []
+            for proj in ("query_proj", "keys_proj", "vals_proj"):
+                w = dec.var(ctx, "{}/{}/kernel".format(scope, proj))                 # [d, d]
+                wt = ctx.buffer(key + (l, proj), (w.shape[1], w.shape[0]))
+                wt.copy_(w.t())
+                wts.append(wt)
+                biases.append(dec.var(ctx, "{}/{}/bias".format(scope, proj)) if dec.use_att_transform_bias else None)
+            qbuf = ctx.buffer(key + (l, "q"), (self.rows, d))
+            probs = []
+            for wt, bias in zip(wts, biases):
+                spec = dict(A=qbuf, lda=d, Bt=wt, ldb=wt.stride(0), N=d, K=d, epilogue=0, C=qbuf, ldc=d)
+                if bias is not None:
+                    spec["bias"] = bias
+                probs.append(spec)
+            self.qkv.append((ops.StepGroup(self.rows, probs), qbuf))
+
+    def _self_projections(self, l: int, normed, t: int, kc, vc):
+        """q (a tape variable) and row t of the layer's key / value caches from the normed input rows."""
+        dec, tape = self.dec, self.tape
+        scope = "layer_{}/self_attention".format(l)
+        if self.qkv is not None:
+            group, qbuf = self.qkv[l]
+            src = normed.data
+            for i in range(3):
+                group.patch(i, A=src, lda=src.stride(0))
+            group.patch(1, C=kc[:, t], ldc=kc.stride(0))
+            group.patch(2, C=vc[:, t], ldc=vc.stride(0))
+            group.launch()
+            return tape.leaf(qbuf)
+        q = TB.project(tape, dec, scope, "query_proj", normed, dec.n_heads_self, dec.use_att_transform_bias)
+        if dec.n_heads_self > 1:
+            bias = lambda p: tape.param(dec, "{}/{}/bias".format(scope, p)) if dec.use_att_transform_bias else None
+            F.linear(tape, normed, tape.param(dec, scope + "/keys_proj/kernel"), bias("keys_proj"),
+                     out=tape.leaf(kc[:, t]))
+            F.linear(tape, normed, tape.param(dec, scope + "/vals_proj/kernel"), bias("vals_proj"),
+                     out=tape.leaf(vc[:, t]))
+        else:
+            ops.ew("copy", normed.data, None, kc[:, t])
+            ops.ew("copy", normed.data, None, vc[:, t])
+        return q
 
     indexed = True       # set_position(t, cur) makes a step a function of its index: HIP-graph capturable
 
@@ -584,17 +642,8 @@ class TransformerStepper:
         for l in range(dec.depth):
             pre = "layer_{}".format(l)
             scope = pre + "/self_attention"
-            q = TB.project(tape, dec, scope, "query_proj", normed, dec.n_heads_self, dec.use_att_transform_bias)
             kc, vc = self.kcache[l][cur if len(self.kcache[l]) > 1 else 0], self.vcache[l][cur if len(self.vcache[l]) > 1 else 0]
-            if dec.n_heads_self > 1:
-                bias = lambda p: tape.param(dec, "{}/{}/bias".format(scope, p)) if dec.use_att_transform_bias else None
-                F.linear(tape, normed, tape.param(dec, scope + "/keys_proj/kernel"), bias("keys_proj"),
-                         out=tape.leaf(kc[:, t]))
-                F.linear(tape, normed, tape.param(dec, scope + "/vals_proj/kernel"), bias("vals_proj"),
-                         out=tape.leaf(vc[:, t]))
-            else:
-                ops.ew("copy", normed.data, None, kc[:, t])
-                ops.ew("copy", normed.data, None, vc[:, t])
+            q = self._self_projections(l, normed, t, kc, vc)
             att = F.sdp_attention(tape, q, None, None, mask[:, :t + 1], dec.n_heads_self, rows, 1, rows, t + 1,
                                   False, 1.0, 0, k_data=kc[:, :t + 1], v_data=vc[:, :t + 1],
                                   ancestors=self.anc[cur] if self.anc is not None else None)

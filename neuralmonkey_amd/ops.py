@@ -992,11 +992,13 @@ def optimizer_chunk_table(store, regularizable, trainable, cuts=(), chunk=65536)
 
 
 def chunk_range_of(starts, lens, lo, hi):
-    """The chunks whose elements lie in [lo, hi) of the flat buffer: (begin, end); the range must start and end on
-    chunk boundaries."""
+    """The chunks whose elements lie in [lo, hi) of the flat buffer: (begin, end).  No chunk may straddle either end
+    (the table was cut there: ``optimizer_chunk_table(..., cuts)``); the ends themselves may fall into the padding
+    between two variables, which belongs to no chunk."""
     import bisect
     b, e = bisect.bisect_left(starts, lo), bisect.bisect_left(starts, hi)
-    assert b == e or (starts[b] == lo and starts[e - 1] + lens[e - 1] == hi), "a slice does not end on a chunk boundary"
+    assert (b == 0 or starts[b - 1] + lens[b - 1] <= lo) and (e == 0 or starts[e - 1] + lens[e - 1] <= hi), \
+        "a chunk straddles the end of a slice: the table was not cut there"
     return b, e
 
 

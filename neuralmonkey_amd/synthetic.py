@@ -174,6 +174,16 @@ def transformer_train_flops(batch, length, vocab=32000, dim=512, ff=2048, depth=
     return 3.0 * fwd
 
 
+def transformer_decode_step_flops(rows, vocab=32000, dim=512, ff=2048, depth=6, cached_len=25, src_len=50) -> float:
+    """Multiply-add flops (x2) of ONE cached decoding step of the same model for ``rows`` rows (sentences, or
+    hypotheses of a beam): per decoder layer the self-attention's q / k / v / output projections (8 d^2), the
+    cross-attention's query and output projections over cached encoder keys / values (4 d^2), the two attention cores
+    over ``cached_len`` own and ``src_len`` encoder positions (4 d each per position), the feed-forward block
+    (4 d ff); the tied vocabulary projection 2 d V.  38.4 M multiply-adds per row at the base size."""
+    per_row = depth * (12 * dim * dim + 4 * dim * (cached_len + src_len) + 4 * dim * ff) + 2 * dim * vocab
+    return float(rows) * per_row
+
+
 def translation_train_flops(batch, length, vocab=32000, dim=512, att=None) -> float:
     """Multiply-add flops (x2) of the DENSE products of one training step of ``build_translation_model`` (emb = rnn =
     ``dim``, attention state size ``att`` = 2 dim by default), forward + backward = 3 x forward (every product has an

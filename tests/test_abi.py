@@ -61,6 +61,32 @@ def test_round5_entry_points_validate_before_any_launch(lib):
     assert rc < 0 and b"null" in lib.nm_last_error()
 
 
+def test_round6_entry_points_validate_before_any_launch(lib):
+    """The ranged optimizer passes (sharded optimizer, the skip word of the cluster-loop recovery), the conditional
+    zeroing of a gradient and the cluster loops' test hooks: arguments are checked before anything is launched."""
+    none9 = [None] * 9
+    rc = lib.nm_optim_partials(None, *none9[:8], 4, 2, 0.0, 0.0, 0, 4, None, 0)
+    assert rc < 0 and b"nm_optim_partials" in lib.nm_last_error()
+    rc = lib.nm_optim_segments(None, *none9[:6], 4, 2, None, None, 0)
+    assert rc < 0 and b"nm_optim_segments" in lib.nm_last_error()
+    buf = (ctypes.c_float * 64)()
+    tabs = [ctypes.cast(buf, ctypes.c_void_p)] * 6
+    # a chunk range that leaves the table is refused (the operands are never touched: no device here)
+    rc = lib.nm_optim_apply(None, 0, buf, buf, buf, buf, *tabs, 4, 2, 1.0, 1e-3, 0.9, 0.999, 1e-8, 3, 9, None, buf, 4096)
+    assert rc < 0 and b"chunk range" in lib.nm_last_error()
+    rc = lib.nm_optim_apply(None, 7, buf, buf, buf, buf, *tabs, 4, 2, 1.0, 1e-3, 0.9, 0.999, 1e-8, 0, 4, None, buf, 4096)
+    assert rc < 0 and b"kind" in lib.nm_last_error()
+    # an empty range is a no-op, not a launch
+    assert lib.nm_optim_apply(None, 0, buf, buf, buf, buf, *tabs, 4, 2, 1.0, 1e-3, 0.9, 0.999, 1e-8, 2, 2, None, buf,
+                              4096) == 0
+    rc = lib.nm_zero_if(None, None, None, 16)
+    assert rc < 0 and b"nm_zero_if" in lib.nm_last_error()
+    assert lib.nm_zero_if(None, buf, buf, 0) == 0
+    assert lib.nm_gru_seq_force_give_up(3) == 0 and lib.nm_gru_seq_force_give_up(0) == 3     # a counter, nothing else
+    rc = lib.nm_gru_seq_test_hog(None, 0, 1024, 10)
+    assert rc < 0 and b"nm_gru_seq_test_hog" in lib.nm_last_error()
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from neuralmonkey_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)

@@ -36,6 +36,8 @@ def _worker(rank, world, port, out_dir):
 
     dp = distributed.init_from_env(backend="gloo")
     assert dp.rank == rank and dp.world_size == world
+    dp.sharded = False          # this test: the replicated update's exchange (spans, early spans, rows); the sharded
+                                # optimizer has test_sharded_optimizer_equals_the_replicated_update below
 
     vocab, dim, batch = 50, 8, 6
     params = O.init_params(seed=5, vocab_src=vocab, vocab_tgt=vocab, emb=dim, rnn=dim, std=0.2)
@@ -170,3 +172,91 @@ def test_shard_sizes_are_even_and_tiny_batches_are_refused():
     dp.world_size = 9
     with pytest.raises(ValueError, match="cannot be sharded"):
         dp.shard(ds)
+
+
+# ---- sharded optimizer: reduce-scatter -> update of the rank's slices -> all-gather -------------------
+def _sharded_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), NM_DP_BIG_VARIABLE="3000")
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    torch.set_num_threads(1)
+    import torch.distributed as tdist
+    from neuralmonkey_amd import distributed
+    from neuralmonkey_amd.variables import VariableStore, random_normal_initializer
+    from tests.cpu_optim_tables import CpuOptimizerTables
+
+    dp = distributed.init_from_env(backend="gloo")
+    dp.bucket_elems = 2501                          # several buckets per big variable, none divisible by 8
+    shapes = {"enc/embedding": (40, 101), "enc/kernel": (37, 9), "enc/bias": (9,), "dec/logits/W": (11, 613),
+              "dec/logits/bias": (613,), "dec/small": (5,), "dec/embedding": (77, 53)}
+
+    def fresh_store():
+        st = VariableStore("cpu", seed=11)
+        for name, shape in shapes.items():
+            st.declare(name, shape, random_normal_initializer(stddev=0.3))
+        st.finalize()
+        st.ensure_grad()
+        st.ensure_adam()
+        return st
+
+    plan = dp.plan(fresh_store())
+    assert any(name for _, _, _, name in plan.buckets) and any(name is None for _, _, _, name in plan.buckets)
+    assert plan.tails(), "the shapes were chosen so that buckets leave indivisible tails"
+    assert len(plan.of_variable["dec/logits/W"]) >= 2
+    owned = sorted(plan.owned(0) + plan.owned(1) + plan.tails())
+    assert owned[0][0] == 0 and owned[-1][1] == plan.total and all(a[1] == b[0] for a, b in zip(owned, owned[1:]))
+
+    def run(sharded, early):
+        st = fresh_store()
+        dp.sharded, dp.poison_foreign = sharded, sharded
+        regularizable = {n for n in shapes if "bias" not in n}
+        tables = CpuOptimizerTables(st, regularizable, set(shapes), cuts=dp.optimizer_cuts(st))
+        m, v = st.ensure_adam()
+        word = torch.zeros(1, dtype=torch.int32)
+        clipped = []
+        thetas = []
+        for step in range(1, 5):
+            g = torch.Generator().manual_seed(100 * step + rank)
+            grad = st.ensure_grad()
+            grad.copy_(torch.randn(st.total, generator=g) * (0.02 if step != 2 else 0.4))
+            word.fill_(1 if (step == 3 and rank == 1) else 0)       # one rank's time loop "gave up" in step 3
+            dp.begin_step()
+            if early:
+                dp.all_reduce_early(st, ["dec/logits/W", "dec/logits/bias"])
+            lr_t = 1e-3 * (1 - 0.999 ** step) ** 0.5 / (1 - 0.9 ** step)
+            dp.optimizer_step(st, tables, 0, m, v, 1e-4, 1e-3, 1.0, (lr_t, 0.9, 0.999, 1e-8), skip=word)
+            norms = torch.sqrt(tables.workspace[3 * tables.nchunk:])
+            clipped.append(int((norms > 1.0).sum()))
+            thetas.append(st.theta.clone())
+            assert int(word.item()) == (1 if step == 3 else 0), "the error word is the maximum over ranks"
+        dp.gather_optimizer_slots(st, m, v)
+        return thetas, m.clone(), v.clone(), clipped, tables.l1l2.clone()
+
+    ref, ref_m, ref_v, clipped, ref_l1l2 = run(sharded=False, early=False)
+    assert 0 < clipped[1] and clipped[0] < len(shapes), "the clip must bite on some tensors and not on all"
+    assert torch.equal(ref[1], ref[2]) and not torch.equal(ref[0], ref[1]), "step 3 is skipped on every rank"
+    for early in (False, True):
+        got, got_m, got_v, _, l1l2 = run(sharded=True, early=early)
+        for a, b in zip(got, ref):
+            assert torch.isfinite(a).all()
+            assert torch.equal(a, b), "sharded update differs from the replicated one"
+        assert torch.equal(got_m, ref_m) and torch.equal(got_v, ref_v) and torch.equal(l1l2, ref_l1l2)
+    both = [torch.zeros_like(ref[-1]) for _ in range(world)]
+    tdist.all_gather(both, got[-1])
+    assert torch.equal(both[0], both[1]), "replicas differ"
+    report = dp.exchange_report()
+    assert report["optimizer"] == "sharded" and report["optimizer_elements_per_rank"] < 0.6 * plan.total
+    if rank == 0:
+        np.save(os.path.join(out_dir, "sharded_ok.npy"), np.array([1]))
+    distributed.shutdown()
+
+
+def test_sharded_optimizer_equals_the_replicated_update(tmp_path):
+    """Reduce-scatter -> norms from the ranks' partial sums -> clip + Adam on the rank's slices -> all-gather gives,
+    bit for bit, what every rank computes when all of them reduce and update everything (generic_trainer.py:179-195);
+    what a rank does not own is never read (it is filled with NaN after the reduction); a device error word raised
+    on one rank voids the step on all."""
+    mp.spawn(_sharded_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "sharded_ok.npy").exists()

@@ -36,12 +36,13 @@ def _batch():
     return synthetic.synthetic_dataset(seed=5, batch=BATCH, src_len=LEN, tgt_len=LEN - 1, vocab=VOCAB, ragged=True)
 
 
-def _worker(rank, world, port, out_dir, backend="gloo", sparse=False):
+def _worker(rank, world, port, out_dir, backend="gloo", sparse=False, sharded=True):
     """backend gloo: all ranks share GPU 0; backend nccl (= RCCL): rank r owns GPU r."""
     local = rank if backend == "nccl" else 0
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(local), NM_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0",
-                      NM_DP_SPARSE_EMB="1" if sparse else "0")
+                      NM_DP_SPARSE_EMB="1" if sparse else "0", NM_DP_SHARDED="1" if sharded else "0",
+                      NM_DP_BIG_VARIABLE="1500")             # (the toy model's matrices own their buckets)
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch.distributed as dist
@@ -49,7 +50,8 @@ def _worker(rank, world, port, out_dir, backend="gloo", sparse=False):
     torch.cuda.set_device(local)
     dp = distributed.init_from_env()
     assert dp is not None and dp.world_size == world and dp.overlap and dist.get_backend() == backend
-    assert dp.sparse_embeddings == sparse
+    assert dp.sparse_embeddings == sparse and dp.sharded_active() == sharded
+    dp.bucket_elems = 1001                          # several buckets per matrix, with indivisible tails
     seen_sparse = []
     real_sparse = dp.exchange_sparse_rows
 
@@ -81,18 +83,37 @@ def _worker(rank, world, port, out_dir, backend="gloo", sparse=False):
     torch.cuda.synchronize()
     assert len(seen_early) == 6 and "decoder/state_to_word_W" in seen_early[0]      # two early spans per step
     assert seen_sparse == ([("encoder_input/embedding_matrix_0", True)] * 3 if sparse else [])
+    # sharded optimizer: a rank's gradient buffer holds the sum (+ the L2 term) on the slices it owns only
+    owned = np.ones(store.total, bool)
+    if sharded:
+        plan = dp.plan(store)
+        owned[:] = False
+        for lo, hi in plan.owned(rank) + plan.tails():
+            owned[lo:hi] = True
+        assert 0.3 * store.total < owned.sum() < 0.7 * store.total
+        dp.gather_optimizer_slots(store, *store.ensure_adam())
+    m, v = store.ensure_adam()
+    report = dp.exchange_report()
+    assert report["optimizer"] == ("sharded" if sharded else "replicated")
     np.savez(os.path.join(out_dir, "rank{}.npz".format(rank)), theta=store.theta.cpu().numpy(),
-             losses=np.asarray(losses), grad1=grad1)
+             losses=np.asarray(losses), grad1=grad1, owned=owned, m=m.cpu().numpy(), v=v.cpu().numpy())
     distributed.shutdown()
 
 
-def _ranks_against_one_process(tmp_path, world, backend, sparse=False):
+def _ranks_against_one_process(tmp_path, world, backend, sparse=False, sharded=True):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path), backend, sparse), nprocs=world, join=True)
-    ranks = [np.load(tmp_path / "rank{}.npz".format(r)) for r in range(world)]
+    mp.spawn(_worker, args=(world, port, str(tmp_path), backend, sparse, sharded), nprocs=world, join=True)
+    ranks = [dict(np.load(tmp_path / "rank{}.npz".format(r))) for r in range(world)]
     r0 = ranks[0]
     for other in ranks[1:]:
         assert np.array_equal(r0["theta"], other["theta"]), "replicas diverged"
+        assert np.array_equal(r0["m"], other["m"]) and np.array_equal(r0["v"], other["v"]), "gathered slots differ"
+    # the summed gradient of step 1, from the slices their owners hold
+    assert np.all(sum(r["owned"].astype(int) for r in ranks) >= 1)
+    grad1 = np.zeros_like(r0["grad1"])
+    for r in reversed(ranks):
+        grad1[r["owned"]] = r["grad1"][r["owned"]]
+    r0["grad1"] = grad1
     # the reference point: one process, whole batch, same seed
     model = _model()
     store = model.tf_manager.sessions[0].store
@@ -113,10 +134,21 @@ def _ranks_against_one_process(tmp_path, world, backend, sparse=False):
     assert np.abs(r0["theta"] - want).max() <= 6.5e-4
     assert np.median(np.abs(r0["theta"] - want)) <= 1e-6
     assert r0["losses"].shape == (3,) and np.all(np.isfinite(r0["losses"])) and r0["losses"][2] < r0["losses"][0]
+    return r0
 
 
 def test_two_ranks_equal_one_process_on_the_full_batch(tmp_path):
-    _ranks_against_one_process(tmp_path, 2, "gloo")
+    """... with the sharded optimizer (reduce-scatter -> update of the rank's slices -> all-gather: the default) and
+    with the replicated one.  Within a run the replicas are bit-identical; the two runs agree to rounding only (the
+    embedding gradients are scattered with float atomics, no two runs add them in the same order) -- that the sharded
+    update IS the replicated one bit for bit is tests/test_distributed_cpu.py's, on deterministic gradients."""
+    (tmp_path / "s").mkdir()
+    (tmp_path / "r").mkdir()
+    sharded = _ranks_against_one_process(tmp_path / "s", 2, "gloo", sharded=True)
+    replicated = _ranks_against_one_process(tmp_path / "r", 2, "gloo", sharded=False)
+    diff = np.abs(sharded["theta"] - replicated["theta"])
+    assert diff.mean() < 2e-8 and diff.max() < 3e-5, (diff.mean(), diff.max())
+    assert np.abs(sharded["m"] - replicated["m"]).max() <= 1e-4 * np.abs(replicated["m"]).max()
 
 
 def test_two_ranks_with_the_encoder_embeddings_exchanged_as_rows(tmp_path):
@@ -139,8 +171,11 @@ def test_ranks_over_rccl_equal_one_process_on_the_full_batch(tmp_path, world):
 
 
 def _rccl_worker(rank, world, port, out_dir, allreduce="torch"):
+    replicated = allreduce.endswith("-replicated")
+    allreduce = allreduce.split("-")[0]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
-                      NM_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", NM_DIST_ALLREDUCE=allreduce)
+                      NM_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", NM_DIST_ALLREDUCE=allreduce,
+                      NM_DP_SHARDED="0" if replicated else "1", NM_DP_BIG_VARIABLE="1500")
     os.environ.pop("NM_DIST_BACKEND", None)             # default on a GPU box: nccl = RCCL
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -149,9 +184,13 @@ def _rccl_worker(rank, world, port, out_dir, allreduce="torch"):
     dp = distributed.init_from_env()
     assert dp is not None and dp.world_size == 1 and dist.get_backend() == "nccl" and dp.forced
     assert (dp._comm is not None) == (allreduce == "nmhip")
+    sharded = dp.sharded_active()
+    assert sharded == (allreduce == "torch" and not replicated)      # (the library's communicator only all-reduces)
+    dp.bucket_elems = 1001
     reduced = []
-    real_span = dp._reduce_span
+    real_span, real_bucket = dp._reduce_span, dp._reduce_bucket
     dp._reduce_span = lambda grad, lo, hi: (reduced.append((lo, hi)), real_span(grad, lo, hi))[1]
+    dp._reduce_bucket = lambda grad, plan, idx: (reduced.append(plan.buckets[idx][:2]), real_bucket(grad, plan, idx))[1]
     model = _model()
     store = model.tf_manager.sessions[0].store
     dp.broadcast_parameters(store)
@@ -169,12 +208,14 @@ def _rccl_worker(rank, world, port, out_dir, allreduce="torch"):
     distributed.shutdown()
 
 
-@pytest.mark.parametrize("allreduce", ["torch", "nmhip"])
+@pytest.mark.parametrize("allreduce", ["torch", "torch-replicated", "nmhip"])
 def test_rccl_process_group_of_one_trains_like_no_process_group(tmp_path, allreduce):
-    """The RCCL path itself (backend nccl: process group, broadcast, early + bucketed all-reduce on their streams,
+    """The RCCL path itself (backend nccl: process group, broadcast, early + bucketed collectives on their streams,
     global token count) with a world of one, where every collective is the identity: three optimizer steps end
-    bit for bit where the same model ends without a process group.  ``nmhip``: the gradient buckets go through the
-    library's own communicator (nm_allreduce_*, NM_DIST_ALLREDUCE=nmhip) instead of torch.distributed's."""
+    bit for bit where the same model ends without a process group.  ``torch``: the sharded optimizer (in-place
+    reduce-scatter of every bucket, update, in-place all-gather: the default); ``torch-replicated``: all-reduce +
+    the whole update (NM_DP_SHARDED=0); ``nmhip``: the gradient buckets go through the library's own communicator
+    (nm_allreduce_*, NM_DIST_ALLREDUCE=nmhip) instead of torch.distributed's."""
     mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path), allreduce), nprocs=1, join=True)
     got = np.load(tmp_path / "rccl.npz")
     model = _model()

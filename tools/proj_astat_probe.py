@@ -116,9 +116,7 @@ def main():
             env = {"NM_PROJ_ASTAT_ABLATE": str(bits), "NM_PROBE_SHAPES": "2"}
             env.update(more)
             return env
-        variants += [("astat_ck64_no_weight_stream", ab(1)), ("astat_ck64_no_matrix_work", ab(2)),
-                     ("astat_ck64_no_stream_no_barrier", ab(9)), ("astat_ck64_no_statistics", ab(16)),
-                     ("astat_ck64_no_stream_no_statistics", ab(17))]
+        variants += [("astat_no_weight_stream", ab(1)), ("astat_no_statistics", ab(16)), ("astat_no_sum_exp", ab(32))]
     for tag, env in variants:
         print("==", tag, flush=True)
         e = dict(os.environ)
