@@ -566,13 +566,9 @@ struct nm_step_problem {          // mirrors include/nmhip.h
 // r06_decode_beam_kernel_stats_v1.csv).  These groups are bound by the ~25 GB/s at which a CU fills its L1, whatever
 // carries the bytes: halving the bytes per tile (64x64 against 32x32) leaves 160-240 workgroups of 256 KB each for 256
 // CUs, and every LDS-DMA piece costs its wave ~150 issue cycles that the register-staged waves spend on MFMAs.
-static bool sgd_switch() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("NM_STEP_DMA");
-        v = (e && e[0] == '1') ? 1 : 0;
-    }
-    return v != 0;
+static bool sgd_switch() {            // (read per call: a test flips it within one process; a getenv is nanoseconds)
+    const char* e = getenv("NM_STEP_DMA");
+    return e && e[0] == '1';
 }
 
 extern "C" int nm_step_group(void* stream, int64_t M, const nm_step_problem* probs, int32_t nprob) {

@@ -497,7 +497,20 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
             ops.embedding_scatter_add(store.g(self.embedding_matrix_name), self._dec_input_ids(ctx).reshape(-1),
                                       d_emb)
             if dp_overlap and not self.tie_embeddings and self.embeddings_source is None:
-                dp.all_reduce_early(store, [self.embedding_matrix_name])     # runs under the encoder's backward
+                # the decoder's embedding gradient is final here and touches at most B*T + 1 rows (the step inputs:
+                # <s> and the shifted targets): NM_DP_SPARSE_EMB=1 exchanges (ids, rows) instead of the dense [V, E]
+                # slice, like the encoder's (model/sequence.py); otherwise the dense collective starts now and runs
+                # under the encoder's backward
+                sparse = False
+                if dp.sparse_embeddings:
+                    ids_host = np.concatenate([np.asarray(ctx.fed(self.train_tokens)).reshape(-1),
+                                               np.asarray([START_TOKEN_INDEX])])
+                    negate = lambda src, dst: ops.ew("scale", src, None, dst, alpha=-1.0)
+                    scatter = lambda table, ids, rows: ops.embedding_scatter_add(table, ids, rows)
+                    sparse = dp.exchange_sparse_rows(store, self.embedding_matrix_name, ids_host, ops.gather_rows,
+                                                     scatter, negate, skip_pad=False)
+                if not sparse:
+                    dp.all_reduce_early(store, [self.embedding_matrix_name])
 
         # ---- initial state projection and the encoders
         d_enc_out = self.encoder_projection.backward(ctx, self, self.rnn_size, self.encoders, ds0)

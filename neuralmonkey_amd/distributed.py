@@ -325,7 +325,8 @@ class DataParallel:
         dist.all_gather_into_tensor(out, mine)
         return [int(x) for x in out.cpu().tolist()]
 
-    def exchange_sparse_rows(self, store, name: str, host_ids, gather_rows, scatter_add, negate) -> bool:
+    def exchange_sparse_rows(self, store, name: str, host_ids, gather_rows, scatter_add, negate,
+                             skip_pad: bool = True) -> bool:
         """Sum the gradient of the embedding matrix ``name`` over ranks by exchanging only the rows that are not
         zero: every rank contributes the rows of ITS tokens (``host_ids``: the ids the rank embedded this step,
         pad id 0 excluded), B*S rows of E floats instead of V rows -- 13 MB instead of 65 MB per rank at the
@@ -358,7 +359,9 @@ class DataParallel:
         if any(lo < dhi and dlo < hi for dlo, dhi in self._early):
             raise RuntimeError("gradient span [{}, {}) was already reduced this step".format(lo, hi))
         ids = np.unique(np.asarray(host_ids).reshape(-1))
-        ids = ids[ids != 0].astype(np.int32)
+        if skip_pad:                              # (a sequence whose pad rows are masked out of the gradient)
+            ids = ids[ids != 0]
+        ids = ids.astype(np.int32)
         counts = self._host_all_gather_int(len(ids))
         cap = max(256, -(-max(counts) // 256) * 256)
         dev = table.device

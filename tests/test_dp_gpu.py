@@ -55,8 +55,8 @@ def _worker(rank, world, port, out_dir, backend="gloo", sparse=False, sharded=Tr
     seen_sparse = []
     real_sparse = dp.exchange_sparse_rows
 
-    def spy_sparse(st, name, *args):
-        done = real_sparse(st, name, *args)
+    def spy_sparse(st, name, *args, **kwargs):
+        done = real_sparse(st, name, *args, **kwargs)
         seen_sparse.append((name, done))
         return done
     dp.exchange_sparse_rows = spy_sparse
@@ -81,8 +81,11 @@ def _worker(rank, world, port, out_dir, backend="gloo", sparse=False, sharded=Tr
         if step == 0:
             grad1 = store.ensure_grad().cpu().numpy().copy()      # summed over ranks + L2 term, before clipping
     torch.cuda.synchronize()
-    assert len(seen_early) == 6 and "decoder/state_to_word_W" in seen_early[0]      # two early spans per step
-    assert seen_sparse == ([("encoder_input/embedding_matrix_0", True)] * 3 if sparse else [])
+    # two early spans per step: the vocabulary projection and the decoder embeddings (rows instead when sparse)
+    assert len(seen_early) == (3 if sparse else 6) and "decoder/state_to_word_W" in seen_early[0]
+    # both embedding matrices travel as rows: the decoder's first (its backward pass runs first), then the encoder's
+    assert seen_sparse == ([("decoder/word_embeddings", True), ("encoder_input/embedding_matrix_0", True)] * 3
+                           if sparse else [])
     # sharded optimizer: a rank's gradient buffer holds the sum (+ the L2 term) on the slices it owns only
     owned = np.ones(store.total, bool)
     if sharded:
@@ -152,8 +155,10 @@ def test_two_ranks_equal_one_process_on_the_full_batch(tmp_path):
 
 
 def test_two_ranks_with_the_encoder_embeddings_exchanged_as_rows(tmp_path):
-    """NM_DP_SPARSE_EMB=1: the encoder's embedding gradient travels as (unique ids, rows) -- gathered, cancelled
-    and re-added by libnmhip kernels in rank order -- instead of through the dense all-reduce; same identities:
+    """NM_DP_SPARSE_EMB=1: the encoder's AND the decoder's embedding gradients travel as (unique ids, rows) --
+    gathered, cancelled and re-added by libnmhip kernels in rank order -- instead of through the dense collective
+    (under the sharded optimizer their buckets are then complete on every rank and skip the reduce-scatter); same
+    identities:
     replicas bit-identical, summed gradient == one process on the full batch."""
     _ranks_against_one_process(tmp_path, 2, "gloo", sparse=True)
 

@@ -159,3 +159,103 @@ def test_unsupported_shapes_are_refused_not_run(dev):
     assert not ops.gru_seq_supported(640, 512, 1)         # more clusters than XCDs can hold: not all resident at once
     assert ops.gru_seq_supported(256, 512, 1) and not ops.gru_seq_supported(256, 512, 2)
     assert ops.gru_seq_supported(128, 256, 2) and not ops.gru_seq_supported(256, 256, 2)      # 16-row clusters only at H = 256
+
+
+# ---- straight against the oracle (not through the per-step kernels) ----------------------------------------------------
+def _oracle_case(rows, steps, e, h, ndir, seed):
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal((rows, steps, e)) * 0.7).astype(np.float32)
+    lens = rng.integers(1, steps + 1, size=rows).astype(np.int32)
+    lens[0] = steps
+    cells = []
+    for _ in range(ndir):
+        cells.append({"gates_kernel": (rng.standard_normal((e + h, 2 * h)) * (1.2 / (e + h) ** 0.5)).astype(np.float32),
+                      "gates_bias": np.ones(2 * h, np.float32),
+                      "cand_kernel": (rng.standard_normal((e + h, h)) * (1.2 / (e + h) ** 0.5)).astype(np.float32),
+                      "cand_bias": (rng.standard_normal(h) * 0.1).astype(np.float32)})
+    return x, lens, cells
+
+
+@pytest.mark.parametrize("rows,steps,h,ndir", [
+    (37, 7, 256, 2),         # rows that do not fill the row tiles
+    (100, 5, 256, 2),        # 14 clusters: the last XCD hosts none
+    (128, 6, 256, 2),        # 16 clusters: two per XCD
+    (16, 6, 512, 1),         # one cluster
+    (128, 12, 512, 2),       # the headline encoder's shape, ragged
+])
+def test_cluster_loops_against_the_oracle(dev, rows, steps, h, ndir):
+    """The one-launch loops against the oracle's tf.nn.(bidirectional_)dynamic_rnn over TF GRUCells
+    (oracle.nm_oracle.bidirectional_rnn / dynamic_rnn, encoders/recurrent.py:86-102, nn/ortho_gru_cell.py:44-53) on
+    ragged batches, and their BPTT against float64 autograd of the same recurrence -- no per-step HIP kernel in
+    between.  Forward 2e-5 of the largest state, gradients 1e-4 of the largest gradient."""
+    from neuralmonkey_amd import ops
+    from oracle import nm_oracle as O
+    e = 48
+    assert ops.gru_seq_supported(rows, h, ndir)
+    x, lens, cells = _oracle_case(rows, steps, e, h, ndir, seed=rows + 3 * steps + h)
+    if ndir == 2:
+        want_out, want_fin = O.bidirectional_rnn(O.gru_cell, x, lens, cells[0], cells[1])
+        want_fin = np.stack([want_fin[:, :h], want_fin[:, h:]])
+    else:
+        want_out, fin = O.dynamic_rnn(O.gru_cell, x, lens, cells[0])
+        want_fin = fin[None]
+    # input halves of the two kernels as one product per direction (what the encoder hoists out of the loop)
+    xp = np.concatenate([np.concatenate([x.reshape(-1, e) @ c["gates_kernel"][:e] + c["gates_bias"],
+                                         x.reshape(-1, e) @ c["cand_kernel"][:e] + c["cand_bias"]], 1) for c in cells], 1)
+    T = lambda a, dt=torch.float32: torch.tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
+    xpd = T(xp.astype(np.float32))
+    wgh = T(np.stack([c["gates_kernel"][e:] for c in cells]))
+    wch = T(np.stack([c["cand_kernel"][e:] for c in cells]))
+    lengths = T(lens, torch.int32)
+    hcur = torch.zeros(ndir, rows, h, device=dev)
+    out = torch.zeros(rows, steps, ndir * h, device=dev)
+    ru_all = torch.empty(steps, ndir, rows, 2 * h, device=dev)
+    c_all = torch.empty(steps, ndir, rows, h, device=dev)
+    ws = ops.gru_seq_workspace(rows, h, ndir, dev)
+    xrs, xts, ors, ots = steps * ndir * 3 * h, ndir * 3 * h, steps * ndir * h, ndir * h
+    ops.gru_seq_fwd(steps, ndir, rows, h, xpd, (3 * h, xrs, xts), hcur, hcur, 0, ru_all[0], ndir * rows * 2 * h,
+                    None, 0, c_all[0], ndir * rows * h, wgh, wch, ws, lengths=lengths, out=out, out_strides=(h, ors, ots))
+    torch.cuda.synchronize()
+    assert not ops.gru_seq_failed(ws)
+    scale = max(1.0, float(np.abs(want_out).max()))
+    assert np.abs(out.cpu().numpy() - want_out).max() <= 2e-5 * scale
+    assert np.abs(hcur.cpu().numpy() - want_fin).max() <= 2e-5 * scale
+
+    # BPTT: float64 autograd of the same recurrence over the pre-activations xp and the (zero) initial state
+    rng = np.random.default_rng(5)
+    d_out = rng.standard_normal((rows, steps, ndir * h)) * (np.arange(steps)[None, :] < lens[:, None])[:, :, None]
+    d_fin = rng.standard_normal((ndir, rows, h))
+    xp64 = torch.tensor(xp, dtype=torch.float64, requires_grad=True)
+    h0_64 = torch.zeros(ndir, rows, h, dtype=torch.float64, requires_grad=True)
+    lt = torch.tensor(lens)
+    loss = 0.0
+    for d in range(ndir):
+        wg64, wc64 = torch.tensor(cells[d]["gates_kernel"][e:], dtype=torch.float64), \
+            torch.tensor(cells[d]["cand_kernel"][e:], dtype=torch.float64)
+        xd = xp64.view(rows, steps, ndir, 3 * h)[:, :, d]
+        hh = h0_64[d]
+        outs = [None] * steps
+        for t in range(steps):
+            pos = (lt - 1 - t).clamp(min=0) if d == 1 else torch.full((rows,), t)
+            live = (t < lt)[:, None]
+            xt = xd[torch.arange(rows), pos]
+            g = torch.sigmoid(xt[:, :2 * h] + hh @ wg64)
+            r, u = g[:, :h], g[:, h:]
+            c = torch.tanh(xt[:, 2 * h:] + (r * hh) @ wc64)
+            new = torch.where(live, u * hh + (1 - u) * c, hh)
+            contrib = torch.tensor(d_out[torch.arange(rows), pos.numpy(), d * h:(d + 1) * h]) * live
+            loss = loss + (torch.where(live, new, torch.zeros_like(new)) * contrib).sum()
+            hh = new
+        loss = loss + (hh * torch.tensor(d_fin[d])).sum()
+    loss.backward()
+    dh = T(d_fin)
+    dxp = torch.zeros(rows * steps, ndir * 3 * h, device=dev)
+    seq = (h, steps * ndir * h, ndir * h)
+    ops.gru_seq_bwd(steps, ndir, rows, h, dh, T(d_out), seq, ru_all[0], ndir * rows * 2 * h, c_all[0], ndir * rows * h,
+                    None, out, seq, dxp, (3 * h, xrs, xts), wgh, wch, ws, lengths=lengths)
+    torch.cuda.synchronize()
+    assert not ops.gru_seq_failed(ws)
+    want_dxp = xp64.grad.numpy().reshape(rows * steps, ndir * 3 * h)
+    gscale = np.abs(want_dxp).max()
+    assert np.abs(dxp.cpu().numpy() - want_dxp).max() <= 1e-4 * gscale
+    assert np.abs(dh.cpu().numpy() - h0_64.grad.numpy()).max() <= 1e-4 * max(gscale, np.abs(h0_64.grad.numpy()).max())

@@ -30,8 +30,16 @@ def rel(got, ref):
     return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-6))
 
 
+@pytest.fixture(params=["register-staged", "lds-dma"])
+def medium_path(request, monkeypatch):
+    """Both medium-M kernels: the register-staged tiles (default) and the opt-in 64x64 LDS-DMA tiles (NM_STEP_DMA=1,
+    step_group_dma_kernel: kept as a measured negative result, DESIGN 4.5 -- but kept correct)."""
+    monkeypatch.setenv("NM_STEP_DMA", "1" if request.param == "lds-dma" else "0")
+    return request.param
+
+
 @pytest.mark.parametrize("m", [128, 37, 640, 300])     # > 256 rows: 32x32 tiles (step_group_medium_kernel)
-def test_plain_problems_share_a_launch(dev, m):
+def test_plain_problems_share_a_launch(dev, m, medium_path):
     from neuralmonkey_amd import ops
     rng = np.random.default_rng(m)
     shapes = [(1024, 512, True, 1), (512, 1024, False, 0), (40, 64, True, 0)]          # (N, K, add?, act)
@@ -58,7 +66,7 @@ def test_plain_problems_share_a_launch(dev, m):
 
 
 @pytest.mark.parametrize("rows,e,h", [(128, 512, 512), (23, 48, 80), (640, 512, 512)])
-def test_gru_groups_match_the_cell(dev, rows, e, h):
+def test_gru_groups_match_the_cell(dev, rows, e, h, medium_path):
     """group 1 ([emb | h] . Wg -> r, u, r*h ; emb . Wc_x -> xc) + group 2 (candidate, blend in place)."""
     from neuralmonkey_amd import ops
     rng = np.random.default_rng(rows + h)
