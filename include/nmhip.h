@@ -64,6 +64,14 @@ int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int64_t N, int6
                 const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
                 const float* bias, int act, int accumulate, int64_t batch, int64_t strideA,
                 int64_t strideB, int64_t strideC, int algo, void* workspace, int64_t workspace_bytes);
+/* `count` independent products of ONE shape in one launch: C_i (+)= op(A_i) . op(B_i); `pointer_table` is a DEVICE
+ * array of 3 * count pointers {A_0, B_0, C_0, A_1, ...} (16-byte aligned operands).  The weight gradients of a
+ * backward pass (tf.gradients of tf.layers.dense kernels, one tf.matmul each in the reference's graph): their K -- the
+ * rows of the batch -- is deep and their output tiles few, so alone each has to split K and reduce slabs; together
+ * they fill the chip with whole-K workgroups.  No two products of a launch may share their C. */
+int nm_gemm_f32_group(void* stream, int transA, int transB, int64_t M, int64_t N, int64_t K,
+                      const void* pointer_table, int64_t lda, int64_t ldb, int64_t ldc, int accumulate,
+                      int64_t count);
 
 /* ---- embedding lookup: model/sequence.py:170-194, decoders/autoregressive.py:269-272 --
  * out[i,:] = table[ids[i],:] * scale * (mask_pad ? ids[i] != 0 : 1) */
@@ -164,6 +172,14 @@ int nm_layer_norm_fwd(void* stream, const float* x, int64_t ldx, const float* ga
 int nm_layer_norm_bwd(void* stream, const float* dy, const float* x, const float* mean,
                       const float* rstd, const float* gamma, float* dx, float* dyx, int64_t rows,
                       int64_t D);
+/* The same with the parameter gradients in the call: dx as above, dgamma = sum over rows of dy * xhat and dbeta = sum
+ * over rows of dy (tf_utils.py:189-219 differentiated), added to what is there when `accumulate`.  Two launches (row
+ * pass with per-workgroup partial sums, a fixed-order reduction) instead of nm_layer_norm_bwd + two nm_colsum and a
+ * [rows, D] buffer of dy * xhat.  workspace: nm_layer_norm_bwd_params_workspace_bytes(D). */
+int64_t nm_layer_norm_bwd_params_workspace_bytes(int64_t D);
+int nm_layer_norm_bwd_params(void* stream, const float* dy, const float* x, const float* mean, const float* rstd,
+                             const float* gamma, float* dx, int64_t rows, int64_t D, float* dgamma, float* dbeta,
+                             int accumulate, void* workspace, int64_t workspace_bytes);
 
 /* ---- Bahdanau attention step: Attention.attention, attention/feed_forward.py:120-166 ------
  * energies + softmax + mask renormalisation (+1e-8) + context, fused; keys of row r are

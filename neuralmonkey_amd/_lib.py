@@ -27,6 +27,7 @@ SIGNATURES = {
     "nm_version": (I, []),
     "nm_crc32c": (ctypes.c_uint32, [ctypes.c_uint32, P, L]),
     "nm_gemm_f32": (I, [P, I, I, L, L, L, P, L, P, L, P, L, P, I, I, L, L, L, L, I, P, L]),
+    "nm_gemm_f32_group": (I, [P, I, I, L, L, L, P, L, L, L, I, L]),
     "nm_embedding_gather": (I, [P, P, L, L, P, L, P, L, I, F]),
     "nm_gru_gates_fwd": (I, [P, P, L, L, L, P, P, P, P, P, I, I, I, L, L]),
     "nm_gru_blend_fwd": (I, [P, P, L, L, L, P, P, P, P, P, P, L, L, L, P, I, I, I, L, L]),
@@ -77,6 +78,8 @@ SIGNATURES = {
     "nm_colsum": (I, [P, P, L, L, L, P, I, P, L]),
     "nm_embedding_scatter_add": (I, [P, P, L, L, P, L, P, L, I]),
     "nm_layer_norm_bwd": (I, [P, P, P, P, P, P, P, P, L, L]),
+    "nm_layer_norm_bwd_params_workspace_bytes": (L, [L]),
+    "nm_layer_norm_bwd_params": (I, [P, P, P, P, P, P, P, L, L, P, P, I, P, L]),
     "nm_gru_step_bwd": (I, [P, I, P, P, L, L, L, P, P, P, P, L, L, L, P, L, L, L, P, P, P, P, I, I, I, L, L]),
     "nm_gru_seq_shift": (I, [P, P, P, P, I, L, L, I, L]),
     "nm_attn_softmax_bwd": (I, [P, P, P, P, P, L, L, L]),

@@ -19,11 +19,18 @@ the same device memory every run.  During inference the tape does not record
 and ``rewind(slot)`` re-uses one step's buffers for every step (two slots, so
 that the state of step t-1 survives while step t is computed).
 """
+import os
 from typing import Callable, List, Optional, Sequence
 
 import torch
 
 from . import ops
+
+# layer norm backward with its parameter gradients in one call (nm_layer_norm_bwd_params); NM_LN_BWD_FUSED=0: the row
+# pass + two column sums of rounds 1-5
+FUSED_LN_BWD = os.environ.get("NM_LN_BWD_FUSED", "1") != "0"
+# the weight gradients of one shape launched together when a backward pass ends (Tape.defer_wgrad)
+GROUP_WGRADS = os.environ.get("NM_WGRAD_GROUPS", "1") != "0"
 
 
 class Var:
@@ -47,6 +54,7 @@ class Tape:
         self.key = key
         self.recording = recording
         self._ops: List[Callable[[], None]] = []
+        self._wgrads = {}
         self._n = 0
         self._slot = 0
 
@@ -124,6 +132,43 @@ class Tape:
         for fn in reversed(self._ops):
             fn()
         self._ops = []
+        self.flush_wgrads()
+
+    # -- weight gradients, grouped -------------------------------------------------------------------------
+    def defer_wgrad(self, a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, trans_a: bool) -> None:
+        """``out += op(a) @ b`` is a weight gradient: nothing of this backward pass reads it, its operands (an
+        activation and the gradient of a product's output: tape buffers, one per creation index) stay as they are
+        until the pass ends.  Alone such a product is deep (K = the rows of the batch) with few output tiles, so it
+        splits K and reduces slabs in a second launch; the weight gradients of ONE shape are launched together when
+        the pass ends (``flush_wgrads``: nm_gemm_f32_group -- 72 of the 512 x 512 kernels of Transformer-base in one
+        grid).  NM_WGRAD_GROUPS=0, shapes the grouped kernel does not take, and lone products: launched at once."""
+        ok = (GROUP_WGRADS and a.is_cuda and a.dim() == 2 and b.dim() == 2 and out.dim() == 2
+              and a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1
+              and a.stride(0) % 4 == 0 and b.stride(0) % 4 == 0 and out.stride(0) % 4 == 0
+              and a.shape[1] % 4 == 0 and b.shape[1] % 4 == 0 and out.shape[1] % 4 == 0
+              and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0
+              and a.shape[0] >= 1024 and out.shape[0] * out.shape[1] <= (1 << 21))
+        if not ok:
+            ops.gemm(a, b, out=out, trans_a=trans_a, accumulate=True)
+            return
+        key = (trans_a, tuple(a.shape), tuple(b.shape), a.stride(0), b.stride(0), out.stride(0))
+        self._wgrads.setdefault(key, []).append((a, b, out))
+
+    def flush_wgrads(self) -> None:
+        pending, self._wgrads = self._wgrads, {}
+        for (trans_a, *_), items in pending.items():
+            while items:
+                # (a kernel that collects several contributions -- tied / shared weights -- gets them one launch
+                # after the other: no two products of a launch write the same output)
+                seen, now, later = set(), [], []
+                for it in items:
+                    (later if it[2].data_ptr() in seen else now).append(it)
+                    seen.add(it[2].data_ptr())
+                if len(now) == 1:
+                    ops.gemm(now[0][0], now[0][1], out=now[0][2], trans_a=trans_a, accumulate=True)
+                else:
+                    ops.gemm_group(now, trans_a=trans_a, accumulate=True)
+                items = later
 
 
 # ------------------------------------------------------------------------------------------------
@@ -150,9 +195,9 @@ def linear(tape: Tape, x: Var, w: Var, b: Optional[Var] = None, out: Optional[Va
             ops.gemm(dy, w.data, out=gx, trans_b=not trans_b, accumulate=acc)
         if w.needs_grad:
             if trans_b:
-                ops.gemm(dy, x.data, out=tape.grad(w), trans_a=True, accumulate=True)
+                tape.defer_wgrad(dy, x.data, tape.grad(w), True)
             else:
-                ops.gemm(x.data, dy, out=tape.grad(w), trans_a=True, accumulate=True)
+                tape.defer_wgrad(x.data, dy, tape.grad(w), True)
         if b is not None and b.needs_grad:
             ops.colsum(dy, tape.grad(b), accumulate=True)
     tape.record(bwd)
@@ -214,7 +259,7 @@ def linear_multi(tape: Tape, x: Var, ws: List[Var]) -> List[Var]:
                 gx, acc = tape.grad_slot(x)
                 ops.gemm(o.grad, w.data, out=gx, trans_b=True, accumulate=acc)
             if w.needs_grad:
-                ops.gemm(x.data, o.grad, out=tape.grad(w), trans_a=True, accumulate=True)
+                tape.defer_wgrad(x.data, o.grad, tape.grad(w), True)
     tape.record(bwd)
     return outs
 
@@ -411,15 +456,21 @@ def layer_norm(tape: Tape, x: Var, gamma: Var, beta: Var, eps: float = 1e-6) -> 
             return
         d = x.shape[-1]
         gx, acc = tape.grad_slot(x)
-        dyx = tape.buf(tuple(x.shape))
         # a fresh gradient buffer takes dx directly (no scratch + copy); otherwise dx is added to what is there
         dx = gx if (gx is not None and not acc and gx.is_contiguous()) else tape.buf(tuple(x.shape))
-        ops.layer_norm_bwd(out.grad, x.data, mean, rstd, gamma.data, dx, dyx)
+        if (FUSED_LN_BWD and gamma.needs_grad and d <= 2048 and d % 4 == 0 and out.grad.is_contiguous()
+                and x.data.is_contiguous() and out.grad.data_ptr() % 16 == 0 and x.data.data_ptr() % 16 == 0
+                and dx.data_ptr() % 16 == 0 and gamma.data.data_ptr() % 16 == 0):
+            # dx, dgamma and dbeta in one call: no [rows, D] buffer of dy * xhat, no separate column sums
+            ops.layer_norm_bwd_params(out.grad, x.data, mean, rstd, gamma.data, dx, gamma.grad, beta.grad)
+        else:
+            dyx = tape.buf(tuple(x.shape))
+            ops.layer_norm_bwd(out.grad, x.data, mean, rstd, gamma.data, dx, dyx)
+            if gamma.needs_grad:
+                ops.colsum(dyx.view(rows, d), gamma.grad, accumulate=True)
+                ops.colsum(out.grad.view(rows, d), beta.grad, accumulate=True)
         if gx is not None and dx is not gx:
             ops.ew("copy", dx, None, gx, accumulate=True)
-        if gamma.needs_grad:
-            ops.colsum(dyx.view(rows, d), gamma.grad, accumulate=True)
-            ops.colsum(out.grad.view(rows, d), beta.grad, accumulate=True)
     tape.record(bwd)
     return out
 

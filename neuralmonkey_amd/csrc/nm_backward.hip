@@ -201,6 +201,177 @@ extern "C" int nm_layer_norm_bwd(void* stream, const float* dy, const float* x, 
     NM_LAUNCH_CHECK("nm_layer_norm_bwd");
 }
 
+// Layer norm backward with its parameter gradients (round 6).  nm_layer_norm_bwd leaves dy * xhat behind and the
+// caller column-sums it and dy for dgamma / dbeta: three launches and a [rows, D] round trip through HBM per layer
+// norm -- 64 of the 88 column sums of a Transformer-base training step (1.65 ms of 30.7,
+// profiles/r05_transformer_train_kernel_stats.csv).  Here a workgroup walks rows blockIdx.x, + gridDim.x, ... : dx as
+// above, and every lane keeps the running column sums of its own columns in registers; the workgroups' partial sums
+// [G][2][D] are added by a second, tiny launch in a fixed order (deterministic; G <= 256).  (A first version with one
+// 256-thread workgroup per row group and two workgroup reductions per row was SLOWER than the three launches it
+// replaced -- Transformer-base 32.6 against 30.7 ms per step: 25 rows one after the other, four barriers each.)
+#define LNB_MAX_CH 8                   // 256-column chunks per row: D <= 2048
+// One WAVE per row (a lane owns 4 consecutive columns of every 256-column chunk: 16-byte loads, the two row sums are
+// DPP wave reductions, no workgroup barrier inside the row loop); a workgroup's four waves walk rows
+// 4 blockIdx.x + wave, + 4 gridDim.x, ... and add their column sums through LDS at the end.
+template <int NCH>
+__global__ __launch_bounds__(256) void layer_norm_bwd_params_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                    const float* __restrict__ mean,
+                                                                    const float* __restrict__ rstd,
+                                                                    const float* __restrict__ gamma, float* __restrict__ dx,
+                                                                    float* __restrict__ part, long rows, int D) {
+    __shared__ float4 sh[3][NCH][2][64];           // waves 1..3: [chunk][dgamma | dbeta][lane]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 sg[NCH], sb[NCH], gm[NCH];
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        sg[c] = z4; sb[c] = z4;
+        const int col = 256 * c + 4 * lane;
+        gm[c] = col < D ? *reinterpret_cast<const float4*>(gamma + col) : z4;
+    }
+    const float invd = 1.0f / (float)D;
+    // RPI rows per trip: their loads are all in flight before the first reduction (a wave that walks its rows one
+    // after the other pays a memory round trip per row: measured slower than the three launches this replaces)
+    constexpr int RPI = NCH <= 2 ? 4 : (NCH <= 4 ? 2 : 1);
+    const long stride = (long)gridDim.x * 4;
+    for (long row0 = (long)blockIdx.x * 4 + wave; row0 < rows; row0 += stride * RPI) {
+        float4 xh[RPI][NCH], d[RPI][NCH];
+        float mu[RPI], rs[RPI];
+#pragma unroll
+        for (int r = 0; r < RPI; ++r) {
+            const long row = row0 + r * stride;
+            const bool live = row < rows;
+            mu[r] = live ? mean[row] : 0.0f;
+            rs[r] = live ? rstd[row] : 0.0f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int col = 256 * c + 4 * lane;
+                xh[r][c] = z4; d[r][c] = z4;
+                if (live && col < D) {
+                    xh[r][c] = *reinterpret_cast<const float4*>(x + row * D + col);
+                    d[r][c] = *reinterpret_cast<const float4*>(dy + row * D + col);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RPI; ++r) {
+            const long row = row0 + r * stride;
+            if (row >= rows) break;
+            float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const float4 xv = xh[r][c];
+                xh[r][c] = make_float4((xv.x - mu[r]) * rs[r], (xv.y - mu[r]) * rs[r], (xv.z - mu[r]) * rs[r],
+                                       (xv.w - mu[r]) * rs[r]);
+                if (256 * c + 4 * lane >= D) xh[r][c] = z4;
+                const float4 g = make_float4(d[r][c].x * gm[c].x, d[r][c].y * gm[c].y, d[r][c].z * gm[c].z,
+                                             d[r][c].w * gm[c].w);
+                s1 += (g.x + g.y) + (g.z + g.w);
+                s2 += (g.x * xh[r][c].x + g.y * xh[r][c].y) + (g.z * xh[r][c].z + g.w * xh[r][c].w);
+            }
+            const float m1 = nm_wave_sum_dpp(s1) * invd, m2 = nm_wave_sum_dpp(s2) * invd;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int col = 256 * c + 4 * lane;
+                if (col < D) {
+                    const float4 dd = d[r][c], hh = xh[r][c];
+                    float4 o;
+                    o.x = rs[r] * (dd.x * gm[c].x - m1 - hh.x * m2);
+                    o.y = rs[r] * (dd.y * gm[c].y - m1 - hh.y * m2);
+                    o.z = rs[r] * (dd.z * gm[c].z - m1 - hh.z * m2);
+                    o.w = rs[r] * (dd.w * gm[c].w - m1 - hh.w * m2);
+                    *reinterpret_cast<float4*>(dx + row * D + col) = o;
+                    sg[c].x += dd.x * hh.x; sg[c].y += dd.y * hh.y; sg[c].z += dd.z * hh.z; sg[c].w += dd.w * hh.w;
+                    sb[c].x += dd.x; sb[c].y += dd.y; sb[c].z += dd.z; sb[c].w += dd.w;
+                }
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) { sh[wave - 1][c][0][lane] = sg[c]; sh[wave - 1][c][1][lane] = sb[c]; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int col = 256 * c + 4 * lane;
+            if (col >= D) continue;
+            float4 a = sg[c], b = sb[c];
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {                       // waves in order: a fixed sum
+                const float4 pa = sh[w][c][0][lane], pb = sh[w][c][1][lane];
+                a.x += pa.x; a.y += pa.y; a.z += pa.z; a.w += pa.w;
+                b.x += pb.x; b.y += pb.y; b.z += pb.z; b.w += pb.w;
+            }
+            *reinterpret_cast<float4*>(part + ((long)blockIdx.x * 2) * D + col) = a;
+            *reinterpret_cast<float4*>(part + ((long)blockIdx.x * 2 + 1) * D + col) = b;
+        }
+    }
+}
+
+// 32 columns x 8 row groups per workgroup: a thread adds every eighth partial row of its column (four loads in flight),
+// the eight groups meet in LDS in a fixed order.  (One thread per column walking all 256 partial rows took 60 us: a
+// chain of dependent loads on four workgroups.)
+__global__ __launch_bounds__(256) void layer_norm_bwd_reduce_kernel(const float* __restrict__ part, int G, int D,
+                                                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                    int accumulate) {
+    __shared__ float sh[8][32];
+    const int cx = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    const bool ok = c < 2 * D;
+    const int which = ok ? c / D : 0, col = ok ? c - which * D : 0;
+    const float* p = part + (long)which * D + col;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int g = q;
+    for (; g + 24 < G; g += 32) {
+        s0 += p[(long)g * 2 * D];
+        s1 += p[(long)(g + 8) * 2 * D];
+        s2 += p[(long)(g + 16) * 2 * D];
+        s3 += p[(long)(g + 24) * 2 * D];
+    }
+    for (; g < G; g += 8) s0 += p[(long)g * 2 * D];
+    sh[q][cx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (q == 0 && ok) {
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += sh[k][cx];
+        float* out = which ? dbeta : dgamma;
+        out[col] = accumulate ? out[col] + s : s;
+    }
+}
+
+extern "C" int64_t nm_layer_norm_bwd_params_workspace_bytes(int64_t D) { return 256 * 2 * D * 4; }
+
+extern "C" int nm_layer_norm_bwd_params(void* stream, const float* dy, const float* x, const float* mean,
+                                        const float* rstd, const float* gamma, float* dx, int64_t rows, int64_t D,
+                                        float* dgamma, float* dbeta, int accumulate, void* workspace,
+                                        int64_t workspace_bytes) {
+    NM_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && workspace && rows >= 0 && D > 0,
+               "nm_layer_norm_bwd_params: bad args");
+    NM_REQUIRE(D <= 256 * LNB_MAX_CH && D % 4 == 0, "nm_layer_norm_bwd_params: D = %ld (a multiple of 4, at most %d)",
+               (long)D, 256 * LNB_MAX_CH);
+    NM_REQUIRE(nm_aligned16(dy) && nm_aligned16(x) && nm_aligned16(dx) && nm_aligned16(gamma) && nm_aligned16(workspace),
+               "nm_layer_norm_bwd_params: operands must be 16-byte aligned");
+    NM_REQUIRE(workspace_bytes >= nm_layer_norm_bwd_params_workspace_bytes(D), "nm_layer_norm_bwd_params: workspace too small");
+    if (rows == 0) return NM_OK;
+    const int G = (int)((rows + 3) / 4 < 256 ? (rows + 3) / 4 : 256);
+    hipStream_t st = nm_stream(stream);
+    float* part = reinterpret_cast<float*>(workspace);
+    const int nch = (int)((D + 255) / 256);
+#define NM_LNB(N_) hipLaunchKernelGGL((layer_norm_bwd_params_kernel<N_>), dim3(G), dim3(256), 0, st, dy, x, mean, rstd, \
+                                      gamma, dx, part, (long)rows, (int)D)
+    if (nch <= 1) NM_LNB(1);
+    else if (nch == 2) NM_LNB(2);
+    else if (nch <= 4) NM_LNB(4);
+    else NM_LNB(8);
+#undef NM_LNB
+    hipLaunchKernelGGL(layer_norm_bwd_reduce_kernel, dim3((unsigned)((2 * D + 31) / 32)), dim3(256), 0, st, part, G,
+                       (int)D, dgamma, dbeta, accumulate);
+    NM_LAUNCH_CHECK("nm_layer_norm_bwd_params");
+}
+
 // ---------------------------------------------------------------------------
 // GRU step backward epilogues (see nm_elementwise.hip for the forward split).
 //   h' = u*h + (1-u)*c ; c = tanh(xc + (r*h).Wc_h) ; [r,u] = sigmoid(xg + h.Wg_h)

@@ -46,6 +46,8 @@ struct GemmArgs {
     int store_c;     // 0: the statistics are the only output (greedy decoding never reads the logits)
     int prio;        // skinny kernels: raise the wave priority (s_setprio) -- launches of a time loop that share the
                      // chip with a background GEMM of another stream get the issue slots first
+    const float* const* ptrs;    // gemm_tiled, grouped products (nm_gemm_f32_group): [batch][3] device pointers {A, B, C} of
+                                 // independent products of one shape instead of base + z * stride
 };
 
 __device__ __forceinline__ float apply_act(float x, int act) {
@@ -132,9 +134,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tiled(GemmArgs g, int tiles
         }
     }
     const int m0 = bm * BM, n0 = bn * BN;
-    const float* __restrict__ A = g.A + (long)blockIdx.z * g.sA;
-    const float* __restrict__ B = g.B + (long)blockIdx.z * g.sB;
-    float* __restrict__ C = g.C + (long)blockIdx.z * g.sC;
+    const float* __restrict__ A = g.ptrs ? g.ptrs[3 * blockIdx.z] : g.A + (long)blockIdx.z * g.sA;
+    const float* __restrict__ B = g.ptrs ? g.ptrs[3 * blockIdx.z + 1] : g.B + (long)blockIdx.z * g.sB;
+    float* __restrict__ C = g.ptrs ? const_cast<float*>(g.ptrs[3 * blockIdx.z + 2]) : g.C + (long)blockIdx.z * g.sC;
 
     float4 ra0[LA], rb0[LB], ra1[PF == 2 ? LA : 1], rb1[PF == 2 ? LB : 1];
 
@@ -1038,6 +1040,33 @@ extern "C" int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int6
         }
     }
     NM_LAUNCH_CHECK("nm_gemm_f32");
+}
+
+// ``count`` independent products of ONE shape in one launch: C_i (+)= op(A_i) . op(B_i), the operands named by a device
+// table of pointers.  Made for the weight gradients of a training step's backward pass (autodiff.Tape.defer_wgrad):
+// K = the rows of the batch is deep, the output tiles of one product are few (16 tiles of 128x128 for a 512x512
+// kernel), so every product alone had to split K over workgroups and add the slabs in a second launch -- 97 products
+// + 121 slab reductions per Transformer-base step.  72 of them in one grid are 1152 workgroups that each walk the
+// whole K: no slabs, no reduction, one launch.  No two products of a launch may share their C.
+extern "C" int nm_gemm_f32_group(void* stream, int transA, int transB, int64_t M, int64_t N, int64_t K,
+                                 const void* pointer_table, int64_t lda, int64_t ldb, int64_t ldc, int accumulate,
+                                 int64_t count) {
+    NM_REQUIRE(pointer_table && count >= 1 && count < 65536, "nm_gemm_f32_group: null table / bad count %ld", (long)count);
+    NM_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1 << 30) && N < (1 << 30) && K < (1 << 30),
+               "nm_gemm_f32_group: bad shape %ld %ld %ld", (long)M, (long)N, (long)K);
+    const bool ta = transA != 0, tb = transB != 0;
+    NM_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && (ta ? M : K) % 4 == 0 && (tb ? K : N) % 4 == 0,
+               "nm_gemm_f32_group: leading dimensions and contiguous extents must be multiples of 4 (the operands "
+               "themselves 16-byte aligned)");
+    GemmArgs g{nullptr, nullptr, nullptr, nullptr, (int)M, (int)N, (int)K, (long)lda, (long)ldb, (long)ldc,
+               0, 0, 0, 0, accumulate, nullptr, 1, 0, nullptr, 1};
+    g.swizzle = nm_cur()->sw.gemm_swz;
+    g.ptrs = reinterpret_cast<const float* const*>(pointer_table);
+    hipStream_t st = nm_stream(stream);
+    const long blocks128 = (long)nm_cdiv(M, 128) * nm_cdiv(N, 128) * count;
+    if (blocks128 >= 192) launch_tiled<4, 2, 1, 2, 16>(g, (int)count, ta, tb, true, st);          // 128x128, 8 waves
+    else launch_tiled<2, 2, 1, 1, 16>(g, (int)count, ta, tb, true, st);                           // 64x64
+    NM_LAUNCH_CHECK("nm_gemm_f32_group");
 }
 
 // ---------------------------------------------------------------------------

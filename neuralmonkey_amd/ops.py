@@ -83,6 +83,35 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, b
     return out
 
 
+_GROUP_TABLES = {}
+
+
+def gemm_group(items, trans_a=False, trans_b=False, accumulate=True):
+    """``items`` = [(a, b, out)] of ONE shape: out_i (+)= op(a_i) @ op(b_i) in one launch (nm_gemm_f32_group).  The
+    device table of operand pointers is built once per distinct list of pointers and kept (a training step names the
+    same persistent buffers every time; a captured step replays the launch with its table)."""
+    lib = _lib.load()
+    a0, b0, o0 = items[0]
+    m, k = (a0.shape[1], a0.shape[0]) if trans_a else (a0.shape[0], a0.shape[1])
+    n = b0.shape[0] if trans_b else b0.shape[1]
+    lda, ldb, ldc = a0.stride(0), b0.stride(0), o0.stride(0)
+    ptrs = []
+    for a, b, o in items:
+        assert a.shape == a0.shape and b.shape == b0.shape and o.shape == o0.shape
+        assert (a.stride(0), b.stride(0), o.stride(0)) == (lda, ldb, ldc) and a.stride(1) == b.stride(1) == o.stride(1) == 1
+        assert a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and o.data_ptr() % 16 == 0
+        ptrs += [a.data_ptr(), b.data_ptr(), o.data_ptr()]
+    assert len({p for p in ptrs[2::3]}) == len(items), "two products of a group share their output"
+    key = (a0.device, tuple(ptrs))
+    table = _GROUP_TABLES.get(key)
+    if table is None:
+        if len(_GROUP_TABLES) > 64:
+            _GROUP_TABLES.clear()
+        table = _GROUP_TABLES[key] = torch.tensor(ptrs, dtype=torch.int64, device=a0.device)
+    _lib.check(lib.nm_gemm_f32_group(_stream(), int(trans_a), int(trans_b), m, n, k, table.data_ptr(), lda, ldb, ldc,
+                                     int(accumulate), len(items)), "nm_gemm_f32_group")
+
+
 _GEMM_WS = {}
 GEMM_WORKSPACE_BYTES = 128 << 20
 # Scratch that kernels re-use from call to call (split-K slabs, column-sum partials + tickets) is keyed by the stream
@@ -535,6 +564,26 @@ def embedding_scatter_add(dtable, ids, d, skip_pad=False):
     _lib.check(lib.nm_embedding_scatter_add(_stream(), dtable.data_ptr(), dtable.shape[0], dtable.shape[1],
                                             ids.data_ptr(), ids.numel(), d.data_ptr(), d.stride(0),
                                             int(skip_pad)), "nm_embedding_scatter_add")
+
+
+_LNB_WS = {}
+
+
+def layer_norm_bwd_params(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, accumulate=True):
+    """dx of a layer norm and its parameter gradients in one call (nm_layer_norm_bwd_params)."""
+    lib = _lib.load()
+    d = x.shape[-1]
+    rows = x.numel() // d
+    assert dy.is_contiguous() and x.is_contiguous() and dx.is_contiguous()
+    key = (x.device, d)
+    ws = _LNB_WS.get(key)
+    if ws is None:
+        ws = _LNB_WS[key] = torch.empty(lib.nm_layer_norm_bwd_params_workspace_bytes(d) // 4, dtype=torch.float32,
+                                        device=x.device)
+    _lib.check(lib.nm_layer_norm_bwd_params(_stream(), dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                            gamma.data_ptr(), dx.data_ptr(), rows, d, dgamma.data_ptr(),
+                                            dbeta.data_ptr(), int(accumulate), ws.data_ptr(), ws.numel() * 4),
+               "nm_layer_norm_bwd_params")
 
 
 def layer_norm_bwd(dy, x, mean, rstd, gamma, dx, dyx):
