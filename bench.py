@@ -29,7 +29,8 @@ Prints ONE JSON line (rank 0) with
   ``cpu_baseline``   torch-CPU / NumPy restatement of the reference's step (NOT TF 1.12 -- TF cannot
                      be installed here) on the headline batch (B=128): SURVEY 8(d)'s protocol (8 threads,
                      median of 5 after 2 warm-ups) on a bounded sample, next to it all host threads;
-  ``configs``        BASELINE configs[3] (captioning) and configs[4] (Transformer-base) at their own shapes:
+  ``configs``        BASELINE configs[3] (captioning) and configs[4] (Transformer-base) at their own shapes, the taped
+                     general path (NematusGRU + conditional GRU) at the headline size:
                      training step, greedy and beam-5 decoding, each with its own roofline.
 """
 import argparse
@@ -233,6 +234,64 @@ def transformer_leg(args, dev):
                          "flops_per_step": flops, "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                          "frac": tf / MFMA_F32_PEAK_TF},
             "roofline_decode": roofline_decode}
+
+
+def general_path_leg(args, dev):
+    """The TAPED general path at the headline size (no BASELINE config of its own: what tests/small.ini = configs[0] and
+    every Nematus-style experiment run on): NematusGRU bidirectional encoder + Bahdanau attention + conditional
+    NematusGRU decoder (nn/ortho_gru_cell.py:57-105, decoders/decoder.py:303-325), H = E = 512, B = 128, len 50,
+    V = 32000.  The encoder layer's time loops are one cluster launch each way (nm_nematus_seq_fwd / _bwd); the
+    conditional decoder steps launch by launch inside one HIP graph per batch shape."""
+    from neuralmonkey_amd import synthetic
+    from neuralmonkey_amd.attention import Attention
+    from neuralmonkey_amd.decoders import BeamSearchDecoder, Decoder
+    from neuralmonkey_amd.encoders import SentenceEncoder
+    from neuralmonkey_amd.runners import BeamSearchRunner, GreedyRunner
+    from neuralmonkey_amd.runtime import reset_registry
+    from neuralmonkey_amd.tf_manager import TensorFlowManager
+    from neuralmonkey_amd.trainers import CrossEntropyTrainer
+    batch, length, vocab, h = args.batch, args.length, args.vocab, args.hidden
+    reset_registry()
+    sv, tv = synthetic.synthetic_vocabulary(vocab), synthetic.synthetic_vocabulary(vocab)
+    enc = SentenceEncoder(name="encoder", vocabulary=sv, data_id="source", embedding_size=h, rnn_size=h,
+                          max_input_len=length, rnn_cell="NematusGRU")
+    att = Attention(name="attention", encoder=enc)
+    dec = Decoder(encoders=[enc], vocabulary=tv, data_id="target", name="decoder", max_output_len=length,
+                  embedding_size=h, rnn_size=h, attentions=[att], rnn_cell="NematusGRU", conditional_gru=True)
+    bdec = BeamSearchDecoder(name="beam_decoder", parent_decoder=dec, beam_size=5, max_steps=length,
+                             length_normalization=0.6)
+    greedy, beam = GreedyRunner(output_series="target", decoder=dec), BeamSearchRunner(output_series="target_beam",
+                                                                                      decoder=bdec, rank=1)
+    trainer = CrossEntropyTrainer(decoders=[dec], l2_weight=1e-8, clip_norm=1.0)
+    tfm = TensorFlowManager(num_sessions=1, num_threads=4, device=dev, seed=1234)
+    tfm.initialize_sessions()
+    store = tfm.sessions[0].store
+    synthetic.load_baseline_weights(store, seed=1234, std=0.05)
+    pool = [synthetic.synthetic_dataset(seed=8000 + i, batch=batch, src_len=length, tgt_len=length, vocab=vocab)
+            for i in range(2)]
+    it = iter(range(1 << 30))
+    res = {}
+
+    def train():
+        res["out"] = tfm.execute(pool[next(it) % 2], trainer.feedables, [trainer], train=True)[0]
+    t_train = _timed_gpu(train, 3, 6)
+    if getattr(args, "general_train_only", False):              # (tools/general_path_probe.py --train-only, for profiles)
+        return {"train_ms_per_step": t_train * 1e3, "loss": res["out"].losses["decoder - cost"]}
+    store["decoder/state_to_word_b"][2] = -1e9                   # </s> unreachable: all steps run
+    dsd = [synthetic.synthetic_dataset(seed=9000 + i, batch=batch, src_len=length, tgt_len=length, vocab=vocab,
+                                       with_target=False) for i in range(2)]
+    out = {}
+    for name, runner in (("greedy", greedy), ("beam5", beam)):
+        t = _timed_gpu(lambda: tfm.execute(dsd[next(it) % 2], runner.feedables, [runner], compute_losses=False), 2, 3)
+        r = tfm.execute(dsd[0], runner.feedables, [runner], compute_losses=False)[0]
+        out[name] = (t, max(len(sent) for sent in r.outputs[runner.output_series]))
+    tokens = batch * length
+    return {"workload": "general (taped) path: NematusGRU biRNN encoder + Bahdanau attention + conditional NematusGRU "
+                        "decoder, H=E={}, B={}, len={}, V={}, CrossEntropyTrainer + Adam".format(h, batch, length, vocab),
+            "train_ms_per_step": t_train * 1e3, "train_tok_s": tokens / t_train,
+            "loss": res["out"].losses["decoder - cost"],
+            "greedy_ms_per_batch": out["greedy"][0] * 1e3, "greedy_steps": out["greedy"][1],
+            "beam5_ms_per_batch": out["beam5"][0] * 1e3, "beam5_steps": out["beam5"][1]}
 
 
 def captioning_leg(args, dev, lib):
@@ -927,6 +986,7 @@ def main():
             legs = {}
             for name, fn in (("transformer", lambda: transformer_leg(args, dev)),
                              ("captioning", lambda: captioning_leg(args, dev, lib)),
+                             ("general_path", lambda: general_path_leg(args, dev)),
                              ("gru_time_loops", lambda: time_loops_leg(args, dev)),
                              ("decode_split_projection", lambda: split_projection_leg(args, dev)),
                              ("logits_gemm_bf16x3", lambda: bf16x3_costing_leg(args, dev, lib))):

@@ -155,6 +155,25 @@ int nm_gru_seq_fwd(void* stream, const nm_gru_epilogue* e, int32_t steps, int64_
 int nm_gru_seq_bwd(void* stream, const nm_gru_epilogue* e, int32_t steps, int64_t ru_step, int64_t c_step,
                    const float* wgh, int64_t ld_g, int64_t stride_g, const float* wch, int64_t ld_c,
                    int64_t stride_c, void* workspace, int64_t workspace_bytes, uint32_t* sticky_error);
+/* The same for NematusGRUCell (nn/ortho_gru_cell.py:73-105: the reset gate multiplies the state projection AFTER the
+ * product, c = tanh(x_c + r * (h.U_c + b_cs))): both recurrent products read h only, so a step is ONE product, one
+ * element-wise stage and one hand-off.  Shapes, workspace ownership, give-up behaviour and `sticky_error` as
+ * nm_gru_seq_*; ug [ndir][H][2H] and uc [ndir][H][H] are the STATE projections (input projections and their biases are
+ * in xp, 3H wide per direction: r | u | c), bgs / bcs their optional biases ([ndir][2H] / [ndir][H]).
+ *   fwd   step t also writes sc = h.U_c + b_cs to e->rh + t*sc_step (required: the backward loop reads it); h_in and
+ *         h_out must be DIFFERENT buffers (one stage per step: a workgroup may write step 0's state while another
+ *         still reads the initial one);
+ *   bwd   dxp is 4H wide per direction: [dr' | du' | dc' | dsc] of the step's position -- columns [0, 3H) are the
+ *         gradient of xp, columns [0, 2H) and [3H, 4H) those of the state projections' outputs. */
+int64_t nm_nematus_seq_workspace_bytes(int64_t R, int64_t H, int32_t ndir);
+int nm_nematus_seq_fwd(void* stream, const nm_gru_epilogue* e, int32_t steps, int64_t h_step, int64_t ru_step,
+                       int64_t sc_step, int64_t c_step, const float* ug, int64_t ld_g, int64_t stride_g,
+                       const float* uc, int64_t ld_c, int64_t stride_c, const float* bgs, const float* bcs,
+                       void* workspace, int64_t workspace_bytes, uint32_t* sticky_error);
+int nm_nematus_seq_bwd(void* stream, const nm_gru_epilogue* e, int32_t steps, int64_t ru_step, int64_t sc_step,
+                       int64_t c_step, const float* ug, int64_t ld_g, int64_t stride_g, const float* uc,
+                       int64_t ld_c, int64_t stride_c, void* workspace, int64_t workspace_bytes,
+                       uint32_t* sticky_error);
 int nm_gru_seq_shift(void* stream, const float* seq, float* out, const int32_t* lengths, int rev_mask,
                      int64_t B, int64_t S, int ndir, int64_t H);
 int nm_gru_rh_seq(void* stream, const float* ru_all, const float* hprev, float* out,

@@ -554,6 +554,235 @@ __global__ __launch_bounds__(512, 3) void gru_cluster_bwd_kernel(GruClu q) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// NematusGRUCell time loops (nn/ortho_gru_cell.py:73-105), round 6.  The reset gate is applied AFTER the state
+// projection -- g = sigmoid(x_g + h.U_g), sc = h.U_c, c = tanh(x_c + sc * r), h' = u h + (1 - u) c -- so both recurrent
+// products read h only: a step is ONE product (16 units' r, u and sc columns per workgroup) with one elementwise stage
+// and ONE hand-off (h'), where the TF GRUCell above needs two.  Steps alternate between the two granule buffers (what
+// step t published is overwritten by step t + 2, behind every consumer).  Saved for the backward pass: r | u, c and sc.
+//   backward, step t (last first):  dhv = dh + dout;  dc' = dhv (1-u)(1-c^2);  du' = dhv (h_prev - c) u (1-u);
+//   dsc = dc' r;  dr' = dc' sc r (1-r);  dh = dhv u + [dr' | du' | dsc] . [U_g ; U_c]^T     (ONE product, K = 3H)
+// dxp (sequence-addressed, 4H wide per direction) receives [dr' | du' | dc' | dsc]: the input-kernel gradients come
+// from its first 3H columns, the state-kernel gradients from columns [0, 2H) and [3H, 4H) against the shifted states.
+// ---------------------------------------------------------------------------------------------------------------
+struct NemClu {
+    GruClu q;                    // e.rh / rh_step: sc of every step; xa / xb: the two buffers (forward: width H,
+                                 // backward: width 3H each)
+    const float* bgs;            // optional state biases [ndir][2H] / [ndir][H]
+    const float* bcs;
+};
+
+template <int RT>
+__global__ __launch_bounds__(512, 3) void nematus_cluster_fwd_kernel(NemClu a) {
+    constexpr int NCH = 4;
+    const GruClu& q = a.q;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NW = (int)(blockDim.x >> 6);
+    const int H = q.e.H, R = (int)q.e.R;
+    if (q.force_fail && blockIdx.x == 0 && tid == 0) __hip_atomic_store((gu32*)q.hdr, 1u, NM_RLX_AGENT);
+    const CluRole role = clu_roles(q.hdr, q.ndir * q.nrb, H / 16, reinterpret_cast<int*>(lds), q.force_global);
+    if (!role.active) {
+        if (tid == 0 && q.sticky && __hip_atomic_load((gu32*)q.hdr, NM_RLX_AGENT) != 0) __hip_atomic_store((gu32*)q.sticky, 1u, NM_RLX_AGENT);
+        return;
+    }
+    __builtin_amdgcn_s_setprio(3);
+    const int jb = role.jb;
+    const int d = role.cl / q.nrb, rb = role.cl % q.nrb;
+    const int row0 = rb * 16 * RT;
+    const int n16 = lane & 15, kq = lane >> 4;
+    const int k_wave = wave * 16 * NCH;
+    float* red = lds;                                    // [NW][3 RT][4][64]
+    gu32* err = (gu32*)q.hdr;
+    float wr[NCH][4], wu[NCH][4], wk[NCH][4];
+    {
+        const float* Wg = q.wg + (long)d * q.sg + 16 * jb + n16;
+        const float* Wc = q.wc + (long)d * q.sc + 16 * jb + n16;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long k = k_wave + 16 * c + 4 * kq + j;
+                wr[c][j] = Wg[k * q.ldg];
+                wu[c][j] = Wg[k * q.ldg + H];
+                wk[c][j] = Wc[k * q.ldc];
+            }
+    }
+    const bool epi = tid < 256 * RT;
+    const int ert = tid >> 8, reg = (tid >> 6) & 3, ln = tid & 63;
+    const int rloc = 4 * (ln >> 4) + reg, col = 16 * jb + (ln & 15);
+    const int row = row0 + 16 * ert + rloc;
+    const bool mine = epi && row < R;
+    const long ro = (long)d * R + min(row, R - 1);
+    const int len = (mine && q.e.lengths) ? q.e.lengths[row] : 0x7fffffff;
+    float hreg = mine ? q.e.h_in[ro * H + col] : 0.0f;
+    const bool rev = ((q.e.rev_mask >> d) & 1) && q.e.lengths;
+    const float b_r = a.bgs ? a.bgs[(long)d * 2 * H + col] : 0.0f, b_u = a.bgs ? a.bgs[(long)d * 2 * H + H + col] : 0.0f;
+    const float b_c = a.bcs ? a.bcs[(long)d * H + col] : 0.0f;
+    u64* X0 = q.xa + (long)role.cl * 16 * RT * H;
+    u64* X1 = q.xb + (long)role.cl * 16 * RT * H;
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+
+    for (int t = 0; t < q.steps; ++t) {
+        const bool live = mine && t < len;
+        const int pos = rev ? len - 1 - t : t;
+        float xr = 0.0f, xu = 0.0f, xc = 0.0f;
+        if (live) {
+            const float* x = q.e.xp + d * q.e.x_dir + (long)row * q.e.x_row + (long)pos * q.e.x_time + col;
+            xr = x[0]; xu = x[H]; xc = x[2 * H];
+        }
+        u64* Xin = (t & 1) ? X0 : X1;                     // what step t - 1 published
+        u64* Xout = (t & 1) ? X1 : X0;
+        float av[4][4];
+        CluWait cw;
+        if (t > 0) clu_wait<RT, NCH>(Xin, wave, lane, (unsigned)t, err, cw);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            if (t == 0) clu_load_plain(q.e.h_in + (long)d * R * H, H, R, row0 + 16 * rt, k_wave, lane, av);
+            else clu_gather<RT, NCH>(Xin, wave, lane, rt, 0, (unsigned)t, err, cw, av);
+            f32x4 ar = zero, au = zero, ak = zero;
+            clu_mma(ar, av, wr);
+            clu_mma(au, av, wu);
+            clu_mma(ak, av, wk);
+            clu_put(red, 3 * RT, wave, 3 * rt, lane, ar);
+            clu_put(red, 3 * RT, wave, 3 * rt + 1, lane, au);
+            clu_put(red, 3 * RT, wave, 3 * rt + 2, lane, ak);
+        }
+        __syncthreads();
+        if (epi) {
+            const float sr = clu_get(red, 3 * RT, NW, 3 * ert, reg, ln);
+            const float su = clu_get(red, 3 * RT, NW, 3 * ert + 1, reg, ln);
+            const float sc = clu_get(red, 3 * RT, NW, 3 * ert + 2, reg, ln) + b_c;
+            float hn = hreg, r = 0.0f, u = 0.0f, c = 0.0f;
+            if (live) {
+                r = nm_sigmoid(xr + sr + b_r);
+                u = nm_sigmoid(xu + su + b_u);
+                c = nm_tanh(xc + sc * r);
+                hn = u * hreg + (1.0f - u) * c;
+            }
+            hreg = hn;
+            if (t + 1 < q.steps) clu_publish<RT, NCH>(Xout, role.local, ert, rloc, col, (unsigned)(t + 1), hn);
+            if (mine) {
+                float* ru = q.e.ru + (long)t * q.ru_step + ro * 2 * H;
+                ru[col] = r;
+                ru[H + col] = u;
+                q.e.c_save[(long)t * q.c_step + ro * H + col] = c;
+                q.e.rh[(long)t * q.rh_step + ro * H + col] = live ? sc : 0.0f;
+                q.e.h_out[(long)t * q.h_step + ro * H + col] = hn;
+                if (live && q.e.out)
+                    q.e.out[d * q.e.o_dir + (long)row * q.e.o_row + (long)pos * q.e.o_time + col] = hn;
+            }
+        }
+        __syncthreads();                                  // the reduction buffer is rewritten by the next step
+    }
+    if (tid == 0 && q.sticky && __hip_atomic_load(err, NM_RLX_AGENT) != 0) __hip_atomic_store((gu32*)q.sticky, 1u, NM_RLX_AGENT);
+}
+
+template <int RT>
+__global__ __launch_bounds__(512, 3) void nematus_cluster_bwd_kernel(NemClu a) {
+    constexpr int NCB = 12;                              // 192 k-values per wave of K = 3H
+    const GruClu& q = a.q;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NW = (int)(blockDim.x >> 6);
+    const int H = q.e.H, R = (int)q.e.R;
+    if (q.force_fail && blockIdx.x == 0 && tid == 0) __hip_atomic_store((gu32*)q.hdr, 1u, NM_RLX_AGENT);
+    const CluRole role = clu_roles(q.hdr, q.ndir * q.nrb, H / 16, reinterpret_cast<int*>(lds), q.force_global);
+    if (!role.active) {
+        if (tid == 0 && q.sticky && __hip_atomic_load((gu32*)q.hdr, NM_RLX_AGENT) != 0) __hip_atomic_store((gu32*)q.sticky, 1u, NM_RLX_AGENT);
+        return;
+    }
+    __builtin_amdgcn_s_setprio(3);
+    const int jb = role.jb;
+    const int d = role.cl / q.nrb, rb = role.cl % q.nrb;
+    const int row0 = rb * 16 * RT;
+    const int n16 = lane & 15, kq = lane >> 4;
+    float* red = lds;                                    // [NW][RT][4][64]
+    gu32* err = (gu32*)q.hdr;
+    // rows 16 jb + n16 of [U_g | U_c] ([K_in = H][2H] and [H][H]): this wave's 192 values of the 3H-long row
+    float w[NCB][4];
+    {
+        const float* Wg = q.wg + (long)d * q.sg + (long)(16 * jb + n16) * q.ldg;
+        const float* Wc = q.wc + (long)d * q.sc + (long)(16 * jb + n16) * q.ldc;
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+            const int k0 = 16 * (wave * NCB + c) + 4 * kq;
+            const float4 v = k0 < 2 * H ? *reinterpret_cast<const float4*>(Wg + k0)
+                                        : *reinterpret_cast<const float4*>(Wc + (k0 - 2 * H));
+            w[c][0] = v.x; w[c][1] = v.y; w[c][2] = v.z; w[c][3] = v.w;
+        }
+    }
+    const bool epi = tid < 256 * RT;
+    const int ert = tid >> 8, reg = (tid >> 6) & 3, ln = tid & 63;
+    const int rloc = 4 * (ln >> 4) + reg, col = 16 * jb + (ln & 15);
+    const int row = row0 + 16 * ert + rloc;
+    const bool mine = epi && row < R;
+    const long ro = (long)d * R + min(row, R - 1);
+    const int len = (mine && q.e.lengths) ? q.e.lengths[row] : 0x7fffffff;
+    float dh = mine ? q.e.dh[ro * H + col] : 0.0f;
+    const bool rev = ((q.e.rev_mask >> d) & 1) && q.e.lengths;
+    u64* X0 = q.xa + (long)role.cl * 16 * RT * 3 * H;
+    u64* X1 = q.xb + (long)role.cl * 16 * RT * 3 * H;
+    float sB = 0.0f;
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+
+    for (int i = 0; i < q.steps; ++i) {
+        const int t = q.steps - 1 - i;
+        const bool live = mine && t < len;
+        const int pos = rev ? len - 1 - t : t;
+        const int ppos = rev ? pos + 1 : pos - 1;
+        u64* X = (i & 1) ? X1 : X0;
+        if (epi) {
+            const float s = (i == 0) ? dh : sB + dh;
+            float drp = 0.0f, dup = 0.0f, dsc = 0.0f, dcp = 0.0f;
+            if (live) {
+                const float* ru = q.e.ru + (long)t * q.ru_step + ro * 2 * H;
+                const float r = ru[col], u = ru[H + col];
+                const float c = q.e.c[(long)t * q.c_step + ro * H + col];
+                const float sc = q.e.rh[(long)t * q.rh_step + ro * H + col];
+                const float hp = gru_epi_hprev(q.e, ro, d, row, t, ppos, col);
+                const float dout = q.e.dout ? q.e.dout[d * q.e.do_dir + (long)row * q.e.do_row + (long)pos * q.e.do_time + col] : 0.0f;
+                const float dhv = s + dout;
+                dcp = dhv * (1.0f - u) * (1.0f - c * c);
+                dup = dhv * (hp - c) * u * (1.0f - u);
+                dsc = dcp * r;
+                drp = dcp * sc * r * (1.0f - r);
+                dh = dhv * u;
+                float* dx = q.e.dxp + d * q.e.dx_dir + (long)row * q.e.dx_row + (long)pos * q.e.dx_time;
+                dx[col] = drp;
+                dx[H + col] = dup;
+                dx[2 * H + col] = dcp;
+                dx[3 * H + col] = dsc;
+            } else {
+                dh = s;
+            }
+            clu_publish<RT, NCB>(X, role.local, ert, rloc, col, (unsigned)(i + 1), drp);
+            clu_publish<RT, NCB>(X, role.local, ert, rloc, H + col, (unsigned)(i + 1), dup);
+            clu_publish<RT, NCB>(X, role.local, ert, rloc, 2 * H + col, (unsigned)(i + 1), dsc);
+        }
+        {
+            float av[4][4];
+            CluWait cw;
+            clu_wait<RT, NCB>(X, wave, lane, (unsigned)(i + 1), err, cw);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                f32x4 acc = zero;
+#pragma unroll
+                for (int piece = 0; piece < NCB / 4; ++piece) {
+                    clu_gather<RT, NCB>(X, wave, lane, rt, piece, (unsigned)(i + 1), err, cw, av);
+                    clu_mma(acc, av, w + 4 * piece);
+                }
+                clu_put(red, RT, wave, rt, lane, acc);
+            }
+        }
+        __syncthreads();
+        if (epi) sB = clu_get(red, RT, NW, ert, reg, ln);
+        __syncthreads();
+    }
+    if (mine) q.e.dh[ro * H + col] = sB + dh;
+    if (tid == 0 && q.sticky && __hip_atomic_load(err, NM_RLX_AGENT) != 0) __hip_atomic_store((gu32*)q.sticky, 1u, NM_RLX_AGENT);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // One DECODING step's recurrent part as one launch (round 6): Decoder.next_state up to the attention query
 // (decoders/decoder.py:279-325, plain GRUCell + input tables, what nm_decoder_step_fused launched as three dependent
 // step groups: 7.2 + 7.2 + 9.4 us of kernels and two graph edges per greedy step):
@@ -1012,3 +1241,79 @@ bool nm_dec_step_cluster_try(hipStream_t st, int64_t R, int64_t H, int64_t A, in
     return hipGetLastError() == hipSuccess;
 }
 
+// ---- NematusGRU loops: host side ------------------------------------------------------------------------------------
+// workspace: header + two buffers of width 3H (the backward loop's; the forward loop uses the first H columns' worth)
+extern "C" int64_t nm_nematus_seq_workspace_bytes(int64_t R, int64_t H, int32_t ndir) {
+    CluShape s;
+    if (!clu_shape(R, H, ndir, &s)) return CLU_HDR_BYTES;
+    return CLU_HDR_BYTES + s.granules * 8 * 6;
+}
+
+static int nem_launch(bool backward, void* stream, const nm_gru_epilogue* e, int32_t steps, int64_t h_step, int64_t ru_step,
+                      int64_t sc_step, int64_t c_step, const float* ug, int64_t ld_g, int64_t stride_g, const float* uc,
+                      int64_t ld_c, int64_t stride_c, const float* bgs, const float* bcs, void* workspace,
+                      int64_t workspace_bytes, uint32_t* sticky_error, const char* who) {
+    NM_REQUIRE(e && ug && uc && workspace, "%s: null pointer / workspace", who);
+    NM_REQUIRE(steps >= 0 && e->R > 0 && e->H > 0 && e->ndir >= 1 && e->ndir <= 2, "%s: bad shape R=%ld H=%ld", who,
+               (long)e->R, (long)e->H);
+    NM_REQUIRE(nm_aligned16(workspace) && nm_aligned16(ug) && nm_aligned16(uc) && ld_g % 4 == 0 && ld_c % 4 == 0 &&
+                   stride_g % 4 == 0 && stride_c % 4 == 0, "%s: kernels / workspace must be 16-byte aligned", who);
+    if (backward) NM_REQUIRE(e->dh && e->ru && e->c && e->rh && e->hseq && e->dxp, "%s: missing operand", who);
+    else {
+        NM_REQUIRE(e->xp && e->h_in && e->h_out && e->ru && e->c_save && e->rh && nm_aligned16(e->h_in),
+                   "%s: missing / unaligned operand", who);
+        // (a step here is ONE stage: a workgroup may finish step 0 -- and write h_out -- while another still loads h_in)
+        NM_REQUIRE(e->h_in != e->h_out, "%s: h_in and h_out must be different buffers", who);
+    }
+    CluShape s;
+    NM_REQUIRE(clu_shape(e->R, e->H, e->ndir, &s), "%s: shape R=%ld H=%ld ndir=%d not supported (nm_gru_seq_supported)",
+               who, (long)e->R, (long)e->H, (int)e->ndir);
+    NM_REQUIRE(workspace_bytes >= nm_nematus_seq_workspace_bytes(e->R, e->H, e->ndir), "%s: workspace too small", who);
+    if (steps == 0) return NM_OK;
+    NemClu a;
+    GruClu& q = a.q;
+    clu_fill(q, e);
+    q.e.rh = e->rh;
+    q.steps = steps; q.nrb = s.nrb;
+    q.h_step = h_step; q.ru_step = ru_step; q.rh_step = sc_step; q.c_step = c_step;
+    q.wg = ug; q.ldg = ld_g; q.sg = stride_g; q.wc = uc; q.ldc = ld_c; q.sc = stride_c;
+    q.hdr = reinterpret_cast<unsigned*>(workspace);
+    q.sticky = sticky_error;
+    q.xa = reinterpret_cast<u64*>(reinterpret_cast<char*>(workspace) + CLU_HDR_BYTES);
+    q.xb = q.xa + s.granules * 3;
+    a.bgs = bgs; a.bcs = bcs;
+    hipStream_t st = nm_stream(stream);
+    if (hipMemsetAsync(workspace, 0, CLU_HDR_BYTES + (size_t)s.granules * 8 * 6, st) != hipSuccess)
+        NM_FAIL(NM_ERR_HIP, "%s: memset failed", who);
+    const size_t lds = (size_t)s.NW * s.RT * (backward ? 1 : 3) * 1024;
+    bool ok;
+    if (backward) {
+        if (s.RT == 1) { ok = clu_prepare(nematus_cluster_bwd_kernel<1>, lds); if (ok) hipLaunchKernelGGL((nematus_cluster_bwd_kernel<1>), dim3(s.grid), dim3(s.NW * 64), lds, st, a); }
+        else { ok = clu_prepare(nematus_cluster_bwd_kernel<2>, lds); if (ok) hipLaunchKernelGGL((nematus_cluster_bwd_kernel<2>), dim3(s.grid), dim3(s.NW * 64), lds, st, a); }
+    } else {
+        if (s.RT == 1) { ok = clu_prepare(nematus_cluster_fwd_kernel<1>, lds); if (ok) hipLaunchKernelGGL((nematus_cluster_fwd_kernel<1>), dim3(s.grid), dim3(s.NW * 64), lds, st, a); }
+        else { ok = clu_prepare(nematus_cluster_fwd_kernel<2>, lds); if (ok) hipLaunchKernelGGL((nematus_cluster_fwd_kernel<2>), dim3(s.grid), dim3(s.NW * 64), lds, st, a); }
+    }
+    if (!ok) NM_FAIL(NM_ERR_HIP, "%s: the kernel cannot be made resident on this device", who);
+    NM_LAUNCH_CHECK(who);
+}
+
+// e->rh: sc of every step ([steps] x sc_step); ug [ndir][H][2H], uc [ndir][H][H]: the STATE projections; bgs / bcs: their
+// optional biases.  Everything else as nm_gru_seq_fwd.
+extern "C" int nm_nematus_seq_fwd(void* stream, const nm_gru_epilogue* e, int32_t steps, int64_t h_step, int64_t ru_step,
+                                  int64_t sc_step, int64_t c_step, const float* ug, int64_t ld_g, int64_t stride_g,
+                                  const float* uc, int64_t ld_c, int64_t stride_c, const float* bgs, const float* bcs,
+                                  void* workspace, int64_t workspace_bytes, uint32_t* sticky_error) {
+    return nem_launch(false, stream, e, steps, h_step, ru_step, sc_step, c_step, ug, ld_g, stride_g, uc, ld_c, stride_c,
+                      bgs, bcs, workspace, workspace_bytes, sticky_error, "nm_nematus_seq_fwd");
+}
+
+// The whole BPTT loop: e->dh in / out as nm_gru_seq_bwd; e->rh = the saved sc; dxp 4H wide per direction:
+// [dr' | du' | dc' | dsc] at the step's sequence position.
+extern "C" int nm_nematus_seq_bwd(void* stream, const nm_gru_epilogue* e, int32_t steps, int64_t ru_step, int64_t sc_step,
+                                  int64_t c_step, const float* ug, int64_t ld_g, int64_t stride_g, const float* uc,
+                                  int64_t ld_c, int64_t stride_c, void* workspace, int64_t workspace_bytes,
+                                  uint32_t* sticky_error) {
+    return nem_launch(true, stream, e, steps, 0, ru_step, sc_step, c_step, ug, ld_g, stride_g, uc, ld_c, stride_c,
+                      nullptr, nullptr, workspace, workspace_bytes, sticky_error, "nm_nematus_seq_bwd");
+}

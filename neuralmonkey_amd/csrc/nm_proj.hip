@@ -191,10 +191,14 @@ __global__ __launch_bounds__(512, 2) void proj_astat_kernel(ProjArgs g) {
             bv[r] = up ? m4 : before;
             bi[r] = up ? i4 : bi[r];
             if (g.ablate & 32) continue;
-            // sum exp(x - max) in base 2: one fma + one v_exp_f32 per value; (max = -inf only while every column so
-            // far was past N: the products below are NaN then and the sum is re-started by the select)
-            const float ml = bv[r] * L2E;
-            float sum = rs[r] * __builtin_amdgcn_exp2f(fmaf(before, L2E, -ml));
+            // sum exp(x - max) in base 2: one fma + one v_exp_f32 per value.  The fma subtracts ROUNDED max * log2(e)
+            // from the exact product, so a lane's sum is 2^lo times the true one, lo = max * log2(e) - rounded(...) (up
+            // to 2.4e-6 at |max| = 40: it showed in the log-sum-exp); the re-scaling below keeps that statement true
+            // when the maximum moves (a difference of two ROUNDED products) and the tile merge divides 2^lo out.  (max
+            // = -inf only while every column so far was past N: the products below are NaN then and the sum is
+            // re-started by the select)
+            const float ml = __fmul_rn(bv[r], L2E);
+            float sum = rs[r] * __builtin_amdgcn_exp2f(__fsub_rn(__fmul_rn(before, L2E), ml));
             sum += __builtin_amdgcn_exp2f(fmaf(x0, L2E, -ml));
             sum += __builtin_amdgcn_exp2f(fmaf(x1, L2E, -ml));
             sum += __builtin_amdgcn_exp2f(fmaf(x2, L2E, -ml));
@@ -211,7 +215,8 @@ __global__ __launch_bounds__(512, 2) void proj_astat_kernel(ProjArgs g) {
                 pj_argmax_step<0x4E>(mv, mi);
                 pj_argmax_step<0x141>(mv, mi);
                 pj_argmax_step<0x140>(mv, mi);
-                const float mine = bv[r] > -INFINITY ? rs[r] * __builtin_amdgcn_exp2f((bv[r] - mv) * L2E) : 0.0f;
+                const float lo = fmaf(bv[r], L2E, -__fmul_rn(bv[r], L2E));        // exact: what the rounding dropped
+                const float mine = bv[r] > -INFINITY ? rs[r] * __builtin_amdgcn_exp2f((bv[r] - mv) * L2E - lo) : 0.0f;
                 const float tot = pj_row16_sum(mine);
                 const int row = row_lane0 + r;
                 if (n == 0 && row < g.M) {

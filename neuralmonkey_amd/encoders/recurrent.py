@@ -11,6 +11,7 @@ GEMMs (both directions batched in one launch) with fused gate / blend
 epilogue kernels that implement the length masking and the reversed indexing
 of the backward direction in-kernel, so there is no reverse_sequence copy.
 """
+import os
 from typing import Callable, List, NamedTuple, Optional, Tuple, Union
 
 import torch
@@ -350,6 +351,115 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
         self.input_sequence.backward(ctx, dx.view(bsz, slen, e))
 
     # -- general (taped) path: any cell, stacked layers, layer norm, residual, dropout ------------
+    def _nematus_cluster_layer(self, tape, x, bsz: int, slen: int, lengths, layer: int):
+        """One NematusGRUCell layer (both directions) as ONE tape operation: the input projections of all positions
+        as products over [B*S] rows, the time loop as one cluster launch (ops.nematus_seq_fwd), and on the way back one
+        launch for the BPTT loop, then the weight gradients as products over all positions -- the schedule of the
+        hand-written GRU path above instead of 8 launches per step and direction each way.  None: this layer stays on
+        the step-by-step tape (shape the cluster kernels do not take, cluster loops switched off, unaligned kernels)."""
+        spec = self.rnn_specs[layer]
+        cells = self._cells[layer]
+        ctx = tape.ctx
+        ndir, h = len(cells), spec.size
+        d_in = x.shape[1]
+        if spec.cell_type != "NematusGRU" or not ctx.session.use_cluster_loops or d_in % 4 or not x.data.is_cuda:
+            return None
+        store = ctx.store
+        theta = store.theta
+        names = {k: [self.var_name(c._n(k)) for c in cells]
+                 for k in ("gates/state_proj/kernel", "candidate/state_proj/kernel")}
+
+        def dir_batch(k, ncols):
+            base = store.offset(names[k][0])
+            stride = store.offset(names[k][1]) - base if ndir == 2 else 0
+            return theta.as_strided((ndir, h, ncols), (stride, ncols, 1), base)
+        ug, uc = dir_batch("gates/state_proj/kernel", 2 * h), dir_batch("candidate/state_proj/kernel", h)
+        if not gru.cluster_ok(ctx.session, bsz, h, ndir, ug, uc):
+            return None
+        use_sb, use_ib = cells[0].use_state_bias, cells[0].use_input_bias
+        rev0 = spec.direction == "backward"
+        width = ndir * h
+
+        def p(cell, name):
+            return tape.param(self, cell._n(name))
+        w_gi = [p(c, "gates/input_proj/kernel") for c in cells]
+        w_ci = [p(c, "candidate/input_proj/kernel") for c in cells]
+        w_gs = [p(c, "gates/state_proj/kernel") for c in cells]
+        w_cs = [p(c, "candidate/state_proj/kernel") for c in cells]
+        b_gi = [p(c, "gates/input_proj/bias") if use_ib else None for c in cells]
+        b_ci = [p(c, "candidate/input_proj/bias") if use_ib else None for c in cells]
+        b_gs = [p(c, "gates/state_proj/bias") if use_sb else None for c in cells]
+        b_cs = [p(c, "candidate/state_proj/bias") if use_sb else None for c in cells]
+        bgs = bcs = None
+        if use_sb:                                  # the loops read the state biases as [ndir, 2H] / [ndir, H]
+            bgs, bcs = tape.buf((ndir, 2 * h)), tape.buf((ndir, h))
+            for d in range(ndir):
+                ops.copy_cols(b_gs[d].data.view(1, -1), bgs[d:d + 1])
+                ops.copy_cols(b_cs[d].data.view(1, -1), bcs[d:d + 1])
+
+        xp = tape.buf((bsz * slen, ndir * 3 * h))
+        for d in range(ndir):
+            ops.gemm(x.data, w_gi[d].data, out=xp[:, d * 3 * h:d * 3 * h + 2 * h],
+                     bias=None if b_gi[d] is None else b_gi[d].data)
+            ops.gemm(x.data, w_ci[d].data, out=xp[:, d * 3 * h + 2 * h:(d + 1) * 3 * h],
+                     bias=None if b_ci[d] is None else b_ci[d].data)
+        out, final = tape.new((bsz * slen, width)), tape.new((bsz, width))
+        hcur, hzero = tape.buf((ndir, bsz, h)), tape.buf((ndir, bsz, h), zero=True)
+        rec = tape.recording
+        nsave = slen if rec else 1
+        ru_all, c_all, sc_all = (tape.buf((nsave, ndir, bsz, 2 * h)), tape.buf((nsave, ndir, bsz, h)),
+                                 tape.buf((nsave, ndir, bsz, h)))
+        ws = ctx.buffer((id(self), "nematus_ws", layer), (ops.nematus_seq_workspace_floats(bsz, h, ndir),))
+        out.data.zero_()
+        xrs, xts = slen * ndir * 3 * h, ndir * 3 * h
+        seq_strides = (h, slen * width, width)
+        ops.nematus_seq_fwd(slen, ndir, bsz, h, xp, (3 * h, xrs, xts), hzero, hcur, 0, ru_all[0],
+                            ndir * bsz * 2 * h if rec else 0, sc_all[0], ndir * bsz * h if rec else 0, c_all[0],
+                            ndir * bsz * h if rec else 0, ug, uc, ws, bgs=bgs, bcs=bcs, lengths=lengths,
+                            reverse_dir0=rev0, out=out.data, out_strides=seq_strides, sticky=ctx.session.error_word())
+        for d in range(ndir):
+            ops.copy_cols(hcur[d], final.data[:, d * h:(d + 1) * h])
+
+        def bwd():
+            if out.grad is None and final.grad is None:
+                return
+            dh = tape.buf((ndir, bsz, h))
+            if final.grad is not None:
+                for d in range(ndir):
+                    ops.copy_cols(final.grad[:, d * h:(d + 1) * h], dh[d])
+            else:
+                dh.zero_()
+            dxp = tape.buf((bsz * slen, ndir * 4 * h), zero=True)
+            ops.nematus_seq_bwd(slen, ndir, bsz, h, dh, out.grad, seq_strides if out.grad is not None else None,
+                                ru_all[0], ndir * bsz * 2 * h, sc_all[0], ndir * bsz * h, c_all[0], ndir * bsz * h,
+                                None, out.data, seq_strides, dxp, (4 * h, slen * ndir * 4 * h, ndir * 4 * h), ug, uc,
+                                ws, lengths=lengths, reverse_dir0=rev0, sticky=ctx.session.error_word())
+            hprev = tape.buf((bsz, slen, ndir, h))
+            ops.gru_seq_shift(out.data.view(bsz, slen, width), hprev, lengths, ndir, h, reverse_dir0=rev0)
+            hp2 = hprev.view(bsz * slen, width)
+            gx, acc = tape.grad_slot(x) if x.needs_grad else (None, False)
+            for d in range(ndir):
+                dg = dxp[:, d * 4 * h:d * 4 * h + 2 * h]
+                dc = dxp[:, d * 4 * h + 2 * h:d * 4 * h + 3 * h]
+                dsc = dxp[:, d * 4 * h + 3 * h:(d + 1) * 4 * h]
+                hp = hp2[:, d * h:(d + 1) * h]
+                ops.gemm(x.data, dg, out=tape.grad(w_gi[d]), trans_a=True, accumulate=True)
+                ops.gemm(x.data, dc, out=tape.grad(w_ci[d]), trans_a=True, accumulate=True)
+                ops.gemm(hp, dg, out=tape.grad(w_gs[d]), trans_a=True, accumulate=True)
+                ops.gemm(hp, dsc, out=tape.grad(w_cs[d]), trans_a=True, accumulate=True)
+                if use_ib:
+                    ops.colsum(dg, tape.grad(b_gi[d]), accumulate=True)
+                    ops.colsum(dc, tape.grad(b_ci[d]), accumulate=True)
+                if use_sb:
+                    ops.colsum(dg, tape.grad(b_gs[d]), accumulate=True)
+                    ops.colsum(dsc, tape.grad(b_cs[d]), accumulate=True)
+                if gx is not None:
+                    ops.gemm(dg, w_gi[d].data, out=gx, trans_b=True, accumulate=acc)
+                    ops.gemm(dc, w_ci[d].data, out=gx, trans_b=True, accumulate=True)
+                    acc = True
+        tape.record(bwd)
+        return out, final
+
     def _general_layer(self, tape, x, bsz: int, slen: int, lengths, layer: int, train: bool):
         """rnn_layer (recurrent.py:71-110) on the tape.  x: Var [B*S, D] -> (outputs Var
         [B*S, ndir*H], final Var [B, ndir*H])."""
@@ -357,6 +467,10 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
         cells = self._cells[layer]
         ndir, h = len(cells), spec.size
         width = ndir * h
+        if os.environ.get("NM_NEMATUS_CLUSTER", "1") != "0":      # (read per call: tests compare both schedules)
+            fused = self._nematus_cluster_layer(tape, x, bsz, slen, lengths, layer)
+            if fused is not None:
+                return fused
         out = tape.new((bsz * slen, width))
         final = tape.new((bsz, width))
         for d, cell in enumerate(cells):

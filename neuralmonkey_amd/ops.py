@@ -1013,6 +1013,65 @@ def gru_seq_bwd(steps, ndir, rows, hsz, dh, dout, dout_strides, ru0, ru_step, c0
     _cluster_serialize_after(serial)
 
 
+def nematus_seq_workspace_floats(rows, hsz, ndir) -> int:
+    return _lib.load().nm_nematus_seq_workspace_bytes(rows, hsz, ndir) // 4
+
+
+def _dir_strides(w):
+    w2 = w[0] if w.dim() == 3 else w
+    assert w2.stride(1) == 1
+    return w2.stride(0), (w.stride(0) if w.dim() == 3 else 0)
+
+
+def nematus_seq_fwd(steps, ndir, rows, hsz, xp, x_strides, h_in0, h_out0, h_step, ru0, ru_step, sc0, sc_step, c0,
+                    c_step, ug, uc, workspace, bgs=None, bcs=None, lengths=None, reverse_dir0=False, out=None,
+                    out_strides=(0, 0, 0), sticky=None):
+    """All ``steps`` forward steps of a NematusGRUCell layer in one launch (nm_nematus_seq_fwd).  As ``gru_seq_fwd``;
+    ``ug`` [ndir,H,2H] / ``uc`` [ndir,H,H]: the state projections, ``bgs`` [ndir,2H] / ``bcs`` [ndir,H] their biases,
+    ``sc0``: where step 0's h.U_c + b_cs is saved."""
+    lib = _lib.load()
+    e = _lib.GruEpilogue()
+    e.mode, e.t, e.rev_mask, e.ndir, e.R, e.H = 1, 0, _rev_mask(ndir, reverse_dir0), ndir, rows, hsz
+    e.lengths = _p(lengths)
+    e.xp = xp.data_ptr()
+    e.x_dir, e.x_row, e.x_time = x_strides
+    e.h_in, e.h_out, e.ru, e.rh, e.c_save, e.out = (h_in0.data_ptr(), h_out0.data_ptr(), ru0.data_ptr(),
+                                                   sc0.data_ptr(), c0.data_ptr(), _p(out))
+    e.o_dir, e.o_row, e.o_time = out_strides
+    ld_g, s_g = _dir_strides(ug)
+    ld_c, s_c = _dir_strides(uc)
+    serial = _cluster_serialize_before()
+    _lib.check(lib.nm_nematus_seq_fwd(_stream(), ctypes.byref(e), steps, h_step, ru_step, sc_step, c_step,
+                                      ug.data_ptr(), ld_g, s_g, uc.data_ptr(), ld_c, s_c, _p(bgs), _p(bcs),
+                                      workspace.data_ptr(), workspace.numel() * workspace.element_size(), _p(sticky)),
+               "nm_nematus_seq_fwd")
+    _cluster_serialize_after(serial)
+
+
+def nematus_seq_bwd(steps, ndir, rows, hsz, dh, dout, dout_strides, ru0, ru_step, sc0, sc_step, c0, c_step, h0, hseq,
+                    hseq_strides, dxp, dxp_strides, ug, uc, workspace, lengths=None, reverse_dir0=False, sticky=None):
+    """The BPTT loop of a NematusGRUCell layer in one launch (nm_nematus_seq_bwd); ``dxp`` is 4H wide per direction:
+    [dr' | du' | dc' | dsc]."""
+    lib = _lib.load()
+    e = _lib.GruEpilogue()
+    e.mode, e.t, e.rev_mask, e.ndir, e.R, e.H = 4, 0, _rev_mask(ndir, reverse_dir0), ndir, rows, hsz
+    e.lengths = _p(lengths)
+    e.dh, e.dout = dh.data_ptr(), _p(dout)
+    e.do_dir, e.do_row, e.do_time = dout_strides or (0, 0, 0)
+    e.ru, e.rh, e.c, e.h0, e.hseq = ru0.data_ptr(), sc0.data_ptr(), c0.data_ptr(), _p(h0), hseq.data_ptr()
+    e.hs_dir, e.hs_row, e.hs_time = hseq_strides
+    e.dxp = dxp.data_ptr()
+    e.dx_dir, e.dx_row, e.dx_time = dxp_strides
+    ld_g, s_g = _dir_strides(ug)
+    ld_c, s_c = _dir_strides(uc)
+    serial = _cluster_serialize_before()
+    _lib.check(lib.nm_nematus_seq_bwd(_stream(), ctypes.byref(e), steps, ru_step, sc_step, c_step,
+                                      ug.data_ptr(), ld_g, s_g, uc.data_ptr(), ld_c, s_c,
+                                      workspace.data_ptr(), workspace.numel() * workspace.element_size(), _p(sticky)),
+               "nm_nematus_seq_bwd")
+    _cluster_serialize_after(serial)
+
+
 def optimizer_chunk_table(store, regularizable, trainable, cuts=(), chunk=65536):
     """The host side of the flat optimizer kernels' tables: every variable ("segment") is cut into chunks of at most
     ``chunk`` elements -- and at every flat offset in ``cuts`` (the slice boundaries of a sharded optimizer,

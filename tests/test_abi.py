@@ -85,6 +85,27 @@ def test_round6_entry_points_validate_before_any_launch(lib):
     assert lib.nm_gru_seq_force_give_up(3) == 0 and lib.nm_gru_seq_force_give_up(0) == 3     # a counter, nothing else
     rc = lib.nm_gru_seq_test_hog(None, 0, 1024, 10)
     assert rc < 0 and b"nm_gru_seq_test_hog" in lib.nm_last_error()
+    # the fused layer-norm backward, the grouped weight-gradient product and the NematusGRU loops
+    assert lib.nm_layer_norm_bwd_params_workspace_bytes(512) > 0
+    rc = lib.nm_layer_norm_bwd_params(None, buf, buf, buf, buf, buf, buf, 4, 6, buf, buf, 0, buf, 1 << 20)
+    assert rc < 0 and b"multiple of 4" in lib.nm_last_error()
+    rc = lib.nm_layer_norm_bwd_params(None, buf, buf, buf, buf, buf, buf, 4, 16, buf, buf, 0, buf, 8)
+    assert rc < 0 and b"workspace too small" in lib.nm_last_error()
+    rc = lib.nm_gemm_f32_group(None, 1, 0, 64, 64, 64, None, 64, 64, 64, 1, 3)
+    assert rc < 0 and b"nm_gemm_f32_group" in lib.nm_last_error()
+    rc = lib.nm_gemm_f32_group(None, 1, 0, 64, 64, 64, buf, 64, 62, 64, 1, 3)
+    assert rc < 0 and b"nm_gemm_f32_group" in lib.nm_last_error()
+    from neuralmonkey_amd import _lib
+    epi = _lib.GruEpilogue()
+    rc = lib.nm_nematus_seq_fwd(None, ctypes.byref(epi), 3, 0, 0, 0, 0, None, 512, 0, None, 256, 0, None, None, None, 0,
+                                None)
+    assert rc < 0 and b"nm_nematus_seq_fwd" in lib.nm_last_error()
+    epi.R, epi.H, epi.ndir = 16, 256, 1
+    rc = lib.nm_nematus_seq_bwd(None, ctypes.byref(epi), 3, 0, 0, 0, buf, 512, 0, buf, 256, 0, buf, 1 << 20, None)
+    assert rc < 0 and b"nm_nematus_seq_bwd: missing operand" in lib.nm_last_error()
+    # (no device here: no shape is "supported", the workspace is the bare header)
+    assert lib.nm_nematus_seq_workspace_bytes(16, 100, 1) == lib.nm_gru_seq_workspace_bytes(16, 100, 1)
+    assert lib.nm_dec_step_cluster_supported(128, 100, 512, 512) == 0
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

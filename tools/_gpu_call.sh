@@ -1,3 +1,5 @@
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests/test_transformer_gpu.py tests/test_general_gpu.py -x -q -m "gpu and not slow" 2>&1 | grep -v "amdgpu.ids\|socket.cpp\|Gloo" | tail -3
-for cfg in "1 1" "0 1"; do set -- $cfg; echo "NM_LN_BWD_FUSED=$1 NM_WGRAD_GROUPS=$2"; NM_LN_BWD_FUSED=$1 NM_WGRAD_GROUPS=$2 timeout 300 python tools/transformer_bench.py --train-only 2>&1 | grep "ms/step"; done
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/gp_prof -- python $GRAFT_REPO_ROOT/tools/general_path_probe.py --train-only NM_NEMATUS_CLUSTER 1 2>&1 | grep "NM_NEMATUS" | tail -3
+cd $GRAFT_REPO_ROOT
+f=$(ls /tmp/gp_prof/*/*_kernel_stats.csv | head -1); head -60 $f > gpurun_out/r06_general_train_kernel_stats.csv; head -45 $f | cut -c1-170
