@@ -593,6 +593,11 @@ int nm_optim_apply(void* stream, int32_t kind, float* theta, const float* grad, 
 /* x[0..n) = 0 when *word != 0: the gradient a given-up time loop left behind must not reach an accumulation buffer
  * (trainers/delayed_update_trainer.py:146-150) or a collective as NaNs */
 int nm_zero_if(void* stream, const int32_t* word, float* x, int64_t n);
+/* Whole-buffer fills (a 4-byte pattern: float and int32 buffers alike; a kernel of this library) and device-to-device
+ * copies (the runtime's: a memcpy node inside a captured graph) instead of a tensor library's fill / copy kernels
+ * (the reference's tf.zeros / tf.assign of its state variables are graph nodes the same way). */
+int nm_fill_u32(void* stream, void* x, int64_t count, uint32_t pattern);
+int nm_copy_d2d(void* stream, void* dst, const void* src, int64_t bytes);
 
 /* ---- data-parallel gradient exchange (the reference is single-device, tf_manager.py:62-100): the
  * in-place sum over ranks of slices of the flat gradient buffer on RCCL, ordered against HIP streams only.  RCCL is

@@ -116,6 +116,8 @@ SIGNATURES = {
     "nm_optim_segments": (I, [P, P, P, P, P, P, P, L, L, P, P, L]),
     "nm_optim_apply": (I, [P, I, P, P, P, P, P, P, P, P, P, P, L, L, F, F, F, F, F, L, L, P, P, L]),
     "nm_zero_if": (I, [P, P, P, L]),
+    "nm_fill_u32": (I, [P, P, L, ctypes.c_uint32]),
+    "nm_copy_d2d": (I, [P, P, P, L]),
     "nm_gather_rows_f32": (I, [P, P, L, P, P, L, L, L]),
     "nm_beam_reorder_tokens": (I, [P, P, P, P, P, L, L]),
     "nm_beam_backtrace": (I, [P, P, P, P, P, L, L]),

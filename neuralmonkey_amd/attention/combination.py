@@ -239,7 +239,7 @@ class FlatSession(_MultiSession):
         keys2 = tape.view(self.keys, lambda t: t.view(b, self.stot * a))
         vals2 = keys2 if share else tape.view(self.vals, lambda t: t.view(b, self.stot * a))
         mask = ctx.buffer((id(att), "mask", b, self.width), (b, self.width))
-        mask.fill_(1.0)
+        ops.fill(mask, 1.0)
         off = 0
         for i, (enc, st, slen) in enumerate(zip(encs, self.states_in, self.lens)):
             for scope, dst in [("logits_projections", keys2)] + ([] if share else [("context_projections", vals2)]):
@@ -258,7 +258,7 @@ class FlatSession(_MultiSession):
         seg = ctx.buffer((id(att), "segments", tuple(self.lens), self.width), (n, self.width), zero=True)
         off = 0
         for i, slen in enumerate(self.lens):
-            seg[i, off:off + slen].fill_(1.0)
+            ops.fill(seg[i, off:off + slen], 1.0)
             off += slen
         biases = F.concat(tape, [tape.view(tape.param(att, "attn_bias_{}".format(i)), lambda t: t.view(1, 1))
                                  for i in range(n)])
@@ -279,7 +279,7 @@ class FlatSession(_MultiSession):
     def _ones_col(self, rows: int) -> F.Var:
         if rows not in self._ones:
             buf = self.tape.ctx.buffer((id(self.att), "ones", rows), (rows, 1))
-            buf.fill_(1.0)
+            ops.fill(buf, 1.0)
             self._ones[rows] = self.tape.leaf(buf)
         return self._ones[rows]
 

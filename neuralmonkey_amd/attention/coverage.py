@@ -131,7 +131,7 @@ class CoverageSession:
         rows, s, a = self.rows, self.slen, self.asz
         assert query.shape[0] == rows
         if self.t == 0:
-            self.wsum.data.zero_()                   # weights_in_time is empty at the first step (:53-56)
+            ops.zero(self.wsum.data)                   # weights_in_time is empty at the first step (:53-56)
         y = F.linear(tape, query, self.wq, self.bq)
         cov = F.div(tape, self.wsum, self.fert)                                          # :57
         if self.mask_rows is not None:

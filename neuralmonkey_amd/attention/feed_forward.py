@@ -106,7 +106,7 @@ class Attention(BaseAttention):
         # the arrival counters of the in-kernel merge (workspace tail) must be zero when a step is launched; the
         # merging workgroup restores the zero, but an aborted launch or a failed capture would leave them counting
         # and every later merge silently skipped -- one small memset per decoding run makes that self-healing
-        ws[-(((rows + 3) // 4) * 4):].zero_()
+        ops.zero(ws[-(((rows + 3) // 4) * 4):])
         return {"ws": ws, "nchunk": nchunk, "energies": ws[:rows * slen].view(rows, slen),
                 "pctx": ws[pctx_off:pctx_off + rows * nchunk * c], "pstat": ws[pstat_off:pstat_off + rows * nchunk * 4],
                 "S": slen, "C": c, "Bk": bk}
@@ -154,7 +154,8 @@ class Attention(BaseAttention):
         de = ctx.buffer(key + ("de",), (steps, bsz, slen))
         ops.attn_softmax_bwd(dw, e_all, mask, de, bsz)
         ops.reduce_sum(de.view(-1), ctx.buffer(key + ("dbias",), (1,)))
-        store.g(self.var_name("attn_bias")).add_(ctx.buffer(key + ("dbias",), (1,)))
+        g_bias = store.g(self.var_name("attn_bias")).view(1)
+        ops.ew("add", g_bias, ctx.buffer(key + ("dbias",), (1,)), g_bias)
         dhf = ctx.buffer(key + ("dhf",), (bsz, slen, a))
         dvp = ctx.buffer(key + ("dvp",), (bsz * slen, a))
         dy = ctx.buffer(key + ("dy",), (steps, bsz, a))

@@ -45,7 +45,7 @@ class StatefulContext(BaseAttention):
 
     def initial_loop_state(self, ctx, rows: int, max_steps: int, precompute: bool = True) -> AttentionLoopState:
         weights = ctx.buffer((id(self), "weights", rows, max_steps), (max_steps, rows, 1))
-        weights.fill_(1.0)                                # :70
+        ops.fill(weights, 1.0)                                # :70
         return AttentionLoopState(
             contexts=ctx.buffer((id(self), "contexts", rows, max_steps), (max_steps, rows, self.context_vector_size)),
             weights=weights, step=0)

@@ -93,7 +93,7 @@ class Tape:
         if v.grad is None:
             v.grad = self.buf(tuple(v.data.shape), zero=True)
         elif v.fresh:
-            v.grad.zero_()
+            ops.zero(v.grad)
             v.fresh = False
         return v.grad
 
@@ -556,7 +556,7 @@ def sdp_attention(tape: Tape, q: Var, k: Var, v: Var, key_mask: Optional[torch.T
         if not (aq == ak == av):         # one accumulate flag for the three outputs: zero whichever buffer is fresh
             for g, a in ((gq, aq), (gk, ak), (gv, av)):
                 if not a:
-                    g.zero_()
+                    ops.zero(g)
             aq = True
         ops.sdp_attn_bwd(q.data.view(bq, tq, d), k3, v3, key_mask, w, out.grad.view(bq, tq, d), heads,
                          gq.view(bq, tq, d), gk.view(bk, tk, d), gv.view(bk, tk, d),
@@ -580,7 +580,7 @@ def rowscale(tape: Tape, x: Var, s: Var, out: Optional[Var] = None, accumulate: 
         if s.needs_grad:                      # ds[r] = <dout[r,:], x[r,:]> as a [R,A].[A,1] product of the products
             prod = ops.ew("mul", out.grad, x.data, tape.buf(tuple(x.shape)))
             ones = tape.buf((x.shape[1], 1))
-            ones.fill_(1.0)
+            ops.fill(ones, 1.0)
             ops.gemm(prod, ones, out=tape.grad(s), accumulate=True)
     tape.record(bwd)
     return out

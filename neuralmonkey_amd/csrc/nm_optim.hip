@@ -242,6 +242,42 @@ extern "C" int nm_zero_if(void* stream, const int32_t* word, float* x, int64_t n
     NM_LAUNCH_CHECK("nm_zero_if");
 }
 
+// Fills of whole buffers with a 4-byte pattern (float and int32 buffers alike) and device-to-device copies: the
+// engine's steps carried ~25 torch fill / copy kernels (tensor.zero_(), fill_(), copy_()) that these replace.  The fill is
+// a kernel of this library (16-byte stores; a kernel node inside a captured graph -- hipMemsetD32Async nodes were tried
+// and a decoding graph with them did not come back on this stack), the copy is the runtime's (a memcpy node).
+__global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t* __restrict__ x, long head, long body4, long tail,
+                                                       uint32_t v) {
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    if (g < head) x[g] = v;
+    if (g < tail) x[head + 4 * body4 + g] = v;
+    uint4* b = reinterpret_cast<uint4*>(x + head);
+    const uint4 v4 = make_uint4(v, v, v, v);
+    for (long i = g; i < body4; i += (long)gridDim.x * 256) b[i] = v4;
+}
+
+extern "C" int nm_fill_u32(void* stream, void* x, int64_t count, uint32_t pattern) {
+    NM_REQUIRE(x && count >= 0 && (reinterpret_cast<uintptr_t>(x) & 3) == 0, "nm_fill_u32: bad arguments");
+    if (count == 0) return NM_OK;
+    long head = (long)(((16 - (reinterpret_cast<uintptr_t>(x) & 15)) & 15) / 4);
+    if (head > count) head = count;
+    const long body4 = (count - head) / 4, tail = count - head - 4 * body4;
+    long blocks = (body4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)blocks), dim3(256), 0, nm_stream(stream),
+                       reinterpret_cast<uint32_t*>(x), head, body4, tail, pattern);
+    NM_LAUNCH_CHECK("nm_fill_u32");
+}
+
+extern "C" int nm_copy_d2d(void* stream, void* dst, const void* src, int64_t bytes) {
+    NM_REQUIRE(dst && src && bytes >= 0, "nm_copy_d2d: bad arguments");
+    if (bytes == 0 || dst == src) return NM_OK;
+    if (hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, nm_stream(stream)) != hipSuccess)
+        NM_FAIL(NM_ERR_HIP, "nm_copy_d2d: hipMemcpyAsync failed: %s", hipGetErrorString(hipGetLastError()));
+    return NM_OK;
+}
+
 extern "C" int nm_optim_regularize_norms(void* stream, const float* theta, float* grad,
                                          const int64_t* chunk_start, const int32_t* chunk_len,
                                          const int32_t* chunk_seg, const int32_t* seg_first,

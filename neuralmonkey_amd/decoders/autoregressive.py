@@ -133,7 +133,7 @@ class AutoregressiveDecoder(ModelPart):
         key = (id(self), "unk_b")
         if key not in ctx.memo:
             beff = ctx.buffer(key, (len(self.vocabulary),))
-            beff.copy_(b)
+            ops.copy(beff, b)
             beff[UNK_TOKEN_INDEX] -= 1e9
             ctx.memo[key] = beff
         return ctx.memo[key]

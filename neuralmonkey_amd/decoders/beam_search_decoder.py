@@ -147,7 +147,7 @@ class BeamSearchDecoder(ModelPart):
         scores = f32("scores", (bsz, k), zero=True)
         word, beam, src = i32("word", (bsz, k)), i32("beam", (bsz, k)), i32("src", (bsz, k))
         allfin = i32("allfin", (max(max_steps, 1),))
-        allfin.fill_(1)
+        ops.fill(allfin, 1)
         ws = ctx0.buffer(key + ("ws",), ((ops._lib.load().nm_beam_workspace_bytes(bsz, k, v) + 3) // 4,))
         penalty = self._length_penalty_table(ctx0, max_steps + 2)
         zero_stat = f32("zero_stat", (rows,), zero=True)      # the averaged log-probs need no max / lse shift
@@ -155,7 +155,7 @@ class BeamSearchDecoder(ModelPart):
         lp_m = f32("lp_m", (rows, v))
         rmax, rlse, argmax = f32("rmax", (rows,)), f32("rlse", (rows,)), i32("argmax", (rows,))
         go = i32("go", (rows,))
-        go.fill_(START_TOKEN_INDEX)
+        ops.fill(go, START_TOKEN_INDEX)
         models = []
         for m, ctx in enumerate(ctxs):
             stepper = dec.make_stepper(ctx, rows, "beam_ens", k, max_positions=max_steps + 1)
@@ -178,7 +178,7 @@ class BeamSearchDecoder(ModelPart):
                 ops.ew("add_scalar", ens, None, ens, alpha=-math.log(nmod))
 
         # ---- initial parent step of every model on the tiled rows (:218-328)
-        fin[0].zero_()
+        ops.zero(fin[0])
         for mod in models:
             ctx, stepper = mod["ctx"], mod["stepper"]
             if hasattr(dec, "initial_state"):
@@ -190,10 +190,10 @@ class BeamSearchDecoder(ModelPart):
             dec.embed_input_symbols(ctx, go, out=mod["emb"])
             mod["att"] = stepper.step(mod["emb"], mod["att"], mod["out"], mod["logits"], finished=fin[0].view(rows))
         average(first_symbols=True)
-        tok[0, 0].copy_(argmax)
-        lps[0].fill_(-INF)
+        ops.copy(tok[0, 0], argmax)
+        ops.fill(lps[0], -INF)
         lps[0, :, 0] = 0.0
-        lens[0].zero_()
+        ops.zero(lens[0])
         srcf, wordf = src.view(rows), word.view(rows)
         steps = executed = 0
         while steps < max_steps:
@@ -247,11 +247,18 @@ class BeamSearchDecoder(ModelPart):
         word_hist = i32("word_hist", (max(max_steps, 1), rows))
         lps = f32("lps", (2, bsz, k))
         lens = i32("lens", (2, bsz, k))
+        # the first step's summed log-probabilities: 0 for hypothesis 0, -INF for the copies (built once per shape)
+        firsts = ctx.session.__dict__.setdefault("_beam_lps_first", {})
+        lps_first = firsts.get((bsz, k))
+        if lps_first is None:
+            lps_first = torch.full((bsz, k), -INF, dtype=torch.float32, device=lps.device)
+            lps_first[:, 0] = 0.0
+            firsts[(bsz, k)] = lps_first
         fin = i32("fin", (2, bsz, k))
         scores = f32("scores", (bsz, k), zero=True)
         word, beam, src = i32("word", (bsz, k)), i32("beam", (bsz, k)), i32("src", (bsz, k))
         allfin = i32("allfin", (max(max_steps, 1),))
-        allfin.fill_(1)
+        ops.fill(allfin, 1)
         ws = ctx.buffer(key + ("ws",), ((ops._lib.load().nm_beam_workspace_bytes(bsz, k, v) + 3) // 4,))
         penalty = self._length_penalty_table(ctx, max_steps + 2)
         att_states = [a.initial_loop_state(ctx, rows, max_steps + 1) for a in dec.attentions]
@@ -284,8 +291,8 @@ class BeamSearchDecoder(ModelPart):
                 stepper.start(hsel)
             else:
                 stepper.start()
-            fin[0].zero_()
-            go.fill_(START_TOKEN_INDEX)
+            ops.zero(fin[0])
+            ops.fill(go, START_TOKEN_INDEX)
             if not (fast and tabled):
                 dec.embed_input_symbols(ctx, go, out=emb)
             if fast:
@@ -294,10 +301,9 @@ class BeamSearchDecoder(ModelPart):
             else:
                 loop0["att"] = stepper.step(emb, att_states, out_state, logits, finished=fin[0].view(rows))
             ops.row_stats(logits, rmax, rlse, argmax)
-            first_sym.copy_(argmax)                       # parent's greedy symbol, dropped by the runner
-            lps[0].fill_(-INF)
-            lps[0, :, 0] = 0.0
-            lens[0].zero_()
+            ops.copy(first_sym, argmax)                   # parent's greedy symbol, dropped by the runner
+            ops.copy(lps[0], lps_first)                   # 0 for hypothesis 0, -INF for the rest
+            ops.zero(lens[0])
         loop0 = {"att": att_states}
         if fast:
             for att in dec.attentions:                    # lazily built tensors (H2D copies): outside the capture

@@ -302,7 +302,7 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
                 for att in self.attentions:
                     att.hidden_features(ctx)
         s_ext = ctx.buffer(key + ("s_ext",), (steps + 1, bsz, h))      # [s0 ; s_1 .. s_T]
-        s_ext[0].copy_(s0)
+        ops.copy(s_ext[0], s0)
         s_all = s_ext[1:]
         ru_all = ctx.buffer(key + ("ru_all",), (steps, bsz, 2 * h))
         c_all = ctx.buffer(key + ("c_all",), (steps, bsz, h))
@@ -465,12 +465,12 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
         seq_strides = (0, h, bsz * h)
         dxp_strides = (0, 3 * h, bsz * 3 * h)
         def bptt_loop():
-            dh.zero_()
+            ops.zero(dh)
             gru.bptt(steps, dh, d_s, seq_strides, sv["ru_all"], sv["c_all"], sv["s0"], s_all, seq_strides, dxp,
                      dxp_strides, cell["wg_h"].unsqueeze(0), cell["wc_h"].unsqueeze(0), None, 1, bsz, h, False,
                      dgpre, dcpre, drh)
         if gru.cluster_ok(ctx.session, bsz, h, 1, cell["wg_h"], cell["wc_h"]):
-            dh.zero_()
+            ops.zero(dh)
             ops.gru_seq_bwd(steps, 1, bsz, h, dh, d_s, seq_strides, sv["ru_all"][0], bsz * 2 * h, sv["c_all"][0],
                             bsz * h, sv["s0"], s_all, seq_strides, dxp, dxp_strides, cell["wg_h"], cell["wc_h"],
                             gru.cluster_workspace(ctx, id(self), bsz, h, 1), sticky=ctx.session.error_word())
@@ -526,7 +526,9 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
     def train_loss(self, ctx) -> torch.Tensor:
         """sum(xent)/sum(mask) (autoregressive.py:312-316)."""
         res = self.train_loop_result(ctx)
-        return res.loss_sum[0] / res.token_count
+        out = ctx.buffer((id(self), "train_loss"), (1,))
+        alpha = 1.0 / res.token_count if res.token_count else float("nan")         # (0 / 0 as the reference's division)
+        return ops.ew("scale", res.loss_sum[0:1], None, out, alpha=alpha)[0]
 
     # -- greedy runtime path -------------------------------------------------------------------
     def _runtime_loop(self, ctx, keep_logits: bool, sample: bool = False, temperature: float = 1.0) -> RuntimeResult:
@@ -549,7 +551,7 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
         omask = ctx.buffer(key + ("mask",), (tmax, bsz), torch.int32, zero=True)
         finished = ctx.buffer(key + ("fin",), (bsz,), torch.int32, zero=True)
         allfin = ctx.buffer(key + ("allfin",), (tmax,), torch.int32)
-        allfin.fill_(1)
+        ops.fill(allfin, 1)
         argmax = ctx.buffer(key + ("argmax",), (bsz,), torch.int32)
         logits_all = ctx.buffer(key + ("logits_all",), (tmax, bsz, v)) if keep_logits else None
         logits_one = ctx.buffer(key + ("logits",), (bsz, v))
@@ -560,7 +562,7 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
         att_states = [a.initial_loop_state(ctx, bsz, tmax) for a in self.attentions]
 
         go = ctx.buffer(key + ("go",), (bsz,), torch.int32)
-        go.fill_(START_TOKEN_INDEX)
+        ops.fill(go, START_TOKEN_INDEX)
         self.embed_input_symbols(ctx, go, out=emb)
         att0 = att_states
         graph_ok = getattr(stepper, "graph_safe", False)

@@ -245,8 +245,8 @@ class FastStepper:
         self.b_in = ctx.buffer(key + ("b_in",), (3 * h,))
         ops.copy_cols(cell["wg_x"], self.w_in[:, :2 * h])
         ops.copy_cols(cell["wc_x"], self.w_in[:, 2 * h:])
-        self.b_in[:2 * h].copy_(cell["bg"])
-        self.b_in[2 * h:].copy_(cell["bc"])
+        ops.copy(self.b_in[:2 * h], cell["bg"])
+        ops.copy(self.b_in[2 * h:], cell["bc"])
         self.cur = 0
         self.src = None
 
@@ -341,10 +341,10 @@ class GeneralStepper:
         out, self.state = dec.general_step(tape, tape.leaf(emb), self.state, self.sessions, w_outs, False,
                                            self.t)
         self._produced[self.t & 1] = self.state
-        out_state.copy_(out.data)
+        ops.copy(out_state, out.data)
         dec.state_to_logits(self.ctx, out_state, logits)
         if h_out is not None:
-            h_out.copy_(self.state[1].data)
+            ops.copy(h_out, self.state[1].data)
         self.t += 1
         return [AttentionLoopState(st.contexts, st.weights, st.step + 1) for st in att_states]
 

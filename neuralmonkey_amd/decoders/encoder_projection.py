@@ -38,7 +38,7 @@ class _Empty(EncoderProjection):
         return rnn_size
 
     def apply(self, ctx, decoder, rnn_size, encoders, out, train_mode):
-        out.zero_()
+        ops.zero(out)
         return out
 
     def apply_var(self, tape, decoder, rnn_size, enc_outputs, bsz, train_mode):

@@ -199,7 +199,7 @@ class TransformerDecoder(AutoregressiveDecoder):
         n = len(contexts)
         stacked = tape.view(F.concat(tape, contexts), lambda t: t.view(rows * n, d))    # [B*T, n, D]
         ones = ctx.buffer((id(self), "hier_mask", rows, n), (rows, n))
-        ones.fill_(1.0)
+        ops.fill(ones, 1.0)
         # the weights of the second attention are dropped with dropout_keep_prob (:221-226)
         att = TB.multihead_attention(tape, self, top + "/enc_hier", queries, stacked, ones, self.n_heads_hier, rows, 1,
                                      rows, n, False, keep, train, ctx.salt(*site, "encdec_hier_weights"), False)
@@ -288,7 +288,9 @@ class TransformerDecoder(AutoregressiveDecoder):
     @tensor
     def train_loss(self, ctx) -> torch.Tensor:
         res = self.train_loop_result(ctx)
-        return res.loss_sum[0] / res.token_count
+        out = ctx.buffer((id(self), "train_loss"), (1,))
+        alpha = 1.0 / res.token_count if res.token_count else float("nan")         # (0 / 0 as the reference's division)
+        return ops.ew("scale", res.loss_sum[0:1], None, out, alpha=alpha)[0]
 
     @tensor
     def train_logits(self, ctx) -> torch.Tensor:
@@ -319,7 +321,7 @@ class TransformerDecoder(AutoregressiveDecoder):
         omask = ctx.buffer(key + ("mask",), (tmax, bsz), torch.int32, zero=True)
         finished = ctx.buffer(key + ("fin",), (bsz,), torch.int32, zero=True)
         allfin = ctx.buffer(key + ("allfin",), (tmax,), torch.int32)
-        allfin.fill_(1)
+        ops.fill(allfin, 1)
         argmax = ctx.buffer(key + ("argmax",), (bsz,), torch.int32)
         logits_all = ctx.buffer(key + ("logits_all",), (tmax, bsz, v)) if keep_logits else None
         logits_one = ctx.buffer(key + ("logits",), (bsz, v))
@@ -328,7 +330,7 @@ class TransformerDecoder(AutoregressiveDecoder):
         stepper = self.make_stepper(ctx, bsz, "greedy")
         stepper.start()
         go = ctx.buffer(key + ("go",), (bsz,), torch.int32)
-        go.fill_(START_TOKEN_INDEX)
+        ops.fill(go, START_TOKEN_INDEX)
         self.embed_input_symbols(ctx, go, out=emb[0])
         self.decoding_bias(ctx)              # lazily built tensors: outside the captured chunks
         t_xent = min(t_target, tmax) if has_tgt else 0
@@ -461,7 +463,7 @@ class TransformerStepper:
         self.anc = ctx.buffer(key + ("anc",), (2, rows, self.tmax), torch.int32) if self.use_anc else None
         self.mask = buf("mask", (2, rows, self.tmax))
         self.hier_ones = buf("hier_ones", (rows, len(dec.encoders)))
-        self.hier_ones.fill_(1.0)
+        ops.fill(self.hier_ones, 1.0)
         self.cur = 0
         self.t = 0
         self.enc_kv = None
@@ -493,7 +495,7 @@ class TransformerStepper:
         self._prepare_qkv()
         if self.anc is not None:                  # every row starts as its own ancestor at every position
             iota = torch.arange(self.rows, dtype=torch.int32, device=self.anc.device).view(1, self.rows, 1)
-            self.anc.copy_(iota.expand(2, self.rows, self.tmax))
+            ops.copy(self.anc, iota.expand(2, self.rows, self.tmax))
 
     def _prepare_qkv(self) -> None:
         """The three self-attention projections of a layer read the same normed rows: ONE launch of nm_step_group
@@ -515,7 +517,7 @@ class TransformerStepper:
             for proj in ("query_proj", "keys_proj", "vals_proj"):
                 w = dec.var(ctx, "{}/{}/kernel".format(scope, proj))                 # [d, d]
                 wt = ctx.buffer(key + (l, proj), (w.shape[1], w.shape[0]))
-                wt.copy_(w.t())
+                ops.copy(wt, w.t())
                 wts.append(wt)
                 biases.append(dec.var(ctx, "{}/{}/bias".format(scope, proj)) if dec.use_att_transform_bias else None)
             qbuf = ctx.buffer(key + (l, "q"), (self.rows, d))

@@ -187,7 +187,7 @@ class SpatialFiller(ModelPart, SpatialStatefulWithOutput):
         states = cur.data.view(bsz, h, w, dim)
         # average_image: mean over the S positions as ones[1,S]/S . states[b]
         avg_w = ctx.buffer((id(self), "avg_w", s), (1, s))
-        avg_w.fill_(1.0 / s)
+        ops.fill(avg_w, 1.0 / s)
         out = ctx.buffer((id(self), "output", bsz), (bsz, 1, dim))
         ops.gemm(avg_w.expand(bsz, 1, s), cur.data.view(bsz, s, dim), out=out)
         return {"tape": tape, "states_var": cur, "states": states, "output": out.view(bsz, dim), "avg_w": avg_w,
@@ -201,7 +201,7 @@ class SpatialFiller(ModelPart, SpatialStatefulWithOutput):
     def spatial_mask(self, ctx) -> torch.Tensor:
         st = self._activations(ctx)["states"]
         mask = ctx.buffer((id(self), "mask", tuple(st.shape[:3])), tuple(st.shape[:3]))
-        mask.fill_(1.0)
+        ops.fill(mask, 1.0)
         return mask
 
     @tensor

@@ -205,8 +205,8 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
         wg_f, wc_f = wgh, wch
 
         def time_loop():
-            states_raw.zero_()
-            hcur.zero_()
+            ops.zero(states_raw)
+            ops.zero(hcur)
             for t in range(slen):
                 ru = ru_all[t] if train else ru_all[0]
                 gru.step_fwd(xp, (3 * h, xrs, xts), hcur, hcur, wg_f, wc_f, ru, rh, c_all[t] if train else None,
@@ -215,8 +215,8 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
         if gru.cluster_ok(ctx.session, bsz, h, ndir, wgh, wch):
             # both directions, all positions: ONE launch (csrc/nm_gru_cluster.hip)
             ctx.session.start_deferred_side()      # work that waits for a time loop to hide under (Session.defer_side)
-            states_raw.zero_()
-            hcur.zero_()
+            ops.zero(states_raw)
+            ops.zero(hcur)
             ops.gru_seq_fwd(slen, ndir, bsz, h, xp, (3 * h, xrs, xts), hcur, hcur, 0, ru_all[0],
                             ndir * bsz * 2 * h if train else 0, None, 0, c_all[0] if train else None,
                             ndir * bsz * h, wgh, wch, gru.cluster_workspace(ctx, key, bsz, h, ndir), lengths=len_arg,
@@ -410,7 +410,7 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
         ru_all, c_all, sc_all = (tape.buf((nsave, ndir, bsz, 2 * h)), tape.buf((nsave, ndir, bsz, h)),
                                  tape.buf((nsave, ndir, bsz, h)))
         ws = ctx.buffer((id(self), "nematus_ws", layer), (ops.nematus_seq_workspace_floats(bsz, h, ndir),))
-        out.data.zero_()
+        ops.zero(out.data)
         xrs, xts = slen * ndir * 3 * h, ndir * 3 * h
         seq_strides = (h, slen * width, width)
         ops.nematus_seq_fwd(slen, ndir, bsz, h, xp, (3 * h, xrs, xts), hzero, hcur, 0, ru_all[0],
@@ -428,7 +428,7 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
                 for d in range(ndir):
                     ops.copy_cols(final.grad[:, d * h:(d + 1) * h], dh[d])
             else:
-                dh.zero_()
+                ops.zero(dh)
             dxp = tape.buf((bsz * slen, ndir * 4 * h), zero=True)
             ops.nematus_seq_bwd(slen, ndir, bsz, h, dh, out.grad, seq_strides if out.grad is not None else None,
                                 ru_all[0], ndir * bsz * 2 * h, sc_all[0], ndir * bsz * h, c_all[0], ndir * bsz * h,

@@ -43,8 +43,8 @@ def transposed_weights(ctx, key, wgh, wch):
     c3 = wch if wch.dim() == 3 else wch.unsqueeze(0)
     wg_t = ctx.buffer((key, "wgh_t"), (g3.shape[0], g3.shape[2], g3.shape[1]))
     wc_t = ctx.buffer((key, "wch_t"), (c3.shape[0], c3.shape[2], c3.shape[1]))
-    wg_t.copy_(g3.transpose(1, 2))
-    wc_t.copy_(c3.transpose(1, 2))
+    ops.copy(wg_t, g3.transpose(1, 2))
+    ops.copy(wc_t, c3.transpose(1, 2))
     return (wg_t, wc_t) if wgh.dim() == 3 else (wg_t[0], wc_t[0])
 
 

@@ -4,6 +4,7 @@ torch is used only as the device allocator and stream owner; every arithmetic
 op on the hot path is a libnmhip kernel launched on torch's current stream.
 """
 import ctypes
+import struct
 import os
 import threading
 from typing import Optional
@@ -225,7 +226,7 @@ def attn_workspace(rows, s, c, device):
     lib = _lib.load()
     nbytes = lib.nm_attn_workspace_bytes(rows, s, c)
     # zeroed ONCE: the tail holds the arrival counters of the in-kernel merge, which the kernels leave at zero
-    return torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=device)
+    return zero(torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device))
 
 
 def gru_rh_seq(ru_all, hprev, out, lengths, ndir, hsz, reverse_dir0=False):
@@ -551,7 +552,9 @@ def colsum(x, out, accumulate=False):
     ws = _COLSUM_WS.get(key)
     if ws is None:
         # zeroed ONCE: the tail holds the arrival counters of the in-kernel final pass, which the kernel leaves at zero
-        ws = torch.zeros(lib.nm_colsum_workspace_bytes(cols) // 4, dtype=torch.float32, device=x.device)
+        # (created inside a stream capture when the capture stream is new to this cache: the fill below is then a node
+        # of that graph, replayed with it -- the library's fill, not a tensor library's)
+        ws = zero(torch.empty(lib.nm_colsum_workspace_bytes(cols) // 4, dtype=torch.float32, device=x.device))
         _COLSUM_WS[key] = ws
     _lib.check(lib.nm_colsum(_stream(), x.data_ptr(), x.stride(0), x.shape[0], cols, out.data_ptr(),
                              int(accumulate), ws.data_ptr(), ws.numel() * 4), "nm_colsum")
@@ -663,6 +666,34 @@ def zero_if(word, x):
     """``x[:] = 0`` when the int32 device word is not zero (nm_zero_if): the gradient of a step whose time loop gave up
     must not reach an accumulation buffer or a collective as NaNs."""
     _lib.check(_lib.load().nm_zero_if(_stream(), word.data_ptr(), x.data_ptr(), x.numel()), "nm_zero_if")
+
+
+def fill(x, value=0):
+    """``x[:] = value`` for a contiguous float32 / int32 buffer with the library's fill kernel (nm_fill_u32).  Other
+    tensors (host tensors, other dtypes, strided views) take torch's fill."""
+    if not x.is_cuda or not x.is_contiguous() or x.dtype not in (torch.float32, torch.int32):
+        return x.fill_(value)
+    if x.dtype == torch.float32:
+        pattern = struct.unpack("<I", struct.pack("<f", float(value)))[0]
+    else:
+        pattern = int(value) & 0xFFFFFFFF
+    _lib.check(_lib.load().nm_fill_u32(_stream(), x.data_ptr(), x.numel(), pattern), "nm_fill_u32")
+    return x
+
+
+def zero(x):
+    return fill(x, 0)
+
+
+def copy(dst, src):
+    """``dst[:] = src`` for two contiguous device buffers of one dtype and size as a runtime device-to-device copy
+    (nm_copy_d2d: a memcpy node inside a captured graph); anything else takes torch's copy_."""
+    if (dst.is_cuda and src.is_cuda and dst.dtype == src.dtype and dst.numel() == src.numel() and dst.is_contiguous()
+            and src.is_contiguous() and dst.device == src.device):
+        _lib.check(_lib.load().nm_copy_d2d(_stream(), dst.data_ptr(), src.data_ptr(), dst.numel() * dst.element_size()),
+                   "nm_copy_d2d")
+        return dst
+    return dst.copy_(src)
 
 
 def ew(op, a, b, out, alpha=0.0, accumulate=False):

@@ -187,11 +187,22 @@ def _to_host(val):
     for t in devs:
         if id(t) in staged or t.numel() == 0:
             continue
-        cap = 1 << max(8, (t.numel() - 1).bit_length())          # few distinct buffers for the varying decode lengths
+        src, shaped = t.detach(), None
+        if not src.is_contiguous():
+            # a strided view (a column block, a transposed history): its whole storage span travels as ONE plain copy
+            # and the view is taken on the host, instead of a gather kernel that packs it on the device first
+            span = 1 + sum((n - 1) * st for n, st in zip(src.shape, src.stride()))
+            if all(st >= 0 for st in src.stride()) and span <= 4 * src.numel() + 1024:
+                shaped = (tuple(src.shape), tuple(src.stride()))
+                src = src.as_strided((span,), (1,))
+        count = src.numel()
+        cap = 1 << max(8, (count - 1).bit_length())              # few distinct buffers for the varying decode lengths
         pool = _PINNED_FETCH.setdefault((cap, t.dtype), [])
         host = pool.pop() if pool else torch.empty(cap, dtype=t.dtype).pin_memory()
-        flat = host[:t.numel()]
-        flat.copy_(t.detach().reshape(-1), non_blocking=True)
+        flat = host[:count]
+        flat.copy_(src.reshape(-1), non_blocking=True)
+        if shaped is not None:
+            flat = flat.as_strided(*shaped)
         staged[id(t)] = (host, flat, (cap, t.dtype))
     for device in {t.device for t in devs}:
         torch.cuda.current_stream(device).synchronize()
@@ -396,11 +407,12 @@ class Session:
         full = (key, shape, dtype) if not self.slot else (("slot", self.slot), key, shape, dtype)
         buf = self._buffers.get(full)
         if buf is None:
-            make = torch.zeros if zero_init else torch.empty
-            buf = make(shape, dtype=dtype, device=self.device)
+            buf = torch.empty(shape, dtype=dtype, device=self.device)
             self._buffers[full] = buf
+            zero = zero or zero_init
         if zero:
-            buf.zero_()
+            from . import ops
+            ops.zero(buf)                # (the library's fill: buffers are also created -- and zeroed -- inside captures)
         return buf
 
     def read_small(self, dev_tensor: torch.Tensor):
@@ -749,7 +761,8 @@ class Session:
             self._step_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
             self._step_dev_value = 0
         if self._step_dev_value != self.global_step:
-            self._step_dev.fill_(self.global_step)
+            from . import ops
+            ops.fill(self._step_dev, self.global_step)
             self._step_dev_value = self.global_step
         return self._step_dev
 

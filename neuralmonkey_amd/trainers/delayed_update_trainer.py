@@ -50,7 +50,7 @@ class DelayedUpdateTrainer(GenericTrainer):
             ops.zero_if(ctx.session.error_word(), grad)       # a given-up time loop's gradient never enters the buffer
         accum = ctx.buffer((id(self), "gradient_buffer"), (store.total,))
         if self._counter == 0:
-            accum.copy_(grad)                                  # first batch after a reset (:160-168)
+            ops.copy(accum, grad)                                  # first batch after a reset (:160-168)
         else:
             ops.ew("copy", grad, None, accum, accumulate=True)     # tf.assign_add (:146-150)
         self._counter += 1

@@ -114,7 +114,7 @@ class GenericTrainer(GraphExecutor, Feedable):
         ctx.memo["want_backward"] = True     # encoders keep their per-step state even when train_mode is fed False
         sess, store = ctx.session, ctx.store
         grad = store.ensure_grad()
-        grad.zero_()
+        ops.zero(grad)
         dp = dist.current()
         if dp is not None:
             dp.begin_step()
@@ -135,7 +135,7 @@ class GenericTrainer(GraphExecutor, Feedable):
             if dp is not None:
                 dp.scale_by_global_count(count, weight, scale)               # on the device: no host exchange
             else:
-                scale.fill_(weight / count if count else 0.0)               # a batch without target tokens: no gradient
+                ops.fill(scale, weight / count if count else 0.0)               # a batch without target tokens: no gradient
             decoders.append(dec)
             scales.append(scale)
             counts.append(count)
@@ -191,7 +191,9 @@ class GenericTrainer(GraphExecutor, Feedable):
         else:
             l1l2 = tables.regularize_and_norms(store.theta, grad, self.l1_weight, self.l2_weight)
             tables.apply(kind, store.theta, grad, state["m"], state["v"], self.clip_norm, params, skip=skip)
-        ctx.memo[(id(self), "l1l2")] = l1l2.clone()
+        # (the norms live in the optimizer's workspace; the copy a step's losses read is one of four persistent slots)
+        keep = ctx.buffer((id(self), "l1l2_kept", sess.global_step % 4), tuple(l1l2.shape))
+        ctx.memo[(id(self), "l1l2")] = ops.copy(keep, l1l2)
         sess.variables_changed()
         return sess.global_step
 
@@ -230,8 +232,8 @@ class GenericTrainer(GraphExecutor, Feedable):
                     import warnings
                     warnings.warn("optimizer slots {} of the restored checkpoint do not belong to {} (slots {}): they "
                                   "are reset to zero".format(store.slot_suffixes, type(self.optimizer).__name__, mine))
-                    m.zero_()
-                    v.zero_()
+                    ops.zero(m)
+                    ops.zero(v)
                 store.slot_suffixes = mine                                    # the slots' names in checkpoints
                 applied = sess.global_step
             else:
@@ -269,8 +271,14 @@ class GenericTrainer(GraphExecutor, Feedable):
         # step keeps the host from enqueuing the next step while this one runs.  NM_DEFER_LOSSES=0: read at once.
         # (behind them travels the session's device error word: a time loop that gave up makes the step garbage)
         if DEFER_LOSSES and all(isinstance(v, torch.Tensor) and v.is_cuda for v in values):
-            pending = ctx.session.to_host_async(torch.stack([v.detach().reshape(()) for v in values]
-                                                            + [ctx.session.error_word()[0].float()]))
+            # (gathered with 4-byte device copies into one of four persistent slots; the error word travels as its
+            # raw int32 bits: zero stays 0.0, one reads as a denormal -- the host only asks "is it zero")
+            sess = ctx.session
+            vals = ctx.buffer((id(self), "loss_vals", sess.global_step % 4), (len(values) + 1,))
+            for i, v in enumerate(values):
+                ops.copy(vals[i:i + 1], v.detach().reshape(1))
+            ops.copy(vals[len(values):].view(torch.int32), sess.error_word()[0:1])
+            pending = sess.to_host_async(vals)
             ctx.session.attach_guarded_losses(self, pending)
             return pending
         if ctx.session.cluster_failure():

@@ -808,3 +808,33 @@ def test_gather_and_token_reorder(dev):
                             out, steps, 15)
     ref = np.concatenate([tok[:steps][:, idx], word[None]], 0)
     assert np.array_equal(out.cpu().numpy()[:steps + 1], ref)
+
+
+@pytest.mark.parametrize("rows,cols,ld", [
+    (6400, 512, 512),        # a Transformer-base bias gradient: the float4 kernel, 48 row slices
+    (6400, 2048, 2048),
+    (6400, 512, 1536),       # a column block of a wider gradient buffer
+    (640, 32000, 32000),     # the output bias
+    (64, 8, 8), (65, 4, 12), (200, 516, 516),
+    (63, 512, 512),          # fewer than 64 rows: the one-float-per-thread kernel
+    (777, 130, 131),         # neither aligned nor a multiple of 4
+])
+def test_colsum_both_kernels(dev, rows, cols, ld):
+    """nm_colsum (bias gradients) against a float64 sum: the float4 kernel (16-byte aligned, ld and cols multiples of
+    4, >= 64 rows) and the scalar one; deterministic from launch to launch; ``accumulate`` adds to what is there."""
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(rows + cols)
+    full = rng.standard_normal((rows, ld)).astype(np.float32)
+    xd = T(full, dev)[:, :cols]
+    want = full[:, :cols].astype(np.float64).sum(0)
+    out = torch.full((cols,), float("nan"), device=dev)
+    ops.colsum(xd, out)
+    tol = 2e-6 * np.sqrt(rows) * max(1.0, np.abs(full).max())
+    assert np.abs(out.cpu().numpy() - want).max() <= tol
+    again = torch.empty_like(out)
+    ops.colsum(xd, again)
+    assert torch.equal(out, again)
+    base = T(rng.standard_normal(cols).astype(np.float32), dev)
+    acc = base.clone()
+    ops.colsum(xd, acc, accumulate=True)
+    assert torch.equal(acc, base + out)

@@ -1,5 +1,3 @@
 export TMPDIR=/tmp
-cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/gp_prof -- python $GRAFT_REPO_ROOT/tools/general_path_probe.py --train-only NM_NEMATUS_CLUSTER 1 2>&1 | grep "NM_NEMATUS" | tail -3
-cd $GRAFT_REPO_ROOT
-f=$(ls /tmp/gp_prof/*/*_kernel_stats.csv | head -1); head -60 $f > gpurun_out/r06_general_train_kernel_stats.csv; head -45 $f | cut -c1-170
+timeout 300 python -m pytest tests/test_no_foreign_kernels_gpu.py -q --timeout=120 2>&1 | grep -v "amdgpu.ids" | grep -E "^FAILED|^E   |passed|failed" | cut -c1-300 | head -10
+timeout 600 python -m pytest tests/test_engine_gpu.py tests/test_beam_gpu.py tests/test_cluster_recovery_gpu.py tests/test_transformer_gpu.py -q -x --timeout=200 2>&1 | grep -v "amdgpu.ids" | grep -E "^FAILED|^E   |passed|failed" | cut -c1-300 | head -10
