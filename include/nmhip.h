@@ -72,6 +72,19 @@ int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int64_t N, int6
 int nm_gemm_f32_group(void* stream, int transA, int transB, int64_t M, int64_t N, int64_t K,
                       const void* pointer_table, int64_t lda, int64_t ldb, int64_t ldc, int accumulate,
                       int64_t count);
+/* C (+)= sum_i A_i^T . B_i over `count` members of `rows` rows each (A_i [rows, M], B_i [rows, N]): ONE product whose
+ * K dimension is the chain of the members; pointer_table: device array [count][3] of {A_i, B_i, unused}.  The weight
+ * gradients of a taped time loop (x_t^T . dy_t of every step) as one launch per kernel instead of one per step.
+ * rows % 16 == 0; M, N, lda, ldb multiples of 4, members 16-byte aligned; K is split over workgroups like nm_gemm_f32
+ * (workspace: split-K slabs, may be null). */
+int nm_gemm_f32_chain(void* stream, int64_t M, int64_t N, int64_t rows, int64_t count, const void* pointer_table,
+                      int64_t lda, int64_t ldb, float* C, int64_t ldc, int accumulate, void* workspace,
+                      int64_t workspace_bytes);
+/* out[c] (+)= sum_i sum_r x_i[r, c]: the column sums (bias gradients) of the same kind of chain; member i is
+ * table[i * table_stride + table_offset].  workspace: nm_colsum_workspace_bytes(cols), zero-initialised once. */
+int nm_colsum_chain(void* stream, const void* pointer_table, int32_t table_stride, int32_t table_offset, int64_t count,
+                    int64_t rows, int64_t ldx, int64_t cols, float* out, int accumulate, void* workspace,
+                    int64_t workspace_bytes);
 
 /* ---- embedding lookup: model/sequence.py:170-194, decoders/autoregressive.py:269-272 --
  * out[i,:] = table[ids[i],:] * scale * (mask_pad ? ids[i] != 0 : 1) */

@@ -31,6 +31,9 @@ from . import ops
 FUSED_LN_BWD = os.environ.get("NM_LN_BWD_FUSED", "1") != "0"
 # the weight gradients of one shape launched together when a backward pass ends (Tape.defer_wgrad)
 GROUP_WGRADS = os.environ.get("NM_WGRAD_GROUPS", "1") != "0"
+# the weight / bias gradients of a taped time loop (one small product per step and kernel) as one chained product per
+# kernel when the backward pass ends
+CHAIN_WGRADS = os.environ.get("NM_WGRAD_CHAINS", "1") != "0"
 
 
 class Var:
@@ -55,6 +58,7 @@ class Tape:
         self.recording = recording
         self._ops: List[Callable[[], None]] = []
         self._wgrads = {}
+        self._chains = {}
         self._n = 0
         self._slot = 0
 
@@ -149,12 +153,45 @@ class Tape:
               and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0
               and a.shape[0] >= 1024 and out.shape[0] * out.shape[1] <= (1 << 21))
         if not ok:
-            ops.gemm(a, b, out=out, trans_a=trans_a, accumulate=True)
+            # a product of a few rows (one step of a taped time loop): the steps' products for one kernel are ONE
+            # product over the chain of their rows when the pass ends (``flush_wgrads``: nm_gemm_f32_chain)
+            small = (CHAIN_WGRADS and trans_a and a.is_cuda and a.dim() == 2 and b.dim() == 2 and out.dim() == 2
+                     and a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1
+                     and a.shape[0] % 16 == 0 and 16 <= a.shape[0] < 1024
+                     and a.stride(0) % 4 == 0 and b.stride(0) % 4 == 0 and a.shape[1] % 4 == 0 and b.shape[1] % 4 == 0
+                     and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
+            if not small:
+                ops.gemm(a, b, out=out, trans_a=trans_a, accumulate=True)
+                return
+            key = ("chain", out.data_ptr(), tuple(a.shape), tuple(b.shape), a.stride(0), b.stride(0))
+            self._chains.setdefault(key, [out, []])[1].append((a, b))
             return
         key = (trans_a, tuple(a.shape), tuple(b.shape), a.stride(0), b.stride(0), out.stride(0))
         self._wgrads.setdefault(key, []).append((a, b, out))
 
+    def defer_bias(self, dy: torch.Tensor, out: torch.Tensor) -> None:
+        """``out += column sums of dy``: a bias gradient.  Those of a taped time loop (one per step and bias) are summed
+        over the chain of the steps' rows when the pass ends (nm_colsum_chain); others at once."""
+        small = (CHAIN_WGRADS and dy.is_cuda and dy.dim() == 2 and dy.stride(1) == 1 and dy.shape[0] < 1024
+                 and dy.stride(0) % 4 == 0 and dy.shape[1] % 4 == 0 and dy.data_ptr() % 16 == 0)
+        if not small:
+            ops.colsum(dy, out, accumulate=True)
+            return
+        key = ("bias", out.data_ptr(), tuple(dy.shape), dy.stride(0))
+        self._chains.setdefault(key, [out, []])[1].append(dy)
+
     def flush_wgrads(self) -> None:
+        chains, self._chains = self._chains, {}
+        for key, (out, members) in chains.items():
+            if key[0] == "bias":
+                if len(members) == 1:
+                    ops.colsum(members[0], out, accumulate=True)
+                else:
+                    ops.colsum_chain(members, out, accumulate=True)
+            elif len(members) == 1:
+                ops.gemm(members[0][0], members[0][1], out=out, trans_a=True, accumulate=True)
+            else:
+                ops.gemm_chain(members, out, accumulate=True)
         pending, self._wgrads = self._wgrads, {}
         for (trans_a, *_), items in pending.items():
             while items:
@@ -199,7 +236,7 @@ def linear(tape: Tape, x: Var, w: Var, b: Optional[Var] = None, out: Optional[Va
             else:
                 tape.defer_wgrad(x.data, dy, tape.grad(w), True)
         if b is not None and b.needs_grad:
-            ops.colsum(dy, tape.grad(b), accumulate=True)
+            tape.defer_bias(dy, tape.grad(b))
     tape.record(bwd)
     return out
 

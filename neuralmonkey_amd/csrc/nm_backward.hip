@@ -172,6 +172,79 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const float* __restrict
     }
 }
 
+// The column sums of a CHAIN of operands -- out[c] (+)= sum_i sum_r x_i[r, c], ``count`` members of ``rows`` rows each,
+// named by a device table of pointers (entry i at table[i * table_stride + table_offset]: the {A, B, -} table of
+// nm_gemm_f32_chain serves both) -- as one launch: the bias gradients of a taped time loop, one colsum_kernel launch
+// per step and bias before (307 launches of 6.5 us per training step of the general-path model at the headline size).
+// Order: as colsum_vec_kernel over the concatenated rows.
+__global__ __launch_bounds__(256) void colsum_chain_kernel(const float* const* __restrict__ table, int table_stride,
+                                                           int table_offset, int mrows, long ldx, long rows, int cols,
+                                                           int nsplit, float* __restrict__ part,
+                                                           unsigned* __restrict__ tickets, float* __restrict__ out,
+                                                           int accumulate) {
+    __shared__ float sh[16][65];
+    __shared__ int s_last;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c4 = blockIdx.x * 64 + 4 * tx;
+    const int sl = blockIdx.y;
+    const long per = (rows + nsplit - 1) / nsplit;
+    const long r0 = sl * per, r1 = min(rows, r0 + per);
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (c4 < cols) {
+        auto at = [&](long r) {
+            const int mem = (int)(r / mrows);
+            return *reinterpret_cast<const float4*>(table[(long)mem * table_stride + table_offset] + (r - (long)mem * mrows) * ldx + c4);
+        };
+        long r = r0 + ty;
+        for (; r + 16 < r1; r += 32) {
+            const float4 a = at(r), b = at(r + 16);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+        }
+        if (r < r1) {
+            const float4 a = at(r);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        }
+    }
+    sh[ty][4 * tx] = s0.x + s1.x;
+    sh[ty][4 * tx + 1] = s0.y + s1.y;
+    sh[ty][4 * tx + 2] = s0.z + s1.z;
+    sh[ty][4 * tx + 3] = s0.w + s1.w;
+    __syncthreads();
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    float mine = 0.0f;
+    if (ry == 0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) mine += sh[k][cx];
+    }
+    if (nsplit == 1) {
+        if (ry == 0 && c < cols) out[c] = accumulate ? out[c] + mine : mine;
+        return;
+    }
+    if (ry == 0 && c < cols) colsum_st_wt(part + (long)sl * cols + c, mine);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(tickets + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (t == (unsigned)(nsplit - 1));
+        if (last) __hip_atomic_store(tickets + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    float f = 0.0f;
+    if (c < cols)
+        for (int k = ry; k < nsplit; k += 4) f += colsum_ld_wt(part + (long)k * cols + c);
+    __syncthreads();
+    sh[ry][cx] = f;
+    __syncthreads();
+    if (ry == 0 && c < cols) {
+        const float tot = (sh[0][cx] + sh[1][cx]) + (sh[2][cx] + sh[3][cx]);
+        out[c] = accumulate ? out[c] + tot : tot;
+    }
+}
+
 // partial sums [COLSUM_MAX_SPLIT][cols] + one arrival counter per 64 columns.  The counters must be ZERO when a
 // launch starts (the kernel leaves them zero): allocate the workspace zero-initialised.
 extern "C" int64_t nm_colsum_workspace_bytes(int64_t cols) {
@@ -205,6 +278,27 @@ extern "C" int nm_colsum(void* stream, const float* x, int64_t ldx, int64_t rows
     hipLaunchKernelGGL(colsum_kernel, dim3(nm_cdiv(cols, 64), nsplit), dim3(256), 0, st, x, (long)ldx, (long)rows,
                        (int)cols, nsplit, part, tickets, out, accumulate);
     NM_LAUNCH_CHECK("nm_colsum");
+}
+
+// workspace: that of nm_colsum for ``cols`` (zero-initialised once; the kernel leaves the counters at zero)
+extern "C" int nm_colsum_chain(void* stream, const void* pointer_table, int32_t table_stride, int32_t table_offset,
+                               int64_t count, int64_t rows, int64_t ldx, int64_t cols, float* out, int accumulate,
+                               void* workspace, int64_t workspace_bytes) {
+    NM_REQUIRE(pointer_table && out && workspace && count >= 1 && rows > 0 && cols > 0 && table_stride >= 1 &&
+                   table_offset >= 0 && table_offset < table_stride, "nm_colsum_chain: bad arguments");
+    NM_REQUIRE(ldx % 4 == 0 && cols % 4 == 0, "nm_colsum_chain: ld and cols must be multiples of 4 (members 16-byte aligned)");
+    NM_REQUIRE(workspace_bytes >= nm_colsum_workspace_bytes(cols), "nm_colsum_chain: workspace too small");
+    float* part = reinterpret_cast<float*>(workspace);
+    unsigned* tickets = reinterpret_cast<unsigned*>(part + cols * COLSUM_MAX_SPLIT);
+    const long total = rows * count;
+    int ns = (int)((768 * 64 + cols - 1) / cols);
+    if (ns > (int)(total / 32)) ns = (int)(total / 32);
+    if (ns > 48) ns = 48;
+    if (ns < 1) ns = 1;
+    hipLaunchKernelGGL(colsum_chain_kernel, dim3(nm_cdiv(cols, 64), ns), dim3(256), 0, nm_stream(stream),
+                       reinterpret_cast<const float* const*>(pointer_table), (int)table_stride, (int)table_offset, (int)rows,
+                       (long)ldx, total, (int)cols, ns, part, tickets, out, accumulate);
+    NM_LAUNCH_CHECK("nm_colsum_chain");
 }
 
 // ---------------------------------------------------------------------------

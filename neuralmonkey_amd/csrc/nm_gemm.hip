@@ -48,6 +48,8 @@ struct GemmArgs {
                      // chip with a background GEMM of another stream get the issue slots first
     const float* const* ptrs;    // gemm_tiled, grouped products (nm_gemm_f32_group): [batch][3] device pointers {A, B, C} of
                                  // independent products of one shape instead of base + z * stride
+    int chain_k;                 // gemm_tiled<..., CHAIN>: K is a chain of members of chain_k rows each, member i's operands
+                                 // are ptrs[3 i] and ptrs[3 i + 1] (nm_gemm_f32_chain); C is one output
 };
 
 __device__ __forceinline__ float apply_act(float x, int act) {
@@ -90,8 +92,9 @@ __device__ __forceinline__ void store_tile32(const GemmArgs& g, float* __restric
 // 2.3e-5 -- the accumulation order of the products is what made the engine "2x noisier".  Costs (NCH - 1) * TM * TN *
 // 16 accumulator registers: used for the 64x64 tiles only.
 template <int WM, int WN, int TM, int TN, bool TA, bool TB, bool VEC, int BK, bool STATS = false, int PF = 1,
-          int NCH = 1>
+          int NCH = 1, bool CHAIN = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_tiled(GemmArgs g, int tiles_m) {
+    static_assert(!CHAIN || (TA && !TB && VEC && !STATS), "chained K: the weight-gradient form only");
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * 32 * TM, BN = WN * 32 * TN;
     constexpr int LA = BM * BK / 4 / NT, LB = BN * BK / 4 / NT, KQ = BK / 4;   // float4 loads per thread; float4s per k-row
@@ -134,9 +137,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tiled(GemmArgs g, int tiles
         }
     }
     const int m0 = bm * BM, n0 = bn * BN;
-    const float* __restrict__ A = g.ptrs ? g.ptrs[3 * blockIdx.z] : g.A + (long)blockIdx.z * g.sA;
-    const float* __restrict__ B = g.ptrs ? g.ptrs[3 * blockIdx.z + 1] : g.B + (long)blockIdx.z * g.sB;
-    float* __restrict__ C = g.ptrs ? const_cast<float*>(g.ptrs[3 * blockIdx.z + 2]) : g.C + (long)blockIdx.z * g.sC;
+    const float* __restrict__ A = (g.ptrs && !CHAIN) ? g.ptrs[3 * blockIdx.z] : g.A + (long)blockIdx.z * g.sA;
+    const float* __restrict__ B = (g.ptrs && !CHAIN) ? g.ptrs[3 * blockIdx.z + 1] : g.B + (long)blockIdx.z * g.sB;
+    float* __restrict__ C = (g.ptrs && !CHAIN) ? const_cast<float*>(g.ptrs[3 * blockIdx.z + 2]) : g.C + (long)blockIdx.z * g.sC;
 
     float4 ra0[LA], rb0[LB], ra1[PF == 2 ? LA : 1], rb1[PF == 2 ? LB : 1];
 
@@ -151,6 +154,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tiled(GemmArgs g, int tiles
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (TA) {
                 const float* p = A + (long)gk * g.lda + gm;
+                if constexpr (CHAIN) {      // (chain_k % BK == 0: a k-tile lies in ONE member; uniform scalar loads)
+                    const int mem = k0 / g.chain_k;
+                    p = g.ptrs[3 * mem] + (long)(gk - mem * g.chain_k) * g.lda + gm;
+                }
                 if (gk < g.K) {
                     if (VEC) { if (gm < g.M) v = *reinterpret_cast<const float4*>(p); }
                     else {
@@ -186,6 +193,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tiled(GemmArgs g, int tiles
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (!TB) {
                 const float* p = B + (long)gk * g.ldb + gn;
+                if constexpr (CHAIN) {
+                    const int mem = k0 / g.chain_k;
+                    p = g.ptrs[3 * mem + 1] + (long)(gk - mem * g.chain_k) * g.ldb + gn;
+                }
                 if (gk < g.K) {
                     if (VEC) { if (gn < g.N) v = *reinterpret_cast<const float4*>(p); }
                     else {
@@ -1067,6 +1078,63 @@ extern "C" int nm_gemm_f32_group(void* stream, int transA, int transB, int64_t M
     if (blocks128 >= 192) launch_tiled<4, 2, 1, 2, 16>(g, (int)count, ta, tb, true, st);          // 128x128, 8 waves
     else launch_tiled<2, 2, 1, 1, 16>(g, (int)count, ta, tb, true, st);                           // 64x64
     NM_LAUNCH_CHECK("nm_gemm_f32_group");
+}
+
+// C (+)= sum_i A_i^T . B_i over ``count`` members of ``rows`` rows each ([rows, M] and [rows, N], one leading dimension
+// each): ONE product whose K dimension is the chain of the members, their operands named by a device table of pointers
+// {A_i, B_i, -}.  Made for the weight gradients of a taped time loop (autodiff.Tape.defer_wgrad): every step of a taped
+// RNN left x_t^T . dy_t as a product of its own -- 128 rows deep, 15 us each, 600 per training step of the general-path
+// model at the headline size (9.2 of its 38 ms) -- where the hand-scheduled GRU path runs one product over all B x T rows.
+// rows % 16 == 0 (a k-tile never straddles two members); split over K like nm_gemm_f32 (slabs + a fixed-order reduction).
+extern "C" int nm_gemm_f32_chain(void* stream, int64_t M, int64_t N, int64_t rows, int64_t count,
+                                 const void* pointer_table, int64_t lda, int64_t ldb, float* C, int64_t ldc,
+                                 int accumulate, void* workspace, int64_t workspace_bytes) {
+    NM_REQUIRE(pointer_table && C && count >= 1 && count < 65536, "nm_gemm_f32_chain: null pointer / bad count %ld", (long)count);
+    NM_REQUIRE(M > 0 && N > 0 && rows > 0 && rows % 16 == 0 && rows * count < (1 << 30) && M < (1 << 30) && N < (1 << 30),
+               "nm_gemm_f32_chain: bad shape M=%ld N=%ld rows=%ld (a multiple of 16) x %ld", (long)M, (long)N, (long)rows,
+               (long)count);
+    NM_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && M % 4 == 0 && N % 4 == 0,
+               "nm_gemm_f32_chain: leading dimensions and M, N must be multiples of 4 (the operands 16-byte aligned)");
+    const long K = rows * count;
+    GemmArgs g{nullptr, nullptr, C, nullptr, (int)M, (int)N, (int)K, (long)lda, (long)ldb, (long)ldc,
+               0, 0, 0, 0, accumulate, nullptr, 1, 0, nullptr, 1};
+    g.swizzle = nm_cur()->sw.gemm_swz;
+    g.ptrs = reinterpret_cast<const float* const*>(pointer_table);
+    g.chain_k = (int)rows;
+    const bool big = M >= 128 && N >= 128;
+    const int tile = big ? 128 : 64;
+    const long tiles = (long)nm_cdiv(M, tile) * nm_cdiv(N, tile);
+    if (workspace && K >= 1024) {           // the makespan model of nm_gemm_f32
+        const long nkt = (K + 15) / 16;
+        const double kt_us = big ? 0.95 : 0.30;
+        long best_sk = 1;
+        double best = 1e30;
+        for (long sk = 1; sk <= 16; ++sk) {
+            if (sk > 1 && (K / sk < 128 || sk * M * N * (long)sizeof(float) > workspace_bytes)) break;
+            const long blocks = tiles * sk;
+            const long rounds = (blocks + 255) / 256;
+            const double per_cu = (double)blocks / 256.0;
+            const double thin = per_cu <= 1.0 ? 1.35 : (per_cu <= 2.0 ? 1.15 : 1.0);
+            double cost = (double)rounds * (double)((nkt + sk - 1) / sk) * kt_us * thin;
+            if (sk > 1) cost += (double)(sk + 1) * M * N * 4.0 / 3.0e6 + 3.0;
+            if (cost < best) { best = cost; best_sk = sk; }
+        }
+        if (best_sk >= 2) { g.splitk = (int)best_sk; g.ws = reinterpret_cast<float*>(workspace); }
+    }
+    hipStream_t st = nm_stream(stream);
+    static DevMask devs[2];
+    if (big) {
+        const int tiles_m = nm_cdiv(g.M, 128), tiles_n = nm_cdiv(g.N, 128);
+        launch_padded(gemm_tiled<4, 2, 1, 2, true, false, true, 16, false, 1, 1, true>, devs[0], 0,
+                      dim3(tiles_m * tiles_n, g.splitk, 1), dim3(512), st, g, tiles_m);
+    } else {
+        const int tiles_m = nm_cdiv(g.M, 64), tiles_n = nm_cdiv(g.N, 64);
+        launch_padded(gemm_tiled<2, 2, 1, 1, true, false, true, 16, false, 1, 1, true>, devs[1], 0,
+                      dim3(tiles_m * tiles_n, g.splitk, 1), dim3(256), st, g, tiles_m);
+    }
+    if (g.splitk > 1)
+        hipLaunchKernelGGL(splitk_reduce, dim3(nm_cdiv((long)M * N, 256)), dim3(256), 0, st, g);
+    NM_LAUNCH_CHECK("nm_gemm_f32_chain");
 }
 
 // ---------------------------------------------------------------------------

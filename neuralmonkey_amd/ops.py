@@ -103,14 +103,54 @@ def gemm_group(items, trans_a=False, trans_b=False, accumulate=True):
         assert a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and o.data_ptr() % 16 == 0
         ptrs += [a.data_ptr(), b.data_ptr(), o.data_ptr()]
     assert len({p for p in ptrs[2::3]}) == len(items), "two products of a group share their output"
-    key = (a0.device, tuple(ptrs))
-    table = _GROUP_TABLES.get(key)
-    if table is None:
-        if len(_GROUP_TABLES) > 64:
-            _GROUP_TABLES.clear()
-        table = _GROUP_TABLES[key] = torch.tensor(ptrs, dtype=torch.int64, device=a0.device)
+    table = _pointer_table(a0.device, ptrs)
     _lib.check(lib.nm_gemm_f32_group(_stream(), int(trans_a), int(trans_b), m, n, k, table.data_ptr(), lda, ldb, ldc,
                                      int(accumulate), len(items)), "nm_gemm_f32_group")
+
+
+def _pointer_table(device, ptrs):
+    key = (device, tuple(ptrs))
+    table = _GROUP_TABLES.get(key)
+    if table is None:
+        if len(_GROUP_TABLES) > 1024:
+            _GROUP_TABLES.clear()
+        table = _GROUP_TABLES[key] = torch.tensor(ptrs, dtype=torch.int64, device=device)
+    return table
+
+
+def gemm_chain(members, out, accumulate=True):
+    """``out (+)= sum_i a_i^T @ b_i`` over ``members`` = [(a_i, b_i)] of one shape ([rows, M] and [rows, N]) as ONE product
+    whose K dimension is the chain of the members (nm_gemm_f32_chain): the weight gradient of a taped time loop."""
+    lib = _lib.load()
+    a0, b0 = members[0]
+    rows, m, n = a0.shape[0], a0.shape[1], b0.shape[1]
+    lda, ldb = a0.stride(0), b0.stride(0)
+    ptrs = []
+    for a, b in members:
+        assert a.shape == a0.shape and b.shape == b0.shape and (a.stride(0), b.stride(0)) == (lda, ldb)
+        assert a.stride(1) == 1 and b.stride(1) == 1 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0
+        ptrs += [a.data_ptr(), b.data_ptr(), 0]
+    assert out.shape == (m, n) and out.stride(1) == 1
+    table = _pointer_table(a0.device, ptrs)
+    ws = _gemm_workspace(a0.device)
+    _lib.check(lib.nm_gemm_f32_chain(_stream(), m, n, rows, len(members), table.data_ptr(), lda, ldb, out.data_ptr(),
+                                     out.stride(0), int(accumulate), ws.data_ptr(), ws.numel() * 4), "nm_gemm_f32_chain")
+    return out
+
+
+def colsum_chain(members, out, accumulate=True):
+    """``out[c] (+)= sum_i sum_r x_i[r, c]`` over tensors of one shape (nm_colsum_chain): a bias gradient of a taped time
+    loop in one launch."""
+    lib = _lib.load()
+    x0 = members[0]
+    rows, cols, ld = x0.shape[0], x0.shape[1], x0.stride(0)
+    for x in members:
+        assert x.shape == x0.shape and x.stride(0) == ld and x.stride(1) == 1 and x.data_ptr() % 16 == 0
+    table = _pointer_table(x0.device, [x.data_ptr() for x in members])
+    ws = _colsum_workspace(x0.device, cols)
+    _lib.check(lib.nm_colsum_chain(_stream(), table.data_ptr(), 1, 0, len(members), rows, ld, cols, out.data_ptr(),
+                                   int(accumulate), ws.data_ptr(), ws.numel() * 4), "nm_colsum_chain")
+    return out
 
 
 _GEMM_WS = {}
@@ -543,19 +583,24 @@ def tanh_bwd(dy, y):
 _COLSUM_WS = {}
 
 
-def colsum(x, out, accumulate=False):
-    """out[c] (+)= sum_r x[r,c] (bias gradients); deterministic."""
-    lib = _lib.load()
-    assert x.dim() == 2 and x.stride(1) == 1
-    cols = x.shape[1]
-    key = (x.device, cols, _stream(), workspace_tag())
+def _colsum_workspace(device, cols):
+    key = (device, cols, _stream(), workspace_tag())
     ws = _COLSUM_WS.get(key)
     if ws is None:
         # zeroed ONCE: the tail holds the arrival counters of the in-kernel final pass, which the kernel leaves at zero
         # (created inside a stream capture when the capture stream is new to this cache: the fill below is then a node
         # of that graph, replayed with it -- the library's fill, not a tensor library's)
-        ws = zero(torch.empty(lib.nm_colsum_workspace_bytes(cols) // 4, dtype=torch.float32, device=x.device))
+        ws = zero(torch.empty(_lib.load().nm_colsum_workspace_bytes(cols) // 4, dtype=torch.float32, device=device))
         _COLSUM_WS[key] = ws
+    return ws
+
+
+def colsum(x, out, accumulate=False):
+    """out[c] (+)= sum_r x[r,c] (bias gradients); deterministic."""
+    lib = _lib.load()
+    assert x.dim() == 2 and x.stride(1) == 1
+    cols = x.shape[1]
+    ws = _colsum_workspace(x.device, cols)
     _lib.check(lib.nm_colsum(_stream(), x.data_ptr(), x.stride(0), x.shape[0], cols, out.data_ptr(),
                              int(accumulate), ws.data_ptr(), ws.numel() * 4), "nm_colsum")
     return out

@@ -259,9 +259,10 @@ def test_register_budgets_of_the_overlapped_kernels(lib):
         sys.path.pop(0)
     table = kernel_resources()
     assert len(table) > 300
-    loops = {k: v for k, v in table.items() if "gru_cluster_" in k}
-    assert len(loops) == 4                                   # forward / backward x one / two row tiles
-    capped = {k: v for k, v in table.items() if re.match(r"_Z10gemm_tiledILi4ELi2ELi1ELi2ELb[01]ELb[01]ELb[01]ELi16ELb0ELi1ELi1EE", k)}
+    loops = {k: v for k, v in table.items() if "gru_cluster_" in k or "nematus_cluster_" in k}
+    assert len(loops) == 8                                   # TF GRU / NematusGRU x forward / backward x one / two row tiles
+    capped = {k: v for k, v in table.items()
+              if re.match(r"_Z10gemm_tiledILi4ELi2ELi1ELi2ELb[01]ELb[01]ELb[01]ELi16ELb0ELi1ELi1ELb0EE", k)}
     assert len(capped) == 8
     for v in list(loops.values()) + list(capped.values()):
         assert v["max_threads"] == 512 and v["scratch"] == 0

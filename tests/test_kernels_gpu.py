@@ -838,3 +838,42 @@ def test_colsum_both_kernels(dev, rows, cols, ld):
     acc = base.clone()
     ops.colsum(xd, acc, accumulate=True)
     assert torch.equal(acc, base + out)
+
+
+@pytest.mark.parametrize("rows,count,m,n,ld_extra", [
+    (128, 50, 512, 1536, 0),      # a NematusGRU gates kernel of the general-path model: 50 steps of 128 sentences
+    (128, 50, 512, 512, 0),
+    (16, 3, 8, 12, 4),            # small, padded rows
+    (48, 7, 132, 68, 0),          # ragged tiles
+    (640, 12, 512, 512, 0),       # beam-sized members
+    (32, 1, 64, 64, 0),           # a chain of one
+])
+def test_chained_weight_and_bias_gradients(dev, rows, count, m, n, ld_extra):
+    """nm_gemm_f32_chain / nm_colsum_chain: sum_i a_i^T b_i and the column sums of the b_i over members that live in
+    separate buffers, against float64; ``accumulate`` adds to what is there; deterministic from launch to launch."""
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(rows + count + m)
+    a_np = [rng.standard_normal((rows, m + ld_extra)).astype(np.float32) for _ in range(count)]
+    b_np = [rng.standard_normal((rows, n + ld_extra)).astype(np.float32) for _ in range(count)]
+    a_d = [T(a, dev)[:, :m] for a in a_np]
+    b_d = [T(b, dev)[:, :n] for b in b_np]
+    want = sum(a[:, :m].astype(np.float64).T @ b[:, :n].astype(np.float64) for a, b in zip(a_np, b_np))
+    base = rng.standard_normal((m, n)).astype(np.float32)
+    out = T(base, dev)
+    ops.gemm_chain(list(zip(a_d, b_d)), out, accumulate=True)
+    tol = 3e-6 * np.sqrt(rows * count) * 4.0
+    assert np.abs(out.cpu().numpy() - (want + base)).max() <= tol * max(1.0, np.abs(want).max() / np.sqrt(rows * count))
+    again = T(base, dev)
+    ops.gemm_chain(list(zip(a_d, b_d)), again, accumulate=True)
+    assert torch.equal(out, again)
+    fresh = torch.full((m, n), float("nan"), device=dev)
+    ops.gemm_chain(list(zip(a_d, b_d)), fresh, accumulate=False)
+    assert np.abs(fresh.cpu().numpy() - want).max() <= tol * max(1.0, np.abs(want).max() / np.sqrt(rows * count))
+    # the bias gradient of the same chain
+    want_b = sum(b[:, :n].astype(np.float64).sum(0) for b in b_np)
+    bias = T(base[0].copy(), dev)
+    ops.colsum_chain(b_d, bias, accumulate=True)
+    assert np.abs(bias.cpu().numpy() - (want_b + base[0])).max() <= 2e-6 * np.sqrt(rows * count) * 4.0
+    bias2 = torch.full((n,), float("nan"), device=dev)
+    ops.colsum_chain(b_d, bias2, accumulate=False)
+    assert np.abs(bias2.cpu().numpy() - want_b).max() <= 2e-6 * np.sqrt(rows * count) * 4.0
