@@ -499,6 +499,18 @@ int nm_lstm_cell_bwd(void* stream, const float* dh, int64_t lddh, const float* d
                      const float* gates, int64_t ldg, const float* c_prev, int64_t ldc, const float* c_new,
                      int64_t ldcn, float* dz, int64_t lddz, float* dc_prev, int64_t lddcp, int64_t rows, int64_t H,
                      int accumulate_dz, int accumulate_dc_prev);
+/* The point-wise part of one NematusGRUCell step (nn/ortho_gru_cell.py:73-105) after its four products:
+ * [r | u] = sigmoid(g_pre), c = tanh(ci + sc * r), h' = u h + (1 - u) c; g_pre [rows, 2H] = input + state gate
+ * projections, sc / ci = state / input candidate projections.  ru [rows, 2H] and c_out [rows, H] (contiguous, may be
+ * null) keep what the backward call reads.  bwd: dg = [dr' | du'], dci, dsc, dh_prev (each written or added to per its
+ * flag; dci / dsc / dh_prev may be null). */
+int nm_nematus_cell_fwd(void* stream, const float* g_pre, int64_t ldg, const float* sc, int64_t ldsc, const float* ci,
+                        int64_t ldci, const float* h_prev, int64_t ldh, float* h_new, int64_t ldhn, float* ru,
+                        float* c_out, int64_t rows, int64_t H);
+int nm_nematus_cell_bwd(void* stream, const float* dh, int64_t lddh, const float* ru, const float* c, const float* sc,
+                        int64_t ldsc, const float* h_prev, int64_t ldh, float* dg, int64_t lddg, float* dci,
+                        int64_t lddci, float* dsc, int64_t lddsc, float* dh_prev, int64_t lddhp, int64_t rows, int64_t H,
+                        int accumulate_dg, int accumulate_dci, int accumulate_dsc, int accumulate_dh_prev);
 /* nn/utils.py:6-22 (tf.nn.dropout): keep iff floor(keep_prob + u_i) == 1, scale 1/keep_prob;
  * u_i = hash(salt, i) (counter based: the backward pass and the CPU oracle regenerate the mask) */
 int nm_dropout(void* stream, const float* x, int64_t ldx, float* out, int64_t ldo, int64_t rows,

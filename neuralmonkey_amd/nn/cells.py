@@ -9,12 +9,16 @@ in scripts/import_nematus.py:88-130) and evaluates one step as MFMA GEMMs plus
 the element-wise kernels of ``autodiff``.  The plain-GRU fast path
 (``nn/gru.py``: fused GEMM epilogues, HIP-graph loops) uses the same variables.
 """
+import os
 from typing import Tuple
 
 from .. import autodiff as F
 from ..variables import constant_initializer, orthogonal_initializer, zeros_initializer
 
 RNN_CELL_TYPES = ("NematusGRU", "GRU", "LSTM")
+# gates, candidate and blend of a NematusGRUCell step in one launch each way (autodiff.nematus_cell); 0: one launch per
+# element-wise operation as in rounds 2-5
+FUSED_NEMATUS_CELL = os.environ.get("NM_NEMATUS_CELL_FUSED", "1") != "0"
 
 
 class Cell:
@@ -104,9 +108,13 @@ class NematusGRUCell(Cell):
         h = self.num_units
         g_pre = self._proj(tape, "gates", "state", h_prev, self.use_state_bias)
         self._proj(tape, "gates", "input", x, self.use_input_bias, out=g_pre, accumulate=True)
+        sc = self._proj(tape, "candidate", "state", h_prev, self.use_state_bias)
+        if FUSED_NEMATUS_CELL and g_pre.data.is_cuda:
+            ci = self._proj(tape, "candidate", "input", x, self.use_input_bias)
+            h_new = F.nematus_cell(tape, g_pre, sc, ci, h_prev)           # gates, candidate and blend: one launch
+            return h_new, (h_new,)
         g = F.sigmoid(tape, g_pre)
         r, u = tape.cols(g, 0, h), tape.cols(g, h, 2 * h)
-        sc = self._proj(tape, "candidate", "state", h_prev, self.use_state_bias)
         c_pre = F.mul(tape, sc, r)
         self._proj(tape, "candidate", "input", x, self.use_input_bias, out=c_pre, accumulate=True)
         c = F.tanh(tape, c_pre)
