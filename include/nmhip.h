@@ -468,6 +468,10 @@ int nm_tanh_bwd(void* stream, float* dy, const float* y, int64_t n);
 int64_t nm_colsum_workspace_bytes(int64_t cols);
 int nm_colsum(void* stream, const float* x, int64_t ldx, int64_t rows, int64_t cols, float* out,
               int accumulate, void* workspace, int64_t workspace_bytes);
+/* The same with the kernel named: algo 0 = nm_colsum's choice, 1 = the low-pressure kernel (one float per thread and
+ * row) for launches that share the chip with a cluster time loop of another stream. */
+int nm_colsum_algo(void* stream, const float* x, int64_t ldx, int64_t rows, int64_t cols, float* out, int accumulate,
+                   void* workspace, int64_t workspace_bytes, int algo);
 
 /* ---- strided element-wise primitives of the general (taped) path -----------------------------
  * Cells other than the fused TF GRU (NematusGRUCell nn/ortho_gru_cell.py:57-105, LSTMCell

@@ -81,6 +81,7 @@ SIGNATURES = {
     "nm_tanh_bwd": (I, [P, P, P, L]),
     "nm_colsum_workspace_bytes": (L, [L]),
     "nm_colsum": (I, [P, P, L, L, L, P, I, P, L]),
+    "nm_colsum_algo": (I, [P, P, L, L, L, P, I, P, L, I]),
     "nm_embedding_scatter_add": (I, [P, P, L, L, P, L, P, L, I]),
     "nm_layer_norm_bwd": (I, [P, P, P, P, P, P, P, P, L, L]),
     "nm_layer_norm_bwd_params_workspace_bytes": (L, [L]),

@@ -251,9 +251,21 @@ extern "C" int64_t nm_colsum_workspace_bytes(int64_t cols) {
     return (cols * COLSUM_MAX_SPLIT + ((cols + 63) / 64 + 3) / 4 * 4) * 4;
 }
 
+extern "C" int nm_colsum_algo(void* stream, const float* x, int64_t ldx, int64_t rows, int64_t cols, float* out,
+                              int accumulate, void* workspace, int64_t workspace_bytes, int algo);
+
 extern "C" int nm_colsum(void* stream, const float* x, int64_t ldx, int64_t rows, int64_t cols, float* out,
                          int accumulate, void* workspace, int64_t workspace_bytes) {
-    NM_REQUIRE(x && out && workspace && rows >= 0 && cols > 0, "nm_colsum: bad args");
+    return nm_colsum_algo(stream, x, ldx, rows, cols, out, accumulate, workspace, workspace_bytes, 0);
+}
+
+// algo 0: the float4 kernel when the operand allows it; 1: the one-float-per-thread kernel whatever the operand -- for
+// launches that run on a side stream BESIDE a cluster time loop: the float4 kernel's 768 workgroups with four 16-byte
+// loads in flight each took the headline training step from 10.59 to 10.73 ms although they are 35 % shorter
+// themselves (profiles/r06_colsum_beside_loops.txt: the BPTT loops next to them slow down).
+extern "C" int nm_colsum_algo(void* stream, const float* x, int64_t ldx, int64_t rows, int64_t cols, float* out,
+                              int accumulate, void* workspace, int64_t workspace_bytes, int algo) {
+    NM_REQUIRE(x && out && workspace && rows >= 0 && cols > 0 && algo >= 0 && algo <= 1, "nm_colsum: bad args");
     NM_REQUIRE(workspace_bytes >= nm_colsum_workspace_bytes(cols), "nm_colsum: workspace too small");
     hipStream_t st = nm_stream(stream);
     float* part = reinterpret_cast<float*>(workspace);
@@ -265,7 +277,7 @@ extern "C" int nm_colsum(void* stream, const float* x, int64_t ldx, int64_t rows
     if (nsplit > 48) nsplit = 48;
     if (nsplit < 1) nsplit = 1;
     static const bool vec_on = !(getenv("NM_COLSUM_VEC") && atoi(getenv("NM_COLSUM_VEC")) == 0);
-    if (vec_on && nm_aligned16(x) && ldx % 4 == 0 && cols % 4 == 0 && rows >= 64) {
+    if (vec_on && algo == 0 && nm_aligned16(x) && ldx % 4 == 0 && cols % 4 == 0 && rows >= 64) {
         // slices of at least 64 rows (a thread's four loads in flight), enough of them for ~768 workgroups
         int ns = (int)((768 * 64 + cols - 1) / cols);
         if (ns > (int)(rows / 64)) ns = (int)(rows / 64);

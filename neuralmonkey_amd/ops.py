@@ -601,8 +601,10 @@ def colsum(x, out, accumulate=False):
     assert x.dim() == 2 and x.stride(1) == 1
     cols = x.shape[1]
     ws = _colsum_workspace(x.device, cols)
-    _lib.check(lib.nm_colsum(_stream(), x.data_ptr(), x.stride(0), x.shape[0], cols, out.data_ptr(),
-                             int(accumulate), ws.data_ptr(), ws.numel() * 4), "nm_colsum")
+    # (on a side stream -- runtime.Session.side -- the launch runs beside a time loop: the low-pressure kernel)
+    _lib.check(lib.nm_colsum_algo(_stream(), x.data_ptr(), x.stride(0), x.shape[0], cols, out.data_ptr(),
+                                  int(accumulate), ws.data_ptr(), ws.numel() * 4,
+                                  1 if getattr(_TLS, "on_side", False) else 0), "nm_colsum")
     return out
 
 

@@ -662,8 +662,14 @@ class Session:
                 done = torch.cuda.Event()
                 done.record(self._side_streams[other])
                 stream.wait_event(done)
-        with torch.cuda.stream(stream):
-            yield
+        from . import ops
+        was = getattr(ops._TLS, "on_side", False)         # pylint: disable=protected-access
+        ops._TLS.on_side = True                           # (ops.colsum: the kernel that leaves the time loops alone)
+        try:
+            with torch.cuda.stream(stream):
+                yield
+        finally:
+            ops._TLS.on_side = was
         self._side_dirty.add(lane)
 
     def defer_side(self, fn) -> None:
