@@ -507,14 +507,17 @@ int nm_lstm_cell_bwd(void* stream, const float* dh, int64_t lddh, const float* d
  * [r | u] = sigmoid(g_pre), c = tanh(ci + sc * r), h' = u h + (1 - u) c; g_pre [rows, 2H] = input + state gate
  * projections, sc / ci = state / input candidate projections.  ru [rows, 2H] and c_out [rows, H] (contiguous, may be
  * null) keep what the backward call reads.  bwd: dg = [dr' | du'], dci, dsc, dh_prev (each written or added to per its
- * flag; dci / dsc / dh_prev may be null). */
+ * flag; dci / dsc / dh_prev may be null).  g2 (may be null): a second gate operand added to g_pre before the sigmoid
+ * -- the input half when the state and input projections of the step are two products [gates | candidate] instead of
+ * four; dg2 (may be null): a second destination that receives dg as well (the gradient of that other product). */
 int nm_nematus_cell_fwd(void* stream, const float* g_pre, int64_t ldg, const float* sc, int64_t ldsc, const float* ci,
                         int64_t ldci, const float* h_prev, int64_t ldh, float* h_new, int64_t ldhn, float* ru,
-                        float* c_out, int64_t rows, int64_t H);
+                        float* c_out, const float* g2, int64_t ldg2, int64_t rows, int64_t H);
 int nm_nematus_cell_bwd(void* stream, const float* dh, int64_t lddh, const float* ru, const float* c, const float* sc,
                         int64_t ldsc, const float* h_prev, int64_t ldh, float* dg, int64_t lddg, float* dci,
-                        int64_t lddci, float* dsc, int64_t lddsc, float* dh_prev, int64_t lddhp, int64_t rows, int64_t H,
-                        int accumulate_dg, int accumulate_dci, int accumulate_dsc, int accumulate_dh_prev);
+                        int64_t lddci, float* dsc, int64_t lddsc, float* dh_prev, int64_t lddhp, float* dg2, int64_t lddg2,
+                        int64_t rows, int64_t H, int accumulate_dg, int accumulate_dci, int accumulate_dsc,
+                        int accumulate_dh_prev);
 /* nn/utils.py:6-22 (tf.nn.dropout): keep iff floor(keep_prob + u_i) == 1, scale 1/keep_prob;
  * u_i = hash(salt, i) (counter based: the backward pass and the CPU oracle regenerate the mask) */
 int nm_dropout(void* stream, const float* x, int64_t ldx, float* out, int64_t ldo, int64_t rows,

@@ -305,13 +305,15 @@ extern "C" int nm_lstm_cell_bwd(void* stream, const float* dh, int64_t lddh, con
 __global__ void nematus_cell_fwd_kernel(const float* __restrict__ g_pre, long ldg, const float* __restrict__ sc, long ldsc,
                                         const float* __restrict__ ci, long ldci, const float* __restrict__ h_prev, long ldh,
                                         float* __restrict__ h_new, long ldhn, float* __restrict__ ru, float* __restrict__ c_out,
-                                        long rows, int H) {
+                                        const float* __restrict__ g2, long ldg2, long rows, int H) {
     const long total = rows * H;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const long r_ = idx / H;
         const int k = (int)(idx - r_ * H);
-        const float r = nm_sigmoid(g_pre[r_ * ldg + k]);
-        const float u = nm_sigmoid(g_pre[r_ * ldg + H + k]);
+        float pr = g_pre[r_ * ldg + k], pu = g_pre[r_ * ldg + H + k];
+        if (g2) { pr += g2[r_ * ldg2 + k]; pu += g2[r_ * ldg2 + H + k]; }      // state half + input half of the gates
+        const float r = nm_sigmoid(pr);
+        const float u = nm_sigmoid(pu);
         const float c = nm_tanh(sc[r_ * ldsc + k] * r + ci[r_ * ldci + k]);
         h_new[r_ * ldhn + k] = u * h_prev[r_ * ldh + k] + (1.0f - u) * c;
         if (ru) { ru[r_ * 2 * H + k] = r; ru[r_ * 2 * H + H + k] = u; }
@@ -324,8 +326,8 @@ __global__ void nematus_cell_bwd_kernel(const float* __restrict__ dh, long lddh,
                                         const float* __restrict__ c, const float* __restrict__ sc, long ldsc,
                                         const float* __restrict__ h_prev, long ldh, float* __restrict__ dg, long lddg,
                                         float* __restrict__ dci, long lddci, float* __restrict__ dsc, long lddsc,
-                                        float* __restrict__ dhp, long lddhp, long rows, int H, int acc_dg, int acc_dci,
-                                        int acc_dsc, int acc_dhp) {
+                                        float* __restrict__ dhp, long lddhp, float* __restrict__ dg2, long lddg2, long rows,
+                                        int H, int acc_dg, int acc_dci, int acc_dsc, int acc_dhp) {
     const long total = rows * H;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const long r_ = idx / H;
@@ -338,6 +340,7 @@ __global__ void nematus_cell_bwd_kernel(const float* __restrict__ dh, long lddh,
         const float drp = dcp * s * r * (1.0f - r);
         float* g = dg + r_ * lddg;
         if (acc_dg) { g[k] += drp; g[H + k] += dup; } else { g[k] = drp; g[H + k] = dup; }
+        if (dg2) { dg2[r_ * lddg2 + k] = drp; dg2[r_ * lddg2 + H + k] = dup; }       // the same gradient for the second product
         if (dci) { float* p = dci + r_ * lddci + k; *p = acc_dci ? *p + dcp : dcp; }
         if (dsc) { float* p = dsc + r_ * lddsc + k; *p = acc_dsc ? *p + dcp * r : dcp * r; }
         if (dhp) { float* p = dhp + r_ * lddhp + k; *p = acc_dhp ? *p + d * u : d * u; }
@@ -346,29 +349,32 @@ __global__ void nematus_cell_bwd_kernel(const float* __restrict__ dh, long lddh,
 
 extern "C" int nm_nematus_cell_fwd(void* stream, const float* g_pre, int64_t ldg, const float* sc, int64_t ldsc,
                                    const float* ci, int64_t ldci, const float* h_prev, int64_t ldh, float* h_new,
-                                   int64_t ldhn, float* ru, float* c_out, int64_t rows, int64_t H) {
+                                   int64_t ldhn, float* ru, float* c_out, const float* g2, int64_t ldg2, int64_t rows,
+                                   int64_t H) {
     NM_REQUIRE(g_pre && sc && ci && h_prev && h_new, "nm_nematus_cell_fwd: null pointer");
-    NM_REQUIRE(rows >= 0 && H > 0 && ldg >= 2 * H && ldsc >= H && ldci >= H && ldh >= H && ldhn >= H,
+    NM_REQUIRE(rows >= 0 && H > 0 && ldg >= 2 * H && ldsc >= H && ldci >= H && ldh >= H && ldhn >= H && (!g2 || ldg2 >= 2 * H),
                "nm_nematus_cell_fwd: bad shape rows=%ld H=%ld", (long)rows, (long)H);
     if (rows == 0) return NM_OK;
     hipLaunchKernelGGL(nematus_cell_fwd_kernel, dim3(ew_blocks(rows * H)), dim3(256), 0, nm_stream(stream), g_pre, (long)ldg,
-                       sc, (long)ldsc, ci, (long)ldci, h_prev, (long)ldh, h_new, (long)ldhn, ru, c_out, (long)rows, (int)H);
+                       sc, (long)ldsc, ci, (long)ldci, h_prev, (long)ldh, h_new, (long)ldhn, ru, c_out, g2, (long)ldg2,
+                       (long)rows, (int)H);
     NM_LAUNCH_CHECK("nm_nematus_cell_fwd");
 }
 
 extern "C" int nm_nematus_cell_bwd(void* stream, const float* dh, int64_t lddh, const float* ru, const float* c,
                                    const float* sc, int64_t ldsc, const float* h_prev, int64_t ldh, float* dg,
                                    int64_t lddg, float* dci, int64_t lddci, float* dsc, int64_t lddsc, float* dh_prev,
-                                   int64_t lddhp, int64_t rows, int64_t H, int accumulate_dg, int accumulate_dci,
-                                   int accumulate_dsc, int accumulate_dh_prev) {
+                                   int64_t lddhp, float* dg2, int64_t lddg2, int64_t rows, int64_t H, int accumulate_dg,
+                                   int accumulate_dci, int accumulate_dsc, int accumulate_dh_prev) {
     NM_REQUIRE(dh && ru && c && sc && h_prev && dg, "nm_nematus_cell_bwd: null pointer");
     NM_REQUIRE(rows >= 0 && H > 0 && lddh >= H && ldsc >= H && ldh >= H && lddg >= 2 * H && (!dci || lddci >= H) &&
-                   (!dsc || lddsc >= H) && (!dh_prev || lddhp >= H), "nm_nematus_cell_bwd: bad shape rows=%ld H=%ld",
-               (long)rows, (long)H);
+                   (!dsc || lddsc >= H) && (!dh_prev || lddhp >= H) && (!dg2 || lddg2 >= 2 * H),
+               "nm_nematus_cell_bwd: bad shape rows=%ld H=%ld", (long)rows, (long)H);
     if (rows == 0) return NM_OK;
     hipLaunchKernelGGL(nematus_cell_bwd_kernel, dim3(ew_blocks(rows * H)), dim3(256), 0, nm_stream(stream), dh, (long)lddh,
                        ru, c, sc, (long)ldsc, h_prev, (long)ldh, dg, (long)lddg, dci, (long)lddci, dsc, (long)lddsc, dh_prev,
-                       (long)lddhp, (long)rows, (int)H, accumulate_dg, accumulate_dci, accumulate_dsc, accumulate_dh_prev);
+                       (long)lddhp, dg2, (long)lddg2, (long)rows, (int)H, accumulate_dg, accumulate_dci, accumulate_dsc,
+                       accumulate_dh_prev);
     NM_LAUNCH_CHECK("nm_nematus_cell_bwd");
 }
 

@@ -19,6 +19,8 @@ RNN_CELL_TYPES = ("NematusGRU", "GRU", "LSTM")
 # gates, candidate and blend of a NematusGRUCell step in one launch each way (autodiff.nematus_cell); 0: one launch per
 # element-wise operation as in rounds 2-5
 FUSED_NEMATUS_CELL = os.environ.get("NM_NEMATUS_CELL_FUSED", "1") != "0"
+# ... and its four products as two against column-concatenated copies of the kernels (autodiff.nematus_cell_merged)
+MERGED_NEMATUS_CELL = os.environ.get("NM_NEMATUS_CELL_MERGED", "1") != "0"
 
 
 class Cell:
@@ -98,6 +100,43 @@ class NematusGRUCell(Cell):
         self.part.declare_checkpoint_only(store, self._n("candidate/kernel"), (d + h, h))
         self.part.declare_checkpoint_only(store, self._n("candidate/bias"), (h,), zeros_initializer())
 
+    def _merged(self, tape):
+        """[W_g | W_c] and [U_g | U_c] (and their biases) as column-concatenated copies, refreshed once per run context
+        (the variables change with every optimizer step; a decoding batch keeps its context)."""
+        ctx = tape.ctx
+        key = (id(self), "merged_kernels", bool(tape.recording))
+        hit = ctx.memo.get(key)
+        if hit is not None:
+            return hit
+        from .. import ops
+        d, h = self.input_size, self.num_units
+
+        def var(block, which, kind):
+            return tape.param(self.part, self._n("{}/{}_proj/{}".format(block, which, kind)))
+        params = {"gi": (var("gates", "input", "kernel"), var("gates", "input", "bias") if self.use_input_bias else None),
+                  "ci": (var("candidate", "input", "kernel"),
+                         var("candidate", "input", "bias") if self.use_input_bias else None),
+                  "gs": (var("gates", "state", "kernel"), var("gates", "state", "bias") if self.use_state_bias else None),
+                  "cs": (var("candidate", "state", "kernel"),
+                         var("candidate", "state", "bias") if self.use_state_bias else None)}
+        w_in = ctx.buffer((id(self), "w_in_cat"), (d, 3 * h))
+        w_st = ctx.buffer((id(self), "w_st_cat"), (h, 3 * h))
+        ops.copy_cols(params["gi"][0].data, w_in[:, :2 * h])
+        ops.copy_cols(params["ci"][0].data, w_in[:, 2 * h:])
+        ops.copy_cols(params["gs"][0].data, w_st[:, :2 * h])
+        ops.copy_cols(params["cs"][0].data, w_st[:, 2 * h:])
+        b_in = b_st = None
+        if self.use_input_bias:
+            b_in = ctx.buffer((id(self), "b_in_cat"), (3 * h,))
+            ops.copy_cols(params["gi"][1].data.view(1, -1), b_in[:2 * h].view(1, -1))
+            ops.copy_cols(params["ci"][1].data.view(1, -1), b_in[2 * h:].view(1, -1))
+        if self.use_state_bias:
+            b_st = ctx.buffer((id(self), "b_st_cat"), (3 * h,))
+            ops.copy_cols(params["gs"][1].data.view(1, -1), b_st[:2 * h].view(1, -1))
+            ops.copy_cols(params["cs"][1].data.view(1, -1), b_st[2 * h:].view(1, -1))
+        hit = ctx.memo[key] = (w_in, b_in, w_st, b_st, params)
+        return hit
+
     def _proj(self, tape, block, which, inp, use_bias, out=None, accumulate=False):
         w = tape.param(self.part, self._n("{}/{}_proj/kernel".format(block, which)))
         b = tape.param(self.part, self._n("{}/{}_proj/bias".format(block, which))) if use_bias else None
@@ -106,6 +145,10 @@ class NematusGRUCell(Cell):
     def step(self, tape, x, state):
         (h_prev,) = state
         h = self.num_units
+        if MERGED_NEMATUS_CELL and FUSED_NEMATUS_CELL and x.data.is_cuda and h % 4 == 0 and self.input_size % 4 == 0:
+            w_in, b_in, w_st, b_st, params = self._merged(tape)
+            h_new = F.nematus_cell_merged(tape, x, h_prev, w_in, b_in, w_st, b_st, params)
+            return h_new, (h_new,)
         g_pre = self._proj(tape, "gates", "state", h_prev, self.use_state_bias)
         self._proj(tape, "gates", "input", x, self.use_input_bias, out=g_pre, accumulate=True)
         sc = self._proj(tape, "candidate", "state", h_prev, self.use_state_bias)

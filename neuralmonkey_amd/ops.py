@@ -787,25 +787,25 @@ def lstm_cell_bwd(dh, dc_new, gates, c_prev, c_new, dz, dc_prev, accumulate_dz=F
                                     int(accumulate_dz), int(accumulate_dc_prev)), "nm_lstm_cell_bwd")
 
 
-def nematus_cell_fwd(g_pre, sc, ci, h_prev, h_new, ru=None, c_out=None):
+def nematus_cell_fwd(g_pre, sc, ci, h_prev, h_new, ru=None, c_out=None, g2=None):
     """h' of one NematusGRUCell step from its products (nm_nematus_cell_fwd); ``ru`` [R,2H] / ``c_out`` [R,H]: contiguous
-    buffers for the backward call."""
+    buffers for the backward call; ``g2``: a second gate operand added to ``g_pre``."""
     rows, h = h_prev.shape
     assert g_pre.shape == (rows, 2 * h) and (ru is None or ru.is_contiguous()) and (c_out is None or c_out.is_contiguous())
     _lib.check(_lib.load().nm_nematus_cell_fwd(_stream(), g_pre.data_ptr(), _rc(g_pre)[2], sc.data_ptr(), _rc(sc)[2],
                                                ci.data_ptr(), _rc(ci)[2], h_prev.data_ptr(), _rc(h_prev)[2],
-                                               h_new.data_ptr(), _rc(h_new)[2], _p(ru), _p(c_out), rows, h),
-               "nm_nematus_cell_fwd")
+                                               h_new.data_ptr(), _rc(h_new)[2], _p(ru), _p(c_out), _p(g2),
+                                               0 if g2 is None else _rc(g2)[2], rows, h), "nm_nematus_cell_fwd")
     return h_new
 
 
 def nematus_cell_bwd(dh, ru, c, sc, h_prev, dg, dci, dsc, dh_prev, acc_dg=False, acc_dci=False, acc_dsc=False,
-                     acc_dh_prev=False):
+                     acc_dh_prev=False, dg2=None):
     rows, h = h_prev.shape
     ld = lambda t: 0 if t is None else _rc(t)[2]
     _lib.check(_lib.load().nm_nematus_cell_bwd(_stream(), dh.data_ptr(), ld(dh), ru.data_ptr(), c.data_ptr(), sc.data_ptr(),
                                                ld(sc), h_prev.data_ptr(), ld(h_prev), dg.data_ptr(), ld(dg), _p(dci), ld(dci),
-                                               _p(dsc), ld(dsc), _p(dh_prev), ld(dh_prev), rows, h, int(acc_dg),
+                                               _p(dsc), ld(dsc), _p(dh_prev), ld(dh_prev), _p(dg2), ld(dg2), rows, h, int(acc_dg),
                                                int(acc_dci), int(acc_dsc), int(acc_dh_prev)), "nm_nematus_cell_bwd")
 
 
