@@ -36,6 +36,8 @@ GROUP_WGRADS = os.environ.get("NM_WGRAD_GROUPS", "1") != "0"
 CHAIN_WGRADS = os.environ.get("NM_WGRAD_CHAINS", "1") != "0"
 # zeroed tape buffers as slices of a few chunks cleared by one fill each (_ZeroArena)
 ZERO_ARENA = os.environ.get("NM_TAPE_ZERO_ARENA", "1") != "0"
+# the gradient buffer of a sum handed to one of its operands instead of copied (autodiff.add)
+ALIAS_ADD_GRADS = os.environ.get("NM_ADD_GRAD_ALIAS", "1") != "0"
 
 
 class Var:
@@ -275,7 +277,8 @@ def linear(tape: Tape, x: Var, w: Var, b: Optional[Var] = None, out: Optional[Va
     if out is None:
         assert not accumulate
         out = tape.new((x.shape[0], n))
-    assert act is None or not tape.recording, "fused activations have no backward closure"
+    assert act in (None, "relu") or not tape.recording, "of the fused activations only relu has a backward closure"
+    assert act is None or not accumulate
     ops.gemm(x.data, w.data, out=out.data, bias=None if b is None else b.data, accumulate=accumulate,
              trans_b=trans_b, act=act)
 
@@ -283,6 +286,8 @@ def linear(tape: Tape, x: Var, w: Var, b: Optional[Var] = None, out: Optional[Va
         dy = out.grad
         if dy is None:
             return
+        if act == "relu":       # relu in the product's epilogue: its gradient from the OUTPUT, in place (dy is dead after)
+            ops.ew("relu_bwd", out.data, dy, dy)
         if x.needs_grad:
             gx, acc = tape.grad_slot(x)
             ops.gemm(dy, w.data, out=gx, trans_b=not trans_b, accumulate=acc)
@@ -469,8 +474,15 @@ def add(tape: Tape, a: Var, b: Var) -> Var:
     def bwd():
         if out.grad is None:
             return
+        # the sum's own gradient buffer is dead once this closure has run: the first operand that has no gradient
+        # buffer yet simply takes it over (whatever else flows into that operand is added to it in place), the other
+        # gets a copy -- one launch per residual connection instead of two
+        handed = a is b or not ALIAS_ADD_GRADS
         for v in (a, b):
             if v.needs_grad:
+                if not handed and v.grad is None and out.grad.is_contiguous():
+                    v.grad, v.fresh, handed = out.grad, False, True
+                    continue
                 gv, acc = tape.grad_slot(v)
                 ops.ew("copy", out.grad, None, gv, accumulate=acc)
     tape.record(bwd)

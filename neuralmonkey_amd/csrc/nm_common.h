@@ -56,6 +56,8 @@ struct NmSwitches {
     int gemm_sk;           // NM_GEMM_SK        split-K override (0 = makespan model)
     int gemm_cfg;          // NM_GEMM_CFG       tile configuration of the large GEMMs (1)
     int gemm_chains;       // NM_GEMM_CHAINS    interleaved accumulation chains of the 64x64 tiles: 1, 2 or 4 (1)
+    int gemm_cfg64;        // NM_GEMM_CFG64     tile of the products too small for 512 tiles of 128x128: 0 = 64x64 (4 waves),
+                           //                   1 = 128x64, 2 = 64x128, 3 = 128x128 with 4 waves (tools/gemm_mid_sweep.py)
     int gemm_bg_wgs;       // NM_GEMM_BG_WGS    workgroups per CU of a background GEMM (algo 4): 1..3, 0 = uncapped (1)
     int gemm_bg_cfg;       // NM_GEMM_BG_CFG    tile of a background GEMM: 1 = 128x128, 2 = 256x128 (1)
     int background;        // (nm_ctx_set_background, not an environment switch) launches run beside a foreground loop

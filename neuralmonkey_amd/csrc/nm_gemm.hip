@@ -1038,6 +1038,12 @@ extern "C" int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int6
             else if (cfg_env == 8) launch_tiled<2, 2, 2, 2, 16, 2>(g, (int)batch, ta, tb, vec, st); // 128x128, 4 waves, 2 ahead
             else if (cfg_env == 9) launch_tiled<4, 2, 1, 2, 32, 2>(g, (int)batch, ta, tb, vec, st); // cfg 4, 2 ahead
             else launch_tiled<2, 2, 2, 2, 16>(g, (int)batch, ta, tb, vec, st);                     // 128x128, 4 waves
+        } else if (sw.gemm_cfg64 == 1 && bg_lds == 0 && g.splitk == 1) {
+            launch_tiled<2, 1, 2, 2, 16>(g, (int)batch, ta, tb, vec, st);                          // 128x64, 4 waves of 64x64
+        } else if (sw.gemm_cfg64 == 2 && bg_lds == 0 && g.splitk == 1) {
+            launch_tiled<1, 2, 2, 2, 16>(g, (int)batch, ta, tb, vec, st);                          // 64x128, 4 waves of 64x64
+        } else if (sw.gemm_cfg64 == 3 && bg_lds == 0 && g.splitk == 1) {
+            launch_tiled<2, 2, 2, 2, 16>(g, (int)batch, ta, tb, vec, st);                          // 128x128, 4 waves
         } else if (sw.gemm_chains == 4) {
             launch_tiled<2, 2, 1, 1, 16, 1, 4>(g, (int)batch, ta, tb, vec, st);                    // 64x64, 4 chains
         } else if (sw.gemm_chains == 2) {

@@ -30,6 +30,7 @@ static void switches_from_env(NmSwitches* sw) {
     sw->gemm_sk = env_int("NM_GEMM_SK", 0);
     sw->gemm_cfg = env_int("NM_GEMM_CFG", 1);
     sw->gemm_chains = env_int("NM_GEMM_CHAINS", 1);
+    sw->gemm_cfg64 = env_int("NM_GEMM_CFG64", 0);
     sw->gemm_bg_wgs = env_int("NM_GEMM_BG_WGS", 1);
     sw->gemm_bg_cfg = env_int("NM_GEMM_BG_CFG", 1);
     sw->background = 0;
@@ -151,7 +152,7 @@ extern "C" int nm_ctx_switch(void* ctx, const char* name, int* value) {
         {"attn_maxrows", s.attn_maxrows}, {"attn_nomerge", s.attn_nomerge}, {"attn_nofast", s.attn_nofast},
         {"attn_whole", s.attn_whole}, {"aeb_wide_off", s.aeb_wide_off}, {"gemm_no16", s.gemm_no16},
         {"gemm_swz", s.gemm_swz}, {"gemm_nostore", s.gemm_nostore}, {"gemm_sk", s.gemm_sk},
-        {"gemm_cfg", s.gemm_cfg}, {"gemm_chains", s.gemm_chains}, {"gemm_bg_wgs", s.gemm_bg_wgs}, {"step_prio", s.step_prio},
+        {"gemm_cfg", s.gemm_cfg}, {"gemm_chains", s.gemm_chains}, {"gemm_cfg64", s.gemm_cfg64}, {"gemm_bg_wgs", s.gemm_bg_wgs}, {"step_prio", s.step_prio},
         {"stats_cfg", s.stats_cfg}, {"stats_ablate", s.stats_ablate},
         {"beam_ns", s.beam_ns}, {"sdp_mfma", s.sdp_mfma}, {"medium_m", s.medium_m},
         {"sdp_decode", s.sdp_decode}};

@@ -6,6 +6,7 @@ Every dense layer is an MFMA GEMM over all B*T rows; the attention core is the f
 ``nm_sdp_attn_fwd`` kernel.  Variable names follow the TF scopes of the reference
 (``layer_<i>/self_attention/query_proj/kernel`` ...), so TF checkpoints map one to one."""
 import math
+import os
 from typing import Optional
 
 import numpy as np
@@ -13,6 +14,9 @@ import torch
 
 from .. import autodiff as F
 from ..variables import ones_initializer, zeros_initializer
+
+
+FF_RELU_FUSED = os.environ.get("NM_FF_RELU_FUSED", "1") != "0"
 
 
 def position_signal(dimension: int, length: int) -> np.ndarray:
@@ -109,8 +113,12 @@ def feedforward_sublayer(tape: F.Tape, part, scope: str, x: F.Var, keep: float, 
     dropout on the hidden activations and on the output, residual."""
     ctx = tape.ctx
     normed = layer_norm(tape, part, scope, x)
-    hidden = F.relu(tape, F.linear(tape, normed, tape.param(part, scope + "/hidden_state/kernel"),
-                                   tape.param(part, scope + "/hidden_state/bias")))
+    # (the ReLU runs in the product's epilogue; NM_FF_RELU_FUSED=0: a launch of its own as in rounds 1-5)
+    w_h, b_h = tape.param(part, scope + "/hidden_state/kernel"), tape.param(part, scope + "/hidden_state/bias")
+    if FF_RELU_FUSED and normed.data.is_cuda:
+        hidden = F.linear(tape, normed, w_h, b_h, act="relu")
+    else:
+        hidden = F.relu(tape, F.linear(tape, normed, w_h, b_h))
     hidden = F.dropout(tape, hidden, keep, train, ctx.salt(*site, "ff_hidden"))
     out = F.linear(tape, hidden, tape.param(part, scope + "/output/kernel"), tape.param(part, scope + "/output/bias"))
     out = F.dropout(tape, out, keep, train, ctx.salt(*site, "ff_output"))
