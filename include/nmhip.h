@@ -205,7 +205,8 @@ int nm_layer_norm_bwd(void* stream, const float* dy, const float* x, const float
                       const float* rstd, const float* gamma, float* dx, float* dyx, int64_t rows,
                       int64_t D);
 /* The same with the parameter gradients in the call: dx as above, dgamma = sum over rows of dy * xhat and dbeta = sum
- * over rows of dy (tf_utils.py:189-219 differentiated), added to what is there when `accumulate`.  Two launches (row
+ * over rows of dy (tf_utils.py:189-219 differentiated), added to what is there when bit 0 of `accumulate` is set; bit 1:
+ * dx is ADDED to what `dx` holds (the gradient a residual connection already left there).  Two launches (row
  * pass with per-workgroup partial sums, a fixed-order reduction) instead of nm_layer_norm_bwd + two nm_colsum and a
  * [rows, D] buffer of dy * xhat.  workspace: nm_layer_norm_bwd_params_workspace_bytes(D). */
 int64_t nm_layer_norm_bwd_params_workspace_bytes(int64_t D);

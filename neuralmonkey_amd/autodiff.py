@@ -625,11 +625,17 @@ def layer_norm(tape: Tape, x: Var, gamma: Var, beta: Var, eps: float = 1e-6) -> 
         d = x.shape[-1]
         gx, acc = tape.grad_slot(x)
         # a fresh gradient buffer takes dx directly (no scratch + copy); otherwise dx is added to what is there
+        fused = (FUSED_LN_BWD and gamma.needs_grad and d <= 2048 and d % 4 == 0 and out.grad.is_contiguous()
+                 and x.data.is_contiguous() and out.grad.data_ptr() % 16 == 0 and x.data.data_ptr() % 16 == 0
+                 and gamma.data.data_ptr() % 16 == 0)
+        if fused and gx is not None and gx.is_contiguous() and gx.data_ptr() % 16 == 0:
+            # dx, dgamma and dbeta in one call: no [rows, D] buffer of dy * xhat, no separate column sums; dx written
+            # to -- or, when a residual connection has left its gradient there already, added to -- x's gradient
+            ops.layer_norm_bwd_params(out.grad, x.data, mean, rstd, gamma.data, gx, gamma.grad, beta.grad,
+                                      accumulate_dx=acc)
+            return
         dx = gx if (gx is not None and not acc and gx.is_contiguous()) else tape.buf(tuple(x.shape))
-        if (FUSED_LN_BWD and gamma.needs_grad and d <= 2048 and d % 4 == 0 and out.grad.is_contiguous()
-                and x.data.is_contiguous() and out.grad.data_ptr() % 16 == 0 and x.data.data_ptr() % 16 == 0
-                and dx.data_ptr() % 16 == 0 and gamma.data.data_ptr() % 16 == 0):
-            # dx, dgamma and dbeta in one call: no [rows, D] buffer of dy * xhat, no separate column sums
+        if fused and dx.data_ptr() % 16 == 0:
             ops.layer_norm_bwd_params(out.grad, x.data, mean, rstd, gamma.data, dx, gamma.grad, beta.grad)
         else:
             dyx = tape.buf(tuple(x.shape))

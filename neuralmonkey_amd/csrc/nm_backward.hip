@@ -405,7 +405,7 @@ extern "C" int nm_layer_norm_bwd(void* stream, const float* dy, const float* x, 
 // One WAVE per row (a lane owns 4 consecutive columns of every 256-column chunk: 16-byte loads, the two row sums are
 // DPP wave reductions, no workgroup barrier inside the row loop); a workgroup's four waves walk rows
 // 4 blockIdx.x + wave, + 4 gridDim.x, ... and add their column sums through LDS at the end.
-template <int NCH>
+template <int NCH, bool ACCDX>
 __global__ __launch_bounds__(256) void layer_norm_bwd_params_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                     const float* __restrict__ mean,
                                                                     const float* __restrict__ rstd,
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void layer_norm_bwd_params_kernel(const float*
     constexpr int RPI = NCH <= 2 ? 4 : (NCH <= 4 ? 2 : 1);
     const long stride = (long)gridDim.x * 4;
     for (long row0 = (long)blockIdx.x * 4 + wave; row0 < rows; row0 += stride * RPI) {
-        float4 xh[RPI][NCH], d[RPI][NCH];
+        float4 xh[RPI][NCH], d[RPI][NCH], was[ACCDX ? RPI : 1][ACCDX ? NCH : 1];     // was: what dx holds (ACCDX: dx += ...)
         float mu[RPI], rs[RPI];
 #pragma unroll
         for (int r = 0; r < RPI; ++r) {
@@ -442,6 +442,7 @@ __global__ __launch_bounds__(256) void layer_norm_bwd_params_kernel(const float*
                 if (live && col < D) {
                     xh[r][c] = *reinterpret_cast<const float4*>(x + row * D + col);
                     d[r][c] = *reinterpret_cast<const float4*>(dy + row * D + col);
+                    if constexpr (ACCDX) was[r][c] = *reinterpret_cast<const float4*>(dx + row * D + col);
                 }
             }
         }
@@ -472,6 +473,7 @@ __global__ __launch_bounds__(256) void layer_norm_bwd_params_kernel(const float*
                     o.y = rs[r] * (dd.y * gm[c].y - m1 - hh.y * m2);
                     o.z = rs[r] * (dd.z * gm[c].z - m1 - hh.z * m2);
                     o.w = rs[r] * (dd.w * gm[c].w - m1 - hh.w * m2);
+                    if constexpr (ACCDX) { o.x += was[r][c].x; o.y += was[r][c].y; o.z += was[r][c].z; o.w += was[r][c].w; }
                     *reinterpret_cast<float4*>(dx + row * D + col) = o;
                     sg[c].x += dd.x * hh.x; sg[c].y += dd.y * hh.y; sg[c].z += dd.z * hh.z; sg[c].w += dd.w * hh.w;
                     sb[c].x += dd.x; sb[c].y += dd.y; sb[c].z += dd.z; sb[c].w += dd.w;
@@ -552,8 +554,15 @@ extern "C" int nm_layer_norm_bwd_params(void* stream, const float* dy, const flo
     hipStream_t st = nm_stream(stream);
     float* part = reinterpret_cast<float*>(workspace);
     const int nch = (int)((D + 255) / 256);
-#define NM_LNB(N_) hipLaunchKernelGGL((layer_norm_bwd_params_kernel<N_>), dim3(G), dim3(256), 0, st, dy, x, mean, rstd, \
-                                      gamma, dx, part, (long)rows, (int)D)
+    const bool acc_dx = (accumulate & 2) != 0;
+    accumulate &= 1;
+#define NM_LNB(N_)                                                                                                      \
+    do {                                                                                                                \
+        if (acc_dx) hipLaunchKernelGGL((layer_norm_bwd_params_kernel<N_, true>), dim3(G), dim3(256), 0, st, dy, x, mean, \
+                                       rstd, gamma, dx, part, (long)rows, (int)D);                                      \
+        else hipLaunchKernelGGL((layer_norm_bwd_params_kernel<N_, false>), dim3(G), dim3(256), 0, st, dy, x, mean, rstd, \
+                                gamma, dx, part, (long)rows, (int)D);                                                   \
+    } while (0)
     if (nch <= 1) NM_LNB(1);
     else if (nch == 2) NM_LNB(2);
     else if (nch <= 4) NM_LNB(4);

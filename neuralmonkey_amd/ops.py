@@ -619,8 +619,9 @@ def embedding_scatter_add(dtable, ids, d, skip_pad=False):
 _LNB_WS = {}
 
 
-def layer_norm_bwd_params(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, accumulate=True):
-    """dx of a layer norm and its parameter gradients in one call (nm_layer_norm_bwd_params)."""
+def layer_norm_bwd_params(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, accumulate=True, accumulate_dx=False):
+    """dx of a layer norm and its parameter gradients in one call (nm_layer_norm_bwd_params); ``accumulate_dx``: dx is
+    added to what ``dx`` holds."""
     lib = _lib.load()
     d = x.shape[-1]
     rows = x.numel() // d
@@ -632,8 +633,8 @@ def layer_norm_bwd_params(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, accumulat
                                         device=x.device)
     _lib.check(lib.nm_layer_norm_bwd_params(_stream(), dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                             gamma.data_ptr(), dx.data_ptr(), rows, d, dgamma.data_ptr(),
-                                            dbeta.data_ptr(), int(accumulate), ws.data_ptr(), ws.numel() * 4),
-               "nm_layer_norm_bwd_params")
+                                            dbeta.data_ptr(), int(bool(accumulate)) | (2 if accumulate_dx else 0),
+                                            ws.data_ptr(), ws.numel() * 4), "nm_layer_norm_bwd_params")
 
 
 def layer_norm_bwd(dy, x, mean, rstd, gamma, dx, dyx):

@@ -877,3 +877,39 @@ def test_chained_weight_and_bias_gradients(dev, rows, count, m, n, ld_extra):
     bias2 = torch.full((n,), float("nan"), device=dev)
     ops.colsum_chain(b_d, bias2, accumulate=False)
     assert np.abs(bias2.cpu().numpy() - want_b).max() <= 2e-6 * np.sqrt(rows * count) * 4.0
+
+
+@pytest.mark.parametrize("rows,d", [(6400, 512), (37, 512), (640, 2048), (5, 8), (300, 132), (1, 1024)])
+def test_layer_norm_bwd_with_parameter_gradients(dev, rows, d):
+    """nm_layer_norm_bwd_params (dx, dgamma, dbeta in one call; tf_utils.py:189-219 differentiated) against float64
+    autograd: written, and added to what dx / the parameter gradients hold (bits 1 / 0 of ``accumulate``)."""
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(rows + d)
+    x = rng.standard_normal((rows, d)).astype(np.float32) * 2.0 + 0.5
+    dy = rng.standard_normal((rows, d)).astype(np.float32)
+    gamma = (1.0 + 0.3 * rng.standard_normal(d)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(d)).astype(np.float32)
+    x64 = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    g64 = torch.tensor(gamma, dtype=torch.float64, requires_grad=True)
+    b64 = torch.tensor(beta, dtype=torch.float64, requires_grad=True)
+    mu = x64.mean(-1, keepdim=True)
+    var = ((x64 - mu) ** 2).mean(-1, keepdim=True)
+    y = (x64 - mu) * torch.rsqrt(var + 1e-6) * g64 + b64
+    (y * torch.tensor(dy, dtype=torch.float64)).sum().backward()
+    xd, dyd, gd, bd = T(x, dev), T(dy, dev), T(gamma, dev), T(beta, dev)
+    out, mean, rstd = torch.empty_like(xd), torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+    ops.layer_norm_fwd(xd, gd, bd, out=out, mean=mean, rstd=rstd, eps=1e-6)
+    dx = torch.full_like(xd, float("nan"))
+    dgam, dbet = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
+    ops.layer_norm_bwd_params(dyd, xd, mean, rstd, gd, dx, dgam, dbet, accumulate=False)
+    tol = lambda ref: 2e-5 * max(1.0, float(np.abs(ref).max()))
+    assert np.abs(dx.cpu().numpy() - x64.grad.numpy()).max() <= tol(x64.grad.numpy())
+    assert np.abs(dgam.cpu().numpy() - g64.grad.numpy()).max() <= tol(g64.grad.numpy()) * np.sqrt(rows)
+    assert np.abs(dbet.cpu().numpy() - b64.grad.numpy()).max() <= tol(b64.grad.numpy()) * np.sqrt(rows)
+    # accumulate: dx += (the gradient a residual connection left there), the parameter gradients likewise
+    base = rng.standard_normal((rows, d)).astype(np.float32)
+    dx2 = T(base, dev)
+    dgam2, dbet2 = dgam.clone(), dbet.clone()
+    ops.layer_norm_bwd_params(dyd, xd, mean, rstd, gd, dx2, dgam2, dbet2, accumulate=True, accumulate_dx=True)
+    assert torch.allclose(dx2, T(base, dev) + dx, rtol=1e-6, atol=1e-6)      # (the add may be contracted into an fma)
+    assert torch.allclose(dgam2, 2 * dgam, rtol=1e-6, atol=1e-6) and torch.allclose(dbet2, 2 * dbet, rtol=1e-6, atol=1e-6)
