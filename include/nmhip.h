@@ -198,6 +198,10 @@ int nm_gru_rh_seq(void* stream, const float* ru_all, const float* hprev, float* 
 int nm_add_layer_norm_fwd(void* stream, const float* a, int64_t lda, const float* x, int64_t ldx,
                           const float* gamma, const float* beta, float* sum_out, int64_t lds, float* y, int64_t ldy,
                           int64_t rows, int64_t D, float eps);
+/* ... with the row statistics the backward pass reads (contiguous rows, D a multiple of 4 up to 2048, 16-byte aligned). */
+int nm_add_layer_norm_stats_fwd(void* stream, const float* a, const float* x, const float* gamma, const float* beta,
+                                float* sum_out, float* y, float* mean_out, float* rstd_out, int64_t rows, int64_t D,
+                                float eps);
 int nm_layer_norm_fwd(void* stream, const float* x, int64_t ldx, const float* gamma, const float* beta,
                       float* y, int64_t ldy, float* mean_out, float* rstd_out, int64_t rows, int64_t D,
                       float eps);

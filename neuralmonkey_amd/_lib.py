@@ -35,6 +35,7 @@ SIGNATURES = {
     "nm_gru_blend_fwd": (I, [P, P, L, L, L, P, P, P, P, P, P, L, L, L, P, I, I, I, L, L]),
     "nm_layer_norm_fwd": (I, [P, P, L, P, P, P, L, P, P, L, L, F]),
     "nm_add_layer_norm_fwd": (I, [P, P, L, P, L, P, P, P, L, P, L, L, L, F]),
+    "nm_add_layer_norm_stats_fwd": (I, [P, P, P, P, P, P, P, P, P, L, L, F]),
     "nm_copy_cols": (I, [P, P, L, P, L, L, L]),
     "nm_reduce_sum": (I, [P, P, L, P]),
     "nm_log_softmax": (I, [P, P, L, P, P, P, L, L, L]),

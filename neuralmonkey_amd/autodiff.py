@@ -38,21 +38,39 @@ CHAIN_WGRADS = os.environ.get("NM_WGRAD_CHAINS", "1") != "0"
 ZERO_ARENA = os.environ.get("NM_TAPE_ZERO_ARENA", "1") != "0"
 # the gradient buffer of a sum handed to one of its operands instead of copied (autodiff.add)
 ALIAS_ADD_GRADS = os.environ.get("NM_ADD_GRAD_ALIAS", "1") != "0"
+# a sum (residual connection) computed by its first reader: a layer norm adds and norms in one pass (autodiff.add)
+LAZY_ADD = os.environ.get("NM_LAZY_ADD", "1") != "0"
 
 
 class Var:
     """A tensor on the tape plus (lazily) its gradient."""
-    __slots__ = ("data", "grad", "needs_grad", "fresh")
+    __slots__ = ("_data", "grad", "needs_grad", "fresh", "pending")
 
     def __init__(self, data: torch.Tensor, grad: Optional[torch.Tensor] = None, needs_grad: bool = True):
-        self.data = data
+        self._data = data
         self.grad = grad
         self.needs_grad = needs_grad
         self.fresh = False          # ``grad`` was handed out unwritten: the first contribution overwrites it
+        self.pending = None         # (a, b): ``data`` is the sum a + b that nobody has computed yet (autodiff.add)
+
+    @property
+    def data(self) -> torch.Tensor:
+        """The tensor.  A pending sum (a residual connection whose first reader may be a layer norm that computes it
+        on the way: ``layer_norm``) is computed when somebody else looks first."""
+        if self.pending is not None:
+            a, b = self.pending
+            self.pending = None
+            ops.ew("add", a, b, self._data)
+        return self._data
+
+    @data.setter
+    def data(self, value: torch.Tensor) -> None:
+        self._data = value
+        self.pending = None
 
     @property
     def shape(self):
-        return self.data.shape
+        return self._data.shape
 
 
 class _ZeroArena:
@@ -153,7 +171,7 @@ class Tape:
         if not v.needs_grad:
             return None
         if v.grad is None:
-            v.grad = self.buf(tuple(v.data.shape), zero=True)
+            v.grad = self.buf(tuple(v.shape), zero=True)
         elif v.fresh:
             ops.zero(v.grad)
             v.fresh = False
@@ -167,7 +185,7 @@ class Tape:
         if not v.needs_grad:
             return None, False
         if v.grad is None:
-            v.grad = self.buf(tuple(v.data.shape), zero=False)
+            v.grad = self.buf(tuple(v.shape), zero=False)
             return v.grad, False
         if v.fresh:                 # a pre-assigned slice of a shared buffer (linear_multi) that nobody wrote yet
             v.fresh = False
@@ -469,7 +487,10 @@ ACTIVATIONS = {"tanh": tanh, "relu": relu, "sigmoid": sigmoid, "identity": lambd
 
 def add(tape: Tape, a: Var, b: Var) -> Var:
     out = tape.new(tuple(a.shape))
-    ops.ew("add", a.data, b.data, out.data)
+    if LAZY_ADD and tape.recording and a.data.is_cuda and a.data.dim() == 2 and a.shape == b.shape:
+        out.pending = (a.data, b.data)      # computed by whoever reads it first: a layer norm does it on the way
+    else:
+        ops.ew("add", a.data, b.data, out.data)
 
     def bwd():
         if out.grad is None:
@@ -614,10 +635,16 @@ def embedding(tape: Tape, table: Var, ids: torch.Tensor, out: Optional[Var] = No
 
 def layer_norm(tape: Tape, x: Var, gamma: Var, beta: Var, eps: float = 1e-6) -> Var:
     """tf_utils.py:189-219."""
-    rows = x.data.numel() // x.shape[-1]
+    rows = x._data.numel() // x.shape[-1]
     out = tape.new(tuple(x.shape))
     mean, rstd = tape.buf((rows,)), tape.buf((rows,))
-    ops.layer_norm_fwd(x.data, gamma.data, beta.data, out=out.data, mean=mean, rstd=rstd, eps=eps)
+    pend = x.pending
+    if pend is not None and ops.add_layer_norm_stats_ok(pend[0], pend[1], gamma.data, beta.data):
+        # x is a residual sum nobody has read yet: sum and norm in one pass over the rows
+        x.pending = None
+        ops.add_layer_norm_stats_fwd(pend[0], pend[1], gamma.data, beta.data, x._data, out.data, mean, rstd, eps)
+    else:
+        ops.layer_norm_fwd(x.data, gamma.data, beta.data, out=out.data, mean=mean, rstd=rstd, eps=eps)
 
     def bwd():
         if out.grad is None:

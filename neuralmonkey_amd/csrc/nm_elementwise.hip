@@ -218,6 +218,113 @@ __global__ __launch_bounds__(256) void layer_norm_fwd_kernel(const float* __rest
     }
 }
 
+// Layer norm forward, one WAVE per row (round 6): a row of D <= 2048 floats is NCH float4s per lane, read once, held in
+// registers for the mean, the variance (around the mean, as above) and the output; the two sums are DPP wave
+// reductions -- no LDS, no barrier; RPI rows of a wave are in flight together.  The workgroup-per-row kernel above
+// spends two block reductions on every 2 KB row: 12.6 us for a [6400, 512] operand (2 TB/s), 32 of them per
+// Transformer-base training step.  ADD: the row is a + x (a residual connection), written to sum_out as well -- what
+// nm_add_layer_norm_fwd does for the decoding steps, here with the statistics the backward pass needs.
+template <int NCH, bool ADD>
+__global__ __launch_bounds__(256) void layer_norm_fwd_wave_kernel(const float* __restrict__ a, const float* __restrict__ x,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta,
+                                                                  float* __restrict__ sum_out, float* __restrict__ y,
+                                                                  float* __restrict__ mean_out,
+                                                                  float* __restrict__ rstd_out, long rows, int D, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int RPI = NCH <= 2 ? 4 : (NCH <= 4 ? 2 : 1);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 gm[NCH], bt[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = 256 * c + 4 * lane;
+        gm[c] = col < D ? *reinterpret_cast<const float4*>(gamma + col) : z4;
+        bt[c] = col < D ? *reinterpret_cast<const float4*>(beta + col) : z4;
+    }
+    const float invd = 1.0f / (float)D;
+    const long stride = (long)gridDim.x * 4;
+    for (long row0 = (long)blockIdx.x * 4 + wave; row0 < rows; row0 += stride * RPI) {
+        float4 v[RPI][NCH];
+#pragma unroll
+        for (int r = 0; r < RPI; ++r) {
+            const long row = row0 + r * stride;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int col = 256 * c + 4 * lane;
+                v[r][c] = z4;
+                if (row < rows && col < D) {
+                    v[r][c] = *reinterpret_cast<const float4*>(x + row * D + col);
+                    if constexpr (ADD) {
+                        const float4 w = *reinterpret_cast<const float4*>(a + row * D + col);
+                        v[r][c].x += w.x; v[r][c].y += w.y; v[r][c].z += w.z; v[r][c].w += w.w;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RPI; ++r) {
+            const long row = row0 + r * stride;
+            if (row >= rows) break;
+            float s = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) s += (v[r][c].x + v[r][c].y) + (v[r][c].z + v[r][c].w);
+            const float mean = nm_wave_sum_dpp(s) * invd;
+            float q = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                if (256 * c + 4 * lane < D) {
+                    const float d0 = v[r][c].x - mean, d1 = v[r][c].y - mean, d2 = v[r][c].z - mean, d3 = v[r][c].w - mean;
+                    q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                }
+            }
+            const float rstd = rsqrtf(nm_wave_sum_dpp(q) * invd + eps);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int col = 256 * c + 4 * lane;
+                if (col < D) {
+                    if constexpr (ADD) *reinterpret_cast<float4*>(sum_out + row * D + col) = v[r][c];
+                    float4 o;
+                    o.x = (v[r][c].x - mean) * rstd * gm[c].x + bt[c].x;
+                    o.y = (v[r][c].y - mean) * rstd * gm[c].y + bt[c].y;
+                    o.z = (v[r][c].z - mean) * rstd * gm[c].z + bt[c].z;
+                    o.w = (v[r][c].w - mean) * rstd * gm[c].w + bt[c].w;
+                    *reinterpret_cast<float4*>(y + row * D + col) = o;
+                }
+            }
+            if (lane == 0) {
+                if (mean_out) mean_out[row] = mean;
+                if (rstd_out) rstd_out[row] = rstd;
+            }
+        }
+    }
+}
+
+// the wave kernel's conditions: contiguous rows of D <= 2048 floats, D % 4 == 0, 16-byte aligned operands
+static bool ln_wave_ok(const float* a, const float* x, int64_t lda, int64_t ldx, const float* gamma, const float* beta,
+                       const float* sum_out, int64_t lds, const float* y, int64_t ldy, int64_t D) {
+    static const bool on = !(getenv("NM_LN_FWD_WAVE") && atoi(getenv("NM_LN_FWD_WAVE")) == 0);
+    return on && D % 4 == 0 && D <= 2048 && ldx == D && ldy == D && (!a || lda == D) && (!sum_out || lds == D) &&
+           nm_aligned16(x) && nm_aligned16(y) && nm_aligned16(gamma) && nm_aligned16(beta) && (!a || nm_aligned16(a)) &&
+           (!sum_out || nm_aligned16(sum_out));
+}
+
+template <bool ADD>
+static void ln_wave_launch(hipStream_t st, const float* a, const float* x, const float* gamma, const float* beta,
+                           float* sum_out, float* y, float* mean_out, float* rstd_out, int64_t rows, int64_t D, float eps) {
+    const int nch = (int)((D + 255) / 256);
+    const int rpi = nch <= 2 ? 4 : (nch <= 4 ? 2 : 1);
+    long G = (rows + 4L * rpi - 1) / (4L * rpi);
+    if (G > 2048) G = 2048;
+    if (G < 1) G = 1;
+#define NM_LNF(N_) hipLaunchKernelGGL((layer_norm_fwd_wave_kernel<N_, ADD>), dim3((unsigned)G), dim3(256), 0, st, a, x, gamma, \
+                                      beta, sum_out, y, mean_out, rstd_out, (long)rows, (int)D, eps)
+    if (nch <= 1) NM_LNF(1);
+    else if (nch == 2) NM_LNF(2);
+    else if (nch <= 4) NM_LNF(4);
+    else NM_LNF(8);
+#undef NM_LNF
+}
+
 // s = a + x ; y = layer_norm(s): a residual connection and the pre-norm of the next sub-layer in one pass
 // (decoders/transformer.py:270-358: every sub-layer ends in `+ x` and the next one starts with layer_norm).  The
 // arithmetic is ew "add" followed by layer_norm_fwd_kernel's, element for element.
@@ -258,10 +365,28 @@ extern "C" int nm_add_layer_norm_fwd(void* stream, const float* a, int64_t lda, 
     NM_REQUIRE(a && x && gamma && beta && sum_out && y, "nm_add_layer_norm_fwd: null pointer");
     NM_REQUIRE(rows >= 0 && D > 0 && D <= 16384, "nm_add_layer_norm_fwd: bad shape rows=%ld D=%ld", (long)rows, (long)D);
     if (rows == 0) return NM_OK;
+    if (ln_wave_ok(a, x, lda, ldx, gamma, beta, sum_out, lds, y, ldy, D)) {
+        ln_wave_launch<true>(nm_stream(stream), a, x, gamma, beta, sum_out, y, nullptr, nullptr, rows, D, eps);
+        NM_LAUNCH_CHECK("nm_add_layer_norm_fwd");
+    }
     hipLaunchKernelGGL(add_layer_norm_fwd_kernel, dim3((unsigned)rows), dim3(256), (size_t)D * sizeof(float),
                        nm_stream(stream), a, (long)lda, x, (long)ldx, gamma, beta, sum_out, (long)lds, y, (long)ldy,
                        (int)D, eps);
     NM_LAUNCH_CHECK("nm_add_layer_norm_fwd");
+}
+
+// The same with the row statistics the backward pass reads (training tapes: autodiff.layer_norm on a pending sum).
+// Contiguous rows only (the wave kernel's conditions); returns NM_ERR_ARG otherwise -- the caller adds, then norms.
+extern "C" int nm_add_layer_norm_stats_fwd(void* stream, const float* a, const float* x, const float* gamma,
+                                           const float* beta, float* sum_out, float* y, float* mean_out, float* rstd_out,
+                                           int64_t rows, int64_t D, float eps) {
+    NM_REQUIRE(a && x && gamma && beta && sum_out && y && mean_out && rstd_out, "nm_add_layer_norm_stats_fwd: null pointer");
+    NM_REQUIRE(rows >= 0 && D > 0, "nm_add_layer_norm_stats_fwd: bad shape");
+    NM_REQUIRE(ln_wave_ok(a, x, D, D, gamma, beta, sum_out, D, y, D, D),
+               "nm_add_layer_norm_stats_fwd: D = %ld must be a multiple of 4 up to 2048, operands 16-byte aligned", (long)D);
+    if (rows == 0) return NM_OK;
+    ln_wave_launch<true>(nm_stream(stream), a, x, gamma, beta, sum_out, y, mean_out, rstd_out, rows, D, eps);
+    NM_LAUNCH_CHECK("nm_add_layer_norm_stats_fwd");
 }
 
 extern "C" int nm_layer_norm_fwd(void* stream, const float* x, int64_t ldx, const float* gamma,
@@ -270,6 +395,10 @@ extern "C" int nm_layer_norm_fwd(void* stream, const float* x, int64_t ldx, cons
     NM_REQUIRE(x && gamma && beta && y, "nm_layer_norm_fwd: null pointer");
     NM_REQUIRE(rows >= 0 && D > 0, "nm_layer_norm_fwd: bad shape");
     if (rows == 0) return NM_OK;
+    if (ln_wave_ok(nullptr, x, 0, ldx, gamma, beta, nullptr, 0, y, ldy, D)) {
+        ln_wave_launch<false>(nm_stream(stream), nullptr, x, gamma, beta, nullptr, y, mean_out, rstd_out, rows, D, eps);
+        NM_LAUNCH_CHECK("nm_layer_norm_fwd");
+    }
     hipLaunchKernelGGL(layer_norm_fwd_kernel, dim3((unsigned)rows), dim3(256), 0, nm_stream(stream), x,
                        (long)ldx, gamma, beta, y, (long)ldy, mean_out, rstd_out, (int)D, eps);
     NM_LAUNCH_CHECK("nm_layer_norm_fwd");

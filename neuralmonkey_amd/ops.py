@@ -48,6 +48,26 @@ def add_layer_norm_fwd(a, x, gamma, beta, sum_out, out, eps=1e-6):
     return sum_out, out
 
 
+def add_layer_norm_stats_ok(a, x, gamma, beta) -> bool:
+    """Can ``add_layer_norm_stats_fwd`` take these operands (contiguous rows of D <= 2048 floats, D % 4 == 0, aligned)?"""
+    d = x.shape[-1]
+    return (x.is_cuda and d % 4 == 0 and d <= 2048 and a.is_contiguous() and x.is_contiguous() and a.shape == x.shape
+            and all(t.data_ptr() % 16 == 0 for t in (a, x, gamma, beta)))
+
+
+def add_layer_norm_stats_fwd(a, x, gamma, beta, sum_out, out, mean, rstd, eps=1e-6):
+    """sum_out = a + x ; out = layer_norm(sum_out), with the row statistics the backward pass reads
+    (nm_add_layer_norm_stats_fwd: one wave per row)."""
+    d = x.shape[-1]
+    rows = x.numel() // d
+    assert sum_out.is_contiguous() and out.is_contiguous()
+    _lib.check(_lib.load().nm_add_layer_norm_stats_fwd(_stream(), a.data_ptr(), x.data_ptr(), gamma.data_ptr(),
+                                                       beta.data_ptr(), sum_out.data_ptr(), out.data_ptr(),
+                                                       mean.data_ptr(), rstd.data_ptr(), rows, d, float(eps)),
+               "nm_add_layer_norm_stats_fwd")
+    return sum_out, out
+
+
 GEMM_BACKGROUND = 4     # nm_gemm_f32 algo: residency-capped 128x128 tiles for a long leaf GEMM on a side stream
 
 

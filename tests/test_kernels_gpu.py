@@ -913,3 +913,41 @@ def test_layer_norm_bwd_with_parameter_gradients(dev, rows, d):
     ops.layer_norm_bwd_params(dyd, xd, mean, rstd, gd, dx2, dgam2, dbet2, accumulate=True, accumulate_dx=True)
     assert torch.allclose(dx2, T(base, dev) + dx, rtol=1e-6, atol=1e-6)      # (the add may be contracted into an fma)
     assert torch.allclose(dgam2, 2 * dgam, rtol=1e-6, atol=1e-6) and torch.allclose(dbet2, 2 * dbet, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("rows,d", [(6400, 512), (37, 512), (640, 2048), (5, 8), (300, 132), (128, 1024), (3, 2052)])
+def test_layer_norm_forward_kernels(dev, rows, d):
+    """nm_layer_norm_fwd (one wave per row for contiguous rows of D <= 2048, D % 4 == 0; a workgroup per row otherwise),
+    nm_add_layer_norm_fwd and nm_add_layer_norm_stats_fwd against float64 (tf_utils.py:189-219: biased variance, eps
+    inside the root)."""
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(rows * 7 + d)
+    x = (rng.standard_normal((rows, d)) * 3.0 + 1.0).astype(np.float32)
+    a = rng.standard_normal((rows, d)).astype(np.float32)
+    gamma = (1.0 + 0.3 * rng.standard_normal(d)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(d)).astype(np.float32)
+
+    def ref(v):
+        v = v.astype(np.float64)
+        mu = v.mean(-1, keepdims=True)
+        var = ((v - mu) ** 2).mean(-1, keepdims=True)
+        rs = 1.0 / np.sqrt(var + 1e-6)
+        return (v - mu) * rs * gamma + beta, mu[:, 0], rs[:, 0]
+    xd, ad, gd, bd = T(x, dev), T(a, dev), T(gamma, dev), T(beta, dev)
+    out, mean, rstd = torch.empty_like(xd), torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+    ops.layer_norm_fwd(xd, gd, bd, out=out, mean=mean, rstd=rstd, eps=1e-6)
+    want, mu, rs = ref(x)
+    assert np.abs(out.cpu().numpy() - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
+    assert np.abs(mean.cpu().numpy() - mu).max() <= 1e-5 and rel_err(rstd.cpu().numpy(), rs) <= 1e-5
+    want2, mu2, rs2 = ref(a + x)                       # (the fp32 sum, as the kernels form it)
+    s1, o1 = torch.empty_like(xd), torch.empty_like(xd)
+    ops.add_layer_norm_fwd(ad, xd, gd, bd, s1, o1)
+    assert torch.equal(s1, ad + xd)
+    assert np.abs(o1.cpu().numpy() - want2).max() <= 2e-5 * max(1.0, np.abs(want2).max())
+    if ops.add_layer_norm_stats_ok(ad, xd, gd, bd):
+        s2, o2 = torch.empty_like(xd), torch.empty_like(xd)
+        ops.add_layer_norm_stats_fwd(ad, xd, gd, bd, s2, o2, mean, rstd)
+        assert torch.equal(s2, s1) and torch.equal(o2, o1)          # the same kernel as nm_add_layer_norm_fwd
+        assert np.abs(mean.cpu().numpy() - mu2).max() <= 1e-5 and rel_err(rstd.cpu().numpy(), rs2) <= 1e-5
+    else:
+        assert d % 4 != 0 or d > 2048
