@@ -627,6 +627,18 @@ int nm_optim_apply(void* stream, int32_t kind, float* theta, const float* grad, 
                    const int32_t* seg_first, const int32_t* seg_count, const int32_t* seg_flags, int64_t nchunk,
                    int64_t nseg, float clip_norm, float p0, float p1, float p2, float p3, int64_t chunk_begin,
                    int64_t chunk_end, const int32_t* skip_word, void* workspace, int64_t workspace_bytes);
+/* nm_optim_partials / nm_optim_apply over a LIST of chunks (device array of `count` chunk indices, any order): all the
+ * chunks a rank of the sharded optimizer owns -- one slice per bucket plus the shared tails -- in one launch each. */
+int nm_optim_partials_list(void* stream, const float* theta, float* grad, const int64_t* chunk_start,
+                           const int32_t* chunk_len, const int32_t* chunk_seg, const int32_t* seg_first,
+                           const int32_t* seg_count, const int32_t* seg_flags, int64_t nchunk, int64_t nseg,
+                           float l1_weight, float l2_weight, const int32_t* chunk_list, int64_t count, void* workspace,
+                           int64_t workspace_bytes);
+int nm_optim_apply_list(void* stream, int32_t kind, float* theta, const float* grad, float* slot0, float* slot1,
+                        const int64_t* chunk_start, const int32_t* chunk_len, const int32_t* chunk_seg,
+                        const int32_t* seg_first, const int32_t* seg_count, const int32_t* seg_flags, int64_t nchunk,
+                        int64_t nseg, float clip_norm, float p0, float p1, float p2, float p3, const int32_t* chunk_list,
+                        int64_t count, const int32_t* skip_word, void* workspace, int64_t workspace_bytes);
 /* x[0..n) = 0 when *word != 0: the gradient a given-up time loop left behind must not reach an accumulation buffer
  * (trainers/delayed_update_trainer.py:146-150) or a collective as NaNs */
 int nm_zero_if(void* stream, const int32_t* word, float* x, int64_t n);

@@ -119,6 +119,8 @@ SIGNATURES = {
     "nm_optim_clip_adam": (I, [P, P, P, P, P, P, P, P, P, P, P, L, L, F, F, F, F, F, P, L]),
     "nm_optim_clip_adadelta": (I, [P, P, P, P, P, P, P, P, P, P, P, L, L, F, F, F, F, P, L]),
     "nm_optim_partials": (I, [P, P, P, P, P, P, P, P, P, L, L, F, F, L, L, P, L]),
+    "nm_optim_partials_list": (I, [P, P, P, P, P, P, P, P, P, L, L, F, F, P, L, P, L]),
+    "nm_optim_apply_list": (I, [P, I, P, P, P, P, P, P, P, P, P, P, L, L, F, F, F, F, F, P, L, P, P, L]),
     "nm_optim_segments": (I, [P, P, P, P, P, P, P, L, L, P, P, L]),
     "nm_optim_apply": (I, [P, I, P, P, P, P, P, P, P, P, P, P, L, L, F, F, F, F, F, L, L, P, P, L]),
     "nm_zero_if": (I, [P, P, P, L]),

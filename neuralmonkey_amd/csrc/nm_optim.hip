@@ -23,9 +23,10 @@ struct OptChunks {
 // pass 1: regulariser terms + squared gradient norm partials per chunk
 __global__ __launch_bounds__(256) void opt_reg_sumsq_kernel(OptChunks t, const float* __restrict__ theta,
                                                             float* __restrict__ grad, float l1w, float l2w,
-                                                            float* __restrict__ partial, int c0) {
+                                                            float* __restrict__ partial, int c0,
+                                                            const int* __restrict__ list) {
     __shared__ float sh[3][4];
-    const int c = c0 + (int)blockIdx.x;
+    const int c = list ? list[blockIdx.x] : c0 + (int)blockIdx.x;     // (list: the chunks a rank owns, in any order)
     const long base = t.chunk_start[c];
     const int len = t.chunk_len[c];
     const int flags = t.seg_flags[t.chunk_seg[c]];
@@ -100,9 +101,9 @@ __global__ __launch_bounds__(256) void opt_adam_kernel(OptChunks t, float* __res
                                                        float* __restrict__ m, float* __restrict__ v,
                                                        const float* __restrict__ seg_norm2, float clip,
                                                        float lr_t, float b1, float b2, float eps, int c0,
-                                                       const int* __restrict__ skip) {
+                                                       const int* __restrict__ skip, const int* __restrict__ list) {
     if (skip && *skip != 0) return;          // the step's gradient is garbage (a time loop gave up): nothing is applied
-    const int c = c0 + (int)blockIdx.x;
+    const int c = list ? list[blockIdx.x] : c0 + (int)blockIdx.x;
     const int seg = t.chunk_seg[c];
     if (!(t.seg_flags[seg] & 2)) return;
     const long base = t.chunk_start[c];
@@ -126,9 +127,9 @@ __global__ __launch_bounds__(256) void opt_adadelta_kernel(OptChunks t, float* _
                                                            float* __restrict__ accum, float* __restrict__ accum_update,
                                                            const float* __restrict__ seg_norm2, float clip,
                                                            float lr, float rho, float eps, int c0,
-                                                           const int* __restrict__ skip) {
+                                                           const int* __restrict__ skip, const int* __restrict__ list) {
     if (skip && *skip != 0) return;
-    const int c = c0 + (int)blockIdx.x;
+    const int c = list ? list[blockIdx.x] : c0 + (int)blockIdx.x;
     const int seg = t.chunk_seg[c];
     if (!(t.seg_flags[seg] & 2)) return;
     const long base = t.chunk_start[c];
@@ -178,8 +179,31 @@ extern "C" int nm_optim_partials(void* stream, const float* theta, float* grad, 
     if (chunk_begin == chunk_end) return NM_OK;
     OptChunks t = make_chunks(chunk_start, chunk_len, chunk_seg, seg_first, seg_count, seg_flags, nchunk, nseg);
     hipLaunchKernelGGL(opt_reg_sumsq_kernel, dim3((unsigned)(chunk_end - chunk_begin)), dim3(256), 0, nm_stream(stream),
-                       t, theta, grad, l1_weight, l2_weight, reinterpret_cast<float*>(workspace), (int)chunk_begin);
+                       t, theta, grad, l1_weight, l2_weight, reinterpret_cast<float*>(workspace), (int)chunk_begin,
+                       (const int*)nullptr);
     NM_LAUNCH_CHECK("nm_optim_partials");
+}
+
+// The same over a LIST of chunks (a device array of ``count`` chunk indices): everything a rank of the sharded optimizer
+// owns -- one slice per bucket plus the shared tails -- in ONE launch.  Range by range (14 launches of ~60 chunks each
+// on the headline model) a launch is as long as its slowest workgroup and the chip is a quarter full: 0.98 instead of
+// 0.14 ms for this pass, 1.20 instead of 0.35 ms for the update (profiles/r06_dp_force_kernel_stats_sharded1.csv).
+extern "C" int nm_optim_partials_list(void* stream, const float* theta, float* grad, const int64_t* chunk_start,
+                                      const int32_t* chunk_len, const int32_t* chunk_seg, const int32_t* seg_first,
+                                      const int32_t* seg_count, const int32_t* seg_flags, int64_t nchunk, int64_t nseg,
+                                      float l1_weight, float l2_weight, const int32_t* chunk_list, int64_t count,
+                                      void* workspace, int64_t workspace_bytes) {
+    NM_REQUIRE(theta && grad && chunk_start && chunk_len && chunk_seg && seg_first && seg_count && seg_flags && workspace,
+               "nm_optim_partials_list: null pointer");
+    NM_REQUIRE(nchunk > 0 && nseg > 0 && workspace_bytes >= nm_optim_workspace_bytes(nchunk, nseg),
+               "nm_optim_partials_list: bad sizes");
+    NM_REQUIRE(count >= 0 && count <= nchunk && (count == 0 || chunk_list), "nm_optim_partials_list: bad chunk list (%ld of %ld)",
+               (long)count, (long)nchunk);
+    if (count == 0) return NM_OK;
+    OptChunks t = make_chunks(chunk_start, chunk_len, chunk_seg, seg_first, seg_count, seg_flags, nchunk, nseg);
+    hipLaunchKernelGGL(opt_reg_sumsq_kernel, dim3((unsigned)count), dim3(256), 0, nm_stream(stream), t, theta, grad,
+                       l1_weight, l2_weight, reinterpret_cast<float*>(workspace), 0, chunk_list);
+    NM_LAUNCH_CHECK("nm_optim_partials_list");
 }
 
 // pass 2: per-variable squared gradient norms and the global L1 / L2 terms from the partial vector, in a fixed order
@@ -220,11 +244,36 @@ extern "C" int nm_optim_apply(void* stream, int32_t kind, float* theta, const fl
     const unsigned grid = (unsigned)(chunk_end - chunk_begin);
     if (kind == 0)
         hipLaunchKernelGGL(opt_adam_kernel, dim3(grid), dim3(256), 0, nm_stream(stream), t, theta, grad, slot0, slot1,
-                           seg_norm2, clip_norm, p0, p1, p2, p3, (int)chunk_begin, skip_word);
+                           seg_norm2, clip_norm, p0, p1, p2, p3, (int)chunk_begin, skip_word, (const int*)nullptr);
     else
         hipLaunchKernelGGL(opt_adadelta_kernel, dim3(grid), dim3(256), 0, nm_stream(stream), t, theta, grad, slot0, slot1,
-                           seg_norm2, clip_norm, p0, p1, p2, (int)chunk_begin, skip_word);
+                           seg_norm2, clip_norm, p0, p1, p2, (int)chunk_begin, skip_word, (const int*)nullptr);
     NM_LAUNCH_CHECK("nm_optim_apply");
+}
+
+// ... over a list of chunks (see nm_optim_partials_list)
+extern "C" int nm_optim_apply_list(void* stream, int32_t kind, float* theta, const float* grad, float* slot0, float* slot1,
+                                   const int64_t* chunk_start, const int32_t* chunk_len, const int32_t* chunk_seg,
+                                   const int32_t* seg_first, const int32_t* seg_count, const int32_t* seg_flags,
+                                   int64_t nchunk, int64_t nseg, float clip_norm, float p0, float p1, float p2, float p3,
+                                   const int32_t* chunk_list, int64_t count, const int32_t* skip_word, void* workspace,
+                                   int64_t workspace_bytes) {
+    NM_REQUIRE(theta && grad && slot0 && slot1 && workspace, "nm_optim_apply_list: null pointer");
+    NM_REQUIRE(kind == 0 || kind == 1, "nm_optim_apply_list: kind %d (0 Adam, 1 Adadelta)", (int)kind);
+    NM_REQUIRE(nchunk > 0 && nseg > 0 && workspace_bytes >= nm_optim_workspace_bytes(nchunk, nseg),
+               "nm_optim_apply_list: bad sizes");
+    NM_REQUIRE(count >= 0 && count <= nchunk && (count == 0 || chunk_list), "nm_optim_apply_list: bad chunk list (%ld of %ld)",
+               (long)count, (long)nchunk);
+    if (count == 0) return NM_OK;
+    OptChunks t = make_chunks(chunk_start, chunk_len, chunk_seg, seg_first, seg_count, seg_flags, nchunk, nseg);
+    const float* seg_norm2 = reinterpret_cast<const float*>(workspace) + nchunk * 3;
+    if (kind == 0)
+        hipLaunchKernelGGL(opt_adam_kernel, dim3((unsigned)count), dim3(256), 0, nm_stream(stream), t, theta, grad, slot0,
+                           slot1, seg_norm2, clip_norm, p0, p1, p2, p3, 0, skip_word, chunk_list);
+    else
+        hipLaunchKernelGGL(opt_adadelta_kernel, dim3((unsigned)count), dim3(256), 0, nm_stream(stream), t, theta, grad, slot0,
+                           slot1, seg_norm2, clip_norm, p0, p1, p2, 0, skip_word, chunk_list);
+    NM_LAUNCH_CHECK("nm_optim_apply_list");
 }
 
 // x[0..n) = 0 when *word != 0 (the session's error word): a gradient that a given-up time loop left behind must not

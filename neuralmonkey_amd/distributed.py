@@ -553,18 +553,31 @@ class DataParallel:
             plan = self.plan(store)
             ranges = [tables.chunk_range(lo, hi) for lo, hi in plan.owned(self.rank)]
             tails = [tables.chunk_range(lo, hi) for lo, hi in plan.tails()]
+            # ONE launch per pass over everything this rank owns (a device list of chunk indices): range by range the
+            # 14 launches of the headline model took 2.2 instead of 0.5 ms (profiles/r06_dp_force_kernel_stats_*.csv).
+            # The tails are everybody's -- every rank regularises and updates them -- but their partial sums count once:
+            # rank 0's (the other ranks multiply theirs by zero).
+            from . import ops
             partial = tables.partial_vector()
-            partial.zero_()
-            for rng in ranges + tails:
-                tables.partials(store.theta, grad, l1_weight, l2_weight, rng)
-            if self.rank != 0:                   # the tails are everybody's: their partial sums count once
-                for b, e in tails:
-                    partial[3 * b:3 * e] = 0.0
+            ops.zero(partial)
+            everything = tables.chunk_list(ranges + tails)
+            tables.partials(store.theta, grad, l1_weight, l2_weight, None, chunk_list=everything)
+            if self.rank != 0 and tails:         # (pass 1 also adds the regulariser terms to the tails' gradient)
+                mask = self.__dict__.setdefault("_tail_masks", {}).get(id(tables))
+                if mask is None:
+                    mask = torch.ones_like(partial)
+                    for b, e in tails:
+                        mask[3 * b:3 * e] = 0.0
+                    self._tail_masks[id(tables)] = mask
+                if partial.is_cuda:
+                    ops.ew("mul", partial, mask, partial)
+                else:
+                    partial.mul_(mask)
             if self.world_size > 1:
                 dist.all_reduce(partial, op=dist.ReduceOp.SUM)
             l1l2 = tables.segments()
-            for rng in ranges + tails:
-                tables.apply(kind, store.theta, grad, slot0, slot1, clip_norm, params, skip=skip, chunks=rng)
+            tables.apply(kind, store.theta, grad, slot0, slot1, clip_norm, params, skip=skip,
+                         chunk_list=everything)
             self.gather_bytes_per_step = self._gather_buckets(store.theta, plan)
             store.epoch += 1                     # (a collective wrote the variables: Session.variables_signature)
         if timed:

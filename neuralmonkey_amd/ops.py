@@ -1275,19 +1275,44 @@ class OptimizerTables:
     def clip_adadelta(self, theta, grad, accum, accum_update, clip_norm, lr, rho, epsilon, skip=None, chunks=None):
         self.apply(1, theta, grad, accum, accum_update, clip_norm, (lr, rho, epsilon, 0.0), skip=skip, chunks=chunks)
 
-    def apply(self, kind, theta, grad, slot0, slot1, clip_norm, params, skip=None, chunks=None):
-        """nm_optim_apply: kind 0 Adam (lr_t, beta1, beta2, epsilon), 1 Adadelta (lr, rho, epsilon, -)."""
+    def chunk_list(self, ranges):
+        """Device int32 array of the chunk indices in the (begin, end) ``ranges`` (kept: a rank's ranges never change)."""
+        key = tuple((int(b), int(e)) for b, e in ranges)
+        lists = self.__dict__.setdefault("_chunk_lists", {})
+        hit = lists.get(key)
+        if hit is None:
+            idx = [c for b, e in key for c in range(b, e)]
+            hit = lists[key] = torch.tensor(idx, dtype=torch.int32, device=self.workspace.device)
+        return hit
+
+    def apply(self, kind, theta, grad, slot0, slot1, clip_norm, params, skip=None, chunks=None, chunk_list=None):
+        """nm_optim_apply: kind 0 Adam (lr_t, beta1, beta2, epsilon), 1 Adadelta (lr, rho, epsilon, -); ``chunks``: a
+        (begin, end) range, ``chunk_list``: a device list of chunk indices (``chunk_list()``) in one launch."""
         lib = _lib.load()
-        c0, c1 = chunks if chunks is not None else (0, self.nchunk)
         p0, p1, p2, p3 = (float(x) for x in params)
+        if chunk_list is not None:
+            _lib.check(lib.nm_optim_apply_list(_stream(), int(kind), theta.data_ptr(), grad.data_ptr(), slot0.data_ptr(),
+                                               slot1.data_ptr(), *self._tabs(), float(clip_norm or 0.0), p0, p1, p2, p3,
+                                               chunk_list.data_ptr(), chunk_list.numel(), _p(skip),
+                                               self.workspace.data_ptr(), self.workspace.numel() * 4),
+                       "nm_optim_apply_list")
+            return
+        c0, c1 = chunks if chunks is not None else (0, self.nchunk)
         _lib.check(lib.nm_optim_apply(_stream(), int(kind), theta.data_ptr(), grad.data_ptr(), slot0.data_ptr(),
                                       slot1.data_ptr(), *self._tabs(), float(clip_norm or 0.0), p0, p1, p2, p3,
                                       int(c0), int(c1), _p(skip), self.workspace.data_ptr(),
                                       self.workspace.numel() * 4), "nm_optim_apply")
 
-    def partials(self, theta, grad, l1_weight, l2_weight, chunks):
-        """Pass 1 over the chunks [begin, end): regulariser terms into ``grad``, partial sums into the workspace."""
+    def partials(self, theta, grad, l1_weight, l2_weight, chunks, chunk_list=None):
+        """Pass 1 over the chunks [begin, end) -- or over a device list of chunks: regulariser terms into ``grad``,
+        partial sums into the workspace."""
         lib = _lib.load()
+        if chunk_list is not None:
+            _lib.check(lib.nm_optim_partials_list(_stream(), theta.data_ptr(), grad.data_ptr(), *self._tabs(),
+                                                  float(l1_weight), float(l2_weight), chunk_list.data_ptr(),
+                                                  chunk_list.numel(), self.workspace.data_ptr(),
+                                                  self.workspace.numel() * 4), "nm_optim_partials_list")
+            return
         _lib.check(lib.nm_optim_partials(_stream(), theta.data_ptr(), grad.data_ptr(), *self._tabs(),
                                          float(l1_weight), float(l2_weight), int(chunks[0]), int(chunks[1]),
                                          self.workspace.data_ptr(), self.workspace.numel() * 4), "nm_optim_partials")

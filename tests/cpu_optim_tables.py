@@ -22,9 +22,13 @@ class CpuOptimizerTables:
     def partial_vector(self):
         return self.workspace[:3 * self.nchunk]
 
-    def partials(self, theta, grad, l1_weight, l2_weight, chunks):
+    def chunk_list(self, ranges):
+        """The chunk indices of the (begin, end) ranges (the product keeps this list on the device)."""
+        return [c for b, e in ranges for c in range(int(b), int(e))]
+
+    def partials(self, theta, grad, l1_weight, l2_weight, chunks, chunk_list=None):
         part = self.partial_vector()
-        for c in range(*chunks):
+        for c in (chunk_list if chunk_list is not None else range(*chunks)):
             lo, n = self.starts[c], self.lens[c]
             th, g = theta[lo:lo + n], grad[lo:lo + n]
             a1 = a2 = torch.zeros((), dtype=torch.float32)
@@ -47,14 +51,14 @@ class CpuOptimizerTables:
         self.l1l2[0], self.l1l2[1] = l1, l2
         return self.l1l2
 
-    def apply(self, kind, theta, grad, slot0, slot1, clip_norm, params, skip=None, chunks=None):
+    def apply(self, kind, theta, grad, slot0, slot1, clip_norm, params, skip=None, chunks=None, chunk_list=None):
         assert kind == 0, "the stand-in restates Adam"
         if skip is not None and int(skip.item()) != 0:
             return
         lr_t, b1, b2, eps = (torch.tensor(float(p), dtype=torch.float32) for p in params)
         norm2 = self.workspace[3 * self.nchunk:]
         one = torch.tensor(1.0, dtype=torch.float32)
-        for c in range(*(chunks if chunks is not None else (0, self.nchunk))):
+        for c in (chunk_list if chunk_list is not None else range(*(chunks if chunks is not None else (0, self.nchunk)))):
             seg = self.segs[c]
             if not self.seg_flags[seg] & 2:
                 continue

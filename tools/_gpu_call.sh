@@ -1,7 +1,10 @@
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_transformer_gpu.py tests/test_transformer_multisource_gpu.py tests/test_general_gpu.py tests/test_captioning_gpu.py tests/test_engine_gpu.py tests/test_transformer_decode_graphs_gpu.py -q -x --timeout=200 2>&1 | grep -v "amdgpu.ids" | grep -E "^FAILED|^E   |passed|failed" | cut -c1-300 | head -10
-cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tt_prof -- python $GRAFT_REPO_ROOT/tools/transformer_bench.py --train-only > /tmp/tt.log 2>&1
-cd $GRAFT_REPO_ROOT
-f=$(ls /tmp/tt_prof/*/*_kernel_stats.csv 2>/dev/null | head -1)
-if [ -n "$f" ]; then head -60 "$f" > gpurun_out/r06_transformer_train_kernel_stats_v6.csv; else tail -5 /tmp/tt.log; fi
+export RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 NM_DIST_FORCE=1
+for mode in 1 0 1 0; do
+echo "== NM_DP_SHARDED=$mode"
+MASTER_PORT=2955$mode NM_DP_SHARDED=$mode timeout 600 python bench.py --gpus 1 --steps 20 --warmup 3 --no-configs --no-feed-legs --no-cpu-baseline --beam-batches 0 2>/dev/null | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print(d['ms_per_step'], {k:d['dp'][k] for k in ('optimizer','optimizer_ms','allreduce_exposed_ms')})"
+done
