@@ -301,9 +301,11 @@ __global__ __launch_bounds__(256) void layer_norm_fwd_wave_kernel(const float* _
 
 // the wave kernel's conditions: contiguous rows of D <= 2048 floats, D % 4 == 0, 16-byte aligned operands
 static bool ln_wave_ok(const float* a, const float* x, int64_t lda, int64_t ldx, const float* gamma, const float* beta,
-                       const float* sum_out, int64_t lds, const float* y, int64_t ldy, int64_t D) {
+                       const float* sum_out, int64_t lds, const float* y, int64_t ldy, int64_t D, int64_t rows) {
     static const bool on = !(getenv("NM_LN_FWD_WAVE") && atoi(getenv("NM_LN_FWD_WAVE")) == 0);
-    return on && D % 4 == 0 && D <= 2048 && ldx == D && ldy == D && (!a || lda == D) && (!sum_out || lds == D) &&
+    // (a decoding step's 128 or 640 rows are a handful of workgroups here and a workgroup each above: measured 2 us per
+    // call slower -- 2.6 ms per Transformer-base greedy batch; the wave kernel is for the B x T rows of training)
+    return on && rows >= 1024 && D % 4 == 0 && D <= 2048 && ldx == D && ldy == D && (!a || lda == D) && (!sum_out || lds == D) &&
            nm_aligned16(x) && nm_aligned16(y) && nm_aligned16(gamma) && nm_aligned16(beta) && (!a || nm_aligned16(a)) &&
            (!sum_out || nm_aligned16(sum_out));
 }
@@ -365,7 +367,7 @@ extern "C" int nm_add_layer_norm_fwd(void* stream, const float* a, int64_t lda, 
     NM_REQUIRE(a && x && gamma && beta && sum_out && y, "nm_add_layer_norm_fwd: null pointer");
     NM_REQUIRE(rows >= 0 && D > 0 && D <= 16384, "nm_add_layer_norm_fwd: bad shape rows=%ld D=%ld", (long)rows, (long)D);
     if (rows == 0) return NM_OK;
-    if (ln_wave_ok(a, x, lda, ldx, gamma, beta, sum_out, lds, y, ldy, D)) {
+    if (ln_wave_ok(a, x, lda, ldx, gamma, beta, sum_out, lds, y, ldy, D, rows)) {
         ln_wave_launch<true>(nm_stream(stream), a, x, gamma, beta, sum_out, y, nullptr, nullptr, rows, D, eps);
         NM_LAUNCH_CHECK("nm_add_layer_norm_fwd");
     }
@@ -382,7 +384,7 @@ extern "C" int nm_add_layer_norm_stats_fwd(void* stream, const float* a, const f
                                            int64_t rows, int64_t D, float eps) {
     NM_REQUIRE(a && x && gamma && beta && sum_out && y && mean_out && rstd_out, "nm_add_layer_norm_stats_fwd: null pointer");
     NM_REQUIRE(rows >= 0 && D > 0, "nm_add_layer_norm_stats_fwd: bad shape");
-    NM_REQUIRE(ln_wave_ok(a, x, D, D, gamma, beta, sum_out, D, y, D, D),
+    NM_REQUIRE(ln_wave_ok(a, x, D, D, gamma, beta, sum_out, D, y, D, D, 1 << 20),
                "nm_add_layer_norm_stats_fwd: D = %ld must be a multiple of 4 up to 2048, operands 16-byte aligned", (long)D);
     if (rows == 0) return NM_OK;
     ln_wave_launch<true>(nm_stream(stream), a, x, gamma, beta, sum_out, y, mean_out, rstd_out, rows, D, eps);
@@ -395,7 +397,7 @@ extern "C" int nm_layer_norm_fwd(void* stream, const float* x, int64_t ldx, cons
     NM_REQUIRE(x && gamma && beta && y, "nm_layer_norm_fwd: null pointer");
     NM_REQUIRE(rows >= 0 && D > 0, "nm_layer_norm_fwd: bad shape");
     if (rows == 0) return NM_OK;
-    if (ln_wave_ok(nullptr, x, 0, ldx, gamma, beta, nullptr, 0, y, ldy, D)) {
+    if (ln_wave_ok(nullptr, x, 0, ldx, gamma, beta, nullptr, 0, y, ldy, D, rows)) {
         ln_wave_launch<false>(nm_stream(stream), nullptr, x, gamma, beta, nullptr, y, mean_out, rstd_out, rows, D, eps);
         NM_LAUNCH_CHECK("nm_layer_norm_fwd");
     }

@@ -947,7 +947,10 @@ def test_layer_norm_forward_kernels(dev, rows, d):
     if ops.add_layer_norm_stats_ok(ad, xd, gd, bd):
         s2, o2 = torch.empty_like(xd), torch.empty_like(xd)
         ops.add_layer_norm_stats_fwd(ad, xd, gd, bd, s2, o2, mean, rstd)
-        assert torch.equal(s2, s1) and torch.equal(o2, o1)          # the same kernel as nm_add_layer_norm_fwd
+        # (from 1024 rows on nm_add_layer_norm_fwd runs this very kernel; below, a workgroup per row sums in another order)
+        assert torch.equal(s2, s1) and torch.allclose(o2, o1, rtol=2e-5, atol=2e-5)
+        if rows >= 1024:
+            assert torch.equal(o2, o1)
         assert np.abs(mean.cpu().numpy() - mu2).max() <= 1e-5 and rel_err(rstd.cpu().numpy(), rs2) <= 1e-5
     else:
         assert d % 4 != 0 or d > 2048
