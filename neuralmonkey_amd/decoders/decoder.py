@@ -321,11 +321,11 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
             for t in range(steps):
                 self._recurrent(ctx, cell, xp, t, bsz * 3 * h, s_ext[t], s_all[t], ru_all[t], c_all[t], bufs,
                                 rh=rh_all[t], wt=wt)
-        if gru.cluster_ok(ctx.session, bsz, h, 1, cell["wg_h"], cell["wc_h"]):
-            # the whole recurrence as ONE launch (csrc/nm_gru_cluster.hip)
-            ops.gru_seq_fwd(steps, 1, bsz, h, xp, (0, 3 * h, bsz * 3 * h), s_ext[0], s_ext[1], bsz * h,
-                            ru_all[0], bsz * 2 * h, rh_all[0], bsz * h, c_all[0], bsz * h, cell["wg_h"],
-                            cell["wc_h"], gru.cluster_workspace(ctx, id(self), bsz, h, 1), sticky=ctx.session.error_word())
+        loop_h = gru.seq_mode(ctx.session, bsz, h, 1, cell["wg_h"], cell["wc_h"])
+        if loop_h:
+            # the whole recurrence as ONE launch (csrc/nm_gru_cluster.hip; padded when the kernels do not take h)
+            gru.seq_fwd(ctx, id(self), loop_h, steps, 1, bsz, h, xp, (0, 3 * h, bsz * 3 * h), s_ext[0], s_ext[1], bsz * h,
+                        ru_all[0], bsz * 2 * h, rh_all[0], bsz * h, c_all[0], bsz * h, cell["wg_h"], cell["wc_h"])
         else:
             ctx.session.graphed((id(self), "train_loop", bsz, steps), time_loop)
         if overlap:
@@ -469,11 +469,12 @@ class Decoder(GeneralDecoderMixin, AutoregressiveDecoder):
             gru.bptt(steps, dh, d_s, seq_strides, sv["ru_all"], sv["c_all"], sv["s0"], s_all, seq_strides, dxp,
                      dxp_strides, cell["wg_h"].unsqueeze(0), cell["wc_h"].unsqueeze(0), None, 1, bsz, h, False,
                      dgpre, dcpre, drh)
-        if gru.cluster_ok(ctx.session, bsz, h, 1, cell["wg_h"], cell["wc_h"]):
+        loop_h = gru.seq_mode(ctx.session, bsz, h, 1, cell["wg_h"], cell["wc_h"])
+        if loop_h:
             ops.zero(dh)
-            ops.gru_seq_bwd(steps, 1, bsz, h, dh, d_s, seq_strides, sv["ru_all"][0], bsz * 2 * h, sv["c_all"][0],
-                            bsz * h, sv["s0"], s_all, seq_strides, dxp, dxp_strides, cell["wg_h"], cell["wc_h"],
-                            gru.cluster_workspace(ctx, id(self), bsz, h, 1), sticky=ctx.session.error_word())
+            gru.seq_bwd(ctx, id(self), loop_h, steps, 1, bsz, h, dh, d_s, seq_strides, sv["ru_all"][0], bsz * 2 * h,
+                        sv["c_all"][0], bsz * h, sv["s0"], s_all, seq_strides, dxp, dxp_strides, cell["wg_h"],
+                        cell["wc_h"])
             if dp is not None:
                 dp.after_time_loops()
         else:

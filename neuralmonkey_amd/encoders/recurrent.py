@@ -212,16 +212,16 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
                 gru.step_fwd(xp, (3 * h, xrs, xts), hcur, hcur, wg_f, wc_f, ru, rh, c_all[t] if train else None,
                              states_raw, (h, ors, ots), len_arg, t, ndir, bsz, h, reverse_only, hg, hc,
                              transposed=fused)
-        if gru.cluster_ok(ctx.session, bsz, h, ndir, wgh, wch):
-            # both directions, all positions: ONE launch (csrc/nm_gru_cluster.hip)
+        loop_h = gru.seq_mode(ctx.session, bsz, h, ndir, wgh, wch)
+        if loop_h:
+            # both directions, all positions: ONE launch (csrc/nm_gru_cluster.hip); a hidden size the kernels do not
+            # take (300) runs at the next one they do, on zero-padded operands (nn/gru.py: seq_fwd)
             ctx.session.start_deferred_side()      # work that waits for a time loop to hide under (Session.defer_side)
             ops.zero(states_raw)
             ops.zero(hcur)
-            ops.gru_seq_fwd(slen, ndir, bsz, h, xp, (3 * h, xrs, xts), hcur, hcur, 0, ru_all[0],
-                            ndir * bsz * 2 * h if train else 0, None, 0, c_all[0] if train else None,
-                            ndir * bsz * h, wgh, wch, gru.cluster_workspace(ctx, key, bsz, h, ndir), lengths=len_arg,
-                            sticky=ctx.session.error_word(),
-                            reverse_dir0=reverse_only, out=states_raw, out_strides=(h, ors, ots))
+            gru.seq_fwd(ctx, key, loop_h, slen, ndir, bsz, h, xp, (3 * h, xrs, xts), hcur, hcur, 0, ru_all[0],
+                        ndir * bsz * 2 * h if train else 0, None, 0, c_all[0] if train else None, ndir * bsz * h, wgh,
+                        wch, lengths=len_arg, reverse_dir0=reverse_only, out=states_raw, out_strides=(h, ors, ots))
         else:
             ctx.session.start_deferred_side()
             ctx.session.graphed((key, "fwd_loop", bsz, slen, train), time_loop)
@@ -288,11 +288,12 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
         seq_strides = (h, slen * c_out, c_out)
         dxp_strides = (3 * h, slen * ndir * 3 * h, ndir * 3 * h)
         wgh, wch = sv["wgh"], sv["wch"]
-        if gru.cluster_ok(ctx.session, bsz, h, ndir, wgh, wch):
-            ops.gru_seq_bwd(slen, ndir, bsz, h, dh, d_states_raw, seq_strides if d_states_raw is not None else None,
-                            sv["ru_all"][0], ndir * bsz * 2 * h, sv["c_all"][0], ndir * bsz * h, None, states_raw,
-                            seq_strides, dxp, dxp_strides, wgh, wch, gru.cluster_workspace(ctx, id(self), bsz, h, ndir),
-                            lengths=lengths, reverse_dir0=rev0, sticky=ctx.session.error_word())
+        loop_h = gru.seq_mode(ctx.session, bsz, h, ndir, wgh, wch)
+        if loop_h:
+            gru.seq_bwd(ctx, id(self), loop_h, slen, ndir, bsz, h, dh, d_states_raw,
+                        seq_strides if d_states_raw is not None else None, sv["ru_all"][0], ndir * bsz * 2 * h,
+                        sv["c_all"][0], ndir * bsz * h, None, states_raw, seq_strides, dxp, dxp_strides, wgh, wch,
+                        lengths=lengths, reverse_dir0=rev0)
             from .. import distributed
             if distributed.current() is not None:
                 distributed.current().after_time_loops()

@@ -35,6 +35,10 @@ def T(x, dev, dtype=torch.float32):
     (1024, 2048, 256, True, False, 1),      # TN weight-gradient form
     (512, 384, 640, False, True, 1),
     (37, 1000, 8, False, False, 0),
+    (80, 260, 520, False, False, 0),        # skinny, K = 16 * 16 * 2 + 8: the last eight k-values belong to the last wave
+    (80, 264, 264, False, True, 0),         # K = 16 * 16 + 8
+    (16, 64, 776, False, False, 3),         # K = 16 * 16 * 3 + 8, skinny forced
+    (90, 520, 264, False, False, 0),
     (512, 1024, 6400, True, False, 0),      # weight-gradient form, deep K -> split-K slabs
     (640, 512, 8192, False, True, 0),       # dlogits . W^T form -> split-K
     (96, 136, 4096, True, True, 2),         # split-K on the 64 tile, ragged
