@@ -1,3 +1,2 @@
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_cluster_pad_gpu.py -q --timeout=200 2>&1 | grep -v "amdgpu.ids" | grep -E "^FAILED|AssertionError|passed|failed" | cut -c1-300 | head -20
-timeout 600 python -m pytest tests/test_kernels_gpu.py -q --timeout=200 -x 2>&1 | grep -v "amdgpu.ids" | grep -E "^FAILED|AssertionError|passed|failed" | cut -c1-300 | head -5
+timeout 1200 python -m pytest tests/test_size_sweep_gpu.py -q --timeout=300 2>&1 | grep -v "amdgpu.ids" | grep -E "^FAILED|^E   |passed|failed" | cut -c1-330 | head -60
