@@ -73,3 +73,108 @@ def test_training_step_and_decoding_at_untuned_sizes(dev, h, e, a, v, b, s, t, s
         if err > 1e-3:
             bad[name] = err
     assert not bad, bad
+
+
+def _transformer_cases():
+    rng = np.random.default_rng(77)
+    out = []
+    for i in range(14):
+        heads = int(rng.choice([1, 2, 4, 8]))
+        dh = int(rng.choice([2, 4, 8, 16, 33, 64]))
+        d = heads * dh
+        ff = int(rng.choice([8, 20, 64, 132, 512]))
+        depth = int(rng.choice([1, 2, 3]))
+        if i < 8:
+            b, s, t = int(rng.choice([1, 3, 9, 20])), int(rng.choice([1, 4, 11, 23])), int(rng.choice([1, 5, 12]))
+        else:                # >= 1024 rows of B x T: the wave-per-row layer norm, the residual sum folded into it, its
+            b, s, t = int(rng.choice([48, 64, 90])), int(rng.choice([24, 30])), int(rng.choice([17, 25]))    # backward
+        bias = bool(rng.integers(0, 2))
+        out.append((heads, dh, ff, depth, b, s, t, bias, 300 + i))
+    return out
+
+
+@pytest.mark.parametrize("heads,dh,ff,depth,b,s,t,bias,seed", _transformer_cases())
+def test_transformer_training_step_and_greedy_at_untuned_sizes(dev, heads, dh, ff, depth, b, s, t, bias, seed):
+    """The same for the Transformer (oracle.transformer_ref): model width = heads x head width, including widths that
+    are no multiple of 4 (every vector path falls back) and batches of >= 1024 rows (the round-6 training kernels)."""
+    from oracle import transformer_ref as TRF
+    from tests.test_transformer_gpu import _build, _data
+    d = heads * dh
+    max_len = max(s, t + 1)
+    cfg = TRF.TConfig(depth=depth, n_heads=heads, n_heads_self=heads, n_heads_enc=heads, use_att_transform_bias=bias)
+    m = _build(dev, cfg, d, ff, max_len=max_len, seed=seed, init_std=0.3)
+    ds, src, tgt = _data(b, s, t, max_len, seed=seed + 1)
+    ref = TRF.TransformerModel(m["params"], cfg, requires_grad=True)
+    ref_loss, ref_g = ref.train_grads(src, tgt, train=True)
+    res = m["tfm"].execute(ds, m["trainer"].feedables, [m["trainer"]], train=True)[0]
+    assert abs(res.losses[cfg.dec_name + " - cost"] - ref_loss) < 1e-4 * abs(ref_loss)
+    store = m["store"]
+    gmax = max(float(np.abs(g).max()) for g in ref_g.values() if g is not None)
+    bad = {}
+    for name in store.names():
+        got = store.g(name).cpu().numpy().reshape(-1)
+        want = ref_g[name]
+        want = np.zeros_like(got) if want is None else want.reshape(-1)
+        err = float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-3 * gmax))
+        if err > 1e-3:
+            bad[name] = err
+    assert not bad, bad
+    if b <= 20:
+        store.load_state_dict(m["params"])
+        dsd, srcd, _ = _data(b, s, t, max_len, seed=seed + 2, with_target=False)
+        ref2 = TRF.TransformerModel(m["params"], cfg)
+        sym, mask, _ = ref2.greedy(srcd, max_len)
+        dec = m["dec"]
+        fd = {}
+        for part in (m["enc"].input_sequence, m["enc"], dec):
+            fd.update(part.feed_dict(dsd, train=False))
+        out = m["tfm"].sessions[0].run({"sym": dec.decoded_symbols, "mask": dec.runtime_mask}, fd)
+        assert np.array_equal(out["sym"], sym) and np.array_equal(out["mask"].astype(bool), mask)
+
+
+def _general_cases():
+    rng = np.random.default_rng(991)
+    out = []
+    for i in range(16):
+        h = int(rng.choice([4, 6, 8, 12, 20, 36, 64] if i < 13 else [256]))
+        direction = str(rng.choice(["bidirectional", "forward", "backward"]))
+        cell = str(rng.choice(["NematusGRU", "GRU", "LSTM"])) if i < 13 else "NematusGRU"
+        dec_cell = str(rng.choice(["NematusGRU", "GRU", "LSTM"]))
+        cond = bool(rng.integers(0, 2)) and dec_cell != "LSTM"
+        r = int(rng.choice([4, 8, 12, 16, 36]))
+        es, et = int(rng.choice([4, 8, 10, 12, 20])), int(rng.choice([4, 8, 12, 20]))
+        # batches of 16 / 32 / 48 rows: the steps' weight and bias gradients go through the chained products
+        # (Tape.defer_wgrad: rows % 16 == 0); the others launch one product per step
+        b = int(rng.choice([16, 32, 48] if i % 2 == 0 else [1, 5, 9, 21]))
+        s, t = int(rng.choice([2, 5, 9])), int(rng.choice([1, 4, 7]))
+        out.append((h, direction, cell, dec_cell, cond, r, es, et, b, s, t, 500 + i))
+    return out
+
+
+@pytest.mark.parametrize("h,direction,cell,dec_cell,cond,r,es,et,b,s,t,seed", _general_cases())
+def test_general_path_training_step_at_untuned_sizes(dev, h, direction, cell, dec_cell, cond, r, es, et, b, s, t, seed):
+    """The taped general path (oracle.general_ref): cell types, directions, conditional GRU and sizes drawn at random;
+    half of the batches are multiples of 16 rows, where the per-step weight / bias gradients are chained products
+    (nm_gemm_f32_chain / nm_colsum_chain), the fused and merged NematusGRU cell steps wherever the sizes allow."""
+    from oracle import general_ref as G
+    from tests.test_general_gpu import _build, _data
+    cfg = G.Config(rnn_layers=((h, direction, cell),), dec_cell=dec_cell, conditional_gru=cond, rnn_size=r)
+    max_len = max(s, t + 1)
+    m = _build(dev, cfg, es, et, max_len=max_len, seed=seed, init_std=0.3 if h < 100 else 0.08)
+    ds, src, tgt = _data(b, s, t, max_len, seed=seed + 1)
+    ref = G.GeneralModel(m["params"], cfg, requires_grad=True)
+    ref_loss, ref_g = ref.train_grads(src, tgt, train=True)
+    res = m["tfm"].execute(ds, m["trainer"].feedables, [m["trainer"]], train=True)[0]
+    assert abs(res.losses[cfg.dec_name + " - cost"] - ref_loss) < 1e-4 * abs(ref_loss)
+    store = m["store"]
+    bad = {}
+    for name in store.names():
+        got = store.g(name).cpu().numpy().reshape(-1)
+        want = ref_g[name]
+        want = np.zeros_like(got) if want is None else want.reshape(-1)
+        if name.endswith("attn_bias"):
+            continue
+        err = float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-6))
+        if err > 1e-3:
+            bad[name] = err
+    assert not bad, bad
