@@ -161,6 +161,9 @@ int nm_gru_seq_force_give_up(int32_t launches);
 /* Test utility: `blocks` workgroups that each hold `lds_bytes` of LDS on a CU for `microseconds` (sleeping): what a
  * long-running kernel of another stream or process does to a cluster loop launched meanwhile. */
 int nm_gru_seq_test_hog(void* stream, int32_t blocks, int64_t lds_bytes, int64_t microseconds);
+/* Test utility: the XCD (0..7) every workgroup of a `blocks` x `threads` launch landed on, into xcc_out[block].  The
+ * wide attention step and the GEMM tile order rest their speed (not their results) on round-robin dispatch. */
+int nm_test_xcc_ids(void* stream, int32_t* xcc_out, int32_t blocks, int32_t threads);
 int nm_gru_seq_fwd(void* stream, const nm_gru_epilogue* e, int32_t steps, int64_t h_step, int64_t ru_step,
                    int64_t rh_step, int64_t c_step, const float* wgh, int64_t ld_g, int64_t stride_g,
                    const float* wch, int64_t ld_c, int64_t stride_c, void* workspace,

@@ -57,6 +57,7 @@ SIGNATURES = {
     "nm_gru_seq_failed": (I, [P]),
     "nm_gru_seq_force_give_up": (I, [ctypes.c_int32]),
     "nm_gru_seq_test_hog": (I, [P, ctypes.c_int32, L, L]),
+    "nm_test_xcc_ids": (I, [P, P, ctypes.c_int32, ctypes.c_int32]),
     "nm_create": (I, [I, P]),
     "nm_destroy": (I, [P]),
     "nm_ctx_bind": (I, [P]),

@@ -1059,6 +1059,24 @@ extern "C" int nm_gru_seq_test_hog(void* stream, int32_t blocks, int64_t lds_byt
     NM_LAUNCH_CHECK("nm_gru_seq_test_hog");
 }
 
+// Test utility: which XCD every workgroup of a launch of ``blocks`` x ``threads`` landed on (HW_REG_XCC_ID), written to
+// xcc_out[blockIdx.x].  Two kernels rest their SPEED (never their results) on the dispatcher dealing consecutive
+// workgroups to the XCDs round-robin: attn_whole_wide (blocks i and i + 8 share an L2) and gemm_tiled's tile order.
+__global__ void xcc_probe_kernel(int* __restrict__ out) {
+    if (threadIdx.x == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        out[blockIdx.x] = (int)(xcc & 7u);
+    }
+}
+
+extern "C" int nm_test_xcc_ids(void* stream, int32_t* xcc_out, int32_t blocks, int32_t threads) {
+    NM_REQUIRE(xcc_out && blocks > 0 && blocks <= 65536 && threads >= 64 && threads <= 1024 && threads % 64 == 0,
+               "nm_test_xcc_ids: bad arguments");
+    hipLaunchKernelGGL(xcc_probe_kernel, dim3((unsigned)blocks), dim3((unsigned)threads), 0, nm_stream(stream), xcc_out);
+    NM_LAUNCH_CHECK("nm_test_xcc_ids");
+}
+
 static void clu_fill(GruClu& q, const nm_gru_epilogue* e) {
     GruEpi& d = q.e;
     d.mode = 0; d.lengths = e->lengths; d.t = 0; d.rev_mask = e->rev_mask; d.H = (int)e->H; d.R = e->R;

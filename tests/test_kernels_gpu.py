@@ -958,3 +958,21 @@ def test_layer_norm_forward_kernels(dev, rows, d):
         assert np.abs(mean.cpu().numpy() - mu2).max() <= 1e-5 and rel_err(rstd.cpu().numpy(), rs2) <= 1e-5
     else:
         assert d % 4 != 0 or d > 2048
+
+
+@pytest.mark.parametrize("blocks,threads", [(256, 1024), (272, 1024), (800, 256), (2048, 512)])
+def test_workgroups_are_dealt_round_robin_to_the_xcds(dev, blocks, threads):
+    """What attn_whole_wide (the two halves of a sentence are workgroups i and i + 8: one XCD, one L2 -- DESIGN 4.2) and
+    gemm_tiled's XCD-aware tile order rest their SPEED on, checked where the cluster kernels check it at run time: on an
+    idle device workgroup i of a launch lands on XCD i mod 8 (HW_REG_XCC_ID)."""
+    from neuralmonkey_amd import _lib
+    lib = _lib.load()
+    out = torch.full((blocks,), -1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    _lib.check(lib.nm_test_xcc_ids(torch.cuda.current_stream().cuda_stream, out.data_ptr(), blocks, threads),
+               "nm_test_xcc_ids")
+    ids = out.cpu().numpy()
+    assert ids.min() >= 0 and ids.max() <= 7 and len(set(ids.tolist())) == 8
+    first = ids[:8]
+    assert sorted(first.tolist()) == list(range(8)), first            # eight consecutive workgroups: eight XCDs
+    assert (ids == np.tile(first, blocks // 8 + 1)[:blocks]).all()    # ... and the deal repeats: i and i + 8 share one

@@ -1,2 +1,2 @@
 export TMPDIR=/tmp
-timeout 1200 python -m pytest tests/test_size_sweep_gpu.py -q --timeout=300 -k general 2>&1 | grep -v "amdgpu.ids" | grep -E "^FAILED|^E   |passed|failed" | cut -c1-400 | head -60
+timeout 300 python -m pytest tests/test_kernels_gpu.py -q --timeout=100 -k "round_robin" 2>&1 | grep -v "amdgpu.ids" | grep -E "^FAILED|^E   |passed|failed" | cut -c1-400 | head -10
