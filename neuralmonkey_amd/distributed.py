@@ -563,12 +563,12 @@ class DataParallel:
             everything = tables.chunk_list(ranges + tails)
             tables.partials(store.theta, grad, l1_weight, l2_weight, None, chunk_list=everything)
             if self.rank != 0 and tails:         # (pass 1 also adds the regulariser terms to the tails' gradient)
-                mask = self.__dict__.setdefault("_tail_masks", {}).get(id(tables))
+                mask = tables.__dict__.get("_tail_mask")          # (kept on the tables: it lives as long as they do)
                 if mask is None:
                     mask = torch.ones_like(partial)
                     for b, e in tails:
                         mask[3 * b:3 * e] = 0.0
-                    self._tail_masks[id(tables)] = mask
+                    tables.__dict__["_tail_mask"] = mask
                 if partial.is_cuda:
                     ops.ew("mul", partial, mask, partial)
                 else:

@@ -375,8 +375,10 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
             stride = store.offset(names[k][1]) - base if ndir == 2 else 0
             return theta.as_strided((ndir, h, ncols), (stride, ncols, 1), base)
         ug, uc = dir_batch("gates/state_proj/kernel", 2 * h), dir_batch("candidate/state_proj/kernel", h)
-        if not gru.cluster_ok(ctx.session, bsz, h, ndir, ug, uc):
+        q = gru.seq_mode(ctx.session, bsz, h, ndir, ug, uc)      # the hidden size the loops run at: h, or h padded
+        if not q:
             return None
+        padded = q != h         # blocks of width h at offsets that are multiples of q; the rest zero (nn/gru.py)
         use_sb, use_ib = cells[0].use_state_bias, cells[0].use_input_bias
         rev0 = spec.direction == "backward"
         width = ndir * h
@@ -391,73 +393,90 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
         b_ci = [p(c, "candidate/input_proj/bias") if use_ib else None for c in cells]
         b_gs = [p(c, "gates/state_proj/bias") if use_sb else None for c in cells]
         b_cs = [p(c, "candidate/state_proj/bias") if use_sb else None for c in cells]
+        key = (id(self), "nematus", layer)
+        if padded:
+            ug, uc = gru._pad_weights(ctx, key, ug, uc, h, q)       # pylint: disable=protected-access
+        # the reset / update halves of the gates: one block [0, 2h) when nothing is padded, else two of width h
+        gate_cols = [(0, 2 * h, 0)] if not padded else [(0, h, 0), (h, 2 * h, q)]
         bgs = bcs = None
-        if use_sb:                                  # the loops read the state biases as [ndir, 2H] / [ndir, H]
-            bgs, bcs = tape.buf((ndir, 2 * h)), tape.buf((ndir, h))
+        if use_sb:                                  # the loops read the state biases as [ndir, 2q] / [ndir, q]
+            bgs, bcs = tape.buf((ndir, 2 * q), zero=padded), tape.buf((ndir, q), zero=padded)
             for d in range(ndir):
-                ops.copy_cols(b_gs[d].data.view(1, -1), bgs[d:d + 1])
-                ops.copy_cols(b_cs[d].data.view(1, -1), bcs[d:d + 1])
+                for lo, hi, off in gate_cols:
+                    ops.copy_cols(b_gs[d].data[lo:hi].view(1, -1), bgs[d:d + 1, off:off + hi - lo])
+                ops.copy_cols(b_cs[d].data.view(1, -1), bcs[d:d + 1, :h])
 
-        xp = tape.buf((bsz * slen, ndir * 3 * h))
+        xp = tape.buf((bsz * slen, ndir * 3 * q), zero=padded)
         for d in range(ndir):
-            ops.gemm(x.data, w_gi[d].data, out=xp[:, d * 3 * h:d * 3 * h + 2 * h],
-                     bias=None if b_gi[d] is None else b_gi[d].data)
-            ops.gemm(x.data, w_ci[d].data, out=xp[:, d * 3 * h + 2 * h:(d + 1) * 3 * h],
+            for lo, hi, off in gate_cols:
+                ops.gemm(x.data, w_gi[d].data[:, lo:hi], out=xp[:, d * 3 * q + off:d * 3 * q + off + hi - lo],
+                         bias=None if b_gi[d] is None else b_gi[d].data[lo:hi])
+            ops.gemm(x.data, w_ci[d].data, out=xp[:, d * 3 * q + 2 * q:d * 3 * q + 2 * q + h],
                      bias=None if b_ci[d] is None else b_ci[d].data)
         out, final = tape.new((bsz * slen, width)), tape.new((bsz, width))
-        hcur, hzero = tape.buf((ndir, bsz, h)), tape.buf((ndir, bsz, h), zero=True)
+        out_q = tape.buf((bsz * slen, ndir * q)) if padded else out.data
+        hcur, hzero = tape.buf((ndir, bsz, q)), tape.buf((ndir, bsz, q), zero=True)
         rec = tape.recording
         nsave = slen if rec else 1
-        ru_all, c_all, sc_all = (tape.buf((nsave, ndir, bsz, 2 * h)), tape.buf((nsave, ndir, bsz, h)),
-                                 tape.buf((nsave, ndir, bsz, h)))
-        ws = ctx.buffer((id(self), "nematus_ws", layer), (ops.nematus_seq_workspace_floats(bsz, h, ndir),))
-        ops.zero(out.data)
-        xrs, xts = slen * ndir * 3 * h, ndir * 3 * h
-        seq_strides = (h, slen * width, width)
-        ops.nematus_seq_fwd(slen, ndir, bsz, h, xp, (3 * h, xrs, xts), hzero, hcur, 0, ru_all[0],
-                            ndir * bsz * 2 * h if rec else 0, sc_all[0], ndir * bsz * h if rec else 0, c_all[0],
-                            ndir * bsz * h if rec else 0, ug, uc, ws, bgs=bgs, bcs=bcs, lengths=lengths,
-                            reverse_dir0=rev0, out=out.data, out_strides=seq_strides, sticky=ctx.session.error_word())
+        ru_all, c_all, sc_all = (tape.buf((nsave, ndir, bsz, 2 * q)), tape.buf((nsave, ndir, bsz, q)),
+                                 tape.buf((nsave, ndir, bsz, q)))
+        ws = ctx.buffer(key + ("ws",), (ops.nematus_seq_workspace_floats(bsz, q, ndir),))
+        ops.zero(out_q)
+        xrs, xts = slen * ndir * 3 * q, ndir * 3 * q
+        seq_strides = (q, slen * ndir * q, ndir * q)
+        ops.nematus_seq_fwd(slen, ndir, bsz, q, xp, (3 * q, xrs, xts), hzero, hcur, 0, ru_all[0],
+                            ndir * bsz * 2 * q if rec else 0, sc_all[0], ndir * bsz * q if rec else 0, c_all[0],
+                            ndir * bsz * q if rec else 0, ug, uc, ws, bgs=bgs, bcs=bcs, lengths=lengths,
+                            reverse_dir0=rev0, out=out_q, out_strides=seq_strides, sticky=ctx.session.error_word())
+        if padded:
+            gru._blocks(out.data, out_q, ndir, 1, h, q, back=True)       # pylint: disable=protected-access
         for d in range(ndir):
-            ops.copy_cols(hcur[d], final.data[:, d * h:(d + 1) * h])
+            ops.copy_cols(hcur[d][:, :h], final.data[:, d * h:(d + 1) * h])
 
         def bwd():
             if out.grad is None and final.grad is None:
                 return
-            dh = tape.buf((ndir, bsz, h))
+            dh = tape.buf((ndir, bsz, q), zero=padded or final.grad is None)
             if final.grad is not None:
                 for d in range(ndir):
-                    ops.copy_cols(final.grad[:, d * h:(d + 1) * h], dh[d])
-            else:
-                ops.zero(dh)
-            dxp = tape.buf((bsz * slen, ndir * 4 * h), zero=True)
-            ops.nematus_seq_bwd(slen, ndir, bsz, h, dh, out.grad, seq_strides if out.grad is not None else None,
-                                ru_all[0], ndir * bsz * 2 * h, sc_all[0], ndir * bsz * h, c_all[0], ndir * bsz * h,
-                                None, out.data, seq_strides, dxp, (4 * h, slen * ndir * 4 * h, ndir * 4 * h), ug, uc,
+                    ops.copy_cols(final.grad[:, d * h:(d + 1) * h], dh[d][:, :h])
+            dout = out.grad
+            if padded and dout is not None:
+                dout = tape.buf((bsz * slen, ndir * q), zero=True)
+                gru._blocks(out.grad, dout, ndir, 1, h, q)                # pylint: disable=protected-access
+            dxp = tape.buf((bsz * slen, ndir * 4 * q), zero=True)
+            ops.nematus_seq_bwd(slen, ndir, bsz, q, dh, dout, seq_strides if dout is not None else None,
+                                ru_all[0], ndir * bsz * 2 * q, sc_all[0], ndir * bsz * q, c_all[0], ndir * bsz * q,
+                                None, out_q, seq_strides, dxp, (4 * q, slen * ndir * 4 * q, ndir * 4 * q), ug, uc,
                                 ws, lengths=lengths, reverse_dir0=rev0, sticky=ctx.session.error_word())
-            hprev = tape.buf((bsz, slen, ndir, h))
-            ops.gru_seq_shift(out.data.view(bsz, slen, width), hprev, lengths, ndir, h, reverse_dir0=rev0)
-            hp2 = hprev.view(bsz * slen, width)
+            hprev = tape.buf((bsz, slen, ndir, q))
+            ops.gru_seq_shift(out_q.view(bsz, slen, ndir * q), hprev, lengths, ndir, q, reverse_dir0=rev0)
+            hp2 = hprev.view(bsz * slen, ndir * q)
             gx, acc = tape.grad_slot(x) if x.needs_grad else (None, False)
             for d in range(ndir):
-                dg = dxp[:, d * 4 * h:d * 4 * h + 2 * h]
-                dc = dxp[:, d * 4 * h + 2 * h:d * 4 * h + 3 * h]
-                dsc = dxp[:, d * 4 * h + 3 * h:(d + 1) * 4 * h]
-                hp = hp2[:, d * h:(d + 1) * h]
-                ops.gemm(x.data, dg, out=tape.grad(w_gi[d]), trans_a=True, accumulate=True)
+                base = d * 4 * q
+                dc = dxp[:, base + 2 * q:base + 2 * q + h]
+                dsc = dxp[:, base + 3 * q:base + 3 * q + h]
+                hp = hp2[:, d * q:d * q + h]
+                for lo, hi, off in gate_cols:
+                    dg = dxp[:, base + off:base + off + hi - lo]
+                    ops.gemm(x.data, dg, out=tape.grad(w_gi[d])[:, lo:hi], trans_a=True, accumulate=True)
+                    ops.gemm(hp, dg, out=tape.grad(w_gs[d])[:, lo:hi], trans_a=True, accumulate=True)
+                    if use_ib:
+                        ops.colsum(dg, tape.grad(b_gi[d])[lo:hi], accumulate=True)
+                    if use_sb:
+                        ops.colsum(dg, tape.grad(b_gs[d])[lo:hi], accumulate=True)
+                    if gx is not None:
+                        ops.gemm(dg, w_gi[d].data[:, lo:hi], out=gx, trans_b=True, accumulate=acc)
+                        acc = True
                 ops.gemm(x.data, dc, out=tape.grad(w_ci[d]), trans_a=True, accumulate=True)
-                ops.gemm(hp, dg, out=tape.grad(w_gs[d]), trans_a=True, accumulate=True)
                 ops.gemm(hp, dsc, out=tape.grad(w_cs[d]), trans_a=True, accumulate=True)
                 if use_ib:
-                    ops.colsum(dg, tape.grad(b_gi[d]), accumulate=True)
                     ops.colsum(dc, tape.grad(b_ci[d]), accumulate=True)
                 if use_sb:
-                    ops.colsum(dg, tape.grad(b_gs[d]), accumulate=True)
                     ops.colsum(dsc, tape.grad(b_cs[d]), accumulate=True)
                 if gx is not None:
-                    ops.gemm(dg, w_gi[d].data, out=gx, trans_b=True, accumulate=acc)
                     ops.gemm(dc, w_ci[d].data, out=gx, trans_b=True, accumulate=True)
-                    acc = True
         tape.record(bwd)
         return out, final
 

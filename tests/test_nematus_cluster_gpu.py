@@ -129,7 +129,8 @@ def test_nematus_loops_against_the_oracle(dev, rows, steps, h, ndir, state_bias)
     assert np.abs(dh.cpu().numpy() - h0_64.grad.numpy()).max() <= 1e-4 * max(gscale, np.abs(h0_64.grad.numpy()).max())
 
 
-@pytest.mark.parametrize("direction,h", [("bidirectional", 256), ("backward", 256), ("forward", 384)])
+@pytest.mark.parametrize("direction,h", [("bidirectional", 256), ("backward", 256), ("forward", 384),
+                                         ("bidirectional", 300), ("forward", 260)])      # 300 / 260: padded to 384
 def test_encoder_layer_takes_the_loops_and_matches_the_model_oracle(dev, direction, h, monkeypatch):
     """A model whose NematusGRU encoder layer is wide enough for the cluster kernels: the training step (loss and
     every gradient) against oracle.general_ref, with the loops (and with NM_NEMATUS_CLUSTER=0: the step-by-step tape)."""
