@@ -1,3 +1,4 @@
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_nematus_cluster_gpu.py tests/test_general_gpu.py tests/test_size_sweep_gpu.py -q -x --timeout=300 -k "not untuned_sizes or general" 2>&1 | grep -v "amdgpu.ids" | grep -E "^FAILED|^E   |passed|failed" | cut -c1-400 | head -20
-timeout 600 python tools/general_path_probe.py NM_NEMATUS_CLUSTER 1 2>&1 | grep "NM_NEM" | tail -2
+timeout 1500 python bench.py > gpurun_out/r06_bench_final.json 2> gpurun_out/r06_bench_final.err; echo "bench rc=$?"
+timeout 900 bash tools/attn_evidence.sh r06 > /tmp/attn_ev.log 2>&1; echo "attn rc=$?"; ls gpurun_out/profiles_r06 | head -30
+timeout 900 bash tools/round_evidence.sh r06 > /tmp/round_ev.log 2>&1; echo "round rc=$?"
