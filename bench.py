@@ -253,11 +253,12 @@ def general_path_leg(args, dev):
     batch, length, vocab, h = args.batch, args.length, args.vocab, args.hidden
     reset_registry()
     sv, tv = synthetic.synthetic_vocabulary(vocab), synthetic.synthetic_vocabulary(vocab)
+    cell = os.environ.get("NM_GP_CELL", "NematusGRU")          # (tools/general_path_probe.py: LSTM layers and decoder)
     enc = SentenceEncoder(name="encoder", vocabulary=sv, data_id="source", embedding_size=h, rnn_size=h,
-                          max_input_len=length, rnn_cell="NematusGRU")
+                          max_input_len=length, rnn_cell=cell)
     att = Attention(name="attention", encoder=enc)
     dec = Decoder(encoders=[enc], vocabulary=tv, data_id="target", name="decoder", max_output_len=length,
-                  embedding_size=h, rnn_size=h, attentions=[att], rnn_cell="NematusGRU", conditional_gru=True)
+                  embedding_size=h, rnn_size=h, attentions=[att], rnn_cell=cell, conditional_gru=cell != "LSTM")
     bdec = BeamSearchDecoder(name="beam_decoder", parent_decoder=dec, beam_size=5, max_steps=length,
                              length_normalization=0.6)
     greedy, beam = GreedyRunner(output_series="target", decoder=dec), BeamSearchRunner(output_series="target_beam",

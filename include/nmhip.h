@@ -190,6 +190,17 @@ int nm_nematus_seq_bwd(void* stream, const nm_gru_epilogue* e, int32_t steps, in
                        int64_t c_step, const float* ug, int64_t ld_g, int64_t stride_g, const float* uc,
                        int64_t ld_c, int64_t stride_c, void* workspace, int64_t workspace_bytes,
                        uint32_t* sticky_error);
+/* ... and for LSTMCell (tf.nn.rnn_cell.LSTMCell as the reference builds it: gate order i, j, f, o, forget_bias added to f,
+ * state (c, h), zero initial cell state): one product per step over wh [ndir][H][4H], the state half of the cell's
+ * kernel; xp and dxp are 4H wide per direction; e->ru holds the ACTIVATED gates [i | j | f | o] of every step (g_step
+ * apart), e->c_save / e->c the cell state after every step.  Shapes, workspace ownership and give-up behaviour as
+ * nm_gru_seq_*; h_in and h_out must be different buffers. */
+int64_t nm_lstm_seq_workspace_bytes(int64_t R, int64_t H, int32_t ndir);
+int nm_lstm_seq_fwd(void* stream, const nm_gru_epilogue* e, int32_t steps, int64_t h_step, int64_t g_step, int64_t c_step,
+                    const float* wh, int64_t ld_w, int64_t stride_w, float forget_bias, void* workspace,
+                    int64_t workspace_bytes, uint32_t* sticky_error);
+int nm_lstm_seq_bwd(void* stream, const nm_gru_epilogue* e, int32_t steps, int64_t g_step, int64_t c_step, const float* wh,
+                    int64_t ld_w, int64_t stride_w, void* workspace, int64_t workspace_bytes, uint32_t* sticky_error);
 int nm_gru_seq_shift(void* stream, const float* seq, float* out, const int32_t* lengths, int rev_mask,
                      int64_t B, int64_t S, int ndir, int64_t H);
 int nm_gru_rh_seq(void* stream, const float* ru_all, const float* hprev, float* out,

@@ -46,6 +46,9 @@ SIGNATURES = {
     "nm_gru_gemm": (I, [P, P, I, L, P, L, L, P, L, L]),
     "nm_gru_seq_fwd": (I, [P, P, ctypes.c_int32, L, L, L, L, P, L, L, P, L, L, P, L, P]),
     "nm_gru_seq_bwd": (I, [P, P, ctypes.c_int32, L, L, P, L, L, P, L, L, P, L, P]),
+    "nm_lstm_seq_workspace_bytes": (L, [L, L, ctypes.c_int32]),
+    "nm_lstm_seq_fwd": (I, [P, P, ctypes.c_int32, L, L, L, P, L, L, F, P, L, P]),
+    "nm_lstm_seq_bwd": (I, [P, P, ctypes.c_int32, L, L, P, L, L, P, L, P]),
     "nm_nematus_seq_workspace_bytes": (L, [L, L, ctypes.c_int32]),
     "nm_nematus_seq_fwd": (I, [P, P, ctypes.c_int32, L, L, L, L, P, L, L, P, L, L, P, P, P, L, P]),
     "nm_nematus_seq_bwd": (I, [P, P, ctypes.c_int32, L, L, L, P, L, L, P, L, L, P, L, P]),

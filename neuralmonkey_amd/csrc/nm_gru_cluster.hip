@@ -783,6 +783,220 @@ __global__ __launch_bounds__(512, 3) void nematus_cluster_bwd_kernel(NemClu a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// LSTMCell time loops (tf.nn.rnn_cell.LSTMCell as encoders/recurrent.py:21 and decoders/decoder.py:29 build it: gate
+// order i, j, f, o, forget bias 1.0, state (c, h)), round 6.  z = xp + h.W_h; c' = sigmoid(f + fb) c + sigmoid(i) tanh(j);
+// h' = sigmoid(o) tanh(c').  One product per step (the four gate columns of 16 units per workgroup), one element-wise
+// stage, ONE hand-off (h'); c never leaves its thread.  Saved per step: the activated gates [i | j | f | o] and c'.
+//   backward, step t (last first): dhv = dh + dout; tc = tanh(c'); do' = dhv tc o(1-o); dct = dc + dhv o (1 - tc^2);
+//   di' = dct j i(1-i); dj' = dct i (1-j^2); df' = dct c_prev f(1-f); dc = dct f;
+//   dh = [di' | dj' | df' | do'] . W_h^T   (ONE product, K = 4H);  dxp (4H wide) receives the four pre-activation gradients.
+// ---------------------------------------------------------------------------------------------------------------
+struct LstmClu {
+    GruClu q;                    // e.ru / ru_step: the gates of every step (4H wide); e.c_save / e.c, c_step: c' of every step
+    float forget_bias;
+};
+
+template <int RT>
+__global__ __launch_bounds__(512, 2) void lstm_cluster_fwd_kernel(LstmClu a) {
+    constexpr int NCH = 4;
+    const GruClu& q = a.q;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NW = (int)(blockDim.x >> 6);
+    const int H = q.e.H, R = (int)q.e.R;
+    if (q.force_fail && blockIdx.x == 0 && tid == 0) __hip_atomic_store((gu32*)q.hdr, 1u, NM_RLX_AGENT);
+    const CluRole role = clu_roles(q.hdr, q.ndir * q.nrb, H / 16, reinterpret_cast<int*>(lds), q.force_global);
+    if (!role.active) {
+        if (tid == 0 && q.sticky && __hip_atomic_load((gu32*)q.hdr, NM_RLX_AGENT) != 0) __hip_atomic_store((gu32*)q.sticky, 1u, NM_RLX_AGENT);
+        return;
+    }
+    __builtin_amdgcn_s_setprio(3);
+    const int jb = role.jb;
+    const int d = role.cl / q.nrb, rb = role.cl % q.nrb;
+    const int row0 = rb * 16 * RT;
+    const int n16 = lane & 15, kq = lane >> 4;
+    const int k_wave = wave * 16 * NCH;
+    float* red = lds;                                    // [NW][4 RT][4][64]
+    gu32* err = (gu32*)q.hdr;
+    float wg[4][NCH][4];                                 // this wave's K-slice of the i, j, f, o columns of its 16 units
+    {
+        const float* W = q.wg + (long)d * q.sg + 16 * jb + n16;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    wg[g][c][j] = W[(long)(k_wave + 16 * c + 4 * kq + j) * q.ldg + g * H];
+    }
+    const bool epi = tid < 256 * RT;
+    const int ert = tid >> 8, reg = (tid >> 6) & 3, ln = tid & 63;
+    const int rloc = 4 * (ln >> 4) + reg, col = 16 * jb + (ln & 15);
+    const int row = row0 + 16 * ert + rloc;
+    const bool mine = epi && row < R;
+    const long ro = (long)d * R + min(row, R - 1);
+    const int len = (mine && q.e.lengths) ? q.e.lengths[row] : 0x7fffffff;
+    float hreg = mine ? q.e.h_in[ro * H + col] : 0.0f;
+    float creg = 0.0f;                                   // (zero initial cell state: what the encoders start from)
+    const bool rev = ((q.e.rev_mask >> d) & 1) && q.e.lengths;
+    u64* X0 = q.xa + (long)role.cl * 16 * RT * H;
+    u64* X1 = q.xb + (long)role.cl * 16 * RT * H;
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+
+    for (int t = 0; t < q.steps; ++t) {
+        const bool live = mine && t < len;
+        const int pos = rev ? len - 1 - t : t;
+        float x4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (live) {
+            const float* x = q.e.xp + d * q.e.x_dir + (long)row * q.e.x_row + (long)pos * q.e.x_time + col;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) x4[g] = x[g * H];
+        }
+        u64* Xin = (t & 1) ? X0 : X1;
+        u64* Xout = (t & 1) ? X1 : X0;
+        float av[4][4];
+        CluWait cw;
+        if (t > 0) clu_wait<RT, NCH>(Xin, wave, lane, (unsigned)t, err, cw);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            if (t == 0) clu_load_plain(q.e.h_in + (long)d * R * H, H, R, row0 + 16 * rt, k_wave, lane, av);
+            else clu_gather<RT, NCH>(Xin, wave, lane, rt, 0, (unsigned)t, err, cw, av);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 acc = zero;
+                clu_mma(acc, av, wg[g]);
+                clu_put(red, 4 * RT, wave, 4 * rt + g, lane, acc);
+            }
+        }
+        __syncthreads();
+        if (epi) {
+            float hn = hreg, gi = 0.0f, gj = 0.0f, gf = 0.0f, go = 0.0f;
+            if (live) {
+                gi = nm_sigmoid(x4[0] + clu_get(red, 4 * RT, NW, 4 * ert, reg, ln));
+                gj = nm_tanh(x4[1] + clu_get(red, 4 * RT, NW, 4 * ert + 1, reg, ln));
+                gf = nm_sigmoid(x4[2] + clu_get(red, 4 * RT, NW, 4 * ert + 2, reg, ln) + a.forget_bias);
+                go = nm_sigmoid(x4[3] + clu_get(red, 4 * RT, NW, 4 * ert + 3, reg, ln));
+                creg = gf * creg + gi * gj;
+                hn = go * nm_tanh(creg);
+            }
+            hreg = hn;
+            if (t + 1 < q.steps) clu_publish<RT, NCH>(Xout, role.local, ert, rloc, col, (unsigned)(t + 1), hn);
+            if (mine) {
+                float* gs = q.e.ru + (long)t * q.ru_step + ro * 4 * H;
+                gs[col] = gi; gs[H + col] = gj; gs[2 * H + col] = gf; gs[3 * H + col] = go;
+                q.e.c_save[(long)t * q.c_step + ro * H + col] = creg;
+                q.e.h_out[(long)t * q.h_step + ro * H + col] = hn;
+                if (live && q.e.out)
+                    q.e.out[d * q.e.o_dir + (long)row * q.e.o_row + (long)pos * q.e.o_time + col] = hn;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && q.sticky && __hip_atomic_load(err, NM_RLX_AGENT) != 0) __hip_atomic_store((gu32*)q.sticky, 1u, NM_RLX_AGENT);
+}
+
+template <int RT>
+__global__ __launch_bounds__(512, 2) void lstm_cluster_bwd_kernel(LstmClu a) {
+    constexpr int NCB = 16;                              // 256 k-values per wave of K = 4H
+    const GruClu& q = a.q;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NW = (int)(blockDim.x >> 6);
+    const int H = q.e.H, R = (int)q.e.R;
+    if (q.force_fail && blockIdx.x == 0 && tid == 0) __hip_atomic_store((gu32*)q.hdr, 1u, NM_RLX_AGENT);
+    const CluRole role = clu_roles(q.hdr, q.ndir * q.nrb, H / 16, reinterpret_cast<int*>(lds), q.force_global);
+    if (!role.active) {
+        if (tid == 0 && q.sticky && __hip_atomic_load((gu32*)q.hdr, NM_RLX_AGENT) != 0) __hip_atomic_store((gu32*)q.sticky, 1u, NM_RLX_AGENT);
+        return;
+    }
+    __builtin_amdgcn_s_setprio(3);
+    const int jb = role.jb;
+    const int d = role.cl / q.nrb, rb = role.cl % q.nrb;
+    const int row0 = rb * 16 * RT;
+    const int n16 = lane & 15, kq = lane >> 4;
+    float* red = lds;                                    // [NW][RT][4][64]
+    gu32* err = (gu32*)q.hdr;
+    float w[NCB][4];                                     // row 16 jb + n16 of W_h ([H][4H]): this wave's 256 of its 4H values
+    {
+        const float* W = q.wg + (long)d * q.sg + (long)(16 * jb + n16) * q.ldg + wave * 16 * NCB + 4 * kq;
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+            const float4 v = *reinterpret_cast<const float4*>(W + 16 * c);
+            w[c][0] = v.x; w[c][1] = v.y; w[c][2] = v.z; w[c][3] = v.w;
+        }
+    }
+    const bool epi = tid < 256 * RT;
+    const int ert = tid >> 8, reg = (tid >> 6) & 3, ln = tid & 63;
+    const int rloc = 4 * (ln >> 4) + reg, col = 16 * jb + (ln & 15);
+    const int row = row0 + 16 * ert + rloc;
+    const bool mine = epi && row < R;
+    const long ro = (long)d * R + min(row, R - 1);
+    const int len = (mine && q.e.lengths) ? q.e.lengths[row] : 0x7fffffff;
+    float dh = mine ? q.e.dh[ro * H + col] : 0.0f;
+    float dc = 0.0f;
+    const bool rev = ((q.e.rev_mask >> d) & 1) && q.e.lengths;
+    u64* X0 = q.xa + (long)role.cl * 16 * RT * 4 * H;
+    u64* X1 = q.xb + (long)role.cl * 16 * RT * 4 * H;
+    float sB = 0.0f;
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+
+    for (int i = 0; i < q.steps; ++i) {
+        const int t = q.steps - 1 - i;
+        const bool live = mine && t < len;
+        const int pos = rev ? len - 1 - t : t;
+        u64* X = (i & 1) ? X1 : X0;
+        if (epi) {
+            const float s = (i == 0) ? dh : sB + dh;
+            float dz[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (live) {
+                const float* gs = q.e.ru + (long)t * q.ru_step + ro * 4 * H;
+                const float gi = gs[col], gj = gs[H + col], gf = gs[2 * H + col], go = gs[3 * H + col];
+                const float cn = q.e.c[(long)t * q.c_step + ro * H + col];
+                const float cp = t > 0 ? q.e.c[(long)(t - 1) * q.c_step + ro * H + col] : 0.0f;
+                const float dout = q.e.dout ? q.e.dout[d * q.e.do_dir + (long)row * q.e.do_row + (long)pos * q.e.do_time + col] : 0.0f;
+                const float dhv = s + dout;
+                const float tc = nm_tanh(cn);
+                const float dct = dc + dhv * go * (1.0f - tc * tc);
+                dz[0] = dct * gj * gi * (1.0f - gi);
+                dz[1] = dct * gi * (1.0f - gj * gj);
+                dz[2] = dct * cp * gf * (1.0f - gf);
+                dz[3] = dhv * tc * go * (1.0f - go);
+                dc = dct * gf;
+                dh = 0.0f;                               // all of dh' flows through the gates: the product below
+                float* dx = q.e.dxp + d * q.e.dx_dir + (long)row * q.e.dx_row + (long)pos * q.e.dx_time;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) dx[g * H + col] = dz[g];
+            } else {
+                dh = s;                                  // beyond the sentence: both states are carried
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                clu_publish<RT, NCB>(X, role.local, ert, rloc, g * H + col, (unsigned)(i + 1), dz[g]);
+        }
+        {
+            float av[4][4];
+            CluWait cw;
+            clu_wait<RT, NCB>(X, wave, lane, (unsigned)(i + 1), err, cw);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                f32x4 acc = zero;
+#pragma unroll
+                for (int piece = 0; piece < NCB / 4; ++piece) {
+                    clu_gather<RT, NCB>(X, wave, lane, rt, piece, (unsigned)(i + 1), err, cw, av);
+                    clu_mma(acc, av, w + 4 * piece);
+                }
+                clu_put(red, RT, wave, rt, lane, acc);
+            }
+        }
+        __syncthreads();
+        if (epi) sB = clu_get(red, RT, NW, ert, reg, ln);
+        __syncthreads();
+    }
+    if (mine) q.e.dh[ro * H + col] = sB + dh;
+    if (tid == 0 && q.sticky && __hip_atomic_load(err, NM_RLX_AGENT) != 0) __hip_atomic_store((gu32*)q.sticky, 1u, NM_RLX_AGENT);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // One DECODING step's recurrent part as one launch (round 6): Decoder.next_state up to the attention query
 // (decoders/decoder.py:279-325, plain GRUCell + input tables, what nm_decoder_step_fused launched as three dependent
 // step groups: 7.2 + 7.2 + 9.4 us of kernels and two graph edges per greedy step):
@@ -1334,4 +1548,75 @@ extern "C" int nm_nematus_seq_bwd(void* stream, const nm_gru_epilogue* e, int32_
                                   uint32_t* sticky_error) {
     return nem_launch(true, stream, e, steps, 0, ru_step, sc_step, c_step, ug, ld_g, stride_g, uc, ld_c, stride_c,
                       nullptr, nullptr, workspace, workspace_bytes, sticky_error, "nm_nematus_seq_bwd");
+}
+
+// ---- LSTM loops: host side ------------------------------------------------------------------------------------------
+// workspace: header + two buffers of width 4H (the backward loop's; the forward loop's two of width H fit inside)
+extern "C" int64_t nm_lstm_seq_workspace_bytes(int64_t R, int64_t H, int32_t ndir) {
+    CluShape s;
+    if (!clu_shape(R, H, ndir, &s)) return CLU_HDR_BYTES;
+    return CLU_HDR_BYTES + s.granules * 8 * 8;
+}
+
+static int lstm_launch(bool backward, void* stream, const nm_gru_epilogue* e, int32_t steps, int64_t h_step, int64_t g_step,
+                       int64_t c_step, const float* wh, int64_t ld_w, int64_t stride_w, float forget_bias, void* workspace,
+                       int64_t workspace_bytes, uint32_t* sticky_error, const char* who) {
+    NM_REQUIRE(e && wh && workspace, "%s: null pointer / workspace", who);
+    NM_REQUIRE(steps >= 0 && e->R > 0 && e->H > 0 && e->ndir >= 1 && e->ndir <= 2, "%s: bad shape R=%ld H=%ld", who,
+               (long)e->R, (long)e->H);
+    NM_REQUIRE(nm_aligned16(workspace) && nm_aligned16(wh) && ld_w % 4 == 0 && stride_w % 4 == 0,
+               "%s: kernel / workspace must be 16-byte aligned", who);
+    if (backward) NM_REQUIRE(e->dh && e->ru && e->c && e->dxp, "%s: missing operand", who);
+    else {
+        NM_REQUIRE(e->xp && e->h_in && e->h_out && e->ru && e->c_save && nm_aligned16(e->h_in),
+                   "%s: missing / unaligned operand", who);
+        NM_REQUIRE(e->h_in != e->h_out, "%s: h_in and h_out must be different buffers", who);
+    }
+    CluShape s;
+    NM_REQUIRE(clu_shape(e->R, e->H, e->ndir, &s), "%s: shape R=%ld H=%ld ndir=%d not supported (nm_gru_seq_supported)",
+               who, (long)e->R, (long)e->H, (int)e->ndir);
+    NM_REQUIRE(workspace_bytes >= nm_lstm_seq_workspace_bytes(e->R, e->H, e->ndir), "%s: workspace too small", who);
+    if (steps == 0) return NM_OK;
+    LstmClu a;
+    GruClu& q = a.q;
+    clu_fill(q, e);
+    q.steps = steps; q.nrb = s.nrb;
+    q.h_step = h_step; q.ru_step = g_step; q.rh_step = 0; q.c_step = c_step;
+    q.wg = wh; q.ldg = ld_w; q.sg = stride_w; q.wc = nullptr; q.ldc = 0; q.sc = 0;
+    q.hdr = reinterpret_cast<unsigned*>(workspace);
+    q.sticky = sticky_error;
+    q.xa = reinterpret_cast<u64*>(reinterpret_cast<char*>(workspace) + CLU_HDR_BYTES);
+    q.xb = q.xa + s.granules * 4;
+    a.forget_bias = forget_bias;
+    hipStream_t st = nm_stream(stream);
+    if (hipMemsetAsync(workspace, 0, CLU_HDR_BYTES + (size_t)s.granules * 8 * 8, st) != hipSuccess)
+        NM_FAIL(NM_ERR_HIP, "%s: memset failed", who);
+    const size_t lds = (size_t)s.NW * s.RT * (backward ? 1 : 4) * 1024;
+    bool ok;
+    if (backward) {
+        if (s.RT == 1) { ok = clu_prepare(lstm_cluster_bwd_kernel<1>, lds); if (ok) hipLaunchKernelGGL((lstm_cluster_bwd_kernel<1>), dim3(s.grid), dim3(s.NW * 64), lds, st, a); }
+        else { ok = clu_prepare(lstm_cluster_bwd_kernel<2>, lds); if (ok) hipLaunchKernelGGL((lstm_cluster_bwd_kernel<2>), dim3(s.grid), dim3(s.NW * 64), lds, st, a); }
+    } else {
+        if (s.RT == 1) { ok = clu_prepare(lstm_cluster_fwd_kernel<1>, lds); if (ok) hipLaunchKernelGGL((lstm_cluster_fwd_kernel<1>), dim3(s.grid), dim3(s.NW * 64), lds, st, a); }
+        else { ok = clu_prepare(lstm_cluster_fwd_kernel<2>, lds); if (ok) hipLaunchKernelGGL((lstm_cluster_fwd_kernel<2>), dim3(s.grid), dim3(s.NW * 64), lds, st, a); }
+    }
+    if (!ok) NM_FAIL(NM_ERR_HIP, "%s: the kernel cannot be made resident on this device", who);
+    NM_LAUNCH_CHECK(who);
+}
+
+// e->ru: the activated gates [i | j | f | o] of every step ([steps] x g_step, 4H wide); e->c_save: c' of every step; xp 4H
+// wide per direction; wh [ndir][H][4H]: the state half of the LSTM kernel; zero initial cell state.
+extern "C" int nm_lstm_seq_fwd(void* stream, const nm_gru_epilogue* e, int32_t steps, int64_t h_step, int64_t g_step,
+                               int64_t c_step, const float* wh, int64_t ld_w, int64_t stride_w, float forget_bias,
+                               void* workspace, int64_t workspace_bytes, uint32_t* sticky_error) {
+    return lstm_launch(false, stream, e, steps, h_step, g_step, c_step, wh, ld_w, stride_w, forget_bias, workspace,
+                       workspace_bytes, sticky_error, "nm_lstm_seq_fwd");
+}
+
+// BPTT: e->dh in / out as nm_gru_seq_bwd; e->ru / e->c the saved gates and cell states; dxp 4H wide per direction.
+extern "C" int nm_lstm_seq_bwd(void* stream, const nm_gru_epilogue* e, int32_t steps, int64_t g_step, int64_t c_step,
+                               const float* wh, int64_t ld_w, int64_t stride_w, void* workspace, int64_t workspace_bytes,
+                               uint32_t* sticky_error) {
+    return lstm_launch(true, stream, e, steps, 0, g_step, c_step, wh, ld_w, stride_w, 0.0f, workspace, workspace_bytes,
+                       sticky_error, "nm_lstm_seq_bwd");
 }

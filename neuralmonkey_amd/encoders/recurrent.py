@@ -480,6 +480,74 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
         tape.record(bwd)
         return out, final
 
+    def _lstm_cluster_layer(self, tape, x, bsz: int, slen: int, lengths, layer: int):
+        """One LSTMCell layer (both directions) as ONE tape operation, like ``_nematus_cluster_layer``: z = x.W_x + b of
+        all positions as one product per direction, the time loop as one cluster launch each way (ops.lstm_seq_fwd /
+        lstm_seq_bwd), the kernel's gradient as two products over all positions.  None: the layer stays on the
+        step-by-step tape."""
+        spec = self.rnn_specs[layer]
+        cells = self._cells[layer]
+        ctx = tape.ctx
+        ndir, h = len(cells), spec.size
+        d_in = x.shape[1]
+        if spec.cell_type != "LSTM" or not ctx.session.use_cluster_loops or d_in % 4 or h % 4 or not x.data.is_cuda:
+            return None
+        store = ctx.store
+        names = [self.var_name(c._n("kernel")) for c in cells]               # pylint: disable=protected-access
+        base = store.offset(names[0]) + d_in * 4 * h                         # rows d_in .. d_in + h: the state half
+        stride = store.offset(names[1]) - store.offset(names[0]) if ndir == 2 else 0
+        wh = store.theta.as_strided((ndir, h, 4 * h), (stride, 4 * h, 1), base)
+        if not gru.cluster_ok(ctx.session, bsz, h, ndir, wh, wh):
+            return None
+        rev0 = spec.direction == "backward"
+        width = ndir * h
+        w = [tape.param(self, c._n("kernel")) for c in cells]                # pylint: disable=protected-access
+        b = [tape.param(self, c._n("bias")) for c in cells]                  # pylint: disable=protected-access
+        xp = tape.buf((bsz * slen, ndir * 4 * h))
+        for d in range(ndir):
+            ops.gemm(x.data, w[d].data[:d_in], out=xp[:, d * 4 * h:(d + 1) * 4 * h], bias=b[d].data)
+        out, final = tape.new((bsz * slen, width)), tape.new((bsz, width))
+        hcur, hzero = tape.buf((ndir, bsz, h)), tape.buf((ndir, bsz, h), zero=True)
+        rec = tape.recording
+        nsave = slen if rec else 1
+        gates, c_all = tape.buf((nsave, ndir, bsz, 4 * h)), tape.buf((nsave, ndir, bsz, h))
+        ws = ctx.buffer((id(self), "lstm_ws", layer), (ops.lstm_seq_workspace_floats(bsz, h, ndir),))
+        ops.zero(out.data)
+        seq_strides = (h, slen * width, width)
+        x_strides = (4 * h, slen * ndir * 4 * h, ndir * 4 * h)
+        ops.lstm_seq_fwd(slen, ndir, bsz, h, xp, x_strides, hzero, hcur, 0, gates[0], ndir * bsz * 4 * h if rec else 0,
+                         c_all[0], ndir * bsz * h if rec else 0, wh, ws, forget_bias=1.0, lengths=lengths,
+                         reverse_dir0=rev0, out=out.data, out_strides=seq_strides, sticky=ctx.session.error_word())
+        for d in range(ndir):
+            ops.copy_cols(hcur[d], final.data[:, d * h:(d + 1) * h])
+
+        def bwd():
+            if out.grad is None and final.grad is None:
+                return
+            dh = tape.buf((ndir, bsz, h), zero=final.grad is None)
+            if final.grad is not None:
+                for d in range(ndir):
+                    ops.copy_cols(final.grad[:, d * h:(d + 1) * h], dh[d])
+            dxp = tape.buf((bsz * slen, ndir * 4 * h), zero=True)
+            ops.lstm_seq_bwd(slen, ndir, bsz, h, dh, out.grad, seq_strides if out.grad is not None else None, gates[0],
+                             ndir * bsz * 4 * h, c_all[0], ndir * bsz * h, dxp, x_strides, wh, ws, lengths=lengths,
+                             reverse_dir0=rev0, sticky=ctx.session.error_word())
+            hprev = tape.buf((bsz, slen, ndir, h))
+            ops.gru_seq_shift(out.data.view(bsz, slen, width), hprev, lengths, ndir, h, reverse_dir0=rev0)
+            hp2 = hprev.view(bsz * slen, width)
+            gx, acc = tape.grad_slot(x) if x.needs_grad else (None, False)
+            for d in range(ndir):
+                dz = dxp[:, d * 4 * h:(d + 1) * 4 * h]
+                gw = tape.grad(w[d])
+                ops.gemm(x.data, dz, out=gw[:d_in], trans_a=True, accumulate=True)
+                ops.gemm(hp2[:, d * h:(d + 1) * h], dz, out=gw[d_in:], trans_a=True, accumulate=True)
+                ops.colsum(dz, tape.grad(b[d]), accumulate=True)
+                if gx is not None:
+                    ops.gemm(dz, w[d].data[:d_in], out=gx, trans_b=True, accumulate=acc)
+                    acc = True
+        tape.record(bwd)
+        return out, final
+
     def _general_layer(self, tape, x, bsz: int, slen: int, lengths, layer: int, train: bool):
         """rnn_layer (recurrent.py:71-110) on the tape.  x: Var [B*S, D] -> (outputs Var
         [B*S, ndir*H], final Var [B, ndir*H])."""
@@ -489,6 +557,8 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
         width = ndir * h
         if os.environ.get("NM_NEMATUS_CLUSTER", "1") != "0":      # (read per call: tests compare both schedules)
             fused = self._nematus_cluster_layer(tape, x, bsz, slen, lengths, layer)
+            if fused is None and os.environ.get("NM_LSTM_CLUSTER", "1") != "0":
+                fused = self._lstm_cluster_layer(tape, x, bsz, slen, lengths, layer)
             if fused is not None:
                 return fused
         out = tape.new((bsz * slen, width))

@@ -1134,6 +1134,52 @@ def gru_seq_bwd(steps, ndir, rows, hsz, dh, dout, dout_strides, ru0, ru_step, c0
     _cluster_serialize_after(serial)
 
 
+def lstm_seq_workspace_floats(rows, hsz, ndir) -> int:
+    return _lib.load().nm_lstm_seq_workspace_bytes(rows, hsz, ndir) // 4
+
+
+def lstm_seq_fwd(steps, ndir, rows, hsz, xp, x_strides, h_in0, h_out0, h_step, gates0, g_step, c0, c_step, wh, workspace,
+                 forget_bias=1.0, lengths=None, reverse_dir0=False, out=None, out_strides=(0, 0, 0), sticky=None):
+    """All ``steps`` forward steps of an LSTMCell layer in one launch (nm_lstm_seq_fwd).  ``xp`` 4H wide per direction
+    (i | j | f | o), ``wh`` [ndir,H,4H]: the state half of the kernel, ``gates0`` / ``c0``: where step 0's activated gates
+    and cell state are saved (step t at + t * step elements); zero initial cell state."""
+    lib = _lib.load()
+    e = _lib.GruEpilogue()
+    e.mode, e.t, e.rev_mask, e.ndir, e.R, e.H = 1, 0, _rev_mask(ndir, reverse_dir0), ndir, rows, hsz
+    e.lengths = _p(lengths)
+    e.xp = xp.data_ptr()
+    e.x_dir, e.x_row, e.x_time = x_strides
+    e.h_in, e.h_out, e.ru, e.c_save, e.out = h_in0.data_ptr(), h_out0.data_ptr(), gates0.data_ptr(), c0.data_ptr(), _p(out)
+    e.o_dir, e.o_row, e.o_time = out_strides
+    ld_w, s_w = _dir_strides(wh)
+    serial = _cluster_serialize_before()
+    _lib.check(lib.nm_lstm_seq_fwd(_stream(), ctypes.byref(e), steps, h_step, g_step, c_step, wh.data_ptr(), ld_w, s_w,
+                                   float(forget_bias), workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+                                   _p(sticky)), "nm_lstm_seq_fwd")
+    _cluster_serialize_after(serial)
+
+
+def lstm_seq_bwd(steps, ndir, rows, hsz, dh, dout, dout_strides, gates0, g_step, c0, c_step, dxp, dxp_strides, wh,
+                 workspace, lengths=None, reverse_dir0=False, sticky=None):
+    """The BPTT loop of an LSTMCell layer in one launch (nm_lstm_seq_bwd): ``dh`` [ndir,R,H] holds dL/dh after the last
+    step on entry and dL/dh_0 on exit; ``dxp`` (4H wide per direction) receives the pre-activation gradients."""
+    lib = _lib.load()
+    e = _lib.GruEpilogue()
+    e.mode, e.t, e.rev_mask, e.ndir, e.R, e.H = 4, 0, _rev_mask(ndir, reverse_dir0), ndir, rows, hsz
+    e.lengths = _p(lengths)
+    e.dh, e.dout = dh.data_ptr(), _p(dout)
+    e.do_dir, e.do_row, e.do_time = dout_strides or (0, 0, 0)
+    e.ru, e.c = gates0.data_ptr(), c0.data_ptr()
+    e.dxp = dxp.data_ptr()
+    e.dx_dir, e.dx_row, e.dx_time = dxp_strides
+    ld_w, s_w = _dir_strides(wh)
+    serial = _cluster_serialize_before()
+    _lib.check(lib.nm_lstm_seq_bwd(_stream(), ctypes.byref(e), steps, g_step, c_step, wh.data_ptr(), ld_w, s_w,
+                                   workspace.data_ptr(), workspace.numel() * workspace.element_size(), _p(sticky)),
+               "nm_lstm_seq_bwd")
+    _cluster_serialize_after(serial)
+
+
 def nematus_seq_workspace_floats(rows, hsz, ndir) -> int:
     return _lib.load().nm_nematus_seq_workspace_bytes(rows, hsz, ndir) // 4
 

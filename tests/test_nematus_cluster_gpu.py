@@ -193,3 +193,65 @@ def test_encoder_layer_takes_the_loops_and_matches_the_model_oracle(dev, directi
     assert calls["fwd"] == before + 1
     assert np.array_equal(out["sym"], ref_sym)
     assert np.abs(out["logits"] - ref_logits).max() <= 1e-4 * np.abs(ref_logits).max()
+
+
+@pytest.mark.parametrize("direction,h,batch", [("bidirectional", 256, 5), ("backward", 384, 9), ("forward", 512, 40),
+                                               ("bidirectional", 512, 33)])
+def test_lstm_layer_takes_the_loops_and_matches_the_model_oracle(dev, direction, h, batch, monkeypatch):
+    """LSTMCell encoder layers (tf.nn.rnn_cell.LSTMCell: encoders/recurrent.py:21) as one cluster launch each way
+    (nm_lstm_seq_fwd / nm_lstm_seq_bwd) against oracle.general_ref: the training step (loss, every gradient) with the
+    loops and with NM_LSTM_CLUSTER=0 (the step-by-step tape), ragged batches, then greedy decoding through the layer."""
+    from oracle import general_ref as G
+    from neuralmonkey_amd import ops
+    from tests.test_general_gpu import _build, _data
+    cfg = G.Config(rnn_layers=((h, direction, "LSTM"),), dec_cell="LSTM", rnn_size=8)
+    calls = {"fwd": 0, "bwd": 0}
+    real_f, real_b = ops.lstm_seq_fwd, ops.lstm_seq_bwd
+
+    def spy_f(*a, **k):
+        calls["fwd"] += 1
+        return real_f(*a, **k)
+
+    def spy_b(*a, **k):
+        calls["bwd"] += 1
+        return real_b(*a, **k)
+    monkeypatch.setattr(ops, "lstm_seq_fwd", spy_f)
+    monkeypatch.setattr(ops, "lstm_seq_bwd", spy_b)
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NM_LSTM_CLUSTER", mode)
+        m = _build(dev, cfg, 12, 8, init_std=0.08)
+        ds, src, tgt = _data(batch, 7, 6, 8)
+        before = dict(calls)
+        res = m["tfm"].execute(ds, m["trainer"].feedables, [m["trainer"]], train=True)[0]
+        if mode == "1":
+            assert calls["fwd"] == before["fwd"] + 1 and calls["bwd"] == before["bwd"] + 1
+        else:
+            assert calls == before
+        ref = G.GeneralModel(m["params"], cfg, requires_grad=True)
+        ref_loss, ref_g = ref.train_grads(src, tgt, train=True)
+        assert abs(res.losses[cfg.dec_name + " - cost"] - ref_loss) < 1e-4 * abs(ref_loss), mode
+        store = m["store"]
+        bad = {}
+        for name in store.names():
+            got = store.g(name).cpu().numpy().reshape(-1)
+            want = ref_g[name]
+            want = np.zeros_like(got) if want is None else want.reshape(-1)
+            if name.endswith("attn_bias"):
+                continue
+            err = float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-6))
+            if err > 1e-3:
+                bad[name] = err
+        assert not bad, "mode {}: gradient mismatch: {}".format(mode, bad)
+    monkeypatch.setenv("NM_LSTM_CLUSTER", "1")
+    m = _build(dev, cfg, 12, 8, init_std=0.08)
+    ds, src, _ = _data(4, 7, 6, 8, with_target=False)
+    ref = G.GeneralModel(m["params"], cfg)
+    ref_sym, _, ref_logits = ref.greedy(src, 8)
+    fd = {}
+    for part in (m["enc"].input_sequence, m["enc"], m["att"], m["dec"]):
+        fd.update(part.feed_dict(ds, train=False))
+    before = calls["fwd"]
+    out = m["tfm"].sessions[0].run({"sym": m["dec"].decoded_symbols, "logits": m["dec"].runtime_logits}, fd)
+    assert calls["fwd"] == before + 1
+    assert np.array_equal(out["sym"], ref_sym)
+    assert np.abs(out["logits"] - ref_logits).max() <= 1e-4 * np.abs(ref_logits).max()
