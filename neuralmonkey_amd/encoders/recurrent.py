@@ -480,6 +480,87 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
         tape.record(bwd)
         return out, final
 
+    def _gru_cluster_layer(self, tape, x, bsz: int, slen: int, lengths, layer: int):
+        """One TF-GRUCell layer of the GENERAL path (stacked / layer-normed / residual / dropout encoders) as one tape
+        operation: the schedule of the hand-written fast path above -- input halves of both kernels hoisted to products
+        over all positions, the time loop as one cluster launch each way (nn/gru.py: seq_fwd / seq_bwd, padded where the
+        kernels do not take the hidden size), weight gradients as products over all positions."""
+        spec = self.rnn_specs[layer]
+        cells = self._cells[layer]
+        ctx = tape.ctx
+        ndir, h = len(cells), spec.size
+        e = x.shape[1]
+        if spec.cell_type != "GRU" or not ctx.session.use_cluster_loops or e % 4 or h % 4 or not x.data.is_cuda:
+            return None
+        store = ctx.store
+        kn = {k: [self.var_name(c._n(k)) for c in cells] for k in ("gates/kernel", "candidate/kernel")}    # pylint: disable=protected-access
+
+        def dir_batch(k, ncols):
+            base = store.offset(kn[k][0]) + e * ncols
+            stride = store.offset(kn[k][1]) - store.offset(kn[k][0]) if ndir == 2 else 0
+            return store.theta.as_strided((ndir, h, ncols), (stride, ncols, 1), base)
+        wgh, wch = dir_batch("gates/kernel", 2 * h), dir_batch("candidate/kernel", h)
+        loop_h = gru.seq_mode(ctx.session, bsz, h, ndir, wgh, wch)
+        if not loop_h:
+            return None
+        rev0 = spec.direction == "backward"
+        width = ndir * h
+        par = lambda c, n: tape.param(self, c._n(n))                         # pylint: disable=protected-access
+        wg, bg = [par(c, "gates/kernel") for c in cells], [par(c, "gates/bias") for c in cells]
+        wc, bc = [par(c, "candidate/kernel") for c in cells], [par(c, "candidate/bias") for c in cells]
+        xp = tape.buf((bsz * slen, ndir * 3 * h))
+        for d in range(ndir):
+            ops.gemm(x.data, wg[d].data[:e], out=xp[:, d * 3 * h:d * 3 * h + 2 * h], bias=bg[d].data)
+            ops.gemm(x.data, wc[d].data[:e], out=xp[:, d * 3 * h + 2 * h:(d + 1) * 3 * h], bias=bc[d].data)
+        out, final = tape.new((bsz * slen, width)), tape.new((bsz, width))
+        hcur = tape.buf((ndir, bsz, h), zero=True)
+        rec = tape.recording
+        nsave = slen if rec else 1
+        ru_all, c_all = tape.buf((nsave, ndir, bsz, 2 * h)), (tape.buf((nsave, ndir, bsz, h)) if rec else None)
+        key = (id(self), "gru_layer", layer)
+        ops.zero(out.data)
+        seq_strides = (h, slen * width, width)
+        x_strides = (3 * h, slen * ndir * 3 * h, ndir * 3 * h)
+        gru.seq_fwd(ctx, key, loop_h, slen, ndir, bsz, h, xp, x_strides, hcur, hcur, 0, ru_all[0],
+                    ndir * bsz * 2 * h if rec else 0, None, 0, c_all[0] if rec else None, ndir * bsz * h, wgh, wch,
+                    lengths=lengths, reverse_dir0=rev0, out=out.data, out_strides=seq_strides)
+        for d in range(ndir):
+            ops.copy_cols(hcur[d], final.data[:, d * h:(d + 1) * h])
+
+        def bwd():
+            if out.grad is None and final.grad is None:
+                return
+            dh = tape.buf((ndir, bsz, h), zero=final.grad is None)
+            if final.grad is not None:
+                for d in range(ndir):
+                    ops.copy_cols(final.grad[:, d * h:(d + 1) * h], dh[d])
+            dxp = tape.buf((bsz * slen, ndir * 3 * h), zero=True)
+            gru.seq_bwd(ctx, key, loop_h, slen, ndir, bsz, h, dh, out.grad, seq_strides if out.grad is not None else None,
+                        ru_all[0], ndir * bsz * 2 * h, c_all[0], ndir * bsz * h, None, out.data, seq_strides, dxp,
+                        x_strides, wgh, wch, lengths=lengths, reverse_dir0=rev0)
+            states = out.data.view(bsz, slen, width)
+            hprev, rh_seq = tape.buf((bsz, slen, ndir, h)), tape.buf((bsz, slen, ndir, h))
+            ops.gru_seq_shift(states, hprev, lengths, ndir, h, reverse_dir0=rev0)
+            ops.gru_rh_seq(ru_all, hprev, rh_seq, lengths, ndir, h, reverse_dir0=rev0)
+            hp2, rh2 = hprev.view(bsz * slen, width), rh_seq.view(bsz * slen, width)
+            gx, acc = tape.grad_slot(x) if x.needs_grad else (None, False)
+            for d in range(ndir):
+                dg = dxp[:, d * 3 * h:d * 3 * h + 2 * h]
+                dc = dxp[:, d * 3 * h + 2 * h:(d + 1) * 3 * h]
+                g_wg, g_wc = tape.grad(wg[d]), tape.grad(wc[d])
+                ops.gemm(x.data, dg, out=g_wg[:e], trans_a=True, accumulate=True)
+                ops.gemm(hp2[:, d * h:(d + 1) * h], dg, out=g_wg[e:], trans_a=True, accumulate=True)
+                ops.gemm(x.data, dc, out=g_wc[:e], trans_a=True, accumulate=True)
+                ops.gemm(rh2[:, d * h:(d + 1) * h], dc, out=g_wc[e:], trans_a=True, accumulate=True)
+                ops.colsum(dg, tape.grad(bg[d]), accumulate=True)
+                ops.colsum(dc, tape.grad(bc[d]), accumulate=True)
+                if gx is not None:
+                    ops.gemm(dg, wg[d].data[:e], out=gx, trans_b=True, accumulate=acc)
+                    ops.gemm(dc, wc[d].data[:e], out=gx, trans_b=True, accumulate=True)
+                    acc = True
+        tape.record(bwd)
+        return out, final
+
     def _lstm_cluster_layer(self, tape, x, bsz: int, slen: int, lengths, layer: int):
         """One LSTMCell layer (both directions) as ONE tape operation, like ``_nematus_cluster_layer``: z = x.W_x + b of
         all positions as one product per direction, the time loop as one cluster launch each way (ops.lstm_seq_fwd /
@@ -559,6 +640,8 @@ class RecurrentEncoder(ModelPart, TemporalStatefulWithOutput):
             fused = self._nematus_cluster_layer(tape, x, bsz, slen, lengths, layer)
             if fused is None and os.environ.get("NM_LSTM_CLUSTER", "1") != "0":
                 fused = self._lstm_cluster_layer(tape, x, bsz, slen, lengths, layer)
+            if fused is None and os.environ.get("NM_GRU_LAYER_CLUSTER", "1") != "0":
+                fused = self._gru_cluster_layer(tape, x, bsz, slen, lengths, layer)
             if fused is not None:
                 return fused
         out = tape.new((bsz * slen, width))

@@ -255,3 +255,53 @@ def test_lstm_layer_takes_the_loops_and_matches_the_model_oracle(dev, direction,
     assert calls["fwd"] == before + 1
     assert np.array_equal(out["sym"], ref_sym)
     assert np.abs(out["logits"] - ref_logits).max() <= 1e-4 * np.abs(ref_logits).max()
+
+
+def test_stacked_gru_layers_of_the_general_path_take_the_loops(dev, monkeypatch):
+    """TF-GRUCell layers of a stacked, layer-normed encoder with dropout (the general path): every layer's
+    time loop is one cluster launch each way (encoders/recurrent.py::_gru_cluster_layer -> nn/gru.py seq_fwd / seq_bwd;
+    the 12-unit layer padded to 256) -- against oracle.general_ref, and NM_GRU_LAYER_CLUSTER=0 (the step-by-step tape)."""
+    from oracle import general_ref as G
+    from neuralmonkey_amd import ops
+    from tests.test_general_gpu import _build, _data
+    cfg = G.Config(rnn_layers=((256, "bidirectional", "GRU"), (512, "backward", "GRU"), (12, "forward", "GRU")),
+                   add_layer_norm=True, enc_dropout=0.8, dec_cell="GRU", rnn_size=8)
+    calls = {"fwd": [], "bwd": []}
+    real_f, real_b = ops.gru_seq_fwd, ops.gru_seq_bwd
+
+    def spy_f(steps, ndir, rows, hsz, *a, **k):
+        calls["fwd"].append((ndir, hsz))
+        return real_f(steps, ndir, rows, hsz, *a, **k)
+
+    def spy_b(steps, ndir, rows, hsz, *a, **k):
+        calls["bwd"].append((ndir, hsz))
+        return real_b(steps, ndir, rows, hsz, *a, **k)
+    monkeypatch.setattr(ops, "gru_seq_fwd", spy_f)
+    monkeypatch.setattr(ops, "gru_seq_bwd", spy_b)
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NM_GRU_LAYER_CLUSTER", mode)
+        m = _build(dev, cfg, 12, 8, init_std=0.08)
+        ds, src, tgt = _data(6, 7, 6, 8)
+        before = {k: len(v) for k, v in calls.items()}
+        res = m["tfm"].execute(ds, m["trainer"].feedables, [m["trainer"]], train=True)[0]
+        if mode == "1":
+            # the three encoder layers, then the decoder's own loop (8 units, hand-scheduled path, padded to 256)
+            assert calls["fwd"][before["fwd"]:] == [(2, 256), (1, 512), (1, 256), (1, 256)]
+            assert sorted(calls["bwd"][before["bwd"]:]) == [(1, 256), (1, 256), (1, 512), (2, 256)]
+        else:                                            # only the decoder's
+            assert [len(v) - before[k] for k, v in calls.items()] == [1, 1]
+        ref = G.GeneralModel(m["params"], cfg, requires_grad=True)
+        ref_loss, ref_g = ref.train_grads(src, tgt, train=True)
+        assert abs(res.losses[cfg.dec_name + " - cost"] - ref_loss) < 1e-4 * abs(ref_loss), mode
+        store = m["store"]
+        bad = {}
+        for name in store.names():
+            got = store.g(name).cpu().numpy().reshape(-1)
+            want = ref_g[name]
+            want = np.zeros_like(got) if want is None else want.reshape(-1)
+            if name.endswith("attn_bias"):
+                continue
+            err = float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-6))
+            if err > 1e-3:
+                bad[name] = err
+        assert not bad, "mode {}: {}".format(mode, bad)

@@ -1,2 +1,2 @@
 export TMPDIR=/tmp
-NM_GP_CELL=LSTM timeout 600 python tools/general_path_probe.py NM_LSTM_CLUSTER 1 0 2>&1 | grep "NM_LSTM" | tail -3
+timeout 600 python -m pytest tests/test_nematus_cluster_gpu.py -q -x --timeout=300 -k stacked 2>&1 | grep -v "amdgpu.ids" | grep -E "^FAILED|^E   |passed|failed" | cut -c1-400 | head -20
