@@ -85,6 +85,11 @@ int nm_gemm_f32_chain(void* stream, int64_t M, int64_t N, int64_t rows, int64_t 
 int nm_colsum_chain(void* stream, const void* pointer_table, int32_t table_stride, int32_t table_offset, int64_t count,
                     int64_t rows, int64_t ldx, int64_t cols, float* out, int accumulate, void* workspace,
                     int64_t workspace_bytes);
+/* out[b, s, c] (+)= sum_t w_t[b, s] * d_t[b, c] over `count` (<= 64) steps named by a device table [count][2] of
+ * {w_t, d_t}: the gradient of the attended states [B, S, C] through the context sums of a taped time loop
+ * (ctx_t = sum_s w_t[., s] states[., s, :]), one launch instead of one batched rank-1 product per step. */
+int nm_outer_chain(void* stream, const void* pointer_table, int64_t count, int64_t B, int64_t S, int64_t C, int64_t ldw,
+                   int64_t ldd, float* out, int accumulate);
 
 /* ---- embedding lookup: model/sequence.py:170-194, decoders/autoregressive.py:269-272 --
  * out[i,:] = table[ids[i],:] * scale * (mask_pad ? ids[i] != 0 : 1) */

@@ -30,6 +30,7 @@ SIGNATURES = {
     "nm_gemm_f32_group": (I, [P, I, I, L, L, L, P, L, L, L, I, L]),
     "nm_gemm_f32_chain": (I, [P, L, L, L, L, P, L, L, P, L, I, P, L]),
     "nm_colsum_chain": (I, [P, P, ctypes.c_int32, ctypes.c_int32, L, L, L, L, P, I, P, L]),
+    "nm_outer_chain": (I, [P, P, L, L, L, L, L, L, P, I]),
     "nm_embedding_gather": (I, [P, P, L, L, P, L, P, L, I, F]),
     "nm_gru_gates_fwd": (I, [P, P, L, L, L, P, P, P, P, P, I, I, I, L, L]),
     "nm_gru_blend_fwd": (I, [P, P, L, L, L, P, P, P, P, P, P, L, L, L, P, I, I, I, L, L]),

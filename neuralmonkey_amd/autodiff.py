@@ -44,7 +44,7 @@ LAZY_ADD = os.environ.get("NM_LAZY_ADD", "1") != "0"
 
 class Var:
     """A tensor on the tape plus (lazily) its gradient."""
-    __slots__ = ("_data", "grad", "needs_grad", "fresh", "pending")
+    __slots__ = ("_data", "grad", "needs_grad", "fresh", "pending", "is_leaf")
 
     def __init__(self, data: torch.Tensor, grad: Optional[torch.Tensor] = None, needs_grad: bool = True):
         self._data = data
@@ -52,6 +52,7 @@ class Var:
         self.needs_grad = needs_grad
         self.fresh = False          # ``grad`` was handed out unwritten: the first contribution overwrites it
         self.pending = None         # (a, b): ``data`` is the sum a + b that nobody has computed yet (autodiff.add)
+        self.is_leaf = False        # no closure of this tape reads ``grad`` (Tape.leaf / param): contributions may be deferred
 
     @property
     def data(self) -> torch.Tensor:
@@ -154,7 +155,9 @@ class Tape:
 
     def leaf(self, data: torch.Tensor, needs_grad: bool = False) -> Var:
         """Wrap an existing tensor (an encoder output, an embedded input)."""
-        return Var(data, None, needs_grad and self.recording)
+        v = Var(data, None, needs_grad and self.recording)
+        v.is_leaf = True
+        return v
 
     def param(self, part, name: str) -> Var:
         """A trainable variable of ``part``; its gradient is its slice of the flat gradient buffer."""
@@ -259,7 +262,10 @@ class Tape:
     def flush_wgrads(self) -> None:
         chains, self._chains = self._chains, {}
         for key, (out, members) in chains.items():
-            if key[0] == "bias":
+            if key[0] == "outer":
+                for i in range(0, len(members), ops.OUTER_CHAIN_MAX):
+                    ops.outer_chain(members[i:i + ops.OUTER_CHAIN_MAX], out, accumulate=True)
+            elif key[0] == "bias":
                 if len(members) == 1:
                     ops.colsum(members[0], out, accumulate=True)
                 else:
@@ -852,7 +858,16 @@ def weighted_sum(tape: Tape, w: Var, vals: Var, bsz: int, slen: int, rows_per_ke
         if w.needs_grad:
             ops.gemm(d3, v3, out=tape.grad(w).view(bsz, k, width)[:, :, :slen], trans_b=True, accumulate=True)
         if vals.needs_grad:
-            ops.gemm(w3, d3, out=tape.grad(vals).view(bsz, slen, a), trans_a=True, accumulate=True)
+            gv = tape.grad(vals).view(bsz, slen, a)
+            if (CHAIN_WGRADS and vals.is_leaf and k == 1 and w.data.is_cuda and gv.is_contiguous()
+                    and slen * ops.OUTER_CHAIN_MAX * 4 <= 65536 and bsz < 65536):
+                # one query per sentence: a rank-1 update per step -- the steps of a taped loop are summed in ONE launch
+                # when the pass ends (flush_wgrads: nm_outer_chain), their K dimension.  (Only for leaves: nothing on
+                # this tape reads their gradient before the pass is over.)
+                key = ("outer", gv.data_ptr(), bsz, slen, a, w.data.stride(0), out.grad.stride(0))
+                tape._chains.setdefault(key, [gv, []])[1].append((w.data, out.grad))     # pylint: disable=protected-access
+            else:
+                ops.gemm(w3, d3, out=gv, trans_a=True, accumulate=True)
     tape.record(bwd)
     return out
 

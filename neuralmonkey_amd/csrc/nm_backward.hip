@@ -292,6 +292,47 @@ extern "C" int nm_colsum_algo(void* stream, const float* x, int64_t ldx, int64_t
     NM_LAUNCH_CHECK("nm_colsum");
 }
 
+// out[b, s, c] (+)= sum_t w_t[b, s] * d_t[b, c]: the gradient of the attended states through the context sums of a taped
+// time loop, ctx_t[b, :] = sum_s w_t[b, s] states[b, s, :] (autodiff.weighted_sum).  Step by step that was one batched
+// rank-1 product per step on 128x128 tiles (M = S = 50, K = 1: 40 us, 50 per training step of the general-path model =
+// 2.0 ms); here the steps are the K dimension: a workgroup owns (sentence, 256 value columns), keeps every step's weights
+// of the sentence in LDS and its column of every d_t in registers.  table: [count][2] device pointers {w_t, d_t}.
+#define OUTER_MAX_T 64
+__global__ __launch_bounds__(256) void outer_chain_kernel(const float* const* __restrict__ table, int count, int S, int C,
+                                                          long ldw, long ldd, float* __restrict__ out, int accumulate) {
+    extern __shared__ float wsh[];                      // [count][S]
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    for (int i = threadIdx.x; i < count * S; i += 256) {
+        const int t = i / S, s = i - t * S;
+        wsh[i] = table[2 * t][(long)b * ldw + s];
+    }
+    float d[OUTER_MAX_T];
+#pragma unroll
+    for (int t = 0; t < OUTER_MAX_T; ++t) d[t] = (t < count && c < C) ? table[2 * t + 1][(long)b * ldd + c] : 0.0f;
+    __syncthreads();
+    if (c >= C) return;
+    float* o = out + ((long)b * S) * C + c;
+    for (int s = 0; s < S; ++s) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int t = 0; t < OUTER_MAX_T; ++t)
+            if (t < count) acc += wsh[t * S + s] * d[t];
+        o[(long)s * C] = accumulate ? o[(long)s * C] + acc : acc;
+    }
+}
+
+extern "C" int nm_outer_chain(void* stream, const void* pointer_table, int64_t count, int64_t B, int64_t S, int64_t C,
+                              int64_t ldw, int64_t ldd, float* out, int accumulate) {
+    NM_REQUIRE(pointer_table && out && count >= 1 && count <= OUTER_MAX_T && B > 0 && S > 0 && C > 0 && ldw >= S && ldd >= C,
+               "nm_outer_chain: bad arguments (count %ld of at most %d steps)", (long)count, OUTER_MAX_T);
+    NM_REQUIRE(count * S * 4 <= 64 * 1024 && B < 65536, "nm_outer_chain: %ld steps x %ld positions do not fit LDS", (long)count, (long)S);
+    hipLaunchKernelGGL(outer_chain_kernel, dim3(nm_cdiv(C, 256), (unsigned)B), dim3(256), (size_t)(count * S * 4),
+                       nm_stream(stream), reinterpret_cast<const float* const*>(pointer_table), (int)count, (int)S, (int)C,
+                       (long)ldw, (long)ldd, out, accumulate);
+    NM_LAUNCH_CHECK("nm_outer_chain");
+}
+
 // workspace: that of nm_colsum for ``cols`` (zero-initialised once; the kernel leaves the counters at zero)
 extern "C" int nm_colsum_chain(void* stream, const void* pointer_table, int32_t table_stride, int32_t table_offset,
                                int64_t count, int64_t rows, int64_t ldx, int64_t cols, float* out, int accumulate,

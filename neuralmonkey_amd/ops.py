@@ -158,6 +158,26 @@ def gemm_chain(members, out, accumulate=True):
     return out
 
 
+OUTER_CHAIN_MAX = 64
+
+
+def outer_chain(members, out, accumulate=True):
+    """``out[b, s, c] (+)= sum_t w_t[b, s] * d_t[b, c]`` over ``members`` = [(w_t [B, >=S], d_t [B, C])] (nm_outer_chain);
+    ``out`` [B, S, C] contiguous."""
+    w0, d0 = members[0]
+    bsz, s, c = out.shape
+    assert out.is_contiguous() and len(members) <= OUTER_CHAIN_MAX
+    ptrs = []
+    for w, d in members:
+        assert w.shape[0] == bsz and d.shape == (bsz, c) and w.stride(1) == 1 and d.stride(1) == 1
+        assert w.stride(0) == w0.stride(0) and d.stride(0) == d0.stride(0) and w.shape[1] >= s
+        ptrs += [w.data_ptr(), d.data_ptr()]
+    table = _pointer_table(out.device, ptrs)
+    _lib.check(_lib.load().nm_outer_chain(_stream(), table.data_ptr(), len(members), bsz, s, c, w0.stride(0), d0.stride(0),
+                                          out.data_ptr(), int(accumulate)), "nm_outer_chain")
+    return out
+
+
 def colsum_chain(members, out, accumulate=True):
     """``out[c] (+)= sum_i sum_r x_i[r, c]`` over tensors of one shape (nm_colsum_chain): a bias gradient of a taped time
     loop in one launch."""

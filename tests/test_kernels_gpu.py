@@ -976,3 +976,22 @@ def test_workgroups_are_dealt_round_robin_to_the_xcds(dev, blocks, threads):
     first = ids[:8]
     assert sorted(first.tolist()) == list(range(8)), first            # eight consecutive workgroups: eight XCDs
     assert (ids == np.tile(first, blocks // 8 + 1)[:blocks]).all()    # ... and the deal repeats: i and i + 8 share one
+
+
+@pytest.mark.parametrize("count,b,s,c,pad", [(50, 128, 50, 1024, 0), (1, 3, 7, 20, 0), (64, 5, 9, 260, 3), (13, 40, 64, 2048, 0)])
+def test_outer_products_of_a_loop_summed_in_one_launch(dev, count, b, s, c, pad):
+    """nm_outer_chain: out[b, s, c] (+)= sum_t w_t[b, s] * d_t[b, c] (the attended states' gradient through the context
+    sums of a taped time loop) against float64; the weights may be the first S columns of wider rows."""
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(count + b)
+    ws = [rng.standard_normal((b, s + pad)).astype(np.float32) for _ in range(count)]
+    ds = [rng.standard_normal((b, c)).astype(np.float32) for _ in range(count)]
+    want = sum(w[:, :s, None].astype(np.float64) * d[:, None, :].astype(np.float64) for w, d in zip(ws, ds))
+    base = rng.standard_normal((b, s, c)).astype(np.float32)
+    out = T(base, dev)
+    members = [(T(w, dev)[:, :s], T(d, dev)) for w, d in zip(ws, ds)]
+    ops.outer_chain(members, out, accumulate=True)
+    assert np.abs(out.cpu().numpy() - (want + base)).max() <= 1e-5 * np.sqrt(count) * 4
+    fresh = torch.full((b, s, c), float("nan"), device=dev)
+    ops.outer_chain(members, fresh, accumulate=False)
+    assert np.abs(fresh.cpu().numpy() - want).max() <= 1e-5 * np.sqrt(count) * 4
