@@ -265,6 +265,8 @@ int nm_attn_softmax_bwd(void* stream, const float* dw, const float* e, const flo
 int nm_attn_energy_bwd(void* stream, const float* de, const float* hf, const float* y, const float* v,
                        float* dhf, float* dv_partial, float* dy, int64_t T, int64_t B, int64_t S,
                        int64_t A, int accumulate /* dhf, dv_partial += (per-step backward) */);
+/* (dhf and dv_partial both null: the query gradients dy alone -- what a step of a taped loop needs at once; the key-side
+ * sums are then one call over all steps when the backward pass has been through them) */
 /* the distribution alone, from energies assembled by the caller (several encoders + a sentinel):
  * attention/combination.py:301-307 (FlatMultiAttention._renorm_softmax), :421 (hierarchical softmax,
  * mask == NULL).  Mask row of query row r: (r / rows_per_key) % B. */

@@ -19,6 +19,9 @@ from .base_attention import (Attendable, AttentionLoopState, BaseAttention, get_
                              get_attention_states)
 
 
+ENERGY_STACK = 64        # steps of a taped loop whose energies' gradients are stacked for one key-side backward call
+
+
 class Attention(BaseAttention):
     # pylint: disable=too-many-arguments
     def __init__(self, name: str, encoder: Attendable, dropout_keep_prob: float = 1.0,
@@ -239,6 +242,28 @@ class AttentionTapeSession:
                 for i in range(0, len(pairs), ops.OUTER_CHAIN_MAX):
                     ops.outer_chain(pairs[i:i + ops.OUTER_CHAIN_MAX], gs, accumulate=True)
         tape.record(flush_outer)
+        # ... and the key-side sums of the energies' backward (dhf, the partial sums of dv): a step needs the QUERY
+        # gradient at once (it flows back into the recurrence), the sums over the steps only when the pass has been
+        # through all of them -- one call over the stacked energies' gradients and queries of all steps (the kernel keeps
+        # a sentence's keys in registers while it walks the T queries) instead of 156 MB of read-modify-write per step
+        self._steps = 0
+        self._stack = None          # (de [cap, B, S], y [cap, B, A]) of the steps, allocated by the first one
+        self._deferred_steps = []
+
+        def flush_energies():
+            idx, self._deferred_steps = self._deferred_steps, []
+            if idx:
+                n = max(idx) + 1
+                de_all, y_all = self._stack
+                for t in sorted(set(range(n)) - set(idx)):       # a step whose context nobody differentiated: no term
+                    ops.zero(de_all[t])
+                # (``finish`` below was recorded later and has run by now: these steps' partial sums of dv are summed here)
+                dvp = tape.buf((self.bsz * self.slen, self.asz), zero=True)
+                scratch = tape.buf((n, self.bsz, self.asz))
+                ops.attn_energy_bwd(de_all[:n], self.hf.data.view(self.bsz, self.slen, self.asz), y_all[:n], self.v.data,
+                                    tape.grad(self.hf).view(self.bsz, self.slen, self.asz), dvp, scratch, accumulate=True)
+                ops.colsum(dvp, self.v.grad, accumulate=True)
+        tape.record(flush_energies)
         self.mask = att.attention_mask(ctx)
         self.wq = tape.param(att, "Attention/attn_query_projection")
         self.bq = tape.param(att, "attn_projection_bias")
@@ -274,7 +299,14 @@ class AttentionTapeSession:
         ctx = tape.ctx
         b, s, c, a = self.bsz, self.slen, self.csz, self.asz
         rows = query.shape[0]
-        y = F.linear(tape, query, self.wq, self.bq)
+        slot = None                                      # this step's row of the stacks (training, one query per sentence)
+        if tape.recording and F.CHAIN_WGRADS and rows == b and query.data.is_cuda and self._steps < ENERGY_STACK:
+            if self._stack is None:
+                self._stack = (tape.buf((ENERGY_STACK, b, s)), tape.buf((ENERGY_STACK, b, a)))
+            slot = self._steps
+        self._steps += 1
+        y = F.linear(tape, query, self.wq, self.bq,
+                     out=None if slot is None else F.Var(self._stack[1][slot], None, True))
         out = tape.new((rows, c))
         w = w_out if w_out is not None else tape.buf((rows, s))
         e = tape.buf((rows, s)) if tape.recording else None
@@ -295,11 +327,15 @@ class AttentionTapeSession:
                 else:
                     ops.gemm(w.view(b, 1, s), dctx.view(b, 1, c), out=tape.grad(self.states).view(b, s, c),
                              trans_a=True, accumulate=True)
-            de = tape.buf((1, b, s))
+            de = tape.buf((1, b, s)) if slot is None else self._stack[0][slot:slot + 1]
             ops.attn_softmax_bwd(dw.view(1, b, s), e.view(1, b, s), self.mask, de, b)
             dbias = tape.buf((1,))
             ops.reduce_sum(de.view(-1), dbias)
             ops.ew("copy", dbias, None, self.bias.grad, accumulate=True)
+            if slot is not None:         # the query gradient now, the key-side sums in flush_energies
+                ops.attn_energy_bwd(de, hf3, y.data.view(1, b, a), self.v.data, None, None, tape.grad(y).view(1, b, a))
+                self._deferred_steps.append(slot)
+                return
             if self._dvp is None:
                 self._dvp = tape.buf((b * s, a), zero=True)
             ops.attn_energy_bwd(de, hf3, y.data.view(1, b, a), self.v.data, tape.grad(self.hf).view(b, s, a),

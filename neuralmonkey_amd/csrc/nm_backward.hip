@@ -967,6 +967,7 @@ __global__ __launch_bounds__(128) void attn_energy_bwd_kernel(
             float* dyp = dy + row * A + a;
             *dyp = (s0 == 0) ? va * dsum : *dyp + va * dsum;
         }
+        if (!dhf) continue;             // query gradients only (a taped step: the key-side sums come later, over all steps)
 #pragma unroll
         for (int i = 0; i < SCH; ++i) {
             if (s0 + i >= S) break;
@@ -985,7 +986,7 @@ __global__ __launch_bounds__(128) void attn_energy_bwd_kernel(
 extern "C" int nm_attn_energy_bwd(void* stream, const float* de, const float* hf, const float* y,
                                   const float* v, float* dhf, float* dv_partial, float* dy, int64_t T,
                                   int64_t B, int64_t S, int64_t A, int accumulate) {
-    NM_REQUIRE(de && hf && y && v && dhf && dv_partial && dy, "nm_attn_energy_bwd: null pointer");
+    NM_REQUIRE(de && hf && y && v && dy && ((dhf == nullptr) == (dv_partial == nullptr)), "nm_attn_energy_bwd: null pointer");
     NM_REQUIRE(T > 0 && B > 0 && S > 0 && A > 0 && S < 65536 && B < 65536 && T < 65536,
                "nm_attn_energy_bwd: bad shape");
     hipStream_t st = nm_stream(stream);

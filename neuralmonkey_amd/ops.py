@@ -727,11 +727,14 @@ def attn_softmax_fwd(e, mask, w, bsz, rows_per_key=1):
 
 
 def attn_energy_bwd(de, hf, y, v, dhf, dv_partial, dy, accumulate=False):
+    """Energies backward of T queries per sentence (nm_attn_energy_bwd); ``dhf`` and ``dv_partial`` both None: the query
+    gradients ``dy`` alone."""
     lib = _lib.load()
     t, b, s = de.shape
     a = hf.shape[-1]
+    assert de.is_contiguous() and y.is_contiguous() and dy.is_contiguous()
     _lib.check(lib.nm_attn_energy_bwd(_stream(), de.data_ptr(), hf.data_ptr(), y.data_ptr(), v.data_ptr(),
-                                      dhf.data_ptr(), dv_partial.data_ptr(), dy.data_ptr(), t, b, s, a,
+                                      _p(dhf), _p(dv_partial), dy.data_ptr(), t, b, s, a,
                                       int(accumulate)), "nm_attn_energy_bwd")
 
 
