@@ -1,4 +1,6 @@
 export TMPDIR=/tmp
-timeout 300 python -m pytest tests/test_kernels_gpu.py -q -x --timeout=100 -k "outer_products" 2>&1 | grep -E "^FAILED|^E   |passed|failed" | cut -c1-300 | head -5
-timeout 1200 python -m pytest tests/test_general_gpu.py tests/test_size_sweep_gpu.py tests/test_coverage_gpu.py tests/test_multisource_gpu.py tests/test_captioning_gpu.py tests/test_dotprod_gpu.py tests/test_reference_ini_parity_gpu.py tests/test_reference_exec_gpu.py tests/test_transformer_gpu.py tests/test_transformer_multisource_gpu.py -q -x --timeout=300 -k "not untuned_sizes or general" 2>&1 | grep -v "amdgpu.ids" | grep -E "^FAILED|^E   |passed|failed" | cut -c1-400 | head -20
-timeout 600 python tools/general_path_probe.py NM_NEMATUS_CLUSTER 1 2>&1 | grep "NM_NEM" | tail -2
+timeout 2400 python -m pytest tests -q -m gpu --timeout=600 --durations=6 > /tmp/suite.log 2>&1; echo "rc=$?"
+grep -v "amdgpu.ids" /tmp/suite.log | grep -E "passed|failed|^FAILED|^ERROR|s call" | tail -12 | cut -c1-200 > gpurun_out/r06_gpu_suite_full.txt
+cat gpurun_out/r06_gpu_suite_full.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+timeout 1500 python bench.py > gpurun_out/r06_bench_final.json 2> gpurun_out/r06_bench_final.err; echo "bench rc=$?"
