@@ -106,6 +106,31 @@ def test_round6_entry_points_validate_before_any_launch(lib):
     # (no device here: no shape is "supported", the workspace is the bare header)
     assert lib.nm_nematus_seq_workspace_bytes(16, 100, 1) == lib.nm_gru_seq_workspace_bytes(16, 100, 1)
     assert lib.nm_dec_step_cluster_supported(128, 100, 512, 512) == 0
+    # ... the LSTM loops, the chained products / column sums / rank-1 updates of taped time loops, the chunk-list optimizer
+    # passes, fills and copies, the fused NematusGRU cell
+    rc = lib.nm_lstm_seq_fwd(None, ctypes.byref(epi), 3, 0, 0, 0, None, 1024, 0, 1.0, None, 0, None)
+    assert rc < 0 and b"nm_lstm_seq_fwd" in lib.nm_last_error()
+    rc = lib.nm_lstm_seq_bwd(None, ctypes.byref(epi), 3, 0, 0, buf, 1024, 0, buf, 1 << 20, None)
+    assert rc < 0 and b"nm_lstm_seq_bwd: missing operand" in lib.nm_last_error()
+    rc = lib.nm_gemm_f32_chain(None, 64, 64, 24, 3, buf, 64, 64, buf, 64, 1, None, 0)
+    assert rc < 0 and b"multiple of 16" in lib.nm_last_error()
+    rc = lib.nm_colsum_chain(None, buf, 1, 0, 3, 16, 62, 64, buf, 1, buf, 1 << 20)
+    assert rc < 0 and b"nm_colsum_chain" in lib.nm_last_error()
+    rc = lib.nm_outer_chain(None, buf, 65, 4, 8, 16, 8, 16, buf, 1)
+    assert rc < 0 and b"at most 64 steps" in lib.nm_last_error()
+    rc = lib.nm_optim_partials_list(None, buf, buf, *tabs, 4, 2, 0.0, 0.0, None, 3, buf, 4096)
+    assert rc < 0 and b"bad chunk list" in lib.nm_last_error()
+    assert lib.nm_optim_apply_list(None, 0, buf, buf, buf, buf, *tabs, 4, 2, 1.0, 1e-3, 0.9, 0.999, 1e-8, None, 0, None, buf,
+                                   4096) == 0                                  # an empty list: no launch
+    rc = lib.nm_fill_u32(None, None, 16, 0)
+    assert rc < 0 and b"nm_fill_u32" in lib.nm_last_error()
+    assert lib.nm_fill_u32(None, buf, 0, 7) == 0 and lib.nm_copy_d2d(None, buf, buf, 256) == 0       # nothing to do
+    rc = lib.nm_nematus_cell_fwd(None, buf, 8, buf, 8, buf, 8, buf, 8, buf, 8, None, None, None, 0, 4, 8)
+    assert rc < 0 and b"nm_nematus_cell_fwd: bad shape" in lib.nm_last_error()       # the gates are 2H wide
+    rc = lib.nm_add_layer_norm_stats_fwd(None, buf, buf, buf, buf, buf, buf, buf, buf, 4, 6, 1e-6)
+    assert rc < 0 and b"multiple of 4" in lib.nm_last_error()
+    rc = lib.nm_test_xcc_ids(None, None, 8, 64)
+    assert rc < 0 and b"nm_test_xcc_ids" in lib.nm_last_error()
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
