@@ -1,7 +1,15 @@
 import os
 import sys
 
-import pytest
+# Two thread pools share the host's cores in these tests: torch's OpenMP threads (the oracles) and NumPy's BLAS threads
+# (the reference executed on the NumPy-eager TensorFlow stand-in).  Idle OpenMP threads that spin for work starve the
+# other pool: the same suite took 70 s or 480 s from run to run.  Waiting threads sleep instead (set before either
+# library is imported; an explicit setting in the environment wins).
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+os.environ.setdefault("KMP_BLOCKTIME", "0")
+
+import pytest  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
