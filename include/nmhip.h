@@ -72,7 +72,9 @@ int nm_gemm_f32(void* stream, int transA, int transB, int64_t M, int64_t N, int6
 int nm_gemm_f32_group(void* stream, int transA, int transB, int64_t M, int64_t N, int64_t K,
                       const void* pointer_table, int64_t lda, int64_t ldb, int64_t ldc, int accumulate,
                       int64_t count);
-/* C (+)= sum_i A_i^T . B_i over `count` members of `rows` rows each (A_i [rows, M], B_i [rows, N]): ONE product whose
+/* (what tf.gradients -- trainers/generic_trainer.py:84-195 -- adds up for a tf.layers.dense kernel used in every step of a
+ * tf.while_loop / unrolled decoder: decoders/decoder.py:226-325, nn/ortho_gru_cell.py:73-105)
+ * C (+)= sum_i A_i^T . B_i over `count` members of `rows` rows each (A_i [rows, M], B_i [rows, N]): ONE product whose
  * K dimension is the chain of the members; pointer_table: device array [count][3] of {A_i, B_i, unused}.  The weight
  * gradients of a taped time loop (x_t^T . dy_t of every step) as one launch per kernel instead of one per step.
  * rows % 16 == 0; M, N, lda, ldb multiples of 4, members 16-byte aligned; K is split over workgroups like nm_gemm_f32
@@ -85,7 +87,8 @@ int nm_gemm_f32_chain(void* stream, int64_t M, int64_t N, int64_t rows, int64_t 
 int nm_colsum_chain(void* stream, const void* pointer_table, int32_t table_stride, int32_t table_offset, int64_t count,
                     int64_t rows, int64_t ldx, int64_t cols, float* out, int accumulate, void* workspace,
                     int64_t workspace_bytes);
-/* out[b, s, c] (+)= sum_t w_t[b, s] * d_t[b, c] over `count` (<= 64) steps named by a device table [count][2] of
+/* (the gradient of attention/feed_forward.py:158-166, context = reduce_sum(weights * attention_states), w.r.t. the states)
+ * out[b, s, c] (+)= sum_t w_t[b, s] * d_t[b, c] over `count` (<= 64) steps named by a device table [count][2] of
  * {w_t, d_t}: the gradient of the attended states [B, S, C] through the context sums of a taped time loop
  * (ctx_t = sum_s w_t[., s] states[., s, :]), one launch instead of one batched rank-1 product per step. */
 int nm_outer_chain(void* stream, const void* pointer_table, int64_t count, int64_t B, int64_t S, int64_t C, int64_t ldw,

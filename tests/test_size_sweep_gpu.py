@@ -35,6 +35,10 @@ def _cases():
         if b * max(s, t) * max(h, e) > cap:             # keep the CPU oracle in seconds
             b = max(1, cap // (max(s, t) * max(h, e)))
         out.append((h, e, a, v, b, s, t, 100 + i))
+    # long sentences: more positions than the whole-sentence attention kernels take, more steps than one chunk of
+    # anything (decode graphs, the stacks of the taped attention)
+    out += [(64, 20, 0, 130, 3, 150, 80, 190), (256, 36, 132, 257, 17, 90, 70, 191), (12, 8, 12, 64, 2, 301, 5, 192),
+            (300, 64, 64, 130, 9, 70, 66, 193)]
     return out
 
 
@@ -148,6 +152,9 @@ def _general_cases():
         b = int(rng.choice([16, 32, 48] if i % 2 == 0 else [1, 5, 9, 21]))
         s, t = int(rng.choice([2, 5, 9])), int(rng.choice([1, 4, 7]))
         out.append((h, direction, cell, dec_cell, cond, r, es, et, b, s, t, 500 + i))
+    # more steps than the taped attention stacks (64): the steps beyond take the per-step backward
+    out += [(8, "bidirectional", "NematusGRU", "NematusGRU", True, 8, 8, 8, 16, 12, 70, 590),
+            (12, "forward", "LSTM", "LSTM", False, 12, 8, 12, 3, 80, 66, 591)]
     return out
 
 
