@@ -25,6 +25,8 @@ from .. import ops
 from ..nn.cells import GRUCell, LSTMCell, NematusGRUCell, make_cell
 from ..variables import zeros_initializer
 
+HOIST_OUTPUT = os.environ.get("NM_HOIST_OUTPUT", "1") != "0"
+
 
 class GeneralDecoderMixin:
     """Mixed into ``Decoder``; relies on its configuration attributes."""
@@ -94,7 +96,7 @@ class GeneralDecoderMixin:
 
     # -- one step --------------------------------------------------------------------------------
     def general_step(self, tape: F.Tape, emb_in: F.Var, state: List[F.Var], sessions, w_outs, train: bool,
-                     t: int):
+                     t: int, project: bool = True):
         """Decoder.next_state (decoders/decoder.py:279-358).  ``state`` = [prev_rnn_state,
         prev_rnn_output, *prev_contexts]; returns (output, new_state)."""
         ctx = tape.ctx
@@ -125,6 +127,8 @@ class GeneralDecoderMixin:
         contexts = [F.dropout(tape, c, keep, train, ctx.salt(self.name, "context", i, t))
                     for i, c in enumerate(contexts)]                   # :331-332
         cell_output = F.dropout(tape, cell_output, keep, train, ctx.salt(self.name, "cell_output", t))
+        if not project:      # the caller projects the outputs of all steps at once (nothing of it feeds the recurrence)
+            return None, [next_state, cell_output] + contexts
         output = self.output_projection.apply_var(tape, self, cell_output, emb_in, contexts, train,
                                                   ctx.salt(self.name, "output_projection", t))
         return output, [next_state, cell_output] + contexts
@@ -159,12 +163,30 @@ class GeneralDecoderMixin:
         att_states = [a.initial_loop_state(ctx, bsz, steps, precompute=False) for a in self.attentions]
         state = [s0, s0] + [tape.leaf(tape.buf((bsz, a.context_vector_size), zero=True))
                             for a in self.attentions]
-        out_all = tape.new((rows, self.output_dimension))
+        # The output projection reads the step's cell output, input embedding and contexts and feeds nothing back into
+        # the recurrence: without dropout (whose masks are drawn per step) it is ONE pass over the rows of all steps
+        # after the loop -- three products and an activation per step otherwise (3 + 3 of the 16 skinny products of a
+        # step of the general-path model at the headline size).  NM_HOIST_OUTPUT=0: inside the loop as in rounds 2-5.
+        op_keep = getattr(self.output_projection, "dropout_keep_prob", 1.0)
+        hoist = HOIST_OUTPUT and (not train or (keep == 1.0 and op_keep == 1.0))
+        out_all = None if hoist else tape.new((rows, self.output_dimension))
+        s_all = c_alls = None
         for t in range(steps):
             emb_t = tape.rows(emb_all, t * bsz, (t + 1) * bsz)
             out_t, state = self.general_step(tape, emb_t, state, sessions, [st.weights[t] for st in att_states],
-                                             train, t)
-            F.copy(tape, out_t, out=tape.rows(out_all, t * bsz, (t + 1) * bsz))
+                                             train, t, project=not hoist)
+            if hoist:
+                if s_all is None:
+                    s_all = tape.new((rows, state[1].shape[1]))
+                    c_alls = [tape.new((rows, c.shape[1])) for c in state[2:]]
+                F.copy(tape, state[1], out=tape.rows(s_all, t * bsz, (t + 1) * bsz))
+                for c_all, c in zip(c_alls, state[2:]):
+                    F.copy(tape, c, out=tape.rows(c_all, t * bsz, (t + 1) * bsz))
+            else:
+                F.copy(tape, out_t, out=tape.rows(out_all, t * bsz, (t + 1) * bsz))
+        if hoist:
+            out_all = self.output_projection.apply_var(tape, self, s_all, emb_all, c_alls, train,
+                                                       ctx.salt(self.name, "output_projection", 0))
         w, trans_b, bias = self._logit_params(tape)
         logits = F.linear(tape, out_all, w, bias, trans_b=trans_b)
         loss_rows = F.xent(tape, logits, tgt.reshape(-1), self.xent_weights(tmask.reshape(-1)), grad_scale,
