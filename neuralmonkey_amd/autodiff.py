@@ -370,17 +370,47 @@ def nematus_cell(tape: Tape, g_pre: Var, sc: Var, ci: Var, h_prev: Var) -> Var:
     return h_new
 
 
-def nematus_cell_merged(tape: Tape, x: Var, h_prev: Var, w_in: torch.Tensor, b_in: Optional[torch.Tensor],
-                        w_st: torch.Tensor, b_st: Optional[torch.Tensor], params) -> Var:
+def nematus_input_projection(tape: Tape, x_all: Var, w_in: torch.Tensor, b_in: Optional[torch.Tensor], params) -> Var:
+    """x . [W_g | W_c] + [b_g | b_c] for the inputs of ALL steps of a loop whose inputs are known beforehand (the target
+    embeddings of a teacher-forced decoder): one product instead of one per step; the steps read their rows
+    (``nematus_cell_merged(..., x_proj=)``) and leave their gradients in the rows of this output's gradient."""
+    rows, h3 = x_all.shape[0], w_in.shape[1]
+    h = h3 // 3
+    out = tape.new((rows, h3))
+    ops.gemm(x_all.data, w_in, out=out.data, bias=b_in)
+
+    def bwd():
+        d = out.grad
+        if d is None:
+            return
+        if x_all.needs_grad:
+            gx, acc = tape.grad_slot(x_all)
+            ops.gemm(d, w_in, out=gx, trans_b=True, accumulate=acc)
+        for key, lo, hi in (("gi", 0, 2 * h), ("ci", 2 * h, 3 * h)):
+            w, b = params[key]
+            if w.needs_grad:
+                tape.defer_wgrad(x_all.data, d[:, lo:hi], tape.grad(w), True)
+            if b is not None and b.needs_grad:
+                tape.defer_bias(d[:, lo:hi], tape.grad(b))
+    tape.record(bwd)
+    return out
+
+
+def nematus_cell_merged(tape: Tape, x: Optional[Var], h_prev: Var, w_in: torch.Tensor, b_in: Optional[torch.Tensor],
+                        w_st: torch.Tensor, b_st: Optional[torch.Tensor], params, x_proj: Optional[Var] = None) -> Var:
     """One NematusGRUCell step as TWO products and one point-wise launch each way: x . [W_g | W_c] and h . [U_g | U_c]
     against column-concatenated copies of the four kernels (``w_in`` [D, 3H], ``w_st`` [H, 3H]: nn/cells.py refreshes them
     once per step), then nm_nematus_cell_fwd on the halves.  ``params``: the Vars of the four kernels and four biases
     ({"gi", "ci", "gs", "cs"} -> (kernel, bias or None)) -- their gradients are products against column slices of the
     two gradient buffers, chained over the steps when the pass ends (Tape.defer_wgrad)."""
     rows, h = h_prev.shape
-    s_all, x_all = tape.buf((rows, 3 * h)), tape.buf((rows, 3 * h))
+    s_all = tape.buf((rows, 3 * h))
     ops.gemm(h_prev.data, w_st, out=s_all, bias=b_st)
-    ops.gemm(x.data, w_in, out=x_all, bias=b_in)
+    if x_proj is not None:            # the input half was projected for all steps at once (nematus_input_projection)
+        x_all = x_proj.data
+    else:
+        x_all = tape.buf((rows, 3 * h))
+        ops.gemm(x.data, w_in, out=x_all, bias=b_in)
     h_new = tape.new((rows, h))
     ru = tape.buf((rows, 2 * h)) if tape.recording else None
     c = tape.buf((rows, h)) if tape.recording else None
@@ -390,17 +420,20 @@ def nematus_cell_merged(tape: Tape, x: Var, h_prev: Var, w_in: torch.Tensor, b_i
     def bwd():
         if h_new.grad is None:
             return
-        d_st, d_in = tape.buf((rows, 3 * h)), tape.buf((rows, 3 * h))
+        d_st = tape.buf((rows, 3 * h))
+        d_in = tape.buf((rows, 3 * h)) if x_proj is None else tape.grad(x_proj)       # (rows of the projection's gradient)
         dhp, acc_hp = tape.grad_slot(h_prev)
         ops.nematus_cell_bwd(h_new.grad, ru, c, s_all[:, 2 * h:], h_prev.data, d_st[:, :2 * h], d_in[:, 2 * h:],
                              d_st[:, 2 * h:], dhp, False, False, False, acc_hp, dg2=d_in[:, :2 * h])
         if dhp is not None:
             ops.gemm(d_st, w_st, out=dhp, trans_b=True, accumulate=True)
-        if x.needs_grad:
-            gx, acc = tape.grad_slot(x)
-            ops.gemm(d_in, w_in, out=gx, trans_b=True, accumulate=acc)
-        for key, src, act, lo, hi in (("gi", d_in, x, 0, 2 * h), ("ci", d_in, x, 2 * h, 3 * h),
-                                      ("gs", d_st, h_prev, 0, 2 * h), ("cs", d_st, h_prev, 2 * h, 3 * h)):
+        blocks = [("gs", d_st, h_prev, 0, 2 * h), ("cs", d_st, h_prev, 2 * h, 3 * h)]
+        if x_proj is None:
+            if x.needs_grad:
+                gx, acc = tape.grad_slot(x)
+                ops.gemm(d_in, w_in, out=gx, trans_b=True, accumulate=acc)
+            blocks += [("gi", d_in, x, 0, 2 * h), ("ci", d_in, x, 2 * h, 3 * h)]
+        for key, src, act, lo, hi in blocks:
             w, b = params[key]
             if w.needs_grad:
                 tape.defer_wgrad(act.data, src[:, lo:hi], tape.grad(w), True)

@@ -96,7 +96,7 @@ class GeneralDecoderMixin:
 
     # -- one step --------------------------------------------------------------------------------
     def general_step(self, tape: F.Tape, emb_in: F.Var, state: List[F.Var], sessions, w_outs, train: bool,
-                     t: int, project: bool = True):
+                     t: int, project: bool = True, x_proj=None):
         """Decoder.next_state (decoders/decoder.py:279-358).  ``state`` = [prev_rnn_state,
         prev_rnn_output, *prev_contexts]; returns (output, new_state)."""
         ctx = tape.ctx
@@ -119,7 +119,10 @@ class GeneralDecoderMixin:
             contexts = [s.step(cell_output, w, prev_state=prev_out, rnn_input=rnn_input)
                         for s, w in zip(sessions, w_outs)]
         else:                                                          # :288-307
-            cell_output, (next_state,) = self._cell_obj.step(tape, rnn_input, (prev_out,))
+            if x_proj is not None:       # the cell's input half of this step: rows of a product over all steps
+                cell_output, (next_state,) = self._cell_obj.step(tape, None, (prev_out,), x_proj=x_proj)
+            else:
+                cell_output, (next_state,) = self._cell_obj.step(tape, rnn_input, (prev_out,))
             contexts = [s.step(cell_output, w, prev_state=prev_out, rnn_input=rnn_input)
                         for s, w in zip(sessions, w_outs)]
             if self._cond_cell is not None:
@@ -171,10 +174,16 @@ class GeneralDecoderMixin:
         hoist = HOIST_OUTPUT and (not train or (keep == 1.0 and op_keep == 1.0))
         out_all = None if hoist else tape.new((rows, self.output_dimension))
         s_all = c_alls = None
+        # the first cell's input half: the embedded target words are all known (teacher forcing) -- one product over
+        # the rows of all steps where the cell offers it (NematusGRUCell) and nothing else enters the cell's input
+        xproj_all = None
+        if not self._attention_on_input and hasattr(self._cell_obj, "project_inputs"):
+            xproj_all = self._cell_obj.project_inputs(tape, emb_all)
         for t in range(steps):
             emb_t = tape.rows(emb_all, t * bsz, (t + 1) * bsz)
             out_t, state = self.general_step(tape, emb_t, state, sessions, [st.weights[t] for st in att_states],
-                                             train, t, project=not hoist)
+                                             train, t, project=not hoist,
+                                             x_proj=None if xproj_all is None else tape.rows(xproj_all, t * bsz, (t + 1) * bsz))
             if hoist:
                 if s_all is None:
                     s_all = tape.new((rows, state[1].shape[1]))

@@ -21,6 +21,8 @@ RNN_CELL_TYPES = ("NematusGRU", "GRU", "LSTM")
 FUSED_NEMATUS_CELL = os.environ.get("NM_NEMATUS_CELL_FUSED", "1") != "0"
 # ... and its four products as two against column-concatenated copies of the kernels (autodiff.nematus_cell_merged)
 MERGED_NEMATUS_CELL = os.environ.get("NM_NEMATUS_CELL_MERGED", "1") != "0"
+# ... and the input half of a loop whose inputs are known beforehand (teacher-forced decoder) for all steps at once
+HOIST_INPUTS = os.environ.get("NM_HOIST_INPUTS", "1") != "0"
 
 
 class Cell:
@@ -142,13 +144,24 @@ class NematusGRUCell(Cell):
         b = tape.param(self.part, self._n("{}/{}_proj/bias".format(block, which))) if use_bias else None
         return F.linear(tape, inp, w, b, out=out, accumulate=accumulate)
 
-    def step(self, tape, x, state):
+    def project_inputs(self, tape, x_all):
+        """The input half of the cell for the inputs of ALL steps at once ([T*B, D] -> Var [T*B, 3H], rows to be handed to
+        ``step(..., x_proj=)``), or None where the merged cell step does not apply."""
+        h = self.num_units
+        if not (MERGED_NEMATUS_CELL and FUSED_NEMATUS_CELL and HOIST_INPUTS and x_all.data.is_cuda and h % 4 == 0
+                and self.input_size % 4 == 0):
+            return None
+        w_in, b_in, _, _, params = self._merged(tape)
+        return F.nematus_input_projection(tape, x_all, w_in, b_in, params)
+
+    def step(self, tape, x, state, x_proj=None):
         (h_prev,) = state
         h = self.num_units
-        if MERGED_NEMATUS_CELL and FUSED_NEMATUS_CELL and x.data.is_cuda and h % 4 == 0 and self.input_size % 4 == 0:
+        if MERGED_NEMATUS_CELL and FUSED_NEMATUS_CELL and h_prev.data.is_cuda and h % 4 == 0 and self.input_size % 4 == 0:
             w_in, b_in, w_st, b_st, params = self._merged(tape)
-            h_new = F.nematus_cell_merged(tape, x, h_prev, w_in, b_in, w_st, b_st, params)
+            h_new = F.nematus_cell_merged(tape, x, h_prev, w_in, b_in, w_st, b_st, params, x_proj=x_proj)
             return h_new, (h_new,)
+        assert x_proj is None, "project_inputs() answered for a cell that does not take the merged step"
         g_pre = self._proj(tape, "gates", "state", h_prev, self.use_state_bias)
         self._proj(tape, "gates", "input", x, self.use_input_bias, out=g_pre, accumulate=True)
         sc = self._proj(tape, "candidate", "state", h_prev, self.use_state_bias)
