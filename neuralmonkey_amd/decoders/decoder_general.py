@@ -115,7 +115,7 @@ class GeneralDecoderMixin:
         else:
             rnn_input = emb_in
         if isinstance(self._cell_obj, LSTMCell):                       # :309-325
-            cell_output, (next_state, _) = self._cell_obj.step(tape, rnn_input, (prev_state, prev_out))
+            cell_output, (next_state, _) = self._cell_obj.step(tape, rnn_input, (prev_state, prev_out), x_proj=x_proj)
             contexts = [s.step(cell_output, w, prev_state=prev_out, rnn_input=rnn_input)
                         for s, w in zip(sessions, w_outs)]
         else:                                                          # :288-307

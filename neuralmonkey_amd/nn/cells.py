@@ -192,11 +192,19 @@ class LSTMCell(Cell):
         self.part.declare(store, self._n("kernel"), (d + h, 4 * h))
         self.part.declare(store, self._n("bias"), (4 * h,), zeros_initializer())
 
-    def step(self, tape, x, state):
+    def project_inputs(self, tape, x_all):
+        """x . W_x + b for the inputs of ALL steps at once ([T*B, D] -> Var [T*B, 4H]; the steps add their state halves
+        to their rows: ``step(..., x_proj=)``), or None."""
+        if not (HOIST_INPUTS and x_all.data.is_cuda):
+            return None
+        w, b = tape.param(self.part, self._n("kernel")), tape.param(self.part, self._n("bias"))
+        return F.linear(tape, x_all, tape.rows(w, 0, self.input_size), b)
+
+    def step(self, tape, x, state, x_proj=None):
         c_prev, h_prev = state
         d, h = self.input_size, self.num_units
         w, b = tape.param(self.part, self._n("kernel")), tape.param(self.part, self._n("bias"))
-        z = F.linear(tape, x, tape.rows(w, 0, d), b)
+        z = x_proj if x_proj is not None else F.linear(tape, x, tape.rows(w, 0, d), b)
         F.linear(tape, h_prev, tape.rows(w, d, d + h), out=z, accumulate=True)
         h_new, c_new = F.lstm_cell(tape, z, c_prev, forget_bias=1.0)      # gates + blend: one launch each way
         return h_new, (c_new, h_new)
