@@ -291,7 +291,7 @@ class AttentionTapeSession:
         g = self.d_states
         return [] if g is None else [(self.att.encoder, g)]
 
-    def step(self, query, w_out: Optional[torch.Tensor] = None, prev_state=None, rnn_input=None):
+    def step(self, query, w_out: Optional[torch.Tensor] = None, prev_state=None, rnn_input=None, out=None):
         """query Var [R,Q] -> context Var [R,C]; ``w_out`` [R,S] receives the weights.  (The previous
         decoder state and the RNN input of the reference's signature only matter to sentinels.)"""
         from .. import autodiff as F
@@ -307,7 +307,8 @@ class AttentionTapeSession:
         self._steps += 1
         y = F.linear(tape, query, self.wq, self.bq,
                      out=None if slot is None else F.Var(self._stack[1][slot], None, True))
-        out = tape.new((rows, c))
+        if out is None:                                  # (else: the step's rows of a buffer of all steps' contexts)
+            out = tape.new((rows, c))
         w = w_out if w_out is not None else tape.buf((rows, s))
         e = tape.buf((rows, s)) if tape.recording else None
         ws = ctx.buffer((id(att), "ws", rows), ((ops._lib.load().nm_attn_workspace_bytes(rows, s, c) + 3) // 4,), zero_init=True)

@@ -397,7 +397,8 @@ def nematus_input_projection(tape: Tape, x_all: Var, w_in: torch.Tensor, b_in: O
 
 
 def nematus_cell_merged(tape: Tape, x: Optional[Var], h_prev: Var, w_in: torch.Tensor, b_in: Optional[torch.Tensor],
-                        w_st: torch.Tensor, b_st: Optional[torch.Tensor], params, x_proj: Optional[Var] = None) -> Var:
+                        w_st: torch.Tensor, b_st: Optional[torch.Tensor], params, x_proj: Optional[Var] = None,
+                        out: Optional[Var] = None) -> Var:
     """One NematusGRUCell step as TWO products and one point-wise launch each way: x . [W_g | W_c] and h . [U_g | U_c]
     against column-concatenated copies of the four kernels (``w_in`` [D, 3H], ``w_st`` [H, 3H]: nn/cells.py refreshes them
     once per step), then nm_nematus_cell_fwd on the halves.  ``params``: the Vars of the four kernels and four biases
@@ -411,7 +412,7 @@ def nematus_cell_merged(tape: Tape, x: Optional[Var], h_prev: Var, w_in: torch.T
     else:
         x_all = tape.buf((rows, 3 * h))
         ops.gemm(x.data, w_in, out=x_all, bias=b_in)
-    h_new = tape.new((rows, h))
+    h_new = out if out is not None else tape.new((rows, h))      # (``out``: the step's rows of a buffer of all steps)
     ru = tape.buf((rows, 2 * h)) if tape.recording else None
     c = tape.buf((rows, h)) if tape.recording else None
     ops.nematus_cell_fwd(s_all[:, :2 * h], s_all[:, 2 * h:], x_all[:, 2 * h:], h_prev.data, h_new.data, ru, c,

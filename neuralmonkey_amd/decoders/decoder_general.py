@@ -96,7 +96,7 @@ class GeneralDecoderMixin:
 
     # -- one step --------------------------------------------------------------------------------
     def general_step(self, tape: F.Tape, emb_in: F.Var, state: List[F.Var], sessions, w_outs, train: bool,
-                     t: int, project: bool = True, x_proj=None):
+                     t: int, project: bool = True, x_proj=None, out_views=None):
         """Decoder.next_state (decoders/decoder.py:279-358).  ``state`` = [prev_rnn_state,
         prev_rnn_output, *prev_contexts]; returns (output, new_state)."""
         ctx = tape.ctx
@@ -119,14 +119,22 @@ class GeneralDecoderMixin:
             contexts = [s.step(cell_output, w, prev_state=prev_out, rnn_input=rnn_input)
                         for s, w in zip(sessions, w_outs)]
         else:                                                          # :288-307
+            # ``out_views`` (training without dropout): the step's rows of the buffers the output projection reads after
+            # the loop -- the last cell and the attentions write there where they can (no copy launches)
+            s_view, c_views = out_views if out_views is not None else (None, [None] * len(sessions))
+            nem = isinstance(self._cell_obj, NematusGRUCell)
+            first_out = s_view if (nem and self._cond_cell is None) else None
+            kw = {"out": first_out} if nem else {}
             if x_proj is not None:       # the cell's input half of this step: rows of a product over all steps
-                cell_output, (next_state,) = self._cell_obj.step(tape, None, (prev_out,), x_proj=x_proj)
+                cell_output, (next_state,) = self._cell_obj.step(tape, None, (prev_out,), x_proj=x_proj, **kw)
             else:
-                cell_output, (next_state,) = self._cell_obj.step(tape, rnn_input, (prev_out,))
-            contexts = [s.step(cell_output, w, prev_state=prev_out, rnn_input=rnn_input)
-                        for s, w in zip(sessions, w_outs)]
+                cell_output, (next_state,) = self._cell_obj.step(tape, rnn_input, (prev_out,), **kw)
+            contexts = [s.step(cell_output, w, prev_state=prev_out, rnn_input=rnn_input,
+                               **({"out": cv} if (cv is not None and hasattr(s, "_stack")) else {}))
+                        for s, w, cv in zip(sessions, w_outs, c_views)]
             if self._cond_cell is not None:
-                cell_output, (next_state,) = self._cond_cell.step(tape, F.concat(tape, contexts), (next_state,))
+                kw2 = {"out": s_view} if isinstance(self._cond_cell, NematusGRUCell) else {}
+                cell_output, (next_state,) = self._cond_cell.step(tape, F.concat(tape, contexts), (next_state,), **kw2)
         contexts = [F.dropout(tape, c, keep, train, ctx.salt(self.name, "context", i, t))
                     for i, c in enumerate(contexts)]                   # :331-332
         cell_output = F.dropout(tape, cell_output, keep, train, ctx.salt(self.name, "cell_output", t))
@@ -181,16 +189,23 @@ class GeneralDecoderMixin:
             xproj_all = self._cell_obj.project_inputs(tape, emb_all)
         for t in range(steps):
             emb_t = tape.rows(emb_all, t * bsz, (t + 1) * bsz)
-            out_t, state = self.general_step(tape, emb_t, state, sessions, [st.weights[t] for st in att_states],
-                                             train, t, project=not hoist,
-                                             x_proj=None if xproj_all is None else tape.rows(xproj_all, t * bsz, (t + 1) * bsz))
+            views = None
             if hoist:
                 if s_all is None:
-                    s_all = tape.new((rows, state[1].shape[1]))
-                    c_alls = [tape.new((rows, c.shape[1])) for c in state[2:]]
-                F.copy(tape, state[1], out=tape.rows(s_all, t * bsz, (t + 1) * bsz))
-                for c_all, c in zip(c_alls, state[2:]):
-                    F.copy(tape, c, out=tape.rows(c_all, t * bsz, (t + 1) * bsz))
+                    s_all = tape.new((rows, self.rnn_size))
+                    c_alls = [tape.new((rows, a.context_vector_size)) for a in self.attentions]
+                views = (tape.rows(s_all, t * bsz, (t + 1) * bsz),
+                         [tape.rows(c_all, t * bsz, (t + 1) * bsz) for c_all in c_alls])
+            out_t, state = self.general_step(tape, emb_t, state, sessions, [st.weights[t] for st in att_states],
+                                             train, t, project=not hoist,
+                                             x_proj=None if xproj_all is None else tape.rows(xproj_all, t * bsz, (t + 1) * bsz),
+                                             out_views=views)
+            if hoist:                # whatever did not write its rows itself is copied there
+                if state[1] is not views[0]:
+                    F.copy(tape, state[1], out=views[0])
+                for cv, c in zip(views[1], state[2:]):
+                    if c is not cv:
+                        F.copy(tape, c, out=cv)
             else:
                 F.copy(tape, out_t, out=tape.rows(out_all, t * bsz, (t + 1) * bsz))
         if hoist:

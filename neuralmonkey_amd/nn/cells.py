@@ -154,12 +154,14 @@ class NematusGRUCell(Cell):
         w_in, b_in, _, _, params = self._merged(tape)
         return F.nematus_input_projection(tape, x_all, w_in, b_in, params)
 
-    def step(self, tape, x, state, x_proj=None):
+    def step(self, tape, x, state, x_proj=None, out=None):
+        """``out`` (optional Var): where the new state is to be written (rows of a buffer of all steps); the caller
+        checks what it got back -- only the merged step writes there."""
         (h_prev,) = state
         h = self.num_units
         if MERGED_NEMATUS_CELL and FUSED_NEMATUS_CELL and h_prev.data.is_cuda and h % 4 == 0 and self.input_size % 4 == 0:
             w_in, b_in, w_st, b_st, params = self._merged(tape)
-            h_new = F.nematus_cell_merged(tape, x, h_prev, w_in, b_in, w_st, b_st, params, x_proj=x_proj)
+            h_new = F.nematus_cell_merged(tape, x, h_prev, w_in, b_in, w_st, b_st, params, x_proj=x_proj, out=out)
             return h_new, (h_new,)
         assert x_proj is None, "project_inputs() answered for a cell that does not take the merged step"
         g_pre = self._proj(tape, "gates", "state", h_prev, self.use_state_bias)
