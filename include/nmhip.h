@@ -268,6 +268,13 @@ int nm_attn_softmax_bwd(void* stream, const float* dw, const float* e, const flo
 int nm_attn_energy_bwd(void* stream, const float* de, const float* hf, const float* y, const float* v,
                        float* dhf, float* dv_partial, float* dy, int64_t T, int64_t B, int64_t S,
                        int64_t A, int accumulate /* dhf, dv_partial += (per-step backward) */);
+/* ONE step's backward up to the query in one launch (a taped decoder step, decoders/decoder.py:303-325 with the cells
+ * of any configuration around the attention): dw = <dctx, states> (feed_forward.py:146-149), the softmax/renorm
+ * backward (:139-144) -> de [B,S] (written: the key-side sums over all steps are taken later from the stacked de),
+ * dy [B,A] = v * sum_s de (1 - tanh^2(hf + y)) (:120-123).  One query per sentence; C and lddctx multiples of 4. */
+int nm_attn_step_bwd(void* stream, const float* dctx, int64_t lddctx, const float* states, const float* e,
+                     const float* mask /* [B,S] or NULL */, const float* hf, const float* y, int64_t ldy,
+                     const float* v, float* de, float* dy, int64_t lddy, int64_t B, int64_t S, int64_t C, int64_t A);
 /* (dhf and dv_partial both null: the query gradients dy alone -- what a step of a taped loop needs at once; the key-side
  * sums are then one call over all steps when the backward pass has been through them) */
 /* the distribution alone, from energies assembled by the caller (several encoders + a sentinel):

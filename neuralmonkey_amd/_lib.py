@@ -96,6 +96,7 @@ SIGNATURES = {
     "nm_gru_seq_shift": (I, [P, P, P, P, I, L, L, I, L]),
     "nm_attn_softmax_bwd": (I, [P, P, P, P, P, L, L, L]),
     "nm_attn_energy_bwd": (I, [P, P, P, P, P, P, P, P, L, L, L, L, I]),
+    "nm_attn_step_bwd": (I, [P, P, L, P, P, P, P, P, L, P, P, P, L, L, L, L, L]),
     "nm_attn_softmax_fwd": (I, [P, P, P, P, L, L, L, L]),
     "nm_ew": (I, [P, I, P, L, P, L, P, L, L, L, F, I]),
     "nm_blend_fwd": (I, [P, P, L, P, L, P, L, P, L, L, L]),

@@ -6,6 +6,7 @@ attention()     = q . Wq + b, then the fused HIP step kernel nm_attn_fwd
 Keys are indexed by ``row // rows_per_key`` so a beam of k hypotheses per
 sentence shares one copy of the keys."""
 import contextlib
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -20,6 +21,7 @@ from .base_attention import (Attendable, AttentionLoopState, BaseAttention, get_
 
 
 ENERGY_STACK = 64        # steps of a taped loop whose energies' gradients are stacked for one key-side backward call
+STEP_BWD_FUSED = os.environ.get("NM_ATTN_STEP_BWD", "1") != "0"        # a taped step's backward up to the query: one launch
 
 
 class Attention(BaseAttention):
@@ -257,6 +259,9 @@ class AttentionTapeSession:
                 de_all, y_all = self._stack
                 for t in sorted(set(range(n)) - set(idx)):       # a step whose context nobody differentiated: no term
                     ops.zero(de_all[t])
+                dbias = tape.buf((1,))                           # the scalar bias: the sum of all the energies' gradients
+                ops.reduce_sum(de_all[:n].reshape(-1), dbias)
+                ops.ew("copy", dbias, None, self.bias.grad, accumulate=True)
                 # (``finish`` below was recorded later and has run by now: these steps' partial sums of dv are summed here)
                 dvp = tape.buf((self.bsz * self.slen, self.asz), zero=True)
                 scratch = tape.buf((n, self.bsz, self.asz))
@@ -320,8 +325,10 @@ class AttentionTapeSession:
             if dctx is None:
                 return
             assert rows == b, "the attention gradient is defined for one query per sentence"
-            dw = tape.buf((b, 1, s))
-            ops.gemm(dctx.view(b, 1, c), st3, out=dw, trans_b=True)
+            fused = (STEP_BWD_FUSED and slot is not None and ops.attn_step_bwd_ok(dctx, c))
+            if not fused:
+                dw = tape.buf((b, 1, s))
+                ops.gemm(dctx.view(b, 1, c), st3, out=dw, trans_b=True)
             if self.states.needs_grad:
                 if F.CHAIN_WGRADS and dctx.is_cuda and s * ops.OUTER_CHAIN_MAX * 4 <= 65536 and b < 65536:
                     self._outer.append((w, dctx))
@@ -329,10 +336,15 @@ class AttentionTapeSession:
                     ops.gemm(w.view(b, 1, s), dctx.view(b, 1, c), out=tape.grad(self.states).view(b, s, c),
                              trans_a=True, accumulate=True)
             de = tape.buf((1, b, s)) if slot is None else self._stack[0][slot:slot + 1]
+            if fused:                    # the context sum's weights, the softmax part and the query gradient: one launch
+                ops.attn_step_bwd(dctx, st3, e, self.mask, hf3, y.data, self.v.data, de[0], tape.grad(y))
+                self._deferred_steps.append(slot)
+                return
             ops.attn_softmax_bwd(dw.view(1, b, s), e.view(1, b, s), self.mask, de, b)
-            dbias = tape.buf((1,))
-            ops.reduce_sum(de.view(-1), dbias)
-            ops.ew("copy", dbias, None, self.bias.grad, accumulate=True)
+            if slot is None:             # (a stacked step's share of the bias gradient: one sum in flush_energies)
+                dbias = tape.buf((1,))
+                ops.reduce_sum(de.view(-1), dbias)
+                ops.ew("copy", dbias, None, self.bias.grad, accumulate=True)
             if slot is not None:         # the query gradient now, the key-side sums in flush_energies
                 ops.attn_energy_bwd(de, hf3, y.data.view(1, b, a), self.v.data, None, None, tape.grad(y).view(1, b, a))
                 self._deferred_steps.append(slot)

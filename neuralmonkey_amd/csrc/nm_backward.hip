@@ -1020,6 +1020,133 @@ extern "C" int nm_attn_energy_bwd(void* stream, const float* de, const float* hf
     NM_LAUNCH_CHECK("nm_attn_energy_bwd");
 }
 
+// ---------------------------------------------------------------------------
+// ONE step's attention backward up to the query (a taped decoder step: the cells around the attention differ per
+// configuration, so the step's gradient has to come back through the attention before the previous step can start):
+//     dw[s] = <dctx[b,:], states[b,s,:]>          (the context sum's weights, feed_forward.py:146-149)
+//     de    = softmax/renorm backward of dw       (the arithmetic of attn_softmax_bwd_kernel, feed_forward.py:139-144)
+//     dy[a] = v[a] * sum_s de[s] (1 - tanh^2(hf[b,s,a] + y[b,a]))        (feed_forward.py:120-123)
+// -- three launches (a batched M = 1 product, the softmax kernel, the energies kernel in its query-only mode: 11 + 5 +
+// 13 us at B = 64, S = 50) in one: a workgroup owns a sentence, its waves share the S dot products, wave 0 does the
+// softmax part on the S values in LDS, then a thread owns feature columns.  de goes out too: the key-side sums over all
+// the steps are taken later from the stacked de (nm_attn_energy_bwd over T steps).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void attn_step_bwd_kernel(
+    const float* __restrict__ dctx, long ldd, const float* __restrict__ states, const float* __restrict__ e,
+    const float* __restrict__ mask, const float* __restrict__ hf, const float* __restrict__ y, long ldy,
+    const float* __restrict__ v, float* __restrict__ de, float* __restrict__ dy, long lddy, int S, int C, int A) {
+    extern __shared__ float sh[];                 // dw[S], then de[S] in place; pt[blockDim]: partial sums of dy
+    float* pt = sh + S;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    // (1) the S dot products: a wave takes four positions at a time (sixteen 16-byte loads in flight per lane at
+    // C = 1024 -- a sentence's 200 KB of states are fetched by ONE compute unit, latency is what there is to hide)
+    const float* dc = dctx + (long)b * ldd;
+    for (int s0 = wave; s0 < S; s0 += 4 * nw) {
+        const float* sr[4];
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sr[i] = states + ((long)b * S + min(s0 + i * nw, S - 1)) * C;
+        for (int c = lane * 4; c < C; c += 256) {
+            const float4 d = *reinterpret_cast<const float4*>(dc + c);
+            float4 x[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[i] = *reinterpret_cast<const float4*>(sr[i] + c);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] += x[i].x * d.x + x[i].y * d.y + x[i].z * d.z + x[i].w * d.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float t = nm_wave_sum(acc[i]);
+            if (lane == 0 && s0 + i * nw < S) sh[s0 + i * nw] = t;
+        }
+    }
+    __syncthreads();
+    // (2) softmax + mask + renormalisation backward on the S values (attn_softmax_bwd_kernel's arithmetic)
+    if (wave == 0) {
+        const float* er = e + (long)b * S;
+        const float* mr = mask ? mask + (long)b * S : nullptr;
+        float mx = -INFINITY;
+        for (int s = lane; s < S; s += 64) mx = fmaxf(mx, er[s]);
+        mx = nm_wave_max(mx);
+        float se = 0.0f, sm = 0.0f;
+        for (int s = lane; s < S; s += 64) {
+            const float x = expf(er[s] - mx);
+            se += x;
+            sm += x * (mr ? mr[s] : 1.0f);
+        }
+        se = nm_wave_sum(se);
+        sm = nm_wave_sum(sm);
+        const float inv_se = 1.0f / se;
+        const float invN = 1.0f / (sm * inv_se + 1e-8f);
+        float sdw = 0.0f;
+        for (int s = lane; s < S; s += 64) sdw += sh[s] * (expf(er[s] - mx) * inv_se * (mr ? mr[s] : 1.0f) * invN);
+        sdw = nm_wave_sum(sdw);
+        float sdp = 0.0f;
+        for (int s = lane; s < S; s += 64)
+            sdp += (mr ? mr[s] : 1.0f) * invN * (sh[s] - sdw) * (expf(er[s] - mx) * inv_se);
+        sdp = nm_wave_sum(sdp);
+        for (int s = lane; s < S; s += 64) {
+            const float p = expf(er[s] - mx) * inv_se;
+            const float dp = (mr ? mr[s] : 1.0f) * invN * (sh[s] - sdw);
+            const float d = p * (dp - sdp);
+            sh[s] = d;
+            de[(long)b * S + s] = d;
+        }
+    }
+    __syncthreads();
+    // (3) the query gradient: a wave owns 64 feature columns; with fewer column chunks than waves the positions are
+    // cut into parts (A = 512, 16 waves: 2 parts of 25 positions) whose sums meet in LDS
+    const float* hb = hf + (long)b * S * A;
+    const int nchunks = (A + 63) >> 6;
+    const bool cut = nchunks <= nw;
+    const int parts = cut ? nw / nchunks : 1;
+    const int part = cut ? wave / nchunks : 0;
+    const int per = (S + parts - 1) / parts;
+    const int sb = part * per, se_ = min(S, sb + per);
+    float total = 0.0f;
+    for (int ch = cut ? wave % nchunks : wave; part < parts && ch < nchunks; ch += cut ? nchunks : nw) {
+        const int a = ch * 64 + lane;
+        float g = 0.0f;
+        if (a < A) {
+            const float ya = y[(long)b * ldy + a];
+            for (int s = sb; s < se_; s += 5) {
+                float hv[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) hv[i] = hb[(long)min(s + i, S - 1) * A + a];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    const float z = nm_tanh(hv[i] + ya);
+                    if (s + i < se_) g += sh[s + i] * (1.0f - z * z);
+                }
+            }
+            if (!cut) dy[(long)b * lddy + a] = v[a] * g;
+        }
+        total = g;
+    }
+    if (!cut) return;                              // (block-uniform)
+    pt[tid] = total;                               // wave = part * nchunks + chunk: pt[part][chunk * 64 + lane]
+    __syncthreads();
+    if (tid < A) {
+        float g = 0.0f;
+        for (int p = 0; p < parts; ++p) g += pt[p * nchunks * 64 + tid];
+        dy[(long)b * lddy + tid] = v[tid] * g;
+    }
+}
+
+extern "C" int nm_attn_step_bwd(void* stream, const float* dctx, int64_t lddctx, const float* states, const float* e,
+                                const float* mask, const float* hf, const float* y, int64_t ldy, const float* v,
+                                float* de, float* dy, int64_t lddy, int64_t B, int64_t S, int64_t C, int64_t A) {
+    NM_REQUIRE(dctx && states && e && hf && y && v && de && dy, "nm_attn_step_bwd: null pointer");
+    NM_REQUIRE(B > 0 && S > 0 && C > 0 && A > 0 && S <= 8192 && C % 4 == 0 && lddctx % 4 == 0 && lddctx >= C &&
+                   ldy >= A && lddy >= A,
+               "nm_attn_step_bwd: bad shape");
+    NM_REQUIRE(((uintptr_t)dctx | (uintptr_t)states) % 16 == 0, "nm_attn_step_bwd: dctx / states not 16-byte aligned");
+    hipLaunchKernelGGL(attn_step_bwd_kernel, dim3((unsigned)B), dim3(1024), (size_t)(S + 1024) * sizeof(float), nm_stream(stream),
+                       dctx, (long)lddctx, states, e, mask, hf, y, (long)ldy, v, de, dy, (long)lddy, (int)S, (int)C,
+                       (int)A);
+    NM_LAUNCH_CHECK("nm_attn_step_bwd");
+}
+
 // r*h_prev of every sequence position, position-major [B,S,ndir,H] (operand of
 // the candidate-kernel weight gradient (r*h_prev)^T . dc_pre).  ru_all is
 // step-major [S,ndir,B,2H]; the step that visited position p is p (forward) or

@@ -715,6 +715,23 @@ def attn_softmax_bwd(dw, e, mask, de, bsz):
                                        rows, bsz, s), "nm_attn_softmax_bwd")
 
 
+def attn_step_bwd(dctx, states, e, mask, hf, y, v, de, dy):
+    """One step's attention backward up to the query in one launch: dctx [B,C] (rows may be strided), states [B,S,C],
+    e [B,S] the step's energies, hf [B,S,A], y [B,A] -> de [B,S] (written), dy [B,A] (written)."""
+    lib = _lib.load()
+    b, s, c = states.shape
+    a = hf.shape[2]
+    assert states.is_contiguous() and hf.is_contiguous() and e.is_contiguous() and de.is_contiguous()
+    assert dctx.stride(1) == 1 and y.stride(1) == 1 and dy.stride(1) == 1
+    _lib.check(lib.nm_attn_step_bwd(_stream(), dctx.data_ptr(), dctx.stride(0), states.data_ptr(), e.data_ptr(), _p(mask),
+                                    hf.data_ptr(), y.data_ptr(), y.stride(0), v.data_ptr(), de.data_ptr(), dy.data_ptr(),
+                                    dy.stride(0), b, s, c, a), "nm_attn_step_bwd")
+
+
+def attn_step_bwd_ok(dctx, c) -> bool:
+    return dctx.is_cuda and c % 4 == 0 and dctx.stride(0) % 4 == 0 and dctx.data_ptr() % 16 == 0
+
+
 def attn_softmax_fwd(e, mask, w, bsz, rows_per_key=1):
     """w = renorm(softmax(e) * mask) of contiguous [R,S] energies assembled by the caller."""
     lib = _lib.load()

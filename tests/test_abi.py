@@ -131,6 +131,11 @@ def test_round6_entry_points_validate_before_any_launch(lib):
     assert rc < 0 and b"multiple of 4" in lib.nm_last_error()
     rc = lib.nm_test_xcc_ids(None, None, 8, 64)
     assert rc < 0 and b"nm_test_xcc_ids" in lib.nm_last_error()
+    # one taped step's attention backward: operands, then shapes (C in float4 steps)
+    rc = lib.nm_attn_step_bwd(None, buf, 8, buf, buf, None, buf, None, 8, buf, buf, buf, 8, 2, 4, 8, 8)
+    assert rc < 0 and b"nm_attn_step_bwd: null pointer" in lib.nm_last_error()
+    rc = lib.nm_attn_step_bwd(None, buf, 6, buf, buf, None, buf, buf, 8, buf, buf, buf, 8, 2, 4, 6, 8)
+    assert rc < 0 and b"nm_attn_step_bwd: bad shape" in lib.nm_last_error()
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -60,3 +60,40 @@ def test_attn_energy_bwd_beyond_the_product_form_range(dev, t, b, s, a):
         assert torch.isfinite(got).all()
         scale = float(want.abs().max())
         assert float((got - want).abs().max()) <= 2e-5 * max(scale, 1.0)
+
+
+@pytest.mark.parametrize("b,s,c,a", [(3, 5, 8, 7), (2, 50, 1024, 512), (4, 33, 260, 130), (64, 50, 1024, 512), (2, 130, 64, 40),
+                                     (1, 1, 4, 1)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_attn_step_bwd_matches_float64_autograd(dev, b, s, c, a, masked):
+    """nm_attn_step_bwd -- a taped decoder step's attention backward up to the query in one launch -- against float64
+    autograd of the reference's arithmetic (feed_forward.py:120-149: energies, softmax, mask, renormalisation with
+    1e-8, context sum), with the context gradient read from rows of a wider buffer as the decoder hands it over.
+    Tolerance 2e-5 of each output's largest magnitude."""
+    from neuralmonkey_amd import ops
+    rng = np.random.default_rng(b * 1000 + s * 10 + a)
+    mk = lambda *shape: torch.tensor(rng.standard_normal(shape).astype(np.float32), device=dev)
+    states, hf, y, v = mk(b, s, c), mk(b, s, a), mk(b, a), mk(a)
+    wide = mk(b, c + 8)
+    dctx = wide[:, :c]                                           # strided rows, 16-byte aligned
+    mask = None
+    if masked:
+        lens = rng.integers(1, s + 1, size=b)
+        mask = torch.tensor((np.arange(s)[None, :] < lens[:, None]).astype(np.float32), device=dev)
+    y64 = y.double().requires_grad_(True)
+    e64 = (torch.tanh(hf.double() + y64.unsqueeze(1)) * v.double()).sum(-1)
+    e64.retain_grad()
+    p = torch.softmax(e64, dim=-1)
+    if mask is not None:
+        p = p * mask.double()
+    w = p / (p.sum(-1, keepdim=True) + 1e-8)
+    ctxv = (w.unsqueeze(-1) * states.double()).sum(1)
+    ctxv.backward(dctx.double())
+    e = e64.detach().float().contiguous()
+    de = torch.full((b, s), 3.0, device=dev)
+    dy = torch.full((b, a + 3), 5.0, device=dev)[:, :a]
+    assert ops.attn_step_bwd_ok(dctx, c)
+    ops.attn_step_bwd(dctx, states, e, mask, hf, y, v, de, dy)
+    for got, want in ((de, e64.grad), (dy, y64.grad)):
+        scale = max(float(want.abs().max()), 1e-3)
+        assert float((got.double() - want).abs().max()) <= 2e-5 * scale
