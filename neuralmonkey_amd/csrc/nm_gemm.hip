@@ -879,7 +879,12 @@ static void launch_skinny(const GemmArgs& g_in, int batch, bool tb, const GruEpi
     if (!no16 && K >= 256 && (long)nm_cdiv(g.M, 32) * nm_cdiv(g.N, 32) * batch < 256) {
         const int tiles_m = nm_cdiv(g.M, 16), tiles_n = nm_cdiv(g.N, 16);
         dim3 grid(tiles_m * tiles_n, 1, (unsigned)batch);
-        const int ks = (K >= 512) ? 16 : 8;
+        // K >= 512: sixteen waves share K -- unless the launch then no longer fits the chip in one round (8192 wave slots:
+        // more than 512 tiles, e.g. 128 rows x 1536 gate columns of a taped decoder step = 768): eight waves, twice the
+        // depth each; the general path's training step 18.0 -> 17.7 ms (four waves: the same).  NM_SKINNY16_WIDE=0: off
+        static const bool wide = !(getenv("NM_SKINNY16_WIDE") && atoi(getenv("NM_SKINNY16_WIDE")) == 0);
+        const long ntiles = (long)tiles_m * tiles_n * batch;
+        const int ks = (K >= 512 && !(wide && ntiles > 512)) ? 16 : 8;
         static DevMask devs16[4];
 #define NM_GS16(KS_, I_)                                                                                               \
     do {                                                                                                               \
