@@ -1046,13 +1046,27 @@ __global__ __launch_bounds__(1024) void attn_step_bwd_kernel(
         float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int i = 0; i < 4; ++i) sr[i] = states + ((long)b * S + min(s0 + i * nw, S - 1)) * C;
-        for (int c = lane * 4; c < C; c += 256) {
-            const float4 d = *reinterpret_cast<const float4*>(dc + c);
-            float4 x[4];
+        // (1024 columns per pass, every load of a pass requested before the first is used: clamped addresses and zeroed
+        // terms instead of an early exit, which would keep the compiler from hoisting the loads)
+        for (int c0 = 0; c0 < C; c0 += 1024) {
+            float4 d[4], x[4][4];
+            bool ok[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) x[i] = *reinterpret_cast<const float4*>(sr[i] + c);
+            for (int j = 0; j < 4; ++j) {
+                const int c = c0 + j * 256 + lane * 4;
+                ok[j] = c < C;
+                const int cc = ok[j] ? c : 0;
+                d[j] = *reinterpret_cast<const float4*>(dc + cc);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] += x[i].x * d.x + x[i].y * d.y + x[i].z * d.z + x[i].w * d.w;
+                for (int i = 0; i < 4; ++i) x[j][i] = *reinterpret_cast<const float4*>(sr[i] + cc);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (!ok[j]) continue;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[i] += x[j][i].x * d[j].x + x[j][i].y * d[j].y + x[j][i].z * d[j].z + x[j][i].w * d[j].w;
+            }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1109,12 +1123,12 @@ __global__ __launch_bounds__(1024) void attn_step_bwd_kernel(
         float g = 0.0f;
         if (a < A) {
             const float ya = y[(long)b * ldy + a];
-            for (int s = sb; s < se_; s += 5) {
-                float hv[5];
+            for (int s = sb; s < se_; s += 13) {                  // (13 keys in flight per thread: 25 positions = two passes)
+                float hv[13];
 #pragma unroll
-                for (int i = 0; i < 5; ++i) hv[i] = hb[(long)min(s + i, S - 1) * A + a];
+                for (int i = 0; i < 13; ++i) hv[i] = hb[(long)min(s + i, S - 1) * A + a];
 #pragma unroll
-                for (int i = 0; i < 5; ++i) {
+                for (int i = 0; i < 13; ++i) {
                     const float z = nm_tanh(hv[i] + ya);
                     if (s + i < se_) g += sh[s + i] * (1.0f - z * z);
                 }
