@@ -3,7 +3,7 @@ issue, and from which line?  A TorchFunctionMode logs every torch function calle
 eagerly (graphs off: NM_GRAPHS=0 semantics are the same launches, just not captured), with the innermost
 neuralmonkey_amd frame that called it.
 
-    python tools/torch_ops_on_path.py [train|greedy|beam|transformer_train|general_train] ..."""
+    python tools/torch_ops_on_path.py [train|greedy|beam|transformer_train] ..."""
 import collections
 import os
 import sys
