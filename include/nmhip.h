@@ -554,6 +554,15 @@ int nm_nematus_cell_bwd(void* stream, const float* dh, int64_t lddh, const float
                         int64_t lddci, float* dsc, int64_t lddsc, float* dh_prev, int64_t lddhp, float* dg2, int64_t lddg2,
                         int64_t rows, int64_t H, int accumulate_dg, int accumulate_dci, int accumulate_dsc,
                         int accumulate_dh_prev);
+/* The state half of a NematusGRUCell step AND its point-wise part in one launch (nn/ortho_gru_cell.py:73-105; the
+ * reset gate multiplies the state projection, so nothing of the step waits for a second product): s = h_prev . w_st
+ * (+ b_st), w_st [H, 3H] = [U_g | U_c]; r, u = sigmoid(x_all[:, :2H] + s[:, :2H]); c = tanh(x_all[:, 2H:] + r * s[:, 2H:]);
+ * h_new = u h_prev + (1 - u) c.  x_all [rows, 3H]: the input half x . [W_g | W_c] + biases.  ru [rows, 2H], c_out
+ * [rows, H] (contiguous) and sc_out [rows, H] = s[:, 2H:] keep what nm_nematus_cell_bwd reads; all three may be null.
+ * H in steps of 8; h_new may not alias h_prev. */
+int nm_nematus_state_step(void* stream, const float* h_prev, int64_t ldh, const float* w_st, int64_t ldw,
+                          const float* b_st, const float* x_all, int64_t ldx, float* h_new, int64_t ldhn, float* ru,
+                          float* c_out, float* sc_out, int64_t ldsc, int64_t rows, int64_t H);
 /* nn/utils.py:6-22 (tf.nn.dropout): keep iff floor(keep_prob + u_i) == 1, scale 1/keep_prob;
  * u_i = hash(salt, i) (counter based: the backward pass and the CPU oracle regenerate the mask) */
 int nm_dropout(void* stream, const float* x, int64_t ldx, float* out, int64_t ldo, int64_t rows,

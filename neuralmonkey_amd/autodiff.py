@@ -40,6 +40,8 @@ ZERO_ARENA = os.environ.get("NM_TAPE_ZERO_ARENA", "1") != "0"
 ALIAS_ADD_GRADS = os.environ.get("NM_ADD_GRAD_ALIAS", "1") != "0"
 # a sum (residual connection) computed by its first reader: a layer norm adds and norms in one pass (autodiff.add)
 LAZY_ADD = os.environ.get("NM_LAZY_ADD", "1") != "0"
+# a NematusGRUCell step's state product and point-wise part in one launch (nm_nematus_state_step)
+FUSED_STATE_STEP = os.environ.get("NM_NEMATUS_STATE_STEP", "1") != "0"
 
 
 class Var:
@@ -406,7 +408,6 @@ def nematus_cell_merged(tape: Tape, x: Optional[Var], h_prev: Var, w_in: torch.T
     two gradient buffers, chained over the steps when the pass ends (Tape.defer_wgrad)."""
     rows, h = h_prev.shape
     s_all = tape.buf((rows, 3 * h))
-    ops.gemm(h_prev.data, w_st, out=s_all, bias=b_st)
     if x_proj is not None:            # the input half was projected for all steps at once (nematus_input_projection)
         x_all = x_proj.data
     else:
@@ -415,8 +416,14 @@ def nematus_cell_merged(tape: Tape, x: Optional[Var], h_prev: Var, w_in: torch.T
     h_new = out if out is not None else tape.new((rows, h))      # (``out``: the step's rows of a buffer of all steps)
     ru = tape.buf((rows, 2 * h)) if tape.recording else None
     c = tape.buf((rows, h)) if tape.recording else None
-    ops.nematus_cell_fwd(s_all[:, :2 * h], s_all[:, 2 * h:], x_all[:, 2 * h:], h_prev.data, h_new.data, ru, c,
-                         g2=x_all[:, :2 * h])
+    if FUSED_STATE_STEP and ops.nematus_state_step_ok(h_prev.data, w_st, x_all, h_new.data):
+        # the state product and the point-wise part in one launch; of s_all only the candidate's columns are kept
+        ops.nematus_state_step(h_prev.data, w_st, b_st, x_all, h_new.data, ru, c,
+                               s_all[:, 2 * h:] if tape.recording else None)
+    else:
+        ops.gemm(h_prev.data, w_st, out=s_all, bias=b_st)
+        ops.nematus_cell_fwd(s_all[:, :2 * h], s_all[:, 2 * h:], x_all[:, 2 * h:], h_prev.data, h_new.data, ru, c,
+                             g2=x_all[:, :2 * h])
 
     def bwd():
         if h_new.grad is None:

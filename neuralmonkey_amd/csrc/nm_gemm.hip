@@ -828,6 +828,128 @@ __global__ __launch_bounds__(KS * 64) void gemm_skinny16(GemmArgs g, int tiles_m
 }
 
 // ---------------------------------------------------------------------------
+// A NematusGRUCell step's state half AND its point-wise part in one launch (nn/ortho_gru_cell.py:73-105; the reset gate
+// is applied AFTER the state projection, so the step is single-stage): a workgroup owns 16 rows x 16 UNITS = the three
+// 16-column blocks (r, u, state candidate) of h . [U_g | U_c]; K is split over the KS waves as in gemm_skinny16, the
+// three partial tiles meet in LDS, and the thread that owns an element finishes the cell:
+//     r, u = sigmoid(x_all[:, r|u] + s[:, r|u]);  c = tanh(x_all[:, c] + r * s[:, c]);  h' = u h + (1 - u) c
+// (x_all = x . [W_g | W_c] + biases, projected by the caller -- for all steps at once where the inputs are known).
+// One launch where the taped decoder step ran a product and nm_nematus_cell_fwd: 100 launches of ~5 us fewer per
+// training step of the conditional decoder at the headline size, as many per greedy batch.
+// ---------------------------------------------------------------------------
+struct NemStep {
+    const float* h; long ldh;          // [M, H] previous state (the A operand and the blend's h)
+    const float* w; long ldw;          // [H, 3H] = [U_g | U_c]
+    const float* b;                    // [3H] or null
+    const float* x; long ldx;          // [M, 3H] input half
+    float* hn; long ldhn;              // [M, H] new state
+    float* ru;                         // [M, 2H] or null (training: r, u for the backward pass)
+    float* c;                          // [M, H] or null
+    float* sc; long ldsc;              // [M, H] or null: h . U_c + b (the backward pass multiplies it by dc' r')
+    int M, H, prio;
+};
+
+template <int KS>
+__global__ __launch_bounds__(KS * 64) void nematus_state_step_kernel(NemStep p) {
+    if (p.prio) __builtin_amdgcn_s_setprio(3);
+    __shared__ float red[KS][3][4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_m = (p.M + 15) / 16;
+    const int bm = blockIdx.x % tiles_m, bu = blockIdx.x / tiles_m;
+    const int m0 = bm * 16, u0 = bu * 16, K = p.H;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int mm = min(m0 + i16, p.M - 1), un = min(u0 + i16, p.H - 1);
+    const int kper = (((K + 15) / 16 + KS - 1) / KS) * 16;
+    const int kbeg = wave * kper, kend = min(K, kbeg + kper);
+    f32x4 acc[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[g][i] = 0.0f;
+    const float* ap = p.h + (long)mm * p.ldh + 4 * kq;
+    const float* bp = p.w + (long)(4 * kq) * p.ldw + un;
+    for (int k0 = kbeg; k0 < kend; k0 += 64) {
+        float4 av[4], bv[3][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k = k0 + 16 * c;
+            av[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) bv[g][c] = av[c];
+            if (k + 4 * kq < kend) {
+                av[c] = *reinterpret_cast<const float4*>(ap + k);
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const float* q = bp + (long)k * p.ldw + (long)g * p.H;
+                    bv[g][c].x = q[0];
+                    bv[g][c].y = q[p.ldw];
+                    bv[g][c].z = q[2 * p.ldw];
+                    bv[g][c].w = q[3 * p.ldw];
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (k0 + 16 * c >= kend) break;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c].x, bv[g][c].x, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c].y, bv[g][c].y, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c].z, bv[g][c].z, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c].w, bv[g][c].w, acc[g], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[wave][g][i][lane] = acc[g][i];
+    __syncthreads();
+    static_assert(KS >= 4, "one output element per thread of the first four waves");
+    const int e_col = u0 + (tid & 15), e_row = m0 + 4 * ((tid & 63) >> 4) + (tid >> 6);
+    if (tid >= 256 || e_row >= p.M || e_col >= p.H) return;
+    const int reg = tid >> 6, ln = tid & 63;
+    float s[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < KS; ++w) t += red[w][g][reg][ln];
+        s[g] = t + (p.b ? p.b[g * p.H + e_col] : 0.0f);
+    }
+    const float* xr = p.x + (long)e_row * p.ldx + e_col;
+    const float r = nm_sigmoid(s[0] + xr[0]);
+    const float u = nm_sigmoid(s[1] + xr[p.H]);
+    const float c = nm_tanh(s[2] * r + xr[2 * p.H]);
+    p.hn[(long)e_row * p.ldhn + e_col] = u * p.h[(long)e_row * p.ldh + e_col] + (1.0f - u) * c;
+    if (p.ru) {
+        p.ru[(long)e_row * 2 * p.H + e_col] = r;
+        p.ru[(long)e_row * 2 * p.H + p.H + e_col] = u;
+    }
+    if (p.c) p.c[(long)e_row * p.H + e_col] = c;
+    if (p.sc) p.sc[(long)e_row * p.ldsc + e_col] = s[2];
+}
+
+extern "C" int nm_nematus_state_step(void* stream, const float* h_prev, int64_t ldh, const float* w_st, int64_t ldw,
+                                     const float* b_st, const float* x_all, int64_t ldx, float* h_new, int64_t ldhn,
+                                     float* ru, float* c_out, float* sc_out, int64_t ldsc, int64_t rows, int64_t H) {
+    NM_REQUIRE(h_prev && w_st && x_all && h_new, "nm_nematus_state_step: null pointer");
+    NM_REQUIRE(rows >= 0 && H > 0 && H % 8 == 0 && ldh >= H && ldh % 4 == 0 && ldw >= 3 * H && ldx >= 3 * H && ldhn >= H &&
+                   (!sc_out || ldsc >= H) && rows < (1 << 24),
+               "nm_nematus_state_step: bad shape rows=%ld H=%ld (H in steps of 8, rows of h 16-byte aligned)", (long)rows,
+               (long)H);
+    NM_REQUIRE(nm_aligned16(h_prev), "nm_nematus_state_step: h_prev not 16-byte aligned");
+    NM_REQUIRE(h_new != h_prev, "nm_nematus_state_step: the new state may not overwrite the old one (other tiles read it)");
+    if (rows == 0) return NM_OK;
+    NemStep p{h_prev, (long)ldh, w_st, (long)ldw, b_st, x_all, (long)ldx, h_new, (long)ldhn, ru, c_out, sc_out, (long)ldsc,
+              (int)rows, (int)H, nm_cur()->sw.background ? 0 : nm_cur()->sw.step_prio};
+    const dim3 grid((unsigned)(nm_cdiv(rows, 16) * nm_cdiv(H, 16)));
+    if (H >= 512) hipLaunchKernelGGL(nematus_state_step_kernel<16>, grid, dim3(1024), 0, nm_stream(stream), p);
+    else hipLaunchKernelGGL(nematus_state_step_kernel<8>, grid, dim3(512), 0, nm_stream(stream), p);
+    NM_LAUNCH_CHECK("nm_nematus_state_step");
+}
+
+// ---------------------------------------------------------------------------
 // host dispatch
 // ---------------------------------------------------------------------------
 // dynamic LDS that brings a workgroup of ``static_lds`` bytes up to ``want_lds`` (0: no padding)
