@@ -408,20 +408,22 @@ def nematus_cell_merged(tape: Tape, x: Optional[Var], h_prev: Var, w_in: torch.T
     two gradient buffers, chained over the steps when the pass ends (Tape.defer_wgrad)."""
     rows, h = h_prev.shape
     s_all = tape.buf((rows, 3 * h))
+    h_new = out if out is not None else tape.new((rows, h))      # (``out``: the step's rows of a buffer of all steps)
+    # the state product and the point-wise part in one launch where that pays (ops.nematus_state_step_ok)
+    fused = FUSED_STATE_STEP and ops.nematus_state_step_ok(h_prev.data, w_st, h_new.data)
+    if not fused:
+        ops.gemm(h_prev.data, w_st, out=s_all, bias=b_st)
     if x_proj is not None:            # the input half was projected for all steps at once (nematus_input_projection)
         x_all = x_proj.data
     else:
         x_all = tape.buf((rows, 3 * h))
         ops.gemm(x.data, w_in, out=x_all, bias=b_in)
-    h_new = out if out is not None else tape.new((rows, h))      # (``out``: the step's rows of a buffer of all steps)
     ru = tape.buf((rows, 2 * h)) if tape.recording else None
     c = tape.buf((rows, h)) if tape.recording else None
-    if FUSED_STATE_STEP and ops.nematus_state_step_ok(h_prev.data, w_st, x_all, h_new.data):
-        # the state product and the point-wise part in one launch; of s_all only the candidate's columns are kept
+    if fused:                         # (of s_all only the candidate's columns are kept: the backward pass reads them)
         ops.nematus_state_step(h_prev.data, w_st, b_st, x_all, h_new.data, ru, c,
                                s_all[:, 2 * h:] if tape.recording else None)
     else:
-        ops.gemm(h_prev.data, w_st, out=s_all, bias=b_st)
         ops.nematus_cell_fwd(s_all[:, :2 * h], s_all[:, 2 * h:], x_all[:, 2 * h:], h_prev.data, h_new.data, ru, c,
                              g2=x_all[:, :2 * h])
 

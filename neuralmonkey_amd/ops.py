@@ -848,15 +848,15 @@ def lstm_cell_bwd(dh, dc_new, gates, c_prev, c_new, dz, dc_prev, accumulate_dz=F
                                     int(accumulate_dz), int(accumulate_dc_prev)), "nm_lstm_cell_bwd")
 
 
-def nematus_state_step_ok(h_prev, w_st, x_all, h_new) -> bool:
+def nematus_state_step_ok(h_prev, w_st, h_new) -> bool:
     """The one-launch step takes it, and pays: up to 512 tiles of 16 rows x 16 units (two per compute unit).  Beyond
     that -- 640 beam rows x 512 units are 1280 -- the product on large tiles and the point-wise launch are faster
     (beam-5 of the general path 24.6 against 25.0 ms per batch)."""
     rows, h = h_prev.shape
-    return (h_prev.is_cuda and h % 8 == 0 and ((rows + 15) // 16) * ((h + 15) // 16) <= 512
-            and h_prev.stride(1) == 1 and h_prev.stride(0) % 4 == 0
-            and h_prev.data_ptr() % 16 == 0 and w_st.stride(1) == 1 and x_all.stride(1) == 1 and h_new.stride(1) == 1
-            and h_new.data_ptr() != h_prev.data_ptr())
+    if ((rows + 15) // 16) * ((h + 15) // 16) > 512 or h % 8:
+        return False
+    return (h_prev.is_cuda and h_prev.stride(1) == 1 and h_prev.stride(0) % 4 == 0 and h_prev.data_ptr() % 16 == 0
+            and w_st.stride(1) == 1 and h_new.stride(1) == 1 and h_new.data_ptr() != h_prev.data_ptr())
 
 
 def nematus_state_step(h_prev, w_st, b_st, x_all, h_new, ru=None, c_out=None, sc_out=None):
@@ -865,7 +865,7 @@ def nematus_state_step(h_prev, w_st, b_st, x_all, h_new, ru=None, c_out=None, sc
     c_out [R,H] (contiguous) and sc_out [R,H] (row stride free) keep what the backward pass reads."""
     lib = _lib.load()
     rows, h = h_prev.shape
-    assert w_st.shape == (h, 3 * h) and x_all.shape == (rows, 3 * h) and h_new.shape == (rows, h)
+    assert w_st.shape == (h, 3 * h) and x_all.shape == (rows, 3 * h) and h_new.shape == (rows, h) and x_all.stride(1) == 1
     assert ru is None or ru.is_contiguous()
     assert c_out is None or c_out.is_contiguous()
     assert sc_out is None or sc_out.stride(1) == 1

@@ -27,7 +27,7 @@ def test_state_step_matches_float64_and_the_two_launches(dev, rows, h, bias, kee
     s_all = torch.full((rows, 3 * h), 9.0, device=dev)
     sc = s_all[:, 2 * h:] if keep else None
     # (the kernel takes any size; the engine asks for it up to 512 tiles of 16 rows x 16 units)
-    assert ops.nematus_state_step_ok(h_prev, w_st, x_all, h_new) == (rows < 640)
+    assert ops.nematus_state_step_ok(h_prev, w_st, h_new) == (rows < 640)
     ops.nematus_state_step(h_prev, w_st, b_st, x_all, h_new, ru, c, sc)
 
     s64 = h_prev.double() @ w_st.double() + (b_st.double() if bias else 0.0)
@@ -59,6 +59,6 @@ def test_state_step_matches_float64_and_the_two_launches(dev, rows, h, bias, kee
 def test_state_step_refuses_what_it_cannot_take(dev):
     from neuralmonkey_amd import ops
     h_prev, h_new = torch.zeros(4, 12, device=dev), torch.zeros(4, 12, device=dev)
-    assert not ops.nematus_state_step_ok(h_prev, torch.zeros(12, 36, device=dev), torch.zeros(4, 36, device=dev), h_new)
+    assert not ops.nematus_state_step_ok(h_prev, torch.zeros(12, 36, device=dev), h_new)
     h8 = torch.zeros(4, 8, device=dev)
-    assert not ops.nematus_state_step_ok(h8, torch.zeros(8, 24, device=dev), torch.zeros(4, 24, device=dev), h8)   # in place
+    assert not ops.nematus_state_step_ok(h8, torch.zeros(8, 24, device=dev), h8)   # in place
