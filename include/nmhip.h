@@ -563,6 +563,13 @@ int nm_nematus_cell_bwd(void* stream, const float* dh, int64_t lddh, const float
 int nm_nematus_state_step(void* stream, const float* h_prev, int64_t ldh, const float* w_st, int64_t ldw,
                           const float* b_st, const float* x_all, int64_t ldx, float* h_new, int64_t ldhn, float* ru,
                           float* c_out, float* sc_out, int64_t ldsc, int64_t rows, int64_t H);
+/* ... and with the step's input half in the same launch: x [rows, D] . w_in [D, 3H] = [W_g | W_c] (+ b_in) takes the
+ * place of x_all (the second cell of a conditional decoder, decoders/decoder.py:303-325: its input is the step's own
+ * attention context).  H and D in steps of 8. */
+int nm_nematus_full_step(void* stream, const float* h_prev, int64_t ldh, const float* w_st, int64_t ldw,
+                         const float* b_st, const float* x, int64_t ldx, const float* w_in, int64_t ldwi,
+                         const float* b_in, float* h_new, int64_t ldhn, float* ru, float* c_out, float* sc_out,
+                         int64_t ldsc, int64_t rows, int64_t H, int64_t D);
 /* nn/utils.py:6-22 (tf.nn.dropout): keep iff floor(keep_prob + u_i) == 1, scale 1/keep_prob;
  * u_i = hash(salt, i) (counter based: the backward pass and the CPU oracle regenerate the mask) */
 int nm_dropout(void* stream, const float* x, int64_t ldx, float* out, int64_t ldo, int64_t rows,

@@ -106,6 +106,7 @@ SIGNATURES = {
     "nm_lstm_cell_bwd": (I, [P, P, L, P, L, P, L, P, L, P, L, P, L, P, L, L, L, I, I]),
     "nm_nematus_cell_fwd": (I, [P, P, L, P, L, P, L, P, L, P, L, P, P, P, L, L, L]),
     "nm_nematus_state_step": (I, [P, P, L, P, L, P, P, L, P, L, P, P, P, L, L, L]),
+    "nm_nematus_full_step": (I, [P, P, L, P, L, P, P, L, P, L, P, P, L, P, P, P, L, L, L, L]),
     "nm_nematus_cell_bwd": (I, [P, P, L, P, P, P, L, P, L, P, L, P, L, P, L, P, L, P, L, L, L, I, I, I, I]),
     "nm_dropout": (I, [P, P, L, P, L, L, L, F, ctypes.c_uint32, P, I]),
     "nm_rnn_select_fwd": (I, [P, P, L, P, L, P, I, P, L, P, L, L, L]),

@@ -42,6 +42,8 @@ ALIAS_ADD_GRADS = os.environ.get("NM_ADD_GRAD_ALIAS", "1") != "0"
 LAZY_ADD = os.environ.get("NM_LAZY_ADD", "1") != "0"
 # a NematusGRUCell step's state product and point-wise part in one launch (nm_nematus_state_step)
 FUSED_STATE_STEP = os.environ.get("NM_NEMATUS_STATE_STEP", "1") != "0"
+# ... and the step's input product as well when nothing projected it ahead of the loop (nm_nematus_full_step)
+FUSED_FULL_STEP = os.environ.get("NM_NEMATUS_FULL_STEP", "1") != "0"
 
 
 class Var:
@@ -413,16 +415,20 @@ def nematus_cell_merged(tape: Tape, x: Optional[Var], h_prev: Var, w_in: torch.T
     fused = FUSED_STATE_STEP and ops.nematus_state_step_ok(h_prev.data, w_st, h_new.data)
     if not fused:
         ops.gemm(h_prev.data, w_st, out=s_all, bias=b_st)
+    # ... and the input half too when it was not projected ahead of the loop (a conditional decoder's second cell)
+    full = fused and FUSED_FULL_STEP and x_proj is None and ops.nematus_full_step_ok(x.data, w_in)
     if x_proj is not None:            # the input half was projected for all steps at once (nematus_input_projection)
         x_all = x_proj.data
-    else:
+    elif not full:
         x_all = tape.buf((rows, 3 * h))
         ops.gemm(x.data, w_in, out=x_all, bias=b_in)
     ru = tape.buf((rows, 2 * h)) if tape.recording else None
     c = tape.buf((rows, h)) if tape.recording else None
-    if fused:                         # (of s_all only the candidate's columns are kept: the backward pass reads them)
-        ops.nematus_state_step(h_prev.data, w_st, b_st, x_all, h_new.data, ru, c,
-                               s_all[:, 2 * h:] if tape.recording else None)
+    keep_sc = s_all[:, 2 * h:] if tape.recording else None      # (of s_all only the candidate's columns are kept: the
+    if full:                                                    #  backward pass reads them)
+        ops.nematus_full_step(h_prev.data, w_st, b_st, x.data, w_in, b_in, h_new.data, ru, c, keep_sc)
+    elif fused:
+        ops.nematus_state_step(h_prev.data, w_st, b_st, x_all, h_new.data, ru, c, keep_sc)
     else:
         ops.nematus_cell_fwd(s_all[:, :2 * h], s_all[:, 2 * h:], x_all[:, 2 * h:], h_prev.data, h_new.data, ru, c,
                              g2=x_all[:, :2 * h])

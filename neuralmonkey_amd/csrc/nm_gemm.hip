@@ -930,6 +930,136 @@ __global__ __launch_bounds__(KS * 64) void nematus_state_step_kernel(NemStep p) 
     if (p.sc) p.sc[(long)e_row * p.ldsc + e_col] = s[2];
 }
 
+// ... and with the step's INPUT half in the same launch (the second cell of a conditional decoder reads the attention
+// contexts of its own step: nothing to project ahead of the loop): the r / u blocks accumulate x . W_g and h . U_g in one
+// chain, the candidate keeps its two products apart (the reset gate multiplies the state's only).  Eight waves share
+// K = D + H (four 16 x 16 partial tiles per wave in LDS: 32 KB).
+struct NemFull {
+    NemStep st;                        // (st.x unused)
+    const float* xin; long ldxi;       // [M, D] the cell's input
+    const float* wi; long ldwi;        // [D, 3H] = [W_g | W_c]
+    const float* bi;                   // [3H] or null
+    float* dbg_x;                      // unused (keeps the struct's tail aligned)
+    int D;
+};
+
+template <int KS>
+__device__ __forceinline__ void nem_accumulate(const float* __restrict__ A, long lda, const float* __restrict__ W, long ldw,
+                                               int H, int K, int mm, int un, int kq, int wave, f32x4& a0, f32x4& a1,
+                                               f32x4& a2) {
+    const int kper = (((K + 15) / 16 + KS - 1) / KS) * 16;
+    const int kbeg = wave * kper, kend = min(K, kbeg + kper);
+    const float* ap = A + (long)mm * lda + 4 * kq;
+    const float* bp = W + (long)(4 * kq) * ldw + un;
+    for (int k0 = kbeg; k0 < kend; k0 += 64) {
+        float4 av[4], bv[3][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k = k0 + 16 * c;
+            av[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) bv[g][c] = av[c];
+            if (k + 4 * kq < kend) {
+                av[c] = *reinterpret_cast<const float4*>(ap + k);
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const float* q = bp + (long)k * ldw + (long)g * H;
+                    bv[g][c].x = q[0];
+                    bv[g][c].y = q[ldw];
+                    bv[g][c].z = q[2 * ldw];
+                    bv[g][c].w = q[3 * ldw];
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (k0 + 16 * c >= kend) break;
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c].x, bv[0][c].x, a0, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c].y, bv[0][c].y, a0, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c].z, bv[0][c].z, a0, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c].w, bv[0][c].w, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c].x, bv[1][c].x, a1, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c].y, bv[1][c].y, a1, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c].z, bv[1][c].z, a1, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c].w, bv[1][c].w, a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c].x, bv[2][c].x, a2, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c].y, bv[2][c].y, a2, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c].z, bv[2][c].z, a2, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c].w, bv[2][c].w, a2, 0, 0, 0);
+        }
+    }
+}
+
+template <int KS>
+__global__ __launch_bounds__(KS * 64) void nematus_full_step_kernel(NemFull f) {
+    const NemStep& p = f.st;
+    if (p.prio) __builtin_amdgcn_s_setprio(3);
+    __shared__ float red[KS][4][4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_m = (p.M + 15) / 16;
+    const int bm = blockIdx.x % tiles_m, bu = blockIdx.x / tiles_m;
+    const int m0 = bm * 16, u0 = bu * 16;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int mm = min(m0 + i16, p.M - 1), un = min(u0 + i16, p.H - 1);
+    f32x4 acc[4];                      // r, u (both halves), state candidate, input candidate
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[g][i] = 0.0f;
+    nem_accumulate<KS>(p.h, p.ldh, p.w, p.ldw, p.H, p.H, mm, un, kq, wave, acc[0], acc[1], acc[2]);
+    nem_accumulate<KS>(f.xin, f.ldxi, f.wi, f.ldwi, p.H, f.D, mm, un, kq, wave, acc[0], acc[1], acc[3]);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[wave][g][i][lane] = acc[g][i];
+    __syncthreads();
+    static_assert(KS >= 4, "one output element per thread of the first four waves");
+    const int e_col = u0 + (tid & 15), e_row = m0 + 4 * ((tid & 63) >> 4) + (tid >> 6);
+    if (tid >= 256 || e_row >= p.M || e_col >= p.H) return;
+    const int reg = tid >> 6, ln = tid & 63;
+    float s[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < KS; ++w) t += red[w][g][reg][ln];
+        s[g] = t;
+    }
+    const int H = p.H;
+    if (p.b) { s[0] += p.b[e_col]; s[1] += p.b[H + e_col]; s[2] += p.b[2 * H + e_col]; }
+    if (f.bi) { s[0] += f.bi[e_col]; s[1] += f.bi[H + e_col]; s[3] += f.bi[2 * H + e_col]; }
+    const float r = nm_sigmoid(s[0]);
+    const float u = nm_sigmoid(s[1]);
+    const float c = nm_tanh(s[2] * r + s[3]);
+    p.hn[(long)e_row * p.ldhn + e_col] = u * p.h[(long)e_row * p.ldh + e_col] + (1.0f - u) * c;
+    if (p.ru) {
+        p.ru[(long)e_row * 2 * H + e_col] = r;
+        p.ru[(long)e_row * 2 * H + H + e_col] = u;
+    }
+    if (p.c) p.c[(long)e_row * H + e_col] = c;
+    if (p.sc) p.sc[(long)e_row * p.ldsc + e_col] = s[2];
+}
+
+extern "C" int nm_nematus_full_step(void* stream, const float* h_prev, int64_t ldh, const float* w_st, int64_t ldw,
+                                    const float* b_st, const float* x, int64_t ldx, const float* w_in, int64_t ldwi,
+                                    const float* b_in, float* h_new, int64_t ldhn, float* ru, float* c_out, float* sc_out,
+                                    int64_t ldsc, int64_t rows, int64_t H, int64_t D) {
+    NM_REQUIRE(h_prev && w_st && x && w_in && h_new, "nm_nematus_full_step: null pointer");
+    NM_REQUIRE(rows >= 0 && H > 0 && H % 8 == 0 && D > 0 && D % 8 == 0 && ldh >= H && ldh % 4 == 0 && ldx >= D &&
+                   ldx % 4 == 0 && ldw >= 3 * H && ldwi >= 3 * H && ldhn >= H && (!sc_out || ldsc >= H) && rows < (1 << 24),
+               "nm_nematus_full_step: bad shape rows=%ld H=%ld D=%ld (H, D in steps of 8, rows of h and x 16-byte aligned)",
+               (long)rows, (long)H, (long)D);
+    NM_REQUIRE(nm_aligned16(h_prev) && nm_aligned16(x), "nm_nematus_full_step: h_prev / x not 16-byte aligned");
+    NM_REQUIRE(h_new != h_prev, "nm_nematus_full_step: the new state may not overwrite the old one (other tiles read it)");
+    if (rows == 0) return NM_OK;
+    NemFull f{{h_prev, (long)ldh, w_st, (long)ldw, b_st, nullptr, 0, h_new, (long)ldhn, ru, c_out, sc_out, (long)ldsc,
+               (int)rows, (int)H, nm_cur()->sw.background ? 0 : nm_cur()->sw.step_prio},
+              x, (long)ldx, w_in, (long)ldwi, b_in, nullptr, (int)D};
+    const dim3 grid((unsigned)(nm_cdiv(rows, 16) * nm_cdiv(H, 16)));
+    hipLaunchKernelGGL(nematus_full_step_kernel<8>, grid, dim3(512), 0, nm_stream(stream), f);
+    NM_LAUNCH_CHECK("nm_nematus_full_step");
+}
+
 extern "C" int nm_nematus_state_step(void* stream, const float* h_prev, int64_t ldh, const float* w_st, int64_t ldw,
                                      const float* b_st, const float* x_all, int64_t ldx, float* h_new, int64_t ldhn,
                                      float* ru, float* c_out, float* sc_out, int64_t ldsc, int64_t rows, int64_t H) {

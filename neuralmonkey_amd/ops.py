@@ -875,6 +875,27 @@ def nematus_state_step(h_prev, w_st, b_st, x_all, h_new, ru=None, c_out=None, sc
                "nm_nematus_state_step")
 
 
+def nematus_full_step_ok(x, w_in) -> bool:
+    """(beside nematus_state_step_ok) the step's input rows can be multiplied in the same launch"""
+    d = x.shape[1]
+    return (d % 8 == 0 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and w_in.stride(1) == 1)
+
+
+def nematus_full_step(h_prev, w_st, b_st, x, w_in, b_in, h_new, ru=None, c_out=None, sc_out=None):
+    """nematus_state_step with the input half x [R,D] . w_in [D,3H] (+ b_in) computed in the same launch."""
+    lib = _lib.load()
+    rows, h = h_prev.shape
+    d = x.shape[1]
+    assert w_st.shape == (h, 3 * h) and w_in.shape == (d, 3 * h) and x.shape[0] == rows and h_new.shape == (rows, h)
+    assert ru is None or ru.is_contiguous()
+    assert c_out is None or c_out.is_contiguous()
+    assert sc_out is None or sc_out.stride(1) == 1
+    _lib.check(lib.nm_nematus_full_step(_stream(), h_prev.data_ptr(), h_prev.stride(0), w_st.data_ptr(), w_st.stride(0),
+                                        _p(b_st), x.data_ptr(), x.stride(0), w_in.data_ptr(), w_in.stride(0), _p(b_in),
+                                        h_new.data_ptr(), h_new.stride(0), _p(ru), _p(c_out), _p(sc_out),
+                                        0 if sc_out is None else sc_out.stride(0), rows, h, d), "nm_nematus_full_step")
+
+
 def nematus_cell_fwd(g_pre, sc, ci, h_prev, h_new, ru=None, c_out=None, g2=None):
     """h' of one NematusGRUCell step from its products (nm_nematus_cell_fwd); ``ru`` [R,2H] / ``c_out`` [R,H]: contiguous
     buffers for the backward call; ``g2``: a second gate operand added to ``g_pre``."""

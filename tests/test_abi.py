@@ -136,6 +136,8 @@ def test_round6_entry_points_validate_before_any_launch(lib):
     assert rc < 0 and b"nm_nematus_state_step: bad shape" in lib.nm_last_error()
     rc = lib.nm_nematus_state_step(None, buf, 8, buf, 24, None, buf, 24, buf, 8, None, None, None, 0, 4, 8)
     assert rc < 0 and b"may not overwrite" in lib.nm_last_error()
+    rc = lib.nm_nematus_full_step(None, buf, 8, buf, 24, None, buf, 12, buf, 24, None, buf, 8, None, None, None, 0, 4, 8, 12)
+    assert rc < 0 and b"nm_nematus_full_step: bad shape" in lib.nm_last_error()
     # one taped step's attention backward: operands, then shapes (C in float4 steps)
     rc = lib.nm_attn_step_bwd(None, buf, 8, buf, buf, None, buf, None, 8, buf, buf, buf, 8, 2, 4, 8, 8)
     assert rc < 0 and b"nm_attn_step_bwd: null pointer" in lib.nm_last_error()
