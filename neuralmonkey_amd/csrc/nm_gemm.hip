@@ -939,7 +939,6 @@ struct NemFull {
     const float* xin; long ldxi;       // [M, D] the cell's input
     const float* wi; long ldwi;        // [D, 3H] = [W_g | W_c]
     const float* bi;                   // [3H] or null
-    float* dbg_x;                      // unused (keeps the struct's tail aligned)
     int D;
 };
 
@@ -1054,7 +1053,7 @@ extern "C" int nm_nematus_full_step(void* stream, const float* h_prev, int64_t l
     if (rows == 0) return NM_OK;
     NemFull f{{h_prev, (long)ldh, w_st, (long)ldw, b_st, nullptr, 0, h_new, (long)ldhn, ru, c_out, sc_out, (long)ldsc,
                (int)rows, (int)H, nm_cur()->sw.background ? 0 : nm_cur()->sw.step_prio},
-              x, (long)ldx, w_in, (long)ldwi, b_in, nullptr, (int)D};
+              x, (long)ldx, w_in, (long)ldwi, b_in, (int)D};
     const dim3 grid((unsigned)(nm_cdiv(rows, 16) * nm_cdiv(H, 16)));
     hipLaunchKernelGGL(nematus_full_step_kernel<8>, grid, dim3(512), 0, nm_stream(stream), f);
     NM_LAUNCH_CHECK("nm_nematus_full_step");
